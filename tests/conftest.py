@@ -1,0 +1,43 @@
+import gzip
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle_bin():
+    """Builds the CPU oracle CLI (test infrastructure) and returns its path."""
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "al_oracle", "libal_oracle.so"], check=True)
+    return os.path.join(ROOT, "oracle", "al_oracle")
+
+
+@pytest.fixture(scope="session")
+def golden_unpacked(tmp_path_factory):
+    """Unpacks tests/golden/*/ *.gz into a temp dir; returns {set: dir}."""
+    out = {}
+    base = tmp_path_factory.mktemp("golden")
+    for name in sorted(os.listdir(GOLDEN)):
+        d = os.path.join(GOLDEN, name)
+        if not os.path.isdir(d):
+            continue
+        o = base / name
+        o.mkdir()
+        for fn in os.listdir(d):
+            src = os.path.join(d, fn)
+            if fn.endswith(".gz"):
+                (o / fn[:-3]).write_bytes(gzip.open(src, "rb").read())
+            else:
+                (o / fn).write_bytes(open(src, "rb").read())
+        out[name] = str(o)
+    return out
