@@ -1,0 +1,264 @@
+// al_api.cpp -- C-ABI glue above the device pipeline: batch / single-fragment mapping entry points,
+// SAM text formatting and the file-level driver that `airlift-align` uses (host side, C++).
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include "al_internal.h"
+#include "al_runtime.h"
+#include "al_io.h"
+
+extern "C" int al_batch_fetch(al_ctx_t *c, int *n_regs, al_reg1_t **regs, int *rep_len)
+{
+	if (!c || !c->ran) return -1;
+	return al_fetch_align(c, n_regs, regs, rep_len);
+}
+
+extern "C" int al_map_batch(al_ctx_t *c, int n_frag, const int *n_segs, const int *qlens, const char *const *seqs,
+                            const char *const *qnames, int *n_regs, al_reg1_t **regs, int *rep_len)
+{
+	int rc;
+	if ((rc = al_batch_upload(c, n_frag, n_segs, qlens, seqs, qnames)) != 0) return rc;
+	if ((rc = al_batch_run(c)) != 0) return rc;
+	return al_batch_fetch(c, n_regs, regs, rep_len);
+}
+
+extern "C" void al_map_frag(const al_idx_t *mi, int n_segs, const int *qlens, const char **seqs, int *n_regs,
+                            al_reg1_t **regs, al_ctx_t *ctx, const al_mapopt_t *opt, const char *qname)
+{   // mm_map_frag (map.c:272): a batch of one fragment
+	(void)mi; (void)opt;
+	int i, rep = 0, qsum = 0;
+	for (i = 0; i < n_segs; ++i) n_regs[i] = 0, regs[i] = 0, qsum += qlens[i];
+	if (qsum == 0 || n_segs <= 0 || n_segs > 2) return;
+	const char *names[2] = { qname, qname };
+	if (al_map_batch(ctx, 1, &n_segs, qlens, seqs, names, n_regs, regs, &rep) != 0)
+		fprintf(stderr, "[airlift] al_map_frag: device pipeline failed\n");
+}
+
+// ---------------------------------------------------------------------------------------------
+// SAM (format.c:82-135, 276-302, 361-544)
+extern "C" int al_write_sam_hdr(FILE *out, const al_idx_t *mi, const char *rg, char *rg_id)
+{
+	for (size_t i = 0; i < mi->seq.size(); ++i) fprintf(out, "@SQ\tSN:%s\tLN:%d\n", mi->seq[i].name.c_str(), (int)mi->seq[i].len);
+	if (rg_id) rg_id[0] = 0;
+	if (rg) {
+		if (strstr(rg, "@RG") != rg) fprintf(stderr, "[ERROR] the read group line is not started with @RG\n");
+		else if (strchr(rg, '\t')) fprintf(stderr, "[ERROR] the read group line contained literal <tab> characters -- replace with escaped tabs: \\t\n");
+		else {
+			std::string line;
+			for (const char *p = rg; *p; ++p) {
+				if (*p == '\\') { ++p; if (*p == 't') line.push_back('\t'); else if (*p == '\\') line.push_back('\\'); if (!*p) break; }
+				else line.push_back(*p);
+			}
+			size_t at = line.find("\tID:");
+			if (at == std::string::npos) fprintf(stderr, "[ERROR] no ID within the read group line\n");
+			else {
+				size_t b = at + 4, e = b;
+				while (e < line.size() && line[e] != '\t' && line[e] != '\n') ++e;
+				if (e - b + 1 > 256) fprintf(stderr, "[ERROR] @RG:ID is longer than 255 characters\n");
+				else { if (rg_id) { memcpy(rg_id, line.data() + b, e - b); rg_id[e - b] = 0; } fprintf(out, "%s\n", line.c_str()); }
+			}
+		}
+	}
+	fprintf(out, "@PG\tID:minimap2\tPN:minimap2\n");
+	return 0;
+}
+
+static inline int qname_len(const char *s)
+{   // bseq.h:31-36
+	int l = (int)strlen(s);
+	return l >= 3 && s[l-1] >= '0' && s[l-1] <= '9' && s[l-2] == '/' ? l - 2 : l;
+}
+
+struct Out {
+	char *p, *end; bool ovf;
+	void ch(char c) { if (p < end) *p++ = c; else ovf = true; }
+	void str(const char *s) { while (*s) ch(*s++); }
+	void mem(const char *s, int l) { if (p + l <= end) { memcpy(p, s, l); p += l; } else ovf = true; }
+	void num(long long v) { char b[24]; int l = 0; unsigned long long x = v < 0 ? -(unsigned long long)v : (unsigned long long)v; do { b[l++] = '0' + x % 10; x /= 10; } while (x); if (v < 0) b[l++] = '-'; while (l) ch(b[--l]); }
+};
+
+static const al_reg1_t *sam_pri(int n, const al_reg1_t *r) { for (int i = 0; i < n; ++i) if (r[i].sam_pri) return &r[i]; return nullptr; }
+
+static void put_sq(Out &o, const char *seq, int l, int rev, int comp)
+{
+	const unsigned char *ct = al_comp();
+	if (rev) for (int i = 0; i < l; ++i) { int c = (unsigned char)seq[l - 1 - i]; o.ch((char)(c < 128 && comp ? ct[c] : c)); }
+	else o.mem(seq, l);
+}
+
+extern "C" int al_write_sam(char *buf, size_t cap, const al_idx_t *mi, const char *qname, int l_seq, const char *seq, const char *qual,
+                            int seg_idx, int reg_idx, int n_seg, const int *n_regss, const al_reg1_t *const *regss, const char *rg_id, int rep_len)
+{
+	Out o{buf, buf + cap - 1, false};
+	const int n_regs = n_regss[seg_idx];
+	const al_reg1_t *regs = regss[seg_idx], *r_prev = nullptr, *r_next = nullptr;
+	const al_reg1_t *r = n_regs > 0 && reg_idx < n_regs && reg_idx >= 0 ? &regs[reg_idx] : nullptr;
+	int this_rid = -1, this_pos = -1, flag;
+	if (n_seg > 1) { int ns = (seg_idx + 1) % n_seg; r_next = sam_pri(n_regss[ns], regss[ns]); r_prev = r_next; }
+	o.mem(qname, n_seg > 1 ? qname_len(qname) : (int)strlen(qname));
+	flag = n_seg > 1 ? 0x1 : 0x0;
+	if (!r) flag |= 0x4;
+	else { if (r->rev) flag |= 0x10; if (r->parent != r->id) flag |= 0x100; else if (!r->sam_pri) flag |= 0x800; }
+	if (n_seg > 1) {
+		if (r && r->proper_frag) flag |= 0x2;
+		if (seg_idx == 0) flag |= 0x40; else if (seg_idx == n_seg - 1) flag |= 0x80;
+		if (!r_next) flag |= 0x8; else if (r_next->rev) flag |= 0x20;
+	}
+	o.ch('\t'); o.num(flag);
+	if (!r) {
+		if (r_prev) { this_rid = r_prev->rid; this_pos = r_prev->rs; o.ch('\t'); o.str(mi->seq[this_rid].name.c_str()); o.ch('\t'); o.num(this_pos + 1); o.str("\t0\t*"); }
+		else o.str("\t*\t0\t0\t*");
+	} else {
+		this_rid = r->rid; this_pos = r->rs;
+		o.ch('\t'); o.str(mi->seq[r->rid].name.c_str()); o.ch('\t'); o.num(r->rs + 1); o.ch('\t'); o.num(r->mapq); o.ch('\t');
+		if (r->n_cigar == 0) o.ch('*');
+		else {
+			const char clip_char = (flag & 0x800) ? 'H' : 'S';
+			const int c0 = r->rev ? l_seq - r->qe : r->qs, c1 = r->rev ? r->qs : l_seq - r->qe;
+			if (c0) { o.num(c0); o.ch(clip_char); }
+			for (uint32_t k = 0; k < r->n_cigar; ++k) { o.num(r->cigar[k] >> 4); o.ch("MIDNSHP=XB"[r->cigar[k] & 0xf]); }
+			if (c1) { o.num(c1); o.ch(clip_char); }
+		}
+	}
+	if (n_seg > 1) {
+		int tlen = 0;
+		if (this_rid >= 0 && r_next) {
+			if (this_rid == r_next->rid) {
+				if (r) { int a5 = r->rev ? r->re - 1 : this_pos, b5 = r_next->rev ? r_next->re - 1 : r_next->rs; tlen = b5 - a5; }
+				o.str("\t=\t");
+			} else { o.ch('\t'); o.str(mi->seq[r_next->rid].name.c_str()); o.ch('\t'); }
+			o.num(r_next->rs + 1); o.ch('\t');
+		} else if (r_next) { o.ch('\t'); o.str(mi->seq[r_next->rid].name.c_str()); o.ch('\t'); o.num(r_next->rs + 1); o.ch('\t'); }
+		else if (this_rid >= 0) { o.str("\t=\t"); o.num(this_pos + 1); o.ch('\t'); }
+		else o.str("\t*\t0\t");
+		if (tlen > 0) ++tlen; else if (tlen < 0) --tlen;
+		o.num(tlen); o.ch('\t');
+	} else o.str("\t*\t0\t0\t");
+	if (!r) { put_sq(o, seq, l_seq, 0, 0); o.ch('\t'); if (qual) put_sq(o, qual, l_seq, 0, 0); else o.ch('*'); }
+	else if ((flag & 0x900) == 0) { put_sq(o, seq, l_seq, r->rev, r->rev); o.ch('\t'); if (qual) put_sq(o, qual, l_seq, r->rev, 0); else o.ch('*'); }
+	else if (flag & 0x100) o.str("*\t*");
+	else { put_sq(o, seq + r->qs, r->qe - r->qs, r->rev, r->rev); o.ch('\t'); if (qual) put_sq(o, qual + r->qs, r->qe - r->qs, r->rev, 0); else o.ch('*'); }
+	if (rg_id && rg_id[0]) { o.str("\tRG:Z:"); o.str(rg_id); }
+	if (r) {
+		const char type = r->id == r->parent ? (r->inv ? 'I' : 'P') : (r->inv ? 'i' : 'S');
+		if (r->n_cigar) { o.str("\tNM:i:"); o.num(r->blen - r->mlen + (int)r->n_ambi); o.str("\tms:i:"); o.num(r->dp_max); o.str("\tAS:i:"); o.num(r->dp_score); o.str("\tnn:i:"); o.num(r->n_ambi); }
+		o.str("\ttp:A:"); o.ch(type); o.str("\tcm:i:"); o.num(r->cnt); o.str("\ts1:i:"); o.num(r->score);
+		if (r->parent == r->id) { o.str("\ts2:i:"); o.num(r->subsc); }
+		if (r->n_cigar) {
+			int n_gapo = 0, n_gap = 0;
+			for (uint32_t i = 0; i < r->n_cigar; ++i) { int op = r->cigar[i] & 0xf, len = r->cigar[i] >> 4; if (op == 1 || op == 2) ++n_gapo, n_gap += len; }
+			const double div = 1.0 - (double)r->mlen / (r->blen - n_gap + n_gapo);
+			if (div == 0.0) o.str("\tde:f:0"); else { char b[32]; snprintf(b, 32, "%.4f", div); o.str("\tde:f:"); o.str(b); }
+		}
+		if (r->split) { o.str("\tzd:i:"); o.num(r->split); }
+		if (r->parent == r->id && r->n_cigar && n_regs > 1) {
+			int n_sa = 0;
+			for (int i = 0; i < n_regs; ++i) if (i != r - regs && regs[i].parent == regs[i].id && regs[i].n_cigar) ++n_sa;
+			if (n_sa > 0) {
+				o.str("\tSA:Z:");
+				for (int i = 0; i < n_regs; ++i) {
+					const al_reg1_t *q = &regs[i]; int l_M, l_I = 0, l_D = 0;
+					if (r == q || q->parent != q->id || q->n_cigar == 0) continue;
+					if (q->qe - q->qs < q->re - q->rs) l_M = q->qe - q->qs, l_D = (q->re - q->rs) - l_M;
+					else l_M = q->re - q->rs, l_I = (q->qe - q->qs) - l_M;
+					const int clip5 = q->rev ? l_seq - q->qe : q->qs, clip3 = q->rev ? q->qs : l_seq - q->qe;
+					o.str(mi->seq[q->rid].name.c_str()); o.ch(','); o.num(q->rs + 1); o.ch(','); o.ch("+-"[q->rev]); o.ch(',');
+					if (clip5) { o.num(clip5); o.ch('S'); }
+					if (l_M) { o.num(l_M); o.ch('M'); }
+					if (l_I) { o.num(l_I); o.ch('I'); }
+					if (l_D) { o.num(l_D); o.ch('D'); }
+					if (clip3) { o.num(clip3); o.ch('S'); }
+					o.ch(','); o.num(q->mapq); o.ch(','); o.num(q->blen - q->mlen + (int)q->n_ambi); o.ch(';');
+				}
+			}
+		}
+	}
+	if (rep_len >= 0) { o.str("\trl:i:"); o.num(rep_len); }
+	o.ch('\n'); *o.p = 0;
+	return o.ovf ? -1 : (int)(o.p - buf);
+}
+
+// ---------------------------------------------------------------------------------------------
+// file-level driver (mm_map_file_frag, map.c:672-700): read -> device batch -> SAM, batch by batch
+static inline bool qname_same(const std::string &a, const std::string &b)
+{
+	int l1 = qname_len(a.c_str()), l2 = qname_len(b.c_str());
+	return l1 == l2 && strncmp(a.c_str(), b.c_str(), l1) == 0;
+}
+
+extern "C" int al_map_file_frag(const al_idx_t *mi, int n_fn, const char **fn, const al_mapopt_t *opt, int n_threads,
+                                FILE *out, const char *rg, int device)
+{
+	(void)n_threads;
+	if (n_fn < 1 || n_fn > 2) return -1;
+	AlSeqFile *f1 = al_sf_open(fn[0]), *f2 = n_fn > 1 ? al_sf_open(fn[1]) : nullptr;
+	if (!f1 || (n_fn > 1 && !f2)) { fprintf(stderr, "ERROR: failed to open file '%s'\n", !f1 ? fn[0] : fn[1]); al_sf_close(f1); al_sf_close(f2); return -1; }
+	al_ctx_t *ctx = al_ctx_init(mi, opt, device);
+	if (!ctx) { al_sf_close(f1); al_sf_close(f2); return -2; }
+	char rg_id[256]; rg_id[0] = 0;
+	if (rg != (const char *)-1) al_write_sam_hdr(out, mi, rg, rg_id);
+	const int64_t batch_bases = opt->mini_batch_size > 0 ? (int64_t)opt->mini_batch_size * 4 : 200000000;   // larger device batches than the CPU's 50 Mbase
+	struct Rd { std::string name, seq, qual; };
+	std::vector<Rd> rds; std::vector<int> n_segs, qlens, n_regs, rep_len; std::vector<const char *> seqs, names; std::vector<al_reg1_t *> regs;
+	Rd pend; bool has_pend = false, done = false; std::vector<char> buf;
+	int rc = 0;
+	while (!done) {
+		rds.clear(); n_segs.clear(); int64_t bases = 0;
+		while (bases < batch_bases) {
+			if (f2) {
+				Rd a, b;
+				if (al_sf_read(f1, a.name, a.seq, a.qual) < 0) { done = true; break; }
+				if (al_sf_read(f2, b.name, b.seq, b.qual) < 0) { fprintf(stderr, "[W::%s] query files have different number of records; extra records skipped.\n", __func__); done = true; break; }
+				bases += a.seq.size() + b.seq.size();
+				rds.push_back(std::move(a)); rds.push_back(std::move(b)); n_segs.push_back(2);
+			} else {   // single file: adjacent reads with the same name form a fragment (frag_mode, map.c:580-586)
+				if (!has_pend) { if (al_sf_read(f1, pend.name, pend.seq, pend.qual) < 0) { done = true; break; } }
+				Rd a = std::move(pend); has_pend = false; pend = Rd();
+				int ns = 1; bases += a.seq.size();
+				rds.push_back(std::move(a));
+				if (al_sf_read(f1, pend.name, pend.seq, pend.qual) >= 0) {
+					if (qname_same(rds.back().name, pend.name)) { bases += pend.seq.size(); rds.push_back(std::move(pend)); pend = Rd(); ns = 2; }
+					else has_pend = true;
+				} else done = true;
+				n_segs.push_back(ns);
+				if (done) break;
+			}
+		}
+		const int nf = (int)n_segs.size(), nr = (int)rds.size();
+		if (nf == 0) break;
+		qlens.resize(nr); seqs.resize(nr); names.resize(nr); n_regs.assign(nr, 0); regs.assign(nr, nullptr); rep_len.assign(nf, 0);
+		for (int i = 0; i < nr; ++i) {
+			for (auto &ch : rds[i].seq) if (ch == 'u' || ch == 'U') --ch;       // bseq.c:72-74
+			qlens[i] = (int)rds[i].seq.size(); seqs[i] = rds[i].seq.c_str(); names[i] = rds[i].name.c_str();
+		}
+		if ((rc = al_map_batch(ctx, nf, n_segs.data(), qlens.data(), seqs.data(), names.data(), n_regs.data(), regs.data(), rep_len.data())) != 0) break;
+		for (int f = 0, i0 = 0; f < nf; i0 += n_segs[f], ++f) {                   // map.c:601-644
+			const int ns = n_segs[f];
+			for (int j = 0; j < ns; ++j) {
+				const int i = i0 + j; const Rd &t = rds[i];
+				size_t need = t.seq.size() * 2 + t.name.size() + 4096;
+				for (int k = 0; k < n_regs[i]; ++k) need += (size_t)regs[i][k].n_cigar * 12 + 128;
+				if (buf.size() < need) buf.resize(need * 2);
+				const char *ql = t.qual.empty() ? nullptr : t.qual.c_str();
+				if (n_regs[i] > 0) {
+					for (int k = 0; k < n_regs[i]; ++k) {
+						const al_reg1_t *r = &regs[i][k];
+						if ((opt->flag & AL_F_NO_PRINT_2ND) && r->id != r->parent) continue;
+						int l = al_write_sam(buf.data(), buf.size(), mi, t.name.c_str(), (int)t.seq.size(), t.seq.c_str(), ql, j, k, ns, &n_regs[i0], (const al_reg1_t *const *)&regs[i0], rg_id, rep_len[f]);
+						if (l > 0) fwrite(buf.data(), 1, l, out);
+					}
+				} else if (!(opt->flag & AL_F_SAM_HIT_ONLY)) {
+					int l = al_write_sam(buf.data(), buf.size(), mi, t.name.c_str(), (int)t.seq.size(), t.seq.c_str(), ql, j, -1, ns, &n_regs[i0], (const al_reg1_t *const *)&regs[i0], rg_id, rep_len[f]);
+					if (l > 0) fwrite(buf.data(), 1, l, out);
+				}
+			}
+		}
+		for (int i = 0; i < nr; ++i) { for (int k = 0; k < n_regs[i]; ++k) free(regs[i][k].cigar); free(regs[i]); }
+	}
+	al_ctx_destroy(ctx);
+	al_sf_close(f1); al_sf_close(f2);
+	fflush(out);
+	return rc;
+}

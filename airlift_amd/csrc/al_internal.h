@@ -1,0 +1,99 @@
+// al_internal.h -- shared host/device declarations of the MI355X re-alignment path.
+// Product code (not the oracle).  Reference citations are to /root/reference/src/minimap2-master_remapping/.
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+#include <string>
+#include <vector>
+#include <map>
+#include <mutex>
+#include "../../include/airlift.h"
+
+#define AL_SEED_TANDEM    (1ULL<<42)       // mmpriv.h:20
+#define AL_SEED_SEG_SHIFT 48               // mmpriv.h:23
+#define AL_SEED_SEG_MASK  (0xffULL<<AL_SEED_SEG_SHIFT)
+#define AL_PARENT_UNSET   (-1)
+#define AL_PARENT_TMP_PRI (-2)
+
+// ---------------------------------------------------------------------------------------------
+// Index.  Semantics of mm_idx_t (index.c:27-98): minimizer hash -> ascending list of
+// (rid<<32 | pos<<1 | strand).  HBM layout (own design):
+//   tab[2*slot+0] = hash+1 (0 = empty), tab[2*slot+1] = off<<32 | n   -- 16 B entries, open addressing,
+//                   slot = (hash * GOLDEN) >> (64 - tab_bits), linear probing, load <= 0.5
+//   pos[off .. off+n) = occurrence list, singletons included (one contiguous array)
+//   S4[]             = reference bases, 4 bit/base, 8 bases per uint32 (same code as mm_seq4_get, mmpriv.h:29)
+// ---------------------------------------------------------------------------------------------
+struct AlSeq { std::string name; uint64_t offset; uint32_t len; };
+
+struct AlDevIndex {           // device pointers (one per GPU)
+	uint32_t *S4 = nullptr;
+	uint64_t *tab = nullptr;
+	uint64_t *pos = nullptr;
+	uint64_t *seq_off = nullptr;
+	uint32_t *seq_len = nullptr;
+	int tab_bits = 0;
+	uint32_t n_seq = 0;
+};
+
+struct al_idx_s {
+	int k = 21, w = 11;
+	std::vector<AlSeq> seq;
+	std::vector<uint32_t> S4;
+	uint64_t tot_len = 0;
+	int tab_bits = 4;
+	std::vector<uint64_t> tab;
+	std::vector<uint64_t> pos;
+	uint64_t n_keys = 0;
+	mutable std::mutex dev_mtx;
+	mutable std::map<int, AlDevIndex> dev;   // lazily uploaded per device
+};
+
+static inline uint64_t al_tab_slot(uint64_t hash, int bits) { return (hash * 0x9E3779B97F4A7C15ULL) >> (64 - bits); }
+
+// host-side helpers (al_index.cpp)
+void al_sketch_host(const uint8_t *codes, uint32_t len, int w, int k, uint32_t rid, std::vector<uint64_t> &hash_out, std::vector<uint64_t> &y_out);
+
+// ---------------------------------------------------------------------------------------------
+// Device-side record types
+// ---------------------------------------------------------------------------------------------
+struct AlParams {             // kernel parameter block (copy of the options the device code needs)
+	int k, w;
+	int seed, bw, max_gap, max_gap_ref, max_frag_len, max_chain_skip, max_chain_iter, min_cnt, min_chain_score;
+	float mask_level, pri_ratio, max_clip_ratio;
+	int best_n, a, b, q, e, q2, e2, sc_ambi, zdrop, zdrop_inv, end_bonus, min_dp_max;
+	int pe_ori, pe_bonus, mid_occ, max_occ;
+};
+
+struct AlMatch {              // one query minimizer that passed the occurrence filter (mm_match_t, map.c:82-88)
+	uint32_t off_lo;          // offset into pos[] (low 32 bits)
+	uint32_t n;               // occurrences
+	uint32_t q_pos;           // (pos<<1 | strand) in the concatenated fragment
+	uint32_t flags;           // seg_id | is_tandem<<8 | off_hi<<16
+};
+
+struct AlAnchor { uint64_t x, y; };   // mm128_t anchor (map.c:176-187)
+
+#define AL_MAX_CIGAR_INLINE 0
+
+struct AlReg {                // device mm_reg1_t (+ mm_extra_t scalars); 96 bytes
+	int32_t id, cnt, rid, score;
+	int32_t qs, qe, rs, re;
+	int32_t parent, subsc, as, mlen;
+	int32_t blen, n_sub, score0;
+	uint32_t hash;
+	uint32_t mapq, flags;     // flags: split(2) | rev<<2 | inv<<3 | sam_pri<<4 | proper<<5 | pe_thru<<6 | seg_split<<7 | seg_id<<8 | split_inv<<16 | has_p<<17
+	int32_t dp_score, dp_max, dp_max2;
+	uint32_t n_ambi, n_cigar, cigar_off;   // cigar_off: index into the fragment-mate cigar arena
+};
+#define ALR_SPLIT(f)     ((f)&3u)
+#define ALR_REV          (1u<<2)
+#define ALR_INV          (1u<<3)
+#define ALR_SAM_PRI      (1u<<4)
+#define ALR_PROPER       (1u<<5)
+#define ALR_PE_THRU      (1u<<6)
+#define ALR_SEG_SPLIT    (1u<<7)
+#define ALR_SEG_ID(f)    (((f)>>8)&0xffu)
+#define ALR_SPLIT_INV    (1u<<16)
+#define ALR_HAS_P        (1u<<17)
+
+enum AlStage { ST_SKETCH = 0, ST_SEED, ST_SCAN, ST_ANCHOR_SORT, ST_CHAIN, ST_RECHAIN, ST_REGS, ST_ALIGN, ST_N };

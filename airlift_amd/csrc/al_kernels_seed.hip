@@ -1,0 +1,543 @@
+// al_kernels_seed.hip -- CDNA4 (gfx950) kernels K1..K4 of the re-alignment path:
+//   K1 k_sketch       minimizer sketch, one lane per read            (mm_sketch, sketch.c:77-143)
+//   K2 k_seed         hash probes + occurrence filter, lane/fragment  (collect_matches, map.c:90-123; mm_idx_get, index.c:81-98)
+//   K3 k_anchor_sort  anchor expansion + x-sort, one wave/fragment    (collect_seed_hits_heap, map.c:149-213)
+//   K4 k_chain        chaining DP + backtrack, one wave/fragment      (mm_chain_dp, chain.c:22-162)
+// Integer / byte work, HBM- and latency-bound: no MFMA.  64-wide wavefronts throughout.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "al_internal.h"
+#include "al_device.h"
+
+// =============================================================================================
+// K1: sketch.  One lane per read runs the reference's streaming window algorithm verbatim (so ties,
+// N resets and the l-counter quirks are reproduced); the w-entry ring lives in LDS laid out
+// [slot][lane] so that a wave's accesses hit 64 consecutive banks.
+// =============================================================================================
+__device__ __forceinline__ uint64_t d_hash64m(uint64_t key, uint64_t mask)
+{   // sketch.c:28-38
+	key = (~key + (key << 21)) & mask; key = key ^ key >> 24;
+	key = ((key + (key << 3)) + (key << 8)) & mask; key = key ^ key >> 14;
+	key = ((key + (key << 2)) + (key << 4)) & mask; key = key ^ key >> 28;
+	key = (key + (key << 31)) & mask;
+	return key;
+}
+
+extern "C" __global__ void __launch_bounds__(64)
+k_sketch(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_off, const uint32_t *__restrict__ rd_len,
+         const uint64_t *__restrict__ mini_off, AlAnchor *__restrict__ mini, uint32_t *__restrict__ mini_cnt,
+         int n_reads, int w, int k)
+{
+	extern __shared__ uint64_t lds[];           // bx[w][64] then by[w][64] (y low word kept as u64 for simplicity)
+	const int lane = threadIdx.x;
+	const int r = blockIdx.x * 64 + lane;
+	uint64_t *bx = lds + lane, *by = lds + (size_t)w * 64 + lane;
+	if (r >= n_reads) return;
+	const uint32_t len = rd_len[r];
+	const uint32_t *seq = rd_seq + rd_off[r];
+	AlAnchor *out = mini + mini_off[r];
+	uint32_t cnt = 0;
+	const uint64_t shift1 = 2 * (k - 1), mask = (1ULL << 2 * k) - 1;
+	uint64_t kmer0 = 0, kmer1 = 0, minx = UINT64_MAX, miny = UINT64_MAX;
+	int l = 0, buf_pos = 0, min_pos = 0;
+	for (int j = 0; j < w; ++j) bx[j * 64] = UINT64_MAX, by[j * 64] = UINT64_MAX;
+	uint32_t word = 0;
+	for (uint32_t i = 0; i < len; ++i) {
+		if ((i & 7) == 0) word = seq[i >> 3];
+		const int c = (word >> ((i & 7) << 2)) & 0xf;
+		uint64_t ix = UINT64_MAX, iy = UINT64_MAX;
+		if (c < 4) {
+			const int span = l + 1 < k ? l + 1 : k;
+			kmer0 = (kmer0 << 2 | (uint64_t)c) & mask;
+			kmer1 = (kmer1 >> 2) | (3ULL ^ (uint64_t)c) << shift1;
+			if (kmer0 == kmer1) continue;                                   // sketch.c:108
+			const int z = kmer0 < kmer1 ? 0 : 1;
+			++l;
+			if (l >= k) { ix = d_hash64m(z ? kmer1 : kmer0, mask) << 8 | (uint64_t)span; iy = (uint64_t)i << 1 | (uint64_t)z; }
+		} else l = 0;
+		bx[buf_pos * 64] = ix; by[buf_pos * 64] = iy;
+		if (l == w + k - 1 && minx != UINT64_MAX) {                         // sketch.c:117-122
+			for (int j = buf_pos + 1; j < w; ++j) { uint64_t x = bx[j * 64], y = by[j * 64]; if (minx == x && y != miny) out[cnt].x = x, out[cnt].y = y, ++cnt; }
+			for (int j = 0; j < buf_pos; ++j)     { uint64_t x = bx[j * 64], y = by[j * 64]; if (minx == x && y != miny) out[cnt].x = x, out[cnt].y = y, ++cnt; }
+		}
+		if (ix <= minx) {                                                   // sketch.c:123-125
+			if (l >= w + k && minx != UINT64_MAX) out[cnt].x = minx, out[cnt].y = miny, ++cnt;
+			minx = ix, miny = iy, min_pos = buf_pos;
+		} else if (buf_pos == min_pos) {                                    // sketch.c:126-138
+			if (l >= w + k - 1 && minx != UINT64_MAX) out[cnt].x = minx, out[cnt].y = miny, ++cnt;
+			minx = UINT64_MAX;
+			for (int j = buf_pos + 1; j < w; ++j) { uint64_t x = bx[j * 64]; if (minx >= x) minx = x, miny = by[j * 64], min_pos = j; }
+			for (int j = 0; j <= buf_pos; ++j)    { uint64_t x = bx[j * 64]; if (minx >= x) minx = x, miny = by[j * 64], min_pos = j; }
+			if (l >= w + k - 1 && minx != UINT64_MAX) {
+				for (int j = buf_pos + 1; j < w; ++j) { uint64_t x = bx[j * 64], y = by[j * 64]; if (minx == x && miny != y) out[cnt].x = x, out[cnt].y = y, ++cnt; }
+				for (int j = 0; j <= buf_pos; ++j)    { uint64_t x = bx[j * 64], y = by[j * 64]; if (minx == x && miny != y) out[cnt].x = x, out[cnt].y = y, ++cnt; }
+			}
+		}
+		if (++buf_pos == w) buf_pos = 0;
+	}
+	if (minx != UINT64_MAX) out[cnt].x = minx, out[cnt].y = miny, ++cnt;
+	mini_cnt[r] = cnt;
+}
+
+// =============================================================================================
+// K2: seed lookup.  One lane per fragment walks the fragment's minimizers in order (mate 1 then mate 2,
+// positions of mate 2 offset by len(mate 1): collect_minimizers, map.c:64-77), probes the 16-byte-entry
+// open-addressing table and applies the occurrence filter / repeat-length bookkeeping of collect_matches.
+// =============================================================================================
+__device__ __forceinline__ uint64_t d_idx_get(const uint64_t *__restrict__ tab, int tab_bits, uint64_t hash)
+{   // returns off<<32|n, or 0 if absent
+	const uint64_t tmask = (1ULL << tab_bits) - 1;
+	uint64_t s = (hash * 0x9E3779B97F4A7C15ULL) >> (64 - tab_bits);
+	for (;;) {
+		const ulonglong2 e = *reinterpret_cast<const ulonglong2 *>(tab + 2 * s);   // one 16-B entry
+		if (e.x == hash + 1) return e.y;
+		if (e.x == 0) return 0;
+		s = (s + 1) & tmask;
+	}
+}
+
+extern "C" __global__ void __launch_bounds__(256)
+k_seed(const uint64_t *__restrict__ tab, int tab_bits,
+       const uint32_t *__restrict__ frag_first, const uint32_t *__restrict__ rd_len,
+       const uint64_t *__restrict__ mini_off, AlAnchor *__restrict__ mini, const uint32_t *__restrict__ mini_cnt,
+       AlMatch *__restrict__ match, uint32_t *__restrict__ frag_nm, uint32_t *__restrict__ frag_na, int32_t *__restrict__ frag_rep,
+       const uint32_t *__restrict__ frag_list, int n_list, int max_occ)
+{
+	const int t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= n_list) return;
+	const uint32_t f = frag_list ? frag_list[t] : (uint32_t)t;
+	const uint32_t r0 = frag_first[f], r1 = frag_first[f + 1];
+	AlMatch *mo = match + mini_off[r0];
+	int rep_st = 0, rep_en = 0, rep_len = 0; uint32_t n_m = 0, n_a = 0, sum = 0;
+	uint64_t prev_hash = ~0ULL; int have_prev = 0;
+	AlMatch *last = nullptr; uint64_t last_hash = 0; int last_valid = 0;
+	for (uint32_t r = r0; r < r1; ++r) {
+		const AlAnchor *mv = mini + mini_off[r];
+		const uint32_t n = mini_cnt[r], seg = r - r0;
+		for (uint32_t i = 0; i < n; ++i) {
+			const uint64_t x = mv[i].x, hash = x >> 8;
+			const uint32_t q_pos = (uint32_t)mv[i].y + (sum << 1), q_span = (uint32_t)(x & 0xff);
+			const uint64_t v = d_idx_get(tab, tab_bits, hash);
+			const uint32_t occ = (uint32_t)v;
+			// is_tandem (map.c:115-116): equal hash with the previous / next minimizer of the whole list
+			const int same_prev = have_prev && prev_hash == hash;
+			if (same_prev && last_valid && last_hash == hash) last->flags |= 1u << 8;   // previous gets "next is same"
+			last_valid = 0;
+			if ((int)occ >= max_occ) {                                       // map.c:105-111
+				const int en = (int)(q_pos >> 1) + 1, st = en - (int)q_span;
+				if (st > rep_en) { rep_len += rep_en - rep_st; rep_st = st, rep_en = en; }
+				else rep_en = en;
+			} else if (occ > 0) {
+				AlMatch m;
+				m.off_lo = (uint32_t)(v >> 32); m.n = occ; m.q_pos = q_pos;
+				m.flags = seg | (same_prev ? 1u << 8 : 0u);
+				mo[n_m] = m; last = &mo[n_m]; last_hash = hash; last_valid = 1;
+				++n_m; n_a += occ;
+			}
+			prev_hash = hash; have_prev = 1;
+		}
+		sum += rd_len[r];
+	}
+	rep_len += rep_en - rep_st;
+	frag_nm[f] = n_m; frag_na[f] = n_a; frag_rep[f] = rep_len;
+}
+
+// a8: ALSER candidate counter (map.c:299-312) on the sorted anchors of single-segment fragments
+extern "C" __global__ void __launch_bounds__(256)
+k_alser_count(const AlAnchor *__restrict__ a, const uint64_t *__restrict__ a_off, const uint32_t *__restrict__ frag_na,
+              const uint32_t *__restrict__ frag_first, const uint32_t *__restrict__ rd_len, int n_frag, int min_cnt,
+              unsigned long long *__restrict__ total)
+{
+	const int f = blockIdx.x * blockDim.x + threadIdx.x;
+	if (f >= n_frag) return;
+	const AlAnchor *p = a + a_off[f]; const uint32_t n = frag_na[f]; const int qlen0 = (int)rd_len[frag_first[f]];
+	int seed_num = 0; unsigned cnt = 0;
+	for (uint32_t i = 1; i < n; ++i) {
+		if (((int32_t)p[i].x - (int32_t)p[i - 1].x) > qlen0) { if (seed_num >= min_cnt - 1) ++cnt; seed_num = 0; }
+		else ++seed_num;
+	}
+	if (cnt) atomicAdd(total, (unsigned long long)cnt);
+}
+
+// =============================================================================================
+// K3: anchor expansion + sort.  One wave per fragment.  Anchors are generated in parallel from the
+// occurrence lists (coalesced 8-byte position reads), sorted by x with an LDS bitonic network, and
+// written out.  Final order = forward-strand anchors by (rid,pos) then reverse-strand anchors: exactly
+// the reference's k-way heap merge (x carries the strand in bit 63).  Equal x can only come from a query
+// k-mer that occurs twice (overlapping mates, tandem repeats); the reference's order among those is
+// heap-shape dependent, so such fragments -- and fragments too large for the LDS tile --
+// are re-done by lane 0 with an exact emulation of the binary heap (ksort.h:43-59).
+// =============================================================================================
+__device__ __forceinline__ void d_make_anchor(const AlMatch &m, uint64_t r, int qlen, uint64_t &x, uint64_t &y)
+{   // map.c:176-190
+	const uint32_t q_span_ = 0; (void)q_span_;
+	const int32_t rpos = (uint32_t)r >> 1;
+	if ((r & 1) == (m.q_pos & 1)) {
+		x = (r & 0xffffffff00000000ULL) | (uint32_t)rpos;
+		y = (uint64_t)(m.q_pos >> 1);
+	} else {
+		x = 1ULL << 63 | (r & 0xffffffff00000000ULL) | (uint32_t)rpos;
+		y = 0;   // filled by caller (needs span)
+	}
+}
+
+template <int CAP>
+__device__ void d_bitonic_sort_lds(AlAnchor *s, int npow2, int lane)
+{   // ascending by x; npow2 <= CAP elements, 64 lanes
+	for (int kk = 2; kk <= npow2; kk <<= 1)
+		for (int j = kk >> 1; j > 0; j >>= 1) {
+			for (int i = lane; i < npow2; i += 64) {
+				const int ixj = i ^ j;
+				if (ixj > i) {
+					const AlAnchor a = s[i], b = s[ixj];
+					const bool up = (i & kk) == 0;
+					if ((a.x > b.x) == up) { s[i] = b; s[ixj] = a; }
+				}
+			}
+			__syncthreads();
+		}
+}
+
+__device__ __forceinline__ void d_heapdown(size_t i, size_t n, AlAnchor *l)
+{   // ksort.h:43-53 with heap_lt(a,b) = a.x > b.x (map.c:80)
+	size_t k = i; AlAnchor tmp = l[i];
+	while ((k = (k << 1) + 1) < n) {
+		if (k != n - 1 && l[k].x > l[k + 1].x) ++k;
+		if (l[k].x > tmp.x) break;
+		l[i] = l[k]; i = k;
+	}
+	l[i] = tmp;
+}
+
+template <int CAP>
+__global__ void __launch_bounds__(64)
+k_anchor_sort(const uint64_t *__restrict__ pos, const uint32_t *__restrict__ frag_first, const uint32_t *__restrict__ rd_len,
+              const uint64_t *__restrict__ mini_off, const AlMatch *__restrict__ match,
+              const uint32_t *__restrict__ frag_nm, const uint32_t *__restrict__ frag_na, const uint64_t *__restrict__ a_off,
+              AlAnchor *__restrict__ anchors, AlAnchor *__restrict__ heap_ws,
+              const uint32_t *__restrict__ frag_list, int n_list, unsigned long long *__restrict__ counters, int mini_span)
+{
+	__shared__ AlAnchor s[CAP];
+	__shared__ uint32_t pre[CAP > 512 ? 513 : CAP + 1];
+	__shared__ int s_flag;
+	const int lane = threadIdx.x;
+	if ((int)blockIdx.x >= n_list) return;
+	const uint32_t f = frag_list ? frag_list[blockIdx.x] : blockIdx.x;
+	const uint32_t n = frag_na[f], n_m = frag_nm[f];
+	if (n == 0) return;
+	const uint32_t r0 = frag_first[f], r1 = frag_first[f + 1];
+	int qlen = 0; for (uint32_t r = r0; r < r1; ++r) qlen += (int)rd_len[r];
+	const AlMatch *m = match + mini_off[r0];
+	AlAnchor *out = anchors + a_off[f];
+	bool fallback = (n > (uint32_t)CAP) || (n_m > 512);
+	if (!fallback) {
+		// prefix sums of occurrence counts (n_m <= 512): serial per 64-chunk scan
+		if (lane == 0) s_flag = 0;
+		uint32_t run = 0;
+		for (uint32_t base = 0; base < n_m; base += 64) {
+			const uint32_t i = base + lane;
+			uint32_t v = i < n_m ? m[i].n : 0, incl = v;
+			for (int d = 1; d < 64; d <<= 1) { uint32_t t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+			if (i < n_m) pre[i] = run + incl - v;
+			run += __shfl(incl, 63);
+		}
+		if (lane == 0) pre[n_m] = run;
+		__syncthreads();
+		int npow2 = 1; while ((uint32_t)npow2 < n) npow2 <<= 1;
+		for (uint32_t t = lane; t < (uint32_t)npow2; t += 64) {
+			AlAnchor a; a.x = UINT64_MAX; a.y = UINT64_MAX;
+			if (t < n) {
+				uint32_t lo = 0, hi = n_m;                                   // last mi with pre[mi] <= t
+				while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (pre[mid] <= t) lo = mid; else hi = mid; }
+				const AlMatch mm = m[lo];
+				const uint64_t off = (uint64_t)mm.off_lo | (uint64_t)(mm.flags >> 16) << 32;
+				const uint64_t r = pos[off + (t - pre[lo])];
+				const uint32_t span = (uint32_t)mini_span, seg = mm.flags & 0xff;
+				const int32_t rpos = (uint32_t)r >> 1;
+				if ((r & 1) == (mm.q_pos & 1)) {
+					a.x = (r & 0xffffffff00000000ULL) | (uint32_t)rpos;
+					a.y = (uint64_t)span << 32 | (mm.q_pos >> 1);
+				} else {
+					a.x = 1ULL << 63 | (r & 0xffffffff00000000ULL) | (uint32_t)rpos;
+					a.y = (uint64_t)span << 32 | (uint32_t)(qlen - ((int)(mm.q_pos >> 1) + 1 - (int)span) - 1);
+				}
+				a.y |= (uint64_t)seg << AL_SEED_SEG_SHIFT;
+				if (mm.flags & (1u << 8)) a.y |= AL_SEED_TANDEM;
+			}
+			s[t] = a;
+		}
+		__syncthreads();
+		d_bitonic_sort_lds<CAP>(s, npow2, lane);
+		int tie = 0;
+		for (uint32_t t = lane; t < n; t += 64) { if (t + 1 < n && s[t].x == s[t + 1].x) tie = 1; }
+		if (tie) s_flag = 1;
+		__syncthreads();
+		fallback = s_flag != 0;
+		if (!fallback) for (uint32_t t = lane; t < n; t += 64) out[t] = s[t];
+	}
+	if (fallback && lane == 0) {
+		// exact emulation of collect_seed_hits_heap (map.c:149-213) by one lane; heap in global scratch
+		AlAnchor *heap = heap_ws + mini_off[r0];
+		size_t hs = 0; uint64_t n_for = 0, n_rev = 0;
+		atomicAdd(&counters[0], 1ULL);
+		for (uint32_t i = 0; i < n_m; ++i) {
+			const uint64_t off = (uint64_t)m[i].off_lo | (uint64_t)(m[i].flags >> 16) << 32;
+			heap[hs].x = pos[off]; heap[hs].y = (uint64_t)i << 32; ++hs;
+		}
+		if (hs > 1) for (size_t i = (hs >> 1) - 1; i != (size_t)-1; --i) d_heapdown(i, hs, heap);
+		while (hs > 0) {
+			const AlMatch mm = m[heap[0].y >> 32];
+			const uint64_t r = heap[0].x; const int32_t rpos = (uint32_t)r >> 1; const uint32_t span = (uint32_t)mini_span;
+			AlAnchor a;
+			if ((r & 1) == (mm.q_pos & 1)) {
+				a.x = (r & 0xffffffff00000000ULL) | (uint32_t)rpos;
+				a.y = (uint64_t)span << 32 | (mm.q_pos >> 1);
+			} else {
+				a.x = 1ULL << 63 | (r & 0xffffffff00000000ULL) | (uint32_t)rpos;
+				a.y = (uint64_t)span << 32 | (uint32_t)(qlen - ((int)(mm.q_pos >> 1) + 1 - (int)span) - 1);
+			}
+			a.y |= (uint64_t)(mm.flags & 0xff) << AL_SEED_SEG_SHIFT;
+			if (mm.flags & (1u << 8)) a.y |= AL_SEED_TANDEM;
+			if (!(a.x >> 63)) out[n_for++] = a; else out[n - (++n_rev)] = a;
+			if ((uint32_t)heap[0].y < mm.n - 1) {
+				++heap[0].y;
+				const AlMatch m2 = m[heap[0].y >> 32];
+				const uint64_t off = (uint64_t)m2.off_lo | (uint64_t)(m2.flags >> 16) << 32;
+				heap[0].x = pos[off + (uint32_t)heap[0].y];
+			} else { heap[0] = heap[hs - 1]; --hs; }
+			if (hs > 0) d_heapdown(0, hs, heap);
+		}
+		for (uint64_t j = 0; j < n_rev >> 1; ++j) {                          // map.c:202-207
+			AlAnchor t = out[n - 1 - j]; out[n - 1 - j] = out[n - (n_rev - j)]; out[n - (n_rev - j)] = t;
+		}
+	}
+}
+
+// =============================================================================================
+// K4: chaining.  One wave per fragment; anchors + DP arrays staged in LDS (global scratch for fragments
+// larger than the tile).  The predecessor scan of anchor i is done 64 candidates at a time: every lane
+// scores one j, an exclusive prefix-max (shuffles) decides which lanes would have raised max_f in the
+// sequential order, the "already a predecessor" marks t[] go through LDS, and the max_skip early exit
+// is replayed on the two ballot masks -- bit-identical to the scalar loop (chain.c:52-82).
+// =============================================================================================
+__device__ __forceinline__ int d_ilog2(uint32_t v) { return 31 - __clz((int)v); }
+
+struct ChainArrays { uint64_t *x; int32_t *q; uint32_t *m; int32_t *f, *p, *t, *v; };   // m: span | sid<<8
+
+template <int CAP>
+__global__ void __launch_bounds__(64)
+k_chain(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_off, const uint32_t *__restrict__ frag_na,
+        const uint32_t *__restrict__ frag_first, const uint32_t *__restrict__ rd_len,
+        AlAnchor *__restrict__ chained, uint64_t *__restrict__ u_out, uint32_t *__restrict__ frag_nu,
+        int32_t *__restrict__ ws_i32 /* 4 ints per anchor */, uint64_t *__restrict__ ws_u64 /* 1 per anchor */,
+        const uint32_t *__restrict__ frag_list, int n_list, AlParams P, unsigned long long *__restrict__ counters)
+{
+	__shared__ uint64_t sx[CAP];
+	__shared__ int32_t sq[CAP], sf[CAP], sp[CAP], st_[CAP], sv[CAP];
+	__shared__ uint32_t sm[CAP];
+	const int lane = threadIdx.x;
+	if ((int)blockIdx.x >= n_list) return;
+	const uint32_t f = frag_list ? frag_list[blockIdx.x] : blockIdx.x;
+	const int64_t n = frag_na[f];
+	if (lane == 0) frag_nu[f] = 0;
+	if (n == 0) return;
+	const uint32_t r0 = frag_first[f], r1 = frag_first[f + 1];
+	const int n_segs = (int)(r1 - r0);
+	int qlen_sum = 0; for (uint32_t r = r0; r < r1; ++r) qlen_sum += (int)rd_len[r];
+	const AlAnchor *a = anchors + a_off[f];
+	const bool in_lds = n <= CAP;
+	uint64_t *X; int32_t *Q, *F, *Pp, *T, *V; uint32_t *M;
+	if (in_lds) { X = sx; Q = sq; F = sf; Pp = sp; T = st_; V = sv; M = sm; }
+	else {
+		int32_t *w = ws_i32 + a_off[f] * 4;
+		F = w; Pp = w + n; T = w + 2 * n; V = w + 3 * n;
+		X = nullptr; Q = nullptr; M = nullptr;
+	}
+	// chaining gaps (map.c:341-351)
+	const int max_dist_y = qlen_sum > P.max_gap ? qlen_sum : P.max_gap;
+	int max_dist_x;
+	if (P.max_gap_ref > 0) max_dist_x = P.max_gap_ref;
+	else if (P.max_frag_len > 0) { max_dist_x = P.max_frag_len - qlen_sum; if (max_dist_x < P.max_gap) max_dist_x = P.max_gap; }
+	else max_dist_x = P.max_gap;
+	const int bw = P.bw, max_skip = P.max_chain_skip, max_iter = P.max_chain_iter, min_cnt = P.min_cnt, min_sc = P.min_chain_score;
+
+	uint64_t sum_qspan = 0;
+	for (int64_t i = lane; i < n; i += 64) {
+		const AlAnchor e = a[i];
+		if (in_lds) { X[i] = e.x; Q[i] = (int32_t)e.y; M[i] = (uint32_t)(e.y >> 32 & 0xff) | (uint32_t)((e.y & AL_SEED_SEG_MASK) >> AL_SEED_SEG_SHIFT) << 8; }
+		T[i] = 0;
+		sum_qspan += e.y >> 32 & 0xff;
+	}
+	for (int d = 32; d > 0; d >>= 1) sum_qspan += __shfl_xor(sum_qspan, d);
+	const float avg_qspan = (float)((double)(float)sum_qspan / (double)(float)n);   // == (float)sum/n in IEEE fp32 (chain.c:42)
+	const double avg_d = (double)avg_qspan;
+	__syncthreads();
+
+#define AX(i) (in_lds ? X[i] : a[i].x)
+#define AQ(i) (in_lds ? Q[i] : (int32_t)a[i].y)
+#define AM(i) (in_lds ? M[i] : ((uint32_t)(a[i].y >> 32 & 0xff) | (uint32_t)((a[i].y & AL_SEED_SEG_MASK) >> AL_SEED_SEG_SHIFT) << 8))
+
+	int64_t st = 0;
+	for (int64_t i = 0; i < n; ++i) {
+		const uint64_t ri = AX(i); const int32_t qi = AQ(i); const uint32_t mi_ = AM(i);
+		const int32_t q_span = mi_ & 0xff, sidi = mi_ >> 8;
+		while (st < i && ri > AX(st) + (uint64_t)max_dist_x) ++st;
+		if (i - st > max_iter) st = i - max_iter;
+		int32_t max_f = q_span, n_skip = 0; int64_t max_j = -1; bool broke = false;
+		for (int64_t base = i - 1; base >= st && !broke; base -= 64) {
+			const int64_t j = base - lane;
+			bool active = j >= st; int32_t sc = INT32_MIN; int32_t pj = -1;
+			if (active) {
+				const int64_t dr = (int64_t)(ri - AX(j));
+				const int32_t dq = qi - AQ(j); const uint32_t mj = AM(j); const int32_t sidj = mj >> 8;
+				bool skip = (sidi == sidj && dr == 0) || dq <= 0;
+				skip = skip || (sidi == sidj && dq > max_dist_y) || dq > max_dist_x;
+				const int32_t dd = dr > dq ? (int32_t)(dr - dq) : (int32_t)(dq - dr);
+				skip = skip || (sidi == sidj && dd > bw);
+				skip = skip || (n_segs > 1 && sidi == sidj && dr > max_dist_y);
+				if (!skip) {
+					const int32_t min_d = dq < dr ? dq : (int32_t)dr;
+					int32_t s0 = min_d > q_span ? q_span : min_d;
+					const int32_t log_dd = dd ? d_ilog2((uint32_t)dd) : 0;
+					const int32_t c_lin = (int)((double)dd * .01 * avg_d);
+					if (sidi != sidj) {
+						if (dr == 0) ++s0;
+						else s0 -= c_lin < log_dd ? c_lin : log_dd;
+					} else s0 -= c_lin + (log_dd >> 1);
+					sc = s0 + F[j];
+					pj = Pp[j];
+				} else active = false;
+			}
+			// sequential replay over lanes 0..63 (descending j)
+			int32_t ex = sc;                                                  // inclusive prefix max -> exclusive
+			for (int d = 1; d < 64; d <<= 1) { int32_t t = __shfl_up(ex, d); if (lane >= d && t > ex) ex = t; }
+			int32_t excl = __shfl_up(ex, 1); if (lane == 0) excl = INT32_MIN;
+			const int32_t before = excl > max_f ? excl : max_f;
+			const bool upd = active && sc > before;
+			if (active && pj >= 0) T[pj] = (int32_t)i;
+			__syncthreads();
+			const bool marked = active && !upd && T[j] == (int32_t)i;
+			unsigned long long U = __ballot(upd), K = __ballot(marked);
+			unsigned long long both = U | K; int brk = 64;
+			while (both) {
+				const int b = __ffsll((long long)both) - 1; both &= both - 1;
+				if (U >> b & 1) { if (n_skip > 0) --n_skip; }
+				else if (++n_skip > max_skip) { brk = b; break; }
+			}
+			if (brk < 64) { broke = true; U &= (brk == 0 ? 0ULL : (~0ULL >> (64 - brk))); }
+			if (U) {
+				const int lastu = 63 - __clzll((long long)U);
+				max_f = __shfl(sc, lastu); max_j = base - lastu;
+			}
+			__syncthreads();
+		}
+		if (lane == 0) {
+			F[i] = max_f; Pp[i] = (int32_t)max_j;
+			V[i] = max_j >= 0 && V[max_j] > max_f ? V[max_j] : max_f;
+		}
+		__syncthreads();
+	}
+
+	// ---- chain ends, peaks, backtrack (chain.c:87-160): lane 0, O(n) -----------------------------------
+	for (int64_t i = lane; i < n; i += 64) T[i] = 0;
+	__syncthreads();
+	for (int64_t i = lane; i < n; i += 64) if (Pp[i] >= 0) T[Pp[i]] = 1;
+	__syncthreads();
+	if (lane == 0) {
+		uint64_t *u = u_out + a_off[f] + f;                 // capacity n + 1
+		uint64_t *utmp = ws_u64 + a_off[f];                 // capacity n
+		int32_t n_u = 0, n_v = 0, k = 0;
+		for (int64_t i = 0; i < n; ++i)
+			if (T[i] == 0 && V[i] >= min_sc) {
+				int64_t j = i;
+				while (j >= 0 && F[j] < V[j]) j = Pp[j];
+				if (j < 0) j = i;
+				utmp[n_u++] = (uint64_t)(uint32_t)F[j] << 32 | (uint64_t)j;
+			}
+		if (n_u > 0) {
+			// keys are unique (distinct j): any sort; descending by insertion / heap sort
+			if (n_u <= 64) {
+				for (int32_t i = 1; i < n_u; ++i) { uint64_t t = utmp[i]; int32_t j = i; while (j > 0 && utmp[j - 1] < t) { utmp[j] = utmp[j - 1]; --j; } utmp[j] = t; }
+			} else {
+				// heap sort ascending then reverse
+				for (int32_t s0 = (n_u >> 1) - 1; s0 >= 0; --s0) { int32_t i = s0; uint64_t t = utmp[i]; for (;;) { int32_t c = 2 * i + 1; if (c >= n_u) break; if (c + 1 < n_u && utmp[c + 1] > utmp[c]) ++c; if (utmp[c] <= t) break; utmp[i] = utmp[c]; i = c; } utmp[i] = t; }
+				for (int32_t e = n_u - 1; e > 0; --e) { uint64_t t = utmp[e]; utmp[e] = utmp[0]; int32_t i = 0; for (;;) { int32_t c = 2 * i + 1; if (c >= e) break; if (c + 1 < e && utmp[c + 1] > utmp[c]) ++c; if (utmp[c] <= t) break; utmp[i] = utmp[c]; i = c; } utmp[i] = t; }
+				for (int32_t i = 0; i < n_u >> 1; ++i) { uint64_t t = utmp[i]; utmp[i] = utmp[n_u - 1 - i]; utmp[n_u - 1 - i] = t; }
+			}
+			for (int64_t i = 0; i < n; ++i) T[i] = 0;
+			// backtrack; V[] is reused as the visit list v[] (chain.c:113-127)
+			for (int32_t i = 0; i < n_u; ++i) {
+				const int32_t n_v0 = n_v, k0 = k; int64_t j = (int32_t)utmp[i];
+				do { V[n_v++] = (int32_t)j; T[j] = 1; j = Pp[j]; } while (j >= 0 && T[j] == 0);
+				if (j < 0) { if (n_v - n_v0 >= min_cnt) utmp[k++] = utmp[i] >> 32 << 32 | (uint32_t)(n_v - n_v0); }
+				else if ((int32_t)(utmp[i] >> 32) - F[j] >= min_sc) { if (n_v - n_v0 >= min_cnt) utmp[k++] = (uint64_t)((utmp[i] >> 32) - (uint64_t)(uint32_t)F[j]) << 32 | (uint32_t)(n_v - n_v0); }
+				if (k0 == k) n_v = n_v0;
+			}
+			n_u = k;
+			// order chains by the x of their first anchor (chain.c:144-160): stable insertion for <= 64 (ksort.h:149)
+			// first anchor of chain c = a[V[k0 + ni - 1]]
+			AlAnchor *b = chained + a_off[f];
+			// P array (Pp) is free now: reuse as chain start offsets into V, T as permutation
+			int32_t off = 0;
+			for (int32_t c = 0; c < n_u; ++c) { Pp[c] = off; off += (int32_t)(uint32_t)utmp[c]; T[c] = c; }
+			bool tie = false;
+			if (n_u <= 64) {
+				for (int32_t i = 1; i < n_u; ++i) {
+					const int32_t ci = T[i]; const uint64_t xi = a[V[Pp[ci] + (int32_t)(uint32_t)utmp[ci] - 1]].x; int32_t j = i;
+					while (j > 0) { const int32_t cj = T[j - 1]; const uint64_t xj = a[V[Pp[cj] + (int32_t)(uint32_t)utmp[cj] - 1]].x; if (xi < xj) { T[j] = cj; --j; } else break; }
+					T[j] = ci;
+				}
+			} else {
+				// > 64 chains: the reference's radix sort is unstable; order is only defined when keys are distinct.
+				// heap sort on (x, original index) and flag fragments that actually contain equal keys.
+#define CX(c) (a[V[Pp[c] + (int32_t)(uint32_t)utmp[c] - 1]].x)
+#define CLT(c1, c2) (CX(c1) < CX(c2) || (CX(c1) == CX(c2) && (c1) < (c2)))
+				for (int32_t s0 = (n_u >> 1) - 1; s0 >= 0; --s0) { int32_t i = s0, t = T[i]; for (;;) { int32_t c = 2 * i + 1; if (c >= n_u) break; if (c + 1 < n_u && CLT(T[c], T[c + 1])) ++c; if (!CLT(t, T[c])) break; T[i] = T[c]; i = c; } T[i] = t; }
+				for (int32_t e = n_u - 1; e > 0; --e) { int32_t t = T[e]; T[e] = T[0]; int32_t i = 0; for (;;) { int32_t c = 2 * i + 1; if (c >= e) break; if (c + 1 < e && CLT(T[c], T[c + 1])) ++c; if (!CLT(t, T[c])) break; T[i] = T[c]; i = c; } T[i] = t; }
+				for (int32_t i = 1; i < n_u; ++i) if (CX(T[i]) == CX(T[i - 1])) tie = true;
+#undef CLT
+#undef CX
+			}
+			if (tie) atomicAdd(&counters[1], 1ULL);
+			int32_t o = 0;
+			for (int32_t i = 0; i < n_u; ++i) {
+				const int32_t c = T[i], ni = (int32_t)(uint32_t)utmp[c], k0 = Pp[c];
+				u[i] = utmp[c];
+				for (int32_t j = 0; j < ni; ++j) b[o++] = a[V[k0 + (ni - j - 1)]];
+			}
+		}
+		frag_nu[f] = (uint32_t)n_u;
+	}
+#undef AX
+#undef AQ
+#undef AM
+}
+
+// explicit instantiations used by the runtime
+template __global__ void k_anchor_sort<1024>(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, AlAnchor *, const uint32_t *, int, unsigned long long *, int);
+template __global__ void k_chain<768>(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, AlAnchor *, uint64_t *, uint32_t *, int32_t *, uint64_t *, const uint32_t *, int, AlParams, unsigned long long *);
+
+// rechain decision (map.c:353-375): one lane per fragment; appends fragments that must be re-seeded with max_occ
+extern "C" __global__ void __launch_bounds__(256)
+k_rechain_test(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__ a_off, const uint64_t *__restrict__ u_all,
+               const uint32_t *__restrict__ frag_nu, const int32_t *__restrict__ frag_rep, const uint32_t *__restrict__ frag_first,
+               int n_frag, uint32_t *__restrict__ list, uint32_t *__restrict__ n_list)
+{
+	const int f = blockIdx.x * blockDim.x + threadIdx.x;
+	if (f >= n_frag) return;
+	if (frag_rep[f] <= 0) return;
+	const int n_segs = (int)(frag_first[f + 1] - frag_first[f]);
+	const uint32_t n_u = frag_nu[f];
+	int rechain = 0;
+	if (n_u > 0) {
+		const uint64_t *u = u_all + a_off[f] + f; const AlAnchor *a = chained + a_off[f];
+		int n_chained_segs = 1, max = 0, max_i = -1, max_off = -1, off = 0;
+		for (uint32_t i = 0; i < n_u; ++i) { if (max < (int)(u[i] >> 32)) max = (int)(u[i] >> 32), max_i = (int)i, max_off = off; off += (int)(uint32_t)u[i]; }
+		if (max_i >= 0) {
+			for (int i = 1; i < (int32_t)(uint32_t)u[max_i]; ++i)
+				if ((a[max_off + i].y & AL_SEED_SEG_MASK) != (a[max_off + i - 1].y & AL_SEED_SEG_MASK)) ++n_chained_segs;
+			if (n_chained_segs < n_segs) rechain = 1;
+		}
+	} else rechain = 1;
+	if (rechain) list[atomicAdd(n_list, 1u)] = (uint32_t)f;
+}

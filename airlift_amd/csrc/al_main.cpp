@@ -1,0 +1,73 @@
+// airlift-align -- drop-in command line for the aligner invocations in AirLift's stage scripts.
+//
+// Accepted argv shapes:
+//   B1/B2  airlift-align mem [-R RG] [-t N] REF.fa R_1.fastq [R_2.fastq]        (src/0-align_reads.sh:13, 0-align_singletons.sh:12)
+//   B3     airlift-align aln [-n X] [-t N] REF.fa GAPS.fa > X.sai               (src/3-align_gaps/align_gaps.sh:14; writes a stub .sai)
+//          airlift-align samse REF.fa X.sai GAPS.fa                              (align_gaps.sh:15; does the actual single-end mapping)
+//   mm2    airlift-align -ax sr [-t N] [-R RG] [-K NUM] [--sam-hit-only] REF.fa R1 [R2]   (fork README usage; main.c:113-273)
+// SAM goes to stdout; exit status 0 on success, non-zero on failure (so the caller's pipe fails).
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include "../../include/airlift.h"
+
+static int usage()
+{
+	fprintf(stderr, "Usage: airlift-align mem [-R RG] [-t N] ref.fa reads_1.fq [reads_2.fq]\n"
+	                "       airlift-align aln [-n X] [-t N] ref.fa reads.fa > x.sai ; airlift-align samse ref.fa x.sai reads.fa\n"
+	                "       airlift-align -ax sr [-t N] [-R RG] ref.fa reads_1.fq [reads_2.fq]\n");
+	return 1;
+}
+
+int main(int argc, char **argv)
+{
+	al_idxopt_t io; al_mapopt_t mo;
+	std::vector<const char *> pos; const char *rg = nullptr; int n_threads = 3, device = -1;
+	enum { MODE_MEM, MODE_ALN, MODE_SAMSE, MODE_MM2 } mode = MODE_MM2;
+	int i = 1;
+	if (argc < 2) return usage();
+	al_set_opt(0, &io, &mo);
+	al_set_opt("sr", &io, &mo);
+	mo.flag |= AL_F_OUT_SAM | AL_F_CIGAR;
+	if (!strcmp(argv[1], "mem")) mode = MODE_MEM, i = 2;
+	else if (!strcmp(argv[1], "aln")) mode = MODE_ALN, i = 2;
+	else if (!strcmp(argv[1], "samse")) mode = MODE_SAMSE, i = 2;
+	for (; i < argc; ++i) {
+		const char *a = argv[i];
+		if (a[0] != '-' || !strcmp(a, "-")) { pos.push_back(a); continue; }
+		if (!strcmp(a, "-R") && i + 1 < argc) rg = argv[++i];
+		else if (!strcmp(a, "-t") && i + 1 < argc) n_threads = atoi(argv[++i]);
+		else if (!strcmp(a, "-x") && i + 1 < argc) { if (al_set_opt(argv[++i], &io, &mo) < 0) { fprintf(stderr, "[ERROR] unknown preset '%s'\n", argv[i]); return 1; } }
+		else if (!strcmp(a, "-ax") && i + 1 < argc) { if (al_set_opt(argv[++i], &io, &mo) < 0) { fprintf(stderr, "[ERROR] unknown preset '%s'\n", argv[i]); return 1; } }
+		else if (!strcmp(a, "-a")) mo.flag |= AL_F_OUT_SAM | AL_F_CIGAR;
+		else if (!strcmp(a, "-k") && i + 1 < argc) io.k = atoi(argv[++i]);
+		else if (!strcmp(a, "-w") && i + 1 < argc) io.w = atoi(argv[++i]);
+		else if (!strcmp(a, "-K") && i + 1 < argc) mo.mini_batch_size = (int)atof(argv[++i]);
+		else if (!strcmp(a, "-n") && i + 1 < argc) ++i;                       // bwa aln -n: accepted, no analogue
+		else if (!strcmp(a, "--sam-hit-only")) mo.flag |= AL_F_SAM_HIT_ONLY;
+		else if (!strcmp(a, "--device") && i + 1 < argc) device = atoi(argv[++i]);
+		else if (!strcmp(a, "--version")) { puts(al_version()); return 0; }
+		else { fprintf(stderr, "[WARNING] airlift-align: option '%s' ignored\n", a); }
+	}
+	if (al_check_opt(&io, &mo) < 0) return 1;
+	const char *ref = nullptr; std::vector<const char *> reads;
+	if (mode == MODE_ALN) {          // the real work happens in samse; emit a small marker so `> x.sai` is non-empty
+		if (pos.size() < 2) return usage();
+		fputs("AIRLIFT-SAI-STUB\n", stdout);
+		return 0;
+	} else if (mode == MODE_SAMSE) {
+		if (pos.size() < 3) return usage();
+		ref = pos[0]; reads.push_back(pos[2]);
+	} else {
+		if (pos.size() < 2 || pos.size() > 3) return usage();
+		ref = pos[0]; for (size_t j = 1; j < pos.size(); ++j) reads.push_back(pos[j]);
+	}
+	al_idx_t *mi = al_idx_build(ref, &io, n_threads);
+	if (!mi) { fprintf(stderr, "[ERROR] failed to open file '%s'\n", ref); return 1; }
+	int rc = al_map_file_frag(mi, (int)reads.size(), reads.data(), &mo, n_threads, stdout, rg, device);
+	al_idx_destroy(mi);
+	if (fflush(stdout) == EOF) { perror("[ERROR] failed to write the results"); return 1; }
+	return rc == 0 ? 0 : 1;
+}

@@ -1,0 +1,62 @@
+// al_runtime.h -- per-context device state of the re-alignment pipeline (product code)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <vector>
+#include <string>
+#include "al_internal.h"
+
+template <typename T> struct DevBuf {
+	T *p = nullptr; size_t cap = 0;
+	int ensure(size_t n, bool keep = false, hipStream_t s = 0);
+	void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct AlRegOut {            // per-read result header copied back to the host
+	uint32_t n_regs, reg_off;   // reg_off: index into the AlReg output array
+};
+
+struct al_ctx_s {
+	const al_idx_t *mi = nullptr;
+	al_mapopt_t opt;
+	AlParams P;
+	int device = 0;
+	hipStream_t stream = nullptr;
+	AlDevIndex di;
+	hipEvent_t ev[ST_N + 1] = {};
+	float ms_stage[ST_N] = {};
+	float ms_total = 0;
+
+	// resident batch (host mirrors kept for fetch / taps)
+	int n_frag = 0, n_reads = 0;
+	uint64_t n_bases = 0, mini_total = 0, seq_words = 0;
+	std::vector<uint32_t> h_rd_len, h_frag_first, h_frag_hash;
+	std::vector<uint64_t> h_rd_off, h_mini_off;
+	std::vector<uint32_t> h_rd_seq;
+	std::vector<uint8_t> h_flip;          // read was reverse-complemented for mapping (worker_for, map.c:468)
+
+	DevBuf<uint32_t> rd_seq, rd_len, frag_first, frag_hash, mini_cnt, frag_nm, frag_na, frag_nu, rechain_list, tmp_u32;
+	DevBuf<uint64_t> rd_off, mini_off, a_off, u, ws_u64, tmp_u64;
+	DevBuf<int32_t> frag_rep, ws_i32;
+	DevBuf<AlAnchor> mini, heap_ws, anchors, chained;
+	DevBuf<AlMatch> match;
+	DevBuf<unsigned long long> counters;   // [0] heap fallbacks, [1] sort-tie flags, [2] alser total, [3] n_rechain, [4..] stage specific
+	DevBuf<uint8_t> scan_tmp;
+	DevBuf<uint64_t> a_off_p1; DevBuf<uint32_t> frag_na_p1; DevBuf<int32_t> frag_rep_p1;   // pass-1 snapshots when a re-chain pass ran (taps)
+	uint64_t n_anchor_total = 0, n_anchor_pass1 = 0;
+	uint32_t n_rechain = 0;
+
+	// alignment stage (al_kernels_align.hip)
+	DevBuf<AlReg> regs0, regs;             // fragment-level chains -> per-mate regions
+	DevBuf<uint32_t> reg_cnt, cigar;
+	DevBuf<uint64_t> reg_off, cig_off;
+	DevBuf<uint8_t> align_ws;
+	DevBuf<AlAnchor> seg_a;
+	DevBuf<uint64_t> seg_u;
+	uint64_t n_regs_cap_total = 0, n_cigar_cap_total = 0;
+	bool ran = false;
+	al_batch_stat_t stat;
+};
+
+int al_upload_index(const al_idx_t *mi, int device, AlDevIndex *out);
+int al_run_align_stage(al_ctx_t *c);      // al_kernels_align.hip: KA (regs) + K5 (extension, MAPQ, pairing)
+int al_fetch_align(al_ctx_t *c, int *n_regs, al_reg1_t **regs, int *rep_len);

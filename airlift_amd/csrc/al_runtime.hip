@@ -1,0 +1,386 @@
+// al_runtime.hip -- host driver of the device pipeline: index upload, batch packing, stage launches
+// on one HIP stream with per-stage events, and the stage taps used by the parity tests.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include "al_internal.h"
+#include "al_device.h"
+#include "al_runtime.h"
+#include "al_io.h"
+
+// kernels (al_kernels_seed.hip)
+extern "C" __global__ void k_sketch(const uint32_t *, const uint64_t *, const uint32_t *, const uint64_t *, AlAnchor *, uint32_t *, int, int, int);
+extern "C" __global__ void k_seed(const uint64_t *, int, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, const uint32_t *, AlMatch *, uint32_t *, uint32_t *, int32_t *, const uint32_t *, int, int);
+extern "C" __global__ void k_alser_count(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, int, int, unsigned long long *);
+extern "C" __global__ void k_rechain_test(const AlAnchor *, const uint64_t *, const uint64_t *, const uint32_t *, const int32_t *, const uint32_t *, int, uint32_t *, uint32_t *);
+template <int CAP> __global__ void k_anchor_sort(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, AlAnchor *, const uint32_t *, int, unsigned long long *, int);
+template <int CAP> __global__ void k_chain(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, AlAnchor *, uint64_t *, uint32_t *, int32_t *, uint64_t *, const uint32_t *, int, AlParams, unsigned long long *);
+
+template <typename T> int DevBuf<T>::ensure(size_t n, bool keep, hipStream_t s)
+{
+	if (n <= cap) return 0;
+	size_t ncap = n + n / 4 + 64;
+	T *np = nullptr;
+	AL_HIP_CHECK(hipMalloc((void **)&np, ncap * sizeof(T)));
+	if (keep && p && cap) { AL_HIP_CHECK(hipMemcpyAsync(np, p, cap * sizeof(T), hipMemcpyDeviceToDevice, s)); AL_HIP_CHECK(hipStreamSynchronize(s)); }
+	if (p) (void)hipFree(p);
+	p = np; cap = ncap;
+	return 0;
+}
+template struct DevBuf<uint32_t>; template struct DevBuf<uint64_t>; template struct DevBuf<int32_t>; template struct DevBuf<AlAnchor>;
+template struct DevBuf<AlMatch>; template struct DevBuf<unsigned long long>; template struct DevBuf<uint8_t>; template struct DevBuf<AlReg>;
+
+static const char *g_stage_names[ST_N] = { "sketch", "seed_lookup", "scan", "anchor_sort", "chain", "rechain", "regs", "align" };
+extern "C" const char *al_stage_name(int i) { return i >= 0 && i < ST_N ? g_stage_names[i] : ""; }
+
+// ---------------------------------------------------------------------------------------------
+int al_upload_index(const al_idx_t *mi, int device, AlDevIndex *out)
+{
+	std::lock_guard<std::mutex> lk(mi->dev_mtx);
+	auto it = mi->dev.find(device);
+	if (it != mi->dev.end()) { *out = it->second; return 0; }
+	AlDevIndex d;
+	AL_HIP_CHECK(hipSetDevice(device));
+	AL_HIP_CHECK(hipMalloc((void **)&d.S4, mi->S4.size() * 4));
+	AL_HIP_CHECK(hipMemcpy(d.S4, mi->S4.data(), mi->S4.size() * 4, hipMemcpyHostToDevice));
+	AL_HIP_CHECK(hipMalloc((void **)&d.tab, mi->tab.size() * 8));
+	AL_HIP_CHECK(hipMemcpy(d.tab, mi->tab.data(), mi->tab.size() * 8, hipMemcpyHostToDevice));
+	AL_HIP_CHECK(hipMalloc((void **)&d.pos, mi->pos.size() * 8));
+	AL_HIP_CHECK(hipMemcpy(d.pos, mi->pos.data(), mi->pos.size() * 8, hipMemcpyHostToDevice));
+	std::vector<uint64_t> so(mi->seq.size()); std::vector<uint32_t> sl(mi->seq.size());
+	for (size_t i = 0; i < mi->seq.size(); ++i) so[i] = mi->seq[i].offset, sl[i] = mi->seq[i].len;
+	AL_HIP_CHECK(hipMalloc((void **)&d.seq_off, so.size() * 8));
+	AL_HIP_CHECK(hipMemcpy(d.seq_off, so.data(), so.size() * 8, hipMemcpyHostToDevice));
+	AL_HIP_CHECK(hipMalloc((void **)&d.seq_len, sl.size() * 4));
+	AL_HIP_CHECK(hipMemcpy(d.seq_len, sl.data(), sl.size() * 4, hipMemcpyHostToDevice));
+	d.tab_bits = mi->tab_bits; d.n_seq = (uint32_t)mi->seq.size();
+	mi->dev[device] = d; *out = d;
+	return 0;
+}
+
+void al_idx_free_device(al_idx_t *mi)
+{
+	std::lock_guard<std::mutex> lk(mi->dev_mtx);
+	for (auto &kv : mi->dev) {
+		if (hipSetDevice(kv.first) != hipSuccess) continue;
+		(void)hipFree(kv.second.S4); (void)hipFree(kv.second.tab); (void)hipFree(kv.second.pos); (void)hipFree(kv.second.seq_off); (void)hipFree(kv.second.seq_len);
+	}
+	mi->dev.clear();
+}
+
+extern "C" al_ctx_t *al_ctx_init(const al_idx_t *mi, const al_mapopt_t *opt, int device)
+{
+	int n_dev = 0;
+	if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) {
+		fprintf(stderr, "[airlift] FATAL: no HIP device available -- this library has no CPU path\n");
+		return nullptr;
+	}
+	if (device < 0) { const char *lr = getenv("LOCAL_RANK"); device = lr ? atoi(lr) % n_dev : 0; }
+	if (device >= n_dev) { fprintf(stderr, "[airlift] FATAL: device %d out of range (%d devices)\n", device, n_dev); return nullptr; }
+	if (mi->w > 32 || mi->k > 28) { fprintf(stderr, "[airlift] FATAL: device sketch supports w <= 32, k <= 28\n"); return nullptr; }
+	al_ctx_t *c = new al_ctx_t();
+	c->mi = mi; c->opt = *opt; c->device = device;
+	if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return nullptr; }
+	for (int i = 0; i <= ST_N; ++i) if (hipEventCreate(&c->ev[i]) != hipSuccess) { delete c; return nullptr; }
+	if (al_upload_index(mi, device, &c->di) != 0) { delete c; return nullptr; }
+	AlParams &P = c->P;
+	P.k = mi->k; P.w = mi->w; P.seed = opt->seed; P.bw = opt->bw; P.max_gap = opt->max_gap; P.max_gap_ref = opt->max_gap_ref; P.max_frag_len = opt->max_frag_len;
+	P.max_chain_skip = opt->max_chain_skip; P.max_chain_iter = opt->max_chain_iter; P.min_cnt = opt->min_cnt; P.min_chain_score = opt->min_chain_score;
+	P.mask_level = opt->mask_level; P.pri_ratio = opt->pri_ratio; P.max_clip_ratio = opt->max_clip_ratio; P.best_n = opt->best_n;
+	P.a = opt->a; P.b = opt->b; P.q = opt->q; P.e = opt->e; P.q2 = opt->q2; P.e2 = opt->e2; P.sc_ambi = opt->sc_ambi; P.zdrop = opt->zdrop; P.zdrop_inv = opt->zdrop_inv;
+	P.end_bonus = opt->end_bonus; P.min_dp_max = opt->min_dp_max; P.pe_ori = opt->pe_ori; P.pe_bonus = opt->pe_bonus; P.mid_occ = opt->mid_occ; P.max_occ = opt->max_occ;
+	memset(&c->stat, 0, sizeof(c->stat));
+	return c;
+}
+
+extern "C" void al_ctx_destroy(al_ctx_t *c)
+{
+	if (!c) return;
+	(void)hipSetDevice(c->device);
+	if (c->stream) (void)hipStreamSynchronize(c->stream);
+	c->rd_seq.release(); c->rd_len.release(); c->frag_first.release(); c->frag_hash.release(); c->mini_cnt.release(); c->frag_nm.release(); c->frag_na.release();
+	c->frag_nu.release(); c->rechain_list.release(); c->tmp_u32.release(); c->rd_off.release(); c->mini_off.release(); c->a_off.release(); c->u.release();
+	c->ws_u64.release(); c->tmp_u64.release(); c->frag_rep.release(); c->ws_i32.release(); c->mini.release(); c->heap_ws.release(); c->anchors.release();
+	c->chained.release(); c->match.release(); c->counters.release(); c->scan_tmp.release(); c->regs0.release(); c->regs.release(); c->reg_cnt.release();
+	c->a_off_p1.release(); c->frag_na_p1.release(); c->frag_rep_p1.release(); c->cigar.release(); c->reg_off.release(); c->cig_off.release(); c->align_ws.release(); c->seg_a.release(); c->seg_u.release();
+	for (int i = 0; i <= ST_N; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+	if (c->stream) (void)hipStreamDestroy(c->stream);
+	delete c;
+}
+
+// ---------------------------------------------------------------------------------------------
+// qname hash (map.c:291-293; khash.h:383-409)
+static inline uint32_t wang_hash(uint32_t key)
+{
+	key += ~(key << 15); key ^= (key >> 10); key += (key << 3); key ^= (key >> 6); key += ~(key << 11); key ^= (key >> 16);
+	return key;
+}
+static uint32_t qname_hash(const char *qname, int qlen_sum, int seed)
+{
+	uint32_t h = 0;
+	if (qname) { const char *s = qname; h = (uint32_t)*s; if (h) for (++s; *s; ++s) h = (h << 5) - h + (uint32_t)*s; }
+	h ^= wang_hash((uint32_t)qlen_sum) + wang_hash((uint32_t)seed);
+	return wang_hash(h);
+}
+
+extern "C" int al_batch_upload(al_ctx_t *c, int n_frag, const int *n_segs, const int *qlens, const char *const *seqs, const char *const *qnames)
+{
+	if (!c || n_frag < 0) return -1;
+	AL_HIP_CHECK(hipSetDevice(c->device));
+	const unsigned char *nt4 = al_nt4();
+	int n_reads = 0;
+	for (int f = 0; f < n_frag; ++f) { if (n_segs[f] < 1 || n_segs[f] > 2) { fprintf(stderr, "[airlift] fragments must have 1 or 2 segments\n"); return -2; } n_reads += n_segs[f]; }
+	c->n_frag = n_frag; c->n_reads = n_reads; c->ran = false;
+	c->h_rd_len.resize(n_reads + 1); c->h_rd_off.resize(n_reads + 1); c->h_mini_off.resize(n_reads + 1); c->h_flip.assign(n_reads, 0);
+	c->h_frag_first.resize(n_frag + 1); c->h_frag_hash.resize(n_frag + 1);
+	uint64_t words = 0, mtot = 0, bases = 0; int r = 0;
+	const int k = c->mi->k, pe_ori = c->opt.pe_ori;
+	for (int f = 0; f < n_frag; ++f) {
+		c->h_frag_first[f] = r; int qsum = 0;
+		for (int j = 0; j < n_segs[f]; ++j, ++r) {
+			const int L = qlens[r];
+			c->h_rd_len[r] = L; c->h_rd_off[r] = words; c->h_mini_off[r] = mtot;
+			words += (uint64_t)(L + 7) / 8 + 1; mtot += (uint64_t)(L >= k ? L - k + 1 : 0) + 1; bases += L; qsum += L;
+			if (n_segs[f] == 2 && ((j == 0 && (pe_ori >> 1 & 1)) || (j == 1 && (pe_ori & 1)))) c->h_flip[r] = 1;
+		}
+		c->h_frag_hash[f] = qname_hash(qnames ? qnames[c->h_frag_first[f]] : nullptr, qsum, c->opt.seed);
+	}
+	c->h_frag_first[n_frag] = r; c->h_rd_off[n_reads] = words; c->h_mini_off[n_reads] = mtot; c->h_rd_len[n_reads] = 0;
+	c->n_bases = bases; c->mini_total = mtot; c->seq_words = words;
+	c->h_rd_seq.assign(words + 1, 0);
+	for (int i = 0; i < n_reads; ++i) {     // 4-bit packing in mapping orientation (mate 2 reverse-complemented: map.c:468, bseq.h:46-58)
+		uint32_t *w = c->h_rd_seq.data() + c->h_rd_off[i]; const char *s = seqs[i]; const int L = qlens[i];
+		if (!c->h_flip[i]) for (int j = 0; j < L; ++j) w[j >> 3] |= (uint32_t)nt4[(unsigned char)s[j]] << ((j & 7) << 2);
+		else for (int j = 0; j < L; ++j) { const unsigned cd = nt4[(unsigned char)s[L - 1 - j]]; w[j >> 3] |= (uint32_t)(cd < 4 ? 3 - cd : 4) << ((j & 7) << 2); }
+	}
+	hipStream_t s = c->stream;
+	if (c->rd_seq.ensure(words + 1) || c->rd_off.ensure(n_reads + 1) || c->rd_len.ensure(n_reads + 1) || c->frag_first.ensure(n_frag + 1) || c->frag_hash.ensure(n_frag + 1) ||
+	    c->mini_off.ensure(n_reads + 1) || c->mini.ensure(mtot + 1) || c->mini_cnt.ensure(n_reads + 1) || c->match.ensure(mtot + 1) || c->heap_ws.ensure(mtot + 1) ||
+	    c->frag_nm.ensure(n_frag + 1) || c->frag_na.ensure(n_frag + 1) || c->frag_rep.ensure(n_frag + 1) || c->frag_nu.ensure(n_frag + 1) || c->a_off.ensure(n_frag + 2) ||
+	    c->rechain_list.ensure(n_frag + 1) || c->tmp_u32.ensure(n_frag + 2) || c->tmp_u64.ensure(n_frag + 2) || c->counters.ensure(16)) return -1;
+	AL_HIP_CHECK(hipMemcpyAsync(c->rd_seq.p, c->h_rd_seq.data(), (words + 1) * 4, hipMemcpyHostToDevice, s));
+	AL_HIP_CHECK(hipMemcpyAsync(c->rd_off.p, c->h_rd_off.data(), (n_reads + 1) * 8, hipMemcpyHostToDevice, s));
+	AL_HIP_CHECK(hipMemcpyAsync(c->rd_len.p, c->h_rd_len.data(), (n_reads + 1) * 4, hipMemcpyHostToDevice, s));
+	AL_HIP_CHECK(hipMemcpyAsync(c->frag_first.p, c->h_frag_first.data(), (n_frag + 1) * 4, hipMemcpyHostToDevice, s));
+	AL_HIP_CHECK(hipMemcpyAsync(c->frag_hash.p, c->h_frag_hash.data(), (n_frag + 1) * 4, hipMemcpyHostToDevice, s));
+	AL_HIP_CHECK(hipMemcpyAsync(c->mini_off.p, c->h_mini_off.data(), (n_reads + 1) * 8, hipMemcpyHostToDevice, s));
+	AL_HIP_CHECK(hipStreamSynchronize(s));
+	return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+struct CastU64 { __host__ __device__ uint64_t operator()(const uint32_t &v) const { return (uint64_t)v; } };
+
+static int scan_u32_to_u64(al_ctx_t *c, const uint32_t *in, uint64_t *out, int n)
+{   // out[0..n] = exclusive prefix sums (n+1 entries; in[n] must be readable: callers pad with 0)
+	hipcub::TransformInputIterator<uint64_t, CastU64, const uint32_t *> it(in, CastU64());
+	size_t bytes = 0;
+	AL_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, it, out, n + 1, c->stream));
+	if (c->scan_tmp.ensure(bytes + 16)) return -1;
+	AL_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(c->scan_tmp.p, bytes, it, out, n + 1, c->stream));
+	return 0;
+}
+
+__global__ void k_gather_na(const uint32_t *frag_na, const uint32_t *list, int n, uint32_t *out)
+{
+	int t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t < n) out[t] = frag_na[list[t]]; else if (t == n) out[t] = 0;
+}
+__global__ void k_scatter_off(const uint64_t *off, const uint32_t *list, int n, uint64_t base, uint64_t *a_off)
+{
+	int t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t < n) a_off[list[t]] = base + off[t];
+}
+
+static int ensure_anchor_space(al_ctx_t *c, uint64_t total, bool keep)
+{
+	const uint64_t nf = c->n_frag;
+	if (c->anchors.ensure(total + 1, keep, c->stream) || c->chained.ensure(total + 1, keep, c->stream) || c->u.ensure(total + nf + 2, keep, c->stream) ||
+	    c->ws_i32.ensure(total * 4 + 4, false, c->stream) || c->ws_u64.ensure(total + 1, false, c->stream)) return -1;
+	return 0;
+}
+
+static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max_occ, uint64_t base_off, bool first)
+{
+	hipStream_t s = c->stream;
+	const int nl = n_list;
+	if (nl == 0) return 0;
+	hipLaunchKernelGGL(k_seed, dim3((nl + 255) / 256), dim3(256), 0, s, c->di.tab, c->di.tab_bits, c->frag_first.p, c->rd_len.p, c->mini_off.p, c->mini.p, c->mini_cnt.p,
+	                   c->match.p, c->frag_nm.p, c->frag_na.p, c->frag_rep.p, list, nl, max_occ);
+	if (first) AL_HIP_CHECK(hipEventRecord(c->ev[ST_SEED + 1], s));
+	uint64_t total = 0;
+	if (first) {
+		AL_HIP_CHECK(hipMemsetAsync(c->frag_na.p + c->n_frag, 0, 4, s));
+		if (scan_u32_to_u64(c, c->frag_na.p, c->a_off.p, c->n_frag)) return -1;
+		AL_HIP_CHECK(hipMemcpyAsync(&total, c->a_off.p + c->n_frag, 8, hipMemcpyDeviceToHost, s));
+		AL_HIP_CHECK(hipStreamSynchronize(s));
+		c->n_anchor_pass1 = total; c->n_anchor_total = total;
+		if (ensure_anchor_space(c, total, false)) return -1;
+		AL_HIP_CHECK(hipEventRecord(c->ev[ST_SCAN + 1], s));
+	} else {
+		hipLaunchKernelGGL(k_gather_na, dim3((nl + 256) / 256), dim3(256), 0, s, c->frag_na.p, list, nl, c->tmp_u32.p);
+		if (scan_u32_to_u64(c, c->tmp_u32.p, c->tmp_u64.p, nl)) return -1;
+		AL_HIP_CHECK(hipMemcpyAsync(&total, c->tmp_u64.p + nl, 8, hipMemcpyDeviceToHost, s));
+		AL_HIP_CHECK(hipStreamSynchronize(s));
+		if (ensure_anchor_space(c, base_off + total, true)) return -1;
+		hipLaunchKernelGGL(k_scatter_off, dim3((nl + 255) / 256), dim3(256), 0, s, c->tmp_u64.p, list, nl, base_off, c->a_off.p);
+		c->n_anchor_total = base_off + total;
+	}
+	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_anchor_sort<1024>), dim3(nl), dim3(64), 0, s, c->di.pos, c->frag_first.p, c->rd_len.p, c->mini_off.p, c->match.p, c->frag_nm.p, c->frag_na.p,
+	                   c->a_off.p, c->anchors.p, c->heap_ws.p, list, nl, c->counters.p, c->mi->k);
+	if (first) AL_HIP_CHECK(hipEventRecord(c->ev[ST_ANCHOR_SORT + 1], s));
+	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<768>), dim3(nl), dim3(64), 0, s, c->anchors.p, c->a_off.p, c->frag_na.p, c->frag_first.p, c->rd_len.p, c->chained.p, c->u.p, c->frag_nu.p,
+	                   c->ws_i32.p, c->ws_u64.p, list, nl, c->P, c->counters.p);
+	if (first) AL_HIP_CHECK(hipEventRecord(c->ev[ST_CHAIN + 1], s));
+	AL_HIP_CHECK(hipGetLastError());
+	return 0;
+}
+
+int al_run_seed_stages(al_ctx_t *c)
+{
+	hipStream_t s = c->stream;
+	AL_HIP_CHECK(hipSetDevice(c->device));
+	AL_HIP_CHECK(hipMemsetAsync(c->counters.p, 0, 16 * sizeof(unsigned long long), s));
+	AL_HIP_CHECK(hipEventRecord(c->ev[0], s));
+	const int nr = c->n_reads, w = c->mi->w, k = c->mi->k;
+	if (nr > 0) hipLaunchKernelGGL(k_sketch, dim3((nr + 63) / 64), dim3(64), (size_t)w * 64 * 16, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, c->mini_off.p, c->mini.p, c->mini_cnt.p, nr, w, k);
+	AL_HIP_CHECK(hipEventRecord(c->ev[ST_SKETCH + 1], s));
+	if (c->n_frag == 0) { for (int i = ST_SEED; i < ST_N; ++i) AL_HIP_CHECK(hipEventRecord(c->ev[i + 1], s)); return 0; }
+	if (run_seed_chain(c, nullptr, c->n_frag, c->opt.mid_occ, 0, true)) return -1;
+	// re-chain with max_occ for fragments whose best chain misses a mate (map.c:353-375)
+	c->n_rechain = 0;
+	if (c->opt.max_occ > c->opt.mid_occ) {
+		uint32_t *cnt = (uint32_t *)(c->counters.p + 3);
+		hipLaunchKernelGGL(k_rechain_test, dim3((c->n_frag + 255) / 256), dim3(256), 0, s, c->chained.p, c->a_off.p, c->u.p, c->frag_nu.p, c->frag_rep.p, c->frag_first.p, c->n_frag, c->rechain_list.p, cnt);
+		uint32_t n = 0;
+		AL_HIP_CHECK(hipMemcpyAsync(&n, cnt, 4, hipMemcpyDeviceToHost, s));
+		AL_HIP_CHECK(hipStreamSynchronize(s));
+		c->n_rechain = n;
+		if (n > 0) {
+			if (c->a_off_p1.ensure(c->n_frag + 2) || c->frag_na_p1.ensure(c->n_frag + 1) || c->frag_rep_p1.ensure(c->n_frag + 1)) return -1;
+			AL_HIP_CHECK(hipMemcpyAsync(c->a_off_p1.p, c->a_off.p, (size_t)(c->n_frag + 1) * 8, hipMemcpyDeviceToDevice, s));
+			AL_HIP_CHECK(hipMemcpyAsync(c->frag_na_p1.p, c->frag_na.p, (size_t)c->n_frag * 4, hipMemcpyDeviceToDevice, s));
+			AL_HIP_CHECK(hipMemcpyAsync(c->frag_rep_p1.p, c->frag_rep.p, (size_t)c->n_frag * 4, hipMemcpyDeviceToDevice, s));
+			// deterministic order (atomic append order is arbitrary; offsets depend on it only for layout, results do not)
+			if (run_seed_chain(c, c->rechain_list.p, (int)n, c->opt.max_occ, c->n_anchor_pass1, false)) return -1;
+		}
+	}
+	AL_HIP_CHECK(hipEventRecord(c->ev[ST_RECHAIN + 1], s));
+	return 0;
+}
+
+extern "C" int al_batch_run(al_ctx_t *c)
+{
+	if (!c) return -1;
+	if (al_run_seed_stages(c)) return -1;
+	if (al_run_align_stage(c)) return -1;
+	AL_HIP_CHECK(hipEventRecord(c->ev[ST_ALIGN + 1], c->stream));
+	AL_HIP_CHECK(hipStreamSynchronize(c->stream));
+	for (int i = 0; i < ST_N; ++i) { float ms = 0; if (hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]) != hipSuccess) ms = 0; c->ms_stage[i] = ms; }
+	float tot = 0; (void)hipEventElapsedTime(&tot, c->ev[0], c->ev[ST_N]); c->ms_total = tot;
+	c->ran = true;
+	// counters + algorithmic bytes
+	unsigned long long h[16]; AL_HIP_CHECK(hipMemcpy(h, c->counters.p, sizeof(h), hipMemcpyDeviceToHost));
+	std::vector<uint32_t> mc(c->n_reads), nu(c->n_frag);
+	if (c->n_reads) AL_HIP_CHECK(hipMemcpy(mc.data(), c->mini_cnt.p, (size_t)c->n_reads * 4, hipMemcpyDeviceToHost));
+	if (c->n_frag) AL_HIP_CHECK(hipMemcpy(nu.data(), c->frag_nu.p, (size_t)c->n_frag * 4, hipMemcpyDeviceToHost));
+	al_batch_stat_t &st = c->stat; memset(&st, 0, sizeof(st));
+	st.n_frag = c->n_frag; st.n_reads = c->n_reads; st.n_bases = c->n_bases;
+	for (auto v : mc) st.n_mini += v;
+	for (auto v : nu) st.n_chain += v;
+	st.n_anchor = c->n_anchor_total; st.n_rechain = c->n_rechain; st.n_heap_fallback = h[0]; st.n_sort_tie_flag = h[1];
+	st.n_regs_aln = h[4]; st.n_refbases = h[5]; st.n_cigar = h[6];
+	double b_in = 0; for (int i = 0; i < c->n_reads; ++i) b_in += (c->h_rd_len[i] * 3 + 7) / 8;
+	st.bytes_in = (uint64_t)b_in; st.bytes_out = 48 * st.n_regs_aln + 4 * st.n_cigar;
+	st.algorithmic_bytes = b_in + 16.0 * st.n_mini + 8.0 * st.n_anchor + 32.0 * st.n_anchor + 0.5 * st.n_refbases + (double)st.bytes_out;
+	st.ms_total = c->ms_total; st.n_stage = ST_N;
+	for (int i = 0; i < ST_N; ++i) st.ms_kernel[i] = c->ms_stage[i];
+	return 0;
+}
+
+extern "C" void al_batch_stat(const al_ctx_t *c, al_batch_stat_t *st) { *st = c->stat; }
+
+// ---------------------------------------------------------------------------------------------
+// stage taps
+extern "C" int al_dbg_minimizers(al_ctx_t *c, int r, uint64_t *xy, int cap)
+{
+	if (!c || r < 0 || r >= c->n_reads) return -1;
+	uint32_t n = 0;
+	AL_HIP_CHECK(hipSetDevice(c->device));
+	AL_HIP_CHECK(hipMemcpy(&n, c->mini_cnt.p + r, 4, hipMemcpyDeviceToHost));
+	int m = (int)n < cap ? (int)n : cap;
+	if (m > 0) AL_HIP_CHECK(hipMemcpy(xy, c->mini.p + c->h_mini_off[r], (size_t)m * 16, hipMemcpyDeviceToHost));
+	return (int)n;
+}
+
+extern "C" int al_dbg_anchors(al_ctx_t *c, int f, uint64_t *xy, int cap, int *rep_len)
+{
+	if (!c || f < 0 || f >= c->n_frag) return -1;
+	uint32_t n = 0; uint64_t off = 0; int32_t rep = 0;
+	AL_HIP_CHECK(hipSetDevice(c->device));
+	const bool p1 = c->n_rechain > 0;   // "SD"/"RS" taps are printed before the re-chain pass (map.c:333-338)
+	AL_HIP_CHECK(hipMemcpy(&n, (p1 ? c->frag_na_p1.p : c->frag_na.p) + f, 4, hipMemcpyDeviceToHost));
+	AL_HIP_CHECK(hipMemcpy(&off, (p1 ? c->a_off_p1.p : c->a_off.p) + f, 8, hipMemcpyDeviceToHost));
+	AL_HIP_CHECK(hipMemcpy(&rep, (p1 ? c->frag_rep_p1.p : c->frag_rep.p) + f, 4, hipMemcpyDeviceToHost));
+	if (rep_len) *rep_len = rep;
+	int m = (int)n < cap ? (int)n : cap;
+	if (m > 0) AL_HIP_CHECK(hipMemcpy(xy, c->anchors.p + off, (size_t)m * 16, hipMemcpyDeviceToHost));
+	return (int)n;
+}
+
+extern "C" int al_dbg_chains(al_ctx_t *c, int f, uint64_t *u, int cap_u, uint64_t *xy, int cap_a)
+{
+	if (!c || f < 0 || f >= c->n_frag) return -1;
+	uint32_t nu = 0; uint64_t off = 0;
+	AL_HIP_CHECK(hipSetDevice(c->device));
+	AL_HIP_CHECK(hipMemcpy(&nu, c->frag_nu.p + f, 4, hipMemcpyDeviceToHost));
+	AL_HIP_CHECK(hipMemcpy(&off, c->a_off.p + f, 8, hipMemcpyDeviceToHost));
+	int m = (int)nu < cap_u ? (int)nu : cap_u;
+	if (m > 0) AL_HIP_CHECK(hipMemcpy(u, c->u.p + off + f, (size_t)m * 8, hipMemcpyDeviceToHost));
+	uint64_t na = 0; for (int i = 0; i < m; ++i) na += (uint32_t)u[i];
+	if ((int64_t)na > cap_a) na = cap_a;
+	if (na > 0) AL_HIP_CHECK(hipMemcpy(xy, c->chained.p + off, na * 16, hipMemcpyDeviceToHost));
+	return (int)nu;
+}
+
+extern "C" int al_dbg_alser_count(al_ctx_t *c, int64_t *total)
+{   // expects a resident batch of single-segment fragments on which al_batch_run() has been called
+	if (!c || !c->ran) return -1;
+	AL_HIP_CHECK(hipSetDevice(c->device));
+	AL_HIP_CHECK(hipMemsetAsync(c->counters.p + 2, 0, 8, c->stream));
+	if (c->n_frag) hipLaunchKernelGGL(k_alser_count, dim3((c->n_frag + 255) / 256), dim3(256), 0, c->stream, c->anchors.p, c->n_rechain ? c->a_off_p1.p : c->a_off.p, c->n_rechain ? c->frag_na_p1.p : c->frag_na.p, c->frag_first.p, c->rd_len.p, c->n_frag, c->opt.min_cnt, c->counters.p + 2);
+	unsigned long long v = 0;
+	AL_HIP_CHECK(hipMemcpyAsync(&v, c->counters.p + 2, 8, hipMemcpyDeviceToHost, c->stream));
+	AL_HIP_CHECK(hipStreamSynchronize(c->stream));
+	*total = (int64_t)v;
+	return 0;
+}
+
+// bulk tap: copies a whole named device array to the host (tests); returns bytes copied or -1
+extern "C" int64_t al_dbg_copy(al_ctx_t *c, const char *name, void *dst, int64_t max_bytes)
+{
+	if (!c) return -1;
+	const void *src = nullptr; int64_t bytes = 0; const bool p1 = c->n_rechain > 0;
+	const int64_t nf = c->n_frag, nr = c->n_reads;
+	if (!strcmp(name, "mini")) src = c->mini.p, bytes = (int64_t)c->mini_total * 16;
+	else if (!strcmp(name, "mini_cnt")) src = c->mini_cnt.p, bytes = nr * 4;
+	else if (!strcmp(name, "frag_na")) src = c->frag_na.p, bytes = nf * 4;
+	else if (!strcmp(name, "frag_na_p1")) src = p1 ? c->frag_na_p1.p : c->frag_na.p, bytes = nf * 4;
+	else if (!strcmp(name, "frag_rep")) src = c->frag_rep.p, bytes = nf * 4;
+	else if (!strcmp(name, "frag_rep_p1")) src = p1 ? c->frag_rep_p1.p : c->frag_rep.p, bytes = nf * 4;
+	else if (!strcmp(name, "frag_nu")) src = c->frag_nu.p, bytes = nf * 4;
+	else if (!strcmp(name, "a_off")) src = c->a_off.p, bytes = (nf + 1) * 8;
+	else if (!strcmp(name, "a_off_p1")) src = p1 ? c->a_off_p1.p : c->a_off.p, bytes = (nf + 1) * 8;
+	else if (!strcmp(name, "anchors")) src = c->anchors.p, bytes = (int64_t)c->n_anchor_total * 16;
+	else if (!strcmp(name, "chained")) src = c->chained.p, bytes = (int64_t)c->n_anchor_total * 16;
+	else if (!strcmp(name, "u")) src = c->u.p, bytes = (int64_t)(c->n_anchor_total + nf + 1) * 8;
+	else if (!strcmp(name, "mini_off")) { bytes = (nr + 1) * 8; if (bytes > max_bytes) bytes = max_bytes; memcpy(dst, c->h_mini_off.data(), bytes); return bytes; }
+	else return -1;
+	if (bytes > max_bytes) bytes = max_bytes;
+	if (hipSetDevice(c->device) != hipSuccess) return -1;
+	if (bytes > 0 && hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+	return bytes;
+}

@@ -1,0 +1,167 @@
+/* airlift.h -- C-ABI of the MI355X-native AirLift re-alignment path (libairlift.so).
+ *
+ * Drop-in boundary for the one hot path AirLift delegates to an external aligner:
+ *   src/0-align_reads.sh:13, src/0-align_singletons.sh:12, src/3-align_gaps/align_gaps.sh:14-15
+ * (process level: `airlift-align` CLI), and, at library level, the C API of the bundled
+ * minimap2 fork (src/minimap2-master_remapping/minimap.h) for the `-ax sr` path.  Each entry point
+ * below names the reference declaration it replaces.  Plain pointers and sizes only.
+ *
+ * Ownership / threading rules are the reference's (minimap.h:296-331): the index is immutable and
+ * shareable after build; one al_ctx_t per host thread (it owns a HIP stream and device workspaces);
+ * hit arrays returned by al_map_frag() and each al_reg1_t::cigar are malloc()ed by the callee and
+ * free()d by the caller.  Errors: NULL / negative return, message on stderr; there is NO CPU
+ * fallback -- without a usable HIP device al_ctx_init() fails loudly.
+ */
+#ifndef AIRLIFT_H
+#define AIRLIFT_H
+
+#include <stdint.h>
+#include <stdio.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AL_VERSION "0.1.0"
+
+/* flag bits: same values as MM_F_* (minimap.h:8-38) for the subset this path uses */
+#define AL_F_CIGAR         0x004
+#define AL_F_OUT_SAM       0x008
+#define AL_F_SR            0x1000
+#define AL_F_FRAG_MODE     0x2000
+#define AL_F_NO_PRINT_2ND  0x4000
+#define AL_F_HEAP_SORT     0x400000
+#define AL_F_SAM_HIT_ONLY  0x40000000
+
+/* replaces mm_idxopt_t (minimap.h:101-105) */
+typedef struct {
+	short k, w, flag, bucket_bits;
+	int mini_batch_size;
+	uint64_t batch_size;
+} al_idxopt_t;
+
+/* replaces mm_mapopt_t (minimap.h:107-152); same field names and meaning */
+typedef struct {
+	int64_t flag;
+	int seed;
+	int bw;
+	int max_gap, max_gap_ref;
+	int max_frag_len;
+	int max_chain_skip, max_chain_iter;
+	int min_cnt;
+	int min_chain_score;
+	float mask_level;
+	float pri_ratio;
+	int best_n;
+	int a, b, q, e, q2, e2;
+	int sc_ambi;
+	int zdrop, zdrop_inv;
+	int end_bonus;
+	int min_dp_max;
+	float max_clip_ratio;
+	int pe_ori, pe_bonus;
+	int32_t mid_occ;
+	int32_t max_occ;
+	int mini_batch_size;
+} al_mapopt_t;
+
+/* replaces mm_reg1_t + mm_extra_t (minimap.h:74-98) */
+typedef struct {
+	int32_t id, cnt, rid, score;
+	int32_t qs, qe, rs, re;
+	int32_t parent, subsc;
+	int32_t mlen, blen;
+	int32_t n_sub, score0;
+	uint32_t mapq:8, split:2, rev:1, inv:1, sam_pri:1, proper_frag:1, pe_thru:1, seg_split:1, seg_id:8, split_inv:1, dummy:7;
+	uint32_t hash;
+	int32_t dp_score, dp_max, dp_max2;
+	uint32_t n_ambi;
+	uint32_t n_cigar;
+	uint32_t *cigar;             /* BAM-encoded, malloc()ed; NULL if n_cigar == 0 */
+} al_reg1_t;
+
+typedef struct al_idx_s al_idx_t;   /* replaces mm_idx_t (minimap.h:63-72); opaque, own HBM-oriented layout */
+typedef struct al_ctx_s al_ctx_t;   /* replaces mm_tbuf_t (minimap.h:296-310): per-thread buffer = HIP stream + workspaces */
+
+/* mm_set_opt (minimap.h:180): preset NULL = defaults; "sr"/"short" = AirLift's preset; else -1 */
+int  al_set_opt(const char *preset, al_idxopt_t *io, al_mapopt_t *mo);
+/* mm_check_opt (minimap.h:181): 0 if usable on this path, negative otherwise (message on stderr) */
+int  al_check_opt(const al_idxopt_t *io, const al_mapopt_t *mo);
+
+/* mm_idx_reader_open + mm_idx_reader_read (minimap.h:206-232) for a FASTA(.gz) file: NULL on failure */
+al_idx_t *al_idx_build(const char *fn, const al_idxopt_t *io, int n_threads);
+/* mm_idx_str (minimap.h:269) */
+al_idx_t *al_idx_str(int w, int k, int n, const char **seq, const char **name);
+/* mm_idx_destroy (minimap.h:291) */
+void      al_idx_destroy(al_idx_t *mi);
+uint32_t  al_idx_n_seq(const al_idx_t *mi);
+const char *al_idx_seq_name(const al_idx_t *mi, uint32_t rid);
+uint32_t  al_idx_seq_len(const al_idx_t *mi, uint32_t rid);
+/* mm_idx_stat-like numbers: distinct minimizers, total positions, total bases */
+void      al_idx_stat(const al_idx_t *mi, uint64_t *n_keys, uint64_t *n_pos, uint64_t *n_bases);
+
+/* mm_tbuf_init / mm_tbuf_destroy (minimap.h:303,310).  device < 0: use LOCAL_RANK or 0.
+ * Uploads the index to that device's HBM on first use.  NULL (with a message) if HIP is unusable. */
+al_ctx_t *al_ctx_init(const al_idx_t *mi, const al_mapopt_t *opt, int device);
+void      al_ctx_destroy(al_ctx_t *ctx);
+
+/* mm_map_frag (minimap.h:334): one fragment of n_segs (1 or 2) reads, reads given in sequencing
+ * orientation; output identical in meaning to the reference incl. the FR flip of worker_for (map.c:458-498). */
+void al_map_frag(const al_idx_t *mi, int n_segs, const int *qlens, const char **seqs, int *n_regs,
+                 al_reg1_t **regs, al_ctx_t *ctx, const al_mapopt_t *opt, const char *qname);
+
+/* Batch entry point (no reference analogue; the reference's kt_for over fragments, map.c:592).
+ * reads are listed fragment-major: n_segs[f] reads for fragment f.  On return n_regs[i] / regs[i]
+ * (i over reads) are filled like al_map_frag; rep_len[f] gets the fragment's repeat length.
+ * Returns 0, or negative on error. */
+int  al_map_batch(al_ctx_t *ctx, int n_frag, const int *n_segs, const int *qlens, const char *const *seqs,
+                  const char *const *qnames, int *n_regs, al_reg1_t **regs, int *rep_len);
+
+/* mm_map_file_frag (minimap.h:348): map 1 or 2 FASTA/FASTQ(.gz) files, SAM to `out` (header included
+ * when rg != (char*)-1; pass rg = NULL for no @RG).  Returns 0, -1 if a file cannot be read. */
+int  al_map_file_frag(const al_idx_t *mi, int n_segs, const char **fn, const al_mapopt_t *opt, int n_threads,
+                      FILE *out, const char *rg, int device);
+
+/* ---- device-resident batch API (bench / multi-GPU harness; inputs already in HBM when timing starts) ---- */
+/* Pack + upload a batch; returns 0.  The batch stays resident until the next upload. */
+int  al_batch_upload(al_ctx_t *ctx, int n_frag, const int *n_segs, const int *qlens, const char *const *seqs,
+                     const char *const *qnames);
+/* Run the whole hot path (sketch .. alignment records) on the resident batch; results stay on device. */
+int  al_batch_run(al_ctx_t *ctx);
+/* Fetch results of the last al_batch_run into host reg arrays (same contract as al_map_batch). */
+int  al_batch_fetch(al_ctx_t *ctx, int *n_regs, al_reg1_t **regs, int *rep_len);
+
+/* per-batch work counters + per-kernel HIP-event times of the last al_batch_run */
+typedef struct {
+	uint64_t n_frag, n_reads, n_bases;
+	uint64_t n_mini, n_anchor, n_chain, n_regs_aln, n_refbases, n_cigar, n_rechain, n_heap_fallback, n_sort_tie_flag;
+	uint64_t bytes_in, bytes_out;
+	double   algorithmic_bytes;       /* SURVEY.md §8(d) formula evaluated with the counters above */
+	float    ms_total;                /* HIP events around the whole device pipeline */
+	float    ms_kernel[16];           /* per stage, see al_stage_name() */
+	int      n_stage;
+} al_batch_stat_t;
+void al_batch_stat(const al_ctx_t *ctx, al_batch_stat_t *st);
+const char *al_stage_name(int i);
+
+/* ---- stage taps for parity tests (analogue of --print-seeds, map.c:333-338,381-385) ---- */
+/* minimizers of read i of the resident batch: returns count, writes up to cap records (x = hash<<8|span, y = i<<32|pos<<1|strand) */
+int  al_dbg_minimizers(al_ctx_t *ctx, int read_idx, uint64_t *xy, int cap);
+/* sorted anchors ("SD") and chained anchors ("CN") of fragment f after al_batch_run; x,y interleaved */
+int  al_dbg_anchors(al_ctx_t *ctx, int frag_idx, uint64_t *xy, int cap, int *rep_len);
+int  al_dbg_chains(al_ctx_t *ctx, int frag_idx, uint64_t *u, int cap_u, uint64_t *xy, int cap_a);
+/* a8 ALSER counter (map.c:299-312) for every read of the resident batch mapped as single segments */
+int  al_dbg_alser_count(al_ctx_t *ctx, int64_t *total);
+
+/* SAM text (format.c:116-135, 387-544) */
+int  al_write_sam_hdr(FILE *out, const al_idx_t *mi, const char *rg, char *rg_id_out /* >=256 bytes or NULL */);
+int  al_write_sam(char *buf, size_t cap, const al_idx_t *mi, const char *qname, int l_seq, const char *seq, const char *qual,
+                  int seg_idx, int reg_idx, int n_seg, const int *n_regss, const al_reg1_t *const *regss,
+                  const char *rg_id, int rep_len);
+
+const char *al_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
