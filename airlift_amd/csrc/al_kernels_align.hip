@@ -1,7 +1,886 @@
-// al_kernels_align.hip -- (stub, replaced below) regions + extension stage
+// al_kernels_align.hip -- CDNA4 (gfx950) kernels of the second half of the re-alignment path:
+//   KA k_regs   chains -> hits, primary/secondary selection, per-mate split   (mm_gen_regs hit.c:52, chain_post map.c:249,
+//               one lane per fragment                                           mm_seg_gen hit.c:356, mm_set_parent hit.c:109)
+//   K5 k_align  base-level extension + rescoring + MAPQ + pairing               (mm_align_skeleton align.c:857, mm_align1 align.c:565,
+//               one 16-lane group per fragment, 4 groups per wavefront           ksw_extd2_sse ksw2_extd2_sse.c:26, mm_set_mapq hit.c:446,
+//                                                                                 mm_pair pe.c:76)
+// The SW band state (u,v,x,y,x2,y2,s: the reference's seven int8 vectors) and the exact-score row H live in LDS; a
+// 16-lane group is one SSE vector of the reference, so the anti-diagonal sweep reproduces its 16-cell block geometry,
+// wrapping int8 arithmetic and tie rules bit for bit.  Traceback bytes go to a per-group HBM scratch.
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+#include <stdio.h>
+#include <string.h>
+#include <math.h>
+#include <vector>
 #include "al_internal.h"
 #include "al_device.h"
 #include "al_runtime.h"
-int al_run_align_stage(al_ctx_t *c) { AL_HIP_CHECK(hipEventRecord(c->ev[ST_REGS + 1], c->stream)); return 0; }
-int al_fetch_align(al_ctx_t *c, int *n_regs, al_reg1_t **regs, int *rep_len) { (void)c; (void)n_regs; (void)regs; (void)rep_len; return -1; }
+#include "al_dev_regs.h"
+
+#define GW 16                    // lanes per extension group (= one 128-bit SSE vector of int8)
+#define KSW_NEG_INF -0x40000000
+#define EZ_RIGHT      0x02
+#define EZ_EXTZ_ONLY  0x40
+#define EZ_REV_CIGAR  0x80
+#define GSYNC() __syncthreads()  // blocks are one wavefront: this is a wave-level LDS/HBM fence, safe under group divergence
+
+struct EzD { int max, zdropped, max_q, max_t, mqe, mqe_t, mte, score, n_cigar, reach_end; };
+
+template <int TMAX, int QMAX> struct GroupLds {
+	int8_t u[TMAX], v[TMAX], x[TMAX], y[TMAX], x2[TMAX], y2[TMAX], s[TMAX];
+	int32_t H[TMAX];
+	uint8_t sq[TMAX + QMAX + 48];   // sf[tlen_*16] immediately followed by qr[] (one allocation in the reference: ksw2_extd2_sse.c:99-103)
+	uint8_t tbuf[TMAX + 16];        // target of the current DP job / alignment window
+	uint8_t qbuf[QMAX + 16];        // query of the current DP job
+	uint8_t q0[QMAX + 16], q1[QMAX + 16];   // qseq0[0] (forward) and qseq0[1] (reverse complement), align.c:865-870
+};
+
+struct GroupWs {                    // per-group HBM scratch
+	uint8_t *p;                     // traceback matrix
+	uint32_t *cig;                  // CIGAR of the region under construction
+	uint32_t *ezc;                  // CIGAR returned by the last DP call
+	uint64_t *sc;                   // pair scores (mm_pair), AL_PAIR_SC_CAP entries
+};
+#define AL_PAIR_SC_CAP 4096
+
+__device__ __forceinline__ void d_ez_reset(EzD &ez)
+{   // ksw2.h:153-158
+	ez.max_q = ez.max_t = ez.mqe_t = -1; ez.max = 0; ez.score = ez.mqe = ez.mte = KSW_NEG_INF;
+	ez.n_cigar = 0; ez.zdropped = 0; ez.reach_end = 0;
+}
+
+__device__ __forceinline__ void d_row_bounds(int r, int qlen, int tlen, int w, int &st, int &en)
+{   // ksw2_extd2_sse.c:131-134
+	st = 0; en = tlen - 1;
+	if (st < r - qlen + 1) st = r - qlen + 1;
+	if (en > r) en = r;
+	if (st < (r - w + 1) >> 1) st = (r - w + 1) >> 1;
+	if (en > (r + w) >> 1) en = (r + w) >> 1;
+}
+
+struct CigW { uint32_t *c; int n; };   // cigar writer: every lane of the group holds the same state and stores the same words
+__device__ __forceinline__ void d_push_cigar(CigW &w, uint32_t op, int len)
+{   // ksw2.h:104-114
+	if (w.n == 0 || op != (w.c[w.n - 1] & 0xf)) w.c[w.n++] = (uint32_t)len << 4 | op;
+	else w.c[w.n - 1] += (uint32_t)len << 4;
+}
+
+__device__ void d_backtrack(const uint8_t *p, int n_col, int qlen, int tlen, int w, int is_rev, int i0, int j0, CigW &cw)
+{   // ksw_backtrack, ksw2.h:119-151 (is_rot = 1, min_intron_len = 0); off[]/off_end[] are recomputed from r
+	int i = i0, j = j0, state = 0;
+	cw.n = 0;
+	while (i >= 0 && j >= 0) {
+		int force_state = -1, st, en; const int r = i + j;
+		d_row_bounds(r, qlen, tlen, w, st, en);
+		const int off = st / 16 * 16, off_end = (en + 16) / 16 * 16 - 1;
+		if (i < off) force_state = 2;
+		if (i > off_end) force_state = 1;
+		const uint32_t tmp = force_state < 0 ? p[(size_t)r * n_col + i - off] : 0;
+		if (state == 0) state = tmp & 7;
+		else if (!(tmp >> (state + 2) & 1)) state = 0;
+		if (state == 0) state = tmp & 7;
+		if (force_state >= 0) state = force_state;
+		if (state == 0) { d_push_cigar(cw, 0, 1); --i; --j; }
+		else if (state == 1 || state == 3) { d_push_cigar(cw, 2, 1); --i; }
+		else { d_push_cigar(cw, 1, 1); --j; }
+	}
+	if (i >= 0) d_push_cigar(cw, 2, i + 1);
+	if (j >= 0) d_push_cigar(cw, 1, j + 1);
+	if (!is_rev) for (int k = 0; k < cw.n >> 1; ++k) { uint32_t t = cw.c[k]; cw.c[k] = cw.c[cw.n - 1 - k]; cw.c[cw.n - 1 - k] = t; }
+}
+
+// ksw_extd2_sse (ksw2_extd2_sse.c:26-393) for one 16-lane group.  Inputs: L.qbuf[0..qlen), L.tbuf[0..tlen).
+template <int TMAX, int QMAX>
+__device__ void d_ksw_extd2(GroupLds<TMAX, QMAX> &L, const int gl, const GroupWs &ws, int qlen, int tlen, const AlParams &P,
+                            int w, int zdrop, int end_bonus, int flag, EzD &ez)
+{
+	int q = P.q, e = P.e, q2 = P.q2, e2 = P.e2;
+	d_ez_reset(ez);
+	if (qlen <= 0 || tlen <= 0) return;
+	if (q2 + e2 < q + e) { int t = q; q = q2; q2 = t; t = e; e = e2; e2 = t; }
+	const int qe = q + e;
+	const int8_t qe_ = (int8_t)(q + e), qe2_ = (int8_t)(q2 + e2);
+	const int8_t sc_mch = (int8_t)P.a, sc_mis = (int8_t)(-P.b), sc_amb = (int8_t)(P.sc_ambi > 0 ? -P.sc_ambi : P.sc_ambi);
+	const int8_t sc_N = sc_amb == 0 ? (int8_t)(-e2) : sc_amb;
+	if (w < 0) w = tlen > qlen ? tlen : qlen;
+	const int tlen_ = (tlen + 15) / 16;
+	int n_col_ = qlen < tlen ? qlen : tlen;
+	n_col_ = ((n_col_ < w + 1 ? n_col_ : w + 1) + 15) / 16 + 1;
+	const int qlen_ = (qlen + 15) / 16;
+	{ int min_sc = sc_mis < sc_amb ? sc_mis : sc_amb; if (-min_sc > 2 * (q + e)) return; }
+	int long_thres = e != e2 ? (q2 - q) / (e - e2) - 1 : 0;
+	if (q2 + e2 + long_thres * e2 > q + e + long_thres * e) ++long_thres;
+	const int long_diff = long_thres * (e - e2) - (q2 - q) - e2;
+	uint8_t *sf = L.sq, *qr = L.sq + tlen_ * 16;
+	// initialise (memset / kcalloc of the reference)
+	for (int t = gl; t < tlen_ * 16; t += GW) {
+		L.u[t] = L.v[t] = L.x[t] = L.y[t] = (int8_t)(-q - e);
+		L.x2[t] = L.y2[t] = (int8_t)(-q2 - e2);
+		L.s[t] = 0; L.H[t] = KSW_NEG_INF;
+		sf[t] = t < tlen ? L.tbuf[t] : 0;
+	}
+	for (int t = gl; t < qlen_ * 16 + 32; t += GW) qr[t] = t < qlen ? L.qbuf[qlen - 1 - t] : 0;
+	GSYNC();
+	const size_t prow = (size_t)n_col_ * 16;
+	int last_st = -1, last_en = -1, r;
+	for (r = 0; r < qlen + tlen - 1; ++r) {
+		int st, en;
+		d_row_bounds(r, qlen, tlen, w, st, en);
+		if (st > en) { ez.zdropped = 1; break; }
+		const int st0 = st, en0 = en;
+		st = st / 16 * 16; en = (en + 16) / 16 * 16 - 1;
+		int8_t x1, x21, v1;
+		if (st > 0) {
+			if (st - 1 >= last_st && st - 1 <= last_en) { x1 = L.x[st - 1]; x21 = L.x2[st - 1]; v1 = L.v[st - 1]; }
+			else { x1 = (int8_t)(-q - e); x21 = (int8_t)(-q2 - e2); v1 = (int8_t)(-q - e); }
+		} else {
+			x1 = (int8_t)(-q - e); x21 = (int8_t)(-q2 - e2);
+			v1 = r == 0 ? (int8_t)(-q - e) : r < long_thres ? (int8_t)(-e) : r == long_thres ? (int8_t)long_diff : (int8_t)(-e2);
+		}
+		if (en >= r) {
+			L.y[r] = (int8_t)(-q - e); L.y2[r] = (int8_t)(-q2 - e2);
+			L.u[r] = r == 0 ? (int8_t)(-q - e) : r < long_thres ? (int8_t)(-e) : r == long_thres ? (int8_t)long_diff : (int8_t)(-e2);
+		}
+		const uint8_t *qrr = qr + (qlen - 1 - r);
+		for (int t = st0; t <= en0; t += 16) {                               // :158-176
+			const uint8_t sq = sf[t + gl], sq2 = qrr[t + gl];
+			int8_t sc = sq == sq2 ? sc_mch : sc_mis;
+			if (sq == 4 || sq2 == 4) sc = sc_N;
+			if (t + gl < tlen_ * 16) L.s[t + gl] = sc;    // the reference's 16-byte store may spill past s[] into bytes it never reads again
+		}
+		GSYNC();
+		uint8_t *pr = ws.p + (size_t)r * prow - st;
+		int xc = x1, x2c = x21, vc = v1;                                      // carries across 16-cell blocks
+		for (int tb = st; tb <= en; tb += 16) {                               // :182-306
+			const int t = tb + gl;
+			int8_t z = L.s[t];
+			const int xo = L.x[t], vo = L.v[t], x2o = L.x2[t];
+			const int8_t ut = L.u[t], yo = L.y[t], y2o = L.y2[t];
+			int xt1 = __shfl_up(xo, 1, GW), vt1 = __shfl_up(vo, 1, GW), x2t1 = __shfl_up(x2o, 1, GW);
+			if (gl == 0) { xt1 = xc; vt1 = vc; x2t1 = x2c; }
+			xc = __shfl(xo, GW - 1, GW); vc = __shfl(vo, GW - 1, GW); x2c = __shfl(x2o, GW - 1, GW);
+			int8_t a = (int8_t)(xt1 + vt1), b = (int8_t)(yo + ut), a2 = (int8_t)(x2t1 + vt1), b2 = (int8_t)(y2o + ut), d;
+			if (!(flag & EZ_RIGHT)) {
+				d = a > z ? 1 : 0;   z = z > a ? z : a;
+				d = b > z ? 2 : d;   z = z > b ? z : b;
+				d = a2 > z ? 3 : d;  z = z > a2 ? z : a2;
+				d = b2 > z ? 4 : d;  z = z > b2 ? z : b2;
+			} else {
+				d = z > a ? 0 : 1;   z = z > a ? z : a;
+				d = z > b ? d : 2;   z = z > b ? z : b;
+				d = z > a2 ? d : 3;  z = z > a2 ? z : a2;
+				d = z > b2 ? d : 4;  z = z > b2 ? z : b2;
+			}
+			z = z < sc_mch ? z : sc_mch;
+			L.u[t] = (int8_t)(z - (int8_t)vt1); L.v[t] = (int8_t)(z - ut);
+			int8_t tmp = (int8_t)(z - q); a = (int8_t)(a - tmp); b = (int8_t)(b - tmp);
+			tmp = (int8_t)(z - q2); a2 = (int8_t)(a2 - tmp); b2 = (int8_t)(b2 - tmp);
+			if (!(flag & EZ_RIGHT)) {
+				L.x[t]  = (int8_t)((a  > 0 ? a  : 0) - qe_);  if (a  > 0) d |= 0x08;
+				L.y[t]  = (int8_t)((b  > 0 ? b  : 0) - qe_);  if (b  > 0) d |= 0x10;
+				L.x2[t] = (int8_t)((a2 > 0 ? a2 : 0) - qe2_); if (a2 > 0) d |= 0x20;
+				L.y2[t] = (int8_t)((b2 > 0 ? b2 : 0) - qe2_); if (b2 > 0) d |= 0x40;
+			} else {
+				L.x[t]  = (int8_t)((a  >= 0 ? a  : 0) - qe_);  if (a  >= 0) d |= 0x08;
+				L.y[t]  = (int8_t)((b  >= 0 ? b  : 0) - qe_);  if (b  >= 0) d |= 0x10;
+				L.x2[t] = (int8_t)((a2 >= 0 ? a2 : 0) - qe2_); if (a2 >= 0) d |= 0x20;
+				L.y2[t] = (int8_t)((b2 >= 0 ? b2 : 0) - qe2_); if (b2 >= 0) d |= 0x40;
+			}
+			pr[t] = (uint8_t)d;
+		}
+		GSYNC();
+		{   // exact max (:307-361): H row update + argmax in the reference's evaluation order
+			int max_H, max_t;
+			if (r > 0) {
+				const int Hen0 = en0 > 0 ? L.H[en0 - 1] + L.u[en0] : L.H[en0] + L.v[en0];
+				const int en1 = st0 + (en0 - st0) / 4 * 4;
+				int bh = Hen0, bo = 0, bt = en0;
+				for (int t = st0 + gl; t < en0; t += GW) {
+					const int h = L.H[t] + L.v[t];
+					L.H[t] = h;
+					const int ord = t < en1 ? 1 + ((t - st0) & 3) * 4096 + ((t - st0) >> 2) : 1 + 4 * 4096 + (t - en1);
+					if (h > bh || (h == bh && ord < bo)) { bh = h; bo = ord; bt = t; }
+				}
+				for (int dlt = GW >> 1; dlt > 0; dlt >>= 1) {
+					const int oh = __shfl_xor(bh, dlt, GW), oo = __shfl_xor(bo, dlt, GW), ot = __shfl_xor(bt, dlt, GW);
+					if (oh > bh || (oh == bh && oo < bo)) { bh = oh; bo = oo; bt = ot; }
+				}
+				L.H[en0] = Hen0;
+				max_H = bh; max_t = bt;
+			} else { L.H[0] = L.v[0] - qe; max_H = L.H[0]; max_t = 0; }
+			GSYNC();
+			if (en0 == tlen - 1 && L.H[en0] > ez.mte) ez.mte = L.H[en0];
+			if (r - st0 == qlen - 1 && L.H[st0] > ez.mqe) { ez.mqe = L.H[st0]; ez.mqe_t = st0; }
+			// ksw_apply_zdrop, ksw2.h:160-176
+			bool brk = false;
+			if (max_H > ez.max) { ez.max = max_H; ez.max_t = max_t; ez.max_q = r - max_t; }
+			else if (max_t >= ez.max_t && r - max_t >= ez.max_q) {
+				const int tl = max_t - ez.max_t, ql = (r - max_t) - ez.max_q, l = tl > ql ? tl - ql : ql - tl;
+				if (zdrop >= 0 && ez.max - max_H > zdrop + l * e2) { ez.zdropped = 1; brk = true; }
+			}
+			if (brk) break;
+			if (r == qlen + tlen - 2 && en0 == tlen - 1) ez.score = L.H[tlen - 1];
+		}
+		last_st = st; last_en = en;
+	}
+	GSYNC();
+	{   // :384-392
+		const int rev_cigar = !!(flag & EZ_REV_CIGAR);
+		CigW cw{ws.ezc, 0};
+		if (!ez.zdropped && !(flag & EZ_EXTZ_ONLY)) d_backtrack(ws.p, n_col_ * 16, qlen, tlen, w, rev_cigar, tlen - 1, qlen - 1, cw);
+		else if (!ez.zdropped && (flag & EZ_EXTZ_ONLY) && ez.mqe + end_bonus > ez.max) { ez.reach_end = 1; d_backtrack(ws.p, n_col_ * 16, qlen, tlen, w, rev_cigar, ez.mqe_t, qlen - 1, cw); }
+		else if (ez.max_t >= 0 && ez.max_q >= 0) d_backtrack(ws.p, n_col_ * 16, qlen, tlen, w, rev_cigar, ez.max_t, ez.max_q, cw);
+		ez.n_cigar = cw.n;
+	}
+	GSYNC();
+}
+
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int d_mat(const AlParams &P, int ct, int cq)
+{   // ksw_gen_simple_mat, align.c:9-22 (m = 5)
+	const int amb = P.sc_ambi > 0 ? -P.sc_ambi : P.sc_ambi;
+	if (ct > 3 || cq > 3) return amb;
+	return ct == cq ? (P.a < 0 ? -P.a : P.a) : (P.b > 0 ? -P.b : P.b);
+}
+
+__device__ int d_test_zdrop(const AlParams &P, const uint8_t *qseq, const uint8_t *tseq, int n_cigar, const uint32_t *cigar)
+{   // mm_test_zdrop, align.c:47-89; the inversion branch is unreachable with MM_F_SR (align.c:72)
+	int score = 0, max = INT32_MIN, max_i = -1, max_j = -1, i = 0, j = 0, max_zdrop = 0;
+	for (int k = 0; k < n_cigar; ++k) {
+		const int op = cigar[k] & 0xf, len = cigar[k] >> 4;
+		if (op == 0) {
+			for (int l = 0; l < len; ++l) {
+				score += d_mat(P, tseq[i + l], qseq[j + l]);
+				if (score < max) { const int li = i + l - max_i, lj = j + l - max_j, diff = li > lj ? li - lj : lj - li, z = max - score - diff * P.e; if (z > max_zdrop) max_zdrop = z; }
+				else { max = score; max_i = i + l; max_j = j + l; }
+			}
+			i += len; j += len;
+		} else if (op == 1 || op == 2 || op == 3) {
+			score -= P.q + P.e * len;
+			if (op == 1) j += len; else i += len;
+			if (score < max) { const int li = i - max_i, lj = j - max_j, diff = li > lj ? li - lj : lj - li, z = max - score - diff * P.e; if (z > max_zdrop) max_zdrop = z; }
+			else { max = score; max_i = i; max_j = j; }
+		}
+	}
+	return max_zdrop > P.zdrop ? 1 : 0;
+}
+
+__device__ void d_fix_cigar(AlReg *r, uint32_t *cigar, const uint8_t *qseq, const uint8_t *tseq, int *qshift, int *tshift)
+{   // mm_fix_cigar, align.c:91-167
+	int toff = 0, qoff = 0, to_shrink = 0; uint32_t k;
+	*qshift = *tshift = 0;
+	if (r->n_cigar <= 1) return;
+	for (k = 0; k < r->n_cigar; ++k) {
+		const uint32_t op = cigar[k] & 0xf, len = cigar[k] >> 4;
+		if (len == 0) to_shrink = 1;
+		if (op == 0) { toff += len; qoff += len; }
+		else if (op == 1 || op == 2) {
+			if (k > 0 && k < r->n_cigar - 1 && (cigar[k - 1] & 0xf) == 0 && (cigar[k + 1] & 0xf) == 0) {
+				int l; const int prev_len = cigar[k - 1] >> 4;
+				if (op == 1) { for (l = 0; l < prev_len; ++l) if (qseq[qoff - 1 - l] != qseq[qoff + len - 1 - l]) break; }
+				else { for (l = 0; l < prev_len; ++l) if (tseq[toff - 1 - l] != tseq[toff + len - 1 - l]) break; }
+				if (l > 0) { cigar[k - 1] -= l << 4; cigar[k + 1] += l << 4; qoff -= l; toff -= l; }
+				if (l == prev_len) to_shrink = 1;
+			}
+			if (op == 1) qoff += len; else toff += len;
+		} else if (op == 3) toff += len;
+	}
+	for (k = 0; k + 2 < r->n_cigar; ++k) {
+		if ((cigar[k] & 0xf) > 0 && (cigar[k] & 0xf) + (cigar[k + 1] & 0xf) == 3) {
+			uint32_t l, s[3] = {0, 0, 0};
+			for (l = k; l < r->n_cigar; ++l) {
+				const uint32_t op = cigar[l] & 0xf;
+				if (op == 1 || op == 2 || cigar[l] >> 4 == 0) s[op] += cigar[l] >> 4;
+				else break;
+			}
+			if (s[1] > 0 && s[2] > 0 && l - k > 2) {
+				cigar[k] = s[1] << 4 | 1; cigar[k + 1] = s[2] << 4 | 2;
+				for (k += 2; k < l; ++k) cigar[k] &= 0xf;
+				to_shrink = 1;
+			}
+			k = l;
+		}
+	}
+	if (to_shrink) {
+		uint32_t l = 0;
+		for (k = 0; k < r->n_cigar; ++k) if (cigar[k] >> 4 != 0) cigar[l++] = cigar[k];
+		r->n_cigar = l;
+		for (k = l = 0; k < r->n_cigar; ++k)
+			if (k == r->n_cigar - 1 || (cigar[k] & 0xf) != (cigar[k + 1] & 0xf)) cigar[l++] = cigar[k];
+			else cigar[k + 1] += cigar[k] >> 4 << 4;
+		r->n_cigar = l;
+	}
+	if ((cigar[0] & 0xf) == 1 || (cigar[0] & 0xf) == 2) {
+		const int l = cigar[0] >> 4;
+		if ((cigar[0] & 0xf) == 1) { if (r->flags & ALR_REV) r->qe -= l; else r->qs += l; *qshift = l; }
+		else { r->rs += l; *tshift = l; }
+		--r->n_cigar;
+		for (k = 0; k < r->n_cigar; ++k) cigar[k] = cigar[k + 1];
+	}
+}
+
+__device__ void d_update_extra(const AlParams &P, AlReg *r, uint32_t *cigar, const uint8_t *qseq, const uint8_t *tseq)
+{   // mm_update_extra, align.c:240-286
+	int s = 0, max = 0, qshift, tshift, toff = 0, qoff = 0;
+	d_fix_cigar(r, cigar, qseq, tseq, &qshift, &tshift);
+	qseq += qshift; tseq += tshift;
+	r->blen = r->mlen = 0;
+	for (uint32_t k = 0; k < r->n_cigar; ++k) {
+		const uint32_t op = cigar[k] & 0xf, len = cigar[k] >> 4;
+		if (op == 0) {
+			int n_ambi = 0, n_diff = 0;
+			for (uint32_t l = 0; l < len; ++l) {
+				const int cq = qseq[qoff + l], ct = tseq[toff + l];
+				if (ct > 3 || cq > 3) ++n_ambi; else if (ct != cq) ++n_diff;
+				s += d_mat(P, ct, cq);
+				if (s < 0) s = 0; else max = max > s ? max : s;
+			}
+			r->blen += len - n_ambi; r->mlen += len - (n_ambi + n_diff); r->n_ambi += n_ambi;
+			toff += len; qoff += len;
+		} else if (op == 1) {
+			int n_ambi = 0;
+			for (uint32_t l = 0; l < len; ++l) if (qseq[qoff + l] > 3) ++n_ambi;
+			r->blen += len - n_ambi; r->n_ambi += n_ambi;
+			s -= P.q + P.e * len; if (s < 0) s = 0;
+			qoff += len;
+		} else if (op == 2) {
+			int n_ambi = 0;
+			for (uint32_t l = 0; l < len; ++l) if (tseq[toff + l] > 3) ++n_ambi;
+			r->blen += len - n_ambi; r->n_ambi += n_ambi;
+			s -= P.q + P.e * len; if (s < 0) s = 0;
+			toff += len;
+		} else if (op == 3) toff += len;
+	}
+	r->dp_max = max;
+}
+
+__device__ __forceinline__ void d_append_cigar(AlReg *r, uint32_t *cig, int n_cigar, const uint32_t *cigar)
+{   // mm_append_cigar, align.c:288-311
+	if (n_cigar == 0) return;
+	r->flags |= ALR_HAS_P;
+	if (r->n_cigar > 0 && (cig[r->n_cigar - 1] & 0xf) == (cigar[0] & 0xf)) {
+		cig[r->n_cigar - 1] += cigar[0] >> 4 << 4;
+		for (int i = 1; i < n_cigar; ++i) cig[r->n_cigar + i - 1] = cigar[i];
+		r->n_cigar += n_cigar - 1;
+	} else {
+		for (int i = 0; i < n_cigar; ++i) cig[r->n_cigar + i] = cigar[i];
+		r->n_cigar += n_cigar;
+	}
+}
+
+__device__ void d_max_stretch(const AlReg *r, const AlAnchor *a, int *as, int *cnt)
+{   // mm_max_stretch, align.c:495-521
+	*as = r->as; *cnt = r->cnt;
+	if (r->cnt < 2) return;
+	int max_score = -1, max_i = -1, max_len = 0, score = (int)(a[r->as].y >> 32 & 0xff), len = 1, i;
+	for (i = r->as + 1; i < r->as + r->cnt; ++i) {
+		const int q_span = (int)(a[i].y >> 32 & 0xff);
+		const int lr = (int32_t)a[i].x - (int32_t)a[i - 1].x, lq = (int32_t)a[i].y - (int32_t)a[i - 1].y;
+		if (lq == lr) { score += lq < q_span ? lq : q_span; ++len; }
+		else { if (score > max_score) { max_score = score; max_len = len; max_i = i - len; } score = q_span; len = 1; }
+	}
+	if (score > max_score) { max_score = score; max_len = len; max_i = i - len; }
+	*as = max_i; *cnt = max_len;
+}
+
+struct AlignShared {            // read-only kernel inputs
+	const uint32_t *S4; const uint64_t *seq_off; const uint32_t *seq_len;
+	uint32_t *arena; unsigned long long *arena_cnt; uint64_t arena_cap;
+	unsigned long long *counters;   // [4] regions aligned, [5] ref bases, [6] cigar ops, [7] errors, [8] logf misses, [9] arena overflow, [10] sort ties
+};
+
+// mm_align1 (align.c:565-788), short-read branch.  Executed by the 16 lanes of a group in lock step.
+template <int TMAX, int QMAX>
+__device__ void d_align1(GroupLds<TMAX, QMAX> &L, const int gl, const GroupWs &ws, const AlParams &P, const AlignShared &G,
+                         int qlen, AlReg *r, AlReg *r2, AlAnchor *a, EzD &ez)
+{
+	const int32_t rid = (int32_t)(a[r->as].x << 1 >> 33), rev = (int32_t)(a[r->as].x >> 63);
+	int32_t as1, cnt1, l, dropped = 0, rs0, re0, qs0, qe0, rs, re, qs, qe, rs1, qs1, re1, qe1;
+	r2->cnt = 0;
+	if (r->cnt == 0) return;
+	const int bw = (int)(P.bw * 1.5 + 1.);
+	const int32_t ref_len = (int32_t)G.seq_len[rid]; const uint64_t ref_off = G.seq_off[rid];
+	const uint8_t *qseq0 = rev ? L.q1 : L.q0;
+	d_max_stretch(r, a, &as1, &cnt1);
+	rs = (int32_t)a[as1].x + 1 - (int32_t)(a[as1].y >> 32 & 0xff);
+	qs = (int32_t)a[as1].y + 1 - (int32_t)(a[as1].y >> 32 & 0xff);
+	re = (int32_t)a[as1 + cnt1 - 1].x + 1;
+	qe = (int32_t)a[as1 + cnt1 - 1].y + 1;
+	qs0 = 0; qe0 = qlen;                                                      // align.c:613-620
+	l = qs;
+	l += l * P.a + P.end_bonus > P.q ? (l * P.a + P.end_bonus - P.q) / P.e : 0;
+	rs0 = rs - l > 0 ? rs - l : 0;
+	l = qlen - qe;
+	l += l * P.a + P.end_bonus > P.q ? (l * P.a + P.end_bonus - P.q) / P.e : 0;
+	re0 = re + l < ref_len ? re + l : ref_len;
+	if (re0 - rs0 > TMAX || qlen > QMAX) { if (gl == 0) atomicAdd(&G.counters[7], 1ULL); r->cnt = 0; return; }
+	if (gl == 0) { atomicAdd(&G.counters[4], 1ULL); atomicAdd(&G.counters[5], (unsigned long long)(re0 - rs0)); }
+	r->n_cigar = 0; r->dp_score = 0; r->dp_max = 0; r->dp_max2 = 0; r->n_ambi = 0;
+
+	if (qs > 0 && rs > 0) {                                                   // left extension, align.c:690-705
+		const int ql = qs - qs0, tl = rs - rs0;
+		for (int i = gl; i < ql; i += GW) L.qbuf[i] = qseq0[qs0 + (ql - 1 - i)];                     // mm_seq_rev of both
+		for (int i = gl; i < tl; i += GW) L.tbuf[i] = (uint8_t)d_seq4(G.S4, ref_off + (uint64_t)(rs - 1 - i));
+		GSYNC();
+		d_ksw_extd2(L, gl, ws, ql, tl, P, bw, (r->flags & ALR_SPLIT_INV) ? P.zdrop_inv : P.zdrop, P.end_bonus, EZ_EXTZ_ONLY | EZ_RIGHT | EZ_REV_CIGAR, ez);
+		if (ez.n_cigar > 0) { d_append_cigar(r, ws.cig, ez.n_cigar, ws.ezc); r->dp_score += ez.max; }
+		rs1 = rs - (ez.reach_end ? ez.mqe_t + 1 : ez.max_t + 1);
+		qs1 = qs - (ez.reach_end ? qs - qs0 : ez.max_q + 1);
+	} else { rs1 = rs; qs1 = qs; }
+	re1 = rs; qe1 = qs;
+	{   // ungapped core, align.c:709-758 with is_sr (single iteration i = cnt1 - 1)
+		const int i = cnt1 - 1;
+		re = (int32_t)a[as1 + i].x + 1; qe = (int32_t)a[as1 + i].y + 1;
+		re1 = re; qe1 = qe;
+		const int len = qe - qs;
+		for (int k = gl; k < len; k += GW) { L.qbuf[k] = qseq0[qs + k]; L.tbuf[k] = (uint8_t)d_seq4(G.S4, ref_off + (uint64_t)(rs + k)); }
+		GSYNC();
+		d_ez_reset(ez);
+		int sc = 0;
+		for (int k = 0; k < len; ++k) {
+			if (L.qbuf[k] >= 4 || L.tbuf[k] >= 4) sc += P.e2;
+			else sc += L.qbuf[k] == L.tbuf[k] ? P.a : -P.b;
+		}
+		ez.score = sc;
+		ws.ezc[0] = (uint32_t)len << 4; ez.n_cigar = 1;
+		if (d_test_zdrop(P, L.qbuf, L.tbuf, ez.n_cigar, ws.ezc) != 0)
+			d_ksw_extd2(L, gl, ws, len, re - rs, P, bw, P.zdrop, -1, 0, ez);    // second pass (align.c:736-737)
+		if (ez.n_cigar > 0) d_append_cigar(r, ws.cig, ez.n_cigar, ws.ezc);
+		if (ez.zdropped) {
+			int j;
+			for (j = i - 1; j >= 0; --j) if ((int32_t)a[as1 + j].x <= rs + ez.max_t) break;
+			dropped = 1;
+			if (j < 0) j = 0;
+			r->dp_score += ez.max;
+			re1 = rs + (ez.max_t + 1);
+			qe1 = qs + (ez.max_q + 1);
+			if (cnt1 - (j + 1) >= P.min_cnt) d_split_reg(r, r2, as1 + j + 1 - r->as, qlen, a);
+		} else { r->dp_score += ez.score; rs = re; qs = qe; }
+	}
+	if (!dropped && qe < qe0 && re < re0) {                                   // right extension, align.c:760-771
+		const int ql = qe0 - qe, tl = re0 - re;
+		for (int i = gl; i < ql; i += GW) L.qbuf[i] = qseq0[qe + i];
+		for (int i = gl; i < tl; i += GW) L.tbuf[i] = (uint8_t)d_seq4(G.S4, ref_off + (uint64_t)(re + i));
+		GSYNC();
+		d_ksw_extd2(L, gl, ws, ql, tl, P, bw, P.zdrop, P.end_bonus, EZ_EXTZ_ONLY, ez);
+		if (ez.n_cigar > 0) { d_append_cigar(r, ws.cig, ez.n_cigar, ws.ezc); r->dp_score += ez.max; }
+		re1 = re + (ez.reach_end ? ez.mqe_t + 1 : ez.max_t + 1);
+		qe1 = qe + (ez.reach_end ? qe0 - qe : ez.max_q + 1);
+	}
+	r->rs = rs1; r->re = re1;
+	if (rev) { r->qs = qlen - qe1; r->qe = qlen - qs1; }
+	else { r->qs = qs1; r->qe = qe1; }
+	if (r->flags & ALR_HAS_P) {
+		const int tl = re1 - rs1;
+		for (int i = gl; i < tl; i += GW) L.tbuf[i] = (uint8_t)d_seq4(G.S4, ref_off + (uint64_t)(rs1 + i));
+		GSYNC();
+		d_update_extra(P, r, ws.cig, qseq0 + qs1, L.tbuf);
+		// publish the finished CIGAR: reserve words in the global arena (one atomic per group) and copy
+		unsigned long long off = 0;
+		if (gl == 0) off = atomicAdd(G.arena_cnt, (unsigned long long)r->n_cigar);
+		off = __shfl(off, 0, GW);
+		if (off + r->n_cigar <= G.arena_cap) { for (uint32_t i = gl; i < r->n_cigar; i += GW) G.arena[off + i] = ws.cig[i]; r->cigar_off = (uint32_t)off; }
+		else { if (gl == 0) atomicAdd(&G.counters[9], 1ULL); r->cigar_off = 0xffffffffu; }
+		if (gl == 0) atomicAdd(&G.counters[6], (unsigned long long)r->n_cigar);
+	}
+	GSYNC();
+}
+
+// mm_pair, pe.c:76-177 (+ mm_set_pe_thru pe.c:45-64).  pa: scratch (n0+n1) x 3 words; sc: scratch u64
+struct PairEnt { uint64_t key; int32_t s, rev, idx; int32_t pad; };
+__device__ void d_pair(const AlParams &P, int max_gap_ref, const int *qlens, int *n_regs, AlReg *const *regs, PairEnt *pa, uint64_t *sc, const AlLogTab &lt, bool *tie, bool *ovf)
+{
+	const int sub_diff = P.a * 2 + P.b, match_sc = P.a;
+	int n = 0, dp_thres = 0, segs = 0;
+	for (int s = 0; s < 2; ++s) {
+		int mx = 0;
+		for (int i = 0; i < n_regs[s]; ++i) {
+			const AlReg *r = &regs[s][i];
+			pa[n].s = s; pa[n].idx = i; pa[n].rev = (r->flags & ALR_REV) ? 1 : 0;
+			pa[n].key = (uint64_t)(uint32_t)r->rid << 32 | (uint64_t)(uint32_t)(r->rs << 1) | (uint64_t)(s ^ pa[n].rev);
+			mx = mx > r->dp_max ? mx : r->dp_max;
+			++n; segs |= 1 << s;
+		}
+		dp_thres += mx;
+	}
+	if (segs == 3) {
+		dp_thres -= P.pe_bonus; if (dp_thres < 0) dp_thres = 0;
+		// radix_sort_pair: stable insertion sort for n <= 64 (ksort.h:149)
+		for (int i = 1; i < n; ++i) if (pa[i].key < pa[i - 1].key) { PairEnt t = pa[i]; int j = i; for (; j > 0 && t.key < pa[j - 1].key; --j) pa[j] = pa[j - 1]; pa[j] = t; }
+		if (n > 64) { for (int i = 1; i < n; ++i) if (pa[i].key == pa[i - 1].key) *tie = true; }
+		long long max = -1; int max_idx[2] = {-1, -1}, last[2] = {-1, -1}; int n_sc = 0;
+#define PR(e) (&regs[(e).s][(e).idx])
+		for (int i = 0; i < n; ++i) {
+			if (pa[i].key & 1) {
+				if (last[pa[i].rev] < 0) continue;
+				const AlReg *r = PR(pa[i]), *q = PR(pa[last[pa[i].rev]]);
+				if (r->rid != q->rid || r->rs - q->re > max_gap_ref) continue;
+				for (int j = last[pa[i].rev]; j >= 0; --j) {
+					if (pa[j].rev != pa[i].rev || pa[j].s == pa[i].s) continue;
+					q = PR(pa[j]);
+					if (r->rid != q->rid || r->rs - q->re > max_gap_ref) break;
+					if (r->dp_max + q->dp_max < dp_thres) continue;
+					const long long score = (long long)((uint64_t)(uint32_t)(r->dp_max + q->dp_max) << 32 | (uint32_t)(r->hash + q->hash));
+					if (score > max) { max = score; max_idx[pa[j].s] = j; max_idx[pa[i].s] = i; }
+					if (n_sc < AL_PAIR_SC_CAP) sc[n_sc++] = (uint64_t)score; else *ovf = true;
+				}
+			} else last[pa[i].rev] = i;
+		}
+		if (n_sc > 1) d_sort64(sc, n_sc);
+		if (n_sc > 0 && max > 0) {
+			int n_sub = 0, mapq_pe; AlReg *r[2];
+			r[0] = PR(pa[max_idx[0]]); r[1] = PR(pa[max_idx[1]]);
+			r[0]->flags |= ALR_PROPER; r[1]->flags |= ALR_PROPER;
+			for (int s = 0; s < 2; ++s) {
+				if (r[s]->id != r[s]->parent) {
+					AlReg *p = &regs[s][r[s]->parent];
+					for (int i = 0; i < n_regs[s]; ++i) if (regs[s][i].parent == p->id) regs[s][i].parent = r[s]->id;
+					p->mapq = 0;
+				}
+				if (!(r[s]->flags & ALR_SAM_PRI)) {
+					for (int i = 0; i < n_regs[s]; ++i) regs[s][i].flags &= ~ALR_SAM_PRI;
+					r[s]->flags |= ALR_SAM_PRI;
+				}
+			}
+			mapq_pe = r[0]->mapq > r[1]->mapq ? (int)r[0]->mapq : (int)r[1]->mapq;
+			for (int i = 0; i < n_sc; ++i) if ((sc[i] >> 32) + sub_diff >= (uint64_t)max >> 32) ++n_sub;
+			if (n_sc > 1) {
+				const uint64_t diff = (uint64_t)(max >> 32) - (sc[n_sc - 2] >> 32);
+				const int mapq_pe_alt = (int)__fsub_rn(al_fdiv(__fmul_rn(6.02f, (float)diff), (float)match_sc), __fmul_rn(4.343f, al_logf_i(lt, n_sub)));
+				mapq_pe = mapq_pe < mapq_pe_alt ? mapq_pe : mapq_pe_alt;
+			}
+			for (int s = 0; s < 2; ++s)
+				if ((int)r[s]->mapq < mapq_pe) r[s]->mapq = (uint32_t)(int)__fadd_rn(__fadd_rn(__fmul_rn(.2f, (float)r[s]->mapq), __fmul_rn(.8f, (float)mapq_pe)), .499f) & 0xffu;
+			if (n_sc == 1) { if (r[0]->mapq < 2) r[0]->mapq = 2; if (r[1]->mapq < 2) r[1]->mapq = 2; }
+			else if ((uint64_t)max >> 32 > sc[n_sc - 2] >> 32) { if (r[0]->mapq < 1) r[0]->mapq = 1; if (r[1]->mapq < 1) r[1]->mapq = 1; }
+		}
+#undef PR
+	}
+	// mm_set_pe_thru
+	int n_pri[2] = {0, 0}, pri[2] = {-1, -1};
+	for (int s = 0; s < 2; ++s) for (int i = 0; i < n_regs[s]; ++i) if (regs[s][i].id == regs[s][i].parent) { ++n_pri[s]; pri[s] = i; }
+	if (n_pri[0] == 1 && n_pri[1] == 1) {
+		AlReg *p = &regs[0][pri[0]], *q = &regs[1][pri[1]];
+		const int d1 = p->rs - q->rs, d2 = p->re - q->re;
+		if (p->rid == q->rid && (p->flags & ALR_REV) == (q->flags & ALR_REV) && (d1 < 0 ? -d1 : d1) < 3 && (d2 < 0 ? -d2 : d2) < 3
+		    && ((p->qs == 0 && qlens[1] - q->qe == 0) || (q->qs == 0 && qlens[0] - p->qe == 0))) { p->flags |= ALR_PE_THRU; q->flags |= ALR_PE_THRU; }
+	}
+}
+
+// ---------------------------------------------------------------------------------------------
+// Per-fragment workspace layout.  With P_f = sum of n_u over earlier fragments and c_f = 2*n_u + 4:
+//   regs0      : AlReg   x n_u         at P_f                      (fragment-level hits)
+//   mate regs  : AlReg   x c_f each    at 2*(2*P_f + 4*f) + s*c_f  (per-mate hits; spare room for z-drop splits)
+//   scratch    : AlAnchor/ u64 / int / AlReg x c_f                 at B_f = 2*P_f + 4*f
+//   seg_u      : u64     x n_u each    at 2*P_f + s*n_u
+//   seg_a      : anchors of mate 0 then mate 1 inside the fragment's anchor range a_off[f]..
+struct FragWs {
+	AlReg *regs0, *mreg[2], *rtmp; AlAnchor *aux128, *seg_a[2]; uint64_t *aux64, *seg_u[2]; int *auxi; int cap;
+};
+struct WsBase {
+	AlReg *regs0, *mregs, *rtmp; AlAnchor *aux128, *seg_a; uint64_t *aux64, *seg_u; int *auxi;
+	const uint64_t *nu_off; const uint32_t *frag_nu; const uint64_t *a_off; uint32_t *reg_cnt /* per read */; uint32_t *seg_na /* per read */;
+};
+__device__ __forceinline__ void d_frag_ws(const WsBase &W, uint32_t f, FragWs &o)
+{
+	const uint64_t Pf = W.nu_off[f]; const uint32_t nu = W.frag_nu[f]; const uint64_t B = 2 * Pf + 4ULL * f; const int c = 2 * (int)nu + 4;
+	o.cap = c; o.regs0 = W.regs0 + Pf; o.mreg[0] = W.mregs + 2 * B; o.mreg[1] = o.mreg[0] + c; o.rtmp = W.rtmp + B;
+	o.aux128 = W.aux128 + B; o.aux64 = W.aux64 + B; o.auxi = W.auxi + 2 * B;
+	o.seg_u[0] = W.seg_u + 2 * Pf; o.seg_u[1] = o.seg_u[0] + nu;
+	o.seg_a[0] = W.seg_a + W.a_off[f]; o.seg_a[1] = nullptr;
+}
+
+extern "C" __global__ void __launch_bounds__(256)
+k_regs(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__ u_all, const uint32_t *__restrict__ frag_first,
+       const uint32_t *__restrict__ rd_len, const uint32_t *__restrict__ frag_hash, WsBase W, int n_frag, AlParams P, unsigned long long *counters)
+{
+	const int f = blockIdx.x * blockDim.x + threadIdx.x;
+	if (f >= n_frag) return;
+	const uint32_t r0 = frag_first[f], n_segs = frag_first[f + 1] - r0, n_u = W.frag_nu[f];
+	for (uint32_t s = 0; s < n_segs; ++s) { W.reg_cnt[r0 + s] = 0; W.seg_na[r0 + s] = 0; }
+	if (n_u == 0) return;
+	FragWs ws; d_frag_ws(W, f, ws);
+	int qlens[2] = {0, 0}, qlen_sum = 0;
+	for (uint32_t s = 0; s < n_segs; ++s) { qlens[s] = (int)rd_len[r0 + s]; qlen_sum += qlens[s]; }
+	const AlAnchor *a = chained + W.a_off[f]; const uint64_t *u = u_all + W.a_off[f] + f;
+	const uint32_t hash = frag_hash[f];
+	int max_gap_ref;
+	if (P.max_gap_ref > 0) max_gap_ref = P.max_gap_ref;
+	else if (P.max_frag_len > 0) { max_gap_ref = P.max_frag_len - qlen_sum; if (max_gap_ref < P.max_gap) max_gap_ref = P.max_gap; }
+	else max_gap_ref = P.max_gap;
+	bool tie = d_gen_regs(hash, qlen_sum, (int)n_u, u, a, ws.regs0, ws.aux128);
+	int n0 = (int)n_u;
+	d_set_parent(P.mask_level, n0, ws.regs0, P.a * 2 + P.b, ws.aux64, ws.auxi);                       // chain_post, map.c:249-258
+	if (n_segs <= 1) d_select_sub(P.pri_ratio, P.k * 2, P.best_n, &n0, ws.regs0, ws.auxi);
+	else d_select_sub_multi(P.pri_ratio, 0.2f, 0.7f, max_gap_ref, P.k * 2, P.best_n, (int)n_segs, qlens, &n0, ws.regs0, ws.auxi);
+	if (n_segs == 1) {
+		for (int i = 0; i < n0; ++i) ws.mreg[0][i] = ws.regs0[i];
+		AlAnchor *sa = ws.seg_a[0];
+		uint32_t tot = 0; for (uint32_t i = 0; i < n_u; ++i) tot += (uint32_t)u[i];
+		for (uint32_t i = 0; i < tot; ++i) sa[i] = a[i];
+		const int na = d_squeeze_a(n0, ws.mreg[0], sa, ws.aux64);                                     // mm_align_skeleton, align.c:873
+		W.reg_cnt[r0] = (uint32_t)n0; W.seg_na[r0] = (uint32_t)na;
+	} else {
+		// mm_seg_gen, hit.c:356-410
+		int acc_qlen[2] = {0, qlens[0]}; uint32_t n_a[2] = {0, 0}, n_us[2] = {0, 0};
+		for (int s = 0; s < 2; ++s) for (int i = 0; i < n0; ++i) ws.seg_u[s][i] = (uint64_t)(uint32_t)ws.regs0[i].score << 32;
+		for (int i = 0; i < n0; ++i) {
+			const AlReg *r = &ws.regs0[i];
+			for (int j = 0; j < r->cnt; ++j) { const int sid = (int)((a[r->as + j].y & AL_SEED_SEG_MASK) >> AL_SEED_SEG_SHIFT); ++ws.seg_u[sid][i]; ++n_a[sid]; }
+		}
+		ws.seg_a[1] = ws.seg_a[0] + n_a[0];
+		for (int s = 0; s < 2; ++s) { for (int i = 0; i < n0; ++i) if ((int32_t)ws.seg_u[s][i] != 0) ws.seg_u[s][n_us[s]++] = ws.seg_u[s][i]; n_a[s] = 0; }
+		for (int i = 0; i < n0; ++i) {
+			const AlReg *r = &ws.regs0[i];
+			for (int j = 0; j < r->cnt; ++j) {
+				AlAnchor a1 = a[r->as + j]; const int sid = (int)((a1.y & AL_SEED_SEG_MASK) >> AL_SEED_SEG_SHIFT);
+				a1.y -= (a1.x >> 63) ? (uint64_t)(qlen_sum - (qlens[sid] + acc_qlen[sid])) : (uint64_t)acc_qlen[sid];
+				ws.seg_a[sid][n_a[sid]++] = a1;
+			}
+		}
+		for (int s = 0; s < 2; ++s) {
+			tie = d_gen_regs(hash, qlens[s], (int)n_us[s], ws.seg_u[s], ws.seg_a[s], ws.mreg[s], ws.aux128) || tie;
+			int n = (int)n_us[s];
+			for (int i = 0; i < n; ++i) ws.mreg[s][i].flags |= ALR_SEG_SPLIT | ((uint32_t)s << 8);
+			d_set_parent(P.mask_level, n, ws.mreg[s], P.a * 2 + P.b, ws.aux64, ws.auxi);                // map.c:401
+			const int na = d_squeeze_a(n, ws.mreg[s], ws.seg_a[s], ws.aux64);                           // align.c:873
+			W.reg_cnt[r0 + s] = (uint32_t)n; W.seg_na[r0 + s] = (uint32_t)na;
+		}
+		W.seg_na[r0] = n_a[0];   // seg_a[1] starts n_a[0] anchors after seg_a[0] (kept un-squeezed size for addressing)
+	}
+	if (tie) atomicAdd(&counters[10], 1ULL);
+}
+
+template <int TMAX, int QMAX>
+__global__ void __launch_bounds__(64)
+k_align(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_off, const uint32_t *__restrict__ rd_len,
+        const uint32_t *__restrict__ frag_first, const int32_t *__restrict__ frag_rep, WsBase W, AlignShared G, AlLogTab lt,
+        uint8_t *__restrict__ gws, size_t gws_stride, size_t p_bytes, size_t cig_words, int n_frag, AlParams P)
+{
+	__shared__ GroupLds<TMAX, QMAX> lds[4];
+	const int g = threadIdx.x / GW, gl = threadIdx.x % GW;
+	GroupLds<TMAX, QMAX> &L = lds[g];
+	GroupWs ws;
+	{
+		uint8_t *base = gws + ((size_t)blockIdx.x * 4 + g) * gws_stride;
+		ws.p = base; ws.cig = (uint32_t *)(base + p_bytes); ws.ezc = ws.cig + cig_words; ws.sc = (uint64_t *)(ws.ezc + cig_words);
+	}
+	for (int f = blockIdx.x * 4 + g; f < n_frag; f += gridDim.x * 4) {
+		const uint32_t r0 = frag_first[f], n_segs = frag_first[f + 1] - r0, n_u = W.frag_nu[f];
+		if (n_u == 0) continue;
+		FragWs fw; d_frag_ws(W, (uint32_t)f, fw);
+		if (n_segs == 2) fw.seg_a[1] = fw.seg_a[0] + W.seg_na[r0];   // see k_regs
+		int qlens[2] = {0, 0}, qlen_sum = 0, n_regs[2] = {0, 0};
+		for (uint32_t s = 0; s < n_segs; ++s) { qlens[s] = (int)rd_len[r0 + s]; qlen_sum += qlens[s]; }
+		int max_gap_ref;
+		if (P.max_gap_ref > 0) max_gap_ref = P.max_gap_ref;
+		else if (P.max_frag_len > 0) { max_gap_ref = P.max_frag_len - qlen_sum; if (max_gap_ref < P.max_gap) max_gap_ref = P.max_gap; }
+		else max_gap_ref = P.max_gap;
+		const int rep_len = frag_rep[f];
+		bool tie = false;
+		for (uint32_t s = 0; s < n_segs; ++s) {
+			const int qlen = qlens[s]; int n = (int)W.reg_cnt[r0 + s];
+			AlReg *regs = fw.mreg[s]; AlAnchor *a = fw.seg_a[s];
+			if (n > 0 && qlen <= QMAX) {
+				const uint32_t *seq = rd_seq + rd_off[r0 + s];
+				for (int i = gl; i < qlen; i += GW) {                          // align.c:865-870
+					const uint8_t c = (uint8_t)((seq[i >> 3] >> ((i & 7) << 2)) & 0xf);
+					L.q0[i] = c; L.q1[qlen - 1 - i] = c < 4 ? 3 - c : 4;
+				}
+				GSYNC();
+				EzD ez; d_ez_reset(ez);
+				for (int i = 0; i < n; ++i) {                                  // align.c:875-906
+					AlReg r2; r2.cnt = 0;
+					d_align1(L, gl, ws, P, G, qlen, &regs[i], &r2, a, ez);
+					if (r2.cnt > 0) {
+						if (n + 1 <= fw.cap) {                                 // mm_insert_reg, align.c:847-855
+							for (int j = n - 1; j > i; --j) regs[j + 1] = regs[j];
+							regs[i + 1] = r2; ++n;
+						} else if (gl == 0) atomicAdd(&G.counters[7], 1ULL);
+					}
+				}
+			} else if (n > 0) { if (gl == 0) atomicAdd(&G.counters[7], 1ULL); n = 0; }
+			d_filter_regs(P, qlen, &n, regs);                                  // align.c:910-911
+			tie = d_hit_sort(&n, regs, fw.aux128, fw.rtmp) || tie;
+			d_set_parent(P.mask_level, n, regs, P.a * 2 + P.b, fw.aux64, fw.auxi);   // align_regs tail, map.c:264-268
+			d_select_sub(P.pri_ratio, P.k * 2, P.best_n, &n, regs, fw.auxi);
+			d_set_sam_pri(n, regs);
+			d_set_mapq(n, regs, P.min_chain_score, P.a, rep_len, lt);
+			n_regs[s] = n;
+			GSYNC();
+		}
+		if (n_segs == 2 && P.pe_ori >= 0) {
+			AlReg *rr[2] = {fw.mreg[0], fw.mreg[1]};
+			bool ovf = false;
+			d_pair(P, max_gap_ref, qlens, n_regs, rr, (PairEnt *)fw.rtmp, ws.sc, lt, &tie, &ovf);
+			if (ovf && gl == 0) atomicAdd(&G.counters[7], 1ULL);
+		}
+		for (uint32_t s = 0; s < n_segs; ++s) {
+			// worker_for un-flip (map.c:486-497) is applied on the host where the flip flag lives
+			W.reg_cnt[r0 + s] = (uint32_t)n_regs[s];
+		}
+		if (tie && gl == 0) atomicAdd(&G.counters[10], 1ULL);
+		GSYNC();
+	}
+}
+
+// compaction of the per-mate hit arrays into one dense output array
+extern "C" __global__ void __launch_bounds__(256)
+k_compact(const uint32_t *__restrict__ frag_first, WsBase W, const uint64_t *__restrict__ out_off, AlReg *__restrict__ out, int n_frag)
+{
+	const int f = blockIdx.x * blockDim.x + threadIdx.x;
+	if (f >= n_frag) return;
+	const uint32_t r0 = frag_first[f], n_segs = frag_first[f + 1] - r0;
+	if (W.frag_nu[f] == 0) return;
+	FragWs fw; d_frag_ws(W, (uint32_t)f, fw);
+	for (uint32_t s = 0; s < n_segs; ++s) {
+		const uint32_t n = W.reg_cnt[r0 + s]; AlReg *o = out + out_off[r0 + s];
+		for (uint32_t i = 0; i < n; ++i) o[i] = fw.mreg[s][i];
+	}
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side of the stage
+struct CastU64b { __host__ __device__ uint64_t operator()(const uint32_t &v) const { return (uint64_t)v; } };
+static int scan32(al_ctx_t *c, const uint32_t *in, uint64_t *out, int n)
+{
+	hipcub::TransformInputIterator<uint64_t, CastU64b, const uint32_t *> it(in, CastU64b());
+	size_t bytes = 0;
+	AL_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, it, out, n + 1, c->stream));
+	if (c->scan_tmp.ensure(bytes + 16)) return -1;
+	AL_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(c->scan_tmp.p, bytes, it, out, n + 1, c->stream));
+	return 0;
+}
+
+struct AlignState {            // lives in al_ctx_s::align_state (opaque there)
+	DevBuf<AlReg> regs0, mregs, rtmp, out;
+	DevBuf<AlAnchor> aux128, seg_a;
+	DevBuf<uint64_t> aux64, seg_u, nu_off, out_off;
+	DevBuf<int32_t> auxi;
+	DevBuf<uint32_t> reg_cnt, seg_na, arena;
+	DevBuf<uint8_t> gws;
+	DevBuf<float> logtab;
+	int logtab_a = -1;
+	uint64_t out_total = 0;
+};
+static std::map<al_ctx_t *, AlignState *> g_states;
+static std::mutex g_states_mtx;
+static AlignState *get_state(al_ctx_t *c)
+{
+	std::lock_guard<std::mutex> lk(g_states_mtx);
+	auto it = g_states.find(c);
+	if (it != g_states.end()) return it->second;
+	AlignState *s = new AlignState(); g_states[c] = s; return s;
+}
+void al_align_state_free(al_ctx_t *c)
+{
+	std::lock_guard<std::mutex> lk(g_states_mtx);
+	auto it = g_states.find(c);
+	if (it == g_states.end()) return;
+	AlignState *s = it->second;
+	s->regs0.release(); s->mregs.release(); s->rtmp.release(); s->out.release(); s->aux128.release(); s->seg_a.release(); s->aux64.release(); s->seg_u.release();
+	s->nu_off.release(); s->out_off.release(); s->auxi.release(); s->reg_cnt.release(); s->seg_na.release(); s->arena.release(); s->gws.release(); s->logtab.release();
+	delete s; g_states.erase(it);
+}
+
+int al_run_align_stage(al_ctx_t *c)
+{
+	hipStream_t s = c->stream;
+	AlignState *A = get_state(c);
+	const int nf = c->n_frag, nr = c->n_reads;
+	if (nf == 0) { AL_HIP_CHECK(hipEventRecord(c->ev[ST_REGS + 1], s)); return 0; }
+	// logf table from the HOST libm (the reference's logf is glibc's): logf((float)k / a) and logf((float)k)
+	if (A->logtab_a != c->opt.a) {
+		std::vector<float> h(2 * AL_LOGTAB_N);
+		for (int k = 0; k < AL_LOGTAB_N; ++k) { h[k] = logf((float)k / c->opt.a); h[AL_LOGTAB_N + k] = logf((float)k); }
+		if (A->logtab.ensure(2 * AL_LOGTAB_N)) return -1;
+		AL_HIP_CHECK(hipMemcpyAsync(A->logtab.p, h.data(), h.size() * 4, hipMemcpyHostToDevice, s));
+		AL_HIP_CHECK(hipStreamSynchronize(s));
+		A->logtab_a = c->opt.a;
+	}
+	// workspace sizes from the number of chains
+	if (A->nu_off.ensure(nf + 2)) return -1;
+	AL_HIP_CHECK(hipMemsetAsync(c->frag_nu.p + nf, 0, 4, s));
+	if (scan32(c, c->frag_nu.p, A->nu_off.p, nf)) return -1;
+	uint64_t nu_total = 0;
+	AL_HIP_CHECK(hipMemcpyAsync(&nu_total, A->nu_off.p + nf, 8, hipMemcpyDeviceToHost, s));
+	AL_HIP_CHECK(hipStreamSynchronize(s));
+	const uint64_t Btot = 2 * nu_total + 4ULL * nf + 8;
+	if (A->regs0.ensure(nu_total + 1) || A->mregs.ensure(2 * Btot) || A->rtmp.ensure(Btot) || A->aux128.ensure(Btot) || A->aux64.ensure(Btot) || A->auxi.ensure(2 * Btot) ||
+	    A->seg_u.ensure(2 * nu_total + 2) || A->seg_a.ensure(c->n_anchor_total + 1) || A->reg_cnt.ensure(nr + 1) || A->seg_na.ensure(nr + 1) || A->out_off.ensure(nr + 2)) return -1;
+	WsBase W;
+	W.regs0 = A->regs0.p; W.mregs = A->mregs.p; W.rtmp = A->rtmp.p; W.aux128 = A->aux128.p; W.seg_a = A->seg_a.p; W.aux64 = A->aux64.p; W.seg_u = A->seg_u.p; W.auxi = A->auxi.p;
+	W.nu_off = A->nu_off.p; W.frag_nu = c->frag_nu.p; W.a_off = c->a_off.p; W.reg_cnt = A->reg_cnt.p; W.seg_na = A->seg_na.p;
+	hipLaunchKernelGGL(k_regs, dim3((nf + 255) / 256), dim3(256), 0, s, c->chained.p, c->u.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, nf, c->P, c->counters.p);
+	AL_HIP_CHECK(hipEventRecord(c->ev[ST_REGS + 1], s));
+	// extension stage geometry
+	int Lmax = 0; for (int i = 0; i < nr; ++i) Lmax = std::max<int>(Lmax, (int)c->h_rd_len[i]);
+	const al_mapopt_t &o = c->opt;
+	int ext = Lmax; { int l = Lmax; ext = l + (l * o.a + o.end_bonus > o.q ? (l * o.a + o.end_bonus - o.q) / o.e : 0); }
+	const int tbound = std::max(2 * Lmax + 16, ext + 16);
+	const int bw = (int)(o.bw * 1.5 + 1.);
+	const int ncol = ((std::min(Lmax, bw + 1) + 15) / 16 + 1);
+	const size_t p_bytes = ((size_t)(Lmax + tbound) * ncol * 16 + 63) / 64 * 64;
+	const size_t cig_words = ((size_t)(Lmax + tbound) + 16 + 15) / 16 * 16;
+	const size_t stride = p_bytes + cig_words * 8 + AL_PAIR_SC_CAP * 8;
+	int nb = (nf + 3) / 4; const int nb_max = 256 * 4; if (nb > nb_max) nb = nb_max;
+	if (A->gws.ensure((size_t)nb * 4 * stride + 64)) return -1;
+	const uint64_t arena_cap = (uint64_t)nr * 12 + 4096 + (uint64_t)c->n_bases / 8;
+	if (A->arena.ensure(arena_cap)) return -1;
+	AlignShared G; G.S4 = c->di.S4; G.seq_off = c->di.seq_off; G.seq_len = c->di.seq_len; G.arena = A->arena.p; G.arena_cnt = c->counters.p + 11; G.arena_cap = arena_cap; G.counters = c->counters.p;
+	AlLogTab lt; lt.t = A->logtab.p; lt.miss = c->counters.p + 8;
+	if (Lmax <= 256 && tbound <= 512) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_align<512, 256>), dim3(nb), dim3(64), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, c->frag_first.p, c->frag_rep.p, W, G, lt, A->gws.p, stride, p_bytes, cig_words, nf, c->P);
+	else if (Lmax <= 512 && tbound <= 1024) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_align<1024, 512>), dim3(nb), dim3(64), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, c->frag_first.p, c->frag_rep.p, W, G, lt, A->gws.p, stride, p_bytes, cig_words, nf, c->P);
+	else { fprintf(stderr, "[airlift] reads longer than 512 bp are not supported by the device extension kernel (max read length in batch: %d)\n", Lmax); return -3; }
+	AL_HIP_CHECK(hipGetLastError());
+	// dense output
+	AL_HIP_CHECK(hipMemsetAsync(A->reg_cnt.p + nr, 0, 4, s));
+	if (scan32(c, A->reg_cnt.p, A->out_off.p, nr)) return -1;
+	uint64_t out_total = 0;
+	AL_HIP_CHECK(hipMemcpyAsync(&out_total, A->out_off.p + nr, 8, hipMemcpyDeviceToHost, s));
+	AL_HIP_CHECK(hipStreamSynchronize(s));
+	if (A->out.ensure(out_total + 1)) return -1;
+	A->out_total = out_total;
+	hipLaunchKernelGGL(k_compact, dim3((nf + 255) / 256), dim3(256), 0, s, c->frag_first.p, W, A->out_off.p, A->out.p, nf);
+	AL_HIP_CHECK(hipGetLastError());
+	return 0;
+}
+
+int al_fetch_align(al_ctx_t *c, int *n_regs, al_reg1_t **regs, int *rep_len)
+{
+	AlignState *A = get_state(c);
+	const int nf = c->n_frag, nr = c->n_reads;
+	AL_HIP_CHECK(hipSetDevice(c->device));
+	unsigned long long h[16]; AL_HIP_CHECK(hipMemcpy(h, c->counters.p, sizeof(h), hipMemcpyDeviceToHost));
+	if (h[7] || h[8] || h[9]) { fprintf(stderr, "[airlift] device pipeline error: limit=%llu logf_miss=%llu cigar_arena_overflow=%llu\n", h[7], h[8], h[9]); return -4; }
+	std::vector<uint64_t> off(nr + 1); std::vector<AlReg> out(A->out_total); std::vector<int32_t> rep(nf);
+	if (nf == 0) return 0;
+	AL_HIP_CHECK(hipMemcpy(off.data(), A->out_off.p, (size_t)(nr + 1) * 8, hipMemcpyDeviceToHost));
+	if (A->out_total) AL_HIP_CHECK(hipMemcpy(out.data(), A->out.p, A->out_total * sizeof(AlReg), hipMemcpyDeviceToHost));
+	AL_HIP_CHECK(hipMemcpy(rep.data(), c->frag_rep.p, (size_t)nf * 4, hipMemcpyDeviceToHost));
+	const uint64_t n_arena = h[11];
+	std::vector<uint32_t> arena(n_arena);
+	if (n_arena) AL_HIP_CHECK(hipMemcpy(arena.data(), A->arena.p, n_arena * 4, hipMemcpyDeviceToHost));
+	for (int f = 0; f < nf; ++f) if (rep_len) rep_len[f] = rep[f];
+	for (int i = 0; i < nr; ++i) {
+		const int n = (int)(off[i + 1] - off[i]);
+		n_regs[i] = n; regs[i] = nullptr;
+		if (n == 0) continue;
+		al_reg1_t *o = (al_reg1_t *)calloc(n, sizeof(al_reg1_t));
+		const int qlen = (int)c->h_rd_len[i];
+		for (int k = 0; k < n; ++k) {
+			const AlReg &r = out[off[i] + k]; al_reg1_t &q = o[k];
+			q.id = r.id; q.cnt = r.cnt; q.rid = r.rid; q.score = r.score; q.qs = r.qs; q.qe = r.qe; q.rs = r.rs; q.re = r.re;
+			q.parent = r.parent; q.subsc = r.subsc; q.mlen = r.mlen; q.blen = r.blen; q.n_sub = r.n_sub; q.score0 = r.score0;
+			q.mapq = r.mapq & 0xff; q.split = r.flags & 3; q.rev = (r.flags & ALR_REV) ? 1 : 0; q.inv = 0; q.sam_pri = (r.flags & ALR_SAM_PRI) ? 1 : 0;
+			q.proper_frag = (r.flags & ALR_PROPER) ? 1 : 0; q.pe_thru = (r.flags & ALR_PE_THRU) ? 1 : 0; q.seg_split = (r.flags & ALR_SEG_SPLIT) ? 1 : 0;
+			q.seg_id = (r.flags >> 8) & 0xff; q.split_inv = 0; q.hash = r.hash; q.dp_score = r.dp_score; q.dp_max = r.dp_max; q.dp_max2 = r.dp_max2; q.n_ambi = r.n_ambi;
+			q.n_cigar = (r.flags & ALR_HAS_P) ? r.n_cigar : 0; q.cigar = nullptr;
+			if (q.n_cigar) { q.cigar = (uint32_t *)malloc((size_t)q.n_cigar * 4); memcpy(q.cigar, arena.data() + r.cigar_off, (size_t)q.n_cigar * 4); }
+			if (c->h_flip[i]) { const int t = q.qs; q.qs = qlen - q.qe; q.qe = qlen - t; q.rev = !q.rev; }   // map.c:486-497
+		}
+		regs[i] = o;
+	}
+	return 0;
+}

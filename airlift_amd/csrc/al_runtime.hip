@@ -31,7 +31,7 @@ template <typename T> int DevBuf<T>::ensure(size_t n, bool keep, hipStream_t s)
 	return 0;
 }
 template struct DevBuf<uint32_t>; template struct DevBuf<uint64_t>; template struct DevBuf<int32_t>; template struct DevBuf<AlAnchor>;
-template struct DevBuf<AlMatch>; template struct DevBuf<unsigned long long>; template struct DevBuf<uint8_t>; template struct DevBuf<AlReg>;
+template struct DevBuf<float>; template struct DevBuf<AlMatch>; template struct DevBuf<unsigned long long>; template struct DevBuf<uint8_t>; template struct DevBuf<AlReg>;
 
 static const char *g_stage_names[ST_N] = { "sketch", "seed_lookup", "scan", "anchor_sort", "chain", "rechain", "regs", "align" };
 extern "C" const char *al_stage_name(int i) { return i >= 0 && i < ST_N ? g_stage_names[i] : ""; }
@@ -96,10 +96,12 @@ extern "C" al_ctx_t *al_ctx_init(const al_idx_t *mi, const al_mapopt_t *opt, int
 	return c;
 }
 
+void al_align_state_free(al_ctx_t *c);
 extern "C" void al_ctx_destroy(al_ctx_t *c)
 {
 	if (!c) return;
 	(void)hipSetDevice(c->device);
+	al_align_state_free(c);
 	if (c->stream) (void)hipStreamSynchronize(c->stream);
 	c->rd_seq.release(); c->rd_len.release(); c->frag_first.release(); c->frag_hash.release(); c->mini_cnt.release(); c->frag_nm.release(); c->frag_na.release();
 	c->frag_nu.release(); c->rechain_list.release(); c->tmp_u32.release(); c->rd_off.release(); c->mini_off.release(); c->a_off.release(); c->u.release();
