@@ -54,6 +54,7 @@ struct al_ctx_s {
 	DevBuf<uint64_t> seg_u;
 	uint64_t n_regs_cap_total = 0, n_cigar_cap_total = 0;
 	bool ran = false;
+	uint64_t stat_bytes_in = 0;
 	al_batch_stat_t stat;
 };
 

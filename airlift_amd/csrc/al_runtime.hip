@@ -152,6 +152,7 @@ extern "C" int al_batch_upload(al_ctx_t *c, int n_frag, const int *n_segs, const
 	}
 	c->h_frag_first[n_frag] = r; c->h_rd_off[n_reads] = words; c->h_mini_off[n_reads] = mtot; c->h_rd_len[n_reads] = 0;
 	c->n_bases = bases; c->mini_total = mtot; c->seq_words = words;
+	{ uint64_t b = 0; for (int i = 0; i < n_reads; ++i) b += (c->h_rd_len[i] * 3 + 7) / 8; c->stat_bytes_in = b; }   // 2-bit base + 1-bit N mask (SURVEY 8d B_in)
 	c->h_rd_seq.assign(words + 1, 0);
 	for (int i = 0; i < n_reads; ++i) {     // 4-bit packing in mapping orientation (mate 2 reverse-complemented: map.c:468, bseq.h:46-58)
 		uint32_t *w = c->h_rd_seq.data() + c->h_rd_off[i]; const char *s = seqs[i]; const int L = qlens[i];
@@ -286,24 +287,41 @@ extern "C" int al_batch_run(al_ctx_t *c)
 	c->ran = true;
 	// counters + algorithmic bytes
 	unsigned long long h[16]; AL_HIP_CHECK(hipMemcpy(h, c->counters.p, sizeof(h), hipMemcpyDeviceToHost));
-	std::vector<uint32_t> mc(c->n_reads), nu(c->n_frag);
-	if (c->n_reads) AL_HIP_CHECK(hipMemcpy(mc.data(), c->mini_cnt.p, (size_t)c->n_reads * 4, hipMemcpyDeviceToHost));
-	if (c->n_frag) AL_HIP_CHECK(hipMemcpy(nu.data(), c->frag_nu.p, (size_t)c->n_frag * 4, hipMemcpyDeviceToHost));
 	al_batch_stat_t &st = c->stat; memset(&st, 0, sizeof(st));
 	st.n_frag = c->n_frag; st.n_reads = c->n_reads; st.n_bases = c->n_bases;
-	for (auto v : mc) st.n_mini += v;
-	for (auto v : nu) st.n_chain += v;
-	st.n_anchor = c->n_anchor_total; st.n_rechain = c->n_rechain; st.n_heap_fallback = h[0]; st.n_sort_tie_flag = h[1];
+	st.n_mini = ~0ULL; st.n_chain = ~0ULL;   // filled lazily by al_batch_stat()
+	st.n_anchor = c->n_anchor_total; st.n_rechain = c->n_rechain; st.n_heap_fallback = h[0]; st.n_sort_tie_flag = h[1] + h[10];
 	st.n_regs_aln = h[4]; st.n_refbases = h[5]; st.n_cigar = h[6];
-	double b_in = 0; for (int i = 0; i < c->n_reads; ++i) b_in += (c->h_rd_len[i] * 3 + 7) / 8;
-	st.bytes_in = (uint64_t)b_in; st.bytes_out = 48 * st.n_regs_aln + 4 * st.n_cigar;
-	st.algorithmic_bytes = b_in + 16.0 * st.n_mini + 8.0 * st.n_anchor + 32.0 * st.n_anchor + 0.5 * st.n_refbases + (double)st.bytes_out;
+	st.bytes_in = c->stat_bytes_in; st.bytes_out = 48 * st.n_regs_aln + 4 * st.n_cigar;
 	st.ms_total = c->ms_total; st.n_stage = ST_N;
 	for (int i = 0; i < ST_N; ++i) st.ms_kernel[i] = c->ms_stage[i];
 	return 0;
 }
 
-extern "C" void al_batch_stat(const al_ctx_t *c, al_batch_stat_t *st) { *st = c->stat; }
+__global__ void k_sum_u32(const uint32_t *a, int n, unsigned long long *out)
+{
+	unsigned long long v = 0;
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) v += a[i];
+	for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
+	if ((threadIdx.x & 63) == 0 && v) atomicAdd(out, v);
+}
+extern "C" void al_batch_stat(const al_ctx_t *cc, al_batch_stat_t *out)
+{
+	al_ctx_t *c = const_cast<al_ctx_t *>(cc);
+	al_batch_stat_t &st = c->stat;
+	if (c->ran && st.n_mini == ~0ULL && hipSetDevice(c->device) == hipSuccess) {
+		unsigned long long h[2] = {0, 0};
+		(void)hipMemsetAsync(c->counters.p + 12, 0, 16, c->stream);
+		if (c->n_reads) hipLaunchKernelGGL(k_sum_u32, dim3(256), dim3(256), 0, c->stream, c->mini_cnt.p, c->n_reads, c->counters.p + 12);
+		if (c->n_frag) hipLaunchKernelGGL(k_sum_u32, dim3(256), dim3(256), 0, c->stream, c->frag_nu.p, c->n_frag, c->counters.p + 13);
+		(void)hipMemcpyAsync(h, c->counters.p + 12, 16, hipMemcpyDeviceToHost, c->stream);
+		(void)hipStreamSynchronize(c->stream);
+		st.n_mini = h[0]; st.n_chain = h[1];
+		// B = B_in + M*16 + A*8 + 2*A*16 + W/2 + B_out
+		st.algorithmic_bytes = (double)st.bytes_in + 16.0 * st.n_mini + 8.0 * st.n_anchor + 32.0 * st.n_anchor + 0.5 * st.n_refbases + (double)st.bytes_out;
+	}
+	*out = st;
+}
 
 // ---------------------------------------------------------------------------------------------
 // stage taps
@@ -385,4 +403,18 @@ extern "C" int64_t al_dbg_copy(al_ctx_t *c, const char *name, void *dst, int64_t
 	if (hipSetDevice(c->device) != hipSuccess) return -1;
 	if (bytes > 0 && hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) != hipSuccess) return -1;
 	return bytes;
+}
+
+// Flat upload for synthetic / benchmark batches: sequences concatenated in read order, names = "<prefix><fragment index>"
+// for every read of a fragment (what BBMap rename.sh produces upstream: extract_sequence.sh:18).
+extern "C" int al_batch_upload_flat(al_ctx_t *c, int n_frag, const int *n_segs, const int *qlens, const char *seq_concat, const char *name_prefix, int64_t first_index)
+{
+	int nr = 0; for (int f = 0; f < n_frag; ++f) nr += n_segs[f];
+	std::vector<const char *> seqs(nr), names(nr); std::vector<std::string> nm(n_frag);
+	const char *p = seq_concat; int r = 0;
+	for (int f = 0; f < n_frag; ++f) {
+		nm[f] = std::string(name_prefix ? name_prefix : "") + std::to_string(first_index + f);
+		for (int j = 0; j < n_segs[f]; ++j, ++r) { seqs[r] = p; p += qlens[r]; names[r] = nm[f].c_str(); }
+	}
+	return al_batch_upload(c, n_frag, n_segs, qlens, seqs.data(), names.data());
 }

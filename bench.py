@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""bench.py -- reads/s remapped by the MI355X re-alignment hot path (BASELINE.json metric).
+
+A "step" is one pass of the whole hot path (minimizer sketch -> seed lookup -> anchor sort -> chaining ->
+banded SW extension -> MAPQ/pairing -> alignment records) over one batch of synthetic 150 bp paired-end reads that is
+already resident in HBM.  Workload at N=1: BASELINE.json configs[1] (yeast-sized reference pair, 150 bp PE; the
+synthetic stand-in C2 of SURVEY.md 8(d), generated here with fixed seeds).  N>1: one process per GPU, reads sharded by
+rank (every rank holds the full index; weak scaling), one 16-byte RCCL all-gather per step for the merged-output offsets.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured streaming ceiling
+
+
+def make_workload(pairs, read_len, seed, ref):
+    """ASCII reads for `pairs` fragments, concatenated fragment-major (mate1, mate2, mate1, ...)."""
+    import gen_synth as g
+    lut = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    out = np.empty((pairs, 2, read_len), dtype=np.uint8)
+    chunk = 250_000
+    for s in range(0, pairs, chunk):
+        n = min(chunk, pairs - s)
+        r1, r2 = g.simulate_pairs(ref, n, read_len, seed=seed + s)
+        out[s:s + n, 0] = lut[r1]; out[s:s + n, 1] = lut[r2]
+    return out
+
+
+def write_fastq_sample(path, arr, mate, prefix="realigned_"):
+    n, _, L = arr.shape
+    q = b"I" * L
+    with open(path, "wb") as f:
+        f.write(b"".join(b"@" + (prefix + str(i)).encode() + b"\n" + arr[i, mate].tobytes() + b"\n+\n" + q + b"\n" for i in range(n)))
+
+
+def cpu_baseline(tmp, ref_fa, arr, n_pairs):
+    """Times the CPU comparator on a bounded sample of the same workload (rank 0, N=1 only)."""
+    cores = os.cpu_count() or 1
+    write_fastq_sample(os.path.join(tmp, "cb_1.fq"), arr[:n_pairs], 0)
+    write_fastq_sample(os.path.join(tmp, "cb_2.fq"), arr[:n_pairs], 1)
+    write_fastq_sample(os.path.join(tmp, "one_1.fq"), arr[:1], 0)
+    write_fastq_sample(os.path.join(tmp, "one_2.fq"), arr[:1], 1)
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "mm2ref")
+    if os.path.exists(ref_bin):
+        kind, cmd = "reference", [ref_bin, "-t", str(cores)]
+    else:
+        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "al_oracle"], check=True)
+        kind, cmd = "port", [os.path.join(ROOT, "oracle", "al_oracle"), "-t", str(cores)]
+    dn = open(os.devnull, "wb")
+    t0 = time.time(); subprocess.run(cmd + [ref_fa, "one_1.fq", "one_2.fq"], cwd=tmp, stdout=dn, stderr=dn, check=True); t_idx = time.time() - t0
+    t0 = time.time(); subprocess.run(cmd + [ref_fa, "cb_1.fq", "cb_2.fq"], cwd=tmp, stdout=dn, stderr=dn, check=True); t_all = time.time() - t0
+    t_map = max(t_all - t_idx, 1e-6)
+    return {"value": 2 * n_pairs / t_map, "unit": "reads/s", "cores": cores, "kind": kind,
+            "sample": "%d pairs x 150 bp of the same workload, SAM to /dev/null, index build (%.2f s) subtracted, wall %.2f s" % (n_pairs, t_idx, t_all)}
+
+
+def parity_sample(tmp, ref_fa, n_pairs):
+    """airlift-align (HIP) vs the CPU oracle on the first n_pairs of the workload: SAM bytes must be identical."""
+    cli = os.path.join(ROOT, "airlift_amd", "bin", "airlift-align")
+    orc = os.path.join(ROOT, "oracle", "al_oracle")
+    if not os.path.exists(orc):
+        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "al_oracle"], check=True)
+    a = subprocess.run([cli, "-ax", "sr", ref_fa, "ps_1.fq", "ps_2.fq"], cwd=tmp, capture_output=True)
+    b = subprocess.run([orc, "-t", str(os.cpu_count() or 1), ref_fa, "ps_1.fq", "ps_2.fq"], cwd=tmp, capture_output=True)
+    return {"pairs": n_pairs, "identical": a.returncode == 0 and b.returncode == 0 and a.stdout == b.stdout}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--pairs", type=int, default=2_000_000, help="fragments per GPU per step (C2: 2 M pairs)")
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--cpu-sample-pairs", type=int, default=150_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local if world > 1 else 0)
+
+    import gen_synth as g
+    import airlift_amd as A
+    L = A.load()
+    L.al_batch_upload_flat.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_char_p, C.c_int64]
+    L.al_batch_upload_flat.restype = C.c_int
+
+    # reference pair stand-in C2: 16 contigs, 12.16 Mbp, 150 planted duplications; identical on every rank
+    rk, _ = g.CONFIGS["c2"]
+    t0 = time.time()
+    ref = g.make_reference(**rk)
+    lut = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    idx = A.Index(seqs=[lut[c].tobytes() for _, c in ref], names=[n.encode() for n, _ in ref])
+    t_index = time.time() - t0
+    arr = make_workload(a.pairs, a.read_len, 20261002 + 7919 * rank, ref)
+    ctx = A.Context(idx, device=local if world > 1 else 0)
+    nf = a.pairs
+    n_segs = (C.c_int * nf)(*([2] * nf)); qlens = (C.c_int * (2 * nf))(*([a.read_len] * (2 * nf)))
+    t0 = time.time()
+    rc = L.al_batch_upload_flat(ctx.h, nf, n_segs, qlens, arr.ctypes.data_as(C.c_char_p), b"realigned_", nf * rank)
+    if rc != 0:
+        raise SystemExit("upload failed")
+    t_upload = time.time() - t0
+    ctx.n_frag, ctx.n_reads = nf, 2 * nf
+
+    def step():
+        ctx.run()
+        if dist is not None:   # merged-output offsets: {n_records, n_bytes} per rank over RCCL/xGMI
+            st = ctx.stat()
+            mine = torch.tensor([int(st.n_regs_aln), int(st.bytes_out)], dtype=torch.int64, device=dev)
+            allr = torch.empty(2 * world, dtype=torch.int64, device=dev)
+            dist.all_gather_into_tensor(allr, mine)
+
+    for _ in range(a.warmup):
+        step()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    stage_ms = np.zeros(16); t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+        st = ctx.stat()
+        stage_ms += np.array(list(st.ms_kernel))
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    st = ctx.stat()
+    if rank == 0:
+        names = [L.al_stage_name(i).decode() for i in range(st.n_stage)]
+        per = {names[i]: float(stage_ms[i] / a.steps) for i in range(st.n_stage)}
+        dom = max(("sketch", "seed_lookup", "anchor_sort", "chain", "regs", "align"), key=lambda k: per[k])
+        alg = float(st.algorithmic_bytes)
+        achieved = alg / (per[dom] * 1e-3) / 1e9
+        out = {
+            "metric": "reads/sec remapped (150 bp PE)", "value": 2.0 * a.pairs * world * a.steps / dt, "unit": "reads/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u8/int32 (int8 SW lanes, u64 hashes)", "data": "synthetic",
+            "config": {"workload": "C2: yeast-sized synthetic reference pair (16 contigs, 12.16 Mbp, 150 planted duplications), %d x 2 x %d bp PE reads per GPU per step, preset sr" % (a.pairs, a.read_len),
+                       "reads_per_step_per_gpu": 2 * a.pairs, "read_len": a.read_len, "sharding": "reads sharded by rank, index replicated"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": dom, "kernel_ms": per[dom], "algorithmic_bytes_per_launch": alg, "algorithmic_bytes_per_read": alg / (2.0 * a.pairs),
+                         "pipeline_GBps": alg / (sum(per.values()) * 1e-3) / 1e9},
+            "stages_ms": per,
+            "counters": {"minimizers_per_read": st.n_mini / (2.0 * a.pairs), "anchors_per_pair": st.n_anchor / float(a.pairs), "chains_per_pair": st.n_chain / float(a.pairs),
+                         "regions_aligned_per_read": st.n_regs_aln / (2.0 * a.pairs), "ref_bases_per_region": st.n_refbases / max(1.0, float(st.n_regs_aln)),
+                         "rechain": int(st.n_rechain), "heap_fallback": int(st.n_heap_fallback), "sort_tie_flags": int(st.n_sort_tie_flag)},
+            "host": {"index_build_s": t_index, "pack_upload_s": t_upload},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            tmp = tempfile.mkdtemp(prefix="al_bench_")
+            g.write_fasta(os.path.join(tmp, "ref.fa"), ref)
+            out["cpu_baseline"] = cpu_baseline(tmp, "ref.fa", arr, min(a.cpu_sample_pairs, a.pairs))
+            write_fastq_sample(os.path.join(tmp, "ps_1.fq"), arr[:5000], 0); write_fastq_sample(os.path.join(tmp, "ps_2.fq"), arr[:5000], 1)
+            out["parity_sample"] = parity_sample(tmp, "ref.fa", min(5000, a.pairs))
+        print(json.dumps(out))
+    ctx.close(); idx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

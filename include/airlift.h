@@ -126,6 +126,10 @@ int  al_map_file_frag(const al_idx_t *mi, int n_segs, const char **fn, const al_
 /* Pack + upload a batch; returns 0.  The batch stays resident until the next upload. */
 int  al_batch_upload(al_ctx_t *ctx, int n_frag, const int *n_segs, const int *qlens, const char *const *seqs,
                      const char *const *qnames);
+/* Same, for flat buffers: sequences concatenated in read order (not NUL-terminated), every read of fragment f
+ * named "<name_prefix><first_index+f>" (BBMap rename.sh naming, extract_sequence.sh:18). */
+int  al_batch_upload_flat(al_ctx_t *ctx, int n_frag, const int *n_segs, const int *qlens, const char *seq_concat,
+                          const char *name_prefix, int64_t first_index);
 /* Run the whole hot path (sketch .. alignment records) on the resident batch; results stay on device. */
 int  al_batch_run(al_ctx_t *ctx);
 /* Fetch results of the last al_batch_run into host reg arrays (same contract as al_map_batch). */
@@ -152,6 +156,8 @@ int  al_dbg_anchors(al_ctx_t *ctx, int frag_idx, uint64_t *xy, int cap, int *rep
 int  al_dbg_chains(al_ctx_t *ctx, int frag_idx, uint64_t *u, int cap_u, uint64_t *xy, int cap_a);
 /* a8 ALSER counter (map.c:299-312) for every read of the resident batch mapped as single segments */
 int  al_dbg_alser_count(al_ctx_t *ctx, int64_t *total);
+/* bulk copy of a named device array of the resident batch (tests); returns bytes copied or -1 */
+int64_t al_dbg_copy(al_ctx_t *ctx, const char *name, void *dst, int64_t max_bytes);
 
 /* SAM text (format.c:116-135, 387-544) */
 int  al_write_sam_hdr(FILE *out, const al_idx_t *mi, const char *rg, char *rg_id_out /* >=256 bytes or NULL */);

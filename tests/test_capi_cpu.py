@@ -1,0 +1,126 @@
+"""CPU tests (-m "not gpu"): the C-ABI library loads, exports every symbol include/airlift.h declares, the host-side
+logic (options, index build, SAM header, read sharding) is right, and there is no CPU compute path."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def A():
+    import airlift_amd
+    if not os.path.exists(airlift_amd.lib_path()):
+        airlift_amd.build()
+    airlift_amd.load()
+    return airlift_amd
+
+
+def test_exports_every_declared_symbol(A):
+    hdr = open(os.path.join(ROOT, "include", "airlift.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = sorted(set(re.findall(r"\b(al_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(names) >= 25
+    L = A.load()
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, missing
+
+
+def test_sr_preset_matches_reference_constants(A):
+    """options.c:105-122 over options.c:13-49 (SURVEY.md 8 preset constants)."""
+    L = A.load(); io, mo = A.IdxOpt(), A.MapOpt()
+    assert L.al_set_opt(None, C.byref(io), C.byref(mo)) == 0
+    assert L.al_set_opt(b"sr", C.byref(io), C.byref(mo)) == 0
+    assert (io.k, io.w) == (21, 11)
+    got = dict(a=mo.a, b=mo.b, q=mo.q, e=mo.e, q2=mo.q2, e2=mo.e2, zdrop=mo.zdrop, zdrop_inv=mo.zdrop_inv, end_bonus=mo.end_bonus,
+               max_frag_len=mo.max_frag_len, max_gap=mo.max_gap, bw=mo.bw, min_cnt=mo.min_cnt, min_chain_score=mo.min_chain_score,
+               min_dp_max=mo.min_dp_max, best_n=mo.best_n, mid_occ=mo.mid_occ, max_occ=mo.max_occ, pe_ori=mo.pe_ori, pe_bonus=mo.pe_bonus,
+               seed=mo.seed, sc_ambi=mo.sc_ambi, max_chain_skip=mo.max_chain_skip, max_chain_iter=mo.max_chain_iter)
+    exp = dict(a=2, b=8, q=12, e=2, q2=24, e2=1, zdrop=100, zdrop_inv=100, end_bonus=10, max_frag_len=800, max_gap=100, bw=100, min_cnt=2,
+               min_chain_score=25, min_dp_max=40, best_n=20, mid_occ=1000, max_occ=5000, pe_ori=1, pe_bonus=33, seed=11, sc_ambi=1,
+               max_chain_skip=25, max_chain_iter=5000)
+    assert got == exp
+    assert abs(mo.pri_ratio - 0.5) < 1e-7 and abs(mo.mask_level - 0.5) < 1e-7
+    assert L.al_check_opt(C.byref(io), C.byref(mo)) == 0
+    assert L.al_set_opt(b"map-ont", C.byref(io), C.byref(mo)) == -1       # not on AirLift's path
+    mo.e = 0
+    assert L.al_check_opt(C.byref(io), C.byref(mo)) < 0                   # options.c:168-172
+
+
+def test_index_matches_oracle_sketch(A, oracle_bin, golden_unpacked):
+    """Host index build: same minimizer multiset as the oracle's sketch of every contig."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from gpu_util import OracleLib
+    d = golden_unpacked["g2_100se"]
+    names, seqs, _ = A.read_fastx(os.path.join(d, "syn.fa"))
+    idx = A.Index(fasta=os.path.join(d, "syn.fa"))
+    st = idx.stat()
+    orc = OracleLib()
+    tot, keys = 0, set()
+    for s in seqs:
+        m = orc.sketch(s)
+        tot += len(m); keys.update((m[:, 0] >> np.uint64(8)).tolist())
+    assert st["n_pos"] == tot and st["n_keys"] == len(keys) and st["n_bases"] == sum(len(s) for s in seqs)
+    assert idx.names == [n.decode() for n in names]
+    idx.close()
+
+
+def test_no_cpu_path(A, golden_unpacked):
+    """Without a HIP device the context creation must fail loudly (no fallback)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    d = golden_unpacked["g4_q2"]
+    idx = A.Index(fasta=os.path.join(d, "t2.fa"))
+    with pytest.raises(A.AirliftError):
+        A.Context(idx)
+    r = subprocess.run([os.path.join(ROOT, "airlift_amd", "bin", "airlift-align"), "-ax", "sr", "t2.fa", "q2.fa"], cwd=d, capture_output=True)
+    assert r.returncode != 0 and b"no HIP device" in r.stderr
+    idx.close()
+
+
+def test_sam_header(A, golden_unpacked, tmp_path):
+    """@SQ/@RG/@PG lines (format.c:116-135) through the C-ABI."""
+    d = golden_unpacked["g1_mt150pe"]
+    idx = A.Index(fasta=os.path.join(d, "MT-human.fa"))
+    L = A.load()
+    libc = C.CDLL(None); libc.fopen.restype = C.c_void_p; libc.fopen.argtypes = [C.c_char_p, C.c_char_p]; libc.fclose.argtypes = [C.c_void_p]
+    p = str(tmp_path / "h.sam").encode()
+    fp = libc.fopen(p, b"w")
+    rgid = C.create_string_buffer(256)
+    L.al_write_sam_hdr.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_char_p]
+    L.al_write_sam_hdr(fp, idx.h, b"@RG\\tID:S1\\tSM:S1\\tPL:illumina\\tLB:S1", rgid)
+    libc.fclose(fp)
+    exp = [l for l in open(os.path.join(d, "expected.sam")).read().split("\n") if l.startswith("@")]
+    assert open(p.decode()).read().split("\n")[:-1] == exp
+    assert rgid.value == b"S1"
+    idx.close()
+
+
+def _shard_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from airlift_amd.shard import frag_range, output_offsets
+    lo, hi = frag_range(1001, rank, world)
+    n_rec = 2 * (hi - lo) + rank; n_bytes = 300 * n_rec
+    q.put((rank, lo, hi) + output_offsets(n_rec, n_bytes, rank, world, device="cpu", dist=dist))
+    dist.barrier(); dist.destroy_process_group()
+
+
+def test_read_sharding_two_ranks_gloo():
+    """N>1 path on CPU: contiguous fragment ranges + the one all-gather that yields merged-output offsets."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn"); q = ctx.Queue(); port = 29500 + os.getpid() % 2000
+    ps = [ctx.Process(target=_shard_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in ps]; res = sorted(q.get(timeout=120) for _ in ps); [p.join(60) for p in ps]
+    (r0, lo0, hi0, ro0, bo0, tr0, tb0), (r1, lo1, hi1, ro1, bo1, tr1, tb1) = res
+    assert (lo0, hi0, lo1, hi1) == (0, 500, 500, 1001)
+    assert ro0 == 0 and bo0 == 0 and ro1 == 2 * 500 and bo1 == 300 * 1000
+    assert tr0 == tr1 == 1000 + 1003 and tb0 == tb1 == 300 * 2003

@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Summarises rocprofv3 CSV output (kernel stats + PMC passes) into a small markdown table for profiles/."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+d = sys.argv[1]
+print("# rocprofv3 summary (%s)\n" % os.path.basename(d))
+stats = glob.glob(os.path.join(d, "trace", "**", "*kernel_stats.csv"), recursive=True)
+if stats:
+    print("## kernel stats (--kernel-trace --stats)\n")
+    print("| kernel | calls | total ms | avg us | % |")
+    print("|---|---|---|---|---|")
+    for row in csv.DictReader(open(stats[0])):
+        nm = row.get("Name", "")[:70]
+        print("| %s | %s | %.3f | %.1f | %s |" % (nm, row.get("Calls"), float(row.get("TotalDurationNs", 0)) / 1e6, float(row.get("AverageNs", 0)) / 1e3, row.get("Percentage")))
+for tag, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+    files = glob.glob(os.path.join(d, tag, "**", "*counter_collection.csv"), recursive=True)
+    if not files:
+        continue
+    agg = defaultdict(lambda: [0, 0.0])
+    for row in csv.DictReader(open(files[0])):
+        if row.get("Counter_Name") != ctr:
+            continue
+        k = row.get("Kernel_Name", "")[:70]
+        agg[k][0] += 1; agg[k][1] += float(row.get("Counter_Value", 0))
+    print("\n## %s per kernel (raw counter units: KiB as reported; gfx950 FETCH_SIZE under-reports wide streaming reads by 2x)\n" % ctr)
+    print("| kernel | dispatches | sum | per dispatch |")
+    print("|---|---|---|---|")
+    for k, (n, v) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:12]:
+        print("| %s | %d | %.0f | %.1f |" % (k, n, v, v / max(n, 1)))
+for f in ("bench_trace.json",):
+    p = os.path.join(d, f)
+    if os.path.exists(p):
+        print("\n## bench line under the profiler\n\n```\n%s\n```" % open(p).read().strip()[:3000])
