@@ -1,0 +1,199 @@
+// al_dev_ksw.h -- register-resident ("systolic") form of the extension DP for one 16-lane group.
+//
+// Same arithmetic as d_ksw_lds() in al_kernels_align.hip (= ksw_extd2_sse, ksw2_extd2_sse.c:26-393) but the seven
+// int8 state rows and the int32 H row live in VGPRs: lane l of the group owns cells t = 16*b + l for b < NB, packed as
+//   A[b] = x | v<<8 | x2<<16 | u<<24        B[b] = y | y2<<8 | s<<16 | sf<<24        H[b]
+// The left-neighbour values (x,v,x2)[t-1] arrive with one DPP row_shr:1 on A (lane 0 takes the carry of the previous
+// 16-cell block, exactly the x1_/v1_/x21_ registers of the SSE code); the row maximum is a 4-step DPP butterfly on a
+// 64-bit key that encodes the reference's evaluation order.  No LDS traffic and no barrier inside a row except the
+// query byte (one ds_read_u8 per active block) and the traceback byte store.
+#pragma once
+
+#define DPP_ROW_SHR1    0x111
+#define DPP_QUAD_XOR1   0xB1
+#define DPP_QUAD_XOR2   0x4E
+#define DPP_HALF_MIRROR 0x141
+#define DPP_ROW_MIRROR  0x140
+
+__device__ __forceinline__ int d_dpp_shr1(int carry, int v) { return __builtin_amdgcn_update_dpp(carry, v, DPP_ROW_SHR1, 0xf, 0xf, false); }
+
+template <int CTRL> __device__ __forceinline__ void d_key_max_step(int &lo, int &hi)
+{
+	const int olo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+	const int ohi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+	const long long a = (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+	const long long b = (long long)(((unsigned long long)(unsigned)ohi << 32) | (unsigned)olo);
+	if (b > a) { lo = olo; hi = ohi; }
+}
+
+template <int NB, int TMAX, int QMAX>
+__device__ __forceinline__ void d_ksw_reg(GroupLds<TMAX, QMAX> &L, const int gl, GroupWs &ws, int qlen, int tlen, const AlParams &P,
+                          int w, int zdrop, int end_bonus, int flag, EzD &ez, bool do_bt = true)
+{
+	int q = P.q, e = P.e, q2 = P.q2, e2 = P.e2;
+	if (q2 + e2 < q + e) { int t = q; q = q2; q2 = t; t = e; e = e2; e2 = t; }
+	const int qe = q + e;
+	const int8_t qe_ = (int8_t)(q + e), qe2_ = (int8_t)(q2 + e2);
+	const int8_t sc_mch = (int8_t)P.a, sc_mis = (int8_t)(-P.b), sc_amb = (int8_t)(P.sc_ambi > 0 ? -P.sc_ambi : P.sc_ambi);
+	const int8_t sc_N = sc_amb == 0 ? (int8_t)(-e2) : sc_amb;
+	if (w < 0) w = tlen > qlen ? tlen : qlen;
+	const int tlen_ = (tlen + 15) / 16;
+	int n_col_ = qlen < tlen ? qlen : tlen;
+	n_col_ = ((n_col_ < w + 1 ? n_col_ : w + 1) + 15) / 16 + 1;
+	const int qlen_ = (qlen + 15) / 16;
+	int long_thres = e != e2 ? (q2 - q) / (e - e2) - 1 : 0;
+	if (q2 + e2 + long_thres * e2 > q + e + long_thres * e) ++long_thres;
+	const int long_diff = long_thres * (e - e2) - (q2 - q) - e2;
+	const bool right = (flag & EZ_RIGHT) != 0;
+	const long long tP0 = PROF_ON(P) ? clock64() : 0;
+	uint8_t *qr = L.sq;                                   // reversed query, zero padded (ksw2_extd2_sse.c:118)
+	for (int t = gl; t < qlen_ * 16 + 32; t += GW) qr[t] = t < qlen ? L.qbuf[qlen - 1 - t] : 0;
+	uint32_t A[NB], B[NB]; int32_t H[NB];
+	{
+		const uint32_t m1 = (uint8_t)(int8_t)(-q - e), m2 = (uint8_t)(int8_t)(-q2 - e2);
+#pragma unroll
+		for (int b = 0; b < NB; ++b) {
+			const int t = 16 * b + gl;
+			const uint32_t sfv = t < tlen ? L.tbuf[t] : 0;
+			A[b] = m1 | m1 << 8 | m2 << 16 | m1 << 24;
+			B[b] = m1 | m2 << 8 | 0u << 16 | sfv << 24;
+			H[b] = KSW_NEG_INF;
+		}
+	}
+	GSYNC();
+	const size_t prow = (size_t)n_col_ * 16;
+	uint8_t *const ptb = (size_t)(qlen + tlen - 1) * prow <= AL_LPTB ? L.ptb : ws.p;
+	int last_st = -1, last_en = -1, r;
+	const long long tP1 = PROF_ON(P) ? clock64() : 0;
+	const int n_rows_dbg = ((P.dbg >> 22) & 1) ? 0 : qlen + tlen - 1;
+	for (r = 0; r < n_rows_dbg; ++r) {
+		int st, en;
+		d_row_bounds(r, qlen, tlen, w, st, en);
+		if (st > en) { ez.zdropped = 1; break; }
+		const int st0 = st, en0 = en;
+		st = st / 16 * 16; en = (en + 16) / 16 * 16 - 1;
+		const int st_ = st >> 4, en_ = en >> 4;
+		const int cover_end = st0 + ((en0 - st0) >> 4) * 16 + 15;       // last byte written by the 16-byte score stores (:158-176)
+		// ---- boundary conditions (:141-157)
+		uint32_t carry;
+		{
+			int8_t x1 = (int8_t)(-q - e), x21 = (int8_t)(-q2 - e2), v1 = (int8_t)(-q - e);
+			if (st > 0) {
+				if (st - 1 >= last_st && st - 1 <= last_en) {
+					uint32_t av = 0;
+#pragma unroll
+					for (int b = 0; b < NB; ++b) if (b == st_ - 1) av = (uint32_t)__shfl((int)A[b], GW - 1, GW);
+					x1 = (int8_t)av; v1 = (int8_t)(av >> 8); x21 = (int8_t)(av >> 16);
+				}
+			} else v1 = r == 0 ? (int8_t)(-q - e) : r < long_thres ? (int8_t)(-e) : r == long_thres ? (int8_t)long_diff : (int8_t)(-e2);
+			carry = (uint32_t)(uint8_t)x1 | (uint32_t)(uint8_t)v1 << 8 | (uint32_t)(uint8_t)x21 << 16;
+		}
+		const int8_t ubound = r == 0 ? (int8_t)(-q - e) : r < long_thres ? (int8_t)(-e) : r == long_thres ? (int8_t)long_diff : (int8_t)(-e2);
+		uint8_t *pr = ptb + (size_t)r * prow - st;
+		const uint8_t *qrr = qr + (qlen - 1 - r);
+		const int be = en0 >> 4;
+		int hprev15 = 0;                                                 // H[en0-1] when en0 is the first lane of its block
+		long long key = (long long)0x8000000000000000ULL;                // this lane's best (H<<16 | 0xffff-ord)
+		const int en1 = st0 + (en0 - st0) / 4 * 4;
+#pragma unroll
+		for (int b = 0; b < NB; ++b) {
+			if (r > 0 && b + 1 == be && (en0 & 15) == 0) hprev15 = __shfl(H[b], GW - 1, GW);   // H[r-1][en0-1] (block may be outside [st_,en_])
+			if (b >= st_ && b <= en_) {
+				const int t = 16 * b + gl;
+				uint32_t a_old = A[b], b_old = B[b];
+				if (en >= r && t == r) {                                     // y[r], y2[r], u[r] (:150-153)
+					b_old = (b_old & 0xffff0000u) | (uint32_t)(uint8_t)(int8_t)(-q - e) | (uint32_t)(uint8_t)(int8_t)(-q2 - e2) << 8;
+					a_old = (a_old & 0x00ffffffu) | (uint32_t)(uint8_t)ubound << 24;
+				}
+				if (t >= st0 && t <= cover_end && t < tlen_ * 16) {          // score bytes (:158-176)
+					const uint8_t sq = (uint8_t)(b_old >> 24), sq2 = qrr[t];
+					int8_t sc = sq == sq2 ? sc_mch : sc_mis;
+					if (sq == 4 || sq2 == 4) sc = sc_N;
+					b_old = (b_old & 0xff00ffffu) | (uint32_t)(uint8_t)sc << 16;
+				}
+				const uint32_t left = (uint32_t)d_dpp_shr1((int)carry, (int)a_old);
+				if (b < en_) carry = (uint32_t)__shfl((int)a_old, GW - 1, GW);
+				const int8_t xt1 = (int8_t)left, vt1 = (int8_t)(left >> 8), x2t1 = (int8_t)(left >> 16);
+				const int8_t ut = (int8_t)(a_old >> 24), yo = (int8_t)b_old, y2o = (int8_t)(b_old >> 8);
+				int8_t z = (int8_t)(b_old >> 16);
+				int8_t a = (int8_t)(xt1 + vt1), bb = (int8_t)(yo + ut), a2 = (int8_t)(x2t1 + vt1), b2 = (int8_t)(y2o + ut);
+				int d;
+				// left-aligned gaps take a strict '>' (ksw2_extd2_sse.c:206-214), right-aligned '>=' (:252-260)
+				d = (a > z || (right && a == z)) ? 1 : 0;   z = z > a ? z : a;
+				d = (bb > z || (right && bb == z)) ? 2 : d; z = z > bb ? z : bb;
+				d = (a2 > z || (right && a2 == z)) ? 3 : d; z = z > a2 ? z : a2;
+				d = (b2 > z || (right && b2 == z)) ? 4 : d; z = z > b2 ? z : b2;
+				z = z < sc_mch ? z : sc_mch;
+				const int8_t un = (int8_t)(z - vt1), vn = (int8_t)(z - ut);
+				int8_t tmp = (int8_t)(z - q); a = (int8_t)(a - tmp); bb = (int8_t)(bb - tmp);
+				tmp = (int8_t)(z - q2); a2 = (int8_t)(a2 - tmp); b2 = (int8_t)(b2 - tmp);
+				const bool pa = right ? a >= 0 : a > 0, pb = right ? bb >= 0 : bb > 0, pa2 = right ? a2 >= 0 : a2 > 0, pb2 = right ? b2 >= 0 : b2 > 0;
+				const int8_t xn = (int8_t)((pa ? a : 0) - qe_), yn = (int8_t)((pb ? bb : 0) - qe_);
+				const int8_t x2n = (int8_t)((pa2 ? a2 : 0) - qe2_), y2n = (int8_t)((pb2 ? b2 : 0) - qe2_);
+				d |= (pa ? 0x08 : 0) | (pb ? 0x10 : 0) | (pa2 ? 0x20 : 0) | (pb2 ? 0x40 : 0);
+				A[b] = (uint32_t)(uint8_t)xn | (uint32_t)(uint8_t)vn << 8 | (uint32_t)(uint8_t)x2n << 16 | (uint32_t)(uint8_t)un << 24;
+				B[b] = (b_old & 0xffff0000u) | (uint32_t)(uint8_t)yn | (uint32_t)(uint8_t)y2n << 8;
+				if (!((P.dbg >> 23) & 1)) pr[t] = (uint8_t)d;
+				// ---- exact max (:307-349): H row update and this lane's candidate
+				if (r > 0 && !((P.dbg >> 24) & 1)) {
+					const int hold = H[b];
+					int hl = 0;
+					if (b == be) hl = d_dpp_shr1(hprev15, hold);             // H[r-1][t-1]
+					if (t >= st0 && t <= en0) {
+						int h, ord;
+						if (t == en0) { h = en0 > 0 ? hl + un : hold + vn; ord = 0; }
+						else { h = hold + vn; ord = t < en1 ? 1 + ((t - st0) & 3) * 4096 + ((t - st0) >> 2) : 1 + 4 * 4096 + (t - en1); }
+						H[b] = h;
+						const long long k2 = (long long)h * 65536 + (0xffff - ord);
+						key = k2 > key ? k2 : key;
+					}
+				} else if (t == 0) { H[b] = (int)vn - qe; key = (long long)H[b] * 65536 + 0xffff; }
+			}
+		}
+		int max_H, max_t;
+		{
+			int lo = (int)(unsigned)(unsigned long long)key, hi = (int)((unsigned long long)key >> 32);
+			d_key_max_step<DPP_QUAD_XOR1>(lo, hi); d_key_max_step<DPP_QUAD_XOR2>(lo, hi);
+			d_key_max_step<DPP_HALF_MIRROR>(lo, hi); d_key_max_step<DPP_ROW_MIRROR>(lo, hi);
+			const long long kk = (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+			max_H = (int)(kk >> 16);
+			const int ord = 0xffff - (int)(kk & 0xffff);
+			if (r == 0) max_t = 0;
+			else if (ord == 0) max_t = en0;
+			else if (ord < 1 + 4 * 4096) max_t = st0 + ((ord - 1) & 4095) * 4 + ((ord - 1) >> 12);
+			else max_t = en1 + (ord - 1 - 4 * 4096);
+		}
+		if (r - st0 == qlen - 1) {                                           // :353-354
+			int hs = 0;
+#pragma unroll
+			for (int b = 0; b < NB; ++b) if (b == (st0 >> 4)) hs = __shfl(H[b], st0 & 15, GW);
+			if (hs > ez.mqe) { ez.mqe = hs; ez.mqe_t = st0; }
+		}
+		bool brk = false;                                                    // ksw_apply_zdrop, ksw2.h:160-176
+		if (max_H > ez.max) { ez.max = max_H; ez.max_t = max_t; ez.max_q = r - max_t; }
+		else if (max_t >= ez.max_t && r - max_t >= ez.max_q) {
+			const int tl = max_t - ez.max_t, ql = (r - max_t) - ez.max_q, l = tl > ql ? tl - ql : ql - tl;
+			if (zdrop >= 0 && ez.max - max_H > zdrop + l * e2) { ez.zdropped = 1; brk = true; }
+		}
+		if (brk) break;
+		if (r == qlen + tlen - 2 && en0 == tlen - 1) {
+			int hs = 0;
+#pragma unroll
+			for (int b = 0; b < NB; ++b) if (b == ((tlen - 1) >> 4)) hs = __shfl(H[b], (tlen - 1) & 15, GW);
+			ez.score = hs;
+		}
+		last_st = st; last_en = en;
+	}
+	GSYNC();
+	const long long tP2 = PROF_ON(P) ? clock64() : 0;
+	if (do_bt && !((P.dbg >> 25) & 1)) {
+		const int rev_cigar = !!(flag & EZ_REV_CIGAR);
+		CigW cw{L.ezc, 0, AL_LCIG, ws.ezc, 0xffffffffu};
+		if (!ez.zdropped && !(flag & EZ_EXTZ_ONLY)) d_backtrack(ptb, n_col_ * 16, qlen, tlen, w, rev_cigar, tlen - 1, qlen - 1, cw);
+		else if (!ez.zdropped && (flag & EZ_EXTZ_ONLY) && ez.mqe + end_bonus > ez.max) { ez.reach_end = 1; d_backtrack(ptb, n_col_ * 16, qlen, tlen, w, rev_cigar, ez.mqe_t, qlen - 1, cw); }
+		else if (ez.max_t >= 0 && ez.max_q >= 0) d_backtrack(ptb, n_col_ * 16, qlen, tlen, w, rev_cigar, ez.max_t, ez.max_q, cw);
+		ez.n_cigar = cw.n; ws.cur_ezc = cw.c;
+	}
+	GSYNC();
+	if (PROF_ON(P) && gl == 0) { const long long tP3 = clock64(); atomicAdd(&ws.dbg[600], (unsigned long long)(tP1 - tP0)); atomicAdd(&ws.dbg[601], (unsigned long long)(tP2 - tP1)); atomicAdd(&ws.dbg[602], (unsigned long long)(tP3 - tP2)); atomicAdd(&ws.dbg[606], 1ULL); atomicAdd(&ws.dbg[607], (unsigned long long)(qlen + tlen - 1)); }
+}

@@ -62,6 +62,7 @@ struct AlParams {             // kernel parameter block (copy of the options the
 	float mask_level, pri_ratio, max_clip_ratio;
 	int best_n, a, b, q, e, q2, e2, sc_ambi, zdrop, zdrop_inv, end_bonus, min_dp_max;
 	int pe_ori, pe_bonus, mid_occ, max_occ;
+	int dbg;                  // timing experiments only (AL_DBG env): skips phases, results become wrong
 };
 
 struct AlMatch {              // one query minimizer that passed the occurrence filter (mm_match_t, map.c:82-88)

@@ -18,6 +18,11 @@
 #include "al_runtime.h"
 #include "al_dev_regs.h"
 
+#define AL_LREG 6                // hits per mate held in LDS
+#define AL_LANC 64               // anchors per mate held in LDS
+#define AL_LCIG 40               // CIGAR words held in LDS (region under construction / last DP call)
+#define AL_LPTB 1280             // traceback bytes held in LDS
+#define AL_GPB 4                 // extension groups per block (1: one fragment per wavefront -> no cross-group divergence)
 #define GW 16                    // lanes per extension group (= one 128-bit SSE vector of int8)
 #define KSW_NEG_INF -0x40000000
 #define EZ_RIGHT      0x02
@@ -34,14 +39,26 @@ template <int TMAX, int QMAX> struct GroupLds {
 	uint8_t tbuf[TMAX + 16];        // target of the current DP job / alignment window
 	uint8_t qbuf[QMAX + 16];        // query of the current DP job
 	uint8_t q0[QMAX + 16], q1[QMAX + 16];   // qseq0[0] (forward) and qseq0[1] (reverse complement), align.c:865-870
+	// small per-fragment state kept on chip (HBM copies are used only when a fragment exceeds these tiles)
+	AlReg regs[2][AL_LREG], rtmp[AL_LREG];
+	AlAnchor aux128[AL_LREG], anc[AL_LANC];
+	uint64_t aux64[AL_LREG], sc[AL_LREG * AL_LREG];
+	int auxi[2 * AL_LREG];
+	uint32_t cig[AL_LCIG], ezc[AL_LCIG];
+	uint8_t ptb[AL_LPTB];
 };
 
-struct GroupWs {                    // per-group HBM scratch
-	uint8_t *p;                     // traceback matrix
-	uint32_t *cig;                  // CIGAR of the region under construction
-	uint32_t *ezc;                  // CIGAR returned by the last DP call
+struct GroupWs {                    // per-group HBM scratch (+ the current location of the two CIGAR buffers)
+	uint8_t *p;                     // traceback matrix (HBM)
+	uint32_t *cig;                  // CIGAR of the region under construction (HBM spill area)
+	uint32_t *ezc;                  // CIGAR returned by the last DP call (HBM spill area)
 	uint64_t *sc;                   // pair scores (mm_pair), AL_PAIR_SC_CAP entries
+	uint32_t *cur_cig; int cur_cig_cap;   // where the region CIGAR currently lives (LDS tile or ws.cig)
+	uint32_t *cur_ezc;              // where the last DP call left its CIGAR
+	unsigned long long *dbg;        // debug records (differential DP check)
+	long long prof[8];              // AL_DBG bit 21: cycle accumulators [0] dp init [1] dp rows [2] backtrack [3] align1 other [4] post [5] stage-in [6] n_dp [7] n_rows
 };
+#define PROF_ON(P) (((P).dbg >> 21) & 1)
 #define AL_PAIR_SC_CAP 4096
 
 __device__ __forceinline__ void d_ez_reset(EzD &ez)
@@ -59,17 +76,25 @@ __device__ __forceinline__ void d_row_bounds(int r, int qlen, int tlen, int w, i
 	if (en > (r + w) >> 1) en = (r + w) >> 1;
 }
 
-struct CigW { uint32_t *c; int n; };   // cigar writer: every lane of the group holds the same state and stores the same words
+// cigar writer: every lane of the group holds the same state and stores the same words.  The run being extended is
+// kept in registers (cur); c[] starts in LDS and migrates to the HBM scratch when it outgrows the tile.
+struct CigW { uint32_t *c; int n; int cap; uint32_t *spill; uint32_t cur; };
+__device__ __forceinline__ void d_cig_store(CigW &w, uint32_t v)
+{
+	if (w.n == w.cap) { for (int i = 0; i < w.n; ++i) w.spill[i] = w.c[i]; w.c = w.spill; w.cap = 0x7fffffff; }
+	w.c[w.n++] = v;
+}
 __device__ __forceinline__ void d_push_cigar(CigW &w, uint32_t op, int len)
 {   // ksw2.h:104-114
-	if (w.n == 0 || op != (w.c[w.n - 1] & 0xf)) w.c[w.n++] = (uint32_t)len << 4 | op;
-	else w.c[w.n - 1] += (uint32_t)len << 4;
+	if (w.cur != 0xffffffffu && op == (w.cur & 0xf)) w.cur += (uint32_t)len << 4;
+	else { if (w.cur != 0xffffffffu) d_cig_store(w, w.cur); w.cur = (uint32_t)len << 4 | op; }
 }
+__device__ __forceinline__ void d_cig_flush(CigW &w) { if (w.cur != 0xffffffffu) { d_cig_store(w, w.cur); w.cur = 0xffffffffu; } }
 
-__device__ void d_backtrack(const uint8_t *p, int n_col, int qlen, int tlen, int w, int is_rev, int i0, int j0, CigW &cw)
+__device__ __forceinline__ void d_backtrack(const uint8_t *p, int n_col, int qlen, int tlen, int w, int is_rev, int i0, int j0, CigW &cw)
 {   // ksw_backtrack, ksw2.h:119-151 (is_rot = 1, min_intron_len = 0); off[]/off_end[] are recomputed from r
 	int i = i0, j = j0, state = 0;
-	cw.n = 0;
+	cw.n = 0; cw.cur = 0xffffffffu;
 	while (i >= 0 && j >= 0) {
 		int force_state = -1, st, en; const int r = i + j;
 		d_row_bounds(r, qlen, tlen, w, st, en);
@@ -87,12 +112,14 @@ __device__ void d_backtrack(const uint8_t *p, int n_col, int qlen, int tlen, int
 	}
 	if (i >= 0) d_push_cigar(cw, 2, i + 1);
 	if (j >= 0) d_push_cigar(cw, 1, j + 1);
+	d_cig_flush(cw);
 	if (!is_rev) for (int k = 0; k < cw.n >> 1; ++k) { uint32_t t = cw.c[k]; cw.c[k] = cw.c[cw.n - 1 - k]; cw.c[cw.n - 1 - k] = t; }
 }
 
-// ksw_extd2_sse (ksw2_extd2_sse.c:26-393) for one 16-lane group.  Inputs: L.qbuf[0..qlen), L.tbuf[0..tlen).
+// ksw_extd2_sse (ksw2_extd2_sse.c:26-393) for one 16-lane group, state rows in LDS (any size up to TMAX).
+// Inputs: L.qbuf[0..qlen), L.tbuf[0..tlen).
 template <int TMAX, int QMAX>
-__device__ void d_ksw_extd2(GroupLds<TMAX, QMAX> &L, const int gl, const GroupWs &ws, int qlen, int tlen, const AlParams &P,
+__device__ __forceinline__ void d_ksw_lds(GroupLds<TMAX, QMAX> &L, const int gl, GroupWs &ws, int qlen, int tlen, const AlParams &P,
                             int w, int zdrop, int end_bonus, int flag, EzD &ez)
 {
 	int q = P.q, e = P.e, q2 = P.q2, e2 = P.e2;
@@ -123,6 +150,7 @@ __device__ void d_ksw_extd2(GroupLds<TMAX, QMAX> &L, const int gl, const GroupWs
 	for (int t = gl; t < qlen_ * 16 + 32; t += GW) qr[t] = t < qlen ? L.qbuf[qlen - 1 - t] : 0;
 	GSYNC();
 	const size_t prow = (size_t)n_col_ * 16;
+	uint8_t *const ptb = (size_t)(qlen + tlen - 1) * prow <= AL_LPTB ? L.ptb : ws.p;   // traceback bytes: LDS tile when they fit
 	int last_st = -1, last_en = -1, r;
 	for (r = 0; r < qlen + tlen - 1; ++r) {
 		int st, en;
@@ -150,7 +178,7 @@ __device__ void d_ksw_extd2(GroupLds<TMAX, QMAX> &L, const int gl, const GroupWs
 			if (t + gl < tlen_ * 16) L.s[t + gl] = sc;    // the reference's 16-byte store may spill past s[] into bytes it never reads again
 		}
 		GSYNC();
-		uint8_t *pr = ws.p + (size_t)r * prow - st;
+		uint8_t *pr = ptb + (size_t)r * prow - st;
 		int xc = x1, x2c = x21, vc = v1;                                      // carries across 16-cell blocks
 		for (int tb = st; tb <= en; tb += 16) {                               // :182-306
 			const int t = tb + gl;
@@ -227,13 +255,36 @@ __device__ void d_ksw_extd2(GroupLds<TMAX, QMAX> &L, const int gl, const GroupWs
 	GSYNC();
 	{   // :384-392
 		const int rev_cigar = !!(flag & EZ_REV_CIGAR);
-		CigW cw{ws.ezc, 0};
-		if (!ez.zdropped && !(flag & EZ_EXTZ_ONLY)) d_backtrack(ws.p, n_col_ * 16, qlen, tlen, w, rev_cigar, tlen - 1, qlen - 1, cw);
-		else if (!ez.zdropped && (flag & EZ_EXTZ_ONLY) && ez.mqe + end_bonus > ez.max) { ez.reach_end = 1; d_backtrack(ws.p, n_col_ * 16, qlen, tlen, w, rev_cigar, ez.mqe_t, qlen - 1, cw); }
-		else if (ez.max_t >= 0 && ez.max_q >= 0) d_backtrack(ws.p, n_col_ * 16, qlen, tlen, w, rev_cigar, ez.max_t, ez.max_q, cw);
-		ez.n_cigar = cw.n;
+		CigW cw{L.ezc, 0, AL_LCIG, ws.ezc, 0xffffffffu};
+		if (!ez.zdropped && !(flag & EZ_EXTZ_ONLY)) d_backtrack(ptb, n_col_ * 16, qlen, tlen, w, rev_cigar, tlen - 1, qlen - 1, cw);
+		else if (!ez.zdropped && (flag & EZ_EXTZ_ONLY) && ez.mqe + end_bonus > ez.max) { ez.reach_end = 1; d_backtrack(ptb, n_col_ * 16, qlen, tlen, w, rev_cigar, ez.mqe_t, qlen - 1, cw); }
+		else if (ez.max_t >= 0 && ez.max_q >= 0) d_backtrack(ptb, n_col_ * 16, qlen, tlen, w, rev_cigar, ez.max_t, ez.max_q, cw);
+		ez.n_cigar = cw.n; ws.cur_ezc = cw.c;
 	}
 	GSYNC();
+}
+
+#include "al_dev_ksw.h"
+
+// dispatcher: targets of up to 22 x 16 cells run register-resident, larger ones use the LDS rows
+template <int TMAX, int QMAX>
+__device__ __forceinline__ void d_ksw_extd2(GroupLds<TMAX, QMAX> &L, const int gl, GroupWs &ws, int qlen, int tlen, const AlParams &P,
+                            int w, int zdrop, int end_bonus, int flag, EzD &ez)
+{
+	d_ez_reset(ez);
+	if (qlen <= 0 || tlen <= 0) return;
+	{ const int sc_mis = -P.b, sc_amb = P.sc_ambi > 0 ? -P.sc_ambi : P.sc_ambi; const int min_sc = sc_mis < sc_amb ? sc_mis : sc_amb;
+	  const int qe1 = P.q + P.e, qe2 = P.q2 + P.e2; if (-min_sc > 2 * (qe1 < qe2 ? qe1 : qe2)) return; }
+	const int tlen_ = (tlen + 15) / 16;
+	const int maxnb = ((P.dbg >> 8) & 0xff) ? ((P.dbg >> 8) & 0xff) - 1 : 22;
+   // AL_DBG>>8 = 1 + largest block count allowed on the register path (experiments)
+	if ((P.dbg & 128) || tlen_ > maxnb) d_ksw_lds(L, gl, ws, qlen, tlen, P, w, zdrop, end_bonus, flag, ez);
+	else if (tlen_ <= 1) d_ksw_reg<1>(L, gl, ws, qlen, tlen, P, w, zdrop, end_bonus, flag, ez);
+	else if (tlen_ <= 2) d_ksw_reg<2>(L, gl, ws, qlen, tlen, P, w, zdrop, end_bonus, flag, ez);
+	else if (tlen_ <= 4) d_ksw_reg<4>(L, gl, ws, qlen, tlen, P, w, zdrop, end_bonus, flag, ez);
+	else if (tlen_ <= 8) d_ksw_reg<8>(L, gl, ws, qlen, tlen, P, w, zdrop, end_bonus, flag, ez);
+	else if (tlen_ <= 22) d_ksw_reg<22>(L, gl, ws, qlen, tlen, P, w, zdrop, end_bonus, flag, ez);
+	else d_ksw_lds(L, gl, ws, qlen, tlen, P, w, zdrop, end_bonus, flag, ez);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -355,9 +406,14 @@ __device__ void d_update_extra(const AlParams &P, AlReg *r, uint32_t *cigar, con
 	r->dp_max = max;
 }
 
-__device__ __forceinline__ void d_append_cigar(AlReg *r, uint32_t *cig, int n_cigar, const uint32_t *cigar)
+__device__ __forceinline__ void d_append_cigar(AlReg *r, GroupWs &ws, int n_cigar, const uint32_t *cigar)
 {   // mm_append_cigar, align.c:288-311
 	if (n_cigar == 0) return;
+	if ((int)r->n_cigar + n_cigar > ws.cur_cig_cap) {      // outgrew the LDS tile: continue in the HBM scratch
+		for (uint32_t i = 0; i < r->n_cigar; ++i) ws.cig[i] = ws.cur_cig[i];
+		ws.cur_cig = ws.cig; ws.cur_cig_cap = 0x7fffffff;
+	}
+	uint32_t *cig = ws.cur_cig;
 	r->flags |= ALR_HAS_P;
 	if (r->n_cigar > 0 && (cig[r->n_cigar - 1] & 0xf) == (cigar[0] & 0xf)) {
 		cig[r->n_cigar - 1] += cigar[0] >> 4 << 4;
@@ -387,13 +443,14 @@ __device__ void d_max_stretch(const AlReg *r, const AlAnchor *a, int *as, int *c
 struct AlignShared {            // read-only kernel inputs
 	const uint32_t *S4; const uint64_t *seq_off; const uint32_t *seq_len;
 	uint32_t *arena; unsigned long long *arena_cnt; uint64_t arena_cap;
+	unsigned long long *dbg;        // 1 + 32*16 words of debug records
 	unsigned long long *counters;   // [4] regions aligned, [5] ref bases, [6] cigar ops, [7] errors, [8] logf misses, [9] arena overflow, [10] sort ties
 };
 
 // mm_align1 (align.c:565-788), short-read branch.  Executed by the 16 lanes of a group in lock step.
 template <int TMAX, int QMAX>
-__device__ void d_align1(GroupLds<TMAX, QMAX> &L, const int gl, const GroupWs &ws, const AlParams &P, const AlignShared &G,
-                         int qlen, AlReg *r, AlReg *r2, AlAnchor *a, EzD &ez)
+__device__ __forceinline__ void d_align1(GroupLds<TMAX, QMAX> &L, const int gl, GroupWs &ws, const AlParams &P, const AlignShared &G,
+                         int qlen, AlReg *r, AlReg *r2, const AlAnchor *a, EzD &ez)
 {
 	const int32_t rid = (int32_t)(a[r->as].x << 1 >> 33), rev = (int32_t)(a[r->as].x >> 63);
 	int32_t as1, cnt1, l, dropped = 0, rs0, re0, qs0, qe0, rs, re, qs, qe, rs1, qs1, re1, qe1;
@@ -417,56 +474,71 @@ __device__ void d_align1(GroupLds<TMAX, QMAX> &L, const int gl, const GroupWs &w
 	if (re0 - rs0 > TMAX || qlen > QMAX) { if (gl == 0) atomicAdd(&G.counters[7], 1ULL); r->cnt = 0; return; }
 	if (gl == 0) { atomicAdd(&G.counters[4], 1ULL); atomicAdd(&G.counters[5], (unsigned long long)(re0 - rs0)); }
 	r->n_cigar = 0; r->dp_score = 0; r->dp_max = 0; r->dp_max2 = 0; r->n_ambi = 0;
+	ws.cur_cig = L.cig; ws.cur_cig_cap = AL_LCIG;
 
-	if (qs > 0 && rs > 0) {                                                   // left extension, align.c:690-705
-		const int ql = qs - qs0, tl = rs - rs0;
-		for (int i = gl; i < ql; i += GW) L.qbuf[i] = qseq0[qs0 + (ql - 1 - i)];                     // mm_seq_rev of both
-		for (int i = gl; i < tl; i += GW) L.tbuf[i] = (uint8_t)d_seq4(G.S4, ref_off + (uint64_t)(rs - 1 - i));
-		GSYNC();
-		d_ksw_extd2(L, gl, ws, ql, tl, P, bw, (r->flags & ALR_SPLIT_INV) ? P.zdrop_inv : P.zdrop, P.end_bonus, EZ_EXTZ_ONLY | EZ_RIGHT | EZ_REV_CIGAR, ez);
-		if (ez.n_cigar > 0) { d_append_cigar(r, ws.cig, ez.n_cigar, ws.ezc); r->dp_score += ez.max; }
-		rs1 = rs - (ez.reach_end ? ez.mqe_t + 1 : ez.max_t + 1);
-		qs1 = qs - (ez.reach_end ? qs - qs0 : ez.max_q + 1);
-	} else { rs1 = rs; qs1 = qs; }
-	re1 = rs; qe1 = qs;
-	{   // ungapped core, align.c:709-758 with is_sr (single iteration i = cnt1 - 1)
-		const int i = cnt1 - 1;
-		re = (int32_t)a[as1 + i].x + 1; qe = (int32_t)a[as1 + i].y + 1;
-		re1 = re; qe1 = qe;
-		const int len = qe - qs;
-		for (int k = gl; k < len; k += GW) { L.qbuf[k] = qseq0[qs + k]; L.tbuf[k] = (uint8_t)d_seq4(G.S4, ref_off + (uint64_t)(rs + k)); }
-		GSYNC();
-		d_ez_reset(ez);
-		int sc = 0;
-		for (int k = 0; k < len; ++k) {
-			if (L.qbuf[k] >= 4 || L.tbuf[k] >= 4) sc += P.e2;
-			else sc += L.qbuf[k] == L.tbuf[k] ? P.a : -P.b;
+	// The three DP opportunities of mm_align1 (left extension, z-drop re-alignment of the ungapped core, right extension)
+	// go through ONE call site of the DP so that it is inlined once per kernel.
+	rs1 = rs; qs1 = qs; re1 = rs; qe1 = qs;
+	for (int ph = 0; ph < 3; ++ph) {
+		bool run = false; int ql = 0, tl = 0, zd = P.zdrop, eb = P.end_bonus, fl = 0;
+		if (ph == 0) {                                                        // left extension, align.c:690-705
+			if (qs > 0 && rs > 0 && !(P.dbg & 1)) {
+				ql = qs - qs0; tl = rs - rs0;
+				for (int i = gl; i < ql; i += GW) L.qbuf[i] = qseq0[qs0 + (ql - 1 - i)];                     // mm_seq_rev of both
+				for (int i = gl; i < tl; i += GW) L.tbuf[i] = (uint8_t)d_seq4(G.S4, ref_off + (uint64_t)(rs - 1 - i));
+				zd = (r->flags & ALR_SPLIT_INV) ? P.zdrop_inv : P.zdrop; fl = EZ_EXTZ_ONLY | EZ_RIGHT | EZ_REV_CIGAR; run = true;
+			}
+		} else if (ph == 1) {                                                 // ungapped core, align.c:709-758 with is_sr (i = cnt1 - 1)
+			const int i = cnt1 - 1;
+			re = (int32_t)a[as1 + i].x + 1; qe = (int32_t)a[as1 + i].y + 1;
+			re1 = re; qe1 = qe;
+			const int len = qe - qs;
+			for (int k = gl; k < len; k += GW) { L.qbuf[k] = qseq0[qs + k]; L.tbuf[k] = (uint8_t)d_seq4(G.S4, ref_off + (uint64_t)(rs + k)); }
+			GSYNC();
+			d_ez_reset(ez);
+			int sc = 0;
+			if (!(P.dbg & 4)) for (int k = 0; k < len; ++k) {
+				if (L.qbuf[k] >= 4 || L.tbuf[k] >= 4) sc += P.e2;
+				else sc += L.qbuf[k] == L.tbuf[k] ? P.a : -P.b;
+			}
+			ez.score = sc;
+			L.ezc[0] = (uint32_t)len << 4; ez.n_cigar = 1; ws.cur_ezc = L.ezc;
+			if (!(P.dbg & 4) && d_test_zdrop(P, L.qbuf, L.tbuf, ez.n_cigar, L.ezc) != 0) {   // second pass (align.c:736-737)
+				ql = len; tl = re - rs; zd = P.zdrop; eb = -1; fl = 0; run = true;
+			}
+		} else {                                                              // right extension, align.c:760-771
+			if (!dropped && qe < qe0 && re < re0 && !(P.dbg & 1)) {
+				ql = qe0 - qe; tl = re0 - re;
+				for (int i = gl; i < ql; i += GW) L.qbuf[i] = qseq0[qe + i];
+				for (int i = gl; i < tl; i += GW) L.tbuf[i] = (uint8_t)d_seq4(G.S4, ref_off + (uint64_t)(re + i));
+				fl = EZ_EXTZ_ONLY; run = true;
+			}
 		}
-		ez.score = sc;
-		ws.ezc[0] = (uint32_t)len << 4; ez.n_cigar = 1;
-		if (d_test_zdrop(P, L.qbuf, L.tbuf, ez.n_cigar, ws.ezc) != 0)
-			d_ksw_extd2(L, gl, ws, len, re - rs, P, bw, P.zdrop, -1, 0, ez);    // second pass (align.c:736-737)
-		if (ez.n_cigar > 0) d_append_cigar(r, ws.cig, ez.n_cigar, ws.ezc);
-		if (ez.zdropped) {
-			int j;
-			for (j = i - 1; j >= 0; --j) if ((int32_t)a[as1 + j].x <= rs + ez.max_t) break;
-			dropped = 1;
-			if (j < 0) j = 0;
-			r->dp_score += ez.max;
-			re1 = rs + (ez.max_t + 1);
-			qe1 = qs + (ez.max_q + 1);
-			if (cnt1 - (j + 1) >= P.min_cnt) d_split_reg(r, r2, as1 + j + 1 - r->as, qlen, a);
-		} else { r->dp_score += ez.score; rs = re; qs = qe; }
-	}
-	if (!dropped && qe < qe0 && re < re0) {                                   // right extension, align.c:760-771
-		const int ql = qe0 - qe, tl = re0 - re;
-		for (int i = gl; i < ql; i += GW) L.qbuf[i] = qseq0[qe + i];
-		for (int i = gl; i < tl; i += GW) L.tbuf[i] = (uint8_t)d_seq4(G.S4, ref_off + (uint64_t)(re + i));
-		GSYNC();
-		d_ksw_extd2(L, gl, ws, ql, tl, P, bw, P.zdrop, P.end_bonus, EZ_EXTZ_ONLY, ez);
-		if (ez.n_cigar > 0) { d_append_cigar(r, ws.cig, ez.n_cigar, ws.ezc); r->dp_score += ez.max; }
-		re1 = re + (ez.reach_end ? ez.mqe_t + 1 : ez.max_t + 1);
-		qe1 = qe + (ez.reach_end ? qe0 - qe : ez.max_q + 1);
+		if (run) { GSYNC(); d_ksw_extd2(L, gl, ws, ql, tl, P, bw, zd, eb, fl, ez); }
+		if (ph == 0) {
+			if (run) {
+				if (ez.n_cigar > 0) { d_append_cigar(r, ws, ez.n_cigar, ws.cur_ezc); r->dp_score += ez.max; }
+				rs1 = rs - (ez.reach_end ? ez.mqe_t + 1 : ez.max_t + 1);
+				qs1 = qs - (ez.reach_end ? qs - qs0 : ez.max_q + 1);
+			}
+		} else if (ph == 1) {
+			const int i = cnt1 - 1;
+			if (ez.n_cigar > 0) d_append_cigar(r, ws, ez.n_cigar, ws.cur_ezc);
+			if (ez.zdropped) {
+				int j;
+				for (j = i - 1; j >= 0; --j) if ((int32_t)a[as1 + j].x <= rs + ez.max_t) break;
+				dropped = 1;
+				if (j < 0) j = 0;
+				r->dp_score += ez.max;
+				re1 = rs + (ez.max_t + 1);
+				qe1 = qs + (ez.max_q + 1);
+				if (cnt1 - (j + 1) >= P.min_cnt) d_split_reg(r, r2, as1 + j + 1 - r->as, qlen, a);
+			} else { r->dp_score += ez.score; rs = re; qs = qe; }
+		} else if (run) {
+			if (ez.n_cigar > 0) { d_append_cigar(r, ws, ez.n_cigar, ws.cur_ezc); r->dp_score += ez.max; }
+			re1 = re + (ez.reach_end ? ez.mqe_t + 1 : ez.max_t + 1);
+			qe1 = qe + (ez.reach_end ? qe0 - qe : ez.max_q + 1);
+		}
 	}
 	r->rs = rs1; r->re = re1;
 	if (rev) { r->qs = qlen - qe1; r->qe = qlen - qs1; }
@@ -475,12 +547,12 @@ __device__ void d_align1(GroupLds<TMAX, QMAX> &L, const int gl, const GroupWs &w
 		const int tl = re1 - rs1;
 		for (int i = gl; i < tl; i += GW) L.tbuf[i] = (uint8_t)d_seq4(G.S4, ref_off + (uint64_t)(rs1 + i));
 		GSYNC();
-		d_update_extra(P, r, ws.cig, qseq0 + qs1, L.tbuf);
+		if (!(P.dbg & 2)) d_update_extra(P, r, ws.cur_cig, qseq0 + qs1, L.tbuf); else r->dp_max = 100;
 		// publish the finished CIGAR: reserve words in the global arena (one atomic per group) and copy
 		unsigned long long off = 0;
 		if (gl == 0) off = atomicAdd(G.arena_cnt, (unsigned long long)r->n_cigar);
 		off = __shfl(off, 0, GW);
-		if (off + r->n_cigar <= G.arena_cap) { for (uint32_t i = gl; i < r->n_cigar; i += GW) G.arena[off + i] = ws.cig[i]; r->cigar_off = (uint32_t)off; }
+		if (off + r->n_cigar <= G.arena_cap) { for (uint32_t i = gl; i < r->n_cigar; i += GW) G.arena[off + i] = ws.cur_cig[i]; r->cigar_off = (uint32_t)off; }
 		else { if (gl == 0) atomicAdd(&G.counters[9], 1ULL); r->cigar_off = 0xffffffffu; }
 		if (gl == 0) atomicAdd(&G.counters[6], (unsigned long long)r->n_cigar);
 	}
@@ -489,7 +561,7 @@ __device__ void d_align1(GroupLds<TMAX, QMAX> &L, const int gl, const GroupWs &w
 
 // mm_pair, pe.c:76-177 (+ mm_set_pe_thru pe.c:45-64).  pa: scratch (n0+n1) x 3 words; sc: scratch u64
 struct PairEnt { uint64_t key; int32_t s, rev, idx; int32_t pad; };
-__device__ void d_pair(const AlParams &P, int max_gap_ref, const int *qlens, int *n_regs, AlReg *const *regs, PairEnt *pa, uint64_t *sc, const AlLogTab &lt, bool *tie, bool *ovf)
+__device__ void d_pair(const AlParams &P, int max_gap_ref, const int *qlens, int *n_regs, AlReg *const *regs, PairEnt *pa, uint64_t *sc, int sc_cap, const AlLogTab &lt, bool *tie, bool *ovf)
 {
 	const int sub_diff = P.a * 2 + P.b, match_sc = P.a;
 	int n = 0, dp_thres = 0, segs = 0;
@@ -523,7 +595,7 @@ __device__ void d_pair(const AlParams &P, int max_gap_ref, const int *qlens, int
 					if (r->dp_max + q->dp_max < dp_thres) continue;
 					const long long score = (long long)((uint64_t)(uint32_t)(r->dp_max + q->dp_max) << 32 | (uint32_t)(r->hash + q->hash));
 					if (score > max) { max = score; max_idx[pa[j].s] = j; max_idx[pa[i].s] = i; }
-					if (n_sc < AL_PAIR_SC_CAP) sc[n_sc++] = (uint64_t)score; else *ovf = true;
+					if (n_sc < sc_cap) sc[n_sc++] = (uint64_t)score; else *ovf = true;
 				}
 			} else last[pa[i].rev] = i;
 		}
@@ -658,15 +730,16 @@ k_align(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_off
         const uint32_t *__restrict__ frag_first, const int32_t *__restrict__ frag_rep, WsBase W, AlignShared G, AlLogTab lt,
         uint8_t *__restrict__ gws, size_t gws_stride, size_t p_bytes, size_t cig_words, int n_frag, AlParams P)
 {
-	__shared__ GroupLds<TMAX, QMAX> lds[4];
+	__shared__ GroupLds<TMAX, QMAX> lds[AL_GPB];
 	const int g = threadIdx.x / GW, gl = threadIdx.x % GW;
 	GroupLds<TMAX, QMAX> &L = lds[g];
 	GroupWs ws;
 	{
-		uint8_t *base = gws + ((size_t)blockIdx.x * 4 + g) * gws_stride;
-		ws.p = base; ws.cig = (uint32_t *)(base + p_bytes); ws.ezc = ws.cig + cig_words; ws.sc = (uint64_t *)(ws.ezc + cig_words);
+		uint8_t *base = gws + ((size_t)blockIdx.x * AL_GPB + g) * gws_stride;
+		ws.p = base; ws.cig = (uint32_t *)(base + p_bytes); ws.ezc = ws.cig + cig_words; ws.sc = (uint64_t *)(ws.ezc + cig_words); ws.dbg = G.dbg;
 	}
-	for (int f = blockIdx.x * 4 + g; f < n_frag; f += gridDim.x * 4) {
+	const long long tK0 = PROF_ON(P) ? clock64() : 0;
+	for (int f = blockIdx.x * AL_GPB + g; f < n_frag; f += gridDim.x * AL_GPB) {
 		const uint32_t r0 = frag_first[f], n_segs = frag_first[f + 1] - r0, n_u = W.frag_nu[f];
 		if (n_u == 0) continue;
 		FragWs fw; d_frag_ws(W, (uint32_t)f, fw);
@@ -679,9 +752,25 @@ k_align(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_off
 		else max_gap_ref = P.max_gap;
 		const int rep_len = frag_rep[f];
 		bool tie = false;
+		AlReg *mregs[2] = {fw.mreg[0], fw.mreg[1]};      // where each mate's hits currently live (LDS tile or HBM)
 		for (uint32_t s = 0; s < n_segs; ++s) {
 			const int qlen = qlens[s]; int n = (int)W.reg_cnt[r0 + s];
-			AlReg *regs = fw.mreg[s]; AlAnchor *a = fw.seg_a[s];
+			// stage the mate's hits, scratch and anchors in LDS when they fit the tiles
+			AlReg *regs = fw.mreg[s]; int cap = fw.cap;
+			AlReg *rtmp = fw.rtmp; AlAnchor *aux128 = fw.aux128; uint64_t *aux64 = fw.aux64; int *auxi = fw.auxi;
+			if (n + 1 <= AL_LREG) {
+				const uint32_t *src = (const uint32_t *)fw.mreg[s]; uint32_t *dst = (uint32_t *)L.regs[s];
+				for (int i = gl; i < n * (int)(sizeof(AlReg) / 4); i += GW) dst[i] = src[i];
+				regs = L.regs[s]; cap = AL_LREG; rtmp = L.rtmp; aux128 = L.aux128; aux64 = L.aux64; auxi = L.auxi;
+			}
+			const AlAnchor *a = fw.seg_a[s];
+			{
+				const uint32_t na = (n_segs == 2 && s == 0) ? W.seg_na[r0] : 0xffffffffu;   // mate 0's count is exact; otherwise bound by the hits
+				int need = 0; for (int i = 0; i < n; ++i) { const int e = fw.mreg[s][i].as + fw.mreg[s][i].cnt; need = e > need ? e : need; }
+				(void)na;
+				if (need <= AL_LANC) { for (int i = gl; i < need; i += GW) L.anc[i] = a[i]; a = L.anc; }
+			}
+			GSYNC();
 			if (n > 0 && qlen <= QMAX) {
 				const uint32_t *seq = rd_seq + rd_off[r0 + s];
 				for (int i = gl; i < qlen; i += GW) {                          // align.c:865-870
@@ -692,37 +781,52 @@ k_align(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_off
 				EzD ez; d_ez_reset(ez);
 				for (int i = 0; i < n; ++i) {                                  // align.c:875-906
 					AlReg r2; r2.cnt = 0;
-					d_align1(L, gl, ws, P, G, qlen, &regs[i], &r2, a, ez);
+					const long long tA = PROF_ON(P) ? clock64() : 0;
+					if (!(P.dbg & 16)) d_align1(L, gl, ws, P, G, qlen, &regs[i], &r2, a, ez);
+					if (PROF_ON(P) && gl == 0) atomicAdd(&ws.dbg[603], (unsigned long long)(clock64() - tA));
 					if (r2.cnt > 0) {
-						if (n + 1 <= fw.cap) {                                 // mm_insert_reg, align.c:847-855
+						if (n + 1 > cap && regs != fw.mreg[s]) {               // outgrew the LDS tile: continue in HBM
+							for (int j = 0; j < n; ++j) fw.mreg[s][j] = regs[j];
+							regs = fw.mreg[s]; cap = fw.cap; rtmp = fw.rtmp; aux128 = fw.aux128; aux64 = fw.aux64; auxi = fw.auxi;
+						}
+						if (n + 1 <= cap) {                                    // mm_insert_reg, align.c:847-855
 							for (int j = n - 1; j > i; --j) regs[j + 1] = regs[j];
 							regs[i + 1] = r2; ++n;
 						} else if (gl == 0) atomicAdd(&G.counters[7], 1ULL);
 					}
 				}
 			} else if (n > 0) { if (gl == 0) atomicAdd(&G.counters[7], 1ULL); n = 0; }
+			if (P.dbg & 8) { n_regs[s] = n; mregs[s] = regs; continue; }
+			const long long tB = PROF_ON(P) ? clock64() : 0;
 			d_filter_regs(P, qlen, &n, regs);                                  // align.c:910-911
-			tie = d_hit_sort(&n, regs, fw.aux128, fw.rtmp) || tie;
-			d_set_parent(P.mask_level, n, regs, P.a * 2 + P.b, fw.aux64, fw.auxi);   // align_regs tail, map.c:264-268
-			d_select_sub(P.pri_ratio, P.k * 2, P.best_n, &n, regs, fw.auxi);
+			tie = d_hit_sort(&n, regs, aux128, rtmp) || tie;
+			d_set_parent(P.mask_level, n, regs, P.a * 2 + P.b, aux64, auxi);   // align_regs tail, map.c:264-268
+			d_select_sub(P.pri_ratio, P.k * 2, P.best_n, &n, regs, auxi);
 			d_set_sam_pri(n, regs);
 			d_set_mapq(n, regs, P.min_chain_score, P.a, rep_len, lt);
-			n_regs[s] = n;
+			n_regs[s] = n; mregs[s] = regs;
+			if (PROF_ON(P) && gl == 0) atomicAdd(&ws.dbg[604], (unsigned long long)(clock64() - tB));
 			GSYNC();
 		}
 		if (n_segs == 2 && P.pe_ori >= 0) {
-			AlReg *rr[2] = {fw.mreg[0], fw.mreg[1]};
 			bool ovf = false;
-			d_pair(P, max_gap_ref, qlens, n_regs, rr, (PairEnt *)fw.rtmp, ws.sc, lt, &tie, &ovf);
+			const bool small = n_regs[0] <= AL_LREG && n_regs[1] <= AL_LREG;
+			d_pair(P, max_gap_ref, qlens, n_regs, mregs, small ? (PairEnt *)L.rtmp : (PairEnt *)fw.rtmp, small ? L.sc : ws.sc, small ? AL_LREG * AL_LREG : AL_PAIR_SC_CAP, lt, &tie, &ovf);
 			if (ovf && gl == 0) atomicAdd(&G.counters[7], 1ULL);
 		}
+		GSYNC();
 		for (uint32_t s = 0; s < n_segs; ++s) {
 			// worker_for un-flip (map.c:486-497) is applied on the host where the flip flag lives
+			if (mregs[s] != fw.mreg[s]) {                                      // publish the LDS-resident hits
+				const uint32_t *src = (const uint32_t *)mregs[s]; uint32_t *dst = (uint32_t *)fw.mreg[s];
+				for (int i = gl; i < n_regs[s] * (int)(sizeof(AlReg) / 4); i += GW) dst[i] = src[i];
+			}
 			W.reg_cnt[r0 + s] = (uint32_t)n_regs[s];
 		}
 		if (tie && gl == 0) atomicAdd(&G.counters[10], 1ULL);
 		GSYNC();
 	}
+	if (PROF_ON(P) && gl == 0) atomicAdd(&G.dbg[605], (unsigned long long)(clock64() - tK0));
 }
 
 // compaction of the per-mate hit arrays into one dense output array
@@ -761,6 +865,7 @@ struct AlignState {            // lives in al_ctx_s::align_state (opaque there)
 	DevBuf<uint32_t> reg_cnt, seg_na, arena;
 	DevBuf<uint8_t> gws;
 	DevBuf<float> logtab;
+	DevBuf<unsigned long long> dbgbuf;
 	int logtab_a = -1;
 	uint64_t out_total = 0;
 };
@@ -824,16 +929,30 @@ int al_run_align_stage(al_ctx_t *c)
 	const size_t p_bytes = ((size_t)(Lmax + tbound) * ncol * 16 + 63) / 64 * 64;
 	const size_t cig_words = ((size_t)(Lmax + tbound) + 16 + 15) / 16 * 16;
 	const size_t stride = p_bytes + cig_words * 8 + AL_PAIR_SC_CAP * 8;
-	int nb = (nf + 3) / 4; const int nb_max = 256 * 4; if (nb > nb_max) nb = nb_max;
-	if (A->gws.ensure((size_t)nb * 4 * stride + 64)) return -1;
+	int nb = (nf + AL_GPB - 1) / AL_GPB; const int nb_max = 256 * 16; if (nb > nb_max) nb = nb_max;
+	if (A->gws.ensure((size_t)nb * AL_GPB * stride + 64)) return -1;
 	const uint64_t arena_cap = (uint64_t)nr * 12 + 4096 + (uint64_t)c->n_bases / 8;
 	if (A->arena.ensure(arena_cap)) return -1;
 	AlignShared G; G.S4 = c->di.S4; G.seq_off = c->di.seq_off; G.seq_len = c->di.seq_len; G.arena = A->arena.p; G.arena_cnt = c->counters.p + 11; G.arena_cap = arena_cap; G.counters = c->counters.p;
+	if (A->dbgbuf.ensure(640)) return -1;
+	AL_HIP_CHECK(hipMemsetAsync(A->dbgbuf.p, 0, 640 * 8, s));
+	G.dbg = A->dbgbuf.p;
 	AlLogTab lt; lt.t = A->logtab.p; lt.miss = c->counters.p + 8;
-	if (Lmax <= 256 && tbound <= 512) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_align<512, 256>), dim3(nb), dim3(64), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, c->frag_first.p, c->frag_rep.p, W, G, lt, A->gws.p, stride, p_bytes, cig_words, nf, c->P);
-	else if (Lmax <= 512 && tbound <= 1024) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_align<1024, 512>), dim3(nb), dim3(64), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, c->frag_first.p, c->frag_rep.p, W, G, lt, A->gws.p, stride, p_bytes, cig_words, nf, c->P);
+	if (Lmax <= 160 && tbound <= 336) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_align<336, 160>), dim3(nb), dim3(GW * AL_GPB), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, c->frag_first.p, c->frag_rep.p, W, G, lt, A->gws.p, stride, p_bytes, cig_words, nf, c->P);
+	else if (Lmax <= 256 && tbound <= 512) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_align<512, 256>), dim3(nb), dim3(GW * AL_GPB), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, c->frag_first.p, c->frag_rep.p, W, G, lt, A->gws.p, stride, p_bytes, cig_words, nf, c->P);
+	else if (Lmax <= 512 && tbound <= 1024) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_align<1024, 512>), dim3(nb), dim3(GW * AL_GPB), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, c->frag_first.p, c->frag_rep.p, W, G, lt, A->gws.p, stride, p_bytes, cig_words, nf, c->P);
 	else { fprintf(stderr, "[airlift] reads longer than 512 bp are not supported by the device extension kernel (max read length in batch: %d)\n", Lmax); return -3; }
 	AL_HIP_CHECK(hipGetLastError());
+	if ((c->P.dbg >> 21) & 1) {
+		unsigned long long h[8]; AL_HIP_CHECK(hipMemcpyAsync(h, A->dbgbuf.p + 600, 64, hipMemcpyDeviceToHost, s)); AL_HIP_CHECK(hipStreamSynchronize(s));
+		fprintf(stderr, "[airlift] K5 profile (group-cycles): dp_init=%llu dp_rows=%llu backtrack=%llu align1_total=%llu post=%llu group_total=%llu n_dp=%llu n_rows=%llu\n", h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
+	}
+	if ((c->P.dbg >> 20) & 1) {
+		std::vector<unsigned long long> h(1 + 32 * 16);
+		AL_HIP_CHECK(hipMemcpyAsync(h.data(), A->dbgbuf.p, h.size() * 8, hipMemcpyDeviceToHost, s)); AL_HIP_CHECK(hipStreamSynchronize(s));
+		fprintf(stderr, "[airlift] DP differential check: %llu mismatching calls\n", h[0]);
+		for (unsigned long long k = 0; k < h[0] && k < 32; ++k) { const unsigned long long *o = h.data() + 1 + k * 16; fprintf(stderr, "  qlen=%llu tlen=%llu flag=%llu max %d/%d max_t %d/%d max_q %d/%d mqe %d/%d mqe_t %d/%d score %d/%d zd %llu\n", o[0], o[1], o[2], (int)o[3], (int)o[4], (int)o[5], (int)o[6], (int)o[7], (int)o[8], (int)o[9], (int)o[10], (int)o[11], (int)o[12], (int)o[13], (int)o[14], o[15]); }
+	}
 	// dense output
 	AL_HIP_CHECK(hipMemsetAsync(A->reg_cnt.p + nr, 0, 4, s));
 	if (scan32(c, A->reg_cnt.p, A->out_off.p, nr)) return -1;

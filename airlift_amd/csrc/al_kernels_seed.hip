@@ -333,8 +333,10 @@ k_chain(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_off
         const uint32_t *__restrict__ frag_list, int n_list, AlParams P, unsigned long long *__restrict__ counters)
 {
 	__shared__ uint64_t sx[CAP];
-	__shared__ int32_t sq[CAP], sf[CAP], sp[CAP], st_[CAP], sv[CAP];
-	__shared__ uint32_t sm[CAP];
+	__shared__ uint64_t s_qm[CAP];                       // Q (int32) and M (u32) halves during the DP; chain list (u64) in the tail
+	__shared__ int32_t sf[CAP], sp[CAP], st_[CAP], sv[CAP];
+	__shared__ int32_t s_nu;
+	int32_t *sq = (int32_t *)s_qm; uint32_t *sm = (uint32_t *)s_qm + CAP;
 	const int lane = threadIdx.x;
 	if ((int)blockIdx.x >= n_list) return;
 	const uint32_t f = frag_list ? frag_list[blockIdx.x] : blockIdx.x;
@@ -378,7 +380,7 @@ k_chain(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_off
 #define AM(i) (in_lds ? M[i] : ((uint32_t)(a[i].y >> 32 & 0xff) | (uint32_t)((a[i].y & AL_SEED_SEG_MASK) >> AL_SEED_SEG_SHIFT) << 8))
 
 	int64_t st = 0;
-	for (int64_t i = 0; i < n; ++i) {
+	for (int64_t i = 0; i < ((P.dbg & 32) ? 0 : n); ++i) {
 		const uint64_t ri = AX(i); const int32_t qi = AQ(i); const uint32_t mi_ = AM(i);
 		const int32_t q_span = mi_ & 0xff, sidi = mi_ >> 8;
 		while (st < i && ri > AX(st) + (uint64_t)max_dist_x) ++st;
@@ -443,10 +445,12 @@ k_chain(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_off
 	__syncthreads();
 	for (int64_t i = lane; i < n; i += 64) if (Pp[i] >= 0) T[Pp[i]] = 1;
 	__syncthreads();
+	AlAnchor *b = chained + a_off[f];
+	uint64_t *u = u_out + a_off[f] + f;                 // capacity n + 1
+	uint64_t *utmp = in_lds ? s_qm : ws_u64 + a_off[f]; // capacity n (Q/M are dead after the DP)
 	if (lane == 0) {
-		uint64_t *u = u_out + a_off[f] + f;                 // capacity n + 1
-		uint64_t *utmp = ws_u64 + a_off[f];                 // capacity n
 		int32_t n_u = 0, n_v = 0, k = 0;
+		if (!(P.dbg & 64))
 		for (int64_t i = 0; i < n; ++i)
 			if (T[i] == 0 && V[i] >= min_sc) {
 				int64_t j = i;
@@ -459,7 +463,6 @@ k_chain(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_off
 			if (n_u <= 64) {
 				for (int32_t i = 1; i < n_u; ++i) { uint64_t t = utmp[i]; int32_t j = i; while (j > 0 && utmp[j - 1] < t) { utmp[j] = utmp[j - 1]; --j; } utmp[j] = t; }
 			} else {
-				// heap sort ascending then reverse
 				for (int32_t s0 = (n_u >> 1) - 1; s0 >= 0; --s0) { int32_t i = s0; uint64_t t = utmp[i]; for (;;) { int32_t c = 2 * i + 1; if (c >= n_u) break; if (c + 1 < n_u && utmp[c + 1] > utmp[c]) ++c; if (utmp[c] <= t) break; utmp[i] = utmp[c]; i = c; } utmp[i] = t; }
 				for (int32_t e = n_u - 1; e > 0; --e) { uint64_t t = utmp[e]; utmp[e] = utmp[0]; int32_t i = 0; for (;;) { int32_t c = 2 * i + 1; if (c >= e) break; if (c + 1 < e && utmp[c + 1] > utmp[c]) ++c; if (utmp[c] <= t) break; utmp[i] = utmp[c]; i = c; } utmp[i] = t; }
 				for (int32_t i = 0; i < n_u >> 1; ++i) { uint64_t t = utmp[i]; utmp[i] = utmp[n_u - 1 - i]; utmp[n_u - 1 - i] = t; }
@@ -474,39 +477,42 @@ k_chain(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_off
 				if (k0 == k) n_v = n_v0;
 			}
 			n_u = k;
-			// order chains by the x of their first anchor (chain.c:144-160): stable insertion for <= 64 (ksort.h:149)
-			// first anchor of chain c = a[V[k0 + ni - 1]]
-			AlAnchor *b = chained + a_off[f];
-			// P array (Pp) is free now: reuse as chain start offsets into V, T as permutation
+			// order chains by the x of their first anchor (chain.c:144-160): stable insertion for <= 64 (ksort.h:149).
+			// first anchor of chain c = a[V[k0 + ni - 1]].  Pp[] (free now) = chain start offsets into V, T[] = permutation.
 			int32_t off = 0;
 			for (int32_t c = 0; c < n_u; ++c) { Pp[c] = off; off += (int32_t)(uint32_t)utmp[c]; T[c] = c; }
 			bool tie = false;
+#define CX(c) (in_lds ? X[V[Pp[c] + (int32_t)(uint32_t)utmp[c] - 1]] : a[V[Pp[c] + (int32_t)(uint32_t)utmp[c] - 1]].x)
 			if (n_u <= 64) {
 				for (int32_t i = 1; i < n_u; ++i) {
-					const int32_t ci = T[i]; const uint64_t xi = a[V[Pp[ci] + (int32_t)(uint32_t)utmp[ci] - 1]].x; int32_t j = i;
-					while (j > 0) { const int32_t cj = T[j - 1]; const uint64_t xj = a[V[Pp[cj] + (int32_t)(uint32_t)utmp[cj] - 1]].x; if (xi < xj) { T[j] = cj; --j; } else break; }
+					const int32_t ci = T[i]; const uint64_t xi = CX(ci); int32_t j = i;
+					while (j > 0) { const int32_t cj = T[j - 1]; if (xi < CX(cj)) { T[j] = cj; --j; } else break; }
 					T[j] = ci;
 				}
 			} else {
 				// > 64 chains: the reference's radix sort is unstable; order is only defined when keys are distinct.
 				// heap sort on (x, original index) and flag fragments that actually contain equal keys.
-#define CX(c) (a[V[Pp[c] + (int32_t)(uint32_t)utmp[c] - 1]].x)
 #define CLT(c1, c2) (CX(c1) < CX(c2) || (CX(c1) == CX(c2) && (c1) < (c2)))
 				for (int32_t s0 = (n_u >> 1) - 1; s0 >= 0; --s0) { int32_t i = s0, t = T[i]; for (;;) { int32_t c = 2 * i + 1; if (c >= n_u) break; if (c + 1 < n_u && CLT(T[c], T[c + 1])) ++c; if (!CLT(t, T[c])) break; T[i] = T[c]; i = c; } T[i] = t; }
 				for (int32_t e = n_u - 1; e > 0; --e) { int32_t t = T[e]; T[e] = T[0]; int32_t i = 0; for (;;) { int32_t c = 2 * i + 1; if (c >= e) break; if (c + 1 < e && CLT(T[c], T[c + 1])) ++c; if (!CLT(t, T[c])) break; T[i] = T[c]; i = c; } T[i] = t; }
 				for (int32_t i = 1; i < n_u; ++i) if (CX(T[i]) == CX(T[i - 1])) tie = true;
 #undef CLT
-#undef CX
 			}
+#undef CX
 			if (tie) atomicAdd(&counters[1], 1ULL);
 			int32_t o = 0;
-			for (int32_t i = 0; i < n_u; ++i) {
-				const int32_t c = T[i], ni = (int32_t)(uint32_t)utmp[c], k0 = Pp[c];
-				u[i] = utmp[c];
-				for (int32_t j = 0; j < ni; ++j) b[o++] = a[V[k0 + (ni - j - 1)]];
-			}
+			for (int32_t i = 0; i < n_u; ++i) { const int32_t c = T[i]; u[i] = utmp[c]; F[i] = o; o += (int32_t)(uint32_t)utmp[c]; }   // F[] = output offset of sorted chain i
 		}
 		frag_nu[f] = (uint32_t)n_u;
+		s_nu = n_u;
+	}
+	__syncthreads();
+	{   // copy-out of the chained anchors by the whole wave: b[F[i] + j] = a[V[k0 + ni - 1 - j]]
+		const int32_t n_u = s_nu;
+		for (int32_t i = 0; i < n_u; ++i) {
+			const int32_t c = T[i], ni = (int32_t)(uint32_t)utmp[c], k0 = Pp[c], o = F[i];
+			for (int32_t j = lane; j < ni; j += 64) b[o + j] = a[V[k0 + (ni - j - 1)]];
+		}
 	}
 #undef AX
 #undef AQ

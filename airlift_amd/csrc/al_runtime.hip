@@ -92,6 +92,7 @@ extern "C" al_ctx_t *al_ctx_init(const al_idx_t *mi, const al_mapopt_t *opt, int
 	P.mask_level = opt->mask_level; P.pri_ratio = opt->pri_ratio; P.max_clip_ratio = opt->max_clip_ratio; P.best_n = opt->best_n;
 	P.a = opt->a; P.b = opt->b; P.q = opt->q; P.e = opt->e; P.q2 = opt->q2; P.e2 = opt->e2; P.sc_ambi = opt->sc_ambi; P.zdrop = opt->zdrop; P.zdrop_inv = opt->zdrop_inv;
 	P.end_bonus = opt->end_bonus; P.min_dp_max = opt->min_dp_max; P.pe_ori = opt->pe_ori; P.pe_bonus = opt->pe_bonus; P.mid_occ = opt->mid_occ; P.max_occ = opt->max_occ;
+	{ const char *d = getenv("AL_DBG"); P.dbg = d ? atoi(d) : 0; if (P.dbg) fprintf(stderr, "[airlift] AL_DBG=%d: timing experiment, results are NOT valid\n", P.dbg); }
 	memset(&c->stat, 0, sizeof(c->stat));
 	return c;
 }

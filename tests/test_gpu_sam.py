@@ -44,6 +44,19 @@ def test_cli_sam_identical(golden_unpacked, name):
     assert r.stdout == exp, _diff_report(r.stdout, exp, name)
 
 
+@pytest.mark.parametrize("name", ["g2_250pe", "g3_adversarial"])
+def test_lds_dp_path_identical(golden_unpacked, name):
+    """AL_DBG=128 forces every extension through the LDS-row DP (the path long targets take) instead of the
+    register-resident one: both must give the reference's bytes."""
+    d = golden_unpacked[name]
+    m = json.load(open(os.path.join(d, "meta.json")))
+    cmd = [CLI, "-ax", "sr"] + (["-R", m["rg"]] if m.get("rg") else [])
+    r = subprocess.run(cmd + [m["ref"]] + m["reads"], cwd=d, capture_output=True, env=dict(os.environ, AL_DBG="128"))
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    exp = open(os.path.join(d, "expected.sam"), "rb").read()
+    assert r.stdout == exp, _diff_report(r.stdout, exp, name + "_lds")
+
+
 def test_bwa_style_argv(golden_unpacked):
     """B1: `<aligner> mem -R RG -t N REF R1 R2` (src/0-align_reads.sh:13) gives the same records."""
     d = golden_unpacked["g1_mt150pe"]
