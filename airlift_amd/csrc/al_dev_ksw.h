@@ -26,8 +26,8 @@ template <int CTRL> __device__ __forceinline__ void d_key_max_step(int &lo, int 
 	if (b > a) { lo = olo; hi = ohi; }
 }
 
-template <int NB, int TMAX, int QMAX>
-__device__ __forceinline__ void d_ksw_reg(GroupLds<TMAX, QMAX> &L, const int gl, GroupWs &ws, int qlen, int tlen, const AlParams &P,
+template <int NB, class LT>
+__device__ __forceinline__ void d_ksw_reg(LT &L, const int gl, GroupWs &ws, int qlen, int tlen, const AlParams &P,
                           int w, int zdrop, int end_bonus, int flag, EzD &ez, bool do_bt = true)
 {
 	int q = P.q, e = P.e, q2 = P.q2, e2 = P.e2;

@@ -76,7 +76,7 @@ struct AlAnchor { uint64_t x, y; };   // mm128_t anchor (map.c:176-187)
 
 #define AL_MAX_CIGAR_INLINE 0
 
-struct AlReg {                // device mm_reg1_t (+ mm_extra_t scalars); 96 bytes
+struct AlReg {                // device mm_reg1_t (+ mm_extra_t scalars); 112 bytes
 	int32_t id, cnt, rid, score;
 	int32_t qs, qe, rs, re;
 	int32_t parent, subsc, as, mlen;
@@ -84,8 +84,10 @@ struct AlReg {                // device mm_reg1_t (+ mm_extra_t scalars); 96 byt
 	uint32_t hash;
 	uint32_t mapq, flags;     // flags: split(2) | rev<<2 | inv<<3 | sam_pri<<4 | proper<<5 | pe_thru<<6 | seg_split<<7 | seg_id<<8 | split_inv<<16 | has_p<<17
 	int32_t dp_score, dp_max, dp_max2;
-	uint32_t n_ambi, n_cigar, cigar_off;   // cigar_off: index into the fragment-mate cigar arena
+	uint32_t n_ambi, n_cigar, cigar_off;   // cigar_off: index into the CIGAR arena, or AL_CIG_INLINE when n_cigar <= 4
+	uint32_t cig_inl[4];                   // short CIGARs are stored in the record itself (no allocation)
 };
+#define AL_CIG_INLINE 0xfffffffeu
 #define ALR_SPLIT(f)     ((f)&3u)
 #define ALR_REV          (1u<<2)
 #define ALR_INV          (1u<<3)

@@ -295,14 +295,30 @@ __device__ __forceinline__ int d_mat(const AlParams &P, int ct, int cq)
 	return ct == cq ? (P.a < 0 ? -P.a : P.a) : (P.b > 0 ? -P.b : P.b);
 }
 
-__device__ int d_test_zdrop(const AlParams &P, const uint8_t *qseq, const uint8_t *tseq, int n_cigar, const uint32_t *cigar)
+// sequence accessors: the same scalar routines run on LDS byte tiles (monolithic kernel) or straight on the packed
+// read / reference words in HBM (lane-per-fragment kernels)
+struct BytesAcc { const uint8_t *p; __device__ __forceinline__ int operator()(int i) const { return p[i]; } __device__ __forceinline__ BytesAcc shift(int n) const { return BytesAcc{p + n}; } };
+struct ReadAcc {     // qseq0[rev][off + i] of a read packed 4 bit/base in mapping orientation (align.c:865-870)
+	const uint32_t *seq; int qlen, rev, off;
+	__device__ __forceinline__ int operator()(int i) const {
+		const int j = off + i;
+		if (!rev) return (int)((seq[j >> 3] >> ((j & 7) << 2)) & 0xf);
+		const int k = qlen - 1 - j; const int c = (int)((seq[k >> 3] >> ((k & 7) << 2)) & 0xf);
+		return c < 4 ? 3 - c : 4;
+	}
+	__device__ __forceinline__ ReadAcc shift(int n) const { return ReadAcc{seq, qlen, rev, off + n}; }
+};
+struct RefAcc { const uint32_t *S4; uint64_t base; __device__ __forceinline__ int operator()(int i) const { return (int)d_seq4(S4, base + (uint64_t)i); } __device__ __forceinline__ RefAcc shift(int n) const { return RefAcc{S4, base + (uint64_t)n}; } };
+
+template <class QA, class TA>
+__device__ int d_test_zdrop(const AlParams &P, QA qseq, TA tseq, int n_cigar, const uint32_t *cigar)
 {   // mm_test_zdrop, align.c:47-89; the inversion branch is unreachable with MM_F_SR (align.c:72)
 	int score = 0, max = INT32_MIN, max_i = -1, max_j = -1, i = 0, j = 0, max_zdrop = 0;
 	for (int k = 0; k < n_cigar; ++k) {
 		const int op = cigar[k] & 0xf, len = cigar[k] >> 4;
 		if (op == 0) {
 			for (int l = 0; l < len; ++l) {
-				score += d_mat(P, tseq[i + l], qseq[j + l]);
+				score += d_mat(P, tseq(i + l), qseq(j + l));
 				if (score < max) { const int li = i + l - max_i, lj = j + l - max_j, diff = li > lj ? li - lj : lj - li, z = max - score - diff * P.e; if (z > max_zdrop) max_zdrop = z; }
 				else { max = score; max_i = i + l; max_j = j + l; }
 			}
@@ -317,7 +333,8 @@ __device__ int d_test_zdrop(const AlParams &P, const uint8_t *qseq, const uint8_
 	return max_zdrop > P.zdrop ? 1 : 0;
 }
 
-__device__ void d_fix_cigar(AlReg *r, uint32_t *cigar, const uint8_t *qseq, const uint8_t *tseq, int *qshift, int *tshift)
+template <class QA, class TA>
+__device__ void d_fix_cigar(AlReg *r, uint32_t *cigar, QA qseq, TA tseq, int *qshift, int *tshift)
 {   // mm_fix_cigar, align.c:91-167
 	int toff = 0, qoff = 0, to_shrink = 0; uint32_t k;
 	*qshift = *tshift = 0;
@@ -329,8 +346,8 @@ __device__ void d_fix_cigar(AlReg *r, uint32_t *cigar, const uint8_t *qseq, cons
 		else if (op == 1 || op == 2) {
 			if (k > 0 && k < r->n_cigar - 1 && (cigar[k - 1] & 0xf) == 0 && (cigar[k + 1] & 0xf) == 0) {
 				int l; const int prev_len = cigar[k - 1] >> 4;
-				if (op == 1) { for (l = 0; l < prev_len; ++l) if (qseq[qoff - 1 - l] != qseq[qoff + len - 1 - l]) break; }
-				else { for (l = 0; l < prev_len; ++l) if (tseq[toff - 1 - l] != tseq[toff + len - 1 - l]) break; }
+				if (op == 1) { for (l = 0; l < prev_len; ++l) if (qseq(qoff - 1 - l) != qseq(qoff + len - 1 - l)) break; }
+				else { for (l = 0; l < prev_len; ++l) if (tseq(toff - 1 - l) != tseq(toff + len - 1 - l)) break; }
 				if (l > 0) { cigar[k - 1] -= l << 4; cigar[k + 1] += l << 4; qoff -= l; toff -= l; }
 				if (l == prev_len) to_shrink = 1;
 			}
@@ -371,18 +388,19 @@ __device__ void d_fix_cigar(AlReg *r, uint32_t *cigar, const uint8_t *qseq, cons
 	}
 }
 
-__device__ void d_update_extra(const AlParams &P, AlReg *r, uint32_t *cigar, const uint8_t *qseq, const uint8_t *tseq)
+template <class QA, class TA>
+__device__ void d_update_extra(const AlParams &P, AlReg *r, uint32_t *cigar, QA qseq0_, TA tseq0_)
 {   // mm_update_extra, align.c:240-286
 	int s = 0, max = 0, qshift, tshift, toff = 0, qoff = 0;
-	d_fix_cigar(r, cigar, qseq, tseq, &qshift, &tshift);
-	qseq += qshift; tseq += tshift;
+	d_fix_cigar(r, cigar, qseq0_, tseq0_, &qshift, &tshift);
+	const QA qseq = qseq0_.shift(qshift); const TA tseq = tseq0_.shift(tshift);
 	r->blen = r->mlen = 0;
 	for (uint32_t k = 0; k < r->n_cigar; ++k) {
 		const uint32_t op = cigar[k] & 0xf, len = cigar[k] >> 4;
 		if (op == 0) {
 			int n_ambi = 0, n_diff = 0;
 			for (uint32_t l = 0; l < len; ++l) {
-				const int cq = qseq[qoff + l], ct = tseq[toff + l];
+				const int cq = qseq(qoff + l), ct = tseq(toff + l);
 				if (ct > 3 || cq > 3) ++n_ambi; else if (ct != cq) ++n_diff;
 				s += d_mat(P, ct, cq);
 				if (s < 0) s = 0; else max = max > s ? max : s;
@@ -391,13 +409,13 @@ __device__ void d_update_extra(const AlParams &P, AlReg *r, uint32_t *cigar, con
 			toff += len; qoff += len;
 		} else if (op == 1) {
 			int n_ambi = 0;
-			for (uint32_t l = 0; l < len; ++l) if (qseq[qoff + l] > 3) ++n_ambi;
+			for (uint32_t l = 0; l < len; ++l) if (qseq(qoff + l) > 3) ++n_ambi;
 			r->blen += len - n_ambi; r->n_ambi += n_ambi;
 			s -= P.q + P.e * len; if (s < 0) s = 0;
 			qoff += len;
 		} else if (op == 2) {
 			int n_ambi = 0;
-			for (uint32_t l = 0; l < len; ++l) if (tseq[toff + l] > 3) ++n_ambi;
+			for (uint32_t l = 0; l < len; ++l) if (tseq(toff + l) > 3) ++n_ambi;
 			r->blen += len - n_ambi; r->n_ambi += n_ambi;
 			s -= P.q + P.e * len; if (s < 0) s = 0;
 			toff += len;
@@ -503,7 +521,7 @@ __device__ __forceinline__ void d_align1(GroupLds<TMAX, QMAX> &L, const int gl, 
 			}
 			ez.score = sc;
 			L.ezc[0] = (uint32_t)len << 4; ez.n_cigar = 1; ws.cur_ezc = L.ezc;
-			if (!(P.dbg & 4) && d_test_zdrop(P, L.qbuf, L.tbuf, ez.n_cigar, L.ezc) != 0) {   // second pass (align.c:736-737)
+			if (!(P.dbg & 4) && d_test_zdrop(P, BytesAcc{L.qbuf}, BytesAcc{L.tbuf}, ez.n_cigar, L.ezc) != 0) {   // second pass (align.c:736-737)
 				ql = len; tl = re - rs; zd = P.zdrop; eb = -1; fl = 0; run = true;
 			}
 		} else {                                                              // right extension, align.c:760-771
@@ -547,13 +565,16 @@ __device__ __forceinline__ void d_align1(GroupLds<TMAX, QMAX> &L, const int gl, 
 		const int tl = re1 - rs1;
 		for (int i = gl; i < tl; i += GW) L.tbuf[i] = (uint8_t)d_seq4(G.S4, ref_off + (uint64_t)(rs1 + i));
 		GSYNC();
-		if (!(P.dbg & 2)) d_update_extra(P, r, ws.cur_cig, qseq0 + qs1, L.tbuf); else r->dp_max = 100;
+		if (!(P.dbg & 2)) d_update_extra(P, r, ws.cur_cig, BytesAcc{qseq0 + qs1}, BytesAcc{L.tbuf}); else r->dp_max = 100;
 		// publish the finished CIGAR: reserve words in the global arena (one atomic per group) and copy
-		unsigned long long off = 0;
-		if (gl == 0) off = atomicAdd(G.arena_cnt, (unsigned long long)r->n_cigar);
-		off = __shfl(off, 0, GW);
-		if (off + r->n_cigar <= G.arena_cap) { for (uint32_t i = gl; i < r->n_cigar; i += GW) G.arena[off + i] = ws.cur_cig[i]; r->cigar_off = (uint32_t)off; }
-		else { if (gl == 0) atomicAdd(&G.counters[9], 1ULL); r->cigar_off = 0xffffffffu; }
+		if (r->n_cigar <= 4) { for (uint32_t i = 0; i < r->n_cigar; ++i) r->cig_inl[i] = ws.cur_cig[i]; r->cigar_off = AL_CIG_INLINE; }
+		else {
+			unsigned long long off = 0;
+			if (gl == 0) off = atomicAdd(G.arena_cnt, (unsigned long long)r->n_cigar);
+			off = __shfl(off, 0, GW);
+			if (off + r->n_cigar <= G.arena_cap) { for (uint32_t i = gl; i < r->n_cigar; i += GW) G.arena[off + i] = ws.cur_cig[i]; r->cigar_off = (uint32_t)off; }
+			else { if (gl == 0) atomicAdd(&G.counters[9], 1ULL); r->cigar_off = 0xffffffffu; }
+		}
 		if (gl == 0) atomicAdd(&G.counters[6], (unsigned long long)r->n_cigar);
 	}
 	GSYNC();
@@ -728,7 +749,8 @@ template <int TMAX, int QMAX>
 __global__ void __launch_bounds__(64)
 k_align(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_off, const uint32_t *__restrict__ rd_len,
         const uint32_t *__restrict__ frag_first, const int32_t *__restrict__ frag_rep, WsBase W, AlignShared G, AlLogTab lt,
-        uint8_t *__restrict__ gws, size_t gws_stride, size_t p_bytes, size_t cig_words, int n_frag, AlParams P)
+        uint8_t *__restrict__ gws, size_t gws_stride, size_t p_bytes, size_t cig_words, int n_frag, AlParams P,
+        const uint32_t *__restrict__ frag_list, int n_list)
 {
 	__shared__ GroupLds<TMAX, QMAX> lds[AL_GPB];
 	const int g = threadIdx.x / GW, gl = threadIdx.x % GW;
@@ -739,7 +761,8 @@ k_align(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_off
 		ws.p = base; ws.cig = (uint32_t *)(base + p_bytes); ws.ezc = ws.cig + cig_words; ws.sc = (uint64_t *)(ws.ezc + cig_words); ws.dbg = G.dbg;
 	}
 	const long long tK0 = PROF_ON(P) ? clock64() : 0;
-	for (int f = blockIdx.x * AL_GPB + g; f < n_frag; f += gridDim.x * AL_GPB) {
+	for (int fi = blockIdx.x * AL_GPB + g; fi < n_list; fi += gridDim.x * AL_GPB) {
+		const int f = frag_list ? (int)frag_list[fi] : fi;
 		const uint32_t r0 = frag_first[f], n_segs = frag_first[f + 1] - r0, n_u = W.frag_nu[f];
 		if (n_u == 0) continue;
 		FragWs fw; d_frag_ws(W, (uint32_t)f, fw);
@@ -829,6 +852,340 @@ k_align(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_off
 	if (PROF_ON(P) && gl == 0) atomicAdd(&G.dbg[605], (unsigned long long)(clock64() - tK0));
 }
 
+// =============================================================================================
+// Fast path of the extension stage: the same work as k_align, batched by KIND of work so that every wavefront runs
+// one code path on similar-sized problems (k_align, with its per-fragment mix of DP sizes, spends most of its cycles
+// waiting on divergent groups):
+//   k_ext_prep    lane / fragment : max colinear stretch, DP windows, ungapped core score + z-drop test, emits <= 2 DP jobs / hit
+//   (hipCUB radix sort of the jobs by (block-count class, rows))
+//   k_ext_dp<NB>  16-lane group / job, 4 jobs / wavefront, one launch per block-count class
+//   k_ext_finish  lane / fragment : CIGAR assembly, mm_update_extra, filtering, MAPQ, pairing
+// Fragments that need something unusual (z-drop re-alignment or split of the core, CIGARs longer than the per-lane
+// buffer) are flagged and re-done from scratch by k_align on that short list.
+// =============================================================================================
+struct ExtJob {                    // 32 bytes
+	uint64_t toff;                 // reference base index of target[0] (left jobs walk downwards from it)
+	uint32_t read;                 // read index (query source)
+	uint32_t qoff;                 // index into qseq0[rev] of query[0] (left jobs walk downwards)
+	uint16_t qlen, tlen;
+	uint8_t rev, kind, pad0, pad1; // kind 0 = left extension (both sequences reversed), 1 = right extension
+	uint32_t pad2;
+};
+struct ExtOut {                    // 48 bytes
+	int32_t max, max_q, max_t, mqe_t;
+	uint32_t flags_ncig;           // bit0 reach_end, bit1 zdropped, n_cigar << 8
+	uint32_t cig_off;              // arena index when n_cigar > 6
+	uint32_t cig[6];
+};
+struct RegExt {                    // per-hit state carried from prep to finish, 32 bytes
+	int32_t rs, qs, re, qe, rs0, re0, core_score;
+	uint32_t job;                  // index of the left job; right job = job + 1
+};
+#define AL_FCIG 32                 // CIGAR words a finish lane can assemble in registers/scratch
+
+struct ExtShared {
+	ExtJob *jobs; ExtOut *outs; RegExt *rext; const uint64_t *job_off; uint32_t *frag_slow; uint32_t *job_key;
+	unsigned long long *hist;      // [0..5] jobs per block-count class, [6] empty slots
+};
+
+__device__ __forceinline__ int d_nb_class(int tlen) { const int b = (tlen + 15) / 16; return b <= 1 ? 0 : b <= 2 ? 1 : b <= 4 ? 2 : b <= 8 ? 3 : b <= 22 ? 4 : 5; }
+
+extern "C" __global__ void __launch_bounds__(256)
+k_ext_prep(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_off, const uint32_t *__restrict__ rd_len,
+           const uint32_t *__restrict__ frag_first, WsBase W, AlignShared G, ExtShared E, int n_frag, AlParams P, int tmax, int qmax)
+{
+	const int f = blockIdx.x * blockDim.x + threadIdx.x;
+	unsigned cls_cnt[7] = {0, 0, 0, 0, 0, 0, 0};
+	if (f < n_frag && W.frag_nu[f] != 0) {
+		const uint32_t r0 = frag_first[f], n_segs = frag_first[f + 1] - r0;
+		FragWs fw; d_frag_ws(W, (uint32_t)f, fw);
+		if (n_segs == 2) fw.seg_a[1] = fw.seg_a[0] + W.seg_na[r0];
+		const uint64_t B2 = (uint64_t)(fw.mreg[0] - W.mregs);      // index of mreg[0][0] in the hit array == index into rext
+		uint32_t jb = (uint32_t)E.job_off[f]; bool slow = false;
+		for (uint32_t s = 0; s < n_segs && !slow; ++s) {
+			const int qlen = (int)rd_len[r0 + s], n = (int)W.reg_cnt[r0 + s];
+			const uint32_t *seq = rd_seq + rd_off[r0 + s];
+			const AlReg *regs = fw.mreg[s]; const AlAnchor *a = fw.seg_a[s];
+			if (n > 0 && qlen > qmax) { atomicAdd(&G.counters[7], 1ULL); slow = true; break; }
+			for (int i = 0; i < n; ++i, jb += 2) {
+				const AlReg *r = &regs[i]; RegExt x; ExtJob jl, jr;
+				jl.qlen = jl.tlen = 0; jr.qlen = jr.tlen = 0; jl.pad0 = jl.pad1 = jr.pad0 = jr.pad1 = 0; jl.pad2 = jr.pad2 = 0;
+				jl.toff = jr.toff = 0; jl.read = jr.read = r0 + s; jl.qoff = jr.qoff = 0; jl.rev = jr.rev = 0; jl.kind = 0; jr.kind = 1;
+				x.job = jb; x.rs = x.qs = x.re = x.qe = x.rs0 = x.re0 = x.core_score = 0;
+				if (r->cnt > 0) {
+					const int32_t rid = (int32_t)(a[r->as].x << 1 >> 33), rev = (int32_t)(a[r->as].x >> 63);
+					const int32_t ref_len = (int32_t)G.seq_len[rid]; const uint64_t ref_off = G.seq_off[rid];
+					int as1, cnt1;
+					d_max_stretch(r, a, &as1, &cnt1);
+					int32_t rs = (int32_t)a[as1].x + 1 - (int32_t)(a[as1].y >> 32 & 0xff);
+					int32_t qs = (int32_t)a[as1].y + 1 - (int32_t)(a[as1].y >> 32 & 0xff);
+					int32_t re = (int32_t)a[as1 + cnt1 - 1].x + 1, qe = (int32_t)a[as1 + cnt1 - 1].y + 1;
+					int l = qs;                                                   // align.c:613-620
+					l += l * P.a + P.end_bonus > P.q ? (l * P.a + P.end_bonus - P.q) / P.e : 0;
+					const int32_t rs0 = rs - l > 0 ? rs - l : 0;
+					l = qlen - qe;
+					l += l * P.a + P.end_bonus > P.q ? (l * P.a + P.end_bonus - P.q) / P.e : 0;
+					const int32_t re0 = re + l < ref_len ? re + l : ref_len;
+					if (re0 - rs0 > tmax) { atomicAdd(&G.counters[7], 1ULL); slow = true; break; }
+					// ungapped core (align.c:724-731) + mm_test_zdrop with the single 'M' op (align.c:47-89)
+					const ReadAcc Q{seq, qlen, rev, qs}; const RefAcc T{G.S4, ref_off + (uint64_t)rs};
+					const int len = qe - qs; int sc = 0, zs = 0, zmax = INT32_MIN, zmi = -1, zdrop_max = 0;
+					for (int k = 0; k < len; ++k) {
+						const int cq = Q(k), ct = T(k);
+						if (cq >= 4 || ct >= 4) sc += P.e2; else sc += cq == ct ? P.a : -P.b;
+						zs += d_mat(P, ct, cq);
+						if (zs < zmax) { const int z = zmax - zs; (void)zmi; if (z > zdrop_max) zdrop_max = z; }   // diff = 0 along the diagonal
+						else { zmax = zs; zmi = k; }
+					}
+					if (zdrop_max > P.zdrop) { slow = true; break; }              // needs the second DP pass / split: monolithic path
+					x.rs = rs; x.qs = qs; x.re = re; x.qe = qe; x.rs0 = rs0; x.re0 = re0; x.core_score = sc;
+					if (qs > 0 && rs > 0) {                                       // left extension job (align.c:690-705)
+						jl.qlen = (uint16_t)qs; jl.tlen = (uint16_t)(rs - rs0); jl.rev = (uint8_t)rev;
+						jl.qoff = (uint32_t)(qs - 1); jl.toff = ref_off + (uint64_t)(rs - 1);
+					}
+					if (qe < qlen && re < re0) {                                  // right extension job (align.c:760-771)
+						jr.qlen = (uint16_t)(qlen - qe); jr.tlen = (uint16_t)(re0 - re); jr.rev = (uint8_t)rev;
+						jr.qoff = (uint32_t)qe; jr.toff = ref_off + (uint64_t)re;
+					}
+				}
+				E.rext[B2 + (uint64_t)s * fw.cap + i] = x;
+				E.jobs[jb] = jl; E.jobs[jb + 1] = jr;
+				{ const int c0 = jl.qlen ? d_nb_class(jl.tlen) : 6, c1 = jr.qlen ? d_nb_class(jr.tlen) : 6;
+				  E.job_key[jb] = jl.qlen ? ((uint32_t)c0 << 20 | (uint32_t)(jl.qlen + jl.tlen)) : 0xffffffffu;
+				  E.job_key[jb + 1] = jr.qlen ? ((uint32_t)c1 << 20 | (uint32_t)(jr.qlen + jr.tlen)) : 0xffffffffu;
+				  ++cls_cnt[c0]; ++cls_cnt[c1]; }
+			}
+		}
+		// unused job slots of this fragment (a slow fragment stops early): mark empty
+		for (uint32_t j = jb; j < (uint32_t)E.job_off[f + 1]; ++j) { E.job_key[j] = 0xffffffffu; ExtJob z; z.qlen = z.tlen = 0; z.toff = 0; z.read = 0; z.qoff = 0; z.rev = z.kind = z.pad0 = z.pad1 = 0; z.pad2 = 0; E.jobs[j] = z; ++cls_cnt[6]; }
+		E.frag_slow[f] = slow ? 1u : 0u;
+	} else if (f < n_frag) E.frag_slow[f] = 0;
+	for (int c = 0; c < 7; ++c) {                                              // one atomic per wavefront and class
+		unsigned v = cls_cnt[c];
+		for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
+		if ((threadIdx.x & 63) == 0 && v) atomicAdd(&E.hist[c], (unsigned long long)v);
+	}
+}
+
+template <int QMAXJ, int TMAXJ> struct JobLds {
+	uint8_t sq[QMAXJ + 64];         // reversed query, zero padded
+	uint8_t tbuf[TMAXJ + 16], qbuf[QMAXJ + 16];
+	uint32_t ezc[AL_LCIG];
+	uint8_t ptb[AL_LPTB];
+};
+
+// DP jobs of one block-count class: 4 jobs per wavefront, all running d_ksw_reg<NB>
+template <int NB, int QMAXJ, int TMAXJ>
+__global__ void __launch_bounds__(64)
+k_ext_dp(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_off, const uint32_t *__restrict__ rd_len,
+         AlignShared G, ExtShared E, const uint32_t *__restrict__ sorted_idx, uint32_t first, uint32_t count,
+         uint8_t *__restrict__ gws, size_t gws_stride, size_t p_bytes, size_t cig_words, AlParams P)
+{
+	__shared__ JobLds<QMAXJ, TMAXJ> lds[4];
+	const int g = threadIdx.x / GW, gl = threadIdx.x % GW;
+	JobLds<QMAXJ, TMAXJ> &L = lds[g];
+	GroupWs ws;
+	{ uint8_t *base = gws + ((size_t)blockIdx.x * 4 + g) * gws_stride; ws.p = base; ws.cig = (uint32_t *)(base + p_bytes); ws.ezc = ws.cig + cig_words; ws.sc = nullptr; ws.dbg = G.dbg; ws.cur_cig = nullptr; ws.cur_cig_cap = 0; ws.cur_ezc = nullptr; }
+	const int bw = (int)(P.bw * 1.5 + 1.);
+	for (uint32_t jj = blockIdx.x * 4 + g; jj < count; jj += gridDim.x * 4) {
+		const uint32_t j = sorted_idx[first + jj];
+		const ExtJob job = E.jobs[j];
+		const int ql = job.qlen, tl = job.tlen;
+		const uint32_t *seq = rd_seq + rd_off[job.read]; const int rqlen = (int)rd_len[job.read];
+		if (job.kind == 0) {                                                  // left: both reversed (mm_seq_rev, align.c:694-695)
+			const ReadAcc Q{seq, rqlen, job.rev, 0};
+			for (int i = gl; i < ql; i += GW) L.qbuf[i] = (uint8_t)Q((int)job.qoff - i);
+			for (int i = gl; i < tl; i += GW) L.tbuf[i] = (uint8_t)d_seq4(G.S4, job.toff - (uint64_t)i);
+		} else {
+			const ReadAcc Q{seq, rqlen, job.rev, (int)job.qoff};
+			for (int i = gl; i < ql; i += GW) L.qbuf[i] = (uint8_t)Q(i);
+			for (int i = gl; i < tl; i += GW) L.tbuf[i] = (uint8_t)d_seq4(G.S4, job.toff + (uint64_t)i);
+		}
+		GSYNC();
+		EzD ez; d_ez_reset(ez);
+		const int flag = job.kind == 0 ? (EZ_EXTZ_ONLY | EZ_RIGHT | EZ_REV_CIGAR) : EZ_EXTZ_ONLY;
+		d_ksw_reg<NB>(L, gl, ws, ql, tl, P, bw, P.zdrop, P.end_bonus, flag, ez);
+		ExtOut o;
+		o.max = ez.max; o.max_q = ez.max_q; o.max_t = ez.max_t; o.mqe_t = ez.mqe_t;
+		o.flags_ncig = (uint32_t)(ez.reach_end ? 1 : 0) | (uint32_t)(ez.zdropped ? 2 : 0) | (uint32_t)ez.n_cigar << 8; o.cig_off = 0;
+		for (int i = 0; i < 6; ++i) o.cig[i] = i < ez.n_cigar ? ws.cur_ezc[i] : 0;
+		if (ez.n_cigar > 6) {
+			unsigned long long off = 0;
+			if (gl == 0) off = atomicAdd(G.arena_cnt, (unsigned long long)ez.n_cigar);
+			off = __shfl(off, 0, GW);
+			if (off + ez.n_cigar <= G.arena_cap) { for (int i = gl; i < ez.n_cigar; i += GW) G.arena[off + i] = ws.cur_ezc[i]; o.cig_off = (uint32_t)off; }
+			else { if (gl == 0) atomicAdd(&G.counters[9], 1ULL); o.cig_off = 0xffffffffu; }
+		}
+		if (gl == 0) E.outs[j] = o;
+		GSYNC();
+	}
+}
+
+// same for targets wider than 22 blocks: LDS-row DP
+template <int TMAX, int QMAX>
+__global__ void __launch_bounds__(64)
+k_ext_dp_lds(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_off, const uint32_t *__restrict__ rd_len,
+             AlignShared G, ExtShared E, const uint32_t *__restrict__ sorted_idx, uint32_t first, uint32_t count,
+             uint8_t *__restrict__ gws, size_t gws_stride, size_t p_bytes, size_t cig_words, AlParams P)
+{
+	__shared__ GroupLds<TMAX, QMAX> lds[1];
+	const int gl = threadIdx.x % GW;
+	GroupLds<TMAX, QMAX> &L = lds[0];
+	GroupWs ws;
+	{ uint8_t *base = gws + (size_t)blockIdx.x * gws_stride; ws.p = base; ws.cig = (uint32_t *)(base + p_bytes); ws.ezc = ws.cig + cig_words; ws.sc = nullptr; ws.dbg = G.dbg; ws.cur_cig = nullptr; ws.cur_cig_cap = 0; ws.cur_ezc = nullptr; }
+	const int bw = (int)(P.bw * 1.5 + 1.);
+	for (uint32_t jj = blockIdx.x; jj < count; jj += gridDim.x) {
+		const uint32_t j = sorted_idx[first + jj];
+		const ExtJob job = E.jobs[j];
+		const int ql = job.qlen, tl = job.tlen;
+		const uint32_t *seq = rd_seq + rd_off[job.read]; const int rqlen = (int)rd_len[job.read];
+		if (job.kind == 0) {
+			const ReadAcc Q{seq, rqlen, job.rev, 0};
+			for (int i = gl; i < ql; i += GW) L.qbuf[i] = (uint8_t)Q((int)job.qoff - i);
+			for (int i = gl; i < tl; i += GW) L.tbuf[i] = (uint8_t)d_seq4(G.S4, job.toff - (uint64_t)i);
+		} else {
+			const ReadAcc Q{seq, rqlen, job.rev, (int)job.qoff};
+			for (int i = gl; i < ql; i += GW) L.qbuf[i] = (uint8_t)Q(i);
+			for (int i = gl; i < tl; i += GW) L.tbuf[i] = (uint8_t)d_seq4(G.S4, job.toff + (uint64_t)i);
+		}
+		GSYNC();
+		EzD ez; d_ez_reset(ez);
+		const int flag = job.kind == 0 ? (EZ_EXTZ_ONLY | EZ_RIGHT | EZ_REV_CIGAR) : EZ_EXTZ_ONLY;
+		d_ksw_lds(L, gl, ws, ql, tl, P, bw, P.zdrop, P.end_bonus, flag, ez);
+		ExtOut o;
+		o.max = ez.max; o.max_q = ez.max_q; o.max_t = ez.max_t; o.mqe_t = ez.mqe_t;
+		o.flags_ncig = (uint32_t)(ez.reach_end ? 1 : 0) | (uint32_t)(ez.zdropped ? 2 : 0) | (uint32_t)ez.n_cigar << 8; o.cig_off = 0;
+		for (int i = 0; i < 6; ++i) o.cig[i] = i < ez.n_cigar ? ws.cur_ezc[i] : 0;
+		if (ez.n_cigar > 6) {
+			unsigned long long off = 0;
+			if (gl == 0) off = atomicAdd(G.arena_cnt, (unsigned long long)ez.n_cigar);
+			off = __shfl(off, 0, GW);
+			if (off + ez.n_cigar <= G.arena_cap) { for (int i = gl; i < ez.n_cigar; i += GW) G.arena[off + i] = ws.cur_ezc[i]; o.cig_off = (uint32_t)off; }
+			else { if (gl == 0) atomicAdd(&G.counters[9], 1ULL); o.cig_off = 0xffffffffu; }
+		}
+		if (gl == 0) E.outs[j] = o;
+		GSYNC();
+	}
+}
+
+__device__ __forceinline__ void d_fcig_append(AlReg *r, uint32_t *cig, int n, const uint32_t *src)
+{   // mm_append_cigar (align.c:288-311) into a per-lane buffer
+	if (n == 0) return;
+	r->flags |= ALR_HAS_P;
+	if (r->n_cigar > 0 && (cig[r->n_cigar - 1] & 0xf) == (src[0] & 0xf)) {
+		cig[r->n_cigar - 1] += src[0] >> 4 << 4;
+		for (int i = 1; i < n; ++i) cig[r->n_cigar + i - 1] = src[i];
+		r->n_cigar += n - 1;
+	} else { for (int i = 0; i < n; ++i) cig[r->n_cigar + i] = src[i]; r->n_cigar += n; }
+}
+
+extern "C" __global__ void __launch_bounds__(256)
+k_ext_finish(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_off, const uint32_t *__restrict__ rd_len,
+             const uint32_t *__restrict__ frag_first, const int32_t *__restrict__ frag_rep, WsBase W, AlignShared G, ExtShared E,
+             AlLogTab lt, uint64_t *__restrict__ sc_ws, const uint64_t *__restrict__ sc_off, int n_frag, AlParams P, uint32_t *__restrict__ slow_list, uint32_t *__restrict__ n_slow)
+{
+	const int f = blockIdx.x * blockDim.x + threadIdx.x;
+	unsigned long long c_regs = 0, c_ref = 0, c_cig = 0;
+	if (f < n_frag && W.frag_nu[f] != 0) {
+		const uint32_t r0 = frag_first[f], n_segs = frag_first[f + 1] - r0;
+		FragWs fw; d_frag_ws(W, (uint32_t)f, fw);
+		if (n_segs == 2) fw.seg_a[1] = fw.seg_a[0] + W.seg_na[r0];
+		const uint64_t B2 = (uint64_t)(fw.mreg[0] - W.mregs);
+		bool slow = E.frag_slow[f] != 0;
+		// pre-check: every hit's CIGAR must fit the per-lane buffer, and none of its DP jobs may have been z-dropped in a
+		// way the monolithic path handles differently (nothing to do: z-dropped extensions are handled identically)
+		for (uint32_t s = 0; s < n_segs && !slow; ++s) {
+			const int n = (int)W.reg_cnt[r0 + s];
+			for (int i = 0; i < n && !slow; ++i) {
+				const RegExt x = E.rext[B2 + (uint64_t)s * fw.cap + i];
+				if (fw.mreg[s][i].cnt == 0) continue;
+				const uint32_t nl = E.jobs[x.job].qlen ? E.outs[x.job].flags_ncig >> 8 : 0, nr = E.jobs[x.job + 1].qlen ? E.outs[x.job + 1].flags_ncig >> 8 : 0;
+				if (nl + 1 + nr > AL_FCIG) slow = true;
+			}
+		}
+		if (slow) { slow_list[atomicAdd(n_slow, 1u)] = (uint32_t)f; }
+		else {
+			int qlens[2] = {0, 0}, qlen_sum = 0, n_regs[2] = {0, 0};
+			for (uint32_t s = 0; s < n_segs; ++s) { qlens[s] = (int)rd_len[r0 + s]; qlen_sum += qlens[s]; }
+			int max_gap_ref;
+			if (P.max_gap_ref > 0) max_gap_ref = P.max_gap_ref;
+			else if (P.max_frag_len > 0) { max_gap_ref = P.max_frag_len - qlen_sum; if (max_gap_ref < P.max_gap) max_gap_ref = P.max_gap; }
+			else max_gap_ref = P.max_gap;
+			const int rep_len = frag_rep[f]; bool tie = false;
+			for (uint32_t s = 0; s < n_segs; ++s) {
+				const int qlen = qlens[s]; int n = (int)W.reg_cnt[r0 + s];
+				const uint32_t *seq = rd_seq + rd_off[r0 + s];
+				AlReg *regs = fw.mreg[s]; const AlAnchor *a = fw.seg_a[s];
+				for (int i = 0; i < n; ++i) {                                    // mm_align1 after the DP calls (align.c:698-788)
+					AlReg *r = &regs[i];
+					if (r->cnt == 0) continue;
+					const RegExt x = E.rext[B2 + (uint64_t)s * fw.cap + i];
+					const int32_t rid = (int32_t)(a[r->as].x << 1 >> 33), rev = (int32_t)(a[r->as].x >> 63);
+					const uint64_t ref_off = G.seq_off[rid];
+					uint32_t cig[AL_FCIG];
+					r->n_cigar = 0; r->dp_score = 0; r->dp_max = 0; r->dp_max2 = 0; r->n_ambi = 0;
+					int32_t rs1 = x.rs, qs1 = x.qs, re1, qe1;
+					++c_regs; c_ref += (unsigned long long)(x.re0 - x.rs0);
+					if (E.jobs[x.job].qlen) {
+						const ExtOut o = E.outs[x.job]; const int nc = (int)(o.flags_ncig >> 8); const bool reach = o.flags_ncig & 1;
+						if (nc > 0) { d_fcig_append(r, cig, nc, nc <= 6 ? o.cig : G.arena + o.cig_off); r->dp_score += o.max; }
+						rs1 = x.rs - (reach ? o.mqe_t + 1 : o.max_t + 1);
+						qs1 = x.qs - (reach ? x.qs : o.max_q + 1);
+					}
+					{ const uint32_t m = (uint32_t)(x.qe - x.qs) << 4; d_fcig_append(r, cig, 1, &m); r->dp_score += x.core_score; }
+					re1 = x.re; qe1 = x.qe;
+					if (E.jobs[x.job + 1].qlen) {
+						const ExtOut o = E.outs[x.job + 1]; const int nc = (int)(o.flags_ncig >> 8); const bool reach = o.flags_ncig & 1;
+						if (nc > 0) { d_fcig_append(r, cig, nc, nc <= 6 ? o.cig : G.arena + o.cig_off); r->dp_score += o.max; }
+						re1 = x.re + (reach ? o.mqe_t + 1 : o.max_t + 1);
+						qe1 = x.qe + (reach ? qlen - x.qe : o.max_q + 1);
+					}
+					r->rs = rs1; r->re = re1;
+					if (rev) { r->qs = qlen - qe1; r->qe = qlen - qs1; } else { r->qs = qs1; r->qe = qe1; }
+					d_update_extra(P, r, cig, ReadAcc{seq, qlen, rev, qs1}, RefAcc{G.S4, ref_off + (uint64_t)rs1});
+					c_cig += r->n_cigar;
+					if (r->n_cigar <= 4) { for (uint32_t k = 0; k < r->n_cigar; ++k) r->cig_inl[k] = cig[k]; r->cigar_off = AL_CIG_INLINE; }
+					else {
+						const unsigned long long off = atomicAdd(G.arena_cnt, (unsigned long long)r->n_cigar);
+						if (off + r->n_cigar <= G.arena_cap) { for (uint32_t k = 0; k < r->n_cigar; ++k) G.arena[off + k] = cig[k]; r->cigar_off = (uint32_t)off; }
+						else { atomicAdd(&G.counters[9], 1ULL); r->cigar_off = 0xffffffffu; }
+					}
+				}
+				d_filter_regs(P, qlen, &n, regs);                                // align.c:910-911
+				tie = d_hit_sort(&n, regs, fw.aux128, fw.rtmp) || tie;
+				d_set_parent(P.mask_level, n, regs, P.a * 2 + P.b, fw.aux64, fw.auxi);
+				d_select_sub(P.pri_ratio, P.k * 2, P.best_n, &n, regs, fw.auxi);
+				d_set_sam_pri(n, regs);
+				d_set_mapq(n, regs, P.min_chain_score, P.a, rep_len, lt);
+				n_regs[s] = n;
+			}
+			if (n_segs == 2 && P.pe_ori >= 0) {
+				bool ovf = false; AlReg *rr[2] = {fw.mreg[0], fw.mreg[1]};
+				// pair scores: at most n0*n1 entries (bounded by the hit counts after k_regs; see k_ext_counts)
+				d_pair(P, max_gap_ref, qlens, n_regs, rr, (PairEnt *)fw.rtmp, sc_ws + sc_off[f], (int)(sc_off[f + 1] - sc_off[f]), lt, &tie, &ovf);
+				if (ovf) { atomicAdd(&G.counters[7], 1ULL); }
+			}
+			for (uint32_t s = 0; s < n_segs; ++s) W.reg_cnt[r0 + s] = (uint32_t)n_regs[s];
+			if (tie) atomicAdd(&G.counters[10], 1ULL);
+		}
+	}
+	for (int d = 32; d > 0; d >>= 1) { c_regs += __shfl_xor(c_regs, d); c_ref += __shfl_xor(c_ref, d); c_cig += __shfl_xor(c_cig, d); }
+	if ((threadIdx.x & 63) == 0) { if (c_regs) atomicAdd(&G.counters[4], c_regs); if (c_ref) atomicAdd(&G.counters[5], c_ref); if (c_cig) atomicAdd(&G.counters[6], c_cig); }
+}
+
+extern "C" __global__ void __launch_bounds__(256)
+k_ext_counts(const uint32_t *__restrict__ frag_first, WsBase W, uint32_t *__restrict__ n_jobs, uint32_t *__restrict__ n_sc, int n_frag)
+{
+	const int f = blockIdx.x * blockDim.x + threadIdx.x;
+	if (f > n_frag) return;
+	if (f == n_frag) { n_jobs[f] = 0; n_sc[f] = 0; return; }
+	const uint32_t r0 = frag_first[f], n_segs = frag_first[f + 1] - r0;
+	uint32_t c0 = 0, c1 = 0;
+	if (W.frag_nu[f] != 0) { c0 = W.reg_cnt[r0]; if (n_segs == 2) c1 = W.reg_cnt[r0 + 1]; }
+	n_jobs[f] = 2 * (c0 + c1); n_sc[f] = c0 * c1;
+}
+extern "C" __global__ void __launch_bounds__(256) k_iota(uint32_t *a, uint32_t n) { const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) a[i] = i; }
+
 // compaction of the per-mate hit arrays into one dense output array
 extern "C" __global__ void __launch_bounds__(256)
 k_compact(const uint32_t *__restrict__ frag_first, WsBase W, const uint64_t *__restrict__ out_off, AlReg *__restrict__ out, int n_frag)
@@ -865,7 +1222,10 @@ struct AlignState {            // lives in al_ctx_s::align_state (opaque there)
 	DevBuf<uint32_t> reg_cnt, seg_na, arena;
 	DevBuf<uint8_t> gws;
 	DevBuf<float> logtab;
-	DevBuf<unsigned long long> dbgbuf;
+	DevBuf<unsigned long long> dbgbuf, hist;
+	DevBuf<ExtJob> jobs; DevBuf<ExtOut> outs; DevBuf<RegExt> rext;
+	DevBuf<uint64_t> job_off, sc_off, sc_ws; DevBuf<uint32_t> n_jobs, n_sc, job_key, job_key2, job_idx, job_idx2, frag_slow, slow_list;
+	DevBuf<uint8_t> sort_tmp;
 	int logtab_a = -1;
 	uint64_t out_total = 0;
 };
@@ -885,7 +1245,8 @@ void al_align_state_free(al_ctx_t *c)
 	if (it == g_states.end()) return;
 	AlignState *s = it->second;
 	s->regs0.release(); s->mregs.release(); s->rtmp.release(); s->out.release(); s->aux128.release(); s->seg_a.release(); s->aux64.release(); s->seg_u.release();
-	s->nu_off.release(); s->out_off.release(); s->auxi.release(); s->reg_cnt.release(); s->seg_na.release(); s->arena.release(); s->gws.release(); s->logtab.release();
+	s->nu_off.release(); s->out_off.release(); s->auxi.release(); s->reg_cnt.release(); s->seg_na.release(); s->arena.release(); s->gws.release(); s->logtab.release(); s->dbgbuf.release(); s->hist.release(); s->jobs.release(); s->outs.release(); s->rext.release();
+	s->job_off.release(); s->sc_off.release(); s->sc_ws.release(); s->n_jobs.release(); s->n_sc.release(); s->job_key.release(); s->job_key2.release(); s->job_idx.release(); s->job_idx2.release(); s->frag_slow.release(); s->slow_list.release(); s->sort_tmp.release();
 	delete s; g_states.erase(it);
 }
 
@@ -938,10 +1299,77 @@ int al_run_align_stage(al_ctx_t *c)
 	AL_HIP_CHECK(hipMemsetAsync(A->dbgbuf.p, 0, 640 * 8, s));
 	G.dbg = A->dbgbuf.p;
 	AlLogTab lt; lt.t = A->logtab.p; lt.miss = c->counters.p + 8;
-	if (Lmax <= 160 && tbound <= 336) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_align<336, 160>), dim3(nb), dim3(GW * AL_GPB), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, c->frag_first.p, c->frag_rep.p, W, G, lt, A->gws.p, stride, p_bytes, cig_words, nf, c->P);
-	else if (Lmax <= 256 && tbound <= 512) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_align<512, 256>), dim3(nb), dim3(GW * AL_GPB), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, c->frag_first.p, c->frag_rep.p, W, G, lt, A->gws.p, stride, p_bytes, cig_words, nf, c->P);
-	else if (Lmax <= 512 && tbound <= 1024) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_align<1024, 512>), dim3(nb), dim3(GW * AL_GPB), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, c->frag_first.p, c->frag_rep.p, W, G, lt, A->gws.p, stride, p_bytes, cig_words, nf, c->P);
-	else { fprintf(stderr, "[airlift] reads longer than 512 bp are not supported by the device extension kernel (max read length in batch: %d)\n", Lmax); return -3; }
+	const int tmax = (Lmax <= 160 && tbound <= 336) ? 336 : (Lmax <= 256 && tbound <= 512) ? 512 : (Lmax <= 512 && tbound <= 1024) ? 1024 : 0;
+	const int qmax = tmax == 336 ? 160 : tmax == 512 ? 256 : 512;
+	if (tmax == 0) { fprintf(stderr, "[airlift] reads longer than 512 bp are not supported by the device extension kernel (max read length in batch: %d)\n", Lmax); return -3; }
+	auto launch_mono = [&](const uint32_t *list, int n_list) -> int {      // monolithic kernel (whole batch, or the slow-path list)
+		int nbm = (n_list + AL_GPB - 1) / AL_GPB; if (nbm > nb) nbm = nb; if (nbm < 1) nbm = 1;
+		if (tmax == 336) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_align<336, 160>), dim3(nbm), dim3(GW * AL_GPB), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, c->frag_first.p, c->frag_rep.p, W, G, lt, A->gws.p, stride, p_bytes, cig_words, nf, c->P, list, n_list);
+		else if (tmax == 512) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_align<512, 256>), dim3(nbm), dim3(GW * AL_GPB), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, c->frag_first.p, c->frag_rep.p, W, G, lt, A->gws.p, stride, p_bytes, cig_words, nf, c->P, list, n_list);
+		else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_align<1024, 512>), dim3(nbm), dim3(GW * AL_GPB), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, c->frag_first.p, c->frag_rep.p, W, G, lt, A->gws.p, stride, p_bytes, cig_words, nf, c->P, list, n_list);
+		return 0;
+	};
+	if ((c->P.dbg >> 26) & 1) { if (launch_mono(nullptr, nf)) return -1; }   // AL_DBG bit 26: whole batch through the monolithic kernel
+	else {
+		// ---- fast path: prep -> size-sorted DP job queue -> finish -> (slow list) monolithic
+		if (A->n_jobs.ensure(nf + 2) || A->n_sc.ensure(nf + 2) || A->job_off.ensure(nf + 2) || A->sc_off.ensure(nf + 2) || A->frag_slow.ensure(nf + 1) || A->slow_list.ensure(nf + 1) || A->hist.ensure(16)) return -1;
+		hipLaunchKernelGGL(k_ext_counts, dim3((nf + 256) / 256), dim3(256), 0, s, c->frag_first.p, W, A->n_jobs.p, A->n_sc.p, nf);
+		if (scan32(c, A->n_jobs.p, A->job_off.p, nf) || scan32(c, A->n_sc.p, A->sc_off.p, nf)) return -1;
+		uint64_t tot[2] = {0, 0};
+		AL_HIP_CHECK(hipMemcpyAsync(&tot[0], A->job_off.p + nf, 8, hipMemcpyDeviceToHost, s));
+		AL_HIP_CHECK(hipMemcpyAsync(&tot[1], A->sc_off.p + nf, 8, hipMemcpyDeviceToHost, s));
+		AL_HIP_CHECK(hipStreamSynchronize(s));
+		const uint32_t nj = (uint32_t)tot[0];
+		if (A->jobs.ensure(nj + 1) || A->outs.ensure(nj + 1) || A->job_key.ensure(nj + 1) || A->job_key2.ensure(nj + 1) || A->job_idx.ensure(nj + 1) || A->job_idx2.ensure(nj + 1) ||
+		    A->rext.ensure(2 * Btot + 1) || A->sc_ws.ensure(tot[1] + 1)) return -1;
+		AL_HIP_CHECK(hipMemsetAsync(A->hist.p, 0, 16 * 8, s));
+		ExtShared E; E.jobs = A->jobs.p; E.outs = A->outs.p; E.rext = A->rext.p; E.job_off = A->job_off.p; E.frag_slow = A->frag_slow.p; E.job_key = A->job_key.p; E.hist = A->hist.p;
+		hipLaunchKernelGGL(k_ext_prep, dim3((nf + 255) / 256), dim3(256), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, c->frag_first.p, W, G, E, nf, c->P, tmax, qmax);
+		unsigned long long hist[8] = {0};
+		if (nj > 0) {
+			hipLaunchKernelGGL(k_iota, dim3((nj + 255) / 256), dim3(256), 0, s, A->job_idx.p, nj);
+			size_t bytes = 0;
+			AL_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, A->job_key.p, A->job_key2.p, A->job_idx.p, A->job_idx2.p, (int)nj, 0, 24, s));
+			if (A->sort_tmp.ensure(bytes + 16)) return -1;
+			AL_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(A->sort_tmp.p, bytes, A->job_key.p, A->job_key2.p, A->job_idx.p, A->job_idx2.p, (int)nj, 0, 24, s));
+			AL_HIP_CHECK(hipMemcpyAsync(hist, A->hist.p, 7 * 8, hipMemcpyDeviceToHost, s));
+			AL_HIP_CHECK(hipStreamSynchronize(s));
+			// one launch per block-count class over its slice of the sorted job list
+			static const int NBs[5] = {1, 2, 4, 8, 22};
+			uint32_t first = 0;
+			for (int cls = 0; cls < 6; ++cls) {
+				const uint32_t cnt = (uint32_t)hist[cls];
+				if (cnt == 0) continue;
+				if (cls < 5) {
+					const int NB = NBs[cls];
+					const size_t pb = (((size_t)(Lmax + 16 * NB) * (size_t)(NB + 1) * 16) + 63) / 64 * 64, cw = ((size_t)(Lmax + 16 * NB) + 31) / 16 * 16, st2 = pb + cw * 8;
+					int nbj = (int)((cnt + 3) / 4); if (nbj > 2048) nbj = 2048;
+					if (A->gws.ensure((size_t)nbj * 4 * st2 + 64)) return -1;
+#define LAUNCH_DP(NBV) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ext_dp<NBV, 512, NBV * 16>), dim3(nbj), dim3(64), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, G, E, A->job_idx2.p, first, cnt, A->gws.p, st2, pb, cw, c->P)
+					if (NB == 1) LAUNCH_DP(1); else if (NB == 2) LAUNCH_DP(2); else if (NB == 4) LAUNCH_DP(4); else if (NB == 8) LAUNCH_DP(8); else LAUNCH_DP(22);
+#undef LAUNCH_DP
+				} else {
+					int nbj = (int)cnt; if (nbj > 2048) nbj = 2048;
+					if (A->gws.ensure((size_t)nbj * stride + 64)) return -1;
+					if (tmax <= 512) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ext_dp_lds<512, 256>), dim3(nbj), dim3(GW), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, G, E, A->job_idx2.p, first, cnt, A->gws.p, stride, p_bytes, cig_words, c->P);
+					else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ext_dp_lds<1024, 512>), dim3(nbj), dim3(GW), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, G, E, A->job_idx2.p, first, cnt, A->gws.p, stride, p_bytes, cig_words, c->P);
+				}
+				first += cnt;
+			}
+		}
+		uint32_t *n_slow_d = (uint32_t *)(c->counters.p + 14);
+		hipLaunchKernelGGL(k_ext_finish, dim3((nf + 255) / 256), dim3(256), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, c->frag_first.p, c->frag_rep.p, W, G, E, lt, A->sc_ws.p, A->sc_off.p, nf, c->P, A->slow_list.p, n_slow_d);
+		uint32_t n_slow = 0;
+		AL_HIP_CHECK(hipMemcpyAsync(&n_slow, n_slow_d, 4, hipMemcpyDeviceToHost, s));
+		AL_HIP_CHECK(hipStreamSynchronize(s));
+		if (n_slow > 0) {
+			int nbs = ((int)n_slow + AL_GPB - 1) / AL_GPB; if (nbs > 1024) nbs = 1024;
+			if (A->gws.ensure((size_t)nbs * AL_GPB * stride + 64)) return -1;
+			nb = nbs;
+			if (launch_mono(A->slow_list.p, (int)n_slow)) return -1;
+		}
+		c->stat_n_slow = n_slow;
+	}
 	AL_HIP_CHECK(hipGetLastError());
 	if ((c->P.dbg >> 21) & 1) {
 		unsigned long long h[8]; AL_HIP_CHECK(hipMemcpyAsync(h, A->dbgbuf.p + 600, 64, hipMemcpyDeviceToHost, s)); AL_HIP_CHECK(hipStreamSynchronize(s));
@@ -996,7 +1424,7 @@ int al_fetch_align(al_ctx_t *c, int *n_regs, al_reg1_t **regs, int *rep_len)
 			q.proper_frag = (r.flags & ALR_PROPER) ? 1 : 0; q.pe_thru = (r.flags & ALR_PE_THRU) ? 1 : 0; q.seg_split = (r.flags & ALR_SEG_SPLIT) ? 1 : 0;
 			q.seg_id = (r.flags >> 8) & 0xff; q.split_inv = 0; q.hash = r.hash; q.dp_score = r.dp_score; q.dp_max = r.dp_max; q.dp_max2 = r.dp_max2; q.n_ambi = r.n_ambi;
 			q.n_cigar = (r.flags & ALR_HAS_P) ? r.n_cigar : 0; q.cigar = nullptr;
-			if (q.n_cigar) { q.cigar = (uint32_t *)malloc((size_t)q.n_cigar * 4); memcpy(q.cigar, arena.data() + r.cigar_off, (size_t)q.n_cigar * 4); }
+			if (q.n_cigar) { q.cigar = (uint32_t *)malloc((size_t)q.n_cigar * 4); memcpy(q.cigar, r.cigar_off == AL_CIG_INLINE ? r.cig_inl : arena.data() + r.cigar_off, (size_t)q.n_cigar * 4); }
 			if (c->h_flip[i]) { const int t = q.qs; q.qs = qlen - q.qe; q.qe = qlen - t; q.rev = !q.rev; }   // map.c:486-497
 		}
 		regs[i] = o;

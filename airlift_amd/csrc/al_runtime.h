@@ -1,13 +1,24 @@
 // al_runtime.h -- per-context device state of the re-alignment pipeline (product code)
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stdio.h>
 #include <vector>
 #include <string>
 #include "al_internal.h"
 
-template <typename T> struct DevBuf {
+template <typename T> struct DevBuf {       // grow-only device array
 	T *p = nullptr; size_t cap = 0;
-	int ensure(size_t n, bool keep = false, hipStream_t s = 0);
+	int ensure(size_t n, bool keep = false, hipStream_t s = 0)
+	{
+		if (n <= cap) return 0;
+		const size_t ncap = n + n / 4 + 64;
+		T *np = nullptr;
+		if (hipMalloc((void **)&np, ncap * sizeof(T)) != hipSuccess) { fprintf(stderr, "[airlift] hipMalloc of %zu bytes failed\n", ncap * sizeof(T)); return -1; }
+		if (keep && p && cap) { if (hipMemcpyAsync(np, p, cap * sizeof(T), hipMemcpyDeviceToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return -1; }
+		if (p) (void)hipFree(p);
+		p = np; cap = ncap;
+		return 0;
+	}
 	void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
@@ -55,6 +66,7 @@ struct al_ctx_s {
 	uint64_t n_regs_cap_total = 0, n_cigar_cap_total = 0;
 	bool ran = false;
 	uint64_t stat_bytes_in = 0;
+	uint32_t stat_n_slow = 0;
 	al_batch_stat_t stat;
 };
 

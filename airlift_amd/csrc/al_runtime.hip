@@ -19,20 +19,6 @@ extern "C" __global__ void k_rechain_test(const AlAnchor *, const uint64_t *, co
 template <int CAP> __global__ void k_anchor_sort(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, AlAnchor *, const uint32_t *, int, unsigned long long *, int);
 template <int CAP> __global__ void k_chain(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, AlAnchor *, uint64_t *, uint32_t *, int32_t *, uint64_t *, const uint32_t *, int, AlParams, unsigned long long *);
 
-template <typename T> int DevBuf<T>::ensure(size_t n, bool keep, hipStream_t s)
-{
-	if (n <= cap) return 0;
-	size_t ncap = n + n / 4 + 64;
-	T *np = nullptr;
-	AL_HIP_CHECK(hipMalloc((void **)&np, ncap * sizeof(T)));
-	if (keep && p && cap) { AL_HIP_CHECK(hipMemcpyAsync(np, p, cap * sizeof(T), hipMemcpyDeviceToDevice, s)); AL_HIP_CHECK(hipStreamSynchronize(s)); }
-	if (p) (void)hipFree(p);
-	p = np; cap = ncap;
-	return 0;
-}
-template struct DevBuf<uint32_t>; template struct DevBuf<uint64_t>; template struct DevBuf<int32_t>; template struct DevBuf<AlAnchor>;
-template struct DevBuf<float>; template struct DevBuf<AlMatch>; template struct DevBuf<unsigned long long>; template struct DevBuf<uint8_t>; template struct DevBuf<AlReg>;
-
 static const char *g_stage_names[ST_N] = { "sketch", "seed_lookup", "scan", "anchor_sort", "chain", "rechain", "regs", "align" };
 extern "C" const char *al_stage_name(int i) { return i >= 0 && i < ST_N ? g_stage_names[i] : ""; }
 
