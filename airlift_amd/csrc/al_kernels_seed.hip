@@ -330,7 +330,7 @@ k_chain(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_off
         const uint32_t *__restrict__ frag_first, const uint32_t *__restrict__ rd_len,
         AlAnchor *__restrict__ chained, uint64_t *__restrict__ u_out, uint32_t *__restrict__ frag_nu,
         int32_t *__restrict__ ws_i32 /* 4 ints per anchor */, uint64_t *__restrict__ ws_u64 /* 1 per anchor */,
-        const uint32_t *__restrict__ frag_list, int n_list, AlParams P, unsigned long long *__restrict__ counters)
+        const uint32_t *__restrict__ frag_list, int n_list, AlParams P, unsigned long long *__restrict__ counters, int min_n)
 {
 	__shared__ uint64_t sx[CAP];
 	__shared__ uint64_t s_qm[CAP];                       // Q (int32) and M (u32) halves during the DP; chain list (u64) in the tail
@@ -341,6 +341,12 @@ k_chain(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_off
 	if ((int)blockIdx.x >= n_list) return;
 	const uint32_t f = frag_list ? frag_list[blockIdx.x] : blockIdx.x;
 	const int64_t n = frag_na[f];
+	if (min_n > 0) {      // wavefront-groups of 64 list entries whose largest fragment has <= min_n anchors belong to k_chain_lds
+		const int idx = ((int)blockIdx.x & ~63) + lane;
+		int v = idx < n_list ? (int)frag_na[frag_list ? frag_list[idx] : (uint32_t)idx] : 0;
+		for (int d = 32; d > 0; d >>= 1) { const int o = __shfl_xor(v, d); v = o > v ? o : v; }
+		if (v <= min_n) return;
+	}
 	if (lane == 0) frag_nu[f] = 0;
 	if (n == 0) return;
 	const uint32_t r0 = frag_first[f], r1 = frag_first[f + 1];
@@ -519,9 +525,262 @@ k_chain(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_off
 #undef AM
 }
 
+// =============================================================================================
+// K4 (small fragments): one lane per fragment.  Short-read fragments carry ~20-60 anchors, far too few to fill a
+// wavefront's predecessor scan, so they run the reference's scalar recurrence verbatim, 64 fragments per wavefront,
+// with their f/p/t/v rows in an HBM scratch that stays L2 resident (4 ints per anchor).  The caller orders fragments by
+// anchor count so that the lanes of a wavefront have (nearly) the same trip counts.
+// =============================================================================================
+extern "C" __global__ void __launch_bounds__(256)
+k_chain_lane(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_off, const uint32_t *__restrict__ frag_na,
+             const uint32_t *__restrict__ frag_first, const uint32_t *__restrict__ rd_len,
+             AlAnchor *__restrict__ chained, uint64_t *__restrict__ u_out, uint32_t *__restrict__ frag_nu,
+             int32_t *__restrict__ ws_i32, uint64_t *__restrict__ ws_u64,
+             const uint32_t *__restrict__ order, int n_list, int lane_max, AlParams P, unsigned long long *__restrict__ counters)
+{
+	const int t0 = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t0 >= n_list) return;
+	const uint32_t f = order ? order[t0] : (uint32_t)t0;
+	const int64_t n = frag_na[f];
+	if (n > lane_max) return;                     // handled by the wave-per-fragment kernel
+	frag_nu[f] = 0;
+	if (n == 0) return;
+	const uint32_t r0 = frag_first[f], r1 = frag_first[f + 1];
+	const int n_segs = (int)(r1 - r0);
+	int qlen_sum = 0; for (uint32_t r = r0; r < r1; ++r) qlen_sum += (int)rd_len[r];
+	const AlAnchor *a = anchors + a_off[f];
+	int32_t *F = ws_i32 + a_off[f] * 4, *Pp = F + n, *T = Pp + n, *V = T + n;
+	uint64_t *utmp = ws_u64 + a_off[f];
+	const int max_dist_y = qlen_sum > P.max_gap ? qlen_sum : P.max_gap;           // map.c:341-351
+	int max_dist_x;
+	if (P.max_gap_ref > 0) max_dist_x = P.max_gap_ref;
+	else if (P.max_frag_len > 0) { max_dist_x = P.max_frag_len - qlen_sum; if (max_dist_x < P.max_gap) max_dist_x = P.max_gap; }
+	else max_dist_x = P.max_gap;
+	const int bw = P.bw, max_skip = P.max_chain_skip, max_iter = P.max_chain_iter, min_cnt = P.min_cnt, min_sc = P.min_chain_score;
+	uint64_t sum_qspan = 0;
+	for (int64_t i = 0; i < n; ++i) { sum_qspan += a[i].y >> 32 & 0xff; T[i] = 0; }
+	const double avg_d = (double)(float)((double)(float)sum_qspan / (double)(float)n);   // (float)sum/n, correctly rounded (chain.c:42)
+	int64_t st = 0;
+	for (int64_t i = 0; i < n; ++i) {                                              // chain.c:46-85
+		const uint64_t ri = a[i].x; const uint64_t yi = a[i].y;
+		const int32_t qi = (int32_t)yi, q_span = (int32_t)(yi >> 32 & 0xff), sidi = (int32_t)((yi & AL_SEED_SEG_MASK) >> AL_SEED_SEG_SHIFT);
+		int64_t max_j = -1; int32_t max_f = q_span, n_skip = 0;
+		while (st < i && ri > a[st].x + (uint64_t)max_dist_x) ++st;
+		if (i - st > max_iter) st = i - max_iter;
+		for (int64_t j = i - 1; j >= st; --j) {
+			const uint64_t xj = a[j].x, yj = a[j].y;
+			const int64_t dr = (int64_t)(ri - xj);
+			const int32_t dq = qi - (int32_t)yj, sidj = (int32_t)((yj & AL_SEED_SEG_MASK) >> AL_SEED_SEG_SHIFT);
+			if ((sidi == sidj && dr == 0) || dq <= 0) continue;
+			if ((sidi == sidj && dq > max_dist_y) || dq > max_dist_x) continue;
+			const int32_t dd = dr > dq ? (int32_t)(dr - dq) : (int32_t)(dq - dr);
+			if (sidi == sidj && dd > bw) continue;
+			if (n_segs > 1 && sidi == sidj && dr > max_dist_y) continue;
+			const int32_t min_d = dq < dr ? dq : (int32_t)dr;
+			int32_t sc = min_d > q_span ? q_span : min_d;
+			const int32_t log_dd = dd ? d_ilog2((uint32_t)dd) : 0;
+			const int32_t c_lin = (int)((double)dd * .01 * avg_d);
+			if (sidi != sidj) { if (dr == 0) ++sc; else sc -= c_lin < log_dd ? c_lin : log_dd; }
+			else sc -= c_lin + (log_dd >> 1);
+			sc += F[j];
+			const int32_t pj = Pp[j];
+			if (sc > max_f) { max_f = sc; max_j = j; if (n_skip > 0) --n_skip; }
+			else if (T[j] == (int32_t)i) { if (++n_skip > max_skip) break; }
+			if (pj >= 0) T[pj] = (int32_t)i;
+		}
+		F[i] = max_f; Pp[i] = (int32_t)max_j;
+		V[i] = max_j >= 0 && V[max_j] > max_f ? V[max_j] : max_f;
+	}
+	for (int64_t i = 0; i < n; ++i) T[i] = 0;                                       // chain.c:87-109
+	for (int64_t i = 0; i < n; ++i) if (Pp[i] >= 0) T[Pp[i]] = 1;
+	int32_t n_u = 0, n_v = 0, k = 0;
+	for (int64_t i = 0; i < n; ++i)
+		if (T[i] == 0 && V[i] >= min_sc) {
+			int64_t j = i;
+			while (j >= 0 && F[j] < V[j]) j = Pp[j];
+			if (j < 0) j = i;
+			utmp[n_u++] = (uint64_t)(uint32_t)F[j] << 32 | (uint64_t)j;
+		}
+	if (n_u == 0) return;
+	// distinct keys: plain insertion sort, descending (n_u <= lane_max / 2)
+	for (int32_t i = 1; i < n_u; ++i) { const uint64_t t = utmp[i]; int32_t j = i; while (j > 0 && utmp[j - 1] < t) { utmp[j] = utmp[j - 1]; --j; } utmp[j] = t; }
+	for (int64_t i = 0; i < n; ++i) T[i] = 0;
+	for (int32_t i = 0; i < n_u; ++i) {                                              // chain.c:111-128
+		const int32_t n_v0 = n_v, k0 = k; int64_t j = (int32_t)utmp[i];
+		do { V[n_v++] = (int32_t)j; T[j] = 1; j = Pp[j]; } while (j >= 0 && T[j] == 0);
+		if (j < 0) { if (n_v - n_v0 >= min_cnt) utmp[k++] = utmp[i] >> 32 << 32 | (uint32_t)(n_v - n_v0); }
+		else if ((int32_t)(utmp[i] >> 32) - F[j] >= min_sc) { if (n_v - n_v0 >= min_cnt) utmp[k++] = (uint64_t)((utmp[i] >> 32) - (uint64_t)(uint32_t)F[j]) << 32 | (uint32_t)(n_v - n_v0); }
+		if (k0 == k) n_v = n_v0;
+	}
+	n_u = k;
+	// chains ordered by the x of their first anchor (chain.c:144-160); <= 64 chains: stable insertion sort (ksort.h:149)
+	int32_t off = 0;
+	for (int32_t c = 0; c < n_u; ++c) { Pp[c] = off; off += (int32_t)(uint32_t)utmp[c]; T[c] = c; }
+	bool tie = false;
+#define CXL(c) (a[V[Pp[c] + (int32_t)(uint32_t)utmp[c] - 1]].x)
+	for (int32_t i = 1; i < n_u; ++i) {
+		const int32_t ci = T[i]; const uint64_t xi = CXL(ci); int32_t j = i;
+		while (j > 0) { const int32_t cj = T[j - 1]; if (xi < CXL(cj)) { T[j] = cj; --j; } else break; }
+		T[j] = ci;
+	}
+	if (n_u > 64) { for (int32_t i = 1; i < n_u; ++i) if (CXL(T[i]) == CXL(T[i - 1])) tie = true; }
+#undef CXL
+	if (tie) atomicAdd(&counters[1], 1ULL);
+	AlAnchor *b = chained + a_off[f]; uint64_t *u = u_out + a_off[f] + f;
+	int32_t o = 0;
+	for (int32_t i = 0; i < n_u; ++i) {
+		const int32_t c = T[i], ni = (int32_t)(uint32_t)utmp[c], k0 = Pp[c];
+		u[i] = utmp[c];
+		for (int32_t j = 0; j < ni; ++j) b[o++] = a[V[k0 + (ni - j - 1)]];
+	}
+	frag_nu[f] = (uint32_t)n_u;
+}
+
+// =============================================================================================
+// K4 (small fragments, LDS resident): one lane per fragment, 64 fragments per wavefront, every per-anchor row
+// (x, qpos, span/segment/tandem, f, p, t, v) staged in LDS as [field][anchor][lane] so that a wavefront's accesses are
+// conflict-free and nothing is re-fetched from HBM inside the O(n^2) recurrence.  20 bytes per anchor: CAPL = 32 or 64
+// anchors per fragment (40 / 80 KB per wavefront).  The caller orders fragments by anchor count; a wavefront whose largest
+// fragment does not fall in (CAPL/2, CAPL] leaves the work to the other instantiation (or to k_chain / k_chain_lane).
+// =============================================================================================
+template <int CAPL>
+__global__ void __launch_bounds__(64)
+k_chain_lds(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_off, const uint32_t *__restrict__ frag_na,
+            const uint32_t *__restrict__ frag_first, const uint32_t *__restrict__ rd_len,
+            AlAnchor *__restrict__ chained, uint64_t *__restrict__ u_out, uint32_t *__restrict__ frag_nu, uint64_t *__restrict__ ws_u64,
+            const uint32_t *__restrict__ order, int n_list, int lo_excl, AlParams P, unsigned long long *__restrict__ counters)
+{
+	__shared__ uint64_t sx[CAPL * 64];
+	__shared__ uint16_t sq[CAPL * 64], sm[CAPL * 64], sp[CAPL * 64], st_[CAPL * 64];
+	__shared__ int16_t sf[CAPL * 64], sv[CAPL * 64];
+	const int lane = threadIdx.x;
+	const int t0 = blockIdx.x * 64 + lane;
+	const bool have = t0 < n_list;
+	const uint32_t f = have ? (order ? order[t0] : (uint32_t)t0) : 0;
+	const int n = have ? (int)frag_na[f] : 0;
+	int nmax = n;
+	for (int d = 32; d > 0; d >>= 1) { const int o = __shfl_xor(nmax, d); nmax = o > nmax ? o : nmax; }
+	if (nmax > CAPL || nmax <= lo_excl) return;                              // another instantiation / kernel owns this wavefront
+	if (!have) return;
+	frag_nu[f] = 0;
+	if (n == 0) return;
+#define XL(j) sx[(j) * 64 + lane]
+#define QL(j) sq[(j) * 64 + lane]
+#define ML(j) sm[(j) * 64 + lane]
+#define FL(j) sf[(j) * 64 + lane]
+#define PL(j) sp[(j) * 64 + lane]
+#define TL(j) st_[(j) * 64 + lane]
+#define VL(j) sv[(j) * 64 + lane]
+	const uint32_t r0 = frag_first[f], r1 = frag_first[f + 1];
+	const int n_segs = (int)(r1 - r0);
+	int qlen_sum = 0; for (uint32_t r = r0; r < r1; ++r) qlen_sum += (int)rd_len[r];
+	const AlAnchor *a = anchors + a_off[f];
+	const int max_dist_y = qlen_sum > P.max_gap ? qlen_sum : P.max_gap;           // map.c:341-351
+	int max_dist_x;
+	if (P.max_gap_ref > 0) max_dist_x = P.max_gap_ref;
+	else if (P.max_frag_len > 0) { max_dist_x = P.max_frag_len - qlen_sum; if (max_dist_x < P.max_gap) max_dist_x = P.max_gap; }
+	else max_dist_x = P.max_gap;
+	const int bw = P.bw, max_skip = P.max_chain_skip, max_iter = P.max_chain_iter, min_cnt = P.min_cnt, min_sc = P.min_chain_score;
+	uint32_t sum_qspan = 0;
+	for (int i = 0; i < n; ++i) {
+		const AlAnchor e = a[i];
+		XL(i) = e.x; QL(i) = (uint16_t)(uint32_t)e.y;
+		ML(i) = (uint16_t)((e.y >> 32 & 0xff) | ((e.y & AL_SEED_SEG_MASK) >> AL_SEED_SEG_SHIFT & 0x7f) << 8 | ((e.y & AL_SEED_TANDEM) ? 0x8000u : 0u));
+		TL(i) = 0xffff;
+		sum_qspan += (uint32_t)(e.y >> 32 & 0xff);
+	}
+	const double avg_d = (double)(float)((double)(float)sum_qspan / (double)(float)n);   // (float)sum/n (chain.c:42)
+	int st = 0;
+	for (int i = 0; i < n; ++i) {                                                 // chain.c:46-85
+		const uint64_t ri = XL(i); const uint32_t mi_ = ML(i);
+		const int32_t qi = (int32_t)QL(i), q_span = (int32_t)(mi_ & 0xff), sidi = (int32_t)(mi_ >> 8 & 0x7f);
+		int max_j = -1; int32_t max_f = q_span, n_skip = 0;
+		while (st < i && ri > XL(st) + (uint64_t)max_dist_x) ++st;
+		if (i - st > max_iter) st = i - max_iter;
+		for (int j = i - 1; j >= st; --j) {
+			const int64_t dr = (int64_t)(ri - XL(j));
+			const uint32_t mj = ML(j);
+			const int32_t dq = qi - (int32_t)QL(j), sidj = (int32_t)(mj >> 8 & 0x7f);
+			if ((sidi == sidj && dr == 0) || dq <= 0) continue;
+			if ((sidi == sidj && dq > max_dist_y) || dq > max_dist_x) continue;
+			const int32_t dd = dr > dq ? (int32_t)(dr - dq) : (int32_t)(dq - dr);
+			if (sidi == sidj && dd > bw) continue;
+			if (n_segs > 1 && sidi == sidj && dr > max_dist_y) continue;
+			const int32_t min_d = dq < dr ? dq : (int32_t)dr;
+			int32_t sc = min_d > q_span ? q_span : min_d;
+			const int32_t log_dd = dd ? d_ilog2((uint32_t)dd) : 0;
+			const int32_t c_lin = (int)((double)dd * .01 * avg_d);
+			if (sidi != sidj) { if (dr == 0) ++sc; else sc -= c_lin < log_dd ? c_lin : log_dd; }
+			else sc -= c_lin + (log_dd >> 1);
+			sc += (int32_t)FL(j);
+			const uint16_t pj = PL(j);
+			if (sc > max_f) { max_f = sc; max_j = j; if (n_skip > 0) --n_skip; }
+			else if (TL(j) == (uint16_t)i) { if (++n_skip > max_skip) break; }
+			if (pj != 0xffff) TL(pj) = (uint16_t)i;
+		}
+		FL(i) = (int16_t)max_f; PL(i) = max_j < 0 ? (uint16_t)0xffff : (uint16_t)max_j;
+		VL(i) = max_j >= 0 && (int32_t)VL(max_j) > max_f ? VL(max_j) : (int16_t)max_f;
+	}
+	// chain.c:87-109.  NB: the t[] marks above use the row index i (< CAPL) with 0xffff as "never"; from here t[] is a 0/1 flag.
+	for (int i = 0; i < n; ++i) TL(i) = 0;
+	for (int i = 0; i < n; ++i) if (PL(i) != 0xffff) TL(PL(i)) = 1;
+	uint64_t *utmp = ws_u64 + a_off[f];
+	int32_t n_u = 0, n_v = 0, k = 0;
+	for (int i = 0; i < n; ++i)
+		if (TL(i) == 0 && (int32_t)VL(i) >= min_sc) {
+			int j = i;
+			while (j >= 0 && FL(j) < VL(j)) j = PL(j) == 0xffff ? -1 : (int)PL(j);
+			if (j < 0) j = i;
+			utmp[n_u++] = (uint64_t)(uint32_t)(int32_t)FL(j) << 32 | (uint64_t)j;
+		}
+	if (n_u == 0) return;
+	for (int32_t i = 1; i < n_u; ++i) { const uint64_t t = utmp[i]; int32_t j = i; while (j > 0 && utmp[j - 1] < t) { utmp[j] = utmp[j - 1]; --j; } utmp[j] = t; }
+	for (int i = 0; i < n; ++i) TL(i) = 0;
+	for (int32_t i = 0; i < n_u; ++i) {                                              // chain.c:111-128; v[] reused as the visit list
+		const int32_t n_v0 = n_v, k0 = k; int j = (int32_t)utmp[i];
+		do { VL(n_v) = (int16_t)j; ++n_v; TL(j) = 1; j = PL(j) == 0xffff ? -1 : (int)PL(j); } while (j >= 0 && TL(j) == 0);
+		if (j < 0) { if (n_v - n_v0 >= min_cnt) utmp[k++] = utmp[i] >> 32 << 32 | (uint32_t)(n_v - n_v0); }
+		else if ((int32_t)(utmp[i] >> 32) - (int32_t)FL(j) >= min_sc) { if (n_v - n_v0 >= min_cnt) utmp[k++] = (uint64_t)((utmp[i] >> 32) - (uint64_t)(uint32_t)(int32_t)FL(j)) << 32 | (uint32_t)(n_v - n_v0); }
+		if (k0 == k) n_v = n_v0;
+	}
+	n_u = k;
+	// chains ordered by the x of their first anchor (chain.c:144-160); n_u <= 32: stable insertion sort (ksort.h:149)
+	int32_t off = 0;
+	for (int32_t c = 0; c < n_u; ++c) { PL(c) = (uint16_t)off; off += (int32_t)(uint32_t)utmp[c]; TL(c) = (uint16_t)c; }
+#define CXL(c) (XL((int)VL((int)PL(c) + (int32_t)(uint32_t)utmp[c] - 1)))
+	for (int32_t i = 1; i < n_u; ++i) {
+		const uint16_t ci = TL(i); const uint64_t xi = CXL(ci); int32_t j = i;
+		while (j > 0) { const uint16_t cj = TL(j - 1); if (xi < CXL(cj)) { TL(j) = cj; --j; } else break; }
+		TL(j) = ci;
+	}
+#undef CXL
+	AlAnchor *b = chained + a_off[f]; uint64_t *u = u_out + a_off[f] + f;
+	int32_t o = 0;
+	for (int32_t i = 0; i < n_u; ++i) {
+		const int32_t c = TL(i), ni = (int32_t)(uint32_t)utmp[c], k0 = PL(c);
+		u[i] = utmp[c];
+		for (int32_t j = 0; j < ni; ++j) {
+			const int idx = (int)VL(k0 + (ni - j - 1)); const uint32_t m = ML(idx);
+			AlAnchor e; e.x = XL(idx);
+			e.y = (uint64_t)QL(idx) | (uint64_t)(m & 0xff) << 32 | (uint64_t)(m >> 8 & 0x7f) << AL_SEED_SEG_SHIFT | ((m & 0x8000u) ? AL_SEED_TANDEM : 0ULL);
+			b[o++] = e;
+		}
+	}
+	frag_nu[f] = (uint32_t)n_u;
+#undef XL
+#undef QL
+#undef ML
+#undef FL
+#undef PL
+#undef TL
+#undef VL
+}
+template __global__ void k_chain_lds<32>(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, AlAnchor *, uint64_t *, uint32_t *, uint64_t *, const uint32_t *, int, int, AlParams, unsigned long long *);
+template __global__ void k_chain_lds<64>(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, AlAnchor *, uint64_t *, uint32_t *, uint64_t *, const uint32_t *, int, int, AlParams, unsigned long long *);
+
 // explicit instantiations used by the runtime
 template __global__ void k_anchor_sort<1024>(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, AlAnchor *, const uint32_t *, int, unsigned long long *, int);
-template __global__ void k_chain<768>(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, AlAnchor *, uint64_t *, uint32_t *, int32_t *, uint64_t *, const uint32_t *, int, AlParams, unsigned long long *);
+template __global__ void k_chain<768>(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, AlAnchor *, uint64_t *, uint32_t *, int32_t *, uint64_t *, const uint32_t *, int, AlParams, unsigned long long *, int);
 
 // rechain decision (map.c:353-375): one lane per fragment; appends fragments that must be re-seeded with max_occ
 extern "C" __global__ void __launch_bounds__(256)

@@ -17,7 +17,9 @@ extern "C" __global__ void k_seed(const uint64_t *, int, const uint32_t *, const
 extern "C" __global__ void k_alser_count(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, int, int, unsigned long long *);
 extern "C" __global__ void k_rechain_test(const AlAnchor *, const uint64_t *, const uint64_t *, const uint32_t *, const int32_t *, const uint32_t *, int, uint32_t *, uint32_t *);
 template <int CAP> __global__ void k_anchor_sort(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, AlAnchor *, const uint32_t *, int, unsigned long long *, int);
-template <int CAP> __global__ void k_chain(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, AlAnchor *, uint64_t *, uint32_t *, int32_t *, uint64_t *, const uint32_t *, int, AlParams, unsigned long long *);
+template <int CAP> __global__ void k_chain(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, AlAnchor *, uint64_t *, uint32_t *, int32_t *, uint64_t *, const uint32_t *, int, AlParams, unsigned long long *, int);
+template <int CAPL> __global__ void k_chain_lds(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, AlAnchor *, uint64_t *, uint32_t *, uint64_t *, const uint32_t *, int, int, AlParams, unsigned long long *);
+extern "C" __global__ void k_chain_lane(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, AlAnchor *, uint64_t *, uint32_t *, int32_t *, uint64_t *, const uint32_t *, int, int, AlParams, unsigned long long *);
 
 static const char *g_stage_names[ST_N] = { "sketch", "seed_lookup", "scan", "anchor_sort", "chain", "rechain", "regs", "align" };
 extern "C" const char *al_stage_name(int i) { return i >= 0 && i < ST_N ? g_stage_names[i] : ""; }
@@ -174,6 +176,7 @@ static int scan_u32_to_u64(al_ctx_t *c, const uint32_t *in, uint64_t *out, int n
 	return 0;
 }
 
+__global__ void k_iota_u32(uint32_t *a, uint32_t n) { const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) a[i] = i; }
 __global__ void k_gather_na(const uint32_t *frag_na, const uint32_t *list, int n, uint32_t *out)
 {
 	int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -222,8 +225,27 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_anchor_sort<1024>), dim3(nl), dim3(64), 0, s, c->di.pos, c->frag_first.p, c->rd_len.p, c->mini_off.p, c->match.p, c->frag_nm.p, c->frag_na.p,
 	                   c->a_off.p, c->anchors.p, c->heap_ws.p, list, nl, c->counters.p, c->mi->k);
 	if (first) AL_HIP_CHECK(hipEventRecord(c->ev[ST_ANCHOR_SORT + 1], s));
-	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<768>), dim3(nl), dim3(64), 0, s, c->anchors.p, c->a_off.p, c->frag_na.p, c->frag_first.p, c->rd_len.p, c->chained.p, c->u.p, c->frag_nu.p,
-	                   c->ws_i32.p, c->ws_u64.p, list, nl, c->P, c->counters.p);
+	{
+		// small fragments: one lane each, ordered by anchor count (uniform trip counts inside a wavefront); the rest: one wave each
+		const int lane_max = (c->P.dbg >> 27) & 1 ? 0 : 64;
+		const uint32_t *order = list;
+		if (first && lane_max > 0 && nl > 1024) {
+			if (c->chain_key.ensure(nl + 1) || c->chain_idx.ensure(nl + 1) || c->chain_idx2.ensure(nl + 1)) return -1;
+			hipLaunchKernelGGL(k_iota_u32, dim3((nl + 255) / 256), dim3(256), 0, s, c->chain_idx.p, (uint32_t)nl);
+			size_t bytes = 0;
+			AL_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const uint32_t *)c->frag_na.p, c->chain_key.p, (const uint32_t *)c->chain_idx.p, c->chain_idx2.p, nl, 0, 20, s));
+			if (c->scan_tmp.ensure(bytes + 16)) return -1;
+			AL_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(c->scan_tmp.p, bytes, (const uint32_t *)c->frag_na.p, c->chain_key.p, (const uint32_t *)c->chain_idx.p, c->chain_idx2.p, nl, 0, 20, s));
+			order = c->chain_idx2.p;
+		}
+		if (lane_max > 0) {
+			const int nw = (nl + 63) / 64;
+			hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain_lds<32>), dim3(nw), dim3(64), 0, s, c->anchors.p, c->a_off.p, c->frag_na.p, c->frag_first.p, c->rd_len.p, c->chained.p, c->u.p, c->frag_nu.p, c->ws_u64.p, order, nl, -1, c->P, c->counters.p);
+			hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain_lds<64>), dim3(nw), dim3(64), 0, s, c->anchors.p, c->a_off.p, c->frag_na.p, c->frag_first.p, c->rd_len.p, c->chained.p, c->u.p, c->frag_nu.p, c->ws_u64.p, order, nl, 32, c->P, c->counters.p);
+		}
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<768>), dim3(nl), dim3(64), 0, s, c->anchors.p, c->a_off.p, c->frag_na.p, c->frag_first.p, c->rd_len.p, c->chained.p, c->u.p, c->frag_nu.p,
+		                   c->ws_i32.p, c->ws_u64.p, order, nl, c->P, c->counters.p, lane_max);
+	}
 	if (first) AL_HIP_CHECK(hipEventRecord(c->ev[ST_CHAIN + 1], s));
 	AL_HIP_CHECK(hipGetLastError());
 	return 0;
