@@ -93,75 +93,88 @@ __device__ __forceinline__ void d_ksw_reg(LT &L, const int gl, GroupWs &ws, int 
 		const uint8_t *qrr = qr + (qlen - 1 - r);
 		const int be = en0 >> 4;
 		int hprev15 = 0;                                                 // H[en0-1] when en0 is the first lane of its block
-		long long key = (long long)0x8000000000000000ULL;                // this lane's best (H<<16 | 0xffff-ord)
 		const int en1 = st0 + (en0 - st0) / 4 * 4;
+		const uint32_t ybits = (uint32_t)(uint8_t)(int8_t)(-q - e) | (uint32_t)(uint8_t)(int8_t)(-q2 - e2) << 8;
+		const bool enr = en >= r;
+		long long key = (long long)0x8000000000000000ULL;            // this lane's best (H<<16 | 0xffff-ord); 32-bit form for NB <= 4
+		int key32 = (int)0x80000000;
+		// The body below is written with selects instead of branches: conditions are uniform inside a 16-lane group but
+		// differ between the four groups of a wavefront, so every `if` would cost an exec-mask round trip.
 #pragma unroll
 		for (int b = 0; b < NB; ++b) {
-			if (r > 0 && b + 1 == be && (en0 & 15) == 0) hprev15 = __shfl(H[b], GW - 1, GW);   // H[r-1][en0-1] (block may be outside [st_,en_])
-			if (b >= st_ && b <= en_) {
-				const int t = 16 * b + gl;
-				uint32_t a_old = A[b], b_old = B[b];
-				if (en >= r && t == r) {                                     // y[r], y2[r], u[r] (:150-153)
-					b_old = (b_old & 0xffff0000u) | (uint32_t)(uint8_t)(int8_t)(-q - e) | (uint32_t)(uint8_t)(int8_t)(-q2 - e2) << 8;
-					a_old = (a_old & 0x00ffffffu) | (uint32_t)(uint8_t)ubound << 24;
-				}
-				if (t >= st0 && t <= cover_end && t < tlen_ * 16) {          // score bytes (:158-176)
-					const uint8_t sq = (uint8_t)(b_old >> 24), sq2 = qrr[t];
-					int8_t sc = sq == sq2 ? sc_mch : sc_mis;
-					if (sq == 4 || sq2 == 4) sc = sc_N;
-					b_old = (b_old & 0xff00ffffu) | (uint32_t)(uint8_t)sc << 16;
-				}
-				const uint32_t left = (uint32_t)d_dpp_shr1((int)carry, (int)a_old);
-				if (b < en_) carry = (uint32_t)__shfl((int)a_old, GW - 1, GW);
-				const int8_t xt1 = (int8_t)left, vt1 = (int8_t)(left >> 8), x2t1 = (int8_t)(left >> 16);
-				const int8_t ut = (int8_t)(a_old >> 24), yo = (int8_t)b_old, y2o = (int8_t)(b_old >> 8);
-				int8_t z = (int8_t)(b_old >> 16);
-				int8_t a = (int8_t)(xt1 + vt1), bb = (int8_t)(yo + ut), a2 = (int8_t)(x2t1 + vt1), b2 = (int8_t)(y2o + ut);
-				int d;
-				// left-aligned gaps take a strict '>' (ksw2_extd2_sse.c:206-214), right-aligned '>=' (:252-260)
-				d = (a > z || (right && a == z)) ? 1 : 0;   z = z > a ? z : a;
-				d = (bb > z || (right && bb == z)) ? 2 : d; z = z > bb ? z : bb;
-				d = (a2 > z || (right && a2 == z)) ? 3 : d; z = z > a2 ? z : a2;
-				d = (b2 > z || (right && b2 == z)) ? 4 : d; z = z > b2 ? z : b2;
-				z = z < sc_mch ? z : sc_mch;
-				const int8_t un = (int8_t)(z - vt1), vn = (int8_t)(z - ut);
-				int8_t tmp = (int8_t)(z - q); a = (int8_t)(a - tmp); bb = (int8_t)(bb - tmp);
-				tmp = (int8_t)(z - q2); a2 = (int8_t)(a2 - tmp); b2 = (int8_t)(b2 - tmp);
-				const bool pa = right ? a >= 0 : a > 0, pb = right ? bb >= 0 : bb > 0, pa2 = right ? a2 >= 0 : a2 > 0, pb2 = right ? b2 >= 0 : b2 > 0;
-				const int8_t xn = (int8_t)((pa ? a : 0) - qe_), yn = (int8_t)((pb ? bb : 0) - qe_);
-				const int8_t x2n = (int8_t)((pa2 ? a2 : 0) - qe2_), y2n = (int8_t)((pb2 ? b2 : 0) - qe2_);
-				d |= (pa ? 0x08 : 0) | (pb ? 0x10 : 0) | (pa2 ? 0x20 : 0) | (pb2 ? 0x40 : 0);
-				A[b] = (uint32_t)(uint8_t)xn | (uint32_t)(uint8_t)vn << 8 | (uint32_t)(uint8_t)x2n << 16 | (uint32_t)(uint8_t)un << 24;
-				B[b] = (b_old & 0xffff0000u) | (uint32_t)(uint8_t)yn | (uint32_t)(uint8_t)y2n << 8;
-				if (!((P.dbg >> 23) & 1)) pr[t] = (uint8_t)d;
-				// ---- exact max (:307-349): H row update and this lane's candidate
-				if (r > 0 && !((P.dbg >> 24) & 1)) {
-					const int hold = H[b];
-					int hl = 0;
-					if (b == be) hl = d_dpp_shr1(hprev15, hold);             // H[r-1][t-1]
-					if (t >= st0 && t <= en0) {
-						int h, ord;
-						if (t == en0) { h = en0 > 0 ? hl + un : hold + vn; ord = 0; }
-						else { h = hold + vn; ord = t < en1 ? 1 + ((t - st0) & 3) * 4096 + ((t - st0) >> 2) : 1 + 4 * 4096 + (t - en1); }
-						H[b] = h;
-						const long long k2 = (long long)h * 65536 + (0xffff - ord);
-						key = k2 > key ? k2 : key;
-					}
-				} else if (t == 0) { H[b] = (int)vn - qe; key = (long long)H[b] * 65536 + 0xffff; }
+			if (NB > 1 && r > 0 && b + 1 == be && (en0 & 15) == 0) hprev15 = __shfl(H[b], GW - 1, GW);   // H[r-1][en0-1] (block may be outside [st_,en_])
+			const bool act = NB == 1 ? true : (b >= st_ && b <= en_);
+			if (NB >= 8 && !act) continue;
+			const int t = 16 * b + gl;
+			uint32_t a_old = A[b], b_old = B[b];
+			const bool isr = act && enr && t == r;                           // y[r], y2[r], u[r] (:150-153)
+			b_old = isr ? ((b_old & 0xffff0000u) | ybits) : b_old;
+			a_old = isr ? ((a_old & 0x00ffffffu) | (uint32_t)(uint8_t)ubound << 24) : a_old;
+			{                                                                // score bytes (:158-176); the LDS read is unconditional on a clamped index
+				const bool son = act && t >= st0 && t <= cover_end && t < tlen_ * 16;
+				int qi = qlen - 1 - r + t; qi = qi < 0 ? 0 : qi; qi = qi > qlen_ * 16 + 31 ? qlen_ * 16 + 31 : qi;
+				const uint8_t sq = (uint8_t)(b_old >> 24), sq2 = qr[qi];
+				int8_t sc = sq == sq2 ? sc_mch : sc_mis;
+				sc = (sq == 4 || sq2 == 4) ? sc_N : sc;
+				b_old = son ? ((b_old & 0xff00ffffu) | (uint32_t)(uint8_t)sc << 16) : b_old;
+			}
+			const uint32_t left = (uint32_t)d_dpp_shr1((int)carry, (int)a_old);
+			if (NB > 1) { const uint32_t cn = (uint32_t)__shfl((int)a_old, GW - 1, GW); carry = act ? cn : carry; }
+			const int8_t xt1 = (int8_t)left, vt1 = (int8_t)(left >> 8), x2t1 = (int8_t)(left >> 16);
+			const int8_t ut = (int8_t)(a_old >> 24), yo = (int8_t)b_old, y2o = (int8_t)(b_old >> 8);
+			int8_t z = (int8_t)(b_old >> 16);
+			int8_t a = (int8_t)(xt1 + vt1), bb = (int8_t)(yo + ut), a2 = (int8_t)(x2t1 + vt1), b2 = (int8_t)(y2o + ut);
+			int d;
+			// left-aligned gaps take a strict '>' (ksw2_extd2_sse.c:206-214), right-aligned '>=' (:252-260)
+			d = (a > z || (right && a == z)) ? 1 : 0;   z = z > a ? z : a;
+			d = (bb > z || (right && bb == z)) ? 2 : d; z = z > bb ? z : bb;
+			d = (a2 > z || (right && a2 == z)) ? 3 : d; z = z > a2 ? z : a2;
+			d = (b2 > z || (right && b2 == z)) ? 4 : d; z = z > b2 ? z : b2;
+			z = z < sc_mch ? z : sc_mch;
+			const int8_t un = (int8_t)(z - vt1), vn = (int8_t)(z - ut);
+			int8_t tmp = (int8_t)(z - q); a = (int8_t)(a - tmp); bb = (int8_t)(bb - tmp);
+			tmp = (int8_t)(z - q2); a2 = (int8_t)(a2 - tmp); b2 = (int8_t)(b2 - tmp);
+			const bool pa = right ? a >= 0 : a > 0, pb = right ? bb >= 0 : bb > 0, pa2 = right ? a2 >= 0 : a2 > 0, pb2 = right ? b2 >= 0 : b2 > 0;
+			const int8_t xn = (int8_t)((pa ? a : 0) - qe_), yn = (int8_t)((pb ? bb : 0) - qe_);
+			const int8_t x2n = (int8_t)((pa2 ? a2 : 0) - qe2_), y2n = (int8_t)((pb2 ? b2 : 0) - qe2_);
+			d |= (pa ? 0x08 : 0) | (pb ? 0x10 : 0) | (pa2 ? 0x20 : 0) | (pb2 ? 0x40 : 0);
+			const uint32_t An = (uint32_t)(uint8_t)xn | (uint32_t)(uint8_t)vn << 8 | (uint32_t)(uint8_t)x2n << 16 | (uint32_t)(uint8_t)un << 24;
+			const uint32_t Bn = (b_old & 0xffff0000u) | (uint32_t)(uint8_t)yn | (uint32_t)(uint8_t)y2n << 8;
+			A[b] = act ? An : A[b]; B[b] = act ? Bn : B[b];
+			if (act && !((P.dbg >> 23) & 1)) pr[t] = (uint8_t)d;
+			// ---- exact max (:307-349): H row update and this lane's candidate
+			{
+				const int hold = H[b];
+				const int hl = (NB == 1 || b == be) ? d_dpp_shr1(hprev15, hold) : 0;      // H[r-1][t-1]
+				const bool inr = act && r > 0 && t >= st0 && t <= en0;
+				const bool r0c = act && r == 0 && t == 0;
+				const bool isen = t == en0;
+				int h = isen ? (en0 > 0 ? hl + un : hold + vn) : hold + vn;
+				h = r0c ? (int)vn - qe : h;
+				const int ord = isen || r0c ? 0 : (t < en1 ? 1 + ((t - st0) & 3) * 4096 + ((t - st0) >> 2) : 1 + 4 * 4096 + (t - en1));
+				H[b] = (inr || r0c) ? h : hold;
+				if (NB <= 4) { const int k2 = h * 65536 + (0xffff - ord); key32 = ((inr || r0c) && k2 > key32) ? k2 : key32; }
+				else { const long long k2 = (long long)h * 65536 + (0xffff - ord); key = ((inr || r0c) && k2 > key) ? k2 : key; }
 			}
 		}
 		int max_H, max_t;
 		{
-			int lo = (int)(unsigned)(unsigned long long)key, hi = (int)((unsigned long long)key >> 32);
-			d_key_max_step<DPP_QUAD_XOR1>(lo, hi); d_key_max_step<DPP_QUAD_XOR2>(lo, hi);
-			d_key_max_step<DPP_HALF_MIRROR>(lo, hi); d_key_max_step<DPP_ROW_MIRROR>(lo, hi);
-			const long long kk = (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
-			max_H = (int)(kk >> 16);
-			const int ord = 0xffff - (int)(kk & 0xffff);
-			if (r == 0) max_t = 0;
-			else if (ord == 0) max_t = en0;
-			else if (ord < 1 + 4 * 4096) max_t = st0 + ((ord - 1) & 4095) * 4 + ((ord - 1) >> 12);
-			else max_t = en1 + (ord - 1 - 4 * 4096);
+			int ord;
+			if (NB <= 4) {                                                   // |H| < 2^15 for targets of <= 64 bases
+				int k = key32;
+				{ const int o = __builtin_amdgcn_update_dpp(k, k, DPP_QUAD_XOR1, 0xf, 0xf, false); k = o > k ? o : k; }
+				{ const int o = __builtin_amdgcn_update_dpp(k, k, DPP_QUAD_XOR2, 0xf, 0xf, false); k = o > k ? o : k; }
+				{ const int o = __builtin_amdgcn_update_dpp(k, k, DPP_HALF_MIRROR, 0xf, 0xf, false); k = o > k ? o : k; }
+				{ const int o = __builtin_amdgcn_update_dpp(k, k, DPP_ROW_MIRROR, 0xf, 0xf, false); k = o > k ? o : k; }
+				max_H = k >> 16; ord = 0xffff - (k & 0xffff);
+			} else {
+				int lo = (int)(unsigned)(unsigned long long)key, hi = (int)((unsigned long long)key >> 32);
+				d_key_max_step<DPP_QUAD_XOR1>(lo, hi); d_key_max_step<DPP_QUAD_XOR2>(lo, hi);
+				d_key_max_step<DPP_HALF_MIRROR>(lo, hi); d_key_max_step<DPP_ROW_MIRROR>(lo, hi);
+				const long long kk = (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+				max_H = (int)(kk >> 16); ord = 0xffff - (int)(kk & 0xffff);
+			}
+			max_t = r == 0 ? 0 : ord == 0 ? en0 : ord < 1 + 4 * 4096 ? st0 + ((ord - 1) & 4095) * 4 + ((ord - 1) >> 12) : en1 + (ord - 1 - 4 * 4096);
 		}
 		if (r - st0 == qlen - 1) {                                           // :353-354
 			int hs = 0;

@@ -99,4 +99,4 @@ struct AlReg {                // device mm_reg1_t (+ mm_extra_t scalars); 112 by
 #define ALR_SPLIT_INV    (1u<<16)
 #define ALR_HAS_P        (1u<<17)
 
-enum AlStage { ST_SKETCH = 0, ST_SEED, ST_SCAN, ST_ANCHOR_SORT, ST_CHAIN, ST_RECHAIN, ST_REGS, ST_ALIGN, ST_N };
+enum AlStage { ST_SKETCH = 0, ST_SEED, ST_SCAN, ST_ANCHOR_SORT, ST_CHAIN, ST_RECHAIN, ST_REGS, ST_EXT_PREP, ST_EXT_SORT, ST_EXT_DP, ST_EXT_FINISH, ST_COMPACT, ST_N };

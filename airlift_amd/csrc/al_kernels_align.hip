@@ -1255,7 +1255,7 @@ int al_run_align_stage(al_ctx_t *c)
 	hipStream_t s = c->stream;
 	AlignState *A = get_state(c);
 	const int nf = c->n_frag, nr = c->n_reads;
-	if (nf == 0) { AL_HIP_CHECK(hipEventRecord(c->ev[ST_REGS + 1], s)); return 0; }
+	if (nf == 0) { for (int i = ST_REGS; i < ST_COMPACT; ++i) AL_HIP_CHECK(hipEventRecord(c->ev[i + 1], s)); return 0; }
 	// logf table from the HOST libm (the reference's logf is glibc's): logf((float)k / a) and logf((float)k)
 	if (A->logtab_a != c->opt.a) {
 		std::vector<float> h(2 * AL_LOGTAB_N);
@@ -1309,7 +1309,7 @@ int al_run_align_stage(al_ctx_t *c)
 		else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_align<1024, 512>), dim3(nbm), dim3(GW * AL_GPB), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, c->frag_first.p, c->frag_rep.p, W, G, lt, A->gws.p, stride, p_bytes, cig_words, nf, c->P, list, n_list);
 		return 0;
 	};
-	if ((c->P.dbg >> 26) & 1) { if (launch_mono(nullptr, nf)) return -1; }   // AL_DBG bit 26: whole batch through the monolithic kernel
+	if ((c->P.dbg >> 26) & 1) { if (launch_mono(nullptr, nf)) return -1; for (int i = ST_EXT_PREP; i <= ST_EXT_FINISH; ++i) AL_HIP_CHECK(hipEventRecord(c->ev[i + 1], s)); }   // AL_DBG bit 26: whole batch through the monolithic kernel
 	else {
 		// ---- fast path: prep -> size-sorted DP job queue -> finish -> (slow list) monolithic
 		if (A->n_jobs.ensure(nf + 2) || A->n_sc.ensure(nf + 2) || A->job_off.ensure(nf + 2) || A->sc_off.ensure(nf + 2) || A->frag_slow.ensure(nf + 1) || A->slow_list.ensure(nf + 1) || A->hist.ensure(16)) return -1;
@@ -1325,6 +1325,7 @@ int al_run_align_stage(al_ctx_t *c)
 		AL_HIP_CHECK(hipMemsetAsync(A->hist.p, 0, 16 * 8, s));
 		ExtShared E; E.jobs = A->jobs.p; E.outs = A->outs.p; E.rext = A->rext.p; E.job_off = A->job_off.p; E.frag_slow = A->frag_slow.p; E.job_key = A->job_key.p; E.hist = A->hist.p;
 		hipLaunchKernelGGL(k_ext_prep, dim3((nf + 255) / 256), dim3(256), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, c->frag_first.p, W, G, E, nf, c->P, tmax, qmax);
+		AL_HIP_CHECK(hipEventRecord(c->ev[ST_EXT_PREP + 1], s));
 		unsigned long long hist[8] = {0};
 		if (nj > 0) {
 			hipLaunchKernelGGL(k_iota, dim3((nj + 255) / 256), dim3(256), 0, s, A->job_idx.p, nj);
@@ -1332,6 +1333,7 @@ int al_run_align_stage(al_ctx_t *c)
 			AL_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, A->job_key.p, A->job_key2.p, A->job_idx.p, A->job_idx2.p, (int)nj, 0, 24, s));
 			if (A->sort_tmp.ensure(bytes + 16)) return -1;
 			AL_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(A->sort_tmp.p, bytes, A->job_key.p, A->job_key2.p, A->job_idx.p, A->job_idx2.p, (int)nj, 0, 24, s));
+			AL_HIP_CHECK(hipEventRecord(c->ev[ST_EXT_SORT + 1], s));
 			AL_HIP_CHECK(hipMemcpyAsync(hist, A->hist.p, 7 * 8, hipMemcpyDeviceToHost, s));
 			AL_HIP_CHECK(hipStreamSynchronize(s));
 			// one launch per block-count class over its slice of the sorted job list
@@ -1357,6 +1359,8 @@ int al_run_align_stage(al_ctx_t *c)
 				first += cnt;
 			}
 		}
+		else AL_HIP_CHECK(hipEventRecord(c->ev[ST_EXT_SORT + 1], s));
+		AL_HIP_CHECK(hipEventRecord(c->ev[ST_EXT_DP + 1], s));
 		uint32_t *n_slow_d = (uint32_t *)(c->counters.p + 14);
 		hipLaunchKernelGGL(k_ext_finish, dim3((nf + 255) / 256), dim3(256), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, c->frag_first.p, c->frag_rep.p, W, G, E, lt, A->sc_ws.p, A->sc_off.p, nf, c->P, A->slow_list.p, n_slow_d);
 		uint32_t n_slow = 0;
@@ -1369,6 +1373,7 @@ int al_run_align_stage(al_ctx_t *c)
 			if (launch_mono(A->slow_list.p, (int)n_slow)) return -1;
 		}
 		c->stat_n_slow = n_slow;
+		AL_HIP_CHECK(hipEventRecord(c->ev[ST_EXT_FINISH + 1], s));
 	}
 	AL_HIP_CHECK(hipGetLastError());
 	if ((c->P.dbg >> 21) & 1) {

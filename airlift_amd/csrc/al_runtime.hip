@@ -21,7 +21,7 @@ template <int CAP> __global__ void k_chain(const AlAnchor *, const uint64_t *, c
 template <int CAPL> __global__ void k_chain_lds(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, AlAnchor *, uint64_t *, uint32_t *, uint64_t *, const uint32_t *, int, int, AlParams, unsigned long long *);
 extern "C" __global__ void k_chain_lane(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, AlAnchor *, uint64_t *, uint32_t *, int32_t *, uint64_t *, const uint32_t *, int, int, AlParams, unsigned long long *);
 
-static const char *g_stage_names[ST_N] = { "sketch", "seed_lookup", "scan", "anchor_sort", "chain", "rechain", "regs", "align" };
+static const char *g_stage_names[ST_N] = { "sketch", "seed_lookup", "scan", "anchor_sort", "chain", "rechain", "regs", "ext_prep", "ext_sort", "ext_dp", "ext_finish", "compact" };
 extern "C" const char *al_stage_name(int i) { return i >= 0 && i < ST_N ? g_stage_names[i] : ""; }
 
 // ---------------------------------------------------------------------------------------------
@@ -176,6 +176,11 @@ static int scan_u32_to_u64(al_ctx_t *c, const uint32_t *in, uint64_t *out, int n
 	return 0;
 }
 
+__global__ void k_lower_bound(const uint32_t *keys, uint32_t n, uint32_t v, uint32_t *out)
+{   // first index with keys[i] >= v in an ascending array (out pre-set to n)
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n && keys[i] >= v && (i == 0 || keys[i - 1] < v)) *out = i;
+}
 __global__ void k_iota_u32(uint32_t *a, uint32_t n) { const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) a[i] = i; }
 __global__ void k_gather_na(const uint32_t *frag_na, const uint32_t *list, int n, uint32_t *out)
 {
@@ -228,7 +233,7 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 	{
 		// small fragments: one lane each, ordered by anchor count (uniform trip counts inside a wavefront); the rest: one wave each
 		const int lane_max = (c->P.dbg >> 27) & 1 ? 0 : 64;
-		const uint32_t *order = list;
+		const uint32_t *order = list; bool sorted = false;
 		if (first && lane_max > 0 && nl > 1024) {
 			if (c->chain_key.ensure(nl + 1) || c->chain_idx.ensure(nl + 1) || c->chain_idx2.ensure(nl + 1)) return -1;
 			hipLaunchKernelGGL(k_iota_u32, dim3((nl + 255) / 256), dim3(256), 0, s, c->chain_idx.p, (uint32_t)nl);
@@ -236,15 +241,29 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 			AL_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const uint32_t *)c->frag_na.p, c->chain_key.p, (const uint32_t *)c->chain_idx.p, c->chain_idx2.p, nl, 0, 20, s));
 			if (c->scan_tmp.ensure(bytes + 16)) return -1;
 			AL_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(c->scan_tmp.p, bytes, (const uint32_t *)c->frag_na.p, c->chain_key.p, (const uint32_t *)c->chain_idx.p, c->chain_idx2.p, nl, 0, 20, s));
-			order = c->chain_idx2.p;
+			order = c->chain_idx2.p; sorted = true;
 		}
 		if (lane_max > 0) {
 			const int nw = (nl + 63) / 64;
 			hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain_lds<32>), dim3(nw), dim3(64), 0, s, c->anchors.p, c->a_off.p, c->frag_na.p, c->frag_first.p, c->rd_len.p, c->chained.p, c->u.p, c->frag_nu.p, c->ws_u64.p, order, nl, -1, c->P, c->counters.p);
 			hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain_lds<64>), dim3(nw), dim3(64), 0, s, c->anchors.p, c->a_off.p, c->frag_na.p, c->frag_first.p, c->rd_len.p, c->chained.p, c->u.p, c->frag_nu.p, c->ws_u64.p, order, nl, 32, c->P, c->counters.p);
 		}
-		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<768>), dim3(nl), dim3(64), 0, s, c->anchors.p, c->a_off.p, c->frag_na.p, c->frag_first.p, c->rd_len.p, c->chained.p, c->u.p, c->frag_nu.p,
-		                   c->ws_i32.p, c->ws_u64.p, order, nl, c->P, c->counters.p, lane_max);
+		{
+			// wave-per-fragment kernel: only the tail of the size-ordered list can contain wavefront-groups it owns
+			uint32_t tail = 0;
+			if (sorted && lane_max > 0) {
+				uint32_t *d_lb = (uint32_t *)(c->counters.p + 15);
+				uint32_t nlu = (uint32_t)nl;
+				AL_HIP_CHECK(hipMemcpyAsync(d_lb, &nlu, 4, hipMemcpyHostToDevice, s));
+				hipLaunchKernelGGL(k_lower_bound, dim3((nl + 255) / 256), dim3(256), 0, s, c->chain_key.p, (uint32_t)nl, (uint32_t)(lane_max + 1), d_lb);
+				AL_HIP_CHECK(hipMemcpyAsync(&tail, d_lb, 4, hipMemcpyDeviceToHost, s));
+				AL_HIP_CHECK(hipStreamSynchronize(s));
+				tail &= ~63u;
+			}
+			const int nt = nl - (int)tail;
+			if (nt > 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<768>), dim3(nt), dim3(64), 0, s, c->anchors.p, c->a_off.p, c->frag_na.p, c->frag_first.p, c->rd_len.p, c->chained.p, c->u.p, c->frag_nu.p,
+			                   c->ws_i32.p, c->ws_u64.p, order ? order + tail : nullptr, nt, c->P, c->counters.p, lane_max);
+		}
 	}
 	if (first) AL_HIP_CHECK(hipEventRecord(c->ev[ST_CHAIN + 1], s));
 	AL_HIP_CHECK(hipGetLastError());
@@ -289,7 +308,7 @@ extern "C" int al_batch_run(al_ctx_t *c)
 	if (!c) return -1;
 	if (al_run_seed_stages(c)) return -1;
 	if (al_run_align_stage(c)) return -1;
-	AL_HIP_CHECK(hipEventRecord(c->ev[ST_ALIGN + 1], c->stream));
+	AL_HIP_CHECK(hipEventRecord(c->ev[ST_COMPACT + 1], c->stream));
 	AL_HIP_CHECK(hipStreamSynchronize(c->stream));
 	for (int i = 0; i < ST_N; ++i) { float ms = 0; if (hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]) != hipSuccess) ms = 0; c->ms_stage[i] = ms; }
 	float tot = 0; (void)hipEventElapsedTime(&tot, c->ev[0], c->ev[ST_N]); c->ms_total = tot;

@@ -157,7 +157,7 @@ def main():
     if rank == 0:
         names = [L.al_stage_name(i).decode() for i in range(st.n_stage)]
         per = {names[i]: float(stage_ms[i] / a.steps) for i in range(st.n_stage)}
-        dom = max(("sketch", "seed_lookup", "anchor_sort", "chain", "regs", "align"), key=lambda k: per[k])
+        dom = max((k for k in per if k not in ("scan", "rechain", "ext_sort", "compact")), key=lambda k: per[k])
         alg = float(st.algorithmic_bytes)
         achieved = alg / (per[dom] * 1e-3) / 1e9
         out = {
