@@ -888,14 +888,22 @@ struct ExtShared {
 	unsigned long long *hist;      // [0..5] jobs per block-count class, [6] empty slots
 };
 
-__device__ __forceinline__ int d_nb_class(int tlen) { const int b = (tlen + 15) / 16; return b <= 1 ? 0 : b <= 2 ? 1 : b <= 4 ? 2 : b <= 8 ? 3 : b <= 22 ? 4 : 5; }
+#define AL_LANE_QC 64              // longest query a lane-per-job DP handles
+#define AL_NCLS 9                  // job classes: 0..2 lane-per-job (target <= 16/32/64), 3..7 group DP (NB = 1,2,4,8,22), 8 LDS-row DP; 9 = empty slot
+__device__ __forceinline__ int d_job_class(int qlen, int tlen, int lane_ok)
+{
+	const int b = (tlen + 15) / 16;
+	if (lane_ok && qlen <= AL_LANE_QC && b <= 2) return b <= 1 ? 0 : 1;   // (class 2, targets <= 64, measured slower than the group DP: LDS-bound)
+	return b <= 1 ? 3 : b <= 2 ? 4 : b <= 4 ? 5 : b <= 8 ? 6 : b <= 22 ? 7 : 8;
+}
 
 extern "C" __global__ void __launch_bounds__(256)
 k_ext_prep(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_off, const uint32_t *__restrict__ rd_len,
            const uint32_t *__restrict__ frag_first, WsBase W, AlignShared G, ExtShared E, int n_frag, AlParams P, int tmax, int qmax)
 {
 	const int f = blockIdx.x * blockDim.x + threadIdx.x;
-	unsigned cls_cnt[7] = {0, 0, 0, 0, 0, 0, 0};
+	unsigned cls_cnt[AL_NCLS + 1] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+	const int lane_ok = !((P.dbg >> 29) & 1);
 	if (f < n_frag && W.frag_nu[f] != 0) {
 		const uint32_t r0 = frag_first[f], n_segs = frag_first[f + 1] - r0;
 		FragWs fw; d_frag_ws(W, (uint32_t)f, fw);
@@ -950,17 +958,17 @@ k_ext_prep(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_
 				}
 				E.rext[B2 + (uint64_t)s * fw.cap + i] = x;
 				E.jobs[jb] = jl; E.jobs[jb + 1] = jr;
-				{ const int c0 = jl.qlen ? d_nb_class(jl.tlen) : 6, c1 = jr.qlen ? d_nb_class(jr.tlen) : 6;
+				{ const int c0 = jl.qlen ? d_job_class(jl.qlen, jl.tlen, lane_ok) : AL_NCLS, c1 = jr.qlen ? d_job_class(jr.qlen, jr.tlen, lane_ok) : AL_NCLS;
 				  E.job_key[jb] = jl.qlen ? ((uint32_t)c0 << 20 | (uint32_t)(jl.qlen + jl.tlen)) : 0xffffffffu;
 				  E.job_key[jb + 1] = jr.qlen ? ((uint32_t)c1 << 20 | (uint32_t)(jr.qlen + jr.tlen)) : 0xffffffffu;
 				  ++cls_cnt[c0]; ++cls_cnt[c1]; }
 			}
 		}
 		// unused job slots of this fragment (a slow fragment stops early): mark empty
-		for (uint32_t j = jb; j < (uint32_t)E.job_off[f + 1]; ++j) { E.job_key[j] = 0xffffffffu; ExtJob z; z.qlen = z.tlen = 0; z.toff = 0; z.read = 0; z.qoff = 0; z.rev = z.kind = z.pad0 = z.pad1 = 0; z.pad2 = 0; E.jobs[j] = z; ++cls_cnt[6]; }
+		for (uint32_t j = jb; j < (uint32_t)E.job_off[f + 1]; ++j) { E.job_key[j] = 0xffffffffu; ExtJob z; z.qlen = z.tlen = 0; z.toff = 0; z.read = 0; z.qoff = 0; z.rev = z.kind = z.pad0 = z.pad1 = 0; z.pad2 = 0; E.jobs[j] = z; ++cls_cnt[AL_NCLS]; }
 		E.frag_slow[f] = slow ? 1u : 0u;
 	} else if (f < n_frag) E.frag_slow[f] = 0;
-	for (int c = 0; c < 7; ++c) {                                              // one atomic per wavefront and class
+	for (int c = 0; c <= AL_NCLS; ++c) {                                       // one atomic per wavefront and class
 		unsigned v = cls_cnt[c];
 		for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
 		if ((threadIdx.x & 63) == 0 && v) atomicAdd(&E.hist[c], (unsigned long long)v);
@@ -1019,6 +1027,186 @@ k_ext_dp(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_of
 		if (gl == 0) E.outs[j] = o;
 		GSYNC();
 	}
+}
+
+// DP jobs with short targets (<= TC cells) and short queries: ONE LANE PER JOB, 64 jobs per wavefront.  A 16-lane group
+// spends one wave-instruction per 4 jobs with most lanes idle on such tiny problems; here every lane walks its own
+// anti-diagonals over the reference's 16-cell blocks (garbage cells included, so results stay bit-identical) with the
+// packed cell state in LDS as [cell][lane] (conflict-free) and the traceback bytes in a wave-interleaved HBM scratch.
+template <int TC, int QC>
+__global__ void __launch_bounds__(64)
+k_ext_dp_lane(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_off, const uint32_t *__restrict__ rd_len,
+              AlignShared G, ExtShared E, const uint32_t *__restrict__ sorted_idx, uint32_t first, uint32_t count,
+              uint8_t *__restrict__ tbws, size_t tb_stride, AlParams P)
+{
+	__shared__ uint32_t sA[TC * 64], sB[TC * 64];
+	__shared__ int32_t sH[TC * 64];
+	__shared__ uint8_t sQ[(QC + 32) * 64];
+	const int lane = threadIdx.x;
+	uint8_t *tb = tbws + (size_t)blockIdx.x * tb_stride;        // [row][cell][lane]
+#define LA(t) sA[(t) * 64 + lane]
+#define LB(t) sB[(t) * 64 + lane]
+#define LH(t) sH[(t) * 64 + lane]
+#define LQ(i) sQ[(i) * 64 + lane]
+	int q = P.q, e = P.e, q2 = P.q2, e2 = P.e2;
+	if (q2 + e2 < q + e) { int t = q; q = q2; q2 = t; t = e; e = e2; e2 = t; }
+	const int qe = q + e;
+	const int8_t qe_ = (int8_t)(q + e), qe2_ = (int8_t)(q2 + e2);
+	const int8_t sc_mch = (int8_t)P.a, sc_mis = (int8_t)(-P.b), sc_amb = (int8_t)(P.sc_ambi > 0 ? -P.sc_ambi : P.sc_ambi);
+	const int8_t sc_N = sc_amb == 0 ? (int8_t)(-e2) : sc_amb;
+	int long_thres = e != e2 ? (q2 - q) / (e - e2) - 1 : 0;
+	if (q2 + e2 + long_thres * e2 > q + e + long_thres * e) ++long_thres;
+	const int long_diff = long_thres * (e - e2) - (q2 - q) - e2;
+	const int w = (int)(P.bw * 1.5 + 1.);
+	const uint32_t m1 = (uint8_t)(int8_t)(-q - e), m2 = (uint8_t)(int8_t)(-q2 - e2);
+	for (uint32_t jj = blockIdx.x * 64 + lane; jj < count; jj += gridDim.x * 64) {
+		const uint32_t j = sorted_idx[first + jj];
+		const ExtJob job = E.jobs[j];
+		const int qlen = job.qlen, tlen = job.tlen;
+		const bool right = job.kind == 0;                                   // left extension: KSW_EZ_RIGHT | REV_CIGAR (align.c:697)
+		const int rev_cigar = job.kind == 0;
+		const uint32_t *seq = rd_seq + rd_off[job.read]; const int rqlen = (int)rd_len[job.read];
+		const int tlen_ = (tlen + 15) / 16, qlen_ = (qlen + 15) / 16;
+		int n_col_ = qlen < tlen ? qlen : tlen;
+		n_col_ = ((n_col_ < w + 1 ? n_col_ : w + 1) + 15) / 16 + 1;
+		const int prow = n_col_ * 16;
+		// reversed query (qr[t] = query[qlen-1-t], zero padded) and target bytes
+		{
+			const ReadAcc Q{seq, rqlen, job.rev, job.kind == 0 ? 0 : (int)job.qoff};
+			for (int t = 0; t < qlen_ * 16 + 32 && t < QC + 32; ++t) {
+				int c = 0;
+				if (t < qlen) { const int i = qlen - 1 - t; c = job.kind == 0 ? Q((int)job.qoff - i) : Q(i); }
+				LQ(t) = (uint8_t)c;
+			}
+			for (int t = 0; t < tlen_ * 16; ++t) {
+				uint32_t sfv = 0;
+				if (t < tlen) sfv = d_seq4(G.S4, job.kind == 0 ? job.toff - (uint64_t)t : job.toff + (uint64_t)t);
+				LA(t) = m1 | m1 << 8 | m2 << 16 | m1 << 24;
+				LB(t) = m1 | m2 << 8 | 0u << 16 | sfv << 24;
+				LH(t) = KSW_NEG_INF;
+			}
+		}
+		EzD ez; d_ez_reset(ez);
+		int last_st = -1, last_en = -1, r;
+		for (r = 0; r < qlen + tlen - 1; ++r) {
+			int st, en;
+			d_row_bounds(r, qlen, tlen, w, st, en);
+			if (st > en) { ez.zdropped = 1; break; }
+			const int st0 = st, en0 = en;
+			st = st / 16 * 16; en = (en + 16) / 16 * 16 - 1;
+			int8_t x1 = (int8_t)(-q - e), x21 = (int8_t)(-q2 - e2), v1 = (int8_t)(-q - e);
+			if (st > 0) {
+				if (st - 1 >= last_st && st - 1 <= last_en) { const uint32_t av = LA(st - 1); x1 = (int8_t)av; v1 = (int8_t)(av >> 8); x21 = (int8_t)(av >> 16); }
+			} else v1 = r == 0 ? (int8_t)(-q - e) : r < long_thres ? (int8_t)(-e) : r == long_thres ? (int8_t)long_diff : (int8_t)(-e2);
+			if (en >= r) {                                                    // :150-153
+				const int8_t ub = r == 0 ? (int8_t)(-q - e) : r < long_thres ? (int8_t)(-e) : r == long_thres ? (int8_t)long_diff : (int8_t)(-e2);
+				LB(r) = (LB(r) & 0xffff0000u) | m1 | m2 << 8;
+				LA(r) = (LA(r) & 0x00ffffffu) | (uint32_t)(uint8_t)ub << 24;
+			}
+			for (int t = st0; t <= en0; t += 16)                               // score bytes, 16 per store (:158-176)
+				for (int i = 0; i < 16; ++i) {
+					const int tt = t + i;
+					if (tt >= tlen_ * 16) break;
+					const uint32_t bv = LB(tt);
+					const uint8_t sq = (uint8_t)(bv >> 24), sq2 = LQ(qlen - 1 - r + tt);
+					int8_t sc = sq == sq2 ? sc_mch : sc_mis;
+					if (sq == 4 || sq2 == 4) sc = sc_N;
+					LB(tt) = (bv & 0xff00ffffu) | (uint32_t)(uint8_t)sc << 16;
+				}
+			uint8_t *pr = tb + ((size_t)r * prow - st) * 64 + lane;
+			int8_t xprev = x1, x2prev = x21, vprev = v1;
+			for (int t = st; t <= en; ++t) {                                   // :182-306, cell by cell
+				const uint32_t av = LA(t), bv = LB(t);
+				const int8_t xt1 = xprev, vt1 = vprev, x2t1 = x2prev;
+				xprev = (int8_t)av; vprev = (int8_t)(av >> 8); x2prev = (int8_t)(av >> 16);
+				const int8_t ut = (int8_t)(av >> 24), yo = (int8_t)bv, y2o = (int8_t)(bv >> 8);
+				int8_t z = (int8_t)(bv >> 16);
+				int8_t a = (int8_t)(xt1 + vt1), bb = (int8_t)(yo + ut), a2 = (int8_t)(x2t1 + vt1), b2 = (int8_t)(y2o + ut);
+				int d;
+				d = (a > z || (right && a == z)) ? 1 : 0;   z = z > a ? z : a;
+				d = (bb > z || (right && bb == z)) ? 2 : d; z = z > bb ? z : bb;
+				d = (a2 > z || (right && a2 == z)) ? 3 : d; z = z > a2 ? z : a2;
+				d = (b2 > z || (right && b2 == z)) ? 4 : d; z = z > b2 ? z : b2;
+				z = z < sc_mch ? z : sc_mch;
+				const int8_t un = (int8_t)(z - vt1), vn = (int8_t)(z - ut);
+				int8_t tmp = (int8_t)(z - q); a = (int8_t)(a - tmp); bb = (int8_t)(bb - tmp);
+				tmp = (int8_t)(z - q2); a2 = (int8_t)(a2 - tmp); b2 = (int8_t)(b2 - tmp);
+				const bool pa = right ? a >= 0 : a > 0, pb = right ? bb >= 0 : bb > 0, pa2 = right ? a2 >= 0 : a2 > 0, pb2 = right ? b2 >= 0 : b2 > 0;
+				const int8_t xn = (int8_t)((pa ? a : 0) - qe_), yn = (int8_t)((pb ? bb : 0) - qe_);
+				const int8_t x2n = (int8_t)((pa2 ? a2 : 0) - qe2_), y2n = (int8_t)((pb2 ? b2 : 0) - qe2_);
+				d |= (pa ? 0x08 : 0) | (pb ? 0x10 : 0) | (pa2 ? 0x20 : 0) | (pb2 ? 0x40 : 0);
+				LA(t) = (uint32_t)(uint8_t)xn | (uint32_t)(uint8_t)vn << 8 | (uint32_t)(uint8_t)x2n << 16 | (uint32_t)(uint8_t)un << 24;
+				LB(t) = (bv & 0xffff0000u) | (uint32_t)(uint8_t)yn | (uint32_t)(uint8_t)y2n << 8;
+				pr[(size_t)t * 64] = (uint8_t)d;
+			}
+			{   // exact max (:307-349) in the reference's evaluation order
+				int max_H, max_t;
+				if (r > 0) {
+					int HH[4], tt4[4]; const int en1 = st0 + (en0 - st0) / 4 * 4; int t;
+					const int u_en0 = (int8_t)(LA(en0) >> 24), v_en0 = (int8_t)(LA(en0) >> 8);
+					max_H = en0 > 0 ? LH(en0 - 1) + u_en0 : LH(en0) + v_en0; LH(en0) = max_H;
+					max_t = en0;
+					for (int i = 0; i < 4; ++i) HH[i] = max_H, tt4[i] = max_t;
+					for (t = st0; t < en1; t += 4)
+						for (int i = 0; i < 4; ++i) { const int h = LH(t + i) + (int)(int8_t)(LA(t + i) >> 8); LH(t + i) = h; if (h > HH[i]) HH[i] = h, tt4[i] = t; }
+					for (int i = 0; i < 4; ++i) if (max_H < HH[i]) max_H = HH[i], max_t = tt4[i] + i;
+					for (; t < en0; ++t) { const int h = LH(t) + (int)(int8_t)(LA(t) >> 8); LH(t) = h; if (h > max_H) max_H = h, max_t = t; }
+				} else { LH(0) = (int)(int8_t)(LA(0) >> 8) - qe; max_H = LH(0); max_t = 0; }
+				if (r - st0 == qlen - 1 && LH(st0) > ez.mqe) { ez.mqe = LH(st0); ez.mqe_t = st0; }
+				bool brk = false;
+				if (max_H > ez.max) { ez.max = max_H; ez.max_t = max_t; ez.max_q = r - max_t; }
+				else if (max_t >= ez.max_t && r - max_t >= ez.max_q) {
+					const int tl = max_t - ez.max_t, ql = (r - max_t) - ez.max_q, l = tl > ql ? tl - ql : ql - tl;
+					if (P.zdrop >= 0 && ez.max - max_H > P.zdrop + l * e2) { ez.zdropped = 1; brk = true; }
+				}
+				if (brk) break;
+				if (r == qlen + tlen - 2 && en0 == tlen - 1) ez.score = LH(tlen - 1);
+			}
+			last_st = st; last_en = en;
+		}
+		// backtrack (ksw2.h:119-151) with the run being extended kept in registers; up to 6 ops inline, longer CIGARs in the arena
+		ExtOut o; uint32_t big[AL_FCIG]; int n_c = 0; uint32_t cur = 0xffffffffu; bool ovf = false;
+		{
+			int i0 = -1, j0 = -1;
+			if (!ez.zdropped && ez.mqe + P.end_bonus > ez.max) { ez.reach_end = 1; i0 = ez.mqe_t; j0 = qlen - 1; }
+			else if (ez.max_t >= 0 && ez.max_q >= 0) { i0 = ez.max_t; j0 = ez.max_q; }
+			int i = i0, jq = j0, state = 0;
+#define PUSH(op_, len_) do { const uint32_t op__ = (op_); if (cur != 0xffffffffu && op__ == (cur & 0xf)) cur += (uint32_t)(len_) << 4; else { if (cur != 0xffffffffu) { if (n_c < AL_FCIG) big[n_c] = cur; else ovf = true; ++n_c; } cur = (uint32_t)(len_) << 4 | op__; } } while (0)
+			while (i >= 0 && jq >= 0) {
+				int force_state = -1, st, en; const int rr = i + jq;
+				d_row_bounds(rr, qlen, tlen, w, st, en);
+				const int off = st / 16 * 16, off_end = (en + 16) / 16 * 16 - 1;
+				if (i < off) force_state = 2;
+				if (i > off_end) force_state = 1;
+				const uint32_t tmp = force_state < 0 ? tb[((size_t)rr * prow + i - off) * 64 + lane] : 0;
+				if (state == 0) state = tmp & 7;
+				else if (!(tmp >> (state + 2) & 1)) state = 0;
+				if (state == 0) state = tmp & 7;
+				if (force_state >= 0) state = force_state;
+				if (state == 0) { PUSH(0, 1); --i; --jq; }
+				else if (state == 1 || state == 3) { PUSH(2, 1); --i; }
+				else { PUSH(1, 1); --jq; }
+			}
+			if (i0 >= 0) { if (i >= 0) PUSH(2, i + 1); if (jq >= 0) PUSH(1, jq + 1); }
+			if (cur != 0xffffffffu) { if (n_c < AL_FCIG) big[n_c] = cur; else ovf = true; ++n_c; }
+#undef PUSH
+			if (!rev_cigar) for (int k2 = 0; k2 < n_c >> 1 && n_c <= AL_FCIG; ++k2) { const uint32_t t = big[k2]; big[k2] = big[n_c - 1 - k2]; big[n_c - 1 - k2] = t; }
+		}
+		if (ovf) atomicAdd(&G.counters[7], 1ULL);
+		o.max = ez.max; o.max_q = ez.max_q; o.max_t = ez.max_t; o.mqe_t = ez.mqe_t;
+		o.flags_ncig = (uint32_t)(ez.reach_end ? 1 : 0) | (uint32_t)(ez.zdropped ? 2 : 0) | (uint32_t)n_c << 8; o.cig_off = 0;
+		for (int k2 = 0; k2 < 6; ++k2) o.cig[k2] = k2 < n_c ? big[k2] : 0;
+		if (n_c > 6 && !ovf) {
+			const unsigned long long aoff = atomicAdd(G.arena_cnt, (unsigned long long)n_c);
+			if (aoff + n_c <= G.arena_cap) { for (int k2 = 0; k2 < n_c; ++k2) G.arena[aoff + k2] = big[k2]; o.cig_off = (uint32_t)aoff; }
+			else { atomicAdd(&G.counters[9], 1ULL); o.cig_off = 0xffffffffu; }
+		}
+		E.outs[j] = o;
+	}
+#undef LA
+#undef LB
+#undef LH
+#undef LQ
 }
 
 // same for targets wider than 22 blocks: LDS-row DP
@@ -1326,7 +1514,7 @@ int al_run_align_stage(al_ctx_t *c)
 		ExtShared E; E.jobs = A->jobs.p; E.outs = A->outs.p; E.rext = A->rext.p; E.job_off = A->job_off.p; E.frag_slow = A->frag_slow.p; E.job_key = A->job_key.p; E.hist = A->hist.p;
 		hipLaunchKernelGGL(k_ext_prep, dim3((nf + 255) / 256), dim3(256), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, c->frag_first.p, W, G, E, nf, c->P, tmax, qmax);
 		AL_HIP_CHECK(hipEventRecord(c->ev[ST_EXT_PREP + 1], s));
-		unsigned long long hist[8] = {0};
+		unsigned long long hist[16] = {0};
 		if (nj > 0) {
 			hipLaunchKernelGGL(k_iota, dim3((nj + 255) / 256), dim3(256), 0, s, A->job_idx.p, nj);
 			size_t bytes = 0;
@@ -1334,16 +1522,24 @@ int al_run_align_stage(al_ctx_t *c)
 			if (A->sort_tmp.ensure(bytes + 16)) return -1;
 			AL_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(A->sort_tmp.p, bytes, A->job_key.p, A->job_key2.p, A->job_idx.p, A->job_idx2.p, (int)nj, 0, 24, s));
 			AL_HIP_CHECK(hipEventRecord(c->ev[ST_EXT_SORT + 1], s));
-			AL_HIP_CHECK(hipMemcpyAsync(hist, A->hist.p, 7 * 8, hipMemcpyDeviceToHost, s));
+			AL_HIP_CHECK(hipMemcpyAsync(hist, A->hist.p, (AL_NCLS + 1) * 8, hipMemcpyDeviceToHost, s));
 			AL_HIP_CHECK(hipStreamSynchronize(s));
-			// one launch per block-count class over its slice of the sorted job list
+			// one launch per job class over its slice of the sorted job list
 			static const int NBs[5] = {1, 2, 4, 8, 22};
 			uint32_t first = 0;
-			for (int cls = 0; cls < 6; ++cls) {
+			for (int cls = 0; cls < AL_NCLS; ++cls) {
 				const uint32_t cnt = (uint32_t)hist[cls];
 				if (cnt == 0) continue;
-				if (cls < 5) {
-					const int NB = NBs[cls];
+				if (cls < 3) {                                                    // lane-per-job
+					const int TC = 16 << cls;
+					const size_t tbs = (size_t)(AL_LANE_QC + TC) * (size_t)(TC + 16) * 64;
+					int nw = (int)((cnt + 63) / 64); if (nw > 1024) nw = 1024;
+					if (A->gws.ensure((size_t)nw * tbs + 64)) return -1;
+					if (cls == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ext_dp_lane<16, AL_LANE_QC>), dim3(nw), dim3(64), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, G, E, A->job_idx2.p, first, cnt, A->gws.p, tbs, c->P);
+					else if (cls == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ext_dp_lane<32, AL_LANE_QC>), dim3(nw), dim3(64), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, G, E, A->job_idx2.p, first, cnt, A->gws.p, tbs, c->P);
+					else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ext_dp_lane<64, AL_LANE_QC>), dim3(nw), dim3(64), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, G, E, A->job_idx2.p, first, cnt, A->gws.p, tbs, c->P);
+				} else if (cls < 8) {
+					const int NB = NBs[cls - 3];
 					const size_t pb = (((size_t)(Lmax + 16 * NB) * (size_t)(NB + 1) * 16) + 63) / 64 * 64, cw = ((size_t)(Lmax + 16 * NB) + 31) / 16 * 16, st2 = pb + cw * 8;
 					int nbj = (int)((cnt + 3) / 4); if (nbj > 2048) nbj = 2048;
 					if (A->gws.ensure((size_t)nbj * 4 * st2 + 64)) return -1;
