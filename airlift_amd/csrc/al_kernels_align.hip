@@ -489,7 +489,7 @@ __device__ __forceinline__ void d_align1(GroupLds<TMAX, QMAX> &L, const int gl, 
 	l = qlen - qe;
 	l += l * P.a + P.end_bonus > P.q ? (l * P.a + P.end_bonus - P.q) / P.e : 0;
 	re0 = re + l < ref_len ? re + l : ref_len;
-	if (re0 - rs0 > TMAX || qlen > QMAX) { if (gl == 0) atomicAdd(&G.counters[7], 1ULL); r->cnt = 0; return; }
+	if (re0 - rs0 > TMAX || qlen > QMAX) { if (gl == 0) atomicAdd(&G.counters[7], 1ULL << 16); r->cnt = 0; return; }
 	if (gl == 0) { atomicAdd(&G.counters[4], 1ULL); atomicAdd(&G.counters[5], (unsigned long long)(re0 - rs0)); }
 	r->n_cigar = 0; r->dp_score = 0; r->dp_max = 0; r->dp_max2 = 0; r->n_ambi = 0;
 	ws.cur_cig = L.cig; ws.cur_cig_cap = AL_LCIG;
@@ -662,9 +662,10 @@ __device__ void d_pair(const AlParams &P, int max_gap_ref, const int *qlens, int
 }
 
 // ---------------------------------------------------------------------------------------------
-// Per-fragment workspace layout.  With P_f = sum of n_u over earlier fragments and c_f = 2*n_u + 4:
+// Per-fragment workspace layout.  With P_f = sum of n_u over earlier fragments and c_f = 4*n_u + 4 (room for up to three
+// z-drop splits per hit; exceeding it is a counted error):
 //   regs0      : AlReg   x n_u         at P_f                      (fragment-level hits)
-//   mate regs  : AlReg   x c_f each    at 2*(2*P_f + 4*f) + s*c_f  (per-mate hits; spare room for z-drop splits)
+//   mate regs  : AlReg   x c_f each    at 2*(4*P_f + 4*f) + s*c_f  (per-mate hits; spare room for z-drop splits)
 //   scratch    : AlAnchor/ u64 / int / AlReg x c_f                 at B_f = 2*P_f + 4*f
 //   seg_u      : u64     x n_u each    at 2*P_f + s*n_u
 //   seg_a      : anchors of mate 0 then mate 1 inside the fragment's anchor range a_off[f]..
@@ -677,7 +678,7 @@ struct WsBase {
 };
 __device__ __forceinline__ void d_frag_ws(const WsBase &W, uint32_t f, FragWs &o)
 {
-	const uint64_t Pf = W.nu_off[f]; const uint32_t nu = W.frag_nu[f]; const uint64_t B = 2 * Pf + 4ULL * f; const int c = 2 * (int)nu + 4;
+	const uint64_t Pf = W.nu_off[f]; const uint32_t nu = W.frag_nu[f]; const uint64_t B = 4 * Pf + 4ULL * f; const int c = 4 * (int)nu + 4;
 	o.cap = c; o.regs0 = W.regs0 + Pf; o.mreg[0] = W.mregs + 2 * B; o.mreg[1] = o.mreg[0] + c; o.rtmp = W.rtmp + B;
 	o.aux128 = W.aux128 + B; o.aux64 = W.aux64 + B; o.auxi = W.auxi + 2 * B;
 	o.seg_u[0] = W.seg_u + 2 * Pf; o.seg_u[1] = o.seg_u[0] + nu;
@@ -815,10 +816,10 @@ k_align(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_off
 						if (n + 1 <= cap) {                                    // mm_insert_reg, align.c:847-855
 							for (int j = n - 1; j > i; --j) regs[j + 1] = regs[j];
 							regs[i + 1] = r2; ++n;
-						} else if (gl == 0) atomicAdd(&G.counters[7], 1ULL);
+						} else if (gl == 0) atomicAdd(&G.counters[7], 1ULL << 32);
 					}
 				}
-			} else if (n > 0) { if (gl == 0) atomicAdd(&G.counters[7], 1ULL); n = 0; }
+			} else if (n > 0) { if (gl == 0) atomicAdd(&G.counters[7], 1ULL << 24); n = 0; }
 			if (P.dbg & 8) { n_regs[s] = n; mregs[s] = regs; continue; }
 			const long long tB = PROF_ON(P) ? clock64() : 0;
 			d_filter_regs(P, qlen, &n, regs);                                  // align.c:910-911
@@ -835,7 +836,7 @@ k_align(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_off
 			bool ovf = false;
 			const bool small = n_regs[0] <= AL_LREG && n_regs[1] <= AL_LREG;
 			d_pair(P, max_gap_ref, qlens, n_regs, mregs, small ? (PairEnt *)L.rtmp : (PairEnt *)fw.rtmp, small ? L.sc : ws.sc, small ? AL_LREG * AL_LREG : AL_PAIR_SC_CAP, lt, &tie, &ovf);
-			if (ovf && gl == 0) atomicAdd(&G.counters[7], 1ULL);
+			if (ovf && gl == 0) atomicAdd(&G.counters[7], 1ULL << 40);
 		}
 		GSYNC();
 		for (uint32_t s = 0; s < n_segs; ++s) {
@@ -914,7 +915,7 @@ k_ext_prep(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_
 			const int qlen = (int)rd_len[r0 + s], n = (int)W.reg_cnt[r0 + s];
 			const uint32_t *seq = rd_seq + rd_off[r0 + s];
 			const AlReg *regs = fw.mreg[s]; const AlAnchor *a = fw.seg_a[s];
-			if (n > 0 && qlen > qmax) { atomicAdd(&G.counters[7], 1ULL); slow = true; break; }
+			if (n > 0 && qlen > qmax) { atomicAdd(&G.counters[7], 1ULL << 0); slow = true; break; }
 			for (int i = 0; i < n; ++i, jb += 2) {
 				const AlReg *r = &regs[i]; RegExt x; ExtJob jl, jr;
 				jl.qlen = jl.tlen = 0; jr.qlen = jr.tlen = 0; jl.pad0 = jl.pad1 = jr.pad0 = jr.pad1 = 0; jl.pad2 = jr.pad2 = 0;
@@ -934,7 +935,7 @@ k_ext_prep(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_
 					l = qlen - qe;
 					l += l * P.a + P.end_bonus > P.q ? (l * P.a + P.end_bonus - P.q) / P.e : 0;
 					const int32_t re0 = re + l < ref_len ? re + l : ref_len;
-					if (re0 - rs0 > tmax) { atomicAdd(&G.counters[7], 1ULL); slow = true; break; }
+					if (re0 - rs0 > tmax) { atomicAdd(&G.counters[7], 1ULL << 8); slow = true; break; }
 					// ungapped core (align.c:724-731) + mm_test_zdrop with the single 'M' op (align.c:47-89)
 					const ReadAcc Q{seq, qlen, rev, qs}; const RefAcc T{G.S4, ref_off + (uint64_t)rs};
 					const int len = qe - qs; int sc = 0, zs = 0, zmax = INT32_MIN, zmi = -1, zdrop_max = 0;
@@ -1192,7 +1193,7 @@ k_ext_dp_lane(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ 
 #undef PUSH
 			if (!rev_cigar) for (int k2 = 0; k2 < n_c >> 1 && n_c <= AL_FCIG; ++k2) { const uint32_t t = big[k2]; big[k2] = big[n_c - 1 - k2]; big[n_c - 1 - k2] = t; }
 		}
-		if (ovf) atomicAdd(&G.counters[7], 1ULL);
+		if (ovf) atomicAdd(&G.counters[7], 1ULL << 48);
 		o.max = ez.max; o.max_q = ez.max_q; o.max_t = ez.max_t; o.mqe_t = ez.mqe_t;
 		o.flags_ncig = (uint32_t)(ez.reach_end ? 1 : 0) | (uint32_t)(ez.zdropped ? 2 : 0) | (uint32_t)n_c << 8; o.cig_off = 0;
 		for (int k2 = 0; k2 < 6; ++k2) o.cig[k2] = k2 < n_c ? big[k2] : 0;
@@ -1351,7 +1352,7 @@ k_ext_finish(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ r
 				bool ovf = false; AlReg *rr[2] = {fw.mreg[0], fw.mreg[1]};
 				// pair scores: at most n0*n1 entries (bounded by the hit counts after k_regs; see k_ext_counts)
 				d_pair(P, max_gap_ref, qlens, n_regs, rr, (PairEnt *)fw.rtmp, sc_ws + sc_off[f], (int)(sc_off[f + 1] - sc_off[f]), lt, &tie, &ovf);
-				if (ovf) { atomicAdd(&G.counters[7], 1ULL); }
+				if (ovf) { atomicAdd(&G.counters[7], 1ULL << 56); }
 			}
 			for (uint32_t s = 0; s < n_segs; ++s) W.reg_cnt[r0 + s] = (uint32_t)n_regs[s];
 			if (tie) atomicAdd(&G.counters[10], 1ULL);
@@ -1460,7 +1461,7 @@ int al_run_align_stage(al_ctx_t *c)
 	uint64_t nu_total = 0;
 	AL_HIP_CHECK(hipMemcpyAsync(&nu_total, A->nu_off.p + nf, 8, hipMemcpyDeviceToHost, s));
 	AL_HIP_CHECK(hipStreamSynchronize(s));
-	const uint64_t Btot = 2 * nu_total + 4ULL * nf + 8;
+	const uint64_t Btot = 4 * nu_total + 4ULL * nf + 8;
 	if (A->regs0.ensure(nu_total + 1) || A->mregs.ensure(2 * Btot) || A->rtmp.ensure(Btot) || A->aux128.ensure(Btot) || A->aux64.ensure(Btot) || A->auxi.ensure(2 * Btot) ||
 	    A->seg_u.ensure(2 * nu_total + 2) || A->seg_a.ensure(c->n_anchor_total + 1) || A->reg_cnt.ensure(nr + 1) || A->seg_na.ensure(nr + 1) || A->out_off.ensure(nr + 2)) return -1;
 	WsBase W;
@@ -1601,7 +1602,7 @@ int al_fetch_align(al_ctx_t *c, int *n_regs, al_reg1_t **regs, int *rep_len)
 	const int nf = c->n_frag, nr = c->n_reads;
 	AL_HIP_CHECK(hipSetDevice(c->device));
 	unsigned long long h[16]; AL_HIP_CHECK(hipMemcpy(h, c->counters.p, sizeof(h), hipMemcpyDeviceToHost));
-	if (h[7] || h[8] || h[9]) { fprintf(stderr, "[airlift] device pipeline error: limit=%llu logf_miss=%llu cigar_arena_overflow=%llu\n", h[7], h[8], h[9]); return -4; }
+	if (h[7] || h[8] || h[9]) { fprintf(stderr, "[airlift] device pipeline error: limit=0x%llx (byte k = site k: 0 prep qlen, 1 prep window, 2 dp window, 3 qlen, 4 split capacity, 5 pair scores, 6 lane cigar, 7 finish pair scores) logf_miss=%llu cigar_arena_overflow=%llu\n", h[7], h[8], h[9]); return -4; }
 	std::vector<uint64_t> off(nr + 1); std::vector<AlReg> out(A->out_total); std::vector<int32_t> rep(nf);
 	if (nf == 0) return 0;
 	AL_HIP_CHECK(hipMemcpy(off.data(), A->out_off.p, (size_t)(nr + 1) * 8, hipMemcpyDeviceToHost));

@@ -296,7 +296,9 @@ int al_run_seed_stages(al_ctx_t *c)
 			AL_HIP_CHECK(hipMemcpyAsync(c->frag_na_p1.p, c->frag_na.p, (size_t)c->n_frag * 4, hipMemcpyDeviceToDevice, s));
 			AL_HIP_CHECK(hipMemcpyAsync(c->frag_rep_p1.p, c->frag_rep.p, (size_t)c->n_frag * 4, hipMemcpyDeviceToDevice, s));
 			// deterministic order (atomic append order is arbitrary; offsets depend on it only for layout, results do not)
-			if (run_seed_chain(c, c->rechain_list.p, (int)n, c->opt.max_occ, c->n_anchor_pass1, false)) return -1;
+			// the chain list u[] is addressed as a_off[f] + f: start the second pass n_frag slots further so that its u[] entries cannot
+			// land on those of the last first-pass fragments
+			if (run_seed_chain(c, c->rechain_list.p, (int)n, c->opt.max_occ, c->n_anchor_pass1 + (uint64_t)c->n_frag, false)) return -1;
 		}
 	}
 	AL_HIP_CHECK(hipEventRecord(c->ev[ST_RECHAIN + 1], s));

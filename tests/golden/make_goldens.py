@@ -123,6 +123,21 @@ def main():
     for t, q in (("MT-human.fa", "MT-orang.fa"), ("t-inv.fa", "q-inv.fa"), ("t2.fa", "q2.fa")):
         shutil.copy(os.path.join(REFTEST, t), os.path.join(tmp, t)); shutil.copy(os.path.join(REFTEST, q), os.path.join(tmp, q))
         emit("g4_" + q.split(".")[0].replace("-", "_"), tmp, t, [q], taps=(q != "MT-orang.fa"))
+    # G6: repeat-rich reference (a 300 bp element in ~2600 copies, 0-3 % divergence): minimizers above mid_occ = 1000, so
+    #     rep_len > 0, the max_occ re-chain pass (map.c:353-375), thousands of anchors per fragment.  SAM + count only.
+    rng = np.random.default_rng(77)
+    rep = g.make_reference(seed=21, n_contigs=2, total_len=1_200_000, n_dups=20, dup_len=(300, 2000), dup_div=0.01)
+    unit = rng.integers(0, 4, size=300, dtype=np.uint8)
+    for _, c in rep:
+        for _ in range(1300):
+            s = int(rng.integers(0, len(c) - 300))
+            u = unit.copy(); m = rng.random(300) < rng.uniform(0, 0.03)
+            u[m] = (u[m] + rng.integers(1, 4, size=int(m.sum()), dtype=np.uint8)) & 3
+            c[s:s + 300] = u
+    g.write_fasta(os.path.join(tmp, "rep.fa"), rep)
+    r1, r2 = g.simulate_pairs(rep, 500, 150, seed=9, ins_mean=380, ins_sd=50, sub_rate=0.005, del_frac=0.05)
+    g.write_fastq(os.path.join(tmp, "g6_1.fq"), r1); g.write_fastq(os.path.join(tmp, "g6_2.fq"), r2)
+    emit("g6_repeats", tmp, "rep.fa", ["g6_1.fq", "g6_2.fq"], taps=False)
     # G5: yeast-sized, only digests committed (inputs are regenerated by tools/gen_synth.py at test time)
     d5 = os.path.join(tmp, "g5")
     g.generate("c2", d5, pairs=100_000)

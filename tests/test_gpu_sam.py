@@ -10,7 +10,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CLI = os.path.join(ROOT, "airlift_amd", "bin", "airlift-align")
-SETS = ["g1_mt150pe", "g2_100se", "g2_250pe", "g3_adversarial", "g4_q2"]
+SETS = ["g1_mt150pe", "g2_100se", "g2_250pe", "g3_adversarial", "g4_q2", "g6_repeats"]
 
 
 def _diff_report(got, exp, name):
@@ -55,6 +55,18 @@ def test_lds_dp_path_identical(golden_unpacked, name):
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     exp = open(os.path.join(d, "expected.sam"), "rb").read()
     assert r.stdout == exp, _diff_report(r.stdout, exp, name + "_lds")
+
+
+def test_yeast100k_digest(tmp_path):
+    """G5: 100 k pairs on the 12 Mbp synthetic genome (the bench workload's shape): md5 of the whole SAM must equal the
+    digest the reference build produced (tests/golden/g5_yeast100k/meta.json)."""
+    import gen_synth
+    from conftest import GOLDEN
+    m = json.load(open(os.path.join(GOLDEN, "g5_yeast100k", "meta.json")))
+    gen_synth.generate(m["config"], str(tmp_path), pairs=m["pairs"], seed=m["seed"])
+    r = subprocess.run([CLI, "-ax", "sr", "ref.fa", "reads_1.fq", "reads_2.fq"], cwd=tmp_path, capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    assert hashlib.md5(r.stdout).hexdigest() == m["sam_md5"]
 
 
 def test_bwa_style_argv(golden_unpacked):

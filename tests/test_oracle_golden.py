@@ -8,7 +8,7 @@ import subprocess
 import pytest
 
 SETS_TAPS = ["g1_mt150pe", "g2_100se", "g2_250pe", "g3_adversarial", "g4_q_inv", "g4_q2"]
-SETS_ALL = SETS_TAPS + ["g4_MT_orang"]
+SETS_ALL = SETS_TAPS + ["g4_MT_orang", "g6_repeats"]
 
 
 def _meta(d):
@@ -46,7 +46,7 @@ def test_ksw_taps(oracle_bin, golden_unpacked, name):
     assert got == open(os.path.join(d, "expected.alnseq"), "rb").read()
 
 
-@pytest.mark.parametrize("name", ["g1_mt150pe", "g2_100se", "g2_250pe", "g3_adversarial"])
+@pytest.mark.parametrize("name", ["g1_mt150pe", "g2_100se", "g2_250pe", "g3_adversarial", "g6_repeats"])
 def test_alser_count(oracle_bin, golden_unpacked, name):
     """a8: the as-shipped fork's only observable (map.c:299-312, main.c:417)."""
     d = golden_unpacked[name]
