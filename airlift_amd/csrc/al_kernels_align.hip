@@ -300,15 +300,22 @@ __device__ __forceinline__ int d_mat(const AlParams &P, int ct, int cq)
 struct BytesAcc { const uint8_t *p; __device__ __forceinline__ int operator()(int i) const { return p[i]; } __device__ __forceinline__ BytesAcc shift(int n) const { return BytesAcc{p + n}; } };
 struct ReadAcc {     // qseq0[rev][off + i] of a read packed 4 bit/base in mapping orientation (align.c:865-870)
 	const uint32_t *seq; int qlen, rev, off;
+	mutable int cw = -1; mutable uint32_t cv = 0;          // last word fetched: sequential scans cost one load per 8 bases
+	__device__ __forceinline__ int nib(int k) const { const int w = k >> 3; if (w != cw) { cw = w; cv = seq[w]; } return (int)((cv >> ((k & 7) << 2)) & 0xf); }
 	__device__ __forceinline__ int operator()(int i) const {
 		const int j = off + i;
-		if (!rev) return (int)((seq[j >> 3] >> ((j & 7) << 2)) & 0xf);
-		const int k = qlen - 1 - j; const int c = (int)((seq[k >> 3] >> ((k & 7) << 2)) & 0xf);
+		if (!rev) return nib(j);
+		const int c = nib(qlen - 1 - j);
 		return c < 4 ? 3 - c : 4;
 	}
 	__device__ __forceinline__ ReadAcc shift(int n) const { return ReadAcc{seq, qlen, rev, off + n}; }
 };
-struct RefAcc { const uint32_t *S4; uint64_t base; __device__ __forceinline__ int operator()(int i) const { return (int)d_seq4(S4, base + (uint64_t)i); } __device__ __forceinline__ RefAcc shift(int n) const { return RefAcc{S4, base + (uint64_t)n}; } };
+struct RefAcc {
+	const uint32_t *S4; uint64_t base;
+	mutable uint64_t cw = ~0ULL; mutable uint32_t cv = 0;
+	__device__ __forceinline__ int operator()(int i) const { const uint64_t a = base + (uint64_t)(int64_t)i, w = a >> 3; if (w != cw) { cw = w; cv = S4[w]; } return (int)((cv >> ((a & 7) << 2)) & 0xf); }
+	__device__ __forceinline__ RefAcc shift(int n) const { return RefAcc{S4, base + (uint64_t)(int64_t)n}; }
+};
 
 template <class QA, class TA>
 __device__ int d_test_zdrop(const AlParams &P, QA qseq, TA tseq, int n_cigar, const uint32_t *cigar)
