@@ -637,25 +637,28 @@ k_chain_lane(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ 
 }
 
 // =============================================================================================
-// K4 (small fragments, LDS resident): one lane per fragment, 64 fragments per wavefront, every per-anchor row
-// (x, qpos, span/segment/tandem, f, p, t, v) staged in LDS as [field][anchor][lane] so that a wavefront's accesses are
-// conflict-free and nothing is re-fetched from HBM inside the O(n^2) recurrence.  20 bytes per anchor: CAPL = 32 or 64
-// anchors per fragment (40 / 80 KB per wavefront).  The caller orders fragments by anchor count; a wavefront whose largest
-// fragment does not fall in (CAPL/2, CAPL] leaves the work to the other instantiation (or to k_chain / k_chain_lane).
+// K4 (small fragments, LDS resident): one lane per fragment, LANES fragments per wavefront, every per-anchor row staged
+// in LDS as [field][anchor][lane] (conflict-free) so that nothing is re-fetched from HBM inside the O(n^2) recurrence.
+// 13 bytes per anchor: 32-bit position, a byte holding (block id | segment | tandem) where "block" numbers the distinct
+// (strand, contig) values of the x-sorted anchors, 16-bit query position, f, v (int16) and p, t (uint8 row indices).
+// CAPL anchors per fragment; the caller orders fragments by anchor count and a wavefront whose largest fragment does not
+// fall in (lo_excl, CAPL] leaves the work to another instantiation or to k_chain.  All spans must equal k (true for the
+// non-HPC sketch of this path); a fragment violating that is left to k_chain via the `other` flag.
 // =============================================================================================
-template <int CAPL>
+template <int CAPL, int LANES>
 __global__ void __launch_bounds__(64)
 k_chain_lds(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_off, const uint32_t *__restrict__ frag_na,
             const uint32_t *__restrict__ frag_first, const uint32_t *__restrict__ rd_len,
             AlAnchor *__restrict__ chained, uint64_t *__restrict__ u_out, uint32_t *__restrict__ frag_nu, uint64_t *__restrict__ ws_u64,
             const uint32_t *__restrict__ order, int n_list, int lo_excl, AlParams P, unsigned long long *__restrict__ counters)
 {
-	__shared__ uint64_t sx[CAPL * 64];
-	__shared__ uint16_t sq[CAPL * 64], sm[CAPL * 64], sp[CAPL * 64], st_[CAPL * 64];
-	__shared__ int16_t sf[CAPL * 64], sv[CAPL * 64];
+	__shared__ uint32_t sx[CAPL * LANES];
+	__shared__ uint16_t sq[CAPL * LANES];
+	__shared__ int16_t sf[CAPL * LANES], sv[CAPL * LANES];
+	__shared__ uint8_t sm[CAPL * LANES], sp[CAPL * LANES], st_[CAPL * LANES];
 	const int lane = threadIdx.x;
-	const int t0 = blockIdx.x * 64 + lane;
-	const bool have = t0 < n_list;
+	const int t0 = blockIdx.x * LANES + lane;
+	const bool have = lane < LANES && t0 < n_list;
 	const uint32_t f = have ? (order ? order[t0] : (uint32_t)t0) : 0;
 	const int n = have ? (int)frag_na[f] : 0;
 	int nmax = n;
@@ -664,13 +667,13 @@ k_chain_lds(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a
 	if (!have) return;
 	frag_nu[f] = 0;
 	if (n == 0) return;
-#define XL(j) sx[(j) * 64 + lane]
-#define QL(j) sq[(j) * 64 + lane]
-#define ML(j) sm[(j) * 64 + lane]
-#define FL(j) sf[(j) * 64 + lane]
-#define PL(j) sp[(j) * 64 + lane]
-#define TL(j) st_[(j) * 64 + lane]
-#define VL(j) sv[(j) * 64 + lane]
+#define XL(j) sx[(j) * LANES + lane]
+#define QL(j) sq[(j) * LANES + lane]
+#define ML(j) sm[(j) * LANES + lane]
+#define FL(j) sf[(j) * LANES + lane]
+#define PL(j) sp[(j) * LANES + lane]
+#define TL(j) st_[(j) * LANES + lane]
+#define VL(j) sv[(j) * LANES + lane]
 	const uint32_t r0 = frag_first[f], r1 = frag_first[f + 1];
 	const int n_segs = (int)(r1 - r0);
 	int qlen_sum = 0; for (uint32_t r = r0; r < r1; ++r) qlen_sum += (int)rd_len[r];
@@ -681,26 +684,34 @@ k_chain_lds(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a
 	else if (P.max_frag_len > 0) { max_dist_x = P.max_frag_len - qlen_sum; if (max_dist_x < P.max_gap) max_dist_x = P.max_gap; }
 	else max_dist_x = P.max_gap;
 	const int bw = P.bw, max_skip = P.max_chain_skip, max_iter = P.max_chain_iter, min_cnt = P.min_cnt, min_sc = P.min_chain_score;
-	uint32_t sum_qspan = 0;
-	for (int i = 0; i < n; ++i) {
-		const AlAnchor e = a[i];
-		XL(i) = e.x; QL(i) = (uint16_t)(uint32_t)e.y;
-		ML(i) = (uint16_t)((e.y >> 32 & 0xff) | ((e.y & AL_SEED_SEG_MASK) >> AL_SEED_SEG_SHIFT & 0x7f) << 8 | ((e.y & AL_SEED_TANDEM) ? 0x8000u : 0u));
-		TL(i) = 0xffff;
-		sum_qspan += (uint32_t)(e.y >> 32 & 0xff);
+	const int32_t q_span = P.k;
+	{
+		uint32_t prev_hi = 0; int blk = -1; bool bad = false;
+		for (int i = 0; i < n; ++i) {
+			const AlAnchor e = a[i];
+			const uint32_t hi = (uint32_t)(e.x >> 32);
+			if (i == 0 || hi != prev_hi) { ++blk; prev_hi = hi; }
+			if ((int)(e.y >> 32 & 0xff) != q_span || ((e.y & AL_SEED_SEG_MASK) >> AL_SEED_SEG_SHIFT) > 1 || (uint32_t)e.y > 0xffffu) bad = true;
+			XL(i) = (uint32_t)e.x; QL(i) = (uint16_t)(uint32_t)e.y;
+			ML(i) = (uint8_t)((uint32_t)blk | (uint32_t)((e.y & AL_SEED_SEG_MASK) >> AL_SEED_SEG_SHIFT & 1) << 6 | ((e.y & AL_SEED_TANDEM) ? 0x80u : 0u));
+			TL(i) = 0xff;
+		}
+		if (bad) { atomicAdd(&counters[7], 1ULL); return; }   // not representable in the compact rows (never on the short-read path)
 	}
-	const double avg_d = (double)(float)((double)(float)sum_qspan / (double)(float)n);   // (float)sum/n (chain.c:42)
+	const double avg_d = (double)(float)((double)(float)((uint32_t)q_span * (uint32_t)n) / (double)(float)n);   // (float)sum/n (chain.c:42)
 	int st = 0;
 	for (int i = 0; i < n; ++i) {                                                 // chain.c:46-85
-		const uint64_t ri = XL(i); const uint32_t mi_ = ML(i);
-		const int32_t qi = (int32_t)QL(i), q_span = (int32_t)(mi_ & 0xff), sidi = (int32_t)(mi_ >> 8 & 0x7f);
+		const uint32_t pi = XL(i); const uint32_t mi_ = ML(i);
+		const int32_t qi = (int32_t)QL(i), sidi = (int32_t)(mi_ >> 6 & 1); const uint32_t blki = mi_ & 0x3f;
 		int max_j = -1; int32_t max_f = q_span, n_skip = 0;
-		while (st < i && ri > XL(st) + (uint64_t)max_dist_x) ++st;
+		// ri > a[st].x + max_dist_x  <=>  different (strand, contig) block, or same block and pos_i > pos_st + max_dist_x
+		while (st < i && ((ML(st) & 0x3f) != blki || (uint64_t)pi > (uint64_t)XL(st) + (uint64_t)max_dist_x)) ++st;
 		if (i - st > max_iter) st = i - max_iter;
 		for (int j = i - 1; j >= st; --j) {
-			const int64_t dr = (int64_t)(ri - XL(j));
 			const uint32_t mj = ML(j);
-			const int32_t dq = qi - (int32_t)QL(j), sidj = (int32_t)(mj >> 8 & 0x7f);
+			// j >= st implies the same block unless max_iter truncated st (then a different block gives a huge dr: every test below fails as in the reference)
+			const int64_t dr = (mj & 0x3f) == blki ? (int64_t)pi - (int64_t)XL(j) : (int64_t)1 << 40;
+			const int32_t dq = qi - (int32_t)QL(j), sidj = (int32_t)(mj >> 6 & 1);
 			if ((sidi == sidj && dr == 0) || dq <= 0) continue;
 			if ((sidi == sidj && dq > max_dist_y) || dq > max_dist_x) continue;
 			const int32_t dd = dr > dq ? (int32_t)(dr - dq) : (int32_t)(dq - dr);
@@ -713,23 +724,23 @@ k_chain_lds(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a
 			if (sidi != sidj) { if (dr == 0) ++sc; else sc -= c_lin < log_dd ? c_lin : log_dd; }
 			else sc -= c_lin + (log_dd >> 1);
 			sc += (int32_t)FL(j);
-			const uint16_t pj = PL(j);
+			const uint8_t pj = PL(j);
 			if (sc > max_f) { max_f = sc; max_j = j; if (n_skip > 0) --n_skip; }
-			else if (TL(j) == (uint16_t)i) { if (++n_skip > max_skip) break; }
-			if (pj != 0xffff) TL(pj) = (uint16_t)i;
+			else if (TL(j) == (uint8_t)i) { if (++n_skip > max_skip) break; }
+			if (pj != 0xff) TL(pj) = (uint8_t)i;
 		}
-		FL(i) = (int16_t)max_f; PL(i) = max_j < 0 ? (uint16_t)0xffff : (uint16_t)max_j;
+		FL(i) = (int16_t)max_f; PL(i) = max_j < 0 ? (uint8_t)0xff : (uint8_t)max_j;
 		VL(i) = max_j >= 0 && (int32_t)VL(max_j) > max_f ? VL(max_j) : (int16_t)max_f;
 	}
-	// chain.c:87-109.  NB: the t[] marks above use the row index i (< CAPL) with 0xffff as "never"; from here t[] is a 0/1 flag.
+	// chain.c:87-109.  NB: the t[] marks above use the row index i (< CAPL <= 128) with 0xff as "never"; from here t[] is a 0/1 flag.
 	for (int i = 0; i < n; ++i) TL(i) = 0;
-	for (int i = 0; i < n; ++i) if (PL(i) != 0xffff) TL(PL(i)) = 1;
+	for (int i = 0; i < n; ++i) if (PL(i) != 0xff) TL(PL(i)) = 1;
 	uint64_t *utmp = ws_u64 + a_off[f];
 	int32_t n_u = 0, n_v = 0, k = 0;
 	for (int i = 0; i < n; ++i)
 		if (TL(i) == 0 && (int32_t)VL(i) >= min_sc) {
 			int j = i;
-			while (j >= 0 && FL(j) < VL(j)) j = PL(j) == 0xffff ? -1 : (int)PL(j);
+			while (j >= 0 && FL(j) < VL(j)) j = PL(j) == 0xff ? -1 : (int)PL(j);
 			if (j < 0) j = i;
 			utmp[n_u++] = (uint64_t)(uint32_t)(int32_t)FL(j) << 32 | (uint64_t)j;
 		}
@@ -738,19 +749,20 @@ k_chain_lds(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a
 	for (int i = 0; i < n; ++i) TL(i) = 0;
 	for (int32_t i = 0; i < n_u; ++i) {                                              // chain.c:111-128; v[] reused as the visit list
 		const int32_t n_v0 = n_v, k0 = k; int j = (int32_t)utmp[i];
-		do { VL(n_v) = (int16_t)j; ++n_v; TL(j) = 1; j = PL(j) == 0xffff ? -1 : (int)PL(j); } while (j >= 0 && TL(j) == 0);
+		do { VL(n_v) = (int16_t)j; ++n_v; TL(j) = 1; j = PL(j) == 0xff ? -1 : (int)PL(j); } while (j >= 0 && TL(j) == 0);
 		if (j < 0) { if (n_v - n_v0 >= min_cnt) utmp[k++] = utmp[i] >> 32 << 32 | (uint32_t)(n_v - n_v0); }
 		else if ((int32_t)(utmp[i] >> 32) - (int32_t)FL(j) >= min_sc) { if (n_v - n_v0 >= min_cnt) utmp[k++] = (uint64_t)((utmp[i] >> 32) - (uint64_t)(uint32_t)(int32_t)FL(j)) << 32 | (uint32_t)(n_v - n_v0); }
 		if (k0 == k) n_v = n_v0;
 	}
 	n_u = k;
-	// chains ordered by the x of their first anchor (chain.c:144-160); n_u <= 32: stable insertion sort (ksort.h:149)
+	// chains ordered by the x of their first anchor (chain.c:144-160); n_u <= 64: stable insertion sort (ksort.h:149).
+	// x order == (block, pos) order.  p[] (free now) = chain start offsets into v[], t[] = permutation.
 	int32_t off = 0;
-	for (int32_t c = 0; c < n_u; ++c) { PL(c) = (uint16_t)off; off += (int32_t)(uint32_t)utmp[c]; TL(c) = (uint16_t)c; }
-#define CXL(c) (XL((int)VL((int)PL(c) + (int32_t)(uint32_t)utmp[c] - 1)))
+	for (int32_t c = 0; c < n_u; ++c) { PL(c) = (uint8_t)off; off += (int32_t)(uint32_t)utmp[c]; TL(c) = (uint8_t)c; }
+#define CXL(c) (((uint64_t)(ML((int)VL((int)PL(c) + (int32_t)(uint32_t)utmp[c] - 1)) & 0x3f) << 32) | XL((int)VL((int)PL(c) + (int32_t)(uint32_t)utmp[c] - 1)))
 	for (int32_t i = 1; i < n_u; ++i) {
-		const uint16_t ci = TL(i); const uint64_t xi = CXL(ci); int32_t j = i;
-		while (j > 0) { const uint16_t cj = TL(j - 1); if (xi < CXL(cj)) { TL(j) = cj; --j; } else break; }
+		const uint8_t ci = TL(i); const uint64_t xi = CXL(ci); int32_t j = i;
+		while (j > 0) { const uint8_t cj = TL(j - 1); if (xi < CXL(cj)) { TL(j) = cj; --j; } else break; }
 		TL(j) = ci;
 	}
 #undef CXL
@@ -759,12 +771,7 @@ k_chain_lds(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a
 	for (int32_t i = 0; i < n_u; ++i) {
 		const int32_t c = TL(i), ni = (int32_t)(uint32_t)utmp[c], k0 = PL(c);
 		u[i] = utmp[c];
-		for (int32_t j = 0; j < ni; ++j) {
-			const int idx = (int)VL(k0 + (ni - j - 1)); const uint32_t m = ML(idx);
-			AlAnchor e; e.x = XL(idx);
-			e.y = (uint64_t)QL(idx) | (uint64_t)(m & 0xff) << 32 | (uint64_t)(m >> 8 & 0x7f) << AL_SEED_SEG_SHIFT | ((m & 0x8000u) ? AL_SEED_TANDEM : 0ULL);
-			b[o++] = e;
-		}
+		for (int32_t j = 0; j < ni; ++j) b[o++] = a[(int)VL(k0 + (ni - j - 1))];
 	}
 	frag_nu[f] = (uint32_t)n_u;
 #undef XL
@@ -775,8 +782,8 @@ k_chain_lds(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a
 #undef TL
 #undef VL
 }
-template __global__ void k_chain_lds<32>(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, AlAnchor *, uint64_t *, uint32_t *, uint64_t *, const uint32_t *, int, int, AlParams, unsigned long long *);
-template __global__ void k_chain_lds<64>(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, AlAnchor *, uint64_t *, uint32_t *, uint64_t *, const uint32_t *, int, int, AlParams, unsigned long long *);
+#define INST_CHAIN_LDS(C, L) template __global__ void k_chain_lds<C, L>(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, AlAnchor *, uint64_t *, uint32_t *, uint64_t *, const uint32_t *, int, int, AlParams, unsigned long long *);
+INST_CHAIN_LDS(16, 64) INST_CHAIN_LDS(24, 64) INST_CHAIN_LDS(32, 64) INST_CHAIN_LDS(48, 64) INST_CHAIN_LDS(64, 64) INST_CHAIN_LDS(128, 32)
 
 // explicit instantiations used by the runtime
 template __global__ void k_anchor_sort<1024>(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, AlAnchor *, const uint32_t *, int, unsigned long long *, int);

@@ -18,7 +18,7 @@ extern "C" __global__ void k_alser_count(const AlAnchor *, const uint64_t *, con
 extern "C" __global__ void k_rechain_test(const AlAnchor *, const uint64_t *, const uint64_t *, const uint32_t *, const int32_t *, const uint32_t *, int, uint32_t *, uint32_t *);
 template <int CAP> __global__ void k_anchor_sort(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, AlAnchor *, const uint32_t *, int, unsigned long long *, int);
 template <int CAP> __global__ void k_chain(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, AlAnchor *, uint64_t *, uint32_t *, int32_t *, uint64_t *, const uint32_t *, int, AlParams, unsigned long long *, int);
-template <int CAPL> __global__ void k_chain_lds(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, AlAnchor *, uint64_t *, uint32_t *, uint64_t *, const uint32_t *, int, int, AlParams, unsigned long long *);
+template <int CAPL, int LANES> __global__ void k_chain_lds(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, AlAnchor *, uint64_t *, uint32_t *, uint64_t *, const uint32_t *, int, int, AlParams, unsigned long long *);
 extern "C" __global__ void k_chain_lane(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, AlAnchor *, uint64_t *, uint32_t *, int32_t *, uint64_t *, const uint32_t *, int, int, AlParams, unsigned long long *);
 
 static const char *g_stage_names[ST_N] = { "sketch", "seed_lookup", "scan", "anchor_sort", "chain", "rechain", "regs", "ext_prep", "ext_sort", "ext_dp", "ext_finish", "compact" };
@@ -243,26 +243,32 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 			AL_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(c->scan_tmp.p, bytes, (const uint32_t *)c->frag_na.p, c->chain_key.p, (const uint32_t *)c->chain_idx.p, c->chain_idx2.p, nl, 0, 20, s));
 			order = c->chain_idx2.p; sorted = true;
 		}
-		if (lane_max > 0) {
-			const int nw = (nl + 63) / 64;
-			hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain_lds<32>), dim3(nw), dim3(64), 0, s, c->anchors.p, c->a_off.p, c->frag_na.p, c->frag_first.p, c->rd_len.p, c->chained.p, c->u.p, c->frag_nu.p, c->ws_u64.p, order, nl, -1, c->P, c->counters.p);
-			hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain_lds<64>), dim3(nw), dim3(64), 0, s, c->anchors.p, c->a_off.p, c->frag_na.p, c->frag_first.p, c->rd_len.p, c->chained.p, c->u.p, c->frag_nu.p, c->ws_u64.p, order, nl, 32, c->P, c->counters.p);
+		// index ranges of the size-ordered list: [0, lb65) <= 64 anchors, [lb65, lb129) <= 128 anchors, rest
+		uint32_t lb65 = (uint32_t)nl, lb129 = (uint32_t)nl;
+		if (sorted) {
+			uint32_t *d_lb = (uint32_t *)(c->counters.p + 15);            // two consecutive u32
+			const uint32_t init[2] = {(uint32_t)nl, (uint32_t)nl};
+			AL_HIP_CHECK(hipMemcpyAsync(d_lb, init, 8, hipMemcpyHostToDevice, s));
+			hipLaunchKernelGGL(k_lower_bound, dim3((nl + 255) / 256), dim3(256), 0, s, c->chain_key.p, (uint32_t)nl, 65u, d_lb);
+			hipLaunchKernelGGL(k_lower_bound, dim3((nl + 255) / 256), dim3(256), 0, s, c->chain_key.p, (uint32_t)nl, 129u, d_lb + 1);
+			uint32_t lb[2];
+			AL_HIP_CHECK(hipMemcpyAsync(lb, d_lb, 8, hipMemcpyDeviceToHost, s));
+			AL_HIP_CHECK(hipStreamSynchronize(s));
+			lb65 = lb[0]; lb129 = lb[1];
 		}
+#define LCH(C, L, LO, LIST, N) do { const int n__ = (N); if (n__ > 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain_lds<C, L>), dim3((n__ + L - 1) / L), dim3(64), 0, s, c->anchors.p, c->a_off.p, c->frag_na.p, c->frag_first.p, c->rd_len.p, c->chained.p, c->u.p, c->frag_nu.p, c->ws_u64.p, LIST, n__, LO, c->P, c->counters.p); } while (0)
+		if (lane_max > 0) {
+			const int n64 = sorted ? (int)lb65 : nl;                        // unsorted: wavefront-group ownership inside the kernels
+			LCH(16, 64, -1, order, n64); LCH(24, 64, 16, order, n64); LCH(32, 64, 24, order, n64); LCH(48, 64, 32, order, n64); LCH(64, 64, 48, order, n64);
+			if (sorted) LCH(128, 32, -1, order + lb65, (int)(lb129 - lb65));
+		}
+#undef LCH
 		{
-			// wave-per-fragment kernel: only the tail of the size-ordered list can contain wavefront-groups it owns
-			uint32_t tail = 0;
-			if (sorted && lane_max > 0) {
-				uint32_t *d_lb = (uint32_t *)(c->counters.p + 15);
-				uint32_t nlu = (uint32_t)nl;
-				AL_HIP_CHECK(hipMemcpyAsync(d_lb, &nlu, 4, hipMemcpyHostToDevice, s));
-				hipLaunchKernelGGL(k_lower_bound, dim3((nl + 255) / 256), dim3(256), 0, s, c->chain_key.p, (uint32_t)nl, (uint32_t)(lane_max + 1), d_lb);
-				AL_HIP_CHECK(hipMemcpyAsync(&tail, d_lb, 4, hipMemcpyDeviceToHost, s));
-				AL_HIP_CHECK(hipStreamSynchronize(s));
-				tail &= ~63u;
-			}
+			// wave-per-fragment kernel: the rest of the size-ordered list (or, unsorted, the wavefront-groups the LDS kernels do not own)
+			const uint32_t tail = sorted && lane_max > 0 ? lb129 : 0;
 			const int nt = nl - (int)tail;
 			if (nt > 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<768>), dim3(nt), dim3(64), 0, s, c->anchors.p, c->a_off.p, c->frag_na.p, c->frag_first.p, c->rd_len.p, c->chained.p, c->u.p, c->frag_nu.p,
-			                   c->ws_i32.p, c->ws_u64.p, order ? order + tail : nullptr, nt, c->P, c->counters.p, lane_max);
+			                   c->ws_i32.p, c->ws_u64.p, order ? order + tail : nullptr, nt, c->P, c->counters.p, sorted ? 0 : lane_max);
 		}
 	}
 	if (first) AL_HIP_CHECK(hipEventRecord(c->ev[ST_CHAIN + 1], s));
