@@ -104,7 +104,7 @@ __device__ __forceinline__ void d_ksw_reg(LT &L, const int gl, GroupWs &ws, int 
 		for (int b = 0; b < NB; ++b) {
 			if (NB > 1 && r > 0 && b + 1 == be && (en0 & 15) == 0) hprev15 = __shfl(H[b], GW - 1, GW);   // H[r-1][en0-1] (block may be outside [st_,en_])
 			const bool act = NB == 1 ? true : (b >= st_ && b <= en_);
-			if (NB >= 8 && !act) continue;
+			if (NB >= 4 && !act) continue;
 			const int t = 16 * b + gl;
 			uint32_t a_old = A[b], b_old = B[b];
 			const bool isr = act && enr && t == r;                           // y[r], y2[r], u[r] (:150-153)

@@ -964,11 +964,41 @@ k_ext_prep(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_
 						jr.qoff = (uint32_t)qe; jr.toff = ref_off + (uint64_t)re;
 					}
 				}
+				// Closed form instead of a DP job when the flank matches its target with at most one mismatch (no N, query not longer
+				// than the target): the extension then runs along the diagonal, every gapped path loses >= q+e > a+b, and max / max_q /
+				// max_t / mqe_t / reach_end / CIGAR follow from the running diagonal score exactly as ksw_extd2 computes them
+				// (checked against the reference DP in tests/test_diag_shortcut.py; jobs done this way carry pad0 = 1).
+				if (!((P.dbg >> 31) & 1) && r->cnt > 0) {
+					const int32_t rid2 = (int32_t)(a[r->as].x << 1 >> 33), rev2 = (int32_t)(a[r->as].x >> 63);
+					const uint64_t ref_off2 = G.seq_off[rid2];
+					for (int side = 0; side < 2; ++side) {
+						ExtJob &jj = side == 0 ? jl : jr;
+						const int ql = jj.qlen, tl = jj.tlen;
+						if (ql == 0 || ql > tl) continue;
+						const ReadAcc Qa{seq, qlen, rev2, 0}; const RefAcc Ta{G.S4, ref_off2};
+						int sc = 0, mx = 0, pos = -1, nmm = 0; bool ok = true;
+						for (int k = 0; k < ql; ++k) {
+							const int cq = side == 0 ? Qa(x.qs - 1 - k) : Qa(x.qe + k);
+							const int ct = side == 0 ? Ta(x.rs - 1 - k) : Ta(x.re + k);
+							if (cq > 3 || ct > 3) { ok = false; break; }
+							if (cq == ct) sc += P.a; else { sc -= P.b; if (++nmm > 1) { ok = false; break; } }
+							if (sc > mx) { mx = sc; pos = k; }
+						}
+						if (!ok) continue;
+						const bool reach = sc + P.end_bonus > mx;
+						const int ncig = (reach || pos >= 0) ? 1 : 0;
+						ExtOut o; o.max = mx; o.max_q = pos; o.max_t = pos; o.mqe_t = ql - 1;
+						o.flags_ncig = (uint32_t)(reach ? 1 : 0) | (uint32_t)ncig << 8; o.cig_off = 0;
+						o.cig[0] = ncig ? (uint32_t)(reach ? ql : pos + 1) << 4 : 0; o.cig[1] = o.cig[2] = o.cig[3] = o.cig[4] = o.cig[5] = 0;
+						E.outs[jb + side] = o;
+						jj.pad0 = 1;
+					}
+				}
 				E.rext[B2 + (uint64_t)s * fw.cap + i] = x;
 				E.jobs[jb] = jl; E.jobs[jb + 1] = jr;
-				{ const int c0 = jl.qlen ? d_job_class(jl.qlen, jl.tlen, lane_ok) : AL_NCLS, c1 = jr.qlen ? d_job_class(jr.qlen, jr.tlen, lane_ok) : AL_NCLS;
-				  E.job_key[jb] = jl.qlen ? ((uint32_t)c0 << 20 | (uint32_t)(jl.qlen + jl.tlen)) : 0xffffffffu;
-				  E.job_key[jb + 1] = jr.qlen ? ((uint32_t)c1 << 20 | (uint32_t)(jr.qlen + jr.tlen)) : 0xffffffffu;
+				{ const int c0 = (jl.qlen && !jl.pad0) ? d_job_class(jl.qlen, jl.tlen, lane_ok) : AL_NCLS, c1 = (jr.qlen && !jr.pad0) ? d_job_class(jr.qlen, jr.tlen, lane_ok) : AL_NCLS;
+				  E.job_key[jb] = c0 < AL_NCLS ? ((uint32_t)c0 << 20 | (uint32_t)(jl.qlen + jl.tlen)) : 0xffffffffu;
+				  E.job_key[jb + 1] = c1 < AL_NCLS ? ((uint32_t)c1 << 20 | (uint32_t)(jr.qlen + jr.tlen)) : 0xffffffffu;
 				  ++cls_cnt[c0]; ++cls_cnt[c1]; }
 			}
 		}
@@ -1532,6 +1562,7 @@ int al_run_align_stage(al_ctx_t *c)
 			AL_HIP_CHECK(hipEventRecord(c->ev[ST_EXT_SORT + 1], s));
 			AL_HIP_CHECK(hipMemcpyAsync(hist, A->hist.p, (AL_NCLS + 1) * 8, hipMemcpyDeviceToHost, s));
 			AL_HIP_CHECK(hipStreamSynchronize(s));
+			if ((c->P.dbg >> 30) & 1) { fprintf(stderr, "[airlift] DP jobs per class (lane16 lane32 lane64 g1 g2 g4 g8 g22 lds | empty):"); for (int i = 0; i <= AL_NCLS; ++i) fprintf(stderr, " %llu", hist[i]); fprintf(stderr, "\n"); }
 			// one launch per job class over its slice of the sorted job list
 			static const int NBs[5] = {1, 2, 4, 8, 22};
 			uint32_t first = 0;
