@@ -645,6 +645,7 @@ k_chain_lane(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ 
 // fall in (lo_excl, CAPL] leaves the work to another instantiation or to k_chain.  All spans must equal k (true for the
 // non-HPC sketch of this path); a fragment violating that is left to k_chain via the `other` flag.
 // =============================================================================================
+#define AL_CLIN_N 1024
 template <int CAPL, int LANES>
 __global__ void __launch_bounds__(64)
 k_chain_lds(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_off, const uint32_t *__restrict__ frag_na,
@@ -656,6 +657,7 @@ k_chain_lds(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a
 	__shared__ uint16_t sq[CAPL * LANES];
 	__shared__ int16_t sf[CAPL * LANES], sv[CAPL * LANES];
 	__shared__ uint8_t sm[CAPL * LANES], sp[CAPL * LANES], st_[CAPL * LANES];
+	__shared__ uint8_t s_clin[AL_CLIN_N];
 	const int lane = threadIdx.x;
 	const int t0 = blockIdx.x * LANES + lane;
 	const bool have = lane < LANES && t0 < n_list;
@@ -664,6 +666,9 @@ k_chain_lds(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a
 	int nmax = n;
 	for (int d = 32; d > 0; d >>= 1) { const int o = __shfl_xor(nmax, d); nmax = o > nmax ? o : nmax; }
 	if (nmax > CAPL || nmax <= lo_excl) return;                              // another instantiation / kernel owns this wavefront
+	// (int)(dd * .01 * avg_d) of chain.c:69 for avg_d == k, tabulated with the same two double multiplications
+	for (int d = lane; d < AL_CLIN_N; d += 64) s_clin[d] = (uint8_t)(int)((double)d * .01 * (double)P.k);
+	__syncthreads();
 	if (!have) return;
 	frag_nu[f] = 0;
 	if (n == 0) return;
@@ -674,6 +679,8 @@ k_chain_lds(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a
 #define PL(j) sp[(j) * LANES + lane]
 #define TL(j) st_[(j) * LANES + lane]
 #define VL(j) sv[(j) * LANES + lane]
+	const bool prof = (P.dbg >> 21) & 1;
+	const long long tc0 = prof ? clock64() : 0;
 	const uint32_t r0 = frag_first[f], r1 = frag_first[f + 1];
 	const int n_segs = (int)(r1 - r0);
 	int qlen_sum = 0; for (uint32_t r = r0; r < r1; ++r) qlen_sum += (int)rd_len[r];
@@ -699,6 +706,8 @@ k_chain_lds(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a
 		if (bad) { atomicAdd(&counters[7], 1ULL); return; }   // not representable in the compact rows (never on the short-read path)
 	}
 	const double avg_d = (double)(float)((double)(float)((uint32_t)q_span * (uint32_t)n) / (double)(float)n);   // (float)sum/n (chain.c:42)
+	const bool tab_ok = avg_d == (double)P.k && P.k * 0.01 * (AL_CLIN_N - 1) < 255.0;
+	const long long tc1 = prof ? clock64() : 0;
 	int st = 0;
 	for (int i = 0; i < n; ++i) {                                                 // chain.c:46-85
 		const uint32_t pi = XL(i); const uint32_t mi_ = ML(i);
@@ -707,31 +716,42 @@ k_chain_lds(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a
 		// ri > a[st].x + max_dist_x  <=>  different (strand, contig) block, or same block and pos_i > pos_st + max_dist_x
 		while (st < i && ((ML(st) & 0x3f) != blki || (uint64_t)pi > (uint64_t)XL(st) + (uint64_t)max_dist_x)) ++st;
 		if (i - st > max_iter) st = i - max_iter;
-		for (int j = i - 1; j >= st; --j) {
-			const uint32_t mj = ML(j);
-			// j >= st implies the same block unless max_iter truncated st (then a different block gives a huge dr: every test below fails as in the reference)
-			const int64_t dr = (mj & 0x3f) == blki ? (int64_t)pi - (int64_t)XL(j) : (int64_t)1 << 40;
-			const int32_t dq = qi - (int32_t)QL(j), sidj = (int32_t)(mj >> 6 & 1);
-			if ((sidi == sidj && dr == 0) || dq <= 0) continue;
-			if ((sidi == sidj && dq > max_dist_y) || dq > max_dist_x) continue;
-			const int32_t dd = dr > dq ? (int32_t)(dr - dq) : (int32_t)(dq - dr);
-			if (sidi == sidj && dd > bw) continue;
-			if (n_segs > 1 && sidi == sidj && dr > max_dist_y) continue;
-			const int32_t min_d = dq < dr ? dq : (int32_t)dr;
+		// The rows of candidate j-1 are fetched while candidate j is scored, and the body is written with selects rather than
+		// branches: one wavefront per SIMD fits (LDS capacity), so the kernel is bound by instruction issue and every
+		// divergent branch costs scalar exec-mask work.  t[j-1] can be overwritten by this iteration's mark after it was
+		// fetched; that case is patched in registers.  i - st <= CAPL < max_iter here, so st..i-1 all lie in anchor i's
+		// (strand, contig) block and dr fits 32 bits.
+		int jn = i > 0 ? i - 1 : 0;
+		uint32_t n_m = ML(jn), n_x = XL(jn); int32_t n_q = (int32_t)QL(jn), n_f = (int32_t)FL(jn); uint8_t n_p = PL(jn), n_t = TL(jn);
+		bool done = false;
+		for (int j = i - 1; j >= st && !done; --j) {
+			const uint32_t mj = n_m, xj = n_x; const int32_t qj = n_q, fj = n_f; const uint8_t pj = n_p, tj = n_t;
+			jn = j > 0 ? j - 1 : 0;
+			n_m = ML(jn); n_x = XL(jn); n_q = (int32_t)QL(jn); n_f = (int32_t)FL(jn); n_p = PL(jn); n_t = TL(jn);
+			const int32_t dr = (int32_t)(pi - xj);
+			const int32_t dq = qi - qj;
+			const bool same = (int32_t)(mj >> 6 & 1) == sidi;
+			const int32_t dd = dr > dq ? dr - dq : dq - dr;
+			const bool skip = (same && dr == 0) | (dq <= 0) | (same && dq > max_dist_y) | (dq > max_dist_x) | (same && dd > bw) |
+			                  (n_segs > 1 && same && dr > max_dist_y);
+			const int32_t min_d = dq < dr ? dq : dr;
 			int32_t sc = min_d > q_span ? q_span : min_d;
 			const int32_t log_dd = dd ? d_ilog2((uint32_t)dd) : 0;
-			const int32_t c_lin = (int)((double)dd * .01 * avg_d);
-			if (sidi != sidj) { if (dr == 0) ++sc; else sc -= c_lin < log_dd ? c_lin : log_dd; }
-			else sc -= c_lin + (log_dd >> 1);
-			sc += (int32_t)FL(j);
-			const uint8_t pj = PL(j);
-			if (sc > max_f) { max_f = sc; max_j = j; if (n_skip > 0) --n_skip; }
-			else if (TL(j) == (uint8_t)i) { if (++n_skip > max_skip) break; }
-			if (pj != 0xff) TL(pj) = (uint8_t)i;
+			int32_t c_lin = (int32_t)s_clin[dd < AL_CLIN_N ? dd : AL_CLIN_N - 1];
+			if (__builtin_expect(!tab_ok || dd >= AL_CLIN_N, 0)) c_lin = (int)((double)dd * .01 * avg_d);
+			const int32_t pen_same = c_lin + (log_dd >> 1), pen_diff = dr == 0 ? -1 : (c_lin < log_dd ? c_lin : log_dd);
+			sc = sc - (same ? pen_same : pen_diff) + fj;
+			const bool better = !skip && sc > max_f;
+			const bool marked = !skip && !better && tj == (uint8_t)i;
+			max_f = better ? sc : max_f; max_j = better ? j : max_j;
+			n_skip += marked ? 1 : (better && n_skip > 0 ? -1 : 0);
+			done = marked && n_skip > max_skip;                                       // the reference breaks before marking p[j]
+			if (!skip && !done && pj != 0xff) { TL(pj) = (uint8_t)i; n_t = (int)pj == jn ? (uint8_t)i : n_t; }
 		}
 		FL(i) = (int16_t)max_f; PL(i) = max_j < 0 ? (uint8_t)0xff : (uint8_t)max_j;
 		VL(i) = max_j >= 0 && (int32_t)VL(max_j) > max_f ? VL(max_j) : (int16_t)max_f;
 	}
+	const long long tc2 = prof ? clock64() : 0;
 	// chain.c:87-109.  NB: the t[] marks above use the row index i (< CAPL <= 128) with 0xff as "never"; from here t[] is a 0/1 flag.
 	for (int i = 0; i < n; ++i) TL(i) = 0;
 	for (int i = 0; i < n; ++i) if (PL(i) != 0xff) TL(PL(i)) = 1;
@@ -774,6 +794,7 @@ k_chain_lds(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a
 		for (int32_t j = 0; j < ni; ++j) b[o++] = a[(int)VL(k0 + (ni - j - 1))];
 	}
 	frag_nu[f] = (uint32_t)n_u;
+	if (prof && lane == 0) { const long long tc3 = clock64(); atomicAdd(&counters[8], (unsigned long long)(tc1 - tc0)); atomicAdd(&counters[9], (unsigned long long)(tc2 - tc1)); atomicAdd(&counters[11], (unsigned long long)(tc3 - tc2)); atomicAdd(&counters[14], 1ULL); }
 #undef XL
 #undef QL
 #undef ML

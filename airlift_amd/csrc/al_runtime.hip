@@ -323,6 +323,7 @@ extern "C" int al_batch_run(al_ctx_t *c)
 	c->ran = true;
 	// counters + algorithmic bytes
 	unsigned long long h[16]; AL_HIP_CHECK(hipMemcpy(h, c->counters.p, sizeof(h), hipMemcpyDeviceToHost));
+	if ((c->P.dbg >> 21) & 1) fprintf(stderr, "[airlift] k_chain_lds lane-0 cycles: load %.1f%%  dp %.1f%%  tail %.1f%%  (%.0f cycles/wave, %llu waves)\n", 100.0 * h[8] / (h[8] + h[9] + h[11] + 1), 100.0 * h[9] / (h[8] + h[9] + h[11] + 1), 100.0 * h[11] / (h[8] + h[9] + h[11] + 1), (double)(h[8] + h[9] + h[11]) / (h[14] + 1), h[14]);
 	al_batch_stat_t &st = c->stat; memset(&st, 0, sizeof(st));
 	st.n_frag = c->n_frag; st.n_reads = c->n_reads; st.n_bases = c->n_bases;
 	st.n_mini = ~0ULL; st.n_chain = ~0ULL;   // filled lazily by al_batch_stat()

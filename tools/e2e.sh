@@ -1,0 +1,19 @@
+#!/bin/bash
+# end-to-end wall clock of the CLI (FASTQ in -> SAM out) against the CPU comparator on the same files: tools/e2e.sh [pairs]
+PAIRS=${1:-500000}
+REPO=${GRAFT_REPO_ROOT:-/root/repo}; D=/tmp/al_e2e; mkdir -p $D
+python3 - <<PY
+import sys; sys.path.insert(0, "$REPO/tools")
+import gen_synth as g, numpy as np
+rk, _ = g.CONFIGS["c2"]; ref = g.make_reference(**rk); g.write_fasta("$D/ref.fa", ref)
+r1, r2 = g.simulate_pairs(ref, $PAIRS, 150, seed=77)
+g.write_fastq("$D/r_1.fq", r1, "realigned_"); g.write_fastq("$D/r_2.fq", r2, "realigned_")
+PY
+cd $D
+for t in 1 ${THREADS:-16}; do
+  TIMEFORMAT="airlift-align -t $t: %R s wall, %U s user ($PAIRS pairs)"; time $REPO/airlift_amd/bin/airlift-align -ax sr -t $t ref.fa r_1.fq r_2.fq > out_gpu.sam 2> err_gpu.txt
+done
+if [ -x $REPO/oracle/_ref/mm2ref ]; then
+  TIMEFORMAT="mm2ref -t $(nproc): %R s wall, %U s user"; time $REPO/oracle/_ref/mm2ref -t $(nproc) ref.fa r_1.fq r_2.fq > out_cpu.sam 2> err_cpu.txt
+  cmp out_gpu.sam out_cpu.sam && echo "SAM identical ($(wc -l < out_gpu.sam) lines)"
+fi
