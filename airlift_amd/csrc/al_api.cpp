@@ -180,85 +180,4 @@ extern "C" int al_write_sam(char *buf, size_t cap, const al_idx_t *mi, const cha
 	return o.ovf ? -1 : (int)(o.p - buf);
 }
 
-// ---------------------------------------------------------------------------------------------
-// file-level driver (mm_map_file_frag, map.c:672-700): read -> device batch -> SAM, batch by batch
-static inline bool qname_same(const std::string &a, const std::string &b)
-{
-	int l1 = qname_len(a.c_str()), l2 = qname_len(b.c_str());
-	return l1 == l2 && strncmp(a.c_str(), b.c_str(), l1) == 0;
-}
-
-extern "C" int al_map_file_frag(const al_idx_t *mi, int n_fn, const char **fn, const al_mapopt_t *opt, int n_threads,
-                                FILE *out, const char *rg, int device)
-{
-	(void)n_threads;
-	if (n_fn < 1 || n_fn > 2) return -1;
-	AlSeqFile *f1 = al_sf_open(fn[0]), *f2 = n_fn > 1 ? al_sf_open(fn[1]) : nullptr;
-	if (!f1 || (n_fn > 1 && !f2)) { fprintf(stderr, "ERROR: failed to open file '%s'\n", !f1 ? fn[0] : fn[1]); al_sf_close(f1); al_sf_close(f2); return -1; }
-	al_ctx_t *ctx = al_ctx_init(mi, opt, device);
-	if (!ctx) { al_sf_close(f1); al_sf_close(f2); return -2; }
-	char rg_id[256]; rg_id[0] = 0;
-	if (rg != (const char *)-1) al_write_sam_hdr(out, mi, rg, rg_id);
-	const int64_t batch_bases = opt->mini_batch_size > 0 ? (int64_t)opt->mini_batch_size * 4 : 200000000;   // larger device batches than the CPU's 50 Mbase
-	struct Rd { std::string name, seq, qual; };
-	std::vector<Rd> rds; std::vector<int> n_segs, qlens, n_regs, rep_len; std::vector<const char *> seqs, names; std::vector<al_reg1_t *> regs;
-	Rd pend; bool has_pend = false, done = false; std::vector<char> buf;
-	int rc = 0;
-	while (!done) {
-		rds.clear(); n_segs.clear(); int64_t bases = 0;
-		while (bases < batch_bases) {
-			if (f2) {
-				Rd a, b;
-				if (al_sf_read(f1, a.name, a.seq, a.qual) < 0) { done = true; break; }
-				if (al_sf_read(f2, b.name, b.seq, b.qual) < 0) { fprintf(stderr, "[W::%s] query files have different number of records; extra records skipped.\n", __func__); done = true; break; }
-				bases += a.seq.size() + b.seq.size();
-				rds.push_back(std::move(a)); rds.push_back(std::move(b)); n_segs.push_back(2);
-			} else {   // single file: adjacent reads with the same name form a fragment (frag_mode, map.c:580-586)
-				if (!has_pend) { if (al_sf_read(f1, pend.name, pend.seq, pend.qual) < 0) { done = true; break; } }
-				Rd a = std::move(pend); has_pend = false; pend = Rd();
-				int ns = 1; bases += a.seq.size();
-				rds.push_back(std::move(a));
-				if (al_sf_read(f1, pend.name, pend.seq, pend.qual) >= 0) {
-					if (qname_same(rds.back().name, pend.name)) { bases += pend.seq.size(); rds.push_back(std::move(pend)); pend = Rd(); ns = 2; }
-					else has_pend = true;
-				} else done = true;
-				n_segs.push_back(ns);
-				if (done) break;
-			}
-		}
-		const int nf = (int)n_segs.size(), nr = (int)rds.size();
-		if (nf == 0) break;
-		qlens.resize(nr); seqs.resize(nr); names.resize(nr); n_regs.assign(nr, 0); regs.assign(nr, nullptr); rep_len.assign(nf, 0);
-		for (int i = 0; i < nr; ++i) {
-			for (auto &ch : rds[i].seq) if (ch == 'u' || ch == 'U') --ch;       // bseq.c:72-74
-			qlens[i] = (int)rds[i].seq.size(); seqs[i] = rds[i].seq.c_str(); names[i] = rds[i].name.c_str();
-		}
-		if ((rc = al_map_batch(ctx, nf, n_segs.data(), qlens.data(), seqs.data(), names.data(), n_regs.data(), regs.data(), rep_len.data())) != 0) break;
-		for (int f = 0, i0 = 0; f < nf; i0 += n_segs[f], ++f) {                   // map.c:601-644
-			const int ns = n_segs[f];
-			for (int j = 0; j < ns; ++j) {
-				const int i = i0 + j; const Rd &t = rds[i];
-				size_t need = t.seq.size() * 2 + t.name.size() + 4096;
-				for (int k = 0; k < n_regs[i]; ++k) need += (size_t)regs[i][k].n_cigar * 12 + 128;
-				if (buf.size() < need) buf.resize(need * 2);
-				const char *ql = t.qual.empty() ? nullptr : t.qual.c_str();
-				if (n_regs[i] > 0) {
-					for (int k = 0; k < n_regs[i]; ++k) {
-						const al_reg1_t *r = &regs[i][k];
-						if ((opt->flag & AL_F_NO_PRINT_2ND) && r->id != r->parent) continue;
-						int l = al_write_sam(buf.data(), buf.size(), mi, t.name.c_str(), (int)t.seq.size(), t.seq.c_str(), ql, j, k, ns, &n_regs[i0], (const al_reg1_t *const *)&regs[i0], rg_id, rep_len[f]);
-						if (l > 0) fwrite(buf.data(), 1, l, out);
-					}
-				} else if (!(opt->flag & AL_F_SAM_HIT_ONLY)) {
-					int l = al_write_sam(buf.data(), buf.size(), mi, t.name.c_str(), (int)t.seq.size(), t.seq.c_str(), ql, j, -1, ns, &n_regs[i0], (const al_reg1_t *const *)&regs[i0], rg_id, rep_len[f]);
-					if (l > 0) fwrite(buf.data(), 1, l, out);
-				}
-			}
-		}
-		for (int i = 0; i < nr; ++i) { for (int k = 0; k < n_regs[i]; ++k) free(regs[i][k].cigar); free(regs[i]); }
-	}
-	al_ctx_destroy(ctx);
-	al_sf_close(f1); al_sf_close(f2);
-	fflush(out);
-	return rc;
-}
+// The file-level driver (al_map_file_frag) lives in al_pipeline.cpp.

@@ -1634,38 +1634,52 @@ int al_run_align_stage(al_ctx_t *c)
 	return 0;
 }
 
-int al_fetch_align(al_ctx_t *c, int *n_regs, al_reg1_t **regs, int *rep_len)
-{
+int al_fetch_raw(al_ctx_t *c, AlRawResult &R)
+{   // device -> host copies of the last al_batch_run: per-read record offsets, records, CIGAR arena, repeat lengths
 	AlignState *A = get_state(c);
 	const int nf = c->n_frag, nr = c->n_reads;
 	AL_HIP_CHECK(hipSetDevice(c->device));
 	unsigned long long h[16]; AL_HIP_CHECK(hipMemcpy(h, c->counters.p, sizeof(h), hipMemcpyDeviceToHost));
 	if (h[7] || h[8] || h[9]) { fprintf(stderr, "[airlift] device pipeline error: limit=0x%llx (byte k = site k: 0 prep qlen, 1 prep window, 2 dp window, 3 qlen, 4 split capacity, 5 pair scores, 6 lane cigar, 7 finish pair scores) logf_miss=%llu cigar_arena_overflow=%llu\n", h[7], h[8], h[9]); return -4; }
-	std::vector<uint64_t> off(nr + 1); std::vector<AlReg> out(A->out_total); std::vector<int32_t> rep(nf);
+	R.off.resize(nr + 1); R.out.resize(A->out_total); R.rep.resize(nf); R.flip = c->h_flip; R.rd_len.assign(c->h_rd_len.begin(), c->h_rd_len.begin() + nr);
 	if (nf == 0) return 0;
-	AL_HIP_CHECK(hipMemcpy(off.data(), A->out_off.p, (size_t)(nr + 1) * 8, hipMemcpyDeviceToHost));
-	if (A->out_total) AL_HIP_CHECK(hipMemcpy(out.data(), A->out.p, A->out_total * sizeof(AlReg), hipMemcpyDeviceToHost));
-	AL_HIP_CHECK(hipMemcpy(rep.data(), c->frag_rep.p, (size_t)nf * 4, hipMemcpyDeviceToHost));
+	AL_HIP_CHECK(hipMemcpy(R.off.data(), A->out_off.p, (size_t)(nr + 1) * 8, hipMemcpyDeviceToHost));
+	if (A->out_total) AL_HIP_CHECK(hipMemcpy(R.out.data(), A->out.p, A->out_total * sizeof(AlReg), hipMemcpyDeviceToHost));
+	AL_HIP_CHECK(hipMemcpy(R.rep.data(), c->frag_rep.p, (size_t)nf * 4, hipMemcpyDeviceToHost));
 	const uint64_t n_arena = h[11];
-	std::vector<uint32_t> arena(n_arena);
-	if (n_arena) AL_HIP_CHECK(hipMemcpy(arena.data(), A->arena.p, n_arena * 4, hipMemcpyDeviceToHost));
-	for (int f = 0; f < nf; ++f) if (rep_len) rep_len[f] = rep[f];
+	R.arena.resize(n_arena);
+	if (n_arena) AL_HIP_CHECK(hipMemcpy(R.arena.data(), A->arena.p, n_arena * 4, hipMemcpyDeviceToHost));
+	return 0;
+}
+
+void al_reg_from_raw(const AlRawResult &R, int read, int k, al_reg1_t &q)
+{   // AlReg -> al_reg1_t; q.cigar points into R (inline words or arena): callers that hand ownership out must copy it
+	const AlReg &r = R.out[R.off[read] + k];
+	q.id = r.id; q.cnt = r.cnt; q.rid = r.rid; q.score = r.score; q.qs = r.qs; q.qe = r.qe; q.rs = r.rs; q.re = r.re;
+	q.parent = r.parent; q.subsc = r.subsc; q.mlen = r.mlen; q.blen = r.blen; q.n_sub = r.n_sub; q.score0 = r.score0;
+	q.mapq = r.mapq & 0xff; q.split = r.flags & 3; q.rev = (r.flags & ALR_REV) ? 1 : 0; q.inv = 0; q.sam_pri = (r.flags & ALR_SAM_PRI) ? 1 : 0;
+	q.proper_frag = (r.flags & ALR_PROPER) ? 1 : 0; q.pe_thru = (r.flags & ALR_PE_THRU) ? 1 : 0; q.seg_split = (r.flags & ALR_SEG_SPLIT) ? 1 : 0;
+	q.seg_id = (r.flags >> 8) & 0xff; q.split_inv = 0; q.dummy = 0; q.hash = r.hash; q.dp_score = r.dp_score; q.dp_max = r.dp_max; q.dp_max2 = r.dp_max2; q.n_ambi = r.n_ambi;
+	q.n_cigar = (r.flags & ALR_HAS_P) ? r.n_cigar : 0;
+	q.cigar = q.n_cigar ? const_cast<uint32_t *>(r.cigar_off == AL_CIG_INLINE ? r.cig_inl : R.arena.data() + r.cigar_off) : nullptr;
+	if (R.flip[read]) { const int qlen = (int)R.rd_len[read], t = q.qs; q.qs = qlen - q.qe; q.qe = qlen - t; q.rev = !q.rev; }   // map.c:486-497
+}
+
+int al_fetch_align(al_ctx_t *c, int *n_regs, al_reg1_t **regs, int *rep_len)
+{
+	AlRawResult R;
+	const int rc = al_fetch_raw(c, R);
+	if (rc) return rc;
+	const int nf = c->n_frag, nr = c->n_reads;
+	for (int f = 0; f < nf; ++f) if (rep_len) rep_len[f] = R.rep[f];
 	for (int i = 0; i < nr; ++i) {
-		const int n = (int)(off[i + 1] - off[i]);
+		const int n = (int)(R.off[i + 1] - R.off[i]);
 		n_regs[i] = n; regs[i] = nullptr;
 		if (n == 0) continue;
 		al_reg1_t *o = (al_reg1_t *)calloc(n, sizeof(al_reg1_t));
-		const int qlen = (int)c->h_rd_len[i];
 		for (int k = 0; k < n; ++k) {
-			const AlReg &r = out[off[i] + k]; al_reg1_t &q = o[k];
-			q.id = r.id; q.cnt = r.cnt; q.rid = r.rid; q.score = r.score; q.qs = r.qs; q.qe = r.qe; q.rs = r.rs; q.re = r.re;
-			q.parent = r.parent; q.subsc = r.subsc; q.mlen = r.mlen; q.blen = r.blen; q.n_sub = r.n_sub; q.score0 = r.score0;
-			q.mapq = r.mapq & 0xff; q.split = r.flags & 3; q.rev = (r.flags & ALR_REV) ? 1 : 0; q.inv = 0; q.sam_pri = (r.flags & ALR_SAM_PRI) ? 1 : 0;
-			q.proper_frag = (r.flags & ALR_PROPER) ? 1 : 0; q.pe_thru = (r.flags & ALR_PE_THRU) ? 1 : 0; q.seg_split = (r.flags & ALR_SEG_SPLIT) ? 1 : 0;
-			q.seg_id = (r.flags >> 8) & 0xff; q.split_inv = 0; q.hash = r.hash; q.dp_score = r.dp_score; q.dp_max = r.dp_max; q.dp_max2 = r.dp_max2; q.n_ambi = r.n_ambi;
-			q.n_cigar = (r.flags & ALR_HAS_P) ? r.n_cigar : 0; q.cigar = nullptr;
-			if (q.n_cigar) { q.cigar = (uint32_t *)malloc((size_t)q.n_cigar * 4); memcpy(q.cigar, r.cigar_off == AL_CIG_INLINE ? r.cig_inl : arena.data() + r.cigar_off, (size_t)q.n_cigar * 4); }
-			if (c->h_flip[i]) { const int t = q.qs; q.qs = qlen - q.qe; q.qe = qlen - t; q.rev = !q.rev; }   // map.c:486-497
+			al_reg_from_raw(R, i, k, o[k]);
+			if (o[k].n_cigar) { uint32_t *cg = (uint32_t *)malloc((size_t)o[k].n_cigar * 4); memcpy(cg, o[k].cigar, (size_t)o[k].n_cigar * 4); o[k].cigar = cg; }
 		}
 		regs[i] = o;
 	}

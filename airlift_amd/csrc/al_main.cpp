@@ -9,6 +9,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <string>
 #include <vector>
 #include "../../include/airlift.h"
@@ -64,7 +65,10 @@ int main(int argc, char **argv)
 		if (pos.size() < 2 || pos.size() > 3) return usage();
 		ref = pos[0]; for (size_t j = 1; j < pos.size(); ++j) reads.push_back(pos[j]);
 	}
+	struct timespec ts0, ts1; clock_gettime(CLOCK_MONOTONIC, &ts0);
 	al_idx_t *mi = al_idx_build(ref, &io, n_threads);
+	clock_gettime(CLOCK_MONOTONIC, &ts1);
+	if (getenv("AL_TIMING")) fprintf(stderr, "[airlift] index build %.3f s\n", (ts1.tv_sec - ts0.tv_sec) + 1e-9 * (ts1.tv_nsec - ts0.tv_nsec));
 	if (!mi) { fprintf(stderr, "[ERROR] failed to open file '%s'\n", ref); return 1; }
 	int rc = al_map_file_frag(mi, (int)reads.size(), reads.data(), &mo, n_threads, stdout, rg, device);
 	al_idx_destroy(mi);

@@ -4,6 +4,7 @@
 #include <stdio.h>
 #include <vector>
 #include <string>
+#include <thread>
 #include "al_internal.h"
 
 template <typename T> struct DevBuf {       // grow-only device array
@@ -31,6 +32,7 @@ struct al_ctx_s {
 	al_mapopt_t opt;
 	AlParams P;
 	int device = 0;
+	int n_threads = 1;                    // host worker threads for packing (al_ctx_set_threads)
 	hipStream_t stream = nullptr;
 	AlDevIndex di;
 	hipEvent_t ev[ST_N + 1] = {};
@@ -74,3 +76,24 @@ struct al_ctx_s {
 int al_upload_index(const al_idx_t *mi, int device, AlDevIndex *out);
 int al_run_align_stage(al_ctx_t *c);      // al_kernels_align.hip: KA (regs) + K5 (extension, MAPQ, pairing)
 int al_fetch_align(al_ctx_t *c, int *n_regs, al_reg1_t **regs, int *rep_len);
+
+struct AlRawResult {         // flat host copy of one batch's results (no per-record allocation)
+	std::vector<uint64_t> off;            // per read: first record in out[]; off[n_reads] = total
+	std::vector<AlReg> out;
+	std::vector<uint32_t> arena;          // CIGAR words of records with more than 4 operations
+	std::vector<int32_t> rep;             // per fragment repeat length
+	std::vector<uint8_t> flip;            // read was mapped reverse-complemented
+	std::vector<uint32_t> rd_len;
+};
+int  al_fetch_raw(al_ctx_t *c, AlRawResult &R);
+void al_reg_from_raw(const AlRawResult &R, int read, int k, al_reg1_t &q);
+
+// host worker pool helper: fn(lo, hi, thread) over [0, n) split into contiguous ranges
+template <class F> static inline void al_parallel_for(int n_threads, size_t n, F fn)
+{
+	if (n_threads <= 1 || n < 2) { fn((size_t)0, n, 0); return; }
+	const size_t nt = (size_t)n_threads < n ? (size_t)n_threads : n;
+	std::vector<std::thread> th; th.reserve(nt);
+	for (size_t t = 0; t < nt; ++t) th.emplace_back(fn, n * t / nt, n * (t + 1) / nt, (int)t);
+	for (auto &x : th) x.join();
+}

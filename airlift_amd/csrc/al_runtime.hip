@@ -117,6 +117,8 @@ static uint32_t qname_hash(const char *qname, int qlen_sum, int seed)
 	return wang_hash(h);
 }
 
+extern "C" void al_ctx_set_threads(al_ctx_t *c, int n_threads) { if (c) c->n_threads = n_threads > 1 ? n_threads : 1; }
+
 extern "C" int al_batch_upload(al_ctx_t *c, int n_frag, const int *n_segs, const int *qlens, const char *const *seqs, const char *const *qnames)
 {
 	if (!c || n_frag < 0) return -1;
@@ -128,6 +130,7 @@ extern "C" int al_batch_upload(al_ctx_t *c, int n_frag, const int *n_segs, const
 	c->h_rd_len.resize(n_reads + 1); c->h_rd_off.resize(n_reads + 1); c->h_mini_off.resize(n_reads + 1); c->h_flip.assign(n_reads, 0);
 	c->h_frag_first.resize(n_frag + 1); c->h_frag_hash.resize(n_frag + 1);
 	uint64_t words = 0, mtot = 0, bases = 0; int r = 0;
+	std::vector<int> qsums(n_frag);
 	const int k = c->mi->k, pe_ori = c->opt.pe_ori;
 	for (int f = 0; f < n_frag; ++f) {
 		c->h_frag_first[f] = r; int qsum = 0;
@@ -137,17 +140,26 @@ extern "C" int al_batch_upload(al_ctx_t *c, int n_frag, const int *n_segs, const
 			words += (uint64_t)(L + 7) / 8 + 1; mtot += (uint64_t)(L >= k ? L - k + 1 : 0) + 1; bases += L; qsum += L;
 			if (n_segs[f] == 2 && ((j == 0 && (pe_ori >> 1 & 1)) || (j == 1 && (pe_ori & 1)))) c->h_flip[r] = 1;
 		}
-		c->h_frag_hash[f] = qname_hash(qnames ? qnames[c->h_frag_first[f]] : nullptr, qsum, c->opt.seed);
+		qsums[f] = qsum;
 	}
+	al_parallel_for(c->n_threads, (size_t)n_frag, [&](size_t lo, size_t hi, int) {
+		for (size_t f = lo; f < hi; ++f) c->h_frag_hash[f] = qname_hash(qnames ? qnames[c->h_frag_first[f]] : nullptr, qsums[f], c->opt.seed);
+	});
 	c->h_frag_first[n_frag] = r; c->h_rd_off[n_reads] = words; c->h_mini_off[n_reads] = mtot; c->h_rd_len[n_reads] = 0;
 	c->n_bases = bases; c->mini_total = mtot; c->seq_words = words;
 	{ uint64_t b = 0; for (int i = 0; i < n_reads; ++i) b += (c->h_rd_len[i] * 3 + 7) / 8; c->stat_bytes_in = b; }   // 2-bit base + 1-bit N mask (SURVEY 8d B_in)
-	c->h_rd_seq.assign(words + 1, 0);
-	for (int i = 0; i < n_reads; ++i) {     // 4-bit packing in mapping orientation (mate 2 reverse-complemented: map.c:468, bseq.h:46-58)
-		uint32_t *w = c->h_rd_seq.data() + c->h_rd_off[i]; const char *s = seqs[i]; const int L = qlens[i];
-		if (!c->h_flip[i]) for (int j = 0; j < L; ++j) w[j >> 3] |= (uint32_t)nt4[(unsigned char)s[j]] << ((j & 7) << 2);
-		else for (int j = 0; j < L; ++j) { const unsigned cd = nt4[(unsigned char)s[L - 1 - j]]; w[j >> 3] |= (uint32_t)(cd < 4 ? 3 - cd : 4) << ((j & 7) << 2); }
-	}
+	c->h_rd_seq.resize(words + 1); c->h_rd_seq[words] = 0;
+	al_parallel_for(c->n_threads, (size_t)n_reads, [&](size_t lo, size_t hi, int) {   // 4-bit packing in mapping orientation (mate 2 reverse-complemented: map.c:468, bseq.h:46-58)
+		for (size_t i = lo; i < hi; ++i) {
+			uint32_t *w = c->h_rd_seq.data() + c->h_rd_off[i]; const char *s = seqs[i]; const int L = qlens[i], nw = (L + 7) / 8 + 1;
+			for (int b = 0; b < nw; ++b) {
+				uint32_t v = 0; const int j0 = b * 8, j1 = j0 + 8 < L ? j0 + 8 : L;
+				if (!c->h_flip[i]) for (int j = j0; j < j1; ++j) v |= (uint32_t)nt4[(unsigned char)s[j]] << ((j & 7) << 2);
+				else for (int j = j0; j < j1; ++j) { const unsigned cd = nt4[(unsigned char)s[L - 1 - j]]; v |= (uint32_t)(cd < 4 ? 3 - cd : 4) << ((j & 7) << 2); }
+				w[b] = v;
+			}
+		}
+	});
 	hipStream_t s = c->stream;
 	if (c->rd_seq.ensure(words + 1) || c->rd_off.ensure(n_reads + 1) || c->rd_len.ensure(n_reads + 1) || c->frag_first.ensure(n_frag + 1) || c->frag_hash.ensure(n_frag + 1) ||
 	    c->mini_off.ensure(n_reads + 1) || c->mini.ensure(mtot + 1) || c->mini_cnt.ensure(n_reads + 1) || c->match.ensure(mtot + 1) || c->heap_ws.ensure(mtot + 1) ||

@@ -104,6 +104,9 @@ void      al_idx_stat(const al_idx_t *mi, uint64_t *n_keys, uint64_t *n_pos, uin
  * Uploads the index to that device's HBM on first use.  NULL (with a message) if HIP is unusable. */
 al_ctx_t *al_ctx_init(const al_idx_t *mi, const al_mapopt_t *opt, int device);
 void      al_ctx_destroy(al_ctx_t *ctx);
+/* host worker threads this context may use for packing a batch before upload (default 1); the analogue of the
+ * n_threads argument of mm_map_file_frag for callers that drive batches themselves */
+void      al_ctx_set_threads(al_ctx_t *ctx, int n_threads);
 
 /* mm_map_frag (minimap.h:334): one fragment of n_segs (1 or 2) reads, reads given in sequencing
  * orientation; output identical in meaning to the reference incl. the FR flip of worker_for (map.c:458-498). */

@@ -11,7 +11,7 @@ g.write_fastq("$D/r_1.fq", r1, "realigned_"); g.write_fastq("$D/r_2.fq", r2, "re
 PY
 cd $D
 for t in 1 ${THREADS:-16}; do
-  TIMEFORMAT="airlift-align -t $t: %R s wall, %U s user ($PAIRS pairs)"; time $REPO/airlift_amd/bin/airlift-align -ax sr -t $t ref.fa r_1.fq r_2.fq > out_gpu.sam 2> err_gpu.txt
+  TIMEFORMAT="airlift-align -t $t: %R s wall, %U s user ($PAIRS pairs)"; time AL_TIMING=1 $REPO/airlift_amd/bin/airlift-align -ax sr -t $t ref.fa r_1.fq r_2.fq > out_gpu.sam 2> err_gpu.txt; grep airlift err_gpu.txt
 done
 if [ -x $REPO/oracle/_ref/mm2ref ]; then
   TIMEFORMAT="mm2ref -t $(nproc): %R s wall, %U s user"; time $REPO/oracle/_ref/mm2ref -t $(nproc) ref.fa r_1.fq r_2.fq > out_cpu.sam 2> err_cpu.txt
