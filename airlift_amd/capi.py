@@ -78,6 +78,9 @@ def load():
     L.al_set_opt.argtypes = [cs, C.POINTER(IdxOpt), C.POINTER(MapOpt)]; L.al_set_opt.restype = ci
     L.al_check_opt.argtypes = [C.POINTER(IdxOpt), C.POINTER(MapOpt)]; L.al_check_opt.restype = ci
     L.al_idx_build.argtypes = [cs, C.POINTER(IdxOpt), ci]; L.al_idx_build.restype = vp
+    L.al_idx_build_device.argtypes = [cs, C.POINTER(IdxOpt), ci]; L.al_idx_build_device.restype = vp
+    L.al_idx_export_pos.argtypes = [vp, vp, C.c_int64]; L.al_idx_export_pos.restype = C.c_int64
+    L.al_ctx_set_threads.argtypes = [vp, ci]; L.al_ctx_set_threads.restype = None
     L.al_idx_str.argtypes = [ci, ci, ci, C.POINTER(cs), C.POINTER(cs)]; L.al_idx_str.restype = vp
     L.al_idx_destroy.argtypes = [vp]; L.al_idx_destroy.restype = None
     L.al_idx_n_seq.argtypes = [vp]; L.al_idx_n_seq.restype = C.c_uint32
@@ -129,14 +132,16 @@ def read_fastx(path):
 class Index:
     """al_idx_t (replaces mm_idx_t)."""
 
-    def __init__(self, fasta=None, seqs=None, names=None, preset="sr", n_threads=4):
+    def __init__(self, fasta=None, seqs=None, names=None, preset="sr", n_threads=4, on_device=None):
         L = load()
         self.io, self.mo = IdxOpt(), MapOpt()
         L.al_set_opt(None, C.byref(self.io), C.byref(self.mo))
         if L.al_set_opt(preset.encode(), C.byref(self.io), C.byref(self.mo)) != 0:
             raise AirliftError("unknown preset " + preset)
         self.mo.flag |= 0x004 | 0x008
-        if fasta is not None:
+        if fasta is not None and on_device is not None:     # sketch + sort + table built by kernels on that GPU
+            self.h = L.al_idx_build_device(fasta.encode(), C.byref(self.io), on_device)
+        elif fasta is not None:
             self.h = L.al_idx_build(fasta.encode(), C.byref(self.io), n_threads)
         else:
             n = len(seqs)
@@ -154,6 +159,14 @@ class Index:
         a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
         load().al_idx_stat(self.h, C.byref(a), C.byref(b), C.byref(c))
         return {"n_keys": a.value, "n_pos": b.value, "n_bases": c.value}
+
+    def positions(self):
+        """The occurrence array (grouped by minimizer hash ascending, positions ascending inside a group)."""
+        n = load().al_idx_export_pos(self.h, None, 0)
+        out = np.zeros(max(n, 0), dtype=np.uint64)
+        if n > 0 and load().al_idx_export_pos(self.h, out.ctypes.data_as(C.c_void_p), n) != n:
+            raise AirliftError("al_idx_export_pos failed")
+        return out
 
     def close(self):
         if self.h:

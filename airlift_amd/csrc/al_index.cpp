@@ -192,7 +192,7 @@ static al_idx_t *idx_from_codes(int w, int k, std::vector<AlSeq> &&seqs, std::ve
 	for (size_t i = 0; i < n; ++i) { for (size_t j = 0; j < hx[i].size(); ++j) all.push_back(P{hx[i][j], hy[i][j]}); std::vector<uint64_t>().swap(hx[i]); std::vector<uint64_t>().swap(hy[i]); }
 	std::sort(all.begin(), all.end(), [](const P &a, const P &b) { return a.h < b.h || (a.h == b.h && a.y < b.y); });
 	uint64_t nk = 0; for (size_t i = 0; i < tot; ++i) if (i == 0 || all[i].h != all[i-1].h) ++nk;
-	mi->n_keys = nk;
+	mi->n_keys = nk; mi->n_pos = tot;
 	int bits = 4; while ((1ULL<<bits) < nk * 2 + 2) ++bits;
 	mi->tab_bits = bits;
 	mi->tab.assign((size_t)2 << bits, 0);
@@ -243,6 +243,6 @@ extern "C" const char *al_idx_seq_name(const al_idx_t *mi, uint32_t rid) { retur
 extern "C" uint32_t al_idx_seq_len(const al_idx_t *mi, uint32_t rid) { return rid < mi->seq.size()? mi->seq[rid].len : 0; }
 extern "C" void al_idx_stat(const al_idx_t *mi, uint64_t *n_keys, uint64_t *n_pos, uint64_t *n_bases)
 {
-	if (n_keys) *n_keys = mi->n_keys; if (n_pos) *n_pos = mi->pos.size(); if (n_bases) *n_bases = mi->tot_len;
+	if (n_keys) *n_keys = mi->n_keys; if (n_pos) *n_pos = mi->n_pos; if (n_bases) *n_bases = mi->tot_len;
 }
 extern "C" const char *al_version(void) { return AL_VERSION; }

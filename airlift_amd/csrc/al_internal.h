@@ -43,7 +43,8 @@ struct al_idx_s {
 	int tab_bits = 4;
 	std::vector<uint64_t> tab;
 	std::vector<uint64_t> pos;
-	uint64_t n_keys = 0;
+	uint64_t n_keys = 0, n_pos = 0;
+	int built_on = -1;                       // >= 0: built by al_idx_build_device on that GPU; the host arrays above stay empty
 	mutable std::mutex dev_mtx;
 	mutable std::map<int, AlDevIndex> dev;   // lazily uploaded per device
 };

@@ -1641,13 +1641,14 @@ int al_fetch_raw(al_ctx_t *c, AlRawResult &R)
 	AL_HIP_CHECK(hipSetDevice(c->device));
 	unsigned long long h[16]; AL_HIP_CHECK(hipMemcpy(h, c->counters.p, sizeof(h), hipMemcpyDeviceToHost));
 	if (h[7] || h[8] || h[9]) { fprintf(stderr, "[airlift] device pipeline error: limit=0x%llx (byte k = site k: 0 prep qlen, 1 prep window, 2 dp window, 3 qlen, 4 split capacity, 5 pair scores, 6 lane cigar, 7 finish pair scores) logf_miss=%llu cigar_arena_overflow=%llu\n", h[7], h[8], h[9]); return -4; }
-	R.off.resize(nr + 1); R.out.resize(A->out_total); R.rep.resize(nf); R.flip = c->h_flip; R.rd_len.assign(c->h_rd_len.begin(), c->h_rd_len.begin() + nr);
+	if (R.off.resize(nr + 1) || R.out.resize(A->out_total) || R.rep.resize(nf)) return -1;
+	R.flip = c->h_flip; R.rd_len.assign(c->h_rd_len.begin(), c->h_rd_len.begin() + nr);
 	if (nf == 0) return 0;
 	AL_HIP_CHECK(hipMemcpy(R.off.data(), A->out_off.p, (size_t)(nr + 1) * 8, hipMemcpyDeviceToHost));
 	if (A->out_total) AL_HIP_CHECK(hipMemcpy(R.out.data(), A->out.p, A->out_total * sizeof(AlReg), hipMemcpyDeviceToHost));
 	AL_HIP_CHECK(hipMemcpy(R.rep.data(), c->frag_rep.p, (size_t)nf * 4, hipMemcpyDeviceToHost));
 	const uint64_t n_arena = h[11];
-	R.arena.resize(n_arena);
+	if (R.arena.resize(n_arena)) return -1;
 	if (n_arena) AL_HIP_CHECK(hipMemcpy(R.arena.data(), A->arena.p, n_arena * 4, hipMemcpyDeviceToHost));
 	return 0;
 }

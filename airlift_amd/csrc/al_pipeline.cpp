@@ -24,82 +24,13 @@
 #include "al_internal.h"
 #include "al_runtime.h"
 #include "al_io.h"
+#include "al_seqio.h"
 
 extern "C" void al_ctx_set_threads(al_ctx_t *c, int n_threads);
 
 namespace {
 
 inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-
-struct Rec { uint32_t name, seq, len, qual; };            // offsets into Chunk::text; name NUL-terminated; qual = ~0u when absent
-struct Chunk { std::vector<char> text; std::vector<Rec> recs; };
-
-// kseq.h record grammar (FASTA/FASTQ, multi-line, optional gzip) on a block buffer; newline search by memchr.
-class SeqReader {
-	gzFile fp = nullptr; std::vector<unsigned char> buf; size_t beg = 0, end = 0; bool eof = false; int last = 0;
-	bool fill()
-	{
-		if (eof) return false;
-		beg = 0; const int n = gzread(fp, buf.data(), (unsigned)buf.size());
-		if (n <= 0) { eof = true; end = 0; return false; }
-		end = (size_t)n; return true;
-	}
-	int getc() { if (beg >= end && !fill()) return -1; return buf[beg++]; }
-	// rest of the current line (without the terminator; one trailing '\r' dropped) appended to t.  -1: EOF before any byte.
-	int line_append(std::vector<char> &t)
-	{
-		bool got = false;
-		for (;;) {
-			if (beg >= end && !fill()) break;
-			got = true;
-			const unsigned char *nl = (const unsigned char *)memchr(buf.data() + beg, '\n', end - beg);
-			const size_t stop = nl ? (size_t)(nl - buf.data()) : end;
-			t.insert(t.end(), (const char *)buf.data() + beg, (const char *)buf.data() + stop);
-			beg = nl ? stop + 1 : stop;
-			if (nl) { if (!t.empty() && t.back() == '\r') t.pop_back(); return 0; }
-		}
-		return got ? 0 : -1;
-	}
-public:
-	bool open(const char *fn)
-	{
-		fp = strcmp(fn, "-") == 0 ? gzdopen(0, "r") : gzopen(fn, "r");
-		if (!fp) return false;
-		gzbuffer(fp, 1 << 20); buf.resize(4 << 20);
-		return true;
-	}
-	~SeqReader() { if (fp) gzclose(fp); }
-	// one record appended to c; false at end of input (a FASTQ record whose quality length differs ends the input, kseq.h -2)
-	bool read(Chunk &c)
-	{
-		int ch;
-		if (last == 0) { while ((ch = getc()) >= 0 && ch != '>' && ch != '@'); if (ch < 0) return false; last = ch; }
-		std::vector<char> &t = c.text; const size_t mark = t.size();
-		Rec r; r.name = (uint32_t)t.size();
-		while ((ch = getc()) >= 0 && ch != ' ' && ch != '\t' && ch != '\n' && ch != '\r' && ch != '\v' && ch != '\f') t.push_back((char)ch);
-		if (ch < 0 && t.size() == mark) return false;
-		t.push_back(0);
-		if (ch >= 0 && ch != '\n') { const size_t m2 = t.size(); line_append(t); t.resize(m2); }    // comment: dropped (no -y)
-		r.seq = (uint32_t)t.size();
-		while ((ch = getc()) >= 0 && ch != '>' && ch != '+' && ch != '@') {
-			if (ch == '\n') continue;
-			t.push_back((char)ch); line_append(t);
-		}
-		r.len = (uint32_t)(t.size() - r.seq); r.qual = ~0u;
-		for (size_t i = r.seq; i < t.size(); ++i) if (t[i] == 'u' || t[i] == 'U') --t[i];      // bseq.c:72-74
-		last = (ch == '>' || ch == '@') ? ch : 0;
-		if (ch == '+') {
-			while ((ch = getc()) >= 0 && ch != '\n');
-			if (ch < 0) { t.resize(mark); return false; }
-			r.qual = (uint32_t)t.size();
-			while (line_append(t) >= 0 && t.size() - r.qual < r.len);
-			last = 0;
-			if (t.size() - r.qual != r.len) { t.resize(mark); return false; }
-		}
-		c.recs.push_back(r);
-		return true;
-	}
-};
 
 template <class T> class Queue {
 	std::mutex m; std::condition_variable cv; std::deque<T> q; size_t cap; bool closed = false;
@@ -111,16 +42,16 @@ public:
 	void abort() { { std::lock_guard<std::mutex> l(m); closed = true; q.clear(); } cv.notify_all(); }
 };
 
-typedef std::unique_ptr<Chunk> ChunkP;
+typedef std::unique_ptr<AlChunk> ChunkP;
 const size_t CHUNK_READS = 1 << 15;
 
 struct Batch {
 	std::vector<ChunkP> chunks;                       // own the text the pointers below refer to
 	std::vector<int> n_segs, qlens;
 	std::vector<const char *> seqs, names, quals;     // per read, fragment-major
-	AlRawResult R;
+	std::unique_ptr<AlRawResult> R;                   // from the driver's pool of page-locked result buffers
 	int64_t bases = 0;
-	void add_read(const Chunk &c, const Rec &r) { seqs.push_back(c.text.data() + r.seq); names.push_back(c.text.data() + r.name); quals.push_back(r.qual == ~0u ? nullptr : c.text.data() + r.qual); qlens.push_back((int)r.len); bases += r.len; }
+	void add_read(const AlChunk &c, const AlRec &r) { seqs.push_back(c.text.data() + r.seq); names.push_back(c.text.data() + r.name); quals.push_back(r.qual == ~0u ? nullptr : c.text.data() + r.qual); qlens.push_back((int)r.len); bases += r.len; }
 };
 typedef std::unique_ptr<Batch> BatchP;
 
@@ -131,10 +62,10 @@ inline int qname_len(const char *s)
 }
 inline bool qname_same(const char *a, const char *b) { const int l1 = qname_len(a), l2 = qname_len(b); return l1 == l2 && strncmp(a, b, l1) == 0; }
 
-void reader_main(SeqReader *rd, Queue<ChunkP> *q)
+void reader_main(AlSeqReader *rd, Queue<ChunkP> *q)
 {
 	for (;;) {
-		ChunkP c(new Chunk()); c->text.reserve(CHUNK_READS * 340); c->recs.reserve(CHUNK_READS);
+		ChunkP c(new AlChunk()); c->text.reserve(CHUNK_READS * 340); c->recs.reserve(CHUNK_READS);
 		while (c->recs.size() < CHUNK_READS && rd->read(*c));
 		const bool last = c->recs.size() < CHUNK_READS;
 		if (!c->recs.empty()) q->push(std::move(c));
@@ -148,7 +79,7 @@ struct WriterState { const al_idx_t *mi; const al_mapopt_t *opt; FILE *out; cons
 void write_batch(WriterState &W, Batch &b)
 {
 	const int nf = (int)b.n_segs.size(), nr = (int)b.seqs.size();
-	const AlRawResult &R = b.R;
+	const AlRawResult &R = *b.R;
 	const double t0 = now_s();
 	std::vector<al_reg1_t> pool(R.out.size()); std::vector<const al_reg1_t *> regs(nr); std::vector<int> n_regs(nr); std::vector<int> first(nf + 1);
 	{ int r = 0; for (int f = 0; f < nf; ++f) { first[f] = r; r += b.n_segs[f]; } first[nf] = r; }
@@ -203,7 +134,7 @@ extern "C" int al_map_file_frag(const al_idx_t *mi, int n_fn, const char **fn, c
 {
 	if (n_fn < 1 || n_fn > 2) return -1;
 	if (n_threads < 1) n_threads = 1;
-	SeqReader rd[2];
+	AlSeqReader rd[2];
 	for (int i = 0; i < n_fn; ++i)
 		if (!rd[i].open(fn[i])) { fprintf(stderr, "ERROR: failed to open file '%s'\n", fn[i]); return -1; }
 	Queue<ChunkP> cq[2] = { Queue<ChunkP>(8), Queue<ChunkP>(8) };
@@ -222,7 +153,15 @@ extern "C" int al_map_file_frag(const al_idx_t *mi, int n_fn, const char **fn, c
 
 	Queue<BatchP> wq(2);
 	WriterState W{mi, opt, out, rg_id, n_threads};
-	std::thread writer([&]() { BatchP b; while (wq.pop(b)) { if (W.rc == 0) write_batch(W, *b); b.reset(); } });
+	std::mutex pool_m; std::vector<std::unique_ptr<AlRawResult>> pool;
+	std::thread writer([&]() {
+		BatchP b;
+		while (wq.pop(b)) {
+			if (W.rc == 0) write_batch(W, *b);
+			{ std::lock_guard<std::mutex> l(pool_m); pool.push_back(std::move(b->R)); }
+			b.reset();
+		}
+	});
 
 	const int64_t batch_bases = opt->mini_batch_size > 0 ? (int64_t)opt->mini_batch_size : 50000000;
 	int rc = 0; bool done = false;
@@ -243,19 +182,19 @@ extern "C" int al_map_file_frag(const al_idx_t *mi, int n_fn, const char **fn, c
 				if (done) break;
 			}
 		} else {   // one file: adjacent reads with the same name form a fragment (frag_mode, map.c:580-586)
-			std::vector<std::pair<const Chunk *, const Rec *>> rs;
+			std::vector<std::pair<const AlChunk *, const AlRec *>> rs;
 			if (carry) { rs.emplace_back(carry.get(), &carry->recs[0]); b->bases += carry->recs[0].len; b->chunks.push_back(std::move(carry)); }
 			while (b->bases < batch_bases) {
 				ChunkP a;
 				if (!cq[0].pop(a)) { done = true; break; }
-				for (const Rec &r : a->recs) { rs.emplace_back(a.get(), &r); b->bases += r.len; }
+				for (const AlRec &r : a->recs) { rs.emplace_back(a.get(), &r); b->bases += r.len; }
 				b->chunks.push_back(std::move(a));
 			}
 			b->bases = 0;
 			size_t n = rs.size();
 			if (!done && n > 0) {                      // hold the last read back: its mate may open the next batch
-				--n; carry.reset(new Chunk());
-				const Chunk &c0 = *rs[n].first; const Rec &r0 = *rs[n].second; Rec r; r.name = 0;
+				--n; carry.reset(new AlChunk());
+				const AlChunk &c0 = *rs[n].first; const AlRec &r0 = *rs[n].second; AlRec r; r.name = 0;
 				carry->text.insert(carry->text.end(), c0.text.data() + r0.name, c0.text.data() + r0.name + strlen(c0.text.data() + r0.name) + 1);
 				r.seq = (uint32_t)carry->text.size(); r.len = r0.len; carry->text.insert(carry->text.end(), c0.text.data() + r0.seq, c0.text.data() + r0.seq + r0.len);
 				r.qual = ~0u; if (r0.qual != ~0u) { r.qual = (uint32_t)carry->text.size(); carry->text.insert(carry->text.end(), c0.text.data() + r0.qual, c0.text.data() + r0.qual + r0.len); }
@@ -275,7 +214,9 @@ extern "C" int al_map_file_frag(const al_idx_t *mi, int n_fn, const char **fn, c
 		const double tc = now_s();
 		if ((rc = al_batch_run(ctx)) != 0) break;
 		const double td = now_s();
-		if ((rc = al_fetch_raw(ctx, b->R)) != 0) break;
+		{ std::lock_guard<std::mutex> l(pool_m); if (!pool.empty()) { b->R = std::move(pool.back()); pool.pop_back(); } }
+		if (!b->R) b->R.reset(new AlRawResult());
+		if ((rc = al_fetch_raw(ctx, *b->R)) != 0) break;
 		const double te = now_s();
 		wq.push(std::move(b));
 		t_asm += tb - ta; t_up += tc - tb; t_run += td - tc; t_fetch += te - td; t_push += now_s() - te; ++n_batch;

@@ -77,11 +77,32 @@ int al_upload_index(const al_idx_t *mi, int device, AlDevIndex *out);
 int al_run_align_stage(al_ctx_t *c);      // al_kernels_align.hip: KA (regs) + K5 (extension, MAPQ, pairing)
 int al_fetch_align(al_ctx_t *c, int *n_regs, al_reg1_t **regs, int *rep_len);
 
-struct AlRawResult {         // flat host copy of one batch's results (no per-record allocation)
-	std::vector<uint64_t> off;            // per read: first record in out[]; off[n_reads] = total
-	std::vector<AlReg> out;
-	std::vector<uint32_t> arena;          // CIGAR words of records with more than 4 operations
-	std::vector<int32_t> rep;             // per fragment repeat length
+template <typename T> struct PinnedVec {    // grow-only page-locked host array (fast, asynchronous-capable D2H target)
+	T *p = nullptr; size_t n = 0, cap = 0;
+	PinnedVec() {}
+	PinnedVec(const PinnedVec &) = delete; PinnedVec &operator=(const PinnedVec &) = delete;
+	~PinnedVec() { if (p) (void)hipHostFree(p); }
+	int resize(size_t m)
+	{
+		if (m > cap) {
+			const size_t ncap = m + m / 4 + 1024;
+			T *np = nullptr;
+			if (hipHostMalloc((void **)&np, ncap * sizeof(T), hipHostMallocDefault) != hipSuccess) { fprintf(stderr, "[airlift] hipHostMalloc of %zu bytes failed\n", ncap * sizeof(T)); return -1; }
+			if (p) (void)hipHostFree(p);
+			p = np; cap = ncap;
+		}
+		n = m; return 0;
+	}
+	T *data() { return p; } const T *data() const { return p; }
+	size_t size() const { return n; }
+	T &operator[](size_t i) { return p[i]; } const T &operator[](size_t i) const { return p[i]; }
+};
+
+struct AlRawResult {         // flat host copy of one batch's results (no per-record allocation); reusable across batches
+	PinnedVec<uint64_t> off;              // per read: first record in out[]; off[n_reads] = total
+	PinnedVec<AlReg> out;
+	PinnedVec<uint32_t> arena;            // CIGAR words of records with more than 4 operations
+	PinnedVec<int32_t> rep;               // per fragment repeat length
 	std::vector<uint8_t> flip;            // read was mapped reverse-complemented
 	std::vector<uint32_t> rd_len;
 };

@@ -32,18 +32,27 @@ int al_upload_index(const al_idx_t *mi, int device, AlDevIndex *out)
 	if (it != mi->dev.end()) { *out = it->second; return 0; }
 	AlDevIndex d;
 	AL_HIP_CHECK(hipSetDevice(device));
-	AL_HIP_CHECK(hipMalloc((void **)&d.S4, mi->S4.size() * 4));
-	AL_HIP_CHECK(hipMemcpy(d.S4, mi->S4.data(), mi->S4.size() * 4, hipMemcpyHostToDevice));
-	AL_HIP_CHECK(hipMalloc((void **)&d.tab, mi->tab.size() * 8));
-	AL_HIP_CHECK(hipMemcpy(d.tab, mi->tab.data(), mi->tab.size() * 8, hipMemcpyHostToDevice));
-	AL_HIP_CHECK(hipMalloc((void **)&d.pos, mi->pos.size() * 8));
-	AL_HIP_CHECK(hipMemcpy(d.pos, mi->pos.data(), mi->pos.size() * 8, hipMemcpyHostToDevice));
 	std::vector<uint64_t> so(mi->seq.size()); std::vector<uint32_t> sl(mi->seq.size());
 	for (size_t i = 0; i < mi->seq.size(); ++i) so[i] = mi->seq[i].offset, sl[i] = mi->seq[i].len;
 	AL_HIP_CHECK(hipMalloc((void **)&d.seq_off, so.size() * 8));
 	AL_HIP_CHECK(hipMemcpy(d.seq_off, so.data(), so.size() * 8, hipMemcpyHostToDevice));
 	AL_HIP_CHECK(hipMalloc((void **)&d.seq_len, sl.size() * 4));
 	AL_HIP_CHECK(hipMemcpy(d.seq_len, sl.data(), sl.size() * 4, hipMemcpyHostToDevice));
+	if (mi->built_on >= 0) {                     // index lives on another GPU only: device-to-device copy over xGMI
+		auto src = mi->dev.find(mi->built_on);
+		if (src == mi->dev.end()) { fprintf(stderr, "[airlift] index was built on device %d but is no longer resident there\n", mi->built_on); return -1; }
+		const size_t nS4 = ((mi->tot_len + 7) / 8 + 8) * 4, nTab = ((size_t)2 << mi->tab_bits) * 8, nPos = (mi->n_pos ? mi->n_pos : 1) * 8;
+		AL_HIP_CHECK(hipMalloc((void **)&d.S4, nS4)); AL_HIP_CHECK(hipMemcpyPeer(d.S4, device, src->second.S4, mi->built_on, nS4));
+		AL_HIP_CHECK(hipMalloc((void **)&d.tab, nTab)); AL_HIP_CHECK(hipMemcpyPeer(d.tab, device, src->second.tab, mi->built_on, nTab));
+		AL_HIP_CHECK(hipMalloc((void **)&d.pos, nPos)); AL_HIP_CHECK(hipMemcpyPeer(d.pos, device, src->second.pos, mi->built_on, nPos));
+	} else {
+		AL_HIP_CHECK(hipMalloc((void **)&d.S4, mi->S4.size() * 4));
+		AL_HIP_CHECK(hipMemcpy(d.S4, mi->S4.data(), mi->S4.size() * 4, hipMemcpyHostToDevice));
+		AL_HIP_CHECK(hipMalloc((void **)&d.tab, mi->tab.size() * 8));
+		AL_HIP_CHECK(hipMemcpy(d.tab, mi->tab.data(), mi->tab.size() * 8, hipMemcpyHostToDevice));
+		AL_HIP_CHECK(hipMalloc((void **)&d.pos, mi->pos.size() * 8));
+		AL_HIP_CHECK(hipMemcpy(d.pos, mi->pos.data(), mi->pos.size() * 8, hipMemcpyHostToDevice));
+	}
 	d.tab_bits = mi->tab_bits; d.n_seq = (uint32_t)mi->seq.size();
 	mi->dev[device] = d; *out = d;
 	return 0;

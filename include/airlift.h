@@ -90,6 +90,10 @@ int  al_check_opt(const al_idxopt_t *io, const al_mapopt_t *mo);
 
 /* mm_idx_reader_open + mm_idx_reader_read (minimap.h:206-232) for a FASTA(.gz) file: NULL on failure */
 al_idx_t *al_idx_build(const char *fn, const al_idxopt_t *io, int n_threads);
+/* Same index, built on the GPU (sketch, sort and table construction as kernels; the host only parses the FASTA): the
+ * index stays resident on `device` (< 0: LOCAL_RANK or 0) and is copied device-to-device if a context on another GPU
+ * asks for it.  Needs odd k.  NULL (with a message) if HIP is unusable -- there is no host path behind this entry point. */
+al_idx_t *al_idx_build_device(const char *fn, const al_idxopt_t *io, int device);
 /* mm_idx_str (minimap.h:269) */
 al_idx_t *al_idx_str(int w, int k, int n, const char **seq, const char **name);
 /* mm_idx_destroy (minimap.h:291) */
@@ -99,6 +103,9 @@ const char *al_idx_seq_name(const al_idx_t *mi, uint32_t rid);
 uint32_t  al_idx_seq_len(const al_idx_t *mi, uint32_t rid);
 /* mm_idx_stat-like numbers: distinct minimizers, total positions, total bases */
 void      al_idx_stat(const al_idx_t *mi, uint64_t *n_keys, uint64_t *n_pos, uint64_t *n_bases);
+/* the occurrence array (all positions, grouped by minimizer hash ascending, ascending inside a group): returns the
+ * number of entries and copies up to cap of them; for tests that compare the two builders */
+int64_t   al_idx_export_pos(const al_idx_t *mi, uint64_t *dst, int64_t cap);
 
 /* mm_tbuf_init / mm_tbuf_destroy (minimap.h:303,310).  device < 0: use LOCAL_RANK or 0.
  * Uploads the index to that device's HBM on first use.  NULL (with a message) if HIP is unusable. */

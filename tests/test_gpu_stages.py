@@ -109,3 +109,51 @@ def test_alser_count(A, golden_unpacked, name):
     ctx.run()
     assert ctx.alser_count() == m["count"]
     ctx.close(); idx.close()
+
+
+def _same_index(A, fasta, n_segs=None, seqs=None, names=None):
+    host = A.Index(fasta=fasta)
+    dev = A.Index(fasta=fasta, on_device=0)
+    assert host.names == dev.names
+    assert host.stat() == dev.stat()
+    assert np.array_equal(host.positions(), dev.positions()), "occurrence arrays differ"
+    if seqs:   # and the table answers the same: anchors of a mapped batch are identical
+        taps = []
+        for idx in (host, dev):
+            ctx = A.Context(idx); ctx.upload(n_segs, seqs, names); ctx.run()
+            na = ctx.tap("frag_na", np.uint32, len(n_segs)); off = ctx.tap("a_off", np.uint64, len(n_segs) + 1)
+            taps.append((na.copy(), ctx.tap("anchors", np.uint64, int(off[-1]) * 2).copy()))
+            ctx.close()
+        assert np.array_equal(taps[0][0], taps[1][0]) and np.array_equal(taps[0][1], taps[1][1])
+    host.close(); dev.close()
+
+
+@pytest.mark.parametrize("name", ["g1_mt150pe", "g3_adversarial", "g4_q_inv", "g6_repeats"])
+def test_device_built_index_equals_host_index(A, golden_unpacked, name):
+    d = golden_unpacked[name]
+    m, n_segs, seqs, names, quals = load_fragments(d)
+    if max(len(x) for x in seqs) > 512:   # long queries are outside this path: compare the index only
+        n_segs = seqs = names = None
+    _same_index(A, os.path.join(d, m["ref"]), n_segs, seqs, names)
+
+
+def test_device_built_index_ragged_contigs(A, tmp_path):
+    """Contigs shorter than k, shorter than one window, exactly on segment boundaries, with N runs, lower case and IUPAC codes."""
+    rng = np.random.default_rng(99)
+    lens = [0, 5, 20, 21, 22, 31, 32, 33, 255, 256, 257, 511, 512, 513, 1000, 4096, 70000]
+    fa = tmp_path / "ragged.fa"
+    with open(fa, "wb") as f:
+        for i, L in enumerate(lens):
+            s = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, L)].copy()
+            if L >= 256:
+                for _ in range(3):   # N runs of assorted lengths, some straddling the 256-base segment boundaries
+                    p = int(rng.integers(0, L - 40)); s[p:p + int(rng.integers(1, 40))] = ord("N")
+                s[250:262] = np.frombuffer(b"NNNNNNNNNNNN", dtype=np.uint8)[:len(s[250:262])]
+                s[100:110] = np.frombuffer(b"acgtRYacgt", dtype=np.uint8)
+            if L == 70000:
+                s[30000:30400] = ord("A")                      # homopolymer: long runs of tied minimizers
+                s[40000:40600] = np.frombuffer(b"AC" * 300, dtype=np.uint8)
+            f.write(b">c%d some comment\n" % i)
+            for o in range(0, L, 70):
+                f.write(s[o:o + 70].tobytes() + b"\n")
+    _same_index(A, str(fa))
