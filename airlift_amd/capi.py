@@ -59,7 +59,7 @@ class BatchStat(C.Structure):
                 ("n_anchor", C.c_uint64), ("n_chain", C.c_uint64), ("n_regs_aln", C.c_uint64), ("n_refbases", C.c_uint64),
                 ("n_cigar", C.c_uint64), ("n_rechain", C.c_uint64), ("n_heap_fallback", C.c_uint64), ("n_sort_tie_flag", C.c_uint64),
                 ("bytes_in", C.c_uint64), ("bytes_out", C.c_uint64), ("algorithmic_bytes", C.c_double),
-                ("ms_total", C.c_float), ("ms_kernel", C.c_float * 16), ("n_stage", C.c_int)]
+                ("ms_total", C.c_float), ("ms_kernel", C.c_float * 24), ("n_stage", C.c_int)]
 
 
 _lib = None
@@ -98,6 +98,7 @@ def load():
     L.al_map_file_frag.argtypes = [vp, ci, C.POINTER(cs), C.POINTER(MapOpt), ci, vp, cs, ci]; L.al_map_file_frag.restype = ci
     L.al_batch_stat.argtypes = [vp, C.POINTER(BatchStat)]; L.al_batch_stat.restype = None
     L.al_stage_name.argtypes = [ci]; L.al_stage_name.restype = cs
+    L.al_stage_kernel.argtypes = [ci]; L.al_stage_kernel.restype = cs
     L.al_dbg_copy.argtypes = [vp, cs, vp, C.c_int64]; L.al_dbg_copy.restype = C.c_int64
     L.al_dbg_alser_count.argtypes = [vp, C.POINTER(C.c_int64)]; L.al_dbg_alser_count.restype = ci
     L.al_write_sam.argtypes = [C.c_char_p, C.c_size_t, vp, cs, ci, cs, cs, ci, ci, ci, C.POINTER(ci), C.POINTER(C.POINTER(Reg)), cs, ci]; L.al_write_sam.restype = ci

@@ -100,4 +100,9 @@ struct AlReg {                // device mm_reg1_t (+ mm_extra_t scalars); 112 by
 #define ALR_SPLIT_INV    (1u<<16)
 #define ALR_HAS_P        (1u<<17)
 
-enum AlStage { ST_SKETCH = 0, ST_SEED, ST_SCAN, ST_ANCHOR_SORT, ST_CHAIN, ST_RECHAIN, ST_REGS, ST_EXT_PREP, ST_EXT_SORT, ST_EXT_DP, ST_EXT_FINISH, ST_COMPACT, ST_N };
+// one HIP-event interval per entry; where a stage is several kernels (chaining and extension DP are dispatched by size class)
+// each kernel with real weight has its own interval so that bench.py's per-kernel times line up with rocprofv3's
+enum AlStage { ST_SKETCH = 0, ST_SEED, ST_SCAN, ST_ORDER, ST_ANCHOR_SORT_S, ST_ANCHOR_SORT, ST_CHAIN_LDS32, ST_CHAIN_LDS48, ST_CHAIN_LDS64, ST_CHAIN_LDS128, ST_CHAIN_WAVE, ST_RECHAIN,
+               ST_REGS, ST_EXT_PREP, ST_EXT_SORT, ST_EXT_DP_LANE, ST_EXT_DP_G4, ST_EXT_DP_G8, ST_EXT_DP_G22, ST_EXT_FINISH, ST_COMPACT, ST_N };
+#define ST_CHAIN ST_CHAIN_WAVE
+#define ST_EXT_DP ST_EXT_DP_G22

@@ -1568,6 +1568,9 @@ int al_run_align_stage(al_ctx_t *c)
 			uint32_t first = 0;
 			for (int cls = 0; cls < AL_NCLS; ++cls) {
 				const uint32_t cnt = (uint32_t)hist[cls];
+				if (cls == 3) AL_HIP_CHECK(hipEventRecord(c->ev[ST_EXT_DP_LANE + 1], s));
+				if (cls == 6) AL_HIP_CHECK(hipEventRecord(c->ev[ST_EXT_DP_G4 + 1], s));
+				if (cls == 7) AL_HIP_CHECK(hipEventRecord(c->ev[ST_EXT_DP_G8 + 1], s));
 				if (cnt == 0) continue;
 				if (cls < 3) {                                                    // lane-per-job
 					const int TC = 16 << cls;
@@ -1594,8 +1597,8 @@ int al_run_align_stage(al_ctx_t *c)
 				first += cnt;
 			}
 		}
-		else AL_HIP_CHECK(hipEventRecord(c->ev[ST_EXT_SORT + 1], s));
-		AL_HIP_CHECK(hipEventRecord(c->ev[ST_EXT_DP + 1], s));
+		else { AL_HIP_CHECK(hipEventRecord(c->ev[ST_EXT_SORT + 1], s)); for (int i = ST_EXT_DP_LANE; i < ST_EXT_DP_G22; ++i) AL_HIP_CHECK(hipEventRecord(c->ev[i + 1], s)); }
+		AL_HIP_CHECK(hipEventRecord(c->ev[ST_EXT_DP_G22 + 1], s));
 		uint32_t *n_slow_d = (uint32_t *)(c->counters.p + 14);
 		hipLaunchKernelGGL(k_ext_finish, dim3((nf + 255) / 256), dim3(256), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, c->frag_first.p, c->frag_rep.p, W, G, E, lt, A->sc_ws.p, A->sc_off.p, nf, c->P, A->slow_list.p, n_slow_d);
 		uint32_t n_slow = 0;

@@ -209,6 +209,44 @@ __device__ __forceinline__ void d_heapdown(size_t i, size_t n, AlAnchor *l)
 	l[i] = tmp;
 }
 
+// exact emulation of collect_seed_hits_heap (map.c:149-213) by one lane; heap in global scratch
+__device__ __forceinline__ void d_anchor_heap_merge(const uint64_t *__restrict__ pos, const AlMatch *__restrict__ m, uint32_t n_m, uint32_t n, int qlen, int mini_span,
+                                                    AlAnchor *__restrict__ heap, AlAnchor *__restrict__ out, unsigned long long *__restrict__ counters)
+{
+	size_t hs = 0; uint64_t n_for = 0, n_rev = 0;
+	atomicAdd(&counters[0], 1ULL);
+	for (uint32_t i = 0; i < n_m; ++i) {
+		const uint64_t off = (uint64_t)m[i].off_lo | (uint64_t)(m[i].flags >> 16) << 32;
+		heap[hs].x = pos[off]; heap[hs].y = (uint64_t)i << 32; ++hs;
+	}
+	if (hs > 1) for (size_t i = (hs >> 1) - 1; i != (size_t)-1; --i) d_heapdown(i, hs, heap);
+	while (hs > 0) {
+		const AlMatch mm = m[heap[0].y >> 32];
+		const uint64_t r = heap[0].x; const int32_t rpos = (uint32_t)r >> 1; const uint32_t span = (uint32_t)mini_span;
+		AlAnchor a;
+		if ((r & 1) == (mm.q_pos & 1)) {
+			a.x = (r & 0xffffffff00000000ULL) | (uint32_t)rpos;
+			a.y = (uint64_t)span << 32 | (mm.q_pos >> 1);
+		} else {
+			a.x = 1ULL << 63 | (r & 0xffffffff00000000ULL) | (uint32_t)rpos;
+			a.y = (uint64_t)span << 32 | (uint32_t)(qlen - ((int)(mm.q_pos >> 1) + 1 - (int)span) - 1);
+		}
+		a.y |= (uint64_t)(mm.flags & 0xff) << AL_SEED_SEG_SHIFT;
+		if (mm.flags & (1u << 8)) a.y |= AL_SEED_TANDEM;
+		if (!(a.x >> 63)) out[n_for++] = a; else out[n - (++n_rev)] = a;
+		if ((uint32_t)heap[0].y < mm.n - 1) {
+			++heap[0].y;
+			const AlMatch m2 = m[heap[0].y >> 32];
+			const uint64_t off = (uint64_t)m2.off_lo | (uint64_t)(m2.flags >> 16) << 32;
+			heap[0].x = pos[off + (uint32_t)heap[0].y];
+		} else { heap[0] = heap[hs - 1]; --hs; }
+		if (hs > 0) d_heapdown(0, hs, heap);
+	}
+	for (uint64_t j = 0; j < n_rev >> 1; ++j) {                          // map.c:202-207
+		AlAnchor t = out[n - 1 - j]; out[n - 1 - j] = out[n - (n_rev - j)]; out[n - (n_rev - j)] = t;
+	}
+}
+
 template <int CAP>
 __global__ void __launch_bounds__(64)
 k_anchor_sort(const uint64_t *__restrict__ pos, const uint32_t *__restrict__ frag_first, const uint32_t *__restrict__ rd_len,
@@ -275,42 +313,70 @@ k_anchor_sort(const uint64_t *__restrict__ pos, const uint32_t *__restrict__ fra
 		fallback = s_flag != 0;
 		if (!fallback) for (uint32_t t = lane; t < n; t += 64) out[t] = s[t];
 	}
-	if (fallback && lane == 0) {
-		// exact emulation of collect_seed_hits_heap (map.c:149-213) by one lane; heap in global scratch
-		AlAnchor *heap = heap_ws + mini_off[r0];
-		size_t hs = 0; uint64_t n_for = 0, n_rev = 0;
-		atomicAdd(&counters[0], 1ULL);
-		for (uint32_t i = 0; i < n_m; ++i) {
-			const uint64_t off = (uint64_t)m[i].off_lo | (uint64_t)(m[i].flags >> 16) << 32;
-			heap[hs].x = pos[off]; heap[hs].y = (uint64_t)i << 32; ++hs;
-		}
-		if (hs > 1) for (size_t i = (hs >> 1) - 1; i != (size_t)-1; --i) d_heapdown(i, hs, heap);
-		while (hs > 0) {
-			const AlMatch mm = m[heap[0].y >> 32];
-			const uint64_t r = heap[0].x; const int32_t rpos = (uint32_t)r >> 1; const uint32_t span = (uint32_t)mini_span;
-			AlAnchor a;
-			if ((r & 1) == (mm.q_pos & 1)) {
-				a.x = (r & 0xffffffff00000000ULL) | (uint32_t)rpos;
-				a.y = (uint64_t)span << 32 | (mm.q_pos >> 1);
-			} else {
-				a.x = 1ULL << 63 | (r & 0xffffffff00000000ULL) | (uint32_t)rpos;
-				a.y = (uint64_t)span << 32 | (uint32_t)(qlen - ((int)(mm.q_pos >> 1) + 1 - (int)span) - 1);
-			}
-			a.y |= (uint64_t)(mm.flags & 0xff) << AL_SEED_SEG_SHIFT;
-			if (mm.flags & (1u << 8)) a.y |= AL_SEED_TANDEM;
-			if (!(a.x >> 63)) out[n_for++] = a; else out[n - (++n_rev)] = a;
-			if ((uint32_t)heap[0].y < mm.n - 1) {
-				++heap[0].y;
-				const AlMatch m2 = m[heap[0].y >> 32];
-				const uint64_t off = (uint64_t)m2.off_lo | (uint64_t)(m2.flags >> 16) << 32;
-				heap[0].x = pos[off + (uint32_t)heap[0].y];
-			} else { heap[0] = heap[hs - 1]; --hs; }
-			if (hs > 0) d_heapdown(0, hs, heap);
-		}
-		for (uint64_t j = 0; j < n_rev >> 1; ++j) {                          // map.c:202-207
-			AlAnchor t = out[n - 1 - j]; out[n - 1 - j] = out[n - (n_rev - j)]; out[n - (n_rev - j)] = t;
-		}
+	if (fallback && lane == 0) d_anchor_heap_merge(pos, m, n_m, n, qlen, mini_span, heap_ws + mini_off[r0], out, counters);
+}
+
+// K3 for fragments with at most 64 anchors (the bulk on a low-repeat genome): nothing but registers, so 32 wavefronts per CU
+// stay resident and hide the dependent HBM reads (count -> match records -> positions) that bound this stage.
+// Lane t builds anchor t (its owning match is found by counting prefix sums, read with wave-uniform readlanes), the
+// sort is a rank sort on x (64-bit compares against one broadcast element per step); equal x -> exact heap emulation.
+__global__ void __launch_bounds__(64)
+k_anchor_sort_small(const uint64_t *__restrict__ pos, const uint32_t *__restrict__ frag_first, const uint32_t *__restrict__ rd_len,
+                    const uint64_t *__restrict__ mini_off, const AlMatch *__restrict__ match,
+                    const uint32_t *__restrict__ frag_nm, const uint32_t *__restrict__ frag_na, const uint64_t *__restrict__ a_off,
+                    AlAnchor *__restrict__ anchors, AlAnchor *__restrict__ heap_ws,
+                    const uint32_t *__restrict__ frag_list, int n_list, unsigned long long *__restrict__ counters, int mini_span)
+{
+	const int lane = threadIdx.x;
+	if ((int)blockIdx.x >= n_list) return;
+	const uint32_t f = frag_list ? frag_list[blockIdx.x] : blockIdx.x;
+	const uint32_t n = frag_na[f], n_m = frag_nm[f];
+	if (n == 0) return;
+	const uint32_t r0 = frag_first[f], r1 = frag_first[f + 1];
+	int qlen = 0; for (uint32_t r = r0; r < r1; ++r) qlen += (int)rd_len[r];
+	const AlMatch *m = match + mini_off[r0];
+	AlAnchor *out = anchors + a_off[f];
+	if (n > 64u) {                                   // not this kernel's class (the caller's ordering makes this unreachable)
+		if (lane == 0) d_anchor_heap_merge(pos, m, n_m, n, qlen, mini_span, heap_ws + mini_off[r0], out, counters);
+		return;
 	}
+	AlMatch mm; mm.off_lo = 0; mm.n = 0; mm.q_pos = 0; mm.flags = 0;
+	if ((uint32_t)lane < n_m) mm = m[lane];
+	uint32_t incl = mm.n;
+	for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+	const uint32_t pre = incl - mm.n;
+	uint32_t le = 0;                                 // matches whose first anchor index is <= lane
+	for (uint32_t mi = 0; mi < n_m; ++mi) le += (uint32_t)__shfl((int)pre, (int)mi) <= (uint32_t)lane ? 1u : 0u;
+	const int own = (int)le - 1;
+	const uint32_t o_off = (uint32_t)__shfl((int)mm.off_lo, own), o_fl = (uint32_t)__shfl((int)mm.flags, own), o_qp = (uint32_t)__shfl((int)mm.q_pos, own), o_pre = (uint32_t)__shfl((int)pre, own);
+	uint64_t x = UINT64_MAX, y = UINT64_MAX;
+	if ((uint32_t)lane < n) {
+		const uint64_t off = (uint64_t)o_off | (uint64_t)(o_fl >> 16) << 32;
+		const uint64_t r = pos[off + ((uint32_t)lane - o_pre)];
+		const uint32_t span = (uint32_t)mini_span, seg = o_fl & 0xff;
+		const int32_t rpos = (uint32_t)r >> 1;
+		if ((r & 1) == (o_qp & 1)) {                                          // map.c:176-190
+			x = (r & 0xffffffff00000000ULL) | (uint32_t)rpos;
+			y = (uint64_t)span << 32 | (o_qp >> 1);
+		} else {
+			x = 1ULL << 63 | (r & 0xffffffff00000000ULL) | (uint32_t)rpos;
+			y = (uint64_t)span << 32 | (uint32_t)(qlen - ((int)(o_qp >> 1) + 1 - (int)span) - 1);
+		}
+		y |= (uint64_t)seg << AL_SEED_SEG_SHIFT;
+		if (o_fl & (1u << 8)) y |= AL_SEED_TANDEM;
+	}
+	uint32_t rank = 0; bool tie = false;
+	const int xlo = (int)(uint32_t)x, xhi = (int)(uint32_t)(x >> 32);
+	for (uint32_t j = 0; j < n; ++j) {
+		const uint64_t xj = (uint64_t)(uint32_t)__shfl(xlo, (int)j) | (uint64_t)(uint32_t)__shfl(xhi, (int)j) << 32;
+		rank += xj < x ? 1u : 0u;
+		tie = tie || (xj == x && j != (uint32_t)lane);
+	}
+	if (__ballot(tie && (uint32_t)lane < n)) {
+		if (lane == 0) d_anchor_heap_merge(pos, m, n_m, n, qlen, mini_span, heap_ws + mini_off[r0], out, counters);
+		return;
+	}
+	if ((uint32_t)lane < n) { AlAnchor a; a.x = x; a.y = y; out[rank] = a; }
 }
 
 // =============================================================================================
@@ -679,8 +745,6 @@ k_chain_lds(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a
 #define PL(j) sp[(j) * LANES + lane]
 #define TL(j) st_[(j) * LANES + lane]
 #define VL(j) sv[(j) * LANES + lane]
-	const bool prof = (P.dbg >> 21) & 1;
-	const long long tc0 = prof ? clock64() : 0;
 	const uint32_t r0 = frag_first[f], r1 = frag_first[f + 1];
 	const int n_segs = (int)(r1 - r0);
 	int qlen_sum = 0; for (uint32_t r = r0; r < r1; ++r) qlen_sum += (int)rd_len[r];
@@ -707,7 +771,6 @@ k_chain_lds(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a
 	}
 	const double avg_d = (double)(float)((double)(float)((uint32_t)q_span * (uint32_t)n) / (double)(float)n);   // (float)sum/n (chain.c:42)
 	const bool tab_ok = avg_d == (double)P.k && P.k * 0.01 * (AL_CLIN_N - 1) < 255.0;
-	const long long tc1 = prof ? clock64() : 0;
 	int st = 0;
 	for (int i = 0; i < n; ++i) {                                                 // chain.c:46-85
 		const uint32_t pi = XL(i); const uint32_t mi_ = ML(i);
@@ -751,7 +814,6 @@ k_chain_lds(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a
 		FL(i) = (int16_t)max_f; PL(i) = max_j < 0 ? (uint8_t)0xff : (uint8_t)max_j;
 		VL(i) = max_j >= 0 && (int32_t)VL(max_j) > max_f ? VL(max_j) : (int16_t)max_f;
 	}
-	const long long tc2 = prof ? clock64() : 0;
 	// chain.c:87-109.  NB: the t[] marks above use the row index i (< CAPL <= 128) with 0xff as "never"; from here t[] is a 0/1 flag.
 	for (int i = 0; i < n; ++i) TL(i) = 0;
 	for (int i = 0; i < n; ++i) if (PL(i) != 0xff) TL(PL(i)) = 1;
@@ -794,7 +856,6 @@ k_chain_lds(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a
 		for (int32_t j = 0; j < ni; ++j) b[o++] = a[(int)VL(k0 + (ni - j - 1))];
 	}
 	frag_nu[f] = (uint32_t)n_u;
-	if (prof && lane == 0) { const long long tc3 = clock64(); atomicAdd(&counters[8], (unsigned long long)(tc1 - tc0)); atomicAdd(&counters[9], (unsigned long long)(tc2 - tc1)); atomicAdd(&counters[11], (unsigned long long)(tc3 - tc2)); atomicAdd(&counters[14], 1ULL); }
 #undef XL
 #undef QL
 #undef ML

@@ -17,11 +17,17 @@ extern "C" __global__ void k_seed(const uint64_t *, int, const uint32_t *, const
 extern "C" __global__ void k_alser_count(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, int, int, unsigned long long *);
 extern "C" __global__ void k_rechain_test(const AlAnchor *, const uint64_t *, const uint64_t *, const uint32_t *, const int32_t *, const uint32_t *, int, uint32_t *, uint32_t *);
 template <int CAP> __global__ void k_anchor_sort(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, AlAnchor *, const uint32_t *, int, unsigned long long *, int);
+__global__ void k_anchor_sort_small(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, AlAnchor *, const uint32_t *, int, unsigned long long *, int);
 template <int CAP> __global__ void k_chain(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, AlAnchor *, uint64_t *, uint32_t *, int32_t *, uint64_t *, const uint32_t *, int, AlParams, unsigned long long *, int);
 template <int CAPL, int LANES> __global__ void k_chain_lds(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, AlAnchor *, uint64_t *, uint32_t *, uint64_t *, const uint32_t *, int, int, AlParams, unsigned long long *);
 extern "C" __global__ void k_chain_lane(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, AlAnchor *, uint64_t *, uint32_t *, int32_t *, uint64_t *, const uint32_t *, int, int, AlParams, unsigned long long *);
 
-static const char *g_stage_names[ST_N] = { "sketch", "seed_lookup", "scan", "anchor_sort", "chain", "rechain", "regs", "ext_prep", "ext_sort", "ext_dp", "ext_finish", "compact" };
+static const char *g_stage_names[ST_N] = { "sketch", "seed_lookup", "scan", "size_order", "anchor_sort_small", "anchor_sort", "chain_lds32", "chain_lds48", "chain_lds64", "chain_lds128", "chain_wave", "rechain",
+                                           "regs", "ext_prep", "ext_sort", "ext_dp_lane", "ext_dp_g4", "ext_dp_g8", "ext_dp_g22", "ext_finish", "compact" };
+// kernel behind each interval (what rocprofv3 --kernel-trace lists); "" = several small launches
+static const char *g_stage_kernels[ST_N] = { "k_sketch", "k_seed", "", "", "k_anchor_sort_small", "k_anchor_sort<1024>", "k_chain_lds<16|24|32, 64>", "k_chain_lds<48, 64>", "k_chain_lds<64, 64>", "k_chain_lds<128, 32>", "k_chain<768>", "",
+                                             "k_regs", "k_ext_prep", "", "k_ext_dp_lane<16|32, 64>", "k_ext_dp<1|2|4, 512, ..>", "k_ext_dp<8, 512, 128>", "k_ext_dp<22, 512, 352>", "k_ext_finish", "k_compact" };
+extern "C" const char *al_stage_kernel(int i) { return i >= 0 && i < ST_N ? g_stage_kernels[i] : ""; }
 extern "C" const char *al_stage_name(int i) { return i >= 0 && i < ST_N ? g_stage_names[i] : ""; }
 
 // ---------------------------------------------------------------------------------------------
@@ -248,41 +254,50 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 		hipLaunchKernelGGL(k_scatter_off, dim3((nl + 255) / 256), dim3(256), 0, s, c->tmp_u64.p, list, nl, base_off, c->a_off.p);
 		c->n_anchor_total = base_off + total;
 	}
-	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_anchor_sort<1024>), dim3(nl), dim3(64), 0, s, c->di.pos, c->frag_first.p, c->rd_len.p, c->mini_off.p, c->match.p, c->frag_nm.p, c->frag_na.p,
-	                   c->a_off.p, c->anchors.p, c->heap_ws.p, list, nl, c->counters.p, c->mi->k);
-	if (first) AL_HIP_CHECK(hipEventRecord(c->ev[ST_ANCHOR_SORT + 1], s));
+	// fragments ordered by anchor count: the sort kernels and the chaining kernels are chosen per size class, and lanes of
+	// one wavefront get equal trip counts.  [0, lb65) <= 64 anchors, [lb65, lb129) <= 128 anchors, rest.
+	const int lane_max = (c->P.dbg >> 27) & 1 ? 0 : 64;
+	const uint32_t *order = list; bool sorted = false;
+	uint32_t lb65 = (uint32_t)nl, lb129 = (uint32_t)nl;
+	if (first && lane_max > 0 && nl > 1024) {
+		if (c->chain_key.ensure(nl + 1) || c->chain_idx.ensure(nl + 1) || c->chain_idx2.ensure(nl + 1)) return -1;
+		hipLaunchKernelGGL(k_iota_u32, dim3((nl + 255) / 256), dim3(256), 0, s, c->chain_idx.p, (uint32_t)nl);
+		size_t bytes = 0;
+		AL_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const uint32_t *)c->frag_na.p, c->chain_key.p, (const uint32_t *)c->chain_idx.p, c->chain_idx2.p, nl, 0, 20, s));
+		if (c->scan_tmp.ensure(bytes + 16)) return -1;
+		AL_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(c->scan_tmp.p, bytes, (const uint32_t *)c->frag_na.p, c->chain_key.p, (const uint32_t *)c->chain_idx.p, c->chain_idx2.p, nl, 0, 20, s));
+		order = c->chain_idx2.p; sorted = true;
+		uint32_t *d_lb = (uint32_t *)(c->counters.p + 15);            // two consecutive u32
+		const uint32_t init[2] = {(uint32_t)nl, (uint32_t)nl};
+		AL_HIP_CHECK(hipMemcpyAsync(d_lb, init, 8, hipMemcpyHostToDevice, s));
+		hipLaunchKernelGGL(k_lower_bound, dim3((nl + 255) / 256), dim3(256), 0, s, c->chain_key.p, (uint32_t)nl, 65u, d_lb);
+		hipLaunchKernelGGL(k_lower_bound, dim3((nl + 255) / 256), dim3(256), 0, s, c->chain_key.p, (uint32_t)nl, 129u, d_lb + 1);
+		uint32_t lb[2];
+		AL_HIP_CHECK(hipMemcpyAsync(lb, d_lb, 8, hipMemcpyDeviceToHost, s));
+		AL_HIP_CHECK(hipStreamSynchronize(s));
+		lb65 = lb[0]; lb129 = lb[1];
+	}
+	if (first) AL_HIP_CHECK(hipEventRecord(c->ev[ST_ORDER + 1], s));
 	{
-		// small fragments: one lane each, ordered by anchor count (uniform trip counts inside a wavefront); the rest: one wave each
-		const int lane_max = (c->P.dbg >> 27) & 1 ? 0 : 64;
-		const uint32_t *order = list; bool sorted = false;
-		if (first && lane_max > 0 && nl > 1024) {
-			if (c->chain_key.ensure(nl + 1) || c->chain_idx.ensure(nl + 1) || c->chain_idx2.ensure(nl + 1)) return -1;
-			hipLaunchKernelGGL(k_iota_u32, dim3((nl + 255) / 256), dim3(256), 0, s, c->chain_idx.p, (uint32_t)nl);
-			size_t bytes = 0;
-			AL_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const uint32_t *)c->frag_na.p, c->chain_key.p, (const uint32_t *)c->chain_idx.p, c->chain_idx2.p, nl, 0, 20, s));
-			if (c->scan_tmp.ensure(bytes + 16)) return -1;
-			AL_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(c->scan_tmp.p, bytes, (const uint32_t *)c->frag_na.p, c->chain_key.p, (const uint32_t *)c->chain_idx.p, c->chain_idx2.p, nl, 0, 20, s));
-			order = c->chain_idx2.p; sorted = true;
-		}
-		// index ranges of the size-ordered list: [0, lb65) <= 64 anchors, [lb65, lb129) <= 128 anchors, rest
-		uint32_t lb65 = (uint32_t)nl, lb129 = (uint32_t)nl;
-		if (sorted) {
-			uint32_t *d_lb = (uint32_t *)(c->counters.p + 15);            // two consecutive u32
-			const uint32_t init[2] = {(uint32_t)nl, (uint32_t)nl};
-			AL_HIP_CHECK(hipMemcpyAsync(d_lb, init, 8, hipMemcpyHostToDevice, s));
-			hipLaunchKernelGGL(k_lower_bound, dim3((nl + 255) / 256), dim3(256), 0, s, c->chain_key.p, (uint32_t)nl, 65u, d_lb);
-			hipLaunchKernelGGL(k_lower_bound, dim3((nl + 255) / 256), dim3(256), 0, s, c->chain_key.p, (uint32_t)nl, 129u, d_lb + 1);
-			uint32_t lb[2];
-			AL_HIP_CHECK(hipMemcpyAsync(lb, d_lb, 8, hipMemcpyDeviceToHost, s));
-			AL_HIP_CHECK(hipStreamSynchronize(s));
-			lb65 = lb[0]; lb129 = lb[1];
-		}
+		const int n_small = sorted ? (int)lb65 : 0;
+		if (n_small > 0) hipLaunchKernelGGL(k_anchor_sort_small, dim3(n_small), dim3(64), 0, s, c->di.pos, c->frag_first.p, c->rd_len.p, c->mini_off.p, c->match.p, c->frag_nm.p, c->frag_na.p,
+		                                    c->a_off.p, c->anchors.p, c->heap_ws.p, order, n_small, c->counters.p, c->mi->k);
+		if (first) AL_HIP_CHECK(hipEventRecord(c->ev[ST_ANCHOR_SORT_S + 1], s));
+		if (nl - n_small > 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_anchor_sort<1024>), dim3(nl - n_small), dim3(64), 0, s, c->di.pos, c->frag_first.p, c->rd_len.p, c->mini_off.p, c->match.p, c->frag_nm.p, c->frag_na.p,
+		                                         c->a_off.p, c->anchors.p, c->heap_ws.p, sorted ? order + n_small : list, nl - n_small, c->counters.p, c->mi->k);
+		if (first) AL_HIP_CHECK(hipEventRecord(c->ev[ST_ANCHOR_SORT + 1], s));
+	}
+	{
 #define LCH(C, L, LO, LIST, N) do { const int n__ = (N); if (n__ > 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain_lds<C, L>), dim3((n__ + L - 1) / L), dim3(64), 0, s, c->anchors.p, c->a_off.p, c->frag_na.p, c->frag_first.p, c->rd_len.p, c->chained.p, c->u.p, c->frag_nu.p, c->ws_u64.p, LIST, n__, LO, c->P, c->counters.p); } while (0)
-		if (lane_max > 0) {
-			const int n64 = sorted ? (int)lb65 : nl;                        // unsorted: wavefront-group ownership inside the kernels
-			LCH(16, 64, -1, order, n64); LCH(24, 64, 16, order, n64); LCH(32, 64, 24, order, n64); LCH(48, 64, 32, order, n64); LCH(64, 64, 48, order, n64);
-			if (sorted) LCH(128, 32, -1, order + lb65, (int)(lb129 - lb65));
-		}
+		const int n64 = sorted ? (int)lb65 : nl;                            // unsorted: wavefront-group ownership inside the kernels
+		if (lane_max > 0) { LCH(16, 64, -1, order, n64); LCH(24, 64, 16, order, n64); LCH(32, 64, 24, order, n64); }
+		if (first) AL_HIP_CHECK(hipEventRecord(c->ev[ST_CHAIN_LDS32 + 1], s));
+		if (lane_max > 0) LCH(48, 64, 32, order, n64);
+		if (first) AL_HIP_CHECK(hipEventRecord(c->ev[ST_CHAIN_LDS48 + 1], s));
+		if (lane_max > 0) LCH(64, 64, 48, order, n64);
+		if (first) AL_HIP_CHECK(hipEventRecord(c->ev[ST_CHAIN_LDS64 + 1], s));
+		if (lane_max > 0 && sorted) LCH(128, 32, -1, order + lb65, (int)(lb129 - lb65));
+		if (first) AL_HIP_CHECK(hipEventRecord(c->ev[ST_CHAIN_LDS128 + 1], s));
 #undef LCH
 		{
 			// wave-per-fragment kernel: the rest of the size-ordered list (or, unsorted, the wavefront-groups the LDS kernels do not own)
@@ -292,7 +307,7 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 			                   c->ws_i32.p, c->ws_u64.p, order ? order + tail : nullptr, nt, c->P, c->counters.p, sorted ? 0 : lane_max);
 		}
 	}
-	if (first) AL_HIP_CHECK(hipEventRecord(c->ev[ST_CHAIN + 1], s));
+	if (first) AL_HIP_CHECK(hipEventRecord(c->ev[ST_CHAIN_WAVE + 1], s));
 	AL_HIP_CHECK(hipGetLastError());
 	return 0;
 }
@@ -344,7 +359,6 @@ extern "C" int al_batch_run(al_ctx_t *c)
 	c->ran = true;
 	// counters + algorithmic bytes
 	unsigned long long h[16]; AL_HIP_CHECK(hipMemcpy(h, c->counters.p, sizeof(h), hipMemcpyDeviceToHost));
-	if ((c->P.dbg >> 21) & 1) fprintf(stderr, "[airlift] k_chain_lds lane-0 cycles: load %.1f%%  dp %.1f%%  tail %.1f%%  (%.0f cycles/wave, %llu waves)\n", 100.0 * h[8] / (h[8] + h[9] + h[11] + 1), 100.0 * h[9] / (h[8] + h[9] + h[11] + 1), 100.0 * h[11] / (h[8] + h[9] + h[11] + 1), (double)(h[8] + h[9] + h[11]) / (h[14] + 1), h[14]);
 	al_batch_stat_t &st = c->stat; memset(&st, 0, sizeof(st));
 	st.n_frag = c->n_frag; st.n_reads = c->n_reads; st.n_bases = c->n_bases;
 	st.n_mini = ~0ULL; st.n_chain = ~0ULL;   // filled lazily by al_batch_stat()

@@ -93,6 +93,17 @@ def cpu_baseline(tmp, ref_fa, arr, n_pairs):
     return base, e2e
 
 
+def load_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/traffic.json, written by
+    tools/prof.sh on the GPU box with the same bench command); None when no profile has been taken."""
+    p = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(p):
+        return None, None
+    t = json.load(open(p))
+    e = t.get("kernels", {}).get(kernel)
+    return (e["bytes_per_launch"], t.get("source")) if e else (None, t.get("source"))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -153,7 +164,7 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    stage_ms = np.zeros(16); t0 = time.perf_counter()
+    stage_ms = np.zeros(24); t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
         st = ctx.stat()
@@ -170,7 +181,9 @@ def main():
     if rank == 0:
         names = [L.al_stage_name(i).decode() for i in range(st.n_stage)]
         per = {names[i]: float(stage_ms[i] / a.steps) for i in range(st.n_stage)}
-        dom = max((k for k in per if k not in ("scan", "rechain", "ext_sort", "compact")), key=lambda k: per[k])
+        kern = {names[i]: L.al_stage_kernel(i).decode() for i in range(st.n_stage)}
+        dom = max((k for k in per if kern[k]), key=lambda k: per[k])          # intervals that are exactly one kernel
+        traffic, traffic_src = load_traffic(kern[dom])
         alg = float(st.algorithmic_bytes)
         achieved = alg / (per[dom] * 1e-3) / 1e9
         out = {
@@ -179,8 +192,8 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "u8/int32 (int8 SW lanes, u64 hashes)", "data": "synthetic",
             "config": {"workload": "C2: yeast-sized synthetic reference pair (16 contigs, 12.16 Mbp, 150 planted duplications), %d x 2 x %d bp PE reads per GPU per step, preset sr" % (a.pairs, a.read_len),
                        "reads_per_step_per_gpu": 2 * a.pairs, "read_len": a.read_len, "sharding": "reads sharded by rank, index replicated"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": dom, "kernel_ms": per[dom], "algorithmic_bytes_per_launch": alg, "algorithmic_bytes_per_read": alg / (2.0 * a.pairs),
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": kern[dom], "interval": dom, "kernel_ms": per[dom], "algorithmic_bytes_per_launch": alg, "algorithmic_bytes_per_read": alg / (2.0 * a.pairs),
                          "pipeline_GBps": alg / (sum(per.values()) * 1e-3) / 1e9},
             "stages_ms": per,
             "counters": {"minimizers_per_read": st.n_mini / (2.0 * a.pairs), "anchors_per_pair": st.n_anchor / float(a.pairs), "chains_per_pair": st.n_chain / float(a.pairs),

@@ -152,11 +152,13 @@ typedef struct {
 	uint64_t bytes_in, bytes_out;
 	double   algorithmic_bytes;       /* SURVEY.md §8(d) formula evaluated with the counters above */
 	float    ms_total;                /* HIP events around the whole device pipeline */
-	float    ms_kernel[16];           /* per stage, see al_stage_name() */
+	float    ms_kernel[24];           /* HIP-event time per pipeline interval, see al_stage_name() / al_stage_kernel() */
 	int      n_stage;
 } al_batch_stat_t;
 void al_batch_stat(const al_ctx_t *ctx, al_batch_stat_t *st);
 const char *al_stage_name(int i);
+/* the kernel that runs in interval i (as rocprofv3 --kernel-trace names it); "" where an interval is a few small launches */
+const char *al_stage_kernel(int i);
 
 /* ---- stage taps for parity tests (analogue of --print-seeds, map.c:333-338,381-385) ---- */
 /* minimizers of read i of the resident batch: returns count, writes up to cap records (x = hash<<8|span, y = i<<32|pos<<1|strand) */

@@ -31,6 +31,33 @@ for tag, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
     print("|---|---|---|---|")
     for k, (n, v) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:12]:
         print("| %s | %d | %.0f | %.1f |" % (k, n, v, v / max(n, 1)))
+# traffic.json for bench.py: HBM bytes per launch per kernel = FETCH_SIZE + WRITE_SIZE (KiB -> bytes).  The guide's x2 FETCH_SIZE
+# correction applies to wide (16 B/lane) coalesced streaming reads only; these kernels read 4-16 B per lane at scattered
+# addresses (uncalibrated width), so the raw counter is recorded and the corrected upper bound is kept next to it.
+try:
+    import json, re
+    tr = {}
+    def short(k):
+        k = re.sub(r"^void ", "", k)
+        return re.sub(r"\(.*$", "", k)
+    per = {}
+    for tag, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+        files = glob.glob(os.path.join(d, tag, "**", "*counter_collection.csv"), recursive=True)
+        if not files:
+            continue
+        for row in csv.DictReader(open(files[0])):
+            if row.get("Counter_Name") != ctr:
+                continue
+            e = per.setdefault(short(row.get("Kernel_Name", "")), {"FETCH_SIZE": [0, 0.0], "WRITE_SIZE": [0, 0.0]})
+            e[ctr][0] += 1; e[ctr][1] += float(row.get("Counter_Value", 0))
+    kernels = {}
+    for k, e in per.items():
+        f = e["FETCH_SIZE"][1] / max(e["FETCH_SIZE"][0], 1) * 1024.0; w = e["WRITE_SIZE"][1] / max(e["WRITE_SIZE"][0], 1) * 1024.0
+        kernels[k] = {"bytes_per_launch": f + w, "fetch_bytes": f, "write_bytes": w, "fetch_bytes_x2_upper": 2 * f, "launches": e["FETCH_SIZE"][0]}
+    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) over `python3 bench.py --no-cpu-baseline`, %s" % os.path.basename(d), "kernels": kernels},
+              open(os.path.join(d, "traffic.json"), "w"), indent=1)
+except Exception as ex:
+    print("traffic.json not written:", ex)
 for f in ("bench_trace.json",):
     p = os.path.join(d, f)
     if os.path.exists(p):
