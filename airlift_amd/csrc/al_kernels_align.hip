@@ -58,6 +58,15 @@ struct GroupWs {                    // per-group HBM scratch (+ the current loca
 	unsigned long long *dbg;        // debug records (differential DP check)
 	long long prof[8];              // AL_DBG bit 21: cycle accumulators [0] dp init [1] dp rows [2] backtrack [3] align1 other [4] post [5] stage-in [6] n_dp [7] n_rows
 };
+#ifndef AL_LB_REGS
+#define AL_LB_REGS 5
+#endif
+#ifndef AL_LB_PREP
+#define AL_LB_PREP 8
+#endif
+#ifndef AL_LB_FIN
+#define AL_LB_FIN 5
+#endif
 #define PROF_ON(P) (((P).dbg >> 21) & 1)
 #define AL_PAIR_SC_CAP 4096
 
@@ -692,7 +701,7 @@ __device__ __forceinline__ void d_frag_ws(const WsBase &W, uint32_t f, FragWs &o
 	o.seg_a[0] = W.seg_a + W.a_off[f]; o.seg_a[1] = nullptr;
 }
 
-extern "C" __global__ void __launch_bounds__(256)
+extern "C" __global__ void __launch_bounds__(256, AL_LB_REGS)
 k_regs(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__ u_all, const uint32_t *__restrict__ frag_first,
        const uint32_t *__restrict__ rd_len, const uint32_t *__restrict__ frag_hash, WsBase W, int n_frag, AlParams P, unsigned long long *counters)
 {
@@ -905,7 +914,7 @@ __device__ __forceinline__ int d_job_class(int qlen, int tlen, int lane_ok)
 	return b <= 1 ? 3 : b <= 2 ? 4 : b <= 4 ? 5 : b <= 8 ? 6 : b <= 22 ? 7 : 8;
 }
 
-extern "C" __global__ void __launch_bounds__(256)
+extern "C" __global__ void __launch_bounds__(256, AL_LB_PREP)
 k_ext_prep(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_off, const uint32_t *__restrict__ rd_len,
            const uint32_t *__restrict__ frag_first, WsBase W, AlignShared G, ExtShared E, int n_frag, AlParams P, int tmax, int qmax)
 {
@@ -1305,7 +1314,7 @@ __device__ __forceinline__ void d_fcig_append(AlReg *r, uint32_t *cig, int n, co
 	} else { for (int i = 0; i < n; ++i) cig[r->n_cigar + i] = src[i]; r->n_cigar += n; }
 }
 
-extern "C" __global__ void __launch_bounds__(256)
+extern "C" __global__ void __launch_bounds__(256, AL_LB_FIN)
 k_ext_finish(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_off, const uint32_t *__restrict__ rd_len,
              const uint32_t *__restrict__ frag_first, const int32_t *__restrict__ frag_rep, WsBase W, AlignShared G, ExtShared E,
              AlLogTab lt, uint64_t *__restrict__ sc_ws, const uint64_t *__restrict__ sc_off, int n_frag, AlParams P, uint32_t *__restrict__ slow_list, uint32_t *__restrict__ n_slow)
