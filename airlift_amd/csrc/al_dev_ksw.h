@@ -92,17 +92,27 @@ __device__ __forceinline__ void d_ksw_reg(LT &L, const int gl, GroupWs &ws, int 
 		uint8_t *pr = ptb + (size_t)r * prow - st;
 		const uint8_t *qrr = qr + (qlen - 1 - r);
 		const int be = en0 >> 4;
-		int hprev15 = 0;                                                 // H[en0-1] when en0 is the first lane of its block
+		int hprev15 = 0;                                                 // H[r-1][en0-1] when en0 is the first lane of its block (that block may be outside [st_,en_])
+		if (NB > 1) {
+			int hsel = 0;
+#pragma unroll
+			for (int b = 0; b < NB; ++b) hsel = (b + 1 == be) ? H[b] : hsel;
+			const int hv = __shfl(hsel, GW - 1, GW);
+			hprev15 = (r > 0 && (en0 & 15) == 0) ? hv : 0;
+		}
 		const int en1 = st0 + (en0 - st0) / 4 * 4;
 		const uint32_t ybits = (uint32_t)(uint8_t)(int8_t)(-q - e) | (uint32_t)(uint8_t)(int8_t)(-q2 - e2) << 8;
 		const bool enr = en >= r;
+		const int tend = tlen_ * 16;
+		const int qclamp = qlen_ * 16 + 31;
+		const bool store_p = !((P.dbg >> 23) & 1);
 		long long key = (long long)0x8000000000000000ULL;            // this lane's best (H<<16 | 0xffff-ord); 32-bit form for NB <= 4
 		int key32 = (int)0x80000000;
-		// The body below is written with selects instead of branches: conditions are uniform inside a 16-lane group but
-		// differ between the four groups of a wavefront, so every `if` would cost an exec-mask round trip.
+		// The block body is straight-line code: every condition below is uniform inside a 16-lane group but differs between
+		// the four groups of a wavefront, so each `if` would cost an exec-mask round trip per block.  Only two branches
+		// remain: skipping a block no group-lane needs, and the timing-experiment switch around the traceback store.
 #pragma unroll
 		for (int b = 0; b < NB; ++b) {
-			if (NB > 1 && r > 0 && b + 1 == be && (en0 & 15) == 0) hprev15 = __shfl(H[b], GW - 1, GW);   // H[r-1][en0-1] (block may be outside [st_,en_])
 			const bool act = NB == 1 ? true : (b >= st_ && b <= en_);
 			if (NB >= 4 && !act) continue;
 			const int t = 16 * b + gl;
@@ -111,50 +121,58 @@ __device__ __forceinline__ void d_ksw_reg(LT &L, const int gl, GroupWs &ws, int 
 			b_old = isr ? ((b_old & 0xffff0000u) | ybits) : b_old;
 			a_old = isr ? ((a_old & 0x00ffffffu) | (uint32_t)(uint8_t)ubound << 24) : a_old;
 			{                                                                // score bytes (:158-176); the LDS read is unconditional on a clamped index
-				const bool son = act && t >= st0 && t <= cover_end && t < tlen_ * 16;
-				int qi = qlen - 1 - r + t; qi = qi < 0 ? 0 : qi; qi = qi > qlen_ * 16 + 31 ? qlen_ * 16 + 31 : qi;
-				const uint8_t sq = (uint8_t)(b_old >> 24), sq2 = qr[qi];
-				int8_t sc = sq == sq2 ? sc_mch : sc_mis;
-				sc = (sq == 4 || sq2 == 4) ? sc_N : sc;
-				b_old = son ? ((b_old & 0xff00ffffu) | (uint32_t)(uint8_t)sc << 16) : b_old;
+				const bool son = act && t >= st0 && t <= cover_end && t < tend;
+				int qi = qlen - 1 - r + t; qi = qi < 0 ? 0 : qi; qi = qi > qclamp ? qclamp : qi;
+				const uint32_t sq = b_old >> 24, sq2 = qr[qi];
+				int sc = sq == sq2 ? (int)sc_mch : (int)sc_mis;
+				sc = (sq == 4 || sq2 == 4) ? (int)sc_N : sc;
+				const uint32_t bs = (b_old & 0xff00ffffu) | ((uint32_t)sc & 0xffu) << 16;
+				b_old = son ? bs : b_old;
 			}
 			const uint32_t left = (uint32_t)d_dpp_shr1((int)carry, (int)a_old);
 			if (NB > 1) { const uint32_t cn = (uint32_t)__shfl((int)a_old, GW - 1, GW); carry = act ? cn : carry; }
-			const int8_t xt1 = (int8_t)left, vt1 = (int8_t)(left >> 8), x2t1 = (int8_t)(left >> 16);
-			const int8_t ut = (int8_t)(a_old >> 24), yo = (int8_t)b_old, y2o = (int8_t)(b_old >> 8);
-			int8_t z = (int8_t)(b_old >> 16);
-			int8_t a = (int8_t)(xt1 + vt1), bb = (int8_t)(yo + ut), a2 = (int8_t)(x2t1 + vt1), b2 = (int8_t)(y2o + ut);
-			int d;
+			const int xt1 = (int8_t)left, vt1 = (int8_t)(left >> 8), x2t1 = (int8_t)(left >> 16);
+			const int ut = (int8_t)(a_old >> 24), yo = (int8_t)b_old, y2o = (int8_t)(b_old >> 8);
+			int z = (int8_t)(b_old >> 16);
+			// int8 lanes of the reference, held sign-extended in 32-bit registers: every sum below is re-wrapped to int8
+			int a = (int8_t)(xt1 + vt1), bb = (int8_t)(yo + ut), a2 = (int8_t)(x2t1 + vt1), b2 = (int8_t)(y2o + ut);
 			// left-aligned gaps take a strict '>' (ksw2_extd2_sse.c:206-214), right-aligned '>=' (:252-260)
-			d = (a > z || (right && a == z)) ? 1 : 0;   z = z > a ? z : a;
-			d = (bb > z || (right && bb == z)) ? 2 : d; z = z > bb ? z : bb;
-			d = (a2 > z || (right && a2 == z)) ? 3 : d; z = z > a2 ? z : a2;
-			d = (b2 > z || (right && b2 == z)) ? 4 : d; z = z > b2 ? z : b2;
-			z = z < sc_mch ? z : sc_mch;
-			const int8_t un = (int8_t)(z - vt1), vn = (int8_t)(z - ut);
-			int8_t tmp = (int8_t)(z - q); a = (int8_t)(a - tmp); bb = (int8_t)(bb - tmp);
+			const int ge = right ? 1 : 0;
+			int d;
+			d = (a + ge > z) ? 1 : 0;  z = z > a ? z : a;
+			d = (bb + ge > z) ? 2 : d; z = z > bb ? z : bb;
+			d = (a2 + ge > z) ? 3 : d; z = z > a2 ? z : a2;
+			d = (b2 + ge > z) ? 4 : d; z = z > b2 ? z : b2;
+			z = z < (int)sc_mch ? z : (int)sc_mch;
+			const int un = (int8_t)(z - vt1), vn = (int8_t)(z - ut);
+			int tmp = (int8_t)(z - q); a = (int8_t)(a - tmp); bb = (int8_t)(bb - tmp);
 			tmp = (int8_t)(z - q2); a2 = (int8_t)(a2 - tmp); b2 = (int8_t)(b2 - tmp);
-			const bool pa = right ? a >= 0 : a > 0, pb = right ? bb >= 0 : bb > 0, pa2 = right ? a2 >= 0 : a2 > 0, pb2 = right ? b2 >= 0 : b2 > 0;
-			const int8_t xn = (int8_t)((pa ? a : 0) - qe_), yn = (int8_t)((pb ? bb : 0) - qe_);
-			const int8_t x2n = (int8_t)((pa2 ? a2 : 0) - qe2_), y2n = (int8_t)((pb2 ? b2 : 0) - qe2_);
+			const bool pa = a + ge > 0, pb = bb + ge > 0, pa2 = a2 + ge > 0, pb2 = b2 + ge > 0;
+			const int xn = (int8_t)((pa ? a : 0) - (int)qe_), yn = (int8_t)((pb ? bb : 0) - (int)qe_);
+			const int x2n = (int8_t)((pa2 ? a2 : 0) - (int)qe2_), y2n = (int8_t)((pb2 ? b2 : 0) - (int)qe2_);
 			d |= (pa ? 0x08 : 0) | (pb ? 0x10 : 0) | (pa2 ? 0x20 : 0) | (pb2 ? 0x40 : 0);
-			const uint32_t An = (uint32_t)(uint8_t)xn | (uint32_t)(uint8_t)vn << 8 | (uint32_t)(uint8_t)x2n << 16 | (uint32_t)(uint8_t)un << 24;
-			const uint32_t Bn = (b_old & 0xffff0000u) | (uint32_t)(uint8_t)yn | (uint32_t)(uint8_t)y2n << 8;
+			const uint32_t An = ((uint32_t)xn & 0xffu) | ((uint32_t)vn & 0xffu) << 8 | ((uint32_t)x2n & 0xffu) << 16 | (uint32_t)un << 24;
+			const uint32_t Bn = (b_old & 0xffff0000u) | ((uint32_t)yn & 0xffu) | ((uint32_t)y2n & 0xffu) << 8;
 			A[b] = act ? An : A[b]; B[b] = act ? Bn : B[b];
-			if (act && !((P.dbg >> 23) & 1)) pr[t] = (uint8_t)d;
+			if (store_p) { if (NB >= 4 || act) pr[t] = (uint8_t)d; }
 			// ---- exact max (:307-349): H row update and this lane's candidate
 			{
 				const int hold = H[b];
-				const int hl = (NB == 1 || b == be) ? d_dpp_shr1(hprev15, hold) : 0;      // H[r-1][t-1]
+				const int hl = d_dpp_shr1(hprev15, hold);                       // H[r-1][t-1]; consumed by the lane t == en0 only
 				const bool inr = act && r > 0 && t >= st0 && t <= en0;
 				const bool r0c = act && r == 0 && t == 0;
 				const bool isen = t == en0;
-				int h = isen ? (en0 > 0 ? hl + un : hold + vn) : hold + vn;
-				h = r0c ? (int)vn - qe : h;
-				const int ord = isen || r0c ? 0 : (t < en1 ? 1 + ((t - st0) & 3) * 4096 + ((t - st0) >> 2) : 1 + 4 * 4096 + (t - en1));
-				H[b] = (inr || r0c) ? h : hold;
-				if (NB <= 4) { const int k2 = h * 65536 + (0xffff - ord); key32 = ((inr || r0c) && k2 > key32) ? k2 : key32; }
-				else { const long long k2 = (long long)h * 65536 + (0xffff - ord); key = ((inr || r0c) && k2 > key) ? k2 : key; }
+				const int h_v = hold + vn, h_u = hl + un, h_0 = vn - qe;
+				int h = (isen && en0 > 0) ? h_u : h_v;
+				h = r0c ? h_0 : h;
+				const int dt = t - st0;
+				const int ord_a = 1 + (dt & 3) * 4096 + (dt >> 2), ord_b = 1 + 4 * 4096 + (t - en1);
+				int ord = t < en1 ? ord_a : ord_b;
+				ord = (isen || r0c) ? 0 : ord;
+				const bool upd = inr || r0c;
+				H[b] = upd ? h : hold;
+				if (NB <= 4) { const int k2 = h * 65536 + (0xffff - ord); key32 = (upd && k2 > key32) ? k2 : key32; }
+				else { const long long k2 = (long long)h * 65536 + (0xffff - ord); key = (upd && k2 > key) ? k2 : key; }
 			}
 		}
 		int max_H, max_t;

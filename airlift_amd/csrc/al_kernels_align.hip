@@ -1042,7 +1042,16 @@ k_ext_dp(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_of
 	GroupWs ws;
 	{ uint8_t *base = gws + ((size_t)blockIdx.x * 4 + g) * gws_stride; ws.p = base; ws.cig = (uint32_t *)(base + p_bytes); ws.ezc = ws.cig + cig_words; ws.sc = nullptr; ws.dbg = G.dbg; ws.cur_cig = nullptr; ws.cur_cig_cap = 0; ws.cur_ezc = nullptr; }
 	const int bw = (int)(P.bw * 1.5 + 1.);
-	for (uint32_t jj = blockIdx.x * 4 + g; jj < count; jj += gridDim.x * 4) {
+	// jobs are handed out largest first from a shared cursor, four neighbours of the size-sorted list per wavefront:
+	// the grid is as large as the chip holds resident and no wavefront is left with a long tail
+	unsigned long long *cursor = E.hist + 10 + (NB == 1 ? 0 : NB == 2 ? 1 : NB == 4 ? 2 : NB == 8 ? 3 : 4);
+	for (;;) {
+		unsigned long long base = 0;
+		if (threadIdx.x == 0) base = atomicAdd(cursor, 4ULL);
+		base = __shfl(base, 0);
+		if (base >= count) break;
+		if (base + g >= count) continue;
+		const uint32_t jj = count - 1 - ((uint32_t)base + g);
 		const uint32_t j = sorted_idx[first + jj];
 		const ExtJob job = E.jobs[j];
 		const int ql = job.qlen, tl = job.tlen;
@@ -1592,7 +1601,8 @@ int al_run_align_stage(al_ctx_t *c)
 				} else if (cls < 8) {
 					const int NB = NBs[cls - 3];
 					const size_t pb = (((size_t)(Lmax + 16 * NB) * (size_t)(NB + 1) * 16) + 63) / 64 * 64, cw = ((size_t)(Lmax + 16 * NB) + 31) / 16 * 16, st2 = pb + cw * 8;
-					int nbj = (int)((cnt + 3) / 4); if (nbj > 2048) nbj = 2048;
+					int nbj = (int)((cnt + 3) / 4); { static const int caps[3] = { getenv("AL_CAP4") ? atoi(getenv("AL_CAP4")) : 4096, getenv("AL_CAP8") ? atoi(getenv("AL_CAP8")) : 3072, getenv("AL_CAP22") ? atoi(getenv("AL_CAP22")) : 2048 };
+					  const int cap = NB <= 4 ? caps[0] : NB <= 8 ? caps[1] : caps[2]; if (nbj > cap) nbj = cap; }
 					if (A->gws.ensure((size_t)nbj * 4 * st2 + 64)) return -1;
 #define LAUNCH_DP(NBV) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ext_dp<NBV, 512, NBV * 16>), dim3(nbj), dim3(64), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, G, E, A->job_idx2.p, first, cnt, A->gws.p, st2, pb, cw, c->P)
 					if (NB == 1) LAUNCH_DP(1); else if (NB == 2) LAUNCH_DP(2); else if (NB == 4) LAUNCH_DP(4); else if (NB == 8) LAUNCH_DP(8); else LAUNCH_DP(22);
