@@ -16,7 +16,8 @@ class AirliftError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(HERE, "lib", "libairlift.so")
+    # AIRLIFT_LIB: another build of the same library (A/B timing of kernel variants on one GPU box)
+    return os.environ.get("AIRLIFT_LIB") or os.path.join(HERE, "lib", "libairlift.so")
 
 
 def build(verbose=False):

@@ -106,8 +106,7 @@ __device__ __forceinline__ void d_ksw_reg(LT &L, const int gl, GroupWs &ws, int 
 		const int tend = tlen_ * 16;
 		const int qclamp = qlen_ * 16 + 31;
 		const bool store_p = !((P.dbg >> 23) & 1);
-		long long key = (long long)0x8000000000000000ULL;            // this lane's best (H<<16 | 0xffff-ord); 32-bit form for NB <= 4
-		int key32 = (int)0x80000000;
+		int key32 = (int)0x80000000;                                     // this lane's best (H<<16 | 0xffff-ord)
 		// The block body is straight-line code: every condition below is uniform inside a 16-lane group but differs between
 		// the four groups of a wavefront, so each `if` would cost an exec-mask round trip per block.  Only two branches
 		// remain: skipping a block no group-lane needs, and the timing-experiment switch around the traceback store.
@@ -171,26 +170,19 @@ __device__ __forceinline__ void d_ksw_reg(LT &L, const int gl, GroupWs &ws, int 
 				ord = (isen || r0c) ? 0 : ord;
 				const bool upd = inr || r0c;
 				H[b] = upd ? h : hold;
-				if (NB <= 4) { const int k2 = h * 65536 + (0xffff - ord); key32 = (upd && k2 > key32) ? k2 : key32; }
-				else { const long long k2 = (long long)h * 65536 + (0xffff - ord); key = (upd && k2 > key) ? k2 : key; }
+				{ const int k2 = h * 65536 + (0xffff - ord); key32 = (upd && k2 > key32) ? k2 : key32; }
 			}
 		}
 		int max_H, max_t;
 		{
 			int ord;
-			if (NB <= 4) {                                                   // |H| < 2^15 for targets of <= 64 bases
+			{   // |H| < 2^15 on this path (targets <= 352, queries <= 512 bases): H and the scan position share one 32-bit key
 				int k = key32;
 				{ const int o = __builtin_amdgcn_update_dpp(k, k, DPP_QUAD_XOR1, 0xf, 0xf, false); k = o > k ? o : k; }
 				{ const int o = __builtin_amdgcn_update_dpp(k, k, DPP_QUAD_XOR2, 0xf, 0xf, false); k = o > k ? o : k; }
 				{ const int o = __builtin_amdgcn_update_dpp(k, k, DPP_HALF_MIRROR, 0xf, 0xf, false); k = o > k ? o : k; }
 				{ const int o = __builtin_amdgcn_update_dpp(k, k, DPP_ROW_MIRROR, 0xf, 0xf, false); k = o > k ? o : k; }
 				max_H = k >> 16; ord = 0xffff - (k & 0xffff);
-			} else {
-				int lo = (int)(unsigned)(unsigned long long)key, hi = (int)((unsigned long long)key >> 32);
-				d_key_max_step<DPP_QUAD_XOR1>(lo, hi); d_key_max_step<DPP_QUAD_XOR2>(lo, hi);
-				d_key_max_step<DPP_HALF_MIRROR>(lo, hi); d_key_max_step<DPP_ROW_MIRROR>(lo, hi);
-				const long long kk = (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
-				max_H = (int)(kk >> 16); ord = 0xffff - (int)(kk & 0xffff);
 			}
 			max_t = r == 0 ? 0 : ord == 0 ? en0 : ord < 1 + 4 * 4096 ? st0 + ((ord - 1) & 4095) * 4 + ((ord - 1) >> 12) : en1 + (ord - 1 - 4 * 4096);
 		}

@@ -58,6 +58,12 @@ struct GroupWs {                    // per-group HBM scratch (+ the current loca
 	unsigned long long *dbg;        // debug records (differential DP check)
 	long long prof[8];              // AL_DBG bit 21: cycle accumulators [0] dp init [1] dp rows [2] backtrack [3] align1 other [4] post [5] stage-in [6] n_dp [7] n_rows
 };
+#ifndef AL_LB_DP8
+#define AL_LB_DP8 4
+#endif
+#ifndef AL_LB_DP22
+#define AL_LB_DP22 3
+#endif
 #ifndef AL_LB_REGS
 #define AL_LB_REGS 5
 #endif
@@ -1031,7 +1037,7 @@ template <int QMAXJ, int TMAXJ> struct JobLds {
 
 // DP jobs of one block-count class: 4 jobs per wavefront, all running d_ksw_reg<NB>
 template <int NB, int QMAXJ, int TMAXJ>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64, (NB <= 4 ? 4 : NB <= 8 ? AL_LB_DP8 : AL_LB_DP22))
 k_ext_dp(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_off, const uint32_t *__restrict__ rd_len,
          AlignShared G, ExtShared E, const uint32_t *__restrict__ sorted_idx, uint32_t first, uint32_t count,
          uint8_t *__restrict__ gws, size_t gws_stride, size_t p_bytes, size_t cig_words, AlParams P)
@@ -1601,7 +1607,7 @@ int al_run_align_stage(al_ctx_t *c)
 				} else if (cls < 8) {
 					const int NB = NBs[cls - 3];
 					const size_t pb = (((size_t)(Lmax + 16 * NB) * (size_t)(NB + 1) * 16) + 63) / 64 * 64, cw = ((size_t)(Lmax + 16 * NB) + 31) / 16 * 16, st2 = pb + cw * 8;
-					int nbj = (int)((cnt + 3) / 4); { static const int caps[3] = { getenv("AL_CAP4") ? atoi(getenv("AL_CAP4")) : 4096, getenv("AL_CAP8") ? atoi(getenv("AL_CAP8")) : 3072, getenv("AL_CAP22") ? atoi(getenv("AL_CAP22")) : 2048 };
+					int nbj = (int)((cnt + 3) / 4); { static const int caps[3] = { getenv("AL_CAP4") ? atoi(getenv("AL_CAP4")) : 4096, getenv("AL_CAP8") ? atoi(getenv("AL_CAP8")) : 4096, getenv("AL_CAP22") ? atoi(getenv("AL_CAP22")) : 3072 };
 					  const int cap = NB <= 4 ? caps[0] : NB <= 8 ? caps[1] : caps[2]; if (nbj > cap) nbj = cap; }
 					if (A->gws.ensure((size_t)nbj * 4 * st2 + 64)) return -1;
 #define LAUNCH_DP(NBV) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ext_dp<NBV, 512, NBV * 16>), dim3(nbj), dim3(64), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, G, E, A->job_idx2.p, first, cnt, A->gws.p, st2, pb, cw, c->P)
