@@ -714,11 +714,14 @@ k_regs(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__ u_all,
 	const int f = blockIdx.x * blockDim.x + threadIdx.x;
 	if (f >= n_frag) return;
 	const uint32_t r0 = frag_first[f], n_segs = frag_first[f + 1] - r0, n_u = W.frag_nu[f];
-	for (uint32_t s = 0; s < n_segs; ++s) { W.reg_cnt[r0 + s] = 0; W.seg_na[r0 + s] = 0; }
+	W.reg_cnt[r0] = 0; W.seg_na[r0] = 0;
+	if (n_segs > 1) { W.reg_cnt[r0 + 1] = 0; W.seg_na[r0 + 1] = 0; }
 	if (n_u == 0) return;
+	// NB: no array below is indexed by a run-time value (mate ids become two-way selects, loops over the <= 2 mates are
+	// unrolled): a dynamically indexed local array would live in scratch memory, whose lines compete with the data for L2.
 	FragWs ws; d_frag_ws(W, f, ws);
-	int qlens[2] = {0, 0}, qlen_sum = 0;
-	for (uint32_t s = 0; s < n_segs; ++s) { qlens[s] = (int)rd_len[r0 + s]; qlen_sum += qlens[s]; }
+	const int ql0 = (int)rd_len[r0], ql1 = n_segs > 1 ? (int)rd_len[r0 + 1] : 0;
+	const int qlens[2] = {ql0, ql1}, qlen_sum = ql0 + ql1;
 	const AlAnchor *a = chained + W.a_off[f]; const uint64_t *u = u_all + W.a_off[f] + f;
 	const uint32_t hash = frag_hash[f];
 	int max_gap_ref;
@@ -730,40 +733,55 @@ k_regs(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__ u_all,
 	d_set_parent(P.mask_level, n0, ws.regs0, P.a * 2 + P.b, ws.aux64, ws.auxi);                       // chain_post, map.c:249-258
 	if (n_segs <= 1) d_select_sub(P.pri_ratio, P.k * 2, P.best_n, &n0, ws.regs0, ws.auxi);
 	else d_select_sub_multi(P.pri_ratio, 0.2f, 0.7f, max_gap_ref, P.k * 2, P.best_n, (int)n_segs, qlens, &n0, ws.regs0, ws.auxi);
+	AlReg *const mreg0 = ws.mreg[0], *const mreg1 = ws.mreg[1];
+	uint64_t *const su0 = ws.seg_u[0], *const su1 = ws.seg_u[1];
+	AlAnchor *const sa0 = ws.seg_a[0];
 	if (n_segs == 1) {
-		for (int i = 0; i < n0; ++i) ws.mreg[0][i] = ws.regs0[i];
-		AlAnchor *sa = ws.seg_a[0];
+		for (int i = 0; i < n0; ++i) mreg0[i] = ws.regs0[i];
 		uint32_t tot = 0; for (uint32_t i = 0; i < n_u; ++i) tot += (uint32_t)u[i];
-		for (uint32_t i = 0; i < tot; ++i) sa[i] = a[i];
-		const int na = d_squeeze_a(n0, ws.mreg[0], sa, ws.aux64);                                     // mm_align_skeleton, align.c:873
+		for (uint32_t i = 0; i < tot; ++i) sa0[i] = a[i];
+		const int na = d_squeeze_a(n0, mreg0, sa0, ws.aux64);                                         // mm_align_skeleton, align.c:873
 		W.reg_cnt[r0] = (uint32_t)n0; W.seg_na[r0] = (uint32_t)na;
 	} else {
 		// mm_seg_gen, hit.c:356-410
-		int acc_qlen[2] = {0, qlens[0]}; uint32_t n_a[2] = {0, 0}, n_us[2] = {0, 0};
-		for (int s = 0; s < 2; ++s) for (int i = 0; i < n0; ++i) ws.seg_u[s][i] = (uint64_t)(uint32_t)ws.regs0[i].score << 32;
+		uint32_t na0 = 0, na1 = 0, nus0 = 0, nus1 = 0;
 		for (int i = 0; i < n0; ++i) {
 			const AlReg *r = &ws.regs0[i];
-			for (int j = 0; j < r->cnt; ++j) { const int sid = (int)((a[r->as + j].y & AL_SEED_SEG_MASK) >> AL_SEED_SEG_SHIFT); ++ws.seg_u[sid][i]; ++n_a[sid]; }
+			uint32_t c1 = 0;
+			for (int j = 0; j < r->cnt; ++j) c1 += (uint32_t)((a[r->as + j].y & AL_SEED_SEG_MASK) >> AL_SEED_SEG_SHIFT) & 1u;
+			const uint32_t c0 = (uint32_t)r->cnt - c1;
+			su0[i] = (uint64_t)(uint32_t)r->score << 32 | c0; su1[i] = (uint64_t)(uint32_t)r->score << 32 | c1;
+			na0 += c0; na1 += c1;
 		}
-		ws.seg_a[1] = ws.seg_a[0] + n_a[0];
-		for (int s = 0; s < 2; ++s) { for (int i = 0; i < n0; ++i) if ((int32_t)ws.seg_u[s][i] != 0) ws.seg_u[s][n_us[s]++] = ws.seg_u[s][i]; n_a[s] = 0; }
+		AlAnchor *const sa1 = sa0 + na0;
+		for (int i = 0; i < n0; ++i) { if ((int32_t)su0[i] != 0) su0[nus0++] = su0[i]; if ((int32_t)su1[i] != 0) su1[nus1++] = su1[i]; }
+		uint32_t w0 = 0, w1 = 0;
 		for (int i = 0; i < n0; ++i) {
 			const AlReg *r = &ws.regs0[i];
 			for (int j = 0; j < r->cnt; ++j) {
-				AlAnchor a1 = a[r->as + j]; const int sid = (int)((a1.y & AL_SEED_SEG_MASK) >> AL_SEED_SEG_SHIFT);
-				a1.y -= (a1.x >> 63) ? (uint64_t)(qlen_sum - (qlens[sid] + acc_qlen[sid])) : (uint64_t)acc_qlen[sid];
-				ws.seg_a[sid][n_a[sid]++] = a1;
+				AlAnchor a1 = a[r->as + j]; const bool s1 = ((a1.y & AL_SEED_SEG_MASK) >> AL_SEED_SEG_SHIFT) & 1;
+				const int qls = s1 ? ql1 : ql0, acc = s1 ? ql0 : 0;
+				a1.y -= (a1.x >> 63) ? (uint64_t)(qlen_sum - (qls + acc)) : (uint64_t)acc;
+				if (s1) sa1[w1++] = a1; else sa0[w0++] = a1;
 			}
 		}
-		for (int s = 0; s < 2; ++s) {
-			tie = d_gen_regs(hash, qlens[s], (int)n_us[s], ws.seg_u[s], ws.seg_a[s], ws.mreg[s], ws.aux128) || tie;
-			int n = (int)n_us[s];
-			for (int i = 0; i < n; ++i) ws.mreg[s][i].flags |= ALR_SEG_SPLIT | ((uint32_t)s << 8);
-			d_set_parent(P.mask_level, n, ws.mreg[s], P.a * 2 + P.b, ws.aux64, ws.auxi);                // map.c:401
-			const int na = d_squeeze_a(n, ws.mreg[s], ws.seg_a[s], ws.aux64);                           // align.c:873
-			W.reg_cnt[r0 + s] = (uint32_t)n; W.seg_na[r0 + s] = (uint32_t)na;
+		{
+			tie = d_gen_regs(hash, ql0, (int)nus0, su0, sa0, mreg0, ws.aux128) || tie;
+			const int n = (int)nus0;
+			for (int i = 0; i < n; ++i) mreg0[i].flags |= ALR_SEG_SPLIT;
+			d_set_parent(P.mask_level, n, mreg0, P.a * 2 + P.b, ws.aux64, ws.auxi);                     // map.c:401
+			const int na = d_squeeze_a(n, mreg0, sa0, ws.aux64);                                        // align.c:873
+			W.reg_cnt[r0] = (uint32_t)n; (void)na;
 		}
-		W.seg_na[r0] = n_a[0];   // seg_a[1] starts n_a[0] anchors after seg_a[0] (kept un-squeezed size for addressing)
+		{
+			tie = d_gen_regs(hash, ql1, (int)nus1, su1, sa1, mreg1, ws.aux128) || tie;
+			const int n = (int)nus1;
+			for (int i = 0; i < n; ++i) mreg1[i].flags |= ALR_SEG_SPLIT | (1u << 8);
+			d_set_parent(P.mask_level, n, mreg1, P.a * 2 + P.b, ws.aux64, ws.auxi);
+			const int na = d_squeeze_a(n, mreg1, sa1, ws.aux64);
+			W.reg_cnt[r0 + 1] = (uint32_t)n; W.seg_na[r0 + 1] = (uint32_t)na;
+		}
+		W.seg_na[r0] = na0;   // seg_a[1] starts na0 anchors after seg_a[0] (kept un-squeezed size for addressing)
 	}
 	if (tie) atomicAdd(&counters[10], 1ULL);
 }
@@ -925,19 +943,21 @@ k_ext_prep(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_
            const uint32_t *__restrict__ frag_first, WsBase W, AlignShared G, ExtShared E, int n_frag, AlParams P, int tmax, int qmax)
 {
 	const int f = blockIdx.x * blockDim.x + threadIdx.x;
-	unsigned cls_cnt[AL_NCLS + 1] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+	__shared__ unsigned s_hist[AL_NCLS + 1];                                   // jobs per class of this block (no run-time indexed local arrays: see k_regs)
+	if (threadIdx.x <= AL_NCLS) s_hist[threadIdx.x] = 0;
+	__syncthreads();
 	const int lane_ok = !((P.dbg >> 29) & 1);
 	if (f < n_frag && W.frag_nu[f] != 0) {
 		const uint32_t r0 = frag_first[f], n_segs = frag_first[f + 1] - r0;
 		FragWs fw; d_frag_ws(W, (uint32_t)f, fw);
-		if (n_segs == 2) fw.seg_a[1] = fw.seg_a[0] + W.seg_na[r0];
 		const uint64_t B2 = (uint64_t)(fw.mreg[0] - W.mregs);      // index of mreg[0][0] in the hit array == index into rext
 		uint32_t jb = (uint32_t)E.job_off[f]; bool slow = false;
-		for (uint32_t s = 0; s < n_segs && !slow; ++s) {
+		AlReg *const mreg0 = fw.mreg[0], *const mreg1 = fw.mreg[1];
+		AlAnchor *const sa0 = fw.seg_a[0], *const sa1 = n_segs == 2 ? fw.seg_a[0] + W.seg_na[r0] : nullptr;
+		auto do_seg = [&](const uint32_t s, const AlReg *regs, const AlAnchor *a) {
 			const int qlen = (int)rd_len[r0 + s], n = (int)W.reg_cnt[r0 + s];
 			const uint32_t *seq = rd_seq + rd_off[r0 + s];
-			const AlReg *regs = fw.mreg[s]; const AlAnchor *a = fw.seg_a[s];
-			if (n > 0 && qlen > qmax) { atomicAdd(&G.counters[7], 1ULL << 0); slow = true; break; }
+			if (n > 0 && qlen > qmax) { atomicAdd(&G.counters[7], 1ULL << 0); slow = true; return; }
 			for (int i = 0; i < n; ++i, jb += 2) {
 				const AlReg *r = &regs[i]; RegExt x; ExtJob jl, jr;
 				jl.qlen = jl.tlen = 0; jr.qlen = jr.tlen = 0; jl.pad0 = jl.pad1 = jr.pad0 = jr.pad1 = 0; jl.pad2 = jr.pad2 = 0;
@@ -957,7 +977,7 @@ k_ext_prep(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_
 					l = qlen - qe;
 					l += l * P.a + P.end_bonus > P.q ? (l * P.a + P.end_bonus - P.q) / P.e : 0;
 					const int32_t re0 = re + l < ref_len ? re + l : ref_len;
-					if (re0 - rs0 > tmax) { atomicAdd(&G.counters[7], 1ULL << 8); slow = true; break; }
+					if (re0 - rs0 > tmax) { atomicAdd(&G.counters[7], 1ULL << 8); slow = true; return; }
 					// ungapped core (align.c:724-731) + mm_test_zdrop with the single 'M' op (align.c:47-89)
 					const ReadAcc Q{seq, qlen, rev, qs}; const RefAcc T{G.S4, ref_off + (uint64_t)rs};
 					const int len = qe - qs; int sc = 0, zs = 0, zmax = INT32_MIN, zmi = -1, zdrop_max = 0;
@@ -968,7 +988,7 @@ k_ext_prep(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_
 						if (zs < zmax) { const int z = zmax - zs; (void)zmi; if (z > zdrop_max) zdrop_max = z; }   // diff = 0 along the diagonal
 						else { zmax = zs; zmi = k; }
 					}
-					if (zdrop_max > P.zdrop) { slow = true; break; }              // needs the second DP pass / split: monolithic path
+					if (zdrop_max > P.zdrop) { slow = true; return; }             // needs the second DP pass / split: monolithic path
 					x.rs = rs; x.qs = qs; x.re = re; x.qe = qe; x.rs0 = rs0; x.re0 = re0; x.core_score = sc;
 					if (qs > 0 && rs > 0) {                                       // left extension job (align.c:690-705)
 						jl.qlen = (uint16_t)qs; jl.tlen = (uint16_t)(rs - rs0); jl.rev = (uint8_t)rev;
@@ -986,46 +1006,44 @@ k_ext_prep(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_
 				if (!((P.dbg >> 31) & 1) && r->cnt > 0) {
 					const int32_t rid2 = (int32_t)(a[r->as].x << 1 >> 33), rev2 = (int32_t)(a[r->as].x >> 63);
 					const uint64_t ref_off2 = G.seq_off[rid2];
-					for (int side = 0; side < 2; ++side) {
-						ExtJob &jj = side == 0 ? jl : jr;
-						const int ql = jj.qlen, tl = jj.tlen;
-						if (ql == 0 || ql > tl) continue;
-						const ReadAcc Qa{seq, qlen, rev2, 0}; const RefAcc Ta{G.S4, ref_off2};
-						int sc = 0, mx = 0, pos = -1, nmm = 0; bool ok = true;
+					const ReadAcc Qa{seq, qlen, rev2, 0}; const RefAcc Ta{G.S4, ref_off2};
+					auto shortcut = [&](const int side, const int ql, const int tl) -> bool {
+						if (ql == 0 || ql > tl) return false;
+						int sc = 0, mx = 0, pos = -1, nmm = 0;
 						for (int k = 0; k < ql; ++k) {
 							const int cq = side == 0 ? Qa(x.qs - 1 - k) : Qa(x.qe + k);
 							const int ct = side == 0 ? Ta(x.rs - 1 - k) : Ta(x.re + k);
-							if (cq > 3 || ct > 3) { ok = false; break; }
-							if (cq == ct) sc += P.a; else { sc -= P.b; if (++nmm > 1) { ok = false; break; } }
+							if (cq > 3 || ct > 3) return false;
+							if (cq == ct) sc += P.a; else { sc -= P.b; if (++nmm > 1) return false; }
 							if (sc > mx) { mx = sc; pos = k; }
 						}
-						if (!ok) continue;
 						const bool reach = sc + P.end_bonus > mx;
 						const int ncig = (reach || pos >= 0) ? 1 : 0;
 						ExtOut o; o.max = mx; o.max_q = pos; o.max_t = pos; o.mqe_t = ql - 1;
 						o.flags_ncig = (uint32_t)(reach ? 1 : 0) | (uint32_t)ncig << 8; o.cig_off = 0;
 						o.cig[0] = ncig ? (uint32_t)(reach ? ql : pos + 1) << 4 : 0; o.cig[1] = o.cig[2] = o.cig[3] = o.cig[4] = o.cig[5] = 0;
 						E.outs[jb + side] = o;
-						jj.pad0 = 1;
-					}
+						return true;
+					};
+					if (shortcut(0, jl.qlen, jl.tlen)) jl.pad0 = 1;
+					if (shortcut(1, jr.qlen, jr.tlen)) jr.pad0 = 1;
 				}
 				E.rext[B2 + (uint64_t)s * fw.cap + i] = x;
 				E.jobs[jb] = jl; E.jobs[jb + 1] = jr;
 				{ const int c0 = (jl.qlen && !jl.pad0) ? d_job_class(jl.qlen, jl.tlen, lane_ok) : AL_NCLS, c1 = (jr.qlen && !jr.pad0) ? d_job_class(jr.qlen, jr.tlen, lane_ok) : AL_NCLS;
 				  E.job_key[jb] = c0 < AL_NCLS ? ((uint32_t)c0 << 20 | (uint32_t)(jl.qlen + jl.tlen)) : 0xffffffffu;
 				  E.job_key[jb + 1] = c1 < AL_NCLS ? ((uint32_t)c1 << 20 | (uint32_t)(jr.qlen + jr.tlen)) : 0xffffffffu;
-				  ++cls_cnt[c0]; ++cls_cnt[c1]; }
+				  atomicAdd(&s_hist[c0], 1u); atomicAdd(&s_hist[c1], 1u); }
 			}
-		}
+		};
+		do_seg(0, mreg0, sa0);
+		if (n_segs == 2 && !slow) do_seg(1, mreg1, sa1);
 		// unused job slots of this fragment (a slow fragment stops early): mark empty
-		for (uint32_t j = jb; j < (uint32_t)E.job_off[f + 1]; ++j) { E.job_key[j] = 0xffffffffu; ExtJob z; z.qlen = z.tlen = 0; z.toff = 0; z.read = 0; z.qoff = 0; z.rev = z.kind = z.pad0 = z.pad1 = 0; z.pad2 = 0; E.jobs[j] = z; ++cls_cnt[AL_NCLS]; }
+		for (uint32_t j = jb; j < (uint32_t)E.job_off[f + 1]; ++j) { E.job_key[j] = 0xffffffffu; ExtJob z; z.qlen = z.tlen = 0; z.toff = 0; z.read = 0; z.qoff = 0; z.rev = z.kind = z.pad0 = z.pad1 = 0; z.pad2 = 0; E.jobs[j] = z; atomicAdd(&s_hist[AL_NCLS], 1u); }
 		E.frag_slow[f] = slow ? 1u : 0u;
 	} else if (f < n_frag) E.frag_slow[f] = 0;
-	for (int c = 0; c <= AL_NCLS; ++c) {                                       // one atomic per wavefront and class
-		unsigned v = cls_cnt[c];
-		for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
-		if ((threadIdx.x & 63) == 0 && v) atomicAdd(&E.hist[c], (unsigned long long)v);
-	}
+	__syncthreads();
+	if (threadIdx.x <= AL_NCLS && s_hist[threadIdx.x]) atomicAdd(&E.hist[threadIdx.x], (unsigned long long)s_hist[threadIdx.x]);   // one atomic per block and class
 }
 
 template <int QMAXJ, int TMAXJ> struct JobLds {

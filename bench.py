@@ -142,6 +142,7 @@ def main():
     t_index = time.time() - t0
     arr = make_workload(a.pairs, a.read_len, 20261002 + 7919 * rank, ref)
     ctx = A.Context(idx, device=local if world > 1 else 0)
+    L.al_ctx_set_threads(ctx.h, min(32, os.cpu_count() or 1))       # host packing threads (outside the timed region)
     nf = a.pairs
     n_segs = (C.c_int * nf)(*([2] * nf)); qlens = (C.c_int * (2 * nf))(*([a.read_len] * (2 * nf)))
     t0 = time.time()
