@@ -355,8 +355,8 @@ __device__ int d_test_zdrop(const AlParams &P, QA qseq, TA tseq, int n_cigar, co
 	return max_zdrop > P.zdrop ? 1 : 0;
 }
 
-template <class QA, class TA>
-__device__ void d_fix_cigar(AlReg *r, uint32_t *cigar, QA qseq, TA tseq, int *qshift, int *tshift)
+template <class CG, class QA, class TA>
+__device__ __forceinline__ void d_fix_cigar(AlReg *r, CG cigar, QA qseq, TA tseq, int *qshift, int *tshift)
 {   // mm_fix_cigar, align.c:91-167
 	int toff = 0, qoff = 0, to_shrink = 0; uint32_t k;
 	*qshift = *tshift = 0;
@@ -378,14 +378,13 @@ __device__ void d_fix_cigar(AlReg *r, uint32_t *cigar, QA qseq, TA tseq, int *qs
 	}
 	for (k = 0; k + 2 < r->n_cigar; ++k) {
 		if ((cigar[k] & 0xf) > 0 && (cigar[k] & 0xf) + (cigar[k + 1] & 0xf) == 3) {
-			uint32_t l, s[3] = {0, 0, 0};
+			uint32_t l, s1 = 0, s2 = 0;
 			for (l = k; l < r->n_cigar; ++l) {
-				const uint32_t op = cigar[l] & 0xf;
-				if (op == 1 || op == 2 || cigar[l] >> 4 == 0) s[op] += cigar[l] >> 4;
-				else break;
+				const uint32_t cl = cigar[l], op = cl & 0xf;
+				if (op == 1) s1 += cl >> 4; else if (op == 2) s2 += cl >> 4; else if (cl >> 4 != 0) break;
 			}
-			if (s[1] > 0 && s[2] > 0 && l - k > 2) {
-				cigar[k] = s[1] << 4 | 1; cigar[k + 1] = s[2] << 4 | 2;
+			if (s1 > 0 && s2 > 0 && l - k > 2) {
+				cigar[k] = s1 << 4 | 1; cigar[k + 1] = s2 << 4 | 2;
 				for (k += 2; k < l; ++k) cigar[k] &= 0xf;
 				to_shrink = 1;
 			}
@@ -410,8 +409,8 @@ __device__ void d_fix_cigar(AlReg *r, uint32_t *cigar, QA qseq, TA tseq, int *qs
 	}
 }
 
-template <class QA, class TA>
-__device__ void d_update_extra(const AlParams &P, AlReg *r, uint32_t *cigar, QA qseq0_, TA tseq0_)
+template <class CG, class QA, class TA>
+__device__ __forceinline__ void d_update_extra(const AlParams &P, AlReg *r, CG cigar, QA qseq0_, TA tseq0_)
 {   // mm_update_extra, align.c:240-286
 	int s = 0, max = 0, qshift, tshift, toff = 0, qoff = 0;
 	d_fix_cigar(r, cigar, qseq0_, tseq0_, &qshift, &tshift);
@@ -604,16 +603,23 @@ __device__ __forceinline__ void d_align1(GroupLds<TMAX, QMAX> &L, const int gl, 
 
 // mm_pair, pe.c:76-177 (+ mm_set_pe_thru pe.c:45-64).  pa: scratch (n0+n1) x 3 words; sc: scratch u64
 struct PairEnt { uint64_t key; int32_t s, rev, idx; int32_t pad; };
-__device__ void d_pair(const AlParams &P, int max_gap_ref, const int *qlens, int *n_regs, AlReg *const *regs, PairEnt *pa, uint64_t *sc, int sc_cap, const AlLogTab &lt, bool *tie, bool *ovf)
+// mm_pair + mm_set_pe_thru (pe.c:45-177).  Mate ids, strands and the two hit arrays are selected with two-way selects
+// instead of indexing small local arrays by run-time values: those arrays would be placed in scratch memory.
+__device__ __forceinline__ void d_pair2(const AlParams &P, int max_gap_ref, const int ql0, const int ql1, const int n0, const int n1, AlReg *const regs0, AlReg *const regs1,
+                                        PairEnt *pa, uint64_t *sc, int sc_cap, const AlLogTab &lt, bool *tie, bool *ovf)
 {
 	const int sub_diff = P.a * 2 + P.b, match_sc = P.a;
 	int n = 0, dp_thres = 0, segs = 0;
+#define RG(s_) ((s_) ? regs1 : regs0)
+#define NR(s_) ((s_) ? n1 : n0)
+#pragma unroll
 	for (int s = 0; s < 2; ++s) {
 		int mx = 0;
-		for (int i = 0; i < n_regs[s]; ++i) {
-			const AlReg *r = &regs[s][i];
-			pa[n].s = s; pa[n].idx = i; pa[n].rev = (r->flags & ALR_REV) ? 1 : 0;
-			pa[n].key = (uint64_t)(uint32_t)r->rid << 32 | (uint64_t)(uint32_t)(r->rs << 1) | (uint64_t)(s ^ pa[n].rev);
+		for (int i = 0; i < NR(s); ++i) {
+			const AlReg *r = &RG(s)[i];
+			PairEnt e; e.s = s; e.idx = i; e.rev = (r->flags & ALR_REV) ? 1 : 0;
+			e.key = (uint64_t)(uint32_t)r->rid << 32 | (uint64_t)(uint32_t)(r->rs << 1) | (uint64_t)(s ^ e.rev);
+			pa[n] = e;
 			mx = mx > r->dp_max ? mx : r->dp_max;
 			++n; segs |= 1 << s;
 		}
@@ -624,63 +630,75 @@ __device__ void d_pair(const AlParams &P, int max_gap_ref, const int *qlens, int
 		// radix_sort_pair: stable insertion sort for n <= 64 (ksort.h:149)
 		for (int i = 1; i < n; ++i) if (pa[i].key < pa[i - 1].key) { PairEnt t = pa[i]; int j = i; for (; j > 0 && t.key < pa[j - 1].key; --j) pa[j] = pa[j - 1]; pa[j] = t; }
 		if (n > 64) { for (int i = 1; i < n; ++i) if (pa[i].key == pa[i - 1].key) *tie = true; }
-		long long max = -1; int max_idx[2] = {-1, -1}, last[2] = {-1, -1}; int n_sc = 0;
-#define PR(e) (&regs[(e).s][(e).idx])
+		long long max = -1; int max_idx0 = -1, max_idx1 = -1, last0 = -1, last1 = -1; int n_sc = 0;
+#define PR(e) (&RG((e).s)[(e).idx])
 		for (int i = 0; i < n; ++i) {
-			if (pa[i].key & 1) {
-				if (last[pa[i].rev] < 0) continue;
-				const AlReg *r = PR(pa[i]), *q = PR(pa[last[pa[i].rev]]);
+			const PairEnt ei = pa[i];
+			if (ei.key & 1) {
+				const int lst = ei.rev ? last1 : last0;
+				if (lst < 0) continue;
+				const AlReg *r = PR(ei), *q = PR(pa[lst]);
 				if (r->rid != q->rid || r->rs - q->re > max_gap_ref) continue;
-				for (int j = last[pa[i].rev]; j >= 0; --j) {
-					if (pa[j].rev != pa[i].rev || pa[j].s == pa[i].s) continue;
-					q = PR(pa[j]);
+				for (int j = lst; j >= 0; --j) {
+					const PairEnt ej = pa[j];
+					if (ej.rev != ei.rev || ej.s == ei.s) continue;
+					q = PR(ej);
 					if (r->rid != q->rid || r->rs - q->re > max_gap_ref) break;
 					if (r->dp_max + q->dp_max < dp_thres) continue;
 					const long long score = (long long)((uint64_t)(uint32_t)(r->dp_max + q->dp_max) << 32 | (uint32_t)(r->hash + q->hash));
-					if (score > max) { max = score; max_idx[pa[j].s] = j; max_idx[pa[i].s] = i; }
+					if (score > max) { max = score; if (ej.s) max_idx1 = j; else max_idx0 = j; if (ei.s) max_idx1 = i; else max_idx0 = i; }
 					if (n_sc < sc_cap) sc[n_sc++] = (uint64_t)score; else *ovf = true;
 				}
-			} else last[pa[i].rev] = i;
+			} else { if (ei.rev) last1 = i; else last0 = i; }
 		}
 		if (n_sc > 1) d_sort64(sc, n_sc);
 		if (n_sc > 0 && max > 0) {
-			int n_sub = 0, mapq_pe; AlReg *r[2];
-			r[0] = PR(pa[max_idx[0]]); r[1] = PR(pa[max_idx[1]]);
-			r[0]->flags |= ALR_PROPER; r[1]->flags |= ALR_PROPER;
+			int n_sub = 0, mapq_pe;
+			AlReg *const ra = PR(pa[max_idx0]), *const rb = PR(pa[max_idx1]);
+			ra->flags |= ALR_PROPER; rb->flags |= ALR_PROPER;
+#pragma unroll
 			for (int s = 0; s < 2; ++s) {
-				if (r[s]->id != r[s]->parent) {
-					AlReg *p = &regs[s][r[s]->parent];
-					for (int i = 0; i < n_regs[s]; ++i) if (regs[s][i].parent == p->id) regs[s][i].parent = r[s]->id;
+				AlReg *const rs_ = s ? rb : ra;
+				if (rs_->id != rs_->parent) {
+					AlReg *p = &RG(s)[rs_->parent];
+					for (int i = 0; i < NR(s); ++i) if (RG(s)[i].parent == p->id) RG(s)[i].parent = rs_->id;
 					p->mapq = 0;
 				}
-				if (!(r[s]->flags & ALR_SAM_PRI)) {
-					for (int i = 0; i < n_regs[s]; ++i) regs[s][i].flags &= ~ALR_SAM_PRI;
-					r[s]->flags |= ALR_SAM_PRI;
+				if (!(rs_->flags & ALR_SAM_PRI)) {
+					for (int i = 0; i < NR(s); ++i) RG(s)[i].flags &= ~ALR_SAM_PRI;
+					rs_->flags |= ALR_SAM_PRI;
 				}
 			}
-			mapq_pe = r[0]->mapq > r[1]->mapq ? (int)r[0]->mapq : (int)r[1]->mapq;
+			mapq_pe = ra->mapq > rb->mapq ? (int)ra->mapq : (int)rb->mapq;
 			for (int i = 0; i < n_sc; ++i) if ((sc[i] >> 32) + sub_diff >= (uint64_t)max >> 32) ++n_sub;
 			if (n_sc > 1) {
 				const uint64_t diff = (uint64_t)(max >> 32) - (sc[n_sc - 2] >> 32);
 				const int mapq_pe_alt = (int)__fsub_rn(al_fdiv(__fmul_rn(6.02f, (float)diff), (float)match_sc), __fmul_rn(4.343f, al_logf_i(lt, n_sub)));
 				mapq_pe = mapq_pe < mapq_pe_alt ? mapq_pe : mapq_pe_alt;
 			}
-			for (int s = 0; s < 2; ++s)
-				if ((int)r[s]->mapq < mapq_pe) r[s]->mapq = (uint32_t)(int)__fadd_rn(__fadd_rn(__fmul_rn(.2f, (float)r[s]->mapq), __fmul_rn(.8f, (float)mapq_pe)), .499f) & 0xffu;
-			if (n_sc == 1) { if (r[0]->mapq < 2) r[0]->mapq = 2; if (r[1]->mapq < 2) r[1]->mapq = 2; }
-			else if ((uint64_t)max >> 32 > sc[n_sc - 2] >> 32) { if (r[0]->mapq < 1) r[0]->mapq = 1; if (r[1]->mapq < 1) r[1]->mapq = 1; }
+			if ((int)ra->mapq < mapq_pe) ra->mapq = (uint32_t)(int)__fadd_rn(__fadd_rn(__fmul_rn(.2f, (float)ra->mapq), __fmul_rn(.8f, (float)mapq_pe)), .499f) & 0xffu;
+			if ((int)rb->mapq < mapq_pe) rb->mapq = (uint32_t)(int)__fadd_rn(__fadd_rn(__fmul_rn(.2f, (float)rb->mapq), __fmul_rn(.8f, (float)mapq_pe)), .499f) & 0xffu;
+			if (n_sc == 1) { if (ra->mapq < 2) ra->mapq = 2; if (rb->mapq < 2) rb->mapq = 2; }
+			else if ((uint64_t)max >> 32 > sc[n_sc - 2] >> 32) { if (ra->mapq < 1) ra->mapq = 1; if (rb->mapq < 1) rb->mapq = 1; }
 		}
 #undef PR
 	}
 	// mm_set_pe_thru
-	int n_pri[2] = {0, 0}, pri[2] = {-1, -1};
-	for (int s = 0; s < 2; ++s) for (int i = 0; i < n_regs[s]; ++i) if (regs[s][i].id == regs[s][i].parent) { ++n_pri[s]; pri[s] = i; }
-	if (n_pri[0] == 1 && n_pri[1] == 1) {
-		AlReg *p = &regs[0][pri[0]], *q = &regs[1][pri[1]];
+	int n_pri0 = 0, n_pri1 = 0, pri0 = -1, pri1 = -1;
+	for (int i = 0; i < n0; ++i) if (regs0[i].id == regs0[i].parent) { ++n_pri0; pri0 = i; }
+	for (int i = 0; i < n1; ++i) if (regs1[i].id == regs1[i].parent) { ++n_pri1; pri1 = i; }
+	if (n_pri0 == 1 && n_pri1 == 1) {
+		AlReg *p = &regs0[pri0], *q = &regs1[pri1];
 		const int d1 = p->rs - q->rs, d2 = p->re - q->re;
 		if (p->rid == q->rid && (p->flags & ALR_REV) == (q->flags & ALR_REV) && (d1 < 0 ? -d1 : d1) < 3 && (d2 < 0 ? -d2 : d2) < 3
-		    && ((p->qs == 0 && qlens[1] - q->qe == 0) || (q->qs == 0 && qlens[0] - p->qe == 0))) { p->flags |= ALR_PE_THRU; q->flags |= ALR_PE_THRU; }
+		    && ((p->qs == 0 && ql1 - q->qe == 0) || (q->qs == 0 && ql0 - p->qe == 0))) { p->flags |= ALR_PE_THRU; q->flags |= ALR_PE_THRU; }
 	}
+#undef RG
+#undef NR
+}
+__device__ __forceinline__ void d_pair(const AlParams &P, int max_gap_ref, const int *qlens, int *n_regs, AlReg *const *regs, PairEnt *pa, uint64_t *sc, int sc_cap, const AlLogTab &lt, bool *tie, bool *ovf)
+{
+	d_pair2(P, max_gap_ref, qlens[0], qlens[1], n_regs[0], n_regs[1], regs[0], regs[1], pa, sc, sc_cap, lt, tie, ovf);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1336,7 +1354,9 @@ k_ext_dp_lds(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ r
 	}
 }
 
-__device__ __forceinline__ void d_fcig_append(AlReg *r, uint32_t *cig, int n, const uint32_t *src)
+struct LdsCig { uint32_t *b; __device__ __forceinline__ uint32_t &operator[](uint32_t i) const { return b[i * 256]; } };
+template <class CG>
+__device__ __forceinline__ void d_fcig_append(AlReg *r, CG cig, int n, const uint32_t *src)
 {   // mm_append_cigar (align.c:288-311) into a per-lane buffer
 	if (n == 0) return;
 	r->flags |= ALR_HAS_P;
@@ -1353,71 +1373,79 @@ k_ext_finish(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ r
              AlLogTab lt, uint64_t *__restrict__ sc_ws, const uint64_t *__restrict__ sc_off, int n_frag, AlParams P, uint32_t *__restrict__ slow_list, uint32_t *__restrict__ n_slow)
 {
 	const int f = blockIdx.x * blockDim.x + threadIdx.x;
+	__shared__ uint32_t s_cig[AL_FCIG * 256];                                  // per-lane CIGAR assembly buffer, [word][lane]
 	unsigned long long c_regs = 0, c_ref = 0, c_cig = 0;
 	if (f < n_frag && W.frag_nu[f] != 0) {
 		const uint32_t r0 = frag_first[f], n_segs = frag_first[f + 1] - r0;
 		FragWs fw; d_frag_ws(W, (uint32_t)f, fw);
-		if (n_segs == 2) fw.seg_a[1] = fw.seg_a[0] + W.seg_na[r0];
 		const uint64_t B2 = (uint64_t)(fw.mreg[0] - W.mregs);
 		bool slow = E.frag_slow[f] != 0;
 		// pre-check: every hit's CIGAR must fit the per-lane buffer, and none of its DP jobs may have been z-dropped in a
 		// way the monolithic path handles differently (nothing to do: z-dropped extensions are handled identically)
-		for (uint32_t s = 0; s < n_segs && !slow; ++s) {
+		auto precheck = [&](const uint32_t s, const AlReg *regs) {
 			const int n = (int)W.reg_cnt[r0 + s];
 			for (int i = 0; i < n && !slow; ++i) {
+				if (regs[i].cnt == 0) continue;
 				const RegExt x = E.rext[B2 + (uint64_t)s * fw.cap + i];
-				if (fw.mreg[s][i].cnt == 0) continue;
 				const uint32_t nl = E.jobs[x.job].qlen ? E.outs[x.job].flags_ncig >> 8 : 0, nr = E.jobs[x.job + 1].qlen ? E.outs[x.job + 1].flags_ncig >> 8 : 0;
 				if (nl + 1 + nr > AL_FCIG) slow = true;
 			}
-		}
+		};
+		if (!slow) precheck(0, fw.mreg[0]);
+		if (!slow && n_segs == 2) precheck(1, fw.mreg[1]);
 		if (slow) { slow_list[atomicAdd(n_slow, 1u)] = (uint32_t)f; }
 		else {
-			int qlens[2] = {0, 0}, qlen_sum = 0, n_regs[2] = {0, 0};
-			for (uint32_t s = 0; s < n_segs; ++s) { qlens[s] = (int)rd_len[r0 + s]; qlen_sum += qlens[s]; }
+			// (no local array is indexed by a run-time value and the hit being finished lives in registers: see k_regs)
+			const int ql0 = (int)rd_len[r0], ql1 = n_segs > 1 ? (int)rd_len[r0 + 1] : 0, qlen_sum = ql0 + ql1;
 			int max_gap_ref;
 			if (P.max_gap_ref > 0) max_gap_ref = P.max_gap_ref;
 			else if (P.max_frag_len > 0) { max_gap_ref = P.max_frag_len - qlen_sum; if (max_gap_ref < P.max_gap) max_gap_ref = P.max_gap; }
 			else max_gap_ref = P.max_gap;
 			const int rep_len = frag_rep[f]; bool tie = false;
-			for (uint32_t s = 0; s < n_segs; ++s) {
-				const int qlen = qlens[s]; int n = (int)W.reg_cnt[r0 + s];
+			const LdsCig cig{s_cig + threadIdx.x};
+			auto do_seg = [&](const uint32_t s, const int qlen, AlReg *regs, const AlAnchor *a) -> int {
+				int n = (int)W.reg_cnt[r0 + s];
 				const uint32_t *seq = rd_seq + rd_off[r0 + s];
-				AlReg *regs = fw.mreg[s]; const AlAnchor *a = fw.seg_a[s];
 				for (int i = 0; i < n; ++i) {                                    // mm_align1 after the DP calls (align.c:698-788)
-					AlReg *r = &regs[i];
-					if (r->cnt == 0) continue;
+					if (regs[i].cnt == 0) continue;
+					AlReg R = regs[i];
 					const RegExt x = E.rext[B2 + (uint64_t)s * fw.cap + i];
-					const int32_t rid = (int32_t)(a[r->as].x << 1 >> 33), rev = (int32_t)(a[r->as].x >> 63);
+					const int32_t rid = (int32_t)(a[R.as].x << 1 >> 33), rev = (int32_t)(a[R.as].x >> 63);
 					const uint64_t ref_off = G.seq_off[rid];
-					uint32_t cig[AL_FCIG];
-					r->n_cigar = 0; r->dp_score = 0; r->dp_max = 0; r->dp_max2 = 0; r->n_ambi = 0;
+					R.n_cigar = 0; R.dp_score = 0; R.dp_max = 0; R.dp_max2 = 0; R.n_ambi = 0;
 					int32_t rs1 = x.rs, qs1 = x.qs, re1, qe1;
 					++c_regs; c_ref += (unsigned long long)(x.re0 - x.rs0);
 					if (E.jobs[x.job].qlen) {
-						const ExtOut o = E.outs[x.job]; const int nc = (int)(o.flags_ncig >> 8); const bool reach = o.flags_ncig & 1;
-						if (nc > 0) { d_fcig_append(r, cig, nc, nc <= 6 ? o.cig : G.arena + o.cig_off); r->dp_score += o.max; }
-						rs1 = x.rs - (reach ? o.mqe_t + 1 : o.max_t + 1);
-						qs1 = x.qs - (reach ? x.qs : o.max_q + 1);
+						const ExtOut *po = &E.outs[x.job];
+						const uint32_t fl = po->flags_ncig; const int nc = (int)(fl >> 8); const bool reach = fl & 1;
+						if (nc > 0) { d_fcig_append(&R, cig, nc, nc <= 6 ? po->cig : G.arena + po->cig_off); R.dp_score += po->max; }
+						rs1 = x.rs - (reach ? po->mqe_t + 1 : po->max_t + 1);
+						qs1 = x.qs - (reach ? x.qs : po->max_q + 1);
 					}
-					{ const uint32_t m = (uint32_t)(x.qe - x.qs) << 4; d_fcig_append(r, cig, 1, &m); r->dp_score += x.core_score; }
+					{ const uint32_t m = (uint32_t)(x.qe - x.qs) << 4; d_fcig_append(&R, cig, 1, &m); R.dp_score += x.core_score; }
 					re1 = x.re; qe1 = x.qe;
 					if (E.jobs[x.job + 1].qlen) {
-						const ExtOut o = E.outs[x.job + 1]; const int nc = (int)(o.flags_ncig >> 8); const bool reach = o.flags_ncig & 1;
-						if (nc > 0) { d_fcig_append(r, cig, nc, nc <= 6 ? o.cig : G.arena + o.cig_off); r->dp_score += o.max; }
-						re1 = x.re + (reach ? o.mqe_t + 1 : o.max_t + 1);
-						qe1 = x.qe + (reach ? qlen - x.qe : o.max_q + 1);
+						const ExtOut *po = &E.outs[x.job + 1];
+						const uint32_t fl = po->flags_ncig; const int nc = (int)(fl >> 8); const bool reach = fl & 1;
+						if (nc > 0) { d_fcig_append(&R, cig, nc, nc <= 6 ? po->cig : G.arena + po->cig_off); R.dp_score += po->max; }
+						re1 = x.re + (reach ? po->mqe_t + 1 : po->max_t + 1);
+						qe1 = x.qe + (reach ? qlen - x.qe : po->max_q + 1);
 					}
-					r->rs = rs1; r->re = re1;
-					if (rev) { r->qs = qlen - qe1; r->qe = qlen - qs1; } else { r->qs = qs1; r->qe = qe1; }
-					d_update_extra(P, r, cig, ReadAcc{seq, qlen, rev, qs1}, RefAcc{G.S4, ref_off + (uint64_t)rs1});
-					c_cig += r->n_cigar;
-					if (r->n_cigar <= 4) { for (uint32_t k = 0; k < r->n_cigar; ++k) r->cig_inl[k] = cig[k]; r->cigar_off = AL_CIG_INLINE; }
-					else {
-						const unsigned long long off = atomicAdd(G.arena_cnt, (unsigned long long)r->n_cigar);
-						if (off + r->n_cigar <= G.arena_cap) { for (uint32_t k = 0; k < r->n_cigar; ++k) G.arena[off + k] = cig[k]; r->cigar_off = (uint32_t)off; }
-						else { atomicAdd(&G.counters[9], 1ULL); r->cigar_off = 0xffffffffu; }
+					R.rs = rs1; R.re = re1;
+					if (rev) { R.qs = qlen - qe1; R.qe = qlen - qs1; } else { R.qs = qs1; R.qe = qe1; }
+					d_update_extra(P, &R, cig, ReadAcc{seq, qlen, rev, qs1}, RefAcc{G.S4, ref_off + (uint64_t)rs1});
+					c_cig += R.n_cigar;
+					uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+					if (R.n_cigar <= 4) {
+						if (R.n_cigar > 0) c0 = cig[0]; if (R.n_cigar > 1) c1 = cig[1]; if (R.n_cigar > 2) c2 = cig[2]; if (R.n_cigar > 3) c3 = cig[3];
+						R.cigar_off = AL_CIG_INLINE;
+					} else {
+						const unsigned long long off = atomicAdd(G.arena_cnt, (unsigned long long)R.n_cigar);
+						if (off + R.n_cigar <= G.arena_cap) { for (uint32_t k = 0; k < R.n_cigar; ++k) G.arena[off + k] = cig[k]; R.cigar_off = (uint32_t)off; }
+						else { atomicAdd(&G.counters[9], 1ULL); R.cigar_off = 0xffffffffu; }
 					}
+					R.cig_inl[0] = c0; R.cig_inl[1] = c1; R.cig_inl[2] = c2; R.cig_inl[3] = c3;
+					regs[i] = R;
 				}
 				d_filter_regs(P, qlen, &n, regs);                                // align.c:910-911
 				tie = d_hit_sort(&n, regs, fw.aux128, fw.rtmp) || tie;
@@ -1425,15 +1453,20 @@ k_ext_finish(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ r
 				d_select_sub(P.pri_ratio, P.k * 2, P.best_n, &n, regs, fw.auxi);
 				d_set_sam_pri(n, regs);
 				d_set_mapq(n, regs, P.min_chain_score, P.a, rep_len, lt);
-				n_regs[s] = n;
-			}
+				return n;
+			};
+			AlReg *const mreg0 = fw.mreg[0], *const mreg1 = fw.mreg[1];
+			const AlAnchor *const sa0 = fw.seg_a[0], *const sa1 = n_segs == 2 ? fw.seg_a[0] + W.seg_na[r0] : nullptr;
+			const int nr0 = do_seg(0, ql0, mreg0, sa0);
+			const int nr1 = n_segs == 2 ? do_seg(1, ql1, mreg1, sa1) : 0;
 			if (n_segs == 2 && P.pe_ori >= 0) {
-				bool ovf = false; AlReg *rr[2] = {fw.mreg[0], fw.mreg[1]};
+				bool ovf = false;
 				// pair scores: at most n0*n1 entries (bounded by the hit counts after k_regs; see k_ext_counts)
-				d_pair(P, max_gap_ref, qlens, n_regs, rr, (PairEnt *)fw.rtmp, sc_ws + sc_off[f], (int)(sc_off[f + 1] - sc_off[f]), lt, &tie, &ovf);
+				d_pair2(P, max_gap_ref, ql0, ql1, nr0, nr1, mreg0, mreg1, (PairEnt *)fw.rtmp, sc_ws + sc_off[f], (int)(sc_off[f + 1] - sc_off[f]), lt, &tie, &ovf);
 				if (ovf) { atomicAdd(&G.counters[7], 1ULL << 56); }
 			}
-			for (uint32_t s = 0; s < n_segs; ++s) W.reg_cnt[r0 + s] = (uint32_t)n_regs[s];
+			W.reg_cnt[r0] = (uint32_t)nr0;
+			if (n_segs == 2) W.reg_cnt[r0 + 1] = (uint32_t)nr1;
 			if (tie) atomicAdd(&G.counters[10], 1ULL);
 		}
 	}
