@@ -26,6 +26,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
+WORKLOADS = {"c2": "C2: yeast-sized synthetic reference pair (16 contigs, 12.16 Mbp, 150 planted duplications)",
+             "c3": "C3: ce11-sized synthetic reference (6 contigs, 100.3 Mbp, 3000 planted repeats)",
+             "c4": "C4: human-sized synthetic reference (24 contigs, 3.1 Gbp, 20000 planted duplications, 2 % N)"}
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured streaming ceiling
 
 
@@ -113,6 +116,7 @@ def main():
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--cpu-sample-pairs", type=int, default=1_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--config", default="c2", help="synthetic reference of tools/gen_synth.py: c2 (BASELINE configs[1], default), c3 (100 Mbp), c4 (3.1 Gbp)")
     a = ap.parse_args()
 
     import torch
@@ -133,12 +137,14 @@ def main():
     L.al_batch_upload_flat.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_char_p, C.c_int64]
     L.al_batch_upload_flat.restype = C.c_int
 
-    # reference pair stand-in C2: 16 contigs, 12.16 Mbp, 150 planted duplications; identical on every rank
-    rk, _ = g.CONFIGS["c2"]
-    t0 = time.time()
+    # reference pair stand-in (C2 = 16 contigs, 12.16 Mbp, 150 planted duplications); identical on every rank.
+    # The index is built on this rank's GPU from the FASTA (al_idx_build_device), as the CLI does.
+    rk, _ = g.CONFIGS[a.config]
     ref = g.make_reference(**rk)
-    lut = np.frombuffer(b"ACGTN", dtype=np.uint8)
-    idx = A.Index(seqs=[lut[c].tobytes() for _, c in ref], names=[n.encode() for n, _ in ref])
+    tmp = tempfile.mkdtemp(prefix="al_bench_")
+    g.write_fasta(os.path.join(tmp, "ref.fa"), ref)
+    t0 = time.time()
+    idx = A.Index(fasta=os.path.join(tmp, "ref.fa"), on_device=local if world > 1 else 0)
     t_index = time.time() - t0
     arr = make_workload(a.pairs, a.read_len, 20261002 + 7919 * rank, ref)
     ctx = A.Context(idx, device=local if world > 1 else 0)
@@ -191,7 +197,7 @@ def main():
             "metric": "reads/sec remapped (150 bp PE)", "value": 2.0 * a.pairs * world * a.steps / dt, "unit": "reads/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8/int32 (int8 SW lanes, u64 hashes)", "data": "synthetic",
-            "config": {"workload": "C2: yeast-sized synthetic reference pair (16 contigs, 12.16 Mbp, 150 planted duplications), %d x 2 x %d bp PE reads per GPU per step, preset sr" % (a.pairs, a.read_len),
+            "config": {"workload": "%s, %d x 2 x %d bp PE reads per GPU per step, preset sr" % (WORKLOADS.get(a.config, a.config), a.pairs, a.read_len),
                        "reads_per_step_per_gpu": 2 * a.pairs, "read_len": a.read_len, "sharding": "reads sharded by rank, index replicated"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": kern[dom], "interval": dom, "kernel_ms": per[dom], "algorithmic_bytes_per_launch": alg, "algorithmic_bytes_per_read": alg / (2.0 * a.pairs),
@@ -200,15 +206,13 @@ def main():
             "counters": {"minimizers_per_read": st.n_mini / (2.0 * a.pairs), "anchors_per_pair": st.n_anchor / float(a.pairs), "chains_per_pair": st.n_chain / float(a.pairs),
                          "regions_aligned_per_read": st.n_regs_aln / (2.0 * a.pairs), "ref_bases_per_region": st.n_refbases / max(1.0, float(st.n_regs_aln)),
                          "rechain": int(st.n_rechain), "heap_fallback": int(st.n_heap_fallback), "sort_tie_flags": int(st.n_sort_tie_flag)},
-            "host": {"index_build_s": t_index, "pack_upload_s": t_upload},
+            "host": {"index_build_on_gpu_s": t_index, "pack_upload_s": t_upload},
         }
         if world == 1 and not a.no_cpu_baseline:
-            tmp = tempfile.mkdtemp(prefix="al_bench_")
-            g.write_fasta(os.path.join(tmp, "ref.fa"), ref)
             out["cpu_baseline"], out["e2e_cli"] = cpu_baseline(tmp, "ref.fa", arr, min(a.cpu_sample_pairs, a.pairs))
             out["parity_sample"] = {"pairs": min(a.cpu_sample_pairs, a.pairs), "identical": out["e2e_cli"]["identical_sam"]}
-            shutil.rmtree(tmp, ignore_errors=True)
         print(json.dumps(out))
+    shutil.rmtree(tmp, ignore_errors=True)
     ctx.close(); idx.close()
     if dist is not None:
         dist.destroy_process_group()

@@ -5,13 +5,13 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}; D=/tmp/al_e2e; mkdir -p $D
 python3 - <<PY
 import sys; sys.path.insert(0, "$REPO/tools")
 import gen_synth as g, numpy as np
-rk, _ = g.CONFIGS["c2"]; ref = g.make_reference(**rk); g.write_fasta("$D/ref.fa", ref)
+rk, _ = g.CONFIGS["${CONFIG:-c2}"]; ref = g.make_reference(**rk); g.write_fasta("$D/ref.fa", ref)
 r1, r2 = g.simulate_pairs(ref, $PAIRS, 150, seed=77)
 g.write_fastq("$D/r_1.fq", r1, "realigned_"); g.write_fastq("$D/r_2.fq", r2, "realigned_")
 PY
 cd $D
 TIMEFORMAT="airlift-align --version (process + library load): %R s"; time $REPO/airlift_amd/bin/airlift-align --version > /dev/null
-for t in 1 ${THREADS:-16}; do
+for t in ${T1:-1} ${THREADS:-16}; do
   TIMEFORMAT="airlift-align -t $t: %R s wall, %U s user ($PAIRS pairs)"; time AL_TIMING=1 $REPO/airlift_amd/bin/airlift-align -ax sr -t $t ref.fa r_1.fq r_2.fq > out_gpu.sam 2> err_gpu.txt; grep airlift err_gpu.txt
 done
 if [ -x $REPO/oracle/_ref/mm2ref ]; then

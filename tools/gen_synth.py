@@ -127,6 +127,8 @@ CONFIGS = {
     "c1": (dict(seed=2026, n_contigs=16, total_len=12_160_000, n_dups=150), dict(n_pairs=100_000, read_len=100, single_end=True, del_frac=0.0)),
     "c2": (dict(seed=2026, n_contigs=16, total_len=12_160_000, n_dups=150), dict(n_pairs=2_000_000, read_len=150)),
     "c3": (dict(seed=2027, n_contigs=6, total_len=100_300_000, n_dups=3000, dup_len=(100, 5000), dup_div=0.03), dict(n_pairs=5_000_000, read_len=150)),
+    # human-sized scale test (uniform sequence + planted diverged duplications + N blocks; not a repeat-structure model of GRCh38)
+    "c4": (dict(seed=2028, n_contigs=24, total_len=3_100_000_000, n_dups=20000, dup_len=(300, 6000), dup_div=0.05, n_frac=0.02), dict(n_pairs=50_000_000, read_len=150)),
     "tiny": (dict(seed=7, n_contigs=3, total_len=300_000, n_dups=12, tandem=6), dict(n_pairs=2000, read_len=150, ins_frac=0.03)),
 }
 
