@@ -191,20 +191,25 @@ extern "C" int al_map_file_frag(const al_idx_t *mi, int n_fn, const char **fn, c
 				b->chunks.push_back(std::move(a));
 			}
 			b->bases = 0;
-			size_t n = rs.size();
-			if (!done && n > 0) {                      // hold the last read back: its mate may open the next batch
-				--n; carry.reset(new AlChunk());
-				const AlChunk &c0 = *rs[n].first; const AlRec &r0 = *rs[n].second; AlRec r; r.name = 0;
+			const size_t n = rs.size();
+			std::vector<std::pair<size_t, int>> frags;        // (first read, segments), greedy from the front like the reference
+			for (size_t i = 0; i < n; ) {
+				int ns = 1;
+				if (i + 1 < n && qname_same(rs[i].first->text.data() + rs[i].second->name, rs[i + 1].first->text.data() + rs[i + 1].second->name)) ns = 2;
+				frags.emplace_back(i, ns); i += ns;
+			}
+			if (!done && !frags.empty() && frags.back().second == 1) {   // a trailing single read may pair with the first read of the next batch: carry it over
+				const size_t k = frags.back().first; frags.pop_back();
+				carry.reset(new AlChunk());
+				const AlChunk &c0 = *rs[k].first; const AlRec &r0 = *rs[k].second; AlRec r; r.name = 0;
 				carry->text.insert(carry->text.end(), c0.text.data() + r0.name, c0.text.data() + r0.name + strlen(c0.text.data() + r0.name) + 1);
 				r.seq = (uint32_t)carry->text.size(); r.len = r0.len; carry->text.insert(carry->text.end(), c0.text.data() + r0.seq, c0.text.data() + r0.seq + r0.len);
 				r.qual = ~0u; if (r0.qual != ~0u) { r.qual = (uint32_t)carry->text.size(); carry->text.insert(carry->text.end(), c0.text.data() + r0.qual, c0.text.data() + r0.qual + r0.len); }
 				carry->recs.push_back(r);
 			}
-			for (size_t i = 0; i < n; ) {
-				int ns = 1;
-				if (i + 1 < n && qname_same(rs[i].first->text.data() + rs[i].second->name, rs[i + 1].first->text.data() + rs[i + 1].second->name)) ns = 2;
-				for (int j = 0; j < ns; ++j) b->add_read(*rs[i + j].first, *rs[i + j].second);
-				b->n_segs.push_back(ns); i += ns;
+			for (const auto &fr : frags) {
+				for (int j = 0; j < fr.second; ++j) b->add_read(*rs[fr.first + j].first, *rs[fr.first + j].second);
+				b->n_segs.push_back(fr.second);
 			}
 		}
 		const int nf = (int)b->n_segs.size();

@@ -110,3 +110,83 @@ def test_map_frag_api(golden_unpacked):
                 a, b = rg[s][k], rb[2 * f + s][k]
                 assert (a.rid, a.rs, a.re, a.qs, a.qe, a.mapq, a.rev, a.n_cigar, a.dp_max) == (b.rid, b.rs, b.re, b.qs, b.qe, b.mapq, b.rev, b.n_cigar, b.dp_max)
     ctx.close(); idx.close()
+
+
+# ---- input formats of the drop-in's reader (al_pipeline.cpp / al_seqio.h): same records whatever the container ----------
+def _golden_pe(golden_unpacked):
+    d = golden_unpacked["g1_mt150pe"]
+    m = json.load(open(os.path.join(d, "meta.json")))
+    return d, m, open(os.path.join(d, "expected.sam"), "rb").read()
+
+
+def _run(cmd, cwd, **kw):
+    r = subprocess.run(cmd, cwd=cwd, capture_output=True, **kw)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    return r
+
+
+def test_gzip_and_crlf_inputs(golden_unpacked, tmp_path):
+    import gzip
+    d, m, exp = _golden_pe(golden_unpacked)
+    for i, fn in enumerate(m["reads"]):
+        raw = open(os.path.join(d, fn), "rb").read()
+        with gzip.open(tmp_path / ("r%d.fq.gz" % i), "wb") as f:
+            f.write(raw)
+        open(tmp_path / ("c%d.fq" % i), "wb").write(raw.replace(b"\n", b"\r\n"))
+    ref = os.path.join(d, m["ref"])
+    with gzip.open(tmp_path / "ref.fa.gz", "wb") as f:
+        f.write(open(ref, "rb").read())
+    rg = ["-R", m["rg"]] if m.get("rg") else []
+    assert _run([CLI, "-ax", "sr", "-t", "3"] + rg + [str(tmp_path / "ref.fa.gz"), "r0.fq.gz", "r1.fq.gz"], tmp_path).stdout == exp
+    assert _run([CLI, "-ax", "sr", "-t", "3"] + rg + [ref, "c0.fq", "c1.fq"], tmp_path).stdout == exp
+
+
+def test_small_device_batches_and_threads(golden_unpacked):
+    """-K 20k bases per device batch (about 66 pairs each): many batches through the reader/mapper/writer pipeline,
+    every worker count, same bytes in the same order."""
+    d, m, exp = _golden_pe(golden_unpacked)
+    rg = ["-R", m["rg"]] if m.get("rg") else []
+    for t in ("1", "2", "7"):
+        assert _run([CLI, "-ax", "sr", "-K", "20000", "-t", t] + rg + [m["ref"]] + m["reads"], d).stdout == exp
+
+
+def test_interleaved_single_file_and_uneven_files(golden_unpacked, oracle_bin, tmp_path):
+    """One file with /1 /2 mates adjacent (frag_mode pairing by name, map.c:580-586) and two files of different length
+    (bseq.c: extra records skipped, with the reference's warning): compared with the oracle on the same inputs."""
+    import airlift_amd as A
+    d, m, _ = _golden_pe(golden_unpacked)
+    (n1, s1, q1), (n2, s2, q2) = [A.read_fastx(os.path.join(d, f)) for f in m["reads"]]
+    with open(tmp_path / "il.fq", "wb") as f:
+        for i in range(300):
+            base = n1[i][:-2] if n1[i][-2:] == b"/1" else n1[i]
+            f.write(b"@" + base + b"/1\n" + s1[i] + b"\n+\n" + q1[i] + b"\n")
+            if i % 7 != 3:   # some singletons in between
+                f.write(b"@" + base + b"/2\n" + s2[i] + b"\n+\n" + q2[i] + b"\n")
+    ref = os.path.join(d, m["ref"])
+    got = _run([CLI, "-ax", "sr", "-K", "9000", ref, "il.fq"], tmp_path).stdout
+    exp = _run([oracle_bin, ref, "il.fq"], tmp_path).stdout
+    assert got == exp, _diff_report(got, exp, "interleaved")
+    with open(tmp_path / "a.fq", "wb") as f:
+        for i in range(200):
+            f.write(b"@" + n1[i] + b"\n" + s1[i] + b"\n+\n" + q1[i] + b"\n")
+    with open(tmp_path / "b.fq", "wb") as f:
+        for i in range(150):
+            f.write(b"@" + n2[i] + b"\n" + s2[i] + b"\n+\n" + q2[i] + b"\n")
+    r = _run([CLI, "-ax", "sr", ref, "a.fq", "b.fq"], tmp_path)
+    assert b"different number of records" in r.stderr
+    exp = _run([oracle_bin, ref, "a.fq", "b.fq"], tmp_path).stdout
+    assert r.stdout == exp, _diff_report(r.stdout, exp, "uneven")
+
+
+def test_fasta_reads_single_end(golden_unpacked, oracle_bin, tmp_path):
+    """B3 shape (align_gaps.sh:14-15): multi-line FASTA queries, single end, `samse` argv."""
+    import airlift_amd as A
+    d, m, _ = _golden_pe(golden_unpacked)
+    n1, s1, _q = A.read_fastx(os.path.join(d, m["reads"][0]))
+    with open(tmp_path / "gaps.fa", "wb") as f:
+        for i in range(250):
+            f.write(b">" + n1[i] + b" some description\n" + s1[i][:70] + b"\n" + s1[i][70:] + b"\n")
+    ref = os.path.join(d, m["ref"])
+    got = _run([CLI, "samse", ref, "x.sai", "gaps.fa"], tmp_path).stdout
+    exp = _run([oracle_bin, ref, "gaps.fa"], tmp_path).stdout
+    assert got == exp, _diff_report(got, exp, "fasta_se")
