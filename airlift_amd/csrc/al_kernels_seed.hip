@@ -719,10 +719,12 @@ k_chain_lds(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a
             AlAnchor *__restrict__ chained, uint64_t *__restrict__ u_out, uint32_t *__restrict__ frag_nu, uint64_t *__restrict__ ws_u64,
             const uint32_t *__restrict__ order, int n_list, int lo_excl, AlParams P, unsigned long long *__restrict__ counters)
 {
-	__shared__ uint32_t sx[CAPL * LANES];
-	__shared__ uint16_t sq[CAPL * LANES];
-	__shared__ int16_t sf[CAPL * LANES], sv[CAPL * LANES];
-	__shared__ uint8_t sm[CAPL * LANES], sp[CAPL * LANES], st_[CAPL * LANES];
+	// 10 bytes per anchor: one 8-byte row  [ xlo:16 | q:12 | seg:1 | far:1 | -:2 | f:16 | p:8 | t:8 ]  + the peak score v:16.
+	//  xlo = low 16 bits of the reference position: inside the predecessor window the true distance is <= max_dist_x < 2^15,
+	//        so (xlo_i - xlo_j) mod 2^16 is the distance; "far" marks an anchor whose predecessor lies in another
+	//        (strand, contig) block or >= 2^15 away, which is all the window start needs to know.
+	__shared__ uint64_t srow[CAPL * LANES];
+	__shared__ int16_t sv[CAPL * LANES];
 	__shared__ uint8_t s_clin[AL_CLIN_N];
 	const int lane = threadIdx.x;
 	const int t0 = blockIdx.x * LANES + lane;
@@ -738,13 +740,16 @@ k_chain_lds(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a
 	if (!have) return;
 	frag_nu[f] = 0;
 	if (n == 0) return;
-#define XL(j) sx[(j) * LANES + lane]
-#define QL(j) sq[(j) * LANES + lane]
-#define ML(j) sm[(j) * LANES + lane]
-#define FL(j) sf[(j) * LANES + lane]
-#define PL(j) sp[(j) * LANES + lane]
-#define TL(j) st_[(j) * LANES + lane]
+#define ROW(j) srow[(j) * LANES + lane]
 #define VL(j) sv[(j) * LANES + lane]
+#define TB(j) (reinterpret_cast<uint8_t *>(&srow[(j) * LANES + lane])[7])
+#define R_XLO(r) ((uint32_t)(r) & 0xffffu)
+#define R_Q(r) ((int32_t)((uint32_t)(r) >> 16 & 0xfffu))
+#define R_SEG(r) ((int32_t)((uint32_t)(r) >> 28 & 1u))
+#define R_FAR(r) ((uint32_t)(r) >> 29 & 1u)
+#define R_F(r) ((int32_t)(int16_t)((r) >> 32))
+#define R_P(r) ((uint32_t)((r) >> 48) & 0xffu)
+#define R_T(r) ((uint32_t)((r) >> 56))
 	const uint32_t r0 = frag_first[f], r1 = frag_first[f + 1];
 	const int n_segs = (int)(r1 - r0);
 	int qlen_sum = 0; for (uint32_t r = r0; r < r1; ++r) qlen_sum += (int)rd_len[r];
@@ -754,115 +759,134 @@ k_chain_lds(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a
 	if (P.max_gap_ref > 0) max_dist_x = P.max_gap_ref;
 	else if (P.max_frag_len > 0) { max_dist_x = P.max_frag_len - qlen_sum; if (max_dist_x < P.max_gap) max_dist_x = P.max_gap; }
 	else max_dist_x = P.max_gap;
-	const int bw = P.bw, max_skip = P.max_chain_skip, max_iter = P.max_chain_iter, min_cnt = P.min_cnt, min_sc = P.min_chain_score;
+	const int bw = P.bw, max_skip = P.max_chain_skip, min_cnt = P.min_cnt, min_sc = P.min_chain_score;
 	const int32_t q_span = P.k;
 	{
-		uint32_t prev_hi = 0; int blk = -1; bool bad = false;
+		uint64_t prev_x = 0; bool bad = max_dist_x > 0x7fff || P.max_chain_iter < CAPL;
 		for (int i = 0; i < n; ++i) {
 			const AlAnchor e = a[i];
-			const uint32_t hi = (uint32_t)(e.x >> 32);
-			if (i == 0 || hi != prev_hi) { ++blk; prev_hi = hi; }
-			if ((int)(e.y >> 32 & 0xff) != q_span || ((e.y & AL_SEED_SEG_MASK) >> AL_SEED_SEG_SHIFT) > 1 || (uint32_t)e.y > 0xffffu) bad = true;
-			XL(i) = (uint32_t)e.x; QL(i) = (uint16_t)(uint32_t)e.y;
-			ML(i) = (uint8_t)((uint32_t)blk | (uint32_t)((e.y & AL_SEED_SEG_MASK) >> AL_SEED_SEG_SHIFT & 1) << 6 | ((e.y & AL_SEED_TANDEM) ? 0x80u : 0u));
-			TL(i) = 0xff;
+			const bool far = i == 0 || (e.x >> 32) != (prev_x >> 32) || (uint32_t)e.x - (uint32_t)prev_x > 0x7fffu;
+			prev_x = e.x;
+			if ((int)(e.y >> 32 & 0xff) != q_span || ((e.y & AL_SEED_SEG_MASK) >> AL_SEED_SEG_SHIFT) > 1 || (uint32_t)e.y > 0xfffu) bad = true;
+			ROW(i) = (uint64_t)((uint32_t)e.x & 0xffffu) | (uint64_t)((uint32_t)e.y & 0xfffu) << 16 | (uint64_t)((e.y & AL_SEED_SEG_MASK) >> AL_SEED_SEG_SHIFT & 1) << 28
+			         | (uint64_t)(far ? 1u : 0u) << 29 | (uint64_t)0xffu << 56;
 		}
 		if (bad) { atomicAdd(&counters[7], 1ULL); return; }   // not representable in the compact rows (never on the short-read path)
 	}
 	const double avg_d = (double)(float)((double)(float)((uint32_t)q_span * (uint32_t)n) / (double)(float)n);   // (float)sum/n (chain.c:42)
 	const bool tab_ok = avg_d == (double)P.k && P.k * 0.01 * (AL_CLIN_N - 1) < 255.0;
-	int st = 0;
+	int st = 0; int32_t dist = 0;                                                 // dist = x_i - x_st while st..i lie in one window
+	uint32_t prev_xlo = 0;
 	for (int i = 0; i < n; ++i) {                                                 // chain.c:46-85
-		const uint32_t pi = XL(i); const uint32_t mi_ = ML(i);
-		const int32_t qi = (int32_t)QL(i), sidi = (int32_t)(mi_ >> 6 & 1); const uint32_t blki = mi_ & 0x3f;
+		const uint64_t ri = ROW(i);
+		const uint32_t xi = R_XLO(ri); const int32_t qi = R_Q(ri), sidi = R_SEG(ri);
 		int max_j = -1; int32_t max_f = q_span, n_skip = 0;
-		// ri > a[st].x + max_dist_x  <=>  different (strand, contig) block, or same block and pos_i > pos_st + max_dist_x
-		while (st < i && ((ML(st) & 0x3f) != blki || (uint64_t)pi > (uint64_t)XL(st) + (uint64_t)max_dist_x)) ++st;
-		if (i - st > max_iter) st = i - max_iter;
-		// The rows of candidate j-1 are fetched while candidate j is scored, and the body is written with selects rather than
-		// branches: one wavefront per SIMD fits (LDS capacity), so the kernel is bound by instruction issue and every
+		// window start (chain.c:52: ri > a[st].x + max_dist_x): a far anchor has no predecessor at all; otherwise the
+		// distance to st grows by this step and st advances while it exceeds max_dist_x (steps inside a window are < 2^15)
+		if (R_FAR(ri)) { st = i; dist = 0; }
+		else {
+			dist += (int32_t)((xi - prev_xlo) & 0xffffu);
+			while (dist > max_dist_x) { ++st; dist -= (int32_t)((R_XLO(ROW(st)) - R_XLO(ROW(st - 1))) & 0xffffu); }
+		}
+		prev_xlo = xi;
+		// The row of candidate j-1 is fetched while candidate j is scored, and the body is written with selects rather than
+		// branches: few wavefronts fit per SIMD (LDS capacity), so the kernel is bound by instruction issue and every
 		// divergent branch costs scalar exec-mask work.  t[j-1] can be overwritten by this iteration's mark after it was
-		// fetched; that case is patched in registers.  i - st <= CAPL < max_iter here, so st..i-1 all lie in anchor i's
-		// (strand, contig) block and dr fits 32 bits.
+		// fetched; that case is patched in registers.
 		int jn = i > 0 ? i - 1 : 0;
-		uint32_t n_m = ML(jn), n_x = XL(jn); int32_t n_q = (int32_t)QL(jn), n_f = (int32_t)FL(jn); uint8_t n_p = PL(jn), n_t = TL(jn);
+		uint64_t nrow = ROW(jn);
 		bool done = false;
 		for (int j = i - 1; j >= st && !done; --j) {
-			const uint32_t mj = n_m, xj = n_x; const int32_t qj = n_q, fj = n_f; const uint8_t pj = n_p, tj = n_t;
+			const uint64_t rj = nrow;
 			jn = j > 0 ? j - 1 : 0;
-			n_m = ML(jn); n_x = XL(jn); n_q = (int32_t)QL(jn); n_f = (int32_t)FL(jn); n_p = PL(jn); n_t = TL(jn);
-			const int32_t dr = (int32_t)(pi - xj);
-			const int32_t dq = qi - qj;
-			const bool same = (int32_t)(mj >> 6 & 1) == sidi;
+			nrow = ROW(jn);
+			const int32_t dr = (int32_t)((xi - R_XLO(rj)) & 0xffffu);
+			const int32_t dq = qi - R_Q(rj);
+			const bool same = R_SEG(rj) == sidi;
 			const int32_t dd = dr > dq ? dr - dq : dq - dr;
 			const bool skip = (same && dr == 0) | (dq <= 0) | (same && dq > max_dist_y) | (dq > max_dist_x) | (same && dd > bw) |
 			                  (n_segs > 1 && same && dr > max_dist_y);
 			const int32_t min_d = dq < dr ? dq : dr;
 			int32_t sc = min_d > q_span ? q_span : min_d;
 			const int32_t log_dd = dd ? d_ilog2((uint32_t)dd) : 0;
-			int32_t c_lin = (int32_t)s_clin[dd < AL_CLIN_N ? dd : AL_CLIN_N - 1];
+			int32_t c_lin = (int32_t)s_clin[dd < AL_CLIN_N ? (dd < 0 ? 0 : dd) : AL_CLIN_N - 1];
 			if (__builtin_expect(!tab_ok || dd >= AL_CLIN_N, 0)) c_lin = (int)((double)dd * .01 * avg_d);
 			const int32_t pen_same = c_lin + (log_dd >> 1), pen_diff = dr == 0 ? -1 : (c_lin < log_dd ? c_lin : log_dd);
-			sc = sc - (same ? pen_same : pen_diff) + fj;
+			sc = sc - (same ? pen_same : pen_diff) + R_F(rj);
+			const uint32_t pj = R_P(rj);
 			const bool better = !skip && sc > max_f;
-			const bool marked = !skip && !better && tj == (uint8_t)i;
+			const bool marked = !skip && !better && R_T(rj) == (uint32_t)i;
 			max_f = better ? sc : max_f; max_j = better ? j : max_j;
 			n_skip += marked ? 1 : (better && n_skip > 0 ? -1 : 0);
 			done = marked && n_skip > max_skip;                                       // the reference breaks before marking p[j]
-			if (!skip && !done && pj != 0xff) { TL(pj) = (uint8_t)i; n_t = (int)pj == jn ? (uint8_t)i : n_t; }
+			if (!skip && !done && pj != 0xff) {
+				TB(pj) = (uint8_t)i;
+				nrow = (int)pj == jn ? ((nrow & 0x00ffffffffffffffULL) | (uint64_t)(uint32_t)i << 56) : nrow;
+			}
 		}
-		FL(i) = (int16_t)max_f; PL(i) = max_j < 0 ? (uint8_t)0xff : (uint8_t)max_j;
-		VL(i) = max_j >= 0 && (int32_t)VL(max_j) > max_f ? VL(max_j) : (int16_t)max_f;
+		const int32_t vmax = max_j >= 0 ? (int32_t)VL(max_j) : 0;
+		ROW(i) = (ri & 0x00000000ffffffffULL) | (uint64_t)((uint32_t)max_f & 0xffffu) << 32 | (uint64_t)(max_j < 0 ? 0xffu : (uint32_t)max_j) << 48 | (ROW(i) & 0xff00000000000000ULL);
+		VL(i) = max_j >= 0 && vmax > max_f ? (int16_t)vmax : (int16_t)max_f;
 	}
+#define FL(j) R_F(ROW(j))
+#define PLv(j) R_P(ROW(j))
 	// chain.c:87-109.  NB: the t[] marks above use the row index i (< CAPL <= 128) with 0xff as "never"; from here t[] is a 0/1 flag.
-	for (int i = 0; i < n; ++i) TL(i) = 0;
-	for (int i = 0; i < n; ++i) if (PL(i) != 0xff) TL(PL(i)) = 1;
+	for (int i = 0; i < n; ++i) TB(i) = 0;
+	for (int i = 0; i < n; ++i) { const uint32_t pi_ = PLv(i); if (pi_ != 0xff) TB(pi_) = 1; }
 	uint64_t *utmp = ws_u64 + a_off[f];
 	int32_t n_u = 0, n_v = 0, k = 0;
 	for (int i = 0; i < n; ++i)
-		if (TL(i) == 0 && (int32_t)VL(i) >= min_sc) {
+		if (TB(i) == 0 && (int32_t)VL(i) >= min_sc) {
 			int j = i;
-			while (j >= 0 && FL(j) < VL(j)) j = PL(j) == 0xff ? -1 : (int)PL(j);
+			while (j >= 0 && FL(j) < (int32_t)VL(j)) j = PLv(j) == 0xff ? -1 : (int)PLv(j);
 			if (j < 0) j = i;
-			utmp[n_u++] = (uint64_t)(uint32_t)(int32_t)FL(j) << 32 | (uint64_t)j;
+			utmp[n_u++] = (uint64_t)(uint32_t)FL(j) << 32 | (uint64_t)j;
 		}
 	if (n_u == 0) return;
 	for (int32_t i = 1; i < n_u; ++i) { const uint64_t t = utmp[i]; int32_t j = i; while (j > 0 && utmp[j - 1] < t) { utmp[j] = utmp[j - 1]; --j; } utmp[j] = t; }
-	for (int i = 0; i < n; ++i) TL(i) = 0;
+	for (int i = 0; i < n; ++i) TB(i) = 0;
 	for (int32_t i = 0; i < n_u; ++i) {                                              // chain.c:111-128; v[] reused as the visit list
 		const int32_t n_v0 = n_v, k0 = k; int j = (int32_t)utmp[i];
-		do { VL(n_v) = (int16_t)j; ++n_v; TL(j) = 1; j = PL(j) == 0xff ? -1 : (int)PL(j); } while (j >= 0 && TL(j) == 0);
+		do { VL(n_v) = (int16_t)j; ++n_v; TB(j) = 1; j = PLv(j) == 0xff ? -1 : (int)PLv(j); } while (j >= 0 && TB(j) == 0);
 		if (j < 0) { if (n_v - n_v0 >= min_cnt) utmp[k++] = utmp[i] >> 32 << 32 | (uint32_t)(n_v - n_v0); }
-		else if ((int32_t)(utmp[i] >> 32) - (int32_t)FL(j) >= min_sc) { if (n_v - n_v0 >= min_cnt) utmp[k++] = (uint64_t)((utmp[i] >> 32) - (uint64_t)(uint32_t)(int32_t)FL(j)) << 32 | (uint32_t)(n_v - n_v0); }
+		else if ((int32_t)(utmp[i] >> 32) - FL(j) >= min_sc) { if (n_v - n_v0 >= min_cnt) utmp[k++] = (uint64_t)((utmp[i] >> 32) - (uint64_t)(uint32_t)FL(j)) << 32 | (uint32_t)(n_v - n_v0); }
 		if (k0 == k) n_v = n_v0;
 	}
 	n_u = k;
 	// chains ordered by the x of their first anchor (chain.c:144-160); n_u <= 64: stable insertion sort (ksort.h:149).
-	// x order == (block, pos) order.  p[] (free now) = chain start offsets into v[], t[] = permutation.
+	// The visit list v[] keeps each chain's anchors last-to-first; t[] (free now) = permutation, p-bytes = start offsets.
+	// First-anchor x is read back from HBM (a few values per fragment).
+#define OFFB(c) (reinterpret_cast<uint8_t *>(&srow[(c) * LANES + lane])[6])
 	int32_t off = 0;
-	for (int32_t c = 0; c < n_u; ++c) { PL(c) = (uint8_t)off; off += (int32_t)(uint32_t)utmp[c]; TL(c) = (uint8_t)c; }
-#define CXL(c) (((uint64_t)(ML((int)VL((int)PL(c) + (int32_t)(uint32_t)utmp[c] - 1)) & 0x3f) << 32) | XL((int)VL((int)PL(c) + (int32_t)(uint32_t)utmp[c] - 1)))
+	for (int32_t c = 0; c < n_u; ++c) { OFFB(c) = (uint8_t)off; off += (int32_t)(uint32_t)utmp[c]; TB(c) = (uint8_t)c; }
+#define CXL(c) (a[(int)VL((int)OFFB(c) + (int32_t)(uint32_t)utmp[c] - 1)].x)
 	for (int32_t i = 1; i < n_u; ++i) {
-		const uint8_t ci = TL(i); const uint64_t xi = CXL(ci); int32_t j = i;
-		while (j > 0) { const uint8_t cj = TL(j - 1); if (xi < CXL(cj)) { TL(j) = cj; --j; } else break; }
-		TL(j) = ci;
+		const uint8_t ci = TB(i); const uint64_t xi = CXL(ci); int32_t j = i;
+		while (j > 0) { const uint8_t cj = TB(j - 1); if (xi < CXL(cj)) { TB(j) = cj; --j; } else break; }
+		TB(j) = ci;
 	}
 #undef CXL
 	AlAnchor *b = chained + a_off[f]; uint64_t *u = u_out + a_off[f] + f;
 	int32_t o = 0;
 	for (int32_t i = 0; i < n_u; ++i) {
-		const int32_t c = TL(i), ni = (int32_t)(uint32_t)utmp[c], k0 = PL(c);
+		const int32_t c = TB(i), ni = (int32_t)(uint32_t)utmp[c], k0 = OFFB(c);
 		u[i] = utmp[c];
 		for (int32_t j = 0; j < ni; ++j) b[o++] = a[(int)VL(k0 + (ni - j - 1))];
 	}
 	frag_nu[f] = (uint32_t)n_u;
-#undef XL
-#undef QL
-#undef ML
+#undef OFFB
 #undef FL
-#undef PL
-#undef TL
+#undef PLv
+#undef ROW
 #undef VL
+#undef TB
+#undef R_XLO
+#undef R_Q
+#undef R_SEG
+#undef R_FAR
+#undef R_F
+#undef R_P
+#undef R_T
 }
 #define INST_CHAIN_LDS(C, L) template __global__ void k_chain_lds<C, L>(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, AlAnchor *, uint64_t *, uint32_t *, uint64_t *, const uint32_t *, int, int, AlParams, unsigned long long *);
 INST_CHAIN_LDS(16, 64) INST_CHAIN_LDS(24, 64) INST_CHAIN_LDS(32, 64) INST_CHAIN_LDS(48, 64) INST_CHAIN_LDS(64, 64) INST_CHAIN_LDS(128, 32)
