@@ -25,7 +25,7 @@ extern "C" __global__ void k_chain_lane(const AlAnchor *, const uint64_t *, cons
 static const char *g_stage_names[ST_N] = { "sketch", "seed_lookup", "scan", "size_order", "anchor_sort_small", "anchor_sort", "chain_lds32", "chain_lds48", "chain_lds64", "chain_lds128", "chain_wave", "rechain",
                                            "regs", "ext_prep", "ext_sort", "ext_dp_lane", "ext_dp_g4", "ext_dp_g8", "ext_dp_g22", "ext_finish", "compact" };
 // kernel behind each interval (what rocprofv3 --kernel-trace lists); "" = several small launches
-static const char *g_stage_kernels[ST_N] = { "k_sketch", "k_seed", "", "", "k_anchor_sort_small", "k_anchor_sort<1024>", "k_chain_lds<16|24|32, 64>", "k_chain_lds<48, 64>", "k_chain_lds<64, 64>", "k_chain_lds<128, 32>", "k_chain<768>", "",
+static const char *g_stage_kernels[ST_N] = { "k_sketch", "k_seed", "", "", "k_anchor_sort_small", "k_anchor_sort<1024>", "k_chain_lds<16|24|32, 64>", "k_chain_lds<40|48, 64>", "k_chain_lds<64, 64>", "k_chain_lds<128, 32>", "k_chain<768>", "",
                                              "k_regs", "k_ext_prep", "", "k_ext_dp_lane<16|32, 64>", "k_ext_dp<1|2|4, 512, ..>", "k_ext_dp<8, 512, 128>", "k_ext_dp<22, 512, 352>", "k_ext_finish", "k_compact" };
 extern "C" const char *al_stage_kernel(int i) { return i >= 0 && i < ST_N ? g_stage_kernels[i] : ""; }
 extern "C" const char *al_stage_name(int i) { return i >= 0 && i < ST_N ? g_stage_names[i] : ""; }
@@ -292,7 +292,7 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 		const int n64 = sorted ? (int)lb65 : nl;                            // unsorted: wavefront-group ownership inside the kernels
 		if (lane_max > 0) { LCH(16, 64, -1, order, n64); LCH(24, 64, 16, order, n64); LCH(32, 64, 24, order, n64); }
 		if (first) AL_HIP_CHECK(hipEventRecord(c->ev[ST_CHAIN_LDS32 + 1], s));
-		if (lane_max > 0) LCH(48, 64, 32, order, n64);
+		if (lane_max > 0) { LCH(40, 64, 32, order, n64); LCH(48, 64, 40, order, n64); }
 		if (first) AL_HIP_CHECK(hipEventRecord(c->ev[ST_CHAIN_LDS48 + 1], s));
 		if (lane_max > 0) LCH(64, 64, 48, order, n64);
 		if (first) AL_HIP_CHECK(hipEventRecord(c->ev[ST_CHAIN_LDS64 + 1], s));
