@@ -198,31 +198,49 @@ __device__ void d_bitonic_sort_lds(AlAnchor *s, int npow2, int lane)
 		}
 }
 
-__device__ __forceinline__ void d_heapdown(size_t i, size_t n, AlAnchor *l)
+// Heap entry of the k-way merge: head position x of one occurrence list, the list (match index) and the cursor in it.
+struct HeapEnt { uint64_t x; uint32_t mi, off; };
+struct HeapGlobal {            // heap in HBM scratch (one AlAnchor per entry: x, mi<<32|off)
+	AlAnchor *h;
+	__device__ __forceinline__ uint64_t x(size_t i) const { return h[i].x; }
+	__device__ __forceinline__ HeapEnt get(size_t i) const { const AlAnchor e = h[i]; return HeapEnt{e.x, (uint32_t)(e.y >> 32), (uint32_t)e.y}; }
+	__device__ __forceinline__ void set(size_t i, const HeapEnt &e) const { h[i].x = e.x; h[i].y = (uint64_t)e.mi << 32 | e.off; }
+};
+template <int LANES> struct HeapLds {   // heap in LDS, [entry][lane]; cursor and list packed in 32 bits (list < 2^16, cursor < 2^16)
+	uint32_t *xlo, *xhi, *y;
+	__device__ __forceinline__ uint64_t x(size_t i) const { return (uint64_t)xlo[i * LANES] | (uint64_t)xhi[i * LANES] << 32; }
+	__device__ __forceinline__ HeapEnt get(size_t i) const { const uint32_t v = y[i * LANES]; return HeapEnt{x(i), v >> 16, v & 0xffffu}; }
+	__device__ __forceinline__ void set(size_t i, const HeapEnt &e) const { xlo[i * LANES] = (uint32_t)e.x; xhi[i * LANES] = (uint32_t)(e.x >> 32); y[i * LANES] = e.mi << 16 | e.off; }
+};
+
+template <class H>
+__device__ __forceinline__ void d_heapdown(size_t i, size_t n, const H &l)
 {   // ksort.h:43-53 with heap_lt(a,b) = a.x > b.x (map.c:80)
-	size_t k = i; AlAnchor tmp = l[i];
+	size_t k = i; const HeapEnt tmp = l.get(i);
 	while ((k = (k << 1) + 1) < n) {
-		if (k != n - 1 && l[k].x > l[k + 1].x) ++k;
-		if (l[k].x > tmp.x) break;
-		l[i] = l[k]; i = k;
+		if (k != n - 1 && l.x(k) > l.x(k + 1)) ++k;
+		if (l.x(k) > tmp.x) break;
+		l.set(i, l.get(k)); i = k;
 	}
-	l[i] = tmp;
+	l.set(i, tmp);
 }
 
-// exact emulation of collect_seed_hits_heap (map.c:149-213) by one lane; heap in global scratch
+// exact emulation of collect_seed_hits_heap (map.c:149-213) by one lane
+template <class H>
 __device__ __forceinline__ void d_anchor_heap_merge(const uint64_t *__restrict__ pos, const AlMatch *__restrict__ m, uint32_t n_m, uint32_t n, int qlen, int mini_span,
-                                                    AlAnchor *__restrict__ heap, AlAnchor *__restrict__ out, unsigned long long *__restrict__ counters)
+                                                    const H &heap, AlAnchor *__restrict__ out, unsigned long long *__restrict__ counters)
 {
 	size_t hs = 0; uint64_t n_for = 0, n_rev = 0;
 	atomicAdd(&counters[0], 1ULL);
 	for (uint32_t i = 0; i < n_m; ++i) {
 		const uint64_t off = (uint64_t)m[i].off_lo | (uint64_t)(m[i].flags >> 16) << 32;
-		heap[hs].x = pos[off]; heap[hs].y = (uint64_t)i << 32; ++hs;
+		heap.set(hs, HeapEnt{pos[off], i, 0u}); ++hs;
 	}
 	if (hs > 1) for (size_t i = (hs >> 1) - 1; i != (size_t)-1; --i) d_heapdown(i, hs, heap);
 	while (hs > 0) {
-		const AlMatch mm = m[heap[0].y >> 32];
-		const uint64_t r = heap[0].x; const int32_t rpos = (uint32_t)r >> 1; const uint32_t span = (uint32_t)mini_span;
+		HeapEnt top = heap.get(0);
+		const AlMatch mm = m[top.mi];
+		const uint64_t r = top.x; const int32_t rpos = (uint32_t)r >> 1; const uint32_t span = (uint32_t)mini_span;
 		AlAnchor a;
 		if ((r & 1) == (mm.q_pos & 1)) {
 			a.x = (r & 0xffffffff00000000ULL) | (uint32_t)rpos;
@@ -234,12 +252,12 @@ __device__ __forceinline__ void d_anchor_heap_merge(const uint64_t *__restrict__
 		a.y |= (uint64_t)(mm.flags & 0xff) << AL_SEED_SEG_SHIFT;
 		if (mm.flags & (1u << 8)) a.y |= AL_SEED_TANDEM;
 		if (!(a.x >> 63)) out[n_for++] = a; else out[n - (++n_rev)] = a;
-		if ((uint32_t)heap[0].y < mm.n - 1) {
-			++heap[0].y;
-			const AlMatch m2 = m[heap[0].y >> 32];
-			const uint64_t off = (uint64_t)m2.off_lo | (uint64_t)(m2.flags >> 16) << 32;
-			heap[0].x = pos[off + (uint32_t)heap[0].y];
-		} else { heap[0] = heap[hs - 1]; --hs; }
+		if (top.off < mm.n - 1) {
+			++top.off;
+			const uint64_t off = (uint64_t)mm.off_lo | (uint64_t)(mm.flags >> 16) << 32;
+			top.x = pos[off + top.off];
+			heap.set(0, top);
+		} else { heap.set(0, heap.get(hs - 1)); --hs; }
 		if (hs > 0) d_heapdown(0, hs, heap);
 	}
 	for (uint64_t j = 0; j < n_rev >> 1; ++j) {                          // map.c:202-207
@@ -247,12 +265,48 @@ __device__ __forceinline__ void d_anchor_heap_merge(const uint64_t *__restrict__
 	}
 }
 
+// Fragments whose anchors have equal x (a query k-mer occurring twice: overlapping mates, tandem repeats) or that do not fit
+// the sort tiles are listed by the sort kernels and merged here, one lane per fragment, with the reference's own binary
+// heap (its pop order among equal heads is heap-shape dependent).  HCAP > 0: heap of <= HCAP lists in LDS,
+// lanes whose fragment has n_m in (LO, HCAP]; HCAP == 0: heap in HBM scratch, n_m > LO.
+template <int HCAP, int LANES>
+__global__ void __launch_bounds__(64)
+k_anchor_heap(const uint64_t *__restrict__ pos, const uint32_t *__restrict__ frag_first, const uint32_t *__restrict__ rd_len,
+              const uint64_t *__restrict__ mini_off, const AlMatch *__restrict__ match,
+              const uint32_t *__restrict__ frag_nm, const uint32_t *__restrict__ frag_na, const uint64_t *__restrict__ a_off,
+              AlAnchor *__restrict__ anchors, AlAnchor *__restrict__ heap_ws,
+              const uint32_t *__restrict__ tie_list, const unsigned int *__restrict__ tie_cnt, int lo_excl,
+              unsigned long long *__restrict__ counters, int mini_span)
+{
+	__shared__ uint32_t s_h[HCAP > 0 ? 3 * HCAP * LANES : 1];
+	const int lane = threadIdx.x;
+	const uint32_t t = blockIdx.x * LANES + lane;
+	if (lane >= LANES || t >= *tie_cnt) return;
+	const uint32_t f = tie_list[t];
+	const uint32_t n = frag_na[f], n_m = frag_nm[f];
+	if ((int)n_m <= lo_excl || (HCAP > 0 && n_m > (uint32_t)HCAP) || n == 0) return;
+	const uint32_t r0 = frag_first[f], r1 = frag_first[f + 1];
+	int qlen = 0; for (uint32_t r = r0; r < r1; ++r) qlen += (int)rd_len[r];
+	const AlMatch *m = match + mini_off[r0];
+	AlAnchor *out = anchors + a_off[f];
+	if (HCAP > 0) {
+		bool fits = true;                                // cursor < 2^16 (occurrence counts are below max_occ) and list index < 2^16
+		for (uint32_t i = 0; i < n_m; ++i) if (m[i].n > 0xffffu) fits = false;
+		if (fits) { const HeapLds<LANES> h{s_h + lane, s_h + HCAP * LANES + lane, s_h + 2 * HCAP * LANES + lane}; d_anchor_heap_merge(pos, m, n_m, n, qlen, mini_span, h, out, counters); return; }
+	}
+	const HeapGlobal h{heap_ws + mini_off[r0]};
+	d_anchor_heap_merge(pos, m, n_m, n, qlen, mini_span, h, out, counters);
+}
+template __global__ void k_anchor_heap<48, 64>(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, AlAnchor *, const uint32_t *, const unsigned int *, int, unsigned long long *, int);
+template __global__ void k_anchor_heap<96, 32>(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, AlAnchor *, const uint32_t *, const unsigned int *, int, unsigned long long *, int);
+template __global__ void k_anchor_heap<0, 64>(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, AlAnchor *, const uint32_t *, const unsigned int *, int, unsigned long long *, int);
+
 template <int CAP>
 __global__ void __launch_bounds__(64)
 k_anchor_sort(const uint64_t *__restrict__ pos, const uint32_t *__restrict__ frag_first, const uint32_t *__restrict__ rd_len,
               const uint64_t *__restrict__ mini_off, const AlMatch *__restrict__ match,
               const uint32_t *__restrict__ frag_nm, const uint32_t *__restrict__ frag_na, const uint64_t *__restrict__ a_off,
-              AlAnchor *__restrict__ anchors, AlAnchor *__restrict__ heap_ws,
+              AlAnchor *__restrict__ anchors, uint32_t *__restrict__ tie_list, unsigned int *__restrict__ tie_cnt,
               const uint32_t *__restrict__ frag_list, int n_list, unsigned long long *__restrict__ counters, int mini_span)
 {
 	__shared__ AlAnchor s[CAP];
@@ -313,7 +367,7 @@ k_anchor_sort(const uint64_t *__restrict__ pos, const uint32_t *__restrict__ fra
 		fallback = s_flag != 0;
 		if (!fallback) for (uint32_t t = lane; t < n; t += 64) out[t] = s[t];
 	}
-	if (fallback && lane == 0) d_anchor_heap_merge(pos, m, n_m, n, qlen, mini_span, heap_ws + mini_off[r0], out, counters);
+	if (fallback && lane == 0) tie_list[atomicAdd(tie_cnt, 1u)] = f;      // merged by k_anchor_heap
 }
 
 // K3 for fragments with at most 64 anchors (the bulk on a low-repeat genome): nothing but registers, so 32 wavefronts per CU
@@ -324,7 +378,7 @@ __global__ void __launch_bounds__(64)
 k_anchor_sort_small(const uint64_t *__restrict__ pos, const uint32_t *__restrict__ frag_first, const uint32_t *__restrict__ rd_len,
                     const uint64_t *__restrict__ mini_off, const AlMatch *__restrict__ match,
                     const uint32_t *__restrict__ frag_nm, const uint32_t *__restrict__ frag_na, const uint64_t *__restrict__ a_off,
-                    AlAnchor *__restrict__ anchors, AlAnchor *__restrict__ heap_ws,
+                    AlAnchor *__restrict__ anchors, uint32_t *__restrict__ tie_list, unsigned int *__restrict__ tie_cnt,
                     const uint32_t *__restrict__ frag_list, int n_list, unsigned long long *__restrict__ counters, int mini_span)
 {
 	const int lane = threadIdx.x;
@@ -336,10 +390,7 @@ k_anchor_sort_small(const uint64_t *__restrict__ pos, const uint32_t *__restrict
 	int qlen = 0; for (uint32_t r = r0; r < r1; ++r) qlen += (int)rd_len[r];
 	const AlMatch *m = match + mini_off[r0];
 	AlAnchor *out = anchors + a_off[f];
-	if (n > 64u) {                                   // not this kernel's class (the caller's ordering makes this unreachable)
-		if (lane == 0) d_anchor_heap_merge(pos, m, n_m, n, qlen, mini_span, heap_ws + mini_off[r0], out, counters);
-		return;
-	}
+	if (n > 64u) { if (lane == 0) tie_list[atomicAdd(tie_cnt, 1u)] = f; return; }   // not this kernel's class (unreachable with the caller's ordering)
 	AlMatch mm; mm.off_lo = 0; mm.n = 0; mm.q_pos = 0; mm.flags = 0;
 	if ((uint32_t)lane < n_m) mm = m[lane];
 	uint32_t incl = mm.n;
@@ -372,10 +423,7 @@ k_anchor_sort_small(const uint64_t *__restrict__ pos, const uint32_t *__restrict
 		rank += xj < x ? 1u : 0u;
 		tie = tie || (xj == x && j != (uint32_t)lane);
 	}
-	if (__ballot(tie && (uint32_t)lane < n)) {
-		if (lane == 0) d_anchor_heap_merge(pos, m, n_m, n, qlen, mini_span, heap_ws + mini_off[r0], out, counters);
-		return;
-	}
+	if (__ballot(tie && (uint32_t)lane < n)) { if (lane == 0) tie_list[atomicAdd(tie_cnt, 1u)] = f; return; }   // merged by k_anchor_heap
 	if ((uint32_t)lane < n) { AlAnchor a; a.x = x; a.y = y; out[rank] = a; }
 }
 
@@ -889,10 +937,10 @@ k_chain_lds(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a
 #undef R_T
 }
 #define INST_CHAIN_LDS(C, L) template __global__ void k_chain_lds<C, L>(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, AlAnchor *, uint64_t *, uint32_t *, uint64_t *, const uint32_t *, int, int, AlParams, unsigned long long *);
-INST_CHAIN_LDS(16, 64) INST_CHAIN_LDS(24, 64) INST_CHAIN_LDS(32, 64) INST_CHAIN_LDS(40, 64) INST_CHAIN_LDS(48, 64) INST_CHAIN_LDS(64, 64) INST_CHAIN_LDS(128, 32)
+INST_CHAIN_LDS(16, 64) INST_CHAIN_LDS(24, 64) INST_CHAIN_LDS(32, 64) INST_CHAIN_LDS(40, 64) INST_CHAIN_LDS(48, 64) INST_CHAIN_LDS(64, 64) INST_CHAIN_LDS(80, 64) INST_CHAIN_LDS(96, 64) INST_CHAIN_LDS(128, 32)
 
 // explicit instantiations used by the runtime
-template __global__ void k_anchor_sort<1024>(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, AlAnchor *, const uint32_t *, int, unsigned long long *, int);
+template __global__ void k_anchor_sort<1024>(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, uint32_t *, unsigned int *, const uint32_t *, int, unsigned long long *, int);
 template __global__ void k_chain<768>(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, AlAnchor *, uint64_t *, uint32_t *, int32_t *, uint64_t *, const uint32_t *, int, AlParams, unsigned long long *, int);
 
 // rechain decision (map.c:353-375): one lane per fragment; appends fragments that must be re-seeded with max_occ

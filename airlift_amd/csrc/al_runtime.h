@@ -54,7 +54,7 @@ struct al_ctx_s {
 	DevBuf<AlMatch> match;
 	DevBuf<unsigned long long> counters;   // [0] heap fallbacks, [1] sort-tie flags, [2] alser total, [3] n_rechain, [4..] stage specific
 	DevBuf<uint8_t> scan_tmp;
-	DevBuf<uint32_t> chain_key, chain_idx, chain_idx2;
+	DevBuf<uint32_t> chain_key, chain_idx, chain_idx2, tie_list, lb_buf;
 	DevBuf<uint64_t> a_off_p1; DevBuf<uint32_t> frag_na_p1; DevBuf<int32_t> frag_rep_p1;   // pass-1 snapshots when a re-chain pass ran (taps)
 	uint64_t n_anchor_total = 0, n_anchor_pass1 = 0;
 	uint32_t n_rechain = 0;

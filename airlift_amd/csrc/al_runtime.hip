@@ -16,8 +16,9 @@ extern "C" __global__ void k_sketch(const uint32_t *, const uint64_t *, const ui
 extern "C" __global__ void k_seed(const uint64_t *, int, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, const uint32_t *, AlMatch *, uint32_t *, uint32_t *, int32_t *, const uint32_t *, int, int);
 extern "C" __global__ void k_alser_count(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, int, int, unsigned long long *);
 extern "C" __global__ void k_rechain_test(const AlAnchor *, const uint64_t *, const uint64_t *, const uint32_t *, const int32_t *, const uint32_t *, int, uint32_t *, uint32_t *);
-template <int CAP> __global__ void k_anchor_sort(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, AlAnchor *, const uint32_t *, int, unsigned long long *, int);
-__global__ void k_anchor_sort_small(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, AlAnchor *, const uint32_t *, int, unsigned long long *, int);
+template <int CAP> __global__ void k_anchor_sort(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, uint32_t *, unsigned int *, const uint32_t *, int, unsigned long long *, int);
+__global__ void k_anchor_sort_small(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, uint32_t *, unsigned int *, const uint32_t *, int, unsigned long long *, int);
+template <int HCAP, int LANES> __global__ void k_anchor_heap(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, AlAnchor *, const uint32_t *, const unsigned int *, int, unsigned long long *, int);
 template <int CAP> __global__ void k_chain(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, AlAnchor *, uint64_t *, uint32_t *, int32_t *, uint64_t *, const uint32_t *, int, AlParams, unsigned long long *, int);
 template <int CAPL, int LANES> __global__ void k_chain_lds(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, AlAnchor *, uint64_t *, uint32_t *, uint64_t *, const uint32_t *, int, int, AlParams, unsigned long long *);
 extern "C" __global__ void k_chain_lane(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, AlAnchor *, uint64_t *, uint32_t *, int32_t *, uint64_t *, const uint32_t *, int, int, AlParams, unsigned long long *);
@@ -25,7 +26,7 @@ extern "C" __global__ void k_chain_lane(const AlAnchor *, const uint64_t *, cons
 static const char *g_stage_names[ST_N] = { "sketch", "seed_lookup", "scan", "size_order", "anchor_sort_small", "anchor_sort", "chain_lds32", "chain_lds48", "chain_lds64", "chain_lds128", "chain_wave", "rechain",
                                            "regs", "ext_prep", "ext_sort", "ext_dp_lane", "ext_dp_g4", "ext_dp_g8", "ext_dp_g22", "ext_finish", "compact" };
 // kernel behind each interval (what rocprofv3 --kernel-trace lists); "" = several small launches
-static const char *g_stage_kernels[ST_N] = { "k_sketch", "k_seed", "", "", "k_anchor_sort_small", "k_anchor_sort<1024>", "k_chain_lds<16|24|32, 64>", "k_chain_lds<40|48, 64>", "k_chain_lds<64, 64>", "k_chain_lds<128, 32>", "k_chain<768>", "",
+static const char *g_stage_kernels[ST_N] = { "k_sketch", "k_seed", "", "", "k_anchor_sort_small", "k_anchor_sort<1024>", "k_chain_lds<16|24|32, 64>", "k_chain_lds<40|48, 64>", "k_chain_lds<64, 64>", "k_chain_lds<80|96, 64>, <128, 32>", "k_chain<768>", "",
                                              "k_regs", "k_ext_prep", "", "k_ext_dp_lane<16|32, 64>", "k_ext_dp<1|2|4, 512, ..>", "k_ext_dp<8, 512, 128>", "k_ext_dp<22, 512, 352>", "k_ext_finish", "k_compact" };
 extern "C" const char *al_stage_kernel(int i) { return i >= 0 && i < ST_N ? g_stage_kernels[i] : ""; }
 extern "C" const char *al_stage_name(int i) { return i >= 0 && i < ST_N ? g_stage_names[i] : ""; }
@@ -111,6 +112,7 @@ extern "C" void al_ctx_destroy(al_ctx_t *c)
 	c->frag_nu.release(); c->rechain_list.release(); c->tmp_u32.release(); c->rd_off.release(); c->mini_off.release(); c->a_off.release(); c->u.release();
 	c->ws_u64.release(); c->tmp_u64.release(); c->frag_rep.release(); c->ws_i32.release(); c->mini.release(); c->heap_ws.release(); c->anchors.release();
 	c->chained.release(); c->match.release(); c->counters.release(); c->scan_tmp.release(); c->regs0.release(); c->regs.release(); c->reg_cnt.release();
+	c->chain_key.release(); c->chain_idx.release(); c->chain_idx2.release(); c->tie_list.release(); c->lb_buf.release();
 	c->a_off_p1.release(); c->frag_na_p1.release(); c->frag_rep_p1.release(); c->cigar.release(); c->reg_off.release(); c->cig_off.release(); c->align_ws.release(); c->seg_a.release(); c->seg_u.release();
 	for (int i = 0; i <= ST_N; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
 	if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -258,7 +260,7 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 	// one wavefront get equal trip counts.  [0, lb65) <= 64 anchors, [lb65, lb129) <= 128 anchors, rest.
 	const int lane_max = (c->P.dbg >> 27) & 1 ? 0 : 64;
 	const uint32_t *order = list; bool sorted = false;
-	uint32_t lb65 = (uint32_t)nl, lb129 = (uint32_t)nl;
+	uint32_t lb65 = (uint32_t)nl, lb81 = (uint32_t)nl, lb97 = (uint32_t)nl, lb129 = (uint32_t)nl;
 	if (first && lane_max > 0 && nl > 1024) {
 		if (c->chain_key.ensure(nl + 1) || c->chain_idx.ensure(nl + 1) || c->chain_idx2.ensure(nl + 1)) return -1;
 		hipLaunchKernelGGL(k_iota_u32, dim3((nl + 255) / 256), dim3(256), 0, s, c->chain_idx.p, (uint32_t)nl);
@@ -267,24 +269,36 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 		if (c->scan_tmp.ensure(bytes + 16)) return -1;
 		AL_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(c->scan_tmp.p, bytes, (const uint32_t *)c->frag_na.p, c->chain_key.p, (const uint32_t *)c->chain_idx.p, c->chain_idx2.p, nl, 0, 20, s));
 		order = c->chain_idx2.p; sorted = true;
-		uint32_t *d_lb = (uint32_t *)(c->counters.p + 15);            // two consecutive u32
-		const uint32_t init[2] = {(uint32_t)nl, (uint32_t)nl};
-		AL_HIP_CHECK(hipMemcpyAsync(d_lb, init, 8, hipMemcpyHostToDevice, s));
+		if (c->lb_buf.ensure(8)) return -1;
+		uint32_t *d_lb = c->lb_buf.p;
+		const uint32_t init[4] = {(uint32_t)nl, (uint32_t)nl, (uint32_t)nl, (uint32_t)nl};
+		AL_HIP_CHECK(hipMemcpyAsync(d_lb, init, 16, hipMemcpyHostToDevice, s));
 		hipLaunchKernelGGL(k_lower_bound, dim3((nl + 255) / 256), dim3(256), 0, s, c->chain_key.p, (uint32_t)nl, 65u, d_lb);
-		hipLaunchKernelGGL(k_lower_bound, dim3((nl + 255) / 256), dim3(256), 0, s, c->chain_key.p, (uint32_t)nl, 129u, d_lb + 1);
-		uint32_t lb[2];
-		AL_HIP_CHECK(hipMemcpyAsync(lb, d_lb, 8, hipMemcpyDeviceToHost, s));
+		hipLaunchKernelGGL(k_lower_bound, dim3((nl + 255) / 256), dim3(256), 0, s, c->chain_key.p, (uint32_t)nl, 81u, d_lb + 1);
+		hipLaunchKernelGGL(k_lower_bound, dim3((nl + 255) / 256), dim3(256), 0, s, c->chain_key.p, (uint32_t)nl, 97u, d_lb + 2);
+		hipLaunchKernelGGL(k_lower_bound, dim3((nl + 255) / 256), dim3(256), 0, s, c->chain_key.p, (uint32_t)nl, 129u, d_lb + 3);
+		uint32_t lb[4];
+		AL_HIP_CHECK(hipMemcpyAsync(lb, d_lb, 16, hipMemcpyDeviceToHost, s));
 		AL_HIP_CHECK(hipStreamSynchronize(s));
-		lb65 = lb[0]; lb129 = lb[1];
+		lb81 = lb[1]; lb97 = lb[2];
+		lb65 = lb[0]; lb129 = lb[3];
 	}
 	if (first) AL_HIP_CHECK(hipEventRecord(c->ev[ST_ORDER + 1], s));
 	{
 		const int n_small = sorted ? (int)lb65 : 0;
+		if (c->tie_list.ensure((size_t)nl + 2)) return -1;
+		unsigned int *tie_cnt = (unsigned int *)(c->tie_list.p + nl + 1);
+		AL_HIP_CHECK(hipMemsetAsync(tie_cnt, 0, 4, s));
 		if (n_small > 0) hipLaunchKernelGGL(k_anchor_sort_small, dim3(n_small), dim3(64), 0, s, c->di.pos, c->frag_first.p, c->rd_len.p, c->mini_off.p, c->match.p, c->frag_nm.p, c->frag_na.p,
-		                                    c->a_off.p, c->anchors.p, c->heap_ws.p, order, n_small, c->counters.p, c->mi->k);
+		                                    c->a_off.p, c->anchors.p, c->tie_list.p, tie_cnt, order, n_small, c->counters.p, c->mi->k);
 		if (first) AL_HIP_CHECK(hipEventRecord(c->ev[ST_ANCHOR_SORT_S + 1], s));
 		if (nl - n_small > 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_anchor_sort<1024>), dim3(nl - n_small), dim3(64), 0, s, c->di.pos, c->frag_first.p, c->rd_len.p, c->mini_off.p, c->match.p, c->frag_nm.p, c->frag_na.p,
-		                                         c->a_off.p, c->anchors.p, c->heap_ws.p, sorted ? order + n_small : list, nl - n_small, c->counters.p, c->mi->k);
+		                                         c->a_off.p, c->anchors.p, c->tie_list.p, tie_cnt, sorted ? order + n_small : list, nl - n_small, c->counters.p, c->mi->k);
+		// fragments the sort kernels handed over (equal keys, oversize): exact heap merge, one lane each, by heap size class
+#define LHEAP(H, LN, LO) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_anchor_heap<H, LN>), dim3((nl + LN - 1) / LN), dim3(64), 0, s, c->di.pos, c->frag_first.p, c->rd_len.p, c->mini_off.p, c->match.p, c->frag_nm.p, c->frag_na.p, \
+		                                  c->a_off.p, c->anchors.p, c->heap_ws.p, c->tie_list.p, tie_cnt, LO, c->counters.p, c->mi->k)
+		LHEAP(48, 64, -1); LHEAP(96, 32, 48); LHEAP(0, 64, 96);
+#undef LHEAP
 		if (first) AL_HIP_CHECK(hipEventRecord(c->ev[ST_ANCHOR_SORT + 1], s));
 	}
 	{
@@ -296,7 +310,14 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 		if (first) AL_HIP_CHECK(hipEventRecord(c->ev[ST_CHAIN_LDS48 + 1], s));
 		if (lane_max > 0) LCH(64, 64, 48, order, n64);
 		if (first) AL_HIP_CHECK(hipEventRecord(c->ev[ST_CHAIN_LDS64 + 1], s));
-		if (lane_max > 0 && sorted) LCH(128, 32, -1, order + lb65, (int)(lb129 - lb65));
+		if (lane_max > 0 && sorted) {   // exact ranges of the size-ordered list (lane counts differ between these classes)
+			// 64-lane wavefronts hold more fragments per CU but need enough of them to cover the chip; a thin class runs on half waves
+			const uint32_t fill = 64u * 3u * 256u * 2u;
+			uint32_t from = lb65;
+			if (lb81 - lb65 >= fill) { LCH(80, 64, -1, order + lb65, (int)(lb81 - lb65)); from = lb81; }
+			if (from == lb81 && lb97 - lb81 >= fill) { LCH(96, 64, -1, order + lb81, (int)(lb97 - lb81)); from = lb97; }
+			LCH(128, 32, -1, order + from, (int)(lb129 - from));
+		}
 		if (first) AL_HIP_CHECK(hipEventRecord(c->ev[ST_CHAIN_LDS128 + 1], s));
 #undef LCH
 		{

@@ -40,7 +40,8 @@ def make_workload(pairs, read_len, seed, ref):
     chunk = 250_000
     for s in range(0, pairs, chunk):
         n = min(chunk, pairs - s)
-        r1, r2 = g.simulate_pairs(ref, n, read_len, seed=seed + s)
+        kw = dict(ins_mean=550, ins_sd=60, ins_hi=1000) if read_len >= 200 else {}      # 250 bp PE, insert N(550,60)
+        r1, r2 = g.simulate_pairs(ref, n, read_len, seed=seed + s, **kw)
         out[s:s + n, 0] = lut[r1]; out[s:s + n, 1] = lut[r2]
     return out
 
