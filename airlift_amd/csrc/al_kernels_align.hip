@@ -948,12 +948,13 @@ struct ExtShared {
 };
 
 #define AL_LANE_QC 64              // longest query a lane-per-job DP handles
-#define AL_NCLS 9                  // job classes: 0..2 lane-per-job (target <= 16/32/64), 3..7 group DP (NB = 1,2,4,8,22), 8 LDS-row DP; 9 = empty slot
+#define AL_NCLS 10                 // job classes: 0..2 lane-per-job (target <= 16/32/64), 3..8 group DP (NB = 1,2,4,8,22,32), 9 LDS-row DP; 10 = empty slot
+#define AL_HIST_N 24               // [0..AL_NCLS] jobs per class, [12..17] job cursors of the group-DP classes
 __device__ __forceinline__ int d_job_class(int qlen, int tlen, int lane_ok)
 {
 	const int b = (tlen + 15) / 16;
 	if (lane_ok && qlen <= AL_LANE_QC && b <= 2) return b <= 1 ? 0 : 1;   // (class 2, targets <= 64, measured slower than the group DP: LDS-bound)
-	return b <= 1 ? 3 : b <= 2 ? 4 : b <= 4 ? 5 : b <= 8 ? 6 : b <= 22 ? 7 : 8;
+	return b <= 1 ? 3 : b <= 2 ? 4 : b <= 4 ? 5 : b <= 8 ? 6 : b <= 22 ? 7 : b <= 32 ? 8 : 9;
 }
 
 extern "C" __global__ void __launch_bounds__(256, AL_LB_PREP)
@@ -1073,7 +1074,7 @@ template <int QMAXJ, int TMAXJ> struct JobLds {
 
 // DP jobs of one block-count class: 4 jobs per wavefront, all running d_ksw_reg<NB>
 template <int NB, int QMAXJ, int TMAXJ>
-__global__ void __launch_bounds__(64, (NB <= 4 ? 4 : NB <= 8 ? AL_LB_DP8 : AL_LB_DP22))
+__global__ void __launch_bounds__(64, (NB <= 4 ? 4 : NB <= 8 ? AL_LB_DP8 : NB <= 22 ? AL_LB_DP22 : 2))
 k_ext_dp(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_off, const uint32_t *__restrict__ rd_len,
          AlignShared G, ExtShared E, const uint32_t *__restrict__ sorted_idx, uint32_t first, uint32_t count,
          uint8_t *__restrict__ gws, size_t gws_stride, size_t p_bytes, size_t cig_words, AlParams P)
@@ -1086,7 +1087,7 @@ k_ext_dp(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_of
 	const int bw = (int)(P.bw * 1.5 + 1.);
 	// jobs are handed out largest first from a shared cursor, four neighbours of the size-sorted list per wavefront:
 	// the grid is as large as the chip holds resident and no wavefront is left with a long tail
-	unsigned long long *cursor = E.hist + 10 + (NB == 1 ? 0 : NB == 2 ? 1 : NB == 4 ? 2 : NB == 8 ? 3 : 4);
+	unsigned long long *cursor = E.hist + 12 + (NB == 1 ? 0 : NB == 2 ? 1 : NB == 4 ? 2 : NB == 8 ? 3 : NB == 22 ? 4 : 5);
 	for (;;) {
 		unsigned long long base = 0;
 		if (threadIdx.x == 0) base = atomicAdd(cursor, 4ULL);
@@ -1613,7 +1614,7 @@ int al_run_align_stage(al_ctx_t *c)
 	if ((c->P.dbg >> 26) & 1) { if (launch_mono(nullptr, nf)) return -1; for (int i = ST_EXT_PREP; i <= ST_EXT_FINISH; ++i) AL_HIP_CHECK(hipEventRecord(c->ev[i + 1], s)); }   // AL_DBG bit 26: whole batch through the monolithic kernel
 	else {
 		// ---- fast path: prep -> size-sorted DP job queue -> finish -> (slow list) monolithic
-		if (A->n_jobs.ensure(nf + 2) || A->n_sc.ensure(nf + 2) || A->job_off.ensure(nf + 2) || A->sc_off.ensure(nf + 2) || A->frag_slow.ensure(nf + 1) || A->slow_list.ensure(nf + 1) || A->hist.ensure(16)) return -1;
+		if (A->n_jobs.ensure(nf + 2) || A->n_sc.ensure(nf + 2) || A->job_off.ensure(nf + 2) || A->sc_off.ensure(nf + 2) || A->frag_slow.ensure(nf + 1) || A->slow_list.ensure(nf + 1) || A->hist.ensure(AL_HIST_N)) return -1;
 		hipLaunchKernelGGL(k_ext_counts, dim3((nf + 256) / 256), dim3(256), 0, s, c->frag_first.p, W, A->n_jobs.p, A->n_sc.p, nf);
 		if (scan32(c, A->n_jobs.p, A->job_off.p, nf) || scan32(c, A->n_sc.p, A->sc_off.p, nf)) return -1;
 		uint64_t tot[2] = {0, 0};
@@ -1623,7 +1624,7 @@ int al_run_align_stage(al_ctx_t *c)
 		const uint32_t nj = (uint32_t)tot[0];
 		if (A->jobs.ensure(nj + 1) || A->outs.ensure(nj + 1) || A->job_key.ensure(nj + 1) || A->job_key2.ensure(nj + 1) || A->job_idx.ensure(nj + 1) || A->job_idx2.ensure(nj + 1) ||
 		    A->rext.ensure(2 * Btot + 1) || A->sc_ws.ensure(tot[1] + 1)) return -1;
-		AL_HIP_CHECK(hipMemsetAsync(A->hist.p, 0, 16 * 8, s));
+		AL_HIP_CHECK(hipMemsetAsync(A->hist.p, 0, AL_HIST_N * 8, s));
 		ExtShared E; E.jobs = A->jobs.p; E.outs = A->outs.p; E.rext = A->rext.p; E.job_off = A->job_off.p; E.frag_slow = A->frag_slow.p; E.job_key = A->job_key.p; E.hist = A->hist.p;
 		hipLaunchKernelGGL(k_ext_prep, dim3((nf + 255) / 256), dim3(256), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, c->frag_first.p, W, G, E, nf, c->P, tmax, qmax);
 		AL_HIP_CHECK(hipEventRecord(c->ev[ST_EXT_PREP + 1], s));
@@ -1637,9 +1638,9 @@ int al_run_align_stage(al_ctx_t *c)
 			AL_HIP_CHECK(hipEventRecord(c->ev[ST_EXT_SORT + 1], s));
 			AL_HIP_CHECK(hipMemcpyAsync(hist, A->hist.p, (AL_NCLS + 1) * 8, hipMemcpyDeviceToHost, s));
 			AL_HIP_CHECK(hipStreamSynchronize(s));
-			if ((c->P.dbg >> 30) & 1) { fprintf(stderr, "[airlift] DP jobs per class (lane16 lane32 lane64 g1 g2 g4 g8 g22 lds | empty):"); for (int i = 0; i <= AL_NCLS; ++i) fprintf(stderr, " %llu", hist[i]); fprintf(stderr, "\n"); }
+			if ((c->P.dbg >> 30) & 1) { fprintf(stderr, "[airlift] DP jobs per class (lane16 lane32 lane64 g1 g2 g4 g8 g22 g32 lds | empty):"); for (int i = 0; i <= AL_NCLS; ++i) fprintf(stderr, " %llu", hist[i]); fprintf(stderr, "\n"); }
 			// one launch per job class over its slice of the sorted job list
-			static const int NBs[5] = {1, 2, 4, 8, 22};
+			static const int NBs[6] = {1, 2, 4, 8, 22, 32};
 			uint32_t first = 0;
 			for (int cls = 0; cls < AL_NCLS; ++cls) {
 				const uint32_t cnt = (uint32_t)hist[cls];
@@ -1655,14 +1656,14 @@ int al_run_align_stage(al_ctx_t *c)
 					if (cls == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ext_dp_lane<16, AL_LANE_QC>), dim3(nw), dim3(64), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, G, E, A->job_idx2.p, first, cnt, A->gws.p, tbs, c->P);
 					else if (cls == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ext_dp_lane<32, AL_LANE_QC>), dim3(nw), dim3(64), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, G, E, A->job_idx2.p, first, cnt, A->gws.p, tbs, c->P);
 					else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ext_dp_lane<64, AL_LANE_QC>), dim3(nw), dim3(64), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, G, E, A->job_idx2.p, first, cnt, A->gws.p, tbs, c->P);
-				} else if (cls < 8) {
+				} else if (cls < 9) {
 					const int NB = NBs[cls - 3];
 					const size_t pb = (((size_t)(Lmax + 16 * NB) * (size_t)(NB + 1) * 16) + 63) / 64 * 64, cw = ((size_t)(Lmax + 16 * NB) + 31) / 16 * 16, st2 = pb + cw * 8;
 					int nbj = (int)((cnt + 3) / 4); { static const int caps[3] = { getenv("AL_CAP4") ? atoi(getenv("AL_CAP4")) : 4096, getenv("AL_CAP8") ? atoi(getenv("AL_CAP8")) : 4096, getenv("AL_CAP22") ? atoi(getenv("AL_CAP22")) : 3072 };
-					  const int cap = NB <= 4 ? caps[0] : NB <= 8 ? caps[1] : caps[2]; if (nbj > cap) nbj = cap; }
+					  const int cap = NB <= 4 ? caps[0] : NB <= 8 ? caps[1] : NB <= 22 ? caps[2] : 2048; if (nbj > cap) nbj = cap; }
 					if (A->gws.ensure((size_t)nbj * 4 * st2 + 64)) return -1;
 #define LAUNCH_DP(NBV) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ext_dp<NBV, 512, NBV * 16>), dim3(nbj), dim3(64), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, G, E, A->job_idx2.p, first, cnt, A->gws.p, st2, pb, cw, c->P)
-					if (NB == 1) LAUNCH_DP(1); else if (NB == 2) LAUNCH_DP(2); else if (NB == 4) LAUNCH_DP(4); else if (NB == 8) LAUNCH_DP(8); else LAUNCH_DP(22);
+					if (NB == 1) LAUNCH_DP(1); else if (NB == 2) LAUNCH_DP(2); else if (NB == 4) LAUNCH_DP(4); else if (NB == 8) LAUNCH_DP(8); else if (NB == 22) LAUNCH_DP(22); else LAUNCH_DP(32);
 #undef LAUNCH_DP
 				} else {
 					int nbj = (int)cnt; if (nbj > 2048) nbj = 2048;

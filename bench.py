@@ -32,7 +32,7 @@ WORKLOADS = {"c2": "C2: yeast-sized synthetic reference pair (16 contigs, 12.16 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured streaming ceiling
 
 
-def make_workload(pairs, read_len, seed, ref):
+def make_workload(pairs, read_len, seed, ref, ins_mean=None):
     """ASCII reads for `pairs` fragments, concatenated fragment-major (mate1, mate2, mate1, ...)."""
     import gen_synth as g
     lut = np.frombuffer(b"ACGTN", dtype=np.uint8)
@@ -41,6 +41,8 @@ def make_workload(pairs, read_len, seed, ref):
     for s in range(0, pairs, chunk):
         n = min(chunk, pairs - s)
         kw = dict(ins_mean=550, ins_sd=60, ins_hi=1000) if read_len >= 200 else {}      # 250 bp PE, insert N(550,60)
+        if ins_mean:
+            kw = dict(ins_mean=ins_mean, ins_sd=ins_mean // 10, ins_hi=1000)
         r1, r2 = g.simulate_pairs(ref, n, read_len, seed=seed + s, **kw)
         out[s:s + n, 0] = lut[r1]; out[s:s + n, 1] = lut[r2]
     return out
@@ -117,6 +119,7 @@ def main():
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--cpu-sample-pairs", type=int, default=1_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ins-mean", type=int, default=0, help="mean insert size override (short inserts make the mates overlap: equal-key anchors)")
     ap.add_argument("--config", default="c2", help="synthetic reference of tools/gen_synth.py: c2 (BASELINE configs[1], default), c3 (100 Mbp), c4 (3.1 Gbp)")
     a = ap.parse_args()
 
@@ -147,7 +150,7 @@ def main():
     t0 = time.time()
     idx = A.Index(fasta=os.path.join(tmp, "ref.fa"), on_device=local if world > 1 else 0)
     t_index = time.time() - t0
-    arr = make_workload(a.pairs, a.read_len, 20261002 + 7919 * rank, ref)
+    arr = make_workload(a.pairs, a.read_len, 20261002 + 7919 * rank, ref, a.ins_mean)
     ctx = A.Context(idx, device=local if world > 1 else 0)
     L.al_ctx_set_threads(ctx.h, min(32, os.cpu_count() or 1))       # host packing threads (outside the timed region)
     nf = a.pairs
