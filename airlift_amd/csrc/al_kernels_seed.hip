@@ -266,7 +266,7 @@ __device__ __forceinline__ void d_anchor_heap_merge(const uint64_t *__restrict__
 }
 
 // Fragments whose anchors have equal x (a query k-mer occurring twice: overlapping mates, tandem repeats) or that do not fit
-// the sort tiles are listed by the sort kernels and merged here, one lane per fragment, with the reference's own binary
+// the sort tiles are flagged by the sort kernels (a flag per fragment: no contended atomic) and merged here, one lane per fragment, with the reference's own binary
 // heap (its pop order among equal heads is heap-shape dependent).  HCAP > 0: heap of <= HCAP lists in LDS,
 // lanes whose fragment has n_m in (LO, HCAP]; HCAP == 0: heap in HBM scratch, n_m > LO.
 template <int HCAP, int LANES>
@@ -275,14 +275,15 @@ k_anchor_heap(const uint64_t *__restrict__ pos, const uint32_t *__restrict__ fra
               const uint64_t *__restrict__ mini_off, const AlMatch *__restrict__ match,
               const uint32_t *__restrict__ frag_nm, const uint32_t *__restrict__ frag_na, const uint64_t *__restrict__ a_off,
               AlAnchor *__restrict__ anchors, AlAnchor *__restrict__ heap_ws,
-              const uint32_t *__restrict__ tie_list, const unsigned int *__restrict__ tie_cnt, int lo_excl,
+              const uint32_t *__restrict__ tie_flag, const uint32_t *__restrict__ frag_list, int n_list, int lo_excl,
               unsigned long long *__restrict__ counters, int mini_span)
 {
 	__shared__ uint32_t s_h[HCAP > 0 ? 3 * HCAP * LANES : 1];
 	const int lane = threadIdx.x;
 	const uint32_t t = blockIdx.x * LANES + lane;
-	if (lane >= LANES || t >= *tie_cnt) return;
-	const uint32_t f = tie_list[t];
+	if (lane >= LANES || t >= (uint32_t)n_list) return;
+	const uint32_t f = frag_list ? frag_list[t] : t;
+	if (!tie_flag[f]) return;
 	const uint32_t n = frag_na[f], n_m = frag_nm[f];
 	if ((int)n_m <= lo_excl || (HCAP > 0 && n_m > (uint32_t)HCAP) || n == 0) return;
 	const uint32_t r0 = frag_first[f], r1 = frag_first[f + 1];
@@ -297,9 +298,9 @@ k_anchor_heap(const uint64_t *__restrict__ pos, const uint32_t *__restrict__ fra
 	const HeapGlobal h{heap_ws + mini_off[r0]};
 	d_anchor_heap_merge(pos, m, n_m, n, qlen, mini_span, h, out, counters);
 }
-template __global__ void k_anchor_heap<48, 64>(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, AlAnchor *, const uint32_t *, const unsigned int *, int, unsigned long long *, int);
-template __global__ void k_anchor_heap<96, 32>(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, AlAnchor *, const uint32_t *, const unsigned int *, int, unsigned long long *, int);
-template __global__ void k_anchor_heap<0, 64>(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, AlAnchor *, const uint32_t *, const unsigned int *, int, unsigned long long *, int);
+template __global__ void k_anchor_heap<48, 64>(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, AlAnchor *, const uint32_t *, const uint32_t *, int, int, unsigned long long *, int);
+template __global__ void k_anchor_heap<96, 32>(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, AlAnchor *, const uint32_t *, const uint32_t *, int, int, unsigned long long *, int);
+template __global__ void k_anchor_heap<0, 64>(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, AlAnchor *, const uint32_t *, const uint32_t *, int, int, unsigned long long *, int);
 
 template <int CAP>
 __global__ void __launch_bounds__(64)
@@ -367,7 +368,7 @@ k_anchor_sort(const uint64_t *__restrict__ pos, const uint32_t *__restrict__ fra
 		fallback = s_flag != 0;
 		if (!fallback) for (uint32_t t = lane; t < n; t += 64) out[t] = s[t];
 	}
-	if (fallback && lane == 0) tie_list[atomicAdd(tie_cnt, 1u)] = f;      // merged by k_anchor_heap
+	if (fallback && lane == 0) tie_list[f] = 1u;                           // merged by k_anchor_heap
 }
 
 // K3 for fragments with at most 64 anchors (the bulk on a low-repeat genome): nothing but registers, so 32 wavefronts per CU
@@ -390,7 +391,7 @@ k_anchor_sort_small(const uint64_t *__restrict__ pos, const uint32_t *__restrict
 	int qlen = 0; for (uint32_t r = r0; r < r1; ++r) qlen += (int)rd_len[r];
 	const AlMatch *m = match + mini_off[r0];
 	AlAnchor *out = anchors + a_off[f];
-	if (n > 64u) { if (lane == 0) tie_list[atomicAdd(tie_cnt, 1u)] = f; return; }   // not this kernel's class (unreachable with the caller's ordering)
+	if (n > 64u) { if (lane == 0) tie_list[f] = 1u; return; }             // not this kernel's class (unreachable with the caller's ordering)
 	AlMatch mm; mm.off_lo = 0; mm.n = 0; mm.q_pos = 0; mm.flags = 0;
 	if ((uint32_t)lane < n_m) mm = m[lane];
 	uint32_t incl = mm.n;
@@ -423,7 +424,7 @@ k_anchor_sort_small(const uint64_t *__restrict__ pos, const uint32_t *__restrict
 		rank += xj < x ? 1u : 0u;
 		tie = tie || (xj == x && j != (uint32_t)lane);
 	}
-	if (__ballot(tie && (uint32_t)lane < n)) { if (lane == 0) tie_list[atomicAdd(tie_cnt, 1u)] = f; return; }   // merged by k_anchor_heap
+	if (__ballot(tie && (uint32_t)lane < n)) { if (lane == 0) tie_list[f] = 1u; return; }   // merged by k_anchor_heap
 	if ((uint32_t)lane < n) { AlAnchor a; a.x = x; a.y = y; out[rank] = a; }
 }
 

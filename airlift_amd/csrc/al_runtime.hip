@@ -18,7 +18,7 @@ extern "C" __global__ void k_alser_count(const AlAnchor *, const uint64_t *, con
 extern "C" __global__ void k_rechain_test(const AlAnchor *, const uint64_t *, const uint64_t *, const uint32_t *, const int32_t *, const uint32_t *, int, uint32_t *, uint32_t *);
 template <int CAP> __global__ void k_anchor_sort(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, uint32_t *, unsigned int *, const uint32_t *, int, unsigned long long *, int);
 __global__ void k_anchor_sort_small(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, uint32_t *, unsigned int *, const uint32_t *, int, unsigned long long *, int);
-template <int HCAP, int LANES> __global__ void k_anchor_heap(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, AlAnchor *, const uint32_t *, const unsigned int *, int, unsigned long long *, int);
+template <int HCAP, int LANES> __global__ void k_anchor_heap(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, AlAnchor *, const uint32_t *, const uint32_t *, int, int, unsigned long long *, int);
 template <int CAP> __global__ void k_chain(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, AlAnchor *, uint64_t *, uint32_t *, int32_t *, uint64_t *, const uint32_t *, int, AlParams, unsigned long long *, int);
 template <int CAPL, int LANES> __global__ void k_chain_lds(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, AlAnchor *, uint64_t *, uint32_t *, uint64_t *, const uint32_t *, int, int, AlParams, unsigned long long *);
 extern "C" __global__ void k_chain_lane(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, AlAnchor *, uint64_t *, uint32_t *, int32_t *, uint64_t *, const uint32_t *, int, int, AlParams, unsigned long long *);
@@ -286,9 +286,9 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 	if (first) AL_HIP_CHECK(hipEventRecord(c->ev[ST_ORDER + 1], s));
 	{
 		const int n_small = sorted ? (int)lb65 : 0;
-		if (c->tie_list.ensure((size_t)nl + 2)) return -1;
-		unsigned int *tie_cnt = (unsigned int *)(c->tie_list.p + nl + 1);
-		AL_HIP_CHECK(hipMemsetAsync(tie_cnt, 0, 4, s));
+		if (c->tie_list.ensure((size_t)c->n_frag + 2)) return -1;         // one flag per fragment id
+		unsigned int *tie_cnt = nullptr;
+		AL_HIP_CHECK(hipMemsetAsync(c->tie_list.p, 0, ((size_t)c->n_frag + 1) * 4, s));
 		if (n_small > 0) hipLaunchKernelGGL(k_anchor_sort_small, dim3(n_small), dim3(64), 0, s, c->di.pos, c->frag_first.p, c->rd_len.p, c->mini_off.p, c->match.p, c->frag_nm.p, c->frag_na.p,
 		                                    c->a_off.p, c->anchors.p, c->tie_list.p, tie_cnt, order, n_small, c->counters.p, c->mi->k);
 		if (first) AL_HIP_CHECK(hipEventRecord(c->ev[ST_ANCHOR_SORT_S + 1], s));
@@ -296,7 +296,7 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 		                                         c->a_off.p, c->anchors.p, c->tie_list.p, tie_cnt, sorted ? order + n_small : list, nl - n_small, c->counters.p, c->mi->k);
 		// fragments the sort kernels handed over (equal keys, oversize): exact heap merge, one lane each, by heap size class
 #define LHEAP(H, LN, LO) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_anchor_heap<H, LN>), dim3((nl + LN - 1) / LN), dim3(64), 0, s, c->di.pos, c->frag_first.p, c->rd_len.p, c->mini_off.p, c->match.p, c->frag_nm.p, c->frag_na.p, \
-		                                  c->a_off.p, c->anchors.p, c->heap_ws.p, c->tie_list.p, tie_cnt, LO, c->counters.p, c->mi->k)
+		                                  c->a_off.p, c->anchors.p, c->heap_ws.p, c->tie_list.p, order, nl, LO, c->counters.p, c->mi->k)
 		LHEAP(48, 64, -1); LHEAP(96, 32, 48); LHEAP(0, 64, 96);
 #undef LHEAP
 		if (first) AL_HIP_CHECK(hipEventRecord(c->ev[ST_ANCHOR_SORT + 1], s));
