@@ -28,54 +28,62 @@ k_sketch(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_of
          const uint64_t *__restrict__ mini_off, AlAnchor *__restrict__ mini, uint32_t *__restrict__ mini_cnt,
          int n_reads, int w, int k)
 {
-	extern __shared__ uint64_t lds[];           // bx[w][64] then by[w][64] (y low word kept as u64 for simplicity)
+	// One 64-bit ring entry per window slot: hash << 14 | pos << 1 | strand (a valid entry always has span == k and reads are
+	// shorter than 8192 bases), UINT64_MAX = no k-mer.  The reference's comparisons are on x = hash<<8|span, i.e. on the
+	// hash part only (E >> 14); "same x, different y" is "same hash part, different entry".
+	extern __shared__ uint64_t lds[];           // ring[w][64]
 	const int lane = threadIdx.x;
 	const int r = blockIdx.x * 64 + lane;
-	uint64_t *bx = lds + lane, *by = lds + (size_t)w * 64 + lane;
+	uint64_t *ring = lds + lane;
 	if (r >= n_reads) return;
 	const uint32_t len = rd_len[r];
 	const uint32_t *seq = rd_seq + rd_off[r];
 	AlAnchor *out = mini + mini_off[r];
 	uint32_t cnt = 0;
 	const uint64_t shift1 = 2 * (k - 1), mask = (1ULL << 2 * k) - 1;
-	uint64_t kmer0 = 0, kmer1 = 0, minx = UINT64_MAX, miny = UINT64_MAX;
+	uint64_t kmer0 = 0, kmer1 = 0, mn = UINT64_MAX;
 	int l = 0, buf_pos = 0, min_pos = 0;
-	for (int j = 0; j < w; ++j) bx[j * 64] = UINT64_MAX, by[j * 64] = UINT64_MAX;
+	for (int j = 0; j < w; ++j) ring[j * 64] = UINT64_MAX;
+#define HX(e) ((e) >> 14)
+#define EMIT(e) do { const uint64_t e__ = (e); out[cnt].x = HX(e__) << 8 | (uint64_t)k; out[cnt].y = e__ & 0x3fffULL; ++cnt; } while (0)
 	uint32_t word = 0;
 	for (uint32_t i = 0; i < len; ++i) {
 		if ((i & 7) == 0) word = seq[i >> 3];
 		const int c = (word >> ((i & 7) << 2)) & 0xf;
-		uint64_t ix = UINT64_MAX, iy = UINT64_MAX;
+		uint64_t info = UINT64_MAX;
 		if (c < 4) {
-			const int span = l + 1 < k ? l + 1 : k;
 			kmer0 = (kmer0 << 2 | (uint64_t)c) & mask;
 			kmer1 = (kmer1 >> 2) | (3ULL ^ (uint64_t)c) << shift1;
 			if (kmer0 == kmer1) continue;                                   // sketch.c:108
 			const int z = kmer0 < kmer1 ? 0 : 1;
 			++l;
-			if (l >= k) { ix = d_hash64m(z ? kmer1 : kmer0, mask) << 8 | (uint64_t)span; iy = (uint64_t)i << 1 | (uint64_t)z; }
+			if (l >= k) info = d_hash64m(z ? kmer1 : kmer0, mask) << 14 | (uint64_t)i << 1 | (uint64_t)z;
 		} else l = 0;
-		bx[buf_pos * 64] = ix; by[buf_pos * 64] = iy;
-		if (l == w + k - 1 && minx != UINT64_MAX) {                         // sketch.c:117-122
-			for (int j = buf_pos + 1; j < w; ++j) { uint64_t x = bx[j * 64], y = by[j * 64]; if (minx == x && y != miny) out[cnt].x = x, out[cnt].y = y, ++cnt; }
-			for (int j = 0; j < buf_pos; ++j)     { uint64_t x = bx[j * 64], y = by[j * 64]; if (minx == x && y != miny) out[cnt].x = x, out[cnt].y = y, ++cnt; }
+		ring[buf_pos * 64] = info;
+		const uint64_t mx = HX(mn);
+		if (l == w + k - 1 && mn != UINT64_MAX) {                           // sketch.c:117-122
+			for (int j = buf_pos + 1; j < w; ++j) { const uint64_t e = ring[j * 64]; if (mx == HX(e) && e != mn) EMIT(e); }
+			for (int j = 0; j < buf_pos; ++j)     { const uint64_t e = ring[j * 64]; if (mx == HX(e) && e != mn) EMIT(e); }
 		}
-		if (ix <= minx) {                                                   // sketch.c:123-125
-			if (l >= w + k && minx != UINT64_MAX) out[cnt].x = minx, out[cnt].y = miny, ++cnt;
-			minx = ix, miny = iy, min_pos = buf_pos;
+		if (HX(info) <= mx) {                                               // sketch.c:123-125 (UINT64_MAX >> 14 is the largest hash part)
+			if (l >= w + k && mn != UINT64_MAX) EMIT(mn);
+			mn = info; min_pos = buf_pos;
 		} else if (buf_pos == min_pos) {                                    // sketch.c:126-138
-			if (l >= w + k - 1 && minx != UINT64_MAX) out[cnt].x = minx, out[cnt].y = miny, ++cnt;
-			minx = UINT64_MAX;
-			for (int j = buf_pos + 1; j < w; ++j) { uint64_t x = bx[j * 64]; if (minx >= x) minx = x, miny = by[j * 64], min_pos = j; }
-			for (int j = 0; j <= buf_pos; ++j)    { uint64_t x = bx[j * 64]; if (minx >= x) minx = x, miny = by[j * 64], min_pos = j; }
-			if (l >= w + k - 1 && minx != UINT64_MAX) {
-				for (int j = buf_pos + 1; j < w; ++j) { uint64_t x = bx[j * 64], y = by[j * 64]; if (minx == x && miny != y) out[cnt].x = x, out[cnt].y = y, ++cnt; }
-				for (int j = 0; j <= buf_pos; ++j)    { uint64_t x = bx[j * 64], y = by[j * 64]; if (minx == x && miny != y) out[cnt].x = x, out[cnt].y = y, ++cnt; }
+			if (l >= w + k - 1 && mn != UINT64_MAX) EMIT(mn);
+			mn = UINT64_MAX;
+			for (int j = buf_pos + 1; j < w; ++j) { const uint64_t e = ring[j * 64]; if (HX(mn) >= HX(e)) mn = e, min_pos = j; }
+			for (int j = 0; j <= buf_pos; ++j)    { const uint64_t e = ring[j * 64]; if (HX(mn) >= HX(e)) mn = e, min_pos = j; }
+			if (l >= w + k - 1 && mn != UINT64_MAX) {
+				const uint64_t m2 = HX(mn);
+				for (int j = buf_pos + 1; j < w; ++j) { const uint64_t e = ring[j * 64]; if (m2 == HX(e) && mn != e) EMIT(e); }
+				for (int j = 0; j <= buf_pos; ++j)    { const uint64_t e = ring[j * 64]; if (m2 == HX(e) && mn != e) EMIT(e); }
 			}
 		}
 		if (++buf_pos == w) buf_pos = 0;
 	}
-	if (minx != UINT64_MAX) out[cnt].x = minx, out[cnt].y = miny, ++cnt;
+	if (mn != UINT64_MAX) EMIT(mn);
+#undef HX
+#undef EMIT
 	mini_cnt[r] = cnt;
 }
 

@@ -340,7 +340,7 @@ int al_run_seed_stages(al_ctx_t *c)
 	AL_HIP_CHECK(hipMemsetAsync(c->counters.p, 0, 16 * sizeof(unsigned long long), s));
 	AL_HIP_CHECK(hipEventRecord(c->ev[0], s));
 	const int nr = c->n_reads, w = c->mi->w, k = c->mi->k;
-	if (nr > 0) hipLaunchKernelGGL(k_sketch, dim3((nr + 63) / 64), dim3(64), (size_t)w * 64 * 16, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, c->mini_off.p, c->mini.p, c->mini_cnt.p, nr, w, k);
+	if (nr > 0) hipLaunchKernelGGL(k_sketch, dim3((nr + 63) / 64), dim3(64), (size_t)w * 64 * 8, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, c->mini_off.p, c->mini.p, c->mini_cnt.p, nr, w, k);
 	AL_HIP_CHECK(hipEventRecord(c->ev[ST_SKETCH + 1], s));
 	if (c->n_frag == 0) { for (int i = ST_SEED; i < ST_N; ++i) AL_HIP_CHECK(hipEventRecord(c->ev[i + 1], s)); return 0; }
 	if (run_seed_chain(c, nullptr, c->n_frag, c->opt.mid_occ, 0, true)) return -1;
