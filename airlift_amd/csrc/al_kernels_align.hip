@@ -746,6 +746,52 @@ k_regs(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__ u_all,
 	if (P.max_gap_ref > 0) max_gap_ref = P.max_gap_ref;
 	else if (P.max_frag_len > 0) { max_gap_ref = P.max_frag_len - qlen_sum; if (max_gap_ref < P.max_gap) max_gap_ref = P.max_gap; }
 	else max_gap_ref = P.max_gap;
+	if (n_u == 1 && n_segs == 2 && !((P.dbg >> 20) & 1)) {
+		// One chain, paired end (the common fragment): the fragment-level hit has no competitor, so chain_post (map.c:249-258)
+		// cannot change it and only mm_seg_gen (hit.c:356-410) matters.  Two passes over the chain's anchors (count, then
+		// split + coordinates + fuzzy lengths), both per-mate hit records built in registers and stored once; nothing else
+		// of the per-fragment workspace is touched.  Same result as the general code below for n_u == 1.
+		const uint64_t u0 = u[0]; const int cnt = (int32_t)(uint32_t)u0;
+		uint32_t c1 = 0;
+		for (int j = 0; j < cnt; ++j) c1 += (uint32_t)((a[j].y & AL_SEED_SEG_MASK) >> AL_SEED_SEG_SHIFT) & 1u;
+		const uint32_t c0 = (uint32_t)cnt - c1;
+		AlAnchor *const sa0 = ws.seg_a[0], *const sa1 = sa0 + c0;
+		uint32_t w0 = 0, w1 = 0;
+		AlAnchor f0{0, 0}, f1{0, 0}, l0{0, 0}, l1{0, 0};                       // first / last (= previous) anchor of each mate, y rebased
+		int32_t bl0 = 0, ml0 = 0, bl1 = 0, ml1 = 0;
+		for (int j = 0; j < cnt; ++j) {
+			AlAnchor a1 = a[j]; const bool s1 = ((a1.y & AL_SEED_SEG_MASK) >> AL_SEED_SEG_SHIFT) & 1;
+			const int qls = s1 ? ql1 : ql0, acc = s1 ? ql0 : 0;
+			a1.y -= (a1.x >> 63) ? (uint64_t)(qlen_sum - (qls + acc)) : (uint64_t)acc;
+			const int span = (int)(a1.y >> 32 & 0xff);
+			const bool first = s1 ? w1 == 0 : w0 == 0;
+			const AlAnchor pv = s1 ? l1 : l0;
+			const int tl = (int32_t)a1.x - (int32_t)pv.x, ql = (int32_t)a1.y - (int32_t)pv.y;      // mm_cal_fuzzy_len, hit.c:8-24
+			const int db = first ? span : (tl > ql ? tl : ql), dm = first ? span : (tl > span && ql > span ? span : tl < ql ? tl : ql);
+			if (s1) { if (first) f1 = a1; l1 = a1; bl1 += db; ml1 += dm; sa1[w1++] = a1; }
+			else { if (first) f0 = a1; l0 = a1; bl0 += db; ml0 += dm; sa0[w0++] = a1; }
+		}
+		auto make = [&](const uint32_t sid, const uint32_t c, const AlAnchor &fa, const AlAnchor &la, const int32_t blen, const int32_t mlen, const int qlen) -> AlReg {
+			AlReg R; d_reg_clear(&R);                                              // mm_gen_regs for one chain (hit.c:52-88) + mm_reg_set_coor (hit.c:26-41)
+			const uint32_t h = (uint32_t)d_hash64((d_hash64(fa.x) + d_hash64(fa.y)) ^ hash);
+			const uint64_t zx = ((u0 >> 32 << 32) | c) ^ h;
+			R.id = 0; R.parent = 0; R.score = R.score0 = (int32_t)(zx >> 32); R.hash = (uint32_t)zx; R.cnt = (int32_t)c; R.as = 0;
+			const int32_t q_span = (int32_t)(fa.y >> 32 & 0xff); const int rev = (int)(fa.x >> 63);
+			R.flags = (rev ? ALR_REV : 0) | ALR_SEG_SPLIT | (sid << 8);
+			R.rid = (int32_t)(fa.x << 1 >> 33);
+			R.rs = (int32_t)fa.x + 1 > q_span ? (int32_t)fa.x + 1 - q_span : 0;
+			R.re = (int32_t)la.x + 1;
+			if (!rev) { R.qs = (int32_t)fa.y + 1 - q_span; R.qe = (int32_t)la.y + 1; }
+			else { R.qs = qlen - ((int32_t)la.y + 1); R.qe = qlen - ((int32_t)fa.y + 1 - q_span); }
+			R.mlen = mlen; R.blen = blen;
+			return R;
+		};
+		if (c0) ws.mreg[0][0] = make(0u, c0, f0, l0, bl0, ml0, ql0);
+		if (c1) ws.mreg[1][0] = make(1u, c1, f1, l1, bl1, ml1, ql1);
+		W.reg_cnt[r0] = c0 ? 1u : 0u; W.reg_cnt[r0 + 1] = c1 ? 1u : 0u;
+		W.seg_na[r0] = c0; W.seg_na[r0 + 1] = c1;
+		return;
+	}
 	bool tie = d_gen_regs(hash, qlen_sum, (int)n_u, u, a, ws.regs0, ws.aux128);
 	int n0 = (int)n_u;
 	d_set_parent(P.mask_level, n0, ws.regs0, P.a * 2 + P.b, ws.aux64, ws.auxi);                       // chain_post, map.c:249-258
