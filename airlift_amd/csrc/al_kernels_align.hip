@@ -701,6 +701,37 @@ __device__ __forceinline__ void d_pair(const AlParams &P, int max_gap_ref, const
 	d_pair2(P, max_gap_ref, qlens[0], qlens[1], n_regs[0], n_regs[1], regs[0], regs[1], pa, sc, sc_cap, lt, tie, ovf);
 }
 
+// d_pair2 for exactly one hit per mate, both held in registers (no sort scratch, no score list): the only candidate pair is
+// (first, second) in key order, found iff the first is on the "left" side (key bit 0 clear), the second on the "right",
+// same strand class and contig, within max_gap_ref and above the score threshold (pe.c:76-150); then the single-pair
+// MAPQ rules (pe.c:152-170) and mm_set_pe_thru (pe.c:45-74).
+__device__ __forceinline__ void d_pair11(const AlParams &P, int max_gap_ref, const int ql0, const int ql1, AlReg &R0, AlReg &R1)
+{
+	const int rev0 = (R0.flags & ALR_REV) ? 1 : 0, rev1 = (R1.flags & ALR_REV) ? 1 : 0;
+	const uint64_t key0 = (uint64_t)(uint32_t)R0.rid << 32 | (uint64_t)(uint32_t)(R0.rs << 1) | (uint64_t)(0 ^ rev0);
+	const uint64_t key1 = (uint64_t)(uint32_t)R1.rid << 32 | (uint64_t)(uint32_t)(R1.rs << 1) | (uint64_t)(1 ^ rev1);
+	int dp_thres = R0.dp_max + R1.dp_max - P.pe_bonus; if (dp_thres < 0) dp_thres = 0;
+	const bool swap = key1 < key0;                                          // stable insertion sort of two keys
+	const uint64_t keyA = swap ? key1 : key0, keyB = swap ? key0 : key1;
+	const int revA = swap ? rev1 : rev0, revB = swap ? rev0 : rev1;
+	const int32_t A_rid = swap ? R1.rid : R0.rid, A_re = swap ? R1.re : R0.re, B_rid = swap ? R0.rid : R1.rid, B_rs = swap ? R0.rs : R1.rs;
+	bool paired = !(keyA & 1) && (keyB & 1) && revA == revB && B_rid == A_rid && B_rs - A_re <= max_gap_ref && R0.dp_max + R1.dp_max >= dp_thres;
+	const long long score = (long long)((uint64_t)(uint32_t)(R0.dp_max + R1.dp_max) << 32 | (uint32_t)(R0.hash + R1.hash));
+	if (paired && score > 0) {
+		R0.flags |= ALR_PROPER; R1.flags |= ALR_PROPER;
+		// (each hit is its own parent and already sam_pri; one pair score: n_sub = 1, no alternative)
+		const int mapq_pe = R0.mapq > R1.mapq ? (int)R0.mapq : (int)R1.mapq;
+		if ((int)R0.mapq < mapq_pe) R0.mapq = (uint32_t)(int)__fadd_rn(__fadd_rn(__fmul_rn(.2f, (float)R0.mapq), __fmul_rn(.8f, (float)mapq_pe)), .499f) & 0xffu;
+		if ((int)R1.mapq < mapq_pe) R1.mapq = (uint32_t)(int)__fadd_rn(__fadd_rn(__fmul_rn(.2f, (float)R1.mapq), __fmul_rn(.8f, (float)mapq_pe)), .499f) & 0xffu;
+		if (R0.mapq < 2) R0.mapq = 2;
+		if (R1.mapq < 2) R1.mapq = 2;
+	}
+	// mm_set_pe_thru
+	const int d1 = R0.rs - R1.rs, d2 = R0.re - R1.re;
+	if (R0.rid == R1.rid && (R0.flags & ALR_REV) == (R1.flags & ALR_REV) && (d1 < 0 ? -d1 : d1) < 3 && (d2 < 0 ? -d2 : d2) < 3
+	    && ((R0.qs == 0 && ql1 - R1.qe == 0) || (R1.qs == 0 && ql0 - R0.qe == 0))) { R0.flags |= ALR_PE_THRU; R1.flags |= ALR_PE_THRU; }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Per-fragment workspace layout.  With P_f = sum of n_u over earlier fragments and c_f = 4*n_u + 4 (room for up to three
 // z-drop splits per hit; exceeding it is a counted error):
@@ -1450,49 +1481,51 @@ k_ext_finish(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ r
 			else max_gap_ref = P.max_gap;
 			const int rep_len = frag_rep[f]; bool tie = false;
 			const LdsCig cig{s_cig + threadIdx.x};
+			auto finish_reg = [&](const int qlen, const uint32_t *seq, const AlReg &Rin, const RegExt x, const AlAnchor *a) -> AlReg {
+				AlReg R = Rin;
+				const int32_t rid = (int32_t)(a[R.as].x << 1 >> 33), rev = (int32_t)(a[R.as].x >> 63);
+				const uint64_t ref_off = G.seq_off[rid];
+				R.n_cigar = 0; R.dp_score = 0; R.dp_max = 0; R.dp_max2 = 0; R.n_ambi = 0;
+				int32_t rs1 = x.rs, qs1 = x.qs, re1, qe1;
+				++c_regs; c_ref += (unsigned long long)(x.re0 - x.rs0);
+				if (E.jobs[x.job].qlen) {
+					const ExtOut *po = &E.outs[x.job];
+					const uint32_t fl = po->flags_ncig; const int nc = (int)(fl >> 8); const bool reach = fl & 1;
+					if (nc > 0) { d_fcig_append(&R, cig, nc, nc <= 6 ? po->cig : G.arena + po->cig_off); R.dp_score += po->max; }
+					rs1 = x.rs - (reach ? po->mqe_t + 1 : po->max_t + 1);
+					qs1 = x.qs - (reach ? x.qs : po->max_q + 1);
+				}
+				{ const uint32_t m = (uint32_t)(x.qe - x.qs) << 4; d_fcig_append(&R, cig, 1, &m); R.dp_score += x.core_score; }
+				re1 = x.re; qe1 = x.qe;
+				if (E.jobs[x.job + 1].qlen) {
+					const ExtOut *po = &E.outs[x.job + 1];
+					const uint32_t fl = po->flags_ncig; const int nc = (int)(fl >> 8); const bool reach = fl & 1;
+					if (nc > 0) { d_fcig_append(&R, cig, nc, nc <= 6 ? po->cig : G.arena + po->cig_off); R.dp_score += po->max; }
+					re1 = x.re + (reach ? po->mqe_t + 1 : po->max_t + 1);
+					qe1 = x.qe + (reach ? qlen - x.qe : po->max_q + 1);
+				}
+				R.rs = rs1; R.re = re1;
+				if (rev) { R.qs = qlen - qe1; R.qe = qlen - qs1; } else { R.qs = qs1; R.qe = qe1; }
+				d_update_extra(P, &R, cig, ReadAcc{seq, qlen, rev, qs1}, RefAcc{G.S4, ref_off + (uint64_t)rs1});
+				c_cig += R.n_cigar;
+				uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+				if (R.n_cigar <= 4) {
+					if (R.n_cigar > 0) c0 = cig[0]; if (R.n_cigar > 1) c1 = cig[1]; if (R.n_cigar > 2) c2 = cig[2]; if (R.n_cigar > 3) c3 = cig[3];
+					R.cigar_off = AL_CIG_INLINE;
+				} else {
+					const unsigned long long off = atomicAdd(G.arena_cnt, (unsigned long long)R.n_cigar);
+					if (off + R.n_cigar <= G.arena_cap) { for (uint32_t k = 0; k < R.n_cigar; ++k) G.arena[off + k] = cig[k]; R.cigar_off = (uint32_t)off; }
+					else { atomicAdd(&G.counters[9], 1ULL); R.cigar_off = 0xffffffffu; }
+				}
+				R.cig_inl[0] = c0; R.cig_inl[1] = c1; R.cig_inl[2] = c2; R.cig_inl[3] = c3;
+				return R;
+			};
 			auto do_seg = [&](const uint32_t s, const int qlen, AlReg *regs, const AlAnchor *a) -> int {
 				int n = (int)W.reg_cnt[r0 + s];
 				const uint32_t *seq = rd_seq + rd_off[r0 + s];
 				for (int i = 0; i < n; ++i) {                                    // mm_align1 after the DP calls (align.c:698-788)
 					if (regs[i].cnt == 0) continue;
-					AlReg R = regs[i];
-					const RegExt x = E.rext[B2 + (uint64_t)s * fw.cap + i];
-					const int32_t rid = (int32_t)(a[R.as].x << 1 >> 33), rev = (int32_t)(a[R.as].x >> 63);
-					const uint64_t ref_off = G.seq_off[rid];
-					R.n_cigar = 0; R.dp_score = 0; R.dp_max = 0; R.dp_max2 = 0; R.n_ambi = 0;
-					int32_t rs1 = x.rs, qs1 = x.qs, re1, qe1;
-					++c_regs; c_ref += (unsigned long long)(x.re0 - x.rs0);
-					if (E.jobs[x.job].qlen) {
-						const ExtOut *po = &E.outs[x.job];
-						const uint32_t fl = po->flags_ncig; const int nc = (int)(fl >> 8); const bool reach = fl & 1;
-						if (nc > 0) { d_fcig_append(&R, cig, nc, nc <= 6 ? po->cig : G.arena + po->cig_off); R.dp_score += po->max; }
-						rs1 = x.rs - (reach ? po->mqe_t + 1 : po->max_t + 1);
-						qs1 = x.qs - (reach ? x.qs : po->max_q + 1);
-					}
-					{ const uint32_t m = (uint32_t)(x.qe - x.qs) << 4; d_fcig_append(&R, cig, 1, &m); R.dp_score += x.core_score; }
-					re1 = x.re; qe1 = x.qe;
-					if (E.jobs[x.job + 1].qlen) {
-						const ExtOut *po = &E.outs[x.job + 1];
-						const uint32_t fl = po->flags_ncig; const int nc = (int)(fl >> 8); const bool reach = fl & 1;
-						if (nc > 0) { d_fcig_append(&R, cig, nc, nc <= 6 ? po->cig : G.arena + po->cig_off); R.dp_score += po->max; }
-						re1 = x.re + (reach ? po->mqe_t + 1 : po->max_t + 1);
-						qe1 = x.qe + (reach ? qlen - x.qe : po->max_q + 1);
-					}
-					R.rs = rs1; R.re = re1;
-					if (rev) { R.qs = qlen - qe1; R.qe = qlen - qs1; } else { R.qs = qs1; R.qe = qe1; }
-					d_update_extra(P, &R, cig, ReadAcc{seq, qlen, rev, qs1}, RefAcc{G.S4, ref_off + (uint64_t)rs1});
-					c_cig += R.n_cigar;
-					uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-					if (R.n_cigar <= 4) {
-						if (R.n_cigar > 0) c0 = cig[0]; if (R.n_cigar > 1) c1 = cig[1]; if (R.n_cigar > 2) c2 = cig[2]; if (R.n_cigar > 3) c3 = cig[3];
-						R.cigar_off = AL_CIG_INLINE;
-					} else {
-						const unsigned long long off = atomicAdd(G.arena_cnt, (unsigned long long)R.n_cigar);
-						if (off + R.n_cigar <= G.arena_cap) { for (uint32_t k = 0; k < R.n_cigar; ++k) G.arena[off + k] = cig[k]; R.cigar_off = (uint32_t)off; }
-						else { atomicAdd(&G.counters[9], 1ULL); R.cigar_off = 0xffffffffu; }
-					}
-					R.cig_inl[0] = c0; R.cig_inl[1] = c1; R.cig_inl[2] = c2; R.cig_inl[3] = c3;
-					regs[i] = R;
+					regs[i] = finish_reg(qlen, seq, regs[i], E.rext[B2 + (uint64_t)s * fw.cap + i], a);
 				}
 				d_filter_regs(P, qlen, &n, regs);                                // align.c:910-911
 				tie = d_hit_sort(&n, regs, fw.aux128, fw.rtmp) || tie;
@@ -1504,6 +1537,30 @@ k_ext_finish(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ r
 			};
 			AlReg *const mreg0 = fw.mreg[0], *const mreg1 = fw.mreg[1];
 			const AlAnchor *const sa0 = fw.seg_a[0], *const sa1 = n_segs == 2 ? fw.seg_a[0] + W.seg_na[r0] : nullptr;
+			if (n_segs == 2 && W.reg_cnt[r0] == 1 && W.reg_cnt[r0 + 1] == 1 && mreg0[0].cnt != 0 && mreg1[0].cnt != 0 && !((P.dbg >> 19) & 1)) {
+				// One hit per mate (the common fragment): both records stay in registers from the DP results to the final store;
+				// the post-DP bookkeeping of a single hit (filter, parent = self, sam_pri, MAPQ) and the 1 x 1 pairing need no
+				// scratch arrays.  Same result as the general code below.
+				AlReg R0 = finish_reg(ql0, rd_seq + rd_off[r0], mreg0[0], E.rext[B2], sa0);
+				AlReg R1 = finish_reg(ql1, rd_seq + rd_off[r0 + 1], mreg1[0], E.rext[B2 + (uint64_t)fw.cap], sa1);
+				auto post1 = [&](AlReg &R, const int qlen) -> int {
+					int n1 = 1;
+					d_filter_regs(P, qlen, &n1, &R);                              // align.c:910-911
+					if (n1 == 0) return 0;
+					R.id = 0; R.parent = 0;                                       // mm_set_parent / mm_select_sub with one hit
+					d_set_sam_pri(1, &R);
+					d_set_mapq(1, &R, P.min_chain_score, P.a, rep_len, lt);
+					return 1;
+				};
+				const int k0 = post1(R0, ql0), k1 = post1(R1, ql1);
+				if (P.pe_ori >= 0 && k0 && k1) {
+					if (sc_off[f + 1] - sc_off[f] < 1) atomicAdd(&G.counters[7], 1ULL << 56);
+					d_pair11(P, max_gap_ref, ql0, ql1, R0, R1);
+				}
+				if (k0) mreg0[0] = R0;
+				if (k1) mreg1[0] = R1;
+				W.reg_cnt[r0] = (uint32_t)k0; W.reg_cnt[r0 + 1] = (uint32_t)k1;
+			} else {
 			const int nr0 = do_seg(0, ql0, mreg0, sa0);
 			const int nr1 = n_segs == 2 ? do_seg(1, ql1, mreg1, sa1) : 0;
 			if (n_segs == 2 && P.pe_ori >= 0) {
@@ -1514,6 +1571,7 @@ k_ext_finish(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ r
 			}
 			W.reg_cnt[r0] = (uint32_t)nr0;
 			if (n_segs == 2) W.reg_cnt[r0 + 1] = (uint32_t)nr1;
+			}
 			if (tie) atomicAdd(&G.counters[10], 1ULL);
 		}
 	}
