@@ -324,13 +324,32 @@ struct ReadAcc {     // qseq0[rev][off + i] of a read packed 4 bit/base in mappi
 		return c < 4 ? 3 - c : 4;
 	}
 	__device__ __forceinline__ ReadAcc shift(int n) const { return ReadAcc{seq, qlen, rev, off + n}; }
+	// 8 consecutive codes (nibble j = position i + j); the caller guarantees 0 <= off + i and off + i + 7 <= qlen - 1
+	__device__ __forceinline__ uint32_t win8(int i) const {
+		const int j = off + i, src = rev ? qlen - 8 - j : j, w = src >> 3, sh = (src & 7) << 2;
+		uint32_t v = (uint32_t)((((uint64_t)seq[w + 1] << 32) | seq[w]) >> sh);
+		if (rev) {                                     // reverse the nibble order, complement codes < 4
+			v = ((v & 0x0f0f0f0fu) << 4) | ((v >> 4) & 0x0f0f0f0fu); v = __builtin_bswap32(v);
+			const uint32_t amb = (v >> 2) & 0x11111111u;
+			v ^= 0x33333333u & ~(amb * 3u);
+		}
+		return v;
+	}
 };
 struct RefAcc {
 	const uint32_t *S4; uint64_t base;
 	mutable uint64_t cw = ~0ULL; mutable uint32_t cv = 0;
 	__device__ __forceinline__ int operator()(int i) const { const uint64_t a = base + (uint64_t)(int64_t)i, w = a >> 3; if (w != cw) { cw = w; cv = S4[w]; } return (int)((cv >> ((a & 7) << 2)) & 0xf); }
 	__device__ __forceinline__ RefAcc shift(int n) const { return RefAcc{S4, base + (uint64_t)(int64_t)n}; }
+	__device__ __forceinline__ uint32_t win8(int i) const { const uint64_t a = base + (uint64_t)(int64_t)i, w = a >> 3; const int sh = (int)(a & 7) << 2; return (uint32_t)((((uint64_t)S4[w + 1] << 32) | S4[w]) >> sh); }
 };
+template <class A> struct HasWin8 { static const bool v = false; };
+template <> struct HasWin8<ReadAcc> { static const bool v = true; };
+template <> struct HasWin8<RefAcc> { static const bool v = true; };
+
+template <class A> __device__ __forceinline__ uint32_t d_win8(const A &, int) { return 0; }
+template <> __device__ __forceinline__ uint32_t d_win8<ReadAcc>(const ReadAcc &a, int i) { return a.win8(i); }
+template <> __device__ __forceinline__ uint32_t d_win8<RefAcc>(const RefAcc &a, int i) { return a.win8(i); }
 
 template <class QA, class TA>
 __device__ int d_test_zdrop(const AlParams &P, QA qseq, TA tseq, int n_cigar, const uint32_t *cigar)
@@ -420,7 +439,23 @@ __device__ __forceinline__ void d_update_extra(const AlParams &P, AlReg *r, CG c
 		const uint32_t op = cigar[k] & 0xf, len = cigar[k] >> 4;
 		if (op == 0) {
 			int n_ambi = 0, n_diff = 0;
-			for (uint32_t l = 0; l < len; ++l) {
+			uint32_t l = 0;
+			if (HasWin8<QA>::v && HasWin8<TA>::v) {
+				// packed sequences: eight bases per step; a window of eight unambiguous matches only raises s (and max with it)
+				const int msc = P.a < 0 ? -P.a : P.a;
+				for (; l + 8 <= len; l += 8) {
+					const uint32_t qw = d_win8(qseq, qoff + (int)l), tw = d_win8(tseq, toff + (int)l);
+					if (qw == tw && !(qw & 0x44444444u)) { s += 8 * msc; max = max > s ? max : s; continue; }
+#pragma unroll
+					for (int b = 0; b < 8; ++b) {
+						const int cq = (int)(qw >> (4 * b) & 0xf), ct = (int)(tw >> (4 * b) & 0xf);
+						if (ct > 3 || cq > 3) ++n_ambi; else if (ct != cq) ++n_diff;
+						s += d_mat(P, ct, cq);
+						if (s < 0) s = 0; else max = max > s ? max : s;
+					}
+				}
+			}
+			for (; l < len; ++l) {
 				const int cq = qseq(qoff + l), ct = tseq(toff + l);
 				if (ct > 3 || cq > 3) ++n_ambi; else if (ct != cq) ++n_diff;
 				s += d_mat(P, ct, cq);
@@ -1039,6 +1074,7 @@ k_ext_prep(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_
            const uint32_t *__restrict__ frag_first, WsBase W, AlignShared G, ExtShared E, int n_frag, AlParams P, int tmax, int qmax)
 {
 	const int f = blockIdx.x * blockDim.x + threadIdx.x;
+	unsigned long long c_regs = 0, c_ref = 0, c_cig = 0;
 	__shared__ unsigned s_hist[AL_NCLS + 1];                                   // jobs per class of this block (no run-time indexed local arrays: see k_regs)
 	if (threadIdx.x <= AL_NCLS) s_hist[threadIdx.x] = 0;
 	__syncthreads();
@@ -1077,7 +1113,23 @@ k_ext_prep(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_
 					// ungapped core (align.c:724-731) + mm_test_zdrop with the single 'M' op (align.c:47-89)
 					const ReadAcc Q{seq, qlen, rev, qs}; const RefAcc T{G.S4, ref_off + (uint64_t)rs};
 					const int len = qe - qs; int sc = 0, zs = 0, zmax = INT32_MIN, zmi = -1, zdrop_max = 0;
-					for (int k = 0; k < len; ++k) {
+					int k = 0;
+					{   // eight bases per step; eight unambiguous matches raise both running scores monotonically
+						const int msc = P.a < 0 ? -P.a : P.a;
+						for (; k + 8 <= len; k += 8) {
+							const uint32_t qw = Q.win8(k), tw = T.win8(k);
+							if (qw == tw && !(qw & 0x44444444u)) { sc += 8 * P.a; zs += 8 * msc; if (zs >= zmax) zmax = zs; else { const int z = zmax - zs; if (z > zdrop_max) zdrop_max = z; } continue; }
+#pragma unroll
+							for (int b = 0; b < 8; ++b) {
+								const int cq = (int)(qw >> (4 * b) & 0xf), ct = (int)(tw >> (4 * b) & 0xf);
+								if (cq >= 4 || ct >= 4) sc += P.e2; else sc += cq == ct ? P.a : -P.b;
+								zs += d_mat(P, ct, cq);
+								if (zs < zmax) { const int z = zmax - zs; if (z > zdrop_max) zdrop_max = z; }   // diff = 0 along the diagonal
+								else zmax = zs;
+							}
+						}
+					}
+					for (; k < len; ++k) {
 						const int cq = Q(k), ct = T(k);
 						if (cq >= 4 || ct >= 4) sc += P.e2; else sc += cq == ct ? P.a : -P.b;
 						zs += d_mat(P, ct, cq);
@@ -1124,6 +1176,7 @@ k_ext_prep(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_
 					if (shortcut(0, jl.qlen, jl.tlen)) jl.pad0 = 1;
 					if (shortcut(1, jr.qlen, jr.tlen)) jr.pad0 = 1;
 				}
+				if (r->cnt > 0 && !((P.dbg >> 18) & 1) && (jl.qlen == 0 || jl.pad0) && (jr.qlen == 0 || jr.pad0)) x.job |= 0x80000000u;   // no DP needed: finished below
 				E.rext[B2 + (uint64_t)s * fw.cap + i] = x;
 				E.jobs[jb] = jl; E.jobs[jb + 1] = jr;
 				{ const int c0 = (jl.qlen && !jl.pad0) ? d_job_class(jl.qlen, jl.tlen, lane_ok) : AL_NCLS, c1 = (jr.qlen && !jr.pad0) ? d_job_class(jr.qlen, jr.tlen, lane_ok) : AL_NCLS;
@@ -1134,12 +1187,54 @@ k_ext_prep(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_
 		};
 		do_seg(0, mreg0, sa0);
 		if (n_segs == 2 && !slow) do_seg(1, mreg1, sa1);
+		// Hits whose two flanks are closed forms (or absent) are finished right here -- what k_ext_finish does for a hit
+		// after its DP jobs (mm_align1 tail, align.c:698-788: CIGAR = one M run, coordinates, mm_update_extra) -- so that
+		// k_ext_finish neither re-reads their job records nor streams their sequences again.  Done after the scan above
+		// because a fragment that turned out "slow" is redone from the untouched hits by the monolithic kernel.
+		auto fin_seg = [&](const uint32_t s, AlReg *regs, const AlAnchor *a) {
+			const int qlen = (int)rd_len[r0 + s], n = (int)W.reg_cnt[r0 + s];
+			const uint32_t *seq = rd_seq + rd_off[r0 + s];
+			for (int i = 0; i < n; ++i) {
+				RegExt x = E.rext[B2 + (uint64_t)s * fw.cap + i];
+				if (!(x.job & 0x80000000u)) continue;
+				x.job &= 0x7fffffffu;
+				AlReg R = regs[i];
+				const int32_t rid = (int32_t)(a[R.as].x << 1 >> 33), rev = (int32_t)(a[R.as].x >> 63);
+				const uint64_t ref_off = G.seq_off[rid];
+				R.n_cigar = 0; R.dp_score = 0; R.dp_max = 0; R.dp_max2 = 0; R.n_ambi = 0;
+				int32_t rs1 = x.rs, qs1 = x.qs, re1 = x.re, qe1 = x.qe;
+				R.dp_score = x.core_score;
+				if (E.jobs[x.job].qlen) {
+					const ExtOut *po = &E.outs[x.job]; const bool reach = po->flags_ncig & 1;
+					if (po->flags_ncig >> 8) R.dp_score += po->max;
+					rs1 = x.rs - (reach ? po->mqe_t + 1 : po->max_t + 1);
+					qs1 = x.qs - (reach ? x.qs : po->max_q + 1);
+				}
+				if (E.jobs[x.job + 1].qlen) {
+					const ExtOut *po = &E.outs[x.job + 1]; const bool reach = po->flags_ncig & 1;
+					if (po->flags_ncig >> 8) R.dp_score += po->max;
+					re1 = x.re + (reach ? po->mqe_t + 1 : po->max_t + 1);
+					qe1 = x.qe + (reach ? qlen - x.qe : po->max_q + 1);
+				}
+				uint32_t cg1[1] = { (uint32_t)(qe1 - qs1) << 4 };                // left M + core M + right M merge into one run (mm_append_cigar)
+				R.n_cigar = 1; R.flags |= ALR_HAS_P;
+				R.rs = rs1; R.re = re1;
+				if (rev) { R.qs = qlen - qe1; R.qe = qlen - qs1; } else { R.qs = qs1; R.qe = qe1; }
+				d_update_extra(P, &R, cg1, ReadAcc{seq, qlen, rev, qs1}, RefAcc{G.S4, ref_off + (uint64_t)rs1});
+				R.cig_inl[0] = cg1[0]; R.cig_inl[1] = R.cig_inl[2] = R.cig_inl[3] = 0; R.cigar_off = AL_CIG_INLINE;
+				regs[i] = R;
+				++c_regs; c_ref += (unsigned long long)(x.re0 - x.rs0); c_cig += 1;
+			}
+		};
+		if (!slow) { fin_seg(0, mreg0, sa0); if (n_segs == 2) fin_seg(1, mreg1, sa1); }
 		// unused job slots of this fragment (a slow fragment stops early): mark empty
 		for (uint32_t j = jb; j < (uint32_t)E.job_off[f + 1]; ++j) { E.job_key[j] = 0xffffffffu; ExtJob z; z.qlen = z.tlen = 0; z.toff = 0; z.read = 0; z.qoff = 0; z.rev = z.kind = z.pad0 = z.pad1 = 0; z.pad2 = 0; E.jobs[j] = z; atomicAdd(&s_hist[AL_NCLS], 1u); }
 		E.frag_slow[f] = slow ? 1u : 0u;
 	} else if (f < n_frag) E.frag_slow[f] = 0;
 	__syncthreads();
 	if (threadIdx.x <= AL_NCLS && s_hist[threadIdx.x]) atomicAdd(&E.hist[threadIdx.x], (unsigned long long)s_hist[threadIdx.x]);   // one atomic per block and class
+	for (int d = 32; d > 0; d >>= 1) { c_regs += __shfl_xor(c_regs, d); c_ref += __shfl_xor(c_ref, d); c_cig += __shfl_xor(c_cig, d); }
+	if ((threadIdx.x & 63) == 0) { if (c_regs) atomicAdd(&G.counters[4], c_regs); if (c_ref) atomicAdd(&G.counters[5], c_ref); if (c_cig) atomicAdd(&G.counters[6], c_cig); }
 }
 
 template <int QMAXJ, int TMAXJ> struct JobLds {
@@ -1463,7 +1558,7 @@ k_ext_finish(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ r
 		auto precheck = [&](const uint32_t s, const AlReg *regs) {
 			const int n = (int)W.reg_cnt[r0 + s];
 			for (int i = 0; i < n && !slow; ++i) {
-				if (regs[i].cnt == 0) continue;
+				if (regs[i].cnt == 0 || (regs[i].flags & ALR_HAS_P)) continue;     // empty, or already finished by k_ext_prep
 				const RegExt x = E.rext[B2 + (uint64_t)s * fw.cap + i];
 				const uint32_t nl = E.jobs[x.job].qlen ? E.outs[x.job].flags_ncig >> 8 : 0, nr = E.jobs[x.job + 1].qlen ? E.outs[x.job + 1].flags_ncig >> 8 : 0;
 				if (nl + 1 + nr > AL_FCIG) slow = true;
@@ -1524,7 +1619,7 @@ k_ext_finish(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ r
 				int n = (int)W.reg_cnt[r0 + s];
 				const uint32_t *seq = rd_seq + rd_off[r0 + s];
 				for (int i = 0; i < n; ++i) {                                    // mm_align1 after the DP calls (align.c:698-788)
-					if (regs[i].cnt == 0) continue;
+					if (regs[i].cnt == 0 || (regs[i].flags & ALR_HAS_P)) continue;
 					regs[i] = finish_reg(qlen, seq, regs[i], E.rext[B2 + (uint64_t)s * fw.cap + i], a);
 				}
 				d_filter_regs(P, qlen, &n, regs);                                // align.c:910-911
@@ -1541,8 +1636,9 @@ k_ext_finish(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ r
 				// One hit per mate (the common fragment): both records stay in registers from the DP results to the final store;
 				// the post-DP bookkeeping of a single hit (filter, parent = self, sam_pri, MAPQ) and the 1 x 1 pairing need no
 				// scratch arrays.  Same result as the general code below.
-				AlReg R0 = finish_reg(ql0, rd_seq + rd_off[r0], mreg0[0], E.rext[B2], sa0);
-				AlReg R1 = finish_reg(ql1, rd_seq + rd_off[r0 + 1], mreg1[0], E.rext[B2 + (uint64_t)fw.cap], sa1);
+				AlReg R0 = mreg0[0], R1 = mreg1[0];
+				if (!(R0.flags & ALR_HAS_P)) R0 = finish_reg(ql0, rd_seq + rd_off[r0], R0, E.rext[B2], sa0);
+				if (!(R1.flags & ALR_HAS_P)) R1 = finish_reg(ql1, rd_seq + rd_off[r0 + 1], R1, E.rext[B2 + (uint64_t)fw.cap], sa1);
 				auto post1 = [&](AlReg &R, const int qlen) -> int {
 					int n1 = 1;
 					d_filter_regs(P, qlen, &n1, &R);                              // align.c:910-911
