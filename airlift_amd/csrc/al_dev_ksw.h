@@ -17,15 +17,6 @@
 
 __device__ __forceinline__ int d_dpp_shr1(int carry, int v) { return __builtin_amdgcn_update_dpp(carry, v, DPP_ROW_SHR1, 0xf, 0xf, false); }
 
-template <int CTRL> __device__ __forceinline__ void d_key_max_step(int &lo, int &hi)
-{
-	const int olo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
-	const int ohi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
-	const long long a = (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
-	const long long b = (long long)(((unsigned long long)(unsigned)ohi << 32) | (unsigned)olo);
-	if (b > a) { lo = olo; hi = ohi; }
-}
-
 template <int NB, class LT>
 __device__ __forceinline__ void d_ksw_reg(LT &L, const int gl, GroupWs &ws, int qlen, int tlen, const AlParams &P,
                           int w, int zdrop, int end_bonus, int flag, EzD &ez, bool do_bt = true)

@@ -1,8 +1,10 @@
 // al_kernels_seed.hip -- CDNA4 (gfx950) kernels K1..K4 of the re-alignment path:
 //   K1 k_sketch       minimizer sketch, one lane per read            (mm_sketch, sketch.c:77-143)
 //   K2 k_seed         hash probes + occurrence filter, lane/fragment  (collect_matches, map.c:90-123; mm_idx_get, index.c:81-98)
-//   K3 k_anchor_sort  anchor expansion + x-sort, one wave/fragment    (collect_seed_hits_heap, map.c:149-213)
-//   K4 k_chain        chaining DP + backtrack, one wave/fragment      (mm_chain_dp, chain.c:22-162)
+//   K3 k_anchor_sort_small / k_anchor_sort / k_anchor_heap   anchor expansion + x-sort, wave/fragment; exact heap merge of
+//                     equal-key fragments, lane/fragment          (collect_seed_hits_heap, map.c:149-213)
+//   K4 k_chain_lds    chaining DP + backtrack, lane/fragment, rows in LDS; k_chain: wave/fragment for > 128 anchors
+//                                                                  (mm_chain_dp, chain.c:22-162)
 // Integer / byte work, HBM- and latency-bound: no MFMA.  64-wide wavefronts throughout.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -176,19 +178,6 @@ k_alser_count(const AlAnchor *__restrict__ a, const uint64_t *__restrict__ a_off
 // heap-shape dependent, so such fragments -- and fragments too large for the LDS tile --
 // are re-done by lane 0 with an exact emulation of the binary heap (ksort.h:43-59).
 // =============================================================================================
-__device__ __forceinline__ void d_make_anchor(const AlMatch &m, uint64_t r, int qlen, uint64_t &x, uint64_t &y)
-{   // map.c:176-190
-	const uint32_t q_span_ = 0; (void)q_span_;
-	const int32_t rpos = (uint32_t)r >> 1;
-	if ((r & 1) == (m.q_pos & 1)) {
-		x = (r & 0xffffffff00000000ULL) | (uint32_t)rpos;
-		y = (uint64_t)(m.q_pos >> 1);
-	} else {
-		x = 1ULL << 63 | (r & 0xffffffff00000000ULL) | (uint32_t)rpos;
-		y = 0;   // filled by caller (needs span)
-	}
-}
-
 template <int CAP>
 __device__ void d_bitonic_sort_lds(AlAnchor *s, int npow2, int lane)
 {   // ascending by x; npow2 <= CAP elements, 64 lanes
@@ -649,124 +638,11 @@ k_chain(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_off
 }
 
 // =============================================================================================
-// K4 (small fragments): one lane per fragment.  Short-read fragments carry ~20-60 anchors, far too few to fill a
-// wavefront's predecessor scan, so they run the reference's scalar recurrence verbatim, 64 fragments per wavefront,
-// with their f/p/t/v rows in an HBM scratch that stays L2 resident (4 ints per anchor).  The caller orders fragments by
-// anchor count so that the lanes of a wavefront have (nearly) the same trip counts.
-// =============================================================================================
-extern "C" __global__ void __launch_bounds__(256)
-k_chain_lane(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_off, const uint32_t *__restrict__ frag_na,
-             const uint32_t *__restrict__ frag_first, const uint32_t *__restrict__ rd_len,
-             AlAnchor *__restrict__ chained, uint64_t *__restrict__ u_out, uint32_t *__restrict__ frag_nu,
-             int32_t *__restrict__ ws_i32, uint64_t *__restrict__ ws_u64,
-             const uint32_t *__restrict__ order, int n_list, int lane_max, AlParams P, unsigned long long *__restrict__ counters)
-{
-	const int t0 = blockIdx.x * blockDim.x + threadIdx.x;
-	if (t0 >= n_list) return;
-	const uint32_t f = order ? order[t0] : (uint32_t)t0;
-	const int64_t n = frag_na[f];
-	if (n > lane_max) return;                     // handled by the wave-per-fragment kernel
-	frag_nu[f] = 0;
-	if (n == 0) return;
-	const uint32_t r0 = frag_first[f], r1 = frag_first[f + 1];
-	const int n_segs = (int)(r1 - r0);
-	int qlen_sum = 0; for (uint32_t r = r0; r < r1; ++r) qlen_sum += (int)rd_len[r];
-	const AlAnchor *a = anchors + a_off[f];
-	int32_t *F = ws_i32 + a_off[f] * 4, *Pp = F + n, *T = Pp + n, *V = T + n;
-	uint64_t *utmp = ws_u64 + a_off[f];
-	const int max_dist_y = qlen_sum > P.max_gap ? qlen_sum : P.max_gap;           // map.c:341-351
-	int max_dist_x;
-	if (P.max_gap_ref > 0) max_dist_x = P.max_gap_ref;
-	else if (P.max_frag_len > 0) { max_dist_x = P.max_frag_len - qlen_sum; if (max_dist_x < P.max_gap) max_dist_x = P.max_gap; }
-	else max_dist_x = P.max_gap;
-	const int bw = P.bw, max_skip = P.max_chain_skip, max_iter = P.max_chain_iter, min_cnt = P.min_cnt, min_sc = P.min_chain_score;
-	uint64_t sum_qspan = 0;
-	for (int64_t i = 0; i < n; ++i) { sum_qspan += a[i].y >> 32 & 0xff; T[i] = 0; }
-	const double avg_d = (double)(float)((double)(float)sum_qspan / (double)(float)n);   // (float)sum/n, correctly rounded (chain.c:42)
-	int64_t st = 0;
-	for (int64_t i = 0; i < n; ++i) {                                              // chain.c:46-85
-		const uint64_t ri = a[i].x; const uint64_t yi = a[i].y;
-		const int32_t qi = (int32_t)yi, q_span = (int32_t)(yi >> 32 & 0xff), sidi = (int32_t)((yi & AL_SEED_SEG_MASK) >> AL_SEED_SEG_SHIFT);
-		int64_t max_j = -1; int32_t max_f = q_span, n_skip = 0;
-		while (st < i && ri > a[st].x + (uint64_t)max_dist_x) ++st;
-		if (i - st > max_iter) st = i - max_iter;
-		for (int64_t j = i - 1; j >= st; --j) {
-			const uint64_t xj = a[j].x, yj = a[j].y;
-			const int64_t dr = (int64_t)(ri - xj);
-			const int32_t dq = qi - (int32_t)yj, sidj = (int32_t)((yj & AL_SEED_SEG_MASK) >> AL_SEED_SEG_SHIFT);
-			if ((sidi == sidj && dr == 0) || dq <= 0) continue;
-			if ((sidi == sidj && dq > max_dist_y) || dq > max_dist_x) continue;
-			const int32_t dd = dr > dq ? (int32_t)(dr - dq) : (int32_t)(dq - dr);
-			if (sidi == sidj && dd > bw) continue;
-			if (n_segs > 1 && sidi == sidj && dr > max_dist_y) continue;
-			const int32_t min_d = dq < dr ? dq : (int32_t)dr;
-			int32_t sc = min_d > q_span ? q_span : min_d;
-			const int32_t log_dd = dd ? d_ilog2((uint32_t)dd) : 0;
-			const int32_t c_lin = (int)((double)dd * .01 * avg_d);
-			if (sidi != sidj) { if (dr == 0) ++sc; else sc -= c_lin < log_dd ? c_lin : log_dd; }
-			else sc -= c_lin + (log_dd >> 1);
-			sc += F[j];
-			const int32_t pj = Pp[j];
-			if (sc > max_f) { max_f = sc; max_j = j; if (n_skip > 0) --n_skip; }
-			else if (T[j] == (int32_t)i) { if (++n_skip > max_skip) break; }
-			if (pj >= 0) T[pj] = (int32_t)i;
-		}
-		F[i] = max_f; Pp[i] = (int32_t)max_j;
-		V[i] = max_j >= 0 && V[max_j] > max_f ? V[max_j] : max_f;
-	}
-	for (int64_t i = 0; i < n; ++i) T[i] = 0;                                       // chain.c:87-109
-	for (int64_t i = 0; i < n; ++i) if (Pp[i] >= 0) T[Pp[i]] = 1;
-	int32_t n_u = 0, n_v = 0, k = 0;
-	for (int64_t i = 0; i < n; ++i)
-		if (T[i] == 0 && V[i] >= min_sc) {
-			int64_t j = i;
-			while (j >= 0 && F[j] < V[j]) j = Pp[j];
-			if (j < 0) j = i;
-			utmp[n_u++] = (uint64_t)(uint32_t)F[j] << 32 | (uint64_t)j;
-		}
-	if (n_u == 0) return;
-	// distinct keys: plain insertion sort, descending (n_u <= lane_max / 2)
-	for (int32_t i = 1; i < n_u; ++i) { const uint64_t t = utmp[i]; int32_t j = i; while (j > 0 && utmp[j - 1] < t) { utmp[j] = utmp[j - 1]; --j; } utmp[j] = t; }
-	for (int64_t i = 0; i < n; ++i) T[i] = 0;
-	for (int32_t i = 0; i < n_u; ++i) {                                              // chain.c:111-128
-		const int32_t n_v0 = n_v, k0 = k; int64_t j = (int32_t)utmp[i];
-		do { V[n_v++] = (int32_t)j; T[j] = 1; j = Pp[j]; } while (j >= 0 && T[j] == 0);
-		if (j < 0) { if (n_v - n_v0 >= min_cnt) utmp[k++] = utmp[i] >> 32 << 32 | (uint32_t)(n_v - n_v0); }
-		else if ((int32_t)(utmp[i] >> 32) - F[j] >= min_sc) { if (n_v - n_v0 >= min_cnt) utmp[k++] = (uint64_t)((utmp[i] >> 32) - (uint64_t)(uint32_t)F[j]) << 32 | (uint32_t)(n_v - n_v0); }
-		if (k0 == k) n_v = n_v0;
-	}
-	n_u = k;
-	// chains ordered by the x of their first anchor (chain.c:144-160); <= 64 chains: stable insertion sort (ksort.h:149)
-	int32_t off = 0;
-	for (int32_t c = 0; c < n_u; ++c) { Pp[c] = off; off += (int32_t)(uint32_t)utmp[c]; T[c] = c; }
-	bool tie = false;
-#define CXL(c) (a[V[Pp[c] + (int32_t)(uint32_t)utmp[c] - 1]].x)
-	for (int32_t i = 1; i < n_u; ++i) {
-		const int32_t ci = T[i]; const uint64_t xi = CXL(ci); int32_t j = i;
-		while (j > 0) { const int32_t cj = T[j - 1]; if (xi < CXL(cj)) { T[j] = cj; --j; } else break; }
-		T[j] = ci;
-	}
-	if (n_u > 64) { for (int32_t i = 1; i < n_u; ++i) if (CXL(T[i]) == CXL(T[i - 1])) tie = true; }
-#undef CXL
-	if (tie) atomicAdd(&counters[1], 1ULL);
-	AlAnchor *b = chained + a_off[f]; uint64_t *u = u_out + a_off[f] + f;
-	int32_t o = 0;
-	for (int32_t i = 0; i < n_u; ++i) {
-		const int32_t c = T[i], ni = (int32_t)(uint32_t)utmp[c], k0 = Pp[c];
-		u[i] = utmp[c];
-		for (int32_t j = 0; j < ni; ++j) b[o++] = a[V[k0 + (ni - j - 1)]];
-	}
-	frag_nu[f] = (uint32_t)n_u;
-}
-
-// =============================================================================================
-// K4 (small fragments, LDS resident): one lane per fragment, LANES fragments per wavefront, every per-anchor row staged
-// in LDS as [field][anchor][lane] (conflict-free) so that nothing is re-fetched from HBM inside the O(n^2) recurrence.
-// 13 bytes per anchor: 32-bit position, a byte holding (block id | segment | tandem) where "block" numbers the distinct
-// (strand, contig) values of the x-sorted anchors, 16-bit query position, f, v (int16) and p, t (uint8 row indices).
-// CAPL anchors per fragment; the caller orders fragments by anchor count and a wavefront whose largest fragment does not
-// fall in (lo_excl, CAPL] leaves the work to another instantiation or to k_chain.  All spans must equal k (true for the
-// non-HPC sketch of this path); a fragment violating that is left to k_chain via the `other` flag.
+// K4 (fragments of <= 128 anchors, LDS resident): one lane per fragment, LANES fragments per wavefront, every per-anchor
+// row staged in LDS as [anchor][lane] (conflict-free) so that nothing is re-fetched from HBM inside the O(n^2) recurrence
+// (10 bytes per anchor, layout in the kernel).  CAPL anchors per fragment; the caller orders fragments by anchor count and
+// a wavefront whose largest fragment does not fall in (lo_excl, CAPL] leaves the work to another instantiation.  All spans
+// must equal k and max_dist_x < 2^15 (true on the short-read path); a fragment violating that is a counted error.
 // =============================================================================================
 #define AL_CLIN_N 1024
 template <int CAPL, int LANES>
