@@ -499,7 +499,7 @@ __device__ __forceinline__ void d_append_cigar(AlReg *r, GroupWs &ws, int n_ciga
 	}
 }
 
-__device__ void d_max_stretch(const AlReg *r, const AlAnchor *a, int *as, int *cnt)
+__device__ __forceinline__ void d_max_stretch(const AlReg *r, const AlAnchor *a, int *as, int *cnt)
 {   // mm_max_stretch, align.c:495-521
 	*as = r->as; *cnt = r->cnt;
 	if (r->cnt < 2) return;
@@ -775,12 +775,17 @@ __device__ __forceinline__ void d_pair11(const AlParams &P, int max_gap_ref, con
 //   scratch    : AlAnchor/ u64 / int / AlReg x c_f                 at B_f = 2*P_f + 4*f
 //   seg_u      : u64     x n_u each    at 2*P_f + s*n_u
 //   seg_a      : anchors of mate 0 then mate 1 inside the fragment's anchor range a_off[f]..
+struct RegExt {                    // per-hit state carried from prep to finish, 32 bytes
+	int32_t rs, qs, re, qe, rs0, re0, core_score;
+	uint32_t job;                  // index of the left job; right job = job + 1
+};
 struct FragWs {
 	AlReg *regs0, *mreg[2], *rtmp; AlAnchor *aux128, *seg_a[2]; uint64_t *aux64, *seg_u[2]; int *auxi; int cap;
 };
 struct WsBase {
 	AlReg *regs0, *mregs, *rtmp; AlAnchor *aux128, *seg_a; uint64_t *aux64, *seg_u; int *auxi;
 	const uint64_t *nu_off; const uint32_t *frag_nu; const uint64_t *a_off; uint32_t *reg_cnt /* per read */; uint32_t *seg_na /* per read */;
+	RegExt *rext; uint32_t *seg_fast;   // per read: 1 = the read's single hit has its ungapped-core coordinates in rext already (k_regs fast path)
 };
 __device__ __forceinline__ void d_frag_ws(const WsBase &W, uint32_t f, FragWs &o)
 {
@@ -798,8 +803,8 @@ k_regs(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__ u_all,
 	const int f = blockIdx.x * blockDim.x + threadIdx.x;
 	if (f >= n_frag) return;
 	const uint32_t r0 = frag_first[f], n_segs = frag_first[f + 1] - r0, n_u = W.frag_nu[f];
-	W.reg_cnt[r0] = 0; W.seg_na[r0] = 0;
-	if (n_segs > 1) { W.reg_cnt[r0 + 1] = 0; W.seg_na[r0 + 1] = 0; }
+	W.reg_cnt[r0] = 0; W.seg_na[r0] = 0; W.seg_fast[r0] = 0;
+	if (n_segs > 1) { W.reg_cnt[r0 + 1] = 0; W.seg_na[r0 + 1] = 0; W.seg_fast[r0 + 1] = 0; }
 	if (n_u == 0) return;
 	// NB: no array below is indexed by a run-time value (mate ids become two-way selects, loops over the <= 2 mates are
 	// unrolled): a dynamically indexed local array would live in scratch memory, whose lines compete with the data for L2.
@@ -825,6 +830,15 @@ k_regs(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__ u_all,
 		uint32_t w0 = 0, w1 = 0;
 		AlAnchor f0{0, 0}, f1{0, 0}, l0{0, 0}, l1{0, 0};                       // first / last (= previous) anchor of each mate, y rebased
 		int32_t bl0 = 0, ml0 = 0, bl1 = 0, ml1 = 0;
+		// mm_max_stretch (align.c:495-521) of each mate's anchors on the fly: the longest run with equal reference and query
+		// steps; its end anchors give the ungapped core k_ext_prep starts from, so that kernel need not re-read the anchors
+		struct Stretch { AlAnchor cf, mf, ml; int score, len, max_score, max_len; };
+		Stretch S0{{0, 0}, {0, 0}, {0, 0}, 0, 0, -1, 0}, S1 = S0;
+		auto st_step = [](Stretch &S, const bool first, const AlAnchor &pv, const AlAnchor &cur, const int tl, const int ql, const int span) {
+			if (first) { S.cf = cur; S.score = span; S.len = 1; }
+			else if (ql == tl) { S.score += ql < span ? ql : span; ++S.len; }
+			else { if (S.score > S.max_score) { S.max_score = S.score; S.max_len = S.len; S.mf = S.cf; S.ml = pv; } S.cf = cur; S.score = span; S.len = 1; }
+		};
 		for (int j = 0; j < cnt; ++j) {
 			AlAnchor a1 = a[j]; const bool s1 = ((a1.y & AL_SEED_SEG_MASK) >> AL_SEED_SEG_SHIFT) & 1;
 			const int qls = s1 ? ql1 : ql0, acc = s1 ? ql0 : 0;
@@ -834,9 +848,20 @@ k_regs(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__ u_all,
 			const AlAnchor pv = s1 ? l1 : l0;
 			const int tl = (int32_t)a1.x - (int32_t)pv.x, ql = (int32_t)a1.y - (int32_t)pv.y;      // mm_cal_fuzzy_len, hit.c:8-24
 			const int db = first ? span : (tl > ql ? tl : ql), dm = first ? span : (tl > span && ql > span ? span : tl < ql ? tl : ql);
-			if (s1) { if (first) f1 = a1; l1 = a1; bl1 += db; ml1 += dm; sa1[w1++] = a1; }
-			else { if (first) f0 = a1; l0 = a1; bl0 += db; ml0 += dm; sa0[w0++] = a1; }
+			if (s1) { st_step(S1, first, pv, a1, tl, ql, span); if (first) f1 = a1; l1 = a1; bl1 += db; ml1 += dm; sa1[w1++] = a1; }
+			else { st_step(S0, first, pv, a1, tl, ql, span); if (first) f0 = a1; l0 = a1; bl0 += db; ml0 += dm; sa0[w0++] = a1; }
 		}
+		auto st_done = [&](Stretch &S, const uint32_t c, const AlAnchor &fa, const AlAnchor &la, const uint32_t sid) {
+			if (c == 0) return;
+			AlAnchor A = fa, B = la;                                              // cnt < 2: the whole (one-anchor) hit
+			if (c >= 2) { if (S.score > S.max_score) { S.mf = S.cf; S.ml = la; } A = S.mf; B = S.ml; }
+			RegExt x; x.rs0 = x.re0 = x.core_score = 0; x.job = 0;
+			x.rs = (int32_t)A.x + 1 - (int32_t)(A.y >> 32 & 0xff); x.qs = (int32_t)A.y + 1 - (int32_t)(A.y >> 32 & 0xff);
+			x.re = (int32_t)B.x + 1; x.qe = (int32_t)B.y + 1;
+			W.rext[(uint64_t)(ws.mreg[0] - W.mregs) + (uint64_t)sid * ws.cap] = x;
+			W.seg_fast[r0 + sid] = 1;
+		};
+		st_done(S0, c0, f0, l0, 0u); st_done(S1, c1, f1, l1, 1u);
 		auto make = [&](const uint32_t sid, const uint32_t c, const AlAnchor &fa, const AlAnchor &la, const int32_t blen, const int32_t mlen, const int qlen) -> AlReg {
 			AlReg R; d_reg_clear(&R);                                              // mm_gen_regs for one chain (hit.c:52-88) + mm_reg_set_coor (hit.c:26-41)
 			const uint32_t h = (uint32_t)d_hash64((d_hash64(fa.x) + d_hash64(fa.y)) ^ hash);
@@ -1048,10 +1073,6 @@ struct ExtOut {                    // 48 bytes
 	uint32_t cig_off;              // arena index when n_cigar > 6
 	uint32_t cig[6];
 };
-struct RegExt {                    // per-hit state carried from prep to finish, 32 bytes
-	int32_t rs, qs, re, qe, rs0, re0, core_score;
-	uint32_t job;                  // index of the left job; right job = job + 1
-};
 #define AL_FCIG 32                 // CIGAR words a finish lane can assemble in registers/scratch
 
 struct ExtShared {
@@ -1096,13 +1117,17 @@ k_ext_prep(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_
 				jl.toff = jr.toff = 0; jl.read = jr.read = r0 + s; jl.qoff = jr.qoff = 0; jl.rev = jr.rev = 0; jl.kind = 0; jr.kind = 1;
 				x.job = jb; x.rs = x.qs = x.re = x.qe = x.rs0 = x.re0 = x.core_score = 0;
 				if (r->cnt > 0) {
-					const int32_t rid = (int32_t)(a[r->as].x << 1 >> 33), rev = (int32_t)(a[r->as].x >> 63);
+					const int32_t rid = r->rid, rev = (r->flags & ALR_REV) ? 1 : 0;   // == contig / strand of a[r->as] (mm_reg_set_coor)
 					const int32_t ref_len = (int32_t)G.seq_len[rid]; const uint64_t ref_off = G.seq_off[rid];
-					int as1, cnt1;
-					d_max_stretch(r, a, &as1, &cnt1);
-					int32_t rs = (int32_t)a[as1].x + 1 - (int32_t)(a[as1].y >> 32 & 0xff);
-					int32_t qs = (int32_t)a[as1].y + 1 - (int32_t)(a[as1].y >> 32 & 0xff);
-					int32_t re = (int32_t)a[as1 + cnt1 - 1].x + 1, qe = (int32_t)a[as1 + cnt1 - 1].y + 1;
+					int32_t rs, qs, re, qe;
+					if (i == 0 && W.seg_fast[r0 + s]) { const RegExt pre = E.rext[B2 + (uint64_t)s * fw.cap]; rs = pre.rs; qs = pre.qs; re = pre.re; qe = pre.qe; }   // from k_regs
+					else {
+						int as1, cnt1;
+						d_max_stretch(r, a, &as1, &cnt1);
+						rs = (int32_t)a[as1].x + 1 - (int32_t)(a[as1].y >> 32 & 0xff);
+						qs = (int32_t)a[as1].y + 1 - (int32_t)(a[as1].y >> 32 & 0xff);
+						re = (int32_t)a[as1 + cnt1 - 1].x + 1; qe = (int32_t)a[as1 + cnt1 - 1].y + 1;
+					}
 					int l = qs;                                                   // align.c:613-620
 					l += l * P.a + P.end_bonus > P.q ? (l * P.a + P.end_bonus - P.q) / P.e : 0;
 					const int32_t rs0 = rs - l > 0 ? rs - l : 0;
@@ -1152,7 +1177,7 @@ k_ext_prep(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_
 				// max_t / mqe_t / reach_end / CIGAR follow from the running diagonal score exactly as ksw_extd2 computes them
 				// (checked against the reference DP in tests/test_diag_shortcut.py; jobs done this way carry pad0 = 1).
 				if (!((P.dbg >> 31) & 1) && r->cnt > 0) {
-					const int32_t rid2 = (int32_t)(a[r->as].x << 1 >> 33), rev2 = (int32_t)(a[r->as].x >> 63);
+					const int32_t rid2 = r->rid, rev2 = (r->flags & ALR_REV) ? 1 : 0;
 					const uint64_t ref_off2 = G.seq_off[rid2];
 					const ReadAcc Qa{seq, qlen, rev2, 0}; const RefAcc Ta{G.S4, ref_off2};
 					auto shortcut = [&](const int side, const int ql, const int tl) -> bool {
@@ -1199,7 +1224,7 @@ k_ext_prep(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_
 				if (!(x.job & 0x80000000u)) continue;
 				x.job &= 0x7fffffffu;
 				AlReg R = regs[i];
-				const int32_t rid = (int32_t)(a[R.as].x << 1 >> 33), rev = (int32_t)(a[R.as].x >> 63);
+				const int32_t rid = R.rid, rev = (R.flags & ALR_REV) ? 1 : 0;
 				const uint64_t ref_off = G.seq_off[rid];
 				R.n_cigar = 0; R.dp_score = 0; R.dp_max = 0; R.dp_max2 = 0; R.n_ambi = 0;
 				int32_t rs1 = x.rs, qs1 = x.qs, re1 = x.re, qe1 = x.qe;
@@ -1578,7 +1603,7 @@ k_ext_finish(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ r
 			const LdsCig cig{s_cig + threadIdx.x};
 			auto finish_reg = [&](const int qlen, const uint32_t *seq, const AlReg &Rin, const RegExt x, const AlAnchor *a) -> AlReg {
 				AlReg R = Rin;
-				const int32_t rid = (int32_t)(a[R.as].x << 1 >> 33), rev = (int32_t)(a[R.as].x >> 63);
+				const int32_t rid = R.rid, rev = (R.flags & ALR_REV) ? 1 : 0;
 				const uint64_t ref_off = G.seq_off[rid];
 				R.n_cigar = 0; R.dp_score = 0; R.dp_max = 0; R.dp_max2 = 0; R.n_ambi = 0;
 				int32_t rs1 = x.rs, qs1 = x.qs, re1, qe1;
@@ -1721,7 +1746,7 @@ struct AlignState {            // lives in al_ctx_s::align_state (opaque there)
 	DevBuf<AlAnchor> aux128, seg_a;
 	DevBuf<uint64_t> aux64, seg_u, nu_off, out_off;
 	DevBuf<int32_t> auxi;
-	DevBuf<uint32_t> reg_cnt, seg_na, arena;
+	DevBuf<uint32_t> reg_cnt, seg_na, arena, seg_fast;
 	DevBuf<uint8_t> gws;
 	DevBuf<float> logtab;
 	DevBuf<unsigned long long> dbgbuf, hist;
@@ -1747,7 +1772,7 @@ void al_align_state_free(al_ctx_t *c)
 	if (it == g_states.end()) return;
 	AlignState *s = it->second;
 	s->regs0.release(); s->mregs.release(); s->rtmp.release(); s->out.release(); s->aux128.release(); s->seg_a.release(); s->aux64.release(); s->seg_u.release();
-	s->nu_off.release(); s->out_off.release(); s->auxi.release(); s->reg_cnt.release(); s->seg_na.release(); s->arena.release(); s->gws.release(); s->logtab.release(); s->dbgbuf.release(); s->hist.release(); s->jobs.release(); s->outs.release(); s->rext.release();
+	s->nu_off.release(); s->out_off.release(); s->auxi.release(); s->reg_cnt.release(); s->seg_na.release(); s->arena.release(); s->gws.release(); s->logtab.release(); s->dbgbuf.release(); s->hist.release(); s->jobs.release(); s->outs.release(); s->rext.release(); s->seg_fast.release();
 	s->job_off.release(); s->sc_off.release(); s->sc_ws.release(); s->n_jobs.release(); s->n_sc.release(); s->job_key.release(); s->job_key2.release(); s->job_idx.release(); s->job_idx2.release(); s->frag_slow.release(); s->slow_list.release(); s->sort_tmp.release();
 	delete s; g_states.erase(it);
 }
@@ -1776,10 +1801,10 @@ int al_run_align_stage(al_ctx_t *c)
 	AL_HIP_CHECK(hipStreamSynchronize(s));
 	const uint64_t Btot = 4 * nu_total + 4ULL * nf + 8;
 	if (A->regs0.ensure(nu_total + 1) || A->mregs.ensure(2 * Btot) || A->rtmp.ensure(Btot) || A->aux128.ensure(Btot) || A->aux64.ensure(Btot) || A->auxi.ensure(2 * Btot) ||
-	    A->seg_u.ensure(2 * nu_total + 2) || A->seg_a.ensure(c->n_anchor_total + 1) || A->reg_cnt.ensure(nr + 1) || A->seg_na.ensure(nr + 1) || A->out_off.ensure(nr + 2)) return -1;
+	    A->seg_u.ensure(2 * nu_total + 2) || A->seg_a.ensure(c->n_anchor_total + 1) || A->reg_cnt.ensure(nr + 1) || A->seg_na.ensure(nr + 1) || A->out_off.ensure(nr + 2) || A->rext.ensure(2 * Btot + 1) || A->seg_fast.ensure(nr + 1)) return -1;
 	WsBase W;
 	W.regs0 = A->regs0.p; W.mregs = A->mregs.p; W.rtmp = A->rtmp.p; W.aux128 = A->aux128.p; W.seg_a = A->seg_a.p; W.aux64 = A->aux64.p; W.seg_u = A->seg_u.p; W.auxi = A->auxi.p;
-	W.nu_off = A->nu_off.p; W.frag_nu = c->frag_nu.p; W.a_off = c->a_off.p; W.reg_cnt = A->reg_cnt.p; W.seg_na = A->seg_na.p;
+	W.nu_off = A->nu_off.p; W.frag_nu = c->frag_nu.p; W.a_off = c->a_off.p; W.reg_cnt = A->reg_cnt.p; W.seg_na = A->seg_na.p; W.rext = A->rext.p; W.seg_fast = A->seg_fast.p;
 	hipLaunchKernelGGL(k_regs, dim3((nf + 255) / 256), dim3(256), 0, s, c->chained.p, c->u.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, nf, c->P, c->counters.p);
 	AL_HIP_CHECK(hipEventRecord(c->ev[ST_REGS + 1], s));
 	// extension stage geometry
