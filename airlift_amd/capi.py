@@ -82,6 +82,8 @@ def load():
     L.al_idx_build_device.argtypes = [cs, C.POINTER(IdxOpt), ci]; L.al_idx_build_device.restype = vp
     L.al_idx_export_pos.argtypes = [vp, vp, C.c_int64]; L.al_idx_export_pos.restype = C.c_int64
     L.al_ctx_set_threads.argtypes = [vp, ci]; L.al_ctx_set_threads.restype = None
+    L.al_batch_count_candidates.argtypes = [vp, C.POINTER(C.c_int64)]; L.al_batch_count_candidates.restype = ci
+    L.al_count_candidates_file.argtypes = [vp, cs, C.POINTER(MapOpt), ci, ci, C.POINTER(C.c_int64)]; L.al_count_candidates_file.restype = ci
     L.al_idx_str.argtypes = [ci, ci, ci, C.POINTER(cs), C.POINTER(cs)]; L.al_idx_str.restype = vp
     L.al_idx_destroy.argtypes = [vp]; L.al_idx_destroy.restype = None
     L.al_idx_n_seq.argtypes = [vp]; L.al_idx_n_seq.restype = C.c_uint32

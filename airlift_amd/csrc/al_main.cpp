@@ -5,6 +5,7 @@
 //   B3     airlift-align aln [-n X] [-t N] REF.fa GAPS.fa > X.sai               (src/3-align_gaps/align_gaps.sh:14; writes a stub .sai)
 //          airlift-align samse REF.fa X.sai GAPS.fa                              (align_gaps.sh:15; does the actual single-end mapping)
 //   mm2    airlift-align -ax sr [-t N] [-R RG] [-K NUM] [--sam-hit-only] REF.fa R1 [R2]   (fork README usage; main.c:113-273)
+//   a8     airlift-align -ax sr --count-candidates REF.fa READS     the as-shipped fork's observable: seed-cluster count on stderr
 // SAM goes to stdout; exit status 0 on success, non-zero on failure (so the caller's pipe fails).
 #include <stdio.h>
 #include <stdlib.h>
@@ -27,7 +28,7 @@ int main(int argc, char **argv)
 {
 	al_idxopt_t io; al_mapopt_t mo;
 	struct timespec tsm; clock_gettime(CLOCK_MONOTONIC, &tsm);
-	std::vector<const char *> pos; const char *rg = nullptr; int n_threads = 3, device = -1;
+	std::vector<const char *> pos; const char *rg = nullptr; int n_threads = 3, device = -1; bool count_only = false;
 	enum { MODE_MEM, MODE_ALN, MODE_SAMSE, MODE_MM2 } mode = MODE_MM2;
 	int i = 1;
 	if (argc < 2) return usage();
@@ -50,6 +51,7 @@ int main(int argc, char **argv)
 		else if (!strcmp(a, "-K") && i + 1 < argc) mo.mini_batch_size = (int)atof(argv[++i]);
 		else if (!strcmp(a, "-n") && i + 1 < argc) ++i;                       // bwa aln -n: accepted, no analogue
 		else if (!strcmp(a, "--sam-hit-only")) mo.flag |= AL_F_SAM_HIT_ONLY;
+		else if (!strcmp(a, "--count-candidates")) count_only = true;
 		else if (!strcmp(a, "--device") && i + 1 < argc) device = atoi(argv[++i]);
 		else if (!strcmp(a, "--version")) { puts(al_version()); return 0; }
 		else { fprintf(stderr, "[WARNING] airlift-align: option '%s' ignored\n", a); }
@@ -72,6 +74,15 @@ int main(int argc, char **argv)
 	clock_gettime(CLOCK_MONOTONIC, &ts1);
 	if (getenv("AL_TIMING")) fprintf(stderr, "[airlift] index build %.3f s\n", (ts1.tv_sec - ts0.tv_sec) + 1e-9 * (ts1.tv_nsec - ts0.tv_nsec));
 	if (!mi) { fprintf(stderr, "[ERROR] failed to open file '%s'\n", ref); return 1; }
+	if (count_only) {   // what the as-shipped fork prints instead of alignments (main.c:384-391, 417)
+		int64_t total = 0;
+		const int rc2 = al_count_candidates_file(mi, reads[0], &mo, n_threads, device, &total);
+		al_idx_destroy(mi);
+		if (rc2 != 0) return 1;
+		fprintf(stderr, "\nTotal No. of Mappings before alignment (verification): %d\n", (int)total);
+		fflush(stderr);
+		_exit(0);
+	}
 	int rc = al_map_file_frag(mi, (int)reads.size(), reads.data(), &mo, n_threads, stdout, rg, device);
 	clock_gettime(CLOCK_MONOTONIC, &ts0);
 	al_idx_destroy(mi);

@@ -233,3 +233,40 @@ extern "C" int al_map_file_frag(const al_idx_t *mi, int n_fn, const char **fn, c
 	fflush(out);
 	return rc ? rc : W.rc;
 }
+
+extern "C" int al_batch_count_candidates(al_ctx_t *c, int64_t *total);
+
+// The unmodified fork's main loop (main.c:384-391) maps every read of ONE file on its own (mm_map) and sums the counter of
+// map.c:299-312; here: reader thread -> single-segment batches -> seed kernels + k_alser_count.
+extern "C" int al_count_candidates_file(const al_idx_t *mi, const char *fn, const al_mapopt_t *opt, int n_threads, int device, int64_t *total)
+{
+	if (!total) return -1;
+	*total = 0;
+	AlSeqReader rd;
+	if (!rd.open(fn)) { fprintf(stderr, "ERROR: failed to open file '%s'\n", fn); return -1; }
+	Queue<ChunkP> cq(8);
+	std::thread reader(reader_main, &rd, &cq);
+	al_ctx_t *ctx = al_ctx_init(mi, opt, device);
+	if (!ctx) { cq.abort(); reader.join(); return -2; }
+	al_ctx_set_threads(ctx, n_threads);
+	const int64_t batch_bases = opt->mini_batch_size > 0 ? (int64_t)opt->mini_batch_size : 50000000;
+	int rc = 0; bool done = false;
+	while (!done && rc == 0) {
+		Batch b;
+		while (b.bases < batch_bases) {
+			ChunkP a;
+			if (!cq.pop(a)) { done = true; break; }
+			for (const AlRec &r : a->recs) { b.add_read(*a, r); b.n_segs.push_back(1); }
+			b.chunks.push_back(std::move(a));
+		}
+		const int nf = (int)b.n_segs.size();
+		if (nf == 0) continue;
+		int64_t t = 0;
+		if ((rc = al_batch_upload(ctx, nf, b.n_segs.data(), b.qlens.data(), b.seqs.data(), nullptr)) != 0) break;   // mm_map passes no query name
+		if ((rc = al_batch_count_candidates(ctx, &t)) != 0) break;
+		*total += t;
+	}
+	cq.abort(); reader.join();
+	al_ctx_destroy(ctx);
+	return rc;
+}

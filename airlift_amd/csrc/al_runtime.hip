@@ -458,9 +458,24 @@ extern "C" int al_dbg_chains(al_ctx_t *c, int f, uint64_t *u, int cap_u, uint64_
 	return (int)nu;
 }
 
+static int alser_count_resident(al_ctx_t *c, int64_t *total);
 extern "C" int al_dbg_alser_count(al_ctx_t *c, int64_t *total)
 {   // expects a resident batch of single-segment fragments on which al_batch_run() has been called
 	if (!c || !c->ran) return -1;
+	return alser_count_resident(c, total);
+}
+
+// a8 as a product entry point: seed stages only (no extension) on the resident batch of single-segment fragments, then the
+// as-shipped fork's candidate counter (map.c:299-312)
+extern "C" int al_batch_count_candidates(al_ctx_t *c, int64_t *total)
+{
+	if (!c || !total) return -1;
+	if (al_run_seed_stages(c)) return -1;
+	return alser_count_resident(c, total);
+}
+
+static int alser_count_resident(al_ctx_t *c, int64_t *total)
+{
 	AL_HIP_CHECK(hipSetDevice(c->device));
 	AL_HIP_CHECK(hipMemsetAsync(c->counters.p + 2, 0, 8, c->stream));
 	if (c->n_frag) hipLaunchKernelGGL(k_alser_count, dim3((c->n_frag + 255) / 256), dim3(256), 0, c->stream, c->anchors.p, c->n_rechain ? c->a_off_p1.p : c->a_off.p, c->n_rechain ? c->frag_na_p1.p : c->frag_na.p, c->frag_first.p, c->rd_len.p, c->n_frag, c->opt.min_cnt, c->counters.p + 2);

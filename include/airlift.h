@@ -160,6 +160,14 @@ const char *al_stage_name(int i);
 /* the kernel that runs in interval i (as rocprofv3 --kernel-trace names it); "" where an interval is a few small launches */
 const char *al_stage_kernel(int i);
 
+/* ---- the fork's as-shipped observable: number of seed clusters that would go on to alignment ---- */
+/* Seed stages only on the resident batch (upload it with one segment per fragment, as the fork's main loop maps read by read,
+ * main.c:384-391); *total gets the batch's count (map.c:299-312). */
+int  al_batch_count_candidates(al_ctx_t *ctx, int64_t *total);
+/* Whole file: the value the unmodified fork prints as "Total No. of Mappings before alignment (verification)" (main.c:417).
+ * Returns 0, negative on error. */
+int  al_count_candidates_file(const al_idx_t *mi, const char *fn, const al_mapopt_t *opt, int n_threads, int device, int64_t *total);
+
 /* ---- stage taps for parity tests (analogue of --print-seeds, map.c:333-338,381-385) ---- */
 /* minimizers of read i of the resident batch: returns count, writes up to cap records (x = hash<<8|span, y = i<<32|pos<<1|strand) */
 int  al_dbg_minimizers(al_ctx_t *ctx, int read_idx, uint64_t *xy, int cap);

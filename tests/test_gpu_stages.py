@@ -157,3 +157,17 @@ def test_device_built_index_ragged_contigs(A, tmp_path):
             for o in range(0, L, 70):
                 f.write(s[o:o + 70].tobytes() + b"\n")
     _same_index(A, str(fa))
+
+
+@pytest.mark.parametrize("name", SETS)
+def test_cli_count_candidates_matches_the_unmodified_fork(golden_unpacked, name):
+    """`airlift-align --count-candidates` prints the number the as-shipped fork prints instead of alignments
+    (main.c:417; golden value produced by the untouched reference tree, oracle/_ref/mm2count)."""
+    import json, subprocess
+    d = golden_unpacked[name]
+    m = json.load(open(os.path.join(d, "meta.json")))
+    cli = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "airlift_amd", "bin", "airlift-align")
+    r = subprocess.run([cli, "-ax", "sr", "--count-candidates", "-K", "30000", m["ref"], m["reads"][-1]], cwd=d, capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    assert r.stdout == b""
+    assert ("Total No. of Mappings before alignment (verification): %d" % m["count"]).encode() in r.stderr, r.stderr.decode()[-500:]
