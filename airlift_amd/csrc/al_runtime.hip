@@ -257,7 +257,11 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 	}
 	// fragments ordered by anchor count: the sort kernels and the chaining kernels are chosen per size class, and lanes of
 	// one wavefront get equal trip counts.  [0, lb65) <= 64 anchors, [lb65, lb129) <= 128 anchors, rest.
-	const int lane_max = (c->P.dbg >> 27) & 1 ? 0 : 64;
+	// the LDS chaining kernels keep 16-bit window-relative positions and 8-bit row indices: they need max_dist_x < 2^15 and
+	// max_chain_iter >= 128 (true for the short-read preset); other option values go through the wave-per-fragment kernel
+	const int mdx = std::max(std::max(c->opt.max_gap_ref, c->opt.max_frag_len), c->opt.max_gap);
+	const bool lds_ok = mdx <= 0x7fff && c->opt.max_chain_iter >= 128;
+	const int lane_max = ((c->P.dbg >> 27) & 1) || !lds_ok ? 0 : 64;
 	const uint32_t *order = list; bool sorted = false;
 	uint32_t lb65 = (uint32_t)nl, lb81 = (uint32_t)nl, lb97 = (uint32_t)nl, lb129 = (uint32_t)nl;
 	if (first && lane_max > 0 && nl > 1024) {
