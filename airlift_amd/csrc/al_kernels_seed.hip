@@ -660,7 +660,9 @@ k_chain_lds(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a
 	__shared__ int16_t sv[CAPL * LANES];
 	__shared__ uint8_t s_clin[AL_CLIN_N];
 	const int lane = threadIdx.x;
-	const int t0 = blockIdx.x * LANES + lane;
+	// the list is ordered by anchor count: blocks are issued roughly in index order, so the heaviest wavefronts go first and
+	// the light ones fill the tail of the launch
+	const int t0 = (int)(gridDim.x - 1 - blockIdx.x) * LANES + lane;
 	const bool have = lane < LANES && t0 < n_list;
 	const uint32_t f = have ? (order ? order[t0] : (uint32_t)t0) : 0;
 	const int n = have ? (int)frag_na[f] : 0;
