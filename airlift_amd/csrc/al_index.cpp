@@ -202,7 +202,8 @@ static al_idx_t *idx_from_codes(int w, int k, std::vector<AlSeq> &&seqs, std::ve
 		for (j = i; j < tot && all[j].h == all[i].h; ++j) mi->pos[j] = all[j].y;
 		uint64_t s = al_tab_slot(all[i].h, bits);
 		while (mi->tab[2*s]) s = (s + 1) & tmask;
-		mi->tab[2*s] = all[i].h + 1; mi->tab[2*s+1] = (uint64_t)i << 32 | (uint32_t)(j - i);
+		if (j - i == 1 && mi->seq.size() <= AL_TAB_SINGLE_MAX_SEQ) { mi->tab[2*s] = (all[i].h + 1) | AL_TAB_SINGLE; mi->tab[2*s+1] = all[i].y; }
+		else { mi->tab[2*s] = all[i].h + 1; mi->tab[2*s+1] = (uint64_t)i << 32 | (uint32_t)(j - i); }
 	}
 	return mi;
 }

@@ -137,14 +137,17 @@ k_ref_sketch(const uint32_t *__restrict__ S4, const uint64_t *__restrict__ seq_o
 
 __global__ void __launch_bounds__(256)
 k_tab_insert(const uint64_t *__restrict__ uniq, const uint32_t *__restrict__ counts, const uint64_t *__restrict__ offs, uint64_t n_keys,
-             unsigned long long *__restrict__ tab, int tab_bits)
+             const uint64_t *__restrict__ pos, int single_ok, unsigned long long *__restrict__ tab, int tab_bits)
 {
 	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n_keys) return;
 	const uint64_t h = uniq[i], tmask = (1ULL << tab_bits) - 1;
+	const bool single = single_ok && counts[i] == 1;
+	const unsigned long long key = (unsigned long long)(h + 1) | (single ? AL_TAB_SINGLE : 0ULL);
+	const uint64_t val = single ? pos[offs[i]] : (offs[i] << 32 | (uint64_t)counts[i]);
 	uint64_t s = (h * 0x9E3779B97F4A7C15ULL) >> (64 - tab_bits);
 	for (;;) {
-		if (atomicCAS(&tab[2 * s], 0ULL, (unsigned long long)(h + 1)) == 0ULL) { tab[2 * s + 1] = offs[i] << 32 | (uint64_t)counts[i]; return; }
+		if (atomicCAS(&tab[2 * s], 0ULL, key) == 0ULL) { tab[2 * s + 1] = val; return; }
 		s = (s + 1) & tmask;
 	}
 }
@@ -252,7 +255,7 @@ extern "C" al_idx_t *al_idx_build_device(const char *fn, const al_idxopt_t *io, 
 	while ((1ULL << bits) < n_keys * 2 + 2) ++bits;
 	IDX_CHECK(hipMalloc((void **)&d.tab, ((size_t)2 << bits) * 8));
 	IDX_CHECK(hipMemsetAsync(d.tab, 0, ((size_t)2 << bits) * 8, st));
-	if (n_keys) hipLaunchKernelGGL(k_tab_insert, dim3((unsigned)((n_keys + 255) / 256)), dim3(256), 0, st, d_uniq, d_kcnt, d_koff, n_keys, (unsigned long long *)d.tab, bits);
+	if (n_keys) hipLaunchKernelGGL(k_tab_insert, dim3((unsigned)((n_keys + 255) / 256)), dim3(256), 0, st, d_uniq, d_kcnt, d_koff, n_keys, d_y, n_seq <= AL_TAB_SINGLE_MAX_SEQ ? 1 : 0, (unsigned long long *)d.tab, bits);
 	IDX_CHECK(hipStreamSynchronize(st));
 	d.pos = d_y; d_y = nullptr;
 	if (!total) IDX_CHECK(hipMalloc((void **)&d.pos, 8));

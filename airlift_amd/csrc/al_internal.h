@@ -50,6 +50,11 @@ struct al_idx_s {
 };
 
 static inline uint64_t al_tab_slot(uint64_t hash, int bits) { return (hash * 0x9E3779B97F4A7C15ULL) >> (64 - bits); }
+// A minimizer that occurs once keeps its position in the table entry itself (key word | AL_TAB_SINGLE, value = the position
+// word rid<<32|pos<<1|strand), as the reference does for singletons (index.c:229-233): one random HBM access less per anchor.
+// Used when contig ids fit 16 bits (the match record carries 48 bits).
+#define AL_TAB_SINGLE (1ULL << 63)
+#define AL_TAB_SINGLE_MAX_SEQ 65536u
 
 // host-side helpers (al_index.cpp)
 void al_sketch_host(const uint8_t *codes, uint32_t len, int w, int k, uint32_t rid, std::vector<uint64_t> &hash_out, std::vector<uint64_t> &y_out);
@@ -70,7 +75,7 @@ struct AlMatch {              // one query minimizer that passed the occurrence 
 	uint32_t off_lo;          // offset into pos[] (low 32 bits)
 	uint32_t n;               // occurrences
 	uint32_t q_pos;           // (pos<<1 | strand) in the concatenated fragment
-	uint32_t flags;           // seg_id | is_tandem<<8 | off_hi<<16
+	uint32_t flags;           // seg_id | is_tandem<<8 | single<<9 | off_hi<<16 (single: off_lo/off_hi hold the position word itself)
 };
 
 struct AlAnchor { uint64_t x, y; };   // mm128_t anchor (map.c:176-187)

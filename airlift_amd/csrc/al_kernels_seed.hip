@@ -94,16 +94,23 @@ k_sketch(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_of
 // positions of mate 2 offset by len(mate 1): collect_minimizers, map.c:64-77), probes the 16-byte-entry
 // open-addressing table and applies the occurrence filter / repeat-length bookkeeping of collect_matches.
 // =============================================================================================
-__device__ __forceinline__ uint64_t d_idx_get(const uint64_t *__restrict__ tab, int tab_bits, uint64_t hash)
-{   // returns off<<32|n, or 0 if absent
+__device__ __forceinline__ uint64_t d_idx_get(const uint64_t *__restrict__ tab, int tab_bits, uint64_t hash, bool &single)
+{   // returns off<<32|n (single == false), the position word of a once-occurring minimizer (single == true), or 0 if absent
 	const uint64_t tmask = (1ULL << tab_bits) - 1;
 	uint64_t s = (hash * 0x9E3779B97F4A7C15ULL) >> (64 - tab_bits);
+	single = false;
 	for (;;) {
 		const ulonglong2 e = *reinterpret_cast<const ulonglong2 *>(tab + 2 * s);   // one 16-B entry
-		if (e.x == hash + 1) return e.y;
+		if ((e.x & ~AL_TAB_SINGLE) == hash + 1) { single = (e.x & AL_TAB_SINGLE) != 0; return e.y; }
 		if (e.x == 0) return 0;
 		s = (s + 1) & tmask;
 	}
+}
+// position word k of a match's occurrence list
+__device__ __forceinline__ uint64_t d_match_pos(const uint64_t *__restrict__ pos, uint32_t off_lo, uint32_t flags, uint32_t k)
+{
+	const uint64_t w = (uint64_t)off_lo | (uint64_t)(flags >> 16) << 32;
+	return (flags >> 9 & 1u) ? w : pos[w + k];
 }
 
 extern "C" __global__ void __launch_bounds__(256)
@@ -127,8 +134,9 @@ k_seed(const uint64_t *__restrict__ tab, int tab_bits,
 		for (uint32_t i = 0; i < n; ++i) {
 			const uint64_t x = mv[i].x, hash = x >> 8;
 			const uint32_t q_pos = (uint32_t)mv[i].y + (sum << 1), q_span = (uint32_t)(x & 0xff);
-			const uint64_t v = d_idx_get(tab, tab_bits, hash);
-			const uint32_t occ = (uint32_t)v;
+			bool single;
+			const uint64_t v = d_idx_get(tab, tab_bits, hash, single);
+			const uint32_t occ = single ? 1u : (uint32_t)v;
 			// is_tandem (map.c:115-116): equal hash with the previous / next minimizer of the whole list
 			const int same_prev = have_prev && prev_hash == hash;
 			if (same_prev && last_valid && last_hash == hash) last->flags |= 1u << 8;   // previous gets "next is same"
@@ -139,8 +147,8 @@ k_seed(const uint64_t *__restrict__ tab, int tab_bits,
 				else rep_en = en;
 			} else if (occ > 0) {
 				AlMatch m;
-				m.off_lo = (uint32_t)(v >> 32); m.n = occ; m.q_pos = q_pos;
-				m.flags = seg | (same_prev ? 1u << 8 : 0u);
+				m.off_lo = single ? (uint32_t)v : (uint32_t)(v >> 32); m.n = occ; m.q_pos = q_pos;
+				m.flags = seg | (same_prev ? 1u << 8 : 0u) | (single ? (1u << 9 | (uint32_t)(v >> 32) << 16) : 0u);
 				mo[n_m] = m; last = &mo[n_m]; last_hash = hash; last_valid = 1;
 				++n_m; n_a += occ;
 			}
@@ -230,8 +238,7 @@ __device__ __forceinline__ void d_anchor_heap_merge(const uint64_t *__restrict__
 	size_t hs = 0; uint64_t n_for = 0, n_rev = 0;
 	atomicAdd(&counters[0], 1ULL);
 	for (uint32_t i = 0; i < n_m; ++i) {
-		const uint64_t off = (uint64_t)m[i].off_lo | (uint64_t)(m[i].flags >> 16) << 32;
-		heap.set(hs, HeapEnt{pos[off], i, 0u}); ++hs;
+		heap.set(hs, HeapEnt{d_match_pos(pos, m[i].off_lo, m[i].flags, 0u), i, 0u}); ++hs;
 	}
 	if (hs > 1) for (size_t i = (hs >> 1) - 1; i != (size_t)-1; --i) d_heapdown(i, hs, heap);
 	while (hs > 0) {
@@ -251,8 +258,7 @@ __device__ __forceinline__ void d_anchor_heap_merge(const uint64_t *__restrict__
 		if (!(a.x >> 63)) out[n_for++] = a; else out[n - (++n_rev)] = a;
 		if (top.off < mm.n - 1) {
 			++top.off;
-			const uint64_t off = (uint64_t)mm.off_lo | (uint64_t)(mm.flags >> 16) << 32;
-			top.x = pos[off + top.off];
+			top.x = d_match_pos(pos, mm.off_lo, mm.flags, top.off);
 			heap.set(0, top);
 		} else { heap.set(0, heap.get(hs - 1)); --hs; }
 		if (hs > 0) d_heapdown(0, hs, heap);
@@ -340,8 +346,7 @@ k_anchor_sort(const uint64_t *__restrict__ pos, const uint32_t *__restrict__ fra
 				uint32_t lo = 0, hi = n_m;                                   // last mi with pre[mi] <= t
 				while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (pre[mid] <= t) lo = mid; else hi = mid; }
 				const AlMatch mm = m[lo];
-				const uint64_t off = (uint64_t)mm.off_lo | (uint64_t)(mm.flags >> 16) << 32;
-				const uint64_t r = pos[off + (t - pre[lo])];
+				const uint64_t r = d_match_pos(pos, mm.off_lo, mm.flags, t - pre[lo]);
 				const uint32_t span = (uint32_t)mini_span, seg = mm.flags & 0xff;
 				const int32_t rpos = (uint32_t)r >> 1;
 				if ((r & 1) == (mm.q_pos & 1)) {
@@ -400,8 +405,7 @@ k_anchor_sort_small(const uint64_t *__restrict__ pos, const uint32_t *__restrict
 	const uint32_t o_off = (uint32_t)__shfl((int)mm.off_lo, own), o_fl = (uint32_t)__shfl((int)mm.flags, own), o_qp = (uint32_t)__shfl((int)mm.q_pos, own), o_pre = (uint32_t)__shfl((int)pre, own);
 	uint64_t x = UINT64_MAX, y = UINT64_MAX;
 	if ((uint32_t)lane < n) {
-		const uint64_t off = (uint64_t)o_off | (uint64_t)(o_fl >> 16) << 32;
-		const uint64_t r = pos[off + ((uint32_t)lane - o_pre)];
+		const uint64_t r = d_match_pos(pos, o_off, o_fl, (uint32_t)lane - o_pre);
 		const uint32_t span = (uint32_t)mini_span, seg = o_fl & 0xff;
 		const int32_t rpos = (uint32_t)r >> 1;
 		if ((r & 1) == (o_qp & 1)) {                                          // map.c:176-190
