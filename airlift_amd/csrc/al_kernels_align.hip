@@ -68,10 +68,10 @@ struct GroupWs {                    // per-group HBM scratch (+ the current loca
 #define AL_LB_REGS 5
 #endif
 #ifndef AL_LB_PREP
-#define AL_LB_PREP 8
+#define AL_LB_PREP 5
 #endif
 #ifndef AL_LB_FIN
-#define AL_LB_FIN 5
+#define AL_LB_FIN 4
 #endif
 #define PROF_ON(P) (((P).dbg >> 21) & 1)
 #define AL_PAIR_SC_CAP 4096
