@@ -648,7 +648,7 @@ k_chain(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_off
 // a wavefront whose largest fragment does not fall in (lo_excl, CAPL] leaves the work to another instantiation.  All spans
 // must equal k and max_dist_x < 2^15 (true on the short-read path); a fragment violating that is a counted error.
 // =============================================================================================
-#define AL_CLIN_N 1024
+#define AL_CLIN_N 512
 template <int CAPL, int LANES>
 __global__ void __launch_bounds__(64)
 k_chain_lds(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_off, const uint32_t *__restrict__ frag_na,
@@ -662,7 +662,7 @@ k_chain_lds(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a
 	//        (strand, contig) block or >= 2^15 away, which is all the window start needs to know.
 	__shared__ uint64_t srow[CAPL * LANES];
 	__shared__ int16_t sv[CAPL * LANES];
-	__shared__ uint8_t s_clin[AL_CLIN_N];
+	__shared__ uint8_t s_pen_same[AL_CLIN_N], s_pen_diff[AL_CLIN_N];
 	const int lane = threadIdx.x;
 	// the list is ordered by anchor count: blocks are issued roughly in index order, so the heaviest wavefronts go first and
 	// the light ones fill the tail of the launch
@@ -673,8 +673,11 @@ k_chain_lds(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a
 	int nmax = n;
 	for (int d = 32; d > 0; d >>= 1) { const int o = __shfl_xor(nmax, d); nmax = o > nmax ? o : nmax; }
 	if (nmax > CAPL || nmax <= lo_excl) return;                              // another instantiation / kernel owns this wavefront
-	// (int)(dd * .01 * avg_d) of chain.c:69 for avg_d == k, tabulated with the same two double multiplications
-	for (int d = lane; d < AL_CLIN_N; d += 64) s_clin[d] = (uint8_t)(int)((double)d * .01 * (double)P.k);
+	// gap costs of chain.c:64-72 for avg_d == k, tabulated with the same two double multiplications for (int)(dd * .01 * avg_d)
+	for (int d = lane; d < AL_CLIN_N; d += 64) {
+		const int c_lin = (int)((double)d * .01 * (double)P.k), lg = d ? d_ilog2((uint32_t)d) : 0;
+		s_pen_same[d] = (uint8_t)(c_lin + (lg >> 1)); s_pen_diff[d] = (uint8_t)(c_lin < lg ? c_lin : lg);
+	}
 	__syncthreads();
 	if (!have) return;
 	frag_nu[f] = 0;
@@ -713,7 +716,8 @@ k_chain_lds(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a
 		if (bad) { atomicAdd(&counters[7], 1ULL); return; }   // not representable in the compact rows (never on the short-read path)
 	}
 	const double avg_d = (double)(float)((double)(float)((uint32_t)q_span * (uint32_t)n) / (double)(float)n);   // (float)sum/n (chain.c:42)
-	const bool tab_ok = avg_d == (double)P.k && P.k * 0.01 * (AL_CLIN_N - 1) < 255.0;
+	const bool tab_ok = avg_d == (double)P.k && P.k * 0.01 * (AL_CLIN_N - 1) + 5.0 < 255.0;
+	const uint32_t dr_lim = n_segs > 1 ? (uint32_t)max_dist_y : 0x7fffffffu;   // (uint32_t)(dr - 1) >= dr_lim  <=>  dr == 0 or dr > max_dist_y (paired end only)
 	int st = 0; int32_t dist = 0;                                                 // dist = x_i - x_st while st..i lie in one window
 	uint32_t prev_xlo = 0;
 	for (int i = 0; i < n; ++i) {                                                 // chain.c:46-85
@@ -743,14 +747,20 @@ k_chain_lds(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a
 			const int32_t dq = qi - R_Q(rj);
 			const bool same = R_SEG(rj) == sidi;
 			const int32_t dd = dr > dq ? dr - dq : dq - dr;
-			const bool skip = (same && dr == 0) | (dq <= 0) | (same && dq > max_dist_y) | (dq > max_dist_x) | (same && dd > bw) |
-			                  (n_segs > 1 && same && dr > max_dist_y);
+			// chain.c:56-63 with the range tests folded into unsigned compares: dq <= 0 or dq > max_dist_x; for anchors of the same
+			// mate also dr == 0 or (paired end) dr > max_dist_y, dq > max_dist_y, dd > bw
+			const bool skip = ((uint32_t)(dq - 1) >= (uint32_t)max_dist_x) |
+			                  (same & (((uint32_t)(dr - 1) >= dr_lim) | (dq > max_dist_y) | (dd > bw)));
 			const int32_t min_d = dq < dr ? dq : dr;
 			int32_t sc = min_d > q_span ? q_span : min_d;
-			const int32_t log_dd = dd ? d_ilog2((uint32_t)dd) : 0;
-			int32_t c_lin = (int32_t)s_clin[dd < AL_CLIN_N ? (dd < 0 ? 0 : dd) : AL_CLIN_N - 1];
-			if (__builtin_expect(!tab_ok || dd >= AL_CLIN_N, 0)) c_lin = (int)((double)dd * .01 * avg_d);
-			const int32_t pen_same = c_lin + (log_dd >> 1), pen_diff = dr == 0 ? -1 : (c_lin < log_dd ? c_lin : log_dd);
+			// gap cost (chain.c:64-72) from two per-wavefront tables: same mate c_lin + (ilog2(dd) >> 1), other mate min(c_lin, ilog2(dd))
+			const uint32_t di = (uint32_t)dd < AL_CLIN_N ? (uint32_t)dd : AL_CLIN_N - 1;
+			int32_t pen_same = (int32_t)s_pen_same[di], pen_diff = (int32_t)s_pen_diff[di];
+			if (__builtin_expect(!tab_ok || dd >= AL_CLIN_N, 0)) {
+				const int32_t log_dd = dd ? d_ilog2((uint32_t)dd) : 0, c_lin = (int)((double)dd * .01 * avg_d);
+				pen_same = c_lin + (log_dd >> 1); pen_diff = c_lin < log_dd ? c_lin : log_dd;
+			}
+			pen_diff = dr == 0 ? -1 : pen_diff;
 			sc = sc - (same ? pen_same : pen_diff) + R_F(rj);
 			const uint32_t pj = R_P(rj);
 			const bool better = !skip && sc > max_f;
