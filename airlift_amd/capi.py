@@ -99,6 +99,7 @@ def load():
     L.al_map_batch.restype = ci
     L.al_map_frag.argtypes = [vp, ci, C.POINTER(ci), C.POINTER(cs), C.POINTER(ci), C.POINTER(C.POINTER(Reg)), vp, C.POINTER(MapOpt), cs]; L.al_map_frag.restype = None
     L.al_map_file_frag.argtypes = [vp, ci, C.POINTER(cs), C.POINTER(MapOpt), ci, vp, cs, ci]; L.al_map_file_frag.restype = ci
+    L.al_map_file_frag_bam.argtypes = [vp, ci, C.POINTER(cs), C.POINTER(MapOpt), ci, vp, cs, ci, ci, ci]; L.al_map_file_frag_bam.restype = ci
     L.al_batch_stat.argtypes = [vp, C.POINTER(BatchStat)]; L.al_batch_stat.restype = None
     L.al_stage_name.argtypes = [ci]; L.al_stage_name.restype = cs
     L.al_stage_kernel.argtypes = [ci]; L.al_stage_kernel.restype = cs

@@ -5,6 +5,8 @@
 //   B3     airlift-align aln [-n X] [-t N] REF.fa GAPS.fa > X.sai               (src/3-align_gaps/align_gaps.sh:14; writes a stub .sai)
 //          airlift-align samse REF.fa X.sai GAPS.fa                              (align_gaps.sh:15; does the actual single-end mapping)
 //   mm2    airlift-align -ax sr [-t N] [-R RG] [-K NUM] [--sam-hit-only] REF.fa R1 [R2]   (fork README usage; main.c:113-273)
+//   N3     airlift-align ... --bam | --sorted-bam [-l LEVEL]       BAM on stdout; sorted = mapped records in coordinate order,
+//                                                                   i.e. the result of `| samtools view -h -F4 | samtools sort -l5`
 //   a8     airlift-align -ax sr --count-candidates REF.fa READS     the as-shipped fork's observable: seed-cluster count on stderr
 // SAM goes to stdout; exit status 0 on success, non-zero on failure (so the caller's pipe fails).
 #include <stdio.h>
@@ -28,7 +30,7 @@ int main(int argc, char **argv)
 {
 	al_idxopt_t io; al_mapopt_t mo;
 	struct timespec tsm; clock_gettime(CLOCK_MONOTONIC, &tsm);
-	std::vector<const char *> pos; const char *rg = nullptr; int n_threads = 3, device = -1; bool count_only = false;
+	std::vector<const char *> pos; const char *rg = nullptr; int n_threads = 3, device = -1; bool count_only = false; int bam_mode = 0, bam_level = 5;
 	enum { MODE_MEM, MODE_ALN, MODE_SAMSE, MODE_MM2 } mode = MODE_MM2;
 	int i = 1;
 	if (argc < 2) return usage();
@@ -52,6 +54,9 @@ int main(int argc, char **argv)
 		else if (!strcmp(a, "-n") && i + 1 < argc) ++i;                       // bwa aln -n: accepted, no analogue
 		else if (!strcmp(a, "--sam-hit-only")) mo.flag |= AL_F_SAM_HIT_ONLY;
 		else if (!strcmp(a, "--count-candidates")) count_only = true;
+		else if (!strcmp(a, "--bam")) bam_mode = 1;
+		else if (!strcmp(a, "--sorted-bam")) bam_mode = 2;
+		else if (!strcmp(a, "-l") && i + 1 < argc) bam_level = atoi(argv[++i]);
 		else if (!strcmp(a, "--device") && i + 1 < argc) device = atoi(argv[++i]);
 		else if (!strcmp(a, "--version")) { puts(al_version()); return 0; }
 		else { fprintf(stderr, "[WARNING] airlift-align: option '%s' ignored\n", a); }
@@ -83,7 +88,8 @@ int main(int argc, char **argv)
 		fflush(stderr);
 		_exit(0);
 	}
-	int rc = al_map_file_frag(mi, (int)reads.size(), reads.data(), &mo, n_threads, stdout, rg, device);
+	int rc = bam_mode ? al_map_file_frag_bam(mi, (int)reads.size(), reads.data(), &mo, n_threads, stdout, rg, device, bam_mode == 2, bam_level)
+	                  : al_map_file_frag(mi, (int)reads.size(), reads.data(), &mo, n_threads, stdout, rg, device);
 	clock_gettime(CLOCK_MONOTONIC, &ts0);
 	al_idx_destroy(mi);
 	clock_gettime(CLOCK_MONOTONIC, &ts1);

@@ -25,6 +25,7 @@
 #include "al_runtime.h"
 #include "al_io.h"
 #include "al_seqio.h"
+#include "al_bam.h"
 
 extern "C" void al_ctx_set_threads(al_ctx_t *c, int n_threads);
 
@@ -74,7 +75,13 @@ void reader_main(AlSeqReader *rd, Queue<ChunkP> *q)
 	q->close();
 }
 
-struct WriterState { const al_idx_t *mi; const al_mapopt_t *opt; FILE *out; const char *rg_id; int n_threads; int rc = 0; double t_conv = 0, t_fmt = 0, t_write = 0; };
+struct SortedStore {            // --sorted-bam: every mapped record is kept until the end of the input
+	std::vector<std::vector<char>> bufs;                  // record bytes, one buffer per (batch, worker)
+	std::vector<uint64_t> keys; std::vector<uint32_t> buf_id, off, len;
+};
+struct WriterState { const al_idx_t *mi; const al_mapopt_t *opt; FILE *out; const char *rg_id; int n_threads; int rc = 0; double t_conv = 0, t_fmt = 0, t_write = 0;
+                     int mode = 0;                 // 0 SAM text, 1 BAM in input order, 2 BAM coordinate-sorted (mapped records only)
+                     AlBgzf *bgzf = nullptr; SortedStore *store = nullptr; };
 
 void write_batch(WriterState &W, Batch &b)
 {
@@ -93,44 +100,78 @@ void write_batch(WriterState &W, Batch &b)
 	const double t1 = now_s();
 	const int nt = W.n_threads > 1 ? W.n_threads : 1;
 	std::vector<std::vector<char>> text(nt); std::vector<int> bad(nt, 0);
+	struct Ent { uint64_t key; uint32_t off, len; };
+	std::vector<std::vector<Ent>> ents(nt);
 	al_parallel_for(nt, (size_t)nf, [&](size_t lo, size_t hi, int t) {
 		std::vector<char> &o = text[t]; size_t used = 0;
-		o.resize((hi - lo) * 800 + 65536);
+		if (W.mode == 0) o.resize((hi - lo) * 800 + 65536); else o.reserve((hi - lo) * 600 + 65536);
+		auto emit = [&](size_t f, int i0, int ns, int j, int k) {
+			const int i = i0 + j;
+			if (W.mode == 0) {
+				const int l = al_write_sam(o.data() + used, o.size() - used, W.mi, b.names[i], b.qlens[i], b.seqs[i], b.quals[i], j, k, ns, &n_regs[i0], &regs[i0], W.rg_id, R.rep[f]);
+				if (l > 0) used += l; else bad[t] = 1;
+			} else {
+				uint64_t key = 0; int unm = 0; const size_t at = o.size();
+				const int l = al_write_bam_rec(o, W.mi, b.names[i], b.qlens[i], b.seqs[i], b.quals[i], j, k, ns, &n_regs[i0], &regs[i0], W.rg_id, R.rep[f], &key, &unm);
+				if (W.mode == 2) { if (unm) o.resize(at); else ents[t].push_back(Ent{key, (uint32_t)at, (uint32_t)l}); }     // -F4
+			}
+		};
 		for (size_t f = lo; f < hi; ++f) {                                   // map.c:601-644
 			const int i0 = first[f], ns = b.n_segs[f];
 			for (int j = 0; j < ns; ++j) {
 				const int i = i0 + j;
-				size_t need = (size_t)b.qlens[i] * 2 + strlen(b.names[i]) + 4096;
-				for (int k = 0; k < n_regs[i]; ++k) need += (size_t)regs[i][k].n_cigar * 12 + 128;
-				const int n_rec = n_regs[i] > 0 ? n_regs[i] : 1;
-				if (o.size() - used < need * n_rec) o.resize((o.size() + need * n_rec) * 3 / 2);
+				if (W.mode == 0) {
+					size_t need = (size_t)b.qlens[i] * 2 + strlen(b.names[i]) + 4096;
+					for (int k = 0; k < n_regs[i]; ++k) need += (size_t)regs[i][k].n_cigar * 12 + 128;
+					const int n_rec = n_regs[i] > 0 ? n_regs[i] : 1;
+					if (o.size() - used < need * n_rec) o.resize((o.size() + need * n_rec) * 3 / 2);
+				}
 				if (n_regs[i] > 0) {
 					for (int k = 0; k < n_regs[i]; ++k) {
 						const al_reg1_t *r = &regs[i][k];
 						if ((W.opt->flag & AL_F_NO_PRINT_2ND) && r->id != r->parent) continue;
-						const int l = al_write_sam(o.data() + used, o.size() - used, W.mi, b.names[i], b.qlens[i], b.seqs[i], b.quals[i], j, k, ns, &n_regs[i0], &regs[i0], W.rg_id, R.rep[f]);
-						if (l > 0) used += l; else bad[t] = 1;
+						emit(f, i0, ns, j, k);
 					}
-				} else if (!(W.opt->flag & AL_F_SAM_HIT_ONLY)) {
-					const int l = al_write_sam(o.data() + used, o.size() - used, W.mi, b.names[i], b.qlens[i], b.seqs[i], b.quals[i], j, -1, ns, &n_regs[i0], &regs[i0], W.rg_id, R.rep[f]);
-					if (l > 0) used += l; else bad[t] = 1;
-				}
+				} else if (!(W.opt->flag & AL_F_SAM_HIT_ONLY)) emit(f, i0, ns, j, -1);
 			}
 		}
-		o.resize(used);
+		if (W.mode == 0) o.resize(used);
 	});
 	const double t2 = now_s();
 	for (int t = 0; t < nt; ++t) {
 		if (bad[t]) W.rc = -3;
-		if (!text[t].empty() && fwrite(text[t].data(), 1, text[t].size(), W.out) != text[t].size()) W.rc = -3;
+		if (text[t].empty()) continue;
+		if (W.mode == 0) { if (fwrite(text[t].data(), 1, text[t].size(), W.out) != text[t].size()) W.rc = -3; }
+		else if (W.mode == 1) { if (W.bgzf->write(text[t].data(), text[t].size())) W.rc = -3; }
+		else {
+			SortedStore &S = *W.store; const uint32_t id = (uint32_t)S.bufs.size();
+			for (const Ent &e : ents[t]) { S.keys.push_back(e.key); S.buf_id.push_back(id); S.off.push_back(e.off); S.len.push_back(e.len); }
+			S.bufs.push_back(std::move(text[t]));
+		}
 	}
 	W.t_conv += t1 - t0; W.t_fmt += t2 - t1; W.t_write += now_s() - t2;
 }
 
 } // namespace
 
+static int map_files(const al_idx_t *mi, int n_fn, const char **fn, const al_mapopt_t *opt, int n_threads, FILE *out, const char *rg, int device, int mode, int level);
+
 extern "C" int al_map_file_frag(const al_idx_t *mi, int n_fn, const char **fn, const al_mapopt_t *opt, int n_threads,
                                 FILE *out, const char *rg, int device)
+{
+	return map_files(mi, n_fn, fn, opt, n_threads, out, rg, device, 0, 0);
+}
+
+// BAM instead of SAM text: sorted == 0 keeps the input order (every record the SAM output would have); sorted != 0 writes the
+// mapped records in coordinate order -- what AirLift gets from `| samtools view -h -F4 | samtools sort -l LEVEL`
+// (src/0-align_reads.sh:13), with the keys sorted on the GPU.
+extern "C" int al_map_file_frag_bam(const al_idx_t *mi, int n_fn, const char **fn, const al_mapopt_t *opt, int n_threads,
+                                    FILE *out, const char *rg, int device, int sorted, int level)
+{
+	return map_files(mi, n_fn, fn, opt, n_threads, out, rg, device, sorted ? 2 : 1, level < 0 || level > 9 ? 5 : level);
+}
+
+static int map_files(const al_idx_t *mi, int n_fn, const char **fn, const al_mapopt_t *opt, int n_threads, FILE *out, const char *rg, int device, int mode, int level)
 {
 	if (n_fn < 1 || n_fn > 2) return -1;
 	if (n_threads < 1) n_threads = 1;
@@ -149,10 +190,13 @@ extern "C" int al_map_file_frag(const al_idx_t *mi, int n_fn, const char **fn, c
 	const double T1 = now_s(); double t_asm = 0, t_up = 0, t_run = 0, t_fetch = 0, t_push = 0; int n_batch = 0;
 	al_ctx_set_threads(ctx, n_threads);
 	char rg_id[256]; rg_id[0] = 0;
-	if (rg != (const char *)-1) al_write_sam_hdr(out, mi, rg, rg_id);
+	AlBgzf bgzf(out, level, n_threads); SortedStore store;
+	if (mode == 0) { if (rg != (const char *)-1) al_write_sam_hdr(out, mi, rg, rg_id); }
+	else if (al_bam_header(bgzf, mi, rg == (const char *)-1 ? nullptr : rg, rg_id, mode == 2)) { stop_readers(); al_ctx_destroy(ctx); return -3; }
 
 	Queue<BatchP> wq(2);
 	WriterState W{mi, opt, out, rg_id, n_threads};
+	W.mode = mode; W.bgzf = &bgzf; W.store = &store;
 	std::mutex pool_m; std::vector<std::unique_ptr<AlRawResult>> pool;
 	std::thread writer([&]() {
 		BatchP b;
@@ -228,6 +272,13 @@ extern "C" int al_map_file_frag(const al_idx_t *mi, int n_fn, const char **fn, c
 	}
 	wq.close(); writer.join();
 	stop_readers();
+	if (rc == 0 && W.rc == 0 && mode == 2) {       // coordinate order: stable radix sort of the keys on the GPU, then the records stream out
+		const size_t n = store.keys.size();
+		std::vector<uint32_t> perm(n);
+		if (al_sort_keys(ctx, store.keys.data(), perm.data(), n)) W.rc = -3;
+		else for (size_t i = 0; i < n && W.rc == 0; ++i) { const uint32_t k = perm[i]; if (bgzf.write(store.bufs[store.buf_id[k]].data() + store.off[k], store.len[k])) W.rc = -3; }
+	}
+	if (rc == 0 && W.rc == 0 && mode != 0 && bgzf.finish()) W.rc = -3;
 	if (timing) fprintf(stderr, "[airlift] pipeline: ctx init %.3f s; %d batches; mapper: wait+assemble %.3f upload %.3f run %.3f fetch %.3f wait-writer %.3f; writer: convert %.3f format %.3f write %.3f; total %.3f s\n", T1 - T0, n_batch, t_asm, t_up, t_run, t_fetch, t_push, W.t_conv, W.t_fmt, W.t_write, now_s() - T0);
 	al_ctx_destroy(ctx);
 	fflush(out);

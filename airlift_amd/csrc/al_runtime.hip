@@ -529,3 +529,26 @@ extern "C" int al_batch_upload_flat(al_ctx_t *c, int n_frag, const int *n_segs, 
 	}
 	return al_batch_upload(c, n_frag, n_segs, qlens, seqs.data(), names.data());
 }
+
+// ---------------------------------------------------------------------------------------------
+// coordinate order for sorted BAM output: stable LSD radix sort of (rid<<32|pos, record index) on the device
+#include "al_bam.h"
+int al_sort_keys(al_ctx_t *c, const uint64_t *keys, uint32_t *perm, size_t n)
+{
+	if (!c) return -1;
+	if (n == 0) return 0;
+	if (n >= (1ULL << 31)) { fprintf(stderr, "[airlift] al_sort_keys: too many records for one sort\n"); return -1; }
+	AL_HIP_CHECK(hipSetDevice(c->device));
+	uint64_t *d_k = nullptr, *d_k2 = nullptr; uint32_t *d_v = nullptr, *d_v2 = nullptr; void *tmp = nullptr; size_t bytes = 0;
+	int rc = -1;
+	if (hipMalloc((void **)&d_k, n * 8) == hipSuccess && hipMalloc((void **)&d_k2, n * 8) == hipSuccess && hipMalloc((void **)&d_v, n * 4) == hipSuccess && hipMalloc((void **)&d_v2, n * 4) == hipSuccess &&
+	    hipMemcpyAsync(d_k, keys, n * 8, hipMemcpyHostToDevice, c->stream) == hipSuccess) {
+		hipLaunchKernelGGL(k_iota_u32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, d_v, (uint32_t)n);
+		if (hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, d_k, d_k2, d_v, d_v2, (int)n, 0, 64, c->stream) == hipSuccess && hipMalloc(&tmp, bytes + 16) == hipSuccess &&
+		    hipcub::DeviceRadixSort::SortPairs(tmp, bytes, d_k, d_k2, d_v, d_v2, (int)n, 0, 64, c->stream) == hipSuccess &&
+		    hipMemcpyAsync(perm, d_v2, n * 4, hipMemcpyDeviceToHost, c->stream) == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess) rc = 0;
+	}
+	(void)hipFree(d_k); (void)hipFree(d_k2); (void)hipFree(d_v); (void)hipFree(d_v2); (void)hipFree(tmp);
+	if (rc) fprintf(stderr, "[airlift] al_sort_keys: device sort failed\n");
+	return rc;
+}

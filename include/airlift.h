@@ -132,6 +132,12 @@ int  al_map_batch(al_ctx_t *ctx, int n_frag, const int *n_segs, const int *qlens
 int  al_map_file_frag(const al_idx_t *mi, int n_segs, const char **fn, const al_mapopt_t *opt, int n_threads,
                       FILE *out, const char *rg, int device);
 
+/* Same mapping, BAM on `out` instead of SAM text (BGZF blocks deflated at `level`, 0-9; n_threads workers).  sorted == 0: input
+ * order, the same records as the SAM output.  sorted != 0: mapped records only, coordinate-sorted -- what AirLift produces with
+ * `| samtools view -h -F4 | samtools sort -l5` (src/0-align_reads.sh:13, run_pipeline.sh:82-87). */
+int  al_map_file_frag_bam(const al_idx_t *mi, int n_segs, const char **fn, const al_mapopt_t *opt, int n_threads,
+                          FILE *out, const char *rg, int device, int sorted, int level);
+
 /* ---- device-resident batch API (bench / multi-GPU harness; inputs already in HBM when timing starts) ---- */
 /* Pack + upload a batch; returns 0.  The batch stays resident until the next upload. */
 int  al_batch_upload(al_ctx_t *ctx, int n_frag, const int *n_segs, const int *qlens, const char *const *seqs,

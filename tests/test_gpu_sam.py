@@ -190,3 +190,45 @@ def test_fasta_reads_single_end(golden_unpacked, oracle_bin, tmp_path):
     got = _run([CLI, "samse", ref, "x.sai", "gaps.fa"], tmp_path).stdout
     exp = _run([oracle_bin, ref, "gaps.fa"], tmp_path).stdout
     assert got == exp, _diff_report(got, exp, "fasta_se")
+
+
+# ---- BAM output: same records as the SAM text; --sorted-bam = `samtools view -F4 | samtools sort` content -----
+def _same_record(b, s):
+    for k in ("qname", "flag", "rid", "pos", "mapq", "cigar", "nrid", "npos", "tlen", "seq", "qual"):
+        assert b[k] == s[k], (k, b, s)
+    assert len(b["tags"]) == len(s["tags"])
+    for x, y in zip(b["tags"], s["tags"]):
+        if isinstance(x, tuple):
+            assert x[:2] == y[:2] and abs(x[2] - y[2]) < 1e-6, (x, y)
+        else:
+            assert x == y, (x, y)
+
+
+@pytest.mark.parametrize("name", ["g1_mt150pe", "g3_adversarial", "g6_repeats"])
+def test_bam_outputs_match_sam(golden_unpacked, name):
+    from bam_util import read_bam, sam_fields
+    d = golden_unpacked[name]
+    m = json.load(open(os.path.join(d, "meta.json")))
+    rg = ["-R", m["rg"]] if m.get("rg") else []
+    sam = open(os.path.join(d, "expected.sam")).read().split("\n")
+    hdr = [l for l in sam if l.startswith("@")]; body = [l for l in sam if l and not l.startswith("@")]
+    # input order
+    r = _run([CLI, "-ax", "sr", "-t", "4", "--bam", "-K", "100000"] + rg + [m["ref"]] + m["reads"], d)
+    text, refs, recs, n_blocks = read_bam(r.stdout)
+    assert text == "\n".join(hdr) + "\n"
+    names = [n for n, _ in refs]
+    assert [("@SQ\tSN:%s\tLN:%d" % x) for x in refs] == [l for l in hdr if l.startswith("@SQ")]
+    assert len(recs) == len(body)
+    exp = [sam_fields(l, names) for l in body]
+    for b, s in zip(recs, exp):
+        _same_record(b, s)
+    # coordinate order, mapped only
+    r = _run([CLI, "-ax", "sr", "-t", "3", "--sorted-bam", "-l", "1", "-K", "100000"] + rg + [m["ref"]] + m["reads"], d)
+    text2, refs2, recs2, _ = read_bam(r.stdout)
+    assert text2 == "@HD\tVN:1.6\tSO:coordinate\n" + text and refs2 == refs
+    keep = [s for s in exp if not (s["flag"] & 4)]
+    keys = [(b["rid"], b["pos"]) for b in recs2]
+    assert keys == sorted(keys) and len(recs2) == len(keep)
+    order = sorted(range(len(keep)), key=lambda i: (keep[i]["rid"], keep[i]["pos"]))     # stable, like the device radix sort
+    for b, i in zip(recs2, order):
+        _same_record(b, keep[i])

@@ -18,3 +18,7 @@ if [ -x $REPO/oracle/_ref/mm2ref ]; then
   TIMEFORMAT="mm2ref -t $(nproc): %R s wall, %U s user"; time $REPO/oracle/_ref/mm2ref -t $(nproc) ref.fa r_1.fq r_2.fq > out_cpu.sam 2> err_cpu.txt
   cmp out_gpu.sam out_cpu.sam && echo "SAM identical ($(wc -l < out_gpu.sam) lines)"
 fi
+# BAM modes of the drop-in on the same files (no samtools in this image to time the pipeline it replaces)
+for m in --bam --sorted-bam; do
+  TIMEFORMAT="airlift-align $m -l 5 -t ${THREADS:-16}: %R s wall"; time $REPO/airlift_amd/bin/airlift-align -ax sr $m -l 5 -t ${THREADS:-16} ref.fa r_1.fq r_2.fq > out.bam 2>/dev/null; ls -la out.bam | awk '{print "  " $5 " bytes"}'
+done
