@@ -80,7 +80,7 @@ __device__ __forceinline__ void d_ksw_reg(LT &L, const int gl, GroupWs &ws, int 
 			carry = (uint32_t)(uint8_t)x1 | (uint32_t)(uint8_t)v1 << 8 | (uint32_t)(uint8_t)x21 << 16;
 		}
 		const int8_t ubound = r == 0 ? (int8_t)(-q - e) : r < long_thres ? (int8_t)(-e) : r == long_thres ? (int8_t)long_diff : (int8_t)(-e2);
-		uint8_t *pr = ptb + (size_t)r * prow - st;
+		uint8_t *const prl = ptb + (size_t)r * prow - st + gl;              // this lane's byte of block 0; block b is a constant 16*b further
 		const uint8_t *qrr = qr + (qlen - 1 - r);
 		const int be = en0 >> 4;
 		int hprev15 = 0;                                                 // H[r-1][en0-1] when en0 is the first lane of its block (that block may be outside [st_,en_])
@@ -144,7 +144,7 @@ __device__ __forceinline__ void d_ksw_reg(LT &L, const int gl, GroupWs &ws, int 
 			const uint32_t An = ((uint32_t)xn & 0xffu) | ((uint32_t)vn & 0xffu) << 8 | ((uint32_t)x2n & 0xffu) << 16 | (uint32_t)un << 24;
 			const uint32_t Bn = (b_old & 0xffff0000u) | ((uint32_t)yn & 0xffu) | ((uint32_t)y2n & 0xffu) << 8;
 			A[b] = act ? An : A[b]; B[b] = act ? Bn : B[b];
-			if (store_p) { if (NB >= 4 || act) pr[t] = (uint8_t)d; }
+			if (store_p) { if (NB >= 4 || act) prl[16 * b] = (uint8_t)d; }
 			// ---- exact max (:307-349): H row update and this lane's candidate
 			{
 				const int hold = H[b];
