@@ -1176,7 +1176,10 @@ k_ext_prep(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_
 				// than the target): the extension then runs along the diagonal, every gapped path loses >= q+e > a+b, and max / max_q /
 				// max_t / mqe_t / reach_end / CIGAR follow from the running diagonal score exactly as ksw_extd2 computes them
 				// (checked against the reference DP in tests/test_diag_shortcut.py; jobs done this way carry pad0 = 1).
-				if (!((P.dbg >> 31) & 1) && r->cnt > 0) {
+				// (the argument needs one mismatch to cost less than any gap: a + b < min(q + e, q2 + e2); true for the short-read
+				// scores 2/8/12,2/24,1 -- with other scores every flank takes the DP kernels)
+				const bool diag_ok = P.a > 0 && P.b > 0 && P.a + P.b < (P.q + P.e < P.q2 + P.e2 ? P.q + P.e : P.q2 + P.e2);
+				if (!((P.dbg >> 31) & 1) && diag_ok && r->cnt > 0) {
 					const int32_t rid2 = r->rid, rev2 = (r->flags & ALR_REV) ? 1 : 0;
 					const uint64_t ref_off2 = G.seq_off[rid2];
 					const ReadAcc Qa{seq, qlen, rev2, 0}; const RefAcc Ta{G.S4, ref_off2};
