@@ -1193,10 +1193,14 @@ k_ext_prep(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_
 							if (cq == ct) sc += P.a; else { sc -= P.b; if (++nmm > 1) return false; }
 							if (sc > mx) { mx = sc; pos = k; }
 						}
-						const bool reach = sc + P.end_bonus > mx;
+						// a target at least w + 1 longer than the query makes the band run off the matrix (st > en at row 2*ql + w - 1,
+						// ksw2_extd2_sse.c:135): the reference flags that like a z-drop and ends at the maximum, never at the query end
+						const int wband = (int)(P.bw * 1.5 + 1.);
+						const bool runoff = tl >= ql + wband + 1;
+						const bool reach = !runoff && sc + P.end_bonus > mx;
 						const int ncig = (reach || pos >= 0) ? 1 : 0;
 						ExtOut o; o.max = mx; o.max_q = pos; o.max_t = pos; o.mqe_t = ql - 1;
-						o.flags_ncig = (uint32_t)(reach ? 1 : 0) | (uint32_t)ncig << 8; o.cig_off = 0;
+						o.flags_ncig = (uint32_t)(reach ? 1 : 0) | (uint32_t)(runoff ? 2 : 0) | (uint32_t)ncig << 8; o.cig_off = 0;
 						o.cig[0] = ncig ? (uint32_t)(reach ? ql : pos + 1) << 4 : 0; o.cig[1] = o.cig[2] = o.cig[3] = o.cig[4] = o.cig[5] = 0;
 						E.outs[jb + side] = o;
 						return true;

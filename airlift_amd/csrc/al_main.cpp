@@ -51,7 +51,25 @@ int main(int argc, char **argv)
 		else if (!strcmp(a, "-k") && i + 1 < argc) io.k = atoi(argv[++i]);
 		else if (!strcmp(a, "-w") && i + 1 < argc) io.w = atoi(argv[++i]);
 		else if (!strcmp(a, "-K") && i + 1 < argc) mo.mini_batch_size = (int)atof(argv[++i]);
-		else if (!strcmp(a, "-n") && i + 1 < argc) ++i;                       // bwa aln -n: accepted, no analogue
+		else if (!strcmp(a, "-n") && i + 1 < argc) { if (mode == MODE_ALN) ++i; else mo.min_cnt = atoi(argv[++i]); }   // bwa aln -n X: accepted, no analogue; minimap2 -n: main.c:165
+		// numeric options of the fork's command line (main.c:144-230), same letters and meaning
+		else if (!strcmp(a, "-g") && i + 1 < argc) mo.max_gap = atoi(argv[++i]);
+		else if (!strcmp(a, "-F") && i + 1 < argc) mo.max_frag_len = atoi(argv[++i]);
+		else if (!strcmp(a, "-r") && i + 1 < argc) mo.bw = atoi(argv[++i]);
+		else if (!strcmp(a, "-N") && i + 1 < argc) mo.best_n = atoi(argv[++i]);
+		else if (!strcmp(a, "-p") && i + 1 < argc) mo.pri_ratio = (float)atof(argv[++i]);
+		else if (!strcmp(a, "-M") && i + 1 < argc) mo.mask_level = (float)atof(argv[++i]);
+		else if (!strcmp(a, "-m") && i + 1 < argc) mo.min_chain_score = atoi(argv[++i]);
+		else if (!strcmp(a, "-A") && i + 1 < argc) mo.a = atoi(argv[++i]);
+		else if (!strcmp(a, "-B") && i + 1 < argc) mo.b = atoi(argv[++i]);
+		else if (!strcmp(a, "-s") && i + 1 < argc) mo.min_dp_max = atoi(argv[++i]);
+		else if (!strcmp(a, "-O") && i + 1 < argc) { char *e; mo.q = mo.q2 = (int)strtol(argv[++i], &e, 10); if (*e == ',') mo.q2 = (int)strtol(e + 1, &e, 10); }
+		else if (!strcmp(a, "-E") && i + 1 < argc) { char *e; mo.e = mo.e2 = (int)strtol(argv[++i], &e, 10); if (*e == ',') mo.e2 = (int)strtol(e + 1, &e, 10); }
+		else if (!strcmp(a, "-z") && i + 1 < argc) { char *e; mo.zdrop = mo.zdrop_inv = (int)strtol(argv[++i], &e, 10); if (*e == ',') mo.zdrop_inv = (int)strtol(e + 1, &e, 10); }
+		else if (!strcmp(a, "--end-bonus") && i + 1 < argc) mo.end_bonus = atoi(argv[++i]);
+		else if (!strcmp(a, "--max-chain-skip") && i + 1 < argc) mo.max_chain_skip = atoi(argv[++i]);
+		else if (!strcmp(a, "--score-N") && i + 1 < argc) mo.sc_ambi = atoi(argv[++i]);
+		else if (!strcmp(a, "--seed") && i + 1 < argc) mo.seed = atoi(argv[++i]);
 		else if (!strcmp(a, "--sam-hit-only")) mo.flag |= AL_F_SAM_HIT_ONLY;
 		else if (!strcmp(a, "--count-candidates")) count_only = true;
 		else if (!strcmp(a, "--bam")) bam_mode = 1;

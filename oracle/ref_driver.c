@@ -34,6 +34,27 @@ int main(int argc, char **argv)
 		else if (!strcmp(argv[i], "--alnseq")) mm_dbg_flag |= MM_DBG_PRINT_ALN_SEQ;
 		else if (!strcmp(argv[i], "--qname")) mm_dbg_flag |= MM_DBG_PRINT_QNAME;
 		else if (!strcmp(argv[i], "--hit-only")) mo.flag |= MM_F_SAM_HIT_ONLY;
+		/* numeric options with the letters and meaning of main.c:144-215 (parity tests at non-default settings) */
+		else if (!strcmp(argv[i], "-k") && i + 1 < argc) io.k = atoi(argv[++i]);
+		else if (!strcmp(argv[i], "-w") && i + 1 < argc) io.w = atoi(argv[++i]);
+		else if (!strcmp(argv[i], "-g") && i + 1 < argc) mo.max_gap = atoi(argv[++i]);
+		else if (!strcmp(argv[i], "-F") && i + 1 < argc) mo.max_frag_len = atoi(argv[++i]);
+		else if (!strcmp(argv[i], "-r") && i + 1 < argc) mo.bw = atoi(argv[++i]);
+		else if (!strcmp(argv[i], "-N") && i + 1 < argc) mo.best_n = atoi(argv[++i]);
+		else if (!strcmp(argv[i], "-p") && i + 1 < argc) mo.pri_ratio = atof(argv[++i]);
+		else if (!strcmp(argv[i], "-M") && i + 1 < argc) mo.mask_level = atof(argv[++i]);
+		else if (!strcmp(argv[i], "-n") && i + 1 < argc) mo.min_cnt = atoi(argv[++i]);
+		else if (!strcmp(argv[i], "-m") && i + 1 < argc) mo.min_chain_score = atoi(argv[++i]);
+		else if (!strcmp(argv[i], "-A") && i + 1 < argc) mo.a = atoi(argv[++i]);
+		else if (!strcmp(argv[i], "-B") && i + 1 < argc) mo.b = atoi(argv[++i]);
+		else if (!strcmp(argv[i], "-s") && i + 1 < argc) mo.min_dp_max = atoi(argv[++i]);
+		else if (!strcmp(argv[i], "-O") && i + 1 < argc) { char *e; mo.q = mo.q2 = strtol(argv[++i], &e, 10); if (*e == ',') mo.q2 = strtol(e + 1, &e, 10); }   /* main.c:226-230 */
+		else if (!strcmp(argv[i], "-E") && i + 1 < argc) { char *e; mo.e = mo.e2 = strtol(argv[++i], &e, 10); if (*e == ',') mo.e2 = strtol(e + 1, &e, 10); }
+		else if (!strcmp(argv[i], "-z") && i + 1 < argc) { char *e; mo.zdrop = mo.zdrop_inv = strtol(argv[++i], &e, 10); if (*e == ',') mo.zdrop_inv = strtol(e + 1, &e, 10); }
+		else if (!strcmp(argv[i], "--end-bonus") && i + 1 < argc) mo.end_bonus = atoi(argv[++i]);
+		else if (!strcmp(argv[i], "--max-chain-skip") && i + 1 < argc) mo.max_chain_skip = atoi(argv[++i]);
+		else if (!strcmp(argv[i], "--score-N") && i + 1 < argc) mo.sc_ambi = atoi(argv[++i]);
+		else if (!strcmp(argv[i], "--seed") && i + 1 < argc) mo.seed = atoi(argv[++i]);
 		else if (nfn < 4) fn[nfn++] = argv[i];
 	}
 	if (nfn < 2) { fprintf(stderr, "usage: mm2ref [opts] ref.fa r1.fq [r2.fq]\n"); return 2; }

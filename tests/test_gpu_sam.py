@@ -232,3 +232,28 @@ def test_bam_outputs_match_sam(golden_unpacked, name):
     order = sorted(range(len(keep)), key=lambda i: (keep[i]["rid"], keep[i]["pos"]))     # stable, like the device radix sort
     for b, i in zip(recs2, order):
         _same_record(b, keep[i])
+
+
+# ---- non-default options: the drop-in against the reference build itself (oracle/_ref/mm2ref travels with the snapshot) ------
+OPTSETS = [
+    ["-g", "300", "-F", "1200", "-r", "50"],
+    ["-A", "1", "-B", "4", "-O", "6,26", "-E", "2,1"],
+    ["-n", "3", "-m", "40", "-s", "60", "-N", "5", "-p", "0.8"],
+    ["-z", "40,20", "--end-bonus", "5", "--max-chain-skip", "3"],
+    ["-k", "19", "-w", "9"],
+    ["-A", "4", "-B", "4", "-O", "4,24", "-E", "2,1"],      # a + b >= q + e: the closed-form flanks switch themselves off
+    ["--score-N", "3", "--seed", "7", "-M", "0.3"],
+]
+
+
+@pytest.mark.parametrize("name", ["g1_mt150pe", "g3_adversarial", "g6_repeats"])
+def test_non_default_options_match_reference(golden_unpacked, name):
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "mm2ref")
+    if not os.path.exists(ref_bin):
+        pytest.skip("reference build oracle/_ref/mm2ref not present")
+    d = golden_unpacked[name]
+    m = json.load(open(os.path.join(d, "meta.json")))
+    for opts in OPTSETS:
+        exp = _run([ref_bin] + opts + [m["ref"]] + m["reads"], d).stdout
+        got = _run([CLI, "-ax", "sr"] + opts + [m["ref"]] + m["reads"], d).stdout
+        assert got == exp, " ".join(opts) + "\n" + _diff_report(got, exp, name + "_opts")
