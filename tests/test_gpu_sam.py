@@ -257,3 +257,22 @@ def test_non_default_options_match_reference(golden_unpacked, name):
         exp = _run([ref_bin] + opts + [m["ref"]] + m["reads"], d).stdout
         got = _run([CLI, "-ax", "sr"] + opts + [m["ref"]] + m["reads"], d).stdout
         assert got == exp, " ".join(opts) + "\n" + _diff_report(got, exp, name + "_opts")
+
+
+def test_250bp_pairs_match_reference(tmp_path):
+    """BASELINE config 5 shape (250 bp PE, insert N(550,60)): long flanks, where a banded extension can run off the matrix
+    (target >= query + w + 1) -- compared with the reference build on freshly simulated reads."""
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "mm2ref")
+    if not os.path.exists(ref_bin):
+        pytest.skip("reference build oracle/_ref/mm2ref not present")
+    import gen_synth as g
+    ref = g.make_reference(seed=11, n_contigs=4, total_len=2_000_000, n_dups=40)
+    g.write_fasta(str(tmp_path / "ref.fa"), ref)
+    r1, r2 = g.simulate_pairs(ref, 30000, 250, seed=3, ins_mean=550, ins_sd=60, ins_hi=1000, sub_rate=0.004)
+    g.write_fastq(str(tmp_path / "r_1.fq"), r1, "realigned_"); g.write_fastq(str(tmp_path / "r_2.fq"), r2, "realigned_")
+    exp = _run([ref_bin, "-t", "8", "ref.fa", "r_1.fq", "r_2.fq"], tmp_path).stdout
+    got = _run([CLI, "-ax", "sr", "ref.fa", "r_1.fq", "r_2.fq"], tmp_path).stdout
+    assert got == exp, _diff_report(got, exp, "pe250")
+    # and with the closed-form flanks disabled the same bytes come out of the DP kernels
+    got2 = _run([CLI, "-ax", "sr", "ref.fa", "r_1.fq", "r_2.fq"], tmp_path, env=dict(os.environ, AL_DBG=str(1 << 31))).stdout
+    assert got2 == exp
