@@ -1178,7 +1178,10 @@ k_ext_prep(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_
 				// (checked against the reference DP in tests/test_diag_shortcut.py; jobs done this way carry pad0 = 1).
 				// (the argument needs one mismatch to cost less than any gap: a + b < min(q + e, q2 + e2); true for the short-read
 				// scores 2/8/12,2/24,1 -- with other scores every flank takes the DP kernels)
-				const bool diag_ok = P.a > 0 && P.b > 0 && P.a + P.b < (P.q + P.e < P.q2 + P.e2 ? P.q + P.e : P.q2 + P.e2);
+				// and the z-drop test (ksw2.h:160-176) must be unable to fire: along and after the diagonal the row maximum stays
+				// within b + max(q + e, q2 + e2) (+ e2 per unit of diagonal offset, which the test allows for) of the running maximum
+				const int ge1 = P.q + P.e, ge2 = P.q2 + P.e2;
+				const bool diag_ok = P.a > 0 && P.b > 0 && P.a + P.b < (ge1 < ge2 ? ge1 : ge2) && (P.zdrop < 0 || P.zdrop >= P.b + (ge1 > ge2 ? ge1 : ge2));
 				if (!((P.dbg >> 31) & 1) && diag_ok && r->cnt > 0) {
 					const int32_t rid2 = r->rid, rev2 = (r->flags & ALR_REV) ? 1 : 0;
 					const uint64_t ref_off2 = G.seq_off[rid2];
@@ -1835,7 +1838,7 @@ int al_run_align_stage(al_ctx_t *c)
 	AlLogTab lt; lt.t = A->logtab.p; lt.miss = c->counters.p + 8;
 	const int tmax = (Lmax <= 160 && tbound <= 336) ? 336 : (Lmax <= 256 && tbound <= 512) ? 512 : (Lmax <= 512 && tbound <= 1024) ? 1024 : 0;
 	const int qmax = tmax == 336 ? 160 : tmax == 512 ? 256 : 512;
-	if (tmax == 0) { fprintf(stderr, "[airlift] reads longer than 512 bp are not supported by the device extension kernel (max read length in batch: %d)\n", Lmax); return -3; }
+	if (tmax == 0) { fprintf(stderr, "[airlift] reads longer than 512 bp (or an extension window longer than 1024 bp: read length + (read length * A + end bonus - O) / E + 16) are not supported by the device extension kernels (max read length in batch: %d, window %d)\n", Lmax, tbound); return -3; }
 	auto launch_mono = [&](const uint32_t *list, int n_list) -> int {      // monolithic kernel (whole batch, or the slow-path list)
 		int nbm = (n_list + AL_GPB - 1) / AL_GPB; if (nbm > nb) nbm = nb; if (nbm < 1) nbm = 1;
 		if (tmax == 336) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_align<336, 160>), dim3(nbm), dim3(GW * AL_GPB), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, c->frag_first.p, c->frag_rep.p, W, G, lt, A->gws.p, stride, p_bytes, cig_words, nf, c->P, list, n_list);

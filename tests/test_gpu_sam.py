@@ -4,6 +4,7 @@ import hashlib
 import json
 import os
 import subprocess
+import sys
 
 import pytest
 
@@ -276,3 +277,13 @@ def test_250bp_pairs_match_reference(tmp_path):
     # and with the closed-form flanks disabled the same bytes come out of the DP kernels
     got2 = _run([CLI, "-ax", "sr", "ref.fa", "r_1.fq", "r_2.fq"], tmp_path, env=dict(os.environ, AL_DBG=str(1 << 31))).stdout
     assert got2 == exp
+
+
+def test_randomised_parity_sweep_against_reference():
+    """tools/fuzz_parity.py: assorted read lengths (30-500 bp), single/paired, error / indel / N rates, repeats, insert sizes and
+    option sets (band, z-drop around the closed-form guard, scores, thresholds) against the reference build."""
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "mm2ref")
+    if not os.path.exists(ref_bin):
+        pytest.skip("reference build oracle/_ref/mm2ref not present")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "45", "20261002"], capture_output=True)
+    assert r.returncode == 0, r.stdout.decode()[-3000:]
