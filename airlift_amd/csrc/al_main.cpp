@@ -4,6 +4,7 @@
 //   B1/B2  airlift-align mem [-R RG] [-t N] REF.fa R_1.fastq [R_2.fastq]        (src/0-align_reads.sh:13, 0-align_singletons.sh:12)
 //   B3     airlift-align aln [-n X] [-t N] REF.fa GAPS.fa > X.sai               (src/3-align_gaps/align_gaps.sh:14; writes a stub .sai)
 //          airlift-align samse REF.fa X.sai GAPS.fa                              (align_gaps.sh:15; does the actual single-end mapping)
+//          airlift-align index REF.fa                                             (accepted, no-op: the index is built on the GPU per run)
 //   mm2    airlift-align -ax sr [-t N] [-R RG] [-K NUM] [--sam-hit-only] REF.fa R1 [R2]   (fork README usage; main.c:113-273)
 //   N3     airlift-align ... --bam | --sorted-bam [-l LEVEL]       BAM on stdout; sorted = mapped records in coordinate order,
 //                                                                   i.e. the result of `| samtools view -h -F4 | samtools sort -l5`
@@ -40,6 +41,7 @@ int main(int argc, char **argv)
 	if (!strcmp(argv[1], "mem")) mode = MODE_MEM, i = 2;
 	else if (!strcmp(argv[1], "aln")) mode = MODE_ALN, i = 2;
 	else if (!strcmp(argv[1], "samse")) mode = MODE_SAMSE, i = 2;
+	else if (!strcmp(argv[1], "index")) return 0;        // `bwa index REF`: nothing to precompute, the minimizer index is built on the GPU at start-up
 	for (; i < argc; ++i) {
 		const char *a = argv[i];
 		if (a[0] != '-' || !strcmp(a, "-")) { pos.push_back(a); continue; }
@@ -76,6 +78,7 @@ int main(int argc, char **argv)
 		else if (!strcmp(a, "--sorted-bam")) bam_mode = 2;
 		else if (!strcmp(a, "-l") && i + 1 < argc) bam_level = atoi(argv[++i]);
 		else if (!strcmp(a, "--device") && i + 1 < argc) device = atoi(argv[++i]);
+		else if (!strcmp(a, "-o") && i + 1 < argc) { const char *fn = argv[++i]; if (strcmp(fn, "-") != 0 && !freopen(fn, "wb", stdout)) { fprintf(stderr, "[ERROR] failed to write the output to file '%s'\n", fn); return 1; } }   // main.c:183-190
 		else if (!strcmp(a, "--version")) { puts(al_version()); return 0; }
 		else { fprintf(stderr, "[WARNING] airlift-align: option '%s' ignored\n", a); }
 	}

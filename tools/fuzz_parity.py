@@ -22,13 +22,13 @@ for case in range(n_cases):
     d = tempfile.mkdtemp(prefix="al_fuzz_")
     rl = int(rng.choice([30, 50, 76, 100, 125, 150, 151, 200, 250, 300, 400, 500]))
     se = bool(rng.random() < 0.3)
-    n_ctg = int(rng.integers(1, 6)); tot = int(rng.integers(60_000, 600_000))
+    n_ctg = int(rng.integers(1, 6)); tot = int(rng.integers(60_000, 600_000)) * int(os.environ.get('FUZZ_REFSCALE', '1'))
     ref = g.make_reference(seed=int(rng.integers(1 << 30)), n_contigs=n_ctg, total_len=tot, n_dups=int(rng.integers(0, 60)), dup_len=(200, 3000),
                            dup_div=float(rng.choice([0.0, 0.01, 0.05])), n_frac=float(rng.choice([0, 0, 0.01])), tandem=int(rng.integers(0, 8)))
     if min(len(c) for _, c in ref) < 2 * rl + 1100:
         continue
     ins = int(rng.choice([rl + 5, int(1.3 * rl), 2 * rl + 100, 3 * rl]))
-    n = int(rng.integers(500, 4000))
+    n = int(rng.integers(500, 4000)) * int(os.environ.get('FUZZ_SCALE', '1'))
     r1, r2 = g.simulate_pairs(ref, n, rl, seed=int(rng.integers(1 << 30)), ins_mean=ins, ins_sd=max(1, ins // 10), ins_lo=rl, ins_hi=max(1000, 4 * rl),
                               sub_rate=float(rng.choice([0, 0.002, 0.01, 0.03])), del_frac=float(rng.choice([0, 0.05, 0.3])), del_len=int(rng.integers(1, 12)),
                               ins_frac=float(rng.choice([0, 0.05, 0.3])), n_rate=float(rng.choice([0, 0, 0.002])), single_end=se)
