@@ -98,13 +98,13 @@ int al_sf_read(AlSeqFile *f, std::string &name, std::string &seq, std::string &q
 {
 	int c;
 	name.clear(); seq.clear(); qual.clear();
-	if (f->last == 0) { while ((c = sf_getc(f)) >= 0 && c != '>' && c != '@'); if (c < 0) return -1; f->last = c; }
+	if (f->last == 0) { while ((c = sf_getc(f)) >= 0 && c != '>' && c != '@') {} if (c < 0) return -1; f->last = c; }
 	while ((c = sf_getc(f)) >= 0 && c != ' ' && c != '\t' && c != '\n' && c != '\r') name.push_back((char)c);
 	while (c >= 0 && c != '\n') c = sf_getc(f);
 	while ((c = sf_getc(f)) >= 0 && c != '>' && c != '+' && c != '@') if (c > 32) seq.push_back((char)c);
 	f->last = (c == '>' || c == '@')? c : 0;
 	if (c != '+') return (int)seq.size();
-	while ((c = sf_getc(f)) >= 0 && c != '\n');
+	while ((c = sf_getc(f)) >= 0 && c != '\n') {}
 	while (qual.size() < seq.size() && (c = sf_getc(f)) >= 0) if (c > 32) qual.push_back((char)c);
 	f->last = 0;
 	return (int)seq.size();

@@ -47,7 +47,7 @@ public:
 	bool read(AlChunk &c)
 	{
 		int ch;
-		if (last == 0) { while ((ch = getc()) >= 0 && ch != '>' && ch != '@'); if (ch < 0) return false; last = ch; }
+		if (last == 0) { while ((ch = getc()) >= 0 && ch != '>' && ch != '@') {} if (ch < 0) return false; last = ch; }
 		std::vector<char> &t = c.text; const size_t mark = t.size();
 		AlRec r; r.name = (uint32_t)t.size();
 		while ((ch = getc()) >= 0 && ch != ' ' && ch != '\t' && ch != '\n' && ch != '\r' && ch != '\v' && ch != '\f') t.push_back((char)ch);
@@ -63,7 +63,7 @@ public:
 		for (size_t i = r.seq; i < t.size(); ++i) if (t[i] == 'u' || t[i] == 'U') --t[i];      // bseq.c:72-74
 		last = (ch == '>' || ch == '@') ? ch : 0;
 		if (ch == '+') {
-			while ((ch = getc()) >= 0 && ch != '\n');
+			while ((ch = getc()) >= 0 && ch != '\n') {}
 			if (ch < 0) { t.resize(mark); return false; }
 			r.qual = (uint32_t)t.size();
 			while (line_append(t) >= 0 && t.size() - r.qual < r.len);
