@@ -100,6 +100,10 @@ def load():
     L.al_map_frag.argtypes = [vp, ci, C.POINTER(ci), C.POINTER(cs), C.POINTER(ci), C.POINTER(C.POINTER(Reg)), vp, C.POINTER(MapOpt), cs]; L.al_map_frag.restype = None
     L.al_map_file_frag.argtypes = [vp, ci, C.POINTER(cs), C.POINTER(MapOpt), ci, vp, cs, ci]; L.al_map_file_frag.restype = ci
     L.al_map_file_frag_bam.argtypes = [vp, ci, C.POINTER(cs), C.POINTER(MapOpt), ci, vp, cs, ci, ci, ci]; L.al_map_file_frag_bam.restype = ci
+    L.al_map_tokens_file.argtypes = [vp, cs, ci, ci, C.POINTER(MapOpt), ci, vp, cs, ci]; L.al_map_tokens_file.restype = ci
+    L.al_winsrc_create.argtypes = [vp, cs, C.c_uint64]; L.al_winsrc_create.restype = vp
+    L.al_winsrc_destroy.argtypes = [vp]; L.al_winsrc_destroy.restype = None
+    L.al_batch_upload_windows.argtypes = [vp, vp, ci, C.POINTER(C.c_uint64), ci, C.POINTER(cs)]; L.al_batch_upload_windows.restype = ci
     L.al_batch_stat.argtypes = [vp, C.POINTER(BatchStat)]; L.al_batch_stat.restype = None
     L.al_stage_name.argtypes = [ci]; L.al_stage_name.restype = cs
     L.al_stage_kernel.argtypes = [ci]; L.al_stage_kernel.restype = cs

@@ -8,6 +8,7 @@
 //   mm2    airlift-align -ax sr [-t N] [-R RG] [-K NUM] [--sam-hit-only] REF.fa R1 [R2]   (fork README usage; main.c:113-273)
 //   N3     airlift-align ... --bam | --sorted-bam [-l LEVEL]       BAM on stdout; sorted = mapped records in coordinate order,
 //                                                                   i.e. the result of `| samtools view -h -F4 | samtools sort -l5`
+//   N2     airlift-align tokens --read-size R --skip S [-t N] REF.fa GAPS.fa      gaps_to_fasta.py GAPS.fa R tokens.fa S ; samse REF x tokens.fa
 //   a8     airlift-align -ax sr --count-candidates REF.fa READS     the as-shipped fork's observable: seed-cluster count on stderr
 // SAM goes to stdout; exit status 0 on success, non-zero on failure (so the caller's pipe fails).
 #include <stdio.h>
@@ -32,7 +33,7 @@ int main(int argc, char **argv)
 	al_idxopt_t io; al_mapopt_t mo;
 	struct timespec tsm; clock_gettime(CLOCK_MONOTONIC, &tsm);
 	std::vector<const char *> pos; const char *rg = nullptr; int n_threads = 3, device = -1; bool count_only = false; int bam_mode = 0, bam_level = 5;
-	enum { MODE_MEM, MODE_ALN, MODE_SAMSE, MODE_MM2 } mode = MODE_MM2;
+	enum { MODE_MEM, MODE_ALN, MODE_SAMSE, MODE_MM2, MODE_TOKENS } mode = MODE_MM2; int tok_size = 0, tok_skip = 1;
 	int i = 1;
 	if (argc < 2) return usage();
 	al_set_opt(0, &io, &mo);
@@ -41,6 +42,7 @@ int main(int argc, char **argv)
 	if (!strcmp(argv[1], "mem")) mode = MODE_MEM, i = 2;
 	else if (!strcmp(argv[1], "aln")) mode = MODE_ALN, i = 2;
 	else if (!strcmp(argv[1], "samse")) mode = MODE_SAMSE, i = 2;
+	else if (!strcmp(argv[1], "tokens")) mode = MODE_TOKENS, i = 2;
 	else if (!strcmp(argv[1], "index")) return 0;        // `bwa index REF`: nothing to precompute, the minimizer index is built on the GPU at start-up
 	for (; i < argc; ++i) {
 		const char *a = argv[i];
@@ -74,6 +76,8 @@ int main(int argc, char **argv)
 		else if (!strcmp(a, "--seed") && i + 1 < argc) mo.seed = atoi(argv[++i]);
 		else if (!strcmp(a, "--sam-hit-only")) mo.flag |= AL_F_SAM_HIT_ONLY;
 		else if (!strcmp(a, "--count-candidates")) count_only = true;
+		else if (!strcmp(a, "--read-size") && i + 1 < argc) tok_size = atoi(argv[++i]);
+		else if (!strcmp(a, "--skip") && i + 1 < argc) tok_skip = atoi(argv[++i]);
 		else if (!strcmp(a, "--bam")) bam_mode = 1;
 		else if (!strcmp(a, "--sorted-bam")) bam_mode = 2;
 		else if (!strcmp(a, "-l") && i + 1 < argc) bam_level = atoi(argv[++i]);
@@ -100,6 +104,13 @@ int main(int argc, char **argv)
 	clock_gettime(CLOCK_MONOTONIC, &ts1);
 	if (getenv("AL_TIMING")) fprintf(stderr, "[airlift] index build %.3f s\n", (ts1.tv_sec - ts0.tv_sec) + 1e-9 * (ts1.tv_nsec - ts0.tv_nsec));
 	if (!mi) { fprintf(stderr, "[ERROR] failed to open file '%s'\n", ref); return 1; }
+	if (mode == MODE_TOKENS) {   // gaps_to_fasta.py + single-end alignment of the tokens in one step (tokens are cut on the GPU)
+		const int rc2 = al_map_tokens_file(mi, reads[0], tok_size, tok_skip, &mo, n_threads, stdout, rg, device);
+		al_idx_destroy(mi);
+		if (fflush(stdout) == EOF) return 1;
+		fflush(stderr);
+		_exit(rc2 == 0 ? 0 : 1);
+	}
 	if (count_only) {   // what the as-shipped fork prints instead of alignments (main.c:384-391, 417)
 		int64_t total = 0;
 		const int rc2 = al_count_candidates_file(mi, reads[0], &mo, n_threads, device, &total);

@@ -48,7 +48,7 @@ struct al_ctx_s {
 	std::vector<uint8_t> h_flip;          // read was reverse-complemented for mapping (worker_for, map.c:468)
 
 	DevBuf<uint32_t> rd_seq, rd_len, frag_first, frag_hash, mini_cnt, frag_nm, frag_na, frag_nu, rechain_list, tmp_u32;
-	DevBuf<uint64_t> rd_off, mini_off, a_off, u, ws_u64, tmp_u64;
+	DevBuf<uint64_t> rd_off, mini_off, a_off, u, ws_u64, tmp_u64, tmp_u64b;
 	DevBuf<int32_t> frag_rep, ws_i32;
 	DevBuf<AlAnchor> mini, heap_ws, anchors, chained;
 	DevBuf<AlMatch> match;

@@ -111,7 +111,7 @@ extern "C" void al_ctx_destroy(al_ctx_t *c)
 	c->frag_nu.release(); c->rechain_list.release(); c->tmp_u32.release(); c->rd_off.release(); c->mini_off.release(); c->a_off.release(); c->u.release();
 	c->ws_u64.release(); c->tmp_u64.release(); c->frag_rep.release(); c->ws_i32.release(); c->mini.release(); c->heap_ws.release(); c->anchors.release();
 	c->chained.release(); c->match.release(); c->counters.release(); c->scan_tmp.release(); c->regs0.release(); c->regs.release(); c->reg_cnt.release();
-	c->chain_key.release(); c->chain_idx.release(); c->chain_idx2.release(); c->tie_list.release(); c->lb_buf.release();
+	c->chain_key.release(); c->chain_idx.release(); c->chain_idx2.release(); c->tie_list.release(); c->lb_buf.release(); c->tmp_u64b.release();
 	c->a_off_p1.release(); c->frag_na_p1.release(); c->frag_rep_p1.release(); c->cigar.release(); c->reg_off.release(); c->cig_off.release(); c->align_ws.release(); c->seg_a.release(); c->seg_u.release();
 	for (int i = 0; i <= ST_N; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
 	if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -551,4 +551,81 @@ int al_sort_keys(al_ctx_t *c, const uint64_t *keys, uint32_t *perm, size_t n)
 	(void)hipFree(d_k); (void)hipFree(d_k2); (void)hipFree(d_v); (void)hipFree(d_v2); (void)hipFree(tmp);
 	if (rc) fprintf(stderr, "[airlift] al_sort_keys: device sort failed\n");
 	return rc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Token batches: the reads of a batch are fixed-length windows of longer source sequences (AirLift tiles the
+// updated regions into read-sized tokens, gaps_to_fasta.py:31-36, then aligns them single-end, align_gaps.sh:14-15).  The
+// source stays packed in HBM (4 bit/base); a kernel cuts the windows, so the host neither writes nor parses the
+// read_size/skip-fold larger token FASTA.
+struct Nt4Tab { uint8_t t[256]; };
+__global__ void k_pack_ref(const uint8_t *, uint64_t, uint32_t *, uint64_t, Nt4Tab);       // al_index_dev.hip
+struct al_winsrc_s { uint32_t *S4 = nullptr; uint64_t n_bases = 0; int device = 0; };
+
+extern "C" al_winsrc_t *al_winsrc_create(al_ctx_t *c, const char *ascii, uint64_t n_bases)
+{
+	if (!c) return nullptr;
+	if (hipSetDevice(c->device) != hipSuccess) return nullptr;
+	al_winsrc_t *w = new al_winsrc_t(); w->n_bases = n_bases; w->device = c->device;
+	const uint64_t n_words = (n_bases + 7) / 8 + 8;
+	uint8_t *d_ascii = nullptr;
+	Nt4Tab T; memcpy(T.t, al_nt4(), 256);
+	if (hipMalloc((void **)&w->S4, n_words * 4) != hipSuccess || hipMalloc((void **)&d_ascii, n_bases + 16) != hipSuccess ||
+	    hipMemcpyAsync(d_ascii, ascii, n_bases, hipMemcpyHostToDevice, c->stream) != hipSuccess) { (void)hipFree(w->S4); (void)hipFree(d_ascii); delete w; return nullptr; }
+	hipLaunchKernelGGL(k_pack_ref, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, c->stream, d_ascii, n_bases, w->S4, n_words, T);
+	(void)hipStreamSynchronize(c->stream);
+	(void)hipFree(d_ascii);
+	return w;
+}
+extern "C" void al_winsrc_destroy(al_winsrc_t *w) { if (!w) return; (void)hipSetDevice(w->device); (void)hipFree(w->S4); delete w; }
+
+__global__ void __launch_bounds__(256)
+k_make_windows(const uint32_t *__restrict__ S4, const uint64_t *__restrict__ start, int n_tok, int len, int wpr, uint32_t *__restrict__ rd_seq)
+{   // thread per (window, output word): eight bases from bit offset 4 * (start & 7) of two source words; bases past the window are zero
+	const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (g >= (uint64_t)n_tok * wpr) return;
+	const int j = (int)(g / wpr), w = (int)(g % wpr);
+	uint32_t v = 0;
+	if (8 * w < len) {
+		const uint64_t src = start[j] + 8ULL * w; const int sh = (int)(src & 7) << 2;
+		v = (uint32_t)((((uint64_t)S4[(src >> 3) + 1] << 32) | S4[src >> 3]) >> sh);
+		const int left = len - 8 * w;
+		if (left < 8) v &= (1u << (4 * left)) - 1u;
+	}
+	rd_seq[(uint64_t)j * wpr + w] = v;
+}
+
+extern "C" int al_batch_upload_windows(al_ctx_t *c, const al_winsrc_t *src, int n_tok, const uint64_t *start, int read_len, const char *const *qnames)
+{
+	if (!c || !src || n_tok < 0 || read_len <= 0 || src->device != c->device) return -1;
+	AL_HIP_CHECK(hipSetDevice(c->device));
+	const int k = c->mi->k, wpr = (read_len + 7) / 8 + 1;
+	c->n_frag = n_tok; c->n_reads = n_tok; c->ran = false;
+	c->h_rd_len.assign(n_tok + 1, (uint32_t)read_len); c->h_rd_len[n_tok] = 0;
+	c->h_rd_off.resize(n_tok + 1); c->h_mini_off.resize(n_tok + 1); c->h_flip.assign(n_tok, 0);
+	c->h_frag_first.resize(n_tok + 1); c->h_frag_hash.resize(n_tok + 1);
+	const uint64_t mper = (uint64_t)(read_len >= k ? read_len - k + 1 : 0) + 1;
+	for (int i = 0; i <= n_tok; ++i) { c->h_rd_off[i] = (uint64_t)i * wpr; c->h_mini_off[i] = (uint64_t)i * mper; c->h_frag_first[i] = (uint32_t)i; }
+	al_parallel_for(c->n_threads, (size_t)n_tok, [&](size_t lo, size_t hi, int) {
+		for (size_t i = lo; i < hi; ++i) c->h_frag_hash[i] = qname_hash(qnames ? qnames[i] : nullptr, read_len, c->opt.seed);
+	});
+	for (int i = 0; i < n_tok; ++i) if (start[i] + (uint64_t)read_len > src->n_bases) { fprintf(stderr, "[airlift] al_batch_upload_windows: window %d leaves the source\n", i); return -2; }
+	const uint64_t words = (uint64_t)n_tok * wpr, mtot = (uint64_t)n_tok * mper, bases = (uint64_t)n_tok * read_len;
+	c->n_bases = bases; c->mini_total = mtot; c->seq_words = words;
+	c->stat_bytes_in = (uint64_t)n_tok * (((uint64_t)read_len * 3 + 7) / 8);
+	hipStream_t s = c->stream; const int n_frag = n_tok, n_reads = n_tok;
+	if (c->rd_seq.ensure(words + 1) || c->rd_off.ensure(n_reads + 1) || c->rd_len.ensure(n_reads + 1) || c->frag_first.ensure(n_frag + 1) || c->frag_hash.ensure(n_frag + 1) ||
+	    c->mini_off.ensure(n_reads + 1) || c->mini.ensure(mtot + 1) || c->mini_cnt.ensure(n_reads + 1) || c->match.ensure(mtot + 1) || c->heap_ws.ensure(mtot + 1) ||
+	    c->frag_nm.ensure(n_frag + 1) || c->frag_na.ensure(n_frag + 1) || c->frag_rep.ensure(n_frag + 1) || c->frag_nu.ensure(n_frag + 1) || c->a_off.ensure(n_frag + 2) ||
+	    c->rechain_list.ensure(n_frag + 1) || c->tmp_u32.ensure(n_frag + 2) || c->tmp_u64.ensure(n_frag + 2) || c->counters.ensure(16) || c->tmp_u64b.ensure(n_tok + 1)) return -1;
+	AL_HIP_CHECK(hipMemcpyAsync(c->tmp_u64b.p, start, (size_t)n_tok * 8, hipMemcpyHostToDevice, s));
+	if (words) hipLaunchKernelGGL(k_make_windows, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s, src->S4, c->tmp_u64b.p, n_tok, read_len, wpr, c->rd_seq.p);
+	AL_HIP_CHECK(hipMemsetAsync(c->rd_seq.p + words, 0, 4, s));
+	AL_HIP_CHECK(hipMemcpyAsync(c->rd_off.p, c->h_rd_off.data(), (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, s));
+	AL_HIP_CHECK(hipMemcpyAsync(c->rd_len.p, c->h_rd_len.data(), (size_t)(n_reads + 1) * 4, hipMemcpyHostToDevice, s));
+	AL_HIP_CHECK(hipMemcpyAsync(c->frag_first.p, c->h_frag_first.data(), (size_t)(n_frag + 1) * 4, hipMemcpyHostToDevice, s));
+	AL_HIP_CHECK(hipMemcpyAsync(c->frag_hash.p, c->h_frag_hash.data(), (size_t)(n_frag + 1) * 4, hipMemcpyHostToDevice, s));
+	AL_HIP_CHECK(hipMemcpyAsync(c->mini_off.p, c->h_mini_off.data(), (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, s));
+	AL_HIP_CHECK(hipStreamSynchronize(s));
+	return 0;
 }

@@ -151,6 +151,18 @@ int  al_batch_run(al_ctx_t *ctx);
 /* Fetch results of the last al_batch_run into host reg arrays (same contract as al_map_batch). */
 int  al_batch_fetch(al_ctx_t *ctx, int *n_regs, al_reg1_t **regs, int *rep_len);
 
+/* ---- token batches: reads that are fixed-length windows of longer sequences, cut on the device ---- */
+typedef struct al_winsrc_s al_winsrc_t;     /* source sequences, concatenated, packed 4 bit/base in the context's GPU memory */
+al_winsrc_t *al_winsrc_create(al_ctx_t *ctx, const char *ascii, uint64_t n_bases);
+void         al_winsrc_destroy(al_winsrc_t *src);
+/* n_tok single-segment reads of read_len bases; read i = source bases [start[i], start[i] + read_len); qnames as in
+ * al_batch_upload.  Then al_batch_run / al_batch_fetch as usual. */
+int  al_batch_upload_windows(al_ctx_t *ctx, const al_winsrc_t *src, int n_tok, const uint64_t *start, int read_len, const char *const *qnames);
+/* Whole stage: what AirLift does with gaps_to_fasta.py (tile every sequence of `gaps_fn` into read_size-base tokens every `skip`
+ * bases, named <sequence>_<start>) followed by the single-end alignment of the tokens (align_gaps.sh:14-15); SAM on `out`. */
+int  al_map_tokens_file(const al_idx_t *mi, const char *gaps_fn, int read_size, int skip, const al_mapopt_t *opt, int n_threads,
+                        FILE *out, const char *rg, int device);
+
 /* per-batch work counters + per-kernel HIP-event times of the last al_batch_run */
 typedef struct {
 	uint64_t n_frag, n_reads, n_bases;

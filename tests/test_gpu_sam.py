@@ -287,3 +287,16 @@ def test_randomised_parity_sweep_against_reference():
         pytest.skip("reference build oracle/_ref/mm2ref not present")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "45", "20261002"], capture_output=True)
     assert r.returncode == 0, r.stdout.decode()[-3000:]
+
+
+def test_token_stage_matches_reference_script_and_aligner(golden_unpacked):
+    """`airlift-align tokens` = the reference's gaps_to_fasta.py (tiling into read-sized tokens) + single-end
+    alignment of the tokens; golden SAM made by that script and the reference build (tests/golden/make_g7_tokens.py).
+    The tokens are cut on the GPU from the packed gap sequences."""
+    d = golden_unpacked["g7_tokens"]
+    m = json.load(open(os.path.join(d, "meta.json")))
+    exp = open(os.path.join(d, "expected.sam"), "rb").read()
+    assert hashlib.md5(exp).hexdigest() == m["sam_md5"]
+    for extra in ([], ["-K", "3000", "-t", "5"]):
+        r = _run([CLI, "tokens", "--read-size", str(m["read_size"]), "--skip", str(m["skip"])] + extra + [m["ref"], m["gaps"]], d)
+        assert r.stdout == exp, _diff_report(r.stdout, exp, "g7_tokens")
