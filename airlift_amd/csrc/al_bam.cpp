@@ -110,6 +110,7 @@ int al_write_bam_rec(std::vector<char> &out, const al_idx_t *mi, const char *qna
 	int64_t ref_end = this_pos + 1;
 	if (r && r->n_cigar) { int64_t e = this_pos; for (uint32_t c : cig) { const uint32_t op = c & 0xf; if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) e += c >> 4; } ref_end = e > this_pos ? e : this_pos + 1; }
 	const int nl = n_seg > 1 ? qname_len(qname) : (int)strlen(qname);
+	if (nl > 254) { fprintf(stderr, "[ERROR] airlift: read name longer than 254 characters cannot be stored in BAM: %.40s...\n", qname); return -1; }
 	const size_t start = out.size();
 	Bw w{out};
 	w.u32(0);                                                             // block_size, patched below
