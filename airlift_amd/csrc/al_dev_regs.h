@@ -8,21 +8,24 @@
 #include "al_device.h"
 
 #define AL_D __device__ __forceinline__
+#include "al_dev_sort.h"
 
-// ---- sorts.  The reference uses a stable insertion sort up to 64 elements and an unstable in-place radix sort
-// above (ksort.h:116-161).  Up to 64 we reproduce the stable order; above 64 the order is only defined when keys
-// are distinct, so we heap-sort and report whether equal keys were seen (counted by the caller, never silent).
+struct AnchorAcc {
+	typedef AlAnchor E; AlAnchor *a;
+	AL_D uint64_t key(int i) const { return a[i].x; }
+	AL_D uint64_t keyof(const AlAnchor &e) const { return e.x; }
+	AL_D AlAnchor get(int i) const { return a[i]; }
+	AL_D void set(int i, const AlAnchor &e) { a[i] = e; }
+};
 AL_D void d_isort128(AlAnchor *a, int n)
 {
 	for (int i = 1; i < n; ++i) if (a[i].x < a[i - 1].x) { AlAnchor t = a[i]; int j = i; for (; j > 0 && t.x < a[j - 1].x; --j) a[j] = a[j - 1]; a[j] = t; }
 }
-AL_D bool d_sort128(AlAnchor *a, int n)
-{   // returns true if n > 64 and equal keys exist
+AL_D bool d_sort128(AlAnchor *a, int n, void *scratch)
+{   // radix_sort_128x.  scratch: AL_RS_SCRATCH bytes, used only when n > 64.  Returns true if the order is not reproduced.
 	if (n <= 64) { d_isort128(a, n); return false; }
-	for (int s = (n >> 1) - 1; s >= 0; --s) { int i = s; AlAnchor t = a[i]; for (;;) { int c = 2 * i + 1; if (c >= n) break; if (c + 1 < n && a[c + 1].x > a[c].x) ++c; if (a[c].x <= t.x) break; a[i] = a[c]; i = c; } a[i] = t; }
-	for (int e = n - 1; e > 0; --e) { AlAnchor t = a[e]; a[e] = a[0]; int i = 0; for (;;) { int c = 2 * i + 1; if (c >= e) break; if (c + 1 < e && a[c + 1].x > a[c].x) ++c; if (a[c].x <= t.x) break; a[i] = a[c]; i = c; } a[i] = t; }
-	bool tie = false; for (int i = 1; i < n; ++i) if (a[i].x == a[i - 1].x) tie = true;
-	return tie;
+	AnchorAcc acc{a};
+	return d_rs_sort(acc, n, (uint16_t *)scratch);
 }
 AL_D void d_sort64(uint64_t *a, int n)
 {   // plain values: ties are indistinguishable
@@ -63,7 +66,8 @@ AL_D void d_reg_set_coor(AlReg *r, int32_t qlen, const AlAnchor *a)
 
 AL_D void d_reg_clear(AlReg *r) { int32_t *p = (int32_t *)r; for (int i = 0; i < (int)(sizeof(AlReg) / 4); ++i) p[i] = 0; }
 
-// mm_gen_regs, hit.c:52-88.  z: scratch of n_u AlAnchor.  Returns true on an undefined (>64, tied) order.
+// mm_gen_regs, hit.c:52-88.  z: scratch of n_u AlAnchor, followed by AL_RS_SCRATCH bytes when n_u > 64 (the work areas
+// hold 4*n_u+4 entries).  Returns true if the sort order could not be reproduced.
 AL_D bool d_gen_regs(uint32_t hash, int qlen, int n_u, const uint64_t *u, const AlAnchor *a, AlReg *r, AlAnchor *z)
 {
 	if (n_u == 0) return false;
@@ -74,7 +78,7 @@ AL_D bool d_gen_regs(uint32_t hash, int qlen, int n_u, const uint64_t *u, const 
 		z[i].y = (uint64_t)k << 32 | (uint32_t)(int32_t)u[i];
 		k += (int32_t)u[i];
 	}
-	const bool tie = d_sort128(z, n_u);
+	const bool tie = d_sort128(z, n_u, z + n_u);
 	for (int i = 0; i < n_u >> 1; ++i) { AlAnchor t = z[i]; z[i] = z[n_u - 1 - i]; z[n_u - 1 - i] = t; }
 	for (int i = 0; i < n_u; ++i) {
 		AlReg *ri = &r[i];
@@ -242,7 +246,8 @@ AL_D void d_filter_regs(const AlParams &P, int qlen, int *n_regs, AlReg *regs)
 	*n_regs = k;
 }
 
-// mm_hit_sort, hit.c:169-201.  aux: n AlAnchor, t: n AlReg scratch.  Returns true on an undefined (>64, tied) order.
+// mm_hit_sort, hit.c:169-201.  aux: n AlAnchor, t: n AlReg scratch (doubles as the radix sort's work area before it
+// receives the permuted hits).  Returns true if the sort order could not be reproduced.
 AL_D bool d_hit_sort(int *n_regs, AlReg *r, AlAnchor *aux, AlReg *t)
 {
 	const int n = *n_regs; int n_aux = 0;
@@ -254,7 +259,7 @@ AL_D bool d_hit_sort(int *n_regs, AlReg *r, AlAnchor *aux, AlReg *t)
 			aux[n_aux++].y = (uint64_t)i;
 		}
 	}
-	const bool tie = d_sort128(aux, n_aux);
+	const bool tie = d_sort128(aux, n_aux, t);
 	for (int i = n_aux - 1; i >= 0; --i) t[n_aux - 1 - i] = r[aux[i].y];
 	for (int i = 0; i < n_aux; ++i) r[i] = t[i];
 	*n_regs = n_aux;

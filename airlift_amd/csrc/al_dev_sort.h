@@ -1,0 +1,68 @@
+// al_dev_sort.h -- device restatement of the reference's sort (klib ksort.h KRADIX_SORT_INIT), shared by the chain
+// kernels and the region bookkeeping.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#ifndef AL_D
+#define AL_D __device__ __forceinline__
+#endif
+
+// ---- sorts.  The reference uses a stable insertion sort up to 64 elements and an unstable in-place MSD radix sort
+// above (ksort.h:105-151).  Both are restated step for step, so the order the radix permutation leaves among
+// equal keys is the reference's too.  d_rs_sort works through an accessor (key(i), keyof(e), get(i), set(i,e)) so
+// the same code sorts anchors, pairing entries and the chain permutation.
+#define AL_RS_STK 40                                  // pending (>64-element) buckets; disjoint, so n <= 65*AL_RS_STK never overflows
+#define AL_RS_SCRATCH (2 * (512 + 3 * AL_RS_STK))     // bytes of scratch d_rs_sort needs
+template <class A>
+AL_D void d_rs_isort(A &acc, int beg, int end)
+{   // rs_insertsort, ksort.h:105-115
+	for (int i = beg + 1; i < end; ++i)
+		if (acc.key(i) < acc.key(i - 1)) {
+			typename A::E t = acc.get(i); const uint64_t kt = acc.keyof(t); int j = i;
+			for (; j > beg && kt < acc.key(j - 1); --j) acc.set(j, acc.get(j - 1));
+			acc.set(j, t);
+		}
+}
+template <class A>
+AL_D bool d_rs_sort(A &acc, int n, uint16_t *scr)
+{   // radix_sort + rs_sort, ksort.h:116-151 (8-bit digits from bit 56 down).  Returns true if the order could not be
+	// reproduced (more than 65535 elements or more than AL_RS_STK pending buckets): stable order then, caller counts it.
+	if (n <= 64) { d_rs_isort(acc, 0, n); return false; }
+	if (n > 65535) { d_rs_isort(acc, 0, n); return true; }
+	uint16_t *bb = scr, *be = scr + 256, *stk = scr + 512;
+	bool bad = false; int sp = 1;
+	stk[0] = 0; stk[1] = (uint16_t)n; stk[2] = 56;
+	while (sp > 0) {
+		--sp;
+		const int beg = stk[3 * sp], end = stk[3 * sp + 1], s = stk[3 * sp + 2];
+		for (int k = 0; k < 256; ++k) bb[k] = be[k] = (uint16_t)beg;
+		for (int i = beg; i < end; ++i) ++be[acc.key(i) >> s & 255];
+		for (int k = 1; k < 256; ++k) { be[k] = (uint16_t)(be[k] + be[k - 1] - beg); bb[k] = be[k - 1]; }
+		for (int k = 0; k < 256;) {
+			if (bb[k] != be[k]) {
+				int l = (int)(acc.key(bb[k]) >> s & 255);
+				if (l != k) {
+					typename A::E tmp = acc.get(bb[k]);
+					do {
+						const typename A::E swap = tmp; tmp = acc.get(bb[l]); acc.set(bb[l]++, swap);
+						l = (int)(acc.keyof(tmp) >> s & 255);
+					} while (l != k);
+					acc.set(bb[k]++, tmp);
+				} else ++bb[k];
+			} else ++k;
+		}
+		bb[0] = (uint16_t)beg; for (int k = 1; k < 256; ++k) bb[k] = be[k - 1];
+		if (s) {
+			const int s2 = s > 8 ? s - 8 : 0;
+			for (int k = 0; k < 256; ++k) {
+				const int sz = be[k] - bb[k];
+				if (sz > 64) {
+					if (sp < AL_RS_STK) { stk[3 * sp] = bb[k]; stk[3 * sp + 1] = be[k]; stk[3 * sp + 2] = (uint16_t)s2; ++sp; }
+					else { d_rs_isort(acc, bb[k], be[k]); bad = true; }
+				} else if (sz > 1) d_rs_isort(acc, bb[k], be[k]);
+			}
+		}
+	}
+	return bad;
+}

@@ -638,6 +638,13 @@ __device__ __forceinline__ void d_align1(GroupLds<TMAX, QMAX> &L, const int gl, 
 
 // mm_pair, pe.c:76-177 (+ mm_set_pe_thru pe.c:45-64).  pa: scratch (n0+n1) x 3 words; sc: scratch u64
 struct PairEnt { uint64_t key; int32_t s, rev, idx; int32_t pad; };
+struct PairAcc {
+	typedef PairEnt E; PairEnt *a;
+	AL_D uint64_t key(int i) const { return a[i].key; }
+	AL_D uint64_t keyof(const PairEnt &e) const { return e.key; }
+	AL_D PairEnt get(int i) const { return a[i]; }
+	AL_D void set(int i, const PairEnt &e) { a[i] = e; }
+};
 // mm_pair + mm_set_pe_thru (pe.c:45-177).  Mate ids, strands and the two hit arrays are selected with two-way selects
 // instead of indexing small local arrays by run-time values: those arrays would be placed in scratch memory.
 __device__ __forceinline__ void d_pair2(const AlParams &P, int max_gap_ref, const int ql0, const int ql1, const int n0, const int n1, AlReg *const regs0, AlReg *const regs1,
@@ -662,9 +669,10 @@ __device__ __forceinline__ void d_pair2(const AlParams &P, int max_gap_ref, cons
 	}
 	if (segs == 3) {
 		dp_thres -= P.pe_bonus; if (dp_thres < 0) dp_thres = 0;
-		// radix_sort_pair: stable insertion sort for n <= 64 (ksort.h:149)
-		for (int i = 1; i < n; ++i) if (pa[i].key < pa[i - 1].key) { PairEnt t = pa[i]; int j = i; for (; j > 0 && t.key < pa[j - 1].key; --j) pa[j] = pa[j - 1]; pa[j] = t; }
-		if (n > 64) { for (int i = 1; i < n; ++i) if (pa[i].key == pa[i - 1].key) *tie = true; }
+		// radix_sort_pair (ksort.h:147-151): stable insertion sort up to 64 entries, the reference's radix permutation above
+		// (work area: the rest of the hit scratch behind pa[n]; more than 64 entries implies a work area of >= 33 hits)
+		if (n <= 64) { for (int i = 1; i < n; ++i) if (pa[i].key < pa[i - 1].key) { PairEnt t = pa[i]; int j = i; for (; j > 0 && t.key < pa[j - 1].key; --j) pa[j] = pa[j - 1]; pa[j] = t; } }
+		else { PairAcc acc{pa}; if (d_rs_sort(acc, n, (uint16_t *)(pa + n))) *tie = true; }
 		long long max = -1; int max_idx0 = -1, max_idx1 = -1, last0 = -1, last1 = -1; int n_sc = 0;
 #define PR(e) (&RG((e).s)[(e).idx])
 		for (int i = 0; i < n; ++i) {
@@ -1621,7 +1629,7 @@ k_ext_finish(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ r
 				if (E.jobs[x.job].qlen) {
 					const ExtOut *po = &E.outs[x.job];
 					const uint32_t fl = po->flags_ncig; const int nc = (int)(fl >> 8); const bool reach = fl & 1;
-					if (nc > 0) { d_fcig_append(&R, cig, nc, nc <= 6 ? po->cig : G.arena + po->cig_off); R.dp_score += po->max; }
+					if (nc > 0 && (nc <= 6 || po->cig_off != 0xffffffffu)) { d_fcig_append(&R, cig, nc, nc <= 6 ? po->cig : G.arena + po->cig_off); R.dp_score += po->max; }
 					rs1 = x.rs - (reach ? po->mqe_t + 1 : po->max_t + 1);
 					qs1 = x.qs - (reach ? x.qs : po->max_q + 1);
 				}
@@ -1630,7 +1638,7 @@ k_ext_finish(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ r
 				if (E.jobs[x.job + 1].qlen) {
 					const ExtOut *po = &E.outs[x.job + 1];
 					const uint32_t fl = po->flags_ncig; const int nc = (int)(fl >> 8); const bool reach = fl & 1;
-					if (nc > 0) { d_fcig_append(&R, cig, nc, nc <= 6 ? po->cig : G.arena + po->cig_off); R.dp_score += po->max; }
+					if (nc > 0 && (nc <= 6 || po->cig_off != 0xffffffffu)) { d_fcig_append(&R, cig, nc, nc <= 6 ? po->cig : G.arena + po->cig_off); R.dp_score += po->max; }
 					re1 = x.re + (reach ? po->mqe_t + 1 : po->max_t + 1);
 					qe1 = x.qe + (reach ? qlen - x.qe : po->max_q + 1);
 				}
@@ -1757,6 +1765,7 @@ struct AlignState {            // lives in al_ctx_s::align_state (opaque there)
 	DevBuf<uint64_t> aux64, seg_u, nu_off, out_off;
 	DevBuf<int32_t> auxi;
 	DevBuf<uint32_t> reg_cnt, seg_na, arena, seg_fast;
+	uint64_t arena_scale = 1;       // doubled by al_align_grow_arena() when a batch's long CIGARs overflowed the arena
 	DevBuf<uint8_t> gws;
 	DevBuf<float> logtab;
 	DevBuf<unsigned long long> dbgbuf, hist;
@@ -1829,7 +1838,7 @@ int al_run_align_stage(al_ctx_t *c)
 	const size_t stride = p_bytes + cig_words * 8 + AL_PAIR_SC_CAP * 8;
 	int nb = (nf + AL_GPB - 1) / AL_GPB; const int nb_max = 256 * 16; if (nb > nb_max) nb = nb_max;
 	if (A->gws.ensure((size_t)nb * AL_GPB * stride + 64)) return -1;
-	const uint64_t arena_cap = (uint64_t)nr * 12 + 4096 + (uint64_t)c->n_bases / 8;
+	const uint64_t arena_cap = ((uint64_t)nr * 12 + 4096 + (uint64_t)c->n_bases / 8) * A->arena_scale;
 	if (A->arena.ensure(arena_cap)) return -1;
 	AlignShared G; G.S4 = c->di.S4; G.seq_off = c->di.seq_off; G.seq_len = c->di.seq_len; G.arena = A->arena.p; G.arena_cnt = c->counters.p + 11; G.arena_cap = arena_cap; G.counters = c->counters.p;
 	if (A->dbgbuf.ensure(640)) return -1;
@@ -1873,6 +1882,7 @@ int al_run_align_stage(al_ctx_t *c)
 			AL_HIP_CHECK(hipEventRecord(c->ev[ST_EXT_SORT + 1], s));
 			AL_HIP_CHECK(hipMemcpyAsync(hist, A->hist.p, (AL_NCLS + 1) * 8, hipMemcpyDeviceToHost, s));
 			AL_HIP_CHECK(hipStreamSynchronize(s));
+			if (getenv("AL_TRACE")) fprintf(stderr, "[airlift] trace: prep + job sort done\n");
 			if ((c->P.dbg >> 30) & 1) { fprintf(stderr, "[airlift] DP jobs per class (lane16 lane32 lane64 g1 g2 g4 g8 g22 g32 lds | empty):"); for (int i = 0; i <= AL_NCLS; ++i) fprintf(stderr, " %llu", hist[i]); fprintf(stderr, "\n"); }
 			// one launch per job class over its slice of the sorted job list
 			static const int NBs[6] = {1, 2, 4, 8, 22, 32};
@@ -1906,6 +1916,7 @@ int al_run_align_stage(al_ctx_t *c)
 					if (tmax <= 512) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ext_dp_lds<512, 256>), dim3(nbj), dim3(GW), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, G, E, A->job_idx2.p, first, cnt, A->gws.p, stride, p_bytes, cig_words, c->P);
 					else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ext_dp_lds<1024, 512>), dim3(nbj), dim3(GW), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, G, E, A->job_idx2.p, first, cnt, A->gws.p, stride, p_bytes, cig_words, c->P);
 				}
+				if (getenv("AL_TRACE")) { const hipError_t e = hipStreamSynchronize(s); fprintf(stderr, "[airlift] trace: DP class %d (%u jobs) -> %s\n", cls, cnt, hipGetErrorName(e)); }
 				first += cnt;
 			}
 		}
@@ -1948,6 +1959,9 @@ int al_run_align_stage(al_ctx_t *c)
 	AL_HIP_CHECK(hipGetLastError());
 	return 0;
 }
+
+// the CIGAR arena of the last al_run_align_stage() was too small (counters[9] != 0): twice the size for the re-run
+void al_align_grow_arena(al_ctx_t *c) { get_state(c)->arena_scale *= 2; }
 
 int al_fetch_raw(al_ctx_t *c, AlRawResult &R)
 {   // device -> host copies of the last al_batch_run: per-read record offsets, records, CIGAR arena, repeat lengths

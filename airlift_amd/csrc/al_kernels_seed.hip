@@ -10,6 +10,7 @@
 #include <stdint.h>
 #include "al_internal.h"
 #include "al_device.h"
+#include "al_dev_sort.h"
 
 // =============================================================================================
 // K1: sketch.  One lane per read runs the reference's streaming window algorithm verbatim (so ties,
@@ -440,6 +441,16 @@ __device__ __forceinline__ int d_ilog2(uint32_t v) { return 31 - __clz((int)v); 
 
 struct ChainArrays { uint64_t *x; int32_t *q; uint32_t *m; int32_t *f, *p, *t, *v; };   // m: span | sid<<8
 
+// accessor for ordering chains by the x of their first anchor: elements are chain ids in T[], chain c's first anchor is
+// a[V[Pp[c] + len(c) - 1]] (V = backtrack visit list, Pp = chain start offsets into V, utmp low word = chain length).
+struct ChainOrderAcc {
+	typedef int32_t E;
+	int32_t *T; const int32_t *V, *Pp; const uint64_t *utmp, *X; const AlAnchor *a; bool in_lds;
+	__device__ __forceinline__ uint64_t keyof(const int32_t &c) const { const int32_t i = V[Pp[c] + (int32_t)(uint32_t)utmp[c] - 1]; return in_lds ? X[i] : a[i].x; }
+	__device__ __forceinline__ uint64_t key(int i) const { return keyof(T[i]); }
+	__device__ __forceinline__ int32_t get(int i) const { return T[i]; }
+	__device__ __forceinline__ void set(int i, const int32_t &c) { T[i] = c; }
+};
 template <int CAP>
 __global__ void __launch_bounds__(64)
 k_chain(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_off, const uint32_t *__restrict__ frag_na,
@@ -452,6 +463,7 @@ k_chain(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_off
 	__shared__ uint64_t s_qm[CAP];                       // Q (int32) and M (u32) halves during the DP; chain list (u64) in the tail
 	__shared__ int32_t sf[CAP], sp[CAP], st_[CAP], sv[CAP];
 	__shared__ int32_t s_nu;
+	__shared__ uint16_t s_rs[AL_RS_SCRATCH / 2];         // work area of the > 64-chain ordering sort
 	int32_t *sq = (int32_t *)s_qm; uint32_t *sm = (uint32_t *)s_qm + CAP;
 	const int lane = threadIdx.x;
 	if ((int)blockIdx.x >= n_list) return;
@@ -470,6 +482,7 @@ k_chain(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_off
 	int qlen_sum = 0; for (uint32_t r = r0; r < r1; ++r) qlen_sum += (int)rd_len[r];
 	const AlAnchor *a = anchors + a_off[f];
 	const bool in_lds = n <= CAP;
+#define CHAIN_SYNC() __syncthreads()
 	uint64_t *X; int32_t *Q, *F, *Pp, *T, *V; uint32_t *M;
 	if (in_lds) { X = sx; Q = sq; F = sf; Pp = sp; T = st_; V = sv; M = sm; }
 	else {
@@ -495,7 +508,7 @@ k_chain(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_off
 	for (int d = 32; d > 0; d >>= 1) sum_qspan += __shfl_xor(sum_qspan, d);
 	const float avg_qspan = (float)((double)(float)sum_qspan / (double)(float)n);   // == (float)sum/n in IEEE fp32 (chain.c:42)
 	const double avg_d = (double)avg_qspan;
-	__syncthreads();
+	CHAIN_SYNC();
 
 #define AX(i) (in_lds ? X[i] : a[i].x)
 #define AQ(i) (in_lds ? Q[i] : (int32_t)a[i].y)
@@ -539,7 +552,7 @@ k_chain(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_off
 			const int32_t before = excl > max_f ? excl : max_f;
 			const bool upd = active && sc > before;
 			if (active && pj >= 0) T[pj] = (int32_t)i;
-			__syncthreads();
+			CHAIN_SYNC();
 			const bool marked = active && !upd && T[j] == (int32_t)i;
 			unsigned long long U = __ballot(upd), K = __ballot(marked);
 			unsigned long long both = U | K; int brk = 64;
@@ -553,20 +566,20 @@ k_chain(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_off
 				const int lastu = 63 - __clzll((long long)U);
 				max_f = __shfl(sc, lastu); max_j = base - lastu;
 			}
-			__syncthreads();
+			CHAIN_SYNC();
 		}
 		if (lane == 0) {
 			F[i] = max_f; Pp[i] = (int32_t)max_j;
 			V[i] = max_j >= 0 && V[max_j] > max_f ? V[max_j] : max_f;
 		}
-		__syncthreads();
+		CHAIN_SYNC();
 	}
 
 	// ---- chain ends, peaks, backtrack (chain.c:87-160): lane 0, O(n) -----------------------------------
 	for (int64_t i = lane; i < n; i += 64) T[i] = 0;
-	__syncthreads();
+	CHAIN_SYNC();
 	for (int64_t i = lane; i < n; i += 64) if (Pp[i] >= 0) T[Pp[i]] = 1;
-	__syncthreads();
+	CHAIN_SYNC();
 	AlAnchor *b = chained + a_off[f];
 	uint64_t *u = u_out + a_off[f] + f;                 // capacity n + 1
 	uint64_t *utmp = in_lds ? s_qm : ws_u64 + a_off[f]; // capacity n (Q/M are dead after the DP)
@@ -603,24 +616,10 @@ k_chain(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_off
 			// first anchor of chain c = a[V[k0 + ni - 1]].  Pp[] (free now) = chain start offsets into V, T[] = permutation.
 			int32_t off = 0;
 			for (int32_t c = 0; c < n_u; ++c) { Pp[c] = off; off += (int32_t)(uint32_t)utmp[c]; T[c] = c; }
-			bool tie = false;
-#define CX(c) (in_lds ? X[V[Pp[c] + (int32_t)(uint32_t)utmp[c] - 1]] : a[V[Pp[c] + (int32_t)(uint32_t)utmp[c] - 1]].x)
-			if (n_u <= 64) {
-				for (int32_t i = 1; i < n_u; ++i) {
-					const int32_t ci = T[i]; const uint64_t xi = CX(ci); int32_t j = i;
-					while (j > 0) { const int32_t cj = T[j - 1]; if (xi < CX(cj)) { T[j] = cj; --j; } else break; }
-					T[j] = ci;
-				}
-			} else {
-				// > 64 chains: the reference's radix sort is unstable; order is only defined when keys are distinct.
-				// heap sort on (x, original index) and flag fragments that actually contain equal keys.
-#define CLT(c1, c2) (CX(c1) < CX(c2) || (CX(c1) == CX(c2) && (c1) < (c2)))
-				for (int32_t s0 = (n_u >> 1) - 1; s0 >= 0; --s0) { int32_t i = s0, t = T[i]; for (;;) { int32_t c = 2 * i + 1; if (c >= n_u) break; if (c + 1 < n_u && CLT(T[c], T[c + 1])) ++c; if (!CLT(t, T[c])) break; T[i] = T[c]; i = c; } T[i] = t; }
-				for (int32_t e = n_u - 1; e > 0; --e) { int32_t t = T[e]; T[e] = T[0]; int32_t i = 0; for (;;) { int32_t c = 2 * i + 1; if (c >= e) break; if (c + 1 < e && CLT(T[c], T[c + 1])) ++c; if (!CLT(t, T[c])) break; T[i] = T[c]; i = c; } T[i] = t; }
-				for (int32_t i = 1; i < n_u; ++i) if (CX(T[i]) == CX(T[i - 1])) tie = true;
-#undef CLT
-			}
-#undef CX
+			// radix_sort_128x (ksort.h:147-151) on the permutation T[]: stable insertion up to 64 chains, the reference's
+			// radix permutation above (its order among equal first-anchor positions is reproduced, not just flagged).
+			ChainOrderAcc acc{T, V, Pp, utmp, X, a, in_lds};
+			const bool tie = d_rs_sort(acc, n_u, s_rs);
 			if (tie) atomicAdd(&counters[1], 1ULL);
 			int32_t o = 0;
 			for (int32_t i = 0; i < n_u; ++i) { const int32_t c = T[i]; u[i] = utmp[c]; F[i] = o; o += (int32_t)(uint32_t)utmp[c]; }   // F[] = output offset of sorted chain i
@@ -628,7 +627,7 @@ k_chain(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_off
 		frag_nu[f] = (uint32_t)n_u;
 		s_nu = n_u;
 	}
-	__syncthreads();
+	CHAIN_SYNC();
 	{   // copy-out of the chained anchors by the whole wave: b[F[i] + j] = a[V[k0 + ni - 1 - j]]
 		const int32_t n_u = s_nu;
 		for (int32_t i = 0; i < n_u; ++i) {
@@ -637,6 +636,7 @@ k_chain(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_off
 		}
 	}
 #undef AX
+#undef CHAIN_SYNC
 #undef AQ
 #undef AM
 }

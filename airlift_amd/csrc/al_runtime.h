@@ -47,7 +47,7 @@ struct al_ctx_s {
 	std::vector<uint32_t> h_rd_seq;
 	std::vector<uint8_t> h_flip;          // read was reverse-complemented for mapping (worker_for, map.c:468)
 
-	DevBuf<uint32_t> rd_seq, rd_len, frag_first, frag_hash, mini_cnt, frag_nm, frag_na, frag_nu, rechain_list, tmp_u32;
+	DevBuf<uint32_t> rd_seq, rd_len, frag_first, frag_hash, mini_cnt, frag_nm, frag_na, frag_nu, rechain_list, rechain_sorted, tmp_u32;
 	DevBuf<uint64_t> rd_off, mini_off, a_off, u, ws_u64, tmp_u64, tmp_u64b;
 	DevBuf<int32_t> frag_rep, ws_i32;
 	DevBuf<AlAnchor> mini, heap_ws, anchors, chained;
@@ -76,6 +76,7 @@ struct al_ctx_s {
 int al_upload_index(const al_idx_t *mi, int device, AlDevIndex *out);
 int al_run_align_stage(al_ctx_t *c);      // al_kernels_align.hip: KA (regs) + K5 (extension, MAPQ, pairing)
 int al_fetch_align(al_ctx_t *c, int *n_regs, al_reg1_t **regs, int *rep_len);
+void al_align_grow_arena(al_ctx_t *c);
 
 template <typename T> struct PinnedVec {    // grow-only page-locked host array (fast, asynchronous-capable D2H target)
 	T *p = nullptr; size_t n = 0, cap = 0;

@@ -108,7 +108,7 @@ extern "C" void al_ctx_destroy(al_ctx_t *c)
 	al_align_state_free(c);
 	if (c->stream) (void)hipStreamSynchronize(c->stream);
 	c->rd_seq.release(); c->rd_len.release(); c->frag_first.release(); c->frag_hash.release(); c->mini_cnt.release(); c->frag_nm.release(); c->frag_na.release();
-	c->frag_nu.release(); c->rechain_list.release(); c->tmp_u32.release(); c->rd_off.release(); c->mini_off.release(); c->a_off.release(); c->u.release();
+	c->frag_nu.release(); c->rechain_list.release(); c->rechain_sorted.release(); c->tmp_u32.release(); c->rd_off.release(); c->mini_off.release(); c->a_off.release(); c->u.release();
 	c->ws_u64.release(); c->tmp_u64.release(); c->frag_rep.release(); c->ws_i32.release(); c->mini.release(); c->heap_ws.release(); c->anchors.release();
 	c->chained.release(); c->match.release(); c->counters.release(); c->scan_tmp.release(); c->regs0.release(); c->regs.release(); c->reg_cnt.release();
 	c->chain_key.release(); c->chain_idx.release(); c->chain_idx2.release(); c->tie_list.release(); c->lb_buf.release(); c->tmp_u64b.release();
@@ -361,10 +361,18 @@ int al_run_seed_stages(al_ctx_t *c)
 			AL_HIP_CHECK(hipMemcpyAsync(c->a_off_p1.p, c->a_off.p, (size_t)(c->n_frag + 1) * 8, hipMemcpyDeviceToDevice, s));
 			AL_HIP_CHECK(hipMemcpyAsync(c->frag_na_p1.p, c->frag_na.p, (size_t)c->n_frag * 4, hipMemcpyDeviceToDevice, s));
 			AL_HIP_CHECK(hipMemcpyAsync(c->frag_rep_p1.p, c->frag_rep.p, (size_t)c->n_frag * 4, hipMemcpyDeviceToDevice, s));
-			// deterministic order (atomic append order is arbitrary; offsets depend on it only for layout, results do not)
-			// the chain list u[] is addressed as a_off[f] + f: start the second pass n_frag slots further so that its u[] entries cannot
-			// land on those of the last first-pass fragments
-			if (run_seed_chain(c, c->rechain_list.p, (int)n, c->opt.max_occ, c->n_anchor_pass1 + (uint64_t)c->n_frag, false)) return -1;
+			// The chain list u[] of fragment f lives at a_off[f] + f, which keeps the regions of two fragments apart only if their
+			// anchor offsets grow with f.  k_rechain_test appends in arbitrary (atomic) order, so put the list in ascending
+			// fragment order first -- that also makes the second-pass layout the same on every run -- and start the second pass
+			// n_frag slots further so that its u[] entries cannot land on those of the last first-pass fragments.
+			{
+				size_t bytes = 0;
+				if (c->rechain_sorted.ensure(n + 1)) return -1;
+				AL_HIP_CHECK(hipcub::DeviceRadixSort::SortKeys(nullptr, bytes, (const uint32_t *)c->rechain_list.p, c->rechain_sorted.p, (int)n, 0, 32, s));
+				if (c->scan_tmp.ensure(bytes + 16)) return -1;
+				AL_HIP_CHECK(hipcub::DeviceRadixSort::SortKeys(c->scan_tmp.p, bytes, (const uint32_t *)c->rechain_list.p, c->rechain_sorted.p, (int)n, 0, 32, s));
+			}
+			if (run_seed_chain(c, c->rechain_sorted.p, (int)n, c->opt.max_occ, c->n_anchor_pass1 + (uint64_t)c->n_frag, false)) return -1;
 		}
 	}
 	AL_HIP_CHECK(hipEventRecord(c->ev[ST_RECHAIN + 1], s));
@@ -375,14 +383,26 @@ extern "C" int al_batch_run(al_ctx_t *c)
 {
 	if (!c) return -1;
 	if (al_run_seed_stages(c)) return -1;
-	if (al_run_align_stage(c)) return -1;
-	AL_HIP_CHECK(hipEventRecord(c->ev[ST_COMPACT + 1], c->stream));
-	AL_HIP_CHECK(hipStreamSynchronize(c->stream));
+	for (int attempt = 0; ; ++attempt) {
+		if (al_run_align_stage(c)) return -1;
+		AL_HIP_CHECK(hipEventRecord(c->ev[ST_COMPACT + 1], c->stream));
+		AL_HIP_CHECK(hipStreamSynchronize(c->stream));
+		unsigned long long ovf = 0;
+		AL_HIP_CHECK(hipMemcpy(&ovf, c->counters.p + 9, 8, hipMemcpyDeviceToHost));
+		if (ovf == 0 || attempt >= 8) break;
+		// long CIGARs (repeat-rich or indel-rich batches) did not fit the arena: the alignment stage only reads the chaining
+		// results, so it is simply run again with twice the arena
+		if (getenv("AL_TRACE")) fprintf(stderr, "[airlift] trace: CIGAR arena overflow (%llu), re-running the alignment stage with twice the arena\n", ovf);
+		al_align_grow_arena(c);
+		AL_HIP_CHECK(hipMemsetAsync(c->counters.p + 4, 0, 8 * sizeof(unsigned long long), c->stream));     // [4..11]: stage statistics, error words, arena cursor
+		AL_HIP_CHECK(hipMemsetAsync(c->counters.p + 14, 0, sizeof(unsigned long long), c->stream));
+	}
 	for (int i = 0; i < ST_N; ++i) { float ms = 0; if (hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]) != hipSuccess) ms = 0; c->ms_stage[i] = ms; }
 	float tot = 0; (void)hipEventElapsedTime(&tot, c->ev[0], c->ev[ST_N]); c->ms_total = tot;
 	c->ran = true;
 	// counters + algorithmic bytes
 	unsigned long long h[16]; AL_HIP_CHECK(hipMemcpy(h, c->counters.p, sizeof(h), hipMemcpyDeviceToHost));
+	if (getenv("AL_TRACE")) { fprintf(stderr, "[airlift] trace: counters"); for (int i = 0; i < 16; ++i) fprintf(stderr, " [%d]=%llu", i, h[i]); fprintf(stderr, " rechain=%u\n", c->n_rechain); }
 	al_batch_stat_t &st = c->stat; memset(&st, 0, sizeof(st));
 	st.n_frag = c->n_frag; st.n_reads = c->n_reads; st.n_bases = c->n_bases;
 	st.n_mini = ~0ULL; st.n_chain = ~0ULL;   // filled lazily by al_batch_stat()

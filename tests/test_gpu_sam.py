@@ -289,6 +289,18 @@ def test_randomised_parity_sweep_against_reference():
     assert r.returncode == 0, r.stdout.decode()[-3000:]
 
 
+def test_randomised_parity_sweep_on_repeat_rich_references():
+    """The same sweep on references that are 70 % repeats: thousands of anchors per fragment, almost every fragment re-chained
+    with max_occ (map.c:353-375), more than 64 chains / hits per read (the reference's radix sort instead of its insertion
+    sort, ksort.h:147-151), CIGAR arena growth.  Seed 31 holds the two cases that exposed the second-pass chain-list layout
+    and the > 64-entry sort order."""
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "mm2ref")
+    if not os.path.exists(ref_bin):
+        pytest.skip("reference build oracle/_ref/mm2ref not present")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "70", "31"], capture_output=True, env=dict(os.environ, FUZZ_REPEAT="0.7"))
+    assert r.returncode == 0, r.stdout.decode()[-3000:]
+
+
 def test_token_stage_matches_reference_script_and_aligner(golden_unpacked):
     """`airlift-align tokens` = the reference's gaps_to_fasta.py (tiling into read-sized tokens) + single-end
     alignment of the tokens; golden SAM made by that script and the reference build (tests/golden/make_g7_tokens.py).

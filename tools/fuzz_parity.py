@@ -27,6 +27,16 @@ for case in range(n_cases):
                            dup_div=float(rng.choice([0.0, 0.01, 0.05])), n_frac=float(rng.choice([0, 0, 0.01])), tandem=int(rng.integers(0, 8)))
     if min(len(c) for _, c in ref) < 2 * rl + 1100:
         continue
+    if rng.random() < float(os.environ.get("FUZZ_REPEAT", "0.15")):   # a high-copy element: minimizers above mid_occ, re-chain pass, many chains per read
+        ulen = int(rng.integers(80, 400)); unit = rng.integers(0, 4, size=ulen, dtype=np.uint8)
+        copies = int(rng.integers(300, 1600)); div = float(rng.choice([0.0, 0.01, 0.04]))
+        for _, c in ref:
+            for _ in range(copies // len(ref) + 1):
+                if len(c) <= ulen + 2:
+                    break
+                p0 = int(rng.integers(0, len(c) - ulen)); u = unit.copy(); msk = rng.random(ulen) < div
+                u[msk] = (u[msk] + rng.integers(1, 4, size=int(msk.sum()), dtype=np.uint8)) & 3
+                c[p0:p0 + ulen] = u
     ins = int(rng.choice([rl + 5, int(1.3 * rl), 2 * rl + 100, 3 * rl]))
     n = int(rng.integers(500, 4000)) * int(os.environ.get('FUZZ_SCALE', '1'))
     r1, r2 = g.simulate_pairs(ref, n, rl, seed=int(rng.integers(1 << 30)), ins_mean=ins, ins_sd=max(1, ins // 10), ins_lo=rl, ins_hi=max(1000, 4 * rl),
@@ -38,16 +48,23 @@ for case in range(n_cases):
     if not se:
         g.write_fastq(os.path.join(d, "r_2.fq"), r2, "realigned_"); files.append("r_2.fq")
     opts = list(OPTS[int(rng.integers(len(OPTS)))])
+    if os.environ.get('FUZZ_ONLY') and case != int(os.environ['FUZZ_ONLY']):
+        subprocess.run(['rm', '-rf', d]); continue
     if only is not None:
         opts = only.split()
     e = subprocess.run([REF, "-t", "8"] + opts + ["ref.fa"] + files, cwd=d, capture_output=True)
     o = subprocess.run([CLI, "-ax", "sr"] + opts + ["ref.fa"] + files, cwd=d, capture_output=True)
+    if os.environ.get('FUZZ_DBGS'):
+        for dbg in os.environ['FUZZ_DBGS'].split():
+            o2 = subprocess.run([CLI, "-ax", "sr"] + opts + ["ref.fa"] + files, cwd=d, capture_output=True, env=dict(os.environ, AL_DBG=dbg))
+            print("   AL_DBG=%s rc=%d same=%s %s" % (dbg, o2.returncode, o2.stdout == e.stdout, o2.stderr.decode()[-900:].replace("\n", " | ")))
     if o.returncode != 0 and b"not supported" in o.stderr:        # a loud refusal (window beyond the kernels' limit) is not a parity failure
         print("skip case %d: %s" % (case, o.stderr.decode().strip()[-120:])); subprocess.run(["rm", "-rf", d]); continue
     same = e.returncode == 0 and o.returncode == 0 and e.stdout == o.stdout
     desc = "case %d: L=%d %s n=%d ins=%d ref=%dx%d opts=%s" % (case, rl, "SE" if se else "PE", n, ins, n_ctg, tot // n_ctg, " ".join(opts))
     if same:
-        print("ok   " + desc); subprocess.run(["rm", "-rf", d])
+        print("ok   " + desc + (" kept in " + d if os.environ.get('FUZZ_KEEP') else ""))
+        if not os.environ.get('FUZZ_KEEP'): subprocess.run(["rm", "-rf", d])
     else:
         bad += 1
         el, ol = e.stdout.split(b"\n"), o.stdout.split(b"\n")
@@ -55,7 +72,7 @@ for case in range(n_cases):
         for a, b in [(a, b) for a, b in zip(el, ol) if a != b][:2]:
             fa, fb = a.split(b"\t"), b.split(b"\t")
             print("   exp " + b"\t".join(fa[:9] + fa[11:]).decode()); print("   got " + b"\t".join(fb[:9] + fb[11:]).decode())
-        print("DIFF " + desc + "  (%d lines differ, rc %d/%d) kept in %s : %s" % (nd, e.returncode, o.returncode, d, o.stderr.decode()[-300:].replace("\n", " | ")))
+        print("DIFF " + desc + "  (%d lines differ, rc %d/%d) kept in %s : %s" % (nd, e.returncode, o.returncode, d, o.stderr.decode()[-700:].replace("\n", " | ")))
         if bad >= 3:
             break
 sys.exit(1 if bad else 0)
