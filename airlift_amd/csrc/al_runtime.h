@@ -7,6 +7,10 @@
 #include <thread>
 #include "al_internal.h"
 
+// Set when a device allocation fails; al_batch_run reports AL_ERR_NOMEM then (the context stays usable: every DevBuf is
+// either at its old size or empty, and the caller may upload a smaller batch).
+inline bool &al_nomem_flag() { static thread_local bool f = false; return f; }
+
 template <typename T> struct DevBuf {       // grow-only device array
 	T *p = nullptr; size_t cap = 0;
 	int ensure(size_t n, bool keep = false, hipStream_t s = 0)
@@ -14,7 +18,11 @@ template <typename T> struct DevBuf {       // grow-only device array
 		if (n <= cap) return 0;
 		const size_t ncap = n + n / 4 + 64;
 		T *np = nullptr;
-		if (hipMalloc((void **)&np, ncap * sizeof(T)) != hipSuccess) { fprintf(stderr, "[airlift] hipMalloc of %zu bytes failed\n", ncap * sizeof(T)); return -1; }
+		if (!keep && p) { (void)hipFree(p); p = nullptr; cap = 0; }       // contents not needed: release first, so the peak is one copy
+		if (hipMalloc((void **)&np, ncap * sizeof(T)) != hipSuccess) {
+			(void)hipGetLastError();                                       // not sticky: the next launch check must not see it
+			fprintf(stderr, "[airlift] hipMalloc of %zu bytes failed\n", ncap * sizeof(T)); al_nomem_flag() = true; return -1;
+		}
 		if (keep && p && cap) { if (hipMemcpyAsync(np, p, cap * sizeof(T), hipMemcpyDeviceToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return -1; }
 		if (p) (void)hipFree(p);
 		p = np; cap = ncap;

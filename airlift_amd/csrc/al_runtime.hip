@@ -101,10 +101,8 @@ extern "C" al_ctx_t *al_ctx_init(const al_idx_t *mi, const al_mapopt_t *opt, int
 }
 
 void al_align_state_free(al_ctx_t *c);
-extern "C" void al_ctx_destroy(al_ctx_t *c)
-{
-	if (!c) return;
-	(void)hipSetDevice(c->device);
+static void ctx_release_buffers(al_ctx_t *c)
+{   // every grow-only batch buffer (the index stays); each is re-ensured before its next use
 	al_align_state_free(c);
 	if (c->stream) (void)hipStreamSynchronize(c->stream);
 	c->rd_seq.release(); c->rd_len.release(); c->frag_first.release(); c->frag_hash.release(); c->mini_cnt.release(); c->frag_nm.release(); c->frag_na.release();
@@ -113,6 +111,12 @@ extern "C" void al_ctx_destroy(al_ctx_t *c)
 	c->chained.release(); c->match.release(); c->counters.release(); c->scan_tmp.release(); c->regs0.release(); c->regs.release(); c->reg_cnt.release();
 	c->chain_key.release(); c->chain_idx.release(); c->chain_idx2.release(); c->tie_list.release(); c->lb_buf.release(); c->tmp_u64b.release();
 	c->a_off_p1.release(); c->frag_na_p1.release(); c->frag_rep_p1.release(); c->cigar.release(); c->reg_off.release(); c->cig_off.release(); c->align_ws.release(); c->seg_a.release(); c->seg_u.release();
+}
+extern "C" void al_ctx_destroy(al_ctx_t *c)
+{
+	if (!c) return;
+	(void)hipSetDevice(c->device);
+	ctx_release_buffers(c);
 	for (int i = 0; i <= ST_N; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
 	if (c->stream) (void)hipStreamDestroy(c->stream);
 	delete c;
@@ -382,9 +386,17 @@ int al_run_seed_stages(al_ctx_t *c)
 extern "C" int al_batch_run(al_ctx_t *c)
 {
 	if (!c) return -1;
-	if (al_run_seed_stages(c)) return -1;
+	al_nomem_flag() = false;
+	// out of device memory: the grow-only buffers are what fills it, so give all of them back (the batch has to be uploaded
+	// again, smaller) and report it as such
+	auto failed = [&]() -> int { if (!al_nomem_flag()) return -1; ctx_release_buffers(c); c->n_frag = c->n_reads = 0; c->ran = false; return AL_ERR_NOMEM; };
+	{   // test hook: behave as if batches above a size did not fit (tests/test_gpu_sam.py drives the halving of the file driver with it)
+		static const char *lim = getenv("AL_TEST_NOMEM_ABOVE");
+		if (lim && c->n_frag > atoi(lim)) { fprintf(stderr, "[airlift] AL_TEST_NOMEM_ABOVE: pretending %d fragments do not fit\n", c->n_frag); al_nomem_flag() = true; return failed(); }
+	}
+	if (al_run_seed_stages(c)) return failed();
 	for (int attempt = 0; ; ++attempt) {
-		if (al_run_align_stage(c)) return -1;
+		if (al_run_align_stage(c)) return failed();
 		AL_HIP_CHECK(hipEventRecord(c->ev[ST_COMPACT + 1], c->stream));
 		AL_HIP_CHECK(hipStreamSynchronize(c->stream));
 		unsigned long long ovf = 0;

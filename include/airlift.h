@@ -146,7 +146,13 @@ int  al_batch_upload(al_ctx_t *ctx, int n_frag, const int *n_segs, const int *ql
  * named "<name_prefix><first_index+f>" (BBMap rename.sh naming, extract_sequence.sh:18). */
 int  al_batch_upload_flat(al_ctx_t *ctx, int n_frag, const int *n_segs, const int *qlens, const char *seq_concat,
                           const char *name_prefix, int64_t first_index);
-/* Run the whole hot path (sketch .. alignment records) on the resident batch; results stay on device. */
+/* Run the whole hot path (sketch .. alignment records) on the resident batch; results stay on device.
+ * Returns 0, or AL_ERR_NOMEM when a device workspace for this batch could not be allocated (workspaces grow with the
+ * number of seed hits: a batch of reads from high-copy repeats can need hundreds of bytes per hit).  The context gives its
+ * batch workspaces back and stays usable: upload fewer fragments and run again -- the file drivers below halve the batch and retry on their own, the
+ * way the reference's per-read loop (map.c:229-400) is unaffected by how many reads share a mini-batch.  Any other
+ * non-zero value is a device error. */
+#define AL_ERR_NOMEM (-12)
 int  al_batch_run(al_ctx_t *ctx);
 /* Fetch results of the last al_batch_run into host reg arrays (same contract as al_map_batch). */
 int  al_batch_fetch(al_ctx_t *ctx, int *n_regs, al_reg1_t **regs, int *rep_len);

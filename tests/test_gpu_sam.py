@@ -151,6 +151,19 @@ def test_small_device_batches_and_threads(golden_unpacked):
         assert _run([CLI, "-ax", "sr", "-K", "20000", "-t", t] + rg + [m["ref"]] + m["reads"], d).stdout == exp
 
 
+def test_batch_is_halved_when_device_workspaces_do_not_fit(golden_unpacked):
+    """al_batch_run reports AL_ERR_NOMEM when a workspace cannot be allocated (reads from high-copy repeats: workspaces grow with
+    the seed hits) and gives its buffers back; the file driver then runs the batch as two halves, recursively.  The test hook
+    AL_TEST_NOMEM_ABOVE makes every batch above 37 fragments 'not fit': same bytes, in the same order, and the halving is announced."""
+    d, m, exp = _golden_pe(golden_unpacked)
+    rg = ["-R", m["rg"]] if m.get("rg") else []
+    r = _run([CLI, "-ax", "sr"] + rg + [m["ref"]] + m["reads"], d, env=dict(os.environ, AL_TEST_NOMEM_ABOVE="37"))
+    assert r.stdout == exp
+    assert b"does not fit the device workspaces" in r.stderr
+    r = _run([CLI, "-ax", "sr", "-K", "20000", "-t", "3"] + rg + [m["ref"]] + m["reads"], d, env=dict(os.environ, AL_TEST_NOMEM_ABOVE="5"))
+    assert r.stdout == exp
+
+
 def test_interleaved_single_file_and_uneven_files(golden_unpacked, oracle_bin, tmp_path):
     """One file with /1 /2 mates adjacent (frag_mode pairing by name, map.c:580-586) and two files of different length
     (bseq.c: extra records skipped, with the reference's warning): compared with the oracle on the same inputs."""

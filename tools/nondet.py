@@ -38,7 +38,7 @@ for it in range(runs):
     rg = []
     for r in range(len(seqs)):
         rg.append(hashlib.md5(b"".join(bytes(regs[r][i]) for i in range(n_regs[r]))).hexdigest())
-    raw_u = {f: u[int(t["a_off"][f]) + f: int(t["a_off"][f]) + f + int(t["frag_nu"][f])].copy() for f in range(nf) if 700 < t["frag_na"][f] < 3000}
+    raw_u = {f: u[int(t["a_off"][f]) + f: int(t["a_off"][f]) + f + int(t["frag_nu"][f])].copy() for f in range(nf) if t["frag_na"][f] < 4000}
     raw_c = {f: chained[int(t["a_off"][f]): int(t["a_off"][f]) + int(t["frag_na"][f])].copy() for f in raw_u}
     raw_a = {f: anchors[int(t["a_off"][f]): int(t["a_off"][f]) + int(t["frag_na"][f])].copy() for f in raw_u}
     cur = dict(t); cur["raw_u"] = raw_u; cur["raw_c"] = raw_c; cur.update({k: np.array(v) for k, v in per.items()}); cur["regs"] = np.array(rg)
@@ -73,7 +73,4 @@ bad = np.nonzero(end[:-1] > off[o][1:])[0]
 print("layout: %d overlapping neighbours" % len(bad))
 for b in bad[:5]:
     print("   frag %d [%d,+%d) overlaps frag %d at %d" % (o[b], off[o[b]], na[o[b]], o[b + 1], off[o[b + 1]]))
-pos = int(np.nonzero(o == 3647)[0][0])
-for q in range(max(0, pos - 2), min(nf, pos + 3)):
-    print("   around: frag %d off %d na %d end %d" % (o[q], off[o[q]], na[o[q]], end[q]))
 print("   total anchors %d" % tot)
