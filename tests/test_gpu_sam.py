@@ -325,3 +325,6 @@ def test_token_stage_matches_reference_script_and_aligner(golden_unpacked):
     for extra in ([], ["-K", "3000", "-t", "5"]):
         r = _run([CLI, "tokens", "--read-size", str(m["read_size"]), "--skip", str(m["skip"])] + extra + [m["ref"], m["gaps"]], d)
         assert r.stdout == exp, _diff_report(r.stdout, exp, "g7_tokens")
+    # token batches that "do not fit" are halved like read batches
+    r = _run([CLI, "tokens", "--read-size", str(m["read_size"]), "--skip", str(m["skip"]), m["ref"], m["gaps"]], d, env=dict(os.environ, AL_TEST_NOMEM_ABOVE="11"))
+    assert r.stdout == exp and b"does not fit the device workspaces" in r.stderr
