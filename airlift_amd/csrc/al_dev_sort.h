@@ -1,19 +1,22 @@
 // al_dev_sort.h -- device restatement of the reference's sort (klib ksort.h KRADIX_SORT_INIT), shared by the chain
 // kernels and the region bookkeeping.
+// AL_SORT_HOST compiles the same code for the CPU (tests/test_dev_sort_cpu.py checks it against the oracle's and the reference's sort).
 #pragma once
-#include <hip/hip_runtime.h>
 #include <stdint.h>
-
+#ifdef AL_SORT_HOST
+#define AL_D static inline
+#else
+#include <hip/hip_runtime.h>
 #ifndef AL_D
 #define AL_D __device__ __forceinline__
+#endif
 #endif
 
 // ---- sorts.  The reference uses a stable insertion sort up to 64 elements and an unstable in-place MSD radix sort
 // above (ksort.h:105-151).  Both are restated step for step, so the order the radix permutation leaves among
 // equal keys is the reference's too.  d_rs_sort works through an accessor (key(i), keyof(e), get(i), set(i,e)) so
 // the same code sorts anchors, pairing entries and the chain permutation.
-#define AL_RS_STK 40                                  // pending (>64-element) buckets; disjoint, so n <= 65*AL_RS_STK never overflows
-#define AL_RS_SCRATCH (2 * (512 + 3 * AL_RS_STK))     // bytes of scratch d_rs_sort needs
+#define AL_RS_SCRATCH (2 * (512 + 4 * 8))             // bytes of scratch d_rs_sort needs: bucket bounds + one frame per digit
 template <class A>
 AL_D void d_rs_isort(A &acc, int beg, int end)
 {   // rs_insertsort, ksort.h:105-115
@@ -26,43 +29,52 @@ AL_D void d_rs_isort(A &acc, int beg, int end)
 }
 template <class A>
 AL_D bool d_rs_sort(A &acc, int n, uint16_t *scr)
-{   // radix_sort + rs_sort, ksort.h:116-151 (8-bit digits from bit 56 down).  Returns true if the order could not be
-	// reproduced (more than 65535 elements or more than AL_RS_STK pending buckets): stable order then, caller counts it.
+{   // radix_sort + rs_sort, ksort.h:116-151 (8-bit digits from bit 56 down).  The reference recurses into every bucket of more
+	// than 64 elements with a fresh bucket table on the C stack; here one table is shared: a frame per digit remembers
+	// (range, shift, next bucket), and on return from a child the parent's bounds are recounted from its (already
+	// partitioned) range.  Buckets are disjoint, so the order they are visited in does not change the result.
+	// Returns true if the order could not be reproduced (more than 65535 elements: stable order then, the caller counts it).
 	if (n <= 64) { d_rs_isort(acc, 0, n); return false; }
 	if (n > 65535) { d_rs_isort(acc, 0, n); return true; }
-	uint16_t *bb = scr, *be = scr + 256, *stk = scr + 512;
-	bool bad = false; int sp = 1;
-	stk[0] = 0; stk[1] = (uint16_t)n; stk[2] = 56;
+	uint16_t *bb = scr, *be = scr + 256, *stk = scr + 512;                 // frame: beg, end, shift, next bucket + 1 (0 = not partitioned yet)
+	int sp = 1;
+	stk[0] = 0; stk[1] = (uint16_t)n; stk[2] = 56; stk[3] = 0;
 	while (sp > 0) {
-		--sp;
-		const int beg = stk[3 * sp], end = stk[3 * sp + 1], s = stk[3 * sp + 2];
+		uint16_t *fr = stk + 4 * (sp - 1);
+		const int beg = fr[0], end = fr[1], s = fr[2];
 		for (int k = 0; k < 256; ++k) bb[k] = be[k] = (uint16_t)beg;
 		for (int i = beg; i < end; ++i) ++be[acc.key(i) >> s & 255];
 		for (int k = 1; k < 256; ++k) { be[k] = (uint16_t)(be[k] + be[k - 1] - beg); bb[k] = be[k - 1]; }
-		for (int k = 0; k < 256;) {
-			if (bb[k] != be[k]) {
-				int l = (int)(acc.key(bb[k]) >> s & 255);
-				if (l != k) {
-					typename A::E tmp = acc.get(bb[k]);
-					do {
-						const typename A::E swap = tmp; tmp = acc.get(bb[l]); acc.set(bb[l]++, swap);
-						l = (int)(acc.keyof(tmp) >> s & 255);
-					} while (l != k);
-					acc.set(bb[k]++, tmp);
-				} else ++bb[k];
-			} else ++k;
-		}
-		bb[0] = (uint16_t)beg; for (int k = 1; k < 256; ++k) bb[k] = be[k - 1];
+		int k0 = 0;
+		if (fr[3] == 0) {
+			for (int k = 0; k < 256;) {
+				if (bb[k] != be[k]) {
+					int l = (int)(acc.key(bb[k]) >> s & 255);
+					if (l != k) {
+						typename A::E tmp = acc.get(bb[k]);
+						do {
+							const typename A::E swap = tmp; tmp = acc.get(bb[l]); acc.set(bb[l]++, swap);
+							l = (int)(acc.keyof(tmp) >> s & 255);
+						} while (l != k);
+						acc.set(bb[k]++, tmp);
+					} else ++bb[k];
+				} else ++k;
+			}
+			bb[0] = (uint16_t)beg; for (int k = 1; k < 256; ++k) bb[k] = be[k - 1];
+		} else k0 = fr[3] - 1;                                                // back from a child: bounds recounted above, go on behind it
+		bool descended = false;
 		if (s) {
 			const int s2 = s > 8 ? s - 8 : 0;
-			for (int k = 0; k < 256; ++k) {
+			for (int k = k0; k < 256; ++k) {
 				const int sz = be[k] - bb[k];
 				if (sz > 64) {
-					if (sp < AL_RS_STK) { stk[3 * sp] = bb[k]; stk[3 * sp + 1] = be[k]; stk[3 * sp + 2] = (uint16_t)s2; ++sp; }
-					else { d_rs_isort(acc, bb[k], be[k]); bad = true; }
+					fr[3] = (uint16_t)(k + 2);
+					uint16_t *ch = stk + 4 * sp; ch[0] = bb[k]; ch[1] = be[k]; ch[2] = (uint16_t)s2; ch[3] = 0; ++sp;   // depth <= 8: one frame per digit
+					descended = true; break;
 				} else if (sz > 1) d_rs_isort(acc, bb[k], be[k]);
 			}
 		}
+		if (!descended) --sp;
 	}
-	return bad;
+	return false;
 }
