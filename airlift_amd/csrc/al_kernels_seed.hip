@@ -510,16 +510,39 @@ k_chain(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_off
 	const double avg_d = (double)avg_qspan;
 	CHAIN_SYNC();
 
-#define AX(i) (in_lds ? X[i] : a[i].x)
-#define AQ(i) (in_lds ? Q[i] : (int32_t)a[i].y)
-#define AM(i) (in_lds ? M[i] : ((uint32_t)(a[i].y >> 32 & 0xff) | (uint32_t)((a[i].y & AL_SEED_SEG_MASK) >> AL_SEED_SEG_SHIFT) << 8))
+	// Fragments of more than CAP anchors keep their DP arrays in global memory (the backtrack needs all of them), but a row only
+	// looks back over its predecessor window [st, i): the last RING rows are mirrored in the LDS arrays (slot = row & (RING-1)),
+	// and a row whose window lies inside the mirror reads and marks LDS only -- the dependent global round trips (F, P, mark,
+	// re-read of the mark) that made such rows latency-bound are gone.  Rows with a longer window (tandem arrays: thousands of
+	// predecessors) take the global path; every row writes F / P / V through to global memory.
+	constexpr int RING = 512;
+	static_assert(CAP >= RING, "ring lives in the LDS arrays");
+	const uint32_t msk = in_lds ? 0xffffffffu : (uint32_t)(RING - 1);
+#define LX(j) sx[(uint32_t)(j) & msk]
+#define LQ(j) sq[(uint32_t)(j) & msk]
+#define LM(j) sm[(uint32_t)(j) & msk]
+#define LF(j) sf[(uint32_t)(j) & msk]
+#define LP(j) sp[(uint32_t)(j) & msk]
+#define LT(j) st_[(uint32_t)(j) & msk]
+#define LV(j) sv[(uint32_t)(j) & msk]
+#define AX(i) (lr ? LX(i) : a[i].x)
+#define AQ(i) (lr ? LQ(i) : (int32_t)a[i].y)
+#define AM(i) (lr ? LM(i) : ((uint32_t)(a[i].y >> 32 & 0xff) | (uint32_t)((a[i].y & AL_SEED_SEG_MASK) >> AL_SEED_SEG_SHIFT) << 8))
 
 	int64_t st = 0;
 	for (int64_t i = 0; i < ((P.dbg & 32) ? 0 : n); ++i) {
-		const uint64_t ri = AX(i); const int32_t qi = AQ(i); const uint32_t mi_ = AM(i);
-		const int32_t q_span = mi_ & 0xff, sidi = mi_ >> 8;
-		while (st < i && ri > AX(st) + (uint64_t)max_dist_x) ++st;
+		if (!in_lds && (i & 63) == 0) {                                   // mirror rows i .. i+63 (their slots held rows i-RING .. i-RING+63)
+			CHAIN_SYNC();
+			const int64_t r = i + lane;
+			if (r < n) { const AlAnchor e = a[r]; LX(r) = e.x; LQ(r) = (int32_t)e.y; LM(r) = (uint32_t)(e.y >> 32 & 0xff) | (uint32_t)((e.y & AL_SEED_SEG_MASK) >> AL_SEED_SEG_SHIFT) << 8; LT(r) = -1; }   // no mark yet
+			CHAIN_SYNC();
+		}
+		const uint64_t ri = in_lds ? LX(i) : a[i].x;
+		while (st < i && ri > (in_lds || st >= (i & ~63LL) + 64 - RING ? LX(st) : a[st].x) + (uint64_t)max_dist_x) ++st;
 		if (i - st > max_iter) st = i - max_iter;
+		const bool lr = in_lds || st >= (i & ~63LL) + 64 - RING;            // this row's window is inside the LDS arrays
+		const int32_t qi = AQ(i); const uint32_t mi_ = AM(i);
+		const int32_t q_span = mi_ & 0xff, sidi = mi_ >> 8;
 		int32_t max_f = q_span, n_skip = 0; int64_t max_j = -1; bool broke = false;
 		for (int64_t base = i - 1; base >= st && !broke; base -= 64) {
 			const int64_t j = base - lane;
@@ -541,8 +564,8 @@ k_chain(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_off
 						if (dr == 0) ++s0;
 						else s0 -= c_lin < log_dd ? c_lin : log_dd;
 					} else s0 -= c_lin + (log_dd >> 1);
-					sc = s0 + F[j];
-					pj = Pp[j];
+					sc = s0 + (lr ? LF(j) : F[j]);
+					pj = lr ? LP(j) : Pp[j];
 				} else active = false;
 			}
 			// sequential replay over lanes 0..63 (descending j)
@@ -551,9 +574,10 @@ k_chain(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_off
 			int32_t excl = __shfl_up(ex, 1); if (lane == 0) excl = INT32_MIN;
 			const int32_t before = excl > max_f ? excl : max_f;
 			const bool upd = active && sc > before;
-			if (active && pj >= 0) T[pj] = (int32_t)i;
+			// t[p[j]] = i (chain.c:81).  A mark below st is never tested in this row (and would alias a newer row's slot in the mirror).
+			if (active && pj >= (int32_t)st) { if (lr) LT(pj) = (int32_t)i; else T[pj] = (int32_t)i; }
 			CHAIN_SYNC();
-			const bool marked = active && !upd && T[j] == (int32_t)i;
+			const bool marked = active && !upd && (lr ? LT(j) : T[j]) == (int32_t)i;
 			unsigned long long U = __ballot(upd), K = __ballot(marked);
 			unsigned long long both = U | K; int brk = 64;
 			while (both) {
@@ -569,11 +593,20 @@ k_chain(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_off
 			CHAIN_SYNC();
 		}
 		if (lane == 0) {
-			F[i] = max_f; Pp[i] = (int32_t)max_j;
-			V[i] = max_j >= 0 && V[max_j] > max_f ? V[max_j] : max_f;
+			const int32_t vj = max_j < 0 ? INT32_MIN : (lr ? LV(max_j) : V[max_j]);
+			const int32_t v = max_j >= 0 && vj > max_f ? vj : max_f;
+			if (in_lds) { LF(i) = max_f; LP(i) = (int32_t)max_j; LV(i) = v; }
+			else { F[i] = max_f; Pp[i] = (int32_t)max_j; V[i] = v; LF(i) = max_f; LP(i) = (int32_t)max_j; LV(i) = v; }
 		}
 		CHAIN_SYNC();
 	}
+#undef LX
+#undef LQ
+#undef LM
+#undef LF
+#undef LP
+#undef LT
+#undef LV
 
 	// ---- chain ends, peaks, backtrack (chain.c:87-160): lane 0, O(n) -----------------------------------
 	for (int64_t i = lane; i < n; i += 64) T[i] = 0;
@@ -583,26 +616,52 @@ k_chain(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_off
 	AlAnchor *b = chained + a_off[f];
 	uint64_t *u = u_out + a_off[f] + f;                 // capacity n + 1
 	uint64_t *utmp = in_lds ? s_qm : ws_u64 + a_off[f]; // capacity n (Q/M are dead after the DP)
+	// Peaks (chain.c:87-110) by all lanes: every chain end walks back to its peak on its own; the list of plain 64-bit keys
+	// (score << 32 | anchor index) is sorted next, so the order the lanes append in does not matter.  At most n/2 entries
+	// (a peak needs a predecessor to reach min_sc), which leaves the upper half of utmp[] free as a second buffer.
+	int32_t n_u0 = 0;
+	if (!(P.dbg & 64))
+	for (int64_t i0 = 0; i0 < n; i0 += 64) {
+		const int64_t i = i0 + lane;
+		const bool end = i < n && T[i] == 0 && V[i] >= min_sc;
+		uint64_t key = 0;
+		if (end) {
+			int64_t j = i;
+			while (j >= 0 && F[j] < V[j]) j = Pp[j];
+			if (j < 0) j = i;
+			key = (uint64_t)(uint32_t)F[j] << 32 | (uint64_t)j;
+		}
+		const unsigned long long m = __ballot(end);
+		if (end) utmp[n_u0 + __popcll(m & ((1ULL << lane) - 1ULL))] = key;
+		n_u0 += __popcll(m);
+	}
+	CHAIN_SYNC();
+	const bool rank_sorted = n_u0 > 64 && 2 * (int64_t)n_u0 <= n;
+	if (rank_sorted) {   // descending order: every lane ranks its entries against all others
+		uint64_t *dst = utmp + n_u0;
+		for (int32_t i0 = 0; i0 < n_u0; i0 += 64) {
+			const int32_t i = i0 + lane;
+			if (i < n_u0) { const uint64_t x = utmp[i]; int32_t r = 0; for (int32_t j = 0; j < n_u0; ++j) { const uint64_t y = utmp[j]; r += y > x || (y == x && j < i); } dst[r] = x; }   // equal keys (two ends, one peak) take consecutive ranks
+		}
+		CHAIN_SYNC();
+		for (int32_t i = lane; i < n_u0; i += 64) utmp[i] = dst[i];
+		CHAIN_SYNC();
+	}
+	if (n_u0 > 0) { for (int64_t i = lane; i < n; i += 64) T[i] = 0; }
+	CHAIN_SYNC();
+	// keys / permutation of the chain-ordering sort: for fragments whose DP arrays are in global memory the LDS arrays are free now
+	const bool lds_order = !in_lds;
 	if (lane == 0) {
-		int32_t n_u = 0, n_v = 0, k = 0;
-		if (!(P.dbg & 64))
-		for (int64_t i = 0; i < n; ++i)
-			if (T[i] == 0 && V[i] >= min_sc) {
-				int64_t j = i;
-				while (j >= 0 && F[j] < V[j]) j = Pp[j];
-				if (j < 0) j = i;
-				utmp[n_u++] = (uint64_t)(uint32_t)F[j] << 32 | (uint64_t)j;
-			}
+		int32_t n_u = n_u0, n_v = 0, k = 0;
 		if (n_u > 0) {
 			// keys are unique (distinct j): any sort; descending by insertion / heap sort
 			if (n_u <= 64) {
 				for (int32_t i = 1; i < n_u; ++i) { uint64_t t = utmp[i]; int32_t j = i; while (j > 0 && utmp[j - 1] < t) { utmp[j] = utmp[j - 1]; --j; } utmp[j] = t; }
-			} else {
+			} else if (!rank_sorted) {
 				for (int32_t s0 = (n_u >> 1) - 1; s0 >= 0; --s0) { int32_t i = s0; uint64_t t = utmp[i]; for (;;) { int32_t c = 2 * i + 1; if (c >= n_u) break; if (c + 1 < n_u && utmp[c + 1] > utmp[c]) ++c; if (utmp[c] <= t) break; utmp[i] = utmp[c]; i = c; } utmp[i] = t; }
 				for (int32_t e = n_u - 1; e > 0; --e) { uint64_t t = utmp[e]; utmp[e] = utmp[0]; int32_t i = 0; for (;;) { int32_t c = 2 * i + 1; if (c >= e) break; if (c + 1 < e && utmp[c + 1] > utmp[c]) ++c; if (utmp[c] <= t) break; utmp[i] = utmp[c]; i = c; } utmp[i] = t; }
 				for (int32_t i = 0; i < n_u >> 1; ++i) { uint64_t t = utmp[i]; utmp[i] = utmp[n_u - 1 - i]; utmp[n_u - 1 - i] = t; }
 			}
-			for (int64_t i = 0; i < n; ++i) T[i] = 0;
 			// backtrack; V[] is reused as the visit list v[] (chain.c:113-127)
 			for (int32_t i = 0; i < n_u; ++i) {
 				const int32_t n_v0 = n_v, k0 = k; int64_t j = (int32_t)utmp[i];
@@ -616,16 +675,38 @@ k_chain(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_off
 			// first anchor of chain c = a[V[k0 + ni - 1]].  Pp[] (free now) = chain start offsets into V, T[] = permutation.
 			int32_t off = 0;
 			for (int32_t c = 0; c < n_u; ++c) { Pp[c] = off; off += (int32_t)(uint32_t)utmp[c]; T[c] = c; }
-			// radix_sort_128x (ksort.h:147-151) on the permutation T[]: stable insertion up to 64 chains, the reference's
+		}
+		s_nu = n_u;
+	}
+	CHAIN_SYNC();
+	const bool use_lds_order = lds_order && s_nu > 1 && s_nu <= CAP;
+	if (use_lds_order) {   // first-anchor positions once, by all lanes, instead of three dependent global loads per comparison
+		for (int32_t c = lane; c < s_nu; c += 64) { sx[c] = a[V[Pp[c] + (int32_t)(uint32_t)utmp[c] - 1]].x; sp[c] = c; }
+	}
+	CHAIN_SYNC();
+	if (lane == 0) {
+		const int32_t n_u = s_nu;
+		if (n_u > 0) {
+			// radix_sort_128x (ksort.h:147-151) on the permutation: stable insertion up to 64 chains, the reference's
 			// radix permutation above (its order among equal first-anchor positions is reproduced, not just flagged).
-			ChainOrderAcc acc{T, V, Pp, utmp, X, a, in_lds};
-			const bool tie = d_rs_sort(acc, n_u, s_rs);
+			bool tie;
+			if (use_lds_order) {
+				struct { typedef int32_t E; int32_t *t; const uint64_t *k;
+				         __device__ __forceinline__ uint64_t keyof(const int32_t &c) const { return k[c]; }
+				         __device__ __forceinline__ uint64_t key(int i) const { return k[t[i]]; }
+				         __device__ __forceinline__ int32_t get(int i) const { return t[i]; }
+				         __device__ __forceinline__ void set(int i, const int32_t &c) { t[i] = c; } } acc{sp, sx};
+				tie = d_rs_sort(acc, n_u, s_rs);
+				for (int32_t i = 0; i < n_u; ++i) T[i] = sp[i];
+			} else {
+				ChainOrderAcc acc{T, V, Pp, utmp, X, a, in_lds};
+				tie = d_rs_sort(acc, n_u, s_rs);
+			}
 			if (tie) atomicAdd(&counters[1], 1ULL);
 			int32_t o = 0;
 			for (int32_t i = 0; i < n_u; ++i) { const int32_t c = T[i]; u[i] = utmp[c]; F[i] = o; o += (int32_t)(uint32_t)utmp[c]; }   // F[] = output offset of sorted chain i
 		}
 		frag_nu[f] = (uint32_t)n_u;
-		s_nu = n_u;
 	}
 	CHAIN_SYNC();
 	{   // copy-out of the chained anchors by the whole wave: b[F[i] + j] = a[V[k0 + ni - 1 - j]]

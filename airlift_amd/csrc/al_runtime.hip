@@ -9,6 +9,7 @@
 #include "al_internal.h"
 #include "al_device.h"
 #include "al_runtime.h"
+#include "al_dev_sort.h"
 #include "al_io.h"
 
 // kernels (al_kernels_seed.hip)

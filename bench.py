@@ -27,6 +27,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 WORKLOADS = {"c2": "C2: yeast-sized synthetic reference pair (16 contigs, 12.16 Mbp, 150 planted duplications)",
+             "c2r": "C2R: the C2 reference plus an interspersed 300 bp element family (4000 copies, 10 % divergence, ~10 % of the sequence)",
              "c3": "C3: ce11-sized synthetic reference (6 contigs, 100.3 Mbp, 3000 planted repeats)",
              "c4": "C4: human-sized synthetic reference (24 contigs, 3.1 Gbp, 20000 planted duplications, 2 % N)"}
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured streaming ceiling
@@ -120,7 +121,7 @@ def main():
     ap.add_argument("--cpu-sample-pairs", type=int, default=1_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ins-mean", type=int, default=0, help="mean insert size override (short inserts make the mates overlap: equal-key anchors)")
-    ap.add_argument("--config", default="c2", help="synthetic reference of tools/gen_synth.py: c2 (BASELINE configs[1], default), c3 (100 Mbp), c4 (3.1 Gbp)")
+    ap.add_argument("--config", default="c2", help="synthetic reference of tools/gen_synth.py: c2 (BASELINE configs[1], default), c2r (c2 + high-copy element family), c3 (100 Mbp), c4 (3.1 Gbp)")
     a = ap.parse_args()
 
     import torch

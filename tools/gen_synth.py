@@ -15,7 +15,7 @@ COMP = np.array([3, 2, 1, 0, 4], dtype=np.uint8)
 
 
 def make_reference(seed, n_contigs, total_len, n_dups=0, dup_len=(2000, 6000), dup_div=0.02,
-                   n_frac=0.0, tandem=0):
+                   n_frac=0.0, tandem=0, family=None):
     """Uniform ACGT contigs with planted diverged duplications (and optional N blocks / tandem repeats)."""
     rng = np.random.default_rng(seed)
     clen = total_len // n_contigs
@@ -37,6 +37,16 @@ def make_reference(seed, n_contigs, total_len, n_dups=0, dup_len=(2000, 6000), d
         s = int(rng.integers(0, clen - unit * cn))
         u = rng.integers(0, 4, size=unit, dtype=np.uint8)
         contigs[c][s:s + unit * cn] = np.tile(u, cn)
+    if family:   # an interspersed high-copy element family (copies, unit length, divergence per copy), Alu-like
+        copies, ulen, div = family
+        unit = rng.integers(0, 4, size=ulen, dtype=np.uint8)
+        for _ in range(copies):
+            c = contigs[int(rng.integers(0, n_contigs))]
+            if len(c) <= ulen + 2:
+                continue
+            p0 = int(rng.integers(0, len(c) - ulen)); u = unit.copy(); m = rng.random(ulen) < div
+            u[m] = (u[m] + rng.integers(1, 4, size=int(m.sum()), dtype=np.uint8)) & 3
+            c[p0:p0 + ulen] = u
     if n_frac > 0:
         for c in contigs:
             L = int(len(c) * n_frac)
@@ -126,6 +136,9 @@ CONFIGS = {
     # name: (ref kwargs, read kwargs)
     "c1": (dict(seed=2026, n_contigs=16, total_len=12_160_000, n_dups=150), dict(n_pairs=100_000, read_len=100, single_end=True, del_frac=0.0)),
     "c2": (dict(seed=2026, n_contigs=16, total_len=12_160_000, n_dups=150), dict(n_pairs=2_000_000, read_len=150)),
+    # C2 plus an interspersed element family covering ~10 % of the reference (4000 copies x 300 bp, 10 % divergence per copy):
+    # minimizers above mid_occ, the max_occ re-chain pass, thousands of anchors for the fragments inside copies
+    "c2r": (dict(seed=2026, n_contigs=16, total_len=12_160_000, n_dups=150, family=(4000, 300, 0.10)), dict(n_pairs=2_000_000, read_len=150)),
     "c3": (dict(seed=2027, n_contigs=6, total_len=100_300_000, n_dups=3000, dup_len=(100, 5000), dup_div=0.03), dict(n_pairs=5_000_000, read_len=150)),
     # human-sized scale test (uniform sequence + planted diverged duplications + N blocks; not a repeat-structure model of GRCh38)
     "c4": (dict(seed=2028, n_contigs=24, total_len=3_100_000_000, n_dups=20000, dup_len=(300, 6000), dup_div=0.05, n_frac=0.02), dict(n_pairs=50_000_000, read_len=150)),
