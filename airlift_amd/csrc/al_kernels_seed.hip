@@ -459,9 +459,9 @@ k_chain(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_off
         int32_t *__restrict__ ws_i32 /* 4 ints per anchor */, uint64_t *__restrict__ ws_u64 /* 1 per anchor */,
         const uint32_t *__restrict__ frag_list, int n_list, AlParams P, unsigned long long *__restrict__ counters, int min_n)
 {
-	__shared__ uint64_t sx[CAP];
-	__shared__ uint64_t s_qm[CAP];                       // Q (int32) and M (u32) halves during the DP; chain list (u64) in the tail
-	__shared__ int32_t sf[CAP], sp[CAP], st_[CAP], sv[CAP];
+	__shared__ uint64_t s_all[4 * CAP];                  // one block, so that the backtrack of a large fragment can use all of it
+	uint64_t *const sx = s_all, *const s_qm = s_all + CAP;   // s_qm: Q (int32) and M (u32) halves during the DP; chain list (u64) in the tail
+	int32_t *const sf = (int32_t *)(s_all + 2 * CAP), *const sp = sf + CAP, *const st_ = sp + CAP, *const sv = st_ + CAP;
 	__shared__ int32_t s_nu;
 	__shared__ uint16_t s_rs[AL_RS_SCRATCH / 2];         // work area of the > 64-chain ordering sort
 	int32_t *sq = (int32_t *)s_qm; uint32_t *sm = (uint32_t *)s_qm + CAP;
@@ -647,7 +647,14 @@ k_chain(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_off
 		for (int32_t i = lane; i < n_u0; i += 64) utmp[i] = dst[i];
 		CHAIN_SYNC();
 	}
-	if (n_u0 > 0) { for (int64_t i = lane; i < n; i += 64) T[i] = 0; }
+	// Backtrack (lane 0, one dependent load per visited anchor): for a fragment whose arrays are in global memory the predecessor
+	// indices and the visit marks are staged in LDS (free after the DP) when they fit: 5 bytes per anchor.
+	const bool stage_bt = !in_lds && 5 * n <= (int64_t)(32 * CAP);
+	int32_t *const bP = (int32_t *)s_all; uint8_t *const bT = (uint8_t *)(bP + n);
+	if (n_u0 > 0) {
+		if (stage_bt) { for (int64_t i = lane; i < n; i += 64) { bP[i] = Pp[i]; bT[i] = 0; } }
+		else { for (int64_t i = lane; i < n; i += 64) T[i] = 0; }
+	}
 	CHAIN_SYNC();
 	// keys / permutation of the chain-ordering sort: for fragments whose DP arrays are in global memory the LDS arrays are free now
 	const bool lds_order = !in_lds;
@@ -665,7 +672,8 @@ k_chain(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_off
 			// backtrack; V[] is reused as the visit list v[] (chain.c:113-127)
 			for (int32_t i = 0; i < n_u; ++i) {
 				const int32_t n_v0 = n_v, k0 = k; int64_t j = (int32_t)utmp[i];
-				do { V[n_v++] = (int32_t)j; T[j] = 1; j = Pp[j]; } while (j >= 0 && T[j] == 0);
+				if (stage_bt) { do { V[n_v++] = (int32_t)j; bT[j] = 1; j = bP[j]; } while (j >= 0 && bT[j] == 0); }
+				else { do { V[n_v++] = (int32_t)j; T[j] = 1; j = Pp[j]; } while (j >= 0 && T[j] == 0); }
 				if (j < 0) { if (n_v - n_v0 >= min_cnt) utmp[k++] = utmp[i] >> 32 << 32 | (uint32_t)(n_v - n_v0); }
 				else if ((int32_t)(utmp[i] >> 32) - F[j] >= min_sc) { if (n_v - n_v0 >= min_cnt) utmp[k++] = (uint64_t)((utmp[i] >> 32) - (uint64_t)(uint32_t)F[j]) << 32 | (uint32_t)(n_v - n_v0); }
 				if (k0 == k) n_v = n_v0;
