@@ -41,7 +41,18 @@ AL_D bool d_rs_sort(A &acc, int n, uint16_t *scr)
 	stk[0] = 0; stk[1] = (uint16_t)n; stk[2] = 56; stk[3] = 0;
 	while (sp > 0) {
 		uint16_t *fr = stk + 4 * (sp - 1);
-		const int beg = fr[0], end = fr[1], s = fr[2];
+		const int beg = fr[0], end = fr[1];
+		if (fr[3] == 0) {
+			// A digit that all keys of the range share gives one bucket holding the whole range, an identity permutation and a
+			// recursion into the same range at the next digit (or nothing at the last digit): go straight to the highest digit
+			// in which the keys differ.  Equal keys throughout: every remaining level is such an identity.
+			const uint64_t k0 = acc.key(beg); uint64_t diff = 0;
+			for (int i = beg + 1; i < end; ++i) diff |= acc.key(i) ^ k0;
+			if (diff == 0) { --sp; continue; }
+			const int top = (63 - __builtin_clzll(diff)) & ~7;
+			if (top < (int)fr[2]) fr[2] = (uint16_t)top;
+		}
+		const int s = fr[2];
 		for (int k = 0; k < 256; ++k) bb[k] = be[k] = (uint16_t)beg;
 		for (int i = beg; i < end; ++i) ++be[acc.key(i) >> s & 255];
 		for (int k = 1; k < 256; ++k) { be[k] = (uint16_t)(be[k] + be[k - 1] - beg); bb[k] = be[k - 1]; }

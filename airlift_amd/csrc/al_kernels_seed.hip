@@ -657,7 +657,6 @@ k_chain(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_off
 	}
 	CHAIN_SYNC();
 	// keys / permutation of the chain-ordering sort: for fragments whose DP arrays are in global memory the LDS arrays are free now
-	const bool lds_order = !in_lds;
 	if (lane == 0) {
 		int32_t n_u = n_u0, n_v = 0, k = 0;
 		if (n_u > 0) {
@@ -687,37 +686,66 @@ k_chain(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_off
 		s_nu = n_u;
 	}
 	CHAIN_SYNC();
-	const bool use_lds_order = lds_order && s_nu > 1 && s_nu <= CAP;
-	if (use_lds_order) {   // first-anchor positions once, by all lanes, instead of three dependent global loads per comparison
-		for (int32_t c = lane; c < s_nu; c += 64) { sx[c] = a[V[Pp[c] + (int32_t)(uint32_t)utmp[c] - 1]].x; sp[c] = c; }
+	// Chain order (chain.c:144-160).  The key of chain c is the position of its first anchor, a[V[Pp[c] + len - 1]].x: three to four
+	// dependent loads, and the sorts compare keys O(n_u^2) times -- so the keys are computed once, by all lanes, into LDS, and up
+	// to 64 chains (almost every fragment) are put in order by the wavefront itself: the rank of a chain among (key, index) pairs
+	// is its place after the reference's stable insertion sort (ksort.h:149).  More chains: lane 0 runs the radix restatement.
+	const int32_t n_u1 = s_nu;
+	uint64_t *keysL = nullptr; int32_t *permL = nullptr;
+	if (n_u1 > 1) {
+		if (!in_lds && n_u1 <= CAP) { keysL = sx; permL = sp; }                       // DP arrays in global memory: LDS is free
+		else if (in_lds && 2 * n_u1 <= CAP) { keysL = s_qm + n_u1; permL = st_; }     // behind the chain list; the permutation is T[]
+	}
+	const bool use_lds_order = keysL != nullptr && !in_lds;                          // per-chain records in LDS too (see the copy-out)
+	if (keysL) {
+		for (int32_t c = lane; c < n_u1; c += 64) {
+			const uint64_t uc = utmp[c]; const int32_t k0 = Pp[c], idx = V[k0 + (int32_t)(uint32_t)uc - 1];
+			keysL[c] = in_lds ? X[idx] : a[idx].x;
+			if (!in_lds) { permL[c] = c; s_qm[c] = uc; sf[c] = k0; }
+		}
+		CHAIN_SYNC();
+		if (n_u1 <= 64) {
+			if (lane < n_u1) {
+				const uint64_t kx = keysL[lane]; int32_t r = 0;
+				for (int32_t j = 0; j < n_u1; ++j) { const uint64_t kj = keysL[j]; r += kj < kx || (kj == kx && j < lane); }
+				permL[r] = lane;
+			}
+		}
 	}
 	CHAIN_SYNC();
 	if (lane == 0) {
-		const int32_t n_u = s_nu;
+		const int32_t n_u = n_u1;
 		if (n_u > 0) {
-			// radix_sort_128x (ksort.h:147-151) on the permutation: stable insertion up to 64 chains, the reference's
-			// radix permutation above (its order among equal first-anchor positions is reproduced, not just flagged).
-			bool tie;
-			if (use_lds_order) {
-				struct { typedef int32_t E; int32_t *t; const uint64_t *k;
-				         __device__ __forceinline__ uint64_t keyof(const int32_t &c) const { return k[c]; }
-				         __device__ __forceinline__ uint64_t key(int i) const { return k[t[i]]; }
-				         __device__ __forceinline__ int32_t get(int i) const { return t[i]; }
-				         __device__ __forceinline__ void set(int i, const int32_t &c) { t[i] = c; } } acc{sp, sx};
-				tie = d_rs_sort(acc, n_u, s_rs);
-				for (int32_t i = 0; i < n_u; ++i) T[i] = sp[i];
-			} else {
+			bool tie = false;
+			if (keysL) {
+				if (n_u > 64) {   // radix_sort_128x above 64 entries (ksort.h:147-151): its order among equal keys is reproduced
+					struct { typedef int32_t E; int32_t *t; const uint64_t *k;
+					         __device__ __forceinline__ uint64_t keyof(const int32_t &c) const { return k[c]; }
+					         __device__ __forceinline__ uint64_t key(int i) const { return k[t[i]]; }
+					         __device__ __forceinline__ int32_t get(int i) const { return t[i]; }
+					         __device__ __forceinline__ void set(int i, const int32_t &c) { t[i] = c; } } acc{permL, keysL};
+					tie = d_rs_sort(acc, n_u, s_rs);
+				}
+			} else if (n_u > 1) {
 				ChainOrderAcc acc{T, V, Pp, utmp, X, a, in_lds};
 				tie = d_rs_sort(acc, n_u, s_rs);
 			}
-			if (tie) atomicAdd(&counters[1], 1ULL);
 			int32_t o = 0;
-			for (int32_t i = 0; i < n_u; ++i) { const int32_t c = T[i]; u[i] = utmp[c]; F[i] = o; o += (int32_t)(uint32_t)utmp[c]; }   // F[] = output offset of sorted chain i
+			if (use_lds_order) { for (int32_t i = 0; i < n_u; ++i) { st_[i] = o; o += (int32_t)(uint32_t)s_qm[sp[i]]; } }                // st_[] = output offset of sorted chain i
+			else { for (int32_t i = 0; i < n_u; ++i) { const int32_t c = T[i]; u[i] = utmp[c]; F[i] = o; o += (int32_t)(uint32_t)utmp[c]; } }   // F[] = output offset of sorted chain i
+			if (tie) atomicAdd(&counters[1], 1ULL);
 		}
 		frag_nu[f] = (uint32_t)n_u;
 	}
 	CHAIN_SYNC();
-	{   // copy-out of the chained anchors by the whole wave: b[F[i] + j] = a[V[k0 + ni - 1 - j]]
+	if (use_lds_order) {   // many short chains: a lane per chain
+		const int32_t n_u = s_nu;
+		for (int32_t i = lane; i < n_u; i += 64) {
+			const int32_t c = sp[i]; const uint64_t uc = s_qm[c]; const int32_t ni = (int32_t)(uint32_t)uc, k0 = sf[c], o = st_[i];
+			u[i] = uc;
+			for (int32_t j = 0; j < ni; ++j) b[o + j] = a[V[k0 + (ni - j - 1)]];
+		}
+	} else {   // copy-out of the chained anchors by the whole wave: b[F[i] + j] = a[V[k0 + ni - 1 - j]]
 		const int32_t n_u = s_nu;
 		for (int32_t i = 0; i < n_u; ++i) {
 			const int32_t c = T[i], ni = (int32_t)(uint32_t)utmp[c], k0 = Pp[c], o = F[i];
