@@ -171,3 +171,39 @@ def test_cli_count_candidates_matches_the_unmodified_fork(golden_unpacked, name)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     assert r.stdout == b""
     assert ("Total No. of Mappings before alignment (verification): %d" % m["count"]).encode() in r.stderr, r.stderr.decode()[-500:]
+
+
+def test_rechain_pass_layout_and_run_to_run_determinism(A):
+    """Reads inside a high-copy element: most fragments are re-chained with max_occ (map.c:353-375).  The second-pass anchor
+    offsets must grow with the fragment id (the chain list of fragment f lives at a_off[f] + f), and two runs of the same batch
+    must give the same chains for every fragment (the re-chain list is built with an atomic append; it is sorted before use)."""
+    import hashlib, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import gen_synth as g
+    ref = g.make_reference(seed=5, n_contigs=2, total_len=900_000, n_dups=4, family=(1500, 200, 0.0))   # copies above mid_occ = 1000
+    r1, r2 = g.simulate_pairs(ref, 3000, 150, seed=9, ins_mean=400, ins_sd=40, ins_lo=150, ins_hi=800)
+    lut = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    seqs, names, n_segs = [], [], []
+    for i in range(len(r1)):
+        n_segs.append(2); seqs += [lut[r1[i]].tobytes(), lut[r2[i]].tobytes()]; names += [b"r%d" % i, b"r%d" % i]
+    idx = A.Index(seqs=[lut[c].tobytes() for _, c in ref], names=[n.encode() for n, _ in ref])
+    ctx = A.Context(idx)
+    nf = len(n_segs); digests = []
+    for it in range(3):
+        ctx.upload(n_segs, seqs, names); ctx.run()
+        st = ctx.stat(); tot = int(st.n_anchor)
+        off = ctx.tap("a_off", np.uint64, nf + 1).astype(np.int64); off1 = ctx.tap("a_off_p1", np.uint64, nf + 1).astype(np.int64)
+        na = ctx.tap("frag_na", np.uint32, nf).astype(np.int64); nu = ctx.tap("frag_nu", np.uint32, nf).astype(np.int64)
+        chained = ctx.tap("chained", np.uint64, tot * 2).reshape(-1, 2); u = ctx.tap("u", np.uint64, tot + nf + 1)
+        assert st.n_rechain > 100, "the workload is meant to exercise the re-chain pass (%d)" % st.n_rechain
+        re = np.nonzero(off[:nf] != off1[:nf])[0]                     # re-chained fragments got new offsets
+        assert len(re) == st.n_rechain and (np.diff(off[re]) > 0).all(), "second-pass offsets must ascend with the fragment id"
+        o = np.argsort(off[:nf], kind="stable")
+        assert (off[o][:-1] + na[o][:-1] <= off[o][1:]).all()
+        d = []
+        for f in range(nf):
+            uu = u[off[f] + f: off[f] + f + nu[f]]; nc = int((uu & 0xffffffff).sum())
+            d.append(hashlib.md5(uu.tobytes() + chained[off[f]: off[f] + nc].tobytes()).hexdigest())
+        digests.append(d)
+    assert digests[0] == digests[1] == digests[2]
+    ctx.close(); idx.close()
