@@ -111,3 +111,9 @@ enum AlStage { ST_SKETCH = 0, ST_SEED, ST_SCAN, ST_ORDER, ST_ANCHOR_SORT_S, ST_A
                ST_REGS, ST_EXT_PREP, ST_EXT_SORT, ST_EXT_DP_LANE, ST_EXT_DP_G4, ST_EXT_DP_G8, ST_EXT_DP_G22, ST_EXT_FINISH, ST_COMPACT, ST_N };
 #define ST_CHAIN ST_CHAIN_WAVE
 #define ST_EXT_DP ST_EXT_DP_G22
+
+// anchors per fragment the wavefront-per-fragment chaining kernel keeps entirely in LDS (32 bytes each); larger fragments keep
+// their DP arrays in global memory and mirror the most recent rows
+#ifndef AL_CHAIN_CAP
+#define AL_CHAIN_CAP 384
+#endif

@@ -515,7 +515,7 @@ k_chain(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_off
 	// and a row whose window lies inside the mirror reads and marks LDS only -- the dependent global round trips (F, P, mark,
 	// re-read of the mark) that made such rows latency-bound are gone.  Rows with a longer window (tandem arrays: thousands of
 	// predecessors) take the global path; every row writes F / P / V through to global memory.
-	constexpr int RING = 512;
+	constexpr int RING = CAP >= 512 ? 512 : 256;
 	static_assert(CAP >= RING, "ring lives in the LDS arrays");
 	const uint32_t msk = in_lds ? 0xffffffffu : (uint32_t)(RING - 1);
 #define LX(j) sx[(uint32_t)(j) & msk]
@@ -959,7 +959,7 @@ INST_CHAIN_LDS(16, 64) INST_CHAIN_LDS(24, 64) INST_CHAIN_LDS(32, 64) INST_CHAIN_
 
 // explicit instantiations used by the runtime
 template __global__ void k_anchor_sort<1024>(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, uint32_t *, unsigned int *, const uint32_t *, int, unsigned long long *, int);
-template __global__ void k_chain<768>(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, AlAnchor *, uint64_t *, uint32_t *, int32_t *, uint64_t *, const uint32_t *, int, AlParams, unsigned long long *, int);
+template __global__ void k_chain<AL_CHAIN_CAP>(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, AlAnchor *, uint64_t *, uint32_t *, int32_t *, uint64_t *, const uint32_t *, int, AlParams, unsigned long long *, int);
 
 // rechain decision (map.c:353-375): one lane per fragment; appends fragments that must be re-seeded with max_occ
 extern "C" __global__ void __launch_bounds__(256)

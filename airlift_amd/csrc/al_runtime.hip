@@ -26,7 +26,7 @@ template <int CAPL, int LANES> __global__ void k_chain_lds(const AlAnchor *, con
 static const char *g_stage_names[ST_N] = { "sketch", "seed_lookup", "scan", "size_order", "anchor_sort_small", "anchor_sort", "chain_lds32", "chain_lds48", "chain_lds64", "chain_lds128", "chain_wave", "rechain",
                                            "regs", "ext_prep", "ext_sort", "ext_dp_lane", "ext_dp_g4", "ext_dp_g8", "ext_dp_g22", "ext_finish", "compact" };
 // kernel behind each interval (what rocprofv3 --kernel-trace lists); "" = several small launches
-static const char *g_stage_kernels[ST_N] = { "k_sketch", "k_seed", "", "", "k_anchor_sort_small", "k_anchor_sort<1024>", "k_chain_lds<16|24|32, 64>", "k_chain_lds<40|48, 64>", "k_chain_lds<64, 64>", "k_chain_lds<80|96, 64>, <128, 32>", "k_chain<768>", "",
+static const char *g_stage_kernels[ST_N] = { "k_sketch", "k_seed", "", "", "k_anchor_sort_small", "k_anchor_sort<1024>", "k_chain_lds<16|24|32, 64>", "k_chain_lds<40|48, 64>", "k_chain_lds<64, 64>", "k_chain_lds<80|96, 64>, <128, 32>", "k_chain<384>", "",
                                              "k_regs", "k_ext_prep", "", "k_ext_dp_lane<16|32, 64>", "k_ext_dp<1|2|4, 512, ..>", "k_ext_dp<8, 512, 128>", "k_ext_dp<22, 512, 352>", "k_ext_finish", "k_compact" };
 extern "C" const char *al_stage_kernel(int i) { return i >= 0 && i < ST_N ? g_stage_kernels[i] : ""; }
 extern "C" const char *al_stage_name(int i) { return i >= 0 && i < ST_N ? g_stage_names[i] : ""; }
@@ -332,7 +332,7 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 			// wave-per-fragment kernel: the rest of the size-ordered list (or, unsorted, the wavefront-groups the LDS kernels do not own)
 			const uint32_t tail = sorted && lane_max > 0 ? lb129 : 0;
 			const int nt = nl - (int)tail;
-			if (nt > 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<768>), dim3(nt), dim3(64), 0, s, c->anchors.p, c->a_off.p, c->frag_na.p, c->frag_first.p, c->rd_len.p, c->chained.p, c->u.p, c->frag_nu.p,
+			if (nt > 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<AL_CHAIN_CAP>), dim3(nt), dim3(64), 0, s, c->anchors.p, c->a_off.p, c->frag_na.p, c->frag_first.p, c->rd_len.p, c->chained.p, c->u.p, c->frag_nu.p,
 			                   c->ws_i32.p, c->ws_u64.p, order ? order + tail : nullptr, nt, c->P, c->counters.p, sorted ? 0 : lane_max);
 		}
 	}
