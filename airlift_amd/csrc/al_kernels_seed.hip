@@ -11,6 +11,8 @@
 #include "al_internal.h"
 #include "al_device.h"
 #include "al_dev_sort.h"
+#include <rocprim/warp/warp_scan.hpp>
+typedef rocprim::warp_scan<int32_t, 64> ChainWarpScan;
 
 // =============================================================================================
 // K1: sketch.  One lane per read runs the reference's streaming window algorithm verbatim (so ties,
@@ -463,6 +465,7 @@ k_chain(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_off
 	uint64_t *const sx = s_all, *const s_qm = s_all + CAP;   // s_qm: Q (int32) and M (u32) halves during the DP; chain list (u64) in the tail
 	int32_t *const sf = (int32_t *)(s_all + 2 * CAP), *const sp = sf + CAP, *const st_ = sp + CAP, *const sv = st_ + CAP;
 	__shared__ int32_t s_nu;
+	__shared__ typename ChainWarpScan::storage_type s_scan;
 	__shared__ uint16_t s_rs[AL_RS_SCRATCH / 2];         // work area of the > 64-chain ordering sort
 	int32_t *sq = (int32_t *)s_qm; uint32_t *sm = (uint32_t *)s_qm + CAP;
 	const int lane = threadIdx.x;
@@ -569,9 +572,8 @@ k_chain(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_off
 				} else active = false;
 			}
 			// sequential replay over lanes 0..63 (descending j)
-			int32_t ex = sc;                                                  // inclusive prefix max -> exclusive
-			for (int d = 1; d < 64; d <<= 1) { int32_t t = __shfl_up(ex, d); if (lane >= d && t > ex) ex = t; }
-			int32_t excl = __shfl_up(ex, 1); if (lane == 0) excl = INT32_MIN;
+			int32_t excl;                                                     // exclusive prefix max over the lower lanes (DPP row shifts, not LDS permutes)
+			ChainWarpScan().exclusive_scan(sc, excl, INT32_MIN, s_scan, rocprim::maximum<int32_t>());
 			const int32_t before = excl > max_f ? excl : max_f;
 			const bool upd = active && sc > before;
 			// t[p[j]] = i (chain.c:81).  A mark below st is never tested in this row (and would alias a newer row's slot in the mirror).
