@@ -3,9 +3,11 @@
 
 A "step" is one pass of the whole hot path (minimizer sketch -> seed lookup -> anchor sort -> chaining ->
 banded SW extension -> MAPQ/pairing -> alignment records) over one batch of synthetic 150 bp paired-end reads that is
-already resident in HBM.  Workload at N=1: BASELINE.json configs[1] (yeast-sized reference pair, 150 bp PE; the
-synthetic stand-in C2 of SURVEY.md 8(d), generated here with fixed seeds).  N>1: one process per GPU, reads sharded by
-rank (every rank holds the full index; weak scaling), one 16-byte RCCL all-gather per step for the merged-output offsets.
+already resident in HBM.  Workload at N=1: the configuration BASELINE.json's metric is quoted on -- synthetic 150 bp
+paired-end reads against a ~3 Gb reference (3.1 Gbp, 45 % repeat content from 200 families, 5 % N,
+mason-like reads; generated here with fixed seeds; it fits one GPU: 23 GB index).  --config c2/c3/c5 select the other
+BASELINE configs.  N>1: one process per GPU, reads sharded by rank (every rank holds the full index; weak scaling), one
+16-byte RCCL all-gather per step for the merged-output offsets.
 
     python bench.py --gpus 1 --steps 5 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
@@ -28,24 +30,33 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 WORKLOADS = {"c2": "C2: yeast-sized synthetic reference pair (16 contigs, 12.16 Mbp, 150 planted duplications)",
              "c2r": "C2R: the C2 reference plus an interspersed 300 bp element family (4000 copies, 10 % divergence, ~10 % of the sequence)",
-             "c3": "C3: ce11-sized synthetic reference (6 contigs, 100.3 Mbp, 3000 planted repeats)",
-             "c4": "C4: human-sized synthetic reference (24 contigs, 3.1 Gbp, 20000 planted duplications, 2 % N)"}
+             "c3": "C3 (SURVEY 8d): ce11-sized synthetic reference (6 contigs, 100.3 Mbp, 3 % of the sequence in 100-5000 bp repeats, copy number 2-50, 1-5 % divergence), mason-like reads",
+             "c4": "C4 (SURVEY 8d): GRCh38-sized synthetic reference (24 contigs, 3.1 Gbp, 5 % N blocks, 45 % repeat content from 200 families: Alu-like 300 bp up to 1e5 copies, L1-like 6 kb up to 1e3 copies, 0-15 % divergence), mason-like reads (SNP 1e-3, indel 2e-4 <= 10 bp, error ramp 0.2 -> 1 %)",
+             "c5": "C5 (SURVEY 8d): the C4 reference, 250 bp PE, insert N(550, 60)",
+             "c4s": "C4S: the C4 repeat model at 1/10 of the size (310 Mbp; copy numbers scaled with the length)",
+             "c3u": "C3U: 100.3 Mbp uniform reference + 3000 planted duplications (round 1)",
+             "c4u": "C4U: 3.1 Gbp uniform reference + 20000 planted duplications, 2 % N (round 1)"}
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured streaming ceiling
 
 
-def make_workload(pairs, read_len, seed, ref, ins_mean=None):
-    """ASCII reads for `pairs` fragments, concatenated fragment-major (mate1, mate2, mate1, ...)."""
+def make_workload(config, pairs, read_len, seed, ref, ins_mean=None):
+    """ASCII reads for `pairs` fragments, concatenated fragment-major (mate1, mate2, mate1, ...); the config's read model
+    (tools/gen_synth.py: mason-like for C3..C5), 250 k-pair chunks simulated on host threads (seed + first pair index)."""
     import gen_synth as g
-    lut = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    from concurrent.futures import ThreadPoolExecutor
+    tr = bytes.maketrans(bytes(range(5)), b"ACGTN")
     out = np.empty((pairs, 2, read_len), dtype=np.uint8)
     chunk = 250_000
-    for s in range(0, pairs, chunk):
+    over = dict(ins_mean=ins_mean, ins_sd=max(1, ins_mean // 10)) if ins_mean else {}
+
+    def one(s):
         n = min(chunk, pairs - s)
-        kw = dict(ins_mean=550, ins_sd=60, ins_hi=1000) if read_len >= 200 else {}      # SURVEY 8d C5: 250 bp PE, insert N(550,60)
-        if ins_mean:
-            kw = dict(ins_mean=ins_mean, ins_sd=ins_mean // 10, ins_hi=1000)
-        r1, r2 = g.simulate_pairs(ref, n, read_len, seed=seed + s, **kw)
-        out[s:s + n, 0] = lut[r1]; out[s:s + n, 1] = lut[r2]
+        r1, r2 = g.simulate(config, ref, n, seed + s, read_len=read_len, **over)
+        out[s:s + n, 0] = np.frombuffer(r1.tobytes().translate(tr), dtype=np.uint8).reshape(n, read_len)
+        out[s:s + n, 1] = np.frombuffer(r2.tobytes().translate(tr), dtype=np.uint8).reshape(n, read_len)
+
+    with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
+        list(ex.map(one, range(0, pairs, chunk)))
     return out
 
 
@@ -56,28 +67,23 @@ def write_fastq_sample(path, arr, mate, prefix="realigned_"):
         f.write(b"".join(b"@" + (prefix + str(i)).encode() + b"\n" + arr[i, mate].tobytes() + b"\n+\n" + q + b"\n" for i in range(n)))
 
 
-def cpu_baseline(tmp, ref_fa, arr, n_pairs):
+def cpu_baseline(tmp, ref_fa, arr, n_pairs, read_len):
     """Times the CPU comparator on a bounded sample of the same workload (rank 0, N=1 only), then the drop-in CLI on the
-    same files: end-to-end wall clock (FASTA + FASTQ in, SAM out) and byte identity of the two SAM streams."""
+    same files: end-to-end wall clock (FASTA + FASTQ in, SAM out) and byte identity of the two SAM streams.
+    The reference build (oracle/_ref/mm2ref) maps the sample once per thread count of a sweep inside ONE process (index
+    built once, its time reported apart); the best point is the baseline."""
     import hashlib
+    import re
     cores = os.cpu_count() or 1
     write_fastq_sample(os.path.join(tmp, "cb_1.fq"), arr[:n_pairs], 0)
     write_fastq_sample(os.path.join(tmp, "cb_2.fq"), arr[:n_pairs], 1)
-    write_fastq_sample(os.path.join(tmp, "one_1.fq"), arr[:1], 0)
-    write_fastq_sample(os.path.join(tmp, "one_2.fq"), arr[:1], 1)
     ref_bin = os.path.join(ROOT, "oracle", "_ref", "mm2ref")
+    sweep = sorted({t for t in (16, 32, 64, 128, cores) if t <= cores} | {cores})
     if os.path.exists(ref_bin):
-        kind, cmd = "reference", [ref_bin, "-t", str(cores)]
+        kind, cmd = "reference", [ref_bin, "-t", ",".join(map(str, sweep))]
     else:
         subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "al_oracle"], check=True)
-        kind, cmd = "port", [os.path.join(ROOT, "oracle", "al_oracle"), "-t", str(cores)]
-    dn = open(os.devnull, "wb")
-
-    def timed(c, out):
-        t0 = time.time()
-        with open(out, "wb") as f:
-            subprocess.run(c, cwd=tmp, stdout=f, stderr=dn, check=True)
-        return time.time() - t0
+        kind, cmd, sweep = "port", [os.path.join(ROOT, "oracle", "al_oracle"), "-t", str(cores)], [cores]
 
     def md5(path):
         h = hashlib.md5()
@@ -86,17 +92,29 @@ def cpu_baseline(tmp, ref_fa, arr, n_pairs):
                 h.update(blk)
         return h.hexdigest()
 
-    t_idx = timed(cmd + [ref_fa, "one_1.fq", "one_2.fq"], os.path.join(tmp, "one.sam"))
-    t_all = timed(cmd + [ref_fa, "cb_1.fq", "cb_2.fq"], os.path.join(tmp, "cpu.sam"))
-    t_map = max(t_all - t_idx, 1e-6)
-    base = {"value": 2 * n_pairs / t_map, "unit": "reads/s", "cores": cores, "kind": kind,
-            "sample": "%d pairs x 150 bp of the same workload, SAM to a file, index build (%.2f s) subtracted, wall %.2f s" % (n_pairs, t_idx, t_all)}
+    t0 = time.time()
+    with open(os.path.join(tmp, "cpu.sam"), "wb") as f:
+        r = subprocess.run(cmd + [ref_fa, "cb_1.fq", "cb_2.fq"], cwd=tmp, stdout=f, stderr=subprocess.PIPE, env=dict(os.environ, MM2REF_TIMING="1"), check=True)
+    t_all = time.time() - t0
+    pts = [(int(m.group(1)), float(m.group(2)), float(m.group(3))) for m in re.finditer(r"\[mm2ref\] threads=(\d+) index_s=([0-9.]+) map_s=([0-9.]+)", r.stderr.decode(errors="replace"))]
+    if pts:
+        best = min(pts, key=lambda x: x[2]); t_idx = pts[0][1]; t_map = best[2]; used = best[0]
+        t_cold = t_idx + pts[-1][2]           # what one cold run at the last sweep point costs (index + mapping)
+    else:                                   # the port prints no timing: whole wall
+        t_idx, t_map, used, t_cold = 0.0, t_all, cores, t_all
+    base = {"value": 2 * n_pairs / t_map, "unit": "reads/s", "cores": used, "kind": kind,
+            "sample": "first %d pairs x %d bp of the same workload, SAM to a file; thread sweep %s in one process, best = %d threads (%.2f s of mapping); index build %.1f s not included"
+                      % (n_pairs, read_len, "/".join("%d:%.2fs" % (p[0], p[2]) for p in pts), used, t_map, t_idx),
+            "host_cores": cores}
     cli = os.path.join(ROOT, "airlift_amd", "bin", "airlift-align")
     nt = min(cores, 32)
-    t_cli = timed([cli, "-ax", "sr", "-t", str(nt), ref_fa, "cb_1.fq", "cb_2.fq"], os.path.join(tmp, "gpu.sam"))
-    e2e = {"wall_s": t_cli, "reads_per_s": 2 * n_pairs / t_cli, "host_threads": nt, "cpu_wall_s": t_all, "speedup_vs_cpu_wall": t_all / t_cli,
+    t0 = time.time()
+    with open(os.path.join(tmp, "gpu.sam"), "wb") as f:
+        subprocess.run([cli, "-ax", "sr", "-t", str(nt), ref_fa, "cb_1.fq", "cb_2.fq"], cwd=tmp, stdout=f, stderr=subprocess.DEVNULL, check=True)
+    t_cli = time.time() - t0
+    e2e = {"wall_s": t_cli, "reads_per_s": 2 * n_pairs / t_cli, "host_threads": nt, "cpu_wall_s": t_cold, "speedup_vs_cpu_wall": t_cold / t_cli,
            "identical_sam": md5(os.path.join(tmp, "gpu.sam")) == md5(os.path.join(tmp, "cpu.sam")),
-           "note": "whole process, cold start: FASTA parse + index build on the GPU + FASTQ parse + mapping + SAM text; CPU wall likewise includes its index build"}
+           "note": "whole process, cold start: FASTA parse + index build on the GPU + FASTQ parse + mapping + SAM text; CPU wall = its index build + one mapping pass at all cores"}
     return base, e2e
 
 
@@ -116,12 +134,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--pairs", type=int, default=2_000_000, help="fragments per GPU per step (C2: 2 M pairs)")
-    ap.add_argument("--read-len", type=int, default=150)
-    ap.add_argument("--cpu-sample-pairs", type=int, default=1_000_000)
+    ap.add_argument("--pairs", type=int, default=2_000_000, help="fragments per GPU per step")
+    ap.add_argument("--read-len", type=int, default=0, help="default: the config's (150; C5: 250)")
+    ap.add_argument("--cpu-sample-pairs", type=int, default=500_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ins-mean", type=int, default=0, help="mean insert size override (short inserts make the mates overlap: equal-key anchors)")
-    ap.add_argument("--config", default="c2", help="synthetic reference of tools/gen_synth.py: c2 (BASELINE configs[1], default), c2r (c2 + high-copy element family), c3 (100 Mbp), c4 (3.1 Gbp)")
+    ap.add_argument("--config", default="c4", help="workload of tools/gen_synth.py: c4 (default: the configuration BASELINE.json's metric is quoted on -- 150 bp PE against a human-sized reference; fits one GPU), c5 (250 bp), c3 (100 Mbp), c2 (yeast-sized), c2r, c4s, c3u, c4u")
     a = ap.parse_args()
 
     import torch
@@ -144,24 +162,41 @@ def main():
 
     # reference pair stand-in (C2 = 16 contigs, 12.16 Mbp, 150 planted duplications); identical on every rank.
     # The index is built on this rank's GPU from the FASTA (al_idx_build_device), as the CLI does.
-    rk, _ = g.CONFIGS[a.config]
-    ref = g.make_reference(**rk)
+    if not a.read_len:
+        a.read_len = g.CONFIGS[a.config][1]["read_len"]
+    t0 = time.time()
+    ref = g.build_reference(a.config)
     tmp = tempfile.mkdtemp(prefix="al_bench_")
     g.write_fasta(os.path.join(tmp, "ref.fa"), ref)
+    t_gen = time.time() - t0
     t0 = time.time()
     idx = A.Index(fasta=os.path.join(tmp, "ref.fa"), on_device=local if world > 1 else 0)
     t_index = time.time() - t0
-    arr = make_workload(a.pairs, a.read_len, 20261002 + 7919 * rank, ref, a.ins_mean)
+    t0 = time.time()
+    arr = make_workload(a.config, a.pairs, a.read_len, 20261002 + 7919 * rank, ref, a.ins_mean)
+    t_reads = time.time() - t0
     ctx = A.Context(idx, device=local if world > 1 else 0)
     L.al_ctx_set_threads(ctx.h, min(32, os.cpu_count() or 1))       # host packing threads (outside the timed region)
-    nf = a.pairs
-    n_segs = (C.c_int * nf)(*([2] * nf)); qlens = (C.c_int * (2 * nf))(*([a.read_len] * (2 * nf)))
-    t0 = time.time()
-    rc = L.al_batch_upload_flat(ctx.h, nf, n_segs, qlens, arr.ctypes.data_as(C.c_char_p), b"realigned_", nf * rank)
-    if rc != 0:
-        raise SystemExit("upload failed")
-    t_upload = time.time() - t0
-    ctx.n_frag, ctx.n_reads = nf, 2 * nf
+    def upload(nf):
+        n_segs = (C.c_int * nf)(*([2] * nf)); qlens = (C.c_int * (2 * nf))(*([a.read_len] * (2 * nf)))
+        if L.al_batch_upload_flat(ctx.h, nf, n_segs, qlens, arr.ctypes.data_as(C.c_char_p), b"realigned_", nf * rank) != 0:
+            raise SystemExit("upload failed")
+        ctx.n_frag, ctx.n_reads = nf, 2 * nf
+
+    # a batch whose seed hits do not fit the device workspaces (al_batch_run -> AL_ERR_NOMEM) is halved, as the file drivers do
+    pairs_asked = a.pairs
+    while True:
+        t0 = time.time(); upload(a.pairs); t_upload = time.time() - t0
+        if L.al_batch_run(ctx.h) == 0:
+            break
+        if a.pairs <= 125_000:
+            raise SystemExit("al_batch_run failed")
+        a.pairs //= 2
+        sys.stderr.write("[bench] batch did not fit / failed: retrying with %d pairs per step\n" % a.pairs)
+    if world > 1:   # every rank steps the same batch size
+        t = torch.tensor([a.pairs], dtype=torch.int64, device=dev); dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        if int(t.item()) != a.pairs:
+            a.pairs = int(t.item()); upload(a.pairs)
 
     def step():
         ctx.run()
@@ -199,7 +234,7 @@ def main():
         alg = float(st.algorithmic_bytes)
         achieved = alg / (per[dom] * 1e-3) / 1e9
         out = {
-            "metric": "reads/sec remapped (150 bp PE)", "value": 2.0 * a.pairs * world * a.steps / dt, "unit": "reads/s",
+            "metric": "reads/sec remapped (%d bp PE)" % a.read_len, "value": 2.0 * a.pairs * world * a.steps / dt, "unit": "reads/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8/int32 (int8 SW lanes, u64 hashes)", "data": "synthetic",
             "config": {"workload": "%s, %d x 2 x %d bp PE reads per GPU per step, preset sr" % (WORKLOADS.get(a.config, a.config), a.pairs, a.read_len),
@@ -211,10 +246,10 @@ def main():
             "counters": {"minimizers_per_read": st.n_mini / (2.0 * a.pairs), "anchors_per_pair": st.n_anchor / float(a.pairs), "chains_per_pair": st.n_chain / float(a.pairs),
                          "regions_aligned_per_read": st.n_regs_aln / (2.0 * a.pairs), "ref_bases_per_region": st.n_refbases / max(1.0, float(st.n_regs_aln)),
                          "rechain": int(st.n_rechain), "heap_fallback": int(st.n_heap_fallback), "sort_tie_flags": int(st.n_sort_tie_flag)},
-            "host": {"index_build_on_gpu_s": t_index, "pack_upload_s": t_upload},
+            "host": {"index_build_on_gpu_s": t_index, "pack_upload_s": t_upload, "reference_generation_s": t_gen, "read_simulation_s": t_reads, "reference_model": getattr(ref, "stats", None)},
         }
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"], out["e2e_cli"] = cpu_baseline(tmp, "ref.fa", arr, min(a.cpu_sample_pairs, a.pairs))
+            out["cpu_baseline"], out["e2e_cli"] = cpu_baseline(tmp, "ref.fa", arr, min(a.cpu_sample_pairs, a.pairs), a.read_len)
             out["parity_sample"] = {"pairs": min(a.cpu_sample_pairs, a.pairs), "identical": out["e2e_cli"]["identical_sam"]}
         print(json.dumps(out))
     shutil.rmtree(tmp, ignore_errors=True)

@@ -6,18 +6,28 @@
  * FASTQ/FASTA files to SAM on stdout.  It exists so that goldens can be generated and the
  * restatement in al_oracle.c can be pinned against the real reference.
  *
- * usage: mm2ref [-t N] [-R rgline] [-K minibatch] [--seeds] [--alnseq] [--hit-only] ref.fa r1.fq [r2.fq]
+ * usage: mm2ref [-t N[,N2,...]] [-R rgline] [-K minibatch] [--seeds] [--alnseq] [--hit-only] ref.fa r1.fq [r2.fq]
+ *   -t a,b,c : thread sweep for the CPU baseline of bench.py: the input is mapped once per value (stdout to /dev/null for all
+ *              but the last) and "[mm2ref] threads=N index_s=.. map_s=.." is printed on stderr for each, so that the index
+ *              build is paid once and is not part of the mapping time
  *   --seeds  : mm_dbg_flag |= MM_DBG_PRINT_SEED  (RS/SD/CN lines on stderr, map.c:333-338,381-385)
  *   --alnseq : mm_dbg_flag |= MM_DBG_PRINT_ALN_SEQ (align.c:315-338)
  */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
+#include <fcntl.h>
+#include <sys/time.h>
 #include "minimap.h"
 #include "mmpriv.h"
 
+static double wall(void) { struct timeval tv; gettimeofday(&tv, 0); return tv.tv_sec + 1e-6 * tv.tv_usec; }
+
 int main(int argc, char **argv)
 {
+	int sweep[16], n_sweep = 0, si;
+	double t_idx0, t_idx;
 	mm_idxopt_t io; mm_mapopt_t mo;
 	int i, n_threads = 1, nfn = 0;
 	const char *rg = 0, *fn[4];
@@ -27,7 +37,11 @@ int main(int argc, char **argv)
 	if (mm_set_opt("sr", &io, &mo) < 0) return 2;
 	mo.flag |= MM_F_OUT_SAM | MM_F_CIGAR;                 /* -a, main.c:162 */
 	for (i = 1; i < argc; ++i) {
-		if (!strcmp(argv[i], "-t") && i + 1 < argc) n_threads = atoi(argv[++i]);
+		if (!strcmp(argv[i], "-t") && i + 1 < argc) {
+			char *e = argv[++i]; n_sweep = 0;
+			while (*e && n_sweep < 16) { sweep[n_sweep++] = (int)strtol(e, &e, 10); if (*e == ',') ++e; else break; }
+			n_threads = 1; for (si = 0; si < n_sweep; ++si) if (sweep[si] > n_threads) n_threads = sweep[si];   /* index build: the largest */
+		}
 		else if (!strcmp(argv[i], "-R") && i + 1 < argc) rg = argv[++i];
 		else if (!strcmp(argv[i], "-K") && i + 1 < argc) mo.mini_batch_size = atoi(argv[++i]);
 		else if (!strcmp(argv[i], "--seeds")) mm_dbg_flag |= MM_DBG_PRINT_SEED;
@@ -61,12 +75,26 @@ int main(int argc, char **argv)
 	if (mm_check_opt(&io, &mo) < 0) return 2;
 	r = mm_idx_reader_open(fn[0], &io, 0);
 	if (r == 0) { fprintf(stderr, "mm2ref: cannot open %s\n", fn[0]); return 1; }
+	if (n_sweep == 0) sweep[n_sweep++] = n_threads;
+	t_idx0 = wall();
 	while ((mi = mm_idx_reader_read(r, n_threads)) != 0) {
-		mm_write_sam_hdr(mi, rg, 0, 0, 0);
+		t_idx = wall() - t_idx0;
 		mm_mapopt_update(&mo, mi);
-		if (nfn == 2 && !(mo.flag & MM_F_FRAG_MODE)) mm_map_file(mi, fn[1], &mo, n_threads);
-		else mm_map_file_frag(mi, nfn - 1, &fn[1], &mo, n_threads);
+		for (si = 0; si < n_sweep; ++si) {
+			int saved = -1; double t0;
+			if (si + 1 < n_sweep) {            /* not the last sweep point: same work, output discarded */
+				int dn; fflush(stdout); saved = dup(1); dn = open("/dev/null", O_WRONLY); dup2(dn, 1); close(dn);
+			}
+			t0 = wall();
+			mm_write_sam_hdr(mi, rg, 0, 0, 0);
+			if (nfn == 2 && !(mo.flag & MM_F_FRAG_MODE)) mm_map_file(mi, fn[1], &mo, sweep[si]);
+			else mm_map_file_frag(mi, nfn - 1, &fn[1], &mo, sweep[si]);
+			fflush(stdout);
+			if (n_sweep > 1 || getenv("MM2REF_TIMING")) fprintf(stderr, "[mm2ref] threads=%d index_s=%.3f map_s=%.3f\n", sweep[si], t_idx, wall() - t0);
+			if (saved >= 0) { dup2(saved, 1); close(saved); }
+		}
 		mm_idx_destroy(mi);
+		t_idx0 = wall();
 	}
 	mm_idx_reader_close(r);
 	fflush(stdout);

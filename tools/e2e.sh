@@ -5,8 +5,8 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}; D=/tmp/al_e2e; mkdir -p $D
 python3 - <<PY
 import sys; sys.path.insert(0, "$REPO/tools")
 import gen_synth as g, numpy as np
-rk, _ = g.CONFIGS["${CONFIG:-c2}"]; ref = g.make_reference(**rk); g.write_fasta("$D/ref.fa", ref)
-r1, r2 = g.simulate_pairs(ref, $PAIRS, ${RLEN:-150}, seed=77, **(dict(ins_mean=550, ins_sd=60, ins_hi=1000) if ${RLEN:-150} >= 200 else {}))
+ref = g.build_reference("${CONFIG:-c2}"); g.write_fasta("$D/ref.fa", ref)
+r1, r2 = g.simulate("${CONFIG:-c2}", ref, $PAIRS, 77, read_len=${RLEN:-150})
 g.write_fastq("$D/r_1.fq", r1, "realigned_"); g.write_fastq("$D/r_2.fq", r2, "realigned_")
 PY
 cd $D

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Does running the batch as S independent sub-batches on S contexts (streams) of one GPU overlap latency-bound and
-issue-bound kernels?  tools/streams_test.py [pairs] [S ...]"""
+issue-bound kernels?  tools/streams_probe.py [pairs] [S ...]"""
 import ctypes as C, os, sys, threading, time, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -13,7 +13,7 @@ L.al_batch_upload_flat.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.PO
 rk, _ = g.CONFIGS["c2"]; ref = g.make_reference(**rk)
 tmp = tempfile.mkdtemp(); g.write_fasta(tmp + "/ref.fa", ref)
 idx = A.Index(fasta=tmp + "/ref.fa", on_device=0)
-arr = bench.make_workload(pairs, 150, 20261002, ref)
+arr = bench.make_workload("c2", pairs, 150, 20261002, ref)
 for S in Ss:
     nf = pairs // S; ctxs = []
     for s in range(S):
