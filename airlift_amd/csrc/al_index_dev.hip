@@ -164,7 +164,7 @@ extern "C" al_idx_t *al_idx_build_device(const char *fn, const al_idxopt_t *io, 
 	if (device < 0) { const char *lr = getenv("LOCAL_RANK"); device = lr ? atoi(lr) % n_dev : 0; }
 	if (device >= n_dev) { fprintf(stderr, "[airlift] FATAL: device %d out of range (%d devices)\n", device, n_dev); return nullptr; }
 	const int w = io->w, k = io->k;
-	if (!(k & 1) || k > 28 || w > 32 || w < 1) { fprintf(stderr, "[airlift] al_idx_build_device: needs odd k <= 28 and w <= 32 (got k=%d w=%d); use al_idx_build\n", k, w); return nullptr; }
+	if (!(k & 1) || k > AL_MAX_K || w > 32 || w < 1) { fprintf(stderr, "[airlift] al_idx_build_device: needs odd k <= %d and w <= 32 (got k=%d w=%d)\n", AL_MAX_K, k, w); return nullptr; }
 	AlSeqReader rd;
 	if (!rd.open(fn)) { fprintf(stderr, "[ERROR] airlift: failed to open '%s'\n", fn); return nullptr; }
 	al_idx_t *mi = new al_idx_t();
@@ -219,7 +219,7 @@ extern "C" al_idx_t *al_idx_build_device(const char *fn, const al_idxopt_t *io, 
 		(void)hipFree(d_tmp); d_tmp = nullptr;
 	}
 	(void)hipFree(d_ascii); d_ascii = nullptr;
-	if (total >= (1ULL << 32)) { fprintf(stderr, "[airlift] al_idx_build_device: %llu minimizers exceed the 32-bit offset of a table entry\n", (unsigned long long)total); goto fail; }
+	if (total >= (1ULL << 31)) { fprintf(stderr, "[airlift] al_idx_build_device: %llu minimizers exceed the 31-bit item count of the device sorts (references above ~12 Gbp need a multi-part index, which this path does not build)\n", (unsigned long long)total); goto fail; }
 	IDX_CHECK(hipMalloc((void **)&d_h, (total + 1) * 8)); IDX_CHECK(hipMalloc((void **)&d_y, (total + 1) * 8));
 	IDX_CHECK(hipMalloc((void **)&d_h2, (total + 1) * 8)); IDX_CHECK(hipMalloc((void **)&d_y2, (total + 1) * 8));
 	if (n_seg) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ref_sketch<1>), dim3((unsigned)((n_seg + 63) / 64)), dim3(64), (size_t)w * 64 * 16, st,

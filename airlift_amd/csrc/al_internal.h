@@ -9,6 +9,7 @@
 #include <mutex>
 #include "../../include/airlift.h"
 
+#define AL_MAX_K 25                        // device read sketch: hash (2k bits) << 14 | pos << 1 | strand must fit 64 bits
 #define AL_SEED_TANDEM    (1ULL<<42)       // mmpriv.h:20
 #define AL_SEED_SEG_SHIFT 48               // mmpriv.h:23
 #define AL_SEED_SEG_MASK  (0xffULL<<AL_SEED_SEG_SHIFT)

@@ -20,6 +20,17 @@
 #include <vector>
 #include "../../include/airlift.h"
 
+// numbers with k/m/g suffixes, as the fork's command line reads -K, -r, -g, -F (mm_parse_num, main.c:87-96)
+static long long parse_num(const char *str, const char *opt)
+{
+	char *p; double x = strtod(str, &p);
+	if (*p == 'G' || *p == 'g') x *= 1e9, ++p;
+	else if (*p == 'M' || *p == 'm') x *= 1e6, ++p;
+	else if (*p == 'K' || *p == 'k') x *= 1e3, ++p;
+	if (*p) fprintf(stderr, "[WARNING] airlift-align: trailing characters in the value of %s: '%s'\n", opt, str);
+	return (long long)(x + .499);
+}
+
 static int usage()
 {
 	fprintf(stderr, "Usage: airlift-align mem [-R RG] [-t N] ref.fa reads_1.fq [reads_2.fq]\n"
@@ -54,12 +65,12 @@ int main(int argc, char **argv)
 		else if (!strcmp(a, "-a")) mo.flag |= AL_F_OUT_SAM | AL_F_CIGAR;
 		else if (!strcmp(a, "-k") && i + 1 < argc) io.k = atoi(argv[++i]);
 		else if (!strcmp(a, "-w") && i + 1 < argc) io.w = atoi(argv[++i]);
-		else if (!strcmp(a, "-K") && i + 1 < argc) mo.mini_batch_size = (int)atof(argv[++i]);
+		else if (!strcmp(a, "-K") && i + 1 < argc) mo.mini_batch_size = (int)parse_num(argv[++i], "-K");
 		else if (!strcmp(a, "-n") && i + 1 < argc) { if (mode == MODE_ALN) ++i; else mo.min_cnt = atoi(argv[++i]); }   // bwa aln -n X: accepted, no analogue; minimap2 -n: main.c:165
 		// numeric options of the fork's command line (main.c:144-230), same letters and meaning
-		else if (!strcmp(a, "-g") && i + 1 < argc) mo.max_gap = atoi(argv[++i]);
-		else if (!strcmp(a, "-F") && i + 1 < argc) mo.max_frag_len = atoi(argv[++i]);
-		else if (!strcmp(a, "-r") && i + 1 < argc) mo.bw = atoi(argv[++i]);
+		else if (!strcmp(a, "-g") && i + 1 < argc) mo.max_gap = (int)parse_num(argv[++i], "-g");
+		else if (!strcmp(a, "-F") && i + 1 < argc) mo.max_frag_len = (int)parse_num(argv[++i], "-F");
+		else if (!strcmp(a, "-r") && i + 1 < argc) mo.bw = (int)parse_num(argv[++i], "-r");
 		else if (!strcmp(a, "-N") && i + 1 < argc) mo.best_n = atoi(argv[++i]);
 		else if (!strcmp(a, "-p") && i + 1 < argc) mo.pri_ratio = (float)atof(argv[++i]);
 		else if (!strcmp(a, "-M") && i + 1 < argc) mo.mask_level = (float)atof(argv[++i]);

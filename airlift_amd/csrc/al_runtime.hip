@@ -84,7 +84,7 @@ extern "C" al_ctx_t *al_ctx_init(const al_idx_t *mi, const al_mapopt_t *opt, int
 	}
 	if (device < 0) { const char *lr = getenv("LOCAL_RANK"); device = lr ? atoi(lr) % n_dev : 0; }
 	if (device >= n_dev) { fprintf(stderr, "[airlift] FATAL: device %d out of range (%d devices)\n", device, n_dev); return nullptr; }
-	if (mi->w > 32 || mi->k > 28) { fprintf(stderr, "[airlift] FATAL: device sketch supports w <= 32, k <= 28\n"); return nullptr; }
+	if (mi->w > 32 || mi->k > AL_MAX_K) { fprintf(stderr, "[airlift] FATAL: device sketch supports w <= 32, k <= %d\n", AL_MAX_K); return nullptr; }
 	al_ctx_t *c = new al_ctx_t();
 	c->mi = mi; c->opt = *opt; c->device = device;
 	if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return nullptr; }
@@ -273,9 +273,9 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 		if (c->chain_key.ensure(nl + 1) || c->chain_idx.ensure(nl + 1) || c->chain_idx2.ensure(nl + 1)) return -1;
 		hipLaunchKernelGGL(k_iota_u32, dim3((nl + 255) / 256), dim3(256), 0, s, c->chain_idx.p, (uint32_t)nl);
 		size_t bytes = 0;
-		AL_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const uint32_t *)c->frag_na.p, c->chain_key.p, (const uint32_t *)c->chain_idx.p, c->chain_idx2.p, nl, 0, 20, s));
+		AL_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const uint32_t *)c->frag_na.p, c->chain_key.p, (const uint32_t *)c->chain_idx.p, c->chain_idx2.p, nl, 0, 32, s));
 		if (c->scan_tmp.ensure(bytes + 16)) return -1;
-		AL_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(c->scan_tmp.p, bytes, (const uint32_t *)c->frag_na.p, c->chain_key.p, (const uint32_t *)c->chain_idx.p, c->chain_idx2.p, nl, 0, 20, s));
+		AL_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(c->scan_tmp.p, bytes, (const uint32_t *)c->frag_na.p, c->chain_key.p, (const uint32_t *)c->chain_idx.p, c->chain_idx2.p, nl, 0, 32, s));
 		order = c->chain_idx2.p; sorted = true;
 		if (c->lb_buf.ensure(8)) return -1;
 		uint32_t *d_lb = c->lb_buf.p;
