@@ -106,11 +106,25 @@ struct AlReg {                // device mm_reg1_t (+ mm_extra_t scalars); 112 by
 #define ALR_SPLIT_INV    (1u<<16)
 #define ALR_HAS_P        (1u<<17)
 
+// Segment mode of the chaining kernels.  A fragment's sorted anchors fall apart into independent sub-problems wherever two
+// neighbours are more than max_dist_x apart (no predecessor window crosses such a gap, chain.c:52): reads inside
+// interspersed repeats have thousands of anchors but only short runs of them, so these runs ("segments") are chained as
+// list entries of their own (a_off / frag_na are then per segment) and k_seg_merge puts the fragment's chain list together.
+// meta == nullptr: the list entries are whole fragments.
+struct ChainSeg {
+	const uint32_t *meta;     // per entry: qlen_sum | (paired ? 1 << 31 : 0) of the fragment it belongs to
+	uint32_t *tie;            // per entry: 1 if two of its chains start at anchors of equal x (their order is the fragment-wide sort's business)
+	uint32_t *nc;             // per entry: number of chained anchors written
+};
+
+struct LbThr { uint32_t v[16]; int n; };     // thresholds of k_lower_bounds
+
 // one HIP-event interval per entry; where a stage is several kernels (chaining and extension DP are dispatched by size class)
 // each kernel with real weight has its own interval so that bench.py's per-kernel times line up with rocprofv3's
-enum AlStage { ST_SKETCH = 0, ST_SEED, ST_SCAN, ST_ORDER, ST_ANCHOR_SORT_S, ST_ANCHOR_SORT, ST_CHAIN_LDS32, ST_CHAIN_LDS48, ST_CHAIN_LDS64, ST_CHAIN_LDS128, ST_CHAIN_WAVE, ST_RECHAIN,
+enum AlStage { ST_SKETCH = 0, ST_SEED, ST_SCAN, ST_ORDER, ST_ANCHOR_SORT_S, ST_ANCHOR_SORT, ST_ANCHOR_SORT_BLK, ST_ANCHOR_SORT_BIG, ST_ANCHOR_HEAP,
+               ST_CHAIN_LDS32, ST_CHAIN_LDS48, ST_CHAIN_LDS64, ST_CHAIN_LDS128, ST_SEG_FIND, ST_SEG_CHAIN_LDS, ST_SEG_CHAIN_WAVE, ST_SEG_MERGE, ST_RECHAIN,
                ST_REGS, ST_EXT_PREP, ST_EXT_SORT, ST_EXT_DP_LANE, ST_EXT_DP_G4, ST_EXT_DP_G8, ST_EXT_DP_G22, ST_EXT_FINISH, ST_COMPACT, ST_N };
-#define ST_CHAIN ST_CHAIN_WAVE
+#define ST_CHAIN ST_SEG_MERGE
 #define ST_EXT_DP ST_EXT_DP_G22
 
 // anchors per fragment the wavefront-per-fragment chaining kernel keeps entirely in LDS (32 bytes each); larger fragments keep

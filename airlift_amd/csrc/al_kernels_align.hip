@@ -1820,9 +1820,9 @@ int al_run_align_stage(al_ctx_t *c)
 	AL_HIP_CHECK(hipStreamSynchronize(s));
 	const uint64_t Btot = 4 * nu_total + 4ULL * nf + 8;
 	if (A->regs0.ensure(nu_total + 1) || A->mregs.ensure(2 * Btot) || A->rtmp.ensure(Btot) || A->aux128.ensure(Btot) || A->aux64.ensure(Btot) || A->auxi.ensure(2 * Btot) ||
-	    A->seg_u.ensure(2 * nu_total + 2) || A->seg_a.ensure(c->n_anchor_total + 1) || A->reg_cnt.ensure(nr + 1) || A->seg_na.ensure(nr + 1) || A->out_off.ensure(nr + 2) || A->rext.ensure(2 * Btot + 1) || A->seg_fast.ensure(nr + 1)) return -1;
+	    A->seg_u.ensure(2 * nu_total + 2) || A->reg_cnt.ensure(nr + 1) || A->seg_na.ensure(nr + 1) || A->out_off.ensure(nr + 2) || A->rext.ensure(2 * Btot + 1) || A->seg_fast.ensure(nr + 1)) return -1;
 	WsBase W;
-	W.regs0 = A->regs0.p; W.mregs = A->mregs.p; W.rtmp = A->rtmp.p; W.aux128 = A->aux128.p; W.seg_a = A->seg_a.p; W.aux64 = A->aux64.p; W.seg_u = A->seg_u.p; W.auxi = A->auxi.p;
+	W.regs0 = A->regs0.p; W.mregs = A->mregs.p; W.rtmp = A->rtmp.p; W.aux128 = A->aux128.p; W.seg_a = c->chain_tmp.p /* chaining scratch, free again */; W.aux64 = A->aux64.p; W.seg_u = A->seg_u.p; W.auxi = A->auxi.p;
 	W.nu_off = A->nu_off.p; W.frag_nu = c->frag_nu.p; W.a_off = c->a_off.p; W.reg_cnt = A->reg_cnt.p; W.seg_na = A->seg_na.p; W.rext = A->rext.p; W.seg_fast = A->seg_fast.p;
 	hipLaunchKernelGGL(k_regs, dim3((nf + 255) / 256), dim3(256), 0, s, c->chained.p, c->u.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, nf, c->P, c->counters.p);
 	AL_HIP_CHECK(hipEventRecord(c->ev[ST_REGS + 1], s));

@@ -376,6 +376,144 @@ k_anchor_sort(const uint64_t *__restrict__ pos, const uint32_t *__restrict__ fra
 	if (fallback && lane == 0) tie_list[f] = 1u;                           // merged by k_anchor_heap
 }
 
+// K3 for fragments of 1025 .. CAP anchors (reads inside interspersed repeats): one 256-thread block per fragment, the (x, list)
+// pairs of all anchors in LDS (10 bytes each), bitonic network across the block; y is rebuilt from the list's match record
+// when the anchors are written out.  Equal x -> exact heap merge, as in the other sort kernels.
+template <int CAP>
+__global__ void __launch_bounds__(256)
+k_anchor_sort_blk(const uint64_t *__restrict__ pos, const uint32_t *__restrict__ frag_first, const uint32_t *__restrict__ rd_len,
+                  const uint64_t *__restrict__ mini_off, const AlMatch *__restrict__ match,
+                  const uint32_t *__restrict__ frag_nm, const uint32_t *__restrict__ frag_na, const uint64_t *__restrict__ a_off,
+                  AlAnchor *__restrict__ anchors, uint32_t *__restrict__ tie_list,
+                  const uint32_t *__restrict__ frag_list, int n_list, int mini_span)
+{
+	constexpr int MCAP = 1024;                          // occurrence lists per fragment (query minimizers that passed the filter)
+	__shared__ uint64_t sx[CAP];
+	__shared__ uint16_t sm[CAP];
+	__shared__ uint32_t pre[MCAP + 1];
+	__shared__ uint32_t s_part[256];
+	__shared__ int s_flag;
+	const int tid = threadIdx.x;
+	if ((int)blockIdx.x >= n_list) return;
+	const uint32_t f = frag_list[blockIdx.x];
+	const uint32_t n = frag_na[f], n_m = frag_nm[f];
+	if (n == 0) return;
+	if (n > (uint32_t)CAP || n_m > (uint32_t)MCAP) { if (tid == 0) tie_list[f] = 1u; return; }   // not this kernel's class: exact merge
+	const uint32_t r0 = frag_first[f], r1 = frag_first[f + 1];
+	int qlen = 0; for (uint32_t r = r0; r < r1; ++r) qlen += (int)rd_len[r];
+	const AlMatch *m = match + mini_off[r0];
+	AlAnchor *out = anchors + a_off[f];
+	if (tid == 0) s_flag = 0;
+	{   // exclusive prefix sums of the list lengths: four lists per thread, block scan of the partial sums
+		uint32_t v[4], sum = 0;
+		for (int j = 0; j < 4; ++j) { const uint32_t i = (uint32_t)tid * 4 + j; v[j] = i < n_m ? m[i].n : 0u; sum += v[j]; }
+		s_part[tid] = sum;
+		__syncthreads();
+		for (int d = 1; d < 256; d <<= 1) { const uint32_t t = tid >= d ? s_part[tid - d] : 0u; __syncthreads(); s_part[tid] += t; __syncthreads(); }
+		uint32_t run = s_part[tid] - sum;
+		for (int j = 0; j < 4; ++j) { const uint32_t i = (uint32_t)tid * 4 + j; if (i <= n_m) pre[i] = run; run += v[j]; }
+	}
+	__syncthreads();
+	int npow2 = 1; while ((uint32_t)npow2 < n) npow2 <<= 1;
+	for (uint32_t t = tid; t < (uint32_t)npow2; t += 256) {
+		uint64_t x = UINT64_MAX; uint32_t mi = 0;
+		if (t < n) {
+			uint32_t lo = 0, hi = n_m;                                       // last list with pre[list] <= t
+			while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (pre[mid] <= t) lo = mid; else hi = mid; }
+			mi = lo;
+			const AlMatch mm = m[lo];
+			const uint64_t r = d_match_pos(pos, mm.off_lo, mm.flags, t - pre[lo]);
+			x = (r & 0xffffffff00000000ULL) | (uint32_t)((uint32_t)r >> 1);
+			if ((r & 1) != (mm.q_pos & 1)) x |= 1ULL << 63;                 // map.c:176-190
+		}
+		sx[t] = x; sm[t] = (uint16_t)mi;
+	}
+	__syncthreads();
+	for (int kk = 2; kk <= npow2; kk <<= 1)
+		for (int j = kk >> 1; j > 0; j >>= 1) {
+			for (int i = tid; i < npow2; i += 256) {
+				const int ixj = i ^ j;
+				if (ixj > i) {
+					const uint64_t a = sx[i], b = sx[ixj];
+					if ((a > b) == ((i & kk) == 0)) { sx[i] = b; sx[ixj] = a; const uint16_t t = sm[i]; sm[i] = sm[ixj]; sm[ixj] = t; }
+				}
+			}
+			__syncthreads();
+		}
+	int tie = 0;
+	for (uint32_t t = tid; t + 1 < n; t += 256) if (sx[t] == sx[t + 1]) tie = 1;
+	if (tie) s_flag = 1;
+	__syncthreads();
+	if (s_flag) { if (tid == 0) tie_list[f] = 1u; return; }                // merged by k_anchor_heap
+	for (uint32_t t = tid; t < n; t += 256) {
+		const uint64_t x = sx[t]; const AlMatch mm = m[sm[t]];
+		const uint32_t span = (uint32_t)mini_span;
+		AlAnchor a; a.x = x;
+		a.y = (x >> 63) ? (uint64_t)span << 32 | (uint32_t)(qlen - ((int)(mm.q_pos >> 1) + 1 - (int)span) - 1) : (uint64_t)span << 32 | (mm.q_pos >> 1);
+		a.y |= (uint64_t)(mm.flags & 0xff) << AL_SEED_SEG_SHIFT;
+		if (mm.flags & (1u << 8)) a.y |= AL_SEED_TANDEM;
+		out[t] = a;
+	}
+}
+template __global__ void k_anchor_sort_blk<4096>(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, uint32_t *, const uint32_t *, int, int);
+
+// K3 for fragments above the LDS tiles (reads inside high-copy families, the max_occ re-chain pass: up to 42 x 5000 anchors):
+// their anchors are expanded unsorted with a composite key  (rank of the fragment in the list) << key_bits | strand | contig |
+// position, one device-wide radix sort (rocPRIM) puts every fragment's anchors in x order at consecutive places, and
+// k_anchor_big_scatter writes them back to the fragment's anchor range.  One wavefront per 64 anchors of a fragment.
+__global__ void __launch_bounds__(256)
+k_anchor_big_expand(const uint64_t *__restrict__ pos, const uint32_t *__restrict__ frag_first, const uint32_t *__restrict__ rd_len,
+                    const uint64_t *__restrict__ mini_off, const AlMatch *__restrict__ match,
+                    const uint32_t *__restrict__ frag_nm, const uint32_t *__restrict__ frag_na,
+                    const uint32_t *__restrict__ frag_list, int n_list, const uint64_t *__restrict__ big_off /* n_list + 1 */,
+                    uint64_t *__restrict__ keys, uint64_t *__restrict__ vals, int rid_bits, int mini_span)
+{
+	// one block per fragment; lists are walked one after the other, 256 positions at a time (coalesced 8-byte reads)
+	if ((int)blockIdx.x >= n_list) return;
+	const uint32_t f = frag_list[blockIdx.x];
+	const uint32_t n_m = frag_nm[f];
+	const uint32_t r0 = frag_first[f], r1 = frag_first[f + 1];
+	int qlen = 0; for (uint32_t r = r0; r < r1; ++r) qlen += (int)rd_len[r];
+	const AlMatch *m = match + mini_off[r0];
+	const int kb = 33 + rid_bits;
+	const uint64_t rank = (uint64_t)blockIdx.x << kb;
+	uint64_t o = big_off[blockIdx.x];
+	for (uint32_t i = 0; i < n_m; ++i) {
+		const AlMatch mm = m[i];
+		const uint32_t span = (uint32_t)mini_span;
+		for (uint32_t t = threadIdx.x; t < mm.n; t += 256) {
+			const uint64_t r = d_match_pos(pos, mm.off_lo, mm.flags, t);
+			const bool rev = (r & 1) != (mm.q_pos & 1);
+			const uint64_t key = rank | (uint64_t)(rev ? 1 : 0) << (kb - 1) | (r >> 32) << 32 | (uint32_t)((uint32_t)r >> 1);
+			uint64_t y = rev ? (uint64_t)span << 32 | (uint32_t)(qlen - ((int)(mm.q_pos >> 1) + 1 - (int)span) - 1) : (uint64_t)span << 32 | (mm.q_pos >> 1);
+			y |= (uint64_t)(mm.flags & 0xff) << AL_SEED_SEG_SHIFT;
+			if (mm.flags & (1u << 8)) y |= AL_SEED_TANDEM;
+			keys[o + t] = key; vals[o + t] = y;
+		}
+		o += mm.n;
+	}
+}
+__global__ void __launch_bounds__(256)
+k_anchor_big_scatter(const uint64_t *__restrict__ keys, const uint64_t *__restrict__ vals, const uint32_t *__restrict__ frag_list, int n_list,
+                     const uint64_t *__restrict__ big_off, const uint64_t *__restrict__ a_off, AlAnchor *__restrict__ anchors,
+                     uint32_t *__restrict__ tie_list, int rid_bits)
+{
+	if ((int)blockIdx.x >= n_list) return;
+	const uint32_t f = frag_list[blockIdx.x];
+	const uint64_t b = big_off[blockIdx.x], n = big_off[blockIdx.x + 1] - b;
+	AlAnchor *out = anchors + a_off[f];
+	const int kb = 33 + rid_bits;
+	const uint64_t lowmask = (1ULL << (kb - 1)) - 1;
+	int tie = 0;
+	for (uint64_t t = threadIdx.x; t < n; t += 256) {
+		const uint64_t k = keys[b + t];
+		AlAnchor a; a.x = (k & lowmask) | (k >> (kb - 1) & 1) << 63; a.y = vals[b + t];
+		if (t + 1 < n && keys[b + t + 1] == k) tie = 1;
+		out[t] = a;
+	}
+	if (tie) tie_list[f] = 1u;                                             // equal x: merged again by k_anchor_heap (exact heap order)
+}
+
 // K3 for fragments with at most 64 anchors (the bulk on a low-repeat genome): nothing but registers, so 32 wavefronts per CU
 // stay resident and hide the dependent HBM reads (count -> match records -> positions) that bound this stage.
 // Lane t builds anchor t (its owning match is found by counting prefix sums, read with wave-uniform readlanes), the
@@ -443,6 +581,7 @@ __device__ __forceinline__ int d_ilog2(uint32_t v) { return 31 - __clz((int)v); 
 
 struct ChainArrays { uint64_t *x; int32_t *q; uint32_t *m; int32_t *f, *p, *t, *v; };   // m: span | sid<<8
 
+
 // accessor for ordering chains by the x of their first anchor: elements are chain ids in T[], chain c's first anchor is
 // a[V[Pp[c] + len(c) - 1]] (V = backtrack visit list, Pp = chain start offsets into V, utmp low word = chain length).
 struct ChainOrderAcc {
@@ -459,7 +598,7 @@ k_chain(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_off
         const uint32_t *__restrict__ frag_first, const uint32_t *__restrict__ rd_len,
         AlAnchor *__restrict__ chained, uint64_t *__restrict__ u_out, uint32_t *__restrict__ frag_nu,
         int32_t *__restrict__ ws_i32 /* 4 ints per anchor */, uint64_t *__restrict__ ws_u64 /* 1 per anchor */,
-        const uint32_t *__restrict__ frag_list, int n_list, AlParams P, unsigned long long *__restrict__ counters, int min_n)
+        const uint32_t *__restrict__ frag_list, int n_list, AlParams P, unsigned long long *__restrict__ counters, ChainSeg seg)
 {
 	__shared__ uint64_t s_all[4 * CAP];                  // one block, so that the backtrack of a large fragment can use all of it
 	uint64_t *const sx = s_all, *const s_qm = s_all + CAP;   // s_qm: Q (int32) and M (u32) halves during the DP; chain list (u64) in the tail
@@ -472,17 +611,15 @@ k_chain(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_off
 	if ((int)blockIdx.x >= n_list) return;
 	const uint32_t f = frag_list ? frag_list[blockIdx.x] : blockIdx.x;
 	const int64_t n = frag_na[f];
-	if (min_n > 0) {      // wavefront-groups of 64 list entries whose largest fragment has <= min_n anchors belong to k_chain_lds
-		const int idx = ((int)blockIdx.x & ~63) + lane;
-		int v = idx < n_list ? (int)frag_na[frag_list ? frag_list[idx] : (uint32_t)idx] : 0;
-		for (int d = 32; d > 0; d >>= 1) { const int o = __shfl_xor(v, d); v = o > v ? o : v; }
-		if (v <= min_n) return;
-	}
-	if (lane == 0) frag_nu[f] = 0;
+	if (lane == 0) { frag_nu[f] = 0; if (seg.meta) { seg.tie[f] = 0; seg.nc[f] = 0; } }
 	if (n == 0) return;
-	const uint32_t r0 = frag_first[f], r1 = frag_first[f + 1];
-	const int n_segs = (int)(r1 - r0);
-	int qlen_sum = 0; for (uint32_t r = r0; r < r1; ++r) qlen_sum += (int)rd_len[r];
+	int n_segs, qlen_sum = 0;
+	if (seg.meta) { const uint32_t mt = seg.meta[f]; qlen_sum = (int)(mt & 0x7fffffffu); n_segs = (mt >> 31) ? 2 : 1; }
+	else {
+		const uint32_t r0 = frag_first[f], r1 = frag_first[f + 1];
+		n_segs = (int)(r1 - r0);
+		for (uint32_t r = r0; r < r1; ++r) qlen_sum += (int)rd_len[r];
+	}
 	const AlAnchor *a = anchors + a_off[f];
 	const bool in_lds = n <= CAP;
 #define CHAIN_SYNC() __syncthreads()
@@ -616,7 +753,7 @@ k_chain(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_off
 	for (int64_t i = lane; i < n; i += 64) if (Pp[i] >= 0) T[Pp[i]] = 1;
 	CHAIN_SYNC();
 	AlAnchor *b = chained + a_off[f];
-	uint64_t *u = u_out + a_off[f] + f;                 // capacity n + 1
+	uint64_t *u = u_out + a_off[f] + (seg.meta ? 0u : f);   // capacity n + 1 (segment mode: n, a chain has at least one anchor)
 	uint64_t *utmp = in_lds ? s_qm : ws_u64 + a_off[f]; // capacity n (Q/M are dead after the DP)
 	// Peaks (chain.c:87-110) by all lanes: every chain end walks back to its peak on its own; the list of plain 64-bit keys
 	// (score << 32 | anchor index) is sorted next, so the order the lanes append in does not matter.  At most n/2 entries
@@ -707,11 +844,13 @@ k_chain(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_off
 		}
 		CHAIN_SYNC();
 		if (n_u1 <= 64) {
+			bool eq = false;
 			if (lane < n_u1) {
 				const uint64_t kx = keysL[lane]; int32_t r = 0;
-				for (int32_t j = 0; j < n_u1; ++j) { const uint64_t kj = keysL[j]; r += kj < kx || (kj == kx && j < lane); }
+				for (int32_t j = 0; j < n_u1; ++j) { const uint64_t kj = keysL[j]; r += kj < kx || (kj == kx && j < lane); eq = eq || (kj == kx && j != lane); }
 				permL[r] = lane;
 			}
+			if (seg.meta && __ballot(eq) && lane == 0) seg.tie[f] = 1u;
 		}
 	}
 	CHAIN_SYNC();
@@ -727,15 +866,18 @@ k_chain(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_off
 					         __device__ __forceinline__ int32_t get(int i) const { return t[i]; }
 					         __device__ __forceinline__ void set(int i, const int32_t &c) { t[i] = c; } } acc{permL, keysL};
 					tie = d_rs_sort(acc, n_u, s_rs);
+					if (seg.meta) for (int32_t i = 1; i < n_u; ++i) tie = tie || acc.key(i) == acc.key(i - 1);   // equal keys: the fragment-wide sort decides
 				}
 			} else if (n_u > 1) {
 				ChainOrderAcc acc{T, V, Pp, utmp, X, a, in_lds};
 				tie = d_rs_sort(acc, n_u, s_rs);
+				if (seg.meta) for (int32_t i = 1; i < n_u; ++i) tie = tie || acc.key(i) == acc.key(i - 1);
 			}
 			int32_t o = 0;
 			if (use_lds_order) { for (int32_t i = 0; i < n_u; ++i) { st_[i] = o; o += (int32_t)(uint32_t)s_qm[sp[i]]; } }                // st_[] = output offset of sorted chain i
 			else { for (int32_t i = 0; i < n_u; ++i) { const int32_t c = T[i]; u[i] = utmp[c]; F[i] = o; o += (int32_t)(uint32_t)utmp[c]; } }   // F[] = output offset of sorted chain i
-			if (tie) atomicAdd(&counters[1], 1ULL);
+			if (tie) { if (seg.meta) seg.tie[f] = 1u; else atomicAdd(&counters[1], 1ULL); }
+			if (seg.meta) seg.nc[f] = (uint32_t)o;
 		}
 		frag_nu[f] = (uint32_t)n_u;
 	}
@@ -773,7 +915,7 @@ __global__ void __launch_bounds__(64)
 k_chain_lds(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_off, const uint32_t *__restrict__ frag_na,
             const uint32_t *__restrict__ frag_first, const uint32_t *__restrict__ rd_len,
             AlAnchor *__restrict__ chained, uint64_t *__restrict__ u_out, uint32_t *__restrict__ frag_nu, uint64_t *__restrict__ ws_u64,
-            const uint32_t *__restrict__ order, int n_list, int lo_excl, AlParams P, unsigned long long *__restrict__ counters)
+            const uint32_t *__restrict__ order, int n_list, int lo_excl, AlParams P, unsigned long long *__restrict__ counters, ChainSeg seg)
 {
 	// 10 bytes per anchor: one 8-byte row  [ xlo:16 | q:12 | seg:1 | far:1 | -:2 | f:16 | p:8 | t:8 ]  + the peak score v:16.
 	//  xlo = low 16 bits of the reference position: inside the predecessor window the true distance is <= max_dist_x < 2^15,
@@ -800,6 +942,7 @@ k_chain_lds(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a
 	__syncthreads();
 	if (!have) return;
 	frag_nu[f] = 0;
+	if (seg.meta) { seg.tie[f] = 0; seg.nc[f] = 0; }
 	if (n == 0) return;
 #define ROW(j) srow[(j) * LANES + lane]
 #define VL(j) sv[(j) * LANES + lane]
@@ -811,9 +954,13 @@ k_chain_lds(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a
 #define R_F(r) ((int32_t)(int16_t)((r) >> 32))
 #define R_P(r) ((uint32_t)((r) >> 48) & 0xffu)
 #define R_T(r) ((uint32_t)((r) >> 56))
-	const uint32_t r0 = frag_first[f], r1 = frag_first[f + 1];
-	const int n_segs = (int)(r1 - r0);
-	int qlen_sum = 0; for (uint32_t r = r0; r < r1; ++r) qlen_sum += (int)rd_len[r];
+	int n_segs, qlen_sum = 0;
+	if (seg.meta) { const uint32_t mt = seg.meta[f]; qlen_sum = (int)(mt & 0x7fffffffu); n_segs = (mt >> 31) ? 2 : 1; }
+	else {
+		const uint32_t r0 = frag_first[f], r1 = frag_first[f + 1];
+		n_segs = (int)(r1 - r0);
+		for (uint32_t r = r0; r < r1; ++r) qlen_sum += (int)rd_len[r];
+	}
 	const AlAnchor *a = anchors + a_off[f];
 	const int max_dist_y = qlen_sum > P.max_gap ? qlen_sum : P.max_gap;           // map.c:341-351
 	int max_dist_x;
@@ -928,13 +1075,14 @@ k_chain_lds(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a
 	int32_t off = 0;
 	for (int32_t c = 0; c < n_u; ++c) { OFFB(c) = (uint8_t)off; off += (int32_t)(uint32_t)utmp[c]; TB(c) = (uint8_t)c; }
 #define CXL(c) (a[(int)VL((int)OFFB(c) + (int32_t)(uint32_t)utmp[c] - 1)].x)
+	bool eqx = false;
 	for (int32_t i = 1; i < n_u; ++i) {
 		const uint8_t ci = TB(i); const uint64_t xi = CXL(ci); int32_t j = i;
-		while (j > 0) { const uint8_t cj = TB(j - 1); if (xi < CXL(cj)) { TB(j) = cj; --j; } else break; }
+		while (j > 0) { const uint8_t cj = TB(j - 1); const uint64_t xj = CXL(cj); if (xi < xj) { TB(j) = cj; --j; } else { eqx = eqx || xi == xj; break; } }
 		TB(j) = ci;
 	}
 #undef CXL
-	AlAnchor *b = chained + a_off[f]; uint64_t *u = u_out + a_off[f] + f;
+	AlAnchor *b = chained + a_off[f]; uint64_t *u = u_out + a_off[f] + (seg.meta ? 0u : f);
 	int32_t o = 0;
 	for (int32_t i = 0; i < n_u; ++i) {
 		const int32_t c = TB(i), ni = (int32_t)(uint32_t)utmp[c], k0 = OFFB(c);
@@ -942,6 +1090,7 @@ k_chain_lds(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a
 		for (int32_t j = 0; j < ni; ++j) b[o++] = a[(int)VL(k0 + (ni - j - 1))];
 	}
 	frag_nu[f] = (uint32_t)n_u;
+	if (seg.meta) { seg.nc[f] = (uint32_t)o; if (eqx) seg.tie[f] = 1u; }
 #undef OFFB
 #undef FL
 #undef PLv
@@ -956,12 +1105,122 @@ k_chain_lds(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a
 #undef R_P
 #undef R_T
 }
-#define INST_CHAIN_LDS(C, L) template __global__ void k_chain_lds<C, L>(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, AlAnchor *, uint64_t *, uint32_t *, uint64_t *, const uint32_t *, int, int, AlParams, unsigned long long *);
+#define INST_CHAIN_LDS(C, L) template __global__ void k_chain_lds<C, L>(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, AlAnchor *, uint64_t *, uint32_t *, uint64_t *, const uint32_t *, int, int, AlParams, unsigned long long *, ChainSeg);
 INST_CHAIN_LDS(16, 64) INST_CHAIN_LDS(24, 64) INST_CHAIN_LDS(32, 64) INST_CHAIN_LDS(40, 64) INST_CHAIN_LDS(48, 64) INST_CHAIN_LDS(64, 64) INST_CHAIN_LDS(80, 64) INST_CHAIN_LDS(96, 64) INST_CHAIN_LDS(128, 32)
 
 // explicit instantiations used by the runtime
 template __global__ void k_anchor_sort<1024>(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, uint32_t *, unsigned int *, const uint32_t *, int, unsigned long long *, int);
-template __global__ void k_chain<AL_CHAIN_CAP>(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, AlAnchor *, uint64_t *, uint32_t *, int32_t *, uint64_t *, const uint32_t *, int, AlParams, unsigned long long *, int);
+template __global__ void k_chain<AL_CHAIN_CAP>(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, AlAnchor *, uint64_t *, uint32_t *, int32_t *, uint64_t *, const uint32_t *, int, AlParams, unsigned long long *, ChainSeg);
+
+// =============================================================================================
+// Segments (see ChainSeg, al_internal.h).  k_seg_scan: one wavefront per fragment of the list walks the sorted anchors 64 at a
+// time and cuts them wherever x[i] > x[i-1] + max_dist_x (the test that moves the window start in chain.c:52 -- once it fails
+// between neighbours no later anchor can reach back over the gap).  Segments that cannot hold a chain (fewer than lmin
+// anchors) are dropped.  mode 0 counts the fragment's segments, mode 1 writes them at seg_first[entry] in x order.
+// =============================================================================================
+__global__ void __launch_bounds__(64)
+k_seg_scan(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_off, const uint32_t *__restrict__ frag_na,
+           const uint32_t *__restrict__ frag_first, const uint32_t *__restrict__ rd_len, const uint32_t *__restrict__ frag_list, int n_list,
+           AlParams P, int lmin, int mode, const uint64_t *__restrict__ seg_first, uint32_t *__restrict__ seg_cnt,
+           uint64_t *__restrict__ vs_off, uint32_t *__restrict__ vs_na, uint32_t *__restrict__ vs_meta)
+{
+	const int lane = threadIdx.x;
+	if ((int)blockIdx.x >= n_list) return;
+	const uint32_t f = frag_list[blockIdx.x];
+	const int64_t n = frag_na[f];
+	const uint32_t r0 = frag_first[f], r1 = frag_first[f + 1];
+	int qlen_sum = 0; for (uint32_t r = r0; r < r1; ++r) qlen_sum += (int)rd_len[r];
+	int max_dist_x;                                                            // map.c:341-351
+	if (P.max_gap_ref > 0) max_dist_x = P.max_gap_ref;
+	else if (P.max_frag_len > 0) { max_dist_x = P.max_frag_len - qlen_sum; if (max_dist_x < P.max_gap) max_dist_x = P.max_gap; }
+	else max_dist_x = P.max_gap;
+	const uint32_t meta = (uint32_t)qlen_sum | (r1 - r0 > 1 ? 1u << 31 : 0u);
+	const uint64_t base_off = a_off[f];
+	const AlAnchor *a = anchors + base_off;
+	uint64_t out = mode ? seg_first[blockIdx.x] : 0;
+	uint32_t cnt = 0; int64_t open_start = 0; uint64_t prev_last = 0;
+	const unsigned long long below = (1ULL << lane) - 1ULL;
+	for (int64_t base = 0; base < n; base += 64) {
+		const int64_t i = base + lane; const bool valid = i < n;
+		const uint64_t x = valid ? a[i].x : 0;
+		uint64_t xp = (uint64_t)(uint32_t)__shfl_up((int)(uint32_t)x, 1) | (uint64_t)(uint32_t)__shfl_up((int)(uint32_t)(x >> 32), 1) << 32;
+		if (lane == 0) xp = prev_last;
+		const bool brk = valid && (i == 0 || x > xp + (uint64_t)max_dist_x);
+		const unsigned long long mask = __ballot(brk);
+		bool useful = false; int64_t start = 0;
+		if (brk && i > 0) {                                                     // this anchor closes the segment before it
+			const unsigned long long lower = mask & below;
+			start = lower ? base + (63 - __clzll((long long)lower)) : open_start;
+			useful = i - start >= lmin;
+		}
+		const unsigned long long um = __ballot(useful);
+		if (mode && useful) { const uint64_t k = out + cnt + __popcll(um & below); vs_off[k] = base_off + (uint64_t)start; vs_na[k] = (uint32_t)(i - start); vs_meta[k] = meta; }
+		cnt += (uint32_t)__popcll(um);
+		if (mask) open_start = base + (63 - __clzll((long long)mask));
+		prev_last = (uint64_t)(uint32_t)__shfl((int)(uint32_t)x, 63) | (uint64_t)(uint32_t)__shfl((int)(uint32_t)(x >> 32), 63) << 32;
+	}
+	if (n > 0 && n - open_start >= lmin) {
+		if (mode && lane == 0) { const uint64_t k = out + cnt; vs_off[k] = base_off + (uint64_t)open_start; vs_na[k] = (uint32_t)(n - open_start); vs_meta[k] = meta; }
+		++cnt;
+	}
+	if (!mode && lane == 0) seg_cnt[blockIdx.x] = cnt;
+}
+
+// k_seg_merge: the fragment's chain list from the chain lists of its segments.  chain.c:144-160 orders the chains by the x of
+// their first anchor; segments are disjoint x ranges in ascending order, so the fragment's order is the segments' orders
+// one after the other -- except that the reference's sort of more than 64 chains is not stable, so a fragment with more than
+// 64 chains of which two start at equal x is handed to the whole-fragment kernel (fb_list), which restates that sort.
+__global__ void __launch_bounds__(64)
+k_seg_merge(const uint32_t *__restrict__ frag_list, int n_list, const uint64_t *__restrict__ seg_first,
+            const uint64_t *__restrict__ vs_off, const uint32_t *__restrict__ vs_nu, const uint32_t *__restrict__ vs_nc, const uint32_t *__restrict__ vs_tie,
+            const uint64_t *__restrict__ u_tmp, const AlAnchor *__restrict__ chain_tmp, const uint64_t *__restrict__ a_off,
+            uint64_t *__restrict__ u_out, AlAnchor *__restrict__ chained, uint32_t *__restrict__ frag_nu,
+            uint32_t *__restrict__ fb_list, uint32_t *__restrict__ fb_cnt)
+{
+	__shared__ uint32_t s_bu[64], s_bc[64];
+	__shared__ uint64_t s_off[64];
+	const int lane = threadIdx.x;
+	if ((int)blockIdx.x >= n_list) return;
+	const uint32_t f = frag_list[blockIdx.x];
+	const uint64_t s0 = seg_first[blockIdx.x], s1 = seg_first[blockIdx.x + 1];
+	uint64_t *u = u_out + a_off[f] + f; AlAnchor *b = chained + a_off[f];
+	uint64_t run_u = 0, run_c = 0; bool tie = false;
+	for (uint64_t sb = s0; sb < s1; sb += 64) {
+		const uint64_t s = sb + lane; const bool valid = s < s1;
+		const uint32_t nu = valid ? vs_nu[s] : 0u, nc = valid ? vs_nc[s] : 0u;
+		tie = tie || (valid && vs_tie[s] != 0);
+		uint32_t iu = nu, ic = nc;
+		for (int d = 1; d < 64; d <<= 1) { const uint32_t tu = __shfl_up(iu, d), tc = __shfl_up(ic, d); if (lane >= d) { iu += tu; ic += tc; } }
+		const uint32_t tot_u = __shfl(iu, 63), tot_c = __shfl(ic, 63);
+		__syncthreads();
+		s_bu[lane] = iu - nu; s_bc[lane] = ic - nc; s_off[lane] = valid ? vs_off[s] : 0;
+		__syncthreads();
+		for (uint32_t t = lane; t < tot_u; t += 64) {
+			int lo = 0, hi = 64; while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_bu[mid] <= t) lo = mid; else hi = mid; }
+			u[run_u + t] = u_tmp[s_off[lo] + (t - s_bu[lo])];
+		}
+		for (uint32_t t = lane; t < tot_c; t += 64) {
+			int lo = 0, hi = 64; while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_bc[mid] <= t) lo = mid; else hi = mid; }
+			b[run_c + t] = chain_tmp[s_off[lo] + (t - s_bc[lo])];
+		}
+		run_u += tot_u; run_c += tot_c;
+	}
+	const bool any_tie = __ballot(tie) != 0;
+	if (lane == 0) {
+		frag_nu[f] = (uint32_t)run_u;
+		if (any_tie && run_u > 64) fb_list[atomicAdd(fb_cnt, 1u)] = f;
+	}
+}
+
+// lower bounds of up to 16 thresholds in an ascending key array (out[k] pre-set to n)
+__global__ void __launch_bounds__(256)
+k_lower_bounds(const uint32_t *__restrict__ keys, uint32_t n, LbThr T, uint32_t *__restrict__ out)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const uint32_t k = keys[i], kp = i ? keys[i - 1] : 0u;
+	for (int j = 0; j < T.n; ++j) if (k >= T.v[j] && (i == 0 || kp < T.v[j])) out[j] = i;
+}
 
 // rechain decision (map.c:353-375): one lane per fragment; appends fragments that must be re-seeded with max_occ
 extern "C" __global__ void __launch_bounds__(256)

@@ -2,6 +2,7 @@
 // on one HIP stream with per-stage events, and the stage taps used by the parity tests.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
+#include <rocprim/rocprim.hpp>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -20,13 +21,21 @@ extern "C" __global__ void k_rechain_test(const AlAnchor *, const uint64_t *, co
 template <int CAP> __global__ void k_anchor_sort(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, uint32_t *, unsigned int *, const uint32_t *, int, unsigned long long *, int);
 __global__ void k_anchor_sort_small(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, uint32_t *, unsigned int *, const uint32_t *, int, unsigned long long *, int);
 template <int HCAP, int LANES> __global__ void k_anchor_heap(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, AlAnchor *, const uint32_t *, const uint32_t *, int, int, unsigned long long *, int);
-template <int CAP> __global__ void k_chain(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, AlAnchor *, uint64_t *, uint32_t *, int32_t *, uint64_t *, const uint32_t *, int, AlParams, unsigned long long *, int);
-template <int CAPL, int LANES> __global__ void k_chain_lds(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, AlAnchor *, uint64_t *, uint32_t *, uint64_t *, const uint32_t *, int, int, AlParams, unsigned long long *);
+template <int CAP> __global__ void k_chain(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, AlAnchor *, uint64_t *, uint32_t *, int32_t *, uint64_t *, const uint32_t *, int, AlParams, unsigned long long *, ChainSeg);
+template <int CAPL, int LANES> __global__ void k_chain_lds(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, AlAnchor *, uint64_t *, uint32_t *, uint64_t *, const uint32_t *, int, int, AlParams, unsigned long long *, ChainSeg);
+template <int CAP> __global__ void k_anchor_sort_blk(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, uint32_t *, const uint32_t *, int, int);
+__global__ void k_anchor_big_expand(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint32_t *, int, const uint64_t *, uint64_t *, uint64_t *, int, int);
+__global__ void k_anchor_big_scatter(const uint64_t *, const uint64_t *, const uint32_t *, int, const uint64_t *, const uint64_t *, AlAnchor *, uint32_t *, int);
+__global__ void k_seg_scan(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *, int, AlParams, int, int, const uint64_t *, uint32_t *, uint64_t *, uint32_t *, uint32_t *);
+__global__ void k_seg_merge(const uint32_t *, int, const uint64_t *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlAnchor *, const uint64_t *, uint64_t *, AlAnchor *, uint32_t *, uint32_t *, uint32_t *);
+__global__ void k_lower_bounds(const uint32_t *, uint32_t, LbThr, uint32_t *);
 
-static const char *g_stage_names[ST_N] = { "sketch", "seed_lookup", "scan", "size_order", "anchor_sort_small", "anchor_sort", "chain_lds32", "chain_lds48", "chain_lds64", "chain_lds128", "chain_wave", "rechain",
+static const char *g_stage_names[ST_N] = { "sketch", "seed_lookup", "scan", "size_order", "anchor_sort_small", "anchor_sort", "anchor_sort_blk", "anchor_sort_big", "anchor_heap",
+                                           "chain_lds32", "chain_lds48", "chain_lds64", "chain_lds128", "seg_find", "seg_chain_lds", "seg_chain_wave", "seg_merge", "rechain",
                                            "regs", "ext_prep", "ext_sort", "ext_dp_lane", "ext_dp_g4", "ext_dp_g8", "ext_dp_g22", "ext_finish", "compact" };
-// kernel behind each interval (what rocprofv3 --kernel-trace lists); "" = several small launches
-static const char *g_stage_kernels[ST_N] = { "k_sketch", "k_seed", "", "", "k_anchor_sort_small", "k_anchor_sort<1024>", "k_chain_lds<16|24|32, 64>", "k_chain_lds<40|48, 64>", "k_chain_lds<64, 64>", "k_chain_lds<80|96, 64>, <128, 32>", "k_chain<384>", "",
+// kernel behind each interval (what rocprofv3 --kernel-trace lists); "" = several launches
+static const char *g_stage_kernels[ST_N] = { "k_sketch", "k_seed", "", "", "k_anchor_sort_small", "k_anchor_sort<1024>", "k_anchor_sort_blk<4096>", "", "",
+                                             "k_chain_lds<16|24|32, 64>", "k_chain_lds<40|48, 64>", "k_chain_lds<64, 64>", "k_chain_lds<80|96, 64>, <128, 32>", "", "", "k_chain<384>", "",  "",
                                              "k_regs", "k_ext_prep", "", "k_ext_dp_lane<16|32, 64>", "k_ext_dp<1|2|4, 512, ..>", "k_ext_dp<8, 512, 128>", "k_ext_dp<22, 512, 352>", "k_ext_finish", "k_compact" };
 extern "C" const char *al_stage_kernel(int i) { return i >= 0 && i < ST_N ? g_stage_kernels[i] : ""; }
 extern "C" const char *al_stage_name(int i) { return i >= 0 && i < ST_N ? g_stage_names[i] : ""; }
@@ -111,6 +120,7 @@ static void ctx_release_buffers(al_ctx_t *c)
 	c->ws_u64.release(); c->tmp_u64.release(); c->frag_rep.release(); c->ws_i32.release(); c->mini.release(); c->heap_ws.release(); c->anchors.release();
 	c->chained.release(); c->match.release(); c->counters.release(); c->scan_tmp.release(); c->regs0.release(); c->regs.release(); c->reg_cnt.release();
 	c->chain_key.release(); c->chain_idx.release(); c->chain_idx2.release(); c->tie_list.release(); c->lb_buf.release(); c->tmp_u64b.release();
+	c->chain_tmp.release(); c->u_tmp.release(); c->seg_cnt.release(); c->seg_first.release(); c->vs_off.release(); c->vs_na.release(); c->vs_meta.release(); c->vs_nu.release(); c->vs_nc.release(); c->vs_tie.release(); c->seg_key.release(); c->seg_idx.release(); c->seg_ord.release(); c->fb_list.release(); c->big_na.release(); c->big_off.release();
 	c->a_off_p1.release(); c->frag_na_p1.release(); c->frag_rep_p1.release(); c->cigar.release(); c->reg_off.release(); c->cig_off.release(); c->align_ws.release(); c->seg_a.release(); c->seg_u.release();
 }
 extern "C" void al_ctx_destroy(al_ctx_t *c)
@@ -209,11 +219,6 @@ static int scan_u32_to_u64(al_ctx_t *c, const uint32_t *in, uint64_t *out, int n
 	return 0;
 }
 
-__global__ void k_lower_bound(const uint32_t *keys, uint32_t n, uint32_t v, uint32_t *out)
-{   // first index with keys[i] >= v in an ascending array (out pre-set to n)
-	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i < n && keys[i] >= v && (i == 0 || keys[i - 1] < v)) *out = i;
-}
 __global__ void k_iota_u32(uint32_t *a, uint32_t n) { const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) a[i] = i; }
 __global__ void k_gather_na(const uint32_t *frag_na, const uint32_t *list, int n, uint32_t *out)
 {
@@ -230,7 +235,95 @@ static int ensure_anchor_space(al_ctx_t *c, uint64_t total, bool keep)
 {
 	const uint64_t nf = c->n_frag;
 	if (c->anchors.ensure(total + 1, keep, c->stream) || c->chained.ensure(total + 1, keep, c->stream) || c->u.ensure(total + nf + 2, keep, c->stream) ||
-	    c->ws_i32.ensure(total * 4 + 4, false, c->stream) || c->ws_u64.ensure(total + 1, false, c->stream)) return -1;
+	    c->ws_i32.ensure(total * 4 + 4, false, c->stream) || c->ws_u64.ensure(total + 1, false, c->stream) ||
+	    c->chain_tmp.ensure(total + 1, false, c->stream) || c->u_tmp.ensure(total + 1, false, c->stream)) return -1;
+	return 0;
+}
+
+// first index with keys[i] >= thr[k] in an ascending device array, for up to 16 thresholds (one kernel, one copy back)
+static int lower_bounds(al_ctx_t *c, const uint32_t *keys, uint32_t n, const uint32_t *thr, int nt, uint32_t *out)
+{
+	if (c->lb_buf.ensure(16)) return -1;
+	uint32_t init[16]; LbThr T; T.n = nt;
+	for (int i = 0; i < 16; ++i) { init[i] = n; T.v[i] = i < nt ? thr[i] : 0xffffffffu; }
+	AL_HIP_CHECK(hipMemcpyAsync(c->lb_buf.p, init, 64, hipMemcpyHostToDevice, c->stream));
+	if (n > 0) hipLaunchKernelGGL(k_lower_bounds, dim3((n + 255) / 256), dim3(256), 0, c->stream, keys, n, T, c->lb_buf.p);
+	AL_HIP_CHECK(hipMemcpyAsync(out, c->lb_buf.p, 4 * nt, hipMemcpyDeviceToHost, c->stream));
+	AL_HIP_CHECK(hipStreamSynchronize(c->stream));
+	return 0;
+}
+static int sort_u32_pairs(al_ctx_t *c, const uint32_t *k_in, uint32_t *k_out, const uint32_t *v_in, uint32_t *v_out, int n)
+{
+	size_t bytes = 0;
+	AL_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, k_in, k_out, v_in, v_out, n, 0, 32, c->stream));
+	if (c->scan_tmp.ensure(bytes + 16)) return -1;
+	AL_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(c->scan_tmp.p, bytes, k_in, k_out, v_in, v_out, n, 0, 32, c->stream));
+	return 0;
+}
+
+#define LCH(C, L, LO, AOFF, NA, CH, UO, NU, LIST, N, SEG) do { const int n__ = (N); if (n__ > 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain_lds<C, L>), dim3((n__ + L - 1) / L), dim3(64), 0, s, c->anchors.p, AOFF, NA, c->frag_first.p, c->rd_len.p, CH, UO, NU, c->ws_u64.p, LIST, n__, LO, c->P, c->counters.p, SEG); } while (0)
+
+// Chaining of the fragments order[0 .. n) (more than 128 anchors each, or any size when the compact LDS rows cannot hold the
+// options in force) through their segments: cut -> order the segments by length -> the lane-per-entry LDS kernels for segments
+// of up to 128 anchors, the wavefront kernel above -> k_seg_merge; fragments the merge hands back (equal-x chain starts among
+// more than 64 chains) are chained whole by the wavefront kernel.
+static int chain_by_segments(al_ctx_t *c, const uint32_t *order, int n, bool lds_ok, bool first)
+{
+	hipStream_t s = c->stream;
+	auto ev = [&](int st) -> int { if (first) AL_HIP_CHECK(hipEventRecord(c->ev[st + 1], s)); return 0; };
+	if (n <= 0) { if (ev(ST_SEG_FIND) || ev(ST_SEG_CHAIN_LDS) || ev(ST_SEG_CHAIN_WAVE) || ev(ST_SEG_MERGE)) return -1; return 0; }
+	// a segment of fewer than lmin anchors cannot hold a chain: min_cnt anchors, and min_chain_score at <= k + 1 per anchor (chain.c:60-73,118-124)
+	int lmin = c->opt.min_cnt > 1 ? c->opt.min_cnt : 1;
+	{ const int per = c->mi->k + 1, need = (c->opt.min_chain_score + per - 1) / per; if (need > lmin) lmin = need; }
+	if (c->seg_cnt.ensure((size_t)n + 2) || c->seg_first.ensure((size_t)n + 2)) return -1;
+	hipLaunchKernelGGL(k_seg_scan, dim3(n), dim3(64), 0, s, c->anchors.p, c->a_off.p, c->frag_na.p, c->frag_first.p, c->rd_len.p, order, n, c->P, lmin, 0,
+	                   (const uint64_t *)nullptr, c->seg_cnt.p, (uint64_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr);
+	AL_HIP_CHECK(hipMemsetAsync(c->seg_cnt.p + n, 0, 4, s));
+	if (scan_u32_to_u64(c, c->seg_cnt.p, c->seg_first.p, n)) return -1;
+	uint64_t ns64 = 0;
+	AL_HIP_CHECK(hipMemcpyAsync(&ns64, c->seg_first.p + n, 8, hipMemcpyDeviceToHost, s));
+	AL_HIP_CHECK(hipStreamSynchronize(s));
+	if (ns64 >= (1ULL << 31)) { fprintf(stderr, "[airlift] %llu chaining segments in one batch: upload fewer fragments\n", (unsigned long long)ns64); al_nomem_flag() = true; return -1; }
+	const int ns = (int)ns64;
+	if (c->vs_off.ensure((size_t)ns + 1) || c->vs_na.ensure((size_t)ns + 1) || c->vs_meta.ensure((size_t)ns + 1) || c->vs_nu.ensure((size_t)ns + 1) || c->vs_nc.ensure((size_t)ns + 1) ||
+	    c->vs_tie.ensure((size_t)ns + 1) || c->seg_key.ensure((size_t)ns + 1) || c->seg_idx.ensure((size_t)ns + 1) || c->seg_ord.ensure((size_t)ns + 1) || c->fb_list.ensure((size_t)n + 2)) return -1;
+	hipLaunchKernelGGL(k_seg_scan, dim3(n), dim3(64), 0, s, c->anchors.p, c->a_off.p, c->frag_na.p, c->frag_first.p, c->rd_len.p, order, n, c->P, lmin, 1,
+	                   (const uint64_t *)c->seg_first.p, (uint32_t *)nullptr, c->vs_off.p, c->vs_na.p, c->vs_meta.p);
+	uint32_t lb[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+	if (ns > 0) {
+		hipLaunchKernelGGL(k_iota_u32, dim3((ns + 255) / 256), dim3(256), 0, s, c->seg_idx.p, (uint32_t)ns);
+		if (sort_u32_pairs(c, c->vs_na.p, c->seg_key.p, c->seg_idx.p, c->seg_ord.p, ns)) return -1;
+		static const uint32_t thr[9] = {17, 25, 33, 41, 49, 65, 81, 97, 129};
+		if (lower_bounds(c, c->seg_key.p, (uint32_t)ns, thr, 9, lb)) return -1;
+	}
+	if (ev(ST_SEG_FIND)) return -1;
+	const ChainSeg sg{c->vs_meta.p, c->vs_tie.p, c->vs_nc.p};
+	if (ns > 0) {
+		const uint32_t *so = c->seg_ord.p;
+		const uint32_t wave_from = lds_ok ? lb[8] : 0u;
+		if (lds_ok) {
+#define LSEG(C, L, A, B) LCH(C, L, -1, c->vs_off.p, c->vs_na.p, c->chain_tmp.p, c->u_tmp.p, c->vs_nu.p, so + (A), (int)((B) - (A)), sg)
+			LSEG(16, 64, 0u, lb[0]); LSEG(24, 64, lb[0], lb[1]); LSEG(32, 64, lb[1], lb[2]); LSEG(40, 64, lb[2], lb[3]); LSEG(48, 64, lb[3], lb[4]);
+			LSEG(64, 64, lb[4], lb[5]); LSEG(80, 64, lb[5], lb[6]); LSEG(96, 64, lb[6], lb[7]); LSEG(128, 32, lb[7], lb[8]);
+#undef LSEG
+		}
+		if (ev(ST_SEG_CHAIN_LDS)) return -1;
+		const int nw = ns - (int)wave_from;
+		if (nw > 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<AL_CHAIN_CAP>), dim3(nw), dim3(64), 0, s, c->anchors.p, c->vs_off.p, c->vs_na.p, c->frag_first.p, c->rd_len.p, c->chain_tmp.p, c->u_tmp.p, c->vs_nu.p,
+		                               c->ws_i32.p, c->ws_u64.p, so + wave_from, nw, c->P, c->counters.p, sg);
+		if (ev(ST_SEG_CHAIN_WAVE)) return -1;
+	} else { if (ev(ST_SEG_CHAIN_LDS) || ev(ST_SEG_CHAIN_WAVE)) return -1; }
+	uint32_t *fb_cnt = (uint32_t *)(c->counters.p + 15);
+	AL_HIP_CHECK(hipMemsetAsync(fb_cnt, 0, 8, s));
+	hipLaunchKernelGGL(k_seg_merge, dim3(n), dim3(64), 0, s, order, n, c->seg_first.p, c->vs_off.p, c->vs_nu.p, c->vs_nc.p, c->vs_tie.p, c->u_tmp.p, c->chain_tmp.p, c->a_off.p,
+	                   c->u.p, c->chained.p, c->frag_nu.p, c->fb_list.p, fb_cnt);
+	uint32_t n_fb = 0;
+	AL_HIP_CHECK(hipMemcpyAsync(&n_fb, fb_cnt, 4, hipMemcpyDeviceToHost, s));
+	AL_HIP_CHECK(hipStreamSynchronize(s));
+	c->n_chain_fallback += n_fb;
+	if (n_fb > 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<AL_CHAIN_CAP>), dim3(n_fb), dim3(64), 0, s, c->anchors.p, c->a_off.p, c->frag_na.p, c->frag_first.p, c->rd_len.p, c->chained.p, c->u.p, c->frag_nu.p,
+	                                 c->ws_i32.p, c->ws_u64.p, c->fb_list.p, (int)n_fb, c->P, c->counters.p, ChainSeg{nullptr, nullptr, nullptr});
+	if (ev(ST_SEG_MERGE)) return -1;
 	return 0;
 }
 
@@ -239,9 +332,11 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 	hipStream_t s = c->stream;
 	const int nl = n_list;
 	if (nl == 0) return 0;
+	auto ev = [&](int st) -> int { if (first) AL_HIP_CHECK(hipEventRecord(c->ev[st + 1], s)); return 0; };
 	hipLaunchKernelGGL(k_seed, dim3((nl + 255) / 256), dim3(256), 0, s, c->di.tab, c->di.tab_bits, c->frag_first.p, c->rd_len.p, c->mini_off.p, c->mini.p, c->mini_cnt.p,
 	                   c->match.p, c->frag_nm.p, c->frag_na.p, c->frag_rep.p, list, nl, max_occ);
-	if (first) AL_HIP_CHECK(hipEventRecord(c->ev[ST_SEED + 1], s));
+	if (ev(ST_SEED)) return -1;
+	if (c->chain_key.ensure(nl + 1) || c->chain_idx.ensure(nl + 1) || c->chain_idx2.ensure(nl + 1)) return -1;
 	uint64_t total = 0;
 	if (first) {
 		AL_HIP_CHECK(hipMemsetAsync(c->frag_na.p + c->n_frag, 0, 4, s));
@@ -250,7 +345,6 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 		AL_HIP_CHECK(hipStreamSynchronize(s));
 		c->n_anchor_pass1 = total; c->n_anchor_total = total;
 		if (ensure_anchor_space(c, total, false)) return -1;
-		AL_HIP_CHECK(hipEventRecord(c->ev[ST_SCAN + 1], s));
 	} else {
 		hipLaunchKernelGGL(k_gather_na, dim3((nl + 256) / 256), dim3(256), 0, s, c->frag_na.p, list, nl, c->tmp_u32.p);
 		if (scan_u32_to_u64(c, c->tmp_u32.p, c->tmp_u64.p, nl)) return -1;
@@ -260,86 +354,100 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 		hipLaunchKernelGGL(k_scatter_off, dim3((nl + 255) / 256), dim3(256), 0, s, c->tmp_u64.p, list, nl, base_off, c->a_off.p);
 		c->n_anchor_total = base_off + total;
 	}
-	// fragments ordered by anchor count: the sort kernels and the chaining kernels are chosen per size class, and lanes of
-	// one wavefront get equal trip counts.  [0, lb65) <= 64 anchors, [lb65, lb129) <= 128 anchors, rest.
-	// the LDS chaining kernels keep 16-bit window-relative positions and 8-bit row indices: they need max_dist_x < 2^15 and
-	// max_chain_iter >= 128 (true for the short-read preset); other option values go through the wave-per-fragment kernel
+	if (ev(ST_SCAN)) return -1;
+	// Fragments ordered by anchor count: the sort kernels and the chaining kernels are chosen per size class, and the lanes of one
+	// wavefront get equal trip counts.  Class boundaries = lower bounds in the sorted counts.
+	// The LDS chaining kernels keep 16-bit window-relative positions and 8-bit row indices: they need max_dist_x < 2^15 and
+	// max_chain_iter >= 128 (true for the short-read preset); other option values go through the wave-per-entry kernel.
 	const int mdx = std::max(std::max(c->opt.max_gap_ref, c->opt.max_frag_len), c->opt.max_gap);
-	const bool lds_ok = mdx <= 0x7fff && c->opt.max_chain_iter >= 128;
-	const int lane_max = ((c->P.dbg >> 27) & 1) || !lds_ok ? 0 : 64;
-	const uint32_t *order = list; bool sorted = false;
-	uint32_t lb65 = (uint32_t)nl, lb81 = (uint32_t)nl, lb97 = (uint32_t)nl, lb129 = (uint32_t)nl;
-	if (first && lane_max > 0 && nl > 1024) {
-		if (c->chain_key.ensure(nl + 1) || c->chain_idx.ensure(nl + 1) || c->chain_idx2.ensure(nl + 1)) return -1;
-		hipLaunchKernelGGL(k_iota_u32, dim3((nl + 255) / 256), dim3(256), 0, s, c->chain_idx.p, (uint32_t)nl);
-		size_t bytes = 0;
-		AL_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const uint32_t *)c->frag_na.p, c->chain_key.p, (const uint32_t *)c->chain_idx.p, c->chain_idx2.p, nl, 0, 32, s));
-		if (c->scan_tmp.ensure(bytes + 16)) return -1;
-		AL_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(c->scan_tmp.p, bytes, (const uint32_t *)c->frag_na.p, c->chain_key.p, (const uint32_t *)c->chain_idx.p, c->chain_idx2.p, nl, 0, 32, s));
-		order = c->chain_idx2.p; sorted = true;
-		if (c->lb_buf.ensure(8)) return -1;
-		uint32_t *d_lb = c->lb_buf.p;
-		const uint32_t init[4] = {(uint32_t)nl, (uint32_t)nl, (uint32_t)nl, (uint32_t)nl};
-		AL_HIP_CHECK(hipMemcpyAsync(d_lb, init, 16, hipMemcpyHostToDevice, s));
-		hipLaunchKernelGGL(k_lower_bound, dim3((nl + 255) / 256), dim3(256), 0, s, c->chain_key.p, (uint32_t)nl, 65u, d_lb);
-		hipLaunchKernelGGL(k_lower_bound, dim3((nl + 255) / 256), dim3(256), 0, s, c->chain_key.p, (uint32_t)nl, 81u, d_lb + 1);
-		hipLaunchKernelGGL(k_lower_bound, dim3((nl + 255) / 256), dim3(256), 0, s, c->chain_key.p, (uint32_t)nl, 97u, d_lb + 2);
-		hipLaunchKernelGGL(k_lower_bound, dim3((nl + 255) / 256), dim3(256), 0, s, c->chain_key.p, (uint32_t)nl, 129u, d_lb + 3);
-		uint32_t lb[4];
-		AL_HIP_CHECK(hipMemcpyAsync(lb, d_lb, 16, hipMemcpyDeviceToHost, s));
-		AL_HIP_CHECK(hipStreamSynchronize(s));
-		lb81 = lb[1]; lb97 = lb[2];
-		lb65 = lb[0]; lb129 = lb[3];
+	const bool lds_ok = mdx <= 0x7fff && c->opt.max_chain_iter >= 128 && !((c->P.dbg >> 27) & 1);
+	if (first) hipLaunchKernelGGL(k_iota_u32, dim3((nl + 255) / 256), dim3(256), 0, s, c->chain_idx.p, (uint32_t)nl);
+	if (sort_u32_pairs(c, first ? c->frag_na.p : c->tmp_u32.p, c->chain_key.p, first ? c->chain_idx.p : list, c->chain_idx2.p, nl)) return -1;
+	const uint32_t *order = c->chain_idx2.p;
+	uint32_t lb[6];
+	{   // AL_TEST_SORT_BLK / AL_TEST_SORT_BIG (tests): smallest anchor count that goes to the block / device-wide sort
+		static const char *e1 = getenv("AL_TEST_SORT_BLK"), *e2 = getenv("AL_TEST_SORT_BIG");
+		uint32_t t_blk = e1 ? (uint32_t)atoi(e1) : 1025u, t_big = e2 ? (uint32_t)atoi(e2) : 4097u;
+		if (t_blk < 65u) t_blk = 65u; if (t_blk > 1025u) t_blk = 1025u; if (t_big < t_blk) t_big = t_blk; if (t_big > 4097u) t_big = 4097u;
+		const uint32_t thr[6] = {65, 81, 97, 129, t_blk, t_big};
+		if (lower_bounds(c, c->chain_key.p, (uint32_t)nl, thr, 6, lb)) return -1;
 	}
-	if (first) AL_HIP_CHECK(hipEventRecord(c->ev[ST_ORDER + 1], s));
+	const uint32_t lb65 = lb[0], lb81 = lb[1], lb97 = lb[2], lb129 = lb[3], lb1025 = lb[4], lb4097 = lb[5];
+	if (ev(ST_ORDER)) return -1;
 	{
-		const int n_small = sorted ? (int)lb65 : 0;
 		if (c->tie_list.ensure((size_t)c->n_frag + 2)) return -1;         // one flag per fragment id
 		unsigned int *tie_cnt = nullptr;
 		AL_HIP_CHECK(hipMemsetAsync(c->tie_list.p, 0, ((size_t)c->n_frag + 1) * 4, s));
-		if (n_small > 0) hipLaunchKernelGGL(k_anchor_sort_small, dim3(n_small), dim3(64), 0, s, c->di.pos, c->frag_first.p, c->rd_len.p, c->mini_off.p, c->match.p, c->frag_nm.p, c->frag_na.p,
-		                                    c->a_off.p, c->anchors.p, c->tie_list.p, tie_cnt, order, n_small, c->counters.p, c->mi->k);
-		if (first) AL_HIP_CHECK(hipEventRecord(c->ev[ST_ANCHOR_SORT_S + 1], s));
-		if (nl - n_small > 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_anchor_sort<1024>), dim3(nl - n_small), dim3(64), 0, s, c->di.pos, c->frag_first.p, c->rd_len.p, c->mini_off.p, c->match.p, c->frag_nm.p, c->frag_na.p,
-		                                         c->a_off.p, c->anchors.p, c->tie_list.p, tie_cnt, sorted ? order + n_small : list, nl - n_small, c->counters.p, c->mi->k);
-		// fragments the sort kernels handed over (equal keys, oversize): exact heap merge, one lane each, by heap size class
+		if (lb65 > 0) hipLaunchKernelGGL(k_anchor_sort_small, dim3(lb65), dim3(64), 0, s, c->di.pos, c->frag_first.p, c->rd_len.p, c->mini_off.p, c->match.p, c->frag_nm.p, c->frag_na.p,
+		                                 c->a_off.p, c->anchors.p, c->tie_list.p, tie_cnt, order, (int)lb65, c->counters.p, c->mi->k);
+		if (ev(ST_ANCHOR_SORT_S)) return -1;
+		if (lb1025 > lb65) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_anchor_sort<1024>), dim3(lb1025 - lb65), dim3(64), 0, s, c->di.pos, c->frag_first.p, c->rd_len.p, c->mini_off.p, c->match.p, c->frag_nm.p, c->frag_na.p,
+		                                      c->a_off.p, c->anchors.p, c->tie_list.p, tie_cnt, order + lb65, (int)(lb1025 - lb65), c->counters.p, c->mi->k);
+		if (ev(ST_ANCHOR_SORT)) return -1;
+		if (lb4097 > lb1025) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_anchor_sort_blk<4096>), dim3(lb4097 - lb1025), dim3(256), 0, s, c->di.pos, c->frag_first.p, c->rd_len.p, c->mini_off.p, c->match.p, c->frag_nm.p, c->frag_na.p,
+		                                        c->a_off.p, c->anchors.p, c->tie_list.p, order + lb1025, (int)(lb4097 - lb1025), c->mi->k);
+		if (ev(ST_ANCHOR_SORT_BLK)) return -1;
+		// above the LDS tiles: composite-key device radix sort, a chunk of fragments at a time so that rank + key bits fit 64
+		int rid_bits = 1; while ((1ULL << rid_bits) < c->mi->seq.size()) ++rid_bits;
+		const int kb = 33 + rid_bits;
+		const uint32_t chunk_max = kb >= 64 ? 1u : (64 - kb >= 31 ? 0x7fffffffu : (1u << (64 - kb)));
+		for (uint32_t b0 = lb4097; b0 < (uint32_t)nl; ) {
+			const uint32_t nb = std::min<uint32_t>((uint32_t)nl - b0, chunk_max);
+			if (c->big_na.ensure(nb + 2) || c->big_off.ensure(nb + 2)) return -1;
+			hipLaunchKernelGGL(k_gather_na, dim3((nb + 256) / 256), dim3(256), 0, s, c->frag_na.p, order + b0, (int)nb, c->big_na.p);
+			if (scan_u32_to_u64(c, c->big_na.p, c->big_off.p, (int)nb)) return -1;
+			uint64_t nbig = 0;
+			AL_HIP_CHECK(hipMemcpyAsync(&nbig, c->big_off.p + nb, 8, hipMemcpyDeviceToHost, s));
+			AL_HIP_CHECK(hipStreamSynchronize(s));
+			// key / value double buffers live in the chaining scratch (16 bytes per anchor each), free at this point
+			uint64_t *ka = (uint64_t *)c->ws_i32.p, *va = ka + nbig, *kbuf = (uint64_t *)c->chain_tmp.p, *vb = kbuf + nbig;
+			hipLaunchKernelGGL(k_anchor_big_expand, dim3(nb), dim3(256), 0, s, c->di.pos, c->frag_first.p, c->rd_len.p, c->mini_off.p, c->match.p, c->frag_nm.p, c->frag_na.p,
+			                   order + b0, (int)nb, c->big_off.p, ka, va, rid_bits, c->mi->k);
+			int rbits = 0; while ((1ULL << rbits) < nb) ++rbits;
+			rocprim::double_buffer<uint64_t> dk(ka, kbuf), dv(va, vb);
+			size_t bytes = 0;
+			AL_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, bytes, dk, dv, (size_t)nbig, 0u, (unsigned)(kb + rbits), s));
+			if (c->scan_tmp.ensure(bytes + 16)) return -1;
+			AL_HIP_CHECK(rocprim::radix_sort_pairs(c->scan_tmp.p, bytes, dk, dv, (size_t)nbig, 0u, (unsigned)(kb + rbits), s));
+			hipLaunchKernelGGL(k_anchor_big_scatter, dim3(nb), dim3(256), 0, s, dk.current(), dv.current(), order + b0, (int)nb, c->big_off.p, c->a_off.p, c->anchors.p, c->tie_list.p, rid_bits);
+			b0 += nb;
+		}
+		if (ev(ST_ANCHOR_SORT_BIG)) return -1;
+		// fragments the sort kernels handed over (equal keys): exact heap merge, one lane each, by heap size class
 #define LHEAP(H, LN, LO) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_anchor_heap<H, LN>), dim3((nl + LN - 1) / LN), dim3(64), 0, s, c->di.pos, c->frag_first.p, c->rd_len.p, c->mini_off.p, c->match.p, c->frag_nm.p, c->frag_na.p, \
 		                                  c->a_off.p, c->anchors.p, c->heap_ws.p, c->tie_list.p, order, nl, LO, c->counters.p, c->mi->k)
 		LHEAP(48, 64, -1); LHEAP(96, 32, 48); LHEAP(0, 64, 96);
 #undef LHEAP
-		if (first) AL_HIP_CHECK(hipEventRecord(c->ev[ST_ANCHOR_SORT + 1], s));
+		if (ev(ST_ANCHOR_HEAP)) return -1;
 	}
 	{
-#define LCH(C, L, LO, LIST, N) do { const int n__ = (N); if (n__ > 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain_lds<C, L>), dim3((n__ + L - 1) / L), dim3(64), 0, s, c->anchors.p, c->a_off.p, c->frag_na.p, c->frag_first.p, c->rd_len.p, c->chained.p, c->u.p, c->frag_nu.p, c->ws_u64.p, LIST, n__, LO, c->P, c->counters.p); } while (0)
-		const int n64 = sorted ? (int)lb65 : nl;                            // unsorted: wavefront-group ownership inside the kernels
-		if (lane_max > 0) { LCH(16, 64, -1, order, n64); LCH(24, 64, 16, order, n64); LCH(32, 64, 24, order, n64); }
-		if (first) AL_HIP_CHECK(hipEventRecord(c->ev[ST_CHAIN_LDS32 + 1], s));
-		if (lane_max > 0) { LCH(40, 64, 32, order, n64); LCH(48, 64, 40, order, n64); }
-		if (first) AL_HIP_CHECK(hipEventRecord(c->ev[ST_CHAIN_LDS48 + 1], s));
-		if (lane_max > 0) LCH(64, 64, 48, order, n64);
-		if (first) AL_HIP_CHECK(hipEventRecord(c->ev[ST_CHAIN_LDS64 + 1], s));
-		if (lane_max > 0 && sorted) {   // exact ranges of the size-ordered list (lane counts differ between these classes)
+		const ChainSeg nosg{nullptr, nullptr, nullptr};
+#define LFR(C, L, A, B) LCH(C, L, -1, c->a_off.p, c->frag_na.p, c->chained.p, c->u.p, c->frag_nu.p, order + (A), (int)((B) - (A)), nosg)
+#define LFRLO(C, L, LO) LCH(C, L, LO, c->a_off.p, c->frag_na.p, c->chained.p, c->u.p, c->frag_nu.p, order, (int)lb65, nosg)
+		if (lds_ok) { LFRLO(16, 64, -1); LFRLO(24, 64, 16); LFRLO(32, 64, 24); }
+		if (ev(ST_CHAIN_LDS32)) return -1;
+		if (lds_ok) { LFRLO(40, 64, 32); LFRLO(48, 64, 40); }
+		if (ev(ST_CHAIN_LDS48)) return -1;
+		if (lds_ok) LFRLO(64, 64, 48);
+		if (ev(ST_CHAIN_LDS64)) return -1;
+		if (lds_ok) {   // exact ranges of the size-ordered list (lane counts differ between these classes)
 			// 64-lane wavefronts hold more fragments per CU but need enough of them to cover the chip; a thin class runs on half waves
 			const uint32_t fill = 64u * 3u * 256u * 2u;
 			uint32_t from = lb65;
-			if (lb81 - lb65 >= fill) { LCH(80, 64, -1, order + lb65, (int)(lb81 - lb65)); from = lb81; }
-			if (from == lb81 && lb97 - lb81 >= fill) { LCH(96, 64, -1, order + lb81, (int)(lb97 - lb81)); from = lb97; }
-			LCH(128, 32, -1, order + from, (int)(lb129 - from));
+			if (lb81 - lb65 >= fill) { LFR(80, 64, lb65, lb81); from = lb81; }
+			if (from == lb81 && lb97 - lb81 >= fill) { LFR(96, 64, lb81, lb97); from = lb97; }
+			LFR(128, 32, from, lb129);
 		}
-		if (first) AL_HIP_CHECK(hipEventRecord(c->ev[ST_CHAIN_LDS128 + 1], s));
-#undef LCH
-		{
-			// wave-per-fragment kernel: the rest of the size-ordered list (or, unsorted, the wavefront-groups the LDS kernels do not own)
-			const uint32_t tail = sorted && lane_max > 0 ? lb129 : 0;
-			const int nt = nl - (int)tail;
-			if (nt > 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<AL_CHAIN_CAP>), dim3(nt), dim3(64), 0, s, c->anchors.p, c->a_off.p, c->frag_na.p, c->frag_first.p, c->rd_len.p, c->chained.p, c->u.p, c->frag_nu.p,
-			                   c->ws_i32.p, c->ws_u64.p, order ? order + tail : nullptr, nt, c->P, c->counters.p, sorted ? 0 : lane_max);
-		}
+		if (ev(ST_CHAIN_LDS128)) return -1;
+#undef LFR
+#undef LFRLO
+		const uint32_t tail = lds_ok ? lb129 : 0u;
+		if (chain_by_segments(c, order + tail, nl - (int)tail, lds_ok, first)) return -1;
 	}
-	if (first) AL_HIP_CHECK(hipEventRecord(c->ev[ST_CHAIN_WAVE + 1], s));
 	AL_HIP_CHECK(hipGetLastError());
 	return 0;
 }
+#undef LCH
 
 int al_run_seed_stages(al_ctx_t *c)
 {

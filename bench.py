@@ -110,8 +110,11 @@ def cpu_baseline(tmp, ref_fa, arr, n_pairs, read_len):
     nt = min(cores, 32)
     t0 = time.time()
     with open(os.path.join(tmp, "gpu.sam"), "wb") as f:
-        subprocess.run([cli, "-ax", "sr", "-t", str(nt), ref_fa, "cb_1.fq", "cb_2.fq"], cwd=tmp, stdout=f, stderr=subprocess.DEVNULL, check=True)
+        rc = subprocess.run([cli, "-ax", "sr", "-t", str(nt), ref_fa, "cb_1.fq", "cb_2.fq"], cwd=tmp, stdout=f, stderr=subprocess.PIPE)
     t_cli = time.time() - t0
+    if rc.returncode != 0:
+        sys.stderr.write("[bench] airlift-align failed (%d): %s\n" % (rc.returncode, rc.stderr.decode(errors="replace")[-2000:]))
+        return base, {"error": "airlift-align exit %d" % rc.returncode, "identical_sam": False}
     e2e = {"wall_s": t_cli, "reads_per_s": 2 * n_pairs / t_cli, "host_threads": nt, "cpu_wall_s": t_cold, "speedup_vs_cpu_wall": t_cold / t_cli,
            "identical_sam": md5(os.path.join(tmp, "gpu.sam")) == md5(os.path.join(tmp, "cpu.sam")),
            "note": "whole process, cold start: FASTA parse + index build on the GPU + FASTQ parse + mapping + SAM text; CPU wall = its index build + one mapping pass at all cores"}
@@ -211,7 +214,7 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    stage_ms = np.zeros(24); t0 = time.perf_counter()
+    stage_ms = np.zeros(40); t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
         st = ctx.stat()

@@ -176,7 +176,7 @@ typedef struct {
 	uint64_t bytes_in, bytes_out;
 	double   algorithmic_bytes;       /* SURVEY.md §8(d) formula evaluated with the counters above */
 	float    ms_total;                /* HIP events around the whole device pipeline */
-	float    ms_kernel[24];           /* HIP-event time per pipeline interval, see al_stage_name() / al_stage_kernel() */
+	float    ms_kernel[40];           /* HIP-event time per pipeline interval, see al_stage_name() / al_stage_kernel() */
 	int      n_stage;
 } al_batch_stat_t;
 void al_batch_stat(const al_ctx_t *ctx, al_batch_stat_t *st);

@@ -10,6 +10,8 @@
  *   -t a,b,c : thread sweep for the CPU baseline of bench.py: the input is mapped once per value (stdout to /dev/null for all
  *              but the last) and "[mm2ref] threads=N index_s=.. map_s=.." is printed on stderr for each, so that the index
  *              build is paid once and is not part of the mapping time
+ *   --save-index FILE : write the index (mm_idx_dump, index.c:438) after building it; a later run given FILE instead of ref.fa
+ *              loads it (mm_idx_reader_open recognises index files), so that several test cases share one index build
  *   --seeds  : mm_dbg_flag |= MM_DBG_PRINT_SEED  (RS/SD/CN lines on stderr, map.c:333-338,381-385)
  *   --alnseq : mm_dbg_flag |= MM_DBG_PRINT_ALN_SEQ (align.c:315-338)
  */
@@ -30,7 +32,7 @@ int main(int argc, char **argv)
 	double t_idx0, t_idx;
 	mm_idxopt_t io; mm_mapopt_t mo;
 	int i, n_threads = 1, nfn = 0;
-	const char *rg = 0, *fn[4];
+	const char *rg = 0, *fn[4], *save_idx = 0;
 	mm_idx_reader_t *r; mm_idx_t *mi;
 	mm_verbose = 1;
 	mm_set_opt(0, &io, &mo);
@@ -44,6 +46,7 @@ int main(int argc, char **argv)
 		}
 		else if (!strcmp(argv[i], "-R") && i + 1 < argc) rg = argv[++i];
 		else if (!strcmp(argv[i], "-K") && i + 1 < argc) mo.mini_batch_size = atoi(argv[++i]);
+		else if (!strcmp(argv[i], "--save-index") && i + 1 < argc) save_idx = argv[++i];
 		else if (!strcmp(argv[i], "--seeds")) mm_dbg_flag |= MM_DBG_PRINT_SEED;
 		else if (!strcmp(argv[i], "--alnseq")) mm_dbg_flag |= MM_DBG_PRINT_ALN_SEQ;
 		else if (!strcmp(argv[i], "--qname")) mm_dbg_flag |= MM_DBG_PRINT_QNAME;
@@ -79,6 +82,7 @@ int main(int argc, char **argv)
 	t_idx0 = wall();
 	while ((mi = mm_idx_reader_read(r, n_threads)) != 0) {
 		t_idx = wall() - t_idx0;
+		if (save_idx) { FILE *fp = fopen(save_idx, "wb"); if (fp) { mm_idx_dump(fp, mi); fclose(fp); } else { perror(save_idx); return 1; } }
 		mm_mapopt_update(&mo, mi);
 		for (si = 0; si < n_sweep; ++si) {
 			int saved = -1; double t0;

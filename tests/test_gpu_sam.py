@@ -58,6 +58,22 @@ def test_lds_dp_path_identical(golden_unpacked, name):
     assert r.stdout == exp, _diff_report(r.stdout, exp, name + "_lds")
 
 
+@pytest.mark.parametrize("env", [dict(AL_DBG=str(1 << 27)), dict(AL_TEST_SORT_BLK="65"), dict(AL_TEST_SORT_BIG="65"), dict(AL_TEST_SORT_BLK="65", AL_TEST_SORT_BIG="200")],
+                         ids=["segments_wave_only", "block_sort", "device_sort", "block_and_device_sort"])
+@pytest.mark.parametrize("name", ["g1_mt150pe", "g2_250pe", "g3_adversarial", "g6_repeats"])
+def test_large_fragment_paths_identical(golden_unpacked, name, env):
+    """The kernels that take over for fragments with many anchors -- chaining by segments (AL_DBG bit 27: every fragment goes
+    through the segment path and the wavefront kernel), the block bitonic sort and the device-wide radix sort of anchors
+    (thresholds lowered so that ordinary fragments reach them) -- must give the reference's bytes as well."""
+    d = golden_unpacked[name]
+    m = json.load(open(os.path.join(d, "meta.json")))
+    cmd = [CLI, "-ax", "sr"] + (["-R", m["rg"]] if m.get("rg") else [])
+    r = subprocess.run(cmd + [m["ref"]] + m["reads"], cwd=d, capture_output=True, env=dict(os.environ, **env))
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    exp = open(os.path.join(d, "expected.sam"), "rb").read()
+    assert r.stdout == exp, _diff_report(r.stdout, exp, name + "_" + "_".join(env))
+
+
 def test_yeast100k_digest(tmp_path):
     """G5: 100 k pairs on the 12 Mbp synthetic genome (the bench workload's shape): md5 of the whole SAM must equal the
     digest the reference build produced (tests/golden/g5_yeast100k/meta.json)."""
