@@ -804,9 +804,219 @@ __device__ __forceinline__ void d_frag_ws(const WsBase &W, uint32_t f, FragWs &o
 	o.seg_a[0] = W.seg_a + W.a_off[f]; o.seg_a[1] = nullptr;
 }
 
+// ---------------------------------------------------------------------------------------------
+// KA for fragments with many chains (reads inside interspersed repeats: hundreds to thousands of chains, of which
+// chain_post keeps the primaries and at most best_n secondaries).  One wavefront per fragment does mm_gen_regs's ordering
+// (hit.c:52-88), mm_set_parent (hit.c:109-167) and mm_select_sub / mm_select_sub_multi (hit.c:238-255, pe.c:6-43) in one
+// pass over the chains in score order, 64 at a time:
+//   * keys (score << 32 | count) ^ hash are sorted in registers (<= 64 chains) or by a bitonic network in LDS;
+//   * every lane tests its chain against the primaries found so far (kept in LDS: they are few, a primary must leave half
+//     of an earlier one uncovered).  The first chain of the group that no primary masks becomes a primary itself and the
+//     lanes behind it are tested again with the longer list; the lanes before it are final -- which is the order the
+//     reference's loop takes its decisions in.  uncov_len is the part of the chain's query interval that no overlapping
+//     primary covers: computed by an O(k^2) sweep without the reference's interval sort (same integer);
+//   * a final lane applies its score / count to the parent's subsc / n_sub (max and a counter: order does not matter),
+//     decides mm_select_sub(_multi) against its parent's record and takes the next output slot if it is kept.
+// Only the kept hits are written (ws.regs0[0 .. n0), ids and parents renumbered as mm_sync_regs does); regs_n0[f] = n0 tells
+// k_regs to start at mm_seg_gen.  Equal sort keys, more than PMAX primaries or more chains than the tile: regs_n0[f] stays
+// unset and k_regs runs the reference's sequence on one lane (exact order among equal keys).
+#define AL_REGS_PMAX 48
+#define AL_REGS_UNSET 0xffffffffu
+struct RegsSelShared {
+	int32_t qs[AL_REGS_PMAX], qe[AL_REGS_PMAX], score[AL_REGS_PMAX], cnt[AL_REGS_PMAX], as[AL_REGS_PMAX], rs[AL_REGS_PMAX], re[AL_REGS_PMAX], ridrev[AL_REGS_PMAX];
+	int32_t subsc[AL_REGS_PMAX], nsub[AL_REGS_PMAX], slot[AL_REGS_PMAX]; uint32_t hash[AL_REGS_PMAX];
+};
+template <int CAP>
+__global__ void __launch_bounds__(64)
+k_regs_select(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__ u_all, const uint32_t *__restrict__ frag_first,
+              const uint32_t *__restrict__ rd_len, const uint32_t *__restrict__ frag_hash, WsBase W, const uint32_t *__restrict__ list, int n_list,
+              AlParams P, uint32_t *__restrict__ regs_n0)
+{
+	__shared__ uint64_t skey[CAP > 0 ? CAP : 1];
+	__shared__ uint16_t sidx[CAP > 0 ? CAP : 1];
+	__shared__ RegsSelShared S;
+	const int lane = threadIdx.x;
+	if ((int)blockIdx.x >= n_list) return;
+	const uint32_t f = list[blockIdx.x];
+	const uint32_t r0 = frag_first[f], n_segs = frag_first[f + 1] - r0;
+	const int n_u = (int)W.frag_nu[f];
+	if (n_u > (CAP > 0 ? CAP : 64) || n_u < 2) return;                     // regs_n0[f] pre-set to AL_REGS_UNSET
+	FragWs ws; d_frag_ws(W, f, ws);
+	const int ql0 = (int)rd_len[r0], ql1 = n_segs > 1 ? (int)rd_len[r0 + 1] : 0, qlen = ql0 + ql1;
+	const AlAnchor *a = chained + W.a_off[f]; const uint64_t *u = u_all + W.a_off[f] + f;
+	const uint32_t fhash = frag_hash[f];
+	int max_gap_ref;
+	if (P.max_gap_ref > 0) max_gap_ref = P.max_gap_ref;
+	else if (P.max_frag_len > 0) { max_gap_ref = P.max_frag_len - qlen; if (max_gap_ref < P.max_gap) max_gap_ref = P.max_gap; }
+	else max_gap_ref = P.max_gap;
+	int32_t *const as_arr = ws.auxi;                                        // first anchor of chain c (capacity 2 * (4 n_u + 4) ints)
+	// ---- keys: (u ^ hash of the chain's first anchor), chain offsets by a running prefix sum ----
+	uint64_t key_r = 0; int idx_r = 0;                                      // n_u <= 64: lane's own entry
+	{
+		uint32_t run = 0;
+		for (int c0 = 0; c0 < n_u; c0 += 64) {
+			const int c = c0 + lane; const bool v = c < n_u;
+			const uint64_t uc = v ? u[c] : 0; const uint32_t cnt = (uint32_t)uc;
+			uint32_t incl = cnt;
+			for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+			const uint32_t as = run + incl - cnt;
+			run += __shfl(incl, 63);
+			if (v) {
+				as_arr[c] = (int32_t)as;
+				const AlAnchor fa = a[as];
+				const uint32_t h = (uint32_t)d_hash64((d_hash64(fa.x) + d_hash64(fa.y)) ^ fhash);
+				const uint64_t key = uc ^ h;
+				if (CAP > 0) { skey[c] = key; sidx[c] = (uint16_t)c; } else { key_r = key; idx_r = c; }
+			}
+		}
+	}
+	bool tie = false;
+	if (CAP > 0) {   // descending bitonic sort of (key, chain) in LDS
+		int npow2 = 1; while (npow2 < n_u) npow2 <<= 1;
+		for (int c = n_u + lane; c < npow2; c += 64) { skey[c] = 0; sidx[c] = 0xffff; }   // keys are > 0 (score >= min_chain_score > 0 in the high word): padding sorts last
+		__syncthreads();
+		for (int kk = 2; kk <= npow2; kk <<= 1)
+			for (int j = kk >> 1; j > 0; j >>= 1) {
+				for (int i = lane; i < npow2; i += 64) {
+					const int ixj = i ^ j;
+					if (ixj > i) {
+						const uint64_t x = skey[i], y = skey[ixj];
+						if ((x < y) == ((i & kk) == 0)) { skey[i] = y; skey[ixj] = x; const uint16_t t = sidx[i]; sidx[i] = sidx[ixj]; sidx[ixj] = t; }
+					}
+				}
+				__syncthreads();
+			}
+		for (int i = lane; i + 1 < n_u; i += 64) if (skey[i] == skey[i + 1]) tie = true;
+	} else {         // rank sort in registers (descending)
+		int rank = 0; const int klo = (int)(uint32_t)key_r, khi = (int)(uint32_t)(key_r >> 32);
+		for (int j = 0; j < n_u; ++j) {
+			const uint64_t kj = (uint64_t)(uint32_t)__shfl(klo, j) | (uint64_t)(uint32_t)__shfl(khi, j) << 32;
+			if (lane < n_u) { rank += kj > key_r ? 1 : 0; tie = tie || (kj == key_r && j != lane); }
+		}
+		// lane takes the entry whose rank is its lane number (ranks are a permutation when there is no tie)
+		int src = 0;
+		for (int j = 0; j < n_u; ++j) { const int rj = __shfl(rank, j); if (rj == lane) src = j; }
+		const int klo2 = __shfl(klo, src), khi2 = __shfl(khi, src), id2 = __shfl(idx_r, src);
+		key_r = (uint64_t)(uint32_t)klo2 | (uint64_t)(uint32_t)khi2 << 32; idx_r = id2;
+	}
+	if (__ballot(tie)) return;                                              // equal keys: the reference's (unstable) order is k_regs's business
+	// ---- one pass in score order ----
+	const float mask_level = P.mask_level;
+	const int min_diff = P.k * 2, best_n = P.best_n;
+	const int max_dist = n_segs == 2 ? ql0 + ql1 + max_gap_ref : 0;
+	int k = 0, slot_base = 0, n_2nd = 0; bool overflow = false;
+	const unsigned long long below = (1ULL << lane) - 1ULL;
+	for (int p0 = 0; p0 < n_u && !overflow; p0 += 64) {
+		const int p = p0 + lane; const bool v = p < n_u;
+		uint64_t key = 0; int c = 0;
+		if (v) { if (CAP > 0) { key = skey[p]; c = sidx[p]; } else { key = key_r; c = idx_r; } }
+		const int score = (int)(key >> 32); const uint32_t hsh = (uint32_t)key;
+		int cnt = 0, as = 0, rs = 0, re = 0, qs = 0, qe = 0, rid = 0, rev = 0;
+		if (v) {
+			cnt = (int)(uint32_t)u[c]; as = as_arr[c];
+			const AlAnchor fa = a[as], la = a[as + cnt - 1];
+			const int q_span = (int)(fa.y >> 32 & 0xff);
+			rev = (int)(fa.x >> 63); rid = (int)(fa.x << 1 >> 33);
+			rs = (int32_t)fa.x + 1 > q_span ? (int32_t)fa.x + 1 - q_span : 0; re = (int32_t)la.x + 1;
+			if (!rev) { qs = (int32_t)fa.y + 1 - q_span; qe = (int32_t)la.y + 1; }
+			else { qs = qlen - ((int32_t)la.y + 1); qe = qlen - ((int32_t)fa.y + 1 - q_span); }
+		}
+		bool pending = v;
+		while (__ballot(pending)) {
+			int pj = -1;                                                     // masking primary
+			if (pending) {
+				int n_cov = 0;
+				for (int j = 0; j < k; ++j) { const int sj = S.qs[j], ej = S.qe[j]; if (!(ej <= qs || sj >= qe)) ++n_cov; }
+				if (n_cov > 0) {
+					// uncov_len (hit.c:133-141): the part of [qs, qe) outside the union of the clipped overlapping intervals
+					int x = qs, uncov = 0;
+					for (;;) {
+						int best = 0x7fffffff;
+						for (int j = 0; j < k; ++j) { int sj = S.qs[j], ej = S.qe[j]; if (ej <= qs || sj >= qe) continue; if (sj < qs) sj = qs; if (ej > qe) ej = qe; if (ej > x && sj < best) best = sj; }
+						if (best == 0x7fffffff) break;
+						if (best > x) { uncov += best - x; x = best; }
+						bool grew = true;
+						while (grew) { grew = false; for (int j = 0; j < k; ++j) { int sj = S.qs[j], ej = S.qe[j]; if (ej <= qs || sj >= qe) continue; if (sj < qs) sj = qs; if (ej > qe) ej = qe; if (sj <= x && ej > x) { x = ej; grew = true; } } }
+					}
+					if (qe > x) uncov += qe - x;
+					for (int j = 0; j < k; ++j) {
+						const int sj = S.qs[j], ej = S.qe[j];
+						if (ej <= qs || sj >= qe) continue;
+						const int mn = ej - sj < qe - qs ? ej - sj : qe - qs, mx = ej - sj > qe - qs ? ej - sj : qe - qs;
+						const int ol = qs < sj ? (qe < sj ? 0 : qe < ej ? qe - sj : ej - sj) : (ej < qs ? 0 : ej < qe ? ej - qs : qe - qs);
+						if (__fsub_rn(al_fdiv((float)ol, (float)mn), al_fdiv((float)uncov, (float)mx)) > mask_level) { pj = j; break; }
+					}
+				}
+			}
+			const unsigned long long um = __ballot(pending && pj < 0);
+			const int first = um ? __ffsll((long long)um) - 1 : 64;
+			const bool fin = pending && lane < first;                        // masked, final
+			bool qual = false;
+			if (fin) {
+				atomicMax(&S.subsc[pj], score);
+				if (cnt >= S.cnt[pj]) atomicAdd(&S.nsub[pj], 1);
+				const int psc = S.score[pj];
+				if (n_segs <= 1) {                                            // mm_select_sub
+					if ((float)score >= __fmul_rn((float)psc, P.pri_ratio) || score + min_diff >= psc)
+						qual = !(qs == S.qs[pj] && qe == S.qe[pj] && (rid << 1 | rev) == S.ridrev[pj] && rs == S.rs[pj] && re == S.re[pj]);
+				} else {                                                       // mm_select_sub_multi
+					if (score + min_diff >= psc) qual = true;
+					else {
+						const int prev = S.ridrev[pj] & 1, prid = S.ridrev[pj] >> 1;
+						if (prev == rev && prid == rid && re - S.rs[pj] < max_dist && S.re[pj] - rs < max_dist) qual = (float)score >= __fmul_rn((float)psc, 0.2f);
+						else {
+							const int is_par_both = (n_segs == 2 && S.qs[pj] < ql0 && S.qe[pj] > ql0);
+							const int is_chi_both = (n_segs == 2 && qs < ql0 && qe > ql0);
+							if (is_chi_both || is_chi_both == is_par_both) qual = (float)score >= __fmul_rn((float)psc, P.pri_ratio);
+							else qual = (float)score >= __fmul_rn((float)psc, 0.7f);
+						}
+					}
+				}
+				if (!(P.pri_ratio > 0.0f)) qual = true;                        // selection switched off: everything is kept
+			}
+			const unsigned long long qm = __ballot(qual);
+			const bool kept = qual && (!(P.pri_ratio > 0.0f) || n_2nd + __popcll(qm & below) < best_n);
+			const unsigned long long km = __ballot(kept);
+			if (kept) {
+				AlReg R; d_reg_clear(&R);
+				R.id = slot_base + __popcll(km & below); R.parent = S.slot[pj]; R.score = R.score0 = score; R.hash = hsh; R.cnt = cnt; R.as = as;
+				d_reg_set_coor(&R, qlen, a);
+				ws.regs0[R.id] = R;
+			}
+			n_2nd += __popcll(qm); slot_base += __popcll(km);
+			if (first < 64) {
+				if (k >= AL_REGS_PMAX) overflow = true;
+				else if (lane == first) {
+					S.qs[k] = qs; S.qe[k] = qe; S.score[k] = score; S.cnt[k] = cnt; S.as[k] = as; S.rs[k] = rs; S.re[k] = re; S.ridrev[k] = rid << 1 | rev;
+					S.subsc[k] = 0; S.nsub[k] = 0; S.slot[k] = slot_base; S.hash[k] = hsh;
+				}
+				if (!overflow) { ++k; ++slot_base; }
+			}
+			__syncthreads();
+			pending = pending && lane > first;
+			if (overflow) break;
+		}
+	}
+	if (overflow) return;
+	const int n0 = slot_base;
+	for (int j = lane; j < k; j += 64) {                                     // the primaries, with their final subsc / n_sub
+		AlReg R; d_reg_clear(&R);
+		R.id = S.slot[j]; R.parent = R.id; R.score = R.score0 = S.score[j]; R.hash = S.hash[j]; R.cnt = S.cnt[j]; R.as = S.as[j];
+		R.subsc = S.subsc[j]; R.n_sub = S.nsub[j];
+		d_reg_set_coor(&R, qlen, a);
+		if (n0 != n_u && j == 0) R.flags |= ALR_SAM_PRI;                    // mm_sync_regs -> mm_set_sam_pri runs only when something was dropped
+		ws.regs0[R.id] = R;
+	}
+	if (lane == 0) regs_n0[f] = (uint32_t)n0;
+}
+template __global__ void k_regs_select<0>(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, WsBase, const uint32_t *, int, AlParams, uint32_t *);
+template __global__ void k_regs_select<1024>(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, WsBase, const uint32_t *, int, AlParams, uint32_t *);
+template __global__ void k_regs_select<8192>(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, WsBase, const uint32_t *, int, AlParams, uint32_t *);
+
 extern "C" __global__ void __launch_bounds__(256, AL_LB_REGS)
 k_regs(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__ u_all, const uint32_t *__restrict__ frag_first,
-       const uint32_t *__restrict__ rd_len, const uint32_t *__restrict__ frag_hash, WsBase W, int n_frag, AlParams P, unsigned long long *counters)
+       const uint32_t *__restrict__ rd_len, const uint32_t *__restrict__ frag_hash, WsBase W, int n_frag, AlParams P, unsigned long long *counters,
+       const uint32_t *__restrict__ regs_n0)
 {
 	const int f = blockIdx.x * blockDim.x + threadIdx.x;
 	if (f >= n_frag) return;
@@ -891,11 +1101,15 @@ k_regs(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__ u_all,
 		W.seg_na[r0] = c0; W.seg_na[r0 + 1] = c1;
 		return;
 	}
-	bool tie = d_gen_regs(hash, qlen_sum, (int)n_u, u, a, ws.regs0, ws.aux128);
-	int n0 = (int)n_u;
-	d_set_parent(P.mask_level, n0, ws.regs0, P.a * 2 + P.b, ws.aux64, ws.auxi);                       // chain_post, map.c:249-258
-	if (n_segs <= 1) d_select_sub(P.pri_ratio, P.k * 2, P.best_n, &n0, ws.regs0, ws.auxi);
-	else d_select_sub_multi(P.pri_ratio, 0.2f, 0.7f, max_gap_ref, P.k * 2, P.best_n, (int)n_segs, qlens, &n0, ws.regs0, ws.auxi);
+	bool tie = false; int n0 = (int)n_u;
+	const uint32_t pre_n0 = regs_n0 ? regs_n0[f] : AL_REGS_UNSET;
+	if (pre_n0 != AL_REGS_UNSET) n0 = (int)pre_n0;                                                    // k_regs_select did chain_post: ws.regs0[0 .. n0) are the kept hits
+	else {
+		tie = d_gen_regs(hash, qlen_sum, (int)n_u, u, a, ws.regs0, ws.aux128);
+		d_set_parent(P.mask_level, n0, ws.regs0, P.a * 2 + P.b, ws.aux64, ws.auxi);                   // chain_post, map.c:249-258
+		if (n_segs <= 1) d_select_sub(P.pri_ratio, P.k * 2, P.best_n, &n0, ws.regs0, ws.auxi);
+		else d_select_sub_multi(P.pri_ratio, 0.2f, 0.7f, max_gap_ref, P.k * 2, P.best_n, (int)n_segs, qlens, &n0, ws.regs0, ws.auxi);
+	}
 	AlReg *const mreg0 = ws.mreg[0], *const mreg1 = ws.mreg[1];
 	uint64_t *const su0 = ws.seg_u[0], *const su1 = ws.seg_u[1];
 	AlAnchor *const sa0 = ws.seg_a[0];
@@ -1759,12 +1973,13 @@ static int scan32(al_ctx_t *c, const uint32_t *in, uint64_t *out, int n)
 	return 0;
 }
 
+__global__ void k_lower_bounds(const uint32_t *, uint32_t, LbThr, uint32_t *);   // al_kernels_seed.hip
 struct AlignState {            // lives in al_ctx_s::align_state (opaque there)
 	DevBuf<AlReg> regs0, mregs, rtmp, out;
 	DevBuf<AlAnchor> aux128, seg_a;
 	DevBuf<uint64_t> aux64, seg_u, nu_off, out_off;
 	DevBuf<int32_t> auxi;
-	DevBuf<uint32_t> reg_cnt, seg_na, arena, seg_fast;
+	DevBuf<uint32_t> reg_cnt, seg_na, arena, seg_fast, regs_n0;
 	uint64_t arena_scale = 1;       // doubled by al_align_grow_arena() when a batch's long CIGARs overflowed the arena
 	DevBuf<uint8_t> gws;
 	DevBuf<float> logtab;
@@ -1791,7 +2006,7 @@ void al_align_state_free(al_ctx_t *c)
 	if (it == g_states.end()) return;
 	AlignState *s = it->second;
 	s->regs0.release(); s->mregs.release(); s->rtmp.release(); s->out.release(); s->aux128.release(); s->seg_a.release(); s->aux64.release(); s->seg_u.release();
-	s->nu_off.release(); s->out_off.release(); s->auxi.release(); s->reg_cnt.release(); s->seg_na.release(); s->arena.release(); s->gws.release(); s->logtab.release(); s->dbgbuf.release(); s->hist.release(); s->jobs.release(); s->outs.release(); s->rext.release(); s->seg_fast.release();
+	s->nu_off.release(); s->out_off.release(); s->auxi.release(); s->reg_cnt.release(); s->seg_na.release(); s->arena.release(); s->gws.release(); s->logtab.release(); s->dbgbuf.release(); s->hist.release(); s->jobs.release(); s->outs.release(); s->rext.release(); s->seg_fast.release(); s->regs_n0.release();
 	s->job_off.release(); s->sc_off.release(); s->sc_ws.release(); s->n_jobs.release(); s->n_sc.release(); s->job_key.release(); s->job_key2.release(); s->job_idx.release(); s->job_idx2.release(); s->frag_slow.release(); s->slow_list.release(); s->sort_tmp.release();
 	delete s; g_states.erase(it);
 }
@@ -1824,7 +2039,29 @@ int al_run_align_stage(al_ctx_t *c)
 	WsBase W;
 	W.regs0 = A->regs0.p; W.mregs = A->mregs.p; W.rtmp = A->rtmp.p; W.aux128 = A->aux128.p; W.seg_a = c->chain_tmp.p /* chaining scratch, free again */; W.aux64 = A->aux64.p; W.seg_u = A->seg_u.p; W.auxi = A->auxi.p;
 	W.nu_off = A->nu_off.p; W.frag_nu = c->frag_nu.p; W.a_off = c->a_off.p; W.reg_cnt = A->reg_cnt.p; W.seg_na = A->seg_na.p; W.rext = A->rext.p; W.seg_fast = A->seg_fast.p;
-	hipLaunchKernelGGL(k_regs, dim3((nf + 255) / 256), dim3(256), 0, s, c->chained.p, c->u.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, nf, c->P, c->counters.p);
+	// fragments with many chains: chain_post by a wavefront each (k_regs_select), by chain-count class
+	uint32_t *regs_n0 = nullptr;
+	if (!((c->P.dbg >> 19) & 1)) {
+		if (A->regs_n0.ensure(nf + 1) || c->chain_key.ensure(nf + 1) || c->chain_idx.ensure(nf + 1) || c->chain_idx2.ensure(nf + 1) || c->lb_buf.ensure(16)) return -1;
+		regs_n0 = A->regs_n0.p;
+		AL_HIP_CHECK(hipMemsetAsync(regs_n0, 0xff, (size_t)nf * 4, s));
+		hipLaunchKernelGGL(k_iota, dim3((nf + 255) / 256), dim3(256), 0, s, c->chain_idx.p, (uint32_t)nf);
+		size_t bytes = 0;
+		AL_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const uint32_t *)c->frag_nu.p, c->chain_key.p, (const uint32_t *)c->chain_idx.p, c->chain_idx2.p, nf, 0, 32, s));
+		if (c->scan_tmp.ensure(bytes + 16)) return -1;
+		AL_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(c->scan_tmp.p, bytes, (const uint32_t *)c->frag_nu.p, c->chain_key.p, (const uint32_t *)c->chain_idx.p, c->chain_idx2.p, nf, 0, 32, s));
+		uint32_t init[4] = {(uint32_t)nf, (uint32_t)nf, (uint32_t)nf, (uint32_t)nf}, lb[4];
+		AL_HIP_CHECK(hipMemcpyAsync(c->lb_buf.p, init, 16, hipMemcpyHostToDevice, s));
+		LbThr T; T.n = 4; T.v[0] = 5; T.v[1] = 65; T.v[2] = 1025; T.v[3] = 8193; for (int i = 4; i < 16; ++i) T.v[i] = 0xffffffffu;
+		hipLaunchKernelGGL(k_lower_bounds, dim3((nf + 255) / 256), dim3(256), 0, s, (const uint32_t *)c->chain_key.p, (uint32_t)nf, T, c->lb_buf.p);
+		AL_HIP_CHECK(hipMemcpyAsync(lb, c->lb_buf.p, 16, hipMemcpyDeviceToHost, s));
+		AL_HIP_CHECK(hipStreamSynchronize(s));
+		const uint32_t *ord = c->chain_idx2.p;
+		if (lb[1] > lb[0]) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_select<0>), dim3(lb[1] - lb[0]), dim3(64), 0, s, c->chained.p, c->u.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, ord + lb[0], (int)(lb[1] - lb[0]), c->P, regs_n0);
+		if (lb[2] > lb[1]) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_select<1024>), dim3(lb[2] - lb[1]), dim3(64), 0, s, c->chained.p, c->u.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, ord + lb[1], (int)(lb[2] - lb[1]), c->P, regs_n0);
+		if (lb[3] > lb[2]) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_select<8192>), dim3(lb[3] - lb[2]), dim3(64), 0, s, c->chained.p, c->u.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, ord + lb[2], (int)(lb[3] - lb[2]), c->P, regs_n0);
+	}
+	hipLaunchKernelGGL(k_regs, dim3((nf + 255) / 256), dim3(256), 0, s, c->chained.p, c->u.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, nf, c->P, c->counters.p, (const uint32_t *)regs_n0);
 	AL_HIP_CHECK(hipEventRecord(c->ev[ST_REGS + 1], s));
 	// extension stage geometry
 	int Lmax = 0; for (int i = 0; i < nr; ++i) Lmax = std::max<int>(Lmax, (int)c->h_rd_len[i]);

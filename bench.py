@@ -228,6 +228,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     st = ctx.stat()
+    dist_info = None
+    if rank == 0:   # distribution of the per-fragment sizes that decide which kernels run
+        na = ctx.tap("frag_na", np.uint32, a.pairs); nu = ctx.tap("frag_nu", np.uint32, a.pairs)
+        pc = lambda v: {"p50": int(np.percentile(v, 50)), "p90": int(np.percentile(v, 90)), "p99": int(np.percentile(v, 99)), "max": int(v.max())} if len(v) else {}
+        dist_info = {"anchors_per_fragment": pc(na), "chains_per_fragment": pc(nu)}
+    ctx.close(); idx.close()          # the CPU baseline / CLI legs below start their own processes on this GPU
     if rank == 0:
         names = [L.al_stage_name(i).decode() for i in range(st.n_stage)]
         per = {names[i]: float(stage_ms[i] / a.steps) for i in range(st.n_stage)}
@@ -248,7 +254,7 @@ def main():
             "stages_ms": per,
             "counters": {"minimizers_per_read": st.n_mini / (2.0 * a.pairs), "anchors_per_pair": st.n_anchor / float(a.pairs), "chains_per_pair": st.n_chain / float(a.pairs),
                          "regions_aligned_per_read": st.n_regs_aln / (2.0 * a.pairs), "ref_bases_per_region": st.n_refbases / max(1.0, float(st.n_regs_aln)),
-                         "rechain": int(st.n_rechain), "heap_fallback": int(st.n_heap_fallback), "sort_tie_flags": int(st.n_sort_tie_flag)},
+                         "rechain": int(st.n_rechain), "heap_fallback": int(st.n_heap_fallback), "sort_tie_flags": int(st.n_sort_tie_flag), **(dist_info or {})},
             "host": {"index_build_on_gpu_s": t_index, "pack_upload_s": t_upload, "reference_generation_s": t_gen, "read_simulation_s": t_reads, "reference_model": getattr(ref, "stats", None)},
         }
         if world == 1 and not a.no_cpu_baseline:
@@ -256,7 +262,6 @@ def main():
             out["parity_sample"] = {"pairs": min(a.cpu_sample_pairs, a.pairs), "identical": out["e2e_cli"]["identical_sam"]}
         print(json.dumps(out))
     shutil.rmtree(tmp, ignore_errors=True)
-    ctx.close(); idx.close()
     if dist is not None:
         dist.destroy_process_group()
 
