@@ -13,6 +13,7 @@
 #include <string.h>
 #include <math.h>
 #include <vector>
+#include <type_traits>
 #include "al_internal.h"
 #include "al_device.h"
 #include "al_runtime.h"
@@ -826,22 +827,26 @@ struct RegsSelShared {
 	int32_t qs[AL_REGS_PMAX], qe[AL_REGS_PMAX], score[AL_REGS_PMAX], cnt[AL_REGS_PMAX], as[AL_REGS_PMAX], rs[AL_REGS_PMAX], re[AL_REGS_PMAX], ridrev[AL_REGS_PMAX];
 	int32_t subsc[AL_REGS_PMAX], nsub[AL_REGS_PMAX], slot[AL_REGS_PMAX]; uint32_t hash[AL_REGS_PMAX];
 };
-template <int CAP>
-__global__ void __launch_bounds__(64)
+template <int CAP>      // CAP > 0: sort tile in LDS; 0: at most 64 chains, registers; < 0: sort keys in the fragment's global work area (any count)
+__global__ void __launch_bounds__(CAP == 0 ? 64 : 256)
 k_regs_select(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__ u_all, const uint32_t *__restrict__ frag_first,
               const uint32_t *__restrict__ rd_len, const uint32_t *__restrict__ frag_hash, WsBase W, const uint32_t *__restrict__ list, int n_list,
               AlParams P, uint32_t *__restrict__ regs_n0)
 {
-	__shared__ uint64_t skey[CAP > 0 ? CAP : 1];
-	__shared__ uint16_t sidx[CAP > 0 ? CAP : 1];
+	__shared__ uint64_t skey_l[CAP > 0 ? CAP : 1];
+	__shared__ uint16_t sidx_l[CAP > 0 ? CAP : 1];
 	__shared__ RegsSelShared S;
-	const int lane = threadIdx.x;
+	constexpr int NT = CAP == 0 ? 64 : 256;                                 // all threads sort; the first wavefront makes the pass
+	const int tid = threadIdx.x, lane = tid & 63;
 	if ((int)blockIdx.x >= n_list) return;
 	const uint32_t f = list[blockIdx.x];
 	const uint32_t r0 = frag_first[f], n_segs = frag_first[f + 1] - r0;
 	const int n_u = (int)W.frag_nu[f];
-	if (n_u > (CAP > 0 ? CAP : 64) || n_u < 2) return;                     // regs_n0[f] pre-set to AL_REGS_UNSET
+	if ((CAP >= 0 && n_u > (CAP > 0 ? CAP : 64)) || n_u < 2) return;        // regs_n0[f] pre-set to AL_REGS_UNSET
 	FragWs ws; d_frag_ws(W, f, ws);
+	uint64_t *const skey = CAP > 0 ? skey_l : ws.aux64;                      // capacity 4 n_u + 4 >= the next power of two
+	typedef typename std::conditional<(CAP > 0), uint16_t, uint32_t>::type IdxT;
+	IdxT *const sidx = CAP > 0 ? (IdxT *)sidx_l : (IdxT *)(ws.auxi + (4 * n_u + 4));
 	const int ql0 = (int)rd_len[r0], ql1 = n_segs > 1 ? (int)rd_len[r0 + 1] : 0, qlen = ql0 + ql1;
 	const AlAnchor *a = chained + W.a_off[f]; const uint64_t *u = u_all + W.a_off[f] + f;
 	const uint32_t fhash = frag_hash[f];
@@ -854,6 +859,7 @@ k_regs_select(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__
 	uint64_t key_r = 0; int idx_r = 0;                                      // n_u <= 64: lane's own entry
 	{
 		uint32_t run = 0;
+		if (tid < 64)
 		for (int c0 = 0; c0 < n_u; c0 += 64) {
 			const int c = c0 + lane; const bool v = c < n_u;
 			const uint64_t uc = v ? u[c] : 0; const uint32_t cnt = (uint32_t)uc;
@@ -866,26 +872,27 @@ k_regs_select(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__
 				const AlAnchor fa = a[as];
 				const uint32_t h = (uint32_t)d_hash64((d_hash64(fa.x) + d_hash64(fa.y)) ^ fhash);
 				const uint64_t key = uc ^ h;
-				if (CAP > 0) { skey[c] = key; sidx[c] = (uint16_t)c; } else { key_r = key; idx_r = c; }
+				if (CAP != 0) { skey[c] = key; sidx[c] = (IdxT)c; } else { key_r = key; idx_r = c; }
 			}
 		}
 	}
 	bool tie = false;
-	if (CAP > 0) {   // descending bitonic sort of (key, chain) in LDS
+	if (CAP != 0) {   // descending bitonic sort of (key, chain), in LDS or in the fragment's work area
 		int npow2 = 1; while (npow2 < n_u) npow2 <<= 1;
-		for (int c = n_u + lane; c < npow2; c += 64) { skey[c] = 0; sidx[c] = 0xffff; }   // keys are > 0 (score >= min_chain_score > 0 in the high word): padding sorts last
+		for (int c = n_u + tid; c < npow2; c += NT) { skey[c] = 0; sidx[c] = (IdxT)~0u; }   // keys are > 0 (a chain's score, in the high word): padding sorts last
 		__syncthreads();
 		for (int kk = 2; kk <= npow2; kk <<= 1)
 			for (int j = kk >> 1; j > 0; j >>= 1) {
-				for (int i = lane; i < npow2; i += 64) {
+				for (int i = tid; i < npow2; i += NT) {
 					const int ixj = i ^ j;
 					if (ixj > i) {
 						const uint64_t x = skey[i], y = skey[ixj];
-						if ((x < y) == ((i & kk) == 0)) { skey[i] = y; skey[ixj] = x; const uint16_t t = sidx[i]; sidx[i] = sidx[ixj]; sidx[ixj] = t; }
+						if ((x < y) == ((i & kk) == 0)) { skey[i] = y; skey[ixj] = x; const IdxT t = sidx[i]; sidx[i] = sidx[ixj]; sidx[ixj] = t; }
 					}
 				}
 				__syncthreads();
 			}
+		if (tid >= 64) return;
 		for (int i = lane; i + 1 < n_u; i += 64) if (skey[i] == skey[i + 1]) tie = true;
 	} else {         // rank sort in registers (descending)
 		int rank = 0; const int klo = (int)(uint32_t)key_r, khi = (int)(uint32_t)(key_r >> 32);
@@ -909,7 +916,7 @@ k_regs_select(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__
 	for (int p0 = 0; p0 < n_u && !overflow; p0 += 64) {
 		const int p = p0 + lane; const bool v = p < n_u;
 		uint64_t key = 0; int c = 0;
-		if (v) { if (CAP > 0) { key = skey[p]; c = sidx[p]; } else { key = key_r; c = idx_r; } }
+		if (v) { if (CAP != 0) { key = skey[p]; c = (int)sidx[p]; } else { key = key_r; c = idx_r; } }
 		const int score = (int)(key >> 32); const uint32_t hsh = (uint32_t)key;
 		int cnt = 0, as = 0, rs = 0, re = 0, qs = 0, qe = 0, rid = 0, rev = 0;
 		if (v) {
@@ -992,7 +999,7 @@ k_regs_select(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__
 				}
 				if (!overflow) { ++k; ++slot_base; }
 			}
-			__syncthreads();
+			__threadfence_block();                                           // one wavefront: the new primary's LDS record before the next round reads it
 			pending = pending && lane > first;
 			if (overflow) break;
 		}
@@ -1012,6 +1019,7 @@ k_regs_select(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__
 template __global__ void k_regs_select<0>(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, WsBase, const uint32_t *, int, AlParams, uint32_t *);
 template __global__ void k_regs_select<1024>(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, WsBase, const uint32_t *, int, AlParams, uint32_t *);
 template __global__ void k_regs_select<8192>(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, WsBase, const uint32_t *, int, AlParams, uint32_t *);
+template __global__ void k_regs_select<-1>(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, WsBase, const uint32_t *, int, AlParams, uint32_t *);
 
 extern "C" __global__ void __launch_bounds__(256, AL_LB_REGS)
 k_regs(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__ u_all, const uint32_t *__restrict__ frag_first,
@@ -2058,8 +2066,9 @@ int al_run_align_stage(al_ctx_t *c)
 		AL_HIP_CHECK(hipStreamSynchronize(s));
 		const uint32_t *ord = c->chain_idx2.p;
 		if (lb[1] > lb[0]) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_select<0>), dim3(lb[1] - lb[0]), dim3(64), 0, s, c->chained.p, c->u.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, ord + lb[0], (int)(lb[1] - lb[0]), c->P, regs_n0);
-		if (lb[2] > lb[1]) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_select<1024>), dim3(lb[2] - lb[1]), dim3(64), 0, s, c->chained.p, c->u.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, ord + lb[1], (int)(lb[2] - lb[1]), c->P, regs_n0);
-		if (lb[3] > lb[2]) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_select<8192>), dim3(lb[3] - lb[2]), dim3(64), 0, s, c->chained.p, c->u.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, ord + lb[2], (int)(lb[3] - lb[2]), c->P, regs_n0);
+		if (lb[2] > lb[1]) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_select<1024>), dim3(lb[2] - lb[1]), dim3(256), 0, s, c->chained.p, c->u.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, ord + lb[1], (int)(lb[2] - lb[1]), c->P, regs_n0);
+		if (lb[3] > lb[2]) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_select<8192>), dim3(lb[3] - lb[2]), dim3(256), 0, s, c->chained.p, c->u.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, ord + lb[2], (int)(lb[3] - lb[2]), c->P, regs_n0);
+		if ((uint32_t)nf > lb[3]) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_select<-1>), dim3((uint32_t)nf - lb[3]), dim3(256), 0, s, c->chained.p, c->u.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, ord + lb[3], (int)((uint32_t)nf - lb[3]), c->P, regs_n0);
 	}
 	hipLaunchKernelGGL(k_regs, dim3((nf + 255) / 256), dim3(256), 0, s, c->chained.p, c->u.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, nf, c->P, c->counters.p, (const uint32_t *)regs_n0);
 	AL_HIP_CHECK(hipEventRecord(c->ev[ST_REGS + 1], s));
