@@ -6,6 +6,8 @@
 //          airlift-align samse REF.fa X.sai GAPS.fa                              (align_gaps.sh:15; does the actual single-end mapping)
 //          airlift-align index REF.fa                                             (accepted, no-op: the index is built on the GPU per run)
 //   mm2    airlift-align -ax sr [-t N] [-R RG] [-K NUM] [--sam-hit-only] REF.fa R1 [R2]   (fork README usage; main.c:113-273)
+//   8e     airlift-align ... --devices 0-7 [-o out.sam]      reads sharded over several GPUs of the node (index built once, copied
+//                                                                   device to device; with a regular output file every lane pwrite()s its block)
 //   N3     airlift-align ... --bam | --sorted-bam [-l LEVEL]       BAM on stdout; sorted = mapped records in coordinate order,
 //                                                                   i.e. the result of `| samtools view -h -F4 | samtools sort -l5`
 //   N2     airlift-align tokens --read-size R --skip S [-t N] REF.fa GAPS.fa      gaps_to_fasta.py GAPS.fa R tokens.fa S ; samse REF x tokens.fa
@@ -43,7 +45,7 @@ int main(int argc, char **argv)
 {
 	al_idxopt_t io; al_mapopt_t mo;
 	struct timespec tsm; clock_gettime(CLOCK_MONOTONIC, &tsm);
-	std::vector<const char *> pos; const char *rg = nullptr; int n_threads = 3, device = -1; bool count_only = false; int bam_mode = 0, bam_level = 5;
+	std::vector<const char *> pos; const char *rg = nullptr; int n_threads = 3, device = -1; std::vector<int> devices; bool count_only = false; int bam_mode = 0, bam_level = 5;
 	enum { MODE_MEM, MODE_ALN, MODE_SAMSE, MODE_MM2, MODE_TOKENS } mode = MODE_MM2; int tok_size = 0, tok_skip = 1;
 	int i = 1;
 	if (argc < 2) return usage();
@@ -93,6 +95,17 @@ int main(int argc, char **argv)
 		else if (!strcmp(a, "--sorted-bam")) bam_mode = 2;
 		else if (!strcmp(a, "-l") && i + 1 < argc) bam_level = atoi(argv[++i]);
 		else if (!strcmp(a, "--device") && i + 1 < argc) device = atoi(argv[++i]);
+		else if (!strcmp(a, "--devices") && i + 1 < argc) {   // "0-7", "0,1,2", "0,0" (two lanes on one GPU): reads of every mini-batch sharded over the lanes
+			const char *p = argv[++i];
+			while (*p) {
+				char *e; const long v0 = strtol(p, &e, 10); long v1 = v0;
+				if (e == p) { fprintf(stderr, "[ERROR] --devices expects a list like 0-7 or 0,1,2\n"); return 1; }
+				if (*e == '-') { p = e + 1; v1 = strtol(p, &e, 10); }
+				for (long v = v0; v <= v1 && devices.size() < 64; ++v) devices.push_back((int)v);
+				p = *e == ',' ? e + 1 : e;
+				if (*e && *e != ',') { fprintf(stderr, "[ERROR] --devices expects a list like 0-7 or 0,1,2\n"); return 1; }
+			}
+		}
 		else if (!strcmp(a, "-o") && i + 1 < argc) { const char *fn = argv[++i]; if (strcmp(fn, "-") != 0 && !freopen(fn, "wb", stdout)) { fprintf(stderr, "[ERROR] failed to write the output to file '%s'\n", fn); return 1; } }   // main.c:183-190
 		else if (!strcmp(a, "--version")) { puts(al_version()); return 0; }
 		else { fprintf(stderr, "[WARNING] airlift-align: option '%s' ignored\n", a); }
@@ -111,6 +124,7 @@ int main(int argc, char **argv)
 		ref = pos[0]; for (size_t j = 1; j < pos.size(); ++j) reads.push_back(pos[j]);
 	}
 	struct timespec ts0, ts1; clock_gettime(CLOCK_MONOTONIC, &ts0);
+	if (!devices.empty()) device = devices[0];
 	al_idx_t *mi = getenv("AL_HOST_INDEX") ? al_idx_build(ref, &io, n_threads) : al_idx_build_device(ref, &io, device);
 	clock_gettime(CLOCK_MONOTONIC, &ts1);
 	if (getenv("AL_TIMING")) fprintf(stderr, "[airlift] index build %.3f s\n", (ts1.tv_sec - ts0.tv_sec) + 1e-9 * (ts1.tv_nsec - ts0.tv_nsec));
@@ -131,7 +145,8 @@ int main(int argc, char **argv)
 		fflush(stderr);
 		_exit(0);
 	}
-	int rc = bam_mode ? al_map_file_frag_bam(mi, (int)reads.size(), reads.data(), &mo, n_threads, stdout, rg, device, bam_mode == 2, bam_level)
+	int rc = devices.size() > 1 ? al_map_file_frag_multi(mi, (int)reads.size(), reads.data(), &mo, n_threads, stdout, rg, devices.data(), (int)devices.size(), bam_mode, bam_level)
+	       : bam_mode ? al_map_file_frag_bam(mi, (int)reads.size(), reads.data(), &mo, n_threads, stdout, rg, device, bam_mode == 2, bam_level)
 	                  : al_map_file_frag(mi, (int)reads.size(), reads.data(), &mo, n_threads, stdout, rg, device);
 	clock_gettime(CLOCK_MONOTONIC, &ts0);
 	al_idx_destroy(mi);

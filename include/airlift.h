@@ -138,6 +138,19 @@ int  al_map_file_frag(const al_idx_t *mi, int n_segs, const char **fn, const al_
 int  al_map_file_frag_bam(const al_idx_t *mi, int n_segs, const char **fn, const al_mapopt_t *opt, int n_threads,
                           FILE *out, const char *rg, int device, int sorted, int level);
 
+/* Several GPUs of one node (the reference's analogue is kt_for over the fragments of a mini-batch, map.c:592, with
+ * its serial ordered writer, map.c:601-644): lane r is a mapping context on devices[r] (a device may appear twice: two lanes
+ * overlap transfers and kernels on it); every mini-batch is cut into n_dev contiguous fragment ranges, lane r maps range r.
+ * The index is built once and copied device to device.  The lanes exchange only {records, bytes} of their output blocks per
+ * batch (a 16-byte ncclAllGather over xGMI when they sit on distinct GPUs), take the exclusive prefix sum as their file offset
+ * and pwrite() their block when `out` is a regular file (ordered turns otherwise).  bam_mode 0 SAM, 1 BAM, 2 sorted BAM.
+ * Output bytes are those of al_map_file_frag / al_map_file_frag_bam. */
+int  al_map_file_frag_multi(const al_idx_t *mi, int n_segs, const char **fn, const al_mapopt_t *opt, int n_threads,
+                            FILE *out, const char *rg, const int *devices, int n_dev, int bam_mode, int level);
+
+/* Self-test of the multi-lane output path (offset exchange + pwrite, or ordered turns) with synthetic blocks; needs no GPU. */
+int  al_dbg_ordered_out_selftest(const char *path, int n_lanes, int n_batches, int use_offsets);
+
 /* ---- device-resident batch API (bench / multi-GPU harness; inputs already in HBM when timing starts) ---- */
 /* Pack + upload a batch; returns 0.  The batch stays resident until the next upload. */
 int  al_batch_upload(al_ctx_t *ctx, int n_frag, const int *n_segs, const int *qlens, const char *const *seqs,

@@ -115,6 +115,15 @@ def test_sam_header(A, golden_unpacked, tmp_path):
     idx.close()
 
 
+@pytest.mark.parametrize("lanes,offsets", [(1, 0), (2, 1), (2, 0), (5, 1), (8, 1), (8, 0)])
+def test_multi_lane_output_order(A, tmp_path, lanes, offsets):
+    """Product path of N>1 (al_map_file_frag_multi): lanes finish their blocks in any order, the output file must hold
+    header + blocks in (batch, lane) order -- offsets from the all-gather of {records, bytes} + pwrite, or ordered turns."""
+    L = A.load()
+    L.al_dbg_ordered_out_selftest.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int]; L.al_dbg_ordered_out_selftest.restype = C.c_int
+    assert L.al_dbg_ordered_out_selftest(str(tmp_path / "o.sam").encode(), lanes, 40, offsets) == 0
+
+
 def _shard_worker(rank, world, port, q):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)

@@ -74,6 +74,30 @@ def test_large_fragment_paths_identical(golden_unpacked, name, env):
     assert r.stdout == exp, _diff_report(r.stdout, exp, name + "_" + "_".join(env))
 
 
+@pytest.mark.parametrize("devs,extra", [("0,0", []), ("0,0,0", ["-K", "20000"]), ("0,0", ["--bam"]), ("0,0", ["--sorted-bam"])], ids=["2lanes", "3lanes_small_batches", "bam", "sorted_bam"])
+@pytest.mark.parametrize("to_file", [True, False], ids=["pwrite", "pipe"])
+def test_multi_lane_identical(golden_unpacked, tmp_path, devs, extra, to_file):
+    """--devices with several lanes (here all on GPU 0: the box has one): every mini-batch is cut into contiguous fragment ranges, one
+    per lane; output = the single-lane bytes, whether the lanes pwrite() at exchanged offsets (regular file) or take turns (pipe)."""
+    d = golden_unpacked["g3_adversarial"]
+    m = json.load(open(os.path.join(d, "meta.json")))
+    base = [CLI, "-ax", "sr"] + (["-R", m["rg"]] if m.get("rg") else []) + extra
+    one = subprocess.run(base + [m["ref"]] + m["reads"], cwd=d, capture_output=True)
+    assert one.returncode == 0, one.stderr.decode()[-2000:]
+    if not extra or extra[0] == "-K":
+        assert one.stdout == open(os.path.join(d, "expected.sam"), "rb").read()
+    if to_file:
+        o = str(tmp_path / "multi.out")
+        r = subprocess.run(base + ["--devices", devs, "-o", o, m["ref"]] + m["reads"], cwd=d, capture_output=True)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        got = open(o, "rb").read()
+    else:
+        r = subprocess.run(base + ["--devices", devs, m["ref"]] + m["reads"], cwd=d, capture_output=True)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        got = r.stdout
+    assert got == one.stdout
+
+
 def test_yeast100k_digest(tmp_path):
     """G5: 100 k pairs on the 12 Mbp synthetic genome (the bench workload's shape): md5 of the whole SAM must equal the
     digest the reference build produced (tests/golden/g5_yeast100k/meta.json)."""
