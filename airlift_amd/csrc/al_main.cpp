@@ -52,6 +52,20 @@ int main(int argc, char **argv)
 	al_set_opt(0, &io, &mo);
 	al_set_opt("sr", &io, &mo);
 	mo.flag |= AL_F_OUT_SAM | AL_F_CIGAR;
+	if (!strcmp(argv[1], "extract-reads")) {       // N1: airlift-align extract-reads [--noprune] READS.bam REGIONS.bed READSIZE > rows   (extract_reads.sh BINDIR BAM BED READSIZE)
+		int prune = 1; std::vector<const char *> p;
+		for (int j = 2; j < argc; ++j) { if (!strcmp(argv[j], "--noprune")) prune = 0; else p.push_back(argv[j]); }
+		if (p.size() < 2 || (prune && p.size() < 3)) { fprintf(stderr, "Usage: airlift-align extract-reads [--noprune] reads.bam regions.bed [readsize]\n"); return 1; }
+		const int64_t n = al_extract_reads(p[0], p[1], p.size() > 2 ? atoi(p[2]) : 0, prune, stdout);
+		return n < 0 || fflush(stdout) == EOF ? 1 : 0;
+	}
+	if (!strcmp(argv[1], "extract-sequence")) {    // N1: airlift-align extract-sequence FQ1 FQ2 ROWS OUTDIR   (extract_sequence.sh BINDIR FQ1 FQ2 BED THREAD OUTPUT)
+		if (argc < 6) { fprintf(stderr, "Usage: airlift-align extract-sequence reads_1.fq reads_2.fq rows.bed outdir\n"); return 1; }
+		int64_t np = 0, ns = 0;
+		const int rc = al_extract_sequence(argv[2], argv[3], argv[4], argv[5], &np, &ns);
+		if (rc == 0) fprintf(stderr, "[airlift] extract-sequence: %lld pairs, %lld singletons\n", (long long)np, (long long)ns);
+		return rc == 0 ? 0 : 1;
+	}
 	if (!strcmp(argv[1], "mem")) mode = MODE_MEM, i = 2;
 	else if (!strcmp(argv[1], "aln")) mode = MODE_ALN, i = 2;
 	else if (!strcmp(argv[1], "samse")) mode = MODE_SAMSE, i = 2;

@@ -36,27 +36,29 @@ WORKLOADS = {"c2": "C2: yeast-sized synthetic reference pair (16 contigs, 12.16 
              "c4s": "C4S: the C4 repeat model at 1/10 of the size (310 Mbp; copy numbers scaled with the length)",
              "c3u": "C3U: 100.3 Mbp uniform reference + 3000 planted duplications (round 1)",
              "c4u": "C4U: 3.1 Gbp uniform reference + 20000 planted duplications, 2 % N (round 1)"}
-HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured streaming ceiling
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_COPY_GBS = 6290.0   # measured device copy bandwidth quoted by the same guide: the second denominator SURVEY 8(d) asks for
 
 
-def make_workload(config, pairs, read_len, seed, ref, ins_mean=None):
-    """ASCII reads for `pairs` fragments, concatenated fragment-major (mate1, mate2, mate1, ...); the config's read model
-    (tools/gen_synth.py: mason-like for C3..C5), 250 k-pair chunks simulated on host threads (seed + first pair index)."""
+def make_workload(config, lo, hi, read_len, seed, ref, ins_mean=None):
+    """ASCII reads of fragments [lo, hi) of THE workload (one input, defined by config + seed: fragment i belongs to chunk
+    i // 250000, simulated with seed + chunk by tools/gen_synth.py -- mason-like for C3..C5), fragment-major (mate1, mate2, ...).
+    A rank simulates only the chunks its range touches; chunks run on host threads."""
     import gen_synth as g
     from concurrent.futures import ThreadPoolExecutor
     tr = bytes.maketrans(bytes(range(5)), b"ACGTN")
-    out = np.empty((pairs, 2, read_len), dtype=np.uint8)
+    out = np.empty((hi - lo, 2, read_len), dtype=np.uint8)
     chunk = 250_000
     over = dict(ins_mean=ins_mean, ins_sd=max(1, ins_mean // 10)) if ins_mean else {}
 
-    def one(s):
-        n = min(chunk, pairs - s)
-        r1, r2 = g.simulate(config, ref, n, seed + s, read_len=read_len, **over)
-        out[s:s + n, 0] = np.frombuffer(r1.tobytes().translate(tr), dtype=np.uint8).reshape(n, read_len)
-        out[s:s + n, 1] = np.frombuffer(r2.tobytes().translate(tr), dtype=np.uint8).reshape(n, read_len)
+    def one(c):
+        r1, r2 = g.simulate(config, ref, chunk, seed + c, read_len=read_len, **over)
+        a, b = max(lo, c * chunk), min(hi, (c + 1) * chunk)
+        for m, r in ((0, r1), (1, r2)):
+            out[a - lo:b - lo, m] = np.frombuffer(r[a - c * chunk:b - c * chunk].tobytes().translate(tr), dtype=np.uint8).reshape(b - a, read_len)
 
     with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
-        list(ex.map(one, range(0, pairs, chunk)))
+        list(ex.map(one, range(lo // chunk, (hi + chunk - 1) // chunk)))
     return out
 
 
@@ -175,14 +177,17 @@ def main():
     t0 = time.time()
     idx = A.Index(fasta=os.path.join(tmp, "ref.fa"), on_device=local if world > 1 else 0)
     t_index = time.time() - t0
+    # ONE input of pairs * world fragments; rank r maps the contiguous range frag_range(N, r, world) of it
+    from airlift_amd.shard import frag_range, output_offsets
     t0 = time.time()
-    arr = make_workload(a.config, a.pairs, a.read_len, 20261002 + 7919 * rank, ref, a.ins_mean)
+    f_lo, f_hi = frag_range(a.pairs * world, rank, world)
+    arr = make_workload(a.config, f_lo, f_hi, a.read_len, 20261002, ref, a.ins_mean)
     t_reads = time.time() - t0
     ctx = A.Context(idx, device=local if world > 1 else 0)
     L.al_ctx_set_threads(ctx.h, min(32, os.cpu_count() or 1))       # host packing threads (outside the timed region)
     def upload(nf):
         n_segs = (C.c_int * nf)(*([2] * nf)); qlens = (C.c_int * (2 * nf))(*([a.read_len] * (2 * nf)))
-        if L.al_batch_upload_flat(ctx.h, nf, n_segs, qlens, arr.ctypes.data_as(C.c_char_p), b"realigned_", nf * rank) != 0:
+        if L.al_batch_upload_flat(ctx.h, nf, n_segs, qlens, arr.ctypes.data_as(C.c_char_p), b"realigned_", f_lo) != 0:
             raise SystemExit("upload failed")
         ctx.n_frag, ctx.n_reads = nf, 2 * nf
 
@@ -201,13 +206,13 @@ def main():
         if int(t.item()) != a.pairs:
             a.pairs = int(t.item()); upload(a.pairs)
 
+    merged = {}
+
     def step():
         ctx.run()
-        if dist is not None:   # merged-output offsets: {n_records, n_bytes} per rank over RCCL/xGMI
-            st = ctx.stat()
-            mine = torch.tensor([int(st.n_regs_aln), int(st.bytes_out)], dtype=torch.int64, device=dev)
-            allr = torch.empty(2 * world, dtype=torch.int64, device=dev)
-            dist.all_gather_into_tensor(allr, mine)
+        # merged-output offsets of this rank's block: one all-gather of {n_records, n_bytes} per step (RCCL over xGMI when N > 1)
+        st = ctx.stat()
+        merged["rec_off"], merged["byte_off"], merged["records"], merged["bytes"] = output_offsets(int(st.n_regs_aln), int(st.bytes_out), rank, world, device=dev, dist=dist)
 
     for _ in range(a.warmup):
         step()
@@ -228,9 +233,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     st = ctx.stat()
-    dist_info = None
+    dist_info = None; na = nu = na_p1 = None
     if rank == 0:   # distribution of the per-fragment sizes that decide which kernels run
         na = ctx.tap("frag_na", np.uint32, a.pairs); nu = ctx.tap("frag_nu", np.uint32, a.pairs)
+        na_p1 = ctx.tap("frag_na_p1", np.uint32, a.pairs)
         pc = lambda v: {"p50": int(np.percentile(v, 50)), "p90": int(np.percentile(v, 90)), "p99": int(np.percentile(v, 99)), "max": int(v.max())} if len(v) else {}
         dist_info = {"anchors_per_fragment": pc(na), "chains_per_fragment": pc(nu)}
     ctx.close(); idx.close()          # the CPU baseline / CLI legs below start their own processes on this GPU
@@ -238,20 +244,52 @@ def main():
         names = [L.al_stage_name(i).decode() for i in range(st.n_stage)]
         per = {names[i]: float(stage_ms[i] / a.steps) for i in range(st.n_stage)}
         kern = {names[i]: L.al_stage_kernel(i).decode() for i in range(st.n_stage)}
-        dom = max((k for k in per if kern[k]), key=lambda k: per[k])          # intervals that are exactly one kernel
-        traffic, traffic_src = load_traffic(kern[dom])
+        # ---- roofline: every stage against ITS OWN algorithmic bytes; the headline fraction is the pipeline's ----
+        M, A, Wb = float(st.n_mini), float(st.n_anchor), float(st.n_refbases)
+        A1 = float(na_p1.sum()) if na_p1 is not None else A                   # anchors of the first pass (the re-chain pass makes the rest)
+        a1 = na_p1 if na_p1 is not None else na
+        cls = lambda lo_, hi_: float(a1[(a1 >= lo_) & (a1 <= hi_)].sum())
+        groups = [   # (name, intervals, algorithmic bytes)
+            ("sketch", ["sketch"], float(st.bytes_in) + 16.0 * M),
+            ("seed_lookup", ["seed_lookup", "scan", "size_order"], 16.0 * M),
+            ("anchor_sort", ["anchor_sort_small", "anchor_sort", "anchor_sort_blk", "anchor_sort_big", "anchor_heap"], 24.0 * A1),
+            ("chain", ["chain_lds32", "chain_lds48", "chain_lds64", "chain_lds128", "seg_find", "seg_chain_lds", "seg_chain_wave", "seg_merge"], 16.0 * A1),
+            ("rechain (max_occ pass: seed + sort + chain)", ["rechain"], 56.0 * (A - A1)),
+            ("regs (chain_post / seg_gen: no bytes in the contract)", ["regs"], 0.0),
+            ("extension", ["ext_prep", "ext_sort", "ext_dp_lane", "ext_dp_g4", "ext_dp_g8", "ext_dp_g22", "ext_finish", "compact"], 0.5 * Wb + float(st.bytes_out)),
+        ]
+        own = {"sketch": float(st.bytes_in) + 16.0 * M, "seed_lookup": 16.0 * M, "anchor_sort_small": 24.0 * cls(0, 64), "anchor_sort": 24.0 * cls(65, 1024),
+               "anchor_sort_blk": 24.0 * cls(1025, 4096), "chain_lds32": 16.0 * cls(0, 32), "chain_lds48": 16.0 * cls(33, 48), "chain_lds64": 16.0 * cls(49, 64), "chain_lds128": 16.0 * cls(65, 128)}
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))) if os.path.exists(os.path.join(ROOT, "profiles", "traffic.json")) else {}
+        stages = []
+        for name, ivs, by in groups:
+            ms = sum(per.get(i, 0.0) for i in ivs)
+            stages.append({"stage": name, "ms": ms, "algorithmic_bytes": by, "GBps": (by / (ms * 1e-3) / 1e9) if ms > 0 else None,
+                           "frac": (by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms > 0 else None})
+        step_ms = sum(per.values())
         alg = float(st.algorithmic_bytes)
-        achieved = alg / (per[dom] * 1e-3) / 1e9
+        dom = max((k for k in per if kern[k]), key=lambda k: per[k])          # longest interval that is exactly one kernel
+        dom_bytes = own.get(dom)
+        dom_traffic = (tj.get("kernels", {}).get(kern[dom]) or {}).get("bytes_per_launch")
+        roof = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "peak_measured_copy": HBM_COPY_GBS,
+                "achieved": alg / (step_ms * 1e-3) / 1e9, "frac": alg / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "frac_of_measured_copy": alg / (step_ms * 1e-3) / 1e9 / HBM_COPY_GBS,
+                "scope": "whole pipeline: algorithmic bytes of one step / sum of the stage intervals (HIP events on the context's stream)",
+                "algorithmic_bytes_per_step": alg, "algorithmic_bytes_per_read": alg / (2.0 * a.pairs),
+                "traffic": tj.get("total_bytes_per_step") if tj.get("workload") == a.config else None, "traffic_source": tj.get("source"),
+                "dominant_kernel": {"kernel": kern[dom], "interval": dom, "ms": per[dom], "algorithmic_bytes": dom_bytes,
+                                    "achieved": (dom_bytes / (per[dom] * 1e-3) / 1e9) if dom_bytes else None, "frac": (dom_bytes / (per[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS) if dom_bytes else None,
+                                    "traffic": dom_traffic if tj.get("workload") == a.config else None,
+                                    "note": None if dom_bytes is not None else "bytes of this kernel's share of the stage are not separable: see its stage row"},
+                "stages": stages}
         out = {
             "metric": "reads/sec remapped (%d bp PE)" % a.read_len, "value": 2.0 * a.pairs * world * a.steps / dt, "unit": "reads/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8/int32 (int8 SW lanes, u64 hashes)", "data": "synthetic",
             "config": {"workload": "%s, %d x 2 x %d bp PE reads per GPU per step, preset sr" % (WORKLOADS.get(a.config, a.config), a.pairs, a.read_len),
-                       "reads_per_step_per_gpu": 2 * a.pairs, "read_len": a.read_len, "sharding": "reads sharded by rank, index replicated"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": kern[dom], "interval": dom, "kernel_ms": per[dom], "algorithmic_bytes_per_launch": alg, "algorithmic_bytes_per_read": alg / (2.0 * a.pairs),
-                         "pipeline_GBps": alg / (sum(per.values()) * 1e-3) / 1e9},
+                       "reads_per_step_per_gpu": 2 * a.pairs, "read_len": a.read_len, "sharding": "one input of %d fragments, rank r maps the contiguous range [r N / R, (r + 1) N / R); index replicated" % (a.pairs * world)},
+            "roofline": roof,
             "stages_ms": per,
+            "merged_output": merged,
             "counters": {"minimizers_per_read": st.n_mini / (2.0 * a.pairs), "anchors_per_pair": st.n_anchor / float(a.pairs), "chains_per_pair": st.n_chain / float(a.pairs),
                          "regions_aligned_per_read": st.n_regs_aln / (2.0 * a.pairs), "ref_bases_per_region": st.n_refbases / max(1.0, float(st.n_regs_aln)),
                          "rechain": int(st.n_rechain), "heap_fallback": int(st.n_heap_fallback), "sort_tie_flags": int(st.n_sort_tie_flag), **(dist_info or {})},

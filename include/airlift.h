@@ -148,6 +148,17 @@ int  al_map_file_frag_bam(const al_idx_t *mi, int n_segs, const char **fn, const
 int  al_map_file_frag_multi(const al_idx_t *mi, int n_segs, const char **fn, const al_mapopt_t *opt, int n_threads,
                             FILE *out, const char *rg, const int *devices, int n_dev, int bam_mode, int level);
 
+/* ---- read extraction feeding the path (host-side; replaces per-region `samtools view | convert2bed | awk`) ---- */
+/* src/4-extract_reads/extract_reads.sh:8 (prune != 0) / extract_reads_noprune.sh:7 (prune == 0) for all lines of a BED file in
+ * one pass over the BAM: rows "chrom start end name[.1|.2] MAPQ CIGAR" of the mapped records that lie inside a BED line
+ * (start >= B-1, end <= E-1) and, when pruning, have MAPQ <= 10 or a CIGAR other than "<read_size>M"; one row per name,
+ * sorted by name (`sort -uk4,4`).  Returns the number of rows, negative on error. */
+int64_t al_extract_reads(const char *bam_fn, const char *bed_fn, int read_size, int prune, FILE *out);
+/* src/4-extract_reads/extract_sequence.sh:17-19: FASTQ subsets by the names in column 4 of `rows_fn` (seqtk subseq), pairing
+ * (BBMap repair.sh) and renaming (rename.sh: realigned_<n>, realigned_singleton_<n>) into out_dir/reads_1.fastq,
+ * reads_2.fastq, singletons.fastq.  Returns 0, negative on error. */
+int  al_extract_sequence(const char *fq1, const char *fq2, const char *rows_fn, const char *out_dir, int64_t *n_pairs, int64_t *n_single);
+
 /* Self-test of the multi-lane output path (offset exchange + pwrite, or ordered turns) with synthetic blocks; needs no GPU. */
 int  al_dbg_ordered_out_selftest(const char *path, int n_lanes, int n_batches, int use_offsets);
 
