@@ -10,6 +10,9 @@
 #include "../../include/airlift.h"
 
 #define AL_MAX_K 25                        // device read sketch: hash (2k bits) << 14 | pos << 1 | strand must fit 64 bits
+// position + strand bits of a device sketch window entry (k_sketch): the hash takes 2k bits of the 64
+static inline int al_sketch_pos_bits(int k) { const int b = 64 - 2 * k; return b > 22 ? 22 : b; }
+#define AL_MAX_READ_LEN 32768               // longest read of the GPU path: state tiles of the long-read extension kernel (al_kernels_align.hip)
 #define AL_SEED_TANDEM    (1ULL<<42)       // mmpriv.h:20
 #define AL_SEED_SEG_SHIFT 48               // mmpriv.h:23
 #define AL_SEED_SEG_MASK  (0xffULL<<AL_SEED_SEG_SHIFT)

@@ -1171,16 +1171,14 @@ k_regs(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__ u_all,
 	if (tie) atomicAdd(&counters[10], 1ULL);
 }
 
+// body of the monolithic kernel: L is the group's state block -- in LDS (k_align) or, for reads beyond the LDS tiles, in HBM (k_align_long)
 template <int TMAX, int QMAX>
-__global__ void __launch_bounds__(64)
-k_align(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_off, const uint32_t *__restrict__ rd_len,
-        const uint32_t *__restrict__ frag_first, const int32_t *__restrict__ frag_rep, WsBase W, AlignShared G, AlLogTab lt,
-        uint8_t *__restrict__ gws, size_t gws_stride, size_t p_bytes, size_t cig_words, int n_frag, AlParams P,
+__device__ __forceinline__ void d_align_frags(GroupLds<TMAX, QMAX> &L, const int g, const int gl,
+        const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_off, const uint32_t *__restrict__ rd_len,
+        const uint32_t *__restrict__ frag_first, const int32_t *__restrict__ frag_rep, const WsBase &W, const AlignShared &G, const AlLogTab &lt,
+        uint8_t *__restrict__ gws, size_t gws_stride, size_t p_bytes, size_t cig_words, int n_frag, const AlParams &P,
         const uint32_t *__restrict__ frag_list, int n_list)
 {
-	__shared__ GroupLds<TMAX, QMAX> lds[AL_GPB];
-	const int g = threadIdx.x / GW, gl = threadIdx.x % GW;
-	GroupLds<TMAX, QMAX> &L = lds[g];
 	GroupWs ws;
 	{
 		uint8_t *base = gws + ((size_t)blockIdx.x * AL_GPB + g) * gws_stride;
@@ -1276,6 +1274,36 @@ k_align(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_off
 		GSYNC();
 	}
 	if (PROF_ON(P) && gl == 0) atomicAdd(&G.dbg[605], (unsigned long long)(clock64() - tK0));
+}
+
+template <int TMAX, int QMAX>
+__global__ void __launch_bounds__(64)
+k_align(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_off, const uint32_t *__restrict__ rd_len,
+        const uint32_t *__restrict__ frag_first, const int32_t *__restrict__ frag_rep, WsBase W, AlignShared G, AlLogTab lt,
+        uint8_t *__restrict__ gws, size_t gws_stride, size_t p_bytes, size_t cig_words, int n_frag, AlParams P,
+        const uint32_t *__restrict__ frag_list, int n_list)
+{
+	__shared__ GroupLds<TMAX, QMAX> lds[AL_GPB];
+	const int g = threadIdx.x / GW, gl = threadIdx.x % GW;
+	d_align_frags<TMAX, QMAX>(lds[g], g, gl, rd_seq, rd_off, rd_len, frag_first, frag_rep, W, G, lt, gws, gws_stride, p_bytes, cig_words, n_frag, P, frag_list, n_list);
+}
+
+// Reads longer than the LDS tiles (the whole regions AirLift's stage 3 feeds the aligner: extract_fasta_regions_with_bedfile.sh:4-7
+// -> align_gaps.sh:14-15; the fork's own test/MT-orang.fa, q-inv.fa): the same code with the group's state block -- sequences, the
+// seven int8 DP rows, H, the hit tiles -- in HBM instead of LDS, up to AL_MAX_READ_LEN bases per read.  Correct for any such
+// length; slow per read (every DP row is a few dependent HBM round trips), which is acceptable for the few thousand
+// sequences of that stage.
+#define AL_LONG_QMAX AL_MAX_READ_LEN
+#define AL_LONG_TMAX (2 * AL_MAX_READ_LEN + 128)
+typedef GroupLds<AL_LONG_TMAX, AL_LONG_QMAX> GroupLong;
+__global__ void __launch_bounds__(64)
+k_align_long(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_off, const uint32_t *__restrict__ rd_len,
+             const uint32_t *__restrict__ frag_first, const int32_t *__restrict__ frag_rep, WsBase W, AlignShared G, AlLogTab lt,
+             uint8_t *__restrict__ gws, size_t gws_stride, size_t p_bytes, size_t cig_words, int n_frag, AlParams P,
+             const uint32_t *__restrict__ frag_list, int n_list, GroupLong *__restrict__ state)
+{
+	const int g = threadIdx.x / GW, gl = threadIdx.x % GW;
+	d_align_frags<AL_LONG_TMAX, AL_LONG_QMAX>(state[(size_t)blockIdx.x * AL_GPB + g], g, gl, rd_seq, rd_off, rd_len, frag_first, frag_rep, W, G, lt, gws, gws_stride, p_bytes, cig_words, n_frag, P, frag_list, n_list);
 }
 
 // =============================================================================================
@@ -1989,7 +2017,7 @@ struct AlignState {            // lives in al_ctx_s::align_state (opaque there)
 	DevBuf<int32_t> auxi;
 	DevBuf<uint32_t> reg_cnt, seg_na, arena, seg_fast, regs_n0;
 	uint64_t arena_scale = 1;       // doubled by al_align_grow_arena() when a batch's long CIGARs overflowed the arena
-	DevBuf<uint8_t> gws;
+	DevBuf<uint8_t> gws, long_state;
 	DevBuf<float> logtab;
 	DevBuf<unsigned long long> dbgbuf, hist;
 	DevBuf<ExtJob> jobs; DevBuf<ExtOut> outs; DevBuf<RegExt> rext;
@@ -2014,7 +2042,7 @@ void al_align_state_free(al_ctx_t *c)
 	if (it == g_states.end()) return;
 	AlignState *s = it->second;
 	s->regs0.release(); s->mregs.release(); s->rtmp.release(); s->out.release(); s->aux128.release(); s->seg_a.release(); s->aux64.release(); s->seg_u.release();
-	s->nu_off.release(); s->out_off.release(); s->auxi.release(); s->reg_cnt.release(); s->seg_na.release(); s->arena.release(); s->gws.release(); s->logtab.release(); s->dbgbuf.release(); s->hist.release(); s->jobs.release(); s->outs.release(); s->rext.release(); s->seg_fast.release(); s->regs_n0.release();
+	s->nu_off.release(); s->out_off.release(); s->auxi.release(); s->reg_cnt.release(); s->seg_na.release(); s->arena.release(); s->gws.release(); s->long_state.release(); s->logtab.release(); s->dbgbuf.release(); s->hist.release(); s->jobs.release(); s->outs.release(); s->rext.release(); s->seg_fast.release(); s->regs_n0.release();
 	s->job_off.release(); s->sc_off.release(); s->sc_ws.release(); s->n_jobs.release(); s->n_sc.release(); s->job_key.release(); s->job_key2.release(); s->job_idx.release(); s->job_idx2.release(); s->frag_slow.release(); s->slow_list.release(); s->sort_tmp.release();
 	delete s; g_states.erase(it);
 }
@@ -2082,7 +2110,7 @@ int al_run_align_stage(al_ctx_t *c)
 	const size_t p_bytes = ((size_t)(Lmax + tbound) * ncol * 16 + 63) / 64 * 64;
 	const size_t cig_words = ((size_t)(Lmax + tbound) + 16 + 15) / 16 * 16;
 	const size_t stride = p_bytes + cig_words * 8 + AL_PAIR_SC_CAP * 8;
-	int nb = (nf + AL_GPB - 1) / AL_GPB; const int nb_max = 256 * 16; if (nb > nb_max) nb = nb_max;
+	int nb = (nf + AL_GPB - 1) / AL_GPB; const int nb_max = Lmax > 512 ? 16 : 256 * 16; if (nb > nb_max) nb = nb_max;   // reads beyond the LDS tiles: few groups (megabytes of traceback each)
 	if (A->gws.ensure((size_t)nb * AL_GPB * stride + 64)) return -1;
 	const uint64_t arena_cap = ((uint64_t)nr * 12 + 4096 + (uint64_t)c->n_bases / 8) * A->arena_scale;
 	if (A->arena.ensure(arena_cap)) return -1;
@@ -2093,15 +2121,21 @@ int al_run_align_stage(al_ctx_t *c)
 	AlLogTab lt; lt.t = A->logtab.p; lt.miss = c->counters.p + 8;
 	const int tmax = (Lmax <= 160 && tbound <= 336) ? 336 : (Lmax <= 256 && tbound <= 512) ? 512 : (Lmax <= 512 && tbound <= 1024) ? 1024 : 0;
 	const int qmax = tmax == 336 ? 160 : tmax == 512 ? 256 : 512;
-	if (tmax == 0) { fprintf(stderr, "[airlift] reads longer than 512 bp (or an extension window longer than 1024 bp: read length + (read length * A + end bonus - O) / E + 16) are not supported by the device extension kernels (max read length in batch: %d, window %d)\n", Lmax, tbound); return -3; }
+	const bool long_mode = tmax == 0;              // reads beyond the LDS tiles: the whole batch through k_align_long (state blocks in HBM)
+	if (long_mode && (Lmax > AL_LONG_QMAX || tbound > AL_LONG_TMAX)) { fprintf(stderr, "[airlift] reads longer than %d bp (or an extension window longer than %d bp: read length + (read length * A + end bonus - O) / E + 16) are not supported by the device extension kernels (max read length in batch: %d, window %d)\n", AL_LONG_QMAX, AL_LONG_TMAX, Lmax, tbound); return -3; }
+	if (long_mode) {   // few groups: each needs a state block of ~1.3 MB and a traceback area of (Lmax + window) * band columns bytes
+		if (nb > 16) nb = 16;
+		if (A->gws.ensure((size_t)nb * AL_GPB * stride + 64) || A->long_state.ensure((size_t)nb * AL_GPB * sizeof(GroupLong) + 64)) return -1;
+	}
 	auto launch_mono = [&](const uint32_t *list, int n_list) -> int {      // monolithic kernel (whole batch, or the slow-path list)
 		int nbm = (n_list + AL_GPB - 1) / AL_GPB; if (nbm > nb) nbm = nb; if (nbm < 1) nbm = 1;
-		if (tmax == 336) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_align<336, 160>), dim3(nbm), dim3(GW * AL_GPB), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, c->frag_first.p, c->frag_rep.p, W, G, lt, A->gws.p, stride, p_bytes, cig_words, nf, c->P, list, n_list);
+		if (long_mode) hipLaunchKernelGGL(k_align_long, dim3(nbm), dim3(GW * AL_GPB), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, c->frag_first.p, c->frag_rep.p, W, G, lt, A->gws.p, stride, p_bytes, cig_words, nf, c->P, list, n_list, (GroupLong *)A->long_state.p);
+		else if (tmax == 336) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_align<336, 160>), dim3(nbm), dim3(GW * AL_GPB), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, c->frag_first.p, c->frag_rep.p, W, G, lt, A->gws.p, stride, p_bytes, cig_words, nf, c->P, list, n_list);
 		else if (tmax == 512) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_align<512, 256>), dim3(nbm), dim3(GW * AL_GPB), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, c->frag_first.p, c->frag_rep.p, W, G, lt, A->gws.p, stride, p_bytes, cig_words, nf, c->P, list, n_list);
 		else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_align<1024, 512>), dim3(nbm), dim3(GW * AL_GPB), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, c->frag_first.p, c->frag_rep.p, W, G, lt, A->gws.p, stride, p_bytes, cig_words, nf, c->P, list, n_list);
 		return 0;
 	};
-	if ((c->P.dbg >> 26) & 1) { if (launch_mono(nullptr, nf)) return -1; for (int i = ST_EXT_PREP; i <= ST_EXT_FINISH; ++i) AL_HIP_CHECK(hipEventRecord(c->ev[i + 1], s)); }   // AL_DBG bit 26: whole batch through the monolithic kernel
+	if (((c->P.dbg >> 26) & 1) || long_mode) { if (launch_mono(nullptr, nf)) return -1; for (int i = ST_EXT_PREP; i <= ST_EXT_FINISH; ++i) AL_HIP_CHECK(hipEventRecord(c->ev[i + 1], s)); }   // AL_DBG bit 26: whole batch through the monolithic kernel
 	else {
 		// ---- fast path: prep -> size-sorted DP job queue -> finish -> (slow list) monolithic
 		if (A->n_jobs.ensure(nf + 2) || A->n_sc.ensure(nf + 2) || A->job_off.ensure(nf + 2) || A->sc_off.ensure(nf + 2) || A->frag_slow.ensure(nf + 1) || A->slow_list.ensure(nf + 1) || A->hist.ensure(AL_HIST_N)) return -1;

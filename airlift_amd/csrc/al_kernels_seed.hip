@@ -31,11 +31,12 @@ __device__ __forceinline__ uint64_t d_hash64m(uint64_t key, uint64_t mask)
 extern "C" __global__ void __launch_bounds__(64)
 k_sketch(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_off, const uint32_t *__restrict__ rd_len,
          const uint64_t *__restrict__ mini_off, AlAnchor *__restrict__ mini, uint32_t *__restrict__ mini_cnt,
-         int n_reads, int w, int k)
+         int n_reads, int w, int k, int pb)
 {
-	// One 64-bit ring entry per window slot: hash << 14 | pos << 1 | strand (a valid entry always has span == k and reads are
-	// shorter than 8192 bases), UINT64_MAX = no k-mer.  The reference's comparisons are on x = hash<<8|span, i.e. on the
-	// hash part only (E >> 14); "same x, different y" is "same hash part, different entry".
+	// One 64-bit ring entry per window slot: hash << pb | pos << 1 | strand (a valid entry always has span == k; pb = min(22,
+	// 64 - 2k) bits hold position and strand: reads shorter than 2^(pb-1) bases -- 2 Mbases for k <= 21, 8192 for k = 25; the
+	// upload checks it), UINT64_MAX = no k-mer.  The reference's comparisons are on x = hash<<8|span, i.e. on the
+	// hash part only (E >> pb); "same x, different y" is "same hash part, different entry".
 	extern __shared__ uint64_t lds[];           // ring[w][64]
 	const int lane = threadIdx.x;
 	const int r = blockIdx.x * 64 + lane;
@@ -49,8 +50,9 @@ k_sketch(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_of
 	uint64_t kmer0 = 0, kmer1 = 0, mn = UINT64_MAX;
 	int l = 0, buf_pos = 0, min_pos = 0;
 	for (int j = 0; j < w; ++j) ring[j * 64] = UINT64_MAX;
-#define HX(e) ((e) >> 14)
-#define EMIT(e) do { const uint64_t e__ = (e); out[cnt].x = HX(e__) << 8 | (uint64_t)k; out[cnt].y = e__ & 0x3fffULL; ++cnt; } while (0)
+#define HX(e) ((e) >> pb)
+	const uint64_t ymask = (1ULL << pb) - 1ULL;
+#define EMIT(e) do { const uint64_t e__ = (e); out[cnt].x = HX(e__) << 8 | (uint64_t)k; out[cnt].y = e__ & ymask; ++cnt; } while (0)
 	uint32_t word = 0;
 	for (uint32_t i = 0; i < len; ++i) {
 		if ((i & 7) == 0) word = seq[i >> 3];
@@ -62,7 +64,7 @@ k_sketch(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_of
 			if (kmer0 == kmer1) continue;                                   // sketch.c:108
 			const int z = kmer0 < kmer1 ? 0 : 1;
 			++l;
-			if (l >= k) info = d_hash64m(z ? kmer1 : kmer0, mask) << 14 | (uint64_t)i << 1 | (uint64_t)z;
+			if (l >= k) info = d_hash64m(z ? kmer1 : kmer0, mask) << pb | (uint64_t)i << 1 | (uint64_t)z;
 		} else l = 0;
 		ring[buf_pos * 64] = info;
 		const uint64_t mx = HX(mn);
@@ -70,7 +72,7 @@ k_sketch(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_of
 			for (int j = buf_pos + 1; j < w; ++j) { const uint64_t e = ring[j * 64]; if (mx == HX(e) && e != mn) EMIT(e); }
 			for (int j = 0; j < buf_pos; ++j)     { const uint64_t e = ring[j * 64]; if (mx == HX(e) && e != mn) EMIT(e); }
 		}
-		if (HX(info) <= mx) {                                               // sketch.c:123-125 (UINT64_MAX >> 14 is the largest hash part)
+		if (HX(info) <= mx) {                                               // sketch.c:123-125 (UINT64_MAX >> pb is the largest hash part)
 			if (l >= w + k && mn != UINT64_MAX) EMIT(mn);
 			mn = info; min_pos = buf_pos;
 		} else if (buf_pos == min_pos) {                                    // sketch.c:126-138

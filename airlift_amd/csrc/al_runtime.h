@@ -67,6 +67,7 @@ struct al_ctx_s {
 	DevBuf<AlAnchor> chain_tmp; DevBuf<uint64_t> u_tmp, seg_first, vs_off, big_off;
 	DevBuf<uint32_t> seg_cnt, vs_na, vs_meta, vs_nu, vs_nc, vs_tie, seg_key, seg_idx, seg_ord, fb_list, big_na;
 	uint64_t n_chain_fallback = 0;
+	int max_qlen_sum = 0;                 // longest fragment of the resident batch
 	DevBuf<uint64_t> a_off_p1; DevBuf<uint32_t> frag_na_p1; DevBuf<int32_t> frag_rep_p1;   // pass-1 snapshots when a re-chain pass ran (taps)
 	uint64_t n_anchor_total = 0, n_anchor_pass1 = 0;
 	uint32_t n_rechain = 0;

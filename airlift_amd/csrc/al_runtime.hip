@@ -14,7 +14,7 @@
 #include "al_io.h"
 
 // kernels (al_kernels_seed.hip)
-extern "C" __global__ void k_sketch(const uint32_t *, const uint64_t *, const uint32_t *, const uint64_t *, AlAnchor *, uint32_t *, int, int, int);
+extern "C" __global__ void k_sketch(const uint32_t *, const uint64_t *, const uint32_t *, const uint64_t *, AlAnchor *, uint32_t *, int, int, int, int);
 extern "C" __global__ void k_seed(const uint64_t *, int, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, const uint32_t *, AlMatch *, uint32_t *, uint32_t *, int32_t *, const uint32_t *, int, int);
 extern "C" __global__ void k_alser_count(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, int, int, unsigned long long *);
 extern "C" __global__ void k_rechain_test(const AlAnchor *, const uint64_t *, const uint64_t *, const uint32_t *, const int32_t *, const uint32_t *, int, uint32_t *, uint32_t *);
@@ -160,7 +160,7 @@ extern "C" int al_batch_upload(al_ctx_t *c, int n_frag, const int *n_segs, const
 	c->n_frag = n_frag; c->n_reads = n_reads; c->ran = false;
 	c->h_rd_len.resize(n_reads + 1); c->h_rd_off.resize(n_reads + 1); c->h_mini_off.resize(n_reads + 1); c->h_flip.assign(n_reads, 0);
 	c->h_frag_first.resize(n_frag + 1); c->h_frag_hash.resize(n_frag + 1);
-	uint64_t words = 0, mtot = 0, bases = 0; int r = 0;
+	uint64_t words = 0, mtot = 0, bases = 0; int r = 0, max_qsum = 0;
 	std::vector<int> qsums(n_frag);
 	const int k = c->mi->k, pe_ori = c->opt.pe_ori;
 	for (int f = 0; f < n_frag; ++f) {
@@ -171,7 +171,12 @@ extern "C" int al_batch_upload(al_ctx_t *c, int n_frag, const int *n_segs, const
 			words += (uint64_t)(L + 7) / 8 + 1; mtot += (uint64_t)(L >= k ? L - k + 1 : 0) + 1; bases += L; qsum += L;
 			if (n_segs[f] == 2 && ((j == 0 && (pe_ori >> 1 & 1)) || (j == 1 && (pe_ori & 1)))) c->h_flip[r] = 1;
 		}
-		qsums[f] = qsum;
+		qsums[f] = qsum; if (qsum > max_qsum) max_qsum = qsum;
+	}
+	c->max_qlen_sum = max_qsum;
+	{   // longest read the device sketch can index (position bits of its packed window entries) and the extension kernels can hold
+		const int lim = std::min(1 << (al_sketch_pos_bits(k) - 1), AL_MAX_READ_LEN);
+		for (int i = 0; i < n_reads; ++i) if ((int)c->h_rd_len[i] >= lim) { fprintf(stderr, "[airlift] a read of %u bases exceeds the limit of the GPU path (%d bases at k = %d)\n", c->h_rd_len[i], lim - 1, k); return -3; }
 	}
 	al_parallel_for(c->n_threads, (size_t)n_frag, [&](size_t lo, size_t hi, int) {
 		for (size_t f = lo; f < hi; ++f) c->h_frag_hash[f] = qname_hash(qnames ? qnames[c->h_frag_first[f]] : nullptr, qsums[f], c->opt.seed);
@@ -360,7 +365,7 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 	// The LDS chaining kernels keep 16-bit window-relative positions and 8-bit row indices: they need max_dist_x < 2^15 and
 	// max_chain_iter >= 128 (true for the short-read preset); other option values go through the wave-per-entry kernel.
 	const int mdx = std::max(std::max(c->opt.max_gap_ref, c->opt.max_frag_len), c->opt.max_gap);
-	const bool lds_ok = mdx <= 0x7fff && c->opt.max_chain_iter >= 128 && !((c->P.dbg >> 27) & 1);
+	const bool lds_ok = mdx <= 0x7fff && c->opt.max_chain_iter >= 128 && !((c->P.dbg >> 27) & 1) && c->max_qlen_sum <= 0xfff;   // 12-bit query positions in the compact rows
 	if (first) hipLaunchKernelGGL(k_iota_u32, dim3((nl + 255) / 256), dim3(256), 0, s, c->chain_idx.p, (uint32_t)nl);
 	if (sort_u32_pairs(c, first ? c->frag_na.p : c->tmp_u32.p, c->chain_key.p, first ? c->chain_idx.p : list, c->chain_idx2.p, nl)) return -1;
 	const uint32_t *order = c->chain_idx2.p;
@@ -456,7 +461,7 @@ int al_run_seed_stages(al_ctx_t *c)
 	AL_HIP_CHECK(hipMemsetAsync(c->counters.p, 0, 16 * sizeof(unsigned long long), s));
 	AL_HIP_CHECK(hipEventRecord(c->ev[0], s));
 	const int nr = c->n_reads, w = c->mi->w, k = c->mi->k;
-	if (nr > 0) hipLaunchKernelGGL(k_sketch, dim3((nr + 63) / 64), dim3(64), (size_t)w * 64 * 8, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, c->mini_off.p, c->mini.p, c->mini_cnt.p, nr, w, k);
+	if (nr > 0) hipLaunchKernelGGL(k_sketch, dim3((nr + 63) / 64), dim3(64), (size_t)w * 64 * 8, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, c->mini_off.p, c->mini.p, c->mini_cnt.p, nr, w, k, al_sketch_pos_bits(k));
 	AL_HIP_CHECK(hipEventRecord(c->ev[ST_SKETCH + 1], s));
 	if (c->n_frag == 0) { for (int i = ST_SEED; i < ST_N; ++i) AL_HIP_CHECK(hipEventRecord(c->ev[i + 1], s)); return 0; }
 	if (run_seed_chain(c, nullptr, c->n_frag, c->opt.mid_occ, 0, true)) return -1;
@@ -741,7 +746,8 @@ extern "C" int al_batch_upload_windows(al_ctx_t *c, const al_winsrc_t *src, int 
 	if (!c || !src || n_tok < 0 || read_len <= 0 || src->device != c->device) return -1;
 	AL_HIP_CHECK(hipSetDevice(c->device));
 	const int k = c->mi->k, wpr = (read_len + 7) / 8 + 1;
-	c->n_frag = n_tok; c->n_reads = n_tok; c->ran = false;
+	c->n_frag = n_tok; c->n_reads = n_tok; c->ran = false; c->max_qlen_sum = read_len;
+	if (read_len >= std::min(1 << (al_sketch_pos_bits(k) - 1), AL_MAX_READ_LEN)) { fprintf(stderr, "[airlift] tokens of %d bases exceed the limit of the GPU path\n", read_len); return -3; }
 	c->h_rd_len.assign(n_tok + 1, (uint32_t)read_len); c->h_rd_len[n_tok] = 0;
 	c->h_rd_off.resize(n_tok + 1); c->h_mini_off.resize(n_tok + 1); c->h_flip.assign(n_tok, 0);
 	c->h_frag_first.resize(n_tok + 1); c->h_frag_hash.resize(n_tok + 1);

@@ -11,7 +11,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CLI = os.path.join(ROOT, "airlift_amd", "bin", "airlift-align")
-SETS = ["g1_mt150pe", "g2_100se", "g2_250pe", "g3_adversarial", "g4_q2", "g6_repeats"]
+SETS = ["g1_mt150pe", "g2_100se", "g2_250pe", "g3_adversarial", "g4_q2", "g6_repeats", "g4_MT_orang", "g4_q_inv"]   # g4_*: the fork's own test/*.fa (16.5 kb and multi-kb queries)
 
 
 def _diff_report(got, exp, name):
@@ -119,13 +119,59 @@ def test_bwa_style_argv(golden_unpacked):
     assert r.stdout == open(os.path.join(d, "expected.sam"), "rb").read()
 
 
-def test_long_reads_fail_loudly(golden_unpacked):
-    """Reads beyond the device extension kernel's limit must produce an error, never a silent fallback."""
-    d = golden_unpacked["g4_MT_orang"]
-    m = json.load(open(os.path.join(d, "meta.json")))
-    r = subprocess.run([CLI, "-ax", "sr", m["ref"]] + m["reads"], cwd=d, capture_output=True)
+def test_reads_above_the_limit_fail_loudly(tmp_path):
+    """Reads beyond the long-read kernel's state tiles (32768 bp) must produce an error, never a silent fallback."""
+    import gen_synth as g
+    ref = g.make_reference(seed=3, n_contigs=1, total_len=200_000)
+    g.write_fasta(str(tmp_path / "ref.fa"), ref)
+    lut = b"ACGT"
+    with open(tmp_path / "long.fa", "wb") as f:
+        f.write(b">toolong\n" + bytes(lut[c] for c in ref[0][1][1000:1000 + 40000]) + b"\n")
+    r = subprocess.run([CLI, "-ax", "sr", "ref.fa", "long.fa"], cwd=tmp_path, capture_output=True)
     assert r.returncode != 0
-    assert b"not supported" in r.stderr
+    assert b"exceeds the limit" in r.stderr or b"not supported" in r.stderr
+
+
+def test_stage3_regions_2_to_20kb(tmp_path):
+    """B3 as AirLift ships it: align_gaps.sh:14-15 (`aln` + `samse`) is fed whole regions (extract_fasta_regions_with_bedfile.sh:4-7),
+    i.e. sequences of kilobases.  300 regions of 2-20 kb cut from a diverged copy of the reference (1 % substitutions, small indels,
+    a few N) through the bwa-style argv; SAM must equal the reference build's for the same files."""
+    import numpy as np
+    import gen_synth as g
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "mm2ref")
+    if not os.path.exists(ref_bin):
+        pytest.skip("oracle/_ref/mm2ref not built")
+    ref = g.make_reference(seed=17, n_contigs=3, total_len=3_000_000, n_dups=30, dup_len=(500, 4000), dup_div=0.03)
+    g.write_fasta(str(tmp_path / "old.fa"), ref)
+    rng = np.random.default_rng(5)
+    lut = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    with open(tmp_path / "gaps.fa", "wb") as f:
+        for i in range(300):
+            ci = int(rng.integers(0, 3)); c = ref[ci][1]
+            L = int(rng.integers(2000, 20001)); st = int(rng.integers(0, len(c) - L))
+            s = c[st:st + L].copy()
+            m = rng.random(L) < 0.01
+            s[m] = (s[m] + rng.integers(1, 4, size=int(m.sum()), dtype=np.uint8)) & 3
+            out = []; p = 0
+            for q in sorted(rng.integers(50, L - 50, size=max(1, L // 1500)).tolist()):     # an indel every ~1.5 kb
+                if q <= p:
+                    continue
+                out.append(s[p:q]); d = int(rng.integers(1, 12))
+                if rng.random() < 0.5:
+                    p = q + d                                                             # deletion
+                else:
+                    out.append(rng.integers(0, 4, size=d, dtype=np.uint8)); p = q         # insertion
+            out.append(s[p:]); s = np.concatenate(out)
+            if i % 17 == 0:
+                s[100:103] = 4
+            if i % 2:
+                s = (np.where(s < 4, 3 - s, 4))[::-1]
+            f.write(b">chr%d:%d-%d\n" % (ci + 1, st + 1, st + L) + lut[s].tobytes() + b"\n")
+    exp = subprocess.run([ref_bin, "-t", "16", "old.fa", "gaps.fa"], cwd=tmp_path, capture_output=True, check=True).stdout
+    subprocess.run([CLI, "aln", "-n", "0.08", "-t", "4", "old.fa", "gaps.fa"], cwd=tmp_path, stdout=open(tmp_path / "x.sai", "wb"), check=True)
+    r = subprocess.run([CLI, "samse", "old.fa", "x.sai", "gaps.fa"], cwd=tmp_path, capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    assert r.stdout == exp, _diff_report(r.stdout, exp, "stage3_regions")
 
 
 def test_map_frag_api(golden_unpacked):
