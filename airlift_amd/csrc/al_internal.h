@@ -118,6 +118,9 @@ struct ChainSeg {
 	const uint32_t *meta;     // per entry: qlen_sum | (paired ? 1 << 31 : 0) of the fragment it belongs to
 	uint32_t *tie;            // per entry: 1 if two of its chains start at anchors of equal x (their order is the fragment-wide sort's business)
 	uint32_t *nc;             // per entry: number of chained anchors written
+	// fragments whose anchors had equal x (tie_flag[f] != 0: exact heap merge, then the whole-fragment wavefront kernel) run on a
+	// side stream next to everything else.  tie_mode 1: skip flagged fragments (main stream), 2: only flagged fragments (side stream)
+	const uint32_t *tie_flag; int tie_mode;
 };
 
 struct LbThr { uint32_t v[16]; int n; };     // thresholds of k_lower_bounds

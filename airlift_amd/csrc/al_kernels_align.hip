@@ -2023,7 +2023,7 @@ struct AlignState {            // lives in al_ctx_s::align_state (opaque there)
 	DevBuf<ExtJob> jobs; DevBuf<ExtOut> outs; DevBuf<RegExt> rext;
 	DevBuf<uint64_t> job_off, sc_off, sc_ws; DevBuf<uint32_t> n_jobs, n_sc, job_key, job_key2, job_idx, job_idx2, frag_slow, slow_list;
 	DevBuf<uint8_t> sort_tmp;
-	int logtab_a = -1;
+	int logtab_a = -1, logtab_n = 0;
 	uint64_t out_total = 0;
 };
 static std::map<al_ctx_t *, AlignState *> g_states;
@@ -2054,13 +2054,15 @@ int al_run_align_stage(al_ctx_t *c)
 	const int nf = c->n_frag, nr = c->n_reads;
 	if (nf == 0) { for (int i = ST_REGS; i < ST_COMPACT; ++i) AL_HIP_CHECK(hipEventRecord(c->ev[i + 1], s)); return 0; }
 	// logf table from the HOST libm (the reference's logf is glibc's): logf((float)k / a) and logf((float)k)
-	if (A->logtab_a != c->opt.a) {
-		std::vector<float> h(2 * AL_LOGTAB_N);
-		for (int k = 0; k < AL_LOGTAB_N; ++k) { h[k] = logf((float)k / c->opt.a); h[AL_LOGTAB_N + k] = logf((float)k); }
-		if (A->logtab.ensure(2 * AL_LOGTAB_N)) return -1;
+	int Lmax0 = 0; for (int i = 0; i < nr; ++i) Lmax0 = std::max<int>(Lmax0, (int)c->h_rd_len[i]);
+	const int log_n = std::max(AL_LOGTAB_N, (std::max(c->opt.a, 1) * 2 * Lmax0 + 1024 + 4095) / 4096 * 4096);   // dp_max <= match_sc * read length; room to spare
+	if (A->logtab_a != c->opt.a || A->logtab_n < log_n) {
+		std::vector<float> h(2 * (size_t)log_n);
+		for (int k = 0; k < log_n; ++k) { h[k] = logf((float)k / c->opt.a); h[log_n + k] = logf((float)k); }
+		if (A->logtab.ensure(2 * (size_t)log_n)) return -1;
 		AL_HIP_CHECK(hipMemcpyAsync(A->logtab.p, h.data(), h.size() * 4, hipMemcpyHostToDevice, s));
 		AL_HIP_CHECK(hipStreamSynchronize(s));
-		A->logtab_a = c->opt.a;
+		A->logtab_a = c->opt.a; A->logtab_n = log_n;
 	}
 	// workspace sizes from the number of chains
 	if (A->nu_off.ensure(nf + 2)) return -1;
@@ -2118,7 +2120,7 @@ int al_run_align_stage(al_ctx_t *c)
 	if (A->dbgbuf.ensure(640)) return -1;
 	AL_HIP_CHECK(hipMemsetAsync(A->dbgbuf.p, 0, 640 * 8, s));
 	G.dbg = A->dbgbuf.p;
-	AlLogTab lt; lt.t = A->logtab.p; lt.miss = c->counters.p + 8;
+	AlLogTab lt; lt.t = A->logtab.p; lt.n = A->logtab_n; lt.miss = c->counters.p + 8;
 	const int tmax = (Lmax <= 160 && tbound <= 336) ? 336 : (Lmax <= 256 && tbound <= 512) ? 512 : (Lmax <= 512 && tbound <= 1024) ? 1024 : 0;
 	const int qmax = tmax == 336 ? 160 : tmax == 512 ? 256 : 512;
 	const bool long_mode = tmax == 0;              // reads beyond the LDS tiles: the whole batch through k_align_long (state blocks in HBM)

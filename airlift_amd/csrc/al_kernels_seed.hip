@@ -378,21 +378,24 @@ k_anchor_sort(const uint64_t *__restrict__ pos, const uint32_t *__restrict__ fra
 	if (fallback && lane == 0) tie_list[f] = 1u;                           // merged by k_anchor_heap
 }
 
-// K3 for fragments of 1025 .. CAP anchors (reads inside interspersed repeats): one 256-thread block per fragment, the (x, list)
-// pairs of all anchors in LDS (10 bytes each), bitonic network across the block; y is rebuilt from the list's match record
-// when the anchors are written out.  Equal x -> exact heap merge, as in the other sort kernels.
+// K3 for fragments of 1025 .. CAP anchors (reads inside interspersed repeats): one 256-thread block per fragment.  An anchor is ONE
+// 64-bit LDS word  (strand | contig | position) << 16 | list  (needs 33 + contig bits + 16 <= 64: the caller sends other
+// indexes to the device-wide sort), the match records of the lists sit in LDS next to it, every thread issues its position loads
+// back to back, then a bitonic network across the block; y is rebuilt from the list's match record when the anchors are
+// written out.  Equal x -> exact heap merge, as in the other sort kernels.
 template <int CAP>
 __global__ void __launch_bounds__(256)
 k_anchor_sort_blk(const uint64_t *__restrict__ pos, const uint32_t *__restrict__ frag_first, const uint32_t *__restrict__ rd_len,
                   const uint64_t *__restrict__ mini_off, const AlMatch *__restrict__ match,
                   const uint32_t *__restrict__ frag_nm, const uint32_t *__restrict__ frag_na, const uint64_t *__restrict__ a_off,
                   AlAnchor *__restrict__ anchors, uint32_t *__restrict__ tie_list,
-                  const uint32_t *__restrict__ frag_list, int n_list, int mini_span)
+                  const uint32_t *__restrict__ frag_list, int n_list, int mini_span, int rid_bits)
 {
 	constexpr int MCAP = 1024;                          // occurrence lists per fragment (query minimizers that passed the filter)
+	constexpr int PER = CAP / 256;
 	__shared__ uint64_t sx[CAP];
-	__shared__ uint16_t sm[CAP];
 	__shared__ uint32_t pre[MCAP + 1];
+	__shared__ uint32_t m_off[MCAP], m_fl[MCAP], m_qp[MCAP];   // match records: off_lo, flags, q_pos
 	__shared__ uint32_t s_part[256];
 	__shared__ int s_flag;
 	const int tid = threadIdx.x;
@@ -408,7 +411,11 @@ k_anchor_sort_blk(const uint64_t *__restrict__ pos, const uint32_t *__restrict__
 	if (tid == 0) s_flag = 0;
 	{   // exclusive prefix sums of the list lengths: four lists per thread, block scan of the partial sums
 		uint32_t v[4], sum = 0;
-		for (int j = 0; j < 4; ++j) { const uint32_t i = (uint32_t)tid * 4 + j; v[j] = i < n_m ? m[i].n : 0u; sum += v[j]; }
+		for (int j = 0; j < 4; ++j) {
+			const uint32_t i = (uint32_t)tid * 4 + j; v[j] = 0;
+			if (i < n_m) { const AlMatch mm = m[i]; v[j] = mm.n; m_off[i] = mm.off_lo; m_fl[i] = mm.flags; m_qp[i] = mm.q_pos; }
+			sum += v[j];
+		}
 		s_part[tid] = sum;
 		__syncthreads();
 		for (int d = 1; d < 256; d <<= 1) { const uint32_t t = tid >= d ? s_part[tid - d] : 0u; __syncthreads(); s_part[tid] += t; __syncthreads(); }
@@ -417,18 +424,31 @@ k_anchor_sort_blk(const uint64_t *__restrict__ pos, const uint32_t *__restrict__
 	}
 	__syncthreads();
 	int npow2 = 1; while ((uint32_t)npow2 < n) npow2 <<= 1;
-	for (uint32_t t = tid; t < (uint32_t)npow2; t += 256) {
-		uint64_t x = UINT64_MAX; uint32_t mi = 0;
-		if (t < n) {
-			uint32_t lo = 0, hi = n_m;                                       // last list with pre[list] <= t
-			while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (pre[mid] <= t) lo = mid; else hi = mid; }
-			mi = lo;
-			const AlMatch mm = m[lo];
-			const uint64_t r = d_match_pos(pos, mm.off_lo, mm.flags, t - pre[lo]);
-			x = (r & 0xffffffff00000000ULL) | (uint32_t)((uint32_t)r >> 1);
-			if ((r & 1) != (mm.q_pos & 1)) x |= 1ULL << 63;                 // map.c:176-190
+	const int sb = 32 + rid_bits;                                           // strand bit of the compact key
+	{   // expansion: owner list by binary search over the prefix sums (LDS), then all of the thread's position loads in flight at once
+		uint64_t rr[PER]; uint32_t mi[PER];
+#pragma unroll
+		for (int j = 0; j < PER; ++j) {
+			const uint32_t t = (uint32_t)tid + (uint32_t)j * 256u; rr[j] = 0; mi[j] = 0;
+			if (t < n) {
+				uint32_t lo = 0, hi = n_m;                                   // last list with pre[list] <= t
+				while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (pre[mid] <= t) lo = mid; else hi = mid; }
+				mi[j] = lo;
+				rr[j] = d_match_pos(pos, m_off[lo], m_fl[lo], t - pre[lo]);
+			}
 		}
-		sx[t] = x; sm[t] = (uint16_t)mi;
+#pragma unroll
+		for (int j = 0; j < PER; ++j) {
+			const uint32_t t = (uint32_t)tid + (uint32_t)j * 256u;
+			if (t < (uint32_t)npow2) {
+				uint64_t key = UINT64_MAX;
+				if (t < n) {
+					const uint64_t r = rr[j]; const bool rev = (r & 1) != (m_qp[mi[j]] & 1);      // map.c:176-190
+					key = ((uint64_t)(rev ? 1 : 0) << sb | (r >> 32) << 32 | (uint32_t)((uint32_t)r >> 1)) << 16 | mi[j];
+				}
+				sx[t] = key;
+			}
+		}
 	}
 	__syncthreads();
 	for (int kk = 2; kk <= npow2; kk <<= 1)
@@ -437,27 +457,28 @@ k_anchor_sort_blk(const uint64_t *__restrict__ pos, const uint32_t *__restrict__
 				const int ixj = i ^ j;
 				if (ixj > i) {
 					const uint64_t a = sx[i], b = sx[ixj];
-					if ((a > b) == ((i & kk) == 0)) { sx[i] = b; sx[ixj] = a; const uint16_t t = sm[i]; sm[i] = sm[ixj]; sm[ixj] = t; }
+					if ((a > b) == ((i & kk) == 0)) { sx[i] = b; sx[ixj] = a; }
 				}
 			}
 			__syncthreads();
 		}
 	int tie = 0;
-	for (uint32_t t = tid; t + 1 < n; t += 256) if (sx[t] == sx[t + 1]) tie = 1;
+	for (uint32_t t = tid; t + 1 < n; t += 256) if ((sx[t] >> 16) == (sx[t + 1] >> 16)) tie = 1;
 	if (tie) s_flag = 1;
 	__syncthreads();
 	if (s_flag) { if (tid == 0) tie_list[f] = 1u; return; }                // merged by k_anchor_heap
+	const uint64_t lowmask = (1ULL << sb) - 1;
 	for (uint32_t t = tid; t < n; t += 256) {
-		const uint64_t x = sx[t]; const AlMatch mm = m[sm[t]];
-		const uint32_t span = (uint32_t)mini_span;
-		AlAnchor a; a.x = x;
-		a.y = (x >> 63) ? (uint64_t)span << 32 | (uint32_t)(qlen - ((int)(mm.q_pos >> 1) + 1 - (int)span) - 1) : (uint64_t)span << 32 | (mm.q_pos >> 1);
-		a.y |= (uint64_t)(mm.flags & 0xff) << AL_SEED_SEG_SHIFT;
-		if (mm.flags & (1u << 8)) a.y |= AL_SEED_TANDEM;
+		const uint64_t key = sx[t]; const uint32_t i = (uint32_t)key & 0xffffu; const uint64_t kx = key >> 16;
+		const uint32_t qp = m_qp[i], fl = m_fl[i], span = (uint32_t)mini_span;
+		AlAnchor a; a.x = (kx & lowmask) | (kx >> sb & 1) << 63;
+		a.y = (a.x >> 63) ? (uint64_t)span << 32 | (uint32_t)(qlen - ((int)(qp >> 1) + 1 - (int)span) - 1) : (uint64_t)span << 32 | (qp >> 1);
+		a.y |= (uint64_t)(fl & 0xff) << AL_SEED_SEG_SHIFT;
+		if (fl & (1u << 8)) a.y |= AL_SEED_TANDEM;
 		out[t] = a;
 	}
 }
-template __global__ void k_anchor_sort_blk<4096>(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, uint32_t *, const uint32_t *, int, int);
+template __global__ void k_anchor_sort_blk<4096>(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, uint32_t *, const uint32_t *, int, int, int);
 
 // K3 for fragments above the LDS tiles (reads inside high-copy families, the max_occ re-chain pass: up to 42 x 5000 anchors):
 // their anchors are expanded unsorted with a composite key  (rank of the fragment in the list) << key_bits | strand | contig |
@@ -612,6 +633,7 @@ k_chain(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_off
 	const int lane = threadIdx.x;
 	if ((int)blockIdx.x >= n_list) return;
 	const uint32_t f = frag_list ? frag_list[blockIdx.x] : blockIdx.x;
+	if (seg.tie_mode) { const bool flagged = seg.tie_flag[f] != 0; if (flagged != (seg.tie_mode == 2)) return; }
 	const int64_t n = frag_na[f];
 	if (lane == 0) { frag_nu[f] = 0; if (seg.meta) { seg.tie[f] = 0; seg.nc[f] = 0; } }
 	if (n == 0) return;
@@ -932,6 +954,7 @@ k_chain_lds(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a
 	const int t0 = (int)(gridDim.x - 1 - blockIdx.x) * LANES + lane;
 	const bool have = lane < LANES && t0 < n_list;
 	const uint32_t f = have ? (order ? order[t0] : (uint32_t)t0) : 0;
+	const bool side = have && seg.tie_mode == 1 && seg.tie_flag[f] != 0;       // chained on the side stream (equal-x anchors)
 	const int n = have ? (int)frag_na[f] : 0;
 	int nmax = n;
 	for (int d = 32; d > 0; d >>= 1) { const int o = __shfl_xor(nmax, d); nmax = o > nmax ? o : nmax; }
@@ -942,7 +965,7 @@ k_chain_lds(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a
 		s_pen_same[d] = (uint8_t)(c_lin + (lg >> 1)); s_pen_diff[d] = (uint8_t)(c_lin < lg ? c_lin : lg);
 	}
 	__syncthreads();
-	if (!have) return;
+	if (!have || side) return;
 	frag_nu[f] = 0;
 	if (seg.meta) { seg.tie[f] = 0; seg.nc[f] = 0; }
 	if (n == 0) return;
@@ -1124,12 +1147,12 @@ __global__ void __launch_bounds__(64)
 k_seg_scan(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_off, const uint32_t *__restrict__ frag_na,
            const uint32_t *__restrict__ frag_first, const uint32_t *__restrict__ rd_len, const uint32_t *__restrict__ frag_list, int n_list,
            AlParams P, int lmin, int mode, const uint64_t *__restrict__ seg_first, uint32_t *__restrict__ seg_cnt,
-           uint64_t *__restrict__ vs_off, uint32_t *__restrict__ vs_na, uint32_t *__restrict__ vs_meta)
+           uint64_t *__restrict__ vs_off, uint32_t *__restrict__ vs_na, uint32_t *__restrict__ vs_meta, const uint32_t *__restrict__ tie_flag)
 {
 	const int lane = threadIdx.x;
 	if ((int)blockIdx.x >= n_list) return;
 	const uint32_t f = frag_list[blockIdx.x];
-	const int64_t n = frag_na[f];
+	const int64_t n = tie_flag && tie_flag[f] ? 0 : frag_na[f];                // equal-x anchors: chained whole on the side stream
 	const uint32_t r0 = frag_first[f], r1 = frag_first[f + 1];
 	int qlen_sum = 0; for (uint32_t r = r0; r < r1; ++r) qlen_sum += (int)rd_len[r];
 	int max_dist_x;                                                            // map.c:341-351
@@ -1177,13 +1200,14 @@ k_seg_merge(const uint32_t *__restrict__ frag_list, int n_list, const uint64_t *
             const uint64_t *__restrict__ vs_off, const uint32_t *__restrict__ vs_nu, const uint32_t *__restrict__ vs_nc, const uint32_t *__restrict__ vs_tie,
             const uint64_t *__restrict__ u_tmp, const AlAnchor *__restrict__ chain_tmp, const uint64_t *__restrict__ a_off,
             uint64_t *__restrict__ u_out, AlAnchor *__restrict__ chained, uint32_t *__restrict__ frag_nu,
-            uint32_t *__restrict__ fb_list, uint32_t *__restrict__ fb_cnt)
+            uint32_t *__restrict__ fb_list, uint32_t *__restrict__ fb_cnt, const uint32_t *__restrict__ tie_flag)
 {
 	__shared__ uint32_t s_bu[64], s_bc[64];
 	__shared__ uint64_t s_off[64];
 	const int lane = threadIdx.x;
 	if ((int)blockIdx.x >= n_list) return;
 	const uint32_t f = frag_list[blockIdx.x];
+	if (tie_flag && tie_flag[f]) return;                                       // the side stream writes this fragment's chains
 	const uint64_t s0 = seg_first[blockIdx.x], s1 = seg_first[blockIdx.x + 1];
 	uint64_t *u = u_out + a_off[f] + f; AlAnchor *b = chained + a_off[f];
 	uint64_t run_u = 0, run_c = 0; bool tie = false;

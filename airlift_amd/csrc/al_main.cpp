@@ -108,6 +108,7 @@ int main(int argc, char **argv)
 		else if (!strcmp(a, "--bam")) bam_mode = 1;
 		else if (!strcmp(a, "--sorted-bam")) bam_mode = 2;
 		else if (!strcmp(a, "-l") && i + 1 < argc) bam_level = atoi(argv[++i]);
+		else if (!strcmp(a, "--sort-mem") && i + 1 < argc) setenv("AL_SORT_MEM", std::to_string(parse_num(argv[++i], "--sort-mem")).c_str(), 1);   // --sorted-bam: bytes held before a sorted run is spilled (samtools sort -m)
 		else if (!strcmp(a, "--device") && i + 1 < argc) device = atoi(argv[++i]);
 		else if (!strcmp(a, "--devices") && i + 1 < argc) {   // "0-7", "0,1,2", "0,0" (two lanes on one GPU): reads of every mini-batch sharded over the lanes
 			const char *p = argv[++i];

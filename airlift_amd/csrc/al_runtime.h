@@ -41,7 +41,9 @@ struct al_ctx_s {
 	AlParams P;
 	int device = 0;
 	int n_threads = 1;                    // host worker threads for packing (al_ctx_set_threads)
-	hipStream_t stream = nullptr;
+	hipStream_t stream = nullptr, side = nullptr;   // side: exact (serial) handling of the few fragments with equal-x anchors, next to the main pipeline
+	hipEvent_t ev_side[4] = {};           // [0],[1]: start / end of the side stream's work in the first pass, [2],[3]: in the re-chain pass
+	float ms_side = 0;
 	AlDevIndex di;
 	hipEvent_t ev[ST_N + 1] = {};
 	float ms_stage[ST_N] = {};

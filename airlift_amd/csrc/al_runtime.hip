@@ -23,11 +23,11 @@ __global__ void k_anchor_sort_small(const uint64_t *, const uint32_t *, const ui
 template <int HCAP, int LANES> __global__ void k_anchor_heap(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, AlAnchor *, const uint32_t *, const uint32_t *, int, int, unsigned long long *, int);
 template <int CAP> __global__ void k_chain(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, AlAnchor *, uint64_t *, uint32_t *, int32_t *, uint64_t *, const uint32_t *, int, AlParams, unsigned long long *, ChainSeg);
 template <int CAPL, int LANES> __global__ void k_chain_lds(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, AlAnchor *, uint64_t *, uint32_t *, uint64_t *, const uint32_t *, int, int, AlParams, unsigned long long *, ChainSeg);
-template <int CAP> __global__ void k_anchor_sort_blk(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, uint32_t *, const uint32_t *, int, int);
+template <int CAP> __global__ void k_anchor_sort_blk(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, uint32_t *, const uint32_t *, int, int, int);
 __global__ void k_anchor_big_expand(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint32_t *, int, const uint64_t *, uint64_t *, uint64_t *, int, int);
 __global__ void k_anchor_big_scatter(const uint64_t *, const uint64_t *, const uint32_t *, int, const uint64_t *, const uint64_t *, AlAnchor *, uint32_t *, int);
-__global__ void k_seg_scan(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *, int, AlParams, int, int, const uint64_t *, uint32_t *, uint64_t *, uint32_t *, uint32_t *);
-__global__ void k_seg_merge(const uint32_t *, int, const uint64_t *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlAnchor *, const uint64_t *, uint64_t *, AlAnchor *, uint32_t *, uint32_t *, uint32_t *);
+__global__ void k_seg_scan(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *, int, AlParams, int, int, const uint64_t *, uint32_t *, uint64_t *, uint32_t *, uint32_t *, const uint32_t *);
+__global__ void k_seg_merge(const uint32_t *, int, const uint64_t *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlAnchor *, const uint64_t *, uint64_t *, AlAnchor *, uint32_t *, uint32_t *, uint32_t *, const uint32_t *);
 __global__ void k_lower_bounds(const uint32_t *, uint32_t, LbThr, uint32_t *);
 
 static const char *g_stage_names[ST_N] = { "sketch", "seed_lookup", "scan", "size_order", "anchor_sort_small", "anchor_sort", "anchor_sort_blk", "anchor_sort_big", "anchor_heap",
@@ -98,6 +98,7 @@ extern "C" al_ctx_t *al_ctx_init(const al_idx_t *mi, const al_mapopt_t *opt, int
 	c->mi = mi; c->opt = *opt; c->device = device;
 	if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return nullptr; }
 	for (int i = 0; i <= ST_N; ++i) if (hipEventCreate(&c->ev[i]) != hipSuccess) { delete c; return nullptr; }
+	if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&c->ev_side[0]) != hipSuccess || hipEventCreate(&c->ev_side[1]) != hipSuccess || hipEventCreate(&c->ev_side[2]) != hipSuccess || hipEventCreate(&c->ev_side[3]) != hipSuccess) { delete c; return nullptr; }
 	if (al_upload_index(mi, device, &c->di) != 0) { delete c; return nullptr; }
 	AlParams &P = c->P;
 	P.k = mi->k; P.w = mi->w; P.seed = opt->seed; P.bw = opt->bw; P.max_gap = opt->max_gap; P.max_gap_ref = opt->max_gap_ref; P.max_frag_len = opt->max_frag_len;
@@ -114,6 +115,7 @@ void al_align_state_free(al_ctx_t *c);
 static void ctx_release_buffers(al_ctx_t *c)
 {   // every grow-only batch buffer (the index stays); each is re-ensured before its next use
 	al_align_state_free(c);
+	if (c->side) (void)hipStreamSynchronize(c->side);
 	if (c->stream) (void)hipStreamSynchronize(c->stream);
 	c->rd_seq.release(); c->rd_len.release(); c->frag_first.release(); c->frag_hash.release(); c->mini_cnt.release(); c->frag_nm.release(); c->frag_na.release();
 	c->frag_nu.release(); c->rechain_list.release(); c->rechain_sorted.release(); c->tmp_u32.release(); c->rd_off.release(); c->mini_off.release(); c->a_off.release(); c->u.release();
@@ -129,6 +131,8 @@ extern "C" void al_ctx_destroy(al_ctx_t *c)
 	(void)hipSetDevice(c->device);
 	ctx_release_buffers(c);
 	for (int i = 0; i <= ST_N; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+	for (int i = 0; i < 4; ++i) if (c->ev_side[i]) (void)hipEventDestroy(c->ev_side[i]);
+	if (c->side) (void)hipStreamDestroy(c->side);
 	if (c->stream) (void)hipStreamDestroy(c->stream);
 	delete c;
 }
@@ -282,7 +286,7 @@ static int chain_by_segments(al_ctx_t *c, const uint32_t *order, int n, bool lds
 	{ const int per = c->mi->k + 1, need = (c->opt.min_chain_score + per - 1) / per; if (need > lmin) lmin = need; }
 	if (c->seg_cnt.ensure((size_t)n + 2) || c->seg_first.ensure((size_t)n + 2)) return -1;
 	hipLaunchKernelGGL(k_seg_scan, dim3(n), dim3(64), 0, s, c->anchors.p, c->a_off.p, c->frag_na.p, c->frag_first.p, c->rd_len.p, order, n, c->P, lmin, 0,
-	                   (const uint64_t *)nullptr, c->seg_cnt.p, (uint64_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr);
+	                   (const uint64_t *)nullptr, c->seg_cnt.p, (uint64_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)c->tie_list.p);
 	AL_HIP_CHECK(hipMemsetAsync(c->seg_cnt.p + n, 0, 4, s));
 	if (scan_u32_to_u64(c, c->seg_cnt.p, c->seg_first.p, n)) return -1;
 	uint64_t ns64 = 0;
@@ -293,7 +297,7 @@ static int chain_by_segments(al_ctx_t *c, const uint32_t *order, int n, bool lds
 	if (c->vs_off.ensure((size_t)ns + 1) || c->vs_na.ensure((size_t)ns + 1) || c->vs_meta.ensure((size_t)ns + 1) || c->vs_nu.ensure((size_t)ns + 1) || c->vs_nc.ensure((size_t)ns + 1) ||
 	    c->vs_tie.ensure((size_t)ns + 1) || c->seg_key.ensure((size_t)ns + 1) || c->seg_idx.ensure((size_t)ns + 1) || c->seg_ord.ensure((size_t)ns + 1) || c->fb_list.ensure((size_t)n + 2)) return -1;
 	hipLaunchKernelGGL(k_seg_scan, dim3(n), dim3(64), 0, s, c->anchors.p, c->a_off.p, c->frag_na.p, c->frag_first.p, c->rd_len.p, order, n, c->P, lmin, 1,
-	                   (const uint64_t *)c->seg_first.p, (uint32_t *)nullptr, c->vs_off.p, c->vs_na.p, c->vs_meta.p);
+	                   (const uint64_t *)c->seg_first.p, (uint32_t *)nullptr, c->vs_off.p, c->vs_na.p, c->vs_meta.p, (const uint32_t *)c->tie_list.p);
 	uint32_t lb[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 	if (ns > 0) {
 		hipLaunchKernelGGL(k_iota_u32, dim3((ns + 255) / 256), dim3(256), 0, s, c->seg_idx.p, (uint32_t)ns);
@@ -302,7 +306,7 @@ static int chain_by_segments(al_ctx_t *c, const uint32_t *order, int n, bool lds
 		if (lower_bounds(c, c->seg_key.p, (uint32_t)ns, thr, 9, lb)) return -1;
 	}
 	if (ev(ST_SEG_FIND)) return -1;
-	const ChainSeg sg{c->vs_meta.p, c->vs_tie.p, c->vs_nc.p};
+	const ChainSeg sg{c->vs_meta.p, c->vs_tie.p, c->vs_nc.p, nullptr, 0};
 	if (ns > 0) {
 		const uint32_t *so = c->seg_ord.p;
 		const uint32_t wave_from = lds_ok ? lb[8] : 0u;
@@ -321,13 +325,13 @@ static int chain_by_segments(al_ctx_t *c, const uint32_t *order, int n, bool lds
 	uint32_t *fb_cnt = (uint32_t *)(c->counters.p + 15);
 	AL_HIP_CHECK(hipMemsetAsync(fb_cnt, 0, 8, s));
 	hipLaunchKernelGGL(k_seg_merge, dim3(n), dim3(64), 0, s, order, n, c->seg_first.p, c->vs_off.p, c->vs_nu.p, c->vs_nc.p, c->vs_tie.p, c->u_tmp.p, c->chain_tmp.p, c->a_off.p,
-	                   c->u.p, c->chained.p, c->frag_nu.p, c->fb_list.p, fb_cnt);
+	                   c->u.p, c->chained.p, c->frag_nu.p, c->fb_list.p, fb_cnt, (const uint32_t *)c->tie_list.p);
 	uint32_t n_fb = 0;
 	AL_HIP_CHECK(hipMemcpyAsync(&n_fb, fb_cnt, 4, hipMemcpyDeviceToHost, s));
 	AL_HIP_CHECK(hipStreamSynchronize(s));
 	c->n_chain_fallback += n_fb;
 	if (n_fb > 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<AL_CHAIN_CAP>), dim3(n_fb), dim3(64), 0, s, c->anchors.p, c->a_off.p, c->frag_na.p, c->frag_first.p, c->rd_len.p, c->chained.p, c->u.p, c->frag_nu.p,
-	                                 c->ws_i32.p, c->ws_u64.p, c->fb_list.p, (int)n_fb, c->P, c->counters.p, ChainSeg{nullptr, nullptr, nullptr});
+	                                 c->ws_i32.p, c->ws_u64.p, c->fb_list.p, (int)n_fb, c->P, c->counters.p, ChainSeg{nullptr, nullptr, nullptr, nullptr, 0});
 	if (ev(ST_SEG_MERGE)) return -1;
 	return 0;
 }
@@ -374,6 +378,7 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 		static const char *e1 = getenv("AL_TEST_SORT_BLK"), *e2 = getenv("AL_TEST_SORT_BIG");
 		uint32_t t_blk = e1 ? (uint32_t)atoi(e1) : 1025u, t_big = e2 ? (uint32_t)atoi(e2) : 4097u;
 		if (t_blk < 65u) t_blk = 65u; if (t_blk > 1025u) t_blk = 1025u; if (t_big < t_blk) t_big = t_blk; if (t_big > 4097u) t_big = 4097u;
+		{ int rb = 1; while ((1ULL << rb) < c->mi->seq.size()) ++rb; if (33 + rb + 16 > 64) t_big = t_blk; }   // compact keys of the block sort: strand | contig | position | list in 64 bits
 		const uint32_t thr[6] = {65, 81, 97, 129, t_blk, t_big};
 		if (lower_bounds(c, c->chain_key.p, (uint32_t)nl, thr, 6, lb)) return -1;
 	}
@@ -389,11 +394,11 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 		if (lb1025 > lb65) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_anchor_sort<1024>), dim3(lb1025 - lb65), dim3(64), 0, s, c->di.pos, c->frag_first.p, c->rd_len.p, c->mini_off.p, c->match.p, c->frag_nm.p, c->frag_na.p,
 		                                      c->a_off.p, c->anchors.p, c->tie_list.p, tie_cnt, order + lb65, (int)(lb1025 - lb65), c->counters.p, c->mi->k);
 		if (ev(ST_ANCHOR_SORT)) return -1;
+		int rid_bits = 1; while ((1ULL << rid_bits) < c->mi->seq.size()) ++rid_bits;
 		if (lb4097 > lb1025) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_anchor_sort_blk<4096>), dim3(lb4097 - lb1025), dim3(256), 0, s, c->di.pos, c->frag_first.p, c->rd_len.p, c->mini_off.p, c->match.p, c->frag_nm.p, c->frag_na.p,
-		                                        c->a_off.p, c->anchors.p, c->tie_list.p, order + lb1025, (int)(lb4097 - lb1025), c->mi->k);
+		                                        c->a_off.p, c->anchors.p, c->tie_list.p, order + lb1025, (int)(lb4097 - lb1025), c->mi->k, rid_bits);
 		if (ev(ST_ANCHOR_SORT_BLK)) return -1;
 		// above the LDS tiles: composite-key device radix sort, a chunk of fragments at a time so that rank + key bits fit 64
-		int rid_bits = 1; while ((1ULL << rid_bits) < c->mi->seq.size()) ++rid_bits;
 		const int kb = 33 + rid_bits;
 		const uint32_t chunk_max = kb >= 64 ? 1u : (64 - kb >= 31 ? 0x7fffffffu : (1u << (64 - kb)));
 		for (uint32_t b0 = lb4097; b0 < (uint32_t)nl; ) {
@@ -418,15 +423,24 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 			b0 += nb;
 		}
 		if (ev(ST_ANCHOR_SORT_BIG)) return -1;
-		// fragments the sort kernels handed over (equal keys): exact heap merge, one lane each, by heap size class
-#define LHEAP(H, LN, LO) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_anchor_heap<H, LN>), dim3((nl + LN - 1) / LN), dim3(64), 0, s, c->di.pos, c->frag_first.p, c->rd_len.p, c->mini_off.p, c->match.p, c->frag_nm.p, c->frag_na.p, \
+		// Fragments the sort kernels flagged (equal x: overlapping mates, tandem repeats): the reference's order among equal heads is
+		// that of its binary heap, which only a serial emulation reproduces (one lane per fragment), and their chains are then made by
+		// the whole-fragment wavefront kernel (it also restates the reference's unstable sort of more than 64 chain starts).  Both are
+		// latency-bound tails on a few hundred fragments: they run on a side stream next to the chaining of everything else.
+		hipEvent_t *const evs = c->ev_side + (first ? 0 : 2);
+		AL_HIP_CHECK(hipEventRecord(evs[0], s));
+		AL_HIP_CHECK(hipStreamWaitEvent(c->side, evs[0], 0));
+#define LHEAP(H, LN, LO) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_anchor_heap<H, LN>), dim3((nl + LN - 1) / LN), dim3(64), 0, c->side, c->di.pos, c->frag_first.p, c->rd_len.p, c->mini_off.p, c->match.p, c->frag_nm.p, c->frag_na.p, \
 		                                  c->a_off.p, c->anchors.p, c->heap_ws.p, c->tie_list.p, order, nl, LO, c->counters.p, c->mi->k)
 		LHEAP(48, 64, -1); LHEAP(96, 32, 48); LHEAP(0, 64, 96);
 #undef LHEAP
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<AL_CHAIN_CAP>), dim3(nl), dim3(64), 0, c->side, c->anchors.p, c->a_off.p, c->frag_na.p, c->frag_first.p, c->rd_len.p, c->chained.p, c->u.p, c->frag_nu.p,
+		                   c->ws_i32.p, c->ws_u64.p, order, nl, c->P, c->counters.p, ChainSeg{nullptr, nullptr, nullptr, (const uint32_t *)c->tie_list.p, 2});
+		AL_HIP_CHECK(hipEventRecord(evs[1], c->side));
 		if (ev(ST_ANCHOR_HEAP)) return -1;
 	}
 	{
-		const ChainSeg nosg{nullptr, nullptr, nullptr};
+		const ChainSeg nosg{nullptr, nullptr, nullptr, (const uint32_t *)c->tie_list.p, 1};
 #define LFR(C, L, A, B) LCH(C, L, -1, c->a_off.p, c->frag_na.p, c->chained.p, c->u.p, c->frag_nu.p, order + (A), (int)((B) - (A)), nosg)
 #define LFRLO(C, L, LO) LCH(C, L, LO, c->a_off.p, c->frag_na.p, c->chained.p, c->u.p, c->frag_nu.p, order, (int)lb65, nosg)
 		if (lds_ok) { LFRLO(16, 64, -1); LFRLO(24, 64, 16); LFRLO(32, 64, 24); }
@@ -449,6 +463,7 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 		const uint32_t tail = lds_ok ? lb129 : 0u;
 		if (chain_by_segments(c, order + tail, nl - (int)tail, lds_ok, first)) return -1;
 	}
+	AL_HIP_CHECK(hipStreamWaitEvent(s, c->ev_side[first ? 1 : 3], 0));       // the side stream's fragments are chained: join
 	AL_HIP_CHECK(hipGetLastError());
 	return 0;
 }
@@ -525,6 +540,7 @@ extern "C" int al_batch_run(al_ctx_t *c)
 	}
 	for (int i = 0; i < ST_N; ++i) { float ms = 0; if (hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]) != hipSuccess) ms = 0; c->ms_stage[i] = ms; }
 	float tot = 0; (void)hipEventElapsedTime(&tot, c->ev[0], c->ev[ST_N]); c->ms_total = tot;
+	{ float a = 0, b = 0; if (hipEventElapsedTime(&a, c->ev_side[0], c->ev_side[1]) != hipSuccess) a = 0; if (c->n_rechain == 0 || hipEventElapsedTime(&b, c->ev_side[2], c->ev_side[3]) != hipSuccess) b = 0; c->ms_side = a + b; (void)hipGetLastError(); }
 	c->ran = true;
 	// counters + algorithmic bytes
 	unsigned long long h[16]; AL_HIP_CHECK(hipMemcpy(h, c->counters.p, sizeof(h), hipMemcpyDeviceToHost));
@@ -535,7 +551,7 @@ extern "C" int al_batch_run(al_ctx_t *c)
 	st.n_anchor = c->n_anchor_total; st.n_rechain = c->n_rechain; st.n_heap_fallback = h[0]; st.n_sort_tie_flag = h[1] + h[10];
 	st.n_regs_aln = h[4]; st.n_refbases = h[5]; st.n_cigar = h[6];
 	st.bytes_in = c->stat_bytes_in; st.bytes_out = 48 * st.n_regs_aln + 4 * st.n_cigar;
-	st.ms_total = c->ms_total; st.n_stage = ST_N;
+	st.ms_total = c->ms_total; st.n_stage = ST_N; st.ms_side_stream = c->ms_side; st.n_chain_fallback = c->n_chain_fallback; c->n_chain_fallback = 0;
 	for (int i = 0; i < ST_N; ++i) st.ms_kernel[i] = c->ms_stage[i];
 	return 0;
 }

@@ -285,14 +285,14 @@ def main():
             "metric": "reads/sec remapped (%d bp PE)" % a.read_len, "value": 2.0 * a.pairs * world * a.steps / dt, "unit": "reads/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8/int32 (int8 SW lanes, u64 hashes)", "data": "synthetic",
-            "config": {"workload": "%s, %d x 2 x %d bp PE reads per GPU per step, preset sr" % (WORKLOADS.get(a.config, a.config), a.pairs, a.read_len),
+            "config": {"workload": "%s, %d x 2 x %d bp PE reads per GPU per step, preset sr" % (WORKLOADS.get(a.config, a.config), a.pairs, a.read_len), "key": a.config,
                        "reads_per_step_per_gpu": 2 * a.pairs, "read_len": a.read_len, "sharding": "one input of %d fragments, rank r maps the contiguous range [r N / R, (r + 1) N / R); index replicated" % (a.pairs * world)},
             "roofline": roof,
             "stages_ms": per,
             "merged_output": merged,
             "counters": {"minimizers_per_read": st.n_mini / (2.0 * a.pairs), "anchors_per_pair": st.n_anchor / float(a.pairs), "chains_per_pair": st.n_chain / float(a.pairs),
                          "regions_aligned_per_read": st.n_regs_aln / (2.0 * a.pairs), "ref_bases_per_region": st.n_refbases / max(1.0, float(st.n_regs_aln)),
-                         "rechain": int(st.n_rechain), "heap_fallback": int(st.n_heap_fallback), "sort_tie_flags": int(st.n_sort_tie_flag), **(dist_info or {})},
+                         "rechain": int(st.n_rechain), "heap_fallback": int(st.n_heap_fallback), "chain_fallback": int(st.n_chain_fallback), "side_stream_ms": float(st.ms_side_stream), "sort_tie_flags": int(st.n_sort_tie_flag), **(dist_info or {})},
             "host": {"index_build_on_gpu_s": t_index, "pack_upload_s": t_upload, "reference_generation_s": t_gen, "read_simulation_s": t_reads, "reference_model": getattr(ref, "stats", None)},
         }
         if world == 1 and not a.no_cpu_baseline:

@@ -202,6 +202,8 @@ typedef struct {
 	float    ms_total;                /* HIP events around the whole device pipeline */
 	float    ms_kernel[40];           /* HIP-event time per pipeline interval, see al_stage_name() / al_stage_kernel() */
 	int      n_stage;
+	float    ms_side_stream;          /* exact (serial) heap merge + whole-fragment chaining of the fragments with equal-x anchors: runs on a side stream, overlapped with the intervals above */
+	uint64_t n_chain_fallback;        /* fragments re-chained whole because of equal-x chain starts among more than 64 chains */
 } al_batch_stat_t;
 void al_batch_stat(const al_ctx_t *ctx, al_batch_stat_t *st);
 const char *al_stage_name(int i);

@@ -54,7 +54,20 @@ try:
     for k, e in per.items():
         f = e["FETCH_SIZE"][1] / max(e["FETCH_SIZE"][0], 1) * 1024.0; w = e["WRITE_SIZE"][1] / max(e["WRITE_SIZE"][0], 1) * 1024.0
         kernels[k] = {"bytes_per_launch": f + w, "fetch_bytes": f, "write_bytes": w, "fetch_bytes_x2_upper": 2 * f, "launches": e["FETCH_SIZE"][0]}
-    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) over `python3 bench.py --no-cpu-baseline`, %s" % os.path.basename(d), "kernels": kernels},
+    # totals per step: every dispatch of the run (index build and stats kernels included) / (warmup + steps) of the bench line
+    meta = {}
+    try:
+        meta = json.loads(open(os.path.join(d, "bench_fetch.json")).read().strip().split("\n")[-1])
+    except Exception:
+        pass
+    n_runs = max(1, int(meta.get("steps", 0)) + int(meta.get("warmup", 0)))
+    tot_f = sum(e["FETCH_SIZE"][1] for e in per.values()) * 1024.0 / n_runs; tot_w = sum(e["WRITE_SIZE"][1] for e in per.values()) * 1024.0 / n_runs
+    wl = meta.get("config", {}).get("key") or (meta.get("config", {}).get("workload", "") or "").split(" ")[0].lower().rstrip(":")
+    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) over `python3 bench.py --no-cpu-baseline`, %s" % os.path.basename(d),
+               "workload": wl, "reads_per_step": meta.get("config", {}).get("reads_per_step_per_gpu"), "runs_in_profile": n_runs,
+               "total_bytes_per_step": tot_f + tot_w, "fetch_bytes_per_step": tot_f, "write_bytes_per_step": tot_w, "fetch_bytes_per_step_x2_upper": 2 * tot_f,
+               "note": "raw counters (KiB -> bytes); gfx950 FETCH_SIZE counts 128-byte requests at 64 bytes for wide streaming reads (guide: x2), uncalibrated for the scattered 4-16 byte accesses that dominate here: the raw value and the x2 upper bound are both kept",
+               "kernels": kernels},
               open(os.path.join(d, "traffic.json"), "w"), indent=1)
 except Exception as ex:
     print("traffic.json not written:", ex)
