@@ -98,6 +98,19 @@ def test_multi_lane_identical(golden_unpacked, tmp_path, devs, extra, to_file):
     assert got == one.stdout
 
 
+def test_sorted_bam_spilled_runs_identical(golden_unpacked):
+    """--sorted-bam with a memory bound far below the output (--sort-mem: sorted runs spilled to temp files, k-way merge at the end,
+    like `samtools sort -m`) gives the bytes of the in-memory sort."""
+    d = golden_unpacked["g1_mt150pe"]
+    m = json.load(open(os.path.join(d, "meta.json")))
+    base = [CLI, "-ax", "sr", "--sorted-bam", "-K", "30000"] + (["-R", m["rg"]] if m.get("rg") else [])
+    a = subprocess.run(base + [m["ref"]] + m["reads"], cwd=d, capture_output=True)
+    b = subprocess.run(base + ["--sort-mem", "40k", m["ref"]] + m["reads"], cwd=d, capture_output=True, env=dict(os.environ, AL_TIMING="1"))
+    assert a.returncode == 0 and b.returncode == 0, b.stderr.decode()[-2000:]
+    assert b"spilled runs" in b.stderr
+    assert len(a.stdout) > 1000 and a.stdout == b.stdout
+
+
 def test_yeast100k_digest(tmp_path):
     """G5: 100 k pairs on the 12 Mbp synthetic genome (the bench workload's shape): md5 of the whole SAM must equal the
     digest the reference build produced (tests/golden/g5_yeast100k/meta.json)."""

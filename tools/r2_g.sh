@@ -1,0 +1,12 @@
+#!/bin/bash
+REPO=${GRAFT_REPO_ROOT:-/root/repo}; O=$REPO/gpurun_out/${TAG:-r2g}; mkdir -p $O
+export AL_REF_CACHE=/tmp/alcache
+cd $REPO
+( time timeout 1500 python3 -m pytest tests/test_gpu_sam.py tests/test_gpu_stages.py -m gpu -x -q ) > $O/pytest1.log 2>&1; tail -6 $O/pytest1.log
+( time python3 bench.py --steps 3 --warmup 1 --pairs ${PAIRS:-500000} --cpu-sample-pairs 100000 ) > $O/c4.json 2> $O/c4.err
+timeout 1200 python3 -m pytest tests/test_gpu_configs.py -m gpu -x -q > $O/pytest2.log 2>&1; tail -3 $O/pytest2.log
+hipcc --offload-arch=gfx950 -O3 -o /tmp/valu_issue tools/micro/valu_issue.hip && /tmp/valu_issue > $O/valu_issue.txt 2>&1
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d $O/trace --output-format csv -- python3 $REPO/bench.py --no-cpu-baseline --steps 2 --warmup 1 --pairs ${PAIRS:-500000} > $O/c4_trace.json 2> $O/c4_trace.err
+find $O -name "*.csv" -size +4M -delete
+tail -n 3 $O/c4.err; cat $O/valu_issue.txt
