@@ -823,6 +823,7 @@ __device__ __forceinline__ void d_frag_ws(const WsBase &W, uint32_t f, FragWs &o
 // unset and k_regs runs the reference's sequence on one lane (exact order among equal keys).
 #define AL_REGS_PMAX 48
 #define AL_REGS_UNSET 0xffffffffu
+#define AL_REGS_DONE 0xfffffffeu
 struct RegsSelShared {
 	int32_t qs[AL_REGS_PMAX], qe[AL_REGS_PMAX], score[AL_REGS_PMAX], cnt[AL_REGS_PMAX], as[AL_REGS_PMAX], rs[AL_REGS_PMAX], re[AL_REGS_PMAX], ridrev[AL_REGS_PMAX];
 	int32_t subsc[AL_REGS_PMAX], nsub[AL_REGS_PMAX], slot[AL_REGS_PMAX]; uint32_t hash[AL_REGS_PMAX];
@@ -1021,6 +1022,127 @@ template __global__ void k_regs_select<1024>(const AlAnchor *, const uint64_t *,
 template __global__ void k_regs_select<8192>(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, WsBase, const uint32_t *, int, AlParams, uint32_t *);
 template __global__ void k_regs_select<-1>(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, WsBase, const uint32_t *, int, AlParams, uint32_t *);
 
+// What follows chain_post in mm_map_frag for the kept hits regs0[0 .. n0): single end -- the hits become the mate's hits and
+// their anchors are squeezed (align.c:873); paired end -- mm_seg_gen (hit.c:356-410): anchors split per mate (y rebased), per-mate
+// mm_gen_regs + mm_set_parent + squeeze.  a[] is indexed by regs0[i].as; sa0 receives mate 0's anchors, mate 1's follow at
+// sa0 + sna0.  Serial code: run by one lane on global memory (k_regs) or on LDS copies (k_regs_heavy).  Returns the sort-tie flag.
+__device__ __forceinline__ bool d_regs_tail(const AlParams &P, const uint32_t hash, const int n_segs, const int ql0, const int ql1, const int n0,
+                                            AlReg *regs0, const AlAnchor *a, const uint32_t tot_se, AlReg *mreg0, AlReg *mreg1, uint64_t *su0, uint64_t *su1,
+                                            AlAnchor *sa0, AlAnchor *aux128, uint64_t *aux64, int *auxi, uint32_t &cnt0, uint32_t &cnt1, uint32_t &sna0, uint32_t &sna1)
+{
+	bool tie = false; const int qlen_sum = ql0 + ql1;
+	if (n_segs == 1) {
+		for (int i = 0; i < n0; ++i) mreg0[i] = regs0[i];
+		for (uint32_t i = 0; i < tot_se; ++i) sa0[i] = a[i];
+		const int na = d_squeeze_a(n0, mreg0, sa0, aux64);                                            // mm_align_skeleton, align.c:873
+		cnt0 = (uint32_t)n0; sna0 = (uint32_t)na;
+	} else {
+		// mm_seg_gen, hit.c:356-410
+		uint32_t na0 = 0, na1 = 0, nus0 = 0, nus1 = 0;
+		for (int i = 0; i < n0; ++i) {
+			const AlReg *r = &regs0[i];
+			uint32_t c1 = 0;
+			for (int j = 0; j < r->cnt; ++j) c1 += (uint32_t)((a[r->as + j].y & AL_SEED_SEG_MASK) >> AL_SEED_SEG_SHIFT) & 1u;
+			const uint32_t c0 = (uint32_t)r->cnt - c1;
+			su0[i] = (uint64_t)(uint32_t)r->score << 32 | c0; su1[i] = (uint64_t)(uint32_t)r->score << 32 | c1;
+			na0 += c0; na1 += c1;
+		}
+		AlAnchor *const sa1 = sa0 + na0;
+		for (int i = 0; i < n0; ++i) { if ((int32_t)su0[i] != 0) su0[nus0++] = su0[i]; if ((int32_t)su1[i] != 0) su1[nus1++] = su1[i]; }
+		uint32_t w0 = 0, w1 = 0;
+		for (int i = 0; i < n0; ++i) {
+			const AlReg *r = &regs0[i];
+			for (int j = 0; j < r->cnt; ++j) {
+				AlAnchor a1 = a[r->as + j]; const bool s1 = ((a1.y & AL_SEED_SEG_MASK) >> AL_SEED_SEG_SHIFT) & 1;
+				const int qls = s1 ? ql1 : ql0, acc = s1 ? ql0 : 0;
+				a1.y -= (a1.x >> 63) ? (uint64_t)(qlen_sum - (qls + acc)) : (uint64_t)acc;
+				if (s1) sa1[w1++] = a1; else sa0[w0++] = a1;
+			}
+		}
+		{
+			tie = d_gen_regs(hash, ql0, (int)nus0, su0, sa0, mreg0, aux128) || tie;
+			const int n = (int)nus0;
+			for (int i = 0; i < n; ++i) mreg0[i].flags |= ALR_SEG_SPLIT;
+			d_set_parent(P.mask_level, n, mreg0, P.a * 2 + P.b, aux64, auxi);                         // map.c:401
+			(void)d_squeeze_a(n, mreg0, sa0, aux64);                                                  // align.c:873
+			cnt0 = (uint32_t)n;
+		}
+		{
+			tie = d_gen_regs(hash, ql1, (int)nus1, su1, sa1, mreg1, aux128) || tie;
+			const int n = (int)nus1;
+			for (int i = 0; i < n; ++i) mreg1[i].flags |= ALR_SEG_SPLIT | (1u << 8);
+			d_set_parent(P.mask_level, n, mreg1, P.a * 2 + P.b, aux64, auxi);
+			const int na = d_squeeze_a(n, mreg1, sa1, aux64);
+			cnt1 = (uint32_t)n; sna1 = (uint32_t)na;
+		}
+		sna0 = na0;   // seg_a[1] starts na0 anchors after seg_a[0] (kept un-squeezed size for addressing)
+	}
+	return tie;
+}
+
+// The tail of KA (d_regs_tail) for fragments that keep many hits (k_regs_select left 9 .. AL_RH_RC of them): the serial code
+// does O(n0^2) small moves and follows every hit's anchors three times -- on global memory that is tens of milliseconds for one
+// lane, and the launch waits for it.  Here a wavefront stages the kept hits and their anchors in LDS, lane 0 runs the same code
+// on the copies, the wavefront writes the results back.  Fragments that do not fit the tiles stay with k_regs.
+#define AL_RH_RC 72
+#define AL_RH_AC 1024
+__global__ void __launch_bounds__(64)
+k_regs_heavy(const AlAnchor *__restrict__ chained, const uint32_t *__restrict__ frag_first, const uint32_t *__restrict__ rd_len,
+             const uint32_t *__restrict__ frag_hash, WsBase W, const uint32_t *__restrict__ list, int n_list, AlParams P, unsigned long long *counters,
+             uint32_t *__restrict__ regs_n0)
+{
+	__shared__ AlReg s_r0[AL_RH_RC], s_m0[AL_RH_RC], s_m1[AL_RH_RC];
+	__shared__ AlAnchor s_src[AL_RH_AC], s_sa[AL_RH_AC], s_aux128[AL_RH_RC + AL_RS_SCRATCH / 16 + 2];
+	__shared__ uint64_t s_aux64[AL_RH_RC], s_su0[AL_RH_RC], s_su1[AL_RH_RC];
+	__shared__ int s_auxi[2 * AL_RH_RC + 4], s_off[AL_RH_RC + 1], s_as[AL_RH_RC];
+	__shared__ uint32_t s_res[5];
+	const int lane = threadIdx.x;
+	if ((int)blockIdx.x >= n_list) return;
+	const uint32_t f = list[blockIdx.x];
+	const uint32_t pre = regs_n0[f];
+	if (pre == AL_REGS_UNSET || pre == AL_REGS_DONE || pre < 9u || pre > (uint32_t)AL_RH_RC) return;
+	const int n0 = (int)pre;
+	const uint32_t r0 = frag_first[f], n_segs = frag_first[f + 1] - r0;
+	FragWs ws; d_frag_ws(W, f, ws);
+	const int ql0 = (int)rd_len[r0], ql1 = n_segs > 1 ? (int)rd_len[r0 + 1] : 0;
+	const AlAnchor *a = chained + W.a_off[f];
+	// stage the kept hits; anchors of hit i at s_off[i] (single end: in ascending order of `as`, which is what squeezing leaves)
+	for (int i = lane; i < n0 * (int)(sizeof(AlReg) / 4); i += 64) ((uint32_t *)s_r0)[i] = ((const uint32_t *)ws.regs0)[i];
+	__syncthreads();
+	if (lane == 0) {
+		int tot = 0;
+		if (n_segs == 1) {     // order of staging = ascending as (ties impossible: chains are disjoint anchor ranges)
+			for (int i = 0; i < n0; ++i) s_auxi[i] = i;
+			for (int i = 1; i < n0; ++i) { const int t = s_auxi[i]; int j = i; while (j > 0 && s_r0[s_auxi[j - 1]].as > s_r0[t].as) { s_auxi[j] = s_auxi[j - 1]; --j; } s_auxi[j] = t; }
+			for (int k = 0; k < n0; ++k) { const int i = s_auxi[k]; s_off[i] = tot; tot += s_r0[i].cnt; }
+		} else for (int i = 0; i < n0; ++i) { s_off[i] = tot; tot += s_r0[i].cnt; }
+		s_off[n0] = tot;
+	}
+	__syncthreads();
+	const int tot = s_off[n0];
+	if (tot > AL_RH_AC) return;                                              // k_regs takes it
+	for (int i = 0; i < n0; ++i) { const int as = s_r0[i].as, cnt = s_r0[i].cnt, o = s_off[i]; for (int j = lane; j < cnt; j += 64) s_src[o + j] = a[as + j]; }
+	__syncthreads();
+	if (lane == 0) {
+		for (int i = 0; i < n0; ++i) { s_as[i] = s_r0[i].as; s_r0[i].as = s_off[i]; }
+		uint32_t cnt0 = 0, cnt1 = 0, sna0 = 0, sna1 = 0;
+		// single end: the staged anchors are already squeezed in `as` order; d_regs_tail copies tot of them and squeezes (a no-op move)
+		const bool tie = d_regs_tail(P, frag_hash[f], (int)n_segs, ql0, ql1, n0, s_r0, s_src, (uint32_t)tot, s_m0, s_m1, s_su0, s_su1, s_sa, s_aux128, s_aux64, s_auxi, cnt0, cnt1, sna0, sna1);
+		s_res[0] = cnt0; s_res[1] = cnt1; s_res[2] = sna0; s_res[3] = sna1; s_res[4] = tie ? 1u : 0u;
+	}
+	__syncthreads();
+	const uint32_t cnt0 = s_res[0], cnt1 = s_res[1], sna0 = s_res[2], sna1 = s_res[3];
+	for (int i = lane; i < (int)cnt0 * (int)(sizeof(AlReg) / 4); i += 64) ((uint32_t *)ws.mreg[0])[i] = ((const uint32_t *)s_m0)[i];
+	if (n_segs > 1) for (int i = lane; i < (int)cnt1 * (int)(sizeof(AlReg) / 4); i += 64) ((uint32_t *)ws.mreg[1])[i] = ((const uint32_t *)s_m1)[i];
+	for (int i = lane; i < tot; i += 64) ws.seg_a[0][i] = s_sa[i];
+	if (lane == 0) {
+		W.reg_cnt[r0] = cnt0; W.seg_na[r0] = sna0; W.seg_fast[r0] = 0;
+		if (n_segs > 1) { W.reg_cnt[r0 + 1] = cnt1; W.seg_na[r0 + 1] = sna1; W.seg_fast[r0 + 1] = 0; }
+		if (s_res[4]) atomicAdd(&counters[10], 1ULL);
+		regs_n0[f] = AL_REGS_DONE;
+	}
+}
+
 extern "C" __global__ void __launch_bounds__(256, AL_LB_REGS)
 k_regs(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__ u_all, const uint32_t *__restrict__ frag_first,
        const uint32_t *__restrict__ rd_len, const uint32_t *__restrict__ frag_hash, WsBase W, int n_frag, AlParams P, unsigned long long *counters,
@@ -1029,6 +1151,7 @@ k_regs(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__ u_all,
 	const int f = blockIdx.x * blockDim.x + threadIdx.x;
 	if (f >= n_frag) return;
 	const uint32_t r0 = frag_first[f], n_segs = frag_first[f + 1] - r0, n_u = W.frag_nu[f];
+	if (regs_n0 && regs_n0[f] == AL_REGS_DONE) return;                        // k_regs_heavy wrote this fragment's hits
 	W.reg_cnt[r0] = 0; W.seg_na[r0] = 0; W.seg_fast[r0] = 0;
 	if (n_segs > 1) { W.reg_cnt[r0 + 1] = 0; W.seg_na[r0 + 1] = 0; W.seg_fast[r0 + 1] = 0; }
 	if (n_u == 0) return;
@@ -1118,56 +1241,11 @@ k_regs(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__ u_all,
 		if (n_segs <= 1) d_select_sub(P.pri_ratio, P.k * 2, P.best_n, &n0, ws.regs0, ws.auxi);
 		else d_select_sub_multi(P.pri_ratio, 0.2f, 0.7f, max_gap_ref, P.k * 2, P.best_n, (int)n_segs, qlens, &n0, ws.regs0, ws.auxi);
 	}
-	AlReg *const mreg0 = ws.mreg[0], *const mreg1 = ws.mreg[1];
-	uint64_t *const su0 = ws.seg_u[0], *const su1 = ws.seg_u[1];
-	AlAnchor *const sa0 = ws.seg_a[0];
-	if (n_segs == 1) {
-		for (int i = 0; i < n0; ++i) mreg0[i] = ws.regs0[i];
-		uint32_t tot = 0; for (uint32_t i = 0; i < n_u; ++i) tot += (uint32_t)u[i];
-		for (uint32_t i = 0; i < tot; ++i) sa0[i] = a[i];
-		const int na = d_squeeze_a(n0, mreg0, sa0, ws.aux64);                                         // mm_align_skeleton, align.c:873
-		W.reg_cnt[r0] = (uint32_t)n0; W.seg_na[r0] = (uint32_t)na;
-	} else {
-		// mm_seg_gen, hit.c:356-410
-		uint32_t na0 = 0, na1 = 0, nus0 = 0, nus1 = 0;
-		for (int i = 0; i < n0; ++i) {
-			const AlReg *r = &ws.regs0[i];
-			uint32_t c1 = 0;
-			for (int j = 0; j < r->cnt; ++j) c1 += (uint32_t)((a[r->as + j].y & AL_SEED_SEG_MASK) >> AL_SEED_SEG_SHIFT) & 1u;
-			const uint32_t c0 = (uint32_t)r->cnt - c1;
-			su0[i] = (uint64_t)(uint32_t)r->score << 32 | c0; su1[i] = (uint64_t)(uint32_t)r->score << 32 | c1;
-			na0 += c0; na1 += c1;
-		}
-		AlAnchor *const sa1 = sa0 + na0;
-		for (int i = 0; i < n0; ++i) { if ((int32_t)su0[i] != 0) su0[nus0++] = su0[i]; if ((int32_t)su1[i] != 0) su1[nus1++] = su1[i]; }
-		uint32_t w0 = 0, w1 = 0;
-		for (int i = 0; i < n0; ++i) {
-			const AlReg *r = &ws.regs0[i];
-			for (int j = 0; j < r->cnt; ++j) {
-				AlAnchor a1 = a[r->as + j]; const bool s1 = ((a1.y & AL_SEED_SEG_MASK) >> AL_SEED_SEG_SHIFT) & 1;
-				const int qls = s1 ? ql1 : ql0, acc = s1 ? ql0 : 0;
-				a1.y -= (a1.x >> 63) ? (uint64_t)(qlen_sum - (qls + acc)) : (uint64_t)acc;
-				if (s1) sa1[w1++] = a1; else sa0[w0++] = a1;
-			}
-		}
-		{
-			tie = d_gen_regs(hash, ql0, (int)nus0, su0, sa0, mreg0, ws.aux128) || tie;
-			const int n = (int)nus0;
-			for (int i = 0; i < n; ++i) mreg0[i].flags |= ALR_SEG_SPLIT;
-			d_set_parent(P.mask_level, n, mreg0, P.a * 2 + P.b, ws.aux64, ws.auxi);                     // map.c:401
-			const int na = d_squeeze_a(n, mreg0, sa0, ws.aux64);                                        // align.c:873
-			W.reg_cnt[r0] = (uint32_t)n; (void)na;
-		}
-		{
-			tie = d_gen_regs(hash, ql1, (int)nus1, su1, sa1, mreg1, ws.aux128) || tie;
-			const int n = (int)nus1;
-			for (int i = 0; i < n; ++i) mreg1[i].flags |= ALR_SEG_SPLIT | (1u << 8);
-			d_set_parent(P.mask_level, n, mreg1, P.a * 2 + P.b, ws.aux64, ws.auxi);
-			const int na = d_squeeze_a(n, mreg1, sa1, ws.aux64);
-			W.reg_cnt[r0 + 1] = (uint32_t)n; W.seg_na[r0 + 1] = (uint32_t)na;
-		}
-		W.seg_na[r0] = na0;   // seg_a[1] starts na0 anchors after seg_a[0] (kept un-squeezed size for addressing)
-	}
+	uint32_t cnt0 = 0, cnt1 = 0, sna0 = 0, sna1 = 0; uint32_t tot = 0;
+	if (n_segs == 1) for (uint32_t i = 0; i < n_u; ++i) tot += (uint32_t)u[i];
+	tie = d_regs_tail(P, hash, (int)n_segs, ql0, ql1, n0, ws.regs0, a, tot, ws.mreg[0], ws.mreg[1], ws.seg_u[0], ws.seg_u[1], ws.seg_a[0], ws.aux128, ws.aux64, ws.auxi, cnt0, cnt1, sna0, sna1) || tie;
+	W.reg_cnt[r0] = cnt0; W.seg_na[r0] = sna0;
+	if (n_segs > 1) { W.reg_cnt[r0 + 1] = cnt1; W.seg_na[r0 + 1] = sna1; }
 	if (tie) atomicAdd(&counters[10], 1ULL);
 }
 
@@ -2078,7 +2156,7 @@ int al_run_align_stage(al_ctx_t *c)
 	W.regs0 = A->regs0.p; W.mregs = A->mregs.p; W.rtmp = A->rtmp.p; W.aux128 = A->aux128.p; W.seg_a = c->chain_tmp.p /* chaining scratch, free again */; W.aux64 = A->aux64.p; W.seg_u = A->seg_u.p; W.auxi = A->auxi.p;
 	W.nu_off = A->nu_off.p; W.frag_nu = c->frag_nu.p; W.a_off = c->a_off.p; W.reg_cnt = A->reg_cnt.p; W.seg_na = A->seg_na.p; W.rext = A->rext.p; W.seg_fast = A->seg_fast.p;
 	// fragments with many chains: chain_post by a wavefront each (k_regs_select), by chain-count class
-	uint32_t *regs_n0 = nullptr;
+	uint32_t *regs_n0 = nullptr; uint32_t heavy_from = 0, heavy_n = 0;
 	if (!((c->P.dbg >> 19) & 1)) {
 		if (A->regs_n0.ensure(nf + 1) || c->chain_key.ensure(nf + 1) || c->chain_idx.ensure(nf + 1) || c->chain_idx2.ensure(nf + 1) || c->lb_buf.ensure(16)) return -1;
 		regs_n0 = A->regs_n0.p;
@@ -2095,11 +2173,15 @@ int al_run_align_stage(al_ctx_t *c)
 		AL_HIP_CHECK(hipMemcpyAsync(lb, c->lb_buf.p, 16, hipMemcpyDeviceToHost, s));
 		AL_HIP_CHECK(hipStreamSynchronize(s));
 		const uint32_t *ord = c->chain_idx2.p;
+		T.n = 1; T.v[0] = 9;      // fragments with at least nine chains may keep at least nine hits: candidates of k_regs_heavy
+		{ uint32_t i9 = (uint32_t)nf; AL_HIP_CHECK(hipMemcpyAsync(c->lb_buf.p, &i9, 4, hipMemcpyHostToDevice, s)); hipLaunchKernelGGL(k_lower_bounds, dim3((nf + 255) / 256), dim3(256), 0, s, (const uint32_t *)c->chain_key.p, (uint32_t)nf, T, c->lb_buf.p);
+		  AL_HIP_CHECK(hipMemcpyAsync(&i9, c->lb_buf.p, 4, hipMemcpyDeviceToHost, s)); AL_HIP_CHECK(hipStreamSynchronize(s)); heavy_from = i9; heavy_n = (uint32_t)nf - i9; }
 		if (lb[1] > lb[0]) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_select<0>), dim3(lb[1] - lb[0]), dim3(64), 0, s, c->chained.p, c->u.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, ord + lb[0], (int)(lb[1] - lb[0]), c->P, regs_n0);
 		if (lb[2] > lb[1]) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_select<1024>), dim3(lb[2] - lb[1]), dim3(256), 0, s, c->chained.p, c->u.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, ord + lb[1], (int)(lb[2] - lb[1]), c->P, regs_n0);
 		if (lb[3] > lb[2]) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_select<8192>), dim3(lb[3] - lb[2]), dim3(256), 0, s, c->chained.p, c->u.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, ord + lb[2], (int)(lb[3] - lb[2]), c->P, regs_n0);
 		if ((uint32_t)nf > lb[3]) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_select<-1>), dim3((uint32_t)nf - lb[3]), dim3(256), 0, s, c->chained.p, c->u.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, ord + lb[3], (int)((uint32_t)nf - lb[3]), c->P, regs_n0);
 	}
+	if (regs_n0 && heavy_n > 0) hipLaunchKernelGGL(k_regs_heavy, dim3(heavy_n), dim3(64), 0, s, c->chained.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, (const uint32_t *)c->chain_idx2.p + heavy_from, (int)heavy_n, c->P, c->counters.p, regs_n0);
 	hipLaunchKernelGGL(k_regs, dim3((nf + 255) / 256), dim3(256), 0, s, c->chained.p, c->u.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, nf, c->P, c->counters.p, (const uint32_t *)regs_n0);
 	AL_HIP_CHECK(hipEventRecord(c->ev[ST_REGS + 1], s));
 	// extension stage geometry

@@ -960,11 +960,16 @@ k_chain_lds(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a
 	for (int d = 32; d > 0; d >>= 1) { const int o = __shfl_xor(nmax, d); nmax = o > nmax ? o : nmax; }
 	if (nmax > CAPL || nmax <= lo_excl) return;                              // another instantiation / kernel owns this wavefront
 	// gap costs of chain.c:64-72 for avg_d == k, tabulated with the same two double multiplications for (int)(dd * .01 * avg_d)
-	for (int d = lane; d < AL_CLIN_N; d += 64) {
-		const int c_lin = (int)((double)d * .01 * (double)P.k), lg = d ? d_ilog2((uint32_t)d) : 0;
-		s_pen_same[d] = (uint8_t)(c_lin + (lg >> 1)); s_pen_diff[d] = (uint8_t)(c_lin < lg ? c_lin : lg);
+	// (entries of at most 16 anchors -- the short segments of repeat-rich fragments, millions per batch -- score too few pairs to
+	// repay building the tables: they compute the two costs directly)
+	constexpr bool USE_TAB = CAPL > 16;
+	if (USE_TAB) {
+		for (int d = lane; d < AL_CLIN_N; d += 64) {
+			const int c_lin = (int)((double)d * .01 * (double)P.k), lg = d ? d_ilog2((uint32_t)d) : 0;
+			s_pen_same[d] = (uint8_t)(c_lin + (lg >> 1)); s_pen_diff[d] = (uint8_t)(c_lin < lg ? c_lin : lg);
+		}
+		__syncthreads();
 	}
-	__syncthreads();
 	if (!have || side) return;
 	frag_nu[f] = 0;
 	if (seg.meta) { seg.tie[f] = 0; seg.nc[f] = 0; }
@@ -1007,7 +1012,7 @@ k_chain_lds(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a
 		if (bad) { atomicAdd(&counters[7], 1ULL); return; }   // not representable in the compact rows (never on the short-read path)
 	}
 	const double avg_d = (double)(float)((double)(float)((uint32_t)q_span * (uint32_t)n) / (double)(float)n);   // (float)sum/n (chain.c:42)
-	const bool tab_ok = avg_d == (double)P.k && P.k * 0.01 * (AL_CLIN_N - 1) + 5.0 < 255.0;
+	const bool tab_ok = USE_TAB && avg_d == (double)P.k && P.k * 0.01 * (AL_CLIN_N - 1) + 5.0 < 255.0;
 	const uint32_t dr_lim = n_segs > 1 ? (uint32_t)max_dist_y : 0x7fffffffu;   // (uint32_t)(dr - 1) >= dr_lim  <=>  dr == 0 or dr > max_dist_y (paired end only)
 	int st = 0; int32_t dist = 0;                                                 // dist = x_i - x_st while st..i lie in one window
 	uint32_t prev_xlo = 0;
@@ -1236,6 +1241,16 @@ k_seg_merge(const uint32_t *__restrict__ frag_list, int n_list, const uint64_t *
 		frag_nu[f] = (uint32_t)run_u;
 		if (any_tie && run_u > 64) fb_list[atomicAdd(fb_cnt, 1u)] = f;
 	}
+}
+
+// list entries whose fragment is flagged, appended to out (any order)
+__global__ void __launch_bounds__(256)
+k_collect_flagged(const uint32_t *__restrict__ list, int n, const uint32_t *__restrict__ flag, uint32_t *__restrict__ out, uint32_t *__restrict__ cnt)
+{
+	const int t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= n) return;
+	const uint32_t f = list[t];
+	if (flag[f]) out[atomicAdd(cnt, 1u)] = f;
 }
 
 // lower bounds of up to 16 thresholds in an ascending key array (out[k] pre-set to n)

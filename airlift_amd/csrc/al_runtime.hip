@@ -29,6 +29,7 @@ __global__ void k_anchor_big_scatter(const uint64_t *, const uint64_t *, const u
 __global__ void k_seg_scan(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *, int, AlParams, int, int, const uint64_t *, uint32_t *, uint64_t *, uint32_t *, uint32_t *, const uint32_t *);
 __global__ void k_seg_merge(const uint32_t *, int, const uint64_t *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlAnchor *, const uint64_t *, uint64_t *, AlAnchor *, uint32_t *, uint32_t *, uint32_t *, const uint32_t *);
 __global__ void k_lower_bounds(const uint32_t *, uint32_t, LbThr, uint32_t *);
+__global__ void k_collect_flagged(const uint32_t *, int, const uint32_t *, uint32_t *, uint32_t *);
 
 static const char *g_stage_names[ST_N] = { "sketch", "seed_lookup", "scan", "size_order", "anchor_sort_small", "anchor_sort", "anchor_sort_blk", "anchor_sort_big", "anchor_heap",
                                            "chain_lds32", "chain_lds48", "chain_lds64", "chain_lds128", "seg_find", "seg_chain_lds", "seg_chain_wave", "seg_merge", "rechain",
@@ -122,7 +123,7 @@ static void ctx_release_buffers(al_ctx_t *c)
 	c->ws_u64.release(); c->tmp_u64.release(); c->frag_rep.release(); c->ws_i32.release(); c->mini.release(); c->heap_ws.release(); c->anchors.release();
 	c->chained.release(); c->match.release(); c->counters.release(); c->scan_tmp.release(); c->regs0.release(); c->regs.release(); c->reg_cnt.release();
 	c->chain_key.release(); c->chain_idx.release(); c->chain_idx2.release(); c->tie_list.release(); c->lb_buf.release(); c->tmp_u64b.release();
-	c->chain_tmp.release(); c->u_tmp.release(); c->seg_cnt.release(); c->seg_first.release(); c->vs_off.release(); c->vs_na.release(); c->vs_meta.release(); c->vs_nu.release(); c->vs_nc.release(); c->vs_tie.release(); c->seg_key.release(); c->seg_idx.release(); c->seg_ord.release(); c->fb_list.release(); c->big_na.release(); c->big_off.release();
+	c->chain_tmp.release(); c->u_tmp.release(); c->seg_cnt.release(); c->seg_first.release(); c->vs_off.release(); c->vs_na.release(); c->vs_meta.release(); c->vs_nu.release(); c->vs_nc.release(); c->vs_tie.release(); c->seg_key.release(); c->seg_idx.release(); c->seg_ord.release(); c->fb_list.release(); c->tie_frags.release(); c->tie_sorted.release(); c->big_na.release(); c->big_off.release();
 	c->a_off_p1.release(); c->frag_na_p1.release(); c->frag_rep_p1.release(); c->cigar.release(); c->reg_off.release(); c->cig_off.release(); c->align_ws.release(); c->seg_a.release(); c->seg_u.release();
 }
 extern "C" void al_ctx_destroy(al_ctx_t *c)
@@ -276,7 +277,7 @@ static int sort_u32_pairs(al_ctx_t *c, const uint32_t *k_in, uint32_t *k_out, co
 // options in force) through their segments: cut -> order the segments by length -> the lane-per-entry LDS kernels for segments
 // of up to 128 anchors, the wavefront kernel above -> k_seg_merge; fragments the merge hands back (equal-x chain starts among
 // more than 64 chains) are chained whole by the wavefront kernel.
-static int chain_by_segments(al_ctx_t *c, const uint32_t *order, int n, bool lds_ok, bool first)
+static int chain_by_segments(al_ctx_t *c, const uint32_t *order, int n, bool lds_ok, bool first, const uint32_t *skip_flag)
 {
 	hipStream_t s = c->stream;
 	auto ev = [&](int st) -> int { if (first) AL_HIP_CHECK(hipEventRecord(c->ev[st + 1], s)); return 0; };
@@ -286,7 +287,7 @@ static int chain_by_segments(al_ctx_t *c, const uint32_t *order, int n, bool lds
 	{ const int per = c->mi->k + 1, need = (c->opt.min_chain_score + per - 1) / per; if (need > lmin) lmin = need; }
 	if (c->seg_cnt.ensure((size_t)n + 2) || c->seg_first.ensure((size_t)n + 2)) return -1;
 	hipLaunchKernelGGL(k_seg_scan, dim3(n), dim3(64), 0, s, c->anchors.p, c->a_off.p, c->frag_na.p, c->frag_first.p, c->rd_len.p, order, n, c->P, lmin, 0,
-	                   (const uint64_t *)nullptr, c->seg_cnt.p, (uint64_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)c->tie_list.p);
+	                   (const uint64_t *)nullptr, c->seg_cnt.p, (uint64_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, skip_flag);
 	AL_HIP_CHECK(hipMemsetAsync(c->seg_cnt.p + n, 0, 4, s));
 	if (scan_u32_to_u64(c, c->seg_cnt.p, c->seg_first.p, n)) return -1;
 	uint64_t ns64 = 0;
@@ -297,7 +298,7 @@ static int chain_by_segments(al_ctx_t *c, const uint32_t *order, int n, bool lds
 	if (c->vs_off.ensure((size_t)ns + 1) || c->vs_na.ensure((size_t)ns + 1) || c->vs_meta.ensure((size_t)ns + 1) || c->vs_nu.ensure((size_t)ns + 1) || c->vs_nc.ensure((size_t)ns + 1) ||
 	    c->vs_tie.ensure((size_t)ns + 1) || c->seg_key.ensure((size_t)ns + 1) || c->seg_idx.ensure((size_t)ns + 1) || c->seg_ord.ensure((size_t)ns + 1) || c->fb_list.ensure((size_t)n + 2)) return -1;
 	hipLaunchKernelGGL(k_seg_scan, dim3(n), dim3(64), 0, s, c->anchors.p, c->a_off.p, c->frag_na.p, c->frag_first.p, c->rd_len.p, order, n, c->P, lmin, 1,
-	                   (const uint64_t *)c->seg_first.p, (uint32_t *)nullptr, c->vs_off.p, c->vs_na.p, c->vs_meta.p, (const uint32_t *)c->tie_list.p);
+	                   (const uint64_t *)c->seg_first.p, (uint32_t *)nullptr, c->vs_off.p, c->vs_na.p, c->vs_meta.p, skip_flag);
 	uint32_t lb[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 	if (ns > 0) {
 		hipLaunchKernelGGL(k_iota_u32, dim3((ns + 255) / 256), dim3(256), 0, s, c->seg_idx.p, (uint32_t)ns);
@@ -325,7 +326,7 @@ static int chain_by_segments(al_ctx_t *c, const uint32_t *order, int n, bool lds
 	uint32_t *fb_cnt = (uint32_t *)(c->counters.p + 15);
 	AL_HIP_CHECK(hipMemsetAsync(fb_cnt, 0, 8, s));
 	hipLaunchKernelGGL(k_seg_merge, dim3(n), dim3(64), 0, s, order, n, c->seg_first.p, c->vs_off.p, c->vs_nu.p, c->vs_nc.p, c->vs_tie.p, c->u_tmp.p, c->chain_tmp.p, c->a_off.p,
-	                   c->u.p, c->chained.p, c->frag_nu.p, c->fb_list.p, fb_cnt, (const uint32_t *)c->tie_list.p);
+	                   c->u.p, c->chained.p, c->frag_nu.p, c->fb_list.p, fb_cnt, skip_flag);
 	uint32_t n_fb = 0;
 	AL_HIP_CHECK(hipMemcpyAsync(&n_fb, fb_cnt, 4, hipMemcpyDeviceToHost, s));
 	AL_HIP_CHECK(hipStreamSynchronize(s));
@@ -424,9 +425,9 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 		}
 		if (ev(ST_ANCHOR_SORT_BIG)) return -1;
 		// Fragments the sort kernels flagged (equal x: overlapping mates, tandem repeats): the reference's order among equal heads is
-		// that of its binary heap, which only a serial emulation reproduces (one lane per fragment), and their chains are then made by
-		// the whole-fragment wavefront kernel (it also restates the reference's unstable sort of more than 64 chain starts).  Both are
-		// latency-bound tails on a few hundred fragments: they run on a side stream next to the chaining of everything else.
+		// that of its binary heap, which only a serial emulation reproduces (one lane per fragment) -- a latency-bound tail on a few
+		// hundred fragments, so it runs on a side stream next to the chaining of everything else; the flagged fragments are chained
+		// (by segments, like the others) in a second, small round once the side stream is done.
 		hipEvent_t *const evs = c->ev_side + (first ? 0 : 2);
 		AL_HIP_CHECK(hipEventRecord(evs[0], s));
 		AL_HIP_CHECK(hipStreamWaitEvent(c->side, evs[0], 0));
@@ -434,8 +435,6 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 		                                  c->a_off.p, c->anchors.p, c->heap_ws.p, c->tie_list.p, order, nl, LO, c->counters.p, c->mi->k)
 		LHEAP(48, 64, -1); LHEAP(96, 32, 48); LHEAP(0, 64, 96);
 #undef LHEAP
-		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<AL_CHAIN_CAP>), dim3(nl), dim3(64), 0, c->side, c->anchors.p, c->a_off.p, c->frag_na.p, c->frag_first.p, c->rd_len.p, c->chained.p, c->u.p, c->frag_nu.p,
-		                   c->ws_i32.p, c->ws_u64.p, order, nl, c->P, c->counters.p, ChainSeg{nullptr, nullptr, nullptr, (const uint32_t *)c->tie_list.p, 2});
 		AL_HIP_CHECK(hipEventRecord(evs[1], c->side));
 		if (ev(ST_ANCHOR_HEAP)) return -1;
 	}
@@ -461,9 +460,26 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 #undef LFR
 #undef LFRLO
 		const uint32_t tail = lds_ok ? lb129 : 0u;
-		if (chain_by_segments(c, order + tail, nl - (int)tail, lds_ok, first)) return -1;
+		if (chain_by_segments(c, order + tail, nl - (int)tail, lds_ok, first, (const uint32_t *)c->tie_list.p)) return -1;
 	}
-	AL_HIP_CHECK(hipStreamWaitEvent(s, c->ev_side[first ? 1 : 3], 0));       // the side stream's fragments are chained: join
+	{   // second round: the fragments whose anchors the side stream merged, any size, through the segment path
+		AL_HIP_CHECK(hipStreamWaitEvent(s, c->ev_side[first ? 1 : 3], 0));
+		if (c->tie_frags.ensure((size_t)nl + 2)) return -1;
+		uint32_t *cnt = (uint32_t *)(c->counters.p + 15);
+		AL_HIP_CHECK(hipMemsetAsync(cnt, 0, 8, s));
+		hipLaunchKernelGGL(k_collect_flagged, dim3((nl + 255) / 256), dim3(256), 0, s, order, nl, (const uint32_t *)c->tie_list.p, c->tie_frags.p, cnt);
+		uint32_t n_tie = 0;
+		AL_HIP_CHECK(hipMemcpyAsync(&n_tie, cnt, 4, hipMemcpyDeviceToHost, s));
+		AL_HIP_CHECK(hipStreamSynchronize(s));
+		if (n_tie > 0) {
+			size_t bytes = 0;    // ascending fragment ids: a deterministic segment order (the collection above appends atomically)
+			if (c->tie_sorted.ensure((size_t)n_tie + 2)) return -1;
+			AL_HIP_CHECK(hipcub::DeviceRadixSort::SortKeys(nullptr, bytes, (const uint32_t *)c->tie_frags.p, c->tie_sorted.p, (int)n_tie, 0, 32, s));
+			if (c->scan_tmp.ensure(bytes + 16)) return -1;
+			AL_HIP_CHECK(hipcub::DeviceRadixSort::SortKeys(c->scan_tmp.p, bytes, (const uint32_t *)c->tie_frags.p, c->tie_sorted.p, (int)n_tie, 0, 32, s));
+			if (chain_by_segments(c, c->tie_sorted.p, (int)n_tie, lds_ok, false, nullptr)) return -1;
+		}
+	}
 	AL_HIP_CHECK(hipGetLastError());
 	return 0;
 }

@@ -43,6 +43,8 @@ public:
 		return true;
 	}
 	~AlSeqReader() { if (fp) gzclose(fp); }
+	// continue at a byte offset of an uncompressed file (a record must start there)
+	bool seek(long long off) { if (gzseek(fp, (z_off_t)off, SEEK_SET) < 0) return false; beg = end = 0; eof = false; last = 0; return true; }
 	// one record appended to c; false at end of input (a FASTQ record whose quality length differs ends the input, kseq.h -2)
 	bool read(AlChunk &c)
 	{

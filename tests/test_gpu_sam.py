@@ -291,6 +291,31 @@ def test_interleaved_single_file_and_uneven_files(golden_unpacked, oracle_bin, t
     assert r.stdout == exp, _diff_report(r.stdout, exp, "uneven")
 
 
+def test_parallel_fastq_parser_matches_serial_reader(tmp_path):
+    """Uncompressed four-line FASTQ is cut into 16 MB blocks at record boundaries and parsed on worker threads (-t 16); the general
+    kseq-grammar reader (AL_SERIAL_PARSE=1) must give the same SAM -- also when the file turns irregular half way (a multi-line
+    record, blank lines, CRLF: the serial reader takes over from that block on) and when the last record lacks its newline."""
+    import gen_synth as g
+    ref = g.make_reference(seed=7, n_contigs=3, total_len=300_000, n_dups=12, tandem=6)
+    g.write_fasta(str(tmp_path / "ref.fa"), ref)
+    r1, r2 = g.simulate_pairs(ref, 70000, 150, seed=4)
+    g.write_fastq(str(tmp_path / "a_1.fq"), r1); g.write_fastq(str(tmp_path / "a_2.fq"), r2)
+    for nm in ("a_1.fq", "a_2.fq"):      # irregular twin: record 40000 split over several lines, blank lines, one CRLF record; no final newline
+        lines = open(tmp_path / nm, "rb").read().split(b"\n")[:-1]
+        i = 4 * 40000
+        lines[i + 1:i + 2] = [lines[i + 1][:70], lines[i + 1][70:]]
+        lines[i + 4:i + 5] = [lines[i + 4][:33], lines[i + 4][33:]]
+        j = 4 * 50000 + 2
+        lines[j] = lines[j] + b"\r"
+        lines.insert(4 * 10000, b"")
+        open(tmp_path / nm.replace("a_", "b_"), "wb").write(b"\n".join(lines))
+    for pre in ("a", "b"):
+        cmd = [CLI, "-ax", "sr", "-t", "16", "ref.fa", pre + "_1.fq", pre + "_2.fq"]
+        par = _run(cmd, tmp_path).stdout
+        ser = _run(cmd, tmp_path, env=dict(os.environ, AL_SERIAL_PARSE="1")).stdout
+        assert len(par) > 10_000_000 and par == ser, pre
+
+
 def test_fasta_reads_single_end(golden_unpacked, oracle_bin, tmp_path):
     """B3 shape (align_gaps.sh:14-15): multi-line FASTA queries, single end, `samse` argv."""
     import airlift_amd as A

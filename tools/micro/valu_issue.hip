@@ -7,7 +7,7 @@
 #include <vector>
 
 template <int KIND>
-__global__ void __launch_bounds__(256) k_issue(int iters, int *out, long long *cyc)
+__global__ void __launch_bounds__(1024) k_issue(int iters, int *out, long long *cyc)
 {
 	int a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
 	const long long t0 = clock64();
