@@ -15,6 +15,20 @@ extern "C" int al_batch_fetch(al_ctx_t *c, int *n_regs, al_reg1_t **regs, int *r
 	return al_fetch_align(c, n_regs, regs, rep_len);
 }
 
+// The device -> host half of a fetch without building per-read arrays: the flat result block (record offsets, records, CIGAR
+// arena, repeat lengths) copied into page-locked buffers the context keeps; reports how much moved.  What the file drivers do
+// per batch; bench.py times upload + run + this as the PCIe-inclusive rate.
+extern "C" int al_batch_fetch_flat(al_ctx_t *c, uint64_t *n_records, uint64_t *n_bytes)
+{
+	if (!c || !c->ran) return -1;
+	static thread_local AlRawResult R;
+	const int rc = al_fetch_raw(c, R);
+	if (rc) return rc;
+	if (n_records) *n_records = R.out.size();
+	if (n_bytes) *n_bytes = R.off.size() * 8 + R.out.size() * sizeof(AlReg) + R.arena.size() * 4 + R.rep.size() * 4;
+	return 0;
+}
+
 extern "C" int al_map_batch(al_ctx_t *c, int n_frag, const int *n_segs, const int *qlens, const char *const *seqs,
                             const char *const *qnames, int *n_regs, al_reg1_t **regs, int *rep_len)
 {

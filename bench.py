@@ -232,6 +232,16 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    # PCIe-inclusive rate of the same batch (never `value`): pack + H2D upload, run, D2H of the flat result block
+    L.al_batch_fetch_flat.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]; L.al_batch_fetch_flat.restype = C.c_int
+    t0 = time.perf_counter(); n_io = 2
+    for _ in range(n_io):
+        upload(a.pairs); ctx.run()
+        nrec, nby = C.c_uint64(), C.c_uint64()
+        if L.al_batch_fetch_flat(ctx.h, C.byref(nrec), C.byref(nby)) != 0:
+            raise SystemExit("fetch failed")
+    torch.cuda.synchronize()
+    dt_io = (time.perf_counter() - t0) / n_io
     st = ctx.stat()
     dist_info = None; na = nu = na_p1 = None
     if rank == 0:   # distribution of the per-fragment sizes that decide which kernels run
@@ -287,6 +297,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "u8/int32 (int8 SW lanes, u64 hashes)", "data": "synthetic",
             "config": {"workload": "%s, %d x 2 x %d bp PE reads per GPU per step, preset sr" % (WORKLOADS.get(a.config, a.config), a.pairs, a.read_len), "key": a.config,
                        "reads_per_step_per_gpu": 2 * a.pairs, "read_len": a.read_len, "sharding": "one input of %d fragments, rank r maps the contiguous range [r N / R, (r + 1) N / R); index replicated" % (a.pairs * world)},
+            "value_incl_pcie": 2.0 * a.pairs / dt_io, "incl_pcie_note": "this rank: 4-bit packing on %d host threads + H2D, one step, D2H of %d records (%.1f MB); serial, no overlap between batches" % (min(32, os.cpu_count() or 1), int(nrec.value), nby.value / 1e6),
             "roofline": roof,
             "stages_ms": per,
             "merged_output": merged,

@@ -181,6 +181,10 @@ int  al_batch_run(al_ctx_t *ctx);
 /* Fetch results of the last al_batch_run into host reg arrays (same contract as al_map_batch). */
 int  al_batch_fetch(al_ctx_t *ctx, int *n_regs, al_reg1_t **regs, int *rep_len);
 
+/* Device -> host copy of the flat result block of the last al_batch_run into page-locked buffers kept by the library (what the file
+ * drivers do per batch); reports the records and bytes moved.  For timing the PCIe-inclusive rate. */
+int  al_batch_fetch_flat(al_ctx_t *ctx, uint64_t *n_records, uint64_t *n_bytes);
+
 /* ---- token batches: reads that are fixed-length windows of longer sequences, cut on the device ---- */
 typedef struct al_winsrc_s al_winsrc_t;     /* source sequences, concatenated, packed 4 bit/base in the context's GPU memory */
 al_winsrc_t *al_winsrc_create(al_ctx_t *ctx, const char *ascii, uint64_t n_bases);
