@@ -2183,6 +2183,19 @@ int al_run_align_stage(al_ctx_t *c)
 	}
 	if (regs_n0 && heavy_n > 0) hipLaunchKernelGGL(k_regs_heavy, dim3(heavy_n), dim3(64), 0, s, c->chained.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, (const uint32_t *)c->chain_idx2.p + heavy_from, (int)heavy_n, c->P, c->counters.p, regs_n0);
 	hipLaunchKernelGGL(k_regs, dim3((nf + 255) / 256), dim3(256), 0, s, c->chained.p, c->u.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, nf, c->P, c->counters.p, (const uint32_t *)regs_n0);
+	if (regs_n0 && getenv("AL_TRACE")) {   // which fragments were left to the one-lane code?
+		std::vector<uint32_t> h0(nf), hu(nf);
+		AL_HIP_CHECK(hipMemcpyAsync(h0.data(), regs_n0, (size_t)nf * 4, hipMemcpyDeviceToHost, s)); AL_HIP_CHECK(hipMemcpyAsync(hu.data(), c->frag_nu.p, (size_t)nf * 4, hipMemcpyDeviceToHost, s));
+		AL_HIP_CHECK(hipStreamSynchronize(s));
+		uint64_t n_unset = 0, n_set = 0, n_done = 0; uint32_t mx_unset = 0, mx_set = 0, mx_set_nu = 0;
+		for (int i = 0; i < nf; ++i) {
+			if (h0[i] == AL_REGS_DONE) ++n_done;
+			else if (h0[i] == AL_REGS_UNSET) { if (hu[i] >= 5) { ++n_unset; mx_unset = std::max(mx_unset, hu[i]); } }
+			else { ++n_set; if (h0[i] > mx_set) { mx_set = h0[i]; mx_set_nu = hu[i]; } }
+		}
+		fprintf(stderr, "[airlift] trace: regs: %llu fragments finished by k_regs_heavy; left to k_regs: %llu after selection (most kept hits %u, of %u chains), %llu without selection (>= 5 chains; most chains %u)\n",
+		        (unsigned long long)n_done, (unsigned long long)n_set, mx_set, mx_set_nu, (unsigned long long)n_unset, mx_unset);
+	}
 	AL_HIP_CHECK(hipEventRecord(c->ev[ST_REGS + 1], s));
 	// extension stage geometry
 	int Lmax = 0; for (int i = 0; i < nr; ++i) Lmax = std::max<int>(Lmax, (int)c->h_rd_len[i]);

@@ -860,6 +860,13 @@ k_chain(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_off
 		else if (in_lds && 2 * n_u1 <= CAP) { keysL = s_qm + n_u1; permL = st_; }     // behind the chain list; the permutation is T[]
 	}
 	const bool use_lds_order = keysL != nullptr && !in_lds;                          // per-chain records in LDS too (see the copy-out)
+	// thousands of chains (fragments inside high-copy families): keys once into the free half of the chain list's work area, so that
+	// the serial sort restatement reads one word per key instead of following chain -> visit list -> anchor
+	uint64_t *const keysG = (!keysL && !in_lds && n_u1 > 1 && 2 * (int64_t)n_u1 <= n) ? utmp + n_u1 : nullptr;
+	if (keysG) {
+		for (int32_t c = lane; c < n_u1; c += 64) { const uint64_t uc = utmp[c]; keysG[c] = a[V[Pp[c] + (int32_t)(uint32_t)uc - 1]].x; }
+		CHAIN_SYNC();
+	}
 	if (keysL) {
 		for (int32_t c = lane; c < n_u1; c += 64) {
 			const uint64_t uc = utmp[c]; const int32_t k0 = Pp[c], idx = V[k0 + (int32_t)(uint32_t)uc - 1];
@@ -892,6 +899,14 @@ k_chain(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_off
 					tie = d_rs_sort(acc, n_u, s_rs);
 					if (seg.meta) for (int32_t i = 1; i < n_u; ++i) tie = tie || acc.key(i) == acc.key(i - 1);   // equal keys: the fragment-wide sort decides
 				}
+			} else if (keysG) {
+				struct { typedef int32_t E; int32_t *t; const uint64_t *k;
+				         __device__ __forceinline__ uint64_t keyof(const int32_t &c) const { return k[c]; }
+				         __device__ __forceinline__ uint64_t key(int i) const { return k[t[i]]; }
+				         __device__ __forceinline__ int32_t get(int i) const { return t[i]; }
+				         __device__ __forceinline__ void set(int i, const int32_t &c) { t[i] = c; } } acc{T, keysG};
+				tie = d_rs_sort(acc, n_u, s_rs);
+				if (seg.meta) for (int32_t i = 1; i < n_u; ++i) tie = tie || acc.key(i) == acc.key(i - 1);
 			} else if (n_u > 1) {
 				ChainOrderAcc acc{T, V, Pp, utmp, X, a, in_lds};
 				tie = d_rs_sort(acc, n_u, s_rs);
