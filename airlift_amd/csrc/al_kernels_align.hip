@@ -821,7 +821,7 @@ __device__ __forceinline__ void d_frag_ws(const WsBase &W, uint32_t f, FragWs &o
 // Only the kept hits are written (ws.regs0[0 .. n0), ids and parents renumbered as mm_sync_regs does); regs_n0[f] = n0 tells
 // k_regs to start at mm_seg_gen.  Equal sort keys, more than PMAX primaries or more chains than the tile: regs_n0[f] stays
 // unset and k_regs runs the reference's sequence on one lane (exact order among equal keys).
-#define AL_REGS_PMAX 48
+#define AL_REGS_PMAX 160              // primaries a fragment can have before k_regs takes it (short chains tiling a pair: dozens)
 #define AL_REGS_UNSET 0xffffffffu
 #define AL_REGS_DONE 0xfffffffeu
 struct RegsSelShared {
@@ -1019,8 +1019,11 @@ k_regs_select(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__
 }
 template __global__ void k_regs_select<0>(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, WsBase, const uint32_t *, int, AlParams, uint32_t *);
 template __global__ void k_regs_select<1024>(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, WsBase, const uint32_t *, int, AlParams, uint32_t *);
+template __global__ void k_regs_select<2048>(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, WsBase, const uint32_t *, int, AlParams, uint32_t *);
 template __global__ void k_regs_select<8192>(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, WsBase, const uint32_t *, int, AlParams, uint32_t *);
 template __global__ void k_regs_select<-1>(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, WsBase, const uint32_t *, int, AlParams, uint32_t *);
+
+static size_t al_regs_heavy_lds(int RC, int AC) { return (size_t)3 * RC * sizeof(AlReg) + ((size_t)2 * AC + RC + AL_RS_SCRATCH / 16 + 2) * sizeof(AlAnchor) + (size_t)3 * RC * 8 + ((size_t)2 * RC + 4 + RC + 1 + RC) * 4 + 8 * 4 + 64; }
 
 // What follows chain_post in mm_map_frag for the kept hits regs0[0 .. n0): single end -- the hits become the mate's hits and
 // their anchors are squeezed (align.c:873); paired end -- mm_seg_gen (hit.c:356-410): anchors split per mate (y rebased), per-mate
@@ -1084,23 +1087,23 @@ __device__ __forceinline__ bool d_regs_tail(const AlParams &P, const uint32_t ha
 // does O(n0^2) small moves and follows every hit's anchors three times -- on global memory that is tens of milliseconds for one
 // lane, and the launch waits for it.  Here a wavefront stages the kept hits and their anchors in LDS, lane 0 runs the same code
 // on the copies, the wavefront writes the results back.  Fragments that do not fit the tiles stay with k_regs.
-#define AL_RH_RC 72
-#define AL_RH_AC 1024
+template <int RC, int AC>      // RC kept hits, AC anchors of theirs: the LDS tiles (72 / 1024: 62 KB, two blocks per CU; 200 / 2048: 141 KB for the few larger ones)
 __global__ void __launch_bounds__(64)
 k_regs_heavy(const AlAnchor *__restrict__ chained, const uint32_t *__restrict__ frag_first, const uint32_t *__restrict__ rd_len,
              const uint32_t *__restrict__ frag_hash, WsBase W, const uint32_t *__restrict__ list, int n_list, AlParams P, unsigned long long *counters,
              uint32_t *__restrict__ regs_n0)
 {
-	__shared__ AlReg s_r0[AL_RH_RC], s_m0[AL_RH_RC], s_m1[AL_RH_RC];
-	__shared__ AlAnchor s_src[AL_RH_AC], s_sa[AL_RH_AC], s_aux128[AL_RH_RC + AL_RS_SCRATCH / 16 + 2];
-	__shared__ uint64_t s_aux64[AL_RH_RC], s_su0[AL_RH_RC], s_su1[AL_RH_RC];
-	__shared__ int s_auxi[2 * AL_RH_RC + 4], s_off[AL_RH_RC + 1], s_as[AL_RH_RC];
-	__shared__ uint32_t s_res[5];
+	extern __shared__ __align__(16) unsigned char s_raw[];
+	AlReg *const s_r0 = (AlReg *)s_raw, *const s_m0 = s_r0 + RC, *const s_m1 = s_m0 + RC;
+	AlAnchor *const s_src = (AlAnchor *)(s_m1 + RC), *const s_sa = s_src + AC, *const s_aux128 = s_sa + AC;
+	uint64_t *const s_aux64 = (uint64_t *)(s_aux128 + RC + AL_RS_SCRATCH / 16 + 2), *const s_su0 = s_aux64 + RC, *const s_su1 = s_su0 + RC;
+	int *const s_auxi = (int *)(s_su1 + RC), *const s_off = s_auxi + 2 * RC + 4, *const s_as = s_off + RC + 1;
+	uint32_t *const s_res = (uint32_t *)(s_as + RC);
 	const int lane = threadIdx.x;
 	if ((int)blockIdx.x >= n_list) return;
 	const uint32_t f = list[blockIdx.x];
 	const uint32_t pre = regs_n0[f];
-	if (pre == AL_REGS_UNSET || pre == AL_REGS_DONE || pre < 9u || pre > (uint32_t)AL_RH_RC) return;
+	if (pre == AL_REGS_UNSET || pre == AL_REGS_DONE || pre < 9u || pre > (uint32_t)RC) return;
 	const int n0 = (int)pre;
 	const uint32_t r0 = frag_first[f], n_segs = frag_first[f + 1] - r0;
 	FragWs ws; d_frag_ws(W, f, ws);
@@ -1120,7 +1123,7 @@ k_regs_heavy(const AlAnchor *__restrict__ chained, const uint32_t *__restrict__ 
 	}
 	__syncthreads();
 	const int tot = s_off[n0];
-	if (tot > AL_RH_AC) return;                                              // k_regs takes it
+	if (tot > AC) return;                                                    // the larger instantiation, or k_regs, takes it
 	for (int i = 0; i < n0; ++i) { const int as = s_r0[i].as, cnt = s_r0[i].cnt, o = s_off[i]; for (int j = lane; j < cnt; j += 64) s_src[o + j] = a[as + j]; }
 	__syncthreads();
 	if (lane == 0) {
@@ -2166,11 +2169,11 @@ int al_run_align_stage(al_ctx_t *c)
 		AL_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const uint32_t *)c->frag_nu.p, c->chain_key.p, (const uint32_t *)c->chain_idx.p, c->chain_idx2.p, nf, 0, 32, s));
 		if (c->scan_tmp.ensure(bytes + 16)) return -1;
 		AL_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(c->scan_tmp.p, bytes, (const uint32_t *)c->frag_nu.p, c->chain_key.p, (const uint32_t *)c->chain_idx.p, c->chain_idx2.p, nf, 0, 32, s));
-		uint32_t init[4] = {(uint32_t)nf, (uint32_t)nf, (uint32_t)nf, (uint32_t)nf}, lb[4];
-		AL_HIP_CHECK(hipMemcpyAsync(c->lb_buf.p, init, 16, hipMemcpyHostToDevice, s));
-		LbThr T; T.n = 4; T.v[0] = 5; T.v[1] = 65; T.v[2] = 1025; T.v[3] = 8193; for (int i = 4; i < 16; ++i) T.v[i] = 0xffffffffu;
+		uint32_t init[5] = {(uint32_t)nf, (uint32_t)nf, (uint32_t)nf, (uint32_t)nf, (uint32_t)nf}, lb[5];
+		AL_HIP_CHECK(hipMemcpyAsync(c->lb_buf.p, init, 20, hipMemcpyHostToDevice, s));
+		LbThr T; T.n = 5; T.v[0] = 5; T.v[1] = 65; T.v[2] = 1025; T.v[3] = 8193; T.v[4] = 2049; for (int i = 5; i < 16; ++i) T.v[i] = 0xffffffffu;
 		hipLaunchKernelGGL(k_lower_bounds, dim3((nf + 255) / 256), dim3(256), 0, s, (const uint32_t *)c->chain_key.p, (uint32_t)nf, T, c->lb_buf.p);
-		AL_HIP_CHECK(hipMemcpyAsync(lb, c->lb_buf.p, 16, hipMemcpyDeviceToHost, s));
+		AL_HIP_CHECK(hipMemcpyAsync(lb, c->lb_buf.p, 20, hipMemcpyDeviceToHost, s));
 		AL_HIP_CHECK(hipStreamSynchronize(s));
 		const uint32_t *ord = c->chain_idx2.p;
 		T.n = 1; T.v[0] = 9;      // fragments with at least nine chains may keep at least nine hits: candidates of k_regs_heavy
@@ -2178,10 +2181,17 @@ int al_run_align_stage(al_ctx_t *c)
 		  AL_HIP_CHECK(hipMemcpyAsync(&i9, c->lb_buf.p, 4, hipMemcpyDeviceToHost, s)); AL_HIP_CHECK(hipStreamSynchronize(s)); heavy_from = i9; heavy_n = (uint32_t)nf - i9; }
 		if (lb[1] > lb[0]) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_select<0>), dim3(lb[1] - lb[0]), dim3(64), 0, s, c->chained.p, c->u.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, ord + lb[0], (int)(lb[1] - lb[0]), c->P, regs_n0);
 		if (lb[2] > lb[1]) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_select<1024>), dim3(lb[2] - lb[1]), dim3(256), 0, s, c->chained.p, c->u.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, ord + lb[1], (int)(lb[2] - lb[1]), c->P, regs_n0);
-		if (lb[3] > lb[2]) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_select<8192>), dim3(lb[3] - lb[2]), dim3(256), 0, s, c->chained.p, c->u.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, ord + lb[2], (int)(lb[3] - lb[2]), c->P, regs_n0);
+		if (lb[4] > lb[2]) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_select<2048>), dim3(lb[4] - lb[2]), dim3(256), 0, s, c->chained.p, c->u.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, ord + lb[2], (int)(lb[4] - lb[2]), c->P, regs_n0);
+		if (lb[3] > lb[4]) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_select<8192>), dim3(lb[3] - lb[4]), dim3(256), 0, s, c->chained.p, c->u.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, ord + lb[4], (int)(lb[3] - lb[4]), c->P, regs_n0);
 		if ((uint32_t)nf > lb[3]) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_select<-1>), dim3((uint32_t)nf - lb[3]), dim3(256), 0, s, c->chained.p, c->u.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, ord + lb[3], (int)((uint32_t)nf - lb[3]), c->P, regs_n0);
 	}
-	if (regs_n0 && heavy_n > 0) hipLaunchKernelGGL(k_regs_heavy, dim3(heavy_n), dim3(64), 0, s, c->chained.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, (const uint32_t *)c->chain_idx2.p + heavy_from, (int)heavy_n, c->P, c->counters.p, regs_n0);
+	if (regs_n0 && heavy_n > 0) {
+		const size_t lds_s = al_regs_heavy_lds(72, 1024), lds_l = al_regs_heavy_lds(200, 2048);
+		static bool attr_set = false;
+		if (!attr_set) { AL_HIP_CHECK(hipFuncSetAttribute((const void *)k_regs_heavy<200, 2048>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_l)); attr_set = true; }
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_heavy<72, 1024>), dim3(heavy_n), dim3(64), lds_s, s, c->chained.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, (const uint32_t *)c->chain_idx2.p + heavy_from, (int)heavy_n, c->P, c->counters.p, regs_n0);
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_heavy<200, 2048>), dim3(heavy_n), dim3(64), lds_l, s, c->chained.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, (const uint32_t *)c->chain_idx2.p + heavy_from, (int)heavy_n, c->P, c->counters.p, regs_n0);
+	}
 	hipLaunchKernelGGL(k_regs, dim3((nf + 255) / 256), dim3(256), 0, s, c->chained.p, c->u.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, nf, c->P, c->counters.p, (const uint32_t *)regs_n0);
 	if (regs_n0 && getenv("AL_TRACE")) {   // which fragments were left to the one-lane code?
 		std::vector<uint32_t> h0(nf), hu(nf);
