@@ -824,6 +824,7 @@ __device__ __forceinline__ void d_frag_ws(const WsBase &W, uint32_t f, FragWs &o
 #define AL_REGS_PMAX 160              // primaries a fragment can have before k_regs takes it (short chains tiling a pair: dozens)
 #define AL_REGS_UNSET 0xffffffffu
 #define AL_REGS_DONE 0xfffffffeu
+#define AL_REGS_BAIL(v) ((v) >= 0xfffffff0u && (v) < AL_REGS_DONE)   // k_regs_select gave up: 0xfffffff1 equal sort keys, 0xfffffff2 too many primaries
 struct RegsSelShared {
 	int32_t qs[AL_REGS_PMAX], qe[AL_REGS_PMAX], score[AL_REGS_PMAX], cnt[AL_REGS_PMAX], as[AL_REGS_PMAX], rs[AL_REGS_PMAX], re[AL_REGS_PMAX], ridrev[AL_REGS_PMAX];
 	int32_t subsc[AL_REGS_PMAX], nsub[AL_REGS_PMAX], slot[AL_REGS_PMAX]; uint32_t hash[AL_REGS_PMAX];
@@ -907,7 +908,7 @@ k_regs_select(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__
 		const int klo2 = __shfl(klo, src), khi2 = __shfl(khi, src), id2 = __shfl(idx_r, src);
 		key_r = (uint64_t)(uint32_t)klo2 | (uint64_t)(uint32_t)khi2 << 32; idx_r = id2;
 	}
-	if (__ballot(tie)) return;                                              // equal keys: the reference's (unstable) order is k_regs's business
+	if (__ballot(tie)) { if (lane == 0) regs_n0[f] = 0xfffffff1u; return; }   // equal keys: the reference's (unstable) order is k_regs's business
 	// ---- one pass in score order ----
 	const float mask_level = P.mask_level;
 	const int min_diff = P.k * 2, best_n = P.best_n;
@@ -1005,7 +1006,7 @@ k_regs_select(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__
 			if (overflow) break;
 		}
 	}
-	if (overflow) return;
+	if (overflow) { if (lane == 0) regs_n0[f] = 0xfffffff2u; return; }
 	const int n0 = slot_base;
 	for (int j = lane; j < k; j += 64) {                                     // the primaries, with their final subsc / n_sub
 		AlReg R; d_reg_clear(&R);
@@ -1103,7 +1104,7 @@ k_regs_heavy(const AlAnchor *__restrict__ chained, const uint32_t *__restrict__ 
 	if ((int)blockIdx.x >= n_list) return;
 	const uint32_t f = list[blockIdx.x];
 	const uint32_t pre = regs_n0[f];
-	if (pre == AL_REGS_UNSET || pre == AL_REGS_DONE || pre < 9u || pre > (uint32_t)RC) return;
+	if (pre == AL_REGS_UNSET || pre == AL_REGS_DONE || AL_REGS_BAIL(pre) || pre < 9u || pre > (uint32_t)RC) return;
 	const int n0 = (int)pre;
 	const uint32_t r0 = frag_first[f], n_segs = frag_first[f + 1] - r0;
 	FragWs ws; d_frag_ws(W, f, ws);
@@ -1237,7 +1238,7 @@ k_regs(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__ u_all,
 	}
 	bool tie = false; int n0 = (int)n_u;
 	const uint32_t pre_n0 = regs_n0 ? regs_n0[f] : AL_REGS_UNSET;
-	if (pre_n0 != AL_REGS_UNSET) n0 = (int)pre_n0;                                                    // k_regs_select did chain_post: ws.regs0[0 .. n0) are the kept hits
+	if (pre_n0 != AL_REGS_UNSET && !AL_REGS_BAIL(pre_n0)) n0 = (int)pre_n0;                                                    // k_regs_select did chain_post: ws.regs0[0 .. n0) are the kept hits
 	else {
 		tie = d_gen_regs(hash, qlen_sum, (int)n_u, u, a, ws.regs0, ws.aux128);
 		d_set_parent(P.mask_level, n0, ws.regs0, P.a * 2 + P.b, ws.aux64, ws.auxi);                   // chain_post, map.c:249-258
@@ -2200,7 +2201,7 @@ int al_run_align_stage(al_ctx_t *c)
 		uint64_t n_unset = 0, n_set = 0, n_done = 0; uint32_t mx_unset = 0, mx_set = 0, mx_set_nu = 0;
 		for (int i = 0; i < nf; ++i) {
 			if (h0[i] == AL_REGS_DONE) ++n_done;
-			else if (h0[i] == AL_REGS_UNSET) { if (hu[i] >= 5) { ++n_unset; mx_unset = std::max(mx_unset, hu[i]); } }
+			else if (h0[i] == AL_REGS_UNSET || AL_REGS_BAIL(h0[i])) { if (hu[i] >= 5) { ++n_unset; mx_unset = std::max(mx_unset, hu[i]); if (hu[i] > 64) fprintf(stderr, "[airlift] trace: regs: fragment %d with %u chains not selected, code %x\n", i, hu[i], h0[i]); } }
 			else { ++n_set; if (h0[i] > mx_set) { mx_set = h0[i]; mx_set_nu = hu[i]; } }
 		}
 		fprintf(stderr, "[airlift] trace: regs: %llu fragments finished by k_regs_heavy; left to k_regs: %llu after selection (most kept hits %u, of %u chains), %llu without selection (>= 5 chains; most chains %u)\n",
