@@ -896,19 +896,45 @@ k_regs_select(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__
 			}
 		if (tid >= 64) return;
 		for (int i = lane; i + 1 < n_u; i += 64) if (skey[i] == skey[i + 1]) tie = true;
-	} else {         // rank sort in registers (descending)
+		if (__ballot(tie)) {
+			// Equal keys (a minimizer the sketch emitted twice makes two identical chains): their order is what the reference's unstable
+			// radix sort (ksort.h:116-151, more than 64 entries here) leaves.  Rare: the keys go back into chain order and lane 0
+			// restates that sort on them (ascending), the wavefront reverses the result (hit.c:76).
+			__shared__ uint16_t s_rs[AL_RS_SCRATCH / 2];
+			if (n_u > 65535) { if (lane == 0) regs_n0[f] = 0xfffffff1u; return; }
+			for (int c0 = 0; c0 < n_u; c0 += 64) {
+				const int c = c0 + lane;
+				if (c < n_u) { const AlAnchor fa = a[as_arr[c]]; skey[c] = u[c] ^ (uint32_t)d_hash64((d_hash64(fa.x) + d_hash64(fa.y)) ^ fhash); sidx[c] = (IdxT)c; }
+			}
+			__threadfence_block();
+			if (lane == 0) {
+				struct KI { uint64_t k; IdxT i; };
+				struct { typedef KI E; uint64_t *k; IdxT *i;
+				         __device__ __forceinline__ uint64_t keyof(const KI &e) const { return e.k; }
+				         __device__ __forceinline__ uint64_t key(int j) const { return k[j]; }
+				         __device__ __forceinline__ KI get(int j) const { return KI{k[j], i[j]}; }
+				         __device__ __forceinline__ void set(int j, const KI &e) { k[j] = e.k; i[j] = e.i; } } acc{skey, sidx};
+				(void)d_rs_sort(acc, n_u, s_rs);
+			}
+			__threadfence_block();
+			for (int i = lane; i < n_u / 2; i += 64) {
+				const uint64_t tk = skey[i]; skey[i] = skey[n_u - 1 - i]; skey[n_u - 1 - i] = tk;
+				const IdxT ti = sidx[i]; sidx[i] = sidx[n_u - 1 - i]; sidx[n_u - 1 - i] = ti;
+			}
+			__threadfence_block();
+		}
+	} else {         // rank sort in registers (descending); equal keys: the stable ascending insertion sort (ksort.h:149), reversed, puts the later chain first
 		int rank = 0; const int klo = (int)(uint32_t)key_r, khi = (int)(uint32_t)(key_r >> 32);
 		for (int j = 0; j < n_u; ++j) {
 			const uint64_t kj = (uint64_t)(uint32_t)__shfl(klo, j) | (uint64_t)(uint32_t)__shfl(khi, j) << 32;
-			if (lane < n_u) { rank += kj > key_r ? 1 : 0; tie = tie || (kj == key_r && j != lane); }
+			if (lane < n_u) rank += (kj > key_r || (kj == key_r && j > lane)) ? 1 : 0;
 		}
-		// lane takes the entry whose rank is its lane number (ranks are a permutation when there is no tie)
+		// lane takes the entry whose rank is its lane number
 		int src = 0;
 		for (int j = 0; j < n_u; ++j) { const int rj = __shfl(rank, j); if (rj == lane) src = j; }
 		const int klo2 = __shfl(klo, src), khi2 = __shfl(khi, src), id2 = __shfl(idx_r, src);
 		key_r = (uint64_t)(uint32_t)klo2 | (uint64_t)(uint32_t)khi2 << 32; idx_r = id2;
 	}
-	if (__ballot(tie)) { if (lane == 0) regs_n0[f] = 0xfffffff1u; return; }   // equal keys: the reference's (unstable) order is k_regs's business
 	// ---- one pass in score order ----
 	const float mask_level = P.mask_level;
 	const int min_diff = P.k * 2, best_n = P.best_n;
