@@ -121,8 +121,12 @@ struct ChainSeg {
 	// fragments whose anchors had equal x (tie_flag[f] != 0: exact heap merge, then the whole-fragment wavefront kernel) run on a
 	// side stream next to everything else.  tie_mode 1: skip flagged fragments (main stream), 2: only flagged fragments (side stream)
 	const uint32_t *tie_flag; int tie_mode;
+	// segment mode, min_cnt >= 2: per chain (same order as the chain list) the key the reference processes chain ends by, peak score << 32 |
+	// peak anchor (chain.c:111-114) -- what k_chain_order needs to restate the fragment-wide sort of equal chain starts
+	uint64_t *okey;
 };
 
+#define AL_ORD_CAP 8192                   // chains of a fragment whose exact order k_chain_order restates in LDS (14 bytes each)
 struct LbThr { uint32_t v[16]; int n; };     // thresholds of k_lower_bounds
 
 // one HIP-event interval per entry; where a stage is several kernels (chaining and extension DP are dispatched by size class)

@@ -779,6 +779,7 @@ k_chain(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_off
 	AlAnchor *b = chained + a_off[f];
 	uint64_t *u = u_out + a_off[f] + (seg.meta ? 0u : f);   // capacity n + 1 (segment mode: n, a chain has at least one anchor)
 	uint64_t *utmp = in_lds ? s_qm : ws_u64 + a_off[f]; // capacity n (Q/M are dead after the DP)
+	uint64_t *const okf = seg.okey ? seg.okey + a_off[f] : nullptr, *const okp = okf ? okf + (n + 1) / 2 : nullptr;   // final / processing-order keys (at most n / 2 chains)
 	// Peaks (chain.c:87-110) by all lanes: every chain end walks back to its peak on its own; the list of plain 64-bit keys
 	// (score << 32 | anchor index) is sorted next, so the order the lanes append in does not matter.  At most n/2 entries
 	// (a peak needs a predecessor to reach min_sc), which leaves the upper half of utmp[] free as a second buffer.
@@ -833,12 +834,13 @@ k_chain(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_off
 			}
 			// backtrack; V[] is reused as the visit list v[] (chain.c:113-127)
 			for (int32_t i = 0; i < n_u; ++i) {
+				const uint64_t key0 = utmp[i];
 				const int32_t n_v0 = n_v, k0 = k; int64_t j = (int32_t)utmp[i];
 				if (stage_bt) { do { V[n_v++] = (int32_t)j; bT[j] = 1; j = bP[j]; } while (j >= 0 && bT[j] == 0); }
 				else { do { V[n_v++] = (int32_t)j; T[j] = 1; j = Pp[j]; } while (j >= 0 && T[j] == 0); }
 				if (j < 0) { if (n_v - n_v0 >= min_cnt) utmp[k++] = utmp[i] >> 32 << 32 | (uint32_t)(n_v - n_v0); }
 				else if ((int32_t)(utmp[i] >> 32) - F[j] >= min_sc) { if (n_v - n_v0 >= min_cnt) utmp[k++] = (uint64_t)((utmp[i] >> 32) - (uint64_t)(uint32_t)F[j]) << 32 | (uint32_t)(n_v - n_v0); }
-				if (k0 == k) n_v = n_v0;
+				if (k0 == k) n_v = n_v0; else if (okp) okp[k0] = key0;
 			}
 			n_u = k;
 			// order chains by the x of their first anchor (chain.c:144-160): stable insertion for <= 64 (ksort.h:149).
@@ -914,7 +916,7 @@ k_chain(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_off
 			}
 			int32_t o = 0;
 			if (use_lds_order) { for (int32_t i = 0; i < n_u; ++i) { st_[i] = o; o += (int32_t)(uint32_t)s_qm[sp[i]]; } }                // st_[] = output offset of sorted chain i
-			else { for (int32_t i = 0; i < n_u; ++i) { const int32_t c = T[i]; u[i] = utmp[c]; F[i] = o; o += (int32_t)(uint32_t)utmp[c]; } }   // F[] = output offset of sorted chain i
+			else { for (int32_t i = 0; i < n_u; ++i) { const int32_t c = T[i]; u[i] = utmp[c]; if (okf) okf[i] = okp[c]; F[i] = o; o += (int32_t)(uint32_t)utmp[c]; } }   // F[] = output offset of sorted chain i
 			if (tie) { if (seg.meta) seg.tie[f] = 1u; else atomicAdd(&counters[1], 1ULL); }
 			if (seg.meta) seg.nc[f] = (uint32_t)o;
 		}
@@ -925,7 +927,7 @@ k_chain(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_off
 		const int32_t n_u = s_nu;
 		for (int32_t i = lane; i < n_u; i += 64) {
 			const int32_t c = sp[i]; const uint64_t uc = s_qm[c]; const int32_t ni = (int32_t)(uint32_t)uc, k0 = sf[c], o = st_[i];
-			u[i] = uc;
+			u[i] = uc; if (okf) okf[i] = okp[c];
 			for (int32_t j = 0; j < ni; ++j) b[o + j] = a[V[k0 + (ni - j - 1)]];
 		}
 	} else {   // copy-out of the chained anchors by the whole wave: b[F[i] + j] = a[V[k0 + ni - 1 - j]]
@@ -1105,12 +1107,14 @@ k_chain_lds(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a
 	if (n_u == 0) return;
 	for (int32_t i = 1; i < n_u; ++i) { const uint64_t t = utmp[i]; int32_t j = i; while (j > 0 && utmp[j - 1] < t) { utmp[j] = utmp[j - 1]; --j; } utmp[j] = t; }
 	for (int i = 0; i < n; ++i) TB(i) = 0;
+	uint64_t *const okf = seg.okey ? seg.okey + a_off[f] : nullptr, *const okp = okf ? okf + (n + 1) / 2 : nullptr;
 	for (int32_t i = 0; i < n_u; ++i) {                                              // chain.c:111-128; v[] reused as the visit list
+		const uint64_t key0 = utmp[i];
 		const int32_t n_v0 = n_v, k0 = k; int j = (int32_t)utmp[i];
 		do { VL(n_v) = (int16_t)j; ++n_v; TB(j) = 1; j = PLv(j) == 0xff ? -1 : (int)PLv(j); } while (j >= 0 && TB(j) == 0);
 		if (j < 0) { if (n_v - n_v0 >= min_cnt) utmp[k++] = utmp[i] >> 32 << 32 | (uint32_t)(n_v - n_v0); }
 		else if ((int32_t)(utmp[i] >> 32) - FL(j) >= min_sc) { if (n_v - n_v0 >= min_cnt) utmp[k++] = (uint64_t)((utmp[i] >> 32) - (uint64_t)(uint32_t)FL(j)) << 32 | (uint32_t)(n_v - n_v0); }
-		if (k0 == k) n_v = n_v0;
+		if (k0 == k) n_v = n_v0; else if (okp) okp[k0] = key0;
 	}
 	n_u = k;
 	// chains ordered by the x of their first anchor (chain.c:144-160); n_u <= 64: stable insertion sort (ksort.h:149).
@@ -1131,7 +1135,7 @@ k_chain_lds(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a
 	int32_t o = 0;
 	for (int32_t i = 0; i < n_u; ++i) {
 		const int32_t c = TB(i), ni = (int32_t)(uint32_t)utmp[c], k0 = OFFB(c);
-		u[i] = utmp[c];
+		u[i] = utmp[c]; if (okf) okf[i] = okp[c];
 		for (int32_t j = 0; j < ni; ++j) b[o++] = a[(int)VL(k0 + (ni - j - 1))];
 	}
 	frag_nu[f] = (uint32_t)n_u;
@@ -1220,7 +1224,8 @@ k_seg_merge(const uint32_t *__restrict__ frag_list, int n_list, const uint64_t *
             const uint64_t *__restrict__ vs_off, const uint32_t *__restrict__ vs_nu, const uint32_t *__restrict__ vs_nc, const uint32_t *__restrict__ vs_tie,
             const uint64_t *__restrict__ u_tmp, const AlAnchor *__restrict__ chain_tmp, const uint64_t *__restrict__ a_off,
             uint64_t *__restrict__ u_out, AlAnchor *__restrict__ chained, uint32_t *__restrict__ frag_nu,
-            uint32_t *__restrict__ fb_list, uint32_t *__restrict__ fb_cnt, const uint32_t *__restrict__ tie_flag)
+            uint32_t *__restrict__ fb_list, uint32_t *__restrict__ fb_cnt, const uint32_t *__restrict__ tie_flag,
+            const uint64_t *__restrict__ okey_tmp, uint64_t *__restrict__ okey_out)
 {
 	__shared__ uint32_t s_bu[64], s_bc[64];
 	__shared__ uint64_t s_off[64];
@@ -1244,6 +1249,10 @@ k_seg_merge(const uint32_t *__restrict__ frag_list, int n_list, const uint64_t *
 		for (uint32_t t = lane; t < tot_u; t += 64) {
 			int lo = 0, hi = 64; while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_bu[mid] <= t) lo = mid; else hi = mid; }
 			u[run_u + t] = u_tmp[s_off[lo] + (t - s_bu[lo])];
+			if (okey_tmp) {   // processing key with the peak anchor's index made fragment-wide
+				const uint64_t k = okey_tmp[s_off[lo] + (t - s_bu[lo])];
+				okey_out[a_off[f] + run_u + t] = (k & 0xffffffff00000000ULL) | (uint32_t)((uint32_t)k + (uint32_t)(s_off[lo] - a_off[f]));
+			}
 		}
 		for (uint32_t t = lane; t < tot_c; t += 64) {
 			int lo = 0, hi = 64; while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_bc[mid] <= t) lo = mid; else hi = mid; }
@@ -1255,6 +1264,77 @@ k_seg_merge(const uint32_t *__restrict__ frag_list, int n_list, const uint64_t *
 	if (lane == 0) {
 		frag_nu[f] = (uint32_t)run_u;
 		if (any_tie && run_u > 64) fb_list[atomicAdd(fb_cnt, 1u)] = f;
+	}
+}
+
+// k_chain_order: the reference's order of a fragment's chains when some of them start at anchors of equal x and there are more than
+// 64 of them -- its sort (radix_sort_128x, ksort.h:116-151) is not stable, so the order among the equal ones depends on where every
+// chain stood before the sort: in the order the chain ends were processed (peak score, peak anchor: chain.c:111-114).
+// k_seg_merge left the chains in (segment, x) order with those processing keys; here a wavefront (1) sorts chain ids by processing key,
+// descending, in LDS, (2) loads the x keys in that order, (3) lane 0 restates the radix sort on the (x, id) pairs, (4) the wavefront
+// writes chain list and chained anchors in the resulting order.  More chains than the LDS tile: fb2_list (whole-fragment kernel).
+
+__global__ void __launch_bounds__(64)
+k_chain_order(const uint32_t *__restrict__ fb_list, int n_fb, const uint64_t *__restrict__ a_off, const uint32_t *__restrict__ frag_nu,
+              uint64_t *__restrict__ u_all, AlAnchor *__restrict__ chained, const uint64_t *__restrict__ okey,
+              uint64_t *__restrict__ u_tmp, AlAnchor *__restrict__ chain_tmp, uint32_t *__restrict__ fb2_list, uint32_t *__restrict__ fb2_cnt)
+{
+	extern __shared__ __align__(16) unsigned char s_raw[];
+	__shared__ uint16_t s_rs[AL_RS_SCRATCH / 2];
+	const int lane = threadIdx.x;
+	if ((int)blockIdx.x >= n_fb) return;
+	const uint32_t f = fb_list[blockIdx.x];
+	const int n_u = (int)frag_nu[f];
+	if (n_u > AL_ORD_CAP) { if (lane == 0) fb2_list[atomicAdd(fb2_cnt, 1u)] = f; return; }
+	uint64_t *const key = (uint64_t *)s_raw; uint32_t *const off = (uint32_t *)(key + AL_ORD_CAP); uint16_t *const id = (uint16_t *)(off + AL_ORD_CAP);
+	uint64_t *u = u_all + a_off[f] + f; AlAnchor *b = chained + a_off[f];
+	const uint64_t *ok = okey + a_off[f];
+	int npow2 = 1; while (npow2 < n_u) npow2 <<= 1;
+	// offsets of the chains' anchors in the merged order (running sum of the counts)
+	{
+		uint32_t run = 0;
+		for (int c0 = 0; c0 < n_u; c0 += 64) {
+			const int c = c0 + lane; const uint32_t cnt = c < n_u ? (uint32_t)u[c] : 0u;
+			uint32_t incl = cnt; for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+			if (c < n_u) off[c] = run + incl - cnt;
+			run += __shfl(incl, 63);
+		}
+	}
+	for (int c = lane; c < npow2; c += 64) { key[c] = c < n_u ? ok[c] : 0; id[c] = (uint16_t)c; }
+	__threadfence_block();
+	for (int kk = 2; kk <= npow2; kk <<= 1)                                  // (1) descending by processing key (keys are distinct: distinct peak anchors)
+		for (int j = kk >> 1; j > 0; j >>= 1) {
+			for (int i = lane; i < npow2; i += 64) {
+				const int ixj = i ^ j;
+				if (ixj > i) { const uint64_t x = key[i], y = key[ixj]; if ((x < y) == ((i & kk) == 0)) { key[i] = y; key[ixj] = x; const uint16_t t = id[i]; id[i] = id[ixj]; id[ixj] = t; } }
+			}
+			__threadfence_block();
+		}
+	for (int i = lane; i < n_u; i += 64) key[i] = b[off[id[i]]].x;           // (2) x of the chain's first anchor
+	__threadfence_block();
+	if (lane == 0) {                                                          // (3)
+		struct KI { uint64_t k; uint16_t i; };
+		struct { typedef KI E; uint64_t *k; uint16_t *i;
+		         __device__ __forceinline__ uint64_t keyof(const KI &e) const { return e.k; }
+		         __device__ __forceinline__ uint64_t key(int j) const { return k[j]; }
+		         __device__ __forceinline__ KI get(int j) const { return KI{k[j], i[j]}; }
+		         __device__ __forceinline__ void set(int j, const KI &e) { k[j] = e.k; i[j] = e.i; } } acc{key, id};
+		(void)d_rs_sort(acc, n_u, s_rs);
+	}
+	__threadfence_block();
+	// (4) new chain list and anchors into the fragment's scratch ranges, then back
+	uint64_t *ut = u_tmp + a_off[f]; AlAnchor *bt = chain_tmp + a_off[f];
+	{
+		uint32_t run = 0;
+		for (int c0 = 0; c0 < n_u; c0 += 64) {
+			const int i = c0 + lane; const int c = i < n_u ? (int)id[i] : 0; const uint64_t uc = i < n_u ? u[c] : 0; const uint32_t cnt = (uint32_t)uc;
+			uint32_t incl = cnt; for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+			if (i < n_u) { ut[i] = uc; const uint32_t o = run + incl - cnt, so = off[c]; for (uint32_t j = 0; j < cnt; ++j) bt[o + j] = b[so + j]; }
+			run += __shfl(incl, 63);
+		}
+		__threadfence_block();
+		for (int i = lane; i < n_u; i += 64) u[i] = ut[i];
+		for (uint32_t t = lane; t < run; t += 64) b[t] = bt[t];
 	}
 }
 

@@ -27,7 +27,8 @@ template <int CAP> __global__ void k_anchor_sort_blk(const uint64_t *, const uin
 __global__ void k_anchor_big_expand(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint32_t *, int, const uint64_t *, uint64_t *, uint64_t *, int, int);
 __global__ void k_anchor_big_scatter(const uint64_t *, const uint64_t *, const uint32_t *, int, const uint64_t *, const uint64_t *, AlAnchor *, uint32_t *, int);
 __global__ void k_seg_scan(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *, int, AlParams, int, int, const uint64_t *, uint32_t *, uint64_t *, uint32_t *, uint32_t *, const uint32_t *);
-__global__ void k_seg_merge(const uint32_t *, int, const uint64_t *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlAnchor *, const uint64_t *, uint64_t *, AlAnchor *, uint32_t *, uint32_t *, uint32_t *, const uint32_t *);
+__global__ void k_seg_merge(const uint32_t *, int, const uint64_t *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlAnchor *, const uint64_t *, uint64_t *, AlAnchor *, uint32_t *, uint32_t *, uint32_t *, const uint32_t *, const uint64_t *, uint64_t *);
+__global__ void k_chain_order(const uint32_t *, int, const uint64_t *, const uint32_t *, uint64_t *, AlAnchor *, const uint64_t *, uint64_t *, AlAnchor *, uint32_t *, uint32_t *);
 __global__ void k_lower_bounds(const uint32_t *, uint32_t, LbThr, uint32_t *);
 __global__ void k_collect_flagged(const uint32_t *, int, const uint32_t *, uint32_t *, uint32_t *);
 
@@ -123,7 +124,7 @@ static void ctx_release_buffers(al_ctx_t *c)
 	c->ws_u64.release(); c->tmp_u64.release(); c->frag_rep.release(); c->ws_i32.release(); c->mini.release(); c->heap_ws.release(); c->anchors.release();
 	c->chained.release(); c->match.release(); c->counters.release(); c->scan_tmp.release(); c->regs0.release(); c->regs.release(); c->reg_cnt.release();
 	c->chain_key.release(); c->chain_idx.release(); c->chain_idx2.release(); c->tie_list.release(); c->lb_buf.release(); c->tmp_u64b.release();
-	c->chain_tmp.release(); c->u_tmp.release(); c->seg_cnt.release(); c->seg_first.release(); c->vs_off.release(); c->vs_na.release(); c->vs_meta.release(); c->vs_nu.release(); c->vs_nc.release(); c->vs_tie.release(); c->seg_key.release(); c->seg_idx.release(); c->seg_ord.release(); c->fb_list.release(); c->tie_frags.release(); c->tie_sorted.release(); c->big_na.release(); c->big_off.release();
+	c->chain_tmp.release(); c->u_tmp.release(); c->okey_tmp.release(); c->fb2_list.release(); c->seg_cnt.release(); c->seg_first.release(); c->vs_off.release(); c->vs_na.release(); c->vs_meta.release(); c->vs_nu.release(); c->vs_nc.release(); c->vs_tie.release(); c->seg_key.release(); c->seg_idx.release(); c->seg_ord.release(); c->fb_list.release(); c->tie_frags.release(); c->tie_sorted.release(); c->big_na.release(); c->big_off.release();
 	c->a_off_p1.release(); c->frag_na_p1.release(); c->frag_rep_p1.release(); c->cigar.release(); c->reg_off.release(); c->cig_off.release(); c->align_ws.release(); c->seg_a.release(); c->seg_u.release();
 }
 extern "C" void al_ctx_destroy(al_ctx_t *c)
@@ -246,7 +247,7 @@ static int ensure_anchor_space(al_ctx_t *c, uint64_t total, bool keep)
 	const uint64_t nf = c->n_frag;
 	if (c->anchors.ensure(total + 1, keep, c->stream) || c->chained.ensure(total + 1, keep, c->stream) || c->u.ensure(total + nf + 2, keep, c->stream) ||
 	    c->ws_i32.ensure(total * 4 + 4, false, c->stream) || c->ws_u64.ensure(total + 1, false, c->stream) ||
-	    c->chain_tmp.ensure(total + 1, false, c->stream) || c->u_tmp.ensure(total + 1, false, c->stream)) return -1;
+	    c->chain_tmp.ensure(total + 1, false, c->stream) || c->u_tmp.ensure(total + 1, false, c->stream) || c->okey_tmp.ensure(total + 2, false, c->stream)) return -1;
 	return 0;
 }
 
@@ -307,7 +308,8 @@ static int chain_by_segments(al_ctx_t *c, const uint32_t *order, int n, bool lds
 		if (lower_bounds(c, c->seg_key.p, (uint32_t)ns, thr, 9, lb)) return -1;
 	}
 	if (ev(ST_SEG_FIND)) return -1;
-	const ChainSeg sg{c->vs_meta.p, c->vs_tie.p, c->vs_nc.p, nullptr, 0};
+	const bool keep_keys = c->opt.min_cnt >= 2;                               // a chain has >= 2 anchors: the keys of a segment fit half of its range
+	const ChainSeg sg{c->vs_meta.p, c->vs_tie.p, c->vs_nc.p, nullptr, 0, keep_keys ? c->okey_tmp.p : nullptr};
 	if (ns > 0) {
 		const uint32_t *so = c->seg_ord.p;
 		const uint32_t wave_from = lds_ok ? lb[8] : 0u;
@@ -326,13 +328,26 @@ static int chain_by_segments(al_ctx_t *c, const uint32_t *order, int n, bool lds
 	uint32_t *fb_cnt = (uint32_t *)(c->counters.p + 15);
 	AL_HIP_CHECK(hipMemsetAsync(fb_cnt, 0, 8, s));
 	hipLaunchKernelGGL(k_seg_merge, dim3(n), dim3(64), 0, s, order, n, c->seg_first.p, c->vs_off.p, c->vs_nu.p, c->vs_nc.p, c->vs_tie.p, c->u_tmp.p, c->chain_tmp.p, c->a_off.p,
-	                   c->u.p, c->chained.p, c->frag_nu.p, c->fb_list.p, fb_cnt, skip_flag);
+	                   c->u.p, c->chained.p, c->frag_nu.p, c->fb_list.p, fb_cnt, skip_flag, keep_keys ? (const uint64_t *)c->okey_tmp.p : nullptr, c->ws_u64.p);
 	uint32_t n_fb = 0;
 	AL_HIP_CHECK(hipMemcpyAsync(&n_fb, fb_cnt, 4, hipMemcpyDeviceToHost, s));
 	AL_HIP_CHECK(hipStreamSynchronize(s));
 	c->n_chain_fallback += n_fb;
+	const uint32_t *fb = c->fb_list.p;
+	if (n_fb > 0 && keep_keys) {   // order restated from the merged chains and their processing keys; only what does not fit its tile is chained again
+		const size_t lds = (size_t)AL_ORD_CAP * (8 + 4 + 2) + 64;
+		static bool attr_set = false;
+		if (!attr_set) { AL_HIP_CHECK(hipFuncSetAttribute((const void *)k_chain_order, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = true; }
+		if (c->fb2_list.ensure((size_t)n_fb + 2)) return -1;
+		AL_HIP_CHECK(hipMemsetAsync(fb_cnt, 0, 8, s));
+		hipLaunchKernelGGL(k_chain_order, dim3(n_fb), dim3(64), lds, s, c->fb_list.p, (int)n_fb, c->a_off.p, c->frag_nu.p, c->u.p, c->chained.p, (const uint64_t *)c->ws_u64.p, c->u_tmp.p, c->chain_tmp.p, c->fb2_list.p, fb_cnt);
+		AL_HIP_CHECK(hipMemcpyAsync(&n_fb, fb_cnt, 4, hipMemcpyDeviceToHost, s));
+		AL_HIP_CHECK(hipStreamSynchronize(s));
+		fb = c->fb2_list.p;
+	}
+	const ChainSeg whole{nullptr, nullptr, nullptr, nullptr, 0, nullptr};
 	if (n_fb > 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<AL_CHAIN_CAP>), dim3(n_fb), dim3(64), 0, s, c->anchors.p, c->a_off.p, c->frag_na.p, c->frag_first.p, c->rd_len.p, c->chained.p, c->u.p, c->frag_nu.p,
-	                                 c->ws_i32.p, c->ws_u64.p, c->fb_list.p, (int)n_fb, c->P, c->counters.p, ChainSeg{nullptr, nullptr, nullptr, nullptr, 0});
+	                                 c->ws_i32.p, c->ws_u64.p, fb, (int)n_fb, c->P, c->counters.p, whole);
 	if (ev(ST_SEG_MERGE)) return -1;
 	return 0;
 }
@@ -439,7 +454,7 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 		if (ev(ST_ANCHOR_HEAP)) return -1;
 	}
 	{
-		const ChainSeg nosg{nullptr, nullptr, nullptr, (const uint32_t *)c->tie_list.p, 1};
+		const ChainSeg nosg{nullptr, nullptr, nullptr, (const uint32_t *)c->tie_list.p, 1, nullptr};
 #define LFR(C, L, A, B) LCH(C, L, -1, c->a_off.p, c->frag_na.p, c->chained.p, c->u.p, c->frag_nu.p, order + (A), (int)((B) - (A)), nosg)
 #define LFRLO(C, L, LO) LCH(C, L, LO, c->a_off.p, c->frag_na.p, c->chained.p, c->u.p, c->frag_nu.p, order, (int)lb65, nosg)
 		if (lds_ok) { LFRLO(16, 64, -1); LFRLO(24, 64, 16); LFRLO(32, 64, 24); }
