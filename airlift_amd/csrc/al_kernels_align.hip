@@ -1047,6 +1047,7 @@ k_regs_select(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__
 template __global__ void k_regs_select<0>(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, WsBase, const uint32_t *, int, AlParams, uint32_t *);
 template __global__ void k_regs_select<1024>(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, WsBase, const uint32_t *, int, AlParams, uint32_t *);
 template __global__ void k_regs_select<2048>(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, WsBase, const uint32_t *, int, AlParams, uint32_t *);
+template __global__ void k_regs_select<4096>(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, WsBase, const uint32_t *, int, AlParams, uint32_t *);
 template __global__ void k_regs_select<8192>(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, WsBase, const uint32_t *, int, AlParams, uint32_t *);
 template __global__ void k_regs_select<-1>(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, WsBase, const uint32_t *, int, AlParams, uint32_t *);
 
@@ -2196,11 +2197,11 @@ int al_run_align_stage(al_ctx_t *c)
 		AL_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const uint32_t *)c->frag_nu.p, c->chain_key.p, (const uint32_t *)c->chain_idx.p, c->chain_idx2.p, nf, 0, 32, s));
 		if (c->scan_tmp.ensure(bytes + 16)) return -1;
 		AL_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(c->scan_tmp.p, bytes, (const uint32_t *)c->frag_nu.p, c->chain_key.p, (const uint32_t *)c->chain_idx.p, c->chain_idx2.p, nf, 0, 32, s));
-		uint32_t init[5] = {(uint32_t)nf, (uint32_t)nf, (uint32_t)nf, (uint32_t)nf, (uint32_t)nf}, lb[5];
-		AL_HIP_CHECK(hipMemcpyAsync(c->lb_buf.p, init, 20, hipMemcpyHostToDevice, s));
-		LbThr T; T.n = 5; T.v[0] = 5; T.v[1] = 65; T.v[2] = 1025; T.v[3] = 8193; T.v[4] = 2049; for (int i = 5; i < 16; ++i) T.v[i] = 0xffffffffu;
+		uint32_t init[6] = {(uint32_t)nf, (uint32_t)nf, (uint32_t)nf, (uint32_t)nf, (uint32_t)nf, (uint32_t)nf}, lb[6];
+		AL_HIP_CHECK(hipMemcpyAsync(c->lb_buf.p, init, 24, hipMemcpyHostToDevice, s));
+		LbThr T; T.n = 6; T.v[0] = 5; T.v[1] = 65; T.v[2] = 1025; T.v[3] = 8193; T.v[4] = 2049; T.v[5] = 4097; for (int i = 6; i < 16; ++i) T.v[i] = 0xffffffffu;
 		hipLaunchKernelGGL(k_lower_bounds, dim3((nf + 255) / 256), dim3(256), 0, s, (const uint32_t *)c->chain_key.p, (uint32_t)nf, T, c->lb_buf.p);
-		AL_HIP_CHECK(hipMemcpyAsync(lb, c->lb_buf.p, 20, hipMemcpyDeviceToHost, s));
+		AL_HIP_CHECK(hipMemcpyAsync(lb, c->lb_buf.p, 24, hipMemcpyDeviceToHost, s));
 		AL_HIP_CHECK(hipStreamSynchronize(s));
 		const uint32_t *ord = c->chain_idx2.p;
 		T.n = 1; T.v[0] = 9;      // fragments with at least nine chains may keep at least nine hits: candidates of k_regs_heavy
@@ -2209,13 +2210,15 @@ int al_run_align_stage(al_ctx_t *c)
 		if (lb[1] > lb[0]) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_select<0>), dim3(lb[1] - lb[0]), dim3(64), 0, s, c->chained.p, c->u.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, ord + lb[0], (int)(lb[1] - lb[0]), c->P, regs_n0);
 		if (lb[2] > lb[1]) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_select<1024>), dim3(lb[2] - lb[1]), dim3(256), 0, s, c->chained.p, c->u.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, ord + lb[1], (int)(lb[2] - lb[1]), c->P, regs_n0);
 		if (lb[4] > lb[2]) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_select<2048>), dim3(lb[4] - lb[2]), dim3(256), 0, s, c->chained.p, c->u.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, ord + lb[2], (int)(lb[4] - lb[2]), c->P, regs_n0);
-		if (lb[3] > lb[4]) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_select<8192>), dim3(lb[3] - lb[4]), dim3(256), 0, s, c->chained.p, c->u.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, ord + lb[4], (int)(lb[3] - lb[4]), c->P, regs_n0);
+		if (lb[5] > lb[4]) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_select<4096>), dim3(lb[5] - lb[4]), dim3(256), 0, s, c->chained.p, c->u.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, ord + lb[4], (int)(lb[5] - lb[4]), c->P, regs_n0);
+		if (lb[3] > lb[5]) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_select<8192>), dim3(lb[3] - lb[5]), dim3(256), 0, s, c->chained.p, c->u.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, ord + lb[5], (int)(lb[3] - lb[5]), c->P, regs_n0);
 		if ((uint32_t)nf > lb[3]) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_select<-1>), dim3((uint32_t)nf - lb[3]), dim3(256), 0, s, c->chained.p, c->u.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, ord + lb[3], (int)((uint32_t)nf - lb[3]), c->P, regs_n0);
 	}
 	if (regs_n0 && heavy_n > 0) {
-		const size_t lds_s = al_regs_heavy_lds(72, 1024), lds_l = al_regs_heavy_lds(200, 2048);
+		const size_t lds_t = al_regs_heavy_lds(24, 512), lds_s = al_regs_heavy_lds(72, 1024), lds_l = al_regs_heavy_lds(200, 2048);
 		static bool attr_set = false;
 		if (!attr_set) { AL_HIP_CHECK(hipFuncSetAttribute((const void *)k_regs_heavy<200, 2048>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_l)); attr_set = true; }
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_heavy<24, 512>), dim3(heavy_n), dim3(64), lds_t, s, c->chained.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, (const uint32_t *)c->chain_idx2.p + heavy_from, (int)heavy_n, c->P, c->counters.p, regs_n0);
 		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_heavy<72, 1024>), dim3(heavy_n), dim3(64), lds_s, s, c->chained.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, (const uint32_t *)c->chain_idx2.p + heavy_from, (int)heavy_n, c->P, c->counters.p, regs_n0);
 		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_heavy<200, 2048>), dim3(heavy_n), dim3(64), lds_l, s, c->chained.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, (const uint32_t *)c->chain_idx2.p + heavy_from, (int)heavy_n, c->P, c->counters.p, regs_n0);
 	}

@@ -478,6 +478,7 @@ k_anchor_sort_blk(const uint64_t *__restrict__ pos, const uint32_t *__restrict__
 		out[t] = a;
 	}
 }
+template __global__ void k_anchor_sort_blk<2048>(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, uint32_t *, const uint32_t *, int, int, int);
 template __global__ void k_anchor_sort_blk<4096>(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, uint32_t *, const uint32_t *, int, int, int);
 
 // K3 for fragments above the LDS tiles (reads inside high-copy families, the max_occ re-chain pass: up to 42 x 5000 anchors):
@@ -1167,11 +1168,14 @@ template __global__ void k_chain<AL_CHAIN_CAP>(const AlAnchor *, const uint64_t 
 // between neighbours no later anchor can reach back over the gap).  Segments that cannot hold a chain (fewer than lmin
 // anchors) are dropped.  mode 0 counts the fragment's segments, mode 1 writes them at seg_first[entry] in x order.
 // =============================================================================================
+// size class of a segment = which chaining kernel takes it (CAPL 16, 24, 32, 40, 48, 64, 80, 96, 128, wave): the segment list is
+// ordered by class only (stable), so that inside a class the segments keep their order in memory
+__device__ __forceinline__ uint32_t d_seg_class(uint32_t n) { return n <= 16 ? 0u : n <= 24 ? 1u : n <= 32 ? 2u : n <= 40 ? 3u : n <= 48 ? 4u : n <= 64 ? 5u : n <= 80 ? 6u : n <= 96 ? 7u : n <= 128 ? 8u : 9u; }
 __global__ void __launch_bounds__(64)
 k_seg_scan(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_off, const uint32_t *__restrict__ frag_na,
            const uint32_t *__restrict__ frag_first, const uint32_t *__restrict__ rd_len, const uint32_t *__restrict__ frag_list, int n_list,
            AlParams P, int lmin, int mode, const uint64_t *__restrict__ seg_first, uint32_t *__restrict__ seg_cnt,
-           uint64_t *__restrict__ vs_off, uint32_t *__restrict__ vs_na, uint32_t *__restrict__ vs_meta, const uint32_t *__restrict__ tie_flag)
+           uint64_t *__restrict__ vs_off, uint32_t *__restrict__ vs_na, uint32_t *__restrict__ vs_meta, const uint32_t *__restrict__ tie_flag, uint32_t *__restrict__ vs_cls)
 {
 	const int lane = threadIdx.x;
 	if ((int)blockIdx.x >= n_list) return;
@@ -1203,13 +1207,13 @@ k_seg_scan(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_
 			useful = i - start >= lmin;
 		}
 		const unsigned long long um = __ballot(useful);
-		if (mode && useful) { const uint64_t k = out + cnt + __popcll(um & below); vs_off[k] = base_off + (uint64_t)start; vs_na[k] = (uint32_t)(i - start); vs_meta[k] = meta; }
+		if (mode && useful) { const uint64_t k = out + cnt + __popcll(um & below); vs_off[k] = base_off + (uint64_t)start; vs_na[k] = (uint32_t)(i - start); vs_meta[k] = meta; vs_cls[k] = d_seg_class((uint32_t)(i - start)); }
 		cnt += (uint32_t)__popcll(um);
 		if (mask) open_start = base + (63 - __clzll((long long)mask));
 		prev_last = (uint64_t)(uint32_t)__shfl((int)(uint32_t)x, 63) | (uint64_t)(uint32_t)__shfl((int)(uint32_t)(x >> 32), 63) << 32;
 	}
 	if (n > 0 && n - open_start >= lmin) {
-		if (mode && lane == 0) { const uint64_t k = out + cnt; vs_off[k] = base_off + (uint64_t)open_start; vs_na[k] = (uint32_t)(n - open_start); vs_meta[k] = meta; }
+		if (mode && lane == 0) { const uint64_t k = out + cnt; vs_off[k] = base_off + (uint64_t)open_start; vs_na[k] = (uint32_t)(n - open_start); vs_meta[k] = meta; vs_cls[k] = d_seg_class((uint32_t)(n - open_start)); }
 		++cnt;
 	}
 	if (!mode && lane == 0) seg_cnt[blockIdx.x] = cnt;

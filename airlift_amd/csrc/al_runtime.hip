@@ -26,7 +26,7 @@ template <int CAPL, int LANES> __global__ void k_chain_lds(const AlAnchor *, con
 template <int CAP> __global__ void k_anchor_sort_blk(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, uint32_t *, const uint32_t *, int, int, int);
 __global__ void k_anchor_big_expand(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint32_t *, int, const uint64_t *, uint64_t *, uint64_t *, int, int);
 __global__ void k_anchor_big_scatter(const uint64_t *, const uint64_t *, const uint32_t *, int, const uint64_t *, const uint64_t *, AlAnchor *, uint32_t *, int);
-__global__ void k_seg_scan(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *, int, AlParams, int, int, const uint64_t *, uint32_t *, uint64_t *, uint32_t *, uint32_t *, const uint32_t *);
+__global__ void k_seg_scan(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *, int, AlParams, int, int, const uint64_t *, uint32_t *, uint64_t *, uint32_t *, uint32_t *, const uint32_t *, uint32_t *);
 __global__ void k_seg_merge(const uint32_t *, int, const uint64_t *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlAnchor *, const uint64_t *, uint64_t *, AlAnchor *, uint32_t *, uint32_t *, uint32_t *, const uint32_t *, const uint64_t *, uint64_t *);
 __global__ void k_chain_order(const uint32_t *, int, const uint64_t *, const uint32_t *, uint64_t *, AlAnchor *, const uint64_t *, uint64_t *, AlAnchor *, uint32_t *, uint32_t *);
 __global__ void k_lower_bounds(const uint32_t *, uint32_t, LbThr, uint32_t *);
@@ -124,7 +124,7 @@ static void ctx_release_buffers(al_ctx_t *c)
 	c->ws_u64.release(); c->tmp_u64.release(); c->frag_rep.release(); c->ws_i32.release(); c->mini.release(); c->heap_ws.release(); c->anchors.release();
 	c->chained.release(); c->match.release(); c->counters.release(); c->scan_tmp.release(); c->regs0.release(); c->regs.release(); c->reg_cnt.release();
 	c->chain_key.release(); c->chain_idx.release(); c->chain_idx2.release(); c->tie_list.release(); c->lb_buf.release(); c->tmp_u64b.release();
-	c->chain_tmp.release(); c->u_tmp.release(); c->okey_tmp.release(); c->fb2_list.release(); c->seg_cnt.release(); c->seg_first.release(); c->vs_off.release(); c->vs_na.release(); c->vs_meta.release(); c->vs_nu.release(); c->vs_nc.release(); c->vs_tie.release(); c->seg_key.release(); c->seg_idx.release(); c->seg_ord.release(); c->fb_list.release(); c->tie_frags.release(); c->tie_sorted.release(); c->big_na.release(); c->big_off.release();
+	c->chain_tmp.release(); c->u_tmp.release(); c->okey_tmp.release(); c->fb2_list.release(); c->seg_cnt.release(); c->seg_first.release(); c->vs_off.release(); c->vs_na.release(); c->vs_meta.release(); c->vs_nu.release(); c->vs_nc.release(); c->vs_tie.release(); c->vs_cls.release(); c->seg_key.release(); c->seg_idx.release(); c->seg_ord.release(); c->fb_list.release(); c->tie_frags.release(); c->tie_sorted.release(); c->big_na.release(); c->big_off.release();
 	c->a_off_p1.release(); c->frag_na_p1.release(); c->frag_rep_p1.release(); c->cigar.release(); c->reg_off.release(); c->cig_off.release(); c->align_ws.release(); c->seg_a.release(); c->seg_u.release();
 }
 extern "C" void al_ctx_destroy(al_ctx_t *c)
@@ -288,7 +288,7 @@ static int chain_by_segments(al_ctx_t *c, const uint32_t *order, int n, bool lds
 	{ const int per = c->mi->k + 1, need = (c->opt.min_chain_score + per - 1) / per; if (need > lmin) lmin = need; }
 	if (c->seg_cnt.ensure((size_t)n + 2) || c->seg_first.ensure((size_t)n + 2)) return -1;
 	hipLaunchKernelGGL(k_seg_scan, dim3(n), dim3(64), 0, s, c->anchors.p, c->a_off.p, c->frag_na.p, c->frag_first.p, c->rd_len.p, order, n, c->P, lmin, 0,
-	                   (const uint64_t *)nullptr, c->seg_cnt.p, (uint64_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, skip_flag);
+	                   (const uint64_t *)nullptr, c->seg_cnt.p, (uint64_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, skip_flag, (uint32_t *)nullptr);
 	AL_HIP_CHECK(hipMemsetAsync(c->seg_cnt.p + n, 0, 4, s));
 	if (scan_u32_to_u64(c, c->seg_cnt.p, c->seg_first.p, n)) return -1;
 	uint64_t ns64 = 0;
@@ -297,14 +297,19 @@ static int chain_by_segments(al_ctx_t *c, const uint32_t *order, int n, bool lds
 	if (ns64 >= (1ULL << 31)) { fprintf(stderr, "[airlift] %llu chaining segments in one batch: upload fewer fragments\n", (unsigned long long)ns64); al_nomem_flag() = true; return -1; }
 	const int ns = (int)ns64;
 	if (c->vs_off.ensure((size_t)ns + 1) || c->vs_na.ensure((size_t)ns + 1) || c->vs_meta.ensure((size_t)ns + 1) || c->vs_nu.ensure((size_t)ns + 1) || c->vs_nc.ensure((size_t)ns + 1) ||
-	    c->vs_tie.ensure((size_t)ns + 1) || c->seg_key.ensure((size_t)ns + 1) || c->seg_idx.ensure((size_t)ns + 1) || c->seg_ord.ensure((size_t)ns + 1) || c->fb_list.ensure((size_t)n + 2)) return -1;
+	    c->vs_tie.ensure((size_t)ns + 1) || c->vs_cls.ensure((size_t)ns + 1) || c->seg_key.ensure((size_t)ns + 1) || c->seg_idx.ensure((size_t)ns + 1) || c->seg_ord.ensure((size_t)ns + 1) || c->fb_list.ensure((size_t)n + 2)) return -1;
 	hipLaunchKernelGGL(k_seg_scan, dim3(n), dim3(64), 0, s, c->anchors.p, c->a_off.p, c->frag_na.p, c->frag_first.p, c->rd_len.p, order, n, c->P, lmin, 1,
-	                   (const uint64_t *)c->seg_first.p, (uint32_t *)nullptr, c->vs_off.p, c->vs_na.p, c->vs_meta.p, skip_flag);
+	                   (const uint64_t *)c->seg_first.p, (uint32_t *)nullptr, c->vs_off.p, c->vs_na.p, c->vs_meta.p, skip_flag, c->vs_cls.p);
 	uint32_t lb[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 	if (ns > 0) {
 		hipLaunchKernelGGL(k_iota_u32, dim3((ns + 255) / 256), dim3(256), 0, s, c->seg_idx.p, (uint32_t)ns);
-		if (sort_u32_pairs(c, c->vs_na.p, c->seg_key.p, c->seg_idx.p, c->seg_ord.p, ns)) return -1;
-		static const uint32_t thr[9] = {17, 25, 33, 41, 49, 65, 81, 97, 129};
+		{   // stable sort by size class only (4 bits: one radix pass)
+			size_t bytes = 0;
+			AL_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const uint32_t *)c->vs_cls.p, c->seg_key.p, (const uint32_t *)c->seg_idx.p, c->seg_ord.p, ns, 0, 4, s));
+			if (c->scan_tmp.ensure(bytes + 16)) return -1;
+			AL_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(c->scan_tmp.p, bytes, (const uint32_t *)c->vs_cls.p, c->seg_key.p, (const uint32_t *)c->seg_idx.p, c->seg_ord.p, ns, 0, 4, s));
+		}
+		static const uint32_t thr[9] = {1, 2, 3, 4, 5, 6, 7, 8, 9};
 		if (lower_bounds(c, c->seg_key.p, (uint32_t)ns, thr, 9, lb)) return -1;
 	}
 	if (ev(ST_SEG_FIND)) return -1;
@@ -389,16 +394,16 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 	if (first) hipLaunchKernelGGL(k_iota_u32, dim3((nl + 255) / 256), dim3(256), 0, s, c->chain_idx.p, (uint32_t)nl);
 	if (sort_u32_pairs(c, first ? c->frag_na.p : c->tmp_u32.p, c->chain_key.p, first ? c->chain_idx.p : list, c->chain_idx2.p, nl)) return -1;
 	const uint32_t *order = c->chain_idx2.p;
-	uint32_t lb[6];
+	uint32_t lb[7];
 	{   // AL_TEST_SORT_BLK / AL_TEST_SORT_BIG (tests): smallest anchor count that goes to the block / device-wide sort
 		static const char *e1 = getenv("AL_TEST_SORT_BLK"), *e2 = getenv("AL_TEST_SORT_BIG");
 		uint32_t t_blk = e1 ? (uint32_t)atoi(e1) : 1025u, t_big = e2 ? (uint32_t)atoi(e2) : 4097u;
 		if (t_blk < 65u) t_blk = 65u; if (t_blk > 1025u) t_blk = 1025u; if (t_big < t_blk) t_big = t_blk; if (t_big > 4097u) t_big = 4097u;
 		{ int rb = 1; while ((1ULL << rb) < c->mi->seq.size()) ++rb; if (33 + rb + 16 > 64) t_big = t_blk; }   // compact keys of the block sort: strand | contig | position | list in 64 bits
-		const uint32_t thr[6] = {65, 81, 97, 129, t_blk, t_big};
-		if (lower_bounds(c, c->chain_key.p, (uint32_t)nl, thr, 6, lb)) return -1;
+		const uint32_t thr[7] = {65, 81, 97, 129, t_blk, t_big, std::min(std::max(t_blk, 2049u), t_big)};
+		if (lower_bounds(c, c->chain_key.p, (uint32_t)nl, thr, 7, lb)) return -1;
 	}
-	const uint32_t lb65 = lb[0], lb81 = lb[1], lb97 = lb[2], lb129 = lb[3], lb1025 = lb[4], lb4097 = lb[5];
+	const uint32_t lb65 = lb[0], lb81 = lb[1], lb97 = lb[2], lb129 = lb[3], lb1025 = lb[4], lb4097 = lb[5], lb2049 = lb[6];
 	if (ev(ST_ORDER)) return -1;
 	{
 		if (c->tie_list.ensure((size_t)c->n_frag + 2)) return -1;         // one flag per fragment id
@@ -411,8 +416,10 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 		                                      c->a_off.p, c->anchors.p, c->tie_list.p, tie_cnt, order + lb65, (int)(lb1025 - lb65), c->counters.p, c->mi->k);
 		if (ev(ST_ANCHOR_SORT)) return -1;
 		int rid_bits = 1; while ((1ULL << rid_bits) < c->mi->seq.size()) ++rid_bits;
-		if (lb4097 > lb1025) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_anchor_sort_blk<4096>), dim3(lb4097 - lb1025), dim3(256), 0, s, c->di.pos, c->frag_first.p, c->rd_len.p, c->mini_off.p, c->match.p, c->frag_nm.p, c->frag_na.p,
-		                                        c->a_off.p, c->anchors.p, c->tie_list.p, order + lb1025, (int)(lb4097 - lb1025), c->mi->k, rid_bits);
+		if (lb2049 > lb1025) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_anchor_sort_blk<2048>), dim3(lb2049 - lb1025), dim3(256), 0, s, c->di.pos, c->frag_first.p, c->rd_len.p, c->mini_off.p, c->match.p, c->frag_nm.p, c->frag_na.p,
+		                                        c->a_off.p, c->anchors.p, c->tie_list.p, order + lb1025, (int)(lb2049 - lb1025), c->mi->k, rid_bits);
+		if (lb4097 > lb2049) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_anchor_sort_blk<4096>), dim3(lb4097 - lb2049), dim3(256), 0, s, c->di.pos, c->frag_first.p, c->rd_len.p, c->mini_off.p, c->match.p, c->frag_nm.p, c->frag_na.p,
+		                                        c->a_off.p, c->anchors.p, c->tie_list.p, order + lb2049, (int)(lb4097 - lb2049), c->mi->k, rid_bits);
 		if (ev(ST_ANCHOR_SORT_BLK)) return -1;
 		// above the LDS tiles: composite-key device radix sort, a chunk of fragments at a time so that rank + key bits fit 64
 		const int kb = 33 + rid_bits;
