@@ -383,8 +383,8 @@ k_anchor_sort(const uint64_t *__restrict__ pos, const uint32_t *__restrict__ fra
 // indexes to the device-wide sort), the match records of the lists sit in LDS next to it, every thread issues its position loads
 // back to back, then a bitonic network across the block; y is rebuilt from the list's match record when the anchors are
 // written out.  Equal x -> exact heap merge, as in the other sort kernels.
-template <int CAP>
-__global__ void __launch_bounds__(256)
+template <int CAP, int NT>     // NT threads; the key tile (8 CAP bytes) is dynamic LDS: 2048 / 4096 with 256 threads, 8192 with 512, 16384 with 1024 (one block per CU)
+__global__ void __launch_bounds__(NT)
 k_anchor_sort_blk(const uint64_t *__restrict__ pos, const uint32_t *__restrict__ frag_first, const uint32_t *__restrict__ rd_len,
                   const uint64_t *__restrict__ mini_off, const AlMatch *__restrict__ match,
                   const uint32_t *__restrict__ frag_nm, const uint32_t *__restrict__ frag_na, const uint64_t *__restrict__ a_off,
@@ -392,11 +392,12 @@ k_anchor_sort_blk(const uint64_t *__restrict__ pos, const uint32_t *__restrict__
                   const uint32_t *__restrict__ frag_list, int n_list, int mini_span, int rid_bits)
 {
 	constexpr int MCAP = 1024;                          // occurrence lists per fragment (query minimizers that passed the filter)
-	constexpr int PER = CAP / 256;
-	__shared__ uint64_t sx[CAP];
+	constexpr int PER = CAP / NT;
+	extern __shared__ __align__(16) unsigned char s_dyn[];
+	uint64_t *const sx = (uint64_t *)s_dyn;
 	__shared__ uint32_t pre[MCAP + 1];
 	__shared__ uint32_t m_off[MCAP], m_fl[MCAP], m_qp[MCAP];   // match records: off_lo, flags, q_pos
-	__shared__ uint32_t s_part[256];
+	__shared__ uint32_t s_part[NT];
 	__shared__ int s_flag;
 	const int tid = threadIdx.x;
 	if ((int)blockIdx.x >= n_list) return;
@@ -409,18 +410,19 @@ k_anchor_sort_blk(const uint64_t *__restrict__ pos, const uint32_t *__restrict__
 	const AlMatch *m = match + mini_off[r0];
 	AlAnchor *out = anchors + a_off[f];
 	if (tid == 0) s_flag = 0;
-	{   // exclusive prefix sums of the list lengths: four lists per thread, block scan of the partial sums
-		uint32_t v[4], sum = 0;
-		for (int j = 0; j < 4; ++j) {
-			const uint32_t i = (uint32_t)tid * 4 + j; v[j] = 0;
+	{   // exclusive prefix sums of the list lengths: LPT lists per thread, block scan of the partial sums
+		constexpr int LPT = (MCAP + NT - 1) / NT;
+		uint32_t v[LPT], sum = 0;
+		for (int j = 0; j < LPT; ++j) {
+			const uint32_t i = (uint32_t)tid * LPT + j; v[j] = 0;
 			if (i < n_m) { const AlMatch mm = m[i]; v[j] = mm.n; m_off[i] = mm.off_lo; m_fl[i] = mm.flags; m_qp[i] = mm.q_pos; }
 			sum += v[j];
 		}
 		s_part[tid] = sum;
 		__syncthreads();
-		for (int d = 1; d < 256; d <<= 1) { const uint32_t t = tid >= d ? s_part[tid - d] : 0u; __syncthreads(); s_part[tid] += t; __syncthreads(); }
+		for (int d = 1; d < NT; d <<= 1) { const uint32_t t = tid >= d ? s_part[tid - d] : 0u; __syncthreads(); s_part[tid] += t; __syncthreads(); }
 		uint32_t run = s_part[tid] - sum;
-		for (int j = 0; j < 4; ++j) { const uint32_t i = (uint32_t)tid * 4 + j; if (i <= n_m) pre[i] = run; run += v[j]; }
+		for (int j = 0; j < LPT; ++j) { const uint32_t i = (uint32_t)tid * LPT + j; if (i <= n_m) pre[i] = run; run += v[j]; }
 	}
 	__syncthreads();
 	int npow2 = 1; while ((uint32_t)npow2 < n) npow2 <<= 1;
@@ -429,7 +431,7 @@ k_anchor_sort_blk(const uint64_t *__restrict__ pos, const uint32_t *__restrict__
 		uint64_t rr[PER]; uint32_t mi[PER];
 #pragma unroll
 		for (int j = 0; j < PER; ++j) {
-			const uint32_t t = (uint32_t)tid + (uint32_t)j * 256u; rr[j] = 0; mi[j] = 0;
+			const uint32_t t = (uint32_t)tid + (uint32_t)j * (uint32_t)NT; rr[j] = 0; mi[j] = 0;
 			if (t < n) {
 				uint32_t lo = 0, hi = n_m;                                   // last list with pre[list] <= t
 				while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (pre[mid] <= t) lo = mid; else hi = mid; }
@@ -439,7 +441,7 @@ k_anchor_sort_blk(const uint64_t *__restrict__ pos, const uint32_t *__restrict__
 		}
 #pragma unroll
 		for (int j = 0; j < PER; ++j) {
-			const uint32_t t = (uint32_t)tid + (uint32_t)j * 256u;
+			const uint32_t t = (uint32_t)tid + (uint32_t)j * (uint32_t)NT;
 			if (t < (uint32_t)npow2) {
 				uint64_t key = UINT64_MAX;
 				if (t < n) {
@@ -453,7 +455,7 @@ k_anchor_sort_blk(const uint64_t *__restrict__ pos, const uint32_t *__restrict__
 	__syncthreads();
 	for (int kk = 2; kk <= npow2; kk <<= 1)
 		for (int j = kk >> 1; j > 0; j >>= 1) {
-			for (int i = tid; i < npow2; i += 256) {
+			for (int i = tid; i < npow2; i += NT) {
 				const int ixj = i ^ j;
 				if (ixj > i) {
 					const uint64_t a = sx[i], b = sx[ixj];
@@ -463,12 +465,12 @@ k_anchor_sort_blk(const uint64_t *__restrict__ pos, const uint32_t *__restrict__
 			__syncthreads();
 		}
 	int tie = 0;
-	for (uint32_t t = tid; t + 1 < n; t += 256) if ((sx[t] >> 16) == (sx[t + 1] >> 16)) tie = 1;
+	for (uint32_t t = tid; t + 1 < n; t += NT) if ((sx[t] >> 16) == (sx[t + 1] >> 16)) tie = 1;
 	if (tie) s_flag = 1;
 	__syncthreads();
 	if (s_flag) { if (tid == 0) tie_list[f] = 1u; return; }                // merged by k_anchor_heap
 	const uint64_t lowmask = (1ULL << sb) - 1;
-	for (uint32_t t = tid; t < n; t += 256) {
+	for (uint32_t t = tid; t < n; t += NT) {
 		const uint64_t key = sx[t]; const uint32_t i = (uint32_t)key & 0xffffu; const uint64_t kx = key >> 16;
 		const uint32_t qp = m_qp[i], fl = m_fl[i], span = (uint32_t)mini_span;
 		AlAnchor a; a.x = (kx & lowmask) | (kx >> sb & 1) << 63;
@@ -478,8 +480,8 @@ k_anchor_sort_blk(const uint64_t *__restrict__ pos, const uint32_t *__restrict__
 		out[t] = a;
 	}
 }
-template __global__ void k_anchor_sort_blk<2048>(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, uint32_t *, const uint32_t *, int, int, int);
-template __global__ void k_anchor_sort_blk<4096>(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, uint32_t *, const uint32_t *, int, int, int);
+#define INST_SORT_BLK(C, T) template __global__ void k_anchor_sort_blk<C, T>(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, uint32_t *, const uint32_t *, int, int, int);
+INST_SORT_BLK(2048, 256) INST_SORT_BLK(4096, 256) INST_SORT_BLK(8192, 512) INST_SORT_BLK(16384, 1024)
 
 // K3 for fragments above the LDS tiles (reads inside high-copy families, the max_occ re-chain pass: up to 42 x 5000 anchors):
 // their anchors are expanded unsorted with a composite key  (rank of the fragment in the list) << key_bits | strand | contig |

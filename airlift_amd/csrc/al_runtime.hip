@@ -23,7 +23,7 @@ __global__ void k_anchor_sort_small(const uint64_t *, const uint32_t *, const ui
 template <int HCAP, int LANES> __global__ void k_anchor_heap(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, AlAnchor *, const uint32_t *, const uint32_t *, int, int, unsigned long long *, int);
 template <int CAP> __global__ void k_chain(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, AlAnchor *, uint64_t *, uint32_t *, int32_t *, uint64_t *, const uint32_t *, int, AlParams, unsigned long long *, ChainSeg);
 template <int CAPL, int LANES> __global__ void k_chain_lds(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, AlAnchor *, uint64_t *, uint32_t *, uint64_t *, const uint32_t *, int, int, AlParams, unsigned long long *, ChainSeg);
-template <int CAP> __global__ void k_anchor_sort_blk(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, uint32_t *, const uint32_t *, int, int, int);
+template <int CAP, int NT> __global__ void k_anchor_sort_blk(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, uint32_t *, const uint32_t *, int, int, int);
 __global__ void k_anchor_big_expand(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint32_t *, int, const uint64_t *, uint64_t *, uint64_t *, int, int);
 __global__ void k_anchor_big_scatter(const uint64_t *, const uint64_t *, const uint32_t *, int, const uint64_t *, const uint64_t *, AlAnchor *, uint32_t *, int);
 __global__ void k_seg_scan(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *, int, AlParams, int, int, const uint64_t *, uint32_t *, uint64_t *, uint32_t *, uint32_t *, const uint32_t *, uint32_t *);
@@ -394,16 +394,16 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 	if (first) hipLaunchKernelGGL(k_iota_u32, dim3((nl + 255) / 256), dim3(256), 0, s, c->chain_idx.p, (uint32_t)nl);
 	if (sort_u32_pairs(c, first ? c->frag_na.p : c->tmp_u32.p, c->chain_key.p, first ? c->chain_idx.p : list, c->chain_idx2.p, nl)) return -1;
 	const uint32_t *order = c->chain_idx2.p;
-	uint32_t lb[7];
+	uint32_t lb[9];
 	{   // AL_TEST_SORT_BLK / AL_TEST_SORT_BIG (tests): smallest anchor count that goes to the block / device-wide sort
 		static const char *e1 = getenv("AL_TEST_SORT_BLK"), *e2 = getenv("AL_TEST_SORT_BIG");
-		uint32_t t_blk = e1 ? (uint32_t)atoi(e1) : 1025u, t_big = e2 ? (uint32_t)atoi(e2) : 4097u;
-		if (t_blk < 65u) t_blk = 65u; if (t_blk > 1025u) t_blk = 1025u; if (t_big < t_blk) t_big = t_blk; if (t_big > 4097u) t_big = 4097u;
+		uint32_t t_blk = e1 ? (uint32_t)atoi(e1) : 1025u, t_big = e2 ? (uint32_t)atoi(e2) : 16385u;
+		if (t_blk < 65u) t_blk = 65u; if (t_blk > 1025u) t_blk = 1025u; if (t_big < t_blk) t_big = t_blk; if (t_big > 16385u) t_big = 16385u;
 		{ int rb = 1; while ((1ULL << rb) < c->mi->seq.size()) ++rb; if (33 + rb + 16 > 64) t_big = t_blk; }   // compact keys of the block sort: strand | contig | position | list in 64 bits
-		const uint32_t thr[7] = {65, 81, 97, 129, t_blk, t_big, std::min(std::max(t_blk, 2049u), t_big)};
-		if (lower_bounds(c, c->chain_key.p, (uint32_t)nl, thr, 7, lb)) return -1;
+		const uint32_t thr[9] = {65, 81, 97, 129, t_blk, t_big, std::min(std::max(t_blk, 2049u), t_big), std::min(std::max(t_blk, 4097u), t_big), std::min(std::max(t_blk, 8193u), t_big)};
+		if (lower_bounds(c, c->chain_key.p, (uint32_t)nl, thr, 9, lb)) return -1;
 	}
-	const uint32_t lb65 = lb[0], lb81 = lb[1], lb97 = lb[2], lb129 = lb[3], lb1025 = lb[4], lb4097 = lb[5], lb2049 = lb[6];
+	const uint32_t lb65 = lb[0], lb81 = lb[1], lb97 = lb[2], lb129 = lb[3], lb1025 = lb[4], lb_big = lb[5], lb2049 = lb[6], lb4097 = lb[7], lb8193 = lb[8];
 	if (ev(ST_ORDER)) return -1;
 	{
 		if (c->tie_list.ensure((size_t)c->n_frag + 2)) return -1;         // one flag per fragment id
@@ -416,15 +416,23 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 		                                      c->a_off.p, c->anchors.p, c->tie_list.p, tie_cnt, order + lb65, (int)(lb1025 - lb65), c->counters.p, c->mi->k);
 		if (ev(ST_ANCHOR_SORT)) return -1;
 		int rid_bits = 1; while ((1ULL << rid_bits) < c->mi->seq.size()) ++rid_bits;
-		if (lb2049 > lb1025) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_anchor_sort_blk<2048>), dim3(lb2049 - lb1025), dim3(256), 0, s, c->di.pos, c->frag_first.p, c->rd_len.p, c->mini_off.p, c->match.p, c->frag_nm.p, c->frag_na.p,
-		                                        c->a_off.p, c->anchors.p, c->tie_list.p, order + lb1025, (int)(lb2049 - lb1025), c->mi->k, rid_bits);
-		if (lb4097 > lb2049) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_anchor_sort_blk<4096>), dim3(lb4097 - lb2049), dim3(256), 0, s, c->di.pos, c->frag_first.p, c->rd_len.p, c->mini_off.p, c->match.p, c->frag_nm.p, c->frag_na.p,
-		                                        c->a_off.p, c->anchors.p, c->tie_list.p, order + lb2049, (int)(lb4097 - lb2049), c->mi->k, rid_bits);
+		{
+#define LBLK(C, T, A, B) do { if ((B) > (A)) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_anchor_sort_blk<C, T>), dim3((B) - (A)), dim3(T), (size_t)C * 8, s, c->di.pos, c->frag_first.p, c->rd_len.p, c->mini_off.p, c->match.p, c->frag_nm.p, c->frag_na.p, \
+		                                        c->a_off.p, c->anchors.p, c->tie_list.p, order + (A), (int)((B) - (A)), c->mi->k, rid_bits); } while (0)
+			static bool attr_set = false;
+			if (!attr_set) {
+				AL_HIP_CHECK(hipFuncSetAttribute((const void *)k_anchor_sort_blk<8192, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8));
+				AL_HIP_CHECK(hipFuncSetAttribute((const void *)k_anchor_sort_blk<16384, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8));
+				attr_set = true;
+			}
+			LBLK(2048, 256, lb1025, lb2049); LBLK(4096, 256, lb2049, lb4097); LBLK(8192, 512, lb4097, lb8193); LBLK(16384, 1024, lb8193, lb_big);
+#undef LBLK
+		}
 		if (ev(ST_ANCHOR_SORT_BLK)) return -1;
 		// above the LDS tiles: composite-key device radix sort, a chunk of fragments at a time so that rank + key bits fit 64
 		const int kb = 33 + rid_bits;
 		const uint32_t chunk_max = kb >= 64 ? 1u : (64 - kb >= 31 ? 0x7fffffffu : (1u << (64 - kb)));
-		for (uint32_t b0 = lb4097; b0 < (uint32_t)nl; ) {
+		for (uint32_t b0 = lb_big; b0 < (uint32_t)nl; ) {
 			const uint32_t nb = std::min<uint32_t>((uint32_t)nl - b0, chunk_max);
 			if (c->big_na.ensure(nb + 2) || c->big_off.ensure(nb + 2)) return -1;
 			hipLaunchKernelGGL(k_gather_na, dim3((nb + 256) / 256), dim3(256), 0, s, c->frag_na.p, order + b0, (int)nb, c->big_na.p);
