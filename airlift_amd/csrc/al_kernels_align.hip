@@ -795,11 +795,16 @@ struct WsBase {
 	AlReg *regs0, *mregs, *rtmp; AlAnchor *aux128, *seg_a; uint64_t *aux64, *seg_u; int *auxi;
 	const uint64_t *nu_off; const uint32_t *frag_nu; const uint64_t *a_off; uint32_t *reg_cnt /* per read */; uint32_t *seg_na /* per read */;
 	RegExt *rext; uint32_t *seg_fast;   // per read: 1 = the read's single hit has its ungapped-core coordinates in rext already (k_regs fast path)
+	// Room for the per-mate hits: 4 n + 4 per mate, n = hits kept by chain_post (cap2 / b2_off, set once k_regs_select has run; a
+	// fragment it did not handle: n = its chains).  nullptr while the selection kernels run (they do not touch the per-mate arrays).
+	const uint32_t *cap2; const uint64_t *b2_off;
 };
 __device__ __forceinline__ void d_frag_ws(const WsBase &W, uint32_t f, FragWs &o)
 {
 	const uint64_t Pf = W.nu_off[f]; const uint32_t nu = W.frag_nu[f]; const uint64_t B = 4 * Pf + 4ULL * f; const int c = 4 * (int)nu + 4;
-	o.cap = c; o.regs0 = W.regs0 + Pf; o.mreg[0] = W.mregs + 2 * B; o.mreg[1] = o.mreg[0] + c; o.rtmp = W.rtmp + B;
+	o.regs0 = W.regs0 + Pf;
+	if (W.b2_off) { const int c2 = (int)W.cap2[f]; const uint64_t B2 = W.b2_off[f]; o.cap = c2; o.mreg[0] = W.mregs + 2 * B2; o.mreg[1] = o.mreg[0] + c2; o.rtmp = W.rtmp + B2; }
+	else { o.cap = c; o.mreg[0] = nullptr; o.mreg[1] = nullptr; o.rtmp = nullptr; }
 	o.aux128 = W.aux128 + B; o.aux64 = W.aux64 + B; o.auxi = W.auxi + 2 * B;
 	o.seg_u[0] = W.seg_u + 2 * Pf; o.seg_u[1] = o.seg_u[0] + nu;
 	o.seg_a[0] = W.seg_a + W.a_off[f]; o.seg_a[1] = nullptr;
@@ -941,6 +946,10 @@ k_regs_select(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__
 	const int max_dist = n_segs == 2 ? ql0 + ql1 + max_gap_ref : 0;
 	int k = 0, slot_base = 0, n_2nd = 0; bool overflow = false;
 	const unsigned long long below = (1ULL << lane) - 1ULL;
+	__shared__ uint32_t s_cov[64];                                           // query positions covered by the primaries so far (fragments of up to 2048 bases)
+	const bool use_cov = qlen <= 2048;
+	s_cov[lane] = 0;
+	__threadfence_block();
 	for (int p0 = 0; p0 < n_u && !overflow; p0 += 64) {
 		const int p = p0 + lane; const bool v = p < n_u;
 		uint64_t key = 0; int c = 0;
@@ -963,8 +972,19 @@ k_regs_select(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__
 				int n_cov = 0;
 				for (int j = 0; j < k; ++j) { const int sj = S.qs[j], ej = S.qe[j]; if (!(ej <= qs || sj >= qe)) ++n_cov; }
 				if (n_cov > 0) {
-					// uncov_len (hit.c:133-141): the part of [qs, qe) outside the union of the clipped overlapping intervals
-					int x = qs, uncov = 0;
+					// uncov_len (hit.c:133-141): the part of [qs, qe) outside the union of the clipped overlapping intervals = outside the
+					// union of ALL primaries (the others do not reach into [qs, qe)): a bitmap of the query positions the primaries cover
+					int uncov = 0;
+					if (use_cov) {
+						int covered = 0;
+						for (int w = qs >> 5; w <= (qe - 1) >> 5; ++w) {
+							const int lo = qs > (w << 5) ? qs - (w << 5) : 0, hi = qe < ((w + 1) << 5) ? qe - (w << 5) : 32;
+							const uint32_t m = (hi >= 32 ? 0xffffffffu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u);
+							covered += __popc(s_cov[w] & m);
+						}
+						uncov = (qe - qs) - covered;
+					} else {
+					int x = qs;
 					for (;;) {
 						int best = 0x7fffffff;
 						for (int j = 0; j < k; ++j) { int sj = S.qs[j], ej = S.qe[j]; if (ej <= qs || sj >= qe) continue; if (sj < qs) sj = qs; if (ej > qe) ej = qe; if (ej > x && sj < best) best = sj; }
@@ -974,6 +994,7 @@ k_regs_select(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__
 						while (grew) { grew = false; for (int j = 0; j < k; ++j) { int sj = S.qs[j], ej = S.qe[j]; if (ej <= qs || sj >= qe) continue; if (sj < qs) sj = qs; if (ej > qe) ej = qe; if (sj <= x && ej > x) { x = ej; grew = true; } } }
 					}
 					if (qe > x) uncov += qe - x;
+					}
 					for (int j = 0; j < k; ++j) {
 						const int sj = S.qs[j], ej = S.qe[j];
 						if (ej <= qs || sj >= qe) continue;
@@ -1024,6 +1045,10 @@ k_regs_select(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__
 				else if (lane == first) {
 					S.qs[k] = qs; S.qe[k] = qe; S.score[k] = score; S.cnt[k] = cnt; S.as[k] = as; S.rs[k] = rs; S.re[k] = re; S.ridrev[k] = rid << 1 | rev;
 					S.subsc[k] = 0; S.nsub[k] = 0; S.slot[k] = slot_base; S.hash[k] = hsh;
+					if (use_cov && qe > qs) for (int w = qs >> 5; w <= (qe - 1) >> 5; ++w) {
+						const int lo = qs > (w << 5) ? qs - (w << 5) : 0, hi = qe < ((w + 1) << 5) ? qe - (w << 5) : 32;
+						s_cov[w] |= (hi >= 32 ? 0xffffffffu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u);
+					}
 				}
 				if (!overflow) { ++k; ++slot_base; }
 			}
@@ -1050,6 +1075,16 @@ template __global__ void k_regs_select<2048>(const AlAnchor *, const uint64_t *,
 template __global__ void k_regs_select<4096>(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, WsBase, const uint32_t *, int, AlParams, uint32_t *);
 template __global__ void k_regs_select<8192>(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, WsBase, const uint32_t *, int, AlParams, uint32_t *);
 template __global__ void k_regs_select<-1>(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, WsBase, const uint32_t *, int, AlParams, uint32_t *);
+
+__global__ void __launch_bounds__(256)
+k_regs_cap2(const uint32_t *__restrict__ frag_nu, const uint32_t *__restrict__ regs_n0, int n_frag, uint32_t *__restrict__ cap2)
+{
+	const int f = blockIdx.x * blockDim.x + threadIdx.x;
+	if (f > n_frag) return;
+	if (f == n_frag) { cap2[f] = 0; return; }
+	const uint32_t n0 = regs_n0 ? regs_n0[f] : AL_REGS_UNSET;
+	cap2[f] = 4u * ((n0 == AL_REGS_UNSET || AL_REGS_BAIL(n0) || n0 == AL_REGS_DONE) ? frag_nu[f] : n0) + 4u;
+}
 
 static size_t al_regs_heavy_lds(int RC, int AC) { return (size_t)3 * RC * sizeof(AlReg) + ((size_t)2 * AC + RC + AL_RS_SCRATCH / 16 + 2) * sizeof(AlAnchor) + (size_t)3 * RC * 8 + ((size_t)2 * RC + 4 + RC + 1 + RC) * 4 + 8 * 4 + 64; }
 
@@ -2124,7 +2159,7 @@ struct AlignState {            // lives in al_ctx_s::align_state (opaque there)
 	DevBuf<AlAnchor> aux128, seg_a;
 	DevBuf<uint64_t> aux64, seg_u, nu_off, out_off;
 	DevBuf<int32_t> auxi;
-	DevBuf<uint32_t> reg_cnt, seg_na, arena, seg_fast, regs_n0;
+	DevBuf<uint32_t> reg_cnt, seg_na, arena, seg_fast, regs_n0, cap2; DevBuf<uint64_t> b2_off;
 	uint64_t arena_scale = 1;       // doubled by al_align_grow_arena() when a batch's long CIGARs overflowed the arena
 	DevBuf<uint8_t> gws, long_state;
 	DevBuf<float> logtab;
@@ -2151,7 +2186,7 @@ void al_align_state_free(al_ctx_t *c)
 	if (it == g_states.end()) return;
 	AlignState *s = it->second;
 	s->regs0.release(); s->mregs.release(); s->rtmp.release(); s->out.release(); s->aux128.release(); s->seg_a.release(); s->aux64.release(); s->seg_u.release();
-	s->nu_off.release(); s->out_off.release(); s->auxi.release(); s->reg_cnt.release(); s->seg_na.release(); s->arena.release(); s->gws.release(); s->long_state.release(); s->logtab.release(); s->dbgbuf.release(); s->hist.release(); s->jobs.release(); s->outs.release(); s->rext.release(); s->seg_fast.release(); s->regs_n0.release();
+	s->nu_off.release(); s->out_off.release(); s->auxi.release(); s->reg_cnt.release(); s->seg_na.release(); s->arena.release(); s->gws.release(); s->long_state.release(); s->logtab.release(); s->dbgbuf.release(); s->hist.release(); s->jobs.release(); s->outs.release(); s->rext.release(); s->seg_fast.release(); s->regs_n0.release(); s->cap2.release(); s->b2_off.release();
 	s->job_off.release(); s->sc_off.release(); s->sc_ws.release(); s->n_jobs.release(); s->n_sc.release(); s->job_key.release(); s->job_key2.release(); s->job_idx.release(); s->job_idx2.release(); s->frag_slow.release(); s->slow_list.release(); s->sort_tmp.release();
 	delete s; g_states.erase(it);
 }
@@ -2181,13 +2216,13 @@ int al_run_align_stage(al_ctx_t *c)
 	AL_HIP_CHECK(hipMemcpyAsync(&nu_total, A->nu_off.p + nf, 8, hipMemcpyDeviceToHost, s));
 	AL_HIP_CHECK(hipStreamSynchronize(s));
 	const uint64_t Btot = 4 * nu_total + 4ULL * nf + 8;
-	if (A->regs0.ensure(nu_total + 1) || A->mregs.ensure(2 * Btot) || A->rtmp.ensure(Btot) || A->aux128.ensure(Btot) || A->aux64.ensure(Btot) || A->auxi.ensure(2 * Btot) ||
-	    A->seg_u.ensure(2 * nu_total + 2) || A->reg_cnt.ensure(nr + 1) || A->seg_na.ensure(nr + 1) || A->out_off.ensure(nr + 2) || A->rext.ensure(2 * Btot + 1) || A->seg_fast.ensure(nr + 1)) return -1;
+	if (A->regs0.ensure(nu_total + 1) || A->aux128.ensure(Btot) || A->aux64.ensure(Btot) || A->auxi.ensure(2 * Btot) ||
+	    A->seg_u.ensure(2 * nu_total + 2) || A->reg_cnt.ensure(nr + 1) || A->seg_na.ensure(nr + 1) || A->out_off.ensure(nr + 2) || A->seg_fast.ensure(nr + 1) || A->cap2.ensure(nf + 2) || A->b2_off.ensure(nf + 2)) return -1;
 	WsBase W;
-	W.regs0 = A->regs0.p; W.mregs = A->mregs.p; W.rtmp = A->rtmp.p; W.aux128 = A->aux128.p; W.seg_a = c->chain_tmp.p /* chaining scratch, free again */; W.aux64 = A->aux64.p; W.seg_u = A->seg_u.p; W.auxi = A->auxi.p;
-	W.nu_off = A->nu_off.p; W.frag_nu = c->frag_nu.p; W.a_off = c->a_off.p; W.reg_cnt = A->reg_cnt.p; W.seg_na = A->seg_na.p; W.rext = A->rext.p; W.seg_fast = A->seg_fast.p;
+	W.regs0 = A->regs0.p; W.aux128 = A->aux128.p; W.seg_a = c->chain_tmp.p /* chaining scratch, free again */; W.aux64 = A->aux64.p; W.seg_u = A->seg_u.p; W.auxi = A->auxi.p;
+	W.nu_off = A->nu_off.p; W.frag_nu = c->frag_nu.p; W.a_off = c->a_off.p; W.reg_cnt = A->reg_cnt.p; W.seg_na = A->seg_na.p; W.seg_fast = A->seg_fast.p; W.cap2 = nullptr; W.b2_off = nullptr; W.mregs = nullptr; W.rtmp = nullptr; W.rext = nullptr;
 	// fragments with many chains: chain_post by a wavefront each (k_regs_select), by chain-count class
-	uint32_t *regs_n0 = nullptr; uint32_t heavy_from = 0, heavy_n = 0;
+	uint32_t *regs_n0 = nullptr; uint32_t heavy_from = 0, heavy_n = 0; uint64_t Btot2 = 0;
 	if (!((c->P.dbg >> 19) & 1)) {
 		if (A->regs_n0.ensure(nf + 1) || c->chain_key.ensure(nf + 1) || c->chain_idx.ensure(nf + 1) || c->chain_idx2.ensure(nf + 1) || c->lb_buf.ensure(16)) return -1;
 		regs_n0 = A->regs_n0.p;
@@ -2213,6 +2248,16 @@ int al_run_align_stage(al_ctx_t *c)
 		if (lb[5] > lb[4]) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_select<4096>), dim3(lb[5] - lb[4]), dim3(256), 0, s, c->chained.p, c->u.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, ord + lb[4], (int)(lb[5] - lb[4]), c->P, regs_n0);
 		if (lb[3] > lb[5]) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_select<8192>), dim3(lb[3] - lb[5]), dim3(256), 0, s, c->chained.p, c->u.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, ord + lb[5], (int)(lb[3] - lb[5]), c->P, regs_n0);
 		if ((uint32_t)nf > lb[3]) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_select<-1>), dim3((uint32_t)nf - lb[3]), dim3(256), 0, s, c->chained.p, c->u.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, ord + lb[3], (int)((uint32_t)nf - lb[3]), c->P, regs_n0);
+	}
+	{   // room for the per-mate hits, from what chain_post kept
+		hipLaunchKernelGGL(k_regs_cap2, dim3((nf + 256) / 256), dim3(256), 0, s, (const uint32_t *)c->frag_nu.p, (const uint32_t *)regs_n0, nf, A->cap2.p);
+		if (scan32(c, A->cap2.p, A->b2_off.p, nf)) return -1;
+		uint64_t b2_total = 0;
+		AL_HIP_CHECK(hipMemcpyAsync(&b2_total, A->b2_off.p + nf, 8, hipMemcpyDeviceToHost, s));
+		AL_HIP_CHECK(hipStreamSynchronize(s));
+		Btot2 = b2_total + 8;
+		if (A->mregs.ensure(2 * Btot2) || A->rtmp.ensure(Btot2) || A->rext.ensure(2 * Btot2 + 1)) return -1;
+		W.mregs = A->mregs.p; W.rtmp = A->rtmp.p; W.rext = A->rext.p; W.cap2 = A->cap2.p; W.b2_off = A->b2_off.p;
 	}
 	if (regs_n0 && heavy_n > 0) {
 		const size_t lds_t = al_regs_heavy_lds(24, 512), lds_s = al_regs_heavy_lds(72, 1024), lds_l = al_regs_heavy_lds(200, 2048);
@@ -2284,7 +2329,7 @@ int al_run_align_stage(al_ctx_t *c)
 		AL_HIP_CHECK(hipStreamSynchronize(s));
 		const uint32_t nj = (uint32_t)tot[0];
 		if (A->jobs.ensure(nj + 1) || A->outs.ensure(nj + 1) || A->job_key.ensure(nj + 1) || A->job_key2.ensure(nj + 1) || A->job_idx.ensure(nj + 1) || A->job_idx2.ensure(nj + 1) ||
-		    A->rext.ensure(2 * Btot + 1) || A->sc_ws.ensure(tot[1] + 1)) return -1;
+		    A->sc_ws.ensure(tot[1] + 1)) return -1;
 		AL_HIP_CHECK(hipMemsetAsync(A->hist.p, 0, AL_HIST_N * 8, s));
 		ExtShared E; E.jobs = A->jobs.p; E.outs = A->outs.p; E.rext = A->rext.p; E.job_off = A->job_off.p; E.frag_slow = A->frag_slow.p; E.job_key = A->job_key.p; E.hist = A->hist.p;
 		hipLaunchKernelGGL(k_ext_prep, dim3((nf + 255) / 256), dim3(256), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, c->frag_first.p, W, G, E, nf, c->P, tmax, qmax);

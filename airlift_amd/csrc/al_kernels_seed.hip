@@ -481,7 +481,7 @@ k_anchor_sort_blk(const uint64_t *__restrict__ pos, const uint32_t *__restrict__
 	}
 }
 #define INST_SORT_BLK(C, T) template __global__ void k_anchor_sort_blk<C, T>(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, uint32_t *, const uint32_t *, int, int, int);
-INST_SORT_BLK(2048, 256) INST_SORT_BLK(4096, 256) INST_SORT_BLK(8192, 512) INST_SORT_BLK(16384, 1024)
+INST_SORT_BLK(2048, 256) INST_SORT_BLK(4096, 256) INST_SORT_BLK(8192, 512)
 
 // K3 for fragments above the LDS tiles (reads inside high-copy families, the max_occ re-chain pass: up to 42 x 5000 anchors):
 // their anchors are expanded unsorted with a composite key  (rank of the fragment in the list) << key_bits | strand | contig |
