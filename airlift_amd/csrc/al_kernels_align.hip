@@ -866,7 +866,7 @@ k_regs_select(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__
 	uint64_t key_r = 0; int idx_r = 0;                                      // n_u <= 64: lane's own entry
 	{
 		uint32_t run = 0;
-		if (tid < 64)
+		if (tid < 64)                                                        // chain offsets: the first wavefront walks the counts
 		for (int c0 = 0; c0 < n_u; c0 += 64) {
 			const int c = c0 + lane; const bool v = c < n_u;
 			const uint64_t uc = v ? u[c] : 0; const uint32_t cnt = (uint32_t)uc;
@@ -876,13 +876,20 @@ k_regs_select(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__
 			run += __shfl(incl, 63);
 			if (v) {
 				as_arr[c] = (int32_t)as;
-				const AlAnchor fa = a[as];
-				const uint32_t h = (uint32_t)d_hash64((d_hash64(fa.x) + d_hash64(fa.y)) ^ fhash);
-				const uint64_t key = uc ^ h;
-				if (CAP != 0) { skey[c] = key; sidx[c] = (IdxT)c; } else { key_r = key; idx_r = c; }
+				if (CAP == 0) {
+					const AlAnchor fa = a[as];
+					key_r = uc ^ (uint32_t)d_hash64((d_hash64(fa.x) + d_hash64(fa.y)) ^ fhash); idx_r = c;
+				}
 			}
 		}
+		if (CAP != 0) {                                                      // keys: every thread of the block (one dependent load each)
+			__syncthreads();
+			for (int c = tid; c < n_u; c += NT) { const AlAnchor fa = a[as_arr[c]]; skey[c] = u[c] ^ (uint32_t)d_hash64((d_hash64(fa.x) + d_hash64(fa.y)) ^ fhash); sidx[c] = (IdxT)c; }
+		}
 	}
+	// per sorted position: query / reference interval, contig + strand, count, first anchor -- written by the whole block once the
+	// order is final, read back 64 at a time by the pass (coalesced, one round trip per group instead of four dependent ones)
+	int4 *const G1 = (int4 *)ws.aux128; int32_t *const G2 = ws.auxi + n_u, *const G3 = G2 + n_u, *const G4 = G3 + n_u;
 	bool tie = false;
 	if (CAP != 0) {   // descending bitonic sort of (key, chain), in LDS or in the fragment's work area
 		int npow2 = 1; while (npow2 < n_u) npow2 <<= 1;
@@ -899,20 +906,19 @@ k_regs_select(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__
 				}
 				__syncthreads();
 			}
-		if (tid >= 64) return;
-		for (int i = lane; i + 1 < n_u; i += 64) if (skey[i] == skey[i + 1]) tie = true;
-		if (__ballot(tie)) {
+		__shared__ int s_tie; __shared__ uint16_t s_rs[AL_RS_SCRATCH / 2];
+		if (tid == 0) s_tie = 0;
+		__syncthreads();
+		for (int i = tid; i + 1 < n_u; i += NT) if (skey[i] == skey[i + 1]) s_tie = 1;
+		__syncthreads();
+		if (s_tie) {
 			// Equal keys (a minimizer the sketch emitted twice makes two identical chains): their order is what the reference's unstable
-			// radix sort (ksort.h:116-151, more than 64 entries here) leaves.  Rare: the keys go back into chain order and lane 0
-			// restates that sort on them (ascending), the wavefront reverses the result (hit.c:76).
-			__shared__ uint16_t s_rs[AL_RS_SCRATCH / 2];
-			if (n_u > 65535) { if (lane == 0) regs_n0[f] = 0xfffffff1u; return; }
-			for (int c0 = 0; c0 < n_u; c0 += 64) {
-				const int c = c0 + lane;
-				if (c < n_u) { const AlAnchor fa = a[as_arr[c]]; skey[c] = u[c] ^ (uint32_t)d_hash64((d_hash64(fa.x) + d_hash64(fa.y)) ^ fhash); sidx[c] = (IdxT)c; }
-			}
-			__threadfence_block();
-			if (lane == 0) {
+			// radix sort (ksort.h:116-151, more than 64 entries here) leaves.  Rare: the keys go back into chain order and one lane
+			// restates that sort on them (ascending), the block reverses the result (hit.c:76).
+			if (n_u > 65535) { if (tid == 0) regs_n0[f] = 0xfffffff1u; return; }
+			for (int c = tid; c < n_u; c += NT) { const AlAnchor fa = a[as_arr[c]]; skey[c] = u[c] ^ (uint32_t)d_hash64((d_hash64(fa.x) + d_hash64(fa.y)) ^ fhash); sidx[c] = (IdxT)c; }
+			__syncthreads();
+			if (tid == 0) {
 				struct KI { uint64_t k; IdxT i; };
 				struct { typedef KI E; uint64_t *k; IdxT *i;
 				         __device__ __forceinline__ uint64_t keyof(const KI &e) const { return e.k; }
@@ -921,13 +927,25 @@ k_regs_select(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__
 				         __device__ __forceinline__ void set(int j, const KI &e) { k[j] = e.k; i[j] = e.i; } } acc{skey, sidx};
 				(void)d_rs_sort(acc, n_u, s_rs);
 			}
-			__threadfence_block();
-			for (int i = lane; i < n_u / 2; i += 64) {
+			__syncthreads();
+			for (int i = tid; i < n_u / 2; i += NT) {
 				const uint64_t tk = skey[i]; skey[i] = skey[n_u - 1 - i]; skey[n_u - 1 - i] = tk;
 				const IdxT ti = sidx[i]; sidx[i] = sidx[n_u - 1 - i]; sidx[n_u - 1 - i] = ti;
 			}
-			__threadfence_block();
+			__syncthreads();
 		}
+		for (int p = tid; p < n_u; p += NT) {
+			const int c = (int)sidx[p]; const int cnt = (int)(uint32_t)u[c], as = as_arr[c];
+			const AlAnchor fa = a[as], la = a[as + cnt - 1];
+			const int q_span = (int)(fa.y >> 32 & 0xff), rev = (int)(fa.x >> 63), rid = (int)(fa.x << 1 >> 33);
+			int4 g;
+			g.z = (int32_t)fa.x + 1 > q_span ? (int32_t)fa.x + 1 - q_span : 0; g.w = (int32_t)la.x + 1;
+			if (!rev) { g.x = (int32_t)fa.y + 1 - q_span; g.y = (int32_t)la.y + 1; }
+			else { g.x = qlen - ((int32_t)la.y + 1); g.y = qlen - ((int32_t)fa.y + 1 - q_span); }
+			G1[p] = g; G2[p] = rid << 1 | rev; G3[p] = cnt; G4[p] = as;
+		}
+		__syncthreads();
+		if (tid >= 64) return;
 	} else {         // rank sort in registers (descending); equal keys: the stable ascending insertion sort (ksort.h:149), reversed, puts the later chain first
 		int rank = 0; const int klo = (int)(uint32_t)key_r, khi = (int)(uint32_t)(key_r >> 32);
 		for (int j = 0; j < n_u; ++j) {
@@ -956,7 +974,10 @@ k_regs_select(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__
 		if (v) { if (CAP != 0) { key = skey[p]; c = (int)sidx[p]; } else { key = key_r; c = idx_r; } }
 		const int score = (int)(key >> 32); const uint32_t hsh = (uint32_t)key;
 		int cnt = 0, as = 0, rs = 0, re = 0, qs = 0, qe = 0, rid = 0, rev = 0;
-		if (v) {
+		if (v && CAP != 0) {
+			const int4 g = G1[p]; const int rr = G2[p];
+			qs = g.x; qe = g.y; rs = g.z; re = g.w; rid = rr >> 1; rev = rr & 1; cnt = G3[p]; as = G4[p];
+		} else if (v) {
 			cnt = (int)(uint32_t)u[c]; as = as_arr[c];
 			const AlAnchor fa = a[as], la = a[as + cnt - 1];
 			const int q_span = (int)(fa.y >> 32 & 0xff);

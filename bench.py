@@ -139,7 +139,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--pairs", type=int, default=500_000, help="fragments per GPU per step (C4: about 1250 seed hits and 155 chains per pair; the workspaces of 500 k pairs take ~150 GB next to the 23 GB index; a batch that does not fit is halved)")
+    ap.add_argument("--pairs", type=int, default=1_000_000, help="fragments per GPU per step (C4: about 1250 seed hits and 155 chains per pair, ~100 bytes of workspace per seed hit: 1 M pairs take ~140 GB next to the 23 GB index; a batch that does not fit is halved)")
     ap.add_argument("--read-len", type=int, default=0, help="default: the config's (150; C5: 250)")
     ap.add_argument("--cpu-sample-pairs", type=int, default=500_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
