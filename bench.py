@@ -145,6 +145,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ins-mean", type=int, default=0, help="mean insert size override (short inserts make the mates overlap: equal-key anchors)")
     ap.add_argument("--config", default="c4", help="workload of tools/gen_synth.py: c4 (default: the configuration BASELINE.json's metric is quoted on -- 150 bp PE against a human-sized reference; fits one GPU), c5 (250 bp), c3 (100 Mbp), c2 (yeast-sized), c2r, c4s, c3u, c4u")
+    ap.add_argument("--test-one-gpu", action="store_true", help="N > 1 on a one-GPU box (validation of the sharded path only): every rank uses device 0, collectives over gloo")
     a = ap.parse_args()
 
     import torch
@@ -153,11 +154,15 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if a.test_one_gpu:
+            local = 0; torch.cuda.set_device(0); dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local if world > 1 else 0)
+    cdev = torch.device("cpu") if a.test_one_gpu else dev          # where the collectives' tensors live
 
     import gen_synth as g
     import airlift_amd as A
@@ -202,7 +207,7 @@ def main():
         a.pairs //= 2
         sys.stderr.write("[bench] batch did not fit / failed: retrying with %d pairs per step\n" % a.pairs)
     if world > 1:   # every rank steps the same batch size
-        t = torch.tensor([a.pairs], dtype=torch.int64, device=dev); dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        t = torch.tensor([a.pairs], dtype=torch.int64, device=cdev); dist.all_reduce(t, op=dist.ReduceOp.MIN)
         if int(t.item()) != a.pairs:
             a.pairs = int(t.item()); upload(a.pairs)
 
@@ -212,7 +217,7 @@ def main():
         ctx.run()
         # merged-output offsets of this rank's block: one all-gather of {n_records, n_bytes} per step (RCCL over xGMI when N > 1)
         st = ctx.stat()
-        merged["rec_off"], merged["byte_off"], merged["records"], merged["bytes"] = output_offsets(int(st.n_regs_aln), int(st.bytes_out), rank, world, device=dev, dist=dist)
+        merged["rec_off"], merged["byte_off"], merged["records"], merged["bytes"] = output_offsets(int(st.n_regs_aln), int(st.bytes_out), rank, world, device=cdev, dist=dist)
 
     for _ in range(a.warmup):
         step()
@@ -229,7 +234,7 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     # PCIe-inclusive rate of the same batch (never `value`): pack + H2D upload, run, D2H of the flat result block
