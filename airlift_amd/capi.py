@@ -110,6 +110,7 @@ def load():
     L.al_dbg_copy.argtypes = [vp, cs, vp, C.c_int64]; L.al_dbg_copy.restype = C.c_int64
     L.al_dbg_alser_count.argtypes = [vp, C.POINTER(C.c_int64)]; L.al_dbg_alser_count.restype = ci
     L.al_write_sam.argtypes = [C.c_char_p, C.c_size_t, vp, cs, ci, cs, cs, ci, ci, ci, C.POINTER(ci), C.POINTER(C.POINTER(Reg)), cs, ci]; L.al_write_sam.restype = ci
+    L.al_dbg_ksw.argtypes = [vp, ci, vp, C.c_size_t, vp, vp, vp, ci]; L.al_dbg_ksw.restype = ci
     L.al_version.restype = cs
     _lib = L
     return L

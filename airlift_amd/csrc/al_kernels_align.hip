@@ -1471,6 +1471,60 @@ k_align_long(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ r
 	d_align_frags<AL_LONG_TMAX, AL_LONG_QMAX>(state[(size_t)blockIdx.x * AL_GPB + g], g, gl, rd_seq, rd_off, rd_len, frag_first, frag_rep, W, G, lt, gws, gws_stride, p_bytes, cig_words, n_frag, P, frag_list, n_list);
 }
 
+// Tap for the parity tests: the extension DP alone on caller-supplied (target, query) pairs, one 16-lane group per pair -- what the
+// reference's --print-aln-seq tap shows per ksw call (align.c:313-339): sequences as passed to ksw_extd2_sse, flag; out: ez->score, CIGAR.
+struct DbgKswJob { uint32_t toff, qoff; int32_t tlen, qlen, flag, pad; };
+__global__ void __launch_bounds__(64)
+k_dbg_ksw(const uint8_t *__restrict__ seqs, const DbgKswJob *__restrict__ jobs, int n, AlParams P, uint8_t *__restrict__ gws, size_t gws_stride, size_t p_bytes, size_t cig_words,
+          int32_t *__restrict__ out /* per job: score, max, max_q, max_t, mqe, mqe_t, zdropped, reach_end, n_cigar */, uint32_t *__restrict__ cig_out, int cig_cap)
+{
+	__shared__ GroupLds<1024, 512> lds[AL_GPB];
+	const int g = threadIdx.x / GW, gl = threadIdx.x % GW;
+	GroupLds<1024, 512> &L = lds[g];
+	GroupWs ws;
+	{
+		uint8_t *base = gws + ((size_t)blockIdx.x * AL_GPB + g) * gws_stride;
+		ws.p = base; ws.cig = (uint32_t *)(base + p_bytes); ws.ezc = ws.cig + cig_words; ws.sc = nullptr; ws.dbg = nullptr;
+	}
+	const int bw = (int)(P.bw * 1.5 + 1.);
+	for (int j = blockIdx.x * AL_GPB + g; j < n; j += gridDim.x * AL_GPB) {
+		const DbgKswJob jb = jobs[j];
+		int32_t *o = out + (size_t)j * 9;
+		if (jb.tlen > 1024 || jb.qlen > 512) { if (gl == 0) o[8] = -1; continue; }
+		for (int i = gl; i < jb.tlen; i += GW) L.tbuf[i] = seqs[jb.toff + i];
+		for (int i = gl; i < jb.qlen; i += GW) L.qbuf[i] = seqs[jb.qoff + i];
+		GSYNC();
+		EzD ez;
+		const int eb = (jb.flag & EZ_EXTZ_ONLY) ? P.end_bonus : -1;                      // align.c: extensions pass opt->end_bonus, the core re-alignment -1
+		d_ksw_extd2(L, gl, ws, jb.qlen, jb.tlen, P, bw, P.zdrop, eb, jb.flag, ez);
+		if (gl == 0) {
+			o[0] = ez.score; o[1] = ez.max; o[2] = ez.max_q; o[3] = ez.max_t; o[4] = ez.mqe; o[5] = ez.mqe_t; o[6] = ez.zdropped; o[7] = ez.reach_end; o[8] = ez.n_cigar;
+			for (int i = 0; i < ez.n_cigar && i < cig_cap; ++i) cig_out[(size_t)j * cig_cap + i] = ws.cur_ezc[i];
+		}
+		GSYNC();
+	}
+}
+extern "C" int al_dbg_ksw(al_ctx_t *c, int n, const uint8_t *seqs, size_t n_seq_bytes, const int32_t *jobs6 /* toff, qoff, tlen, qlen, flag, 0 per job */, int32_t *out9, uint32_t *cig_out, int cig_cap)
+{
+	if (!c || n <= 0) return -1;
+	AL_HIP_CHECK(hipSetDevice(c->device));
+	hipStream_t s = c->stream;
+	const int bw = (int)(c->opt.bw * 1.5 + 1.), ncol = ((std::min(512, bw + 1) + 15) / 16 + 1);
+	const size_t p_bytes = ((size_t)(512 + 1024) * ncol * 16 + 63) / 64 * 64, cig_words = 1600, stride = p_bytes + cig_words * 8;
+	int nb = (n + AL_GPB - 1) / AL_GPB; if (nb > 512) nb = 512;
+	uint8_t *d_seq = nullptr, *d_ws = nullptr; DbgKswJob *d_jobs = nullptr; int32_t *d_out = nullptr; uint32_t *d_cig = nullptr;
+	int rc = -1;
+	if (hipMalloc((void **)&d_seq, n_seq_bytes + 64) == hipSuccess && hipMalloc((void **)&d_ws, (size_t)nb * AL_GPB * stride) == hipSuccess && hipMalloc((void **)&d_jobs, (size_t)n * sizeof(DbgKswJob)) == hipSuccess &&
+	    hipMalloc((void **)&d_out, (size_t)n * 36) == hipSuccess && hipMalloc((void **)&d_cig, (size_t)n * cig_cap * 4 + 16) == hipSuccess &&
+	    hipMemcpyAsync(d_seq, seqs, n_seq_bytes, hipMemcpyHostToDevice, s) == hipSuccess && hipMemcpyAsync(d_jobs, jobs6, (size_t)n * sizeof(DbgKswJob), hipMemcpyHostToDevice, s) == hipSuccess) {
+		hipLaunchKernelGGL(k_dbg_ksw, dim3(nb), dim3(GW * AL_GPB), 0, s, (const uint8_t *)d_seq, (const DbgKswJob *)d_jobs, n, c->P, d_ws, stride, p_bytes, cig_words, d_out, d_cig, cig_cap);
+		if (hipMemcpyAsync(out9, d_out, (size_t)n * 36, hipMemcpyDeviceToHost, s) == hipSuccess && hipMemcpyAsync(cig_out, d_cig, (size_t)n * cig_cap * 4, hipMemcpyDeviceToHost, s) == hipSuccess &&
+		    hipStreamSynchronize(s) == hipSuccess) rc = 0;
+	}
+	(void)hipFree(d_seq); (void)hipFree(d_ws); (void)hipFree(d_jobs); (void)hipFree(d_out); (void)hipFree(d_cig);
+	return rc;
+}
+
 // =============================================================================================
 // Fast path of the extension stage: the same work as k_align, batched by KIND of work so that every wavefront runs
 // one code path on similar-sized problems (k_align, with its per-fragment mix of DP sizes, spends most of its cycles

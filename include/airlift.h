@@ -159,6 +159,12 @@ int64_t al_extract_reads(const char *bam_fn, const char *bed_fn, int read_size, 
  * reads_2.fastq, singletons.fastq.  Returns 0, negative on error. */
 int  al_extract_sequence(const char *fq1, const char *fq2, const char *rows_fn, const char *out_dir, int64_t *n_pairs, int64_t *n_single);
 
+/* Tap (parity tests): the extension DP alone -- ksw_extd2_sse's result for n caller-supplied pairs, as the reference's --print-aln-seq
+ * shows them (align.c:313-339).  seqs: nt4 codes (0..4); jobs6: {target offset, query offset, tlen, qlen, ksw flag, 0} per pair (the
+ * sequences as passed to ksw, i.e. already reversed for left extensions); out9 per pair: score, max, max_q, max_t, mqe, mqe_t, zdropped,
+ * reach_end, n_cigar (-1: pair larger than 1024 x 512); cig_out: cig_cap words per pair.  Uses the context's options. */
+int  al_dbg_ksw(al_ctx_t *ctx, int n, const uint8_t *seqs, size_t n_seq_bytes, const int32_t *jobs6, int32_t *out9, uint32_t *cig_out, int cig_cap);
+
 /* Self-test of the multi-lane output path (offset exchange + pwrite, or ordered turns) with synthetic blocks; needs no GPU. */
 int  al_dbg_ordered_out_selftest(const char *path, int n_lanes, int n_batches, int use_offsets);
 

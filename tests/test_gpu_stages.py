@@ -1,5 +1,6 @@
 """-m gpu parity tests, stage level: the HIP kernels K1..K4 (through the C-ABI) against
 (a) the oracle's sketch and (b) the golden --print-seeds taps the reference build produced."""
+import json
 import os
 
 import numpy as np
@@ -207,3 +208,46 @@ def test_rechain_pass_layout_and_run_to_run_determinism(A):
         digests.append(d)
     assert digests[0] == digests[1] == digests[2]
     ctx.close(); idx.close()
+
+
+@pytest.mark.parametrize("name", ["g1_mt150pe", "g2_100se", "g2_250pe", "g3_adversarial", "g4_q_inv"])
+def test_ksw_calls_match_aln_seq_taps(golden_unpacked, name):
+    """Every ksw_extd2_sse call the reference made on a golden set (--print-aln-seq taps, align.c:313-339: target, query, flag ->
+    ez->score and CIGAR) replayed through the device DP (al_dbg_ksw: register-resident systolic form up to 22 x 16 target cells, LDS
+    rows above): score and CIGAR must be identical call by call."""
+    import ctypes as C
+    import numpy as np
+    import airlift_amd as A
+    d = golden_unpacked[name]
+    m = json.load(open(os.path.join(d, "meta.json")))
+    lines = open(os.path.join(d, "expected.alnseq")).read().split("\n")
+    calls = []
+    i = 0
+    while i + 3 < len(lines) + 1 and i < len(lines):
+        if not lines[i].startswith("===>"):
+            i += 1; continue
+        flag = int(lines[i].split("flag=")[1].split(",")[0])
+        t, q, res = lines[i + 1], lines[i + 2], lines[i + 3]
+        calls.append((flag, t, q, res)); i += 4
+    calls = [c for c in calls if 0 < len(c[1]) <= 1024 and 0 < len(c[2]) <= 512]
+    assert len(calls) > 10
+    code = np.full(256, 4, dtype=np.uint8)
+    for k, ch in enumerate(b"ACGT"):
+        code[ch] = k
+    blob = bytearray(); jobs = np.zeros((len(calls), 6), dtype=np.int32)
+    for j, (flag, t, q, _) in enumerate(calls):
+        jobs[j] = (len(blob), len(blob) + len(t), len(t), len(q), flag, 0)
+        blob += t.encode() + q.encode()
+    seqs = code[np.frombuffer(bytes(blob), dtype=np.uint8)]
+    idx = A.Index(fasta=os.path.join(d, m["ref"])); ctx = A.Context(idx)
+    out = np.zeros((len(calls), 9), dtype=np.int32); cap = 512; cig = np.zeros((len(calls), cap), dtype=np.uint32)
+    rc = A.load().al_dbg_ksw(ctx.h, len(calls), seqs.ctypes.data_as(C.c_void_p), seqs.nbytes, jobs.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), cig.ctypes.data_as(C.c_void_p), cap)
+    assert rc == 0
+    bad = []
+    for j, (flag, t, q, res) in enumerate(calls):
+        n = int(out[j, 8])
+        got = "score=%d, cigar=%s" % (out[j, 0], "".join("%d%s" % (int(c) >> 4, "MIDN"[int(c) & 15]) for c in cig[j, :n]))
+        if got != res:
+            bad.append((j, flag, len(t), len(q), got, res))
+    ctx.close(); idx.close()
+    assert not bad, bad[:5]
