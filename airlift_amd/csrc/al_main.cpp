@@ -125,9 +125,9 @@ int main(int argc, char **argv)
 		else if (!strcmp(a, "--version")) { puts(al_version()); return 0; }
 		else { fprintf(stderr, "[WARNING] airlift-align: option '%s' ignored\n", a); }
 	}
-	// Device batches: results do not depend on how reads are grouped (the reference's -K only bounds its memory), and the GPU path is
-	// about twice as efficient on 1 M-pair batches as on the preset's 50 Mbases (166 k pairs): 250 Mbases unless -K is given
-	if (!k_given) mo.mini_batch_size = 250000000;
+	// (-K: the preset's 50 Mbases per device batch, as the reference.  Larger batches map faster per read -- 1 M pairs: 2.5x -- but their
+	// workspaces, ~100 bytes per seed hit, cost seconds of hipMalloc per process: worth passing -K 300M only for inputs of many millions of reads)
+	(void)k_given;
 	if (al_check_opt(&io, &mo) < 0) return 1;
 	const char *ref = nullptr; std::vector<const char *> reads;
 	if (mode == MODE_ALN) {          // the real work happens in samse; emit a small marker so `> x.sai` is non-empty

@@ -230,7 +230,7 @@ def test_ksw_calls_match_aln_seq_taps(golden_unpacked, name):
         t, q, res = lines[i + 1], lines[i + 2], lines[i + 3]
         calls.append((flag, t, q, res)); i += 4
     calls = [c for c in calls if 0 < len(c[1]) <= 1024 and 0 < len(c[2]) <= 512]
-    assert len(calls) > 10
+    assert len(calls) >= 5
     code = np.full(256, 4, dtype=np.uint8)
     for k, ch in enumerate(b"ACGT"):
         code[ch] = k
