@@ -170,6 +170,15 @@ class Index:
         load().al_idx_stat(self.h, C.byref(a), C.byref(b), C.byref(c))
         return {"n_keys": a.value, "n_pos": b.value, "n_bases": c.value}
 
+    def cal_max_occ(self, f):
+        """mm_idx_cal_max_occ (index.c:164-185)."""
+        fn = load().al_idx_cal_max_occ
+        fn.restype = C.c_int32; fn.argtypes = [C.c_void_p, C.c_float]
+        v = fn(self.h, f)
+        if v < 0:
+            raise AirliftError("al_idx_cal_max_occ failed")
+        return v
+
     def positions(self):
         """The occurrence array (grouped by minimizer hash ascending, positions ascending inside a group)."""
         n = load().al_idx_export_pos(self.h, None, 0)

@@ -23,6 +23,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
+#include <algorithm>
 #include "al_internal.h"
 #include "al_device.h"
 #include "al_io.h"
@@ -291,3 +292,94 @@ extern "C" int64_t al_idx_export_pos(const al_idx_t *mi, uint64_t *dst, int64_t 
 	if (dst && n) { if (hipSetDevice(mi->built_on) != hipSuccess || hipMemcpy(dst, it->second.pos, (size_t)(n < cap ? n : cap) * 8, hipMemcpyDeviceToHost) != hipSuccess) return -1; }
 	return n;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Occurrence threshold from the index (mm_idx_cal_max_occ, index.c:164-185): the (1-f) quantile of the per-minimizer
+// occurrence counts, plus one.  Host-built index: the table is walked on the host; device-built index: one kernel
+// gathers the counts of the occupied slots, a device radix sort orders them and one element comes back.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_tab_counts(const uint64_t *__restrict__ tab, uint64_t n_slots, uint32_t *__restrict__ out, unsigned long long *__restrict__ n_out)
+{
+	const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (s >= n_slots) return;
+	const uint64_t key = tab[2 * s];
+	if (!key) return;
+	const uint32_t c = (key & AL_TAB_SINGLE) ? 1u : (uint32_t)tab[2 * s + 1];
+	out[atomicAdd(n_out, 1ULL)] = c;
+}
+
+extern "C" int32_t al_idx_cal_max_occ(const al_idx_t *mi, float f)
+{
+	if (!mi || f <= 0.f) return INT32_MAX;
+	const uint64_t n = mi->n_keys;
+	if (n == 0) return INT32_MAX;
+	const uint64_t kth = (uint64_t)((1. - (double)f) * (double)n);           // ks_ksmall's 0-based rank (index.c:182)
+	if (mi->built_on < 0) {
+		std::vector<uint32_t> a; a.reserve(n);
+		const uint64_t n_slots = 1ULL << mi->tab_bits;
+		for (uint64_t s = 0; s < n_slots; ++s) if (mi->tab[2 * s]) a.push_back((mi->tab[2 * s] & AL_TAB_SINGLE) ? 1u : (uint32_t)mi->tab[2 * s + 1]);
+		if (a.empty()) return INT32_MAX;
+		const uint64_t kk = kth < a.size() ? kth : a.size() - 1;
+		std::nth_element(a.begin(), a.begin() + kk, a.end());
+		return (int32_t)a[kk] + 1;
+	}
+	std::lock_guard<std::mutex> lk(mi->dev_mtx);
+	auto it = mi->dev.find(mi->built_on);
+	if (it == mi->dev.end() || hipSetDevice(mi->built_on) != hipSuccess) return -1;
+	const uint64_t n_slots = 1ULL << mi->tab_bits;
+	uint32_t *d_c = nullptr, *d_s = nullptr; unsigned long long *d_n = nullptr; void *d_tmp = nullptr; size_t tmp_bytes = 0;
+	uint32_t v = 0; int32_t ret = -1;
+	const uint64_t kk = kth < n ? kth : n - 1;
+	if (hipMalloc((void **)&d_c, n * 4) != hipSuccess || hipMalloc((void **)&d_s, n * 4) != hipSuccess || hipMalloc((void **)&d_n, 8) != hipSuccess) goto done;
+	if (hipMemset(d_n, 0, 8) != hipSuccess) goto done;
+	hipLaunchKernelGGL(k_tab_counts, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, 0, it->second.tab, n_slots, d_c, d_n);
+	if (hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, d_c, d_s, (int)n) != hipSuccess) goto done;
+	if (hipMalloc(&d_tmp, tmp_bytes + 16) != hipSuccess) goto done;
+	if (hipcub::DeviceRadixSort::SortKeys(d_tmp, tmp_bytes, d_c, d_s, (int)n) != hipSuccess) goto done;
+	if (hipMemcpy(&v, d_s + kk, 4, hipMemcpyDeviceToHost) != hipSuccess) goto done;
+	ret = (int32_t)v + 1;
+done:
+	(void)hipFree(d_c); (void)hipFree(d_s); (void)hipFree(d_n); (void)hipFree(d_tmp);
+	if (ret < 0) fprintf(stderr, "[airlift] al_idx_cal_max_occ: HIP error: %s\n", hipGetErrorString(hipGetLastError()));
+	return ret;
+}
+
+// mm_mapopt_update (options.c:51-61): fills the index-dependent fields.  With mid_occ > 0 (every preset on this path sets
+// 1000 for `sr`) nothing changes.
+extern "C" void al_mapopt_update(al_mapopt_t *opt, const al_idx_t *mi)
+{
+	if (!opt || !mi) return;
+	if (opt->mid_occ <= 0) {
+		const int32_t m = al_idx_cal_max_occ(mi, 2e-4f);                       // mid_occ_frac of mm_mapopt_init (options.c:25)
+		if (m > 0) opt->mid_occ = m;
+	}
+}
+
+// mm_idx_reader_open/read/close (minimap.h:206-232, index.c:585-648): the reference hands out one index part per read()
+// call; this path builds a single part (the sr preset's batch size of 4 Gbp covers AirLift's references, larger inputs are
+// refused by the builders), so the first read() returns the whole index and the second NULL.
+struct al_idx_reader_s { std::string fn; al_idxopt_t opt; int n_parts; };
+
+extern "C" al_idx_reader_t *al_idx_reader_open(const char *fn, const al_idxopt_t *io, const char *fn_out)
+{
+	if (!fn || !io) return nullptr;
+	if (fn_out) { fprintf(stderr, "[airlift] al_idx_reader_open: index dumps (-d) are not supported: the index is rebuilt on the GPU in seconds\n"); return nullptr; }
+	FILE *fp = fopen(fn, "rb");
+	if (!fp) return nullptr;                                                   // minimap.h:206: NULL when the file cannot be opened
+	fclose(fp);
+	al_idx_reader_t *r = new al_idx_reader_t();
+	r->fn = fn; r->opt = *io; r->n_parts = 0;
+	return r;
+}
+
+extern "C" al_idx_t *al_idx_reader_read(al_idx_reader_t *r, int device)
+{
+	if (!r || r->n_parts > 0) return nullptr;
+	al_idx_t *mi = al_idx_build_device(r->fn.c_str(), &r->opt, device);
+	if (mi) ++r->n_parts;
+	return mi;
+}
+
+extern "C" int al_idx_reader_eof(const al_idx_reader_t *r) { return !r || r->n_parts > 0; }
+extern "C" void al_idx_reader_close(al_idx_reader_t *r) { delete r; }

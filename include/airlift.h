@@ -94,6 +94,18 @@ al_idx_t *al_idx_build(const char *fn, const al_idxopt_t *io, int n_threads);
  * index stays resident on `device` (< 0: LOCAL_RANK or 0) and is copied device-to-device if a context on another GPU
  * asks for it.  Needs odd k.  NULL (with a message) if HIP is unusable -- there is no host path behind this entry point. */
 al_idx_t *al_idx_build_device(const char *fn, const al_idxopt_t *io, int device);
+/* mm_idx_reader_open / mm_idx_reader_read / mm_idx_reader_eof / mm_idx_reader_close (minimap.h:206-232): the reference's
+ * iterator over index parts.  This path builds one part: the first read() returns the whole index (built on `device`, as
+ * al_idx_build_device), the next NULL.  open() returns NULL if the file cannot be opened or fn_out (index dump) is set. */
+typedef struct al_idx_reader_s al_idx_reader_t;
+al_idx_reader_t *al_idx_reader_open(const char *fn, const al_idxopt_t *io, const char *fn_out);
+al_idx_t *al_idx_reader_read(al_idx_reader_t *r, int device);
+int       al_idx_reader_eof(const al_idx_reader_t *r);
+void      al_idx_reader_close(al_idx_reader_t *r);
+/* mm_idx_cal_max_occ (index.c:164-185): (1-f) quantile of the per-minimizer occurrence counts + 1; INT32_MAX for f <= 0 */
+int32_t   al_idx_cal_max_occ(const al_idx_t *mi, float f);
+/* mm_mapopt_update (minimap.h:183, options.c:51-61): mid_occ <= 0 is replaced by al_idx_cal_max_occ(mi, 2e-4) */
+void      al_mapopt_update(al_mapopt_t *opt, const al_idx_t *mi);
 /* mm_idx_str (minimap.h:269) */
 al_idx_t *al_idx_str(int w, int k, int n, const char **seq, const char **name);
 /* mm_idx_destroy (minimap.h:291) */

@@ -12,6 +12,7 @@
  *              build is paid once and is not part of the mapping time
  *   --save-index FILE : write the index (mm_idx_dump, index.c:438) after building it; a later run given FILE instead of ref.fa
  *              loads it (mm_idx_reader_open recognises index files), so that several test cases share one index build
+ *   --max-occ F : print "[mm2ref] max_occ f=F value=V" (mm_idx_cal_max_occ, index.c:164) for the index and exit without mapping
  *   --seeds  : mm_dbg_flag |= MM_DBG_PRINT_SEED  (RS/SD/CN lines on stderr, map.c:333-338,381-385)
  *   --alnseq : mm_dbg_flag |= MM_DBG_PRINT_ALN_SEQ (align.c:315-338)
  */
@@ -33,6 +34,7 @@ int main(int argc, char **argv)
 	mm_idxopt_t io; mm_mapopt_t mo;
 	int i, n_threads = 1, nfn = 0;
 	const char *rg = 0, *fn[4], *save_idx = 0;
+	float max_occ_f = 0.f;
 	mm_idx_reader_t *r; mm_idx_t *mi;
 	mm_verbose = 1;
 	mm_set_opt(0, &io, &mo);
@@ -47,6 +49,7 @@ int main(int argc, char **argv)
 		else if (!strcmp(argv[i], "-R") && i + 1 < argc) rg = argv[++i];
 		else if (!strcmp(argv[i], "-K") && i + 1 < argc) mo.mini_batch_size = atoi(argv[++i]);
 		else if (!strcmp(argv[i], "--save-index") && i + 1 < argc) save_idx = argv[++i];
+		else if (!strcmp(argv[i], "--max-occ") && i + 1 < argc) max_occ_f = atof(argv[++i]);
 		else if (!strcmp(argv[i], "--seeds")) mm_dbg_flag |= MM_DBG_PRINT_SEED;
 		else if (!strcmp(argv[i], "--alnseq")) mm_dbg_flag |= MM_DBG_PRINT_ALN_SEQ;
 		else if (!strcmp(argv[i], "--qname")) mm_dbg_flag |= MM_DBG_PRINT_QNAME;
@@ -74,7 +77,7 @@ int main(int argc, char **argv)
 		else if (!strcmp(argv[i], "--seed") && i + 1 < argc) mo.seed = atoi(argv[++i]);
 		else if (nfn < 4) fn[nfn++] = argv[i];
 	}
-	if (nfn < 2) { fprintf(stderr, "usage: mm2ref [opts] ref.fa r1.fq [r2.fq]\n"); return 2; }
+	if (nfn < 2 && !(nfn == 1 && max_occ_f > 0.f)) { fprintf(stderr, "usage: mm2ref [opts] ref.fa r1.fq [r2.fq]\n"); return 2; }
 	if (mm_check_opt(&io, &mo) < 0) return 2;
 	r = mm_idx_reader_open(fn[0], &io, 0);
 	if (r == 0) { fprintf(stderr, "mm2ref: cannot open %s\n", fn[0]); return 1; }
@@ -83,6 +86,7 @@ int main(int argc, char **argv)
 	while ((mi = mm_idx_reader_read(r, n_threads)) != 0) {
 		t_idx = wall() - t_idx0;
 		if (save_idx) { FILE *fp = fopen(save_idx, "wb"); if (fp) { mm_idx_dump(fp, mi); fclose(fp); } else { perror(save_idx); return 1; } }
+		if (max_occ_f > 0.f) { fprintf(stderr, "[mm2ref] max_occ f=%g value=%d\n", max_occ_f, mm_idx_cal_max_occ(mi, max_occ_f)); mm_idx_destroy(mi); continue; }
 		mm_mapopt_update(&mo, mi);
 		for (si = 0; si < n_sweep; ++si) {
 			int saved = -1; double t0;

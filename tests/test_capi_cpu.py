@@ -83,6 +83,45 @@ def test_index_matches_oracle_sketch(A, oracle_bin, golden_unpacked):
     idx.close()
 
 
+MM2REF = os.path.join(ROOT, "oracle", "_ref", "mm2ref")
+
+
+def _ref_max_occ(fa, f):
+    r = subprocess.run([MM2REF, "--max-occ", repr(f), fa], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return int(r.stderr.strip().splitlines()[-1].split("value=")[1])
+
+
+@pytest.mark.skipif(not os.path.exists(MM2REF), reason="reference build absent")
+@pytest.mark.parametrize("gset,fa", [("g6_repeats", "rep.fa"), ("g2_100se", "syn.fa"), ("g1_mt150pe", "MT-human.fa")])
+def test_cal_max_occ_and_mapopt_update_match_reference(A, golden_unpacked, gset, fa):
+    """al_idx_cal_max_occ == mm_idx_cal_max_occ (index.c:164-185) of the reference build on the host-built index;
+    al_mapopt_update only touches mid_occ when it is <= 0 (options.c:51-61)."""
+    path = os.path.join(golden_unpacked[gset], fa)
+    idx = A.Index(fasta=path)
+    for f in (2e-4, 0.01, 0.2):
+        assert idx.cal_max_occ(f) == _ref_max_occ(path, f), (gset, f)
+    L = A.load()
+    io, mo = A.IdxOpt(), A.MapOpt()
+    L.al_set_opt(None, C.byref(io), C.byref(mo)); L.al_set_opt(b"sr", C.byref(io), C.byref(mo))
+    L.al_mapopt_update(C.byref(mo), C.c_void_p(idx.h))
+    assert mo.mid_occ == 1000
+    mo.mid_occ = 0
+    L.al_mapopt_update(C.byref(mo), C.c_void_p(idx.h))
+    assert mo.mid_occ == _ref_max_occ(path, 2e-4)
+    idx.close()
+
+
+def test_idx_reader_open_fails_like_reference(A):
+    L = A.load()
+    L.al_idx_reader_open.restype = C.c_void_p
+    io, mo = A.IdxOpt(), A.MapOpt()
+    L.al_set_opt(None, C.byref(io), C.byref(mo))
+    assert L.al_idx_reader_open(b"/nonexistent/ref.fa", C.byref(io), None) is None       # minimap.h:206
+    assert L.al_idx_reader_eof(None) == 1
+    L.al_idx_reader_close(None)
+
+
 def test_no_cpu_path(A, golden_unpacked):
     """Without a HIP device the context creation must fail loudly (no fallback)."""
     import torch

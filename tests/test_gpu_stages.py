@@ -138,6 +138,40 @@ def test_device_built_index_equals_host_index(A, golden_unpacked, name):
     _same_index(A, os.path.join(d, m["ref"]), n_segs, seqs, names)
 
 
+@pytest.mark.parametrize("name", ["g1_mt150pe", "g6_repeats"])
+def test_idx_reader_and_max_occ_on_device_index(A, golden_unpacked, name):
+    """al_idx_reader_open/read/eof/close (minimap.h:206-232): one part, then NULL; al_idx_cal_max_occ on the device-resident
+    table == the host-built index's value == mm_idx_cal_max_occ of the reference build (index.c:164-185)."""
+    import ctypes as C
+    import subprocess
+    d = golden_unpacked[name]
+    m = json.load(open(os.path.join(d, "meta.json")))
+    fasta = os.path.join(d, m["ref"])
+    L = A.load()
+    L.al_idx_reader_open.restype = C.c_void_p; L.al_idx_reader_read.restype = C.c_void_p
+    L.al_idx_cal_max_occ.restype = C.c_int32; L.al_idx_cal_max_occ.argtypes = [C.c_void_p, C.c_float]
+    io, mo = A.IdxOpt(), A.MapOpt()
+    L.al_set_opt(None, C.byref(io), C.byref(mo)); L.al_set_opt(b"sr", C.byref(io), C.byref(mo))
+    r = L.al_idx_reader_open(fasta.encode(), C.byref(io), None)
+    assert r and L.al_idx_reader_eof(C.c_void_p(r)) == 0
+    mi = L.al_idx_reader_read(C.c_void_p(r), 0)
+    assert mi and L.al_idx_reader_eof(C.c_void_p(r)) == 1
+    assert L.al_idx_reader_read(C.c_void_p(r), 0) is None
+    L.al_idx_reader_close(C.c_void_p(r))
+    host = A.Index(fasta=fasta)
+    mm2ref = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "mm2ref")
+    for f in (2e-4, 0.01, 0.2):
+        v = L.al_idx_cal_max_occ(C.c_void_p(mi), f)
+        assert v == host.cal_max_occ(f) and v > 0
+        if os.path.exists(mm2ref):
+            out = subprocess.run([mm2ref, "--max-occ", repr(f), fasta], capture_output=True, text=True)
+            assert out.returncode == 0 and v == int(out.stderr.strip().splitlines()[-1].split("value=")[1])
+    mo.mid_occ = -1
+    L.al_mapopt_update(C.byref(mo), C.c_void_p(mi))
+    assert mo.mid_occ == host.cal_max_occ(2e-4)
+    host.close(); L.al_idx_destroy(C.c_void_p(mi))
+
+
 def test_device_built_index_ragged_contigs(A, tmp_path):
     """Contigs shorter than k, shorter than one window, exactly on segment boundaries, with N runs, lower case and IUPAC codes."""
     rng = np.random.default_rng(99)
