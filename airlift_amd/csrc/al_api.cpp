@@ -52,6 +52,19 @@ extern "C" void al_map_frag(const al_idx_t *mi, int n_segs, const int *qlens, co
 
 // ---------------------------------------------------------------------------------------------
 // SAM (format.c:82-135, 276-302, 361-544)
+// The tail of the @PG line: mm_write_sam_hdr's `ver` / `argc, argv` arguments (format.c:116-135, called from main.c:369 with
+// MM_VERSION and the process's own argv).  Set once by the program that owns main(); empty for library callers that pass none.
+static std::string g_pg_tail;
+extern "C" void al_set_program_line(const char *ver, int argc, char *const *argv)
+{
+	g_pg_tail.clear();
+	if (ver) { g_pg_tail += "\tVN:"; g_pg_tail += ver; }
+	if (argc > 1 && argv) {
+		g_pg_tail += "\tCL:minimap2";
+		for (int i = 1; i < argc; ++i) { g_pg_tail += ' '; g_pg_tail += argv[i]; }
+	}
+}
+
 extern "C" int al_write_sam_hdr(FILE *out, const al_idx_t *mi, const char *rg, char *rg_id)
 {
 	for (size_t i = 0; i < mi->seq.size(); ++i) fprintf(out, "@SQ\tSN:%s\tLN:%d\n", mi->seq[i].name.c_str(), (int)mi->seq[i].len);
@@ -75,7 +88,7 @@ extern "C" int al_write_sam_hdr(FILE *out, const al_idx_t *mi, const char *rg, c
 			}
 		}
 	}
-	fprintf(out, "@PG\tID:minimap2\tPN:minimap2\n");
+	fprintf(out, "@PG\tID:minimap2\tPN:minimap2%s\n", g_pg_tail.c_str());
 	return 0;
 }
 

@@ -66,6 +66,9 @@ int main(int argc, char **argv)
 		if (rc == 0) fprintf(stderr, "[airlift] extract-sequence: %lld pairs, %lld singletons\n", (long long)np, (long long)ns);
 		return rc == 0 ? 0 : 1;
 	}
+	// @PG as main.c:369 writes it (VN = the fork's MM_VERSION, main.c:16: the version whose records this path reproduces;
+	// CL = this process's argv).  AL_PG_PLAIN=1 leaves the bare line (the tests' goldens come from a driver without argv).
+	if (!getenv("AL_PG_PLAIN")) al_set_program_line(AL_MM_VERSION, argc, argv);
 	if (!strcmp(argv[1], "mem")) mode = MODE_MEM, i = 2;
 	else if (!strcmp(argv[1], "aln")) mode = MODE_ALN, i = 2;
 	else if (!strcmp(argv[1], "samse")) mode = MODE_SAMSE, i = 2;

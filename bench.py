@@ -112,7 +112,8 @@ def cpu_baseline(tmp, ref_fa, arr, n_pairs, read_len):
     nt = min(cores, 32)
     t0 = time.time()
     with open(os.path.join(tmp, "gpu.sam"), "wb") as f:
-        rc = subprocess.run([cli, "-ax", "sr", "-t", str(nt), ref_fa, "cb_1.fq", "cb_2.fq"], cwd=tmp, stdout=f, stderr=subprocess.PIPE)
+        rc = subprocess.run([cli, "-ax", "sr", "-t", str(nt), ref_fa, "cb_1.fq", "cb_2.fq"], cwd=tmp, stdout=f, stderr=subprocess.PIPE,
+                            env=dict(os.environ, AL_PG_PLAIN="1"))    # bare @PG line, as the reference driver (no argv) prints it
     t_cli = time.time() - t0
     if rc.returncode != 0:
         sys.stderr.write("[bench] airlift-align failed (%d): %s\n" % (rc.returncode, rc.stderr.decode(errors="replace")[-2000:]))

@@ -252,6 +252,11 @@ int  al_dbg_alser_count(al_ctx_t *ctx, int64_t *total);
 int64_t al_dbg_copy(al_ctx_t *ctx, const char *name, void *dst, int64_t max_bytes);
 
 /* SAM text (format.c:116-135, 387-544) */
+#define AL_MM_VERSION "2.17-r954-dirty"   /* MM_VERSION of the fork (main.c:16): the version whose records this path reproduces */
+/* the `ver` and `argc, argv` arguments of mm_write_sam_hdr (format.c:116-135; main.c:369 passes MM_VERSION and its own
+ * argv): `\tVN:<ver>` and `\tCL:minimap2 <argv[1..]>` appended to the @PG line of every header written afterwards.
+ * Process-wide; NULL / argc <= 1 leave the respective part out (the default). */
+void al_set_program_line(const char *ver, int argc, char *const *argv);
 int  al_write_sam_hdr(FILE *out, const al_idx_t *mi, const char *rg, char *rg_id_out /* >=256 bytes or NULL */);
 int  al_write_sam(char *buf, size_t cap, const al_idx_t *mi, const char *qname, int l_seq, const char *seq, const char *qual,
                   int seg_idx, int reg_idx, int n_seg, const int *n_regss, const al_reg1_t *const *regss,

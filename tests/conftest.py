@@ -9,6 +9,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+# The goldens' @PG line has no VN:/CL: (the reference driver that made them has no argv to pass, oracle/ref_driver.c): the CLI
+# is run with the bare line except in the test that pins VN:/CL: against the fork's own main() (test_pg_line_*).
+os.environ.setdefault("AL_PG_PLAIN", "1")
 
 
 def pytest_configure(config):

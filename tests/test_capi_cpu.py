@@ -154,6 +154,35 @@ def test_sam_header(A, golden_unpacked, tmp_path):
     idx.close()
 
 
+def test_pg_line_matches_the_forks_main(A, golden_unpacked, tmp_path):
+    """@PG VN:/CL: (main.c:369 -> format.c:126-133): al_set_program_line + al_write_sam_hdr print the line the fork's own
+    main() prints for the same argv (oracle/_ref/mm2count = the fork as shipped: header, then its candidate counter)."""
+    mm2count = os.path.join(ROOT, "oracle", "_ref", "mm2count")
+    if not os.path.exists(mm2count):
+        pytest.skip("reference build absent")
+    d = golden_unpacked["g1_mt150pe"]
+    args = ["-ax", "sr", "-t", "2", "-R", "@RG\\tID:S1\\tSM:S1", "MT-human.fa", "g1_1.fq", "g1_2.fq"]
+    r = subprocess.run([mm2count] + args, cwd=d, capture_output=True, text=True)
+    exp = [l for l in r.stdout.split("\n") if l.startswith("@")]
+    assert exp and exp[-1].startswith("@PG\tID:minimap2\tPN:minimap2\tVN:") and "\tCL:minimap2 -ax sr" in exp[-1]
+    ver = subprocess.run([mm2count, "--version"], capture_output=True, text=True).stdout.strip()
+    hdr = open(os.path.join(ROOT, "include", "airlift.h")).read()
+    assert '#define AL_MM_VERSION "%s"' % ver in hdr
+    idx = A.Index(fasta=os.path.join(d, "MT-human.fa"))
+    L = A.load()
+    argv = (C.c_char_p * (len(args) + 1))(b"airlift-align", *[a.encode() for a in args])
+    L.al_set_program_line(ver.encode(), len(args) + 1, argv)
+    libc = C.CDLL(None); libc.fopen.restype = C.c_void_p; libc.fopen.argtypes = [C.c_char_p, C.c_char_p]; libc.fclose.argtypes = [C.c_void_p]
+    p = str(tmp_path / "h.sam").encode()
+    fp = libc.fopen(p, b"w")
+    L.al_write_sam_hdr.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_char_p]
+    L.al_write_sam_hdr(fp, idx.h, args[5].encode(), None)
+    libc.fclose(fp)
+    L.al_set_program_line(None, 0, None)
+    assert open(p.decode()).read().split("\n")[:-1] == exp
+    idx.close()
+
+
 @pytest.mark.parametrize("lanes,offsets", [(1, 0), (2, 1), (2, 0), (5, 1), (8, 1), (8, 0)])
 def test_multi_lane_output_order(A, tmp_path, lanes, offsets):
     """Product path of N>1 (al_map_file_frag_multi): lanes finish their blocks in any order, the output file must hold

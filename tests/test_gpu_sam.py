@@ -45,6 +45,21 @@ def test_cli_sam_identical(golden_unpacked, name):
     assert r.stdout == exp, _diff_report(r.stdout, exp, name)
 
 
+def test_cli_pg_line_as_the_forks_main(golden_unpacked):
+    """Without AL_PG_PLAIN the drop-in prints @PG the way main.c:369 does: VN = the fork's MM_VERSION, CL = its own argv;
+    everything else is the golden's bytes.  (The format is pinned against the fork's main() in tests/test_capi_cpu.py.)"""
+    d = golden_unpacked["g1_mt150pe"]
+    m = json.load(open(os.path.join(d, "meta.json")))
+    args = ["-ax", "sr", "-t", "2", "-R", m["rg"], m["ref"]] + m["reads"]
+    env = {k: v for k, v in os.environ.items() if k != "AL_PG_PLAIN"}
+    r = subprocess.run([CLI] + args, cwd=d, capture_output=True, env=env)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    exp = open(os.path.join(d, "expected.sam"), "rb").read()
+    bare = b"@PG\tID:minimap2\tPN:minimap2\n"
+    assert bare in exp
+    assert r.stdout == exp.replace(bare, b"@PG\tID:minimap2\tPN:minimap2\tVN:2.17-r954-dirty\tCL:minimap2 " + " ".join(args).encode() + b"\n")
+
+
 @pytest.mark.parametrize("name", ["g2_250pe", "g3_adversarial"])
 def test_lds_dp_path_identical(golden_unpacked, name):
     """AL_DBG=128 forces every extension through the LDS-row DP (the path long targets take) instead of the

@@ -1,6 +1,7 @@
 #!/bin/bash
 # end-to-end wall clock of the CLI (FASTQ in -> SAM out) against the CPU comparator on the same files: tools/e2e.sh [pairs]
 PAIRS=${1:-500000}
+export AL_PG_PLAIN=1
 REPO=${GRAFT_REPO_ROOT:-/root/repo}; D=/tmp/al_e2e; mkdir -p $D
 python3 - <<PY
 import sys; sys.path.insert(0, "$REPO/tools")

@@ -1,5 +1,6 @@
 #!/bin/bash
 # steady-state rate of the drop-in on C4: 2 M pairs from files, one lane vs two lanes on the GPU, vs the reference
+export AL_PG_PLAIN=1
 REPO=${GRAFT_REPO_ROOT:-/root/repo}; O=$REPO/gpurun_out/${TAG:-r2cli}; mkdir -p $O
 export AL_REF_CACHE=/tmp/alcache
 python3 - <<PY
