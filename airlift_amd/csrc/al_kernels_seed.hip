@@ -378,25 +378,91 @@ k_anchor_sort(const uint64_t *__restrict__ pos, const uint32_t *__restrict__ fra
 	if (fallback && lane == 0) tie_list[f] = 1u;                           // merged by k_anchor_heap
 }
 
-// K3 for fragments of 1025 .. CAP anchors (reads inside interspersed repeats): one 256-thread block per fragment.  An anchor is ONE
-// 64-bit LDS word  (strand | contig | position) << 16 | list  (needs 33 + contig bits + 16 <= 64: the caller sends other
-// indexes to the device-wide sort), the match records of the lists sit in LDS next to it, every thread issues its position loads
-// back to back, then a bitonic network across the block; y is rebuilt from the list's match record when the anchors are
-// written out.  Equal x -> exact heap merge, as in the other sort kernels.
-template <int CAP, int NT>     // NT threads; the key tile (8 CAP bytes) is dynamic LDS: 2048 / 4096 with 256 threads, 8192 with 512, 16384 with 1024 (one block per CU)
-__global__ void __launch_bounds__(NT)
-k_anchor_sort_blk(const uint64_t *__restrict__ pos, const uint32_t *__restrict__ frag_first, const uint32_t *__restrict__ rd_len,
+// ---------------------------------------------------------------------------------------------
+// K3, register network, for fragments of 65 .. 8192 anchors (reads inside interspersed repeats).  An anchor is ONE 64-bit key
+// (strand | contig | position) << 16 | list  (needs 33 + contig bits + 16 <= 64: the caller sends other indexes to k_anchor_sort /
+// the device-wide sort); y is rebuilt from the list's match record when the anchors are written out; equal x -> exact heap merge,
+// as in the other sort kernels.  The bitonic network runs on PER keys per thread held in registers.  Element e = thread * PER + r: compare-exchange distances below PER are register-to-register, distances inside a
+// wavefront are cross-lane moves (DPP quad permutes, ds_swizzle, ds_bpermute: no LDS storage, no barrier), and only the top
+// log2(NW) bits of the index go through an LDS exchange (three rounds for 4096 keys on 4 waves, against 78 LDS passes with a
+// barrier each in the plain network).  All comparators ascend: the first step of a merge level pairs e with e ^ (kk - 1).
+// ---------------------------------------------------------------------------------------------
+template <int M> __device__ __forceinline__ uint32_t d_lane_xor32(uint32_t v, int lane)
+{
+	if (M == 1) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xf, 0xf, true);          // quad_perm [1,0,3,2]
+	else if (M == 2) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xf, 0xf, true);     // quad_perm [2,3,0,1]
+	else if (M == 3) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x1B, 0xf, 0xf, true);     // quad_perm [3,2,1,0]
+	else if (M < 32) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x1f | ((M & 31) << 10));   // bit mode: and 0x1f, or 0, xor M
+	else return (uint32_t)__builtin_amdgcn_ds_bpermute(((lane ^ M) & 63) << 2, (int)v);
+}
+template <int M> __device__ __forceinline__ uint64_t d_lane_xor64(uint64_t v, int lane)
+{
+	return (uint64_t)d_lane_xor32<M>((uint32_t)v, lane) | (uint64_t)d_lane_xor32<M>((uint32_t)(v >> 32), lane) << 32;
+}
+__device__ __forceinline__ void d_cx64(uint64_t &a, uint64_t &b) { const bool sw = a > b; const uint64_t lo = sw ? b : a, hi = sw ? a : b; a = lo; b = hi; }
+
+// one cross-thread step: partner thread T ^ TM, partner register PER-1-r (FLIP: first step of a level) or r
+template <int PER, int NT, int TM, bool FLIP>
+__device__ __forceinline__ void d_bt_x(uint64_t (&k)[PER], uint64_t *sx, const int T)
+{
+	constexpr int TOP = 1 << (31 - __builtin_clz((unsigned)TM));
+	const bool lower = (T & TOP) == 0;
+	uint64_t p[PER];
+	if (TM < 64) {
+		const int lane = T & 63;
+#pragma unroll
+		for (int r = 0; r < PER; ++r) p[r] = d_lane_xor64<(TM < 64 ? TM : 1)>(k[FLIP ? PER - 1 - r : r], lane);
+	} else {                                                          // across wavefronts: register-major LDS tile, conflict-free both ways
+		__syncthreads();
+#pragma unroll
+		for (int r = 0; r < PER; ++r) sx[r * NT + T] = k[r];
+		__syncthreads();
+#pragma unroll
+		for (int r = 0; r < PER; ++r) p[r] = sx[(FLIP ? PER - 1 - r : r) * NT + (T ^ TM)];
+	}
+#pragma unroll
+	for (int r = 0; r < PER; ++r) { const bool gt = k[r] > p[r]; k[r] = (gt == lower) ? p[r] : k[r]; }
+}
+template <int PER, int NT, int J>
+__device__ __forceinline__ void d_bt_down(uint64_t (&k)[PER], uint64_t *sx, const int T)
+{
+	if constexpr (J >= 1) {
+		if constexpr (J >= PER) d_bt_x<PER, NT, J / PER, false>(k, sx, T);
+		else {
+#pragma unroll
+			for (int r = 0; r < PER; ++r) if ((r & J) == 0) d_cx64(k[r], k[r | J]);
+		}
+		d_bt_down<PER, NT, J / 2>(k, sx, T);
+	}
+}
+template <int PER, int NT, int KK>
+__device__ __forceinline__ void d_bt_levels(uint64_t (&k)[PER], uint64_t *sx, const int T)
+{
+	if constexpr (KK <= PER * NT) {
+		if constexpr (KK <= PER) {
+#pragma unroll
+			for (int r = 0; r < PER; ++r) { const int r2 = r ^ (KK - 1); if (r < r2) d_cx64(k[r], k[r2]); }
+		} else d_bt_x<PER, NT, KK / PER - 1, true>(k, sx, T);
+		d_bt_down<PER, NT, KK / 4>(k, sx, T);
+		d_bt_levels<PER, NT, KK * 2>(k, sx, T);
+	}
+}
+
+// One block of NT = 64 NW threads per fragment of at most PER * NT anchors and MCAP occurrence lists.
+template <int PER, int NW, int MCAP>
+__global__ void __launch_bounds__(64 * NW)
+k_anchor_sort_reg(const uint64_t *__restrict__ pos, const uint32_t *__restrict__ frag_first, const uint32_t *__restrict__ rd_len,
                   const uint64_t *__restrict__ mini_off, const AlMatch *__restrict__ match,
                   const uint32_t *__restrict__ frag_nm, const uint32_t *__restrict__ frag_na, const uint64_t *__restrict__ a_off,
                   AlAnchor *__restrict__ anchors, uint32_t *__restrict__ tie_list,
                   const uint32_t *__restrict__ frag_list, int n_list, int mini_span, int rid_bits)
 {
-	constexpr int MCAP = 1024;                          // occurrence lists per fragment (query minimizers that passed the filter)
-	constexpr int PER = CAP / NT;
-	extern __shared__ __align__(16) unsigned char s_dyn[];
-	uint64_t *const sx = (uint64_t *)s_dyn;
+	constexpr int NT = 64 * NW, CAP = PER * NT;
+	constexpr int PADW = CAP + CAP / 16 + 2;                // output transpose: one pad word per 16 keys
+	__shared__ uint64_t sx[PADW];
 	__shared__ uint32_t pre[MCAP + 1];
-	__shared__ uint32_t m_off[MCAP], m_fl[MCAP], m_qp[MCAP];   // match records: off_lo, flags, q_pos
+	constexpr bool MLDS = NW > 1;                           // match records in LDS (block kernels); the one-wave kernels read them through L1 / L2
+	__shared__ uint32_t m_off[MLDS ? MCAP : 1], m_fl[MLDS ? MCAP : 1], m_qp[MLDS ? MCAP : 1];   // off_lo, flags, q_pos
 	__shared__ uint32_t s_part[NT];
 	__shared__ int s_flag;
 	const int tid = threadIdx.x;
@@ -413,66 +479,65 @@ k_anchor_sort_blk(const uint64_t *__restrict__ pos, const uint32_t *__restrict__
 	{   // exclusive prefix sums of the list lengths: LPT lists per thread, block scan of the partial sums
 		constexpr int LPT = (MCAP + NT - 1) / NT;
 		uint32_t v[LPT], sum = 0;
+#pragma unroll
 		for (int j = 0; j < LPT; ++j) {
 			const uint32_t i = (uint32_t)tid * LPT + j; v[j] = 0;
-			if (i < n_m) { const AlMatch mm = m[i]; v[j] = mm.n; m_off[i] = mm.off_lo; m_fl[i] = mm.flags; m_qp[i] = mm.q_pos; }
+			if (i < n_m) { const AlMatch mm = m[i]; v[j] = mm.n; if (MLDS) { m_off[i] = mm.off_lo; m_fl[i] = mm.flags; m_qp[i] = mm.q_pos; } }
 			sum += v[j];
 		}
-		s_part[tid] = sum;
-		__syncthreads();
-		for (int d = 1; d < NT; d <<= 1) { const uint32_t t = tid >= d ? s_part[tid - d] : 0u; __syncthreads(); s_part[tid] += t; __syncthreads(); }
-		uint32_t run = s_part[tid] - sum;
+		uint32_t incl = sum;                                              // wave scan, then the wave totals through LDS
+		for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(incl, d); if ((tid & 63) >= d) incl += t; }
+		if (NW > 1) {
+			if ((tid & 63) == 63) s_part[tid >> 6] = incl;
+			__syncthreads();
+			for (int w = 0; w < (tid >> 6); ++w) incl += s_part[w];
+		}
+		uint32_t run = incl - sum;
+#pragma unroll
 		for (int j = 0; j < LPT; ++j) { const uint32_t i = (uint32_t)tid * LPT + j; if (i <= n_m) pre[i] = run; run += v[j]; }
 	}
 	__syncthreads();
-	int npow2 = 1; while ((uint32_t)npow2 < n) npow2 <<= 1;
 	const int sb = 32 + rid_bits;                                           // strand bit of the compact key
-	{   // expansion: owner list by binary search over the prefix sums (LDS), then all of the thread's position loads in flight at once
-		uint64_t rr[PER]; uint32_t mi[PER];
+	uint64_t k[PER];
+	{   // expansion, element t = tid + j NT (coalesced position loads); the network does not care where a key starts
+		uint64_t rr[PER]; uint32_t mi[PER], qb[PER];
 #pragma unroll
 		for (int j = 0; j < PER; ++j) {
-			const uint32_t t = (uint32_t)tid + (uint32_t)j * (uint32_t)NT; rr[j] = 0; mi[j] = 0;
+			const uint32_t t = (uint32_t)tid + (uint32_t)j * (uint32_t)NT; rr[j] = 0; mi[j] = 0; qb[j] = 0;
 			if (t < n) {
 				uint32_t lo = 0, hi = n_m;                                   // last list with pre[list] <= t
 				while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (pre[mid] <= t) lo = mid; else hi = mid; }
 				mi[j] = lo;
-				rr[j] = d_match_pos(pos, m_off[lo], m_fl[lo], t - pre[lo]);
+				if (MLDS) { rr[j] = d_match_pos(pos, m_off[lo], m_fl[lo], t - pre[lo]); qb[j] = m_qp[lo]; }
+				else { const AlMatch mm = m[lo]; rr[j] = d_match_pos(pos, mm.off_lo, mm.flags, t - pre[lo]); qb[j] = mm.q_pos; }
 			}
 		}
 #pragma unroll
 		for (int j = 0; j < PER; ++j) {
 			const uint32_t t = (uint32_t)tid + (uint32_t)j * (uint32_t)NT;
-			if (t < (uint32_t)npow2) {
-				uint64_t key = UINT64_MAX;
-				if (t < n) {
-					const uint64_t r = rr[j]; const bool rev = (r & 1) != (m_qp[mi[j]] & 1);      // map.c:176-190
-					key = ((uint64_t)(rev ? 1 : 0) << sb | (r >> 32) << 32 | (uint32_t)((uint32_t)r >> 1)) << 16 | mi[j];
-				}
-				sx[t] = key;
+			uint64_t key = UINT64_MAX;
+			if (t < n) {
+				const uint64_t r = rr[j]; const bool rev = (r & 1) != (qb[j] & 1);      // map.c:176-190
+				key = ((uint64_t)(rev ? 1 : 0) << sb | (r >> 32) << 32 | (uint32_t)((uint32_t)r >> 1)) << 16 | mi[j];
 			}
+			k[j] = key;
 		}
 	}
+	d_bt_levels<PER, NT, 2>(k, sx, tid);
 	__syncthreads();
-	for (int kk = 2; kk <= npow2; kk <<= 1)
-		for (int j = kk >> 1; j > 0; j >>= 1) {
-			for (int i = tid; i < npow2; i += NT) {
-				const int ixj = i ^ j;
-				if (ixj > i) {
-					const uint64_t a = sx[i], b = sx[ixj];
-					if ((a > b) == ((i & kk) == 0)) { sx[i] = b; sx[ixj] = a; }
-				}
-			}
-			__syncthreads();
-		}
+#pragma unroll
+	for (int r = 0; r < PER; ++r) { const int e = tid * PER + r; sx[e + (e >> 4)] = k[r]; }
+	__syncthreads();
 	int tie = 0;
-	for (uint32_t t = tid; t + 1 < n; t += NT) if ((sx[t] >> 16) == (sx[t + 1] >> 16)) tie = 1;
+	for (uint32_t t = tid; t + 1 < n; t += NT) if ((sx[t + (t >> 4)] >> 16) == (sx[t + 1 + ((t + 1) >> 4)] >> 16)) tie = 1;
 	if (tie) s_flag = 1;
 	__syncthreads();
 	if (s_flag) { if (tid == 0) tie_list[f] = 1u; return; }                // merged by k_anchor_heap
 	const uint64_t lowmask = (1ULL << sb) - 1;
 	for (uint32_t t = tid; t < n; t += NT) {
-		const uint64_t key = sx[t]; const uint32_t i = (uint32_t)key & 0xffffu; const uint64_t kx = key >> 16;
-		const uint32_t qp = m_qp[i], fl = m_fl[i], span = (uint32_t)mini_span;
+		const uint64_t key = sx[t + (t >> 4)]; const uint32_t i = (uint32_t)key & 0xffffu; const uint64_t kx = key >> 16;
+		uint32_t qp, fl; const uint32_t span = (uint32_t)mini_span;
+		if (MLDS) { qp = m_qp[i]; fl = m_fl[i]; } else { const AlMatch mm = m[i]; qp = mm.q_pos; fl = mm.flags; }
 		AlAnchor a; a.x = (kx & lowmask) | (kx >> sb & 1) << 63;
 		a.y = (a.x >> 63) ? (uint64_t)span << 32 | (uint32_t)(qlen - ((int)(qp >> 1) + 1 - (int)span) - 1) : (uint64_t)span << 32 | (qp >> 1);
 		a.y |= (uint64_t)(fl & 0xff) << AL_SEED_SEG_SHIFT;
@@ -480,8 +545,8 @@ k_anchor_sort_blk(const uint64_t *__restrict__ pos, const uint32_t *__restrict__
 		out[t] = a;
 	}
 }
-#define INST_SORT_BLK(C, T) template __global__ void k_anchor_sort_blk<C, T>(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, uint32_t *, const uint32_t *, int, int, int);
-INST_SORT_BLK(2048, 256) INST_SORT_BLK(4096, 256) INST_SORT_BLK(8192, 512)
+#define INST_SORT_REG(P, W, M) template __global__ void k_anchor_sort_reg<P, W, M>(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, uint32_t *, const uint32_t *, int, int, int);
+INST_SORT_REG(2, 1, 128) INST_SORT_REG(4, 1, 256) INST_SORT_REG(8, 1, 512) INST_SORT_REG(16, 1, 512) INST_SORT_REG(8, 4, 1024) INST_SORT_REG(16, 4, 1024) INST_SORT_REG(16, 8, 1024)
 
 // K3 for fragments above the LDS tiles (reads inside high-copy families, the max_occ re-chain pass: up to 42 x 5000 anchors):
 // their anchors are expanded unsorted with a composite key  (rank of the fragment in the list) << key_bits | strand | contig |

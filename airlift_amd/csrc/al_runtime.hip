@@ -23,7 +23,7 @@ __global__ void k_anchor_sort_small(const uint64_t *, const uint32_t *, const ui
 template <int HCAP, int LANES> __global__ void k_anchor_heap(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, AlAnchor *, const uint32_t *, const uint32_t *, int, int, unsigned long long *, int);
 template <int CAP> __global__ void k_chain(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, AlAnchor *, uint64_t *, uint32_t *, int32_t *, uint64_t *, const uint32_t *, int, AlParams, unsigned long long *, ChainSeg);
 template <int CAPL, int LANES> __global__ void k_chain_lds(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, AlAnchor *, uint64_t *, uint32_t *, uint64_t *, const uint32_t *, int, int, AlParams, unsigned long long *, ChainSeg);
-template <int CAP, int NT> __global__ void k_anchor_sort_blk(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, uint32_t *, const uint32_t *, int, int, int);
+template <int PER, int NW, int MCAP> __global__ void k_anchor_sort_reg(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, uint32_t *, const uint32_t *, int, int, int);
 __global__ void k_anchor_big_expand(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint32_t *, int, const uint64_t *, uint64_t *, uint64_t *, int, int);
 __global__ void k_anchor_big_scatter(const uint64_t *, const uint64_t *, const uint32_t *, int, const uint64_t *, const uint64_t *, AlAnchor *, uint32_t *, int);
 __global__ void k_seg_scan(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *, int, AlParams, int, int, const uint64_t *, uint32_t *, uint64_t *, uint32_t *, uint32_t *, const uint32_t *, uint32_t *);
@@ -36,7 +36,7 @@ static const char *g_stage_names[ST_N] = { "sketch", "seed_lookup", "scan", "siz
                                            "chain_lds32", "chain_lds48", "chain_lds64", "chain_lds128", "seg_find", "seg_chain_lds", "seg_chain_wave", "seg_merge", "rechain",
                                            "regs", "ext_prep", "ext_sort", "ext_dp_lane", "ext_dp_g4", "ext_dp_g8", "ext_dp_g22", "ext_finish", "compact" };
 // kernel behind each interval (what rocprofv3 --kernel-trace lists); "" = several launches
-static const char *g_stage_kernels[ST_N] = { "k_sketch", "k_seed", "", "", "k_anchor_sort_small", "k_anchor_sort<1024>", "k_anchor_sort_blk<4096>", "", "",
+static const char *g_stage_kernels[ST_N] = { "k_sketch", "k_seed", "", "", "k_anchor_sort_small", "k_anchor_sort_reg<16,1>", "k_anchor_sort_reg<16,4>", "", "",
                                              "k_chain_lds<16|24|32, 64>", "k_chain_lds<40|48, 64>", "k_chain_lds<64, 64>", "k_chain_lds<80|96, 64>, <128, 32>", "", "", "k_chain<384>", "",  "",
                                              "k_regs", "k_ext_prep", "", "k_ext_dp_lane<16|32, 64>", "k_ext_dp<1|2|4, 512, ..>", "k_ext_dp<8, 512, 128>", "k_ext_dp<22, 512, 352>", "k_ext_finish", "k_compact" };
 extern "C" const char *al_stage_kernel(int i) { return i >= 0 && i < ST_N ? g_stage_kernels[i] : ""; }
@@ -394,16 +394,17 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 	if (first) hipLaunchKernelGGL(k_iota_u32, dim3((nl + 255) / 256), dim3(256), 0, s, c->chain_idx.p, (uint32_t)nl);
 	if (sort_u32_pairs(c, first ? c->frag_na.p : c->tmp_u32.p, c->chain_key.p, first ? c->chain_idx.p : list, c->chain_idx2.p, nl)) return -1;
 	const uint32_t *order = c->chain_idx2.p;
-	uint32_t lb[9];
+	uint32_t lb[11];
 	{   // AL_TEST_SORT_BLK / AL_TEST_SORT_BIG (tests): smallest anchor count that goes to the block / device-wide sort
 		static const char *e1 = getenv("AL_TEST_SORT_BLK"), *e2 = getenv("AL_TEST_SORT_BIG");
 		uint32_t t_blk = e1 ? (uint32_t)atoi(e1) : 1025u, t_big = e2 ? (uint32_t)atoi(e2) : 4097u;   // (8192 and 16384 tiles -- 512 / 1024 threads, one or two blocks per CU -- measured slower than the device-wide sort)
 		if (t_blk < 65u) t_blk = 65u; if (t_blk > 1025u) t_blk = 1025u; if (t_big < t_blk) t_big = t_blk; if (t_big > 8193u) t_big = 8193u;
 		{ int rb = 1; while ((1ULL << rb) < c->mi->seq.size()) ++rb; if (33 + rb + 16 > 64) t_big = t_blk; }   // compact keys of the block sort: strand | contig | position | list in 64 bits
-		const uint32_t thr[9] = {65, 81, 97, 129, t_blk, t_big, std::min(std::max(t_blk, 2049u), t_big), std::min(std::max(t_blk, 4097u), t_big), std::min(std::max(t_blk, 8193u), t_big)};
-		if (lower_bounds(c, c->chain_key.p, (uint32_t)nl, thr, 9, lb)) return -1;
+		const uint32_t thr[11] = {65, 81, 97, 129, t_blk, t_big, std::min(std::max(t_blk, 2049u), t_big), std::min(std::max(t_blk, 4097u), t_big), std::min(std::max(t_blk, 8193u), t_big),
+		                          std::min(257u, t_blk), std::min(513u, t_blk)};
+		if (lower_bounds(c, c->chain_key.p, (uint32_t)nl, thr, 11, lb)) return -1;
 	}
-	const uint32_t lb65 = lb[0], lb81 = lb[1], lb97 = lb[2], lb129 = lb[3], lb1025 = lb[4], lb_big = lb[5], lb2049 = lb[6], lb4097 = lb[7], lb8193 = lb[8];
+	const uint32_t lb65 = lb[0], lb81 = lb[1], lb97 = lb[2], lb129 = lb[3], lb1025 = lb[4], lb_big = lb[5], lb2049 = lb[6], lb4097 = lb[7], lb8193 = lb[8], lb257 = lb[9], lb513 = lb[10];
 	if (ev(ST_ORDER)) return -1;
 	{
 		if (c->tie_list.ensure((size_t)c->n_frag + 2)) return -1;         // one flag per fragment id
@@ -412,21 +413,16 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 		if (lb65 > 0) hipLaunchKernelGGL(k_anchor_sort_small, dim3(lb65), dim3(64), 0, s, c->di.pos, c->frag_first.p, c->rd_len.p, c->mini_off.p, c->match.p, c->frag_nm.p, c->frag_na.p,
 		                                 c->a_off.p, c->anchors.p, c->tie_list.p, tie_cnt, order, (int)lb65, c->counters.p, c->mi->k);
 		if (ev(ST_ANCHOR_SORT_S)) return -1;
-		if (lb1025 > lb65) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_anchor_sort<1024>), dim3(lb1025 - lb65), dim3(64), 0, s, c->di.pos, c->frag_first.p, c->rd_len.p, c->mini_off.p, c->match.p, c->frag_nm.p, c->frag_na.p,
-		                                      c->a_off.p, c->anchors.p, c->tie_list.p, tie_cnt, order + lb65, (int)(lb1025 - lb65), c->counters.p, c->mi->k);
-		if (ev(ST_ANCHOR_SORT)) return -1;
 		int rid_bits = 1; while ((1ULL << rid_bits) < c->mi->seq.size()) ++rid_bits;
-		{
-#define LBLK(C, T, A, B) do { if ((B) > (A)) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_anchor_sort_blk<C, T>), dim3((B) - (A)), dim3(T), (size_t)C * 8, s, c->di.pos, c->frag_first.p, c->rd_len.p, c->mini_off.p, c->match.p, c->frag_nm.p, c->frag_na.p, \
+		const bool compact = 33 + rid_bits + 16 <= 64;                   // strand | contig | position | list in one 64-bit key
+#define LREG(P, W, M, A, B) do { if ((B) > (A)) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_anchor_sort_reg<P, W, M>), dim3((B) - (A)), dim3(64 * W), 0, s, c->di.pos, c->frag_first.p, c->rd_len.p, c->mini_off.p, c->match.p, c->frag_nm.p, c->frag_na.p, \
 		                                        c->a_off.p, c->anchors.p, c->tie_list.p, order + (A), (int)((B) - (A)), c->mi->k, rid_bits); } while (0)
-			static bool attr_set = false;
-			if (!attr_set) {
-				AL_HIP_CHECK(hipFuncSetAttribute((const void *)k_anchor_sort_blk<8192, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8));
-				attr_set = true;
-			}
-			LBLK(2048, 256, lb1025, lb2049); LBLK(4096, 256, lb2049, lb4097); LBLK(8192, 512, lb4097, lb_big);
-#undef LBLK
-		}
+		if (compact) { LREG(2, 1, 128, lb65, std::min(lb129, lb1025)); LREG(4, 1, 256, lb129, lb257); LREG(8, 1, 512, lb257, lb513); LREG(16, 1, 512, lb513, lb1025); }
+		else if (lb1025 > lb65) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_anchor_sort<1024>), dim3(lb1025 - lb65), dim3(64), 0, s, c->di.pos, c->frag_first.p, c->rd_len.p, c->mini_off.p, c->match.p, c->frag_nm.p, c->frag_na.p,
+		                                           c->a_off.p, c->anchors.p, c->tie_list.p, tie_cnt, order + lb65, (int)(lb1025 - lb65), c->counters.p, c->mi->k);
+		if (ev(ST_ANCHOR_SORT)) return -1;
+		LREG(8, 4, 1024, lb1025, lb2049); LREG(16, 4, 1024, lb2049, lb4097); LREG(16, 8, 1024, lb4097, lb_big);   // (non-compact keys: t_big == t_blk, empty ranges)
+#undef LREG
 		if (ev(ST_ANCHOR_SORT_BLK)) return -1;
 		// above the LDS tiles: composite-key device radix sort, a chunk of fragments at a time so that rank + key bits fit 64
 		const int kb = 33 + rid_bits;
