@@ -397,7 +397,7 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 	uint32_t lb[11];
 	{   // AL_TEST_SORT_BLK / AL_TEST_SORT_BIG (tests): smallest anchor count that goes to the block / device-wide sort
 		static const char *e1 = getenv("AL_TEST_SORT_BLK"), *e2 = getenv("AL_TEST_SORT_BIG");
-		uint32_t t_blk = e1 ? (uint32_t)atoi(e1) : 1025u, t_big = e2 ? (uint32_t)atoi(e2) : 4097u;   // (8192 and 16384 tiles -- 512 / 1024 threads, one or two blocks per CU -- measured slower than the device-wide sort)
+		uint32_t t_blk = e1 ? (uint32_t)atoi(e1) : 1025u, t_big = e2 ? (uint32_t)atoi(e2) : 8193u;   // above 8192 anchors: device-wide radix sort
 		if (t_blk < 65u) t_blk = 65u; if (t_blk > 1025u) t_blk = 1025u; if (t_big < t_blk) t_big = t_blk; if (t_big > 8193u) t_big = 8193u;
 		{ int rb = 1; while ((1ULL << rb) < c->mi->seq.size()) ++rb; if (33 + rb + 16 > 64) t_big = t_blk; }   // compact keys of the block sort: strand | contig | position | list in 64 bits
 		const uint32_t thr[11] = {65, 81, 97, 129, t_blk, t_big, std::min(std::max(t_blk, 2049u), t_big), std::min(std::max(t_blk, 4097u), t_big), std::min(std::max(t_blk, 8193u), t_big),
