@@ -549,57 +549,58 @@ k_anchor_sort_reg(const uint64_t *__restrict__ pos, const uint32_t *__restrict__
 INST_SORT_REG(2, 1, 128) INST_SORT_REG(4, 1, 256) INST_SORT_REG(8, 1, 512) INST_SORT_REG(16, 1, 512) INST_SORT_REG(8, 4, 1024) INST_SORT_REG(16, 4, 1024) INST_SORT_REG(16, 8, 1024)
 
 // K3 for fragments above the LDS tiles (reads inside high-copy families, the max_occ re-chain pass: up to 42 x 5000 anchors):
-// their anchors are expanded unsorted with a composite key  (rank of the fragment in the list) << key_bits | strand | contig |
-// position, one device-wide radix sort (rocPRIM) puts every fragment's anchors in x order at consecutive places, and
-// k_anchor_big_scatter writes them back to the fragment's anchor range.  One wavefront per 64 anchors of a fragment.
+// their anchors are expanded unsorted as ONE 64-bit key each,  ((rank of the fragment in the chunk) | strand | contig | position) << 16 |
+// list  with contig and position at the widths this index needs, a device-wide keys-only radix sort (rocPRIM) over the bits above
+// the list puts every fragment's anchors in x order at consecutive places, and k_anchor_big_scatter rebuilds (x, y) from the key and
+// the list's match record into the fragment's anchor range (8 bytes per anchor and pass instead of 16).  One wavefront per 64 anchors of a fragment.
 __global__ void __launch_bounds__(256)
-k_anchor_big_expand(const uint64_t *__restrict__ pos, const uint32_t *__restrict__ frag_first, const uint32_t *__restrict__ rd_len,
-                    const uint64_t *__restrict__ mini_off, const AlMatch *__restrict__ match,
-                    const uint32_t *__restrict__ frag_nm, const uint32_t *__restrict__ frag_na,
-                    const uint32_t *__restrict__ frag_list, int n_list, const uint64_t *__restrict__ big_off /* n_list + 1 */,
-                    uint64_t *__restrict__ keys, uint64_t *__restrict__ vals, int rid_bits, int mini_span)
+k_anchor_big_expand(const uint64_t *__restrict__ pos, const uint64_t *__restrict__ mini_off, const uint32_t *__restrict__ frag_first, const AlMatch *__restrict__ match,
+                    const uint32_t *__restrict__ frag_nm, const uint32_t *__restrict__ frag_list, int n_list, const uint64_t *__restrict__ big_off /* n_list + 1 */,
+                    uint64_t *__restrict__ keys, int rid_bits, int pos_bits)
 {
 	// one block per fragment; lists are walked one after the other, 256 positions at a time (coalesced 8-byte reads)
 	if ((int)blockIdx.x >= n_list) return;
 	const uint32_t f = frag_list[blockIdx.x];
 	const uint32_t n_m = frag_nm[f];
-	const uint32_t r0 = frag_first[f], r1 = frag_first[f + 1];
-	int qlen = 0; for (uint32_t r = r0; r < r1; ++r) qlen += (int)rd_len[r];
-	const AlMatch *m = match + mini_off[r0];
-	const int kb = 33 + rid_bits;
-	const uint64_t rank = (uint64_t)blockIdx.x << kb;
+	const AlMatch *m = match + mini_off[frag_first[f]];
+	const int sb = rid_bits + pos_bits;                                    // strand bit of the x part
+	const uint64_t rank = (uint64_t)blockIdx.x << (sb + 1);
 	uint64_t o = big_off[blockIdx.x];
 	for (uint32_t i = 0; i < n_m; ++i) {
 		const AlMatch mm = m[i];
-		const uint32_t span = (uint32_t)mini_span;
 		for (uint32_t t = threadIdx.x; t < mm.n; t += 256) {
 			const uint64_t r = d_match_pos(pos, mm.off_lo, mm.flags, t);
 			const bool rev = (r & 1) != (mm.q_pos & 1);
-			const uint64_t key = rank | (uint64_t)(rev ? 1 : 0) << (kb - 1) | (r >> 32) << 32 | (uint32_t)((uint32_t)r >> 1);
-			uint64_t y = rev ? (uint64_t)span << 32 | (uint32_t)(qlen - ((int)(mm.q_pos >> 1) + 1 - (int)span) - 1) : (uint64_t)span << 32 | (mm.q_pos >> 1);
-			y |= (uint64_t)(mm.flags & 0xff) << AL_SEED_SEG_SHIFT;
-			if (mm.flags & (1u << 8)) y |= AL_SEED_TANDEM;
-			keys[o + t] = key; vals[o + t] = y;
+			keys[o + t] = (rank | (uint64_t)(rev ? 1 : 0) << sb | (r >> 32) << pos_bits | (uint32_t)((uint32_t)r >> 1)) << 16 | (i & 0xffffu);
 		}
 		o += mm.n;
 	}
 }
 __global__ void __launch_bounds__(256)
-k_anchor_big_scatter(const uint64_t *__restrict__ keys, const uint64_t *__restrict__ vals, const uint32_t *__restrict__ frag_list, int n_list,
-                     const uint64_t *__restrict__ big_off, const uint64_t *__restrict__ a_off, AlAnchor *__restrict__ anchors,
-                     uint32_t *__restrict__ tie_list, int rid_bits)
+k_anchor_big_scatter(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ frag_list, int n_list,
+                     const uint64_t *__restrict__ big_off, const uint64_t *__restrict__ a_off,
+                     const uint64_t *__restrict__ mini_off, const uint32_t *__restrict__ frag_first, const uint32_t *__restrict__ rd_len, const AlMatch *__restrict__ match,
+                     const uint32_t *__restrict__ frag_nm, AlAnchor *__restrict__ anchors, uint32_t *__restrict__ tie_list, int rid_bits, int pos_bits, int mini_span)
 {
 	if ((int)blockIdx.x >= n_list) return;
 	const uint32_t f = frag_list[blockIdx.x];
 	const uint64_t b = big_off[blockIdx.x], n = big_off[blockIdx.x + 1] - b;
+	const uint32_t r0 = frag_first[f], r1 = frag_first[f + 1];
+	int qlen = 0; for (uint32_t r = r0; r < r1; ++r) qlen += (int)rd_len[r];
+	const AlMatch *m = match + mini_off[r0];
 	AlAnchor *out = anchors + a_off[f];
-	const int kb = 33 + rid_bits;
-	const uint64_t lowmask = (1ULL << (kb - 1)) - 1;
-	int tie = 0;
+	const int sb = rid_bits + pos_bits;
+	const uint64_t pmask = (1ULL << pos_bits) - 1, rmask = (1ULL << rid_bits) - 1;
+	const uint32_t span = (uint32_t)mini_span;
+	int tie = frag_nm[f] > 0x10000u ? 1 : 0;                               // list index does not fit the key: exact merge instead
 	for (uint64_t t = threadIdx.x; t < n; t += 256) {
-		const uint64_t k = keys[b + t];
-		AlAnchor a; a.x = (k & lowmask) | (k >> (kb - 1) & 1) << 63; a.y = vals[b + t];
-		if (t + 1 < n && keys[b + t + 1] == k) tie = 1;
+		const uint64_t k = keys[b + t], kx = k >> 16;
+		const AlMatch mm = m[(uint32_t)k & 0xffffu];
+		AlAnchor a; a.x = (kx >> sb & 1) << 63 | (kx >> pos_bits & rmask) << 32 | (kx & pmask);
+		a.y = (a.x >> 63) ? (uint64_t)span << 32 | (uint32_t)(qlen - ((int)(mm.q_pos >> 1) + 1 - (int)span) - 1) : (uint64_t)span << 32 | (mm.q_pos >> 1);
+		a.y |= (uint64_t)(mm.flags & 0xff) << AL_SEED_SEG_SHIFT;
+		if (mm.flags & (1u << 8)) a.y |= AL_SEED_TANDEM;
+		if (t + 1 < n && (keys[b + t + 1] >> 16) == kx) tie = 1;
 		out[t] = a;
 	}
 	if (tie) tie_list[f] = 1u;                                             // equal x: merged again by k_anchor_heap (exact heap order)

@@ -24,8 +24,8 @@ template <int HCAP, int LANES> __global__ void k_anchor_heap(const uint64_t *, c
 template <int CAP> __global__ void k_chain(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, AlAnchor *, uint64_t *, uint32_t *, int32_t *, uint64_t *, const uint32_t *, int, AlParams, unsigned long long *, ChainSeg);
 template <int CAPL, int LANES> __global__ void k_chain_lds(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, AlAnchor *, uint64_t *, uint32_t *, uint64_t *, const uint32_t *, int, int, AlParams, unsigned long long *, ChainSeg);
 template <int PER, int NW, int MCAP> __global__ void k_anchor_sort_reg(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, uint32_t *, const uint32_t *, int, int, int);
-__global__ void k_anchor_big_expand(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint32_t *, int, const uint64_t *, uint64_t *, uint64_t *, int, int);
-__global__ void k_anchor_big_scatter(const uint64_t *, const uint64_t *, const uint32_t *, int, const uint64_t *, const uint64_t *, AlAnchor *, uint32_t *, int);
+__global__ void k_anchor_big_expand(const uint64_t *, const uint64_t *, const uint32_t *, const AlMatch *, const uint32_t *, const uint32_t *, int, const uint64_t *, uint64_t *, int, int);
+__global__ void k_anchor_big_scatter(const uint64_t *, const uint32_t *, int, const uint64_t *, const uint64_t *, const uint64_t *, const uint32_t *, const uint32_t *, const AlMatch *, const uint32_t *, AlAnchor *, uint32_t *, int, int, int);
 __global__ void k_seg_scan(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *, int, AlParams, int, int, const uint64_t *, uint32_t *, uint64_t *, uint32_t *, uint32_t *, const uint32_t *, uint32_t *);
 __global__ void k_seg_merge(const uint32_t *, int, const uint64_t *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlAnchor *, const uint64_t *, uint64_t *, AlAnchor *, uint32_t *, uint32_t *, uint32_t *, const uint32_t *, const uint64_t *, uint64_t *);
 __global__ void k_chain_order(const uint32_t *, int, const uint64_t *, const uint32_t *, uint64_t *, AlAnchor *, const uint64_t *, uint64_t *, AlAnchor *, uint32_t *, uint32_t *);
@@ -231,6 +231,11 @@ static int scan_u32_to_u64(al_ctx_t *c, const uint32_t *in, uint64_t *out, int n
 }
 
 __global__ void k_iota_u32(uint32_t *a, uint32_t n) { const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) a[i] = i; }
+__global__ void k_flag_list(const uint32_t *list, int n, uint32_t *flag)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) flag[list[i]] = 1u;
+}
 __global__ void k_gather_na(const uint32_t *frag_na, const uint32_t *list, int n, uint32_t *out)
 {
 	int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -424,10 +429,16 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 		LREG(8, 4, 1024, lb1025, lb2049); LREG(16, 4, 1024, lb2049, lb4097); LREG(16, 8, 1024, lb4097, lb_big);   // (non-compact keys: t_big == t_blk, empty ranges)
 #undef LREG
 		if (ev(ST_ANCHOR_SORT_BLK)) return -1;
-		// above the LDS tiles: composite-key device radix sort, a chunk of fragments at a time so that rank + key bits fit 64
-		const int kb = 33 + rid_bits;
-		const uint32_t chunk_max = kb >= 64 ? 1u : (64 - kb >= 31 ? 0x7fffffffu : (1u << (64 - kb)));
-		for (uint32_t b0 = lb_big; b0 < (uint32_t)nl; ) {
+		// above the register tiles: composite-key device radix sort, a chunk of fragments at a time so that rank + x + list fit 64 bits
+		int pos_bits = 1; { uint32_t mx = 1; for (const AlSeq &sq : c->mi->seq) mx = std::max(mx, sq.len); while (pos_bits < 31 && (1ULL << pos_bits) < mx) ++pos_bits; }
+		const int rank_bits = 64 - 16 - 1 - rid_bits - pos_bits;
+		static const char *e3 = getenv("AL_TEST_BIG_CHUNK");                // tests: fragments per device-wide sort
+		uint32_t chunk_max = rank_bits >= 31 ? 0x7fffffffu : rank_bits >= 1 ? (1u << rank_bits) : 1u;
+		if (e3 && atoi(e3) > 0) chunk_max = std::min<uint32_t>(chunk_max, (uint32_t)atoi(e3));
+		if (rank_bits < 0 && lb_big < (uint32_t)nl) {                       // (no such index in practice: > 2^46 contig-id x position range) exact merge for all of them
+			hipLaunchKernelGGL(k_flag_list, dim3(((uint32_t)nl - lb_big + 255) / 256), dim3(256), 0, s, order + lb_big, (int)((uint32_t)nl - lb_big), c->tie_list.p);
+		}
+		for (uint32_t b0 = lb_big; rank_bits >= 0 && b0 < (uint32_t)nl; ) {
 			const uint32_t nb = std::min<uint32_t>((uint32_t)nl - b0, chunk_max);
 			if (c->big_na.ensure(nb + 2) || c->big_off.ensure(nb + 2)) return -1;
 			hipLaunchKernelGGL(k_gather_na, dim3((nb + 256) / 256), dim3(256), 0, s, c->frag_na.p, order + b0, (int)nb, c->big_na.p);
@@ -435,17 +446,19 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 			uint64_t nbig = 0;
 			AL_HIP_CHECK(hipMemcpyAsync(&nbig, c->big_off.p + nb, 8, hipMemcpyDeviceToHost, s));
 			AL_HIP_CHECK(hipStreamSynchronize(s));
-			// key / value double buffers live in the chaining scratch (16 bytes per anchor each), free at this point
-			uint64_t *ka = (uint64_t *)c->ws_i32.p, *va = ka + nbig, *kbuf = (uint64_t *)c->chain_tmp.p, *vb = kbuf + nbig;
-			hipLaunchKernelGGL(k_anchor_big_expand, dim3(nb), dim3(256), 0, s, c->di.pos, c->frag_first.p, c->rd_len.p, c->mini_off.p, c->match.p, c->frag_nm.p, c->frag_na.p,
-			                   order + b0, (int)nb, c->big_off.p, ka, va, rid_bits, c->mi->k);
+			// key double buffer in the chaining scratch (16 bytes per anchor each), free at this point
+			uint64_t *ka = (uint64_t *)c->ws_i32.p, *kbuf = (uint64_t *)c->chain_tmp.p;
+			hipLaunchKernelGGL(k_anchor_big_expand, dim3(nb), dim3(256), 0, s, c->di.pos, c->mini_off.p, c->frag_first.p, c->match.p, c->frag_nm.p,
+			                   order + b0, (int)nb, c->big_off.p, ka, rid_bits, pos_bits);
 			int rbits = 0; while ((1ULL << rbits) < nb) ++rbits;
-			rocprim::double_buffer<uint64_t> dk(ka, kbuf), dv(va, vb);
+			rocprim::double_buffer<uint64_t> dk(ka, kbuf);
+			const unsigned end_bit = (unsigned)(16 + 1 + rid_bits + pos_bits + rbits);
 			size_t bytes = 0;
-			AL_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, bytes, dk, dv, (size_t)nbig, 0u, (unsigned)(kb + rbits), s));
+			AL_HIP_CHECK(rocprim::radix_sort_keys(nullptr, bytes, dk, (size_t)nbig, 16u, end_bit, s));
 			if (c->scan_tmp.ensure(bytes + 16)) return -1;
-			AL_HIP_CHECK(rocprim::radix_sort_pairs(c->scan_tmp.p, bytes, dk, dv, (size_t)nbig, 0u, (unsigned)(kb + rbits), s));
-			hipLaunchKernelGGL(k_anchor_big_scatter, dim3(nb), dim3(256), 0, s, dk.current(), dv.current(), order + b0, (int)nb, c->big_off.p, c->a_off.p, c->anchors.p, c->tie_list.p, rid_bits);
+			AL_HIP_CHECK(rocprim::radix_sort_keys(c->scan_tmp.p, bytes, dk, (size_t)nbig, 16u, end_bit, s));
+			hipLaunchKernelGGL(k_anchor_big_scatter, dim3(nb), dim3(256), 0, s, dk.current(), order + b0, (int)nb, c->big_off.p, c->a_off.p,
+			                   c->mini_off.p, c->frag_first.p, c->rd_len.p, c->match.p, c->frag_nm.p, c->anchors.p, c->tie_list.p, rid_bits, pos_bits, c->mi->k);
 			b0 += nb;
 		}
 		if (ev(ST_ANCHOR_SORT_BIG)) return -1;

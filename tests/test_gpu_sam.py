@@ -73,12 +73,13 @@ def test_lds_dp_path_identical(golden_unpacked, name):
     assert r.stdout == exp, _diff_report(r.stdout, exp, name + "_lds")
 
 
-@pytest.mark.parametrize("env", [dict(AL_DBG=str(1 << 27)), dict(AL_TEST_SORT_BLK="65"), dict(AL_TEST_SORT_BIG="65"), dict(AL_TEST_SORT_BLK="65", AL_TEST_SORT_BIG="200")],
-                         ids=["segments_wave_only", "block_sort", "device_sort", "block_and_device_sort"])
+@pytest.mark.parametrize("env", [dict(AL_DBG=str(1 << 27)), dict(AL_TEST_SORT_BLK="65"), dict(AL_TEST_SORT_BIG="65"), dict(AL_TEST_SORT_BLK="65", AL_TEST_SORT_BIG="200"),
+                                 dict(AL_TEST_SORT_BIG="65", AL_TEST_BIG_CHUNK="3")],
+                         ids=["segments_wave_only", "block_sort", "device_sort", "block_and_device_sort", "device_sort_chunks"])
 @pytest.mark.parametrize("name", ["g1_mt150pe", "g2_250pe", "g3_adversarial", "g6_repeats"])
 def test_large_fragment_paths_identical(golden_unpacked, name, env):
     """The kernels that take over for fragments with many anchors -- chaining by segments (AL_DBG bit 27: every fragment goes
-    through the segment path and the wavefront kernel), the block bitonic sort and the device-wide radix sort of anchors
+    through the segment path and the wavefront kernel), the register-network block sort and the device-wide radix sort of anchors (also cut into chunks of three fragments)
     (thresholds lowered so that ordinary fragments reach them) -- must give the reference's bytes as well."""
     d = golden_unpacked[name]
     m = json.load(open(os.path.join(d, "meta.json")))
