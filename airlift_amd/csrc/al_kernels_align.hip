@@ -1171,7 +1171,8 @@ __device__ __forceinline__ bool d_regs_tail(const AlParams &P, const uint32_t ha
 // does O(n0^2) small moves and follows every hit's anchors three times -- on global memory that is tens of milliseconds for one
 // lane, and the launch waits for it.  Here a wavefront stages the kept hits and their anchors in LDS, lane 0 runs the same code
 // on the copies, the wavefront writes the results back.  Fragments that do not fit the tiles stay with k_regs.
-template <int RC, int AC>      // RC kept hits, AC anchors of theirs: the LDS tiles (72 / 1024: 62 KB, two blocks per CU; 200 / 2048: 141 KB for the few larger ones)
+template <int RC, int AC, int RCL, int ACL>   // RC kept hits, AC anchors of theirs: the LDS tiles (72 / 1024: 62 KB, two blocks per CU; 200 / 2048: 141 KB for the few larger ones);
+                                              // RCL / ACL: tiles of the next smaller instance, which takes what fits them (the instances run side by side)
 __global__ void __launch_bounds__(64)
 k_regs_heavy(const AlAnchor *__restrict__ chained, const uint32_t *__restrict__ frag_first, const uint32_t *__restrict__ rd_len,
              const uint32_t *__restrict__ frag_hash, WsBase W, const uint32_t *__restrict__ list, int n_list, AlParams P, unsigned long long *counters,
@@ -1207,7 +1208,7 @@ k_regs_heavy(const AlAnchor *__restrict__ chained, const uint32_t *__restrict__ 
 	}
 	__syncthreads();
 	const int tot = s_off[n0];
-	if (tot > AC) return;                                                    // the larger instantiation, or k_regs, takes it
+	if (tot > AC || (n0 <= RCL && tot <= ACL)) return;                       // the larger / the smaller instantiation, or k_regs, takes it
 	for (int i = 0; i < n0; ++i) { const int as = s_r0[i].as, cnt = s_r0[i].cnt, o = s_off[i]; for (int j = lane; j < cnt; j += 64) s_src[o + j] = a[as + j]; }
 	__syncthreads();
 	if (lane == 0) {
@@ -2317,12 +2318,18 @@ int al_run_align_stage(al_ctx_t *c)
 		T.n = 1; T.v[0] = 9;      // fragments with at least nine chains may keep at least nine hits: candidates of k_regs_heavy
 		{ uint32_t i9 = (uint32_t)nf; AL_HIP_CHECK(hipMemcpyAsync(c->lb_buf.p, &i9, 4, hipMemcpyHostToDevice, s)); hipLaunchKernelGGL(k_lower_bounds, dim3((nf + 255) / 256), dim3(256), 0, s, (const uint32_t *)c->chain_key.p, (uint32_t)nf, T, c->lb_buf.p);
 		  AL_HIP_CHECK(hipMemcpyAsync(&i9, c->lb_buf.p, 4, hipMemcpyDeviceToHost, s)); AL_HIP_CHECK(hipStreamSynchronize(s)); heavy_from = i9; heavy_n = (uint32_t)nf - i9; }
-		if (lb[1] > lb[0]) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_select<0>), dim3(lb[1] - lb[0]), dim3(64), 0, s, c->chained.p, c->u.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, ord + lb[0], (int)(lb[1] - lb[0]), c->P, regs_n0);
+		// the classes are disjoint sets of fragments: the few fragments with thousands of chains (long blocks, a thin grid) run on the
+		// side stream next to the bulk
+		hipStream_t sd = c->side;
+		AL_HIP_CHECK(hipEventRecord(c->ev_fj[0], s)); AL_HIP_CHECK(hipStreamWaitEvent(sd, c->ev_fj[0], 0));
+		if ((uint32_t)nf > lb[3]) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_select<-1>), dim3((uint32_t)nf - lb[3]), dim3(256), 0, sd, c->chained.p, c->u.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, ord + lb[3], (int)((uint32_t)nf - lb[3]), c->P, regs_n0);
+		if (lb[3] > lb[5]) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_select<8192>), dim3(lb[3] - lb[5]), dim3(256), 0, sd, c->chained.p, c->u.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, ord + lb[5], (int)(lb[3] - lb[5]), c->P, regs_n0);
+		if (lb[5] > lb[4]) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_select<4096>), dim3(lb[5] - lb[4]), dim3(256), 0, sd, c->chained.p, c->u.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, ord + lb[4], (int)(lb[5] - lb[4]), c->P, regs_n0);
+		if (lb[4] > lb[2]) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_select<2048>), dim3(lb[4] - lb[2]), dim3(256), 0, sd, c->chained.p, c->u.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, ord + lb[2], (int)(lb[4] - lb[2]), c->P, regs_n0);
+		AL_HIP_CHECK(hipEventRecord(c->ev_fj[1], sd));
 		if (lb[2] > lb[1]) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_select<1024>), dim3(lb[2] - lb[1]), dim3(256), 0, s, c->chained.p, c->u.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, ord + lb[1], (int)(lb[2] - lb[1]), c->P, regs_n0);
-		if (lb[4] > lb[2]) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_select<2048>), dim3(lb[4] - lb[2]), dim3(256), 0, s, c->chained.p, c->u.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, ord + lb[2], (int)(lb[4] - lb[2]), c->P, regs_n0);
-		if (lb[5] > lb[4]) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_select<4096>), dim3(lb[5] - lb[4]), dim3(256), 0, s, c->chained.p, c->u.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, ord + lb[4], (int)(lb[5] - lb[4]), c->P, regs_n0);
-		if (lb[3] > lb[5]) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_select<8192>), dim3(lb[3] - lb[5]), dim3(256), 0, s, c->chained.p, c->u.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, ord + lb[5], (int)(lb[3] - lb[5]), c->P, regs_n0);
-		if ((uint32_t)nf > lb[3]) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_select<-1>), dim3((uint32_t)nf - lb[3]), dim3(256), 0, s, c->chained.p, c->u.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, ord + lb[3], (int)((uint32_t)nf - lb[3]), c->P, regs_n0);
+		if (lb[1] > lb[0]) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_select<0>), dim3(lb[1] - lb[0]), dim3(64), 0, s, c->chained.p, c->u.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, ord + lb[0], (int)(lb[1] - lb[0]), c->P, regs_n0);
+		AL_HIP_CHECK(hipStreamWaitEvent(s, c->ev_fj[1], 0));
 	}
 	{   // room for the per-mate hits, from what chain_post kept
 		hipLaunchKernelGGL(k_regs_cap2, dim3((nf + 256) / 256), dim3(256), 0, s, (const uint32_t *)c->frag_nu.p, (const uint32_t *)regs_n0, nf, A->cap2.p);
@@ -2337,10 +2344,15 @@ int al_run_align_stage(al_ctx_t *c)
 	if (regs_n0 && heavy_n > 0) {
 		const size_t lds_t = al_regs_heavy_lds(24, 512), lds_s = al_regs_heavy_lds(72, 1024), lds_l = al_regs_heavy_lds(200, 2048);
 		static bool attr_set = false;
-		if (!attr_set) { AL_HIP_CHECK(hipFuncSetAttribute((const void *)k_regs_heavy<200, 2048>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_l)); attr_set = true; }
-		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_heavy<24, 512>), dim3(heavy_n), dim3(64), lds_t, s, c->chained.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, (const uint32_t *)c->chain_idx2.p + heavy_from, (int)heavy_n, c->P, c->counters.p, regs_n0);
-		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_heavy<72, 1024>), dim3(heavy_n), dim3(64), lds_s, s, c->chained.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, (const uint32_t *)c->chain_idx2.p + heavy_from, (int)heavy_n, c->P, c->counters.p, regs_n0);
-		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_heavy<200, 2048>), dim3(heavy_n), dim3(64), lds_l, s, c->chained.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, (const uint32_t *)c->chain_idx2.p + heavy_from, (int)heavy_n, c->P, c->counters.p, regs_n0);
+		if (!attr_set) { AL_HIP_CHECK(hipFuncSetAttribute((const void *)k_regs_heavy<200, 2048, 72, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_l)); attr_set = true; }
+		// every block takes the fragment only if its kept hits fit the instance's tiles: the three instances work on disjoint fragments
+		hipStream_t sd = c->side;
+		AL_HIP_CHECK(hipEventRecord(c->ev_fj[0], s)); AL_HIP_CHECK(hipStreamWaitEvent(sd, c->ev_fj[0], 0));
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_heavy<72, 1024, 24, 512>), dim3(heavy_n), dim3(64), lds_s, sd, c->chained.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, (const uint32_t *)c->chain_idx2.p + heavy_from, (int)heavy_n, c->P, c->counters.p, regs_n0);
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_heavy<200, 2048, 72, 1024>), dim3(heavy_n), dim3(64), lds_l, sd, c->chained.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, (const uint32_t *)c->chain_idx2.p + heavy_from, (int)heavy_n, c->P, c->counters.p, regs_n0);
+		AL_HIP_CHECK(hipEventRecord(c->ev_fj[1], sd));
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_heavy<24, 512, 0, 0>), dim3(heavy_n), dim3(64), lds_t, s, c->chained.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, (const uint32_t *)c->chain_idx2.p + heavy_from, (int)heavy_n, c->P, c->counters.p, regs_n0);
+		AL_HIP_CHECK(hipStreamWaitEvent(s, c->ev_fj[1], 0));
 	}
 	hipLaunchKernelGGL(k_regs, dim3((nf + 255) / 256), dim3(256), 0, s, c->chained.p, c->u.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, nf, c->P, c->counters.p, (const uint32_t *)regs_n0);
 	if (regs_n0 && getenv("AL_TRACE")) {   // which fragments were left to the one-lane code?

@@ -100,7 +100,8 @@ extern "C" al_ctx_t *al_ctx_init(const al_idx_t *mi, const al_mapopt_t *opt, int
 	c->mi = mi; c->opt = *opt; c->device = device;
 	if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return nullptr; }
 	for (int i = 0; i <= ST_N; ++i) if (hipEventCreate(&c->ev[i]) != hipSuccess) { delete c; return nullptr; }
-	if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&c->ev_side[0]) != hipSuccess || hipEventCreate(&c->ev_side[1]) != hipSuccess || hipEventCreate(&c->ev_side[2]) != hipSuccess || hipEventCreate(&c->ev_side[3]) != hipSuccess) { delete c; return nullptr; }
+	if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&c->ev_side[0]) != hipSuccess || hipEventCreate(&c->ev_side[1]) != hipSuccess || hipEventCreate(&c->ev_side[2]) != hipSuccess || hipEventCreate(&c->ev_side[3]) != hipSuccess ||
+	    hipEventCreateWithFlags(&c->ev_fj[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_fj[1], hipEventDisableTiming) != hipSuccess) { delete c; return nullptr; }
 	if (al_upload_index(mi, device, &c->di) != 0) { delete c; return nullptr; }
 	AlParams &P = c->P;
 	P.k = mi->k; P.w = mi->w; P.seed = opt->seed; P.bw = opt->bw; P.max_gap = opt->max_gap; P.max_gap_ref = opt->max_gap_ref; P.max_frag_len = opt->max_frag_len;
@@ -134,6 +135,7 @@ extern "C" void al_ctx_destroy(al_ctx_t *c)
 	ctx_release_buffers(c);
 	for (int i = 0; i <= ST_N; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
 	for (int i = 0; i < 4; ++i) if (c->ev_side[i]) (void)hipEventDestroy(c->ev_side[i]);
+	for (int i = 0; i < 2; ++i) if (c->ev_fj[i]) (void)hipEventDestroy(c->ev_fj[i]);
 	if (c->side) (void)hipStreamDestroy(c->side);
 	if (c->stream) (void)hipStreamDestroy(c->stream);
 	delete c;
@@ -317,6 +319,9 @@ static int chain_by_segments(al_ctx_t *c, const uint32_t *order, int n, bool lds
 		static const uint32_t thr[9] = {1, 2, 3, 4, 5, 6, 7, 8, 9};
 		if (lower_bounds(c, c->seg_key.p, (uint32_t)ns, thr, 9, lb)) return -1;
 	}
+	{ static const bool tr = getenv("AL_TRACE") != nullptr;
+	  if (tr && first) fprintf(stderr, "[airlift] trace: segments: %d in %d fragments; by size <=16:%u <=24:%u <=32:%u <=48:%u <=64:%u <=128:%u more:%u\n", ns, n,
+	                          lb[0], lb[1] - lb[0], lb[2] - lb[1], lb[4] - lb[2], lb[5] - lb[4], lb[8] - lb[5], (uint32_t)ns - lb[8]); }
 	if (ev(ST_SEG_FIND)) return -1;
 	const bool keep_keys = c->opt.min_cnt >= 2;                               // a chain has >= 2 anchors: the keys of a segment fit half of its range
 	const ChainSeg sg{c->vs_meta.p, c->vs_tie.p, c->vs_nc.p, nullptr, 0, keep_keys ? c->okey_tmp.p : nullptr};
