@@ -24,6 +24,8 @@
 #include <string.h>
 #include <vector>
 #include <algorithm>
+#include <thread>
+#include <time.h>
 #include "al_internal.h"
 #include "al_device.h"
 #include "al_io.h"
@@ -171,7 +173,12 @@ extern "C" al_idx_t *al_idx_build_device(const char *fn, const al_idxopt_t *io, 
 	al_idx_t *mi = new al_idx_t();
 	mi->k = k; mi->w = w;
 	std::vector<char> ascii; uint64_t sum = 0;
-	{
+	const bool timing = getenv("AL_TIMING") != nullptr;
+	struct timespec tq0, tq1, tq2; clock_gettime(CLOCK_MONOTONIC, &tq0);
+	auto secs = [](const struct timespec &a, const struct timespec &b) { return (double)(b.tv_sec - a.tv_sec) + 1e-9 * (double)(b.tv_nsec - a.tv_nsec); };
+	int n_host = getenv("AL_IDX_THREADS") ? atoi(getenv("AL_IDX_THREADS")) : (int)std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
+	if (al_fasta_load_parallel(fn, n_host, mi->seq, ascii)) sum = ascii.size();
+	else {
 		AlChunk c;
 		for (;;) {
 			c.text.clear(); c.recs.clear();
@@ -182,6 +189,7 @@ extern "C" al_idx_t *al_idx_build_device(const char *fn, const al_idxopt_t *io, 
 		}
 	}
 	if (mi->seq.empty()) { fprintf(stderr, "[ERROR] airlift: no sequences in '%s'\n", fn); delete mi; return nullptr; }
+	clock_gettime(CLOCK_MONOTONIC, &tq1);
 	mi->tot_len = sum;
 	const uint32_t n_seq = (uint32_t)mi->seq.size();
 	const uint64_t n_words = (sum + 7) / 8 + 8;
@@ -266,6 +274,7 @@ extern "C" al_idx_t *al_idx_build_device(const char *fn, const al_idxopt_t *io, 
 	(void)hipFree(d_tmp); (void)hipFree(d_segf); (void)hipFree(d_cnt); (void)hipFree(d_off); (void)hipFree(d_h); (void)hipFree(d_uniq); (void)hipFree(d_koff); (void)hipFree(d_kcnt); (void)hipFree(d_nruns);
 	(void)hipFree(d_h2); (void)hipFree(d_y2);
 	(void)hipStreamDestroy(st);
+	if (timing) { clock_gettime(CLOCK_MONOTONIC, &tq2); fprintf(stderr, "[airlift] index: FASTA load %.3f s (%d threads), upload + kernels %.3f s; %llu minimizers, %llu distinct\n", secs(tq0, tq1), n_host, secs(tq1, tq2), (unsigned long long)total, (unsigned long long)n_keys); }
 	return mi;
 fail:
 	(void)hipFree(d_tmp); (void)hipFree(d_ascii); (void)hipFree(d_segf); (void)hipFree(d_cnt); (void)hipFree(d_off); (void)hipFree(d_h); (void)hipFree(d_y); (void)hipFree(d_h2); (void)hipFree(d_y2);

@@ -60,6 +60,8 @@ static inline uint64_t al_tab_slot(uint64_t hash, int bits) { return (hash * 0x9
 #define AL_TAB_SINGLE (1ULL << 63)
 #define AL_TAB_SINGLE_MAX_SEQ 65536u
 
+// whole-file parallel FASTA loader (al_fasta.cpp); false: not a plain uncompressed FASTA file, use the block reader
+bool al_fasta_load_parallel(const char *fn, int n_threads, std::vector<AlSeq> &seqs, std::vector<char> &ascii);
 // host-side helpers (al_index.cpp)
 void al_sketch_host(const uint8_t *codes, uint32_t len, int w, int k, uint32_t rid, std::vector<uint64_t> &hash_out, std::vector<uint64_t> &y_out);
 

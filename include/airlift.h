@@ -179,6 +179,9 @@ int  al_dbg_ksw(al_ctx_t *ctx, int n, const uint8_t *seqs, size_t n_seq_bytes, c
 
 /* Self-test of the multi-lane output path (offset exchange + pwrite, or ordered turns) with synthetic blocks; needs no GPU. */
 int  al_dbg_ordered_out_selftest(const char *path, int n_lanes, int n_batches, int use_offsets);
+/* Self-test of the whole-file parallel FASTA loader of the index builders against the block reader: 0 = same names, lengths and
+ * bytes, 1 = the loader declined the file (not a plain uncompressed FASTA), -1 = they differ; needs no GPU. */
+int  al_dbg_fasta_selftest(const char *fn, int n_threads);
 
 /* ---- device-resident batch API (bench / multi-GPU harness; inputs already in HBM when timing starts) ---- */
 /* Pack + upload a batch; returns 0.  The batch stays resident until the next upload. */

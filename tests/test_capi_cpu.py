@@ -122,6 +122,38 @@ def test_idx_reader_open_fails_like_reference(A):
     L.al_idx_reader_close(None)
 
 
+def test_parallel_fasta_loader_equals_block_reader(A, golden_unpacked, tmp_path):
+    """The index builders' whole-file loader (al_fasta.cpp: header scan, pieces cut at line ends, count + copy by a thread pool) against
+    the block reader (kseq.h grammar) on awkward files; files it must decline (gzip, FASTQ, junk before the first header)."""
+    import gzip
+    L = A.load()
+    rng = np.random.default_rng(5)
+    def seq(n):
+        return np.frombuffer(b"ACGTacgtNnUuRY", dtype=np.uint8)[rng.integers(0, 14, n)].tobytes()
+    big = seq(21_000_003)                                   # several 8 MB pieces, cut at line ends
+    cases = {}
+    cases["wrapped"] = b"".join(b">c%d comment > with gt\n" % i + b"\n".join(s[o:o + 60] for o in range(0, len(s), 60)) + b"\n" for i, s in enumerate([seq(1000), seq(59), seq(60), seq(61), b"", seq(7)]))
+    cases["crlf_blank_noeol"] = b">a\tx y\r\nACGT\r\n\r\nTTuU\r\n\n>b\r\n\r\nGG\rA\r\n>c\n" + seq(130)     # '\r' inside a line stays, last line without newline
+    cases["one_line_big"] = b">big\n" + big + b"\n>tail desc\n" + seq(100) + b"\n"
+    cases["wrapped_big"] = b">w\n" + b"\n".join(big[o:o + 70] for o in range(0, len(big), 70)) + b"\n>z\nAC\n"
+    cases["header_only_at_eof"] = b">x\nACGT\n>y"
+    cases["many"] = b"".join(b">s%d\n%s\n" % (i, seq(int(rng.integers(0, 200)))) for i in range(5000))
+    for name, data in cases.items():
+        fn = tmp_path / (name + ".fa")
+        fn.write_bytes(data)
+        for nt in (1, 3, 8):
+            assert L.al_dbg_fasta_selftest(str(fn).encode(), nt) == 0, (name, nt)
+    declined = {"fastq": b"@r\nACGT\n+\nIIII\n", "junk_first": b"\n>a\nACGT\n", "plus_line": b">a\nACGT\n+\nIIII\n", "empty_name": b"> x\nACGT\n>b\nAC\n"}
+    for name, data in declined.items():
+        fn = tmp_path / (name + ".fa")
+        fn.write_bytes(data)
+        assert L.al_dbg_fasta_selftest(str(fn).encode(), 4) == 1, name
+    gz = tmp_path / "r.fa.gz"
+    with gzip.open(gz, "wb") as f:
+        f.write(cases["wrapped"])
+    assert L.al_dbg_fasta_selftest(str(gz).encode(), 4) == 1
+
+
 def test_no_cpu_path(A, golden_unpacked):
     """Without a HIP device the context creation must fail loudly (no fallback)."""
     import torch
