@@ -2483,6 +2483,7 @@ int al_run_align_stage(al_ctx_t *c)
 			if (launch_mono(A->slow_list.p, (int)n_slow)) return -1;
 		}
 		c->stat_n_slow = n_slow;
+		if (getenv("AL_TRACE")) fprintf(stderr, "[airlift] trace: ext: %u of %d fragments redone by the monolithic kernel (z-drop split, long CIGAR, oversize)\n", n_slow, nf);
 		AL_HIP_CHECK(hipEventRecord(c->ev[ST_EXT_FINISH + 1], s));
 	}
 	AL_HIP_CHECK(hipGetLastError());
