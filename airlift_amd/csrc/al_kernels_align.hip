@@ -2053,15 +2053,24 @@ __device__ __forceinline__ void d_fcig_append(AlReg *r, CG cig, int n, const uin
 	} else { for (int i = 0; i < n; ++i) cig[r->n_cigar + i] = src[i]; r->n_cigar += n; }
 }
 
+// fragments k_ext_prep left to the monolithic kernel (oversize, z-drop inside a closed-form flank): known before the DP jobs run
+__global__ void __launch_bounds__(256)
+k_collect_slow(const uint32_t *__restrict__ frag_slow, int n_frag, uint32_t *__restrict__ list, uint32_t *__restrict__ cnt)
+{
+	const int f = blockIdx.x * blockDim.x + threadIdx.x;
+	if (f < n_frag && frag_slow[f] != 0) list[atomicAdd(cnt, 1u)] = (uint32_t)f;
+}
+
 extern "C" __global__ void __launch_bounds__(256, AL_LB_FIN)
 k_ext_finish(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_off, const uint32_t *__restrict__ rd_len,
              const uint32_t *__restrict__ frag_first, const int32_t *__restrict__ frag_rep, WsBase W, AlignShared G, ExtShared E,
-             AlLogTab lt, uint64_t *__restrict__ sc_ws, const uint64_t *__restrict__ sc_off, int n_frag, AlParams P, uint32_t *__restrict__ slow_list, uint32_t *__restrict__ n_slow)
+             AlLogTab lt, uint64_t *__restrict__ sc_ws, const uint64_t *__restrict__ sc_off, int n_frag, AlParams P, uint32_t *__restrict__ slow_list, uint32_t *__restrict__ n_slow,
+             int early_done /* fragments k_ext_prep marked slow are already with the monolithic kernel (side stream) */)
 {
 	const int f = blockIdx.x * blockDim.x + threadIdx.x;
 	__shared__ uint32_t s_cig[AL_FCIG * 256];                                  // per-lane CIGAR assembly buffer, [word][lane]
 	unsigned long long c_regs = 0, c_ref = 0, c_cig = 0;
-	if (f < n_frag && W.frag_nu[f] != 0) {
+	if (f < n_frag && W.frag_nu[f] != 0 && !(early_done && E.frag_slow[f] != 0)) {
 		const uint32_t r0 = frag_first[f], n_segs = frag_first[f + 1] - r0;
 		FragWs fw; d_frag_ws(W, (uint32_t)f, fw);
 		const uint64_t B2 = (uint64_t)(fw.mreg[0] - W.mregs);
@@ -2237,11 +2246,11 @@ struct AlignState {            // lives in al_ctx_s::align_state (opaque there)
 	DevBuf<int32_t> auxi;
 	DevBuf<uint32_t> reg_cnt, seg_na, arena, seg_fast, regs_n0, cap2; DevBuf<uint64_t> b2_off;
 	uint64_t arena_scale = 1;       // doubled by al_align_grow_arena() when a batch's long CIGARs overflowed the arena
-	DevBuf<uint8_t> gws, long_state;
+	DevBuf<uint8_t> gws, gws2, long_state;
 	DevBuf<float> logtab;
 	DevBuf<unsigned long long> dbgbuf, hist;
 	DevBuf<ExtJob> jobs; DevBuf<ExtOut> outs; DevBuf<RegExt> rext;
-	DevBuf<uint64_t> job_off, sc_off, sc_ws; DevBuf<uint32_t> n_jobs, n_sc, job_key, job_key2, job_idx, job_idx2, frag_slow, slow_list;
+	DevBuf<uint64_t> job_off, sc_off, sc_ws; DevBuf<uint32_t> n_jobs, n_sc, job_key, job_key2, job_idx, job_idx2, frag_slow, slow_list, early_list;
 	DevBuf<uint8_t> sort_tmp;
 	int logtab_a = -1, logtab_n = 0;
 	uint64_t out_total = 0;
@@ -2263,7 +2272,7 @@ void al_align_state_free(al_ctx_t *c)
 	AlignState *s = it->second;
 	s->regs0.release(); s->mregs.release(); s->rtmp.release(); s->out.release(); s->aux128.release(); s->seg_a.release(); s->aux64.release(); s->seg_u.release();
 	s->nu_off.release(); s->out_off.release(); s->auxi.release(); s->reg_cnt.release(); s->seg_na.release(); s->arena.release(); s->gws.release(); s->long_state.release(); s->logtab.release(); s->dbgbuf.release(); s->hist.release(); s->jobs.release(); s->outs.release(); s->rext.release(); s->seg_fast.release(); s->regs_n0.release(); s->cap2.release(); s->b2_off.release();
-	s->job_off.release(); s->sc_off.release(); s->sc_ws.release(); s->n_jobs.release(); s->n_sc.release(); s->job_key.release(); s->job_key2.release(); s->job_idx.release(); s->job_idx2.release(); s->frag_slow.release(); s->slow_list.release(); s->sort_tmp.release();
+	s->job_off.release(); s->sc_off.release(); s->sc_ws.release(); s->n_jobs.release(); s->n_sc.release(); s->job_key.release(); s->job_key2.release(); s->job_idx.release(); s->job_idx2.release(); s->frag_slow.release(); s->slow_list.release(); s->early_list.release(); s->gws2.release(); s->sort_tmp.release();
 	delete s; g_states.erase(it);
 }
 
@@ -2396,15 +2405,15 @@ int al_run_align_stage(al_ctx_t *c)
 		if (nb > 16) nb = 16;
 		if (A->gws.ensure((size_t)nb * AL_GPB * stride + 64) || A->long_state.ensure((size_t)nb * AL_GPB * sizeof(GroupLong) + 64)) return -1;
 	}
-	auto launch_mono = [&](const uint32_t *list, int n_list) -> int {      // monolithic kernel (whole batch, or the slow-path list)
+	auto launch_mono = [&](const uint32_t *list, int n_list, hipStream_t st, uint8_t *wsp, int nb) -> int {      // monolithic kernel (whole batch, or the slow-path list)
 		int nbm = (n_list + AL_GPB - 1) / AL_GPB; if (nbm > nb) nbm = nb; if (nbm < 1) nbm = 1;
-		if (long_mode) hipLaunchKernelGGL(k_align_long, dim3(nbm), dim3(GW * AL_GPB), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, c->frag_first.p, c->frag_rep.p, W, G, lt, A->gws.p, stride, p_bytes, cig_words, nf, c->P, list, n_list, (GroupLong *)A->long_state.p);
-		else if (tmax == 336) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_align<336, 160>), dim3(nbm), dim3(GW * AL_GPB), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, c->frag_first.p, c->frag_rep.p, W, G, lt, A->gws.p, stride, p_bytes, cig_words, nf, c->P, list, n_list);
-		else if (tmax == 512) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_align<512, 256>), dim3(nbm), dim3(GW * AL_GPB), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, c->frag_first.p, c->frag_rep.p, W, G, lt, A->gws.p, stride, p_bytes, cig_words, nf, c->P, list, n_list);
-		else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_align<1024, 512>), dim3(nbm), dim3(GW * AL_GPB), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, c->frag_first.p, c->frag_rep.p, W, G, lt, A->gws.p, stride, p_bytes, cig_words, nf, c->P, list, n_list);
+		if (long_mode) hipLaunchKernelGGL(k_align_long, dim3(nbm), dim3(GW * AL_GPB), 0, st, c->rd_seq.p, c->rd_off.p, c->rd_len.p, c->frag_first.p, c->frag_rep.p, W, G, lt, wsp, stride, p_bytes, cig_words, nf, c->P, list, n_list, (GroupLong *)A->long_state.p);
+		else if (tmax == 336) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_align<336, 160>), dim3(nbm), dim3(GW * AL_GPB), 0, st, c->rd_seq.p, c->rd_off.p, c->rd_len.p, c->frag_first.p, c->frag_rep.p, W, G, lt, wsp, stride, p_bytes, cig_words, nf, c->P, list, n_list);
+		else if (tmax == 512) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_align<512, 256>), dim3(nbm), dim3(GW * AL_GPB), 0, st, c->rd_seq.p, c->rd_off.p, c->rd_len.p, c->frag_first.p, c->frag_rep.p, W, G, lt, wsp, stride, p_bytes, cig_words, nf, c->P, list, n_list);
+		else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_align<1024, 512>), dim3(nbm), dim3(GW * AL_GPB), 0, st, c->rd_seq.p, c->rd_off.p, c->rd_len.p, c->frag_first.p, c->frag_rep.p, W, G, lt, wsp, stride, p_bytes, cig_words, nf, c->P, list, n_list);
 		return 0;
 	};
-	if (((c->P.dbg >> 26) & 1) || long_mode) { if (launch_mono(nullptr, nf)) return -1; for (int i = ST_EXT_PREP; i <= ST_EXT_FINISH; ++i) AL_HIP_CHECK(hipEventRecord(c->ev[i + 1], s)); }   // AL_DBG bit 26: whole batch through the monolithic kernel
+	if (((c->P.dbg >> 26) & 1) || long_mode) { if (launch_mono(nullptr, nf, s, A->gws.p, nb)) return -1; for (int i = ST_EXT_PREP; i <= ST_EXT_FINISH; ++i) AL_HIP_CHECK(hipEventRecord(c->ev[i + 1], s)); }   // AL_DBG bit 26: whole batch through the monolithic kernel
 	else {
 		// ---- fast path: prep -> size-sorted DP job queue -> finish -> (slow list) monolithic
 		if (A->n_jobs.ensure(nf + 2) || A->n_sc.ensure(nf + 2) || A->job_off.ensure(nf + 2) || A->sc_off.ensure(nf + 2) || A->frag_slow.ensure(nf + 1) || A->slow_list.ensure(nf + 1) || A->hist.ensure(AL_HIST_N)) return -1;
@@ -2420,8 +2429,24 @@ int al_run_align_stage(al_ctx_t *c)
 		AL_HIP_CHECK(hipMemsetAsync(A->hist.p, 0, AL_HIST_N * 8, s));
 		ExtShared E; E.jobs = A->jobs.p; E.outs = A->outs.p; E.rext = A->rext.p; E.job_off = A->job_off.p; E.frag_slow = A->frag_slow.p; E.job_key = A->job_key.p; E.hist = A->hist.p;
 		hipLaunchKernelGGL(k_ext_prep, dim3((nf + 255) / 256), dim3(256), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, c->frag_first.p, W, G, E, nf, c->P, tmax, qmax);
+		// fragments k_ext_prep left to the monolithic kernel are known now: a handful of them, milliseconds each on one 16-lane group --
+		// they go to the side stream at once and run beside the DP jobs
+		uint32_t *const n_early_d = (uint32_t *)(A->hist.p + 20); uint32_t n_early = 0;
+		if (A->early_list.ensure(nf + 1)) return -1;
+		hipLaunchKernelGGL(k_collect_slow, dim3((nf + 255) / 256), dim3(256), 0, s, (const uint32_t *)A->frag_slow.p, nf, A->early_list.p, n_early_d);
 		AL_HIP_CHECK(hipEventRecord(c->ev[ST_EXT_PREP + 1], s));
 		unsigned long long hist[16] = {0};
+		auto early_mono = [&]() -> int {                                         // (after a synchronisation point of the main stream: n_early is on the host)
+			if (n_early == 0) return 0;
+			int nbs = ((int)n_early + AL_GPB - 1) / AL_GPB; if (nbs > 1024) nbs = 1024;
+			if (A->gws2.ensure((size_t)nbs * AL_GPB * stride + 64)) return -1;
+			AL_HIP_CHECK(hipEventRecord(c->ev_fj[0], s)); AL_HIP_CHECK(hipStreamWaitEvent(c->side, c->ev_fj[0], 0));
+			if (launch_mono(A->early_list.p, (int)n_early, c->side, A->gws2.p, nbs)) return -1;
+			AL_HIP_CHECK(hipEventRecord(c->ev_fj[1], c->side));
+			return 0;
+		};
+		AL_HIP_CHECK(hipMemcpyAsync(&n_early, n_early_d, 4, hipMemcpyDeviceToHost, s));
+		if (nj == 0) { AL_HIP_CHECK(hipStreamSynchronize(s)); if (early_mono()) return -1; }
 		if (nj > 0) {
 			hipLaunchKernelGGL(k_iota, dim3((nj + 255) / 256), dim3(256), 0, s, A->job_idx.p, nj);
 			size_t bytes = 0;
@@ -2431,6 +2456,7 @@ int al_run_align_stage(al_ctx_t *c)
 			AL_HIP_CHECK(hipEventRecord(c->ev[ST_EXT_SORT + 1], s));
 			AL_HIP_CHECK(hipMemcpyAsync(hist, A->hist.p, (AL_NCLS + 1) * 8, hipMemcpyDeviceToHost, s));
 			AL_HIP_CHECK(hipStreamSynchronize(s));
+			if (early_mono()) return -1;
 			if (getenv("AL_TRACE")) fprintf(stderr, "[airlift] trace: prep + job sort done\n");
 			if ((c->P.dbg >> 30) & 1) { fprintf(stderr, "[airlift] DP jobs per class (lane16 lane32 lane64 g1 g2 g4 g8 g22 g32 lds | empty):"); for (int i = 0; i <= AL_NCLS; ++i) fprintf(stderr, " %llu", hist[i]); fprintf(stderr, "\n"); }
 			// one launch per job class over its slice of the sorted job list
@@ -2472,18 +2498,18 @@ int al_run_align_stage(al_ctx_t *c)
 		else { AL_HIP_CHECK(hipEventRecord(c->ev[ST_EXT_SORT + 1], s)); for (int i = ST_EXT_DP_LANE; i < ST_EXT_DP_G22; ++i) AL_HIP_CHECK(hipEventRecord(c->ev[i + 1], s)); }
 		AL_HIP_CHECK(hipEventRecord(c->ev[ST_EXT_DP_G22 + 1], s));
 		uint32_t *n_slow_d = (uint32_t *)(c->counters.p + 14);
-		hipLaunchKernelGGL(k_ext_finish, dim3((nf + 255) / 256), dim3(256), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, c->frag_first.p, c->frag_rep.p, W, G, E, lt, A->sc_ws.p, A->sc_off.p, nf, c->P, A->slow_list.p, n_slow_d);
+		hipLaunchKernelGGL(k_ext_finish, dim3((nf + 255) / 256), dim3(256), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, c->frag_first.p, c->frag_rep.p, W, G, E, lt, A->sc_ws.p, A->sc_off.p, nf, c->P, A->slow_list.p, n_slow_d, 1);
 		uint32_t n_slow = 0;
 		AL_HIP_CHECK(hipMemcpyAsync(&n_slow, n_slow_d, 4, hipMemcpyDeviceToHost, s));
 		AL_HIP_CHECK(hipStreamSynchronize(s));
 		if (n_slow > 0) {
 			int nbs = ((int)n_slow + AL_GPB - 1) / AL_GPB; if (nbs > 1024) nbs = 1024;
 			if (A->gws.ensure((size_t)nbs * AL_GPB * stride + 64)) return -1;
-			nb = nbs;
-			if (launch_mono(A->slow_list.p, (int)n_slow)) return -1;
+			if (launch_mono(A->slow_list.p, (int)n_slow, s, A->gws.p, nbs)) return -1;
 		}
-		c->stat_n_slow = n_slow;
-		if (getenv("AL_TRACE")) fprintf(stderr, "[airlift] trace: ext: %u of %d fragments redone by the monolithic kernel (z-drop split, long CIGAR, oversize)\n", n_slow, nf);
+		if (n_early > 0) AL_HIP_CHECK(hipStreamWaitEvent(s, c->ev_fj[1], 0));
+		c->stat_n_slow = n_slow + n_early;
+		if (getenv("AL_TRACE")) fprintf(stderr, "[airlift] trace: ext: of %d fragments the monolithic kernel takes %u known after prep (oversize, z-drop in a closed-form flank; side stream) and %u after the DP (CIGAR above the fast path's buffer)\n", nf, n_early, n_slow);
 		AL_HIP_CHECK(hipEventRecord(c->ev[ST_EXT_FINISH + 1], s));
 	}
 	AL_HIP_CHECK(hipGetLastError());
