@@ -60,8 +60,12 @@ try:
         meta = json.loads(open(os.path.join(d, "bench_fetch.json")).read().strip().split("\n")[-1])
     except Exception:
         pass
-    n_runs = max(1, int(meta.get("steps", 0)) + int(meta.get("warmup", 0)))
-    tot_f = sum(e["FETCH_SIZE"][1] for e in per.values()) * 1024.0 / n_runs; tot_w = sum(e["WRITE_SIZE"][1] for e in per.values()) * 1024.0 / n_runs
+    # batch runs under the profiler = launches of a once-per-run kernel (bench.py also runs the batch for its counters and its
+    # PCIe-inclusive figure, not only warmup + steps)
+    n_runs = per.get("k_sketch", {}).get("FETCH_SIZE", [0])[0] or max(1, int(meta.get("steps", 0)) + int(meta.get("warmup", 0)))
+    once = ("k_pack_ref", "k_ref_sketch", "k_tab_insert")          # index build (once per process, not part of a step); its library sorts stay in
+    tot_f = sum(e["FETCH_SIZE"][1] for k, e in per.items() if not k.startswith(once)) * 1024.0 / n_runs
+    tot_w = sum(e["WRITE_SIZE"][1] for k, e in per.items() if not k.startswith(once)) * 1024.0 / n_runs
     wl = meta.get("config", {}).get("key") or (meta.get("config", {}).get("workload", "") or "").split(" ")[0].lower().rstrip(":")
     json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) over `python3 bench.py --no-cpu-baseline`, %s" % os.path.basename(d),
                "workload": wl, "reads_per_step": meta.get("config", {}).get("reads_per_step_per_gpu"), "runs_in_profile": n_runs,
