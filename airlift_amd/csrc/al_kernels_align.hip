@@ -918,14 +918,14 @@ k_regs_select(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__
 			if (n_u > 65535) { if (tid == 0) regs_n0[f] = 0xfffffff1u; return; }
 			for (int c = tid; c < n_u; c += NT) { const AlAnchor fa = a[as_arr[c]]; skey[c] = u[c] ^ (uint32_t)d_hash64((d_hash64(fa.x) + d_hash64(fa.y)) ^ fhash); sidx[c] = (IdxT)c; }
 			__syncthreads();
-			if (tid == 0) {
+			if (tid < 64) {                                                       // the first wavefront: counts and small buckets in parallel, the permutation by lane 0
 				struct KI { uint64_t k; IdxT i; };
 				struct { typedef KI E; uint64_t *k; IdxT *i;
 				         __device__ __forceinline__ uint64_t keyof(const KI &e) const { return e.k; }
 				         __device__ __forceinline__ uint64_t key(int j) const { return k[j]; }
 				         __device__ __forceinline__ KI get(int j) const { return KI{k[j], i[j]}; }
 				         __device__ __forceinline__ void set(int j, const KI &e) { k[j] = e.k; i[j] = e.i; } } acc{skey, sidx};
-				(void)d_rs_sort(acc, n_u, s_rs);
+				(void)d_rs_sort_wave(acc, n_u, s_rs, tid);
 			}
 			__syncthreads();
 			for (int i = tid; i < n_u / 2; i += NT) {

@@ -1384,14 +1384,14 @@ k_chain_order(const uint32_t *__restrict__ fb_list, int n_fb, const uint64_t *__
 		}
 	for (int i = lane; i < n_u; i += 64) key[i] = b[off[id[i]]].x;           // (2) x of the chain's first anchor
 	__threadfence_block();
-	if (lane == 0) {                                                          // (3)
+	{                                                                         // (3) by the wavefront: counts and small buckets in parallel, the permutation by lane 0
 		struct KI { uint64_t k; uint16_t i; };
 		struct { typedef KI E; uint64_t *k; uint16_t *i;
 		         __device__ __forceinline__ uint64_t keyof(const KI &e) const { return e.k; }
 		         __device__ __forceinline__ uint64_t key(int j) const { return k[j]; }
 		         __device__ __forceinline__ KI get(int j) const { return KI{k[j], i[j]}; }
 		         __device__ __forceinline__ void set(int j, const KI &e) { k[j] = e.k; i[j] = e.i; } } acc{key, id};
-		(void)d_rs_sort(acc, n_u, s_rs);
+		(void)d_rs_sort_wave(acc, n_u, s_rs, lane);
 	}
 	__threadfence_block();
 	// (4) new chain list and anchors into the fragment's scratch ranges, then back
@@ -1453,4 +1453,40 @@ k_rechain_test(const AlAnchor *__restrict__ chained, const uint64_t *__restrict_
 		}
 	} else rechain = 1;
 	if (rechain) list[atomicAdd(n_list, 1u)] = (uint32_t)f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// test hook (tests/test_gpu_stages.py): the serial and the wavefront form of the radix-sort restatement on the same keys; both
+// permutations come back (they must be equal -- and equal to the reference's ksort.h, which the CPU test of the serial form pins)
+// ---------------------------------------------------------------------------------------------
+struct DbgKI { uint64_t k; uint16_t i; };
+struct DbgRsAcc { typedef DbgKI E; uint64_t *k; uint16_t *i;
+	__device__ __forceinline__ uint64_t keyof(const DbgKI &e) const { return e.k; }
+	__device__ __forceinline__ uint64_t key(int j) const { return k[j]; }
+	__device__ __forceinline__ DbgKI get(int j) const { return DbgKI{k[j], i[j]}; }
+	__device__ __forceinline__ void set(int j, const DbgKI &e) { k[j] = e.k; i[j] = e.i; } };
+__global__ void __launch_bounds__(64)
+k_dbg_rs_sort(uint64_t *ka, uint16_t *ia, uint64_t *kb, uint16_t *ib, int n)
+{
+	__shared__ uint16_t s_rs[AL_RS_SCRATCH / 2];
+	const int lane = threadIdx.x;
+	if (blockIdx.x == 0) { if (lane == 0) { DbgRsAcc acc{ka, ia}; (void)d_rs_sort(acc, n, s_rs); } }
+	else { DbgRsAcc acc{kb, ib}; (void)d_rs_sort_wave(acc, n, s_rs, lane); }
+}
+extern "C" int al_dbg_rs_sort(int device, const uint64_t *keys, int n, uint16_t *order_serial, uint16_t *order_wave)
+{
+	if (n <= 0 || n > 65535 || hipSetDevice(device < 0 ? 0 : device) != hipSuccess) return -1;
+	uint64_t *ka = nullptr, *kb = nullptr; uint16_t *ia = nullptr, *ib = nullptr; int rc = -1;
+	std::vector<uint16_t> id((size_t)n); for (int i = 0; i < n; ++i) id[i] = (uint16_t)i;
+	if (hipMalloc((void **)&ka, (size_t)n * 8) != hipSuccess || hipMalloc((void **)&kb, (size_t)n * 8) != hipSuccess ||
+	    hipMalloc((void **)&ia, (size_t)n * 2) != hipSuccess || hipMalloc((void **)&ib, (size_t)n * 2) != hipSuccess) goto done;
+	if (hipMemcpy(ka, keys, (size_t)n * 8, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(kb, keys, (size_t)n * 8, hipMemcpyHostToDevice) != hipSuccess ||
+	    hipMemcpy(ia, id.data(), (size_t)n * 2, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(ib, id.data(), (size_t)n * 2, hipMemcpyHostToDevice) != hipSuccess) goto done;
+	hipLaunchKernelGGL(k_dbg_rs_sort, dim3(2), dim3(64), 0, 0, ka, ia, kb, ib, n);
+	if (hipDeviceSynchronize() != hipSuccess) goto done;
+	if (hipMemcpy(order_serial, ia, (size_t)n * 2, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(order_wave, ib, (size_t)n * 2, hipMemcpyDeviceToHost) != hipSuccess) goto done;
+	rc = 0;
+done:
+	(void)hipFree(ka); (void)hipFree(kb); (void)hipFree(ia); (void)hipFree(ib);
+	return rc;
 }

@@ -179,6 +179,9 @@ int  al_dbg_ksw(al_ctx_t *ctx, int n, const uint8_t *seqs, size_t n_seq_bytes, c
 
 /* Self-test of the multi-lane output path (offset exchange + pwrite, or ordered turns) with synthetic blocks; needs no GPU. */
 int  al_dbg_ordered_out_selftest(const char *path, int n_lanes, int n_batches, int use_offsets);
+/* The radix-sort restatement (klib ksort.h radix_sort, unstable above 64 elements) in its serial and its wavefront form on the same
+ * keys: both permutations of 0..n-1 come back; n <= 65535.  Test hook. */
+int  al_dbg_rs_sort(int device, const uint64_t *keys, int n, uint16_t *order_serial, uint16_t *order_wave);
 /* Self-test of the whole-file parallel FASTA loader of the index builders against the block reader: 0 = same names, lengths and
  * bytes, 1 = the loader declined the file (not a plain uncompressed FASTA), -1 = they differ; needs no GPU. */
 int  al_dbg_fasta_selftest(const char *fn, int n_threads);

@@ -285,3 +285,30 @@ def test_ksw_calls_match_aln_seq_taps(golden_unpacked, name):
             bad.append((j, flag, len(t), len(q), got, res))
     ctx.close(); idx.close()
     assert not bad, bad[:5]
+
+
+def test_wavefront_radix_restatement_equals_serial(A, oracle_bin):
+    """d_rs_sort_wave (counts and small buckets by the wavefront, permutation by lane 0) leaves every permutation the serial
+    restatement leaves -- which tests/test_dev_sort_cpu.py pins to the reference's ksort.h -- and the oracle's o_radix_sort_128x."""
+    import ctypes as C
+    L = A.load()
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    O = C.CDLL(os.path.join(ROOT, "oracle", "libal_oracle.so"))
+    O.o_radix_sort_128x.argtypes = [C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(21)
+    for it in range(60):
+        n = int([65, 66, 100, 129, 300, 1000, 2500, 4200, 8192, 9000, 20000, 65535][it % 12])
+        kind = it % 6
+        if kind == 0:    x = rng.integers(0, 1 << 63, size=n, dtype=np.uint64)
+        elif kind == 1:  x = rng.integers(0, 4, size=n, dtype=np.uint64)
+        elif kind == 2:  x = rng.integers(0, 50, size=n, dtype=np.uint64) << np.uint64(int(rng.integers(0, 57)))
+        elif kind == 3:  x = (rng.integers(20, 300, size=n, dtype=np.uint64) << np.uint64(32)) | rng.integers(0, 1 << 32, size=n, dtype=np.uint64) // np.uint64(1 << 22) * np.uint64(1 << 22)   # chain keys: score | hash, with ties
+        elif kind == 4:  x = np.full(n, 12345, dtype=np.uint64)
+        else:            x = np.sort(rng.integers(0, 300, size=n, dtype=np.uint64))[::-1].copy()
+        x = np.ascontiguousarray(x)
+        a = np.zeros(n, dtype=np.uint16); b = np.zeros(n, dtype=np.uint16)
+        assert L.al_dbg_rs_sort(0, x.ctypes.data_as(C.c_void_p), n, a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p)) == 0
+        assert np.array_equal(a, b), (it, n, kind)
+        ref = np.empty((n, 2), dtype=np.uint64); ref[:, 0] = x; ref[:, 1] = np.arange(n, dtype=np.uint64)
+        O.o_radix_sort_128x(ref.ctypes.data, ref.ctypes.data + ref.nbytes)
+        assert np.array_equal(a.astype(np.uint64), ref[:, 1]), (it, n, kind)
