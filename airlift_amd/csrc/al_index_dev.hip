@@ -30,6 +30,7 @@
 #include "al_device.h"
 #include "al_io.h"
 #include "al_seqio.h"
+#include "al_runtime.h"
 
 #define AL_ISEG 256            // reference positions per lane
 
@@ -206,58 +207,58 @@ extern "C" al_idx_t *al_idx_build_device(const char *fn, const al_idxopt_t *io, 
 	hipStream_t st = nullptr;
 	if (hipSetDevice(device) != hipSuccess) { delete mi; return nullptr; }
 	IDX_CHECK(hipStreamCreate(&st));
-	IDX_CHECK(hipMalloc((void **)&d_ascii, sum + 16));
+	IDX_CHECK(al_dev_malloc((void **)&d_ascii, sum + 16));
 	IDX_CHECK(hipMemcpyAsync(d_ascii, ascii.data(), sum, hipMemcpyHostToDevice, st));
 	IDX_CHECK(hipMalloc((void **)&d.S4, n_words * 4));
 	hipLaunchKernelGGL(k_pack_ref, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, st, d_ascii, sum, d.S4, n_words, T);
-	IDX_CHECK(hipMalloc((void **)&d.seq_off, (size_t)n_seq * 8)); IDX_CHECK(hipMalloc((void **)&d.seq_len, (size_t)n_seq * 4)); IDX_CHECK(hipMalloc((void **)&d_segf, (size_t)(n_seq + 1) * 8));
+	IDX_CHECK(hipMalloc((void **)&d.seq_off, (size_t)n_seq * 8)); IDX_CHECK(hipMalloc((void **)&d.seq_len, (size_t)n_seq * 4)); IDX_CHECK(al_dev_malloc((void **)&d_segf, (size_t)(n_seq + 1) * 8));
 	IDX_CHECK(hipMemcpyAsync(d.seq_off, so.data(), (size_t)n_seq * 8, hipMemcpyHostToDevice, st));
 	IDX_CHECK(hipMemcpyAsync(d.seq_len, sl.data(), (size_t)n_seq * 4, hipMemcpyHostToDevice, st));
 	IDX_CHECK(hipMemcpyAsync(d_segf, seg_first.data(), (size_t)(n_seq + 1) * 8, hipMemcpyHostToDevice, st));
-	IDX_CHECK(hipMalloc((void **)&d_cnt, (n_seg + 1) * 4)); IDX_CHECK(hipMalloc((void **)&d_off, (n_seg + 2) * 8));
+	IDX_CHECK(al_dev_malloc((void **)&d_cnt, (n_seg + 1) * 4)); IDX_CHECK(al_dev_malloc((void **)&d_off, (n_seg + 2) * 8));
 	IDX_CHECK(hipMemsetAsync(d_cnt, 0, (n_seg + 1) * 4, st));
 	if (n_seg) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ref_sketch<0>), dim3((unsigned)((n_seg + 63) / 64)), dim3(64), (size_t)w * 64 * 16, st,
 	                              d.S4, d.seq_off, d.seq_len, d_segf, n_seq, n_seg, w, k, d_cnt, (const uint64_t *)nullptr, (uint64_t *)nullptr, (uint64_t *)nullptr);
 	{
 		hipcub::TransformInputIterator<uint64_t, CastU64I, const uint32_t *> it(d_cnt, CastU64I());
 		IDX_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, it, d_off, (int)(n_seg + 1), st));
-		IDX_CHECK(hipMalloc(&d_tmp, tmp_bytes + 16));
+		IDX_CHECK(al_dev_malloc(&d_tmp, tmp_bytes + 16));
 		IDX_CHECK(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, it, d_off, (int)(n_seg + 1), st));
 		IDX_CHECK(hipMemcpyAsync(&total, d_off + n_seg, 8, hipMemcpyDeviceToHost, st));
 		IDX_CHECK(hipStreamSynchronize(st));
-		(void)hipFree(d_tmp); d_tmp = nullptr;
+		al_dev_free(d_tmp); d_tmp = nullptr;
 	}
-	(void)hipFree(d_ascii); d_ascii = nullptr;
+	al_dev_free(d_ascii); d_ascii = nullptr;
 	if (total >= (1ULL << 31)) { fprintf(stderr, "[airlift] al_idx_build_device: %llu minimizers exceed the 31-bit item count of the device sorts (references above ~12 Gbp need a multi-part index, which this path does not build)\n", (unsigned long long)total); goto fail; }
-	IDX_CHECK(hipMalloc((void **)&d_h, (total + 1) * 8)); IDX_CHECK(hipMalloc((void **)&d_y, (total + 1) * 8));
-	IDX_CHECK(hipMalloc((void **)&d_h2, (total + 1) * 8)); IDX_CHECK(hipMalloc((void **)&d_y2, (total + 1) * 8));
+	IDX_CHECK(al_dev_malloc((void **)&d_h, (total + 1) * 8)); IDX_CHECK(hipMalloc((void **)&d_y, (total + 1) * 8));
+	IDX_CHECK(al_dev_malloc((void **)&d_h2, (total + 1) * 8)); IDX_CHECK(al_dev_malloc((void **)&d_y2, (total + 1) * 8));
 	if (n_seg) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ref_sketch<1>), dim3((unsigned)((n_seg + 63) / 64)), dim3(64), (size_t)w * 64 * 16, st,
 	                              d.S4, d.seq_off, d.seq_len, d_segf, n_seq, n_seg, w, k, (uint32_t *)nullptr, d_off, d_h, d_y);
 	while ((1u << rid_bits) < n_seq) ++rid_bits;
 	if (total) {
 		// (hash, position) order: stable LSD sorts, position word first (keys y, values h), then hash (keys h, values y)
 		IDX_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, d_y, d_y2, d_h, d_h2, (int)total, 0, 32 + rid_bits, st));
-		IDX_CHECK(hipMalloc(&d_tmp, tmp_bytes + 16));
+		IDX_CHECK(al_dev_malloc(&d_tmp, tmp_bytes + 16));
 		IDX_CHECK(hipcub::DeviceRadixSort::SortPairs(d_tmp, tmp_bytes, d_y, d_y2, d_h, d_h2, (int)total, 0, 32 + rid_bits, st));
-		(void)hipStreamSynchronize(st); (void)hipFree(d_tmp); d_tmp = nullptr;
+		(void)hipStreamSynchronize(st); al_dev_free(d_tmp); d_tmp = nullptr;
 		IDX_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, d_h2, d_h, d_y2, d_y, (int)total, 0, 2 * k, st));
-		IDX_CHECK(hipMalloc(&d_tmp, tmp_bytes + 16));
+		IDX_CHECK(al_dev_malloc(&d_tmp, tmp_bytes + 16));
 		IDX_CHECK(hipcub::DeviceRadixSort::SortPairs(d_tmp, tmp_bytes, d_h2, d_h, d_y2, d_y, (int)total, 0, 2 * k, st));
-		(void)hipStreamSynchronize(st); (void)hipFree(d_tmp); d_tmp = nullptr;
+		(void)hipStreamSynchronize(st); al_dev_free(d_tmp); d_tmp = nullptr;
 		// d_h / d_y now sorted.  Distinct hashes, their counts and offsets:
 		d_uniq = d_h2; d_h2 = nullptr;                                    // reuse
-		IDX_CHECK(hipMalloc((void **)&d_kcnt, (total + 1) * 4)); IDX_CHECK(hipMalloc((void **)&d_nruns, 8));
+		IDX_CHECK(al_dev_malloc((void **)&d_kcnt, (total + 1) * 4)); IDX_CHECK(al_dev_malloc((void **)&d_nruns, 8));
 		IDX_CHECK(hipcub::DeviceRunLengthEncode::Encode(nullptr, tmp_bytes, d_h, d_uniq, d_kcnt, d_nruns, (int)total, st));
-		IDX_CHECK(hipMalloc(&d_tmp, tmp_bytes + 16));
+		IDX_CHECK(al_dev_malloc(&d_tmp, tmp_bytes + 16));
 		IDX_CHECK(hipcub::DeviceRunLengthEncode::Encode(d_tmp, tmp_bytes, d_h, d_uniq, d_kcnt, d_nruns, (int)total, st));
 		IDX_CHECK(hipMemcpyAsync(&n_keys, d_nruns, 8, hipMemcpyDeviceToHost, st));
 		IDX_CHECK(hipStreamSynchronize(st));
-		(void)hipFree(d_tmp); d_tmp = nullptr;
+		al_dev_free(d_tmp); d_tmp = nullptr;
 		d_koff = d_y2; d_y2 = nullptr;                                    // reuse
 		{
 			hipcub::TransformInputIterator<uint64_t, CastU64I, const uint32_t *> it(d_kcnt, CastU64I());
 			IDX_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, it, d_koff, (int)n_keys, st));
-			IDX_CHECK(hipMalloc(&d_tmp, tmp_bytes + 16));
+			IDX_CHECK(al_dev_malloc(&d_tmp, tmp_bytes + 16));
 			IDX_CHECK(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, it, d_koff, (int)n_keys, st));
 		}
 	}
@@ -271,14 +272,14 @@ extern "C" al_idx_t *al_idx_build_device(const char *fn, const al_idxopt_t *io, 
 	d.tab_bits = bits; d.n_seq = n_seq;
 	mi->tab_bits = bits; mi->n_keys = n_keys; mi->n_pos = total; mi->built_on = device;
 	mi->dev[device] = d;
-	(void)hipFree(d_tmp); (void)hipFree(d_segf); (void)hipFree(d_cnt); (void)hipFree(d_off); (void)hipFree(d_h); (void)hipFree(d_uniq); (void)hipFree(d_koff); (void)hipFree(d_kcnt); (void)hipFree(d_nruns);
-	(void)hipFree(d_h2); (void)hipFree(d_y2);
+	al_dev_free(d_tmp); al_dev_free(d_segf); al_dev_free(d_cnt); al_dev_free(d_off); al_dev_free(d_h); al_dev_free(d_uniq); al_dev_free(d_koff); al_dev_free(d_kcnt); al_dev_free(d_nruns);
+	al_dev_free(d_h2); al_dev_free(d_y2);
 	(void)hipStreamDestroy(st);
 	if (timing) { clock_gettime(CLOCK_MONOTONIC, &tq2); fprintf(stderr, "[airlift] index: FASTA load %.3f s (%d threads), upload + kernels %.3f s; %llu minimizers, %llu distinct\n", secs(tq0, tq1), n_host, secs(tq1, tq2), (unsigned long long)total, (unsigned long long)n_keys); }
 	return mi;
 fail:
-	(void)hipFree(d_tmp); (void)hipFree(d_ascii); (void)hipFree(d_segf); (void)hipFree(d_cnt); (void)hipFree(d_off); (void)hipFree(d_h); (void)hipFree(d_y); (void)hipFree(d_h2); (void)hipFree(d_y2);
-	(void)hipFree(d_uniq); (void)hipFree(d_koff); (void)hipFree(d_kcnt); (void)hipFree(d_nruns);
+	al_dev_free(d_tmp); al_dev_free(d_ascii); al_dev_free(d_segf); al_dev_free(d_cnt); al_dev_free(d_off); al_dev_free(d_h); (void)hipFree(d_y); al_dev_free(d_h2); al_dev_free(d_y2);
+	al_dev_free(d_uniq); al_dev_free(d_koff); al_dev_free(d_kcnt); al_dev_free(d_nruns);
 	(void)hipFree(d.S4); (void)hipFree(d.tab); (void)hipFree(d.seq_off); (void)hipFree(d.seq_len);
 	if (st) (void)hipStreamDestroy(st);
 	delete mi;

@@ -11,6 +11,14 @@
 // either at its old size or empty, and the caller may upload a smaller batch).
 inline bool &al_nomem_flag() { static thread_local bool f = false; return f; }
 
+// Device ranges of the grow-only arenas and the index builder's temporaries: hipMalloc / hipFree behind one pair of functions so that
+// the test switches AL_TEST_POISON / AL_TEST_GUARD (al_runtime.hip) see every range.  (The stream-ordered pool allocator was measured:
+// hipMalloc maps memory at 20-25 GB/s on this platform and the pool recycles a range in milliseconds, tools/micro/malloc_cost.hip, but
+// what a process pays is the driver scrubbing memory a previous process held -- 1.4 s per 60 GB either way -- so the plain calls stay.)
+hipError_t al_dev_malloc(void **p, size_t bytes);
+void al_dev_free(void *p);
+int al_dev_guard_check();            // AL_TEST_GUARD=1: number of live ranges whose guard zones were written (messages on stderr)
+
 template <typename T> struct DevBuf {       // grow-only device array
 	T *p = nullptr; size_t cap = 0;
 	int ensure(size_t n, bool keep = false, hipStream_t s = 0)
@@ -18,17 +26,17 @@ template <typename T> struct DevBuf {       // grow-only device array
 		if (n <= cap) return 0;
 		const size_t ncap = n + n / 4 + 64;
 		T *np = nullptr;
-		if (!keep && p) { (void)hipFree(p); p = nullptr; cap = 0; }       // contents not needed: release first, so the peak is one copy
-		if (hipMalloc((void **)&np, ncap * sizeof(T)) != hipSuccess) {
+		if (!keep && p) { al_dev_free(p); p = nullptr; cap = 0; }         // contents not needed: release first, so the peak is one copy
+		if (al_dev_malloc((void **)&np, ncap * sizeof(T)) != hipSuccess) {
 			(void)hipGetLastError();                                       // not sticky: the next launch check must not see it
-			fprintf(stderr, "[airlift] hipMalloc of %zu bytes failed\n", ncap * sizeof(T)); al_nomem_flag() = true; return -1;
+			fprintf(stderr, "[airlift] device allocation of %zu bytes failed\n", ncap * sizeof(T)); al_nomem_flag() = true; return -1;
 		}
 		if (keep && p && cap) { if (hipMemcpyAsync(np, p, cap * sizeof(T), hipMemcpyDeviceToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return -1; }
-		if (p) (void)hipFree(p);
+		if (p) al_dev_free(p);
 		p = np; cap = ncap;
 		return 0;
 	}
-	void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+	void release() { if (p) al_dev_free(p); p = nullptr; cap = 0; }
 };
 
 struct AlRegOut {            // per-read result header copied back to the host

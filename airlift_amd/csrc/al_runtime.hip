@@ -9,6 +9,10 @@
 #include <algorithm>
 #include "al_internal.h"
 #include "al_device.h"
+#include <mutex>
+#include <atomic>
+#include <map>
+#include <vector>
 #include "al_runtime.h"
 #include "al_dev_sort.h"
 #include "al_io.h"
@@ -31,6 +35,67 @@ __global__ void k_seg_merge(const uint32_t *, int, const uint64_t *, const uint6
 __global__ void k_chain_order(const uint32_t *, int, const uint64_t *, const uint32_t *, uint64_t *, AlAnchor *, const uint64_t *, uint64_t *, AlAnchor *, uint32_t *, uint32_t *);
 __global__ void k_lower_bounds(const uint32_t *, uint32_t, LbThr, uint32_t *);
 __global__ void k_collect_flagged(const uint32_t *, int, const uint32_t *, uint32_t *, uint32_t *);
+
+// Test switches of the allocator.  AL_TEST_POISON=<byte>: every new range is filled with that byte, so that a kernel that reads
+// what nobody wrote shows up (the driver's fresh ranges are zero, which hides such reads);
+// AL_TEST_POISON_ONLY=<n> restricts it to the n-th allocation of the process, AL_TEST_POISON_LOG prints sequence numbers and sizes.
+// AL_TEST_GUARD=1: 4 KB of 0xCD on either side of every range, checked when the range is freed and by al_dev_guard_check():
+// the driver pads ranges to pages, so a kernel that writes a few bytes past its buffer goes unnoticed otherwise.
+static hipError_t al_dev_malloc_raw(void **p, size_t bytes);
+static void al_dev_free_raw(void *p);
+namespace { struct GuardRec { size_t bytes; int seq; }; std::mutex g_guard_m; std::map<void *, GuardRec> g_guard; std::atomic<int> g_alloc_seq(0); const size_t GUARD = 4096; }
+static int guard_check_one(void *user, const GuardRec &r)
+{
+	std::vector<unsigned char> h(2 * GUARD);
+	if (hipDeviceSynchronize() != hipSuccess) return 0;
+	if (hipMemcpy(h.data(), (char *)user - GUARD, GUARD, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(h.data() + GUARD, (char *)user + r.bytes, GUARD, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+	int bad = 0;
+	for (size_t i = 0; i < GUARD; ++i) if (h[i] != 0xCD) { fprintf(stderr, "[airlift] GUARD: alloc #%d (%zu bytes): byte %zd BEFORE the range overwritten (0x%02x)\n", r.seq, r.bytes, (ssize_t)i - (ssize_t)GUARD, h[i]); ++bad; break; }
+	for (size_t i = 0; i < GUARD; ++i) if (h[GUARD + i] != 0xCD) { fprintf(stderr, "[airlift] GUARD: alloc #%d (%zu bytes): byte +%zu AFTER the range overwritten (0x%02x)\n", r.seq, r.bytes, i, h[GUARD + i]); ++bad; break; }
+	return bad;
+}
+int al_dev_guard_check()
+{
+	std::lock_guard<std::mutex> l(g_guard_m);
+	int bad = 0;
+	for (auto &kv : g_guard) bad += guard_check_one(kv.first, kv.second);
+	return bad;
+}
+hipError_t al_dev_malloc(void **p, size_t bytes)
+{
+	static const char *poison = getenv("AL_TEST_POISON"), *only = getenv("AL_TEST_POISON_ONLY"), *plog = getenv("AL_TEST_POISON_LOG"), *guard = getenv("AL_TEST_GUARD");
+	if (guard) {
+		void *raw = nullptr;
+		const hipError_t e = al_dev_malloc_raw(&raw, bytes + 2 * GUARD);
+		if (e != hipSuccess) return e;
+		const int n = g_alloc_seq.fetch_add(1);
+		(void)hipMemset(raw, 0xCD, bytes + 2 * GUARD); (void)hipMemset((char *)raw + GUARD, poison ? atoi(poison) : 0, bytes); (void)hipDeviceSynchronize();
+		*p = (char *)raw + GUARD;
+		if (plog) fprintf(stderr, "[airlift] alloc #%d: %zu bytes\n", n, bytes);
+		std::lock_guard<std::mutex> l(g_guard_m); g_guard[*p] = GuardRec{bytes, n};
+		return hipSuccess;
+	}
+	const hipError_t e = al_dev_malloc_raw(p, bytes);
+	if (e == hipSuccess && poison) {
+		const int n = g_alloc_seq.fetch_add(1);
+		if (plog) fprintf(stderr, "[airlift] alloc #%d: %zu bytes\n", n, bytes);
+		if (!only || atoi(only) == n) { (void)hipMemset(*p, atoi(poison), bytes); (void)hipDeviceSynchronize(); }
+	}
+	return e;
+}
+void al_dev_free(void *p)
+{
+	if (!p) return;
+	static const char *guard = getenv("AL_TEST_GUARD");
+	if (guard) {
+		GuardRec r{0, -1}; bool found = false;
+		{ std::lock_guard<std::mutex> l(g_guard_m); auto it = g_guard.find(p); if (it != g_guard.end()) { r = it->second; found = true; g_guard.erase(it); } }
+		if (found) { (void)guard_check_one(p, r); al_dev_free_raw((char *)p - GUARD); return; }
+	}
+	al_dev_free_raw(p);
+}
+static hipError_t al_dev_malloc_raw(void **p, size_t bytes) { return hipMalloc(p, bytes); }
+static void al_dev_free_raw(void *p) { if (p) (void)hipFree(p); }
 
 static const char *g_stage_names[ST_N] = { "sketch", "seed_lookup", "scan", "size_order", "anchor_sort_small", "anchor_sort", "anchor_sort_blk", "anchor_sort_big", "anchor_heap",
                                            "chain_lds32", "chain_lds48", "chain_lds64", "chain_lds128", "seg_find", "seg_chain_lds", "seg_chain_wave", "seg_merge", "rechain",
@@ -601,6 +666,7 @@ extern "C" int al_batch_run(al_ctx_t *c)
 	float tot = 0; (void)hipEventElapsedTime(&tot, c->ev[0], c->ev[ST_N]); c->ms_total = tot;
 	{ float a = 0, b = 0; if (hipEventElapsedTime(&a, c->ev_side[0], c->ev_side[1]) != hipSuccess) a = 0; if (c->n_rechain == 0 || hipEventElapsedTime(&b, c->ev_side[2], c->ev_side[3]) != hipSuccess) b = 0; c->ms_side = a + b; (void)hipGetLastError(); }
 	c->ran = true;
+	{ static const bool guard = getenv("AL_TEST_GUARD") != nullptr; if (guard && al_dev_guard_check()) fprintf(stderr, "[airlift] GUARD: violations after al_batch_run\n"); }
 	// counters + algorithmic bytes
 	unsigned long long h[16]; AL_HIP_CHECK(hipMemcpy(h, c->counters.p, sizeof(h), hipMemcpyDeviceToHost));
 	if (getenv("AL_TRACE")) { fprintf(stderr, "[airlift] trace: counters"); for (int i = 0; i < 16; ++i) fprintf(stderr, " [%d]=%llu", i, h[i]); fprintf(stderr, " rechain=%u\n", c->n_rechain); }

@@ -90,6 +90,21 @@ def test_large_fragment_paths_identical(golden_unpacked, name, env):
     assert r.stdout == exp, _diff_report(r.stdout, exp, name + "_" + "_".join(env))
 
 
+@pytest.mark.parametrize("name", ["g1_mt150pe", "g3_adversarial", "g6_repeats"])
+def test_no_uninitialised_reads_no_overruns(golden_unpacked, name):
+    """The allocator's test switches: every device range filled with 0xAA before use (a kernel reading what nobody wrote would
+    change the result: fresh hipMalloc ranges are zero, which hides that) and 4 KB guard zones on either side of every range, checked
+    after every batch and when a range is freed (a write past a buffer's end lands in the driver's page padding otherwise)."""
+    d = golden_unpacked[name]
+    m = json.load(open(os.path.join(d, "meta.json")))
+    cmd = [CLI, "-ax", "sr", "-K", "60000"] + (["-R", m["rg"]] if m.get("rg") else [])
+    r = subprocess.run(cmd + [m["ref"]] + m["reads"], cwd=d, capture_output=True, env=dict(os.environ, AL_TEST_POISON="170", AL_TEST_GUARD="1"))
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    assert b"GUARD" not in r.stderr, r.stderr.decode()[-2000:]
+    exp = open(os.path.join(d, "expected.sam"), "rb").read()
+    assert r.stdout == exp, _diff_report(r.stdout, exp, name + "_poison")
+
+
 @pytest.mark.parametrize("devs,extra", [("0,0", []), ("0,0,0", ["-K", "20000"]), ("0,0", ["--bam"]), ("0,0", ["--sorted-bam"])], ids=["2lanes", "3lanes_small_batches", "bam", "sorted_bam"])
 @pytest.mark.parametrize("to_file", [True, False], ids=["pwrite", "pipe"])
 def test_multi_lane_identical(golden_unpacked, tmp_path, devs, extra, to_file):

@@ -53,7 +53,7 @@ for case in range(n_cases):
     if only is not None:
         opts = only.split()
     e = subprocess.run([REF, "-t", "8"] + opts + ["ref.fa"] + files, cwd=d, capture_output=True)
-    o = subprocess.run([CLI, "-ax", "sr"] + opts + ["ref.fa"] + files, cwd=d, capture_output=True)
+    o = subprocess.run([CLI, "-ax", "sr"] + opts + ["ref.fa"] + files, cwd=d, capture_output=True, env=dict(os.environ, AL_PG_PLAIN="1"))
     if os.environ.get('FUZZ_DBGS'):
         for dbg in os.environ['FUZZ_DBGS'].split():
             o2 = subprocess.run([CLI, "-ax", "sr"] + opts + ["ref.fa"] + files, cwd=d, capture_output=True, env=dict(os.environ, AL_DBG=dbg))
