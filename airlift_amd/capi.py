@@ -60,7 +60,8 @@ class BatchStat(C.Structure):
                 ("n_anchor", C.c_uint64), ("n_chain", C.c_uint64), ("n_regs_aln", C.c_uint64), ("n_refbases", C.c_uint64),
                 ("n_cigar", C.c_uint64), ("n_rechain", C.c_uint64), ("n_heap_fallback", C.c_uint64), ("n_sort_tie_flag", C.c_uint64),
                 ("bytes_in", C.c_uint64), ("bytes_out", C.c_uint64), ("algorithmic_bytes", C.c_double),
-                ("ms_total", C.c_float), ("ms_kernel", C.c_float * 40), ("n_stage", C.c_int), ("ms_side_stream", C.c_float), ("n_chain_fallback", C.c_uint64)]
+                ("ms_total", C.c_float), ("ms_kernel", C.c_float * 40), ("n_stage", C.c_int), ("ms_side_stream", C.c_float), ("n_chain_fallback", C.c_uint64),
+                ("dp_jobs", C.c_uint64 * 10), ("dp_target_bases", C.c_uint64 * 10)]
 
 
 _lib = None

@@ -1560,7 +1560,7 @@ struct ExtShared {
 
 #define AL_LANE_QC 64              // longest query a lane-per-job DP handles
 #define AL_NCLS 10                 // job classes: 0..2 lane-per-job (target <= 16/32/64), 3..8 group DP (NB = 1,2,4,8,22,32), 9 LDS-row DP; 10 = empty slot
-#define AL_HIST_N 24               // [0..AL_NCLS] jobs per class, [12..17] job cursors of the group-DP classes
+#define AL_HIST_N 40               // [0..AL_NCLS] jobs per class, [12..17] job cursors of the group-DP classes, [20] fragments left to the monolithic kernel by prep, [24..24+AL_NCLS] target bases per class
 __device__ __forceinline__ int d_job_class(int qlen, int tlen, int lane_ok)
 {
 	const int b = (tlen + 15) / 16;
@@ -1574,8 +1574,8 @@ k_ext_prep(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_
 {
 	const int f = blockIdx.x * blockDim.x + threadIdx.x;
 	unsigned long long c_regs = 0, c_ref = 0, c_cig = 0;
-	__shared__ unsigned s_hist[AL_NCLS + 1];                                   // jobs per class of this block (no run-time indexed local arrays: see k_regs)
-	if (threadIdx.x <= AL_NCLS) s_hist[threadIdx.x] = 0;
+	__shared__ unsigned s_hist[AL_NCLS + 1], s_tl[AL_NCLS + 1];                // jobs / target bases per class of this block (no run-time indexed local arrays: see k_regs)
+	if (threadIdx.x <= AL_NCLS) { s_hist[threadIdx.x] = 0; s_tl[threadIdx.x] = 0; }
 	__syncthreads();
 	const int lane_ok = !((P.dbg >> 29) & 1);
 	if (f < n_frag && W.frag_nu[f] != 0) {
@@ -1695,7 +1695,8 @@ k_ext_prep(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_
 				{ const int c0 = (jl.qlen && !jl.pad0) ? d_job_class(jl.qlen, jl.tlen, lane_ok) : AL_NCLS, c1 = (jr.qlen && !jr.pad0) ? d_job_class(jr.qlen, jr.tlen, lane_ok) : AL_NCLS;
 				  E.job_key[jb] = c0 < AL_NCLS ? ((uint32_t)c0 << 20 | (uint32_t)(jl.qlen + jl.tlen)) : 0xffffffffu;
 				  E.job_key[jb + 1] = c1 < AL_NCLS ? ((uint32_t)c1 << 20 | (uint32_t)(jr.qlen + jr.tlen)) : 0xffffffffu;
-				  atomicAdd(&s_hist[c0], 1u); atomicAdd(&s_hist[c1], 1u); }
+				  atomicAdd(&s_hist[c0], 1u); atomicAdd(&s_hist[c1], 1u);
+				  if (c0 < AL_NCLS) atomicAdd(&s_tl[c0], (unsigned)jl.tlen); if (c1 < AL_NCLS) atomicAdd(&s_tl[c1], (unsigned)jr.tlen); }
 			}
 		};
 		do_seg(0, mreg0, sa0);
@@ -1746,6 +1747,7 @@ k_ext_prep(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_
 	} else if (f < n_frag) E.frag_slow[f] = 0;
 	__syncthreads();
 	if (threadIdx.x <= AL_NCLS && s_hist[threadIdx.x]) atomicAdd(&E.hist[threadIdx.x], (unsigned long long)s_hist[threadIdx.x]);   // one atomic per block and class
+	if (threadIdx.x <= AL_NCLS && s_tl[threadIdx.x]) atomicAdd(&E.hist[24 + threadIdx.x], (unsigned long long)s_tl[threadIdx.x]);
 	for (int d = 32; d > 0; d >>= 1) { c_regs += __shfl_xor(c_regs, d); c_ref += __shfl_xor(c_ref, d); c_cig += __shfl_xor(c_cig, d); }
 	if ((threadIdx.x & 63) == 0) { if (c_regs) atomicAdd(&G.counters[4], c_regs); if (c_ref) atomicAdd(&G.counters[5], c_ref); if (c_cig) atomicAdd(&G.counters[6], c_cig); }
 }
@@ -2436,6 +2438,7 @@ int al_run_align_stage(al_ctx_t *c)
 		hipLaunchKernelGGL(k_collect_slow, dim3((nf + 255) / 256), dim3(256), 0, s, (const uint32_t *)A->frag_slow.p, nf, A->early_list.p, n_early_d);
 		AL_HIP_CHECK(hipEventRecord(c->ev[ST_EXT_PREP + 1], s));
 		unsigned long long hist[16] = {0};
+		for (int i = 0; i < 10; ++i) c->stat_dp_jobs[i] = c->stat_dp_tbases[i] = 0;
 		auto early_mono = [&]() -> int {                                         // (after a synchronisation point of the main stream: n_early is on the host)
 			if (n_early == 0) return 0;
 			int nbs = ((int)n_early + AL_GPB - 1) / AL_GPB; if (nbs > 1024) nbs = 1024;
@@ -2455,7 +2458,9 @@ int al_run_align_stage(al_ctx_t *c)
 			AL_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(A->sort_tmp.p, bytes, A->job_key.p, A->job_key2.p, A->job_idx.p, A->job_idx2.p, (int)nj, 0, 24, s));
 			AL_HIP_CHECK(hipEventRecord(c->ev[ST_EXT_SORT + 1], s));
 			AL_HIP_CHECK(hipMemcpyAsync(hist, A->hist.p, (AL_NCLS + 1) * 8, hipMemcpyDeviceToHost, s));
+			AL_HIP_CHECK(hipMemcpyAsync(c->stat_dp_tbases, A->hist.p + 24, AL_NCLS * 8, hipMemcpyDeviceToHost, s));
 			AL_HIP_CHECK(hipStreamSynchronize(s));
+			for (int i = 0; i < AL_NCLS; ++i) c->stat_dp_jobs[i] = hist[i];
 			if (early_mono()) return -1;
 			if (getenv("AL_TRACE")) fprintf(stderr, "[airlift] trace: prep + job sort done\n");
 			if ((c->P.dbg >> 30) & 1) { fprintf(stderr, "[airlift] DP jobs per class (lane16 lane32 lane64 g1 g2 g4 g8 g22 g32 lds | empty):"); for (int i = 0; i <= AL_NCLS; ++i) fprintf(stderr, " %llu", hist[i]); fprintf(stderr, "\n"); }

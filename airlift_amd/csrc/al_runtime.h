@@ -94,6 +94,7 @@ struct al_ctx_s {
 	bool ran = false;
 	uint64_t stat_bytes_in = 0;
 	uint32_t stat_n_slow = 0;
+	unsigned long long stat_dp_jobs[10] = {}, stat_dp_tbases[10] = {};   // extension DP: jobs and target (reference window) bases per job class of the last run
 	al_batch_stat_t stat;
 };
 

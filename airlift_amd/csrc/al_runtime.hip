@@ -101,9 +101,10 @@ static const char *g_stage_names[ST_N] = { "sketch", "seed_lookup", "scan", "siz
                                            "chain_lds32", "chain_lds48", "chain_lds64", "chain_lds128", "seg_find", "seg_chain_lds", "seg_chain_wave", "seg_merge", "rechain",
                                            "regs", "ext_prep", "ext_sort", "ext_dp_lane", "ext_dp_g4", "ext_dp_g8", "ext_dp_g22", "ext_finish", "compact" };
 // kernel behind each interval (what rocprofv3 --kernel-trace lists); "" = several launches
-static const char *g_stage_kernels[ST_N] = { "k_sketch", "k_seed", "", "", "k_anchor_sort_small", "k_anchor_sort_reg<16,1>", "k_anchor_sort_reg<16,4>", "", "",
-                                             "k_chain_lds<16|24|32, 64>", "k_chain_lds<40|48, 64>", "k_chain_lds<64, 64>", "k_chain_lds<80|96, 64>, <128, 32>", "", "", "k_chain<384>", "",  "",
-                                             "k_regs", "k_ext_prep", "", "k_ext_dp_lane<16|32, 64>", "k_ext_dp<1|2|4, 512, ..>", "k_ext_dp<8, 512, 128>", "k_ext_dp<22, 512, 352>", "k_ext_finish", "k_compact" };
+// the kernel of an interval that is exactly one launch of one kernel ("" otherwise: several kernels or several launches)
+static const char *g_stage_kernels[ST_N] = { "k_sketch", "k_seed", "", "", "k_anchor_sort_small", "", "", "", "",
+                                             "", "", "k_chain_lds<64, 64>", "", "", "", "", "",  "",
+                                             "", "k_ext_prep", "", "", "", "k_ext_dp<8, 512, 128>", "k_ext_dp<22, 512, 352>", "k_ext_finish", "k_compact" };
 extern "C" const char *al_stage_kernel(int i) { return i >= 0 && i < ST_N ? g_stage_kernels[i] : ""; }
 extern "C" const char *al_stage_name(int i) { return i >= 0 && i < ST_N ? g_stage_names[i] : ""; }
 
@@ -677,6 +678,7 @@ extern "C" int al_batch_run(al_ctx_t *c)
 	st.n_regs_aln = h[4]; st.n_refbases = h[5]; st.n_cigar = h[6];
 	st.bytes_in = c->stat_bytes_in; st.bytes_out = 48 * st.n_regs_aln + 4 * st.n_cigar;
 	st.ms_total = c->ms_total; st.n_stage = ST_N; st.ms_side_stream = c->ms_side; st.n_chain_fallback = c->n_chain_fallback; c->n_chain_fallback = 0;
+	for (int i = 0; i < 10; ++i) { st.dp_jobs[i] = c->stat_dp_jobs[i]; st.dp_target_bases[i] = c->stat_dp_tbases[i]; }
 	for (int i = 0; i < ST_N; ++i) st.ms_kernel[i] = c->ms_stage[i];
 	return 0;
 }

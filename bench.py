@@ -275,7 +275,10 @@ def main():
             ("extension", ["ext_prep", "ext_sort", "ext_dp_lane", "ext_dp_g4", "ext_dp_g8", "ext_dp_g22", "ext_finish", "compact"], 0.5 * Wb + float(st.bytes_out)),
         ]
         own = {"sketch": float(st.bytes_in) + 16.0 * M, "seed_lookup": 16.0 * M, "anchor_sort_small": 24.0 * cls(0, 64), "anchor_sort": 24.0 * cls(65, 1024),
-               "anchor_sort_blk": 24.0 * cls(1025, 4096), "chain_lds32": 16.0 * cls(0, 32), "chain_lds48": 16.0 * cls(33, 48), "chain_lds64": 16.0 * cls(49, 64), "chain_lds128": 16.0 * cls(65, 128)}
+               "anchor_sort_blk": 24.0 * cls(1025, 8192), "chain_lds32": 16.0 * cls(0, 32), "chain_lds48": 16.0 * cls(33, 48), "chain_lds64": 16.0 * cls(49, 64), "chain_lds128": 16.0 * cls(65, 128)}
+        # extension DP kernels: reference windows of their jobs at 4 bits / base + one 48-byte ExtOut record per job (the W/2 + B_out terms)
+        for iv, ci in (("ext_dp_g4", 5), ("ext_dp_g8", 6), ("ext_dp_g22", 7)):
+            own[iv] = 0.5 * float(st.dp_target_bases[ci]) + 48.0 * float(st.dp_jobs[ci])
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))) if os.path.exists(os.path.join(ROOT, "profiles", "traffic.json")) else {}
         stages = []
         for name, ivs, by in groups:
@@ -295,7 +298,8 @@ def main():
                 "dominant_kernel": {"kernel": kern[dom], "interval": dom, "ms": per[dom], "algorithmic_bytes": dom_bytes,
                                     "achieved": (dom_bytes / (per[dom] * 1e-3) / 1e9) if dom_bytes else None, "frac": (dom_bytes / (per[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS) if dom_bytes else None,
                                     "traffic": dom_traffic if tj.get("workload") == a.config else None,
-                                    "note": None if dom_bytes is not None else "bytes of this kernel's share of the stage are not separable: see its stage row"},
+                                    "jobs": int(st.dp_jobs[7]) if dom == "ext_dp_g22" else None,
+                                    "note": ("integer-VALU bound: %.0f target bases x ~150 query bases of affine-gap DP cells per launch; its HBM bytes are the 4-bit reference windows and the result records" % float(st.dp_target_bases[7])) if dom == "ext_dp_g22" else (None if dom_bytes is not None else "bytes of this kernel's share of the stage are not separable: see its stage row")},
                 "stages": stages}
         out = {
             "metric": "reads/sec remapped (%d bp PE)" % a.read_len, "value": 2.0 * a.pairs * world * a.steps / dt, "unit": "reads/s",

@@ -232,6 +232,8 @@ typedef struct {
 	int      n_stage;
 	float    ms_side_stream;          /* exact (serial) heap merge + whole-fragment chaining of the fragments with equal-x anchors: runs on a side stream, overlapped with the intervals above */
 	uint64_t n_chain_fallback;        /* fragments re-chained whole because of equal-x chain starts among more than 64 chains */
+	uint64_t dp_jobs[10];             /* extension DP jobs per class (lane 16/32/64 targets, group DP of 1/2/4/8/22/32 16-column blocks, LDS rows) ... */
+	uint64_t dp_target_bases[10];     /* ... and the reference-window bases of those jobs: the W term of the algorithmic bytes, per DP kernel */
 } al_batch_stat_t;
 void al_batch_stat(const al_ctx_t *ctx, al_batch_stat_t *st);
 const char *al_stage_name(int i);

@@ -45,10 +45,15 @@ try:
         files = glob.glob(os.path.join(d, tag, "**", "*counter_collection.csv"), recursive=True)
         if not files:
             continue
-        for row in csv.DictReader(open(files[0])):
-            if row.get("Counter_Name") != ctr:
-                continue
-            e = per.setdefault(short(row.get("Kernel_Name", "")), {"FETCH_SIZE": [0, 0.0], "WRITE_SIZE": [0, 0.0]})
+        rows = [r for r in csv.DictReader(open(files[0])) if r.get("Counter_Name") == ctr]
+        rows.sort(key=lambda r: int(r.get("Dispatch_Id", 0)))
+        # the index build (once per process: its kernels and its library sorts) ends where the first batch run starts
+        first = next((i for i, r in enumerate(rows) if short(r.get("Kernel_Name", "")) == "k_sketch"), 0)
+        for i, row in enumerate(rows):
+            nm = short(row.get("Kernel_Name", ""))
+            if i < first:
+                nm = "index build: " + nm
+            e = per.setdefault(nm, {"FETCH_SIZE": [0, 0.0], "WRITE_SIZE": [0, 0.0]})
             e[ctr][0] += 1; e[ctr][1] += float(row.get("Counter_Value", 0))
     kernels = {}
     for k, e in per.items():
@@ -63,7 +68,7 @@ try:
     # batch runs under the profiler = launches of a once-per-run kernel (bench.py also runs the batch for its counters and its
     # PCIe-inclusive figure, not only warmup + steps)
     n_runs = per.get("k_sketch", {}).get("FETCH_SIZE", [0])[0] or max(1, int(meta.get("steps", 0)) + int(meta.get("warmup", 0)))
-    once = ("k_pack_ref", "k_ref_sketch", "k_tab_insert")          # index build (once per process, not part of a step); its library sorts stay in
+    once = ("index build: ",)                                       # once per process, not part of a step
     tot_f = sum(e["FETCH_SIZE"][1] for k, e in per.items() if not k.startswith(once)) * 1024.0 / n_runs
     tot_w = sum(e["WRITE_SIZE"][1] for k, e in per.items() if not k.startswith(once)) * 1024.0 / n_runs
     wl = meta.get("config", {}).get("key") or (meta.get("config", {}).get("workload", "") or "").split(" ")[0].lower().rstrip(":")
