@@ -118,8 +118,11 @@ struct AlReg {                // device mm_reg1_t (+ mm_extra_t scalars); 112 by
 // meta == nullptr: the list entries are whole fragments.
 struct ChainSeg {
 	const uint32_t *meta;     // per entry: qlen_sum | (paired ? 1 << 31 : 0) of the fragment it belongs to
-	uint32_t *tie;            // per entry: 1 if two of its chains start at anchors of equal x (their order is the fragment-wide sort's business)
-	uint32_t *nc;             // per entry: number of chained anchors written
+	// per entry ONE 16-byte result record (one store by the kernel, one load by k_seg_merge):
+	//   words 0-1: the chain list entry (score << 32 | count) when the entry has exactly one chain (0: the list is in the scratch range),
+	//   word 2: number of chains, word 3: number of chained anchors written | 1 << 31 if two of its chains start at anchors of equal x
+	//   (their order is the fragment-wide sort's business)
+	uint32_t *res;
 	// fragments whose anchors had equal x (tie_flag[f] != 0: exact heap merge, then the whole-fragment wavefront kernel) run on a
 	// side stream next to everything else.  tie_mode 1: skip flagged fragments (main stream), 2: only flagged fragments (side stream)
 	const uint32_t *tie_flag; int tie_mode;

@@ -704,7 +704,9 @@ k_chain(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_off
 	const uint32_t f = frag_list ? frag_list[blockIdx.x] : blockIdx.x;
 	if (seg.tie_mode) { const bool flagged = seg.tie_flag[f] != 0; if (flagged != (seg.tie_mode == 2)) return; }
 	const int64_t n = frag_na[f];
-	if (lane == 0) { frag_nu[f] = 0; if (seg.meta) { seg.tie[f] = 0; seg.nc[f] = 0; } }
+	__shared__ int s_tie_eq;                                                   // segment mode: equal chain starts seen by the <= 64-chain ranking
+	uint32_t *const rec = seg.meta ? seg.res + 4 * (size_t)f : nullptr;         // the entry's result record (ChainSeg)
+	if (lane == 0) { s_tie_eq = 0; if (rec) *reinterpret_cast<uint4 *>(rec) = make_uint4(0u, 0u, 0u, 0u); else frag_nu[f] = 0; }
 	if (n == 0) return;
 	int n_segs, qlen_sum = 0;
 	if (seg.meta) { const uint32_t mt = seg.meta[f]; qlen_sum = (int)(mt & 0x7fffffffu); n_segs = (mt >> 31) ? 2 : 1; }
@@ -952,7 +954,7 @@ k_chain(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_off
 				for (int32_t j = 0; j < n_u1; ++j) { const uint64_t kj = keysL[j]; r += kj < kx || (kj == kx && j < lane); eq = eq || (kj == kx && j != lane); }
 				permL[r] = lane;
 			}
-			if (seg.meta && __ballot(eq) && lane == 0) seg.tie[f] = 1u;
+			if (seg.meta && __ballot(eq) && lane == 0) s_tie_eq = 1;
 		}
 	}
 	CHAIN_SYNC();
@@ -986,10 +988,10 @@ k_chain(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_off
 			int32_t o = 0;
 			if (use_lds_order) { for (int32_t i = 0; i < n_u; ++i) { st_[i] = o; o += (int32_t)(uint32_t)s_qm[sp[i]]; } }                // st_[] = output offset of sorted chain i
 			else { for (int32_t i = 0; i < n_u; ++i) { const int32_t c = T[i]; u[i] = utmp[c]; if (okf) okf[i] = okp[c]; F[i] = o; o += (int32_t)(uint32_t)utmp[c]; } }   // F[] = output offset of sorted chain i
-			if (tie) { if (seg.meta) seg.tie[f] = 1u; else atomicAdd(&counters[1], 1ULL); }
-			if (seg.meta) seg.nc[f] = (uint32_t)o;
+			if (tie && !seg.meta) atomicAdd(&counters[1], 1ULL);
+			if (rec) { rec[3] = (uint32_t)o | ((tie || s_tie_eq) ? 1u << 31 : 0u); }    // (the chain list of this kernel's entries always goes to the scratch range: words 0-1 stay 0)
 		}
-		frag_nu[f] = (uint32_t)n_u;
+		if (rec) rec[2] = (uint32_t)n_u; else frag_nu[f] = (uint32_t)n_u;
 	}
 	CHAIN_SYNC();
 	if (use_lds_order) {   // many short chains: a lane per chain
@@ -1057,9 +1059,9 @@ k_chain_lds(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a
 		__syncthreads();
 	}
 	if (!have || side) return;
-	frag_nu[f] = 0;
-	if (seg.meta) { seg.tie[f] = 0; seg.nc[f] = 0; }
-	if (n == 0) return;
+	uint32_t *const rec = seg.meta ? seg.res + 4 * (size_t)f : nullptr;         // the entry's result record (ChainSeg): written once, at the exits
+#define CHAIN_EXIT0() do { if (rec) *reinterpret_cast<uint4 *>(rec) = make_uint4(0u, 0u, 0u, 0u); else frag_nu[f] = 0; return; } while (0)
+	if (n == 0) CHAIN_EXIT0();
 #define ROW(j) srow[(j) * LANES + lane]
 #define VL(j) sv[(j) * LANES + lane]
 #define TB(j) (reinterpret_cast<uint8_t *>(&srow[(j) * LANES + lane])[7])
@@ -1095,7 +1097,7 @@ k_chain_lds(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a
 			ROW(i) = (uint64_t)((uint32_t)e.x & 0xffffu) | (uint64_t)((uint32_t)e.y & 0xfffu) << 16 | (uint64_t)((e.y & AL_SEED_SEG_MASK) >> AL_SEED_SEG_SHIFT & 1) << 28
 			         | (uint64_t)(far ? 1u : 0u) << 29 | (uint64_t)0xffu << 56;
 		}
-		if (bad) { atomicAdd(&counters[7], 1ULL); return; }   // not representable in the compact rows (never on the short-read path)
+		if (bad) { atomicAdd(&counters[7], 1ULL); CHAIN_EXIT0(); }   // not representable in the compact rows (never on the short-read path)
 	}
 	const double avg_d = (double)(float)((double)(float)((uint32_t)q_span * (uint32_t)n) / (double)(float)n);   // (float)sum/n (chain.c:42)
 	const bool tab_ok = USE_TAB && avg_d == (double)P.k && P.k * 0.01 * (AL_CLIN_N - 1) + 5.0 < 255.0;
@@ -1173,7 +1175,7 @@ k_chain_lds(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a
 			if (j < 0) j = i;
 			utmp[n_u++] = (uint64_t)(uint32_t)FL(j) << 32 | (uint64_t)j;
 		}
-	if (n_u == 0) return;
+	if (n_u == 0) CHAIN_EXIT0();
 	for (int32_t i = 1; i < n_u; ++i) { const uint64_t t = utmp[i]; int32_t j = i; while (j > 0 && utmp[j - 1] < t) { utmp[j] = utmp[j - 1]; --j; } utmp[j] = t; }
 	for (int i = 0; i < n; ++i) TB(i) = 0;
 	uint64_t *const okf = seg.okey ? seg.okey + a_off[f] : nullptr, *const okp = okf ? okf + (n + 1) / 2 : nullptr;
@@ -1201,14 +1203,17 @@ k_chain_lds(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a
 	}
 #undef CXL
 	AlAnchor *b = chained + a_off[f]; uint64_t *u = u_out + a_off[f] + (seg.meta ? 0u : f);
-	int32_t o = 0;
+	int32_t o = 0; uint64_t u1 = 0;
+	const bool one = rec && n_u == 1;                                          // a segment with one chain (most of them): its list entry travels in the record
 	for (int32_t i = 0; i < n_u; ++i) {
 		const int32_t c = TB(i), ni = (int32_t)(uint32_t)utmp[c], k0 = OFFB(c);
-		u[i] = utmp[c]; if (okf) okf[i] = okp[c];
+		if (one) u1 = utmp[c]; else u[i] = utmp[c];
+		if (okf) okf[i] = okp[c];
 		for (int32_t j = 0; j < ni; ++j) b[o++] = a[(int)VL(k0 + (ni - j - 1))];
 	}
-	frag_nu[f] = (uint32_t)n_u;
-	if (seg.meta) { seg.nc[f] = (uint32_t)o; if (eqx) seg.tie[f] = 1u; }
+	if (rec) *reinterpret_cast<uint4 *>(rec) = make_uint4((uint32_t)u1, (uint32_t)(u1 >> 32), (uint32_t)n_u, (uint32_t)o | (eqx ? 1u << 31 : 0u));
+	else frag_nu[f] = (uint32_t)n_u;
+#undef CHAIN_EXIT0
 #undef OFFB
 #undef FL
 #undef PLv
@@ -1293,14 +1298,14 @@ k_seg_scan(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_
 // 64 chains of which two start at equal x is handed to the whole-fragment kernel (fb_list), which restates that sort.
 __global__ void __launch_bounds__(64)
 k_seg_merge(const uint32_t *__restrict__ frag_list, int n_list, const uint64_t *__restrict__ seg_first,
-            const uint64_t *__restrict__ vs_off, const uint32_t *__restrict__ vs_nu, const uint32_t *__restrict__ vs_nc, const uint32_t *__restrict__ vs_tie,
+            const uint64_t *__restrict__ vs_off, const uint4 *__restrict__ vs_res /* ChainSeg::res */,
             const uint64_t *__restrict__ u_tmp, const AlAnchor *__restrict__ chain_tmp, const uint64_t *__restrict__ a_off,
             uint64_t *__restrict__ u_out, AlAnchor *__restrict__ chained, uint32_t *__restrict__ frag_nu,
             uint32_t *__restrict__ fb_list, uint32_t *__restrict__ fb_cnt, const uint32_t *__restrict__ tie_flag,
             const uint64_t *__restrict__ okey_tmp, uint64_t *__restrict__ okey_out)
 {
 	__shared__ uint32_t s_bu[64], s_bc[64];
-	__shared__ uint64_t s_off[64];
+	__shared__ uint64_t s_off[64], s_u1[64];
 	const int lane = threadIdx.x;
 	if ((int)blockIdx.x >= n_list) return;
 	const uint32_t f = frag_list[blockIdx.x];
@@ -1310,17 +1315,19 @@ k_seg_merge(const uint32_t *__restrict__ frag_list, int n_list, const uint64_t *
 	uint64_t run_u = 0, run_c = 0; bool tie = false;
 	for (uint64_t sb = s0; sb < s1; sb += 64) {
 		const uint64_t s = sb + lane; const bool valid = s < s1;
-		const uint32_t nu = valid ? vs_nu[s] : 0u, nc = valid ? vs_nc[s] : 0u;
-		tie = tie || (valid && vs_tie[s] != 0);
+		const uint4 r = valid ? vs_res[s] : make_uint4(0u, 0u, 0u, 0u);
+		const uint32_t nu = r.z, nc = r.w & 0x7fffffffu;
+		tie = tie || (r.w >> 31) != 0;
 		uint32_t iu = nu, ic = nc;
 		for (int d = 1; d < 64; d <<= 1) { const uint32_t tu = __shfl_up(iu, d), tc = __shfl_up(ic, d); if (lane >= d) { iu += tu; ic += tc; } }
 		const uint32_t tot_u = __shfl(iu, 63), tot_c = __shfl(ic, 63);
 		__syncthreads();
-		s_bu[lane] = iu - nu; s_bc[lane] = ic - nc; s_off[lane] = valid ? vs_off[s] : 0;
+		s_bu[lane] = iu - nu; s_bc[lane] = ic - nc; s_off[lane] = valid ? vs_off[s] : 0; s_u1[lane] = nu == 1 ? ((uint64_t)r.x | (uint64_t)r.y << 32) : 0;
 		__syncthreads();
 		for (uint32_t t = lane; t < tot_u; t += 64) {
 			int lo = 0, hi = 64; while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_bu[mid] <= t) lo = mid; else hi = mid; }
-			u[run_u + t] = u_tmp[s_off[lo] + (t - s_bu[lo])];
+			const uint64_t u1 = s_u1[lo];
+			u[run_u + t] = u1 ? u1 : u_tmp[s_off[lo] + (t - s_bu[lo])];
 			if (okey_tmp) {   // processing key with the peak anchor's index made fragment-wide
 				const uint64_t k = okey_tmp[s_off[lo] + (t - s_bu[lo])];
 				okey_out[a_off[f] + run_u + t] = (k & 0xffffffff00000000ULL) | (uint32_t)((uint32_t)k + (uint32_t)(s_off[lo] - a_off[f]));

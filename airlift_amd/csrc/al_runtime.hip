@@ -31,7 +31,7 @@ template <int PER, int NW, int MCAP> __global__ void k_anchor_sort_reg(const uin
 __global__ void k_anchor_big_expand(const uint64_t *, const uint64_t *, const uint32_t *, const AlMatch *, const uint32_t *, const uint32_t *, int, const uint64_t *, uint64_t *, int, int);
 __global__ void k_anchor_big_scatter(const uint64_t *, const uint32_t *, int, const uint64_t *, const uint64_t *, const uint64_t *, const uint32_t *, const uint32_t *, const AlMatch *, const uint32_t *, AlAnchor *, uint32_t *, int, int, int);
 __global__ void k_seg_scan(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *, int, AlParams, int, int, const uint64_t *, uint32_t *, uint64_t *, uint32_t *, uint32_t *, const uint32_t *, uint32_t *);
-__global__ void k_seg_merge(const uint32_t *, int, const uint64_t *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlAnchor *, const uint64_t *, uint64_t *, AlAnchor *, uint32_t *, uint32_t *, uint32_t *, const uint32_t *, const uint64_t *, uint64_t *);
+__global__ void k_seg_merge(const uint32_t *, int, const uint64_t *, const uint64_t *, const uint4 *, const uint64_t *, const AlAnchor *, const uint64_t *, uint64_t *, AlAnchor *, uint32_t *, uint32_t *, uint32_t *, const uint32_t *, const uint64_t *, uint64_t *);
 __global__ void k_chain_order(const uint32_t *, int, const uint64_t *, const uint32_t *, uint64_t *, AlAnchor *, const uint64_t *, uint64_t *, AlAnchor *, uint32_t *, uint32_t *);
 __global__ void k_lower_bounds(const uint32_t *, uint32_t, LbThr, uint32_t *);
 __global__ void k_collect_flagged(const uint32_t *, int, const uint32_t *, uint32_t *, uint32_t *);
@@ -191,7 +191,7 @@ static void ctx_release_buffers(al_ctx_t *c)
 	c->ws_u64.release(); c->tmp_u64.release(); c->frag_rep.release(); c->ws_i32.release(); c->mini.release(); c->heap_ws.release(); c->anchors.release();
 	c->chained.release(); c->match.release(); c->counters.release(); c->scan_tmp.release(); c->regs0.release(); c->regs.release(); c->reg_cnt.release();
 	c->chain_key.release(); c->chain_idx.release(); c->chain_idx2.release(); c->tie_list.release(); c->lb_buf.release(); c->tmp_u64b.release();
-	c->chain_tmp.release(); c->u_tmp.release(); c->okey_tmp.release(); c->fb2_list.release(); c->seg_cnt.release(); c->seg_first.release(); c->vs_off.release(); c->vs_na.release(); c->vs_meta.release(); c->vs_nu.release(); c->vs_nc.release(); c->vs_tie.release(); c->vs_cls.release(); c->seg_key.release(); c->seg_idx.release(); c->seg_ord.release(); c->fb_list.release(); c->tie_frags.release(); c->tie_sorted.release(); c->big_na.release(); c->big_off.release();
+	c->chain_tmp.release(); c->u_tmp.release(); c->okey_tmp.release(); c->fb2_list.release(); c->fb3_list.release(); c->seg_cnt.release(); c->seg_first.release(); c->vs_off.release(); c->vs_na.release(); c->vs_meta.release(); c->vs_res.release(); c->vs_cls.release(); c->seg_key.release(); c->seg_idx.release(); c->seg_ord.release(); c->fb_list.release(); c->tie_frags.release(); c->tie_sorted.release(); c->big_na.release(); c->big_off.release();
 	c->a_off_p1.release(); c->frag_na_p1.release(); c->frag_rep_p1.release(); c->cigar.release(); c->reg_off.release(); c->cig_off.release(); c->align_ws.release(); c->seg_a.release(); c->seg_u.release();
 }
 extern "C" void al_ctx_destroy(al_ctx_t *c)
@@ -351,7 +351,10 @@ static int sort_u32_pairs(al_ctx_t *c, const uint32_t *k_in, uint32_t *k_out, co
 // options in force) through their segments: cut -> order the segments by length -> the lane-per-entry LDS kernels for segments
 // of up to 128 anchors, the wavefront kernel above -> k_seg_merge; fragments the merge hands back (equal-x chain starts among
 // more than 64 chains) are chained whole by the wavefront kernel.
-static int chain_by_segments(al_ctx_t *c, const uint32_t *order, int n, bool lds_ok, bool first, const uint32_t *skip_flag)
+// with_keys: the per-chain processing keys (ChainSeg::okey) are written as well, and fragments whose chain starts tie get their order
+// from k_chain_order.  The hot call runs without them (8 scattered bytes per chain less to write and to read back) and hands the few
+// fragments that turn out to need them (ties among more than 64 chains) to a second call, on those fragments only, with keys.
+static int chain_by_segments(al_ctx_t *c, const uint32_t *order, int n, bool lds_ok, bool first, const uint32_t *skip_flag, bool with_keys = false)
 {
 	hipStream_t s = c->stream;
 	auto ev = [&](int st) -> int { if (first) AL_HIP_CHECK(hipEventRecord(c->ev[st + 1], s)); return 0; };
@@ -369,8 +372,8 @@ static int chain_by_segments(al_ctx_t *c, const uint32_t *order, int n, bool lds
 	AL_HIP_CHECK(hipStreamSynchronize(s));
 	if (ns64 >= (1ULL << 31)) { fprintf(stderr, "[airlift] %llu chaining segments in one batch: upload fewer fragments\n", (unsigned long long)ns64); al_nomem_flag() = true; return -1; }
 	const int ns = (int)ns64;
-	if (c->vs_off.ensure((size_t)ns + 1) || c->vs_na.ensure((size_t)ns + 1) || c->vs_meta.ensure((size_t)ns + 1) || c->vs_nu.ensure((size_t)ns + 1) || c->vs_nc.ensure((size_t)ns + 1) ||
-	    c->vs_tie.ensure((size_t)ns + 1) || c->vs_cls.ensure((size_t)ns + 1) || c->seg_key.ensure((size_t)ns + 1) || c->seg_idx.ensure((size_t)ns + 1) || c->seg_ord.ensure((size_t)ns + 1) || c->fb_list.ensure((size_t)n + 2)) return -1;
+	if (c->vs_off.ensure((size_t)ns + 1) || c->vs_na.ensure((size_t)ns + 1) || c->vs_meta.ensure((size_t)ns + 1) || c->vs_res.ensure(2 * ((size_t)ns + 1)) ||
+	    c->vs_cls.ensure((size_t)ns + 1) || c->seg_key.ensure((size_t)ns + 1) || c->seg_idx.ensure((size_t)ns + 1) || c->seg_ord.ensure((size_t)ns + 1) || c->fb_list.ensure((size_t)n + 2)) return -1;
 	hipLaunchKernelGGL(k_seg_scan, dim3(n), dim3(64), 0, s, c->anchors.p, c->a_off.p, c->frag_na.p, c->frag_first.p, c->rd_len.p, order, n, c->P, lmin, 1,
 	                   (const uint64_t *)c->seg_first.p, (uint32_t *)nullptr, c->vs_off.p, c->vs_na.p, c->vs_meta.p, skip_flag, c->vs_cls.p);
 	uint32_t lb[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -389,30 +392,38 @@ static int chain_by_segments(al_ctx_t *c, const uint32_t *order, int n, bool lds
 	  if (tr && first) fprintf(stderr, "[airlift] trace: segments: %d in %d fragments; by size <=16:%u <=24:%u <=32:%u <=48:%u <=64:%u <=128:%u more:%u\n", ns, n,
 	                          lb[0], lb[1] - lb[0], lb[2] - lb[1], lb[4] - lb[2], lb[5] - lb[4], lb[8] - lb[5], (uint32_t)ns - lb[8]); }
 	if (ev(ST_SEG_FIND)) return -1;
-	const bool keep_keys = c->opt.min_cnt >= 2;                               // a chain has >= 2 anchors: the keys of a segment fit half of its range
-	const ChainSeg sg{c->vs_meta.p, c->vs_tie.p, c->vs_nc.p, nullptr, 0, keep_keys ? c->okey_tmp.p : nullptr};
+	const bool keys_possible = c->opt.min_cnt >= 2;                           // a chain has >= 2 anchors: the keys of a segment fit half of its range
+	const bool keep_keys = with_keys && keys_possible;
+	const ChainSeg sg{c->vs_meta.p, (uint32_t *)c->vs_res.p, nullptr, 0, keep_keys ? c->okey_tmp.p : nullptr};
 	if (ns > 0) {
 		const uint32_t *so = c->seg_ord.p;
 		const uint32_t wave_from = lds_ok ? lb[8] : 0u;
 		if (lds_ok) {
-#define LSEG(C, L, A, B) LCH(C, L, -1, c->vs_off.p, c->vs_na.p, c->chain_tmp.p, c->u_tmp.p, c->vs_nu.p, so + (A), (int)((B) - (A)), sg)
+#define LSEG(C, L, A, B) LCH(C, L, -1, c->vs_off.p, c->vs_na.p, c->chain_tmp.p, c->u_tmp.p, (uint32_t *)nullptr, so + (A), (int)((B) - (A)), sg)
 			LSEG(16, 64, 0u, lb[0]); LSEG(24, 64, lb[0], lb[1]); LSEG(32, 64, lb[1], lb[2]); LSEG(40, 64, lb[2], lb[3]); LSEG(48, 64, lb[3], lb[4]);
 			LSEG(64, 64, lb[4], lb[5]); LSEG(80, 64, lb[5], lb[6]); LSEG(96, 64, lb[6], lb[7]); LSEG(128, 32, lb[7], lb[8]);
 #undef LSEG
 		}
 		if (ev(ST_SEG_CHAIN_LDS)) return -1;
 		const int nw = ns - (int)wave_from;
-		if (nw > 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<AL_CHAIN_CAP>), dim3(nw), dim3(64), 0, s, c->anchors.p, c->vs_off.p, c->vs_na.p, c->frag_first.p, c->rd_len.p, c->chain_tmp.p, c->u_tmp.p, c->vs_nu.p,
+		if (nw > 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<AL_CHAIN_CAP>), dim3(nw), dim3(64), 0, s, c->anchors.p, c->vs_off.p, c->vs_na.p, c->frag_first.p, c->rd_len.p, c->chain_tmp.p, c->u_tmp.p, (uint32_t *)nullptr,
 		                               c->ws_i32.p, c->ws_u64.p, so + wave_from, nw, c->P, c->counters.p, sg);
 		if (ev(ST_SEG_CHAIN_WAVE)) return -1;
 	} else { if (ev(ST_SEG_CHAIN_LDS) || ev(ST_SEG_CHAIN_WAVE)) return -1; }
 	uint32_t *fb_cnt = (uint32_t *)(c->counters.p + 15);
 	AL_HIP_CHECK(hipMemsetAsync(fb_cnt, 0, 8, s));
-	hipLaunchKernelGGL(k_seg_merge, dim3(n), dim3(64), 0, s, order, n, c->seg_first.p, c->vs_off.p, c->vs_nu.p, c->vs_nc.p, c->vs_tie.p, c->u_tmp.p, c->chain_tmp.p, c->a_off.p,
+	hipLaunchKernelGGL(k_seg_merge, dim3(n), dim3(64), 0, s, order, n, c->seg_first.p, c->vs_off.p, (const uint4 *)c->vs_res.p, c->u_tmp.p, c->chain_tmp.p, c->a_off.p,
 	                   c->u.p, c->chained.p, c->frag_nu.p, c->fb_list.p, fb_cnt, skip_flag, keep_keys ? (const uint64_t *)c->okey_tmp.p : nullptr, c->ws_u64.p);
 	uint32_t n_fb = 0;
 	AL_HIP_CHECK(hipMemcpyAsync(&n_fb, fb_cnt, 4, hipMemcpyDeviceToHost, s));
 	AL_HIP_CHECK(hipStreamSynchronize(s));
+	if (n_fb > 0 && keys_possible && !with_keys) {   // the same fragments once more, with keys (the segment arrays are free again; the list moves out of the way)
+		if (c->fb3_list.ensure((size_t)n_fb + 2)) return -1;
+		AL_HIP_CHECK(hipMemcpyAsync(c->fb3_list.p, c->fb_list.p, (size_t)n_fb * 4, hipMemcpyDeviceToDevice, s));
+		if (chain_by_segments(c, c->fb3_list.p, (int)n_fb, lds_ok, false, skip_flag, true)) return -1;
+		if (ev(ST_SEG_MERGE)) return -1;
+		return 0;
+	}
 	c->n_chain_fallback += n_fb;
 	const uint32_t *fb = c->fb_list.p;
 	if (n_fb > 0 && keep_keys) {   // order restated from the merged chains and their processing keys; only what does not fit its tile is chained again
@@ -426,7 +437,7 @@ static int chain_by_segments(al_ctx_t *c, const uint32_t *order, int n, bool lds
 		AL_HIP_CHECK(hipStreamSynchronize(s));
 		fb = c->fb2_list.p;
 	}
-	const ChainSeg whole{nullptr, nullptr, nullptr, nullptr, 0, nullptr};
+	const ChainSeg whole{nullptr, nullptr, nullptr, 0, nullptr};
 	if (n_fb > 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<AL_CHAIN_CAP>), dim3(n_fb), dim3(64), 0, s, c->anchors.p, c->a_off.p, c->frag_na.p, c->frag_first.p, c->rd_len.p, c->chained.p, c->u.p, c->frag_nu.p,
 	                                 c->ws_i32.p, c->ws_u64.p, fb, (int)n_fb, c->P, c->counters.p, whole);
 	if (ev(ST_SEG_MERGE)) return -1;
@@ -548,7 +559,7 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 		if (ev(ST_ANCHOR_HEAP)) return -1;
 	}
 	{
-		const ChainSeg nosg{nullptr, nullptr, nullptr, (const uint32_t *)c->tie_list.p, 1, nullptr};
+		const ChainSeg nosg{nullptr, nullptr, (const uint32_t *)c->tie_list.p, 1, nullptr};
 #define LFR(C, L, A, B) LCH(C, L, -1, c->a_off.p, c->frag_na.p, c->chained.p, c->u.p, c->frag_nu.p, order + (A), (int)((B) - (A)), nosg)
 #define LFRLO(C, L, LO) LCH(C, L, LO, c->a_off.p, c->frag_na.p, c->chained.p, c->u.p, c->frag_nu.p, order, (int)lb65, nosg)
 		if (lds_ok) { LFRLO(16, 64, -1); LFRLO(24, 64, 16); LFRLO(32, 64, 24); }
