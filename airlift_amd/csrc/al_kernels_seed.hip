@@ -284,15 +284,18 @@ k_anchor_heap(const uint64_t *__restrict__ pos, const uint32_t *__restrict__ fra
               const uint32_t *__restrict__ frag_nm, const uint32_t *__restrict__ frag_na, const uint64_t *__restrict__ a_off,
               AlAnchor *__restrict__ anchors, AlAnchor *__restrict__ heap_ws,
               const uint32_t *__restrict__ tie_flag, const uint32_t *__restrict__ frag_list, int n_list, int lo_excl,
-              unsigned long long *__restrict__ counters, int mini_span)
+              unsigned long long *__restrict__ counters, int mini_span, const uint32_t *__restrict__ n_list_dev /* length of frag_list when it was compacted on the device (else null) */,
+              uint32_t wave_na_min /* fragments of at least this many anchors (and <= 128 lists) are left to k_anchor_heap_wave */)
 {
 	__shared__ uint32_t s_h[HCAP > 0 ? 3 * HCAP * LANES : 1];
 	const int lane = threadIdx.x;
 	const uint32_t t = blockIdx.x * LANES + lane;
+	if (n_list_dev) n_list = (int)*n_list_dev;
 	if (lane >= LANES || t >= (uint32_t)n_list) return;
 	const uint32_t f = frag_list ? frag_list[t] : t;
 	if (!tie_flag[f]) return;
 	const uint32_t n = frag_na[f], n_m = frag_nm[f];
+	if (n >= wave_na_min && n_m <= 128u) return;                               // k_anchor_heap_wave takes it
 	if ((int)n_m <= lo_excl || (HCAP > 0 && n_m > (uint32_t)HCAP) || n == 0) return;
 	const uint32_t r0 = frag_first[f], r1 = frag_first[f + 1];
 	int qlen = 0; for (uint32_t r = r0; r < r1; ++r) qlen += (int)rd_len[r];
@@ -306,9 +309,108 @@ k_anchor_heap(const uint64_t *__restrict__ pos, const uint32_t *__restrict__ fra
 	const HeapGlobal h{heap_ws + mini_off[r0]};
 	d_anchor_heap_merge(pos, m, n_m, n, qlen, mini_span, h, out, counters);
 }
-template __global__ void k_anchor_heap<48, 64>(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, AlAnchor *, const uint32_t *, const uint32_t *, int, int, unsigned long long *, int);
-template __global__ void k_anchor_heap<96, 32>(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, AlAnchor *, const uint32_t *, const uint32_t *, int, int, unsigned long long *, int);
-template __global__ void k_anchor_heap<0, 64>(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, AlAnchor *, const uint32_t *, const uint32_t *, int, int, unsigned long long *, int);
+template __global__ void k_anchor_heap<48, 64>(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, AlAnchor *, const uint32_t *, const uint32_t *, int, int, unsigned long long *, int, const uint32_t *, uint32_t);
+template __global__ void k_anchor_heap<96, 32>(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, AlAnchor *, const uint32_t *, const uint32_t *, int, int, unsigned long long *, int, const uint32_t *, uint32_t);
+template __global__ void k_anchor_heap<0, 64>(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, AlAnchor *, const uint32_t *, const uint32_t *, int, int, unsigned long long *, int, const uint32_t *, uint32_t);
+
+// The same merge for the few flagged fragments with tens or hundreds of thousands of anchors (a pair inside a high-copy family, re-seeded
+// with max_occ): one lane per fragment means one dependent HBM load per pop -- 2.5 us each, 0.8 s for 3 * 10^5 anchors, and the launch
+// waits for it.  Here a wavefront takes one fragment: every occurrence list has a ring of RING positions in LDS that all lanes refill
+// together (a lane per list, loads in flight at once), the binary heap sits in LDS, and lane 0 pops -- exactly as d_anchor_heap_merge --
+// until the list it is about to advance has nothing prefetched, which starts the next refill.  A pop then costs LDS round trips only.
+template <int MCAPH, int RING>
+__global__ void __launch_bounds__(64)
+k_anchor_heap_wave(const uint64_t *__restrict__ pos, const uint32_t *__restrict__ frag_first, const uint32_t *__restrict__ rd_len,
+                   const uint64_t *__restrict__ mini_off, const AlMatch *__restrict__ match,
+                   const uint32_t *__restrict__ frag_nm, const uint32_t *__restrict__ frag_na, const uint64_t *__restrict__ a_off,
+                   AlAnchor *__restrict__ anchors, const uint32_t *__restrict__ tie_flag, const uint32_t *__restrict__ frag_list,
+                   const uint32_t *__restrict__ n_list_dev, uint32_t na_min, unsigned long long *__restrict__ counters, int mini_span)
+{
+	__shared__ uint64_t h_x[MCAPH]; __shared__ uint16_t h_mi[MCAPH];          // heap: head position word, list
+	__shared__ uint32_t l_cur[MCAPH], l_have[MCAPH];                           // per list: index of its head, elements fetched so far (the ring holds (cur, have))
+	__shared__ uint64_t ring[MCAPH * RING];
+	__shared__ uint32_t m_off[MCAPH], m_fl[MCAPH], m_qp[MCAPH], m_n[MCAPH];
+	__shared__ uint32_t s_hs, s_nfor, s_nrev;
+	const int lane = threadIdx.x;
+	const uint32_t n_list = *n_list_dev;
+	for (uint32_t t = blockIdx.x; t < n_list; t += gridDim.x) {
+		const uint32_t f = frag_list[t];
+		const uint32_t n = frag_na[f], n_m = frag_nm[f];
+		if (!tie_flag[f] || n < na_min || n_m > (uint32_t)MCAPH || n_m == 0) continue;   // the lane kernels take it
+		const uint32_t r0 = frag_first[f], r1 = frag_first[f + 1];
+		int qlen = 0; for (uint32_t r = r0; r < r1; ++r) qlen += (int)rd_len[r];
+		const AlMatch *m = match + mini_off[r0];
+		AlAnchor *out = anchors + a_off[f];
+		__syncthreads();                                                       // (one wavefront: the LDS arrays of the previous fragment are done with)
+		for (uint32_t i = lane; i < n_m; i += 64) {
+			const AlMatch mm = m[i];
+			m_off[i] = mm.off_lo; m_fl[i] = mm.flags; m_qp[i] = mm.q_pos; m_n[i] = mm.n;
+			const uint32_t k = mm.n < (uint32_t)RING ? mm.n : (uint32_t)RING;    // element j of list i sits in ring[i * RING + j % RING]
+			for (uint32_t j = 0; j < k; ++j) ring[i * RING + j] = d_match_pos(pos, mm.off_lo, mm.flags, j);
+			l_have[i] = k; l_cur[i] = 0;
+			h_x[i] = ring[i * RING]; h_mi[i] = (uint16_t)i;
+		}
+		__syncthreads();
+		if (lane == 0) {
+			atomicAdd(&counters[0], 1ULL);
+			// ks_heapmake (ksort.h:55-59) with heap_lt(a, b) = a.x > b.x (map.c:80)
+			const uint32_t hs = n_m;
+			auto down = [&](uint32_t i, uint32_t nn) {
+				uint32_t k = i; const uint64_t tx = h_x[i]; const uint16_t tm = h_mi[i];
+				while ((k = (k << 1) + 1) < nn) {
+					if (k != nn - 1 && h_x[k] > h_x[k + 1]) ++k;
+					if (h_x[k] > tx) break;
+					h_x[i] = h_x[k]; h_mi[i] = h_mi[k]; i = k;
+				}
+				h_x[i] = tx; h_mi[i] = tm;
+			};
+			if (hs > 1) for (uint32_t i = (hs >> 1) - 1; i != (uint32_t)-1; --i) down(i, hs);
+			s_hs = hs; s_nfor = 0; s_nrev = 0;
+		}
+		__syncthreads();
+		for (;;) {
+			if (lane == 0) {
+				uint32_t hs = s_hs, n_for = s_nfor, n_rev = s_nrev;
+				while (hs > 0) {
+					const uint32_t mi = h_mi[0], cur = l_cur[mi] + 1, ln = m_n[mi];
+					if (cur < ln && cur >= l_have[mi]) break;                      // its next position is not in LDS yet: refill first
+					const uint64_t r = h_x[0]; const uint32_t qp = m_qp[mi], fl = m_fl[mi];
+					const int32_t rpos = (uint32_t)r >> 1; const uint32_t span = (uint32_t)mini_span;
+					AlAnchor a;
+					if ((r & 1) == (qp & 1)) { a.x = (r & 0xffffffff00000000ULL) | (uint32_t)rpos; a.y = (uint64_t)span << 32 | (qp >> 1); }
+					else { a.x = 1ULL << 63 | (r & 0xffffffff00000000ULL) | (uint32_t)rpos; a.y = (uint64_t)span << 32 | (uint32_t)(qlen - ((int)(qp >> 1) + 1 - (int)span) - 1); }
+					a.y |= (uint64_t)(fl & 0xff) << AL_SEED_SEG_SHIFT;
+					if (fl & (1u << 8)) a.y |= AL_SEED_TANDEM;
+					if (!(a.x >> 63)) out[n_for++] = a; else out[n - (++n_rev)] = a;
+					if (cur < ln) { h_x[0] = ring[mi * RING + cur % RING]; l_cur[mi] = cur; }
+					else { --hs; h_x[0] = h_x[hs]; h_mi[0] = h_mi[hs]; }
+					if (hs > 0) {                                                  // ks_heapdown (ksort.h:43-53)
+						uint32_t i = 0, k = 0; const uint64_t tx = h_x[0]; const uint16_t tm = h_mi[0];
+						while ((k = (k << 1) + 1) < hs) {
+							if (k != hs - 1 && h_x[k] > h_x[k + 1]) ++k;
+							if (h_x[k] > tx) break;
+							h_x[i] = h_x[k]; h_mi[i] = h_mi[k]; i = k;
+						}
+						h_x[i] = tx; h_mi[i] = tm;
+					}
+				}
+				s_hs = hs; s_nfor = n_for; s_nrev = n_rev;
+			}
+			__syncthreads();
+			if (s_hs == 0) break;
+			for (uint32_t i = lane; i < n_m; i += 64) {                          // refill: everything that fits behind each list's head
+				uint32_t have = l_have[i]; const uint32_t cur = l_cur[i], ln = m_n[i], off = m_off[i], fl = m_fl[i];
+				while (have < ln && have - cur - 1 < (uint32_t)RING) { ring[i * RING + have % RING] = d_match_pos(pos, off, fl, have); ++have; }
+				l_have[i] = have;
+			}
+			__syncthreads();
+		}
+		__threadfence();                                                        // lane 0's stores before the other lanes read them back
+		const uint32_t n_rev = s_nrev;                                          // map.c:202-207: the reverse-strand tail was written back to front
+		for (uint32_t j = lane; j < n_rev >> 1; j += 64) { const AlAnchor tA = out[n - 1 - j]; out[n - 1 - j] = out[n - (n_rev - j)]; out[n - (n_rev - j)] = tA; }
+	}
+}
+template __global__ void k_anchor_heap_wave<128, 32>(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, const uint32_t *, const uint32_t *, const uint32_t *, uint32_t, unsigned long long *, int);
 
 template <int CAP>
 __global__ void __launch_bounds__(64)
@@ -1356,7 +1458,8 @@ k_seg_merge(const uint32_t *__restrict__ frag_list, int n_list, const uint64_t *
 __global__ void __launch_bounds__(64)
 k_chain_order(const uint32_t *__restrict__ fb_list, int n_fb, const uint64_t *__restrict__ a_off, const uint32_t *__restrict__ frag_nu,
               uint64_t *__restrict__ u_all, AlAnchor *__restrict__ chained, const uint64_t *__restrict__ okey,
-              uint64_t *__restrict__ u_tmp, AlAnchor *__restrict__ chain_tmp, uint32_t *__restrict__ fb2_list, uint32_t *__restrict__ fb2_cnt)
+              uint64_t *__restrict__ u_tmp, AlAnchor *__restrict__ chain_tmp, uint32_t *__restrict__ fb2_list, uint32_t *__restrict__ fb2_cnt,
+              int32_t *__restrict__ ws_i32 /* chaining scratch, 16 bytes per anchor, free here */)
 {
 	extern __shared__ __align__(16) unsigned char s_raw[];
 	__shared__ uint16_t s_rs[AL_RS_SCRATCH / 2];
@@ -1364,11 +1467,16 @@ k_chain_order(const uint32_t *__restrict__ fb_list, int n_fb, const uint64_t *__
 	if ((int)blockIdx.x >= n_fb) return;
 	const uint32_t f = fb_list[blockIdx.x];
 	const int n_u = (int)frag_nu[f];
-	if (n_u > AL_ORD_CAP) { if (lane == 0) fb2_list[atomicAdd(fb2_cnt, 1u)] = f; return; }
-	uint64_t *const key = (uint64_t *)s_raw; uint32_t *const off = (uint32_t *)(key + AL_ORD_CAP); uint16_t *const id = (uint16_t *)(off + AL_ORD_CAP);
+	if (n_u > 65535) { if (lane == 0) fb2_list[atomicAdd(fb2_cnt, 1u)] = f; return; }   // beyond the 16-bit chain ids of the sort restatement
+	int npow2 = 1; while (npow2 < n_u) npow2 <<= 1;
+	// keys, offsets and ids in LDS for up to AL_ORD_CAP chains; more (a read pair inside a high-copy family, re-seeded with max_occ: tens
+	// of thousands of chains) use the fragment's range of the chaining scratch: a chain has >= 2 anchors, so 10 npow2 + 4 n_u < 12 n bytes
+	// fit its 16 n (slower per step, and still milliseconds against seconds for chaining 3 * 10^5 anchors again as one problem)
+	uint64_t *key; uint32_t *off; uint16_t *id;
+	if (n_u <= AL_ORD_CAP) { key = (uint64_t *)s_raw; off = (uint32_t *)(key + AL_ORD_CAP); id = (uint16_t *)(off + AL_ORD_CAP); }
+	else { key = (uint64_t *)(ws_i32 + 4 * a_off[f]); off = (uint32_t *)(key + npow2); id = (uint16_t *)(off + n_u); }
 	uint64_t *u = u_all + a_off[f] + f; AlAnchor *b = chained + a_off[f];
 	const uint64_t *ok = okey + a_off[f];
-	int npow2 = 1; while (npow2 < n_u) npow2 <<= 1;
 	// offsets of the chains' anchors in the merged order (running sum of the counts)
 	{
 		uint32_t run = 0;
@@ -1415,6 +1523,23 @@ k_chain_order(const uint32_t *__restrict__ fb_list, int n_fb, const uint64_t *__
 		for (int i = lane; i < n_u; i += 64) u[i] = ut[i];
 		for (uint32_t t = lane; t < run; t += 64) b[t] = bt[t];
 	}
+}
+
+// list entries whose fragment is flagged, appended to out block by block: inside a block of 256 entries the order of the list is kept
+// (the list is ordered by anchor count: the lanes of a wavefront that walks `out` get fragments of similar size)
+__global__ void __launch_bounds__(256)
+k_collect_flagged_blk(const uint32_t *__restrict__ list, int n, const uint32_t *__restrict__ flag, uint32_t *__restrict__ out, uint32_t *__restrict__ cnt)
+{
+	__shared__ uint32_t s_w[4], s_base;
+	const int t = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	const uint32_t f = t < n ? list[t] : 0u;
+	const bool on = t < n && flag[f] != 0;
+	const unsigned long long m = __ballot(on);
+	if (lane == 0) s_w[w] = (uint32_t)__popcll(m);
+	__syncthreads();
+	if (threadIdx.x == 0) { const uint32_t tot = s_w[0] + s_w[1] + s_w[2] + s_w[3]; s_base = tot ? atomicAdd(cnt, tot) : 0u; }
+	__syncthreads();
+	if (on) { uint32_t o = s_base; for (int i = 0; i < w; ++i) o += s_w[i]; out[o + (uint32_t)__popcll(m & ((1ULL << lane) - 1ULL))] = f; }
 }
 
 // list entries whose fragment is flagged, appended to out (any order)

@@ -24,7 +24,8 @@ extern "C" __global__ void k_alser_count(const AlAnchor *, const uint64_t *, con
 extern "C" __global__ void k_rechain_test(const AlAnchor *, const uint64_t *, const uint64_t *, const uint32_t *, const int32_t *, const uint32_t *, int, uint32_t *, uint32_t *);
 template <int CAP> __global__ void k_anchor_sort(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, uint32_t *, unsigned int *, const uint32_t *, int, unsigned long long *, int);
 __global__ void k_anchor_sort_small(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, uint32_t *, unsigned int *, const uint32_t *, int, unsigned long long *, int);
-template <int HCAP, int LANES> __global__ void k_anchor_heap(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, AlAnchor *, const uint32_t *, const uint32_t *, int, int, unsigned long long *, int);
+template <int HCAP, int LANES> __global__ void k_anchor_heap(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, AlAnchor *, const uint32_t *, const uint32_t *, int, int, unsigned long long *, int, const uint32_t *, uint32_t);
+template <int MCAPH, int RING> __global__ void k_anchor_heap_wave(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, const uint32_t *, const uint32_t *, const uint32_t *, uint32_t, unsigned long long *, int);
 template <int CAP> __global__ void k_chain(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, AlAnchor *, uint64_t *, uint32_t *, int32_t *, uint64_t *, const uint32_t *, int, AlParams, unsigned long long *, ChainSeg);
 template <int CAPL, int LANES> __global__ void k_chain_lds(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, AlAnchor *, uint64_t *, uint32_t *, uint64_t *, const uint32_t *, int, int, AlParams, unsigned long long *, ChainSeg);
 template <int PER, int NW, int MCAP> __global__ void k_anchor_sort_reg(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, uint32_t *, const uint32_t *, int, int, int);
@@ -32,9 +33,10 @@ __global__ void k_anchor_big_expand(const uint64_t *, const uint64_t *, const ui
 __global__ void k_anchor_big_scatter(const uint64_t *, const uint32_t *, int, const uint64_t *, const uint64_t *, const uint64_t *, const uint32_t *, const uint32_t *, const AlMatch *, const uint32_t *, AlAnchor *, uint32_t *, int, int, int);
 __global__ void k_seg_scan(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *, int, AlParams, int, int, const uint64_t *, uint32_t *, uint64_t *, uint32_t *, uint32_t *, const uint32_t *, uint32_t *);
 __global__ void k_seg_merge(const uint32_t *, int, const uint64_t *, const uint64_t *, const uint4 *, const uint64_t *, const AlAnchor *, const uint64_t *, uint64_t *, AlAnchor *, uint32_t *, uint32_t *, uint32_t *, const uint32_t *, const uint64_t *, uint64_t *);
-__global__ void k_chain_order(const uint32_t *, int, const uint64_t *, const uint32_t *, uint64_t *, AlAnchor *, const uint64_t *, uint64_t *, AlAnchor *, uint32_t *, uint32_t *);
+__global__ void k_chain_order(const uint32_t *, int, const uint64_t *, const uint32_t *, uint64_t *, AlAnchor *, const uint64_t *, uint64_t *, AlAnchor *, uint32_t *, uint32_t *, int32_t *);
 __global__ void k_lower_bounds(const uint32_t *, uint32_t, LbThr, uint32_t *);
 __global__ void k_collect_flagged(const uint32_t *, int, const uint32_t *, uint32_t *, uint32_t *);
+__global__ void k_collect_flagged_blk(const uint32_t *, int, const uint32_t *, uint32_t *, uint32_t *);
 
 // Test switches of the allocator.  AL_TEST_POISON=<byte>: every new range is filled with that byte, so that a kernel that reads
 // what nobody wrote shows up (the driver's fresh ranges are zero, which hides such reads);
@@ -191,7 +193,7 @@ static void ctx_release_buffers(al_ctx_t *c)
 	c->ws_u64.release(); c->tmp_u64.release(); c->frag_rep.release(); c->ws_i32.release(); c->mini.release(); c->heap_ws.release(); c->anchors.release();
 	c->chained.release(); c->match.release(); c->counters.release(); c->scan_tmp.release(); c->regs0.release(); c->regs.release(); c->reg_cnt.release();
 	c->chain_key.release(); c->chain_idx.release(); c->chain_idx2.release(); c->tie_list.release(); c->lb_buf.release(); c->tmp_u64b.release();
-	c->chain_tmp.release(); c->u_tmp.release(); c->okey_tmp.release(); c->fb2_list.release(); c->fb3_list.release(); c->seg_cnt.release(); c->seg_first.release(); c->vs_off.release(); c->vs_na.release(); c->vs_meta.release(); c->vs_res.release(); c->vs_cls.release(); c->seg_key.release(); c->seg_idx.release(); c->seg_ord.release(); c->fb_list.release(); c->tie_frags.release(); c->tie_sorted.release(); c->big_na.release(); c->big_off.release();
+	c->chain_tmp.release(); c->u_tmp.release(); c->okey_tmp.release(); c->fb2_list.release(); c->fb3_list.release(); c->seg_cnt.release(); c->seg_first.release(); c->vs_off.release(); c->vs_na.release(); c->vs_meta.release(); c->vs_res.release(); c->vs_cls.release(); c->seg_key.release(); c->seg_idx.release(); c->seg_ord.release(); c->fb_list.release(); c->tie_frags.release(); c->heap_cnt.release(); c->tie_sorted.release(); c->big_na.release(); c->big_off.release();
 	c->a_off_p1.release(); c->frag_na_p1.release(); c->frag_rep_p1.release(); c->cigar.release(); c->reg_off.release(); c->cig_off.release(); c->align_ws.release(); c->seg_a.release(); c->seg_u.release();
 }
 extern "C" void al_ctx_destroy(al_ctx_t *c)
@@ -406,6 +408,7 @@ static int chain_by_segments(al_ctx_t *c, const uint32_t *order, int n, bool lds
 		}
 		if (ev(ST_SEG_CHAIN_LDS)) return -1;
 		const int nw = ns - (int)wave_from;
+		{ static const bool tr = getenv("AL_TRACE") != nullptr; if (tr && nw > 0) fprintf(stderr, "[airlift] trace: %d segments of more than 128 anchors to the wavefront kernel (of %d segments in %d fragments)\n", nw, ns, n); }
 		if (nw > 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<AL_CHAIN_CAP>), dim3(nw), dim3(64), 0, s, c->anchors.p, c->vs_off.p, c->vs_na.p, c->frag_first.p, c->rd_len.p, c->chain_tmp.p, c->u_tmp.p, (uint32_t *)nullptr,
 		                               c->ws_i32.p, c->ws_u64.p, so + wave_from, nw, c->P, c->counters.p, sg);
 		if (ev(ST_SEG_CHAIN_WAVE)) return -1;
@@ -432,12 +435,13 @@ static int chain_by_segments(al_ctx_t *c, const uint32_t *order, int n, bool lds
 		if (!attr_set) { AL_HIP_CHECK(hipFuncSetAttribute((const void *)k_chain_order, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = true; }
 		if (c->fb2_list.ensure((size_t)n_fb + 2)) return -1;
 		AL_HIP_CHECK(hipMemsetAsync(fb_cnt, 0, 8, s));
-		hipLaunchKernelGGL(k_chain_order, dim3(n_fb), dim3(64), lds, s, c->fb_list.p, (int)n_fb, c->a_off.p, c->frag_nu.p, c->u.p, c->chained.p, (const uint64_t *)c->ws_u64.p, c->u_tmp.p, c->chain_tmp.p, c->fb2_list.p, fb_cnt);
+		hipLaunchKernelGGL(k_chain_order, dim3(n_fb), dim3(64), lds, s, c->fb_list.p, (int)n_fb, c->a_off.p, c->frag_nu.p, c->u.p, c->chained.p, (const uint64_t *)c->ws_u64.p, c->u_tmp.p, c->chain_tmp.p, c->fb2_list.p, fb_cnt, c->ws_i32.p);
 		AL_HIP_CHECK(hipMemcpyAsync(&n_fb, fb_cnt, 4, hipMemcpyDeviceToHost, s));
 		AL_HIP_CHECK(hipStreamSynchronize(s));
 		fb = c->fb2_list.p;
 	}
 	const ChainSeg whole{nullptr, nullptr, nullptr, 0, nullptr};
+	{ static const bool tr = getenv("AL_TRACE") != nullptr; if (tr) fprintf(stderr, "[airlift] trace: chain order: %llu fragments with tied chain starts among > 64 chains (%s keys), %u of them chained whole by the wavefront kernel\n", (unsigned long long)c->n_chain_fallback, keep_keys ? "with" : "without", n_fb); }
 	if (n_fb > 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<AL_CHAIN_CAP>), dim3(n_fb), dim3(64), 0, s, c->anchors.p, c->a_off.p, c->frag_na.p, c->frag_first.p, c->rd_len.p, c->chained.p, c->u.p, c->frag_nu.p,
 	                                 c->ws_i32.p, c->ws_u64.p, fb, (int)n_fb, c->P, c->counters.p, whole);
 	if (ev(ST_SEG_MERGE)) return -1;
@@ -551,8 +555,17 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 		hipEvent_t *const evs = c->ev_side + (first ? 0 : 2);
 		AL_HIP_CHECK(hipEventRecord(evs[0], s));
 		AL_HIP_CHECK(hipStreamWaitEvent(c->side, evs[0], 0));
+		// the flagged fragments are compacted first (on the side stream, count on the device): a wavefront of the merge kernels then holds 32 / 64
+		// of them instead of the few that happen to sit among 64 neighbours of the size-ordered list
+		if (c->tie_frags.ensure((size_t)nl + 2) || c->heap_cnt.ensure(4)) return -1;
+		uint32_t *const n_heap_d = c->heap_cnt.p + (first ? 0 : 1);
+		AL_HIP_CHECK(hipMemsetAsync(n_heap_d, 0, 4, c->side));
+		hipLaunchKernelGGL(k_collect_flagged_blk, dim3((nl + 255) / 256), dim3(256), 0, c->side, order, nl, (const uint32_t *)c->tie_list.p, c->tie_frags.p, n_heap_d);
 #define LHEAP(H, LN, LO) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_anchor_heap<H, LN>), dim3((nl + LN - 1) / LN), dim3(64), 0, c->side, c->di.pos, c->frag_first.p, c->rd_len.p, c->mini_off.p, c->match.p, c->frag_nm.p, c->frag_na.p, \
-		                                  c->a_off.p, c->anchors.p, c->heap_ws.p, c->tie_list.p, order, nl, LO, c->counters.p, c->mi->k)
+		                                  c->a_off.p, c->anchors.p, c->heap_ws.p, c->tie_list.p, (const uint32_t *)c->tie_frags.p, nl, LO, c->counters.p, c->mi->k, (const uint32_t *)n_heap_d, wave_na_min)
+		static const uint32_t wave_na_min = getenv("AL_TEST_HEAP_WAVE") ? (uint32_t)atoi(getenv("AL_TEST_HEAP_WAVE")) : 16384u;   // (tests lower it so that small fragments take the wavefront form)
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_anchor_heap_wave<128, 32>), dim3(std::min(nl, 2048)), dim3(64), 0, c->side, c->di.pos, c->frag_first.p, c->rd_len.p, c->mini_off.p, c->match.p, c->frag_nm.p, c->frag_na.p,
+		                   c->a_off.p, c->anchors.p, (const uint32_t *)c->tie_list.p, (const uint32_t *)c->tie_frags.p, (const uint32_t *)n_heap_d, wave_na_min, c->counters.p, c->mi->k);
 		LHEAP(48, 64, -1); LHEAP(96, 32, 48); LHEAP(0, 64, 96);
 #undef LHEAP
 		AL_HIP_CHECK(hipEventRecord(evs[1], c->side));

@@ -74,13 +74,14 @@ def test_lds_dp_path_identical(golden_unpacked, name):
 
 
 @pytest.mark.parametrize("env", [dict(AL_DBG=str(1 << 27)), dict(AL_TEST_SORT_BLK="65"), dict(AL_TEST_SORT_BIG="65"), dict(AL_TEST_SORT_BLK="65", AL_TEST_SORT_BIG="200"),
-                                 dict(AL_TEST_SORT_BIG="65", AL_TEST_BIG_CHUNK="3")],
-                         ids=["segments_wave_only", "block_sort", "device_sort", "block_and_device_sort", "device_sort_chunks"])
+                                 dict(AL_TEST_SORT_BIG="65", AL_TEST_BIG_CHUNK="3"), dict(AL_TEST_HEAP_WAVE="1")],
+                         ids=["segments_wave_only", "block_sort", "device_sort", "block_and_device_sort", "device_sort_chunks", "heap_merge_by_wavefront"])
 @pytest.mark.parametrize("name", ["g1_mt150pe", "g2_250pe", "g3_adversarial", "g6_repeats"])
 def test_large_fragment_paths_identical(golden_unpacked, name, env):
     """The kernels that take over for fragments with many anchors -- chaining by segments (AL_DBG bit 27: every fragment goes
     through the segment path and the wavefront kernel), the register-network block sort and the device-wide radix sort of anchors (also cut into chunks of three fragments)
-    (thresholds lowered so that ordinary fragments reach them) -- must give the reference's bytes as well."""
+    (thresholds lowered so that ordinary fragments reach them), the wavefront form of the exact heap merge for every fragment with equal-x
+    anchors -- must give the reference's bytes as well."""
     d = golden_unpacked[name]
     m = json.load(open(os.path.join(d, "meta.json")))
     cmd = [CLI, "-ax", "sr"] + (["-R", m["rg"]] if m.get("rg") else [])
