@@ -316,8 +316,11 @@ template __global__ void k_anchor_heap<0, 64>(const uint64_t *, const uint32_t *
 // The same merge for the few flagged fragments with tens or hundreds of thousands of anchors (a pair inside a high-copy family, re-seeded
 // with max_occ): one lane per fragment means one dependent HBM load per pop -- 2.5 us each, 0.8 s for 3 * 10^5 anchors, and the launch
 // waits for it.  Here a wavefront takes one fragment: every occurrence list has a ring of RING positions in LDS that all lanes refill
-// together (a lane per list, loads in flight at once), the binary heap sits in LDS, and lane 0 pops -- exactly as d_anchor_heap_merge --
-// until the list it is about to advance has nothing prefetched, which starts the next refill.  A pop then costs LDS round trips only.
+// together (a lane per list, loads in flight at once), the binary heap sits in LDS as 16-byte entries, and lane 0 pops -- exactly as
+// d_anchor_heap_merge -- until the list it is about to advance has nothing prefetched, which starts the next refill.  A pop then costs
+// LDS round trips only: one per sift level (both children at once), the root stays in registers.
+struct HeapW { uint64_t x; uint32_t mi, pad; };                               // heap entry of k_anchor_heap_wave: one 16-byte LDS word
+struct ListW { uint32_t cur, have, n, qp; };                                   // per list: index of its head, elements fetched so far (the ring holds (cur, have)), length, query position word
 template <int MCAPH, int RING>
 __global__ void __launch_bounds__(64)
 k_anchor_heap_wave(const uint64_t *__restrict__ pos, const uint32_t *__restrict__ frag_first, const uint32_t *__restrict__ rd_len,
@@ -326,10 +329,10 @@ k_anchor_heap_wave(const uint64_t *__restrict__ pos, const uint32_t *__restrict_
                    AlAnchor *__restrict__ anchors, const uint32_t *__restrict__ tie_flag, const uint32_t *__restrict__ frag_list,
                    const uint32_t *__restrict__ n_list_dev, uint32_t na_min, unsigned long long *__restrict__ counters, int mini_span)
 {
-	__shared__ uint64_t h_x[MCAPH]; __shared__ uint16_t h_mi[MCAPH];          // heap: head position word, list
-	__shared__ uint32_t l_cur[MCAPH], l_have[MCAPH];                           // per list: index of its head, elements fetched so far (the ring holds (cur, have))
+	__shared__ __align__(16) HeapW h[MCAPH + 1];                               // (+1: the sift reads slot k + 1 unconditionally)
+	__shared__ __align__(16) ListW ls[MCAPH];
 	__shared__ uint64_t ring[MCAPH * RING];
-	__shared__ uint32_t m_off[MCAPH], m_fl[MCAPH], m_qp[MCAPH], m_n[MCAPH];
+	__shared__ uint32_t m_off[MCAPH], m_fl[MCAPH];
 	__shared__ uint32_t s_hs, s_nfor, s_nrev;
 	const int lane = threadIdx.x;
 	const uint32_t n_list = *n_list_dev;
@@ -344,37 +347,45 @@ k_anchor_heap_wave(const uint64_t *__restrict__ pos, const uint32_t *__restrict_
 		__syncthreads();                                                       // (one wavefront: the LDS arrays of the previous fragment are done with)
 		for (uint32_t i = lane; i < n_m; i += 64) {
 			const AlMatch mm = m[i];
-			m_off[i] = mm.off_lo; m_fl[i] = mm.flags; m_qp[i] = mm.q_pos; m_n[i] = mm.n;
+			m_off[i] = mm.off_lo; m_fl[i] = mm.flags;
 			const uint32_t k = mm.n < (uint32_t)RING ? mm.n : (uint32_t)RING;    // element j of list i sits in ring[i * RING + j % RING]
-			for (uint32_t j = 0; j < k; ++j) ring[i * RING + j] = d_match_pos(pos, mm.off_lo, mm.flags, j);
-			l_have[i] = k; l_cur[i] = 0;
-			h_x[i] = ring[i * RING]; h_mi[i] = (uint16_t)i;
+			uint64_t v[RING];
+#pragma unroll
+			for (int j = 0; j < RING; ++j) v[j] = (uint32_t)j < k ? d_match_pos(pos, mm.off_lo, mm.flags, (uint32_t)j) : 0;
+#pragma unroll
+			for (int j = 0; j < RING; ++j) if ((uint32_t)j < k) ring[i * RING + j] = v[j];
+			ls[i] = ListW{0u, k, mm.n, mm.q_pos};
+			h[i] = HeapW{v[0], i, 0u};
 		}
+		if (lane == 0) h[n_m] = HeapW{UINT64_MAX, 0u, 0u};
 		__syncthreads();
 		if (lane == 0) {
 			atomicAdd(&counters[0], 1ULL);
 			// ks_heapmake (ksort.h:55-59) with heap_lt(a, b) = a.x > b.x (map.c:80)
 			const uint32_t hs = n_m;
-			auto down = [&](uint32_t i, uint32_t nn) {
-				uint32_t k = i; const uint64_t tx = h_x[i]; const uint16_t tm = h_mi[i];
-				while ((k = (k << 1) + 1) < nn) {
-					if (k != nn - 1 && h_x[k] > h_x[k + 1]) ++k;
-					if (h_x[k] > tx) break;
-					h_x[i] = h_x[k]; h_mi[i] = h_mi[k]; i = k;
+			if (hs > 1) for (uint32_t i0 = (hs >> 1) - 1; i0 != (uint32_t)-1; --i0) {
+				uint32_t i = i0, k = i0; const HeapW tmp = h[i0];
+				while ((k = (k << 1) + 1) < hs) {
+					if (k != hs - 1 && h[k].x > h[k + 1].x) ++k;
+					if (h[k].x > tmp.x) break;
+					h[i] = h[k]; i = k;
 				}
-				h_x[i] = tx; h_mi[i] = tm;
-			};
-			if (hs > 1) for (uint32_t i = (hs >> 1) - 1; i != (uint32_t)-1; --i) down(i, hs);
+				h[i] = tmp;
+			}
 			s_hs = hs; s_nfor = 0; s_nrev = 0;
 		}
 		__syncthreads();
 		for (;;) {
 			if (lane == 0) {
 				uint32_t hs = s_hs, n_for = s_nfor, n_rev = s_nrev;
+				HeapW top = h[0];                                                  // kept in registers from one pop to the next
 				while (hs > 0) {
-					const uint32_t mi = h_mi[0], cur = l_cur[mi] + 1, ln = m_n[mi];
-					if (cur < ln && cur >= l_have[mi]) break;                      // its next position is not in LDS yet: refill first
-					const uint64_t r = h_x[0]; const uint32_t qp = m_qp[mi], fl = m_fl[mi];
+					const uint32_t mi = top.mi; const ListW L = ls[mi];
+					const uint32_t cur = L.cur + 1;
+					if (cur < L.n && cur >= L.have) break;                          // its next position is not in LDS yet: refill first
+					const uint64_t nx = ring[mi * RING + cur % RING];                // (read ahead of its use: one LDS round trip together with the match flags)
+					const uint32_t fl = m_fl[mi], qp = L.qp;
+					const uint64_t r = top.x;
 					const int32_t rpos = (uint32_t)r >> 1; const uint32_t span = (uint32_t)mini_span;
 					AlAnchor a;
 					if ((r & 1) == (qp & 1)) { a.x = (r & 0xffffffff00000000ULL) | (uint32_t)rpos; a.y = (uint64_t)span << 32 | (qp >> 1); }
@@ -382,26 +393,38 @@ k_anchor_heap_wave(const uint64_t *__restrict__ pos, const uint32_t *__restrict_
 					a.y |= (uint64_t)(fl & 0xff) << AL_SEED_SEG_SHIFT;
 					if (fl & (1u << 8)) a.y |= AL_SEED_TANDEM;
 					if (!(a.x >> 63)) out[n_for++] = a; else out[n - (++n_rev)] = a;
-					if (cur < ln) { h_x[0] = ring[mi * RING + cur % RING]; l_cur[mi] = cur; }
-					else { --hs; h_x[0] = h_x[hs]; h_mi[0] = h_mi[hs]; }
-					if (hs > 0) {                                                  // ks_heapdown (ksort.h:43-53)
-						uint32_t i = 0, k = 0; const uint64_t tx = h_x[0]; const uint16_t tm = h_mi[0];
-						while ((k = (k << 1) + 1) < hs) {
-							if (k != hs - 1 && h_x[k] > h_x[k + 1]) ++k;
-							if (h_x[k] > tx) break;
-							h_x[i] = h_x[k]; h_mi[i] = h_mi[k]; i = k;
-						}
-						h_x[i] = tx; h_mi[i] = tm;
+					HeapW tmp;
+					if (cur < L.n) { tmp = HeapW{nx, mi, 0u}; ls[mi].cur = cur; }
+					else { --hs; tmp = h[hs]; h[hs] = HeapW{UINT64_MAX, 0u, 0u}; }   // (the vacated slot reads as +inf for the unconditional k + 1 loads)
+					if (hs == 0) break;
+					// ks_heapdown (ksort.h:43-53) from the root; both children come with one round trip (16-byte entries), the comparison
+					// that picks between them is the reference's (the right child only if strictly smaller and inside the heap)
+					uint32_t i = 0, k = 0; bool first = true;
+					while ((k = (k << 1) + 1) < hs) {
+						HeapW c0, c1;                                                  // whole entries, two 16-byte reads in flight: one round trip per level
+						{ const uint4 q0 = *reinterpret_cast<const uint4 *>(&h[k]), q1 = *reinterpret_cast<const uint4 *>(&h[k + 1]);
+						  c0.x = (uint64_t)q0.x | (uint64_t)q0.y << 32; c0.mi = q0.z; c0.pad = 0; c1.x = (uint64_t)q1.x | (uint64_t)q1.y << 32; c1.mi = q1.z; c1.pad = 0; }
+						const bool right = k != hs - 1 && c0.x > c1.x;
+						const HeapW c = right ? c1 : c0; k += right ? 1u : 0u;
+						if (c.x > tmp.x) break;
+						h[i] = c; if (first) { top = c; first = false; }
+						i = k;
 					}
+					h[i] = tmp; if (first) top = tmp;
 				}
 				s_hs = hs; s_nfor = n_for; s_nrev = n_rev;
 			}
 			__syncthreads();
 			if (s_hs == 0) break;
 			for (uint32_t i = lane; i < n_m; i += 64) {                          // refill: everything that fits behind each list's head
-				uint32_t have = l_have[i]; const uint32_t cur = l_cur[i], ln = m_n[i], off = m_off[i], fl = m_fl[i];
-				while (have < ln && have - cur - 1 < (uint32_t)RING) { ring[i * RING + have % RING] = d_match_pos(pos, off, fl, have); ++have; }
-				l_have[i] = have;
+				const ListW L = ls[i]; const uint32_t off = m_off[i], fl = m_fl[i];
+				const uint32_t room = (uint32_t)RING - (L.have - L.cur - 1), left = L.n - L.have, need = room < left ? room : left;
+				uint64_t v[RING];                                                  // all loads of the lane in flight at once, then the LDS stores
+#pragma unroll
+				for (int j = 0; j < RING; ++j) v[j] = (uint32_t)j < need ? d_match_pos(pos, off, fl, L.have + (uint32_t)j) : 0;
+#pragma unroll
+				for (int j = 0; j < RING; ++j) if ((uint32_t)j < need) ring[i * RING + (L.have + (uint32_t)j) % RING] = v[j];
+				ls[i].have = L.have + need;
 			}
 			__syncthreads();
 		}
