@@ -16,6 +16,7 @@ import argparse
 import ctypes as C
 import json
 import os
+import re
 import shutil
 import subprocess
 import sys
@@ -113,13 +114,19 @@ def cpu_baseline(tmp, ref_fa, arr, n_pairs, read_len):
     t0 = time.time()
     with open(os.path.join(tmp, "gpu.sam"), "wb") as f:
         rc = subprocess.run([cli, "-ax", "sr", "-t", str(nt), ref_fa, "cb_1.fq", "cb_2.fq"], cwd=tmp, stdout=f, stderr=subprocess.PIPE,
-                            env=dict(os.environ, AL_PG_PLAIN="1"))    # bare @PG line, as the reference driver (no argv) prints it
+                            env=dict(os.environ, AL_PG_PLAIN="1", AL_TIMING="1"))    # bare @PG line, as the reference driver (no argv) prints it
     t_cli = time.time() - t0
+    err = rc.stderr.decode(errors="replace")
+    m_idx = re.search(r"index build ([0-9.]+) s", err); m_pipe = re.search(r"pipeline lane 0 .*total ([0-9.]+) s", err)
     if rc.returncode != 0:
         sys.stderr.write("[bench] airlift-align failed (%d): %s\n" % (rc.returncode, rc.stderr.decode(errors="replace")[-2000:]))
         return base, {"error": "airlift-align exit %d" % rc.returncode, "identical_sam": False}
     e2e = {"wall_s": t_cli, "reads_per_s": 2 * n_pairs / t_cli, "host_threads": nt, "cpu_wall_s": t_cold, "speedup_vs_cpu_wall": t_cold / t_cli,
            "identical_sam": md5(os.path.join(tmp, "gpu.sam")) == md5(os.path.join(tmp, "cpu.sam")),
+           # the same process without its start-up: FASTQ parse -> pack -> H2D -> map -> D2H -> SAM text -> file (the reference's counterpart
+           # is cpu_baseline: its mapping pass without the index build)
+           "index_build_s": float(m_idx.group(1)) if m_idx else None, "pipeline_s": float(m_pipe.group(1)) if m_pipe else None,
+           "pipeline_reads_per_s": (2 * n_pairs / float(m_pipe.group(1))) if m_pipe and float(m_pipe.group(1)) > 0 else None,
            "note": "whole process, cold start: FASTA parse + index build on the GPU + FASTQ parse + mapping + SAM text; CPU wall = its index build + one mapping pass at all cores"}
     return base, e2e
 
