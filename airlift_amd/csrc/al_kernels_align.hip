@@ -2353,16 +2353,19 @@ int al_run_align_stage(al_ctx_t *c)
 		W.mregs = A->mregs.p; W.rtmp = A->rtmp.p; W.rext = A->rext.p; W.cap2 = A->cap2.p; W.b2_off = A->b2_off.p;
 	}
 	if (regs_n0 && heavy_n > 0) {
-		const size_t lds_t = al_regs_heavy_lds(24, 512), lds_s = al_regs_heavy_lds(72, 1024), lds_l = al_regs_heavy_lds(200, 2048);
+		// Five tile sizes; every block takes its fragment only if the kept hits fit its tiles and not the next smaller instance's, so the
+		// instances work on disjoint fragments and run side by side.  The code is one lane on LDS copies: what sets the rate is how many
+		// wavefronts a CU holds, i.e. the tile (17 KB: 9 per CU ... 141 KB: one).
+		const size_t lds_a = al_regs_heavy_lds(12, 256), lds_t = al_regs_heavy_lds(24, 512), lds_b = al_regs_heavy_lds(48, 768), lds_s = al_regs_heavy_lds(72, 1024), lds_l = al_regs_heavy_lds(200, 2048);
 		static bool attr_set = false;
 		if (!attr_set) { AL_HIP_CHECK(hipFuncSetAttribute((const void *)k_regs_heavy<200, 2048, 72, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_l)); attr_set = true; }
-		// every block takes the fragment only if its kept hits fit the instance's tiles: the three instances work on disjoint fragments
 		hipStream_t sd = c->side;
 		AL_HIP_CHECK(hipEventRecord(c->ev_fj[0], s)); AL_HIP_CHECK(hipStreamWaitEvent(sd, c->ev_fj[0], 0));
-		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_heavy<72, 1024, 24, 512>), dim3(heavy_n), dim3(64), lds_s, sd, c->chained.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, (const uint32_t *)c->chain_idx2.p + heavy_from, (int)heavy_n, c->P, c->counters.p, regs_n0);
-		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_heavy<200, 2048, 72, 1024>), dim3(heavy_n), dim3(64), lds_l, sd, c->chained.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, (const uint32_t *)c->chain_idx2.p + heavy_from, (int)heavy_n, c->P, c->counters.p, regs_n0);
+#define LHV(RC, AC, RCL, ACL, LDS, ST) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_heavy<RC, AC, RCL, ACL>), dim3(heavy_n), dim3(64), LDS, ST, c->chained.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, (const uint32_t *)c->chain_idx2.p + heavy_from, (int)heavy_n, c->P, c->counters.p, regs_n0)
+		LHV(72, 1024, 48, 768, lds_s, sd); LHV(48, 768, 24, 512, lds_b, sd); LHV(200, 2048, 72, 1024, lds_l, sd);
 		AL_HIP_CHECK(hipEventRecord(c->ev_fj[1], sd));
-		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_heavy<24, 512, 0, 0>), dim3(heavy_n), dim3(64), lds_t, s, c->chained.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, (const uint32_t *)c->chain_idx2.p + heavy_from, (int)heavy_n, c->P, c->counters.p, regs_n0);
+		LHV(24, 512, 12, 256, lds_t, s); LHV(12, 256, 0, 0, lds_a, s);
+#undef LHV
 		AL_HIP_CHECK(hipStreamWaitEvent(s, c->ev_fj[1], 0));
 	}
 	hipLaunchKernelGGL(k_regs, dim3((nf + 255) / 256), dim3(256), 0, s, c->chained.p, c->u.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, nf, c->P, c->counters.p, (const uint32_t *)regs_n0);
