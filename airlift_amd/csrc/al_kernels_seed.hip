@@ -1366,14 +1366,16 @@ template __global__ void k_chain<AL_CHAIN_CAP>(const AlAnchor *, const uint64_t 
 // between neighbours no later anchor can reach back over the gap).  Segments that cannot hold a chain (fewer than lmin
 // anchors) are dropped.  mode 0 counts the fragment's segments, mode 1 writes them at seg_first[entry] in x order.
 // =============================================================================================
-// size class of a segment = which chaining kernel takes it (CAPL 16, 24, 32, 40, 48, 64, 80, 96, 128, wave): the segment list is
-// ordered by class only (stable), so that inside a class the segments keep their order in memory
+// size class of a segment = which chaining kernel takes it (CAPL 16, 24, 32, 40, 48, 64, 80, 96, 128, wave).  Class 0 (almost all
+// segments of a repeat-rich fragment) is listed by k_seg_scan itself, in memory order; the others are ordered by class (stable: inside a
+// class the segments keep their order in memory)
 __device__ __forceinline__ uint32_t d_seg_class(uint32_t n) { return n <= 16 ? 0u : n <= 24 ? 1u : n <= 32 ? 2u : n <= 40 ? 3u : n <= 48 ? 4u : n <= 64 ? 5u : n <= 80 ? 6u : n <= 96 ? 7u : n <= 128 ? 8u : 9u; }
 __global__ void __launch_bounds__(64)
 k_seg_scan(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_off, const uint32_t *__restrict__ frag_na,
            const uint32_t *__restrict__ frag_first, const uint32_t *__restrict__ rd_len, const uint32_t *__restrict__ frag_list, int n_list,
-           AlParams P, int lmin, int mode, const uint64_t *__restrict__ seg_first, uint32_t *__restrict__ seg_cnt,
-           uint64_t *__restrict__ vs_off, uint32_t *__restrict__ vs_na, uint32_t *__restrict__ vs_meta, const uint32_t *__restrict__ tie_flag, uint32_t *__restrict__ vs_cls)
+           AlParams P, int lmin, int mode, const uint64_t *__restrict__ seg_first, const uint64_t *__restrict__ seg_first0, uint32_t *__restrict__ seg_cnt, uint32_t *__restrict__ seg_cnt0,
+           uint64_t *__restrict__ vs_off, uint32_t *__restrict__ vs_na, uint32_t *__restrict__ vs_meta, const uint32_t *__restrict__ tie_flag,
+           uint32_t *__restrict__ list0 /* mode 1: the segments of class 0 (<= 16 anchors), in memory order */, uint32_t *__restrict__ list1, uint32_t *__restrict__ cls1 /* the others and their classes */)
 {
 	const int lane = threadIdx.x;
 	if ((int)blockIdx.x >= n_list) return;
@@ -1388,9 +1390,15 @@ k_seg_scan(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_
 	const uint32_t meta = (uint32_t)qlen_sum | (r1 - r0 > 1 ? 1u << 31 : 0u);
 	const uint64_t base_off = a_off[f];
 	const AlAnchor *a = anchors + base_off;
-	uint64_t out = mode ? seg_first[blockIdx.x] : 0;
-	uint32_t cnt = 0; int64_t open_start = 0; uint64_t prev_last = 0;
+	const uint64_t out = mode ? seg_first[blockIdx.x] : 0, out0 = mode ? seg_first0[blockIdx.x] : 0;   // first segment / first class-0 segment of this fragment
+	uint32_t cnt = 0, cnt0 = 0; int64_t open_start = 0; uint64_t prev_last = 0;
 	const unsigned long long below = (1ULL << lane) - 1ULL;
+	// a segment's record index k; class 0 goes to list0 at its running number among the class-0 segments, the rest to list1 / cls1
+	auto emit = [&](uint64_t k, uint64_t k0, uint64_t k1, int64_t start, uint32_t len) {
+		vs_off[k] = base_off + (uint64_t)start; vs_na[k] = len; vs_meta[k] = meta;
+		const uint32_t cl = d_seg_class(len);
+		if (cl == 0) list0[k0] = (uint32_t)k; else { list1[k1] = (uint32_t)k; cls1[k1] = cl; }
+	};
 	for (int64_t base = 0; base < n; base += 64) {
 		const int64_t i = base + lane; const bool valid = i < n;
 		const uint64_t x = valid ? a[i].x : 0;
@@ -1404,17 +1412,21 @@ k_seg_scan(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_
 			start = lower ? base + (63 - __clzll((long long)lower)) : open_start;
 			useful = i - start >= lmin;
 		}
-		const unsigned long long um = __ballot(useful);
-		if (mode && useful) { const uint64_t k = out + cnt + __popcll(um & below); vs_off[k] = base_off + (uint64_t)start; vs_na[k] = (uint32_t)(i - start); vs_meta[k] = meta; vs_cls[k] = d_seg_class((uint32_t)(i - start)); }
-		cnt += (uint32_t)__popcll(um);
+		const bool small = useful && d_seg_class((uint32_t)(i - start)) == 0;
+		const unsigned long long um = __ballot(useful), um0 = __ballot(small);
+		if (mode && useful) {
+			const uint32_t o = cnt + (uint32_t)__popcll(um & below), o0 = cnt0 + (uint32_t)__popcll(um0 & below);
+			emit(out + o, out0 + o0, (out - out0) + (o - o0), start, (uint32_t)(i - start));
+		}
+		cnt += (uint32_t)__popcll(um); cnt0 += (uint32_t)__popcll(um0);
 		if (mask) open_start = base + (63 - __clzll((long long)mask));
 		prev_last = (uint64_t)(uint32_t)__shfl((int)(uint32_t)x, 63) | (uint64_t)(uint32_t)__shfl((int)(uint32_t)(x >> 32), 63) << 32;
 	}
 	if (n > 0 && n - open_start >= lmin) {
-		if (mode && lane == 0) { const uint64_t k = out + cnt; vs_off[k] = base_off + (uint64_t)open_start; vs_na[k] = (uint32_t)(n - open_start); vs_meta[k] = meta; vs_cls[k] = d_seg_class((uint32_t)(n - open_start)); }
-		++cnt;
+		if (mode && lane == 0) emit(out + cnt, out0 + cnt0, (out - out0) + (cnt - cnt0), open_start, (uint32_t)(n - open_start));
+		++cnt; cnt0 += d_seg_class((uint32_t)(n - open_start)) == 0 ? 1u : 0u;
 	}
-	if (!mode && lane == 0) seg_cnt[blockIdx.x] = cnt;
+	if (!mode && lane == 0) { seg_cnt[blockIdx.x] = cnt; seg_cnt0[blockIdx.x] = cnt0; }
 }
 
 // k_seg_merge: the fragment's chain list from the chain lists of its segments.  chain.c:144-160 orders the chains by the x of

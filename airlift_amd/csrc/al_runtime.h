@@ -75,9 +75,9 @@ struct al_ctx_s {
 	DevBuf<uint8_t> scan_tmp;
 	DevBuf<uint32_t> chain_key, chain_idx, chain_idx2, tie_list, lb_buf;
 	// segment-wise chaining of large fragments (al_runtime.hip: chain_by_segments) and the device-wide sort of their anchors
-	DevBuf<AlAnchor> chain_tmp; DevBuf<uint64_t> u_tmp, okey_tmp, seg_first, vs_off, big_off;
+	DevBuf<AlAnchor> chain_tmp; DevBuf<uint64_t> u_tmp, okey_tmp, seg_first, seg_first0, vs_off, big_off;
 	DevBuf<uint64_t> vs_res;                 // two words per segment: ChainSeg::res
-	DevBuf<uint32_t> seg_cnt, vs_na, vs_meta, vs_cls, seg_key, seg_idx, seg_ord, fb_list, fb2_list, fb3_list, big_na, tie_frags, tie_sorted, heap_cnt;
+	DevBuf<uint32_t> seg_cnt, seg_cnt0, seg_t1, vs_na, vs_meta, vs_cls, seg_key, seg_idx, seg_ord, fb_list, fb2_list, fb3_list, big_na, tie_frags, tie_sorted, heap_cnt;
 	uint64_t n_chain_fallback = 0;
 	int max_qlen_sum = 0;                 // longest fragment of the resident batch
 	DevBuf<uint64_t> a_off_p1; DevBuf<uint32_t> frag_na_p1; DevBuf<int32_t> frag_rep_p1;   // pass-1 snapshots when a re-chain pass ran (taps)

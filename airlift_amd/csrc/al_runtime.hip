@@ -31,7 +31,7 @@ template <int CAPL, int LANES> __global__ void k_chain_lds(const AlAnchor *, con
 template <int PER, int NW, int MCAP> __global__ void k_anchor_sort_reg(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, uint32_t *, const uint32_t *, int, int, int);
 __global__ void k_anchor_big_expand(const uint64_t *, const uint64_t *, const uint32_t *, const AlMatch *, const uint32_t *, const uint32_t *, int, const uint64_t *, uint64_t *, int, int);
 __global__ void k_anchor_big_scatter(const uint64_t *, const uint32_t *, int, const uint64_t *, const uint64_t *, const uint64_t *, const uint32_t *, const uint32_t *, const AlMatch *, const uint32_t *, AlAnchor *, uint32_t *, int, int, int);
-__global__ void k_seg_scan(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *, int, AlParams, int, int, const uint64_t *, uint32_t *, uint64_t *, uint32_t *, uint32_t *, const uint32_t *, uint32_t *);
+__global__ void k_seg_scan(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *, int, AlParams, int, int, const uint64_t *, const uint64_t *, uint32_t *, uint32_t *, uint64_t *, uint32_t *, uint32_t *, const uint32_t *, uint32_t *, uint32_t *, uint32_t *);
 __global__ void k_seg_merge(const uint32_t *, int, const uint64_t *, const uint64_t *, const uint4 *, const uint64_t *, const AlAnchor *, const uint64_t *, uint64_t *, AlAnchor *, uint32_t *, uint32_t *, uint32_t *, const uint32_t *, const uint64_t *, uint64_t *);
 __global__ void k_chain_order(const uint32_t *, int, const uint64_t *, const uint32_t *, uint64_t *, AlAnchor *, const uint64_t *, uint64_t *, AlAnchor *, uint32_t *, uint32_t *, int32_t *);
 __global__ void k_lower_bounds(const uint32_t *, uint32_t, LbThr, uint32_t *);
@@ -193,7 +193,7 @@ static void ctx_release_buffers(al_ctx_t *c)
 	c->ws_u64.release(); c->tmp_u64.release(); c->frag_rep.release(); c->ws_i32.release(); c->mini.release(); c->heap_ws.release(); c->anchors.release();
 	c->chained.release(); c->match.release(); c->counters.release(); c->scan_tmp.release(); c->regs0.release(); c->regs.release(); c->reg_cnt.release();
 	c->chain_key.release(); c->chain_idx.release(); c->chain_idx2.release(); c->tie_list.release(); c->lb_buf.release(); c->tmp_u64b.release();
-	c->chain_tmp.release(); c->u_tmp.release(); c->okey_tmp.release(); c->fb2_list.release(); c->fb3_list.release(); c->seg_cnt.release(); c->seg_first.release(); c->vs_off.release(); c->vs_na.release(); c->vs_meta.release(); c->vs_res.release(); c->vs_cls.release(); c->seg_key.release(); c->seg_idx.release(); c->seg_ord.release(); c->fb_list.release(); c->tie_frags.release(); c->heap_cnt.release(); c->tie_sorted.release(); c->big_na.release(); c->big_off.release();
+	c->chain_tmp.release(); c->u_tmp.release(); c->okey_tmp.release(); c->fb2_list.release(); c->fb3_list.release(); c->seg_cnt.release(); c->seg_first.release(); c->seg_cnt0.release(); c->seg_first0.release(); c->seg_t1.release(); c->vs_off.release(); c->vs_na.release(); c->vs_meta.release(); c->vs_res.release(); c->vs_cls.release(); c->seg_key.release(); c->seg_idx.release(); c->seg_ord.release(); c->fb_list.release(); c->tie_frags.release(); c->heap_cnt.release(); c->tie_sorted.release(); c->big_na.release(); c->big_off.release();
 	c->a_off_p1.release(); c->frag_na_p1.release(); c->frag_rep_p1.release(); c->cigar.release(); c->reg_off.release(); c->cig_off.release(); c->align_ws.release(); c->seg_a.release(); c->seg_u.release();
 }
 extern "C" void al_ctx_destroy(al_ctx_t *c)
@@ -364,53 +364,59 @@ static int chain_by_segments(al_ctx_t *c, const uint32_t *order, int n, bool lds
 	// a segment of fewer than lmin anchors cannot hold a chain: min_cnt anchors, and min_chain_score at <= k + 1 per anchor (chain.c:60-73,118-124)
 	int lmin = c->opt.min_cnt > 1 ? c->opt.min_cnt : 1;
 	{ const int per = c->mi->k + 1, need = (c->opt.min_chain_score + per - 1) / per; if (need > lmin) lmin = need; }
-	if (c->seg_cnt.ensure((size_t)n + 2) || c->seg_first.ensure((size_t)n + 2)) return -1;
+	if (c->seg_cnt.ensure((size_t)n + 2) || c->seg_first.ensure((size_t)n + 2) || c->seg_cnt0.ensure((size_t)n + 2) || c->seg_first0.ensure((size_t)n + 2)) return -1;
 	hipLaunchKernelGGL(k_seg_scan, dim3(n), dim3(64), 0, s, c->anchors.p, c->a_off.p, c->frag_na.p, c->frag_first.p, c->rd_len.p, order, n, c->P, lmin, 0,
-	                   (const uint64_t *)nullptr, c->seg_cnt.p, (uint64_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, skip_flag, (uint32_t *)nullptr);
-	AL_HIP_CHECK(hipMemsetAsync(c->seg_cnt.p + n, 0, 4, s));
-	if (scan_u32_to_u64(c, c->seg_cnt.p, c->seg_first.p, n)) return -1;
-	uint64_t ns64 = 0;
+	                   (const uint64_t *)nullptr, (const uint64_t *)nullptr, c->seg_cnt.p, c->seg_cnt0.p, (uint64_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, skip_flag,
+	                   (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr);
+	AL_HIP_CHECK(hipMemsetAsync(c->seg_cnt.p + n, 0, 4, s)); AL_HIP_CHECK(hipMemsetAsync(c->seg_cnt0.p + n, 0, 4, s));
+	if (scan_u32_to_u64(c, c->seg_cnt.p, c->seg_first.p, n) || scan_u32_to_u64(c, c->seg_cnt0.p, c->seg_first0.p, n)) return -1;
+	uint64_t ns64 = 0, ns0_64 = 0;
 	AL_HIP_CHECK(hipMemcpyAsync(&ns64, c->seg_first.p + n, 8, hipMemcpyDeviceToHost, s));
+	AL_HIP_CHECK(hipMemcpyAsync(&ns0_64, c->seg_first0.p + n, 8, hipMemcpyDeviceToHost, s));
 	AL_HIP_CHECK(hipStreamSynchronize(s));
 	if (ns64 >= (1ULL << 31)) { fprintf(stderr, "[airlift] %llu chaining segments in one batch: upload fewer fragments\n", (unsigned long long)ns64); al_nomem_flag() = true; return -1; }
-	const int ns = (int)ns64;
+	// ns segments, ns0 of them of class 0 (at most 16 anchors: listed by the fill pass in memory order), n1 others (ordered by class below)
+	const int ns = (int)ns64, ns0 = (int)ns0_64, n1 = ns - ns0;
 	if (c->vs_off.ensure((size_t)ns + 1) || c->vs_na.ensure((size_t)ns + 1) || c->vs_meta.ensure((size_t)ns + 1) || c->vs_res.ensure(2 * ((size_t)ns + 1)) ||
-	    c->vs_cls.ensure((size_t)ns + 1) || c->seg_key.ensure((size_t)ns + 1) || c->seg_idx.ensure((size_t)ns + 1) || c->seg_ord.ensure((size_t)ns + 1) || c->fb_list.ensure((size_t)n + 2)) return -1;
+	    c->seg_idx.ensure((size_t)ns0 + 1) || c->vs_cls.ensure((size_t)n1 + 1) || c->seg_t1.ensure((size_t)n1 + 1) || c->seg_key.ensure((size_t)n1 + 1) || c->seg_ord.ensure((size_t)n1 + 1) || c->fb_list.ensure((size_t)n + 2)) return -1;
 	hipLaunchKernelGGL(k_seg_scan, dim3(n), dim3(64), 0, s, c->anchors.p, c->a_off.p, c->frag_na.p, c->frag_first.p, c->rd_len.p, order, n, c->P, lmin, 1,
-	                   (const uint64_t *)c->seg_first.p, (uint32_t *)nullptr, c->vs_off.p, c->vs_na.p, c->vs_meta.p, skip_flag, c->vs_cls.p);
-	uint32_t lb[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-	if (ns > 0) {
-		hipLaunchKernelGGL(k_iota_u32, dim3((ns + 255) / 256), dim3(256), 0, s, c->seg_idx.p, (uint32_t)ns);
+	                   (const uint64_t *)c->seg_first.p, (const uint64_t *)c->seg_first0.p, (uint32_t *)nullptr, (uint32_t *)nullptr, c->vs_off.p, c->vs_na.p, c->vs_meta.p, skip_flag,
+	                   c->seg_idx.p, c->seg_t1.p, c->vs_cls.p);
+	uint32_t lb[8] = {0, 0, 0, 0, 0, 0, 0, 0};                                // starts of classes 2 .. 9 in the class-ordered list of the n1 others
+	if (n1 > 0) {
 		{   // stable sort by size class only (4 bits: one radix pass)
 			size_t bytes = 0;
-			AL_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const uint32_t *)c->vs_cls.p, c->seg_key.p, (const uint32_t *)c->seg_idx.p, c->seg_ord.p, ns, 0, 4, s));
+			AL_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const uint32_t *)c->vs_cls.p, c->seg_key.p, (const uint32_t *)c->seg_t1.p, c->seg_ord.p, n1, 0, 4, s));
 			if (c->scan_tmp.ensure(bytes + 16)) return -1;
-			AL_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(c->scan_tmp.p, bytes, (const uint32_t *)c->vs_cls.p, c->seg_key.p, (const uint32_t *)c->seg_idx.p, c->seg_ord.p, ns, 0, 4, s));
+			AL_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(c->scan_tmp.p, bytes, (const uint32_t *)c->vs_cls.p, c->seg_key.p, (const uint32_t *)c->seg_t1.p, c->seg_ord.p, n1, 0, 4, s));
 		}
-		static const uint32_t thr[9] = {1, 2, 3, 4, 5, 6, 7, 8, 9};
-		if (lower_bounds(c, c->seg_key.p, (uint32_t)ns, thr, 9, lb)) return -1;
+		static const uint32_t thr[8] = {2, 3, 4, 5, 6, 7, 8, 9};
+		if (lower_bounds(c, c->seg_key.p, (uint32_t)n1, thr, 8, lb)) return -1;
 	}
 	{ static const bool tr = getenv("AL_TRACE") != nullptr;
-	  if (tr && first) fprintf(stderr, "[airlift] trace: segments: %d in %d fragments; by size <=16:%u <=24:%u <=32:%u <=48:%u <=64:%u <=128:%u more:%u\n", ns, n,
-	                          lb[0], lb[1] - lb[0], lb[2] - lb[1], lb[4] - lb[2], lb[5] - lb[4], lb[8] - lb[5], (uint32_t)ns - lb[8]); }
+	  if (tr && first) fprintf(stderr, "[airlift] trace: segments: %d in %d fragments; by size <=16:%d <=24:%u <=32:%u <=48:%u <=64:%u <=128:%u more:%u\n", ns, n,
+	                          ns0, lb[0], lb[1] - lb[0], lb[3] - lb[1], lb[4] - lb[3], lb[7] - lb[4], (uint32_t)n1 - lb[7]); }
 	if (ev(ST_SEG_FIND)) return -1;
 	const bool keys_possible = c->opt.min_cnt >= 2;                           // a chain has >= 2 anchors: the keys of a segment fit half of its range
 	const bool keep_keys = with_keys && keys_possible;
 	const ChainSeg sg{c->vs_meta.p, (uint32_t *)c->vs_res.p, nullptr, 0, keep_keys ? c->okey_tmp.p : nullptr};
 	if (ns > 0) {
-		const uint32_t *so = c->seg_ord.p;
-		const uint32_t wave_from = lds_ok ? lb[8] : 0u;
+		const uint32_t *so0 = c->seg_idx.p, *so1 = c->seg_ord.p;
 		if (lds_ok) {
-#define LSEG(C, L, A, B) LCH(C, L, -1, c->vs_off.p, c->vs_na.p, c->chain_tmp.p, c->u_tmp.p, (uint32_t *)nullptr, so + (A), (int)((B) - (A)), sg)
-			LSEG(16, 64, 0u, lb[0]); LSEG(24, 64, lb[0], lb[1]); LSEG(32, 64, lb[1], lb[2]); LSEG(40, 64, lb[2], lb[3]); LSEG(48, 64, lb[3], lb[4]);
-			LSEG(64, 64, lb[4], lb[5]); LSEG(80, 64, lb[5], lb[6]); LSEG(96, 64, lb[6], lb[7]); LSEG(128, 32, lb[7], lb[8]);
+#define LSEG(C, L, LIST, A, B) LCH(C, L, -1, c->vs_off.p, c->vs_na.p, c->chain_tmp.p, c->u_tmp.p, (uint32_t *)nullptr, (LIST) + (A), (int)((B) - (A)), sg)
+			LSEG(16, 64, so0, 0u, (uint32_t)ns0);
+			LSEG(24, 64, so1, 0u, lb[0]); LSEG(32, 64, so1, lb[0], lb[1]); LSEG(40, 64, so1, lb[1], lb[2]); LSEG(48, 64, so1, lb[2], lb[3]);
+			LSEG(64, 64, so1, lb[3], lb[4]); LSEG(80, 64, so1, lb[4], lb[5]); LSEG(96, 64, so1, lb[5], lb[6]); LSEG(128, 32, so1, lb[6], lb[7]);
 #undef LSEG
 		}
 		if (ev(ST_SEG_CHAIN_LDS)) return -1;
-		const int nw = ns - (int)wave_from;
-		{ static const bool tr = getenv("AL_TRACE") != nullptr; if (tr && nw > 0) fprintf(stderr, "[airlift] trace: %d segments of more than 128 anchors to the wavefront kernel (of %d segments in %d fragments)\n", nw, ns, n); }
-		if (nw > 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<AL_CHAIN_CAP>), dim3(nw), dim3(64), 0, s, c->anchors.p, c->vs_off.p, c->vs_na.p, c->frag_first.p, c->rd_len.p, c->chain_tmp.p, c->u_tmp.p, (uint32_t *)nullptr,
-		                               c->ws_i32.p, c->ws_u64.p, so + wave_from, nw, c->P, c->counters.p, sg);
+		// the wavefront kernel: segments of more than 128 anchors, or (options outside the compact rows' range) all of them
+#define LWAVE(LIST, N) do { const int nw__ = (N); if (nw__ > 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<AL_CHAIN_CAP>), dim3(nw__), dim3(64), 0, s, c->anchors.p, c->vs_off.p, c->vs_na.p, c->frag_first.p, c->rd_len.p, c->chain_tmp.p, c->u_tmp.p, (uint32_t *)nullptr, \
+		                               c->ws_i32.p, c->ws_u64.p, (LIST), nw__, c->P, c->counters.p, sg); } while (0)
+		const int nw = lds_ok ? n1 - (int)lb[7] : ns;
+		{ static const bool tr = getenv("AL_TRACE") != nullptr; if (tr && nw > 0) fprintf(stderr, "[airlift] trace: %d segments to the wavefront kernel (of %d segments in %d fragments)\n", nw, ns, n); }
+		if (lds_ok) LWAVE(so1 + lb[7], n1 - (int)lb[7]); else { LWAVE(so0, ns0); LWAVE(so1, n1); }
+#undef LWAVE
 		if (ev(ST_SEG_CHAIN_WAVE)) return -1;
 	} else { if (ev(ST_SEG_CHAIN_LDS) || ev(ST_SEG_CHAIN_WAVE)) return -1; }
 	uint32_t *fb_cnt = (uint32_t *)(c->counters.p + 15);
