@@ -829,10 +829,12 @@ __device__ __forceinline__ void d_frag_ws(const WsBase &W, uint32_t f, FragWs &o
 #define AL_REGS_PMAX 160              // primaries a fragment can have before k_regs takes it (short chains tiling a pair: dozens)
 #define AL_REGS_UNSET 0xffffffffu
 #define AL_REGS_DONE 0xfffffffeu
-#define AL_REGS_BAIL(v) ((v) >= 0xfffffff0u && (v) < AL_REGS_DONE)   // k_regs_select gave up: 0xfffffff1 equal sort keys, 0xfffffff2 too many primaries
+#define AL_REGS_BAIL(v) ((v) >= 0xfffffff0u && (v) < AL_REGS_DONE)   // k_regs_select gave up: 0xfffffff1 equal sort keys (> 65535 chains), 0xfffffff2 too many primaries, 0xfffffff3 parent slot reused (in-place compaction of the reference)
+#define AL_REGS_KCAP 256              // kept hits whose records k_regs_select holds for the in-place compaction of the reference's selection
+struct RegsSelKept { int32_t score[AL_REGS_KCAP], qs[AL_REGS_KCAP], qe[AL_REGS_KCAP], ridrev[AL_REGS_KCAP], rs[AL_REGS_KCAP], re[AL_REGS_KCAP]; };
 struct RegsSelShared {
 	int32_t qs[AL_REGS_PMAX], qe[AL_REGS_PMAX], score[AL_REGS_PMAX], cnt[AL_REGS_PMAX], as[AL_REGS_PMAX], rs[AL_REGS_PMAX], re[AL_REGS_PMAX], ridrev[AL_REGS_PMAX];
-	int32_t subsc[AL_REGS_PMAX], nsub[AL_REGS_PMAX], slot[AL_REGS_PMAX]; uint32_t hash[AL_REGS_PMAX];
+	int32_t subsc[AL_REGS_PMAX], nsub[AL_REGS_PMAX], slot[AL_REGS_PMAX], orig[AL_REGS_PMAX]; uint32_t hash[AL_REGS_PMAX];   // slot: rank among the kept hits; orig: position in score order
 };
 template <int CAP>      // CAP > 0: sort tile in LDS; 0: at most 64 chains, registers; < 0: sort keys in the fragment's global work area (any count)
 __global__ void __launch_bounds__(CAP == 0 ? 64 : 256)
@@ -842,7 +844,7 @@ k_regs_select(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__
 {
 	__shared__ uint64_t skey_l[CAP > 0 ? CAP : 1];
 	__shared__ uint16_t sidx_l[CAP > 0 ? CAP : 1];
-	__shared__ RegsSelShared S;
+	__shared__ RegsSelShared S; __shared__ RegsSelKept K;
 	constexpr int NT = CAP == 0 ? 64 : 256;                                 // all threads sort; the first wavefront makes the pass
 	const int tid = threadIdx.x, lane = tid & 63;
 	if ((int)blockIdx.x >= n_list) return;
@@ -911,6 +913,7 @@ k_regs_select(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__
 		__syncthreads();
 		for (int i = tid; i + 1 < n_u; i += NT) if (skey[i] == skey[i + 1]) s_tie = 1;
 		__syncthreads();
+		if (s_tie && ((P.dbg >> 17) & 1)) { if (tid == 0) regs_n0[f] = 0xfffffff1u; return; }
 		if (s_tie) {
 			// Equal keys (a minimizer the sketch emitted twice makes two identical chains): their order is what the reference's unstable
 			// radix sort (ksort.h:116-151, more than 64 entries here) leaves.  Rare: the keys go back into chain order and one lane
@@ -947,11 +950,12 @@ k_regs_select(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__
 		__syncthreads();
 		if (tid >= 64) return;
 	} else {         // rank sort in registers (descending); equal keys: the stable ascending insertion sort (ksort.h:149), reversed, puts the later chain first
-		int rank = 0; const int klo = (int)(uint32_t)key_r, khi = (int)(uint32_t)(key_r >> 32);
+		int rank = 0; const int klo = (int)(uint32_t)key_r, khi = (int)(uint32_t)(key_r >> 32); bool tie16 = false;
 		for (int j = 0; j < n_u; ++j) {
 			const uint64_t kj = (uint64_t)(uint32_t)__shfl(klo, j) | (uint64_t)(uint32_t)__shfl(khi, j) << 32;
-			if (lane < n_u) rank += (kj > key_r || (kj == key_r && j > lane)) ? 1 : 0;
+			if (lane < n_u) { rank += (kj > key_r || (kj == key_r && j > lane)) ? 1 : 0; tie16 = tie16 || (kj == key_r && j != lane); }
 		}
+		if (((P.dbg >> 16) & 1) && __ballot(tie16)) { if (lane == 0) regs_n0[f] = 0xfffffff1u; return; }
 		// lane takes the entry whose rank is its lane number
 		int src = 0;
 		for (int j = 0; j < n_u; ++j) { const int rj = __shfl(rank, j); if (rj == lane) src = j; }
@@ -1028,44 +1032,75 @@ k_regs_select(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__
 			const unsigned long long um = __ballot(pending && pj < 0);
 			const int first = um ? __ffsll((long long)um) - 1 : 64;
 			const bool fin = pending && lane < first;                        // masked, final
-			bool qual = false;
+			// mm_select_sub(_multi) compact the hit array in place while they still look a hit's parent up by its OLD index P (hit.c:238-255,
+			// pe.c:6-43): once more hits have been kept than P, slot P holds the kept hit of rank P, and the tests are made against THAT
+			// record -- unless nothing in front of the parent was dropped (its rank is P: it was copied onto itself).  K[] keeps the fields
+			// those tests read for every kept hit, by rank.  k_now (hits kept before this one) is known exactly except while the kept count
+			// crosses P inside this group of lanes: then the lanes are settled one after the other.
+			const unsigned long long fm = __ballot(fin);
+			int P_o = 0; bool moved = false;
 			if (fin) {
 				atomicMax(&S.subsc[pj], score);
 				if (cnt >= S.cnt[pj]) atomicAdd(&S.nsub[pj], 1);
-				const int psc = S.score[pj];
-				if (n_segs <= 1) {                                            // mm_select_sub
-					if ((float)score >= __fmul_rn((float)psc, P.pri_ratio) || score + min_diff >= psc)
-						qual = !(qs == S.qs[pj] && qe == S.qe[pj] && (rid << 1 | rev) == S.ridrev[pj] && rs == S.rs[pj] && re == S.re[pj]);
-				} else {                                                       // mm_select_sub_multi
-					if (score + min_diff >= psc) qual = true;
-					else {
-						const int prev = S.ridrev[pj] & 1, prid = S.ridrev[pj] >> 1;
-						if (prev == rev && prid == rid && re - S.rs[pj] < max_dist && S.re[pj] - rs < max_dist) qual = (float)score >= __fmul_rn((float)psc, 0.2f);
-						else {
-							const int is_par_both = (n_segs == 2 && S.qs[pj] < ql0 && S.qe[pj] > ql0);
-							const int is_chi_both = (n_segs == 2 && qs < ql0 && qe > ql0);
-							if (is_chi_both || is_chi_both == is_par_both) qual = (float)score >= __fmul_rn((float)psc, P.pri_ratio);
-							else qual = (float)score >= __fmul_rn((float)psc, 0.7f);
-						}
-					}
-				}
-				if (!(P.pri_ratio > 0.0f)) qual = true;                        // selection switched off: everything is kept
+				P_o = S.orig[pj]; moved = S.slot[pj] != P_o;
 			}
-			const unsigned long long qm = __ballot(qual);
-			const bool kept = qual && (!(P.pri_ratio > 0.0f) || n_2nd + __popcll(qm & below) < best_n);
-			const unsigned long long km = __ballot(kept);
-			if (kept) {
+			auto decide = [&](int psc, int pqs, int pqe, int pridrev, int prs, int pre) -> bool {
+				if (!(P.pri_ratio > 0.0f)) return true;                          // selection switched off: everything is kept
+				if (n_segs <= 1) {                                              // mm_select_sub
+					if ((float)score >= __fmul_rn((float)psc, P.pri_ratio) || score + min_diff >= psc)
+						return !(qs == pqs && qe == pqe && (rid << 1 | rev) == pridrev && rs == prs && re == pre);
+					return false;
+				}
+				if (score + min_diff >= psc) return true;                       // mm_select_sub_multi
+				const int prev = pridrev & 1, prid = pridrev >> 1;
+				if (prev == rev && prid == rid && re - prs < max_dist && pre - rs < max_dist) return (float)score >= __fmul_rn((float)psc, 0.2f);
+				const int is_par_both = (n_segs == 2 && pqs < ql0 && pqe > ql0);
+				const int is_chi_both = (n_segs == 2 && qs < ql0 && qe > ql0);
+				if (is_chi_both || is_chi_both == is_par_both) return (float)score >= __fmul_rn((float)psc, P.pri_ratio);
+				return (float)score >= __fmul_rn((float)psc, 0.7f);
+			};
+			auto decide_at = [&](bool aliased) -> bool {                       // against the slot's present content
+				if (aliased) return decide(K.score[P_o], K.qs[P_o], K.qe[P_o], K.ridrev[P_o], K.rs[P_o], K.re[P_o]);
+				return decide(S.score[pj], S.qs[pj], S.qe[pj], S.ridrev[pj], S.rs[pj], S.re[pj]);
+			};
+			auto keep_hit = [&](int rank) {
 				AlReg R; d_reg_clear(&R);
-				R.id = slot_base + __popcll(km & below); R.parent = S.slot[pj]; R.score = R.score0 = score; R.hash = hsh; R.cnt = cnt; R.as = as;
+				R.id = rank; R.parent = S.slot[pj]; R.score = R.score0 = score; R.hash = hsh; R.cnt = cnt; R.as = as;
 				d_reg_set_coor(&R, qlen, a);
 				ws.regs0[R.id] = R;
+				if (rank < AL_REGS_KCAP) { K.score[rank] = score; K.qs[rank] = qs; K.qe[rank] = qe; K.ridrev[rank] = rid << 1 | rev; K.rs[rank] = rs; K.re[rank] = re; }
+			};
+			const int n_before = (int)__popcll(fm & below);
+			const bool amb = fin && moved && (P.pri_ratio > 0.0f) && slot_base <= P_o && P_o < slot_base + n_before;   // k_now may or may not have passed P
+			if (__ballot(fin && moved && slot_base + n_before > P_o && P_o >= AL_REGS_KCAP)) { if (lane == 0) regs_n0[f] = 0xfffffff3u; return; }   // beyond the kept records: serial code
+			if (!__ballot(amb)) {
+				bool qual = false;
+				if (fin) qual = decide_at(moved && slot_base > P_o);              // (not ambiguous: P < slot_base <= k_now, or k_now <= P)
+				const unsigned long long qm = __ballot(qual);
+				const bool kept = qual && (!(P.pri_ratio > 0.0f) || n_2nd + __popcll(qm & below) < best_n);
+				const unsigned long long km = __ballot(kept);
+				if (kept) keep_hit(slot_base + (int)__popcll(km & below));
+				n_2nd += __popcll(qm); slot_base += __popcll(km);
+			} else {
+				for (unsigned long long rem = fm; rem; rem &= rem - 1) {          // in order; slot_base and n_2nd are the running counts
+					const int l = __ffsll((long long)rem) - 1;
+					int q = 0, kp = 0;
+					if (lane == l) {
+						q = decide_at(moved && slot_base > P_o) ? 1 : 0;
+						kp = q && n_2nd < best_n ? 1 : 0;
+						if (kp) keep_hit(slot_base);
+					}
+					__threadfence_block();
+					n_2nd += __shfl(q, l); slot_base += __shfl(kp, l);
+				}
 			}
-			n_2nd += __popcll(qm); slot_base += __popcll(km);
+			__threadfence_block();
 			if (first < 64) {
 				if (k >= AL_REGS_PMAX) overflow = true;
 				else if (lane == first) {
 					S.qs[k] = qs; S.qe[k] = qe; S.score[k] = score; S.cnt[k] = cnt; S.as[k] = as; S.rs[k] = rs; S.re[k] = re; S.ridrev[k] = rid << 1 | rev;
-					S.subsc[k] = 0; S.nsub[k] = 0; S.slot[k] = slot_base; S.hash[k] = hsh;
+					S.subsc[k] = 0; S.nsub[k] = 0; S.slot[k] = slot_base; S.orig[k] = p; S.hash[k] = hsh;
+					if (slot_base < AL_REGS_KCAP) { K.score[slot_base] = score; K.qs[slot_base] = qs; K.qe[slot_base] = qe; K.ridrev[slot_base] = rid << 1 | rev; K.rs[slot_base] = rs; K.re[slot_base] = re; }
 					if (use_cov && qe > qs) for (int w = qs >> 5; w <= (qe - 1) >> 5; ++w) {
 						const int lo = qs > (w << 5) ? qs - (w << 5) : 0, hi = qe < ((w + 1) << 5) ? qe - (w << 5) : 32;
 						s_cov[w] |= (hi >= 32 ? 0xffffffffu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u);
@@ -2305,6 +2340,17 @@ int al_run_align_stage(al_ctx_t *c)
 	const uint64_t Btot = 4 * nu_total + 4ULL * nf + 8;
 	if (A->regs0.ensure(nu_total + 1) || A->aux128.ensure(Btot) || A->aux64.ensure(Btot) || A->auxi.ensure(2 * Btot) ||
 	    A->seg_u.ensure(2 * nu_total + 2) || A->reg_cnt.ensure(nr + 1) || A->seg_na.ensure(nr + 1) || A->out_off.ensure(nr + 2) || A->seg_fast.ensure(nr + 1) || A->cap2.ensure(nf + 2) || A->b2_off.ensure(nf + 2)) return -1;
+	{   // AL_TEST_SCRUB=<byte> (tests): the stage's work areas -- and the chaining scratch it reuses -- filled with that byte first: a result
+		// that depends on what an earlier stage or batch left there shows up as a difference between two byte values
+		static const char *scrub = getenv("AL_TEST_SCRUB");
+		if (scrub) {
+			const int v = atoi(scrub);
+			AL_HIP_CHECK(hipMemsetAsync(A->regs0.p, v, A->regs0.cap * sizeof(AlReg), s)); AL_HIP_CHECK(hipMemsetAsync(A->aux128.p, v, A->aux128.cap * sizeof(AlAnchor), s));
+			AL_HIP_CHECK(hipMemsetAsync(A->aux64.p, v, A->aux64.cap * 8, s)); AL_HIP_CHECK(hipMemsetAsync(A->auxi.p, v, A->auxi.cap * 4, s)); AL_HIP_CHECK(hipMemsetAsync(A->seg_u.p, v, A->seg_u.cap * 8, s));
+			AL_HIP_CHECK(hipMemsetAsync(c->chain_tmp.p, v, c->chain_tmp.cap * sizeof(AlAnchor), s));
+			AL_HIP_CHECK(hipMemsetAsync(A->reg_cnt.p, v, A->reg_cnt.cap * 4, s)); AL_HIP_CHECK(hipMemsetAsync(A->seg_na.p, v, A->seg_na.cap * 4, s)); AL_HIP_CHECK(hipMemsetAsync(A->seg_fast.p, v, A->seg_fast.cap * 4, s));
+		}
+	}
 	WsBase W;
 	W.regs0 = A->regs0.p; W.aux128 = A->aux128.p; W.seg_a = c->chain_tmp.p /* chaining scratch, free again */; W.aux64 = A->aux64.p; W.seg_u = A->seg_u.p; W.auxi = A->auxi.p;
 	W.nu_off = A->nu_off.p; W.frag_nu = c->frag_nu.p; W.a_off = c->a_off.p; W.reg_cnt = A->reg_cnt.p; W.seg_na = A->seg_na.p; W.seg_fast = A->seg_fast.p; W.cap2 = nullptr; W.b2_off = nullptr; W.mregs = nullptr; W.rtmp = nullptr; W.rext = nullptr;
@@ -2350,6 +2396,8 @@ int al_run_align_stage(al_ctx_t *c)
 		AL_HIP_CHECK(hipStreamSynchronize(s));
 		Btot2 = b2_total + 8;
 		if (A->mregs.ensure(2 * Btot2) || A->rtmp.ensure(Btot2) || A->rext.ensure(2 * Btot2 + 1)) return -1;
+		{ static const char *scrub = getenv("AL_TEST_SCRUB");
+		  if (scrub) { const int v = atoi(scrub); AL_HIP_CHECK(hipMemsetAsync(A->mregs.p, v, A->mregs.cap * sizeof(AlReg), s)); AL_HIP_CHECK(hipMemsetAsync(A->rtmp.p, v, A->rtmp.cap * sizeof(AlReg), s)); AL_HIP_CHECK(hipMemsetAsync(A->rext.p, v, A->rext.cap * sizeof(RegExt), s)); } }
 		W.mregs = A->mregs.p; W.rtmp = A->rtmp.p; W.rext = A->rext.p; W.cap2 = A->cap2.p; W.b2_off = A->b2_off.p;
 	}
 	if (regs_n0 && heavy_n > 0) {
@@ -2369,6 +2417,28 @@ int al_run_align_stage(al_ctx_t *c)
 		AL_HIP_CHECK(hipStreamWaitEvent(s, c->ev_fj[1], 0));
 	}
 	hipLaunchKernelGGL(k_regs, dim3((nf + 255) / 256), dim3(256), 0, s, c->chained.p, c->u.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, nf, c->P, c->counters.p, (const uint32_t *)regs_n0);
+	if (getenv("AL_DBG_FRAG")) {   // debugging aid: the chain_post result of one fragment (the kept hits at the front of its regs0 range)
+		const int f = atoi(getenv("AL_DBG_FRAG"));
+		if (f >= 0 && f < nf) {
+			uint64_t o[2]; uint32_t n0v = 0, nu = 0;
+			AL_HIP_CHECK(hipMemcpy(o, A->nu_off.p + f, 16, hipMemcpyDeviceToHost)); AL_HIP_CHECK(hipMemcpy(&nu, c->frag_nu.p + f, 4, hipMemcpyDeviceToHost));
+			if (regs_n0) AL_HIP_CHECK(hipMemcpy(&n0v, regs_n0 + f, 4, hipMemcpyDeviceToHost));
+			const int show = (int)std::min<uint64_t>(o[1] - o[0], 40);
+			std::vector<AlReg> h(show);
+			AL_HIP_CHECK(hipMemcpy(h.data(), A->regs0.p + o[0], (size_t)show * sizeof(AlReg), hipMemcpyDeviceToHost));
+			fprintf(stderr, "[airlift] dbg frag %d: %u chains, regs_n0 %x\n", f, nu, n0v);
+			for (int i = 0; i < show; ++i) fprintf(stderr, "  [%d] id %d parent %d score %d cnt %d as %d hash %08x qs %d qe %d rs %d re %d subsc %d n_sub %d flags %x\n", i, h[i].id, h[i].parent, h[i].score, h[i].cnt, h[i].as, h[i].hash, h[i].qs, h[i].qe, h[i].rs, h[i].re, h[i].subsc, h[i].n_sub, h[i].flags);
+			// the per-mate hit lists chain_post / seg_gen left for the extension stage
+			uint64_t b2 = 0; uint32_t cap2 = 0, r0 = 0, rc[2] = {0, 0};
+			AL_HIP_CHECK(hipMemcpy(&b2, A->b2_off.p + f, 8, hipMemcpyDeviceToHost)); AL_HIP_CHECK(hipMemcpy(&cap2, A->cap2.p + f, 4, hipMemcpyDeviceToHost)); AL_HIP_CHECK(hipMemcpy(&r0, c->frag_first.p + f, 4, hipMemcpyDeviceToHost));
+			AL_HIP_CHECK(hipMemcpy(rc, A->reg_cnt.p + r0, 8, hipMemcpyDeviceToHost));
+			for (int m = 0; m < 2; ++m) {
+				const int nn = (int)std::min<uint32_t>(rc[m], 30u); std::vector<AlReg> g(nn + 1);
+				if (nn) AL_HIP_CHECK(hipMemcpy(g.data(), A->mregs.p + 2 * b2 + (uint64_t)m * cap2, (size_t)nn * sizeof(AlReg), hipMemcpyDeviceToHost));
+				for (int i = 0; i < nn; ++i) fprintf(stderr, "  mate %d [%d] id %d parent %d score %d cnt %d as %d hash %08x qs %d qe %d rs %d re %d subsc %d n_sub %d\n", m, i, g[i].id, g[i].parent, g[i].score, g[i].cnt, g[i].as, g[i].hash, g[i].qs, g[i].qe, g[i].rs, g[i].re, g[i].subsc, g[i].n_sub);
+			}
+		}
+	}
 	if (regs_n0 && getenv("AL_TRACE")) {   // which fragments were left to the one-lane code?
 		std::vector<uint32_t> h0(nf), hu(nf);
 		AL_HIP_CHECK(hipMemcpyAsync(h0.data(), regs_n0, (size_t)nf * 4, hipMemcpyDeviceToHost, s)); AL_HIP_CHECK(hipMemcpyAsync(hu.data(), c->frag_nu.p, (size_t)nf * 4, hipMemcpyDeviceToHost, s));

@@ -470,6 +470,18 @@ def test_randomised_parity_sweep_on_repeat_rich_references():
     assert r.returncode == 0, r.stdout.decode()[-3000:]
 
 
+def test_selection_reproduces_the_references_in_place_compaction():
+    """mm_select_sub(_multi) compact the hit array in place while they still look a hit's parent up by its old index (hit.c:238-255,
+    pe.c:6-43): once more hits are kept than that index, the tests are made against the kept hit that now sits there.  Case 99 of
+    sweep 778 (250 bp pairs, 70 % repeats, -n 1 -m 10 -s 10: hundreds of short chains and several primaries per pair) is the one that
+    showed k_regs_select testing against the true parent instead."""
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "mm2ref")
+    if not os.path.exists(ref_bin):
+        pytest.skip("reference build oracle/_ref/mm2ref not present")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "120", "778"], capture_output=True, env=dict(os.environ, FUZZ_REPEAT="0.7", FUZZ_ONLY="99"))
+    assert r.returncode == 0 and b"ok   case 99" in r.stdout, r.stdout.decode()[-3000:]
+
+
 def test_token_stage_matches_reference_script_and_aligner(golden_unpacked):
     """`airlift-align tokens` = the reference's gaps_to_fasta.py (tiling into read-sized tokens) + single-end
     alignment of the tokens; golden SAM made by that script and the reference build (tests/golden/make_g7_tokens.py).
