@@ -830,8 +830,8 @@ __device__ __forceinline__ void d_frag_ws(const WsBase &W, uint32_t f, FragWs &o
 #define AL_REGS_UNSET 0xffffffffu
 #define AL_REGS_DONE 0xfffffffeu
 #define AL_REGS_BAIL(v) ((v) >= 0xfffffff0u && (v) < AL_REGS_DONE)   // k_regs_select gave up: 0xfffffff1 equal sort keys (> 65535 chains), 0xfffffff2 too many primaries, 0xfffffff3 parent slot reused (in-place compaction of the reference)
-#define AL_REGS_KCAP 256              // kept hits whose records k_regs_select holds for the in-place compaction of the reference's selection
-struct RegsSelKept { int32_t score[AL_REGS_KCAP], qs[AL_REGS_KCAP], qe[AL_REGS_KCAP], ridrev[AL_REGS_KCAP], rs[AL_REGS_KCAP], re[AL_REGS_KCAP]; };
+#define AL_REGS_KCAP 192              // kept hits whose records k_regs_select holds for the in-place compaction of the reference's selection (primaries + best_n)
+struct RegsSelKept { int32_t score[AL_REGS_KCAP], ridrev[AL_REGS_KCAP], rs[AL_REGS_KCAP], re[AL_REGS_KCAP]; uint16_t qs[AL_REGS_KCAP], qe[AL_REGS_KCAP]; };   // (query coordinates are below 2^16: reads of at most 32768 bases)
 struct RegsSelShared {
 	int32_t qs[AL_REGS_PMAX], qe[AL_REGS_PMAX], score[AL_REGS_PMAX], cnt[AL_REGS_PMAX], as[AL_REGS_PMAX], rs[AL_REGS_PMAX], re[AL_REGS_PMAX], ridrev[AL_REGS_PMAX];
 	int32_t subsc[AL_REGS_PMAX], nsub[AL_REGS_PMAX], slot[AL_REGS_PMAX], orig[AL_REGS_PMAX]; uint32_t hash[AL_REGS_PMAX];   // slot: rank among the kept hits; orig: position in score order
@@ -970,6 +970,7 @@ k_regs_select(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__
 	const unsigned long long below = (1ULL << lane) - 1ULL;
 	__shared__ uint32_t s_cov[64];                                           // query positions covered by the primaries so far (fragments of up to 2048 bases)
 	const bool use_cov = qlen <= 2048;
+	if (qlen > 65535) { if (lane == 0) regs_n0[f] = 0xfffffff3u; return; }       // (the kept-hit records hold query coordinates in 16 bits: a pair of two 32768-base reads goes to the serial code)
 	s_cov[lane] = 0;
 	__threadfence_block();
 	for (int p0 = 0; p0 < n_u && !overflow; p0 += 64) {
@@ -1060,7 +1061,7 @@ k_regs_select(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__
 				return (float)score >= __fmul_rn((float)psc, 0.7f);
 			};
 			auto decide_at = [&](bool aliased) -> bool {                       // against the slot's present content
-				if (aliased) return decide(K.score[P_o], K.qs[P_o], K.qe[P_o], K.ridrev[P_o], K.rs[P_o], K.re[P_o]);
+				if (aliased) return decide(K.score[P_o], (int)K.qs[P_o], (int)K.qe[P_o], K.ridrev[P_o], K.rs[P_o], K.re[P_o]);
 				return decide(S.score[pj], S.qs[pj], S.qe[pj], S.ridrev[pj], S.rs[pj], S.re[pj]);
 			};
 			auto keep_hit = [&](int rank) {
@@ -1068,7 +1069,7 @@ k_regs_select(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__
 				R.id = rank; R.parent = S.slot[pj]; R.score = R.score0 = score; R.hash = hsh; R.cnt = cnt; R.as = as;
 				d_reg_set_coor(&R, qlen, a);
 				ws.regs0[R.id] = R;
-				if (rank < AL_REGS_KCAP) { K.score[rank] = score; K.qs[rank] = qs; K.qe[rank] = qe; K.ridrev[rank] = rid << 1 | rev; K.rs[rank] = rs; K.re[rank] = re; }
+				if (rank < AL_REGS_KCAP) { K.score[rank] = score; K.qs[rank] = (uint16_t)qs; K.qe[rank] = (uint16_t)qe; K.ridrev[rank] = rid << 1 | rev; K.rs[rank] = rs; K.re[rank] = re; }
 			};
 			const int n_before = (int)__popcll(fm & below);
 			const bool amb = fin && moved && (P.pri_ratio > 0.0f) && slot_base <= P_o && P_o < slot_base + n_before;   // k_now may or may not have passed P
@@ -1100,7 +1101,7 @@ k_regs_select(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__
 				else if (lane == first) {
 					S.qs[k] = qs; S.qe[k] = qe; S.score[k] = score; S.cnt[k] = cnt; S.as[k] = as; S.rs[k] = rs; S.re[k] = re; S.ridrev[k] = rid << 1 | rev;
 					S.subsc[k] = 0; S.nsub[k] = 0; S.slot[k] = slot_base; S.orig[k] = p; S.hash[k] = hsh;
-					if (slot_base < AL_REGS_KCAP) { K.score[slot_base] = score; K.qs[slot_base] = qs; K.qe[slot_base] = qe; K.ridrev[slot_base] = rid << 1 | rev; K.rs[slot_base] = rs; K.re[slot_base] = re; }
+					if (slot_base < AL_REGS_KCAP) { K.score[slot_base] = score; K.qs[slot_base] = (uint16_t)qs; K.qe[slot_base] = (uint16_t)qe; K.ridrev[slot_base] = rid << 1 | rev; K.rs[slot_base] = rs; K.re[slot_base] = re; }
 					if (use_cov && qe > qs) for (int w = qs >> 5; w <= (qe - 1) >> 5; ++w) {
 						const int lo = qs > (w << 5) ? qs - (w << 5) : 0, hi = qe < ((w + 1) << 5) ? qe - (w << 5) : 32;
 						s_cov[w] |= (hi >= 32 ? 0xffffffffu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u);
