@@ -1072,9 +1072,11 @@ k_regs_select(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__
 				if (rank < AL_REGS_KCAP) { K.score[rank] = score; K.qs[rank] = (uint16_t)qs; K.qe[rank] = (uint16_t)qe; K.ridrev[rank] = rid << 1 | rev; K.rs[rank] = rs; K.re[rank] = re; }
 			};
 			const int n_before = (int)__popcll(fm & below);
-			const bool amb = fin && moved && (P.pri_ratio > 0.0f) && slot_base <= P_o && P_o < slot_base + n_before;   // k_now may or may not have passed P
-			if (__ballot(fin && moved && slot_base + n_before > P_o && P_o >= AL_REGS_KCAP)) { if (lane == 0) regs_n0[f] = 0xfffffff3u; return; }   // beyond the kept records: serial code
-			if (!__ballot(amb)) {
+			const bool full = (P.pri_ratio > 0.0f) && n_2nd >= best_n;           // best_n secondaries have qualified: every further one is dropped whatever its test says
+			const bool amb = !full && fin && moved && (P.pri_ratio > 0.0f) && slot_base <= P_o && P_o < slot_base + n_before;   // k_now may or may not have passed P
+			if (__ballot(!full && fin && moved && slot_base + n_before > P_o && P_o >= AL_REGS_KCAP)) { if (lane == 0) regs_n0[f] = 0xfffffff3u; return; }   // beyond the kept records: serial code
+			if (full) { /* nothing to decide */ }
+			else if (!__ballot(amb)) {
 				bool qual = false;
 				if (fin) qual = decide_at(moved && slot_base > P_o);              // (not ambiguous: P < slot_base <= k_now, or k_now <= P)
 				const unsigned long long qm = __ballot(qual);
