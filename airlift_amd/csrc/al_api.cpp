@@ -208,3 +208,124 @@ extern "C" int al_write_sam(char *buf, size_t cap, const al_idx_t *mi, const cha
 }
 
 // The file-level driver (al_map_file_frag) lives in al_pipeline.cpp.
+
+// ---------------------------------------------------------------------------------------------
+// The device SAM formatter (al_dev_sam.h; kernels in al_stream.hip) compiled for the CPU and checked against al_write_sam above on
+// random records: every flag / clipping / mate / tag branch, both read orientations, short and long CIGARs, `de:f:%.4f` against
+// printf.  Returns the number of differences (0 = identical); needs no GPU.  tests/test_capi_cpu.py.
+#define AL_SAM_HOST
+#include "al_dev_sam.h"
+namespace {
+struct HostSamSink {
+	const AlSamCfg *C; const char *text; std::string out;
+	char peek(uint32_t off) const { return text[off]; }
+	void begin_record() {}
+	void ch(char c) { out.push_back(c); }
+	void lit(const char *s) { out += s; }
+	void num(long long v) { out += std::to_string(v); }
+	void txt(uint32_t off, uint32_t len) { out.append(text + off, len); }
+	void mem(const char *s, int len) { out.append(s, (size_t)len); }
+	void cname(int rid) { out.append(C->names + C->name_off[rid], C->name_off[rid + 1] - C->name_off[rid]); }
+	void seqfld(uint32_t off, int len, int rev, int comp, int is_seq)
+	{
+		const unsigned char *ct = al_comp();
+		for (int j = 0; j < len; ++j) { unsigned char c = (unsigned char)text[off + (rev ? len - 1 - j : j)]; if (is_seq && (c == 'u' || c == 'U')) --c; if (comp && c < 128) c = ct[c]; out.push_back((char)c); }
+	}
+};
+struct Rng { uint64_t s; uint64_t next() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; } uint32_t below(uint32_t n) { return (uint32_t)(next() % n); } };
+}
+
+extern "C" int al_dbg_sam_selftest(uint64_t seed, int n_frag)
+{
+	int bad = 0;
+	Rng R{seed * 2654435761ULL + 88172645463325252ULL};
+	// (1) "%.4f": every ratio 1 - m / d the tag can take for short reads, and random doubles
+	for (int d = 1; d <= 700 && bad < 10; ++d) for (int m = 0; m <= d; ++m) {
+		const double v = 1.0 - (double)m / d; char a[64], b[64]; bool neg; uint64_t q;
+		snprintf(a, sizeof(a), "%.4f", v); al_fmt_f4(v, &neg, &q); snprintf(b, sizeof(b), "%s%llu.%04d", neg ? "-" : "", (unsigned long long)(q / 10000), (int)(q % 10000));
+		if (strcmp(a, b)) { if (bad < 5) fprintf(stderr, "[airlift] sam selftest: %%.4f of 1 - %d/%d: printf '%s', formatter '%s'\n", m, d, a, b); ++bad; }
+	}
+	for (int i = 0; i < 200000 && bad < 10; ++i) {
+		double v; const uint64_t u = R.next(); const int kind = i % 4;
+		if (kind == 0) v = (double)(u >> 11) / 9007199254740992.0;                       // uniform in [0, 1)
+		else if (kind == 1) v = ((double)(u % 200001) - 100000.0) / 20000.0;             // multiples of 0.00005: ties of the decimal text, not of the binary value
+		else if (kind == 2) v = (double)(u % 4096) / 4096.0 + ((u >> 20) % 3 == 0 ? 0.0 : 1.0 / 8192.0);   // exact binary ties at the fifth digit are impossible below 2^-4; these have few bits
+		else v = ldexp((double)(u >> 11), -(int)(53 + (u & 63)));                        // small values
+		char a[64], b[64]; bool neg; uint64_t q;
+		snprintf(a, sizeof(a), "%.4f", v); al_fmt_f4(v, &neg, &q); snprintf(b, sizeof(b), "%s%llu.%04d", neg ? "-" : "", (unsigned long long)(q / 10000), (int)(q % 10000));
+		if (strcmp(a, b)) { if (bad < 5) fprintf(stderr, "[airlift] sam selftest: %%.4f of %.17g: printf '%s', formatter '%s'\n", v, a, b); ++bad; }
+	}
+	// (2) records
+	al_idx_t mi; const char *cn[3] = {"chr1", "contig_two", "c"};
+	for (int i = 0; i < 3; ++i) { AlSeq s; s.name = cn[i]; s.offset = 0; s.len = 1000000; mi.seq.push_back(s); }
+	std::string names; std::vector<uint32_t> noff; for (int i = 0; i < 3; ++i) { noff.push_back((uint32_t)names.size()); names += cn[i]; } noff.push_back((uint32_t)names.size());
+	const char *bases = "ACGTNUacgtun";
+	for (int f = 0; f < n_frag && bad < 20; ++f) {
+		const int n_seg = 1 + (int)R.below(2), rep_len = (int)R.below(3) == 0 ? -1 : (int)R.below(200);
+		const bool with_qual = R.below(5) != 0; const bool with_rg = R.below(2) != 0;
+		std::string text; AlSamRead rd[2]; std::vector<AlReg> regs[2]; std::vector<uint32_t> arena; std::string nm[2];
+		for (int j = 0; j < n_seg; ++j) {
+			const int L = 30 + (int)R.below(220);
+			nm[j] = "read" + std::to_string(f) + (R.below(3) == 0 ? "/" + std::to_string(j + 1) : std::string());
+			rd[j].name = (uint32_t)text.size(); rd[j].name_len = (uint32_t)nm[j].size(); text += nm[j]; text.push_back('\n');
+			rd[j].seq = (uint32_t)text.size(); for (int i = 0; i < L; ++i) text.push_back(bases[R.below(12)]); text.push_back('\n');
+			rd[j].qual = ~0u; if (with_qual) { rd[j].qual = (uint32_t)text.size(); for (int i = 0; i < L; ++i) text.push_back((char)(33 + R.below(60))); text.push_back('\n'); }
+			rd[j].qlen = L; rd[j].flip = n_seg == 2 && j == 1 ? 1 : (int)R.below(4) == 0;
+			const int n = (int)R.below(5) == 0 ? 0 : 1 + (int)R.below(4);
+			int pri = n ? (int)R.below((uint32_t)n + 1) : 0;          // == n: no sam_pri record at all
+			for (int k = 0; k < n; ++k) {
+				AlReg r; memset(&r, 0, sizeof(r));
+				r.id = k; r.parent = R.below(3) == 0 && k > 0 ? (int)R.below((uint32_t)k) : k; r.rid = (int)R.below(3); r.cnt = 1 + (int)R.below(30); r.score = (int)R.below(300);
+				r.qs = (int)R.below((uint32_t)L / 2); r.qe = r.qs + 1 + (int)R.below((uint32_t)(L - r.qs)); r.rs = (int)R.below(900000); r.re = r.rs + (r.qe - r.qs) + (int)R.below(7) - 3; if (r.re <= r.rs) r.re = r.rs + 1;
+				r.subsc = (int)R.below(200); r.mlen = (int)R.below(200); r.blen = r.mlen + (int)R.below(30); r.n_sub = (int)R.below(4); r.mapq = R.below(61); r.hash = (uint32_t)R.next();
+				r.dp_score = (int)R.below(300); r.dp_max = (int)R.below(300); r.dp_max2 = (int)R.below(300); r.n_ambi = R.below(3);
+				r.flags = R.below(4) == 0 ? R.below(4) : 0;               // split
+				if (R.below(2)) r.flags |= ALR_REV; if (k == pri && r.parent == r.id) r.flags |= ALR_SAM_PRI; if (R.below(2)) r.flags |= ALR_PROPER;
+				if (R.below(8) != 0) {
+					r.flags |= ALR_HAS_P; r.n_cigar = 1 + R.below(R.below(4) == 0 ? 9u : 3u);
+					uint32_t *cg;
+					if (r.n_cigar <= 4) { r.cigar_off = AL_CIG_INLINE; cg = r.cig_inl; } else { r.cigar_off = (uint32_t)arena.size(); arena.resize(arena.size() + r.n_cigar); cg = arena.data() + r.cigar_off; }
+					int bl = 0, ml = 0;
+					for (uint32_t i = 0; i < r.n_cigar; ++i) { cg[i] = (1 + R.below(120)) << 4 | (i % 2 == 0 ? 0u : 1u + R.below(2)); bl += (int)(cg[i] >> 4); if ((cg[i] & 0xf) == 0) ml += (int)(cg[i] >> 4); }
+					r.blen = bl; r.mlen = (int)R.below((uint32_t)ml + 1);               // what mm_update_extra leaves: blen = all columns, mlen <= matched columns
+				}
+				regs[j].push_back(r);
+			}
+		}
+		for (int j = 0; j < n_seg; ++j) { rd[j].regs = regs[j].data(); rd[j].n_regs = (int)regs[j].size(); rd[j].arena = arena.data(); }
+		// cigar pointers into `arena` were taken before it stopped growing: rebuild the host-side view afterwards (below)
+		al_mapopt_t mo; memset(&mo, 0, sizeof(mo)); if (R.below(2)) mo.flag |= AL_F_NO_PRINT_2ND; if (R.below(3) == 0) mo.flag |= AL_F_SAM_HIT_ONLY;
+		AlSamCfg C; C.names = names.data(); C.name_off = noff.data(); C.rg_id = "grp1"; C.rg_len = with_rg ? 4 : 0; C.no_print_2nd = (mo.flag & AL_F_NO_PRINT_2ND) ? 1 : 0; C.hit_only = (mo.flag & AL_F_SAM_HIT_ONLY) ? 1 : 0; C.pe_ori = 1;
+		// the host records al_write_sam takes: AlReg -> al_reg1_t with the un-flip of al_reg_from_raw
+		std::vector<al_reg1_t> hr[2]; int n_regss[2] = {0, 0}; const al_reg1_t *regss[2] = {nullptr, nullptr};
+		for (int j = 0; j < n_seg; ++j) {
+			for (const AlReg &r : regs[j]) {
+				al_reg1_t q; memset(&q, 0, sizeof(q));
+				q.id = r.id; q.cnt = r.cnt; q.rid = r.rid; q.score = r.score; q.qs = r.qs; q.qe = r.qe; q.rs = r.rs; q.re = r.re; q.parent = r.parent; q.subsc = r.subsc; q.mlen = r.mlen; q.blen = r.blen; q.n_sub = r.n_sub;
+				q.mapq = r.mapq & 0xff; q.split = r.flags & 3; q.rev = (r.flags & ALR_REV) ? 1 : 0; q.sam_pri = (r.flags & ALR_SAM_PRI) ? 1 : 0; q.proper_frag = (r.flags & ALR_PROPER) ? 1 : 0; q.hash = r.hash;
+				q.dp_score = r.dp_score; q.dp_max = r.dp_max; q.dp_max2 = r.dp_max2; q.n_ambi = r.n_ambi; q.n_cigar = (r.flags & ALR_HAS_P) ? r.n_cigar : 0;
+				q.cigar = q.n_cigar ? const_cast<uint32_t *>(r.cigar_off == AL_CIG_INLINE ? r.cig_inl : arena.data() + r.cigar_off) : nullptr;
+				if (rd[j].flip) { const int t = q.qs; q.qs = rd[j].qlen - q.qe; q.qe = rd[j].qlen - t; q.rev = !q.rev; }
+				hr[j].push_back(q);
+			}
+			n_regss[j] = (int)hr[j].size(); regss[j] = hr[j].data();
+		}
+		for (int j = 0; j < n_seg; ++j) {
+			std::string exp; std::vector<char> buf(1 << 16);
+			std::string seq(text.data() + rd[j].seq, (size_t)rd[j].qlen); for (char &c : seq) if (c == 'u' || c == 'U') --c;       // what the host parsers hand to al_write_sam (bseq.c:72-74)
+			std::string qual; if (with_qual) qual.assign(text.data() + rd[j].qual, (size_t)rd[j].qlen);
+			auto emit = [&](int k) { const int l = al_write_sam(buf.data(), buf.size(), &mi, nm[j].c_str(), rd[j].qlen, seq.c_str(), with_qual ? qual.c_str() : nullptr, j, k, n_seg, n_regss, regss, with_rg ? "grp1" : "", rep_len); if (l > 0) exp.append(buf.data(), (size_t)l); };
+			if (n_regss[j] > 0) { for (int k = 0; k < n_regss[j]; ++k) { if ((mo.flag & AL_F_NO_PRINT_2ND) && hr[j][k].id != hr[j][k].parent) continue; emit(k); } }
+			else if (!(mo.flag & AL_F_SAM_HIT_ONLY)) emit(-1);
+			HostSamSink o; o.C = &C; o.text = text.data();
+			AlSamCountSink cnt; cnt.C = &C; cnt.text = text.data();
+			al_sam_read_records(o, C, rd[j], n_seg == 2 ? &rd[1 - j] : nullptr, j, n_seg, rep_len);
+			al_sam_read_records(cnt, C, rd[j], n_seg == 2 ? &rd[1 - j] : nullptr, j, n_seg, rep_len);
+			if (o.out != exp || cnt.n != exp.size()) {
+				if (bad < 2) fprintf(stderr, "[airlift] sam selftest: fragment %d read %d differs (counted %llu bytes)\n  al_write_sam: %s  formatter:    %s", f, j, (unsigned long long)cnt.n, exp.c_str(), o.out.c_str());
+				++bad;
+			}
+		}
+	}
+	return bad;
+}

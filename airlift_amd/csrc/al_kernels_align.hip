@@ -2323,7 +2323,7 @@ int al_run_align_stage(al_ctx_t *c)
 	const int nf = c->n_frag, nr = c->n_reads;
 	if (nf == 0) { for (int i = ST_REGS; i < ST_COMPACT; ++i) AL_HIP_CHECK(hipEventRecord(c->ev[i + 1], s)); return 0; }
 	// logf table from the HOST libm (the reference's logf is glibc's): logf((float)k / a) and logf((float)k)
-	int Lmax0 = 0; for (int i = 0; i < nr; ++i) Lmax0 = std::max<int>(Lmax0, (int)c->h_rd_len[i]);
+	const int Lmax0 = c->max_rd_len;
 	const int log_n = std::max(AL_LOGTAB_N, (std::max(c->opt.a, 1) * 2 * Lmax0 + 1024 + 4095) / 4096 * 4096);   // dp_max <= match_sc * read length; room to spare
 	if (A->logtab_a != c->opt.a || A->logtab_n < log_n) {
 		std::vector<float> h(2 * (size_t)log_n);
@@ -2457,7 +2457,7 @@ int al_run_align_stage(al_ctx_t *c)
 	}
 	AL_HIP_CHECK(hipEventRecord(c->ev[ST_REGS + 1], s));
 	// extension stage geometry
-	int Lmax = 0; for (int i = 0; i < nr; ++i) Lmax = std::max<int>(Lmax, (int)c->h_rd_len[i]);
+	const int Lmax = c->max_rd_len;
 	const al_mapopt_t &o = c->opt;
 	int ext = Lmax; { int l = Lmax; ext = l + (l * o.a + o.end_bonus > o.q ? (l * o.a + o.end_bonus - o.q) / o.e : 0); }
 	const int tbound = std::max(2 * Lmax + 16, ext + 16);
@@ -2625,6 +2625,7 @@ int al_fetch_raw(al_ctx_t *c, AlRawResult &R)
 	AlignState *A = get_state(c);
 	const int nf = c->n_frag, nr = c->n_reads;
 	AL_HIP_CHECK(hipSetDevice(c->device));
+	if (c->dev_batch) { fprintf(stderr, "[airlift] al_fetch_raw: the batch was built on the device (stream driver); its records are read through al_stream_sam\n"); return -1; }
 	unsigned long long h[16]; AL_HIP_CHECK(hipMemcpy(h, c->counters.p, sizeof(h), hipMemcpyDeviceToHost));
 	if (h[7] || h[8] || h[9]) { fprintf(stderr, "[airlift] device pipeline error: limit=0x%llx (byte k = site k: 0 prep qlen, 1 prep window, 2 dp window, 3 qlen, 4 split capacity, 5 pair scores, 6 lane cigar, 7 finish pair scores) logf_miss=%llu cigar_arena_overflow=%llu\n", h[7], h[8], h[9]); return -4; }
 	if (R.off.resize(nr + 1) || R.out.resize(A->out_total) || R.rep.resize(nf)) return -1;
@@ -2636,6 +2637,19 @@ int al_fetch_raw(al_ctx_t *c, AlRawResult &R)
 	const uint64_t n_arena = h[11];
 	if (R.arena.resize(n_arena)) return -1;
 	if (n_arena) AL_HIP_CHECK(hipMemcpy(R.arena.data(), A->arena.p, n_arena * 4, hipMemcpyDeviceToHost));
+	return 0;
+}
+
+// device pointers of the last al_batch_run's result block (records per read, CIGAR arena) for the device SAM writer
+#include "al_stream.h"
+int al_align_result(al_ctx_t *c, AlDevResult *r)
+{
+	AlignState *A = get_state(c);
+	if (!c->ran) return -1;
+	AL_HIP_CHECK(hipSetDevice(c->device));
+	unsigned long long h[16]; AL_HIP_CHECK(hipMemcpyAsync(h, c->counters.p, sizeof(h), hipMemcpyDeviceToHost, c->stream)); AL_HIP_CHECK(hipStreamSynchronize(c->stream));
+	if (h[7] || h[8] || h[9]) { fprintf(stderr, "[airlift] device pipeline error: limit=0x%llx logf_miss=%llu cigar_arena_overflow=%llu\n", h[7], h[8], h[9]); return -4; }
+	r->out = A->out.p; r->out_off = A->out_off.p; r->arena = A->arena.p; r->out_total = A->out_total;
 	return 0;
 }
 

@@ -128,9 +128,9 @@ int main(int argc, char **argv)
 		else if (!strcmp(a, "--version")) { puts(al_version()); return 0; }
 		else { fprintf(stderr, "[WARNING] airlift-align: option '%s' ignored\n", a); }
 	}
-	// (-K: the preset's 50 Mbases per device batch, as the reference.  Larger batches map faster per read -- 1 M pairs: 2.5x -- but their
-	// workspaces, ~100 bytes per seed hit, cost seconds of hipMalloc per process: worth passing -K 300M only for inputs of many millions of reads)
-	(void)k_given;
+	// -K given: an upper bound of the bases per device batch.  Not given: the stream driver (plain FASTQ in, SAM out) sizes its batches
+	// from the free device memory (al_stream_pipe.cpp); the host driver keeps the preset's 50 Mbases, as the reference.
+	if (!k_given) setenv("AL_AUTO_BATCH", "1", 0);
 	if (al_check_opt(&io, &mo) < 0) return 1;
 	const char *ref = nullptr; std::vector<const char *> reads;
 	if (mode == MODE_ALN) {          // the real work happens in samse; emit a small marker so `> x.sai` is non-empty

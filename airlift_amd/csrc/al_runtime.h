@@ -16,6 +16,10 @@ inline bool &al_nomem_flag() { static thread_local bool f = false; return f; }
 // hipMalloc maps memory at 20-25 GB/s on this platform and the pool recycles a range in milliseconds, tools/micro/malloc_cost.hip, but
 // what a process pays is the driver scrubbing memory a previous process held -- 1.4 s per 60 GB either way -- so the plain calls stay.)
 hipError_t al_dev_malloc(void **p, size_t bytes);
+// Accounting: while a thread has set al_acct() to a counter, the bytes of every range it allocates are added to it (and taken off
+// again when the range is freed, by whichever thread): the stream driver sizes its batches from what one batch held.
+#include <atomic>
+std::atomic<size_t> *&al_acct();
 void al_dev_free(void *p);
 int al_dev_guard_check();            // AL_TEST_GUARD=1: number of live ranges whose guard zones were written (messages on stderr)
 
@@ -80,6 +84,8 @@ struct al_ctx_s {
 	DevBuf<uint32_t> seg_cnt, seg_cnt0, seg_t1, vs_na, vs_meta, vs_cls, seg_key, seg_idx, seg_ord, fb_list, fb2_list, fb3_list, big_na, tie_frags, tie_sorted, heap_cnt;
 	uint64_t n_chain_fallback = 0;
 	int max_qlen_sum = 0;                 // longest fragment of the resident batch
+	int max_rd_len = 0;                   // longest read of the resident batch
+	bool dev_batch = false;               // the batch was parsed and packed on the device (al_stream.hip): no host mirrors of the read arrays
 	DevBuf<uint64_t> a_off_p1; DevBuf<uint32_t> frag_na_p1; DevBuf<int32_t> frag_rep_p1;   // pass-1 snapshots when a re-chain pass ran (taps)
 	uint64_t n_anchor_total = 0, n_anchor_pass1 = 0;
 	uint32_t n_rechain = 0;

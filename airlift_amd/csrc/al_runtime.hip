@@ -96,8 +96,21 @@ void al_dev_free(void *p)
 	}
 	al_dev_free_raw(p);
 }
-static hipError_t al_dev_malloc_raw(void **p, size_t bytes) { return hipMalloc(p, bytes); }
-static void al_dev_free_raw(void *p) { if (p) (void)hipFree(p); }
+std::atomic<size_t> *&al_acct() { static thread_local std::atomic<size_t> *a = nullptr; return a; }
+namespace { struct OwnRec { size_t bytes; std::atomic<size_t> *owner; }; std::mutex g_own_m; std::map<void *, OwnRec> g_own; }
+static hipError_t al_dev_malloc_raw(void **p, size_t bytes)
+{
+	const hipError_t e = hipMalloc(p, bytes);
+	std::atomic<size_t> *a = al_acct();
+	if (e == hipSuccess && a) { a->fetch_add(bytes); std::lock_guard<std::mutex> l(g_own_m); g_own[*p] = OwnRec{bytes, a}; }
+	return e;
+}
+static void al_dev_free_raw(void *p)
+{
+	if (!p) return;
+	{ std::lock_guard<std::mutex> l(g_own_m); auto it = g_own.find(p); if (it != g_own.end()) { it->second.owner->fetch_sub(it->second.bytes); g_own.erase(it); } }
+	(void)hipFree(p);
+}
 
 static const char *g_stage_names[ST_N] = { "sketch", "seed_lookup", "scan", "size_order", "anchor_sort_small", "anchor_sort", "anchor_sort_blk", "anchor_sort_big", "anchor_heap",
                                            "chain_lds32", "chain_lds48", "chain_lds64", "chain_lds128", "seg_find", "seg_chain_lds", "seg_chain_wave", "seg_merge", "rechain",
@@ -249,7 +262,8 @@ extern "C" int al_batch_upload(al_ctx_t *c, int n_frag, const int *n_segs, const
 		}
 		qsums[f] = qsum; if (qsum > max_qsum) max_qsum = qsum;
 	}
-	c->max_qlen_sum = max_qsum;
+	c->max_qlen_sum = max_qsum; c->dev_batch = false;
+	{ int lm = 0; for (int i = 0; i < n_reads; ++i) lm = std::max(lm, (int)c->h_rd_len[i]); c->max_rd_len = lm; }
 	{   // longest read the device sketch can index (position bits of its packed window entries) and the extension kernels can hold
 		const int lim = std::min(1 << (al_sketch_pos_bits(k) - 1), AL_MAX_READ_LEN);
 		for (int i = 0; i < n_reads; ++i) if ((int)c->h_rd_len[i] >= lim) { fprintf(stderr, "[airlift] a read of %u bases exceeds the limit of the GPU path (%d bases at k = %d)\n", c->h_rd_len[i], lim - 1, k); return -3; }
@@ -747,7 +761,9 @@ extern "C" int al_dbg_minimizers(al_ctx_t *c, int r, uint64_t *xy, int cap)
 	AL_HIP_CHECK(hipSetDevice(c->device));
 	AL_HIP_CHECK(hipMemcpy(&n, c->mini_cnt.p + r, 4, hipMemcpyDeviceToHost));
 	int m = (int)n < cap ? (int)n : cap;
-	if (m > 0) AL_HIP_CHECK(hipMemcpy(xy, c->mini.p + c->h_mini_off[r], (size_t)m * 16, hipMemcpyDeviceToHost));
+	uint64_t mo = 0;
+	if (c->dev_batch) AL_HIP_CHECK(hipMemcpy(&mo, c->mini_off.p + r, 8, hipMemcpyDeviceToHost)); else mo = c->h_mini_off[r];
+	if (m > 0) AL_HIP_CHECK(hipMemcpy(xy, c->mini.p + mo, (size_t)m * 16, hipMemcpyDeviceToHost));
 	return (int)n;
 }
 
@@ -827,7 +843,8 @@ extern "C" int64_t al_dbg_copy(al_ctx_t *c, const char *name, void *dst, int64_t
 	else if (!strcmp(name, "anchors")) src = c->anchors.p, bytes = (int64_t)c->n_anchor_total * 16;
 	else if (!strcmp(name, "chained")) src = c->chained.p, bytes = (int64_t)c->n_anchor_total * 16;
 	else if (!strcmp(name, "u")) src = c->u.p, bytes = (int64_t)(c->n_anchor_total + nf + 1) * 8;
-	else if (!strcmp(name, "mini_off")) { bytes = (nr + 1) * 8; if (bytes > max_bytes) bytes = max_bytes; memcpy(dst, c->h_mini_off.data(), bytes); return bytes; }
+	else if (!strcmp(name, "mini_off") && !c->dev_batch) { bytes = (nr + 1) * 8; if (bytes > max_bytes) bytes = max_bytes; memcpy(dst, c->h_mini_off.data(), bytes); return bytes; }
+	else if (!strcmp(name, "mini_off")) src = c->mini_off.p, bytes = (nr + 1) * 8;
 	else return -1;
 	if (bytes > max_bytes) bytes = max_bytes;
 	if (hipSetDevice(c->device) != hipSuccess) return -1;
@@ -919,7 +936,7 @@ extern "C" int al_batch_upload_windows(al_ctx_t *c, const al_winsrc_t *src, int 
 	if (!c || !src || n_tok < 0 || read_len <= 0 || src->device != c->device) return -1;
 	AL_HIP_CHECK(hipSetDevice(c->device));
 	const int k = c->mi->k, wpr = (read_len + 7) / 8 + 1;
-	c->n_frag = n_tok; c->n_reads = n_tok; c->ran = false; c->max_qlen_sum = read_len;
+	c->n_frag = n_tok; c->n_reads = n_tok; c->ran = false; c->max_qlen_sum = read_len; c->max_rd_len = n_tok ? read_len : 0; c->dev_batch = false;
 	if (read_len >= std::min(1 << (al_sketch_pos_bits(k) - 1), AL_MAX_READ_LEN)) { fprintf(stderr, "[airlift] tokens of %d bases exceed the limit of the GPU path\n", read_len); return -3; }
 	c->h_rd_len.assign(n_tok + 1, (uint32_t)read_len); c->h_rd_len[n_tok] = 0;
 	c->h_rd_off.resize(n_tok + 1); c->h_mini_off.resize(n_tok + 1); c->h_flip.assign(n_tok, 0);

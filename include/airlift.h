@@ -185,6 +185,10 @@ int  al_dbg_rs_sort(int device, const uint64_t *keys, int n, uint16_t *order_ser
 /* Self-test of the whole-file parallel FASTA loader of the index builders against the block reader: 0 = same names, lengths and
  * bytes, 1 = the loader declined the file (not a plain uncompressed FASTA), -1 = they differ; needs no GPU. */
 int  al_dbg_fasta_selftest(const char *fn, int n_threads);
+/* Self-test of the SAM record formatter the GPU runs (k_sam_len / k_sam_write; mm_write_sam3, format.c:387-544), compiled for the CPU:
+ * n_frag random fragments formatted by it and by al_write_sam, `de:f:%.4f` checked against printf; returns the number of
+ * differences (0 = identical); needs no GPU. */
+int  al_dbg_sam_selftest(uint64_t seed, int n_frag);
 
 /* ---- device-resident batch API (bench / multi-GPU harness; inputs already in HBM when timing starts) ---- */
 /* Pack + upload a batch; returns 0.  The batch stays resident until the next upload. */

@@ -246,3 +246,13 @@ def test_read_sharding_two_ranks_gloo():
     assert (lo0, hi0, lo1, hi1) == (0, 500, 500, 1001)
     assert ro0 == 0 and bo0 == 0 and ro1 == 2 * 500 and bo1 == 300 * 1000
     assert tr0 == tr1 == 1000 + 1003 and tb0 == tb1 == 300 * 2003
+
+
+@pytest.mark.parametrize("seed", [1, 7, 2026])
+def test_device_sam_formatter_equals_al_write_sam(A, seed):
+    """The SAM record routine the GPU runs (al_dev_sam.h: k_sam_len / k_sam_write; mm_write_sam3, format.c:387-544) compiled for
+    the CPU: random fragments through it and through al_write_sam (which the golden SAM files pin to the reference), `de:f:%.4f`
+    (format.c:292) against printf for every ratio 1 - m/d up to d = 700 and for random doubles."""
+    L = A.load()
+    L.al_dbg_sam_selftest.argtypes = [C.c_uint64, C.c_int]; L.al_dbg_sam_selftest.restype = C.c_int
+    assert L.al_dbg_sam_selftest(seed, 8000) == 0
