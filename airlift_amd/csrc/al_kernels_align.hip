@@ -2467,7 +2467,6 @@ int al_run_align_stage(al_ctx_t *c)
 	const size_t cig_words = ((size_t)(Lmax + tbound) + 16 + 15) / 16 * 16;
 	const size_t stride = p_bytes + cig_words * 8 + AL_PAIR_SC_CAP * 8;
 	int nb = (nf + AL_GPB - 1) / AL_GPB; const int nb_max = Lmax > 512 ? 16 : 256 * 16; if (nb > nb_max) nb = nb_max;   // reads beyond the LDS tiles: few groups (megabytes of traceback each)
-	if (A->gws.ensure((size_t)nb * AL_GPB * stride + 64)) return -1;
 	const uint64_t arena_cap = ((uint64_t)nr * 12 + 4096 + (uint64_t)c->n_bases / 8) * A->arena_scale;
 	if (A->arena.ensure(arena_cap)) return -1;
 	AlignShared G; G.S4 = c->di.S4; G.seq_off = c->di.seq_off; G.seq_len = c->di.seq_len; G.arena = A->arena.p; G.arena_cnt = c->counters.p + 11; G.arena_cap = arena_cap; G.counters = c->counters.p;
@@ -2491,7 +2490,7 @@ int al_run_align_stage(al_ctx_t *c)
 		else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_align<1024, 512>), dim3(nbm), dim3(GW * AL_GPB), 0, st, c->rd_seq.p, c->rd_off.p, c->rd_len.p, c->frag_first.p, c->frag_rep.p, W, G, lt, wsp, stride, p_bytes, cig_words, nf, c->P, list, n_list);
 		return 0;
 	};
-	if (((c->P.dbg >> 26) & 1) || long_mode) { if (launch_mono(nullptr, nf, s, A->gws.p, nb)) return -1; for (int i = ST_EXT_PREP; i <= ST_EXT_FINISH; ++i) AL_HIP_CHECK(hipEventRecord(c->ev[i + 1], s)); }   // AL_DBG bit 26: whole batch through the monolithic kernel
+	if (((c->P.dbg >> 26) & 1) || long_mode) { if (A->gws.ensure((size_t)nb * AL_GPB * stride + 64)) return -1; if (launch_mono(nullptr, nf, s, A->gws.p, nb)) return -1; for (int i = ST_EXT_PREP; i <= ST_EXT_FINISH; ++i) AL_HIP_CHECK(hipEventRecord(c->ev[i + 1], s)); }   // AL_DBG bit 26: whole batch through the monolithic kernel
 	else {
 		// ---- fast path: prep -> size-sorted DP job queue -> finish -> (slow list) monolithic
 		if (A->n_jobs.ensure(nf + 2) || A->n_sc.ensure(nf + 2) || A->job_off.ensure(nf + 2) || A->sc_off.ensure(nf + 2) || A->frag_slow.ensure(nf + 1) || A->slow_list.ensure(nf + 1) || A->hist.ensure(AL_HIST_N)) return -1;

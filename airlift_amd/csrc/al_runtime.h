@@ -5,6 +5,7 @@
 #include <vector>
 #include <string>
 #include <thread>
+#include <chrono>
 #include "al_internal.h"
 
 // Set when a device allocation fails; al_batch_run reports AL_ERR_NOMEM then (the context stays usable: every DevBuf is
@@ -20,6 +21,9 @@ hipError_t al_dev_malloc(void **p, size_t bytes);
 // again when the range is freed, by whichever thread): the stream driver sizes its batches from what one batch held.
 #include <atomic>
 std::atomic<size_t> *&al_acct();
+// time this process has spent in device / page-locked host allocation calls (AL_TIMING report)
+struct AlAllocStat { std::atomic<long long> dev_ns{0}, dev_bytes{0}, dev_calls{0}, host_ns{0}, host_bytes{0}, host_calls{0}; };
+AlAllocStat &al_alloc_stat();
 void al_dev_free(void *p);
 int al_dev_guard_check();            // AL_TEST_GUARD=1: number of live ranges whose guard zones were written (messages on stderr)
 
@@ -120,7 +124,10 @@ template <typename T> struct PinnedVec {    // grow-only page-locked host array 
 		if (m > cap) {
 			const size_t ncap = m + m / 4 + 1024;
 			T *np = nullptr;
-			if (hipHostMalloc((void **)&np, ncap * sizeof(T), hipHostMallocDefault) != hipSuccess) { fprintf(stderr, "[airlift] hipHostMalloc of %zu bytes failed\n", ncap * sizeof(T)); return -1; }
+			const auto t0__ = std::chrono::steady_clock::now();
+			const hipError_t e__ = hipHostMalloc((void **)&np, ncap * sizeof(T), hipHostMallocDefault);
+			{ AlAllocStat &a = al_alloc_stat(); a.host_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0__).count(); a.host_bytes += (long long)(ncap * sizeof(T)); ++a.host_calls; }
+			if (e__ != hipSuccess) { fprintf(stderr, "[airlift] hipHostMalloc of %zu bytes failed\n", ncap * sizeof(T)); return -1; }
 			if (p) (void)hipHostFree(p);
 			p = np; cap = ncap;
 		}

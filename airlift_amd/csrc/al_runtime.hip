@@ -98,9 +98,12 @@ void al_dev_free(void *p)
 }
 std::atomic<size_t> *&al_acct() { static thread_local std::atomic<size_t> *a = nullptr; return a; }
 namespace { struct OwnRec { size_t bytes; std::atomic<size_t> *owner; }; std::mutex g_own_m; std::map<void *, OwnRec> g_own; }
+AlAllocStat &al_alloc_stat() { static AlAllocStat s; return s; }
 static hipError_t al_dev_malloc_raw(void **p, size_t bytes)
 {
+	const auto t0 = std::chrono::steady_clock::now();
 	const hipError_t e = hipMalloc(p, bytes);
+	{ AlAllocStat &a = al_alloc_stat(); a.dev_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); a.dev_bytes += (long long)bytes; ++a.dev_calls; }
 	std::atomic<size_t> *a = al_acct();
 	if (e == hipSuccess && a) { a->fetch_add(bytes); std::lock_guard<std::mutex> l(g_own_m); g_own[*p] = OwnRec{bytes, a}; }
 	return e;
@@ -109,7 +112,9 @@ static void al_dev_free_raw(void *p)
 {
 	if (!p) return;
 	{ std::lock_guard<std::mutex> l(g_own_m); auto it = g_own.find(p); if (it != g_own.end()) { it->second.owner->fetch_sub(it->second.bytes); g_own.erase(it); } }
+	const auto t0 = std::chrono::steady_clock::now();
 	(void)hipFree(p);
+	al_alloc_stat().dev_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
 }
 
 static const char *g_stage_names[ST_N] = { "sketch", "seed_lookup", "scan", "size_order", "anchor_sort_small", "anchor_sort", "anchor_sort_blk", "anchor_sort_big", "anchor_heap",

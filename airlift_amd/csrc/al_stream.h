@@ -5,9 +5,11 @@
 // raw file bytes: FASTQ blocks go to HBM as they are, kernels find the records, pack the bases and hash the names (rows a1, a4 of
 // SURVEY.md 8a), and after the mapping kernels the SAM text (row a22) is written by kernels as well; the host write()s it.
 //
-// One AlStreamSlot = one batch in flight: a mapping context (al_ctx_t: streams + workspaces) plus the batch's text and SAM
-// buffers.  A lane (one GPU) runs several slots so that H2D + parsing of batch n+1 and SAM formatting + D2H of batch n-1 overlap
-// the mapping of batch n (the reference's three-step kt_pipeline, map.c:557-652, kthread.c:130-159).
+// One AlStreamSlot = the text and SAM buffers of one batch in flight, with a stream of its own for the transfers and the parsing
+// kernels; the mapping kernels run in a mapping context (al_ctx_t: streams + workspaces, ~100 bytes per seed hit) that batches take
+// turns on.  A lane (one GPU) has several slots per context, so H2D + parsing of batch n+1 and D2H + write() of batch n-1 overlap the
+// mapping of batch n (the reference's three-step kt_pipeline, map.c:557-652, kthread.c:130-159) while only one batch's workspaces
+// exist: what a process pays for device memory is per byte it ever touches (the driver maps and scrubs at 20-40 GB/s).
 #pragma once
 #include <stdint.h>
 #include <vector>
@@ -32,7 +34,8 @@ struct AlIngestResult {
 };
 
 struct AlStreamSlot {
-	al_ctx_t *ctx = nullptr;
+	int device = 0; hipStream_t io = nullptr; hipEvent_t ev = nullptr;
+	const al_idx_t *mi = nullptr;
 	int n_files = 1;
 	// input
 	DevBuf<uint8_t> txt[2]; uint64_t txt_n[2] = {0, 0};
@@ -46,12 +49,12 @@ struct AlStreamSlot {
 	// output
 	DevBuf<char> names; DevBuf<uint32_t> name_off; DevBuf<char> rg;
 	DevBuf<uint32_t> sam_len, sam_nrec; DevBuf<uint64_t> sam_off, rec_off; DevBuf<AlBulk> bulk; DevBuf<char> sam;
-	PinnedVec<char> h_sam; uint64_t sam_bytes = 0, sam_records = 0;
+	uint64_t sam_bytes = 0, sam_records = 0;
 	bool cfg_ready = false; int rg_len = 0;
 	void release();
 };
 
-int  al_stream_slot_init(AlStreamSlot &S, const al_idx_t *mi, const al_mapopt_t *opt, int device, int n_files);
+int  al_stream_slot_init(AlStreamSlot &S, const al_idx_t *mi, int device, int n_files);
 void al_stream_slot_destroy(AlStreamSlot &S);
 // text of file i: begin (room for cap_bytes), then host pieces appended in file order (each call returns when its copy is done)
 int  al_stream_begin_text(AlStreamSlot &S, int i, size_t cap_bytes);
@@ -63,11 +66,14 @@ int  al_stream_parse(AlStreamSlot &S, const bool *eof, int max_reads, AlIngestRe
 int  al_stream_fetch_text(AlStreamSlot &S, int i, uint64_t from, uint64_t n, char *dst);
 // fragment / read arrays of the mapping context from the parsed records [rec_lo, rec_hi) = fragments [frag_lo, frag_hi) (names hashed,
 // bases packed 4 bit/base in mapping orientation); the whole batch is (0, n_reads or n_frag, 0, n_frag)
-int  al_stream_setup(AlStreamSlot &S, uint32_t rec_lo, uint32_t rec_hi, uint32_t frag_lo, uint32_t frag_hi);
+int  al_stream_setup(AlStreamSlot &S, al_ctx_t *c, uint32_t rec_lo, uint32_t rec_hi, uint32_t frag_lo, uint32_t frag_hi);
 // single-file input: the record each fragment of the parsed text starts at (frag_first, n_frag + 1 entries), for cutting a batch
 int  al_stream_frag_starts(AlStreamSlot &S, const AlIngestResult &res, std::vector<uint32_t> &first);
-// SAM text of the mapped batch (after al_batch_run) into S.h_sam (page-locked); sets sam_bytes / sam_records
-int  al_stream_sam(AlStreamSlot &S, const char *rg_id);
+// SAM text of the batch context c has mapped (after al_batch_run) into S.sam (device): kernels on c's stream; the slot's stream is made
+// to wait for them and the call returns (c is free for its next batch); sets sam_bytes / sam_records.
+int  al_stream_sam(AlStreamSlot &S, al_ctx_t *c, const char *rg_id);
+// bytes [off, off + n) of the text to a page-locked host buffer, on the slot's stream; `done` is recorded behind the copy
+int  al_stream_sam_fetch(AlStreamSlot &S, uint64_t off, uint64_t n, char *dst, hipEvent_t done);
 
 // device result arrays of the last al_batch_run (al_kernels_align.hip)
 struct AlDevResult { const AlReg *out; const uint64_t *out_off; const uint32_t *arena; uint64_t out_total; };

@@ -318,13 +318,12 @@ void AlStreamSlot::release()
 	names.release(); name_off.release(); rg.release(); sam_len.release(); sam_nrec.release(); sam_off.release(); rec_off.release(); bulk.release(); sam.release();
 }
 
-int al_stream_slot_init(AlStreamSlot &S, const al_idx_t *mi, const al_mapopt_t *opt, int device, int n_files)
+int al_stream_slot_init(AlStreamSlot &S, const al_idx_t *mi, int device, int n_files)
 {
-	S.ctx = al_ctx_init(mi, opt, device);
-	if (!S.ctx) return -1;
-	S.n_files = n_files;
-	al_ctx_t *c = S.ctx;
-	AL_HIP_CHECK(hipSetDevice(c->device));
+	S.n_files = n_files; S.device = device; S.mi = mi;
+	AL_HIP_CHECK(hipSetDevice(device));
+	AL_HIP_CHECK(hipStreamCreateWithFlags(&S.io, hipStreamNonBlocking));
+	AL_HIP_CHECK(hipEventCreateWithFlags(&S.ev, hipEventDisableTiming));
 	if (S.tabs.ensure(512) || S.st.ensure(16)) return -1;
 	uint8_t h[512]; memcpy(h, al_nt4(), 256); memcpy(h + 256, al_comp(), 256);
 	AL_HIP_CHECK(hipMemcpy(S.tabs.p, h, 512, hipMemcpyHostToDevice));
@@ -338,16 +337,16 @@ int al_stream_slot_init(AlStreamSlot &S, const al_idx_t *mi, const al_mapopt_t *
 }
 void al_stream_slot_destroy(AlStreamSlot &S)
 {
-	if (!S.ctx) return;
-	(void)hipSetDevice(S.ctx->device);
-	(void)hipStreamSynchronize(S.ctx->stream);
+	if (!S.io) return;
+	(void)hipSetDevice(S.device);
+	(void)hipStreamSynchronize(S.io);
 	S.release();
-	al_ctx_destroy(S.ctx); S.ctx = nullptr;
+	(void)hipEventDestroy(S.ev); (void)hipStreamDestroy(S.io); S.io = nullptr; S.ev = nullptr;
 }
 
 int al_stream_begin_text(AlStreamSlot &S, int i, size_t cap_bytes)
 {
-	AL_HIP_CHECK(hipSetDevice(S.ctx->device));
+	AL_HIP_CHECK(hipSetDevice(S.device));
 	if (cap_bytes >= (1ULL << 31)) { fprintf(stderr, "[airlift] a text block of %zu bytes exceeds the 2 GB the device parser indexes\n", cap_bytes); return -1; }
 	if (S.txt[i].ensure(cap_bytes + NL_TILE + 16)) return -1;
 	S.txt_n[i] = 0;
@@ -356,10 +355,9 @@ int al_stream_begin_text(AlStreamSlot &S, int i, size_t cap_bytes)
 int al_stream_append_text(AlStreamSlot &S, int i, const char *p, size_t n)
 {   // host bytes (page-locked or not) to the end of file i's text; returns when the copy is done (the caller reuses the buffer)
 	if (n == 0) return 0;
-	al_ctx_t *c = S.ctx;
 	if (S.txt_n[i] + n + NL_TILE + 16 > S.txt[i].cap) { fprintf(stderr, "[airlift] al_stream_append_text: text buffer too small\n"); return -1; }
-	AL_HIP_CHECK(hipMemcpyAsync(S.txt[i].p + S.txt_n[i], p, n, hipMemcpyHostToDevice, c->stream));
-	AL_HIP_CHECK(hipStreamSynchronize(c->stream));
+	AL_HIP_CHECK(hipMemcpyAsync(S.txt[i].p + S.txt_n[i], p, n, hipMemcpyHostToDevice, S.io));
+	AL_HIP_CHECK(hipStreamSynchronize(S.io));
 	S.txt_n[i] += n;
 	return 0;
 }
@@ -367,16 +365,16 @@ int al_stream_append_text(AlStreamSlot &S, int i, const char *p, size_t n)
 int al_stream_fetch_text(AlStreamSlot &S, int i, uint64_t from, uint64_t n, char *dst)
 {
 	if (n == 0) return 0;
-	AL_HIP_CHECK(hipSetDevice(S.ctx->device));
-	AL_HIP_CHECK(hipMemcpyAsync(dst, S.txt[i].p + from, n, hipMemcpyDeviceToHost, S.ctx->stream));
-	AL_HIP_CHECK(hipStreamSynchronize(S.ctx->stream));
+	AL_HIP_CHECK(hipSetDevice(S.device));
+	AL_HIP_CHECK(hipMemcpyAsync(dst, S.txt[i].p + from, n, hipMemcpyDeviceToHost, S.io));
+	AL_HIP_CHECK(hipStreamSynchronize(S.io));
 	return 0;
 }
 
 int al_stream_parse(AlStreamSlot &S, const bool *eof, int max_reads, AlIngestResult *res)
 {
-	al_ctx_t *c = S.ctx; hipStream_t s = c->stream;
-	AL_HIP_CHECK(hipSetDevice(c->device));
+	hipStream_t s = S.io;
+	AL_HIP_CHECK(hipSetDevice(S.device));
 	memset(res, 0, sizeof(*res));
 	const int nf = S.n_files;
 	unsigned long long h_st[16];
@@ -447,9 +445,9 @@ int al_stream_parse(AlStreamSlot &S, const bool *eof, int max_reads, AlIngestRes
 	return 0;
 }
 
-int al_stream_setup(AlStreamSlot &S, uint32_t rec_lo, uint32_t rec_hi, uint32_t frag_lo, uint32_t frag_hi)
+int al_stream_setup(AlStreamSlot &S, al_ctx_t *c, uint32_t rec_lo, uint32_t rec_hi, uint32_t frag_lo, uint32_t frag_hi)
 {   // records [rec_lo, rec_hi) of the parsed text (two files: record = fragment) = fragments [frag_lo, frag_hi)
-	al_ctx_t *c = S.ctx; hipStream_t s = c->stream;
+	hipStream_t s = c->stream;
 	AL_HIP_CHECK(hipSetDevice(c->device));
 	const int n_frag = (int)(frag_hi - frag_lo), n_reads = S.n_files == 2 ? 2 * n_frag : (int)(rec_hi - rec_lo), k = c->mi->k;
 	c->n_frag = n_frag; c->n_reads = n_reads; c->ran = false; c->dev_batch = true;
@@ -479,9 +477,9 @@ int al_stream_setup(AlStreamSlot &S, uint32_t rec_lo, uint32_t rec_hi, uint32_t 
 	return 0;
 }
 
-int al_stream_sam(AlStreamSlot &S, const char *rg_id)
+int al_stream_sam(AlStreamSlot &S, al_ctx_t *c, const char *rg_id)
 {
-	al_ctx_t *c = S.ctx; hipStream_t s = c->stream;
+	hipStream_t s = c->stream;
 	AL_HIP_CHECK(hipSetDevice(c->device));
 	S.sam_bytes = 0; S.sam_records = 0;
 	const uint32_t nr = (uint32_t)c->n_reads;
@@ -505,23 +503,30 @@ int al_stream_sam(AlStreamSlot &S, const char *rg_id)
 	AL_HIP_CHECK(hipMemcpyAsync(&tot[0], S.sam_off.p + nr, 8, hipMemcpyDeviceToHost, s));
 	AL_HIP_CHECK(hipMemcpyAsync(&tot[1], S.rec_off.p + nr, 8, hipMemcpyDeviceToHost, s));
 	AL_HIP_CHECK(hipStreamSynchronize(s));
-	if (S.sam.ensure(tot[0] + 64) || S.bulk.ensure(2 * tot[1] + 2) || S.h_sam.resize(tot[0] + 64)) return -1;
+	if (S.sam.ensure(tot[0] + 64) || S.bulk.ensure(2 * tot[1] + 2)) return -1;
 	if (tot[1]) {
 		AL_HIP_CHECK(hipMemsetAsync(S.bulk.p, 0, 2 * tot[1] * sizeof(AlBulk), s));
 		hipLaunchKernelGGL(k_sam_write, dim3((nr + 255) / 256), dim3(256), 0, s, I, S.sam_off.p, S.rec_off.p, S.sam.p, S.bulk.p);
 		hipLaunchKernelGGL(k_sam_bulk, dim3((unsigned)((2 * tot[1] + 3) / 4)), dim3(256), 0, s, S.bulk.p, 2 * tot[1], I.t0, I.t1, S.tabs.p, S.sam.p);
-		AL_HIP_CHECK(hipMemcpyAsync(S.h_sam.data(), S.sam.p, tot[0], hipMemcpyDeviceToHost, s));
+		// the text leaves on the slot's own stream (al_stream_sam_fetch): the context goes on with its next batch
+		AL_HIP_CHECK(hipEventRecord(S.ev, s));
+		AL_HIP_CHECK(hipStreamWaitEvent(S.io, S.ev, 0));
 	}
-	AL_HIP_CHECK(hipStreamSynchronize(s));
 	AL_HIP_CHECK(hipGetLastError());
 	S.sam_bytes = tot[0]; S.sam_records = tot[1];
+	return 0;
+}
+int al_stream_sam_fetch(AlStreamSlot &S, uint64_t off, uint64_t n, char *dst, hipEvent_t done)
+{
+	AL_HIP_CHECK(hipSetDevice(S.device));
+	if (n) AL_HIP_CHECK(hipMemcpyAsync(dst, S.sam.p + off, n, hipMemcpyDeviceToHost, S.io));
+	AL_HIP_CHECK(hipEventRecord(done, S.io));
 	return 0;
 }
 
 int al_stream_frag_starts(AlStreamSlot &S, const AlIngestResult &res, std::vector<uint32_t> &first)
 {   // single-file input: record index of every fragment start of the parsed batch (rare path: a batch that has to be cut)
-	al_ctx_t *c = S.ctx;
-	AL_HIP_CHECK(hipSetDevice(c->device));
+	AL_HIP_CHECK(hipSetDevice(S.device));
 	const size_t n = (size_t)res.n_reads;
 	std::vector<uint32_t> fs(n + 1);
 	if (n) AL_HIP_CHECK(hipMemcpy(fs.data(), S.se_fs.p, n * 4, hipMemcpyDeviceToHost));

@@ -109,14 +109,18 @@ public:
 };
 
 enum { SL_FREE = 0, SL_READY, SL_MAPPED };
-struct Slot {
+struct Slot {                                           // text + SAM buffers of one batch in flight
 	AlStreamSlot S; int lane = 0, device = 0;
 	int state = SL_FREE; uint64_t seq = 0;
 	AlIngestResult res;
-	std::atomic<size_t> held{0};                        // device bytes this slot's context and buffers hold
+	std::atomic<size_t> held{0};                        // device bytes of its buffers
 	std::vector<std::vector<char>> chunks;              // SAM text of a batch that had to be cut (else it is in S.h_sam)
-	std::thread mapper;
-	double t_setup = 0, t_run = 0, t_sam = 0; int n_batch = 0;
+};
+struct Mapper {                                         // a mapping context and the thread that runs batches on it
+	al_ctx_t *ctx = nullptr; int lane = 0, device = 0, idx = 0;
+	std::atomic<size_t> held{0};                        // device bytes of its workspaces
+	std::thread th;
+	double t_setup = 0, t_run = 0, t_sam = 0, t_wait = 0; int n_batch = 0;
 };
 
 // plain, uncompressed, starts like FASTQ?
@@ -140,21 +144,36 @@ int al_stream_map_files(const al_idx_t *mi, int n_fn, const char **fn, const al_
 	for (int i = 0; i < n_fn; ++i) if (!eligible_file(fn[i])) return AL_STREAM_NA;
 	const bool timing = getenv("AL_TIMING") != nullptr, trace = getenv("AL_TRACE") != nullptr;
 	const double T0 = now_s();
-	const int n_slots_lane = std::max(1, std::min(8, getenv("AL_SLOTS") ? atoi(getenv("AL_SLOTS")) : 3));
-	const int NL = n_dev, NS = NL * n_slots_lane;
+	const int n_slots_lane = std::max(2, std::min(8, getenv("AL_SLOTS") ? atoi(getenv("AL_SLOTS")) : 3));      // text / SAM buffer sets per GPU
+	const int n_ctx_lane = std::max(1, std::min(n_slots_lane, getenv("AL_CTXS") ? atoi(getenv("AL_CTXS")) : 1));  // mapping contexts per GPU
+	const int NL = n_dev, NS = NL * n_slots_lane, NM = NL * n_ctx_lane;
 	const size_t PIECE = (size_t)(getenv("AL_PIECE_MB") ? std::max(1, atoi(getenv("AL_PIECE_MB"))) : 8) << 20;
 
 	std::mutex m; std::condition_variable cv; int rc = 0;
 	auto fail = [&](int code) { { std::lock_guard<std::mutex> l(m); if (rc == 0) rc = code ? code : -1; } cv.notify_all(); };
 
-	std::vector<std::unique_ptr<Slot>> slots;
-	for (int i = 0; i < NS; ++i) {          // batch k goes to slot k % NS: lane (k % NL), so consecutive batches sit on different GPUs
-		std::unique_ptr<Slot> sl(new Slot()); sl->lane = i % NL; sl->device = devices[i % NL];
-		al_acct() = &sl->held;
-		const int e = al_stream_slot_init(sl->S, mi, opt, sl->device, n_fn);
-		al_acct() = nullptr;
-		if (e) { for (auto &s : slots) al_stream_slot_destroy(s->S); al_stream_slot_destroy(sl->S); return -2; }
-		slots.push_back(std::move(sl));
+	// batch k: lane k % NL, the lane's batch number j = k / NL, slot j % n_slots_lane and context j % n_ctx_lane of that lane
+	std::vector<std::unique_ptr<Slot>> slots; std::vector<std::unique_ptr<Mapper>> mappers;
+	auto slot_of = [&](uint64_t k) -> Slot * { return slots[(size_t)((k % NL) * n_slots_lane + (k / NL) % n_slots_lane)].get(); };
+	auto destroy_all = [&]() { for (auto &s : slots) { al_acct() = nullptr; al_stream_slot_destroy(s->S); } for (auto &mp : mappers) if (mp->ctx) al_ctx_destroy(mp->ctx); };
+	for (int l = 0; l < NL; ++l) {
+		for (int i = 0; i < n_ctx_lane; ++i) {
+			std::unique_ptr<Mapper> mp(new Mapper()); mp->lane = l; mp->idx = i;
+			al_acct() = &mp->held;
+			mp->ctx = al_ctx_init(mi, opt, devices[l]);
+			al_acct() = nullptr;
+			if (!mp->ctx) { destroy_all(); return -2; }
+			mp->device = mp->ctx->device;                // (a negative device argument means LOCAL_RANK or 0)
+			mappers.push_back(std::move(mp));
+		}
+		for (int i = 0; i < n_slots_lane; ++i) {
+			std::unique_ptr<Slot> sl(new Slot()); sl->lane = l; sl->device = mappers[(size_t)l * n_ctx_lane]->device;
+			al_acct() = &sl->held;
+			const int e = al_stream_slot_init(sl->S, mi, sl->device, n_fn);
+			al_acct() = nullptr;
+			slots.push_back(std::move(sl));
+			if (e) { destroy_all(); return -2; }
+		}
 	}
 	const double T1 = now_s();
 	char rg_id[256]; rg_id[0] = 0;
@@ -163,29 +182,57 @@ int al_stream_map_files(const al_idx_t *mi, int n_fn, const char **fn, const al_
 	const int ofd = fileno(out);
 	memcpy(rs->rg_id, rg_id, 256);
 
-	// batch size in reads.  Upper bound: mini_batch_size bases (-K); the first batches are small probes, then what they held per read
-	// decides how many reads fill the free device memory.
+	// Batch size in reads.  Upper bound: mini_batch_size bases (-K) unless the caller leaves it to the driver.  The first batches are
+	// small probes; what a probe held per read and how fast it ran decide the size: device memory costs per byte a process touches
+	// for the first time, so the workspaces of a batch are sized to cost a fraction of the job's estimated mapping time, inside the
+	// free memory.
 	const int64_t k_bases = getenv("AL_AUTO_BATCH") ? (int64_t)1 << 40 : opt->mini_batch_size > 0 ? (int64_t)opt->mini_batch_size : 50000000;
 	std::atomic<int> max_reads{0}; std::atomic<bool> sized{false};
-	const int probe_reads = getenv("AL_PROBE_READS") ? std::max(2, atoi(getenv("AL_PROBE_READS"))) : 65536;
+	const int probe_reads = getenv("AL_PROBE_READS") ? std::max(2, atoi(getenv("AL_PROBE_READS"))) : 32768;
 	std::atomic<int> reads_cap_k{1 << 30};                 // mini_batch_size in reads, once a read length is known
-	max_reads = probe_reads;
+	std::atomic<long long> est_total_reads{0};             // from the file sizes and the bytes per read of the first batch
+	max_reads = (int)std::max<int64_t>(2, std::min<int64_t>(probe_reads, k_bases / 64));   // batch 0 (-K is an upper bound: reads of >= 64 bases assumed until a batch has been seen); the following ones 4 x the probe until the size is decided
+	double probe_held0 = 0, probe_n0 = 0;
 	if (getenv("AL_BATCH_READS")) { max_reads = std::max(2, atoi(getenv("AL_BATCH_READS"))); sized = true; }    // tests / tuning: fixed batches
+
+	// SAM text leaves the device through a small ring of page-locked buffers (page-locking memory costs ~0.2 s per GB: no buffer of a
+	// batch's size): the copy of piece n + 1 runs while piece n is written
+	const size_t CH = (size_t)(getenv("AL_OUT_PIECE_MB") ? std::max(1, atoi(getenv("AL_OUT_PIECE_MB"))) : 32) << 20;
+	struct OutRing { char *buf[2] = {nullptr, nullptr}; hipEvent_t ev[2] = {nullptr, nullptr}; };
+	auto ring_make = [&](OutRing &r) -> bool { for (int i = 0; i < 2; ++i) if (hipHostMalloc((void **)&r.buf[i], CH, hipHostMallocDefault) != hipSuccess || hipEventCreateWithFlags(&r.ev[i], hipEventDisableTiming) != hipSuccess) return false; return true; };
+	auto ring_free = [&](OutRing &r) { for (int i = 0; i < 2; ++i) { if (r.buf[i]) (void)hipHostFree(r.buf[i]); if (r.ev[i]) (void)hipEventDestroy(r.ev[i]); } };
+	// text [0, n) of slot S through ring r to sink(ptr, len)
+	auto drain_sam = [&](AlStreamSlot &S, OutRing &r, const std::function<bool(const char *, size_t)> &sink) -> int {
+		const uint64_t n = S.sam_bytes; const uint64_t np = (n + CH - 1) / CH;
+		if (np && al_stream_sam_fetch(S, 0, std::min<uint64_t>(CH, n), r.buf[0], r.ev[0])) return -1;
+		for (uint64_t c = 0; c < np; ++c) {
+			if (c + 1 < np && al_stream_sam_fetch(S, (c + 1) * CH, std::min<uint64_t>(CH, n - (c + 1) * CH), r.buf[(c + 1) & 1], r.ev[(c + 1) & 1])) return -1;
+			if (hipEventSynchronize(r.ev[c & 1]) != hipSuccess) return -1;
+			if (!sink(r.buf[c & 1], (size_t)std::min<uint64_t>(CH, n - c * CH))) return -3;
+		}
+		return 0;
+	};
+	OutRing wring; std::vector<OutRing> mrings(mappers.size());
+	if (!ring_make(wring)) { ring_free(wring); destroy_all(); return -2; }
 
 	// ---- mappers -------------------------------------------------------------------------------------------------------------
 	uint64_t n_batches = ~0ULL;                            // set by the ingest thread when the input is exhausted
-	for (auto &sp : slots) {
-		Slot *sl = sp.get();
-		sl->mapper = std::thread([&, sl]() {
-			al_acct() = &sl->held;
-			AlStreamSlot &S = sl->S;
-			for (;;) {
+	for (auto &mpp : mappers) {
+		Mapper *mp = mpp.get();
+		mp->th = std::thread([&, mp]() {
+			al_acct() = &mp->held;
+			al_ctx_t *ctx = mp->ctx;
+			for (uint64_t j = (uint64_t)mp->idx;; j += (uint64_t)n_ctx_lane) {      // this context's batches of its lane, in order
+				const uint64_t k = j * (uint64_t)NL + (uint64_t)mp->lane;
+				Slot *sl = slot_of(k);
 				{
+					const double tw = now_s();
 					std::unique_lock<std::mutex> l(m);
-					cv.wait(l, [&] { return rc != 0 || sl->state == SL_READY || n_batches != ~0ULL; });
-					if (rc != 0) return;
-					if (sl->state != SL_READY) return;               // the input is exhausted and every batch dealt to this slot is done (batches are marked READY before n_batches is set)
+					cv.wait(l, [&] { return rc != 0 || (sl->state == SL_READY && sl->seq == k) || (n_batches != ~0ULL && k >= n_batches); });
+					mp->t_wait += now_s() - tw;
+					if (rc != 0 || (n_batches != ~0ULL && k >= n_batches)) return;
 				}
+				AlStreamSlot &S = sl->S;
 				const AlIngestResult &res = sl->res;
 				sl->chunks.clear();
 				std::vector<uint32_t> fstart;                  // single-file input, a batch that has to be cut: fragment -> first record
@@ -197,42 +244,62 @@ int al_stream_map_files(const al_idx_t *mi, int n_fn, const char **fn, const al_
 					uint32_t rlo = flo, rhi = fhi;
 					if (n_fn == 1) { if (flo == 0 && fhi == (uint32_t)res.n_frag) { rlo = 0; rhi = (uint32_t)res.n_reads; } else { rlo = fstart[flo]; rhi = fstart[fhi]; } }
 					const double t0 = now_s();
-					int r = al_stream_setup(S, rlo, rhi, flo, fhi);
-					if (r == 0) { const double t1 = now_s(); sl->t_setup += t1 - t0; r = al_batch_run(S.ctx); sl->t_run += now_s() - t1; }
+					al_nomem_flag() = false;
+					int r = al_stream_setup(S, ctx, rlo, rhi, flo, fhi);
+					if (r == 0) { const double t1 = now_s(); mp->t_setup += t1 - t0; r = al_batch_run(ctx); mp->t_run += now_s() - t1; }
 					else if (al_nomem_flag()) r = AL_ERR_NOMEM;
 					if (r == AL_ERR_NOMEM && fhi - flo > 1) {
 						const uint32_t mid = flo + (fhi - flo) / 2;
 						fprintf(stderr, "[airlift] batch of %u fragments does not fit the device workspaces: running it as %u + %u\n", fhi - flo, mid - flo, fhi - mid);
 						if (n_fn == 1 && fstart.empty() && al_stream_frag_starts(S, res, fstart)) return -1;
 						cut = true;
-						{ int mr = max_reads.load(); const int half = std::max(2, (int)((uint64_t)(n_fn == 2 ? 2 : 1) * (fhi - flo) / 2)); if (half < mr) max_reads = half; }
+						{ const int mr = max_reads.load(), half = std::max(2, (int)((uint64_t)(n_fn == 2 ? 2 : 1) * (fhi - flo) / 2)); if (half < mr) max_reads = half; }
 						if ((r = process(flo, mid)) != 0) return r;
 						return process(mid, fhi);
 					}
 					if (r != 0) return r;
 					const double t2 = now_s();
-					if ((r = al_stream_sam(S, rg_id)) != 0) return r;
-					sl->t_sam += now_s() - t2;
-					if (cut) sl->chunks.emplace_back(S.h_sam.data(), S.h_sam.data() + S.sam_bytes);
+					if ((r = al_stream_sam(S, ctx, rg_id)) != 0) return r;
+					if (cut) {   // (rare: the pieces of a cut batch are kept on the host until its turn to be written)
+						OutRing &mr = mrings[(size_t)(mp->lane * n_ctx_lane + mp->idx)];
+						if (!mr.buf[0] && !ring_make(mr)) return -1;
+						sl->chunks.emplace_back(); std::vector<char> &dst = sl->chunks.back(); dst.reserve(S.sam_bytes);
+						if ((r = drain_sam(S, mr, [&](const char *p, size_t n) { dst.insert(dst.end(), p, p + n); return true; })) != 0) return r;
+					}
+					mp->t_sam += now_s() - t2;
 					return 0;
 				};
+				const double tb = now_s();
 				const int r = process(0, (uint32_t)res.n_frag);
 				if (r != 0) { fail(r); return; }
-				++sl->n_batch;
-				if (!sized.load() && res.n_reads >= std::min(probe_reads, 1024)) {
-					// what this batch held per read -> reads that fill the device's free memory, shared by the lane's slots
-					size_t free_b = 0, total_b = 0;
-					if (hipSetDevice(sl->device) == hipSuccess && hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-						size_t held_dev = 0; for (auto &o : slots) if (o->device == sl->device) held_dev += o->held.load();
-						const double per_read = (double)sl->held.load() / (double)res.n_reads;
-						const double budget = ((double)free_b + (double)held_dev) * 0.90 / (double)n_slots_lane;
-						double mr = budget / (per_read * 1.30);         // arenas grow in steps of 25 %; seed hits per read vary between batches
-						mr = std::min(mr, (double)reads_cap_k.load()); mr = std::min(mr, 4.0e6); mr = std::max(mr, (double)std::min(probe_reads, res.n_reads));
-						bool exp = false;
-						if (sized.compare_exchange_strong(exp, true)) {
-							max_reads = (int)mr;
-							if (timing || trace) fprintf(stderr, "[airlift] stream driver: probe batch of %d reads held %.1f MB (%.0f bytes per read); %.1f GB free on device %d -> batches of %d reads on %d slots\n",
-							                             res.n_reads, sl->held.load() / 1e6, per_read, free_b / 1e9, sl->device, (int)mr, n_slots_lane);
+				++mp->n_batch;
+				// Sizing (first context of the first lane): its first batch is a small probe, its second a larger one; what the two held and
+				// how long the second ran give workspace bytes and time per read.
+				if (!sized.load() && mp->lane == 0 && mp->idx == 0) {
+					if (mp->n_batch == 1) { probe_held0 = (double)mp->held.load(); probe_n0 = (double)res.n_reads; }
+					else {
+						size_t free_b = 0, total_b = 0;
+						if (hipSetDevice(mp->device) == hipSuccess && hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+							size_t held_ctx = 0; for (auto &o : mappers) if (o->device == mp->device) held_ctx += o->held.load();
+							const double h1 = (double)mp->held.load(), n1 = (double)res.n_reads, t_batch = now_s() - tb;
+							double v = n1 > probe_n0 ? (h1 - probe_held0) / (n1 - probe_n0) : h1 / n1; if (v < 1024.0) v = 1024.0;   // workspace bytes per read ...
+							const double F = std::max(0.0, h1 - v * n1);                                                               // ... on top of what does not grow with the batch
+							// memory: the lane's contexts share what is free now plus what they hold; the slots' text / SAM buffers (~2 KB per read each) come out of the same
+							double mr = (((double)free_b + (double)held_ctx) * 0.85 / (double)n_ctx_lane - F) / (v * 1.30 + (double)n_slots_lane * 2048.0 / (double)n_ctx_lane);
+							// time: device memory costs a process ~1 s per 25 GB it touches for the first time: a batch's workspaces may cost a fraction
+							// (AL_WS_FRAC, default 0.4) of the mapping time the probe predicts for the rest of the input
+							const double total_reads = (double)std::max<long long>(est_total_reads.load(), res.n_reads) / (double)NL;
+							const double t_job = t_batch / n1 * total_reads;
+							static const double frac = getenv("AL_WS_FRAC") ? atof(getenv("AL_WS_FRAC")) : 0.4;
+							const double ws_budget = std::max(4.0e9, frac * t_job * 25.0e9) / (double)n_ctx_lane;
+							if (frac > 0) mr = std::min(mr, (ws_budget - F) / v);
+							mr = std::min(mr, (double)reads_cap_k.load()); mr = std::min(mr, 4.0e6); mr = std::max(mr, n1);
+							bool exp = false;
+							if (sized.compare_exchange_strong(exp, true)) {
+								max_reads = (int)mr;
+								if (timing || trace) fprintf(stderr, "[airlift] stream driver: probe batches of %.0f / %.0f reads held %.1f / %.1f MB (%.0f bytes per read + %.1f MB) and the second took %.1f ms; %.1f GB free on device %d, ~%.1f M reads to map -> batches of %d reads (%d context(s), %d slots per GPU)\n",
+								                             probe_n0, n1, probe_held0 / 1e6, h1 / 1e6, v, F / 1e6, t_batch * 1e3, free_b / 1e9, mp->device, total_reads / 1e6, (int)mr, n_ctx_lane, n_slots_lane);
+							}
 						}
 					}
 				}
@@ -246,17 +313,17 @@ int al_stream_map_files(const al_idx_t *mi, int n_fn, const char **fn, const al_
 	double t_write = 0; uint64_t bytes_out = 0, recs_out = 0;
 	std::thread writer([&]() {
 		for (uint64_t k = 0;; ++k) {
-			Slot *sl = slots[k % NS].get();
+			Slot *sl = slot_of(k);
 			{
 				std::unique_lock<std::mutex> l(m);
 				cv.wait(l, [&] { return rc != 0 || (sl->state == SL_MAPPED && sl->seq == k) || (n_batches != ~0ULL && k >= n_batches); });
 				if (rc != 0 || (n_batches != ~0ULL && k >= n_batches)) return;
 			}
 			const double t0 = now_s();
-			auto put = [&](const char *p, size_t n) -> bool { while (n) { const ssize_t w = write(ofd, p, n); if (w <= 0) return false; p += w; n -= (size_t)w; } return true; };
+			const std::function<bool(const char *, size_t)> put = [&](const char *p, size_t n) -> bool { while (n) { const ssize_t w = write(ofd, p, n); if (w <= 0) return false; p += w; n -= (size_t)w; } return true; };
 			bool ok = true;
 			if (!sl->chunks.empty()) { for (auto &c : sl->chunks) { ok = ok && put(c.data(), c.size()); bytes_out += c.size(); } sl->chunks.clear(); }
-			else { ok = put(sl->S.h_sam.data(), sl->S.sam_bytes); bytes_out += sl->S.sam_bytes; }
+			else { const int dr = drain_sam(sl->S, wring, put); ok = dr == 0; if (dr == -1) { fail(-1); return; } bytes_out += sl->S.sam_bytes; }
 			recs_out += sl->S.sam_records;
 			t_write += now_s() - t0;
 			if (!ok) { perror("[airlift] writing the SAM output failed"); fail(-3); return; }
@@ -278,7 +345,7 @@ int al_stream_map_files(const al_idx_t *mi, int n_fn, const char **fn, const al_
 		double bytes_per_read = 360.0;                      // refined from every batch
 		uint64_t k = 0; bool stop = false;
 		while (!stop) {
-			Slot *sl = slots[k % NS].get();
+			Slot *sl = slot_of(k);
 			{
 				const double t0 = now_s();
 				std::unique_lock<std::mutex> l(m);
@@ -288,7 +355,7 @@ int al_stream_map_files(const al_idx_t *mi, int n_fn, const char **fn, const al_
 			}
 			al_acct() = &sl->held;
 			AlStreamSlot &S = sl->S;
-			const int mr = max_reads.load();
+			const int mr = (!sized.load() && k > 0) ? std::min(4 * probe_reads, reads_cap_k.load()) : max_reads.load();
 			int err = 0;
 			const double t1 = now_s();
 			for (int i = 0; i < n_fn && !err; ++i) {
@@ -328,6 +395,7 @@ int al_stream_map_files(const al_idx_t *mi, int n_fn, const char **fn, const al_
 			if (res.n_reads > 0) {
 				double used = 0; for (int i = 0; i < n_fn; ++i) used += (double)res.consumed[i];
 				bytes_per_read = used / (double)res.n_reads;
+				if (est_total_reads.load() == 0) { double fs = 0; for (int i = 0; i < n_fn; ++i) fs += (double)rd[i]->file_size(); est_total_reads = (long long)(fs / bytes_per_read); }
 				if (reads_cap_k.load() == (1 << 30)) {          // -K bases as reads: a record is about 2 L + name + 6 bytes
 					const double L = std::max(1.0, (bytes_per_read - 16.0) / 2.0);
 					reads_cap_k = (int)std::max(2.0, std::min(1.0e9, (double)k_bases / L));
@@ -350,15 +418,20 @@ int al_stream_map_files(const al_idx_t *mi, int n_fn, const char **fn, const al_
 		cv.notify_all();
 	}
 	writer.join();
-	for (auto &sp : slots) sp->mapper.join();
+	for (auto &mp : mappers) mp->th.join();
 	const double T2 = now_s();
 	if (timing) {
-		double ts = 0, tr = 0, tm = 0; for (auto &sp : slots) { ts += sp->t_setup; tr += sp->t_run; tm += sp->t_sam; }
-		fprintf(stderr, "[airlift] stream pipeline: %d lane(s) x %d slots; slot init %.3f s; %llu fragments, %llu reads, %llu records, %.1f MB of SAM in %.3f s (%.2f M reads/s); ingest: wait-slot %.3f load %.3f (wait-read %.3f) parse+carry %.3f; mappers (sum): setup %.3f run %.3f sam %.3f; writer %.3f; total %.3f s\n",
-		        NL, n_slots_lane, T1 - T0, (unsigned long long)n_frag_total, (unsigned long long)n_reads_total, (unsigned long long)recs_out, bytes_out / 1e6, T2 - T1, n_reads_total / std::max(1e-9, T2 - T1) / 1e6,
+		double ts = 0, tr = 0, tm = 0; for (auto &mp : mappers) { ts += mp->t_setup; tr += mp->t_run; tm += mp->t_sam; }
+		fprintf(stderr, "[airlift] stream pipeline: %d lane(s) x (%d context(s), %d slots); init %.3f s; %llu fragments, %llu reads, %llu records, %.1f MB of SAM in %.3f s (%.2f M reads/s); ingest: wait-slot %.3f load %.3f (wait-read %.3f) parse+carry %.3f; mappers (sum): setup %.3f run %.3f sam %.3f; writer %.3f; total %.3f s\n",
+		        NL, n_ctx_lane, n_slots_lane, T1 - T0, (unsigned long long)n_frag_total, (unsigned long long)n_reads_total, (unsigned long long)recs_out, bytes_out / 1e6, T2 - T1, n_reads_total / std::max(1e-9, T2 - T1) / 1e6,
 		        t_wait_slot, t_load, t_wait_read, t_parse, ts, tr, tm, t_write, T2 - T0);
-		for (auto &sp : slots) fprintf(stderr, "[airlift] pipeline lane %d (device %d): slot: %d batches, setup %.3f run %.3f sam %.3f; held %.1f MB; total %.3f s\n", sp->lane, sp->device, sp->n_batch, sp->t_setup, sp->t_run, sp->t_sam, sp->held.load() / 1e6, T2 - T1);
+		for (auto &mp : mappers) fprintf(stderr, "[airlift] pipeline lane %d (device %d): context %d: %d batches, wait %.3f setup %.3f run %.3f sam %.3f; workspaces %.1f MB; total %.3f s\n", mp->lane, mp->device, mp->idx, mp->n_batch, mp->t_wait, mp->t_setup, mp->t_run, mp->t_sam, mp->held.load() / 1e6, T2 - T1);
+		{ AlAllocStat &a = al_alloc_stat(); fprintf(stderr, "[airlift] allocation calls of the process so far: device %lld calls, %.1f GB, %.3f s (hipMalloc + hipFree); page-locked host %lld calls, %.1f MB, %.3f s\n", (long long)a.dev_calls, a.dev_bytes / 1e9, a.dev_ns / 1e9, (long long)a.host_calls, a.host_bytes / 1e6, a.host_ns / 1e9); }
+		size_t sh = 0; for (auto &sp : slots) sh += sp->held.load();
+		fprintf(stderr, "[airlift] stream pipeline: text / SAM buffers of the %d slots: %.1f MB\n", NS, sh / 1e6);
 	}
-	for (auto &sp : slots) { al_acct() = nullptr; al_stream_slot_destroy(sp->S); }
+	ring_free(wring); for (auto &r : mrings) ring_free(r);
+	destroy_all();
+	(void)NM;
 	return rc;
 }
