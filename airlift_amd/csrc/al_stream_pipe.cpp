@@ -144,8 +144,8 @@ int al_stream_map_files(const al_idx_t *mi, int n_fn, const char **fn, const al_
 	for (int i = 0; i < n_fn; ++i) if (!eligible_file(fn[i])) return AL_STREAM_NA;
 	const bool timing = getenv("AL_TIMING") != nullptr, trace = getenv("AL_TRACE") != nullptr;
 	const double T0 = now_s();
-	const int n_slots_lane = std::max(2, std::min(8, getenv("AL_SLOTS") ? atoi(getenv("AL_SLOTS")) : 3));      // text / SAM buffer sets per GPU
-	const int n_ctx_lane = std::max(1, std::min(n_slots_lane, getenv("AL_CTXS") ? atoi(getenv("AL_CTXS")) : 1));  // mapping contexts per GPU
+	const int n_slots_lane = std::max(2, std::min(8, getenv("AL_SLOTS") ? atoi(getenv("AL_SLOTS")) : 4));      // text / SAM buffer sets per GPU
+	const int n_ctx_lane = std::max(1, std::min(n_slots_lane, getenv("AL_CTXS") ? atoi(getenv("AL_CTXS")) : 2));  // mapping contexts per GPU
 	const int NL = n_dev, NS = NL * n_slots_lane, NM = NL * n_ctx_lane;
 	const size_t PIECE = (size_t)(getenv("AL_PIECE_MB") ? std::max(1, atoi(getenv("AL_PIECE_MB"))) : 8) << 20;
 
@@ -311,6 +311,10 @@ int al_stream_map_files(const al_idx_t *mi, int n_fn, const char **fn, const al_
 
 	// ---- writer --------------------------------------------------------------------------------------------------------------
 	double t_write = 0; uint64_t bytes_out = 0, recs_out = 0;
+	// a regular output file is written by a few threads at once (pwrite of the parts of a piece: one thread copies ~3 GB/s into the page cache)
+	long long woff = -1; int n_wr = 1;
+	{ struct stat sb; const int fl = fcntl(ofd, F_GETFL); const off_t at = lseek(ofd, 0, SEEK_CUR);
+	  if (fstat(ofd, &sb) == 0 && S_ISREG(sb.st_mode) && at >= 0 && fl >= 0 && !(fl & O_APPEND) && !getenv("AL_NO_PWRITE")) { woff = (long long)at; n_wr = std::max(1, std::min(8, n_threads / 4)); } }
 	std::thread writer([&]() {
 		for (uint64_t k = 0;; ++k) {
 			Slot *sl = slot_of(k);
@@ -320,7 +324,16 @@ int al_stream_map_files(const al_idx_t *mi, int n_fn, const char **fn, const al_
 				if (rc != 0 || (n_batches != ~0ULL && k >= n_batches)) return;
 			}
 			const double t0 = now_s();
-			const std::function<bool(const char *, size_t)> put = [&](const char *p, size_t n) -> bool { while (n) { const ssize_t w = write(ofd, p, n); if (w <= 0) return false; p += w; n -= (size_t)w; } return true; };
+			const std::function<bool(const char *, size_t)> put = [&](const char *p, size_t n) -> bool {
+				if (woff >= 0) {
+					std::atomic<bool> okw{true}; const long long base = woff;
+					al_parallel_for(n >= ((size_t)4 << 20) ? n_wr : 1, n, [&](size_t lo, size_t hi, int) { while (lo < hi) { const ssize_t w = pwrite(ofd, p + lo, hi - lo, (off_t)(base + (long long)lo)); if (w <= 0) { okw = false; return; } lo += (size_t)w; } });
+					woff += (long long)n;
+					return okw.load();
+				}
+				while (n) { const ssize_t w = write(ofd, p, n); if (w <= 0) return false; p += w; n -= (size_t)w; }
+				return true;
+			};
 			bool ok = true;
 			if (!sl->chunks.empty()) { for (auto &c : sl->chunks) { ok = ok && put(c.data(), c.size()); bytes_out += c.size(); } sl->chunks.clear(); }
 			else { const int dr = drain_sam(sl->S, wring, put); ok = dr == 0; if (dr == -1) { fail(-1); return; } bytes_out += sl->S.sam_bytes; }
@@ -418,6 +431,7 @@ int al_stream_map_files(const al_idx_t *mi, int n_fn, const char **fn, const al_
 		cv.notify_all();
 	}
 	writer.join();
+	if (woff >= 0) (void)lseek(ofd, (off_t)woff, SEEK_SET);           // whoever writes next (the host driver taking over, the caller) continues behind the text
 	for (auto &mp : mappers) mp->th.join();
 	const double T2 = now_s();
 	if (timing) {
