@@ -18,7 +18,9 @@
 // k must be odd (a k-mer then never equals its reverse complement, so the `continue` of sketch.c:108 never fires and the
 // ring phase carries no long-range state); the short-read preset uses k=21.
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
+#include <string.h>
+#include <cstring>
+#include <rocprim/rocprim.hpp>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -220,10 +222,10 @@ extern "C" al_idx_t *al_idx_build_device(const char *fn, const al_idxopt_t *io, 
 	if (n_seg) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ref_sketch<0>), dim3((unsigned)((n_seg + 63) / 64)), dim3(64), (size_t)w * 64 * 16, st,
 	                              d.S4, d.seq_off, d.seq_len, d_segf, n_seq, n_seg, w, k, d_cnt, (const uint64_t *)nullptr, (uint64_t *)nullptr, (uint64_t *)nullptr);
 	{
-		hipcub::TransformInputIterator<uint64_t, CastU64I, const uint32_t *> it(d_cnt, CastU64I());
-		IDX_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, it, d_off, (int)(n_seg + 1), st));
+		auto it = rocprim::make_transform_iterator((const uint32_t *)d_cnt, CastU64I());
+		IDX_CHECK(rocprim::exclusive_scan(nullptr, tmp_bytes, it, d_off, (uint64_t)0, (size_t)((int)(n_seg + 1)), rocprim::plus<uint64_t>(), st));
 		IDX_CHECK(al_dev_malloc(&d_tmp, tmp_bytes + 16));
-		IDX_CHECK(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, it, d_off, (int)(n_seg + 1), st));
+		IDX_CHECK(rocprim::exclusive_scan(d_tmp, tmp_bytes, it, d_off, (uint64_t)0, (size_t)((int)(n_seg + 1)), rocprim::plus<uint64_t>(), st));
 		IDX_CHECK(hipMemcpyAsync(&total, d_off + n_seg, 8, hipMemcpyDeviceToHost, st));
 		IDX_CHECK(hipStreamSynchronize(st));
 		al_dev_free(d_tmp); d_tmp = nullptr;
@@ -237,29 +239,29 @@ extern "C" al_idx_t *al_idx_build_device(const char *fn, const al_idxopt_t *io, 
 	while ((1u << rid_bits) < n_seq) ++rid_bits;
 	if (total) {
 		// (hash, position) order: stable LSD sorts, position word first (keys y, values h), then hash (keys h, values y)
-		IDX_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, d_y, d_y2, d_h, d_h2, (int)total, 0, 32 + rid_bits, st));
+		IDX_CHECK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_y, d_y2, d_h, d_h2, (int)total, 0, 32 + rid_bits, st));
 		IDX_CHECK(al_dev_malloc(&d_tmp, tmp_bytes + 16));
-		IDX_CHECK(hipcub::DeviceRadixSort::SortPairs(d_tmp, tmp_bytes, d_y, d_y2, d_h, d_h2, (int)total, 0, 32 + rid_bits, st));
+		IDX_CHECK(rocprim::radix_sort_pairs(d_tmp, tmp_bytes, d_y, d_y2, d_h, d_h2, (int)total, 0, 32 + rid_bits, st));
 		(void)hipStreamSynchronize(st); al_dev_free(d_tmp); d_tmp = nullptr;
-		IDX_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, d_h2, d_h, d_y2, d_y, (int)total, 0, 2 * k, st));
+		IDX_CHECK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_h2, d_h, d_y2, d_y, (int)total, 0, 2 * k, st));
 		IDX_CHECK(al_dev_malloc(&d_tmp, tmp_bytes + 16));
-		IDX_CHECK(hipcub::DeviceRadixSort::SortPairs(d_tmp, tmp_bytes, d_h2, d_h, d_y2, d_y, (int)total, 0, 2 * k, st));
+		IDX_CHECK(rocprim::radix_sort_pairs(d_tmp, tmp_bytes, d_h2, d_h, d_y2, d_y, (int)total, 0, 2 * k, st));
 		(void)hipStreamSynchronize(st); al_dev_free(d_tmp); d_tmp = nullptr;
 		// d_h / d_y now sorted.  Distinct hashes, their counts and offsets:
 		d_uniq = d_h2; d_h2 = nullptr;                                    // reuse
 		IDX_CHECK(al_dev_malloc((void **)&d_kcnt, (total + 1) * 4)); IDX_CHECK(al_dev_malloc((void **)&d_nruns, 8));
-		IDX_CHECK(hipcub::DeviceRunLengthEncode::Encode(nullptr, tmp_bytes, d_h, d_uniq, d_kcnt, d_nruns, (int)total, st));
+		IDX_CHECK(rocprim::run_length_encode(nullptr, tmp_bytes, d_h, (unsigned int)((int)total), d_uniq, d_kcnt, d_nruns, st));
 		IDX_CHECK(al_dev_malloc(&d_tmp, tmp_bytes + 16));
-		IDX_CHECK(hipcub::DeviceRunLengthEncode::Encode(d_tmp, tmp_bytes, d_h, d_uniq, d_kcnt, d_nruns, (int)total, st));
+		IDX_CHECK(rocprim::run_length_encode(d_tmp, tmp_bytes, d_h, (unsigned int)((int)total), d_uniq, d_kcnt, d_nruns, st));
 		IDX_CHECK(hipMemcpyAsync(&n_keys, d_nruns, 8, hipMemcpyDeviceToHost, st));
 		IDX_CHECK(hipStreamSynchronize(st));
 		al_dev_free(d_tmp); d_tmp = nullptr;
 		d_koff = d_y2; d_y2 = nullptr;                                    // reuse
 		{
-			hipcub::TransformInputIterator<uint64_t, CastU64I, const uint32_t *> it(d_kcnt, CastU64I());
-			IDX_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, it, d_koff, (int)n_keys, st));
+			auto it = rocprim::make_transform_iterator((const uint32_t *)d_kcnt, CastU64I());
+			IDX_CHECK(rocprim::exclusive_scan(nullptr, tmp_bytes, it, d_koff, (uint64_t)0, (size_t)((int)n_keys), rocprim::plus<uint64_t>(), st));
 			IDX_CHECK(al_dev_malloc(&d_tmp, tmp_bytes + 16));
-			IDX_CHECK(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, it, d_koff, (int)n_keys, st));
+			IDX_CHECK(rocprim::exclusive_scan(d_tmp, tmp_bytes, it, d_koff, (uint64_t)0, (size_t)((int)n_keys), rocprim::plus<uint64_t>(), st));
 		}
 	}
 	while ((1ULL << bits) < n_keys * 2 + 2) ++bits;
@@ -344,9 +346,9 @@ extern "C" int32_t al_idx_cal_max_occ(const al_idx_t *mi, float f)
 	if (hipMalloc((void **)&d_c, n * 4) != hipSuccess || hipMalloc((void **)&d_s, n * 4) != hipSuccess || hipMalloc((void **)&d_n, 8) != hipSuccess) goto done;
 	if (hipMemset(d_n, 0, 8) != hipSuccess) goto done;
 	hipLaunchKernelGGL(k_tab_counts, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, 0, it->second.tab, n_slots, d_c, d_n);
-	if (hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, d_c, d_s, (int)n) != hipSuccess) goto done;
+	if (rocprim::radix_sort_keys(nullptr, tmp_bytes, d_c, d_s, (int)n) != hipSuccess) goto done;
 	if (hipMalloc(&d_tmp, tmp_bytes + 16) != hipSuccess) goto done;
-	if (hipcub::DeviceRadixSort::SortKeys(d_tmp, tmp_bytes, d_c, d_s, (int)n) != hipSuccess) goto done;
+	if (rocprim::radix_sort_keys(d_tmp, tmp_bytes, d_c, d_s, (int)n) != hipSuccess) goto done;
 	if (hipMemcpy(&v, d_s + kk, 4, hipMemcpyDeviceToHost) != hipSuccess) goto done;
 	ret = (int32_t)v + 1;
 done:

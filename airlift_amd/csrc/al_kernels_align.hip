@@ -8,7 +8,9 @@
 // 16-lane group is one SSE vector of the reference, so the anti-diagonal sweep reproduces its 16-cell block geometry,
 // wrapping int8 arithmetic and tie rules bit for bit.  Traceback bytes go to a per-group HBM scratch.
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
+#include <string.h>
+#include <cstring>
+#include <rocprim/rocprim.hpp>
 #include <stdio.h>
 #include <string.h>
 #include <math.h>
@@ -2270,11 +2272,11 @@ k_compact(const uint32_t *__restrict__ frag_first, WsBase W, const uint64_t *__r
 struct CastU64b { __host__ __device__ uint64_t operator()(const uint32_t &v) const { return (uint64_t)v; } };
 static int scan32(al_ctx_t *c, const uint32_t *in, uint64_t *out, int n)
 {
-	hipcub::TransformInputIterator<uint64_t, CastU64b, const uint32_t *> it(in, CastU64b());
+	auto it = rocprim::make_transform_iterator((const uint32_t *)in, CastU64b());
 	size_t bytes = 0;
-	AL_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, it, out, n + 1, c->stream));
+	AL_HIP_CHECK(rocprim::exclusive_scan(nullptr, bytes, it, out, (uint64_t)0, (size_t)(n + 1), rocprim::plus<uint64_t>(), c->stream));
 	if (c->scan_tmp.ensure(bytes + 16)) return -1;
-	AL_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(c->scan_tmp.p, bytes, it, out, n + 1, c->stream));
+	AL_HIP_CHECK(rocprim::exclusive_scan(c->scan_tmp.p, bytes, it, out, (uint64_t)0, (size_t)(n + 1), rocprim::plus<uint64_t>(), c->stream));
 	return 0;
 }
 
@@ -2365,9 +2367,9 @@ int al_run_align_stage(al_ctx_t *c)
 		AL_HIP_CHECK(hipMemsetAsync(regs_n0, 0xff, (size_t)nf * 4, s));
 		hipLaunchKernelGGL(k_iota, dim3((nf + 255) / 256), dim3(256), 0, s, c->chain_idx.p, (uint32_t)nf);
 		size_t bytes = 0;
-		AL_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const uint32_t *)c->frag_nu.p, c->chain_key.p, (const uint32_t *)c->chain_idx.p, c->chain_idx2.p, nf, 0, 32, s));
+		AL_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, bytes, (const uint32_t *)c->frag_nu.p, c->chain_key.p, (const uint32_t *)c->chain_idx.p, c->chain_idx2.p, nf, 0, 32, s));
 		if (c->scan_tmp.ensure(bytes + 16)) return -1;
-		AL_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(c->scan_tmp.p, bytes, (const uint32_t *)c->frag_nu.p, c->chain_key.p, (const uint32_t *)c->chain_idx.p, c->chain_idx2.p, nf, 0, 32, s));
+		AL_HIP_CHECK(rocprim::radix_sort_pairs(c->scan_tmp.p, bytes, (const uint32_t *)c->frag_nu.p, c->chain_key.p, (const uint32_t *)c->chain_idx.p, c->chain_idx2.p, nf, 0, 32, s));
 		uint32_t init[6] = {(uint32_t)nf, (uint32_t)nf, (uint32_t)nf, (uint32_t)nf, (uint32_t)nf, (uint32_t)nf}, lb[6];
 		AL_HIP_CHECK(hipMemcpyAsync(c->lb_buf.p, init, 24, hipMemcpyHostToDevice, s));
 		LbThr T; T.n = 6; T.v[0] = 5; T.v[1] = 65; T.v[2] = 1025; T.v[3] = 8193; T.v[4] = 2049; T.v[5] = 4097; for (int i = 6; i < 16; ++i) T.v[i] = 0xffffffffu;
@@ -2408,8 +2410,7 @@ int al_run_align_stage(al_ctx_t *c)
 		// instances work on disjoint fragments and run side by side.  The code is one lane on LDS copies: what sets the rate is how many
 		// wavefronts a CU holds, i.e. the tile (17 KB: 9 per CU ... 141 KB: one).
 		const size_t lds_a = al_regs_heavy_lds(12, 256), lds_t = al_regs_heavy_lds(24, 512), lds_b = al_regs_heavy_lds(48, 768), lds_s = al_regs_heavy_lds(72, 1024), lds_l = al_regs_heavy_lds(200, 2048);
-		static bool attr_set = false;
-		if (!attr_set) { AL_HIP_CHECK(hipFuncSetAttribute((const void *)k_regs_heavy<200, 2048, 72, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_l)); attr_set = true; }
+		if (!c->attr_regs_heavy) { AL_HIP_CHECK(hipFuncSetAttribute((const void *)k_regs_heavy<200, 2048, 72, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_l)); c->attr_regs_heavy = true; }
 		hipStream_t sd = c->side;
 		AL_HIP_CHECK(hipEventRecord(c->ev_fj[0], s)); AL_HIP_CHECK(hipStreamWaitEvent(sd, c->ev_fj[0], 0));
 #define LHV(RC, AC, RCL, ACL, LDS, ST) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_heavy<RC, AC, RCL, ACL>), dim3(heavy_n), dim3(64), LDS, ST, c->chained.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, (const uint32_t *)c->chain_idx2.p + heavy_from, (int)heavy_n, c->P, c->counters.p, regs_n0)
@@ -2528,9 +2529,9 @@ int al_run_align_stage(al_ctx_t *c)
 		if (nj > 0) {
 			hipLaunchKernelGGL(k_iota, dim3((nj + 255) / 256), dim3(256), 0, s, A->job_idx.p, nj);
 			size_t bytes = 0;
-			AL_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, A->job_key.p, A->job_key2.p, A->job_idx.p, A->job_idx2.p, (int)nj, 0, 24, s));
+			AL_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, bytes, A->job_key.p, A->job_key2.p, A->job_idx.p, A->job_idx2.p, (int)nj, 0, 24, s));
 			if (A->sort_tmp.ensure(bytes + 16)) return -1;
-			AL_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(A->sort_tmp.p, bytes, A->job_key.p, A->job_key2.p, A->job_idx.p, A->job_idx2.p, (int)nj, 0, 24, s));
+			AL_HIP_CHECK(rocprim::radix_sort_pairs(A->sort_tmp.p, bytes, A->job_key.p, A->job_key2.p, A->job_idx.p, A->job_idx2.p, (int)nj, 0, 24, s));
 			AL_HIP_CHECK(hipEventRecord(c->ev[ST_EXT_SORT + 1], s));
 			AL_HIP_CHECK(hipMemcpyAsync(hist, A->hist.p, (AL_NCLS + 1) * 8, hipMemcpyDeviceToHost, s));
 			AL_HIP_CHECK(hipMemcpyAsync(c->stat_dp_tbases, A->hist.p + 24, AL_NCLS * 8, hipMemcpyDeviceToHost, s));

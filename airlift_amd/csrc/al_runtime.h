@@ -89,6 +89,7 @@ struct al_ctx_s {
 	uint64_t n_chain_fallback = 0;
 	int max_qlen_sum = 0;                 // longest fragment of the resident batch
 	int max_rd_len = 0;                   // longest read of the resident batch
+	bool attr_chain_order = false, attr_regs_heavy = false;   // > 64 KB dynamic-LDS opt-in of two kernels: per device (hipFuncSetAttribute acts on the current device), kept per context
 	bool dev_batch = false;               // the batch was parsed and packed on the device (al_stream.hip): no host mirrors of the read arrays
 	DevBuf<uint64_t> a_off_p1; DevBuf<uint32_t> frag_na_p1; DevBuf<int32_t> frag_rep_p1;   // pass-1 snapshots when a re-chain pass ran (taps)
 	uint64_t n_anchor_total = 0, n_anchor_pass1 = 0;

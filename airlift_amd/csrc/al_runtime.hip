@@ -1,11 +1,11 @@
 // al_runtime.hip -- host driver of the device pipeline: index upload, batch packing, stage launches
 // on one HIP stream with per-stage events, and the stage taps used by the parity tests.
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
-#include <rocprim/rocprim.hpp>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <cstring>
+#include <rocprim/rocprim.hpp>
 #include <algorithm>
 #include "al_internal.h"
 #include "al_device.h"
@@ -311,11 +311,11 @@ struct CastU64 { __host__ __device__ uint64_t operator()(const uint32_t &v) cons
 
 static int scan_u32_to_u64(al_ctx_t *c, const uint32_t *in, uint64_t *out, int n)
 {   // out[0..n] = exclusive prefix sums (n+1 entries; in[n] must be readable: callers pad with 0)
-	hipcub::TransformInputIterator<uint64_t, CastU64, const uint32_t *> it(in, CastU64());
+	auto it = rocprim::make_transform_iterator((const uint32_t *)in, CastU64());
 	size_t bytes = 0;
-	AL_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, it, out, n + 1, c->stream));
+	AL_HIP_CHECK(rocprim::exclusive_scan(nullptr, bytes, it, out, (uint64_t)0, (size_t)(n + 1), rocprim::plus<uint64_t>(), c->stream));
 	if (c->scan_tmp.ensure(bytes + 16)) return -1;
-	AL_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(c->scan_tmp.p, bytes, it, out, n + 1, c->stream));
+	AL_HIP_CHECK(rocprim::exclusive_scan(c->scan_tmp.p, bytes, it, out, (uint64_t)0, (size_t)(n + 1), rocprim::plus<uint64_t>(), c->stream));
 	return 0;
 }
 
@@ -360,9 +360,9 @@ static int lower_bounds(al_ctx_t *c, const uint32_t *keys, uint32_t n, const uin
 static int sort_u32_pairs(al_ctx_t *c, const uint32_t *k_in, uint32_t *k_out, const uint32_t *v_in, uint32_t *v_out, int n)
 {
 	size_t bytes = 0;
-	AL_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, k_in, k_out, v_in, v_out, n, 0, 32, c->stream));
+	AL_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, bytes, k_in, k_out, v_in, v_out, n, 0, 32, c->stream));
 	if (c->scan_tmp.ensure(bytes + 16)) return -1;
-	AL_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(c->scan_tmp.p, bytes, k_in, k_out, v_in, v_out, n, 0, 32, c->stream));
+	AL_HIP_CHECK(rocprim::radix_sort_pairs(c->scan_tmp.p, bytes, k_in, k_out, v_in, v_out, n, 0, 32, c->stream));
 	return 0;
 }
 
@@ -405,9 +405,9 @@ static int chain_by_segments(al_ctx_t *c, const uint32_t *order, int n, bool lds
 	if (n1 > 0) {
 		{   // stable sort by size class only (4 bits: one radix pass)
 			size_t bytes = 0;
-			AL_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const uint32_t *)c->vs_cls.p, c->seg_key.p, (const uint32_t *)c->seg_t1.p, c->seg_ord.p, n1, 0, 4, s));
+			AL_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, bytes, (const uint32_t *)c->vs_cls.p, c->seg_key.p, (const uint32_t *)c->seg_t1.p, c->seg_ord.p, n1, 0, 4, s));
 			if (c->scan_tmp.ensure(bytes + 16)) return -1;
-			AL_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(c->scan_tmp.p, bytes, (const uint32_t *)c->vs_cls.p, c->seg_key.p, (const uint32_t *)c->seg_t1.p, c->seg_ord.p, n1, 0, 4, s));
+			AL_HIP_CHECK(rocprim::radix_sort_pairs(c->scan_tmp.p, bytes, (const uint32_t *)c->vs_cls.p, c->seg_key.p, (const uint32_t *)c->seg_t1.p, c->seg_ord.p, n1, 0, 4, s));
 		}
 		static const uint32_t thr[8] = {2, 3, 4, 5, 6, 7, 8, 9};
 		if (lower_bounds(c, c->seg_key.p, (uint32_t)n1, thr, 8, lb)) return -1;
@@ -456,8 +456,7 @@ static int chain_by_segments(al_ctx_t *c, const uint32_t *order, int n, bool lds
 	const uint32_t *fb = c->fb_list.p;
 	if (n_fb > 0 && keep_keys) {   // order restated from the merged chains and their processing keys; only what does not fit its tile is chained again
 		const size_t lds = (size_t)AL_ORD_CAP * (8 + 4 + 2) + 64;
-		static bool attr_set = false;
-		if (!attr_set) { AL_HIP_CHECK(hipFuncSetAttribute((const void *)k_chain_order, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = true; }
+		if (!c->attr_chain_order) { AL_HIP_CHECK(hipFuncSetAttribute((const void *)k_chain_order, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); c->attr_chain_order = true; }
 		if (c->fb2_list.ensure((size_t)n_fb + 2)) return -1;
 		AL_HIP_CHECK(hipMemsetAsync(fb_cnt, 0, 8, s));
 		hipLaunchKernelGGL(k_chain_order, dim3(n_fb), dim3(64), lds, s, c->fb_list.p, (int)n_fb, c->a_off.p, c->frag_nu.p, c->u.p, c->chained.p, (const uint64_t *)c->ws_u64.p, c->u_tmp.p, c->chain_tmp.p, c->fb2_list.p, fb_cnt, c->ws_i32.p);
@@ -632,9 +631,9 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 		if (n_tie > 0) {
 			size_t bytes = 0;    // ascending fragment ids: a deterministic segment order (the collection above appends atomically)
 			if (c->tie_sorted.ensure((size_t)n_tie + 2)) return -1;
-			AL_HIP_CHECK(hipcub::DeviceRadixSort::SortKeys(nullptr, bytes, (const uint32_t *)c->tie_frags.p, c->tie_sorted.p, (int)n_tie, 0, 32, s));
+			AL_HIP_CHECK(rocprim::radix_sort_keys(nullptr, bytes, (const uint32_t *)c->tie_frags.p, c->tie_sorted.p, (int)n_tie, 0, 32, s));
 			if (c->scan_tmp.ensure(bytes + 16)) return -1;
-			AL_HIP_CHECK(hipcub::DeviceRadixSort::SortKeys(c->scan_tmp.p, bytes, (const uint32_t *)c->tie_frags.p, c->tie_sorted.p, (int)n_tie, 0, 32, s));
+			AL_HIP_CHECK(rocprim::radix_sort_keys(c->scan_tmp.p, bytes, (const uint32_t *)c->tie_frags.p, c->tie_sorted.p, (int)n_tie, 0, 32, s));
 			if (chain_by_segments(c, c->tie_sorted.p, (int)n_tie, lds_ok, false, nullptr)) return -1;
 		}
 	}
@@ -675,9 +674,9 @@ int al_run_seed_stages(al_ctx_t *c)
 			{
 				size_t bytes = 0;
 				if (c->rechain_sorted.ensure(n + 1)) return -1;
-				AL_HIP_CHECK(hipcub::DeviceRadixSort::SortKeys(nullptr, bytes, (const uint32_t *)c->rechain_list.p, c->rechain_sorted.p, (int)n, 0, 32, s));
+				AL_HIP_CHECK(rocprim::radix_sort_keys(nullptr, bytes, (const uint32_t *)c->rechain_list.p, c->rechain_sorted.p, (int)n, 0, 32, s));
 				if (c->scan_tmp.ensure(bytes + 16)) return -1;
-				AL_HIP_CHECK(hipcub::DeviceRadixSort::SortKeys(c->scan_tmp.p, bytes, (const uint32_t *)c->rechain_list.p, c->rechain_sorted.p, (int)n, 0, 32, s));
+				AL_HIP_CHECK(rocprim::radix_sort_keys(c->scan_tmp.p, bytes, (const uint32_t *)c->rechain_list.p, c->rechain_sorted.p, (int)n, 0, 32, s));
 			}
 			if (run_seed_chain(c, c->rechain_sorted.p, (int)n, c->opt.max_occ, c->n_anchor_pass1 + (uint64_t)c->n_frag, false)) return -1;
 		}
@@ -885,8 +884,8 @@ int al_sort_keys(al_ctx_t *c, const uint64_t *keys, uint32_t *perm, size_t n)
 	if (hipMalloc((void **)&d_k, n * 8) == hipSuccess && hipMalloc((void **)&d_k2, n * 8) == hipSuccess && hipMalloc((void **)&d_v, n * 4) == hipSuccess && hipMalloc((void **)&d_v2, n * 4) == hipSuccess &&
 	    hipMemcpyAsync(d_k, keys, n * 8, hipMemcpyHostToDevice, c->stream) == hipSuccess) {
 		hipLaunchKernelGGL(k_iota_u32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, d_v, (uint32_t)n);
-		if (hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, d_k, d_k2, d_v, d_v2, (int)n, 0, 64, c->stream) == hipSuccess && hipMalloc(&tmp, bytes + 16) == hipSuccess &&
-		    hipcub::DeviceRadixSort::SortPairs(tmp, bytes, d_k, d_k2, d_v, d_v2, (int)n, 0, 64, c->stream) == hipSuccess &&
+		if (rocprim::radix_sort_pairs(nullptr, bytes, d_k, d_k2, d_v, d_v2, (int)n, 0, 64, c->stream) == hipSuccess && hipMalloc(&tmp, bytes + 16) == hipSuccess &&
+		    rocprim::radix_sort_pairs(tmp, bytes, d_k, d_k2, d_v, d_v2, (int)n, 0, 64, c->stream) == hipSuccess &&
 		    hipMemcpyAsync(perm, d_v2, n * 4, hipMemcpyDeviceToHost, c->stream) == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess) rc = 0;
 	}
 	(void)hipFree(d_k); (void)hipFree(d_k2); (void)hipFree(d_v); (void)hipFree(d_v2); (void)hipFree(tmp);

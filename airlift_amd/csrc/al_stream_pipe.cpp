@@ -273,6 +273,7 @@ int al_stream_map_files(const al_idx_t *mi, int n_fn, const char **fn, const al_
 				const int r = process(0, (uint32_t)res.n_frag);
 				if (r != 0) { fail(r); return; }
 				++mp->n_batch;
+				if (trace) fprintf(stderr, "[airlift] trace: batch %llu (lane %d context %d): %d reads in %.1f ms at +%.3f s (device pipeline %.1f ms, side stream %.1f ms)\n", (unsigned long long)k, mp->lane, mp->idx, res.n_reads, (now_s() - tb) * 1e3, now_s() - T1, ctx->ms_total, ctx->ms_side);
 				// Sizing (first context of the first lane): its first batch is a small probe, its second a larger one; what the two held and
 				// how long the second ran give workspace bytes and time per read.
 				if (!sized.load() && mp->lane == 0 && mp->idx == 0) {
@@ -287,10 +288,10 @@ int al_stream_map_files(const al_idx_t *mi, int n_fn, const char **fn, const al_
 							// memory: the lane's contexts share what is free now plus what they hold; the slots' text / SAM buffers (~2 KB per read each) come out of the same
 							double mr = (((double)free_b + (double)held_ctx) * 0.85 / (double)n_ctx_lane - F) / (v * 1.30 + (double)n_slots_lane * 2048.0 / (double)n_ctx_lane);
 							// time: device memory costs a process ~1 s per 25 GB it touches for the first time: a batch's workspaces may cost a fraction
-							// (AL_WS_FRAC, default 0.4) of the mapping time the probe predicts for the rest of the input
+							// (AL_WS_FRAC, default 0.8) of the mapping time the probe predicts for the rest of the input
 							const double total_reads = (double)std::max<long long>(est_total_reads.load(), res.n_reads) / (double)NL;
 							const double t_job = t_batch / n1 * total_reads;
-							static const double frac = getenv("AL_WS_FRAC") ? atof(getenv("AL_WS_FRAC")) : 0.4;
+							static const double frac = getenv("AL_WS_FRAC") ? atof(getenv("AL_WS_FRAC")) : 0.8;
 							const double ws_budget = std::max(4.0e9, frac * t_job * 25.0e9) / (double)n_ctx_lane;
 							if (frac > 0) mr = std::min(mr, (ws_budget - F) / v);
 							mr = std::min(mr, (double)reads_cap_k.load()); mr = std::min(mr, 4.0e6); mr = std::max(mr, n1);

@@ -185,6 +185,9 @@ int  al_dbg_rs_sort(int device, const uint64_t *keys, int n, uint16_t *order_ser
 /* Self-test of the whole-file parallel FASTA loader of the index builders against the block reader: 0 = same names, lengths and
  * bytes, 1 = the loader declined the file (not a plain uncompressed FASTA), -1 = they differ; needs no GPU. */
 int  al_dbg_fasta_selftest(const char *fn, int n_threads);
+/* Self-test of the block-parallel FASTQ parser of the host driver against its serial kseq-grammar reader on one file: 0 = the same
+ * records, -1 = they differ, -2 = the file cannot be opened; needs no GPU. */
+int  al_dbg_fastq_selftest(const char *fn, int n_threads);
 /* Self-test of the SAM record formatter the GPU runs (k_sam_len / k_sam_write; mm_write_sam3, format.c:387-544), compiled for the CPU:
  * n_frag random fragments formatted by it and by al_write_sam, `de:f:%.4f` checked against printf; returns the number of
  * differences (0 = identical); needs no GPU. */

@@ -54,7 +54,7 @@ class _Workload:
 
     def check(self, tag, p1, p2):
         if not os.path.exists(REF):
-            pytest.skip("oracle/_ref/mm2ref not built")
+            pytest.fail("oracle/_ref/mm2ref is missing: the reference build (oracle/Makefile, target ref) must travel to the GPU box with the snapshot -- without it this comparison against the reference would silently not run")
         nt = str(min(os.cpu_count() or 1, 64))
         cpu, gpu = os.path.join(self.dir, tag + "_cpu.sam"), os.path.join(self.dir, tag + "_gpu.sam")
         with open(cpu, "wb") as f:      # first use builds the CPU index and saves it; later cases load the dump

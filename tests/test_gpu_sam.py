@@ -185,7 +185,7 @@ def test_stage3_regions_2_to_20kb(tmp_path):
     import gen_synth as g
     ref_bin = os.path.join(ROOT, "oracle", "_ref", "mm2ref")
     if not os.path.exists(ref_bin):
-        pytest.skip("oracle/_ref/mm2ref not built")
+        pytest.fail("oracle/_ref/mm2ref is missing: the reference build (oracle/Makefile, target ref) must travel to the GPU box with the snapshot -- without it this comparison against the reference would silently not run")
     ref = g.make_reference(seed=17, n_contigs=3, total_len=3_000_000, n_dups=30, dup_len=(500, 4000), dup_div=0.03)
     g.write_fasta(str(tmp_path / "old.fa"), ref)
     rng = np.random.default_rng(5)
@@ -420,7 +420,7 @@ OPTSETS = [
 def test_non_default_options_match_reference(golden_unpacked, name):
     ref_bin = os.path.join(ROOT, "oracle", "_ref", "mm2ref")
     if not os.path.exists(ref_bin):
-        pytest.skip("reference build oracle/_ref/mm2ref not present")
+        pytest.fail("oracle/_ref/mm2ref is missing: the reference build (oracle/Makefile, target ref) must travel to the GPU box with the snapshot -- without it this comparison against the reference would silently not run")
     d = golden_unpacked[name]
     m = json.load(open(os.path.join(d, "meta.json")))
     for opts in OPTSETS:
@@ -434,7 +434,7 @@ def test_250bp_pairs_match_reference(tmp_path):
     (target >= query + w + 1) -- compared with the reference build on freshly simulated reads."""
     ref_bin = os.path.join(ROOT, "oracle", "_ref", "mm2ref")
     if not os.path.exists(ref_bin):
-        pytest.skip("reference build oracle/_ref/mm2ref not present")
+        pytest.fail("oracle/_ref/mm2ref is missing: the reference build (oracle/Makefile, target ref) must travel to the GPU box with the snapshot -- without it this comparison against the reference would silently not run")
     import gen_synth as g
     ref = g.make_reference(seed=11, n_contigs=4, total_len=2_000_000, n_dups=40)
     g.write_fasta(str(tmp_path / "ref.fa"), ref)
@@ -453,7 +453,7 @@ def test_randomised_parity_sweep_against_reference():
     option sets (band, z-drop around the closed-form guard, scores, thresholds) against the reference build."""
     ref_bin = os.path.join(ROOT, "oracle", "_ref", "mm2ref")
     if not os.path.exists(ref_bin):
-        pytest.skip("reference build oracle/_ref/mm2ref not present")
+        pytest.fail("oracle/_ref/mm2ref is missing: the reference build (oracle/Makefile, target ref) must travel to the GPU box with the snapshot -- without it this comparison against the reference would silently not run")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "45", "20261002"], capture_output=True)
     assert r.returncode == 0, r.stdout.decode()[-3000:]
 
@@ -465,7 +465,7 @@ def test_randomised_parity_sweep_on_repeat_rich_references():
     and the > 64-entry sort order."""
     ref_bin = os.path.join(ROOT, "oracle", "_ref", "mm2ref")
     if not os.path.exists(ref_bin):
-        pytest.skip("reference build oracle/_ref/mm2ref not present")
+        pytest.fail("oracle/_ref/mm2ref is missing: the reference build (oracle/Makefile, target ref) must travel to the GPU box with the snapshot -- without it this comparison against the reference would silently not run")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "70", "31"], capture_output=True, env=dict(os.environ, FUZZ_REPEAT="0.7"))
     assert r.returncode == 0, r.stdout.decode()[-3000:]
 
@@ -477,7 +477,7 @@ def test_selection_reproduces_the_references_in_place_compaction():
     showed k_regs_select testing against the true parent instead."""
     ref_bin = os.path.join(ROOT, "oracle", "_ref", "mm2ref")
     if not os.path.exists(ref_bin):
-        pytest.skip("reference build oracle/_ref/mm2ref not present")
+        pytest.fail("oracle/_ref/mm2ref is missing: the reference build (oracle/Makefile, target ref) must travel to the GPU box with the snapshot -- without it this comparison against the reference would silently not run")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "120", "778"], capture_output=True, env=dict(os.environ, FUZZ_REPEAT="0.7", FUZZ_ONLY="99"))
     assert r.returncode == 0 and b"ok   case 99" in r.stdout, r.stdout.decode()[-3000:]
 

@@ -1,0 +1,124 @@
+"""-m gpu tests of the stream driver (al_stream.hip / al_stream_pipe.cpp): FASTQ record parsing, 4-bit packing (rows a1, a4 of
+SURVEY.md 8a: bseq.c:56-130, sketch.c:9-26, map.c:291-293) and SAM text (row a22: format.c:387-544) as kernels.  Every case
+must give the bytes of the golden SAM (printed by the reference build) or of the host driver (AL_HOST_IO=1: host parser + host
+formatter, itself pinned by tests/test_gpu_sam.py) on the same input."""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "airlift_amd", "bin", "airlift-align")
+
+
+def _run(cmd, cwd, env=None):
+    r = subprocess.run(cmd, cwd=cwd, capture_output=True, env=dict(os.environ, **(env or {})))
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    return r
+
+
+def _golden(golden_unpacked, name):
+    d = golden_unpacked[name]
+    m = json.load(open(os.path.join(d, "meta.json")))
+    return d, m, open(os.path.join(d, "expected.sam"), "rb").read(), (["-R", m["rg"]] if m.get("rg") else [])
+
+
+@pytest.mark.parametrize("name", ["g1_mt150pe", "g2_100se", "g2_250pe", "g3_adversarial", "g6_repeats"])
+@pytest.mark.parametrize("env", [dict(AL_BATCH_READS="64", AL_CTXS="1", AL_SLOTS="2", AL_PIECE_MB="1"), dict(AL_BATCH_READS="301", AL_CTXS="3", AL_SLOTS="5"),
+                                 dict(AL_PROBE_READS="100", AL_WS_FRAC="0.001"), dict(AL_OUT_PIECE_MB="1", AL_NO_PWRITE="1")],
+                         ids=["64_reads_per_batch", "301_reads_3_contexts", "probe_sizing", "small_out_pieces_write"])
+def test_stream_batches_carry_and_contexts(golden_unpacked, name, env, tmp_path):
+    """Many small batches: every batch boundary falls inside the loaded text, so each batch starts with the previous one's carry;
+    batches take turns on 1 / 3 mapping contexts; the batch size chosen from two probe batches; SAM text leaving through 1 MB
+    pieces.  Output to a file (pwrite by several threads) and to a pipe."""
+    d, m, exp, rg = _golden(golden_unpacked, name)
+    r = _run([CLI, "-ax", "sr", "-t", "8"] + rg + [m["ref"]] + m["reads"], d, env=dict(env, AL_TIMING="1"))
+    assert b"stream pipeline" in r.stderr, "the stream driver did not run"
+    assert r.stdout == exp
+    out = tmp_path / "o.sam"
+    _run([CLI, "-ax", "sr", "-t", "8", "-o", str(out)] + rg + [m["ref"]] + m["reads"], d, env=env)
+    assert out.read_bytes() == exp
+
+
+def test_stream_equals_host_driver_on_irregular_text(golden_unpacked, tmp_path):
+    """What the device parser takes and where it stops: CRLF line ends, a comment after the name, `+name` separator lines and a last
+    record without its newline are strict four-line FASTQ; a multi-line record, blank lines between records or a quality string of
+    another length are not -- the batch ends in front of the first such record and the general (kseq grammar) reader continues at that
+    byte.  Same bytes as the host driver in every case, and the hand-over is announced."""
+    import airlift_amd as A
+    d, m, exp, rg = _golden(golden_unpacked, "g1_mt150pe")
+    (n1, s1, q1), (n2, s2, q2) = [A.read_fastx(os.path.join(d, f)) for f in m["reads"]]
+    ref = os.path.join(d, m["ref"])
+
+    def write(path, names, seqs, quals, style):
+        with open(path, "wb") as f:
+            for i in range(len(names)):
+                nm, s, q = names[i], seqs[i], quals[i]
+                if style == "crlf":
+                    f.write(b"@" + nm + b" a comment\r\n" + s + b"\r\n+" + nm + b"\r\n" + q + b"\r\n")
+                elif style == "multiline" and i == 40:
+                    h = len(s) // 2
+                    f.write(b"@" + nm + b"\n" + s[:h] + b"\n" + s[h:] + b"\n+\n" + q[:h] + b"\n" + q[h:] + b"\n")
+                elif style == "blank" and i == 77:
+                    f.write(b"\n\n@" + nm + b"\n" + s + b"\n+\n" + q + b"\n")
+                else:
+                    f.write(b"@" + nm + b"\n" + s + b"\n+\n" + q + (b"" if style == "noeol" and i == len(names) - 1 else b"\n"))
+
+    for style, resume in (("crlf", False), ("noeol", False), ("multiline", True), ("blank", True)):
+        write(tmp_path / "a.fq", n1[:200], s1[:200], q1[:200], style)
+        write(tmp_path / "b.fq", n2[:200], s2[:200], q2[:200], style)
+        host = _run([CLI, "-ax", "sr", "-t", "4"] + rg + [ref, "a.fq", "b.fq"], tmp_path, env=dict(AL_HOST_IO="1")).stdout
+        for extra in (dict(), dict(AL_BATCH_READS="50")):
+            r = _run([CLI, "-ax", "sr", "-t", "4"] + rg + [ref, "a.fq", "b.fq"], tmp_path, env=dict(extra, AL_TIMING="1"))
+            assert r.stdout == host, style
+            assert (b"general reader takes over" in r.stderr) == resume, (style, r.stderr[-600:])
+
+
+def test_stream_single_file_fragments(golden_unpacked, oracle_bin, tmp_path):
+    """One input file: adjacent records with the same name (a trailing /1 /2 ignored) are the reads of a fragment, runs of three or
+    more are cut in twos from the front, the last read of a batch waits for the next batch's first (map.c:580-586, bseq.h:31-36).
+    Batches of 7 reads make every position of a pair fall on a batch boundary.  Compared with the CPU oracle."""
+    import airlift_amd as A
+    d, m, _, _ = _golden(golden_unpacked, "g1_mt150pe")
+    (n1, s1, q1), (n2, s2, q2) = [A.read_fastx(os.path.join(d, f)) for f in m["reads"]]
+    with open(tmp_path / "il.fq", "wb") as f:
+        for i in range(240):
+            base = n1[i][:-2] if n1[i][-2:] == b"/1" else n1[i]
+            f.write(b"@" + base + b"/1\n" + s1[i] + b"\n+\n" + q1[i] + b"\n")
+            if i % 5 != 3:
+                f.write(b"@" + base + b"/2\n" + s2[i] + b"\n+\n" + q2[i] + b"\n")
+            if i % 50 == 49:      # a run of three equal names
+                f.write(b"@" + base + b"\n" + s1[i][::-1] + b"\n+\n" + q1[i] + b"\n")
+    ref = os.path.join(d, m["ref"])
+    exp = _run([oracle_bin, ref, "il.fq"], tmp_path).stdout
+    for env in (dict(AL_BATCH_READS="7"), dict(AL_BATCH_READS="64", AL_CTXS="1"), dict()):
+        r = _run([CLI, "-ax", "sr", ref, "il.fq"], tmp_path, env=dict(env, AL_TIMING="1"))
+        assert b"stream pipeline" in r.stderr
+        assert r.stdout == exp, env
+
+
+def test_stream_cuts_a_batch_that_does_not_fit(golden_unpacked):
+    """AL_ERR_NOMEM from al_batch_run in the stream driver: the batch is mapped as two halves, recursively, its SAM pieces written in
+    order (two files: by fragments; one file: at fragment boundaries), later batches are smaller."""
+    d, m, exp, rg = _golden(golden_unpacked, "g1_mt150pe")
+    r = _run([CLI, "-ax", "sr"] + rg + [m["ref"]] + m["reads"], d, env=dict(AL_TEST_NOMEM_ABOVE="37", AL_TIMING="1"))
+    assert b"stream pipeline" in r.stderr and b"does not fit the device workspaces" in r.stderr
+    assert r.stdout == exp
+    d, m, exp, rg = _golden(golden_unpacked, "g2_100se")
+    r = _run([CLI, "-ax", "sr"] + rg + [m["ref"]] + m["reads"], d, env=dict(AL_TEST_NOMEM_ABOVE="50", AL_TIMING="1"))
+    assert b"does not fit the device workspaces" in r.stderr
+    assert r.stdout == exp
+
+
+def test_stream_options_and_flags(golden_unpacked):
+    """--sam-hit-only, secondary records printed (no NO_PRINT_2ND is not reachable from the CLI: -N / -p change which hits survive),
+    no read group, U bases: the device formatter against the host formatter."""
+    d, m, exp, rg = _golden(golden_unpacked, "g6_repeats")
+    for opts in (["--sam-hit-only"], ["-N", "3", "-p", "0.3"], ["-k", "19", "-w", "9"], ["-n", "1", "-m", "10"]):
+        host = _run([CLI, "-ax", "sr"] + opts + [m["ref"]] + m["reads"], d, env=dict(AL_HOST_IO="1")).stdout
+        got = _run([CLI, "-ax", "sr"] + opts + [m["ref"]] + m["reads"], d, env=dict(AL_BATCH_READS="500")).stdout
+        assert got == host, opts
