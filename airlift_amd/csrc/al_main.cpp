@@ -47,7 +47,7 @@ int main(int argc, char **argv)
 	struct timespec tsm; clock_gettime(CLOCK_MONOTONIC, &tsm);
 	std::vector<const char *> pos; const char *rg = nullptr; int n_threads = 3, device = -1; std::vector<int> devices; bool count_only = false; int bam_mode = 0, bam_level = 5;
 	enum { MODE_MEM, MODE_ALN, MODE_SAMSE, MODE_MM2, MODE_TOKENS } mode = MODE_MM2; int tok_size = 0, tok_skip = 1;
-	int i = 1; bool k_given = false;
+	int i = 1; bool k_given = false; int rank = -1, world = 0; const char *rendezvous = nullptr, *out_path = nullptr;
 	if (argc < 2) return usage();
 	al_set_opt(0, &io, &mo);
 	al_set_opt("sr", &io, &mo);
@@ -113,6 +113,9 @@ int main(int argc, char **argv)
 		else if (!strcmp(a, "-l") && i + 1 < argc) bam_level = atoi(argv[++i]);
 		else if (!strcmp(a, "--sort-mem") && i + 1 < argc) setenv("AL_SORT_MEM", std::to_string(parse_num(argv[++i], "--sort-mem")).c_str(), 1);   // --sorted-bam: bytes held before a sorted run is spilled (samtools sort -m)
 		else if (!strcmp(a, "--device") && i + 1 < argc) device = atoi(argv[++i]);
+		else if (!strcmp(a, "--rank") && i + 1 < argc) rank = atoi(argv[++i]);             // one process per GPU: --rank r --world R -o OUT (al_map_file_frag_ranked)
+		else if (!strcmp(a, "--world") && i + 1 < argc) world = atoi(argv[++i]);
+		else if (!strcmp(a, "--rendezvous") && i + 1 < argc) rendezvous = argv[++i];
 		else if (!strcmp(a, "--devices") && i + 1 < argc) {   // "0-7", "0,1,2", "0,0" (two lanes on one GPU): reads of every mini-batch sharded over the lanes
 			const char *p = argv[++i];
 			while (*p) {
@@ -124,7 +127,8 @@ int main(int argc, char **argv)
 				if (*e && *e != ',') { fprintf(stderr, "[ERROR] --devices expects a list like 0-7 or 0,1,2\n"); return 1; }
 			}
 		}
-		else if (!strcmp(a, "-o") && i + 1 < argc) { const char *fn = argv[++i]; if (strcmp(fn, "-") != 0 && !freopen(fn, "wb", stdout)) { fprintf(stderr, "[ERROR] failed to write the output to file '%s'\n", fn); return 1; } }   // main.c:183-190
+		else if (!strcmp(a, "-o") && i + 1 < argc && (world > 1 || getenv("WORLD_SIZE"))) out_path = argv[++i];      // (a multi-process run opens the merged file itself; --world comes before -o, or WORLD_SIZE is set)
+		else if (!strcmp(a, "-o") && i + 1 < argc) { const char *fn = argv[++i]; out_path = fn; if (strcmp(fn, "-") != 0 && !freopen(fn, "wb", stdout)) { fprintf(stderr, "[ERROR] failed to write the output to file '%s'\n", fn); return 1; } }   // main.c:183-190
 		else if (!strcmp(a, "--version")) { puts(al_version()); return 0; }
 		else { fprintf(stderr, "[WARNING] airlift-align: option '%s' ignored\n", a); }
 	}
@@ -165,6 +169,15 @@ int main(int argc, char **argv)
 		fprintf(stderr, "\nTotal No. of Mappings before alignment (verification): %d\n", (int)total);
 		fflush(stderr);
 		_exit(0);
+	}
+	if (world <= 0 && rank >= 0 && getenv("WORLD_SIZE")) world = atoi(getenv("WORLD_SIZE"));
+	if (world > 1) {   // one process per GPU
+		if (rank < 0 && getenv("RANK")) rank = atoi(getenv("RANK"));
+		if (rank < 0 || rank >= world || !out_path || bam_mode) { fprintf(stderr, "[ERROR] a multi-process run needs --rank r (or RANK) below --world, -o FILE after --world, and SAM output\n"); return 1; }
+		const int rc2 = al_map_file_frag_ranked(mi, (int)reads.size(), reads.data(), &mo, n_threads, out_path, rg, device, rank, world, rendezvous, 0.0);
+		al_idx_destroy(mi);
+		fflush(stderr);
+		_exit(rc2 == 0 ? 0 : 1);
 	}
 	int rc = devices.size() > 1 ? al_map_file_frag_multi(mi, (int)reads.size(), reads.data(), &mo, n_threads, stdout, rg, devices.data(), (int)devices.size(), bam_mode, bam_level)
 	       : bam_mode ? al_map_file_frag_bam(mi, (int)reads.size(), reads.data(), &mo, n_threads, stdout, rg, device, bam_mode == 2, bam_level)

@@ -1,0 +1,319 @@
+// al_ranked.cpp -- one process per GPU (BASELINE.json north_star: "reads trivially sharded across the 8 GPUs of one
+// node with a RCCL all-gather over xGMI only for the final merged offsets").
+//
+// Rank r of R maps a contiguous range of the input's fragments and nothing is parsed centrally:
+//   1. every rank counts the lines of ITS byte range [r S / R, (r + 1) S / R) of each input file (a few threads, memchr speed);
+//      one all-gather of the counts gives every rank the number of lines in front of each range;
+//   2. rank r's first record is the first record that starts in its range of file 1; its number K_r follows from the counts, and
+//      the byte where record K_r starts in file 2 is found by walking the one range of file 2 that holds line 4 K_r
+//      (the reference's reader pairs the two files record by record, bseq.c:129-167); a second all-gather of the starts gives the ends;
+//   3. the rank maps its range with the stream driver (al_stream_pipe.cpp) into a part file next to the output;
+//   4. one all-gather of {records, bytes} per rank -- the exchange the north star names -- gives every part its offset in the
+//      merged output (rank-major = input order, as the reference's serial writer keeps it, map.c:601-644); each rank copies its
+//      part into place (copy_file_range), all ranks at once.
+// The all-gathers carry 16-32 bytes per rank: RCCL (ncclAllGather over xGMI; communicator from ncclGetUniqueId exchanged through a
+// file) when every rank has its own GPU, files in the rendezvous directory otherwise (ranks sharing a GPU, no librccl, AL_NO_RCCL).
+// A rank that does not arrive within the timeout makes the others fail with a message and a non-zero status.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <errno.h>
+#include <fcntl.h>
+#include <unistd.h>
+#include <dlfcn.h>
+#include <sys/stat.h>
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <memory>
+#include <string>
+#include <thread>
+#include <vector>
+#include <hip/hip_runtime.h>
+#include "al_internal.h"
+#include "al_runtime.h"
+#include "al_stream_pipe.h"
+
+namespace {
+
+inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+struct ProcExchange {
+	virtual ~ProcExchange() {}
+	virtual int allgather(const uint64_t *mine, int n_words, uint64_t *all) = 0;   // all: n_words * world; < 0 on timeout / failure
+	virtual const char *name() const = 0;
+};
+
+// ---- files in a directory every rank sees: round k of rank r is "<dir>/x<k>.<r>" (written under a temporary name, then renamed) ----
+// The names carry a run id every rank of one launch shares (AL_RUN_ID, else TORCHELASTIC_RUN_ID / MASTER_PORT, else the parent process id:
+// the ranks of a launch are children of one launcher), so that files a crashed earlier run left behind are not taken for this run's.
+// A rank removes its files of round k once round k + 1 is complete (everybody has read them by then); the last round's few bytes stay.
+static std::string run_id()
+{
+	for (const char *k : {"AL_RUN_ID", "TORCHELASTIC_RUN_ID", "MASTER_PORT"}) { const char *v = getenv(k); if (v && *v) { std::string s; for (const char *p = v; *p; ++p) s.push_back((*p >= '0' && *p <= '9') || (*p >= 'a' && *p <= 'z') || (*p >= 'A' && *p <= 'Z') ? *p : '_'); return s; } }
+	return "p" + std::to_string((long long)getppid());
+}
+struct FileExchange : ProcExchange {
+	std::string dir, id; int rank, world; double timeout; int round = 0;
+	FileExchange(const std::string &d, int r, int w, double t, const std::string &tag = std::string()) : dir(d), id(tag.empty() ? run_id() : tag), rank(r), world(w), timeout(t)
+	{ for (int k = 0; k < 64; ++k) unlink(path(k, rank).c_str()); }             // my own leftovers of an earlier run under the same id
+	std::string path(int k, int r) const { return dir + "/.al_x" + id + "_" + std::to_string(k) + "." + std::to_string(r); }
+	int allgather(const uint64_t *mine, int n_words, uint64_t *all) override
+	{
+		const int k = round++;
+		const std::string fin = path(k, rank), tmp = fin + ".tmp";
+		FILE *f = fopen(tmp.c_str(), "wb");
+		if (!f || fwrite(mine, 8, (size_t)n_words, f) != (size_t)n_words || fclose(f) != 0 || rename(tmp.c_str(), fin.c_str()) != 0) { fprintf(stderr, "[airlift] rank %d: cannot write '%s': %s\n", rank, fin.c_str(), strerror(errno)); return -1; }
+		const double t0 = now_s();
+		for (int r = 0; r < world; ++r) {
+			const std::string fr = path(k, r);
+			for (;;) {
+				FILE *g = fopen(fr.c_str(), "rb");
+				if (g) { const size_t n = fread(all + (size_t)r * n_words, 8, (size_t)n_words, g); fclose(g); if (n == (size_t)n_words) break; }
+				if (now_s() - t0 > timeout) { fprintf(stderr, "[airlift] rank %d: rank %d did not arrive at exchange %d within %.0f s\n", rank, r, k, timeout); return -2; }
+				usleep(2000);
+			}
+		}
+		if (k > 0) unlink(path(k - 1, rank).c_str());       // round k complete: every rank has read round k - 1
+		return 0;
+	}
+	void purge() { for (int k = 0; k < round; ++k) unlink(path(k, rank).c_str()); }   // (only behind a barrier on another channel)
+	const char *name() const override { return "files in the rendezvous directory"; }
+};
+
+// ---- RCCL: one communicator over the ranks' GPUs; the unique id travels through a file ------------------------------------------------
+struct RcclProcExchange : ProcExchange {
+	typedef struct { char internal[128]; } UniqueId;
+	typedef int (*get_id_t)(UniqueId *); typedef int (*init_rank_t)(void **, int, UniqueId, int); typedef int (*allgather_t)(const void *, void *, size_t, int, void *, hipStream_t); typedef int (*destroy_t)(void *);
+	void *lib = nullptr, *comm = nullptr; allgather_t f_ag = nullptr; destroy_t f_destroy = nullptr;
+	hipStream_t st = nullptr; uint64_t *d_send = nullptr, *d_recv = nullptr; int rank, world, device; double timeout; bool ok = false;
+	RcclProcExchange(const std::string &dir, int r, int w, int dev, double t) : rank(r), world(w), device(dev), timeout(t)
+	{
+		for (const char *nm : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) if ((lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL)) != nullptr) break;
+		if (!lib) return;
+		get_id_t f_id = (get_id_t)dlsym(lib, "ncclGetUniqueId"); init_rank_t f_init = (init_rank_t)dlsym(lib, "ncclCommInitRank");
+		f_ag = (allgather_t)dlsym(lib, "ncclAllGather"); f_destroy = (destroy_t)dlsym(lib, "ncclCommDestroy");
+		if (!f_id || !f_init || !f_ag || !f_destroy || hipSetDevice(device) != hipSuccess) return;
+		UniqueId id; memset(&id, 0, sizeof(id));
+		const std::string fid = dir + "/.al_rccl_id_" + run_id();
+		if (rank == 0) {
+			if (f_id(&id) != 0) return;
+			const std::string tmp = fid + ".tmp"; FILE *f = fopen(tmp.c_str(), "wb");
+			if (!f || fwrite(&id, sizeof(id), 1, f) != 1 || fclose(f) != 0 || rename(tmp.c_str(), fid.c_str()) != 0) return;
+		} else {
+			const double t0 = now_s();
+			for (;;) { FILE *f = fopen(fid.c_str(), "rb"); if (f) { const size_t n = fread(&id, sizeof(id), 1, f); fclose(f); if (n == 1) break; } if (now_s() - t0 > timeout) { fprintf(stderr, "[airlift] rank %d: no RCCL id from rank 0 within %.0f s\n", rank, timeout); return; } usleep(2000); }
+		}
+		if (f_init(&comm, world, id, rank) != 0) { comm = nullptr; return; }
+		if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess || hipMalloc((void **)&d_send, 64) != hipSuccess || hipMalloc((void **)&d_recv, 64 * (size_t)world) != hipSuccess) return;
+		ok = true;
+	}
+	~RcclProcExchange() override
+	{
+		if (d_send) (void)hipFree(d_send); if (d_recv) (void)hipFree(d_recv); if (st) (void)hipStreamDestroy(st);
+		if (comm && f_destroy) f_destroy(comm);
+	}
+	int allgather(const uint64_t *mine, int n_words, uint64_t *all) override
+	{
+		if (n_words > 8 || hipSetDevice(device) != hipSuccess) return -1;
+		if (hipMemcpyAsync(d_send, mine, 8 * (size_t)n_words, hipMemcpyHostToDevice, st) != hipSuccess) return -1;
+		if (f_ag(d_send, d_recv, (size_t)n_words, 5 /* ncclUint64 */, comm, st) != 0) return -1;
+		if (hipMemcpyAsync(all, d_recv, 8 * (size_t)n_words * (size_t)world, hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
+		const double t0 = now_s();                     // a peer that never joins the collective must not hang this rank for ever
+		for (;;) { const hipError_t e = hipStreamQuery(st); if (e == hipSuccess) return 0; if (e != hipErrorNotReady) return -1; if (now_s() - t0 > timeout) { fprintf(stderr, "[airlift] rank %d: the RCCL all-gather did not complete within %.0f s (a rank is missing)\n", rank, timeout); return -2; } usleep(200); }
+	}
+	const char *name() const override { return "RCCL ncclAllGather"; }
+};
+
+// ---- lines of a byte range, record starts ----------------------------------------------------------------------------------------
+struct FileMap { int fd = -1; long long size = 0; bool open(const char *fn) { fd = ::open(fn, O_RDONLY); struct stat sb; if (fd < 0 || fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode)) return false; size = (long long)sb.st_size; return true; } ~FileMap() { if (fd >= 0) close(fd); } };
+
+long long count_newlines(int fd, long long lo, long long hi, int n_threads)
+{
+	if (hi <= lo) return 0;
+	std::atomic<long long> total{0}; std::atomic<bool> bad{false};
+	al_parallel_for(std::max(1, n_threads), (size_t)(hi - lo), [&](size_t a, size_t b, int) {
+		std::vector<char> buf(4 << 20); long long c = 0, off = lo + (long long)a; const long long end = lo + (long long)b;
+		while (off < end) {
+			const ssize_t k = pread(fd, buf.data(), (size_t)std::min<long long>((long long)buf.size(), end - off), (off_t)off);
+			if (k <= 0) { bad = true; break; }
+			const char *p = buf.data(), *e = p + k;
+			while ((p = (const char *)memchr(p, '\n', (size_t)(e - p))) != nullptr) { ++c; ++p; }
+			off += k;
+		}
+		total += c;
+	});
+	return bad ? -1 : total.load();
+}
+// offset just behind the n-th newline (n >= 1) at or after `from`; -1 if the file ends first
+long long after_nth_newline(int fd, long long from, long long size, long long n)
+{
+	std::vector<char> buf(4 << 20); long long off = from;
+	while (off < size) {
+		const ssize_t k = pread(fd, buf.data(), (size_t)std::min<long long>((long long)buf.size(), size - off), (off_t)off);
+		if (k <= 0) return -1;
+		const char *p = buf.data(), *e = p + k;
+		while ((p = (const char *)memchr(p, '\n', (size_t)(e - p))) != nullptr) { ++p; if (--n == 0) return off + (p - buf.data()); }
+		off += k;
+	}
+	return -1;
+}
+
+struct RankRange { long long start[2] = {0, 0}, end[2] = {-1, -1}; long long first_record = 0; };
+
+// the byte ranges rank r maps.  Line counts, not a record grammar, decide the cuts: rank r starts at the first line of file 1 that begins in
+// its byte share and whose number is a multiple of four (strict four-line FASTQ: the stream driver checks the grammar of every record
+// it takes and refuses the input otherwise).
+int find_ranges(const char *const *fn, int n_fn, int rank, int world, int n_threads, ProcExchange &ex, RankRange *out)
+{
+	FileMap f[2];
+	for (int i = 0; i < n_fn; ++i) if (!f[i].open(fn[i])) { fprintf(stderr, "ERROR: failed to open file '%s'\n", fn[i]); return -1; }
+	auto share = [&](int i, int r) -> long long { return f[i].size * (long long)r / (long long)world; };
+	// (1) lines of my share of every file
+	uint64_t mine[2] = {0, 0}; std::vector<uint64_t> all(2 * (size_t)world);
+	for (int i = 0; i < n_fn; ++i) { const long long c = count_newlines(f[i].fd, share(i, rank), share(i, rank + 1), n_threads); if (c < 0) return -1; mine[i] = (uint64_t)c; }
+	if (ex.allgather(mine, 2, all.data())) return -2;
+	std::vector<long long> before[2];                  // newlines in front of each share
+	for (int i = 0; i < n_fn; ++i) { before[i].assign((size_t)world + 1, 0); for (int r = 0; r < world; ++r) before[i][(size_t)r + 1] = before[i][(size_t)r] + (long long)all[2 * (size_t)r + (size_t)i]; }
+	// (2) my first record: the first line start at or behind my share's first byte whose line number is a multiple of 4
+	long long start0, line0;                           // line0 = number of the line that starts at start0
+	if (rank == 0) { start0 = 0; line0 = 0; }
+	else {
+		const long long s = share(0, rank);
+		// the line that contains byte s - 1 ends at the first newline at or after s - 1; lines in front of byte s - 1 ... count from `before`, corrected for the byte s - 1 itself
+		char prev = 0; if (pread(f[0].fd, &prev, 1, (off_t)(s - 1)) != 1) return -1;
+		long long pos, ln;
+		if (prev == '\n') { pos = s; ln = before[0][(size_t)rank]; }                                  // a line starts exactly at s
+		else { pos = after_nth_newline(f[0].fd, s, f[0].size, 1); ln = before[0][(size_t)rank] + 1; }  // behind the line that straddles s
+		if (pos >= 0 && (ln & 3) != 0) { pos = after_nth_newline(f[0].fd, pos, f[0].size, 4 - (ln & 3)); ln += 4 - (ln & 3); }
+		if (pos < 0) { pos = f[0].size; ln = before[0][(size_t)world]; ln = (ln + 3) / 4 * 4; }        // nothing starts in my share
+		start0 = pos; line0 = ln;
+	}
+	const long long K = line0 / 4;
+	out->first_record = K; out->start[0] = start0; out->start[1] = 0;
+	if (n_fn == 2) {   // the byte where record K starts in file 2 = behind newline number 4 K
+		const long long want = 4 * K;
+		if (want == 0) out->start[1] = 0;
+		else if (want > before[1][(size_t)world]) out->start[1] = f[1].size;
+		else {
+			int q = 0; while (q + 1 < world && before[1][(size_t)q + 1] < want) ++q;                     // share q holds newline number `want`
+			const long long pos = after_nth_newline(f[1].fd, share(1, q), f[1].size, want - before[1][(size_t)q]);
+			out->start[1] = pos < 0 ? f[1].size : pos;
+		}
+	}
+	// (3) everybody's starts -> my ends
+	uint64_t st[2] = {(uint64_t)out->start[0], (uint64_t)out->start[1]};
+	if (ex.allgather(st, 2, all.data())) return -2;
+	for (int i = 0; i < n_fn; ++i) out->end[i] = rank + 1 < world ? (long long)all[2 * (size_t)(rank + 1) + (size_t)i] : f[i].size;
+	for (int i = 0; i < n_fn; ++i) if (out->end[i] < out->start[i]) out->end[i] = out->start[i];
+	return 0;
+}
+
+int copy_into(int out_fd, long long off, const char *part_path, long long n)
+{
+	const int in = open(part_path, O_RDONLY);
+	if (in < 0) return -1;
+	long long done = 0; off_t in_off = 0, o = (off_t)off; int rc = 0;
+	while (done < n) {
+		ssize_t k = copy_file_range(in, &in_off, out_fd, &o, (size_t)std::min<long long>(n - done, 1LL << 30), 0);
+		if (k < 0 && (errno == EXDEV || errno == EINVAL || errno == ENOSYS || errno == EOPNOTSUPP)) {   // not on this pair of file systems: read + pwrite
+			std::vector<char> buf(8 << 20);
+			while (done < n) { const ssize_t r = pread(in, buf.data(), (size_t)std::min<long long>((long long)buf.size(), n - done), (off_t)done); if (r <= 0) { rc = -1; break; } ssize_t w = 0; while (w < r) { const ssize_t x = pwrite(out_fd, buf.data() + w, (size_t)(r - w), (off_t)(off + done + w)); if (x <= 0) { rc = -1; break; } w += x; } if (rc) break; done += r; }
+			break;
+		}
+		if (k <= 0) { rc = -1; break; }
+		done += k;
+	}
+	close(in);
+	return rc;
+}
+
+} // namespace
+
+// One rank of a multi-process run.  out_path: the merged SAM file (rank 0 creates it); rendezvous: a directory every rank sees
+// (default: the output's directory); device < 0: LOCAL_RANK or rank.  Returns 0, negative on error (message on stderr).
+extern "C" int al_map_file_frag_ranked(const al_idx_t *mi, int n_fn, const char **fn, const al_mapopt_t *opt, int n_threads, const char *out_path, const char *rg,
+                                       int device, int rank, int world, const char *rendezvous, double timeout_s)
+{
+	if (!mi || !fn || !out_path || n_fn < 1 || n_fn > 2 || world < 1 || rank < 0 || rank >= world) return -1;
+	if (timeout_s <= 0) timeout_s = getenv("AL_RANK_TIMEOUT") ? atof(getenv("AL_RANK_TIMEOUT")) : 600.0;
+	std::string dir = rendezvous && *rendezvous ? rendezvous : std::string(out_path);
+	if (!(rendezvous && *rendezvous)) { const size_t sl = dir.rfind('/'); dir = sl == std::string::npos ? "." : dir.substr(0, sl ? sl : 1); }
+	const bool timing = getenv("AL_TIMING") != nullptr;
+	int n_dev = 0; (void)hipGetDeviceCount(&n_dev);
+	if (device < 0) { const char *lr = getenv("LOCAL_RANK"); device = lr ? atoi(lr) : rank; if (n_dev > 0) device %= n_dev; }
+	// the exchange: RCCL when the ranks sit on distinct GPUs, files otherwise
+	std::unique_ptr<FileExchange> fex(new FileExchange(dir, rank, world, timeout_s)); std::unique_ptr<RcclProcExchange> rx;
+	ProcExchange *ex = fex.get();
+	if (world > 1 && !getenv("AL_NO_RCCL") && n_dev >= world) {
+		// every rank tells its device first (through the files): a communicator cannot hold one GPU twice
+		uint64_t d = (uint64_t)device; std::vector<uint64_t> all((size_t)world);
+		if (ex->allgather(&d, 1, all.data())) return -2;
+		bool distinct = true; for (int i = 0; i < world; ++i) for (int j = 0; j < i; ++j) if (all[(size_t)i] == all[(size_t)j]) distinct = false;
+		if (distinct) {
+			rx.reset(new RcclProcExchange(dir, rank, world, device, timeout_s));
+			uint64_t okw = rx->ok ? 1 : 0; if (ex->allgather(&okw, 1, all.data())) return -2;
+			bool all_ok = true; for (int i = 0; i < world; ++i) if (!all[(size_t)i]) all_ok = false;
+			if (all_ok) ex = rx.get();
+		}
+	}
+	if (timing && rank == 0) fprintf(stderr, "[airlift] %d ranks, exchanges by: %s\n", world, ex->name());
+	const double t0 = now_s();
+	RankRange rr;
+	{ const int e = find_ranges(fn, n_fn, rank, world, std::max(1, n_threads / 2), *ex, &rr); if (e) return e; }
+	if (timing) fprintf(stderr, "[airlift] rank %d of %d: records from %lld; bytes [%lld, %lld) of '%s'%s found in %.3f s\n", rank, world, rr.first_record, rr.start[0], rr.end[0], fn[0], n_fn == 2 ? " (and the matching range of the second file)" : "", now_s() - t0);
+	// map my range into a part file
+	const std::string part = std::string(out_path) + ".part" + std::to_string(rank);
+	FILE *pf = fopen(part.c_str(), "wb");
+	if (!pf) { fprintf(stderr, "[airlift] rank %d: cannot create '%s': %s\n", rank, part.c_str(), strerror(errno)); return -3; }
+	AlStreamRange range; for (int i = 0; i < 2; ++i) { range.start[i] = rr.start[i]; range.end[i] = rr.end[i]; } range.header = rank == 0;
+	AlStreamResume rs;
+	int rc = al_stream_map_files(mi, n_fn, fn, opt, n_threads, pf, rg, &device, 1, &rs, &range);
+	if (rc == AL_STREAM_NA) { fprintf(stderr, "[airlift] rank %d: a multi-process run takes plain (uncompressed, four-line) FASTQ files only\n", rank); rc = -1; }
+	if (rc == 0 && rs.resume) { fprintf(stderr, "[airlift] rank %d: the input is not strict four-line FASTQ at byte %lld: not supported in a multi-process run\n", rank, rs.off[0]); rc = -1; }
+	if (fflush(pf) == EOF) rc = rc ? rc : -3;
+	const long long my_bytes = rc == 0 ? (long long)ftello(pf) : 0;
+	fclose(pf);
+	// the exchange of the north star: {ok, bytes} of every part -> offsets
+	uint64_t mine[2] = {rc == 0 ? 1ULL : 0ULL, (uint64_t)my_bytes}; std::vector<uint64_t> all(2 * (size_t)world);
+	int out_fd = -1;
+	if (rank == 0) { out_fd = open(out_path, O_WRONLY | O_CREAT | O_TRUNC, 0644); if (out_fd < 0) { fprintf(stderr, "[airlift] cannot create '%s': %s\n", out_path, strerror(errno)); mine[0] = 0; } }
+	if (ex->allgather(mine, 2, all.data())) { unlink(part.c_str()); if (out_fd >= 0) close(out_fd); return -2; }
+	long long off = 0; bool all_ok = true;
+	for (int r = 0; r < world; ++r) { if (!all[2 * (size_t)r]) all_ok = false; if (r < rank) off += (long long)all[2 * (size_t)r + 1]; }
+	if (all_ok) {
+		if (rank != 0) out_fd = open(out_path, O_WRONLY);
+		if (out_fd < 0 || copy_into(out_fd, off, part.c_str(), my_bytes)) { fprintf(stderr, "[airlift] rank %d: writing its %lld bytes at offset %lld of '%s' failed\n", rank, my_bytes, off, out_path); rc = -3; }
+	} else if (rc == 0) { fprintf(stderr, "[airlift] rank %d: another rank failed; no output\n", rank); rc = -4; }
+	if (out_fd >= 0) close(out_fd);
+	unlink(part.c_str());
+	// everybody is done with the exchange files
+	uint64_t fin = rc == 0 ? 1 : 0;
+	if (ex->allgather(&fin, 1, all.data()) == 0) { for (int r = 0; r < world; ++r) if (!all[(size_t)r] && rc == 0) rc = -4; }
+	if (ex != fex.get()) fex->purge();                 // (the RCCL all-gather above was a barrier: nobody reads the files any more)
+	if (rank == 0) unlink((dir + "/.al_rccl_id_" + run_id()).c_str());
+	if (timing) fprintf(stderr, "[airlift] rank %d: %lld bytes at offset %lld of the merged output; total %.3f s\n", rank, my_bytes, off, now_s() - t0);
+	return rc;
+}
+
+// Self-test of the range finding without a GPU: `world` threads act as the ranks (file exchange in `dir`); the ranges must tile both
+// files, start at records, and pair record for record.  Returns 0, or a negative code.
+extern "C" int al_dbg_ranked_selftest(const char *fn1, const char *fn2, int world, const char *dir)
+{
+	const int n_fn = fn2 && *fn2 ? 2 : 1; const char *fn[2] = {fn1, fn2};
+	std::vector<RankRange> rr((size_t)world); std::vector<int> rcs((size_t)world, 0); std::vector<std::thread> th;
+	for (int r = 0; r < world; ++r) th.emplace_back([&, r]() { FileExchange ex(dir, r, world, 60.0, "selftest"); rcs[(size_t)r] = find_ranges(fn, n_fn, r, world, 2, ex, &rr[(size_t)r]); });
+	for (auto &t : th) t.join();
+	for (int r = 0; r < world; ++r) if (rcs[(size_t)r]) return -1;
+	for (int i = 0; i < n_fn; ++i) {
+		FileMap f; if (!f.open(fn[i])) return -2;
+		if (rr[0].start[i] != 0 || rr[(size_t)world - 1].end[i] != f.size) return -3;
+		for (int r = 0; r + 1 < world; ++r) if (rr[(size_t)r].end[i] != rr[(size_t)r + 1].start[i]) return -4;
+		for (int r = 0; r < world; ++r) {
+			const long long s = rr[(size_t)r].start[i];
+			if (s < f.size) { char c[2] = {0, 0}; if (pread(f.fd, c, 1, (off_t)s) != 1 || c[0] != '@') return -5; if (s > 0 && (pread(f.fd, c + 1, 1, (off_t)(s - 1)) != 1 || c[1] != '\n')) return -5; }
+			if (count_newlines(f.fd, 0, s, 2) != 4 * rr[(size_t)r].first_record && s < f.size) return -6;     // both files: record first_record starts here
+		}
+	}
+	return 0;
+}

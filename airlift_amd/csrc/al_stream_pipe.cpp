@@ -73,18 +73,18 @@ class PieceReader {
 		}
 	}
 public:
-	bool open(const char *fn, long long start_off, size_t piece_bytes, int n_buffers, int n_threads)
+	bool open(const char *fn, long long start_off, long long end_off, size_t piece_bytes, int n_buffers, int n_threads)
 	{
 		fd = ::open(fn, O_RDONLY);
 		struct stat sb;
 		if (fd < 0 || fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode)) return false;
-		size = (long long)sb.st_size; start = start_off; piece = piece_bytes; n_buf = n_buffers;
+		size = (long long)sb.st_size; if (end_off >= 0 && end_off < size) size = end_off; start = start_off; piece = piece_bytes; n_buf = n_buffers;
 		n_pieces = size > start ? (size - start + (long long)piece - 1) / (long long)piece : 0;
 		for (int i = 0; i < n_buf; ++i) { char *p = nullptr; if (hipHostMalloc((void **)&p, piece + 16, hipHostMallocDefault) != hipSuccess) return false; bufs.push_back(p); free_bufs.push_back(i); }
 		for (int t = 0; t < n_threads; ++t) workers.emplace_back(&PieceReader::work, this);
 		return true;
 	}
-	long long file_size() const { return size; }
+	long long file_size() const { return size > start ? size - start : 0; }
 	// next piece in file order; false at end of file (or after a read error: failed() tells)
 	bool next(Piece &pc)
 	{
@@ -138,8 +138,10 @@ bool eligible_file(const char *fn)
 } // namespace
 
 int al_stream_map_files(const al_idx_t *mi, int n_fn, const char **fn, const al_mapopt_t *opt, int n_threads, FILE *out, const char *rg,
-                        const int *devices, int n_dev, AlStreamResume *rs)
+                        const int *devices, int n_dev, AlStreamResume *rs, const AlStreamRange *range)
 {
+	static const AlStreamRange whole;
+	if (!range) range = &whole;
 	if (getenv("AL_HOST_IO") || n_fn < 1 || n_fn > 2 || n_dev < 1) return AL_STREAM_NA;
 	for (int i = 0; i < n_fn; ++i) if (!eligible_file(fn[i])) return AL_STREAM_NA;
 	const bool timing = getenv("AL_TIMING") != nullptr, trace = getenv("AL_TRACE") != nullptr;
@@ -177,7 +179,10 @@ int al_stream_map_files(const al_idx_t *mi, int n_fn, const char **fn, const al_
 	}
 	const double T1 = now_s();
 	char rg_id[256]; rg_id[0] = 0;
-	if (rg != (const char *)-1) al_write_sam_hdr(out, mi, rg, rg_id);
+	if (rg != (const char *)-1) {
+		if (range->header) al_write_sam_hdr(out, mi, rg, rg_id);
+		else { FILE *nul = fopen("/dev/null", "w"); if (nul) { al_write_sam_hdr(nul, mi, rg, rg_id); fclose(nul); } }     // (the read group's ID still goes into every record)
+	}
 	fflush(out);
 	const int ofd = fileno(out);
 	memcpy(rs->rg_id, rg_id, 256);
@@ -352,9 +357,9 @@ int al_stream_map_files(const al_idx_t *mi, int n_fn, const char **fn, const al_
 		const int rd_threads = std::max(1, std::min(4, n_threads / (2 * n_fn)));
 		std::unique_ptr<PieceReader> rd[2];
 		bool open_ok = true;
-		for (int i = 0; i < n_fn; ++i) { rd[i].reset(new PieceReader()); if (!rd[i]->open(fn[i], 0, PIECE, 2 * rd_threads + 2, rd_threads)) open_ok = false; }
+		for (int i = 0; i < n_fn; ++i) { rd[i].reset(new PieceReader()); if (!rd[i]->open(fn[i], range->start[i], range->end[i], PIECE, 2 * rd_threads + 2, rd_threads)) open_ok = false; }
 		if (!open_ok) fail(-1);
-		std::vector<char> carry[2]; long long base_off[2] = {0, 0}; bool eof[2] = {false, false};
+		std::vector<char> carry[2]; long long base_off[2] = {range->start[0], range->start[1]}; bool eof[2] = {false, false};
 		for (int i = 0; i < n_fn; ++i) if (rd[i] && rd[i]->file_size() == 0) eof[i] = true;
 		double bytes_per_read = 360.0;                      // refined from every batch
 		uint64_t k = 0; bool stop = false;

@@ -160,6 +160,18 @@ int  al_map_file_frag_bam(const al_idx_t *mi, int n_segs, const char **fn, const
 int  al_map_file_frag_multi(const al_idx_t *mi, int n_segs, const char **fn, const al_mapopt_t *opt, int n_threads,
                             FILE *out, const char *rg, const int *devices, int n_dev, int bam_mode, int level);
 
+/* One process per GPU: rank `rank` of `world` maps a contiguous range of the input's fragments -- it finds its own byte
+ * ranges of the plain FASTQ files (line counts of every rank's share, exchanged once) -- and writes its SAM text into `out_path` at the
+ * offset the final all-gather of {ok, bytes} per rank gives it (rank-major = input order).  The exchanges are 16-byte all-gathers: RCCL
+ * over xGMI when every rank has its own GPU, files in `rendezvous` (default: the output's directory) otherwise; a rank that does not
+ * arrive within timeout_s (<= 0: AL_RANK_TIMEOUT or 600) makes the others fail.  device < 0: LOCAL_RANK or `rank`.  Output bytes are
+ * those of al_map_file_frag on the whole input. */
+int  al_map_file_frag_ranked(const al_idx_t *mi, int n_segs, const char **fn, const al_mapopt_t *opt, int n_threads, const char *out_path,
+                             const char *rg, int device, int rank, int world, const char *rendezvous, double timeout_s);
+/* Self-test of the range finding of al_map_file_frag_ranked without a GPU: `world` threads act as the ranks; 0 = the ranges tile the
+ * files, start at records and pair record for record. */
+int  al_dbg_ranked_selftest(const char *fn1, const char *fn2, int world, const char *dir);
+
 /* ---- read extraction feeding the path (host-side; replaces per-region `samtools view | convert2bed | awk`) ---- */
 /* src/4-extract_reads/extract_reads.sh:8 (prune != 0) / extract_reads_noprune.sh:7 (prune == 0) for all lines of a BED file in
  * one pass over the BAM: rows "chrom start end name[.1|.2] MAPQ CIGAR" of the mapped records that lie inside a BED line

@@ -45,6 +45,19 @@ int main(int argc, char **argv)
 		write_file(path("t.fq"), fq);
 		for (int t : {2, 8}) { const int r = al_dbg_fastq_selftest(path("t.fq").c_str(), t); if (r != 0) { fprintf(stderr, "FASTQ parser self-test kind %d with %d threads: %d\n", kind, t, r); ++bad; } }
 	}
+	// multi-process range finding (threads as ranks): variable record lengths, more ranks than records, one and two files
+	{
+		std::string a, b;
+		for (int i = 0; i < 5000; ++i) {
+			const int L1 = 30 + (int)(rnd() % 200), L2 = 30 + (int)(rnd() % 200);
+			a += "@frag" + std::to_string(i) + "/1\n" + std::string((size_t)L1, 'A') + "\n+\n" + std::string((size_t)L1, '@') + "\n";      // quality lines that start with '@'
+			b += "@frag" + std::to_string(i * 7) + "/2 comment\n" + std::string((size_t)L2, 'C') + "\n+\n" + std::string((size_t)L2, 'I') + "\n";
+		}
+		write_file(path("p_1.fq"), a); write_file(path("p_2.fq"), b); write_file(path("tiny.fq"), "@x\nACGT\n+\nIIII\n@y\nAC\n+\nII\n");
+		for (int w : {1, 2, 3, 8, 17}) { const int r = al_dbg_ranked_selftest(path("p_1.fq").c_str(), path("p_2.fq").c_str(), w, g_dir.c_str()); if (r != 0) { fprintf(stderr, "rank range self-test, %d ranks, two files: %d\n", w, r); ++bad; } }
+		for (int w : {2, 5}) { const int r = al_dbg_ranked_selftest(path("p_2.fq").c_str(), "", w, g_dir.c_str()); if (r != 0) { fprintf(stderr, "rank range self-test, %d ranks, one file: %d\n", w, r); ++bad; } }
+		{ const int r = al_dbg_ranked_selftest(path("tiny.fq").c_str(), path("tiny.fq").c_str(), 6, g_dir.c_str()); if (r != 0) { fprintf(stderr, "rank range self-test, 6 ranks on 2 records: %d\n", r); ++bad; } }
+	}
 	// ordered output of several lanes
 	for (int lanes : {1, 2, 5}) for (int off : {0, 1}) { const int r = al_dbg_ordered_out_selftest(path("o.txt").c_str(), lanes, 40, off); if (r != 0) { fprintf(stderr, "ordered output self-test (%d lanes, offsets %d): %d\n", lanes, off, r); ++bad; } }
 	// SAM formatter (device routine compiled for the host) against al_write_sam

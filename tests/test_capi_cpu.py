@@ -256,3 +256,20 @@ def test_device_sam_formatter_equals_al_write_sam(A, seed):
     L = A.load()
     L.al_dbg_sam_selftest.argtypes = [C.c_uint64, C.c_int]; L.al_dbg_sam_selftest.restype = C.c_int
     assert L.al_dbg_sam_selftest(seed, 8000) == 0
+
+
+def test_rank_ranges_tile_the_input(A, tmp_path):
+    """One process per GPU (al_map_file_frag_ranked): the byte ranges the ranks find for themselves -- line counts of every rank's share
+    of each file, one exchange -- tile both files, start at records and pair record k of file 1 with record k of file 2, for records of
+    varying length, quality lines that begin with '@', more ranks than records.  Threads act as the ranks (file exchange)."""
+    import random
+    L = A.load(); L.al_dbg_ranked_selftest.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_char_p]
+    rnd = random.Random(5)
+    with open(tmp_path / "a.fq", "wb") as fa, open(tmp_path / "b.fq", "wb") as fb:
+        for i in range(3000):
+            l1, l2 = rnd.randint(20, 300), rnd.randint(20, 300)
+            fa.write(b"@r%d/1\n" % i + b"A" * l1 + b"\n+\n" + b"@" * l1 + b"\n")
+            fb.write(b"@r%d/2 x\n" % (i * 13) + b"C" * l2 + b"\n+r\n" + b"I" * l2 + b"\n")
+    for w in (1, 2, 3, 8, 16):
+        assert L.al_dbg_ranked_selftest(str(tmp_path / "a.fq").encode(), str(tmp_path / "b.fq").encode(), w, str(tmp_path).encode()) == 0, w
+    assert L.al_dbg_ranked_selftest(str(tmp_path / "b.fq").encode(), b"", 4, str(tmp_path).encode()) == 0

@@ -122,3 +122,30 @@ def test_stream_options_and_flags(golden_unpacked):
         host = _run([CLI, "-ax", "sr"] + opts + [m["ref"]] + m["reads"], d, env=dict(AL_HOST_IO="1")).stdout
         got = _run([CLI, "-ax", "sr"] + opts + [m["ref"]] + m["reads"], d, env=dict(AL_BATCH_READS="500")).stdout
         assert got == host, opts
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_one_process_per_gpu_mode_on_one_gpu(golden_unpacked, tmp_path, world):
+    """SURVEY.md 8e as processes: --rank r --world R.  Every rank finds its own byte ranges of the two FASTQ files (line counts of
+    the ranks' shares exchanged once), maps them, and copies its part into the merged file at the offset the final all-gather of the
+    part sizes gives it.  Here the ranks share device 0, so the exchanges go through files in the rendezvous directory (RCCL needs a
+    GPU per rank); the merged file must be the single-process output byte for byte."""
+    d, m, exp, rg = _golden(golden_unpacked, "g1_mt150pe")
+    out = tmp_path / "merged.sam"
+    env = dict(os.environ, AL_RUN_ID="t%d" % world, AL_TIMING="1", AL_RANK_TIMEOUT="120")
+    ps = [subprocess.Popen([CLI, "-ax", "sr", "-t", "4", "--device", "0", "--rank", str(r), "--world", str(world), "--rendezvous", str(tmp_path), "-o", str(out)] + rg + [m["ref"]] + m["reads"],
+                           cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env) for r in range(world)]
+    outs = [p.communicate(timeout=300) for p in ps]
+    assert all(p.returncode == 0 for p in ps), b"\n".join(o[1][-800:] for o in outs).decode()
+    assert out.read_bytes() == exp
+    assert not [f for f in os.listdir(tmp_path) if ".part" in f]
+    assert b"bytes at offset" in outs[1][1]
+
+
+def test_a_missing_rank_makes_the_others_fail(golden_unpacked, tmp_path):
+    """Rank 1 of 2 never starts: rank 0 gives up at the first exchange after AL_RANK_TIMEOUT seconds, with a message and status 1."""
+    d, m, exp, rg = _golden(golden_unpacked, "g1_mt150pe")
+    r = subprocess.run([CLI, "-ax", "sr", "--device", "0", "--rank", "0", "--world", "2", "--rendezvous", str(tmp_path), "-o", str(tmp_path / "o.sam")] + rg + [m["ref"]] + m["reads"],
+                       cwd=d, capture_output=True, env=dict(os.environ, AL_RUN_ID="lonely", AL_RANK_TIMEOUT="3"), timeout=300)
+    assert r.returncode == 1
+    assert b"did not arrive" in r.stderr
