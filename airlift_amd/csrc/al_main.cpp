@@ -47,6 +47,7 @@ int main(int argc, char **argv)
 	struct timespec tsm; clock_gettime(CLOCK_MONOTONIC, &tsm);
 	std::vector<const char *> pos; const char *rg = nullptr; int n_threads = 3, device = -1; std::vector<int> devices; bool count_only = false; int bam_mode = 0, bam_level = 5;
 	enum { MODE_MEM, MODE_ALN, MODE_SAMSE, MODE_MM2, MODE_TOKENS } mode = MODE_MM2; int tok_size = 0, tok_skip = 1;
+	bool prefilter = false; int pf[4] = {3, 3, 5, 3};          // adjacency e, GreedySnake e, k-mer size, rounds
 	int i = 1; bool k_given = false; int rank = -1, world = 0; const char *rendezvous = nullptr, *out_path = nullptr;
 	if (argc < 2) return usage();
 	al_set_opt(0, &io, &mo);
@@ -106,6 +107,10 @@ int main(int argc, char **argv)
 		else if (!strcmp(a, "--seed") && i + 1 < argc) mo.seed = atoi(argv[++i]);
 		else if (!strcmp(a, "--sam-hit-only")) mo.flag |= AL_F_SAM_HIT_ONLY;
 		else if (!strcmp(a, "--count-candidates")) count_only = true;
+		else if (!strcmp(a, "--prefilter") && i + 1 < argc) {   // N4: --prefilter ADJ_E[,SNAKE_E[,SNAKE_K[,SNAKE_ITER]]] with --count-candidates
+			prefilter = true; char *e; const char *v = argv[++i];
+			pf[0] = (int)strtol(v, &e, 10); if (*e == ',') { pf[1] = (int)strtol(e + 1, &e, 10); if (*e == ',') { pf[2] = (int)strtol(e + 1, &e, 10); if (*e == ',') pf[3] = (int)strtol(e + 1, &e, 10); } } else pf[1] = pf[0];
+		}
 		else if (!strcmp(a, "--read-size") && i + 1 < argc) tok_size = atoi(argv[++i]);
 		else if (!strcmp(a, "--skip") && i + 1 < argc) tok_skip = atoi(argv[++i]);
 		else if (!strcmp(a, "--bam")) bam_mode = 1;
@@ -162,11 +167,14 @@ int main(int argc, char **argv)
 		_exit(rc2 == 0 ? 0 : 1);
 	}
 	if (count_only) {   // what the as-shipped fork prints instead of alignments (main.c:384-391, 417)
-		int64_t total = 0;
-		const int rc2 = al_count_candidates_file(mi, reads[0], &mo, n_threads, device, &total);
+		int64_t total = 0, o4[4] = {0, 0, 0, 0};
+		const int rc2 = prefilter ? al_count_candidates_file_filtered(mi, reads[0], &mo, n_threads, device, pf[0], pf[1], pf[2] > 0 ? pf[2] : 5, pf[3], o4)
+		                          : al_count_candidates_file(mi, reads[0], &mo, n_threads, device, &total);
 		al_idx_destroy(mi);
 		if (rc2 != 0) return 1;
+		if (prefilter) total = o4[0];
 		fprintf(stderr, "\nTotal No. of Mappings before alignment (verification): %d\n", (int)total);
+		if (prefilter) fprintf(stderr, "Candidates kept by the adjacency filter (at most %d absent seeds): %lld\nCandidates kept by GreedySnake (e = %d, k-mer %d, %d rounds): %lld\nCandidates kept by both: %lld\n", pf[0], (long long)o4[1], pf[1], pf[2], pf[3], (long long)o4[2], (long long)o4[3]);
 		fflush(stderr);
 		_exit(0);
 	}

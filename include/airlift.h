@@ -267,6 +267,15 @@ int  al_batch_count_candidates(al_ctx_t *ctx, int64_t *total);
  * Returns 0, negative on error. */
 int  al_count_candidates_file(const al_idx_t *mi, const char *fn, const al_mapopt_t *opt, int n_threads, int device, int64_t *total);
 
+/* the pre-alignment filters of the bundled mrFAST fork applied to those candidates, on the device (al_prefilter.hip): the
+ * adjacency filter (MrFAST.c:1741-1764: every other seed of the read looked up at the position the candidate predicts; more than adj_e
+ * absent seeds reject) and GreedySnake (GreedySnake.c:52-200 with EditThreshold snake_e, KmerSize snake_k, IterationNo snake_iter).
+ * out4: candidates (= the count above), kept by adjacency, kept by GreedySnake, kept by both.  Resident batch of single-segment
+ * fragments (first, mid_occ, seeding pass); the alignment path does not use it. */
+int  al_batch_prefilter(al_ctx_t *ctx, int adj_e, int snake_e, int snake_k, int snake_iter, int64_t *out4);
+int  al_count_candidates_file_filtered(const al_idx_t *mi, const char *fn, const al_mapopt_t *opt, int n_threads, int device,
+                                       int adj_e, int snake_e, int snake_k, int snake_iter, int64_t *out4);
+
 /* ---- stage taps for parity tests (analogue of --print-seeds, map.c:333-338,381-385) ---- */
 /* minimizers of read i of the resident batch: returns count, writes up to cap records (x = hash<<8|span, y = i<<32|pos<<1|strand) */
 int  al_dbg_minimizers(al_ctx_t *ctx, int read_idx, uint64_t *xy, int cap);
