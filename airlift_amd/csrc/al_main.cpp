@@ -140,6 +140,7 @@ int main(int argc, char **argv)
 	// -K given: an upper bound of the bases per device batch.  Not given: the stream driver (plain FASTQ in, SAM out) sizes its batches
 	// from the free device memory (al_stream_pipe.cpp); the host driver keeps the preset's 50 Mbases, as the reference.
 	if (!k_given) setenv("AL_AUTO_BATCH", "1", 0);
+	setenv("GPU_MAX_HW_QUEUES", "8", 0);       // (HIP reads it when the runtime starts) the contexts' and slots' streams on separate hardware queues: the default of 4 makes streams that share a queue wait for each other
 	if (al_check_opt(&io, &mo) < 0) return 1;
 	const char *ref = nullptr; std::vector<const char *> reads;
 	if (mode == MODE_ALN) {          // the real work happens in samse; emit a small marker so `> x.sai` is non-empty

@@ -22,6 +22,8 @@ hipError_t al_dev_malloc(void **p, size_t bytes);
 #include <atomic>
 std::atomic<size_t> *&al_acct();
 // time this process has spent in device / page-locked host allocation calls (AL_TIMING report)
+struct AlAllocSite { const char *file; int line; };
+AlAllocSite &al_alloc_site();      // who asked (AL_TRACE_ALLOC lists the large allocations with their call site)
 struct AlAllocStat { std::atomic<long long> dev_ns{0}, dev_bytes{0}, dev_calls{0}, host_ns{0}, host_bytes{0}, host_calls{0}; };
 AlAllocStat &al_alloc_stat();
 void al_dev_free(void *p);
@@ -29,9 +31,10 @@ int al_dev_guard_check();            // AL_TEST_GUARD=1: number of live ranges w
 
 template <typename T> struct DevBuf {       // grow-only device array
 	T *p = nullptr; size_t cap = 0;
-	int ensure(size_t n, bool keep = false, hipStream_t s = 0)
+	int ensure(size_t n, bool keep = false, hipStream_t s = 0, int line = __builtin_LINE(), const char *file = __builtin_FILE())
 	{
 		if (n <= cap) return 0;
+		al_alloc_site() = AlAllocSite{file, line};
 		const size_t ncap = n + n / 4 + 64;
 		T *np = nullptr;
 		if (!keep && p) { al_dev_free(p); p = nullptr; cap = 0; }         // contents not needed: release first, so the peak is one copy
@@ -93,6 +96,7 @@ struct al_ctx_s {
 	bool dev_batch = false;               // the batch was parsed and packed on the device (al_stream.hip): no host mirrors of the read arrays
 	DevBuf<uint64_t> a_off_p1; DevBuf<uint32_t> frag_na_p1; DevBuf<int32_t> frag_rep_p1;   // pass-1 snapshots when a re-chain pass ran (taps)
 	uint64_t n_anchor_total = 0, n_anchor_pass1 = 0;
+	double anchor_grow_hw = 1.0;          // largest (anchors after the re-seeding pass) / (anchors of the first pass) this context has seen: the first pass reserves for it, so that the second does not reallocate
 	uint32_t n_rechain = 0;
 
 	// alignment stage (al_kernels_align.hip)

@@ -99,11 +99,15 @@ void al_dev_free(void *p)
 std::atomic<size_t> *&al_acct() { static thread_local std::atomic<size_t> *a = nullptr; return a; }
 namespace { struct OwnRec { size_t bytes; std::atomic<size_t> *owner; }; std::mutex g_own_m; std::map<void *, OwnRec> g_own; }
 AlAllocStat &al_alloc_stat() { static AlAllocStat s; return s; }
+AlAllocSite &al_alloc_site() { static thread_local AlAllocSite s{"", 0}; return s; }
 static hipError_t al_dev_malloc_raw(void **p, size_t bytes)
 {
 	const auto t0 = std::chrono::steady_clock::now();
 	const hipError_t e = hipMalloc(p, bytes);
-	{ AlAllocStat &a = al_alloc_stat(); a.dev_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); a.dev_bytes += (long long)bytes; ++a.dev_calls; }
+	{ AlAllocStat &a = al_alloc_stat(); const long long ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); a.dev_ns += ns; a.dev_bytes += (long long)bytes; ++a.dev_calls;
+	  static const bool tr = getenv("AL_TRACE_ALLOC") != nullptr;
+	  if (tr && bytes >= (32u << 20)) { const AlAllocSite &w = al_alloc_site(); const char *b = strrchr(w.file, '/'); fprintf(stderr, "[airlift] alloc: %8.1f MB in %7.1f ms for %s:%d\n", bytes / 1e6, ns / 1e6, b ? b + 1 : w.file, w.line); } }
+	al_alloc_site() = AlAllocSite{"", 0};
 	std::atomic<size_t> *a = al_acct();
 	if (e == hipSuccess && a) { a->fetch_add(bytes); std::lock_guard<std::mutex> l(g_own_m); g_own[*p] = OwnRec{bytes, a}; }
 	return e;
@@ -489,12 +493,13 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 		AL_HIP_CHECK(hipMemcpyAsync(&total, c->a_off.p + c->n_frag, 8, hipMemcpyDeviceToHost, s));
 		AL_HIP_CHECK(hipStreamSynchronize(s));
 		c->n_anchor_pass1 = total; c->n_anchor_total = total;
-		if (ensure_anchor_space(c, total, false)) return -1;
+		if (ensure_anchor_space(c, (uint64_t)((double)total * c->anchor_grow_hw) + 1, false)) return -1;
 	} else {
 		hipLaunchKernelGGL(k_gather_na, dim3((nl + 256) / 256), dim3(256), 0, s, c->frag_na.p, list, nl, c->tmp_u32.p);
 		if (scan_u32_to_u64(c, c->tmp_u32.p, c->tmp_u64.p, nl)) return -1;
 		AL_HIP_CHECK(hipMemcpyAsync(&total, c->tmp_u64.p + nl, 8, hipMemcpyDeviceToHost, s));
 		AL_HIP_CHECK(hipStreamSynchronize(s));
+		if (c->n_anchor_pass1 > 0) { const double g = 1.03 * (double)(base_off + total) / (double)c->n_anchor_pass1; if (g > c->anchor_grow_hw) c->anchor_grow_hw = g < 3.0 ? g : 3.0; }
 		if (ensure_anchor_space(c, base_off + total, true)) return -1;
 		hipLaunchKernelGGL(k_scatter_off, dim3((nl + 255) / 256), dim3(256), 0, s, c->tmp_u64.p, list, nl, base_off, c->a_off.p);
 		c->n_anchor_total = base_off + total;

@@ -18,6 +18,7 @@
 // from the byte where the device parser stops.
 #include <stdio.h>
 #include <stdlib.h>
+#include <math.h>
 #include <string.h>
 #include <fcntl.h>
 #include <unistd.h>
@@ -146,8 +147,8 @@ int al_stream_map_files(const al_idx_t *mi, int n_fn, const char **fn, const al_
 	for (int i = 0; i < n_fn; ++i) if (!eligible_file(fn[i])) return AL_STREAM_NA;
 	const bool timing = getenv("AL_TIMING") != nullptr, trace = getenv("AL_TRACE") != nullptr;
 	const double T0 = now_s();
-	const int n_slots_lane = std::max(2, std::min(8, getenv("AL_SLOTS") ? atoi(getenv("AL_SLOTS")) : 4));      // text / SAM buffer sets per GPU
-	const int n_ctx_lane = std::max(1, std::min(n_slots_lane, getenv("AL_CTXS") ? atoi(getenv("AL_CTXS")) : 2));  // mapping contexts per GPU
+	const int n_slots_lane = std::max(2, std::min(8, getenv("AL_SLOTS") ? atoi(getenv("AL_SLOTS")) : 5));      // text / SAM buffer sets per GPU
+	const int n_ctx_lane = std::max(1, std::min(n_slots_lane, getenv("AL_CTXS") ? atoi(getenv("AL_CTXS")) : 3));  // mapping contexts per GPU
 	const int NL = n_dev, NS = NL * n_slots_lane, NM = NL * n_ctx_lane;
 	const size_t PIECE = (size_t)(getenv("AL_PIECE_MB") ? std::max(1, atoi(getenv("AL_PIECE_MB"))) : 8) << 20;
 
@@ -292,18 +293,19 @@ int al_stream_map_files(const al_idx_t *mi, int n_fn, const char **fn, const al_
 							const double F = std::max(0.0, h1 - v * n1);                                                               // ... on top of what does not grow with the batch
 							// memory: the lane's contexts share what is free now plus what they hold; the slots' text / SAM buffers (~2 KB per read each) come out of the same
 							double mr = (((double)free_b + (double)held_ctx) * 0.85 / (double)n_ctx_lane - F) / (v * 1.30 + (double)n_slots_lane * 2048.0 / (double)n_ctx_lane);
-							// time: device memory costs a process ~1 s per 25 GB it touches for the first time: a batch's workspaces may cost a fraction
-							// (AL_WS_FRAC, default 0.8) of the mapping time the probe predicts for the rest of the input
+							// time: device memory costs a process ~1 s per 30 GB it obtains for the first time (AL_ALLOC_GBS), a batch costs ~25 ms of
+							// launch gaps and serial tails on top of what scales with its reads (AL_BATCH_MS): with N reads over n contexts in batches
+							// of B, allocation costs n (F + 1.3 v B) / A and the gaps N t0 / (n B) -- least at B = sqrt(N t0 A / (1.3 v n^2)).
+							// (A short input keeps the probe's size; a genome's worth of reads is bounded by memory alone.)
 							const double total_reads = (double)std::max<long long>(est_total_reads.load(), res.n_reads) / (double)NL;
-							const double t_job = t_batch / n1 * total_reads;
-							static const double frac = getenv("AL_WS_FRAC") ? atof(getenv("AL_WS_FRAC")) : 0.8;
-							const double ws_budget = std::max(4.0e9, frac * t_job * 25.0e9) / (double)n_ctx_lane;
-							if (frac > 0) mr = std::min(mr, (ws_budget - F) / v);
+							static const double A = (getenv("AL_ALLOC_GBS") ? atof(getenv("AL_ALLOC_GBS")) : 30.0) * 1e9, t0b = (getenv("AL_BATCH_MS") ? atof(getenv("AL_BATCH_MS")) : 25.0) * 1e-3;
+							const double b_opt = sqrt(total_reads * t0b * A / (1.30 * v * (double)n_ctx_lane * (double)n_ctx_lane));
+							if (A > 0) mr = std::min(mr, b_opt);
 							mr = std::min(mr, (double)reads_cap_k.load()); mr = std::min(mr, 4.0e6); mr = std::max(mr, n1);
 							bool exp = false;
 							if (sized.compare_exchange_strong(exp, true)) {
 								max_reads = (int)mr;
-								if (timing || trace) fprintf(stderr, "[airlift] stream driver: probe batches of %.0f / %.0f reads held %.1f / %.1f MB (%.0f bytes per read + %.1f MB) and the second took %.1f ms; %.1f GB free on device %d, ~%.1f M reads to map -> batches of %d reads (%d context(s), %d slots per GPU)\n",
+								if (timing || trace) fprintf(stderr, "[airlift] stream driver: probe batches of %.0f / %.0f reads held %.1f / %.1f MB (%.0f bytes per read + %.1f MB; the second took %.1f ms); %.1f GB free on device %d, ~%.1f M reads to map -> batches of %d reads (%d context(s), %d slots per GPU)\n",
 								                             probe_n0, n1, probe_held0 / 1e6, h1 / 1e6, v, F / 1e6, t_batch * 1e3, free_b / 1e9, mp->device, total_reads / 1e6, (int)mr, n_ctx_lane, n_slots_lane);
 							}
 						}

@@ -29,7 +29,7 @@ def _golden(golden_unpacked, name):
 
 @pytest.mark.parametrize("name", ["g1_mt150pe", "g2_100se", "g2_250pe", "g3_adversarial", "g6_repeats"])
 @pytest.mark.parametrize("env", [dict(AL_BATCH_READS="64", AL_CTXS="1", AL_SLOTS="2", AL_PIECE_MB="1"), dict(AL_BATCH_READS="301", AL_CTXS="3", AL_SLOTS="5"),
-                                 dict(AL_PROBE_READS="100", AL_WS_FRAC="0.001"), dict(AL_OUT_PIECE_MB="1", AL_NO_PWRITE="1")],
+                                 dict(AL_PROBE_READS="100", AL_ALLOC_GBS="0.001"), dict(AL_OUT_PIECE_MB="1", AL_NO_PWRITE="1")],
                          ids=["64_reads_per_batch", "301_reads_3_contexts", "probe_sizing", "small_out_pieces_write"])
 def test_stream_batches_carry_and_contexts(golden_unpacked, name, env, tmp_path):
     """Many small batches: every batch boundary falls inside the loaded text, so each batch starts with the previous one's carry;
