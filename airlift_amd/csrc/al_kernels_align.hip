@@ -996,14 +996,15 @@ k_regs_select(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__
 		bool pending = v;
 		while (__ballot(pending)) {
 			int pj = -1;                                                     // masking primary
-			if (pending) {
-				int n_cov = 0;
-				for (int j = 0; j < k; ++j) { const int sj = S.qs[j], ej = S.qe[j]; if (!(ej <= qs || sj >= qe)) ++n_cov; }
-				if (n_cov > 0) {
-					// uncov_len (hit.c:133-141): the part of [qs, qe) outside the union of the clipped overlapping intervals = outside the
-					// union of ALL primaries (the others do not reach into [qs, qe)): a bitmap of the query positions the primaries cover
-					int uncov = 0;
-					if (use_cov) {
+			if (pending && use_cov) {
+				// uncov_len (hit.c:133-141): the part of [qs, qe) outside the union of the clipped overlapping intervals = outside the union
+				// of ALL primaries (the others do not reach into [qs, qe)): a bitmap of the query positions the primaries cover, looked at
+				// once the first overlapping primary turns up
+				int uncov = -1;
+				for (int j = 0; j < k; ++j) {
+					const int sj = S.qs[j], ej = S.qe[j];
+					if (ej <= qs || sj >= qe) continue;
+					if (uncov < 0) {
 						int covered = 0;
 						for (int w = qs >> 5; w <= (qe - 1) >> 5; ++w) {
 							const int lo = qs > (w << 5) ? qs - (w << 5) : 0, hi = qe < ((w + 1) << 5) ? qe - (w << 5) : 32;
@@ -1011,7 +1012,16 @@ k_regs_select(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__
 							covered += __popc(s_cov[w] & m);
 						}
 						uncov = (qe - qs) - covered;
-					} else {
+					}
+					const int mn = ej - sj < qe - qs ? ej - sj : qe - qs, mx = ej - sj > qe - qs ? ej - sj : qe - qs;
+					const int ol = qs < sj ? (qe < sj ? 0 : qe < ej ? qe - sj : ej - sj) : (ej < qs ? 0 : ej < qe ? ej - qs : qe - qs);
+					if (__fsub_rn(al_fdiv((float)ol, (float)mn), al_fdiv((float)uncov, (float)mx)) > mask_level) { pj = j; break; }
+				}
+			} else if (pending) {
+				int n_cov = 0;
+				for (int j = 0; j < k; ++j) { const int sj = S.qs[j], ej = S.qe[j]; if (!(ej <= qs || sj >= qe)) ++n_cov; }
+				if (n_cov > 0) {
+					int uncov = 0;
 					int x = qs;
 					for (;;) {
 						int best = 0x7fffffff;
@@ -1022,7 +1032,6 @@ k_regs_select(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__
 						while (grew) { grew = false; for (int j = 0; j < k; ++j) { int sj = S.qs[j], ej = S.qe[j]; if (ej <= qs || sj >= qe) continue; if (sj < qs) sj = qs; if (ej > qe) ej = qe; if (sj <= x && ej > x) { x = ej; grew = true; } } }
 					}
 					if (qe > x) uncov += qe - x;
-					}
 					for (int j = 0; j < k; ++j) {
 						const int sj = S.qs[j], ej = S.qe[j];
 						if (ej <= qs || sj >= qe) continue;
@@ -2414,9 +2423,11 @@ int al_run_align_stage(al_ctx_t *c)
 		hipStream_t sd = c->side;
 		AL_HIP_CHECK(hipEventRecord(c->ev_fj[0], s)); AL_HIP_CHECK(hipStreamWaitEvent(sd, c->ev_fj[0], 0));
 #define LHV(RC, AC, RCL, ACL, LDS, ST) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_heavy<RC, AC, RCL, ACL>), dim3(heavy_n), dim3(64), LDS, ST, c->chained.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, (const uint32_t *)c->chain_idx2.p + heavy_from, (int)heavy_n, c->P, c->counters.p, regs_n0)
-		LHV(72, 1024, 48, 768, lds_s, sd); LHV(48, 768, 24, 512, lds_b, sd); LHV(200, 2048, 72, 1024, lds_l, sd);
+		for (int i = 0; i < 3; ++i) AL_HIP_CHECK(hipStreamWaitEvent(c->aux[i], c->ev_fj[0], 0));
+		LHV(72, 1024, 48, 768, lds_s, sd); LHV(48, 768, 24, 512, lds_b, c->aux[0]); LHV(200, 2048, 72, 1024, lds_l, c->aux[1]); LHV(12, 256, 0, 0, lds_a, c->aux[2]);
 		AL_HIP_CHECK(hipEventRecord(c->ev_fj[1], sd));
-		LHV(24, 512, 12, 256, lds_t, s); LHV(12, 256, 0, 0, lds_a, s);
+		for (int i = 0; i < 3; ++i) { AL_HIP_CHECK(hipEventRecord(c->ev_aux[i], c->aux[i])); AL_HIP_CHECK(hipStreamWaitEvent(s, c->ev_aux[i], 0)); }
+		LHV(24, 512, 12, 256, lds_t, s);
 #undef LHV
 		AL_HIP_CHECK(hipStreamWaitEvent(s, c->ev_fj[1], 0));
 	}

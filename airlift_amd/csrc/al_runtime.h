@@ -62,6 +62,8 @@ struct al_ctx_s {
 	int n_threads = 1;                    // host worker threads for packing (al_ctx_set_threads)
 	hipStream_t stream = nullptr, side = nullptr;   // side: exact (serial) handling of the few fragments with equal-x anchors, next to the main pipeline
 	hipEvent_t ev_fj[2] = {};             // fork / join of the side stream inside a stage (chain_post classes, DP job classes)
+	hipStream_t aux[3] = {};              // more streams for stages made of independent latency-bound launches over disjoint fragments (heap merge classes, k_regs_heavy tiles)
+	hipEvent_t ev_aux[3] = {};            // ... their join events
 	hipEvent_t ev_side[4] = {};           // [0],[1]: start / end of the side stream's work in the first pass, [2],[3]: in the re-chain pass
 	float ms_side = 0;
 	AlDevIndex di;

@@ -192,6 +192,7 @@ extern "C" al_ctx_t *al_ctx_init(const al_idx_t *mi, const al_mapopt_t *opt, int
 	for (int i = 0; i <= ST_N; ++i) if (hipEventCreate(&c->ev[i]) != hipSuccess) { delete c; return nullptr; }
 	if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&c->ev_side[0]) != hipSuccess || hipEventCreate(&c->ev_side[1]) != hipSuccess || hipEventCreate(&c->ev_side[2]) != hipSuccess || hipEventCreate(&c->ev_side[3]) != hipSuccess ||
 	    hipEventCreateWithFlags(&c->ev_fj[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_fj[1], hipEventDisableTiming) != hipSuccess) { delete c; return nullptr; }
+	for (int i = 0; i < 3; ++i) if (hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_aux[i], hipEventDisableTiming) != hipSuccess) { delete c; return nullptr; }
 	if (al_upload_index(mi, device, &c->di) != 0) { delete c; return nullptr; }
 	AlParams &P = c->P;
 	P.k = mi->k; P.w = mi->w; P.seed = opt->seed; P.bw = opt->bw; P.max_gap = opt->max_gap; P.max_gap_ref = opt->max_gap_ref; P.max_frag_len = opt->max_frag_len;
@@ -209,6 +210,7 @@ static void ctx_release_buffers(al_ctx_t *c)
 {   // every grow-only batch buffer (the index stays); each is re-ensured before its next use
 	al_align_state_free(c);
 	if (c->side) (void)hipStreamSynchronize(c->side);
+	for (int i = 0; i < 3; ++i) if (c->aux[i]) (void)hipStreamSynchronize(c->aux[i]);
 	if (c->stream) (void)hipStreamSynchronize(c->stream);
 	c->rd_seq.release(); c->rd_len.release(); c->frag_first.release(); c->frag_hash.release(); c->mini_cnt.release(); c->frag_nm.release(); c->frag_na.release();
 	c->frag_nu.release(); c->rechain_list.release(); c->rechain_sorted.release(); c->tmp_u32.release(); c->rd_off.release(); c->mini_off.release(); c->a_off.release(); c->u.release();
@@ -227,6 +229,7 @@ extern "C" void al_ctx_destroy(al_ctx_t *c)
 	for (int i = 0; i < 4; ++i) if (c->ev_side[i]) (void)hipEventDestroy(c->ev_side[i]);
 	for (int i = 0; i < 2; ++i) if (c->ev_fj[i]) (void)hipEventDestroy(c->ev_fj[i]);
 	if (c->side) (void)hipStreamDestroy(c->side);
+	for (int i = 0; i < 3; ++i) { if (c->aux[i]) (void)hipStreamDestroy(c->aux[i]); if (c->ev_aux[i]) (void)hipEventDestroy(c->ev_aux[i]); }
 	if (c->stream) (void)hipStreamDestroy(c->stream);
 	delete c;
 }
@@ -590,13 +593,17 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 		uint32_t *const n_heap_d = c->heap_cnt.p + (first ? 0 : 1);
 		AL_HIP_CHECK(hipMemsetAsync(n_heap_d, 0, 4, c->side));
 		hipLaunchKernelGGL(k_collect_flagged_blk, dim3((nl + 255) / 256), dim3(256), 0, c->side, order, nl, (const uint32_t *)c->tie_list.p, c->tie_frags.p, n_heap_d);
-#define LHEAP(H, LN, LO) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_anchor_heap<H, LN>), dim3((nl + LN - 1) / LN), dim3(64), 0, c->side, c->di.pos, c->frag_first.p, c->rd_len.p, c->mini_off.p, c->match.p, c->frag_nm.p, c->frag_na.p, \
+		// the four merge kernels take disjoint fragments and each waits for its slowest one: side by side, on a stream each
+		AL_HIP_CHECK(hipEventRecord(c->ev_fj[0], c->side));
+		for (int i = 0; i < 3; ++i) AL_HIP_CHECK(hipStreamWaitEvent(c->aux[i], c->ev_fj[0], 0));
+#define LHEAP(H, LN, LO, ST) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_anchor_heap<H, LN>), dim3((nl + LN - 1) / LN), dim3(64), 0, ST, c->di.pos, c->frag_first.p, c->rd_len.p, c->mini_off.p, c->match.p, c->frag_nm.p, c->frag_na.p, \
 		                                  c->a_off.p, c->anchors.p, c->heap_ws.p, c->tie_list.p, (const uint32_t *)c->tie_frags.p, nl, LO, c->counters.p, c->mi->k, (const uint32_t *)n_heap_d, wave_na_min)
 		static const uint32_t wave_na_min = getenv("AL_TEST_HEAP_WAVE") ? (uint32_t)atoi(getenv("AL_TEST_HEAP_WAVE")) : 16384u;   // (tests lower it so that small fragments take the wavefront form)
 		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_anchor_heap_wave<128, 32>), dim3(std::min(nl, 2048)), dim3(64), 0, c->side, c->di.pos, c->frag_first.p, c->rd_len.p, c->mini_off.p, c->match.p, c->frag_nm.p, c->frag_na.p,
 		                   c->a_off.p, c->anchors.p, (const uint32_t *)c->tie_list.p, (const uint32_t *)c->tie_frags.p, (const uint32_t *)n_heap_d, wave_na_min, c->counters.p, c->mi->k);
-		LHEAP(48, 64, -1); LHEAP(96, 32, 48); LHEAP(0, 64, 96);
+		LHEAP(48, 64, -1, c->aux[0]); LHEAP(96, 32, 48, c->aux[1]); LHEAP(0, 64, 96, c->aux[2]);
 #undef LHEAP
+		for (int i = 0; i < 3; ++i) { AL_HIP_CHECK(hipEventRecord(c->ev_aux[i], c->aux[i])); AL_HIP_CHECK(hipStreamWaitEvent(c->side, c->ev_aux[i], 0)); }
 		AL_HIP_CHECK(hipEventRecord(evs[1], c->side));
 		if (ev(ST_ANCHOR_HEAP)) return -1;
 	}
