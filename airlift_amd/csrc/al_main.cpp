@@ -120,6 +120,10 @@ int main(int argc, char **argv)
 		else if (!strcmp(a, "--device") && i + 1 < argc) device = atoi(argv[++i]);
 		else if (!strcmp(a, "--rank") && i + 1 < argc) rank = atoi(argv[++i]);             // one process per GPU: --rank r --world R -o OUT (al_map_file_frag_ranked)
 		else if (!strcmp(a, "--world") && i + 1 < argc) world = atoi(argv[++i]);
+		else if (!strcmp(a, "--ranked")) {                                                 // ... with rank and world from the launcher's environment (torchrun: RANK, WORLD_SIZE; the GPU is LOCAL_RANK)
+			if (!getenv("RANK") || !getenv("WORLD_SIZE")) { fprintf(stderr, "[ERROR] --ranked needs RANK and WORLD_SIZE in the environment\n"); return 1; }
+			rank = atoi(getenv("RANK")); world = atoi(getenv("WORLD_SIZE"));
+		}
 		else if (!strcmp(a, "--rendezvous") && i + 1 < argc) rendezvous = argv[++i];
 		else if (!strcmp(a, "--devices") && i + 1 < argc) {   // "0-7", "0,1,2", "0,0" (two lanes on one GPU): reads of every mini-batch sharded over the lanes
 			const char *p = argv[++i];

@@ -142,6 +142,19 @@ def test_one_process_per_gpu_mode_on_one_gpu(golden_unpacked, tmp_path, world):
     assert b"bytes at offset" in outs[1][1]
 
 
+def test_ranked_mode_takes_rank_and_world_from_the_launcher(golden_unpacked, tmp_path):
+    """--ranked: RANK / WORLD_SIZE as torchrun exports them (the default rendezvous directory is the output file's)."""
+    d, m, exp, rg = _golden(golden_unpacked, "g2_250pe")
+    out = tmp_path / "merged.sam"
+    ps = [subprocess.Popen([CLI, "-ax", "sr", "-t", "4", "--device", "0", "--ranked", "-o", str(out)] + rg + [m["ref"]] + m["reads"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           env=dict(os.environ, AL_RUN_ID="env2", AL_RANK_TIMEOUT="120", RANK=str(r), WORLD_SIZE="2", LOCAL_RANK="0")) for r in range(2)]
+    outs = [p.communicate(timeout=300) for p in ps]
+    assert all(p.returncode == 0 for p in ps), b"\n".join(o[1][-800:] for o in outs).decode()
+    assert out.read_bytes() == exp
+    r = subprocess.run([CLI, "-ax", "sr", "--ranked", "-o", str(out), m["ref"]] + m["reads"], cwd=d, capture_output=True, env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE")})
+    assert r.returncode == 1 and b"--ranked needs RANK and WORLD_SIZE" in r.stderr
+
+
 def test_a_missing_rank_makes_the_others_fail(golden_unpacked, tmp_path):
     """Rank 1 of 2 never starts: rank 0 gives up at the first exchange after AL_RANK_TIMEOUT seconds, with a message and status 1."""
     d, m, exp, rg = _golden(golden_unpacked, "g1_mt150pe")

@@ -8,7 +8,7 @@ OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export AL_REF_CACHE=/tmp/alcache
 cd /tmp && export TMPDIR=/tmp
-ARGS="--no-cpu-baseline --steps 3 --warmup 1 $*"
+ARGS="--no-cpu-baseline --f2f-pairs 0 --steps 3 --warmup 1 $*"
 rocprofv3 --kernel-trace --stats -d $OUT/trace --output-format csv -- python3 $REPO/bench.py $ARGS > $OUT/bench_trace.json 2> $OUT/trace.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch --output-format csv -- python3 $REPO/bench.py $ARGS > $OUT/bench_fetch.json 2> $OUT/fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write --output-format csv -- python3 $REPO/bench.py $ARGS > $OUT/bench_write.json 2> $OUT/write.err
