@@ -72,31 +72,35 @@ extern "C" int64_t al_extract_reads(const char *bam_fn, const char *bed_fn, int 
 	if (!in.open(bam_fn)) { fprintf(stderr, "ERROR: failed to open file '%s'\n", bam_fn); return -1; }
 	char magic[4]; int32_t l_text, n_ref;
 	if (!in.read(magic, 4) || memcmp(magic, "BAM\1", 4) != 0 || !in.read(&l_text, 4)) { fprintf(stderr, "ERROR: '%s' is not a BAM file\n", bam_fn); return -2; }
+	// every length field of the file is checked before it sizes anything: a truncated or corrupt BAM is error -2, not a crash
+	if (l_text < 0) return -2;
 	{ std::vector<char> t((size_t)l_text); if (l_text && !in.read(t.data(), t.size())) return -2; }
-	if (!in.read(&n_ref, 4)) return -2;
+	if (!in.read(&n_ref, 4) || n_ref < 0 || n_ref > (1 << 24)) return -2;
 	std::vector<const ChromIdx *> ref_idx((size_t)n_ref, nullptr); std::vector<std::string> ref_name((size_t)n_ref);
 	for (int i = 0; i < n_ref; ++i) {
-		int32_t l; if (!in.read(&l, 4)) return -2;
+		int32_t l; if (!in.read(&l, 4) || l < 1 || l > (1 << 20)) return -2;       // l_name counts the terminating NUL
 		std::vector<char> nm((size_t)l); int32_t len;
-		if (!in.read(nm.data(), nm.size()) || !in.read(&len, 4)) return -2;
+		if (!in.read(nm.data(), nm.size()) || !in.read(&len, 4) || nm[(size_t)l - 1] != 0) return -2;
 		ref_name[i] = nm.data();
 		auto it = idx.find(ref_name[i]); if (it != idx.end()) ref_idx[i] = &it->second;
 	}
 	struct Row { uint32_t bed; uint64_t ord; std::string text; };
 	std::unordered_map<std::string, Row> rows;          // name (with suffix) -> first row in (BED line, BAM) order
 	const std::string rs = std::to_string(read_size) + "M";
-	std::vector<unsigned char> rec; uint64_t ord = 0;
+	std::vector<unsigned char> rec; std::vector<uint32_t> cg; uint64_t ord = 0;
 	for (;;) {
 		int32_t bs;
 		if (!in.read(&bs, 4)) break;
-		if (bs < 32) return -2;
+		if (bs < 32 || bs > (1 << 28)) return -2;
 		rec.resize((size_t)bs);
 		if (!in.read(rec.data(), rec.size())) return -2;
 		++ord;
 		int32_t rid, pos; memcpy(&rid, rec.data(), 4); memcpy(&pos, rec.data() + 4, 4);
 		const uint32_t l_rn = rec[8], mapq = rec[9]; uint16_t n_cig, flag; memcpy(&n_cig, rec.data() + 12, 2); memcpy(&flag, rec.data() + 14, 2);
+		if (l_rn < 1 || (size_t)32 + l_rn + 4 * (size_t)n_cig > (size_t)bs || rec[32 + l_rn - 1] != 0) return -2;   // name (NUL-terminated) and CIGAR inside the record
 		if (rid < 0 || rid >= n_ref || !ref_idx[rid] || (flag & 4)) continue;          // convert2bed drops unmapped records
-		const uint32_t *cg = (const uint32_t *)(rec.data() + 32 + l_rn);
+		cg.resize(n_cig); if (n_cig) memcpy(cg.data(), rec.data() + 32 + l_rn, 4 * (size_t)n_cig);   // (the words are not aligned in the record)
+		if (n_cig == 2 && (cg[0] & 15) == 4 && (cg[1] & 15) == 3) { fprintf(stderr, "ERROR: '%s' holds a CIGAR of more than 65535 operations (CG tag): not supported\n", bam_fn); return -2; }
 		int64_t rl = 0; for (int i = 0; i < n_cig; ++i) { const uint32_t op = cg[i] & 15; if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rl += cg[i] >> 4; }
 		const int64_t s = pos, e = pos + rl;
 		// smallest BED line number with B-1 <= s and e <= E-1

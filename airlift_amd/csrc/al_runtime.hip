@@ -901,7 +901,7 @@ int al_sort_keys(al_ctx_t *c, const uint64_t *keys, uint32_t *perm, size_t n)
 		    hipMemcpyAsync(perm, d_v2, n * 4, hipMemcpyDeviceToHost, c->stream) == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess) rc = 0;
 	}
 	(void)hipFree(d_k); (void)hipFree(d_k2); (void)hipFree(d_v); (void)hipFree(d_v2); (void)hipFree(tmp);
-	if (rc) fprintf(stderr, "[airlift] al_sort_keys: device sort failed\n");
+	if (rc) { (void)hipGetLastError(); fprintf(stderr, "[airlift] al_sort_keys: device sort failed\n"); }      // (not sticky: the caller falls back to a host sort)
 	return rc;
 }
 

@@ -278,26 +278,34 @@ def main():
     t_reads = time.time() - t0
     ctx = A.Context(idx, device=local if world > 1 else 0)
     L.al_ctx_set_threads(ctx.h, min(32, os.cpu_count() or 1))       # host packing threads (outside the timed region)
+    state = {"f_lo": f_lo, "arr": arr}
+
     def upload(nf):
         n_segs = (C.c_int * nf)(*([2] * nf)); qlens = (C.c_int * (2 * nf))(*([a.read_len] * (2 * nf)))
-        if L.al_batch_upload_flat(ctx.h, nf, n_segs, qlens, arr.ctypes.data_as(C.c_char_p), b"realigned_", f_lo) != 0:
-            raise SystemExit("upload failed")
-        ctx.n_frag, ctx.n_reads = nf, 2 * nf
+        return L.al_batch_upload_flat(ctx.h, nf, n_segs, qlens, state["arr"].ctypes.data_as(C.c_char_p), b"realigned_", state["f_lo"]) == 0
 
-    # a batch whose seed hits do not fit the device workspaces (al_batch_run -> AL_ERR_NOMEM) is halved, as the file drivers do
+    def all_ok(ok):   # a failure on one rank is every rank's failure: nobody is left waiting in a collective
+        if world > 1:
+            t = torch.tensor([1 if ok else 0], dtype=torch.int64, device=cdev); dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return int(t.item()) == 1
+        return ok
+
+    # A batch whose seed hits do not fit the device workspaces (al_batch_run -> AL_ERR_NOMEM) is halved, as the file drivers do --
+    # on every rank at once, and the input stays ONE input of pairs * world fragments split contiguously: the ranks' ranges are cut again.
     pairs_asked = a.pairs
     while True:
-        t0 = time.time(); upload(a.pairs); t_upload = time.time() - t0
-        if L.al_batch_run(ctx.h) == 0:
+        t0 = time.time(); ok = upload(a.pairs); t_upload = time.time() - t0
+        if not all_ok(ok):
+            raise SystemExit("upload failed")
+        if all_ok(L.al_batch_run(ctx.h) == 0):
             break
         if a.pairs <= 125_000:
             raise SystemExit("al_batch_run failed")
         a.pairs //= 2
         sys.stderr.write("[bench] batch did not fit / failed: retrying with %d pairs per step\n" % a.pairs)
-    if world > 1:   # every rank steps the same batch size
-        t = torch.tensor([a.pairs], dtype=torch.int64, device=cdev); dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        if int(t.item()) != a.pairs:
-            a.pairs = int(t.item()); upload(a.pairs)
+        f_lo, f_hi = frag_range(a.pairs * world, rank, world)
+        state["f_lo"] = f_lo; state["arr"] = arr = make_workload(a.config, f_lo, f_hi, a.read_len, 20261002, ref, a.ins_mean)
+    ctx.n_frag, ctx.n_reads = a.pairs, 2 * a.pairs
 
     merged = {}
 
@@ -348,8 +356,8 @@ def main():
         per = {names[i]: float(stage_ms[i] / a.steps) for i in range(st.n_stage)}
         kern = {names[i]: L.al_stage_kernel(i).decode() for i in range(st.n_stage)}
         # ---- roofline: every stage against ITS OWN algorithmic bytes; the headline fraction is the pipeline's ----
-        M, A, Wb = float(st.n_mini), float(st.n_anchor), float(st.n_refbases)
-        A1 = float(na_p1.sum()) if na_p1 is not None else A                   # anchors of the first pass (the re-chain pass makes the rest)
+        M, An, Wb = float(st.n_mini), float(st.n_anchor), float(st.n_refbases)
+        A1 = float(na_p1.sum()) if na_p1 is not None else An                  # anchors of the first pass (the re-chain pass makes the rest)
         a1 = na_p1 if na_p1 is not None else na
         cls = lambda lo_, hi_: float(a1[(a1 >= lo_) & (a1 <= hi_)].sum())
         groups = [   # (name, intervals, algorithmic bytes)
@@ -357,7 +365,7 @@ def main():
             ("seed_lookup", ["seed_lookup", "scan", "size_order"], 16.0 * M),
             ("anchor_sort", ["anchor_sort_small", "anchor_sort", "anchor_sort_blk", "anchor_sort_big", "anchor_heap"], 24.0 * A1),
             ("chain", ["chain_lds32", "chain_lds48", "chain_lds64", "chain_lds128", "seg_find", "seg_chain_lds", "seg_chain_wave", "seg_merge"], 16.0 * A1),
-            ("rechain (max_occ pass: seed + sort + chain)", ["rechain"], 56.0 * (A - A1)),
+            ("rechain (max_occ pass: seed + sort + chain)", ["rechain"], 56.0 * (An - A1)),
             ("regs (chain_post / seg_gen: no bytes in the contract)", ["regs"], 0.0),
             ("extension", ["ext_prep", "ext_sort", "ext_dp_lane", "ext_dp_g4", "ext_dp_g8", "ext_dp_g22", "ext_finish", "compact"], 0.5 * Wb + float(st.bytes_out)),
         ]
@@ -393,7 +401,7 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8/int32 (int8 SW lanes, u64 hashes)", "data": "synthetic",
             "config": {"workload": "%s, %d x 2 x %d bp PE reads per GPU per step, preset sr" % (WORKLOADS.get(a.config, a.config), a.pairs, a.read_len), "key": a.config,
-                       "reads_per_step_per_gpu": 2 * a.pairs, "read_len": a.read_len, "sharding": "one input of %d fragments, rank r maps the contiguous range [r N / R, (r + 1) N / R); index replicated" % (a.pairs * world)},
+                       "reads_per_step_per_gpu": 2 * a.pairs, "pairs_asked_per_gpu": pairs_asked, "read_len": a.read_len, "sharding": "one input of %d fragments, rank r maps the contiguous range [r N / R, (r + 1) N / R); index replicated" % (a.pairs * world)},
             "value_incl_pcie": 2.0 * a.pairs / dt_io, "incl_pcie_note": "this rank: 4-bit packing on %d host threads + H2D, one step, D2H of %d records (%.1f MB); serial, no overlap between batches" % (min(32, os.cpu_count() or 1), int(nrec.value), nby.value / 1e6),
             "roofline": roof,
             "stages_ms": per,
