@@ -322,7 +322,7 @@ int al_stream_map_files(const al_idx_t *mi, int n_fn, const char **fn, const al_
 	// a regular output file is written by a few threads at once (pwrite of the parts of a piece: one thread copies ~3 GB/s into the page cache)
 	long long woff = -1; int n_wr = 1;
 	{ struct stat sb; const int fl = fcntl(ofd, F_GETFL); const off_t at = lseek(ofd, 0, SEEK_CUR);
-	  if (fstat(ofd, &sb) == 0 && S_ISREG(sb.st_mode) && at >= 0 && fl >= 0 && !(fl & O_APPEND) && !getenv("AL_NO_PWRITE")) { woff = (long long)at; n_wr = std::max(1, std::min(8, n_threads / 4)); } }
+	  if (fstat(ofd, &sb) == 0 && S_ISREG(sb.st_mode) && at >= 0 && fl >= 0 && !(fl & O_APPEND) && !getenv("AL_NO_PWRITE")) { woff = (long long)at; n_wr = std::max(1, std::min(16, n_threads / 2)); } }
 	std::thread writer([&]() {
 		for (uint64_t k = 0;; ++k) {
 			Slot *sl = slot_of(k);
