@@ -14,6 +14,8 @@
 #include <string.h>
 #include <stdint.h>
 #include <zlib.h>
+#include <unistd.h>
+#include <sys/mman.h>
 #include <algorithm>
 #include <string>
 #include <unordered_map>
@@ -148,10 +150,8 @@ int subseq(const char *fn, const std::unordered_set<std::string> &want, std::vec
 	return 0;
 }
 std::string pair_key(const std::string &n) { const size_t l = n.size(); return l > 2 && n[l - 2] == '/' && (n[l - 1] == '1' || n[l - 1] == '2') ? n.substr(0, l - 2) : n; }
-int write_fq(const std::string &path, const std::vector<const FqRec *> &v, const char *prefix)
+int write_fq_to(FILE *f, const std::vector<const FqRec *> &v, const char *prefix)
 {
-	FILE *f = fopen(path.c_str(), "wb");
-	if (!f) { fprintf(stderr, "ERROR: failed to write '%s'\n", path.c_str()); return -1; }
 	size_t i = 0;
 	for (const FqRec *r : v) {
 		fprintf(f, "@%s_%zu\n", prefix, i++);
@@ -159,31 +159,32 @@ int write_fq(const std::string &path, const std::vector<const FqRec *> &v, const
 		if (!r->qual.empty()) { fputs("\n+\n", f); fwrite(r->qual.data(), 1, r->qual.size(), f); fputc('\n', f); }
 		else { fputs("\n+\n", f); for (size_t j = 0; j < r->seq.size(); ++j) fputc('I', f); fputc('\n', f); }
 	}
-	return fclose(f) == 0 ? 0 : -1;
+	return ferror(f) ? -1 : 0;
 }
-} // namespace
-
-// extract_sequence.sh:17-19: rows_fn = the concatenated rows of al_extract_reads (only column 4 is used); writes
-// out_dir/reads_1.fastq, reads_2.fastq (pairs, renamed realigned_<n>) and singletons.fastq (realigned_singleton_<n>).
-// n_pairs / n_single receive the counts.  Returns 0, negative on error.
-extern "C" int al_extract_sequence(const char *fq1, const char *fq2, const char *rows_fn, const char *out_dir, int64_t *n_pairs, int64_t *n_single)
+int write_fq(const std::string &path, const std::vector<const FqRec *> &v, const char *prefix)
 {
-	std::unordered_set<std::string> l1, l2;
-	{
-		FILE *f = strcmp(rows_fn, "-") == 0 ? stdin : fopen(rows_fn, "r");
-		if (!f) { fprintf(stderr, "ERROR: failed to open file '%s'\n", rows_fn); return -1; }
-		char line[1 << 16];
-		while (fgets(line, sizeof(line), f)) {
-			// awk '{if(substr($4, length($4), 1) == 1) print substr($4, 1, length($4)-2);}' : fields split on blanks
-			char *save = nullptr, *tok = strtok_r(line, " \t\n", &save); int k = 1;
-			while (tok && k < 4) { tok = strtok_r(nullptr, " \t\n", &save); ++k; }
-			if (!tok) continue;
-			const size_t l = strlen(tok);
-			if (l < 2) continue;
-			if (tok[l - 1] == '1') l1.insert(std::string(tok, l - 2)); else if (tok[l - 1] == '2') l2.insert(std::string(tok, l - 2));
-		}
-		if (f != stdin) fclose(f);
+	FILE *f = fopen(path.c_str(), "wb");
+	if (!f) { fprintf(stderr, "ERROR: failed to write '%s'\n", path.c_str()); return -1; }
+	const int w = write_fq_to(f, v, prefix);
+	return fclose(f) == 0 && w == 0 ? 0 : -1;
+}
+// the names extract_sequence.sh's two awk lines pick from the rows (column 4 ending in 1 / 2, suffix dropped)
+void names_of_rows(FILE *f, std::unordered_set<std::string> &l1, std::unordered_set<std::string> &l2)
+{
+	char line[1 << 16];
+	while (fgets(line, sizeof(line), f)) {
+		// awk '{if(substr($4, length($4), 1) == 1) print substr($4, 1, length($4)-2);}' : fields split on blanks
+		char *save = nullptr, *tok = strtok_r(line, " \t\n", &save); int k = 1;
+		while (tok && k < 4) { tok = strtok_r(nullptr, " \t\n", &save); ++k; }
+		if (!tok) continue;
+		const size_t l = strlen(tok);
+		if (l < 2) continue;
+		if (tok[l - 1] == '1') l1.insert(std::string(tok, l - 2)); else if (tok[l - 1] == '2') l2.insert(std::string(tok, l - 2));
 	}
+}
+// seqtk subseq of both files, repair.sh pairing, rename.sh names: sink(which, records, prefix) with which = 0 reads_1, 1 reads_2, 2 singletons
+template <class Sink> int subset_pair_rename(const char *fq1, const char *fq2, const std::unordered_set<std::string> &l1, const std::unordered_set<std::string> &l2, Sink sink, int64_t *n_pairs, int64_t *n_single)
+{
 	std::vector<FqRec> s1, s2;
 	if (subseq(fq1, l1, s1) || subseq(fq2, l2, s2)) return -1;
 	// repair.sh: pair by name (a trailing /1 or /2 is not part of it); the rest are singletons
@@ -197,9 +198,59 @@ extern "C" int al_extract_sequence(const char *fq1, const char *fq2, const char 
 		if (j == SIZE_MAX) sg.push_back(&r); else { used2[j] = 1; p1.push_back(&r); p2.push_back(&s2[j]); }
 	}
 	for (size_t i = 0; i < s2.size(); ++i) if (!used2[i]) sg.push_back(&s2[i]);
-	const std::string d = out_dir;
-	if (write_fq(d + "/reads_1.fastq", p1, "realigned") || write_fq(d + "/reads_2.fastq", p2, "realigned") || write_fq(d + "/singletons.fastq", sg, "realigned_singleton")) return -3;
+	if (sink(0, p1, "realigned") || sink(1, p2, "realigned") || sink(2, sg, "realigned_singleton")) return -3;
 	if (n_pairs) *n_pairs = (int64_t)p1.size();
 	if (n_single) *n_single = (int64_t)sg.size();
 	return 0;
+}
+} // namespace
+
+// extract_sequence.sh:17-19: rows_fn = the concatenated rows of al_extract_reads (only column 4 is used); writes
+// out_dir/reads_1.fastq, reads_2.fastq (pairs, renamed realigned_<n>) and singletons.fastq (realigned_singleton_<n>).
+// n_pairs / n_single receive the counts.  Returns 0, negative on error.
+extern "C" int al_extract_sequence(const char *fq1, const char *fq2, const char *rows_fn, const char *out_dir, int64_t *n_pairs, int64_t *n_single)
+{
+	std::unordered_set<std::string> l1, l2;
+	{
+		FILE *f = strcmp(rows_fn, "-") == 0 ? stdin : fopen(rows_fn, "r");
+		if (!f) { fprintf(stderr, "ERROR: failed to open file '%s'\n", rows_fn); return -1; }
+		names_of_rows(f, l1, l2);
+		if (f != stdin) fclose(f);
+	}
+	const std::string d = out_dir;
+	static const char *const fn[3] = {"/reads_1.fastq", "/reads_2.fastq", "/singletons.fastq"};
+	return subset_pair_rename(fq1, fq2, l1, l2, [&](int which, const std::vector<const FqRec *> &v, const char *prefix) { return write_fq(d + fn[which], v, prefix); }, n_pairs, n_single);
+}
+
+// N1 fused: extract_reads.sh + extract_sequence.sh in one call, nothing written to disk -- one pass over the BAM, the
+// selected names, one scan of each FASTQ file, pairing and renaming; the three FASTQ texts (reads_1, reads_2, singletons) are left in
+// anonymous memory files (memfd_create) whose descriptors go to fds[0..2].  A caller maps them by path (/proc/self/fd/<n>): for the
+// stream driver that is file bytes in RAM, which it hands to the GPU as they are -- the device finds the records and packs the bases.
+// The caller closes the descriptors.  Returns 0, negative on error.
+extern "C" int al_extract_to_memory(const char *bam_fn, const char *bed_fn, int read_size, int prune, const char *fq1, const char *fq2, int fds[3], int64_t *n_pairs, int64_t *n_single)
+{
+	fds[0] = fds[1] = fds[2] = -1;
+	char *rows = nullptr; size_t rows_len = 0;
+	FILE *rf = open_memstream(&rows, &rows_len);
+	if (!rf) return -1;
+	const int64_t n = al_extract_reads(bam_fn, bed_fn, read_size, prune, rf);
+	if (fflush(rf) == EOF || n < 0) { fclose(rf); free(rows); return n < 0 ? (int)n : -3; }
+	fclose(rf);
+	std::unordered_set<std::string> l1, l2;
+	{ FILE *f = fmemopen(rows, rows_len ? rows_len : 1, "r"); if (!f) { free(rows); return -1; } if (rows_len) names_of_rows(f, l1, l2); fclose(f); }
+	free(rows);
+	static const char *const nm[3] = {"airlift_reads_1", "airlift_reads_2", "airlift_singletons"};
+	const int rc = subset_pair_rename(fq1, fq2, l1, l2, [&](int which, const std::vector<const FqRec *> &v, const char *prefix) -> int {
+		const int fd = memfd_create(nm[which], 0);
+		if (fd < 0) { perror("[airlift] memfd_create"); return -1; }
+		FILE *f = fdopen(dup(fd), "wb");
+		if (!f) { close(fd); return -1; }
+		setvbuf(f, nullptr, _IOFBF, 8 << 20);
+		const int w = write_fq_to(f, v, prefix);
+		if (fclose(f) == EOF || w) { close(fd); return -1; }
+		fds[which] = fd;
+		return 0;
+	}, n_pairs, n_single);
+	if (rc) for (int i = 0; i < 3; ++i) if (fds[i] >= 0) { close(fds[i]); fds[i] = -1; }
+	return rc;
 }

@@ -67,6 +67,40 @@ int main(int argc, char **argv)
 		if (rc == 0) fprintf(stderr, "[airlift] extract-sequence: %lld pairs, %lld singletons\n", (long long)np, (long long)ns);
 		return rc == 0 ? 0 : 1;
 	}
+	if (!strcmp(argv[1], "remap")) {
+		// N1 fused with the re-alignment: airlift-align remap [-t N] [-R RG] [--noprune] [--readsize R] -o PAIRS.sam [--singletons SINGLE.sam] REF.fa READS.bam REGIONS.bed FQ1 FQ2
+		// = extract_reads.sh + extract_sequence.sh + 0-align_reads.sh + 0-align_singletons.sh (run_pipeline.sh:58,103-113) without the rows file, the
+		// three FASTQ files and the tool processes in between: the selected reads stay in memory files that the stream driver hands to the GPU.
+		int prune = 1, read_size = 0, n_threads = 3; const char *rg = nullptr, *out_p = nullptr, *out_s = nullptr; std::vector<const char *> p;
+		for (int j = 2; j < argc; ++j) {
+			if (!strcmp(argv[j], "--noprune")) prune = 0;
+			else if (!strcmp(argv[j], "--readsize") && j + 1 < argc) read_size = atoi(argv[++j]);
+			else if (!strcmp(argv[j], "-t") && j + 1 < argc) n_threads = atoi(argv[++j]);
+			else if (!strcmp(argv[j], "-R") && j + 1 < argc) rg = argv[++j];
+			else if (!strcmp(argv[j], "-o") && j + 1 < argc) out_p = argv[++j];
+			else if (!strcmp(argv[j], "--singletons") && j + 1 < argc) out_s = argv[++j];
+			else p.push_back(argv[j]);
+		}
+		if (p.size() != 5 || !out_p || (prune && read_size <= 0)) { fprintf(stderr, "Usage: airlift-align remap [-t N] [-R RG] [--noprune | --readsize R] -o pairs.sam [--singletons single.sam] ref.fa reads.bam regions.bed reads_1.fq reads_2.fq\n"); return 1; }
+		if (!getenv("AL_PG_PLAIN")) al_set_program_line(AL_MM_VERSION, argc, argv);
+		if (!k_given) setenv("AL_AUTO_BATCH", "1", 0);
+		setenv("GPU_MAX_HW_QUEUES", "8", 0);
+		int fds[3]; int64_t np = 0, ns = 0;
+		if (al_extract_to_memory(p[1], p[2], read_size, prune, p[3], p[4], fds, &np, &ns) != 0) return 1;
+		fprintf(stderr, "[airlift] remap: %lld pairs, %lld singletons selected\n", (long long)np, (long long)ns);
+		if (al_check_opt(&io, &mo) < 0) return 1;
+		al_idx_t *mi = al_idx_build_device(p[0], &io, -1);
+		if (!mi) return 1;
+		int rc = 0;
+		const std::string f1 = "/proc/self/fd/" + std::to_string(fds[0]), f2 = "/proc/self/fd/" + std::to_string(fds[1]), f3 = "/proc/self/fd/" + std::to_string(fds[2]);
+		{ FILE *o = fopen(out_p, "wb"); const char *fn[2] = {f1.c_str(), f2.c_str()};
+		  if (!o) { perror(out_p); rc = 1; } else { if (al_map_file_frag(mi, 2, fn, &mo, n_threads, o, rg, -1) != 0) rc = 1; if (fclose(o) == EOF) rc = 1; } }
+		if (out_s && rc == 0) { FILE *o = fopen(out_s, "wb"); const char *fn[1] = {f3.c_str()};
+		  if (!o) { perror(out_s); rc = 1; } else { if (al_map_file_frag(mi, 1, fn, &mo, n_threads, o, rg, -1) != 0) rc = 1; if (fclose(o) == EOF) rc = 1; } }
+		for (int j = 0; j < 3; ++j) if (fds[j] >= 0) close(fds[j]);
+		al_idx_destroy(mi);
+		return rc;
+	}
 	// @PG as main.c:369 writes it (VN = the fork's MM_VERSION, main.c:16: the version whose records this path reproduces;
 	// CL = this process's argv).  AL_PG_PLAIN=1 leaves the bare line (the tests' goldens come from a driver without argv).
 	if (!getenv("AL_PG_PLAIN")) al_set_program_line(AL_MM_VERSION, argc, argv);

@@ -182,6 +182,10 @@ int64_t al_extract_reads(const char *bam_fn, const char *bed_fn, int read_size, 
  * (BBMap repair.sh) and renaming (rename.sh: realigned_<n>, realigned_singleton_<n>) into out_dir/reads_1.fastq,
  * reads_2.fastq, singletons.fastq.  Returns 0, negative on error. */
 int  al_extract_sequence(const char *fq1, const char *fq2, const char *rows_fn, const char *out_dir, int64_t *n_pairs, int64_t *n_single);
+/* N1 fused: extract_reads.sh:8 + extract_sequence.sh:17-19 in one call, nothing written to disk.  The three FASTQ texts
+ * (pairs file 1, pairs file 2, singletons) are left in anonymous memory files whose descriptors go to fds[0..2]; map them by path
+ * ("/proc/self/fd/<n>") with al_map_file_frag -- `airlift-align remap` does exactly that -- and close() them.  0, negative on error. */
+int  al_extract_to_memory(const char *bam_fn, const char *bed_fn, int read_size, int prune, const char *fq1, const char *fq2, int fds[3], int64_t *n_pairs, int64_t *n_single);
 
 /* Tap (parity tests): the extension DP alone -- ksw_extd2_sse's result for n caller-supplied pairs, as the reference's --print-aln-seq
  * shows them (align.c:313-339).  seqs: nt4 codes (0..4); jobs6: {target offset, query offset, tlen, qlen, ksw flag, 0} per pair (the

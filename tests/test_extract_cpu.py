@@ -104,3 +104,26 @@ def test_extract_sequence_matches_oracle_and_seqtk(case, tmp_path):
     assert set(seqs_seqtk) <= set(mine) and len(seqs_seqtk) > 0
     got1 = o.subseq(case["fq"][0], [x.encode() for x in open(lst).read().split()])
     assert [r[2] for r in got1] == seqs_seqtk
+
+
+def test_fused_extraction_leaves_the_same_fastq_texts_in_memory(case, tmp_path):
+    """al_extract_to_memory (N1 fused, no files): the three memory files hold exactly what extract-reads | extract-sequence write."""
+    import ctypes as C
+    rows = subprocess.run([CLI, "extract-reads", case["bam"], case["bed"], "150"], capture_output=True, check=True).stdout
+    rows_fn = str(tmp_path / "rows.bed"); open(rows_fn, "wb").write(rows)
+    subprocess.run([CLI, "extract-sequence", case["fq"][0], case["fq"][1], rows_fn, str(tmp_path)], capture_output=True, check=True)
+    L = C.CDLL(os.path.join(ROOT, "airlift_amd", "lib", "libairlift.so"))
+    L.al_extract_to_memory.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.al_extract_to_memory.restype = C.c_int
+    fds = (C.c_int * 3)(); npairs, nsingle = C.c_int64(), C.c_int64()
+    assert L.al_extract_to_memory(case["bam"].encode(), case["bed"].encode(), 150, 1, case["fq"][0].encode(), case["fq"][1].encode(), fds, C.byref(npairs), C.byref(nsingle)) == 0
+    got = []
+    for fd in fds:
+        assert fd >= 0
+        got.append(open("/proc/self/fd/%d" % fd, "rb").read()); os.close(fd)
+    exp = [open(tmp_path / n, "rb").read() for n in ("reads_1.fastq", "reads_2.fastq", "singletons.fastq")]
+    assert got == exp and npairs.value == exp[0].count(b"\n") // 4 and nsingle.value == exp[2].count(b"\n") // 4 and npairs.value > 100
+    # a BAM cut short is an error, and no descriptor is left behind
+    bad = str(tmp_path / "cut.bam"); open(bad, "wb").write(open(case["bam"], "rb").read()[:3000])
+    assert L.al_extract_to_memory(bad.encode(), case["bed"].encode(), 150, 1, case["fq"][0].encode(), case["fq"][1].encode(), fds, C.byref(npairs), C.byref(nsingle)) < 0
+    assert list(fds) == [-1, -1, -1]
