@@ -84,7 +84,7 @@ int main(int argc, char **argv)
 		if (p.size() != 5 || !out_p || (prune && read_size <= 0)) { fprintf(stderr, "Usage: airlift-align remap [-t N] [-R RG] [--noprune | --readsize R] -o pairs.sam [--singletons single.sam] ref.fa reads.bam regions.bed reads_1.fq reads_2.fq\n"); return 1; }
 		if (!getenv("AL_PG_PLAIN")) al_set_program_line(AL_MM_VERSION, argc, argv);
 		if (!k_given) setenv("AL_AUTO_BATCH", "1", 0);
-		setenv("GPU_MAX_HW_QUEUES", "8", 0);
+		setenv("GPU_MAX_HW_QUEUES", "16", 0);
 		int fds[3]; int64_t np = 0, ns = 0;
 		if (al_extract_to_memory(p[1], p[2], read_size, prune, p[3], p[4], fds, &np, &ns) != 0) return 1;
 		fprintf(stderr, "[airlift] remap: %lld pairs, %lld singletons selected\n", (long long)np, (long long)ns);
@@ -178,7 +178,7 @@ int main(int argc, char **argv)
 	// -K given: an upper bound of the bases per device batch.  Not given: the stream driver (plain FASTQ in, SAM out) sizes its batches
 	// from the free device memory (al_stream_pipe.cpp); the host driver keeps the preset's 50 Mbases, as the reference.
 	if (!k_given) setenv("AL_AUTO_BATCH", "1", 0);
-	setenv("GPU_MAX_HW_QUEUES", "8", 0);       // (HIP reads it when the runtime starts) the contexts' and slots' streams on separate hardware queues: the default of 4 makes streams that share a queue wait for each other
+	setenv("GPU_MAX_HW_QUEUES", "16", 0);       // (HIP reads it when the runtime starts) the contexts' and slots' streams on separate hardware queues: the default of 4 makes streams that share a queue wait for each other
 	if (al_check_opt(&io, &mo) < 0) return 1;
 	const char *ref = nullptr; std::vector<const char *> reads;
 	if (mode == MODE_ALN) {          // the real work happens in samse; emit a small marker so `> x.sai` is non-empty

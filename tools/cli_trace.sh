@@ -18,4 +18,4 @@ export AL_TIMING=1 AL_NO_FAST_EXIT=1 ${ENVX:-}
 rocprofv3 --kernel-trace --stats -d $O/trace --output-format csv -- $REPO/airlift_amd/bin/airlift-align -ax sr -t ${T:-32} -o /tmp/so_trace.sam /tmp/sref.fa /tmp/s_1.fq /tmp/s_2.fq 2> $O/trace.err
 grep -E "stream|context" $O/trace.err | cut -c1-600
 python3 $REPO/tools/trace_busy.py $O/trace > $O/busy.md; cat $O/busy.md | head -60
-find $O -name "*.csv" -size +8M -delete
+find $O -name "*.csv" -size +40M -delete
