@@ -302,6 +302,7 @@ int al_stream_map_files(const al_idx_t *mi, int n_fn, const char **fn, const al_
 							const double b_opt = sqrt(total_reads * t0b * A / (1.30 * v * (double)n_ctx_lane * (double)n_ctx_lane));
 							if (A > 0) mr = std::min(mr, b_opt);
 							mr = std::min(mr, (double)reads_cap_k.load()); mr = std::min(mr, 4.0e6); mr = std::max(mr, n1);
+							if (mr < 2.0 * n1) mr = n1;          // growing past the probe's size frees and re-obtains every workspace (seconds): only for at least twice the batch
 							bool exp = false;
 							if (sized.compare_exchange_strong(exp, true)) {
 								max_reads = (int)mr;
