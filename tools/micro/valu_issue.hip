@@ -14,7 +14,16 @@ __global__ void __launch_bounds__(1024) k_issue(int iters, int *out, long long *
 	for (int i = 0; i < iters; ++i) {
 #pragma unroll
 		for (int u = 0; u < 8; ++u) {      // 8 independent chains x 8 = 64 instructions per iteration
-			if (KIND == 0) { a0 += i; a1 += i; a2 += i; a3 += i; a4 += i; a5 += i; a6 += i; a7 += i; }
+			if (KIND == 0) {   // (written out: the compiler folds eight `a += i` into one multiply-add)
+#define ADDU(x) asm volatile("v_add_u32 %0, %0, %1" : "+v"(x) : "v"(i))
+				ADDU(a0); ADDU(a1); ADDU(a2); ADDU(a3); ADDU(a4); ADDU(a5); ADDU(a6); ADDU(a7);
+#undef ADDU
+			}
+			else if (KIND == 3) {
+#define PKADD(x, y) asm volatile("v_pk_add_u16 %0, %0, %1" : "+v"(x) : "v"(y))
+				PKADD(a0, a1); PKADD(a1, a2); PKADD(a2, a3); PKADD(a3, a4); PKADD(a4, a5); PKADD(a5, a6); PKADD(a6, a7); PKADD(a7, a0);
+#undef PKADD
+			}
 			else if (KIND == 1) { a0 = max(a0, i ^ a1); a1 = max(a1, i ^ a2); a2 = max(a2, i ^ a3); a3 = max(a3, i ^ a4); a4 = max(a4, i ^ a5); a5 = max(a5, i ^ a6); a6 = max(a6, i ^ a7); a7 = max(a7, i ^ a0); }
 			else {
 				a0 = __builtin_amdgcn_update_dpp(a0, a1, 0x111, 0xf, 0xf, false); a1 = __builtin_amdgcn_update_dpp(a1, a2, 0x111, 0xf, 0xf, false);
@@ -33,8 +42,8 @@ int main()
 {
 	const int iters = 20000; int *out; long long *cyc;
 	hipMalloc(&out, 256 * 2048 * 4); hipMalloc(&cyc, 2048 * 8);
-	const char *names[3] = {"v_add_u32", "v_max_i32 + v_xor", "v_mov_dpp row_shr:1"};
-	for (int kind = 0; kind < 3; ++kind)
+	const char *names[4] = {"v_add_u32", "v_max_i32 + v_xor", "v_mov_dpp row_shr:1", "v_pk_add_u16"};
+	for (int kind = 0; kind < 4; ++kind)
 		for (int wps = 1; wps <= 8; wps *= 2) {                 // waves per SIMD: one block of 4*wps waves per CU (256 CUs x 1 block)
 			const int threads = 64 * 4 * wps > 1024 ? 1024 : 64 * 4 * wps, blocks = 256 * (64 * 4 * wps / threads);
 			hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -42,7 +51,8 @@ int main()
 				hipEventRecord(e0);
 				if (kind == 0) hipLaunchKernelGGL(k_issue<0>, dim3(blocks), dim3(threads), 0, 0, iters, out, cyc);
 				else if (kind == 1) hipLaunchKernelGGL(k_issue<1>, dim3(blocks), dim3(threads), 0, 0, iters, out, cyc);
-				else hipLaunchKernelGGL(k_issue<2>, dim3(blocks), dim3(threads), 0, 0, iters, out, cyc);
+				else if (kind == 2) hipLaunchKernelGGL(k_issue<2>, dim3(blocks), dim3(threads), 0, 0, iters, out, cyc);
+				else hipLaunchKernelGGL(k_issue<3>, dim3(blocks), dim3(threads), 0, 0, iters, out, cyc);
 				hipEventRecord(e1); hipEventSynchronize(e1);
 			}
 			float ms = 0; hipEventElapsedTime(&ms, e0, e1);
