@@ -1370,17 +1370,26 @@ template __global__ void k_chain<AL_CHAIN_CAP>(const AlAnchor *, const uint64_t 
 // segments of a repeat-rich fragment) is listed by k_seg_scan itself, in memory order; the others are ordered by class (stable: inside a
 // class the segments keep their order in memory)
 __device__ __forceinline__ uint32_t d_seg_class(uint32_t n) { return n <= 16 ? 0u : n <= 24 ? 1u : n <= 32 ? 2u : n <= 40 ? 3u : n <= 48 ? 4u : n <= 64 ? 5u : n <= 80 ? 6u : n <= 96 ? 7u : n <= 128 ? 8u : 9u; }
-__global__ void __launch_bounds__(64)
+// NW wavefronts per fragment: fragments of more than AL_SEGS_BIG anchors are taken by the NW = 8 launch -- every wavefront walks its slice
+// of the anchors: first for the last cut inside it (the open segment a later slice starts in begins at the last cut before it), then
+// counting, then (mode 1) writing at the block prefix of the counts -- the others by the NW = 1 launch.
+#define AL_SEGS_BIG 8192
+template <int NW>
+__global__ void __launch_bounds__(64 * NW)
 k_seg_scan(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_off, const uint32_t *__restrict__ frag_na,
            const uint32_t *__restrict__ frag_first, const uint32_t *__restrict__ rd_len, const uint32_t *__restrict__ frag_list, int n_list,
            AlParams P, int lmin, int mode, const uint64_t *__restrict__ seg_first, const uint64_t *__restrict__ seg_first0, uint32_t *__restrict__ seg_cnt, uint32_t *__restrict__ seg_cnt0,
            uint64_t *__restrict__ vs_off, uint32_t *__restrict__ vs_na, uint32_t *__restrict__ vs_meta, const uint32_t *__restrict__ tie_flag,
-           uint32_t *__restrict__ list0 /* mode 1: the segments of class 0 (<= 16 anchors), in memory order */, uint32_t *__restrict__ list1, uint32_t *__restrict__ cls1 /* the others and their classes */)
+           uint32_t *__restrict__ list0 /* mode 1: the segments of class 0 (<= 16 anchors), in memory order */, uint32_t *__restrict__ list1, uint32_t *__restrict__ cls1 /* the others and their classes */,
+           int big_from /* NW == 1: the NW = 8 launch covers the list entries from this one on */)
 {
-	const int lane = threadIdx.x;
+	__shared__ long long s_last[NW];
+	__shared__ uint32_t s_cnt[NW], s_cnt0[NW];
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 	if ((int)blockIdx.x >= n_list) return;
 	const uint32_t f = frag_list[blockIdx.x];
 	const int64_t n = tie_flag && tie_flag[f] ? 0 : frag_na[f];                // equal-x anchors: chained whole on the side stream
+	if (NW > 1 ? n <= AL_SEGS_BIG : (n > AL_SEGS_BIG && (int)blockIdx.x >= big_from)) return;   // the other instantiation's fragment
 	const uint32_t r0 = frag_first[f], r1 = frag_first[f + 1];
 	int qlen_sum = 0; for (uint32_t r = r0; r < r1; ++r) qlen_sum += (int)rd_len[r];
 	int max_dist_x;                                                            // map.c:341-351
@@ -1391,7 +1400,6 @@ k_seg_scan(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_
 	const uint64_t base_off = a_off[f];
 	const AlAnchor *a = anchors + base_off;
 	const uint64_t out = mode ? seg_first[blockIdx.x] : 0, out0 = mode ? seg_first0[blockIdx.x] : 0;   // first segment / first class-0 segment of this fragment
-	uint32_t cnt = 0, cnt0 = 0; int64_t open_start = 0; uint64_t prev_last = 0;
 	const unsigned long long below = (1ULL << lane) - 1ULL;
 	// a segment's record index k; class 0 goes to list0 at its running number among the class-0 segments, the rest to list1 / cls1
 	auto emit = [&](uint64_t k, uint64_t k0, uint64_t k1, int64_t start, uint32_t len) {
@@ -1399,68 +1407,135 @@ k_seg_scan(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_
 		const uint32_t cl = d_seg_class(len);
 		if (cl == 0) list0[k0] = (uint32_t)k; else { list1[k1] = (uint32_t)k; cls1[k1] = cl; }
 	};
-	for (int64_t base = 0; base < n; base += 64) {
-		const int64_t i = base + lane; const bool valid = i < n;
-		const uint64_t x = valid ? a[i].x : 0;
-		uint64_t xp = (uint64_t)(uint32_t)__shfl_up((int)(uint32_t)x, 1) | (uint64_t)(uint32_t)__shfl_up((int)(uint32_t)(x >> 32), 1) << 32;
-		if (lane == 0) xp = prev_last;
-		const bool brk = valid && (i == 0 || x > xp + (uint64_t)max_dist_x);
-		const unsigned long long mask = __ballot(brk);
-		bool useful = false; int64_t start = 0;
-		if (brk && i > 0) {                                                     // this anchor closes the segment before it
-			const unsigned long long lower = mask & below;
-			start = lower ? base + (63 - __clzll((long long)lower)) : open_start;
-			useful = i - start >= lmin;
+	// this wavefront's slice of the anchors (whole windows of 64)
+	int64_t i0 = 0, i1 = n;
+	if (NW > 1) { const int64_t per = ((n + NW - 1) / NW + 63) / 64 * 64; i0 = (int64_t)w * per; if (i0 > n) i0 = n; i1 = i0 + per < n ? i0 + per : n; }
+	const uint64_t x_before = i0 > 0 && i0 < n ? a[i0 - 1].x : 0;                // x of the anchor in front of the slice
+	// the walk over [i0, i1): what == 0 finds the last cut, 1 counts, 2 writes (cnt / cnt0 then hold the slice's offsets); the segment
+	// that is open at i0 starts at open_in
+	auto walk = [&](int what, int64_t open_in, uint32_t &cnt, uint32_t &cnt0, int64_t &open_out) {
+		int64_t open_start = open_in; uint64_t prev_last = x_before;
+		for (int64_t base = i0; base < i1; base += 64) {
+			const int64_t i = base + lane; const bool valid = i < i1;
+			const uint64_t x = valid ? a[i].x : 0;
+			uint64_t xp = (uint64_t)(uint32_t)__shfl_up((int)(uint32_t)x, 1) | (uint64_t)(uint32_t)__shfl_up((int)(uint32_t)(x >> 32), 1) << 32;
+			if (lane == 0) xp = prev_last;
+			const bool brk = valid && (i == 0 || x > xp + (uint64_t)max_dist_x);
+			const unsigned long long mask = __ballot(brk);
+			if (what != 0) {
+				bool useful = false; int64_t start = 0;
+				if (brk && i > 0) {                                                 // this anchor closes the segment before it
+					const unsigned long long lower = mask & below;
+					start = lower ? base + (63 - __clzll((long long)lower)) : open_start;
+					useful = i - start >= lmin;
+				}
+				const bool small = useful && d_seg_class((uint32_t)(i - start)) == 0;
+				const unsigned long long um = __ballot(useful), um0 = __ballot(small);
+				if (what == 2 && useful) {
+					const uint32_t o = cnt + (uint32_t)__popcll(um & below), o0 = cnt0 + (uint32_t)__popcll(um0 & below);
+					emit(out + o, out0 + o0, (out - out0) + (o - o0), start, (uint32_t)(i - start));
+				}
+				cnt += (uint32_t)__popcll(um); cnt0 += (uint32_t)__popcll(um0);
+			}
+			if (mask) open_start = base + (63 - __clzll((long long)mask));
+			prev_last = (uint64_t)(uint32_t)__shfl((int)(uint32_t)x, 63) | (uint64_t)(uint32_t)__shfl((int)(uint32_t)(x >> 32), 63) << 32;
 		}
-		const bool small = useful && d_seg_class((uint32_t)(i - start)) == 0;
-		const unsigned long long um = __ballot(useful), um0 = __ballot(small);
-		if (mode && useful) {
-			const uint32_t o = cnt + (uint32_t)__popcll(um & below), o0 = cnt0 + (uint32_t)__popcll(um0 & below);
-			emit(out + o, out0 + o0, (out - out0) + (o - o0), start, (uint32_t)(i - start));
-		}
-		cnt += (uint32_t)__popcll(um); cnt0 += (uint32_t)__popcll(um0);
-		if (mask) open_start = base + (63 - __clzll((long long)mask));
-		prev_last = (uint64_t)(uint32_t)__shfl((int)(uint32_t)x, 63) | (uint64_t)(uint32_t)__shfl((int)(uint32_t)(x >> 32), 63) << 32;
+		open_out = open_start;
+	};
+	int64_t open_in = 0;
+	if (NW > 1) {
+		uint32_t d0 = 0, d1 = 0; int64_t last = -1;
+		walk(0, -1, d0, d1, last);
+		if (lane == 0) s_last[w] = last;
+		__syncthreads();
+		for (int j = 0; j < w; ++j) if (s_last[j] >= 0) open_in = s_last[j];
 	}
-	if (n > 0 && n - open_start >= lmin) {
-		if (mode && lane == 0) emit(out + cnt, out0 + cnt0, (out - out0) + (cnt - cnt0), open_start, (uint32_t)(n - open_start));
-		++cnt; cnt0 += d_seg_class((uint32_t)(n - open_start)) == 0 ? 1u : 0u;
+	uint32_t cnt = 0, cnt0 = 0; int64_t open_end = 0;
+	const bool last_wave = w == NW - 1;
+	if (NW == 1) {
+		walk(mode ? 2 : 1, 0, cnt, cnt0, open_end);
+	} else {
+		walk(1, open_in, cnt, cnt0, open_end);
+		// (the fragment's last segment is the last wavefront's: it ends at n whatever the slices are)
+		uint32_t tail = 0, tail0 = 0;
+		if (last_wave && n > 0 && n - open_end >= lmin) { tail = 1; tail0 = d_seg_class((uint32_t)(n - open_end)) == 0 ? 1u : 0u; }
+		if (lane == 0) { s_cnt[w] = cnt + tail; s_cnt0[w] = cnt0 + tail0; }
+		__syncthreads();
+		if (mode) {
+			uint32_t b = 0, b0 = 0; for (int j = 0; j < w; ++j) { b += s_cnt[j]; b0 += s_cnt0[j]; }
+			cnt = b; cnt0 = b0;
+			walk(2, open_in, cnt, cnt0, open_end);
+		} else if (threadIdx.x == 0) {
+			uint32_t t = 0, t0 = 0; for (int j = 0; j < NW; ++j) { t += s_cnt[j]; t0 += s_cnt0[j]; }
+			seg_cnt[blockIdx.x] = t; seg_cnt0[blockIdx.x] = t0;
+		}
+		if (!last_wave || !mode) return;
+		if (n > 0 && n - open_end >= lmin && lane == 0) emit(out + cnt, out0 + cnt0, (out - out0) + (cnt - cnt0), open_end, (uint32_t)(n - open_end));
+		return;
+	}
+	if (n > 0 && n - open_end >= lmin) {
+		if (mode && lane == 0) emit(out + cnt, out0 + cnt0, (out - out0) + (cnt - cnt0), open_end, (uint32_t)(n - open_end));
+		++cnt; cnt0 += d_seg_class((uint32_t)(n - open_end)) == 0 ? 1u : 0u;
 	}
 	if (!mode && lane == 0) { seg_cnt[blockIdx.x] = cnt; seg_cnt0[blockIdx.x] = cnt0; }
 }
+#define INST_SEG_SCAN(NWV) template __global__ void k_seg_scan<NWV>(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *, int, AlParams, int, int, const uint64_t *, const uint64_t *, uint32_t *, uint32_t *, uint64_t *, uint32_t *, uint32_t *, const uint32_t *, uint32_t *, uint32_t *, uint32_t *, int);
+INST_SEG_SCAN(1) INST_SEG_SCAN(8)
+#undef INST_SEG_SCAN
 
 // k_seg_merge: the fragment's chain list from the chain lists of its segments.  chain.c:144-160 orders the chains by the x of
 // their first anchor; segments are disjoint x ranges in ascending order, so the fragment's order is the segments' orders
 // one after the other -- except that the reference's sort of more than 64 chains is not stable, so a fragment with more than
 // 64 chains of which two start at equal x is handed to the whole-fragment kernel (fb_list), which restates that sort.
-__global__ void __launch_bounds__(64)
+// NW wavefronts per fragment: fragments with more than AL_SEGM_BIG segments are taken by the NW = 8 launch (each wavefront sums the
+// chains / chained anchors of its slice of the segments, a block prefix gives the slices their offsets, then every wavefront copies its
+// slice), the others by the NW = 1 launch -- so that a launch does not wait for one wavefront walking a fragment of 10^5 anchors.
+#define AL_SEGM_BIG 1024
+template <int NW>
+__global__ void __launch_bounds__(64 * NW)
 k_seg_merge(const uint32_t *__restrict__ frag_list, int n_list, const uint64_t *__restrict__ seg_first,
             const uint64_t *__restrict__ vs_off, const uint4 *__restrict__ vs_res /* ChainSeg::res */,
             const uint64_t *__restrict__ u_tmp, const AlAnchor *__restrict__ chain_tmp, const uint64_t *__restrict__ a_off,
             uint64_t *__restrict__ u_out, AlAnchor *__restrict__ chained, uint32_t *__restrict__ frag_nu,
             uint32_t *__restrict__ fb_list, uint32_t *__restrict__ fb_cnt, const uint32_t *__restrict__ tie_flag,
-            const uint64_t *__restrict__ okey_tmp, uint64_t *__restrict__ okey_out)
+            const uint64_t *__restrict__ okey_tmp, uint64_t *__restrict__ okey_out, int big_from /* NW == 1: the NW = 8 launch covers the list entries from this one on */)
 {
-	__shared__ uint32_t s_bu[64], s_bc[64];
-	__shared__ uint64_t s_off[64], s_u1[64];
-	const int lane = threadIdx.x;
+	__shared__ uint32_t s_bu_[NW][64], s_bc_[NW][64];
+	__shared__ uint64_t s_off_[NW][64], s_u1_[NW][64];
+	__shared__ uint64_t s_sum_u[NW], s_sum_c[NW];
+	__shared__ int s_tie_any;
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 	if ((int)blockIdx.x >= n_list) return;
 	const uint32_t f = frag_list[blockIdx.x];
 	if (tie_flag && tie_flag[f]) return;                                       // the side stream writes this fragment's chains
 	const uint64_t s0 = seg_first[blockIdx.x], s1 = seg_first[blockIdx.x + 1];
-	uint64_t *u = u_out + a_off[f] + f; AlAnchor *b = chained + a_off[f];
+	if (NW > 1 ? s1 - s0 <= AL_SEGM_BIG : (s1 - s0 > AL_SEGM_BIG && (int)blockIdx.x >= big_from)) return;   // the other instantiation's fragment
+	uint32_t *const s_bu = s_bu_[w], *const s_bc = s_bc_[w]; uint64_t *const s_off = s_off_[w], *const s_u1 = s_u1_[w];
+	// this wavefront's slice of the segments (whole groups of 64)
+	uint64_t w0 = s0, w1 = s1;
+	if (NW > 1) { const uint64_t per = ((s1 - s0 + NW - 1) / NW + 63) / 64 * 64; w0 = s0 + (uint64_t)w * per; if (w0 > s1) w0 = s1; w1 = w0 + per < s1 ? w0 + per : s1; }
 	uint64_t run_u = 0, run_c = 0; bool tie = false;
-	for (uint64_t sb = s0; sb < s1; sb += 64) {
-		const uint64_t s = sb + lane; const bool valid = s < s1;
+	if (NW > 1) {
+		uint64_t su = 0, sc = 0;
+		for (uint64_t s = w0 + lane; s < w1; s += 64) { const uint4 r = vs_res[s]; su += r.z; sc += r.w & 0x7fffffffu; }
+		for (int d = 32; d > 0; d >>= 1) { su += __shfl_xor(su, d); sc += __shfl_xor(sc, d); }
+		if (threadIdx.x == 0) s_tie_any = 0;
+		if (lane == 0) { s_sum_u[w] = su; s_sum_c[w] = sc; }
+		__syncthreads();
+		for (int i = 0; i < w; ++i) { run_u += s_sum_u[i]; run_c += s_sum_c[i]; }
+	}
+	uint64_t *u = u_out + a_off[f] + f; AlAnchor *b = chained + a_off[f];
+	for (uint64_t sb = w0; sb < w1; sb += 64) {
+		const uint64_t s = sb + lane; const bool valid = s < w1;
 		const uint4 r = valid ? vs_res[s] : make_uint4(0u, 0u, 0u, 0u);
 		const uint32_t nu = r.z, nc = r.w & 0x7fffffffu;
 		tie = tie || (r.w >> 31) != 0;
 		uint32_t iu = nu, ic = nc;
 		for (int d = 1; d < 64; d <<= 1) { const uint32_t tu = __shfl_up(iu, d), tc = __shfl_up(ic, d); if (lane >= d) { iu += tu; ic += tc; } }
 		const uint32_t tot_u = __shfl(iu, 63), tot_c = __shfl(ic, 63);
-		__syncthreads();
+		__threadfence_block();                                                   // (one wavefront per slice: its LDS rows of the last round are done with)
 		s_bu[lane] = iu - nu; s_bc[lane] = ic - nc; s_off[lane] = valid ? vs_off[s] : 0; s_u1[lane] = nu == 1 ? ((uint64_t)r.x | (uint64_t)r.y << 32) : 0;
-		__syncthreads();
+		__threadfence_block();
 		for (uint32_t t = lane; t < tot_u; t += 64) {
 			int lo = 0, hi = 64; while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_bu[mid] <= t) lo = mid; else hi = mid; }
 			const uint64_t u1 = s_u1[lo];
@@ -1476,12 +1551,20 @@ k_seg_merge(const uint32_t *__restrict__ frag_list, int n_list, const uint64_t *
 		}
 		run_u += tot_u; run_c += tot_c;
 	}
-	const bool any_tie = __ballot(tie) != 0;
+	bool any_tie = __ballot(tie) != 0;
+	if (NW > 1) {
+		if (any_tie && lane == 0) s_tie_any = 1;
+		__syncthreads();
+		any_tie = s_tie_any != 0;
+		if (w != NW - 1) return;                                                // the last slice ends at the fragment's totals
+	}
 	if (lane == 0) {
 		frag_nu[f] = (uint32_t)run_u;
 		if (any_tie && run_u > 64) fb_list[atomicAdd(fb_cnt, 1u)] = f;
 	}
 }
+template __global__ void k_seg_merge<1>(const uint32_t *, int, const uint64_t *, const uint64_t *, const uint4 *, const uint64_t *, const AlAnchor *, const uint64_t *, uint64_t *, AlAnchor *, uint32_t *, uint32_t *, uint32_t *, const uint32_t *, const uint64_t *, uint64_t *, int);
+template __global__ void k_seg_merge<8>(const uint32_t *, int, const uint64_t *, const uint64_t *, const uint4 *, const uint64_t *, const AlAnchor *, const uint64_t *, uint64_t *, AlAnchor *, uint32_t *, uint32_t *, uint32_t *, const uint32_t *, const uint64_t *, uint64_t *, int);
 
 // k_chain_order: the reference's order of a fragment's chains when some of them start at anchors of equal x and there are more than
 // 64 of them -- its sort (radix_sort_128x, ksort.h:116-151) is not stable, so the order among the equal ones depends on where every

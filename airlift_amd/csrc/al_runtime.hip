@@ -31,8 +31,8 @@ template <int CAPL, int LANES> __global__ void k_chain_lds(const AlAnchor *, con
 template <int PER, int NW, int MCAP> __global__ void k_anchor_sort_reg(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, uint32_t *, const uint32_t *, int, int, int);
 __global__ void k_anchor_big_expand(const uint64_t *, const uint64_t *, const uint32_t *, const AlMatch *, const uint32_t *, const uint32_t *, int, const uint64_t *, uint64_t *, int, int);
 __global__ void k_anchor_big_scatter(const uint64_t *, const uint32_t *, int, const uint64_t *, const uint64_t *, const uint64_t *, const uint32_t *, const uint32_t *, const AlMatch *, const uint32_t *, AlAnchor *, uint32_t *, int, int, int);
-__global__ void k_seg_scan(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *, int, AlParams, int, int, const uint64_t *, const uint64_t *, uint32_t *, uint32_t *, uint64_t *, uint32_t *, uint32_t *, const uint32_t *, uint32_t *, uint32_t *, uint32_t *);
-__global__ void k_seg_merge(const uint32_t *, int, const uint64_t *, const uint64_t *, const uint4 *, const uint64_t *, const AlAnchor *, const uint64_t *, uint64_t *, AlAnchor *, uint32_t *, uint32_t *, uint32_t *, const uint32_t *, const uint64_t *, uint64_t *);
+template <int NW> __global__ void k_seg_scan(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *, int, AlParams, int, int, const uint64_t *, const uint64_t *, uint32_t *, uint32_t *, uint64_t *, uint32_t *, uint32_t *, const uint32_t *, uint32_t *, uint32_t *, uint32_t *, int);
+template <int NW> __global__ void k_seg_merge(const uint32_t *, int, const uint64_t *, const uint64_t *, const uint4 *, const uint64_t *, const AlAnchor *, const uint64_t *, uint64_t *, AlAnchor *, uint32_t *, uint32_t *, uint32_t *, const uint32_t *, const uint64_t *, uint64_t *, int);
 __global__ void k_chain_order(const uint32_t *, int, const uint64_t *, const uint32_t *, uint64_t *, AlAnchor *, const uint64_t *, uint64_t *, AlAnchor *, uint32_t *, uint32_t *, int32_t *);
 __global__ void k_lower_bounds(const uint32_t *, uint32_t, LbThr, uint32_t *);
 __global__ void k_collect_flagged(const uint32_t *, int, const uint32_t *, uint32_t *, uint32_t *);
@@ -382,7 +382,7 @@ static int sort_u32_pairs(al_ctx_t *c, const uint32_t *k_in, uint32_t *k_out, co
 // with_keys: the per-chain processing keys (ChainSeg::okey) are written as well, and fragments whose chain starts tie get their order
 // from k_chain_order.  The hot call runs without them (8 scattered bytes per chain less to write and to read back) and hands the few
 // fragments that turn out to need them (ties among more than 64 chains) to a second call, on those fragments only, with keys.
-static int chain_by_segments(al_ctx_t *c, const uint32_t *order, int n, bool lds_ok, bool first, const uint32_t *skip_flag, bool with_keys = false)
+static int chain_by_segments(al_ctx_t *c, const uint32_t *order, int n, bool lds_ok, bool first, const uint32_t *skip_flag, bool with_keys = false, int big_from = 0 /* entries before this one have too few anchors for AL_SEGM_BIG segments */, int big8_from = 0 /* ... at most AL_SEGS_BIG anchors */)
 {
 	hipStream_t s = c->stream;
 	auto ev = [&](int st) -> int { if (first) AL_HIP_CHECK(hipEventRecord(c->ev[st + 1], s)); return 0; };
@@ -391,9 +391,14 @@ static int chain_by_segments(al_ctx_t *c, const uint32_t *order, int n, bool lds
 	int lmin = c->opt.min_cnt > 1 ? c->opt.min_cnt : 1;
 	{ const int per = c->mi->k + 1, need = (c->opt.min_chain_score + per - 1) / per; if (need > lmin) lmin = need; }
 	if (c->seg_cnt.ensure((size_t)n + 2) || c->seg_first.ensure((size_t)n + 2) || c->seg_cnt0.ensure((size_t)n + 2) || c->seg_first0.ensure((size_t)n + 2)) return -1;
-	hipLaunchKernelGGL(k_seg_scan, dim3(n), dim3(64), 0, s, c->anchors.p, c->a_off.p, c->frag_na.p, c->frag_first.p, c->rd_len.p, order, n, c->P, lmin, 0,
+	// (fragments of more than AL_SEGS_BIG anchors: eight wavefronts each, launched first; big8_from: the entries before it have at most 8192 anchors)
+	if (big8_from < 0 || big8_from > n) big8_from = 0;
+	if (n > big8_from) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_seg_scan<8>), dim3(n - big8_from), dim3(512), 0, s, c->anchors.p, c->a_off.p, c->frag_na.p, c->frag_first.p, c->rd_len.p, order + big8_from, n - big8_from, c->P, lmin, 0,
+	                   (const uint64_t *)nullptr, (const uint64_t *)nullptr, c->seg_cnt.p + big8_from, c->seg_cnt0.p + big8_from, (uint64_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, skip_flag,
+	                   (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, big8_from);
+	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_seg_scan<1>), dim3(n), dim3(64), 0, s, c->anchors.p, c->a_off.p, c->frag_na.p, c->frag_first.p, c->rd_len.p, order, n, c->P, lmin, 0,
 	                   (const uint64_t *)nullptr, (const uint64_t *)nullptr, c->seg_cnt.p, c->seg_cnt0.p, (uint64_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, skip_flag,
-	                   (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr);
+	                   (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, big8_from);
 	AL_HIP_CHECK(hipMemsetAsync(c->seg_cnt.p + n, 0, 4, s)); AL_HIP_CHECK(hipMemsetAsync(c->seg_cnt0.p + n, 0, 4, s));
 	if (scan_u32_to_u64(c, c->seg_cnt.p, c->seg_first.p, n) || scan_u32_to_u64(c, c->seg_cnt0.p, c->seg_first0.p, n)) return -1;
 	uint64_t ns64 = 0, ns0_64 = 0;
@@ -405,9 +410,12 @@ static int chain_by_segments(al_ctx_t *c, const uint32_t *order, int n, bool lds
 	const int ns = (int)ns64, ns0 = (int)ns0_64, n1 = ns - ns0;
 	if (c->vs_off.ensure((size_t)ns + 1) || c->vs_na.ensure((size_t)ns + 1) || c->vs_meta.ensure((size_t)ns + 1) || c->vs_res.ensure(2 * ((size_t)ns + 1)) ||
 	    c->seg_idx.ensure((size_t)ns0 + 1) || c->vs_cls.ensure((size_t)n1 + 1) || c->seg_t1.ensure((size_t)n1 + 1) || c->seg_key.ensure((size_t)n1 + 1) || c->seg_ord.ensure((size_t)n1 + 1) || c->fb_list.ensure((size_t)n + 2)) return -1;
-	hipLaunchKernelGGL(k_seg_scan, dim3(n), dim3(64), 0, s, c->anchors.p, c->a_off.p, c->frag_na.p, c->frag_first.p, c->rd_len.p, order, n, c->P, lmin, 1,
+	if (n > big8_from) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_seg_scan<8>), dim3(n - big8_from), dim3(512), 0, s, c->anchors.p, c->a_off.p, c->frag_na.p, c->frag_first.p, c->rd_len.p, order + big8_from, n - big8_from, c->P, lmin, 1,
+	                   (const uint64_t *)c->seg_first.p + big8_from, (const uint64_t *)c->seg_first0.p + big8_from, (uint32_t *)nullptr, (uint32_t *)nullptr, c->vs_off.p, c->vs_na.p, c->vs_meta.p, skip_flag,
+	                   c->seg_idx.p, c->seg_t1.p, c->vs_cls.p, big8_from);
+	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_seg_scan<1>), dim3(n), dim3(64), 0, s, c->anchors.p, c->a_off.p, c->frag_na.p, c->frag_first.p, c->rd_len.p, order, n, c->P, lmin, 1,
 	                   (const uint64_t *)c->seg_first.p, (const uint64_t *)c->seg_first0.p, (uint32_t *)nullptr, (uint32_t *)nullptr, c->vs_off.p, c->vs_na.p, c->vs_meta.p, skip_flag,
-	                   c->seg_idx.p, c->seg_t1.p, c->vs_cls.p);
+	                   c->seg_idx.p, c->seg_t1.p, c->vs_cls.p, big8_from);
 	uint32_t lb[8] = {0, 0, 0, 0, 0, 0, 0, 0};                                // starts of classes 2 .. 9 in the class-ordered list of the n1 others
 	if (n1 > 0) {
 		{   // stable sort by size class only (4 bits: one radix pass)
@@ -447,8 +455,12 @@ static int chain_by_segments(al_ctx_t *c, const uint32_t *order, int n, bool lds
 	} else { if (ev(ST_SEG_CHAIN_LDS) || ev(ST_SEG_CHAIN_WAVE)) return -1; }
 	uint32_t *fb_cnt = (uint32_t *)(c->counters.p + 15);
 	AL_HIP_CHECK(hipMemsetAsync(fb_cnt, 0, 8, s));
-	hipLaunchKernelGGL(k_seg_merge, dim3(n), dim3(64), 0, s, order, n, c->seg_first.p, c->vs_off.p, (const uint4 *)c->vs_res.p, c->u_tmp.p, c->chain_tmp.p, c->a_off.p,
-	                   c->u.p, c->chained.p, c->frag_nu.p, c->fb_list.p, fb_cnt, skip_flag, keep_keys ? (const uint64_t *)c->okey_tmp.p : nullptr, c->ws_u64.p);
+	// (the fragments with many segments first: eight wavefronts each, next to the one-wavefront launch of the others)
+	if (big_from < 0 || big_from > n) big_from = 0;
+	if (n > big_from) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_seg_merge<8>), dim3(n - big_from), dim3(512), 0, s, order + big_from, n - big_from, c->seg_first.p + big_from, c->vs_off.p, (const uint4 *)c->vs_res.p, c->u_tmp.p, c->chain_tmp.p, c->a_off.p,
+	                   c->u.p, c->chained.p, c->frag_nu.p, c->fb_list.p, fb_cnt, skip_flag, keep_keys ? (const uint64_t *)c->okey_tmp.p : nullptr, c->ws_u64.p, big_from);
+	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_seg_merge<1>), dim3(n), dim3(64), 0, s, order, n, c->seg_first.p, c->vs_off.p, (const uint4 *)c->vs_res.p, c->u_tmp.p, c->chain_tmp.p, c->a_off.p,
+	                   c->u.p, c->chained.p, c->frag_nu.p, c->fb_list.p, fb_cnt, skip_flag, keep_keys ? (const uint64_t *)c->okey_tmp.p : nullptr, c->ws_u64.p, big_from);
 	uint32_t n_fb = 0;
 	AL_HIP_CHECK(hipMemcpyAsync(&n_fb, fb_cnt, 4, hipMemcpyDeviceToHost, s));
 	AL_HIP_CHECK(hipStreamSynchronize(s));
@@ -629,7 +641,7 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 #undef LFR
 #undef LFRLO
 		const uint32_t tail = lds_ok ? lb129 : 0u;
-		if (chain_by_segments(c, order + tail, nl - (int)tail, lds_ok, first, (const uint32_t *)c->tie_list.p)) return -1;
+		if (chain_by_segments(c, order + tail, nl - (int)tail, lds_ok, first, (const uint32_t *)c->tie_list.p, false, lb2049 > tail ? (int)(lb2049 - tail) : 0, lb8193 > tail ? (int)(lb8193 - tail) : 0)) return -1;
 	}
 	{   // second round: the fragments whose anchors the side stream merged, any size, through the segment path
 		AL_HIP_CHECK(hipStreamWaitEvent(s, c->ev_side[first ? 1 : 3], 0));
