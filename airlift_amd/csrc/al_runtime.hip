@@ -434,13 +434,21 @@ static int chain_by_segments(al_ctx_t *c, const uint32_t *order, int n, bool lds
 	const bool keys_possible = c->opt.min_cnt >= 2;                           // a chain has >= 2 anchors: the keys of a segment fit half of its range
 	const bool keep_keys = with_keys && keys_possible;
 	const ChainSeg sg{c->vs_meta.p, (uint32_t *)c->vs_res.p, nullptr, 0, keep_keys ? c->okey_tmp.p : nullptr};
+	bool thin[4] = {false, false, false, false};
+	static const uint32_t wave_max = getenv("AL_CHAIN_WAVE_MAX") ? (uint32_t)atoi(getenv("AL_CHAIN_WAVE_MAX")) : 8192u;   // (tests: 0 = never, a large value = always)
 	if (ns > 0) {
 		const uint32_t *so0 = c->seg_idx.p, *so1 = c->seg_ord.p;
 		if (lds_ok) {
 #define LSEG(C, L, LIST, A, B) LCH(C, L, -1, c->vs_off.p, c->vs_na.p, c->chain_tmp.p, c->u_tmp.p, (uint32_t *)nullptr, (LIST) + (A), (int)((B) - (A)), sg)
 			LSEG(16, 64, so0, 0u, (uint32_t)ns0);
 			LSEG(24, 64, so1, 0u, lb[0]); LSEG(32, 64, so1, lb[0], lb[1]); LSEG(40, 64, so1, lb[1], lb[2]); LSEG(48, 64, so1, lb[2], lb[3]);
-			LSEG(64, 64, so1, lb[3], lb[4]); LSEG(80, 64, so1, lb[4], lb[5]); LSEG(96, 64, so1, lb[5], lb[6]); LSEG(128, 32, so1, lb[6], lb[7]);
+			// A lane walks a 49 ... 128-anchor entry for 0.5 - 1.3 ms whatever the launch holds; the wavefront kernel takes ~1 us per anchor of an
+			// entry.  A class with few entries (a small batch, the re-seeding pass) is over sooner through the latter: marked here, launched below.
+			for (int k = 3; k < 7; ++k) thin[k - 3] = lb[k + 1] - lb[k] > 0 && lb[k + 1] - lb[k] < wave_max;
+			if (!thin[0]) LSEG(64, 64, so1, lb[3], lb[4]);
+			if (!thin[1]) LSEG(80, 64, so1, lb[4], lb[5]);
+			if (!thin[2]) LSEG(96, 64, so1, lb[5], lb[6]);
+			if (!thin[3]) LSEG(128, 32, so1, lb[6], lb[7]);
 #undef LSEG
 		}
 		if (ev(ST_SEG_CHAIN_LDS)) return -1;
@@ -449,7 +457,7 @@ static int chain_by_segments(al_ctx_t *c, const uint32_t *order, int n, bool lds
 		                               c->ws_i32.p, c->ws_u64.p, (LIST), nw__, c->P, c->counters.p, sg); } while (0)
 		const int nw = lds_ok ? n1 - (int)lb[7] : ns;
 		{ static const bool tr = getenv("AL_TRACE") != nullptr; if (tr && nw > 0) fprintf(stderr, "[airlift] trace: %d segments to the wavefront kernel (of %d segments in %d fragments)\n", nw, ns, n); }
-		if (lds_ok) LWAVE(so1 + lb[7], n1 - (int)lb[7]); else { LWAVE(so0, ns0); LWAVE(so1, n1); }
+		if (lds_ok) { LWAVE(so1 + lb[7], n1 - (int)lb[7]); for (int k = 3; k < 7; ++k) if (thin[k - 3]) LWAVE(so1 + lb[k], (int)(lb[k + 1] - lb[k])); } else { LWAVE(so0, ns0); LWAVE(so1, n1); }
 #undef LWAVE
 		if (ev(ST_SEG_CHAIN_WAVE)) return -1;
 	} else { if (ev(ST_SEG_CHAIN_LDS) || ev(ST_SEG_CHAIN_WAVE)) return -1; }
@@ -632,10 +640,16 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 		if (lds_ok) {   // exact ranges of the size-ordered list (lane counts differ between these classes)
 			// 64-lane wavefronts hold more fragments per CU but need enough of them to cover the chip; a thin class runs on half waves
 			const uint32_t fill = 64u * 3u * 256u * 2u;
+			static const uint32_t wave_max = getenv("AL_CHAIN_WAVE_MAX") ? (uint32_t)atoi(getenv("AL_CHAIN_WAVE_MAX")) : 8192u;
 			uint32_t from = lb65;
-			if (lb81 - lb65 >= fill) { LFR(80, 64, lb65, lb81); from = lb81; }
-			if (from == lb81 && lb97 - lb81 >= fill) { LFR(96, 64, lb81, lb97); from = lb97; }
-			LFR(128, 32, from, lb129);
+			if (lb129 > lb65 && lb129 - lb65 < wave_max)   // few fragments of 65 ... 128 anchors (a small batch): a wavefront each is over sooner than a lane each
+				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<AL_CHAIN_CAP>), dim3(lb129 - lb65), dim3(64), 0, s, c->anchors.p, c->a_off.p, c->frag_na.p, c->frag_first.p, c->rd_len.p, c->chained.p, c->u.p, c->frag_nu.p,
+				                   c->ws_i32.p, c->ws_u64.p, order + lb65, (int)(lb129 - lb65), c->P, c->counters.p, nosg);
+			else {
+				if (lb81 - lb65 >= fill) { LFR(80, 64, lb65, lb81); from = lb81; }
+				if (from == lb81 && lb97 - lb81 >= fill) { LFR(96, 64, lb81, lb97); from = lb97; }
+				LFR(128, 32, from, lb129);
+			}
 		}
 		if (ev(ST_CHAIN_LDS128)) return -1;
 #undef LFR

@@ -74,8 +74,8 @@ def test_lds_dp_path_identical(golden_unpacked, name):
 
 
 @pytest.mark.parametrize("env", [dict(AL_DBG=str(1 << 27)), dict(AL_TEST_SORT_BLK="65"), dict(AL_TEST_SORT_BIG="65"), dict(AL_TEST_SORT_BLK="65", AL_TEST_SORT_BIG="200"),
-                                 dict(AL_TEST_SORT_BIG="65", AL_TEST_BIG_CHUNK="3"), dict(AL_TEST_HEAP_WAVE="1")],
-                         ids=["segments_wave_only", "block_sort", "device_sort", "block_and_device_sort", "device_sort_chunks", "heap_merge_by_wavefront"])
+                                 dict(AL_TEST_SORT_BIG="65", AL_TEST_BIG_CHUNK="3"), dict(AL_TEST_HEAP_WAVE="1"), dict(AL_CHAIN_WAVE_MAX="0")],
+                         ids=["segments_wave_only", "block_sort", "device_sort", "block_and_device_sort", "device_sort_chunks", "heap_merge_by_wavefront", "lds_chain_kernels_for_thin_classes"])
 @pytest.mark.parametrize("name", ["g1_mt150pe", "g2_250pe", "g3_adversarial", "g6_repeats"])
 def test_large_fragment_paths_identical(golden_unpacked, name, env):
     """The kernels that take over for fragments with many anchors -- chaining by segments (AL_DBG bit 27: every fragment goes
