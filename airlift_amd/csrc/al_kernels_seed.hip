@@ -1381,7 +1381,7 @@ k_seg_scan(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_
            AlParams P, int lmin, int mode, const uint64_t *__restrict__ seg_first, const uint64_t *__restrict__ seg_first0, uint32_t *__restrict__ seg_cnt, uint32_t *__restrict__ seg_cnt0,
            uint64_t *__restrict__ vs_off, uint32_t *__restrict__ vs_na, uint32_t *__restrict__ vs_meta, const uint32_t *__restrict__ tie_flag,
            uint32_t *__restrict__ list0 /* mode 1: the segments of class 0 (<= 16 anchors), in memory order */, uint32_t *__restrict__ list1, uint32_t *__restrict__ cls1 /* the others and their classes */,
-           int big_from /* NW == 1: the NW = 8 launch covers the list entries from this one on */)
+           int big_from /* NW == 1: the NW = 8 launch covers the list entries from this one on */, int big_n /* anchors above which the NW = 8 launch takes a fragment */)
 {
 	__shared__ long long s_last[NW];
 	__shared__ uint32_t s_cnt[NW], s_cnt0[NW];
@@ -1389,7 +1389,7 @@ k_seg_scan(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_
 	if ((int)blockIdx.x >= n_list) return;
 	const uint32_t f = frag_list[blockIdx.x];
 	const int64_t n = tie_flag && tie_flag[f] ? 0 : frag_na[f];                // equal-x anchors: chained whole on the side stream
-	if (NW > 1 ? n <= AL_SEGS_BIG : (n > AL_SEGS_BIG && (int)blockIdx.x >= big_from)) return;   // the other instantiation's fragment
+	if (NW > 1 ? n <= big_n : (n > big_n && (int)blockIdx.x >= big_from)) return;   // the other instantiation's fragment
 	const uint32_t r0 = frag_first[f], r1 = frag_first[f + 1];
 	int qlen_sum = 0; for (uint32_t r = r0; r < r1; ++r) qlen_sum += (int)rd_len[r];
 	int max_dist_x;                                                            // map.c:341-351
@@ -1479,7 +1479,7 @@ k_seg_scan(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_
 	}
 	if (!mode && lane == 0) { seg_cnt[blockIdx.x] = cnt; seg_cnt0[blockIdx.x] = cnt0; }
 }
-#define INST_SEG_SCAN(NWV) template __global__ void k_seg_scan<NWV>(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *, int, AlParams, int, int, const uint64_t *, const uint64_t *, uint32_t *, uint32_t *, uint64_t *, uint32_t *, uint32_t *, const uint32_t *, uint32_t *, uint32_t *, uint32_t *, int);
+#define INST_SEG_SCAN(NWV) template __global__ void k_seg_scan<NWV>(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *, int, AlParams, int, int, const uint64_t *, const uint64_t *, uint32_t *, uint32_t *, uint64_t *, uint32_t *, uint32_t *, const uint32_t *, uint32_t *, uint32_t *, uint32_t *, int, int);
 INST_SEG_SCAN(1) INST_SEG_SCAN(8)
 #undef INST_SEG_SCAN
 
@@ -1498,7 +1498,7 @@ k_seg_merge(const uint32_t *__restrict__ frag_list, int n_list, const uint64_t *
             const uint64_t *__restrict__ u_tmp, const AlAnchor *__restrict__ chain_tmp, const uint64_t *__restrict__ a_off,
             uint64_t *__restrict__ u_out, AlAnchor *__restrict__ chained, uint32_t *__restrict__ frag_nu,
             uint32_t *__restrict__ fb_list, uint32_t *__restrict__ fb_cnt, const uint32_t *__restrict__ tie_flag,
-            const uint64_t *__restrict__ okey_tmp, uint64_t *__restrict__ okey_out, int big_from /* NW == 1: the NW = 8 launch covers the list entries from this one on */)
+            const uint64_t *__restrict__ okey_tmp, uint64_t *__restrict__ okey_out, int big_from /* NW == 1: the NW = 8 launch covers the list entries from this one on */, int big_n /* segments above which the NW = 8 launch takes a fragment */)
 {
 	__shared__ uint32_t s_bu_[NW][64], s_bc_[NW][64];
 	__shared__ uint64_t s_off_[NW][64], s_u1_[NW][64];
@@ -1509,7 +1509,7 @@ k_seg_merge(const uint32_t *__restrict__ frag_list, int n_list, const uint64_t *
 	const uint32_t f = frag_list[blockIdx.x];
 	if (tie_flag && tie_flag[f]) return;                                       // the side stream writes this fragment's chains
 	const uint64_t s0 = seg_first[blockIdx.x], s1 = seg_first[blockIdx.x + 1];
-	if (NW > 1 ? s1 - s0 <= AL_SEGM_BIG : (s1 - s0 > AL_SEGM_BIG && (int)blockIdx.x >= big_from)) return;   // the other instantiation's fragment
+	if (NW > 1 ? s1 - s0 <= (uint64_t)big_n : (s1 - s0 > (uint64_t)big_n && (int)blockIdx.x >= big_from)) return;   // the other instantiation's fragment
 	uint32_t *const s_bu = s_bu_[w], *const s_bc = s_bc_[w]; uint64_t *const s_off = s_off_[w], *const s_u1 = s_u1_[w];
 	// this wavefront's slice of the segments (whole groups of 64)
 	uint64_t w0 = s0, w1 = s1;
@@ -1563,8 +1563,8 @@ k_seg_merge(const uint32_t *__restrict__ frag_list, int n_list, const uint64_t *
 		if (any_tie && run_u > 64) fb_list[atomicAdd(fb_cnt, 1u)] = f;
 	}
 }
-template __global__ void k_seg_merge<1>(const uint32_t *, int, const uint64_t *, const uint64_t *, const uint4 *, const uint64_t *, const AlAnchor *, const uint64_t *, uint64_t *, AlAnchor *, uint32_t *, uint32_t *, uint32_t *, const uint32_t *, const uint64_t *, uint64_t *, int);
-template __global__ void k_seg_merge<8>(const uint32_t *, int, const uint64_t *, const uint64_t *, const uint4 *, const uint64_t *, const AlAnchor *, const uint64_t *, uint64_t *, AlAnchor *, uint32_t *, uint32_t *, uint32_t *, const uint32_t *, const uint64_t *, uint64_t *, int);
+template __global__ void k_seg_merge<1>(const uint32_t *, int, const uint64_t *, const uint64_t *, const uint4 *, const uint64_t *, const AlAnchor *, const uint64_t *, uint64_t *, AlAnchor *, uint32_t *, uint32_t *, uint32_t *, const uint32_t *, const uint64_t *, uint64_t *, int, int);
+template __global__ void k_seg_merge<8>(const uint32_t *, int, const uint64_t *, const uint64_t *, const uint4 *, const uint64_t *, const AlAnchor *, const uint64_t *, uint64_t *, AlAnchor *, uint32_t *, uint32_t *, uint32_t *, const uint32_t *, const uint64_t *, uint64_t *, int, int);
 
 // k_chain_order: the reference's order of a fragment's chains when some of them start at anchors of equal x and there are more than
 // 64 of them -- its sort (radix_sort_128x, ksort.h:116-151) is not stable, so the order among the equal ones depends on where every

@@ -31,8 +31,8 @@ template <int CAPL, int LANES> __global__ void k_chain_lds(const AlAnchor *, con
 template <int PER, int NW, int MCAP> __global__ void k_anchor_sort_reg(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, uint32_t *, const uint32_t *, int, int, int);
 __global__ void k_anchor_big_expand(const uint64_t *, const uint64_t *, const uint32_t *, const AlMatch *, const uint32_t *, const uint32_t *, int, const uint64_t *, uint64_t *, int, int);
 __global__ void k_anchor_big_scatter(const uint64_t *, const uint32_t *, int, const uint64_t *, const uint64_t *, const uint64_t *, const uint32_t *, const uint32_t *, const AlMatch *, const uint32_t *, AlAnchor *, uint32_t *, int, int, int);
-template <int NW> __global__ void k_seg_scan(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *, int, AlParams, int, int, const uint64_t *, const uint64_t *, uint32_t *, uint32_t *, uint64_t *, uint32_t *, uint32_t *, const uint32_t *, uint32_t *, uint32_t *, uint32_t *, int);
-template <int NW> __global__ void k_seg_merge(const uint32_t *, int, const uint64_t *, const uint64_t *, const uint4 *, const uint64_t *, const AlAnchor *, const uint64_t *, uint64_t *, AlAnchor *, uint32_t *, uint32_t *, uint32_t *, const uint32_t *, const uint64_t *, uint64_t *, int);
+template <int NW> __global__ void k_seg_scan(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *, int, AlParams, int, int, const uint64_t *, const uint64_t *, uint32_t *, uint32_t *, uint64_t *, uint32_t *, uint32_t *, const uint32_t *, uint32_t *, uint32_t *, uint32_t *, int, int);
+template <int NW> __global__ void k_seg_merge(const uint32_t *, int, const uint64_t *, const uint64_t *, const uint4 *, const uint64_t *, const AlAnchor *, const uint64_t *, uint64_t *, AlAnchor *, uint32_t *, uint32_t *, uint32_t *, const uint32_t *, const uint64_t *, uint64_t *, int, int);
 __global__ void k_chain_order(const uint32_t *, int, const uint64_t *, const uint32_t *, uint64_t *, AlAnchor *, const uint64_t *, uint64_t *, AlAnchor *, uint32_t *, uint32_t *, int32_t *);
 __global__ void k_lower_bounds(const uint32_t *, uint32_t, LbThr, uint32_t *);
 __global__ void k_collect_flagged(const uint32_t *, int, const uint32_t *, uint32_t *, uint32_t *);
@@ -392,13 +392,16 @@ static int chain_by_segments(al_ctx_t *c, const uint32_t *order, int n, bool lds
 	{ const int per = c->mi->k + 1, need = (c->opt.min_chain_score + per - 1) / per; if (need > lmin) lmin = need; }
 	if (c->seg_cnt.ensure((size_t)n + 2) || c->seg_first.ensure((size_t)n + 2) || c->seg_cnt0.ensure((size_t)n + 2) || c->seg_first0.ensure((size_t)n + 2)) return -1;
 	// (fragments of more than AL_SEGS_BIG anchors: eight wavefronts each, launched first; big8_from: the entries before it have at most 8192 anchors)
+	// (tests lower the two sizes so that ordinary fragments take the eight-wavefront forms; the list positions are then no bound any more)
+	static const int segs_big = getenv("AL_TEST_SEG_BIG") ? atoi(getenv("AL_TEST_SEG_BIG")) : 8192, segm_big = getenv("AL_TEST_SEG_BIG") ? std::max(1, atoi(getenv("AL_TEST_SEG_BIG")) / 8) : 1024;
+	if (getenv("AL_TEST_SEG_BIG")) { big_from = 0; big8_from = 0; }
 	if (big8_from < 0 || big8_from > n) big8_from = 0;
 	if (n > big8_from) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_seg_scan<8>), dim3(n - big8_from), dim3(512), 0, s, c->anchors.p, c->a_off.p, c->frag_na.p, c->frag_first.p, c->rd_len.p, order + big8_from, n - big8_from, c->P, lmin, 0,
 	                   (const uint64_t *)nullptr, (const uint64_t *)nullptr, c->seg_cnt.p + big8_from, c->seg_cnt0.p + big8_from, (uint64_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, skip_flag,
-	                   (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, big8_from);
+	                   (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, big8_from, segs_big);
 	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_seg_scan<1>), dim3(n), dim3(64), 0, s, c->anchors.p, c->a_off.p, c->frag_na.p, c->frag_first.p, c->rd_len.p, order, n, c->P, lmin, 0,
 	                   (const uint64_t *)nullptr, (const uint64_t *)nullptr, c->seg_cnt.p, c->seg_cnt0.p, (uint64_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, skip_flag,
-	                   (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, big8_from);
+	                   (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, big8_from, segs_big);
 	AL_HIP_CHECK(hipMemsetAsync(c->seg_cnt.p + n, 0, 4, s)); AL_HIP_CHECK(hipMemsetAsync(c->seg_cnt0.p + n, 0, 4, s));
 	if (scan_u32_to_u64(c, c->seg_cnt.p, c->seg_first.p, n) || scan_u32_to_u64(c, c->seg_cnt0.p, c->seg_first0.p, n)) return -1;
 	uint64_t ns64 = 0, ns0_64 = 0;
@@ -412,10 +415,10 @@ static int chain_by_segments(al_ctx_t *c, const uint32_t *order, int n, bool lds
 	    c->seg_idx.ensure((size_t)ns0 + 1) || c->vs_cls.ensure((size_t)n1 + 1) || c->seg_t1.ensure((size_t)n1 + 1) || c->seg_key.ensure((size_t)n1 + 1) || c->seg_ord.ensure((size_t)n1 + 1) || c->fb_list.ensure((size_t)n + 2)) return -1;
 	if (n > big8_from) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_seg_scan<8>), dim3(n - big8_from), dim3(512), 0, s, c->anchors.p, c->a_off.p, c->frag_na.p, c->frag_first.p, c->rd_len.p, order + big8_from, n - big8_from, c->P, lmin, 1,
 	                   (const uint64_t *)c->seg_first.p + big8_from, (const uint64_t *)c->seg_first0.p + big8_from, (uint32_t *)nullptr, (uint32_t *)nullptr, c->vs_off.p, c->vs_na.p, c->vs_meta.p, skip_flag,
-	                   c->seg_idx.p, c->seg_t1.p, c->vs_cls.p, big8_from);
+	                   c->seg_idx.p, c->seg_t1.p, c->vs_cls.p, big8_from, segs_big);
 	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_seg_scan<1>), dim3(n), dim3(64), 0, s, c->anchors.p, c->a_off.p, c->frag_na.p, c->frag_first.p, c->rd_len.p, order, n, c->P, lmin, 1,
 	                   (const uint64_t *)c->seg_first.p, (const uint64_t *)c->seg_first0.p, (uint32_t *)nullptr, (uint32_t *)nullptr, c->vs_off.p, c->vs_na.p, c->vs_meta.p, skip_flag,
-	                   c->seg_idx.p, c->seg_t1.p, c->vs_cls.p, big8_from);
+	                   c->seg_idx.p, c->seg_t1.p, c->vs_cls.p, big8_from, segs_big);
 	uint32_t lb[8] = {0, 0, 0, 0, 0, 0, 0, 0};                                // starts of classes 2 .. 9 in the class-ordered list of the n1 others
 	if (n1 > 0) {
 		{   // stable sort by size class only (4 bits: one radix pass)
@@ -466,9 +469,9 @@ static int chain_by_segments(al_ctx_t *c, const uint32_t *order, int n, bool lds
 	// (the fragments with many segments first: eight wavefronts each, next to the one-wavefront launch of the others)
 	if (big_from < 0 || big_from > n) big_from = 0;
 	if (n > big_from) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_seg_merge<8>), dim3(n - big_from), dim3(512), 0, s, order + big_from, n - big_from, c->seg_first.p + big_from, c->vs_off.p, (const uint4 *)c->vs_res.p, c->u_tmp.p, c->chain_tmp.p, c->a_off.p,
-	                   c->u.p, c->chained.p, c->frag_nu.p, c->fb_list.p, fb_cnt, skip_flag, keep_keys ? (const uint64_t *)c->okey_tmp.p : nullptr, c->ws_u64.p, big_from);
+	                   c->u.p, c->chained.p, c->frag_nu.p, c->fb_list.p, fb_cnt, skip_flag, keep_keys ? (const uint64_t *)c->okey_tmp.p : nullptr, c->ws_u64.p, big_from, segm_big);
 	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_seg_merge<1>), dim3(n), dim3(64), 0, s, order, n, c->seg_first.p, c->vs_off.p, (const uint4 *)c->vs_res.p, c->u_tmp.p, c->chain_tmp.p, c->a_off.p,
-	                   c->u.p, c->chained.p, c->frag_nu.p, c->fb_list.p, fb_cnt, skip_flag, keep_keys ? (const uint64_t *)c->okey_tmp.p : nullptr, c->ws_u64.p, big_from);
+	                   c->u.p, c->chained.p, c->frag_nu.p, c->fb_list.p, fb_cnt, skip_flag, keep_keys ? (const uint64_t *)c->okey_tmp.p : nullptr, c->ws_u64.p, big_from, segm_big);
 	uint32_t n_fb = 0;
 	AL_HIP_CHECK(hipMemcpyAsync(&n_fb, fb_cnt, 4, hipMemcpyDeviceToHost, s));
 	AL_HIP_CHECK(hipStreamSynchronize(s));

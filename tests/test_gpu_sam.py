@@ -74,8 +74,10 @@ def test_lds_dp_path_identical(golden_unpacked, name):
 
 
 @pytest.mark.parametrize("env", [dict(AL_DBG=str(1 << 27)), dict(AL_TEST_SORT_BLK="65"), dict(AL_TEST_SORT_BIG="65"), dict(AL_TEST_SORT_BLK="65", AL_TEST_SORT_BIG="200"),
-                                 dict(AL_TEST_SORT_BIG="65", AL_TEST_BIG_CHUNK="3"), dict(AL_TEST_HEAP_WAVE="1"), dict(AL_CHAIN_WAVE_MAX="0")],
-                         ids=["segments_wave_only", "block_sort", "device_sort", "block_and_device_sort", "device_sort_chunks", "heap_merge_by_wavefront", "lds_chain_kernels_for_thin_classes"])
+                                 dict(AL_TEST_SORT_BIG="65", AL_TEST_BIG_CHUNK="3"), dict(AL_TEST_HEAP_WAVE="1"), dict(AL_CHAIN_WAVE_MAX="0"),
+                                 dict(AL_TEST_SEG_BIG="160", AL_DBG=str(1 << 27)), dict(AL_TEST_SEG_BIG="64", AL_TEST_POISON="170", AL_TEST_GUARD="1")],
+                         ids=["segments_wave_only", "block_sort", "device_sort", "block_and_device_sort", "device_sort_chunks", "heap_merge_by_wavefront", "lds_chain_kernels_for_thin_classes",
+                              "cut_and_merge_by_eight_wavefronts_all_fragments", "cut_and_merge_by_eight_wavefronts_poisoned_memory"])
 @pytest.mark.parametrize("name", ["g1_mt150pe", "g2_250pe", "g3_adversarial", "g6_repeats"])
 def test_large_fragment_paths_identical(golden_unpacked, name, env):
     """The kernels that take over for fragments with many anchors -- chaining by segments (AL_DBG bit 27: every fragment goes
@@ -89,6 +91,7 @@ def test_large_fragment_paths_identical(golden_unpacked, name, env):
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     exp = open(os.path.join(d, "expected.sam"), "rb").read()
     assert r.stdout == exp, _diff_report(r.stdout, exp, name + "_" + "_".join(env))
+    assert b"GUARD:" not in r.stderr, r.stderr.decode()[-1500:]
 
 
 @pytest.mark.parametrize("name", ["g1_mt150pe", "g3_adversarial", "g6_repeats"])
