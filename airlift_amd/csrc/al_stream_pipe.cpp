@@ -198,7 +198,7 @@ int al_stream_map_files(const al_idx_t *mi, int n_fn, const char **fn, const al_
 	std::atomic<int> reads_cap_k{1 << 30};                 // mini_batch_size in reads, once a read length is known
 	std::atomic<long long> est_total_reads{0};             // from the file sizes and the bytes per read of the first batch
 	max_reads = (int)std::max<int64_t>(2, std::min<int64_t>(probe_reads, k_bases / 64));   // batch 0 (-K is an upper bound: reads of >= 64 bases assumed until a batch has been seen); the following ones 4 x the probe until the size is decided
-	double probe_held0 = 0, probe_n0 = 0;
+	double probe_held0 = 0, probe_n0 = 0; int probe_mult = 0;
 	if (getenv("AL_BATCH_READS")) { max_reads = std::max(2, atoi(getenv("AL_BATCH_READS"))); sized = true; }    // tests / tuning: fixed batches
 
 	// SAM text leaves the device through a small ring of page-locked buffers (page-locking memory costs ~0.2 s per GB: no buffer of a
@@ -377,7 +377,15 @@ int al_stream_map_files(const al_idx_t *mi, int n_fn, const char **fn, const al_
 			}
 			al_acct() = &sl->held;
 			AlStreamSlot &S = sl->S;
-			const int mr = (!sized.load() && k > 0) ? std::min(4 * probe_reads, reads_cap_k.load()) : max_reads.load();
+			// The second batch is the size the run keeps unless the input is long (growing later re-obtains every workspace): 4 x the first
+			// probe, 8 x when the input has at least 6 M reads and this process has been getting device memory fast so far (index, slots).
+			if (k == 1 && probe_mult == 0) {
+				probe_mult = 4;
+				if (getenv("AL_PROBE_MULT")) probe_mult = std::max(1, atoi(getenv("AL_PROBE_MULT")));
+				else { const AlAllocStat &as = al_alloc_stat(); const double ns = (double)as.dev_ns.load(), by = (double)as.dev_bytes.load();
+				       if (est_total_reads.load() / NL >= 6000000 && ns > 0 && by / (ns * 1e-9) >= 100e9) probe_mult = 8; }
+			}
+			const int mr = (!sized.load() && k > 0) ? std::min((probe_mult ? probe_mult : 4) * probe_reads, reads_cap_k.load()) : max_reads.load();
 			int err = 0;
 			const double t1 = now_s();
 			for (int i = 0; i < n_fn && !err; ++i) {
