@@ -199,6 +199,7 @@ int al_stream_map_files(const al_idx_t *mi, int n_fn, const char **fn, const al_
 	std::atomic<long long> est_total_reads{0};             // from the file sizes and the bytes per read of the first batch
 	max_reads = (int)std::max<int64_t>(2, std::min<int64_t>(probe_reads, k_bases / 64));   // batch 0 (-K is an upper bound: reads of >= 64 bases assumed until a batch has been seen); the following ones 4 x the probe until the size is decided
 	double probe_held0 = 0, probe_n0 = 0; int probe_mult = 0;
+	std::atomic<bool> single_probe{false};               // a long input (by its file sizes): no small first batch, the first batch already has the size the run keeps
 	if (getenv("AL_BATCH_READS")) { max_reads = std::max(2, atoi(getenv("AL_BATCH_READS"))); sized = true; }    // tests / tuning: fixed batches
 
 	// SAM text leaves the device through a small ring of page-locked buffers (page-locking memory costs ~0.2 s per GB: no buffer of a
@@ -283,8 +284,9 @@ int al_stream_map_files(const al_idx_t *mi, int n_fn, const char **fn, const al_
 				// Sizing (first context of the first lane): its first batch is a small probe, its second a larger one; what the two held and
 				// how long the second ran give workspace bytes and time per read.
 				if (!sized.load() && mp->lane == 0 && mp->idx == 0) {
-					if (mp->n_batch == 1) { probe_held0 = (double)mp->held.load(); probe_n0 = (double)res.n_reads; }
+					if (mp->n_batch == 1 && !single_probe.load()) { probe_held0 = (double)mp->held.load(); probe_n0 = (double)res.n_reads; }
 					else {
+						if (single_probe.load() && mp->n_batch == 1) { probe_n0 = 0; probe_held0 = std::min(1.0e9, 0.25 * (double)mp->held.load()); }   // one point: the part that does not grow with the batch is taken as 1 GB (measured 0.8 - 1.5)
 						size_t free_b = 0, total_b = 0;
 						if (hipSetDevice(mp->device) == hipSuccess && hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
 							size_t held_ctx = 0; for (auto &o : mappers) if (o->device == mp->device) held_ctx += o->held.load();
@@ -379,6 +381,16 @@ int al_stream_map_files(const al_idx_t *mi, int n_fn, const char **fn, const al_
 			AlStreamSlot &S = sl->S;
 			// The second batch is the size the run keeps unless the input is long (growing later re-obtains every workspace): 4 x the first
 			// probe, 8 x when the input has at least 6 M reads and this process has been getting device memory fast so far (index, slots).
+			if (k == 0 && !sized.load() && !getenv("AL_PROBE_READS") && !getenv("AL_PROBE_MULT")) {
+				double fs = 0; for (int i = 0; i < n_fn; ++i) fs += (double)rd[i]->file_size();
+				const double est0 = fs / bytes_per_read / (double)NL;                 // (360 bytes per read until a batch has been seen)
+				if (est0 >= 1.0e6) {
+					const AlAllocStat &as = al_alloc_stat(); const double ns = (double)as.dev_ns.load(), by = (double)as.dev_bytes.load();
+					probe_mult = est0 >= 6.0e6 && ns > 0 && by / (ns * 1e-9) >= 100e9 ? 8 : 4;
+					single_probe = true;
+					max_reads = (int)std::max<int64_t>(2, std::min<int64_t>((int64_t)probe_mult * probe_reads, k_bases / 64));
+				}
+			}
 			if (k == 1 && probe_mult == 0) {
 				probe_mult = 4;
 				if (getenv("AL_PROBE_MULT")) probe_mult = std::max(1, atoi(getenv("AL_PROBE_MULT")));
