@@ -381,12 +381,12 @@ int al_stream_map_files(const al_idx_t *mi, int n_fn, const char **fn, const al_
 			AlStreamSlot &S = sl->S;
 			// The second batch is the size the run keeps unless the input is long (growing later re-obtains every workspace): 4 x the first
 			// probe, 8 x when the input has at least 6 M reads and this process has been getting device memory fast so far (index, slots).
-			if (k == 0 && !sized.load() && !getenv("AL_PROBE_READS") && !getenv("AL_PROBE_MULT")) {
+			if (k == 0 && !sized.load() && !getenv("AL_PROBE_READS") && !getenv("AL_TWO_PROBES")) {
 				double fs = 0; for (int i = 0; i < n_fn; ++i) fs += (double)rd[i]->file_size();
 				const double est0 = fs / bytes_per_read / (double)NL;                 // (360 bytes per read until a batch has been seen)
 				if (est0 >= 1.0e6) {
 					const AlAllocStat &as = al_alloc_stat(); const double ns = (double)as.dev_ns.load(), by = (double)as.dev_bytes.load();
-					probe_mult = est0 >= 6.0e6 && ns > 0 && by / (ns * 1e-9) >= 100e9 ? 8 : 4;
+					probe_mult = getenv("AL_PROBE_MULT") ? std::max(1, atoi(getenv("AL_PROBE_MULT"))) : est0 >= 6.0e6 && ns > 0 && by / (ns * 1e-9) >= 100e9 ? 8 : 4;
 					single_probe = true;
 					max_reads = (int)std::max<int64_t>(2, std::min<int64_t>((int64_t)probe_mult * probe_reads, k_bases / 64));
 				}
