@@ -35,7 +35,8 @@ template <typename T> struct DevBuf {       // grow-only device array
 	{
 		if (n <= cap) return 0;
 		al_alloc_site() = AlAllocSite{file, line};
-		const size_t ncap = n + n / 4 + 64;
+		static const size_t big_div = getenv("AL_GROW_DIV") ? (size_t)std::max(1, atoi(getenv("AL_GROW_DIV"))) : 8;
+		const size_t ncap = n + (n * sizeof(T) >= ((size_t)256 << 20) ? n / big_div : n / 4) + 64;   // headroom against regrowing: an eighth for the large arrays (batches of one run differ by a few per cent), a quarter for the small
 		T *np = nullptr;
 		if (!keep && p) { al_dev_free(p); p = nullptr; cap = 0; }         // contents not needed: release first, so the peak is one copy
 		if (al_dev_malloc((void **)&np, ncap * sizeof(T)) != hipSuccess) {
@@ -98,7 +99,7 @@ struct al_ctx_s {
 	bool dev_batch = false;               // the batch was parsed and packed on the device (al_stream.hip): no host mirrors of the read arrays
 	DevBuf<uint64_t> a_off_p1; DevBuf<uint32_t> frag_na_p1; DevBuf<int32_t> frag_rep_p1;   // pass-1 snapshots when a re-chain pass ran (taps)
 	uint64_t n_anchor_total = 0, n_anchor_pass1 = 0;
-	double anchor_grow_hw = 1.0;          // largest (anchors after the re-seeding pass) / (anchors of the first pass) this context has seen: the first pass reserves for it, so that the second does not reallocate
+	double anchor_grow_hw = 1.3;          // (starts at what a repeat-rich genome needs: C4 1.26; a batch without re-seeded fragments leaves it unused) largest (anchors after the re-seeding pass) / (anchors of the first pass) this context has seen: the first pass reserves for it, so that the second does not reallocate
 	uint32_t n_rechain = 0;
 
 	// alignment stage (al_kernels_align.hip)
