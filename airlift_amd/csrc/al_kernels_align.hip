@@ -2554,6 +2554,23 @@ int al_run_align_stage(al_ctx_t *c)
 			// one launch per job class over its slice of the sorted job list
 			static const int NBs[6] = {1, 2, 4, 8, 22, 32};
 			uint32_t first = 0;
+			{   // one workspace range for every class of this batch: sized for the largest now, not grown class by class (a regrow frees -- and waits for -- what the running class uses)
+				size_t need = 0;
+				for (int cls = 0; cls < AL_NCLS; ++cls) {
+					const uint32_t cnt = (uint32_t)hist[cls]; if (cnt == 0) continue;
+					size_t b;
+					if (cls < 3) { const int TC = 16 << cls; int nw = (int)((cnt + 63) / 64); if (nw > 1024) nw = 1024; b = (size_t)nw * ((size_t)(AL_LANE_QC + TC) * (size_t)(TC + 16) * 64); }
+					else if (cls < 9) {
+						const int NB = NBs[cls - 3];
+						const size_t pb = (((size_t)(Lmax + 16 * NB) * (size_t)(NB + 1) * 16) + 63) / 64 * 64, cw = ((size_t)(Lmax + 16 * NB) + 31) / 16 * 16, st2 = pb + cw * 8;
+						const int cap = NB <= 4 ? (getenv("AL_CAP4") ? atoi(getenv("AL_CAP4")) : 4096) : NB <= 8 ? (getenv("AL_CAP8") ? atoi(getenv("AL_CAP8")) : 4096) : NB <= 22 ? (getenv("AL_CAP22") ? atoi(getenv("AL_CAP22")) : 3072) : 2048;
+						int nbj = (int)((cnt + 3) / 4); if (nbj > cap) nbj = cap;
+						b = (size_t)nbj * 4 * st2;
+					} else { int nbj = (int)cnt; if (nbj > 2048) nbj = 2048; b = (size_t)nbj * stride; }
+					if (b > need) need = b;
+				}
+				if (need && A->gws.ensure(need + 64)) return -1;
+			}
 			for (int cls = 0; cls < AL_NCLS; ++cls) {
 				const uint32_t cnt = (uint32_t)hist[cls];
 				if (cls == 3) AL_HIP_CHECK(hipEventRecord(c->ev[ST_EXT_DP_LANE + 1], s));
