@@ -621,8 +621,12 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 		for (int i = 0; i < 3; ++i) AL_HIP_CHECK(hipStreamWaitEvent(c->aux[i], c->ev_fj[0], 0));
 #define LHEAP(H, LN, LO, ST) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_anchor_heap<H, LN>), dim3((nl + LN - 1) / LN), dim3(64), 0, ST, c->di.pos, c->frag_first.p, c->rd_len.p, c->mini_off.p, c->match.p, c->frag_nm.p, c->frag_na.p, \
 		                                  c->a_off.p, c->anchors.p, c->heap_ws.p, c->tie_list.p, (const uint32_t *)c->tie_frags.p, nl, LO, c->counters.p, c->mi->k, (const uint32_t *)n_heap_d, wave_na_min)
-		static const uint32_t wave_na_min = getenv("AL_TEST_HEAP_WAVE") ? (uint32_t)atoi(getenv("AL_TEST_HEAP_WAVE")) : 16384u;   // (tests lower it so that small fragments take the wavefront form)
-		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_anchor_heap_wave<128, 32>), dim3(std::min(nl, 2048)), dim3(64), 0, c->side, c->di.pos, c->frag_first.p, c->rd_len.p, c->mini_off.p, c->match.p, c->frag_nm.p, c->frag_na.p,
+		// A lane of the lane kernels pops ~1 us per anchor with its 63 neighbours busy, the wavefront kernel 0.8 us with a wavefront to itself: in a
+		// small batch the lane kernels' longest fragment is what the main stream ends up waiting for (131 k pairs of C4: 18 -> 11 ms with the bound
+		// at 8192 anchors), in a large one the wavefront kernel's share is (C5, 500 k pairs: 652 vs 672 ms): the bound follows the batch.
+		static const int wave_env = getenv("AL_TEST_HEAP_WAVE") ? atoi(getenv("AL_TEST_HEAP_WAVE")) : -1;                           // (tests lower it so that small fragments take the wavefront form)
+		const uint32_t wave_na_min = wave_env >= 0 ? (uint32_t)wave_env : c->n_frag >= 400000 ? 16384u : 8192u;
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_anchor_heap_wave<128, 32>), dim3(std::min(nl, 65536)), dim3(64), 0, c->side, c->di.pos, c->frag_first.p, c->rd_len.p, c->mini_off.p, c->match.p, c->frag_nm.p, c->frag_na.p,
 		                   c->a_off.p, c->anchors.p, (const uint32_t *)c->tie_list.p, (const uint32_t *)c->tie_frags.p, (const uint32_t *)n_heap_d, wave_na_min, c->counters.p, c->mi->k);
 		LHEAP(48, 64, -1, c->aux[0]); LHEAP(96, 32, 48, c->aux[1]); LHEAP(0, 64, 96, c->aux[2]);
 #undef LHEAP
