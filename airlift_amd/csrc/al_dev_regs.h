@@ -68,11 +68,13 @@ AL_D void d_reg_clear(AlReg *r) { int32_t *p = (int32_t *)r; for (int i = 0; i <
 
 // mm_gen_regs, hit.c:52-88.  z: scratch of n_u AlAnchor, followed by AL_RS_SCRATCH bytes when n_u > 64 (the work areas
 // hold 4*n_u+4 entries).  Returns true if the sort order could not be reproduced.
-AL_D bool d_gen_regs(uint32_t hash, int qlen, int n_u, const uint64_t *u, const AlAnchor *a, AlReg *r, AlAnchor *z)
+// uo: offset of every chain's first anchor in a[] (nullptr: the chains' anchors follow one another)
+AL_D bool d_gen_regs(uint32_t hash, int qlen, int n_u, const uint64_t *u, const AlAnchor *a, AlReg *r, AlAnchor *z, const uint32_t *uo = nullptr)
 {
 	if (n_u == 0) return false;
 	int k = 0;
 	for (int i = 0; i < n_u; ++i) {
+		if (uo) k = (int)uo[i];
 		const uint32_t h = (uint32_t)d_hash64((d_hash64(a[k].x) + d_hash64(a[k].y)) ^ hash);
 		z[i].x = u[i] ^ h;
 		z[i].y = (uint64_t)k << 32 | (uint32_t)(int32_t)u[i];

@@ -840,7 +840,7 @@ struct RegsSelShared {
 };
 template <int CAP>      // CAP > 0: sort tile in LDS; 0: at most 64 chains, registers; < 0: sort keys in the fragment's global work area (any count)
 __global__ void __launch_bounds__(CAP == 0 ? 64 : CAP < 0 ? 1024 : 256)
-k_regs_select(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__ u_all, const uint32_t *__restrict__ frag_first,
+k_regs_select(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__ u_all, const uint32_t *__restrict__ uo_all, const uint32_t *__restrict__ frag_first,
               const uint32_t *__restrict__ rd_len, const uint32_t *__restrict__ frag_hash, WsBase W, const uint32_t *__restrict__ list, int n_list,
               AlParams P, uint32_t *__restrict__ regs_n0)
 {
@@ -860,34 +860,21 @@ k_regs_select(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__
 	IdxT *const sidx = CAP > 0 ? (IdxT *)sidx_l : (IdxT *)(ws.auxi + (4 * n_u + 4));
 	const int ql0 = (int)rd_len[r0], ql1 = n_segs > 1 ? (int)rd_len[r0 + 1] : 0, qlen = ql0 + ql1;
 	const AlAnchor *a = chained + W.a_off[f]; const uint64_t *u = u_all + W.a_off[f] + f;
+	const uint32_t *const as_arr = uo_all + W.a_off[f] + f;                  // first anchor of chain c: carried by the chain list (the chaining kernels write every chain at its segment's place)
 	const uint32_t fhash = frag_hash[f];
 	int max_gap_ref;
 	if (P.max_gap_ref > 0) max_gap_ref = P.max_gap_ref;
 	else if (P.max_frag_len > 0) { max_gap_ref = P.max_frag_len - qlen; if (max_gap_ref < P.max_gap) max_gap_ref = P.max_gap; }
 	else max_gap_ref = P.max_gap;
-	int32_t *const as_arr = ws.auxi;                                        // first anchor of chain c (capacity 2 * (4 n_u + 4) ints)
-	// ---- keys: (u ^ hash of the chain's first anchor), chain offsets by a running prefix sum ----
+	// ---- keys: (u ^ hash of the chain's first anchor) ----
 	uint64_t key_r = 0; int idx_r = 0;                                      // n_u <= 64: lane's own entry
 	{
-		uint32_t run = 0;
-		if (tid < 64)                                                        // chain offsets: the first wavefront walks the counts
-		for (int c0 = 0; c0 < n_u; c0 += 64) {
-			const int c = c0 + lane; const bool v = c < n_u;
-			const uint64_t uc = v ? u[c] : 0; const uint32_t cnt = (uint32_t)uc;
-			uint32_t incl = cnt;
-			for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(incl, d); if (lane >= d) incl += t; }
-			const uint32_t as = run + incl - cnt;
-			run += __shfl(incl, 63);
-			if (v) {
-				as_arr[c] = (int32_t)as;
-				if (CAP == 0) {
-					const AlAnchor fa = a[as];
-					key_r = uc ^ (uint32_t)d_hash64((d_hash64(fa.x) + d_hash64(fa.y)) ^ fhash); idx_r = c;
-				}
+		if (CAP == 0) {
+			if (lane < n_u) {
+				const uint64_t uc = u[lane]; const AlAnchor fa = a[as_arr[lane]];
+				key_r = uc ^ (uint32_t)d_hash64((d_hash64(fa.x) + d_hash64(fa.y)) ^ fhash); idx_r = lane;
 			}
-		}
-		if (CAP != 0) {                                                      // keys: every thread of the block (one dependent load each)
-			__syncthreads();
+		} else {                                                             // keys: every thread of the block (two dependent loads each)
 			for (int c = tid; c < n_u; c += NT) { const AlAnchor fa = a[as_arr[c]]; skey[c] = u[c] ^ (uint32_t)d_hash64((d_hash64(fa.x) + d_hash64(fa.y)) ^ fhash); sidx[c] = (IdxT)c; }
 		}
 	}
@@ -940,7 +927,7 @@ k_regs_select(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__
 			__syncthreads();
 		}
 		for (int p = tid; p < n_u; p += NT) {
-			const int c = (int)sidx[p]; const int cnt = (int)(uint32_t)u[c], as = as_arr[c];
+			const int c = (int)sidx[p]; const int cnt = (int)(uint32_t)u[c], as = (int)as_arr[c];
 			const AlAnchor fa = a[as], la = a[as + cnt - 1];
 			const int q_span = (int)(fa.y >> 32 & 0xff), rev = (int)(fa.x >> 63), rid = (int)(fa.x << 1 >> 33);
 			int4 g;
@@ -985,7 +972,7 @@ k_regs_select(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__
 			const int4 g = G1[p]; const int rr = G2[p];
 			qs = g.x; qe = g.y; rs = g.z; re = g.w; rid = rr >> 1; rev = rr & 1; cnt = G3[p]; as = G4[p];
 		} else if (v) {
-			cnt = (int)(uint32_t)u[c]; as = as_arr[c];
+			cnt = (int)(uint32_t)u[c]; as = (int)as_arr[c];
 			const AlAnchor fa = a[as], la = a[as + cnt - 1];
 			const int q_span = (int)(fa.y >> 32 & 0xff);
 			rev = (int)(fa.x >> 63); rid = (int)(fa.x << 1 >> 33);
@@ -1139,12 +1126,12 @@ k_regs_select(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__
 	}
 	if (lane == 0) regs_n0[f] = (uint32_t)n0;
 }
-template __global__ void k_regs_select<0>(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, WsBase, const uint32_t *, int, AlParams, uint32_t *);
-template __global__ void k_regs_select<1024>(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, WsBase, const uint32_t *, int, AlParams, uint32_t *);
-template __global__ void k_regs_select<2048>(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, WsBase, const uint32_t *, int, AlParams, uint32_t *);
-template __global__ void k_regs_select<4096>(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, WsBase, const uint32_t *, int, AlParams, uint32_t *);
-template __global__ void k_regs_select<8192>(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, WsBase, const uint32_t *, int, AlParams, uint32_t *);
-template __global__ void k_regs_select<-1>(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, WsBase, const uint32_t *, int, AlParams, uint32_t *);
+template __global__ void k_regs_select<0>(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *, WsBase, const uint32_t *, int, AlParams, uint32_t *);
+template __global__ void k_regs_select<1024>(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *, WsBase, const uint32_t *, int, AlParams, uint32_t *);
+template __global__ void k_regs_select<2048>(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *, WsBase, const uint32_t *, int, AlParams, uint32_t *);
+template __global__ void k_regs_select<4096>(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *, WsBase, const uint32_t *, int, AlParams, uint32_t *);
+template __global__ void k_regs_select<8192>(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *, WsBase, const uint32_t *, int, AlParams, uint32_t *);
+template __global__ void k_regs_select<-1>(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *, WsBase, const uint32_t *, int, AlParams, uint32_t *);
 
 __global__ void __launch_bounds__(256)
 k_regs_cap2(const uint32_t *__restrict__ frag_nu, const uint32_t *__restrict__ regs_n0, int n_frag, uint32_t *__restrict__ cap2)
@@ -1281,7 +1268,7 @@ k_regs_heavy(const AlAnchor *__restrict__ chained, const uint32_t *__restrict__ 
 }
 
 extern "C" __global__ void __launch_bounds__(256, AL_LB_REGS)
-k_regs(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__ u_all, const uint32_t *__restrict__ frag_first,
+k_regs(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__ u_all, const uint32_t *__restrict__ uo_all, const uint32_t *__restrict__ frag_first,
        const uint32_t *__restrict__ rd_len, const uint32_t *__restrict__ frag_hash, WsBase W, int n_frag, AlParams P, unsigned long long *counters,
        const uint32_t *__restrict__ regs_n0)
 {
@@ -1297,7 +1284,7 @@ k_regs(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__ u_all,
 	FragWs ws; d_frag_ws(W, f, ws);
 	const int ql0 = (int)rd_len[r0], ql1 = n_segs > 1 ? (int)rd_len[r0 + 1] : 0;
 	const int qlens[2] = {ql0, ql1}, qlen_sum = ql0 + ql1;
-	const AlAnchor *a = chained + W.a_off[f]; const uint64_t *u = u_all + W.a_off[f] + f;
+	const AlAnchor *a = chained + W.a_off[f]; const uint64_t *u = u_all + W.a_off[f] + f; const uint32_t *uo = uo_all + W.a_off[f] + f;
 	const uint32_t hash = frag_hash[f];
 	int max_gap_ref;
 	if (P.max_gap_ref > 0) max_gap_ref = P.max_gap_ref;
@@ -1309,6 +1296,7 @@ k_regs(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__ u_all,
 		// split + coordinates + fuzzy lengths), both per-mate hit records built in registers and stored once; nothing else
 		// of the per-fragment workspace is touched.  Same result as the general code below for n_u == 1.
 		const uint64_t u0 = u[0]; const int cnt = (int32_t)(uint32_t)u0;
+		a += uo[0];                                                             // the chain's anchors, at their segment's place
 		uint32_t c1 = 0;
 		for (int j = 0; j < cnt; ++j) c1 += (uint32_t)((a[j].y & AL_SEED_SEG_MASK) >> AL_SEED_SEG_SHIFT) & 1u;
 		const uint32_t c0 = (uint32_t)cnt - c1;
@@ -1373,13 +1361,13 @@ k_regs(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__ u_all,
 	const uint32_t pre_n0 = regs_n0 ? regs_n0[f] : AL_REGS_UNSET;
 	if (pre_n0 != AL_REGS_UNSET && !AL_REGS_BAIL(pre_n0)) n0 = (int)pre_n0;                                                    // k_regs_select did chain_post: ws.regs0[0 .. n0) are the kept hits
 	else {
-		tie = d_gen_regs(hash, qlen_sum, (int)n_u, u, a, ws.regs0, ws.aux128);
+		tie = d_gen_regs(hash, qlen_sum, (int)n_u, u, a, ws.regs0, ws.aux128, uo);
 		d_set_parent(P.mask_level, n0, ws.regs0, P.a * 2 + P.b, ws.aux64, ws.auxi);                   // chain_post, map.c:249-258
 		if (n_segs <= 1) d_select_sub(P.pri_ratio, P.k * 2, P.best_n, &n0, ws.regs0, ws.auxi);
 		else d_select_sub_multi(P.pri_ratio, 0.2f, 0.7f, max_gap_ref, P.k * 2, P.best_n, (int)n_segs, qlens, &n0, ws.regs0, ws.auxi);
 	}
 	uint32_t cnt0 = 0, cnt1 = 0, sna0 = 0, sna1 = 0; uint32_t tot = 0;
-	if (n_segs == 1) for (uint32_t i = 0; i < n_u; ++i) tot += (uint32_t)u[i];
+	if (n_segs == 1) for (int i = 0; i < n0; ++i) { const uint32_t e = (uint32_t)(ws.regs0[i].as + ws.regs0[i].cnt); tot = e > tot ? e : tot; }   // single end: the range of a[] the kept hits' anchors lie in
 	tie = d_regs_tail(P, hash, (int)n_segs, ql0, ql1, n0, ws.regs0, a, tot, ws.mreg[0], ws.mreg[1], ws.seg_u[0], ws.seg_u[1], ws.seg_a[0], ws.aux128, ws.aux64, ws.auxi, cnt0, cnt1, sna0, sna1) || tie;
 	W.reg_cnt[r0] = cnt0; W.seg_na[r0] = sna0;
 	if (n_segs > 1) { W.reg_cnt[r0 + 1] = cnt1; W.seg_na[r0 + 1] = sna1; }
@@ -2352,7 +2340,7 @@ int al_run_align_stage(al_ctx_t *c)
 	AL_HIP_CHECK(hipMemcpyAsync(&nu_total, A->nu_off.p + nf, 8, hipMemcpyDeviceToHost, s));
 	AL_HIP_CHECK(hipStreamSynchronize(s));
 	const uint64_t Btot = 4 * nu_total + 4ULL * nf + 8;
-	if (A->regs0.ensure(nu_total + 1) || A->aux128.ensure(Btot) || A->aux64.ensure(Btot) || A->auxi.ensure(2 * Btot) ||
+	if (c->seg_a.ensure(c->n_anchor_total + 1) || A->regs0.ensure(nu_total + 1) || A->aux128.ensure(Btot) || A->aux64.ensure(Btot) || A->auxi.ensure(2 * Btot) ||
 	    A->seg_u.ensure(2 * nu_total + 2) || A->reg_cnt.ensure(nr + 1) || A->seg_na.ensure(nr + 1) || A->out_off.ensure(nr + 2) || A->seg_fast.ensure(nr + 1) || A->cap2.ensure(nf + 2) || A->b2_off.ensure(nf + 2)) return -1;
 	{   // AL_TEST_SCRUB=<byte> (tests): the stage's work areas -- and the chaining scratch it reuses -- filled with that byte first: a result
 		// that depends on what an earlier stage or batch left there shows up as a difference between two byte values
@@ -2361,12 +2349,12 @@ int al_run_align_stage(al_ctx_t *c)
 			const int v = atoi(scrub);
 			AL_HIP_CHECK(hipMemsetAsync(A->regs0.p, v, A->regs0.cap * sizeof(AlReg), s)); AL_HIP_CHECK(hipMemsetAsync(A->aux128.p, v, A->aux128.cap * sizeof(AlAnchor), s));
 			AL_HIP_CHECK(hipMemsetAsync(A->aux64.p, v, A->aux64.cap * 8, s)); AL_HIP_CHECK(hipMemsetAsync(A->auxi.p, v, A->auxi.cap * 4, s)); AL_HIP_CHECK(hipMemsetAsync(A->seg_u.p, v, A->seg_u.cap * 8, s));
-			AL_HIP_CHECK(hipMemsetAsync(c->chain_tmp.p, v, c->chain_tmp.cap * sizeof(AlAnchor), s));
+			AL_HIP_CHECK(hipMemsetAsync(c->seg_a.p, v, c->seg_a.cap * sizeof(AlAnchor), s));
 			AL_HIP_CHECK(hipMemsetAsync(A->reg_cnt.p, v, A->reg_cnt.cap * 4, s)); AL_HIP_CHECK(hipMemsetAsync(A->seg_na.p, v, A->seg_na.cap * 4, s)); AL_HIP_CHECK(hipMemsetAsync(A->seg_fast.p, v, A->seg_fast.cap * 4, s));
 		}
 	}
 	WsBase W;
-	W.regs0 = A->regs0.p; W.aux128 = A->aux128.p; W.seg_a = c->chain_tmp.p /* chaining scratch, free again */; W.aux64 = A->aux64.p; W.seg_u = A->seg_u.p; W.auxi = A->auxi.p;
+	W.regs0 = A->regs0.p; W.aux128 = A->aux128.p; W.seg_a = c->seg_a.p; W.aux64 = A->aux64.p; W.seg_u = A->seg_u.p; W.auxi = A->auxi.p;
 	W.nu_off = A->nu_off.p; W.frag_nu = c->frag_nu.p; W.a_off = c->a_off.p; W.reg_cnt = A->reg_cnt.p; W.seg_na = A->seg_na.p; W.seg_fast = A->seg_fast.p; W.cap2 = nullptr; W.b2_off = nullptr; W.mregs = nullptr; W.rtmp = nullptr; W.rext = nullptr;
 	// fragments with many chains: chain_post by a wavefront each (k_regs_select), by chain-count class
 	uint32_t *regs_n0 = nullptr; uint32_t heavy_from = 0, heavy_n = 0; uint64_t Btot2 = 0;
@@ -2393,13 +2381,13 @@ int al_run_align_stage(al_ctx_t *c)
 		// the side stream next to the rest
 		hipStream_t sd = c->side;
 		AL_HIP_CHECK(hipEventRecord(c->ev_fj[0], s)); AL_HIP_CHECK(hipStreamWaitEvent(sd, c->ev_fj[0], 0));
-		if (lb[3] > lb[5]) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_select<8192>), dim3(lb[3] - lb[5]), dim3(256), 0, sd, c->chained.p, c->u.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, ord + lb[5], (int)(lb[3] - lb[5]), c->P, regs_n0);
+		if (lb[3] > lb[5]) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_select<8192>), dim3(lb[3] - lb[5]), dim3(256), 0, sd, c->chained.p, c->u.p, c->uo.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, ord + lb[5], (int)(lb[3] - lb[5]), c->P, regs_n0);
 		AL_HIP_CHECK(hipEventRecord(c->ev_fj[1], sd));
-		if ((uint32_t)nf > lb[3]) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_select<-1>), dim3((uint32_t)nf - lb[3]), dim3(1024), 0, s, c->chained.p, c->u.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, ord + lb[3], (int)((uint32_t)nf - lb[3]), c->P, regs_n0);
-		if (lb[2] > lb[1]) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_select<1024>), dim3(lb[2] - lb[1]), dim3(256), 0, s, c->chained.p, c->u.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, ord + lb[1], (int)(lb[2] - lb[1]), c->P, regs_n0);
-		if (lb[5] > lb[4]) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_select<4096>), dim3(lb[5] - lb[4]), dim3(256), 0, s, c->chained.p, c->u.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, ord + lb[4], (int)(lb[5] - lb[4]), c->P, regs_n0);
-		if (lb[4] > lb[2]) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_select<2048>), dim3(lb[4] - lb[2]), dim3(256), 0, s, c->chained.p, c->u.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, ord + lb[2], (int)(lb[4] - lb[2]), c->P, regs_n0);
-		if (lb[1] > lb[0]) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_select<0>), dim3(lb[1] - lb[0]), dim3(64), 0, s, c->chained.p, c->u.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, ord + lb[0], (int)(lb[1] - lb[0]), c->P, regs_n0);
+		if ((uint32_t)nf > lb[3]) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_select<-1>), dim3((uint32_t)nf - lb[3]), dim3(1024), 0, s, c->chained.p, c->u.p, c->uo.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, ord + lb[3], (int)((uint32_t)nf - lb[3]), c->P, regs_n0);
+		if (lb[2] > lb[1]) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_select<1024>), dim3(lb[2] - lb[1]), dim3(256), 0, s, c->chained.p, c->u.p, c->uo.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, ord + lb[1], (int)(lb[2] - lb[1]), c->P, regs_n0);
+		if (lb[5] > lb[4]) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_select<4096>), dim3(lb[5] - lb[4]), dim3(256), 0, s, c->chained.p, c->u.p, c->uo.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, ord + lb[4], (int)(lb[5] - lb[4]), c->P, regs_n0);
+		if (lb[4] > lb[2]) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_select<2048>), dim3(lb[4] - lb[2]), dim3(256), 0, s, c->chained.p, c->u.p, c->uo.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, ord + lb[2], (int)(lb[4] - lb[2]), c->P, regs_n0);
+		if (lb[1] > lb[0]) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_select<0>), dim3(lb[1] - lb[0]), dim3(64), 0, s, c->chained.p, c->u.p, c->uo.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, ord + lb[0], (int)(lb[1] - lb[0]), c->P, regs_n0);
 		AL_HIP_CHECK(hipStreamWaitEvent(s, c->ev_fj[1], 0));
 	}
 	{   // room for the per-mate hits, from what chain_post kept
@@ -2431,7 +2419,7 @@ int al_run_align_stage(al_ctx_t *c)
 #undef LHV
 		AL_HIP_CHECK(hipStreamWaitEvent(s, c->ev_fj[1], 0));
 	}
-	hipLaunchKernelGGL(k_regs, dim3((nf + 255) / 256), dim3(256), 0, s, c->chained.p, c->u.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, nf, c->P, c->counters.p, (const uint32_t *)regs_n0);
+	hipLaunchKernelGGL(k_regs, dim3((nf + 255) / 256), dim3(256), 0, s, c->chained.p, c->u.p, c->uo.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, nf, c->P, c->counters.p, (const uint32_t *)regs_n0);
 	if (getenv("AL_DBG_FRAG")) {   // debugging aid: the chain_post result of one fragment (the kept hits at the front of its regs0 range)
 		const int f = atoi(getenv("AL_DBG_FRAG"));
 		if (f >= 0 && f < nf) {

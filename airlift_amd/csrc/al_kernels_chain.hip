@@ -1,0 +1,525 @@
+// al_kernels_chain.hip -- K4t: chaining (mm_chain_dp, chain.c:22-162) of fragments with many anchors, ONE pass per fragment.
+//
+// A fragment's sorted anchors fall apart into independent chaining problems ("segments") wherever two neighbours are further
+// apart than max_dist_x: the test that moves the predecessor window in chain.c:52 can never reach back over such a gap.  A read
+// pair inside interspersed repeats has thousands of anchors but segments of 2 - 40.  k_chain_tile gives a wavefront a TILE of
+// up to CT_TILE anchors -- several small fragments, one fragment, or a slice of a large one that ends at a segment boundary --
+// and does everything for it from LDS:
+//   load     coalesced 16-byte loads -> compact 8-byte rows [xlo:16 | q:12 | mate:1 | cut:1 | flags:2 | f:16 | p:16]
+//   cut      ballots over the cut flags -> segment list (start, length) in tile order, ordered by size class for the next steps
+//   DP       segments of <= 16 anchors: a lane each (64 at a time, equal size classes together);
+//            longer segments: 16 lanes each, one row at a time, the row's predecessors scored 16 at a time -- the sequential
+//            max_skip rule of chain.c:74-81 replayed on two ballot masks (only rows with more than max_skip predecessors need it)
+//   back     chain ends, peaks, backtrack, min_cnt / min_sc filters, order by first anchor (chain.c:87-160): a lane per segment
+//   emit     chain list entries appended at the fragment's running offset (the segments' x ranges ascend, so tile order is
+//            the reference's order by first-anchor x); every chain's anchors are written at the SEGMENT's own place in
+//            `chained` -- a chain keeps <= the segment's anchors -- and the entry carries that offset (uo[]): nothing is
+//            compacted or merged afterwards, the consumers read (u, uo) pairs.
+// Handed to the caller's fallback list (the segment-wise kernels of al_kernels_seed.hip on a compact copy): fragments with a
+// segment longer than the tile or with more than CT_NU_CAP chain ends, anchors outside the compact rows, and fragments with
+// more than 64 chains of which two start at equal x (the reference's unstable sort decides their order, k_chain_order).
+// Integer work on LDS; HBM traffic = the anchors once in, the chained anchors and 12 bytes per chain out.  No MFMA.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "al_internal.h"
+#include "al_device.h"
+
+#define CT_TILE 1024
+#define CT_SEGS (CT_TILE / 2)            // a segment that can hold a chain has >= 2 anchors (the caller checks lmin >= 2)
+#define CT_FRAGS 32
+#define CT_NU_CAP 64                     // chain ends of one segment the serial sorts take; more: fallback
+#define CT_CLIN_N 512
+#define CT_NONE 0xffffu
+
+#define R_XLO(r) ((uint32_t)(r) & 0xffffu)
+#define R_Q(r) ((int32_t)((uint32_t)(r) >> 16 & 0xfffu))
+#define R_SEG(r) ((int32_t)((uint32_t)(r) >> 28 & 1u))
+#define R_F(r) ((int32_t)(int16_t)((r) >> 32))
+#define R_P(r) ((uint32_t)((r) >> 48))
+#define ROW_B30 (1u << 30)
+#define ROW_B31 (1u << 31)
+
+struct CtFrag {                 // one fragment of the tile
+	uint64_t aoff;              // its anchors in the batch arrays
+	uint32_t f, na;
+	int32_t mdx, mdy; uint32_t drlim;
+	uint32_t start;             // first row of the tile that is this fragment's
+	uint32_t flags;             // 1: skipped (chained elsewhere), 2: bad row / overflow -> fallback, 4: tie
+};
+
+__device__ __forceinline__ int ct_ilog2(uint32_t v) { return 31 - __clz((int)v); }
+__device__ __forceinline__ int ct_dpp_shr(int old, int v, const int n)
+{
+	switch (n) {
+	case 1: return __builtin_amdgcn_update_dpp(old, v, 0x111, 0xf, 0xf, false);
+	case 2: return __builtin_amdgcn_update_dpp(old, v, 0x112, 0xf, 0xf, false);
+	case 4: return __builtin_amdgcn_update_dpp(old, v, 0x114, 0xf, 0xf, false);
+	default: return __builtin_amdgcn_update_dpp(old, v, 0x118, 0xf, 0xf, false);
+	}
+}
+
+// score of predecessor row rj for row (xi, qi, sidi): chain.c:53-73 with the range tests folded into unsigned compares.
+// Returns false when the pair is skipped.
+struct CtPen { const uint8_t *same, *diff; bool tab_ok; double avg_d; };
+__device__ __forceinline__ bool ct_score(const uint64_t rj, const uint32_t xi, const int32_t qi, const int32_t sidi, const int32_t q_span,
+                                         const int32_t mdx, const int32_t mdy, const uint32_t drlim, const int32_t bw, const CtPen &pen, int32_t &sc_out)
+{
+	const int32_t dr = (int32_t)((xi - R_XLO(rj)) & 0xffffu);
+	const int32_t dq = qi - R_Q(rj);
+	const bool same = R_SEG(rj) == sidi;
+	const int32_t dd = dr > dq ? dr - dq : dq - dr;
+	// dq <= 0 or dq > max_dist_x; for anchors of the same mate also dr == 0 or (paired end) dr > max_dist_y, dq > max_dist_y, dd > bw
+	const bool skip = ((uint32_t)(dq - 1) >= (uint32_t)mdx) | (same & (((uint32_t)(dr - 1) >= drlim) | (dq > mdy) | (dd > bw)));
+	const int32_t min_d = dq < dr ? dq : dr;
+	int32_t sc = min_d > q_span ? q_span : min_d;
+	const uint32_t di = (uint32_t)dd < CT_CLIN_N ? (uint32_t)dd : CT_CLIN_N - 1;
+	int32_t pen_same = (int32_t)pen.same[di], pen_diff = (int32_t)pen.diff[di];
+	if (__builtin_expect(!pen.tab_ok || dd >= CT_CLIN_N, 0)) {
+		const int32_t log_dd = dd ? ct_ilog2((uint32_t)dd) : 0, c_lin = (int)((double)dd * .01 * pen.avg_d);
+		pen_same = c_lin + (log_dd >> 1); pen_diff = c_lin < log_dd ? c_lin : log_dd;
+	}
+	pen_diff = dr == 0 ? -1 : pen_diff;                                        // other mate, same position: + 1 (chain.c:67)
+	sc_out = sc - (same ? pen_same : pen_diff) + R_F(rj);
+	return !skip;
+}
+
+struct TileSched {
+	uint32_t n_items;
+	uint32_t ent[7];      // first list entry of class c: c = 0 .. 4: 32, 16, 8, 4, 2 fragments per item (at most 32, 64, ..., 512 anchors each), 5: one; ent[6] = end
+	uint32_t item[7];     // first item of class c
+};
+
+template <bool MARKS>      // the lane path keeps the t[] marks of chain.c:81 only when 15 predecessors can exceed max_skip
+__global__ void __launch_bounds__(64)
+k_chain_tile(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_off, const uint32_t *__restrict__ frag_na,
+             const uint32_t *__restrict__ frag_first, const uint32_t *__restrict__ rd_len, const uint32_t *__restrict__ list, const TileSched S,
+             const uint32_t *__restrict__ skip_flag, AlAnchor *__restrict__ chained, uint64_t *__restrict__ u_out, uint32_t *__restrict__ uo_out,
+             uint32_t *__restrict__ frag_nu, uint32_t *__restrict__ fb_list, uint32_t *__restrict__ fb_cnt, const AlParams P, const int lmin,
+             unsigned long long *__restrict__ counters, const int force_fb /* tests: every fragment is handed back */)
+{
+	__shared__ uint64_t s_row[CT_TILE];
+	__shared__ uint32_t s_u[CT_TILE];
+	__shared__ uint16_t s_v[CT_TILE], s_tm[CT_TILE], s_perm[CT_TILE];
+	__shared__ uint16_t s_sstart[CT_SEGS], s_slen[CT_SEGS], s_snu[CT_SEGS], s_proc[CT_SEGS];
+	__shared__ uint8_t s_sfrag[CT_SEGS];
+	__shared__ uint8_t s_pen_same[CT_CLIN_N], s_pen_diff[CT_CLIN_N];
+	__shared__ CtFrag s_tf[CT_FRAGS];
+	__shared__ uint32_t s_fseg[CT_FRAGS + 1];                                  // first segment (tile order) of every fragment of the tile
+	const int lane = threadIdx.x;
+	const unsigned long long below = (1ULL << lane) - 1ULL;
+	if (blockIdx.x >= S.n_items) return;
+	const uint32_t it = S.n_items - 1u - blockIdx.x;                            // the list ascends by anchor count: the heaviest items first
+	int cl = 0; while (cl < 5 && it >= S.item[cl + 1]) ++cl;
+	const uint32_t per = 32u >> cl;
+	const uint32_t e0 = S.ent[cl] + (it - S.item[cl]) * per, e1 = e0 + per < S.ent[cl + 1] ? e0 + per : S.ent[cl + 1];
+	const int nfr = (int)(e1 - e0);
+	const int32_t q_span = P.k, bw = P.bw, max_skip = P.max_chain_skip, max_iter = P.max_chain_iter, min_cnt = P.min_cnt, min_sc = P.min_chain_score;
+	// gap costs of chain.c:64-72 for avg_qspan == k, tabulated with the same two double multiplications
+	for (int d = lane; d < CT_CLIN_N; d += 64) {
+		const int c_lin = (int)((double)d * .01 * (double)P.k), lg = d ? ct_ilog2((uint32_t)d) : 0;
+		s_pen_same[d] = (uint8_t)(c_lin + (lg >> 1)); s_pen_diff[d] = (uint8_t)(c_lin < lg ? c_lin : lg);
+	}
+	CtPen pen; pen.same = s_pen_same; pen.diff = s_pen_diff; pen.avg_d = (double)P.k;     // every span is k (checked per row): (float)sum / n == k exactly (chain.c:42)
+	pen.tab_ok = P.k * 0.01 * (CT_CLIN_N - 1) + 5.0 < 255.0;
+	// ---- the fragments of this item ----
+	{
+		const bool mine = lane < nfr;
+		const uint32_t f = mine ? list[e0 + lane] : 0u;
+		const bool skipped = mine && skip_flag && skip_flag[f] != 0;
+		const uint32_t na = mine && !skipped ? frag_na[f] : 0u;
+		uint32_t incl = na;                                                     // rows of the fragments in front of this one
+		for (int d = 1; d < 32; d <<= 1) { const uint32_t o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+		if (mine) {
+			const uint32_t r0 = frag_first[f], r1 = frag_first[f + 1];
+			int qlen_sum = 0; for (uint32_t r = r0; r < r1; ++r) qlen_sum += (int)rd_len[r];
+			const int mdy = qlen_sum > P.max_gap ? qlen_sum : P.max_gap;               // map.c:341-351
+			int mdx;
+			if (P.max_gap_ref > 0) mdx = P.max_gap_ref;
+			else if (P.max_frag_len > 0) { mdx = P.max_frag_len - qlen_sum; if (mdx < P.max_gap) mdx = P.max_gap; }
+			else mdx = P.max_gap;
+			CtFrag t; t.aoff = a_off[f]; t.f = f; t.na = na; t.mdx = mdx; t.mdy = mdy; t.drlim = r1 - r0 > 1 ? (uint32_t)mdy : 0x7fffffffu; t.flags = skipped ? 1u : 0u;
+			t.start = incl - na;
+			s_tf[lane] = t;
+		}
+	}
+	__syncthreads();
+	const bool single = nfr == 1;
+	if (!single) {                                                              // (the size classes guarantee the fit; a caller's mistake must not be silent)
+		const CtFrag &tl = s_tf[nfr - 1];
+		if (tl.start + tl.na > CT_TILE) { if (lane == 0) atomicAdd(&counters[7], 1ULL << 48); return; }
+	}
+	uint32_t pos = 0;                    // single: rows of the fragment in front of this tile
+	uint32_t u_run = 0;                  // single: chains written by the earlier tiles
+	for (;;) {
+		// ---- load + cut: rows, segment list in tile order, size-class counts ----
+		uint32_t n_seg = 0, cnt0 = 0, cnt1 = 0, cnt2 = 0, cnt3 = 0, cnt4 = 0;
+		uint32_t proc_end = 0, next_pos = 0; bool more = false, too_long = false;
+		for (int fi = 0; fi < nfr; ++fi) {
+			const CtFrag tf = s_tf[fi];
+			const uint32_t base_t = tf.start;
+			const uint32_t n = single ? (tf.na - pos < CT_TILE ? tf.na - pos : CT_TILE) : tf.na;
+			const AlAnchor *src = anchors + tf.aoff + pos;
+			if (lane == 0) s_fseg[fi] = n_seg;
+			uint32_t open = base_t; uint64_t carry_x = 0; bool bad = false;
+			for (uint32_t b = 0; b < n; b += 64) {
+				const uint32_t i = b + lane; const bool valid = i < n;
+				AlAnchor e; e.x = 0; e.y = 0;
+				if (valid) e = src[i];
+				uint64_t xp = (uint64_t)(uint32_t)__shfl_up((int)(uint32_t)e.x, 1) | (uint64_t)(uint32_t)__shfl_up((int)(uint32_t)(e.x >> 32), 1) << 32;
+				if (lane == 0) xp = carry_x;
+				const bool cut = valid && (i == 0 || e.x - xp > (uint64_t)(int64_t)tf.mdx);
+				bad = bad || (valid && ((int32_t)(e.y >> 32 & 0xff) != q_span || ((e.y & AL_SEED_SEG_MASK) >> AL_SEED_SEG_SHIFT) > 1 || (uint32_t)e.y > 0xfffu));
+				if (valid) {
+					s_row[base_t + i] = (uint64_t)((uint32_t)e.x & 0xffffu) | (uint64_t)((uint32_t)e.y & 0xfffu) << 16 | (uint64_t)((e.y & AL_SEED_SEG_MASK) >> AL_SEED_SEG_SHIFT & 1) << 28
+					                    | (uint64_t)(cut ? 1u : 0u) << 29 | (uint64_t)CT_NONE << 48;
+					s_tm[base_t + i] = (uint16_t)CT_NONE;
+				}
+				const unsigned long long mask = __ballot(cut);
+				bool useful = false; uint32_t start = 0, len = 0;
+				if (cut && i > 0) {                                                 // this anchor closes the segment in front of it
+					const unsigned long long lower = mask & below;
+					start = lower ? base_t + b + (uint32_t)(63 - __clzll((long long)lower)) : open;
+					len = base_t + i - start;
+					useful = (int)len >= lmin;
+				}
+				const int sc = len <= 2 ? 0 : len <= 4 ? 1 : len <= 8 ? 2 : len <= 16 ? 3 : 4;
+				const unsigned long long um = __ballot(useful);
+				if (useful) { const uint32_t k = n_seg + (uint32_t)__popcll(um & below); s_sstart[k] = (uint16_t)start; s_slen[k] = (uint16_t)len; s_sfrag[k] = (uint8_t)fi; }
+				n_seg += (uint32_t)__popcll(um);
+				cnt0 += (uint32_t)__popcll(__ballot(useful && sc == 0)); cnt1 += (uint32_t)__popcll(__ballot(useful && sc == 1));
+				cnt2 += (uint32_t)__popcll(__ballot(useful && sc == 2)); cnt3 += (uint32_t)__popcll(__ballot(useful && sc == 3)); cnt4 += (uint32_t)__popcll(__ballot(useful && sc == 4));
+				if (mask) open = base_t + b + (uint32_t)(63 - __clzll((long long)mask));
+				carry_x = (uint64_t)(uint32_t)__shfl((int)(uint32_t)e.x, 63) | (uint64_t)(uint32_t)__shfl((int)(uint32_t)(e.x >> 32), 63) << 32;
+			}
+			if (__ballot(bad) && lane == 0) s_tf[fi].flags |= 2u;
+			const uint32_t end_t = base_t + n;
+			if (single && pos + n < tf.na) {                                        // a slice: its open segment belongs to the next tile
+				more = true; proc_end = open; next_pos = pos + (open - base_t);
+				if (open == base_t) too_long = true;                                // a segment longer than the tile
+			} else {
+				proc_end = end_t;
+				const uint32_t len = end_t - open;
+				if (n > 0 && (int)len >= lmin) {
+					if (lane == 0) { s_sstart[n_seg] = (uint16_t)open; s_slen[n_seg] = (uint16_t)len; s_sfrag[n_seg] = (uint8_t)fi; }
+					++n_seg;
+					if (len <= 2) ++cnt0; else if (len <= 4) ++cnt1; else if (len <= 8) ++cnt2; else if (len <= 16) ++cnt3; else ++cnt4;
+				}
+			}
+		}
+		if (lane == 0) s_fseg[nfr] = n_seg;
+		if (too_long) { if (lane == 0) s_tf[0].flags |= 2u; break; }
+		__syncthreads();
+		// ---- segments by size class: s_proc[] ----
+		const uint32_t n_lane = cnt0 + cnt1 + cnt2 + cnt3;
+		{
+			uint32_t b0 = 0, b1 = cnt0, b2 = cnt0 + cnt1, b3 = b2 + cnt2, b4 = n_lane;
+			for (uint32_t kb = 0; kb < n_seg; kb += 64) {
+				const uint32_t k = kb + lane; const bool v = k < n_seg;
+				const uint32_t len = v ? s_slen[k] : 0u;
+				const int sc = len <= 2 ? 0 : len <= 4 ? 1 : len <= 8 ? 2 : len <= 16 ? 3 : 4;
+				const unsigned long long m0 = __ballot(v && sc == 0), m1 = __ballot(v && sc == 1), m2 = __ballot(v && sc == 2), m3 = __ballot(v && sc == 3), m4 = __ballot(v && sc == 4);
+				if (v) {
+					const uint32_t o = sc == 0 ? b0 + (uint32_t)__popcll(m0 & below) : sc == 1 ? b1 + (uint32_t)__popcll(m1 & below) : sc == 2 ? b2 + (uint32_t)__popcll(m2 & below)
+					                 : sc == 3 ? b3 + (uint32_t)__popcll(m3 & below) : b4 + (uint32_t)__popcll(m4 & below);
+					s_proc[o] = (uint16_t)k;
+				}
+				b0 += (uint32_t)__popcll(m0); b1 += (uint32_t)__popcll(m1); b2 += (uint32_t)__popcll(m2); b3 += (uint32_t)__popcll(m3); b4 += (uint32_t)__popcll(m4);
+			}
+		}
+		__syncthreads();
+		// ---- DP, a lane per segment of <= 16 anchors (chain.c:46-85) ----
+		for (uint32_t r0 = 0; r0 < n_lane; r0 += 64) {
+			const bool have = r0 + lane < n_lane;
+			const uint32_t k = have ? s_proc[r0 + lane] : 0u;
+			const int n = have ? (int)s_slen[k] : 0;
+			const uint32_t Sg = s_sstart[k];
+			const CtFrag &tf = s_tf[s_sfrag[k]];
+			const int32_t mdx = tf.mdx, mdy = tf.mdy; const uint32_t drlim = tf.drlim;
+			int st = 0; int32_t dist = 0; uint32_t prev_xlo = 0;
+			for (int i = 0; i < n; ++i) {
+				const uint64_t ri = s_row[Sg + i];
+				const uint32_t xi = R_XLO(ri); const int32_t qi = R_Q(ri), sidi = R_SEG(ri);
+				if (i > 0) {                                                        // window start (chain.c:52-53): x[i] - x[st] <= max_dist_x, at most max_iter rows
+					dist += (int32_t)((xi - prev_xlo) & 0xffffu);
+					while (dist > mdx || i - st > max_iter) { ++st; dist -= (int32_t)((R_XLO(s_row[Sg + st]) - R_XLO(s_row[Sg + st - 1])) & 0xffffu); }
+				}
+				prev_xlo = xi;
+				int max_j = -1; int32_t max_f = q_span, n_skip = 0;
+				int jn = i > 0 ? i - 1 : 0;
+				uint64_t nrow = s_row[Sg + jn];
+				bool done = false;
+				for (int j = i - 1; j >= st && !done; --j) {
+					const uint64_t rj = nrow;
+					jn = j > 0 ? j - 1 : 0;
+					nrow = s_row[Sg + jn];
+					int32_t sc;
+					const bool ok = ct_score(rj, xi, qi, sidi, q_span, mdx, mdy, drlim, bw, pen, sc);
+					const bool better = ok && sc > max_f;
+					if (MARKS) {
+						const uint32_t pj = R_P(rj);
+						const bool marked = ok && !better && s_tm[Sg + j] == (uint16_t)i;
+						n_skip += marked ? 1 : (better && n_skip > 0 ? -1 : 0);
+						done = marked && n_skip > max_skip;                          // the reference breaks before marking p[j]
+						if (ok && !done && pj != CT_NONE) s_tm[Sg + pj] = (uint16_t)i;
+					}
+					max_f = better ? sc : max_f; max_j = better ? j : max_j;
+				}
+				const int32_t vmax = max_j >= 0 ? (int32_t)s_v[Sg + max_j] : 0;
+				s_row[Sg + i] = (ri & 0x00000000ffffffffULL) | (uint64_t)((uint32_t)max_f & 0xffffu) << 32 | (uint64_t)(max_j < 0 ? CT_NONE : (uint32_t)max_j) << 48;
+				s_v[Sg + i] = (uint16_t)(max_j >= 0 && vmax > max_f ? vmax : max_f);
+			}
+		}
+		// ---- DP, 16 lanes per longer segment, four segments at a time ----
+		for (uint32_t r0 = n_lane; r0 < n_seg; r0 += 4) {
+			const int gl = lane & 15, gbase = lane & 48, g = lane >> 4;
+			const bool have = r0 + g < n_seg;
+			const uint32_t k = have ? s_proc[r0 + g] : 0u;
+			const int n = have ? (int)s_slen[k] : 0;
+			const uint32_t Sg = s_sstart[k];
+			const CtFrag &tf = s_tf[s_sfrag[k]];
+			const int32_t mdx = tf.mdx, mdy = tf.mdy; const uint32_t drlim = tf.drlim;
+			int nmax = n;
+			{ int o = __shfl_xor(nmax, 16); nmax = o > nmax ? o : nmax; o = __shfl_xor(nmax, 32); nmax = o > nmax ? o : nmax; }
+			int st = 0; int32_t dist = 0; uint32_t prev_xlo = 0;
+			for (int i = 0; i < nmax; ++i) {
+				const bool ga = i < n;
+				const uint64_t ri = ga ? s_row[Sg + i] : 0ULL;
+				const uint32_t xi = R_XLO(ri); const int32_t qi = R_Q(ri), sidi = R_SEG(ri);
+				if (ga && i > 0) {
+					dist += (int32_t)((xi - prev_xlo) & 0xffffu);
+					while (dist > mdx || i - st > max_iter) { ++st; dist -= (int32_t)((R_XLO(s_row[Sg + st]) - R_XLO(s_row[Sg + st - 1])) & 0xffffu); }
+				}
+				prev_xlo = ga ? xi : prev_xlo;
+				int32_t max_f = q_span, n_skip = 0; int max_j = -1; bool broke = !ga;
+				const bool need_marks = ga && (i - st) > max_skip;                    // fewer predecessors can never count max_skip + 1 skips: no marks, no replay
+				for (int base = i - 1; ; base -= 16) {
+					const bool work = !broke && base >= st;
+					if (!__ballot(work)) break;
+					const int j = base - gl;
+					bool act = work && j >= st;
+					const uint64_t rj = act ? s_row[Sg + j] : 0ULL;
+					int32_t sc;
+					const bool ok = ct_score(rj, xi, qi, sidi, q_span, mdx, mdy, drlim, bw, pen, sc);
+					act = act && ok;
+					const uint32_t pj = R_P(rj);
+					if (need_marks && act && pj != CT_NONE) s_tm[Sg + pj] = (uint16_t)i;   // t[p[j]] = i (chain.c:81); marks of lanes behind the break are never tested
+					const int32_t scm = act ? sc : INT32_MIN;
+					int32_t inc = scm;                                                  // prefix maximum in processing order (lane order inside the 16-lane row)
+					{ int o = ct_dpp_shr(INT32_MIN, inc, 1); inc = o > inc ? o : inc; o = ct_dpp_shr(INT32_MIN, inc, 2); inc = o > inc ? o : inc;
+					  o = ct_dpp_shr(INT32_MIN, inc, 4); inc = o > inc ? o : inc; o = ct_dpp_shr(INT32_MIN, inc, 8); inc = o > inc ? o : inc; }
+					const int32_t excl = ct_dpp_shr(INT32_MIN, inc, 1);
+					const int32_t before = excl > max_f ? excl : max_f;
+					const bool upd = act && sc > before;
+					__threadfence_block();
+					const bool marked = need_marks && act && !upd && s_tm[Sg + j] == (uint16_t)i;
+					const unsigned long long Uw = __ballot(upd), Kw = __ballot(marked);
+					uint32_t U = (uint32_t)(Uw >> gbase) & 0xffffu; const uint32_t K = (uint32_t)(Kw >> gbase) & 0xffffu;
+					if (need_marks) {                                                   // chain.c:74-80 replayed in order over the two masks
+						uint32_t both = U | K; int brk = 16;
+						while (both) {
+							const int b = __ffs((int)both) - 1; both &= both - 1;
+							if (U >> b & 1) { if (n_skip > 0) --n_skip; }
+							else if (++n_skip > max_skip) { brk = b; break; }
+						}
+						if (brk < 16) { broke = true; U &= (1u << brk) - 1u; }
+					}
+					const int lastu = U ? 31 - __clz((int)U) : 0;
+					const int32_t scl = __shfl(sc, gbase + lastu);
+					if (work && U) { max_f = scl; max_j = base - lastu; }
+				}
+				if (ga && gl == 0) {
+					const int32_t vmax = max_j >= 0 ? (int32_t)s_v[Sg + max_j] : 0;
+					s_row[Sg + i] = (ri & 0x00000000ffffffffULL) | (uint64_t)((uint32_t)max_f & 0xffffu) << 32 | (uint64_t)(max_j < 0 ? CT_NONE : (uint32_t)max_j) << 48;
+					s_v[Sg + i] = (uint16_t)(max_j >= 0 && vmax > max_f ? vmax : max_f);
+				}
+				__threadfence_block();
+			}
+		}
+		__syncthreads();
+		// ---- chain ends, peaks, backtrack, order (chain.c:87-160): a lane per segment ----
+		for (uint32_t r0 = 0; r0 < n_seg; r0 += 64) {
+			const bool have = r0 + lane < n_seg;
+			if (!have) continue;
+			const uint32_t k = s_proc[r0 + lane];
+			const int n = (int)s_slen[k];
+			const uint32_t Sg = s_sstart[k];
+			const int fi = (int)s_sfrag[k];
+			uint32_t *const rlo = reinterpret_cast<uint32_t *>(s_row);               // rlo[2 t]: static half of row t, rlo[2 t + 1]: f | p << 16
+#define FLG(t) rlo[2 * (Sg + (t))]
+#define F_(t) ((int32_t)(int16_t)(rlo[2 * (Sg + (t)) + 1] & 0xffffu))
+#define P_(t) (rlo[2 * (Sg + (t)) + 1] >> 16)
+			for (int i = 0; i < n; ++i) { const uint32_t p = P_(i); if (p != CT_NONE) FLG(p) |= ROW_B30; }     // has a successor
+			int32_t n_u = 0;
+			bool ovf = false;
+			for (int i = 0; i < n; ++i)
+				if (!(FLG(i) & ROW_B30) && (int32_t)s_v[Sg + i] >= min_sc) {
+					int j = i;
+					while (j >= 0 && F_(j) < (int32_t)s_v[Sg + j]) { const uint32_t p = P_(j); j = p == CT_NONE ? -1 : (int)p; }
+					if (j < 0) j = i;
+					if (n_u < CT_NU_CAP) s_u[Sg + n_u] = (uint32_t)F_(j) << 16 | (uint32_t)j; else ovf = true;
+					++n_u;
+				}
+			if (ovf) { atomicOr(&s_tf[fi].flags, 2u); s_snu[k] = 0; continue; }
+			if (n_u == 0) { s_snu[k] = 0; continue; }
+			for (int32_t i = 1; i < n_u; ++i) { const uint32_t t = s_u[Sg + i]; int32_t j = i; while (j > 0 && s_u[Sg + j - 1] < t) { s_u[Sg + j] = s_u[Sg + j - 1]; --j; } s_u[Sg + j] = t; }
+			int32_t n_v = 0, kk = 0;
+			for (int32_t i = 0; i < n_u; ++i) {                                          // chain.c:111-128; v[] becomes the visit list
+				const uint32_t key0 = s_u[Sg + i];
+				const int32_t n_v0 = n_v, k0 = kk, sc_i = (int32_t)(key0 >> 16); int j = (int)(key0 & 0xffffu);
+				do { s_v[Sg + n_v] = (uint16_t)j; ++n_v; FLG(j) |= ROW_B31; const uint32_t p = P_(j); j = p == CT_NONE ? -1 : (int)p; } while (j >= 0 && !(FLG(j) & ROW_B31));
+				if (j < 0) { if (n_v - n_v0 >= min_cnt) s_u[Sg + kk++] = (uint32_t)sc_i << 16 | (uint32_t)(n_v - n_v0); }
+				else if (sc_i - F_(j) >= min_sc) { if (n_v - n_v0 >= min_cnt) s_u[Sg + kk++] = (uint32_t)(sc_i - F_(j)) << 16 | (uint32_t)(n_v - n_v0); }
+				if (k0 == kk) n_v = n_v0;
+			}
+			n_u = kk;
+			// chains by the x of their first anchor (chain.c:144-160): a stable insertion sort is the reference's order for the <= 64 chains of a
+			// fragment (ksort.h:149); with more chains in the fragment the order among equal x is the fallback's business (tie flag)
+			int32_t off = 0;
+			for (int32_t c = 0; c < n_u; ++c) { s_tm[Sg + c] = (uint16_t)off; off += (int32_t)(s_u[Sg + c] & 0xffffu); s_perm[Sg + c] = (uint16_t)c; }
+			bool eqx = false;
+			if (n_u > 1) {
+				const CtFrag &tf = s_tf[fi];
+				const AlAnchor *a = anchors + tf.aoff + pos + (Sg - tf.start);
+#define CX(c) (a[(int)s_v[Sg + (int)s_tm[Sg + (c)] + (int32_t)(s_u[Sg + (c)] & 0xffffu) - 1]].x)
+				for (int32_t i = 1; i < n_u; ++i) {
+					const uint16_t ci = s_perm[Sg + i]; const uint64_t xi = CX(ci); int32_t j = i;
+					while (j > 0) { const uint16_t cj = s_perm[Sg + j - 1]; const uint64_t xj = CX(cj); if (xi < xj) { s_perm[Sg + j] = cj; --j; } else { eqx = eqx || xi == xj; break; } }
+					s_perm[Sg + j] = ci;
+				}
+#undef CX
+			}
+			s_snu[k] = (uint16_t)((uint32_t)n_u | (eqx ? 0x8000u : 0u));
+#undef FLG
+#undef F_
+#undef P_
+		}
+		__syncthreads();
+		{ uint32_t *const rlo = reinterpret_cast<uint32_t *>(s_row); for (uint32_t t = lane; t < proc_end; t += 64) rlo[2 * t + 1] = 0xffffffffu; }   // f / p are dead: the half becomes "source row of the chained anchor at this place"
+		__syncthreads();
+		// ---- emit: chain list entries in tile order at the fragment's running offset; chained anchors at the segment's own place ----
+		for (int fi = 0; fi < nfr; ++fi) {
+			const CtFrag tf = s_tf[fi];
+			const uint32_t k0 = s_fseg[fi], k1 = s_fseg[fi + 1];
+			uint64_t *const ub = u_out + tf.aoff + tf.f; uint32_t *const uob = uo_out + tf.aoff + tf.f;
+			uint32_t run = single ? u_run : 0u; bool tie = false;
+			uint32_t *const rlo = reinterpret_cast<uint32_t *>(s_row);
+			for (uint32_t kb = k0; kb < k1; kb += 64) {
+				const uint32_t k = kb + lane; const bool v = k < k1;
+				const uint32_t snu = v ? s_snu[k] : 0u, nu = snu & 0x7fffu;
+				tie = tie || (snu & 0x8000u) != 0;
+				uint32_t incl = nu;
+				for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+				const uint32_t tot = __shfl(incl, 63);
+				if (nu) {
+					const uint32_t Sg = s_sstart[k], rel = pos + (Sg - tf.start);
+					uint32_t o = 0; const uint32_t w0 = run + incl - nu;
+					for (uint32_t i = 0; i < nu; ++i) {
+						const uint32_t c = s_perm[Sg + i], e = s_u[Sg + c], cnt = e & 0xffffu, off = s_tm[Sg + c];
+						ub[w0 + i] = (uint64_t)(e >> 16) << 32 | cnt; uob[w0 + i] = rel + o;
+						for (uint32_t j = 0; j < cnt; ++j) rlo[2 * (Sg + o + j) + 1] = Sg + (uint32_t)s_v[Sg + off + (cnt - 1 - j)];
+						o += cnt;
+					}
+				}
+				run += tot;
+			}
+			__syncthreads();
+			{   // the chained anchors, by all lanes
+				const uint32_t t1 = single ? proc_end : tf.start + tf.na;
+				const AlAnchor *src = anchors + tf.aoff + pos; AlAnchor *dst = chained + tf.aoff + pos;
+				for (uint32_t t = tf.start + lane; t < t1; t += 64) { const uint32_t s = rlo[2 * t + 1]; if (s != 0xffffffffu) dst[t - tf.start] = src[s - tf.start]; }
+			}
+			if (__ballot(tie) && lane == 0) s_tf[fi].flags |= 4u;
+			if (single) u_run = run;
+			else if (lane == 0 && !(tf.flags & 1u)) {
+				const uint32_t fl = s_tf[fi].flags;
+				frag_nu[tf.f] = run;
+				if ((fl & 2u) || ((fl & 4u) && run > 64) || force_fb) fb_list[atomicAdd(fb_cnt, 1u)] = tf.f;
+			}
+		}
+		if (!more) break;
+		pos = next_pos;
+		__syncthreads();
+	}
+	if (single && lane == 0) {
+		const CtFrag &tf = s_tf[0];
+		if (!(tf.flags & 1u)) {
+			frag_nu[tf.f] = (tf.flags & 2u) ? 0u : u_run;
+			if ((tf.flags & 2u) || ((tf.flags & 4u) && u_run > 64) || force_fb) fb_list[atomicAdd(fb_cnt, 1u)] = tf.f;
+		}
+	}
+}
+template __global__ void k_chain_tile<false>(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *, const TileSched, const uint32_t *, AlAnchor *, uint64_t *, uint32_t *, uint32_t *, uint32_t *, uint32_t *, const AlParams, const int, unsigned long long *, const int);
+template __global__ void k_chain_tile<true>(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *, const TileSched, const uint32_t *, AlAnchor *, uint64_t *, uint32_t *, uint32_t *, uint32_t *, uint32_t *, const AlParams, const int, unsigned long long *, const int);
+
+// uo[] for chain lists whose anchors were written back to back (the whole-fragment kernels and the fallback): running sum of the counts.
+// One wavefront per list entry.
+__global__ void __launch_bounds__(64)
+k_uo_fill(const uint32_t *__restrict__ list, int n_list, const uint64_t *__restrict__ a_off, const uint32_t *__restrict__ frag_nu,
+          const uint64_t *__restrict__ u_all, uint32_t *__restrict__ uo_all, const uint32_t *__restrict__ skip_flag)
+{
+	const int lane = threadIdx.x;
+	if ((int)blockIdx.x >= n_list) return;
+	const uint32_t f = list ? list[blockIdx.x] : blockIdx.x;
+	if (skip_flag && skip_flag[f]) return;
+	const uint32_t n_u = frag_nu[f];
+	const uint64_t *u = u_all + a_off[f] + f; uint32_t *uo = uo_all + a_off[f] + f;
+	uint32_t run = 0;
+	for (uint32_t c0 = 0; c0 < n_u; c0 += 64) {
+		const uint32_t c = c0 + lane; const uint32_t cnt = c < n_u ? (uint32_t)u[c] : 0u;
+		uint32_t incl = cnt; for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+		if (c < n_u) uo[c] = run + incl - cnt;
+		run += __shfl(incl, 63);
+	}
+}
+
+// ---- the fallback's compact copy: fragment v of the list becomes fragment v of a small virtual batch ----
+// meta: per v the anchor count and the number of mates (two scans give the virtual a_off / frag_first)
+__global__ void __launch_bounds__(256)
+k_fb_meta(const uint32_t *__restrict__ fb_list, int n_fb, const uint32_t *__restrict__ frag_na, const uint32_t *__restrict__ frag_first, uint32_t *__restrict__ v_na, uint32_t *__restrict__ v_nseg)
+{
+	const int v = blockIdx.x * blockDim.x + threadIdx.x;
+	if (v > n_fb) return;
+	if (v == n_fb) { v_na[v] = 0; v_nseg[v] = 0; return; }
+	const uint32_t f = fb_list[v];
+	v_na[v] = frag_na[f]; v_nseg[v] = frag_first[f + 1] - frag_first[f];
+}
+__global__ void __launch_bounds__(256)
+k_fb_reads(const uint32_t *__restrict__ fb_list, int n_fb, const uint32_t *__restrict__ frag_first, const uint32_t *__restrict__ rd_len, const uint64_t *__restrict__ v_first64,
+           uint32_t *__restrict__ v_first, uint32_t *__restrict__ v_rd_len, uint32_t *__restrict__ v_order)
+{
+	const int v = blockIdx.x * blockDim.x + threadIdx.x;
+	if (v > n_fb) return;
+	v_first[v] = (uint32_t)v_first64[v];
+	if (v == n_fb) return;
+	v_order[v] = (uint32_t)v;
+	const uint32_t f = fb_list[v], r0 = frag_first[f], r1 = frag_first[f + 1];
+	for (uint32_t r = r0; r < r1; ++r) v_rd_len[(uint32_t)v_first64[v] + (r - r0)] = rd_len[r];
+}
+__global__ void __launch_bounds__(64)
+k_fb_copy_in(const uint32_t *__restrict__ fb_list, int n_fb, const uint64_t *__restrict__ a_off, const uint32_t *__restrict__ frag_na, const AlAnchor *__restrict__ anchors,
+             const uint64_t *__restrict__ v_a_off, AlAnchor *__restrict__ v_anchors)
+{
+	if ((int)blockIdx.x >= n_fb) return;
+	const uint32_t f = fb_list[blockIdx.x]; const uint32_t n = frag_na[f];
+	const AlAnchor *s = anchors + a_off[f]; AlAnchor *d = v_anchors + v_a_off[blockIdx.x];
+	for (uint32_t i = threadIdx.x; i < n; i += 64) d[i] = s[i];
+}
+__global__ void __launch_bounds__(64)
+k_fb_copy_out(const uint32_t *__restrict__ fb_list, int n_fb, const uint64_t *__restrict__ a_off, const uint64_t *__restrict__ v_a_off, const uint32_t *__restrict__ v_nu,
+              const uint64_t *__restrict__ v_u, const AlAnchor *__restrict__ v_chained, uint32_t *__restrict__ frag_nu, uint64_t *__restrict__ u_all, uint32_t *__restrict__ uo_all, AlAnchor *__restrict__ chained)
+{
+	const int lane = threadIdx.x, v = blockIdx.x;
+	if (v >= n_fb) return;
+	const uint32_t f = fb_list[v]; const uint32_t n_u = v_nu[v];
+	const uint64_t *su = v_u + v_a_off[v] + v; uint64_t *du = u_all + a_off[f] + f; uint32_t *duo = uo_all + a_off[f] + f;
+	uint32_t run = 0;
+	for (uint32_t c0 = 0; c0 < n_u; c0 += 64) {
+		const uint32_t c = c0 + lane; const uint64_t uc = c < n_u ? su[c] : 0ULL; const uint32_t cnt = (uint32_t)uc;
+		uint32_t incl = cnt; for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+		if (c < n_u) { du[c] = uc; duo[c] = run + incl - cnt; }
+		run += __shfl(incl, 63);
+	}
+	const AlAnchor *sc = v_chained + v_a_off[v]; AlAnchor *dc = chained + a_off[f];
+	for (uint32_t t = lane; t < run; t += 64) dc[t] = sc[t];
+	if (lane == 0) frag_nu[f] = n_u;
+}

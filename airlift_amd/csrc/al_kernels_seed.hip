@@ -1152,7 +1152,9 @@ __global__ void __launch_bounds__(64)
 k_chain_lds(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_off, const uint32_t *__restrict__ frag_na,
             const uint32_t *__restrict__ frag_first, const uint32_t *__restrict__ rd_len,
             AlAnchor *__restrict__ chained, uint64_t *__restrict__ u_out, uint32_t *__restrict__ frag_nu, uint64_t *__restrict__ ws_u64,
-            const uint32_t *__restrict__ order, int n_list, int lo_excl, AlParams P, unsigned long long *__restrict__ counters, ChainSeg seg)
+            const uint32_t *__restrict__ order, int n_list, int lo_excl, AlParams P, unsigned long long *__restrict__ counters, ChainSeg seg,
+            uint32_t *__restrict__ uo_out /* whole-fragment mode: offset of every chain's first anchor in the fragment's range of chained[] */,
+            int utmp_stride /* > 0: the entry's chain-end scratch is ws_u64 + list position * stride (whole fragments: no per-anchor scratch array); 0: ws_u64 + a_off */)
 {
 	// 10 bytes per anchor: one 8-byte row  [ xlo:16 | q:12 | seg:1 | far:1 | -:2 | f:16 | p:8 | t:8 ]  + the peak score v:16.
 	//  xlo = low 16 bits of the reference position: inside the predecessor window the true distance is <= max_dist_x < 2^15,
@@ -1291,7 +1293,7 @@ k_chain_lds(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a
 	// chain.c:87-109.  NB: the t[] marks above use the row index i (< CAPL <= 128) with 0xff as "never"; from here t[] is a 0/1 flag.
 	for (int i = 0; i < n; ++i) TB(i) = 0;
 	for (int i = 0; i < n; ++i) { const uint32_t pi_ = PLv(i); if (pi_ != 0xff) TB(pi_) = 1; }
-	uint64_t *utmp = ws_u64 + a_off[f];
+	uint64_t *utmp = utmp_stride > 0 ? ws_u64 + (size_t)t0 * (size_t)utmp_stride : ws_u64 + a_off[f];
 	int32_t n_u = 0, n_v = 0, k = 0;
 	for (int i = 0; i < n; ++i)
 		if (TB(i) == 0 && (int32_t)VL(i) >= min_sc) {
@@ -1328,11 +1330,13 @@ k_chain_lds(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a
 	}
 #undef CXL
 	AlAnchor *b = chained + a_off[f]; uint64_t *u = u_out + a_off[f] + (seg.meta ? 0u : f);
+	uint32_t *const uo = (!seg.meta && uo_out) ? uo_out + a_off[f] + f : nullptr;
 	int32_t o = 0; uint64_t u1 = 0;
 	const bool one = rec && n_u == 1;                                          // a segment with one chain (most of them): its list entry travels in the record
 	for (int32_t i = 0; i < n_u; ++i) {
 		const int32_t c = TB(i), ni = (int32_t)(uint32_t)utmp[c], k0 = OFFB(c);
 		if (one) u1 = utmp[c]; else u[i] = utmp[c];
+		if (uo) uo[i] = (uint32_t)o;
 		if (okf) okf[i] = okp[c];
 		for (int32_t j = 0; j < ni; ++j) b[o++] = a[(int)VL(k0 + (ni - j - 1))];
 	}
@@ -1353,7 +1357,7 @@ k_chain_lds(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a
 #undef R_P
 #undef R_T
 }
-#define INST_CHAIN_LDS(C, L) template __global__ void k_chain_lds<C, L>(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, AlAnchor *, uint64_t *, uint32_t *, uint64_t *, const uint32_t *, int, int, AlParams, unsigned long long *, ChainSeg);
+#define INST_CHAIN_LDS(C, L) template __global__ void k_chain_lds<C, L>(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, AlAnchor *, uint64_t *, uint32_t *, uint64_t *, const uint32_t *, int, int, AlParams, unsigned long long *, ChainSeg, uint32_t *, int);
 INST_CHAIN_LDS(16, 64) INST_CHAIN_LDS(24, 64) INST_CHAIN_LDS(32, 64) INST_CHAIN_LDS(40, 64) INST_CHAIN_LDS(48, 64) INST_CHAIN_LDS(64, 64) INST_CHAIN_LDS(80, 64) INST_CHAIN_LDS(96, 64) INST_CHAIN_LDS(128, 32)
 
 // explicit instantiations used by the runtime
@@ -1682,7 +1686,7 @@ k_lower_bounds(const uint32_t *__restrict__ keys, uint32_t n, LbThr T, uint32_t 
 
 // rechain decision (map.c:353-375): one lane per fragment; appends fragments that must be re-seeded with max_occ
 extern "C" __global__ void __launch_bounds__(256)
-k_rechain_test(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__ a_off, const uint64_t *__restrict__ u_all,
+k_rechain_test(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__ a_off, const uint64_t *__restrict__ u_all, const uint32_t *__restrict__ uo_all,
                const uint32_t *__restrict__ frag_nu, const int32_t *__restrict__ frag_rep, const uint32_t *__restrict__ frag_first,
                int n_frag, uint32_t *__restrict__ list, uint32_t *__restrict__ n_list)
 {
@@ -1693,9 +1697,10 @@ k_rechain_test(const AlAnchor *__restrict__ chained, const uint64_t *__restrict_
 	const uint32_t n_u = frag_nu[f];
 	int rechain = 0;
 	if (n_u > 0) {
-		const uint64_t *u = u_all + a_off[f] + f; const AlAnchor *a = chained + a_off[f];
-		int n_chained_segs = 1, max = 0, max_i = -1, max_off = -1, off = 0;
-		for (uint32_t i = 0; i < n_u; ++i) { if (max < (int)(u[i] >> 32)) max = (int)(u[i] >> 32), max_i = (int)i, max_off = off; off += (int)(uint32_t)u[i]; }
+		const uint64_t *u = u_all + a_off[f] + f; const uint32_t *uo = uo_all + a_off[f] + f; const AlAnchor *a = chained + a_off[f];
+		int n_chained_segs = 1, max = 0, max_i = -1, max_off = -1;
+		for (uint32_t i = 0; i < n_u; ++i) { if (max < (int)(u[i] >> 32)) max = (int)(u[i] >> 32), max_i = (int)i; }
+		if (max_i >= 0) max_off = (int)uo[max_i];
 		if (max_i >= 0) {
 			for (int i = 1; i < (int32_t)(uint32_t)u[max_i]; ++i)
 				if ((a[max_off + i].y & AL_SEED_SEG_MASK) != (a[max_off + i - 1].y & AL_SEED_SEG_MASK)) ++n_chained_segs;

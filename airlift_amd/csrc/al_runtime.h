@@ -82,6 +82,10 @@ struct al_ctx_s {
 
 	DevBuf<uint32_t> rd_seq, rd_len, frag_first, frag_hash, mini_cnt, frag_nm, frag_na, frag_nu, rechain_list, rechain_sorted, tmp_u32;
 	DevBuf<uint64_t> rd_off, mini_off, a_off, u, ws_u64, tmp_u64, tmp_u64b;
+	DevBuf<uint32_t> uo;                   // per chain list entry: offset of the chain's first anchor in the fragment's range of chained[]
+	DevBuf<uint64_t> big_k0, big_k1;       // key double buffer of the device-wide anchor sort (fragments above the register tiles)
+	// compact copy of the fragments the tile chaining kernel hands back (al_runtime.hip: chain_fallback): a small virtual batch for the segment-wise kernels
+	DevBuf<AlAnchor> v_anchors, v_chained; DevBuf<uint64_t> v_u, v_a_off, v_first64; DevBuf<uint32_t> v_na, v_nseg, v_first, v_rd_len, v_order, v_nu, fbk_list;
 	DevBuf<int32_t> frag_rep, ws_i32;
 	DevBuf<AlAnchor> mini, heap_ws, anchors, chained;
 	DevBuf<AlMatch> match;

@@ -21,13 +21,21 @@
 extern "C" __global__ void k_sketch(const uint32_t *, const uint64_t *, const uint32_t *, const uint64_t *, AlAnchor *, uint32_t *, int, int, int, int);
 extern "C" __global__ void k_seed(const uint64_t *, int, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, const uint32_t *, AlMatch *, uint32_t *, uint32_t *, int32_t *, const uint32_t *, int, int);
 extern "C" __global__ void k_alser_count(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, int, int, unsigned long long *);
-extern "C" __global__ void k_rechain_test(const AlAnchor *, const uint64_t *, const uint64_t *, const uint32_t *, const int32_t *, const uint32_t *, int, uint32_t *, uint32_t *);
+extern "C" __global__ void k_rechain_test(const AlAnchor *, const uint64_t *, const uint64_t *, const uint32_t *, const uint32_t *, const int32_t *, const uint32_t *, int, uint32_t *, uint32_t *);
+// al_kernels_chain.hip
+struct TileSched { uint32_t n_items; uint32_t ent[7]; uint32_t item[7]; };
+template <bool MARKS> __global__ void k_chain_tile(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *, const TileSched, const uint32_t *, AlAnchor *, uint64_t *, uint32_t *, uint32_t *, uint32_t *, uint32_t *, const AlParams, const int, unsigned long long *, const int);
+__global__ void k_uo_fill(const uint32_t *, int, const uint64_t *, const uint32_t *, const uint64_t *, uint32_t *, const uint32_t *);
+__global__ void k_fb_meta(const uint32_t *, int, const uint32_t *, const uint32_t *, uint32_t *, uint32_t *);
+__global__ void k_fb_reads(const uint32_t *, int, const uint32_t *, const uint32_t *, const uint64_t *, uint32_t *, uint32_t *, uint32_t *);
+__global__ void k_fb_copy_in(const uint32_t *, int, const uint64_t *, const uint32_t *, const AlAnchor *, const uint64_t *, AlAnchor *);
+__global__ void k_fb_copy_out(const uint32_t *, int, const uint64_t *, const uint64_t *, const uint32_t *, const uint64_t *, const AlAnchor *, uint32_t *, uint64_t *, uint32_t *, AlAnchor *);
 template <int CAP> __global__ void k_anchor_sort(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, uint32_t *, unsigned int *, const uint32_t *, int, unsigned long long *, int);
 __global__ void k_anchor_sort_small(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, uint32_t *, unsigned int *, const uint32_t *, int, unsigned long long *, int);
 template <int HCAP, int LANES> __global__ void k_anchor_heap(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, AlAnchor *, const uint32_t *, const uint32_t *, int, int, unsigned long long *, int, const uint32_t *, uint32_t);
 template <int MCAPH, int RING> __global__ void k_anchor_heap_wave(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, const uint32_t *, const uint32_t *, const uint32_t *, uint32_t, unsigned long long *, int);
 template <int CAP> __global__ void k_chain(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, AlAnchor *, uint64_t *, uint32_t *, int32_t *, uint64_t *, const uint32_t *, int, AlParams, unsigned long long *, ChainSeg);
-template <int CAPL, int LANES> __global__ void k_chain_lds(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, AlAnchor *, uint64_t *, uint32_t *, uint64_t *, const uint32_t *, int, int, AlParams, unsigned long long *, ChainSeg);
+template <int CAPL, int LANES> __global__ void k_chain_lds(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, AlAnchor *, uint64_t *, uint32_t *, uint64_t *, const uint32_t *, int, int, AlParams, unsigned long long *, ChainSeg, uint32_t *, int);
 template <int PER, int NW, int MCAP> __global__ void k_anchor_sort_reg(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, uint32_t *, const uint32_t *, int, int, int);
 __global__ void k_anchor_big_expand(const uint64_t *, const uint64_t *, const uint32_t *, const AlMatch *, const uint32_t *, const uint32_t *, int, const uint64_t *, uint64_t *, int, int);
 __global__ void k_anchor_big_scatter(const uint64_t *, const uint32_t *, int, const uint64_t *, const uint64_t *, const uint64_t *, const uint32_t *, const uint32_t *, const AlMatch *, const uint32_t *, AlAnchor *, uint32_t *, int, int, int);
@@ -122,7 +130,7 @@ static void al_dev_free_raw(void *p)
 }
 
 static const char *g_stage_names[ST_N] = { "sketch", "seed_lookup", "scan", "size_order", "anchor_sort_small", "anchor_sort", "anchor_sort_blk", "anchor_sort_big", "anchor_heap",
-                                           "chain_lds32", "chain_lds48", "chain_lds64", "chain_lds128", "seg_find", "seg_chain_lds", "seg_chain_wave", "seg_merge", "rechain",
+                                           "chain_lds32", "chain_lds48", "chain_lds64", "chain_lds128", "chain_tile", "chain_fallback", "chain_legacy", "chain_ties", "rechain",
                                            "regs", "ext_prep", "ext_sort", "ext_dp_lane", "ext_dp_g4", "ext_dp_g8", "ext_dp_g22", "ext_finish", "compact" };
 // kernel behind each interval (what rocprofv3 --kernel-trace lists); "" = several launches
 // the kernel of an interval that is exactly one launch of one kernel ("" otherwise: several kernels or several launches)
@@ -218,6 +226,7 @@ static void ctx_release_buffers(al_ctx_t *c)
 	c->chained.release(); c->match.release(); c->counters.release(); c->scan_tmp.release(); c->regs0.release(); c->regs.release(); c->reg_cnt.release();
 	c->chain_key.release(); c->chain_idx.release(); c->chain_idx2.release(); c->tie_list.release(); c->lb_buf.release(); c->tmp_u64b.release();
 	c->chain_tmp.release(); c->u_tmp.release(); c->okey_tmp.release(); c->fb2_list.release(); c->fb3_list.release(); c->seg_cnt.release(); c->seg_first.release(); c->seg_cnt0.release(); c->seg_first0.release(); c->seg_t1.release(); c->vs_off.release(); c->vs_na.release(); c->vs_meta.release(); c->vs_res.release(); c->vs_cls.release(); c->seg_key.release(); c->seg_idx.release(); c->seg_ord.release(); c->fb_list.release(); c->tie_frags.release(); c->heap_cnt.release(); c->tie_sorted.release(); c->big_na.release(); c->big_off.release();
+	c->uo.release(); c->big_k0.release(); c->big_k1.release(); c->v_anchors.release(); c->v_chained.release(); c->v_u.release(); c->v_a_off.release(); c->v_first64.release(); c->v_na.release(); c->v_nseg.release(); c->v_first.release(); c->v_rd_len.release(); c->v_order.release(); c->v_nu.release(); c->fbk_list.release();
 	c->a_off_p1.release(); c->frag_na_p1.release(); c->frag_rep_p1.release(); c->cigar.release(); c->reg_off.release(); c->cig_off.release(); c->align_ws.release(); c->seg_a.release(); c->seg_u.release();
 }
 extern "C" void al_ctx_destroy(al_ctx_t *c)
@@ -346,9 +355,10 @@ __global__ void k_scatter_off(const uint64_t *off, const uint32_t *list, int n, 
 static int ensure_anchor_space(al_ctx_t *c, uint64_t total, bool keep)
 {
 	const uint64_t nf = c->n_frag;
+	// per seed hit: the sorted anchor 16 B, its place in chained[] 16 B, a chain list slot (u 8 B + uo 4 B).  The chaining scratch of the
+	// segment-wise kernels (56 B per seed hit) is sized for the few fragments that still take them (chain_fallback / chain_legacy).
 	if (c->anchors.ensure(total + 1, keep, c->stream) || c->chained.ensure(total + 1, keep, c->stream) || c->u.ensure(total + nf + 2, keep, c->stream) ||
-	    c->ws_i32.ensure(total * 4 + 4, false, c->stream) || c->ws_u64.ensure(total + 1, false, c->stream) ||
-	    c->chain_tmp.ensure(total + 1, false, c->stream) || c->u_tmp.ensure(total + 1, false, c->stream) || c->okey_tmp.ensure(total + 2, false, c->stream)) return -1;
+	    c->uo.ensure(total + nf + 2, keep, c->stream)) return -1;
 	return 0;
 }
 
@@ -373,7 +383,7 @@ static int sort_u32_pairs(al_ctx_t *c, const uint32_t *k_in, uint32_t *k_out, co
 	return 0;
 }
 
-#define LCH(C, L, LO, AOFF, NA, CH, UO, NU, LIST, N, SEG) do { const int n__ = (N); if (n__ > 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain_lds<C, L>), dim3((n__ + L - 1) / L), dim3(64), 0, s, c->anchors.p, AOFF, NA, c->frag_first.p, c->rd_len.p, CH, UO, NU, c->ws_u64.p, LIST, n__, LO, c->P, c->counters.p, SEG); } while (0)
+#define LCH(C, L, LO, AOFF, NA, CH, UO, NU, LIST, N, SEG, UOFF, WS, STRIDE) do { const int n__ = (N); if (n__ > 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain_lds<C, L>), dim3((n__ + L - 1) / L), dim3(64), 0, s, c->anchors.p, AOFF, NA, c->frag_first.p, c->rd_len.p, CH, UO, NU, WS, LIST, n__, LO, c->P, c->counters.p, SEG, UOFF, STRIDE); } while (0)
 
 // Chaining of the fragments order[0 .. n) (more than 128 anchors each, or any size when the compact LDS rows cannot hold the
 // options in force) through their segments: cut -> order the segments by length -> the lane-per-entry LDS kernels for segments
@@ -442,7 +452,7 @@ static int chain_by_segments(al_ctx_t *c, const uint32_t *order, int n, bool lds
 	if (ns > 0) {
 		const uint32_t *so0 = c->seg_idx.p, *so1 = c->seg_ord.p;
 		if (lds_ok) {
-#define LSEG(C, L, LIST, A, B) LCH(C, L, -1, c->vs_off.p, c->vs_na.p, c->chain_tmp.p, c->u_tmp.p, (uint32_t *)nullptr, (LIST) + (A), (int)((B) - (A)), sg)
+#define LSEG(C, L, LIST, A, B) LCH(C, L, -1, c->vs_off.p, c->vs_na.p, c->chain_tmp.p, c->u_tmp.p, (uint32_t *)nullptr, (LIST) + (A), (int)((B) - (A)), sg, (uint32_t *)nullptr, c->ws_u64.p, 0)
 			LSEG(16, 64, so0, 0u, (uint32_t)ns0);
 			LSEG(24, 64, so1, 0u, lb[0]); LSEG(32, 64, so1, lb[0], lb[1]); LSEG(40, 64, so1, lb[1], lb[2]); LSEG(48, 64, so1, lb[2], lb[3]);
 			// A lane walks a 49 ... 128-anchor entry for 0.5 - 1.3 ms whatever the launch holds; the wavefront kernel takes ~1 us per anchor of an
@@ -502,6 +512,83 @@ static int chain_by_segments(al_ctx_t *c, const uint32_t *order, int n, bool lds
 	return 0;
 }
 
+// The segment-wise kernels on fragments list[0 .. n) of the batch arrays (option values outside the tile kernel's range), then uo[].
+static int chain_legacy(al_ctx_t *c, const uint32_t *list, int n, bool lds_ok, const uint32_t *skip_flag)
+{
+	if (n <= 0) return 0;
+	const uint64_t total = c->n_anchor_total;
+	if (c->ws_i32.ensure(total * 4 + 4, false, c->stream) || c->ws_u64.ensure(total + 1, false, c->stream) ||
+	    c->chain_tmp.ensure(total + 1, false, c->stream) || c->u_tmp.ensure(total + 1, false, c->stream) || c->okey_tmp.ensure(total + 2, false, c->stream)) return -1;
+	if (chain_by_segments(c, list, n, lds_ok, false, skip_flag)) return -1;
+	hipLaunchKernelGGL(k_uo_fill, dim3(n), dim3(64), 0, c->stream, list, n, c->a_off.p, c->frag_nu.p, c->u.p, c->uo.p, skip_flag);
+	return 0;
+}
+
+// Fragments the tile kernel handed back (a segment longer than its tile, more chain ends in a segment than its serial sorts take, tied
+// chain starts among more than 64 chains): a compact copy of their anchors becomes a small virtual batch -- fragment v of the list is
+// fragment v there -- which the segment-wise kernels chain (their per-anchor scratch is sized for this copy, not for the batch); the
+// results go back to the fragments' places with their uo[].
+static int chain_fallback(al_ctx_t *c, const uint32_t *fb, int n_fb, bool lds_ok)
+{
+	hipStream_t s = c->stream;
+	if (n_fb <= 0) return 0;
+	if (c->v_na.ensure((size_t)n_fb + 2) || c->v_nseg.ensure((size_t)n_fb + 2) || c->v_a_off.ensure((size_t)n_fb + 2) || c->v_first64.ensure((size_t)n_fb + 2) ||
+	    c->v_first.ensure((size_t)n_fb + 2) || c->v_rd_len.ensure(2 * (size_t)n_fb + 2) || c->v_order.ensure((size_t)n_fb + 2) || c->v_nu.ensure((size_t)n_fb + 2)) return -1;
+	hipLaunchKernelGGL(k_fb_meta, dim3((n_fb + 256) / 256), dim3(256), 0, s, fb, n_fb, c->frag_na.p, c->frag_first.p, c->v_na.p, c->v_nseg.p);
+	if (scan_u32_to_u64(c, c->v_na.p, c->v_a_off.p, n_fb) || scan_u32_to_u64(c, c->v_nseg.p, c->v_first64.p, n_fb)) return -1;
+	uint64_t vt = 0;
+	AL_HIP_CHECK(hipMemcpyAsync(&vt, c->v_a_off.p + n_fb, 8, hipMemcpyDeviceToHost, s));
+	AL_HIP_CHECK(hipStreamSynchronize(s));
+	{ static const bool tr = getenv("AL_TRACE") != nullptr; if (tr) fprintf(stderr, "[airlift] trace: chain fallback: %d fragments, %llu anchors, through the segment-wise kernels\n", n_fb, (unsigned long long)vt); }
+	if (c->v_anchors.ensure(vt + 1, false, s) || c->v_chained.ensure(vt + 1, false, s) || c->v_u.ensure(vt + (uint64_t)n_fb + 2, false, s) ||
+	    c->ws_i32.ensure(vt * 4 + 4, false, s) || c->ws_u64.ensure(vt + 1, false, s) || c->chain_tmp.ensure(vt + 1, false, s) || c->u_tmp.ensure(vt + 1, false, s) || c->okey_tmp.ensure(vt + 2, false, s)) return -1;
+	hipLaunchKernelGGL(k_fb_reads, dim3((n_fb + 256) / 256), dim3(256), 0, s, fb, n_fb, c->frag_first.p, c->rd_len.p, c->v_first64.p, c->v_first.p, c->v_rd_len.p, c->v_order.p);
+	hipLaunchKernelGGL(k_fb_copy_in, dim3(n_fb), dim3(64), 0, s, fb, n_fb, c->a_off.p, c->frag_na.p, c->anchors.p, c->v_a_off.p, c->v_anchors.p);
+	// the virtual batch stands in for the batch arrays while the segment-wise kernels run
+	AlAnchor *const sv_anchors = c->anchors.p, *const sv_chained = c->chained.p; uint64_t *const sv_a_off = c->a_off.p, *const sv_u = c->u.p;
+	uint32_t *const sv_na = c->frag_na.p, *const sv_first = c->frag_first.p, *const sv_rd_len = c->rd_len.p, *const sv_nu = c->frag_nu.p;
+	c->anchors.p = c->v_anchors.p; c->chained.p = c->v_chained.p; c->a_off.p = c->v_a_off.p; c->u.p = c->v_u.p;
+	c->frag_na.p = c->v_na.p; c->frag_first.p = c->v_first.p; c->rd_len.p = c->v_rd_len.p; c->frag_nu.p = c->v_nu.p;
+	const int rc = chain_by_segments(c, c->v_order.p, n_fb, lds_ok, false, nullptr);
+	c->anchors.p = sv_anchors; c->chained.p = sv_chained; c->a_off.p = sv_a_off; c->u.p = sv_u;
+	c->frag_na.p = sv_na; c->frag_first.p = sv_first; c->rd_len.p = sv_rd_len; c->frag_nu.p = sv_nu;
+	if (rc) return -1;
+	hipLaunchKernelGGL(k_fb_copy_out, dim3(n_fb), dim3(64), 0, s, fb, n_fb, c->a_off.p, c->v_a_off.p, c->v_nu.p, c->v_u.p, c->v_chained.p, c->frag_nu.p, c->u.p, c->uo.p, c->chained.p);
+	return 0;
+}
+
+// The tile kernel over the items of S (list entries grouped by size class), then the fallback for what it hands back.
+static int chain_tiles(al_ctx_t *c, const uint32_t *list, const TileSched &S, const uint32_t *skip_flag, int lmin, bool first, bool lds_ok)
+{
+	hipStream_t s = c->stream;
+	auto ev = [&](int st) -> int { if (first) AL_HIP_CHECK(hipEventRecord(c->ev[st + 1], s)); return 0; };
+	uint32_t n_fb = 0;
+	if (S.n_items > 0) {
+		uint32_t *fb_cnt = (uint32_t *)(c->counters.p + 15);
+		static const int force_fb = getenv("AL_TEST_TILE_FB") ? 1 : 0;
+		AL_HIP_CHECK(hipMemsetAsync(fb_cnt, 0, 8, s));
+		if (c->opt.max_chain_skip < 15) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain_tile<true>), dim3(S.n_items), dim3(64), 0, s, c->anchors.p, c->a_off.p, c->frag_na.p, c->frag_first.p, c->rd_len.p, list, S, skip_flag,
+		                                                  c->chained.p, c->u.p, c->uo.p, c->frag_nu.p, c->fb_list.p, fb_cnt, c->P, lmin, c->counters.p, force_fb);
+		else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain_tile<false>), dim3(S.n_items), dim3(64), 0, s, c->anchors.p, c->a_off.p, c->frag_na.p, c->frag_first.p, c->rd_len.p, list, S, skip_flag,
+		                        c->chained.p, c->u.p, c->uo.p, c->frag_nu.p, c->fb_list.p, fb_cnt, c->P, lmin, c->counters.p, force_fb);
+		if (ev(ST_SEG_FIND)) return -1;
+		AL_HIP_CHECK(hipMemcpyAsync(&n_fb, fb_cnt, 4, hipMemcpyDeviceToHost, s));
+		AL_HIP_CHECK(hipStreamSynchronize(s));
+	} else if (ev(ST_SEG_FIND)) return -1;
+	if (n_fb > 0) {
+		c->n_chain_fallback += n_fb;
+		// (the list the kernel appended to atomically, in ascending fragment order: the same virtual batch on every run)
+		size_t bytes = 0;
+		if (c->fbk_list.ensure((size_t)n_fb + 2)) return -1;
+		AL_HIP_CHECK(rocprim::radix_sort_keys(nullptr, bytes, (const uint32_t *)c->fb_list.p, c->fbk_list.p, (int)n_fb, 0, 32, s));
+		if (c->scan_tmp.ensure(bytes + 16)) return -1;
+		AL_HIP_CHECK(rocprim::radix_sort_keys(c->scan_tmp.p, bytes, (const uint32_t *)c->fb_list.p, c->fbk_list.p, (int)n_fb, 0, 32, s));
+		if (chain_fallback(c, c->fbk_list.p, (int)n_fb, lds_ok)) return -1;
+	}
+	if (ev(ST_SEG_CHAIN_LDS)) return -1;
+	return 0;
+}
+
 static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max_occ, uint64_t base_off, bool first)
 {
 	hipStream_t s = c->stream;
@@ -540,17 +627,27 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 	if (first) hipLaunchKernelGGL(k_iota_u32, dim3((nl + 255) / 256), dim3(256), 0, s, c->chain_idx.p, (uint32_t)nl);
 	if (sort_u32_pairs(c, first ? c->frag_na.p : c->tmp_u32.p, c->chain_key.p, first ? c->chain_idx.p : list, c->chain_idx2.p, nl)) return -1;
 	const uint32_t *order = c->chain_idx2.p;
-	uint32_t lb[11];
+	uint32_t lb[15];
 	{   // AL_TEST_SORT_BLK / AL_TEST_SORT_BIG (tests): smallest anchor count that goes to the block / device-wide sort
 		static const char *e1 = getenv("AL_TEST_SORT_BLK"), *e2 = getenv("AL_TEST_SORT_BIG");
 		uint32_t t_blk = e1 ? (uint32_t)atoi(e1) : 1025u, t_big = e2 ? (uint32_t)atoi(e2) : 8193u;   // above 8192 anchors: device-wide radix sort
 		if (t_blk < 65u) t_blk = 65u; if (t_blk > 1025u) t_blk = 1025u; if (t_big < t_blk) t_big = t_blk; if (t_big > 8193u) t_big = 8193u;
 		{ int rb = 1; while ((1ULL << rb) < c->mi->seq.size()) ++rb; if (33 + rb + 16 > 64) t_big = t_blk; }   // compact keys of the block sort: strand | contig | position | list in 64 bits
-		const uint32_t thr[11] = {65, 81, 97, 129, t_blk, t_big, std::min(std::max(t_blk, 2049u), t_big), std::min(std::max(t_blk, 4097u), t_big), std::min(std::max(t_blk, 8193u), t_big),
-		                          std::min(257u, t_blk), std::min(513u, t_blk)};
-		if (lower_bounds(c, c->chain_key.p, (uint32_t)nl, thr, 11, lb)) return -1;
+		const uint32_t thr[15] = {65, 81, 97, 129, t_blk, t_big, std::min(std::max(t_blk, 2049u), t_big), std::min(std::max(t_blk, 4097u), t_big), std::min(std::max(t_blk, 8193u), t_big),
+		                          std::min(257u, t_blk), std::min(513u, t_blk), 1, 33, 257, 513};
+		if (lower_bounds(c, c->chain_key.p, (uint32_t)nl, thr, 15, lb)) return -1;
 	}
+	const uint32_t lb1 = lb[11], lb33 = lb[12], lb257x = lb[13], lb513x = lb[14];
 	const uint32_t lb65 = lb[0], lb81 = lb[1], lb97 = lb[2], lb129 = lb[3], lb1025 = lb[4], lb_big = lb[5], lb2049 = lb[6], lb4097 = lb[7], lb8193 = lb[8], lb257 = lb[9], lb513 = lb[10];
+	// Fragments of more than 128 anchors: the tile kernel (al_kernels_chain.hip).  Its compact rows need what the lane kernels need, and a
+	// segment that can hold a chain must have >= 2 anchors (min_cnt anchors, min_chain_score at <= k + 1 per anchor: chain.c:60-73,118-124);
+	// other option values: the segment-wise kernels (chain_legacy).  AL_TEST_TILE_ALL (tests): every fragment through the tile kernel.
+	int lmin = c->opt.min_cnt > 1 ? c->opt.min_cnt : 1;
+	{ const int per = c->mi->k + 1, need = (c->opt.min_chain_score + per - 1) / per; if (need > lmin) lmin = need; }
+	static const bool tile_all = getenv("AL_TEST_TILE_ALL") != nullptr;
+	const bool tiles_ok = lds_ok && lmin >= 2 && !((c->P.dbg >> 28) & 1);
+	const uint32_t tile_from = !tiles_ok ? (uint32_t)nl : tile_all ? lb1 : lb129;
+	if (c->fb_list.ensure((size_t)nl + 2)) return -1;
 	if (ev(ST_ORDER)) return -1;
 	{
 		if (c->tie_list.ensure((size_t)c->n_frag + 2)) return -1;         // one flag per fragment id
@@ -587,8 +684,8 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 			uint64_t nbig = 0;
 			AL_HIP_CHECK(hipMemcpyAsync(&nbig, c->big_off.p + nb, 8, hipMemcpyDeviceToHost, s));
 			AL_HIP_CHECK(hipStreamSynchronize(s));
-			// key double buffer in the chaining scratch (16 bytes per anchor each), free at this point
-			uint64_t *ka = (uint64_t *)c->ws_i32.p, *kbuf = (uint64_t *)c->chain_tmp.p;
+			if (c->big_k0.ensure((size_t)nbig + 1, false, s) || c->big_k1.ensure((size_t)nbig + 1, false, s)) return -1;
+			uint64_t *ka = c->big_k0.p, *kbuf = c->big_k1.p;                   // key double buffer
 			hipLaunchKernelGGL(k_anchor_big_expand, dim3(nb), dim3(256), 0, s, c->di.pos, c->mini_off.p, c->frag_first.p, c->match.p, c->frag_nm.p,
 			                   order + b0, (int)nb, c->big_off.p, ka, rid_bits, pos_bits);
 			int rbits = 0; while ((1ULL << rbits) < nb) ++rbits;
@@ -636,23 +733,27 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 	}
 	{
 		const ChainSeg nosg{nullptr, nullptr, (const uint32_t *)c->tie_list.p, 1, nullptr};
-#define LFR(C, L, A, B) LCH(C, L, -1, c->a_off.p, c->frag_na.p, c->chained.p, c->u.p, c->frag_nu.p, order + (A), (int)((B) - (A)), nosg)
-#define LFRLO(C, L, LO) LCH(C, L, LO, c->a_off.p, c->frag_na.p, c->chained.p, c->u.p, c->frag_nu.p, order, (int)lb65, nosg)
+		// chain-end scratch of the whole-fragment lane kernels: 64 words per entry of the <= 64-anchor classes, 128 above, by list position
+		const uint32_t n_lo = std::min(lb65, tile_from), n_mid_end = std::min(lb129, tile_from);
+		if (lds_ok && c->ws_u64.ensure((size_t)n_lo * 64 + (size_t)(n_mid_end > lb65 ? n_mid_end - lb65 : 0u) * 128 + 64, false, s)) return -1;
+#define LFR(C, L, A, B) LCH(C, L, -1, c->a_off.p, c->frag_na.p, c->chained.p, c->u.p, c->frag_nu.p, order + (A), (int)((B) - (A)), nosg, c->uo.p, c->ws_u64.p + (size_t)n_lo * 64 + (size_t)((A) - lb65) * 128, 128)
+#define LFRLO(C, L, LO) LCH(C, L, LO, c->a_off.p, c->frag_na.p, c->chained.p, c->u.p, c->frag_nu.p, order, (int)n_lo, nosg, c->uo.p, c->ws_u64.p, 64)
 		if (lds_ok) { LFRLO(16, 64, -1); LFRLO(24, 64, 16); LFRLO(32, 64, 24); }
 		if (ev(ST_CHAIN_LDS32)) return -1;
 		if (lds_ok) { LFRLO(40, 64, 32); LFRLO(48, 64, 40); }
 		if (ev(ST_CHAIN_LDS48)) return -1;
 		if (lds_ok) LFRLO(64, 64, 48);
 		if (ev(ST_CHAIN_LDS64)) return -1;
-		if (lds_ok) {   // exact ranges of the size-ordered list (lane counts differ between these classes)
+		if (lds_ok && n_mid_end > lb65) {   // exact ranges of the size-ordered list (lane counts differ between these classes)
 			// 64-lane wavefronts hold more fragments per CU but need enough of them to cover the chip; a thin class runs on half waves
 			const uint32_t fill = 64u * 3u * 256u * 2u;
 			static const uint32_t wave_max = getenv("AL_CHAIN_WAVE_MAX") ? (uint32_t)atoi(getenv("AL_CHAIN_WAVE_MAX")) : 8192u;
 			uint32_t from = lb65;
-			if (lb129 > lb65 && lb129 - lb65 < wave_max)   // few fragments of 65 ... 128 anchors (a small batch): a wavefront each is over sooner than a lane each
+			if (lb129 - lb65 < wave_max) {   // few fragments of 65 ... 128 anchors (a small batch): a wavefront each is over sooner than a lane each
 				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<AL_CHAIN_CAP>), dim3(lb129 - lb65), dim3(64), 0, s, c->anchors.p, c->a_off.p, c->frag_na.p, c->frag_first.p, c->rd_len.p, c->chained.p, c->u.p, c->frag_nu.p,
-				                   c->ws_i32.p, c->ws_u64.p, order + lb65, (int)(lb129 - lb65), c->P, c->counters.p, nosg);
-			else {
+				                   (int32_t *)nullptr, (uint64_t *)nullptr, order + lb65, (int)(lb129 - lb65), c->P, c->counters.p, nosg);   // (<= 128 anchors: its rows are in LDS, no scratch)
+				hipLaunchKernelGGL(k_uo_fill, dim3(lb129 - lb65), dim3(64), 0, s, order + lb65, (int)(lb129 - lb65), c->a_off.p, c->frag_nu.p, c->u.p, c->uo.p, (const uint32_t *)c->tie_list.p);
+			} else {
 				if (lb81 - lb65 >= fill) { LFR(80, 64, lb65, lb81); from = lb81; }
 				if (from == lb81 && lb97 - lb81 >= fill) { LFR(96, 64, lb81, lb97); from = lb97; }
 				LFR(128, 32, from, lb129);
@@ -661,10 +762,20 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 		if (ev(ST_CHAIN_LDS128)) return -1;
 #undef LFR
 #undef LFRLO
-		const uint32_t tail = lds_ok ? lb129 : 0u;
-		if (chain_by_segments(c, order + tail, nl - (int)tail, lds_ok, first, (const uint32_t *)c->tie_list.p, false, lb2049 > tail ? (int)(lb2049 - tail) : 0, lb8193 > tail ? (int)(lb8193 - tail) : 0)) return -1;
+		if (tiles_ok) {
+			TileSched S; const uint32_t b[6] = {tile_from, std::max(tile_from, lb33), std::max(tile_from, lb65), std::max(tile_from, lb129), std::max(tile_from, lb257x), std::max(tile_from, lb513x)};
+			for (int k = 0; k < 6; ++k) S.ent[k] = b[k]; S.ent[6] = (uint32_t)nl;
+			S.item[0] = 0; for (int k = 0; k < 6; ++k) { const uint32_t per = 32u >> k; S.item[k + 1] = S.item[k] + (S.ent[k + 1] - S.ent[k] + per - 1) / per; }
+			S.n_items = S.item[6];
+			if (chain_tiles(c, order, S, (const uint32_t *)c->tie_list.p, lmin, first, lds_ok)) return -1;
+		} else {
+			if (ev(ST_SEG_FIND) || ev(ST_SEG_CHAIN_LDS)) return -1;
+			const uint32_t tail = lds_ok ? lb129 : 0u;
+			if (chain_legacy(c, order + tail, nl - (int)tail, lds_ok, (const uint32_t *)c->tie_list.p)) return -1;
+		}
+		if (ev(ST_SEG_CHAIN_WAVE)) return -1;
 	}
-	{   // second round: the fragments whose anchors the side stream merged, any size, through the segment path
+	{   // second round: the fragments whose anchors the side stream merged, any size
 		AL_HIP_CHECK(hipStreamWaitEvent(s, c->ev_side[first ? 1 : 3], 0));
 		if (c->tie_frags.ensure((size_t)nl + 2)) return -1;
 		uint32_t *cnt = (uint32_t *)(c->counters.p + 15);
@@ -674,13 +785,17 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 		AL_HIP_CHECK(hipMemcpyAsync(&n_tie, cnt, 4, hipMemcpyDeviceToHost, s));
 		AL_HIP_CHECK(hipStreamSynchronize(s));
 		if (n_tie > 0) {
-			size_t bytes = 0;    // ascending fragment ids: a deterministic segment order (the collection above appends atomically)
+			size_t bytes = 0;    // ascending fragment ids: a deterministic order (the collection above appends atomically)
 			if (c->tie_sorted.ensure((size_t)n_tie + 2)) return -1;
 			AL_HIP_CHECK(rocprim::radix_sort_keys(nullptr, bytes, (const uint32_t *)c->tie_frags.p, c->tie_sorted.p, (int)n_tie, 0, 32, s));
 			if (c->scan_tmp.ensure(bytes + 16)) return -1;
 			AL_HIP_CHECK(rocprim::radix_sort_keys(c->scan_tmp.p, bytes, (const uint32_t *)c->tie_frags.p, c->tie_sorted.p, (int)n_tie, 0, 32, s));
-			if (chain_by_segments(c, c->tie_sorted.p, (int)n_tie, lds_ok, false, nullptr)) return -1;
+			if (tiles_ok) {
+				TileSched S; for (int k = 0; k < 6; ++k) { S.ent[k] = 0; S.item[k] = 0; } S.ent[6] = n_tie; S.item[6] = n_tie; S.n_items = n_tie;   // a fragment per item, any size
+				if (chain_tiles(c, c->tie_sorted.p, S, nullptr, lmin, false, lds_ok)) return -1;
+			} else if (chain_legacy(c, c->tie_sorted.p, (int)n_tie, lds_ok, nullptr)) return -1;
 		}
+		if (ev(ST_SEG_MERGE)) return -1;
 	}
 	AL_HIP_CHECK(hipGetLastError());
 	return 0;
@@ -702,7 +817,7 @@ int al_run_seed_stages(al_ctx_t *c)
 	c->n_rechain = 0;
 	if (c->opt.max_occ > c->opt.mid_occ) {
 		uint32_t *cnt = (uint32_t *)(c->counters.p + 3);
-		hipLaunchKernelGGL(k_rechain_test, dim3((c->n_frag + 255) / 256), dim3(256), 0, s, c->chained.p, c->a_off.p, c->u.p, c->frag_nu.p, c->frag_rep.p, c->frag_first.p, c->n_frag, c->rechain_list.p, cnt);
+		hipLaunchKernelGGL(k_rechain_test, dim3((c->n_frag + 255) / 256), dim3(256), 0, s, c->chained.p, c->a_off.p, c->u.p, c->uo.p, c->frag_nu.p, c->frag_rep.p, c->frag_first.p, c->n_frag, c->rechain_list.p, cnt);
 		uint32_t n = 0;
 		AL_HIP_CHECK(hipMemcpyAsync(&n, cnt, 4, hipMemcpyDeviceToHost, s));
 		AL_HIP_CHECK(hipStreamSynchronize(s));
@@ -840,9 +955,17 @@ extern "C" int al_dbg_chains(al_ctx_t *c, int f, uint64_t *u, int cap_u, uint64_
 	AL_HIP_CHECK(hipMemcpy(&off, c->a_off.p + f, 8, hipMemcpyDeviceToHost));
 	int m = (int)nu < cap_u ? (int)nu : cap_u;
 	if (m > 0) AL_HIP_CHECK(hipMemcpy(u, c->u.p + off + f, (size_t)m * 8, hipMemcpyDeviceToHost));
-	uint64_t na = 0; for (int i = 0; i < m; ++i) na += (uint32_t)u[i];
-	if ((int64_t)na > cap_a) na = cap_a;
-	if (na > 0) AL_HIP_CHECK(hipMemcpy(xy, c->chained.p + off, na * 16, hipMemcpyDeviceToHost));
+	// the chains' anchors lie at their segments' places (uo[]): gathered here into the reference's back-to-back order
+	std::vector<uint32_t> uo((size_t)(m > 0 ? m : 1));
+	if (m > 0) AL_HIP_CHECK(hipMemcpy(uo.data(), c->uo.p + off + f, (size_t)m * 4, hipMemcpyDeviceToHost));
+	uint32_t fna = 0; AL_HIP_CHECK(hipMemcpy(&fna, c->frag_na.p + f, 4, hipMemcpyDeviceToHost));
+	std::vector<uint64_t> all((size_t)fna * 2 + 2);
+	if (fna > 0 && m > 0) AL_HIP_CHECK(hipMemcpy(all.data(), c->chained.p + off, (size_t)fna * 16, hipMemcpyDeviceToHost));
+	int64_t na = 0;
+	for (int i = 0; i < m; ++i) {
+		const uint32_t cnt = (uint32_t)u[i];
+		for (uint32_t j = 0; j < cnt && na < cap_a; ++j, ++na) { if ((uint64_t)uo[i] + j >= fna) return -1; xy[2 * na] = all[2 * ((size_t)uo[i] + j)]; xy[2 * na + 1] = all[2 * ((size_t)uo[i] + j) + 1]; }
+	}
 	return (int)nu;
 }
 
