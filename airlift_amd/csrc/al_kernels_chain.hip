@@ -89,8 +89,12 @@ struct TileSched {
 	uint32_t item[7];     // first item of class c
 };
 
+#define CT_NW 4                          // wavefronts per tile: they share the rows and take the segments of every step in turn
+#define CT_NT (64 * CT_NW)
+struct CtMisc { uint32_t n_seg, cnt[5], proc_end, next_pos, more, too_long; };
+
 template <bool MARKS>      // the lane path keeps the t[] marks of chain.c:81 only when 15 predecessors can exceed max_skip
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(CT_NT)
 k_chain_tile(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_off, const uint32_t *__restrict__ frag_na,
              const uint32_t *__restrict__ frag_first, const uint32_t *__restrict__ rd_len, const uint32_t *__restrict__ list, const TileSched S,
              const uint32_t *__restrict__ skip_flag, AlAnchor *__restrict__ chained, uint64_t *__restrict__ u_out, uint32_t *__restrict__ uo_out,
@@ -100,12 +104,14 @@ k_chain_tile(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ 
 	__shared__ uint64_t s_row[CT_TILE];
 	__shared__ uint32_t s_u[CT_TILE];
 	__shared__ uint16_t s_v[CT_TILE], s_tm[CT_TILE], s_perm[CT_TILE];
-	__shared__ uint16_t s_sstart[CT_SEGS], s_slen[CT_SEGS], s_snu[CT_SEGS], s_proc[CT_SEGS];
+	__shared__ uint16_t s_sstart[CT_SEGS], s_slen[CT_SEGS], s_snu[CT_SEGS], s_proc[CT_SEGS], s_G[CT_SEGS];
 	__shared__ uint8_t s_sfrag[CT_SEGS];
 	__shared__ uint8_t s_pen_same[CT_CLIN_N], s_pen_diff[CT_CLIN_N];
 	__shared__ CtFrag s_tf[CT_FRAGS];
 	__shared__ uint32_t s_fseg[CT_FRAGS + 1];                                  // first segment (tile order) of every fragment of the tile
-	const int lane = threadIdx.x;
+	__shared__ uint32_t s_ctot[CT_SEGS / 64 + 1];
+	__shared__ CtMisc s_misc;
+	const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
 	const unsigned long long below = (1ULL << lane) - 1ULL;
 	if (blockIdx.x >= S.n_items) return;
 	const uint32_t it = S.n_items - 1u - blockIdx.x;                            // the list ascends by anchor count: the heaviest items first
@@ -115,14 +121,14 @@ k_chain_tile(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ 
 	const int nfr = (int)(e1 - e0);
 	const int32_t q_span = P.k, bw = P.bw, max_skip = P.max_chain_skip, max_iter = P.max_chain_iter, min_cnt = P.min_cnt, min_sc = P.min_chain_score;
 	// gap costs of chain.c:64-72 for avg_qspan == k, tabulated with the same two double multiplications
-	for (int d = lane; d < CT_CLIN_N; d += 64) {
+	for (int d = tid; d < CT_CLIN_N; d += CT_NT) {
 		const int c_lin = (int)((double)d * .01 * (double)P.k), lg = d ? ct_ilog2((uint32_t)d) : 0;
 		s_pen_same[d] = (uint8_t)(c_lin + (lg >> 1)); s_pen_diff[d] = (uint8_t)(c_lin < lg ? c_lin : lg);
 	}
 	CtPen pen; pen.same = s_pen_same; pen.diff = s_pen_diff; pen.avg_d = (double)P.k;     // every span is k (checked per row): (float)sum / n == k exactly (chain.c:42)
 	pen.tab_ok = P.k * 0.01 * (CT_CLIN_N - 1) + 5.0 < 255.0;
 	// ---- the fragments of this item ----
-	{
+	if (w == 0) {
 		const bool mine = lane < nfr;
 		const uint32_t f = mine ? list[e0 + lane] : 0u;
 		const bool skipped = mine && skip_flag && skip_flag[f] != 0;
@@ -146,27 +152,25 @@ k_chain_tile(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ 
 	const bool single = nfr == 1;
 	if (!single) {                                                              // (the size classes guarantee the fit; a caller's mistake must not be silent)
 		const CtFrag &tl = s_tf[nfr - 1];
-		if (tl.start + tl.na > CT_TILE) { if (lane == 0) atomicAdd(&counters[7], 1ULL << 48); return; }
+		if (tl.start + tl.na > CT_TILE) { if (tid == 0) atomicAdd(&counters[7], 1ULL << 48); return; }
 	}
+	uint32_t *const rlo = reinterpret_cast<uint32_t *>(s_row);                   // rlo[2 t]: static half of row t, rlo[2 t + 1]: f | p << 16
 	uint32_t pos = 0;                    // single: rows of the fragment in front of this tile
 	uint32_t u_run = 0;                  // single: chains written by the earlier tiles
 	for (;;) {
-		// ---- load + cut: rows, segment list in tile order, size-class counts ----
-		uint32_t n_seg = 0, cnt0 = 0, cnt1 = 0, cnt2 = 0, cnt3 = 0, cnt4 = 0;
-		uint32_t proc_end = 0, next_pos = 0; bool more = false, too_long = false;
+		// ---- load: rows with their cut flags, by all wavefronts ----
 		for (int fi = 0; fi < nfr; ++fi) {
 			const CtFrag tf = s_tf[fi];
 			const uint32_t base_t = tf.start;
 			const uint32_t n = single ? (tf.na - pos < CT_TILE ? tf.na - pos : CT_TILE) : tf.na;
 			const AlAnchor *src = anchors + tf.aoff + pos;
-			if (lane == 0) s_fseg[fi] = n_seg;
-			uint32_t open = base_t; uint64_t carry_x = 0; bool bad = false;
-			for (uint32_t b = 0; b < n; b += 64) {
-				const uint32_t i = b + lane; const bool valid = i < n;
+			bool bad = false;
+			for (uint32_t b = 0; b < n; b += CT_NT) {
+				const uint32_t i = b + tid; const bool valid = i < n;
 				AlAnchor e; e.x = 0; e.y = 0;
 				if (valid) e = src[i];
 				uint64_t xp = (uint64_t)(uint32_t)__shfl_up((int)(uint32_t)e.x, 1) | (uint64_t)(uint32_t)__shfl_up((int)(uint32_t)(e.x >> 32), 1) << 32;
-				if (lane == 0) xp = carry_x;
+				if (lane == 0 && valid && i > 0) xp = src[i - 1].x;
 				const bool cut = valid && (i == 0 || e.x - xp > (uint64_t)(int64_t)tf.mdx);
 				bad = bad || (valid && ((int32_t)(e.y >> 32 & 0xff) != q_span || ((e.y & AL_SEED_SEG_MASK) >> AL_SEED_SEG_SHIFT) > 1 || (uint32_t)e.y > 0xfffu));
 				if (valid) {
@@ -174,63 +178,85 @@ k_chain_tile(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ 
 					                    | (uint64_t)(cut ? 1u : 0u) << 29 | (uint64_t)CT_NONE << 48;
 					s_tm[base_t + i] = (uint16_t)CT_NONE;
 				}
-				const unsigned long long mask = __ballot(cut);
-				bool useful = false; uint32_t start = 0, len = 0;
-				if (cut && i > 0) {                                                 // this anchor closes the segment in front of it
-					const unsigned long long lower = mask & below;
-					start = lower ? base_t + b + (uint32_t)(63 - __clzll((long long)lower)) : open;
-					len = base_t + i - start;
-					useful = (int)len >= lmin;
-				}
-				const int sc = len <= 2 ? 0 : len <= 4 ? 1 : len <= 8 ? 2 : len <= 16 ? 3 : 4;
-				const unsigned long long um = __ballot(useful);
-				if (useful) { const uint32_t k = n_seg + (uint32_t)__popcll(um & below); s_sstart[k] = (uint16_t)start; s_slen[k] = (uint16_t)len; s_sfrag[k] = (uint8_t)fi; }
-				n_seg += (uint32_t)__popcll(um);
-				cnt0 += (uint32_t)__popcll(__ballot(useful && sc == 0)); cnt1 += (uint32_t)__popcll(__ballot(useful && sc == 1));
-				cnt2 += (uint32_t)__popcll(__ballot(useful && sc == 2)); cnt3 += (uint32_t)__popcll(__ballot(useful && sc == 3)); cnt4 += (uint32_t)__popcll(__ballot(useful && sc == 4));
-				if (mask) open = base_t + b + (uint32_t)(63 - __clzll((long long)mask));
-				carry_x = (uint64_t)(uint32_t)__shfl((int)(uint32_t)e.x, 63) | (uint64_t)(uint32_t)__shfl((int)(uint32_t)(e.x >> 32), 63) << 32;
 			}
-			if (__ballot(bad) && lane == 0) s_tf[fi].flags |= 2u;
-			const uint32_t end_t = base_t + n;
-			if (single && pos + n < tf.na) {                                        // a slice: its open segment belongs to the next tile
-				more = true; proc_end = open; next_pos = pos + (open - base_t);
-				if (open == base_t) too_long = true;                                // a segment longer than the tile
-			} else {
-				proc_end = end_t;
-				const uint32_t len = end_t - open;
-				if (n > 0 && (int)len >= lmin) {
-					if (lane == 0) { s_sstart[n_seg] = (uint16_t)open; s_slen[n_seg] = (uint16_t)len; s_sfrag[n_seg] = (uint8_t)fi; }
-					++n_seg;
-					if (len <= 2) ++cnt0; else if (len <= 4) ++cnt1; else if (len <= 8) ++cnt2; else if (len <= 16) ++cnt3; else ++cnt4;
-				}
-			}
-		}
-		if (lane == 0) s_fseg[nfr] = n_seg;
-		if (too_long) { if (lane == 0) s_tf[0].flags |= 2u; break; }
-		__syncthreads();
-		// ---- segments by size class: s_proc[] ----
-		const uint32_t n_lane = cnt0 + cnt1 + cnt2 + cnt3;
-		{
-			uint32_t b0 = 0, b1 = cnt0, b2 = cnt0 + cnt1, b3 = b2 + cnt2, b4 = n_lane;
-			for (uint32_t kb = 0; kb < n_seg; kb += 64) {
-				const uint32_t k = kb + lane; const bool v = k < n_seg;
-				const uint32_t len = v ? s_slen[k] : 0u;
-				const int sc = len <= 2 ? 0 : len <= 4 ? 1 : len <= 8 ? 2 : len <= 16 ? 3 : 4;
-				const unsigned long long m0 = __ballot(v && sc == 0), m1 = __ballot(v && sc == 1), m2 = __ballot(v && sc == 2), m3 = __ballot(v && sc == 3), m4 = __ballot(v && sc == 4);
-				if (v) {
-					const uint32_t o = sc == 0 ? b0 + (uint32_t)__popcll(m0 & below) : sc == 1 ? b1 + (uint32_t)__popcll(m1 & below) : sc == 2 ? b2 + (uint32_t)__popcll(m2 & below)
-					                 : sc == 3 ? b3 + (uint32_t)__popcll(m3 & below) : b4 + (uint32_t)__popcll(m4 & below);
-					s_proc[o] = (uint16_t)k;
-				}
-				b0 += (uint32_t)__popcll(m0); b1 += (uint32_t)__popcll(m1); b2 += (uint32_t)__popcll(m2); b3 += (uint32_t)__popcll(m3); b4 += (uint32_t)__popcll(m4);
-			}
+			if (bad) atomicOr(&s_tf[fi].flags, 2u);
 		}
 		__syncthreads();
-		// ---- DP, a lane per segment of <= 16 anchors (chain.c:46-85) ----
-		for (uint32_t r0 = 0; r0 < n_lane; r0 += 64) {
-			const bool have = r0 + lane < n_lane;
-			const uint32_t k = have ? s_proc[r0 + lane] : 0u;
+		// ---- cut: segment list in tile order and size-class counts (one wavefront walks the cut flags) ----
+		if (w == 0) {
+			uint32_t n_seg = 0, cnt0 = 0, cnt1 = 0, cnt2 = 0, cnt3 = 0, cnt4 = 0;
+			uint32_t proc_end = 0, next_pos = 0; bool more = false, too_long = false;
+			for (int fi = 0; fi < nfr; ++fi) {
+				const CtFrag tf = s_tf[fi];
+				const uint32_t base_t = tf.start;
+				const uint32_t n = single ? (tf.na - pos < CT_TILE ? tf.na - pos : CT_TILE) : tf.na;
+				if (lane == 0) s_fseg[fi] = n_seg;
+				uint32_t open = base_t;
+				for (uint32_t b = 0; b < n; b += 64) {
+					const uint32_t i = b + lane; const bool valid = i < n;
+					const bool cut = valid && (rlo[2 * (base_t + i)] >> 29 & 1u);
+					const unsigned long long mask = __ballot(cut);
+					bool useful = false; uint32_t start = 0, len = 0;
+					if (cut && i > 0) {                                                 // this anchor closes the segment in front of it
+						const unsigned long long lower = mask & below;
+						start = lower ? base_t + b + (uint32_t)(63 - __clzll((long long)lower)) : open;
+						len = base_t + i - start;
+						useful = (int)len >= lmin;
+					}
+					const int sc = len <= 2 ? 0 : len <= 4 ? 1 : len <= 8 ? 2 : len <= 16 ? 3 : 4;
+					const unsigned long long um = __ballot(useful);
+					if (useful) { const uint32_t k = n_seg + (uint32_t)__popcll(um & below); s_sstart[k] = (uint16_t)start; s_slen[k] = (uint16_t)len; s_sfrag[k] = (uint8_t)fi; }
+					n_seg += (uint32_t)__popcll(um);
+					cnt0 += (uint32_t)__popcll(__ballot(useful && sc == 0)); cnt1 += (uint32_t)__popcll(__ballot(useful && sc == 1));
+					cnt2 += (uint32_t)__popcll(__ballot(useful && sc == 2)); cnt3 += (uint32_t)__popcll(__ballot(useful && sc == 3)); cnt4 += (uint32_t)__popcll(__ballot(useful && sc == 4));
+					if (mask) open = base_t + b + (uint32_t)(63 - __clzll((long long)mask));
+				}
+				const uint32_t end_t = base_t + n;
+				if (single && pos + n < tf.na) {                                        // a slice: its open segment belongs to the next tile
+					more = true; proc_end = open; next_pos = pos + (open - base_t);
+					if (open == base_t) too_long = true;                                // a segment longer than the tile
+				} else {
+					proc_end = end_t;
+					const uint32_t len = end_t - open;
+					if (n > 0 && (int)len >= lmin) {
+						if (lane == 0) { s_sstart[n_seg] = (uint16_t)open; s_slen[n_seg] = (uint16_t)len; s_sfrag[n_seg] = (uint8_t)fi; }
+						++n_seg;
+						if (len <= 2) ++cnt0; else if (len <= 4) ++cnt1; else if (len <= 8) ++cnt2; else if (len <= 16) ++cnt3; else ++cnt4;
+					}
+				}
+			}
+			__threadfence_block();
+			// segments by size class: s_proc[]
+			{
+				uint32_t b0 = 0, b1 = cnt0, b2 = cnt0 + cnt1, b3 = b2 + cnt2, b4 = b3 + cnt3;
+				for (uint32_t kb = 0; kb < n_seg; kb += 64) {
+					const uint32_t k = kb + lane; const bool v = k < n_seg;
+					const uint32_t len = v ? s_slen[k] : 0u;
+					const int sc = len <= 2 ? 0 : len <= 4 ? 1 : len <= 8 ? 2 : len <= 16 ? 3 : 4;
+					const unsigned long long m0 = __ballot(v && sc == 0), m1 = __ballot(v && sc == 1), m2 = __ballot(v && sc == 2), m3 = __ballot(v && sc == 3), m4 = __ballot(v && sc == 4);
+					if (v) {
+						const uint32_t o = sc == 0 ? b0 + (uint32_t)__popcll(m0 & below) : sc == 1 ? b1 + (uint32_t)__popcll(m1 & below) : sc == 2 ? b2 + (uint32_t)__popcll(m2 & below)
+						                 : sc == 3 ? b3 + (uint32_t)__popcll(m3 & below) : b4 + (uint32_t)__popcll(m4 & below);
+						s_proc[o] = (uint16_t)k;
+					}
+					b0 += (uint32_t)__popcll(m0); b1 += (uint32_t)__popcll(m1); b2 += (uint32_t)__popcll(m2); b3 += (uint32_t)__popcll(m3); b4 += (uint32_t)__popcll(m4);
+				}
+			}
+			if (lane == 0) {
+				s_fseg[nfr] = n_seg;
+				CtMisc m; m.n_seg = n_seg; m.cnt[0] = cnt0; m.cnt[1] = cnt1; m.cnt[2] = cnt2; m.cnt[3] = cnt3; m.cnt[4] = cnt4; m.proc_end = proc_end; m.next_pos = next_pos; m.more = more ? 1u : 0u; m.too_long = too_long ? 1u : 0u;
+				s_misc = m;
+			}
+		}
+		__syncthreads();
+		const uint32_t n_seg = s_misc.n_seg, n_lane = s_misc.cnt[0] + s_misc.cnt[1] + s_misc.cnt[2] + s_misc.cnt[3], proc_end = s_misc.proc_end;
+		const bool more = s_misc.more != 0;
+		if (s_misc.too_long) { if (tid == 0) s_tf[0].flags |= 2u; break; }
+		// ---- DP, a lane per segment of <= 16 anchors (chain.c:46-85); the wavefronts take every fourth segment of the size-ordered list ----
+		for (uint32_t r0 = 0; r0 * CT_NW < n_lane; r0 += 64) {
+			const uint32_t pi = (r0 + lane) * CT_NW + w;
+			const bool have = pi < n_lane;
+			const uint32_t k = have ? s_proc[pi] : 0u;
 			const int n = have ? (int)s_slen[k] : 0;
 			const uint32_t Sg = s_sstart[k];
 			const CtFrag &tf = s_tf[s_sfrag[k]];
@@ -269,11 +295,12 @@ k_chain_tile(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ 
 				s_v[Sg + i] = (uint16_t)(max_j >= 0 && vmax > max_f ? vmax : max_f);
 			}
 		}
-		// ---- DP, 16 lanes per longer segment, four segments at a time ----
-		for (uint32_t r0 = n_lane; r0 < n_seg; r0 += 4) {
+		// ---- DP, 16 lanes per longer segment: four segments per wavefront at a time ----
+		for (uint32_t r0 = 0; n_lane + r0 * CT_NW < n_seg; r0 += 4) {
 			const int gl = lane & 15, gbase = lane & 48, g = lane >> 4;
-			const bool have = r0 + g < n_seg;
-			const uint32_t k = have ? s_proc[r0 + g] : 0u;
+			const uint32_t pi = n_lane + (r0 + g) * CT_NW + w;
+			const bool have = pi < n_seg;
+			const uint32_t k = have ? s_proc[pi] : 0u;
 			const int n = have ? (int)s_slen[k] : 0;
 			const uint32_t Sg = s_sstart[k];
 			const CtFrag &tf = s_tf[s_sfrag[k]];
@@ -292,6 +319,24 @@ k_chain_tile(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ 
 				prev_xlo = ga ? xi : prev_xlo;
 				int32_t max_f = q_span, n_skip = 0; int max_j = -1; bool broke = !ga;
 				const bool need_marks = ga && (i - st) > max_skip;                    // fewer predecessors can never count max_skip + 1 skips: no marks, no replay
+				if (!__ballot(need_marks)) {
+					// the row's maximum is the first predecessor (in processing order) with the highest score: a 16-lane reduction per 16 predecessors
+					for (int base = i - 1; ; base -= 16) {
+						const bool work = ga && base >= st;
+						if (!__ballot(work)) break;
+						const int j = base - gl;
+						const bool act0 = work && j >= st;
+						const uint64_t rj = act0 ? s_row[Sg + j] : 0ULL;
+						int32_t sc;
+						const bool ok = ct_score(rj, xi, qi, sidi, q_span, mdx, mdy, drlim, bw, pen, sc);
+						int32_t key = (act0 && ok) ? sc * 16 + (15 - gl) : INT32_MIN;
+						{ int o = __builtin_amdgcn_update_dpp(key, key, 0xB1, 0xf, 0xf, false); key = o > key ? o : key; }
+						{ int o = __builtin_amdgcn_update_dpp(key, key, 0x4E, 0xf, 0xf, false); key = o > key ? o : key; }
+						{ int o = __builtin_amdgcn_update_dpp(key, key, 0x141, 0xf, 0xf, false); key = o > key ? o : key; }
+						{ int o = __builtin_amdgcn_update_dpp(key, key, 0x140, 0xf, 0xf, false); key = o > key ? o : key; }
+						if (key != INT32_MIN && (key >> 4) > max_f) { max_f = key >> 4; max_j = base - (15 - (key & 15)); }
+					}
+				} else
 				for (int base = i - 1; ; base -= 16) {
 					const bool work = !broke && base >= st;
 					if (!__ballot(work)) break;
@@ -337,14 +382,13 @@ k_chain_tile(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ 
 		}
 		__syncthreads();
 		// ---- chain ends, peaks, backtrack, order (chain.c:87-160): a lane per segment ----
-		for (uint32_t r0 = 0; r0 < n_seg; r0 += 64) {
-			const bool have = r0 + lane < n_seg;
-			if (!have) continue;
-			const uint32_t k = s_proc[r0 + lane];
+		for (uint32_t r0 = 0; r0 * CT_NW < n_seg; r0 += 64) {
+			const uint32_t pi = (r0 + lane) * CT_NW + w;
+			if (pi >= n_seg) continue;
+			const uint32_t k = s_proc[pi];
 			const int n = (int)s_slen[k];
 			const uint32_t Sg = s_sstart[k];
 			const int fi = (int)s_sfrag[k];
-			uint32_t *const rlo = reinterpret_cast<uint32_t *>(s_row);               // rlo[2 t]: static half of row t, rlo[2 t + 1]: f | p << 16
 #define FLG(t) rlo[2 * (Sg + (t))]
 #define F_(t) ((int32_t)(int16_t)(rlo[2 * (Sg + (t)) + 1] & 0xffffu))
 #define P_(t) (rlo[2 * (Sg + (t)) + 1] >> 16)
@@ -394,53 +438,62 @@ k_chain_tile(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ 
 #undef P_
 		}
 		__syncthreads();
-		{ uint32_t *const rlo = reinterpret_cast<uint32_t *>(s_row); for (uint32_t t = lane; t < proc_end; t += 64) rlo[2 * t + 1] = 0xffffffffu; }   // f / p are dead: the half becomes "source row of the chained anchor at this place"
-		__syncthreads();
 		// ---- emit: chain list entries in tile order at the fragment's running offset; chained anchors at the segment's own place ----
-		for (int fi = 0; fi < nfr; ++fi) {
-			const CtFrag tf = s_tf[fi];
-			const uint32_t k0 = s_fseg[fi], k1 = s_fseg[fi + 1];
+		for (uint32_t t = tid; t < proc_end; t += CT_NT) rlo[2 * t + 1] = 0xffffffffu;   // f / p are dead: the half becomes "source row of the chained anchor at this place"
+		for (uint32_t c = w; c * 64 < n_seg; c += CT_NW) {                                // chains in front of every segment: inside its group of 64 ...
+			const uint32_t k = c * 64 + lane;
+			const uint32_t nu = k < n_seg ? (uint32_t)s_snu[k] & 0x7fffu : 0u;
+			uint32_t incl = nu;
+			for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+			if (k < n_seg) s_G[k] = (uint16_t)(incl - nu);
+			if (lane == 63) s_ctot[c] = incl;
+		}
+		__syncthreads();
+		auto G_of = [&](uint32_t k) -> uint32_t {                                        // ... and in the tile (k == n_seg: all of them)
+			uint32_t g = 0; const uint32_t cc = k >> 6;
+			for (uint32_t c = 0; c < cc; ++c) g += s_ctot[c];
+			return k < n_seg ? g + s_G[k] : ((k & 63) ? g + s_ctot[cc] : g);
+		};
+		for (uint32_t c = w; c * 64 < n_seg; c += CT_NW) {
+			const uint32_t k = c * 64 + lane;
+			if (k >= n_seg) continue;
+			const uint32_t snu = s_snu[k], nu = snu & 0x7fffu;
+			const int fi = (int)s_sfrag[k];
+			if (snu & 0x8000u) atomicOr(&s_tf[fi].flags, 4u);
+			if (!nu) continue;
+			const CtFrag &tf = s_tf[fi];
+			const uint32_t w0 = (single ? u_run : 0u) + G_of(k) - G_of(s_fseg[fi]);
 			uint64_t *const ub = u_out + tf.aoff + tf.f; uint32_t *const uob = uo_out + tf.aoff + tf.f;
-			uint32_t run = single ? u_run : 0u; bool tie = false;
-			uint32_t *const rlo = reinterpret_cast<uint32_t *>(s_row);
-			for (uint32_t kb = k0; kb < k1; kb += 64) {
-				const uint32_t k = kb + lane; const bool v = k < k1;
-				const uint32_t snu = v ? s_snu[k] : 0u, nu = snu & 0x7fffu;
-				tie = tie || (snu & 0x8000u) != 0;
-				uint32_t incl = nu;
-				for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d); if (lane >= d) incl += o; }
-				const uint32_t tot = __shfl(incl, 63);
-				if (nu) {
-					const uint32_t Sg = s_sstart[k], rel = pos + (Sg - tf.start);
-					uint32_t o = 0; const uint32_t w0 = run + incl - nu;
-					for (uint32_t i = 0; i < nu; ++i) {
-						const uint32_t c = s_perm[Sg + i], e = s_u[Sg + c], cnt = e & 0xffffu, off = s_tm[Sg + c];
-						ub[w0 + i] = (uint64_t)(e >> 16) << 32 | cnt; uob[w0 + i] = rel + o;
-						for (uint32_t j = 0; j < cnt; ++j) rlo[2 * (Sg + o + j) + 1] = Sg + (uint32_t)s_v[Sg + off + (cnt - 1 - j)];
-						o += cnt;
-					}
-				}
-				run += tot;
+			const uint32_t Sg = s_sstart[k], rel = pos + (Sg - tf.start);
+			uint32_t o = 0;
+			for (uint32_t i = 0; i < nu; ++i) {
+				const uint32_t cc = s_perm[Sg + i], e = s_u[Sg + cc], cnt = e & 0xffffu, off = s_tm[Sg + cc];
+				ub[w0 + i] = (uint64_t)(e >> 16) << 32 | cnt; uob[w0 + i] = rel + o;
+				for (uint32_t j = 0; j < cnt; ++j) rlo[2 * (Sg + o + j) + 1] = Sg + (uint32_t)s_v[Sg + off + (cnt - 1 - j)];
+				o += cnt;
 			}
-			__syncthreads();
-			{   // the chained anchors, by all lanes
-				const uint32_t t1 = single ? proc_end : tf.start + tf.na;
-				const AlAnchor *src = anchors + tf.aoff + pos; AlAnchor *dst = chained + tf.aoff + pos;
-				for (uint32_t t = tf.start + lane; t < t1; t += 64) { const uint32_t s = rlo[2 * t + 1]; if (s != 0xffffffffu) dst[t - tf.start] = src[s - tf.start]; }
-			}
-			if (__ballot(tie) && lane == 0) s_tf[fi].flags |= 4u;
-			if (single) u_run = run;
-			else if (lane == 0 && !(tf.flags & 1u)) {
-				const uint32_t fl = s_tf[fi].flags;
+		}
+		__syncthreads();
+		for (int fi = 0; fi < nfr; ++fi) {   // the chained anchors, by all lanes
+			const CtFrag tf = s_tf[fi];
+			const uint32_t t1 = single ? proc_end : tf.start + tf.na;
+			const AlAnchor *src = anchors + tf.aoff + pos; AlAnchor *dst = chained + tf.aoff + pos;
+			for (uint32_t t = tf.start + tid; t < t1; t += CT_NT) { const uint32_t s = rlo[2 * t + 1]; if (s != 0xffffffffu) dst[t - tf.start] = src[s - tf.start]; }
+		}
+		if (single) u_run += G_of(n_seg);
+		else if (w == 0 && lane < nfr) {
+			const CtFrag &tf = s_tf[lane];
+			if (!(tf.flags & 1u)) {
+				const uint32_t run = G_of(s_fseg[lane + 1]) - G_of(s_fseg[lane]);
 				frag_nu[tf.f] = run;
-				if ((fl & 2u) || ((fl & 4u) && run > 64) || force_fb) fb_list[atomicAdd(fb_cnt, 1u)] = tf.f;
+				if ((tf.flags & 2u) || ((tf.flags & 4u) && run > 64) || force_fb) fb_list[atomicAdd(fb_cnt, 1u)] = tf.f;
 			}
 		}
 		if (!more) break;
-		pos = next_pos;
+		pos = s_misc.next_pos;
 		__syncthreads();
 	}
-	if (single && lane == 0) {
+	if (single && tid == 0) {
 		const CtFrag &tf = s_tf[0];
 		if (!(tf.flags & 1u)) {
 			frag_nu[tf.f] = (tf.flags & 2u) ? 0u : u_run;

@@ -567,9 +567,9 @@ static int chain_tiles(al_ctx_t *c, const uint32_t *list, const TileSched &S, co
 		uint32_t *fb_cnt = (uint32_t *)(c->counters.p + 15);
 		static const int force_fb = getenv("AL_TEST_TILE_FB") ? 1 : 0;
 		AL_HIP_CHECK(hipMemsetAsync(fb_cnt, 0, 8, s));
-		if (c->opt.max_chain_skip < 15) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain_tile<true>), dim3(S.n_items), dim3(64), 0, s, c->anchors.p, c->a_off.p, c->frag_na.p, c->frag_first.p, c->rd_len.p, list, S, skip_flag,
+		if (c->opt.max_chain_skip < 15) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain_tile<true>), dim3(S.n_items), dim3(256), 0, s, c->anchors.p, c->a_off.p, c->frag_na.p, c->frag_first.p, c->rd_len.p, list, S, skip_flag,
 		                                                  c->chained.p, c->u.p, c->uo.p, c->frag_nu.p, c->fb_list.p, fb_cnt, c->P, lmin, c->counters.p, force_fb);
-		else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain_tile<false>), dim3(S.n_items), dim3(64), 0, s, c->anchors.p, c->a_off.p, c->frag_na.p, c->frag_first.p, c->rd_len.p, list, S, skip_flag,
+		else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain_tile<false>), dim3(S.n_items), dim3(256), 0, s, c->anchors.p, c->a_off.p, c->frag_na.p, c->frag_first.p, c->rd_len.p, list, S, skip_flag,
 		                        c->chained.p, c->u.p, c->uo.p, c->frag_nu.p, c->fb_list.p, fb_cnt, c->P, lmin, c->counters.p, force_fb);
 		if (ev(ST_SEG_FIND)) return -1;
 		AL_HIP_CHECK(hipMemcpyAsync(&n_fb, fb_cnt, 4, hipMemcpyDeviceToHost, s));
@@ -1015,6 +1015,7 @@ extern "C" int64_t al_dbg_copy(al_ctx_t *c, const char *name, void *dst, int64_t
 	else if (!strcmp(name, "anchors")) src = c->anchors.p, bytes = (int64_t)c->n_anchor_total * 16;
 	else if (!strcmp(name, "chained")) src = c->chained.p, bytes = (int64_t)c->n_anchor_total * 16;
 	else if (!strcmp(name, "u")) src = c->u.p, bytes = (int64_t)(c->n_anchor_total + nf + 1) * 8;
+	else if (!strcmp(name, "uo")) src = c->uo.p, bytes = (int64_t)(c->n_anchor_total + nf + 1) * 4;
 	else if (!strcmp(name, "mini_off") && !c->dev_batch) { bytes = (nr + 1) * 8; if (bytes > max_bytes) bytes = max_bytes; memcpy(dst, c->h_mini_off.data(), bytes); return bytes; }
 	else if (!strcmp(name, "mini_off")) src = c->mini_off.p, bytes = (nr + 1) * 8;
 	else return -1;

@@ -61,6 +61,8 @@ def test_seeds_and_chains_match_reference_taps(A, golden_unpacked, name):
     anchors = ctx.tap("anchors", np.uint64, tot * 2).reshape(-1, 2)
     chained = ctx.tap("chained", np.uint64, tot * 2).reshape(-1, 2)
     u = ctx.tap("u", np.uint64, tot + nf + 1)
+    uo = ctx.tap("uo", np.uint32, tot + nf + 1)
+    na = ctx.tap("frag_na", np.uint32, nf)
     ref_names = idx.names
     bad = 0
     for f in range(nf):
@@ -229,7 +231,7 @@ def test_rechain_pass_layout_and_run_to_run_determinism(A):
         st = ctx.stat(); tot = int(st.n_anchor)
         off = ctx.tap("a_off", np.uint64, nf + 1).astype(np.int64); off1 = ctx.tap("a_off_p1", np.uint64, nf + 1).astype(np.int64)
         na = ctx.tap("frag_na", np.uint32, nf).astype(np.int64); nu = ctx.tap("frag_nu", np.uint32, nf).astype(np.int64)
-        chained = ctx.tap("chained", np.uint64, tot * 2).reshape(-1, 2); u = ctx.tap("u", np.uint64, tot + nf + 1)
+        chained = ctx.tap("chained", np.uint64, tot * 2).reshape(-1, 2); u = ctx.tap("u", np.uint64, tot + nf + 1); uo = ctx.tap("uo", np.uint32, tot + nf + 1).astype(np.int64)
         assert st.n_rechain > 100, "the workload is meant to exercise the re-chain pass (%d)" % st.n_rechain
         re = np.nonzero(off[:nf] != off1[:nf])[0]                     # re-chained fragments got new offsets
         assert len(re) == st.n_rechain and (np.diff(off[re]) > 0).all(), "second-pass offsets must ascend with the fragment id"
@@ -237,8 +239,12 @@ def test_rechain_pass_layout_and_run_to_run_determinism(A):
         assert (off[o][:-1] + na[o][:-1] <= off[o][1:]).all()
         d = []
         for f in range(nf):
-            uu = u[off[f] + f: off[f] + f + nu[f]]; nc = int((uu & 0xffffffff).sum())
-            d.append(hashlib.md5(uu.tobytes() + chained[off[f]: off[f] + nc].tobytes()).hexdigest())
+            uu = u[off[f] + f: off[f] + f + nu[f]]; oo = uo[off[f] + f: off[f] + f + nu[f]]
+            h = hashlib.md5(uu.tobytes())
+            for c in range(int(nu[f])):   # every chain's anchors lie at uo[] inside the fragment's range of chained[]
+                n = int(uu[c] & np.uint64(0xffffffff)); assert oo[c] + n <= na[f]
+                h.update(chained[off[f] + oo[c]: off[f] + oo[c] + n].tobytes())
+            d.append(h.hexdigest())
         digests.append(d)
     assert digests[0] == digests[1] == digests[2]
     ctx.close(); idx.close()
