@@ -129,6 +129,10 @@ struct ChainSeg {
 	// segment mode, min_cnt >= 2: per chain (same order as the chain list) the key the reference processes chain ends by, peak score << 32 |
 	// peak anchor (chain.c:111-114) -- what k_chain_order needs to restate the fragment-wide sort of equal chain starts
 	uint64_t *okey;
+	// direct mode (the segments the tile kernel defers, al_kernels_chain.hip): the entry's chains go straight to the fragment's arrays -- their anchors
+	// at the segment's own place in chained[] (a_off[] = the segment's first anchor), the list entries at u[uslot[entry] ...] (slots the tile kernel
+	// reserved and zeroed), uo = rel[entry] + offset inside the segment; equal chain starts set ctie[fragid[entry]]
+	const uint64_t *uslot; const uint32_t *rel; const uint32_t *fragid; uint32_t *ctie;
 };
 
 #define AL_ORD_CAP 8192                   // chains of a fragment whose exact order k_chain_order restates in LDS (14 bytes each)

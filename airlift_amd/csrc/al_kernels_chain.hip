@@ -44,7 +44,8 @@ struct CtFrag {                 // one fragment of the tile
 	uint32_t f, na;
 	int32_t mdx, mdy; uint32_t drlim;
 	uint32_t start;             // first row of the tile that is this fragment's
-	uint32_t flags;             // 1: skipped (chained elsewhere), 2: bad row / overflow -> fallback, 4: tie
+	uint32_t flags;             // 1: skipped (chained elsewhere), 2: bad row / segment beyond the kernels -> fallback, 4: tie, 8: has deferred segments
+	uint32_t meta;              // ChainSeg::meta of its segments: qlen_sum | paired << 31
 };
 
 __device__ __forceinline__ int ct_ilog2(uint32_t v) { return 31 - __clz((int)v); }
@@ -91,25 +92,33 @@ struct TileSched {
 
 #define CT_NW 4                          // wavefronts per tile: they share the rows and take the segments of every step in turn
 #define CT_NT (64 * CT_NW)
-struct CtMisc { uint32_t n_seg, cnt[5], proc_end, next_pos, more, too_long; };
+#define CT_INLINE 8                      // segments of up to this many anchors are chained here; longer ones are deferred to the lane kernels
+#define CT_DEFER_MAX 128                 // ... whose rows hold up to 128 anchors; a longer segment hands the fragment to the fallback
+#define CT_DEF 0x4000u                   // s_snu: the segment is deferred (the count is the number of chain list slots reserved for it)
+struct CtMisc { uint32_t n_seg, n_inl, proc_end, next_pos, more, too_long, def_base; };
+struct CtDefer {                         // the deferred segments (ChainSeg direct mode), appended tile by tile
+	uint64_t *off, *uslot; uint32_t *na, *meta, *rel, *fragid, *cls; uint32_t *cnt; uint32_t cap;
+	uint32_t *cmp_list, *cmp_cnt;        // fragments with deferred segments: their chain lists have gaps until k_u_compact has run
+	uint32_t *ctie;                      // per fragment: 1 = two chains start at equal x
+};
+__device__ __forceinline__ uint32_t ct_defer_class(uint32_t n) { return n <= 16 ? 0u : n <= 24 ? 1u : n <= 32 ? 2u : n <= 40 ? 3u : n <= 48 ? 4u : n <= 64 ? 5u : n <= 80 ? 6u : n <= 96 ? 7u : 8u; }
 
-template <bool MARKS>      // the lane path keeps the t[] marks of chain.c:81 only when 15 predecessors can exceed max_skip
 __global__ void __launch_bounds__(CT_NT)
 k_chain_tile(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_off, const uint32_t *__restrict__ frag_na,
              const uint32_t *__restrict__ frag_first, const uint32_t *__restrict__ rd_len, const uint32_t *__restrict__ list, const TileSched S,
              const uint32_t *__restrict__ skip_flag, AlAnchor *__restrict__ chained, uint64_t *__restrict__ u_out, uint32_t *__restrict__ uo_out,
              uint32_t *__restrict__ frag_nu, uint32_t *__restrict__ fb_list, uint32_t *__restrict__ fb_cnt, const AlParams P, const int lmin,
-             unsigned long long *__restrict__ counters, const int force_fb /* tests: every fragment is handed back */)
+             unsigned long long *__restrict__ counters, const int force_fb /* tests: every fragment is handed back */, const CtDefer D)
 {
 	__shared__ uint64_t s_row[CT_TILE];
 	__shared__ uint32_t s_u[CT_TILE];
 	__shared__ uint16_t s_v[CT_TILE], s_tm[CT_TILE], s_perm[CT_TILE];
-	__shared__ uint16_t s_sstart[CT_SEGS], s_slen[CT_SEGS], s_snu[CT_SEGS], s_proc[CT_SEGS], s_G[CT_SEGS];
+	__shared__ uint16_t s_sstart[CT_SEGS], s_slen[CT_SEGS], s_snu[CT_SEGS], s_proc[CT_SEGS], s_G[CT_SEGS], s_Dn[CT_SEGS];
 	__shared__ uint8_t s_sfrag[CT_SEGS];
 	__shared__ uint8_t s_pen_same[CT_CLIN_N], s_pen_diff[CT_CLIN_N];
 	__shared__ CtFrag s_tf[CT_FRAGS];
 	__shared__ uint32_t s_fseg[CT_FRAGS + 1];                                  // first segment (tile order) of every fragment of the tile
-	__shared__ uint32_t s_ctot[CT_SEGS / 64 + 1];
+	__shared__ uint32_t s_ctot[CT_SEGS / 64 + 1], s_dtot[CT_SEGS / 64 + 1];
 	__shared__ CtMisc s_misc;
 	const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
 	const unsigned long long below = (1ULL << lane) - 1ULL;
@@ -119,7 +128,7 @@ k_chain_tile(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ 
 	const uint32_t per = 32u >> cl;
 	const uint32_t e0 = S.ent[cl] + (it - S.item[cl]) * per, e1 = e0 + per < S.ent[cl + 1] ? e0 + per : S.ent[cl + 1];
 	const int nfr = (int)(e1 - e0);
-	const int32_t q_span = P.k, bw = P.bw, max_skip = P.max_chain_skip, max_iter = P.max_chain_iter, min_cnt = P.min_cnt, min_sc = P.min_chain_score;
+	const int32_t q_span = P.k, bw = P.bw, max_iter = P.max_chain_iter, min_cnt = P.min_cnt, min_sc = P.min_chain_score;
 	// gap costs of chain.c:64-72 for avg_qspan == k, tabulated with the same two double multiplications
 	for (int d = tid; d < CT_CLIN_N; d += CT_NT) {
 		const int c_lin = (int)((double)d * .01 * (double)P.k), lg = d ? ct_ilog2((uint32_t)d) : 0;
@@ -144,6 +153,7 @@ k_chain_tile(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ 
 			else if (P.max_frag_len > 0) { mdx = P.max_frag_len - qlen_sum; if (mdx < P.max_gap) mdx = P.max_gap; }
 			else mdx = P.max_gap;
 			CtFrag t; t.aoff = a_off[f]; t.f = f; t.na = na; t.mdx = mdx; t.mdy = mdy; t.drlim = r1 - r0 > 1 ? (uint32_t)mdy : 0x7fffffffu; t.flags = skipped ? 1u : 0u;
+			t.meta = (uint32_t)qlen_sum | (r1 - r0 > 1 ? 1u << 31 : 0u);
 			t.start = incl - na;
 			s_tf[lane] = t;
 		}
@@ -156,7 +166,8 @@ k_chain_tile(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ 
 	}
 	uint32_t *const rlo = reinterpret_cast<uint32_t *>(s_row);                   // rlo[2 t]: static half of row t, rlo[2 t + 1]: f | p << 16
 	uint32_t pos = 0;                    // single: rows of the fragment in front of this tile
-	uint32_t u_run = 0;                  // single: chains written by the earlier tiles
+	uint32_t u_run = 0;                  // single: chain list slots written by the earlier tiles
+	bool any_def = false;                // single: a segment of an earlier tile was deferred
 	for (;;) {
 		// ---- load: rows with their cut flags, by all wavefronts ----
 		for (int fi = 0; fi < nfr; ++fi) {
@@ -173,25 +184,22 @@ k_chain_tile(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ 
 				if (lane == 0 && valid && i > 0) xp = src[i - 1].x;
 				const bool cut = valid && (i == 0 || e.x - xp > (uint64_t)(int64_t)tf.mdx);
 				bad = bad || (valid && ((int32_t)(e.y >> 32 & 0xff) != q_span || ((e.y & AL_SEED_SEG_MASK) >> AL_SEED_SEG_SHIFT) > 1 || (uint32_t)e.y > 0xfffu));
-				if (valid) {
-					s_row[base_t + i] = (uint64_t)((uint32_t)e.x & 0xffffu) | (uint64_t)((uint32_t)e.y & 0xfffu) << 16 | (uint64_t)((e.y & AL_SEED_SEG_MASK) >> AL_SEED_SEG_SHIFT & 1) << 28
-					                    | (uint64_t)(cut ? 1u : 0u) << 29 | (uint64_t)CT_NONE << 48;
-					s_tm[base_t + i] = (uint16_t)CT_NONE;
-				}
+				if (valid) s_row[base_t + i] = (uint64_t)((uint32_t)e.x & 0xffffu) | (uint64_t)((uint32_t)e.y & 0xfffu) << 16 | (uint64_t)((e.y & AL_SEED_SEG_MASK) >> AL_SEED_SEG_SHIFT & 1) << 28
+				                               | (uint64_t)(cut ? 1u : 0u) << 29 | (uint64_t)CT_NONE << 48;
 			}
 			if (bad) atomicOr(&s_tf[fi].flags, 2u);
 		}
 		__syncthreads();
-		// ---- cut: segment list in tile order and size-class counts (one wavefront walks the cut flags) ----
+		// ---- cut: segment list in tile order; the segments chained here ordered by size class (one wavefront walks the cut flags) ----
 		if (w == 0) {
-			uint32_t n_seg = 0, cnt0 = 0, cnt1 = 0, cnt2 = 0, cnt3 = 0, cnt4 = 0;
+			uint32_t n_seg = 0, cnt0 = 0, cnt1 = 0, cnt2 = 0;
 			uint32_t proc_end = 0, next_pos = 0; bool more = false, too_long = false;
 			for (int fi = 0; fi < nfr; ++fi) {
 				const CtFrag tf = s_tf[fi];
 				const uint32_t base_t = tf.start;
 				const uint32_t n = single ? (tf.na - pos < CT_TILE ? tf.na - pos : CT_TILE) : tf.na;
 				if (lane == 0) s_fseg[fi] = n_seg;
-				uint32_t open = base_t;
+				uint32_t open = base_t; bool over = false;
 				for (uint32_t b = 0; b < n; b += 64) {
 					const uint32_t i = b + lane; const bool valid = i < n;
 					const bool cut = valid && (rlo[2 * (base_t + i)] >> 29 & 1u);
@@ -203,12 +211,12 @@ k_chain_tile(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ 
 						len = base_t + i - start;
 						useful = (int)len >= lmin;
 					}
-					const int sc = len <= 2 ? 0 : len <= 4 ? 1 : len <= 8 ? 2 : len <= 16 ? 3 : 4;
+					over = over || (useful && len > CT_DEFER_MAX);
+					const int sc = len <= 2 ? 0 : len <= 4 ? 1 : len <= CT_INLINE ? 2 : 3;
 					const unsigned long long um = __ballot(useful);
 					if (useful) { const uint32_t k = n_seg + (uint32_t)__popcll(um & below); s_sstart[k] = (uint16_t)start; s_slen[k] = (uint16_t)len; s_sfrag[k] = (uint8_t)fi; }
 					n_seg += (uint32_t)__popcll(um);
-					cnt0 += (uint32_t)__popcll(__ballot(useful && sc == 0)); cnt1 += (uint32_t)__popcll(__ballot(useful && sc == 1));
-					cnt2 += (uint32_t)__popcll(__ballot(useful && sc == 2)); cnt3 += (uint32_t)__popcll(__ballot(useful && sc == 3)); cnt4 += (uint32_t)__popcll(__ballot(useful && sc == 4));
+					cnt0 += (uint32_t)__popcll(__ballot(useful && sc == 0)); cnt1 += (uint32_t)__popcll(__ballot(useful && sc == 1)); cnt2 += (uint32_t)__popcll(__ballot(useful && sc == 2));
 					if (mask) open = base_t + b + (uint32_t)(63 - __clzll((long long)mask));
 				}
 				const uint32_t end_t = base_t + n;
@@ -221,41 +229,44 @@ k_chain_tile(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ 
 					if (n > 0 && (int)len >= lmin) {
 						if (lane == 0) { s_sstart[n_seg] = (uint16_t)open; s_slen[n_seg] = (uint16_t)len; s_sfrag[n_seg] = (uint8_t)fi; }
 						++n_seg;
-						if (len <= 2) ++cnt0; else if (len <= 4) ++cnt1; else if (len <= 8) ++cnt2; else if (len <= 16) ++cnt3; else ++cnt4;
+						if (len <= 2) ++cnt0; else if (len <= 4) ++cnt1; else if (len <= CT_INLINE) ++cnt2;
+						over = over || len > CT_DEFER_MAX;
 					}
 				}
+				if (__ballot(over) && lane == 0) s_tf[fi].flags |= 2u;                  // beyond the lane kernels' rows: the fallback takes the fragment
 			}
 			__threadfence_block();
-			// segments by size class: s_proc[]
+			// the inline segments by size class: s_proc[]
 			{
-				uint32_t b0 = 0, b1 = cnt0, b2 = cnt0 + cnt1, b3 = b2 + cnt2, b4 = b3 + cnt3;
+				uint32_t b0 = 0, b1 = cnt0, b2 = cnt0 + cnt1;
 				for (uint32_t kb = 0; kb < n_seg; kb += 64) {
 					const uint32_t k = kb + lane; const bool v = k < n_seg;
 					const uint32_t len = v ? s_slen[k] : 0u;
-					const int sc = len <= 2 ? 0 : len <= 4 ? 1 : len <= 8 ? 2 : len <= 16 ? 3 : 4;
-					const unsigned long long m0 = __ballot(v && sc == 0), m1 = __ballot(v && sc == 1), m2 = __ballot(v && sc == 2), m3 = __ballot(v && sc == 3), m4 = __ballot(v && sc == 4);
-					if (v) {
-						const uint32_t o = sc == 0 ? b0 + (uint32_t)__popcll(m0 & below) : sc == 1 ? b1 + (uint32_t)__popcll(m1 & below) : sc == 2 ? b2 + (uint32_t)__popcll(m2 & below)
-						                 : sc == 3 ? b3 + (uint32_t)__popcll(m3 & below) : b4 + (uint32_t)__popcll(m4 & below);
+					const int sc = len <= 2 ? 0 : len <= 4 ? 1 : len <= CT_INLINE ? 2 : 3;
+					const unsigned long long m0 = __ballot(v && sc == 0), m1 = __ballot(v && sc == 1), m2 = __ballot(v && sc == 2);
+					if (v && sc < 3) {
+						const uint32_t o = sc == 0 ? b0 + (uint32_t)__popcll(m0 & below) : sc == 1 ? b1 + (uint32_t)__popcll(m1 & below) : b2 + (uint32_t)__popcll(m2 & below);
 						s_proc[o] = (uint16_t)k;
 					}
-					b0 += (uint32_t)__popcll(m0); b1 += (uint32_t)__popcll(m1); b2 += (uint32_t)__popcll(m2); b3 += (uint32_t)__popcll(m3); b4 += (uint32_t)__popcll(m4);
+					if (v && sc == 3) s_snu[k] = (uint16_t)(CT_DEF | (len >> 1));       // a chain has >= 2 anchors (lmin >= 2: min_cnt >= 2 or two anchors cannot reach min_chain_score ... the caller checks min_cnt >= 2)
+					b0 += (uint32_t)__popcll(m0); b1 += (uint32_t)__popcll(m1); b2 += (uint32_t)__popcll(m2);
 				}
 			}
 			if (lane == 0) {
 				s_fseg[nfr] = n_seg;
-				CtMisc m; m.n_seg = n_seg; m.cnt[0] = cnt0; m.cnt[1] = cnt1; m.cnt[2] = cnt2; m.cnt[3] = cnt3; m.cnt[4] = cnt4; m.proc_end = proc_end; m.next_pos = next_pos; m.more = more ? 1u : 0u; m.too_long = too_long ? 1u : 0u;
+				CtMisc m; m.n_seg = n_seg; m.n_inl = cnt0 + cnt1 + cnt2; m.proc_end = proc_end; m.next_pos = next_pos; m.more = more ? 1u : 0u; m.too_long = too_long ? 1u : 0u; m.def_base = 0;
 				s_misc = m;
 			}
 		}
 		__syncthreads();
-		const uint32_t n_seg = s_misc.n_seg, n_lane = s_misc.cnt[0] + s_misc.cnt[1] + s_misc.cnt[2] + s_misc.cnt[3], proc_end = s_misc.proc_end;
+		const uint32_t n_seg = s_misc.n_seg, n_inl = s_misc.n_inl, proc_end = s_misc.proc_end;
 		const bool more = s_misc.more != 0;
 		if (s_misc.too_long) { if (tid == 0) s_tf[0].flags |= 2u; break; }
-		// ---- DP, a lane per segment of <= 16 anchors (chain.c:46-85); the wavefronts take every fourth segment of the size-ordered list ----
-		for (uint32_t r0 = 0; r0 * CT_NW < n_lane; r0 += 64) {
+		// ---- DP, a lane per segment (chain.c:46-85; at most CT_INLINE - 1 predecessors: the max_skip rule of chain.c:74-80 cannot fire, the caller
+		//      checks max_chain_skip); the wavefronts take every fourth segment of the size-ordered list ----
+		for (uint32_t r0 = 0; r0 * CT_NW < n_inl; r0 += 64) {
 			const uint32_t pi = (r0 + lane) * CT_NW + w;
-			const bool have = pi < n_lane;
+			const bool have = pi < n_inl;
 			const uint32_t k = have ? s_proc[pi] : 0u;
 			const int n = have ? (int)s_slen[k] : 0;
 			const uint32_t Sg = s_sstart[k];
@@ -270,140 +281,38 @@ k_chain_tile(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ 
 					while (dist > mdx || i - st > max_iter) { ++st; dist -= (int32_t)((R_XLO(s_row[Sg + st]) - R_XLO(s_row[Sg + st - 1])) & 0xffffu); }
 				}
 				prev_xlo = xi;
-				int max_j = -1; int32_t max_f = q_span, n_skip = 0;
+				int max_j = -1; int32_t max_f = q_span;
 				int jn = i > 0 ? i - 1 : 0;
 				uint64_t nrow = s_row[Sg + jn];
-				bool done = false;
-				for (int j = i - 1; j >= st && !done; --j) {
+				for (int j = i - 1; j >= st; --j) {
 					const uint64_t rj = nrow;
 					jn = j > 0 ? j - 1 : 0;
 					nrow = s_row[Sg + jn];
 					int32_t sc;
 					const bool ok = ct_score(rj, xi, qi, sidi, q_span, mdx, mdy, drlim, bw, pen, sc);
 					const bool better = ok && sc > max_f;
-					if (MARKS) {
-						const uint32_t pj = R_P(rj);
-						const bool marked = ok && !better && s_tm[Sg + j] == (uint16_t)i;
-						n_skip += marked ? 1 : (better && n_skip > 0 ? -1 : 0);
-						done = marked && n_skip > max_skip;                          // the reference breaks before marking p[j]
-						if (ok && !done && pj != CT_NONE) s_tm[Sg + pj] = (uint16_t)i;
-					}
 					max_f = better ? sc : max_f; max_j = better ? j : max_j;
 				}
 				const int32_t vmax = max_j >= 0 ? (int32_t)s_v[Sg + max_j] : 0;
 				s_row[Sg + i] = (ri & 0x00000000ffffffffULL) | (uint64_t)((uint32_t)max_f & 0xffffu) << 32 | (uint64_t)(max_j < 0 ? CT_NONE : (uint32_t)max_j) << 48;
 				s_v[Sg + i] = (uint16_t)(max_j >= 0 && vmax > max_f ? vmax : max_f);
 			}
-		}
-		// ---- DP, 16 lanes per longer segment: four segments per wavefront at a time ----
-		for (uint32_t r0 = 0; n_lane + r0 * CT_NW < n_seg; r0 += 4) {
-			const int gl = lane & 15, gbase = lane & 48, g = lane >> 4;
-			const uint32_t pi = n_lane + (r0 + g) * CT_NW + w;
-			const bool have = pi < n_seg;
-			const uint32_t k = have ? s_proc[pi] : 0u;
-			const int n = have ? (int)s_slen[k] : 0;
-			const uint32_t Sg = s_sstart[k];
-			const CtFrag &tf = s_tf[s_sfrag[k]];
-			const int32_t mdx = tf.mdx, mdy = tf.mdy; const uint32_t drlim = tf.drlim;
-			int nmax = n;
-			{ int o = __shfl_xor(nmax, 16); nmax = o > nmax ? o : nmax; o = __shfl_xor(nmax, 32); nmax = o > nmax ? o : nmax; }
-			int st = 0; int32_t dist = 0; uint32_t prev_xlo = 0;
-			for (int i = 0; i < nmax; ++i) {
-				const bool ga = i < n;
-				const uint64_t ri = ga ? s_row[Sg + i] : 0ULL;
-				const uint32_t xi = R_XLO(ri); const int32_t qi = R_Q(ri), sidi = R_SEG(ri);
-				if (ga && i > 0) {
-					dist += (int32_t)((xi - prev_xlo) & 0xffffu);
-					while (dist > mdx || i - st > max_iter) { ++st; dist -= (int32_t)((R_XLO(s_row[Sg + st]) - R_XLO(s_row[Sg + st - 1])) & 0xffffu); }
-				}
-				prev_xlo = ga ? xi : prev_xlo;
-				int32_t max_f = q_span, n_skip = 0; int max_j = -1; bool broke = !ga;
-				const bool need_marks = ga && (i - st) > max_skip;                    // fewer predecessors can never count max_skip + 1 skips: no marks, no replay
-				if (!__ballot(need_marks)) {
-					// the row's maximum is the first predecessor (in processing order) with the highest score: a 16-lane reduction per 16 predecessors
-					for (int base = i - 1; ; base -= 16) {
-						const bool work = ga && base >= st;
-						if (!__ballot(work)) break;
-						const int j = base - gl;
-						const bool act0 = work && j >= st;
-						const uint64_t rj = act0 ? s_row[Sg + j] : 0ULL;
-						int32_t sc;
-						const bool ok = ct_score(rj, xi, qi, sidi, q_span, mdx, mdy, drlim, bw, pen, sc);
-						int32_t key = (act0 && ok) ? sc * 16 + (15 - gl) : INT32_MIN;
-						{ int o = __builtin_amdgcn_update_dpp(key, key, 0xB1, 0xf, 0xf, false); key = o > key ? o : key; }
-						{ int o = __builtin_amdgcn_update_dpp(key, key, 0x4E, 0xf, 0xf, false); key = o > key ? o : key; }
-						{ int o = __builtin_amdgcn_update_dpp(key, key, 0x141, 0xf, 0xf, false); key = o > key ? o : key; }
-						{ int o = __builtin_amdgcn_update_dpp(key, key, 0x140, 0xf, 0xf, false); key = o > key ? o : key; }
-						if (key != INT32_MIN && (key >> 4) > max_f) { max_f = key >> 4; max_j = base - (15 - (key & 15)); }
-					}
-				} else
-				for (int base = i - 1; ; base -= 16) {
-					const bool work = !broke && base >= st;
-					if (!__ballot(work)) break;
-					const int j = base - gl;
-					bool act = work && j >= st;
-					const uint64_t rj = act ? s_row[Sg + j] : 0ULL;
-					int32_t sc;
-					const bool ok = ct_score(rj, xi, qi, sidi, q_span, mdx, mdy, drlim, bw, pen, sc);
-					act = act && ok;
-					const uint32_t pj = R_P(rj);
-					if (need_marks && act && pj != CT_NONE) s_tm[Sg + pj] = (uint16_t)i;   // t[p[j]] = i (chain.c:81); marks of lanes behind the break are never tested
-					const int32_t scm = act ? sc : INT32_MIN;
-					int32_t inc = scm;                                                  // prefix maximum in processing order (lane order inside the 16-lane row)
-					{ int o = ct_dpp_shr(INT32_MIN, inc, 1); inc = o > inc ? o : inc; o = ct_dpp_shr(INT32_MIN, inc, 2); inc = o > inc ? o : inc;
-					  o = ct_dpp_shr(INT32_MIN, inc, 4); inc = o > inc ? o : inc; o = ct_dpp_shr(INT32_MIN, inc, 8); inc = o > inc ? o : inc; }
-					const int32_t excl = ct_dpp_shr(INT32_MIN, inc, 1);
-					const int32_t before = excl > max_f ? excl : max_f;
-					const bool upd = act && sc > before;
-					__threadfence_block();
-					const bool marked = need_marks && act && !upd && s_tm[Sg + j] == (uint16_t)i;
-					const unsigned long long Uw = __ballot(upd), Kw = __ballot(marked);
-					uint32_t U = (uint32_t)(Uw >> gbase) & 0xffffu; const uint32_t K = (uint32_t)(Kw >> gbase) & 0xffffu;
-					if (need_marks) {                                                   // chain.c:74-80 replayed in order over the two masks
-						uint32_t both = U | K; int brk = 16;
-						while (both) {
-							const int b = __ffs((int)both) - 1; both &= both - 1;
-							if (U >> b & 1) { if (n_skip > 0) --n_skip; }
-							else if (++n_skip > max_skip) { brk = b; break; }
-						}
-						if (brk < 16) { broke = true; U &= (1u << brk) - 1u; }
-					}
-					const int lastu = U ? 31 - __clz((int)U) : 0;
-					const int32_t scl = __shfl(sc, gbase + lastu);
-					if (work && U) { max_f = scl; max_j = base - lastu; }
-				}
-				if (ga && gl == 0) {
-					const int32_t vmax = max_j >= 0 ? (int32_t)s_v[Sg + max_j] : 0;
-					s_row[Sg + i] = (ri & 0x00000000ffffffffULL) | (uint64_t)((uint32_t)max_f & 0xffffu) << 32 | (uint64_t)(max_j < 0 ? CT_NONE : (uint32_t)max_j) << 48;
-					s_v[Sg + i] = (uint16_t)(max_j >= 0 && vmax > max_f ? vmax : max_f);
-				}
-				__threadfence_block();
-			}
-		}
-		__syncthreads();
-		// ---- chain ends, peaks, backtrack, order (chain.c:87-160): a lane per segment ----
-		for (uint32_t r0 = 0; r0 * CT_NW < n_seg; r0 += 64) {
-			const uint32_t pi = (r0 + lane) * CT_NW + w;
-			if (pi >= n_seg) continue;
-			const uint32_t k = s_proc[pi];
-			const int n = (int)s_slen[k];
-			const uint32_t Sg = s_sstart[k];
+			// ---- chain ends, peaks, backtrack, order (chain.c:87-160), same lane ----
+			if (!have) continue;
 			const int fi = (int)s_sfrag[k];
 #define FLG(t) rlo[2 * (Sg + (t))]
 #define F_(t) ((int32_t)(int16_t)(rlo[2 * (Sg + (t)) + 1] & 0xffffu))
 #define P_(t) (rlo[2 * (Sg + (t)) + 1] >> 16)
 			for (int i = 0; i < n; ++i) { const uint32_t p = P_(i); if (p != CT_NONE) FLG(p) |= ROW_B30; }     // has a successor
 			int32_t n_u = 0;
-			bool ovf = false;
 			for (int i = 0; i < n; ++i)
 				if (!(FLG(i) & ROW_B30) && (int32_t)s_v[Sg + i] >= min_sc) {
 					int j = i;
 					while (j >= 0 && F_(j) < (int32_t)s_v[Sg + j]) { const uint32_t p = P_(j); j = p == CT_NONE ? -1 : (int)p; }
 					if (j < 0) j = i;
-					if (n_u < CT_NU_CAP) s_u[Sg + n_u] = (uint32_t)F_(j) << 16 | (uint32_t)j; else ovf = true;
+					s_u[Sg + n_u] = (uint32_t)F_(j) << 16 | (uint32_t)j;
 					++n_u;
 				}
-			if (ovf) { atomicOr(&s_tf[fi].flags, 2u); s_snu[k] = 0; continue; }
 			if (n_u == 0) { s_snu[k] = 0; continue; }
 			for (int32_t i = 1; i < n_u; ++i) { const uint32_t t = s_u[Sg + i]; int32_t j = i; while (j > 0 && s_u[Sg + j - 1] < t) { s_u[Sg + j] = s_u[Sg + j - 1]; --j; } s_u[Sg + j] = t; }
 			int32_t n_v = 0, kk = 0;
@@ -422,7 +331,6 @@ k_chain_tile(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ 
 			for (int32_t c = 0; c < n_u; ++c) { s_tm[Sg + c] = (uint16_t)off; off += (int32_t)(s_u[Sg + c] & 0xffffu); s_perm[Sg + c] = (uint16_t)c; }
 			bool eqx = false;
 			if (n_u > 1) {
-				const CtFrag &tf = s_tf[fi];
 				const AlAnchor *a = anchors + tf.aoff + pos + (Sg - tf.start);
 #define CX(c) (a[(int)s_v[Sg + (int)s_tm[Sg + (c)] + (int32_t)(s_u[Sg + (c)] & 0xffffu) - 1]].x)
 				for (int32_t i = 1; i < n_u; ++i) {
@@ -440,13 +348,14 @@ k_chain_tile(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ 
 		__syncthreads();
 		// ---- emit: chain list entries in tile order at the fragment's running offset; chained anchors at the segment's own place ----
 		for (uint32_t t = tid; t < proc_end; t += CT_NT) rlo[2 * t + 1] = 0xffffffffu;   // f / p are dead: the half becomes "source row of the chained anchor at this place"
-		for (uint32_t c = w; c * 64 < n_seg; c += CT_NW) {                                // chains in front of every segment: inside its group of 64 ...
+		for (uint32_t c = w; c * 64 < n_seg; c += CT_NW) {                                // list slots / deferred segments in front of every segment: inside its group of 64 ...
 			const uint32_t k = c * 64 + lane;
-			const uint32_t nu = k < n_seg ? (uint32_t)s_snu[k] & 0x7fffu : 0u;
-			uint32_t incl = nu;
-			for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d); if (lane >= d) incl += o; }
-			if (k < n_seg) s_G[k] = (uint16_t)(incl - nu);
-			if (lane == 63) s_ctot[c] = incl;
+			const uint32_t snu = k < n_seg ? (uint32_t)s_snu[k] : 0u;
+			const uint32_t nu = snu & 0x3fffu, df = (snu & CT_DEF) ? 1u : 0u;
+			uint32_t incl = nu, incd = df;
+			for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d), od = __shfl_up(incd, d); if (lane >= d) { incl += o; incd += od; } }
+			if (k < n_seg) { s_G[k] = (uint16_t)(incl - nu); s_Dn[k] = (uint16_t)(incd - df); }
+			if (lane == 63) { s_ctot[c] = incl; s_dtot[c] = incd; }
 		}
 		__syncthreads();
 		auto G_of = [&](uint32_t k) -> uint32_t {                                        // ... and in the tile (k == n_seg: all of them)
@@ -454,17 +363,37 @@ k_chain_tile(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ 
 			for (uint32_t c = 0; c < cc; ++c) g += s_ctot[c];
 			return k < n_seg ? g + s_G[k] : ((k & 63) ? g + s_ctot[cc] : g);
 		};
+		auto D_of = [&](uint32_t k) -> uint32_t {
+			uint32_t g = 0; const uint32_t cc = k >> 6;
+			for (uint32_t c = 0; c < cc; ++c) g += s_dtot[c];
+			return k < n_seg ? g + s_Dn[k] : ((k & 63) ? g + s_dtot[cc] : g);
+		};
+		const uint32_t n_def = D_of(n_seg);
+		if (tid == 0 && n_def) s_misc.def_base = atomicAdd(D.cnt, n_def);                 // the tile's deferred segments, one range of the list
+		__syncthreads();
+		const uint32_t def_base = s_misc.def_base;
+		const bool def_ok = n_def == 0 || def_base + n_def <= D.cap;
+		if (!def_ok && tid == 0) atomicAdd(&counters[7], 1ULL << 52);                     // (the list is sized for every possible deferred segment: a caller's mistake must not be silent)
 		for (uint32_t c = w; c * 64 < n_seg; c += CT_NW) {
 			const uint32_t k = c * 64 + lane;
 			if (k >= n_seg) continue;
-			const uint32_t snu = s_snu[k], nu = snu & 0x7fffu;
+			const uint32_t snu = s_snu[k], nu = snu & 0x3fffu;
 			const int fi = (int)s_sfrag[k];
-			if (snu & 0x8000u) atomicOr(&s_tf[fi].flags, 4u);
-			if (!nu) continue;
 			const CtFrag &tf = s_tf[fi];
+			if ((snu & 0x8000u) && !(snu & CT_DEF)) { atomicOr(&s_tf[fi].flags, 4u); }
+			if (!nu) continue;
 			const uint32_t w0 = (single ? u_run : 0u) + G_of(k) - G_of(s_fseg[fi]);
 			uint64_t *const ub = u_out + tf.aoff + tf.f; uint32_t *const uob = uo_out + tf.aoff + tf.f;
 			const uint32_t Sg = s_sstart[k], rel = pos + (Sg - tf.start);
+			if (snu & CT_DEF) {                                                          // reserved slots, empty until the lane kernels fill them
+				for (uint32_t i = 0; i < nu; ++i) ub[w0 + i] = 0ULL;
+				atomicOr(&s_tf[fi].flags, 8u);
+				if (def_ok && !(tf.flags & 2u)) {
+					const uint32_t d = def_base + D_of(k), len = s_slen[k];
+					D.off[d] = tf.aoff + rel; D.na[d] = len; D.meta[d] = tf.meta; D.uslot[d] = tf.aoff + tf.f + w0; D.rel[d] = rel; D.fragid[d] = tf.f; D.cls[d] = ct_defer_class(len);
+				}
+				continue;
+			}
 			uint32_t o = 0;
 			for (uint32_t i = 0; i < nu; ++i) {
 				const uint32_t cc = s_perm[Sg + i], e = s_u[Sg + cc], cnt = e & 0xffffu, off = s_tm[Sg + cc];
@@ -480,13 +409,16 @@ k_chain_tile(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ 
 			const AlAnchor *src = anchors + tf.aoff + pos; AlAnchor *dst = chained + tf.aoff + pos;
 			for (uint32_t t = tf.start + tid; t < t1; t += CT_NT) { const uint32_t s = rlo[2 * t + 1]; if (s != 0xffffffffu) dst[t - tf.start] = src[s - tf.start]; }
 		}
-		if (single) u_run += G_of(n_seg);
+		if (single) { u_run += G_of(n_seg); any_def = any_def || n_def != 0; }
 		else if (w == 0 && lane < nfr) {
 			const CtFrag &tf = s_tf[lane];
 			if (!(tf.flags & 1u)) {
 				const uint32_t run = G_of(s_fseg[lane + 1]) - G_of(s_fseg[lane]);
 				frag_nu[tf.f] = run;
-				if ((tf.flags & 2u) || ((tf.flags & 4u) && run > 64) || force_fb) fb_list[atomicAdd(fb_cnt, 1u)] = tf.f;
+				if (tf.flags & 4u) D.ctie[tf.f] = 1u;
+				if ((tf.flags & 2u) || force_fb) fb_list[atomicAdd(fb_cnt, 1u)] = tf.f;
+				else if (tf.flags & 8u) D.cmp_list[atomicAdd(D.cmp_cnt, 1u)] = tf.f;       // gaps in its list: k_u_compact decides about ties afterwards
+				else if ((tf.flags & 4u) && run > 64) fb_list[atomicAdd(fb_cnt, 1u)] = tf.f;
 			}
 		}
 		if (!more) break;
@@ -497,12 +429,40 @@ k_chain_tile(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ 
 		const CtFrag &tf = s_tf[0];
 		if (!(tf.flags & 1u)) {
 			frag_nu[tf.f] = (tf.flags & 2u) ? 0u : u_run;
-			if ((tf.flags & 2u) || ((tf.flags & 4u) && u_run > 64) || force_fb) fb_list[atomicAdd(fb_cnt, 1u)] = tf.f;
+			if (tf.flags & 4u) D.ctie[tf.f] = 1u;
+			if ((tf.flags & 2u) || force_fb) fb_list[atomicAdd(fb_cnt, 1u)] = tf.f;
+			else if (any_def) D.cmp_list[atomicAdd(D.cmp_cnt, 1u)] = tf.f;
+			else if ((tf.flags & 4u) && u_run > 64) fb_list[atomicAdd(fb_cnt, 1u)] = tf.f;
 		}
 	}
 }
-template __global__ void k_chain_tile<false>(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *, const TileSched, const uint32_t *, AlAnchor *, uint64_t *, uint32_t *, uint32_t *, uint32_t *, uint32_t *, const AlParams, const int, unsigned long long *, const int);
-template __global__ void k_chain_tile<true>(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *, const TileSched, const uint32_t *, AlAnchor *, uint64_t *, uint32_t *, uint32_t *, uint32_t *, uint32_t *, const AlParams, const int, unsigned long long *, const int);
+
+// The chain lists of the fragments with deferred segments have empty slots (the reserve the lane kernels did not need): closed here, a wavefront per
+// fragment, in place and in order.  Then the fragment-wide tie rule: more than 64 chains of which two start at equal x -> fallback list.
+__global__ void __launch_bounds__(64)
+k_u_compact(const uint32_t *__restrict__ cmp_list, const uint32_t *__restrict__ cmp_cnt, const uint64_t *__restrict__ a_off, uint32_t *__restrict__ frag_nu,
+            uint64_t *__restrict__ u_all, uint32_t *__restrict__ uo_all, const uint32_t *__restrict__ ctie, uint32_t *__restrict__ fb_list, uint32_t *__restrict__ fb_cnt)
+{
+	const int lane = threadIdx.x;
+	const uint32_t n = *cmp_cnt;
+	for (uint32_t e = blockIdx.x; e < n; e += gridDim.x) {
+		const uint32_t f = cmp_list[e];
+		const uint32_t n_slots = frag_nu[f];
+		uint64_t *u = u_all + a_off[f] + f; uint32_t *uo = uo_all + a_off[f] + f;
+		uint32_t run = 0;
+		for (uint32_t c0 = 0; c0 < n_slots; c0 += 64) {
+			const uint32_t c = c0 + lane;
+			const uint64_t uc = c < n_slots ? u[c] : 0ULL; const uint32_t oc = c < n_slots ? uo[c] : 0u;
+			const unsigned long long m = __ballot(uc != 0ULL);
+			if (uc != 0ULL) { const uint32_t d = run + (uint32_t)__popcll(m & ((1ULL << lane) - 1ULL)); u[d] = uc; uo[d] = oc; }   // d <= c; the wavefront has read this group before any of it is written
+			run += (uint32_t)__popcll(m);
+		}
+		if (lane == 0) {
+			frag_nu[f] = run;
+			if (ctie[f] && run > 64) fb_list[atomicAdd(fb_cnt, 1u)] = f;
+		}
+	}
+}
 
 // uo[] for chain lists whose anchors were written back to back (the whole-fragment kernels and the fallback): running sum of the counts.
 // One wavefront per list entry.

@@ -1186,8 +1186,9 @@ k_chain_lds(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a
 		__syncthreads();
 	}
 	if (!have || side) return;
-	uint32_t *const rec = seg.meta ? seg.res + 4 * (size_t)f : nullptr;         // the entry's result record (ChainSeg): written once, at the exits
-#define CHAIN_EXIT0() do { if (rec) *reinterpret_cast<uint4 *>(rec) = make_uint4(0u, 0u, 0u, 0u); else frag_nu[f] = 0; return; } while (0)
+	const bool direct = seg.uslot != nullptr;                                  // deferred segment of the tile kernel: straight to the fragment's arrays
+	uint32_t *const rec = (seg.meta && !direct) ? seg.res + 4 * (size_t)f : nullptr;         // the entry's result record (ChainSeg): written once, at the exits
+#define CHAIN_EXIT0() do { if (rec) *reinterpret_cast<uint4 *>(rec) = make_uint4(0u, 0u, 0u, 0u); else if (!direct) frag_nu[f] = 0; return; } while (0)
 	if (n == 0) CHAIN_EXIT0();
 #define ROW(j) srow[(j) * LANES + lane]
 #define VL(j) sv[(j) * LANES + lane]
@@ -1329,18 +1330,20 @@ k_chain_lds(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a
 		TB(j) = ci;
 	}
 #undef CXL
-	AlAnchor *b = chained + a_off[f]; uint64_t *u = u_out + a_off[f] + (seg.meta ? 0u : f);
-	uint32_t *const uo = (!seg.meta && uo_out) ? uo_out + a_off[f] + f : nullptr;
+	AlAnchor *b = chained + a_off[f]; uint64_t *u = direct ? u_out + seg.uslot[f] : u_out + a_off[f] + (seg.meta ? 0u : f);
+	uint32_t *const uo = direct ? uo_out + seg.uslot[f] : (!seg.meta && uo_out) ? uo_out + a_off[f] + f : nullptr;
+	const uint32_t uo_base = direct ? seg.rel[f] : 0u;
 	int32_t o = 0; uint64_t u1 = 0;
 	const bool one = rec && n_u == 1;                                          // a segment with one chain (most of them): its list entry travels in the record
 	for (int32_t i = 0; i < n_u; ++i) {
 		const int32_t c = TB(i), ni = (int32_t)(uint32_t)utmp[c], k0 = OFFB(c);
 		if (one) u1 = utmp[c]; else u[i] = utmp[c];
-		if (uo) uo[i] = (uint32_t)o;
+		if (uo) uo[i] = uo_base + (uint32_t)o;
 		if (okf) okf[i] = okp[c];
 		for (int32_t j = 0; j < ni; ++j) b[o++] = a[(int)VL(k0 + (ni - j - 1))];
 	}
 	if (rec) *reinterpret_cast<uint4 *>(rec) = make_uint4((uint32_t)u1, (uint32_t)(u1 >> 32), (uint32_t)n_u, (uint32_t)o | (eqx ? 1u << 31 : 0u));
+	else if (direct) { if (eqx) seg.ctie[seg.fragid[f]] = 1u; }
 	else frag_nu[f] = (uint32_t)n_u;
 #undef CHAIN_EXIT0
 #undef OFFB

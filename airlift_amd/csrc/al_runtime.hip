@@ -24,7 +24,9 @@ extern "C" __global__ void k_alser_count(const AlAnchor *, const uint64_t *, con
 extern "C" __global__ void k_rechain_test(const AlAnchor *, const uint64_t *, const uint64_t *, const uint32_t *, const uint32_t *, const int32_t *, const uint32_t *, int, uint32_t *, uint32_t *);
 // al_kernels_chain.hip
 struct TileSched { uint32_t n_items; uint32_t ent[7]; uint32_t item[7]; };
-template <bool MARKS> __global__ void k_chain_tile(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *, const TileSched, const uint32_t *, AlAnchor *, uint64_t *, uint32_t *, uint32_t *, uint32_t *, uint32_t *, const AlParams, const int, unsigned long long *, const int);
+struct CtDefer { uint64_t *off, *uslot; uint32_t *na, *meta, *rel, *fragid, *cls; uint32_t *cnt; uint32_t cap; uint32_t *cmp_list, *cmp_cnt; uint32_t *ctie; };
+__global__ void k_chain_tile(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *, const TileSched, const uint32_t *, AlAnchor *, uint64_t *, uint32_t *, uint32_t *, uint32_t *, uint32_t *, const AlParams, const int, unsigned long long *, const int, const CtDefer);
+__global__ void k_u_compact(const uint32_t *, const uint32_t *, const uint64_t *, uint32_t *, uint64_t *, uint32_t *, const uint32_t *, uint32_t *, uint32_t *);
 __global__ void k_uo_fill(const uint32_t *, int, const uint64_t *, const uint32_t *, const uint64_t *, uint32_t *, const uint32_t *);
 __global__ void k_fb_meta(const uint32_t *, int, const uint32_t *, const uint32_t *, uint32_t *, uint32_t *);
 __global__ void k_fb_reads(const uint32_t *, int, const uint32_t *, const uint32_t *, const uint64_t *, uint32_t *, uint32_t *, uint32_t *);
@@ -130,7 +132,7 @@ static void al_dev_free_raw(void *p)
 }
 
 static const char *g_stage_names[ST_N] = { "sketch", "seed_lookup", "scan", "size_order", "anchor_sort_small", "anchor_sort", "anchor_sort_blk", "anchor_sort_big", "anchor_heap",
-                                           "chain_lds32", "chain_lds48", "chain_lds64", "chain_lds128", "chain_tile", "chain_fallback", "chain_legacy", "chain_ties", "rechain",
+                                           "chain_lds32", "chain_lds48", "chain_lds64", "chain_lds128", "chain_tile", "chain_deferred", "chain_fallback", "chain_ties", "rechain",
                                            "regs", "ext_prep", "ext_sort", "ext_dp_lane", "ext_dp_g4", "ext_dp_g8", "ext_dp_g22", "ext_finish", "compact" };
 // kernel behind each interval (what rocprofv3 --kernel-trace lists); "" = several launches
 // the kernel of an interval that is exactly one launch of one kernel ("" otherwise: several kernels or several launches)
@@ -226,7 +228,7 @@ static void ctx_release_buffers(al_ctx_t *c)
 	c->chained.release(); c->match.release(); c->counters.release(); c->scan_tmp.release(); c->regs0.release(); c->regs.release(); c->reg_cnt.release();
 	c->chain_key.release(); c->chain_idx.release(); c->chain_idx2.release(); c->tie_list.release(); c->lb_buf.release(); c->tmp_u64b.release();
 	c->chain_tmp.release(); c->u_tmp.release(); c->okey_tmp.release(); c->fb2_list.release(); c->fb3_list.release(); c->seg_cnt.release(); c->seg_first.release(); c->seg_cnt0.release(); c->seg_first0.release(); c->seg_t1.release(); c->vs_off.release(); c->vs_na.release(); c->vs_meta.release(); c->vs_res.release(); c->vs_cls.release(); c->seg_key.release(); c->seg_idx.release(); c->seg_ord.release(); c->fb_list.release(); c->tie_frags.release(); c->heap_cnt.release(); c->tie_sorted.release(); c->big_na.release(); c->big_off.release();
-	c->uo.release(); c->big_k0.release(); c->big_k1.release(); c->v_anchors.release(); c->v_chained.release(); c->v_u.release(); c->v_a_off.release(); c->v_first64.release(); c->v_na.release(); c->v_nseg.release(); c->v_first.release(); c->v_rd_len.release(); c->v_order.release(); c->v_nu.release(); c->fbk_list.release();
+	c->uo.release(); c->big_k0.release(); c->big_k1.release(); c->v_anchors.release(); c->v_chained.release(); c->v_u.release(); c->v_a_off.release(); c->v_first64.release(); c->v_na.release(); c->v_nseg.release(); c->v_first.release(); c->v_rd_len.release(); c->v_order.release(); c->v_nu.release(); c->fbk_list.release(); c->d_uslot.release(); c->d_rel.release(); c->d_fragid.release(); c->cmp_list.release(); c->ctie.release();
 	c->a_off_p1.release(); c->frag_na_p1.release(); c->frag_rep_p1.release(); c->cigar.release(); c->reg_off.release(); c->cig_off.release(); c->align_ws.release(); c->seg_a.release(); c->seg_u.release();
 }
 extern "C" void al_ctx_destroy(al_ctx_t *c)
@@ -311,7 +313,7 @@ extern "C" int al_batch_upload(al_ctx_t *c, int n_frag, const int *n_segs, const
 	if (c->rd_seq.ensure(words + 1) || c->rd_off.ensure(n_reads + 1) || c->rd_len.ensure(n_reads + 1) || c->frag_first.ensure(n_frag + 1) || c->frag_hash.ensure(n_frag + 1) ||
 	    c->mini_off.ensure(n_reads + 1) || c->mini.ensure(mtot + 1) || c->mini_cnt.ensure(n_reads + 1) || c->match.ensure(mtot + 1) || c->heap_ws.ensure(mtot + 1) ||
 	    c->frag_nm.ensure(n_frag + 1) || c->frag_na.ensure(n_frag + 1) || c->frag_rep.ensure(n_frag + 1) || c->frag_nu.ensure(n_frag + 1) || c->a_off.ensure(n_frag + 2) ||
-	    c->rechain_list.ensure(n_frag + 1) || c->tmp_u32.ensure(n_frag + 2) || c->tmp_u64.ensure(n_frag + 2) || c->counters.ensure(16)) return -1;
+	    c->rechain_list.ensure(n_frag + 1) || c->tmp_u32.ensure(n_frag + 2) || c->tmp_u64.ensure(n_frag + 2) || c->counters.ensure(24)) return -1;
 	AL_HIP_CHECK(hipMemcpyAsync(c->rd_seq.p, c->h_rd_seq.data(), (words + 1) * 4, hipMemcpyHostToDevice, s));
 	AL_HIP_CHECK(hipMemcpyAsync(c->rd_off.p, c->h_rd_off.data(), (n_reads + 1) * 8, hipMemcpyHostToDevice, s));
 	AL_HIP_CHECK(hipMemcpyAsync(c->rd_len.p, c->h_rd_len.data(), (n_reads + 1) * 4, hipMemcpyHostToDevice, s));
@@ -557,27 +559,63 @@ static int chain_fallback(al_ctx_t *c, const uint32_t *fb, int n_fb, bool lds_ok
 	return 0;
 }
 
-// The tile kernel over the items of S (list entries grouped by size class), then the fallback for what it hands back.
+// The tile kernel over the items of S (list entries grouped by size class): it chains the segments of up to 8 anchors itself and defers the
+// longer ones, which the lane-per-segment kernels take by size class across all fragments (64 equally long segments per wavefront) and write
+// straight to the fragments' arrays; k_u_compact closes the unused reserve in the chain lists; then the fallback for what was handed back.
 static int chain_tiles(al_ctx_t *c, const uint32_t *list, const TileSched &S, const uint32_t *skip_flag, int lmin, bool first, bool lds_ok)
 {
 	hipStream_t s = c->stream;
 	auto ev = [&](int st) -> int { if (first) AL_HIP_CHECK(hipEventRecord(c->ev[st + 1], s)); return 0; };
 	uint32_t n_fb = 0;
 	if (S.n_items > 0) {
-		uint32_t *fb_cnt = (uint32_t *)(c->counters.p + 15);
+		uint32_t *cnts = (uint32_t *)(c->counters.p + 16);                          // (counters[16..17]) [0] handed back, [1] deferred segments, [2] fragments to compact
 		static const int force_fb = getenv("AL_TEST_TILE_FB") ? 1 : 0;
-		AL_HIP_CHECK(hipMemsetAsync(fb_cnt, 0, 8, s));
-		if (c->opt.max_chain_skip < 15) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain_tile<true>), dim3(S.n_items), dim3(256), 0, s, c->anchors.p, c->a_off.p, c->frag_na.p, c->frag_first.p, c->rd_len.p, list, S, skip_flag,
-		                                                  c->chained.p, c->u.p, c->uo.p, c->frag_nu.p, c->fb_list.p, fb_cnt, c->P, lmin, c->counters.p, force_fb);
-		else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain_tile<false>), dim3(S.n_items), dim3(256), 0, s, c->anchors.p, c->a_off.p, c->frag_na.p, c->frag_first.p, c->rd_len.p, list, S, skip_flag,
-		                        c->chained.p, c->u.p, c->uo.p, c->frag_nu.p, c->fb_list.p, fb_cnt, c->P, lmin, c->counters.p, force_fb);
+		const size_t cap = (size_t)(c->n_anchor_total / 9) + 64;                    // a deferred segment has at least 9 anchors
+		if (cap >= (1ULL << 31)) { fprintf(stderr, "[airlift] too many anchors in one batch for the deferred-segment list: upload fewer fragments\n"); al_nomem_flag() = true; return -1; }
+		if (c->vs_off.ensure(cap) || c->d_uslot.ensure(cap) || c->vs_na.ensure(cap) || c->vs_meta.ensure(cap) || c->d_rel.ensure(cap) || c->d_fragid.ensure(cap) || c->vs_cls.ensure(cap) ||
+		    c->cmp_list.ensure((size_t)c->n_frag + 2) || c->ctie.ensure((size_t)c->n_frag + 2)) return -1;
+		AL_HIP_CHECK(hipMemsetAsync(cnts, 0, 16, s));
+		AL_HIP_CHECK(hipMemsetAsync(c->ctie.p, 0, ((size_t)c->n_frag + 1) * 4, s));
+		CtDefer D; D.off = c->vs_off.p; D.uslot = c->d_uslot.p; D.na = c->vs_na.p; D.meta = c->vs_meta.p; D.rel = c->d_rel.p; D.fragid = c->d_fragid.p; D.cls = c->vs_cls.p; D.cnt = cnts + 1; D.cap = (uint32_t)cap;
+		D.cmp_list = c->cmp_list.p; D.cmp_cnt = cnts + 2; D.ctie = c->ctie.p;
+		hipLaunchKernelGGL(k_chain_tile, dim3(S.n_items), dim3(256), 0, s, c->anchors.p, c->a_off.p, c->frag_na.p, c->frag_first.p, c->rd_len.p, list, S, skip_flag,
+		                   c->chained.p, c->u.p, c->uo.p, c->frag_nu.p, c->fb_list.p, cnts, c->P, lmin, c->counters.p, force_fb, D);
 		if (ev(ST_SEG_FIND)) return -1;
-		AL_HIP_CHECK(hipMemcpyAsync(&n_fb, fb_cnt, 4, hipMemcpyDeviceToHost, s));
+		uint32_t h[3] = {0, 0, 0};
+		AL_HIP_CHECK(hipMemcpyAsync(h, cnts, 12, hipMemcpyDeviceToHost, s));
 		AL_HIP_CHECK(hipStreamSynchronize(s));
-	} else if (ev(ST_SEG_FIND)) return -1;
+		const uint32_t n_def = h[1], n_cmp = h[2];
+		if (n_def > cap) { fprintf(stderr, "[airlift] deferred-segment list overflow (%u > %zu)\n", n_def, cap); return -1; }
+		if (n_def > 0) {
+			// the deferred segments by size class (stable: inside a class they keep the tiles' order, i.e. memory order inside a tile)
+			if (c->seg_key.ensure((size_t)n_def + 1) || c->seg_ord.ensure((size_t)n_def + 1) || c->seg_t1.ensure((size_t)n_def + 1)) return -1;
+			hipLaunchKernelGGL(k_iota_u32, dim3((n_def + 255) / 256), dim3(256), 0, s, c->seg_t1.p, n_def);
+			size_t bytes = 0;
+			AL_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, bytes, (const uint32_t *)c->vs_cls.p, c->seg_key.p, (const uint32_t *)c->seg_t1.p, c->seg_ord.p, (int)n_def, 0, 4, s));
+			if (c->scan_tmp.ensure(bytes + 16)) return -1;
+			AL_HIP_CHECK(rocprim::radix_sort_pairs(c->scan_tmp.p, bytes, (const uint32_t *)c->vs_cls.p, c->seg_key.p, (const uint32_t *)c->seg_t1.p, c->seg_ord.p, (int)n_def, 0, 4, s));
+			static const uint32_t thr[8] = {1, 2, 3, 4, 5, 6, 7, 8};
+			uint32_t lb[8];
+			if (lower_bounds(c, c->seg_key.p, n_def, thr, 8, lb)) return -1;
+			const uint32_t cb[10] = {0, lb[0], lb[1], lb[2], lb[3], lb[4], lb[5], lb[6], lb[7], n_def};   // class k: entries [cb[k], cb[k + 1])
+			static const uint32_t capl[9] = {16, 24, 32, 40, 48, 64, 80, 96, 128};
+			size_t wsb[10]; wsb[0] = 0; for (int k = 0; k < 9; ++k) wsb[k + 1] = wsb[k] + (size_t)(cb[k + 1] - cb[k]) * capl[k];   // chain-end scratch: CAPL words per entry, by list position
+			if (c->ws_u64.ensure(wsb[9] + 64, false, s)) return -1;
+			{ static const bool tr = getenv("AL_TRACE") != nullptr;
+			  if (tr && first) fprintf(stderr, "[airlift] trace: tile chaining: %u items, %u deferred segments (<=16:%u <=24:%u <=32:%u <=40:%u <=48:%u <=64:%u <=80:%u <=96:%u <=128:%u), %u fragments to compact\n", S.n_items, n_def,
+			                          cb[1] - cb[0], cb[2] - cb[1], cb[3] - cb[2], cb[4] - cb[3], cb[5] - cb[4], cb[6] - cb[5], cb[7] - cb[6], cb[8] - cb[7], cb[9] - cb[8], n_cmp); }
+			ChainSeg sg{c->vs_meta.p, nullptr, nullptr, 0, nullptr, c->d_uslot.p, c->d_rel.p, c->d_fragid.p, c->ctie.p};
+#define LDEF(C, L, K) LCH(C, L, -1, c->vs_off.p, c->vs_na.p, c->chained.p, c->u.p, (uint32_t *)nullptr, c->seg_ord.p + cb[K], (int)(cb[K + 1] - cb[K]), sg, c->uo.p, c->ws_u64.p + wsb[K], C)
+			LDEF(16, 64, 0); LDEF(24, 64, 1); LDEF(32, 64, 2); LDEF(40, 64, 3); LDEF(48, 64, 4); LDEF(64, 64, 5); LDEF(80, 64, 6); LDEF(96, 64, 7); LDEF(128, 32, 8);
+#undef LDEF
+		}
+		if (n_cmp > 0) hipLaunchKernelGGL(k_u_compact, dim3(std::min<uint32_t>(n_cmp, 8192u)), dim3(64), 0, s, (const uint32_t *)c->cmp_list.p, (const uint32_t *)(cnts + 2), c->a_off.p, c->frag_nu.p, c->u.p, c->uo.p, (const uint32_t *)c->ctie.p, c->fb_list.p, cnts);
+		if (ev(ST_SEG_CHAIN_LDS)) return -1;
+		if (n_cmp > 0) { AL_HIP_CHECK(hipMemcpyAsync(&n_fb, cnts, 4, hipMemcpyDeviceToHost, s)); AL_HIP_CHECK(hipStreamSynchronize(s)); } else n_fb = h[0];
+	} else if (ev(ST_SEG_FIND) || ev(ST_SEG_CHAIN_LDS)) return -1;
 	if (n_fb > 0) {
 		c->n_chain_fallback += n_fb;
-		// (the list the kernel appended to atomically, in ascending fragment order: the same virtual batch on every run)
+		// (the list the kernels appended to atomically, in ascending fragment order: the same virtual batch on every run)
 		size_t bytes = 0;
 		if (c->fbk_list.ensure((size_t)n_fb + 2)) return -1;
 		AL_HIP_CHECK(rocprim::radix_sort_keys(nullptr, bytes, (const uint32_t *)c->fb_list.p, c->fbk_list.p, (int)n_fb, 0, 32, s));
@@ -585,7 +623,7 @@ static int chain_tiles(al_ctx_t *c, const uint32_t *list, const TileSched &S, co
 		AL_HIP_CHECK(rocprim::radix_sort_keys(c->scan_tmp.p, bytes, (const uint32_t *)c->fb_list.p, c->fbk_list.p, (int)n_fb, 0, 32, s));
 		if (chain_fallback(c, c->fbk_list.p, (int)n_fb, lds_ok)) return -1;
 	}
-	if (ev(ST_SEG_CHAIN_LDS)) return -1;
+	if (ev(ST_SEG_CHAIN_WAVE)) return -1;
 	return 0;
 }
 
@@ -645,7 +683,7 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 	int lmin = c->opt.min_cnt > 1 ? c->opt.min_cnt : 1;
 	{ const int per = c->mi->k + 1, need = (c->opt.min_chain_score + per - 1) / per; if (need > lmin) lmin = need; }
 	static const bool tile_all = getenv("AL_TEST_TILE_ALL") != nullptr;
-	const bool tiles_ok = lds_ok && lmin >= 2 && !((c->P.dbg >> 28) & 1);
+	const bool tiles_ok = lds_ok && lmin >= 2 && c->opt.max_chain_skip >= 7 && !((c->P.dbg >> 28) & 1);   // (at most 7 predecessors in the segments the tile kernel chains itself: no skip rule)
 	const uint32_t tile_from = !tiles_ok ? (uint32_t)nl : tile_all ? lb1 : lb129;
 	if (c->fb_list.ensure((size_t)nl + 2)) return -1;
 	if (ev(ST_ORDER)) return -1;
@@ -772,8 +810,8 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 			if (ev(ST_SEG_FIND) || ev(ST_SEG_CHAIN_LDS)) return -1;
 			const uint32_t tail = lds_ok ? lb129 : 0u;
 			if (chain_legacy(c, order + tail, nl - (int)tail, lds_ok, (const uint32_t *)c->tie_list.p)) return -1;
+			if (ev(ST_SEG_CHAIN_WAVE)) return -1;
 		}
-		if (ev(ST_SEG_CHAIN_WAVE)) return -1;
 	}
 	{   // second round: the fragments whose anchors the side stream merged, any size
 		AL_HIP_CHECK(hipStreamWaitEvent(s, c->ev_side[first ? 1 : 3], 0));
@@ -1127,7 +1165,7 @@ extern "C" int al_batch_upload_windows(al_ctx_t *c, const al_winsrc_t *src, int 
 	if (c->rd_seq.ensure(words + 1) || c->rd_off.ensure(n_reads + 1) || c->rd_len.ensure(n_reads + 1) || c->frag_first.ensure(n_frag + 1) || c->frag_hash.ensure(n_frag + 1) ||
 	    c->mini_off.ensure(n_reads + 1) || c->mini.ensure(mtot + 1) || c->mini_cnt.ensure(n_reads + 1) || c->match.ensure(mtot + 1) || c->heap_ws.ensure(mtot + 1) ||
 	    c->frag_nm.ensure(n_frag + 1) || c->frag_na.ensure(n_frag + 1) || c->frag_rep.ensure(n_frag + 1) || c->frag_nu.ensure(n_frag + 1) || c->a_off.ensure(n_frag + 2) ||
-	    c->rechain_list.ensure(n_frag + 1) || c->tmp_u32.ensure(n_frag + 2) || c->tmp_u64.ensure(n_frag + 2) || c->counters.ensure(16) || c->tmp_u64b.ensure(n_tok + 1)) return -1;
+	    c->rechain_list.ensure(n_frag + 1) || c->tmp_u32.ensure(n_frag + 2) || c->tmp_u64.ensure(n_frag + 2) || c->counters.ensure(24) || c->tmp_u64b.ensure(n_tok + 1)) return -1;
 	AL_HIP_CHECK(hipMemcpyAsync(c->tmp_u64b.p, start, (size_t)n_tok * 8, hipMemcpyHostToDevice, s));
 	if (words) hipLaunchKernelGGL(k_make_windows, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s, src->S4, c->tmp_u64b.p, n_tok, read_len, wpr, c->rd_seq.p);
 	AL_HIP_CHECK(hipMemsetAsync(c->rd_seq.p + words, 0, 4, s));
