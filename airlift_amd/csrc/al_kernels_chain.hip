@@ -264,14 +264,30 @@ k_chain_tile(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ 
 		if (s_misc.too_long) { if (tid == 0) s_tf[0].flags |= 2u; break; }
 		// ---- DP, a lane per segment (chain.c:46-85; at most CT_INLINE - 1 predecessors: the max_skip rule of chain.c:74-80 cannot fire, the caller
 		//      checks max_chain_skip); the wavefronts take every fourth segment of the size-ordered list ----
-		for (uint32_t r0 = 0; r0 * CT_NW < n_inl; r0 += 64) {
-			const uint32_t pi = (r0 + lane) * CT_NW + w;
-			const bool have = pi < n_inl;
+		// (every wavefront takes a contiguous quarter of the size-ordered list: the two-anchor segments -- more than half of them -- end up in
+		//  wavefronts of their own, which take the closed form below and leave the issue slots to the others)
+		const uint32_t q_inl = (n_inl + CT_NW - 1) / CT_NW, p_end = (w + 1) * q_inl < n_inl ? (w + 1) * q_inl : n_inl;
+		for (uint32_t r0 = w * q_inl; r0 < p_end; r0 += 64) {
+			const uint32_t pi = r0 + lane;
+			const bool have = pi < p_end;
 			const uint32_t k = have ? s_proc[pi] : 0u;
 			const int n = have ? (int)s_slen[k] : 0;
 			const uint32_t Sg = s_sstart[k];
 			const CtFrag &tf = s_tf[s_sfrag[k]];
 			const int32_t mdx = tf.mdx, mdy = tf.mdy; const uint32_t drlim = tf.drlim;
+			if (!__ballot(n > 2)) {
+				// two anchors: one pair to score.  A chain needs the pair (a lone anchor scores k < min_chain_score, or min_cnt >= 2 rejects it -- lmin >= 2):
+				// f[1] = sc > k makes anchor 1 the only chain end and its own peak (chain.c:87-109), the backtrack visits 1, 0 (chain.c:111-128)
+				if (have) {
+					const uint64_t r0w = s_row[Sg], r1w = s_row[Sg + 1];
+					int32_t sc;
+					const bool ok = ct_score(r0w | (uint64_t)(uint32_t)q_span << 32, R_XLO(r1w), R_Q(r1w), R_SEG(r1w), q_span, mdx, mdy, drlim, bw, pen, sc);   // f[0] = k
+					const bool chain = ok && sc > q_span && sc >= min_sc && 2 >= min_cnt && (int32_t)((R_XLO(r1w) - R_XLO(r0w)) & 0xffffu) <= mdx && 1 <= max_iter;
+					if (chain) { s_u[Sg] = (uint32_t)sc << 16 | 2u; s_v[Sg] = 1; s_v[Sg + 1] = 0; s_tm[Sg] = 0; s_perm[Sg] = 0; s_snu[k] = 1; }
+					else s_snu[k] = 0;
+				}
+				continue;
+			}
 			int st = 0; int32_t dist = 0; uint32_t prev_xlo = 0;
 			for (int i = 0; i < n; ++i) {
 				const uint64_t ri = s_row[Sg + i];

@@ -598,15 +598,20 @@ static int chain_tiles(al_ctx_t *c, const uint32_t *list, const TileSched &S, co
 			uint32_t lb[8];
 			if (lower_bounds(c, c->seg_key.p, n_def, thr, 8, lb)) return -1;
 			const uint32_t cb[10] = {0, lb[0], lb[1], lb[2], lb[3], lb[4], lb[5], lb[6], lb[7], n_def};   // class k: entries [cb[k], cb[k + 1])
-			static const uint32_t capl[9] = {16, 24, 32, 40, 48, 64, 80, 96, 128};
+			static const uint32_t capl0[9] = {16, 24, 32, 40, 48, 64, 80, 96, 128};
+			// the long classes hold few segments, and a lane walks a 49 ... 128-anchor segment for half a millisecond whatever the launch holds: as long
+			// as they are thin they share ONE launch of the 128-anchor kernel (the list is ordered by class: their entries are one range)
+			int mfrom = 9; while (mfrom > 5 && n_def - cb[mfrom - 1] < 4096u) --mfrom;
+			uint32_t capl[9]; for (int k = 0; k < 9; ++k) capl[k] = k >= mfrom ? 128u : capl0[k];
 			size_t wsb[10]; wsb[0] = 0; for (int k = 0; k < 9; ++k) wsb[k + 1] = wsb[k] + (size_t)(cb[k + 1] - cb[k]) * capl[k];   // chain-end scratch: CAPL words per entry, by list position
 			if (c->ws_u64.ensure(wsb[9] + 64, false, s)) return -1;
 			{ static const bool tr = getenv("AL_TRACE") != nullptr;
 			  if (tr && first) fprintf(stderr, "[airlift] trace: tile chaining: %u items, %u deferred segments (<=16:%u <=24:%u <=32:%u <=40:%u <=48:%u <=64:%u <=80:%u <=96:%u <=128:%u), %u fragments to compact\n", S.n_items, n_def,
 			                          cb[1] - cb[0], cb[2] - cb[1], cb[3] - cb[2], cb[4] - cb[3], cb[5] - cb[4], cb[6] - cb[5], cb[7] - cb[6], cb[8] - cb[7], cb[9] - cb[8], n_cmp); }
 			ChainSeg sg{c->vs_meta.p, nullptr, nullptr, 0, nullptr, c->d_uslot.p, c->d_rel.p, c->d_fragid.p, c->ctie.p};
-#define LDEF(C, L, K) LCH(C, L, -1, c->vs_off.p, c->vs_na.p, c->chained.p, c->u.p, (uint32_t *)nullptr, c->seg_ord.p + cb[K], (int)(cb[K + 1] - cb[K]), sg, c->uo.p, c->ws_u64.p + wsb[K], C)
+#define LDEF(C, L, K) do { if ((K) < mfrom) LCH(C, L, -1, c->vs_off.p, c->vs_na.p, c->chained.p, c->u.p, (uint32_t *)nullptr, c->seg_ord.p + cb[K], (int)(cb[K + 1] - cb[K]), sg, c->uo.p, c->ws_u64.p + wsb[K], C); } while (0)
 			LDEF(16, 64, 0); LDEF(24, 64, 1); LDEF(32, 64, 2); LDEF(40, 64, 3); LDEF(48, 64, 4); LDEF(64, 64, 5); LDEF(80, 64, 6); LDEF(96, 64, 7); LDEF(128, 32, 8);
+			if (mfrom < 9) LCH(128, 32, -1, c->vs_off.p, c->vs_na.p, c->chained.p, c->u.p, (uint32_t *)nullptr, c->seg_ord.p + cb[mfrom], (int)(n_def - cb[mfrom]), sg, c->uo.p, c->ws_u64.p + wsb[mfrom], 128);
 #undef LDEF
 		}
 		if (n_cmp > 0) hipLaunchKernelGGL(k_u_compact, dim3(std::min<uint32_t>(n_cmp, 8192u)), dim3(64), 0, s, (const uint32_t *)c->cmp_list.p, (const uint32_t *)(cnts + 2), c->a_off.p, c->frag_nu.p, c->u.p, c->uo.p, (const uint32_t *)c->ctie.p, c->fb_list.p, cnts);
