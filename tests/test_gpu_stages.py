@@ -75,11 +75,12 @@ def test_seeds_and_chains_match_reference_taps(A, golden_unpacked, name):
     for f in range(nf):
         exp_cn = [l.split("\t", 2)[2] for l in blocks[f] if l.startswith("CN\t")]
         uu = u[int(off[f]) + f: int(off[f]) + f + int(nu[f])]
-        k = int(off[f]); got_chains = []
+        oo = uo[int(off[f]) + f: int(off[f]) + f + int(nu[f])]          # every chain's anchors lie at uo[] inside the fragment's range of chained[]
+        got_chains = []
         for c in range(int(nu[f])):
-            n = int(uu[c] & np.uint64(0xffffffff))
+            n = int(uu[c] & np.uint64(0xffffffff)); k = int(off[f]) + int(oo[c])
+            assert int(oo[c]) + n <= int(na[f])
             got_chains.append(tuple(l.split("\t", 2)[2] for l in seed_lines("CN", ref_names, chained[k:k + n], 0)))
-            k += n
         # split expected CN lines into chains (gap column of the first anchor of a chain is 0 and id increments)
         exp_chains, cur, last = [], [], None
         for l in blocks[f]:
