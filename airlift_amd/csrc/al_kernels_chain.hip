@@ -404,8 +404,8 @@ k_chain_tile(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ 
 			if (snu & CT_DEF) {                                                          // reserved slots, empty until the lane kernels fill them
 				for (uint32_t i = 0; i < nu; ++i) ub[w0 + i] = 0ULL;
 				atomicOr(&s_tf[fi].flags, 8u);
-				if (def_ok && !(tf.flags & 2u)) {
-					const uint32_t d = def_base + D_of(k), len = s_slen[k];
+				if (def_ok) {                                                            // (a fragment the fallback takes anyway: an empty entry)
+					const uint32_t d = def_base + D_of(k), len = (tf.flags & 2u) ? 0u : (uint32_t)s_slen[k];
 					D.off[d] = tf.aoff + rel; D.na[d] = len; D.meta[d] = tf.meta; D.uslot[d] = tf.aoff + tf.f + w0; D.rel[d] = rel; D.fragid[d] = tf.f; D.cls[d] = ct_defer_class(len);
 				}
 				continue;

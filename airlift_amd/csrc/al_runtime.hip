@@ -581,6 +581,7 @@ static int chain_tiles(al_ctx_t *c, const uint32_t *list, const TileSched &S, co
 		hipLaunchKernelGGL(k_chain_tile, dim3(S.n_items), dim3(256), 0, s, c->anchors.p, c->a_off.p, c->frag_na.p, c->frag_first.p, c->rd_len.p, list, S, skip_flag,
 		                   c->chained.p, c->u.p, c->uo.p, c->frag_nu.p, c->fb_list.p, cnts, c->P, lmin, c->counters.p, force_fb, D);
 		if (ev(ST_SEG_FIND)) return -1;
+		{ static const bool tr = getenv("AL_TRACE") != nullptr; if (tr) { const hipError_t e = hipStreamSynchronize(s); fprintf(stderr, "[airlift] trace: tile kernel (%u items, first pass %d) -> %s\n", S.n_items, (int)first, hipGetErrorName(e)); } }
 		uint32_t h[3] = {0, 0, 0};
 		AL_HIP_CHECK(hipMemcpyAsync(h, cnts, 12, hipMemcpyDeviceToHost, s));
 		AL_HIP_CHECK(hipStreamSynchronize(s));
@@ -609,13 +610,17 @@ static int chain_tiles(al_ctx_t *c, const uint32_t *list, const TileSched &S, co
 			  if (tr && first) fprintf(stderr, "[airlift] trace: tile chaining: %u items, %u deferred segments (<=16:%u <=24:%u <=32:%u <=40:%u <=48:%u <=64:%u <=80:%u <=96:%u <=128:%u), %u fragments to compact\n", S.n_items, n_def,
 			                          cb[1] - cb[0], cb[2] - cb[1], cb[3] - cb[2], cb[4] - cb[3], cb[5] - cb[4], cb[6] - cb[5], cb[7] - cb[6], cb[8] - cb[7], cb[9] - cb[8], n_cmp); }
 			ChainSeg sg{c->vs_meta.p, nullptr, nullptr, 0, nullptr, c->d_uslot.p, c->d_rel.p, c->d_fragid.p, c->ctie.p};
-#define LDEF(C, L, K) do { if ((K) < mfrom) LCH(C, L, -1, c->vs_off.p, c->vs_na.p, c->chained.p, c->u.p, (uint32_t *)nullptr, c->seg_ord.p + cb[K], (int)(cb[K + 1] - cb[K]), sg, c->uo.p, c->ws_u64.p + wsb[K], C); } while (0)
+			if (getenv("AL_TRACE")) { const hipError_t e = hipStreamSynchronize(s); fprintf(stderr, "[airlift] trace: deferred sort, scratch %zu words, mfrom %d -> %s\n", wsb[9], mfrom, hipGetErrorName(e)); }
+#define LDEF(C, L, K) do { if ((K) < mfrom) LCH(C, L, -1, c->vs_off.p, c->vs_na.p, c->chained.p, c->u.p, (uint32_t *)nullptr, c->seg_ord.p + cb[K], (int)(cb[K + 1] - cb[K]), sg, c->uo.p, c->ws_u64.p + wsb[K], C); \
+			if (getenv("AL_TRACE")) { const hipError_t e = hipStreamSynchronize(s); fprintf(stderr, "[airlift] trace: deferred class %d (%u) -> %s\n", K, cb[K + 1] - cb[K], hipGetErrorName(e)); } } while (0)
 			LDEF(16, 64, 0); LDEF(24, 64, 1); LDEF(32, 64, 2); LDEF(40, 64, 3); LDEF(48, 64, 4); LDEF(64, 64, 5); LDEF(80, 64, 6); LDEF(96, 64, 7); LDEF(128, 32, 8);
 			if (mfrom < 9) LCH(128, 32, -1, c->vs_off.p, c->vs_na.p, c->chained.p, c->u.p, (uint32_t *)nullptr, c->seg_ord.p + cb[mfrom], (int)(n_def - cb[mfrom]), sg, c->uo.p, c->ws_u64.p + wsb[mfrom], 128);
+			{ static const bool tr = getenv("AL_TRACE") != nullptr; if (tr) { const hipError_t e = hipStreamSynchronize(s); fprintf(stderr, "[airlift] trace: deferred segments (%u, first pass %d) -> %s\n", n_def, (int)first, hipGetErrorName(e)); } }
 #undef LDEF
 		}
 		if (n_cmp > 0) hipLaunchKernelGGL(k_u_compact, dim3(std::min<uint32_t>(n_cmp, 8192u)), dim3(64), 0, s, (const uint32_t *)c->cmp_list.p, (const uint32_t *)(cnts + 2), c->a_off.p, c->frag_nu.p, c->u.p, c->uo.p, (const uint32_t *)c->ctie.p, c->fb_list.p, cnts);
 		if (ev(ST_SEG_CHAIN_LDS)) return -1;
+		{ static const bool tr = getenv("AL_TRACE") != nullptr; if (tr) { const hipError_t e = hipStreamSynchronize(s); fprintf(stderr, "[airlift] trace: compact (%u fragments) -> %s\n", n_cmp, hipGetErrorName(e)); } }
 		if (n_cmp > 0) { AL_HIP_CHECK(hipMemcpyAsync(&n_fb, cnts, 4, hipMemcpyDeviceToHost, s)); AL_HIP_CHECK(hipStreamSynchronize(s)); } else n_fb = h[0];
 	} else if (ev(ST_SEG_FIND) || ev(ST_SEG_CHAIN_LDS)) return -1;
 	if (n_fb > 0) {
