@@ -95,7 +95,7 @@ struct TileSched {
 #define CT_INLINE 8                      // segments of up to this many anchors are chained here; longer ones are deferred to the lane kernels
 #define CT_DEFER_MAX 128                 // ... whose rows hold up to 128 anchors; a longer segment hands the fragment to the fallback
 #define CT_DEF 0x4000u                   // s_snu: the segment is deferred (the count is the number of chain list slots reserved for it)
-struct CtMisc { uint32_t n_seg, n_inl, proc_end, next_pos, more, too_long, def_base; };
+struct CtMisc { uint32_t n_seg, n_inl, n_def, proc_end, next_pos, more, too_long, def_base; };
 struct CtDefer {                         // the deferred segments (ChainSeg direct mode), appended tile by tile
 	uint64_t *off, *uslot; uint32_t *na, *meta, *rel, *fragid, *cls; uint32_t *cnt; uint32_t cap;
 	uint32_t *cmp_list, *cmp_cnt;        // fragments with deferred segments: their chain lists have gaps until k_u_compact has run
@@ -123,6 +123,9 @@ k_chain_tile(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ 
 	const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
 	const unsigned long long below = (1ULL << lane) - 1ULL;
 	if (blockIdx.x >= S.n_items) return;
+	const bool prof = (P.dbg >> 24) & 1;                                       // timing experiment: cycles per step of the tile loop, summed over the blocks (counters[24 ..])
+	long long tp = prof ? clock64() : 0;
+#define CT_PROF(i) do { if (prof && tid == 0) { const long long t_ = clock64(); atomicAdd(&counters[24 + (i)], (unsigned long long)(t_ - tp)); tp = t_; } } while (0)
 	const uint32_t it = S.n_items - 1u - blockIdx.x;                            // the list ascends by anchor count: the heaviest items first
 	int cl = 0; while (cl < 5 && it >= S.item[cl + 1]) ++cl;
 	const uint32_t per = 32u >> cl;
@@ -164,32 +167,44 @@ k_chain_tile(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ 
 		const CtFrag &tl = s_tf[nfr - 1];
 		if (tl.start + tl.na > CT_TILE) { if (tid == 0) atomicAdd(&counters[7], 1ULL << 48); return; }
 	}
+ 	CT_PROF(0);
 	uint32_t *const rlo = reinterpret_cast<uint32_t *>(s_row);                   // rlo[2 t]: static half of row t, rlo[2 t + 1]: f | p << 16
 	uint32_t pos = 0;                    // single: rows of the fragment in front of this tile
 	uint32_t u_run = 0;                  // single: chain list slots written by the earlier tiles
 	bool any_def = false;                // single: a segment of an earlier tile was deferred
 	for (;;) {
-		// ---- load: rows with their cut flags, by all wavefronts ----
-		for (int fi = 0; fi < nfr; ++fi) {
-			const CtFrag tf = s_tf[fi];
-			const uint32_t base_t = tf.start;
-			const uint32_t n = single ? (tf.na - pos < CT_TILE ? tf.na - pos : CT_TILE) : tf.na;
-			const AlAnchor *src = anchors + tf.aoff + pos;
-			bool bad = false;
-			for (uint32_t b = 0; b < n; b += CT_NT) {
-				const uint32_t i = b + tid; const bool valid = i < n;
-				AlAnchor e; e.x = 0; e.y = 0;
-				if (valid) e = src[i];
-				uint64_t xp = (uint64_t)(uint32_t)__shfl_up((int)(uint32_t)e.x, 1) | (uint64_t)(uint32_t)__shfl_up((int)(uint32_t)(e.x >> 32), 1) << 32;
-				if (lane == 0 && valid && i > 0) xp = src[i - 1].x;
-				const bool cut = valid && (i == 0 || e.x - xp > (uint64_t)(int64_t)tf.mdx);
-				bad = bad || (valid && ((int32_t)(e.y >> 32 & 0xff) != q_span || ((e.y & AL_SEED_SEG_MASK) >> AL_SEED_SEG_SHIFT) > 1 || (uint32_t)e.y > 0xfffu));
-				if (valid) s_row[base_t + i] = (uint64_t)((uint32_t)e.x & 0xffffu) | (uint64_t)((uint32_t)e.y & 0xfffu) << 16 | (uint64_t)((e.y & AL_SEED_SEG_MASK) >> AL_SEED_SEG_SHIFT & 1) << 28
-				                               | (uint64_t)(cut ? 1u : 0u) << 29 | (uint64_t)CT_NONE << 48;
+		// ---- load: rows with their cut flags, by all wavefronts; every thread's loads (a row and its left neighbour's x, four times) are in flight together ----
+		{
+			const uint32_t rows = single ? (s_tf[0].na - pos < CT_TILE ? s_tf[0].na - pos : CT_TILE) : s_tf[nfr - 1].start + s_tf[nfr - 1].na;
+			AlAnchor e[CT_TILE / CT_NT]; uint64_t xp[CT_TILE / CT_NT]; int fis[CT_TILE / CT_NT]; uint32_t is[CT_TILE / CT_NT];
+#pragma unroll
+			for (int j = 0; j < CT_TILE / CT_NT; ++j) {
+				const uint32_t r = (uint32_t)j * CT_NT + tid;
+				int fi = 0;
+				if (!single) while (fi + 1 < nfr && s_tf[fi + 1].start <= r) ++fi;
+				fis[j] = fi; e[j].x = 0; e[j].y = 0; xp[j] = 0; is[j] = 0;
+				if (r < rows) {
+					const uint32_t i = r - s_tf[fi].start; is[j] = i;
+					const AlAnchor *src = anchors + s_tf[fi].aoff + pos;
+					e[j] = src[i];
+					if (i > 0) xp[j] = src[i - 1].x;
+				}
 			}
-			if (bad) atomicOr(&s_tf[fi].flags, 2u);
+#pragma unroll
+			for (int j = 0; j < CT_TILE / CT_NT; ++j) {
+				const uint32_t r = (uint32_t)j * CT_NT + tid;
+				if (r < rows) {
+					const AlAnchor ee = e[j];
+					const bool cut = is[j] == 0 || ee.x - xp[j] > (uint64_t)(int64_t)s_tf[fis[j]].mdx;
+					const bool bad = (int32_t)(ee.y >> 32 & 0xff) != q_span || ((ee.y & AL_SEED_SEG_MASK) >> AL_SEED_SEG_SHIFT) > 1 || (uint32_t)ee.y > 0xfffu;
+					s_row[r] = (uint64_t)((uint32_t)ee.x & 0xffffu) | (uint64_t)((uint32_t)ee.y & 0xfffu) << 16 | (uint64_t)((ee.y & AL_SEED_SEG_MASK) >> AL_SEED_SEG_SHIFT & 1) << 28
+					           | (uint64_t)(cut ? 1u : 0u) << 29 | (uint64_t)CT_NONE << 48;
+					if (bad) atomicOr(&s_tf[fis[j]].flags, 2u);
+				}
+			}
 		}
 		__syncthreads();
+		CT_PROF(1);
 		// ---- cut: segment list in tile order; the segments chained here ordered by size class (one wavefront walks the cut flags) ----
 		if (w == 0) {
 			uint32_t n_seg = 0, cnt0 = 0, cnt1 = 0, cnt2 = 0;
@@ -254,14 +269,17 @@ k_chain_tile(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ 
 			}
 			if (lane == 0) {
 				s_fseg[nfr] = n_seg;
-				CtMisc m; m.n_seg = n_seg; m.n_inl = cnt0 + cnt1 + cnt2; m.proc_end = proc_end; m.next_pos = next_pos; m.more = more ? 1u : 0u; m.too_long = too_long ? 1u : 0u; m.def_base = 0;
+				CtMisc m; m.n_seg = n_seg; m.n_inl = cnt0 + cnt1 + cnt2; m.n_def = n_seg - (cnt0 + cnt1 + cnt2); m.proc_end = proc_end; m.next_pos = next_pos; m.more = more ? 1u : 0u; m.too_long = too_long ? 1u : 0u; m.def_base = 0;
 				s_misc = m;
 			}
 		}
 		__syncthreads();
-		const uint32_t n_seg = s_misc.n_seg, n_inl = s_misc.n_inl, proc_end = s_misc.proc_end;
+		CT_PROF(2);
+		const uint32_t n_seg = s_misc.n_seg, n_inl = s_misc.n_inl, proc_end = s_misc.proc_end, n_def = s_misc.n_def;
 		const bool more = s_misc.more != 0;
 		if (s_misc.too_long) { if (tid == 0) s_tf[0].flags |= 2u; break; }
+		uint32_t def_base_r = 0;
+		if (tid == 0 && n_def) def_base_r = atomicAdd(D.cnt, n_def);                      // the tile's deferred segments, one range of the list (the answer is needed at the emit step)
 		// ---- DP, a lane per segment (chain.c:46-85; at most CT_INLINE - 1 predecessors: the max_skip rule of chain.c:74-80 cannot fire, the caller
 		//      checks max_chain_skip); the wavefronts take every fourth segment of the size-ordered list ----
 		// (every wavefront takes a contiguous quarter of the size-ordered list: the two-anchor segments -- more than half of them -- end up in
@@ -362,6 +380,7 @@ k_chain_tile(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ 
 #undef P_
 		}
 		__syncthreads();
+		CT_PROF(3);
 		// ---- emit: chain list entries in tile order at the fragment's running offset; chained anchors at the segment's own place ----
 		for (uint32_t t = tid; t < proc_end; t += CT_NT) rlo[2 * t + 1] = 0xffffffffu;   // f / p are dead: the half becomes "source row of the chained anchor at this place"
 		for (uint32_t c = w; c * 64 < n_seg; c += CT_NW) {                                // list slots / deferred segments in front of every segment: inside its group of 64 ...
@@ -384,8 +403,7 @@ k_chain_tile(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ 
 			for (uint32_t c = 0; c < cc; ++c) g += s_dtot[c];
 			return k < n_seg ? g + s_Dn[k] : ((k & 63) ? g + s_dtot[cc] : g);
 		};
-		const uint32_t n_def = D_of(n_seg);
-		if (tid == 0 && n_def) s_misc.def_base = atomicAdd(D.cnt, n_def);                 // the tile's deferred segments, one range of the list
+		if (tid == 0) s_misc.def_base = def_base_r;
 		__syncthreads();
 		const uint32_t def_base = s_misc.def_base;
 		const bool def_ok = n_def == 0 || def_base + n_def <= D.cap;
@@ -419,11 +437,23 @@ k_chain_tile(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ 
 			}
 		}
 		__syncthreads();
-		for (int fi = 0; fi < nfr; ++fi) {   // the chained anchors, by all lanes
-			const CtFrag tf = s_tf[fi];
-			const uint32_t t1 = single ? proc_end : tf.start + tf.na;
-			const AlAnchor *src = anchors + tf.aoff + pos; AlAnchor *dst = chained + tf.aoff + pos;
-			for (uint32_t t = tf.start + tid; t < t1; t += CT_NT) { const uint32_t s = rlo[2 * t + 1]; if (s != 0xffffffffu) dst[t - tf.start] = src[s - tf.start]; }
+		CT_PROF(4);
+		{   // the chained anchors, by all lanes: every thread's (up to four) loads in flight together, then its stores
+			const uint32_t t1 = single ? proc_end : s_tf[nfr - 1].start + s_tf[nfr - 1].na;
+			AlAnchor v[CT_TILE / CT_NT]; uint64_t di[CT_TILE / CT_NT]; bool ok[CT_TILE / CT_NT];
+#pragma unroll
+			for (int j = 0; j < CT_TILE / CT_NT; ++j) {
+				const uint32_t t = (uint32_t)j * CT_NT + tid;
+				const uint32_t sr = t < t1 ? rlo[2 * t + 1] : 0xffffffffu;
+				ok[j] = sr != 0xffffffffu;
+				int fi = 0;
+				if (!single) while (fi + 1 < nfr && s_tf[fi + 1].start <= t) ++fi;
+				const uint64_t base = s_tf[fi].aoff + pos; const uint32_t st0 = s_tf[fi].start;
+				di[j] = base + (t - st0);
+				v[j] = anchors[ok[j] ? base + (sr - st0) : s_tf[0].aoff];          // (a place without a chained anchor: any readable anchor, not stored)
+			}
+#pragma unroll
+			for (int j = 0; j < CT_TILE / CT_NT; ++j) if (ok[j]) chained[di[j]] = v[j];
 		}
 		if (single) { u_run += G_of(n_seg); any_def = any_def || n_def != 0; }
 		else if (w == 0 && lane < nfr) {
@@ -437,6 +467,8 @@ k_chain_tile(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ 
 				else if ((tf.flags & 4u) && run > 64) fb_list[atomicAdd(fb_cnt, 1u)] = tf.f;
 			}
 		}
+		CT_PROF(5);
+		if (prof && tid == 0) atomicAdd(&counters[30], 1ULL);
 		if (!more) break;
 		pos = s_misc.next_pos;
 		__syncthreads();

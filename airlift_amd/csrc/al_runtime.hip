@@ -313,7 +313,7 @@ extern "C" int al_batch_upload(al_ctx_t *c, int n_frag, const int *n_segs, const
 	if (c->rd_seq.ensure(words + 1) || c->rd_off.ensure(n_reads + 1) || c->rd_len.ensure(n_reads + 1) || c->frag_first.ensure(n_frag + 1) || c->frag_hash.ensure(n_frag + 1) ||
 	    c->mini_off.ensure(n_reads + 1) || c->mini.ensure(mtot + 1) || c->mini_cnt.ensure(n_reads + 1) || c->match.ensure(mtot + 1) || c->heap_ws.ensure(mtot + 1) ||
 	    c->frag_nm.ensure(n_frag + 1) || c->frag_na.ensure(n_frag + 1) || c->frag_rep.ensure(n_frag + 1) || c->frag_nu.ensure(n_frag + 1) || c->a_off.ensure(n_frag + 2) ||
-	    c->rechain_list.ensure(n_frag + 1) || c->tmp_u32.ensure(n_frag + 2) || c->tmp_u64.ensure(n_frag + 2) || c->counters.ensure(24)) return -1;
+	    c->rechain_list.ensure(n_frag + 1) || c->tmp_u32.ensure(n_frag + 2) || c->tmp_u64.ensure(n_frag + 2) || c->counters.ensure(32)) return -1;
 	AL_HIP_CHECK(hipMemcpyAsync(c->rd_seq.p, c->h_rd_seq.data(), (words + 1) * 4, hipMemcpyHostToDevice, s));
 	AL_HIP_CHECK(hipMemcpyAsync(c->rd_off.p, c->h_rd_off.data(), (n_reads + 1) * 8, hipMemcpyHostToDevice, s));
 	AL_HIP_CHECK(hipMemcpyAsync(c->rd_len.p, c->h_rd_len.data(), (n_reads + 1) * 4, hipMemcpyHostToDevice, s));
@@ -854,7 +854,7 @@ int al_run_seed_stages(al_ctx_t *c)
 {
 	hipStream_t s = c->stream;
 	AL_HIP_CHECK(hipSetDevice(c->device));
-	AL_HIP_CHECK(hipMemsetAsync(c->counters.p, 0, 16 * sizeof(unsigned long long), s));
+	AL_HIP_CHECK(hipMemsetAsync(c->counters.p, 0, 32 * sizeof(unsigned long long), s));
 	AL_HIP_CHECK(hipEventRecord(c->ev[0], s));
 	const int nr = c->n_reads, w = c->mi->w, k = c->mi->k;
 	if (nr > 0) hipLaunchKernelGGL(k_sketch, dim3((nr + 63) / 64), dim3(64), (size_t)w * 64 * 8, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, c->mini_off.p, c->mini.p, c->mini_cnt.p, nr, w, k, al_sketch_pos_bits(k));
@@ -926,6 +926,8 @@ extern "C" int al_batch_run(al_ctx_t *c)
 	{ static const bool guard = getenv("AL_TEST_GUARD") != nullptr; if (guard && al_dev_guard_check()) fprintf(stderr, "[airlift] GUARD: violations after al_batch_run\n"); }
 	// counters + algorithmic bytes
 	unsigned long long h[16]; AL_HIP_CHECK(hipMemcpy(h, c->counters.p, sizeof(h), hipMemcpyDeviceToHost));
+	if ((c->P.dbg >> 24) & 1) { unsigned long long t[8]; AL_HIP_CHECK(hipMemcpy(t, c->counters.p + 24, sizeof(t), hipMemcpyDeviceToHost));
+		fprintf(stderr, "[airlift] tile kernel profile (cycles of thread 0, all blocks, both passes): setup %llu load %llu cut %llu dp %llu emit %llu copy %llu; tiles %llu\n", t[0], t[1], t[2], t[3], t[4], t[5], t[6]); }
 	if (getenv("AL_TRACE")) { fprintf(stderr, "[airlift] trace: counters"); for (int i = 0; i < 16; ++i) fprintf(stderr, " [%d]=%llu", i, h[i]); fprintf(stderr, " rechain=%u\n", c->n_rechain); }
 	al_batch_stat_t &st = c->stat; memset(&st, 0, sizeof(st));
 	st.n_frag = c->n_frag; st.n_reads = c->n_reads; st.n_bases = c->n_bases;
@@ -1175,7 +1177,7 @@ extern "C" int al_batch_upload_windows(al_ctx_t *c, const al_winsrc_t *src, int 
 	if (c->rd_seq.ensure(words + 1) || c->rd_off.ensure(n_reads + 1) || c->rd_len.ensure(n_reads + 1) || c->frag_first.ensure(n_frag + 1) || c->frag_hash.ensure(n_frag + 1) ||
 	    c->mini_off.ensure(n_reads + 1) || c->mini.ensure(mtot + 1) || c->mini_cnt.ensure(n_reads + 1) || c->match.ensure(mtot + 1) || c->heap_ws.ensure(mtot + 1) ||
 	    c->frag_nm.ensure(n_frag + 1) || c->frag_na.ensure(n_frag + 1) || c->frag_rep.ensure(n_frag + 1) || c->frag_nu.ensure(n_frag + 1) || c->a_off.ensure(n_frag + 2) ||
-	    c->rechain_list.ensure(n_frag + 1) || c->tmp_u32.ensure(n_frag + 2) || c->tmp_u64.ensure(n_frag + 2) || c->counters.ensure(24) || c->tmp_u64b.ensure(n_tok + 1)) return -1;
+	    c->rechain_list.ensure(n_frag + 1) || c->tmp_u32.ensure(n_frag + 2) || c->tmp_u64.ensure(n_frag + 2) || c->counters.ensure(32) || c->tmp_u64b.ensure(n_tok + 1)) return -1;
 	AL_HIP_CHECK(hipMemcpyAsync(c->tmp_u64b.p, start, (size_t)n_tok * 8, hipMemcpyHostToDevice, s));
 	if (words) hipLaunchKernelGGL(k_make_windows, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s, src->S4, c->tmp_u64b.p, n_tok, read_len, wpr, c->rd_seq.p);
 	AL_HIP_CHECK(hipMemsetAsync(c->rd_seq.p + words, 0, 4, s));

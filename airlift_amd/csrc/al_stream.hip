@@ -454,7 +454,7 @@ int al_stream_setup(AlStreamSlot &S, al_ctx_t *c, uint32_t rec_lo, uint32_t rec_
 	if (S.rtxt.ensure((size_t)n_reads + 1) || S.rd_info.ensure((size_t)n_reads + 1) || S.rd_frag.ensure((size_t)n_reads + 1) || S.rd_words.ensure((size_t)n_reads + 2) || S.rd_mcnt.ensure((size_t)n_reads + 2)) return -1;
 	if (c->rd_off.ensure(n_reads + 2) || c->rd_len.ensure(n_reads + 2) || c->frag_first.ensure(n_frag + 2) || c->frag_hash.ensure(n_frag + 2) || c->mini_off.ensure(n_reads + 2) || c->mini_cnt.ensure(n_reads + 1) ||
 	    c->frag_nm.ensure(n_frag + 1) || c->frag_na.ensure(n_frag + 1) || c->frag_rep.ensure(n_frag + 1) || c->frag_nu.ensure(n_frag + 1) || c->a_off.ensure(n_frag + 2) ||
-	    c->rechain_list.ensure(n_frag + 1) || c->tmp_u32.ensure(n_frag + 2) || c->tmp_u64.ensure(n_frag + 2) || c->counters.ensure(24)) return -1;
+	    c->rechain_list.ensure(n_frag + 1) || c->tmp_u32.ensure(n_frag + 2) || c->tmp_u64.ensure(n_frag + 2) || c->counters.ensure(32)) return -1;
 	SetupOut O{S.rtxt.p, S.rd_info.p, S.rd_frag.p, c->rd_len.p, S.rd_words.p, S.rd_mcnt.p, c->frag_first.p, c->frag_hash.p, S.st.p};
 	AL_HIP_CHECK(hipMemsetAsync(S.st.p + 4, 0, 4 * 8, s));
 	if (S.n_files == 2) hipLaunchKernelGGL(k_setup_pe, dim3((unsigned)((n_frag + 256) / 256)), dim3(256), 0, s, S.txt[0].p, S.frec[0].p + rec_lo, S.frec[1].p + rec_lo, (uint32_t)n_frag, O, k, c->opt.seed, c->opt.pe_ori);
