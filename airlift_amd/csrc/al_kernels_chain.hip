@@ -105,7 +105,7 @@ __device__ __forceinline__ uint32_t ct_defer_class(uint32_t n) { return n <= 16 
 
 __global__ void __launch_bounds__(CT_NT)
 k_chain_tile(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_off, const uint32_t *__restrict__ frag_na,
-             const uint32_t *__restrict__ frag_first, const uint32_t *__restrict__ rd_len, const uint32_t *__restrict__ list, const TileSched S,
+             const uint32_t *__restrict__ frag_meta /* per fragment: qlen_sum | paired << 31 (k_frag_meta) */, const uint32_t *__restrict__ list, const TileSched S,
              const uint32_t *__restrict__ skip_flag, AlAnchor *__restrict__ chained, uint64_t *__restrict__ u_out, uint32_t *__restrict__ uo_out,
              uint32_t *__restrict__ frag_nu, uint32_t *__restrict__ fb_list, uint32_t *__restrict__ fb_cnt, const AlParams P, const int lmin,
              unsigned long long *__restrict__ counters, const int force_fb /* tests: every fragment is handed back */, const CtDefer D)
@@ -143,20 +143,22 @@ k_chain_tile(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ 
 	if (w == 0) {
 		const bool mine = lane < nfr;
 		const uint32_t f = mine ? list[e0 + lane] : 0u;
-		const bool skipped = mine && skip_flag && skip_flag[f] != 0;
-		const uint32_t na = mine && !skipped ? frag_na[f] : 0u;
+		uint32_t fl = skip_flag ? skip_flag[f] : 0u, na0 = frag_na[f], mt = frag_meta[f];   // (lanes without an entry read fragment 0: harmless, one latency for all)
+		uint64_t ao = a_off[f];
+		asm volatile("" : "+v"(fl), "+v"(na0), "+v"(mt), "+v"(ao));
+		const bool skipped = fl != 0;
+		const uint32_t na = mine && !skipped ? na0 : 0u;
 		uint32_t incl = na;                                                     // rows of the fragments in front of this one
 		for (int d = 1; d < 32; d <<= 1) { const uint32_t o = __shfl_up(incl, d); if (lane >= d) incl += o; }
 		if (mine) {
-			const uint32_t r0 = frag_first[f], r1 = frag_first[f + 1];
-			int qlen_sum = 0; for (uint32_t r = r0; r < r1; ++r) qlen_sum += (int)rd_len[r];
+			const int qlen_sum = (int)(mt & 0x7fffffffu);
 			const int mdy = qlen_sum > P.max_gap ? qlen_sum : P.max_gap;               // map.c:341-351
 			int mdx;
 			if (P.max_gap_ref > 0) mdx = P.max_gap_ref;
 			else if (P.max_frag_len > 0) { mdx = P.max_frag_len - qlen_sum; if (mdx < P.max_gap) mdx = P.max_gap; }
 			else mdx = P.max_gap;
-			CtFrag t; t.aoff = a_off[f]; t.f = f; t.na = na; t.mdx = mdx; t.mdy = mdy; t.drlim = r1 - r0 > 1 ? (uint32_t)mdy : 0x7fffffffu; t.flags = skipped ? 1u : 0u;
-			t.meta = (uint32_t)qlen_sum | (r1 - r0 > 1 ? 1u << 31 : 0u);
+			CtFrag t; t.aoff = ao; t.f = f; t.na = na; t.mdx = mdx; t.mdy = mdy; t.drlim = (mt >> 31) ? (uint32_t)mdy : 0x7fffffffu; t.flags = skipped ? 1u : 0u;
+			t.meta = mt;
 			t.start = incl - na;
 			s_tf[lane] = t;
 		}
@@ -190,6 +192,9 @@ k_chain_tile(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ 
 					if (i > 0) xp[j] = src[i - 1].x;
 				}
 			}
+			// (the compiler would sink every load to its use -- one memory latency per row instead of one per tile: all loaded values are pinned here)
+			static_assert(CT_TILE / CT_NT == 4, "four rows per thread");
+			asm volatile("" : "+v"(e[0].x), "+v"(e[0].y), "+v"(e[1].x), "+v"(e[1].y), "+v"(e[2].x), "+v"(e[2].y), "+v"(e[3].x), "+v"(e[3].y), "+v"(xp[0]), "+v"(xp[1]), "+v"(xp[2]), "+v"(xp[3]));
 #pragma unroll
 			for (int j = 0; j < CT_TILE / CT_NT; ++j) {
 				const uint32_t r = (uint32_t)j * CT_NT + tid;
@@ -452,6 +457,7 @@ k_chain_tile(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ 
 				di[j] = base + (t - st0);
 				v[j] = anchors[ok[j] ? base + (sr - st0) : s_tf[0].aoff];          // (a place without a chained anchor: any readable anchor, not stored)
 			}
+			asm volatile("" : "+v"(v[0].x), "+v"(v[0].y), "+v"(v[1].x), "+v"(v[1].y), "+v"(v[2].x), "+v"(v[2].y), "+v"(v[3].x), "+v"(v[3].y));
 #pragma unroll
 			for (int j = 0; j < CT_TILE / CT_NT; ++j) if (ok[j]) chained[di[j]] = v[j];
 		}
@@ -583,4 +589,15 @@ k_fb_copy_out(const uint32_t *__restrict__ fb_list, int n_fb, const uint64_t *__
 	const AlAnchor *sc = v_chained + v_a_off[v]; AlAnchor *dc = chained + a_off[f];
 	for (uint32_t t = lane; t < run; t += 64) dc[t] = sc[t];
 	if (lane == 0) frag_nu[f] = n_u;
+}
+
+// per fragment: qlen_sum | paired << 31 (what the chaining kernels derive max_dist_x / max_dist_y from, map.c:341-351)
+__global__ void __launch_bounds__(256)
+k_frag_meta(const uint32_t *__restrict__ frag_first, const uint32_t *__restrict__ rd_len, int n_frag, uint32_t *__restrict__ meta)
+{
+	const int f = blockIdx.x * blockDim.x + threadIdx.x;
+	if (f >= n_frag) return;
+	const uint32_t r0 = frag_first[f], r1 = frag_first[f + 1];
+	uint32_t q = 0; for (uint32_t r = r0; r < r1; ++r) q += rd_len[r];
+	meta[f] = q | (r1 - r0 > 1 ? 1u << 31 : 0u);
 }

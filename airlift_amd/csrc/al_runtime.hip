@@ -25,7 +25,8 @@ extern "C" __global__ void k_rechain_test(const AlAnchor *, const uint64_t *, co
 // al_kernels_chain.hip
 struct TileSched { uint32_t n_items; uint32_t ent[7]; uint32_t item[7]; };
 struct CtDefer { uint64_t *off, *uslot; uint32_t *na, *meta, *rel, *fragid, *cls; uint32_t *cnt; uint32_t cap; uint32_t *cmp_list, *cmp_cnt; uint32_t *ctie; };
-__global__ void k_chain_tile(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *, const TileSched, const uint32_t *, AlAnchor *, uint64_t *, uint32_t *, uint32_t *, uint32_t *, uint32_t *, const AlParams, const int, unsigned long long *, const int, const CtDefer);
+__global__ void k_frag_meta(const uint32_t *, const uint32_t *, int, uint32_t *);
+__global__ void k_chain_tile(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, const TileSched, const uint32_t *, AlAnchor *, uint64_t *, uint32_t *, uint32_t *, uint32_t *, uint32_t *, const AlParams, const int, unsigned long long *, const int, const CtDefer);
 __global__ void k_u_compact(const uint32_t *, const uint32_t *, const uint64_t *, uint32_t *, uint64_t *, uint32_t *, const uint32_t *, uint32_t *, uint32_t *);
 __global__ void k_uo_fill(const uint32_t *, int, const uint64_t *, const uint32_t *, const uint64_t *, uint32_t *, const uint32_t *);
 __global__ void k_fb_meta(const uint32_t *, int, const uint32_t *, const uint32_t *, uint32_t *, uint32_t *);
@@ -228,7 +229,7 @@ static void ctx_release_buffers(al_ctx_t *c)
 	c->chained.release(); c->match.release(); c->counters.release(); c->scan_tmp.release(); c->regs0.release(); c->regs.release(); c->reg_cnt.release();
 	c->chain_key.release(); c->chain_idx.release(); c->chain_idx2.release(); c->tie_list.release(); c->lb_buf.release(); c->tmp_u64b.release();
 	c->chain_tmp.release(); c->u_tmp.release(); c->okey_tmp.release(); c->fb2_list.release(); c->fb3_list.release(); c->seg_cnt.release(); c->seg_first.release(); c->seg_cnt0.release(); c->seg_first0.release(); c->seg_t1.release(); c->vs_off.release(); c->vs_na.release(); c->vs_meta.release(); c->vs_res.release(); c->vs_cls.release(); c->seg_key.release(); c->seg_idx.release(); c->seg_ord.release(); c->fb_list.release(); c->tie_frags.release(); c->heap_cnt.release(); c->tie_sorted.release(); c->big_na.release(); c->big_off.release();
-	c->uo.release(); c->big_k0.release(); c->big_k1.release(); c->v_anchors.release(); c->v_chained.release(); c->v_u.release(); c->v_a_off.release(); c->v_first64.release(); c->v_na.release(); c->v_nseg.release(); c->v_first.release(); c->v_rd_len.release(); c->v_order.release(); c->v_nu.release(); c->fbk_list.release(); c->d_uslot.release(); c->d_rel.release(); c->d_fragid.release(); c->cmp_list.release(); c->ctie.release();
+	c->uo.release(); c->big_k0.release(); c->big_k1.release(); c->v_anchors.release(); c->v_chained.release(); c->v_u.release(); c->v_a_off.release(); c->v_first64.release(); c->v_na.release(); c->v_nseg.release(); c->v_first.release(); c->v_rd_len.release(); c->v_order.release(); c->v_nu.release(); c->fbk_list.release(); c->d_uslot.release(); c->d_rel.release(); c->d_fragid.release(); c->cmp_list.release(); c->ctie.release(); c->frag_meta.release();
 	c->a_off_p1.release(); c->frag_na_p1.release(); c->frag_rep_p1.release(); c->cigar.release(); c->reg_off.release(); c->cig_off.release(); c->align_ws.release(); c->seg_a.release(); c->seg_u.release();
 }
 extern "C" void al_ctx_destroy(al_ctx_t *c)
@@ -578,7 +579,7 @@ static int chain_tiles(al_ctx_t *c, const uint32_t *list, const TileSched &S, co
 		AL_HIP_CHECK(hipMemsetAsync(c->ctie.p, 0, ((size_t)c->n_frag + 1) * 4, s));
 		CtDefer D; D.off = c->vs_off.p; D.uslot = c->d_uslot.p; D.na = c->vs_na.p; D.meta = c->vs_meta.p; D.rel = c->d_rel.p; D.fragid = c->d_fragid.p; D.cls = c->vs_cls.p; D.cnt = cnts + 1; D.cap = (uint32_t)cap;
 		D.cmp_list = c->cmp_list.p; D.cmp_cnt = cnts + 2; D.ctie = c->ctie.p;
-		hipLaunchKernelGGL(k_chain_tile, dim3(S.n_items), dim3(256), 0, s, c->anchors.p, c->a_off.p, c->frag_na.p, c->frag_first.p, c->rd_len.p, list, S, skip_flag,
+		hipLaunchKernelGGL(k_chain_tile, dim3(S.n_items), dim3(256), 0, s, c->anchors.p, c->a_off.p, c->frag_na.p, c->frag_meta.p, list, S, skip_flag,
 		                   c->chained.p, c->u.p, c->uo.p, c->frag_nu.p, c->fb_list.p, cnts, c->P, lmin, c->counters.p, force_fb, D);
 		if (ev(ST_SEG_FIND)) return -1;
 		{ static const bool tr = getenv("AL_TRACE") != nullptr; if (tr) { const hipError_t e = hipStreamSynchronize(s); fprintf(stderr, "[airlift] trace: tile kernel (%u items, first pass %d) -> %s\n", S.n_items, (int)first, hipGetErrorName(e)); } }
@@ -860,6 +861,8 @@ int al_run_seed_stages(al_ctx_t *c)
 	if (nr > 0) hipLaunchKernelGGL(k_sketch, dim3((nr + 63) / 64), dim3(64), (size_t)w * 64 * 8, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, c->mini_off.p, c->mini.p, c->mini_cnt.p, nr, w, k, al_sketch_pos_bits(k));
 	AL_HIP_CHECK(hipEventRecord(c->ev[ST_SKETCH + 1], s));
 	if (c->n_frag == 0) { for (int i = ST_SEED; i < ST_N; ++i) AL_HIP_CHECK(hipEventRecord(c->ev[i + 1], s)); return 0; }
+	if (c->frag_meta.ensure((size_t)c->n_frag + 1)) return -1;
+	hipLaunchKernelGGL(k_frag_meta, dim3((c->n_frag + 255) / 256), dim3(256), 0, s, c->frag_first.p, c->rd_len.p, c->n_frag, c->frag_meta.p);
 	if (run_seed_chain(c, nullptr, c->n_frag, c->opt.mid_occ, 0, true)) return -1;
 	// re-chain with max_occ for fragments whose best chain misses a mate (map.c:353-375)
 	c->n_rechain = 0;
