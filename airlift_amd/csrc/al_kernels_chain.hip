@@ -103,6 +103,11 @@ struct CtDefer {                         // the deferred segments (ChainSeg dire
 };
 __device__ __forceinline__ uint32_t ct_defer_class(uint32_t n) { return n <= 16 ? 0u : n <= 24 ? 1u : n <= 32 ? 2u : n <= 40 ? 3u : n <= 48 ? 4u : n <= 64 ? 5u : n <= 80 ? 6u : n <= 96 ? 7u : 8u; }
 
+// Barrier of the tile kernel: the steps hand rows over through LDS only, so a wavefront waits for ITS LDS operations and the barrier -- not, as
+// __syncthreads() does on this target, for every global store it has in flight (chain list entries, chained anchors: microseconds each when the
+// page is not in the TLB).
+__device__ __forceinline__ void ct_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier\n\ts_waitcnt lgkmcnt(0)" ::: "memory"); }
+
 __global__ void __launch_bounds__(CT_NT)
 k_chain_tile(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_off, const uint32_t *__restrict__ frag_na,
              const uint32_t *__restrict__ frag_meta /* per fragment: qlen_sum | paired << 31 (k_frag_meta) */, const uint32_t *__restrict__ list, const TileSched S,
@@ -163,7 +168,7 @@ k_chain_tile(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ 
 			s_tf[lane] = t;
 		}
 	}
-	__syncthreads();
+	ct_sync();
 	const bool single = nfr == 1;
 	if (!single) {                                                              // (the size classes guarantee the fit; a caller's mistake must not be silent)
 		const CtFrag &tl = s_tf[nfr - 1];
@@ -208,7 +213,7 @@ k_chain_tile(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ 
 				}
 			}
 		}
-		__syncthreads();
+		ct_sync();
 		CT_PROF(1);
 		// ---- cut: segment list in tile order; the segments chained here ordered by size class (one wavefront walks the cut flags) ----
 		if (w == 0) {
@@ -278,7 +283,7 @@ k_chain_tile(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ 
 				s_misc = m;
 			}
 		}
-		__syncthreads();
+		ct_sync();
 		CT_PROF(2);
 		const uint32_t n_seg = s_misc.n_seg, n_inl = s_misc.n_inl, proc_end = s_misc.proc_end, n_def = s_misc.n_def;
 		const bool more = s_misc.more != 0;
@@ -384,7 +389,7 @@ k_chain_tile(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ 
 #undef F_
 #undef P_
 		}
-		__syncthreads();
+		ct_sync();
 		CT_PROF(3);
 		// ---- emit: chain list entries in tile order at the fragment's running offset; chained anchors at the segment's own place ----
 		for (uint32_t t = tid; t < proc_end; t += CT_NT) rlo[2 * t + 1] = 0xffffffffu;   // f / p are dead: the half becomes "source row of the chained anchor at this place"
@@ -397,7 +402,7 @@ k_chain_tile(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ 
 			if (k < n_seg) { s_G[k] = (uint16_t)(incl - nu); s_Dn[k] = (uint16_t)(incd - df); }
 			if (lane == 63) { s_ctot[c] = incl; s_dtot[c] = incd; }
 		}
-		__syncthreads();
+		ct_sync();
 		auto G_of = [&](uint32_t k) -> uint32_t {                                        // ... and in the tile (k == n_seg: all of them)
 			uint32_t g = 0; const uint32_t cc = k >> 6;
 			for (uint32_t c = 0; c < cc; ++c) g += s_ctot[c];
@@ -409,7 +414,7 @@ k_chain_tile(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ 
 			return k < n_seg ? g + s_Dn[k] : ((k & 63) ? g + s_dtot[cc] : g);
 		};
 		if (tid == 0) s_misc.def_base = def_base_r;
-		__syncthreads();
+		ct_sync();
 		const uint32_t def_base = s_misc.def_base;
 		const bool def_ok = n_def == 0 || def_base + n_def <= D.cap;
 		if (!def_ok && tid == 0) atomicAdd(&counters[7], 1ULL << 52);                     // (the list is sized for every possible deferred segment: a caller's mistake must not be silent)
@@ -441,7 +446,7 @@ k_chain_tile(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ 
 				o += cnt;
 			}
 		}
-		__syncthreads();
+		ct_sync();
 		CT_PROF(4);
 		{   // the chained anchors, by all lanes: every thread's (up to four) loads in flight together, then its stores
 			const uint32_t t1 = single ? proc_end : s_tf[nfr - 1].start + s_tf[nfr - 1].na;
@@ -477,7 +482,7 @@ k_chain_tile(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ 
 		if (prof && tid == 0) atomicAdd(&counters[30], 1ULL);
 		if (!more) break;
 		pos = s_misc.next_pos;
-		__syncthreads();
+		ct_sync();
 	}
 	if (single && tid == 0) {
 		const CtFrag &tf = s_tf[0];

@@ -86,7 +86,7 @@ struct al_ctx_s {
 	DevBuf<uint64_t> big_k0, big_k1;       // key double buffer of the device-wide anchor sort (fragments above the register tiles)
 	// compact copy of the fragments the tile chaining kernel hands back (al_runtime.hip: chain_fallback): a small virtual batch for the segment-wise kernels
 	DevBuf<AlAnchor> v_anchors, v_chained; DevBuf<uint64_t> v_u, v_a_off, v_first64; DevBuf<uint32_t> v_na, v_nseg, v_first, v_rd_len, v_order, v_nu, fbk_list;
-	DevBuf<uint64_t> d_uslot; DevBuf<uint32_t> d_rel, d_fragid, cmp_list, ctie, frag_meta;   // deferred segments of the tile kernel (ChainSeg direct mode), fragments whose chain lists have gaps, per-fragment tie flags
+	DevBuf<uint64_t> d_uslot; DevBuf<uint32_t> d_rel, d_fragid, cmp_list, ctie, frag_meta, chain_cls;   // deferred segments of the tile kernel (ChainSeg direct mode), fragments whose chain lists have gaps, per-fragment tie flags
 	DevBuf<int32_t> frag_rep, ws_i32;
 	DevBuf<AlAnchor> mini, heap_ws, anchors, chained;
 	DevBuf<AlMatch> match;

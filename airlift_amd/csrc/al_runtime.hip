@@ -229,7 +229,7 @@ static void ctx_release_buffers(al_ctx_t *c)
 	c->chained.release(); c->match.release(); c->counters.release(); c->scan_tmp.release(); c->regs0.release(); c->regs.release(); c->reg_cnt.release();
 	c->chain_key.release(); c->chain_idx.release(); c->chain_idx2.release(); c->tie_list.release(); c->lb_buf.release(); c->tmp_u64b.release();
 	c->chain_tmp.release(); c->u_tmp.release(); c->okey_tmp.release(); c->fb2_list.release(); c->fb3_list.release(); c->seg_cnt.release(); c->seg_first.release(); c->seg_cnt0.release(); c->seg_first0.release(); c->seg_t1.release(); c->vs_off.release(); c->vs_na.release(); c->vs_meta.release(); c->vs_res.release(); c->vs_cls.release(); c->seg_key.release(); c->seg_idx.release(); c->seg_ord.release(); c->fb_list.release(); c->tie_frags.release(); c->heap_cnt.release(); c->tie_sorted.release(); c->big_na.release(); c->big_off.release();
-	c->uo.release(); c->big_k0.release(); c->big_k1.release(); c->v_anchors.release(); c->v_chained.release(); c->v_u.release(); c->v_a_off.release(); c->v_first64.release(); c->v_na.release(); c->v_nseg.release(); c->v_first.release(); c->v_rd_len.release(); c->v_order.release(); c->v_nu.release(); c->fbk_list.release(); c->d_uslot.release(); c->d_rel.release(); c->d_fragid.release(); c->cmp_list.release(); c->ctie.release(); c->frag_meta.release();
+	c->uo.release(); c->big_k0.release(); c->big_k1.release(); c->v_anchors.release(); c->v_chained.release(); c->v_u.release(); c->v_a_off.release(); c->v_first64.release(); c->v_na.release(); c->v_nseg.release(); c->v_first.release(); c->v_rd_len.release(); c->v_order.release(); c->v_nu.release(); c->fbk_list.release(); c->d_uslot.release(); c->d_rel.release(); c->chain_cls.release(); c->d_fragid.release(); c->cmp_list.release(); c->ctie.release(); c->frag_meta.release();
 	c->a_off_p1.release(); c->frag_na_p1.release(); c->frag_rep_p1.release(); c->cigar.release(); c->reg_off.release(); c->cig_off.release(); c->align_ws.release(); c->seg_a.release(); c->seg_u.release();
 }
 extern "C" void al_ctx_destroy(al_ctx_t *c)
@@ -338,6 +338,15 @@ static int scan_u32_to_u64(al_ctx_t *c, const uint32_t *in, uint64_t *out, int n
 	return 0;
 }
 
+struct SizeThr { uint32_t v[28]; int n; };
+__global__ void k_size_class(const uint32_t *__restrict__ na, int n, SizeThr T, uint32_t *__restrict__ cls)
+{   // class of a fragment = number of thresholds <= its anchor count
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const uint32_t v = na[i]; uint32_t k = 0;
+	for (int j = 0; j < T.n; ++j) k += T.v[j] <= v ? 1u : 0u;
+	cls[i] = k;
+}
 __global__ void k_iota_u32(uint32_t *a, uint32_t n) { const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) a[i] = i; }
 __global__ void k_flag_list(const uint32_t *list, int n, uint32_t *flag)
 {
@@ -674,8 +683,10 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 	const int mdx = std::max(std::max(c->opt.max_gap_ref, c->opt.max_frag_len), c->opt.max_gap);
 	const bool lds_ok = mdx <= 0x7fff && c->opt.max_chain_iter >= 128 && !((c->P.dbg >> 27) & 1) && c->max_qlen_sum <= 0xfff;   // 12-bit query positions in the compact rows
 	if (first) hipLaunchKernelGGL(k_iota_u32, dim3((nl + 255) / 256), dim3(256), 0, s, c->chain_idx.p, (uint32_t)nl);
-	if (sort_u32_pairs(c, first ? c->frag_na.p : c->tmp_u32.p, c->chain_key.p, first ? c->chain_idx.p : list, c->chain_idx2.p, nl)) return -1;
-	const uint32_t *order = c->chain_idx2.p;
+	// The list by SIZE CLASS, not by exact count: the class boundaries are all the kernels below ask for, and inside a class the fragments stay in
+	// memory order (the sort is stable) -- the blocks that run side by side then work on neighbouring ranges of the anchor arrays instead of
+	// ranges scattered over tens of gigabytes (a TLB miss per tile cost the tile kernel a third of its time), and the lanes of the lane-per-fragment
+	// kernels read neighbouring fragments.  One 5-bit radix pass instead of four 8-bit ones.
 	uint32_t lb[15];
 	{   // AL_TEST_SORT_BLK / AL_TEST_SORT_BIG (tests): smallest anchor count that goes to the block / device-wide sort
 		static const char *e1 = getenv("AL_TEST_SORT_BLK"), *e2 = getenv("AL_TEST_SORT_BIG");
@@ -684,8 +695,23 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 		{ int rb = 1; while ((1ULL << rb) < c->mi->seq.size()) ++rb; if (33 + rb + 16 > 64) t_big = t_blk; }   // compact keys of the block sort: strand | contig | position | list in 64 bits
 		const uint32_t thr[15] = {65, 81, 97, 129, t_blk, t_big, std::min(std::max(t_blk, 2049u), t_big), std::min(std::max(t_blk, 4097u), t_big), std::min(std::max(t_blk, 8193u), t_big),
 		                          std::min(257u, t_blk), std::min(513u, t_blk), 1, 33, 257, 513};
-		if (lower_bounds(c, c->chain_key.p, (uint32_t)nl, thr, 15, lb)) return -1;
+		std::vector<uint32_t> T(thr, thr + 15);
+		for (uint32_t t : {17u, 25u, 41u, 49u, 1025u, 2049u, 4097u, 8193u}) T.push_back(t);   // the lane kernels' row sizes; the large classes, so that the heaviest items start first
+		std::sort(T.begin(), T.end()); T.erase(std::unique(T.begin(), T.end()), T.end());
+		SizeThr ST; ST.n = (int)T.size();
+		if (ST.n > 28) { fprintf(stderr, "[airlift] internal: too many size classes\n"); return -1; }
+		for (int i = 0; i < 28; ++i) ST.v[i] = i < ST.n ? T[i] : 0xffffffffu;
+		if (c->chain_cls.ensure((size_t)nl + 1)) return -1;
+		hipLaunchKernelGGL(k_size_class, dim3((nl + 255) / 256), dim3(256), 0, s, first ? (const uint32_t *)c->frag_na.p : (const uint32_t *)c->tmp_u32.p, nl, ST, c->chain_cls.p);
+		size_t bytes = 0;
+		AL_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, bytes, (const uint32_t *)c->chain_cls.p, c->chain_key.p, first ? (const uint32_t *)c->chain_idx.p : list, c->chain_idx2.p, nl, 0, 5, s));
+		if (c->scan_tmp.ensure(bytes + 16)) return -1;
+		AL_HIP_CHECK(rocprim::radix_sort_pairs(c->scan_tmp.p, bytes, (const uint32_t *)c->chain_cls.p, c->chain_key.p, first ? (const uint32_t *)c->chain_idx.p : list, c->chain_idx2.p, nl, 0, 5, s));
+		uint32_t thr_cls[15];                                                 // count >= thr[k]  <=>  class >= (rank of thr[k] among the thresholds) + 1
+		for (int k = 0; k < 15; ++k) thr_cls[k] = (uint32_t)(std::lower_bound(T.begin(), T.end(), thr[k]) - T.begin()) + 1u;
+		if (lower_bounds(c, c->chain_key.p, (uint32_t)nl, thr_cls, 15, lb)) return -1;
 	}
+	const uint32_t *order = c->chain_idx2.p;
 	const uint32_t lb1 = lb[11], lb33 = lb[12], lb257x = lb[13], lb513x = lb[14];
 	const uint32_t lb65 = lb[0], lb81 = lb[1], lb97 = lb[2], lb129 = lb[3], lb1025 = lb[4], lb_big = lb[5], lb2049 = lb[6], lb4097 = lb[7], lb8193 = lb[8], lb257 = lb[9], lb513 = lb[10];
 	// Fragments of more than 128 anchors: the tile kernel (al_kernels_chain.hip).  Its compact rows need what the lane kernels need, and a
