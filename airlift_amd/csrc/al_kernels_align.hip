@@ -2340,7 +2340,7 @@ int al_run_align_stage(al_ctx_t *c)
 	AL_HIP_CHECK(hipMemcpyAsync(&nu_total, A->nu_off.p + nf, 8, hipMemcpyDeviceToHost, s));
 	AL_HIP_CHECK(hipStreamSynchronize(s));
 	const uint64_t Btot = 4 * nu_total + 4ULL * nf + 8;
-	if (c->seg_a.ensure(c->n_anchor_total + 1) || A->regs0.ensure(nu_total + 1) || A->aux128.ensure(Btot) || A->aux64.ensure(Btot) || A->auxi.ensure(2 * Btot) ||
+	if ((!c->no_taps && c->seg_a.ensure(c->n_anchor_total + 1)) || A->regs0.ensure(nu_total + 1) || A->aux128.ensure(Btot) || A->aux64.ensure(Btot) || A->auxi.ensure(2 * Btot) ||
 	    A->seg_u.ensure(2 * nu_total + 2) || A->reg_cnt.ensure(nr + 1) || A->seg_na.ensure(nr + 1) || A->out_off.ensure(nr + 2) || A->seg_fast.ensure(nr + 1) || A->cap2.ensure(nf + 2) || A->b2_off.ensure(nf + 2)) return -1;
 	{   // AL_TEST_SCRUB=<byte> (tests): the stage's work areas -- and the chaining scratch it reuses -- filled with that byte first: a result
 		// that depends on what an earlier stage or batch left there shows up as a difference between two byte values
@@ -2349,12 +2349,12 @@ int al_run_align_stage(al_ctx_t *c)
 			const int v = atoi(scrub);
 			AL_HIP_CHECK(hipMemsetAsync(A->regs0.p, v, A->regs0.cap * sizeof(AlReg), s)); AL_HIP_CHECK(hipMemsetAsync(A->aux128.p, v, A->aux128.cap * sizeof(AlAnchor), s));
 			AL_HIP_CHECK(hipMemsetAsync(A->aux64.p, v, A->aux64.cap * 8, s)); AL_HIP_CHECK(hipMemsetAsync(A->auxi.p, v, A->auxi.cap * 4, s)); AL_HIP_CHECK(hipMemsetAsync(A->seg_u.p, v, A->seg_u.cap * 8, s));
-			AL_HIP_CHECK(hipMemsetAsync(c->seg_a.p, v, c->seg_a.cap * sizeof(AlAnchor), s));
+			if (!c->no_taps) AL_HIP_CHECK(hipMemsetAsync(c->seg_a.p, v, c->seg_a.cap * sizeof(AlAnchor), s));
 			AL_HIP_CHECK(hipMemsetAsync(A->reg_cnt.p, v, A->reg_cnt.cap * 4, s)); AL_HIP_CHECK(hipMemsetAsync(A->seg_na.p, v, A->seg_na.cap * 4, s)); AL_HIP_CHECK(hipMemsetAsync(A->seg_fast.p, v, A->seg_fast.cap * 4, s));
 		}
 	}
 	WsBase W;
-	W.regs0 = A->regs0.p; W.aux128 = A->aux128.p; W.seg_a = c->seg_a.p; W.aux64 = A->aux64.p; W.seg_u = A->seg_u.p; W.auxi = A->auxi.p;
+	W.regs0 = A->regs0.p; W.aux128 = A->aux128.p; W.seg_a = c->no_taps ? c->anchors.p : c->seg_a.p; W.aux64 = A->aux64.p; W.seg_u = A->seg_u.p; W.auxi = A->auxi.p;
 	W.nu_off = A->nu_off.p; W.frag_nu = c->frag_nu.p; W.a_off = c->a_off.p; W.reg_cnt = A->reg_cnt.p; W.seg_na = A->seg_na.p; W.seg_fast = A->seg_fast.p; W.cap2 = nullptr; W.b2_off = nullptr; W.mregs = nullptr; W.rtmp = nullptr; W.rext = nullptr;
 	// fragments with many chains: chain_post by a wavefront each (k_regs_select), by chain-count class
 	uint32_t *regs_n0 = nullptr; uint32_t heavy_from = 0, heavy_n = 0; uint64_t Btot2 = 0;

@@ -101,6 +101,7 @@ struct al_ctx_s {
 	int max_qlen_sum = 0;                 // longest fragment of the resident batch
 	int max_rd_len = 0;                   // longest read of the resident batch
 	bool attr_chain_order = false, attr_regs_heavy = false;   // > 64 KB dynamic-LDS opt-in of two kernels: per device (hipFuncSetAttribute acts on the current device), kept per context
+	bool no_taps = false;                 // the drivers' contexts: nobody reads the sorted anchors after chaining (al_dbg_* taps, candidate counting), so the alignment stage's per-mate anchor arrays take their place (16 bytes per seed hit less)
 	bool dev_batch = false;               // the batch was parsed and packed on the device (al_stream.hip): no host mirrors of the read arrays
 	DevBuf<uint64_t> a_off_p1; DevBuf<uint32_t> frag_na_p1; DevBuf<int32_t> frag_rep_p1;   // pass-1 snapshots when a re-chain pass ran (taps)
 	uint64_t n_anchor_total = 0, n_anchor_pass1 = 0;
@@ -123,6 +124,7 @@ struct al_ctx_s {
 };
 
 int al_upload_index(const al_idx_t *mi, int device, AlDevIndex *out);
+void al_ctx_no_taps(al_ctx_t *c);         // see al_ctx_s::no_taps
 int al_run_align_stage(al_ctx_t *c);      // al_kernels_align.hip: KA (regs) + K5 (extension, MAPQ, pairing)
 int al_fetch_align(al_ctx_t *c, int *n_regs, al_reg1_t **regs, int *rep_len);
 void al_align_grow_arena(al_ctx_t *c);

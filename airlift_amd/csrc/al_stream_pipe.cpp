@@ -166,6 +166,7 @@ int al_stream_map_files(const al_idx_t *mi, int n_fn, const char **fn, const al_
 			mp->ctx = al_ctx_init(mi, opt, devices[l]);
 			al_acct() = nullptr;
 			if (!mp->ctx) { destroy_all(); return -2; }
+			al_ctx_no_taps(mp->ctx);
 			mp->device = mp->ctx->device;                // (a negative device argument means LOCAL_RANK or 0)
 			mappers.push_back(std::move(mp));
 		}
