@@ -147,8 +147,15 @@ int al_stream_map_files(const al_idx_t *mi, int n_fn, const char **fn, const al_
 	for (int i = 0; i < n_fn; ++i) if (!eligible_file(fn[i])) return AL_STREAM_NA;
 	const bool timing = getenv("AL_TIMING") != nullptr, trace = getenv("AL_TRACE") != nullptr;
 	const double T0 = now_s();
-	const int n_slots_lane = std::max(2, std::min(8, getenv("AL_SLOTS") ? atoi(getenv("AL_SLOTS")) : 5));      // text / SAM buffer sets per GPU
-	const int n_ctx_lane = std::max(1, std::min(n_slots_lane, getenv("AL_CTXS") ? atoi(getenv("AL_CTXS")) : 3));  // mapping contexts per GPU
+	// A long input (by its file sizes, ~360 bytes per read) is mapped in batches of up to 2^20 reads on TWO contexts per GPU: since the chaining
+	// scratch went (44 instead of 96 workspace bytes per seed hit: ~70 KB per read on a repeat-rich genome) two such contexts fit next to the
+	// index, a batch of that size runs at the resident rate (the tails inside the launches are amortised), and a third context of that size is what
+	// made the device run short of fast memory (3 x 2^20 reads on C4: 1.7 M reads/s; 2 x 2^20: 7.1 M).  Short inputs keep three contexts and the probes.
+	double est_reads0 = 0;
+	{ struct stat sb; for (int i = 0; i < n_fn; ++i) if (stat(fn[i], &sb) == 0) { const double hi = range->end[i] >= 0 ? (double)range->end[i] : (double)sb.st_size; est_reads0 += std::max(0.0, hi - (double)range->start[i]) / 360.0; } est_reads0 /= (double)n_dev; }
+	const bool long_input = est_reads0 >= 3.0e6;
+	const int n_slots_lane = std::max(2, std::min(8, getenv("AL_SLOTS") ? atoi(getenv("AL_SLOTS")) : long_input ? 4 : 5));      // text / SAM buffer sets per GPU
+	const int n_ctx_lane = std::max(1, std::min(n_slots_lane, getenv("AL_CTXS") ? atoi(getenv("AL_CTXS")) : long_input ? 2 : 3));  // mapping contexts per GPU
 	const int NL = n_dev, NS = NL * n_slots_lane, NM = NL * n_ctx_lane;
 	const size_t PIECE = (size_t)(getenv("AL_PIECE_MB") ? std::max(1, atoi(getenv("AL_PIECE_MB"))) : 8) << 20;
 
@@ -389,7 +396,14 @@ int al_stream_map_files(const al_idx_t *mi, int n_fn, const char **fn, const al_
 					const AlAllocStat &as = al_alloc_stat(); const double ns = (double)as.dev_ns.load(), by = (double)as.dev_bytes.load();
 					probe_mult = getenv("AL_PROBE_MULT") ? std::max(1, atoi(getenv("AL_PROBE_MULT"))) : est0 >= 6.0e6 && ns > 0 && by / (ns * 1e-9) >= 100e9 ? 8 : 4;
 					single_probe = true;
-					max_reads = (int)std::max<int64_t>(2, std::min<int64_t>((int64_t)probe_mult * probe_reads, k_bases / 64));
+					int64_t first = (int64_t)probe_mult * probe_reads;
+					if (long_input && !getenv("AL_PROBE_MULT")) {   // at least three batches per context, at most 2^20 reads, within 60 % of the free memory at ~80 KB per read
+						size_t free_b = 0, total_b = 0;
+						double b = std::min(1048576.0, std::max(262144.0, est0 / (3.0 * n_ctx_lane)));
+						if (hipSetDevice(mappers[0]->device) == hipSuccess && hipMemGetInfo(&free_b, &total_b) == hipSuccess) b = std::min(b, 0.6 * (double)free_b / ((double)n_ctx_lane * 81920.0));
+						first = std::max<int64_t>(first, (int64_t)b);
+					}
+					max_reads = (int)std::max<int64_t>(2, std::min<int64_t>(first, k_bases / 64));
 				}
 			}
 			if (k == 1 && probe_mult == 0) {
