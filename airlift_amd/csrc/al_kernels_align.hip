@@ -2414,8 +2414,8 @@ int al_run_align_stage(al_ctx_t *c)
 		for (int i = 0; i < 3; ++i) AL_HIP_CHECK(hipStreamWaitEvent(c->aux[i], c->ev_fj[0], 0));
 		LHV(72, 1024, 48, 768, lds_s, sd); LHV(48, 768, 24, 512, lds_b, c->aux[0]); LHV(200, 2048, 72, 1024, lds_l, c->aux[1]); LHV(12, 256, 0, 0, lds_a, c->aux[2]);
 		AL_HIP_CHECK(hipEventRecord(c->ev_fj[1], sd));
+		LHV(24, 512, 12, 256, lds_t, s);                                          // (the fifth tile size on the main stream, beside the other four: it used to wait for them)
 		for (int i = 0; i < 3; ++i) { AL_HIP_CHECK(hipEventRecord(c->ev_aux[i], c->aux[i])); AL_HIP_CHECK(hipStreamWaitEvent(s, c->ev_aux[i], 0)); }
-		LHV(24, 512, 12, 256, lds_t, s);
 #undef LHV
 		AL_HIP_CHECK(hipStreamWaitEvent(s, c->ev_fj[1], 0));
 	}

@@ -73,12 +73,8 @@ __device__ __forceinline__ bool ct_score(const uint64_t rj, const uint32_t xi, c
 	const bool skip = ((uint32_t)(dq - 1) >= (uint32_t)mdx) | (same & (((uint32_t)(dr - 1) >= drlim) | (dq > mdy) | (dd > bw)));
 	const int32_t min_d = dq < dr ? dq : dr;
 	int32_t sc = min_d > q_span ? q_span : min_d;
-	const uint32_t di = (uint32_t)dd < CT_CLIN_N ? (uint32_t)dd : CT_CLIN_N - 1;
-	int32_t pen_same = (int32_t)pen.same[di], pen_diff = (int32_t)pen.diff[di];
-	if (__builtin_expect(!pen.tab_ok || dd >= CT_CLIN_N, 0)) {
-		const int32_t log_dd = dd ? ct_ilog2((uint32_t)dd) : 0, c_lin = (int)((double)dd * .01 * pen.avg_d);
-		pen_same = c_lin + (log_dd >> 1); pen_diff = c_lin < log_dd ? c_lin : log_dd;
-	}
+	const int32_t log_dd = dd ? ct_ilog2((uint32_t)dd) : 0, c_lin = (int)((double)dd * .01 * pen.avg_d);
+	int32_t pen_same = c_lin + (log_dd >> 1), pen_diff = c_lin < log_dd ? c_lin : log_dd;
 	pen_diff = dr == 0 ? -1 : pen_diff;                                        // other mate, same position: + 1 (chain.c:67)
 	sc_out = sc - (same ? pen_same : pen_diff) + R_F(rj);
 	return !skip;
@@ -108,19 +104,21 @@ __device__ __forceinline__ uint32_t ct_defer_class(uint32_t n) { return n <= 16 
 // page is not in the TLB).
 __device__ __forceinline__ void ct_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier\n\ts_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-__global__ void __launch_bounds__(CT_NT)
+template <int OCC>   // tiles per CU the registers are capped for (the LDS allows eight)
+__global__ void __launch_bounds__(CT_NT) __attribute__((amdgpu_waves_per_eu(OCC)))
 k_chain_tile(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_off, const uint32_t *__restrict__ frag_na,
              const uint32_t *__restrict__ frag_meta /* per fragment: qlen_sum | paired << 31 (k_frag_meta) */, const uint32_t *__restrict__ list, const TileSched S,
              const uint32_t *__restrict__ skip_flag, AlAnchor *__restrict__ chained, uint64_t *__restrict__ u_out, uint32_t *__restrict__ uo_out,
              uint32_t *__restrict__ frag_nu, uint32_t *__restrict__ fb_list, uint32_t *__restrict__ fb_cnt, const AlParams P, const int lmin,
              unsigned long long *__restrict__ counters, const int force_fb /* tests: every fragment is handed back */, const CtDefer D)
 {
+	// 14 bytes per row + 6.5 per possible segment: 19.6 KB, eight tiles per CU by LDS (six by the compiler's count, which caps the registers at 80)
 	__shared__ uint64_t s_row[CT_TILE];
-	__shared__ uint32_t s_u[CT_TILE];
-	__shared__ uint16_t s_v[CT_TILE], s_tm[CT_TILE], s_perm[CT_TILE];
-	__shared__ uint16_t s_sstart[CT_SEGS], s_slen[CT_SEGS], s_snu[CT_SEGS], s_proc[CT_SEGS], s_G[CT_SEGS], s_Dn[CT_SEGS];
-	__shared__ uint8_t s_sfrag[CT_SEGS];
-	__shared__ uint8_t s_pen_same[CT_CLIN_N], s_pen_diff[CT_CLIN_N];
+	__shared__ uint16_t s_u[CT_TILE];                                          // chain ends (peak score << 4 | anchor), then chains (score << 4 | anchors): at most CT_INLINE = 8 anchors per segment here
+	__shared__ uint16_t s_v[CT_TILE], s_tm[CT_TILE];                           // s_tm: low byte = first visit-list entry of chain c, high byte = chain at sorted position i
+	__shared__ uint16_t s_sstart[CT_SEGS], s_snu[CT_SEGS], s_proc[CT_SEGS];
+	uint16_t *const s_G = s_proc;                                              // (the size-ordered list is dead when the emit step starts)
+	__shared__ uint8_t s_slen[CT_SEGS], s_Dn[CT_SEGS], s_sfrag[CT_SEGS];
 	__shared__ CtFrag s_tf[CT_FRAGS];
 	__shared__ uint32_t s_fseg[CT_FRAGS + 1];                                  // first segment (tile order) of every fragment of the tile
 	__shared__ uint32_t s_ctot[CT_SEGS / 64 + 1], s_dtot[CT_SEGS / 64 + 1];
@@ -137,13 +135,9 @@ k_chain_tile(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ 
 	const uint32_t e0 = S.ent[cl] + (it - S.item[cl]) * per, e1 = e0 + per < S.ent[cl + 1] ? e0 + per : S.ent[cl + 1];
 	const int nfr = (int)(e1 - e0);
 	const int32_t q_span = P.k, bw = P.bw, max_iter = P.max_chain_iter, min_cnt = P.min_cnt, min_sc = P.min_chain_score;
-	// gap costs of chain.c:64-72 for avg_qspan == k, tabulated with the same two double multiplications
-	for (int d = tid; d < CT_CLIN_N; d += CT_NT) {
-		const int c_lin = (int)((double)d * .01 * (double)P.k), lg = d ? ct_ilog2((uint32_t)d) : 0;
-		s_pen_same[d] = (uint8_t)(c_lin + (lg >> 1)); s_pen_diff[d] = (uint8_t)(c_lin < lg ? c_lin : lg);
-	}
-	CtPen pen; pen.same = s_pen_same; pen.diff = s_pen_diff; pen.avg_d = (double)P.k;     // every span is k (checked per row): (float)sum / n == k exactly (chain.c:42)
-	pen.tab_ok = P.k * 0.01 * (CT_CLIN_N - 1) + 5.0 < 255.0;
+	// gap costs of chain.c:64-72 computed per pair (the segments chained here score too few pairs to repay tables); every span is k (checked per
+	// row): avg_qspan = (float)sum / n == k exactly (chain.c:42)
+	CtPen pen; pen.same = nullptr; pen.diff = nullptr; pen.avg_d = (double)P.k; pen.tab_ok = false;
 	// ---- the fragments of this item ----
 	if (w == 0) {
 		const bool mine = lane < nfr;
@@ -180,36 +174,39 @@ k_chain_tile(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ 
 	uint32_t u_run = 0;                  // single: chain list slots written by the earlier tiles
 	bool any_def = false;                // single: a segment of an earlier tile was deferred
 	for (;;) {
-		// ---- load: rows with their cut flags, by all wavefronts; every thread's loads (a row and its left neighbour's x, four times) are in flight together ----
+		// ---- load: rows with their cut flags, by all wavefronts; a thread's four rows in two rounds of two (a row and its left neighbour's x each): the loads
+		//      of a round are in flight together, and two rounds keep the kernel at 80 registers, i.e. at the six tiles per CU the LDS allows ----
 		{
 			const uint32_t rows = single ? (s_tf[0].na - pos < CT_TILE ? s_tf[0].na - pos : CT_TILE) : s_tf[nfr - 1].start + s_tf[nfr - 1].na;
-			AlAnchor e[CT_TILE / CT_NT]; uint64_t xp[CT_TILE / CT_NT]; int fis[CT_TILE / CT_NT]; uint32_t is[CT_TILE / CT_NT];
-#pragma unroll
-			for (int j = 0; j < CT_TILE / CT_NT; ++j) {
-				const uint32_t r = (uint32_t)j * CT_NT + tid;
-				int fi = 0;
-				if (!single) while (fi + 1 < nfr && s_tf[fi + 1].start <= r) ++fi;
-				fis[j] = fi; e[j].x = 0; e[j].y = 0; xp[j] = 0; is[j] = 0;
-				if (r < rows) {
-					const uint32_t i = r - s_tf[fi].start; is[j] = i;
-					const AlAnchor *src = anchors + s_tf[fi].aoff + pos;
-					e[j] = src[i];
-					if (i > 0) xp[j] = src[i - 1].x;
-				}
-			}
-			// (the compiler would sink every load to its use -- one memory latency per row instead of one per tile: all loaded values are pinned here)
 			static_assert(CT_TILE / CT_NT == 4, "four rows per thread");
-			asm volatile("" : "+v"(e[0].x), "+v"(e[0].y), "+v"(e[1].x), "+v"(e[1].y), "+v"(e[2].x), "+v"(e[2].y), "+v"(e[3].x), "+v"(e[3].y), "+v"(xp[0]), "+v"(xp[1]), "+v"(xp[2]), "+v"(xp[3]));
+			for (int h = 0; h < 2; ++h) {
+				AlAnchor e[2]; uint64_t xp[2]; int fis[2]; uint32_t is[2];
 #pragma unroll
-			for (int j = 0; j < CT_TILE / CT_NT; ++j) {
-				const uint32_t r = (uint32_t)j * CT_NT + tid;
-				if (r < rows) {
-					const AlAnchor ee = e[j];
-					const bool cut = is[j] == 0 || ee.x - xp[j] > (uint64_t)(int64_t)s_tf[fis[j]].mdx;
-					const bool bad = (int32_t)(ee.y >> 32 & 0xff) != q_span || ((ee.y & AL_SEED_SEG_MASK) >> AL_SEED_SEG_SHIFT) > 1 || (uint32_t)ee.y > 0xfffu;
-					s_row[r] = (uint64_t)((uint32_t)ee.x & 0xffffu) | (uint64_t)((uint32_t)ee.y & 0xfffu) << 16 | (uint64_t)((ee.y & AL_SEED_SEG_MASK) >> AL_SEED_SEG_SHIFT & 1) << 28
-					           | (uint64_t)(cut ? 1u : 0u) << 29 | (uint64_t)CT_NONE << 48;
-					if (bad) atomicOr(&s_tf[fis[j]].flags, 2u);
+				for (int j = 0; j < 2; ++j) {
+					const uint32_t r = (uint32_t)(2 * h + j) * CT_NT + tid;
+					int fi = 0;
+					if (!single) while (fi + 1 < nfr && s_tf[fi + 1].start <= r) ++fi;
+					fis[j] = fi; e[j].x = 0; e[j].y = 0; xp[j] = 0; is[j] = 0;
+					if (r < rows) {
+						const uint32_t i = r - s_tf[fi].start; is[j] = i;
+						const AlAnchor *src = anchors + s_tf[fi].aoff + pos;
+						e[j] = src[i];
+						if (i > 0) xp[j] = src[i - 1].x;
+					}
+				}
+				// (the compiler would sink every load to its use -- one memory latency per row: the loaded values are pinned here)
+				asm volatile("" : "+v"(e[0].x), "+v"(e[0].y), "+v"(e[1].x), "+v"(e[1].y), "+v"(xp[0]), "+v"(xp[1]));
+#pragma unroll
+				for (int j = 0; j < 2; ++j) {
+					const uint32_t r = (uint32_t)(2 * h + j) * CT_NT + tid;
+					if (r < rows) {
+						const AlAnchor ee = e[j];
+						const bool cut = is[j] == 0 || ee.x - xp[j] > (uint64_t)(int64_t)s_tf[fis[j]].mdx;
+						const bool bad = (int32_t)(ee.y >> 32 & 0xff) != q_span || ((ee.y & AL_SEED_SEG_MASK) >> AL_SEED_SEG_SHIFT) > 1 || (uint32_t)ee.y > 0xfffu;
+						s_row[r] = (uint64_t)((uint32_t)ee.x & 0xffffu) | (uint64_t)((uint32_t)ee.y & 0xfffu) << 16 | (uint64_t)((ee.y & AL_SEED_SEG_MASK) >> AL_SEED_SEG_SHIFT & 1) << 28
+						           | (uint64_t)(cut ? 1u : 0u) << 29 | (uint64_t)CT_NONE << 48;
+						if (bad) atomicOr(&s_tf[fis[j]].flags, 2u);
+					}
 				}
 			}
 		}
@@ -239,7 +236,7 @@ k_chain_tile(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ 
 					over = over || (useful && len > CT_DEFER_MAX);
 					const int sc = len <= 2 ? 0 : len <= 4 ? 1 : len <= CT_INLINE ? 2 : 3;
 					const unsigned long long um = __ballot(useful);
-					if (useful) { const uint32_t k = n_seg + (uint32_t)__popcll(um & below); s_sstart[k] = (uint16_t)start; s_slen[k] = (uint16_t)len; s_sfrag[k] = (uint8_t)fi; }
+					if (useful) { const uint32_t k = n_seg + (uint32_t)__popcll(um & below); s_sstart[k] = (uint16_t)start; s_slen[k] = (uint8_t)(len < 255u ? len : 255u); s_sfrag[k] = (uint8_t)fi; }
 					n_seg += (uint32_t)__popcll(um);
 					cnt0 += (uint32_t)__popcll(__ballot(useful && sc == 0)); cnt1 += (uint32_t)__popcll(__ballot(useful && sc == 1)); cnt2 += (uint32_t)__popcll(__ballot(useful && sc == 2));
 					if (mask) open = base_t + b + (uint32_t)(63 - __clzll((long long)mask));
@@ -252,7 +249,7 @@ k_chain_tile(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ 
 					proc_end = end_t;
 					const uint32_t len = end_t - open;
 					if (n > 0 && (int)len >= lmin) {
-						if (lane == 0) { s_sstart[n_seg] = (uint16_t)open; s_slen[n_seg] = (uint16_t)len; s_sfrag[n_seg] = (uint8_t)fi; }
+						if (lane == 0) { s_sstart[n_seg] = (uint16_t)open; s_slen[n_seg] = (uint8_t)(len < 255u ? len : 255u); s_sfrag[n_seg] = (uint8_t)fi; }
 						++n_seg;
 						if (len <= 2) ++cnt0; else if (len <= 4) ++cnt1; else if (len <= CT_INLINE) ++cnt2;
 						over = over || len > CT_DEFER_MAX;
@@ -311,7 +308,7 @@ k_chain_tile(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ 
 					int32_t sc;
 					const bool ok = ct_score(r0w | (uint64_t)(uint32_t)q_span << 32, R_XLO(r1w), R_Q(r1w), R_SEG(r1w), q_span, mdx, mdy, drlim, bw, pen, sc);   // f[0] = k
 					const bool chain = ok && sc > q_span && sc >= min_sc && 2 >= min_cnt && (int32_t)((R_XLO(r1w) - R_XLO(r0w)) & 0xffffu) <= mdx && 1 <= max_iter;
-					if (chain) { s_u[Sg] = (uint32_t)sc << 16 | 2u; s_v[Sg] = 1; s_v[Sg + 1] = 0; s_tm[Sg] = 0; s_perm[Sg] = 0; s_snu[k] = 1; }
+					if (chain) { s_u[Sg] = (uint16_t)((uint32_t)sc << 4 | 2u); s_v[Sg] = 1; s_v[Sg + 1] = 0; s_tm[Sg] = 0; s_snu[k] = 1; }
 					else s_snu[k] = 0;
 				}
 				continue;
@@ -354,35 +351,39 @@ k_chain_tile(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ 
 					int j = i;
 					while (j >= 0 && F_(j) < (int32_t)s_v[Sg + j]) { const uint32_t p = P_(j); j = p == CT_NONE ? -1 : (int)p; }
 					if (j < 0) j = i;
-					s_u[Sg + n_u] = (uint32_t)F_(j) << 16 | (uint32_t)j;
+					s_u[Sg + n_u] = (uint16_t)((uint32_t)F_(j) << 4 | (uint32_t)j);
 					++n_u;
 				}
 			if (n_u == 0) { s_snu[k] = 0; continue; }
-			for (int32_t i = 1; i < n_u; ++i) { const uint32_t t = s_u[Sg + i]; int32_t j = i; while (j > 0 && s_u[Sg + j - 1] < t) { s_u[Sg + j] = s_u[Sg + j - 1]; --j; } s_u[Sg + j] = t; }
+			for (int32_t i = 1; i < n_u; ++i) { const uint16_t t = s_u[Sg + i]; int32_t j = i; while (j > 0 && s_u[Sg + j - 1] < t) { s_u[Sg + j] = s_u[Sg + j - 1]; --j; } s_u[Sg + j] = t; }
 			int32_t n_v = 0, kk = 0;
 			for (int32_t i = 0; i < n_u; ++i) {                                          // chain.c:111-128; v[] becomes the visit list
 				const uint32_t key0 = s_u[Sg + i];
-				const int32_t n_v0 = n_v, k0 = kk, sc_i = (int32_t)(key0 >> 16); int j = (int)(key0 & 0xffffu);
+				const int32_t n_v0 = n_v, k0 = kk, sc_i = (int32_t)(key0 >> 4); int j = (int)(key0 & 0xfu);
 				do { s_v[Sg + n_v] = (uint16_t)j; ++n_v; FLG(j) |= ROW_B31; const uint32_t p = P_(j); j = p == CT_NONE ? -1 : (int)p; } while (j >= 0 && !(FLG(j) & ROW_B31));
-				if (j < 0) { if (n_v - n_v0 >= min_cnt) s_u[Sg + kk++] = (uint32_t)sc_i << 16 | (uint32_t)(n_v - n_v0); }
-				else if (sc_i - F_(j) >= min_sc) { if (n_v - n_v0 >= min_cnt) s_u[Sg + kk++] = (uint32_t)(sc_i - F_(j)) << 16 | (uint32_t)(n_v - n_v0); }
+				if (j < 0) { if (n_v - n_v0 >= min_cnt) s_u[Sg + kk++] = (uint16_t)((uint32_t)sc_i << 4 | (uint32_t)(n_v - n_v0)); }
+				else if (sc_i - F_(j) >= min_sc) { if (n_v - n_v0 >= min_cnt) s_u[Sg + kk++] = (uint16_t)((uint32_t)(sc_i - F_(j)) << 4 | (uint32_t)(n_v - n_v0)); }
 				if (k0 == kk) n_v = n_v0;
 			}
 			n_u = kk;
 			// chains by the x of their first anchor (chain.c:144-160): a stable insertion sort is the reference's order for the <= 64 chains of a
 			// fragment (ksort.h:149); with more chains in the fragment the order among equal x is the fallback's business (tie flag)
 			int32_t off = 0;
-			for (int32_t c = 0; c < n_u; ++c) { s_tm[Sg + c] = (uint16_t)off; off += (int32_t)(s_u[Sg + c] & 0xffffu); s_perm[Sg + c] = (uint16_t)c; }
+			for (int32_t c = 0; c < n_u; ++c) { s_tm[Sg + c] = (uint16_t)((uint32_t)off | (uint32_t)c << 8); off += (int32_t)(s_u[Sg + c] & 0xfu); }
 			bool eqx = false;
 			if (n_u > 1) {
 				const AlAnchor *a = anchors + tf.aoff + pos + (Sg - tf.start);
-#define CX(c) (a[(int)s_v[Sg + (int)s_tm[Sg + (c)] + (int32_t)(s_u[Sg + (c)] & 0xffffu) - 1]].x)
+#define CX(c) (a[(int)s_v[Sg + (int)(s_tm[Sg + (c)] & 0xffu) + (int32_t)(s_u[Sg + (c)] & 0xfu) - 1]].x)
+#define PERM(i) (s_tm[Sg + (i)] >> 8)
+#define SETPERM(i, c) (s_tm[Sg + (i)] = (uint16_t)((s_tm[Sg + (i)] & 0xffu) | (uint32_t)(c) << 8))
 				for (int32_t i = 1; i < n_u; ++i) {
-					const uint16_t ci = s_perm[Sg + i]; const uint64_t xi = CX(ci); int32_t j = i;
-					while (j > 0) { const uint16_t cj = s_perm[Sg + j - 1]; const uint64_t xj = CX(cj); if (xi < xj) { s_perm[Sg + j] = cj; --j; } else { eqx = eqx || xi == xj; break; } }
-					s_perm[Sg + j] = ci;
+					const uint32_t ci = PERM(i); const uint64_t xi = CX(ci); int32_t j = i;
+					while (j > 0) { const uint32_t cj = PERM(j - 1); const uint64_t xj = CX(cj); if (xi < xj) { SETPERM(j, cj); --j; } else { eqx = eqx || xi == xj; break; } }
+					SETPERM(j, ci);
 				}
 #undef CX
+#undef PERM
+#undef SETPERM
 			}
 			s_snu[k] = (uint16_t)((uint32_t)n_u | (eqx ? 0x8000u : 0u));
 #undef FLG
@@ -399,7 +400,7 @@ k_chain_tile(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ 
 			const uint32_t nu = snu & 0x3fffu, df = (snu & CT_DEF) ? 1u : 0u;
 			uint32_t incl = nu, incd = df;
 			for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d), od = __shfl_up(incd, d); if (lane >= d) { incl += o; incd += od; } }
-			if (k < n_seg) { s_G[k] = (uint16_t)(incl - nu); s_Dn[k] = (uint16_t)(incd - df); }
+			if (k < n_seg) { s_G[k] = (uint16_t)(incl - nu); s_Dn[k] = (uint8_t)(incd - df); }
 			if (lane == 63) { s_ctot[c] = incl; s_dtot[c] = incd; }
 		}
 		ct_sync();
@@ -440,31 +441,33 @@ k_chain_tile(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ 
 			}
 			uint32_t o = 0;
 			for (uint32_t i = 0; i < nu; ++i) {
-				const uint32_t cc = s_perm[Sg + i], e = s_u[Sg + cc], cnt = e & 0xffffu, off = s_tm[Sg + cc];
-				ub[w0 + i] = (uint64_t)(e >> 16) << 32 | cnt; uob[w0 + i] = rel + o;
+				const uint32_t cc = s_tm[Sg + i] >> 8, e = s_u[Sg + cc], cnt = e & 0xfu, off = s_tm[Sg + cc] & 0xffu;
+				ub[w0 + i] = (uint64_t)(e >> 4) << 32 | cnt; uob[w0 + i] = rel + o;
 				for (uint32_t j = 0; j < cnt; ++j) rlo[2 * (Sg + o + j) + 1] = Sg + (uint32_t)s_v[Sg + off + (cnt - 1 - j)];
 				o += cnt;
 			}
 		}
 		ct_sync();
 		CT_PROF(4);
-		{   // the chained anchors, by all lanes: every thread's (up to four) loads in flight together, then its stores
+		{   // the chained anchors, by all lanes: a thread's four places in two rounds of two loads in flight together, then their stores
 			const uint32_t t1 = single ? proc_end : s_tf[nfr - 1].start + s_tf[nfr - 1].na;
-			AlAnchor v[CT_TILE / CT_NT]; uint64_t di[CT_TILE / CT_NT]; bool ok[CT_TILE / CT_NT];
+			for (int h = 0; h < 2; ++h) {
+				AlAnchor v[2]; uint64_t di[2]; bool ok[2];
 #pragma unroll
-			for (int j = 0; j < CT_TILE / CT_NT; ++j) {
-				const uint32_t t = (uint32_t)j * CT_NT + tid;
-				const uint32_t sr = t < t1 ? rlo[2 * t + 1] : 0xffffffffu;
-				ok[j] = sr != 0xffffffffu;
-				int fi = 0;
-				if (!single) while (fi + 1 < nfr && s_tf[fi + 1].start <= t) ++fi;
-				const uint64_t base = s_tf[fi].aoff + pos; const uint32_t st0 = s_tf[fi].start;
-				di[j] = base + (t - st0);
-				v[j] = anchors[ok[j] ? base + (sr - st0) : s_tf[0].aoff];          // (a place without a chained anchor: any readable anchor, not stored)
+				for (int j = 0; j < 2; ++j) {
+					const uint32_t t = (uint32_t)(2 * h + j) * CT_NT + tid;
+					const uint32_t sr = t < t1 ? rlo[2 * t + 1] : 0xffffffffu;
+					ok[j] = sr != 0xffffffffu;
+					int fi = 0;
+					if (!single) while (fi + 1 < nfr && s_tf[fi + 1].start <= t) ++fi;
+					const uint64_t base = s_tf[fi].aoff + pos; const uint32_t st0 = s_tf[fi].start;
+					di[j] = base + (t - st0);
+					v[j] = anchors[ok[j] ? base + (sr - st0) : s_tf[0].aoff];          // (a place without a chained anchor: any readable anchor, not stored)
+				}
+				asm volatile("" : "+v"(v[0].x), "+v"(v[0].y), "+v"(v[1].x), "+v"(v[1].y));
+#pragma unroll
+				for (int j = 0; j < 2; ++j) if (ok[j]) chained[di[j]] = v[j];
 			}
-			asm volatile("" : "+v"(v[0].x), "+v"(v[0].y), "+v"(v[1].x), "+v"(v[1].y), "+v"(v[2].x), "+v"(v[2].y), "+v"(v[3].x), "+v"(v[3].y));
-#pragma unroll
-			for (int j = 0; j < CT_TILE / CT_NT; ++j) if (ok[j]) chained[di[j]] = v[j];
 		}
 		if (single) { u_run += G_of(n_seg); any_def = any_def || n_def != 0; }
 		else if (w == 0 && lane < nfr) {
@@ -495,6 +498,9 @@ k_chain_tile(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ 
 		}
 	}
 }
+
+template __global__ void k_chain_tile<6>(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, const TileSched, const uint32_t *, AlAnchor *, uint64_t *, uint32_t *, uint32_t *, uint32_t *, uint32_t *, const AlParams, const int, unsigned long long *, const int, const CtDefer);
+template __global__ void k_chain_tile<8>(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, const TileSched, const uint32_t *, AlAnchor *, uint64_t *, uint32_t *, uint32_t *, uint32_t *, uint32_t *, const AlParams, const int, unsigned long long *, const int, const CtDefer);
 
 // The chain lists of the fragments with deferred segments have empty slots (the reserve the lane kernels did not need): closed here, a wavefront per
 // fragment, in place and in order.  Then the fragment-wide tie rule: more than 64 chains of which two start at equal x -> fallback list.
