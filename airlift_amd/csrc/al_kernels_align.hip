@@ -839,7 +839,7 @@ struct RegsSelShared {
 	int32_t subsc[AL_REGS_PMAX], nsub[AL_REGS_PMAX], slot[AL_REGS_PMAX], orig[AL_REGS_PMAX]; uint32_t hash[AL_REGS_PMAX];   // slot: rank among the kept hits; orig: position in score order
 };
 template <int CAP>      // CAP > 0: sort tile in LDS; 0: at most 64 chains, registers; < 0: sort keys in the fragment's global work area (any count)
-__global__ void __launch_bounds__(CAP == 0 ? 64 : CAP < 0 ? 1024 : 256)
+__global__ void __launch_bounds__(CAP == 0 || CAP == 256 ? 64 : CAP < 0 ? 1024 : 256)
 k_regs_select(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__ u_all, const uint32_t *__restrict__ uo_all, const uint32_t *__restrict__ frag_first,
               const uint32_t *__restrict__ rd_len, const uint32_t *__restrict__ frag_hash, WsBase W, const uint32_t *__restrict__ list, int n_list,
               AlParams P, uint32_t *__restrict__ regs_n0)
@@ -847,7 +847,8 @@ k_regs_select(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__
 	__shared__ uint64_t skey_l[CAP > 0 ? CAP : 1];
 	__shared__ uint16_t sidx_l[CAP > 0 ? CAP : 1];
 	__shared__ RegsSelShared S; __shared__ RegsSelKept K;
-	constexpr int NT = CAP == 0 ? 64 : CAP < 0 ? 1024 : 256;                // all threads sort (the sort in global memory, any count: 1024 of them); the first wavefront makes the pass
+	constexpr int NT = CAP == 0 || CAP == 256 ? 64 : CAP < 0 ? 1024 : 256;   // (65 ... 256 chains: one wavefront sorts and makes the pass -- four times the blocks per CU of the 256-thread form, whose other three wavefronts only sort)
+	                // all threads sort (the sort in global memory, any count: 1024 of them); the first wavefront makes the pass
 	const int tid = threadIdx.x, lane = tid & 63;
 	if ((int)blockIdx.x >= n_list) return;
 	const uint32_t f = list[blockIdx.x];
@@ -1127,6 +1128,7 @@ k_regs_select(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__
 	if (lane == 0) regs_n0[f] = (uint32_t)n0;
 }
 template __global__ void k_regs_select<0>(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *, WsBase, const uint32_t *, int, AlParams, uint32_t *);
+template __global__ void k_regs_select<256>(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *, WsBase, const uint32_t *, int, AlParams, uint32_t *);
 template __global__ void k_regs_select<1024>(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *, WsBase, const uint32_t *, int, AlParams, uint32_t *);
 template __global__ void k_regs_select<2048>(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *, WsBase, const uint32_t *, int, AlParams, uint32_t *);
 template __global__ void k_regs_select<4096>(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *, WsBase, const uint32_t *, int, AlParams, uint32_t *);
@@ -2367,11 +2369,11 @@ int al_run_align_stage(al_ctx_t *c)
 		AL_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, bytes, (const uint32_t *)c->frag_nu.p, c->chain_key.p, (const uint32_t *)c->chain_idx.p, c->chain_idx2.p, nf, 0, 32, s));
 		if (c->scan_tmp.ensure(bytes + 16)) return -1;
 		AL_HIP_CHECK(rocprim::radix_sort_pairs(c->scan_tmp.p, bytes, (const uint32_t *)c->frag_nu.p, c->chain_key.p, (const uint32_t *)c->chain_idx.p, c->chain_idx2.p, nf, 0, 32, s));
-		uint32_t init[6] = {(uint32_t)nf, (uint32_t)nf, (uint32_t)nf, (uint32_t)nf, (uint32_t)nf, (uint32_t)nf}, lb[6];
-		AL_HIP_CHECK(hipMemcpyAsync(c->lb_buf.p, init, 24, hipMemcpyHostToDevice, s));
-		LbThr T; T.n = 6; T.v[0] = 5; T.v[1] = 65; T.v[2] = 1025; T.v[3] = 8193; T.v[4] = 2049; T.v[5] = 4097; for (int i = 6; i < 16; ++i) T.v[i] = 0xffffffffu;
+		uint32_t init[7] = {(uint32_t)nf, (uint32_t)nf, (uint32_t)nf, (uint32_t)nf, (uint32_t)nf, (uint32_t)nf, (uint32_t)nf}, lb[7];
+		AL_HIP_CHECK(hipMemcpyAsync(c->lb_buf.p, init, 28, hipMemcpyHostToDevice, s));
+		LbThr T; T.n = 7; T.v[0] = 5; T.v[1] = 65; T.v[2] = 1025; T.v[3] = 8193; T.v[4] = 2049; T.v[5] = 4097; T.v[6] = 257; for (int i = 7; i < 16; ++i) T.v[i] = 0xffffffffu;
 		hipLaunchKernelGGL(k_lower_bounds, dim3((nf + 255) / 256), dim3(256), 0, s, (const uint32_t *)c->chain_key.p, (uint32_t)nf, T, c->lb_buf.p);
-		AL_HIP_CHECK(hipMemcpyAsync(lb, c->lb_buf.p, 24, hipMemcpyDeviceToHost, s));
+		AL_HIP_CHECK(hipMemcpyAsync(lb, c->lb_buf.p, 28, hipMemcpyDeviceToHost, s));
 		AL_HIP_CHECK(hipStreamSynchronize(s));
 		const uint32_t *ord = c->chain_idx2.p;
 		T.n = 1; T.v[0] = 9;      // fragments with at least nine chains may keep at least nine hits: candidates of k_regs_heavy
@@ -2384,7 +2386,8 @@ int al_run_align_stage(al_ctx_t *c)
 		if (lb[3] > lb[5]) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_select<8192>), dim3(lb[3] - lb[5]), dim3(256), 0, sd, c->chained.p, c->u.p, c->uo.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, ord + lb[5], (int)(lb[3] - lb[5]), c->P, regs_n0);
 		AL_HIP_CHECK(hipEventRecord(c->ev_fj[1], sd));
 		if ((uint32_t)nf > lb[3]) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_select<-1>), dim3((uint32_t)nf - lb[3]), dim3(1024), 0, s, c->chained.p, c->u.p, c->uo.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, ord + lb[3], (int)((uint32_t)nf - lb[3]), c->P, regs_n0);
-		if (lb[2] > lb[1]) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_select<1024>), dim3(lb[2] - lb[1]), dim3(256), 0, s, c->chained.p, c->u.p, c->uo.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, ord + lb[1], (int)(lb[2] - lb[1]), c->P, regs_n0);
+		if (lb[2] > lb[6]) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_select<1024>), dim3(lb[2] - lb[6]), dim3(256), 0, s, c->chained.p, c->u.p, c->uo.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, ord + lb[6], (int)(lb[2] - lb[6]), c->P, regs_n0);
+		if (lb[6] > lb[1]) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_select<256>), dim3(lb[6] - lb[1]), dim3(64), 0, s, c->chained.p, c->u.p, c->uo.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, ord + lb[1], (int)(lb[6] - lb[1]), c->P, regs_n0);
 		if (lb[5] > lb[4]) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_select<4096>), dim3(lb[5] - lb[4]), dim3(256), 0, s, c->chained.p, c->u.p, c->uo.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, ord + lb[4], (int)(lb[5] - lb[4]), c->P, regs_n0);
 		if (lb[4] > lb[2]) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_select<2048>), dim3(lb[4] - lb[2]), dim3(256), 0, s, c->chained.p, c->u.p, c->uo.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, ord + lb[2], (int)(lb[4] - lb[2]), c->P, regs_n0);
 		if (lb[1] > lb[0]) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_select<0>), dim3(lb[1] - lb[0]), dim3(64), 0, s, c->chained.p, c->u.p, c->uo.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, ord + lb[0], (int)(lb[1] - lb[0]), c->P, regs_n0);

@@ -104,13 +104,12 @@ __device__ __forceinline__ uint32_t ct_defer_class(uint32_t n) { return n <= 16 
 // page is not in the TLB).
 __device__ __forceinline__ void ct_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier\n\ts_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-template <int OCC>   // tiles per CU the registers are capped for (the LDS allows eight)
-__global__ void __launch_bounds__(CT_NT) __attribute__((amdgpu_waves_per_eu(OCC)))
-k_chain_tile(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_off, const uint32_t *__restrict__ frag_na,
-             const uint32_t *__restrict__ frag_meta /* per fragment: qlen_sum | paired << 31 (k_frag_meta) */, const uint32_t *__restrict__ list, const TileSched S,
+__device__ __forceinline__ void
+ct_tile_body(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_off, const uint32_t *__restrict__ frag_na,
+             const uint32_t *__restrict__ frag_meta /* per fragment: qlen_sum | paired << 31 (k_frag_meta) */, const uint32_t *__restrict__ list, const TileSched &S,
              const uint32_t *__restrict__ skip_flag, AlAnchor *__restrict__ chained, uint64_t *__restrict__ u_out, uint32_t *__restrict__ uo_out,
-             uint32_t *__restrict__ frag_nu, uint32_t *__restrict__ fb_list, uint32_t *__restrict__ fb_cnt, const AlParams P, const int lmin,
-             unsigned long long *__restrict__ counters, const int force_fb /* tests: every fragment is handed back */, const CtDefer D)
+             uint32_t *__restrict__ frag_nu, uint32_t *__restrict__ fb_list, uint32_t *__restrict__ fb_cnt, const AlParams &P, const int lmin,
+             unsigned long long *__restrict__ counters, const int force_fb /* tests: every fragment is handed back */, const CtDefer &D)
 {
 	// 14 bytes per row + 6.5 per possible segment: 19.6 KB, eight tiles per CU by LDS (six by the compiler's count, which caps the registers at 80)
 	__shared__ uint64_t s_row[CT_TILE];
@@ -499,8 +498,12 @@ k_chain_tile(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ 
 	}
 }
 
-template __global__ void k_chain_tile<6>(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, const TileSched, const uint32_t *, AlAnchor *, uint64_t *, uint32_t *, uint32_t *, uint32_t *, uint32_t *, const AlParams, const int, unsigned long long *, const int, const CtDefer);
-template __global__ void k_chain_tile<8>(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, const TileSched, const uint32_t *, AlAnchor *, uint64_t *, uint32_t *, uint32_t *, uint32_t *, uint32_t *, const AlParams, const int, unsigned long long *, const int, const CtDefer);
+// registers capped at 80: six tiles per CU (the 20 KB of LDS would allow eight; at 64 registers the compiler gives up the cap altogether)
+#define CT_ARGS const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_off, const uint32_t *__restrict__ frag_na, const uint32_t *__restrict__ frag_meta, const uint32_t *__restrict__ list, const TileSched S, \
+	const uint32_t *__restrict__ skip_flag, AlAnchor *__restrict__ chained, uint64_t *__restrict__ u_out, uint32_t *__restrict__ uo_out, uint32_t *__restrict__ frag_nu, uint32_t *__restrict__ fb_list, uint32_t *__restrict__ fb_cnt, \
+	const AlParams P, const int lmin, unsigned long long *__restrict__ counters, const int force_fb, const CtDefer D
+#define CT_PASS anchors, a_off, frag_na, frag_meta, list, S, skip_flag, chained, u_out, uo_out, frag_nu, fb_list, fb_cnt, P, lmin, counters, force_fb, D
+__global__ void __launch_bounds__(CT_NT) __attribute__((amdgpu_waves_per_eu(6))) k_chain_tile6(CT_ARGS) { ct_tile_body(CT_PASS); }
 
 // The chain lists of the fragments with deferred segments have empty slots (the reserve the lane kernels did not need): closed here, a wavefront per
 // fragment, in place and in order.  Then the fragment-wide tie rule: more than 64 chains of which two start at equal x -> fallback list.

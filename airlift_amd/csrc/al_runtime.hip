@@ -26,7 +26,7 @@ extern "C" __global__ void k_rechain_test(const AlAnchor *, const uint64_t *, co
 struct TileSched { uint32_t n_items; uint32_t ent[7]; uint32_t item[7]; };
 struct CtDefer { uint64_t *off, *uslot; uint32_t *na, *meta, *rel, *fragid, *cls; uint32_t *cnt; uint32_t cap; uint32_t *cmp_list, *cmp_cnt; uint32_t *ctie; };
 __global__ void k_frag_meta(const uint32_t *, const uint32_t *, int, uint32_t *);
-template <int OCC> __global__ void k_chain_tile(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, const TileSched, const uint32_t *, AlAnchor *, uint64_t *, uint32_t *, uint32_t *, uint32_t *, uint32_t *, const AlParams, const int, unsigned long long *, const int, const CtDefer);
+__global__ void k_chain_tile6(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, const TileSched, const uint32_t *, AlAnchor *, uint64_t *, uint32_t *, uint32_t *, uint32_t *, uint32_t *, const AlParams, const int, unsigned long long *, const int, const CtDefer);
 __global__ void k_u_compact(const uint32_t *, const uint32_t *, const uint64_t *, uint32_t *, uint64_t *, uint32_t *, const uint32_t *, uint32_t *, uint32_t *);
 __global__ void k_uo_fill(const uint32_t *, int, const uint64_t *, const uint32_t *, const uint64_t *, uint32_t *, const uint32_t *);
 __global__ void k_fb_meta(const uint32_t *, int, const uint32_t *, const uint32_t *, uint32_t *, uint32_t *);
@@ -589,11 +589,8 @@ static int chain_tiles(al_ctx_t *c, const uint32_t *list, const TileSched &S, co
 		AL_HIP_CHECK(hipMemsetAsync(c->ctie.p, 0, ((size_t)c->n_frag + 1) * 4, s));
 		CtDefer D; D.off = c->vs_off.p; D.uslot = c->d_uslot.p; D.na = c->vs_na.p; D.meta = c->vs_meta.p; D.rel = c->d_rel.p; D.fragid = c->d_fragid.p; D.cls = c->vs_cls.p; D.cnt = cnts + 1; D.cap = (uint32_t)cap;
 		D.cmp_list = c->cmp_list.p; D.cmp_cnt = cnts + 2; D.ctie = c->ctie.p;
-		static const int occ = getenv("AL_TILE_OCC") ? atoi(getenv("AL_TILE_OCC")) : 8;
-		if (occ == 6) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain_tile<6>), dim3(S.n_items), dim3(256), 0, s, c->anchors.p, c->a_off.p, c->frag_na.p, c->frag_meta.p, list, S, skip_flag,
-		                                 c->chained.p, c->u.p, c->uo.p, c->frag_nu.p, c->fb_list.p, cnts, c->P, lmin, c->counters.p, force_fb, D);
-		else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain_tile<8>), dim3(S.n_items), dim3(256), 0, s, c->anchors.p, c->a_off.p, c->frag_na.p, c->frag_meta.p, list, S, skip_flag,
-		                        c->chained.p, c->u.p, c->uo.p, c->frag_nu.p, c->fb_list.p, cnts, c->P, lmin, c->counters.p, force_fb, D);
+		hipLaunchKernelGGL(k_chain_tile6, dim3(S.n_items), dim3(256), 0, s, c->anchors.p, c->a_off.p, c->frag_na.p, c->frag_meta.p, list, S, skip_flag,
+		                   c->chained.p, c->u.p, c->uo.p, c->frag_nu.p, c->fb_list.p, cnts, c->P, lmin, c->counters.p, force_fb, D);
 		if (ev(ST_SEG_FIND)) return -1;
 		{ static const bool tr = getenv("AL_TRACE") != nullptr; if (tr) { const hipError_t e = hipStreamSynchronize(s); fprintf(stderr, "[airlift] trace: tile kernel (%u items, first pass %d) -> %s\n", S.n_items, (int)first, hipGetErrorName(e)); } }
 		uint32_t h[3] = {0, 0, 0};
