@@ -170,11 +170,14 @@ int main(int argc, char **argv)
 				if (*e && *e != ',') { fprintf(stderr, "[ERROR] --devices expects a list like 0-7 or 0,1,2\n"); return 1; }
 			}
 		}
-		else if (!strcmp(a, "-o") && i + 1 < argc && (world > 1 || getenv("WORLD_SIZE"))) out_path = argv[++i];      // (a multi-process run opens the merged file itself; --world comes before -o, or WORLD_SIZE is set)
-		else if (!strcmp(a, "-o") && i + 1 < argc) { const char *fn = argv[++i]; out_path = fn; if (strcmp(fn, "-") != 0 && !freopen(fn, "wb", stdout)) { fprintf(stderr, "[ERROR] failed to write the output to file '%s'\n", fn); return 1; } }   // main.c:183-190
+		else if (!strcmp(a, "-o") && i + 1 < argc) out_path = argv[++i];                   // opened below, once it is known whether this is one of several processes (which open the merged file themselves)
 		else if (!strcmp(a, "--version")) { puts(al_version()); return 0; }
 		else { fprintf(stderr, "[WARNING] airlift-align: option '%s' ignored\n", a); }
 	}
+	// one process per GPU?  (--world, or --rank / --ranked with the launcher's WORLD_SIZE.)  Anything else -- also WORLD_SIZE = 1, or WORLD_SIZE set
+	// without --rank / --ranked -- is a single process and writes -o FILE itself (main.c:183-190).
+	if (world <= 0 && rank >= 0 && getenv("WORLD_SIZE")) world = atoi(getenv("WORLD_SIZE"));
+	if (world <= 1 && out_path && strcmp(out_path, "-") != 0 && !freopen(out_path, "wb", stdout)) { fprintf(stderr, "[ERROR] failed to write the output to file '%s'\n", out_path); return 1; }
 	// -K given: an upper bound of the bases per device batch.  Not given: the stream driver (plain FASTQ in, SAM out) sizes its batches
 	// from the free device memory (al_stream_pipe.cpp); the host driver keeps the preset's 50 Mbases, as the reference.
 	if (!k_given) setenv("AL_AUTO_BATCH", "1", 0);
@@ -217,7 +220,6 @@ int main(int argc, char **argv)
 		fflush(stderr);
 		_exit(0);
 	}
-	if (world <= 0 && rank >= 0 && getenv("WORLD_SIZE")) world = atoi(getenv("WORLD_SIZE"));
 	if (world > 1) {   // one process per GPU
 		if (rank < 0 && getenv("RANK")) rank = atoi(getenv("RANK"));
 		if (rank < 0 || rank >= world || !out_path || bam_mode) { fprintf(stderr, "[ERROR] a multi-process run needs --rank r (or RANK) below --world, -o FILE after --world, and SAM output\n"); return 1; }

@@ -48,10 +48,39 @@ struct ProcExchange {
 // The names carry a run id every rank of one launch shares (AL_RUN_ID, else TORCHELASTIC_RUN_ID / MASTER_PORT, else the parent process id:
 // the ranks of a launch are children of one launcher), so that files a crashed earlier run left behind are not taken for this run's.
 // A rank removes its files of round k once round k + 1 is complete (everybody has read them by then); the last round's few bytes stay.
-static std::string run_id()
+static std::string g_nonce;                                // set once the launch's token has been agreed on (al_map_file_frag_ranked): part of every file name below
+static std::string run_id_base()
 {
 	for (const char *k : {"AL_RUN_ID", "TORCHELASTIC_RUN_ID", "MASTER_PORT"}) { const char *v = getenv(k); if (v && *v) { std::string s; for (const char *p = v; *p; ++p) s.push_back((*p >= '0' && *p <= '9') || (*p >= 'a' && *p <= 'z') || (*p >= 'A' && *p <= 'Z') ? *p : '_'); return s; } }
 	return "p" + std::to_string((long long)getppid());
+}
+static std::string run_id() { return g_nonce.empty() ? run_id_base() : run_id_base() + "_" + g_nonce; }
+// The launch's token: rank 0 writes a fresh random word under the base id; the others take the token file only if it is not older than their own
+// start (a crashed earlier run under the same MASTER_PORT / 'none' run id leaves its files behind: without this a late rank could read a stale
+// exchange file or a stale RCCL id and wait in ncclCommInitRank for ever).
+static int agree_on_token(const std::string &dir, int rank, double timeout, double my_start_wall)
+{
+	const std::string ft = dir + "/.al_token_" + run_id_base();
+	if (rank == 0) {
+		unlink(ft.c_str());
+		unsigned long long w = (unsigned long long)getpid() * 1000003ULL ^ (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count();
+		{ FILE *r = fopen("/dev/urandom", "rb"); unsigned long long x = 0; if (r) { if (fread(&x, 8, 1, r) == 1) w ^= x; fclose(r); } }
+		char buf[32]; snprintf(buf, sizeof(buf), "%016llx", w);
+		const std::string tmp = ft + ".tmp"; FILE *f = fopen(tmp.c_str(), "wb");
+		if (!f || fwrite(buf, 16, 1, f) != 1 || fclose(f) != 0 || rename(tmp.c_str(), ft.c_str()) != 0) { fprintf(stderr, "[airlift] rank 0: cannot write '%s': %s\n", ft.c_str(), strerror(errno)); return -1; }
+		g_nonce = buf;
+		return 0;
+	}
+	const double t0 = now_s();
+	for (;;) {
+		struct stat sb;
+		if (stat(ft.c_str(), &sb) == 0 && (double)sb.st_mtime + 1.0 >= my_start_wall - 2.0) {     // (file times have a granularity; ranks of one launch start within seconds of each other)
+			FILE *f = fopen(ft.c_str(), "rb"); char buf[17] = {0};
+			if (f) { const size_t n = fread(buf, 16, 1, f); fclose(f); if (n == 1) { g_nonce = buf; return 0; } }
+		}
+		if (now_s() - t0 > timeout) { fprintf(stderr, "[airlift] rank %d: no token of this launch from rank 0 in '%s' within %.0f s\n", rank, dir.c_str(), timeout); return -2; }
+		usleep(2000);
+	}
 }
 struct FileExchange : ProcExchange {
 	std::string dir, id; int rank, world; double timeout; int round = 0;
@@ -86,7 +115,7 @@ struct RcclProcExchange : ProcExchange {
 	typedef struct { char internal[128]; } UniqueId;
 	typedef int (*get_id_t)(UniqueId *); typedef int (*init_rank_t)(void **, int, UniqueId, int); typedef int (*allgather_t)(const void *, void *, size_t, int, void *, hipStream_t); typedef int (*destroy_t)(void *);
 	void *lib = nullptr, *comm = nullptr; allgather_t f_ag = nullptr; destroy_t f_destroy = nullptr;
-	hipStream_t st = nullptr; uint64_t *d_send = nullptr, *d_recv = nullptr; int rank, world, device; double timeout; bool ok = false;
+	hipStream_t st = nullptr; uint64_t *d_send = nullptr, *d_recv = nullptr; int rank, world, device; double timeout; bool ok = false, timed_out = false;
 	RcclProcExchange(const std::string &dir, int r, int w, int dev, double t) : rank(r), world(w), device(dev), timeout(t)
 	{
 		for (const char *nm : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) if ((lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL)) != nullptr) break;
@@ -104,12 +133,24 @@ struct RcclProcExchange : ProcExchange {
 			const double t0 = now_s();
 			for (;;) { FILE *f = fopen(fid.c_str(), "rb"); if (f) { const size_t n = fread(&id, sizeof(id), 1, f); fclose(f); if (n == 1) break; } if (now_s() - t0 > timeout) { fprintf(stderr, "[airlift] rank %d: no RCCL id from rank 0 within %.0f s\n", rank, timeout); return; } usleep(2000); }
 		}
-		if (f_init(&comm, world, id, rank) != 0) { comm = nullptr; return; }
+		{   // ncclCommInitRank blocks until every rank has joined: a missing peer must not hang this rank for ever
+			struct InitState { std::atomic<int> done{0}; void *comm = nullptr; int rc = -1; };
+			std::shared_ptr<InitState> is(new InitState());
+			const int dev = device, wld = world, rk = rank;
+			std::thread th([is, f_init, id, dev, wld, rk]() { if (hipSetDevice(dev) == hipSuccess) is->rc = f_init(&is->comm, wld, id, rk); is->done = 1; });
+			const double t0 = now_s();
+			while (!is->done.load() && now_s() - t0 <= timeout) usleep(1000);
+			if (!is->done.load()) { th.detach(); timed_out = true; fprintf(stderr, "[airlift] rank %d: ncclCommInitRank did not return within %.0f s (a rank is missing)\n", rank, timeout); return; }
+			th.join();
+			if (is->rc != 0) { comm = nullptr; return; }
+			comm = is->comm;
+		}
 		if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess || hipMalloc((void **)&d_send, 64) != hipSuccess || hipMalloc((void **)&d_recv, 64 * (size_t)world) != hipSuccess) return;
 		ok = true;
 	}
 	~RcclProcExchange() override
 	{
+		if (timed_out) return;                          // a collective is stuck on the stream: destroying the communicator (or the stream) could hang as well -- the process exits non-zero
 		if (d_send) (void)hipFree(d_send); if (d_recv) (void)hipFree(d_recv); if (st) (void)hipStreamDestroy(st);
 		if (comm && f_destroy) f_destroy(comm);
 	}
@@ -120,7 +161,7 @@ struct RcclProcExchange : ProcExchange {
 		if (f_ag(d_send, d_recv, (size_t)n_words, 5 /* ncclUint64 */, comm, st) != 0) return -1;
 		if (hipMemcpyAsync(all, d_recv, 8 * (size_t)n_words * (size_t)world, hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
 		const double t0 = now_s();                     // a peer that never joins the collective must not hang this rank for ever
-		for (;;) { const hipError_t e = hipStreamQuery(st); if (e == hipSuccess) return 0; if (e != hipErrorNotReady) return -1; if (now_s() - t0 > timeout) { fprintf(stderr, "[airlift] rank %d: the RCCL all-gather did not complete within %.0f s (a rank is missing)\n", rank, timeout); return -2; } usleep(200); }
+		for (;;) { const hipError_t e = hipStreamQuery(st); if (e == hipSuccess) return 0; if (e != hipErrorNotReady) return -1; if (now_s() - t0 > timeout) { timed_out = true; fprintf(stderr, "[airlift] rank %d: the RCCL all-gather did not complete within %.0f s (a rank is missing)\n", rank, timeout); return -2; } usleep(200); }
 	}
 	const char *name() const override { return "RCCL ncclAllGather"; }
 };
@@ -166,13 +207,18 @@ struct RankRange { long long start[2] = {0, 0}, end[2] = {-1, -1}; long long fir
 // it takes and refuses the input otherwise).
 int find_ranges(const char *const *fn, int n_fn, int rank, int world, int n_threads, ProcExchange &ex, RankRange *out)
 {
-	FileMap f[2];
-	for (int i = 0; i < n_fn; ++i) if (!f[i].open(fn[i])) { fprintf(stderr, "ERROR: failed to open file '%s'\n", fn[i]); return -1; }
+	// A rank that fails locally (a file it cannot open or read) still takes part in the exchanges, with a poison word: its peers fail at once
+	// instead of waiting for the timeout.
+	const uint64_t POISON = ~0ULL;
+	FileMap f[2]; bool bad = false;
+	for (int i = 0; i < n_fn; ++i) if (!f[i].open(fn[i])) { fprintf(stderr, "ERROR: failed to open file '%s'\n", fn[i]); bad = true; }
 	auto share = [&](int i, int r) -> long long { return f[i].size * (long long)r / (long long)world; };
 	// (1) lines of my share of every file
 	uint64_t mine[2] = {0, 0}; std::vector<uint64_t> all(2 * (size_t)world);
-	for (int i = 0; i < n_fn; ++i) { const long long c = count_newlines(f[i].fd, share(i, rank), share(i, rank + 1), n_threads); if (c < 0) return -1; mine[i] = (uint64_t)c; }
+	for (int i = 0; i < n_fn && !bad; ++i) { const long long c = count_newlines(f[i].fd, share(i, rank), share(i, rank + 1), n_threads); if (c < 0) bad = true; else mine[i] = (uint64_t)c; }
+	if (bad) mine[0] = mine[1] = POISON;
 	if (ex.allgather(mine, 2, all.data())) return -2;
+	for (int r = 0; r < world; ++r) if (all[2 * (size_t)r] == POISON) { if (!bad) fprintf(stderr, "[airlift] rank %d: rank %d could not read its share of the input\n", rank, r); return -1; }
 	std::vector<long long> before[2];                  // newlines in front of each share
 	for (int i = 0; i < n_fn; ++i) { before[i].assign((size_t)world + 1, 0); for (int r = 0; r < world; ++r) before[i][(size_t)r + 1] = before[i][(size_t)r] + (long long)all[2 * (size_t)r + (size_t)i]; }
 	// (2) my first record: the first line start at or behind my share's first byte whose line number is a multiple of 4
@@ -181,7 +227,9 @@ int find_ranges(const char *const *fn, int n_fn, int rank, int world, int n_thre
 	else {
 		const long long s = share(0, rank);
 		// the line that contains byte s - 1 ends at the first newline at or after s - 1; lines in front of byte s - 1 ... count from `before`, corrected for the byte s - 1 itself
-		char prev = 0; if (pread(f[0].fd, &prev, 1, (off_t)(s - 1)) != 1) return -1;
+		// (s == 0: a file shorter than the number of ranks -- byte 0 is rank 0's, this rank looks for a later record start like any other)
+		char prev = 0; bool rd_bad = s > 0 && pread(f[0].fd, &prev, 1, (off_t)(s - 1)) != 1;
+		if (rd_bad) bad = true;
 		long long pos, ln;
 		if (prev == '\n') { pos = s; ln = before[0][(size_t)rank]; }                                  // a line starts exactly at s
 		else { pos = after_nth_newline(f[0].fd, s, f[0].size, 1); ln = before[0][(size_t)rank] + 1; }  // behind the line that straddles s
@@ -203,7 +251,9 @@ int find_ranges(const char *const *fn, int n_fn, int rank, int world, int n_thre
 	}
 	// (3) everybody's starts -> my ends
 	uint64_t st[2] = {(uint64_t)out->start[0], (uint64_t)out->start[1]};
+	if (bad) st[0] = st[1] = POISON;
 	if (ex.allgather(st, 2, all.data())) return -2;
+	for (int r = 0; r < world; ++r) if (all[2 * (size_t)r] == POISON) { if (!bad) fprintf(stderr, "[airlift] rank %d: rank %d could not find its first record\n", rank, r); return -1; }
 	for (int i = 0; i < n_fn; ++i) out->end[i] = rank + 1 < world ? (long long)all[2 * (size_t)(rank + 1) + (size_t)i] : f[i].size;
 	for (int i = 0; i < n_fn; ++i) if (out->end[i] < out->start[i]) out->end[i] = out->start[i];
 	return 0;
@@ -242,7 +292,9 @@ extern "C" int al_map_file_frag_ranked(const al_idx_t *mi, int n_fn, const char 
 	const bool timing = getenv("AL_TIMING") != nullptr;
 	int n_dev = 0; (void)hipGetDeviceCount(&n_dev);
 	if (device < 0) { const char *lr = getenv("LOCAL_RANK"); device = lr ? atoi(lr) : rank; if (n_dev > 0) device %= n_dev; }
-	// the exchange: RCCL when the ranks sit on distinct GPUs, files otherwise
+	// the launch's token (see agree_on_token), then the exchange: RCCL when the ranks sit on distinct GPUs, files otherwise
+	static const double proc_start_wall = [] { struct timespec ts; clock_gettime(CLOCK_REALTIME, &ts); return (double)ts.tv_sec + ts.tv_nsec * 1e-9; }();
+	if (world > 1 && !getenv("AL_RUN_ID")) { const int e = agree_on_token(dir, rank, timeout_s, proc_start_wall); if (e) return e; }   // (AL_RUN_ID: the caller vouches for a fresh id)
 	std::unique_ptr<FileExchange> fex(new FileExchange(dir, rank, world, timeout_s)); std::unique_ptr<RcclProcExchange> rx;
 	ProcExchange *ex = fex.get();
 	if (world > 1 && !getenv("AL_NO_RCCL") && n_dev >= world) {
@@ -260,20 +312,21 @@ extern "C" int al_map_file_frag_ranked(const al_idx_t *mi, int n_fn, const char 
 	if (timing && rank == 0) fprintf(stderr, "[airlift] %d ranks, exchanges by: %s\n", world, ex->name());
 	const double t0 = now_s();
 	RankRange rr;
-	{ const int e = find_ranges(fn, n_fn, rank, world, std::max(1, n_threads / 2), *ex, &rr); if (e) return e; }
+	{ const int e = find_ranges(fn, n_fn, rank, world, std::max(1, n_threads / 2), *ex, &rr); if (e) return e; }   // (every rank leaves here together: local failures travel as a poison word)
 	if (timing) fprintf(stderr, "[airlift] rank %d of %d: records from %lld; bytes [%lld, %lld) of '%s'%s found in %.3f s\n", rank, world, rr.first_record, rr.start[0], rr.end[0], fn[0], n_fn == 2 ? " (and the matching range of the second file)" : "", now_s() - t0);
 	// map my range into a part file
 	const std::string part = std::string(out_path) + ".part" + std::to_string(rank);
 	FILE *pf = fopen(part.c_str(), "wb");
-	if (!pf) { fprintf(stderr, "[airlift] rank %d: cannot create '%s': %s\n", rank, part.c_str(), strerror(errno)); return -3; }
 	AlStreamRange range; for (int i = 0; i < 2; ++i) { range.start[i] = rr.start[i]; range.end[i] = rr.end[i]; } range.header = rank == 0;
 	AlStreamResume rs;
-	int rc = al_stream_map_files(mi, n_fn, fn, opt, n_threads, pf, rg, &device, 1, &rs, &range);
+	int rc;
+	if (!pf) { fprintf(stderr, "[airlift] rank %d: cannot create '%s': %s\n", rank, part.c_str(), strerror(errno)); rc = -3; }   // (still joins the exchange below, with ok = 0)
+	else rc = al_stream_map_files(mi, n_fn, fn, opt, n_threads, pf, rg, &device, 1, &rs, &range);
 	if (rc == AL_STREAM_NA) { fprintf(stderr, "[airlift] rank %d: a multi-process run takes plain (uncompressed, four-line) FASTQ files only\n", rank); rc = -1; }
 	if (rc == 0 && rs.resume) { fprintf(stderr, "[airlift] rank %d: the input is not strict four-line FASTQ at byte %lld: not supported in a multi-process run\n", rank, rs.off[0]); rc = -1; }
-	if (fflush(pf) == EOF) rc = rc ? rc : -3;
-	const long long my_bytes = rc == 0 ? (long long)ftello(pf) : 0;
-	fclose(pf);
+	if (pf && fflush(pf) == EOF) rc = rc ? rc : -3;
+	const long long my_bytes = rc == 0 && pf ? (long long)ftello(pf) : 0;
+	if (pf) fclose(pf);
 	// the exchange of the north star: {ok, bytes} of every part -> offsets
 	uint64_t mine[2] = {rc == 0 ? 1ULL : 0ULL, (uint64_t)my_bytes}; std::vector<uint64_t> all(2 * (size_t)world);
 	int out_fd = -1;
@@ -291,7 +344,7 @@ extern "C" int al_map_file_frag_ranked(const al_idx_t *mi, int n_fn, const char 
 	uint64_t fin = rc == 0 ? 1 : 0;
 	if (ex->allgather(&fin, 1, all.data()) == 0) { for (int r = 0; r < world; ++r) if (!all[(size_t)r] && rc == 0) rc = -4; }
 	if (ex != fex.get()) fex->purge();                 // (the RCCL all-gather above was a barrier: nobody reads the files any more)
-	if (rank == 0) unlink((dir + "/.al_rccl_id_" + run_id()).c_str());
+	if (rank == 0) { unlink((dir + "/.al_rccl_id_" + run_id()).c_str()); unlink((dir + "/.al_token_" + run_id_base()).c_str()); }
 	if (timing) fprintf(stderr, "[airlift] rank %d: %lld bytes at offset %lld of the merged output; total %.3f s\n", rank, my_bytes, off, now_s() - t0);
 	return rc;
 }

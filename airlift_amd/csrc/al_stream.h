@@ -35,6 +35,7 @@ struct AlIngestResult {
 
 struct AlStreamSlot {
 	int device = 0; hipStream_t io = nullptr; hipEvent_t ev = nullptr;
+	hipEvent_t ev_out[2] = {nullptr, nullptr};   // 'piece copied' events of the SAM drain, created on THIS slot's device (an event must be recorded on a stream of its own device: the writer's shared ring must not own them when the lanes sit on different GPUs)
 	const al_idx_t *mi = nullptr;
 	int n_files = 1;
 	// input

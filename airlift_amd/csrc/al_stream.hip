@@ -324,6 +324,7 @@ int al_stream_slot_init(AlStreamSlot &S, const al_idx_t *mi, int device, int n_f
 	AL_HIP_CHECK(hipSetDevice(device));
 	AL_HIP_CHECK(hipStreamCreateWithFlags(&S.io, hipStreamNonBlocking));
 	AL_HIP_CHECK(hipEventCreateWithFlags(&S.ev, hipEventDisableTiming));
+	for (int i = 0; i < 2; ++i) AL_HIP_CHECK(hipEventCreateWithFlags(&S.ev_out[i], hipEventDisableTiming));
 	if (S.tabs.ensure(512) || S.st.ensure(16)) return -1;
 	uint8_t h[512]; memcpy(h, al_nt4(), 256); memcpy(h + 256, al_comp(), 256);
 	AL_HIP_CHECK(hipMemcpy(S.tabs.p, h, 512, hipMemcpyHostToDevice));
@@ -342,6 +343,7 @@ void al_stream_slot_destroy(AlStreamSlot &S)
 	(void)hipStreamSynchronize(S.io);
 	S.release();
 	(void)hipEventDestroy(S.ev); (void)hipStreamDestroy(S.io); S.io = nullptr; S.ev = nullptr;
+	for (int i = 0; i < 2; ++i) if (S.ev_out[i]) { (void)hipEventDestroy(S.ev_out[i]); S.ev_out[i] = nullptr; }
 }
 
 int al_stream_begin_text(AlStreamSlot &S, int i, size_t cap_bytes)

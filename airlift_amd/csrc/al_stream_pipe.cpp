@@ -213,16 +213,18 @@ int al_stream_map_files(const al_idx_t *mi, int n_fn, const char **fn, const al_
 	// SAM text leaves the device through a small ring of page-locked buffers (page-locking memory costs ~0.2 s per GB: no buffer of a
 	// batch's size): the copy of piece n + 1 runs while piece n is written
 	const size_t CH = (size_t)(getenv("AL_OUT_PIECE_MB") ? std::max(1, atoi(getenv("AL_OUT_PIECE_MB"))) : 32) << 20;
-	struct OutRing { char *buf[2] = {nullptr, nullptr}; hipEvent_t ev[2] = {nullptr, nullptr}; };
-	auto ring_make = [&](OutRing &r) -> bool { for (int i = 0; i < 2; ++i) if (hipHostMalloc((void **)&r.buf[i], CH, hipHostMallocDefault) != hipSuccess || hipEventCreateWithFlags(&r.ev[i], hipEventDisableTiming) != hipSuccess) return false; return true; };
-	auto ring_free = [&](OutRing &r) { for (int i = 0; i < 2; ++i) { if (r.buf[i]) (void)hipHostFree(r.buf[i]); if (r.ev[i]) (void)hipEventDestroy(r.ev[i]); } };
+	// (page-locked buffers only: the 'piece copied' events belong to the slot that is drained -- AlStreamSlot::ev_out, created on the slot's device;
+	//  an event of another device cannot be recorded on the slot's stream, which is what a ring-owned pair amounted to with lanes on several GPUs)
+	struct OutRing { char *buf[2] = {nullptr, nullptr}; };
+	auto ring_make = [&](OutRing &r) -> bool { for (int i = 0; i < 2; ++i) if (hipHostMalloc((void **)&r.buf[i], CH, hipHostMallocDefault) != hipSuccess) return false; return true; };
+	auto ring_free = [&](OutRing &r) { for (int i = 0; i < 2; ++i) if (r.buf[i]) (void)hipHostFree(r.buf[i]); };
 	// text [0, n) of slot S through ring r to sink(ptr, len)
 	auto drain_sam = [&](AlStreamSlot &S, OutRing &r, const std::function<bool(const char *, size_t)> &sink) -> int {
 		const uint64_t n = S.sam_bytes; const uint64_t np = (n + CH - 1) / CH;
-		if (np && al_stream_sam_fetch(S, 0, std::min<uint64_t>(CH, n), r.buf[0], r.ev[0])) return -1;
+		if (np && al_stream_sam_fetch(S, 0, std::min<uint64_t>(CH, n), r.buf[0], S.ev_out[0])) return -1;
 		for (uint64_t c = 0; c < np; ++c) {
-			if (c + 1 < np && al_stream_sam_fetch(S, (c + 1) * CH, std::min<uint64_t>(CH, n - (c + 1) * CH), r.buf[(c + 1) & 1], r.ev[(c + 1) & 1])) return -1;
-			if (hipEventSynchronize(r.ev[c & 1]) != hipSuccess) return -1;
+			if (c + 1 < np && al_stream_sam_fetch(S, (c + 1) * CH, std::min<uint64_t>(CH, n - (c + 1) * CH), r.buf[(c + 1) & 1], S.ev_out[(c + 1) & 1])) return -1;
+			if (hipEventSynchronize(S.ev_out[c & 1]) != hipSuccess) return -1;
 			if (!sink(r.buf[c & 1], (size_t)std::min<uint64_t>(CH, n - c * CH))) return -3;
 		}
 		return 0;
@@ -413,7 +415,13 @@ int al_stream_map_files(const al_idx_t *mi, int n_fn, const char **fn, const al_
 				else { const AlAllocStat &as = al_alloc_stat(); const double ns = (double)as.dev_ns.load(), by = (double)as.dev_bytes.load();
 				       if (est_total_reads.load() / NL >= 6000000 && ns > 0 && by / (ns * 1e-9) >= 100e9) probe_mult = 8; }
 			}
-			const int mr = (!sized.load() && k > 0) ? std::min((probe_mult ? probe_mult : 4) * probe_reads, reads_cap_k.load()) : max_reads.load();
+			int mr = (!sized.load() && k > 0) ? std::min((probe_mult ? probe_mult : 4) * probe_reads, reads_cap_k.load()) : max_reads.load();
+			{   // a slot's text block of one file stays below 2^31 bytes (al_stream_begin_text refuses more): long reads / huge batches get fewer reads per batch
+				size_t cmax = 0; for (int i = 0; i < n_fn; ++i) cmax = std::max(cmax, carry[i].size());
+				const double room = 1.9e9 - (double)cmax - 2.0 * (double)(PIECE + 16);
+				const double lim = room > 0 ? room / (bytes_per_read * 1.02) * (double)n_fn : 2.0;
+				if ((double)mr > lim) mr = (int)std::max(2.0, lim);
+			}
 			int err = 0;
 			const double t1 = now_s();
 			for (int i = 0; i < n_fn && !err; ++i) {
