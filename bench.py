@@ -123,8 +123,8 @@ def file_to_file(tmp, ref_fa, a, arr, ref, resident_value):
             pass
         out = os.path.join(out_dir, "f2f_out.sam"); nt = min(os.cpu_count() or 1, 32)
         runs = []
-        for rep in range(2):          # the second run is the steady one (the first process on a box pays the driver's first touch of the device memory)
-            time.sleep(5.0)           # the process before this one (this script's own contexts, or the first run) has just given back > 100 GB: the driver scrubs it in the background, and a process that starts at once waits for that
+        for rep in range(2):          # reported as {first run, second run}: the first is what a user's cold run gets, nothing is picked
+            time.sleep(a.f2f_sleep)   # (stated in the record) the process before this one -- this script's own contexts, or the first run -- has just given back > 100 GB, which the driver scrubs in the background; a process that starts at once waits for that
             t0 = time.time()
             rc = subprocess.run([cli, "-ax", "sr", "-t", str(nt), "-o", out, os.path.join(tmp, ref_fa), f1, f2], stderr=subprocess.PIPE, env=dict(os.environ, AL_PG_PLAIN="1", AL_TIMING="1"))
             wall = time.time() - t0
@@ -137,12 +137,17 @@ def file_to_file(tmp, ref_fa, a, arr, ref, resident_value):
             runs.append({"wall_s": wall, "pipeline_s": float(m.group(3)) if m else None, "records": int(m.group(1)) if m else None, "sam_mb": float(m.group(2)) if m else None,
                          "index_build_s": float(mi.group(1)) if mi else None, "device_alloc_gb": float(ma.group(2)) if ma else None, "device_alloc_s": float(ma.group(3)) if ma else None,
                          "batch_reads": int(mb.group(1)) if mb else None, "contexts": int(mb.group(2)) if mb else None, "slots": int(mb.group(3)) if mb else None})
-        best = min((r for r in runs if r["pipeline_s"]), key=lambda r: r["pipeline_s"], default=None)
-        res = {"pairs": n, "reads": 2 * n, "host_threads": nt, "storage": shm, "output_storage": out_dir, "fastq_generation_s": t_gen, "runs": runs}
+        best = next((r for r in runs if r["pipeline_s"]), None)     # the FIRST run is the headline of this leg
+        for r in runs:
+            if r["pipeline_s"]:
+                r["reads_per_s"] = 2 * n / r["pipeline_s"]; r["frac_of_resident_value"] = r["reads_per_s"] / resident_value if resident_value else None
+                if r.get("device_alloc_gb") and r.get("batch_reads") and r.get("contexts"):   # what the mapping contexts hold per read of a batch (the index, ~23 GB on C4, is in device_alloc_gb too: taken off at its file-independent size when known)
+                    r["workspace_kb_per_read_incl_index"] = r["device_alloc_gb"] * 1e6 / (r["batch_reads"] * r["contexts"])
+        res = {"pairs": n, "reads": 2 * n, "host_threads": nt, "storage": shm, "output_storage": out_dir, "fastq_generation_s": t_gen, "sleep_before_each_run_s": a.f2f_sleep, "runs": runs}
         if best:
             res.update({"reads_per_s": 2 * n / best["pipeline_s"], "pipeline_s": best["pipeline_s"], "startup_s": best["wall_s"] - best["pipeline_s"],
                         "whole_process_reads_per_s": 2 * n / best["wall_s"], "frac_of_resident_value": (2 * n / best["pipeline_s"]) / resident_value if resident_value else None,
-                        "note": "FASTQ -> SAM through the drop-in: raw file blocks to HBM, record parsing / 4-bit packing / SAM text by kernels, batches of `batch_reads` on `contexts` mapping contexts; pipeline_s = first block read -> last byte written (the process's own clock), start-up (FASTA load + index build on the GPU + contexts) apart; best of two runs"})
+                        "note": "FASTQ -> SAM through the drop-in: raw file blocks to HBM, record parsing / 4-bit packing / SAM text by kernels, batches of `batch_reads` on `contexts` mapping contexts; pipeline_s = first block read -> last byte written (the process's own clock), start-up (FASTA load + index build on the GPU + contexts) apart; reads_per_s = the FIRST (cold) run of the process, the second run is in `runs`"})
         # parity: the first cpu-sample pairs are the reads the CPU comparator mapped: its SAM must be the head of this one
         ref_sam = os.path.join(tmp, "cpu.sam")
         if os.path.exists(ref_sam) and os.path.exists(out):
@@ -244,6 +249,7 @@ def main():
     ap.add_argument("--read-len", type=int, default=0, help="default: the config's (150; C5: 250)")
     ap.add_argument("--cpu-sample-pairs", type=int, default=500_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--f2f-sleep", type=float, default=5.0, help="seconds to wait before each process of the file-to-file leg (recorded in the output)")
     ap.add_argument("--f2f-pairs", type=int, default=4_000_000, help="pairs of the file-to-file leg (FASTQ files -> airlift-align -> SAM file; rank 0, N=1 only; 0 = skip)")
     ap.add_argument("--ins-mean", type=int, default=0, help="mean insert size override (short inserts make the mates overlap: equal-key anchors)")
     ap.add_argument("--config", default="c4", help="workload of tools/gen_synth.py: c4 (default: the configuration BASELINE.json's metric is quoted on -- 150 bp PE against a human-sized reference; fits one GPU), c5 (250 bp), c3 (100 Mbp), c2 (yeast-sized), c2r, c4s, c3u, c4u")
@@ -378,7 +384,7 @@ def main():
             ("sketch", ["sketch"], float(st.bytes_in) + 16.0 * M),
             ("seed_lookup", ["seed_lookup", "scan", "size_order"], 16.0 * M),
             ("anchor_sort", ["anchor_sort_small", "anchor_sort", "anchor_sort_blk", "anchor_sort_big", "anchor_heap"], 24.0 * A1),
-            ("chain", ["chain_lds32", "chain_lds48", "chain_lds64", "chain_lds128", "seg_find", "seg_chain_lds", "seg_chain_wave", "seg_merge"], 16.0 * A1),
+            ("chain", ["chain_lds32", "chain_lds48", "chain_lds64", "chain_lds128", "chain_tile", "chain_deferred", "chain_fallback", "chain_ties"], 16.0 * A1),
             ("rechain (max_occ pass: seed + sort + chain)", ["rechain"], 56.0 * (An - A1)),
             ("regs (chain_post / seg_gen: no bytes in the contract)", ["regs"], 0.0),
             ("extension", ["ext_prep", "ext_sort", "ext_dp_lane", "ext_dp_g4", "ext_dp_g8", "ext_dp_g22", "ext_finish", "compact"], 0.5 * Wb + float(st.bytes_out)),
@@ -410,6 +416,19 @@ def main():
                                     "jobs": int(st.dp_jobs[7]) if dom == "ext_dp_g22" else None,
                                     "note": ("integer-VALU bound: %.0f target bases x ~150 query bases of affine-gap DP cells per launch; its HBM bytes are the 4-bit reference windows and the result records" % float(st.dp_target_bases[7])) if dom == "ext_dp_g22" else (None if dom_bytes is not None else "bytes of this kernel's share of the stage are not separable: see its stage row")},
                 "stages": stages}
+        # The extension DP is bound by integer VALU issue, not by HBM: its row against THAT ceiling.  Wave-instructions per launch come from the
+        # committed SQ_INSTS_VALU pass (profiles/traffic.json, tools/prof.sh); the ceiling is the measured integer issue rate of a SIMD, one
+        # wave-instruction per 4.4 cycles whatever the occupancy (tools/micro/valu_issue.hip), x 1024 SIMDs x 2.4 GHz.
+        VALU_CEIL = 1024 * 2.4e9 / 4.4
+        valu = []
+        dpk = {"ext_dp_g4": "k_ext_dp<4, 512, 64>", "ext_dp_g8": "k_ext_dp<8, 512, 128>", "ext_dp_g22": "k_ext_dp<22, 512, 352>"}
+        for iv in ("ext_dp_g4", "ext_dp_g8", "ext_dp_g22"):
+            ins = (tj.get("kernels", {}).get(dpk[iv]) or {}).get("valu_insts_per_launch") if tj.get("workload") == a.config else None
+            ci = {"ext_dp_g4": 5, "ext_dp_g8": 6, "ext_dp_g22": 7}[iv]
+            valu.append({"interval": iv, "kernel": dpk[iv], "ms": per.get(iv), "jobs": int(st.dp_jobs[ci]), "target_bases": int(st.dp_target_bases[ci]),
+                         "valu_wave_insts_per_launch_from_committed_profile": ins, "wave_insts_per_s": (ins / (per[iv] * 1e-3)) if ins and per.get(iv) else None,
+                         "issue_ceiling_wave_insts_per_s": VALU_CEIL, "frac_of_issue_ceiling": (ins / (per[iv] * 1e-3) / VALU_CEIL) if ins and per.get(iv) else None})
+        roof["valu"] = valu
         out = {
             "metric": "reads/sec remapped (%d bp PE)" % a.read_len, "value": 2.0 * a.pairs * world * a.steps / dt, "unit": "reads/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True,

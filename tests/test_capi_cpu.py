@@ -273,3 +273,11 @@ def test_rank_ranges_tile_the_input(A, tmp_path):
     for w in (1, 2, 3, 8, 16):
         assert L.al_dbg_ranked_selftest(str(tmp_path / "a.fq").encode(), str(tmp_path / "b.fq").encode(), w, str(tmp_path).encode()) == 0, w
     assert L.al_dbg_ranked_selftest(str(tmp_path / "b.fq").encode(), b"", 4, str(tmp_path).encode()) == 0
+    # an empty file (AirLift's singleton FASTQ often is) and a file shorter than the number of ranks: every rank gets a (possibly empty) range
+    open(tmp_path / "e.fq", "wb").close()
+    with open(tmp_path / "t.fq", "wb") as ft:
+        ft.write(b"@x\nA\n+\nI\n")
+    for w in (2, 5, 16):
+        assert L.al_dbg_ranked_selftest(str(tmp_path / "e.fq").encode(), b"", w, str(tmp_path).encode()) == 0, ("empty", w)
+        assert L.al_dbg_ranked_selftest(str(tmp_path / "t.fq").encode(), b"", w, str(tmp_path).encode()) == 0, ("tiny", w)
+        assert L.al_dbg_ranked_selftest(str(tmp_path / "t.fq").encode(), str(tmp_path / "t.fq").encode(), w, str(tmp_path).encode()) == 0, ("tiny pair", w)

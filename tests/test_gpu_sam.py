@@ -161,6 +161,23 @@ def test_yeast100k_digest(tmp_path):
     assert hashlib.md5(r.stdout).hexdigest() == m["sam_md5"]
 
 
+def test_output_file_with_a_launchers_world_size_of_one(golden_unpacked, tmp_path):
+    """`-o FILE` when WORLD_SIZE is in the environment but the run is a single process (torchrun --nproc_per_node=1, or WORLD_SIZE exported
+    without --rank / --ranked): the file is written, nothing goes to stdout (main.c:183-190)."""
+    d = golden_unpacked["g1_mt150pe"]
+    m = json.load(open(os.path.join(d, "meta.json")))
+    exp = open(os.path.join(d, "expected.sam"), "rb").read()
+    for env in (dict(WORLD_SIZE="1"), dict(WORLD_SIZE="1", RANK="0"), dict(WORLD_SIZE="4")):
+        out = tmp_path / "o.sam"
+        if out.exists():
+            out.unlink()
+        extra = ["--ranked"] if "RANK" in env else []
+        cmd = [CLI, "-ax", "sr"] + extra + (["-R", m["rg"]] if m.get("rg") else []) + ["-o", str(out), m["ref"]] + m["reads"]
+        r = subprocess.run(cmd, cwd=d, capture_output=True, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr.decode()[-1500:]
+        assert r.stdout == b"" and out.read_bytes() == exp, env
+
+
 def test_bwa_style_argv(golden_unpacked):
     """B1: `<aligner> mem -R RG -t N REF R1 R2` (src/0-align_reads.sh:13) gives the same records."""
     d = golden_unpacked["g1_mt150pe"]

@@ -12,6 +12,7 @@ ARGS="--no-cpu-baseline --f2f-pairs 0 --steps 3 --warmup 1 $*"
 rocprofv3 --kernel-trace --stats -d $OUT/trace --output-format csv -- python3 $REPO/bench.py $ARGS > $OUT/bench_trace.json 2> $OUT/trace.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch --output-format csv -- python3 $REPO/bench.py $ARGS > $OUT/bench_fetch.json 2> $OUT/fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write --output-format csv -- python3 $REPO/bench.py $ARGS > $OUT/bench_write.json 2> $OUT/write.err
+rocprofv3 --pmc SQ_INSTS_VALU --kernel-trace -d $OUT/pmc_valu --output-format csv -- python3 $REPO/bench.py $ARGS > $OUT/bench_valu.json 2> $OUT/valu.err
 python3 $REPO/tools/prof_summary.py $OUT > $OUT/summary.md 2>&1
 # keep only small files for the merge back (<= 64 MiB)
 find $OUT -name "*.csv" -size +6M -delete

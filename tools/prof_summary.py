@@ -55,10 +55,20 @@ try:
                 nm = "index build: " + nm
             e = per.setdefault(nm, {"FETCH_SIZE": [0, 0.0], "WRITE_SIZE": [0, 0.0]})
             e[ctr][0] += 1; e[ctr][1] += float(row.get("Counter_Value", 0))
+    valu = {}
+    vf = glob.glob(os.path.join(d, "pmc_valu", "**", "*counter_collection.csv"), recursive=True)
+    if vf:
+        acc = defaultdict(lambda: [0, 0.0])
+        for row in csv.DictReader(open(vf[0])):
+            if row.get("Counter_Name") == "SQ_INSTS_VALU":
+                nm = short(row.get("Kernel_Name", "")); acc[nm][0] += 1; acc[nm][1] += float(row.get("Counter_Value", 0))
+        valu = {k: v[1] / max(v[0], 1) for k, v in acc.items()}
     kernels = {}
     for k, e in per.items():
         f = e["FETCH_SIZE"][1] / max(e["FETCH_SIZE"][0], 1) * 1024.0; w = e["WRITE_SIZE"][1] / max(e["WRITE_SIZE"][0], 1) * 1024.0
         kernels[k] = {"bytes_per_launch": f + w, "fetch_bytes": f, "write_bytes": w, "fetch_bytes_x2_upper": 2 * f, "launches": e["FETCH_SIZE"][0]}
+        if k in valu:
+            kernels[k]["valu_insts_per_launch"] = valu[k]        # SQ_INSTS_VALU: wave-instructions (own pass)
     # totals per step: every dispatch of the run (index build and stats kernels included) / (warmup + steps) of the bench line
     meta = {}
     try:
