@@ -219,6 +219,25 @@ int AlBgzf::flush_full()
 	buf.erase(buf.begin(), buf.begin() + nb * BGZF_IN);
 	return 0;
 }
+int AlBgzf::flush_all()
+{
+	if (flush_full()) return -1;
+	if (!buf.empty()) { std::vector<unsigned char> b; if (bgzf_block(buf.data(), buf.size(), level, b) || fwrite(b.data(), 1, b.size(), out) != b.size()) return -1; buf.clear(); }
+	return 0;
+}
+const unsigned char AL_BGZF_EOF[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+int al_bgzf_blocks(const char *src, size_t n, int level, int n_threads, std::vector<char> &dst)
+{
+	const size_t nb = (n + BGZF_IN - 1) / BGZF_IN;
+	if (nb == 0) return 0;
+	std::vector<std::vector<unsigned char>> blk(nb); std::vector<int> bad(n_threads > 1 ? n_threads : 1, 0);
+	al_parallel_for(n_threads, nb, [&](size_t lo, size_t hi, int t) { for (size_t b = lo; b < hi; ++b) if (bgzf_block(src + b * BGZF_IN, std::min(BGZF_IN, n - b * BGZF_IN), level, blk[b])) bad[t] = 1; });
+	for (int b : bad) if (b) return -1;
+	size_t tot = 0; for (auto &b : blk) tot += b.size();
+	dst.reserve(dst.size() + tot);
+	for (auto &b : blk) dst.insert(dst.end(), b.begin(), b.end());
+	return 0;
+}
 int AlBgzf::finish()
 {
 	if (flush_full()) return -1;

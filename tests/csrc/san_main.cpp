@@ -59,7 +59,7 @@ int main(int argc, char **argv)
 		{ const int r = al_dbg_ranked_selftest(path("tiny.fq").c_str(), path("tiny.fq").c_str(), 6, g_dir.c_str()); if (r != 0) { fprintf(stderr, "rank range self-test, 6 ranks on 2 records: %d\n", r); ++bad; } }
 	}
 	// ordered output of several lanes
-	for (int lanes : {1, 2, 5}) for (int off : {0, 1}) { const int r = al_dbg_ordered_out_selftest(path("o.txt").c_str(), lanes, 40, off); if (r != 0) { fprintf(stderr, "ordered output self-test (%d lanes, offsets %d): %d\n", lanes, off, r); ++bad; } }
+	for (int lanes : {1, 2, 5}) for (int off : {0, 1, 2}) { const int r = al_dbg_ordered_out_selftest(path("o.txt").c_str(), lanes, 40, off); if (r != 0) { fprintf(stderr, "ordered output self-test (%d lanes, offsets %d): %d\n", lanes, off, r); ++bad; } }
 	// SAM formatter (device routine compiled for the host) against al_write_sam
 	{ const int r = al_dbg_sam_selftest(3, 3000); if (r != 0) { fprintf(stderr, "SAM formatter self-test: %d differences\n", r); ++bad; } }
 	// read extraction: a corrupt / truncated BAM must come back as an error, not a crash

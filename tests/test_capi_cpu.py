@@ -215,10 +215,12 @@ def test_pg_line_matches_the_forks_main(A, golden_unpacked, tmp_path):
     idx.close()
 
 
-@pytest.mark.parametrize("lanes,offsets", [(1, 0), (2, 1), (2, 0), (5, 1), (8, 1), (8, 0)])
+@pytest.mark.parametrize("lanes,offsets", [(1, 0), (2, 1), (2, 0), (5, 1), (8, 1), (8, 0), (1, 2), (2, 2), (3, 2), (8, 2)])
 def test_multi_lane_output_order(A, tmp_path, lanes, offsets):
     """Product path of N>1 (al_map_file_frag_multi): lanes finish their blocks in any order, the output file must hold
-    header + blocks in (batch, lane) order -- offsets from the all-gather of {records, bytes} + pwrite, or ordered turns."""
+    header + blocks in (batch, lane) order -- offsets from the all-gather of {records, bytes} + pwrite, or ordered turns.
+    offsets == 2: BAM bytes, every lane deflates its own share into whole BGZF blocks and writes them at the exchanged offset (SURVEY 8e:
+    "BGZF blocks are rank-local"); the file is a sequence of valid BGZF members ending in the EOF block and inflates to header + blocks."""
     L = A.load()
     L.al_dbg_ordered_out_selftest.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int]; L.al_dbg_ordered_out_selftest.restype = C.c_int
     assert L.al_dbg_ordered_out_selftest(str(tmp_path / "o.sam").encode(), lanes, 40, offsets) == 0
