@@ -1609,9 +1609,11 @@ __device__ __forceinline__ int d_job_class(int qlen, int tlen, int lane_ok)
 
 extern "C" __global__ void __launch_bounds__(256, AL_LB_PREP)
 k_ext_prep(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_off, const uint32_t *__restrict__ rd_len,
-           const uint32_t *__restrict__ frag_first, WsBase W, AlignShared G, ExtShared E, int n_frag, AlParams P, int tmax, int qmax)
+           const uint32_t *__restrict__ frag_first, WsBase W, AlignShared G, ExtShared E, int n_frag, AlParams P, int tmax, int qmax,
+           const uint32_t *__restrict__ order /* fragments by number of hits, descending: the lanes of a wavefront walk equally many hits (a lane per fragment runs as long as its wavefront's longest) */)
 {
-	const int f = blockIdx.x * blockDim.x + threadIdx.x;
+	const int t_ = blockIdx.x * blockDim.x + threadIdx.x;
+	const int f = t_ < n_frag ? (order ? (int)order[t_] : t_) : n_frag;
 	unsigned long long c_regs = 0, c_ref = 0, c_cig = 0;
 	__shared__ unsigned s_hist[AL_NCLS + 1], s_tl[AL_NCLS + 1];                // jobs / target bases per class of this block (no run-time indexed local arrays: see k_regs)
 	if (threadIdx.x <= AL_NCLS) { s_hist[threadIdx.x] = 0; s_tl[threadIdx.x] = 0; }
@@ -2106,9 +2108,10 @@ extern "C" __global__ void __launch_bounds__(256, AL_LB_FIN)
 k_ext_finish(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_off, const uint32_t *__restrict__ rd_len,
              const uint32_t *__restrict__ frag_first, const int32_t *__restrict__ frag_rep, WsBase W, AlignShared G, ExtShared E,
              AlLogTab lt, uint64_t *__restrict__ sc_ws, const uint64_t *__restrict__ sc_off, int n_frag, AlParams P, uint32_t *__restrict__ slow_list, uint32_t *__restrict__ n_slow,
-             int early_done /* fragments k_ext_prep marked slow are already with the monolithic kernel (side stream) */)
+             int early_done /* fragments k_ext_prep marked slow are already with the monolithic kernel (side stream) */, const uint32_t *__restrict__ order /* as k_ext_prep */)
 {
-	const int f = blockIdx.x * blockDim.x + threadIdx.x;
+	const int t_ = blockIdx.x * blockDim.x + threadIdx.x;
+	const int f = t_ < n_frag ? (order ? (int)order[t_] : t_) : n_frag;
 	__shared__ uint32_t s_cig[AL_FCIG * 256];                                  // per-lane CIGAR assembly buffer, [word][lane]
 	unsigned long long c_regs = 0, c_ref = 0, c_cig = 0;
 	if (f < n_frag && W.frag_nu[f] != 0 && !(early_done && E.frag_slow[f] != 0)) {
@@ -2293,6 +2296,7 @@ struct AlignState {            // lives in al_ctx_s::align_state (opaque there)
 	DevBuf<ExtJob> jobs; DevBuf<ExtOut> outs; DevBuf<RegExt> rext;
 	DevBuf<uint64_t> job_off, sc_off, sc_ws; DevBuf<uint32_t> n_jobs, n_sc, job_key, job_key2, job_idx, job_idx2, frag_slow, slow_list, early_list;
 	DevBuf<uint8_t> sort_tmp;
+	DevBuf<uint32_t> ford_key, ford_idx, ford;   // fragments ordered by their number of hits (k_ext_prep / k_ext_finish)
 	int logtab_a = -1, logtab_n = 0;
 	uint64_t out_total = 0;
 };
@@ -2313,7 +2317,7 @@ void al_align_state_free(al_ctx_t *c)
 	AlignState *s = it->second;
 	s->regs0.release(); s->mregs.release(); s->rtmp.release(); s->out.release(); s->aux128.release(); s->seg_a.release(); s->aux64.release(); s->seg_u.release();
 	s->nu_off.release(); s->out_off.release(); s->auxi.release(); s->reg_cnt.release(); s->seg_na.release(); s->arena.release(); s->gws.release(); s->long_state.release(); s->logtab.release(); s->dbgbuf.release(); s->hist.release(); s->jobs.release(); s->outs.release(); s->rext.release(); s->seg_fast.release(); s->regs_n0.release(); s->cap2.release(); s->b2_off.release();
-	s->job_off.release(); s->sc_off.release(); s->sc_ws.release(); s->n_jobs.release(); s->n_sc.release(); s->job_key.release(); s->job_key2.release(); s->job_idx.release(); s->job_idx2.release(); s->frag_slow.release(); s->slow_list.release(); s->early_list.release(); s->gws2.release(); s->sort_tmp.release();
+	s->job_off.release(); s->sc_off.release(); s->sc_ws.release(); s->n_jobs.release(); s->n_sc.release(); s->job_key.release(); s->job_key2.release(); s->job_idx.release(); s->job_idx2.release(); s->frag_slow.release(); s->slow_list.release(); s->early_list.release(); s->gws2.release(); s->sort_tmp.release(); s->ford_key.release(); s->ford_idx.release(); s->ford.release();
 	delete s; g_states.erase(it);
 }
 
@@ -2498,6 +2502,18 @@ int al_run_align_stage(al_ctx_t *c)
 		// ---- fast path: prep -> size-sorted DP job queue -> finish -> (slow list) monolithic
 		if (A->n_jobs.ensure(nf + 2) || A->n_sc.ensure(nf + 2) || A->job_off.ensure(nf + 2) || A->sc_off.ensure(nf + 2) || A->frag_slow.ensure(nf + 1) || A->slow_list.ensure(nf + 1) || A->hist.ensure(AL_HIST_N)) return -1;
 		hipLaunchKernelGGL(k_ext_counts, dim3((nf + 256) / 256), dim3(256), 0, s, c->frag_first.p, W, A->n_jobs.p, A->n_sc.p, nf);
+		// fragments by number of hits, descending: k_ext_prep / k_ext_finish give a lane to a fragment and a wavefront runs as long as its longest lane
+		// (a read pair inside repeats keeps a primary and twenty secondaries per mate, most pairs one hit per mate)
+		const uint32_t *frag_ord = nullptr;
+		if (!((c->P.dbg >> 18) & 1)) {
+			if (A->ford_key.ensure(nf + 1) || A->ford_idx.ensure(nf + 1) || A->ford.ensure(nf + 1)) return -1;
+			hipLaunchKernelGGL(k_iota, dim3((nf + 255) / 256), dim3(256), 0, s, A->ford_idx.p, (uint32_t)nf);
+			size_t bytes = 0;
+			AL_HIP_CHECK(rocprim::radix_sort_pairs_desc(nullptr, bytes, (const uint32_t *)A->n_jobs.p, A->ford_key.p, (const uint32_t *)A->ford_idx.p, A->ford.p, nf, 0, 16, s));
+			if (A->sort_tmp.ensure(bytes + 16)) return -1;
+			AL_HIP_CHECK(rocprim::radix_sort_pairs_desc(A->sort_tmp.p, bytes, (const uint32_t *)A->n_jobs.p, A->ford_key.p, (const uint32_t *)A->ford_idx.p, A->ford.p, nf, 0, 16, s));
+			frag_ord = A->ford.p;
+		}
 		if (scan32(c, A->n_jobs.p, A->job_off.p, nf) || scan32(c, A->n_sc.p, A->sc_off.p, nf)) return -1;
 		uint64_t tot[2] = {0, 0};
 		AL_HIP_CHECK(hipMemcpyAsync(&tot[0], A->job_off.p + nf, 8, hipMemcpyDeviceToHost, s));
@@ -2508,7 +2524,7 @@ int al_run_align_stage(al_ctx_t *c)
 		    A->sc_ws.ensure(tot[1] + 1)) return -1;
 		AL_HIP_CHECK(hipMemsetAsync(A->hist.p, 0, AL_HIST_N * 8, s));
 		ExtShared E; E.jobs = A->jobs.p; E.outs = A->outs.p; E.rext = A->rext.p; E.job_off = A->job_off.p; E.frag_slow = A->frag_slow.p; E.job_key = A->job_key.p; E.hist = A->hist.p;
-		hipLaunchKernelGGL(k_ext_prep, dim3((nf + 255) / 256), dim3(256), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, c->frag_first.p, W, G, E, nf, c->P, tmax, qmax);
+		hipLaunchKernelGGL(k_ext_prep, dim3((nf + 255) / 256), dim3(256), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, c->frag_first.p, W, G, E, nf, c->P, tmax, qmax, frag_ord);
 		// fragments k_ext_prep left to the monolithic kernel are known now: a handful of them, milliseconds each on one 16-lane group --
 		// they go to the side stream at once and run beside the DP jobs
 		uint32_t *const n_early_d = (uint32_t *)(A->hist.p + 20); uint32_t n_early = 0;
@@ -2598,7 +2614,7 @@ int al_run_align_stage(al_ctx_t *c)
 		else { AL_HIP_CHECK(hipEventRecord(c->ev[ST_EXT_SORT + 1], s)); for (int i = ST_EXT_DP_LANE; i < ST_EXT_DP_G22; ++i) AL_HIP_CHECK(hipEventRecord(c->ev[i + 1], s)); }
 		AL_HIP_CHECK(hipEventRecord(c->ev[ST_EXT_DP_G22 + 1], s));
 		uint32_t *n_slow_d = (uint32_t *)(c->counters.p + 14);
-		hipLaunchKernelGGL(k_ext_finish, dim3((nf + 255) / 256), dim3(256), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, c->frag_first.p, c->frag_rep.p, W, G, E, lt, A->sc_ws.p, A->sc_off.p, nf, c->P, A->slow_list.p, n_slow_d, 1);
+		hipLaunchKernelGGL(k_ext_finish, dim3((nf + 255) / 256), dim3(256), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, c->frag_first.p, c->frag_rep.p, W, G, E, lt, A->sc_ws.p, A->sc_off.p, nf, c->P, A->slow_list.p, n_slow_d, 1, frag_ord);
 		uint32_t n_slow = 0;
 		AL_HIP_CHECK(hipMemcpyAsync(&n_slow, n_slow_d, 4, hipMemcpyDeviceToHost, s));
 		AL_HIP_CHECK(hipStreamSynchronize(s));
