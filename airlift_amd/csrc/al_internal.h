@@ -142,7 +142,7 @@ struct LbThr { uint32_t v[16]; int n; };     // thresholds of k_lower_bounds
 // each kernel with real weight has its own interval so that bench.py's per-kernel times line up with rocprofv3's
 enum AlStage { ST_SKETCH = 0, ST_SEED, ST_SCAN, ST_ORDER, ST_ANCHOR_SORT_S, ST_ANCHOR_SORT, ST_ANCHOR_SORT_BLK, ST_ANCHOR_SORT_BIG, ST_ANCHOR_HEAP,
                ST_CHAIN_LDS32, ST_CHAIN_LDS48, ST_CHAIN_LDS64, ST_CHAIN_LDS128, ST_SEG_FIND, ST_SEG_CHAIN_LDS, ST_SEG_CHAIN_WAVE, ST_SEG_MERGE, ST_RECHAIN,
-               ST_REGS, ST_EXT_PREP, ST_EXT_SORT, ST_EXT_DP_LANE, ST_EXT_DP_G4, ST_EXT_DP_G8, ST_EXT_DP_G22, ST_EXT_FINISH, ST_COMPACT, ST_N };
+               ST_REGS, ST_EXT_PREP, ST_EXT_SORT, ST_EXT_DP_LANE, ST_EXT_DP_G4, ST_EXT_DP_G8, ST_EXT_DP_G12, ST_EXT_DP_G16, ST_EXT_DP_G22, ST_EXT_FINISH, ST_COMPACT, ST_N };
 #define ST_CHAIN ST_SEG_MERGE
 #define ST_EXT_DP ST_EXT_DP_G22
 

@@ -1599,7 +1599,7 @@ struct ExtShared {
 
 #define AL_LANE_QC 64              // longest query a lane-per-job DP handles
 #define AL_NCLS 10                 // job classes: 0..2 lane-per-job (target <= 16/32/64), 3..8 group DP (NB = 1,2,4,8,22,32), 9 LDS-row DP; 10 = empty slot
-#define AL_HIST_N 40               // [0..AL_NCLS] jobs per class, [12..17] job cursors of the group-DP classes, [20] fragments left to the monolithic kernel by prep, [24..24+AL_NCLS] target bases per class
+#define AL_HIST_N 40               // [0..AL_NCLS] jobs per class, [12..19] job cursors of the group-DP kernels, [20] fragments left to the monolithic kernel by prep, [24..24+AL_NCLS] target bases per class, [36..37] jobs of class 7 with <= 12 / 13 ... 16 blocks
 __device__ __forceinline__ int d_job_class(int qlen, int tlen, int lane_ok)
 {
 	const int b = (tlen + 15) / 16;
@@ -1615,8 +1615,9 @@ k_ext_prep(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_
 	const int t_ = blockIdx.x * blockDim.x + threadIdx.x;
 	const int f = t_ < n_frag ? (order ? (int)order[t_] : t_) : n_frag;
 	unsigned long long c_regs = 0, c_ref = 0, c_cig = 0;
-	__shared__ unsigned s_hist[AL_NCLS + 1], s_tl[AL_NCLS + 1];                // jobs / target bases per class of this block (no run-time indexed local arrays: see k_regs)
+	__shared__ unsigned s_hist[AL_NCLS + 1], s_tl[AL_NCLS + 1], s_sub[2];      // jobs / target bases per class of this block (no run-time indexed local arrays: see k_regs); s_sub: jobs of class 7 with <= 12 / 13 ... 16 blocks
 	if (threadIdx.x <= AL_NCLS) { s_hist[threadIdx.x] = 0; s_tl[threadIdx.x] = 0; }
+	if (threadIdx.x < 2) s_sub[threadIdx.x] = 0;
 	__syncthreads();
 	const int lane_ok = !((P.dbg >> 29) & 1);
 	if (f < n_frag && W.frag_nu[f] != 0) {
@@ -1734,9 +1735,14 @@ k_ext_prep(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_
 				E.rext[B2 + (uint64_t)s * fw.cap + i] = x;
 				E.jobs[jb] = jl; E.jobs[jb + 1] = jr;
 				{ const int c0 = (jl.qlen && !jl.pad0) ? d_job_class(jl.qlen, jl.tlen, lane_ok) : AL_NCLS, c1 = (jr.qlen && !jr.pad0) ? d_job_class(jr.qlen, jr.tlen, lane_ok) : AL_NCLS;
-				  E.job_key[jb] = c0 < AL_NCLS ? ((uint32_t)c0 << 20 | (uint32_t)(jl.qlen + jl.tlen)) : 0xffffffffu;
-				  E.job_key[jb + 1] = c1 < AL_NCLS ? ((uint32_t)c1 << 20 | (uint32_t)(jr.qlen + jr.tlen)) : 0xffffffffu;
+				  // key: class | 16-cell blocks of the target | size -- inside a class the jobs are ordered by block count first, so that the 9 ... 22-block class
+				  // can be launched as three kernels (12, 16, 22 register blocks: a row costs every instantiated block a skip test and two selects)
+				  const uint32_t b0 = (uint32_t)std::min(63, (jl.tlen + 15) / 16), b1 = (uint32_t)std::min(63, (jr.tlen + 15) / 16);
+				  E.job_key[jb] = c0 < AL_NCLS ? ((uint32_t)c0 << 20 | b0 << 14 | (uint32_t)std::min(0x3fff, jl.qlen + jl.tlen)) : 0xffffffffu;
+				  E.job_key[jb + 1] = c1 < AL_NCLS ? ((uint32_t)c1 << 20 | b1 << 14 | (uint32_t)std::min(0x3fff, jr.qlen + jr.tlen)) : 0xffffffffu;
 				  atomicAdd(&s_hist[c0], 1u); atomicAdd(&s_hist[c1], 1u);
+				  if (c0 == 7 && b0 <= 16) atomicAdd(&s_sub[b0 <= 12 ? 0 : 1], 1u);
+				  if (c1 == 7 && b1 <= 16) atomicAdd(&s_sub[b1 <= 12 ? 0 : 1], 1u);
 				  if (c0 < AL_NCLS) atomicAdd(&s_tl[c0], (unsigned)jl.tlen); if (c1 < AL_NCLS) atomicAdd(&s_tl[c1], (unsigned)jr.tlen); }
 			}
 		};
@@ -1789,6 +1795,7 @@ k_ext_prep(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_
 	__syncthreads();
 	if (threadIdx.x <= AL_NCLS && s_hist[threadIdx.x]) atomicAdd(&E.hist[threadIdx.x], (unsigned long long)s_hist[threadIdx.x]);   // one atomic per block and class
 	if (threadIdx.x <= AL_NCLS && s_tl[threadIdx.x]) atomicAdd(&E.hist[24 + threadIdx.x], (unsigned long long)s_tl[threadIdx.x]);
+	if (threadIdx.x < 2 && s_sub[threadIdx.x]) atomicAdd(&E.hist[36 + threadIdx.x], (unsigned long long)s_sub[threadIdx.x]);
 	for (int d = 32; d > 0; d >>= 1) { c_regs += __shfl_xor(c_regs, d); c_ref += __shfl_xor(c_ref, d); c_cig += __shfl_xor(c_cig, d); }
 	if ((threadIdx.x & 63) == 0) { if (c_regs) atomicAdd(&G.counters[4], c_regs); if (c_ref) atomicAdd(&G.counters[5], c_ref); if (c_cig) atomicAdd(&G.counters[6], c_cig); }
 }
@@ -1802,7 +1809,7 @@ template <int QMAXJ, int TMAXJ> struct JobLds {
 
 // DP jobs of one block-count class: 4 jobs per wavefront, all running d_ksw_reg<NB>
 template <int NB, int QMAXJ, int TMAXJ>
-__global__ void __launch_bounds__(64, (NB <= 4 ? 4 : NB <= 8 ? AL_LB_DP8 : NB <= 22 ? AL_LB_DP22 : 2))
+__global__ void __launch_bounds__(64, (NB <= 4 ? 4 : NB <= 8 ? AL_LB_DP8 : NB <= 12 ? 4 : NB <= 22 ? AL_LB_DP22 : 2))
 k_ext_dp(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_off, const uint32_t *__restrict__ rd_len,
          AlignShared G, ExtShared E, const uint32_t *__restrict__ sorted_idx, uint32_t first, uint32_t count,
          uint8_t *__restrict__ gws, size_t gws_stride, size_t p_bytes, size_t cig_words, AlParams P)
@@ -1815,7 +1822,7 @@ k_ext_dp(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_of
 	const int bw = (int)(P.bw * 1.5 + 1.);
 	// jobs are handed out largest first from a shared cursor, four neighbours of the size-sorted list per wavefront:
 	// the grid is as large as the chip holds resident and no wavefront is left with a long tail
-	unsigned long long *cursor = E.hist + 12 + (NB == 1 ? 0 : NB == 2 ? 1 : NB == 4 ? 2 : NB == 8 ? 3 : NB == 22 ? 4 : 5);
+	unsigned long long *cursor = E.hist + 12 + (NB == 1 ? 0 : NB == 2 ? 1 : NB == 4 ? 2 : NB == 8 ? 3 : NB == 22 ? 4 : NB == 32 ? 5 : NB == 12 ? 6 : 7);
 	for (;;) {
 		unsigned long long base = 0;
 		if (threadIdx.x == 0) base = atomicAdd(cursor, 4ULL);
@@ -2551,7 +2558,9 @@ int al_run_align_stage(al_ctx_t *c)
 			if (A->sort_tmp.ensure(bytes + 16)) return -1;
 			AL_HIP_CHECK(rocprim::radix_sort_pairs(A->sort_tmp.p, bytes, A->job_key.p, A->job_key2.p, A->job_idx.p, A->job_idx2.p, (int)nj, 0, 24, s));
 			AL_HIP_CHECK(hipEventRecord(c->ev[ST_EXT_SORT + 1], s));
+			unsigned long long sub7[2] = {0, 0};
 			AL_HIP_CHECK(hipMemcpyAsync(hist, A->hist.p, (AL_NCLS + 1) * 8, hipMemcpyDeviceToHost, s));
+			AL_HIP_CHECK(hipMemcpyAsync(sub7, A->hist.p + 36, 16, hipMemcpyDeviceToHost, s));
 			AL_HIP_CHECK(hipMemcpyAsync(c->stat_dp_tbases, A->hist.p + 24, AL_NCLS * 8, hipMemcpyDeviceToHost, s));
 			AL_HIP_CHECK(hipStreamSynchronize(s));
 			for (int i = 0; i < AL_NCLS; ++i) c->stat_dp_jobs[i] = hist[i];
@@ -2578,11 +2587,13 @@ int al_run_align_stage(al_ctx_t *c)
 				}
 				if (need && A->gws.ensure(need + 64)) return -1;
 			}
+			bool g12_done = false;
 			for (int cls = 0; cls < AL_NCLS; ++cls) {
 				const uint32_t cnt = (uint32_t)hist[cls];
 				if (cls == 3) AL_HIP_CHECK(hipEventRecord(c->ev[ST_EXT_DP_LANE + 1], s));
 				if (cls == 6) AL_HIP_CHECK(hipEventRecord(c->ev[ST_EXT_DP_G4 + 1], s));
 				if (cls == 7) AL_HIP_CHECK(hipEventRecord(c->ev[ST_EXT_DP_G8 + 1], s));
+				if (cls == 8 && !g12_done) { AL_HIP_CHECK(hipEventRecord(c->ev[ST_EXT_DP_G12 + 1], s)); AL_HIP_CHECK(hipEventRecord(c->ev[ST_EXT_DP_G16 + 1], s)); g12_done = true; }
 				if (cnt == 0) continue;
 				if (cls < 3) {                                                    // lane-per-job
 					const int TC = 16 << cls;
@@ -2599,7 +2610,18 @@ int al_run_align_stage(al_ctx_t *c)
 					  const int cap = NB <= 4 ? caps[0] : NB <= 8 ? caps[1] : NB <= 22 ? caps[2] : 2048; if (nbj > cap) nbj = cap; }
 					if (A->gws.ensure((size_t)nbj * 4 * st2 + 64)) return -1;
 #define LAUNCH_DP(NBV) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ext_dp<NBV, 512, NBV * 16>), dim3(nbj), dim3(64), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, G, E, A->job_idx2.p, first, cnt, A->gws.p, st2, pb, cw, c->P)
-					if (NB == 1) LAUNCH_DP(1); else if (NB == 2) LAUNCH_DP(2); else if (NB == 4) LAUNCH_DP(4); else if (NB == 8) LAUNCH_DP(8); else if (NB == 22) LAUNCH_DP(22); else LAUNCH_DP(32);
+					if (NB == 1) LAUNCH_DP(1); else if (NB == 2) LAUNCH_DP(2); else if (NB == 4) LAUNCH_DP(4); else if (NB == 8) LAUNCH_DP(8); else if (NB == 32) LAUNCH_DP(32);
+					else {   // 9 ... 22 blocks: the sorted slice holds the jobs of <= 12 blocks first, then 13 ... 16, then the rest
+						static const bool split = !getenv("AL_DP_NO_SPLIT");
+						const uint32_t c12 = split ? (uint32_t)std::min<unsigned long long>(sub7[0], cnt) : 0u, c16 = split ? (uint32_t)std::min<unsigned long long>(sub7[1], cnt - c12) : 0u, c22 = cnt - c12 - c16;
+						const uint32_t first0 = first, cnt0 = cnt;
+#define LAUNCH_DPS(NBV, F, N) do { if ((N) > 0) { int nb2 = (int)(((N) + 3) / 4); if (nb2 > nbj) nb2 = nbj; hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ext_dp<NBV, 512, NBV * 16>), dim3(nb2), dim3(64), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, G, E, A->job_idx2.p, (F), (N), A->gws.p + (size_t)gw_used * 4 * st2, st2, pb, cw, c->P); gw_used += nb2; } } while (0)
+						// (the three kernels run one after the other on this stream: they may share the workspace range)
+						int gw_used = 0; LAUNCH_DPS(12, first0, c12); AL_HIP_CHECK(hipEventRecord(c->ev[ST_EXT_DP_G12 + 1], s)); gw_used = 0; LAUNCH_DPS(16, first0 + c12, c16); AL_HIP_CHECK(hipEventRecord(c->ev[ST_EXT_DP_G16 + 1], s)); gw_used = 0; LAUNCH_DPS(22, first0 + c12 + c16, c22);
+						g12_done = true;
+						(void)cnt0;
+#undef LAUNCH_DPS
+					}
 #undef LAUNCH_DP
 				} else {
 					int nbj = (int)cnt; if (nbj > 2048) nbj = 2048;
@@ -2611,7 +2633,7 @@ int al_run_align_stage(al_ctx_t *c)
 				first += cnt;
 			}
 		}
-		else { AL_HIP_CHECK(hipEventRecord(c->ev[ST_EXT_SORT + 1], s)); for (int i = ST_EXT_DP_LANE; i < ST_EXT_DP_G22; ++i) AL_HIP_CHECK(hipEventRecord(c->ev[i + 1], s)); }
+		else { AL_HIP_CHECK(hipEventRecord(c->ev[ST_EXT_SORT + 1], s)); for (int i = ST_EXT_DP_LANE; i < ST_EXT_DP_G22; ++i) AL_HIP_CHECK(hipEventRecord(c->ev[i + 1], s)); }   // (no jobs: empty intervals)
 		AL_HIP_CHECK(hipEventRecord(c->ev[ST_EXT_DP_G22 + 1], s));
 		uint32_t *n_slow_d = (uint32_t *)(c->counters.p + 14);
 		hipLaunchKernelGGL(k_ext_finish, dim3((nf + 255) / 256), dim3(256), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, c->frag_first.p, c->frag_rep.p, W, G, E, lt, A->sc_ws.p, A->sc_off.p, nf, c->P, A->slow_list.p, n_slow_d, 1, frag_ord);

@@ -134,12 +134,12 @@ static void al_dev_free_raw(void *p)
 
 static const char *g_stage_names[ST_N] = { "sketch", "seed_lookup", "scan", "size_order", "anchor_sort_small", "anchor_sort", "anchor_sort_blk", "anchor_sort_big", "anchor_heap",
                                            "chain_lds32", "chain_lds48", "chain_lds64", "chain_lds128", "chain_tile", "chain_deferred", "chain_fallback", "chain_ties", "rechain",
-                                           "regs", "ext_prep", "ext_sort", "ext_dp_lane", "ext_dp_g4", "ext_dp_g8", "ext_dp_g22", "ext_finish", "compact" };
+                                           "regs", "ext_prep", "ext_sort", "ext_dp_lane", "ext_dp_g4", "ext_dp_g8", "ext_dp_g12", "ext_dp_g16", "ext_dp_g22", "ext_finish", "compact" };
 // kernel behind each interval (what rocprofv3 --kernel-trace lists); "" = several launches
 // the kernel of an interval that is exactly one launch of one kernel ("" otherwise: several kernels or several launches)
 static const char *g_stage_kernels[ST_N] = { "k_sketch", "k_seed", "", "", "k_anchor_sort_small", "", "", "", "",
                                              "", "", "k_chain_lds<64, 64>", "", "", "", "", "",  "",
-                                             "", "k_ext_prep", "", "", "", "k_ext_dp<8, 512, 128>", "k_ext_dp<22, 512, 352>", "k_ext_finish", "k_compact" };
+                                             "", "k_ext_prep", "", "", "", "k_ext_dp<8, 512, 128>", "k_ext_dp<12, 512, 192>", "k_ext_dp<16, 512, 256>", "k_ext_dp<22, 512, 352>", "k_ext_finish", "k_compact" };
 extern "C" const char *al_stage_kernel(int i) { return i >= 0 && i < ST_N ? g_stage_kernels[i] : ""; }
 extern "C" const char *al_stage_name(int i) { return i >= 0 && i < ST_N ? g_stage_names[i] : ""; }
 

@@ -387,13 +387,18 @@ def main():
             ("chain", ["chain_lds32", "chain_lds48", "chain_lds64", "chain_lds128", "chain_tile", "chain_deferred", "chain_fallback", "chain_ties"], 16.0 * A1),
             ("rechain (max_occ pass: seed + sort + chain)", ["rechain"], 56.0 * (An - A1)),
             ("regs (chain_post / seg_gen: no bytes in the contract)", ["regs"], 0.0),
-            ("extension", ["ext_prep", "ext_sort", "ext_dp_lane", "ext_dp_g4", "ext_dp_g8", "ext_dp_g22", "ext_finish", "compact"], 0.5 * Wb + float(st.bytes_out)),
+            ("extension", ["ext_prep", "ext_sort", "ext_dp_lane", "ext_dp_g4", "ext_dp_g8", "ext_dp_g12", "ext_dp_g16", "ext_dp_g22", "ext_finish", "compact"], 0.5 * Wb + float(st.bytes_out)),
         ]
         own = {"sketch": float(st.bytes_in) + 16.0 * M, "seed_lookup": 16.0 * M, "anchor_sort_small": 24.0 * cls(0, 64), "anchor_sort": 24.0 * cls(65, 1024),
                "anchor_sort_blk": 24.0 * cls(1025, 8192), "chain_lds32": 16.0 * cls(0, 32), "chain_lds48": 16.0 * cls(33, 48), "chain_lds64": 16.0 * cls(49, 64), "chain_lds128": 16.0 * cls(65, 128)}
         # extension DP kernels: reference windows of their jobs at 4 bits / base + one 48-byte ExtOut record per job (the W/2 + B_out terms)
-        for iv, ci in (("ext_dp_g4", 5), ("ext_dp_g8", 6), ("ext_dp_g22", 7)):
+        for iv, ci in (("ext_dp_g4", 5), ("ext_dp_g8", 6)):
             own[iv] = 0.5 * float(st.dp_target_bases[ci]) + 48.0 * float(st.dp_jobs[ci])
+        # (the 9 ... 22-block job class runs as three kernels -- 12, 16, 22 register blocks; its reference windows and records are counted for the class:
+        #  the share of each kernel is taken in proportion to its time)
+        g7 = [iv for iv in ("ext_dp_g12", "ext_dp_g16", "ext_dp_g22") if per.get(iv, 0) > 0]
+        for iv in g7:
+            own[iv] = (0.5 * float(st.dp_target_bases[7]) + 48.0 * float(st.dp_jobs[7])) * per[iv] / sum(per[i] for i in g7)
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))) if os.path.exists(os.path.join(ROOT, "profiles", "traffic.json")) else {}
         stages = []
         for name, ivs, by in groups:
@@ -413,18 +418,18 @@ def main():
                 "dominant_kernel": {"kernel": kern[dom], "interval": dom, "ms": per[dom], "algorithmic_bytes": dom_bytes,
                                     "achieved": (dom_bytes / (per[dom] * 1e-3) / 1e9) if dom_bytes else None, "frac": (dom_bytes / (per[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS) if dom_bytes else None,
                                     "traffic": None, "traffic_from_committed_profile": dom_traffic if tj.get("workload") == a.config else None,
-                                    "jobs": int(st.dp_jobs[7]) if dom == "ext_dp_g22" else None,
-                                    "note": ("integer-VALU bound: %.0f target bases x ~150 query bases of affine-gap DP cells per launch; its HBM bytes are the 4-bit reference windows and the result records" % float(st.dp_target_bases[7])) if dom == "ext_dp_g22" else (None if dom_bytes is not None else "bytes of this kernel's share of the stage are not separable: see its stage row")},
+                                    "jobs": None,
+                                    "note": ("integer-VALU bound (see roofline.valu): affine-gap DP cells of its jobs; its HBM bytes are the 4-bit reference windows and the result records (the 9 ... 22-block class has %.0f target bases in %d jobs, over its three kernels)" % (float(st.dp_target_bases[7]), int(st.dp_jobs[7]))) if dom.startswith("ext_dp_g") else (None if dom_bytes is not None else "bytes of this kernel's share of the stage are not separable: see its stage row")},
                 "stages": stages}
         # The extension DP is bound by integer VALU issue, not by HBM: its row against THAT ceiling.  Wave-instructions per launch come from the
         # committed SQ_INSTS_VALU pass (profiles/traffic.json, tools/prof.sh); the ceiling is the measured integer issue rate of a SIMD, one
         # wave-instruction per 4.4 cycles whatever the occupancy (tools/micro/valu_issue.hip), x 1024 SIMDs x 2.4 GHz.
         VALU_CEIL = 1024 * 2.4e9 / 4.4
         valu = []
-        dpk = {"ext_dp_g4": "k_ext_dp<4, 512, 64>", "ext_dp_g8": "k_ext_dp<8, 512, 128>", "ext_dp_g22": "k_ext_dp<22, 512, 352>"}
-        for iv in ("ext_dp_g4", "ext_dp_g8", "ext_dp_g22"):
+        dpk = {"ext_dp_g4": "k_ext_dp<4, 512, 64>", "ext_dp_g8": "k_ext_dp<8, 512, 128>", "ext_dp_g12": "k_ext_dp<12, 512, 192>", "ext_dp_g16": "k_ext_dp<16, 512, 256>", "ext_dp_g22": "k_ext_dp<22, 512, 352>"}
+        for iv in ("ext_dp_g4", "ext_dp_g8", "ext_dp_g12", "ext_dp_g16", "ext_dp_g22"):
             ins = (tj.get("kernels", {}).get(dpk[iv]) or {}).get("valu_insts_per_launch") if tj.get("workload") == a.config else None
-            ci = {"ext_dp_g4": 5, "ext_dp_g8": 6, "ext_dp_g22": 7}[iv]
+            ci = {"ext_dp_g4": 5, "ext_dp_g8": 6, "ext_dp_g12": 7, "ext_dp_g16": 7, "ext_dp_g22": 7}[iv]
             valu.append({"interval": iv, "kernel": dpk[iv], "ms": per.get(iv), "jobs": int(st.dp_jobs[ci]), "target_bases": int(st.dp_target_bases[ci]),
                          "valu_wave_insts_per_launch_from_committed_profile": ins, "wave_insts_per_s": (ins / (per[iv] * 1e-3)) if ins and per.get(iv) else None,
                          "issue_ceiling_wave_insts_per_s": VALU_CEIL, "frac_of_issue_ceiling": (ins / (per[iv] * 1e-3) / VALU_CEIL) if ins and per.get(iv) else None})
