@@ -532,6 +532,190 @@ k_u_compact(const uint32_t *__restrict__ cmp_list, const uint32_t *__restrict__ 
 	}
 }
 
+// =============================================================================================
+// The deferred segments of 17 ... 128 anchors: SIXTEEN LANES PER SEGMENT, four segments per wavefront (ChainSeg direct mode, like the lane kernels:
+// chains straight to the fragment's arrays).  The lane-per-segment kernels keep 10 bytes per anchor and LANE in LDS -- 25 KB per wavefront at 40
+// anchors, six wavefronts per CU, every one of them a chain of dependent LDS round trips -- and took as long as the tile kernel itself.  Here a
+// segment's rows are 18 bytes per anchor for the whole GROUP (3.5 KB per wavefront at 48 anchors: the CU is full), a row scores its predecessors 16
+// at a time, and the row maximum is a 16-lane reduction; the sequential max_skip rule of chain.c:74-80 is replayed on two ballot masks for the rows
+// that have more than max_skip predecessors.  Chain ends, backtrack and order (chain.c:87-160): lane 0 of the group; the chained anchors leave by
+// all sixteen lanes.
+// =============================================================================================
+template <int CAP>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8)))
+k_chain_coop(const AlAnchor *__restrict__ anchors, AlAnchor *__restrict__ chained, uint64_t *__restrict__ u_all, uint32_t *__restrict__ uo_all,
+             const uint64_t *__restrict__ vs_off, const uint32_t *__restrict__ vs_na, const uint32_t *__restrict__ vs_meta, const uint64_t *__restrict__ uslot,
+             const uint32_t *__restrict__ rel, const uint32_t *__restrict__ fragid, uint32_t *__restrict__ ctie, const uint32_t *__restrict__ list, int n_list,
+             const AlParams P, unsigned long long *__restrict__ counters)
+{
+	__shared__ uint64_t s_row_[4][CAP];
+	__shared__ uint32_t s_u_[4][CAP];
+	__shared__ uint16_t s_v_[4][CAP], s_tm_[4][CAP], s_perm_[4][CAP];
+	const int lane = threadIdx.x, g = lane >> 4, gl = lane & 15, gbase = lane & 48;
+	uint64_t *const s_row = s_row_[g]; uint32_t *const s_u = s_u_[g]; uint16_t *const s_v = s_v_[g], *const s_tm = s_tm_[g], *const s_perm = s_perm_[g];
+	uint32_t *const rlo = reinterpret_cast<uint32_t *>(s_row);
+	const int e = (int)blockIdx.x * 4 + g;
+	const bool have = e < n_list;
+	const uint32_t d = have ? list[e] : 0u;
+	int n = have ? (int)vs_na[d] : 0;
+	if (n > CAP) { if (gl == 0) atomicAdd(&counters[7], 1ULL << 56); n = 0; }    // (the caller's classes guarantee the fit)
+	const uint64_t off = have ? vs_off[d] : 0ULL;
+	const uint32_t mt = have ? vs_meta[d] : 0u;
+	const int32_t q_span = P.k, bw = P.bw, max_skip = P.max_chain_skip, max_iter = P.max_chain_iter, min_cnt = P.min_cnt, min_sc = P.min_chain_score;
+	const int qlen_sum = (int)(mt & 0x7fffffffu);
+	const int32_t mdy = qlen_sum > P.max_gap ? qlen_sum : P.max_gap;                   // map.c:341-351
+	int32_t mdx;
+	if (P.max_gap_ref > 0) mdx = P.max_gap_ref;
+	else if (P.max_frag_len > 0) { mdx = P.max_frag_len - qlen_sum; if (mdx < P.max_gap) mdx = P.max_gap; }
+	else mdx = P.max_gap;
+	const uint32_t drlim = (mt >> 31) ? (uint32_t)mdy : 0x7fffffffu;
+	CtPen pen; pen.same = nullptr; pen.diff = nullptr; pen.avg_d = (double)P.k; pen.tab_ok = false;
+	const AlAnchor *a = anchors + off;
+	// ---- rows ----
+	bool bad = false;
+	for (int i = gl; i < n; i += 16) {
+		const AlAnchor ee = a[i];
+		bad = bad || (int32_t)(ee.y >> 32 & 0xff) != q_span || ((ee.y & AL_SEED_SEG_MASK) >> AL_SEED_SEG_SHIFT) > 1 || (uint32_t)ee.y > 0xfffu;
+		s_row[i] = (uint64_t)((uint32_t)ee.x & 0xffffu) | (uint64_t)((uint32_t)ee.y & 0xfffu) << 16 | (uint64_t)((ee.y & AL_SEED_SEG_MASK) >> AL_SEED_SEG_SHIFT & 1) << 28 | (uint64_t)CT_NONE << 48;
+		s_tm[i] = (uint16_t)CT_NONE;
+	}
+	{ const unsigned long long bm = __ballot(bad); if ((uint32_t)(bm >> gbase) & 0xffffu) { if (gl == 0) atomicAdd(&counters[7], 1ULL); n = 0; } }   // not representable in the compact rows (the tile kernel checked: never)
+	__threadfence_block();
+	// ---- DP (chain.c:46-85) ----
+	int nmax = n;
+	{ int o = __shfl_xor(nmax, 16); nmax = o > nmax ? o : nmax; o = __shfl_xor(nmax, 32); nmax = o > nmax ? o : nmax; }
+	int st = 0; int32_t dist = 0; uint32_t prev_xlo = 0;
+	for (int i = 0; i < nmax; ++i) {
+		const bool ga = i < n;
+		const uint64_t ri = ga ? s_row[i] : 0ULL;
+		const uint32_t xi = R_XLO(ri); const int32_t qi = R_Q(ri), sidi = R_SEG(ri);
+		if (ga && i > 0) {                                                          // window start (chain.c:52-53)
+			dist += (int32_t)((xi - prev_xlo) & 0xffffu);
+			while (dist > mdx || i - st > max_iter) { ++st; dist -= (int32_t)((R_XLO(s_row[st]) - R_XLO(s_row[st - 1])) & 0xffffu); }
+		}
+		prev_xlo = ga ? xi : prev_xlo;
+		int32_t max_f = q_span, n_skip = 0; int max_j = -1; bool broke = !ga;
+		const bool need_marks = ga && (i - st) > max_skip;                            // fewer predecessors can never count max_skip + 1 skips: no marks, no replay
+		if (!__ballot(need_marks)) {
+			// the row's maximum is the first predecessor (in processing order) with the highest score: a 16-lane reduction per 16 predecessors
+			for (int base = i - 1; ; base -= 16) {
+				const bool work = ga && base >= st;
+				if (!__ballot(work)) break;
+				const int j = base - gl;
+				const bool act0 = work && j >= st;
+				const uint64_t rj = act0 ? s_row[j] : 0ULL;
+				int32_t sc;
+				const bool ok = ct_score(rj, xi, qi, sidi, q_span, mdx, mdy, drlim, bw, pen, sc);
+				int32_t key = (act0 && ok) ? sc * 16 + (15 - gl) : INT32_MIN;
+				{ int o = __builtin_amdgcn_update_dpp(key, key, 0xB1, 0xf, 0xf, false); key = o > key ? o : key; }
+				{ int o = __builtin_amdgcn_update_dpp(key, key, 0x4E, 0xf, 0xf, false); key = o > key ? o : key; }
+				{ int o = __builtin_amdgcn_update_dpp(key, key, 0x141, 0xf, 0xf, false); key = o > key ? o : key; }
+				{ int o = __builtin_amdgcn_update_dpp(key, key, 0x140, 0xf, 0xf, false); key = o > key ? o : key; }
+				if (key != INT32_MIN && (key >> 4) > max_f) { max_f = key >> 4; max_j = base - (15 - (key & 15)); }
+			}
+		} else
+		for (int base = i - 1; ; base -= 16) {
+			const bool work = !broke && base >= st;
+			if (!__ballot(work)) break;
+			const int j = base - gl;
+			bool act = work && j >= st;
+			const uint64_t rj = act ? s_row[j] : 0ULL;
+			int32_t sc;
+			const bool ok = ct_score(rj, xi, qi, sidi, q_span, mdx, mdy, drlim, bw, pen, sc);
+			act = act && ok;
+			const uint32_t pj = R_P(rj);
+			if (need_marks && act && pj != CT_NONE) s_tm[pj] = (uint16_t)i;           // t[p[j]] = i (chain.c:81); marks of lanes behind the break are never tested
+			const int32_t scm = act ? sc : INT32_MIN;
+			int32_t inc = scm;                                                          // prefix maximum in processing order (lane order inside the 16-lane row)
+			{ int o = ct_dpp_shr(INT32_MIN, inc, 1); inc = o > inc ? o : inc; o = ct_dpp_shr(INT32_MIN, inc, 2); inc = o > inc ? o : inc;
+			  o = ct_dpp_shr(INT32_MIN, inc, 4); inc = o > inc ? o : inc; o = ct_dpp_shr(INT32_MIN, inc, 8); inc = o > inc ? o : inc; }
+			const int32_t excl = ct_dpp_shr(INT32_MIN, inc, 1);
+			const int32_t before = excl > max_f ? excl : max_f;
+			const bool upd = act && sc > before;
+			__threadfence_block();
+			const bool marked = need_marks && act && !upd && s_tm[j] == (uint16_t)i;
+			const unsigned long long Uw = __ballot(upd), Kw = __ballot(marked);
+			uint32_t U = (uint32_t)(Uw >> gbase) & 0xffffu; const uint32_t K = (uint32_t)(Kw >> gbase) & 0xffffu;
+			if (need_marks) {                                                           // chain.c:74-80 replayed in order over the two masks
+				uint32_t both = U | K; int brk = 16;
+				while (both) {
+					const int b = __ffs((int)both) - 1; both &= both - 1;
+					if (U >> b & 1) { if (n_skip > 0) --n_skip; }
+					else if (++n_skip > max_skip) { brk = b; break; }
+				}
+				if (brk < 16) { broke = true; U &= (1u << brk) - 1u; }
+			}
+			const int lastu = U ? 31 - __clz((int)U) : 0;
+			const int32_t scl = __shfl(sc, gbase + lastu);
+			if (work && U) { max_f = scl; max_j = base - lastu; }
+		}
+		if (ga && gl == 0) {
+			const int32_t vmax = max_j >= 0 ? (int32_t)s_v[max_j] : 0;
+			s_row[i] = (ri & 0x00000000ffffffffULL) | (uint64_t)((uint32_t)max_f & 0xffffu) << 32 | (uint64_t)(max_j < 0 ? CT_NONE : (uint32_t)max_j) << 48;
+			s_v[i] = (uint16_t)(max_j >= 0 && vmax > max_f ? vmax : max_f);
+		}
+		__threadfence_block();
+	}
+	// ---- chain ends, peaks, backtrack, order (chain.c:87-160): lane 0 of the group ----
+	if (gl == 0 && n > 0) {
+#define FLG(t) rlo[2 * (t)]
+#define F_(t) ((int32_t)(int16_t)(rlo[2 * (t) + 1] & 0xffffu))
+#define P_(t) (rlo[2 * (t) + 1] >> 16)
+		for (int i = 0; i < n; ++i) { const uint32_t p = P_(i); if (p != CT_NONE) FLG(p) |= ROW_B30; }     // has a successor
+		int32_t n_u = 0;
+		for (int i = 0; i < n; ++i)
+			if (!(FLG(i) & ROW_B30) && (int32_t)s_v[i] >= min_sc) {
+				int j = i;
+				while (j >= 0 && F_(j) < (int32_t)s_v[j]) { const uint32_t p = P_(j); j = p == CT_NONE ? -1 : (int)p; }
+				if (j < 0) j = i;
+				s_u[n_u++] = (uint32_t)F_(j) << 16 | (uint32_t)j;
+			}
+		for (int32_t i = 1; i < n_u; ++i) { const uint32_t t = s_u[i]; int32_t j = i; while (j > 0 && s_u[j - 1] < t) { s_u[j] = s_u[j - 1]; --j; } s_u[j] = t; }
+		int32_t n_v = 0, kk = 0;
+		for (int32_t i = 0; i < n_u; ++i) {                                          // chain.c:111-128; v[] becomes the visit list
+			const uint32_t key0 = s_u[i];
+			const int32_t n_v0 = n_v, k0 = kk, sc_i = (int32_t)(key0 >> 16); int j = (int)(key0 & 0xffffu);
+			do { s_v[n_v] = (uint16_t)j; ++n_v; FLG(j) |= ROW_B31; const uint32_t p = P_(j); j = p == CT_NONE ? -1 : (int)p; } while (j >= 0 && !(FLG(j) & ROW_B31));
+			if (j < 0) { if (n_v - n_v0 >= min_cnt) s_u[kk++] = (uint32_t)sc_i << 16 | (uint32_t)(n_v - n_v0); }
+			else if (sc_i - F_(j) >= min_sc) { if (n_v - n_v0 >= min_cnt) s_u[kk++] = (uint32_t)(sc_i - F_(j)) << 16 | (uint32_t)(n_v - n_v0); }
+			if (k0 == kk) n_v = n_v0;
+		}
+		n_u = kk;
+		// chains by the x of their first anchor (chain.c:144-160): stable insertion sort (ksort.h:149 for the <= 64 chains of a fragment; with more
+		// chains in the fragment the order among equal x is the fallback's business: ctie)
+		int32_t offv = 0;
+		for (int32_t c = 0; c < n_u; ++c) { s_tm[c] = (uint16_t)offv; offv += (int32_t)(s_u[c] & 0xffffu); s_perm[c] = (uint16_t)c; }
+		bool eqx = false;
+#define CX(c) (a[(int)s_v[(int)s_tm[(c)] + (int32_t)(s_u[(c)] & 0xffffu) - 1]].x)
+		for (int32_t i = 1; i < n_u; ++i) {
+			const uint16_t ci = s_perm[i]; const uint64_t xi = CX(ci); int32_t j = i;
+			while (j > 0) { const uint16_t cj = s_perm[j - 1]; const uint64_t xj = CX(cj); if (xi < xj) { s_perm[j] = cj; --j; } else { eqx = eqx || xi == xj; break; } }
+			s_perm[j] = ci;
+		}
+#undef CX
+		for (int t = 0; t < n; ++t) rlo[2 * t + 1] = 0xffffffffu;                      // f / p are dead: "source row of the chained anchor at this place"
+		uint64_t *const ub = u_all + uslot[d]; uint32_t *const uob = uo_all + uslot[d]; const uint32_t rl = rel[d];
+		uint32_t o = 0;
+		for (int32_t i = 0; i < n_u; ++i) {
+			const uint32_t cc = s_perm[i], ee = s_u[cc], cnt = ee & 0xffffu, offc = s_tm[cc];
+			ub[i] = (uint64_t)(ee >> 16) << 32 | cnt; uob[i] = rl + o;
+			for (uint32_t j = 0; j < cnt; ++j) rlo[2 * (o + j) + 1] = (uint32_t)s_v[offc + (cnt - 1 - j)];
+			o += cnt;
+		}
+		if (eqx) ctie[fragid[d]] = 1u;
+#undef FLG
+#undef F_
+#undef P_
+	}
+	__threadfence_block();
+	{   // the chained anchors, by the sixteen lanes
+		AlAnchor *const b = chained + off;
+		for (int t = gl; t < n; t += 16) { const uint32_t sr = rlo[2 * t + 1]; if (sr != 0xffffffffu) b[t] = a[sr]; }
+	}
+}
+template __global__ void k_chain_coop<48>(const AlAnchor *, AlAnchor *, uint64_t *, uint32_t *, const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const uint32_t *, const uint32_t *, uint32_t *, const uint32_t *, int, const AlParams, unsigned long long *);
+template __global__ void k_chain_coop<128>(const AlAnchor *, AlAnchor *, uint64_t *, uint32_t *, const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const uint32_t *, const uint32_t *, uint32_t *, const uint32_t *, int, const AlParams, unsigned long long *);
+
 // uo[] for chain lists whose anchors were written back to back (the whole-fragment kernels and the fallback): running sum of the counts.
 // One wavefront per list entry.
 __global__ void __launch_bounds__(64)

@@ -27,6 +27,7 @@ struct TileSched { uint32_t n_items; uint32_t ent[7]; uint32_t item[7]; };
 struct CtDefer { uint64_t *off, *uslot; uint32_t *na, *meta, *rel, *fragid, *cls; uint32_t *cnt; uint32_t cap; uint32_t *cmp_list, *cmp_cnt; uint32_t *ctie; };
 __global__ void k_frag_meta(const uint32_t *, const uint32_t *, int, uint32_t *);
 __global__ void k_chain_tile6(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, const TileSched, const uint32_t *, AlAnchor *, uint64_t *, uint32_t *, uint32_t *, uint32_t *, uint32_t *, const AlParams, const int, unsigned long long *, const int, const CtDefer);
+template <int CAP> __global__ void k_chain_coop(const AlAnchor *, AlAnchor *, uint64_t *, uint32_t *, const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const uint32_t *, const uint32_t *, uint32_t *, const uint32_t *, int, const AlParams, unsigned long long *);
 __global__ void k_u_compact(const uint32_t *, const uint32_t *, const uint64_t *, uint32_t *, uint64_t *, uint32_t *, const uint32_t *, uint32_t *, uint32_t *);
 __global__ void k_uo_fill(const uint32_t *, int, const uint64_t *, const uint32_t *, const uint64_t *, uint32_t *, const uint32_t *);
 __global__ void k_fb_meta(const uint32_t *, int, const uint32_t *, const uint32_t *, uint32_t *, uint32_t *);
@@ -613,19 +614,27 @@ static int chain_tiles(al_ctx_t *c, const uint32_t *list, const TileSched &S, co
 			static const uint32_t capl0[9] = {16, 24, 32, 40, 48, 64, 80, 96, 128};
 			// the long classes hold few segments, and a lane walks a 49 ... 128-anchor segment for half a millisecond whatever the launch holds: as long
 			// as they are thin they share ONE launch of the 128-anchor kernel (the list is ordered by class: their entries are one range)
+			// segments of 9 ... 16 anchors: the lane-per-segment kernel (64 of them per wavefront, rows in LDS); 17 ... 128: sixteen lanes per segment
+			// (k_chain_coop: a few KB of LDS per wavefront instead of 25, the CU full).  AL_CHAIN_COOP=0 (tests): the lane kernels for every class.
+			static const bool coop = !(getenv("AL_CHAIN_COOP") && atoi(getenv("AL_CHAIN_COOP")) == 0);
 			int mfrom = 9; while (mfrom > 5 && n_def - cb[mfrom - 1] < 4096u) --mfrom;
-			uint32_t capl[9]; for (int k = 0; k < 9; ++k) capl[k] = k >= mfrom ? 128u : capl0[k];
+			if (coop) mfrom = 1;
+			uint32_t capl[9]; for (int k = 0; k < 9; ++k) capl[k] = coop && k >= 1 ? 0u : k >= mfrom ? 128u : capl0[k];
 			size_t wsb[10]; wsb[0] = 0; for (int k = 0; k < 9; ++k) wsb[k + 1] = wsb[k] + (size_t)(cb[k + 1] - cb[k]) * capl[k];   // chain-end scratch: CAPL words per entry, by list position
 			if (c->ws_u64.ensure(wsb[9] + 64, false, s)) return -1;
 			{ static const bool tr = getenv("AL_TRACE") != nullptr;
 			  if (tr && first) fprintf(stderr, "[airlift] trace: tile chaining: %u items, %u deferred segments (<=16:%u <=24:%u <=32:%u <=40:%u <=48:%u <=64:%u <=80:%u <=96:%u <=128:%u), %u fragments to compact\n", S.n_items, n_def,
 			                          cb[1] - cb[0], cb[2] - cb[1], cb[3] - cb[2], cb[4] - cb[3], cb[5] - cb[4], cb[6] - cb[5], cb[7] - cb[6], cb[8] - cb[7], cb[9] - cb[8], n_cmp); }
 			ChainSeg sg{c->vs_meta.p, nullptr, nullptr, 0, nullptr, c->d_uslot.p, c->d_rel.p, c->d_fragid.p, c->ctie.p};
-			if (getenv("AL_TRACE")) { const hipError_t e = hipStreamSynchronize(s); fprintf(stderr, "[airlift] trace: deferred sort, scratch %zu words, mfrom %d -> %s\n", wsb[9], mfrom, hipGetErrorName(e)); }
-#define LDEF(C, L, K) do { if ((K) < mfrom) LCH(C, L, -1, c->vs_off.p, c->vs_na.p, c->chained.p, c->u.p, (uint32_t *)nullptr, c->seg_ord.p + cb[K], (int)(cb[K + 1] - cb[K]), sg, c->uo.p, c->ws_u64.p + wsb[K], C); \
-			if (getenv("AL_TRACE")) { const hipError_t e = hipStreamSynchronize(s); fprintf(stderr, "[airlift] trace: deferred class %d (%u) -> %s\n", K, cb[K + 1] - cb[K], hipGetErrorName(e)); } } while (0)
+#define LDEF(C, L, K) do { if ((K) < mfrom) LCH(C, L, -1, c->vs_off.p, c->vs_na.p, c->chained.p, c->u.p, (uint32_t *)nullptr, c->seg_ord.p + cb[K], (int)(cb[K + 1] - cb[K]), sg, c->uo.p, c->ws_u64.p + wsb[K], C); } while (0)
 			LDEF(16, 64, 0); LDEF(24, 64, 1); LDEF(32, 64, 2); LDEF(40, 64, 3); LDEF(48, 64, 4); LDEF(64, 64, 5); LDEF(80, 64, 6); LDEF(96, 64, 7); LDEF(128, 32, 8);
-			if (mfrom < 9) LCH(128, 32, -1, c->vs_off.p, c->vs_na.p, c->chained.p, c->u.p, (uint32_t *)nullptr, c->seg_ord.p + cb[mfrom], (int)(n_def - cb[mfrom]), sg, c->uo.p, c->ws_u64.p + wsb[mfrom], 128);
+			if (coop) {
+				const int n48 = (int)(cb[5] - cb[1]), n128 = (int)(cb[9] - cb[5]);
+				if (n48 > 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain_coop<48>), dim3((n48 + 3) / 4), dim3(64), 0, s, c->anchors.p, c->chained.p, c->u.p, c->uo.p, c->vs_off.p, c->vs_na.p, c->vs_meta.p, c->d_uslot.p, c->d_rel.p, c->d_fragid.p, c->ctie.p,
+				                                (const uint32_t *)c->seg_ord.p + cb[1], n48, c->P, c->counters.p);
+				if (n128 > 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain_coop<128>), dim3((n128 + 3) / 4), dim3(64), 0, s, c->anchors.p, c->chained.p, c->u.p, c->uo.p, c->vs_off.p, c->vs_na.p, c->vs_meta.p, c->d_uslot.p, c->d_rel.p, c->d_fragid.p, c->ctie.p,
+				                                 (const uint32_t *)c->seg_ord.p + cb[5], n128, c->P, c->counters.p);
+			} else if (mfrom < 9) LCH(128, 32, -1, c->vs_off.p, c->vs_na.p, c->chained.p, c->u.p, (uint32_t *)nullptr, c->seg_ord.p + cb[mfrom], (int)(n_def - cb[mfrom]), sg, c->uo.p, c->ws_u64.p + wsb[mfrom], 128);
 			{ static const bool tr = getenv("AL_TRACE") != nullptr; if (tr) { const hipError_t e = hipStreamSynchronize(s); fprintf(stderr, "[airlift] trace: deferred segments (%u, first pass %d) -> %s\n", n_def, (int)first, hipGetErrorName(e)); } }
 #undef LDEF
 		}
