@@ -614,27 +614,34 @@ static int chain_tiles(al_ctx_t *c, const uint32_t *list, const TileSched &S, co
 			static const uint32_t capl0[9] = {16, 24, 32, 40, 48, 64, 80, 96, 128};
 			// the long classes hold few segments, and a lane walks a 49 ... 128-anchor segment for half a millisecond whatever the launch holds: as long
 			// as they are thin they share ONE launch of the 128-anchor kernel (the list is ordered by class: their entries are one range)
-			// segments of 9 ... 16 anchors: the lane-per-segment kernel (64 of them per wavefront, rows in LDS); 17 ... 128: sixteen lanes per segment
-			// (k_chain_coop: a few KB of LDS per wavefront instead of 25, the CU full).  AL_CHAIN_COOP=0 (tests): the lane kernels for every class.
-			static const bool coop = !(getenv("AL_CHAIN_COOP") && atoi(getenv("AL_CHAIN_COOP")) == 0);
-			int mfrom = 9; while (mfrom > 5 && n_def - cb[mfrom - 1] < 4096u) --mfrom;
-			if (coop) mfrom = 1;
-			uint32_t capl[9]; for (int k = 0; k < 9; ++k) capl[k] = coop && k >= 1 ? 0u : k >= mfrom ? 128u : capl0[k];
+			// A class with many segments: the lane-per-segment kernel (64 equally long segments per wavefront, rows in LDS).  A lane walks a 17 ... 128-anchor
+			// segment for 0.1 - 0.5 ms whatever the launch holds, so a THIN class (a small batch, the tie rounds, the long classes) goes to k_chain_coop
+			// instead -- sixteen lanes per segment, over sooner, and neighbouring thin classes share a launch.  (Measured on the full classes of a
+			// 1 M-pair batch the sixteen-lane form is the slower one: 12.7 against 9.8 ms.)  AL_CHAIN_COOP = 0 / 1 (tests): never / always.
+			static const int coop_env = getenv("AL_CHAIN_COOP") ? atoi(getenv("AL_CHAIN_COOP")) : -1;
+			bool thin[9]; thin[0] = false;
+			for (int k = 1; k < 9; ++k) thin[k] = coop_env == 1 || (coop_env != 0 && cb[k + 1] - cb[k] < 4096u);
+			uint32_t capl[9]; for (int k = 0; k < 9; ++k) capl[k] = thin[k] ? 0u : capl0[k];
 			size_t wsb[10]; wsb[0] = 0; for (int k = 0; k < 9; ++k) wsb[k + 1] = wsb[k] + (size_t)(cb[k + 1] - cb[k]) * capl[k];   // chain-end scratch: CAPL words per entry, by list position
 			if (c->ws_u64.ensure(wsb[9] + 64, false, s)) return -1;
 			{ static const bool tr = getenv("AL_TRACE") != nullptr;
 			  if (tr && first) fprintf(stderr, "[airlift] trace: tile chaining: %u items, %u deferred segments (<=16:%u <=24:%u <=32:%u <=40:%u <=48:%u <=64:%u <=80:%u <=96:%u <=128:%u), %u fragments to compact\n", S.n_items, n_def,
 			                          cb[1] - cb[0], cb[2] - cb[1], cb[3] - cb[2], cb[4] - cb[3], cb[5] - cb[4], cb[6] - cb[5], cb[7] - cb[6], cb[8] - cb[7], cb[9] - cb[8], n_cmp); }
 			ChainSeg sg{c->vs_meta.p, nullptr, nullptr, 0, nullptr, c->d_uslot.p, c->d_rel.p, c->d_fragid.p, c->ctie.p};
-#define LDEF(C, L, K) do { if ((K) < mfrom) LCH(C, L, -1, c->vs_off.p, c->vs_na.p, c->chained.p, c->u.p, (uint32_t *)nullptr, c->seg_ord.p + cb[K], (int)(cb[K + 1] - cb[K]), sg, c->uo.p, c->ws_u64.p + wsb[K], C); } while (0)
+#define LDEF(C, L, K) do { if (!thin[K]) LCH(C, L, -1, c->vs_off.p, c->vs_na.p, c->chained.p, c->u.p, (uint32_t *)nullptr, c->seg_ord.p + cb[K], (int)(cb[K + 1] - cb[K]), sg, c->uo.p, c->ws_u64.p + wsb[K], C); } while (0)
 			LDEF(16, 64, 0); LDEF(24, 64, 1); LDEF(32, 64, 2); LDEF(40, 64, 3); LDEF(48, 64, 4); LDEF(64, 64, 5); LDEF(80, 64, 6); LDEF(96, 64, 7); LDEF(128, 32, 8);
-			if (coop) {
-				const int n48 = (int)(cb[5] - cb[1]), n128 = (int)(cb[9] - cb[5]);
-				if (n48 > 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain_coop<48>), dim3((n48 + 3) / 4), dim3(64), 0, s, c->anchors.p, c->chained.p, c->u.p, c->uo.p, c->vs_off.p, c->vs_na.p, c->vs_meta.p, c->d_uslot.p, c->d_rel.p, c->d_fragid.p, c->ctie.p,
-				                                (const uint32_t *)c->seg_ord.p + cb[1], n48, c->P, c->counters.p);
-				if (n128 > 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain_coop<128>), dim3((n128 + 3) / 4), dim3(64), 0, s, c->anchors.p, c->chained.p, c->u.p, c->uo.p, c->vs_off.p, c->vs_na.p, c->vs_meta.p, c->d_uslot.p, c->d_rel.p, c->d_fragid.p, c->ctie.p,
-				                                 (const uint32_t *)c->seg_ord.p + cb[5], n128, c->P, c->counters.p);
-			} else if (mfrom < 9) LCH(128, 32, -1, c->vs_off.p, c->vs_na.p, c->chained.p, c->u.p, (uint32_t *)nullptr, c->seg_ord.p + cb[mfrom], (int)(n_def - cb[mfrom]), sg, c->uo.p, c->ws_u64.p + wsb[mfrom], 128);
+			for (int k = 1; k < 9; ) {   // runs of neighbouring thin classes: one launch each
+				if (!thin[k]) { ++k; continue; }
+				int k1 = k; while (k1 + 1 < 9 && thin[k1 + 1]) ++k1;
+				const int nn = (int)(cb[k1 + 1] - cb[k]);
+				if (nn > 0) {
+					if (k1 <= 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain_coop<48>), dim3((nn + 3) / 4), dim3(64), 0, s, c->anchors.p, c->chained.p, c->u.p, c->uo.p, c->vs_off.p, c->vs_na.p, c->vs_meta.p, c->d_uslot.p, c->d_rel.p, c->d_fragid.p, c->ctie.p,
+					                                (const uint32_t *)c->seg_ord.p + cb[k], nn, c->P, c->counters.p);
+					else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain_coop<128>), dim3((nn + 3) / 4), dim3(64), 0, s, c->anchors.p, c->chained.p, c->u.p, c->uo.p, c->vs_off.p, c->vs_na.p, c->vs_meta.p, c->d_uslot.p, c->d_rel.p, c->d_fragid.p, c->ctie.p,
+					                        (const uint32_t *)c->seg_ord.p + cb[k], nn, c->P, c->counters.p);
+				}
+				k = k1 + 1;
+			}
 			{ static const bool tr = getenv("AL_TRACE") != nullptr; if (tr) { const hipError_t e = hipStreamSynchronize(s); fprintf(stderr, "[airlift] trace: deferred segments (%u, first pass %d) -> %s\n", n_def, (int)first, hipGetErrorName(e)); } }
 #undef LDEF
 		}

@@ -76,10 +76,12 @@ def test_lds_dp_path_identical(golden_unpacked, name):
 @pytest.mark.parametrize("env", [dict(AL_DBG=str(1 << 27)), dict(AL_TEST_SORT_BLK="65"), dict(AL_TEST_SORT_BIG="65"), dict(AL_TEST_SORT_BLK="65", AL_TEST_SORT_BIG="200"),
                                  dict(AL_TEST_SORT_BIG="65", AL_TEST_BIG_CHUNK="3"), dict(AL_TEST_HEAP_WAVE="1"), dict(AL_CHAIN_WAVE_MAX="0"),
                                  dict(AL_TEST_SEG_BIG="160", AL_DBG=str(1 << 27)), dict(AL_TEST_SEG_BIG="64", AL_TEST_POISON="170", AL_TEST_GUARD="1", AL_DBG=str(1 << 28)),
-                                 dict(AL_TEST_TILE_ALL="1"), dict(AL_TEST_TILE_ALL="1", AL_TEST_POISON="170", AL_TEST_GUARD="1"), dict(AL_DBG=str(1 << 28)), dict(AL_TEST_TILE_ALL="1", AL_TEST_TILE_FB="1")],
+                                 dict(AL_TEST_TILE_ALL="1"), dict(AL_TEST_TILE_ALL="1", AL_TEST_POISON="170", AL_TEST_GUARD="1"), dict(AL_DBG=str(1 << 28)), dict(AL_TEST_TILE_ALL="1", AL_TEST_TILE_FB="1"),
+                                 dict(AL_TEST_TILE_ALL="1", AL_CHAIN_COOP="1"), dict(AL_TEST_TILE_ALL="1", AL_CHAIN_COOP="0")],
                          ids=["segments_wave_only", "block_sort", "device_sort", "block_and_device_sort", "device_sort_chunks", "heap_merge_by_wavefront", "lds_chain_kernels_for_thin_classes",
                               "cut_and_merge_by_eight_wavefronts_all_fragments", "cut_and_merge_by_eight_wavefronts_poisoned_memory",
-                              "tile_kernel_all_fragments", "tile_kernel_all_fragments_poisoned_memory", "segment_kernels_instead_of_tiles", "tile_kernel_hands_every_fragment_back"])
+                              "tile_kernel_all_fragments", "tile_kernel_all_fragments_poisoned_memory", "segment_kernels_instead_of_tiles", "tile_kernel_hands_every_fragment_back",
+                              "deferred_segments_sixteen_lanes_each", "deferred_segments_a_lane_each"])
 @pytest.mark.parametrize("name", ["g1_mt150pe", "g2_250pe", "g3_adversarial", "g6_repeats"])
 def test_large_fragment_paths_identical(golden_unpacked, name, env):
     """The kernels that take over for fragments with many anchors -- the tile chaining kernel (AL_TEST_TILE_ALL: every fragment goes through it,
