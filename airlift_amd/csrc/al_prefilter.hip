@@ -73,7 +73,8 @@ k_prefilter(const AlAnchor *__restrict__ a, const uint64_t *__restrict__ a_off, 
             const uint32_t *__restrict__ rd_len, const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_off,
             const AlMatch *__restrict__ match, const uint64_t *__restrict__ mini_off, const uint32_t *__restrict__ frag_nm,
             const uint64_t *__restrict__ pos, const uint32_t *__restrict__ S4, const uint64_t *__restrict__ seq_off, const uint32_t *__restrict__ seq_len,
-            int n_frag, N4Par P, uint8_t *__restrict__ ws /* 3 * N4_LMAX bytes per lane */, unsigned long long *__restrict__ out)
+            int n_frag, N4Par P, uint8_t *__restrict__ ws /* 3 * N4_LMAX bytes per lane */, unsigned long long *__restrict__ out,
+            uint64_t *__restrict__ dec /* optional: one word per candidate, fragment << 32 | first anchor of the cluster << 2 | kept by adjacency << 1 | kept by GreedySnake */, uint32_t dec_cap)
 {
 	const int f = blockIdx.x * blockDim.x + threadIdx.x;
 	unsigned long long c_all = 0, c_adj = 0, c_snk = 0, c_both = 0;
@@ -112,6 +113,7 @@ k_prefilter(const AlAnchor *__restrict__ a, const uint64_t *__restrict__ a_off, 
 					for (int j = 0; j < L; ++j) { const int64_t g = ref_start + j; rf[j] = (g >= 0 && g < sl) ? (uint8_t)d_seq4(S4, so + (uint64_t)g) : (uint8_t)5; }
 					const bool keep_snk = d_greedy_snake(L, rf, rev ? rv : fw, P.snake_e, P.snake_k, P.snake_iter) != 0;
 					c_adj += keep_adj; c_snk += keep_snk; c_both += keep_adj && keep_snk;
+					if (dec) { const unsigned long long at = atomicAdd(out + 4, 1ULL); if (at < dec_cap) dec[at] = (uint64_t)(uint32_t)f << 32 | (uint64_t)cs << 2 | (keep_adj ? 2u : 0u) | (keep_snk ? 1u : 0u); }
 				}
 				seed_num = 0; cs = i;
 			} else ++seed_num;
@@ -125,7 +127,11 @@ int al_run_seed_stages(al_ctx_t *c);     // al_runtime.hip
 
 // Seed stages on the resident batch of single-segment fragments, then the filters on the ALSER candidates.
 // out4: candidates (= the ALSER count), kept by the adjacency filter, kept by GreedySnake, kept by both.
-extern "C" int al_batch_prefilter(al_ctx_t *c, int adj_e, int snake_e, int snake_k, int snake_iter, int64_t *out4)
+extern "C" int al_batch_prefilter_decisions(al_ctx_t *c, int adj_e, int snake_e, int snake_k, int snake_iter, int64_t *out4, uint64_t *dec, int64_t dec_cap);
+extern "C" int al_batch_prefilter(al_ctx_t *c, int adj_e, int snake_e, int snake_k, int snake_iter, int64_t *out4) { return al_batch_prefilter_decisions(c, adj_e, snake_e, snake_k, snake_iter, out4, nullptr, 0); }
+// ... and every candidate's two decisions (tests): dec[0 .. min(out4[0], dec_cap)) = fragment << 32 | first anchor of the candidate's cluster << 2 | kept by the
+// adjacency filter << 1 | kept by GreedySnake, in no particular order
+extern "C" int al_batch_prefilter_decisions(al_ctx_t *c, int adj_e, int snake_e, int snake_k, int snake_iter, int64_t *out4, uint64_t *dec, int64_t dec_cap)
 {
 	if (!c || !out4 || snake_k < 1) return -1;
 	if (c->max_rd_len > N4_LMAX) { fprintf(stderr, "[airlift] the pre-alignment filters take reads of up to %d bases\n", N4_LMAX); return -3; }
@@ -138,16 +144,19 @@ extern "C" int al_batch_prefilter(al_ctx_t *c, int adj_e, int snake_e, int snake
 	AL_HIP_CHECK(hipSetDevice(c->device));
 	hipStream_t s = c->stream;
 	const int nf = c->n_frag;
-	uint8_t *ws = nullptr; unsigned long long *d_out = nullptr; unsigned long long h[4] = {0, 0, 0, 0};
+	uint8_t *ws = nullptr; unsigned long long *d_out = nullptr; unsigned long long h[4] = {0, 0, 0, 0}; uint64_t *d_dec = nullptr;
 	int rc = -1;
-	if (hipMalloc((void **)&ws, (size_t)(nf > 0 ? nf : 1) * 3 * N4_LMAX) == hipSuccess && hipMalloc((void **)&d_out, 32) == hipSuccess && hipMemsetAsync(d_out, 0, 32, s) == hipSuccess) {
+	if (dec_cap < 0 || dec_cap > 0x7fffffff) return -1;
+	if (dec && dec_cap > 0 && hipMalloc((void **)&d_dec, (size_t)dec_cap * 8) != hipSuccess) return -1;
+	if (hipMalloc((void **)&ws, (size_t)(nf > 0 ? nf : 1) * 3 * N4_LMAX) == hipSuccess && hipMalloc((void **)&d_out, 64) == hipSuccess && hipMemsetAsync(d_out, 0, 64, s) == hipSuccess) {
 		const N4Par P{adj_e, snake_e, snake_k, snake_iter, c->opt.min_cnt, c->mi->k};
 		const bool p1 = c->n_rechain > 0;
 		if (nf) hipLaunchKernelGGL(k_prefilter, dim3((nf + 63) / 64), dim3(64), 0, s, c->anchors.p, p1 ? c->a_off_p1.p : c->a_off.p, p1 ? c->frag_na_p1.p : c->frag_na.p, c->frag_first.p,
-		                           c->rd_len.p, c->rd_seq.p, c->rd_off.p, c->match.p, c->mini_off.p, c->frag_nm.p, c->di.pos, c->di.S4, c->di.seq_off, c->di.seq_len, nf, P, ws, d_out);
+		                           c->rd_len.p, c->rd_seq.p, c->rd_off.p, c->match.p, c->mini_off.p, c->frag_nm.p, c->di.pos, c->di.S4, c->di.seq_off, c->di.seq_len, nf, P, ws, d_out, d_dec, (uint32_t)dec_cap);
 		if (hipMemcpyAsync(h, d_out, 32, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess && hipGetLastError() == hipSuccess) rc = 0;
+		if (rc == 0 && d_dec) { const size_t nd = (size_t)std::min<unsigned long long>(h[0], (unsigned long long)dec_cap); if (nd && hipMemcpy(dec, d_dec, nd * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = -1; }
 	}
-	(void)hipFree(ws); (void)hipFree(d_out);
+	(void)hipFree(ws); (void)hipFree(d_out); (void)hipFree(d_dec);
 	for (int i = 0; i < 4; ++i) out4[i] = (int64_t)h[i];
 	return rc;
 }

@@ -277,6 +277,9 @@ int  al_count_candidates_file(const al_idx_t *mi, const char *fn, const al_mapop
  * out4: candidates (= the count above), kept by adjacency, kept by GreedySnake, kept by both.  Resident batch of single-segment
  * fragments (first, mid_occ, seeding pass); the alignment path does not use it. */
 int  al_batch_prefilter(al_ctx_t *ctx, int adj_e, int snake_e, int snake_k, int snake_iter, int64_t *out4);
+/* ... and every candidate's two decisions: dec[0 .. min(out4[0], dec_cap)) = fragment << 32 | first anchor of the candidate's cluster << 2 |
+ * kept by the adjacency filter << 1 | kept by GreedySnake (no particular order) */
+int  al_batch_prefilter_decisions(al_ctx_t *ctx, int adj_e, int snake_e, int snake_k, int snake_iter, int64_t *out4, uint64_t *dec, int64_t dec_cap);
 int  al_count_candidates_file_filtered(const al_idx_t *mi, const char *fn, const al_mapopt_t *opt, int n_threads, int device,
                                        int adj_e, int snake_e, int snake_k, int snake_iter, int64_t *out4);
 

@@ -2,8 +2,9 @@
 minimap2 fork counts (ALSER loop, map.c:299-312).
   * GreedySnake: every decision of the kernel against the reference's own GreedySnake() -- GreedySnake.c:52 compiled where it lies into
     oracle/_ref/libgreedysnake.so (oracle/Makefile) -- on the same read and reference window;
-  * adjacency filter (MrFAST.c:1741-1764 on minimizer seeds): against a restatement in this file over the oracle's sketch of the
-    reference and of the reads (test infrastructure).
+  * adjacency filter (MrFAST.c:1741-1764 on minimizer seeds): against oracle/n4_oracle.py over the oracle's sketch of the reference and of the
+    reads;
+  * candidate by candidate (al_batch_prefilter_decisions), not by aggregate counts.
 The candidates are rebuilt here from the device's sorted anchors, which tests/test_gpu_stages.py pins to the reference's --print-seeds taps."""
 import ctypes as C
 import json
@@ -34,17 +35,25 @@ def _snake_lib():
 
 
 def _expected(A, d, adj_e, snake_e, snake_k, snake_iter, k=21, w=11, mid_occ=1000, min_cnt=2):
-    """(candidates, kept by adjacency, kept by GreedySnake, kept by both) for the single-end reads of golden set d, and the device's four."""
+    """Per candidate of golden set d (every read as a single-segment fragment): {(fragment, first anchor of its cluster): (kept by adjacency,
+    kept by GreedySnake)} by the oracle / the reference's GreedySnake, and the device's dictionary and four counts."""
+    import sys
     import airlift_amd
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import n4_oracle
     m, n_segs, seqs, names, quals = load_fragments(d)
-    assert set(n_segs) == {1}
+    seqs = [s for s in seqs if 0 < len(s) <= 512]
     idx = A.Index(fasta=os.path.join(d, m["ref"]))
     ctx = A.Context(idx)
-    ctx.upload(n_segs, seqs, names)
+    ctx.upload([1] * len(seqs), seqs, [b""] * len(seqs))
     L = A.load()
-    L.al_batch_prefilter.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64)]; L.al_batch_prefilter.restype = C.c_int
+    L.al_batch_prefilter_decisions.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64), C.c_void_p, C.c_int64]; L.al_batch_prefilter_decisions.restype = C.c_int
     got = (C.c_int64 * 4)()
-    assert L.al_batch_prefilter(ctx.h, adj_e, snake_e, snake_k, snake_iter, got) == 0
+    cap = 1 << 20; dec = np.zeros(cap, dtype=np.uint64)
+    assert L.al_batch_prefilter_decisions(ctx.h, adj_e, snake_e, snake_k, snake_iter, got, dec.ctypes.data_as(C.c_void_p), cap) == 0
+    assert got[0] <= cap
+    got_dec = {(int(v) >> 32, (int(v) & 0xffffffff) >> 2): (bool(int(v) & 2), bool(int(v) & 1)) for v in dec[: got[0]]}
+    assert len(got_dec) == got[0], "a candidate was reported twice"
     nf = len(seqs)
     na = ctx.tap("frag_na", np.uint32, nf); off = ctx.tap("a_off", np.uint64, nf + 1)
     anchors = ctx.tap("anchors", np.uint64, int(off[nf]) * 2).reshape(-1, 2)
@@ -54,52 +63,31 @@ def _expected(A, d, adj_e, snake_e, snake_k, snake_iter, k=21, w=11, mid_occ=100
     ref_codes = [NT4[np.frombuffer(s, dtype=np.uint8)] for s in ref[1]]
     occ = {}
     for rid, s in enumerate(ref[1]):
-        mz = orc.sketch(s, w, k)
-        for x, y in mz:
+        for x, y in orc.sketch(s, w, k):
             occ.setdefault(int(x) >> 8, []).append(rid << 32 | (int(y) & 0xffffffff))
-    for v in occ.values():
-        v.sort()
-    exp = [0, 0, 0, 0]
+    occ = {h: (sorted(v), set(v)) for h, v in occ.items()}
+    exp = {}
     for f in range(nf):
         s = seqs[f]; Lr = len(s)
         fw = NT4[np.frombuffer(s, dtype=np.uint8)]; rv = np.where(fw[::-1] < 4, 3 - fw[::-1], 4).astype(np.uint8)
         seeds = []                                                  # collect_matches (map.c:90-123): query minimizers with 0 < occurrences < mid_occ
         for x, y in orc.sketch(s, w, k):
-            lst = occ.get(int(x) >> 8)
-            if lst and len(lst) < mid_occ:
-                seeds.append((int(y) & 0xffffffff, lst))
+            e = occ.get(int(x) >> 8)
+            if e and len(e[0]) < mid_occ:
+                seeds.append((int(y) & 0xffffffff, e[1]))
         a = anchors[int(off[f]): int(off[f]) + int(na[f])]
-        xs = (a[:, 0] & np.uint64(0xffffffff)).astype(np.int64); xs = np.where(xs >= 2**31, xs - 2**32, xs)
-        seed_num, cs = 0, 0
-        for i in range(1, len(a)):
-            if xs[i] - xs[i - 1] > Lr:                              # map.c:301-308
-                if seed_num >= min_cnt - 1:
-                    exp[0] += 1
-                    ax, ay = int(a[cs, 0]), int(a[cs, 1])
-                    rev = ax >> 63; rid = (ax << 1 & (2**64 - 1)) >> 33
-                    rpos = ax & 0xffffffff; qpos = ay & 0xffffffff
-                    ref_start = rpos - qpos
-                    diff = 0                                        # MrFAST.c:1741-1764
-                    for qp, lst in seeds:
-                        qend, qs = qp >> 1, qp & 1
-                        rp = ref_start + (Lr - (qend + 1 - k) - 1) if rev else ref_start + qend
-                        word = rid << 32 | rp << 1 | ((1 - qs) if rev else qs)
-                        hit = 0 <= rp < len(ref_codes[rid]) and word in lst
-                        if not hit:
-                            diff += 1
-                    keep_adj = diff <= adj_e
-                    win = np.full(Lr, 5, dtype=np.uint8)
-                    lo, hi = max(0, ref_start), min(len(ref_codes[rid]), ref_start + Lr)
-                    if hi > lo:
-                        win[lo - ref_start: hi - ref_start] = ref_codes[rid][lo:hi]
-                    rd = rv if rev else fw
-                    keep_snk = snake.GreedySnake(Lr, (win + 48).tobytes(), (rd + 48).tobytes(), snake_e, snake_k, 0, snake_iter) != 0
-                    exp[1] += keep_adj; exp[2] += keep_snk; exp[3] += keep_adj and keep_snk
-                seed_num, cs = 0, i
-            else:
-                seed_num += 1
+        for cs in n4_oracle.candidates(a, Lr, min_cnt):
+            rev, rid, ref_start = n4_oracle.candidate_location(a[cs, 0], a[cs, 1])
+            keep_adj = n4_oracle.adjacency(seeds, rev, rid, ref_start, Lr, k, len(ref_codes[rid]), adj_e)
+            win = np.full(Lr, 5, dtype=np.uint8)
+            lo, hi = max(0, ref_start), min(len(ref_codes[rid]), ref_start + Lr)
+            if hi > lo:
+                win[lo - ref_start: hi - ref_start] = ref_codes[rid][lo:hi]
+            rd = rv if rev else fw
+            keep_snk = snake.GreedySnake(Lr, (win + 48).tobytes(), (rd + 48).tobytes(), snake_e, snake_k, 0, snake_iter) != 0     # the reference's own function (GreedySnake.c:52)
+            exp[(f, cs)] = (bool(keep_adj), bool(keep_snk))
     ctx.close(); idx.close()
-    return exp, [int(v) for v in got]
+    return exp, got_dec, [int(v) for v in got]
 
 
 @pytest.fixture(scope="module")
@@ -109,11 +97,18 @@ def A():
     return airlift_amd
 
 
+@pytest.mark.parametrize("name", ["g2_100se", "g1_mt150pe", "g3_adversarial", "g6_repeats"])
 @pytest.mark.parametrize("par", [(3, 3, 5, 3), (0, 1, 10, 1), (8, 6, 4, 5), (1, 0, 7, 2)], ids=["e3_k5", "e0_e1_k10", "e8_e6_k4", "e1_e0_k7"])
-def test_filters_match_the_reference_functions(A, oracle_bin, golden_unpacked, par):
-    exp, got = _expected(A, golden_unpacked["g2_100se"], *par)
-    assert exp[0] > 100, "too few candidates for a meaningful comparison: %s" % exp
-    assert got == exp
+def test_filters_match_the_reference_functions(A, oracle_bin, golden_unpacked, name, par):
+    """EVERY candidate's two decisions: GreedySnake against the reference's own function on the same read and window, the adjacency filter against
+    oracle/n4_oracle.py; on four golden sets (their reads taken as single-end) and four parameter sets.  The four counts follow."""
+    exp, got_dec, got = _expected(A, golden_unpacked[name], *par)
+    if name == "g2_100se":
+        assert len(exp) > 100, "too few candidates for a meaningful comparison: %d" % len(exp)
+    assert set(got_dec) == set(exp), "candidate sets differ: %s" % sorted(set(got_dec) ^ set(exp))[:5]
+    bad = [(c, got_dec[c], exp[c]) for c in exp if got_dec[c] != exp[c]]
+    assert not bad, "%d of %d decisions differ, first: %s" % (len(bad), len(exp), bad[:5])
+    assert got == [len(exp), sum(v[0] for v in exp.values()), sum(v[1] for v in exp.values()), sum(v[0] and v[1] for v in exp.values())]
 
 
 def test_cli_reports_the_filtered_counts(golden_unpacked):
