@@ -838,8 +838,10 @@ struct RegsSelShared {
 	int32_t qs[AL_REGS_PMAX], qe[AL_REGS_PMAX], score[AL_REGS_PMAX], cnt[AL_REGS_PMAX], as[AL_REGS_PMAX], rs[AL_REGS_PMAX], re[AL_REGS_PMAX], ridrev[AL_REGS_PMAX];
 	int32_t subsc[AL_REGS_PMAX], nsub[AL_REGS_PMAX], slot[AL_REGS_PMAX], orig[AL_REGS_PMAX]; uint32_t hash[AL_REGS_PMAX];   // slot: rank among the kept hits; orig: position in score order
 };
-template <int CAP>      // CAP > 0: sort tile in LDS; 0: at most 64 chains, registers; < 0: sort keys in the fragment's global work area (any count)
-__global__ void __launch_bounds__(CAP == 0 || CAP == 256 ? 64 : CAP < 0 ? 1024 : 256)
+// PHASE 1 (CAP > 0): the sort only -- keys, order and the per-position tables are left in the fragment's global work area, and
+// k_regs_select<-2> (one wavefront, no sort tile: a dozen blocks per CU instead of the one or two the tile allows) makes the pass.
+template <int CAP, int PHASE = 0>      // CAP > 0: sort tile in LDS; 0: at most 64 chains, registers; -1: sort keys in the fragment's global work area (any count); -2: keys sorted already (PHASE 1 ran), the pass only
+__global__ void __launch_bounds__(CAP == 0 || CAP == 256 || CAP == -2 ? 64 : CAP < 0 || (PHASE == 1 && CAP >= 8192) ? 1024 : 256)
 k_regs_select(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__ u_all, const uint32_t *__restrict__ uo_all, const uint32_t *__restrict__ frag_first,
               const uint32_t *__restrict__ rd_len, const uint32_t *__restrict__ frag_hash, WsBase W, const uint32_t *__restrict__ list, int n_list,
               AlParams P, uint32_t *__restrict__ regs_n0)
@@ -847,7 +849,7 @@ k_regs_select(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__
 	__shared__ uint64_t skey_l[CAP > 0 ? CAP : 1];
 	__shared__ uint16_t sidx_l[CAP > 0 ? CAP : 1];
 	__shared__ RegsSelShared S; __shared__ RegsSelKept K;
-	constexpr int NT = CAP == 0 || CAP == 256 ? 64 : CAP < 0 ? 1024 : 256;   // (65 ... 256 chains: one wavefront sorts and makes the pass -- four times the blocks per CU of the 256-thread form, whose other three wavefronts only sort)
+	constexpr int NT = CAP == 0 || CAP == 256 || CAP == -2 ? 64 : CAP < 0 || (PHASE == 1 && CAP >= 8192) ? 1024 : 256;   // (the sort-only form of the largest tile: one block per CU, all of its wavefronts)   // (65 ... 256 chains: one wavefront sorts and makes the pass -- four times the blocks per CU of the 256-thread form, whose other three wavefronts only sort)
 	                // all threads sort (the sort in global memory, any count: 1024 of them); the first wavefront makes the pass
 	const int tid = threadIdx.x, lane = tid & 63;
 	if ((int)blockIdx.x >= n_list) return;
@@ -855,6 +857,7 @@ k_regs_select(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__
 	const uint32_t r0 = frag_first[f], n_segs = frag_first[f + 1] - r0;
 	const int n_u = (int)W.frag_nu[f];
 	if ((CAP >= 0 && n_u > (CAP > 0 ? CAP : 64)) || n_u < 2) return;        // regs_n0[f] pre-set to AL_REGS_UNSET
+	if (CAP == -2 && regs_n0[f] != AL_REGS_UNSET) return;                   // the sort kernel gave up on it
 	FragWs ws; d_frag_ws(W, f, ws);
 	uint64_t *const skey = CAP > 0 ? skey_l : ws.aux64;                      // capacity 4 n_u + 4 >= the next power of two
 	typedef typename std::conditional<(CAP > 0), uint16_t, uint32_t>::type IdxT;
@@ -869,7 +872,7 @@ k_regs_select(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__
 	else max_gap_ref = P.max_gap;
 	// ---- keys: (u ^ hash of the chain's first anchor) ----
 	uint64_t key_r = 0; int idx_r = 0;                                      // n_u <= 64: lane's own entry
-	{
+	if (CAP != -2) {
 		if (CAP == 0) {
 			if (lane < n_u) {
 				const uint64_t uc = u[lane]; const AlAnchor fa = a[as_arr[lane]];
@@ -883,7 +886,7 @@ k_regs_select(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__
 	// order is final, read back 64 at a time by the pass (coalesced, one round trip per group instead of four dependent ones)
 	int4 *const G1 = (int4 *)ws.aux128; int32_t *const G2 = ws.auxi + n_u, *const G3 = G2 + n_u, *const G4 = G3 + n_u;
 	bool tie = false;
-	if (CAP != 0) {   // descending bitonic sort of (key, chain), in LDS or in the fragment's work area
+	if (CAP != 0 && CAP != -2) {   // descending bitonic sort of (key, chain), in LDS or in the fragment's work area
 		int npow2 = 1; while (npow2 < n_u) npow2 <<= 1;
 		for (int c = n_u + tid; c < npow2; c += NT) { skey[c] = 0; sidx[c] = (IdxT)~0u; }   // keys are > 0 (a chain's score, in the high word): padding sorts last
 		__syncthreads();
@@ -936,10 +939,12 @@ k_regs_select(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__
 			if (!rev) { g.x = (int32_t)fa.y + 1 - q_span; g.y = (int32_t)la.y + 1; }
 			else { g.x = qlen - ((int32_t)la.y + 1); g.y = qlen - ((int32_t)fa.y + 1 - q_span); }
 			G1[p] = g; G2[p] = rid << 1 | rev; G3[p] = cnt; G4[p] = as;
+			if (PHASE == 1) { ws.aux64[p] = skey[p]; ((uint32_t *)(ws.auxi + (4 * n_u + 4)))[p] = (uint32_t)c; }
 		}
+		if (PHASE == 1) return;
 		__syncthreads();
 		if (tid >= 64) return;
-	} else {         // rank sort in registers (descending); equal keys: the stable ascending insertion sort (ksort.h:149), reversed, puts the later chain first
+	} else if (CAP == 0) {         // rank sort in registers (descending); equal keys: the stable ascending insertion sort (ksort.h:149), reversed, puts the later chain first
 		int rank = 0; const int klo = (int)(uint32_t)key_r, khi = (int)(uint32_t)(key_r >> 32); bool tie16 = false;
 		for (int j = 0; j < n_u; ++j) {
 			const uint64_t kj = (uint64_t)(uint32_t)__shfl(klo, j) | (uint64_t)(uint32_t)__shfl(khi, j) << 32;
@@ -1133,6 +1138,9 @@ template __global__ void k_regs_select<1024>(const AlAnchor *, const uint64_t *,
 template __global__ void k_regs_select<2048>(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *, WsBase, const uint32_t *, int, AlParams, uint32_t *);
 template __global__ void k_regs_select<4096>(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *, WsBase, const uint32_t *, int, AlParams, uint32_t *);
 template __global__ void k_regs_select<8192>(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *, WsBase, const uint32_t *, int, AlParams, uint32_t *);
+template __global__ void k_regs_select<1024, 1>(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *, WsBase, const uint32_t *, int, AlParams, uint32_t *);
+template __global__ void k_regs_select<8192, 1>(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *, WsBase, const uint32_t *, int, AlParams, uint32_t *);
+template __global__ void k_regs_select<-2>(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *, WsBase, const uint32_t *, int, AlParams, uint32_t *);
 template __global__ void k_regs_select<-1>(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *, WsBase, const uint32_t *, int, AlParams, uint32_t *);
 
 __global__ void __launch_bounds__(256)
@@ -2390,18 +2398,29 @@ int al_run_align_stage(al_ctx_t *c)
 		T.n = 1; T.v[0] = 9;      // fragments with at least nine chains may keep at least nine hits: candidates of k_regs_heavy
 		{ uint32_t i9 = (uint32_t)nf; AL_HIP_CHECK(hipMemcpyAsync(c->lb_buf.p, &i9, 4, hipMemcpyHostToDevice, s)); hipLaunchKernelGGL(k_lower_bounds, dim3((nf + 255) / 256), dim3(256), 0, s, (const uint32_t *)c->chain_key.p, (uint32_t)nf, T, c->lb_buf.p);
 		  AL_HIP_CHECK(hipMemcpyAsync(&i9, c->lb_buf.p, 4, hipMemcpyDeviceToHost, s)); AL_HIP_CHECK(hipStreamSynchronize(s)); heavy_from = i9; heavy_n = (uint32_t)nf - i9; }
-		// the classes are disjoint sets of fragments: the 4097..8192-chain class (blocks that run for milliseconds, a thin grid) runs on
-		// the side stream next to the rest
+		// The classes are disjoint sets of fragments.  Two fill the chip (65 ... 256 and 257 ... 1024 chains: hundreds of thousands of blocks); the
+		// others are a few hundred to a few thousand blocks that sort for a millisecond: on the side streams (higher priority: their blocks get the
+		// next free CU slot instead of queueing behind the small blocks), beside the two.  4097 ... 8192 chains: the sort tile (80 KB) never finds
+		// room on a CU the small blocks keep refilling (20 ms beside them, 4.5 ms alone): its sort runs first, alone on the main stream with the
+		// thin classes beside it, and leaves keys and order in the work area for a one-wavefront pass (k_regs_select<-2>) on the side stream.
 		hipStream_t sd = c->side;
+		static const int split = getenv("AL_REGS_SPLIT") ? atoi(getenv("AL_REGS_SPLIT")) : 0;   // experiment: bit 0: 257 ... 1024 chains sorted and passed over by two kernels as well
+#define LSEL(CAPV, PH, NT, A, B, ST) do { if ((B) > (A)) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_select<CAPV, PH>), dim3((B) - (A)), dim3(NT), 0, ST, c->chained.p, c->u.p, c->uo.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, ord + (A), (int)((B) - (A)), c->P, regs_n0); } while (0)
+		AL_HIP_CHECK(hipEventRecord(c->ev_fj[0], s));
+		for (int i = 0; i < 3; ++i) AL_HIP_CHECK(hipStreamWaitEvent(c->aux[i], c->ev_fj[0], 0));
+		LSEL(-1, 0, 1024, lb[3], (uint32_t)nf, c->aux[0]);
+		LSEL(4096, 0, 256, lb[4], lb[5], c->aux[1]);
+		LSEL(2048, 0, 256, lb[2], lb[4], c->aux[2]);
+		LSEL(8192, 1, 1024, lb[5], lb[3], s);
+		if (split & 1) LSEL(1024, 1, 256, lb[6], lb[2], s);
 		AL_HIP_CHECK(hipEventRecord(c->ev_fj[0], s)); AL_HIP_CHECK(hipStreamWaitEvent(sd, c->ev_fj[0], 0));
-		if (lb[3] > lb[5]) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_select<8192>), dim3(lb[3] - lb[5]), dim3(256), 0, sd, c->chained.p, c->u.p, c->uo.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, ord + lb[5], (int)(lb[3] - lb[5]), c->P, regs_n0);
+		LSEL(-2, 0, 64, lb[5], lb[3], sd);
 		AL_HIP_CHECK(hipEventRecord(c->ev_fj[1], sd));
-		if ((uint32_t)nf > lb[3]) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_select<-1>), dim3((uint32_t)nf - lb[3]), dim3(1024), 0, s, c->chained.p, c->u.p, c->uo.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, ord + lb[3], (int)((uint32_t)nf - lb[3]), c->P, regs_n0);
-		if (lb[2] > lb[6]) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_select<1024>), dim3(lb[2] - lb[6]), dim3(256), 0, s, c->chained.p, c->u.p, c->uo.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, ord + lb[6], (int)(lb[2] - lb[6]), c->P, regs_n0);
-		if (lb[6] > lb[1]) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_select<256>), dim3(lb[6] - lb[1]), dim3(64), 0, s, c->chained.p, c->u.p, c->uo.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, ord + lb[1], (int)(lb[6] - lb[1]), c->P, regs_n0);
-		if (lb[5] > lb[4]) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_select<4096>), dim3(lb[5] - lb[4]), dim3(256), 0, s, c->chained.p, c->u.p, c->uo.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, ord + lb[4], (int)(lb[5] - lb[4]), c->P, regs_n0);
-		if (lb[4] > lb[2]) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_select<2048>), dim3(lb[4] - lb[2]), dim3(256), 0, s, c->chained.p, c->u.p, c->uo.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, ord + lb[2], (int)(lb[4] - lb[2]), c->P, regs_n0);
-		if (lb[1] > lb[0]) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_select<0>), dim3(lb[1] - lb[0]), dim3(64), 0, s, c->chained.p, c->u.p, c->uo.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, ord + lb[0], (int)(lb[1] - lb[0]), c->P, regs_n0);
+		if (split & 1) LSEL(-2, 0, 64, lb[6], lb[2], s); else LSEL(1024, 0, 256, lb[6], lb[2], s);
+		LSEL(256, 0, 64, lb[1], lb[6], s);
+		LSEL(0, 0, 64, lb[0], lb[1], s);
+#undef LSEL
+		for (int i = 0; i < 3; ++i) { AL_HIP_CHECK(hipEventRecord(c->ev_aux[i], c->aux[i])); AL_HIP_CHECK(hipStreamWaitEvent(s, c->ev_aux[i], 0)); }
 		AL_HIP_CHECK(hipStreamWaitEvent(s, c->ev_fj[1], 0));
 	}
 	{   // room for the per-mate hits, from what chain_post kept

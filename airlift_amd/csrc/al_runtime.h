@@ -65,6 +65,9 @@ struct al_ctx_s {
 	hipEvent_t ev_fj[2] = {};             // fork / join of the side stream inside a stage (chain_post classes, DP job classes)
 	hipStream_t aux[3] = {};              // more streams for stages made of independent latency-bound launches over disjoint fragments (heap merge classes, k_regs_heavy tiles)
 	hipEvent_t ev_aux[3] = {};            // ... their join events
+	hipStream_t ovl[2] = {};              // stages of the seed pass that run beside the main stream's: the device-wide anchor sort next to the block sorts, the lane chaining kernels next to the tile kernel
+	hipEvent_t ev_ovl[4] = {};            // ... fork and join events of the two
+	bool ovl_pending = false;             // chaining kernels in flight on ovl[1]: chain_tiles joins them before it reuses their scratch
 	hipEvent_t ev_side[4] = {};           // [0],[1]: start / end of the side stream's work in the first pass, [2],[3]: in the re-chain pass
 	float ms_side = 0;
 	AlDevIndex di;
@@ -92,6 +95,7 @@ struct al_ctx_s {
 	DevBuf<AlMatch> match;
 	DevBuf<unsigned long long> counters;   // [0] heap fallbacks, [1] sort-tie flags, [2] alser total, [3] n_rechain, [4..] stage specific
 	DevBuf<uint8_t> scan_tmp;
+	DevBuf<uint8_t> big_tmp;               // rocprim scratch of the device-wide anchor sort (it runs on ovl[0], beside users of scan_tmp)
 	DevBuf<uint32_t> chain_key, chain_idx, chain_idx2, tie_list, lb_buf;
 	// segment-wise chaining of large fragments (al_runtime.hip: chain_by_segments) and the device-wide sort of their anchors
 	DevBuf<AlAnchor> chain_tmp; DevBuf<uint64_t> u_tmp, okey_tmp, seg_first, seg_first0, vs_off, big_off;

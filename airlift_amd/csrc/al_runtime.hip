@@ -202,9 +202,17 @@ extern "C" al_ctx_t *al_ctx_init(const al_idx_t *mi, const al_mapopt_t *opt, int
 	c->mi = mi; c->opt = *opt; c->device = device;
 	if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return nullptr; }
 	for (int i = 0; i <= ST_N; ++i) if (hipEventCreate(&c->ev[i]) != hipSuccess) { delete c; return nullptr; }
-	if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&c->ev_side[0]) != hipSuccess || hipEventCreate(&c->ev_side[1]) != hipSuccess || hipEventCreate(&c->ev_side[2]) != hipSuccess || hipEventCreate(&c->ev_side[3]) != hipSuccess ||
+	// The side streams carry the thin, latency-bound classes (a few hundred to a few thousand blocks that wait on one lane, or on a large LDS
+	// tile): at the main stream's priority their blocks wait for a CU slot behind the hundreds of thousands of small blocks of the kernel that
+	// runs beside them (k_regs_select<8192>: 4.5 ms alone, 20 ms beside <1024>).  AL_SIDE_PRIO=0: same priority as the main stream.
+	int prio_lo = 0, prio_hi = 0; (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+	static const bool side_hi = !(getenv("AL_SIDE_PRIO") && atoi(getenv("AL_SIDE_PRIO")) == 0);
+	const int sp = side_hi ? prio_hi : 0;
+	if (hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, sp) != hipSuccess || hipEventCreate(&c->ev_side[0]) != hipSuccess || hipEventCreate(&c->ev_side[1]) != hipSuccess || hipEventCreate(&c->ev_side[2]) != hipSuccess || hipEventCreate(&c->ev_side[3]) != hipSuccess ||
 	    hipEventCreateWithFlags(&c->ev_fj[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_fj[1], hipEventDisableTiming) != hipSuccess) { delete c; return nullptr; }
-	for (int i = 0; i < 3; ++i) if (hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_aux[i], hipEventDisableTiming) != hipSuccess) { delete c; return nullptr; }
+	for (int i = 0; i < 3; ++i) if (hipStreamCreateWithPriority(&c->aux[i], hipStreamNonBlocking, sp) != hipSuccess || hipEventCreateWithFlags(&c->ev_aux[i], hipEventDisableTiming) != hipSuccess) { delete c; return nullptr; }
+	for (int i = 0; i < 2; ++i) if (hipStreamCreateWithFlags(&c->ovl[i], hipStreamNonBlocking) != hipSuccess) { delete c; return nullptr; }
+	for (int i = 0; i < 4; ++i) if (hipEventCreateWithFlags(&c->ev_ovl[i], hipEventDisableTiming) != hipSuccess) { delete c; return nullptr; }
 	if (al_upload_index(mi, device, &c->di) != 0) { delete c; return nullptr; }
 	AlParams &P = c->P;
 	P.k = mi->k; P.w = mi->w; P.seed = opt->seed; P.bw = opt->bw; P.max_gap = opt->max_gap; P.max_gap_ref = opt->max_gap_ref; P.max_frag_len = opt->max_frag_len;
@@ -223,6 +231,7 @@ static void ctx_release_buffers(al_ctx_t *c)
 	al_align_state_free(c);
 	if (c->side) (void)hipStreamSynchronize(c->side);
 	for (int i = 0; i < 3; ++i) if (c->aux[i]) (void)hipStreamSynchronize(c->aux[i]);
+	for (int i = 0; i < 2; ++i) if (c->ovl[i]) (void)hipStreamSynchronize(c->ovl[i]);
 	if (c->stream) (void)hipStreamSynchronize(c->stream);
 	c->rd_seq.release(); c->rd_len.release(); c->frag_first.release(); c->frag_hash.release(); c->mini_cnt.release(); c->frag_nm.release(); c->frag_na.release();
 	c->frag_nu.release(); c->rechain_list.release(); c->rechain_sorted.release(); c->tmp_u32.release(); c->rd_off.release(); c->mini_off.release(); c->a_off.release(); c->u.release();
@@ -243,6 +252,8 @@ extern "C" void al_ctx_destroy(al_ctx_t *c)
 	for (int i = 0; i < 2; ++i) if (c->ev_fj[i]) (void)hipEventDestroy(c->ev_fj[i]);
 	if (c->side) (void)hipStreamDestroy(c->side);
 	for (int i = 0; i < 3; ++i) { if (c->aux[i]) (void)hipStreamDestroy(c->aux[i]); if (c->ev_aux[i]) (void)hipEventDestroy(c->ev_aux[i]); }
+	for (int i = 0; i < 2; ++i) if (c->ovl[i]) (void)hipStreamDestroy(c->ovl[i]);
+	for (int i = 0; i < 4; ++i) if (c->ev_ovl[i]) (void)hipEventDestroy(c->ev_ovl[i]);
 	if (c->stream) (void)hipStreamDestroy(c->stream);
 	delete c;
 }
@@ -330,13 +341,14 @@ extern "C" int al_batch_upload(al_ctx_t *c, int n_frag, const int *n_segs, const
 // ---------------------------------------------------------------------------------------------
 struct CastU64 { __host__ __device__ uint64_t operator()(const uint32_t &v) const { return (uint64_t)v; } };
 
-static int scan_u32_to_u64(al_ctx_t *c, const uint32_t *in, uint64_t *out, int n)
-{   // out[0..n] = exclusive prefix sums (n+1 entries; in[n] must be readable: callers pad with 0)
+static int scan_u32_to_u64(al_ctx_t *c, const uint32_t *in, uint64_t *out, int n, hipStream_t st = nullptr, DevBuf<unsigned char> *tmp = nullptr)
+{
+	hipStream_t s_ = st ? st : c->stream; DevBuf<unsigned char> &T_ = tmp ? *tmp : c->scan_tmp;   // out[0..n] = exclusive prefix sums (n+1 entries; in[n] must be readable: callers pad with 0)
 	auto it = rocprim::make_transform_iterator((const uint32_t *)in, CastU64());
 	size_t bytes = 0;
-	AL_HIP_CHECK(rocprim::exclusive_scan(nullptr, bytes, it, out, (uint64_t)0, (size_t)(n + 1), rocprim::plus<uint64_t>(), c->stream));
-	if (c->scan_tmp.ensure(bytes + 16)) return -1;
-	AL_HIP_CHECK(rocprim::exclusive_scan(c->scan_tmp.p, bytes, it, out, (uint64_t)0, (size_t)(n + 1), rocprim::plus<uint64_t>(), c->stream));
+	AL_HIP_CHECK(rocprim::exclusive_scan(nullptr, bytes, it, out, (uint64_t)0, (size_t)(n + 1), rocprim::plus<uint64_t>(), s_));
+	if (T_.ensure(bytes + 16)) return -1;
+	AL_HIP_CHECK(rocprim::exclusive_scan(T_.p, bytes, it, out, (uint64_t)0, (size_t)(n + 1), rocprim::plus<uint64_t>(), s_));
 	return 0;
 }
 
@@ -593,6 +605,7 @@ static int chain_tiles(al_ctx_t *c, const uint32_t *list, const TileSched &S, co
 		hipLaunchKernelGGL(k_chain_tile6, dim3(S.n_items), dim3(256), 0, s, c->anchors.p, c->a_off.p, c->frag_na.p, c->frag_meta.p, list, S, skip_flag,
 		                   c->chained.p, c->u.p, c->uo.p, c->frag_nu.p, c->fb_list.p, cnts, c->P, lmin, c->counters.p, force_fb, D);
 		if (ev(ST_SEG_FIND)) return -1;
+		if (c->ovl_pending) { AL_HIP_CHECK(hipStreamWaitEvent(s, c->ev_ovl[3], 0)); c->ovl_pending = false; }   // the lane kernels of the small fragments (ovl[1]): done before their scratch is used again
 		{ static const bool tr = getenv("AL_TRACE") != nullptr; if (tr) { const hipError_t e = hipStreamSynchronize(s); fprintf(stderr, "[airlift] trace: tile kernel (%u items, first pass %d) -> %s\n", S.n_items, (int)first, hipGetErrorName(e)); } }
 		uint32_t h[3] = {0, 0, 0};
 		AL_HIP_CHECK(hipMemcpyAsync(h, cnts, 12, hipMemcpyDeviceToHost, s));
@@ -650,6 +663,7 @@ static int chain_tiles(al_ctx_t *c, const uint32_t *list, const TileSched &S, co
 		{ static const bool tr = getenv("AL_TRACE") != nullptr; if (tr) { const hipError_t e = hipStreamSynchronize(s); fprintf(stderr, "[airlift] trace: compact (%u fragments) -> %s\n", n_cmp, hipGetErrorName(e)); } }
 		if (n_cmp > 0) { AL_HIP_CHECK(hipMemcpyAsync(&n_fb, cnts, 4, hipMemcpyDeviceToHost, s)); AL_HIP_CHECK(hipStreamSynchronize(s)); } else n_fb = h[0];
 	} else if (ev(ST_SEG_FIND) || ev(ST_SEG_CHAIN_LDS)) return -1;
+	if (c->ovl_pending) { AL_HIP_CHECK(hipStreamWaitEvent(s, c->ev_ovl[3], 0)); c->ovl_pending = false; }
 	if (n_fb > 0) {
 		c->n_chain_fallback += n_fb;
 		// (the list the kernels appended to atomically, in ascending fragment order: the same virtual batch on every run)
@@ -745,10 +759,46 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 		if (c->tie_list.ensure((size_t)c->n_frag + 2)) return -1;         // one flag per fragment id
 		unsigned int *tie_cnt = nullptr;
 		AL_HIP_CHECK(hipMemsetAsync(c->tie_list.p, 0, ((size_t)c->n_frag + 1) * 4, s));
+		int rid_bits = 1; while ((1ULL << rid_bits) < c->mi->seq.size()) ++rid_bits;
+		// above the register tiles: composite-key device radix sort, a chunk of fragments at a time so that rank + x + list fit 64 bits.
+		// Bandwidth-bound passes over a few hundred fragments' keys: on a stream of its own, beside the tile sorts (instruction-bound) of everything else.
+		hipStream_t sb = c->ovl[0];
+		AL_HIP_CHECK(hipEventRecord(c->ev_ovl[0], s)); AL_HIP_CHECK(hipStreamWaitEvent(sb, c->ev_ovl[0], 0));
+		int pos_bits = 1; { uint32_t mx = 1; for (const AlSeq &sq : c->mi->seq) mx = std::max(mx, sq.len); while (pos_bits < 31 && (1ULL << pos_bits) < mx) ++pos_bits; }
+		const int rank_bits = 64 - 16 - 1 - rid_bits - pos_bits;
+		static const char *e3 = getenv("AL_TEST_BIG_CHUNK");                // tests: fragments per device-wide sort
+		uint32_t chunk_max = rank_bits >= 31 ? 0x7fffffffu : rank_bits >= 1 ? (1u << rank_bits) : 1u;
+		if (e3 && atoi(e3) > 0) chunk_max = std::min<uint32_t>(chunk_max, (uint32_t)atoi(e3));
+		if (rank_bits < 0 && lb_big < (uint32_t)nl) {                       // (no such index in practice: > 2^46 contig-id x position range) exact merge for all of them
+			hipLaunchKernelGGL(k_flag_list, dim3(((uint32_t)nl - lb_big + 255) / 256), dim3(256), 0, sb, order + lb_big, (int)((uint32_t)nl - lb_big), c->tie_list.p);
+		}
+		for (uint32_t b0 = lb_big; rank_bits >= 0 && b0 < (uint32_t)nl; ) {
+			const uint32_t nb = std::min<uint32_t>((uint32_t)nl - b0, chunk_max);
+			if (c->big_na.ensure(nb + 2) || c->big_off.ensure(nb + 2)) return -1;
+			hipLaunchKernelGGL(k_gather_na, dim3((nb + 256) / 256), dim3(256), 0, sb, c->frag_na.p, order + b0, (int)nb, c->big_na.p);
+			if (scan_u32_to_u64(c, c->big_na.p, c->big_off.p, (int)nb, sb, &c->big_tmp)) return -1;
+			uint64_t nbig = 0;
+			AL_HIP_CHECK(hipMemcpyAsync(&nbig, c->big_off.p + nb, 8, hipMemcpyDeviceToHost, sb));
+			AL_HIP_CHECK(hipStreamSynchronize(sb));
+			if (c->big_k0.ensure((size_t)nbig + 1, false, sb) || c->big_k1.ensure((size_t)nbig + 1, false, sb)) return -1;
+			uint64_t *ka = c->big_k0.p, *kbuf = c->big_k1.p;                   // key double buffer
+			hipLaunchKernelGGL(k_anchor_big_expand, dim3(nb), dim3(256), 0, sb, c->di.pos, c->mini_off.p, c->frag_first.p, c->match.p, c->frag_nm.p,
+			                   order + b0, (int)nb, c->big_off.p, ka, rid_bits, pos_bits);
+			int rbits = 0; while ((1ULL << rbits) < nb) ++rbits;
+			rocprim::double_buffer<uint64_t> dk(ka, kbuf);
+			const unsigned end_bit = (unsigned)(16 + 1 + rid_bits + pos_bits + rbits);
+			size_t bytes = 0;
+			AL_HIP_CHECK(rocprim::radix_sort_keys(nullptr, bytes, dk, (size_t)nbig, 16u, end_bit, sb));
+			if (c->big_tmp.ensure(bytes + 16)) return -1;
+			AL_HIP_CHECK(rocprim::radix_sort_keys(c->big_tmp.p, bytes, dk, (size_t)nbig, 16u, end_bit, sb));
+			hipLaunchKernelGGL(k_anchor_big_scatter, dim3(nb), dim3(256), 0, sb, dk.current(), order + b0, (int)nb, c->big_off.p, c->a_off.p,
+			                   c->mini_off.p, c->frag_first.p, c->rd_len.p, c->match.p, c->frag_nm.p, c->anchors.p, c->tie_list.p, rid_bits, pos_bits, c->mi->k);
+			b0 += nb;
+		}
+		AL_HIP_CHECK(hipEventRecord(c->ev_ovl[1], sb));
 		if (lb65 > 0) hipLaunchKernelGGL(k_anchor_sort_small, dim3(lb65), dim3(64), 0, s, c->di.pos, c->frag_first.p, c->rd_len.p, c->mini_off.p, c->match.p, c->frag_nm.p, c->frag_na.p,
 		                                 c->a_off.p, c->anchors.p, c->tie_list.p, tie_cnt, order, (int)lb65, c->counters.p, c->mi->k);
 		if (ev(ST_ANCHOR_SORT_S)) return -1;
-		int rid_bits = 1; while ((1ULL << rid_bits) < c->mi->seq.size()) ++rid_bits;
 		const bool compact = 33 + rid_bits + 16 <= 64;                   // strand | contig | position | list in one 64-bit key
 #define LREG(P, W, M, A, B) do { if ((B) > (A)) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_anchor_sort_reg<P, W, M>), dim3((B) - (A)), dim3(64 * W), 0, s, c->di.pos, c->frag_first.p, c->rd_len.p, c->mini_off.p, c->match.p, c->frag_nm.p, c->frag_na.p, \
 		                                        c->a_off.p, c->anchors.p, c->tie_list.p, order + (A), (int)((B) - (A)), c->mi->k, rid_bits); } while (0)
@@ -756,41 +806,11 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 		else if (lb1025 > lb65) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_anchor_sort<1024>), dim3(lb1025 - lb65), dim3(64), 0, s, c->di.pos, c->frag_first.p, c->rd_len.p, c->mini_off.p, c->match.p, c->frag_nm.p, c->frag_na.p,
 		                                           c->a_off.p, c->anchors.p, c->tie_list.p, tie_cnt, order + lb65, (int)(lb1025 - lb65), c->counters.p, c->mi->k);
 		if (ev(ST_ANCHOR_SORT)) return -1;
+		AL_HIP_CHECK(hipEventRecord(c->ev_ovl[2], s));                       // fragments of up to 128 anchors are in order: their chaining (ovl[1], below) may start
 		LREG(8, 4, 1024, lb1025, lb2049); LREG(16, 4, 1024, lb2049, lb4097); LREG(16, 8, 1024, lb4097, lb_big);   // (non-compact keys: t_big == t_blk, empty ranges)
 #undef LREG
 		if (ev(ST_ANCHOR_SORT_BLK)) return -1;
-		// above the register tiles: composite-key device radix sort, a chunk of fragments at a time so that rank + x + list fit 64 bits
-		int pos_bits = 1; { uint32_t mx = 1; for (const AlSeq &sq : c->mi->seq) mx = std::max(mx, sq.len); while (pos_bits < 31 && (1ULL << pos_bits) < mx) ++pos_bits; }
-		const int rank_bits = 64 - 16 - 1 - rid_bits - pos_bits;
-		static const char *e3 = getenv("AL_TEST_BIG_CHUNK");                // tests: fragments per device-wide sort
-		uint32_t chunk_max = rank_bits >= 31 ? 0x7fffffffu : rank_bits >= 1 ? (1u << rank_bits) : 1u;
-		if (e3 && atoi(e3) > 0) chunk_max = std::min<uint32_t>(chunk_max, (uint32_t)atoi(e3));
-		if (rank_bits < 0 && lb_big < (uint32_t)nl) {                       // (no such index in practice: > 2^46 contig-id x position range) exact merge for all of them
-			hipLaunchKernelGGL(k_flag_list, dim3(((uint32_t)nl - lb_big + 255) / 256), dim3(256), 0, s, order + lb_big, (int)((uint32_t)nl - lb_big), c->tie_list.p);
-		}
-		for (uint32_t b0 = lb_big; rank_bits >= 0 && b0 < (uint32_t)nl; ) {
-			const uint32_t nb = std::min<uint32_t>((uint32_t)nl - b0, chunk_max);
-			if (c->big_na.ensure(nb + 2) || c->big_off.ensure(nb + 2)) return -1;
-			hipLaunchKernelGGL(k_gather_na, dim3((nb + 256) / 256), dim3(256), 0, s, c->frag_na.p, order + b0, (int)nb, c->big_na.p);
-			if (scan_u32_to_u64(c, c->big_na.p, c->big_off.p, (int)nb)) return -1;
-			uint64_t nbig = 0;
-			AL_HIP_CHECK(hipMemcpyAsync(&nbig, c->big_off.p + nb, 8, hipMemcpyDeviceToHost, s));
-			AL_HIP_CHECK(hipStreamSynchronize(s));
-			if (c->big_k0.ensure((size_t)nbig + 1, false, s) || c->big_k1.ensure((size_t)nbig + 1, false, s)) return -1;
-			uint64_t *ka = c->big_k0.p, *kbuf = c->big_k1.p;                   // key double buffer
-			hipLaunchKernelGGL(k_anchor_big_expand, dim3(nb), dim3(256), 0, s, c->di.pos, c->mini_off.p, c->frag_first.p, c->match.p, c->frag_nm.p,
-			                   order + b0, (int)nb, c->big_off.p, ka, rid_bits, pos_bits);
-			int rbits = 0; while ((1ULL << rbits) < nb) ++rbits;
-			rocprim::double_buffer<uint64_t> dk(ka, kbuf);
-			const unsigned end_bit = (unsigned)(16 + 1 + rid_bits + pos_bits + rbits);
-			size_t bytes = 0;
-			AL_HIP_CHECK(rocprim::radix_sort_keys(nullptr, bytes, dk, (size_t)nbig, 16u, end_bit, s));
-			if (c->scan_tmp.ensure(bytes + 16)) return -1;
-			AL_HIP_CHECK(rocprim::radix_sort_keys(c->scan_tmp.p, bytes, dk, (size_t)nbig, 16u, end_bit, s));
-			hipLaunchKernelGGL(k_anchor_big_scatter, dim3(nb), dim3(256), 0, s, dk.current(), order + b0, (int)nb, c->big_off.p, c->a_off.p,
-			                   c->mini_off.p, c->frag_first.p, c->rd_len.p, c->match.p, c->frag_nm.p, c->anchors.p, c->tie_list.p, rid_bits, pos_bits, c->mi->k);
-			b0 += nb;
-		}
+		AL_HIP_CHECK(hipStreamWaitEvent(s, c->ev_ovl[1], 0));                 // the device-wide sort (ovl[0], started before the tile sorts)
 		if (ev(ST_ANCHOR_SORT_BIG)) return -1;
 		// Fragments the sort kernels flagged (equal x: overlapping mates, tandem repeats): the reference's order among equal heads is
 		// that of its binary heap, which only a serial emulation reproduces (one lane per fragment) -- a latency-bound tail on a few
@@ -828,6 +848,12 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 		// chain-end scratch of the whole-fragment lane kernels: 64 words per entry of the <= 64-anchor classes, 128 above, by list position
 		const uint32_t n_lo = std::min(lb65, tile_from), n_mid_end = std::min(lb129, tile_from);
 		if (lds_ok && c->ws_u64.ensure((size_t)n_lo * 64 + (size_t)(n_mid_end > lb65 ? n_mid_end - lb65 : 0u) * 128 + 64, false, s)) return -1;
+		// The lane-per-fragment kernels (fragments of up to 128 anchors, memory latency) run on a stream of their own: beside the tile sorts
+		// of the large fragments and beside the tile kernel, which takes the rest of the list.
+		hipStream_t const s_main = s;
+		static const bool use_ovl = getenv("AL_CHAIN_OVL") != nullptr;        // (off: measured no gain -- these kernels and the sorts are bound by the same units)
+		if (use_ovl) AL_HIP_CHECK(hipStreamWaitEvent(c->ovl[1], c->ev_ovl[2], 0));
+		{ hipStream_t const s = use_ovl ? c->ovl[1] : s_main;
 #define LFR(C, L, A, B) LCH(C, L, -1, c->a_off.p, c->frag_na.p, c->chained.p, c->u.p, c->frag_nu.p, order + (A), (int)((B) - (A)), nosg, c->uo.p, c->ws_u64.p + (size_t)n_lo * 64 + (size_t)((A) - lb65) * 128, 128)
 #define LFRLO(C, L, LO) LCH(C, L, LO, c->a_off.p, c->frag_na.p, c->chained.p, c->u.p, c->frag_nu.p, order, (int)n_lo, nosg, c->uo.p, c->ws_u64.p, 64)
 		if (lds_ok) { LFRLO(16, 64, -1); LFRLO(24, 64, 16); LFRLO(32, 64, 24); }
@@ -852,6 +878,7 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 			}
 		}
 		if (ev(ST_CHAIN_LDS128)) return -1;
+		if (use_ovl) { AL_HIP_CHECK(hipEventRecord(c->ev_ovl[3], s)); c->ovl_pending = true; } }
 #undef LFR
 #undef LFRLO
 		if (tiles_ok) {
@@ -862,6 +889,7 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 			if (chain_tiles(c, order, S, (const uint32_t *)c->tie_list.p, lmin, first, lds_ok)) return -1;
 		} else {
 			if (ev(ST_SEG_FIND) || ev(ST_SEG_CHAIN_LDS)) return -1;
+			if (c->ovl_pending) { AL_HIP_CHECK(hipStreamWaitEvent(s, c->ev_ovl[3], 0)); c->ovl_pending = false; }
 			const uint32_t tail = lds_ok ? lb129 : 0u;
 			if (chain_legacy(c, order + tail, nl - (int)tail, lds_ok, (const uint32_t *)c->tie_list.p)) return -1;
 			if (ev(ST_SEG_CHAIN_WAVE)) return -1;
