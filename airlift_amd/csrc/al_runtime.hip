@@ -202,11 +202,11 @@ extern "C" al_ctx_t *al_ctx_init(const al_idx_t *mi, const al_mapopt_t *opt, int
 	c->mi = mi; c->opt = *opt; c->device = device;
 	if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return nullptr; }
 	for (int i = 0; i <= ST_N; ++i) if (hipEventCreate(&c->ev[i]) != hipSuccess) { delete c; return nullptr; }
-	// The side streams carry the thin, latency-bound classes (a few hundred to a few thousand blocks that wait on one lane, or on a large LDS
-	// tile): at the main stream's priority their blocks wait for a CU slot behind the hundreds of thousands of small blocks of the kernel that
-	// runs beside them (k_regs_select<8192>: 4.5 ms alone, 20 ms beside <1024>).  AL_SIDE_PRIO=0: same priority as the main stream.
+	// AL_SIDE_PRIO=1 (experiment): the side streams at the highest stream priority.  Their thin classes then get CU slots ahead of the small
+	// blocks of the kernels beside them, but the main stream's kernel does not start before they are all placed and the hardware queues are
+	// shared out differently: measured 3 ms slower per C4 step than equal priorities.
 	int prio_lo = 0, prio_hi = 0; (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-	static const bool side_hi = !(getenv("AL_SIDE_PRIO") && atoi(getenv("AL_SIDE_PRIO")) == 0);
+	static const bool side_hi = getenv("AL_SIDE_PRIO") && atoi(getenv("AL_SIDE_PRIO")) == 1;
 	const int sp = side_hi ? prio_hi : 0;
 	if (hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, sp) != hipSuccess || hipEventCreate(&c->ev_side[0]) != hipSuccess || hipEventCreate(&c->ev_side[1]) != hipSuccess || hipEventCreate(&c->ev_side[2]) != hipSuccess || hipEventCreate(&c->ev_side[3]) != hipSuccess ||
 	    hipEventCreateWithFlags(&c->ev_fj[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_fj[1], hipEventDisableTiming) != hipSuccess) { delete c; return nullptr; }
@@ -851,7 +851,7 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 		// The lane-per-fragment kernels (fragments of up to 128 anchors, memory latency) run on a stream of their own: beside the tile sorts
 		// of the large fragments and beside the tile kernel, which takes the rest of the list.
 		hipStream_t const s_main = s;
-		static const bool use_ovl = getenv("AL_CHAIN_OVL") != nullptr;        // (off: measured no gain -- these kernels and the sorts are bound by the same units)
+		static const bool use_ovl = !(getenv("AL_CHAIN_OVL") && atoi(getenv("AL_CHAIN_OVL")) == 0);   // (AL_CHAIN_OVL=0: on the main stream, after the sorts)
 		if (use_ovl) AL_HIP_CHECK(hipStreamWaitEvent(c->ovl[1], c->ev_ovl[2], 0));
 		{ hipStream_t const s = use_ovl ? c->ovl[1] : s_main;
 #define LFR(C, L, A, B) LCH(C, L, -1, c->a_off.p, c->frag_na.p, c->chained.p, c->u.p, c->frag_nu.p, order + (A), (int)((B) - (A)), nosg, c->uo.p, c->ws_u64.p + (size_t)n_lo * 64 + (size_t)((A) - lb65) * 128, 128)
