@@ -7,6 +7,13 @@
 // 16-cell block, exactly the x1_/v1_/x21_ registers of the SSE code); the row maximum is a 4-step DPP butterfly on a
 // 64-bit key that encodes the reference's evaluation order.  No LDS traffic and no barrier inside a row except the
 // query byte (one ds_read_u8 per active block) and the traceback byte store.
+// Instruction diet of the block body (it runs at the VALU issue rate, so every instruction is time):
+//   * the substitution score is one v_perm_b32: W[b] holds the lane's target base scored against query bases 0..3, one per byte
+//     (all sc_N for a target N), the query byte is the selector (4 = N picks sc_N from the other source);
+//   * the query row is padded by 16*NB bytes on both sides, so the query byte of block b is a constant 16*b from the lane's
+//     row pointer -- no index clamps;
+//   * inside the row a lane only tracks its best cell as H*64 | end-cell flag | (31 - block): the position key of the
+//     reference's evaluation order (:307-349) is rebuilt once per row from the winning block, not once per block.
 #pragma once
 
 #define DPP_ROW_SHR1    0x111
@@ -37,20 +44,28 @@ __device__ __forceinline__ void d_ksw_reg(LT &L, const int gl, GroupWs &ws, int 
 	const int long_diff = long_thres * (e - e2) - (q2 - q) - e2;
 	const bool right = (flag & EZ_RIGHT) != 0;
 	const long long tP0 = PROF_ON(P) ? clock64() : 0;
-	uint8_t *qr = L.sq;                                   // reversed query, zero padded (ksw2_extd2_sse.c:118)
-	for (int t = gl; t < qlen_ * 16 + 32; t += GW) qr[t] = t < qlen ? L.qbuf[qlen - 1 - t] : 0;
-	uint32_t A[NB], B[NB]; int32_t H[NB];
+	// reversed query, zero padded (ksw2_extd2_sse.c:118), with 16*NB bytes in front (never used by a cell that takes its score) and
+	// zeros up to qlen + 16*NB + 16 behind: every block of every row reads in bounds without a clamp
+	constexpr int QPAD = 16 * NB;
+	uint8_t *qr = L.sq + QPAD;
+	if constexpr (!LT::kQrReady) for (int t = gl; t < qlen + QPAD + 16; t += GW) qr[t] = t < qlen ? L.qbuf[qlen - 1 - t] : 0;
+	(void)qlen_;
+	uint32_t A[NB], B[NB], W[NB]; int32_t H[NB];
+	uint32_t nreg = (uint32_t)(uint8_t)sc_N;                  // source 0 of the score permute: byte 0 = score against a query N
 	{
 		const uint32_t m1 = (uint8_t)(int8_t)(-q - e), m2 = (uint8_t)(int8_t)(-q2 - e2);
+		const uint32_t misrep = 0x01010101u * (uint32_t)(uint8_t)sc_mis, nrep = 0x01010101u * (uint32_t)(uint8_t)sc_N;
 #pragma unroll
 		for (int b = 0; b < NB; ++b) {
 			const int t = 16 * b + gl;
-			const uint32_t sfv = t < tlen ? L.tbuf[t] : 0;
+			const uint32_t tb = t < tlen ? L.tbuf[t] : 0;
 			A[b] = m1 | m1 << 8 | m2 << 16 | m1 << 24;
-			B[b] = m1 | m2 << 8 | 0u << 16 | sfv << 24;
+			B[b] = m1 | m2 << 8;
+			W[b] = tb >= 4 ? nrep : ((misrep & ~(0xffu << (8 * tb))) | (uint32_t)(uint8_t)sc_mch << (8 * tb));
 			H[b] = KSW_NEG_INF;
 		}
 	}
+	asm volatile("" : "+v"(nreg));
 	GSYNC();
 	const size_t prow = (size_t)n_col_ * 16;
 	uint8_t *const ptb = (size_t)(qlen + tlen - 1) * prow <= AL_LPTB ? L.ptb : ws.p;
@@ -81,7 +96,7 @@ __device__ __forceinline__ void d_ksw_reg(LT &L, const int gl, GroupWs &ws, int 
 		}
 		const int8_t ubound = r == 0 ? (int8_t)(-q - e) : r < long_thres ? (int8_t)(-e) : r == long_thres ? (int8_t)long_diff : (int8_t)(-e2);
 		uint8_t *const prl = ptb + (size_t)r * prow - st + gl;              // this lane's byte of block 0; block b is a constant 16*b further
-		const uint8_t *qrr = qr + (qlen - 1 - r);
+		const uint8_t *const qrow = qr + (qlen - 1 - r) + gl;               // this lane's query byte of block 0; block b is a constant 16*b further
 		const int be = en0 >> 4;
 		int hprev15 = 0;                                                 // H[r-1][en0-1] when en0 is the first lane of its block (that block may be outside [st_,en_])
 		if (NB > 1) {
@@ -92,12 +107,12 @@ __device__ __forceinline__ void d_ksw_reg(LT &L, const int gl, GroupWs &ws, int 
 			hprev15 = (r > 0 && (en0 & 15) == 0) ? hv : 0;
 		}
 		const int en1 = st0 + (en0 - st0) / 4 * 4;
-		const uint32_t ybits = (uint32_t)(uint8_t)(int8_t)(-q - e) | (uint32_t)(uint8_t)(int8_t)(-q2 - e2) << 8;
+		uint32_t ybits = (uint32_t)(uint8_t)(int8_t)(-q - e) | (uint32_t)(uint8_t)(int8_t)(-q2 - e2) << 8, ub0 = (uint32_t)(uint8_t)ubound;
+		asm volatile("" : "+v"(ybits), "+v"(ub0));                         // (in VGPRs: one v_perm_b32 each below, no second literal on the constant bus)
 		const bool enr = en >= r;
 		const int tend = tlen_ * 16;
-		const int qclamp = qlen_ * 16 + 31;
 		const bool store_p = !((P.dbg >> 23) & 1);
-		int key32 = (int)0x80000000;                                     // this lane's best (H<<16 | 0xffff-ord)
+		int lkey = (int)0x80000000;                                      // this lane's best cell: H*64 | (end cell or row 0) << 5 | 31 - block
 		// The block body is straight-line code: every condition below is uniform inside a 16-lane group but differs between
 		// the four groups of a wavefront, so each `if` would cost an exec-mask round trip per block.  Only two branches
 		// remain: skipping a block no group-lane needs, and the timing-experiment switch around the traceback store.
@@ -108,15 +123,16 @@ __device__ __forceinline__ void d_ksw_reg(LT &L, const int gl, GroupWs &ws, int 
 			const int t = 16 * b + gl;
 			uint32_t a_old = A[b], b_old = B[b];
 			const bool isr = act && enr && t == r;                           // y[r], y2[r], u[r] (:150-153)
-			b_old = isr ? ((b_old & 0xffff0000u) | ybits) : b_old;
-			a_old = isr ? ((a_old & 0x00ffffffu) | (uint32_t)(uint8_t)ubound << 24) : a_old;
-			{                                                                // score bytes (:158-176); the LDS read is unconditional on a clamped index
+			{
+				const uint32_t by = __builtin_amdgcn_perm(b_old, ybits, 0x07060100u);   // bytes 0,1 <- y, y2
+				const uint32_t au = __builtin_amdgcn_perm(ub0, a_old, 0x04020100u);     // byte 3 <- u
+				b_old = isr ? by : b_old; a_old = isr ? au : a_old;
+			}
+			{                                                                // score bytes (:158-176): score of (target base of this lane, query byte) by one byte permute
 				const bool son = act && t >= st0 && t <= cover_end && t < tend;
-				int qi = qlen - 1 - r + t; qi = qi < 0 ? 0 : qi; qi = qi > qclamp ? qclamp : qi;
-				const uint32_t sq = b_old >> 24, sq2 = qr[qi];
-				int sc = sq == sq2 ? (int)sc_mch : (int)sc_mis;
-				sc = (sq == 4 || sq2 == 4) ? (int)sc_N : sc;
-				const uint32_t bs = (b_old & 0xff00ffffu) | ((uint32_t)sc & 0xffu) << 16;
+				const uint32_t sq2 = qrow[16 * b];
+				const uint32_t scw = __builtin_amdgcn_perm(nreg, W[b], sq2);
+				const uint32_t bs = __builtin_amdgcn_perm(b_old, scw, 0x07000504u);     // byte 2 <- score
 				b_old = son ? bs : b_old;
 			}
 			const uint32_t left = (uint32_t)d_dpp_shr1((int)carry, (int)a_old);
@@ -155,14 +171,20 @@ __device__ __forceinline__ void d_ksw_reg(LT &L, const int gl, GroupWs &ws, int 
 				const int h_v = hold + vn, h_u = hl + un, h_0 = vn - qe;
 				int h = (isen && en0 > 0) ? h_u : h_v;
 				h = r0c ? h_0 : h;
-				const int dt = t - st0;
-				const int ord_a = 1 + (dt & 3) * 4096 + (dt >> 2), ord_b = 1 + 4 * 4096 + (t - en1);
-				int ord = t < en1 ? ord_a : ord_b;
-				ord = (isen || r0c) ? 0 : ord;
 				const bool upd = inr || r0c;
 				H[b] = upd ? h : hold;
-				{ const int k2 = h * 65536 + (0xffff - ord); key32 = (upd && k2 > key32) ? k2 : key32; }
+				// equal H inside a lane: the end cell (evaluated first by the reference) wins, then the lower block (its cells come earlier in the
+				// reference's order: (t - st0) & 3 is the same for all of a lane's cells, the tail cells t >= en1 sit in the last blocks)
+				{ const int k2 = h * 64 + ((isen || r0c) ? 63 - b : 31 - b); lkey = (upd && k2 > lkey) ? k2 : lkey; }
 			}
+		}
+		int key32;                                                       // this lane's best as (H<<16 | 0xffff-ord), ord = rank in the reference's evaluation order
+		{
+			const int cb = lkey & 63, tt = 16 * (31 - (cb & 31)) + gl, dt = tt - st0;
+			const int ord_a = 1 + (dt & 3) * 4096 + (dt >> 2), ord_b = 1 + 4 * 4096 + (tt - en1);
+			int ord = tt < en1 ? ord_a : ord_b;
+			ord = cb >= 32 ? 0 : ord;
+			key32 = lkey == (int)0x80000000 ? lkey : (lkey >> 6) * 65536 + (0xffff - ord);
 		}
 		int max_H, max_t;
 		{

@@ -38,7 +38,8 @@ struct EzD { int max, zdropped, max_q, max_t, mqe, mqe_t, mte, score, n_cigar, r
 template <int TMAX, int QMAX> struct GroupLds {
 	int8_t u[TMAX], v[TMAX], x[TMAX], y[TMAX], x2[TMAX], y2[TMAX], s[TMAX];
 	int32_t H[TMAX];
-	uint8_t sq[TMAX + QMAX + 48];   // sf[tlen_*16] immediately followed by qr[] (one allocation in the reference: ksw2_extd2_sse.c:99-103)
+	static constexpr bool kQrReady = false;   // d_ksw_reg builds the reversed query from qbuf
+	uint8_t sq[QMAX + 2 * (TMAX + 16) + 64];   // LDS-row DP: sf[tlen_*16] immediately followed by qr[] (one allocation in the reference: ksw2_extd2_sse.c:99-103); register DP: the reversed query between two pads of 16 bytes per block
 	uint8_t tbuf[TMAX + 16];        // target of the current DP job / alignment window
 	uint8_t qbuf[QMAX + 16];        // query of the current DP job
 	uint8_t q0[QMAX + 16], q1[QMAX + 16];   // qseq0[0] (forward) and qseq0[1] (reverse complement), align.c:865-870
@@ -1809,8 +1810,9 @@ k_ext_prep(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_
 }
 
 template <int QMAXJ, int TMAXJ> struct JobLds {
-	uint8_t sq[QMAXJ + 64];         // reversed query, zero padded
-	uint8_t tbuf[TMAXJ + 16], qbuf[QMAXJ + 16];
+	static constexpr bool kQrReady = true;   // k_ext_dp stores the reversed, padded query itself
+	uint8_t sq[QMAXJ + 2 * TMAXJ + 32];      // TMAXJ bytes of front pad, the reversed query, zeros up to qlen + TMAXJ + 16 (al_dev_ksw.h)
+	uint8_t tbuf[TMAXJ + 16];
 	uint32_t ezc[AL_LCIG];
 	uint8_t ptb[AL_LPTB];
 };
@@ -1842,18 +1844,21 @@ k_ext_dp(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_of
 		const ExtJob job = E.jobs[j];
 		const int ql = job.qlen, tl = job.tlen;
 		const uint32_t *seq = rd_seq + rd_off[job.read]; const int rqlen = (int)rd_len[job.read];
-		if (job.kind == 0) {                                                  // left: both reversed (mm_seq_rev, align.c:694-695)
+		// the query goes in reversed (ksw2_extd2_sse.c:118: qr[t] = query[qlen - 1 - t]) behind the front pad, zeros after it
+		uint8_t *const qr = L.sq + TMAXJ;
+		if (job.kind == 0) {                                                  // left: both reversed (mm_seq_rev, align.c:694-695): query[i] = Q(qoff - i)
 			const ReadAcc Q{seq, rqlen, job.rev, 0};
-			for (int i = gl; i < ql; i += GW) L.qbuf[i] = (uint8_t)Q((int)job.qoff - i);
+			for (int t = gl; t < ql + TMAXJ + 16; t += GW) qr[t] = t < ql ? (uint8_t)Q((int)job.qoff - (ql - 1 - t)) : 0;
 			for (int i = gl; i < tl; i += GW) L.tbuf[i] = (uint8_t)d_seq4(G.S4, job.toff - (uint64_t)i);
 		} else {
 			const ReadAcc Q{seq, rqlen, job.rev, (int)job.qoff};
-			for (int i = gl; i < ql; i += GW) L.qbuf[i] = (uint8_t)Q(i);
+			for (int t = gl; t < ql + TMAXJ + 16; t += GW) qr[t] = t < ql ? (uint8_t)Q(ql - 1 - t) : 0;
 			for (int i = gl; i < tl; i += GW) L.tbuf[i] = (uint8_t)d_seq4(G.S4, job.toff + (uint64_t)i);
 		}
 		GSYNC();
 		EzD ez; d_ez_reset(ez);
 		const int flag = job.kind == 0 ? (EZ_EXTZ_ONLY | EZ_RIGHT | EZ_REV_CIGAR) : EZ_EXTZ_ONLY;
+		static_assert(TMAXJ == 16 * NB, "the query pad of JobLds is one block row");
 		d_ksw_reg<NB>(L, gl, ws, ql, tl, P, bw, P.zdrop, P.end_bonus, flag, ez);
 		ExtOut o;
 		o.max = ez.max; o.max_q = ez.max_q; o.max_t = ez.max_t; o.mqe_t = ez.mqe_t;

@@ -755,6 +755,42 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 	const uint32_t tile_from = !tiles_ok ? (uint32_t)nl : tile_all ? lb1 : lb129;
 	if (c->fb_list.ensure((size_t)nl + 2)) return -1;
 	if (ev(ST_ORDER)) return -1;
+	auto chain_small = [&]() -> int {   // fragments of up to 128 anchors: the lane-per-fragment kernels
+		const ChainSeg nosg{nullptr, nullptr, (const uint32_t *)c->tie_list.p, 1, nullptr};
+		// chain-end scratch of the whole-fragment lane kernels: 64 words per entry of the <= 64-anchor classes, 128 above, by list position
+		const uint32_t n_lo = std::min(lb65, tile_from), n_mid_end = std::min(lb129, tile_from);
+		if (lds_ok && c->ws_u64.ensure((size_t)n_lo * 64 + (size_t)(n_mid_end > lb65 ? n_mid_end - lb65 : 0u) * 128 + 64, false, s)) return -1;
+		// The lane-per-fragment kernels (fragments of up to 128 anchors, memory latency) run on a stream of their own: beside the tile sorts
+		// of the large fragments and beside the tile kernel, which takes the rest of the list.
+		hipStream_t const s_main = s;
+		static const bool use_ovl = !(getenv("AL_CHAIN_OVL") && atoi(getenv("AL_CHAIN_OVL")) == 0);   // (AL_CHAIN_OVL=0: on the main stream, after the sorts)
+		if (use_ovl) AL_HIP_CHECK(hipStreamWaitEvent(c->ovl[1], c->ev_ovl[2], 0));
+		{ hipStream_t const s = use_ovl ? c->ovl[1] : s_main;
+#define LFR(C, L, A, B) LCH(C, L, -1, c->a_off.p, c->frag_na.p, c->chained.p, c->u.p, c->frag_nu.p, order + (A), (int)((B) - (A)), nosg, c->uo.p, c->ws_u64.p + (size_t)n_lo * 64 + (size_t)((A) - lb65) * 128, 128)
+#define LFRLO(C, L, LO) LCH(C, L, LO, c->a_off.p, c->frag_na.p, c->chained.p, c->u.p, c->frag_nu.p, order, (int)n_lo, nosg, c->uo.p, c->ws_u64.p, 64)
+		if (lds_ok) { LFRLO(16, 64, -1); LFRLO(24, 64, 16); LFRLO(32, 64, 24); }
+		if (lds_ok) { LFRLO(40, 64, 32); LFRLO(48, 64, 40); }
+		if (lds_ok) LFRLO(64, 64, 48);
+		if (lds_ok && n_mid_end > lb65) {   // exact ranges of the size-ordered list (lane counts differ between these classes)
+			// 64-lane wavefronts hold more fragments per CU but need enough of them to cover the chip; a thin class runs on half waves
+			const uint32_t fill = 64u * 3u * 256u * 2u;
+			static const uint32_t wave_max = getenv("AL_CHAIN_WAVE_MAX") ? (uint32_t)atoi(getenv("AL_CHAIN_WAVE_MAX")) : 8192u;
+			uint32_t from = lb65;
+			if (lb129 - lb65 < wave_max) {   // few fragments of 65 ... 128 anchors (a small batch): a wavefront each is over sooner than a lane each
+				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<AL_CHAIN_CAP>), dim3(lb129 - lb65), dim3(64), 0, s, c->anchors.p, c->a_off.p, c->frag_na.p, c->frag_first.p, c->rd_len.p, c->chained.p, c->u.p, c->frag_nu.p,
+				                   (int32_t *)nullptr, (uint64_t *)nullptr, order + lb65, (int)(lb129 - lb65), c->P, c->counters.p, nosg);   // (<= 128 anchors: its rows are in LDS, no scratch)
+				hipLaunchKernelGGL(k_uo_fill, dim3(lb129 - lb65), dim3(64), 0, s, order + lb65, (int)(lb129 - lb65), c->a_off.p, c->frag_nu.p, c->u.p, c->uo.p, (const uint32_t *)c->tie_list.p);
+			} else {
+				if (lb81 - lb65 >= fill) { LFR(80, 64, lb65, lb81); from = lb81; }
+				if (from == lb81 && lb97 - lb81 >= fill) { LFR(96, 64, lb81, lb97); from = lb97; }
+				LFR(128, 32, from, lb129);
+			}
+		}
+		if (use_ovl) { AL_HIP_CHECK(hipEventRecord(c->ev_ovl[3], s)); c->ovl_pending = true; } }
+#undef LFR
+#undef LFRLO
+		return 0;
+	};
 	{
 		if (c->tie_list.ensure((size_t)c->n_frag + 2)) return -1;         // one flag per fragment id
 		unsigned int *tie_cnt = nullptr;
@@ -809,6 +845,8 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 		AL_HIP_CHECK(hipEventRecord(c->ev_ovl[2], s));                       // fragments of up to 128 anchors are in order: their chaining (ovl[1], below) may start
 		LREG(8, 4, 1024, lb1025, lb2049); LREG(16, 4, 1024, lb2049, lb4097); LREG(16, 8, 1024, lb4097, lb_big);   // (non-compact keys: t_big == t_blk, empty ranges)
 #undef LREG
+		// (enqueued before the merge kernels of the side streams below: whichever hardware queue ovl[1] shares, these do not wait behind one of those)
+		if (chain_small()) return -1;
 		if (ev(ST_ANCHOR_SORT_BLK)) return -1;
 		AL_HIP_CHECK(hipStreamWaitEvent(s, c->ev_ovl[1], 0));                 // the device-wide sort (ovl[0], started before the tile sorts)
 		if (ev(ST_ANCHOR_SORT_BIG)) return -1;
@@ -844,43 +882,7 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 		if (ev(ST_ANCHOR_HEAP)) return -1;
 	}
 	{
-		const ChainSeg nosg{nullptr, nullptr, (const uint32_t *)c->tie_list.p, 1, nullptr};
-		// chain-end scratch of the whole-fragment lane kernels: 64 words per entry of the <= 64-anchor classes, 128 above, by list position
-		const uint32_t n_lo = std::min(lb65, tile_from), n_mid_end = std::min(lb129, tile_from);
-		if (lds_ok && c->ws_u64.ensure((size_t)n_lo * 64 + (size_t)(n_mid_end > lb65 ? n_mid_end - lb65 : 0u) * 128 + 64, false, s)) return -1;
-		// The lane-per-fragment kernels (fragments of up to 128 anchors, memory latency) run on a stream of their own: beside the tile sorts
-		// of the large fragments and beside the tile kernel, which takes the rest of the list.
-		hipStream_t const s_main = s;
-		static const bool use_ovl = !(getenv("AL_CHAIN_OVL") && atoi(getenv("AL_CHAIN_OVL")) == 0);   // (AL_CHAIN_OVL=0: on the main stream, after the sorts)
-		if (use_ovl) AL_HIP_CHECK(hipStreamWaitEvent(c->ovl[1], c->ev_ovl[2], 0));
-		{ hipStream_t const s = use_ovl ? c->ovl[1] : s_main;
-#define LFR(C, L, A, B) LCH(C, L, -1, c->a_off.p, c->frag_na.p, c->chained.p, c->u.p, c->frag_nu.p, order + (A), (int)((B) - (A)), nosg, c->uo.p, c->ws_u64.p + (size_t)n_lo * 64 + (size_t)((A) - lb65) * 128, 128)
-#define LFRLO(C, L, LO) LCH(C, L, LO, c->a_off.p, c->frag_na.p, c->chained.p, c->u.p, c->frag_nu.p, order, (int)n_lo, nosg, c->uo.p, c->ws_u64.p, 64)
-		if (lds_ok) { LFRLO(16, 64, -1); LFRLO(24, 64, 16); LFRLO(32, 64, 24); }
-		if (ev(ST_CHAIN_LDS32)) return -1;
-		if (lds_ok) { LFRLO(40, 64, 32); LFRLO(48, 64, 40); }
-		if (ev(ST_CHAIN_LDS48)) return -1;
-		if (lds_ok) LFRLO(64, 64, 48);
-		if (ev(ST_CHAIN_LDS64)) return -1;
-		if (lds_ok && n_mid_end > lb65) {   // exact ranges of the size-ordered list (lane counts differ between these classes)
-			// 64-lane wavefronts hold more fragments per CU but need enough of them to cover the chip; a thin class runs on half waves
-			const uint32_t fill = 64u * 3u * 256u * 2u;
-			static const uint32_t wave_max = getenv("AL_CHAIN_WAVE_MAX") ? (uint32_t)atoi(getenv("AL_CHAIN_WAVE_MAX")) : 8192u;
-			uint32_t from = lb65;
-			if (lb129 - lb65 < wave_max) {   // few fragments of 65 ... 128 anchors (a small batch): a wavefront each is over sooner than a lane each
-				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<AL_CHAIN_CAP>), dim3(lb129 - lb65), dim3(64), 0, s, c->anchors.p, c->a_off.p, c->frag_na.p, c->frag_first.p, c->rd_len.p, c->chained.p, c->u.p, c->frag_nu.p,
-				                   (int32_t *)nullptr, (uint64_t *)nullptr, order + lb65, (int)(lb129 - lb65), c->P, c->counters.p, nosg);   // (<= 128 anchors: its rows are in LDS, no scratch)
-				hipLaunchKernelGGL(k_uo_fill, dim3(lb129 - lb65), dim3(64), 0, s, order + lb65, (int)(lb129 - lb65), c->a_off.p, c->frag_nu.p, c->u.p, c->uo.p, (const uint32_t *)c->tie_list.p);
-			} else {
-				if (lb81 - lb65 >= fill) { LFR(80, 64, lb65, lb81); from = lb81; }
-				if (from == lb81 && lb97 - lb81 >= fill) { LFR(96, 64, lb81, lb97); from = lb97; }
-				LFR(128, 32, from, lb129);
-			}
-		}
-		if (ev(ST_CHAIN_LDS128)) return -1;
-		if (use_ovl) { AL_HIP_CHECK(hipEventRecord(c->ev_ovl[3], s)); c->ovl_pending = true; } }
-#undef LFR
-#undef LFRLO
+		if (ev(ST_CHAIN_LDS32) || ev(ST_CHAIN_LDS48) || ev(ST_CHAIN_LDS64) || ev(ST_CHAIN_LDS128)) return -1;
 		if (tiles_ok) {
 			TileSched S; const uint32_t b[6] = {tile_from, std::max(tile_from, lb33), std::max(tile_from, lb65), std::max(tile_from, lb129), std::max(tile_from, lb257x), std::max(tile_from, lb513x)};
 			for (int k = 0; k < 6; ++k) S.ent[k] = b[k]; S.ent[6] = (uint32_t)nl;
