@@ -22,7 +22,10 @@
 #define DPP_HALF_MIRROR 0x141
 #define DPP_ROW_MIRROR  0x140
 
+#define DPP_ROW_BCAST15 0x15F    // row_newbcast:15 -- lane 15 of every 16-lane row to all lanes of the row
+
 __device__ __forceinline__ int d_dpp_shr1(int carry, int v) { return __builtin_amdgcn_update_dpp(carry, v, DPP_ROW_SHR1, 0xf, 0xf, false); }
+__device__ __forceinline__ int d_dpp_last(int v) { return __builtin_amdgcn_update_dpp(0, v, DPP_ROW_BCAST15, 0xf, 0xf, false); }   // (a VALU move: no LDS round trip as with ds_bpermute)
 
 template <int NB, class LT>
 __device__ __forceinline__ void d_ksw_reg(LT &L, const int gl, GroupWs &ws, int qlen, int tlen, const AlParams &P,
@@ -68,7 +71,8 @@ __device__ __forceinline__ void d_ksw_reg(LT &L, const int gl, GroupWs &ws, int 
 	asm volatile("" : "+v"(nreg));
 	GSYNC();
 	const size_t prow = (size_t)n_col_ * 16;
-	uint8_t *const ptb = (size_t)(qlen + tlen - 1) * prow <= AL_LPTB ? L.ptb : ws.p;
+	uint8_t *ptb = ws.p;                                  // traceback bytes: the LDS tile when the job's rows fit (a structure without a tile: always the HBM scratch)
+	if constexpr (LT::kPtb > 0) { if ((size_t)(qlen + tlen - 1) * prow <= (size_t)LT::kPtb) ptb = L.ptb; }
 	int last_st = -1, last_en = -1, r;
 	const long long tP1 = PROF_ON(P) ? clock64() : 0;
 	const int n_rows_dbg = ((P.dbg >> 22) & 1) ? 0 : qlen + tlen - 1;
@@ -88,7 +92,7 @@ __device__ __forceinline__ void d_ksw_reg(LT &L, const int gl, GroupWs &ws, int 
 				if (st - 1 >= last_st && st - 1 <= last_en) {
 					uint32_t av = 0;
 #pragma unroll
-					for (int b = 0; b < NB; ++b) if (b == st_ - 1) av = (uint32_t)__shfl((int)A[b], GW - 1, GW);
+					for (int b = 0; b < NB; ++b) if (b == st_ - 1) av = (uint32_t)d_dpp_last((int)A[b]);
 					x1 = (int8_t)av; v1 = (int8_t)(av >> 8); x21 = (int8_t)(av >> 16);
 				}
 			} else v1 = r == 0 ? (int8_t)(-q - e) : r < long_thres ? (int8_t)(-e) : r == long_thres ? (int8_t)long_diff : (int8_t)(-e2);
@@ -99,12 +103,11 @@ __device__ __forceinline__ void d_ksw_reg(LT &L, const int gl, GroupWs &ws, int 
 		const uint8_t *const qrow = qr + (qlen - 1 - r) + gl;               // this lane's query byte of block 0; block b is a constant 16*b further
 		const int be = en0 >> 4;
 		int hprev15 = 0;                                                 // H[r-1][en0-1] when en0 is the first lane of its block (that block may be outside [st_,en_])
-		if (NB > 1) {
+		if (NB > 1 && r > 0 && (en0 & 15) == 0) {                           // (one row in sixteen per group: skipped when no group of the wavefront needs it)
 			int hsel = 0;
 #pragma unroll
 			for (int b = 0; b < NB; ++b) hsel = (b + 1 == be) ? H[b] : hsel;
-			const int hv = __shfl(hsel, GW - 1, GW);
-			hprev15 = (r > 0 && (en0 & 15) == 0) ? hv : 0;
+			hprev15 = d_dpp_last(hsel);
 		}
 		const int en1 = st0 + (en0 - st0) / 4 * 4;
 		uint32_t ybits = (uint32_t)(uint8_t)(int8_t)(-q - e) | (uint32_t)(uint8_t)(int8_t)(-q2 - e2) << 8, ub0 = (uint32_t)(uint8_t)ubound;
@@ -136,19 +139,22 @@ __device__ __forceinline__ void d_ksw_reg(LT &L, const int gl, GroupWs &ws, int 
 				b_old = son ? bs : b_old;
 			}
 			const uint32_t left = (uint32_t)d_dpp_shr1((int)carry, (int)a_old);
-			if (NB > 1) { const uint32_t cn = (uint32_t)__shfl((int)a_old, GW - 1, GW); carry = act ? cn : carry; }
+			if (NB > 1) { const uint32_t cn = (uint32_t)d_dpp_last((int)a_old); carry = act ? cn : carry; }
 			const int xt1 = (int8_t)left, vt1 = (int8_t)(left >> 8), x2t1 = (int8_t)(left >> 16);
 			const int ut = (int8_t)(a_old >> 24), yo = (int8_t)b_old, y2o = (int8_t)(b_old >> 8);
 			int z = (int8_t)(b_old >> 16);
 			// int8 lanes of the reference, held sign-extended in 32-bit registers: every sum below is re-wrapped to int8
 			int a = (int8_t)(xt1 + vt1), bb = (int8_t)(yo + ut), a2 = (int8_t)(x2t1 + vt1), b2 = (int8_t)(y2o + ut);
 			// left-aligned gaps take a strict '>' (ksw2_extd2_sse.c:206-214), right-aligned '>=' (:252-260)
+			// The four gap candidates among themselves first, the substitution score (it comes from the LDS read above) last.  Same result as the
+			// reference's chain score -> a -> b -> a2 -> b2: with '>' d is the FIRST position of the maximum of the five, with '>=' the LAST one, and
+			// the score sits at position 0 either way.
 			const int ge = right ? 1 : 0;
-			int d;
-			d = (a + ge > z) ? 1 : 0;  z = z > a ? z : a;
-			d = (bb + ge > z) ? 2 : d; z = z > bb ? z : bb;
-			d = (a2 + ge > z) ? 3 : d; z = z > a2 ? z : a2;
-			d = (b2 + ge > z) ? 4 : d; z = z > b2 ? z : b2;
+			int d = 1, zc = a;
+			d = (bb + ge > zc) ? 2 : d; zc = zc > bb ? zc : bb;
+			d = (a2 + ge > zc) ? 3 : d; zc = zc > a2 ? zc : a2;
+			d = (b2 + ge > zc) ? 4 : d; zc = zc > b2 ? zc : b2;
+			d = (zc + ge > z) ? d : 0;  z = z > zc ? z : zc;
 			z = z < (int)sc_mch ? z : (int)sc_mch;
 			const int un = (int8_t)(z - vt1), vn = (int8_t)(z - ut);
 			int tmp = (int8_t)(z - q); a = (int8_t)(a - tmp); bb = (int8_t)(bb - tmp);

@@ -39,6 +39,7 @@ template <int TMAX, int QMAX> struct GroupLds {
 	int8_t u[TMAX], v[TMAX], x[TMAX], y[TMAX], x2[TMAX], y2[TMAX], s[TMAX];
 	int32_t H[TMAX];
 	static constexpr bool kQrReady = false;   // d_ksw_reg builds the reversed query from qbuf
+	static constexpr int kPtb = AL_LPTB;
 	uint8_t sq[QMAX + 2 * (TMAX + 16) + 64];   // LDS-row DP: sf[tlen_*16] immediately followed by qr[] (one allocation in the reference: ksw2_extd2_sse.c:99-103); register DP: the reversed query between two pads of 16 bytes per block
 	uint8_t tbuf[TMAX + 16];        // target of the current DP job / alignment window
 	uint8_t qbuf[QMAX + 16];        // query of the current DP job
@@ -1811,10 +1812,13 @@ k_ext_prep(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_
 
 template <int QMAXJ, int TMAXJ> struct JobLds {
 	static constexpr bool kQrReady = true;   // k_ext_dp stores the reversed, padded query itself
+	// traceback tile: jobs of more than 64 target bases have more than 40 rows of at least 32 bytes -- they never fit it, and without it twice
+	// as many wavefronts fit a CU (the kernel waits on LDS reads and byte stores with 3.5 waves per SIMD)
+	static constexpr int kPtb = TMAXJ <= 64 ? AL_LPTB : 0;
 	uint8_t sq[QMAXJ + 2 * TMAXJ + 32];      // TMAXJ bytes of front pad, the reversed query, zeros up to qlen + TMAXJ + 16 (al_dev_ksw.h)
 	uint8_t tbuf[TMAXJ + 16];
 	uint32_t ezc[AL_LCIG];
-	uint8_t ptb[AL_LPTB];
+	uint8_t ptb[kPtb > 0 ? kPtb : 4];
 };
 
 // DP jobs of one block-count class: 4 jobs per wavefront, all running d_ksw_reg<NB>
