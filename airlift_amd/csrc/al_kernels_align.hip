@@ -1617,10 +1617,222 @@ __device__ __forceinline__ int d_job_class(int qlen, int tlen, int lane_ok)
 	return b <= 1 ? 3 : b <= 2 ? 4 : b <= 4 ? 5 : b <= 8 ? 6 : b <= 22 ? 7 : b <= 32 ? 8 : 9;
 }
 
+// One fragment's share of k_ext_prep.  WAVE = false: the calling lane walks the fragment's hits one after the other.  WAVE = true: the 64 lanes
+// of the calling wavefront take a hit each (fragments with many hits: a lane per fragment ran 6 ms on them while the rest of the batch was done
+// in 2).  Everything a hit needs is its own -- window, ungapped core, z-drop test, the two flank jobs at job_off[f] + 2 * (hit's position) --
+// except the rule that the first hit that needs the monolithic kernel ends the fragment: hits before it keep their jobs, it and the hits
+// after it leave empty slots.  The wavefront form settles that with a ballot per group of 64 hits.
+#define AL_PREP_HEAVY 8            // jobs (two per hit) from which a fragment goes to the wavefront form
+template <bool WAVE>
+__device__ __forceinline__ void d_ext_prep_frag(const int f, const int lane, const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_off, const uint32_t *__restrict__ rd_len,
+                                const uint32_t *__restrict__ frag_first, const WsBase &W, const AlignShared &G, const ExtShared &E, const AlParams &P, const int tmax, const int qmax,
+                                unsigned *s_hist, unsigned *s_tl, unsigned *s_sub, unsigned long long &c_regs, unsigned long long &c_ref, unsigned long long &c_cig)
+{
+	const int lane_ok = !((P.dbg >> 29) & 1);
+	const uint32_t r0 = frag_first[f], n_segs = frag_first[f + 1] - r0;
+	FragWs fw; d_frag_ws(W, (uint32_t)f, fw);
+	const uint64_t B2 = (uint64_t)(fw.mreg[0] - W.mregs);      // index of mreg[0][0] in the hit array == index into rext
+	const uint32_t jb0 = (uint32_t)E.job_off[f]; bool slow = false;
+	uint32_t n_done = 0;                                       // hits whose jobs were emitted
+	AlReg *const mreg0 = fw.mreg[0], *const mreg1 = fw.mreg[1];
+	AlAnchor *const sa0 = fw.seg_a[0], *const sa1 = n_segs == 2 ? fw.seg_a[0] + W.seg_na[r0] : nullptr;
+	const int ge1 = P.q + P.e, ge2 = P.q2 + P.e2;
+	const bool diag_ok = P.a > 0 && P.b > 0 && P.a + P.b < (ge1 < ge2 ? ge1 : ge2) && (P.zdrop < 0 || P.zdrop >= P.b + (ge1 > ge2 ? ge1 : ge2));
+	// one hit: 0 = jobs in x / jl / jr, 1 = needs the monolithic kernel, 2 = the same because its window exceeds the tiles (counted)
+	auto hit = [&](const uint32_t s, const int i, const AlReg *regs, const AlAnchor *a, const int qlen, const uint32_t *seq, const uint32_t jb, RegExt &x, ExtJob &jl, ExtJob &jr) -> int {
+		const AlReg *r = &regs[i];
+		jl.qlen = jl.tlen = 0; jr.qlen = jr.tlen = 0; jl.pad0 = jl.pad1 = jr.pad0 = jr.pad1 = 0; jl.pad2 = jr.pad2 = 0;
+		jl.toff = jr.toff = 0; jl.read = jr.read = r0 + s; jl.qoff = jr.qoff = 0; jl.rev = jr.rev = 0; jl.kind = 0; jr.kind = 1;
+		x.job = jb; x.rs = x.qs = x.re = x.qe = x.rs0 = x.re0 = x.core_score = 0;
+		if (r->cnt > 0) {
+			const int32_t rid = r->rid, rev = (r->flags & ALR_REV) ? 1 : 0;   // == contig / strand of a[r->as] (mm_reg_set_coor)
+			const int32_t ref_len = (int32_t)G.seq_len[rid]; const uint64_t ref_off = G.seq_off[rid];
+			int32_t rs, qs, re, qe;
+			if (i == 0 && W.seg_fast[r0 + s]) { const RegExt pre = E.rext[B2 + (uint64_t)s * fw.cap]; rs = pre.rs; qs = pre.qs; re = pre.re; qe = pre.qe; }   // from k_regs
+			else {
+				int as1, cnt1;
+				d_max_stretch(r, a, &as1, &cnt1);
+				rs = (int32_t)a[as1].x + 1 - (int32_t)(a[as1].y >> 32 & 0xff);
+				qs = (int32_t)a[as1].y + 1 - (int32_t)(a[as1].y >> 32 & 0xff);
+				re = (int32_t)a[as1 + cnt1 - 1].x + 1; qe = (int32_t)a[as1 + cnt1 - 1].y + 1;
+			}
+			int l = qs;                                                   // align.c:613-620
+			l += l * P.a + P.end_bonus > P.q ? (l * P.a + P.end_bonus - P.q) / P.e : 0;
+			const int32_t rs0 = rs - l > 0 ? rs - l : 0;
+			l = qlen - qe;
+			l += l * P.a + P.end_bonus > P.q ? (l * P.a + P.end_bonus - P.q) / P.e : 0;
+			const int32_t re0 = re + l < ref_len ? re + l : ref_len;
+			if (re0 - rs0 > tmax) return 2;
+			// ungapped core (align.c:724-731) + mm_test_zdrop with the single 'M' op (align.c:47-89)
+			const ReadAcc Q{seq, qlen, rev, qs}; const RefAcc T{G.S4, ref_off + (uint64_t)rs};
+			const int len = qe - qs; int sc = 0, zs = 0, zmax = INT32_MIN, zmi = -1, zdrop_max = 0;
+			int k = 0;
+			{   // eight bases per step; eight unambiguous matches raise both running scores monotonically
+				const int msc = P.a < 0 ? -P.a : P.a;
+				for (; k + 8 <= len; k += 8) {
+					const uint32_t qw = Q.win8(k), tw = T.win8(k);
+					if (qw == tw && !(qw & 0x44444444u)) { sc += 8 * P.a; zs += 8 * msc; if (zs >= zmax) zmax = zs; else { const int z = zmax - zs; if (z > zdrop_max) zdrop_max = z; } continue; }
+#pragma unroll
+					for (int b = 0; b < 8; ++b) {
+						const int cq = (int)(qw >> (4 * b) & 0xf), ct = (int)(tw >> (4 * b) & 0xf);
+						if (cq >= 4 || ct >= 4) sc += P.e2; else sc += cq == ct ? P.a : -P.b;
+						zs += d_mat(P, ct, cq);
+						if (zs < zmax) { const int z = zmax - zs; if (z > zdrop_max) zdrop_max = z; }   // diff = 0 along the diagonal
+						else zmax = zs;
+					}
+				}
+			}
+			for (; k < len; ++k) {
+				const int cq = Q(k), ct = T(k);
+				if (cq >= 4 || ct >= 4) sc += P.e2; else sc += cq == ct ? P.a : -P.b;
+				zs += d_mat(P, ct, cq);
+				if (zs < zmax) { const int z = zmax - zs; (void)zmi; if (z > zdrop_max) zdrop_max = z; }   // diff = 0 along the diagonal
+				else { zmax = zs; zmi = k; }
+			}
+			if (zdrop_max > P.zdrop) return 1;                            // needs the second DP pass / split: monolithic path
+			x.rs = rs; x.qs = qs; x.re = re; x.qe = qe; x.rs0 = rs0; x.re0 = re0; x.core_score = sc;
+			if (qs > 0 && rs > 0) {                                       // left extension job (align.c:690-705)
+				jl.qlen = (uint16_t)qs; jl.tlen = (uint16_t)(rs - rs0); jl.rev = (uint8_t)rev;
+				jl.qoff = (uint32_t)(qs - 1); jl.toff = ref_off + (uint64_t)(rs - 1);
+			}
+			if (qe < qlen && re < re0) {                                  // right extension job (align.c:760-771)
+				jr.qlen = (uint16_t)(qlen - qe); jr.tlen = (uint16_t)(re0 - re); jr.rev = (uint8_t)rev;
+				jr.qoff = (uint32_t)qe; jr.toff = ref_off + (uint64_t)re;
+			}
+		}
+		// Closed form instead of a DP job when the flank matches its target with at most one mismatch (no N, query not longer
+		// than the target): the extension then runs along the diagonal, every gapped path loses >= q+e > a+b, and max / max_q /
+		// max_t / mqe_t / reach_end / CIGAR follow from the running diagonal score exactly as ksw_extd2 computes them
+		// (checked against the reference DP in tests/test_diag_shortcut.py; jobs done this way carry pad0 = 1).
+		// (the argument needs one mismatch to cost less than any gap: a + b < min(q + e, q2 + e2); true for the short-read
+		// scores 2/8/12,2/24,1 -- with other scores every flank takes the DP kernels)
+		// and the z-drop test (ksw2.h:160-176) must be unable to fire: along and after the diagonal the row maximum stays
+		// within b + max(q + e, q2 + e2) (+ e2 per unit of diagonal offset, which the test allows for) of the running maximum
+		if (!((P.dbg >> 31) & 1) && diag_ok && r->cnt > 0) {
+			const int32_t rid2 = r->rid, rev2 = (r->flags & ALR_REV) ? 1 : 0;
+			const uint64_t ref_off2 = G.seq_off[rid2];
+			const ReadAcc Qa{seq, qlen, rev2, 0}; const RefAcc Ta{G.S4, ref_off2};
+			auto shortcut = [&](const int side, const int ql, const int tl) -> bool {
+				if (ql == 0 || ql > tl) return false;
+				int sc = 0, mx = 0, pos = -1, nmm = 0;
+				for (int k = 0; k < ql; ++k) {
+					const int cq = side == 0 ? Qa(x.qs - 1 - k) : Qa(x.qe + k);
+					const int ct = side == 0 ? Ta(x.rs - 1 - k) : Ta(x.re + k);
+					if (cq > 3 || ct > 3) return false;
+					if (cq == ct) sc += P.a; else { sc -= P.b; if (++nmm > 1) return false; }
+					if (sc > mx) { mx = sc; pos = k; }
+				}
+				// a target at least w + 1 longer than the query makes the band run off the matrix (st > en at row 2*ql + w - 1,
+				// ksw2_extd2_sse.c:135): the reference flags that like a z-drop and ends at the maximum, never at the query end
+				const int wband = (int)(P.bw * 1.5 + 1.);
+				const bool runoff = tl >= ql + wband + 1;
+				const bool reach = !runoff && sc + P.end_bonus > mx;
+				const int ncig = (reach || pos >= 0) ? 1 : 0;
+				ExtOut o; o.max = mx; o.max_q = pos; o.max_t = pos; o.mqe_t = ql - 1;
+				o.flags_ncig = (uint32_t)(reach ? 1 : 0) | (uint32_t)(runoff ? 2 : 0) | (uint32_t)ncig << 8; o.cig_off = 0;
+				o.cig[0] = ncig ? (uint32_t)(reach ? ql : pos + 1) << 4 : 0; o.cig[1] = o.cig[2] = o.cig[3] = o.cig[4] = o.cig[5] = 0;
+				E.outs[jb + side] = o;                                        // (the slot is this hit's own: harmless if the hit ends up behind the fragment's first slow one)
+				return true;
+			};
+			if (shortcut(0, jl.qlen, jl.tlen)) jl.pad0 = 1;
+			if (shortcut(1, jr.qlen, jr.tlen)) jr.pad0 = 1;
+		}
+		if (r->cnt > 0 && !((P.dbg >> 18) & 1) && (jl.qlen == 0 || jl.pad0) && (jr.qlen == 0 || jr.pad0)) x.job |= 0x80000000u;   // no DP needed: finished below
+		return 0;
+	};
+	auto commit = [&](const uint32_t s, const int i, const uint32_t jb, const RegExt &x, const ExtJob &jl, const ExtJob &jr) {
+		E.rext[B2 + (uint64_t)s * fw.cap + i] = x;
+		E.jobs[jb] = jl; E.jobs[jb + 1] = jr;
+		const int c0 = (jl.qlen && !jl.pad0) ? d_job_class(jl.qlen, jl.tlen, lane_ok) : AL_NCLS, c1 = (jr.qlen && !jr.pad0) ? d_job_class(jr.qlen, jr.tlen, lane_ok) : AL_NCLS;
+		// key: class | 16-cell blocks of the target | size -- inside a class the jobs are ordered by block count first, so that the 9 ... 22-block class
+		// can be launched as three kernels (12, 16, 22 register blocks: a row costs every instantiated block a skip test and two selects)
+		const uint32_t b0 = (uint32_t)std::min(63, (jl.tlen + 15) / 16), b1 = (uint32_t)std::min(63, (jr.tlen + 15) / 16);
+		E.job_key[jb] = c0 < AL_NCLS ? ((uint32_t)c0 << 20 | b0 << 14 | (uint32_t)std::min(0x3fff, jl.qlen + jl.tlen)) : 0xffffffffu;
+		E.job_key[jb + 1] = c1 < AL_NCLS ? ((uint32_t)c1 << 20 | b1 << 14 | (uint32_t)std::min(0x3fff, jr.qlen + jr.tlen)) : 0xffffffffu;
+		atomicAdd(&s_hist[c0], 1u); atomicAdd(&s_hist[c1], 1u);
+		if (c0 == 7 && b0 <= 16) atomicAdd(&s_sub[b0 <= 12 ? 0 : 1], 1u);
+		if (c1 == 7 && b1 <= 16) atomicAdd(&s_sub[b1 <= 12 ? 0 : 1], 1u);
+		if (c0 < AL_NCLS) atomicAdd(&s_tl[c0], (unsigned)jl.tlen); if (c1 < AL_NCLS) atomicAdd(&s_tl[c1], (unsigned)jr.tlen);
+	};
+	auto do_seg = [&](const uint32_t s, const AlReg *regs, const AlAnchor *a) {
+		const int qlen = (int)rd_len[r0 + s], n = (int)W.reg_cnt[r0 + s];
+		const uint32_t *seq = rd_seq + rd_off[r0 + s];
+		if (n > 0 && qlen > qmax) { if (!WAVE || lane == 0) atomicAdd(&G.counters[7], 1ULL << 0); slow = true; return; }
+		if (!WAVE) {
+			for (int i = 0; i < n; ++i) {
+				RegExt x; ExtJob jl, jr; const uint32_t jb = jb0 + 2u * n_done;
+				const int code = hit(s, i, regs, a, qlen, seq, jb, x, jl, jr);
+				if (code) { if (code == 2) atomicAdd(&G.counters[7], 1ULL << 8); slow = true; return; }
+				commit(s, i, jb, x, jl, jr); ++n_done;
+			}
+		} else {
+			for (int base = 0; base < n; base += 64) {
+				const int i = base + lane; const bool on = i < n;
+				RegExt x; ExtJob jl, jr; const uint32_t jb = jb0 + 2u * (n_done + (uint32_t)lane);
+				const int code = on ? hit(s, i, regs, a, qlen, seq, jb, x, jl, jr) : 0;
+				const unsigned long long bad = __ballot(code != 0);
+				const int first = bad ? __ffsll((long long)bad) - 1 : 64;
+				if (on && lane < first) commit(s, i, jb, x, jl, jr);
+				if (bad) { if (lane == first && code == 2) atomicAdd(&G.counters[7], 1ULL << 8); n_done += (uint32_t)first; slow = true; return; }
+				n_done += (uint32_t)(n - base < 64 ? n - base : 64);
+			}
+		}
+	};
+	do_seg(0, mreg0, sa0);
+	if (n_segs == 2 && !slow) do_seg(1, mreg1, sa1);
+	// Hits whose two flanks are closed forms (or absent) are finished right here -- what k_ext_finish does for a hit
+	// after its DP jobs (mm_align1 tail, align.c:698-788: CIGAR = one M run, coordinates, mm_update_extra) -- so that
+	// k_ext_finish neither re-reads their job records nor streams their sequences again.  Done after the scan above
+	// because a fragment that turned out "slow" is redone from the untouched hits by the monolithic kernel.
+	if (WAVE) __threadfence_block();                                  // (the hits' records written by other lanes of the wavefront)
+	auto fin_seg = [&](const uint32_t s, AlReg *regs, const AlAnchor *a) {
+		const int qlen = (int)rd_len[r0 + s], n = (int)W.reg_cnt[r0 + s];
+		const uint32_t *seq = rd_seq + rd_off[r0 + s];
+		for (int i = WAVE ? lane : 0; i < n; i += WAVE ? 64 : 1) {
+			RegExt x = E.rext[B2 + (uint64_t)s * fw.cap + i];
+			if (!(x.job & 0x80000000u)) continue;
+			x.job &= 0x7fffffffu;
+			AlReg R = regs[i];
+			const int32_t rid = R.rid, rev = (R.flags & ALR_REV) ? 1 : 0;
+			const uint64_t ref_off = G.seq_off[rid];
+			R.n_cigar = 0; R.dp_score = 0; R.dp_max = 0; R.dp_max2 = 0; R.n_ambi = 0;
+			int32_t rs1 = x.rs, qs1 = x.qs, re1 = x.re, qe1 = x.qe;
+			R.dp_score = x.core_score;
+			if (E.jobs[x.job].qlen) {
+				const ExtOut *po = &E.outs[x.job]; const bool reach = po->flags_ncig & 1;
+				if (po->flags_ncig >> 8) R.dp_score += po->max;
+				rs1 = x.rs - (reach ? po->mqe_t + 1 : po->max_t + 1);
+				qs1 = x.qs - (reach ? x.qs : po->max_q + 1);
+			}
+			if (E.jobs[x.job + 1].qlen) {
+				const ExtOut *po = &E.outs[x.job + 1]; const bool reach = po->flags_ncig & 1;
+				if (po->flags_ncig >> 8) R.dp_score += po->max;
+				re1 = x.re + (reach ? po->mqe_t + 1 : po->max_t + 1);
+				qe1 = x.qe + (reach ? qlen - x.qe : po->max_q + 1);
+			}
+			uint32_t cg1[1] = { (uint32_t)(qe1 - qs1) << 4 };                // left M + core M + right M merge into one run (mm_append_cigar)
+			R.n_cigar = 1; R.flags |= ALR_HAS_P;
+			R.rs = rs1; R.re = re1;
+			if (rev) { R.qs = qlen - qe1; R.qe = qlen - qs1; } else { R.qs = qs1; R.qe = qe1; }
+			d_update_extra(P, &R, cg1, ReadAcc{seq, qlen, rev, qs1}, RefAcc{G.S4, ref_off + (uint64_t)rs1});
+			R.cig_inl[0] = cg1[0]; R.cig_inl[1] = R.cig_inl[2] = R.cig_inl[3] = 0; R.cigar_off = AL_CIG_INLINE;
+			regs[i] = R;
+			++c_regs; c_ref += (unsigned long long)(x.re0 - x.rs0); c_cig += 1;
+		}
+	};
+	if (!slow) { fin_seg(0, mreg0, sa0); if (n_segs == 2) fin_seg(1, mreg1, sa1); }
+	// unused job slots of this fragment (a slow fragment stops early): mark empty
+	for (uint32_t j = jb0 + 2u * n_done + (WAVE ? (uint32_t)lane : 0u); j < (uint32_t)E.job_off[f + 1]; j += WAVE ? 64u : 1u) {
+		E.job_key[j] = 0xffffffffu; ExtJob z; z.qlen = z.tlen = 0; z.toff = 0; z.read = 0; z.qoff = 0; z.rev = z.kind = z.pad0 = z.pad1 = 0; z.pad2 = 0; E.jobs[j] = z; atomicAdd(&s_hist[AL_NCLS], 1u);
+	}
+	if (!WAVE || lane == 0) E.frag_slow[f] = slow ? 1u : 0u;
+}
+
 extern "C" __global__ void __launch_bounds__(256, AL_LB_PREP)
 k_ext_prep(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_off, const uint32_t *__restrict__ rd_len,
            const uint32_t *__restrict__ frag_first, WsBase W, AlignShared G, ExtShared E, int n_frag, AlParams P, int tmax, int qmax,
-           const uint32_t *__restrict__ order /* fragments by number of hits, descending: the lanes of a wavefront walk equally many hits (a lane per fragment runs as long as its wavefront's longest) */)
+           const uint32_t *__restrict__ order /* fragments by number of hits, descending: the lanes of a wavefront walk equally many hits (a lane per fragment runs as long as its wavefront's longest) */,
+           int heavy_jobs /* fragments with at least this many job slots are k_ext_prep_wave's (0: none) */)
 {
 	const int t_ = blockIdx.x * blockDim.x + threadIdx.x;
 	const int f = t_ < n_frag ? (order ? (int)order[t_] : t_) : n_frag;
@@ -1629,178 +1841,9 @@ k_ext_prep(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_
 	if (threadIdx.x <= AL_NCLS) { s_hist[threadIdx.x] = 0; s_tl[threadIdx.x] = 0; }
 	if (threadIdx.x < 2) s_sub[threadIdx.x] = 0;
 	__syncthreads();
-	const int lane_ok = !((P.dbg >> 29) & 1);
 	if (f < n_frag && W.frag_nu[f] != 0) {
-		const uint32_t r0 = frag_first[f], n_segs = frag_first[f + 1] - r0;
-		FragWs fw; d_frag_ws(W, (uint32_t)f, fw);
-		const uint64_t B2 = (uint64_t)(fw.mreg[0] - W.mregs);      // index of mreg[0][0] in the hit array == index into rext
-		uint32_t jb = (uint32_t)E.job_off[f]; bool slow = false;
-		AlReg *const mreg0 = fw.mreg[0], *const mreg1 = fw.mreg[1];
-		AlAnchor *const sa0 = fw.seg_a[0], *const sa1 = n_segs == 2 ? fw.seg_a[0] + W.seg_na[r0] : nullptr;
-		auto do_seg = [&](const uint32_t s, const AlReg *regs, const AlAnchor *a) {
-			const int qlen = (int)rd_len[r0 + s], n = (int)W.reg_cnt[r0 + s];
-			const uint32_t *seq = rd_seq + rd_off[r0 + s];
-			if (n > 0 && qlen > qmax) { atomicAdd(&G.counters[7], 1ULL << 0); slow = true; return; }
-			for (int i = 0; i < n; ++i, jb += 2) {
-				const AlReg *r = &regs[i]; RegExt x; ExtJob jl, jr;
-				jl.qlen = jl.tlen = 0; jr.qlen = jr.tlen = 0; jl.pad0 = jl.pad1 = jr.pad0 = jr.pad1 = 0; jl.pad2 = jr.pad2 = 0;
-				jl.toff = jr.toff = 0; jl.read = jr.read = r0 + s; jl.qoff = jr.qoff = 0; jl.rev = jr.rev = 0; jl.kind = 0; jr.kind = 1;
-				x.job = jb; x.rs = x.qs = x.re = x.qe = x.rs0 = x.re0 = x.core_score = 0;
-				if (r->cnt > 0) {
-					const int32_t rid = r->rid, rev = (r->flags & ALR_REV) ? 1 : 0;   // == contig / strand of a[r->as] (mm_reg_set_coor)
-					const int32_t ref_len = (int32_t)G.seq_len[rid]; const uint64_t ref_off = G.seq_off[rid];
-					int32_t rs, qs, re, qe;
-					if (i == 0 && W.seg_fast[r0 + s]) { const RegExt pre = E.rext[B2 + (uint64_t)s * fw.cap]; rs = pre.rs; qs = pre.qs; re = pre.re; qe = pre.qe; }   // from k_regs
-					else {
-						int as1, cnt1;
-						d_max_stretch(r, a, &as1, &cnt1);
-						rs = (int32_t)a[as1].x + 1 - (int32_t)(a[as1].y >> 32 & 0xff);
-						qs = (int32_t)a[as1].y + 1 - (int32_t)(a[as1].y >> 32 & 0xff);
-						re = (int32_t)a[as1 + cnt1 - 1].x + 1; qe = (int32_t)a[as1 + cnt1 - 1].y + 1;
-					}
-					int l = qs;                                                   // align.c:613-620
-					l += l * P.a + P.end_bonus > P.q ? (l * P.a + P.end_bonus - P.q) / P.e : 0;
-					const int32_t rs0 = rs - l > 0 ? rs - l : 0;
-					l = qlen - qe;
-					l += l * P.a + P.end_bonus > P.q ? (l * P.a + P.end_bonus - P.q) / P.e : 0;
-					const int32_t re0 = re + l < ref_len ? re + l : ref_len;
-					if (re0 - rs0 > tmax) { atomicAdd(&G.counters[7], 1ULL << 8); slow = true; return; }
-					// ungapped core (align.c:724-731) + mm_test_zdrop with the single 'M' op (align.c:47-89)
-					const ReadAcc Q{seq, qlen, rev, qs}; const RefAcc T{G.S4, ref_off + (uint64_t)rs};
-					const int len = qe - qs; int sc = 0, zs = 0, zmax = INT32_MIN, zmi = -1, zdrop_max = 0;
-					int k = 0;
-					{   // eight bases per step; eight unambiguous matches raise both running scores monotonically
-						const int msc = P.a < 0 ? -P.a : P.a;
-						for (; k + 8 <= len; k += 8) {
-							const uint32_t qw = Q.win8(k), tw = T.win8(k);
-							if (qw == tw && !(qw & 0x44444444u)) { sc += 8 * P.a; zs += 8 * msc; if (zs >= zmax) zmax = zs; else { const int z = zmax - zs; if (z > zdrop_max) zdrop_max = z; } continue; }
-#pragma unroll
-							for (int b = 0; b < 8; ++b) {
-								const int cq = (int)(qw >> (4 * b) & 0xf), ct = (int)(tw >> (4 * b) & 0xf);
-								if (cq >= 4 || ct >= 4) sc += P.e2; else sc += cq == ct ? P.a : -P.b;
-								zs += d_mat(P, ct, cq);
-								if (zs < zmax) { const int z = zmax - zs; if (z > zdrop_max) zdrop_max = z; }   // diff = 0 along the diagonal
-								else zmax = zs;
-							}
-						}
-					}
-					for (; k < len; ++k) {
-						const int cq = Q(k), ct = T(k);
-						if (cq >= 4 || ct >= 4) sc += P.e2; else sc += cq == ct ? P.a : -P.b;
-						zs += d_mat(P, ct, cq);
-						if (zs < zmax) { const int z = zmax - zs; (void)zmi; if (z > zdrop_max) zdrop_max = z; }   // diff = 0 along the diagonal
-						else { zmax = zs; zmi = k; }
-					}
-					if (zdrop_max > P.zdrop) { slow = true; return; }             // needs the second DP pass / split: monolithic path
-					x.rs = rs; x.qs = qs; x.re = re; x.qe = qe; x.rs0 = rs0; x.re0 = re0; x.core_score = sc;
-					if (qs > 0 && rs > 0) {                                       // left extension job (align.c:690-705)
-						jl.qlen = (uint16_t)qs; jl.tlen = (uint16_t)(rs - rs0); jl.rev = (uint8_t)rev;
-						jl.qoff = (uint32_t)(qs - 1); jl.toff = ref_off + (uint64_t)(rs - 1);
-					}
-					if (qe < qlen && re < re0) {                                  // right extension job (align.c:760-771)
-						jr.qlen = (uint16_t)(qlen - qe); jr.tlen = (uint16_t)(re0 - re); jr.rev = (uint8_t)rev;
-						jr.qoff = (uint32_t)qe; jr.toff = ref_off + (uint64_t)re;
-					}
-				}
-				// Closed form instead of a DP job when the flank matches its target with at most one mismatch (no N, query not longer
-				// than the target): the extension then runs along the diagonal, every gapped path loses >= q+e > a+b, and max / max_q /
-				// max_t / mqe_t / reach_end / CIGAR follow from the running diagonal score exactly as ksw_extd2 computes them
-				// (checked against the reference DP in tests/test_diag_shortcut.py; jobs done this way carry pad0 = 1).
-				// (the argument needs one mismatch to cost less than any gap: a + b < min(q + e, q2 + e2); true for the short-read
-				// scores 2/8/12,2/24,1 -- with other scores every flank takes the DP kernels)
-				// and the z-drop test (ksw2.h:160-176) must be unable to fire: along and after the diagonal the row maximum stays
-				// within b + max(q + e, q2 + e2) (+ e2 per unit of diagonal offset, which the test allows for) of the running maximum
-				const int ge1 = P.q + P.e, ge2 = P.q2 + P.e2;
-				const bool diag_ok = P.a > 0 && P.b > 0 && P.a + P.b < (ge1 < ge2 ? ge1 : ge2) && (P.zdrop < 0 || P.zdrop >= P.b + (ge1 > ge2 ? ge1 : ge2));
-				if (!((P.dbg >> 31) & 1) && diag_ok && r->cnt > 0) {
-					const int32_t rid2 = r->rid, rev2 = (r->flags & ALR_REV) ? 1 : 0;
-					const uint64_t ref_off2 = G.seq_off[rid2];
-					const ReadAcc Qa{seq, qlen, rev2, 0}; const RefAcc Ta{G.S4, ref_off2};
-					auto shortcut = [&](const int side, const int ql, const int tl) -> bool {
-						if (ql == 0 || ql > tl) return false;
-						int sc = 0, mx = 0, pos = -1, nmm = 0;
-						for (int k = 0; k < ql; ++k) {
-							const int cq = side == 0 ? Qa(x.qs - 1 - k) : Qa(x.qe + k);
-							const int ct = side == 0 ? Ta(x.rs - 1 - k) : Ta(x.re + k);
-							if (cq > 3 || ct > 3) return false;
-							if (cq == ct) sc += P.a; else { sc -= P.b; if (++nmm > 1) return false; }
-							if (sc > mx) { mx = sc; pos = k; }
-						}
-						// a target at least w + 1 longer than the query makes the band run off the matrix (st > en at row 2*ql + w - 1,
-						// ksw2_extd2_sse.c:135): the reference flags that like a z-drop and ends at the maximum, never at the query end
-						const int wband = (int)(P.bw * 1.5 + 1.);
-						const bool runoff = tl >= ql + wband + 1;
-						const bool reach = !runoff && sc + P.end_bonus > mx;
-						const int ncig = (reach || pos >= 0) ? 1 : 0;
-						ExtOut o; o.max = mx; o.max_q = pos; o.max_t = pos; o.mqe_t = ql - 1;
-						o.flags_ncig = (uint32_t)(reach ? 1 : 0) | (uint32_t)(runoff ? 2 : 0) | (uint32_t)ncig << 8; o.cig_off = 0;
-						o.cig[0] = ncig ? (uint32_t)(reach ? ql : pos + 1) << 4 : 0; o.cig[1] = o.cig[2] = o.cig[3] = o.cig[4] = o.cig[5] = 0;
-						E.outs[jb + side] = o;
-						return true;
-					};
-					if (shortcut(0, jl.qlen, jl.tlen)) jl.pad0 = 1;
-					if (shortcut(1, jr.qlen, jr.tlen)) jr.pad0 = 1;
-				}
-				if (r->cnt > 0 && !((P.dbg >> 18) & 1) && (jl.qlen == 0 || jl.pad0) && (jr.qlen == 0 || jr.pad0)) x.job |= 0x80000000u;   // no DP needed: finished below
-				E.rext[B2 + (uint64_t)s * fw.cap + i] = x;
-				E.jobs[jb] = jl; E.jobs[jb + 1] = jr;
-				{ const int c0 = (jl.qlen && !jl.pad0) ? d_job_class(jl.qlen, jl.tlen, lane_ok) : AL_NCLS, c1 = (jr.qlen && !jr.pad0) ? d_job_class(jr.qlen, jr.tlen, lane_ok) : AL_NCLS;
-				  // key: class | 16-cell blocks of the target | size -- inside a class the jobs are ordered by block count first, so that the 9 ... 22-block class
-				  // can be launched as three kernels (12, 16, 22 register blocks: a row costs every instantiated block a skip test and two selects)
-				  const uint32_t b0 = (uint32_t)std::min(63, (jl.tlen + 15) / 16), b1 = (uint32_t)std::min(63, (jr.tlen + 15) / 16);
-				  E.job_key[jb] = c0 < AL_NCLS ? ((uint32_t)c0 << 20 | b0 << 14 | (uint32_t)std::min(0x3fff, jl.qlen + jl.tlen)) : 0xffffffffu;
-				  E.job_key[jb + 1] = c1 < AL_NCLS ? ((uint32_t)c1 << 20 | b1 << 14 | (uint32_t)std::min(0x3fff, jr.qlen + jr.tlen)) : 0xffffffffu;
-				  atomicAdd(&s_hist[c0], 1u); atomicAdd(&s_hist[c1], 1u);
-				  if (c0 == 7 && b0 <= 16) atomicAdd(&s_sub[b0 <= 12 ? 0 : 1], 1u);
-				  if (c1 == 7 && b1 <= 16) atomicAdd(&s_sub[b1 <= 12 ? 0 : 1], 1u);
-				  if (c0 < AL_NCLS) atomicAdd(&s_tl[c0], (unsigned)jl.tlen); if (c1 < AL_NCLS) atomicAdd(&s_tl[c1], (unsigned)jr.tlen); }
-			}
-		};
-		do_seg(0, mreg0, sa0);
-		if (n_segs == 2 && !slow) do_seg(1, mreg1, sa1);
-		// Hits whose two flanks are closed forms (or absent) are finished right here -- what k_ext_finish does for a hit
-		// after its DP jobs (mm_align1 tail, align.c:698-788: CIGAR = one M run, coordinates, mm_update_extra) -- so that
-		// k_ext_finish neither re-reads their job records nor streams their sequences again.  Done after the scan above
-		// because a fragment that turned out "slow" is redone from the untouched hits by the monolithic kernel.
-		auto fin_seg = [&](const uint32_t s, AlReg *regs, const AlAnchor *a) {
-			const int qlen = (int)rd_len[r0 + s], n = (int)W.reg_cnt[r0 + s];
-			const uint32_t *seq = rd_seq + rd_off[r0 + s];
-			for (int i = 0; i < n; ++i) {
-				RegExt x = E.rext[B2 + (uint64_t)s * fw.cap + i];
-				if (!(x.job & 0x80000000u)) continue;
-				x.job &= 0x7fffffffu;
-				AlReg R = regs[i];
-				const int32_t rid = R.rid, rev = (R.flags & ALR_REV) ? 1 : 0;
-				const uint64_t ref_off = G.seq_off[rid];
-				R.n_cigar = 0; R.dp_score = 0; R.dp_max = 0; R.dp_max2 = 0; R.n_ambi = 0;
-				int32_t rs1 = x.rs, qs1 = x.qs, re1 = x.re, qe1 = x.qe;
-				R.dp_score = x.core_score;
-				if (E.jobs[x.job].qlen) {
-					const ExtOut *po = &E.outs[x.job]; const bool reach = po->flags_ncig & 1;
-					if (po->flags_ncig >> 8) R.dp_score += po->max;
-					rs1 = x.rs - (reach ? po->mqe_t + 1 : po->max_t + 1);
-					qs1 = x.qs - (reach ? x.qs : po->max_q + 1);
-				}
-				if (E.jobs[x.job + 1].qlen) {
-					const ExtOut *po = &E.outs[x.job + 1]; const bool reach = po->flags_ncig & 1;
-					if (po->flags_ncig >> 8) R.dp_score += po->max;
-					re1 = x.re + (reach ? po->mqe_t + 1 : po->max_t + 1);
-					qe1 = x.qe + (reach ? qlen - x.qe : po->max_q + 1);
-				}
-				uint32_t cg1[1] = { (uint32_t)(qe1 - qs1) << 4 };                // left M + core M + right M merge into one run (mm_append_cigar)
-				R.n_cigar = 1; R.flags |= ALR_HAS_P;
-				R.rs = rs1; R.re = re1;
-				if (rev) { R.qs = qlen - qe1; R.qe = qlen - qs1; } else { R.qs = qs1; R.qe = qe1; }
-				d_update_extra(P, &R, cg1, ReadAcc{seq, qlen, rev, qs1}, RefAcc{G.S4, ref_off + (uint64_t)rs1});
-				R.cig_inl[0] = cg1[0]; R.cig_inl[1] = R.cig_inl[2] = R.cig_inl[3] = 0; R.cigar_off = AL_CIG_INLINE;
-				regs[i] = R;
-				++c_regs; c_ref += (unsigned long long)(x.re0 - x.rs0); c_cig += 1;
-			}
-		};
-		if (!slow) { fin_seg(0, mreg0, sa0); if (n_segs == 2) fin_seg(1, mreg1, sa1); }
-		// unused job slots of this fragment (a slow fragment stops early): mark empty
-		for (uint32_t j = jb; j < (uint32_t)E.job_off[f + 1]; ++j) { E.job_key[j] = 0xffffffffu; ExtJob z; z.qlen = z.tlen = 0; z.toff = 0; z.read = 0; z.qoff = 0; z.rev = z.kind = z.pad0 = z.pad1 = 0; z.pad2 = 0; E.jobs[j] = z; atomicAdd(&s_hist[AL_NCLS], 1u); }
-		E.frag_slow[f] = slow ? 1u : 0u;
+		if (!(heavy_jobs > 0 && (int)(E.job_off[f + 1] - E.job_off[f]) >= heavy_jobs))
+			d_ext_prep_frag<false>(f, 0, rd_seq, rd_off, rd_len, frag_first, W, G, E, P, tmax, qmax, s_hist, s_tl, s_sub, c_regs, c_ref, c_cig);
 	} else if (f < n_frag) E.frag_slow[f] = 0;
 	__syncthreads();
 	if (threadIdx.x <= AL_NCLS && s_hist[threadIdx.x]) atomicAdd(&E.hist[threadIdx.x], (unsigned long long)s_hist[threadIdx.x]);   // one atomic per block and class
@@ -1808,6 +1851,31 @@ k_ext_prep(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_
 	if (threadIdx.x < 2 && s_sub[threadIdx.x]) atomicAdd(&E.hist[36 + threadIdx.x], (unsigned long long)s_sub[threadIdx.x]);
 	for (int d = 32; d > 0; d >>= 1) { c_regs += __shfl_xor(c_regs, d); c_ref += __shfl_xor(c_ref, d); c_cig += __shfl_xor(c_cig, d); }
 	if ((threadIdx.x & 63) == 0) { if (c_regs) atomicAdd(&G.counters[4], c_regs); if (c_ref) atomicAdd(&G.counters[5], c_ref); if (c_cig) atomicAdd(&G.counters[6], c_cig); }
+}
+
+// the fragments at the head of the hits-descending order (at least heavy_jobs job slots), a wavefront each
+extern "C" __global__ void __launch_bounds__(64)
+k_ext_prep_wave(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_off, const uint32_t *__restrict__ rd_len,
+                const uint32_t *__restrict__ frag_first, WsBase W, AlignShared G, ExtShared E, int n_frag, AlParams P, int tmax, int qmax,
+                const uint32_t *__restrict__ order, int heavy_jobs)
+{
+	unsigned long long c_regs = 0, c_ref = 0, c_cig = 0;
+	__shared__ unsigned s_hist[AL_NCLS + 1], s_tl[AL_NCLS + 1], s_sub[2];
+	if (threadIdx.x <= AL_NCLS) { s_hist[threadIdx.x] = 0; s_tl[threadIdx.x] = 0; }
+	if (threadIdx.x < 2) s_sub[threadIdx.x] = 0;
+	__syncthreads();
+	for (int t = blockIdx.x; t < n_frag; t += gridDim.x) {
+		const int f = (int)order[t];
+		if ((int)(E.job_off[f + 1] - E.job_off[f]) < heavy_jobs) break;     // (descending order: nothing heavy behind it)
+		if (W.frag_nu[f] == 0) continue;
+		d_ext_prep_frag<true>(f, (int)threadIdx.x, rd_seq, rd_off, rd_len, frag_first, W, G, E, P, tmax, qmax, s_hist, s_tl, s_sub, c_regs, c_ref, c_cig);
+	}
+	__syncthreads();
+	if (threadIdx.x <= AL_NCLS && s_hist[threadIdx.x]) atomicAdd(&E.hist[threadIdx.x], (unsigned long long)s_hist[threadIdx.x]);
+	if (threadIdx.x <= AL_NCLS && s_tl[threadIdx.x]) atomicAdd(&E.hist[24 + threadIdx.x], (unsigned long long)s_tl[threadIdx.x]);
+	if (threadIdx.x < 2 && s_sub[threadIdx.x]) atomicAdd(&E.hist[36 + threadIdx.x], (unsigned long long)s_sub[threadIdx.x]);
+	for (int d = 32; d > 0; d >>= 1) { c_regs += __shfl_xor(c_regs, d); c_ref += __shfl_xor(c_ref, d); c_cig += __shfl_xor(c_cig, d); }
+	if (threadIdx.x == 0) { if (c_regs) atomicAdd(&G.counters[4], c_regs); if (c_ref) atomicAdd(&G.counters[5], c_ref); if (c_cig) atomicAdd(&G.counters[6], c_cig); }
 }
 
 template <int QMAXJ, int TMAXJ> struct JobLds {
@@ -2559,7 +2627,16 @@ int al_run_align_stage(al_ctx_t *c)
 		    A->sc_ws.ensure(tot[1] + 1)) return -1;
 		AL_HIP_CHECK(hipMemsetAsync(A->hist.p, 0, AL_HIST_N * 8, s));
 		ExtShared E; E.jobs = A->jobs.p; E.outs = A->outs.p; E.rext = A->rext.p; E.job_off = A->job_off.p; E.frag_slow = A->frag_slow.p; E.job_key = A->job_key.p; E.hist = A->hist.p;
-		hipLaunchKernelGGL(k_ext_prep, dim3((nf + 255) / 256), dim3(256), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, c->frag_first.p, W, G, E, nf, c->P, tmax, qmax, frag_ord);
+		// fragments with a dozen hits or more (the head of the hits-descending order): a wavefront each, a lane per hit, on the side stream beside the rest
+		static const int heavy_env = getenv("AL_PREP_HEAVY") ? atoi(getenv("AL_PREP_HEAVY")) : AL_PREP_HEAVY;      // (0: every fragment on a lane)
+		const int heavy_jobs = frag_ord ? heavy_env : 0;
+		if (heavy_jobs > 0) {
+			AL_HIP_CHECK(hipEventRecord(c->ev_fj[0], s)); AL_HIP_CHECK(hipStreamWaitEvent(c->side, c->ev_fj[0], 0));
+			hipLaunchKernelGGL(k_ext_prep_wave, dim3(std::min(nf, 16384)), dim3(64), 0, c->side, c->rd_seq.p, c->rd_off.p, c->rd_len.p, c->frag_first.p, W, G, E, nf, c->P, tmax, qmax, frag_ord, heavy_jobs);
+			AL_HIP_CHECK(hipEventRecord(c->ev_fj[1], c->side));
+		}
+		hipLaunchKernelGGL(k_ext_prep, dim3((nf + 255) / 256), dim3(256), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, c->frag_first.p, W, G, E, nf, c->P, tmax, qmax, frag_ord, heavy_jobs);
+		if (heavy_jobs > 0) AL_HIP_CHECK(hipStreamWaitEvent(s, c->ev_fj[1], 0));
 		// fragments k_ext_prep left to the monolithic kernel are known now: a handful of them, milliseconds each on one 16-lane group --
 		// they go to the side stream at once and run beside the DP jobs
 		uint32_t *const n_early_d = (uint32_t *)(A->hist.p + 20); uint32_t n_early = 0;

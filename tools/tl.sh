@@ -3,6 +3,6 @@
 TAG=${1:-tl}; MINUS=${2:-300}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$REPO/gpurun_out/tl_$TAG; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace -d $OUT/trace --output-format csv -- python3 $REPO/bench.py --no-cpu-baseline --f2f-pairs 0 --steps 1 --warmup 1 > $OUT/bench.json 2> $OUT/err.txt
+rocprofv3 --kernel-trace -d $OUT/trace --output-format csv -- python3 $REPO/bench.py --no-cpu-baseline --f2f-pairs 0 --steps 1 --warmup 1 $TLARGS > $OUT/bench.json 2> $OUT/err.txt
 python3 $REPO/tools/timeline.py $OUT/trace $MINUS > $OUT/timeline.txt
 find $OUT -name "*.csv" -size +6M -delete
