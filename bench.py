@@ -422,9 +422,9 @@ def main():
                                     "note": ("integer-VALU bound (see roofline.valu): affine-gap DP cells of its jobs; its HBM bytes are the 4-bit reference windows and the result records (the 9 ... 22-block class has %.0f target bases in %d jobs, over its three kernels)" % (float(st.dp_target_bases[7]), int(st.dp_jobs[7]))) if dom.startswith("ext_dp_g") else (None if dom_bytes is not None else "bytes of this kernel's share of the stage are not separable: see its stage row")},
                 "stages": stages}
         # The extension DP is bound by integer VALU issue, not by HBM: its row against THAT ceiling.  Wave-instructions per launch come from the
-        # committed SQ_INSTS_VALU pass (profiles/traffic.json, tools/prof.sh); the ceiling is the measured integer issue rate of a SIMD, one
-        # wave-instruction per 4.4 cycles whatever the occupancy (tools/micro/valu_issue.hip), x 1024 SIMDs x 2.4 GHz.
-        VALU_CEIL = 1024 * 2.4e9 / 4.4
+        # committed SQ_INSTS_VALU pass (profiles/traffic.json, tools/prof.sh); the ceiling is the issue rate of the SIMDs: a 64-wide wavefront
+        # instruction occupies a 16-lane SIMD for 4 cycles, x 1024 SIMDs x 2.4 GHz (the DP kernels of profiles/r04b run at 0.9 ... 1.0 of it).
+        VALU_CEIL = 1024 * 2.4e9 / 4.0
         valu = []
         dpk = {"ext_dp_g4": "k_ext_dp<4, 512, 64>", "ext_dp_g8": "k_ext_dp<8, 512, 128>", "ext_dp_g12": "k_ext_dp<12, 512, 192>", "ext_dp_g16": "k_ext_dp<16, 512, 256>", "ext_dp_g22": "k_ext_dp<22, 512, 352>"}
         for iv in ("ext_dp_g4", "ext_dp_g8", "ext_dp_g12", "ext_dp_g16", "ext_dp_g22"):
