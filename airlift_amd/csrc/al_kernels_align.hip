@@ -1279,6 +1279,27 @@ k_regs_heavy(const AlAnchor *__restrict__ chained, const uint32_t *__restrict__ 
 	}
 }
 
+// Which tile size of k_regs_heavy takes a fragment: the smallest (kept hits, their anchors) tile it fits (the tiles are nested).  One lane per
+// candidate; the five lists go to five launches of exactly their length -- every instance used to be launched on all candidates, staging each
+// fragment's hits to find out that it was not its own, the largest tile at one block per CU.
+struct HeavyCls { int rc[5], ac[5]; };
+__global__ void __launch_bounds__(256)
+k_regs_heavy_classify(WsBase W, const uint32_t *__restrict__ list, int n_list, const uint32_t *__restrict__ regs_n0, HeavyCls T,
+                      uint32_t *__restrict__ cls_list /* 5 x n_list */, uint32_t *__restrict__ cls_cnt /* 5 */)
+{
+	const int t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= n_list) return;
+	const uint32_t f = list[t];
+	const uint32_t pre = regs_n0[f];
+	if (pre == AL_REGS_UNSET || pre == AL_REGS_DONE || AL_REGS_BAIL(pre) || pre < 9u || pre > (uint32_t)T.rc[4]) return;
+	const AlReg *r = W.regs0 + W.nu_off[f];
+	int tot = 0;
+	for (uint32_t i = 0; i < pre; ++i) tot += r[i].cnt;
+	int k = 0;
+	while (k < 5 && !((int)pre <= T.rc[k] && tot <= T.ac[k])) ++k;
+	if (k < 5) cls_list[(size_t)k * n_list + atomicAdd(&cls_cnt[k], 1u)] = f;
+}
+
 extern "C" __global__ void __launch_bounds__(256, AL_LB_REGS)
 k_regs(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__ u_all, const uint32_t *__restrict__ uo_all, const uint32_t *__restrict__ frag_first,
        const uint32_t *__restrict__ rd_len, const uint32_t *__restrict__ frag_hash, WsBase W, int n_frag, AlParams P, unsigned long long *counters,
@@ -2388,6 +2409,7 @@ struct AlignState {            // lives in al_ctx_s::align_state (opaque there)
 	DevBuf<ExtJob> jobs; DevBuf<ExtOut> outs; DevBuf<RegExt> rext;
 	DevBuf<uint64_t> job_off, sc_off, sc_ws; DevBuf<uint32_t> n_jobs, n_sc, job_key, job_key2, job_idx, job_idx2, frag_slow, slow_list, early_list;
 	DevBuf<uint8_t> sort_tmp;
+	DevBuf<uint32_t> heavy_list;                 // k_regs_heavy: the candidates by tile size, five lists
 	DevBuf<uint32_t> ford_key, ford_idx, ford;   // fragments ordered by their number of hits (k_ext_prep / k_ext_finish)
 	int logtab_a = -1, logtab_n = 0;
 	uint64_t out_total = 0;
@@ -2500,6 +2522,15 @@ int al_run_align_stage(al_ctx_t *c)
 		for (int i = 0; i < 3; ++i) { AL_HIP_CHECK(hipEventRecord(c->ev_aux[i], c->aux[i])); AL_HIP_CHECK(hipStreamWaitEvent(s, c->ev_aux[i], 0)); }
 		AL_HIP_CHECK(hipStreamWaitEvent(s, c->ev_fj[1], 0));
 	}
+	uint32_t hv_cnt[5] = {0, 0, 0, 0, 0};
+	const HeavyCls HT{{12, 24, 48, 72, 200}, {256, 512, 768, 1024, 2048}};
+	if (regs_n0 && heavy_n > 0) {
+		if (A->heavy_list.ensure((size_t)5 * heavy_n + 8)) return -1;
+		uint32_t *const cnt_d = (uint32_t *)(c->counters.p + 20);               // (counters[20..22]: five 32-bit counts)
+		AL_HIP_CHECK(hipMemsetAsync(cnt_d, 0, 24, s));
+		hipLaunchKernelGGL(k_regs_heavy_classify, dim3((heavy_n + 255) / 256), dim3(256), 0, s, W, (const uint32_t *)c->chain_idx2.p + heavy_from, (int)heavy_n, (const uint32_t *)regs_n0, HT, A->heavy_list.p, cnt_d);
+		AL_HIP_CHECK(hipMemcpyAsync(hv_cnt, cnt_d, 20, hipMemcpyDeviceToHost, s));   // (read with the total below: one synchronisation)
+	}
 	{   // room for the per-mate hits, from what chain_post kept
 		hipLaunchKernelGGL(k_regs_cap2, dim3((nf + 256) / 256), dim3(256), 0, s, (const uint32_t *)c->frag_nu.p, (const uint32_t *)regs_n0, nf, A->cap2.p);
 		if (scan32(c, A->cap2.p, A->b2_off.p, nf)) return -1;
@@ -2520,11 +2551,11 @@ int al_run_align_stage(al_ctx_t *c)
 		if (!c->attr_regs_heavy) { AL_HIP_CHECK(hipFuncSetAttribute((const void *)k_regs_heavy<200, 2048, 72, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_l)); c->attr_regs_heavy = true; }
 		hipStream_t sd = c->side;
 		AL_HIP_CHECK(hipEventRecord(c->ev_fj[0], s)); AL_HIP_CHECK(hipStreamWaitEvent(sd, c->ev_fj[0], 0));
-#define LHV(RC, AC, RCL, ACL, LDS, ST) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_heavy<RC, AC, RCL, ACL>), dim3(heavy_n), dim3(64), LDS, ST, c->chained.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, (const uint32_t *)c->chain_idx2.p + heavy_from, (int)heavy_n, c->P, c->counters.p, regs_n0)
+#define LHV(K, RC, AC, RCL, ACL, LDS, ST) do { if (hv_cnt[K] > 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_heavy<RC, AC, RCL, ACL>), dim3(hv_cnt[K]), dim3(64), LDS, ST, c->chained.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, (const uint32_t *)A->heavy_list.p + (size_t)(K) * heavy_n, (int)hv_cnt[K], c->P, c->counters.p, regs_n0); } while (0)
 		for (int i = 0; i < 3; ++i) AL_HIP_CHECK(hipStreamWaitEvent(c->aux[i], c->ev_fj[0], 0));
-		LHV(72, 1024, 48, 768, lds_s, sd); LHV(48, 768, 24, 512, lds_b, c->aux[0]); LHV(200, 2048, 72, 1024, lds_l, c->aux[1]); LHV(12, 256, 0, 0, lds_a, c->aux[2]);
+		LHV(3, 72, 1024, 48, 768, lds_s, sd); LHV(2, 48, 768, 24, 512, lds_b, c->aux[0]); LHV(4, 200, 2048, 72, 1024, lds_l, c->aux[1]); LHV(0, 12, 256, 0, 0, lds_a, c->aux[2]);
 		AL_HIP_CHECK(hipEventRecord(c->ev_fj[1], sd));
-		LHV(24, 512, 12, 256, lds_t, s);                                          // (the fifth tile size on the main stream, beside the other four: it used to wait for them)
+		LHV(1, 24, 512, 12, 256, lds_t, s);                                       // (the fifth tile size on the main stream, beside the other four)
 		for (int i = 0; i < 3; ++i) { AL_HIP_CHECK(hipEventRecord(c->ev_aux[i], c->aux[i])); AL_HIP_CHECK(hipStreamWaitEvent(s, c->ev_aux[i], 0)); }
 #undef LHV
 		AL_HIP_CHECK(hipStreamWaitEvent(s, c->ev_fj[1], 0));
