@@ -1155,7 +1155,18 @@ k_regs_cap2(const uint32_t *__restrict__ frag_nu, const uint32_t *__restrict__ r
 	cap2[f] = 4u * ((n0 == AL_REGS_UNSET || AL_REGS_BAIL(n0) || n0 == AL_REGS_DONE) ? frag_nu[f] : n0) + 4u;
 }
 
-static size_t al_regs_heavy_lds(int RC, int AC) { return (size_t)3 * RC * sizeof(AlReg) + ((size_t)2 * AC + RC + AL_RS_SCRATCH / 16 + 2) * sizeof(AlAnchor) + (size_t)3 * RC * 8 + ((size_t)2 * RC + 4 + RC + 1 + RC) * 4 + 8 * 4 + 64; }
+static size_t al_regs_heavy_lds(int RC, int AC) { return (size_t)3 * RC * sizeof(AlReg) + ((size_t)2 * AC + 2 * ((size_t)RC + AL_RS_SCRATCH / 16 + 2)) * sizeof(AlAnchor) + (size_t)4 * RC * 8 + ((size_t)2 * (2 * RC + 4) + RC + 1 + RC) * 4 + 8 * 4 + 64; }   // (the scratch of the per-mate code twice: the mates run on a lane each)
+
+// one mate's share of mm_seg_gen's tail (hit.c:395-408 + map.c:401 + align.c:873): its hits from its chains, parents, anchors squeezed
+__device__ __forceinline__ bool d_regs_mate(const AlParams &P, const uint32_t hash, const int ql, const int n, const uint64_t *su, AlAnchor *sa, AlReg *mreg,
+                                            AlAnchor *aux128, uint64_t *aux64, int *auxi, const uint32_t seg_flag, int &na_squeezed)
+{
+	const bool tie = d_gen_regs(hash, ql, n, su, sa, mreg, aux128);
+	for (int i = 0; i < n; ++i) mreg[i].flags |= ALR_SEG_SPLIT | seg_flag;
+	d_set_parent(P.mask_level, n, mreg, P.a * 2 + P.b, aux64, auxi);                              // map.c:401
+	na_squeezed = d_squeeze_a(n, mreg, sa, aux64);                                                // align.c:873
+	return tie;
+}
 
 // What follows chain_post in mm_map_frag for the kept hits regs0[0 .. n0): single end -- the hits become the mate's hits and
 // their anchors are squeezed (align.c:873); paired end -- mm_seg_gen (hit.c:356-410): anchors split per mate (y rebased), per-mate
@@ -1194,22 +1205,9 @@ __device__ __forceinline__ bool d_regs_tail(const AlParams &P, const uint32_t ha
 				if (s1) sa1[w1++] = a1; else sa0[w0++] = a1;
 			}
 		}
-		{
-			tie = d_gen_regs(hash, ql0, (int)nus0, su0, sa0, mreg0, aux128) || tie;
-			const int n = (int)nus0;
-			for (int i = 0; i < n; ++i) mreg0[i].flags |= ALR_SEG_SPLIT;
-			d_set_parent(P.mask_level, n, mreg0, P.a * 2 + P.b, aux64, auxi);                         // map.c:401
-			(void)d_squeeze_a(n, mreg0, sa0, aux64);                                                  // align.c:873
-			cnt0 = (uint32_t)n;
-		}
-		{
-			tie = d_gen_regs(hash, ql1, (int)nus1, su1, sa1, mreg1, aux128) || tie;
-			const int n = (int)nus1;
-			for (int i = 0; i < n; ++i) mreg1[i].flags |= ALR_SEG_SPLIT | (1u << 8);
-			d_set_parent(P.mask_level, n, mreg1, P.a * 2 + P.b, aux64, auxi);
-			const int na = d_squeeze_a(n, mreg1, sa1, aux64);
-			cnt1 = (uint32_t)n; sna1 = (uint32_t)na;
-		}
+		int na_sq = 0;
+		tie = d_regs_mate(P, hash, ql0, (int)nus0, su0, sa0, mreg0, aux128, aux64, auxi, 0u, na_sq) || tie; cnt0 = nus0;
+		tie = d_regs_mate(P, hash, ql1, (int)nus1, su1, sa1, mreg1, aux128, aux64, auxi, 1u << 8, na_sq) || tie; cnt1 = nus1; sna1 = (uint32_t)na_sq;
 		sna0 = na0;   // seg_a[1] starts na0 anchors after seg_a[0] (kept un-squeezed size for addressing)
 	}
 	return tie;
@@ -1228,9 +1226,9 @@ k_regs_heavy(const AlAnchor *__restrict__ chained, const uint32_t *__restrict__ 
 {
 	extern __shared__ __align__(16) unsigned char s_raw[];
 	AlReg *const s_r0 = (AlReg *)s_raw, *const s_m0 = s_r0 + RC, *const s_m1 = s_m0 + RC;
-	AlAnchor *const s_src = (AlAnchor *)(s_m1 + RC), *const s_sa = s_src + AC, *const s_aux128 = s_sa + AC;
-	uint64_t *const s_aux64 = (uint64_t *)(s_aux128 + RC + AL_RS_SCRATCH / 16 + 2), *const s_su0 = s_aux64 + RC, *const s_su1 = s_su0 + RC;
-	int *const s_auxi = (int *)(s_su1 + RC), *const s_off = s_auxi + 2 * RC + 4, *const s_as = s_off + RC + 1;
+	AlAnchor *const s_src = (AlAnchor *)(s_m1 + RC), *const s_sa = s_src + AC, *const s_aux128 = s_sa + AC, *const s_aux128b = s_aux128 + RC + AL_RS_SCRATCH / 16 + 2;
+	uint64_t *const s_aux64 = (uint64_t *)(s_aux128b + RC + AL_RS_SCRATCH / 16 + 2), *const s_aux64b = s_aux64 + RC, *const s_su0 = s_aux64b + RC, *const s_su1 = s_su0 + RC;
+	int *const s_auxi = (int *)(s_su1 + RC), *const s_auxib = s_auxi + 2 * RC + 4, *const s_off = s_auxib + 2 * RC + 4, *const s_as = s_off + RC + 1;
 	uint32_t *const s_res = (uint32_t *)(s_as + RC);
 	const int lane = threadIdx.x;
 	if ((int)blockIdx.x >= n_list) return;
@@ -1259,12 +1257,62 @@ k_regs_heavy(const AlAnchor *__restrict__ chained, const uint32_t *__restrict__ 
 	if (tot > AC || (n0 <= RCL && tot <= ACL)) return;                       // the larger / the smaller instantiation, or k_regs, takes it
 	for (int i = 0; i < n0; ++i) { const int as = s_r0[i].as, cnt = s_r0[i].cnt, o = s_off[i]; for (int j = lane; j < cnt; j += 64) s_src[o + j] = a[as + j]; }
 	__syncthreads();
-	if (lane == 0) {
-		for (int i = 0; i < n0; ++i) { s_as[i] = s_r0[i].as; s_r0[i].as = s_off[i]; }
-		uint32_t cnt0 = 0, cnt1 = 0, sna0 = 0, sna1 = 0;
-		// single end: the staged anchors are already squeezed in `as` order; d_regs_tail copies tot of them and squeezes (a no-op move)
-		const bool tie = d_regs_tail(P, frag_hash[f], (int)n_segs, ql0, ql1, n0, s_r0, s_src, (uint32_t)tot, s_m0, s_m1, s_su0, s_su1, s_sa, s_aux128, s_aux64, s_auxi, cnt0, cnt1, sna0, sna1);
-		s_res[0] = cnt0; s_res[1] = cnt1; s_res[2] = sna0; s_res[3] = sna1; s_res[4] = tie ? 1u : 0u;
+	if (n_segs != 2) {
+		if (lane == 0) {
+			for (int i = 0; i < n0; ++i) { s_as[i] = s_r0[i].as; s_r0[i].as = s_off[i]; }
+			uint32_t cnt0 = 0, cnt1 = 0, sna0 = 0, sna1 = 0;
+			// single end: the staged anchors are already squeezed in `as` order; d_regs_tail copies tot of them and squeezes (a no-op move)
+			const bool tie = d_regs_tail(P, frag_hash[f], (int)n_segs, ql0, ql1, n0, s_r0, s_src, (uint32_t)tot, s_m0, s_m1, s_su0, s_su1, s_sa, s_aux128, s_aux64, s_auxi, cnt0, cnt1, sna0, sna1);
+			s_res[0] = cnt0; s_res[1] = cnt1; s_res[2] = sna0; s_res[3] = sna1; s_res[4] = tie ? 1u : 0u;
+		}
+	} else {
+		// Paired end, d_regs_tail's sequence with the wavefront's lanes put to use: mm_seg_gen's two passes over the anchors (hit.c:356-394: count
+		// per hit and mate, then split with y rebased) are per-anchor work -- a lane per hit for the counts, a lane per anchor for the split -- and
+		// the per-mate tails (hits from chains, parents, squeeze) are independent of each other: lane 0 takes mate 0, lane 1 mate 1.
+		const int qlen_sum = ql0 + ql1;
+		for (int i = lane; i < n0; i += 64) {
+			const int o = s_off[i], cnt = s_r0[i].cnt; uint32_t c1 = 0;
+			for (int j = 0; j < cnt; ++j) c1 += (uint32_t)((s_src[o + j].y & AL_SEED_SEG_MASK) >> AL_SEED_SEG_SHIFT) & 1u;
+			const uint64_t sc = (uint64_t)(uint32_t)s_r0[i].score << 32;
+			s_su0[i] = sc | ((uint32_t)cnt - c1); s_su1[i] = sc | c1;
+		}
+		__syncthreads();
+		if (lane == 0) {
+			uint32_t na0 = 0, nus0 = 0, nus1 = 0;
+			for (int i = 0; i < n0; ++i) na0 += (uint32_t)s_su0[i];
+			for (int i = 0; i < n0; ++i) { if ((int32_t)s_su0[i] != 0) s_su0[nus0++] = s_su0[i]; if ((int32_t)s_su1[i] != 0) s_su1[nus1++] = s_su1[i]; }
+			s_res[0] = nus0; s_res[1] = nus1; s_res[2] = na0;
+		}
+		__syncthreads();
+		const uint32_t na0 = s_res[2];
+		AlAnchor *const sa1 = s_sa + na0;
+		{   // the split: anchor t of the staged list (hits in order, their anchors in order) goes behind the earlier anchors of its mate
+			uint32_t run1 = 0;
+			for (int base = 0; base < tot; base += 64) {
+				const int t = base + lane; const bool on = t < tot;
+				AlAnchor a1; a1.x = 0; a1.y = 0; bool s1 = false;
+				if (on) { a1 = s_src[t]; s1 = ((a1.y & AL_SEED_SEG_MASK) >> AL_SEED_SEG_SHIFT) & 1; }
+				const unsigned long long b1 = __ballot(on && s1);
+				const uint32_t r1 = run1 + (uint32_t)__popcll(b1 & ((1ULL << lane) - 1ULL));
+				if (on) {
+					const int qls = s1 ? ql1 : ql0, acc = s1 ? ql0 : 0;
+					a1.y -= (a1.x >> 63) ? (uint64_t)(qlen_sum - (qls + acc)) : (uint64_t)acc;
+					if (s1) sa1[r1] = a1; else s_sa[(uint32_t)t - r1] = a1;
+				}
+				run1 += (uint32_t)__popcll(b1);
+			}
+		}
+		__syncthreads();
+		bool tie = false; int na_sq = 0;
+		if (lane < 2) {
+			const bool m1 = lane == 1;
+			tie = d_regs_mate(P, frag_hash[f], m1 ? ql1 : ql0, (int)s_res[m1 ? 1 : 0], m1 ? s_su1 : s_su0, m1 ? sa1 : s_sa, m1 ? s_m1 : s_m0,
+			                  m1 ? s_aux128b : s_aux128, m1 ? s_aux64b : s_aux64, m1 ? s_auxib : s_auxi, m1 ? 1u << 8 : 0u, na_sq);
+		}
+		const unsigned long long tb = __ballot(tie);
+		const int na1 = __shfl(na_sq, 1);
+		__syncthreads();
+		if (lane == 0) { const uint32_t c0 = s_res[0], c1 = s_res[1]; s_res[0] = c0; s_res[1] = c1; s_res[2] = na0; s_res[3] = (uint32_t)na1; s_res[4] = tb ? 1u : 0u; }
 	}
 	__syncthreads();
 	const uint32_t cnt0 = s_res[0], cnt1 = s_res[1], sna0 = s_res[2], sna1 = s_res[3];
@@ -2548,7 +2596,11 @@ int al_run_align_stage(al_ctx_t *c)
 		// instances work on disjoint fragments and run side by side.  The code is one lane on LDS copies: what sets the rate is how many
 		// wavefronts a CU holds, i.e. the tile (17 KB: 9 per CU ... 141 KB: one).
 		const size_t lds_a = al_regs_heavy_lds(12, 256), lds_t = al_regs_heavy_lds(24, 512), lds_b = al_regs_heavy_lds(48, 768), lds_s = al_regs_heavy_lds(72, 1024), lds_l = al_regs_heavy_lds(200, 2048);
-		if (!c->attr_regs_heavy) { AL_HIP_CHECK(hipFuncSetAttribute((const void *)k_regs_heavy<200, 2048, 72, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_l)); c->attr_regs_heavy = true; }
+		if (!c->attr_regs_heavy) {
+			AL_HIP_CHECK(hipFuncSetAttribute((const void *)k_regs_heavy<200, 2048, 72, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_l));
+			AL_HIP_CHECK(hipFuncSetAttribute((const void *)k_regs_heavy<72, 1024, 48, 768>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
+			c->attr_regs_heavy = true;
+		}
 		hipStream_t sd = c->side;
 		AL_HIP_CHECK(hipEventRecord(c->ev_fj[0], s)); AL_HIP_CHECK(hipStreamWaitEvent(sd, c->ev_fj[0], 0));
 #define LHV(K, RC, AC, RCL, ACL, LDS, ST) do { if (hv_cnt[K] > 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_heavy<RC, AC, RCL, ACL>), dim3(hv_cnt[K]), dim3(64), LDS, ST, c->chained.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, (const uint32_t *)A->heavy_list.p + (size_t)(K) * heavy_n, (int)hv_cnt[K], c->P, c->counters.p, regs_n0); } while (0)
