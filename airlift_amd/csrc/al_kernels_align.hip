@@ -2551,7 +2551,7 @@ int al_run_align_stage(al_ctx_t *c)
 		// room on a CU the small blocks keep refilling (20 ms beside them, 4.5 ms alone): its sort runs first, alone on the main stream with the
 		// thin classes beside it, and leaves keys and order in the work area for a one-wavefront pass (k_regs_select<-2>) on the side stream.
 		hipStream_t sd = c->side;
-		static const int split = getenv("AL_REGS_SPLIT") ? atoi(getenv("AL_REGS_SPLIT")) : 0;   // experiment: bit 0: 257 ... 1024 chains sorted and passed over by two kernels as well
+		static const int split = getenv("AL_REGS_SPLIT") ? atoi(getenv("AL_REGS_SPLIT")) : 1;   // bit 0: 257 ... 1024 chains sorted and passed over by two kernels as well (4.6 + 2.2 ms against 7.7 in one: the pass alone fits twelve blocks a CU)
 #define LSEL(CAPV, PH, NT, A, B, ST) do { if ((B) > (A)) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_select<CAPV, PH>), dim3((B) - (A)), dim3(NT), 0, ST, c->chained.p, c->u.p, c->uo.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, ord + (A), (int)((B) - (A)), c->P, regs_n0); } while (0)
 		AL_HIP_CHECK(hipEventRecord(c->ev_fj[0], s));
 		for (int i = 0; i < 3; ++i) AL_HIP_CHECK(hipStreamWaitEvent(c->aux[i], c->ev_fj[0], 0));
