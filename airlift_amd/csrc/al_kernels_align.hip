@@ -892,11 +892,28 @@ k_regs_select(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__
 		int npow2 = 1; while (npow2 < n_u) npow2 <<= 1;
 		for (int c = n_u + tid; c < npow2; c += NT) { skey[c] = 0; sidx[c] = (IdxT)~0u; }   // keys are > 0 (a chain's score, in the high word): padding sorts last
 		__syncthreads();
-		for (int kk = 2; kk <= npow2; kk <<= 1)
+		// A thread takes comparators, not elements: pair p of a step works on i = p with a zero inserted at bit log2(j) and on i | j, so every
+		// thread is busy, and the loads of all its pairs (LDS tiles: a compile-time count) are in flight before the first comparison -- one LDS
+		// round trip per step instead of two per pair (the 8192-key tile: 3.9 of the kernel's 6.7 ms were these steps).
+		constexpr int PP = CAP > 0 ? (CAP / 2 + NT - 1) / NT : 1;
+		const int half = npow2 >> 1;
+		for (int kk = 2; kk <= (((P.dbg >> 15) & 1) ? 0 : npow2); kk <<= 1)   // (AL_DBG bit 15: timing experiment, no sort)
 			for (int j = kk >> 1; j > 0; j >>= 1) {
-				for (int i = tid; i < npow2; i += NT) {
-					const int ixj = i ^ j;
-					if (ixj > i) {
+				if (CAP > 0) {
+					uint64_t kx[PP], ky[PP]; IdxT ix[PP], iy[PP];
+#pragma unroll
+					for (int q = 0; q < PP; ++q) {
+						const int p_ = tid + q * NT, i = ((p_ & ~(j - 1)) << 1) | (p_ & (j - 1));
+						if (p_ < half) { kx[q] = skey[i]; ky[q] = skey[i | j]; ix[q] = sidx[i]; iy[q] = sidx[i | j]; }
+					}
+#pragma unroll
+					for (int q = 0; q < PP; ++q) {
+						const int p_ = tid + q * NT, i = ((p_ & ~(j - 1)) << 1) | (p_ & (j - 1));
+						if (p_ < half && (kx[q] < ky[q]) == ((i & kk) == 0)) { skey[i] = ky[q]; skey[i | j] = kx[q]; sidx[i] = iy[q]; sidx[i | j] = ix[q]; }
+					}
+				} else {
+					for (int p_ = tid; p_ < half; p_ += NT) {
+						const int i = ((p_ & ~(j - 1)) << 1) | (p_ & (j - 1)), ixj = i | j;
 						const uint64_t x = skey[i], y = skey[ixj];
 						if ((x < y) == ((i & kk) == 0)) { skey[i] = y; skey[ixj] = x; const IdxT t = sidx[i]; sidx[i] = sidx[ixj]; sidx[ixj] = t; }
 					}
