@@ -1801,12 +1801,21 @@ __device__ __forceinline__ void d_ext_prep_frag(const int f, const int lane, con
 			auto shortcut = [&](const int side, const int ql, const int tl) -> bool {
 				if (ql == 0 || ql > tl) return false;
 				int sc = 0, mx = 0, pos = -1, nmm = 0;
-				for (int k = 0; k < ql; ++k) {
-					const int cq = side == 0 ? Qa(x.qs - 1 - k) : Qa(x.qe + k);
-					const int ct = side == 0 ? Ta(x.rs - 1 - k) : Ta(x.re + k);
-					if (cq > 3 || ct > 3) return false;
-					if (cq == ct) sc += P.a; else { sc -= P.b; if (++nmm > 1) return false; }
-					if (sc > mx) { mx = sc; pos = k; }
+				for (int k = 0; k < ql; ) {
+					// eight bases at once while they all match (the order inside the eight does not matter for that: the left flank's window
+					// is read forwards): the running score rises with every base, so the maximum and its position are the last of them
+					if (k + 8 <= ql) {
+						const uint32_t qw = side == 0 ? Qa.win8(x.qs - 8 - k) : Qa.win8(x.qe + k), tw = side == 0 ? Ta.win8(x.rs - 8 - k) : Ta.win8(x.re + k);
+						if (qw == tw && !(qw & 0x44444444u)) { sc += 8 * P.a; if (sc > mx) { mx = sc; pos = k + 7; } k += 8; continue; }
+					}
+					const int kend = k + 8 <= ql ? k + 8 : ql;
+					for (; k < kend; ++k) {
+						const int cq = side == 0 ? Qa(x.qs - 1 - k) : Qa(x.qe + k);
+						const int ct = side == 0 ? Ta(x.rs - 1 - k) : Ta(x.re + k);
+						if (cq > 3 || ct > 3) return false;
+						if (cq == ct) sc += P.a; else { sc -= P.b; if (++nmm > 1) return false; }
+						if (sc > mx) { mx = sc; pos = k; }
+					}
 				}
 				// a target at least w + 1 longer than the query makes the band run off the matrix (st > en at row 2*ql + w - 1,
 				// ksw2_extd2_sse.c:135): the reference flags that like a z-drop and ends at the maximum, never at the query end
