@@ -2291,17 +2291,17 @@ k_collect_slow(const uint32_t *__restrict__ frag_slow, int n_frag, uint32_t *__r
 	if (f < n_frag && frag_slow[f] != 0) list[atomicAdd(cnt, 1u)] = (uint32_t)f;
 }
 
-extern "C" __global__ void __launch_bounds__(256, AL_LB_FIN)
-k_ext_finish(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_off, const uint32_t *__restrict__ rd_len,
-             const uint32_t *__restrict__ frag_first, const int32_t *__restrict__ frag_rep, WsBase W, AlignShared G, ExtShared E,
-             AlLogTab lt, uint64_t *__restrict__ sc_ws, const uint64_t *__restrict__ sc_off, int n_frag, AlParams P, uint32_t *__restrict__ slow_list, uint32_t *__restrict__ n_slow,
-             int early_done /* fragments k_ext_prep marked slow are already with the monolithic kernel (side stream) */, const uint32_t *__restrict__ order /* as k_ext_prep */)
+// One fragment's share of k_ext_finish.  WAVE: the wavefront's lanes take a hit each for the per-hit part (CIGAR assembly, mm_update_extra: loops over
+// the hit's bases), lane 0 does the bookkeeping between hits (filter, order, parents, selection, MAPQ, pairing) as the lane form does.
+// CS: lane stride of the CIGAR assembly buffer (s_cig points at the calling lane's first word).
+template <int S> struct LdsCigS { uint32_t *b; __device__ __forceinline__ uint32_t &operator[](uint32_t i) const { return b[i * S]; } };
+#define AL_FIN_HEAVY 24            // job slots (two per hit) from which a fragment goes to the wavefront form (batches of at most 400 k fragments)
+template <bool WAVE, int CS>
+__device__ __forceinline__ void d_ext_finish_frag(const int f, const int lane, uint32_t *s_cig, const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_off, const uint32_t *__restrict__ rd_len,
+                                  const uint32_t *__restrict__ frag_first, const int32_t *__restrict__ frag_rep, const WsBase &W, const AlignShared &G, const ExtShared &E,
+                                  const AlLogTab &lt, uint64_t *__restrict__ sc_ws, const uint64_t *__restrict__ sc_off, const AlParams &P, uint32_t *__restrict__ slow_list, uint32_t *__restrict__ n_slow,
+                                  unsigned long long &c_regs, unsigned long long &c_ref, unsigned long long &c_cig)
 {
-	const int t_ = blockIdx.x * blockDim.x + threadIdx.x;
-	const int f = t_ < n_frag ? (order ? (int)order[t_] : t_) : n_frag;
-	__shared__ uint32_t s_cig[AL_FCIG * 256];                                  // per-lane CIGAR assembly buffer, [word][lane]
-	unsigned long long c_regs = 0, c_ref = 0, c_cig = 0;
-	if (f < n_frag && W.frag_nu[f] != 0 && !(early_done && E.frag_slow[f] != 0)) {
 		const uint32_t r0 = frag_first[f], n_segs = frag_first[f + 1] - r0;
 		FragWs fw; d_frag_ws(W, (uint32_t)f, fw);
 		const uint64_t B2 = (uint64_t)(fw.mreg[0] - W.mregs);
@@ -2310,16 +2310,18 @@ k_ext_finish(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ r
 		// way the monolithic path handles differently (nothing to do: z-dropped extensions are handled identically)
 		auto precheck = [&](const uint32_t s, const AlReg *regs) {
 			const int n = (int)W.reg_cnt[r0 + s];
-			for (int i = 0; i < n && !slow; ++i) {
+			bool bad = false;
+			for (int i = WAVE ? lane : 0; i < n && !bad && (WAVE || !slow); i += WAVE ? 64 : 1) {
 				if (regs[i].cnt == 0 || (regs[i].flags & ALR_HAS_P)) continue;     // empty, or already finished by k_ext_prep
 				const RegExt x = E.rext[B2 + (uint64_t)s * fw.cap + i];
 				const uint32_t nl = E.jobs[x.job].qlen ? E.outs[x.job].flags_ncig >> 8 : 0, nr = E.jobs[x.job + 1].qlen ? E.outs[x.job + 1].flags_ncig >> 8 : 0;
-				if (nl + 1 + nr > AL_FCIG) slow = true;
+				if (nl + 1 + nr > AL_FCIG) bad = true;
 			}
+			if (WAVE ? (__ballot(bad) != 0ULL) : bad) slow = true;
 		};
 		if (!slow) precheck(0, fw.mreg[0]);
 		if (!slow && n_segs == 2) precheck(1, fw.mreg[1]);
-		if (slow) { slow_list[atomicAdd(n_slow, 1u)] = (uint32_t)f; }
+		if (slow) { if (!WAVE || lane == 0) slow_list[atomicAdd(n_slow, 1u)] = (uint32_t)f; }
 		else {
 			// (no local array is indexed by a run-time value and the hit being finished lives in registers: see k_regs)
 			const int ql0 = (int)rd_len[r0], ql1 = n_segs > 1 ? (int)rd_len[r0 + 1] : 0, qlen_sum = ql0 + ql1;
@@ -2328,7 +2330,7 @@ k_ext_finish(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ r
 			else if (P.max_frag_len > 0) { max_gap_ref = P.max_frag_len - qlen_sum; if (max_gap_ref < P.max_gap) max_gap_ref = P.max_gap; }
 			else max_gap_ref = P.max_gap;
 			const int rep_len = frag_rep[f]; bool tie = false;
-			const LdsCig cig{s_cig + threadIdx.x};
+			const LdsCigS<CS> cig{s_cig};
 			auto finish_reg = [&](const int qlen, const uint32_t *seq, const AlReg &Rin, const RegExt x, const AlAnchor *a) -> AlReg {
 				AlReg R = Rin;
 				const int32_t rid = R.rid, rev = (R.flags & ALR_REV) ? 1 : 0;
@@ -2371,10 +2373,11 @@ k_ext_finish(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ r
 			auto do_seg = [&](const uint32_t s, const int qlen, AlReg *regs, const AlAnchor *a) -> int {
 				int n = (int)W.reg_cnt[r0 + s];
 				const uint32_t *seq = rd_seq + rd_off[r0 + s];
-				for (int i = 0; i < n; ++i) {                                    // mm_align1 after the DP calls (align.c:698-788)
+				for (int i = WAVE ? lane : 0; i < n; i += WAVE ? 64 : 1) {       // mm_align1 after the DP calls (align.c:698-788); wavefront form: a lane per hit
 					if (regs[i].cnt == 0 || (regs[i].flags & ALR_HAS_P)) continue;
 					regs[i] = finish_reg(qlen, seq, regs[i], E.rext[B2 + (uint64_t)s * fw.cap + i], a);
 				}
+				if (WAVE) { __threadfence_block(); if (lane != 0) return 0; }     // the hit-level bookkeeping below is one lane's
 				d_filter_regs(P, qlen, &n, regs);                                // align.c:910-911
 				tie = d_hit_sort(&n, regs, fw.aux128, fw.rtmp) || tie;
 				d_set_parent(P.mask_level, n, regs, P.a * 2 + P.b, fw.aux64, fw.auxi);
@@ -2385,7 +2388,7 @@ k_ext_finish(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ r
 			};
 			AlReg *const mreg0 = fw.mreg[0], *const mreg1 = fw.mreg[1];
 			const AlAnchor *const sa0 = fw.seg_a[0], *const sa1 = n_segs == 2 ? fw.seg_a[0] + W.seg_na[r0] : nullptr;
-			if (n_segs == 2 && W.reg_cnt[r0] == 1 && W.reg_cnt[r0 + 1] == 1 && mreg0[0].cnt != 0 && mreg1[0].cnt != 0 && !((P.dbg >> 19) & 1)) {
+			if (!WAVE && n_segs == 2 && W.reg_cnt[r0] == 1 && W.reg_cnt[r0 + 1] == 1 && mreg0[0].cnt != 0 && mreg1[0].cnt != 0 && !((P.dbg >> 19) & 1)) {
 				// One hit per mate (the common fragment): both records stay in registers from the DP results to the final store;
 				// the post-DP bookkeeping of a single hit (filter, parent = self, sam_pri, MAPQ) and the 1 x 1 pairing need no
 				// scratch arrays.  Same result as the general code below.
@@ -2412,6 +2415,7 @@ k_ext_finish(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ r
 			} else {
 			const int nr0 = do_seg(0, ql0, mreg0, sa0);
 			const int nr1 = n_segs == 2 ? do_seg(1, ql1, mreg1, sa1) : 0;
+			if (WAVE && lane != 0) return;
 			if (n_segs == 2 && P.pe_ori >= 0) {
 				bool ovf = false;
 				// pair scores: at most n0*n1 entries (bounded by the hit counts after k_regs; see k_ext_counts)
@@ -2423,9 +2427,43 @@ k_ext_finish(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ r
 			}
 			if (tie) atomicAdd(&G.counters[10], 1ULL);
 		}
-	}
+}
+
+extern "C" __global__ void __launch_bounds__(256, AL_LB_FIN)
+k_ext_finish(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_off, const uint32_t *__restrict__ rd_len,
+             const uint32_t *__restrict__ frag_first, const int32_t *__restrict__ frag_rep, WsBase W, AlignShared G, ExtShared E,
+             AlLogTab lt, uint64_t *__restrict__ sc_ws, const uint64_t *__restrict__ sc_off, int n_frag, AlParams P, uint32_t *__restrict__ slow_list, uint32_t *__restrict__ n_slow,
+             int early_done /* fragments k_ext_prep marked slow are already with the monolithic kernel (side stream) */, const uint32_t *__restrict__ order /* as k_ext_prep */,
+             int heavy_jobs /* fragments with at least this many job slots are k_ext_finish_wave's (0: none) */)
+{
+	const int t_ = blockIdx.x * blockDim.x + threadIdx.x;
+	const int f = t_ < n_frag ? (order ? (int)order[t_] : t_) : n_frag;
+	__shared__ uint32_t s_cig[AL_FCIG * 256];                                  // per-lane CIGAR assembly buffer, [word][lane]
+	unsigned long long c_regs = 0, c_ref = 0, c_cig = 0;
+	if (f < n_frag && W.frag_nu[f] != 0 && !(early_done && E.frag_slow[f] != 0) && !(heavy_jobs > 0 && (int)(E.job_off[f + 1] - E.job_off[f]) >= heavy_jobs))
+		d_ext_finish_frag<false, 256>(f, 0, s_cig + threadIdx.x, rd_seq, rd_off, rd_len, frag_first, frag_rep, W, G, E, lt, sc_ws, sc_off, P, slow_list, n_slow, c_regs, c_ref, c_cig);
 	for (int d = 32; d > 0; d >>= 1) { c_regs += __shfl_xor(c_regs, d); c_ref += __shfl_xor(c_ref, d); c_cig += __shfl_xor(c_cig, d); }
 	if ((threadIdx.x & 63) == 0) { if (c_regs) atomicAdd(&G.counters[4], c_regs); if (c_ref) atomicAdd(&G.counters[5], c_ref); if (c_cig) atomicAdd(&G.counters[6], c_cig); }
+}
+
+// the fragments at the head of the hits-descending order, a wavefront each
+extern "C" __global__ void __launch_bounds__(64)
+k_ext_finish_wave(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_off, const uint32_t *__restrict__ rd_len,
+                  const uint32_t *__restrict__ frag_first, const int32_t *__restrict__ frag_rep, WsBase W, AlignShared G, ExtShared E,
+                  AlLogTab lt, uint64_t *__restrict__ sc_ws, const uint64_t *__restrict__ sc_off, int n_frag, AlParams P, uint32_t *__restrict__ slow_list, uint32_t *__restrict__ n_slow,
+                  int early_done, const uint32_t *__restrict__ order, int heavy_jobs)
+{
+	__shared__ uint32_t s_cig[AL_FCIG * 64];
+	unsigned long long c_regs = 0, c_ref = 0, c_cig = 0;
+	for (int t = blockIdx.x; t < n_frag; t += gridDim.x) {
+		const int f = (int)order[t];
+		if ((int)(E.job_off[f + 1] - E.job_off[f]) < heavy_jobs) break;     // (descending order: nothing heavy behind it)
+		if (W.frag_nu[f] == 0 || (early_done && E.frag_slow[f] != 0)) continue;
+		d_ext_finish_frag<true, 64>(f, (int)threadIdx.x, s_cig + threadIdx.x, rd_seq, rd_off, rd_len, frag_first, frag_rep, W, G, E, lt, sc_ws, sc_off, P, slow_list, n_slow, c_regs, c_ref, c_cig);
+		__syncthreads();
+	}
+	for (int d = 32; d > 0; d >>= 1) { c_regs += __shfl_xor(c_regs, d); c_ref += __shfl_xor(c_ref, d); c_cig += __shfl_xor(c_cig, d); }
+	if (threadIdx.x == 0) { if (c_regs) atomicAdd(&G.counters[4], c_regs); if (c_ref) atomicAdd(&G.counters[5], c_ref); if (c_cig) atomicAdd(&G.counters[6], c_cig); }
 }
 
 extern "C" __global__ void __launch_bounds__(256)
@@ -2850,7 +2888,20 @@ int al_run_align_stage(al_ctx_t *c)
 		else { AL_HIP_CHECK(hipEventRecord(c->ev[ST_EXT_SORT + 1], s)); for (int i = ST_EXT_DP_LANE; i < ST_EXT_DP_G22; ++i) AL_HIP_CHECK(hipEventRecord(c->ev[i + 1], s)); }   // (no jobs: empty intervals)
 		AL_HIP_CHECK(hipEventRecord(c->ev[ST_EXT_DP_G22 + 1], s));
 		uint32_t *n_slow_d = (uint32_t *)(c->counters.p + 14);
-		hipLaunchKernelGGL(k_ext_finish, dim3((nf + 255) / 256), dim3(256), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, c->frag_first.p, c->frag_rep.p, W, G, E, lt, A->sc_ws.p, A->sc_off.p, nf, c->P, A->slow_list.p, n_slow_d, 1, frag_ord);
+		{   // Fragments with a dozen hits or more: a wavefront each for the per-hit part (its own stream), the rest a lane each -- in SMALL batches only.
+			// Such a fragment's bookkeeping between hits (order, parents, pairing of ~20 x 20 hits on global memory) is a millisecond of one lane
+			// whichever form runs it; sixty-four of them to a wavefront is how a large batch gets through its tens of thousands (1 M pairs: 5.1 ms
+			// against 6.5 ... 8.4 with the wavefront form), while a 262 144-pair batch has few enough for the per-hit part to matter (3.6 -> 2.2 ms).
+			static const int fin_env = getenv("AL_FIN_HEAVY") ? atoi(getenv("AL_FIN_HEAVY")) : -1;                    // (0: every fragment on a lane)
+			const int fin_heavy = !frag_ord ? 0 : fin_env >= 0 ? fin_env : nf <= 400000 ? AL_FIN_HEAVY : 0;
+			if (fin_heavy > 0) {
+				AL_HIP_CHECK(hipEventRecord(c->ev_fj[0], s)); AL_HIP_CHECK(hipStreamWaitEvent(c->aux[0], c->ev_fj[0], 0));   // (not the side stream: the monolithic kernel may still be running there)
+				hipLaunchKernelGGL(k_ext_finish_wave, dim3(std::min(nf, 16384)), dim3(64), 0, c->aux[0], c->rd_seq.p, c->rd_off.p, c->rd_len.p, c->frag_first.p, c->frag_rep.p, W, G, E, lt, A->sc_ws.p, A->sc_off.p, nf, c->P, A->slow_list.p, n_slow_d, 1, frag_ord, fin_heavy);
+				AL_HIP_CHECK(hipEventRecord(c->ev_aux[0], c->aux[0]));
+			}
+			hipLaunchKernelGGL(k_ext_finish, dim3((nf + 255) / 256), dim3(256), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, c->frag_first.p, c->frag_rep.p, W, G, E, lt, A->sc_ws.p, A->sc_off.p, nf, c->P, A->slow_list.p, n_slow_d, 1, frag_ord, fin_heavy);
+			if (fin_heavy > 0) AL_HIP_CHECK(hipStreamWaitEvent(s, c->ev_aux[0], 0));
+		}
 		uint32_t n_slow = 0;
 		AL_HIP_CHECK(hipMemcpyAsync(&n_slow, n_slow_d, 4, hipMemcpyDeviceToHost, s));
 		AL_HIP_CHECK(hipStreamSynchronize(s));
