@@ -575,7 +575,7 @@ static int chain_fallback(al_ctx_t *c, const uint32_t *fb, int n_fb, bool lds_ok
 	uint32_t *const sv_na = c->frag_na.p, *const sv_first = c->frag_first.p, *const sv_rd_len = c->rd_len.p, *const sv_nu = c->frag_nu.p;
 	c->anchors.p = c->v_anchors.p; c->chained.p = c->v_chained.p; c->a_off.p = c->v_a_off.p; c->u.p = c->v_u.p;
 	c->frag_na.p = c->v_na.p; c->frag_first.p = c->v_first.p; c->rd_len.p = c->v_rd_len.p; c->frag_nu.p = c->v_nu.p;
-	const int rc = chain_by_segments(c, c->v_order.p, n_fb, lds_ok, false, nullptr);
+	const int rc = chain_by_segments(c, c->v_order.p, n_fb, lds_ok, false, nullptr, true);   // (with the processing keys at once: most of these fragments were handed back for tied chain starts, which need them -- one pass instead of two)
 	c->anchors.p = sv_anchors; c->chained.p = sv_chained; c->a_off.p = sv_a_off; c->u.p = sv_u;
 	c->frag_na.p = sv_na; c->frag_first.p = sv_first; c->rd_len.p = sv_rd_len; c->frag_nu.p = sv_nu;
 	if (rc) return -1;
