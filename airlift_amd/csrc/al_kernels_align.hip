@@ -830,11 +830,11 @@ __device__ __forceinline__ void d_frag_ws(const WsBase &W, uint32_t f, FragWs &o
 // Only the kept hits are written (ws.regs0[0 .. n0), ids and parents renumbered as mm_sync_regs does); regs_n0[f] = n0 tells
 // k_regs to start at mm_seg_gen.  Equal sort keys, more than PMAX primaries or more chains than the tile: regs_n0[f] stays
 // unset and k_regs runs the reference's sequence on one lane (exact order among equal keys).
-#define AL_REGS_PMAX 160              // primaries a fragment can have before k_regs takes it (short chains tiling a pair: dozens)
+#define AL_REGS_PMAX 64               // primaries a fragment can have before k_regs takes it (short chains tiling a pair: dozens).  With AL_REGS_KCAP these two tables set the LDS of the pass (5.5 KB at 64 / 96 against 12.8 KB at 160 / 192: the one-wavefront kernels are then bound by wave slots, not LDS: regs 22.5 -> 20.0 ms on C4, no fragment more for the serial code)
 #define AL_REGS_UNSET 0xffffffffu
 #define AL_REGS_DONE 0xfffffffeu
 #define AL_REGS_BAIL(v) ((v) >= 0xfffffff0u && (v) < AL_REGS_DONE)   // k_regs_select gave up: 0xfffffff1 equal sort keys (> 65535 chains), 0xfffffff2 too many primaries, 0xfffffff3 parent slot reused (in-place compaction of the reference)
-#define AL_REGS_KCAP 192              // kept hits whose records k_regs_select holds for the in-place compaction of the reference's selection (primaries + best_n)
+#define AL_REGS_KCAP 96               // kept hits whose records k_regs_select holds for the in-place compaction of the reference's selection (primaries + best_n)
 struct RegsSelKept { int32_t score[AL_REGS_KCAP], ridrev[AL_REGS_KCAP], rs[AL_REGS_KCAP], re[AL_REGS_KCAP]; uint16_t qs[AL_REGS_KCAP], qe[AL_REGS_KCAP]; };   // (query coordinates are below 2^16: reads of at most 32768 bases)
 struct RegsSelShared {
 	int32_t qs[AL_REGS_PMAX], qe[AL_REGS_PMAX], score[AL_REGS_PMAX], cnt[AL_REGS_PMAX], as[AL_REGS_PMAX], rs[AL_REGS_PMAX], re[AL_REGS_PMAX], ridrev[AL_REGS_PMAX];
