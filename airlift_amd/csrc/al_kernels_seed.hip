@@ -586,7 +586,7 @@ k_anchor_sort_reg(const uint64_t *__restrict__ pos, const uint32_t *__restrict__
 	constexpr int PADW = CAP + CAP / 16 + 2;                // output transpose: one pad word per 16 keys
 	__shared__ uint64_t sx[PADW];
 	__shared__ uint32_t pre[MCAP + 1];
-	constexpr bool MLDS = NW > 1;                           // match records in LDS (block kernels); the one-wave kernels read them through L1 / L2
+	constexpr bool MLDS = false;                            // (match records in LDS for the block kernels: 12 KB that cost a block per CU -- 52.7 -> 40.7 KB, 88.5 -> 76.5 KB: four and two blocks instead of three and one; the records are read through L1 / L2 like the one-wave kernels do: block sorts 19.4 -> 17.4 ms)
 	__shared__ uint32_t m_off[MLDS ? MCAP : 1], m_fl[MLDS ? MCAP : 1], m_qp[MLDS ? MCAP : 1];   // off_lo, flags, q_pos
 	__shared__ uint32_t s_part[NT];
 	__shared__ int s_flag;
