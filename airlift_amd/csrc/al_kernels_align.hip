@@ -2543,7 +2543,7 @@ void al_align_state_free(al_ctx_t *c)
 	AlignState *s = it->second;
 	s->regs0.release(); s->mregs.release(); s->rtmp.release(); s->out.release(); s->aux128.release(); s->seg_a.release(); s->aux64.release(); s->seg_u.release();
 	s->nu_off.release(); s->out_off.release(); s->auxi.release(); s->reg_cnt.release(); s->seg_na.release(); s->arena.release(); s->gws.release(); s->long_state.release(); s->logtab.release(); s->dbgbuf.release(); s->hist.release(); s->jobs.release(); s->outs.release(); s->rext.release(); s->seg_fast.release(); s->regs_n0.release(); s->cap2.release(); s->b2_off.release();
-	s->job_off.release(); s->sc_off.release(); s->sc_ws.release(); s->n_jobs.release(); s->n_sc.release(); s->job_key.release(); s->job_key2.release(); s->job_idx.release(); s->job_idx2.release(); s->frag_slow.release(); s->slow_list.release(); s->early_list.release(); s->gws2.release(); s->sort_tmp.release(); s->ford_key.release(); s->ford_idx.release(); s->ford.release();
+	s->job_off.release(); s->sc_off.release(); s->sc_ws.release(); s->n_jobs.release(); s->n_sc.release(); s->job_key.release(); s->job_key2.release(); s->job_idx.release(); s->job_idx2.release(); s->frag_slow.release(); s->slow_list.release(); s->early_list.release(); s->gws2.release(); s->sort_tmp.release(); s->ford_key.release(); s->ford_idx.release(); s->ford.release(); s->heavy_list.release();
 	delete s; g_states.erase(it);
 }
 

@@ -55,28 +55,73 @@ static std::string run_id_base()
 	return "p" + std::to_string((long long)getppid());
 }
 static std::string run_id() { return g_nonce.empty() ? run_id_base() : run_id_base() + "_" + g_nonce; }
-// The launch's token: rank 0 writes a fresh random word under the base id; the others take the token file only if it is not older than their own
-// start (a crashed earlier run under the same MASTER_PORT / 'none' run id leaves its files behind: without this a late rank could read a stale
-// exchange file or a stale RCCL id and wait in ncclCommInitRank for ever).
-static int agree_on_token(const std::string &dir, int rank, double timeout, double my_start_wall)
+// The launch's token, agreed on without comparing file times with a local clock (ranks reach this point seconds apart -- each after its own
+// FASTA load and index build -- and a shared directory's server clock need not be ours).  Every rank r > 0 writes a fresh random word to its
+// hello file; rank 0 writes the token file = a fresh token followed by the hello word it has read for every rank, and writes it again whenever a
+// hello file changes (a crashed earlier run under the same MASTER_PORT / 'none' run id may have left stale ones); rank r takes the token only
+// when the word behind it is its OWN hello word -- a stale token file cannot carry it -- and acknowledges under a name that contains the token;
+// rank 0 is done when every rank has acknowledged.  Everything polls with the caller's timeout.
+static unsigned long long random_word()
 {
-	const std::string ft = dir + "/.al_token_" + run_id_base();
+	unsigned long long w = (unsigned long long)getpid() * 1000003ULL ^ (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count();
+	FILE *r = fopen("/dev/urandom", "rb"); unsigned long long x = 0; if (r) { if (fread(&x, 8, 1, r) == 1) w ^= x; fclose(r); }
+	return w;
+}
+static int write_small_file(const std::string &fn, const std::string &body)
+{
+	const std::string tmp = fn + ".tmp"; FILE *f = fopen(tmp.c_str(), "wb");
+	if (!f) return -1;
+	const bool ok = fwrite(body.data(), 1, body.size(), f) == body.size();
+	if (fclose(f) != 0 || !ok || rename(tmp.c_str(), fn.c_str()) != 0) return -1;
+	return 0;
+}
+static std::string read_small_file(const std::string &fn)
+{
+	std::string s; FILE *f = fopen(fn.c_str(), "rb"); if (!f) return s;
+	char buf[4096]; size_t n; while ((n = fread(buf, 1, sizeof(buf), f)) > 0) s.append(buf, n);
+	fclose(f); return s;
+}
+static int agree_on_token(const std::string &dir, int rank, int world, double timeout)
+{
+	const std::string base = run_id_base(), ft = dir + "/.al_token_" + base;
+	auto hello = [&](int r) { return dir + "/.al_hello_" + base + "." + std::to_string(r); };
+	auto ack = [&](const std::string &tok, int r) { return dir + "/.al_ack_" + base + "_" + tok + "." + std::to_string(r); };
+	char buf[32];
+	const double t0 = now_s();
 	if (rank == 0) {
 		unlink(ft.c_str());
-		unsigned long long w = (unsigned long long)getpid() * 1000003ULL ^ (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count();
-		{ FILE *r = fopen("/dev/urandom", "rb"); unsigned long long x = 0; if (r) { if (fread(&x, 8, 1, r) == 1) w ^= x; fclose(r); } }
-		char buf[32]; snprintf(buf, sizeof(buf), "%016llx", w);
-		const std::string tmp = ft + ".tmp"; FILE *f = fopen(tmp.c_str(), "wb");
-		if (!f || fwrite(buf, 16, 1, f) != 1 || fclose(f) != 0 || rename(tmp.c_str(), ft.c_str()) != 0) { fprintf(stderr, "[airlift] rank 0: cannot write '%s': %s\n", ft.c_str(), strerror(errno)); return -1; }
-		g_nonce = buf;
-		return 0;
+		snprintf(buf, sizeof(buf), "%016llx", random_word());
+		const std::string tok = buf;
+		std::vector<std::string> seen((size_t)world), cur((size_t)world);
+		for (;;) {
+			bool all = true, changed = false;
+			for (int r = 1; r < world; ++r) {
+				const std::string h = read_small_file(hello(r));
+				if (h.size() == 16) { cur[r] = h; if (h != seen[r]) changed = true; } else all = false;
+			}
+			if (all && changed) {
+				std::string body = tok; for (int r = 1; r < world; ++r) body += cur[r];
+				if (write_small_file(ft, body) != 0) { fprintf(stderr, "[airlift] rank 0: cannot write '%s': %s\n", ft.c_str(), strerror(errno)); return -1; }
+				seen = cur;
+			}
+			if (all) {
+				bool acked = true; struct stat sb;
+				for (int r = 1; r < world && acked; ++r) if (stat(ack(tok, r).c_str(), &sb) != 0) acked = false;
+				if (acked) { for (int r = 1; r < world; ++r) { unlink(ack(tok, r).c_str()); unlink(hello(r).c_str()); } g_nonce = tok; return 0; }
+			}
+			if (now_s() - t0 > timeout) { fprintf(stderr, "[airlift] rank 0: not every rank of this launch arrived in '%s' within %.0f s\n", dir.c_str(), timeout); return -2; }
+			usleep(2000);
+		}
 	}
-	const double t0 = now_s();
+	snprintf(buf, sizeof(buf), "%016llx", random_word());
+	const std::string mine = buf;
+	if (write_small_file(hello(rank), mine) != 0) { fprintf(stderr, "[airlift] rank %d: cannot write '%s': %s\n", rank, hello(rank).c_str(), strerror(errno)); return -1; }
 	for (;;) {
-		struct stat sb;
-		if (stat(ft.c_str(), &sb) == 0 && (double)sb.st_mtime + 1.0 >= my_start_wall - 2.0) {     // (file times have a granularity; ranks of one launch start within seconds of each other)
-			FILE *f = fopen(ft.c_str(), "rb"); char buf[17] = {0};
-			if (f) { const size_t n = fread(buf, 16, 1, f); fclose(f); if (n == 1) { g_nonce = buf; return 0; } }
+		const std::string t = read_small_file(ft);
+		if (t.size() == 16 * (size_t)world && t.compare(16 * (size_t)rank, 16, mine) == 0) {
+			const std::string tok = t.substr(0, 16);
+			if (write_small_file(ack(tok, rank), "1") != 0) { fprintf(stderr, "[airlift] rank %d: cannot acknowledge the token in '%s': %s\n", rank, dir.c_str(), strerror(errno)); return -1; }
+			g_nonce = tok; return 0;                                           // (rank 0 removes the hello and acknowledgement files)
 		}
 		if (now_s() - t0 > timeout) { fprintf(stderr, "[airlift] rank %d: no token of this launch from rank 0 in '%s' within %.0f s\n", rank, dir.c_str(), timeout); return -2; }
 		usleep(2000);
@@ -293,8 +338,7 @@ extern "C" int al_map_file_frag_ranked(const al_idx_t *mi, int n_fn, const char 
 	int n_dev = 0; (void)hipGetDeviceCount(&n_dev);
 	if (device < 0) { const char *lr = getenv("LOCAL_RANK"); device = lr ? atoi(lr) : rank; if (n_dev > 0) device %= n_dev; }
 	// the launch's token (see agree_on_token), then the exchange: RCCL when the ranks sit on distinct GPUs, files otherwise
-	static const double proc_start_wall = [] { struct timespec ts; clock_gettime(CLOCK_REALTIME, &ts); return (double)ts.tv_sec + ts.tv_nsec * 1e-9; }();
-	if (world > 1 && !getenv("AL_RUN_ID")) { const int e = agree_on_token(dir, rank, timeout_s, proc_start_wall); if (e) return e; }   // (AL_RUN_ID: the caller vouches for a fresh id)
+	if (world > 1 && !getenv("AL_RUN_ID")) { const int e = agree_on_token(dir, rank, world, timeout_s); if (e) return e; }   // (AL_RUN_ID: the caller vouches for a fresh id)
 	std::unique_ptr<FileExchange> fex(new FileExchange(dir, rank, world, timeout_s)); std::unique_ptr<RcclProcExchange> rx;
 	ProcExchange *ex = fex.get();
 	if (world > 1 && !getenv("AL_NO_RCCL") && n_dev >= world) {

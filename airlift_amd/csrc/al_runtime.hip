@@ -139,7 +139,7 @@ static const char *g_stage_names[ST_N] = { "sketch", "seed_lookup", "scan", "siz
 // kernel behind each interval (what rocprofv3 --kernel-trace lists); "" = several launches
 // the kernel of an interval that is exactly one launch of one kernel ("" otherwise: several kernels or several launches)
 static const char *g_stage_kernels[ST_N] = { "k_sketch", "k_seed", "", "", "k_anchor_sort_small", "", "", "", "",
-                                             "", "", "k_chain_lds<64, 64>", "", "", "", "", "",  "",
+                                             "", "", "", "", "", "", "", "",  "",
                                              "", "k_ext_prep", "", "", "", "k_ext_dp<8, 512, 128>", "k_ext_dp<12, 512, 192>", "k_ext_dp<16, 512, 256>", "k_ext_dp<22, 512, 352>", "k_ext_finish", "k_compact" };
 extern "C" const char *al_stage_kernel(int i) { return i >= 0 && i < ST_N ? g_stage_kernels[i] : ""; }
 extern "C" const char *al_stage_name(int i) { return i >= 0 && i < ST_N ? g_stage_names[i] : ""; }
@@ -237,7 +237,7 @@ static void ctx_release_buffers(al_ctx_t *c)
 	c->frag_nu.release(); c->rechain_list.release(); c->rechain_sorted.release(); c->tmp_u32.release(); c->rd_off.release(); c->mini_off.release(); c->a_off.release(); c->u.release();
 	c->ws_u64.release(); c->tmp_u64.release(); c->frag_rep.release(); c->ws_i32.release(); c->mini.release(); c->heap_ws.release(); c->anchors.release();
 	c->chained.release(); c->match.release(); c->counters.release(); c->scan_tmp.release(); c->regs0.release(); c->regs.release(); c->reg_cnt.release();
-	c->chain_key.release(); c->chain_idx.release(); c->chain_idx2.release(); c->tie_list.release(); c->lb_buf.release(); c->tmp_u64b.release();
+	c->big_tmp.release(); c->chain_key.release(); c->chain_idx.release(); c->chain_idx2.release(); c->tie_list.release(); c->lb_buf.release(); c->tmp_u64b.release();
 	c->chain_tmp.release(); c->u_tmp.release(); c->okey_tmp.release(); c->fb2_list.release(); c->fb3_list.release(); c->seg_cnt.release(); c->seg_first.release(); c->seg_cnt0.release(); c->seg_first0.release(); c->seg_t1.release(); c->vs_off.release(); c->vs_na.release(); c->vs_meta.release(); c->vs_res.release(); c->vs_cls.release(); c->seg_key.release(); c->seg_idx.release(); c->seg_ord.release(); c->fb_list.release(); c->tie_frags.release(); c->heap_cnt.release(); c->tie_sorted.release(); c->big_na.release(); c->big_off.release();
 	c->uo.release(); c->big_k0.release(); c->big_k1.release(); c->v_anchors.release(); c->v_chained.release(); c->v_u.release(); c->v_a_off.release(); c->v_first64.release(); c->v_na.release(); c->v_nseg.release(); c->v_first.release(); c->v_rd_len.release(); c->v_order.release(); c->v_nu.release(); c->fbk_list.release(); c->d_uslot.release(); c->d_rel.release(); c->chain_cls.release(); c->d_fragid.release(); c->cmp_list.release(); c->ctie.release(); c->frag_meta.release();
 	c->a_off_p1.release(); c->frag_na_p1.release(); c->frag_rep_p1.release(); c->cigar.release(); c->reg_off.release(); c->cig_off.release(); c->align_ws.release(); c->seg_a.release(); c->seg_u.release();
@@ -842,8 +842,12 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 		else if (lb1025 > lb65) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_anchor_sort<1024>), dim3(lb1025 - lb65), dim3(64), 0, s, c->di.pos, c->frag_first.p, c->rd_len.p, c->mini_off.p, c->match.p, c->frag_nm.p, c->frag_na.p,
 		                                           c->a_off.p, c->anchors.p, c->tie_list.p, tie_cnt, order + lb65, (int)(lb1025 - lb65), c->counters.p, c->mi->k);
 		if (ev(ST_ANCHOR_SORT)) return -1;
-		AL_HIP_CHECK(hipEventRecord(c->ev_ovl[2], s));                       // fragments of up to 128 anchors are in order: their chaining (ovl[1], below) may start
+		// fragments of up to 128 anchors are in order: their chaining (ovl[1], below) may start -- unless a test lowered the block sorts' bound
+		// below 129 anchors (AL_TEST_SORT_BLK): then some of them are sorted by the block kernels below, and the event follows those
+		const bool small_by_blk = lb1025 < lb129;
+		if (!small_by_blk) AL_HIP_CHECK(hipEventRecord(c->ev_ovl[2], s));
 		LREG(8, 4, 1024, lb1025, lb2049); LREG(16, 4, 1024, lb2049, lb4097); LREG(16, 8, 1024, lb4097, lb_big);   // (non-compact keys: t_big == t_blk, empty ranges)
+		if (small_by_blk) AL_HIP_CHECK(hipEventRecord(c->ev_ovl[2], s));
 #undef LREG
 		// (enqueued before the merge kernels of the side streams below: whichever hardware queue ovl[1] shares, these do not wait behind one of those)
 		if (chain_small()) return -1;
@@ -882,6 +886,8 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 		if (ev(ST_ANCHOR_HEAP)) return -1;
 	}
 	{
+		// (the four chain_lds intervals are empty since the lane-per-fragment kernels of the <= 128-anchor fragments moved to ovl[1], beside the block
+		//  sorts and the tile kernel: their time is inside anchor_sort_blk / chain_tile; the names stay so that the stage table keeps its columns)
 		if (ev(ST_CHAIN_LDS32) || ev(ST_CHAIN_LDS48) || ev(ST_CHAIN_LDS64) || ev(ST_CHAIN_LDS128)) return -1;
 		if (tiles_ok) {
 			TileSched S; const uint32_t b[6] = {tile_from, std::max(tile_from, lb33), std::max(tile_from, lb65), std::max(tile_from, lb129), std::max(tile_from, lb257x), std::max(tile_from, lb513x)};

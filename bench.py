@@ -390,7 +390,7 @@ def main():
             ("extension", ["ext_prep", "ext_sort", "ext_dp_lane", "ext_dp_g4", "ext_dp_g8", "ext_dp_g12", "ext_dp_g16", "ext_dp_g22", "ext_finish", "compact"], 0.5 * Wb + float(st.bytes_out)),
         ]
         own = {"sketch": float(st.bytes_in) + 16.0 * M, "seed_lookup": 16.0 * M, "anchor_sort_small": 24.0 * cls(0, 64), "anchor_sort": 24.0 * cls(65, 1024),
-               "anchor_sort_blk": 24.0 * cls(1025, 8192), "chain_lds32": 16.0 * cls(0, 32), "chain_lds48": 16.0 * cls(33, 48), "chain_lds64": 16.0 * cls(49, 64), "chain_lds128": 16.0 * cls(65, 128)}
+               "anchor_sort_blk": 24.0 * cls(1025, 8192)}   # (chain_lds32..128: empty intervals, their kernels run on a stream of their own beside the sorts)
         # extension DP kernels: reference windows of their jobs at 4 bits / base + one 48-byte ExtOut record per job (the W/2 + B_out terms)
         for iv, ci in (("ext_dp_g4", 5), ("ext_dp_g8", 6)):
             own[iv] = 0.5 * float(st.dp_target_bases[ci]) + 48.0 * float(st.dp_jobs[ci])
