@@ -435,6 +435,227 @@ k_anchor_heap_wave(const uint64_t *__restrict__ pos, const uint32_t *__restrict_
 }
 template __global__ void k_anchor_heap_wave<128, 32>(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, const uint32_t *, const uint32_t *, const uint32_t *, uint32_t, unsigned long long *, int);
 
+// ---------------------------------------------------------------------------------------------
+// The same merge with the binary heap IN THE LANES of a wavefront (round 5).  The serial forms above pay one LDS (or HBM) round trip
+// per sift level and pop; here a pop costs a fixed number of wave-wide instructions whatever the depth:
+//   * heap node v (1-based: children 2v, 2v + 1, siblings v ^ 1) lives in lane v & 63 of register set v >> 6 as (x, list); absent nodes
+//     hold x = +inf.  Siblings are neighbouring lanes, so "which child does ks_heapdown prefer" (ksort.h:47: the right one only if
+//     strictly smaller) is one DPP quad permute and two compares for ALL nodes at once -> a 64-bit mask PM of preferred children;
+//   * the sift path of ks_heapdown from a node is the chain of preferred children below it, independent of the value being sifted:
+//     node v is on it iff v and all its ancestors below the start are preferred -- (PM & ANC[v]) == ANC[v] with a per-lane constant;
+//   * the heap order makes the x along that path non-decreasing, so the nodes that move up are exactly the path nodes with x <= tmp.x
+//     (ksort.h:48 breaks on the first child that is greater): one compare + ballot -> mask LE; every node of LE (and the start) takes
+//     the content of its child in LE (ds_bpermute), the last one takes tmp.
+// ks_heapmake is the same step from the nodes n/2 .. 1.  Occurrence lists: list l belongs to the lane of node l + 1; its next
+// position waits in a register of that lane, the RING positions behind it in that lane's LDS ring, refilled from HBM by all lanes
+// together when the list about to advance has run dry.  Up to 63 (NSET 1) / 126 (NSET 2) lists; larger fragments keep the serial form.
+// Checked against the serial emulation by a model of these steps (tests/test_heap_lanes_model.py) and by the tie-order goldens.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t d_sel_mask(uint64_t mask, uint32_t if_set, uint32_t if_clear)
+{   // per lane: bit `lane` of a wave-uniform mask picks (one v_cndmask with the mask as its SGPR-pair condition)
+	uint32_t r; asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(mask)); return r;
+}
+__device__ __forceinline__ uint64_t d_sel_mask64(uint64_t mask, uint64_t if_set, uint64_t if_clear)
+{
+	return (uint64_t)d_sel_mask(mask, (uint32_t)if_set, (uint32_t)if_clear) | (uint64_t)d_sel_mask(mask, (uint32_t)(if_set >> 32), (uint32_t)(if_clear >> 32)) << 32;
+}
+__device__ __forceinline__ uint64_t d_readlane64(uint64_t v, int l)
+{
+	return (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l) | (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l) << 32;
+}
+__device__ __forceinline__ uint64_t d_sibling64(uint64_t v)
+{   // the value of lane ^ 1 (DPP quad_perm [1,0,3,2])
+	return (uint64_t)(uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)v, 0xB1, 0xf, 0xf, true) | (uint64_t)(uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)(v >> 32), 0xB1, 0xf, 0xf, true) << 32;
+}
+
+template <int NSET>
+struct HeapLanes {
+	uint64_t hx[NSET]; uint32_t hl[NSET];   // node content: head position, list
+	uint64_t anc[NSET];                     // set-0 bits of the node's ancestors below the root (set 0: and of the node itself)
+	// ks_heapdown (ksort.h:43-53) from node `start` (< 64) with the value (tx, tl); as0: bits of start and its ancestors, ins0 / ins1: its strict descendants
+	__device__ __forceinline__ void sink(const int lane, const uint32_t start, const uint64_t as0, const uint64_t ins0, const uint64_t ins1, const uint64_t tx, const uint32_t tl)
+	{
+		uint64_t pm[NSET];
+#pragma unroll
+		for (int s = 0; s < NSET; ++s) {
+			const uint64_t sib = d_sibling64(hx[s]);
+			pm[s] = __ballot(hx[s] < sib) | (__ballot(hx[s] == sib) & 0x5555555555555555ULL);   // left child (even node) on a tie
+		}
+		const uint64_t pmi = pm[0] | as0;
+		uint64_t le[NSET];
+		le[0] = __ballot((pmi & anc[0]) == anc[0]) & __ballot(hx[0] <= tx) & ins0;
+		if (NSET > 1) le[NSET - 1] = __ballot((pmi & anc[NSET - 1]) == anc[NSET - 1]) & __ballot(hx[NSET - 1] <= tx) & pm[NSET - 1] & ins1;
+		// children of my set-0 node that move up (at most one): nodes 2 * lane, 2 * lane + 1
+		uint32_t ch;
+		if (NSET > 1) { const uint64_t m = lane < 32 ? le[0] : le[NSET - 1]; ch = (uint32_t)(m >> ((2 * lane) & 63)) & 3u; }
+		else ch = lane < 32 ? (uint32_t)(le[0] >> (2 * lane)) & 3u : 0u;
+		const int src = (((2 * lane) & 63) + (int)(ch >> 1)) << 2;
+		// what a lane hands to its parent: its set-1 node when that one moves, else its set-0 node
+		uint32_t dlo = (uint32_t)hx[0], dhi = (uint32_t)(hx[0] >> 32), dl = hl[0];
+		if (NSET > 1) { dlo = d_sel_mask(le[NSET - 1], (uint32_t)hx[NSET - 1], dlo); dhi = d_sel_mask(le[NSET - 1], (uint32_t)(hx[NSET - 1] >> 32), dhi); dl = d_sel_mask(le[NSET - 1], hl[NSET - 1], dl); }
+		uint32_t plo = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)dlo), phi = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)dhi), pl = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)dl);
+		if (NSET > 1) {
+			// Both nodes of a lane move when node j and node 64 + j lie on one path (j an ancestor of 64 + j: lanes 2, 4, 9, 21, 63): the parent of the
+			// set-0 node then got the set-1 node above.  Rare, wave-uniform: a second round with the set-0 nodes for those parents.
+			const uint64_t both = le[0] & le[NSET - 1];
+			if (both != 0) {
+				const uint32_t qlo = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(uint32_t)hx[0]), qhi = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(uint32_t)(hx[0] >> 32)), ql = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)hl[0]);
+				const bool fix = lane < 32 && ((both >> (2 * lane + (int)(ch >> 1))) & 1ULL) != 0;
+				plo = fix ? qlo : plo; phi = fix ? qhi : phi; pl = fix ? ql : pl;
+			}
+		}
+		const uint64_t in0 = le[0] | 1ULL << start;
+		const bool pull = ch != 0;
+		const uint32_t vlo = pull ? plo : (uint32_t)tx, vhi = pull ? phi : (uint32_t)(tx >> 32), vl = pull ? pl : tl;
+		hx[0] = (uint64_t)d_sel_mask(in0, vlo, (uint32_t)hx[0]) | (uint64_t)d_sel_mask(in0, vhi, (uint32_t)(hx[0] >> 32)) << 32;
+		hl[0] = d_sel_mask(in0, vl, hl[0]);
+		if (NSET > 1) { hx[NSET - 1] = d_sel_mask64(le[NSET - 1], tx, hx[NSET - 1]); hl[NSET - 1] = d_sel_mask(le[NSET - 1], tl, hl[NSET - 1]); }   // (set-1 nodes are leaves: a moving one is where the value lands)
+	}
+};
+
+template <int NSET, int RING>
+__global__ void __launch_bounds__(64)
+k_anchor_heap_lanes(const uint64_t *__restrict__ pos, const uint32_t *__restrict__ frag_first, const uint32_t *__restrict__ rd_len,
+                    const uint64_t *__restrict__ mini_off, const AlMatch *__restrict__ match,
+                    const uint32_t *__restrict__ frag_nm, const uint32_t *__restrict__ frag_na, const uint64_t *__restrict__ a_off,
+                    AlAnchor *__restrict__ anchors, const uint32_t *__restrict__ tie_flag, const uint32_t *__restrict__ frag_list,
+                    const uint32_t *__restrict__ n_list_dev, int lo_excl, unsigned long long *__restrict__ counters, int mini_span)
+{
+	static_assert(NSET == 1 || NSET == 2, "one or two register sets");
+	static_assert((RING & (RING - 1)) == 0 && RING <= 32, "ring size");
+	constexpr uint32_t NCAP = NSET == 1 ? 63u : 126u;
+	__shared__ uint64_t ring[NSET * 64 * RING];                                // [node][RING]: only the node's own lane touches its ring
+	const int lane = threadIdx.x;
+	HeapLanes<NSET> H;
+#pragma unroll
+	for (int s = 0; s < NSET; ++s) {
+		const uint32_t v = (uint32_t)(s * 64 + lane); uint64_t a = 0;
+		for (uint32_t k = s == 0 ? v : v >> 1; k >= 2; k >>= 1) a |= 1ULL << k;
+		H.anc[s] = v < 2 ? ~0ULL : a;                                          // (lanes 0 and 1 of set 0 are never on a path below the start)
+	}
+	const uint32_t n_list = *n_list_dev;
+	for (uint32_t t = blockIdx.x; t < n_list; t += gridDim.x) {
+		const uint32_t f = frag_list[t];
+		const uint32_t n = frag_na[f], n_m = frag_nm[f];
+		if (!tie_flag[f] || (int)n_m <= lo_excl || n_m > NCAP || n == 0) continue;
+		const uint32_t r0 = frag_first[f], r1 = frag_first[f + 1];
+		int qlen = 0; for (uint32_t r = r0; r < r1; ++r) qlen += (int)rd_len[r];
+		const AlMatch *m = match + mini_off[r0];
+		AlAnchor *out = anchors + a_off[f];
+		// ---- the lists: node v = list v - 1; its first position is the node's content, the next up to RING go to the ring
+		uint64_t nxt[NSET]; uint32_t l_st[NSET], l_ins[NSET], l_off[NSET], l_fl[NSET], l_info[NSET];   // l_st = (positions not yet in the heap) << 8 | (of those, in the ring)
+#pragma unroll
+		for (int s = 0; s < NSET; ++s) {
+			const uint32_t v = (uint32_t)(s * 64 + lane);
+			const bool valid = v >= 1 && v <= n_m;
+			AlMatch mm{0u, 0u, 0u, 0u}; if (valid) mm = m[v - 1];
+			l_off[s] = mm.off_lo; l_fl[s] = mm.flags; l_ins[s] = 1;
+			l_info[s] = (mm.q_pos & 0xfffffu) | (mm.flags & 0xffu) << 20 | (mm.flags >> 8 & 1u) << 28;
+			const uint32_t have = mm.n < (uint32_t)RING + 1u ? mm.n : (uint32_t)RING + 1u;
+			uint64_t e[RING + 1];
+#pragma unroll
+			for (int j = 0; j <= RING; ++j) e[j] = (uint32_t)j < have ? d_match_pos(pos, mm.off_lo, mm.flags, (uint32_t)j) : UINT64_MAX;
+#pragma unroll
+			for (int j = 1; j <= RING; ++j) if ((uint32_t)j < have) ring[v * RING + (j & (RING - 1))] = e[j];
+			H.hx[s] = e[0]; H.hl[s] = valid ? v - 1 : 0u;
+			nxt[s] = e[1];
+			l_st[s] = valid ? (mm.n - 1) << 8 | (have - 1) : 0u;
+		}
+		if (lane == 0) atomicAdd(&counters[0], 1ULL);
+		// (every register the loops below carry comes from the loads above: used here once, so that the wait for those loads sits here and not
+		//  inside the pop loop, where a vmcnt(0) would also wait for the previous pop's anchor store)
+#pragma unroll
+		for (int s = 0; s < NSET; ++s) asm volatile("" :: "v"(H.hx[s]), "v"(H.hl[s]), "v"(nxt[s]), "v"(l_st[s]), "v"(l_info[s]), "v"(l_off[s]), "v"(l_fl[s]));
+		// ---- ks_heapmake (ksort.h:55-59)
+		uint32_t hs = n_m;
+		for (uint32_t node = hs >> 1; node >= 1; --node) {
+			const int dn = 31 - __clz((int)node);
+			uint64_t ins[NSET];
+#pragma unroll
+			for (int s = 0; s < NSET; ++s) {
+				const uint32_t v = (uint32_t)(s * 64 + lane); const int d = (31 - __clz((int)(v | 1u))) - dn;
+				ins[s] = __ballot(v >= 2 && d > 0 && (v >> d) == node);
+			}
+			const int dl0 = 31 - __clz(lane | 1);
+			const uint64_t as0 = __ballot(lane >= 1 && dl0 <= dn && (node >> (dn - dl0)) == (uint32_t)lane);
+			const uint64_t tx = d_readlane64(H.hx[0], (int)node); const uint32_t tl = (uint32_t)__builtin_amdgcn_readlane((int)H.hl[0], (int)node);
+			H.sink(lane, node, as0, ins[0], ins[NSET - 1], tx, tl);
+		}
+		// ---- the merge (map.c:168-199).  A pop leaves (position word, list info) in lane `cnt` of three registers (v_writelane); every 64 pops the
+		// lanes turn them into anchors together (map.c:176-187) and store them: forward strand from the front, reverse strand from the back.
+		uint32_t n_for = 0, n_rev = 0, cnt = 0;
+		uint32_t b_lo = 0, b_hi = 0, b_info = 0;
+		auto flush = [&]() {
+			const bool valid = (uint32_t)lane < cnt;
+			const uint64_t rx = (uint64_t)b_lo | (uint64_t)b_hi << 32; const uint32_t info = b_info;
+			const uint32_t qp = info & 0xfffffu, span = (uint32_t)mini_span;
+			const bool fwd = (((uint32_t)rx ^ qp) & 1u) == 0;
+			const uint64_t vm = __ballot(valid), fm = __ballot(fwd) & vm, rm = vm & ~fm, below = (1ULL << lane) - 1ULL;
+			AlAnchor a;
+			a.x = (rx & 0xffffffff00000000ULL) | ((uint32_t)rx >> 1) | (fwd ? 0ULL : 1ULL << 63);
+			a.y = (uint64_t)span << 32 | (fwd ? qp >> 1 : (uint32_t)(qlen - ((int)(qp >> 1) + 1 - (int)span) - 1));
+			a.y |= (uint64_t)(info >> 20 & 0xffu) << AL_SEED_SEG_SHIFT;
+			if (info >> 28 & 1u) a.y |= AL_SEED_TANDEM;
+			const uint32_t idx = fwd ? n_for + (uint32_t)__popcll(fm & below) : n - 1u - (n_rev + (uint32_t)__popcll(rm & below));
+			if (valid) out[idx] = a;
+			n_for += (uint32_t)__popcll(fm); n_rev += (uint32_t)__popcll(rm); cnt = 0;
+		};
+		while (hs > 0) {
+			const uint32_t li = (uint32_t)__builtin_amdgcn_readlane((int)H.hl[0], 1);
+			const uint64_t rx = d_readlane64(H.hx[0], 1);
+			const uint32_t on = li + 1u; const int ol = (int)(on & 63u); const bool o1 = NSET > 1 && on >= 64u;
+			uint32_t st = (uint32_t)__builtin_amdgcn_readlane((int)l_st[0], ol), info = (uint32_t)__builtin_amdgcn_readlane((int)l_info[0], ol);
+			if (NSET > 1) { const uint32_t st1 = (uint32_t)__builtin_amdgcn_readlane((int)l_st[NSET - 1], ol), info1 = (uint32_t)__builtin_amdgcn_readlane((int)l_info[NSET - 1], ol); st = o1 ? st1 : st; info = o1 ? info1 : info; }
+			if (__builtin_expect(st >= 0x100u && (st & 0xffu) == 0, 0)) {         // the list about to advance has nothing prefetched: every lane tops its ring(s) up
+#pragma unroll
+				for (int s = 0; s < NSET; ++s) {
+					const uint32_t v = (uint32_t)(s * 64 + lane);
+					const uint32_t av = l_st[s] & 0xffu, lf = l_st[s] >> 8, room = (uint32_t)RING - av, more = lf - av, need = room < more ? room : more;
+					const uint32_t base = l_ins[s] + av;
+					uint64_t e[RING];
+#pragma unroll
+					for (int j = 0; j < RING; ++j) e[j] = (uint32_t)j < need ? d_match_pos(pos, l_off[s], l_fl[s], base + (uint32_t)j) : 0;
+#pragma unroll
+					for (int j = 0; j < RING; ++j) if ((uint32_t)j < need) ring[v * RING + ((base + (uint32_t)j) & (RING - 1))] = e[j];
+					l_st[s] += need;
+					nxt[s] = ring[v * RING + (l_ins[s] & (RING - 1))];
+				}
+				st = (uint32_t)__builtin_amdgcn_readlane((int)l_st[0], ol);
+				if (NSET > 1) { const uint32_t st1 = (uint32_t)__builtin_amdgcn_readlane((int)l_st[NSET - 1], ol); st = o1 ? st1 : st; }
+			}
+			const uint32_t left = st >> 8;
+			// (the lane select through M0: one SGPR operand per VOP3 instruction on this target)
+			asm("s_mov_b32 m0, %3\n\tv_writelane_b32 %0, %4, m0\n\tv_writelane_b32 %1, %5, m0\n\tv_writelane_b32 %2, %6, m0"
+			    : "+v"(b_lo), "+v"(b_hi), "+v"(b_info) : "s"(cnt), "s"((uint32_t)rx), "s"((uint32_t)(rx >> 32)), "s"(info) : "m0");
+			if (++cnt == 64u) flush();
+			uint64_t tx; uint32_t tl;
+			if (left > 0) {                                                     // the list's next position takes the root's place
+				tx = d_readlane64(nxt[0], ol); tl = li;
+				if (NSET > 1) { const uint64_t t1 = d_readlane64(nxt[NSET - 1], ol); tx = o1 ? t1 : tx; }
+#pragma unroll
+				for (int s = 0; s < NSET; ++s) {
+					const bool own = lane == ol && (s == 1) == o1;
+					l_ins[s] += own ? 1u : 0u; l_st[s] -= own ? 0x101u : 0u;
+					nxt[s] = ring[(uint32_t)(s * 64 + lane) * RING + (l_ins[s] & (RING - 1))];
+				}
+			} else {                                                            // list exhausted: the last node moves to the root (map.c:193-196)
+				const int hlane = (int)(hs & 63u); const bool h1 = NSET > 1 && hs >= 64u;
+				tx = d_readlane64(H.hx[0], hlane); tl = (uint32_t)__builtin_amdgcn_readlane((int)H.hl[0], hlane);
+				if (NSET > 1) { const uint64_t t1 = d_readlane64(H.hx[NSET - 1], hlane); const uint32_t l1 = (uint32_t)__builtin_amdgcn_readlane((int)H.hl[NSET - 1], hlane); tx = h1 ? t1 : tx; tl = h1 ? l1 : tl; }
+#pragma unroll
+				for (int s = 0; s < NSET; ++s) if (lane == hlane && (s == 1) == h1) H.hx[s] = UINT64_MAX;
+				if (--hs == 0) break;
+			}
+			H.sink(lane, 1u, 2ULL, ~3ULL, ~0ULL, tx, tl);
+		}
+		if (cnt > 0) flush();
+		__threadfence();                                                        // the stores above before other lanes read them back
+		for (uint32_t j = lane; j < n_rev >> 1; j += 64) { const AlAnchor tA = out[n - 1 - j]; out[n - 1 - j] = out[n - (n_rev - j)]; out[n - (n_rev - j)] = tA; }   // map.c:202-207
+	}
+}
+template __global__ void k_anchor_heap_lanes<1, 16>(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, const uint32_t *, const uint32_t *, const uint32_t *, int, unsigned long long *, int);
+template __global__ void k_anchor_heap_lanes<2, 16>(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, const uint32_t *, const uint32_t *, const uint32_t *, int, unsigned long long *, int);
+
 template <int CAP>
 __global__ void __launch_bounds__(64)
 k_anchor_sort(const uint64_t *__restrict__ pos, const uint32_t *__restrict__ frag_first, const uint32_t *__restrict__ rd_len,

@@ -38,6 +38,7 @@ template <int CAP> __global__ void k_anchor_sort(const uint64_t *, const uint32_
 __global__ void k_anchor_sort_small(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, uint32_t *, unsigned int *, const uint32_t *, int, unsigned long long *, int);
 template <int HCAP, int LANES> __global__ void k_anchor_heap(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, AlAnchor *, const uint32_t *, const uint32_t *, int, int, unsigned long long *, int, const uint32_t *, uint32_t);
 template <int MCAPH, int RING> __global__ void k_anchor_heap_wave(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, const uint32_t *, const uint32_t *, const uint32_t *, uint32_t, unsigned long long *, int);
+template <int NSET, int RING> __global__ void k_anchor_heap_lanes(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, const uint32_t *, const uint32_t *, const uint32_t *, int, unsigned long long *, int);
 template <int CAP> __global__ void k_chain(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, AlAnchor *, uint64_t *, uint32_t *, int32_t *, uint64_t *, const uint32_t *, int, AlParams, unsigned long long *, ChainSeg);
 template <int CAPL, int LANES> __global__ void k_chain_lds(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, AlAnchor *, uint64_t *, uint32_t *, uint64_t *, const uint32_t *, int, int, AlParams, unsigned long long *, ChainSeg, uint32_t *, int);
 template <int PER, int NW, int MCAP> __global__ void k_anchor_sort_reg(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, uint32_t *, const uint32_t *, int, int, int);
@@ -877,9 +878,20 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 		// at 8192 anchors), in a large one the wavefront kernel's share is (C5, 500 k pairs: 652 vs 672 ms): the bound follows the batch.
 		static const int wave_env = getenv("AL_TEST_HEAP_WAVE") ? atoi(getenv("AL_TEST_HEAP_WAVE")) : -1;                           // (tests lower it so that small fragments take the wavefront form)
 		const uint32_t wave_na_min = wave_env >= 0 ? (uint32_t)wave_env : c->n_frag >= 400000 ? 16384u : 8192u;
+		// Round 5: the heap in the lanes of a wavefront (k_anchor_heap_lanes: a fixed number of wave-wide instructions per pop instead of an LDS round trip
+		// per sift level) for every flagged fragment of up to 126 lists; the serial forms remain for more lists and behind AL_HEAP_OLD=1 (tests, A/B).
+		static const bool heap_old = getenv("AL_HEAP_OLD") && atoi(getenv("AL_HEAP_OLD")) == 1;
+		if (!heap_old) {
+#define LHL(NS, LO, ST) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_anchor_heap_lanes<NS, 16>), dim3(std::min(nl, 65536)), dim3(64), 0, ST, c->di.pos, c->frag_first.p, c->rd_len.p, c->mini_off.p, c->match.p, c->frag_nm.p, c->frag_na.p, \
+		                                    c->a_off.p, c->anchors.p, (const uint32_t *)c->tie_list.p, (const uint32_t *)c->tie_frags.p, (const uint32_t *)n_heap_d, LO, c->counters.p, c->mi->k)
+			LHL(2, 63, c->side); LHL(1, -1, c->aux[0]);
+#undef LHL
+			{ const uint32_t wave_na_min = 0xffffffffu; LHEAP(0, 64, 126, c->aux[2]); }
+		} else {
 		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_anchor_heap_wave<128, 32>), dim3(std::min(nl, 65536)), dim3(64), 0, c->side, c->di.pos, c->frag_first.p, c->rd_len.p, c->mini_off.p, c->match.p, c->frag_nm.p, c->frag_na.p,
 		                   c->a_off.p, c->anchors.p, (const uint32_t *)c->tie_list.p, (const uint32_t *)c->tie_frags.p, (const uint32_t *)n_heap_d, wave_na_min, c->counters.p, c->mi->k);
 		LHEAP(48, 64, -1, c->aux[0]); LHEAP(96, 32, 48, c->aux[1]); LHEAP(0, 64, 96, c->aux[2]);
+		}
 #undef LHEAP
 		for (int i = 0; i < 3; ++i) { AL_HIP_CHECK(hipEventRecord(c->ev_aux[i], c->aux[i])); AL_HIP_CHECK(hipStreamWaitEvent(c->side, c->ev_aux[i], 0)); }
 		AL_HIP_CHECK(hipEventRecord(evs[1], c->side));

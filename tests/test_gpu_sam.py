@@ -74,13 +74,13 @@ def test_lds_dp_path_identical(golden_unpacked, name):
 
 
 @pytest.mark.parametrize("env", [dict(AL_DBG=str(1 << 27)), dict(AL_TEST_SORT_BLK="65"), dict(AL_TEST_SORT_BIG="65"), dict(AL_TEST_SORT_BLK="65", AL_TEST_SORT_BIG="200"),
-                                 dict(AL_TEST_SORT_BIG="65", AL_TEST_BIG_CHUNK="3"), dict(AL_TEST_HEAP_WAVE="1"), dict(AL_CHAIN_WAVE_MAX="0"),
+                                 dict(AL_TEST_SORT_BIG="65", AL_TEST_BIG_CHUNK="3"), dict(AL_HEAP_OLD="1", AL_TEST_HEAP_WAVE="1"), dict(AL_HEAP_OLD="1"), dict(AL_CHAIN_WAVE_MAX="0"),
                                  dict(AL_TEST_SEG_BIG="160", AL_DBG=str(1 << 27)), dict(AL_TEST_SEG_BIG="64", AL_TEST_POISON="170", AL_TEST_GUARD="1", AL_DBG=str(1 << 28)),
                                  dict(AL_TEST_TILE_ALL="1"), dict(AL_TEST_TILE_ALL="1", AL_TEST_POISON="170", AL_TEST_GUARD="1"), dict(AL_DBG=str(1 << 28)), dict(AL_TEST_TILE_ALL="1", AL_TEST_TILE_FB="1"),
                                  dict(AL_TEST_TILE_ALL="1", AL_CHAIN_COOP="1"), dict(AL_TEST_TILE_ALL="1", AL_CHAIN_COOP="0"),
                                  dict(AL_PREP_HEAVY="2", AL_FIN_HEAVY="2"), dict(AL_PREP_HEAVY="2", AL_FIN_HEAVY="2", AL_TEST_POISON="170", AL_TEST_GUARD="1"), dict(AL_PREP_HEAVY="0", AL_FIN_HEAVY="0"),
                                  dict(AL_REGS_SPLIT="0"), dict(AL_CHAIN_OVL="0", AL_SIDE_PRIO="1")],
-                         ids=["segments_wave_only", "block_sort", "device_sort", "block_and_device_sort", "device_sort_chunks", "heap_merge_by_wavefront", "lds_chain_kernels_for_thin_classes",
+                         ids=["segments_wave_only", "block_sort", "device_sort", "block_and_device_sort", "device_sort_chunks", "serial_heap_merge_by_wavefront", "serial_heap_merge_by_lanes", "lds_chain_kernels_for_thin_classes",
                               "cut_and_merge_by_eight_wavefronts_all_fragments", "cut_and_merge_by_eight_wavefronts_poisoned_memory",
                               "tile_kernel_all_fragments", "tile_kernel_all_fragments_poisoned_memory", "segment_kernels_instead_of_tiles", "tile_kernel_hands_every_fragment_back",
                               "deferred_segments_sixteen_lanes_each", "deferred_segments_a_lane_each",
@@ -91,8 +91,8 @@ def test_large_fragment_paths_identical(golden_unpacked, name, env):
     """The kernels that take over for fragments with many anchors -- the tile chaining kernel (AL_TEST_TILE_ALL: every fragment goes through it,
     several small fragments per tile; AL_TEST_TILE_FB: it hands every fragment to its fallback, the compact virtual batch), chaining by segments
     (AL_DBG bit 28: instead of the tile kernel; bit 27: every fragment goes through the segment path and the wavefront kernel), the register-network block sort and the device-wide radix sort of anchors (also cut into chunks of three fragments)
-    (thresholds lowered so that ordinary fragments reach them), the wavefront form of the exact heap merge for every fragment with equal-x
-    anchors -- must give the reference's bytes as well.  Round 4: k_ext_prep / k_ext_finish with a wavefront per fragment and a lane per hit for EVERY
+    (thresholds lowered so that ordinary fragments reach them), the serial forms of the exact heap merge (AL_HEAP_OLD: a lane or a wavefront per fragment with the heap in LDS; the default since round 5 is the heap in the
+    lanes of a wavefront, k_anchor_heap_lanes) for every fragment with equal-x anchors -- must give the reference's bytes as well.  Round 4: k_ext_prep / k_ext_finish with a wavefront per fragment and a lane per hit for EVERY
     fragment (AL_PREP_HEAVY / AL_FIN_HEAVY = 2 job slots) and for none, chain_post's 257 ... 1024-chain class sorted and passed over in one kernel
     (AL_REGS_SPLIT=0), the stream arrangement switches."""
     d = golden_unpacked[name]
