@@ -211,9 +211,9 @@ extern "C" al_idx_t *al_idx_build_device(const char *fn, const al_idxopt_t *io, 
 	IDX_CHECK(hipStreamCreate(&st));
 	IDX_CHECK(al_dev_malloc((void **)&d_ascii, sum + 16));
 	IDX_CHECK(hipMemcpyAsync(d_ascii, ascii.data(), sum, hipMemcpyHostToDevice, st));
-	IDX_CHECK(hipMalloc((void **)&d.S4, n_words * 4));
+	IDX_CHECK(al_dev_malloc((void **)&d.S4, n_words * 4));
 	hipLaunchKernelGGL(k_pack_ref, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, st, d_ascii, sum, d.S4, n_words, T);
-	IDX_CHECK(hipMalloc((void **)&d.seq_off, (size_t)n_seq * 8)); IDX_CHECK(hipMalloc((void **)&d.seq_len, (size_t)n_seq * 4)); IDX_CHECK(al_dev_malloc((void **)&d_segf, (size_t)(n_seq + 1) * 8));
+	IDX_CHECK(al_dev_malloc((void **)&d.seq_off, (size_t)n_seq * 8)); IDX_CHECK(al_dev_malloc((void **)&d.seq_len, (size_t)n_seq * 4)); IDX_CHECK(al_dev_malloc((void **)&d_segf, (size_t)(n_seq + 1) * 8));
 	IDX_CHECK(hipMemcpyAsync(d.seq_off, so.data(), (size_t)n_seq * 8, hipMemcpyHostToDevice, st));
 	IDX_CHECK(hipMemcpyAsync(d.seq_len, sl.data(), (size_t)n_seq * 4, hipMemcpyHostToDevice, st));
 	IDX_CHECK(hipMemcpyAsync(d_segf, seg_first.data(), (size_t)(n_seq + 1) * 8, hipMemcpyHostToDevice, st));
@@ -232,7 +232,7 @@ extern "C" al_idx_t *al_idx_build_device(const char *fn, const al_idxopt_t *io, 
 	}
 	al_dev_free(d_ascii); d_ascii = nullptr;
 	if (total >= (1ULL << 31)) { fprintf(stderr, "[airlift] al_idx_build_device: %llu minimizers exceed the 31-bit item count of the device sorts (references above ~12 Gbp need a multi-part index, which this path does not build)\n", (unsigned long long)total); goto fail; }
-	IDX_CHECK(al_dev_malloc((void **)&d_h, (total + 1) * 8)); IDX_CHECK(hipMalloc((void **)&d_y, (total + 1) * 8));
+	IDX_CHECK(al_dev_malloc((void **)&d_h, (total + 1) * 8)); IDX_CHECK(al_dev_malloc((void **)&d_y, (total + 1) * 8));
 	IDX_CHECK(al_dev_malloc((void **)&d_h2, (total + 1) * 8)); IDX_CHECK(al_dev_malloc((void **)&d_y2, (total + 1) * 8));
 	if (n_seg) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ref_sketch<1>), dim3((unsigned)((n_seg + 63) / 64)), dim3(64), (size_t)w * 64 * 16, st,
 	                              d.S4, d.seq_off, d.seq_len, d_segf, n_seq, n_seg, w, k, (uint32_t *)nullptr, d_off, d_h, d_y);
@@ -265,24 +265,25 @@ extern "C" al_idx_t *al_idx_build_device(const char *fn, const al_idxopt_t *io, 
 		}
 	}
 	while ((1ULL << bits) < n_keys * 2 + 2) ++bits;
-	IDX_CHECK(hipMalloc((void **)&d.tab, ((size_t)2 << bits) * 8));
+	IDX_CHECK(al_dev_malloc((void **)&d.tab, ((size_t)2 << bits) * 8));
 	IDX_CHECK(hipMemsetAsync(d.tab, 0, ((size_t)2 << bits) * 8, st));
 	if (n_keys) hipLaunchKernelGGL(k_tab_insert, dim3((unsigned)((n_keys + 255) / 256)), dim3(256), 0, st, d_uniq, d_kcnt, d_koff, n_keys, d_y, n_seq <= AL_TAB_SINGLE_MAX_SEQ ? 1 : 0, (unsigned long long *)d.tab, bits);
 	IDX_CHECK(hipStreamSynchronize(st));
 	d.pos = d_y; d_y = nullptr;
-	if (!total) IDX_CHECK(hipMalloc((void **)&d.pos, 8));
+	if (!total) IDX_CHECK(al_dev_malloc((void **)&d.pos, 8));
 	d.tab_bits = bits; d.n_seq = n_seq;
 	mi->tab_bits = bits; mi->n_keys = n_keys; mi->n_pos = total; mi->built_on = device;
 	mi->dev[device] = d;
 	al_dev_free(d_tmp); al_dev_free(d_segf); al_dev_free(d_cnt); al_dev_free(d_off); al_dev_free(d_h); al_dev_free(d_uniq); al_dev_free(d_koff); al_dev_free(d_kcnt); al_dev_free(d_nruns);
 	al_dev_free(d_h2); al_dev_free(d_y2);
 	(void)hipStreamDestroy(st);
-	if (timing) { clock_gettime(CLOCK_MONOTONIC, &tq2); fprintf(stderr, "[airlift] index: FASTA load %.3f s (%d threads), upload + kernels %.3f s; %llu minimizers, %llu distinct\n", secs(tq0, tq1), n_host, secs(tq1, tq2), (unsigned long long)total, (unsigned long long)n_keys); }
+	if (timing) { clock_gettime(CLOCK_MONOTONIC, &tq2); fprintf(stderr, "[airlift] index: FASTA load %.3f s (%d threads), upload + kernels %.3f s; %llu minimizers, %llu distinct; index arrays %.2f GB on the device\n", secs(tq0, tq1), n_host, secs(tq1, tq2), (unsigned long long)total, (unsigned long long)n_keys,
+	                    (n_words * 4.0 + ((double)((size_t)2 << bits)) * 8.0 + (total + 1) * 8.0) / 1e9); }
 	return mi;
 fail:
-	al_dev_free(d_tmp); al_dev_free(d_ascii); al_dev_free(d_segf); al_dev_free(d_cnt); al_dev_free(d_off); al_dev_free(d_h); (void)hipFree(d_y); al_dev_free(d_h2); al_dev_free(d_y2);
+	al_dev_free(d_tmp); al_dev_free(d_ascii); al_dev_free(d_segf); al_dev_free(d_cnt); al_dev_free(d_off); al_dev_free(d_h); al_dev_free(d_y); al_dev_free(d_h2); al_dev_free(d_y2);
 	al_dev_free(d_uniq); al_dev_free(d_koff); al_dev_free(d_kcnt); al_dev_free(d_nruns);
-	(void)hipFree(d.S4); (void)hipFree(d.tab); (void)hipFree(d.seq_off); (void)hipFree(d.seq_len);
+	al_dev_free(d.S4); al_dev_free(d.tab); al_dev_free(d.seq_off); al_dev_free(d.seq_len);
 	if (st) (void)hipStreamDestroy(st);
 	delete mi;
 	return nullptr;

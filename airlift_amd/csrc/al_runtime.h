@@ -27,6 +27,8 @@ AlAllocSite &al_alloc_site();      // who asked (AL_TRACE_ALLOC lists the large 
 struct AlAllocStat { std::atomic<long long> dev_ns{0}, dev_bytes{0}, dev_calls{0}, host_ns{0}, host_bytes{0}, host_calls{0}; };
 AlAllocStat &al_alloc_stat();
 void al_dev_free(void *p);
+long long al_dev_reserve_room();      // bytes the process's reserve still holds free (or is yet to obtain) on the current device; -1 = no reserve there
+hipError_t al_dev_mem_info(size_t *free_b, size_t *total_b);   // hipMemGetInfo plus what the process's reserve (al_device_reserve) holds free
 int al_dev_guard_check();            // AL_TEST_GUARD=1: number of live ranges whose guard zones were written (messages on stderr)
 
 template <typename T> struct DevBuf {       // grow-only device array

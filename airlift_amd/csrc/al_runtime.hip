@@ -4,12 +4,15 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
 #include <cstring>
 #include <rocprim/rocprim.hpp>
 #include <algorithm>
 #include "al_internal.h"
 #include "al_device.h"
 #include <mutex>
+#include <condition_variable>
+#include <thread>
 #include <atomic>
 #include <map>
 #include <vector>
@@ -113,10 +116,168 @@ std::atomic<size_t> *&al_acct() { static thread_local std::atomic<size_t> *a = n
 namespace { struct OwnRec { size_t bytes; std::atomic<size_t> *owner; }; std::mutex g_own_m; std::map<void *, OwnRec> g_own; }
 AlAllocStat &al_alloc_stat() { static AlAllocStat s; return s; }
 AlAllocSite &al_alloc_site() { static thread_local AlAllocSite s{"", 0}; return s; }
+// ---- device memory reserve (round 5) ----------------------------------------------------------------------------------------------------
+// What a process pays for device memory on this platform is the driver mapping (and scrubbing) it: tenths of a second to seconds per 100 GB, inside
+// the first batches of a file-to-file run.  al_device_reserve() starts a thread that obtains the run's memory in a few large chunks WHILE the
+// reference is loaded and the index is built; al_dev_malloc / al_dev_free then serve every range -- index arrays, the index builder's temporaries,
+// the contexts' grow-only workspaces, the slots' text buffers -- from those chunks (best fit, neighbours coalesced), without a driver call.
+// A request that finds no room waits for the filler while it is still at work and falls back to hipMalloc otherwise (also: other devices, ranges
+// larger than a chunk).  Peak use is reported (AL_TIMING) -- the workspace figure of the run.
+namespace {
+struct DevPool {
+	int device = -1; std::mutex m; std::condition_variable cv;
+	std::map<char *, size_t> free_;                               // free blocks by address
+	std::map<char *, size_t> used_;                               // handed-out blocks
+	std::vector<std::pair<char *, size_t>> regions;
+	bool filling = false, started = false; size_t target = 0, obtained = 0, chunk = 0, in_use = 0, peak = 0, n_served = 0, n_missed = 0; double t_fill = 0, t_first = 0;
+	std::thread filler;
+	const std::pair<char *, size_t> *region_of(char *p) const { for (const auto &r : regions) if (p >= r.first && p < r.first + r.second) return &r; return nullptr; }
+};
+DevPool &pool() { static DevPool *P = new DevPool(); return *P; }   // (never destroyed: the filler may outlive main())
+const size_t POOL_ALIGN = 4096;
+void *pool_alloc(size_t bytes)
+{
+	DevPool &P = pool();
+	if (!P.started) return nullptr;
+	int dev = -1; if (hipGetDevice(&dev) != hipSuccess || dev != P.device) return nullptr;
+	const size_t need = (bytes + POOL_ALIGN - 1) / POOL_ALIGN * POOL_ALIGN;
+	std::unique_lock<std::mutex> l(P.m);
+	for (;;) {
+		auto best = P.free_.end();
+		for (auto it = P.free_.begin(); it != P.free_.end(); ++it) if (it->second >= need && (best == P.free_.end() || it->second < best->second)) best = it;
+		if (best != P.free_.end()) {
+			char *p = best->first; const size_t sz = best->second;
+			P.free_.erase(best);
+			if (sz > need) P.free_[p + need] = sz - need;
+			P.used_[p] = need; P.in_use += need; if (P.in_use > P.peak) P.peak = P.in_use; ++P.n_served;
+			return p;
+		}
+		if (!P.filling || need > P.chunk) { ++P.n_missed; return nullptr; }
+		P.cv.wait(l);
+	}
+}
+bool pool_free(void *ptr)
+{
+	DevPool &P = pool();
+	if (!P.started) return false;
+	std::lock_guard<std::mutex> l(P.m);
+	auto it = P.used_.find((char *)ptr);
+	if (it == P.used_.end()) return false;
+	char *p = it->first; size_t sz = it->second;
+	P.used_.erase(it); P.in_use -= sz;
+	const auto *rg = P.region_of(p);
+	auto nx = P.free_.find(p + sz);                               // coalesce with the free neighbours inside the same chunk
+	if (nx != P.free_.end() && rg && nx->first < rg->first + rg->second) { sz += nx->second; P.free_.erase(nx); }
+	auto pv = P.free_.lower_bound(p);
+	if (pv != P.free_.begin()) { --pv; if (pv->first + pv->second == p && rg && pv->first >= rg->first) { p = pv->first; sz += pv->second; P.free_.erase(pv); } }
+	P.free_[p] = sz;
+	return true;
+}
+}
+extern "C" int al_device_reserve(int device, uint64_t bytes)
+{
+	DevPool &P = pool();
+	int n_dev = 0;
+	if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return -1;
+	if (device < 0) { const char *lr = getenv("LOCAL_RANK"); device = lr ? atoi(lr) % n_dev : 0; }
+	if (device >= n_dev || bytes == 0) return -1;
+	{
+		std::lock_guard<std::mutex> l(P.m);
+		if (P.started) return P.device == device ? 0 : -1;          // one reserve per process
+		size_t free_b = 0, total_b = 0;
+		if (hipSetDevice(device) != hipSuccess || hipMemGetInfo(&free_b, &total_b) != hipSuccess) return -1;
+		P.device = device; P.target = (size_t)std::min<uint64_t>(bytes, (uint64_t)((double)free_b * 0.92));
+		static const double chunk_gb = getenv("AL_POOL_CHUNK_GB") ? atof(getenv("AL_POOL_CHUNK_GB")) : 0.0;
+		P.chunk = chunk_gb > 0 ? (size_t)(chunk_gb * 1e9) : std::min<size_t>(std::max<size_t>(P.target / 6, (size_t)2 << 30), (size_t)24 << 30);
+		P.chunk = P.chunk / POOL_ALIGN * POOL_ALIGN;
+		P.started = true; P.filling = true;
+	}
+	P.filler = std::thread([&P]() {
+		const auto t0 = std::chrono::steady_clock::now();
+		(void)hipSetDevice(P.device);
+		for (;;) {
+			size_t want;
+			{ std::lock_guard<std::mutex> l(P.m); want = P.target > P.obtained ? std::min(P.chunk, P.target - P.obtained) : 0; }
+			if (want < ((size_t)64 << 20)) break;
+			void *p = nullptr;
+			if (hipMalloc(&p, want) != hipSuccess) { (void)hipGetLastError(); break; }
+			std::lock_guard<std::mutex> l(P.m);
+			P.regions.emplace_back((char *)p, want); P.free_[(char *)p] = want; P.obtained += want;
+			if (P.regions.size() == 1) P.t_first = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+			P.cv.notify_all();
+		}
+		std::lock_guard<std::mutex> l(P.m);
+		P.filling = false; P.t_fill = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+		P.cv.notify_all();
+	});
+	P.filler.detach();
+	return 0;
+}
+// The reserve a file-to-file run needs, from its file sizes alone (the stream driver's own arithmetic, al_stream_pipe.cpp: ~360 bytes of FASTQ per
+// read; inputs of >= 3 M reads run 2 contexts x 524288-read batches, shorter ones 3 x 131072): the index (4-bit sequence, 8 bytes per minimizer
+// occurrence at one minimizer per ~5.7 bases, a table of 16-byte entries at load <= 0.5) + the larger of the index builder's temporaries and the
+// contexts' workspaces + the slots' text.  Workspace bytes per read of a batch follow the reference's size -- seed hits per read grow with its repeat
+// content: ~78 KB per read measured on a 3.1 Gbp reference with 45 % repeats, ~5 KB on a yeast-sized one; AL_RESERVE_KB_PER_READ overrides.
+extern "C" int64_t al_device_reserve_for_run(int device, const char *ref_fn, int n_fn, const char *const *fn)
+{
+	if (getenv("AL_NO_RESERVE")) return 0;
+	struct stat sb;
+	if (!ref_fn || stat(ref_fn, &sb) != 0 || !S_ISREG(sb.st_mode)) return 0;
+	const double G = (double)sb.st_size;
+	double fq = 0;
+	for (int i = 0; i < n_fn; ++i) { if (!fn[i] || stat(fn[i], &sb) != 0 || !S_ISREG(sb.st_mode)) return 0; const size_t L = strlen(fn[i]); if (L > 3 && !strcmp(fn[i] + L - 3, ".gz")) return 0; fq += (double)sb.st_size; }
+	const double reads = fq / 360.0;
+	if (reads < 2.0e5) return 0;                                   // a short run: the driver's own pace is no issue
+	const double n_min = G / 5.7;
+	double tab = 32.0; while (tab < 2.0 * 0.9 * n_min + 2.0) tab *= 2.0; tab *= 16.0;
+	const double index = 0.5 * G + 8.0 * n_min + tab, build_tmp = G + 4.0 * 8.0 * n_min + 4.0 * n_min;
+	const double kb = getenv("AL_RESERVE_KB_PER_READ") ? atof(getenv("AL_RESERVE_KB_PER_READ")) : G >= 1.0e9 ? 85.0 : G >= 2.0e8 ? 40.0 : 12.0;
+	const bool long_input = reads >= 3.0e6;
+	const double batch = long_input ? 524288.0 : std::min(131072.0, reads), n_ctx = long_input ? 2.0 : 3.0, n_slots = long_input ? 4.0 : 5.0;
+	const double ws = n_ctx * batch * kb * 1024.0 + n_slots * batch * 2300.0 + 1.5e9;
+	const double need = index + std::max(build_tmp, ws) * 1.08;
+	if (al_device_reserve(device, (uint64_t)need) != 0) return -1;
+	return (int64_t)need;
+}
+// free / total device memory as the batch sizing sees it: what the driver reports plus what the reserve holds free (and is still to obtain)
+hipError_t al_dev_mem_info(size_t *free_b, size_t *total_b)
+{
+	const hipError_t e = hipMemGetInfo(free_b, total_b);
+	DevPool &P = pool();
+	int dev = -1;
+	if (e == hipSuccess && P.started && hipGetDevice(&dev) == hipSuccess && dev == P.device) {
+		std::lock_guard<std::mutex> l(P.m);
+		size_t f = 0; for (const auto &kv : P.free_) f += kv.second;
+		// (memory the filler has yet to obtain is already part of the driver's free figure)
+		*free_b += f;
+	}
+	return e;
+}
+// bytes the reserve holds free on the current device (and still has to obtain); -1 without a reserve there
+long long al_dev_reserve_room()
+{
+	DevPool &P = pool(); int dev = -1;
+	if (!P.started || hipGetDevice(&dev) != hipSuccess || dev != P.device) return -1;
+	std::lock_guard<std::mutex> l(P.m);
+	size_t f = 0; for (const auto &kv : P.free_) f += kv.second;
+	return (long long)(f + (P.filling && P.target > P.obtained ? P.target - P.obtained : 0));
+}
+extern "C" void al_device_reserve_report(FILE *fp)
+{
+	DevPool &P = pool();
+	if (!P.started) return;
+	std::lock_guard<std::mutex> l(P.m);
+	fprintf(fp, "[airlift] device memory reserve: %.1f of %.1f GB obtained in %zu chunk(s) of %.1f GB by the background thread in %.3f s%s (first chunk after %.3f s); peak in use %.2f GB, %zu ranges served, %zu requests passed on to hipMalloc\n",
+	        P.obtained / 1e9, P.target / 1e9, P.regions.size(), P.chunk / 1e9, P.t_fill, P.filling ? " (still filling)" : "", P.t_first, P.peak / 1e9, P.n_served, P.n_missed);
+}
+extern "C" uint64_t al_device_reserve_peak(void) { DevPool &P = pool(); if (!P.started) return 0; std::lock_guard<std::mutex> l(P.m); return (uint64_t)P.peak; }
+extern "C" void al_device_reserve_reset_peak(void) { DevPool &P = pool(); if (!P.started) return; std::lock_guard<std::mutex> l(P.m); P.peak = P.in_use; }
+
 static hipError_t al_dev_malloc_raw(void **p, size_t bytes)
 {
 	const auto t0 = std::chrono::steady_clock::now();
-	const hipError_t e = hipMalloc(p, bytes);
+	hipError_t e = hipSuccess;
+	if (void *q = pool_alloc(bytes)) *p = q; else e = hipMalloc(p, bytes);
 	{ AlAllocStat &a = al_alloc_stat(); const long long ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); a.dev_ns += ns; a.dev_bytes += (long long)bytes; ++a.dev_calls;
 	  static const bool tr = getenv("AL_TRACE_ALLOC") != nullptr;
 	  if (tr && bytes >= (32u << 20)) { const AlAllocSite &w = al_alloc_site(); const char *b = strrchr(w.file, '/'); fprintf(stderr, "[airlift] alloc: %8.1f MB in %7.1f ms for %s:%d\n", bytes / 1e6, ns / 1e6, b ? b + 1 : w.file, w.line); } }
@@ -130,7 +291,7 @@ static void al_dev_free_raw(void *p)
 	if (!p) return;
 	{ std::lock_guard<std::mutex> l(g_own_m); auto it = g_own.find(p); if (it != g_own.end()) { it->second.owner->fetch_sub(it->second.bytes); g_own.erase(it); } }
 	const auto t0 = std::chrono::steady_clock::now();
-	(void)hipFree(p);
+	if (!pool_free(p)) (void)hipFree(p);
 	al_alloc_stat().dev_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
 }
 
@@ -155,23 +316,23 @@ int al_upload_index(const al_idx_t *mi, int device, AlDevIndex *out)
 	AL_HIP_CHECK(hipSetDevice(device));
 	std::vector<uint64_t> so(mi->seq.size()); std::vector<uint32_t> sl(mi->seq.size());
 	for (size_t i = 0; i < mi->seq.size(); ++i) so[i] = mi->seq[i].offset, sl[i] = mi->seq[i].len;
-	AL_HIP_CHECK(hipMalloc((void **)&d.seq_off, so.size() * 8));
+	AL_HIP_CHECK(al_dev_malloc((void **)&d.seq_off, so.size() * 8));
 	AL_HIP_CHECK(hipMemcpy(d.seq_off, so.data(), so.size() * 8, hipMemcpyHostToDevice));
-	AL_HIP_CHECK(hipMalloc((void **)&d.seq_len, sl.size() * 4));
+	AL_HIP_CHECK(al_dev_malloc((void **)&d.seq_len, sl.size() * 4));
 	AL_HIP_CHECK(hipMemcpy(d.seq_len, sl.data(), sl.size() * 4, hipMemcpyHostToDevice));
 	if (mi->built_on >= 0) {                     // index lives on another GPU only: device-to-device copy over xGMI
 		auto src = mi->dev.find(mi->built_on);
 		if (src == mi->dev.end()) { fprintf(stderr, "[airlift] index was built on device %d but is no longer resident there\n", mi->built_on); return -1; }
 		const size_t nS4 = ((mi->tot_len + 7) / 8 + 8) * 4, nTab = ((size_t)2 << mi->tab_bits) * 8, nPos = (mi->n_pos ? mi->n_pos : 1) * 8;
-		AL_HIP_CHECK(hipMalloc((void **)&d.S4, nS4)); AL_HIP_CHECK(hipMemcpyPeer(d.S4, device, src->second.S4, mi->built_on, nS4));
-		AL_HIP_CHECK(hipMalloc((void **)&d.tab, nTab)); AL_HIP_CHECK(hipMemcpyPeer(d.tab, device, src->second.tab, mi->built_on, nTab));
-		AL_HIP_CHECK(hipMalloc((void **)&d.pos, nPos)); AL_HIP_CHECK(hipMemcpyPeer(d.pos, device, src->second.pos, mi->built_on, nPos));
+		AL_HIP_CHECK(al_dev_malloc((void **)&d.S4, nS4)); AL_HIP_CHECK(hipMemcpyPeer(d.S4, device, src->second.S4, mi->built_on, nS4));
+		AL_HIP_CHECK(al_dev_malloc((void **)&d.tab, nTab)); AL_HIP_CHECK(hipMemcpyPeer(d.tab, device, src->second.tab, mi->built_on, nTab));
+		AL_HIP_CHECK(al_dev_malloc((void **)&d.pos, nPos)); AL_HIP_CHECK(hipMemcpyPeer(d.pos, device, src->second.pos, mi->built_on, nPos));
 	} else {
-		AL_HIP_CHECK(hipMalloc((void **)&d.S4, mi->S4.size() * 4));
+		AL_HIP_CHECK(al_dev_malloc((void **)&d.S4, mi->S4.size() * 4));
 		AL_HIP_CHECK(hipMemcpy(d.S4, mi->S4.data(), mi->S4.size() * 4, hipMemcpyHostToDevice));
-		AL_HIP_CHECK(hipMalloc((void **)&d.tab, mi->tab.size() * 8));
+		AL_HIP_CHECK(al_dev_malloc((void **)&d.tab, mi->tab.size() * 8));
 		AL_HIP_CHECK(hipMemcpy(d.tab, mi->tab.data(), mi->tab.size() * 8, hipMemcpyHostToDevice));
-		AL_HIP_CHECK(hipMalloc((void **)&d.pos, mi->pos.size() * 8));
+		AL_HIP_CHECK(al_dev_malloc((void **)&d.pos, mi->pos.size() * 8));
 		AL_HIP_CHECK(hipMemcpy(d.pos, mi->pos.data(), mi->pos.size() * 8, hipMemcpyHostToDevice));
 	}
 	d.tab_bits = mi->tab_bits; d.n_seq = (uint32_t)mi->seq.size();
@@ -184,7 +345,7 @@ void al_idx_free_device(al_idx_t *mi)
 	std::lock_guard<std::mutex> lk(mi->dev_mtx);
 	for (auto &kv : mi->dev) {
 		if (hipSetDevice(kv.first) != hipSuccess) continue;
-		(void)hipFree(kv.second.S4); (void)hipFree(kv.second.tab); (void)hipFree(kv.second.pos); (void)hipFree(kv.second.seq_off); (void)hipFree(kv.second.seq_len);
+		al_dev_free(kv.second.S4); al_dev_free(kv.second.tab); al_dev_free(kv.second.pos); al_dev_free(kv.second.seq_off); al_dev_free(kv.second.seq_len);
 	}
 	mi->dev.clear();
 }

@@ -298,7 +298,7 @@ int al_stream_map_files(const al_idx_t *mi, int n_fn, const char **fn, const al_
 					else {
 						if (single_probe.load() && mp->n_batch == 1) { probe_n0 = 0; probe_held0 = std::min(1.0e9, 0.25 * (double)mp->held.load()); }   // one point: the part that does not grow with the batch is taken as 1 GB (measured 0.8 - 1.5)
 						size_t free_b = 0, total_b = 0;
-						if (hipSetDevice(mp->device) == hipSuccess && hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+						if (hipSetDevice(mp->device) == hipSuccess && al_dev_mem_info(&free_b, &total_b) == hipSuccess) {
 							size_t held_ctx = 0; for (auto &o : mappers) if (o->device == mp->device) held_ctx += o->held.load();
 							const double h1 = (double)mp->held.load(), n1 = (double)res.n_reads, t_batch = now_s() - tb;
 							double v = n1 > probe_n0 ? (h1 - probe_held0) / (n1 - probe_n0) : h1 / n1; if (v < 1024.0) v = 1024.0;   // workspace bytes per read ...
@@ -310,9 +310,13 @@ int al_stream_map_files(const al_idx_t *mi, int n_fn, const char **fn, const al_
 							// of B, allocation costs n (F + 1.3 v B) / A and the gaps N t0 / (n B) -- least at B = sqrt(N t0 A / (1.3 v n^2)).
 							// (A short input keeps the probe's size; a genome's worth of reads is bounded by memory alone.)
 							const double total_reads = (double)std::max<long long>(est_total_reads.load(), res.n_reads) / (double)NL;
+							// With a reserve (al_device_reserve: the run's memory was obtained in the background during start-up) allocation costs nothing any more
+							// and the bound is what the reserve still has room for; without one, the fitted model of the driver's pace stays.
+							const long long room = al_dev_reserve_room();
 							static const double A = (getenv("AL_ALLOC_GBS") ? atof(getenv("AL_ALLOC_GBS")) : 30.0) * 1e9, t0b = (getenv("AL_BATCH_MS") ? atof(getenv("AL_BATCH_MS")) : 25.0) * 1e-3;
 							const double b_opt = sqrt(total_reads * t0b * A / (1.30 * v * (double)n_ctx_lane * (double)n_ctx_lane));
-							if (A > 0) mr = std::min(mr, b_opt);
+							if (room >= 0) mr = std::min(mr, (((double)room + (double)held_ctx) * 0.95 / (double)n_ctx_lane - F) / (v * 1.30 + (double)n_slots_lane * 2048.0 / (double)n_ctx_lane));
+							else if (A > 0) mr = std::min(mr, b_opt);
 							mr = std::min(mr, (double)reads_cap_k.load()); mr = std::min(mr, 4.0e6); mr = std::max(mr, n1);
 							if (mr < 2.0 * n1) mr = n1;          // growing past the probe's size frees and re-obtains every workspace (seconds): only for at least twice the batch
 							bool exp = false;
@@ -403,7 +407,7 @@ int al_stream_map_files(const al_idx_t *mi, int n_fn, const char **fn, const al_
 						size_t free_b = 0, total_b = 0;
 						static const double cap_long = getenv("AL_LONG_BATCH") ? atof(getenv("AL_LONG_BATCH")) : 524288.0;
 						double b = std::min(cap_long, std::max(262144.0, est0 / (3.0 * n_ctx_lane)));
-						if (hipSetDevice(mappers[0]->device) == hipSuccess && hipMemGetInfo(&free_b, &total_b) == hipSuccess) b = std::min(b, 0.6 * (double)free_b / ((double)n_ctx_lane * 81920.0));
+						if (hipSetDevice(mappers[0]->device) == hipSuccess && al_dev_mem_info(&free_b, &total_b) == hipSuccess) b = std::min(b, 0.6 * (double)free_b / ((double)n_ctx_lane * 81920.0));
 						first = std::max<int64_t>(first, (int64_t)b);
 					}
 					max_reads = (int)std::max<int64_t>(2, std::min<int64_t>(first, k_bases / 64));

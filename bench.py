@@ -134,20 +134,24 @@ def file_to_file(tmp, ref_fa, a, arr, ref, resident_value):
             m = re.search(r"stream pipeline: .*? reads, (\d+) records, ([0-9.]+) MB of SAM in ([0-9.]+) s", err)
             mi = re.search(r"index build ([0-9.]+) s", err); ma = re.search(r"allocation calls of the process so far: device (\d+) calls, ([0-9.]+) GB, ([0-9.]+) s", err)
             mb = re.search(r"-> batches of (\d+) reads \((\d+) context\(s\), (\d+) slots", err)
+            mr = re.search(r"device memory reserve: ([0-9.]+) of ([0-9.]+) GB obtained in (\d+) chunk\(s\) of [0-9.]+ GB by the background thread in ([0-9.]+) s.*?peak in use ([0-9.]+) GB, (\d+) ranges served, (\d+) requests passed on", err)
+            mx = re.search(r"index arrays ([0-9.]+) GB on the device", err)
             runs.append({"wall_s": wall, "pipeline_s": float(m.group(3)) if m else None, "records": int(m.group(1)) if m else None, "sam_mb": float(m.group(2)) if m else None,
                          "index_build_s": float(mi.group(1)) if mi else None, "device_alloc_gb": float(ma.group(2)) if ma else None, "device_alloc_s": float(ma.group(3)) if ma else None,
-                         "batch_reads": int(mb.group(1)) if mb else None, "contexts": int(mb.group(2)) if mb else None, "slots": int(mb.group(3)) if mb else None})
+                         "batch_reads": int(mb.group(1)) if mb else None, "contexts": int(mb.group(2)) if mb else None, "slots": int(mb.group(3)) if mb else None,
+                         "reserve_gb": float(mr.group(1)) if mr else None, "reserve_obtained_in_background_s": float(mr.group(4)) if mr else None, "peak_device_gb_in_use": float(mr.group(5)) if mr else None,
+                         "requests_passed_on_to_hipMalloc": int(mr.group(7)) if mr else None, "index_gb": float(mx.group(1)) if mx else None})
         best = next((r for r in runs if r["pipeline_s"]), None)     # the FIRST run is the headline of this leg
         for r in runs:
             if r["pipeline_s"]:
                 r["reads_per_s"] = 2 * n / r["pipeline_s"]; r["frac_of_resident_value"] = r["reads_per_s"] / resident_value if resident_value else None
-                if r.get("device_alloc_gb") and r.get("batch_reads") and r.get("contexts"):   # what the mapping contexts hold per read of a batch (the index, ~23 GB on C4, is in device_alloc_gb too: taken off at its file-independent size when known)
-                    r["workspace_kb_per_read_incl_index"] = r["device_alloc_gb"] * 1e6 / (r["batch_reads"] * r["contexts"])
+                if r.get("peak_device_gb_in_use") and r.get("index_gb") and r.get("batch_reads") and r.get("contexts"):   # PEAK bytes in use at once (the reserve's own count), index apart, per read of the batches in flight
+                    r["peak_workspace_kb_per_read"] = (r["peak_device_gb_in_use"] - r["index_gb"]) * 1e6 / (r["batch_reads"] * r["contexts"])
         res = {"pairs": n, "reads": 2 * n, "host_threads": nt, "storage": shm, "output_storage": out_dir, "fastq_generation_s": t_gen, "sleep_before_each_run_s": a.f2f_sleep, "runs": runs}
         if best:
             res.update({"reads_per_s": 2 * n / best["pipeline_s"], "pipeline_s": best["pipeline_s"], "startup_s": best["wall_s"] - best["pipeline_s"],
                         "whole_process_reads_per_s": 2 * n / best["wall_s"], "frac_of_resident_value": (2 * n / best["pipeline_s"]) / resident_value if resident_value else None,
-                        "note": "FASTQ -> SAM through the drop-in: raw file blocks to HBM, record parsing / 4-bit packing / SAM text by kernels, batches of `batch_reads` on `contexts` mapping contexts; pipeline_s = first block read -> last byte written (the process's own clock), start-up (FASTA load + index build on the GPU + contexts) apart; reads_per_s = the FIRST (cold) run of the process, the second run is in `runs`"})
+                        "note": "FASTQ -> SAM through the drop-in: raw file blocks to HBM, record parsing / 4-bit packing / SAM text by kernels, batches of `batch_reads` on `contexts` mapping contexts; pipeline_s = first block read -> last byte written (the process's own clock), start-up (FASTA load + index build on the GPU + contexts; the run's device memory is obtained by a background thread meanwhile: device_alloc_s is what the pipeline still waited for) apart; reads_per_s = the FIRST (cold) run of the process, the second run is in `runs`"})
         # parity: the first cpu-sample pairs are the reads the CPU comparator mapped: its SAM must be the head of this one
         ref_sam = os.path.join(tmp, "cpu.sam")
         if os.path.exists(ref_sam) and os.path.exists(out):
@@ -250,7 +254,7 @@ def main():
     ap.add_argument("--cpu-sample-pairs", type=int, default=500_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--f2f-sleep", type=float, default=5.0, help="seconds to wait before each process of the file-to-file leg (recorded in the output)")
-    ap.add_argument("--f2f-pairs", type=int, default=4_000_000, help="pairs of the file-to-file leg (FASTQ files -> airlift-align -> SAM file; rank 0, N=1 only; 0 = skip)")
+    ap.add_argument("--f2f-pairs", type=int, default=6_250_000, help="pairs of the file-to-file leg (FASTQ files -> airlift-align -> SAM file; rank 0, N=1 only; 0 = skip)")
     ap.add_argument("--ins-mean", type=int, default=0, help="mean insert size override (short inserts make the mates overlap: equal-key anchors)")
     ap.add_argument("--config", default="c4", help="workload of tools/gen_synth.py: c4 (default: the configuration BASELINE.json's metric is quoted on -- 150 bp PE against a human-sized reference; fits one GPU), c5 (250 bp), c3 (100 Mbp), c2 (yeast-sized), c2r, c4s, c3u, c4u")
     ap.add_argument("--test-one-gpu", action="store_true", help="N > 1 on a one-GPU box (validation of the sharded path only): every rank uses device 0, collectives over gloo")

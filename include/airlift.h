@@ -307,6 +307,18 @@ int  al_write_sam(char *buf, size_t cap, const al_idx_t *mi, const char *qname, 
 
 const char *al_version(void);
 
+/* Device memory reserve (no reference analogue: kalloc's per-thread arenas, kalloc.c:38-205 / map.c:13-36, are the nearest thing).  Starts a
+ * thread that obtains `bytes` of memory on `device` (< 0: LOCAL_RANK or 0) in a few large chunks and returns at once; every device range the
+ * library uses afterwards -- index arrays, the index builder's temporaries, the mapping contexts' workspaces -- is served from those chunks
+ * (requests that find no room fall back to the driver).  Meant to be called before al_idx_build_device so that obtaining the memory overlaps
+ * the FASTA load and the index build.  One reserve per process; 0, or -1 if there is no usable device / a reserve on another device exists.
+ * al_device_reserve_for_run sizes it from the reference and read files (bytes it asked for, 0 = run too small to be worth it, -1 = error). */
+int al_device_reserve(int device, uint64_t bytes);
+int64_t al_device_reserve_for_run(int device, const char *ref_fn, int n_fn, const char *const *fn);
+uint64_t al_device_reserve_peak(void);        /* largest number of bytes in use at once so far (0 without a reserve) */
+void al_device_reserve_reset_peak(void);
+void al_device_reserve_report(FILE *fp);      /* one line: chunks, time, peak use */
+
 #ifdef __cplusplus
 }
 #endif
