@@ -285,6 +285,7 @@ __device__ __forceinline__ void d_ksw_lds(GroupLds<TMAX, QMAX> &L, const int gl,
 }
 
 #include "al_dev_ksw.h"
+#include "al_dev_ksw2.h"
 
 // dispatcher: targets of up to 22 x 16 cells run register-resident, larger ones use the LDS rows
 template <int TMAX, int QMAX>
@@ -1610,11 +1611,20 @@ k_align_long(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ r
 // Tap for the parity tests: the extension DP alone on caller-supplied (target, query) pairs, one 16-lane group per pair -- what the
 // reference's --print-aln-seq tap shows per ksw call (align.c:313-339): sequences as passed to ksw_extd2_sse, flag; out: ez->score, CIGAR.
 struct DbgKswJob { uint32_t toff, qoff; int32_t tlen, qlen, flag, pad; };
+struct DbgPkLds {                  // what d_ksw_pk asks of its LDS structure (AL_DBG bit 20: the two-cells-per-lane form on every tap call of up to 352 target bases)
+	static constexpr int kPtb = 0;
+	uint8_t selE[512 + 2 * 352 + 32], selO[512 + 2 * 352 + 32];
+	uint32_t __attribute__((aligned(8))) wtab[352];
+	uint8_t tbuf[352 + 16];
+	uint32_t ezc[AL_LCIG];
+	uint8_t ptb[4];
+};
 __global__ void __launch_bounds__(64)
 k_dbg_ksw(const uint8_t *__restrict__ seqs, const DbgKswJob *__restrict__ jobs, int n, AlParams P, uint8_t *__restrict__ gws, size_t gws_stride, size_t p_bytes, size_t cig_words,
           int32_t *__restrict__ out /* per job: score, max, max_q, max_t, mqe, mqe_t, zdropped, reach_end, n_cigar */, uint32_t *__restrict__ cig_out, int cig_cap)
 {
 	__shared__ GroupLds<1024, 512> lds[AL_GPB];
+	__shared__ DbgPkLds pk[AL_GPB];
 	const int g = threadIdx.x / GW, gl = threadIdx.x % GW;
 	GroupLds<1024, 512> &L = lds[g];
 	GroupWs ws;
@@ -1632,6 +1642,19 @@ k_dbg_ksw(const uint8_t *__restrict__ seqs, const DbgKswJob *__restrict__ jobs, 
 		GSYNC();
 		EzD ez;
 		const int eb = (jb.flag & EZ_EXTZ_ONLY) ? P.end_bonus : -1;                      // align.c: extensions pass opt->end_bonus, the core re-alignment -1
+		if (((P.dbg >> 20) & 1) && jb.tlen <= 352) {
+			DbgPkLds &K = pk[g];
+			const int nb = (jb.tlen + 15) / 16, np = nb <= 4 ? 2 : nb <= 8 ? 4 : nb <= 12 ? 6 : nb <= 16 ? 8 : 11, pad = 32 * np;
+			for (int i = gl; i < jb.tlen; i += GW) K.tbuf[i] = L.tbuf[i];
+			for (int i = gl; i < jb.qlen + 2 * pad + 16; i += GW) { const int t = i - pad; const uint32_t b0 = t >= 0 && t < jb.qlen ? L.qbuf[jb.qlen - 1 - t] : 0u; K.selE[i] = (uint8_t)(b0 < 4 ? b0 : 0x0du); K.selO[i] = (uint8_t)(b0 < 4 ? 4u + b0 : 0x0du); }
+			GSYNC();
+			d_ez_reset(ez);
+			if (np == 2) d_ksw_pk<2>(K, K.selE + pad, K.selO + pad, gl, ws, jb.qlen, jb.tlen, P, bw, P.zdrop, eb, jb.flag, ez);
+			else if (np == 4) d_ksw_pk<4>(K, K.selE + pad, K.selO + pad, gl, ws, jb.qlen, jb.tlen, P, bw, P.zdrop, eb, jb.flag, ez);
+			else if (np == 6) d_ksw_pk<6>(K, K.selE + pad, K.selO + pad, gl, ws, jb.qlen, jb.tlen, P, bw, P.zdrop, eb, jb.flag, ez);
+			else if (np == 8) d_ksw_pk<8>(K, K.selE + pad, K.selO + pad, gl, ws, jb.qlen, jb.tlen, P, bw, P.zdrop, eb, jb.flag, ez);
+			else d_ksw_pk<11>(K, K.selE + pad, K.selO + pad, gl, ws, jb.qlen, jb.tlen, P, bw, P.zdrop, eb, jb.flag, ez);
+		} else
 		d_ksw_extd2(L, gl, ws, jb.qlen, jb.tlen, P, bw, P.zdrop, eb, jb.flag, ez);
 		if (gl == 0) {
 			o[0] = ez.score; o[1] = ez.max; o[2] = ez.max_q; o[3] = ez.max_t; o[4] = ez.mqe; o[5] = ez.mqe_t; o[6] = ez.zdropped; o[7] = ez.reach_end; o[8] = ez.n_cigar;
@@ -1973,27 +1996,29 @@ k_ext_prep_wave(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict_
 	if (threadIdx.x == 0) { if (c_regs) atomicAdd(&G.counters[4], c_regs); if (c_ref) atomicAdd(&G.counters[5], c_ref); if (c_cig) atomicAdd(&G.counters[6], c_cig); }
 }
 
-template <int QMAXJ, int TMAXJ> struct JobLds {
+template <int QMAXJ, int TMAXJ, bool PK = false> struct JobLds {
 	static constexpr bool kQrReady = true;   // k_ext_dp stores the reversed, padded query itself
 	// traceback tile: jobs of more than 64 target bases have more than 40 rows of at least 32 bytes -- they never fit it, and without it twice
 	// as many wavefronts fit a CU (the kernel waits on LDS reads and byte stores with 3.5 waves per SIMD)
 	static constexpr int kPtb = TMAXJ <= 64 ? AL_LPTB : 0;
 	uint8_t sq[QMAXJ + 2 * TMAXJ + 32];      // TMAXJ bytes of front pad, the reversed query, zeros up to qlen + TMAXJ + 16 (al_dev_ksw.h)
+	uint8_t selO[PK ? QMAXJ + 2 * TMAXJ + 32 : 1];   // two-cells-per-lane form (al_dev_ksw2.h): sq holds the score permute's selector bytes for a cell in the low half, selO for one in the high half
+	uint32_t __attribute__((aligned(8))) wtab[PK ? TMAXJ : 2];   // ... and the score tables of the target bases, two words per lane and superblock
 	uint8_t tbuf[TMAXJ + 16];
 	uint32_t ezc[AL_LCIG];
 	uint8_t ptb[kPtb > 0 ? kPtb : 4];
 };
 
 // DP jobs of one block-count class: 4 jobs per wavefront, all running d_ksw_reg<NB>
-template <int NB, int QMAXJ, int TMAXJ>
+template <int NB, int QMAXJ, int TMAXJ, bool PK = false>
 __global__ void __launch_bounds__(64, (NB <= 4 ? 4 : NB <= 8 ? AL_LB_DP8 : NB <= 12 ? 4 : NB <= 22 ? AL_LB_DP22 : 2))
 k_ext_dp(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_off, const uint32_t *__restrict__ rd_len,
          AlignShared G, ExtShared E, const uint32_t *__restrict__ sorted_idx, uint32_t first, uint32_t count,
          uint8_t *__restrict__ gws, size_t gws_stride, size_t p_bytes, size_t cig_words, AlParams P)
 {
-	__shared__ JobLds<QMAXJ, TMAXJ> lds[4];
+	__shared__ JobLds<QMAXJ, TMAXJ, PK> lds[4];
 	const int g = threadIdx.x / GW, gl = threadIdx.x % GW;
-	JobLds<QMAXJ, TMAXJ> &L = lds[g];
+	JobLds<QMAXJ, TMAXJ, PK> &L = lds[g];
 	GroupWs ws;
 	{ uint8_t *base = gws + ((size_t)blockIdx.x * 4 + g) * gws_stride; ws.p = base; ws.cig = (uint32_t *)(base + p_bytes); ws.ezc = ws.cig + cig_words; ws.sc = nullptr; ws.dbg = G.dbg; ws.cur_cig = nullptr; ws.cur_cig_cap = 0; ws.cur_ezc = nullptr; }
 	const int bw = (int)(P.bw * 1.5 + 1.);
@@ -2026,6 +2051,13 @@ k_ext_dp(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_of
 		EzD ez; d_ez_reset(ez);
 		const int flag = job.kind == 0 ? (EZ_EXTZ_ONLY | EZ_RIGHT | EZ_REV_CIGAR) : EZ_EXTZ_ONLY;
 		static_assert(TMAXJ == 16 * NB, "the query pad of JobLds is one block row");
+		if constexpr (PK) {
+			static_assert(NB % 2 == 0, "two blocks per superblock");
+			// selector words of the score permute, from the staged bytes (front pad included: whatever it holds, its words are in bounds and unused)
+			for (int i = gl; i < ql + 2 * TMAXJ + 16; i += GW) { const uint32_t b0 = L.sq[i]; L.selO[i] = (uint8_t)(b0 < 4 ? 4u + b0 : 0x0du); L.sq[i] = (uint8_t)(b0 < 4 ? b0 : 0x0du); }
+			GSYNC();
+			d_ksw_pk<NB / 2>(L, L.sq + TMAXJ, L.selO + TMAXJ, gl, ws, ql, tl, P, bw, P.zdrop, P.end_bonus, flag, ez);
+		} else
 		d_ksw_reg<NB>(L, gl, ws, ql, tl, P, bw, P.zdrop, P.end_bonus, flag, ez);
 		ExtOut o;
 		o.max = ez.max; o.max_q = ez.max_q; o.max_t = ez.max_t; o.mqe_t = ez.mqe_t;
@@ -2840,6 +2872,11 @@ int al_run_align_stage(al_ctx_t *c)
 				if (need && A->gws.ensure(need + 64)) return -1;
 			}
 			bool g12_done = false;
+			// two cells per lane (al_dev_ksw2.h) where its arithmetic holds: the permute's constant 0xff is the score of an N, scores within +-16
+			// (int16 H of the 352 x 512 tile); AL_DP_PK=0: the one-cell form everywhere (tests, A/B)
+			static const int pk_env = getenv("AL_DP_PK") ? atoi(getenv("AL_DP_PK")) : 1;
+			const int sc_amb_ = c->P.sc_ambi > 0 ? -c->P.sc_ambi : c->P.sc_ambi, sc_N_ = sc_amb_ == 0 ? -std::min(c->P.e2, c->P.e) : sc_amb_;
+			const bool dp_pk = pk_env != 0 && sc_N_ == -1 && c->P.a > 0 && c->P.a <= 16 && c->P.b >= 0 && c->P.b <= 16 && c->P.q + c->P.e <= 64 && c->P.q2 + c->P.e2 <= 64 && c->P.q >= 0 && c->P.e >= 0 && c->P.q2 >= 0 && c->P.e2 >= 0;
 			for (int cls = 0; cls < AL_NCLS; ++cls) {
 				const uint32_t cnt = (uint32_t)hist[cls];
 				if (cls == 3) AL_HIP_CHECK(hipEventRecord(c->ev[ST_EXT_DP_LANE + 1], s));
@@ -2862,12 +2899,15 @@ int al_run_align_stage(al_ctx_t *c)
 					  const int cap = NB <= 4 ? caps[0] : NB <= 8 ? caps[1] : NB <= 22 ? caps[2] : 2048; if (nbj > cap) nbj = cap; }
 					if (A->gws.ensure((size_t)nbj * 4 * st2 + 64)) return -1;
 #define LAUNCH_DP(NBV) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ext_dp<NBV, 512, NBV * 16>), dim3(nbj), dim3(64), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, G, E, A->job_idx2.p, first, cnt, A->gws.p, st2, pb, cw, c->P)
-					if (NB == 1) LAUNCH_DP(1); else if (NB == 2) LAUNCH_DP(2); else if (NB == 4) LAUNCH_DP(4); else if (NB == 8) LAUNCH_DP(8); else if (NB == 32) LAUNCH_DP(32);
+#define LAUNCH_DPK(NBV) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ext_dp<NBV, 512, NBV * 16, true>), dim3(nbj), dim3(64), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, G, E, A->job_idx2.p, first, cnt, A->gws.p, st2, pb, cw, c->P)
+					if (NB == 1) LAUNCH_DP(1); else if (NB == 2) LAUNCH_DP(2); else if (NB == 4) LAUNCH_DP(4); else if (NB == 8) { if (dp_pk) LAUNCH_DPK(8); else LAUNCH_DP(8); } else if (NB == 32) LAUNCH_DP(32);
 					else {   // 9 ... 22 blocks: the sorted slice holds the jobs of <= 12 blocks first, then 13 ... 16, then the rest
 						static const bool split = !getenv("AL_DP_NO_SPLIT");
 						const uint32_t c12 = split ? (uint32_t)std::min<unsigned long long>(sub7[0], cnt) : 0u, c16 = split ? (uint32_t)std::min<unsigned long long>(sub7[1], cnt - c12) : 0u, c22 = cnt - c12 - c16;
 						const uint32_t first0 = first, cnt0 = cnt;
-#define LAUNCH_DPS(NBV, F, N) do { if ((N) > 0) { int nb2 = (int)(((N) + 3) / 4); if (nb2 > nbj) nb2 = nbj; hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ext_dp<NBV, 512, NBV * 16>), dim3(nb2), dim3(64), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, G, E, A->job_idx2.p, (F), (N), A->gws.p + (size_t)gw_used * 4 * st2, st2, pb, cw, c->P); gw_used += nb2; } } while (0)
+#define LAUNCH_DPS(NBV, F, N) do { if ((N) > 0) { int nb2 = (int)(((N) + 3) / 4); if (nb2 > nbj) nb2 = nbj; \
+							if (dp_pk) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ext_dp<NBV, 512, NBV * 16, true>), dim3(nb2), dim3(64), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, G, E, A->job_idx2.p, (F), (N), A->gws.p + (size_t)gw_used * 4 * st2, st2, pb, cw, c->P); \
+							else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ext_dp<NBV, 512, NBV * 16>), dim3(nb2), dim3(64), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, G, E, A->job_idx2.p, (F), (N), A->gws.p + (size_t)gw_used * 4 * st2, st2, pb, cw, c->P); gw_used += nb2; } } while (0)
 						// (the three kernels run one after the other on this stream: they may share the workspace range)
 						int gw_used = 0; LAUNCH_DPS(12, first0, c12); AL_HIP_CHECK(hipEventRecord(c->ev[ST_EXT_DP_G12 + 1], s)); gw_used = 0; LAUNCH_DPS(16, first0 + c12, c16); AL_HIP_CHECK(hipEventRecord(c->ev[ST_EXT_DP_G16 + 1], s)); gw_used = 0; LAUNCH_DPS(22, first0 + c12 + c16, c22);
 						g12_done = true;
@@ -2875,6 +2915,7 @@ int al_run_align_stage(al_ctx_t *c)
 #undef LAUNCH_DPS
 					}
 #undef LAUNCH_DP
+#undef LAUNCH_DPK
 				} else {
 					int nbj = (int)cnt; if (nbj > 2048) nbj = 2048;
 					if (A->gws.ensure((size_t)nbj * stride + 64)) return -1;

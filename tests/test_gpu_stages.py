@@ -251,14 +251,17 @@ def test_rechain_pass_layout_and_run_to_run_determinism(A):
     ctx.close(); idx.close()
 
 
+@pytest.mark.parametrize("form", ["one_cell_per_lane", "two_cells_per_lane"])
 @pytest.mark.parametrize("name", ["g1_mt150pe", "g2_100se", "g2_250pe", "g3_adversarial", "g4_q_inv"])
-def test_ksw_calls_match_aln_seq_taps(golden_unpacked, name):
+def test_ksw_calls_match_aln_seq_taps(golden_unpacked, name, form, monkeypatch):
     """Every ksw_extd2_sse call the reference made on a golden set (--print-aln-seq taps, align.c:313-339: target, query, flag ->
     ez->score and CIGAR) replayed through the device DP (al_dbg_ksw: register-resident systolic form up to 22 x 16 target cells, LDS
     rows above): score and CIGAR must be identical call by call."""
     import ctypes as C
     import numpy as np
     import airlift_amd as A
+    if form == "two_cells_per_lane":      # AL_DBG bit 20: d_ksw_pk (al_dev_ksw2.h) on every call of up to 352 target bases (read when the context is created)
+        monkeypatch.setenv("AL_DBG", str(1 << 20))
     d = golden_unpacked[name]
     m = json.load(open(os.path.join(d, "meta.json")))
     lines = open(os.path.join(d, "expected.alnseq")).read().split("\n")
