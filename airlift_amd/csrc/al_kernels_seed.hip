@@ -118,18 +118,12 @@ __device__ __forceinline__ uint64_t d_match_pos(const uint64_t *__restrict__ pos
 	return (flags >> 9 & 1u) ? w : pos[w + k];
 }
 
-extern "C" __global__ void __launch_bounds__(256)
-k_seed(const uint64_t *__restrict__ tab, int tab_bits,
-       const uint32_t *__restrict__ frag_first, const uint32_t *__restrict__ rd_len,
-       const uint64_t *__restrict__ mini_off, AlAnchor *__restrict__ mini, const uint32_t *__restrict__ mini_cnt,
-       AlMatch *__restrict__ match, uint32_t *__restrict__ frag_nm, uint32_t *__restrict__ frag_na, int32_t *__restrict__ frag_rep,
-       const uint32_t *__restrict__ frag_list, int n_list, int max_occ)
+// collect_matches (map.c:90-123) of one fragment: its minimizers looked up with `max_occ`; mo == nullptr: counts only
+__device__ __forceinline__ void d_seed_frag(const uint64_t *__restrict__ tab, int tab_bits, const uint32_t *__restrict__ frag_first, const uint32_t *__restrict__ rd_len,
+                                            const uint64_t *__restrict__ mini_off, const AlAnchor *__restrict__ mini, const uint32_t *__restrict__ mini_cnt,
+                                            const uint32_t f, const int max_occ, AlMatch *__restrict__ mo, uint32_t &n_m_out, uint32_t &n_a_out, int &rep_out, int &qlen_out)
 {
-	const int t = blockIdx.x * blockDim.x + threadIdx.x;
-	if (t >= n_list) return;
-	const uint32_t f = frag_list ? frag_list[t] : (uint32_t)t;
 	const uint32_t r0 = frag_first[f], r1 = frag_first[f + 1];
-	AlMatch *mo = match + mini_off[r0];
 	int rep_st = 0, rep_en = 0, rep_len = 0; uint32_t n_m = 0, n_a = 0, sum = 0;
 	uint64_t prev_hash = ~0ULL; int have_prev = 0;
 	AlMatch *last = nullptr; uint64_t last_hash = 0; int last_valid = 0;
@@ -144,17 +138,19 @@ k_seed(const uint64_t *__restrict__ tab, int tab_bits,
 			const uint32_t occ = single ? 1u : (uint32_t)v;
 			// is_tandem (map.c:115-116): equal hash with the previous / next minimizer of the whole list
 			const int same_prev = have_prev && prev_hash == hash;
-			if (same_prev && last_valid && last_hash == hash) last->flags |= 1u << 8;   // previous gets "next is same"
+			if (mo && same_prev && last_valid && last_hash == hash) last->flags |= 1u << 8;   // previous gets "next is same"
 			last_valid = 0;
 			if ((int)occ >= max_occ) {                                       // map.c:105-111
 				const int en = (int)(q_pos >> 1) + 1, st = en - (int)q_span;
 				if (st > rep_en) { rep_len += rep_en - rep_st; rep_st = st, rep_en = en; }
 				else rep_en = en;
 			} else if (occ > 0) {
-				AlMatch m;
-				m.off_lo = single ? (uint32_t)v : (uint32_t)(v >> 32); m.n = occ; m.q_pos = q_pos;
-				m.flags = seg | (same_prev ? 1u << 8 : 0u) | (single ? (1u << 9 | (uint32_t)(v >> 32) << 16) : 0u);
-				mo[n_m] = m; last = &mo[n_m]; last_hash = hash; last_valid = 1;
+				if (mo) {
+					AlMatch m;
+					m.off_lo = single ? (uint32_t)v : (uint32_t)(v >> 32); m.n = occ; m.q_pos = q_pos;
+					m.flags = seg | (same_prev ? 1u << 8 : 0u) | (single ? (1u << 9 | (uint32_t)(v >> 32) << 16) : 0u);
+					mo[n_m] = m; last = &mo[n_m]; last_hash = hash; last_valid = 1;
+				}
 				++n_m; n_a += occ;
 			}
 			prev_hash = hash; have_prev = 1;
@@ -162,7 +158,114 @@ k_seed(const uint64_t *__restrict__ tab, int tab_bits,
 		sum += rd_len[r];
 	}
 	rep_len += rep_en - rep_st;
+	n_m_out = n_m; n_a_out = n_a; rep_out = rep_len; qlen_out = (int)sum;
+}
+
+extern "C" __global__ void __launch_bounds__(256)
+k_seed(const uint64_t *__restrict__ tab, int tab_bits,
+       const uint32_t *__restrict__ frag_first, const uint32_t *__restrict__ rd_len,
+       const uint64_t *__restrict__ mini_off, AlAnchor *__restrict__ mini, const uint32_t *__restrict__ mini_cnt,
+       AlMatch *__restrict__ match, uint32_t *__restrict__ frag_nm, uint32_t *__restrict__ frag_na, int32_t *__restrict__ frag_rep,
+       const uint32_t *__restrict__ frag_list, int n_list, int max_occ)
+{
+	const int t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= n_list) return;
+	const uint32_t f = frag_list ? frag_list[t] : (uint32_t)t;
+	uint32_t n_m, n_a; int rep_len, qlen;
+	d_seed_frag(tab, tab_bits, frag_first, rd_len, mini_off, mini, mini_cnt, f, max_occ, match + mini_off[frag_first[f]], n_m, n_a, rep_len, qlen);
 	frag_nm[f] = n_m; frag_na[f] = n_a; frag_rep[f] = rep_len;
+}
+
+// ---- the equal-x merge of the few GIANT re-seeded fragments, started ahead of time (round 5) ------------------------------------------------
+// A pair inside a high-copy family that gets re-seeded with max_occ (map.c:353-375) has 10^5 anchors, and if a query k-mer occurs twice its
+// anchors need the serial heap emulation: 0.3-0.45 us per pop, > 100 ms for ONE fragment, which the re-chain pass used to wait for.  Whether a
+// fragment is re-seeded is known only after its first chaining -- but what its anchors would be is known right after seeding.  So: every fragment
+// with a repeat-masked minimizer (rep_len > 0: the necessary condition) whose max_occ anchors would number at least `thr` gets a slot here, its
+// match lists are written to the slot, and the merge runs on a stream of its own beside the whole first pass.  If the fragment is re-seeded and
+// flagged in the re-chain pass, its anchors are copied from the slot (k_spec_mark / k_spec_apply); if not, the work was wasted on a few fragments.
+struct SpecOut { AlMatch *match; uint32_t *meta /* per slot: fragment, lists, anchors, fragment length */; uint32_t *cnt /* [0] slots taken, [1] candidates */; uint64_t *cand; uint32_t cap, per, cand_cap; };
+// candidates: rep_len > 0, at least `thr` anchors with max_occ in at most `per` lists, and a k-mer that occurs twice among those lists (no equal x
+// otherwise: the sort kernels' order is the heap's) -> key (anchors << 32 | fragment) appended to S.cand
+extern "C" __global__ void __launch_bounds__(256)
+k_spec_count(const uint64_t *__restrict__ tab, int tab_bits, const uint32_t *__restrict__ frag_first, const uint32_t *__restrict__ rd_len,
+             const uint64_t *__restrict__ mini_off, const AlAnchor *__restrict__ mini, const uint32_t *__restrict__ mini_cnt,
+             const int32_t *__restrict__ frag_rep, int n_frag, int max_occ, uint32_t thr, SpecOut S, int mid_occ)
+{
+	const int f = blockIdx.x * blockDim.x + threadIdx.x;
+	if (f >= n_frag || frag_rep[f] <= 0) return;
+	const uint32_t r0 = frag_first[f], r1 = frag_first[f + 1];
+	if (r1 - r0 > 2) return;
+	uint32_t n_mid[2] = {0, 0};                                             // per mate: minimizers the FIRST pass keeps (a mate without any has no chain there: the usual reason for the re-seeding)
+	const uint32_t c0 = mini_cnt[r0], c1 = r1 - r0 == 2 ? mini_cnt[r0 + 1] : 0u, M = c0 + c1;
+	if (M > 256u) return;
+	const AlAnchor *m0 = mini + mini_off[r0], *m1 = r1 - r0 == 2 ? mini + mini_off[r0 + 1] : m0;
+	uint64_t mk[4] = {0, 0, 0, 0}; uint32_t n_m = 0, n_a = 0;
+	for (uint32_t i = 0; i < M; ++i) {
+		const uint64_t hash = (i < c0 ? m0[i].x : m1[i - c0].x) >> 8;
+		bool single; const uint64_t v = d_idx_get(tab, tab_bits, hash, single);
+		const uint32_t occ = single ? 1u : (uint32_t)v;
+		if (occ > 0 && (int)occ < max_occ) { mk[i >> 6] |= 1ULL << (i & 63); ++n_m; n_a += occ; }
+		if (occ > 0 && (int)occ < mid_occ) ++n_mid[i < c0 ? 0 : 1];
+	}
+	if (n_a < thr || n_m > S.per || n_m < 2) return;
+	bool dup = false;
+	for (uint32_t i = 1; i < M && !dup; ++i) {
+		if (!(mk[i >> 6] >> (i & 63) & 1ULL)) continue;
+		const uint64_t hi = (i < c0 ? m0[i].x : m1[i - c0].x) >> 8;
+		for (uint32_t j = 0; j < i; ++j) if ((mk[j >> 6] >> (j & 63) & 1ULL) && ((j < c0 ? m0[j].x : m1[j - c0].x) >> 8) == hi) { dup = true; break; }
+	}
+	if (!dup) return;
+	const uint32_t k = atomicAdd(&S.cnt[1], 1u);
+	const bool likely = n_mid[0] < 2u || (r1 - r0 == 2 && n_mid[1] < 2u);
+	if (k < S.cand_cap) S.cand[k] = (likely ? 1ULL << 63 : 0ULL) | (uint64_t)n_a << 32 | (uint32_t)f;   // (slots go to the likely ones first, by size)
+}
+// the S.cap largest candidates get the slots (rank among the keys: the same choice on every run), their lists are written by a lane each
+extern "C" __global__ void __launch_bounds__(256)
+k_spec_pick(const uint64_t *__restrict__ tab, int tab_bits, const uint32_t *__restrict__ frag_first, const uint32_t *__restrict__ rd_len,
+            const uint64_t *__restrict__ mini_off, const AlAnchor *__restrict__ mini, const uint32_t *__restrict__ mini_cnt, int max_occ, SpecOut S)
+{
+	const uint32_t n = S.cnt[1] < S.cand_cap ? S.cnt[1] : S.cand_cap;
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+		const uint64_t k = S.cand[i]; uint32_t rank = 0;
+		for (uint32_t j = 0; j < n; ++j) rank += S.cand[j] > k ? 1u : 0u;
+		if (rank < S.cap) {
+			const uint32_t f = (uint32_t)k; uint32_t n_m, n_a; int rep, qlen;
+			d_seed_frag(tab, tab_bits, frag_first, rd_len, mini_off, mini, mini_cnt, f, max_occ, S.match + (size_t)rank * S.per, n_m, n_a, rep, qlen);
+			S.meta[4 * rank] = f; S.meta[4 * rank + 1] = n_m; S.meta[4 * rank + 2] = n_a; S.meta[4 * rank + 3] = (uint32_t)qlen;
+		}
+	}
+	if (threadIdx.x == 0 && blockIdx.x == 0) S.cnt[0] = n < S.cap ? n : S.cap;
+}
+// the slots as a virtual batch for k_anchor_heap_lanes: slot i is "fragment" i with one "read" of the fragment's length
+struct SpecView { uint32_t *first, *rdlen, *nm, *na, *tie, *list, *n_list; uint64_t *moff, *aoff; };
+__global__ void k_spec_layout(const uint32_t *__restrict__ meta, uint32_t n, uint32_t per, SpecView V)
+{
+	if (threadIdx.x != 0 || blockIdx.x != 0) return;
+	uint64_t off = 0;
+	for (uint32_t i = 0; i < n; ++i) {
+		V.first[i] = i; V.rdlen[i] = meta[4 * i + 3]; V.nm[i] = meta[4 * i + 1]; V.na[i] = meta[4 * i + 2]; V.tie[i] = 1u; V.list[i] = i;
+		V.moff[i] = (uint64_t)i * per; V.aoff[i] = off; off += meta[4 * i + 2];
+	}
+	V.first[n] = n; V.moff[n] = (uint64_t)n * per; V.aoff[n] = off; V.n_list[0] = n;
+}
+// re-chain pass, after its sorts: a slot whose fragment was re-seeded to the same lists and flagged for the merge is taken (flag 2: "merged already")
+__global__ void k_spec_mark(const uint32_t *__restrict__ meta, uint32_t n, const uint32_t *__restrict__ frag_nm, const uint32_t *__restrict__ frag_na, uint32_t *__restrict__ tie_flag, uint32_t *__restrict__ use)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const uint32_t f = meta[4 * i];
+	const bool ok = tie_flag[f] == 1u && frag_nm[f] == meta[4 * i + 1] && frag_na[f] == meta[4 * i + 2];
+	if (ok) tie_flag[f] = 2u;
+	use[i] = ok ? 1u : 0u;
+}
+__global__ void __launch_bounds__(256)
+k_spec_apply(const uint32_t *__restrict__ meta, const uint32_t *__restrict__ use, const uint64_t *__restrict__ v_aoff, const AlAnchor *__restrict__ src, const uint64_t *__restrict__ a_off, AlAnchor *__restrict__ anchors)
+{
+	const uint32_t i = blockIdx.y;
+	if (!use[i]) return;
+	const uint32_t f = meta[4 * i], n = meta[4 * i + 2];
+	const uint4 *s4 = reinterpret_cast<const uint4 *>(src + v_aoff[i]); uint4 *d4 = reinterpret_cast<uint4 *>(anchors + a_off[f]);
+	for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) d4[k] = s4[k];
 }
 
 // a8: ALSER candidate counter (map.c:299-312) on the sorted anchors of single-segment fragments
@@ -1879,7 +1982,7 @@ k_collect_flagged_blk(const uint32_t *__restrict__ list, int n, const uint32_t *
 	__shared__ uint32_t s_w[4], s_base;
 	const int t = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 	const uint32_t f = t < n ? list[t] : 0u;
-	const bool on = t < n && flag[f] != 0;
+	const bool on = t < n && flag[f] == 1u;                                  // (2 = merged ahead of time, k_spec_mark: not for the merge kernels)
 	const unsigned long long m = __ballot(on);
 	if (lane == 0) s_w[w] = (uint32_t)__popcll(m);
 	__syncthreads();

@@ -23,6 +23,13 @@
 // kernels (al_kernels_seed.hip)
 extern "C" __global__ void k_sketch(const uint32_t *, const uint64_t *, const uint32_t *, const uint64_t *, AlAnchor *, uint32_t *, int, int, int, int);
 extern "C" __global__ void k_seed(const uint64_t *, int, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, const uint32_t *, AlMatch *, uint32_t *, uint32_t *, int32_t *, const uint32_t *, int, int);
+struct SpecOut { AlMatch *match; uint32_t *meta; uint32_t *cnt; uint64_t *cand; uint32_t cap, per, cand_cap; };
+struct SpecView { uint32_t *first, *rdlen, *nm, *na, *tie, *list, *n_list; uint64_t *moff, *aoff; };
+extern "C" __global__ void k_spec_count(const uint64_t *, int, const uint32_t *, const uint32_t *, const uint64_t *, const AlAnchor *, const uint32_t *, const int32_t *, int, int, uint32_t, SpecOut, int);
+extern "C" __global__ void k_spec_pick(const uint64_t *, int, const uint32_t *, const uint32_t *, const uint64_t *, const AlAnchor *, const uint32_t *, int, SpecOut);
+__global__ void k_spec_layout(const uint32_t *, uint32_t, uint32_t, SpecView);
+__global__ void k_spec_mark(const uint32_t *, uint32_t, const uint32_t *, const uint32_t *, uint32_t *, uint32_t *);
+__global__ void k_spec_apply(const uint32_t *, const uint32_t *, const uint64_t *, const AlAnchor *, const uint64_t *, AlAnchor *);
 extern "C" __global__ void k_alser_count(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, int, int, unsigned long long *);
 extern "C" __global__ void k_rechain_test(const AlAnchor *, const uint64_t *, const uint64_t *, const uint32_t *, const uint32_t *, const int32_t *, const uint32_t *, int, uint32_t *, uint32_t *);
 // al_kernels_chain.hip
@@ -374,6 +381,8 @@ extern "C" al_ctx_t *al_ctx_init(const al_idx_t *mi, const al_mapopt_t *opt, int
 	    hipEventCreateWithFlags(&c->ev_fj[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_fj[1], hipEventDisableTiming) != hipSuccess) { delete c; return nullptr; }
 	for (int i = 0; i < 3; ++i) if (hipStreamCreateWithPriority(&c->aux[i], hipStreamNonBlocking, sp) != hipSuccess || hipEventCreateWithFlags(&c->ev_aux[i], hipEventDisableTiming) != hipSuccess) { delete c; return nullptr; }
 	for (int i = 0; i < 2; ++i) if (hipStreamCreateWithFlags(&c->ovl[i], hipStreamNonBlocking) != hipSuccess) { delete c; return nullptr; }
+	if (hipStreamCreateWithFlags(&c->spec, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&c->spec2, hipStreamNonBlocking) != hipSuccess) { delete c; return nullptr; }
+	for (int i = 0; i < 3; ++i) if (hipEventCreateWithFlags(&c->ev_spec[i], hipEventDisableTiming) != hipSuccess) { delete c; return nullptr; }
 	for (int i = 0; i < 4; ++i) if (hipEventCreateWithFlags(&c->ev_ovl[i], hipEventDisableTiming) != hipSuccess) { delete c; return nullptr; }
 	if (al_upload_index(mi, device, &c->di) != 0) { delete c; return nullptr; }
 	AlParams &P = c->P;
@@ -394,6 +403,10 @@ static void ctx_release_buffers(al_ctx_t *c)
 	if (c->side) (void)hipStreamSynchronize(c->side);
 	for (int i = 0; i < 3; ++i) if (c->aux[i]) (void)hipStreamSynchronize(c->aux[i]);
 	for (int i = 0; i < 2; ++i) if (c->ovl[i]) (void)hipStreamSynchronize(c->ovl[i]);
+	if (c->spec) (void)hipStreamSynchronize(c->spec);
+	if (c->spec2) (void)hipStreamSynchronize(c->spec2);
+	c->spec_busy = false; c->spec_pending = false; c->n_spec = 0;
+	c->spec_match.release(); c->spec_meta.release(); c->spec_cnt.release(); c->spec_use.release(); c->spec_v32.release(); c->spec_v64.release(); c->spec_anchors.release();
 	if (c->stream) (void)hipStreamSynchronize(c->stream);
 	c->rd_seq.release(); c->rd_len.release(); c->frag_first.release(); c->frag_hash.release(); c->mini_cnt.release(); c->frag_nm.release(); c->frag_na.release();
 	c->frag_nu.release(); c->rechain_list.release(); c->rechain_sorted.release(); c->tmp_u32.release(); c->rd_off.release(); c->mini_off.release(); c->a_off.release(); c->u.release();
@@ -416,6 +429,9 @@ extern "C" void al_ctx_destroy(al_ctx_t *c)
 	for (int i = 0; i < 3; ++i) { if (c->aux[i]) (void)hipStreamDestroy(c->aux[i]); if (c->ev_aux[i]) (void)hipEventDestroy(c->ev_aux[i]); }
 	for (int i = 0; i < 2; ++i) if (c->ovl[i]) (void)hipStreamDestroy(c->ovl[i]);
 	for (int i = 0; i < 4; ++i) if (c->ev_ovl[i]) (void)hipEventDestroy(c->ev_ovl[i]);
+	if (c->spec) (void)hipStreamDestroy(c->spec);
+	if (c->spec2) (void)hipStreamDestroy(c->spec2);
+	for (int i = 0; i < 3; ++i) if (c->ev_spec[i]) (void)hipEventDestroy(c->ev_spec[i]);
 	if (c->stream) (void)hipStreamDestroy(c->stream);
 	delete c;
 }
@@ -851,11 +867,47 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 	if (ev(ST_SEED)) return -1;
 	if (c->chain_key.ensure(nl + 1) || c->chain_idx.ensure(nl + 1) || c->chain_idx2.ensure(nl + 1)) return -1;
 	uint64_t total = 0;
+	// The exact merge of GIANT fragments the re-chain pass may ask for, started now (k_spec_build, al_kernels_seed.hip): AL_SPEC_MERGE=0 turns it off,
+	// AL_SPEC_MIN sets the smallest max_occ anchor count that gets a slot (tests lower it so that ordinary fragments take this path).
+	const uint32_t SPEC_CAP = 256, SPEC_PER = 126;
+	static const bool spec_on = !(getenv("AL_SPEC_MERGE") && atoi(getenv("AL_SPEC_MERGE")) == 0) && !(getenv("AL_HEAP_OLD") && atoi(getenv("AL_HEAP_OLD")) == 1);
+	static const uint32_t spec_min = getenv("AL_SPEC_MIN") ? (uint32_t)atoi(getenv("AL_SPEC_MIN")) : 49152u;
+	uint32_t h_spec[2 + 4 * 256] = {0, 0};
 	if (first) {
+		if (c->spec_busy) { AL_HIP_CHECK(hipStreamSynchronize(c->spec)); AL_HIP_CHECK(hipStreamSynchronize(c->spec2)); c->spec_busy = false; }   // (the previous batch's slots: free again)
+		c->n_spec = 0; c->spec_pending = false;
+		if (spec_on && c->opt.max_occ > c->opt.mid_occ) {
+			const uint32_t SPEC_CAND = 16384;
+			if (c->spec_match.ensure((size_t)SPEC_CAP * SPEC_PER + 1) || c->spec_meta.ensure(4 * SPEC_CAP + 4) || c->spec_cnt.ensure(4) || c->spec_use.ensure(SPEC_CAP + 1) || c->spec_v32.ensure(7 * (SPEC_CAP + 2)) || c->spec_v64.ensure(2 * (SPEC_CAP + 2) + SPEC_CAND)) return -1;
+			AL_HIP_CHECK(hipMemsetAsync(c->spec_cnt.p, 0, 16, s));
+			const SpecOut S{c->spec_match.p, c->spec_meta.p, c->spec_cnt.p, c->spec_v64.p + 2 * (SPEC_CAP + 2), SPEC_CAP, SPEC_PER, SPEC_CAND};
+			hipLaunchKernelGGL(k_spec_count, dim3((c->n_frag + 255) / 256), dim3(256), 0, s, c->di.tab, c->di.tab_bits, c->frag_first.p, c->rd_len.p, c->mini_off.p, (const AlAnchor *)c->mini.p, (const uint32_t *)c->mini_cnt.p,
+			                   (const int32_t *)c->frag_rep.p, c->n_frag, c->opt.max_occ, spec_min, S, c->opt.mid_occ);
+			hipLaunchKernelGGL(k_spec_pick, dim3(64), dim3(256), 0, s, c->di.tab, c->di.tab_bits, c->frag_first.p, c->rd_len.p, c->mini_off.p, (const AlAnchor *)c->mini.p, (const uint32_t *)c->mini_cnt.p, c->opt.max_occ, S);
+			AL_HIP_CHECK(hipMemcpyAsync(h_spec, c->spec_cnt.p, 8, hipMemcpyDeviceToHost, s));
+			AL_HIP_CHECK(hipMemcpyAsync(h_spec + 2, c->spec_meta.p, 16 * SPEC_CAP, hipMemcpyDeviceToHost, s));
+		}
 		AL_HIP_CHECK(hipMemsetAsync(c->frag_na.p + c->n_frag, 0, 4, s));
 		if (scan_u32_to_u64(c, c->frag_na.p, c->a_off.p, c->n_frag)) return -1;
 		AL_HIP_CHECK(hipMemcpyAsync(&total, c->a_off.p + c->n_frag, 8, hipMemcpyDeviceToHost, s));
 		AL_HIP_CHECK(hipStreamSynchronize(s));
+		if (h_spec[0] > 0) {
+			const uint32_t ns = std::min(h_spec[0], SPEC_CAP); uint64_t na = 0;
+			for (uint32_t i = 0; i < ns; ++i) na += h_spec[2 + 4 * i + 2];
+			if (c->spec_anchors.ensure(na + 1) == 0) {
+				uint32_t *v = c->spec_v32.p; const uint32_t st = SPEC_CAP + 2;
+				const SpecView V{v, v + st, v + 2 * st, v + 3 * st, v + 4 * st, v + 5 * st, v + 6 * st, c->spec_v64.p, c->spec_v64.p + st};
+				hipLaunchKernelGGL(k_spec_layout, dim3(1), dim3(64), 0, c->spec, (const uint32_t *)c->spec_meta.p, ns, SPEC_PER, V);
+				AL_HIP_CHECK(hipEventRecord(c->ev_spec[2], c->spec)); AL_HIP_CHECK(hipStreamWaitEvent(c->spec2, c->ev_spec[2], 0));   // (the two list-count classes side by side)
+#define LSPEC(NS, LO) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_anchor_heap_lanes<NS, 16>), dim3(ns), dim3(64), 0, NS == 2 ? c->spec : c->spec2, c->di.pos, (const uint32_t *)V.first, (const uint32_t *)V.rdlen, (const uint64_t *)V.moff, (const AlMatch *)c->spec_match.p, \
+				                                     (const uint32_t *)V.nm, (const uint32_t *)V.na, (const uint64_t *)V.aoff, c->spec_anchors.p, (const uint32_t *)V.tie, (const uint32_t *)V.list, (const uint32_t *)V.n_list, LO, c->counters.p + 23, c->mi->k)
+				LSPEC(2, 63); LSPEC(1, -1);
+#undef LSPEC
+				c->n_spec = ns; c->spec_busy = true;
+				{ static const bool tr = getenv("AL_TRACE") != nullptr; if (tr) { uint32_t mx = 0, mn = 0xffffffffu; for (uint32_t i = 0; i < ns; ++i) { mx = std::max(mx, h_spec[2 + 4 * i + 2]); mn = std::min(mn, h_spec[2 + 4 * i + 2]); }
+				  fprintf(stderr, "[airlift] trace: %u giant fragment(s) of %u candidates (%llu anchors with max_occ, %u ... %u each) merged ahead of the re-chain pass\n", ns, h_spec[1], (unsigned long long)na, mn, mx); } }
+			} else al_nomem_flag() = false;                                  // (no room: the re-chain pass merges them itself)
+		}
 		c->n_anchor_pass1 = total; c->n_anchor_total = total;
 		if (ensure_anchor_space(c, (uint64_t)((double)total * c->anchor_grow_hw) + 1, false)) return -1;
 	} else {
@@ -1028,6 +1080,17 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 		if (c->tie_frags.ensure((size_t)nl + 2) || c->heap_cnt.ensure(4)) return -1;
 		uint32_t *const n_heap_d = c->heap_cnt.p + (first ? 0 : 1);
 		AL_HIP_CHECK(hipMemsetAsync(n_heap_d, 0, 4, c->side));
+		if (!first && c->n_spec > 0) {   // slots of the merge that was started after the first seeding: taken (flag 2) before the merge kernels' list is made, copied in on their own stream
+			const uint32_t st = 256 + 2;
+			AL_HIP_CHECK(hipEventRecord(c->ev_spec[2], c->spec2)); AL_HIP_CHECK(hipStreamWaitEvent(c->spec, c->ev_spec[2], 0));   // (both merge kernels done before the copy)
+			hipLaunchKernelGGL(k_spec_mark, dim3(1), dim3(256), 0, c->side, (const uint32_t *)c->spec_meta.p, c->n_spec, (const uint32_t *)c->frag_nm.p, (const uint32_t *)c->frag_na.p, c->tie_list.p, c->spec_use.p);
+			AL_HIP_CHECK(hipEventRecord(c->ev_spec[0], c->side)); AL_HIP_CHECK(hipStreamWaitEvent(c->spec, c->ev_spec[0], 0));
+			hipLaunchKernelGGL(k_spec_apply, dim3(64, c->n_spec), dim3(256), 0, c->spec, (const uint32_t *)c->spec_meta.p, (const uint32_t *)c->spec_use.p, (const uint64_t *)(c->spec_v64.p + st), (const AlAnchor *)c->spec_anchors.p, (const uint64_t *)c->a_off.p, c->anchors.p);
+			AL_HIP_CHECK(hipEventRecord(c->ev_spec[1], c->spec));
+			c->spec_pending = true;
+			{ static const bool tr = getenv("AL_TRACE") != nullptr; if (tr) { std::vector<uint32_t> u(c->n_spec); AL_HIP_CHECK(hipStreamSynchronize(c->side)); AL_HIP_CHECK(hipMemcpy(u.data(), c->spec_use.p, (size_t)c->n_spec * 4, hipMemcpyDeviceToHost));
+			  uint32_t k = 0; for (uint32_t x : u) k += x; fprintf(stderr, "[airlift] trace: re-chain pass takes %u of the %u merges made ahead\n", k, c->n_spec); } }
+		}
 		hipLaunchKernelGGL(k_collect_flagged_blk, dim3((nl + 255) / 256), dim3(256), 0, c->side, order, nl, (const uint32_t *)c->tie_list.p, c->tie_frags.p, n_heap_d);
 		// the four merge kernels take disjoint fragments and each waits for its slowest one: side by side, on a stream each
 		AL_HIP_CHECK(hipEventRecord(c->ev_fj[0], c->side));
@@ -1078,6 +1141,7 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 	}
 	{   // second round: the fragments whose anchors the side stream merged, any size
 		AL_HIP_CHECK(hipStreamWaitEvent(s, c->ev_side[first ? 1 : 3], 0));
+		if (!first && c->spec_pending) { AL_HIP_CHECK(hipStreamWaitEvent(s, c->ev_spec[1], 0)); c->spec_pending = false; }
 		if (c->tie_frags.ensure((size_t)nl + 2)) return -1;
 		uint32_t *cnt = (uint32_t *)(c->counters.p + 15);
 		AL_HIP_CHECK(hipMemsetAsync(cnt, 0, 8, s));

@@ -13,6 +13,8 @@ BASELINE configs.  N>1: one process per GPU, reads sharded by rank (every rank h
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 """
 import argparse
+import os as _os
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # (read when the HIP runtime starts, as airlift-align sets it: a context has nine streams and a kernel that runs for 100 ms on one must not share a hardware queue with the main stream; the default is 4)
 import ctypes as C
 import json
 import os
