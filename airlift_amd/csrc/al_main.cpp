@@ -227,8 +227,9 @@ int main(int argc, char **argv)
 	}
 	if (world > 1) {   // one process per GPU
 		if (rank < 0 && getenv("RANK")) rank = atoi(getenv("RANK"));
-		if (rank < 0 || rank >= world || !out_path || bam_mode) { fprintf(stderr, "[ERROR] a multi-process run needs --rank r (or RANK) below --world, -o FILE after --world, and SAM output\n"); return 1; }
-		const int rc2 = al_map_file_frag_ranked(mi, (int)reads.size(), reads.data(), &mo, n_threads, out_path, rg, device, rank, world, rendezvous, 0.0);
+		if (rank < 0 || rank >= world || !out_path || bam_mode == 2) { fprintf(stderr, "[ERROR] a multi-process run needs --rank r (or RANK) below --world, -o FILE after --world, and SAM or unsorted BAM output\n"); return 1; }
+		const int rc2 = bam_mode ? al_map_file_frag_ranked_bam(mi, (int)reads.size(), reads.data(), &mo, n_threads, out_path, rg, device, rank, world, rendezvous, 0.0, bam_level)
+		                         : al_map_file_frag_ranked(mi, (int)reads.size(), reads.data(), &mo, n_threads, out_path, rg, device, rank, world, rendezvous, 0.0);
 		al_idx_destroy(mi);
 		fflush(stderr);
 		_exit(rc2 == 0 ? 0 : 1);

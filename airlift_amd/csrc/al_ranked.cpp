@@ -327,8 +327,23 @@ int copy_into(int out_fd, long long off, const char *part_path, long long n)
 
 // One rank of a multi-process run.  out_path: the merged SAM file (rank 0 creates it); rendezvous: a directory every rank sees
 // (default: the output's directory); device < 0: LOCAL_RANK or rank.  Returns 0, negative on error (message on stderr).
+static int map_ranked(const al_idx_t *mi, int n_fn, const char **fn, const al_mapopt_t *opt, int n_threads, const char *out_path, const char *rg,
+                      int device, int rank, int world, const char *rendezvous, double timeout_s, int bam, int bam_level);
 extern "C" int al_map_file_frag_ranked(const al_idx_t *mi, int n_fn, const char **fn, const al_mapopt_t *opt, int n_threads, const char *out_path, const char *rg,
                                        int device, int rank, int world, const char *rendezvous, double timeout_s)
+{
+	return map_ranked(mi, n_fn, fn, opt, n_threads, out_path, rg, device, rank, world, rendezvous, timeout_s, 0, 0);
+}
+// The same with unsorted BAM output (the consumer of AirLift's realign step keeps BAM: 0-align_reads.sh:13): every rank deflates its own records into
+// whole BGZF blocks -- no compressed stream crosses processes --, rank 0's part starts with the header, the last rank's ends with the EOF block, and
+// the parts go behind each other at the exchanged offsets like the SAM parts.
+extern "C" int al_map_file_frag_ranked_bam(const al_idx_t *mi, int n_fn, const char **fn, const al_mapopt_t *opt, int n_threads, const char *out_path, const char *rg,
+                                           int device, int rank, int world, const char *rendezvous, double timeout_s, int bam_level)
+{
+	return map_ranked(mi, n_fn, fn, opt, n_threads, out_path, rg, device, rank, world, rendezvous, timeout_s, 1, bam_level);
+}
+static int map_ranked(const al_idx_t *mi, int n_fn, const char **fn, const al_mapopt_t *opt, int n_threads, const char *out_path, const char *rg,
+                      int device, int rank, int world, const char *rendezvous, double timeout_s, int bam, int bam_level)
 {
 	if (!mi || !fn || !out_path || n_fn < 1 || n_fn > 2 || world < 1 || rank < 0 || rank >= world) return -1;
 	if (timeout_s <= 0) timeout_s = getenv("AL_RANK_TIMEOUT") ? atof(getenv("AL_RANK_TIMEOUT")) : 600.0;
@@ -359,12 +374,14 @@ extern "C" int al_map_file_frag_ranked(const al_idx_t *mi, int n_fn, const char 
 	{ const int e = find_ranges(fn, n_fn, rank, world, std::max(1, n_threads / 2), *ex, &rr); if (e) return e; }   // (every rank leaves here together: local failures travel as a poison word)
 	if (timing) fprintf(stderr, "[airlift] rank %d of %d: records from %lld; bytes [%lld, %lld) of '%s'%s found in %.3f s\n", rank, world, rr.first_record, rr.start[0], rr.end[0], fn[0], n_fn == 2 ? " (and the matching range of the second file)" : "", now_s() - t0);
 	// map my range into a part file
-	const std::string part = std::string(out_path) + ".part" + std::to_string(rank);
+	// (rank 0's offset in the merged file is known: it writes there directly, no part file and no copy; the others learn theirs from the final exchange)
+	const std::string part = rank == 0 ? std::string(out_path) : std::string(out_path) + ".part" + std::to_string(rank);
 	FILE *pf = fopen(part.c_str(), "wb");
 	AlStreamRange range; for (int i = 0; i < 2; ++i) { range.start[i] = rr.start[i]; range.end[i] = rr.end[i]; } range.header = rank == 0;
 	AlStreamResume rs;
 	int rc;
 	if (!pf) { fprintf(stderr, "[airlift] rank %d: cannot create '%s': %s\n", rank, part.c_str(), strerror(errno)); rc = -3; }   // (still joins the exchange below, with ok = 0)
+	else if (bam) rc = al_map_file_frag_bam_part(mi, n_fn, fn, opt, n_threads, pf, rg, device, bam_level, rr.start, rr.end, rank == 0, rank == world - 1);
 	else rc = al_stream_map_files(mi, n_fn, fn, opt, n_threads, pf, rg, &device, 1, &rs, &range);
 	if (rc == AL_STREAM_NA) { fprintf(stderr, "[airlift] rank %d: a multi-process run takes plain (uncompressed, four-line) FASTQ files only\n", rank); rc = -1; }
 	if (rc == 0 && rs.resume) { fprintf(stderr, "[airlift] rank %d: the input is not strict four-line FASTQ at byte %lld: not supported in a multi-process run\n", rank, rs.off[0]); rc = -1; }
@@ -374,16 +391,17 @@ extern "C" int al_map_file_frag_ranked(const al_idx_t *mi, int n_fn, const char 
 	// the exchange of the north star: {ok, bytes} of every part -> offsets
 	uint64_t mine[2] = {rc == 0 ? 1ULL : 0ULL, (uint64_t)my_bytes}; std::vector<uint64_t> all(2 * (size_t)world);
 	int out_fd = -1;
-	if (rank == 0) { out_fd = open(out_path, O_WRONLY | O_CREAT | O_TRUNC, 0644); if (out_fd < 0) { fprintf(stderr, "[airlift] cannot create '%s': %s\n", out_path, strerror(errno)); mine[0] = 0; } }
-	if (ex->allgather(mine, 2, all.data())) { unlink(part.c_str()); if (out_fd >= 0) close(out_fd); return -2; }
+	if (ex->allgather(mine, 2, all.data())) { if (rank != 0) unlink(part.c_str()); return -2; }
 	long long off = 0; bool all_ok = true;
 	for (int r = 0; r < world; ++r) { if (!all[2 * (size_t)r]) all_ok = false; if (r < rank) off += (long long)all[2 * (size_t)r + 1]; }
 	if (all_ok) {
-		if (rank != 0) out_fd = open(out_path, O_WRONLY);
-		if (out_fd < 0 || copy_into(out_fd, off, part.c_str(), my_bytes)) { fprintf(stderr, "[airlift] rank %d: writing its %lld bytes at offset %lld of '%s' failed\n", rank, my_bytes, off, out_path); rc = -3; }
+		if (rank != 0) {
+			out_fd = open(out_path, O_WRONLY);
+			if (out_fd < 0 || copy_into(out_fd, off, part.c_str(), my_bytes)) { fprintf(stderr, "[airlift] rank %d: writing its %lld bytes at offset %lld of '%s' failed\n", rank, my_bytes, off, out_path); rc = -3; }
+		}
 	} else if (rc == 0) { fprintf(stderr, "[airlift] rank %d: another rank failed; no output\n", rank); rc = -4; }
 	if (out_fd >= 0) close(out_fd);
-	unlink(part.c_str());
+	if (rank != 0) unlink(part.c_str()); else if (!all_ok) unlink(out_path);
 	// everybody is done with the exchange files
 	uint64_t fin = rc == 0 ? 1 : 0;
 	if (ex->allgather(&fin, 1, all.data()) == 0) { for (int r = 0; r < world; ++r) if (!all[(size_t)r] && rc == 0) rc = -4; }

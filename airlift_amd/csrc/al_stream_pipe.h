@@ -11,3 +11,6 @@ struct AlStreamRange { long long start[2] = {0, 0}, end[2] = {-1, -1}; bool head
 // input, from rs->off, is for the general reader; the header is out), AL_STREAM_NA, or a negative error.
 int al_stream_map_files(const al_idx_t *mi, int n_fn, const char **fn, const al_mapopt_t *opt, int n_threads, FILE *out, const char *rg,
                         const int *devices, int n_dev, AlStreamResume *rs, const AlStreamRange *range = nullptr);
+// one part of a concatenated unsorted BAM (al_pipeline.cpp): the byte range [start, end) of the inputs through the host driver
+int al_map_file_frag_bam_part(const al_idx_t *mi, int n_fn, const char **fn, const al_mapopt_t *opt, int n_threads, FILE *out, const char *rg, int device, int level,
+                              const long long *start, const long long *end, bool header, bool eof);

@@ -168,6 +168,10 @@ int  al_map_file_frag_multi(const al_idx_t *mi, int n_segs, const char **fn, con
  * those of al_map_file_frag on the whole input. */
 int  al_map_file_frag_ranked(const al_idx_t *mi, int n_segs, const char **fn, const al_mapopt_t *opt, int n_threads, const char *out_path,
                              const char *rg, int device, int rank, int world, const char *rendezvous, double timeout_s);
+/* The same with unsorted BAM output: every rank deflates its own records into whole BGZF blocks (rank 0's part carries the header, the last
+ * rank's the EOF block), the parts go behind each other at the exchanged offsets.  Decoded records = those of al_map_file_frag_bam. */
+int  al_map_file_frag_ranked_bam(const al_idx_t *mi, int n_segs, const char **fn, const al_mapopt_t *opt, int n_threads, const char *out_path,
+                                 const char *rg, int device, int rank, int world, const char *rendezvous, double timeout_s, int bam_level);
 /* Self-test of the range finding of al_map_file_frag_ranked without a GPU: `world` threads act as the ranks; 0 = the ranges tile the
  * files, start at records and pair record for record. */
 int  al_dbg_ranked_selftest(const char *fn1, const char *fn2, int world, const char *dir);

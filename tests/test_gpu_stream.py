@@ -142,6 +142,32 @@ def test_one_process_per_gpu_mode_on_one_gpu(golden_unpacked, tmp_path, world):
     assert b"bytes at offset" in outs[1][1]
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_one_process_per_gpu_mode_writes_bam(golden_unpacked, tmp_path, world):
+    """--bam under --rank / --world (round 5): every rank deflates its own records into whole BGZF blocks, rank 0 writes header and records straight
+    into the merged file, the others' parts go behind it at the exchanged offsets, the last rank's part ends with the EOF block.  The merged file must
+    decode to the header and, record for record, the fields of the single-process SAM (the reference has no BAM writer: bytes are unpinned)."""
+    from bam_util import read_bam, sam_fields
+    from test_gpu_sam import _same_record
+    d, m, exp, rg = _golden(golden_unpacked, "g1_mt150pe")
+    out = tmp_path / "merged.bam"
+    env = dict(os.environ, AL_RUN_ID="b%d" % world, AL_TIMING="1", AL_RANK_TIMEOUT="120")
+    ps = [subprocess.Popen([CLI, "-ax", "sr", "-t", "4", "--device", "0", "--bam", "-K", "100000", "--rank", str(r), "--world", str(world), "--rendezvous", str(tmp_path), "-o", str(out)] + rg + [m["ref"]] + m["reads"],
+                           cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env) for r in range(world)]
+    outs = [p.communicate(timeout=300) for p in ps]
+    assert all(p.returncode == 0 for p in ps), b"\n".join(o[1][-800:] for o in outs).decode()
+    assert not [f for f in os.listdir(tmp_path) if ".part" in f]
+    sam = exp.decode().split("\n")
+    hdr = [l for l in sam if l.startswith("@")]; body = [l for l in sam if l and not l.startswith("@")]
+    text, refs, recs, n_blocks = read_bam(str(out))
+    assert text == "\n".join(hdr) + "\n"
+    names = [n for n, _ in refs]
+    assert len(recs) == len(body) and n_blocks >= world
+    for b, l in zip(recs, body):
+        _same_record(b, sam_fields(l, names))
+    assert out.read_bytes()[-28:] == bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0])   # one EOF block, at the end
+
+
 def test_ranked_mode_takes_rank_and_world_from_the_launcher(golden_unpacked, tmp_path):
     """--ranked: RANK / WORLD_SIZE as torchrun exports them (the default rendezvous directory is the output file's)."""
     d, m, exp, rg = _golden(golden_unpacked, "g2_250pe")
