@@ -2010,8 +2010,11 @@ template <int QMAXJ, int TMAXJ, bool PK = false> struct JobLds {
 };
 
 // DP jobs of one block-count class: 4 jobs per wavefront, all running d_ksw_reg<NB>
+#ifndef AL_WPE_DP
+#define AL_WPE_DP(NB) ((NB) <= 8 ? 4 : (NB) <= 16 ? 3 : 2)
+#endif
 template <int NB, int QMAXJ, int TMAXJ, bool PK = false>
-__global__ void __launch_bounds__(64, (NB <= 4 ? 4 : NB <= 8 ? AL_LB_DP8 : NB <= 12 ? 4 : NB <= 22 ? AL_LB_DP22 : 2))
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AL_WPE_DP(NB), AL_WPE_DP(NB))))
 k_ext_dp(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_off, const uint32_t *__restrict__ rd_len,
          AlignShared G, ExtShared E, const uint32_t *__restrict__ sorted_idx, uint32_t first, uint32_t count,
          uint8_t *__restrict__ gws, size_t gws_stride, size_t p_bytes, size_t cig_words, AlParams P)
@@ -2899,14 +2902,17 @@ int al_run_align_stage(al_ctx_t *c)
 					  const int cap = NB <= 4 ? caps[0] : NB <= 8 ? caps[1] : NB <= 22 ? caps[2] : 2048; if (nbj > cap) nbj = cap; }
 					if (A->gws.ensure((size_t)nbj * 4 * st2 + 64)) return -1;
 #define LAUNCH_DP(NBV) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ext_dp<NBV, 512, NBV * 16>), dim3(nbj), dim3(64), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, G, E, A->job_idx2.p, first, cnt, A->gws.p, st2, pb, cw, c->P)
-#define LAUNCH_DPK(NBV) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ext_dp<NBV, 512, NBV * 16, true>), dim3(nbj), dim3(64), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, G, E, A->job_idx2.p, first, cnt, A->gws.p, st2, pb, cw, c->P)
+// (queries of up to 256 bases -- every short-read set -- get the instance with the smaller query arrays: 12 instead of 14 KB of LDS per block at 16 blocks, a third wavefront per SIMD)
+#define LAUNCH_DPK(NBV) do { if (Lmax <= 256) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ext_dp<NBV, 256, NBV * 16, true>), dim3(nbj), dim3(64), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, G, E, A->job_idx2.p, first, cnt, A->gws.p, st2, pb, cw, c->P); \
+	                         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ext_dp<NBV, 512, NBV * 16, true>), dim3(nbj), dim3(64), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, G, E, A->job_idx2.p, first, cnt, A->gws.p, st2, pb, cw, c->P); } while (0)
 					if (NB == 1) LAUNCH_DP(1); else if (NB == 2) LAUNCH_DP(2); else if (NB == 4) LAUNCH_DP(4); else if (NB == 8) { if (dp_pk) LAUNCH_DPK(8); else LAUNCH_DP(8); } else if (NB == 32) LAUNCH_DP(32);
 					else {   // 9 ... 22 blocks: the sorted slice holds the jobs of <= 12 blocks first, then 13 ... 16, then the rest
 						static const bool split = !getenv("AL_DP_NO_SPLIT");
 						const uint32_t c12 = split ? (uint32_t)std::min<unsigned long long>(sub7[0], cnt) : 0u, c16 = split ? (uint32_t)std::min<unsigned long long>(sub7[1], cnt - c12) : 0u, c22 = cnt - c12 - c16;
 						const uint32_t first0 = first, cnt0 = cnt;
 #define LAUNCH_DPS(NBV, F, N) do { if ((N) > 0) { int nb2 = (int)(((N) + 3) / 4); if (nb2 > nbj) nb2 = nbj; \
-							if (dp_pk) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ext_dp<NBV, 512, NBV * 16, true>), dim3(nb2), dim3(64), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, G, E, A->job_idx2.p, (F), (N), A->gws.p + (size_t)gw_used * 4 * st2, st2, pb, cw, c->P); \
+							if (dp_pk && Lmax <= 256) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ext_dp<NBV, 256, NBV * 16, true>), dim3(nb2), dim3(64), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, G, E, A->job_idx2.p, (F), (N), A->gws.p + (size_t)gw_used * 4 * st2, st2, pb, cw, c->P); \
+							else if (dp_pk) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ext_dp<NBV, 512, NBV * 16, true>), dim3(nb2), dim3(64), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, G, E, A->job_idx2.p, (F), (N), A->gws.p + (size_t)gw_used * 4 * st2, st2, pb, cw, c->P); \
 							else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ext_dp<NBV, 512, NBV * 16>), dim3(nb2), dim3(64), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, G, E, A->job_idx2.p, (F), (N), A->gws.p + (size_t)gw_used * 4 * st2, st2, pb, cw, c->P); gw_used += nb2; } } while (0)
 						// (the three kernels run one after the other on this stream: they may share the workspace range)
 						int gw_used = 0; LAUNCH_DPS(12, first0, c12); AL_HIP_CHECK(hipEventRecord(c->ev[ST_EXT_DP_G12 + 1], s)); gw_used = 0; LAUNCH_DPS(16, first0 + c12, c16); AL_HIP_CHECK(hipEventRecord(c->ev[ST_EXT_DP_G16 + 1], s)); gw_used = 0; LAUNCH_DPS(22, first0 + c12 + c16, c22);
