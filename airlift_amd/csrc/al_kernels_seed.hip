@@ -121,8 +121,10 @@ __device__ __forceinline__ uint64_t d_match_pos(const uint64_t *__restrict__ pos
 // collect_matches (map.c:90-123) of one fragment: its minimizers looked up with `max_occ`; mo == nullptr: counts only
 __device__ __forceinline__ void d_seed_frag(const uint64_t *__restrict__ tab, int tab_bits, const uint32_t *__restrict__ frag_first, const uint32_t *__restrict__ rd_len,
                                             const uint64_t *__restrict__ mini_off, const AlAnchor *__restrict__ mini, const uint32_t *__restrict__ mini_cnt,
-                                            const uint32_t f, const int max_occ, AlMatch *__restrict__ mo, uint32_t &n_m_out, uint32_t &n_a_out, int &rep_out, int &qlen_out)
+                                            const uint32_t f, const int max_occ, AlMatch *__restrict__ mo, uint32_t &n_m_out, uint32_t &n_a_out, int &rep_out, int &qlen_out,
+                                            const int max_occ2 = 0, uint32_t *n_a2_out = nullptr /* anchors there would be with the larger bound max_occ2 (the re-seeding pass's) */)
 {
+	uint32_t n_a2 = 0;
 	const uint32_t r0 = frag_first[f], r1 = frag_first[f + 1];
 	int rep_st = 0, rep_en = 0, rep_len = 0; uint32_t n_m = 0, n_a = 0, sum = 0;
 	uint64_t prev_hash = ~0ULL; int have_prev = 0;
@@ -140,6 +142,7 @@ __device__ __forceinline__ void d_seed_frag(const uint64_t *__restrict__ tab, in
 			const int same_prev = have_prev && prev_hash == hash;
 			if (mo && same_prev && last_valid && last_hash == hash) last->flags |= 1u << 8;   // previous gets "next is same"
 			last_valid = 0;
+			if (occ > 0 && (int)occ < max_occ2) n_a2 += occ;
 			if ((int)occ >= max_occ) {                                       // map.c:105-111
 				const int en = (int)(q_pos >> 1) + 1, st = en - (int)q_span;
 				if (st > rep_en) { rep_len += rep_en - rep_st; rep_st = st, rep_en = en; }
@@ -159,6 +162,7 @@ __device__ __forceinline__ void d_seed_frag(const uint64_t *__restrict__ tab, in
 	}
 	rep_len += rep_en - rep_st;
 	n_m_out = n_m; n_a_out = n_a; rep_out = rep_len; qlen_out = (int)sum;
+	if (n_a2_out) *n_a2_out = n_a2;
 }
 
 extern "C" __global__ void __launch_bounds__(256)
@@ -166,14 +170,15 @@ k_seed(const uint64_t *__restrict__ tab, int tab_bits,
        const uint32_t *__restrict__ frag_first, const uint32_t *__restrict__ rd_len,
        const uint64_t *__restrict__ mini_off, AlAnchor *__restrict__ mini, const uint32_t *__restrict__ mini_cnt,
        AlMatch *__restrict__ match, uint32_t *__restrict__ frag_nm, uint32_t *__restrict__ frag_na, int32_t *__restrict__ frag_rep,
-       const uint32_t *__restrict__ frag_list, int n_list, int max_occ)
+       const uint32_t *__restrict__ frag_list, int n_list, int max_occ, int max_occ2, uint32_t *__restrict__ frag_na2 /* (first pass, may be null) anchors with the re-seeding pass's bound */)
 {
 	const int t = blockIdx.x * blockDim.x + threadIdx.x;
 	if (t >= n_list) return;
 	const uint32_t f = frag_list ? frag_list[t] : (uint32_t)t;
-	uint32_t n_m, n_a; int rep_len, qlen;
-	d_seed_frag(tab, tab_bits, frag_first, rd_len, mini_off, mini, mini_cnt, f, max_occ, match + mini_off[frag_first[f]], n_m, n_a, rep_len, qlen);
+	uint32_t n_m, n_a, n_a2; int rep_len, qlen;
+	d_seed_frag(tab, tab_bits, frag_first, rd_len, mini_off, mini, mini_cnt, f, max_occ, match + mini_off[frag_first[f]], n_m, n_a, rep_len, qlen, frag_na2 ? max_occ2 : 0, &n_a2);
 	frag_nm[f] = n_m; frag_na[f] = n_a; frag_rep[f] = rep_len;
+	if (frag_na2) frag_na2[f] = n_a2;
 }
 
 // ---- the equal-x merge of the few GIANT re-seeded fragments, started ahead of time (round 5) ------------------------------------------------
@@ -189,10 +194,10 @@ struct SpecOut { AlMatch *match; uint32_t *meta /* per slot: fragment, lists, an
 extern "C" __global__ void __launch_bounds__(256)
 k_spec_count(const uint64_t *__restrict__ tab, int tab_bits, const uint32_t *__restrict__ frag_first, const uint32_t *__restrict__ rd_len,
              const uint64_t *__restrict__ mini_off, const AlAnchor *__restrict__ mini, const uint32_t *__restrict__ mini_cnt,
-             const int32_t *__restrict__ frag_rep, int n_frag, int max_occ, uint32_t thr, SpecOut S, int mid_occ)
+             const int32_t *__restrict__ frag_rep, int n_frag, int max_occ, uint32_t thr, SpecOut S, int mid_occ, const uint32_t *__restrict__ frag_na2)
 {
 	const int f = blockIdx.x * blockDim.x + threadIdx.x;
-	if (f >= n_frag || frag_rep[f] <= 0) return;
+	if (f >= n_frag || frag_rep[f] <= 0 || frag_na2[f] < thr) return;       // (k_seed counted the max_occ anchors on its way: the lookups below run for the few candidates only)
 	const uint32_t r0 = frag_first[f], r1 = frag_first[f + 1];
 	if (r1 - r0 > 2) return;
 	uint32_t n_mid[2] = {0, 0};                                             // per mate: minimizers the FIRST pass keeps (a mate without any has no chain there: the usual reason for the re-seeding)
@@ -249,13 +254,14 @@ __global__ void k_spec_layout(const uint32_t *__restrict__ meta, uint32_t n, uin
 	V.first[n] = n; V.moff[n] = (uint64_t)n * per; V.aoff[n] = off; V.n_list[0] = n;
 }
 // re-chain pass, after its sorts: a slot whose fragment was re-seeded to the same lists and flagged for the merge is taken (flag 2: "merged already")
-__global__ void k_spec_mark(const uint32_t *__restrict__ meta, uint32_t n, const uint32_t *__restrict__ frag_nm, const uint32_t *__restrict__ frag_na, uint32_t *__restrict__ tie_flag, uint32_t *__restrict__ use)
+__global__ void k_spec_mark(const uint32_t *__restrict__ meta, uint32_t n, const uint32_t *__restrict__ frag_nm, const uint32_t *__restrict__ frag_na, uint32_t *__restrict__ tie_flag, uint32_t *__restrict__ use,
+                            uint32_t *__restrict__ n_used)
 {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
 	const uint32_t f = meta[4 * i];
 	const bool ok = tie_flag[f] == 1u && frag_nm[f] == meta[4 * i + 1] && frag_na[f] == meta[4 * i + 2];
-	if (ok) tie_flag[f] = 2u;
+	if (ok) { tie_flag[f] = 2u; atomicAdd(n_used, 1u); }
 	use[i] = ok ? 1u : 0u;
 }
 __global__ void __launch_bounds__(256)

@@ -72,8 +72,8 @@ struct al_ctx_s {
 	bool ovl_pending = false;             // chaining kernels in flight on ovl[1]: chain_tiles joins them before it reuses their scratch
 	hipEvent_t ev_side[4] = {};           // [0],[1]: start / end of the side stream's work in the first pass, [2],[3]: in the re-chain pass
 	// the equal-x merge of giant fragments started ahead of the re-chain pass (al_kernels_seed.hip: k_spec_build): its stream, events, slots
-	hipStream_t spec = nullptr, spec2 = nullptr; hipEvent_t ev_spec[3] = {}; uint32_t n_spec = 0; bool spec_pending = false, spec_busy = false;
-	DevBuf<AlMatch> spec_match; DevBuf<uint32_t> spec_meta, spec_cnt, spec_use, spec_v32; DevBuf<uint64_t> spec_v64; DevBuf<AlAnchor> spec_anchors;
+	hipStream_t spec = nullptr, spec2 = nullptr; hipEvent_t ev_spec[3] = {}; uint32_t n_spec = 0, spec_idle = 0, spec_batch = 0; bool spec_pending = false, spec_busy = false;   // spec_idle: batches in a row whose re-chain pass took none of the merges made ahead
+	DevBuf<AlMatch> spec_match; DevBuf<uint32_t> spec_meta, spec_cnt, spec_use, spec_v32, spec_na2; DevBuf<uint64_t> spec_v64; DevBuf<AlAnchor> spec_anchors;
 	float ms_side = 0;
 	AlDevIndex di;
 	hipEvent_t ev[ST_N + 1] = {};

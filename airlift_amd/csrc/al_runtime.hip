@@ -22,13 +22,13 @@
 
 // kernels (al_kernels_seed.hip)
 extern "C" __global__ void k_sketch(const uint32_t *, const uint64_t *, const uint32_t *, const uint64_t *, AlAnchor *, uint32_t *, int, int, int, int);
-extern "C" __global__ void k_seed(const uint64_t *, int, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, const uint32_t *, AlMatch *, uint32_t *, uint32_t *, int32_t *, const uint32_t *, int, int);
+extern "C" __global__ void k_seed(const uint64_t *, int, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, const uint32_t *, AlMatch *, uint32_t *, uint32_t *, int32_t *, const uint32_t *, int, int, int, uint32_t *);
 struct SpecOut { AlMatch *match; uint32_t *meta; uint32_t *cnt; uint64_t *cand; uint32_t cap, per, cand_cap; };
 struct SpecView { uint32_t *first, *rdlen, *nm, *na, *tie, *list, *n_list; uint64_t *moff, *aoff; };
-extern "C" __global__ void k_spec_count(const uint64_t *, int, const uint32_t *, const uint32_t *, const uint64_t *, const AlAnchor *, const uint32_t *, const int32_t *, int, int, uint32_t, SpecOut, int);
+extern "C" __global__ void k_spec_count(const uint64_t *, int, const uint32_t *, const uint32_t *, const uint64_t *, const AlAnchor *, const uint32_t *, const int32_t *, int, int, uint32_t, SpecOut, int, const uint32_t *);
 extern "C" __global__ void k_spec_pick(const uint64_t *, int, const uint32_t *, const uint32_t *, const uint64_t *, const AlAnchor *, const uint32_t *, int, SpecOut);
 __global__ void k_spec_layout(const uint32_t *, uint32_t, uint32_t, SpecView);
-__global__ void k_spec_mark(const uint32_t *, uint32_t, const uint32_t *, const uint32_t *, uint32_t *, uint32_t *);
+__global__ void k_spec_mark(const uint32_t *, uint32_t, const uint32_t *, const uint32_t *, uint32_t *, uint32_t *, uint32_t *);
 __global__ void k_spec_apply(const uint32_t *, const uint32_t *, const uint64_t *, const AlAnchor *, const uint64_t *, AlAnchor *);
 extern "C" __global__ void k_alser_count(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, int, int, unsigned long long *);
 extern "C" __global__ void k_rechain_test(const AlAnchor *, const uint64_t *, const uint64_t *, const uint32_t *, const uint32_t *, const int32_t *, const uint32_t *, int, uint32_t *, uint32_t *);
@@ -406,7 +406,7 @@ static void ctx_release_buffers(al_ctx_t *c)
 	if (c->spec) (void)hipStreamSynchronize(c->spec);
 	if (c->spec2) (void)hipStreamSynchronize(c->spec2);
 	c->spec_busy = false; c->spec_pending = false; c->n_spec = 0;
-	c->spec_match.release(); c->spec_meta.release(); c->spec_cnt.release(); c->spec_use.release(); c->spec_v32.release(); c->spec_v64.release(); c->spec_anchors.release();
+	c->spec_match.release(); c->spec_meta.release(); c->spec_cnt.release(); c->spec_use.release(); c->spec_v32.release(); c->spec_v64.release(); c->spec_anchors.release(); c->spec_na2.release();
 	if (c->stream) (void)hipStreamSynchronize(c->stream);
 	c->rd_seq.release(); c->rd_len.release(); c->frag_first.release(); c->frag_hash.release(); c->mini_cnt.release(); c->frag_nm.release(); c->frag_na.release();
 	c->frag_nu.release(); c->rechain_list.release(); c->rechain_sorted.release(); c->tmp_u32.release(); c->rd_off.release(); c->mini_off.release(); c->a_off.release(); c->u.release();
@@ -862,27 +862,32 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 	const int nl = n_list;
 	if (nl == 0) return 0;
 	auto ev = [&](int st) -> int { if (first) AL_HIP_CHECK(hipEventRecord(c->ev[st + 1], s)); return 0; };
+	static const bool spec_on0 = !(getenv("AL_SPEC_MERGE") && atoi(getenv("AL_SPEC_MERGE")) == 0) && !(getenv("AL_HEAP_OLD") && atoi(getenv("AL_HEAP_OLD")) == 1);
+	// (the merges made ahead cost a few milliseconds of the first pass even when the re-chain pass ends up taking none -- a genome whose re-seeded fragments are
+	//  small: after two such batches in a row a context makes them for every eighth batch only, until one is taken again)
+	if (first) ++c->spec_batch;
+	const bool spec_now = first && spec_on0 && c->opt.max_occ > c->opt.mid_occ && (c->spec_idle < 2 || c->spec_batch % 8 == 0 || getenv("AL_SPEC_MIN") != nullptr);
+	if (spec_now && c->spec_na2.ensure((size_t)c->n_frag + 1)) return -1;
 	hipLaunchKernelGGL(k_seed, dim3((nl + 255) / 256), dim3(256), 0, s, c->di.tab, c->di.tab_bits, c->frag_first.p, c->rd_len.p, c->mini_off.p, c->mini.p, c->mini_cnt.p,
-	                   c->match.p, c->frag_nm.p, c->frag_na.p, c->frag_rep.p, list, nl, max_occ);
+	                   c->match.p, c->frag_nm.p, c->frag_na.p, c->frag_rep.p, list, nl, max_occ, c->opt.max_occ, spec_now ? c->spec_na2.p : (uint32_t *)nullptr);
 	if (ev(ST_SEED)) return -1;
 	if (c->chain_key.ensure(nl + 1) || c->chain_idx.ensure(nl + 1) || c->chain_idx2.ensure(nl + 1)) return -1;
 	uint64_t total = 0;
 	// The exact merge of GIANT fragments the re-chain pass may ask for, started now (k_spec_build, al_kernels_seed.hip): AL_SPEC_MERGE=0 turns it off,
 	// AL_SPEC_MIN sets the smallest max_occ anchor count that gets a slot (tests lower it so that ordinary fragments take this path).
 	const uint32_t SPEC_CAP = 256, SPEC_PER = 126;
-	static const bool spec_on = !(getenv("AL_SPEC_MERGE") && atoi(getenv("AL_SPEC_MERGE")) == 0) && !(getenv("AL_HEAP_OLD") && atoi(getenv("AL_HEAP_OLD")) == 1);
 	static const uint32_t spec_min = getenv("AL_SPEC_MIN") ? (uint32_t)atoi(getenv("AL_SPEC_MIN")) : 49152u;
 	uint32_t h_spec[2 + 4 * 256] = {0, 0};
 	if (first) {
 		if (c->spec_busy) { AL_HIP_CHECK(hipStreamSynchronize(c->spec)); AL_HIP_CHECK(hipStreamSynchronize(c->spec2)); c->spec_busy = false; }   // (the previous batch's slots: free again)
 		c->n_spec = 0; c->spec_pending = false;
-		if (spec_on && c->opt.max_occ > c->opt.mid_occ) {
+		if (spec_now) {
 			const uint32_t SPEC_CAND = 16384;
 			if (c->spec_match.ensure((size_t)SPEC_CAP * SPEC_PER + 1) || c->spec_meta.ensure(4 * SPEC_CAP + 4) || c->spec_cnt.ensure(4) || c->spec_use.ensure(SPEC_CAP + 1) || c->spec_v32.ensure(7 * (SPEC_CAP + 2)) || c->spec_v64.ensure(2 * (SPEC_CAP + 2) + SPEC_CAND)) return -1;
 			AL_HIP_CHECK(hipMemsetAsync(c->spec_cnt.p, 0, 16, s));
 			const SpecOut S{c->spec_match.p, c->spec_meta.p, c->spec_cnt.p, c->spec_v64.p + 2 * (SPEC_CAP + 2), SPEC_CAP, SPEC_PER, SPEC_CAND};
 			hipLaunchKernelGGL(k_spec_count, dim3((c->n_frag + 255) / 256), dim3(256), 0, s, c->di.tab, c->di.tab_bits, c->frag_first.p, c->rd_len.p, c->mini_off.p, (const AlAnchor *)c->mini.p, (const uint32_t *)c->mini_cnt.p,
-			                   (const int32_t *)c->frag_rep.p, c->n_frag, c->opt.max_occ, spec_min, S, c->opt.mid_occ);
+			                   (const int32_t *)c->frag_rep.p, c->n_frag, c->opt.max_occ, spec_min, S, c->opt.mid_occ, (const uint32_t *)c->spec_na2.p);
 			hipLaunchKernelGGL(k_spec_pick, dim3(64), dim3(256), 0, s, c->di.tab, c->di.tab_bits, c->frag_first.p, c->rd_len.p, c->mini_off.p, (const AlAnchor *)c->mini.p, (const uint32_t *)c->mini_cnt.p, c->opt.max_occ, S);
 			AL_HIP_CHECK(hipMemcpyAsync(h_spec, c->spec_cnt.p, 8, hipMemcpyDeviceToHost, s));
 			AL_HIP_CHECK(hipMemcpyAsync(h_spec + 2, c->spec_meta.p, 16 * SPEC_CAP, hipMemcpyDeviceToHost, s));
@@ -891,6 +896,7 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 		if (scan_u32_to_u64(c, c->frag_na.p, c->a_off.p, c->n_frag)) return -1;
 		AL_HIP_CHECK(hipMemcpyAsync(&total, c->a_off.p + c->n_frag, 8, hipMemcpyDeviceToHost, s));
 		AL_HIP_CHECK(hipStreamSynchronize(s));
+		if (spec_now && h_spec[0] == 0) ++c->spec_idle;                        // no candidate at all
 		if (h_spec[0] > 0) {
 			const uint32_t ns = std::min(h_spec[0], SPEC_CAP); uint64_t na = 0;
 			for (uint32_t i = 0; i < ns; ++i) na += h_spec[2 + 4 * i + 2];
@@ -1083,7 +1089,7 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 		if (!first && c->n_spec > 0) {   // slots of the merge that was started after the first seeding: taken (flag 2) before the merge kernels' list is made, copied in on their own stream
 			const uint32_t st = 256 + 2;
 			AL_HIP_CHECK(hipEventRecord(c->ev_spec[2], c->spec2)); AL_HIP_CHECK(hipStreamWaitEvent(c->spec, c->ev_spec[2], 0));   // (both merge kernels done before the copy)
-			hipLaunchKernelGGL(k_spec_mark, dim3(1), dim3(256), 0, c->side, (const uint32_t *)c->spec_meta.p, c->n_spec, (const uint32_t *)c->frag_nm.p, (const uint32_t *)c->frag_na.p, c->tie_list.p, c->spec_use.p);
+			hipLaunchKernelGGL(k_spec_mark, dim3(1), dim3(256), 0, c->side, (const uint32_t *)c->spec_meta.p, c->n_spec, (const uint32_t *)c->frag_nm.p, (const uint32_t *)c->frag_na.p, c->tie_list.p, c->spec_use.p, c->spec_cnt.p + 2);
 			AL_HIP_CHECK(hipEventRecord(c->ev_spec[0], c->side)); AL_HIP_CHECK(hipStreamWaitEvent(c->spec, c->ev_spec[0], 0));
 			hipLaunchKernelGGL(k_spec_apply, dim3(64, c->n_spec), dim3(256), 0, c->spec, (const uint32_t *)c->spec_meta.p, (const uint32_t *)c->spec_use.p, (const uint64_t *)(c->spec_v64.p + st), (const AlAnchor *)c->spec_anchors.p, (const uint64_t *)c->a_off.p, c->anchors.p);
 			AL_HIP_CHECK(hipEventRecord(c->ev_spec[1], c->spec));
@@ -1146,9 +1152,11 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 		uint32_t *cnt = (uint32_t *)(c->counters.p + 15);
 		AL_HIP_CHECK(hipMemsetAsync(cnt, 0, 8, s));
 		hipLaunchKernelGGL(k_collect_flagged, dim3((nl + 255) / 256), dim3(256), 0, s, order, nl, (const uint32_t *)c->tie_list.p, c->tie_frags.p, cnt);
-		uint32_t n_tie = 0;
+		uint32_t n_tie = 0, n_spec_used = 0;
 		AL_HIP_CHECK(hipMemcpyAsync(&n_tie, cnt, 4, hipMemcpyDeviceToHost, s));
+		if (!first && c->n_spec > 0) AL_HIP_CHECK(hipMemcpyAsync(&n_spec_used, c->spec_cnt.p + 2, 4, hipMemcpyDeviceToHost, s));
 		AL_HIP_CHECK(hipStreamSynchronize(s));
+		if (!first && c->n_spec > 0) c->spec_idle = n_spec_used ? 0u : c->spec_idle + 1u;
 		if (n_tie > 0) {
 			size_t bytes = 0;    // ascending fragment ids: a deterministic order (the collection above appends atomically)
 			if (c->tie_sorted.ensure((size_t)n_tie + 2)) return -1;
@@ -1189,6 +1197,7 @@ int al_run_seed_stages(al_ctx_t *c)
 		AL_HIP_CHECK(hipMemcpyAsync(&n, cnt, 4, hipMemcpyDeviceToHost, s));
 		AL_HIP_CHECK(hipStreamSynchronize(s));
 		c->n_rechain = n;
+		if (n == 0 && c->n_spec > 0) ++c->spec_idle;                             // (no re-chain pass: nothing taken)
 		if (n > 0) {
 			if (c->a_off_p1.ensure(c->n_frag + 2) || c->frag_na_p1.ensure(c->n_frag + 1) || c->frag_rep_p1.ensure(c->n_frag + 1)) return -1;
 			AL_HIP_CHECK(hipMemcpyAsync(c->a_off_p1.p, c->a_off.p, (size_t)(c->n_frag + 1) * 8, hipMemcpyDeviceToDevice, s));
