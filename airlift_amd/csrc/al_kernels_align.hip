@@ -1483,11 +1483,11 @@ __device__ __forceinline__ void d_align_frags(GroupLds<TMAX, QMAX> &L, const int
 {
 	GroupWs ws;
 	{
-		uint8_t *base = gws + ((size_t)blockIdx.x * AL_GPB + g) * gws_stride;
+		uint8_t *base = gws + ((size_t)blockIdx.x * (blockDim.x / GW) + g) * gws_stride;   // (groups per block from the launch: a short list runs ONE group per wavefront, see launch_mono)
 		ws.p = base; ws.cig = (uint32_t *)(base + p_bytes); ws.ezc = ws.cig + cig_words; ws.sc = (uint64_t *)(ws.ezc + cig_words); ws.dbg = G.dbg;
 	}
 	const long long tK0 = PROF_ON(P) ? clock64() : 0;
-	for (int fi = blockIdx.x * AL_GPB + g; fi < n_list; fi += gridDim.x * AL_GPB) {
+	for (int fi = blockIdx.x * (int)(blockDim.x / GW) + g; fi < n_list; fi += gridDim.x * (int)(blockDim.x / GW)) {
 		const int f = frag_list ? (int)frag_list[fi] : fi;
 		const uint32_t r0 = frag_first[f], n_segs = frag_first[f + 1] - r0, n_u = W.frag_nu[f];
 		if (n_u == 0) continue;
@@ -2776,10 +2776,16 @@ int al_run_align_stage(al_ctx_t *c)
 	}
 	auto launch_mono = [&](const uint32_t *list, int n_list, hipStream_t st, uint8_t *wsp, int nb) -> int {      // monolithic kernel (whole batch, or the slow-path list)
 		int nbm = (n_list + AL_GPB - 1) / AL_GPB; if (nbm > nb) nbm = nb; if (nbm < 1) nbm = 1;
+		// A short list (the z-drop fragments of a batch: tens) runs ONE fragment per wavefront: the four groups of a wavefront each walk their own fragment's
+		// hits and DP calls, i.e. four divergent code paths executed one after the other -- and the stage waits for the slowest fragment (C5: 70 fragments,
+		// 111 ms).  Sixteen lanes of a wavefront alone run it up to four times as fast; the chip has room for a few hundred such wavefronts.
+		const bool solo = !long_mode && n_list > 0 && n_list <= nb * AL_GPB && n_list <= 512;
+		const dim3 blk(solo ? GW : GW * AL_GPB);
+		if (solo) nbm = n_list;
 		if (long_mode) hipLaunchKernelGGL(k_align_long, dim3(nbm), dim3(GW * AL_GPB), 0, st, c->rd_seq.p, c->rd_off.p, c->rd_len.p, c->frag_first.p, c->frag_rep.p, W, G, lt, wsp, stride, p_bytes, cig_words, nf, c->P, list, n_list, (GroupLong *)A->long_state.p);
-		else if (tmax == 336) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_align<336, 160>), dim3(nbm), dim3(GW * AL_GPB), 0, st, c->rd_seq.p, c->rd_off.p, c->rd_len.p, c->frag_first.p, c->frag_rep.p, W, G, lt, wsp, stride, p_bytes, cig_words, nf, c->P, list, n_list);
-		else if (tmax == 512) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_align<512, 256>), dim3(nbm), dim3(GW * AL_GPB), 0, st, c->rd_seq.p, c->rd_off.p, c->rd_len.p, c->frag_first.p, c->frag_rep.p, W, G, lt, wsp, stride, p_bytes, cig_words, nf, c->P, list, n_list);
-		else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_align<1024, 512>), dim3(nbm), dim3(GW * AL_GPB), 0, st, c->rd_seq.p, c->rd_off.p, c->rd_len.p, c->frag_first.p, c->frag_rep.p, W, G, lt, wsp, stride, p_bytes, cig_words, nf, c->P, list, n_list);
+		else if (tmax == 336) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_align<336, 160>), dim3(nbm), blk, 0, st, c->rd_seq.p, c->rd_off.p, c->rd_len.p, c->frag_first.p, c->frag_rep.p, W, G, lt, wsp, stride, p_bytes, cig_words, nf, c->P, list, n_list);
+		else if (tmax == 512) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_align<512, 256>), dim3(nbm), blk, 0, st, c->rd_seq.p, c->rd_off.p, c->rd_len.p, c->frag_first.p, c->frag_rep.p, W, G, lt, wsp, stride, p_bytes, cig_words, nf, c->P, list, n_list);
+		else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_align<1024, 512>), dim3(nbm), blk, 0, st, c->rd_seq.p, c->rd_off.p, c->rd_len.p, c->frag_first.p, c->frag_rep.p, W, G, lt, wsp, stride, p_bytes, cig_words, nf, c->P, list, n_list);
 		return 0;
 	};
 	if (((c->P.dbg >> 26) & 1) || long_mode) { if (A->gws.ensure((size_t)nb * AL_GPB * stride + 64)) return -1; if (launch_mono(nullptr, nf, s, A->gws.p, nb)) return -1; for (int i = ST_EXT_PREP; i <= ST_EXT_FINISH; ++i) AL_HIP_CHECK(hipEventRecord(c->ev[i + 1], s)); }   // AL_DBG bit 26: whole batch through the monolithic kernel
