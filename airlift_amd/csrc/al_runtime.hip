@@ -23,6 +23,9 @@
 // kernels (al_kernels_seed.hip)
 extern "C" __global__ void k_sketch(const uint32_t *, const uint64_t *, const uint32_t *, const uint64_t *, AlAnchor *, uint32_t *, int, int, int, int);
 extern "C" __global__ void k_seed(const uint64_t *, int, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, const uint32_t *, AlMatch *, uint32_t *, uint32_t *, int32_t *, const uint32_t *, int, int, int, uint32_t *);
+#ifndef AL_SPEC_CAP
+#define AL_SPEC_CAP 512            // slots of the merges made ahead of the re-chain pass
+#endif
 struct SpecOut { AlMatch *match; uint32_t *meta; uint32_t *cnt; uint64_t *cand; uint32_t cap, per, cand_cap; };
 struct SpecView { uint32_t *first, *rdlen, *nm, *na, *tie, *list, *n_list; uint64_t *moff, *aoff; };
 extern "C" __global__ void k_spec_count(const uint64_t *, int, const uint32_t *, const uint32_t *, const uint64_t *, const AlAnchor *, const uint32_t *, const int32_t *, int, int, uint32_t, SpecOut, int, const uint32_t *);
@@ -875,9 +878,9 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 	uint64_t total = 0;
 	// The exact merge of GIANT fragments the re-chain pass may ask for, started now (k_spec_build, al_kernels_seed.hip): AL_SPEC_MERGE=0 turns it off,
 	// AL_SPEC_MIN sets the smallest max_occ anchor count that gets a slot (tests lower it so that ordinary fragments take this path).
-	const uint32_t SPEC_CAP = 256, SPEC_PER = 126;
+	constexpr uint32_t SPEC_CAP = AL_SPEC_CAP, SPEC_PER = 126;
 	static const uint32_t spec_min = getenv("AL_SPEC_MIN") ? (uint32_t)atoi(getenv("AL_SPEC_MIN")) : 49152u;
-	uint32_t h_spec[2 + 4 * 256] = {0, 0};
+	uint32_t h_spec[2 + 4 * AL_SPEC_CAP] = {0, 0};
 	if (first) {
 		if (c->spec_busy) { AL_HIP_CHECK(hipStreamSynchronize(c->spec)); AL_HIP_CHECK(hipStreamSynchronize(c->spec2)); c->spec_busy = false; }   // (the previous batch's slots: free again)
 		c->n_spec = 0; c->spec_pending = false;
@@ -1087,9 +1090,9 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 		uint32_t *const n_heap_d = c->heap_cnt.p + (first ? 0 : 1);
 		AL_HIP_CHECK(hipMemsetAsync(n_heap_d, 0, 4, c->side));
 		if (!first && c->n_spec > 0) {   // slots of the merge that was started after the first seeding: taken (flag 2) before the merge kernels' list is made, copied in on their own stream
-			const uint32_t st = 256 + 2;
+			const uint32_t st = AL_SPEC_CAP + 2;
 			AL_HIP_CHECK(hipEventRecord(c->ev_spec[2], c->spec2)); AL_HIP_CHECK(hipStreamWaitEvent(c->spec, c->ev_spec[2], 0));   // (both merge kernels done before the copy)
-			hipLaunchKernelGGL(k_spec_mark, dim3(1), dim3(256), 0, c->side, (const uint32_t *)c->spec_meta.p, c->n_spec, (const uint32_t *)c->frag_nm.p, (const uint32_t *)c->frag_na.p, c->tie_list.p, c->spec_use.p, c->spec_cnt.p + 2);
+			hipLaunchKernelGGL(k_spec_mark, dim3((AL_SPEC_CAP + 255) / 256), dim3(256), 0, c->side, (const uint32_t *)c->spec_meta.p, c->n_spec, (const uint32_t *)c->frag_nm.p, (const uint32_t *)c->frag_na.p, c->tie_list.p, c->spec_use.p, c->spec_cnt.p + 2);
 			AL_HIP_CHECK(hipEventRecord(c->ev_spec[0], c->side)); AL_HIP_CHECK(hipStreamWaitEvent(c->spec, c->ev_spec[0], 0));
 			hipLaunchKernelGGL(k_spec_apply, dim3(64, c->n_spec), dim3(256), 0, c->spec, (const uint32_t *)c->spec_meta.p, (const uint32_t *)c->spec_use.p, (const uint64_t *)(c->spec_v64.p + st), (const AlAnchor *)c->spec_anchors.p, (const uint64_t *)c->a_off.p, c->anchors.p);
 			AL_HIP_CHECK(hipEventRecord(c->ev_spec[1], c->spec));
