@@ -136,6 +136,7 @@ struct ChainSeg {
 };
 
 #define AL_ORD_CAP 8192                   // chains of a fragment whose exact order k_chain_order restates in LDS (14 bytes each)
+#define AL_ORD_CAP2 16128                 // (x, id) pairs of the block form of k_chain_order in LDS for the sort restatement (10 bytes each; the 160 KB of a CU less the sort's scratch)
 struct LbThr { uint32_t v[16]; int n; };     // thresholds of k_lower_bounds
 
 // one HIP-event interval per entry; where a stage is several kernels (chaining and extension DP are dispatched by size class)

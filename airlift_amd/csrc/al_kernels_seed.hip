@@ -1910,19 +1910,26 @@ template __global__ void k_seg_merge<8>(const uint32_t *, int, const uint64_t *,
 // descending, in LDS, (2) loads the x keys in that order, (3) lane 0 restates the radix sort on the (x, id) pairs, (4) the wavefront
 // writes chain list and chained anchors in the resulting order.  More chains than the LDS tile: fb2_list (whole-fragment kernel).
 
-__global__ void __launch_bounds__(64)
-k_chain_order(const uint32_t *__restrict__ fb_list, int n_fb, const uint64_t *__restrict__ a_off, const uint32_t *__restrict__ frag_nu,
+
+// (round 5) the same by a block of NWV wavefronts for the fragments with many chains: the bitonic steps and the copies are spread over the block (a
+// 16 000-chain fragment of a re-seeded repeat pair took one wavefront 21 ms of dependent global-memory steps), the two prefix passes and the
+// restatement of the reference's sort stay with the first wavefront.
+#define CO_SYNC() do { __threadfence_block(); if (NWV > 1) __syncthreads(); } while (0)
+template <int NWV>
+__global__ void __launch_bounds__(64 * NWV)
+k_chain_order_t(const uint32_t *__restrict__ fb_list, int n_fb, const uint64_t *__restrict__ a_off, const uint32_t *__restrict__ frag_nu,
               uint64_t *__restrict__ u_all, AlAnchor *__restrict__ chained, const uint64_t *__restrict__ okey,
               uint64_t *__restrict__ u_tmp, AlAnchor *__restrict__ chain_tmp, uint32_t *__restrict__ fb2_list, uint32_t *__restrict__ fb2_cnt,
-              int32_t *__restrict__ ws_i32 /* chaining scratch, 16 bytes per anchor, free here */)
+              int32_t *__restrict__ ws_i32 /* chaining scratch, 16 bytes per anchor, free here */, int nu_lo /* fragments of nu_lo <= chains < nu_hi */, int nu_hi)
 {
 	extern __shared__ __align__(16) unsigned char s_raw[];
 	__shared__ uint16_t s_rs[AL_RS_SCRATCH / 2];
-	const int lane = threadIdx.x;
+	const int lane = threadIdx.x & 63, tid = threadIdx.x, wv = threadIdx.x >> 6; constexpr int NT = 64 * NWV;
 	if ((int)blockIdx.x >= n_fb) return;
 	const uint32_t f = fb_list[blockIdx.x];
 	const int n_u = (int)frag_nu[f];
-	if (n_u > 65535) { if (lane == 0) fb2_list[atomicAdd(fb2_cnt, 1u)] = f; return; }   // beyond the 16-bit chain ids of the sort restatement
+	if (n_u < nu_lo || n_u >= nu_hi) return;                                 // (the other instance's)
+	if (n_u > 65535) { if (tid == 0) fb2_list[atomicAdd(fb2_cnt, 1u)] = f; return; }   // beyond the 16-bit chain ids of the sort restatement
 	int npow2 = 1; while (npow2 < n_u) npow2 <<= 1;
 	// keys, offsets and ids in LDS for up to AL_ORD_CAP chains; more (a read pair inside a high-copy family, re-seeded with max_occ: tens
 	// of thousands of chains) use the fragment's range of the chaining scratch: a chain has >= 2 anchors, so 10 npow2 + 4 n_u < 12 n bytes
@@ -1933,7 +1940,7 @@ k_chain_order(const uint32_t *__restrict__ fb_list, int n_fb, const uint64_t *__
 	uint64_t *u = u_all + a_off[f] + f; AlAnchor *b = chained + a_off[f];
 	const uint64_t *ok = okey + a_off[f];
 	// offsets of the chains' anchors in the merged order (running sum of the counts)
-	{
+	if (wv == 0) {
 		uint32_t run = 0;
 		for (int c0 = 0; c0 < n_u; c0 += 64) {
 			const int c = c0 + lane; const uint32_t cnt = c < n_u ? (uint32_t)u[c] : 0u;
@@ -1942,19 +1949,24 @@ k_chain_order(const uint32_t *__restrict__ fb_list, int n_fb, const uint64_t *__
 			run += __shfl(incl, 63);
 		}
 	}
-	for (int c = lane; c < npow2; c += 64) { key[c] = c < n_u ? ok[c] : 0; id[c] = (uint16_t)c; }
-	__threadfence_block();
+	for (int c = tid; c < npow2; c += NT) { key[c] = c < n_u ? ok[c] : 0; id[c] = (uint16_t)c; }
+	CO_SYNC();
 	for (int kk = 2; kk <= npow2; kk <<= 1)                                  // (1) descending by processing key (keys are distinct: distinct peak anchors)
 		for (int j = kk >> 1; j > 0; j >>= 1) {
-			for (int i = lane; i < npow2; i += 64) {
+			for (int i = tid; i < npow2; i += NT) {
 				const int ixj = i ^ j;
 				if (ixj > i) { const uint64_t x = key[i], y = key[ixj]; if ((x < y) == ((i & kk) == 0)) { key[i] = y; key[ixj] = x; const uint16_t t = id[i]; id[i] = id[ixj]; id[ixj] = t; } }
 			}
-			__threadfence_block();
+			CO_SYNC();
 		}
-	for (int i = lane; i < n_u; i += 64) key[i] = b[off[id[i]]].x;           // (2) x of the chain's first anchor
-	__threadfence_block();
-	{                                                                         // (3) by the wavefront: counts and small buckets in parallel, the permutation by lane 0
+	if (NWV > 1 && n_u > AL_ORD_CAP && n_u <= AL_ORD_CAP2) {                  // sorted in the scratch; (x, id) pairs fit the tile without the offsets: the serial
+		uint64_t *key2 = (uint64_t *)s_raw; uint16_t *id2 = (uint16_t *)(key2 + AL_ORD_CAP2);   // permutation of (3) then takes LDS steps instead of global-memory ones
+		for (int i = tid; i < n_u; i += NT) { const uint16_t c = id[i]; id2[i] = c; key2[i] = b[off[c]].x; }
+		key = key2; id = id2;
+	} else
+	for (int i = tid; i < n_u; i += NT) key[i] = b[off[id[i]]].x;           // (2) x of the chain's first anchor
+	CO_SYNC();
+	if (wv == 0) {                                                            // (3) by the first wavefront: counts and small buckets in parallel, the permutation by lane 0
 		struct KI { uint64_t k; uint16_t i; };
 		struct { typedef KI E; uint64_t *k; uint16_t *i;
 		         __device__ __forceinline__ uint64_t keyof(const KI &e) const { return e.k; }
@@ -1963,22 +1975,35 @@ k_chain_order(const uint32_t *__restrict__ fb_list, int n_fb, const uint64_t *__
 		         __device__ __forceinline__ void set(int j, const KI &e) { k[j] = e.k; i[j] = e.i; } } acc{key, id};
 		(void)d_rs_sort_wave(acc, n_u, s_rs, lane);
 	}
-	__threadfence_block();
+	CO_SYNC();
 	// (4) new chain list and anchors into the fragment's scratch ranges, then back
 	uint64_t *ut = u_tmp + a_off[f]; AlAnchor *bt = chain_tmp + a_off[f];
-	{
+	__shared__ uint32_t s_run;
+	if (wv == 0) {
 		uint32_t run = 0;
 		for (int c0 = 0; c0 < n_u; c0 += 64) {
 			const int i = c0 + lane; const int c = i < n_u ? (int)id[i] : 0; const uint64_t uc = i < n_u ? u[c] : 0; const uint32_t cnt = (uint32_t)uc;
 			uint32_t incl = cnt; for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(incl, d); if (lane >= d) incl += t; }
-			if (i < n_u) { ut[i] = uc; const uint32_t o = run + incl - cnt, so = off[c]; for (uint32_t j = 0; j < cnt; ++j) bt[o + j] = b[so + j]; }
+			if (i < n_u) { ut[i] = uc; key[i] = (uint64_t)(run + incl - cnt) << 32 | off[c]; }   // (the sorted keys are done with: new and old offset)
 			run += __shfl(incl, 63);
 		}
-		__threadfence_block();
-		for (int i = lane; i < n_u; i += 64) u[i] = ut[i];
-		for (uint32_t t = lane; t < run; t += 64) b[t] = bt[t];
+		if (lane == 0) s_run = run;
+	}
+	CO_SYNC();
+	for (int i = tid; i < n_u; i += NT) {
+		const uint32_t cnt = (uint32_t)ut[i], o = (uint32_t)(key[i] >> 32), so = (uint32_t)key[i];
+		for (uint32_t j = 0; j < cnt; ++j) bt[o + j] = b[so + j];
+	}
+	CO_SYNC();
+	{
+		const uint32_t run = s_run;
+		for (int i = tid; i < n_u; i += NT) u[i] = ut[i];
+		for (uint32_t t = tid; t < run; t += NT) b[t] = bt[t];
 	}
 }
+#undef CO_SYNC
+template __global__ void k_chain_order_t<1>(const uint32_t *, int, const uint64_t *, const uint32_t *, uint64_t *, AlAnchor *, const uint64_t *, uint64_t *, AlAnchor *, uint32_t *, uint32_t *, int32_t *, int, int);
+template __global__ void k_chain_order_t<16>(const uint32_t *, int, const uint64_t *, const uint32_t *, uint64_t *, AlAnchor *, const uint64_t *, uint64_t *, AlAnchor *, uint32_t *, uint32_t *, int32_t *, int, int);
 
 // list entries whose fragment is flagged, appended to out block by block: inside a block of 256 entries the order of the list is kept
 // (the list is ordered by anchor count: the lanes of a wavefront that walks `out` get fragments of similar size)

@@ -59,7 +59,7 @@ __global__ void k_anchor_big_expand(const uint64_t *, const uint64_t *, const ui
 __global__ void k_anchor_big_scatter(const uint64_t *, const uint32_t *, int, const uint64_t *, const uint64_t *, const uint64_t *, const uint32_t *, const uint32_t *, const AlMatch *, const uint32_t *, AlAnchor *, uint32_t *, int, int, int);
 template <int NW> __global__ void k_seg_scan(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *, int, AlParams, int, int, const uint64_t *, const uint64_t *, uint32_t *, uint32_t *, uint64_t *, uint32_t *, uint32_t *, const uint32_t *, uint32_t *, uint32_t *, uint32_t *, int, int);
 template <int NW> __global__ void k_seg_merge(const uint32_t *, int, const uint64_t *, const uint64_t *, const uint4 *, const uint64_t *, const AlAnchor *, const uint64_t *, uint64_t *, AlAnchor *, uint32_t *, uint32_t *, uint32_t *, const uint32_t *, const uint64_t *, uint64_t *, int, int);
-__global__ void k_chain_order(const uint32_t *, int, const uint64_t *, const uint32_t *, uint64_t *, AlAnchor *, const uint64_t *, uint64_t *, AlAnchor *, uint32_t *, uint32_t *, int32_t *);
+template <int NWV> __global__ void k_chain_order_t(const uint32_t *, int, const uint64_t *, const uint32_t *, uint64_t *, AlAnchor *, const uint64_t *, uint64_t *, AlAnchor *, uint32_t *, uint32_t *, int32_t *, int, int);
 __global__ void k_lower_bounds(const uint32_t *, uint32_t, LbThr, uint32_t *);
 __global__ void k_collect_flagged(const uint32_t *, int, const uint32_t *, uint32_t *, uint32_t *);
 __global__ void k_collect_flagged_blk(const uint32_t *, int, const uint32_t *, uint32_t *, uint32_t *);
@@ -702,11 +702,17 @@ static int chain_by_segments(al_ctx_t *c, const uint32_t *order, int n, bool lds
 	c->n_chain_fallback += n_fb;
 	const uint32_t *fb = c->fb_list.p;
 	if (n_fb > 0 && keep_keys) {   // order restated from the merged chains and their processing keys; only what does not fit its tile is chained again
-		const size_t lds = (size_t)AL_ORD_CAP * (8 + 4 + 2) + 64;
-		if (!c->attr_chain_order) { AL_HIP_CHECK(hipFuncSetAttribute((const void *)k_chain_order, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); c->attr_chain_order = true; }
+		const size_t lds = (size_t)AL_ORD_CAP * (8 + 4 + 2) + 64, lds16 = (size_t)AL_ORD_CAP2 * (8 + 2) + 64;   // (lds16 >= lds: the block form keeps the one-wavefront layout up to AL_ORD_CAP chains)
+		static const int nu_block = getenv("AL_ORDER_BLOCK") ? atoi(getenv("AL_ORDER_BLOCK")) : 512;             // chains from which a block of 16 wavefronts takes the fragment
+		if (!c->attr_chain_order) {
+			AL_HIP_CHECK(hipFuncSetAttribute((const void *)k_chain_order_t<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+			AL_HIP_CHECK(hipFuncSetAttribute((const void *)k_chain_order_t<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16));
+			c->attr_chain_order = true;
+		}
 		if (c->fb2_list.ensure((size_t)n_fb + 2)) return -1;
 		AL_HIP_CHECK(hipMemsetAsync(fb_cnt, 0, 8, s));
-		hipLaunchKernelGGL(k_chain_order, dim3(n_fb), dim3(64), lds, s, c->fb_list.p, (int)n_fb, c->a_off.p, c->frag_nu.p, c->u.p, c->chained.p, (const uint64_t *)c->ws_u64.p, c->u_tmp.p, c->chain_tmp.p, c->fb2_list.p, fb_cnt, c->ws_i32.p);
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain_order_t<16>), dim3(n_fb), dim3(1024), lds16, s, c->fb_list.p, (int)n_fb, c->a_off.p, c->frag_nu.p, c->u.p, c->chained.p, (const uint64_t *)c->ws_u64.p, c->u_tmp.p, c->chain_tmp.p, c->fb2_list.p, fb_cnt, c->ws_i32.p, nu_block, 1 << 30);
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain_order_t<1>), dim3(n_fb), dim3(64), lds, s, c->fb_list.p, (int)n_fb, c->a_off.p, c->frag_nu.p, c->u.p, c->chained.p, (const uint64_t *)c->ws_u64.p, c->u_tmp.p, c->chain_tmp.p, c->fb2_list.p, fb_cnt, c->ws_i32.p, 0, nu_block);
 		AL_HIP_CHECK(hipMemcpyAsync(&n_fb, fb_cnt, 4, hipMemcpyDeviceToHost, s));
 		AL_HIP_CHECK(hipStreamSynchronize(s));
 		fb = c->fb2_list.p;
