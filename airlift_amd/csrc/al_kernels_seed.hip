@@ -1061,6 +1061,205 @@ k_anchor_big_scatter(const uint64_t *__restrict__ keys, const uint32_t *__restri
 	if (tie) tie_list[f] = 1u;                                             // equal x: merged again by k_anchor_heap (exact heap order)
 }
 
+// (round 5) The same fragments WITHOUT the device-wide sort: runs of AL_RUN_CAP = 8192 anchors are sorted by the register network above (a block per run, keys
+// only, into the key buffer), then merged pairwise -- run length 8192, 16384, ... -- by k_anchor_run_merge: a block per AL_MERGE_TILE = 2048 output keys finds
+// the tile's two input ranges by binary search (merge path), stages them in LDS, every thread merges eight outputs from its own diagonal.  A fragment of n
+// anchors takes ceil(log2(ceil(n / 8192))) passes -- one for <= 16384 anchors, three for <= 65536 -- of 8 bytes in and out per anchor, instead of the
+// expansion, seven radix passes over rank | x and the scatter; its last pass writes the anchors (x, y rebuilt from the list's match record) and raises the
+// tie flag for equal x.  The keys carry the list in the low 16 bits, so no two are equal and the merge needs no stability rule.
+// The entry of a block: largest i with off[i] <= block (off = running sum of the tiles per fragment, n + 1 entries).
+#define AL_RUN_CAP 8192
+#define AL_MERGE_TILE 2048
+__device__ __forceinline__ uint32_t d_entry_of(const uint64_t *__restrict__ off, int n, uint64_t b)
+{
+	uint32_t lo = 0, hi = (uint32_t)n;
+	while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (off[mid] <= b) lo = mid; else hi = mid; }
+	return lo;
+}
+__global__ void k_big_tiles(const uint32_t *__restrict__ na, int n, uint32_t *__restrict__ nt, unsigned int *__restrict__ max_na, const uint32_t tile)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i > n) return;
+	const uint32_t v = i < n ? na[i] : 0u;
+	nt[i] = (v + tile - 1) / tile;                                            // (nt[n] = 0: the scan's pad)
+	if (i < n) atomicMax(max_na, v);
+}
+__global__ void k_big_tile_ent(const uint64_t *__restrict__ tile_off, int n_list, uint32_t n_tile, uint32_t *__restrict__ tile_ent)
+{   // the entry of every tile, once: the blocks of the sort and of every merge pass start from it instead of a twelve-step search each
+	const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+	if (b < n_tile) tile_ent[b] = d_entry_of(tile_off, n_list, b);
+}
+template <int PER, int NW, int MCAP>
+__global__ void __launch_bounds__(64 * NW)
+k_anchor_run_sort(const uint64_t *__restrict__ pos, const uint32_t *__restrict__ frag_first, const uint64_t *__restrict__ mini_off, const AlMatch *__restrict__ match,
+                  const uint32_t *__restrict__ frag_nm, const uint32_t *__restrict__ frag_na, const uint32_t *__restrict__ frag_list, int n_list,
+                  const uint64_t *__restrict__ tile_off /* n_list + 1 */, const uint32_t *__restrict__ tile_ent, const uint64_t *__restrict__ big_off /* n_list + 1: the entry's keys */,
+                  uint64_t *__restrict__ keys, uint32_t *__restrict__ tie_list, int rid_bits, const uint32_t run_len /* <= AL_RUN_CAP (tests: shorter) */, const uint32_t tile)
+{
+	constexpr int NT = 64 * NW, CAP = PER * NT;
+	static_assert(CAP == AL_RUN_CAP, "run length");
+	constexpr int PADW = CAP + CAP / 16 + 2;
+	__shared__ uint64_t sx[PADW];
+	__shared__ uint32_t pre[MCAP + 1];
+	__shared__ uint32_t s_part[NT];
+	const int tid = threadIdx.x;
+	const uint64_t blk = blockIdx.x;                                           // the grid counts merge tiles: the block of a run's first tile sorts the run, the other three leave
+	const uint32_t ent = tile_ent[blk];
+	const uint32_t tl = (uint32_t)(blk - tile_off[ent]);
+	if (tl % (run_len / tile)) return;
+	const uint32_t f = frag_list[ent];
+	const uint32_t n = frag_na[f], n_m = frag_nm[f];
+	if (n_m > (uint32_t)MCAP) { if (tid == 0 && tl == 0) tie_list[f] = 1u; return; }   // more lists than the prefix table: exact merge
+	const uint32_t base = tl * tile, cnt = n - base < run_len ? n - base : run_len;
+	const AlMatch *m = match + mini_off[frag_first[f]];
+	{
+		constexpr int LPT = (MCAP + NT - 1) / NT;
+		uint32_t v[LPT], sum = 0;
+#pragma unroll
+		for (int j = 0; j < LPT; ++j) { const uint32_t i = (uint32_t)tid * LPT + j; v[j] = i < n_m ? m[i].n : 0u; sum += v[j]; }
+		uint32_t incl = sum;
+		for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(incl, d); if ((tid & 63) >= d) incl += t; }
+		if ((tid & 63) == 63) s_part[tid >> 6] = incl;
+		__syncthreads();
+		for (int w = 0; w < (tid >> 6); ++w) incl += s_part[w];
+		uint32_t run = incl - sum;
+#pragma unroll
+		for (int j = 0; j < LPT; ++j) { const uint32_t i = (uint32_t)tid * LPT + j; if (i <= n_m) pre[i] = run; run += v[j]; }
+	}
+	__syncthreads();
+	const int sb = 32 + rid_bits;
+	uint64_t k[PER];
+	{
+		uint64_t rr[PER]; uint32_t mi[PER], qb[PER];
+#pragma unroll
+		for (int j = 0; j < PER; ++j) {
+			const uint32_t e = (uint32_t)tid + (uint32_t)j * (uint32_t)NT, t = base + e; rr[j] = 0; mi[j] = 0; qb[j] = 0;
+			if (e < cnt) {
+				uint32_t lo = 0, hi = n_m;
+				while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (pre[mid] <= t) lo = mid; else hi = mid; }
+				mi[j] = lo;
+				const AlMatch mm = m[lo]; rr[j] = d_match_pos(pos, mm.off_lo, mm.flags, t - pre[lo]); qb[j] = mm.q_pos;
+			}
+		}
+#pragma unroll
+		for (int j = 0; j < PER; ++j) {
+			const uint32_t e = (uint32_t)tid + (uint32_t)j * (uint32_t)NT;
+			uint64_t key = UINT64_MAX;
+			if (e < cnt) { const uint64_t r = rr[j]; const bool rev = (r & 1) != (qb[j] & 1); key = ((uint64_t)(rev ? 1 : 0) << sb | (r >> 32) << 32 | (uint32_t)((uint32_t)r >> 1)) << 16 | mi[j]; }
+			k[j] = key;
+		}
+	}
+	d_bt_levels<PER, NT, 2>(k, sx, tid);
+	__syncthreads();
+#pragma unroll
+	for (int r = 0; r < PER; ++r) { const int e = tid * PER + r; sx[e + (e >> 4)] = k[r]; }
+	__syncthreads();
+	uint64_t *out = keys + big_off[ent] + base;
+	for (uint32_t t = tid; t < cnt; t += NT) out[t] = sx[t + (t >> 4)];
+}
+template __global__ void k_anchor_run_sort<16, 8, 1024>(const uint64_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint32_t *, int, const uint64_t *, const uint32_t *, const uint64_t *, uint64_t *, uint32_t *, int, uint32_t, uint32_t);
+
+struct RunMergeOut { const uint64_t *a_off, *mini_off; const uint32_t *frag_first, *rd_len; const AlMatch *match; AlAnchor *anchors; uint32_t *tie_list; int rid_bits, mini_span; };
+struct RunGeo { uint32_t ent, f, n, o, la, lb, d0, d1; uint64_t A0; int last; bool skip; };
+__device__ __forceinline__ RunGeo d_run_geo(const uint32_t blk, const uint32_t *__restrict__ tile_ent, const uint64_t *__restrict__ tile_off, const uint32_t *__restrict__ frag_list,
+                                            const uint32_t *__restrict__ frag_na, const uint32_t *__restrict__ frag_nm, const int pass, const uint32_t run_len, const uint32_t tile)
+{
+	RunGeo g; g.ent = tile_ent[blk]; g.f = frag_list[g.ent]; g.n = frag_na[g.f];
+	g.last = 0; while (((uint64_t)run_len << (g.last + 1)) < g.n) ++g.last;   // the fragment's last pass: two runs of run_len << last cover it
+	g.skip = frag_nm[g.f] > 1024u || pass > g.last;                           // (k_anchor_run_sort's MCAP: flagged there)
+	g.o = (uint32_t)(blk - tile_off[g.ent]) * tile;
+	const uint64_t L = (uint64_t)run_len << pass, B0 = (uint64_t)g.o / (2 * L) * (2 * L) + L;
+	g.A0 = B0 - L;
+	g.la = (uint32_t)(g.n - g.A0 < L ? g.n - g.A0 : L); g.lb = B0 < g.n ? (uint32_t)(g.n - B0 < L ? g.n - B0 : L) : 0u;
+	g.d0 = g.o - (uint32_t)g.A0; g.d1 = g.d0 + tile < g.la + g.lb ? g.d0 + tile : g.la + g.lb;
+	return g;
+}
+// merge path, a thread per tile: how many keys of run A are among the first d0 of the pair's merged sequence (the tile's end is the next tile's start, or the end of the pair)
+__global__ void __launch_bounds__(256)
+k_anchor_run_cuts(const uint64_t *__restrict__ kin, const uint32_t *__restrict__ frag_list, const uint32_t *__restrict__ tile_ent, uint32_t n_tile, const uint64_t *__restrict__ tile_off,
+                  const uint64_t *__restrict__ big_off, const uint32_t *__restrict__ frag_na, const uint32_t *__restrict__ frag_nm, const int pass, const uint32_t run_len, const uint32_t tile, uint32_t *__restrict__ cuts)
+{
+	const uint32_t blk = blockIdx.x * blockDim.x + threadIdx.x;
+	if (blk >= n_tile) return;
+	const RunGeo g = d_run_geo(blk, tile_ent, tile_off, frag_list, frag_na, frag_nm, pass, run_len, tile);
+	if (g.skip || g.lb == 0) { cuts[blk] = g.d0; return; }
+	const uint64_t *A = kin + big_off[g.ent] + g.A0, *B = A + ((uint64_t)run_len << pass);
+	const uint32_t d = g.d0;
+	uint32_t lo = d > g.lb ? d - g.lb : 0u, hi = d < g.la ? d : g.la;
+	while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (A[mid] < B[d - 1 - mid]) lo = mid + 1; else hi = mid; }
+	cuts[blk] = lo;
+}
+__global__ void __launch_bounds__(256)
+k_anchor_run_merge(const uint64_t *__restrict__ kin, uint64_t *__restrict__ kout, const uint32_t *__restrict__ frag_list, const uint32_t *__restrict__ tile_ent, const uint32_t *__restrict__ cuts, const uint64_t *__restrict__ tile_off,
+                   const uint64_t *__restrict__ big_off, const uint32_t *__restrict__ frag_na, const uint32_t *__restrict__ frag_nm, const int pass /* input runs of run_len << pass keys */, const RunMergeOut O, const uint32_t run_len, const uint32_t tile /* <= AL_MERGE_TILE */)
+{
+	constexpr int NT = 256, PER = AL_MERGE_TILE / NT;
+	__shared__ uint64_t sk[AL_MERGE_TILE + 1];
+	const int tid = threadIdx.x;
+	const uint32_t blk = blockIdx.x;
+	const RunGeo g = d_run_geo(blk, tile_ent, tile_off, frag_list, frag_na, frag_nm, pass, run_len, tile);
+	if (g.skip) return;
+	const uint32_t ent = g.ent, f = g.f, n = g.n, o = g.o, la = g.la, lb = g.lb, d0 = g.d0, d1 = g.d1, tot = d1 - d0; const int last = g.last;
+	const uint64_t L = (uint64_t)run_len << pass;
+	const uint64_t *A = kin + big_off[ent] + g.A0, *B = A + L;
+	if (lb == 0 && pass < last) {   // a run without a partner in this pass: copied  (lb == 0 in the last pass: a fragment of one run -- tests lower the class bound)
+		uint64_t *out = kout + big_off[ent] + o;
+		for (uint32_t t = tid; t < tot; t += NT) out[t] = A[d0 + t];
+		return;
+	}
+	const uint32_t a0 = lb ? cuts[blk] : d0, a1 = !lb ? d1 : d1 == la + lb ? la : cuts[blk + 1];   // (d1 < la + lb: the next tile is this pair's too)
+	(void)n;
+	const uint32_t b0 = d0 - a0, b1 = d1 - a1, na = a1 - a0, nb = b1 - b0;
+	for (uint32_t t = tid; t < tot; t += NT) sk[t] = t < na ? A[a0 + t] : B[b0 + (t - na)];
+	__syncthreads();
+	uint64_t v[PER];
+	{
+		const uint64_t *sa = sk, *sb = sk + na;
+		const uint32_t d = (uint32_t)tid * PER < tot ? (uint32_t)tid * PER : tot;
+		uint32_t lo = d > nb ? d - nb : 0u, hi = d < na ? d : na;
+		while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (sa[mid] < sb[d - 1 - mid]) lo = mid + 1; else hi = mid; }
+		uint32_t ia = lo, ib = d - lo;
+		uint64_t ka = ia < na ? sa[ia] : UINT64_MAX, kb = ib < nb ? sb[ib] : UINT64_MAX;   // (a key is never all ones: its list index would be 0xffff with every x bit set)
+#pragma unroll
+		for (int r = 0; r < PER; ++r) {
+			const bool ta = ka < kb;
+			v[r] = ta ? ka : kb;
+			if (ta) { ++ia; ka = ia < na ? sa[ia] : UINT64_MAX; } else { ++ib; kb = ib < nb ? sb[ib] : UINT64_MAX; }
+		}
+	}
+	if (pass < last) {
+		uint64_t *out = kout + big_off[ent] + o;
+#pragma unroll
+		for (int r = 0; r < PER; ++r) { const uint32_t t = (uint32_t)tid * PER + r; if (t < tot) out[t] = v[r]; }
+		return;
+	}
+	// the fragment's last pass: anchors out, tie flag
+	uint64_t pred = 0; bool has_pred = false;
+	if (tid == 0) { if (a0) { pred = A[a0 - 1]; has_pred = true; } if (b0) { const uint64_t q = B[b0 - 1]; if (!has_pred || q > pred) pred = q; has_pred = true; } }
+	__syncthreads();
+#pragma unroll
+	for (int r = 0; r < PER; ++r) { const uint32_t t = (uint32_t)tid * PER + r; if (t < tot) sk[t + 1] = v[r]; }
+	if (tid == 0) sk[0] = has_pred ? pred : ~v[0];                             // (no predecessor: anything with another x)
+	__syncthreads();
+	const uint32_t r0 = O.frag_first[f], r1 = O.frag_first[f + 1];
+	int qlen = 0; for (uint32_t r = r0; r < r1; ++r) qlen += (int)O.rd_len[r];
+	const AlMatch *m = O.match + O.mini_off[r0];
+	AlAnchor *out = O.anchors + O.a_off[f] + o;
+	const int sbit = 32 + O.rid_bits; const uint64_t lowmask = (1ULL << sbit) - 1; const uint32_t span = (uint32_t)O.mini_span;
+	int tie = 0;
+	for (uint32_t t = tid; t < tot; t += NT) {
+		const uint64_t key = sk[t + 1]; const uint32_t i = (uint32_t)key & 0xffffu; const uint64_t kx = key >> 16;
+		if ((sk[t] >> 16) == kx) tie = 1;
+		const AlMatch mm = m[i];
+		AlAnchor a; a.x = (kx & lowmask) | (kx >> sbit & 1) << 63;
+		a.y = (a.x >> 63) ? (uint64_t)span << 32 | (uint32_t)(qlen - ((int)(mm.q_pos >> 1) + 1 - (int)span) - 1) : (uint64_t)span << 32 | (mm.q_pos >> 1);
+		a.y |= (uint64_t)(mm.flags & 0xff) << AL_SEED_SEG_SHIFT;
+		if (mm.flags & (1u << 8)) a.y |= AL_SEED_TANDEM;
+		out[t] = a;
+	}
+	if (tie) O.tie_list[f] = 1u;                                              // merged again by the heap kernels (exact order among equal x)
+}
+
 // K3 for fragments with at most 64 anchors (the bulk on a low-repeat genome): nothing but registers, so 32 wavefronts per CU
 // stay resident and hide the dependent HBM reads (count -> match records -> positions) that bound this stage.
 // Lane t builds anchor t (its owning match is found by counting prefix sums, read with wave-uniform readlanes), the

@@ -103,9 +103,9 @@ struct al_ctx_s {
 	DevBuf<uint8_t> big_tmp;               // rocprim scratch of the device-wide anchor sort (it runs on ovl[0], beside users of scan_tmp)
 	DevBuf<uint32_t> chain_key, chain_idx, chain_idx2, tie_list, lb_buf;
 	// segment-wise chaining of large fragments (al_runtime.hip: chain_by_segments) and the device-wide sort of their anchors
-	DevBuf<AlAnchor> chain_tmp; DevBuf<uint64_t> u_tmp, okey_tmp, seg_first, seg_first0, vs_off, big_off;
+	DevBuf<AlAnchor> chain_tmp; DevBuf<uint64_t> u_tmp, okey_tmp, seg_first, seg_first0, vs_off, big_off, big_toff;
 	DevBuf<uint64_t> vs_res;                 // two words per segment: ChainSeg::res
-	DevBuf<uint32_t> seg_cnt, seg_cnt0, seg_t1, vs_na, vs_meta, vs_cls, seg_key, seg_idx, seg_ord, fb_list, fb2_list, fb3_list, big_na, tie_frags, tie_sorted, heap_cnt;
+	DevBuf<uint32_t> seg_cnt, seg_cnt0, seg_t1, vs_na, vs_meta, vs_cls, seg_key, seg_idx, seg_ord, fb_list, fb2_list, fb3_list, big_na, big_nt, big_tent, big_cuts, tie_frags, tie_sorted, heap_cnt;
 	uint64_t n_chain_fallback = 0;
 	int max_qlen_sum = 0;                 // longest fragment of the resident batch
 	int max_rd_len = 0;                   // longest read of the resident batch

@@ -56,6 +56,12 @@ template <int CAP> __global__ void k_chain(const AlAnchor *, const uint64_t *, c
 template <int CAPL, int LANES> __global__ void k_chain_lds(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, AlAnchor *, uint64_t *, uint32_t *, uint64_t *, const uint32_t *, int, int, AlParams, unsigned long long *, ChainSeg, uint32_t *, int);
 template <int PER, int NW, int MCAP> __global__ void k_anchor_sort_reg(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, uint32_t *, const uint32_t *, int, int, int);
 __global__ void k_anchor_big_expand(const uint64_t *, const uint64_t *, const uint32_t *, const AlMatch *, const uint32_t *, const uint32_t *, int, const uint64_t *, uint64_t *, int, int);
+struct RunMergeOut { const uint64_t *a_off, *mini_off; const uint32_t *frag_first, *rd_len; const AlMatch *match; AlAnchor *anchors; uint32_t *tie_list; int rid_bits, mini_span; };
+__global__ void k_big_tiles(const uint32_t *, int, uint32_t *, unsigned int *, uint32_t);
+template <int PER, int NW, int MCAP> __global__ void k_anchor_run_sort(const uint64_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint32_t *, int, const uint64_t *, const uint32_t *, const uint64_t *, uint64_t *, uint32_t *, int, uint32_t, uint32_t);
+__global__ void k_big_tile_ent(const uint64_t *, int, uint32_t, uint32_t *);
+__global__ void k_anchor_run_cuts(const uint64_t *, const uint32_t *, const uint32_t *, uint32_t, const uint64_t *, const uint64_t *, const uint32_t *, const uint32_t *, int, uint32_t, uint32_t, uint32_t *);
+__global__ void k_anchor_run_merge(const uint64_t *, uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, const uint64_t *, const uint64_t *, const uint32_t *, const uint32_t *, int, RunMergeOut, uint32_t, uint32_t);
 __global__ void k_anchor_big_scatter(const uint64_t *, const uint32_t *, int, const uint64_t *, const uint64_t *, const uint64_t *, const uint32_t *, const uint32_t *, const AlMatch *, const uint32_t *, AlAnchor *, uint32_t *, int, int, int);
 template <int NW> __global__ void k_seg_scan(const AlAnchor *, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *, int, AlParams, int, int, const uint64_t *, const uint64_t *, uint32_t *, uint32_t *, uint64_t *, uint32_t *, uint32_t *, const uint32_t *, uint32_t *, uint32_t *, uint32_t *, int, int);
 template <int NW> __global__ void k_seg_merge(const uint32_t *, int, const uint64_t *, const uint64_t *, const uint4 *, const uint64_t *, const AlAnchor *, const uint64_t *, uint64_t *, AlAnchor *, uint32_t *, uint32_t *, uint32_t *, const uint32_t *, const uint64_t *, uint64_t *, int, int);
@@ -1037,7 +1043,44 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 		if (rank_bits < 0 && lb_big < (uint32_t)nl) {                       // (no such index in practice: > 2^46 contig-id x position range) exact merge for all of them
 			hipLaunchKernelGGL(k_flag_list, dim3(((uint32_t)nl - lb_big + 255) / 256), dim3(256), 0, sb, order + lb_big, (int)((uint32_t)nl - lb_big), c->tie_list.p);
 		}
-		for (uint32_t b0 = lb_big; rank_bits >= 0 && b0 < (uint32_t)nl; ) {
+		// (round 5) runs of 8192 anchors sorted by the register network, then merged pairwise (k_anchor_run_sort / k_anchor_run_merge): one to six passes of 8 bytes
+		// per anchor by the fragment's size instead of expansion + seven radix passes + scatter.  AL_BIG_MERGE=0: the device-wide sort (tests run both).
+		static const bool big_merge = !(getenv("AL_BIG_MERGE") && atoi(getenv("AL_BIG_MERGE")) == 0);
+		const bool use_merge = big_merge && 33 + rid_bits + 16 <= 64 && lb_big < (uint32_t)nl;
+		// AL_TEST_RUN=<run>,<tile> (tests): shorter runs and merge tiles (powers of two, tile <= run <= 8192, tile <= 2048) so that the golden sets' fragments take several passes
+		static uint32_t run_len = 8192, tile = 2048;
+		{ static bool once = false; if (!once) { once = true; const char *e = getenv("AL_TEST_RUN"); unsigned a = 0, b = 0;
+		  if (e && sscanf(e, "%u,%u", &a, &b) == 2 && a && b && !(a & (a - 1)) && !(b & (b - 1)) && b <= a && a <= 8192 && b <= 2048) { run_len = a; tile = b; } } }
+		if (use_merge) {
+			const uint32_t nb = (uint32_t)nl - lb_big;
+			unsigned int *const mx_d = (unsigned int *)(c->counters.p + 18);
+			if (c->big_na.ensure(nb + 2) || c->big_off.ensure(nb + 2) || c->big_nt.ensure(nb + 2) || c->big_toff.ensure(nb + 2)) return -1;
+			AL_HIP_CHECK(hipMemsetAsync(mx_d, 0, 8, sb));
+			hipLaunchKernelGGL(k_gather_na, dim3((nb + 256) / 256), dim3(256), 0, sb, c->frag_na.p, order + lb_big, (int)nb, c->big_na.p);
+			hipLaunchKernelGGL(k_big_tiles, dim3((nb + 256) / 256), dim3(256), 0, sb, (const uint32_t *)c->big_na.p, (int)nb, c->big_nt.p, mx_d, tile);
+			if (scan_u32_to_u64(c, c->big_na.p, c->big_off.p, (int)nb, sb, &c->big_tmp) || scan_u32_to_u64(c, c->big_nt.p, c->big_toff.p, (int)nb, sb, &c->big_tmp)) return -1;
+			uint64_t nbig = 0, ntile = 0; unsigned int mx = 0;
+			AL_HIP_CHECK(hipMemcpyAsync(&nbig, c->big_off.p + nb, 8, hipMemcpyDeviceToHost, sb));
+			AL_HIP_CHECK(hipMemcpyAsync(&ntile, c->big_toff.p + nb, 8, hipMemcpyDeviceToHost, sb));
+			AL_HIP_CHECK(hipMemcpyAsync(&mx, mx_d, 4, hipMemcpyDeviceToHost, sb));
+			AL_HIP_CHECK(hipStreamSynchronize(sb));
+			if (ntile >= (1ULL << 31)) { fprintf(stderr, "[airlift] too many anchors in one batch for the run merge: upload fewer fragments\n"); al_nomem_flag() = true; return -1; }
+			if (c->big_k0.ensure((size_t)nbig + 1, false, sb) || c->big_k1.ensure((size_t)nbig + 1, false, sb) || c->big_tent.ensure((size_t)ntile + 1) || c->big_cuts.ensure((size_t)ntile + 2)) return -1;
+			const uint32_t nt32 = (uint32_t)ntile;
+			hipLaunchKernelGGL(k_big_tile_ent, dim3((nt32 + 255) / 256), dim3(256), 0, sb, (const uint64_t *)c->big_toff.p, (int)nb, nt32, c->big_tent.p);
+			hipLaunchKernelGGL(HIP_KERNEL_NAME(k_anchor_run_sort<16, 8, 1024>), dim3(nt32), dim3(512), 0, sb, c->di.pos, c->frag_first.p, c->mini_off.p, c->match.p, c->frag_nm.p, c->frag_na.p,
+			                   order + lb_big, (int)nb, (const uint64_t *)c->big_toff.p, (const uint32_t *)c->big_tent.p, (const uint64_t *)c->big_off.p, c->big_k0.p, c->tie_list.p, rid_bits, run_len, tile);
+			int n_pass = 1; while (((uint64_t)run_len << n_pass) < mx) ++n_pass;
+			const RunMergeOut O{c->a_off.p, c->mini_off.p, c->frag_first.p, c->rd_len.p, c->match.p, c->anchors.p, c->tie_list.p, rid_bits, c->mi->k};
+			for (int p = 0; p < n_pass; ++p) {
+				const uint64_t *kin = (p & 1) ? c->big_k1.p : c->big_k0.p; uint64_t *kout = (p & 1) ? c->big_k0.p : c->big_k1.p;
+				hipLaunchKernelGGL(k_anchor_run_cuts, dim3((nt32 + 255) / 256), dim3(256), 0, sb, kin, order + lb_big, (const uint32_t *)c->big_tent.p, nt32, (const uint64_t *)c->big_toff.p, (const uint64_t *)c->big_off.p,
+				                   (const uint32_t *)c->frag_na.p, (const uint32_t *)c->frag_nm.p, p, run_len, tile, c->big_cuts.p);
+				hipLaunchKernelGGL(k_anchor_run_merge, dim3(nt32), dim3(256), 0, sb, kin, kout, order + lb_big, (const uint32_t *)c->big_tent.p, (const uint32_t *)c->big_cuts.p, (const uint64_t *)c->big_toff.p,
+				                   (const uint64_t *)c->big_off.p, (const uint32_t *)c->frag_na.p, (const uint32_t *)c->frag_nm.p, p, O, run_len, tile);
+			}
+		}
+		for (uint32_t b0 = lb_big; !use_merge && rank_bits >= 0 && b0 < (uint32_t)nl; ) {
 			const uint32_t nb = std::min<uint32_t>((uint32_t)nl - b0, chunk_max);
 			if (c->big_na.ensure(nb + 2) || c->big_off.ensure(nb + 2)) return -1;
 			hipLaunchKernelGGL(k_gather_na, dim3((nb + 256) / 256), dim3(256), 0, sb, c->frag_na.p, order + b0, (int)nb, c->big_na.p);
