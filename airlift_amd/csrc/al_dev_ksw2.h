@@ -41,7 +41,10 @@ __device__ __forceinline__ uint32_t pk_splat8(int v) { return (uint32_t)((v & 0x
 // NP superblocks of 32 cells; LT as for d_ksw_reg; selE / selO: the reversed query as selector bytes of the score permute for a cell in the low
 // half (E(base) = base) and in the high half (O(base) = 4 + base), E(N) = O(N) = 0x0d (the permute's constant 0xff = sc_N); 32 * NP bytes of front
 // pad before byte 0 and E(0) / O(0) (base 0, as the reference's zero padding) up to qlen + 32 * NP + 1 behind the query.
-template <int NP, class LT>
+// DIR: 0 = left-aligned gaps, 1 = right-aligned (EZ_RIGHT), 2 = by the flag (a wavefront whose groups differ).  The tags of the five-way choice RIDE IN THE STATE: x, y, x2, y2
+// carry theirs in the low byte of either half from the moment they are made (the constant subtracted there is q + e less the tag), u and v have zero low bytes,
+// so the sums a = x + v ... come out tagged and the four ors per cell pair are gone; with DIR known the gap-stays-open test needs no or either.
+template <int NP, class LT, int DIR = 2>
 __device__ __forceinline__ void d_ksw_pk(LT &L, const uint8_t *__restrict__ selE, const uint8_t *__restrict__ selO, const int gl, GroupWs &ws, int qlen, int tlen, const AlParams &P,
                                          int w, int zdrop, int end_bonus, int flag, EzD &ez, bool do_bt = true)
 {
@@ -56,11 +59,14 @@ __device__ __forceinline__ void d_ksw_pk(LT &L, const uint8_t *__restrict__ selE
 	int long_thres = e != e2 ? (q2 - q) / (e - e2) - 1 : 0;
 	if (q2 + e2 + long_thres * e2 > q + e + long_thres * e) ++long_thres;
 	const int long_diff = long_thres * (e - e2) - (q2 - q) - e2;
-	const bool right = (flag & EZ_RIGHT) != 0;
+	const bool right = DIR == 2 ? (flag & EZ_RIGHT) != 0 : DIR == 1;
 	const uint32_t M1 = pk_splat8(-q - e), M2 = pk_splat8(-q2 - e2), QE = pk_splat8(q + e), QE2 = pk_splat8(q2 + e2), QQ = pk_splat8(q), QQ2 = pk_splat8(q2), MCH = pk_splat8(sc_mch);
 	// tags of the five candidates in the low byte of a half: first maximum wins (left-aligned) <=> larger tag for the earlier position
 	const uint32_t TG0 = right ? 0x00000000u : 0x00070007u, TG1 = right ? 0x00010001u : 0x00060006u, TG2 = right ? 0x00020002u : 0x00050005u,
-	               TG3 = right ? 0x00030003u : 0x00040004u, TG4 = right ? 0x00040004u : 0x00030003u, TGX = right ? 0u : 0x00070007u, GE = right ? 0x00010001u : 0u;
+	               TG3 = right ? 0x00030003u : 0x00040004u, TG4 = right ? 0x00040004u : 0x00030003u, TGX = right ? 0u : 0x00070007u;
+	const uint32_t M1X = M1 | TG1, M1Y = M1 | TG2, M2X = M2 | TG3, M2Y = M2 | TG4;                    // boundary values of x, y, x2, y2 with their tags
+	const uint32_t QE_X = pk_sub(QE, TG1), QE_Y = pk_sub(QE, TG2), QE2_X = pk_sub(QE2, TG3), QE2_Y = pk_sub(QE2, TG4);
+	const uint32_t FM = right ? 0xffffffffu : 0xff00ff00u;                                          // (DIR == 2) what of max(a - (z - q), 0) says "the gap stays open": >= 0 (the tag counts) or > 0
 	// ---- state: cells t0 = 32c + 2gl (low half) and t0 + 1 (high half)
 	uint32_t X[NP], V[NP], X2[NP], U[NP], Y[NP], Y2[NP], S[NP], H[NP];
 	// the score tables of the lane's two target bases (byte k = score against query base k; all 0xff = sc_N for a target N) wait in LDS: a 64-bit read
@@ -72,7 +78,7 @@ __device__ __forceinline__ void d_ksw_pk(LT &L, const uint8_t *__restrict__ selE
 		for (int c = 0; c < NP; ++c) {
 			const int t0 = 32 * c + 2 * gl;
 			const uint32_t tb0 = t0 < tlen ? L.tbuf[t0] : 0, tb1 = t0 + 1 < tlen ? L.tbuf[t0 + 1] : 0;
-			X[c] = M1; V[c] = M1; X2[c] = M2; U[c] = M1; Y[c] = M1; Y2[c] = M2; S[c] = 0; H[c] = 0;
+			X[c] = M1X; V[c] = M1; X2[c] = M2X; U[c] = M1; Y[c] = M1Y; Y2[c] = M2Y; S[c] = TG0; H[c] = 0;
 			wt[16 * c] = make_uint2(tb0 >= 4 ? 0xffffffffu : ((misrep & ~(0xffu << (8 * tb0))) | (uint32_t)(uint8_t)(int8_t)sc_mch << (8 * tb0)),
 			                        tb1 >= 4 ? 0xffffffffu : ((misrep & ~(0xffu << (8 * tb1))) | (uint32_t)(uint8_t)(int8_t)sc_mch << (8 * tb1)));
 		}
@@ -95,7 +101,7 @@ __device__ __forceinline__ void d_ksw_pk(LT &L, const uint8_t *__restrict__ selE
 		const int cover_end = st0 + ((en0 - st0) >> 4) * 16 + 15;
 		const int tend = tlen_ * 16;
 		// ---- boundary conditions (:141-157): x, v, x2 left of the first cell of block st_
-		uint32_t cX = M1, cV = M1, cX2 = M2;
+		uint32_t cX = M1X, cV = M1, cX2 = M2X;
 		if (st > 0) {
 			if (st - 1 >= last_st && st - 1 <= last_en) {                      // (only in a row whose first block moved)
 				const int cb = (st_ - 1) >> 1;                                 // cell st - 1 = the last cell of block st_ - 1: high half of lane 7 or 15 of superblock cb
@@ -132,17 +138,20 @@ __device__ __forceinline__ void d_ksw_pk(LT &L, const uint8_t *__restrict__ selE
 		// the cell recurrence (:177-265) on two cells: left neighbours (xt1, vt1, x2t1), the cells' own u, y, y2 and score -> new state and traceback byte
 		auto cell = [&](const uint32_t xt1, const uint32_t vt1, const uint32_t x2t1, const uint32_t uo, const uint32_t yo, const uint32_t y2o, const uint32_t so,
 		                uint32_t &xn, uint32_t &vn, uint32_t &x2n, uint32_t &un, uint32_t &yn, uint32_t &y2n, uint32_t &d) {
-			const uint32_t a = pk_add(xt1, vt1), bb = pk_add(yo, uo), a2 = pk_add(x2t1, vt1), b2 = pk_add(y2o, uo);
-			uint32_t zk = pk_max(so | TG0, a | TG1);
-			zk = pk_max(zk, bb | TG2); zk = pk_max(zk, a2 | TG3); zk = pk_max(zk, b2 | TG4);
+			const uint32_t a = pk_add(xt1, vt1), bb = pk_add(yo, uo), a2 = pk_add(x2t1, vt1), b2 = pk_add(y2o, uo);   // (tagged: x, y, x2, y2 are; so is so)
+			uint32_t zk = pk_max(so, a);
+			zk = pk_max(zk, bb); zk = pk_max(zk, a2); zk = pk_max(zk, b2);
 			d = (zk & 0x00070007u) ^ TGX;
 			const uint32_t z = pk_min(zk & 0xff00ff00u, MCH);
 			un = pk_sub(z, vt1); vn = pk_sub(z, uo);
 			const uint32_t tq = pk_sub(z, QQ), tq2 = pk_sub(z, QQ2);
 			const uint32_t aa = pk_sub(a, tq), ab = pk_sub(bb, tq), aa2 = pk_sub(a2, tq2), ab2 = pk_sub(b2, tq2);
-			const uint32_t pa = pk_max(aa | GE, 0u), pb = pk_max(ab | GE, 0u), pa2 = pk_max(aa2 | GE, 0u), pb2 = pk_max(ab2 | GE, 0u);   // > 0 exactly where the gap stays open
-			xn = pk_sub(pa & 0xff00ff00u, QE); yn = pk_sub(pb & 0xff00ff00u, QE); x2n = pk_sub(pa2 & 0xff00ff00u, QE2); y2n = pk_sub(pb2 & 0xff00ff00u, QE2);
-			d |= pk_minu1(pa) << 3 | pk_minu1(pb) << 4 | pk_minu1(pa2) << 5 | pk_minu1(pb2) << 6;
+			const uint32_t pa = pk_max(aa, 0u), pb = pk_max(ab, 0u), pa2 = pk_max(aa2, 0u), pb2 = pk_max(ab2, 0u);   // != 0 where the value is >= 0 (low byte = its tag, never 0 there); high byte != 0 where it is > 0
+			const uint32_t ma = pa & 0xff00ff00u, mb = pb & 0xff00ff00u, ma2 = pa2 & 0xff00ff00u, mb2 = pb2 & 0xff00ff00u;
+			xn = pk_sub(ma, QE_X); yn = pk_sub(mb, QE_Y); x2n = pk_sub(ma2, QE2_X); y2n = pk_sub(mb2, QE2_Y);
+			if (DIR == 0) d |= pk_minu1(ma) << 3 | pk_minu1(mb) << 4 | pk_minu1(ma2) << 5 | pk_minu1(mb2) << 6;                // the gap stays open: > 0
+			else if (DIR == 1) d |= pk_minu1(pa) << 3 | pk_minu1(pb) << 4 | pk_minu1(pa2) << 5 | pk_minu1(pb2) << 6;           // >= 0
+			else d |= pk_minu1(pa & FM) << 3 | pk_minu1(pb & FM) << 4 | pk_minu1(pa2 & FM) << 5 | pk_minu1(pb2 & FM) << 6;
 		};
 #pragma unroll
 		for (int c = 0; c < NP; ++c) {
@@ -154,7 +163,7 @@ __device__ __forceinline__ void d_ksw_pk(LT &L, const uint8_t *__restrict__ selE
 				const uint32_t xo = X[c], vo = V[c], x2o = X2[c];
 				const uint32_t sel = __builtin_amdgcn_perm((uint32_t)qrO[32 * c], (uint32_t)qrE[32 * c], 0x040c000cu);
 				const uint2 wv = wt[16 * c];
-				const uint32_t so = __builtin_amdgcn_perm(wv.y, wv.x, sel) & 0xff00ff00u;
+				const uint32_t so = (__builtin_amdgcn_perm(wv.y, wv.x, sel) & 0xff00ff00u) | TG0;
 				const uint32_t xl = (uint32_t)d_dpp_shr1((int)cX, (int)xo), vl = (uint32_t)d_dpp_shr1((int)cV, (int)vo), x2l = (uint32_t)d_dpp_shr1((int)cX2, (int)x2o);
 				const uint32_t xt1 = __builtin_amdgcn_alignbit(xo, xl, 16), vt1 = __builtin_amdgcn_alignbit(vo, vl, 16), x2t1 = __builtin_amdgcn_alignbit(x2o, x2l, 16);
 				cX = (uint32_t)__builtin_amdgcn_mov_dpp((int)xo, DPP_ROW_BCAST15, 0xf, 0xf, true); cV = (uint32_t)__builtin_amdgcn_mov_dpp((int)vo, DPP_ROW_BCAST15, 0xf, 0xf, true); cX2 = (uint32_t)__builtin_amdgcn_mov_dpp((int)x2o, DPP_ROW_BCAST15, 0xf, 0xf, true);
@@ -176,7 +185,7 @@ __device__ __forceinline__ void d_ksw_pk(LT &L, const uint8_t *__restrict__ selE
 			uint32_t xo = X[c], vo = V[c], x2o = X2[c], uo = U[c], yo = Y[c], y2o = Y2[c], so = S[c];
 			{   // y[r], y2[r], u[r]
 				const uint32_t m = pk_mask_eq(T, R_);
-				yo = d_bfi(m, M1, yo); y2o = d_bfi(m, M2, y2o); uo = d_bfi(m, UB, uo);
+				yo = d_bfi(m, M1Y, yo); y2o = d_bfi(m, M2Y, y2o); uo = d_bfi(m, UB, uo);
 			}
 			{   // score bytes (:158-176) of the cells [st0, cover_end] below the padded target length
 				const uint32_t sel = __builtin_amdgcn_perm((uint32_t)qrO[32 * c], (uint32_t)qrE[32 * c], 0x040c000cu);   // E << 8 | O << 24

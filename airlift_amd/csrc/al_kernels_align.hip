@@ -1865,8 +1865,9 @@ __device__ __forceinline__ void d_ext_prep_frag(const int f, const int lane, con
 		// key: class | 16-cell blocks of the target | size -- inside a class the jobs are ordered by block count first, so that the 9 ... 22-block class
 		// can be launched as three kernels (12, 16, 22 register blocks: a row costs every instantiated block a skip test and two selects)
 		const uint32_t b0 = (uint32_t)std::min(63, (jl.tlen + 15) / 16), b1 = (uint32_t)std::min(63, (jr.tlen + 15) / 16);
-		E.job_key[jb] = c0 < AL_NCLS ? ((uint32_t)c0 << 20 | b0 << 14 | (uint32_t)std::min(0x3fff, jl.qlen + jl.tlen)) : 0xffffffffu;
-		E.job_key[jb + 1] = c1 < AL_NCLS ? ((uint32_t)c1 << 20 | b1 << 14 | (uint32_t)std::min(0x3fff, jr.qlen + jr.tlen)) : 0xffffffffu;
+		// (round 5) ... then by direction (left extensions have right-aligned gaps, align.c:694-704): a wavefront of the DP kernels holds four jobs of one direction
+		E.job_key[jb] = c0 < AL_NCLS ? ((uint32_t)c0 << 20 | b0 << 14 | 0u << 13 | (uint32_t)std::min(0x1fff, jl.qlen + jl.tlen)) : 0xffffffffu;
+		E.job_key[jb + 1] = c1 < AL_NCLS ? ((uint32_t)c1 << 20 | b1 << 14 | 1u << 13 | (uint32_t)std::min(0x1fff, jr.qlen + jr.tlen)) : 0xffffffffu;
 		atomicAdd(&s_hist[c0], 1u); atomicAdd(&s_hist[c1], 1u);
 		if (c0 == 7 && b0 <= 16) atomicAdd(&s_sub[b0 <= 12 ? 0 : 1], 1u);
 		if (c1 == 7 && b1 <= 16) atomicAdd(&s_sub[b1 <= 12 ? 0 : 1], 1u);
@@ -2059,7 +2060,11 @@ k_ext_dp(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_of
 			// selector words of the score permute, from the staged bytes (front pad included: whatever it holds, its words are in bounds and unused)
 			for (int i = gl; i < ql + 2 * TMAXJ + 16; i += GW) { const uint32_t b0 = L.sq[i]; L.selO[i] = (uint8_t)(b0 < 4 ? 4u + b0 : 0x0du); L.sq[i] = (uint8_t)(b0 < 4 ? b0 : 0x0du); }
 			GSYNC();
-			d_ksw_pk<NB / 2>(L, L.sq + TMAXJ, L.selO + TMAXJ, gl, ws, ql, tl, P, bw, P.zdrop, P.end_bonus, flag, ez);
+			// the job list is ordered by direction inside a block count (k_ext_prep's key): nearly every wavefront holds jobs of one direction and takes the form compiled for it
+			const unsigned long long w_act = __ballot(1), w_right = __ballot((flag & EZ_RIGHT) != 0);
+			if (w_right == 0) d_ksw_pk<NB / 2, JobLds<QMAXJ, TMAXJ, PK>, 0>(L, L.sq + TMAXJ, L.selO + TMAXJ, gl, ws, ql, tl, P, bw, P.zdrop, P.end_bonus, flag, ez);
+			else if (w_right == w_act) d_ksw_pk<NB / 2, JobLds<QMAXJ, TMAXJ, PK>, 1>(L, L.sq + TMAXJ, L.selO + TMAXJ, gl, ws, ql, tl, P, bw, P.zdrop, P.end_bonus, flag, ez);
+			else d_ksw_pk<NB / 2, JobLds<QMAXJ, TMAXJ, PK>, 2>(L, L.sq + TMAXJ, L.selO + TMAXJ, gl, ws, ql, tl, P, bw, P.zdrop, P.end_bonus, flag, ez);
 		} else
 		d_ksw_reg<NB>(L, gl, ws, ql, tl, P, bw, P.zdrop, P.end_bonus, flag, ez);
 		ExtOut o;

@@ -2247,23 +2247,44 @@ k_rechain_test(const AlAnchor *__restrict__ chained, const uint64_t *__restrict_
                const uint32_t *__restrict__ frag_nu, const int32_t *__restrict__ frag_rep, const uint32_t *__restrict__ frag_first,
                int n_frag, uint32_t *__restrict__ list, uint32_t *__restrict__ n_list)
 {
-	const int f = blockIdx.x * blockDim.x + threadIdx.x;
-	if (f >= n_frag) return;
-	if (frag_rep[f] <= 0) return;
-	const int n_segs = (int)(frag_first[f + 1] - frag_first[f]);
-	const uint32_t n_u = frag_nu[f];
+	// a lane per fragment; a fragment with more than 64 chains (a thread walked the 12 000 chains of one for a millisecond and a half while the rest of the
+	// chip waited) by the whole wavefront, one such fragment after the other: the best chain is the FIRST of the highest score (map.c:357-358)
+	const int f = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
+	const bool act = f < n_frag && frag_rep[f] > 0;
+	const int n_segs = act ? (int)(frag_first[f + 1] - frag_first[f]) : 0;
+	const uint32_t n_u = act ? frag_nu[f] : 0u;
 	int rechain = 0;
-	if (n_u > 0) {
-		const uint64_t *u = u_all + a_off[f] + f; const uint32_t *uo = uo_all + a_off[f] + f; const AlAnchor *a = chained + a_off[f];
-		int n_chained_segs = 1, max = 0, max_i = -1, max_off = -1;
-		for (uint32_t i = 0; i < n_u; ++i) { if (max < (int)(u[i] >> 32)) max = (int)(u[i] >> 32), max_i = (int)i; }
-		if (max_i >= 0) max_off = (int)uo[max_i];
-		if (max_i >= 0) {
-			for (int i = 1; i < (int32_t)(uint32_t)u[max_i]; ++i)
-				if ((a[max_off + i].y & AL_SEED_SEG_MASK) != (a[max_off + i - 1].y & AL_SEED_SEG_MASK)) ++n_chained_segs;
-			if (n_chained_segs < n_segs) rechain = 1;
+	const bool heavy = act && n_u > 64u;
+	if (act && !heavy) {
+		if (n_u > 0) {
+			const uint64_t *u = u_all + a_off[f] + f; const uint32_t *uo = uo_all + a_off[f] + f; const AlAnchor *a = chained + a_off[f];
+			int n_chained_segs = 1, max = 0, max_i = -1, max_off = -1;
+			for (uint32_t i = 0; i < n_u; ++i) { if (max < (int)(u[i] >> 32)) max = (int)(u[i] >> 32), max_i = (int)i; }
+			if (max_i >= 0) max_off = (int)uo[max_i];
+			if (max_i >= 0) {
+				for (int i = 1; i < (int32_t)(uint32_t)u[max_i]; ++i)
+					if ((a[max_off + i].y & AL_SEED_SEG_MASK) != (a[max_off + i - 1].y & AL_SEED_SEG_MASK)) ++n_chained_segs;
+				if (n_chained_segs < n_segs) rechain = 1;
+			}
+		} else rechain = 1;
+	}
+	for (unsigned long long hm = __ballot(heavy); hm; hm &= hm - 1) {
+		const int src = __ffsll((long long)hm) - 1;
+		const int ff = __shfl(f, src), nsg = __shfl(n_segs, src); const uint32_t nu = (uint32_t)__shfl((int)n_u, src);
+		const uint64_t *u = u_all + a_off[ff] + ff; const uint32_t *uo = uo_all + a_off[ff] + ff; const AlAnchor *a = chained + a_off[ff];
+		int bs = 0, bi = -1;
+		for (uint32_t i = (uint32_t)lane; i < nu; i += 64u) { const int sc = (int)(u[i] >> 32); if (sc > bs) { bs = sc; bi = (int)i; } }
+		for (int d = 32; d > 0; d >>= 1) { const int os = __shfl_xor(bs, d), oi = __shfl_xor(bi, d); if (oi >= 0 && (bi < 0 || os > bs || (os == bs && oi < bi))) { bs = os; bi = oi; } }
+		int r = 0;
+		if (bi >= 0) {
+			const int off = (int)uo[bi], cnt = (int32_t)(uint32_t)u[bi];
+			int chg = 0;
+			for (int i = 1 + lane; i < cnt; i += 64) chg += (a[off + i].y & AL_SEED_SEG_MASK) != (a[off + i - 1].y & AL_SEED_SEG_MASK) ? 1 : 0;
+			for (int d = 32; d > 0; d >>= 1) chg += __shfl_xor(chg, d);
+			r = 1 + chg < nsg ? 1 : 0;
 		}
-	} else rechain = 1;
+		if (lane == src) rechain = r;
+	}
 	if (rechain) list[atomicAdd(n_list, 1u)] = (uint32_t)f;
 }
 
