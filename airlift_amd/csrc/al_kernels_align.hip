@@ -2916,7 +2916,7 @@ int al_run_align_stage(al_ctx_t *c)
 // (queries of up to 256 bases -- every short-read set -- get the instance with the smaller query arrays: 12 instead of 14 KB of LDS per block at 16 blocks, a third wavefront per SIMD)
 #define LAUNCH_DPK(NBV) do { if (Lmax <= 256) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ext_dp<NBV, 256, NBV * 16, true>), dim3(nbj), dim3(64), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, G, E, A->job_idx2.p, first, cnt, A->gws.p, st2, pb, cw, c->P); \
 	                         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ext_dp<NBV, 512, NBV * 16, true>), dim3(nbj), dim3(64), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, G, E, A->job_idx2.p, first, cnt, A->gws.p, st2, pb, cw, c->P); } while (0)
-					if (NB == 1) LAUNCH_DP(1); else if (NB == 2) LAUNCH_DP(2); else if (NB == 4) LAUNCH_DP(4); else if (NB == 8) { if (dp_pk) LAUNCH_DPK(8); else LAUNCH_DP(8); } else if (NB == 32) LAUNCH_DP(32);
+					if (NB == 1) LAUNCH_DP(1); else if (NB == 2) LAUNCH_DP(2); else if (NB == 4) LAUNCH_DP(4); else if (NB == 8) { if (dp_pk) LAUNCH_DPK(8); else LAUNCH_DP(8); } else if (NB == 32) { static const bool pk32 = !(getenv("AL_DP_PK32") && atoi(getenv("AL_DP_PK32")) == 0); if (dp_pk && pk32) LAUNCH_DPK(32); else LAUNCH_DP(32); }
 					else {   // 9 ... 22 blocks: the sorted slice holds the jobs of <= 12 blocks first, then 13 ... 16, then the rest
 						static const bool split = !getenv("AL_DP_NO_SPLIT");
 						const uint32_t c12 = split ? (uint32_t)std::min<unsigned long long>(sub7[0], cnt) : 0u, c16 = split ? (uint32_t)std::min<unsigned long long>(sub7[1], cnt - c12) : 0u, c22 = cnt - c12 - c16;

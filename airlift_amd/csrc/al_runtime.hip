@@ -318,7 +318,7 @@ static const char *g_stage_names[ST_N] = { "sketch", "seed_lookup", "scan", "siz
 // the kernel of an interval that is exactly one launch of one kernel ("" otherwise: several kernels or several launches)
 static const char *g_stage_kernels[ST_N] = { "k_sketch", "k_seed", "", "", "k_anchor_sort_small", "", "", "", "",
                                              "", "", "", "", "", "", "", "",  "",
-                                             "", "k_ext_prep", "", "", "", "k_ext_dp<8, 512, 128>", "k_ext_dp<12, 512, 192>", "k_ext_dp<16, 512, 256>", "k_ext_dp<22, 512, 352>", "k_ext_finish", "k_compact" };
+                                             "", "k_ext_prep", "", "", "", "k_ext_dp<8, 256, 128, true>", "k_ext_dp<12, 256, 192, true>", "k_ext_dp<16, 256, 256, true>", "k_ext_dp<22, 256, 352, true>", "k_ext_finish", "k_compact" };   // (the DP instances of reads up to 256 bases with the default scores: two cells per lane; bench.py resolves the name against the committed profile)
 extern "C" const char *al_stage_kernel(int i) { return i >= 0 && i < ST_N ? g_stage_kernels[i] : ""; }
 extern "C" const char *al_stage_name(int i) { return i >= 0 && i < ST_N ? g_stage_names[i] : ""; }
 

@@ -422,6 +422,19 @@ def main():
         for iv in g7:
             own[iv] = (0.5 * float(st.dp_target_bases[7]) + 48.0 * float(st.dp_jobs[7])) * per[iv] / sum(per[i] for i in g7)
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))) if os.path.exists(os.path.join(ROOT, "profiles", "traffic.json")) else {}
+        # the DP kernel behind an interval as the committed profile names it: which instance runs depends on the read length (query arrays of 256 or 512 bases)
+        # and on the scores (two cells per lane, `true`, or the one-cell form)
+        dp_geo = {"ext_dp_g4": (4, 64), "ext_dp_g8": (8, 128), "ext_dp_g12": (12, 192), "ext_dp_g16": (16, 256), "ext_dp_g22": (22, 352)}
+        def dp_name(iv):
+            nb, t = dp_geo[iv]
+            cand = ["k_ext_dp<%d, %d, %d, true>" % (nb, 256 if a.read_len <= 256 else 512, t), "k_ext_dp<%d, 512, %d, true>" % (nb, t), "k_ext_dp<%d, 512, %d, false>" % (nb, t), "k_ext_dp<%d, 512, %d>" % (nb, t)]
+            for c_ in cand:
+                if c_ in tj.get("kernels", {}):
+                    return c_
+            return cand[0] if nb > 4 else cand[2]
+        for iv in dp_geo:
+            if kern.get(iv):
+                kern[iv] = dp_name(iv)
         stages = []
         for name, ivs, by in groups:
             ms = sum(per.get(i, 0.0) for i in ivs)
@@ -448,7 +461,7 @@ def main():
         # instruction occupies a 16-lane SIMD for 4 cycles, x 1024 SIMDs x 2.4 GHz (the DP kernels of profiles/r04b run at 0.9 ... 1.0 of it).
         VALU_CEIL = 1024 * 2.4e9 / 4.0
         valu = []
-        dpk = {"ext_dp_g4": "k_ext_dp<4, 512, 64>", "ext_dp_g8": "k_ext_dp<8, 512, 128>", "ext_dp_g12": "k_ext_dp<12, 512, 192>", "ext_dp_g16": "k_ext_dp<16, 512, 256>", "ext_dp_g22": "k_ext_dp<22, 512, 352>"}
+        dpk = {iv: dp_name(iv) for iv in dp_geo}
         for iv in ("ext_dp_g4", "ext_dp_g8", "ext_dp_g12", "ext_dp_g16", "ext_dp_g22"):
             ins = (tj.get("kernels", {}).get(dpk[iv]) or {}).get("valu_insts_per_launch") if tj.get("workload") == a.config else None
             ci = {"ext_dp_g4": 5, "ext_dp_g8": 6, "ext_dp_g12": 7, "ext_dp_g16": 7, "ext_dp_g22": 7}[iv]
