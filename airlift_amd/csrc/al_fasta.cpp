@@ -31,7 +31,7 @@ template <class F> void par_for(size_t n, int n_threads, F f)
 }
 
 // names / lengths / offsets into seq (AlSeq) and the concatenated sequence bytes (ASCII as in the file, terminators removed).
-bool al_fasta_load_parallel(const char *fn, int n_threads, std::vector<AlSeq> &seqs, std::vector<char> &ascii)
+bool al_fasta_load_parallel(const char *fn, int n_threads, std::vector<AlSeq> &seqs, AlText &ascii)
 {
 	if (!fn || !strcmp(fn, "-") || getenv("AL_SERIAL_PARSE")) return false;
 	const int fd = open(fn, O_RDONLY);
@@ -137,7 +137,7 @@ bool al_fasta_load_parallel(const char *fn, int n_threads, std::vector<AlSeq> &s
 #include "al_seqio.h"
 extern "C" int al_dbg_fasta_selftest(const char *fn, int n_threads)
 {
-	std::vector<AlSeq> ps; std::vector<char> pa;
+	std::vector<AlSeq> ps; AlText pa;
 	if (!al_fasta_load_parallel(fn, n_threads, ps, pa)) return 1;
 	AlSeqReader rd;
 	if (!rd.open(fn)) return -1;

@@ -175,7 +175,7 @@ extern "C" al_idx_t *al_idx_build_device(const char *fn, const al_idxopt_t *io, 
 	if (!rd.open(fn)) { fprintf(stderr, "[ERROR] airlift: failed to open '%s'\n", fn); return nullptr; }
 	al_idx_t *mi = new al_idx_t();
 	mi->k = k; mi->w = w;
-	std::vector<char> ascii; uint64_t sum = 0;
+	AlText ascii; uint64_t sum = 0;
 	const bool timing = getenv("AL_TIMING") != nullptr;
 	struct timespec tq0, tq1, tq2; clock_gettime(CLOCK_MONOTONIC, &tq0);
 	auto secs = [](const struct timespec &a, const struct timespec &b) { return (double)(b.tv_sec - a.tv_sec) + 1e-9 * (double)(b.tv_nsec - a.tv_nsec); };

@@ -5,6 +5,8 @@
 #include <stddef.h>
 #include <string>
 #include <vector>
+#include <memory>
+#include <utility>
 #include <map>
 #include <mutex>
 #include "../../include/airlift.h"
@@ -61,7 +63,15 @@ static inline uint64_t al_tab_slot(uint64_t hash, int bits) { return (hash * 0x9
 #define AL_TAB_SINGLE_MAX_SEQ 65536u
 
 // whole-file parallel FASTA loader (al_fasta.cpp); false: not a plain uncompressed FASTA file, use the block reader
-bool al_fasta_load_parallel(const char *fn, int n_threads, std::vector<AlSeq> &seqs, std::vector<char> &ascii);
+// bytes whose resize() does not write them: the loader's threads touch the pages of a genome's worth of text first (a value-initialising vector zeroes -- and
+// faults in -- 3 GB on one thread before the copy starts)
+template <class T> struct AlNoInit : std::allocator<T> {
+	template <class U> struct rebind { typedef AlNoInit<U> other; };
+	AlNoInit() = default; template <class U> AlNoInit(const AlNoInit<U> &) {}
+	template <class U, class... A> void construct(U *p, A &&...a) { if constexpr (sizeof...(A) == 0) ::new ((void *)p) U; else ::new ((void *)p) U(std::forward<A>(a)...); }
+};
+typedef std::vector<char, AlNoInit<char>> AlText;
+bool al_fasta_load_parallel(const char *fn, int n_threads, std::vector<AlSeq> &seqs, AlText &ascii);
 // host-side helpers (al_index.cpp)
 void al_sketch_host(const uint8_t *codes, uint32_t len, int w, int k, uint32_t rid, std::vector<uint64_t> &hash_out, std::vector<uint64_t> &y_out);
 

@@ -249,7 +249,8 @@ extern "C" int64_t al_device_reserve_for_run(int device, const char *ref_fn, int
 	const double index = 0.5 * G + 8.0 * n_min + tab, build_tmp = G + 4.0 * 8.0 * n_min + 4.0 * n_min;
 	const double kb = getenv("AL_RESERVE_KB_PER_READ") ? atof(getenv("AL_RESERVE_KB_PER_READ")) : G >= 1.0e9 ? 85.0 : G >= 2.0e8 ? 40.0 : 12.0;
 	const bool long_input = reads >= 3.0e6;
-	const double batch = long_input ? 524288.0 : std::min(131072.0, reads), n_ctx = long_input ? 2.0 : 3.0, n_slots = long_input ? 4.0 : 5.0;
+	static const double cap_long = getenv("AL_LONG_BATCH") ? atof(getenv("AL_LONG_BATCH")) : 524288.0;   // (the stream driver's bound on a long input's batches)
+	const double batch = long_input ? cap_long : std::min(131072.0, reads), n_ctx = long_input ? 2.0 : 3.0, n_slots = long_input ? 4.0 : 5.0;
 	const double ws = n_ctx * batch * kb * 1024.0 + n_slots * batch * 2300.0 + 1.5e9;
 	const double need = index + std::max(build_tmp, ws) * 1.08;
 	if (al_device_reserve(device, (uint64_t)need) != 0) return -1;
