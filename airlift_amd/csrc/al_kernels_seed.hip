@@ -28,11 +28,14 @@ __device__ __forceinline__ uint64_t d_hash64m(uint64_t key, uint64_t mask)
 	return key;
 }
 
-extern "C" __global__ void __launch_bounds__(64)
-k_sketch(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_off, const uint32_t *__restrict__ rd_len,
+// W: the window as a constant (the loops over the ring unroll, their LDS reads go out back to back), 0 = the argument
+template <int W>
+__device__ __forceinline__ void
+d_sketch(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_off, const uint32_t *__restrict__ rd_len,
          const uint64_t *__restrict__ mini_off, AlAnchor *__restrict__ mini, uint32_t *__restrict__ mini_cnt,
-         int n_reads, int w, int k, int pb)
+         int n_reads, const int w_arg, int k, int pb)
 {
+	const int w = W ? W : w_arg;
 	// One 64-bit ring entry per window slot: hash << pb | pos << 1 | strand (a valid entry always has span == k; pb = min(22,
 	// 64 - 2k) bits hold position and strand: reads shorter than 2^(pb-1) bases -- 2 Mbases for k <= 21, 8192 for k = 25; the
 	// upload checks it), UINT64_MAX = no k-mer.  The reference's comparisons are on x = hash<<8|span, i.e. on the
@@ -78,9 +81,13 @@ k_sketch(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_of
 		} else if (buf_pos == min_pos) {                                    // sketch.c:126-138
 			if (l >= w + k - 1 && mn != UINT64_MAX) EMIT(mn);
 			mn = UINT64_MAX;
-			for (int j = buf_pos + 1; j < w; ++j) { const uint64_t e = ring[j * 64]; if (HX(mn) >= HX(e)) mn = e, min_pos = j; }
-			for (int j = 0; j <= buf_pos; ++j)    { const uint64_t e = ring[j * 64]; if (HX(mn) >= HX(e)) mn = e, min_pos = j; }
-			if (l >= w + k - 1 && mn != UINT64_MAX) {
+			// (dup: another entry of the window has the new minimum's hash -- the only case in which the two loops below emit anything.  Some lane of the wavefront
+			//  is in this branch at nearly every base, so what it costs is paid per base by all 64: the second pair of loops only where it has something to write)
+			bool dup = false;
+			// (slots buf_pos + 1 ... w - 1, then 0 ... buf_pos -- oldest to newest -- as ONE loop of w steps: it unrolls when the window is a constant)
+#pragma unroll
+			for (int t = 0; t < w; ++t) { int j = buf_pos + 1 + t; j = j >= w ? j - w : j; const uint64_t e = ring[j * 64]; if (HX(mn) >= HX(e)) { dup = HX(mn) == HX(e); mn = e, min_pos = j; } }
+			if (dup && l >= w + k - 1 && mn != UINT64_MAX) {
 				const uint64_t m2 = HX(mn);
 				for (int j = buf_pos + 1; j < w; ++j) { const uint64_t e = ring[j * 64]; if (m2 == HX(e) && mn != e) EMIT(e); }
 				for (int j = 0; j <= buf_pos; ++j)    { const uint64_t e = ring[j * 64]; if (m2 == HX(e) && mn != e) EMIT(e); }
@@ -92,6 +99,14 @@ k_sketch(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_of
 #undef HX
 #undef EMIT
 	mini_cnt[r] = cnt;
+}
+extern "C" __global__ void __launch_bounds__(64)
+k_sketch(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_off, const uint32_t *__restrict__ rd_len,
+         const uint64_t *__restrict__ mini_off, AlAnchor *__restrict__ mini, uint32_t *__restrict__ mini_cnt,
+         int n_reads, int w, int k, int pb)
+{
+	if (w == 11) d_sketch<11>(rd_seq, rd_off, rd_len, mini_off, mini, mini_cnt, n_reads, w, k, pb);    // (the short-read preset's window)
+	else d_sketch<0>(rd_seq, rd_off, rd_len, mini_off, mini, mini_cnt, n_reads, w, k, pb);
 }
 
 // =============================================================================================
