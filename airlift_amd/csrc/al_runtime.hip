@@ -710,7 +710,7 @@ static int chain_by_segments(al_ctx_t *c, const uint32_t *order, int n, bool lds
 	const uint32_t *fb = c->fb_list.p;
 	if (n_fb > 0 && keep_keys) {   // order restated from the merged chains and their processing keys; only what does not fit its tile is chained again
 		const size_t lds = (size_t)AL_ORD_CAP * (8 + 4 + 2) + 64, lds16 = (size_t)AL_ORD_CAP2 * (8 + 2) + 64;   // (lds16 >= lds: the block form keeps the one-wavefront layout up to AL_ORD_CAP chains)
-		static const int nu_block = getenv("AL_ORDER_BLOCK") ? atoi(getenv("AL_ORDER_BLOCK")) : 512;             // chains from which a block of 16 wavefronts takes the fragment
+		static const int nu_block = getenv("AL_ORDER_BLOCK") ? atoi(getenv("AL_ORDER_BLOCK")) : 128;             // chains from which a block of 16 wavefronts takes the fragment
 		if (!c->attr_chain_order) {
 			AL_HIP_CHECK(hipFuncSetAttribute((const void *)k_chain_order_t<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 			AL_HIP_CHECK(hipFuncSetAttribute((const void *)k_chain_order_t<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16));
