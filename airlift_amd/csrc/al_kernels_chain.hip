@@ -503,7 +503,7 @@ ct_tile_body(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ 
 	const uint32_t *__restrict__ skip_flag, AlAnchor *__restrict__ chained, uint64_t *__restrict__ u_out, uint32_t *__restrict__ uo_out, uint32_t *__restrict__ frag_nu, uint32_t *__restrict__ fb_list, uint32_t *__restrict__ fb_cnt, \
 	const AlParams P, const int lmin, unsigned long long *__restrict__ counters, const int force_fb, const CtDefer D
 #define CT_PASS anchors, a_off, frag_na, frag_meta, list, S, skip_flag, chained, u_out, uo_out, frag_nu, fb_list, fb_cnt, P, lmin, counters, force_fb, D
-__global__ void __launch_bounds__(CT_NT) __attribute__((amdgpu_waves_per_eu(6))) k_chain_tile6(CT_ARGS) { ct_tile_body(CT_PASS); }
+__global__ void __launch_bounds__(CT_NT) __attribute__((amdgpu_waves_per_eu(7))) k_chain_tile6(CT_ARGS) { ct_tile_body(CT_PASS); }
 
 // The chain lists of the fragments with deferred segments have empty slots (the reserve the lane kernels did not need): closed here, a wavefront per
 // fragment, in place and in order.  Then the fragment-wide tie rule: more than 64 chains of which two start at equal x -> fallback list.
