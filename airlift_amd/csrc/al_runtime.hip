@@ -1046,8 +1046,8 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 		}
 		// (round 5) runs of 8192 anchors sorted by the register network, then merged pairwise (k_anchor_run_sort / k_anchor_run_merge): one to six passes of 8 bytes
 		// per anchor by the fragment's size instead of expansion + seven radix passes + scatter.  AL_BIG_MERGE=0: the device-wide sort (tests run both).
-		static const bool big_merge = !(getenv("AL_BIG_MERGE") && atoi(getenv("AL_BIG_MERGE")) == 0);
-		const bool use_merge = big_merge && 33 + rid_bits + 16 <= 64 && lb_big < (uint32_t)nl;
+		static const int big_merge = getenv("AL_BIG_MERGE") ? atoi(getenv("AL_BIG_MERGE")) : 1;        // 0: radix everywhere, 1: run merge everywhere, 2: run merge in the re-chain pass only
+		const bool use_merge = (big_merge == 1 || (big_merge == 2 && !first)) && 33 + rid_bits + 16 <= 64 && lb_big < (uint32_t)nl;
 		// AL_TEST_RUN=<run>,<tile> (tests): shorter runs and merge tiles (powers of two, tile <= run <= 8192, tile <= 2048) so that the golden sets' fragments take several passes
 		static uint32_t run_len = 8192, tile = 2048;
 		{ static bool once = false; if (!once) { once = true; const char *e = getenv("AL_TEST_RUN"); unsigned a = 0, b = 0;
