@@ -2868,23 +2868,36 @@ int al_run_align_stage(al_ctx_t *c)
 			// one launch per job class over its slice of the sorted job list
 			static const int NBs[6] = {1, 2, 4, 8, 22, 32};
 			uint32_t first = 0;
+			// (round 5) A small batch's classes do not fill the chip (C2: 32 000 jobs of 9 ... 22 blocks over three kernels, 8 blocks per CU) and every class ends in the
+			// tail of its longest job (the 22-block kernel: 0.85 ms whatever the batch): below AL_DP_CONC jobs (default 700 000; 0: never) the class kernels run side by
+			// side on four streams, each on a workspace range of its own; the per-class intervals of the stage table then hold launch order only.
+			static const long long conc_thr = getenv("AL_DP_CONC") ? atoll(getenv("AL_DP_CONC")) : 700000;
+			long long n_real = 0; for (int cls = 0; cls < AL_NCLS; ++cls) n_real += (long long)hist[cls];                   // (nj counts two slots per hit, most of them empty)
+			const bool dp_conc = n_real < conc_thr;
+			size_t ws_off[AL_NCLS + 1]; ws_off[0] = 0;
 			{   // one workspace range for every class of this batch: sized for the largest now, not grown class by class (a regrow frees -- and waits for -- what the running class uses)
 				size_t need = 0;
 				for (int cls = 0; cls < AL_NCLS; ++cls) {
-					const uint32_t cnt = (uint32_t)hist[cls]; if (cnt == 0) continue;
-					size_t b;
-					if (cls < 3) { const int TC = 16 << cls; int nw = (int)((cnt + 63) / 64); if (nw > 1024) nw = 1024; b = (size_t)nw * ((size_t)(AL_LANE_QC + TC) * (size_t)(TC + 16) * 64); }
+					const uint32_t cnt = (uint32_t)hist[cls];
+					size_t b = 0;
+					if (cnt == 0) b = 0;
+					else if (cls < 3) { const int TC = 16 << cls; int nw = (int)((cnt + 63) / 64); if (nw > 1024) nw = 1024; b = (size_t)nw * ((size_t)(AL_LANE_QC + TC) * (size_t)(TC + 16) * 64); }
 					else if (cls < 9) {
 						const int NB = NBs[cls - 3];
 						const size_t pb = (((size_t)(Lmax + 16 * NB) * (size_t)(NB + 1) * 16) + 63) / 64 * 64, cw = ((size_t)(Lmax + 16 * NB) + 31) / 16 * 16, st2 = pb + cw * 8;
 						const int cap = NB <= 4 ? (getenv("AL_CAP4") ? atoi(getenv("AL_CAP4")) : 4096) : NB <= 8 ? (getenv("AL_CAP8") ? atoi(getenv("AL_CAP8")) : 4096) : NB <= 22 ? (getenv("AL_CAP22") ? atoi(getenv("AL_CAP22")) : 3072) : 2048;
 						int nbj = (int)((cnt + 3) / 4); if (nbj > cap) nbj = cap;
-						b = (size_t)nbj * 4 * st2;
+						b = (size_t)nbj * 4 * st2 * (dp_conc && cls == 7 ? 3 : 1);         // (side by side the 12 / 16 / 22-block kernels of class 7 take a range each)
 					} else { int nbj = (int)cnt; if (nbj > 2048) nbj = 2048; b = (size_t)nbj * stride; }
-					if (b > need) need = b;
+					b = (b + 255) / 256 * 256;
+					ws_off[cls + 1] = dp_conc ? ws_off[cls] + b : 0;
+					if (dp_conc) need += b; else if (b > need) need = b;
 				}
 				if (need && A->gws.ensure(need + 64)) return -1;
 			}
+			hipStream_t dps[4] = {s, c->aux[0], c->aux[1], c->aux[2]}; int dpk = 0;
+			if (dp_conc) { AL_HIP_CHECK(hipEventRecord(c->ev_fj[0], s)); for (int i = 0; i < 3; ++i) AL_HIP_CHECK(hipStreamWaitEvent(c->aux[i], c->ev_fj[0], 0)); }
+			hipStream_t const s_main = s;
 			bool g12_done = false;
 			// two cells per lane (al_dev_ksw2.h) where its arithmetic holds: the permute's constant 0xff is the score of an N, scores within +-16
 			// (int16 H of the 352 x 512 tile); AL_DP_PK=0: the one-cell form everywhere (tests, A/B)
@@ -2898,35 +2911,38 @@ int al_run_align_stage(al_ctx_t *c)
 				if (cls == 7) AL_HIP_CHECK(hipEventRecord(c->ev[ST_EXT_DP_G8 + 1], s));
 				if (cls == 8 && !g12_done) { AL_HIP_CHECK(hipEventRecord(c->ev[ST_EXT_DP_G12 + 1], s)); AL_HIP_CHECK(hipEventRecord(c->ev[ST_EXT_DP_G16 + 1], s)); g12_done = true; }
 				if (cnt == 0) continue;
+				unsigned char *const gbase = A->gws.p + ws_off[cls];
+				hipStream_t s = dp_conc ? dps[dpk++ & 3] : s_main;                 // (shadows the stage's stream inside the class)
 				if (cls < 3) {                                                    // lane-per-job
 					const int TC = 16 << cls;
 					const size_t tbs = (size_t)(AL_LANE_QC + TC) * (size_t)(TC + 16) * 64;
 					int nw = (int)((cnt + 63) / 64); if (nw > 1024) nw = 1024;
-					if (A->gws.ensure((size_t)nw * tbs + 64)) return -1;
-					if (cls == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ext_dp_lane<16, AL_LANE_QC>), dim3(nw), dim3(64), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, G, E, A->job_idx2.p, first, cnt, A->gws.p, tbs, c->P);
-					else if (cls == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ext_dp_lane<32, AL_LANE_QC>), dim3(nw), dim3(64), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, G, E, A->job_idx2.p, first, cnt, A->gws.p, tbs, c->P);
-					else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ext_dp_lane<64, AL_LANE_QC>), dim3(nw), dim3(64), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, G, E, A->job_idx2.p, first, cnt, A->gws.p, tbs, c->P);
+					if (cls == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ext_dp_lane<16, AL_LANE_QC>), dim3(nw), dim3(64), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, G, E, A->job_idx2.p, first, cnt, gbase, tbs, c->P);
+					else if (cls == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ext_dp_lane<32, AL_LANE_QC>), dim3(nw), dim3(64), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, G, E, A->job_idx2.p, first, cnt, gbase, tbs, c->P);
+					else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ext_dp_lane<64, AL_LANE_QC>), dim3(nw), dim3(64), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, G, E, A->job_idx2.p, first, cnt, gbase, tbs, c->P);
 				} else if (cls < 9) {
 					const int NB = NBs[cls - 3];
 					const size_t pb = (((size_t)(Lmax + 16 * NB) * (size_t)(NB + 1) * 16) + 63) / 64 * 64, cw = ((size_t)(Lmax + 16 * NB) + 31) / 16 * 16, st2 = pb + cw * 8;
 					int nbj = (int)((cnt + 3) / 4); { static const int caps[3] = { getenv("AL_CAP4") ? atoi(getenv("AL_CAP4")) : 4096, getenv("AL_CAP8") ? atoi(getenv("AL_CAP8")) : 4096, getenv("AL_CAP22") ? atoi(getenv("AL_CAP22")) : 3072 };
 					  const int cap = NB <= 4 ? caps[0] : NB <= 8 ? caps[1] : NB <= 22 ? caps[2] : 2048; if (nbj > cap) nbj = cap; }
-					if (A->gws.ensure((size_t)nbj * 4 * st2 + 64)) return -1;
-#define LAUNCH_DP(NBV) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ext_dp<NBV, 512, NBV * 16>), dim3(nbj), dim3(64), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, G, E, A->job_idx2.p, first, cnt, A->gws.p, st2, pb, cw, c->P)
+#define LAUNCH_DP(NBV) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ext_dp<NBV, 512, NBV * 16>), dim3(nbj), dim3(64), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, G, E, A->job_idx2.p, first, cnt, gbase, st2, pb, cw, c->P)
 // (queries of up to 256 bases -- every short-read set -- get the instance with the smaller query arrays: 12 instead of 14 KB of LDS per block at 16 blocks, a third wavefront per SIMD)
-#define LAUNCH_DPK(NBV) do { if (Lmax <= 256) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ext_dp<NBV, 256, NBV * 16, true>), dim3(nbj), dim3(64), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, G, E, A->job_idx2.p, first, cnt, A->gws.p, st2, pb, cw, c->P); \
-	                         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ext_dp<NBV, 512, NBV * 16, true>), dim3(nbj), dim3(64), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, G, E, A->job_idx2.p, first, cnt, A->gws.p, st2, pb, cw, c->P); } while (0)
+#define LAUNCH_DPK(NBV) do { if (Lmax <= 256) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ext_dp<NBV, 256, NBV * 16, true>), dim3(nbj), dim3(64), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, G, E, A->job_idx2.p, first, cnt, gbase, st2, pb, cw, c->P); \
+	                         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ext_dp<NBV, 512, NBV * 16, true>), dim3(nbj), dim3(64), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, G, E, A->job_idx2.p, first, cnt, gbase, st2, pb, cw, c->P); } while (0)
 					if (NB == 1) LAUNCH_DP(1); else if (NB == 2) LAUNCH_DP(2); else if (NB == 4) LAUNCH_DP(4); else if (NB == 8) { if (dp_pk) LAUNCH_DPK(8); else LAUNCH_DP(8); } else if (NB == 32) { static const bool pk32 = !(getenv("AL_DP_PK32") && atoi(getenv("AL_DP_PK32")) == 0); if (dp_pk && pk32) LAUNCH_DPK(32); else LAUNCH_DP(32); }
 					else {   // 9 ... 22 blocks: the sorted slice holds the jobs of <= 12 blocks first, then 13 ... 16, then the rest
 						static const bool split = !getenv("AL_DP_NO_SPLIT");
 						const uint32_t c12 = split ? (uint32_t)std::min<unsigned long long>(sub7[0], cnt) : 0u, c16 = split ? (uint32_t)std::min<unsigned long long>(sub7[1], cnt - c12) : 0u, c22 = cnt - c12 - c16;
 						const uint32_t first0 = first, cnt0 = cnt;
 #define LAUNCH_DPS(NBV, F, N) do { if ((N) > 0) { int nb2 = (int)(((N) + 3) / 4); if (nb2 > nbj) nb2 = nbj; \
-							if (dp_pk && Lmax <= 256) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ext_dp<NBV, 256, NBV * 16, true>), dim3(nb2), dim3(64), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, G, E, A->job_idx2.p, (F), (N), A->gws.p + (size_t)gw_used * 4 * st2, st2, pb, cw, c->P); \
-							else if (dp_pk) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ext_dp<NBV, 512, NBV * 16, true>), dim3(nb2), dim3(64), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, G, E, A->job_idx2.p, (F), (N), A->gws.p + (size_t)gw_used * 4 * st2, st2, pb, cw, c->P); \
-							else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ext_dp<NBV, 512, NBV * 16>), dim3(nb2), dim3(64), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, G, E, A->job_idx2.p, (F), (N), A->gws.p + (size_t)gw_used * 4 * st2, st2, pb, cw, c->P); gw_used += nb2; } } while (0)
+							if (dp_pk && Lmax <= 256) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ext_dp<NBV, 256, NBV * 16, true>), dim3(nb2), dim3(64), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, G, E, A->job_idx2.p, (F), (N), gbase + (size_t)gw_used * 4 * st2, st2, pb, cw, c->P); \
+							else if (dp_pk) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ext_dp<NBV, 512, NBV * 16, true>), dim3(nb2), dim3(64), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, G, E, A->job_idx2.p, (F), (N), gbase + (size_t)gw_used * 4 * st2, st2, pb, cw, c->P); \
+							else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ext_dp<NBV, 512, NBV * 16>), dim3(nb2), dim3(64), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, G, E, A->job_idx2.p, (F), (N), gbase + (size_t)gw_used * 4 * st2, st2, pb, cw, c->P); gw_used += nb2; } } while (0)
 						// (the three kernels run one after the other on this stream: they may share the workspace range)
-						int gw_used = 0; LAUNCH_DPS(12, first0, c12); AL_HIP_CHECK(hipEventRecord(c->ev[ST_EXT_DP_G12 + 1], s)); gw_used = 0; LAUNCH_DPS(16, first0 + c12, c16); AL_HIP_CHECK(hipEventRecord(c->ev[ST_EXT_DP_G16 + 1], s)); gw_used = 0; LAUNCH_DPS(22, first0 + c12 + c16, c22);
+						int gw_used = 0;
+						if (dp_conc) { LAUNCH_DPS(16, first0 + c12, c16); s = dps[dpk++ & 3]; LAUNCH_DPS(12, first0, c12); s = dps[dpk++ & 3]; LAUNCH_DPS(22, first0 + c12 + c16, c22);
+						               AL_HIP_CHECK(hipEventRecord(c->ev[ST_EXT_DP_G12 + 1], s_main)); AL_HIP_CHECK(hipEventRecord(c->ev[ST_EXT_DP_G16 + 1], s_main)); }
+						else { LAUNCH_DPS(12, first0, c12); AL_HIP_CHECK(hipEventRecord(c->ev[ST_EXT_DP_G12 + 1], s)); gw_used = 0; LAUNCH_DPS(16, first0 + c12, c16); AL_HIP_CHECK(hipEventRecord(c->ev[ST_EXT_DP_G16 + 1], s)); gw_used = 0; LAUNCH_DPS(22, first0 + c12 + c16, c22); }
 						g12_done = true;
 						(void)cnt0;
 #undef LAUNCH_DPS
@@ -2935,13 +2951,13 @@ int al_run_align_stage(al_ctx_t *c)
 #undef LAUNCH_DPK
 				} else {
 					int nbj = (int)cnt; if (nbj > 2048) nbj = 2048;
-					if (A->gws.ensure((size_t)nbj * stride + 64)) return -1;
-					if (tmax <= 512) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ext_dp_lds<512, 256>), dim3(nbj), dim3(GW), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, G, E, A->job_idx2.p, first, cnt, A->gws.p, stride, p_bytes, cig_words, c->P);
-					else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ext_dp_lds<1024, 512>), dim3(nbj), dim3(GW), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, G, E, A->job_idx2.p, first, cnt, A->gws.p, stride, p_bytes, cig_words, c->P);
+					if (tmax <= 512) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ext_dp_lds<512, 256>), dim3(nbj), dim3(GW), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, G, E, A->job_idx2.p, first, cnt, gbase, stride, p_bytes, cig_words, c->P);
+					else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ext_dp_lds<1024, 512>), dim3(nbj), dim3(GW), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, G, E, A->job_idx2.p, first, cnt, gbase, stride, p_bytes, cig_words, c->P);
 				}
 				if (getenv("AL_TRACE")) { const hipError_t e = hipStreamSynchronize(s); fprintf(stderr, "[airlift] trace: DP class %d (%u jobs) -> %s\n", cls, cnt, hipGetErrorName(e)); }
 				first += cnt;
 			}
+			if (dp_conc) for (int i = 0; i < 3; ++i) { AL_HIP_CHECK(hipEventRecord(c->ev_aux[i], c->aux[i])); AL_HIP_CHECK(hipStreamWaitEvent(s, c->ev_aux[i], 0)); }
 		}
 		else { AL_HIP_CHECK(hipEventRecord(c->ev[ST_EXT_SORT + 1], s)); for (int i = ST_EXT_DP_LANE; i < ST_EXT_DP_G22; ++i) AL_HIP_CHECK(hipEventRecord(c->ev[i + 1], s)); }   // (no jobs: empty intervals)
 		AL_HIP_CHECK(hipEventRecord(c->ev[ST_EXT_DP_G22 + 1], s));

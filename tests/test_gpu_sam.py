@@ -75,14 +75,14 @@ def test_lds_dp_path_identical(golden_unpacked, name):
 
 @pytest.mark.parametrize("env", [dict(AL_DBG=str(1 << 27)), dict(AL_TEST_SORT_BLK="65"), dict(AL_TEST_SORT_BIG="65"), dict(AL_TEST_SORT_BLK="65", AL_TEST_SORT_BIG="200"),
                                  dict(AL_TEST_SORT_BIG="65", AL_TEST_BIG_CHUNK="3", AL_BIG_MERGE="0"), dict(AL_TEST_SORT_BIG="65", AL_BIG_MERGE="0"), dict(AL_TEST_SORT_BIG="65", AL_TEST_RUN="64,16"), dict(AL_TEST_SORT_BIG="65", AL_TEST_RUN="128,128", AL_TEST_POISON="170", AL_TEST_GUARD="1"),
-                                 dict(AL_ORDER_BLOCK="65"), dict(AL_ORDER_BLOCK="100000"),
+                                 dict(AL_ORDER_BLOCK="65"), dict(AL_ORDER_BLOCK="100000"), dict(AL_DP_CONC="0"),
                                  dict(AL_HEAP_OLD="1", AL_TEST_HEAP_WAVE="1"), dict(AL_HEAP_OLD="1"), dict(AL_SPEC_MIN="1"), dict(AL_SPEC_MERGE="0"), dict(AL_CHAIN_WAVE_MAX="0"),
                                  dict(AL_TEST_SEG_BIG="160", AL_DBG=str(1 << 27)), dict(AL_TEST_SEG_BIG="64", AL_TEST_POISON="170", AL_TEST_GUARD="1", AL_DBG=str(1 << 28)),
                                  dict(AL_TEST_TILE_ALL="1"), dict(AL_TEST_TILE_ALL="1", AL_TEST_POISON="170", AL_TEST_GUARD="1"), dict(AL_DBG=str(1 << 28)), dict(AL_TEST_TILE_ALL="1", AL_TEST_TILE_FB="1"),
                                  dict(AL_TEST_TILE_ALL="1", AL_CHAIN_COOP="1"), dict(AL_TEST_TILE_ALL="1", AL_CHAIN_COOP="0"),
                                  dict(AL_PREP_HEAVY="2", AL_FIN_HEAVY="2"), dict(AL_PREP_HEAVY="2", AL_FIN_HEAVY="2", AL_TEST_POISON="170", AL_TEST_GUARD="1"), dict(AL_PREP_HEAVY="0", AL_FIN_HEAVY="0"),
                                  dict(AL_REGS_SPLIT="0"), dict(AL_CHAIN_OVL="0", AL_SIDE_PRIO="1")],
-                         ids=["segments_wave_only", "block_sort", "run_merge_sort", "block_and_run_merge_sort", "device_radix_sort_chunks", "device_radix_sort", "run_merge_sort_runs_of_64_tiles_of_16", "run_merge_sort_runs_of_128_poisoned_memory", "chain_order_by_a_block_of_16_wavefronts", "chain_order_by_one_wavefront", "serial_heap_merge_by_wavefront", "serial_heap_merge_by_lanes", "merge_ahead_of_the_rechain_pass_every_candidate", "no_merge_ahead_of_the_rechain_pass", "lds_chain_kernels_for_thin_classes",
+                         ids=["segments_wave_only", "block_sort", "run_merge_sort", "block_and_run_merge_sort", "device_radix_sort_chunks", "device_radix_sort", "run_merge_sort_runs_of_64_tiles_of_16", "run_merge_sort_runs_of_128_poisoned_memory", "chain_order_by_a_block_of_16_wavefronts", "chain_order_by_one_wavefront", "dp_classes_one_after_the_other", "serial_heap_merge_by_wavefront", "serial_heap_merge_by_lanes", "merge_ahead_of_the_rechain_pass_every_candidate", "no_merge_ahead_of_the_rechain_pass", "lds_chain_kernels_for_thin_classes",
                               "cut_and_merge_by_eight_wavefronts_all_fragments", "cut_and_merge_by_eight_wavefronts_poisoned_memory",
                               "tile_kernel_all_fragments", "tile_kernel_all_fragments_poisoned_memory", "segment_kernels_instead_of_tiles", "tile_kernel_hands_every_fragment_back",
                               "deferred_segments_sixteen_lanes_each", "deferred_segments_a_lane_each",
