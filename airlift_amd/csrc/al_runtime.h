@@ -67,8 +67,8 @@ struct al_ctx_s {
 	hipEvent_t ev_fj[2] = {};             // fork / join of the side stream inside a stage (chain_post classes, DP job classes)
 	hipStream_t aux[3] = {};              // more streams for stages made of independent latency-bound launches over disjoint fragments (heap merge classes, k_regs_heavy tiles)
 	hipEvent_t ev_aux[3] = {};            // ... their join events
-	hipStream_t ovl[2] = {};              // stages of the seed pass that run beside the main stream's: the device-wide anchor sort next to the block sorts, the lane chaining kernels next to the tile kernel
-	hipEvent_t ev_ovl[4] = {};            // ... fork and join events of the two
+	hipStream_t ovl[3] = {};              // stages of the seed pass that run beside the main stream's: the device-wide anchor sort next to the block sorts, the lane chaining kernels next to the tile kernel
+	hipEvent_t ev_ovl[5] = {};            // ... fork and join events of the two
 	bool ovl_pending = false;             // chaining kernels in flight on ovl[1]: chain_tiles joins them before it reuses their scratch
 	hipEvent_t ev_side[4] = {};           // [0],[1]: start / end of the side stream's work in the first pass, [2],[3]: in the re-chain pass
 	// the equal-x merge of giant fragments started ahead of the re-chain pass (al_kernels_seed.hip: k_spec_build): its stream, events, slots

@@ -390,10 +390,10 @@ extern "C" al_ctx_t *al_ctx_init(const al_idx_t *mi, const al_mapopt_t *opt, int
 	if (hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, sp) != hipSuccess || hipEventCreate(&c->ev_side[0]) != hipSuccess || hipEventCreate(&c->ev_side[1]) != hipSuccess || hipEventCreate(&c->ev_side[2]) != hipSuccess || hipEventCreate(&c->ev_side[3]) != hipSuccess ||
 	    hipEventCreateWithFlags(&c->ev_fj[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_fj[1], hipEventDisableTiming) != hipSuccess) { delete c; return nullptr; }
 	for (int i = 0; i < 3; ++i) if (hipStreamCreateWithPriority(&c->aux[i], hipStreamNonBlocking, sp) != hipSuccess || hipEventCreateWithFlags(&c->ev_aux[i], hipEventDisableTiming) != hipSuccess) { delete c; return nullptr; }
-	for (int i = 0; i < 2; ++i) if (hipStreamCreateWithFlags(&c->ovl[i], hipStreamNonBlocking) != hipSuccess) { delete c; return nullptr; }
+	for (int i = 0; i < 3; ++i) if (hipStreamCreateWithFlags(&c->ovl[i], hipStreamNonBlocking) != hipSuccess) { delete c; return nullptr; }
 	if (hipStreamCreateWithFlags(&c->spec, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&c->spec2, hipStreamNonBlocking) != hipSuccess) { delete c; return nullptr; }
 	for (int i = 0; i < 3; ++i) if (hipEventCreateWithFlags(&c->ev_spec[i], hipEventDisableTiming) != hipSuccess) { delete c; return nullptr; }
-	for (int i = 0; i < 4; ++i) if (hipEventCreateWithFlags(&c->ev_ovl[i], hipEventDisableTiming) != hipSuccess) { delete c; return nullptr; }
+	for (int i = 0; i < 5; ++i) if (hipEventCreateWithFlags(&c->ev_ovl[i], hipEventDisableTiming) != hipSuccess) { delete c; return nullptr; }
 	if (al_upload_index(mi, device, &c->di) != 0) { delete c; return nullptr; }
 	AlParams &P = c->P;
 	P.k = mi->k; P.w = mi->w; P.seed = opt->seed; P.bw = opt->bw; P.max_gap = opt->max_gap; P.max_gap_ref = opt->max_gap_ref; P.max_frag_len = opt->max_frag_len;
@@ -412,7 +412,7 @@ static void ctx_release_buffers(al_ctx_t *c)
 	al_align_state_free(c);
 	if (c->side) (void)hipStreamSynchronize(c->side);
 	for (int i = 0; i < 3; ++i) if (c->aux[i]) (void)hipStreamSynchronize(c->aux[i]);
-	for (int i = 0; i < 2; ++i) if (c->ovl[i]) (void)hipStreamSynchronize(c->ovl[i]);
+	for (int i = 0; i < 3; ++i) if (c->ovl[i]) (void)hipStreamSynchronize(c->ovl[i]);
 	if (c->spec) (void)hipStreamSynchronize(c->spec);
 	if (c->spec2) (void)hipStreamSynchronize(c->spec2);
 	c->spec_busy = false; c->spec_pending = false; c->n_spec = 0;
@@ -437,8 +437,8 @@ extern "C" void al_ctx_destroy(al_ctx_t *c)
 	for (int i = 0; i < 2; ++i) if (c->ev_fj[i]) (void)hipEventDestroy(c->ev_fj[i]);
 	if (c->side) (void)hipStreamDestroy(c->side);
 	for (int i = 0; i < 3; ++i) { if (c->aux[i]) (void)hipStreamDestroy(c->aux[i]); if (c->ev_aux[i]) (void)hipEventDestroy(c->ev_aux[i]); }
-	for (int i = 0; i < 2; ++i) if (c->ovl[i]) (void)hipStreamDestroy(c->ovl[i]);
-	for (int i = 0; i < 4; ++i) if (c->ev_ovl[i]) (void)hipEventDestroy(c->ev_ovl[i]);
+	for (int i = 0; i < 3; ++i) if (c->ovl[i]) (void)hipStreamDestroy(c->ovl[i]);
+	for (int i = 0; i < 5; ++i) if (c->ev_ovl[i]) (void)hipEventDestroy(c->ev_ovl[i]);
 	if (c->spec) (void)hipStreamDestroy(c->spec);
 	if (c->spec2) (void)hipStreamDestroy(c->spec2);
 	for (int i = 0; i < 3; ++i) if (c->ev_spec[i]) (void)hipEventDestroy(c->ev_spec[i]);
@@ -1000,13 +1000,16 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 		// of the large fragments and beside the tile kernel, which takes the rest of the list.
 		hipStream_t const s_main = s;
 		static const bool use_ovl = !(getenv("AL_CHAIN_OVL") && atoi(getenv("AL_CHAIN_OVL")) == 0);   // (AL_CHAIN_OVL=0: on the main stream, after the sorts)
-		if (use_ovl) AL_HIP_CHECK(hipStreamWaitEvent(c->ovl[1], c->ev_ovl[2], 0));
-		{ hipStream_t const s = use_ovl ? c->ovl[1] : s_main;
+		// (round 5) ... on TWO streams, the classes in turn (AL_CHAIN_OVL2=0: one): a class ends in the tail of its slowest wavefronts, and the next one's start fills it
+		static const bool two = !(getenv("AL_CHAIN_OVL2") && atoi(getenv("AL_CHAIN_OVL2")) == 0);
+		if (use_ovl) { AL_HIP_CHECK(hipStreamWaitEvent(c->ovl[1], c->ev_ovl[2], 0)); if (two) AL_HIP_CHECK(hipStreamWaitEvent(c->ovl[2], c->ev_ovl[2], 0)); }
+		{ hipStream_t s = use_ovl ? c->ovl[1] : s_main; int turn = 0;
+#define NEXT_S() do { if (use_ovl && two) s = c->ovl[1 + (++turn & 1)]; } while (0)
 #define LFR(C, L, A, B) LCH(C, L, -1, c->a_off.p, c->frag_na.p, c->chained.p, c->u.p, c->frag_nu.p, order + (A), (int)((B) - (A)), nosg, c->uo.p, c->ws_u64.p + (size_t)n_lo * 64 + (size_t)((A) - lb65) * 128, 128)
 #define LFRLO(C, L, LO) LCH(C, L, LO, c->a_off.p, c->frag_na.p, c->chained.p, c->u.p, c->frag_nu.p, order, (int)n_lo, nosg, c->uo.p, c->ws_u64.p, 64)
-		if (lds_ok) { LFRLO(16, 64, -1); LFRLO(24, 64, 16); LFRLO(32, 64, 24); }
-		if (lds_ok) { LFRLO(40, 64, 32); LFRLO(48, 64, 40); }
-		if (lds_ok) LFRLO(64, 64, 48);
+		if (lds_ok) { LFRLO(16, 64, -1); NEXT_S(); LFRLO(24, 64, 16); NEXT_S(); LFRLO(32, 64, 24); NEXT_S(); }
+		if (lds_ok) { LFRLO(40, 64, 32); NEXT_S(); LFRLO(48, 64, 40); NEXT_S(); }
+		if (lds_ok) { LFRLO(64, 64, 48); NEXT_S(); }
 		if (lds_ok && n_mid_end > lb65) {   // exact ranges of the size-ordered list (lane counts differ between these classes)
 			// 64-lane wavefronts hold more fragments per CU but need enough of them to cover the chip; a thin class runs on half waves
 			const uint32_t fill = 64u * 3u * 256u * 2u;
@@ -1017,12 +1020,14 @@ static int run_seed_chain(al_ctx_t *c, const uint32_t *list, int n_list, int max
 				                   (int32_t *)nullptr, (uint64_t *)nullptr, order + lb65, (int)(lb129 - lb65), c->P, c->counters.p, nosg);   // (<= 128 anchors: its rows are in LDS, no scratch)
 				hipLaunchKernelGGL(k_uo_fill, dim3(lb129 - lb65), dim3(64), 0, s, order + lb65, (int)(lb129 - lb65), c->a_off.p, c->frag_nu.p, c->u.p, c->uo.p, (const uint32_t *)c->tie_list.p);
 			} else {
-				if (lb81 - lb65 >= fill) { LFR(80, 64, lb65, lb81); from = lb81; }
-				if (from == lb81 && lb97 - lb81 >= fill) { LFR(96, 64, lb81, lb97); from = lb97; }
+				if (lb81 - lb65 >= fill) { LFR(80, 64, lb65, lb81); from = lb81; NEXT_S(); }
+				if (from == lb81 && lb97 - lb81 >= fill) { LFR(96, 64, lb81, lb97); from = lb97; NEXT_S(); }
 				LFR(128, 32, from, lb129);
 			}
 		}
+		if (use_ovl && two) { AL_HIP_CHECK(hipEventRecord(c->ev_ovl[4], c->ovl[2])); AL_HIP_CHECK(hipStreamWaitEvent(c->ovl[1], c->ev_ovl[4], 0)); s = c->ovl[1]; }   // (joined on ovl[1]: one event for the main stream)
 		if (use_ovl) { AL_HIP_CHECK(hipEventRecord(c->ev_ovl[3], s)); c->ovl_pending = true; } }
+#undef NEXT_S
 #undef LFR
 #undef LFRLO
 		return 0;
