@@ -836,7 +836,17 @@ static int chain_tiles(al_ctx_t *c, const uint32_t *list, const TileSched &S, co
 			                          cb[1] - cb[0], cb[2] - cb[1], cb[3] - cb[2], cb[4] - cb[3], cb[5] - cb[4], cb[6] - cb[5], cb[7] - cb[6], cb[8] - cb[7], cb[9] - cb[8], n_cmp); }
 			ChainSeg sg{c->vs_meta.p, nullptr, nullptr, 0, nullptr, c->d_uslot.p, c->d_rel.p, c->d_fragid.p, c->ctie.p};
 #define LDEF(C, L, K) do { if (!thin[K]) LCH(C, L, -1, c->vs_off.p, c->vs_na.p, c->chained.p, c->u.p, (uint32_t *)nullptr, c->seg_ord.p + cb[K], (int)(cb[K + 1] - cb[K]), sg, c->uo.p, c->ws_u64.p + wsb[K], C); } while (0)
-			LDEF(16, 64, 0); LDEF(24, 64, 1); LDEF(32, 64, 2); LDEF(40, 64, 3); LDEF(48, 64, 4); LDEF(64, 64, 5); LDEF(80, 64, 6); LDEF(96, 64, 7); LDEF(128, 32, 8);
+			// (round 5) the classes on two streams in turn, like the lane kernels of the small fragments (ovl[2] is idle here: they were joined above); AL_CHAIN_OVL2=0: all on this one
+			static const bool two_env = !(getenv("AL_CHAIN_OVL2") && atoi(getenv("AL_CHAIN_OVL2")) == 0);
+			const bool two = two_env && c->n_frag < 400000;                          // (a 1 M-pair batch's classes fill the chip: no gain there, C5 slightly slower)
+			hipStream_t const s_cls[2] = {s, two ? c->ovl[2] : s};
+			if (two) { AL_HIP_CHECK(hipEventRecord(c->ev_ovl[4], s)); AL_HIP_CHECK(hipStreamWaitEvent(c->ovl[2], c->ev_ovl[4], 0)); }
+			{ int turn = 0;
+#define LDEF2(C, L, K) do { if (!thin[K] && cb[K + 1] > cb[K]) { hipStream_t const s = s_cls[turn++ & 1]; LDEF(C, L, K); } } while (0)
+			LDEF2(16, 64, 0); LDEF2(24, 64, 1); LDEF2(32, 64, 2); LDEF2(40, 64, 3); LDEF2(48, 64, 4); LDEF2(64, 64, 5); LDEF2(80, 64, 6); LDEF2(96, 64, 7); LDEF2(128, 32, 8);
+#undef LDEF2
+			}
+			if (two) { AL_HIP_CHECK(hipEventRecord(c->ev_ovl[4], c->ovl[2])); AL_HIP_CHECK(hipStreamWaitEvent(s, c->ev_ovl[4], 0)); }
 			for (int k = 1; k < 9; ) {   // runs of neighbouring thin classes: one launch each
 				if (!thin[k]) { ++k; continue; }
 				int k1 = k; while (k1 + 1 < 9 && thin[k1 + 1]) ++k1;
