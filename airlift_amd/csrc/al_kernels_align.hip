@@ -2888,6 +2888,7 @@ int al_run_align_stage(al_ctx_t *c)
 						const int cap = NB <= 4 ? (getenv("AL_CAP4") ? atoi(getenv("AL_CAP4")) : 4096) : NB <= 8 ? (getenv("AL_CAP8") ? atoi(getenv("AL_CAP8")) : 4096) : NB <= 22 ? (getenv("AL_CAP22") ? atoi(getenv("AL_CAP22")) : 3072) : 2048;
 						int nbj = (int)((cnt + 3) / 4); if (nbj > cap) nbj = cap;
 						b = (size_t)nbj * 4 * st2 * (dp_conc && cls == 7 ? 3 : 1);         // (side by side the 12 / 16 / 22-block kernels of class 7 take a range each)
+						if (!dp_conc && cls == 7) b += (size_t)std::min(2048, nbj) * 4 * st2;   // (a thin 22-block kernel beside the other two: its own range behind theirs)
 					} else { int nbj = (int)cnt; if (nbj > 2048) nbj = 2048; b = (size_t)nbj * stride; }
 					b = (b + 255) / 256 * 256;
 					ws_off[cls + 1] = dp_conc ? ws_off[cls] + b : 0;
@@ -2898,7 +2899,7 @@ int al_run_align_stage(al_ctx_t *c)
 			hipStream_t dps[4] = {s, c->aux[0], c->aux[1], c->aux[2]}; int dpk = 0;
 			if (dp_conc) { AL_HIP_CHECK(hipEventRecord(c->ev_fj[0], s)); for (int i = 0; i < 3; ++i) AL_HIP_CHECK(hipStreamWaitEvent(c->aux[i], c->ev_fj[0], 0)); }
 			hipStream_t const s_main = s;
-			bool g12_done = false;
+			bool g12_done = false, thin22_join = false;
 			// two cells per lane (al_dev_ksw2.h) where its arithmetic holds: the permute's constant 0xff is the score of an N, scores within +-16
 			// (int16 H of the 352 x 512 tile); AL_DP_PK=0: the one-cell form everywhere (tests, A/B)
 			static const int pk_env = getenv("AL_DP_PK") ? atoi(getenv("AL_DP_PK")) : 1;
@@ -2942,7 +2943,13 @@ int al_run_align_stage(al_ctx_t *c)
 						int gw_used = 0;
 						if (dp_conc) { LAUNCH_DPS(16, first0 + c12, c16); s = dps[dpk++ & 3]; LAUNCH_DPS(12, first0, c12); s = dps[dpk++ & 3]; LAUNCH_DPS(22, first0 + c12 + c16, c22);
 						               AL_HIP_CHECK(hipEventRecord(c->ev[ST_EXT_DP_G12 + 1], s_main)); AL_HIP_CHECK(hipEventRecord(c->ev[ST_EXT_DP_G16 + 1], s_main)); }
-						else { LAUNCH_DPS(12, first0, c12); AL_HIP_CHECK(hipEventRecord(c->ev[ST_EXT_DP_G12 + 1], s)); gw_used = 0; LAUNCH_DPS(16, first0 + c12, c16); AL_HIP_CHECK(hipEventRecord(c->ev[ST_EXT_DP_G16 + 1], s)); gw_used = 0; LAUNCH_DPS(22, first0 + c12 + c16, c22); }
+						else {
+							// few 22-block jobs (C4: a few hundred): the kernel is the tail of its longest job, 0.85 ms alone at the end of the stage -- it starts first, on a side stream, beside the other two
+							const bool thin22 = c22 > 0 && c22 <= 8192u && split;
+							if (thin22) { AL_HIP_CHECK(hipEventRecord(c->ev_fj[0], s)); AL_HIP_CHECK(hipStreamWaitEvent(c->aux[1], c->ev_fj[0], 0)); s = c->aux[1]; gw_used = nbj; LAUNCH_DPS(22, first0 + c12 + c16, c22); s = s_main; gw_used = 0; thin22_join = true; }
+							LAUNCH_DPS(12, first0, c12); AL_HIP_CHECK(hipEventRecord(c->ev[ST_EXT_DP_G12 + 1], s)); gw_used = 0; LAUNCH_DPS(16, first0 + c12, c16); AL_HIP_CHECK(hipEventRecord(c->ev[ST_EXT_DP_G16 + 1], s)); gw_used = 0;
+							if (!thin22) LAUNCH_DPS(22, first0 + c12 + c16, c22);
+						}
 						g12_done = true;
 						(void)cnt0;
 #undef LAUNCH_DPS
@@ -2958,6 +2965,7 @@ int al_run_align_stage(al_ctx_t *c)
 				first += cnt;
 			}
 			if (dp_conc) for (int i = 0; i < 3; ++i) { AL_HIP_CHECK(hipEventRecord(c->ev_aux[i], c->aux[i])); AL_HIP_CHECK(hipStreamWaitEvent(s, c->ev_aux[i], 0)); }
+			if (thin22_join) { AL_HIP_CHECK(hipEventRecord(c->ev_aux[1], c->aux[1])); AL_HIP_CHECK(hipStreamWaitEvent(s, c->ev_aux[1], 0)); }
 		}
 		else { AL_HIP_CHECK(hipEventRecord(c->ev[ST_EXT_SORT + 1], s)); for (int i = ST_EXT_DP_LANE; i < ST_EXT_DP_G22; ++i) AL_HIP_CHECK(hipEventRecord(c->ev[i + 1], s)); }   // (no jobs: empty intervals)
 		AL_HIP_CHECK(hipEventRecord(c->ev[ST_EXT_DP_G22 + 1], s));
