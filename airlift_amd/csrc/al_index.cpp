@@ -62,8 +62,6 @@ extern "C" int al_check_opt(const al_idxopt_t *io, const al_mapopt_t *mo)
 {
 	if (io->k <= 0 || io->w <= 0) { fprintf(stderr, "[ERROR] -k and -w must be positive\n"); return -5; }
 	if (io->k > 28 || io->w >= 256) { fprintf(stderr, "[ERROR] k must be <= 28 and w < 256\n"); return -5; }
-	// the device read sketch packs hash (2k bits) | position (13 bits) | strand in one 64-bit ring entry (al_kernels_seed.hip): 2k + 14 <= 64
-	if (io->k > AL_MAX_K) { fprintf(stderr, "[ERROR] airlift: k must be <= %d on the GPU path (the reference allows 28)\n", AL_MAX_K); return -5; }
 	if (mo->best_n < 0) { fprintf(stderr, "[ERROR] -N must be no less than 0\n"); return -4; }
 	if (mo->pri_ratio < 0.0f || mo->pri_ratio > 1.0f) { fprintf(stderr, "[ERROR] -p must be within 0 and 1 (including 0 and 1)\n"); return -4; }
 	if (mo->e <= 0 || mo->q <= 0) { fprintf(stderr, "[ERROR] -O and -E must be positive\n"); return -1; }

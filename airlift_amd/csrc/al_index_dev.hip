@@ -112,7 +112,7 @@ k_ref_sketch(const uint32_t *__restrict__ S4, const uint64_t *__restrict__ seq_o
 			const int span = l + 1 < k ? l + 1 : k;
 			kmer0 = (kmer0 << 2 | (uint64_t)c) & mask;
 			kmer1 = (kmer1 >> 2) | (3ULL ^ (uint64_t)c) << shift1;
-			const int z = kmer0 < kmer1 ? 0 : 1;                                // k odd: kmer0 != kmer1 always
+			const int z = kmer0 < kmer1 ? 0 : 1;                                // k odd (even k: the host builder, see al_idx_build_device): kmer0 != kmer1 always
 			++l;
 			if (l >= k) { ix = di_hash64m(z ? kmer1 : kmer0, mask) << 8 | (uint64_t)span; iy = (uint64_t)rid << 32 | (uint64_t)i << 1 | (uint64_t)z; }
 		} else l = 0;
@@ -170,7 +170,14 @@ extern "C" al_idx_t *al_idx_build_device(const char *fn, const al_idxopt_t *io, 
 	if (device < 0) { const char *lr = getenv("LOCAL_RANK"); device = lr ? atoi(lr) % n_dev : 0; }
 	if (device >= n_dev) { fprintf(stderr, "[airlift] FATAL: device %d out of range (%d devices)\n", device, n_dev); return nullptr; }
 	const int w = io->w, k = io->k;
-	if (!(k & 1) || k > AL_MAX_K || w > 32 || w < 1) { fprintf(stderr, "[airlift] al_idx_build_device: needs odd k <= %d and w <= 32 (got k=%d w=%d)\n", AL_MAX_K, k, w); return nullptr; }
+	if (k < 1 || k > AL_MAX_K || w > 32 || w < 1) { fprintf(stderr, "[airlift] al_idx_build_device: needs k <= %d and w <= 32 (got k=%d w=%d)\n", AL_MAX_K, k, w); return nullptr; }
+	if (!(k & 1)) {
+		// Even k: a k-mer can be its own reverse complement and is then skipped WITHOUT moving the window (sketch.c:108), so inside a palindromic repeat -- (AT)n -- the window
+		// keeps entries from arbitrarily far back, which a lane that starts 2 (w + k) + 8 bases before its segment cannot know.  The serial host builder takes those
+		// references (same index, uploaded once per GPU).
+		if (getenv("AL_TIMING") || getenv("AL_TRACE")) fprintf(stderr, "[airlift] even k = %d: index built by the host builder\n", k);
+		return al_idx_build(fn, io, (int)std::min(32u, std::max(1u, std::thread::hardware_concurrency())));
+	}
 	AlSeqReader rd;
 	if (!rd.open(fn)) { fprintf(stderr, "[ERROR] airlift: failed to open '%s'\n", fn); return nullptr; }
 	al_idx_t *mi = new al_idx_t();

@@ -11,9 +11,10 @@
 #include <mutex>
 #include "../../include/airlift.h"
 
-#define AL_MAX_K 25                        // device read sketch: hash (2k bits) << 14 | pos << 1 | strand must fit 64 bits
-// position + strand bits of a device sketch window entry (k_sketch): the hash takes 2k bits of the 64
+#define AL_MAX_K 28                        // sketch.c:84.  The packed ring entry of the read sketch (hash (2k bits) << pb | pos << 1 | strand in 64 bits) holds k <= 25 and reads below
+                                           // 2^(pb - 1) bases; beyond either, k_sketch keeps two words per slot (al_sketch_wide)
 static inline int al_sketch_pos_bits(int k) { const int b = 64 - 2 * k; return b > 22 ? 22 : b; }
+static inline bool al_sketch_wide(int k, int max_read_len) { const int pb = al_sketch_pos_bits(k); return k > 25 || max_read_len >= (1 << (pb - 1)); }
 #define AL_MAX_READ_LEN 32768               // longest read of the GPU path: state tiles of the long-read extension kernel (al_kernels_align.hip)
 #define AL_SEED_TANDEM    (1ULL<<42)       // mmpriv.h:20
 #define AL_SEED_SEG_SHIFT 48               // mmpriv.h:23

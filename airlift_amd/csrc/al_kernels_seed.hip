@@ -100,12 +100,70 @@ d_sketch(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_of
 #undef EMIT
 	mini_cnt[r] = cnt;
 }
+// The same with TWO words per ring slot -- the hash, and position << 1 | strand -- for what the packed entry cannot hold: k of 26 ... 28 (56 hash bits leave 8 for position
+// and strand) and reads beyond 2^(pb - 1) bases.  pb < 0 selects it.  Not the hot path: plain loops.
+__device__ __forceinline__ void
+d_sketch_wide(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_off, const uint32_t *__restrict__ rd_len,
+              const uint64_t *__restrict__ mini_off, AlAnchor *__restrict__ mini, uint32_t *__restrict__ mini_cnt, int n_reads, const int w, int k)
+{
+	extern __shared__ uint64_t lds[];           // rh[w][64] hashes, then rp[w][64] positions (32-bit)
+	const int lane = threadIdx.x;
+	const int r = blockIdx.x * 64 + lane;
+	uint64_t *rh = lds + lane; uint32_t *rp = reinterpret_cast<uint32_t *>(lds + (size_t)w * 64) + lane;
+	if (r >= n_reads) return;
+	const uint32_t len = rd_len[r];
+	const uint32_t *seq = rd_seq + rd_off[r];
+	AlAnchor *out = mini + mini_off[r];
+	uint32_t cnt = 0;
+	const uint64_t shift1 = 2 * (k - 1), mask = (1ULL << 2 * k) - 1;
+	uint64_t kmer0 = 0, kmer1 = 0, mh = UINT64_MAX; uint32_t mp = 0;
+	int l = 0, buf_pos = 0, min_pos = 0;
+	for (int j = 0; j < w; ++j) rh[j * 64] = UINT64_MAX, rp[j * 64] = 0;
+#define EMITW(h, q) do { out[cnt].x = (h) << 8 | (uint64_t)k; out[cnt].y = (uint64_t)(q); ++cnt; } while (0)
+	uint32_t word = 0;
+	for (uint32_t i = 0; i < len; ++i) {
+		if ((i & 7) == 0) word = seq[i >> 3];
+		const int c = (word >> ((i & 7) << 2)) & 0xf;
+		uint64_t ih = UINT64_MAX; uint32_t ip = 0;
+		if (c < 4) {
+			kmer0 = (kmer0 << 2 | (uint64_t)c) & mask;
+			kmer1 = (kmer1 >> 2) | (3ULL ^ (uint64_t)c) << shift1;
+			if (kmer0 == kmer1) continue;                                   // sketch.c:108
+			const int z = kmer0 < kmer1 ? 0 : 1;
+			++l;
+			if (l >= k) { ih = d_hash64m(z ? kmer1 : kmer0, mask); ip = i << 1 | (uint32_t)z; }
+		} else l = 0;
+		rh[buf_pos * 64] = ih; rp[buf_pos * 64] = ip;
+		if (l == w + k - 1 && mh != UINT64_MAX) {                           // sketch.c:117-122
+			for (int j = buf_pos + 1; j < w; ++j) { const uint64_t h = rh[j * 64]; const uint32_t q = rp[j * 64]; if (mh == h && q != mp) EMITW(h, q); }
+			for (int j = 0; j < buf_pos; ++j)     { const uint64_t h = rh[j * 64]; const uint32_t q = rp[j * 64]; if (mh == h && q != mp) EMITW(h, q); }
+		}
+		if (ih <= mh) {                                                     // sketch.c:123-125
+			if (l >= w + k && mh != UINT64_MAX) EMITW(mh, mp);
+			mh = ih; mp = ip; min_pos = buf_pos;
+		} else if (buf_pos == min_pos) {                                    // sketch.c:126-138
+			if (l >= w + k - 1 && mh != UINT64_MAX) EMITW(mh, mp);
+			mh = UINT64_MAX;
+			for (int j = buf_pos + 1; j < w; ++j) { const uint64_t h = rh[j * 64]; if (mh >= h) mh = h, mp = rp[j * 64], min_pos = j; }
+			for (int j = 0; j <= buf_pos; ++j)    { const uint64_t h = rh[j * 64]; if (mh >= h) mh = h, mp = rp[j * 64], min_pos = j; }
+			if (l >= w + k - 1 && mh != UINT64_MAX) {
+				for (int j = buf_pos + 1; j < w; ++j) { const uint64_t h = rh[j * 64]; const uint32_t q = rp[j * 64]; if (mh == h && mp != q) EMITW(h, q); }
+				for (int j = 0; j <= buf_pos; ++j)    { const uint64_t h = rh[j * 64]; const uint32_t q = rp[j * 64]; if (mh == h && mp != q) EMITW(h, q); }
+			}
+		}
+		if (++buf_pos == w) buf_pos = 0;
+	}
+	if (mh != UINT64_MAX) EMITW(mh, mp);
+#undef EMITW
+	mini_cnt[r] = cnt;
+}
 extern "C" __global__ void __launch_bounds__(64)
 k_sketch(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_off, const uint32_t *__restrict__ rd_len,
          const uint64_t *__restrict__ mini_off, AlAnchor *__restrict__ mini, uint32_t *__restrict__ mini_cnt,
          int n_reads, int w, int k, int pb)
 {
-	if (w == 11) d_sketch<11>(rd_seq, rd_off, rd_len, mini_off, mini, mini_cnt, n_reads, w, k, pb);    // (the short-read preset's window)
+	if (pb < 0) d_sketch_wide(rd_seq, rd_off, rd_len, mini_off, mini, mini_cnt, n_reads, w, k);        // (k of 26 ... 28, or reads too long for the packed entry)
+	else if (w == 11) d_sketch<11>(rd_seq, rd_off, rd_len, mini_off, mini, mini_cnt, n_reads, w, k, pb);    // (the short-read preset's window)
 	else d_sketch<0>(rd_seq, rd_off, rd_len, mini_off, mini, mini_cnt, n_reads, w, k, pb);
 }
 

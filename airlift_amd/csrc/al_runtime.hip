@@ -490,7 +490,7 @@ extern "C" int al_batch_upload(al_ctx_t *c, int n_frag, const int *n_segs, const
 	c->max_qlen_sum = max_qsum; c->dev_batch = false;
 	{ int lm = 0; for (int i = 0; i < n_reads; ++i) lm = std::max(lm, (int)c->h_rd_len[i]); c->max_rd_len = lm; }
 	{   // longest read the device sketch can index (position bits of its packed window entries) and the extension kernels can hold
-		const int lim = std::min(1 << (al_sketch_pos_bits(k) - 1), AL_MAX_READ_LEN);
+		const int lim = AL_MAX_READ_LEN;                                         // (the packed window entries of the sketch hold fewer position bits at large k: k_sketch then keeps two words per slot)
 		for (int i = 0; i < n_reads; ++i) if ((int)c->h_rd_len[i] >= lim) { fprintf(stderr, "[airlift] a read of %u bases exceeds the limit of the GPU path (%d bases at k = %d)\n", c->h_rd_len[i], lim - 1, k); return -3; }
 	}
 	al_parallel_for(c->n_threads, (size_t)n_frag, [&](size_t lo, size_t hi, int) {
@@ -1250,7 +1250,8 @@ int al_run_seed_stages(al_ctx_t *c)
 	AL_HIP_CHECK(hipMemsetAsync(c->counters.p, 0, 32 * sizeof(unsigned long long), s));
 	AL_HIP_CHECK(hipEventRecord(c->ev[0], s));
 	const int nr = c->n_reads, w = c->mi->w, k = c->mi->k;
-	if (nr > 0) hipLaunchKernelGGL(k_sketch, dim3((nr + 63) / 64), dim3(64), (size_t)w * 64 * 8, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, c->mini_off.p, c->mini.p, c->mini_cnt.p, nr, w, k, al_sketch_pos_bits(k));
+	const bool sk_wide = al_sketch_wide(k, c->max_rd_len);                       // two words per window slot: k of 26 ... 28, reads beyond the packed entry's position bits
+	if (nr > 0) hipLaunchKernelGGL(k_sketch, dim3((nr + 63) / 64), dim3(64), (size_t)w * 64 * (sk_wide ? 12 : 8), s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, c->mini_off.p, c->mini.p, c->mini_cnt.p, nr, w, k, sk_wide ? -1 : al_sketch_pos_bits(k));
 	AL_HIP_CHECK(hipEventRecord(c->ev[ST_SKETCH + 1], s));
 	if (c->n_frag == 0) { for (int i = ST_SEED; i < ST_N; ++i) AL_HIP_CHECK(hipEventRecord(c->ev[i + 1], s)); return 0; }
 	if (c->frag_meta.ensure((size_t)c->n_frag + 1)) return -1;
@@ -1556,7 +1557,7 @@ extern "C" int al_batch_upload_windows(al_ctx_t *c, const al_winsrc_t *src, int 
 	AL_HIP_CHECK(hipSetDevice(c->device));
 	const int k = c->mi->k, wpr = (read_len + 7) / 8 + 1;
 	c->n_frag = n_tok; c->n_reads = n_tok; c->ran = false; c->max_qlen_sum = read_len; c->max_rd_len = n_tok ? read_len : 0; c->dev_batch = false;
-	if (read_len >= std::min(1 << (al_sketch_pos_bits(k) - 1), AL_MAX_READ_LEN)) { fprintf(stderr, "[airlift] tokens of %d bases exceed the limit of the GPU path\n", read_len); return -3; }
+	if (read_len >= AL_MAX_READ_LEN) { fprintf(stderr, "[airlift] tokens of %d bases exceed the limit of the GPU path\n", read_len); return -3; }
 	c->h_rd_len.assign(n_tok + 1, (uint32_t)read_len); c->h_rd_len[n_tok] = 0;
 	c->h_rd_off.resize(n_tok + 1); c->h_mini_off.resize(n_tok + 1); c->h_flip.assign(n_tok, 0);
 	c->h_frag_first.resize(n_tok + 1); c->h_frag_hash.resize(n_tok + 1);

@@ -469,7 +469,7 @@ int al_stream_setup(AlStreamSlot &S, al_ctx_t *c, uint32_t rec_lo, uint32_t rec_
 	AL_HIP_CHECK(hipStreamSynchronize(s));
 	c->max_rd_len = (int)h[0]; c->max_qlen_sum = (int)h[1]; c->n_bases = h[2]; c->stat_bytes_in = h[3]; c->seq_words = words; c->mini_total = mtot;
 	{   // the same limit al_batch_upload enforces
-		const int lim = std::min(1 << (al_sketch_pos_bits(k) - 1), AL_MAX_READ_LEN);
+		const int lim = AL_MAX_READ_LEN;
 		if (c->max_rd_len >= lim) { fprintf(stderr, "[airlift] a read of %d bases exceeds the limit of the GPU path (%d bases at k = %d)\n", c->max_rd_len, lim - 1, k); return -3; }
 	}
 	if (c->rd_seq.ensure(words + 1) || c->mini.ensure(mtot + 1) || c->match.ensure(mtot + 1) || c->heap_ws.ensure(mtot + 1)) return -1;

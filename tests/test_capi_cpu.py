@@ -52,17 +52,18 @@ def test_sr_preset_matches_reference_constants(A):
     assert L.al_check_opt(C.byref(io), C.byref(mo)) < 0                   # options.c:168-172
 
 
-def test_k_above_device_limit_fails_loudly(A):
-    """The device read sketch packs hash (2k bits) | pos | strand in 64 bits: k > 25 must be rejected, not silently truncated."""
+def test_k_limit_is_the_references(A):
+    """sketch.c:84 allows k <= 28.  Round 5: the read sketch keeps two words per window slot where its packed 64-bit entry cannot hold hash | position | strand
+    (k of 26 ... 28), and an even k goes through the host index builder -- so the option check accepts what the reference accepts and rejects 29."""
     L = A.load(); io, mo = A.IdxOpt(), A.MapOpt()
     L.al_set_opt(None, C.byref(io), C.byref(mo)); L.al_set_opt(b"sr", C.byref(io), C.byref(mo))
-    io.k = 25
-    assert L.al_check_opt(C.byref(io), C.byref(mo)) == 0
-    for k in (26, 27, 28):
+    for k in (25, 26, 27, 28):
         io.k = k
-        assert L.al_check_opt(C.byref(io), C.byref(mo)) < 0
-    r = subprocess.run([os.path.join(ROOT, "airlift_amd", "bin", "airlift-align"), "-ax", "sr", "-k", "27", "x.fa", "y.fq"], capture_output=True)
-    assert r.returncode != 0 and b"k must be <= 25" in r.stderr
+        assert L.al_check_opt(C.byref(io), C.byref(mo)) == 0
+    io.k = 29
+    assert L.al_check_opt(C.byref(io), C.byref(mo)) < 0
+    r = subprocess.run([os.path.join(ROOT, "airlift_amd", "bin", "airlift-align"), "-ax", "sr", "-k", "29", "x.fa", "y.fq"], capture_output=True)
+    assert r.returncode != 0 and b"k must be <= 28" in r.stderr
 
 
 def test_index_matches_oracle_sketch(A, oracle_bin, golden_unpacked):

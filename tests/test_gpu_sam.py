@@ -451,6 +451,9 @@ OPTSETS = [
     ["-k", "19", "-w", "9"],
     ["-A", "4", "-B", "4", "-O", "4,24", "-E", "2,1"],      # a + b >= q + e: the closed-form flanks switch themselves off
     ["--score-N", "3", "--seed", "7", "-M", "0.3"],
+    ["-k", "27", "-w", "10"],        # round 5: two words per window slot of the read sketch (k > 25)
+    ["-k", "28", "-w", "12"],        # ... and an even k: the host index builder (a k-mer can be its own reverse complement, sketch.c:108)
+    ["-k", "26", "-w", "8"],
 ]
 
 
@@ -465,6 +468,20 @@ def test_non_default_options_match_reference(golden_unpacked, name):
         exp = _run([ref_bin] + opts + [m["ref"]] + m["reads"], d).stdout
         got = _run([CLI, "-ax", "sr"] + opts + [m["ref"]] + m["reads"], d).stdout
         assert got == exp, " ".join(opts) + "\n" + _diff_report(got, exp, name + "_opts")
+
+
+@pytest.mark.parametrize("opts", [["-k", "25", "-w", "10"], ["-k", "27", "-w", "10"]], ids=["k25_reads_beyond_the_packed_entrys_position_bits", "k27"])
+def test_long_reads_at_large_k_match_reference(golden_unpacked, opts):
+    """The 16.5 kb query of the fork's own test set at k = 25 (the packed window entry of the read sketch holds positions below 8192 there) and k = 27: two words per
+    window slot (d_sketch_wide), compared with the reference build."""
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "mm2ref")
+    if not os.path.exists(ref_bin):
+        pytest.fail("oracle/_ref/mm2ref is missing: the reference build (oracle/Makefile, target ref) must travel to the GPU box with the snapshot")
+    d = golden_unpacked["g4_MT_orang"]
+    m = json.load(open(os.path.join(d, "meta.json")))
+    exp = _run([ref_bin] + opts + [m["ref"]] + m["reads"], d).stdout
+    got = _run([CLI, "-ax", "sr"] + opts + [m["ref"]] + m["reads"], d).stdout
+    assert got == exp, " ".join(opts) + "\n" + _diff_report(got, exp, "orang_" + opts[1])
 
 
 def test_250bp_pairs_match_reference(tmp_path):
