@@ -240,6 +240,8 @@ extern "C" al_idx_t *al_idx_build(const char *fn, const al_idxopt_t *io, int n_t
 void al_idx_free_device(al_idx_t *mi);   // al_runtime.hip
 extern "C" void al_idx_destroy(al_idx_t *mi) { if (mi) { al_idx_free_device(mi); delete mi; } }
 extern "C" uint32_t al_idx_n_seq(const al_idx_t *mi) { return (uint32_t)mi->seq.size(); }
+extern "C" int al_idx_k(const al_idx_t *mi) { return mi ? mi->k : 0; }
+extern "C" int al_idx_w(const al_idx_t *mi) { return mi ? mi->w : 0; }
 extern "C" const char *al_idx_seq_name(const al_idx_t *mi, uint32_t rid) { return rid < mi->seq.size()? mi->seq[rid].name.c_str() : nullptr; }
 extern "C" uint32_t al_idx_seq_len(const al_idx_t *mi, uint32_t rid) { return rid < mi->seq.size()? mi->seq[rid].len : 0; }
 extern "C" void al_idx_stat(const al_idx_t *mi, uint64_t *n_keys, uint64_t *n_pos, uint64_t *n_bases)

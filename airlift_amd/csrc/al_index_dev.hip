@@ -296,6 +296,21 @@ fail:
 	return nullptr;
 }
 
+// the host arrays of a device-built index (al_idx_dump): table, positions and packed sequence copied back once
+int al_idx_to_host(al_idx_t *mi)
+{
+	if (!mi || mi->built_on < 0) return mi ? 0 : -1;
+	std::lock_guard<std::mutex> lk(mi->dev_mtx);
+	auto it = mi->dev.find(mi->built_on);
+	if (it == mi->dev.end() || hipSetDevice(mi->built_on) != hipSuccess) return -1;
+	const AlDevIndex &d = it->second;
+	mi->tab.resize((size_t)2 << mi->tab_bits); mi->pos.resize(mi->n_pos ? mi->n_pos : 1); mi->S4.assign((size_t)((mi->tot_len + 7) / 8) + 8, 0);
+	if (hipMemcpy(mi->tab.data(), d.tab, mi->tab.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+	if (mi->n_pos && hipMemcpy(mi->pos.data(), d.pos, (size_t)mi->n_pos * 8, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+	if (mi->tot_len && hipMemcpy(mi->S4.data(), d.S4, (size_t)((mi->tot_len + 7) / 8) * 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+	return 0;
+}
+
 // copy of the sorted position array (host- or device-built index); returns the number of entries, or -1
 extern "C" int64_t al_idx_export_pos(const al_idx_t *mi, uint64_t *dst, int64_t cap)
 {
@@ -379,25 +394,27 @@ extern "C" void al_mapopt_update(al_mapopt_t *opt, const al_idx_t *mi)
 // mm_idx_reader_open/read/close (minimap.h:206-232, index.c:585-648): the reference hands out one index part per read()
 // call; this path builds a single part (the sr preset's batch size of 4 Gbp covers AirLift's references, larger inputs are
 // refused by the builders), so the first read() returns the whole index and the second NULL.
-struct al_idx_reader_s { std::string fn; al_idxopt_t opt; int n_parts; };
+struct al_idx_reader_s { std::string fn, fn_out; al_idxopt_t opt; int n_parts; bool is_idx; };
+extern "C" int64_t al_idx_is_idx(const char *fn);
+extern "C" al_idx_t *al_idx_load(const char *fn);
+extern "C" int al_idx_dump(const char *fn, al_idx_t *mi);
 
 extern "C" al_idx_reader_t *al_idx_reader_open(const char *fn, const al_idxopt_t *io, const char *fn_out)
 {
 	if (!fn || !io) return nullptr;
-	if (fn_out) { fprintf(stderr, "[airlift] al_idx_reader_open: index dumps (-d) are not supported: the index is rebuilt on the GPU in seconds\n"); return nullptr; }
-	FILE *fp = fopen(fn, "rb");
-	if (!fp) return nullptr;                                                   // minimap.h:206: NULL when the file cannot be opened
-	fclose(fp);
+	const int64_t is_idx = al_idx_is_idx(fn);                                  // index.c:585-600: a file that starts with the magic is a prebuilt index
+	if (is_idx < 0) return nullptr;                                            // minimap.h:206: NULL when the file cannot be opened
 	al_idx_reader_t *r = new al_idx_reader_t();
-	r->fn = fn; r->opt = *io; r->n_parts = 0;
+	r->fn = fn; r->opt = *io; r->n_parts = 0; r->is_idx = is_idx > 0; if (fn_out) r->fn_out = fn_out;
 	return r;
 }
 
 extern "C" al_idx_t *al_idx_reader_read(al_idx_reader_t *r, int device)
 {
 	if (!r || r->n_parts > 0) return nullptr;
-	al_idx_t *mi = al_idx_build_device(r->fn.c_str(), &r->opt, device);
+	al_idx_t *mi = r->is_idx ? al_idx_load(r->fn.c_str()) : al_idx_build_device(r->fn.c_str(), &r->opt, device);
 	if (mi) ++r->n_parts;
+	if (mi && !r->is_idx && !r->fn_out.empty() && al_idx_dump(r->fn_out.c_str(), mi) != 0) { al_idx_destroy(mi); return nullptr; }   // index.c:629-630: a part is dumped as it is read
 	return mi;
 }
 

@@ -48,6 +48,7 @@ int main(int argc, char **argv)
 	std::vector<const char *> pos; const char *rg = nullptr; int n_threads = 3, device = -1; std::vector<int> devices; bool count_only = false; int bam_mode = 0, bam_level = 5;
 	enum { MODE_MEM, MODE_ALN, MODE_SAMSE, MODE_MM2, MODE_TOKENS } mode = MODE_MM2; int tok_size = 0, tok_skip = 1;
 	bool prefilter = false; int pf[4] = {3, 3, 5, 3};          // adjacency e, GreedySnake e, k-mer size, rounds
+	const char *dump_fn = nullptr;
 	int i = 1; bool k_given = false; int rank = -1, world = 0; const char *rendezvous = nullptr, *out_path = nullptr;
 	if (argc < 2) return usage();
 	al_set_opt(0, &io, &mo);
@@ -117,6 +118,7 @@ int main(int argc, char **argv)
 		else if (!strcmp(a, "-x") && i + 1 < argc) { if (al_set_opt(argv[++i], &io, &mo) < 0) { fprintf(stderr, "[ERROR] unknown preset '%s'\n", argv[i]); return 1; } }
 		else if (!strcmp(a, "-ax") && i + 1 < argc) { if (al_set_opt(argv[++i], &io, &mo) < 0) { fprintf(stderr, "[ERROR] unknown preset '%s'\n", argv[i]); return 1; } }
 		else if (!strcmp(a, "-a")) mo.flag |= AL_F_OUT_SAM | AL_F_CIGAR;
+		else if (!strcmp(a, "-d") && i + 1 < argc) dump_fn = argv[++i];                       // main.c:150: dump the index to FILE (mm_idx_dump's format)
 		else if (!strcmp(a, "-k") && i + 1 < argc) io.k = atoi(argv[++i]);
 		else if (!strcmp(a, "-w") && i + 1 < argc) io.w = atoi(argv[++i]);
 		else if (!strcmp(a, "-K") && i + 1 < argc) { mo.mini_batch_size = (int)parse_num(argv[++i], "-K"); k_given = true; }
@@ -192,20 +194,24 @@ int main(int argc, char **argv)
 		if (pos.size() < 3) return usage();
 		ref = pos[0]; reads.push_back(pos[2]);
 	} else {
-		if (pos.size() < 2 || pos.size() > 3) return usage();
+		if ((pos.size() < 2 && !(dump_fn && pos.size() == 1)) || pos.size() > 3) return usage();   // (-d FILE ref.fa: index only, main.c:374-376)
 		ref = pos[0]; for (size_t j = 1; j < pos.size(); ++j) reads.push_back(pos[j]);
 	}
 	struct timespec ts0, ts1; clock_gettime(CLOCK_MONOTONIC, &ts0);
 	if (!devices.empty()) device = devices[0];
 	// plain FASTQ files in, SAM out, one GPU: the run's device memory is obtained by a background thread while the reference is loaded and indexed
-	if (devices.size() <= 1 && world <= 1 && !bam_mode && !count_only && mode != MODE_TOKENS && !getenv("AL_HOST_INDEX") && !getenv("AL_HOST_IO")) {
+	const bool ref_is_idx = al_idx_is_idx(ref) > 0;                              // index.c:585-600: a prebuilt index (the fork's -d file, or this program's) instead of a FASTA
+	if (devices.size() <= 1 && world <= 1 && !bam_mode && !count_only && mode != MODE_TOKENS && !getenv("AL_HOST_INDEX") && !getenv("AL_HOST_IO") && !ref_is_idx && !reads.empty()) {
 		const int64_t rb = al_device_reserve_for_run(device, ref, (int)reads.size(), reads.data());
 		if (rb > 0 && getenv("AL_TIMING")) fprintf(stderr, "[airlift] device memory reserve of %.1f GB started\n", rb / 1e9);
 	}
-	al_idx_t *mi = getenv("AL_HOST_INDEX") ? al_idx_build(ref, &io, n_threads) : al_idx_build_device(ref, &io, device);
+	al_idx_t *mi = ref_is_idx ? al_idx_load(ref) : getenv("AL_HOST_INDEX") ? al_idx_build(ref, &io, n_threads) : al_idx_build_device(ref, &io, device);
+	if (mi && ref_is_idx && (al_idx_k(mi) != io.k || al_idx_w(mi) != io.w)) fprintf(stderr, "[WARNING]\033[1;31m Indexing parameters (-k, -w or -H) overridden by parameters used in the prebuilt index.\033[0m\n");   // main.c:378-380
 	clock_gettime(CLOCK_MONOTONIC, &ts1);
 	if (getenv("AL_TIMING")) fprintf(stderr, "[airlift] index build %.3f s\n", (ts1.tv_sec - ts0.tv_sec) + 1e-9 * (ts1.tv_nsec - ts0.tv_nsec));
 	if (!mi) { fprintf(stderr, "[ERROR] failed to open file '%s'\n", ref); return 1; }
+	if (dump_fn && !ref_is_idx && al_idx_dump(dump_fn, mi) != 0) { al_idx_destroy(mi); return 1; }
+	if (reads.empty()) { al_idx_destroy(mi); fflush(stderr); _exit(0); }       // (index only)
 	if (mode == MODE_TOKENS) {   // gaps_to_fasta.py + single-end alignment of the tokens in one step (tokens are cut on the GPU)
 		const int rc2 = al_map_tokens_file(mi, reads[0], tok_size, tok_skip, &mo, n_threads, stdout, rg, device);
 		al_idx_destroy(mi);

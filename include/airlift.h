@@ -96,12 +96,20 @@ al_idx_t *al_idx_build(const char *fn, const al_idxopt_t *io, int n_threads);
 al_idx_t *al_idx_build_device(const char *fn, const al_idxopt_t *io, int device);
 /* mm_idx_reader_open / mm_idx_reader_read / mm_idx_reader_eof / mm_idx_reader_close (minimap.h:206-232): the reference's
  * iterator over index parts.  This path builds one part: the first read() returns the whole index (built on `device`, as
- * al_idx_build_device), the next NULL.  open() returns NULL if the file cannot be opened or fn_out (index dump) is set. */
+ * al_idx_build_device), the next NULL.  A file that starts with the index magic (mm_idx_is_idx, index.c:531) is a prebuilt index and is loaded instead; fn_out
+ * (minimap2's -d) makes read() write the index it built there.  open() returns NULL if the file cannot be opened. */
 typedef struct al_idx_reader_s al_idx_reader_t;
 al_idx_reader_t *al_idx_reader_open(const char *fn, const al_idxopt_t *io, const char *fn_out);
 al_idx_t *al_idx_reader_read(al_idx_reader_t *r, int device);
 int       al_idx_reader_eof(const al_idx_reader_t *r);
 void      al_idx_reader_close(al_idx_reader_t *r);
+/* mm_idx_dump / mm_idx_load / mm_idx_is_idx (index.c:438-552): the reference's index file, both ways -- an .mmi the fork wrote is read here, one written here is read
+ * by the fork (the files differ in the order of a bucket's hash pairs only).  dump copies a device-built index off the GPU first; 0 / -1. */
+int       al_idx_dump(const char *fn, al_idx_t *mi);
+al_idx_t *al_idx_load(const char *fn);
+int64_t   al_idx_is_idx(const char *fn);
+int       al_idx_k(const al_idx_t *mi);      /* mm_idx_t::k, ::w (minimap.h:57) */
+int       al_idx_w(const al_idx_t *mi);
 /* mm_idx_cal_max_occ (index.c:164-185): (1-f) quantile of the per-minimizer occurrence counts + 1; INT32_MAX for f <= 0 */
 int32_t   al_idx_cal_max_occ(const al_idx_t *mi, float f);
 /* mm_mapopt_update (minimap.h:183, options.c:51-61): mid_occ <= 0 is replaced by al_idx_cal_max_occ(mi, 2e-4) */

@@ -1,6 +1,7 @@
 """CPU tests (-m "not gpu"): the C-ABI library loads, exports every symbol include/airlift.h declares, the host-side
 logic (options, index build, SAM header, read sharding) is right, and there is no CPU compute path."""
 import ctypes as C
+import json
 import os
 import re
 import subprocess
@@ -91,6 +92,39 @@ def _ref_max_occ(fa, f):
     r = subprocess.run([MM2REF, "--max-occ", repr(f), fa], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     return int(r.stderr.strip().splitlines()[-1].split("value=")[1])
+
+
+@pytest.mark.skipif(not os.path.exists(MM2REF), reason="reference build absent")
+@pytest.mark.parametrize("gset", ["g6_repeats", "g1_mt150pe"])
+def test_index_file_both_ways_with_the_reference(A, golden_unpacked, gset, tmp_path):
+    """mm_idx_dump / mm_idx_load (index.c:438-531) on the host-built index: (1) the reference build writes its index, al_idx_load reads it, al_idx_dump writes it again and
+    the reference maps with THAT file -- its SAM must be the golden one; (2) the same with an index built here (al_idx_build -> al_idx_dump -> the reference)."""
+    d = golden_unpacked[gset]
+    m = json.load(open(os.path.join(d, "meta.json")))
+    exp = open(os.path.join(d, "expected.sam"), "rb").read()
+    L = A.load()
+    L.al_idx_load.restype = C.c_void_p; L.al_idx_load.argtypes = [C.c_char_p]
+    L.al_idx_dump.restype = C.c_int; L.al_idx_dump.argtypes = [C.c_char_p, C.c_void_p]
+    L.al_idx_is_idx.restype = C.c_int64; L.al_idx_is_idx.argtypes = [C.c_char_p]
+    L.al_idx_destroy.argtypes = [C.c_void_p]
+    rg = ["-R", m["rg"]] if m.get("rg") else []
+    ref_mmi, mine_mmi, mine2_mmi = str(tmp_path / "ref.mmi"), str(tmp_path / "mine.mmi"), str(tmp_path / "mine2.mmi")
+    r = subprocess.run([MM2REF] + rg + ["--save-index", ref_mmi, m["ref"]] + m["reads"], cwd=d, capture_output=True)
+    assert r.returncode == 0 and r.stdout == exp
+    assert L.al_idx_is_idx(ref_mmi.encode()) == os.path.getsize(ref_mmi) and L.al_idx_is_idx(os.path.join(d, m["ref"]).encode()) == 0
+    mi = L.al_idx_load(ref_mmi.encode())
+    assert mi
+    assert L.al_idx_dump(mine_mmi.encode(), C.c_void_p(mi)) == 0
+    L.al_idx_destroy(C.c_void_p(mi))
+    assert os.path.getsize(mine_mmi) == os.path.getsize(ref_mmi)              # same content, a bucket's hash pairs in another order
+    r = subprocess.run([MM2REF] + rg + [mine_mmi] + m["reads"], cwd=d, capture_output=True)
+    assert r.returncode == 0 and r.stdout == exp, r.stderr.decode()[-500:]
+    idx = A.Index(fasta=os.path.join(d, m["ref"]))
+    assert L.al_idx_dump(mine2_mmi.encode(), C.c_void_p(idx.h)) == 0
+    idx.close()
+    assert os.path.getsize(mine2_mmi) == os.path.getsize(ref_mmi)
+    r = subprocess.run([MM2REF] + rg + [mine2_mmi] + m["reads"], cwd=d, capture_output=True)
+    assert r.returncode == 0 and r.stdout == exp, r.stderr.decode()[-500:]
 
 
 @pytest.mark.skipif(not os.path.exists(MM2REF), reason="reference build absent")

@@ -484,6 +484,30 @@ def test_long_reads_at_large_k_match_reference(golden_unpacked, opts):
     assert got == exp, " ".join(opts) + "\n" + _diff_report(got, exp, "orang_" + opts[1])
 
 
+@pytest.mark.parametrize("name", ["g1_mt150pe", "g6_repeats"])
+def test_index_file_written_and_read_like_the_references(golden_unpacked, name, tmp_path):
+    """`-d FILE` (mm_idx_dump, index.c:438) on the index built on the GPU, and a prebuilt index in place of the FASTA (mm_idx_load, index.c:476): the reference maps with the file
+    this program wrote, this program maps with the file the reference wrote (and with its own) -- all three the golden SAM."""
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "mm2ref")
+    if not os.path.exists(ref_bin):
+        pytest.fail("oracle/_ref/mm2ref is missing: the reference build (oracle/Makefile, target ref) must travel to the GPU box with the snapshot")
+    d = golden_unpacked[name]
+    m = json.load(open(os.path.join(d, "meta.json")))
+    exp = open(os.path.join(d, "expected.sam"), "rb").read()
+    rg = ["-R", m["rg"]] if m.get("rg") else []
+    mine, theirs = str(tmp_path / "mine.mmi"), str(tmp_path / "theirs.mmi")
+    r = subprocess.run([CLI, "-ax", "sr", "-d", mine, m["ref"]], cwd=d, capture_output=True)           # index only
+    assert r.returncode == 0 and r.stdout == b"" and os.path.getsize(mine) > 0, r.stderr.decode()[-500:]
+    assert _run([ref_bin] + rg + [mine] + m["reads"], d).stdout == exp
+    assert _run([ref_bin] + rg + ["--save-index", theirs, m["ref"]] + m["reads"], d).stdout == exp
+    assert os.path.getsize(mine) == os.path.getsize(theirs)
+    assert _run([CLI, "-ax", "sr"] + rg + [theirs] + m["reads"], d).stdout == exp
+    assert _run([CLI, "-ax", "sr"] + rg + [mine] + m["reads"], d).stdout == exp
+    # -d together with reads: the index is written and the reads are mapped (main.c:374-401)
+    both = str(tmp_path / "both.mmi")
+    assert _run([CLI, "-ax", "sr"] + rg + ["-d", both, m["ref"]] + m["reads"], d).stdout == exp and os.path.getsize(both) == os.path.getsize(mine)
+
+
 def test_250bp_pairs_match_reference(tmp_path):
     """BASELINE config 5 shape (250 bp PE, insert N(550,60)): long flanks, where a banded extension can run off the matrix
     (target >= query + w + 1) -- compared with the reference build on freshly simulated reads."""
