@@ -2886,9 +2886,11 @@ int al_run_align_stage(al_ctx_t *c)
 						const int NB = NBs[cls - 3];
 						const size_t pb = (((size_t)(Lmax + 16 * NB) * (size_t)(NB + 1) * 16) + 63) / 64 * 64, cw = ((size_t)(Lmax + 16 * NB) + 31) / 16 * 16, st2 = pb + cw * 8;
 						const int cap = NB <= 4 ? (getenv("AL_CAP4") ? atoi(getenv("AL_CAP4")) : 4096) : NB <= 8 ? (getenv("AL_CAP8") ? atoi(getenv("AL_CAP8")) : 4096) : NB <= 22 ? (getenv("AL_CAP22") ? atoi(getenv("AL_CAP22")) : 3072) : 2048;
-						int nbj = (int)((cnt + 3) / 4); if (nbj > cap) nbj = cap;
-						b = (size_t)nbj * 4 * st2 * (dp_conc && cls == 7 ? 3 : 1);         // (side by side the 12 / 16 / 22-block kernels of class 7 take a range each)
-						if (!dp_conc && cls == 7) b += (size_t)std::min(2048, nbj) * 4 * st2;   // (a thin 22-block kernel beside the other two: its own range behind theirs)
+						const int cap_eff = dp_conc ? (NB <= 4 ? cap / 2 : NB <= 8 ? cap * 5 / 8 : NB <= 22 ? cap * 5 / 6 : cap) : cap;   // (side by side the ranges add up: slightly fewer blocks each keep the sum near what the largest range was)
+						int nbj = (int)((cnt + 3) / 4); if (nbj > cap_eff) nbj = cap_eff;
+						b = (size_t)nbj * 4 * st2;
+						if (cls == 7) { const unsigned long long c12 = std::min<unsigned long long>(sub7[0], cnt), c16 = std::min<unsigned long long>(sub7[1], cnt - c12), c22 = cnt - c12 - c16;
+						                if (c22 > 0 && c22 <= 8192) b += (size_t)std::min<unsigned long long>((c22 + 3) / 4, (unsigned long long)nbj) * 4 * st2; }   // (a thin 22-block kernel beside the other two of its class: its own range behind theirs)
 					} else { int nbj = (int)cnt; if (nbj > 2048) nbj = 2048; b = (size_t)nbj * stride; }
 					b = (b + 255) / 256 * 256;
 					ws_off[cls + 1] = dp_conc ? ws_off[cls] + b : 0;
@@ -2899,7 +2901,7 @@ int al_run_align_stage(al_ctx_t *c)
 			hipStream_t dps[4] = {s, c->aux[0], c->aux[1], c->aux[2]}; int dpk = 0;
 			if (dp_conc) { AL_HIP_CHECK(hipEventRecord(c->ev_fj[0], s)); for (int i = 0; i < 3; ++i) AL_HIP_CHECK(hipStreamWaitEvent(c->aux[i], c->ev_fj[0], 0)); }
 			hipStream_t const s_main = s;
-			bool g12_done = false, thin22_join = false;
+			bool g12_done = false, thin22_join = false; hipStream_t thin22_stream = nullptr;
 			// two cells per lane (al_dev_ksw2.h) where its arithmetic holds: the permute's constant 0xff is the score of an N, scores within +-16
 			// (int16 H of the 352 x 512 tile); AL_DP_PK=0: the one-cell form everywhere (tests, A/B)
 			static const int pk_env = getenv("AL_DP_PK") ? atoi(getenv("AL_DP_PK")) : 1;
@@ -2925,7 +2927,7 @@ int al_run_align_stage(al_ctx_t *c)
 					const int NB = NBs[cls - 3];
 					const size_t pb = (((size_t)(Lmax + 16 * NB) * (size_t)(NB + 1) * 16) + 63) / 64 * 64, cw = ((size_t)(Lmax + 16 * NB) + 31) / 16 * 16, st2 = pb + cw * 8;
 					int nbj = (int)((cnt + 3) / 4); { static const int caps[3] = { getenv("AL_CAP4") ? atoi(getenv("AL_CAP4")) : 4096, getenv("AL_CAP8") ? atoi(getenv("AL_CAP8")) : 4096, getenv("AL_CAP22") ? atoi(getenv("AL_CAP22")) : 3072 };
-					  const int cap = NB <= 4 ? caps[0] : NB <= 8 ? caps[1] : NB <= 22 ? caps[2] : 2048; if (nbj > cap) nbj = cap; }
+					  const int cap = NB <= 4 ? caps[0] : NB <= 8 ? caps[1] : NB <= 22 ? caps[2] : 2048; const int cap_eff = dp_conc ? (NB <= 4 ? cap / 2 : NB <= 8 ? cap * 5 / 8 : NB <= 22 ? cap * 5 / 6 : cap) : cap; if (nbj > cap_eff) nbj = cap_eff; }
 #define LAUNCH_DP(NBV) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ext_dp<NBV, 512, NBV * 16>), dim3(nbj), dim3(64), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, G, E, A->job_idx2.p, first, cnt, gbase, st2, pb, cw, c->P)
 // (queries of up to 256 bases -- every short-read set -- get the instance with the smaller query arrays: 12 instead of 14 KB of LDS per block at 16 blocks, a third wavefront per SIMD)
 #define LAUNCH_DPK(NBV) do { if (Lmax <= 256) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ext_dp<NBV, 256, NBV * 16, true>), dim3(nbj), dim3(64), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, G, E, A->job_idx2.p, first, cnt, gbase, st2, pb, cw, c->P); \
@@ -2941,14 +2943,15 @@ int al_run_align_stage(al_ctx_t *c)
 							else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ext_dp<NBV, 512, NBV * 16>), dim3(nb2), dim3(64), 0, s, c->rd_seq.p, c->rd_off.p, c->rd_len.p, G, E, A->job_idx2.p, (F), (N), gbase + (size_t)gw_used * 4 * st2, st2, pb, cw, c->P); gw_used += nb2; } } while (0)
 						// (the three kernels run one after the other on this stream: they may share the workspace range)
 						int gw_used = 0;
-						if (dp_conc) { LAUNCH_DPS(16, first0 + c12, c16); s = dps[dpk++ & 3]; LAUNCH_DPS(12, first0, c12); s = dps[dpk++ & 3]; LAUNCH_DPS(22, first0 + c12 + c16, c22);
-						               AL_HIP_CHECK(hipEventRecord(c->ev[ST_EXT_DP_G12 + 1], s_main)); AL_HIP_CHECK(hipEventRecord(c->ev[ST_EXT_DP_G16 + 1], s_main)); }
-						else {
-							// few 22-block jobs (C4: a few hundred): the kernel is the tail of its longest job, 0.85 ms alone at the end of the stage -- it starts first, on a side stream, beside the other two
+						{
+							// few 22-block jobs (C4: a few hundred): the kernel is the tail of its longest job, 0.85 ms alone at the end of the stage -- it starts first, on a side stream, beside the other two.
+							// (Side by side with the other classes the three kernels of this one still run one after the other and share a range: a range each cost 6.8 GB per context.)
+							hipStream_t const s_cls = s;
 							const bool thin22 = c22 > 0 && c22 <= 8192u && split;
-							if (thin22) { AL_HIP_CHECK(hipEventRecord(c->ev_fj[0], s)); AL_HIP_CHECK(hipStreamWaitEvent(c->aux[1], c->ev_fj[0], 0)); s = c->aux[1]; gw_used = nbj; LAUNCH_DPS(22, first0 + c12 + c16, c22); s = s_main; gw_used = 0; thin22_join = true; }
-							LAUNCH_DPS(12, first0, c12); AL_HIP_CHECK(hipEventRecord(c->ev[ST_EXT_DP_G12 + 1], s)); gw_used = 0; LAUNCH_DPS(16, first0 + c12, c16); AL_HIP_CHECK(hipEventRecord(c->ev[ST_EXT_DP_G16 + 1], s)); gw_used = 0;
+							if (thin22) { hipStream_t const s22 = s_cls == c->aux[1] ? c->aux[2] : c->aux[1]; AL_HIP_CHECK(hipEventRecord(c->ev_fj[0], s_cls)); AL_HIP_CHECK(hipStreamWaitEvent(s22, c->ev_fj[0], 0)); s = s22; gw_used = nbj; LAUNCH_DPS(22, first0 + c12 + c16, c22); s = s_cls; gw_used = 0; thin22_join = true; thin22_stream = s22; }
+							LAUNCH_DPS(12, first0, c12); if (!dp_conc) AL_HIP_CHECK(hipEventRecord(c->ev[ST_EXT_DP_G12 + 1], s_main)); gw_used = 0; LAUNCH_DPS(16, first0 + c12, c16); if (!dp_conc) AL_HIP_CHECK(hipEventRecord(c->ev[ST_EXT_DP_G16 + 1], s_main)); gw_used = 0;
 							if (!thin22) LAUNCH_DPS(22, first0 + c12 + c16, c22);
+							if (dp_conc) { AL_HIP_CHECK(hipEventRecord(c->ev[ST_EXT_DP_G12 + 1], s_main)); AL_HIP_CHECK(hipEventRecord(c->ev[ST_EXT_DP_G16 + 1], s_main)); }
 						}
 						g12_done = true;
 						(void)cnt0;
@@ -2965,7 +2968,7 @@ int al_run_align_stage(al_ctx_t *c)
 				first += cnt;
 			}
 			if (dp_conc) for (int i = 0; i < 3; ++i) { AL_HIP_CHECK(hipEventRecord(c->ev_aux[i], c->aux[i])); AL_HIP_CHECK(hipStreamWaitEvent(s, c->ev_aux[i], 0)); }
-			if (thin22_join) { AL_HIP_CHECK(hipEventRecord(c->ev_aux[1], c->aux[1])); AL_HIP_CHECK(hipStreamWaitEvent(s, c->ev_aux[1], 0)); }
+			if (thin22_join && !dp_conc) { AL_HIP_CHECK(hipEventRecord(c->ev_aux[1], thin22_stream)); AL_HIP_CHECK(hipStreamWaitEvent(s, c->ev_aux[1], 0)); }   // (side by side: the join above covers every aux stream)
 		}
 		else { AL_HIP_CHECK(hipEventRecord(c->ev[ST_EXT_SORT + 1], s)); for (int i = ST_EXT_DP_LANE; i < ST_EXT_DP_G22; ++i) AL_HIP_CHECK(hipEventRecord(c->ev[i + 1], s)); }   // (no jobs: empty intervals)
 		AL_HIP_CHECK(hipEventRecord(c->ev[ST_EXT_DP_G22 + 1], s));
