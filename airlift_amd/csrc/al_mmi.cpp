@@ -122,8 +122,9 @@ extern "C" al_idx_t *al_idx_load(const char *fn)
 	ok = ok && (nw == 0 || fread(mi->S4.data(), 4, nw, fp) == nw);
 	fclose(fp);
 	if (!ok) { fprintf(stderr, "[ERROR] airlift: '%s' is truncated or not an index of this format\n", fn); delete mi; return nullptr; }
-	// singletons that cannot live in the table entry (more than 65536 contigs) become lists of one
-	if (!single_ok) for (Ent &e : ents) if (e.single) { const uint64_t o = mi->pos.size(); mi->pos.push_back(e.v); e.v = o << 32 | 1u; e.single = false; }
+	// every occurrence has its entry in the position array, as in an index built here (n_pos counts occurrences); singletons that cannot live in the table entry
+	// (more than 65536 contigs) become lists of one
+	for (Ent &e : ents) if (e.single) { const uint64_t o = mi->pos.size(); mi->pos.push_back(e.v); if (!single_ok) { e.v = o << 32 | 1u; e.single = false; } }
 	if (mi->pos.size() >= (1ULL << 32)) { fprintf(stderr, "[ERROR] airlift: '%s' holds more than 2^32 positions\n", fn); delete mi; return nullptr; }
 	mi->n_keys = ents.size(); mi->n_pos = mi->pos.size();
 	if (mi->pos.empty()) mi->pos.resize(1);

@@ -58,6 +58,26 @@ int main(int argc, char **argv)
 		for (int w : {2, 5}) { const int r = al_dbg_ranked_selftest(path("p_2.fq").c_str(), "", w, g_dir.c_str()); if (r != 0) { fprintf(stderr, "rank range self-test, %d ranks, one file: %d\n", w, r); ++bad; } }
 		{ const int r = al_dbg_ranked_selftest(path("tiny.fq").c_str(), path("tiny.fq").c_str(), 6, g_dir.c_str()); if (r != 0) { fprintf(stderr, "rank range self-test, 6 ranks on 2 records: %d\n", r); ++bad; } }
 	}
+	// the index file (al_mmi.cpp): host-built index of the FASTA above -> dump -> load -> dump again: same size, same key and position counts; a truncated file is an error, not a crash
+	{
+		al_idxopt_t io; al_mapopt_t mo; al_set_opt(nullptr, &io, &mo); al_set_opt("sr", &io, &mo);
+		al_idx_t *mi = al_idx_build(path("t.fa").c_str(), &io, 3);
+		if (!mi || al_idx_dump(path("t.mmi").c_str(), mi) != 0) { fprintf(stderr, "index dump failed\n"); ++bad; }
+		al_idx_t *m2 = al_idx_is_idx(path("t.mmi").c_str()) > 0 ? al_idx_load(path("t.mmi").c_str()) : nullptr;
+		uint64_t a[3] = {0, 0, 0}, b[3] = {1, 1, 1};
+		if (mi) al_idx_stat(mi, &a[0], &a[1], &a[2]);
+		if (m2) al_idx_stat(m2, &b[0], &b[1], &b[2]);
+		if (!m2 || a[0] != b[0] || a[1] != b[1] || a[2] != b[2] || al_idx_dump(path("t2.mmi").c_str(), m2) != 0 || al_idx_is_idx(path("t2.mmi").c_str()) != al_idx_is_idx(path("t.mmi").c_str())) { fprintf(stderr, "index file round trip differs\n"); ++bad; }
+		{   // truncated copy
+			FILE *f = fopen(path("t.mmi").c_str(), "rb"); std::string buf;
+			if (f) { char tmp[65536]; size_t n; while ((n = fread(tmp, 1, sizeof(tmp), f)) > 0) buf.append(tmp, n); fclose(f); }
+			write_file(path("t3.mmi"), buf.substr(0, buf.size() / 2));
+			al_idx_t *m3 = al_idx_load(path("t3.mmi").c_str());
+			if (m3) { fprintf(stderr, "al_idx_load accepted a truncated index\n"); ++bad; al_idx_destroy(m3); }
+		}
+		if (m2) al_idx_destroy(m2);
+		if (mi) al_idx_destroy(mi);
+	}
 	// ordered output of several lanes
 	for (int lanes : {1, 2, 5}) for (int off : {0, 1, 2}) { const int r = al_dbg_ordered_out_selftest(path("o.txt").c_str(), lanes, 40, off); if (r != 0) { fprintf(stderr, "ordered output self-test (%d lanes, offsets %d): %d\n", lanes, off, r); ++bad; } }
 	// SAM formatter (device routine compiled for the host) against al_write_sam
