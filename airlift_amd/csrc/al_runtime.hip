@@ -462,6 +462,7 @@ static uint32_t qname_hash(const char *qname, int qlen_sum, int seed)
 }
 
 void al_ctx_no_taps(al_ctx_t *c) { if (c) c->no_taps = true; }
+extern "C" void al_ctx_set_no_taps(al_ctx_t *c, int on) { if (c) c->no_taps = on != 0; }
 extern "C" void al_ctx_set_threads(al_ctx_t *c, int n_threads) { if (c) c->n_threads = n_threads > 1 ? n_threads : 1; }
 
 extern "C" int al_batch_upload(al_ctx_t *c, int n_frag, const int *n_segs, const int *qlens, const char *const *seqs, const char *const *qnames)

@@ -251,7 +251,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--pairs", type=int, default=1_000_000, help="fragments per GPU per step (C4: about 1250 seed hits and 155 chains per pair, ~100 bytes of workspace per seed hit: 1 M pairs take ~140 GB next to the 23 GB index; a batch that does not fit is halved)")
+    ap.add_argument("--pairs", type=int, default=0, help="(default: 1 M; 500 k for c5, the size its earlier lines were quoted at) fragments per GPU per step (C4: about 1250 seed hits and 155 chains per pair, ~100 bytes of workspace per seed hit: 1 M pairs take ~140 GB next to the 23 GB index; a batch that does not fit is halved)")
     ap.add_argument("--read-len", type=int, default=0, help="default: the config's (150; C5: 250)")
     ap.add_argument("--cpu-sample-pairs", type=int, default=500_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -261,6 +261,8 @@ def main():
     ap.add_argument("--config", default="c4", help="workload of tools/gen_synth.py: c4 (default: the configuration BASELINE.json's metric is quoted on -- 150 bp PE against a human-sized reference; fits one GPU), c5 (250 bp), c3 (100 Mbp), c2 (yeast-sized), c2r, c4s, c3u, c4u")
     ap.add_argument("--test-one-gpu", action="store_true", help="N > 1 on a one-GPU box (validation of the sharded path only): every rank uses device 0, collectives over gloo")
     a = ap.parse_args()
+    if a.pairs <= 0:
+        a.pairs = 500_000 if a.config == "c5" else 1_000_000        # (c5: 250 bp pairs hold 2100 seed hits each -- 1 M pairs fill the HBM to within what the runtime's queues need for scratch)
 
     import torch
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -320,6 +322,8 @@ def main():
     t_reads = time.time() - t0
     ctx = A.Context(idx, device=local if world > 1 else 0)
     L.al_ctx_set_threads(ctx.h, min(32, os.cpu_count() or 1))       # host packing threads (outside the timed region)
+    L.al_ctx_set_no_taps.argtypes = [C.c_void_p, C.c_int]; L.al_ctx_set_no_taps.restype = None
+    L.al_ctx_set_no_taps(ctx.h, 1)                                  # as the file drivers' contexts: no copy of the sorted anchors kept for the debug taps (16 bytes per seed hit: 19 GB of C5's 500 k-pair batch, which fills the HBM otherwise)
     state = {"f_lo": f_lo, "arr": arr}
 
     def upload(nf):

@@ -110,6 +110,9 @@ al_idx_t *al_idx_load(const char *fn);
 int64_t   al_idx_is_idx(const char *fn);
 int       al_idx_k(const al_idx_t *mi);      /* mm_idx_t::k, ::w (minimap.h:57) */
 int       al_idx_w(const al_idx_t *mi);
+/* Batch API: the caller will not read the sorted-anchor taps (al_dbg_anchors after a run) of this context, so the alignment stage's per-mate anchor arrays take the
+ * place of their copy: 16 bytes per seed hit less (20 GB on a 1 M-pair batch against a human-sized reference).  The file drivers set it for their contexts. */
+void      al_ctx_set_no_taps(al_ctx_t *ctx, int on);
 /* mm_idx_cal_max_occ (index.c:164-185): (1-f) quantile of the per-minimizer occurrence counts + 1; INT32_MAX for f <= 0 */
 int32_t   al_idx_cal_max_occ(const al_idx_t *mi, float f);
 /* mm_mapopt_update (minimap.h:183, options.c:51-61): mid_occ <= 0 is replaced by al_idx_cal_max_occ(mi, 2e-4) */
