@@ -142,7 +142,8 @@ def file_to_file(tmp, ref_fa, a, arr, ref, resident_value):
                          "index_build_s": float(mi.group(1)) if mi else None, "device_alloc_gb": float(ma.group(2)) if ma else None, "device_alloc_s": float(ma.group(3)) if ma else None,
                          "batch_reads": int(mb.group(1)) if mb else None, "contexts": int(mb.group(2)) if mb else None, "slots": int(mb.group(3)) if mb else None,
                          "reserve_gb": float(mr.group(1)) if mr else None, "reserve_obtained_in_background_s": float(mr.group(4)) if mr else None, "peak_device_gb_in_use": float(mr.group(5)) if mr else None,
-                         "requests_passed_on_to_hipMalloc": int(mr.group(7)) if mr else None, "index_gb": float(mx.group(1)) if mx else None})
+                         "requests_passed_on_to_hipMalloc": int(mr.group(7)) if mr else None, "index_gb": float(mx.group(1)) if mx else None,
+                         "driver_lines": [l[10:330] for l in err.splitlines() if l.startswith("[airlift] stream pipeline: ") or l.startswith("[airlift] pipeline lane") or l.startswith("[airlift] index: ")][:4]})
         best = next((r for r in runs if r["pipeline_s"]), None)     # the FIRST run is the headline of this leg
         for r in runs:
             if r["pipeline_s"]:
