@@ -189,8 +189,9 @@ ct_tile_body(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ 
 					if (r < rows) {
 						const uint32_t i = r - s_tf[fi].start; is[j] = i;
 						const AlAnchor *src = anchors + s_tf[fi].aoff + pos;
+						if (P.dbg2 & 32) { e[j].x = reinterpret_cast<const uint64_t *>(src)[i]; e[j].y = (uint64_t)q_span << 32 | (i & 0xfff); xp[j] = i > 0 ? e[j].x - 700 : 0; } else {   // (AL_DBG2 bit 5, timing experiment: one 8-byte load per row)
 						e[j] = src[i];
-						if (i > 0) xp[j] = src[i - 1].x;
+						if (i > 0) xp[j] = src[i - 1].x; }
 					}
 				}
 				// (the compiler would sink every load to its use -- one memory latency per row: the loaded values are pinned here)
@@ -461,6 +462,7 @@ ct_tile_body(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ 
 					if (!single) while (fi + 1 < nfr && s_tf[fi + 1].start <= t) ++fi;
 					const uint64_t base = s_tf[fi].aoff + pos; const uint32_t st0 = s_tf[fi].start;
 					di[j] = base + (t - st0);
+					if (P.dbg2 & 16) { v[j].x = sr; v[j].y = di[j]; } else               // (AL_DBG2 bit 4, timing experiment: no gather)
 					v[j] = anchors[ok[j] ? base + (sr - st0) : s_tf[0].aoff];          // (a place without a chained anchor: any readable anchor, not stored)
 				}
 				asm volatile("" : "+v"(v[0].x), "+v"(v[0].y), "+v"(v[1].x), "+v"(v[1].y));

@@ -4,6 +4,8 @@
 // is regrouped into this library's one open-addressing table + one position array on load, and back on dump.  The order of a bucket's pairs is the table's slot order
 // here and khash's slot order there: the loader of either side inserts them one by one, so the files differ in that order only.
 #include "al_internal.h"
+#include <sys/stat.h>
+#include <stdexcept>
 #include <cstdio>
 #include <cstring>
 #include <algorithm>
@@ -77,7 +79,13 @@ extern "C" int al_idx_dump(const char *fn, al_idx_t *mi)
 	return ok ? 0 : -1;
 }
 
+static al_idx_t *al_idx_load_impl(const char *fn);
 extern "C" al_idx_t *al_idx_load(const char *fn)
+{   // (a corrupt or hostile file must come back as NULL, not as an exception through the C boundary)
+	try { return al_idx_load_impl(fn); }
+	catch (const std::exception &e) { fprintf(stderr, "[ERROR] airlift: loading the index '%s' failed (%s)\n", fn ? fn : "(null)", e.what()); return nullptr; }
+}
+static al_idx_t *al_idx_load_impl(const char *fn)
 {
 	FILE *fp = fn && strcmp(fn, "-") ? fopen(fn, "rb") : nullptr;
 	if (!fp) { fprintf(stderr, "[ERROR] airlift: failed to open '%s'\n", fn ? fn : "(null)"); return nullptr; }
@@ -85,7 +93,12 @@ extern "C" al_idx_t *al_idx_load(const char *fn)
 	if (fread(magic, 1, 4, fp) != 4 || memcmp(magic, AL_MMI_MAGIC, 4) != 0 || fread(x, 4, 5, fp) != 5) { fclose(fp); return nullptr; }
 	if (x[4] & AL_MMI_HPC) { fprintf(stderr, "[ERROR] airlift: '%s' is a homopolymer-compressed index (not on the short-read path)\n", fn); fclose(fp); return nullptr; }
 	if (x[4] & AL_MMI_NO_SEQ) { fprintf(stderr, "[ERROR] airlift: '%s' was written without the sequences; alignment needs them\n", fn); fclose(fp); return nullptr; }
+	if (x[0] > 32 && x[0] < 256) { fprintf(stderr, "[ERROR] airlift: '%s' was built with a minimizer window of w=%u; the device sketch holds windows of up to 32 k-mers\n", fn, x[0]); fclose(fp); return nullptr; }
 	if (x[1] < 1 || x[1] > AL_MAX_K || x[0] < 1 || x[0] > 32 || x[2] > 30) { fprintf(stderr, "[ERROR] airlift: index parameters out of range in '%s' (w=%u k=%u b=%u)\n", fn, x[0], x[1], x[2]); fclose(fp); return nullptr; }
+	// sizes in the file are checked against what the file can hold before anything is resized to them: a contig costs >= 5 bytes, an occurrence 8, a key 16
+	uint64_t fsz = 0;
+	{ struct stat sb; if (fstat(fileno(fp), &sb) == 0 && S_ISREG(sb.st_mode)) fsz = (uint64_t)sb.st_size; }
+	if (fsz && (uint64_t)x[3] * 5 > fsz) { fprintf(stderr, "[ERROR] airlift: '%s' names %u contigs, more than its %llu bytes can hold\n", fn, x[3], (unsigned long long)fsz); fclose(fp); return nullptr; }
 	al_idx_t *mi = new al_idx_t();
 	mi->w = (int)x[0]; mi->k = (int)x[1];
 	const int b = (int)x[2]; const uint32_t nb = 1u << b;
@@ -102,10 +115,10 @@ extern "C" al_idx_t *al_idx_load(const char *fn)
 	const bool single_ok = mi->seq.size() <= AL_TAB_SINGLE_MAX_SEQ;
 	for (uint32_t i = 0; i < nb && ok; ++i) {
 		int32_t n = 0; uint32_t size = 0;
-		ok = fread(&n, 4, 1, fp) == 1 && n >= 0;
+		ok = fread(&n, 4, 1, fp) == 1 && n >= 0 && (!fsz || (uint64_t)n * 8 <= fsz);
 		const uint64_t base = mi->pos.size();
 		if (ok && n) { mi->pos.resize(base + (size_t)n); ok = fread(&mi->pos[base], 8, (size_t)n, fp) == (size_t)n; }
-		ok = ok && fread(&size, 4, 1, fp) == 1;
+		ok = ok && fread(&size, 4, 1, fp) == 1 && (!fsz || (uint64_t)size * 16 <= fsz);
 		if (ok && size) {
 			buf.resize(2 * (size_t)size); ok = fread(buf.data(), 8, buf.size(), fp) == buf.size();
 			for (uint32_t j = 0; j < size && ok; ++j) {
@@ -118,7 +131,8 @@ extern "C" al_idx_t *al_idx_load(const char *fn)
 		}
 	}
 	const size_t nw = (size_t)((sum + 7) / 8);
-	mi->S4.assign(nw + 8, 0);
+	ok = ok && (!fsz || (uint64_t)nw * 4 <= fsz);
+	if (ok) mi->S4.assign(nw + 8, 0);
 	ok = ok && (nw == 0 || fread(mi->S4.data(), 4, nw, fp) == nw);
 	fclose(fp);
 	if (!ok) { fprintf(stderr, "[ERROR] airlift: '%s' is truncated or not an index of this format\n", fn); delete mi; return nullptr; }

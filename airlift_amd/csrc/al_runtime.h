@@ -12,10 +12,12 @@
 // either at its old size or empty, and the caller may upload a smaller batch).
 inline bool &al_nomem_flag() { static thread_local bool f = false; return f; }
 
-// Device ranges of the grow-only arenas and the index builder's temporaries: hipMalloc / hipFree behind one pair of functions so that
-// the test switches AL_TEST_POISON / AL_TEST_GUARD (al_runtime.hip) see every range.  (The stream-ordered pool allocator was measured:
-// hipMalloc maps memory at 20-25 GB/s on this platform and the pool recycles a range in milliseconds, tools/micro/malloc_cost.hip, but
-// what a process pays is the driver scrubbing memory a previous process held -- 1.4 s per 60 GB either way -- so the plain calls stay.)
+// Device ranges of the grow-only arenas and the index builder's temporaries, behind one pair of functions so that the test switches
+// AL_TEST_POISON / AL_TEST_GUARD (al_runtime.hip) see every range.  With a reserve (al_device_reserve: chunks obtained by a background thread) they are
+// served from it, best fit, no driver call; without one, or for a request larger than a chunk, by hipMalloc / hipFree.
+// al_dev_free does NOT synchronise the device (hipFree did): a range goes back to the reserve at once and may be handed to another context's thread in the
+// next microsecond, so the caller frees a range only when no kernel or copy that uses it can still be in flight -- DevBuf::ensure(!keep) / release() are
+// called between a context's batches, on the thread that has just synchronised its streams; ctx_release_buffers drains every stream first.
 hipError_t al_dev_malloc(void **p, size_t bytes);
 // Accounting: while a thread has set al_acct() to a counter, the bytes of every range it allocates are added to it (and taken off
 // again when the range is freed, by whichever thread): the stream driver sizes its batches from what one batch held.

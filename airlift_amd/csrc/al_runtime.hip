@@ -189,7 +189,27 @@ bool pool_free(void *ptr)
 	P.free_[p] = sz;
 	return true;
 }
+// chunks nothing is using go back to the driver (and the filler stops): the request that did not fit the reserve gets a chance at hipMalloc
+size_t pool_release_free(void)
+{
+	DevPool &P = pool();
+	if (!P.started) return 0;
+	std::vector<char *> rel; size_t bytes = 0;
+	{
+		std::lock_guard<std::mutex> l(P.m);
+		P.target = P.obtained;                                       // (the filler asks for no further chunk)
+		for (size_t i = 0; i < P.regions.size(); ) {
+			auto it = P.free_.find(P.regions[i].first);
+			if (it != P.free_.end() && it->second == P.regions[i].second) { rel.push_back(P.regions[i].first); bytes += P.regions[i].second; P.obtained -= P.regions[i].second; P.target = P.obtained; P.free_.erase(it); P.regions.erase(P.regions.begin() + (long)i); }
+			else ++i;
+		}
+	}
+	for (char *q : rel) (void)hipFree(q);
+	if (bytes && getenv("AL_TIMING")) fprintf(stderr, "[airlift] device memory reserve: %.1f GB in %zu unused chunk(s) given back to the driver for a request the reserve could not serve\n", bytes / 1e9, rel.size());
+	return bytes;
 }
+}
+static size_t pool_release_free_chunks() { return pool_release_free(); }
 extern "C" int al_device_reserve(int device, uint64_t bytes)
 {
 	DevPool &P = pool();
@@ -290,11 +310,35 @@ extern "C" void al_device_reserve_report(FILE *fp)
 extern "C" uint64_t al_device_reserve_peak(void) { DevPool &P = pool(); if (!P.started) return 0; std::lock_guard<std::mutex> l(P.m); return (uint64_t)P.peak; }
 extern "C" void al_device_reserve_reset_peak(void) { DevPool &P = pool(); if (!P.started) return; std::lock_guard<std::mutex> l(P.m); P.peak = P.in_use; }
 
+// hipMalloc that leaves the runtime room (round 6).  The HIP runtime obtains device memory of its own while kernels run -- the scratch of a hardware queue the
+// first time a kernel with private memory is dispatched on it (k_align: 272 bytes per lane, x 64 lanes x the wave slots of 256 CUs = 142 MB per queue, and a
+// context spreads its streams over up to 16 queues), code objects, signals -- and when it cannot, the process dies with HSA_STATUS_ERROR_OUT_OF_RESOURCES: no
+// error a caller can catch.  So a request that would leave less than a margin free is refused HERE, as out of memory (AL_ERR_NOMEM upstream: the drivers halve
+// the batch).  AL_HBM_MARGIN_MB, default 2048.  With a reserve, its free chunks go back to the driver first and the request is tried again -- also for a request
+// larger than a chunk, which the reserve can never serve itself.
+static size_t pool_release_free_chunks();
+static hipError_t al_hip_malloc_margin(void **p, size_t bytes)
+{
+	static const size_t margin = (size_t)(getenv("AL_HBM_MARGIN_MB") ? std::max(0, atoi(getenv("AL_HBM_MARGIN_MB"))) : 2048) << 20;
+	for (int attempt = 0; attempt < 2; ++attempt) {
+		size_t fr = 0, tot = 0;
+		const bool known = hipMemGetInfo(&fr, &tot) == hipSuccess;
+		if (!known) (void)hipGetLastError();
+		if (!known || fr >= bytes + margin) {
+			const hipError_t e = hipMalloc(p, bytes);
+			if (e == hipSuccess) return e;
+			(void)hipGetLastError();
+		}
+		if (attempt == 0 && pool_release_free_chunks() == 0) break;
+	}
+	*p = nullptr;
+	return hipErrorOutOfMemory;
+}
 static hipError_t al_dev_malloc_raw(void **p, size_t bytes)
 {
 	const auto t0 = std::chrono::steady_clock::now();
 	hipError_t e = hipSuccess;
-	if (void *q = pool_alloc(bytes)) *p = q; else e = hipMalloc(p, bytes);
+	if (void *q = pool_alloc(bytes)) *p = q; else e = al_hip_malloc_margin(p, bytes);
 	{ AlAllocStat &a = al_alloc_stat(); const long long ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); a.dev_ns += ns; a.dev_bytes += (long long)bytes; ++a.dev_calls;
 	  static const bool tr = getenv("AL_TRACE_ALLOC") != nullptr;
 	  if (tr && bytes >= (32u << 20)) { const AlAllocSite &w = al_alloc_site(); const char *b = strrchr(w.file, '/'); fprintf(stderr, "[airlift] alloc: %8.1f MB in %7.1f ms for %s:%d\n", bytes / 1e6, ns / 1e6, b ? b + 1 : w.file, w.line); } }
@@ -402,6 +446,7 @@ extern "C" al_ctx_t *al_ctx_init(const al_idx_t *mi, const al_mapopt_t *opt, int
 	P.a = opt->a; P.b = opt->b; P.q = opt->q; P.e = opt->e; P.q2 = opt->q2; P.e2 = opt->e2; P.sc_ambi = opt->sc_ambi; P.zdrop = opt->zdrop; P.zdrop_inv = opt->zdrop_inv;
 	P.end_bonus = opt->end_bonus; P.min_dp_max = opt->min_dp_max; P.pe_ori = opt->pe_ori; P.pe_bonus = opt->pe_bonus; P.mid_occ = opt->mid_occ; P.max_occ = opt->max_occ;
 	{ const char *d = getenv("AL_DBG"); P.dbg = d ? atoi(d) : 0; if (P.dbg) fprintf(stderr, "[airlift] AL_DBG=%d: timing experiment, results are NOT valid\n", P.dbg); }
+	{ const char *d = getenv("AL_DBG2"); P.dbg2 = d ? atoi(d) : 0; if (P.dbg2) fprintf(stderr, "[airlift] AL_DBG2=%d: timing experiment, results are NOT valid\n", P.dbg2); }
 	memset(&c->stat, 0, sizeof(c->stat));
 	return c;
 }
@@ -409,6 +454,16 @@ extern "C" al_ctx_t *al_ctx_init(const al_idx_t *mi, const al_mapopt_t *opt, int
 void al_align_state_free(al_ctx_t *c);
 static void ctx_release_buffers(al_ctx_t *c)
 {   // every grow-only batch buffer (the index stays); each is re-ensured before its next use
+	// A range given back to the reserve is handed out again at once, to any context's thread, with no device synchronisation in between (hipFree had one):
+	// every stream of this context is drained BEFORE the first range goes back -- this is reached from al_batch_run's out-of-memory exit with the
+	// alignment stage's kernels possibly still in flight.  (al_dev_free: the caller guarantees that nothing on the device still uses the range.)
+	if (c->stream) (void)hipStreamSynchronize(c->stream);
+	if (c->side) (void)hipStreamSynchronize(c->side);
+	for (int i = 0; i < 3; ++i) if (c->aux[i]) (void)hipStreamSynchronize(c->aux[i]);
+	for (int i = 0; i < 3; ++i) if (c->ovl[i]) (void)hipStreamSynchronize(c->ovl[i]);
+	if (c->spec) (void)hipStreamSynchronize(c->spec);
+	if (c->spec2) (void)hipStreamSynchronize(c->spec2);
+	(void)hipGetLastError();
 	al_align_state_free(c);
 	if (c->side) (void)hipStreamSynchronize(c->side);
 	for (int i = 0; i < 3; ++i) if (c->aux[i]) (void)hipStreamSynchronize(c->aux[i]);
@@ -425,6 +480,7 @@ static void ctx_release_buffers(al_ctx_t *c)
 	c->big_tmp.release(); c->chain_key.release(); c->chain_idx.release(); c->chain_idx2.release(); c->tie_list.release(); c->lb_buf.release(); c->tmp_u64b.release();
 	c->chain_tmp.release(); c->u_tmp.release(); c->okey_tmp.release(); c->fb2_list.release(); c->fb3_list.release(); c->seg_cnt.release(); c->seg_first.release(); c->seg_cnt0.release(); c->seg_first0.release(); c->seg_t1.release(); c->vs_off.release(); c->vs_na.release(); c->vs_meta.release(); c->vs_res.release(); c->vs_cls.release(); c->seg_key.release(); c->seg_idx.release(); c->seg_ord.release(); c->fb_list.release(); c->tie_frags.release(); c->heap_cnt.release(); c->tie_sorted.release(); c->big_na.release(); c->big_off.release();
 	c->uo.release(); c->big_k0.release(); c->big_k1.release(); c->v_anchors.release(); c->v_chained.release(); c->v_u.release(); c->v_a_off.release(); c->v_first64.release(); c->v_na.release(); c->v_nseg.release(); c->v_first.release(); c->v_rd_len.release(); c->v_order.release(); c->v_nu.release(); c->fbk_list.release(); c->d_uslot.release(); c->d_rel.release(); c->chain_cls.release(); c->d_fragid.release(); c->cmp_list.release(); c->ctie.release(); c->frag_meta.release();
+	c->big_nt.release(); c->big_toff.release(); c->big_tent.release(); c->big_cuts.release();
 	c->a_off_p1.release(); c->frag_na_p1.release(); c->frag_rep_p1.release(); c->cigar.release(); c->reg_off.release(); c->cig_off.release(); c->align_ws.release(); c->seg_a.release(); c->seg_u.release();
 }
 extern "C" void al_ctx_destroy(al_ctx_t *c)
@@ -1304,6 +1360,7 @@ extern "C" int al_batch_run(al_ctx_t *c)
 	}
 	if (al_run_seed_stages(c)) return failed();
 	for (int attempt = 0; ; ++attempt) {
+		if ((c->P.dbg2 >> 20) & 1) { for (int i = ST_REGS; i < ST_N; ++i) AL_HIP_CHECK(hipEventRecord(c->ev[i + 1], c->stream)); AL_HIP_CHECK(hipStreamSynchronize(c->stream)); break; }   // (AL_DBG2 bit 20, timing experiments: seed / sort / chain stages only)
 		if (al_run_align_stage(c)) return failed();
 		AL_HIP_CHECK(hipEventRecord(c->ev[ST_COMPACT + 1], c->stream));
 		AL_HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -1326,6 +1383,8 @@ extern "C" int al_batch_run(al_ctx_t *c)
 	unsigned long long h[16]; AL_HIP_CHECK(hipMemcpy(h, c->counters.p, sizeof(h), hipMemcpyDeviceToHost));
 	if ((c->P.dbg >> 24) & 1) { unsigned long long t[8]; AL_HIP_CHECK(hipMemcpy(t, c->counters.p + 24, sizeof(t), hipMemcpyDeviceToHost));
 		fprintf(stderr, "[airlift] tile kernel profile (cycles of thread 0, all blocks, both passes): setup %llu load %llu cut %llu dp %llu emit %llu copy %llu; tiles %llu\n", t[0], t[1], t[2], t[3], t[4], t[5], t[6]); }
+	if ((c->P.dbg2 >> 3) & 1) { unsigned long long t[8]; AL_HIP_CHECK(hipMemcpy(t, c->counters.p + 24, sizeof(t), hipMemcpyDeviceToHost));
+		fprintf(stderr, "[airlift] lane chaining kernels (cycles per wavefront, all launches of the batch): setup %llu load %llu recurrence %llu ends/backtrack/order %llu copy %llu; wavefronts %llu\n", t[5] ? t[0] / t[5] : 0, t[5] ? t[1] / t[5] : 0, t[5] ? t[2] / t[5] : 0, t[5] ? t[3] / t[5] : 0, t[5] ? t[4] / t[5] : 0, t[5]); }
 	if (getenv("AL_TRACE")) { fprintf(stderr, "[airlift] trace: counters"); for (int i = 0; i < 16; ++i) fprintf(stderr, " [%d]=%llu", i, h[i]); fprintf(stderr, " rechain=%u\n", c->n_rechain); }
 	al_batch_stat_t &st = c->stat; memset(&st, 0, sizeof(st));
 	st.n_frag = c->n_frag; st.n_reads = c->n_reads; st.n_bases = c->n_bases;

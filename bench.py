@@ -186,9 +186,10 @@ def cpu_baseline(tmp, ref_fa, arr, n_pairs, read_len):
     write_fastq_sample(os.path.join(tmp, "cb_1.fq"), arr[:n_pairs], 0)
     write_fastq_sample(os.path.join(tmp, "cb_2.fq"), arr[:n_pairs], 1)
     ref_bin = os.path.join(ROOT, "oracle", "_ref", "mm2ref")
-    sweep = sorted({t for t in (16, 32, 64, 128, cores) if t <= cores} | {cores})
+    sweep = sorted({t for t in (16, 32, 64, 128) if t <= cores} or {cores})
+    k_big = "500M"                            # one more point with a ten times larger mini-batch (the fork's -K): fewer, longer parallel sections
     if os.path.exists(ref_bin):
-        kind, cmd = "reference", [ref_bin, "-t", ",".join(map(str, sweep))]
+        kind, cmd = "reference", [ref_bin, "-t", ",".join(list(map(str, sweep)) + ["%d@%s" % (min(64, max(sweep)), k_big)])]
     else:
         subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "al_oracle"], check=True)
         kind, cmd, sweep = "port", [os.path.join(ROOT, "oracle", "al_oracle"), "-t", str(cores)], [cores]
@@ -204,15 +205,17 @@ def cpu_baseline(tmp, ref_fa, arr, n_pairs, read_len):
     with open(os.path.join(tmp, "cpu.sam"), "wb") as f:
         r = subprocess.run(cmd + [ref_fa, "cb_1.fq", "cb_2.fq"], cwd=tmp, stdout=f, stderr=subprocess.PIPE, env=dict(os.environ, MM2REF_TIMING="1"), check=True)
     t_all = time.time() - t0
-    pts = [(int(m.group(1)), float(m.group(2)), float(m.group(3))) for m in re.finditer(r"\[mm2ref\] threads=(\d+) index_s=([0-9.]+) map_s=([0-9.]+)", r.stderr.decode(errors="replace"))]
+    pts = [(int(m.group(1)), float(m.group(3)), float(m.group(4)), int(m.group(2) or 0)) for m in re.finditer(r"\[mm2ref\] threads=(\d+)(?: K=(\d+))? index_s=([0-9.]+) map_s=([0-9.]+)", r.stderr.decode(errors="replace"))]
     if pts:
         best = min(pts, key=lambda x: x[2]); t_idx = pts[0][1]; t_map = best[2]; used = best[0]
         t_cold = t_idx + pts[-1][2]           # what one cold run at the last sweep point costs (index + mapping)
     else:                                   # the port prints no timing: whole wall
         t_idx, t_map, used, t_cold = 0.0, t_all, cores, t_all
     base = {"value": 2 * n_pairs / t_map, "unit": "reads/s", "cores": used, "kind": kind,
-            "sample": "first %d pairs x %d bp of the same workload, SAM to a file; thread sweep %s in one process, best = %d threads (%.2f s of mapping); index build %.1f s not included"
-                      % (n_pairs, read_len, "/".join("%d:%.2fs" % (p[0], p[2]) for p in pts), used, t_map, t_idx),
+            "sample": "first %d pairs x %d bp of the same workload (%d mini-batches at the preset's 50 Mbases), SAM to a file; sweep threads[@mini-batch bases] %s in one process, best = %d threads%s (%.2f s of mapping); index build %.1f s not included"
+                      % (n_pairs, read_len, -(-2 * n_pairs * read_len // 50_000_000), "/".join("%d%s:%.2fs" % (p[0], ("@%dM" % (p[3] // 1000000)) if len(p) > 3 and p[3] not in (0, 50_000_000) else "", p[2]) for p in pts), used,
+                         (" at -K %dM" % (best[3] // 1000000)) if pts and len(best) > 3 and best[3] not in (0, 50_000_000) else "", t_map, t_idx),
+            "sweep": [{"threads": p[0], "mini_batch_bases": (p[3] if len(p) > 3 and p[3] else 50_000_000), "map_s": p[2], "reads_per_s": 2 * n_pairs / p[2]} for p in pts],
             "host_cores": cores}
     cli = os.path.join(ROOT, "airlift_amd", "bin", "airlift-align")
     nt = min(cores, 32)
@@ -254,7 +257,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--pairs", type=int, default=0, help="(default: 1 M; 500 k for c5, the size its earlier lines were quoted at) fragments per GPU per step (C4: about 1250 seed hits and 155 chains per pair, ~100 bytes of workspace per seed hit: 1 M pairs take ~140 GB next to the 23 GB index; a batch that does not fit is halved)")
     ap.add_argument("--read-len", type=int, default=0, help="default: the config's (150; C5: 250)")
-    ap.add_argument("--cpu-sample-pairs", type=int, default=500_000)
+    ap.add_argument("--cpu-sample-pairs", type=int, default=2_000_000)   # >= 12 mini-batches of the preset's 50 Mbases: the reference's three-step pipeline has something to overlap
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--f2f-sleep", type=float, default=5.0, help="seconds to wait before each process of the file-to-file leg (recorded in the output)")
     ap.add_argument("--f2f-pairs", type=int, default=6_250_000, help="pairs of the file-to-file leg (FASTQ files -> airlift-align -> SAM file; rank 0, N=1 only; 0 = skip)")
@@ -462,18 +465,27 @@ def main():
                                     "note": ("integer-VALU bound (see roofline.valu): affine-gap DP cells of its jobs; its HBM bytes are the 4-bit reference windows and the result records (the 9 ... 22-block class has %.0f target bases in %d jobs, over its three kernels)" % (float(st.dp_target_bases[7]), int(st.dp_jobs[7]))) if dom.startswith("ext_dp_g") else (None if dom_bytes is not None else "bytes of this kernel's share of the stage are not separable: see its stage row")},
                 "stages": stages}
         # The extension DP is bound by integer VALU issue, not by HBM: its row against THAT ceiling.  Wave-instructions per launch come from the
-        # committed SQ_INSTS_VALU pass (profiles/traffic.json, tools/prof.sh); the ceiling is the issue rate of the SIMDs: a 64-wide wavefront
-        # instruction occupies a 16-lane SIMD for 4 cycles, x 1024 SIMDs x 2.4 GHz (the DP kernels of profiles/r04b run at 0.9 ... 1.0 of it).
-        VALU_CEIL = 1024 * 2.4e9 / 4.0
+        # committed SQ_INSTS_VALU pass (profiles/traffic.json, tools/prof.sh).  The ceiling is PER KERNEL (round 6): a wave-instruction does not cost a SIMD a
+        # fixed 4 cycles -- profiles/r05_valu_issue.txt measures 2.3 - 2.5 cycles for plain 32-bit VALU instructions, 4.2 - 4.6 for v_pk_*16 and DPP-modified
+        # ones -- so it follows from the instruction mix of the kernel's row loop (profiles/valu_mix.json, tools/valu_mix.py: counts by kind x those cycles):
+        # 1024 SIMDs x 2.4 GHz / (mean cycles per VALU instruction of that mix).  A kernel absent from the mix file is priced at the plain rate (the highest ceiling).
+        try:
+            vmix = json.load(open(os.path.join(ROOT, "profiles", "valu_mix.json")))
+        except (OSError, ValueError):
+            vmix = {}
         valu = []
         dpk = {iv: dp_name(iv) for iv in dp_geo}
         for iv in ("ext_dp_g4", "ext_dp_g8", "ext_dp_g12", "ext_dp_g16", "ext_dp_g22"):
             ins = (tj.get("kernels", {}).get(dpk[iv]) or {}).get("valu_insts_per_launch") if tj.get("workload") == a.config else None
             ci = {"ext_dp_g4": 5, "ext_dp_g8": 6, "ext_dp_g12": 7, "ext_dp_g16": 7, "ext_dp_g22": 7}[iv]
             own_iv = per.get(iv, 0) > 0.05                                      # (a thin 22-block class runs on a side stream beside the 12- and 16-block kernels: its interval is empty)
+            km = (vmix.get("kernels", {}) or {}).get(dpk[iv]) or {}
+            cyc = km.get("cycles_per_valu_inst") or (vmix.get("cycles_per_kind", {}) or {}).get("plain", 2.5)
+            ceil_k = 1024 * 2.4e9 / cyc
             valu.append({"interval": iv, "kernel": dpk[iv], "ms": per.get(iv), "jobs": int(st.dp_jobs[ci]), "target_bases": int(st.dp_target_bases[ci]),
                          "valu_wave_insts_per_launch_from_committed_profile": ins, "wave_insts_per_s": (ins / (per[iv] * 1e-3)) if ins and own_iv else None,
-                         "issue_ceiling_wave_insts_per_s": VALU_CEIL, "frac_of_issue_ceiling": (ins / (per[iv] * 1e-3) / VALU_CEIL) if ins and own_iv else None,
+                         "row_loop_mix": km.get("by_kind"), "cycles_per_valu_inst_of_that_mix": cyc,
+                         "issue_ceiling_wave_insts_per_s": ceil_k, "frac_of_issue_ceiling": (ins / (per[iv] * 1e-3) / ceil_k) if ins and own_iv else None,
                          **({} if own_iv else {"note": "runs beside the neighbouring classes on a side stream: no interval of its own"})})
         roof["valu"] = valu
         out = {
@@ -489,11 +501,14 @@ def main():
             "counters": {"minimizers_per_read": st.n_mini / (2.0 * a.pairs), "anchors_per_pair": st.n_anchor / float(a.pairs), "chains_per_pair": st.n_chain / float(a.pairs),
                          "regions_aligned_per_read": st.n_regs_aln / (2.0 * a.pairs), "ref_bases_per_region": st.n_refbases / max(1.0, float(st.n_regs_aln)),
                          "rechain": int(st.n_rechain), "heap_fallback": int(st.n_heap_fallback), "chain_fallback": int(st.n_chain_fallback), "side_stream_ms": float(st.ms_side_stream), "sort_tie_flags": int(st.n_sort_tie_flag), **(dist_info or {})},
-            "host": {"index_build_on_gpu_s": t_index, "pack_upload_s": t_upload, "reference_generation_s": t_gen, "read_simulation_s": t_reads, "reference_model": getattr(ref, "stats", None)},
+            "host": {"gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "index_build_on_gpu_s": t_index, "pack_upload_s": t_upload, "reference_generation_s": t_gen, "read_simulation_s": t_reads, "reference_model": getattr(ref, "stats", None)},
         }
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"], out["e2e_cli"] = cpu_baseline(tmp, "ref.fa", arr, min(a.cpu_sample_pairs, a.pairs), a.read_len)
-            out["parity_sample"] = {"pairs": min(a.cpu_sample_pairs, a.pairs), "identical": out["e2e_cli"]["identical_sam"]}
+            n_cpu = max(1, a.cpu_sample_pairs)
+            arr_cpu = arr if n_cpu <= a.pairs else np.concatenate([arr[:a.pairs], make_workload(a.config, a.pairs, n_cpu, a.read_len, 20261002, ref, a.ins_mean)])   # (the same input's next fragments: the sample stays the head of the file-to-file leg's files)
+            out["cpu_baseline"], out["e2e_cli"] = cpu_baseline(tmp, "ref.fa", arr_cpu, n_cpu, a.read_len)
+            out["parity_sample"] = {"pairs": n_cpu, "identical": out["e2e_cli"]["identical_sam"]}
+            del arr_cpu
         if world == 1 and a.f2f_pairs > 0:
             out["file_to_file"] = file_to_file(tmp, "ref.fa", a, arr, ref, out["value"])
         print(json.dumps(out))

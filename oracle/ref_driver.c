@@ -8,8 +8,9 @@
  *
  * usage: mm2ref [-t N[,N2,...]] [-R rgline] [-K minibatch] [--seeds] [--alnseq] [--hit-only] ref.fa r1.fq [r2.fq]
  *   -t a,b,c : thread sweep for the CPU baseline of bench.py: the input is mapped once per value (stdout to /dev/null for all
- *              but the last) and "[mm2ref] threads=N index_s=.. map_s=.." is printed on stderr for each, so that the index
- *              build is paid once and is not part of the mapping time
+ *              but the last) and "[mm2ref] threads=N K=B index_s=.. map_s=.." is printed on stderr for each, so that the index
+ *              build is paid once and is not part of the mapping time; a value N@B maps with a mini-batch of B bases
+ *              (options.c:122 sets 50M for `sr`; the fork's -K, main.c:185; suffixes k / M / G), the others with the preset's
  *   --save-index FILE : write the index (mm_idx_dump, index.c:438) after building it; a later run given FILE instead of ref.fa
  *              loads it (mm_idx_reader_open recognises index files), so that several test cases share one index build
  *   --max-occ F : print "[mm2ref] max_occ f=F value=V" (mm_idx_cal_max_occ, index.c:164) for the index and exit without mapping
@@ -30,6 +31,7 @@ static double wall(void) { struct timeval tv; gettimeofday(&tv, 0); return tv.tv
 int main(int argc, char **argv)
 {
 	int sweep[16], n_sweep = 0, si;
+	long long sweep_k[16], k_default;
 	double t_idx0, t_idx;
 	mm_idxopt_t io; mm_mapopt_t mo;
 	int i, n_threads = 1, nfn = 0;
@@ -43,7 +45,12 @@ int main(int argc, char **argv)
 	for (i = 1; i < argc; ++i) {
 		if (!strcmp(argv[i], "-t") && i + 1 < argc) {
 			char *e = argv[++i]; n_sweep = 0;
-			while (*e && n_sweep < 16) { sweep[n_sweep++] = (int)strtol(e, &e, 10); if (*e == ',') ++e; else break; }
+			while (*e && n_sweep < 16) {
+				sweep[n_sweep] = (int)strtol(e, &e, 10); sweep_k[n_sweep] = 0;
+				if (*e == '@') { double x = strtod(e + 1, &e); if (*e == 'G' || *e == 'g') x *= 1e9, ++e; else if (*e == 'M' || *e == 'm') x *= 1e6, ++e; else if (*e == 'K' || *e == 'k') x *= 1e3, ++e; sweep_k[n_sweep] = (long long)(x + .499); }
+				++n_sweep;
+				if (*e == ',') ++e; else break;
+			}
 			n_threads = 1; for (si = 0; si < n_sweep; ++si) if (sweep[si] > n_threads) n_threads = sweep[si];   /* index build: the largest */
 		}
 		else if (!strcmp(argv[i], "-R") && i + 1 < argc) rg = argv[++i];
@@ -81,7 +88,8 @@ int main(int argc, char **argv)
 	if (mm_check_opt(&io, &mo) < 0) return 2;
 	r = mm_idx_reader_open(fn[0], &io, 0);
 	if (r == 0) { fprintf(stderr, "mm2ref: cannot open %s\n", fn[0]); return 1; }
-	if (n_sweep == 0) sweep[n_sweep++] = n_threads;
+	if (n_sweep == 0) { sweep_k[n_sweep] = 0; sweep[n_sweep++] = n_threads; }
+	k_default = mo.mini_batch_size;
 	t_idx0 = wall();
 	while ((mi = mm_idx_reader_read(r, n_threads)) != 0) {
 		t_idx = wall() - t_idx0;
@@ -93,12 +101,13 @@ int main(int argc, char **argv)
 			if (si + 1 < n_sweep) {            /* not the last sweep point: same work, output discarded */
 				int dn; fflush(stdout); saved = dup(1); dn = open("/dev/null", O_WRONLY); dup2(dn, 1); close(dn);
 			}
+			mo.mini_batch_size = sweep_k[si] > 0 ? sweep_k[si] : k_default;
 			t0 = wall();
 			mm_write_sam_hdr(mi, rg, 0, 0, 0);
 			if (nfn == 2 && !(mo.flag & MM_F_FRAG_MODE)) mm_map_file(mi, fn[1], &mo, sweep[si]);
 			else mm_map_file_frag(mi, nfn - 1, &fn[1], &mo, sweep[si]);
 			fflush(stdout);
-			if (n_sweep > 1 || getenv("MM2REF_TIMING")) fprintf(stderr, "[mm2ref] threads=%d index_s=%.3f map_s=%.3f\n", sweep[si], t_idx, wall() - t0);
+			if (n_sweep > 1 || getenv("MM2REF_TIMING")) fprintf(stderr, "[mm2ref] threads=%d K=%lld index_s=%.3f map_s=%.3f\n", sweep[si], (long long)mo.mini_batch_size, t_idx, wall() - t0);
 			if (saved >= 0) { dup2(saved, 1); close(saved); }
 		}
 		mm_idx_destroy(mi);

@@ -333,6 +333,35 @@ def test_batch_is_halved_when_device_workspaces_do_not_fit(golden_unpacked):
     assert r.stdout == exp
 
 
+def test_full_device_gives_nomem_and_a_halved_batch_not_an_abort(golden_unpacked):
+    """HBM headroom (round 6): with the device filled to within 2 GB by a FOREIGN process, the mapper's allocations that would leave the
+    HIP runtime less than the margin (AL_HBM_MARGIN_MB; the runtime places queue scratch there while kernels run, and dies with
+    HSA_STATUS_ERROR_OUT_OF_RESOURCES when it cannot) are refused as out of memory: al_batch_run returns AL_ERR_NOMEM, the file driver runs
+    the batch in halves, the bytes are the reference's.  The process must never end by a signal."""
+    d = golden_unpacked["g6_repeats"]
+    m = json.load(open(os.path.join(d, "meta.json")))
+    exp = open(os.path.join(d, "expected.sam"), "rb").read()
+    rg = ["-R", m["rg"]] if m.get("rg") else []
+    cmd = [CLI, "-ax", "sr"] + rg + [m["ref"]] + m["reads"]
+    seen_halved = False
+    for keep_mb, margin_mb in ((2048, 1024), (3000, 2048), (2500, 1024)):
+        fill = subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "helpers", "hbm_fill.py"), str(keep_mb)], stdin=subprocess.PIPE, stdout=subprocess.PIPE)
+        try:
+            line = fill.stdout.readline().decode()
+            assert line.startswith("ready"), line
+            r = subprocess.run(cmd, cwd=d, capture_output=True, env=dict(os.environ, AL_HBM_MARGIN_MB=str(margin_mb)), timeout=300)
+        finally:
+            fill.stdin.close(); fill.wait(timeout=60)
+        assert r.returncode >= 0, "killed by signal %d: %s" % (-r.returncode, r.stderr.decode()[-1500:])       # an abort of the runtime is SIGABRT
+        assert b"HSA_STATUS_ERROR" not in r.stderr
+        if r.returncode == 0:
+            assert r.stdout == exp, _diff_report(r.stdout, exp, "g6_full_device_%d" % keep_mb)
+            seen_halved = seen_halved or b"does not fit the device workspaces" in r.stderr
+        else:                                                                    # nothing fits at all: a message and a non-zero status, no records
+            assert b"failed" in r.stderr or b"out of memory" in r.stderr.lower()
+    assert seen_halved, "no setting went through AL_ERR_NOMEM and a halved batch"
+
+
 def test_interleaved_single_file_and_uneven_files(golden_unpacked, oracle_bin, tmp_path):
     """One file with /1 /2 mates adjacent (frag_mode pairing by name, map.c:580-586) and two files of different length
     (bseq.c: extra records skipped, with the reference's warning): compared with the oracle on the same inputs."""

@@ -2,6 +2,7 @@
 # quick per-kernel timing: tools/ktrace.sh <tag> [bench args]
 TAG=${1:-kt}; shift || true
 REPO=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$REPO/gpurun_out/kt_$TAG; mkdir -p $OUT
+export GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-16}   # (set before the profiler's preloaded library initialises HIP: bench.py's own setdefault comes too late under rocprofv3)
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $OUT/trace --output-format csv -- python3 $REPO/bench.py --no-cpu-baseline $* > $OUT/bench.json 2> $OUT/err.txt
 python3 - <<PY

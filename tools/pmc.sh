@@ -2,6 +2,7 @@
 # tools/pmc.sh <tag> "<counters>" [bench args]  -- one PMC pass (counters in their own run, kernel-trace only)
 TAG=$1; CTR=$2; shift 2
 REPO=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$REPO/gpurun_out/pmc_$TAG; mkdir -p $OUT
+export GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-16}   # (set before the profiler's preloaded library initialises HIP: bench.py's own setdefault comes too late under rocprofv3)
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --pmc $CTR --kernel-trace -d $OUT/run --output-format csv -- python3 $REPO/bench.py --no-cpu-baseline $* > $OUT/bench.json 2> $OUT/err.txt
 python3 - <<PY
