@@ -87,8 +87,10 @@ __device__ __forceinline__ void d_ksw_pk(LT &L, const uint8_t *__restrict__ selE
 	const int myb = gl >> 3;                                                   // this lane's block inside a superblock
 	GSYNC();
 	const size_t prow = (size_t)n_col_ * 16;
-	uint8_t *ptb = ws.p;
-	if constexpr (LT::kPtb > 0) { if ((size_t)(qlen + tlen - 1) * prow <= (size_t)LT::kPtb) ptb = L.ptb; }
+	// (round 6) the traceback bytes of this form always go to the group's HBM workspace: with the LDS tile of the <= 4-block jobs (JobLds::kPtb) it gave
+	// CIGARs that differ from the reference's, the cause was never found, and the code path is gone -- that class runs d_ksw_reg (k_ext_dp<4, ., ., false>)
+	static_assert(LT::kPtb == 0, "d_ksw_pk keeps its traceback in the HBM workspace: instantiate it with an LDS structure without a traceback tile");
+	uint8_t *const ptb = ws.p;
 	int last_st = -1, last_en = -1, r;
 	const int n_rows = qlen + tlen - 1;
 	for (r = 0; r < n_rows; ++r) {

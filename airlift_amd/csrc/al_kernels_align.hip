@@ -2001,7 +2001,7 @@ template <int QMAXJ, int TMAXJ, bool PK = false> struct JobLds {
 	static constexpr bool kQrReady = true;   // k_ext_dp stores the reversed, padded query itself
 	// traceback tile: jobs of more than 64 target bases have more than 40 rows of at least 32 bytes -- they never fit it, and without it twice
 	// as many wavefronts fit a CU (the kernel waits on LDS reads and byte stores with 3.5 waves per SIMD)
-	static constexpr int kPtb = TMAXJ <= 64 ? AL_LPTB : 0;
+	static constexpr int kPtb = TMAXJ <= 64 && !PK ? AL_LPTB : 0;   // (the two-cells-per-lane form has no LDS traceback tile: al_dev_ksw2.h)
 	uint8_t sq[QMAXJ + 2 * TMAXJ + 32];      // TMAXJ bytes of front pad, the reversed query, zeros up to qlen + TMAXJ + 16 (al_dev_ksw.h)
 	uint8_t selO[PK ? QMAXJ + 2 * TMAXJ + 32 : 1];   // two-cells-per-lane form (al_dev_ksw2.h): sq holds the score permute's selector bytes for a cell in the low half, selO for one in the high half
 	uint32_t __attribute__((aligned(8))) wtab[PK ? TMAXJ : 2];   // ... and the score tables of the target bases, two words per lane and superblock

@@ -1743,12 +1743,21 @@ k_chain(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_off
 
 // =============================================================================================
 // K4 (fragments of <= 128 anchors, LDS resident): one lane per fragment, LANES fragments per wavefront, every per-anchor
-// row staged in LDS as [anchor][lane] (conflict-free) so that nothing is re-fetched from HBM inside the O(n^2) recurrence
+// row staged in LDS as [anchor][lane] so that nothing is re-fetched from HBM inside the O(n^2) recurrence
 // (10 bytes per anchor, layout in the kernel).  CAPL anchors per fragment; the caller orders fragments by anchor count and
 // a wavefront whose largest fragment does not fall in (lo_excl, CAPL] leaves the work to another instantiation.  All spans
 // must equal k and max_dist_x < 2^15 (true on the short-read path); a fragment violating that is a counted error.
+// Round 6: nothing in this kernel waits for HBM one access at a time any more.  By the cycle counters (AL_DBG2 bit 3) a wavefront spent 92 k
+// cycles loading its entries' anchors (a dependent 16-byte load per anchor and lane), 168 k in the recurrence, 50 k on chain ends / backtrack /
+// order (their scratch lay in HBM, ws_u64: a round trip per access, and the chains' first x came back from HBM too) and 105 k copying the chained
+// anchors out (load, then store, one at a time).  Now: the anchors are loaded four at a time (clamped indices, no branch around a load); the chain
+// ends' scratch lives in the rows' dead halves (after the recurrence bytes 0-2 of row c hold chain end / chain c); chains are ordered by
+// first-anchor x without reading x back -- the anchors are sorted, so index order is x order but for equal x, which the loading loop notes in a
+// bit mask per lane; the chained anchors leave four at a time.  (Measured and dropped on the way: the WAVEFRONT loading entry by entry, 64 anchors
+// per load -- coalesced, but 64 entries x two phases of cross-lane work and LDS round trips at ~480 cycles each under this kernel's LDS load.)
 // =============================================================================================
 #define AL_CLIN_N 512
+__device__ __forceinline__ uint64_t d_rl64(uint64_t v, int l) { return (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l) | (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l) << 32; }
 template <int CAPL, int LANES>
 __global__ void __launch_bounds__(64)
 k_chain_lds(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a_off, const uint32_t *__restrict__ frag_na,
@@ -1756,15 +1765,18 @@ k_chain_lds(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a
             AlAnchor *__restrict__ chained, uint64_t *__restrict__ u_out, uint32_t *__restrict__ frag_nu, uint64_t *__restrict__ ws_u64,
             const uint32_t *__restrict__ order, int n_list, int lo_excl, AlParams P, unsigned long long *__restrict__ counters, ChainSeg seg,
             uint32_t *__restrict__ uo_out /* whole-fragment mode: offset of every chain's first anchor in the fragment's range of chained[] */,
-            int utmp_stride /* > 0: the entry's chain-end scratch is ws_u64 + list position * stride (whole fragments: no per-anchor scratch array); 0: ws_u64 + a_off */)
+            int utmp_stride /* (rounds 2-5: where the chain-end scratch lay in ws_u64; unused since it moved into the rows) */)
 {
 	// 10 bytes per anchor: one 8-byte row  [ xlo:16 | q:12 | seg:1 | far:1 | -:2 | f:16 | p:8 | t:8 ]  + the peak score v:16.
 	//  xlo = low 16 bits of the reference position: inside the predecessor window the true distance is <= max_dist_x < 2^15,
 	//        so (xlo_i - xlo_j) mod 2^16 is the distance; "far" marks an anchor whose predecessor lies in another
 	//        (strand, contig) block or >= 2^15 away, which is all the window start needs to know.
-	__shared__ uint64_t srow[CAPL * LANES];
+	constexpr int RS = LANES;
+	constexpr int NR = (CAPL + 63) / 64;                                         // rounds of 64 anchors per entry
+	__shared__ uint64_t srow[CAPL * RS];
 	__shared__ int16_t sv[CAPL * LANES];
 	__shared__ uint8_t s_pen_same[AL_CLIN_N], s_pen_diff[AL_CLIN_N];
+	(void)ws_u64; (void)utmp_stride;
 	const int lane = threadIdx.x;
 	// the list is ordered by anchor count: blocks are issued roughly in index order, so the heaviest wavefronts go first and
 	// the light ones fill the tail of the launch
@@ -1787,14 +1799,19 @@ k_chain_lds(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a
 		}
 		__syncthreads();
 	}
-	if (!have || side) return;
+	bool alive = have && !side;                                                // (the others: no result at all, as before)
+	const bool prof = (P.dbg2 >> 3) & 1;                                        // timing experiment: cycles per phase, summed over the wavefronts (counters[24 ..]; printed by al_batch_run)
+	long long tp = prof ? clock64() : 0;
+#define CL_PROF(i) do { if (prof) { const long long t_ = clock64(); if (lane == 0) atomicAdd(&counters[24 + (i)], (unsigned long long)(t_ - tp)); tp = t_; } } while (0)
 	const bool direct = seg.uslot != nullptr;                                  // deferred segment of the tile kernel: straight to the fragment's arrays
 	uint32_t *const rec = (seg.meta && !direct) ? seg.res + 4 * (size_t)f : nullptr;         // the entry's result record (ChainSeg): written once, at the exits
-#define CHAIN_EXIT0() do { if (rec) *reinterpret_cast<uint4 *>(rec) = make_uint4(0u, 0u, 0u, 0u); else if (!direct) frag_nu[f] = 0; return; } while (0)
-	if (n == 0) CHAIN_EXIT0();
-#define ROW(j) srow[(j) * LANES + lane]
+#define CHAIN_EXIT0() do { if (rec) *reinterpret_cast<uint4 *>(rec) = make_uint4(0u, 0u, 0u, 0u); else if (!direct) frag_nu[f] = 0; alive = false; } while (0)
+	if (alive && n == 0) CHAIN_EXIT0();
+#define ROW(j) srow[(j) * RS + lane]
+#define ROW32(j) (reinterpret_cast<uint32_t *>(&srow[(j) * RS + lane])[0])
 #define VL(j) sv[(j) * LANES + lane]
-#define TB(j) (reinterpret_cast<uint8_t *>(&srow[(j) * LANES + lane])[7])
+#define TB(j) (reinterpret_cast<uint8_t *>(&srow[(j) * RS + lane])[7])
+#define SRCB(j) (reinterpret_cast<uint8_t *>(&srow[(j) * RS + lane])[3])
 #define R_XLO(r) ((uint32_t)(r) & 0xffffu)
 #define R_Q(r) ((int32_t)((uint32_t)(r) >> 16 & 0xfffu))
 #define R_SEG(r) ((int32_t)((uint32_t)(r) >> 28 & 1u))
@@ -1802,14 +1819,17 @@ k_chain_lds(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a
 #define R_F(r) ((int32_t)(int16_t)((r) >> 32))
 #define R_P(r) ((uint32_t)((r) >> 48) & 0xffu)
 #define R_T(r) ((uint32_t)((r) >> 56))
-	int n_segs, qlen_sum = 0;
-	if (seg.meta) { const uint32_t mt = seg.meta[f]; qlen_sum = (int)(mt & 0x7fffffffu); n_segs = (mt >> 31) ? 2 : 1; }
-	else {
-		const uint32_t r0 = frag_first[f], r1 = frag_first[f + 1];
-		n_segs = (int)(r1 - r0);
-		for (uint32_t r = r0; r < r1; ++r) qlen_sum += (int)rd_len[r];
+	int n_segs = 1, qlen_sum = 0;
+	if (have) {
+		if (seg.meta) { const uint32_t mt = seg.meta[f]; qlen_sum = (int)(mt & 0x7fffffffu); n_segs = (mt >> 31) ? 2 : 1; }
+		else {
+			const uint32_t r0 = frag_first[f], r1 = frag_first[f + 1];
+			n_segs = (int)(r1 - r0);
+			for (uint32_t r = r0; r < r1; ++r) qlen_sum += (int)rd_len[r];
+		}
 	}
-	const AlAnchor *a = anchors + a_off[f];
+	const uint64_t aoff = have ? a_off[f] : 0ULL;
+	const AlAnchor *a = anchors + aoff;
 	const int max_dist_y = qlen_sum > P.max_gap ? qlen_sum : P.max_gap;           // map.c:341-351
 	int max_dist_x;
 	if (P.max_gap_ref > 0) max_dist_x = P.max_gap_ref;
@@ -1817,18 +1837,38 @@ k_chain_lds(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a
 	else max_dist_x = P.max_gap;
 	const int bw = P.bw, max_skip = P.max_chain_skip, min_cnt = P.min_cnt, min_sc = P.min_chain_score;
 	const int32_t q_span = P.k;
-	{
-		uint64_t prev_x = 0; bool bad = max_dist_x > 0x7fff || P.max_chain_iter < CAPL;
-		for (int i = 0; i < n; ++i) {
-			const AlAnchor e = a[i];
-			const bool far = i == 0 || (e.x >> 32) != (prev_x >> 32) || (uint32_t)e.x - (uint32_t)prev_x > 0x7fffu;
-			prev_x = e.x;
-			if ((int)(e.y >> 32 & 0xff) != q_span || ((e.y & AL_SEED_SEG_MASK) >> AL_SEED_SEG_SHIFT) > 1 || (uint32_t)e.y > 0xfffu) bad = true;
-			ROW(i) = (uint64_t)((uint32_t)e.x & 0xffffu) | (uint64_t)((uint32_t)e.y & 0xfffu) << 16 | (uint64_t)((e.y & AL_SEED_SEG_MASK) >> AL_SEED_SEG_SHIFT & 1) << 28
-			         | (uint64_t)(far ? 1u : 0u) << 29 | (uint64_t)0xffu << 56;
+	CL_PROF(0);
+	// ---- rows: eight anchors per round, their loads in flight together ----
+	uint64_t eqm[NR];                                                          // bit i of word r: anchor 64 r + i has the x of the anchor in front of it
+	bool bad = max_dist_x > 0x7fff || P.max_chain_iter < CAPL;
+#pragma unroll
+	for (int r = 0; r < NR; ++r) eqm[r] = 0;
+	if (alive) {
+		uint64_t prev_x = 0;
+		for (int i0 = 0; i0 < n; i0 += 8) {
+			AlAnchor e[8];
+#pragma unroll
+			for (int u = 0; u < 8; ++u) e[u] = a[i0 + u < n ? i0 + u : n - 1];      // (clamped: no branch around a load -- the compiler waits for everything in flight at each join)
+#pragma unroll
+			for (int u = 0; u < 8; ++u) asm volatile("" : "+v"(e[u].x), "+v"(e[u].y));
+#pragma unroll
+			for (int u = 0; u < 8; ++u) {
+				const int i = i0 + u;
+				if (i < n) {
+					const uint64_t x = e[u].x, y = e[u].y;
+					const bool far = i == 0 || (x >> 32) != (prev_x >> 32) || (uint32_t)x - (uint32_t)prev_x > 0x7fffu;
+					if (i > 0 && x == prev_x) { if (NR == 1 || i < 64) eqm[0] |= 1ULL << (i & 63); else eqm[NR - 1] |= 1ULL << (i & 63); }
+					prev_x = x;
+					if ((int)(y >> 32 & 0xff) != q_span || ((y & AL_SEED_SEG_MASK) >> AL_SEED_SEG_SHIFT) > 1 || (uint32_t)y > 0xfffu) bad = true;
+					ROW(i) = (uint64_t)((uint32_t)x & 0xffffu) | (uint64_t)((uint32_t)y & 0xfffu) << 16 | (uint64_t)((y & AL_SEED_SEG_MASK) >> AL_SEED_SEG_SHIFT & 1) << 28
+					         | (uint64_t)(far ? 1u : 0u) << 29 | (uint64_t)0xffu << 56;
+				}
+			}
 		}
-		if (bad) { atomicAdd(&counters[7], 1ULL); CHAIN_EXIT0(); }   // not representable in the compact rows (never on the short-read path)
 	}
+	CL_PROF(1);
+	if (alive && bad) { atomicAdd(&counters[7], 1ULL); CHAIN_EXIT0(); }   // not representable in the compact rows (never on the short-read path)
+	if (alive) {
 	const double avg_d = (double)(float)((double)(float)((uint32_t)q_span * (uint32_t)n) / (double)(float)n);   // (float)sum/n (chain.c:42)
 	const bool tab_ok = USE_TAB && avg_d == (double)P.k && P.k * 0.01 * (AL_CLIN_N - 1) + 5.0 < 255.0;
 	const uint32_t dr_lim = n_segs > 1 ? (uint32_t)max_dist_y : 0x7fffffffu;   // (uint32_t)(dr - 1) >= dr_lim  <=>  dr == 0 or dr > max_dist_y (paired end only)
@@ -1846,25 +1886,20 @@ k_chain_lds(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a
 			while (dist > max_dist_x) { ++st; dist -= (int32_t)((R_XLO(ROW(st)) - R_XLO(ROW(st - 1))) & 0xffffu); }
 		}
 		prev_xlo = xi;
-		// The row of candidate j-1 is fetched while candidate j is scored, and the body is written with selects rather than
-		// branches: few wavefronts fit per SIMD (LDS capacity), so the kernel is bound by instruction issue and every
-		// divergent branch costs scalar exec-mask work.  t[j-1] can be overwritten by this iteration's mark after it was
-		// fetched; that case is patched in registers.
-		int jn = i > 0 ? i - 1 : 0;
-		uint64_t nrow = ROW(jn);
-		bool done = false;
-		for (int j = i - 1; j >= st && !done; --j) {
-			const uint64_t rj = nrow;
-			jn = j > 0 ? j - 1 : 0;
-			nrow = ROW(jn);
-			const int32_t dr = (int32_t)((xi - R_XLO(rj)) & 0xffffu);
-			const int32_t dq = qi - R_Q(rj);
-			const bool same = R_SEG(rj) == sidi;
+		// (round 6) TWO candidates per round: their scores are independent (row halves fetched a round ahead, two table lookups each), only the few
+		// instructions of the sequential rule -- first maximum wins, marks, max_skip (chain.c:74-81) -- run one after the other.  With 1.5 - 3.5
+		// wavefronts per SIMD (LDS capacity) a round's chain of dependent VALU and LDS latencies was what a wavefront waited for.
+		// The body is written with selects rather than branches.  t[] marks made by this round for rows already fetched are patched in registers.
+		// A row with at most max_skip candidates can never break (it takes max_skip + 1 marked ones), and marks are read only by the row that makes
+		// them: such rows -- all rows of the <= 24-anchor classes -- take the loop without marks.
+		auto score = [&](const uint32_t lo, const uint32_t hi, bool &skip) -> int32_t {
+			const int32_t dr = (int32_t)((xi - (lo & 0xffffu)) & 0xffffu);
+			const int32_t dq = qi - (int32_t)(lo >> 16 & 0xfffu);
+			const bool same = (int32_t)(lo >> 28 & 1u) == sidi;
 			const int32_t dd = dr > dq ? dr - dq : dq - dr;
 			// chain.c:56-63 with the range tests folded into unsigned compares: dq <= 0 or dq > max_dist_x; for anchors of the same
 			// mate also dr == 0 or (paired end) dr > max_dist_y, dq > max_dist_y, dd > bw
-			const bool skip = ((uint32_t)(dq - 1) >= (uint32_t)max_dist_x) |
-			                  (same & (((uint32_t)(dr - 1) >= dr_lim) | (dq > max_dist_y) | (dd > bw)));
+			skip = ((uint32_t)(dq - 1) >= (uint32_t)max_dist_x) | (same & (((uint32_t)(dr - 1) >= dr_lim) | (dq > max_dist_y) | (dd > bw)));
 			const int32_t min_d = dq < dr ? dq : dr;
 			int32_t sc = min_d > q_span ? q_span : min_d;
 			// gap cost (chain.c:64-72) from two per-wavefront tables: same mate c_lin + (ilog2(dd) >> 1), other mate min(c_lin, ilog2(dd))
@@ -1875,85 +1910,177 @@ k_chain_lds(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a
 				pen_same = c_lin + (log_dd >> 1); pen_diff = c_lin < log_dd ? c_lin : log_dd;
 			}
 			pen_diff = dr == 0 ? -1 : pen_diff;
-			sc = sc - (same ? pen_same : pen_diff) + R_F(rj);
-			const uint32_t pj = R_P(rj);
-			const bool better = !skip && sc > max_f;
-			const bool marked = !skip && !better && R_T(rj) == (uint32_t)i;
-			max_f = better ? sc : max_f; max_j = better ? j : max_j;
-			n_skip += marked ? 1 : (better && n_skip > 0 ? -1 : 0);
-			done = marked && n_skip > max_skip;                                       // the reference breaks before marking p[j]
-			if (!skip && !done && pj != 0xff) {
-				TB(pj) = (uint8_t)i;
-				nrow = (int)pj == jn ? ((nrow & 0x00ffffffffffffffULL) | (uint64_t)(uint32_t)i << 56) : nrow;
+			return sc - (same ? pen_same : pen_diff) + (int32_t)(int16_t)(hi & 0xffffu);
+		};
+#define ROWLO(j) (reinterpret_cast<const uint32_t *>(&srow[(j) * RS + lane])[0])
+#define ROWHI(j) (reinterpret_cast<const uint32_t *>(&srow[(j) * RS + lane])[1])
+		const bool marks = i - st > max_skip;
+		if (!__any(marks)) {
+			int j = i - 1;
+			uint32_t l0 = ROWLO(j > 0 ? j : 0), h0 = ROWHI(j > 0 ? j : 0), l1 = ROWLO(j > 1 ? j - 1 : 0), h1 = ROWHI(j > 1 ? j - 1 : 0);
+			for (; j >= st; j -= 2) {
+				const uint32_t la = l0, ha = h0, lb = l1, hb = h1;
+				const int ja = j > 2 ? j - 2 : 0, jb = j > 3 ? j - 3 : 0;
+				l0 = ROWLO(ja); h0 = ROWHI(ja); l1 = ROWLO(jb); h1 = ROWHI(jb);
+				bool skip_a, skip_b;
+				const int32_t sa = score(la, ha, skip_a), sb = score(lb, hb, skip_b);
+				const bool better_a = !skip_a && sa > max_f;
+				max_f = better_a ? sa : max_f; max_j = better_a ? j : max_j;
+				const bool better_b = j - 1 >= st && !skip_b && sb > max_f;
+				max_f = better_b ? sb : max_f; max_j = better_b ? j - 1 : max_j;
+			}
+		} else {
+			int j = i - 1;
+			uint32_t l0 = ROWLO(j > 0 ? j : 0), h0 = ROWHI(j > 0 ? j : 0), l1 = ROWLO(j > 1 ? j - 1 : 0), h1 = ROWHI(j > 1 ? j - 1 : 0);
+			bool done = false;
+			const uint32_t im = (uint32_t)i << 24;
+			for (; j >= st && !done; j -= 2) {
+				const uint32_t la = l0, ha = h0, lb = l1; uint32_t hb = h1;
+				const int ja = j > 2 ? j - 2 : 0, jb = j > 3 ? j - 3 : 0;
+				l0 = ROWLO(ja); h0 = ROWHI(ja); l1 = ROWLO(jb); h1 = ROWHI(jb);
+				bool skip_a, skip_b;
+				const int32_t sa = score(la, ha, skip_a), sb = score(lb, hb, skip_b);
+				// candidate j
+				const uint32_t pa = ha >> 16 & 0xffu;
+				const bool better_a = !skip_a && sa > max_f;
+				const bool marked_a = !skip_a && !better_a && (ha >> 24) == (uint32_t)i;
+				max_f = better_a ? sa : max_f; max_j = better_a ? j : max_j;
+				n_skip += marked_a ? 1 : (better_a && n_skip > 0 ? -1 : 0);
+				const bool done_a = marked_a && n_skip > max_skip;                       // the reference breaks before marking p[j]
+				const bool mark_a = !skip_a && !done_a && pa != 0xff;
+				if (mark_a) TB(pa) = (uint8_t)i;
+				hb = mark_a && (int)pa == j - 1 ? ((hb & 0x00ffffffu) | im) : hb;         // (rows fetched before the mark was made)
+				h0 = mark_a && (int)pa == ja ? ((h0 & 0x00ffffffu) | im) : h0;
+				h1 = mark_a && (int)pa == jb ? ((h1 & 0x00ffffffu) | im) : h1;
+				// candidate j - 1
+				const bool act_b = j - 1 >= st && !done_a;
+				const uint32_t pb = hb >> 16 & 0xffu;
+				const bool better_b = act_b && !skip_b && sb > max_f;
+				const bool marked_b = act_b && !skip_b && !better_b && (hb >> 24) == (uint32_t)i;
+				max_f = better_b ? sb : max_f; max_j = better_b ? j - 1 : max_j;
+				n_skip += marked_b ? 1 : (better_b && n_skip > 0 ? -1 : 0);
+				const bool done_b = marked_b && n_skip > max_skip;
+				const bool mark_b = act_b && !skip_b && !done_b && pb != 0xff;
+				if (mark_b) TB(pb) = (uint8_t)i;
+				h0 = mark_b && (int)pb == ja ? ((h0 & 0x00ffffffu) | im) : h0;
+				h1 = mark_b && (int)pb == jb ? ((h1 & 0x00ffffffu) | im) : h1;
+				done = done_a || done_b;
 			}
 		}
+#undef ROWLO
+#undef ROWHI
 		const int32_t vmax = max_j >= 0 ? (int32_t)VL(max_j) : 0;
 		ROW(i) = (ri & 0x00000000ffffffffULL) | (uint64_t)((uint32_t)max_f & 0xffffu) << 32 | (uint64_t)(max_j < 0 ? 0xffu : (uint32_t)max_j) << 48 | (ROW(i) & 0xff00000000000000ULL);
 		VL(i) = max_j >= 0 && vmax > max_f ? (int16_t)vmax : (int16_t)max_f;
 	}
+	CL_PROF(2);
 #define FL(j) R_F(ROW(j))
 #define PLv(j) R_P(ROW(j))
 	// chain.c:87-109.  NB: the t[] marks above use the row index i (< CAPL <= 128) with 0xff as "never"; from here t[] is a 0/1 flag.
+	// From here the rows' low halves are dead too: bytes 0-2 of row c = chain end c (peak f << 8 | peak anchor), later chain c (score << 8 | anchors).
+#define UT(c) (ROW32(c) & 0xffffffu)
+#define SET_UT(c, v) (ROW32(c) = (ROW32(c) & 0xff000000u) | ((uint32_t)(v) & 0xffffffu))
 	for (int i = 0; i < n; ++i) TB(i) = 0;
 	for (int i = 0; i < n; ++i) { const uint32_t pi_ = PLv(i); if (pi_ != 0xff) TB(pi_) = 1; }
-	uint64_t *utmp = utmp_stride > 0 ? ws_u64 + (size_t)t0 * (size_t)utmp_stride : ws_u64 + a_off[f];
 	int32_t n_u = 0, n_v = 0, k = 0;
 	for (int i = 0; i < n; ++i)
 		if (TB(i) == 0 && (int32_t)VL(i) >= min_sc) {
 			int j = i;
 			while (j >= 0 && FL(j) < (int32_t)VL(j)) j = PLv(j) == 0xff ? -1 : (int)PLv(j);
 			if (j < 0) j = i;
-			utmp[n_u++] = (uint64_t)(uint32_t)FL(j) << 32 | (uint64_t)j;
+			const uint32_t key = (uint32_t)FL(j) << 8 | (uint32_t)j;            // (n_u <= i / 2: rows in front of i, whose low halves nothing reads any more)
+			SET_UT(n_u, key); ++n_u;
 		}
 	if (n_u == 0) CHAIN_EXIT0();
-	for (int32_t i = 1; i < n_u; ++i) { const uint64_t t = utmp[i]; int32_t j = i; while (j > 0 && utmp[j - 1] < t) { utmp[j] = utmp[j - 1]; --j; } utmp[j] = t; }
+	if (alive) {
+	for (int32_t i = 1; i < n_u; ++i) { const uint32_t t = UT(i); int32_t j = i; while (j > 0 && UT(j - 1) < t) { SET_UT(j, UT(j - 1)); --j; } SET_UT(j, t); }
 	for (int i = 0; i < n; ++i) TB(i) = 0;
-	uint64_t *const okf = seg.okey ? seg.okey + a_off[f] : nullptr, *const okp = okf ? okf + (n + 1) / 2 : nullptr;
+	uint64_t *const okf = seg.okey ? seg.okey + aoff : nullptr, *const okp = okf ? okf + (n + 1) / 2 : nullptr;
 	for (int32_t i = 0; i < n_u; ++i) {                                              // chain.c:111-128; v[] reused as the visit list
-		const uint64_t key0 = utmp[i];
-		const int32_t n_v0 = n_v, k0 = k; int j = (int32_t)utmp[i];
+		const uint32_t key0 = UT(i);
+		const int32_t n_v0 = n_v, k0 = k, sc0 = (int32_t)(key0 >> 8); int j = (int32_t)(key0 & 0xffu);
 		do { VL(n_v) = (int16_t)j; ++n_v; TB(j) = 1; j = PLv(j) == 0xff ? -1 : (int)PLv(j); } while (j >= 0 && TB(j) == 0);
-		if (j < 0) { if (n_v - n_v0 >= min_cnt) utmp[k++] = utmp[i] >> 32 << 32 | (uint32_t)(n_v - n_v0); }
-		else if ((int32_t)(utmp[i] >> 32) - FL(j) >= min_sc) { if (n_v - n_v0 >= min_cnt) utmp[k++] = (uint64_t)((utmp[i] >> 32) - (uint64_t)(uint32_t)FL(j)) << 32 | (uint32_t)(n_v - n_v0); }
-		if (k0 == k) n_v = n_v0; else if (okp) okp[k0] = key0;
+		if (j < 0) { if (n_v - n_v0 >= min_cnt) { SET_UT(k, (uint32_t)sc0 << 8 | (uint32_t)(n_v - n_v0)); ++k; } }
+		else if (sc0 - FL(j) >= min_sc) { if (n_v - n_v0 >= min_cnt) { SET_UT(k, (uint32_t)(sc0 - FL(j)) << 8 | (uint32_t)(n_v - n_v0)); ++k; } }
+		if (k0 == k) n_v = n_v0; else if (okp) okp[k0] = (uint64_t)(uint32_t)sc0 << 32 | (uint64_t)(key0 & 0xffu);
 	}
 	n_u = k;
 	// chains ordered by the x of their first anchor (chain.c:144-160); n_u <= 64: stable insertion sort (ksort.h:149).
 	// The visit list v[] keeps each chain's anchors last-to-first; t[] (free now) = permutation, p-bytes = start offsets.
-	// First-anchor x is read back from HBM (a few values per fragment).
-#define OFFB(c) (reinterpret_cast<uint8_t *>(&srow[(c) * LANES + lane])[6])
+	// The anchors are sorted by x, so the first anchors compare as their indices do unless every anchor between them repeats its neighbour's x.
+#define OFFB(c) (reinterpret_cast<uint8_t *>(&srow[(c) * RS + lane])[6])
+#define UCNT(c) ((int32_t)(UT(c) & 0xffu))
+#define U64OF(c) ((uint64_t)(UT(c) >> 8) << 32 | (uint64_t)(UT(c) & 0xffu))
 	int32_t off = 0;
-	for (int32_t c = 0; c < n_u; ++c) { OFFB(c) = (uint8_t)off; off += (int32_t)(uint32_t)utmp[c]; TB(c) = (uint8_t)c; }
-#define CXL(c) (a[(int)VL((int)OFFB(c) + (int32_t)(uint32_t)utmp[c] - 1)].x)
+	for (int32_t c = 0; c < n_u; ++c) { OFFB(c) = (uint8_t)off; off += UCNT(c); TB(c) = (uint8_t)c; }
+#define CIDX(c) ((int)VL((int)OFFB(c) + UCNT(c) - 1))
+	auto same_x = [&](int lo, int hi) -> bool {                                  // anchors lo < hi: equal x <=> every anchor in (lo, hi] has the x of the one in front of it
+		bool all = true;
+#pragma unroll
+		for (int r = 0; r < NR; ++r) {
+			const int l = lo + 1 - 64 * r, h = hi - 64 * r;                          // bits [l, h] of word r, clipped
+			if (h < 0 || l > 63) continue;
+			const int l0 = l < 0 ? 0 : l, h0 = h > 63 ? 63 : h;
+			const uint64_t m = (h0 == 63 ? ~0ULL : (1ULL << (h0 + 1)) - 1ULL) & ~((1ULL << l0) - 1ULL);
+			all = all && (eqm[r] & m) == m;
+		}
+		return all;
+	};
 	bool eqx = false;
 	for (int32_t i = 1; i < n_u; ++i) {
-		const uint8_t ci = TB(i); const uint64_t xi = CXL(ci); int32_t j = i;
-		while (j > 0) { const uint8_t cj = TB(j - 1); const uint64_t xj = CXL(cj); if (xi < xj) { TB(j) = cj; --j; } else { eqx = eqx || xi == xj; break; } }
+		const uint8_t ci = TB(i); const int xi = CIDX(ci); int32_t j = i;
+		while (j > 0) {
+			const uint8_t cj = TB(j - 1); const int xj = CIDX(cj);
+			const bool eq = xi == xj || same_x(xi < xj ? xi : xj, xi < xj ? xj : xi);
+			if (!eq && xi < xj) { TB(j) = cj; --j; } else { eqx = eqx || eq; break; }
+		}
 		TB(j) = ci;
 	}
-#undef CXL
-	AlAnchor *b = chained + a_off[f]; uint64_t *u = direct ? u_out + seg.uslot[f] : u_out + a_off[f] + (seg.meta ? 0u : f);
-	uint32_t *const uo = direct ? uo_out + seg.uslot[f] : (!seg.meta && uo_out) ? uo_out + a_off[f] + f : nullptr;
+#undef CIDX
+	AlAnchor *const b = chained + aoff;
+	uint64_t *u = direct ? u_out + seg.uslot[f] : u_out + aoff + (seg.meta ? 0u : f);
+	uint32_t *const uo = direct ? uo_out + seg.uslot[f] : (!seg.meta && uo_out) ? uo_out + aoff + f : nullptr;
 	const uint32_t uo_base = direct ? seg.rel[f] : 0u;
 	int32_t o = 0; uint64_t u1 = 0;
 	const bool one = rec && n_u == 1;                                          // a segment with one chain (most of them): its list entry travels in the record
 	for (int32_t i = 0; i < n_u; ++i) {
-		const int32_t c = TB(i), ni = (int32_t)(uint32_t)utmp[c], k0 = OFFB(c);
-		if (one) u1 = utmp[c]; else u[i] = utmp[c];
+		const int32_t c = TB(i), ni = UCNT(c), k0 = OFFB(c);
+		if (one) u1 = U64OF(c); else u[i] = U64OF(c);
 		if (uo) uo[i] = uo_base + (uint32_t)o;
 		if (okf) okf[i] = okp[c];
-		for (int32_t j = 0; j < ni; ++j) b[o++] = a[(int)VL(k0 + (ni - j - 1))];
+		for (int32_t j = 0; j < ni; ++j) { SRCB(o) = (uint8_t)VL(k0 + (ni - j - 1)); ++o; }   // source of chained anchor o (the visit list holds a chain last to first) in byte 3 of row o: bytes 0-2 may still be a chain's entry
+	}
+	for (int32_t j0 = 0; j0 < o; j0 += 8) {                                      // the chained anchors: eight loads in flight, then their stores
+		AlAnchor v[8];
+#pragma unroll
+		for (int u = 0; u < 8; ++u) v[u] = a[(int)SRCB(j0 + u < o ? j0 + u : o - 1)];
+#pragma unroll
+		for (int u = 0; u < 8; ++u) asm volatile("" : "+v"(v[u].x), "+v"(v[u].y));
+#pragma unroll
+		for (int u = 0; u < 8; ++u) if (j0 + u < o) b[j0 + u] = v[u];
 	}
 	if (rec) *reinterpret_cast<uint4 *>(rec) = make_uint4((uint32_t)u1, (uint32_t)(u1 >> 32), (uint32_t)n_u, (uint32_t)o | (eqx ? 1u << 31 : 0u));
 	else if (direct) { if (eqx) seg.ctie[seg.fragid[f]] = 1u; }
 	else frag_nu[f] = (uint32_t)n_u;
+	}
+	}
+	CL_PROF(3);
+	CL_PROF(4);
+	if (prof && lane == 0) atomicAdd(&counters[29], 1ULL);
+#undef CL_PROF
 #undef CHAIN_EXIT0
 #undef OFFB
+#undef UCNT
+#undef U64OF
+#undef UT
+#undef SET_UT
 #undef FL
 #undef PLv
 #undef ROW
+#undef ROW32
 #undef VL
 #undef TB
+#undef SRCB
 #undef R_XLO
 #undef R_Q
 #undef R_SEG
