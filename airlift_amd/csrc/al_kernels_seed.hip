@@ -1783,8 +1783,14 @@ k_chain_lds(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a
 	const int t0 = (int)(gridDim.x - 1 - blockIdx.x) * LANES + lane;
 	const bool have = lane < LANES && t0 < n_list;
 	const uint32_t f = have ? (order ? order[t0] : (uint32_t)t0) : 0;
-	const bool side = have && seg.tie_mode == 1 && seg.tie_flag[f] != 0;       // chained on the side stream (equal-x anchors)
-	const int n = have ? (int)frag_na[f] : 0;
+	// the entry's record: every word fetched NOW, unconditionally (a lane without an entry reads entry 0, an absent array is stood in for by one that exists),
+	// so that the loads are in flight together -- behind a branch each would be a dependent HBM round trip of its own
+	const uint32_t *const p_tie = seg.tie_mode == 1 ? seg.tie_flag : frag_na, *const p_meta = seg.meta ? seg.meta : frag_na;
+	const uint64_t *const p_uslot = seg.uslot ? seg.uslot : a_off; const uint32_t *const p_rel = seg.uslot ? seg.rel : frag_na, *const p_fid = seg.uslot ? seg.fragid : frag_na;
+	uint32_t v_na = frag_na[f], v_tie = p_tie[f], v_meta = p_meta[f], rel_f = p_rel[f], fragid_f = p_fid[f]; uint64_t aoff = a_off[f], uslot_f = p_uslot[f];
+	asm volatile("" : "+v"(v_na), "+v"(v_tie), "+v"(v_meta), "+v"(rel_f), "+v"(fragid_f), "+v"(aoff), "+v"(uslot_f));
+	const bool side = have && seg.tie_mode == 1 && v_tie != 0;                 // chained on the side stream (equal-x anchors)
+	const int n = have ? (int)v_na : 0;
 	int nmax = n;
 	for (int d = 32; d > 0; d >>= 1) { const int o = __shfl_xor(nmax, d); nmax = o > nmax ? o : nmax; }
 	if (nmax > CAPL || nmax <= lo_excl) return;                              // another instantiation / kernel owns this wavefront
@@ -1821,14 +1827,13 @@ k_chain_lds(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a
 #define R_T(r) ((uint32_t)((r) >> 56))
 	int n_segs = 1, qlen_sum = 0;
 	if (have) {
-		if (seg.meta) { const uint32_t mt = seg.meta[f]; qlen_sum = (int)(mt & 0x7fffffffu); n_segs = (mt >> 31) ? 2 : 1; }
+		if (seg.meta) { const uint32_t mt = v_meta; qlen_sum = (int)(mt & 0x7fffffffu); n_segs = (mt >> 31) ? 2 : 1; }
 		else {
 			const uint32_t r0 = frag_first[f], r1 = frag_first[f + 1];
 			n_segs = (int)(r1 - r0);
 			for (uint32_t r = r0; r < r1; ++r) qlen_sum += (int)rd_len[r];
 		}
 	}
-	const uint64_t aoff = have ? a_off[f] : 0ULL;
 	const AlAnchor *a = anchors + aoff;
 	const int max_dist_y = qlen_sum > P.max_gap ? qlen_sum : P.max_gap;           // map.c:341-351
 	int max_dist_x;
@@ -1874,6 +1879,11 @@ k_chain_lds(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a
 	const uint32_t dr_lim = n_segs > 1 ? (uint32_t)max_dist_y : 0x7fffffffu;   // (uint32_t)(dr - 1) >= dr_lim  <=>  dr == 0 or dr > max_dist_y (paired end only)
 	int st = 0; int32_t dist = 0;                                                 // dist = x_i - x_st while st..i lie in one window
 	uint32_t prev_xlo = 0;
+	uint64_t succ[NR], vis[NR];                                                   // per anchor, in registers: is some anchor's best predecessor / visited by the backtrack (the reference's t[] after chain.c:87)
+#pragma unroll
+	for (int r = 0; r < NR; ++r) { succ[r] = 0; vis[r] = 0; }
+#define BIT_SET(m, j) do { if (NR == 1 || (j) < 64) m[0] |= 1ULL << ((j) & 63); else m[NR - 1] |= 1ULL << ((j) & 63); } while (0)
+#define BIT_GET(m, j) (((NR == 1 || (j) < 64 ? m[0] : m[NR - 1]) >> ((j) & 63)) & 1ULL)
 	for (int i = 0; i < n; ++i) {                                                 // chain.c:46-85
 		const uint64_t ri = ROW(i);
 		const uint32_t xi = R_XLO(ri); const int32_t qi = R_Q(ri), sidi = R_SEG(ri);
@@ -1972,6 +1982,7 @@ k_chain_lds(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a
 		const int32_t vmax = max_j >= 0 ? (int32_t)VL(max_j) : 0;
 		ROW(i) = (ri & 0x00000000ffffffffULL) | (uint64_t)((uint32_t)max_f & 0xffffu) << 32 | (uint64_t)(max_j < 0 ? 0xffu : (uint32_t)max_j) << 48 | (ROW(i) & 0xff00000000000000ULL);
 		VL(i) = max_j >= 0 && vmax > max_f ? (int16_t)vmax : (int16_t)max_f;
+		if (max_j >= 0) BIT_SET(succ, max_j);
 	}
 	CL_PROF(2);
 #define FL(j) R_F(ROW(j))
@@ -1980,11 +1991,9 @@ k_chain_lds(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a
 	// From here the rows' low halves are dead too: bytes 0-2 of row c = chain end c (peak f << 8 | peak anchor), later chain c (score << 8 | anchors).
 #define UT(c) (ROW32(c) & 0xffffffu)
 #define SET_UT(c, v) (ROW32(c) = (ROW32(c) & 0xff000000u) | ((uint32_t)(v) & 0xffffffu))
-	for (int i = 0; i < n; ++i) TB(i) = 0;
-	for (int i = 0; i < n; ++i) { const uint32_t pi_ = PLv(i); if (pi_ != 0xff) TB(pi_) = 1; }
 	int32_t n_u = 0, n_v = 0, k = 0;
 	for (int i = 0; i < n; ++i)
-		if (TB(i) == 0 && (int32_t)VL(i) >= min_sc) {
+		if (!BIT_GET(succ, i) && (int32_t)VL(i) >= min_sc) {
 			int j = i;
 			while (j >= 0 && FL(j) < (int32_t)VL(j)) j = PLv(j) == 0xff ? -1 : (int)PLv(j);
 			if (j < 0) j = i;
@@ -1994,12 +2003,11 @@ k_chain_lds(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a
 	if (n_u == 0) CHAIN_EXIT0();
 	if (alive) {
 	for (int32_t i = 1; i < n_u; ++i) { const uint32_t t = UT(i); int32_t j = i; while (j > 0 && UT(j - 1) < t) { SET_UT(j, UT(j - 1)); --j; } SET_UT(j, t); }
-	for (int i = 0; i < n; ++i) TB(i) = 0;
 	uint64_t *const okf = seg.okey ? seg.okey + aoff : nullptr, *const okp = okf ? okf + (n + 1) / 2 : nullptr;
 	for (int32_t i = 0; i < n_u; ++i) {                                              // chain.c:111-128; v[] reused as the visit list
 		const uint32_t key0 = UT(i);
 		const int32_t n_v0 = n_v, k0 = k, sc0 = (int32_t)(key0 >> 8); int j = (int32_t)(key0 & 0xffu);
-		do { VL(n_v) = (int16_t)j; ++n_v; TB(j) = 1; j = PLv(j) == 0xff ? -1 : (int)PLv(j); } while (j >= 0 && TB(j) == 0);
+		do { VL(n_v) = (int16_t)j; ++n_v; BIT_SET(vis, j); const uint32_t pj_ = PLv(j); j = pj_ == 0xff ? -1 : (int)pj_; } while (j >= 0 && !BIT_GET(vis, j));
 		if (j < 0) { if (n_v - n_v0 >= min_cnt) { SET_UT(k, (uint32_t)sc0 << 8 | (uint32_t)(n_v - n_v0)); ++k; } }
 		else if (sc0 - FL(j) >= min_sc) { if (n_v - n_v0 >= min_cnt) { SET_UT(k, (uint32_t)(sc0 - FL(j)) << 8 | (uint32_t)(n_v - n_v0)); ++k; } }
 		if (k0 == k) n_v = n_v0; else if (okp) okp[k0] = (uint64_t)(uint32_t)sc0 << 32 | (uint64_t)(key0 & 0xffu);
@@ -2038,9 +2046,9 @@ k_chain_lds(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a
 	}
 #undef CIDX
 	AlAnchor *const b = chained + aoff;
-	uint64_t *u = direct ? u_out + seg.uslot[f] : u_out + aoff + (seg.meta ? 0u : f);
-	uint32_t *const uo = direct ? uo_out + seg.uslot[f] : (!seg.meta && uo_out) ? uo_out + aoff + f : nullptr;
-	const uint32_t uo_base = direct ? seg.rel[f] : 0u;
+	uint64_t *u = direct ? u_out + uslot_f : u_out + aoff + (seg.meta ? 0u : f);
+	uint32_t *const uo = direct ? uo_out + uslot_f : (!seg.meta && uo_out) ? uo_out + aoff + f : nullptr;
+	const uint32_t uo_base = direct ? rel_f : 0u;
 	int32_t o = 0; uint64_t u1 = 0;
 	const bool one = rec && n_u == 1;                                          // a segment with one chain (most of them): its list entry travels in the record
 	for (int32_t i = 0; i < n_u; ++i) {
@@ -2060,13 +2068,15 @@ k_chain_lds(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ a
 		for (int u = 0; u < 8; ++u) if (j0 + u < o) b[j0 + u] = v[u];
 	}
 	if (rec) *reinterpret_cast<uint4 *>(rec) = make_uint4((uint32_t)u1, (uint32_t)(u1 >> 32), (uint32_t)n_u, (uint32_t)o | (eqx ? 1u << 31 : 0u));
-	else if (direct) { if (eqx) seg.ctie[seg.fragid[f]] = 1u; }
+	else if (direct) { if (eqx) seg.ctie[fragid_f] = 1u; }
 	else frag_nu[f] = (uint32_t)n_u;
 	}
 	}
 	CL_PROF(3);
 	CL_PROF(4);
 	if (prof && lane == 0) atomicAdd(&counters[29], 1ULL);
+#undef BIT_SET
+#undef BIT_GET
 #undef CL_PROF
 #undef CHAIN_EXIT0
 #undef OFFB
