@@ -286,6 +286,7 @@ __device__ __forceinline__ void d_ksw_lds(GroupLds<TMAX, QMAX> &L, const int gl,
 
 #include "al_dev_ksw.h"
 #include "al_dev_ksw2.h"
+#include "al_dev_net.h"
 
 // dispatcher: targets of up to 22 x 16 cells run register-resident, larger ones use the LDS rows
 template <int TMAX, int QMAX>
@@ -889,8 +890,43 @@ k_regs_select(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__
 	// order is final, read back 64 at a time by the pass (coalesced, one round trip per group instead of four dependent ones)
 	int4 *const G1 = (int4 *)ws.aux128; int32_t *const G2 = ws.auxi + n_u, *const G3 = G2 + n_u, *const G4 = G3 + n_u;
 	bool tie = false;
-	if (CAP != 0 && CAP != -2) {   // descending bitonic sort of (key, chain), in LDS or in the fragment's work area
+	if (CAP != 0 && CAP != -2) {   // descending sort of (key, chain)
+		// (round 6) LDS tiles of up to 16 keys per thread: the register network of the anchor sorts (al_dev_net.h) on ONE word per chain,
+		// (~key & 2^48 - 1) << 16 | chain -- a key is (score << 32 | count) ^ a 32-bit hash, below 2^48 while scores stay below 2^16, which is checked --
+		// ascending, i.e. descending by key.  The bitonic steps through LDS with a barrier each were most of these kernels (the 8192-chain tile:
+		// 3.9 of 4.6 ms, a block per CU and nothing else on the main stream meanwhile).  Equal keys end up next to each other either way and are
+		// put in the reference's order below; a key of 2^48 or more sends the block to the LDS steps.
+		constexpr int PERN = CAP > 0 ? CAP / NT : 0;
+		bool net_done = false;
+		if constexpr (CAP > 0 && PERN >= 1 && PERN <= 16 && PERN * NT == CAP) {
+			__shared__ int s_big;
+			if (tid == 0) s_big = 0;
+			__syncthreads();
+			const uint64_t M48 = (1ULL << 48) - 1ULL;
+			uint64_t kn[PERN]; bool big = false;
+#pragma unroll
+			for (int j = 0; j < PERN; ++j) {
+				const int e = tid + j * NT;
+				uint64_t v = UINT64_MAX;
+				if (e < n_u) { const uint64_t key = skey[e]; big = big || (key >> 48) != 0; v = ((~key) & M48) << 16 | (uint64_t)(uint32_t)e; }
+				kn[j] = v;
+			}
+			if (big) s_big = 1;
+			__syncthreads();
+			if (!s_big && !((P.dbg >> 15) & 1)) {
+				d_bt_levels<PERN, NT, 2>(kn, skey, tid);                          // (its exchange tile is the key tile: every thread holds its keys in registers by now)
+				__syncthreads();
+#pragma unroll
+				for (int r = 0; r < PERN; ++r) {
+					const int e = tid * PERN + r; const uint64_t v = kn[r];
+					skey[e] = v == UINT64_MAX ? 0ULL : ((~(v >> 16)) & M48); sidx[e] = v == UINT64_MAX ? (IdxT)~0u : (IdxT)(v & 0xffffu);
+				}
+				__syncthreads();
+				net_done = true;
+			}
+		}
 		int npow2 = 1; while (npow2 < n_u) npow2 <<= 1;
+		if (!net_done) {
 		for (int c = n_u + tid; c < npow2; c += NT) { skey[c] = 0; sidx[c] = (IdxT)~0u; }   // keys are > 0 (a chain's score, in the high word): padding sorts last
 		__syncthreads();
 		// A thread takes comparators, not elements: pair p of a step works on i = p with a zero inserted at bit log2(j) and on i | j, so every
@@ -921,6 +957,7 @@ k_regs_select(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__
 				}
 				__syncthreads();
 			}
+		}
 		__shared__ int s_tie; __shared__ uint16_t s_rs[AL_RS_SCRATCH / 2];
 		if (tid == 0) s_tie = 0;
 		__syncthreads();
