@@ -850,8 +850,9 @@ k_regs_select(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__
               const uint32_t *__restrict__ rd_len, const uint32_t *__restrict__ frag_hash, WsBase W, const uint32_t *__restrict__ list, int n_list,
               AlParams P, uint32_t *__restrict__ regs_n0)
 {
+	constexpr bool IDX_GLOBAL = CAP <= 0;   // (measured with the 8192-chain sort tile's chain numbers there too, for two blocks per CU: 3.0 -> 4.3 ms)
 	__shared__ uint64_t skey_l[CAP > 0 ? CAP : 1];
-	__shared__ uint16_t sidx_l[CAP > 0 ? CAP : 1];
+	__shared__ uint16_t sidx_l[CAP > 0 && !IDX_GLOBAL ? CAP : 1];
 	__shared__ RegsSelShared S; __shared__ RegsSelKept K;
 	constexpr int NT = CAP == 0 || CAP == 256 || CAP == -2 ? 64 : CAP < 0 || (PHASE == 1 && CAP >= 8192) ? 1024 : 256;   // (the sort-only form of the largest tile: one block per CU, all of its wavefronts)   // (65 ... 256 chains: one wavefront sorts and makes the pass -- four times the blocks per CU of the 256-thread form, whose other three wavefronts only sort)
 	                // all threads sort (the sort in global memory, any count: 1024 of them); the first wavefront makes the pass
@@ -864,8 +865,8 @@ k_regs_select(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__
 	if (CAP == -2 && regs_n0[f] != AL_REGS_UNSET) return;                   // the sort kernel gave up on it
 	FragWs ws; d_frag_ws(W, f, ws);
 	uint64_t *const skey = CAP > 0 ? skey_l : ws.aux64;                      // capacity 4 n_u + 4 >= the next power of two
-	typedef typename std::conditional<(CAP > 0), uint16_t, uint32_t>::type IdxT;
-	IdxT *const sidx = CAP > 0 ? (IdxT *)sidx_l : (IdxT *)(ws.auxi + (4 * n_u + 4));
+	typedef typename std::conditional<!IDX_GLOBAL, uint16_t, uint32_t>::type IdxT;
+	IdxT *const sidx = !IDX_GLOBAL ? (IdxT *)sidx_l : (IdxT *)(ws.auxi + (4 * n_u + 4));
 	const int ql0 = (int)rd_len[r0], ql1 = n_segs > 1 ? (int)rd_len[r0 + 1] : 0, qlen = ql0 + ql1;
 	const AlAnchor *a = chained + W.a_off[f]; const uint64_t *u = u_all + W.a_off[f] + f;
 	const uint32_t *const as_arr = uo_all + W.a_off[f] + f;                  // first anchor of chain c: carried by the chain list (the chaining kernels write every chain at its segment's place)
@@ -882,8 +883,20 @@ k_regs_select(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__
 				const uint64_t uc = u[lane]; const AlAnchor fa = a[as_arr[lane]];
 				key_r = uc ^ (uint32_t)d_hash64((d_hash64(fa.x) + d_hash64(fa.y)) ^ fhash); idx_r = lane;
 			}
-		} else {                                                             // keys: every thread of the block (two dependent loads each)
-			for (int c = tid; c < n_u; c += NT) { const AlAnchor fa = a[as_arr[c]]; skey[c] = u[c] ^ (uint32_t)d_hash64((d_hash64(fa.x) + d_hash64(fa.y)) ^ fhash); sidx[c] = (IdxT)c; }
+		} else {                                                             // keys: every thread of the block; four chains per round, the two dependent loads of each round in flight together (clamped indices: no branch around a load)
+			for (int c0 = tid; c0 < n_u; c0 += 4 * NT) {
+				int cc[4]; uint32_t as4[4]; uint64_t u4[4]; AlAnchor f4[4];
+#pragma unroll
+				for (int q = 0; q < 4; ++q) { cc[q] = c0 + q * NT < n_u ? c0 + q * NT : n_u - 1; as4[q] = as_arr[cc[q]]; u4[q] = u[cc[q]]; }
+#pragma unroll
+				for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(as4[q]), "+v"(u4[q]));
+#pragma unroll
+				for (int q = 0; q < 4; ++q) f4[q] = a[as4[q]];
+#pragma unroll
+				for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(f4[q].x), "+v"(f4[q].y));
+#pragma unroll
+				for (int q = 0; q < 4; ++q) if (c0 + q * NT < n_u) { skey[cc[q]] = u4[q] ^ (uint32_t)d_hash64((d_hash64(f4[q].x) + d_hash64(f4[q].y)) ^ fhash); sidx[cc[q]] = (IdxT)cc[q]; }
+			}
 		}
 	}
 	// per sorted position: query / reference interval, contig + strand, count, first anchor -- written by the whole block once the
@@ -919,7 +932,8 @@ k_regs_select(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__
 #pragma unroll
 				for (int r = 0; r < PERN; ++r) {
 					const int e = tid * PERN + r; const uint64_t v = kn[r];
-					skey[e] = v == UINT64_MAX ? 0ULL : ((~(v >> 16)) & M48); sidx[e] = v == UINT64_MAX ? (IdxT)~0u : (IdxT)(v & 0xffffu);
+					skey[e] = v == UINT64_MAX ? 0ULL : ((~(v >> 16)) & M48);
+					if (e < n_u) sidx[e] = (IdxT)(v & 0xffffu);                   // (the pads sort last: positions n_u and up, which nothing reads -- and which the work area of a small fragment does not have)
 				}
 				__syncthreads();
 				net_done = true;
@@ -987,16 +1001,30 @@ k_regs_select(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__
 			}
 			__syncthreads();
 		}
-		for (int p = tid; p < n_u; p += NT) {
-			const int c = (int)sidx[p]; const int cnt = (int)(uint32_t)u[c], as = (int)as_arr[c];
-			const AlAnchor fa = a[as], la = a[as + cnt - 1];
-			const int q_span = (int)(fa.y >> 32 & 0xff), rev = (int)(fa.x >> 63), rid = (int)(fa.x << 1 >> 33);
-			int4 g;
-			g.z = (int32_t)fa.x + 1 > q_span ? (int32_t)fa.x + 1 - q_span : 0; g.w = (int32_t)la.x + 1;
-			if (!rev) { g.x = (int32_t)fa.y + 1 - q_span; g.y = (int32_t)la.y + 1; }
-			else { g.x = qlen - ((int32_t)la.y + 1); g.y = qlen - ((int32_t)fa.y + 1 - q_span); }
-			G1[p] = g; G2[p] = rid << 1 | rev; G3[p] = cnt; G4[p] = as;
-			if (PHASE == 1) { ws.aux64[p] = skey[p]; ((uint32_t *)(ws.auxi + (4 * n_u + 4)))[p] = (uint32_t)c; }
+		for (int p0 = tid; p0 < n_u; p0 += 4 * NT) {                          // four positions per round: chain -> (count, first anchor) -> its two end anchors, each level's loads in flight together
+			int pp[4], c4[4], cnt4[4], as4[4]; AlAnchor f4[4], l4[4];
+#pragma unroll
+			for (int q = 0; q < 4; ++q) { pp[q] = p0 + q * NT < n_u ? p0 + q * NT : n_u - 1; c4[q] = (int)sidx[pp[q]]; }
+#pragma unroll
+			for (int q = 0; q < 4; ++q) { cnt4[q] = (int)(uint32_t)u[c4[q]]; as4[q] = (int)as_arr[c4[q]]; }
+#pragma unroll
+			for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(cnt4[q]), "+v"(as4[q]));
+#pragma unroll
+			for (int q = 0; q < 4; ++q) { f4[q] = a[as4[q]]; l4[q] = a[as4[q] + cnt4[q] - 1]; }
+#pragma unroll
+			for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(f4[q].x), "+v"(f4[q].y), "+v"(l4[q].x), "+v"(l4[q].y));
+#pragma unroll
+			for (int q = 0; q < 4; ++q) if (p0 + q * NT < n_u) {
+				const int p = pp[q], c = c4[q], cnt = cnt4[q], as = as4[q];
+				const AlAnchor fa = f4[q], la = l4[q];
+				const int q_span = (int)(fa.y >> 32 & 0xff), rev = (int)(fa.x >> 63), rid = (int)(fa.x << 1 >> 33);
+				int4 g;
+				g.z = (int32_t)fa.x + 1 > q_span ? (int32_t)fa.x + 1 - q_span : 0; g.w = (int32_t)la.x + 1;
+				if (!rev) { g.x = (int32_t)fa.y + 1 - q_span; g.y = (int32_t)la.y + 1; }
+				else { g.x = qlen - ((int32_t)la.y + 1); g.y = qlen - ((int32_t)fa.y + 1 - q_span); }
+				G1[p] = g; G2[p] = rid << 1 | rev; G3[p] = cnt; G4[p] = as;
+				if (PHASE == 1) { ws.aux64[p] = skey[p]; ((uint32_t *)(ws.auxi + (4 * n_u + 4)))[p] = (uint32_t)c; }
+			}
 		}
 		if (PHASE == 1) return;
 		__syncthreads();
