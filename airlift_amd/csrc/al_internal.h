@@ -86,7 +86,7 @@ struct AlParams {             // kernel parameter block (copy of the options the
 	int best_n, a, b, q, e, q2, e2, sc_ambi, zdrop, zdrop_inv, end_bonus, min_dp_max;
 	int pe_ori, pe_bonus, mid_occ, max_occ;
 	int dbg;                  // timing experiments only (AL_DBG env): skips phases, results become wrong
-	int dbg2;                 // more of the same (AL_DBG2 env): 1 lane chaining without the pair loop, 2 without the chained-anchor copy, 4 without the row loads
+	int dbg2;                 // more of the same (AL_DBG2 env): bit 3 cycle counters of the lane chaining kernels' phases (printed per batch), bit 20 the seed / sort / chain stages only
 };
 
 struct AlMatch {              // one query minimizer that passed the occurrence filter (mm_match_t, map.c:82-88)

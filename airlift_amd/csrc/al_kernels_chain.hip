@@ -173,32 +173,34 @@ ct_tile_body(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ 
 	uint32_t u_run = 0;                  // single: chain list slots written by the earlier tiles
 	bool any_def = false;                // single: a segment of an earlier tile was deferred
 	for (;;) {
-		// ---- load: rows with their cut flags, by all wavefronts; a thread's four rows in two rounds of two (a row and its left neighbour's x each): the loads
-		//      of a round are in flight together, and two rounds keep the kernel at 80 registers, i.e. at the six tiles per CU the LDS allows ----
+		// ---- load: rows with their cut flags, by all wavefronts; a thread's four rows (a row and its left neighbour's x each) in one round of eight loads in flight
+		//      together (round 6; two rounds of two until then, to stay at 80 registers: it is 72 either way at seven wavefronts per SIMD) ----
 		{
 			const uint32_t rows = single ? (s_tf[0].na - pos < CT_TILE ? s_tf[0].na - pos : CT_TILE) : s_tf[nfr - 1].start + s_tf[nfr - 1].na;
 			static_assert(CT_TILE / CT_NT == 4, "four rows per thread");
-			for (int h = 0; h < 2; ++h) {
-				AlAnchor e[2]; uint64_t xp[2]; int fis[2]; uint32_t is[2];
+			{
+				AlAnchor e[4]; uint64_t xp[4]; int fis[4]; uint32_t is[4];
 #pragma unroll
-				for (int j = 0; j < 2; ++j) {
-					const uint32_t r = (uint32_t)(2 * h + j) * CT_NT + tid;
+				for (int j = 0; j < 4; ++j) {
+					const uint32_t r = (uint32_t)j * CT_NT + tid;
 					int fi = 0;
 					if (!single) while (fi + 1 < nfr && s_tf[fi + 1].start <= r) ++fi;
-					fis[j] = fi; e[j].x = 0; e[j].y = 0; xp[j] = 0; is[j] = 0;
-					if (r < rows) {
-						const uint32_t i = r - s_tf[fi].start; is[j] = i;
-						const AlAnchor *src = anchors + s_tf[fi].aoff + pos;
-						if (P.dbg2 & 32) { e[j].x = reinterpret_cast<const uint64_t *>(src)[i]; e[j].y = (uint64_t)q_span << 32 | (i & 0xfff); xp[j] = i > 0 ? e[j].x - 700 : 0; } else {   // (AL_DBG2 bit 5, timing experiment: one 8-byte load per row)
-						e[j] = src[i];
-						if (i > 0) xp[j] = src[i - 1].x; }
-					}
+					// (round 6) no branch around the loads: the compiler waits for everything in flight wherever a conditionally loaded value meets its default,
+					// which made the four rows' loads four round trips.  A thread without a row reads the last row the tile has (or the fragment's first
+					// anchor, readable even when the tile is empty), and stores nothing below.
+					const uint32_t rr = r < rows ? r : (rows ? rows - 1u : 0u);
+					if (!single && r >= rows) { fi = 0; while (fi + 1 < nfr && s_tf[fi + 1].start <= rr) ++fi; }
+					fis[j] = fi;
+					const uint32_t i = rows ? rr - s_tf[fi].start : 0u; is[j] = i;
+					const AlAnchor *src = anchors + s_tf[fi].aoff + pos;
+					e[j] = src[i];
+					xp[j] = src[i > 0 ? i - 1 : 0].x;
 				}
 				// (the compiler would sink every load to its use -- one memory latency per row: the loaded values are pinned here)
-				asm volatile("" : "+v"(e[0].x), "+v"(e[0].y), "+v"(e[1].x), "+v"(e[1].y), "+v"(xp[0]), "+v"(xp[1]));
+				asm volatile("" : "+v"(e[0].x), "+v"(e[0].y), "+v"(e[1].x), "+v"(e[1].y), "+v"(xp[0]), "+v"(xp[1]), "+v"(e[2].x), "+v"(e[2].y), "+v"(e[3].x), "+v"(e[3].y), "+v"(xp[2]), "+v"(xp[3]));
 #pragma unroll
-				for (int j = 0; j < 2; ++j) {
-					const uint32_t r = (uint32_t)(2 * h + j) * CT_NT + tid;
+				for (int j = 0; j < 4; ++j) {
+					const uint32_t r = (uint32_t)j * CT_NT + tid;
 					if (r < rows) {
 						const AlAnchor ee = e[j];
 						const bool cut = is[j] == 0 || ee.x - xp[j] > (uint64_t)(int64_t)s_tf[fis[j]].mdx;
@@ -462,7 +464,6 @@ ct_tile_body(const AlAnchor *__restrict__ anchors, const uint64_t *__restrict__ 
 					if (!single) while (fi + 1 < nfr && s_tf[fi + 1].start <= t) ++fi;
 					const uint64_t base = s_tf[fi].aoff + pos; const uint32_t st0 = s_tf[fi].start;
 					di[j] = base + (t - st0);
-					if (P.dbg2 & 16) { v[j].x = sr; v[j].y = di[j]; } else               // (AL_DBG2 bit 4, timing experiment: no gather)
 					v[j] = anchors[ok[j] ? base + (sr - st0) : s_tf[0].aoff];          // (a place without a chained anchor: any readable anchor, not stored)
 				}
 				asm volatile("" : "+v"(v[0].x), "+v"(v[0].y), "+v"(v[1].x), "+v"(v[1].y));
