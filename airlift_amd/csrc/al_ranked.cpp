@@ -157,6 +157,7 @@ struct FileExchange : ProcExchange {
 
 // ---- RCCL: one communicator over the ranks' GPUs; the unique id travels through a file ------------------------------------------------
 struct RcclProcExchange : ProcExchange {
+	enum { kMaxWords = 512 };                          // words per rank and all-gather (the grid's boundary table travels in pieces of this size)
 	typedef struct { char internal[128]; } UniqueId;
 	typedef int (*get_id_t)(UniqueId *); typedef int (*init_rank_t)(void **, int, UniqueId, int); typedef int (*allgather_t)(const void *, void *, size_t, int, void *, hipStream_t); typedef int (*destroy_t)(void *);
 	void *lib = nullptr, *comm = nullptr; allgather_t f_ag = nullptr; destroy_t f_destroy = nullptr;
@@ -190,7 +191,7 @@ struct RcclProcExchange : ProcExchange {
 			if (is->rc != 0) { comm = nullptr; return; }
 			comm = is->comm;
 		}
-		if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess || hipMalloc((void **)&d_send, 64) != hipSuccess || hipMalloc((void **)&d_recv, 64 * (size_t)world) != hipSuccess) return;
+		if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess || hipMalloc((void **)&d_send, 8 * kMaxWords) != hipSuccess || hipMalloc((void **)&d_recv, 8 * kMaxWords * (size_t)world) != hipSuccess) return;
 		ok = true;
 	}
 	~RcclProcExchange() override
@@ -201,7 +202,7 @@ struct RcclProcExchange : ProcExchange {
 	}
 	int allgather(const uint64_t *mine, int n_words, uint64_t *all) override
 	{
-		if (n_words > 8 || hipSetDevice(device) != hipSuccess) return -1;
+		if (n_words > kMaxWords || hipSetDevice(device) != hipSuccess) return -1;
 		if (hipMemcpyAsync(d_send, mine, 8 * (size_t)n_words, hipMemcpyHostToDevice, st) != hipSuccess) return -1;
 		if (f_ag(d_send, d_recv, (size_t)n_words, 5 /* ncclUint64 */, comm, st) != 0) return -1;
 		if (hipMemcpyAsync(all, d_recv, 8 * (size_t)n_words * (size_t)world, hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
@@ -304,6 +305,83 @@ int find_ranges(const char *const *fn, int n_fn, int rank, int world, int n_thre
 	return 0;
 }
 
+// ---- (round 6) the common grid of batches of a multi-process SAM run --------------------------------------------------------------------------
+// The input's records are cut into batches of G records; batch k is mapped by rank k mod R, so that every ROUND of R batches is a contiguous stretch
+// of the input and its text can be written in input order after ONE all-gather of the R sizes (the north star's exchange; the reference's writer keeps
+// input order by being serial, map.c:601-644).  B[i][k] = the byte where record k G starts in file i (B[i][n_grid] = the file's size): every rank finds
+// the boundaries whose line starts lie in ITS byte share in one pass over that share, the table is put together by all-gathers.
+struct GridPlan { uint64_t n_grid = 0, G = 0, records = 0; std::vector<long long> B[2]; };
+int find_grid(const char *const *fn, int n_fn, int rank, int world, int n_threads, ProcExchange &ex, GridPlan *gp)
+{
+	const uint64_t POISON = ~0ULL;
+	FileMap f[2]; bool bad = false;
+	for (int i = 0; i < n_fn; ++i) if (!f[i].open(fn[i])) { fprintf(stderr, "ERROR: failed to open file '%s'\n", fn[i]); bad = true; }
+	auto share = [&](int i, int r) -> long long { return f[i].size * (long long)r / (long long)world; };
+	uint64_t mine[2] = {0, 0}; std::vector<uint64_t> all(2 * (size_t)world);
+	for (int i = 0; i < n_fn && !bad; ++i) { const long long c = count_newlines(f[i].fd, share(i, rank), share(i, rank + 1), n_threads); if (c < 0) bad = true; else mine[i] = (uint64_t)c; }
+	if (!bad) for (int i = 0; i < n_fn; ++i) if (rank == world - 1 && f[i].size > 0) { char c = 0; if (pread(f[i].fd, &c, 1, (off_t)(f[i].size - 1)) == 1 && c != '\n') ++mine[i]; }   // (an unterminated last line still is one)
+	if (bad) mine[0] = mine[1] = POISON;
+	if (ex.allgather(mine, 2, all.data())) return -2;
+	for (int r = 0; r < world; ++r) if (all[2 * (size_t)r] == POISON) { if (!bad) fprintf(stderr, "[airlift] rank %d: rank %d could not read its share of the input\n", rank, r); return -1; }
+	std::vector<long long> before[2];
+	for (int i = 0; i < n_fn; ++i) { before[i].assign((size_t)world + 1, 0); for (int r = 0; r < world; ++r) before[i][(size_t)r + 1] = before[i][(size_t)r] + (long long)all[2 * (size_t)r + (size_t)i]; }
+	const uint64_t R = (uint64_t)(before[0][(size_t)world] / 4);
+	bool shape_ok = before[0][(size_t)world] % 4 == 0 && (n_fn == 1 || before[1][(size_t)world] == before[0][(size_t)world]);
+	if (!shape_ok) { if (rank == 0) fprintf(stderr, "[airlift] the input is not whole four-line FASTQ records (%lld lines%s): not supported in a multi-process run\n", before[0][(size_t)world], n_fn == 2 ? ", or the two files differ in their line counts" : ""); return -1; }
+	// batch size: what a long input's batches hold in a single process (262144 pairs), less for a short input so that every rank has a few batches; AL_RANK_BATCH (records) overrides
+	uint64_t G = n_fn == 2 ? 262144u : 524288u;
+	{ const uint64_t per = (R + 4ULL * (uint64_t)world - 1) / (4ULL * (uint64_t)world); if (per < G) G = per ? per : 1; }
+	if (getenv("AL_RANK_BATCH") && atoll(getenv("AL_RANK_BATCH")) > 0) G = (uint64_t)atoll(getenv("AL_RANK_BATCH"));
+	if (n_fn == 1 && (G & 1)) ++G;                                   // (one interleaved file: a pair's two records stay in one batch)
+	gp->G = G; gp->records = R; gp->n_grid = (R + G - 1) / G;
+	const uint64_t ng = gp->n_grid;
+	for (int i = 0; i < n_fn; ++i) gp->B[i].assign((size_t)ng + 1, 0);
+	if (ng == 0) return 0;
+	// the boundaries inside my share: record k G starts behind newline number 4 k G; one forward pass
+	std::vector<uint64_t> tab((size_t)n_fn * (size_t)(ng + 1), 0);
+	for (int i = 0; i < n_fn && !bad; ++i) {
+		long long off = share(i, rank), cnt = before[i][(size_t)rank];
+		for (uint64_t k = 1; k < ng; ++k) {
+			const long long want = (long long)(4 * k * G);
+			if (want <= before[i][(size_t)rank] || want > before[i][(size_t)rank + 1]) continue;
+			const long long pos = after_nth_newline(f[i].fd, off, f[i].size, want - cnt);
+			if (pos < 0) { bad = true; break; }
+			tab[(size_t)i * (size_t)(ng + 1) + (size_t)k] = (uint64_t)pos; off = pos; cnt = want;
+		}
+	}
+	// all-gather of the table, in pieces (every entry is written by exactly one rank: the others hold 0)
+	const size_t nw = tab.size(), PW = 256;
+	std::vector<uint64_t> piece(PW + 1), got((PW + 1) * (size_t)world);
+	for (size_t a = 0; a < nw; a += PW) {
+		const size_t n = std::min(PW, nw - a);
+		for (size_t j = 0; j < n; ++j) piece[j] = tab[a + j];
+		piece[n] = bad ? POISON : 0;
+		if (ex.allgather(piece.data(), (int)(n + 1), got.data())) return -2;
+		for (int r = 0; r < world; ++r) { if (got[(size_t)r * (n + 1) + n] == POISON) { if (!bad) fprintf(stderr, "[airlift] rank %d: rank %d could not find its batch boundaries\n", rank, r); return -1; }
+		                                  for (size_t j = 0; j < n; ++j) if (got[(size_t)r * (n + 1) + j]) tab[a + j] = got[(size_t)r * (n + 1) + j]; }
+	}
+	for (int i = 0; i < n_fn; ++i) { for (uint64_t k = 1; k < ng; ++k) gp->B[i][(size_t)k] = (long long)tab[(size_t)i * (size_t)(ng + 1) + (size_t)k]; gp->B[i][0] = 0; gp->B[i][(size_t)ng] = f[i].size; }
+	for (int i = 0; i < n_fn; ++i) for (uint64_t k = 0; k < ng; ++k) if (gp->B[i][(size_t)k + 1] <= gp->B[i][(size_t)k]) { if (rank == 0) fprintf(stderr, "[airlift] batch boundaries of '%s' are not ascending (irregular input?)\n", fn[i]); return -1; }
+	return 0;
+}
+// the sink of the stream driver (AlStreamBatchSink): one all-gather of {ok, bytes, bytes already at the start of the file} per round
+struct RankSink { ProcExchange *ex; int rank, world; long long base = 0, first_off = -1; uint64_t bytes_total = 0, rounds = 0; bool failed = false; };
+long long rank_sink_offset(void *ctx, uint64_t round, uint64_t bytes, uint64_t pre_bytes, int ok)
+{
+	RankSink *S = (RankSink *)ctx; (void)round;
+	uint64_t mine[3] = {ok ? 1ULL : 0ULL, bytes, pre_bytes}; std::vector<uint64_t> all(3 * (size_t)S->world);
+	++S->rounds;
+	if (S->ex->allgather(mine, 3, all.data())) { S->failed = true; return -2; }
+	long long off = S->base, tot = 0; bool all_ok = true;
+	for (int r = 0; r < S->world; ++r) { if (!all[3 * (size_t)r]) all_ok = false; off += (long long)all[3 * (size_t)r + 2]; tot += (long long)all[3 * (size_t)r + 2]; }
+	for (int r = 0; r < S->world; ++r) { if (r < S->rank) off += (long long)all[3 * (size_t)r + 1]; tot += (long long)all[3 * (size_t)r + 1]; }
+	S->base += tot;
+	if (!all_ok) { if (ok) fprintf(stderr, "[airlift] rank %d: another rank failed; the output is incomplete\n", S->rank); S->failed = true; return -1; }
+	if (bytes && S->first_off < 0) S->first_off = off;
+	S->bytes_total += bytes;
+	return off;
+}
+
 int copy_into(int out_fd, long long off, const char *part_path, long long n)
 {
 	const int in = open(part_path, O_RDONLY);
@@ -370,6 +448,38 @@ static int map_ranked(const al_idx_t *mi, int n_fn, const char **fn, const al_ma
 	}
 	if (timing && rank == 0) fprintf(stderr, "[airlift] %d ranks, exchanges by: %s\n", world, ex->name());
 	const double t0 = now_s();
+	if (!bam) {
+		// (round 6) SAM: no part files and no copy at the end -- the ranks share one grid of batches, a round of `world` batches is a contiguous stretch of the
+		// input, and after one all-gather of the round's sizes every rank writes its batch's text into the ONE output file at its offset (pwrite)
+		GridPlan gp;
+		{ const int e = find_grid(fn, n_fn, rank, world, std::max(1, n_threads / 2), *ex, &gp); if (e) return e; }
+		std::vector<long long> lo[2], hi[2];
+		for (uint64_t k = (uint64_t)rank; k < gp.n_grid; k += (uint64_t)world) for (int i = 0; i < n_fn; ++i) { lo[i].push_back(gp.B[i][(size_t)k]); hi[i].push_back(gp.B[i][(size_t)k + 1]); }
+		if (timing) fprintf(stderr, "[airlift] rank %d of %d: %llu records in %llu batches of %llu, %zu of them this rank's; boundaries found in %.3f s\n", rank, world, (unsigned long long)gp.records, (unsigned long long)gp.n_grid, (unsigned long long)gp.G, lo[0].size(), now_s() - t0);
+		// rank 0 creates the file; the others open it once it exists (an all-gather in between)
+		FILE *pf = nullptr; uint64_t okw = 1; std::vector<uint64_t> allw((size_t)world);
+		if (rank == 0) { pf = fopen(out_path, "wb"); if (!pf) { fprintf(stderr, "[airlift] rank 0: cannot create '%s': %s\n", out_path, strerror(errno)); okw = 0; } }
+		if (ex->allgather(&okw, 1, allw.data())) { if (pf) fclose(pf); return -2; }
+		if (!allw[0]) { if (pf) fclose(pf); return -3; }
+		if (rank != 0) { pf = fopen(out_path, "r+b"); if (!pf) { fprintf(stderr, "[airlift] rank %d: cannot open '%s': %s\n", rank, out_path, strerror(errno)); } }
+		RankSink rsk; rsk.ex = ex; rsk.rank = rank; rsk.world = world;
+		AlStreamBatchSink sink; sink.offset_of = rank_sink_offset; sink.ctx = &rsk; sink.n_rounds = (gp.n_grid + (uint64_t)world - 1) / (uint64_t)world;
+		if (gp.n_grid == 0) sink.n_rounds = 1;                                   // (an empty input: one round places the header)
+		AlStreamRange range; range.header = rank == 0; range.list = true; range.n_ranges = (int)lo[0].size(); range.sink = &sink;
+		for (int i = 0; i < n_fn; ++i) { range.rstart[i] = lo[i].data(); range.rend[i] = hi[i].data(); }
+		AlStreamResume rs;
+		int rc = pf ? al_stream_map_files(mi, n_fn, fn, opt, n_threads, pf, rg, &device, 1, &rs, &range) : -3;
+		if (rc == AL_STREAM_NA) { fprintf(stderr, "[airlift] rank %d: a multi-process run takes plain (uncompressed, four-line) FASTQ files only\n", rank); rc = -1; }
+		if (rc != 0 && !rsk.failed && rsk.rounds < sink.n_rounds) (void)rank_sink_offset(&rsk, rsk.rounds, 0, 0, 0);   // (the driver did not get as far as its rounds: the peers must still learn)
+		if (pf && fclose(pf) != 0 && rc == 0) rc = -3;
+		if (rc == 0 && rsk.failed) rc = -4;
+		uint64_t fin = rc == 0 ? 1 : 0; std::vector<uint64_t> allf((size_t)world);
+		if (!rsk.failed && ex->allgather(&fin, 1, allf.data()) == 0) { for (int r = 0; r < world; ++r) if (!allf[(size_t)r] && rc == 0) rc = -4; }
+		if (ex != fex.get()) fex->purge();
+		if (rank == 0) { unlink((dir + "/.al_rccl_id_" + run_id()).c_str()); unlink((dir + "/.al_token_" + run_id_base()).c_str()); if (rc != 0) unlink(out_path); }
+		if (timing) fprintf(stderr, "[airlift] rank %d: %llu bytes in %llu rounds, its first batch's bytes at offset %lld of the merged output; total %.3f s\n", rank, (unsigned long long)rsk.bytes_total, (unsigned long long)rsk.rounds, rsk.first_off, now_s() - t0);
+		return rc;
+	}
 	RankRange rr;
 	{ const int e = find_ranges(fn, n_fn, rank, world, std::max(1, n_threads / 2), *ex, &rr); if (e) return e; }   // (every rank leaves here together: local failures travel as a poison word)
 	if (timing) fprintf(stderr, "[airlift] rank %d of %d: records from %lld; bytes [%lld, %lld) of '%s'%s found in %.3f s\n", rank, world, rr.first_record, rr.start[0], rr.end[0], fn[0], n_fn == 2 ? " (and the matching range of the second file)" : "", now_s() - t0);
@@ -428,6 +538,28 @@ extern "C" int al_dbg_ranked_selftest(const char *fn1, const char *fn2, int worl
 			const long long s = rr[(size_t)r].start[i];
 			if (s < f.size) { char c[2] = {0, 0}; if (pread(f.fd, c, 1, (off_t)s) != 1 || c[0] != '@') return -5; if (s > 0 && (pread(f.fd, c + 1, 1, (off_t)(s - 1)) != 1 || c[1] != '\n')) return -5; }
 			if (count_newlines(f.fd, 0, s, 2) != 4 * rr[(size_t)r].first_record && s < f.size) return -6;     // both files: record first_record starts here
+		}
+	}
+	// (round 6) the grid of batches of the SAM path: the same table on every rank, every boundary at the record it names
+	static std::atomic<int> call_no{0}; const std::string call_tag = "c" + std::to_string(call_no.fetch_add(1));   // (a directory reused by the caller: no call reads another's files)
+	for (const char *gb : {"1", "3", "1000"}) {
+		setenv("AL_RANK_BATCH", gb, 1);
+		std::vector<GridPlan> gp((size_t)world); std::vector<int> rg((size_t)world, 0); std::vector<std::thread> tg;
+		for (int r = 0; r < world; ++r) tg.emplace_back([&, r]() { FileExchange ex(dir, r, world, 60.0, std::string("selfgrid") + gb + call_tag); rg[(size_t)r] = find_grid(fn, n_fn, r, world, 2, ex, &gp[(size_t)r]); });   // (no purge: a rank's last files may still be unread by a slower one)
+		for (auto &t : tg) t.join();
+		unsetenv("AL_RANK_BATCH");
+		for (int r = 0; r < world; ++r) if (rg[(size_t)r]) return -7;
+		for (int r = 1; r < world; ++r) if (gp[(size_t)r].n_grid != gp[0].n_grid || gp[(size_t)r].G != gp[0].G || gp[(size_t)r].B[0] != gp[0].B[0] || gp[(size_t)r].B[1] != gp[0].B[1]) return -8;
+		for (int i = 0; i < n_fn; ++i) {
+			FileMap f; if (!f.open(fn[i])) return -2;
+			const GridPlan &g = gp[0];
+			if (g.n_grid == 0) continue;
+			if (g.B[i][0] != 0 || g.B[i][(size_t)g.n_grid] != f.size) return -9;
+			for (uint64_t k = 1; k < g.n_grid; ++k) {
+				const long long s = g.B[i][(size_t)k]; char c[2] = {0, 0};
+				if (s <= g.B[i][(size_t)k - 1] || s >= f.size || pread(f.fd, c, 1, (off_t)s) != 1 || c[0] != '@' || pread(f.fd, c + 1, 1, (off_t)(s - 1)) != 1 || c[1] != '\n') return -10;
+				if (count_newlines(f.fd, 0, s, 2) != (long long)(4 * k * g.G)) return -11;
+			}
 		}
 	}
 	return 0;

@@ -48,6 +48,7 @@ inline double now_s() { return std::chrono::duration<double>(std::chrono::steady
 struct Piece { char *p = nullptr; size_t n = 0; long long idx = -1; bool last = false; int buf = -1; };
 class PieceReader {
 	int fd = -1; long long size = 0, start = 0; size_t piece; int n_buf;
+	std::vector<long long> r_lo, r_hi, r_first;  // (a list of ranges, round 6) bounds of range j and the number of its first piece; a piece never spans two ranges, `last` marks a range's last piece
 	std::vector<char *> bufs; std::vector<int> free_bufs;
 	std::mutex m; std::condition_variable cv;
 	long long next_assign = 0, next_deliver = 0, n_pieces = 0; bool stop = false, failed = false;
@@ -64,10 +65,14 @@ class PieceReader {
 				pc.idx = next_assign++; pc.buf = free_bufs.back(); free_bufs.pop_back();
 			}
 			pc.p = bufs[pc.buf];
-			const long long off = start + pc.idx * (long long)piece;
-			size_t want = (size_t)std::min<long long>((long long)piece, size - off), got = 0;
+			long long off = start + pc.idx * (long long)piece, lim = size; bool last = pc.idx == n_pieces - 1;
+			if (!r_lo.empty()) {
+				size_t j = (size_t)(std::upper_bound(r_first.begin(), r_first.end(), pc.idx) - r_first.begin()) - 1;
+				off = r_lo[j] + (pc.idx - r_first[j]) * (long long)piece; lim = r_hi[j]; last = pc.idx + 1 == (j + 1 < r_first.size() ? r_first[j + 1] : n_pieces);
+			}
+			size_t want = (size_t)std::min<long long>((long long)piece, lim - off), got = 0;
 			while (got < want) { const ssize_t k = pread(fd, pc.p + got, want - got, (off_t)(off + (long long)got)); if (k <= 0) break; got += (size_t)k; }
-			pc.n = got; pc.last = pc.idx == n_pieces - 1;
+			pc.n = got; pc.last = last;
 			if (pc.last && got > 0 && pc.p[got - 1] != '\n') pc.p[pc.n++] = '\n';     // an unterminated last line still counts (kseq.h)
 			{ std::lock_guard<std::mutex> l(m); if (got < want) failed = true; done.push_back(pc); }
 			cv.notify_all();
@@ -82,6 +87,16 @@ public:
 		size = (long long)sb.st_size; if (end_off >= 0 && end_off < size) size = end_off; start = start_off; piece = piece_bytes; n_buf = n_buffers;
 		n_pieces = size > start ? (size - start + (long long)piece - 1) / (long long)piece : 0;
 		for (int i = 0; i < n_buf; ++i) { char *p = nullptr; if (hipHostMalloc((void **)&p, piece + 16, hipHostMallocDefault) != hipSuccess) return false; bufs.push_back(p); free_bufs.push_back(i); }
+		for (int t = 0; t < n_threads; ++t) workers.emplace_back(&PieceReader::work, this);
+		return true;
+	}
+	// the same over a list of non-empty byte ranges, read one after the other (pieces never span two of them)
+	bool open_ranges(const char *fn, const long long *lo, const long long *hi, int n, size_t piece_bytes, int n_buffers, int n_threads)
+	{
+		long long np = 0;
+		for (int j = 0; j < n; ++j) { if (hi[j] <= lo[j]) return false; r_lo.push_back(lo[j]); r_hi.push_back(hi[j]); r_first.push_back(np); np += (hi[j] - lo[j] + (long long)piece_bytes - 1) / (long long)piece_bytes; }
+		if (!open(fn, 0, -1, piece_bytes, n_buffers, 0)) return false;
+		{ std::lock_guard<std::mutex> l(m); n_pieces = np; }
 		for (int t = 0; t < n_threads; ++t) workers.emplace_back(&PieceReader::work, this);
 		return true;
 	}
@@ -151,8 +166,11 @@ int al_stream_map_files(const al_idx_t *mi, int n_fn, const char **fn, const al_
 	// scratch went (44 instead of 96 workspace bytes per seed hit: ~70 KB per read on a repeat-rich genome) two such contexts fit next to the
 	// index, a batch of that size runs at the resident rate (the tails inside the launches are amortised), and a third context of that size is what
 	// made the device run short of fast memory (3 x 2^20 reads on C4: 1.7 M reads/s; 2 x 2^20: 7.1 M).  Short inputs keep three contexts and the probes.
+	const bool ranged = range->list;                      // (round 6) the caller's list of byte ranges, one batch each, placed by its sink (a multi-process run)
+	if (ranged && (!range->sink || !range->sink->offset_of || (range->n_ranges > 0 && (!range->rstart[0] || !range->rend[0] || (n_fn == 2 && (!range->rstart[1] || !range->rend[1])))))) return -1;
 	double est_reads0 = 0;
-	{ struct stat sb; for (int i = 0; i < n_fn; ++i) if (stat(fn[i], &sb) == 0) { const double hi = range->end[i] >= 0 ? (double)range->end[i] : (double)sb.st_size; est_reads0 += std::max(0.0, hi - (double)range->start[i]) / 360.0; } est_reads0 /= (double)n_dev; }
+	if (ranged) { for (int i = 0; i < n_fn; ++i) for (int j = 0; j < range->n_ranges; ++j) est_reads0 += (double)(range->rend[i][j] - range->rstart[i][j]) / 360.0; est_reads0 /= (double)n_dev; }
+	else { struct stat sb; for (int i = 0; i < n_fn; ++i) if (stat(fn[i], &sb) == 0) { const double hi = range->end[i] >= 0 ? (double)range->end[i] : (double)sb.st_size; est_reads0 += std::max(0.0, hi - (double)range->start[i]) / 360.0; } est_reads0 /= (double)n_dev; }
 	const bool long_input = est_reads0 >= 3.0e6;
 	const int n_slots_lane = std::max(2, std::min(8, getenv("AL_SLOTS") ? atoi(getenv("AL_SLOTS")) : long_input ? 4 : 5));      // text / SAM buffer sets per GPU
 	const int n_ctx_lane = std::max(1, std::min(n_slots_lane, getenv("AL_CTXS") ? atoi(getenv("AL_CTXS")) : long_input ? 2 : 3));  // mapping contexts per GPU
@@ -209,6 +227,7 @@ int al_stream_map_files(const al_idx_t *mi, int n_fn, const char **fn, const al_
 	double probe_held0 = 0, probe_n0 = 0; int probe_mult = 0;
 	std::atomic<bool> single_probe{false};               // a long input (by its file sizes): no small first batch, the first batch already has the size the run keeps
 	if (getenv("AL_BATCH_READS")) { max_reads = std::max(2, atoi(getenv("AL_BATCH_READS"))); sized = true; }    // tests / tuning: fixed batches
+	if (ranged) { max_reads = 1 << 30; sized = true; }     // a range is a batch, whatever it holds (one that does not fit the device is halved by its mapper like any other)
 
 	// SAM text leaves the device through a small ring of page-locked buffers (page-locking memory costs ~0.2 s per GB: no buffer of a
 	// batch's size): the copy of piece n + 1 runs while piece n is written
@@ -340,6 +359,8 @@ int al_stream_map_files(const al_idx_t *mi, int n_fn, const char **fn, const al_
 	long long woff = -1; int n_wr = 1;
 	{ struct stat sb; const int fl = fcntl(ofd, F_GETFL); const off_t at = lseek(ofd, 0, SEEK_CUR);
 	  if (fstat(ofd, &sb) == 0 && S_ISREG(sb.st_mode) && at >= 0 && fl >= 0 && !(fl & O_APPEND) && !getenv("AL_NO_PWRITE")) { woff = (long long)at; n_wr = std::max(1, std::min(16, n_threads / 2)); } }
+	uint64_t sink_rounds = 0;                             // rounds of the caller's sink this process has taken part in
+	const uint64_t pre_bytes = ranged && range->header && woff > 0 ? (uint64_t)woff : 0;   // (the header, already in the file)
 	std::thread writer([&]() {
 		for (uint64_t k = 0;; ++k) {
 			Slot *sl = slot_of(k);
@@ -349,6 +370,12 @@ int al_stream_map_files(const al_idx_t *mi, int n_fn, const char **fn, const al_
 				if (rc != 0 || (n_batches != ~0ULL && k >= n_batches)) return;
 			}
 			const double t0 = now_s();
+			if (ranged) {   // where this batch goes: the sizes of the round's batches of all processes, exchanged by the sink
+				uint64_t nb = 0; if (!sl->chunks.empty()) for (auto &c : sl->chunks) nb += c.size(); else nb = sl->S.sam_bytes;
+				const long long off = range->sink->offset_of(range->sink->ctx, k, nb, k == 0 ? pre_bytes : 0, 1); ++sink_rounds;
+				if (off < 0 || woff < 0) { fail(-4); return; }
+				woff = off;
+			}
 			const std::function<bool(const char *, size_t)> put = [&](const char *p, size_t n) -> bool {
 				if (woff >= 0) {
 					std::atomic<bool> okw{true}; const long long base = woff;
@@ -376,8 +403,62 @@ int al_stream_map_files(const al_idx_t *mi, int n_fn, const char **fn, const al_
 		const int rd_threads = std::max(1, std::min(4, n_threads / (2 * n_fn)));
 		std::unique_ptr<PieceReader> rd[2];
 		bool open_ok = true;
-		for (int i = 0; i < n_fn; ++i) { rd[i].reset(new PieceReader()); if (!rd[i]->open(fn[i], range->start[i], range->end[i], PIECE, 2 * rd_threads + 2, rd_threads)) open_ok = false; }
+		for (int i = 0; i < n_fn; ++i) {
+			rd[i].reset(new PieceReader());
+			if (ranged ? !rd[i]->open_ranges(fn[i], range->rstart[i], range->rend[i], range->n_ranges, PIECE, 2 * rd_threads + 2, rd_threads)
+			           : !rd[i]->open(fn[i], range->start[i], range->end[i], PIECE, 2 * rd_threads + 2, rd_threads)) open_ok = false;
+		}
 		if (!open_ok) fail(-1);
+		if (ranged) {
+			// every range of the list is ONE batch: all of its text goes to the slot, the parser must take all of it (the ranges start and end at records
+			// and hold the same records of both files: the caller counted lines, the grammar is checked here)
+			uint64_t kk = 0;
+			for (int j = 0; j < range->n_ranges && open_ok; ++j) {
+				Slot *sl = slot_of(kk);
+				{
+					const double t0 = now_s();
+					std::unique_lock<std::mutex> l(m);
+					cv.wait(l, [&] { return rc != 0 || sl->state == SL_FREE; });
+					t_wait_slot += now_s() - t0;
+					if (rc != 0) break;
+				}
+				al_acct() = &sl->held;
+				AlStreamSlot &S = sl->S;
+				int err = 0;
+				const double t1 = now_s();
+				for (int i = 0; i < n_fn && !err; ++i) {
+					const long long nb = range->rend[i][j] - range->rstart[i][j];
+					const size_t n_pc = (size_t)((nb + (long long)PIECE - 1) / (long long)PIECE);
+					if (al_stream_begin_text(S, i, n_pc * (PIECE + 16) + 64)) { err = -1; break; }
+					for (;;) {
+						Piece pc; const double tw = now_s();
+						if (!rd[i]->next(pc)) { fprintf(stderr, "[airlift] reading '%s' failed\n", fn[i]); err = -1; break; }
+						t_wait_read += now_s() - tw;
+						if (al_stream_append_text(S, i, pc.p, pc.n)) err = -1;
+						const bool last = pc.last;
+						rd[i]->release(pc);
+						if (err || last) break;
+					}
+				}
+				const double t2 = now_s(); t_load += t2 - t1;
+				AlIngestResult res; const bool ends[2] = {true, true};
+				if (!err && al_stream_parse(S, ends, 1 << 30, &res)) err = al_nomem_flag() ? AL_ERR_NOMEM : -1;
+				if (!err) {
+					bool whole = res.n_frag > 0;
+					for (int i = 0; i < n_fn; ++i) if (res.consumed[i] != S.txt_n[i] || res.first_bad[i] != ~0ULL) whole = false;
+					if (!whole) { fprintf(stderr, "[airlift] range %d of the input (bytes %lld ... of '%s') is not whole four-line FASTQ records pairing up between the files: not supported in a multi-process run\n", j, range->rstart[0][j], fn[0]); err = -1; }
+				}
+				t_parse += now_s() - t2;
+				al_acct() = nullptr;
+				if (err) { fail(err); break; }
+				n_reads_total += (uint64_t)res.n_reads; n_frag_total += (uint64_t)res.n_frag;
+				{ std::lock_guard<std::mutex> l(m); sl->res = res; sl->seq = kk; sl->state = SL_READY; }
+				cv.notify_all();
+				++kk;
+			}
+			{ std::lock_guard<std::mutex> l(m); n_batches = kk; }
+			cv.notify_all();
+		} else {
 		std::vector<char> carry[2]; long long base_off[2] = {range->start[0], range->start[1]}; bool eof[2] = {false, false};
 		for (int i = 0; i < n_fn; ++i) if (rd[i] && rd[i]->file_size() == 0) eof[i] = true;
 		double bytes_per_read = 360.0;                      // refined from every batch
@@ -486,8 +567,17 @@ int al_stream_map_files(const al_idx_t *mi, int n_fn, const char **fn, const al_
 		}
 		{ std::lock_guard<std::mutex> l(m); n_batches = k; }
 		cv.notify_all();
+		}
 	}
 	writer.join();
+	if (ranged) {   // the rounds this process has no batch in (or did not get to): its peers wait for every process in every round
+		int okr; { std::lock_guard<std::mutex> l(m); okr = rc == 0 ? 1 : 0; }
+		for (; sink_rounds < range->sink->n_rounds; ++sink_rounds) {
+			const long long off = range->sink->offset_of(range->sink->ctx, sink_rounds, 0, sink_rounds == 0 ? pre_bytes : 0, okr);
+			if (off < 0) { if (okr) fail(-4); break; }
+			if (!okr) break;                                 // (one round with ok = 0 tells everybody)
+		}
+	}
 	if (woff >= 0) (void)lseek(ofd, (off_t)woff, SEEK_SET);           // whoever writes next (the host driver taking over, the caller) continues behind the text
 	for (auto &mp : mappers) mp->th.join();
 	const double T2 = now_s();

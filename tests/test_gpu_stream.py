@@ -124,15 +124,22 @@ def test_stream_options_and_flags(golden_unpacked):
         assert got == host, opts
 
 
+@pytest.mark.parametrize("batch", [None, "37", "1"])
 @pytest.mark.parametrize("world", [2, 3])
-def test_one_process_per_gpu_mode_on_one_gpu(golden_unpacked, tmp_path, world):
-    """SURVEY.md 8e as processes: --rank r --world R.  Every rank finds its own byte ranges of the two FASTQ files (line counts of
-    the ranks' shares exchanged once), maps them, and copies its part into the merged file at the offset the final all-gather of the
-    part sizes gives it.  Here the ranks share device 0, so the exchanges go through files in the rendezvous directory (RCCL needs a
-    GPU per rank); the merged file must be the single-process output byte for byte."""
+def test_one_process_per_gpu_mode_on_one_gpu(golden_unpacked, tmp_path, world, batch):
+    """SURVEY.md 8e as processes: --rank r --world R.  (Round 6.)  The ranks count the lines of their byte shares of the two FASTQ files, agree
+    on ONE grid of batches of G records (batch k is rank k mod R's), and after one all-gather of the sizes of a round's R batches every rank
+    writes its batch's SAM text into the one output file at its offset: no part files, no copy at the end.  Here the ranks share device 0, so
+    the exchanges go through files in the rendezvous directory (RCCL needs a GPU per rank); the merged file must be the single-process output
+    byte for byte -- with the default grid (a few batches per rank), with 37-record batches (many rounds, a ragged last one) and with one
+    record per batch (more rounds than some ranks have batches)."""
     d, m, exp, rg = _golden(golden_unpacked, "g1_mt150pe")
     out = tmp_path / "merged.sam"
-    env = dict(os.environ, AL_RUN_ID="t%d" % world, AL_TIMING="1", AL_RANK_TIMEOUT="120")
+    env = dict(os.environ, AL_RUN_ID="t%d%s" % (world, batch or "d"), AL_TIMING="1", AL_RANK_TIMEOUT="120")
+    if batch:
+        env["AL_RANK_BATCH"] = batch
+        if batch == "1":
+            d, m, exp, rg = _golden(golden_unpacked, "g3_adversarial")
     ps = [subprocess.Popen([CLI, "-ax", "sr", "-t", "4", "--device", "0", "--rank", str(r), "--world", str(world), "--rendezvous", str(tmp_path), "-o", str(out)] + rg + [m["ref"]] + m["reads"],
                            cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env) for r in range(world)]
     outs = [p.communicate(timeout=300) for p in ps]
