@@ -850,7 +850,9 @@ k_regs_select(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__
               const uint32_t *__restrict__ rd_len, const uint32_t *__restrict__ frag_hash, WsBase W, const uint32_t *__restrict__ list, int n_list,
               AlParams P, uint32_t *__restrict__ regs_n0)
 {
-	constexpr bool IDX_GLOBAL = CAP <= 0;   // (measured with the 8192-chain sort tile's chain numbers there too, for two blocks per CU: 3.0 -> 4.3 ms)
+	// (measured twice in round 6 with the 8192-chain sort tile's chain numbers in the work area instead of LDS, for two blocks per CU: 3.0 -> 4.0 - 4.3 ms: that class is not short of wavefronts)
+	constexpr bool PK1 = false;
+	constexpr bool IDX_GLOBAL = CAP <= 0;
 	__shared__ uint64_t skey_l[CAP > 0 ? CAP : 1];
 	__shared__ uint16_t sidx_l[CAP > 0 && !IDX_GLOBAL ? CAP : 1];
 	__shared__ RegsSelShared S; __shared__ RegsSelKept K;
@@ -875,6 +877,7 @@ k_regs_select(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__
 	if (P.max_gap_ref > 0) max_gap_ref = P.max_gap_ref;
 	else if (P.max_frag_len > 0) { max_gap_ref = P.max_frag_len - qlen; if (max_gap_ref < P.max_gap) max_gap_ref = P.max_gap; }
 	else max_gap_ref = P.max_gap;
+	int4 *const GR = (int4 *)ws.aux128;                                      // two words of 16 bytes per chain, by chain number (capacity 4 n_u + 4)
 	// ---- keys: (u ^ hash of the chain's first anchor) ----
 	uint64_t key_r = 0; int idx_r = 0;                                      // n_u <= 64: lane's own entry
 	if (CAP != -2) {
@@ -885,23 +888,32 @@ k_regs_select(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__
 			}
 		} else {                                                             // keys: every thread of the block; four chains per round, the two dependent loads of each round in flight together (clamped indices: no branch around a load)
 			for (int c0 = tid; c0 < n_u; c0 += 4 * NT) {
-				int cc[4]; uint32_t as4[4]; uint64_t u4[4]; AlAnchor f4[4];
+				int cc[4]; uint32_t as4[4]; uint64_t u4[4]; AlAnchor f4[4], l4[4];
 #pragma unroll
 				for (int q = 0; q < 4; ++q) { cc[q] = c0 + q * NT < n_u ? c0 + q * NT : n_u - 1; as4[q] = as_arr[cc[q]]; u4[q] = u[cc[q]]; }
 #pragma unroll
 				for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(as4[q]), "+v"(u4[q]));
 #pragma unroll
-				for (int q = 0; q < 4; ++q) f4[q] = a[as4[q]];
+				for (int q = 0; q < 4; ++q) { f4[q] = a[as4[q]]; const uint32_t cn = (uint32_t)u4[q]; l4[q] = a[as4[q] + (cn ? cn - 1u : 0u)]; }
 #pragma unroll
-				for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(f4[q].x), "+v"(f4[q].y));
+				for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(f4[q].x), "+v"(f4[q].y), "+v"(l4[q].x), "+v"(l4[q].y));
 #pragma unroll
-				for (int q = 0; q < 4; ++q) if (c0 + q * NT < n_u) { skey[cc[q]] = u4[q] ^ (uint32_t)d_hash64((d_hash64(f4[q].x) + d_hash64(f4[q].y)) ^ fhash); sidx[cc[q]] = (IdxT)cc[q]; }
+				for (int q = 0; q < 4; ++q) if (c0 + q * NT < n_u) {
+					skey[cc[q]] = u4[q] ^ (uint32_t)d_hash64((d_hash64(f4[q].x) + d_hash64(f4[q].y)) ^ fhash); if (!PK1) sidx[cc[q]] = (IdxT)cc[q];
+					// (round 6) the chain's record for the pass -- query / reference interval, contig + strand, count, first anchor -- is made HERE, in chain order, where
+					// the chains' anchors are read front to back; the pass fetches the record of the chain at a sorted position (32 bytes out of a table that stays in L2)
+					// instead of a second, randomly ordered round of two 16-byte anchor reads per chain after the sort (11 GB per launch of the 257 ... 1024-chain class)
+					const AlAnchor fa = f4[q], la = l4[q]; const int cnt = (int)(uint32_t)u4[q];
+					const int q_span = (int)(fa.y >> 32 & 0xff), rev = (int)(fa.x >> 63), rid = (int)(fa.x << 1 >> 33);
+					int4 g;
+					g.z = (int32_t)fa.x + 1 > q_span ? (int32_t)fa.x + 1 - q_span : 0; g.w = (int32_t)la.x + 1;
+					if (!rev) { g.x = (int32_t)fa.y + 1 - q_span; g.y = (int32_t)la.y + 1; }
+					else { g.x = qlen - ((int32_t)la.y + 1); g.y = qlen - ((int32_t)fa.y + 1 - q_span); }
+					GR[2 * cc[q]] = g; GR[2 * cc[q] + 1] = make_int4(rid << 1 | rev, cnt, (int)as4[q], 0);
+				}
 			}
 		}
 	}
-	// per sorted position: query / reference interval, contig + strand, count, first anchor -- written by the whole block once the
-	// order is final, read back 64 at a time by the pass (coalesced, one round trip per group instead of four dependent ones)
-	int4 *const G1 = (int4 *)ws.aux128; int32_t *const G2 = ws.auxi + n_u, *const G3 = G2 + n_u, *const G4 = G3 + n_u;
 	bool tie = false;
 	if (CAP != 0 && CAP != -2) {   // descending sort of (key, chain)
 		// (round 6) LDS tiles of up to 16 keys per thread: the register network of the anchor sorts (al_dev_net.h) on ONE word per chain,
@@ -941,6 +953,7 @@ k_regs_select(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__
 		}
 		int npow2 = 1; while (npow2 < n_u) npow2 <<= 1;
 		if (!net_done) {
+		if (PK1) { for (int c = tid; c < n_u; c += NT) sidx[c] = (IdxT)c; }   // (the key phase left them out)
 		for (int c = n_u + tid; c < npow2; c += NT) { skey[c] = 0; sidx[c] = (IdxT)~0u; }   // keys are > 0 (a chain's score, in the high word): padding sorts last
 		__syncthreads();
 		// A thread takes comparators, not elements: pair p of a step works on i = p with a zero inserted at bit log2(j) and on i | j, so every
@@ -1001,31 +1014,7 @@ k_regs_select(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__
 			}
 			__syncthreads();
 		}
-		for (int p0 = tid; p0 < n_u; p0 += 4 * NT) {                          // four positions per round: chain -> (count, first anchor) -> its two end anchors, each level's loads in flight together
-			int pp[4], c4[4], cnt4[4], as4[4]; AlAnchor f4[4], l4[4];
-#pragma unroll
-			for (int q = 0; q < 4; ++q) { pp[q] = p0 + q * NT < n_u ? p0 + q * NT : n_u - 1; c4[q] = (int)sidx[pp[q]]; }
-#pragma unroll
-			for (int q = 0; q < 4; ++q) { cnt4[q] = (int)(uint32_t)u[c4[q]]; as4[q] = (int)as_arr[c4[q]]; }
-#pragma unroll
-			for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(cnt4[q]), "+v"(as4[q]));
-#pragma unroll
-			for (int q = 0; q < 4; ++q) { f4[q] = a[as4[q]]; l4[q] = a[as4[q] + cnt4[q] - 1]; }
-#pragma unroll
-			for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(f4[q].x), "+v"(f4[q].y), "+v"(l4[q].x), "+v"(l4[q].y));
-#pragma unroll
-			for (int q = 0; q < 4; ++q) if (p0 + q * NT < n_u) {
-				const int p = pp[q], c = c4[q], cnt = cnt4[q], as = as4[q];
-				const AlAnchor fa = f4[q], la = l4[q];
-				const int q_span = (int)(fa.y >> 32 & 0xff), rev = (int)(fa.x >> 63), rid = (int)(fa.x << 1 >> 33);
-				int4 g;
-				g.z = (int32_t)fa.x + 1 > q_span ? (int32_t)fa.x + 1 - q_span : 0; g.w = (int32_t)la.x + 1;
-				if (!rev) { g.x = (int32_t)fa.y + 1 - q_span; g.y = (int32_t)la.y + 1; }
-				else { g.x = qlen - ((int32_t)la.y + 1); g.y = qlen - ((int32_t)fa.y + 1 - q_span); }
-				G1[p] = g; G2[p] = rid << 1 | rev; G3[p] = cnt; G4[p] = as;
-				if (PHASE == 1) { ws.aux64[p] = skey[p]; ((uint32_t *)(ws.auxi + (4 * n_u + 4)))[p] = (uint32_t)c; }
-			}
-		}
+		if (PHASE == 1) for (int p = tid; p < n_u; p += NT) { ws.aux64[p] = skey[p]; if (!PK1) ((uint32_t *)(ws.auxi + (4 * n_u + 4)))[p] = (uint32_t)sidx[p]; }   // keys and order for the pass kernel (PK1: the order is there already)
 		if (PHASE == 1) return;
 		__syncthreads();
 		if (tid >= 64) return;
@@ -1060,8 +1049,8 @@ k_regs_select(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__
 		const int score = (int)(key >> 32); const uint32_t hsh = (uint32_t)key;
 		int cnt = 0, as = 0, rs = 0, re = 0, qs = 0, qe = 0, rid = 0, rev = 0;
 		if (v && CAP != 0) {
-			const int4 g = G1[p]; const int rr = G2[p];
-			qs = g.x; qe = g.y; rs = g.z; re = g.w; rid = rr >> 1; rev = rr & 1; cnt = G3[p]; as = G4[p];
+			const int4 g = GR[2 * c], h = GR[2 * c + 1];
+			qs = g.x; qe = g.y; rs = g.z; re = g.w; rid = h.x >> 1; rev = h.x & 1; cnt = h.y; as = h.z;
 		} else if (v) {
 			cnt = (int)(uint32_t)u[c]; as = (int)as_arr[c];
 			const AlAnchor fa = a[as], la = a[as + cnt - 1];
