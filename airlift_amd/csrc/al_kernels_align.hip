@@ -845,7 +845,7 @@ struct RegsSelShared {
 // PHASE 1 (CAP > 0): the sort only -- keys, order and the per-position tables are left in the fragment's global work area, and
 // k_regs_select<-2> (one wavefront, no sort tile: a dozen blocks per CU instead of the one or two the tile allows) makes the pass.
 template <int CAP, int PHASE = 0>      // CAP > 0: sort tile in LDS; 0: at most 64 chains, registers; -1: sort keys in the fragment's global work area (any count); -2: keys sorted already (PHASE 1 ran), the pass only
-__global__ void __launch_bounds__(CAP == 0 || CAP == 256 || CAP == -2 ? 64 : CAP < 0 || (PHASE == 1 && CAP >= 8192) ? 1024 : 256)
+__global__ void __launch_bounds__(CAP == 0 || CAP == 256 || CAP == -2 ? 64 : CAP < 0 ? 1024 : (PHASE == 1 && CAP >= 8192) ? 512 : 256)
 k_regs_select(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__ u_all, const uint32_t *__restrict__ uo_all, const uint32_t *__restrict__ frag_first,
               const uint32_t *__restrict__ rd_len, const uint32_t *__restrict__ frag_hash, WsBase W, const uint32_t *__restrict__ list, int n_list,
               AlParams P, uint32_t *__restrict__ regs_n0)
@@ -856,7 +856,7 @@ k_regs_select(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__
 	__shared__ uint64_t skey_l[CAP > 0 ? CAP : 1];
 	__shared__ uint16_t sidx_l[CAP > 0 && !IDX_GLOBAL ? CAP : 1];
 	__shared__ RegsSelShared S; __shared__ RegsSelKept K;
-	constexpr int NT = CAP == 0 || CAP == 256 || CAP == -2 ? 64 : CAP < 0 || (PHASE == 1 && CAP >= 8192) ? 1024 : 256;   // (the sort-only form of the largest tile: one block per CU, all of its wavefronts)   // (65 ... 256 chains: one wavefront sorts and makes the pass -- four times the blocks per CU of the 256-thread form, whose other three wavefronts only sort)
+	constexpr int NT = CAP == 0 || CAP == 256 || CAP == -2 ? 64 : CAP < 0 ? 1024 : (PHASE == 1 && CAP >= 8192) ? 512 : 256;   // (the sort-only form of the largest tile: one block per CU, all of its wavefronts)   // (65 ... 256 chains: one wavefront sorts and makes the pass -- four times the blocks per CU of the 256-thread form, whose other three wavefronts only sort)
 	                // all threads sort (the sort in global memory, any count: 1024 of them); the first wavefront makes the pass
 	const int tid = threadIdx.x, lane = tid & 63;
 	if ((int)blockIdx.x >= n_list) return;
@@ -2716,7 +2716,7 @@ int al_run_align_stage(al_ctx_t *c)
 		LSEL(-1, 0, 1024, lb[3], (uint32_t)nf, c->aux[0]);
 		LSEL(4096, 0, 256, lb[4], lb[5], c->aux[1]);
 		LSEL(2048, 0, 256, lb[2], lb[4], c->aux[2]);
-		LSEL(8192, 1, 1024, lb[5], lb[3], s);
+		LSEL(8192, 1, 512, lb[5], lb[3], s);
 		if (split & 1) LSEL(1024, 1, 256, lb[6], lb[2], s);
 		AL_HIP_CHECK(hipEventRecord(c->ev_fj[0], s)); AL_HIP_CHECK(hipStreamWaitEvent(sd, c->ev_fj[0], 0));
 		LSEL(-2, 0, 64, lb[5], lb[3], sd);
