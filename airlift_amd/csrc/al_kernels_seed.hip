@@ -190,6 +190,16 @@ __device__ __forceinline__ uint64_t d_match_pos(const uint64_t *__restrict__ pos
 	const uint64_t w = (uint64_t)off_lo | (uint64_t)(flags >> 16) << 32;
 	return (flags >> 9 & 1u) ? w : pos[w + k];
 }
+// ... as an address and a select: the load is unconditional (a once-occurring minimizer reads pos[0] and ignores it), so that a thread's loads can be in flight together
+__device__ __forceinline__ const uint64_t *d_match_pos_addr(const uint64_t *__restrict__ pos, uint32_t off_lo, uint32_t flags, uint32_t k)
+{
+	const uint64_t w = (uint64_t)off_lo | (uint64_t)(flags >> 16) << 32;
+	return (flags >> 9 & 1u) ? pos : pos + (w + k);
+}
+__device__ __forceinline__ uint64_t d_match_pos_pick(uint64_t loaded, uint32_t off_lo, uint32_t flags)
+{
+	return (flags >> 9 & 1u) ? ((uint64_t)off_lo | (uint64_t)(flags >> 16) << 32) : loaded;
+}
 
 // collect_matches (map.c:90-123) of one fragment: its minimizers looked up with `max_occ`; mo == nullptr: counts only
 __device__ __forceinline__ void d_seed_frag(const uint64_t *__restrict__ tab, int tab_bits, const uint32_t *__restrict__ frag_first, const uint32_t *__restrict__ rd_len,
@@ -929,8 +939,7 @@ k_anchor_sort_reg(const uint64_t *__restrict__ pos, const uint32_t *__restrict__
 	constexpr int PADW = CAP + CAP / 16 + 2;                // output transpose: one pad word per 16 keys
 	__shared__ uint64_t sx[PADW];
 	__shared__ uint32_t pre[MCAP + 1];
-	constexpr bool MLDS = false;                            // (match records in LDS for the block kernels: 12 KB that cost a block per CU -- 52.7 -> 40.7 KB, 88.5 -> 76.5 KB: four and two blocks instead of three and one; the records are read through L1 / L2 like the one-wave kernels do: block sorts 19.4 -> 17.4 ms)
-	__shared__ uint32_t m_off[MLDS ? MCAP : 1], m_fl[MLDS ? MCAP : 1], m_qp[MLDS ? MCAP : 1];   // off_lo, flags, q_pos
+	// (the match records stay in global memory, read through L1 / L2: a copy in LDS cost the block kernels a block per CU -- block sorts 19.4 -> 17.4 ms without it)
 	__shared__ uint32_t s_part[NT];
 	__shared__ int s_flag;
 	const int tid = threadIdx.x;
@@ -950,7 +959,7 @@ k_anchor_sort_reg(const uint64_t *__restrict__ pos, const uint32_t *__restrict__
 #pragma unroll
 		for (int j = 0; j < LPT; ++j) {
 			const uint32_t i = (uint32_t)tid * LPT + j; v[j] = 0;
-			if (i < n_m) { const AlMatch mm = m[i]; v[j] = mm.n; if (MLDS) { m_off[i] = mm.off_lo; m_fl[i] = mm.flags; m_qp[i] = mm.q_pos; } }
+			if (i < n_m) v[j] = m[i].n;
 			sum += v[j];
 		}
 		uint32_t incl = sum;                                              // wave scan, then the wave totals through LDS
@@ -968,28 +977,47 @@ k_anchor_sort_reg(const uint64_t *__restrict__ pos, const uint32_t *__restrict__
 	const int sb = 32 + rid_bits;                                           // strand bit of the compact key
 	uint64_t k[PER];
 	{   // expansion, element t = tid + j NT (coalesced position loads); the network does not care where a key starts
-		uint64_t rr[PER]; uint32_t mi[PER], qb[PER];
+		// (round 6) per eight elements, three rounds without a branch around a load -- every element's list by a search of the prefix table with a fixed trip
+		// count (a thread without an element searches for the last one), then the eight match records, then the eight positions: the loads of a round are in flight
+		// together; with `if (t < n) { search; record; position }` per element the compiler waited at every join, and a thread's PER x 2 dependent round trips
+		// were most of these kernels.  Keys are built per eight so that only they stay live.
+#define TT(j) (((uint32_t)tid + (uint32_t)(j) * (uint32_t)NT) < n ? ((uint32_t)tid + (uint32_t)(j) * (uint32_t)NT) : n - 1u)
+#define LIVE(j) ((uint32_t)tid + (uint32_t)(j) * (uint32_t)NT < n)
+		int steps = 0; while ((1u << steps) < n_m) ++steps;
+		constexpr int CH = PER < 8 ? PER : 8;
 #pragma unroll
-		for (int j = 0; j < PER; ++j) {
-			const uint32_t t = (uint32_t)tid + (uint32_t)j * (uint32_t)NT; rr[j] = 0; mi[j] = 0; qb[j] = 0;
-			if (t < n) {
-				uint32_t lo = 0, hi = n_m;                                   // last list with pre[list] <= t
-				while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (pre[mid] <= t) lo = mid; else hi = mid; }
-				mi[j] = lo;
-				if (MLDS) { rr[j] = d_match_pos(pos, m_off[lo], m_fl[lo], t - pre[lo]); qb[j] = m_qp[lo]; }
-				else { const AlMatch mm = m[lo]; rr[j] = d_match_pos(pos, mm.off_lo, mm.flags, t - pre[lo]); qb[j] = mm.q_pos; }
-			}
-		}
+		for (int j0 = 0; j0 < PER; j0 += CH) {
+			uint32_t mi[CH], fl[CH], ol[CH], qb[CH]; uint64_t rr[CH];
+			if ((uint32_t)j0 * (uint32_t)NT >= n) {                             // (block-uniform) nobody has an element in this eight
 #pragma unroll
-		for (int j = 0; j < PER; ++j) {
-			const uint32_t t = (uint32_t)tid + (uint32_t)j * (uint32_t)NT;
-			uint64_t key = UINT64_MAX;
-			if (t < n) {
-				const uint64_t r = rr[j]; const bool rev = (r & 1) != (qb[j] & 1);      // map.c:176-190
-				key = ((uint64_t)(rev ? 1 : 0) << sb | (r >> 32) << 32 | (uint32_t)((uint32_t)r >> 1)) << 16 | mi[j];
+				for (int j = 0; j < CH; ++j) k[j0 + j] = UINT64_MAX;
+				continue;
 			}
-			k[j] = key;
+#pragma unroll
+			for (int j = 0; j < CH; ++j) mi[j] = 0;
+			for (int b = steps - 1; b >= 0; --b) {                             // mi = last list with pre[list] <= t, bit by bit (pre[0] = 0 <= t)
+#pragma unroll
+				for (int j = 0; j < CH; ++j) { const uint32_t c_ = mi[j] | (1u << b); if (c_ < n_m && pre[c_] <= TT(j0 + j)) mi[j] = c_; }
+			}
+#pragma unroll
+			for (int j = 0; j < CH; ++j) { const AlMatch mm = m[mi[j]]; fl[j] = mm.flags; ol[j] = mm.off_lo; qb[j] = mm.q_pos; }
+#pragma unroll
+			for (int j = 0; j < CH; ++j) asm volatile("" : "+v"(fl[j]), "+v"(ol[j]), "+v"(qb[j]));
+#pragma unroll
+			for (int j = 0; j < CH; ++j) rr[j] = *d_match_pos_addr(pos, ol[j], fl[j], TT(j0 + j) - pre[mi[j]]);
+#pragma unroll
+			for (int j = 0; j < CH; ++j) asm volatile("" : "+v"(rr[j]));
+#pragma unroll
+			for (int j = 0; j < CH; ++j) {
+				const uint64_t r = d_match_pos_pick(rr[j], ol[j], fl[j]); const bool rev = (r & 1) != (qb[j] & 1);      // map.c:176-190
+				const uint64_t key = ((uint64_t)(rev ? 1 : 0) << sb | (r >> 32) << 32 | (uint32_t)((uint32_t)r >> 1)) << 16 | mi[j];
+				k[j0 + j] = LIVE(j0 + j) ? key : UINT64_MAX;
+			}
+#pragma unroll
+			for (int j = 0; j < CH; ++j) asm volatile("" : "+v"(k[j0 + j]));
 		}
+#undef TT
+#undef LIVE
 	}
 	d_bt_levels<PER, NT, 2>(k, sx, tid);
 	__syncthreads();
@@ -1002,15 +1030,28 @@ k_anchor_sort_reg(const uint64_t *__restrict__ pos, const uint32_t *__restrict__
 	__syncthreads();
 	if (s_flag) { if (tid == 0) tie_list[f] = 1u; return; }                // merged by k_anchor_heap
 	const uint64_t lowmask = (1ULL << sb) - 1;
-	for (uint32_t t = tid; t < n; t += NT) {
-		const uint64_t key = sx[t + (t >> 4)]; const uint32_t i = (uint32_t)key & 0xffffu; const uint64_t kx = key >> 16;
-		uint32_t qp, fl; const uint32_t span = (uint32_t)mini_span;
-		if (MLDS) { qp = m_qp[i]; fl = m_fl[i]; } else { const AlMatch mm = m[i]; qp = mm.q_pos; fl = mm.flags; }
-		AlAnchor a; a.x = (kx & lowmask) | (kx >> sb & 1) << 63;
-		a.y = (a.x >> 63) ? (uint64_t)span << 32 | (uint32_t)(qlen - ((int)(qp >> 1) + 1 - (int)span) - 1) : (uint64_t)span << 32 | (qp >> 1);
-		a.y |= (uint64_t)(fl & 0xff) << AL_SEED_SEG_SHIFT;
-		if (fl & (1u << 8)) a.y |= AL_SEED_TANDEM;
-		out[t] = a;
+	constexpr int CHO = PER < 8 ? PER : 8;                                  // the records of eight anchors at a time, loads without a branch around them
+#pragma unroll
+	for (int j0 = 0; j0 < PER; j0 += CHO) {
+		if ((uint32_t)j0 * (uint32_t)NT >= n) break;                         // (block-uniform)
+		uint64_t kx[CHO]; uint32_t qp[CHO], fl[CHO];
+#pragma unroll
+		for (int j = 0; j < CHO; ++j) {
+			const uint32_t t = (uint32_t)tid + (uint32_t)(j0 + j) * (uint32_t)NT, tc = t < n ? t : n - 1u;
+			const uint64_t key = sx[tc + (tc >> 4)]; kx[j] = key >> 16;
+			const AlMatch mm = m[(uint32_t)key & 0xffffu]; qp[j] = mm.q_pos; fl[j] = mm.flags;
+		}
+#pragma unroll
+		for (int j = 0; j < CHO; ++j) asm volatile("" : "+v"(qp[j]), "+v"(fl[j]));
+#pragma unroll
+		for (int j = 0; j < CHO; ++j) {
+			const uint32_t t = (uint32_t)tid + (uint32_t)(j0 + j) * (uint32_t)NT; const uint32_t span = (uint32_t)mini_span;
+			AlAnchor a; a.x = (kx[j] & lowmask) | (kx[j] >> sb & 1) << 63;
+			a.y = (a.x >> 63) ? (uint64_t)span << 32 | (uint32_t)(qlen - ((int)(qp[j] >> 1) + 1 - (int)span) - 1) : (uint64_t)span << 32 | (qp[j] >> 1);
+			a.y |= (uint64_t)(fl[j] & 0xff) << AL_SEED_SEG_SHIFT;
+			if (fl[j] & (1u << 8)) a.y |= AL_SEED_TANDEM;
+			if (t < n) out[t] = a;
+		}
 	}
 }
 #define INST_SORT_REG(P, W, M) template __global__ void k_anchor_sort_reg<P, W, M>(const uint64_t *, const uint32_t *, const uint32_t *, const uint64_t *, const AlMatch *, const uint32_t *, const uint32_t *, const uint64_t *, AlAnchor *, uint32_t *, const uint32_t *, int, int, int);
@@ -1143,24 +1184,44 @@ k_anchor_run_sort(const uint64_t *__restrict__ pos, const uint32_t *__restrict__
 	const int sb = 32 + rid_bits;
 	uint64_t k[PER];
 	{
-		uint64_t rr[PER]; uint32_t mi[PER], qb[PER];
+		// as in k_anchor_sort_reg: per eight elements the searches with a fixed trip count, then the records, then the positions, no branch around a load
+#define TT(j) (base + (((uint32_t)tid + (uint32_t)(j) * (uint32_t)NT) < cnt ? ((uint32_t)tid + (uint32_t)(j) * (uint32_t)NT) : cnt - 1u))
+#define LIVE(j) ((uint32_t)tid + (uint32_t)(j) * (uint32_t)NT < cnt)
+		int steps = 0; while ((1u << steps) < n_m) ++steps;
+		constexpr int CH = PER < 8 ? PER : 8;
 #pragma unroll
-		for (int j = 0; j < PER; ++j) {
-			const uint32_t e = (uint32_t)tid + (uint32_t)j * (uint32_t)NT, t = base + e; rr[j] = 0; mi[j] = 0; qb[j] = 0;
-			if (e < cnt) {
-				uint32_t lo = 0, hi = n_m;
-				while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (pre[mid] <= t) lo = mid; else hi = mid; }
-				mi[j] = lo;
-				const AlMatch mm = m[lo]; rr[j] = d_match_pos(pos, mm.off_lo, mm.flags, t - pre[lo]); qb[j] = mm.q_pos;
+		for (int j0 = 0; j0 < PER; j0 += CH) {
+			uint32_t mi[CH], fl[CH], ol[CH], qb[CH]; uint64_t rr[CH];
+			if ((uint32_t)j0 * (uint32_t)NT >= cnt) {
+#pragma unroll
+				for (int j = 0; j < CH; ++j) k[j0 + j] = UINT64_MAX;
+				continue;
 			}
-		}
 #pragma unroll
-		for (int j = 0; j < PER; ++j) {
-			const uint32_t e = (uint32_t)tid + (uint32_t)j * (uint32_t)NT;
-			uint64_t key = UINT64_MAX;
-			if (e < cnt) { const uint64_t r = rr[j]; const bool rev = (r & 1) != (qb[j] & 1); key = ((uint64_t)(rev ? 1 : 0) << sb | (r >> 32) << 32 | (uint32_t)((uint32_t)r >> 1)) << 16 | mi[j]; }
-			k[j] = key;
+			for (int j = 0; j < CH; ++j) mi[j] = 0;
+			for (int b = steps - 1; b >= 0; --b) {
+#pragma unroll
+				for (int j = 0; j < CH; ++j) { const uint32_t c_ = mi[j] | (1u << b); if (c_ < n_m && pre[c_] <= TT(j0 + j)) mi[j] = c_; }
+			}
+#pragma unroll
+			for (int j = 0; j < CH; ++j) { const AlMatch mm = m[mi[j]]; fl[j] = mm.flags; ol[j] = mm.off_lo; qb[j] = mm.q_pos; }
+#pragma unroll
+			for (int j = 0; j < CH; ++j) asm volatile("" : "+v"(fl[j]), "+v"(ol[j]), "+v"(qb[j]));
+#pragma unroll
+			for (int j = 0; j < CH; ++j) rr[j] = *d_match_pos_addr(pos, ol[j], fl[j], TT(j0 + j) - pre[mi[j]]);
+#pragma unroll
+			for (int j = 0; j < CH; ++j) asm volatile("" : "+v"(rr[j]));
+#pragma unroll
+			for (int j = 0; j < CH; ++j) {
+				const uint64_t r = d_match_pos_pick(rr[j], ol[j], fl[j]); const bool rev = (r & 1) != (qb[j] & 1);      // map.c:176-190
+				const uint64_t key = ((uint64_t)(rev ? 1 : 0) << sb | (r >> 32) << 32 | (uint32_t)((uint32_t)r >> 1)) << 16 | mi[j];
+				k[j0 + j] = LIVE(j0 + j) ? key : UINT64_MAX;
+			}
+#pragma unroll
+			for (int j = 0; j < CH; ++j) asm volatile("" : "+v"(k[j0 + j]));
 		}
+#undef TT
+#undef LIVE
 	}
 	d_bt_levels<PER, NT, 2>(k, sx, tid);
 	__syncthreads();
