@@ -143,12 +143,16 @@ def read_fastx(path):
 class Index:
     """al_idx_t (replaces mm_idx_t)."""
 
-    def __init__(self, fasta=None, seqs=None, names=None, preset="sr", n_threads=4, on_device=None):
+    def __init__(self, fasta=None, seqs=None, names=None, preset="sr", n_threads=4, on_device=None, k=None, w=None):
         L = load()
         self.io, self.mo = IdxOpt(), MapOpt()
         L.al_set_opt(None, C.byref(self.io), C.byref(self.mo))
         if L.al_set_opt(preset.encode(), C.byref(self.io), C.byref(self.mo)) != 0:
             raise AirliftError("unknown preset " + preset)
+        if k is not None:
+            self.io.k = k
+        if w is not None:
+            self.io.w = w
         self.mo.flag |= 0x004 | 0x008
         if fasta is not None and on_device is not None:     # sketch + sort + table built by kernels on that GPU
             self.h = L.al_idx_build_device(fasta.encode(), C.byref(self.io), on_device)

@@ -15,8 +15,8 @@
 //   rocPRIM run-length encode + scan -> distinct hashes, counts, offsets
 //   KI3     k_tab_insert     open-addressing table of 16-byte entries {hash+1, off<<32|n}; atomicCAS claims a slot
 //
-// k must be odd (a k-mer then never equals its reverse complement, so the `continue` of sketch.c:108 never fires and the
-// ring phase carries no long-range state); the short-read preset uses k=21.
+// Odd k (the short-read preset: 21): a k-mer never equals its reverse complement, the `continue` of sketch.c:108 never fires and 2 (w + k) + 8 bases of
+// lead-in are enough.  Even k: the lead-in is counted in iterations that move the window (k_ref_sketch).
 #include <hip/hip_runtime.h>
 #include <string.h>
 #include <cstring>
@@ -94,47 +94,65 @@ k_ref_sketch(const uint32_t *__restrict__ S4, const uint64_t *__restrict__ seq_o
 	const uint64_t base = seq_off[rid];
 	const uint32_t s0 = (uint32_t)(sg - seg_first[rid]) * AL_ISEG;
 	const uint32_t e0 = s0 + AL_ISEG < len ? s0 + AL_ISEG : len;
-	const uint32_t lead = 2 * (uint32_t)(w + k) + 8;
-	const uint32_t i0 = s0 > lead ? s0 - lead : 0;
-	uint64_t o = EMIT ? out_off[sg] : 0; uint32_t cnt = 0;
+	// Even k (round 6): a k-mer that is its own reverse complement is skipped WITHOUT moving the window or the run length (sketch.c:108), so the lead-in is
+	// measured in iterations that DO move it, after the first k bases (the k-mer words hold the last k non-N bases -- an N does not clear them, sketch.c:116 -- and
+	// are not known before): 2 (w + k) + 8 of them put the ring, the minimum and every threshold on l where the serial run has them (l is at most k off after
+	// the warm-up and only compared with w + k and below; an N sets both to 0).  A lane that finds fewer -- its lead-in lies in a palindromic repeat, (AT)n -- starts
+	// again from twice as far back, up to the contig's start.
+	const bool even = !(k & 1);
+	const uint32_t need = 2 * (uint32_t)(w + k) + 8;
+	uint32_t lead = even ? need + (uint32_t)k : need;
+	const uint64_t o_first = EMIT ? out_off[sg] : 0;
 	const uint64_t shift1 = 2 * (k - 1), mask = (1ULL << 2 * k) - 1;
-	uint64_t kmer0 = 0, kmer1 = 0, minx = UINT64_MAX, miny = UINT64_MAX;
-	int l = 0, buf_pos = 0, min_pos = 0;
-	for (int j = 0; j < w; ++j) bx[j * 64] = UINT64_MAX, by[j * 64] = UINT64_MAX;
+	uint64_t o = o_first; uint32_t cnt = 0;
+	uint64_t minx = UINT64_MAX, miny = UINT64_MAX;
 #define EMIT_XY(X, Y) do { if (i >= s0) { if (EMIT) { out_h[o] = (X) >> 8; out_y[o] = (Y); ++o; } ++cnt; } } while (0)
-	uint32_t word = 0;
-	for (uint32_t i = i0; i < e0; ++i) {
-		const uint64_t gp = base + i;
-		if (i == i0 || (gp & 7) == 0) word = S4[gp >> 3];
-		const int c = (word >> ((gp & 7) << 2)) & 0xf;
-		uint64_t ix = UINT64_MAX, iy = UINT64_MAX;
-		if (c < 4) {
-			const int span = l + 1 < k ? l + 1 : k;
-			kmer0 = (kmer0 << 2 | (uint64_t)c) & mask;
-			kmer1 = (kmer1 >> 2) | (3ULL ^ (uint64_t)c) << shift1;
-			const int z = kmer0 < kmer1 ? 0 : 1;                                // k odd (even k: the host builder, see al_idx_build_device): kmer0 != kmer1 always
-			++l;
-			if (l >= k) { ix = di_hash64m(z ? kmer1 : kmer0, mask) << 8 | (uint64_t)span; iy = (uint64_t)rid << 32 | (uint64_t)i << 1 | (uint64_t)z; }
-		} else l = 0;
-		bx[buf_pos * 64] = ix; by[buf_pos * 64] = iy;
-		if (l == w + k - 1 && minx != UINT64_MAX) {                         // sketch.c:117-122
-			for (int j = buf_pos + 1; j < w; ++j) { const uint64_t x = bx[j * 64], y = by[j * 64]; if (minx == x && y != miny) EMIT_XY(x, y); }
-			for (int j = 0; j < buf_pos; ++j)     { const uint64_t x = bx[j * 64], y = by[j * 64]; if (minx == x && y != miny) EMIT_XY(x, y); }
-		}
-		if (ix <= minx) {                                                   // sketch.c:123-125
-			if (l >= w + k && minx != UINT64_MAX) EMIT_XY(minx, miny);
-			minx = ix, miny = iy, min_pos = buf_pos;
-		} else if (buf_pos == min_pos) {                                    // sketch.c:126-138
-			if (l >= w + k - 1 && minx != UINT64_MAX) EMIT_XY(minx, miny);
-			minx = UINT64_MAX;
-			for (int j = buf_pos + 1; j < w; ++j) { const uint64_t x = bx[j * 64]; if (minx >= x) minx = x, miny = by[j * 64], min_pos = j; }
-			for (int j = 0; j <= buf_pos; ++j)    { const uint64_t x = bx[j * 64]; if (minx >= x) minx = x, miny = by[j * 64], min_pos = j; }
-			if (l >= w + k - 1 && minx != UINT64_MAX) {
-				for (int j = buf_pos + 1; j < w; ++j) { const uint64_t x = bx[j * 64], y = by[j * 64]; if (minx == x && miny != y) EMIT_XY(x, y); }
-				for (int j = 0; j <= buf_pos; ++j)    { const uint64_t x = bx[j * 64], y = by[j * 64]; if (minx == x && miny != y) EMIT_XY(x, y); }
+	for (;;) {
+		const uint32_t i0 = s0 > lead ? s0 - lead : 0;
+		uint64_t kmer0 = 0, kmer1 = 0; minx = UINT64_MAX; miny = UINT64_MAX;
+		int l = 0, buf_pos = 0, min_pos = 0;
+		uint32_t moved = 0, warm = 0;                                        // even k: window moves after the first k non-N bases of the lead-in
+		bool again = false;
+		for (int j = 0; j < w; ++j) bx[j * 64] = UINT64_MAX, by[j * 64] = UINT64_MAX;
+		uint32_t word = 0;
+		for (uint32_t i = i0; i < e0; ++i) {
+			if (even && i == s0 && i0 > 0 && moved < need) { again = true; break; }
+			const uint64_t gp = base + i;
+			if (i == i0 || (gp & 7) == 0) word = S4[gp >> 3];
+			const int c = (word >> ((gp & 7) << 2)) & 0xf;
+			uint64_t ix = UINT64_MAX, iy = UINT64_MAX;
+			if (c < 4) {
+				const int span = l + 1 < k ? l + 1 : k;
+				kmer0 = (kmer0 << 2 | (uint64_t)c) & mask;
+				kmer1 = (kmer1 >> 2) | (3ULL ^ (uint64_t)c) << shift1;
+				if (even) { if (warm < (uint32_t)k) ++warm; if (kmer0 == kmer1) continue; }   // sketch.c:108 (odd k: never equal)
+				const int z = kmer0 < kmer1 ? 0 : 1;
+				++l;
+				if (l >= k) { ix = di_hash64m(z ? kmer1 : kmer0, mask) << 8 | (uint64_t)span; iy = (uint64_t)rid << 32 | (uint64_t)i << 1 | (uint64_t)z; }
+			} else l = 0;
+			if (even && warm >= (uint32_t)k && i < s0) ++moved;
+			bx[buf_pos * 64] = ix; by[buf_pos * 64] = iy;
+			if (l == w + k - 1 && minx != UINT64_MAX) {                         // sketch.c:117-122
+				for (int j = buf_pos + 1; j < w; ++j) { const uint64_t x = bx[j * 64], y = by[j * 64]; if (minx == x && y != miny) EMIT_XY(x, y); }
+				for (int j = 0; j < buf_pos; ++j)     { const uint64_t x = bx[j * 64], y = by[j * 64]; if (minx == x && y != miny) EMIT_XY(x, y); }
 			}
+			if (ix <= minx) {                                                   // sketch.c:123-125
+				if (l >= w + k && minx != UINT64_MAX) EMIT_XY(minx, miny);
+				minx = ix, miny = iy, min_pos = buf_pos;
+			} else if (buf_pos == min_pos) {                                    // sketch.c:126-138
+				if (l >= w + k - 1 && minx != UINT64_MAX) EMIT_XY(minx, miny);
+				minx = UINT64_MAX;
+				for (int j = buf_pos + 1; j < w; ++j) { const uint64_t x = bx[j * 64]; if (minx >= x) minx = x, miny = by[j * 64], min_pos = j; }
+				for (int j = 0; j <= buf_pos; ++j)    { const uint64_t x = bx[j * 64]; if (minx >= x) minx = x, miny = by[j * 64], min_pos = j; }
+				if (l >= w + k - 1 && minx != UINT64_MAX) {
+					for (int j = buf_pos + 1; j < w; ++j) { const uint64_t x = bx[j * 64], y = by[j * 64]; if (minx == x && miny != y) EMIT_XY(x, y); }
+					for (int j = 0; j <= buf_pos; ++j)    { const uint64_t x = bx[j * 64], y = by[j * 64]; if (minx == x && miny != y) EMIT_XY(x, y); }
+				}
+			}
+			if (++buf_pos == w) buf_pos = 0;
 		}
-		if (++buf_pos == w) buf_pos = 0;
+		if (!again) break;
+		lead *= 2;
 	}
 	if (e0 == len && minx != UINT64_MAX) { const uint32_t i = e0; EMIT_XY(minx, miny); }   // sketch.c:141-142 (end of the contig only)
 #undef EMIT_XY
@@ -171,13 +189,6 @@ extern "C" al_idx_t *al_idx_build_device(const char *fn, const al_idxopt_t *io, 
 	if (device >= n_dev) { fprintf(stderr, "[airlift] FATAL: device %d out of range (%d devices)\n", device, n_dev); return nullptr; }
 	const int w = io->w, k = io->k;
 	if (k < 1 || k > AL_MAX_K || w > 32 || w < 1) { fprintf(stderr, "[airlift] al_idx_build_device: needs k <= %d and w <= 32 (got k=%d w=%d)\n", AL_MAX_K, k, w); return nullptr; }
-	if (!(k & 1)) {
-		// Even k: a k-mer can be its own reverse complement and is then skipped WITHOUT moving the window (sketch.c:108), so inside a palindromic repeat -- (AT)n -- the window
-		// keeps entries from arbitrarily far back, which a lane that starts 2 (w + k) + 8 bases before its segment cannot know.  The serial host builder takes those
-		// references (same index, uploaded once per GPU).
-		if (getenv("AL_TIMING") || getenv("AL_TRACE")) fprintf(stderr, "[airlift] even k = %d: index built by the host builder\n", k);
-		return al_idx_build(fn, io, (int)std::min(32u, std::max(1u, std::thread::hardware_concurrency())));
-	}
 	AlSeqReader rd;
 	if (!rd.open(fn)) { fprintf(stderr, "[ERROR] airlift: failed to open '%s'\n", fn); return nullptr; }
 	al_idx_t *mi = new al_idx_t();

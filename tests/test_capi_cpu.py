@@ -55,7 +55,7 @@ def test_sr_preset_matches_reference_constants(A):
 
 def test_k_limit_is_the_references(A):
     """sketch.c:84 allows k <= 28.  Round 5: the read sketch keeps two words per window slot where its packed 64-bit entry cannot hold hash | position | strand
-    (k of 26 ... 28), and an even k goes through the host index builder -- so the option check accepts what the reference accepts and rejects 29."""
+    (k of 26 ... 28), and the index builders take an even k (round 6: the device builder too) -- so the option check accepts what the reference accepts and rejects 29."""
     L = A.load(); io, mo = A.IdxOpt(), A.MapOpt()
     L.al_set_opt(None, C.byref(io), C.byref(mo)); L.al_set_opt(b"sr", C.byref(io), C.byref(mo))
     for k in (25, 26, 27, 28):

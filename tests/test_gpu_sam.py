@@ -481,7 +481,7 @@ OPTSETS = [
     ["-A", "4", "-B", "4", "-O", "4,24", "-E", "2,1"],      # a + b >= q + e: the closed-form flanks switch themselves off
     ["--score-N", "3", "--seed", "7", "-M", "0.3"],
     ["-k", "27", "-w", "10"],        # round 5: two words per window slot of the read sketch (k > 25)
-    ["-k", "28", "-w", "12"],        # ... and an even k: the host index builder (a k-mer can be its own reverse complement, sketch.c:108)
+    ["-k", "28", "-w", "12"],        # ... and an even k (a k-mer can be its own reverse complement and is then skipped, sketch.c:108; round 6: on the device builder too)
     ["-k", "26", "-w", "8"],
 ]
 

@@ -115,9 +115,9 @@ def test_alser_count(A, golden_unpacked, name):
     ctx.close(); idx.close()
 
 
-def _same_index(A, fasta, n_segs=None, seqs=None, names=None):
-    host = A.Index(fasta=fasta)
-    dev = A.Index(fasta=fasta, on_device=0)
+def _same_index(A, fasta, n_segs=None, seqs=None, names=None, k=None, w=None):
+    host = A.Index(fasta=fasta, k=k, w=w)
+    dev = A.Index(fasta=fasta, on_device=0, k=k, w=w)
     assert host.names == dev.names
     assert host.stat() == dev.stat()
     assert np.array_equal(host.positions(), dev.positions()), "occurrence arrays differ"
@@ -195,6 +195,35 @@ def test_device_built_index_ragged_contigs(A, tmp_path):
             for o in range(0, L, 70):
                 f.write(s[o:o + 70].tobytes() + b"\n")
     _same_index(A, str(fa))
+
+
+@pytest.mark.parametrize("k,w", [(20, 10), (28, 12), (14, 5), (22, 32)])
+def test_device_built_index_even_k_palindromic_repeats(A, tmp_path, k, w):
+    """Even k on the device builder: a k-mer equal to its reverse complement is skipped without moving the window (sketch.c:108), so inside (AT)n, (ACGT)n, (GC)n
+    or a long inverted repeat the window keeps entries from far back; a lane's lead-in is counted in iterations that move the window and doubled until there are
+    enough.  Repeats shorter and much longer than the 256-base segments and the default lead-in, at contig starts and ends, beside N runs; the host builder
+    (checked against the reference's index file in the CPU tests) is the comparison."""
+    rng = np.random.default_rng(1234 + k)
+    def rnd(n):
+        return np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, n)].tobytes()
+    def revcomp(b):
+        return b.translate(bytes.maketrans(b"ACGT", b"TGCA"))[::-1]
+    contigs = []
+    contigs.append(rnd(3000) + b"AT" * 40 + rnd(500) + b"AT" * 700 + rnd(700) + b"ACGT" * 900 + rnd(333) + b"GC" * 2000 + rnd(1000))
+    contigs.append(b"AT" * 3000 + rnd(2000) + b"TA" * 5000)                               # a repeat at the contig's start and at its end
+    contigs.append(rnd(1000) + b"AT" * 300 + b"NNNNN" + b"AT" * 300 + rnd(40) + b"N" + b"CG" * 600 + rnd(1500))
+    stem = rnd(5000); contigs.append(rnd(500) + stem + revcomp(stem) + rnd(500))           # one long inverted repeat: a single palindromic k-mer at its centre
+    unit = rnd(k // 2); pal = unit + revcomp(unit)                                         # a palindromic k-mer as the repeat unit
+    contigs.append(rnd(800) + pal * 400 + rnd(800))
+    contigs.append(b"AT" * 20000)                                                          # nothing but the repeat
+    contigs.append(rnd(70000))
+    fa = tmp_path / ("even_k%d.fa" % k)
+    with open(fa, "wb") as f:
+        for i, s in enumerate(contigs):
+            f.write(b">p%d\n" % i)
+            for o in range(0, len(s), 60):
+                f.write(s[o:o + 60] + b"\n")
+    _same_index(A, str(fa), k=k, w=w)
 
 
 @pytest.mark.parametrize("name", SETS)
