@@ -212,34 +212,71 @@ __device__ __forceinline__ void d_seed_frag(const uint64_t *__restrict__ tab, in
 	int rep_st = 0, rep_en = 0, rep_len = 0; uint32_t n_m = 0, n_a = 0, sum = 0;
 	uint64_t prev_hash = ~0ULL; int have_prev = 0;
 	AlMatch *last = nullptr; uint64_t last_hash = 0; int last_valid = 0;
+	const uint64_t tmask = (1ULL << tab_bits) - 1;
 	for (uint32_t r = r0; r < r1; ++r) {
 		const AlAnchor *mv = mini + mini_off[r];
 		const uint32_t n = mini_cnt[r], seg = r - r0;
-		for (uint32_t i = 0; i < n; ++i) {
-			const uint64_t x = mv[i].x, hash = x >> 8;
-			const uint32_t q_pos = (uint32_t)mv[i].y + (sum << 1), q_span = (uint32_t)(x & 0xff);
-			bool single;
-			const uint64_t v = d_idx_get(tab, tab_bits, hash, single);
-			const uint32_t occ = single ? 1u : (uint32_t)v;
-			// is_tandem (map.c:115-116): equal hash with the previous / next minimizer of the whole list
-			const int same_prev = have_prev && prev_hash == hash;
-			if (mo && same_prev && last_valid && last_hash == hash) last->flags |= 1u << 8;   // previous gets "next is same"
-			last_valid = 0;
-			if (occ > 0 && (int)occ < max_occ2) n_a2 += occ;
-			if ((int)occ >= max_occ) {                                       // map.c:105-111
-				const int en = (int)(q_pos >> 1) + 1, st = en - (int)q_span;
-				if (st > rep_en) { rep_len += rep_en - rep_st; rep_st = st, rep_en = en; }
-				else rep_en = en;
-			} else if (occ > 0) {
-				if (mo) {
-					AlMatch m;
-					m.off_lo = single ? (uint32_t)v : (uint32_t)(v >> 32); m.n = occ; m.q_pos = q_pos;
-					m.flags = seg | (same_prev ? 1u << 8 : 0u) | (single ? (1u << 9 | (uint32_t)(v >> 32) << 16) : 0u);
-					mo[n_m] = m; last = &mo[n_m]; last_hash = hash; last_valid = 1;
+		// (round 6) four minimizers at a time: their records, then the first table slot of each, loaded without a branch around the loads (a lane past the end reads
+		// the last minimizer again), so that four probes are in flight per lane instead of one; a probe that finds another key in its slot walks on as before.
+		// The bookkeeping of collect_matches stays in the list's order.
+		uint64_t xn[4], yn[4];                                                  // the next four's records: asked for beside this four's table slots
+		if (n) {
+#pragma unroll
+			for (int j = 0; j < 4; ++j) { const uint32_t i = (uint32_t)j < n ? (uint32_t)j : n - 1u; const AlAnchor a = mv[i]; xn[j] = a.x; yn[j] = a.y; }
+		}
+		for (uint32_t i0 = 0; i0 < n; i0 += 4) {
+			uint64_t xs[4], ys[4], ex[4], ey[4], sl[4];
+#pragma unroll
+			for (int j = 0; j < 4; ++j) { xs[j] = xn[j]; ys[j] = yn[j]; }
+#pragma unroll
+			for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(xs[j]), "+v"(ys[j]));
+#pragma unroll
+			for (int j = 0; j < 4; ++j) { sl[j] = ((xs[j] >> 8) * 0x9E3779B97F4A7C15ULL) >> (64 - tab_bits); const ulonglong2 e = *reinterpret_cast<const ulonglong2 *>(tab + 2 * sl[j]); ex[j] = e.x; ey[j] = e.y; }
+#pragma unroll
+			for (int j = 0; j < 4; ++j) { const uint32_t i = i0 + 4 + j < n ? i0 + 4 + j : n - 1u; const AlAnchor a = mv[i]; xn[j] = a.x; yn[j] = a.y; }
+#pragma unroll
+			for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(ex[j]), "+v"(ey[j]));
+			// the four's matches stay in registers and are stored after the four (a store inside the walk would be waited for at the next branch that holds a load)
+			AlMatch mk[4]; bool made[4]; uint32_t at[4];
+#pragma unroll
+			for (int j = 0; j < 4; ++j) {
+				made[j] = false; at[j] = 0; mk[j].off_lo = mk[j].n = mk[j].q_pos = mk[j].flags = 0;
+				if (i0 + j < n) {
+					const uint64_t x = xs[j], hash = x >> 8;
+					const uint32_t q_pos = (uint32_t)ys[j] + (sum << 1), q_span = (uint32_t)(x & 0xff);
+					uint64_t kx = ex[j], v = ey[j];
+					if ((kx & ~AL_TAB_SINGLE) != hash + 1 && kx != 0) {          // another key in the slot: walk on (d_idx_get)
+						uint64_t sp = sl[j];
+						do { sp = (sp + 1) & tmask; const ulonglong2 e = *reinterpret_cast<const ulonglong2 *>(tab + 2 * sp); kx = e.x; v = e.y; } while ((kx & ~AL_TAB_SINGLE) != hash + 1 && kx != 0);
+					}
+					const bool found = kx != 0, single = found && (kx & AL_TAB_SINGLE) != 0;
+					if (!found) v = 0;
+					const uint32_t occ = single ? 1u : (uint32_t)v;
+					// is_tandem (map.c:115-116): equal hash with the previous / next minimizer of the whole list
+					const int same_prev = have_prev && prev_hash == hash;
+					if (mo && same_prev && last_valid && last_hash == hash) {      // previous gets "next is same"
+						if (j == 0) last->flags |= 1u << 8;                          // (the previous four's last match: stored already)
+						else mk[j > 0 ? j - 1 : 0].flags |= 1u << 8;                 // (last_valid: the minimizer before this one made a match)
+					}
+					last_valid = 0;
+					if (occ > 0 && (int)occ < max_occ2) n_a2 += occ;
+					if ((int)occ >= max_occ) {                                       // map.c:105-111
+						const int en = (int)(q_pos >> 1) + 1, st = en - (int)q_span;
+						if (st > rep_en) { rep_len += rep_en - rep_st; rep_st = st, rep_en = en; }
+						else rep_en = en;
+					} else if (occ > 0) {
+						if (mo) {
+							mk[j].off_lo = single ? (uint32_t)v : (uint32_t)(v >> 32); mk[j].n = occ; mk[j].q_pos = q_pos;
+							mk[j].flags = seg | (same_prev ? 1u << 8 : 0u) | (single ? (1u << 9 | (uint32_t)(v >> 32) << 16) : 0u);
+							made[j] = true; at[j] = n_m; last = &mo[n_m]; last_hash = hash; last_valid = 1;
+						}
+						++n_m; n_a += occ;
+					}
+					prev_hash = hash; have_prev = 1;
 				}
-				++n_m; n_a += occ;
 			}
-			prev_hash = hash; have_prev = 1;
+#pragma unroll
+			for (int j = 0; j < 4; ++j) if (made[j]) mo[at[j]] = mk[j];
 		}
 		sum += rd_len[r];
 	}
