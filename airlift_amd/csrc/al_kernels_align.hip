@@ -357,6 +357,15 @@ template <> struct HasWin8<RefAcc> { static const bool v = true; };
 template <class A> __device__ __forceinline__ uint32_t d_win8(const A &, int) { return 0; }
 template <> __device__ __forceinline__ uint32_t d_win8<ReadAcc>(const ReadAcc &a, int i) { return a.win8(i); }
 template <> __device__ __forceinline__ uint32_t d_win8<RefAcc>(const RefAcc &a, int i) { return a.win8(i); }
+// four windows of eight bases of a query and a target, their sixteen loads in flight together (a loop of one window per step waits for its loads every step:
+// 19 dependent round trips for a 150-base read)
+template <class QA, class TA> __device__ __forceinline__ void d_win8x4(const QA &q, const int qo, const TA &t, const int to, uint32_t (&qw)[4], uint32_t (&tw)[4])
+{
+#pragma unroll
+	for (int u = 0; u < 4; ++u) { qw[u] = d_win8(q, qo + 8 * u); tw[u] = d_win8(t, to + 8 * u); }
+#pragma unroll
+	for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(qw[u]), "+v"(tw[u]));
+}
 
 template <class QA, class TA>
 __device__ int d_test_zdrop(const AlParams &P, QA qseq, TA tseq, int n_cigar, const uint32_t *cigar)
@@ -435,7 +444,7 @@ __device__ __forceinline__ void d_fix_cigar(AlReg *r, CG cigar, QA qseq, TA tseq
 	}
 }
 
-template <class CG, class QA, class TA>
+template <bool BATCH = false /* four windows' loads at a time: k_ext_prep's one-run hits (in k_ext_finish it costs registers: 5.1 -> 6.3 ms) */, class CG, class QA, class TA>
 __device__ __forceinline__ void d_update_extra(const AlParams &P, AlReg *r, CG cigar, QA qseq0_, TA tseq0_)
 {   // mm_update_extra, align.c:240-286
 	int s = 0, max = 0, qshift, tshift, toff = 0, qoff = 0;
@@ -450,15 +459,34 @@ __device__ __forceinline__ void d_update_extra(const AlParams &P, AlReg *r, CG c
 			if (HasWin8<QA>::v && HasWin8<TA>::v) {
 				// packed sequences: eight bases per step; a window of eight unambiguous matches only raises s (and max with it)
 				const int msc = P.a < 0 ? -P.a : P.a;
-				for (; l + 8 <= len; l += 8) {
-					const uint32_t qw = d_win8(qseq, qoff + (int)l), tw = d_win8(tseq, toff + (int)l);
-					if (qw == tw && !(qw & 0x44444444u)) { s += 8 * msc; max = max > s ? max : s; continue; }
+				auto win = [&](const uint32_t qw, const uint32_t tw) {
+					if (qw == tw && !(qw & 0x44444444u)) { s += 8 * msc; max = max > s ? max : s; return; }
 #pragma unroll
 					for (int b = 0; b < 8; ++b) {
 						const int cq = (int)(qw >> (4 * b) & 0xf), ct = (int)(tw >> (4 * b) & 0xf);
 						if (ct > 3 || cq > 3) ++n_ambi; else if (ct != cq) ++n_diff;
 						s += d_mat(P, ct, cq);
 						if (s < 0) s = 0; else max = max > s ? max : s;
+					}
+				};
+				if constexpr (BATCH) {
+					for (; l + 32 <= len; l += 32) {
+						uint32_t qw[4], tw[4]; d_win8x4(qseq, qoff + (int)l, tseq, toff + (int)l, qw, tw);
+#pragma unroll
+						for (int u = 0; u < 4; ++u) win(qw[u], tw[u]);
+					}
+					for (; l + 8 <= len; l += 8) win(d_win8(qseq, qoff + (int)l), d_win8(tseq, toff + (int)l));
+				} else {
+					for (; l + 8 <= len; l += 8) {
+						const uint32_t qw = d_win8(qseq, qoff + (int)l), tw = d_win8(tseq, toff + (int)l);
+						if (qw == tw && !(qw & 0x44444444u)) { s += 8 * msc; max = max > s ? max : s; continue; }
+#pragma unroll
+						for (int b = 0; b < 8; ++b) {
+							const int cq = (int)(qw >> (4 * b) & 0xf), ct = (int)(tw >> (4 * b) & 0xf);
+							if (ct > 3 || cq > 3) ++n_ambi; else if (ct != cq) ++n_diff;
+							s += d_mat(P, ct, cq);
+							if (s < 0) s = 0; else max = max > s ? max : s;
+						}
 					}
 				}
 			}
@@ -1832,9 +1860,8 @@ __device__ __forceinline__ void d_ext_prep_frag(const int f, const int lane, con
 			int k = 0;
 			{   // eight bases per step; eight unambiguous matches raise both running scores monotonically
 				const int msc = P.a < 0 ? -P.a : P.a;
-				for (; k + 8 <= len; k += 8) {
-					const uint32_t qw = Q.win8(k), tw = T.win8(k);
-					if (qw == tw && !(qw & 0x44444444u)) { sc += 8 * P.a; zs += 8 * msc; if (zs >= zmax) zmax = zs; else { const int z = zmax - zs; if (z > zdrop_max) zdrop_max = z; } continue; }
+				auto win = [&](const uint32_t qw, const uint32_t tw) {
+					if (qw == tw && !(qw & 0x44444444u)) { sc += 8 * P.a; zs += 8 * msc; if (zs >= zmax) zmax = zs; else { const int z = zmax - zs; if (z > zdrop_max) zdrop_max = z; } return; }
 #pragma unroll
 					for (int b = 0; b < 8; ++b) {
 						const int cq = (int)(qw >> (4 * b) & 0xf), ct = (int)(tw >> (4 * b) & 0xf);
@@ -1843,7 +1870,13 @@ __device__ __forceinline__ void d_ext_prep_frag(const int f, const int lane, con
 						if (zs < zmax) { const int z = zmax - zs; if (z > zdrop_max) zdrop_max = z; }   // diff = 0 along the diagonal
 						else zmax = zs;
 					}
+				};
+				for (; k + 32 <= len; k += 32) {                                 // (round 6) four windows' loads at a time
+					uint32_t qw[4], tw[4]; d_win8x4(Q, k, T, k, qw, tw);
+#pragma unroll
+					for (int u = 0; u < 4; ++u) win(qw[u], tw[u]);
 				}
+				for (; k + 8 <= len; k += 8) win(Q.win8(k), T.win8(k));
 			}
 			for (; k < len; ++k) {
 				const int cq = Q(k), ct = T(k);
@@ -1987,7 +2020,7 @@ __device__ __forceinline__ void d_ext_prep_frag(const int f, const int lane, con
 			R.n_cigar = 1; R.flags |= ALR_HAS_P;
 			R.rs = rs1; R.re = re1;
 			if (rev) { R.qs = qlen - qe1; R.qe = qlen - qs1; } else { R.qs = qs1; R.qe = qe1; }
-			d_update_extra(P, &R, cg1, ReadAcc{seq, qlen, rev, qs1}, RefAcc{G.S4, ref_off + (uint64_t)rs1});
+			d_update_extra<true>(P, &R, cg1, ReadAcc{seq, qlen, rev, qs1}, RefAcc{G.S4, ref_off + (uint64_t)rs1});
 			R.cig_inl[0] = cg1[0]; R.cig_inl[1] = R.cig_inl[2] = R.cig_inl[3] = 0; R.cigar_off = AL_CIG_INLINE;
 			regs[i] = R;
 			++c_regs; c_ref += (unsigned long long)(x.re0 - x.rs0); c_cig += 1;

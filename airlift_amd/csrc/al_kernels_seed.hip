@@ -56,9 +56,15 @@ d_sketch(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_of
 #define HX(e) ((e) >> pb)
 	const uint64_t ymask = (1ULL << pb) - 1ULL;
 #define EMIT(e) do { const uint64_t e__ = (e); out[cnt].x = HX(e__) << 8 | (uint64_t)k; out[cnt].y = e__ & ymask; ++cnt; } while (0)
-	uint32_t word = 0;
-	for (uint32_t i = 0; i < len; ++i) {
-		if ((i & 7) == 0) word = seq[i >> 3];
+	// (round 6) a word of eight bases per outer step, the next word asked for at the top of the step (no branch around the load: `if ((i & 7) == 0) word = ...` made
+	// every eighth base wait for its load and for the minimizers stored since)
+	const uint32_t nw = (len + 7) >> 3;
+	uint32_t wnext = nw ? seq[0] : 0u;
+	for (uint32_t wi = 0; wi < nw; ++wi) {
+	const uint32_t word = wnext;
+	wnext = seq[wi + 1 < nw ? wi + 1 : nw - 1];
+	const uint32_t iend = (wi + 1) * 8 < len ? (wi + 1) * 8 : len;
+	for (uint32_t i = wi * 8; i < iend; ++i) {
 		const int c = (word >> ((i & 7) << 2)) & 0xf;
 		uint64_t info = UINT64_MAX;
 		if (c < 4) {
@@ -94,6 +100,7 @@ d_sketch(const uint32_t *__restrict__ rd_seq, const uint64_t *__restrict__ rd_of
 			}
 		}
 		if (++buf_pos == w) buf_pos = 0;
+	}
 	}
 	if (mn != UINT64_MAX) EMIT(mn);
 #undef HX
