@@ -2737,15 +2737,14 @@ int al_run_align_stage(al_ctx_t *c)
 		{ uint32_t i9 = (uint32_t)nf; AL_HIP_CHECK(hipMemcpyAsync(c->lb_buf.p, &i9, 4, hipMemcpyHostToDevice, s)); hipLaunchKernelGGL(k_lower_bounds, dim3((nf + 255) / 256), dim3(256), 0, s, (const uint32_t *)c->chain_key.p, (uint32_t)nf, T, c->lb_buf.p);
 		  AL_HIP_CHECK(hipMemcpyAsync(&i9, c->lb_buf.p, 4, hipMemcpyDeviceToHost, s)); AL_HIP_CHECK(hipStreamSynchronize(s)); heavy_from = i9; heavy_n = (uint32_t)nf - i9; }
 		// The classes are disjoint sets of fragments.  Two fill the chip (65 ... 256 and 257 ... 1024 chains: hundreds of thousands of blocks); the
-		// others are a few hundred to a few thousand blocks that sort for a millisecond: on the side streams (higher priority: their blocks get the
-		// next free CU slot instead of queueing behind the small blocks), beside the two.  4097 ... 8192 chains: the sort tile is 80 KB; its sort
+		// others are a few hundred to a few thousand blocks that sort for a millisecond: on the side streams, beside the two.  4097 ... 8192 chains: the sort tile is 80 KB; its sort
 		// leaves keys and order in the work area for a one-wavefront pass (k_regs_select<-2>).
 		static const int split = getenv("AL_REGS_SPLIT") ? atoi(getenv("AL_REGS_SPLIT")) : 1;   // bit 0: 257 ... 1024 chains sorted and passed over by two kernels as well (4.6 + 2.2 ms against 7.7 in one: the pass alone fits twelve blocks a CU)
 #define LSEL(CAPV, PH, NT, A, B, ST) do { if ((B) > (A)) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_select<CAPV, PH>), dim3((B) - (A)), dim3(NT), 0, ST, c->chained.p, c->u.p, c->uo.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, ord + (A), (int)((B) - (A)), c->P, regs_n0); } while (0)
 		AL_HIP_CHECK(hipEventRecord(c->ev_fj[0], s));
 		for (int i = 0; i < 3; ++i) AL_HIP_CHECK(hipStreamWaitEvent(c->aux[i], c->ev_fj[0], 0));
-		// (round 6) the 4097 ... 8192 class on a side stream BESIDE the chip-filling classes (its sort, then its one-wavefront pass k_regs_select<-2>): with the
-		// side streams' priority its blocks do get the CUs they need (6.5 ms beside the others instead of 4.3 ms before them: regs 16.5 -> 15.7 ms)
+		// (round 6) the 4097 ... 8192 class on a side stream BESIDE the chip-filling classes (its sort, then its one-wavefront pass k_regs_select<-2>), launched first:
+		// 6.5 ms beside the others instead of 4.3 ms before them (regs 16.5 -> 15.7 ms; round 4 had measured 20 ms beside them, with the sort and the pass in one kernel)
 		LSEL(8192, 1, 512, lb[5], lb[3], c->aux[0]);
 		LSEL(-2, 0, 64, lb[5], lb[3], c->aux[0]);
 		LSEL(4096, 0, 256, lb[4], lb[5], c->aux[1]);
