@@ -1320,6 +1320,7 @@ k_anchor_run_merge(const uint64_t *__restrict__ kin, uint64_t *__restrict__ kout
 	const uint32_t ent = g.ent, f = g.f, n = g.n, o = g.o, la = g.la, lb = g.lb, d0 = g.d0, d1 = g.d1, tot = d1 - d0; const int last = g.last;
 	const uint64_t L = (uint64_t)run_len << pass;
 	const uint64_t *A = kin + big_off[ent] + g.A0, *B = A + L;
+	if (tot == 0) return;                                                     // (block-uniform; every tile of a fragment holds a key)
 	if (lb == 0 && pass < last) {   // a run without a partner in this pass: copied  (lb == 0 in the last pass: a fragment of one run -- tests lower the class bound)
 		uint64_t *out = kout + big_off[ent] + o;
 		for (uint32_t t = tid; t < tot; t += NT) out[t] = A[d0 + t];
@@ -1328,7 +1329,20 @@ k_anchor_run_merge(const uint64_t *__restrict__ kin, uint64_t *__restrict__ kout
 	const uint32_t a0 = lb ? cuts[blk] : d0, a1 = !lb ? d1 : d1 == la + lb ? la : cuts[blk + 1];   // (d1 < la + lb: the next tile is this pair's too)
 	(void)n;
 	const uint32_t b0 = d0 - a0, b1 = d1 - a1, na = a1 - a0, nb = b1 - b0;
-	for (uint32_t t = tid; t < tot; t += NT) sk[t] = t < na ? A[a0 + t] : B[b0 + (t - na)];
+	{   // (round 6) the tile's PER loads per thread in flight together: one address per key (run A's or run B's), no branch around the load -- a thread past the tile's end reads
+		// its last key again -- the stores to LDS after them (`sk[t] = t < na ? A[..] : B[..]` in a loop waited for every key's load in turn: 1.25 -> ms per pass of 238 M keys)
+		uint64_t kk[PER];
+#pragma unroll
+		for (int r = 0; r < PER; ++r) {
+			const uint32_t t = (uint32_t)tid + (uint32_t)r * NT, tc = t < tot ? t : tot - 1u;
+			const uint64_t *src = tc < na ? A + a0 + tc : B + b0 + (tc - na);
+			kk[r] = *src;
+		}
+#pragma unroll
+		for (int r = 0; r < PER; ++r) asm volatile("" : "+v"(kk[r]));
+#pragma unroll
+		for (int r = 0; r < PER; ++r) { const uint32_t t = (uint32_t)tid + (uint32_t)r * NT; if (t < tot) sk[t] = kk[r]; }
+	}
 	__syncthreads();
 	uint64_t v[PER];
 	{
@@ -1365,15 +1379,26 @@ k_anchor_run_merge(const uint64_t *__restrict__ kin, uint64_t *__restrict__ kout
 	AlAnchor *out = O.anchors + O.a_off[f] + o;
 	const int sbit = 32 + O.rid_bits; const uint64_t lowmask = (1ULL << sbit) - 1; const uint32_t span = (uint32_t)O.mini_span;
 	int tie = 0;
-	for (uint32_t t = tid; t < tot; t += NT) {
-		const uint64_t key = sk[t + 1]; const uint32_t i = (uint32_t)key & 0xffffu; const uint64_t kx = key >> 16;
-		if ((sk[t] >> 16) == kx) tie = 1;
-		const AlMatch mm = m[i];
-		AlAnchor a; a.x = (kx & lowmask) | (kx >> sbit & 1) << 63;
-		a.y = (a.x >> 63) ? (uint64_t)span << 32 | (uint32_t)(qlen - ((int)(mm.q_pos >> 1) + 1 - (int)span) - 1) : (uint64_t)span << 32 | (mm.q_pos >> 1);
-		a.y |= (uint64_t)(mm.flags & 0xff) << AL_SEED_SEG_SHIFT;
-		if (mm.flags & (1u << 8)) a.y |= AL_SEED_TANDEM;
-		out[t] = a;
+	{   // the PER match records of a thread's keys loaded together, then the anchors stored
+		uint64_t kx[PER]; uint32_t qp[PER], fl[PER];
+#pragma unroll
+		for (int r = 0; r < PER; ++r) {
+			const uint32_t t = (uint32_t)tid + (uint32_t)r * NT, tc = t < tot ? t : tot - 1u;
+			const uint64_t key = sk[tc + 1]; kx[r] = key >> 16;
+			if (t < tot && (sk[tc] >> 16) == kx[r]) tie = 1;
+			const AlMatch mm = m[(uint32_t)key & 0xffffu]; qp[r] = mm.q_pos; fl[r] = mm.flags;
+		}
+#pragma unroll
+		for (int r = 0; r < PER; ++r) asm volatile("" : "+v"(qp[r]), "+v"(fl[r]));
+#pragma unroll
+		for (int r = 0; r < PER; ++r) {
+			const uint32_t t = (uint32_t)tid + (uint32_t)r * NT;
+			AlAnchor a; a.x = (kx[r] & lowmask) | (kx[r] >> sbit & 1) << 63;
+			a.y = (a.x >> 63) ? (uint64_t)span << 32 | (uint32_t)(qlen - ((int)(qp[r] >> 1) + 1 - (int)span) - 1) : (uint64_t)span << 32 | (qp[r] >> 1);
+			a.y |= (uint64_t)(fl[r] & 0xff) << AL_SEED_SEG_SHIFT;
+			if (fl[r] & (1u << 8)) a.y |= AL_SEED_TANDEM;
+			if (t < tot) out[t] = a;
+		}
 	}
 	if (tie) O.tie_list[f] = 1u;                                              // merged again by the heap kernels (exact order among equal x)
 }
