@@ -1355,7 +1355,24 @@ k_regs_heavy(const AlAnchor *__restrict__ chained, const uint32_t *__restrict__ 
 	__syncthreads();
 	const int tot = s_off[n0];
 	if (tot > AC || (n0 <= RCL && tot <= ACL)) return;                       // the larger / the smaller instantiation, or k_regs, takes it
-	for (int i = 0; i < n0; ++i) { const int as = s_r0[i].as, cnt = s_r0[i].cnt, o = s_off[i]; for (int j = lane; j < cnt; j += 64) s_src[o + j] = a[as + j]; }
+	// (round 6) four hits' anchors per round, their loads without a branch around them (a lane past a hit's count reads the hit's last anchor): one round trip per four
+	// hits instead of one per hit (n0 reaches 200)
+	for (int i0 = 0; i0 < n0; i0 += 4) {
+		AlAnchor v[4]; int as_[4], cnt_[4], o_[4];
+#pragma unroll
+		for (int u = 0; u < 4; ++u) {
+			const int i = i0 + u < n0 ? i0 + u : n0 - 1;
+			as_[u] = s_r0[i].as; cnt_[u] = i0 + u < n0 ? s_r0[i].cnt : 0; o_[u] = s_off[i];
+			const int j = lane < cnt_[u] ? lane : (cnt_[u] > 0 ? cnt_[u] - 1 : 0);
+			v[u] = a[as_[u] + j];
+		}
+#pragma unroll
+		for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(v[u].x), "+v"(v[u].y));
+#pragma unroll
+		for (int u = 0; u < 4; ++u) if (lane < cnt_[u]) s_src[o_[u] + lane] = v[u];
+#pragma unroll
+		for (int u = 0; u < 4; ++u) for (int j = lane + 64; j < cnt_[u]; j += 64) s_src[o_[u] + j] = a[as_[u] + j];   // (chains of more than 64 anchors)
+	}
 	__syncthreads();
 	if (n_segs != 2) {
 		if (lane == 0) {
@@ -1451,12 +1468,17 @@ k_regs_heavy_classify(WsBase W, const uint32_t *__restrict__ list, int n_list, c
 extern "C" __global__ void __launch_bounds__(256, AL_LB_REGS)
 k_regs(const AlAnchor *__restrict__ chained, const uint64_t *__restrict__ u_all, const uint32_t *__restrict__ uo_all, const uint32_t *__restrict__ frag_first,
        const uint32_t *__restrict__ rd_len, const uint32_t *__restrict__ frag_hash, WsBase W, int n_frag, AlParams P, unsigned long long *counters,
-       const uint32_t *__restrict__ regs_n0)
+       const uint32_t *__restrict__ regs_n0, const int part /* 0: every fragment; 1: all but k_regs_heavy's candidates (9 ... 200 kept hits), beside those kernels; 2: the candidates they left */)
 {
 	const int f = blockIdx.x * blockDim.x + threadIdx.x;
 	if (f >= n_frag) return;
 	const uint32_t r0 = frag_first[f], n_segs = frag_first[f + 1] - r0, n_u = W.frag_nu[f];
-	if (regs_n0 && regs_n0[f] == AL_REGS_DONE) return;                        // k_regs_heavy wrote this fragment's hits
+	if (regs_n0) {
+		const uint32_t v = regs_n0[f];
+		if (v == AL_REGS_DONE) return;                                          // k_regs_heavy wrote this fragment's hits
+		const bool cand = v >= 9u && v <= 200u;                                 // (k_regs_heavy turns such a value into AL_REGS_DONE and nothing else: part 1 may run beside it)
+		if (part == 1 ? cand : part == 2 ? !cand : false) return;
+	}
 	W.reg_cnt[r0] = 0; W.seg_na[r0] = 0; W.seg_fast[r0] = 0;
 	if (n_segs > 1) { W.reg_cnt[r0 + 1] = 0; W.seg_na[r0 + 1] = 0; W.seg_fast[r0 + 1] = 0; }
 	if (n_u == 0) return;
@@ -2777,6 +2799,7 @@ int al_run_align_stage(al_ctx_t *c)
 		  if (scrub) { const int v = atoi(scrub); AL_HIP_CHECK(hipMemsetAsync(A->mregs.p, v, A->mregs.cap * sizeof(AlReg), s)); AL_HIP_CHECK(hipMemsetAsync(A->rtmp.p, v, A->rtmp.cap * sizeof(AlReg), s)); AL_HIP_CHECK(hipMemsetAsync(A->rext.p, v, A->rext.cap * sizeof(RegExt), s)); } }
 		W.mregs = A->mregs.p; W.rtmp = A->rtmp.p; W.rext = A->rext.p; W.cap2 = A->cap2.p; W.b2_off = A->b2_off.p;
 	}
+	int regs_part = 0;
 	if (regs_n0 && heavy_n > 0) {
 		// Five tile sizes; every block takes its fragment only if the kept hits fit its tiles and not the next smaller instance's, so the
 		// instances work on disjoint fragments and run side by side.  The code is one lane on LDS copies: what sets the rate is how many
@@ -2792,13 +2815,16 @@ int al_run_align_stage(al_ctx_t *c)
 #define LHV(K, RC, AC, RCL, ACL, LDS, ST) do { if (hv_cnt[K] > 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_regs_heavy<RC, AC, RCL, ACL>), dim3(hv_cnt[K]), dim3(64), LDS, ST, c->chained.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, (const uint32_t *)A->heavy_list.p + (size_t)(K) * heavy_n, (int)hv_cnt[K], c->P, c->counters.p, regs_n0); } while (0)
 		for (int i = 0; i < 3; ++i) AL_HIP_CHECK(hipStreamWaitEvent(c->aux[i], c->ev_fj[0], 0));
 		LHV(3, 72, 1024, 48, 768, lds_s, sd); LHV(2, 48, 768, 24, 512, lds_b, c->aux[0]); LHV(4, 200, 2048, 72, 1024, lds_l, c->aux[1]); LHV(0, 12, 256, 0, 0, lds_a, c->aux[2]);
+		// (round 6) every fragment that is not one of these kernels' candidates: k_regs beside them, behind the shortest class (1.8 ms that used to follow the longest, 4 ms)
+		hipLaunchKernelGGL(k_regs, dim3((nf + 255) / 256), dim3(256), 0, c->aux[2], c->chained.p, c->u.p, c->uo.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, nf, c->P, c->counters.p, (const uint32_t *)regs_n0, 1);
+		regs_part = 2;
 		AL_HIP_CHECK(hipEventRecord(c->ev_fj[1], sd));
 		LHV(1, 24, 512, 12, 256, lds_t, s);                                       // (the fifth tile size on the main stream, beside the other four)
 		for (int i = 0; i < 3; ++i) { AL_HIP_CHECK(hipEventRecord(c->ev_aux[i], c->aux[i])); AL_HIP_CHECK(hipStreamWaitEvent(s, c->ev_aux[i], 0)); }
 #undef LHV
 		AL_HIP_CHECK(hipStreamWaitEvent(s, c->ev_fj[1], 0));
 	}
-	hipLaunchKernelGGL(k_regs, dim3((nf + 255) / 256), dim3(256), 0, s, c->chained.p, c->u.p, c->uo.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, nf, c->P, c->counters.p, (const uint32_t *)regs_n0);
+	hipLaunchKernelGGL(k_regs, dim3((nf + 255) / 256), dim3(256), 0, s, c->chained.p, c->u.p, c->uo.p, c->frag_first.p, c->rd_len.p, c->frag_hash.p, W, nf, c->P, c->counters.p, (const uint32_t *)regs_n0, regs_part);
 	if (getenv("AL_DBG_FRAG")) {   // debugging aid: the chain_post result of one fragment (the kept hits at the front of its regs0 range)
 		const int f = atoi(getenv("AL_DBG_FRAG"));
 		if (f >= 0 && f < nf) {
