@@ -29,6 +29,7 @@ AlAllocSite &al_alloc_site();      // who asked (AL_TRACE_ALLOC lists the large 
 struct AlAllocStat { std::atomic<long long> dev_ns{0}, dev_bytes{0}, dev_calls{0}, host_ns{0}, host_bytes{0}, host_calls{0}; };
 AlAllocStat &al_alloc_stat();
 void al_dev_free(void *p);
+double al_long_batch_cap(double reads); // the stream driver's bound on a long input's batches (reads per batch) for an input of about `reads` reads: AL_LONG_BATCH, else 524 288, 2^20 from 200 M reads (al_runtime.hip)
 long long al_dev_reserve_room();      // bytes the process's reserve still holds free (or is yet to obtain) on the current device; -1 = no reserve there
 hipError_t al_dev_mem_info(size_t *free_b, size_t *total_b);   // hipMemGetInfo plus what the process's reserve (al_device_reserve) holds free
 int al_dev_guard_check();            // AL_TEST_GUARD=1: number of live ranges whose guard zones were written (messages on stderr)

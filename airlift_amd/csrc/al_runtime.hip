@@ -254,6 +254,16 @@ extern "C" int al_device_reserve(int device, uint64_t bytes)
 // occurrence at one minimizer per ~5.7 bases, a table of 16-byte entries at load <= 0.5) + the larger of the index builder's temporaries and the
 // contexts' workspaces + the slots' text.  Workspace bytes per read of a batch follow the reference's size -- seed hits per read grow with its repeat
 // content: ~78 KB per read measured on a 3.1 Gbp reference with 45 % repeats, ~5 KB on a yeast-sized one; AL_RESERVE_KB_PER_READ overrides.
+// Reads per batch of a long input.  Measured on 12.5 M reads of C4 (round 6): batches of 2^20 reads map 11.7 M reads/s against 10.95 M with 524 288 (a batch's serial tails weigh
+// half as much), but the run then holds 183 GB instead of 106 GB, and what a process asks for beyond ~128 GB the driver hands out at 35 - 70 GB/s (it clears the pages): start-up
+// + 1.5 ... 2.9 s, whole process 2.7 -> 4.9 - 5.3 s.  So the large batch is for inputs whose pipeline runs long enough to pay for that: from AL_LONG_BATCH_BIG_FROM reads
+// (default 200 M: ~20 s of pipeline, 7 % of which is 1.4 s).
+double al_long_batch_cap(double reads)
+{
+	static const double fixed = getenv("AL_LONG_BATCH") ? atof(getenv("AL_LONG_BATCH")) : 0.0;
+	static const double big_from = getenv("AL_LONG_BATCH_BIG_FROM") ? atof(getenv("AL_LONG_BATCH_BIG_FROM")) : 2.0e8;
+	return fixed > 0 ? fixed : reads >= big_from ? 1048576.0 : 524288.0;
+}
 extern "C" int64_t al_device_reserve_for_run(int device, const char *ref_fn, int n_fn, const char *const *fn)
 {
 	if (getenv("AL_NO_RESERVE")) return 0;
@@ -269,8 +279,8 @@ extern "C" int64_t al_device_reserve_for_run(int device, const char *ref_fn, int
 	const double index = 0.5 * G + 8.0 * n_min + tab, build_tmp = G + 4.0 * 8.0 * n_min + 4.0 * n_min;
 	const double kb = getenv("AL_RESERVE_KB_PER_READ") ? atof(getenv("AL_RESERVE_KB_PER_READ")) : G >= 1.0e9 ? 85.0 : G >= 2.0e8 ? 40.0 : 12.0;
 	const bool long_input = reads >= 3.0e6;
-	static const double cap_long = getenv("AL_LONG_BATCH") ? atof(getenv("AL_LONG_BATCH")) : 524288.0;   // (the stream driver's bound on a long input's batches)
-	const double batch = long_input ? cap_long : std::min(131072.0, reads), n_ctx = long_input ? 2.0 : 3.0, n_slots = long_input ? 4.0 : 5.0;
+	// (a long input's batch by the stream driver's own rule: at least three batches per context)
+	const double batch = long_input ? std::min(al_long_batch_cap(reads), std::max(262144.0, reads / 6.0)) : std::min(131072.0, reads), n_ctx = long_input ? 2.0 : 3.0, n_slots = long_input ? 4.0 : 5.0;
 	const double ws = n_ctx * batch * kb * 1024.0 + n_slots * batch * 2300.0 + 1.5e9;
 	const double need = index + std::max(build_tmp, ws) * 1.08;
 	if (al_device_reserve(device, (uint64_t)need) != 0) return -1;

@@ -486,8 +486,7 @@ int al_stream_map_files(const al_idx_t *mi, int n_fn, const char **fn, const al_
 					int64_t first = (int64_t)probe_mult * probe_reads;
 					if (long_input && !getenv("AL_PROBE_MULT")) {   // at least three batches per context, at most 2^20 reads, within 60 % of the free memory at ~80 KB per read
 						size_t free_b = 0, total_b = 0;
-						static const double cap_long = getenv("AL_LONG_BATCH") ? atof(getenv("AL_LONG_BATCH")) : 524288.0;
-						double b = std::min(cap_long, std::max(262144.0, est0 / (3.0 * n_ctx_lane)));
+						double b = std::min(al_long_batch_cap(est0 * (double)NL), std::max(262144.0, est0 / (3.0 * n_ctx_lane)));   // (524 288 reads; 2^20 for very long inputs: al_runtime.hip)
 						if (hipSetDevice(mappers[0]->device) == hipSuccess && al_dev_mem_info(&free_b, &total_b) == hipSuccess) b = std::min(b, 0.6 * (double)free_b / ((double)n_ctx_lane * 81920.0));
 						first = std::max<int64_t>(first, (int64_t)b);
 					}
