@@ -44,24 +44,32 @@ AL_D uint64_t d_hash64(uint64_t key)
 }
 
 AL_D void d_reg_set_coor(AlReg *r, int32_t qlen, const AlAnchor *a)
-{   // mm_reg_set_coor + mm_cal_fuzzy_len, hit.c:8-41
-	const int32_t k = r->as, q_span = (int32_t)(a[k].y >> 32 & 0xff);
-	const int rev = (int)(a[k].x >> 63);
+{   // mm_reg_set_coor + mm_cal_fuzzy_len, hit.c:8-41.  (round 6) Everything is computed in locals and stored once: through `r` every `r->blen += ...` of the fuzzy-length
+	// loop was a load, an add and a store that the next iteration waited for (the compiler cannot know that `r` and `a` do not overlap) -- 6600 cycles per hit in k_regs_heavy.
+	const int32_t k = r->as, cnt = r->cnt;
+	const AlAnchor a0 = a[k], a1 = a[k + cnt - 1];
+	const int32_t q_span = (int32_t)(a0.y >> 32 & 0xff);
+	const int rev = (int)(a0.x >> 63);
 	r->flags = (r->flags & ~ALR_REV) | (rev ? ALR_REV : 0);
-	r->rid = (int32_t)(a[k].x << 1 >> 33);
-	r->rs = (int32_t)a[k].x + 1 > q_span ? (int32_t)a[k].x + 1 - q_span : 0;
-	r->re = (int32_t)a[k + r->cnt - 1].x + 1;
-	if (!rev) { r->qs = (int32_t)a[k].y + 1 - q_span; r->qe = (int32_t)a[k + r->cnt - 1].y + 1; }
-	else { r->qs = qlen - ((int32_t)a[k + r->cnt - 1].y + 1); r->qe = qlen - ((int32_t)a[k].y + 1 - q_span); }
-	r->mlen = r->blen = 0;
-	if (r->cnt <= 0) return;
-	r->mlen = r->blen = q_span;
-	for (int i = r->as + 1; i < r->as + r->cnt; ++i) {
-		const int span = (int)(a[i].y >> 32 & 0xff);
-		const int tl = (int32_t)a[i].x - (int32_t)a[i - 1].x, ql = (int32_t)a[i].y - (int32_t)a[i - 1].y;
-		r->blen += tl > ql ? tl : ql;
-		r->mlen += tl > span && ql > span ? span : tl < ql ? tl : ql;
+	r->rid = (int32_t)(a0.x << 1 >> 33);
+	r->rs = (int32_t)a0.x + 1 > q_span ? (int32_t)a0.x + 1 - q_span : 0;
+	r->re = (int32_t)a1.x + 1;
+	if (!rev) { r->qs = (int32_t)a0.y + 1 - q_span; r->qe = (int32_t)a1.y + 1; }
+	else { r->qs = qlen - ((int32_t)a1.y + 1); r->qe = qlen - ((int32_t)a0.y + 1 - q_span); }
+	int32_t mlen = 0, blen = 0;
+	if (cnt > 0) {
+		mlen = blen = q_span;
+		AlAnchor p = a0;
+		for (int i = k + 1; i < k + cnt; ++i) {
+			const AlAnchor c = a[i];
+			const int span = (int)(c.y >> 32 & 0xff);
+			const int tl = (int32_t)c.x - (int32_t)p.x, ql = (int32_t)c.y - (int32_t)p.y;
+			blen += tl > ql ? tl : ql;
+			mlen += tl > span && ql > span ? span : tl < ql ? tl : ql;
+			p = c;
+		}
 	}
+	r->mlen = mlen; r->blen = blen;
 }
 
 AL_D void d_reg_clear(AlReg *r) { int32_t *p = (int32_t *)r; for (int i = 0; i < (int)(sizeof(AlReg) / 4); ++i) p[i] = 0; }
@@ -82,14 +90,16 @@ AL_D bool d_gen_regs(uint32_t hash, int qlen, int n_u, const uint64_t *u, const 
 	}
 	const bool tie = d_sort128(z, n_u, z + n_u);
 	for (int i = 0; i < n_u >> 1; ++i) { AlAnchor t = z[i]; z[i] = z[n_u - 1 - i]; z[n_u - 1 - i] = t; }
-	for (int i = 0; i < n_u; ++i) {
-		AlReg *ri = &r[i];
-		d_reg_clear(ri);
-		ri->id = i; ri->parent = AL_PARENT_UNSET;
-		ri->score = ri->score0 = (int32_t)(z[i].x >> 32);
-		ri->hash = (uint32_t)z[i].x;
-		ri->cnt = (int32_t)z[i].y; ri->as = (int32_t)(z[i].y >> 32);
-		d_reg_set_coor(ri, qlen, a);
+	for (int i = 0; i < n_u; ++i) {   // (the record is made in registers and stored once)
+		const AlAnchor zi = z[i];
+		AlReg R;
+		d_reg_clear(&R);
+		R.id = i; R.parent = AL_PARENT_UNSET;
+		R.score = R.score0 = (int32_t)(zi.x >> 32);
+		R.hash = (uint32_t)zi.x;
+		R.cnt = (int32_t)zi.y; R.as = (int32_t)(zi.y >> 32);
+		d_reg_set_coor(&R, qlen, a);
+		r[i] = R;
 	}
 	return tie;
 }
@@ -157,6 +167,56 @@ AL_D void d_set_parent(float mask_level, int n, AlReg *r, int sub_diff, uint64_t
 			}
 		}
 		if (j == k) { w[k++] = i; ri->parent = i; ri->n_sub = 0; }
+	}
+}
+// The same with the primaries' query intervals kept beside their indices (w[n + j] = qs << 16 | qe of primary j; reads are at most 32 768 bases): the two loops over the
+// primaries read one word per primary instead of following w[j] to the record's qs and qe (three dependent LDS reads).  k_regs_heavy (w: 2 n ints).
+AL_D void d_set_parent_pq(float mask_level, int n, AlReg *r, int sub_diff, uint64_t *cov, int *w)
+{
+	if (n <= 0) return;
+	for (int i = 0; i < n; ++i) r[i].id = i;
+	w[0] = 0; r[0].parent = 0; w[n] = (int)((uint32_t)r[0].qs << 16 | (uint32_t)r[0].qe);
+	int k = 1;
+	for (int i = 1; i < n; ++i) {
+		AlReg *ri = &r[i];
+		const int si = ri->qs, ei = ri->qe; int n_cov = 0, uncov_len = 0, j;
+		for (j = 0; j < k; ++j) {
+			const uint32_t q = (uint32_t)w[n + j]; int sj = (int)(q >> 16), ej = (int)(q & 0xffffu);
+			if (ej <= si || sj >= ei) continue;
+			if (sj < si) sj = si;
+			if (ej > ei) ej = ei;
+			cov[n_cov++] = (uint64_t)(uint32_t)sj << 32 | (uint32_t)ej;
+		}
+		j = k;   // "goto set_parent_test" with no overlap leaves j == k
+		if (n_cov > 0) {
+			int x = si;
+			d_sort64(cov, n_cov);
+			for (int jj = 0; jj < n_cov; ++jj) {
+				if ((int)(cov[jj] >> 32) > x) uncov_len += (int)(cov[jj] >> 32) - x;
+				x = (int32_t)cov[jj] > x ? (int32_t)cov[jj] : x;
+			}
+			if (ei > x) uncov_len += ei - x;
+			for (j = 0; j < k; ++j) {
+				const uint32_t q = (uint32_t)w[n + j]; const int sj = (int)(q >> 16), ej = (int)(q & 0xffffu);
+				if (ej <= si || sj >= ei) continue;
+				const int mn = ej - sj < ei - si ? ej - sj : ei - si, mx = ej - sj > ei - si ? ej - sj : ei - si;
+				const int ol = si < sj ? (ei < sj ? 0 : ei < ej ? ei - sj : ej - sj) : (ej < si ? 0 : ej < ei ? ej - si : ei - si);
+				if (__fsub_rn(al_fdiv((float)ol, (float)mn), al_fdiv((float)uncov_len, (float)mx)) > mask_level) {
+					AlReg *rp = &r[w[j]];
+					int cnt_sub = 0;
+					ri->parent = rp->parent;
+					rp->subsc = rp->subsc > ri->score ? rp->subsc : ri->score;
+					if (ri->cnt >= rp->cnt) cnt_sub = 1;
+					if ((rp->flags & ALR_HAS_P) && (ri->flags & ALR_HAS_P) && (rp->rid != ri->rid || rp->rs != ri->rs || rp->re != ri->re || ol != mn)) {
+						rp->dp_max2 = rp->dp_max2 > ri->dp_max ? rp->dp_max2 : ri->dp_max;
+						if (rp->dp_max - ri->dp_max <= sub_diff) cnt_sub = 1;
+					}
+					if (cnt_sub) ++rp->n_sub;
+					break;
+				}
+			}
+		}
+		if (j == k) { w[n + k] = (int)((uint32_t)si << 16 | (uint32_t)ei); w[k++] = i; ri->parent = i; ri->n_sub = 0; }
 	}
 }
 
@@ -275,8 +335,9 @@ AL_D int d_squeeze_a(int n_regs, AlReg *regs, AlAnchor *a, uint64_t *aux)
 	d_sort64(aux, n_regs);
 	for (int i = 0; i < n_regs; ++i) {
 		AlReg *r = &regs[(int32_t)aux[i]];
-		if (r->as != as) { for (int j = 0; j < r->cnt; ++j) a[as + j] = a[r->as + j]; r->as = as; }   // memmove to lower addresses
-		as += r->cnt;
+		const int ras = r->as, rcnt = r->cnt;                                   // (locals: `a` and `r` may overlap for all the compiler knows)
+		if (ras != as) { for (int j = 0; j < rcnt; ++j) a[as + j] = a[ras + j]; r->as = as; }   // memmove to lower addresses
+		as += rcnt;
 	}
 	return as;
 }

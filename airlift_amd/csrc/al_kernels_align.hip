@@ -1332,6 +1332,7 @@ k_regs_heavy(const AlAnchor *__restrict__ chained, const uint32_t *__restrict__ 
 	uint32_t *const s_res = (uint32_t *)(s_as + RC);
 	const int lane = threadIdx.x;
 	if ((int)blockIdx.x >= n_list) return;
+	const long long tk0 = clock64();
 	const uint32_t f = list[blockIdx.x];
 	const uint32_t pre = regs_n0[f];
 	if (pre == AL_REGS_UNSET || pre == AL_REGS_DONE || AL_REGS_BAIL(pre) || pre < 9u || pre > (uint32_t)RC) return;
@@ -1341,7 +1342,18 @@ k_regs_heavy(const AlAnchor *__restrict__ chained, const uint32_t *__restrict__ 
 	const int ql0 = (int)rd_len[r0], ql1 = n_segs > 1 ? (int)rd_len[r0 + 1] : 0;
 	const AlAnchor *a = chained + W.a_off[f];
 	// stage the kept hits; anchors of hit i at s_off[i] (single end: in ascending order of `as`, which is what squeezing leaves)
-	for (int i = lane; i < n0 * (int)(sizeof(AlReg) / 4); i += 64) ((uint32_t *)s_r0)[i] = ((const uint32_t *)ws.regs0)[i];
+	{   // the kept hits' records, four words per lane in flight (a lane past the end reads the last word again)
+		const int nw = n0 * (int)(sizeof(AlReg) / 4);
+		for (int i0 = 0; i0 < nw; i0 += 256) {
+			uint32_t v[4];
+#pragma unroll
+			for (int u = 0; u < 4; ++u) { const int i = i0 + u * 64 + lane; v[u] = ((const uint32_t *)ws.regs0)[i < nw ? i : nw - 1]; }
+#pragma unroll
+			for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(v[u]));
+#pragma unroll
+			for (int u = 0; u < 4; ++u) { const int i = i0 + u * 64 + lane; if (i < nw) ((uint32_t *)s_r0)[i] = v[u]; }
+		}
+	}
 	__syncthreads();
 	if (lane == 0) {
 		int tot = 0;
@@ -1421,10 +1433,75 @@ k_regs_heavy(const AlAnchor *__restrict__ chained, const uint32_t *__restrict__ 
 		}
 		__syncthreads();
 		bool tie = false; int na_sq = 0;
+		// (round 6) mm_gen_regs of the two mates by the whole wavefront.  One lane's insertion sort of the kept hits (radix_sort_128x below 65 elements, ksort.h) was half of this
+		// kernel -- 6600 cycles per hit at 15 hits per mate: O(n^2) moves of 16-byte LDS records.  It is a STABLE ascending sort followed by a reversal, so hit e goes to
+		// n - 1 - #{j : x_j < x_e or (x_j = x_e and j < e)}: a lane per hit counts that over n broadcast reads.  The keys (a lane per hit, the hits' anchor offsets by a wavefront
+		// scan) and the records (a lane per hit: coordinates and fuzzy lengths walk the hit's anchors) likewise; above 64 hits the reference takes its radix passes, whose
+		// order only the serial restatement reproduces: lane m for mate m, as before.  mm_set_parent and the squeeze stay one lane per mate.
+		const long long tg0 = (P.dbg2 & 16) ? clock64() : 0;
+		const uint32_t fh = frag_hash[f];
+#pragma unroll 1
+		for (int m = 0; m < 2; ++m) {
+			const int n = (int)s_res[m]; const uint64_t *su = m ? s_su1 : s_su0; const AlAnchor *sa = m ? sa1 : s_sa; AlAnchor *z = m ? s_aux128b : s_aux128;
+			int run = 0;
+			for (int base = 0; base < n; base += 64) {                         // keys: hit.c:60-67
+				const int i = base + lane; const bool on = i < n;
+				const uint64_t ui = on ? su[i] : 0ULL; const int c = (int32_t)(uint32_t)ui;
+				int incl = c;
+				for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+				const int k = run + incl - c;
+				if (on) {
+					const AlAnchor ak = sa[k];
+					const uint32_t h = (uint32_t)d_hash64((d_hash64(ak.x) + d_hash64(ak.y)) ^ fh);
+					AlAnchor e; e.x = ui ^ (uint64_t)h; e.y = (uint64_t)k << 32 | (uint32_t)(int32_t)(uint32_t)ui;
+					z[i] = e;
+				}
+				run += __shfl(incl, 63);
+			}
+		}
+		__syncthreads();
+#pragma unroll 1
+		for (int m = 0; m < 2; ++m) {                                            // order: descending by key, equal keys as the reference's sort leaves them
+			const int n = (int)s_res[m]; AlAnchor *z = m ? s_aux128b : s_aux128;
+			if (n > 64 || n <= 0) continue;
+			AlAnchor e; e.x = 0; e.y = 0; if (lane < n) e = z[lane];
+			int rank = 0;
+			for (int j = 0; j < n; ++j) { const uint64_t xj = z[j].x; rank += (xj < e.x || (xj == e.x && j < lane)) ? 1 : 0; }
+			__syncthreads();
+			if (lane < n) z[n - 1 - rank] = e;
+		}
+		__syncthreads();
 		if (lane < 2) {
-			const bool m1 = lane == 1;
-			tie = d_regs_mate(P, frag_hash[f], m1 ? ql1 : ql0, (int)s_res[m1 ? 1 : 0], m1 ? s_su1 : s_su0, m1 ? sa1 : s_sa, m1 ? s_m1 : s_m0,
-			                  m1 ? s_aux128b : s_aux128, m1 ? s_aux64b : s_aux64, m1 ? s_auxib : s_auxi, m1 ? 1u << 8 : 0u, na_sq);
+			const int n = (int)s_res[lane]; AlAnchor *z = lane ? s_aux128b : s_aux128;
+			if (n > 64) {
+				tie = d_sort128(z, n, z + n);
+				for (int i = 0; i < n >> 1; ++i) { const AlAnchor t = z[i]; z[i] = z[n - 1 - i]; z[n - 1 - i] = t; }
+			}
+		}
+		__syncthreads();
+#pragma unroll 1
+		for (int m = 0; m < 2; ++m) {                                            // records: hit.c:70-86, then the mate's flags (hit.c:397-399)
+			const int n = (int)s_res[m], ql = m ? ql1 : ql0; const AlAnchor *sa = m ? sa1 : s_sa; const AlAnchor *z = m ? s_aux128b : s_aux128; AlReg *mreg = m ? s_m1 : s_m0;
+			for (int i = lane; i < n; i += 64) {
+				const AlAnchor zi = z[i];
+				AlReg R; d_reg_clear(&R);
+				R.id = i; R.parent = AL_PARENT_UNSET;
+				R.score = R.score0 = (int32_t)(zi.x >> 32);
+				R.hash = (uint32_t)zi.x;
+				R.cnt = (int32_t)zi.y; R.as = (int32_t)(zi.y >> 32);
+				d_reg_set_coor(&R, ql, sa);
+				R.flags |= ALR_SEG_SPLIT | (m ? 1u << 8 : 0u);
+				mreg[i] = R;
+			}
+		}
+		__syncthreads();
+		const long long tg1 = (P.dbg2 & 16) ? clock64() : 0;
+		if (lane < 2) {
+			const bool m1 = lane == 1; const int n = (int)s_res[m1 ? 1 : 0]; AlReg *mreg = m1 ? s_m1 : s_m0;
+			d_set_parent_pq(P.mask_level, n, mreg, P.a * 2 + P.b, m1 ? s_aux64b : s_aux64, m1 ? s_auxib : s_auxi);   // map.c:401 (s_auxi: 2 RC + 4 ints per mate)
+			const long long tg2 = (P.dbg2 & 16) ? clock64() : 0;
+			na_sq = d_squeeze_a(n, mreg, m1 ? sa1 : s_sa, m1 ? s_aux64b : s_aux64);                                  // align.c:873
+			if ((P.dbg2 & 16) && lane == 0) { const long long tg3 = clock64(); atomicAdd(&counters[24], (unsigned long long)(tg1 - tg0)); atomicAdd(&counters[25], (unsigned long long)(tg2 - tg1)); atomicAdd(&counters[26], (unsigned long long)(tg3 - tg2)); atomicAdd(&counters[27], (unsigned long long)n); }
 		}
 		const unsigned long long tb = __ballot(tie);
 		const int na1 = __shfl(na_sq, 1);
@@ -1440,6 +1517,7 @@ k_regs_heavy(const AlAnchor *__restrict__ chained, const uint32_t *__restrict__ 
 		W.reg_cnt[r0] = cnt0; W.seg_na[r0] = sna0; W.seg_fast[r0] = 0;
 		if (n_segs > 1) { W.reg_cnt[r0 + 1] = cnt1; W.seg_na[r0 + 1] = sna1; W.seg_fast[r0 + 1] = 0; }
 		if (s_res[4]) atomicAdd(&counters[10], 1ULL);
+		if (P.dbg2 & 16) { atomicAdd(&counters[28], (unsigned long long)(clock64() - tk0)); atomicAdd(&counters[29], 1ULL); }
 		regs_n0[f] = AL_REGS_DONE;
 	}
 }

@@ -1395,6 +1395,8 @@ extern "C" int al_batch_run(al_ctx_t *c)
 		fprintf(stderr, "[airlift] tile kernel profile (cycles of thread 0, all blocks, both passes): setup %llu load %llu cut %llu dp %llu emit %llu copy %llu; tiles %llu\n", t[0], t[1], t[2], t[3], t[4], t[5], t[6]); }
 	if ((c->P.dbg2 >> 3) & 1) { unsigned long long t[8]; AL_HIP_CHECK(hipMemcpy(t, c->counters.p + 24, sizeof(t), hipMemcpyDeviceToHost));
 		fprintf(stderr, "[airlift] lane chaining kernels (cycles per wavefront, all launches of the batch): setup %llu load %llu recurrence %llu ends/backtrack/order %llu copy %llu; wavefronts %llu\n", t[5] ? t[0] / t[5] : 0, t[5] ? t[1] / t[5] : 0, t[5] ? t[2] / t[5] : 0, t[5] ? t[3] / t[5] : 0, t[5] ? t[4] / t[5] : 0, t[5]); }
+	if ((c->P.dbg2 >> 4) & 1) { unsigned long long t[8]; AL_HIP_CHECK(hipMemcpy(t, c->counters.p + 24, sizeof(t), hipMemcpyDeviceToHost));
+		fprintf(stderr, "[airlift] k_regs_heavy (lane 0 = mate 0, cycles summed over fragments): gen_regs %llu set_parent %llu squeeze %llu; hits %llu; whole blocks %llu over %llu fragments\n", t[0], t[1], t[2], t[3], t[4], t[5]); }
 	if (getenv("AL_TRACE")) { fprintf(stderr, "[airlift] trace: counters"); for (int i = 0; i < 16; ++i) fprintf(stderr, " [%d]=%llu", i, h[i]); fprintf(stderr, " rechain=%u\n", c->n_rechain); }
 	al_batch_stat_t &st = c->stat; memset(&st, 0, sizeof(st));
 	st.n_frag = c->n_frag; st.n_reads = c->n_reads; st.n_bases = c->n_bases;
